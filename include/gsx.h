@@ -1,0 +1,187 @@
+/*
+ * gsx.h — C ABI of libgsx.so, the MI355X-native 3D Gaussian Splatting render path.
+ *
+ * This header is the drop-in boundary for the one hot path of LioQing/wgpu-3dgs-viewer-app:
+ * the per-splat render pipeline that the app drives through the Rust crate
+ * `wgpu-3dgs-viewer 0.2.0` (Cargo.toml:25-31).  The reference has no C ABI; each entry point
+ * below cites the reference call site (file:line under /root/reference/src) whose crate call it
+ * replaces.  A Rust `gs::` facade over these symbols is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C, no C++ / torch types; all matrices column-major (glam `Mat4::to_cols_array()`).
+ *  - every function returns gsx_status (0 = OK); gsx_last_error_string() gives a thread-local
+ *    message.  Nothing aborts or throws across the ABI (reference: fallible calls return
+ *    Result<_, gs::Error>, app.rs:548, scene.rs:234).
+ *  - one viewer is used by one thread at a time (reference: "should not be used in multiple
+ *    threads", scene.rs:1924-1930).
+ *  - all device work is enqueued on the viewer's HIP stream; gsx_sync() is
+ *    `device.poll(wgpu::Maintain::Wait)` (scene.rs:614, scene.rs:873).
+ */
+#ifndef GSX_H
+#define GSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSX_ABI_VERSION 1u
+#define GSX_TILE 16u /* screen tile edge in pixels (build-internal; the reference has no tiles) */
+#define GSX_SH_COEFFS 15u /* SH degree 1..3 coefficients, each an RGB triple (gs::Gaussian::sh) */
+
+typedef int32_t gsx_status;
+enum {
+    GSX_OK = 0,
+    GSX_ERR_INVALID_ARG = 1,
+    GSX_ERR_OOM = 2,
+    GSX_ERR_HIP = 3,
+    GSX_ERR_RCCL = 4,
+    GSX_ERR_IO = 5, /* gs::Error::Io, scene.rs:234 */
+    GSX_ERR_PLY = 6,
+    GSX_ERR_NOT_FOUND = 7,
+    GSX_ERR_UNSUPPORTED = 8,
+    GSX_ERR_NO_DEVICE = 9
+};
+
+typedef struct gsx_viewer gsx_viewer; /* gs::MultiModelViewer<G>, scene.rs:1930 */
+
+/* gs::Gaussian — the CPU-side Gaussian the app streams in (app.rs:1029-1031, scene.rs:2069-2085).
+ * Field list follows wgpu-3dgs-viewer 0.2.0 (rot, pos, color, sh, scale). 224 bytes. */
+typedef struct gsx_gaussian {
+    float rot[4];    /* unit quaternion x,y,z,w (glam Quat) */
+    float pos[3];
+    uint8_t color[4]; /* r,g,b = clamp(0.5 + SH_C0*f_dc), a = sigmoid(opacity), UNORM8 */
+    float sh[GSX_SH_COEFFS][3];
+    float scale[3];  /* linear scale (exp already applied) */
+} gsx_gaussian;
+
+/* 8-way pod dispatch of the reference (scene.rs:23-81, app.rs:352-383). */
+typedef enum gsx_sh_kind { GSX_SH_SINGLE = 0, GSX_SH_HALF = 1, GSX_SH_NORM8 = 2, GSX_SH_NONE = 3 } gsx_sh_kind;
+typedef enum gsx_cov3d_kind { GSX_COV3D_SINGLE = 0, GSX_COV3D_HALF = 1 } gsx_cov3d_kind;
+
+/* gs::GaussianDisplayMode (app.rs:1141-1165, transform.rs:106-146). */
+typedef enum gsx_display_mode { GSX_DISPLAY_SPLAT = 0, GSX_DISPLAY_ELLIPSE = 1, GSX_DISPLAY_POINT = 2 } gsx_display_mode;
+
+/* Constants of the render spec that the reference tree does not pin (SURVEY.md §8c [BUILD-SPEC]).
+ * They are named and switchable so they can be reconciled against the real crate. */
+typedef struct gsx_spec_params {
+    float max_std_dev;    /* support cutoff: d^T Sigma^-1 d <= max_std_dev^2   (default 3.0) */
+    float cull_margin;    /* clip-space frustum margin m: |x|,|y| <= m*w        (default 1.3) */
+    float jacobian_clamp; /* view-space x/z,y/z clamp as a multiple of tan(fov/2) (default 1.3) */
+    float low_pass;       /* added to the cov2d diagonal, px^2                  (default 0.3) */
+    float alpha_max;      /* alpha = min(alpha_max, opacity*weight)             (default 1.0) */
+    float alpha_min;      /* contributions with alpha < alpha_min are skipped   (default 0.0) */
+    float t_epsilon;      /* front-to-back early termination: stop when T < eps (default 1e-4) */
+    float point_radius;   /* GSX_DISPLAY_POINT dot radius in px at size 1       (default 2.0) */
+} gsx_spec_params;
+
+typedef struct gsx_viewer_desc {
+    uint32_t abi_version; /* GSX_ABI_VERSION */
+    int32_t device;       /* HIP device ordinal */
+    void* stream;         /* hipStream_t to enqueue on, or NULL to create one */
+    uint32_t width, height; /* initial size; reference passes uvec2(1,1), scene.rs:1980 */
+} gsx_viewer_desc;
+
+/* ---- error / info ---- */
+const char* gsx_last_error_string(void);
+uint32_t gsx_abi_version(void);
+void gsx_spec_params_default(gsx_spec_params* out);
+
+/* ---- construction: gs::MultiModelViewer::new_with(device, format, depth_stencil, size), scene.rs:1969-1980 ---- */
+gsx_status gsx_viewer_create(const gsx_viewer_desc* desc, gsx_viewer** out);
+void gsx_viewer_destroy(gsx_viewer* v);
+gsx_status gsx_viewer_set_spec_params(gsx_viewer* v, const gsx_spec_params* p);
+
+/* ---- models: MultiModelViewerGaussianBuffers::new_empty + BindGroups::new + models.insert,
+ *      scene.rs:2111-2139; viewer.remove_model(&key), scene.rs:2176 ---- */
+gsx_status gsx_model_create(gsx_viewer* v, const char* key, uint64_t count, gsx_sh_kind sh, gsx_cov3d_kind cov3d);
+gsx_status gsx_model_remove(gsx_viewer* v, const char* key);
+gsx_status gsx_model_len(gsx_viewer* v, const char* key, uint64_t* out_count); /* gaussians_buffer.len(), scene.rs:608 */
+
+/* ---- upload: gaussians_buffer.update_range(queue, start, &[gs::Gaussian]), scene.rs:2083-2084.
+ *      Converts Gaussian -> pod on the GPU (cov3d from rot/scale) into the resident SoA planes. ---- */
+gsx_status gsx_model_upload_range(gsx_viewer* v, const char* key, uint64_t start, const gsx_gaussian* src, uint64_t n);
+/* Zero-copy variant: pod-ready planes already in DEVICE memory (pos 3n, color n, sh 45n, cov3d 6n). */
+gsx_status gsx_model_upload_pod_device(gsx_viewer* v, const char* key, uint64_t start, uint64_t n,
+                                       const float* d_pos, const uint32_t* d_color, const float* d_sh,
+                                       const float* d_cov3d);
+
+/* ---- per-frame uniform setters (scene.rs:795-809) ---- */
+/* viewer.update_camera(queue, &impl CameraTrait, uvec2 size), scene.rs:795 */
+gsx_status gsx_update_camera(gsx_viewer* v, const float view[16], const float proj[16], uint32_t width, uint32_t height);
+/* viewer.update_model_transform(queue, key, pos, quat, scale), scene.rs:796-802 */
+gsx_status gsx_update_model_transform(gsx_viewer* v, const char* key, const float pos[3], const float quat_xyzw[4],
+                                      const float scale[3]);
+/* viewer.update_gaussian_transform(queue, size, display_mode, sh_deg, no_sh0), scene.rs:803-809 */
+gsx_status gsx_update_gaussian_transform(gsx_viewer* v, float size, gsx_display_mode mode, uint32_t sh_deg,
+                                         uint32_t no_sh0);
+
+/* ---- mask (gs::MaskEvaluator result buffer, one bit per Gaussian, scene.rs:1851; app.rs:806-807) ---- */
+gsx_status gsx_model_upload_mask(gsx_viewer* v, const char* key, const uint32_t* words, uint64_t n_words);
+gsx_status gsx_model_download_mask(gsx_viewer* v, const char* key, uint32_t* words, uint64_t n_words);
+
+/* ---- frame execution, split exactly like the reference's per-frame protocol (scene.rs:856-873, 2302-2314) ---- */
+/* preprocessor.preprocess(encoder, bind_group, N): cull + SH colour + 3D->2D covariance + depth key. scene.rs:856-863 */
+gsx_status gsx_preprocess(gsx_viewer* v, const char* key);
+/* radix_sorter.sort(encoder, bind_group, indirect_args): depth radix sort of the surviving Gaussians. scene.rs:865-869 */
+gsx_status gsx_sort(gsx_viewer* v, const char* key);
+/* device.poll(Maintain::Wait), scene.rs:614 / scene.rs:873 */
+gsx_status gsx_sync(gsx_viewer* v);
+/* for key in model_render_keys (far -> near): renderer.render_with_pass(...), scene.rs:2302-2314.
+ * Bins every model's sorted splats into 16x16 tiles and composites them; the result is the
+ * premultiplied (r,g,b) + transmittance T framebuffer. */
+gsx_status gsx_render(gsx_viewer* v, const char* const* keys_far_to_near, uint32_t n_keys);
+/* preprocess + sort for every key, then render: one call per frame. */
+gsx_status gsx_render_frame(gsx_viewer* v, const char* const* keys_far_to_near, uint32_t n_keys);
+
+/* ---- readback (buffer.download(&device,&queue), app.rs:789, app.rs:806) ---- */
+/* float32 [height][width][4] = premultiplied r,g,b and transmittance T. Synchronises. */
+gsx_status gsx_download_framebuffer(gsx_viewer* v, float* rgbt, uint64_t n_floats);
+/* resolve against a background colour into RGBA8 (what the egui target would hold). Synchronises. */
+gsx_status gsx_download_rgba8(gsx_viewer* v, const float background_rgb[3], uint8_t* rgba, uint64_t n_bytes);
+/* device pointer of the (rgb,T) framebuffer, for zero-copy consumers (RCCL merge, torch). */
+gsx_status gsx_framebuffer_device_ptr(gsx_viewer* v, void** out_ptr, uint32_t* out_w, uint32_t* out_h);
+
+/* ---- parity / introspection (no reference counterpart; used by tests and bench) ---- */
+typedef struct gsx_frame_stats {
+    uint64_t n_gaussians; /* N of the model */
+    uint64_t n_visible;   /* N_vis after cull */
+    uint64_t n_tile_entries; /* D = sum over visible splats of tiles touched */
+} gsx_frame_stats;
+gsx_status gsx_model_frame_stats(gsx_viewer* v, const char* key, gsx_frame_stats* out);
+/* Per-Gaussian projection outputs of the last gsx_preprocess (host arrays of length N; any may be NULL):
+ * depth_key (0xFFFFFFFF = culled), rect[4] = tile x0,y0,x1,y1 (exclusive max), mean2d[2],
+ * conic_opacity[4], rgb[3]. */
+gsx_status gsx_model_download_projection(gsx_viewer* v, const char* key, uint32_t* depth_key, uint32_t* rect,
+                                         float* mean2d, float* conic_opacity, float* rgb);
+/* Front-to-back order of the last gsx_sort: first n_visible entries are Gaussian indices. */
+gsx_status gsx_model_download_sorted(gsx_viewer* v, const char* key, uint32_t* indices, uint64_t capacity,
+                                     uint64_t* out_n_visible);
+/* Tile lists of the last gsx_render for `key`: tile_offsets has tiles_x*tiles_y+1 entries, list holds D
+ * Gaussian indices in front-to-back order per tile. */
+gsx_status gsx_model_download_tile_lists(gsx_viewer* v, const char* key, uint32_t* tile_offsets,
+                                         uint64_t n_offsets, uint32_t* list, uint64_t capacity);
+/* Pod planes as resident in HBM (pos 3n, color n, sh 45n, cov3d 6n), for upload-conversion parity. */
+gsx_status gsx_model_download_pod(gsx_viewer* v, const char* key, float* pos, uint32_t* color, float* sh,
+                                  float* cov3d);
+
+/* ---- timing: HIP events recorded on the viewer's stream around each pass of the last frame ---- */
+typedef enum gsx_pass {
+    GSX_PASS_PROJECT = 0,
+    GSX_PASS_DEPTH_SORT = 1,
+    GSX_PASS_BIN = 2,
+    GSX_PASS_TILE_SORT = 3,
+    GSX_PASS_COMPOSITE = 4,
+    GSX_PASS_COUNT = 5
+} gsx_pass;
+gsx_status gsx_set_pass_timing(gsx_viewer* v, uint32_t enabled);
+/* milliseconds of each pass accumulated over all models since the last call (resets accumulators);
+ * synchronises. launches[i] = kernel launches of the dominant kernel of pass i. */
+gsx_status gsx_get_pass_timing(gsx_viewer* v, float ms[GSX_PASS_COUNT], uint32_t launches[GSX_PASS_COUNT]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSX_H */

@@ -1,0 +1,172 @@
+"""ctypes front-end of the CPU oracle (oracle/gsx_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED — see the header of gsx_oracle.c: the reference's arithmetic for this path is in the
+un-vendored crate wgpu-3dgs-viewer 0.2.0 and the reference tree holds no golden vectors; this oracle
+restates spec/RENDER_SPEC.md.  Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this package; the product package never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libgsx_oracle.so")
+
+
+class SpecParams(C.Structure):
+    """``gsx_spec_params`` (include/gsx.h)."""
+
+    _fields_ = [(n, C.c_float) for n in ("max_std_dev", "cull_margin", "jacobian_clamp", "low_pass", "alpha_max",
+                                        "alpha_min", "t_epsilon", "point_radius")]
+
+    @classmethod
+    def default(cls) -> "SpecParams":
+        return cls(3.0, 1.3, 1.3, 0.3, 1.0, 0.0, 1e-4, 2.0)
+
+
+class Frame(C.Structure):
+    """``gsxo_frame`` (gsx_oracle.c)."""
+
+    _fields_ = [("T", C.c_float * 9), ("vt", C.c_float * 3), ("P", C.c_float * 16), ("cam_m", C.c_float * 3),
+                ("s_m", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float), ("limx", C.c_float),
+                ("limy", C.c_float), ("width", C.c_float), ("height", C.c_float), ("size2", C.c_float),
+                ("k", C.c_float), ("k2", C.c_float), ("low_pass", C.c_float), ("cull_margin", C.c_float),
+                ("alpha_max", C.c_float), ("alpha_min", C.c_float), ("point_radius", C.c_float),
+                ("w_px", C.c_uint32), ("h_px", C.c_uint32), ("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32),
+                ("sh_deg", C.c_uint32), ("no_sh0", C.c_uint32), ("display_mode", C.c_uint32)]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "gsx_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libgsx_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        fp, u32p, vp = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p
+        L.gsxo_frame_setup.argtypes = [fp, fp, C.c_uint32, C.c_uint32, fp, fp, fp, C.c_float, C.c_uint32, C.c_uint32,
+                                       C.c_uint32, C.POINTER(SpecParams), C.POINTER(Frame)]
+        L.gsxo_frame_setup.restype = None
+        L.gsxo_convert.argtypes = [vp, C.c_uint64, fp, u32p, fp, fp]
+        L.gsxo_convert.restype = None
+        L.gsxo_project.argtypes = [C.POINTER(Frame), C.c_uint64, fp, u32p, fp, fp, u32p, u32p, u32p, fp, fp, fp]
+        L.gsxo_project.restype = C.c_uint64
+        L.gsxo_depth_sort.argtypes = [C.c_uint64, u32p, u32p]
+        L.gsxo_depth_sort.restype = C.c_uint64
+        L.gsxo_tile_lists.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, u32p, u32p, u32p, u32p]
+        L.gsxo_tile_lists.restype = C.c_uint64
+        L.gsxo_rasterize.argtypes = [C.POINTER(Frame), C.c_uint64, u32p, u32p, fp, fp, fp, fp]
+        L.gsxo_rasterize.restype = None
+        L.gsxo_composite_tiles.argtypes = [C.POINTER(Frame), u32p, u32p, fp, fp, fp, fp]
+        L.gsxo_composite_tiles.restype = None
+        L.gsxo_render_model.argtypes = [C.POINTER(Frame), C.c_uint64, fp, u32p, fp, fp, u32p, fp]
+        L.gsxo_render_model.restype = C.c_uint64
+        L.gsxo_num_threads.restype = C.c_int
+        L.gsxo_frame_sizeof.restype = C.c_size_t
+        assert L.gsxo_frame_sizeof() == C.sizeof(Frame), "gsxo_frame layout drifted"
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _up(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def _f32(a, n=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert n is None or a.size == n
+    return a
+
+
+def frame_setup(view, proj, width, height, m_pos=(0, 0, 0), m_quat=(0, 0, 0, 1), m_scale=(1, 1, 1), size=1.0,
+                display_mode=0, sh_deg=3, no_sh0=0, params: SpecParams | None = None) -> Frame:
+    f = Frame()
+    sp = params or SpecParams.default()
+    v, p = _f32(view, 16), _f32(proj, 16)
+    mp, mq, ms = _f32(m_pos, 3), _f32(m_quat, 4), _f32(m_scale, 3)
+    lib().gsxo_frame_setup(_fp(v), _fp(p), width, height, _fp(mp), _fp(mq), _fp(ms), float(size), int(display_mode),
+                           int(sh_deg), int(no_sh0), C.byref(sp), C.byref(f))
+    return f
+
+
+def convert(gaussians: np.ndarray):
+    """``gs::Gaussian`` array (scene.GAUSSIAN_DTYPE) -> pod planes (pos, color, sh, cov3d)."""
+    g = np.ascontiguousarray(gaussians)
+    n = g.shape[0]
+    pos = np.empty((n, 3), np.float32)
+    color = np.empty(n, np.uint32)
+    sh = np.empty((n, 45), np.float32)
+    cov = np.empty((n, 6), np.float32)
+    lib().gsxo_convert(g.ctypes.data_as(C.c_void_p), n, _fp(pos), _up(color), _fp(sh), _fp(cov))
+    return pos, color, sh, cov
+
+
+def project(frame: Frame, pos, color, sh, cov3d, mask=None):
+    n = pos.shape[0]
+    key = np.empty(n, np.uint32)
+    rect = np.empty((n, 4), np.uint32)
+    mean2d = np.empty((n, 2), np.float32)
+    conic = np.empty((n, 4), np.float32)
+    rgb = np.empty((n, 3), np.float32)
+    nvis = lib().gsxo_project(C.byref(frame), n, _fp(pos), _up(color), _fp(sh), _fp(cov3d), _up(mask), _up(key),
+                              _up(rect), _fp(mean2d), _fp(conic), _fp(rgb))
+    return dict(key=key, rect=rect, mean2d=mean2d, conic_opacity=conic, rgb=rgb, n_visible=int(nvis))
+
+
+def depth_sort(key: np.ndarray):
+    n = key.shape[0]
+    idx = np.empty(n, np.uint32)
+    nvis = lib().gsxo_depth_sort(n, _up(np.ascontiguousarray(key)), _up(idx))
+    return idx, int(nvis)
+
+
+def tile_lists(frame: Frame, sorted_idx, n_visible, rect):
+    tiles = frame.tiles_x * frame.tiles_y
+    off = np.empty(tiles + 1, np.uint32)
+    d = lib().gsxo_tile_lists(frame.tiles_x, frame.tiles_y, n_visible, _up(sorted_idx), _up(rect), _up(off), None)
+    lst = np.empty(max(int(d), 1), np.uint32)
+    lib().gsxo_tile_lists(frame.tiles_x, frame.tiles_y, n_visible, _up(sorted_idx), _up(rect), _up(off), _up(lst))
+    return off, lst[: int(d)]
+
+
+def new_framebuffer(frame: Frame) -> np.ndarray:
+    fb = np.zeros((frame.h_px, frame.w_px, 4), np.float32)
+    fb[..., 3] = 1.0
+    return fb
+
+
+def rasterize(frame: Frame, proj: dict, sorted_idx, n_visible, fb: np.ndarray) -> None:
+    lib().gsxo_rasterize(C.byref(frame), n_visible, _up(sorted_idx), _up(proj["rect"]), _fp(proj["mean2d"]),
+                         _fp(proj["conic_opacity"]), _fp(proj["rgb"]), _fp(fb))
+
+
+def composite_tiles(frame: Frame, proj: dict, tile_offsets, tile_list, fb: np.ndarray) -> None:
+    lst = tile_list if tile_list.size else np.zeros(1, np.uint32)
+    lib().gsxo_composite_tiles(C.byref(frame), _up(tile_offsets), _up(lst), _fp(proj["mean2d"]),
+                               _fp(proj["conic_opacity"]), _fp(proj["rgb"]), _fp(fb))
+
+
+def render_model(frame: Frame, pos, color, sh, cov3d, fb: np.ndarray, mask=None) -> int:
+    """project -> depth sort -> back-to-front rasterise one model over ``fb`` (paint far models first)."""
+    return int(lib().gsxo_render_model(C.byref(frame), pos.shape[0], _fp(pos), _up(color), _fp(sh), _fp(cov3d),
+                                       _up(mask), _fp(fb)))
+
+
+def num_threads() -> int:
+    return int(lib().gsxo_num_threads())
