@@ -1,0 +1,277 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): integer / index work bit-exact (cull set, depth keys, tile rectangles,
+depth order, tile lists); framebuffer within 1e-3 per-channel L-infinity (tolerance written below; the
+observed error is ~1e-5, dominated by the t_epsilon = 1e-4 early termination of the tile compositor).
+"""
+import numpy as np
+import pytest
+
+import oracle
+from tests import common
+from wgpu_3dgs_viewer_app_amd import camera
+from wgpu_3dgs_viewer_app_amd.viewer import GaussianDisplayMode, GaussianShDegree, GsxError, MultiModelViewer, ShKind
+
+pytestmark = pytest.mark.gpu
+
+FB_TOL = 1e-3  # north_star: <= 1e-3 per-channel L-inf
+FLOAT_TOL = 1e-6
+
+
+def run_gpu_model(v, key, g, cam, w, h, mt=None, size=1.0, mode=GaussianDisplayMode.Splat, sh_deg=3, no_sh0=False):
+    mt = mt or camera.ModelTransform()
+    v.add_model(key, g.shape[0])
+    v.models[key].gaussian_buffers.gaussians_buffer.update_range(0, g)
+    v.update_camera(cam, (w, h))
+    v.update_model_transform(key, mt.pos, mt.quat(), mt.scale)
+    v.update_gaussian_transform(size, mode, GaussianShDegree.new(sh_deg), no_sh0)
+    v.preprocessor.preprocess(key)
+    v.radix_sorter.sort(key)
+    v.poll()
+
+
+def assert_projection_equal(gpu, ref):
+    assert np.array_equal(gpu["key"], ref["key"]), "depth keys / cull set differ"
+    assert np.array_equal(gpu["rect"], ref["rect"]), "tile rectangles differ"
+    for name in ("mean2d", "conic_opacity", "rgb"):
+        np.testing.assert_allclose(gpu[name], ref[name], rtol=FLOAT_TOL, atol=FLOAT_TOL, err_msg=name)
+
+
+@pytest.mark.parametrize("n,seed", [(1, 3), (255, 4), (4097, 5), (20000, 6)])
+def test_upload_conversion_bit_exact(n, seed):
+    g = common.small_scene(n, seed)
+    with MultiModelViewer() as v:
+        v.add_model("m", n)
+        buf = v.models["m"].gaussian_buffers.gaussians_buffer
+        # ragged streaming upload like the app's loader batches (scene.rs:341-380)
+        cut = n // 3
+        buf.update_range(cut, g[cut:])
+        buf.update_range(0, g[:cut])
+        assert buf.len() == n
+        pos, color, sh, cov = buf.download_pod()
+    rpos, rcolor, rsh, rcov = oracle.convert(g)
+    assert np.array_equal(pos, rpos) and np.array_equal(color, rcolor) and np.array_equal(sh, rsh)
+    assert np.array_equal(cov, rcov), "cov3d = (RS)(RS)^T must be bit-exact"
+
+
+@pytest.mark.parametrize("mt_kind,sh_deg,no_sh0", [("id", 3, False), ("odd", 3, False), ("odd", 2, False), ("odd", 1, True), ("id", 0, False)])
+def test_projection_sort_tiles_frame(mt_kind, sh_deg, no_sh0):
+    n, w, h = 6000, 200, 136  # not a multiple of the tile size on purpose
+    g = common.small_scene(n, 11)
+    cam = camera.orbit_pose(23)
+    mt = common.odd_transform() if mt_kind == "odd" else common.default_transform()
+    f, pr, idx, nvis, fb_ref = common.oracle_model_frame(g, cam, w, h, mt, sh_deg=sh_deg, no_sh0=int(no_sh0))
+    with MultiModelViewer() as v:
+        run_gpu_model(v, "m", g, cam, w, h, mt, sh_deg=sh_deg, no_sh0=no_sh0)
+        gp = v.download_projection("m")
+        assert_projection_equal(gp, pr)
+        assert np.array_equal(v.download_sorted("m"), idx[:nvis]), "depth order differs"
+        v.renderer.render(["m"])
+        st = v.frame_stats("m")
+        off, lst = v.download_tile_lists("m")
+        roff, rlst = oracle.tile_lists(f, idx, nvis, pr["rect"])
+        assert st["n_visible"] == nvis and st["n_tile_entries"] == rlst.size
+        assert np.array_equal(off, roff) and np.array_equal(lst, rlst), "tile lists differ"
+        fb = v.download_framebuffer()
+    assert nvis > n // 4
+    err = np.abs(fb - fb_ref).max()
+    assert err <= FB_TOL, f"framebuffer L-inf {err}"
+    assert err <= 2e-4, f"framebuffer L-inf {err} (expected ~t_epsilon)"
+
+
+def test_render_frame_matches_split_protocol():
+    n, w, h = 5000, 160, 120
+    g = common.small_scene(n, 12)
+    cam = camera.orbit_pose(100)
+    with MultiModelViewer() as v:
+        run_gpu_model(v, "m", g, cam, w, h)
+        v.renderer.render(["m"])
+        a = v.download_framebuffer()
+        v.render_frame(["m"])
+        b = v.download_framebuffer()
+    assert np.array_equal(a, b)
+
+
+def test_multi_model_painter_order():
+    """Models are layered far -> near by centre distance, never merged (scene.rs:533-558, 2302-2314)."""
+    w, h = 160, 128
+    cam = camera.orbit_pose(5)
+    ga, gb = common.small_scene(3000, 21), common.small_scene(2500, 22)
+    mta = camera.ModelTransform(pos=np.array([0.0, 0.0, 1.5], np.float32))
+    mtb = camera.ModelTransform(pos=np.array([0.5, 0.2, -1.0], np.float32), rot=np.array([0, 40, 0], np.float32))
+    keys = camera.model_render_order(cam.pos, {"a": mta.world_center(), "b": mtb.world_center()})
+    assert sorted(keys) == ["a", "b"]
+    # oracle: paint far first, near over it
+    fb_ref = None
+    for k in keys:
+        g, mt = (ga, mta) if k == "a" else (gb, mtb)
+        _, _, _, _, fb_ref = common.oracle_model_frame(g, cam, w, h, mt, fb=fb_ref)
+    with MultiModelViewer() as v:
+        run_gpu_model(v, "a", ga, cam, w, h, mta)
+        run_gpu_model(v, "b", gb, cam, w, h, mtb)
+        v.renderer.render(keys)
+        fb = v.download_framebuffer()
+        v.renderer.render(keys[::-1])
+        fb_rev = v.download_framebuffer()
+    assert np.abs(fb - fb_ref).max() <= 2e-4
+    assert np.abs(fb_rev - fb_ref).max() > 1e-2, "paint order must matter for interpenetrating models"
+
+
+@pytest.mark.parametrize("mode,size", [(GaussianDisplayMode.Ellipse, 1.0), (GaussianDisplayMode.Point, 1.5), (GaussianDisplayMode.Splat, 0.5), (GaussianDisplayMode.Splat, 2.0)])
+def test_display_modes_and_size(mode, size):
+    n, w, h = 3000, 128, 96
+    g = common.small_scene(n, 31)
+    cam = camera.orbit_pose(77)
+    f, pr, idx, nvis, fb_ref = common.oracle_model_frame(g, cam, w, h, None, size=size, display_mode=int(mode))
+    with MultiModelViewer() as v:
+        run_gpu_model(v, "m", g, cam, w, h, size=size, mode=mode)
+        assert_projection_equal(v.download_projection("m"), pr)
+        v.renderer.render(["m"])
+        fb = v.download_framebuffer()
+    assert np.abs(fb - fb_ref).max() <= 2e-4
+
+
+def test_sh_none_pod_and_spec_params():
+    n, w, h = 3000, 128, 96
+    g = common.small_scene(n, 41, sh_degree=0)
+    cam = camera.orbit_pose(140)
+    sp = oracle.SpecParams.default()
+    sp.max_std_dev, sp.alpha_max, sp.alpha_min, sp.cull_margin = 2.5, 0.99, 1.0 / 255.0, 1.1
+    f = common.oracle_frame(cam, w, h, params=sp, sh_deg=3)
+    pos, color, _, cov = oracle.convert(g)
+    pr = oracle.project(f, pos, color, None, cov)
+    idx, nvis = oracle.depth_sort(pr["key"])
+    fb_ref = oracle.new_framebuffer(f)
+    oracle.rasterize(f, pr, idx, nvis, fb_ref)
+    with MultiModelViewer(sh=ShKind.Remove) as v:
+        v.set_spec_params(max_std_dev=2.5, alpha_max=0.99, alpha_min=1.0 / 255.0, cull_margin=1.1)
+        run_gpu_model(v, "m", g, cam, w, h)
+        assert_projection_equal(v.download_projection("m"), pr)
+        v.renderer.render(["m"])
+        fb = v.download_framebuffer()
+    # alpha_min makes alpha a thresholded function of exp(): allow a handful of 1/255-sized flips
+    diff = np.abs(fb - fb_ref)
+    assert np.count_nonzero(diff > 2e-4) <= 4 and diff.max() <= 5e-3
+
+
+def test_mask_bits_cull():
+    n, w, h = 4000, 128, 96
+    g = common.small_scene(n, 51)
+    cam = camera.orbit_pose(10)
+    rng = np.random.default_rng(5)
+    mask = rng.integers(0, 2**32, size=(n + 31) // 32, dtype=np.uint32)
+    f, pr, idx, nvis, fb_ref = common.oracle_model_frame(g, cam, w, h, mask=mask)
+    with MultiModelViewer() as v:
+        v.add_model("m", n)
+        v.models["m"].gaussian_buffers.mask_buffer.upload(mask)
+        assert np.array_equal(v.models["m"].gaussian_buffers.mask_buffer.download(), mask)
+        v.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g)
+        v.update_camera(cam, (w, h))
+        v.update_gaussian_transform(1.0, GaussianDisplayMode.Splat, GaussianShDegree.new(3), False)
+        v.render_frame(["m"])
+        assert_projection_equal(v.download_projection("m"), pr)
+        fb = v.download_framebuffer()
+        v.models["m"].gaussian_buffers.mask_buffer.upload(None)  # MaskOpTree::Reset
+        v.render_frame(["m"])
+        assert v.frame_stats("m")["n_visible"] > nvis
+    assert np.abs(fb - fb_ref).max() <= 2e-4
+
+
+def test_edge_cases_empty_culled_huge():
+    w, h = 96, 64
+    cam = camera.orbit_pose(0)
+    with MultiModelViewer() as v:
+        # no models at all: cleared framebuffer
+        v.update_camera(cam, (w, h))
+        v.renderer.render([])
+        fb = v.download_framebuffer()
+        assert np.all(fb[..., :3] == 0) and np.all(fb[..., 3] == 1)
+        # empty model
+        v.add_model("empty", 0)
+        v.render_frame(["empty"])
+        assert v.frame_stats("empty") == dict(n_gaussians=0, n_visible=0, n_tile_entries=0)
+        assert np.all(v.download_framebuffer()[..., 3] == 1)
+        # everything behind the camera: all culled
+        g = common.small_scene(500, 61)
+        g["pos"] = g["pos"] * 0.1 + np.array([0, 1.5, -30.0], np.float32)
+        v.add_model("behind", 500)
+        v.models["behind"].gaussian_buffers.gaussians_buffer.update_range(0, g)
+        v.render_frame(["behind"])
+        assert v.frame_stats("behind")["n_visible"] == 0
+        # one huge opaque splat covering every tile (maximum tile rectangle)
+        big = common.small_scene(1, 62)
+        big["pos"][:] = 0
+        big["scale"][:] = 50.0
+        big["color"][:, 3] = 255
+        f, pr, idx, nvis, fb_ref = common.oracle_model_frame(big, cam, w, h)
+        v.add_model("big", 1)
+        v.models["big"].gaussian_buffers.gaussians_buffer.update_range(0, big)
+        v.render_frame(["big"])
+        st = v.frame_stats("big")
+        assert st["n_visible"] == 1 and st["n_tile_entries"] == ((w + 15) // 16) * ((h + 15) // 16)
+        assert np.abs(v.download_framebuffer() - fb_ref).max() <= 2e-4
+        # errors follow the reference's Result convention
+        with pytest.raises(GsxError) as e:
+            v.preprocessor.preprocess("nope")
+        assert e.value.status == 7
+        with pytest.raises(GsxError):
+            v.update_gaussian_transform(1.0, GaussianDisplayMode.Splat, 4, False)
+        v.remove_model("big")
+        with pytest.raises(GsxError):
+            v.render_frame(["big"])
+
+
+def test_equal_depth_ties_break_by_index():
+    """Coplanar splats share a depth key; order must be by Gaussian index (stable radix sort)."""
+    n, w, h = 2000, 128, 96
+    g = common.small_scene(n, 71)
+    cam = camera.CameraOrbitControl(target=np.zeros(3, np.float32), pos=np.array([0, 0, -6], np.float32))
+    g["pos"][:, 2] = 0.0  # one plane perpendicular to the view axis -> identical view depth
+    f, pr, idx, nvis, fb_ref = common.oracle_model_frame(g, cam, w, h)
+    assert len(np.unique(pr["key"][pr["key"] != 0xFFFFFFFF])) < nvis // 4
+    with MultiModelViewer() as v:
+        run_gpu_model(v, "m", g, cam, w, h)
+        assert np.array_equal(v.download_sorted("m"), idx[:nvis])
+        v.renderer.render(["m"])
+        fb = v.download_framebuffer()
+    assert np.abs(fb - fb_ref).max() <= 2e-4
+
+
+def test_full_size_properties():
+    """BASELINE cfg2 size (1 M, SH-3, 1920x1080): size-independent properties instead of the slow oracle."""
+    from wgpu_3dgs_viewer_app_amd import scene
+    n, sh, w, h, seed = scene.CONFIGS["cfg2"]
+    g = scene.synthetic_gaussians(n, seed, sh)
+    cam = camera.orbit_pose(0)
+    with MultiModelViewer() as v:
+        run_gpu_model(v, "m", g, cam, w, h)
+        pr = v.download_projection("m")
+        order = v.download_sorted("m")
+        v.renderer.render(["m"])
+        st = v.frame_stats("m")
+        off, lst = v.download_tile_lists("m")
+        fb = v.download_framebuffer()
+        v.render_frame(["m"])
+        fb2 = v.download_framebuffer()
+    vis = pr["key"] != 0xFFFFFFFF
+    assert st["n_visible"] == vis.sum() == order.size
+    # sortedness + permutation + tie-break
+    k = pr["key"][order].astype(np.int64)
+    assert np.all(np.diff(k) >= 0)
+    same = np.diff(k) == 0
+    assert np.all(np.diff(order.astype(np.int64))[same] > 0)
+    assert np.array_equal(np.sort(order), np.nonzero(vis)[0])
+    # checksum of tile lists: every visible splat appears once per tile of its rectangle, lists depth-ordered
+    r = pr["rect"][vis].astype(np.int64)
+    assert st["n_tile_entries"] == int(((r[:, 2] - r[:, 0]) * (r[:, 3] - r[:, 1])).sum()) == lst.size
+    counts = np.bincount(lst, minlength=n)
+    assert np.array_equal(counts[vis], (r[:, 2] - r[:, 0]) * (r[:, 3] - r[:, 1]))
+    rank = np.empty(n, np.int64)
+    rank[order] = np.arange(order.size)
+    seg = np.repeat(np.arange(off.size - 1), np.diff(off.astype(np.int64)))
+    rl = rank[lst]
+    inside = np.diff(seg) == 0
+    assert np.all(np.diff(rl)[inside] > 0), "tile lists must be front-to-back"
+    # framebuffer sanity + determinism (idempotence of the whole frame)
+    assert np.isfinite(fb).all() and fb[..., 3].min() >= 0 and fb[..., 3].max() <= 1
+    assert np.array_equal(fb, fb2)

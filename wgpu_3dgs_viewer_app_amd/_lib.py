@@ -1,0 +1,113 @@
+"""ctypes binding of libgsx.so (include/gsx.h).  The library is the product; this file is plumbing.
+
+The shared object is built in-tree by ``__graft_entry__.build()`` (``make -C csrc``).  If it is missing
+the import of the product path FAILS LOUDLY — there is no CPU or PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsx.so")
+
+GSX_ABI_VERSION = 1
+(GSX_OK, GSX_ERR_INVALID_ARG, GSX_ERR_OOM, GSX_ERR_HIP, GSX_ERR_RCCL, GSX_ERR_IO, GSX_ERR_PLY, GSX_ERR_NOT_FOUND,
+ GSX_ERR_UNSUPPORTED, GSX_ERR_NO_DEVICE) = range(10)
+GSX_PASS_NAMES = ("project", "depth_sort", "bin", "tile_sort", "composite")
+GSX_PASS_COUNT = len(GSX_PASS_NAMES)
+
+#: every symbol include/gsx.h declares (tests check the library exports exactly these)
+EXPORTS = (
+    "gsx_last_error_string", "gsx_abi_version", "gsx_spec_params_default", "gsx_viewer_create", "gsx_viewer_destroy",
+    "gsx_viewer_set_spec_params", "gsx_model_create", "gsx_model_remove", "gsx_model_len", "gsx_model_upload_range",
+    "gsx_model_upload_pod_device", "gsx_update_camera", "gsx_update_model_transform", "gsx_update_gaussian_transform",
+    "gsx_model_upload_mask", "gsx_model_download_mask", "gsx_preprocess", "gsx_sort", "gsx_sync", "gsx_render",
+    "gsx_render_frame", "gsx_download_framebuffer", "gsx_download_rgba8", "gsx_framebuffer_device_ptr",
+    "gsx_model_frame_stats", "gsx_model_download_projection", "gsx_model_download_sorted",
+    "gsx_model_download_tile_lists", "gsx_model_download_pod", "gsx_set_pass_timing", "gsx_get_pass_timing",
+)
+
+
+class SpecParams(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("max_std_dev", "cull_margin", "jacobian_clamp", "low_pass", "alpha_max",
+                                        "alpha_min", "t_epsilon", "point_radius")]
+
+
+class ViewerDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("stream", C.c_void_p), ("width", C.c_uint32),
+                ("height", C.c_uint32)]
+
+
+class FrameStats(C.Structure):
+    _fields_ = [("n_gaussians", C.c_uint64), ("n_visible", C.c_uint64), ("n_tile_entries", C.c_uint64)]
+
+
+class GsxError(RuntimeError):
+    """``gs::Error``: raised for every non-zero ``gsx_status``; ``status`` holds the code."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"gsx status {status}: {message}")
+        self.status = status
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "There is no CPU fallback for the render path.")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, f32p, u32p, cp = C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_char_p
+    sig = {
+        "gsx_last_error_string": ([], C.c_char_p),
+        "gsx_abi_version": ([], u32),
+        "gsx_spec_params_default": ([C.POINTER(SpecParams)], None),
+        "gsx_viewer_create": ([C.POINTER(ViewerDesc), C.POINTER(vp)], C.c_int32),
+        "gsx_viewer_destroy": ([vp], None),
+        "gsx_viewer_set_spec_params": ([vp, C.POINTER(SpecParams)], C.c_int32),
+        "gsx_model_create": ([vp, cp, u64, C.c_int, C.c_int], C.c_int32),
+        "gsx_model_remove": ([vp, cp], C.c_int32),
+        "gsx_model_len": ([vp, cp, C.POINTER(u64)], C.c_int32),
+        "gsx_model_upload_range": ([vp, cp, u64, vp, u64], C.c_int32),
+        "gsx_model_upload_pod_device": ([vp, cp, u64, u64, vp, vp, vp, vp], C.c_int32),
+        "gsx_update_camera": ([vp, f32p, f32p, u32, u32], C.c_int32),
+        "gsx_update_model_transform": ([vp, cp, f32p, f32p, f32p], C.c_int32),
+        "gsx_update_gaussian_transform": ([vp, C.c_float, C.c_int, u32, u32], C.c_int32),
+        "gsx_model_upload_mask": ([vp, cp, u32p, u64], C.c_int32),
+        "gsx_model_download_mask": ([vp, cp, u32p, u64], C.c_int32),
+        "gsx_preprocess": ([vp, cp], C.c_int32),
+        "gsx_sort": ([vp, cp], C.c_int32),
+        "gsx_sync": ([vp], C.c_int32),
+        "gsx_render": ([vp, C.POINTER(cp), u32], C.c_int32),
+        "gsx_render_frame": ([vp, C.POINTER(cp), u32], C.c_int32),
+        "gsx_download_framebuffer": ([vp, f32p, u64], C.c_int32),
+        "gsx_download_rgba8": ([vp, f32p, C.POINTER(C.c_uint8), u64], C.c_int32),
+        "gsx_framebuffer_device_ptr": ([vp, C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)], C.c_int32),
+        "gsx_model_frame_stats": ([vp, cp, C.POINTER(FrameStats)], C.c_int32),
+        "gsx_model_download_projection": ([vp, cp, u32p, u32p, f32p, f32p, f32p], C.c_int32),
+        "gsx_model_download_sorted": ([vp, cp, u32p, u64, C.POINTER(u64)], C.c_int32),
+        "gsx_model_download_tile_lists": ([vp, cp, u32p, u64, u32p, u64], C.c_int32),
+        "gsx_model_download_pod": ([vp, cp, f32p, u32p, f32p, f32p], C.c_int32),
+        "gsx_set_pass_timing": ([vp, u32], C.c_int32),
+        "gsx_get_pass_timing": ([vp, f32p, u32p], C.c_int32),
+    }
+    assert set(sig) == set(EXPORTS)
+    for name, (args, res) in sig.items():
+        fn = getattr(L, name)  # AttributeError here = the library does not export what gsx.h declares
+        fn.argtypes = args
+        fn.restype = res
+    if L.gsx_abi_version() != GSX_ABI_VERSION:
+        raise ImportError(f"libgsx ABI {L.gsx_abi_version()} != binding {GSX_ABI_VERSION}")
+    _lib = L
+    return L
+
+
+def check(status: int) -> None:
+    if status != GSX_OK:
+        raise GsxError(status, load().gsx_last_error_string().decode("utf-8", "replace"))

@@ -1,0 +1,792 @@
+// gsx_api.cpp — host side of libgsx.so: the C ABI of include/gsx.h over the gfx950 kernels.
+//
+// Mirrors the call protocol the app drives every frame (src/tab/scene.rs:699-874 and 2263-2326):
+//   update_* uniforms -> per model preprocess + radix sort -> submit/poll -> per model render far->near.
+// One viewer = one HIP device + one stream; every buffer of a model lives in HBM for the model's
+// lifetime (the reference's MultiModelViewerGaussianBuffers, scene.rs:2111-2112).
+// There is NO CPU fallback: without a HIP device every entry point fails with GSX_ERR_NO_DEVICE.
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "gsx_internal.h"
+
+namespace gsx {
+
+static thread_local std::string g_err;
+
+static gsx_status fail(gsx_status st, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return st;
+}
+
+#define HIPCHK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess)                                                                         \
+            return fail(_e == hipErrorOutOfMemory ? GSX_ERR_OOM : GSX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(_e), __FILE__, __LINE__);                                   \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    // grow-only; contents are NOT preserved
+    hipError_t ensure(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        release();
+        size_t want = need + need / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            e = hipMalloc(&p, need);
+            want = need;
+        }
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct Counters {  // device + pinned host mirror
+    uint32_t n_visible;
+    uint32_t n_entries;  // D
+};
+
+struct Model {
+    std::string key;
+    uint64_t n = 0;
+    gsx_sh_kind sh_kind = GSX_SH_SINGLE;
+    gsx_cov3d_kind cov_kind = GSX_COV3D_SINGLE;
+    bool has_sh = true;
+    bool has_mask = false;
+    ModelTransform mt;
+    FrameConsts fc{};
+
+    DevBuf pc, cov_a, cov_b, sh4, sh1, mask;
+    DevBuf key_buf, rec_a, rec_b, rec_c;
+    DevBuf sk_a, sk_b, sv_a, sv_b, table;      // depth sort ping-pong + histogram table
+    DevBuf cnt, block_sums;                     // tile counts in depth order + scan partials
+    DevBuf tk_src, tv_src, tk_a, tk_b, tv_a, tv_b, ttable;  // tile pairs
+    DevBuf ranges;
+    DevBuf counters;
+    Counters* h_counters = nullptr;             // pinned
+    uint32_t* sorted_idx = nullptr;             // -> sv_a or sv_b after the depth sort
+    uint32_t* tile_list = nullptr;              // -> tv_* after the tile sort
+    uint32_t* tile_keys = nullptr;
+    bool preprocessed = false, sorted = false, counters_valid = false, binned = false;
+    uint32_t n_visible = 0, n_entries = 0;
+
+    ~Model() {
+        if (h_counters) (void)hipHostFree(h_counters);
+    }
+    PodPlanes pod() const {
+        PodPlanes p;
+        p.pc = pc.as<float4>();
+        p.cov_a = cov_a.as<float4>();
+        p.cov_b = cov_b.as<float2>();
+        p.sh4 = sh4.as<float4>();
+        p.sh1 = sh1.as<float>();
+        p.mask = has_mask ? mask.as<uint32_t>() : nullptr;
+        return p;
+    }
+    Records rec() const {
+        Records r;
+        r.key = key_buf.as<uint32_t>();
+        r.a = rec_a.as<float4>();
+        r.b = rec_b.as<float4>();
+        r.c = rec_c.as<float4>();
+        return r;
+    }
+};
+
+struct PassTimer {
+    hipEvent_t start, stop;
+    int pass;
+};
+
+}  // namespace gsx
+
+using namespace gsx;
+
+struct gsx_viewer {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    gsx_spec_params params{};
+    float view[16]{}, proj[16]{};
+    uint32_t width = 1, height = 1;
+    float size = 1.0f;
+    uint32_t display_mode = GSX_DISPLAY_SPLAT, sh_deg = 3, no_sh0 = 0;
+    std::map<std::string, std::unique_ptr<Model>> models;
+    DevBuf fb, staging, scratch;
+    bool timing = false;
+    std::vector<PassTimer> timers;     // recorded, not yet read
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
+    float pass_ms[GSX_PASS_COUNT]{};
+    uint32_t pass_launches[GSX_PASS_COUNT]{};
+};
+
+namespace gsx {
+
+static Model* find_model(gsx_viewer* v, const char* key) {
+    if (!v || !key) return nullptr;
+    auto it = v->models.find(key);
+    return it == v->models.end() ? nullptr : it->second.get();
+}
+
+struct ScopedPass {
+    gsx_viewer* v;
+    int pass;
+    hipEvent_t a = nullptr, b = nullptr;
+    ScopedPass(gsx_viewer* v_, int pass_) : v(v_), pass(pass_) {
+        if (!v->timing) return;
+        if (!v->event_pool.empty()) {
+            a = v->event_pool.back().first;
+            b = v->event_pool.back().second;
+            v->event_pool.pop_back();
+        } else {
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+        }
+        (void)hipEventRecord(a, v->stream);
+    }
+    ~ScopedPass() {
+        if (!a) return;
+        (void)hipEventRecord(b, v->stream);
+        v->timers.push_back({a, b, pass});
+    }
+};
+
+static uint32_t ceil_log2(uint32_t x) {
+    uint32_t b = 0;
+    while ((1ull << b) < x) ++b;
+    return b;
+}
+
+static gsx_status viewer_bind(gsx_viewer* v) {
+    if (!v) return fail(GSX_ERR_INVALID_ARG, "viewer is null");
+    HIPCHK(hipSetDevice(v->device));
+    return GSX_OK;
+}
+
+static gsx_status ensure_fb(gsx_viewer* v) {
+    HIPCHK(v->fb.ensure(sizeof(float4) * (size_t)v->width * v->height));
+    return GSX_OK;
+}
+
+static gsx_status sync_counters(gsx_viewer* v) {
+    bool need = false;
+    for (auto& kv : v->models) need |= kv.second->sorted && !kv.second->counters_valid;
+    if (!need) return GSX_OK;
+    HIPCHK(hipStreamSynchronize(v->stream));
+    for (auto& kv : v->models) {
+        Model* m = kv.second.get();
+        if (m->sorted && !m->counters_valid) {
+            m->n_visible = m->h_counters->n_visible;
+            m->n_entries = m->h_counters->n_entries;
+            m->counters_valid = true;
+        }
+    }
+    return GSX_OK;
+}
+
+static gsx_status do_preprocess(gsx_viewer* v, Model* m) {
+    frame_consts_setup(v->view, v->proj, v->width, v->height, m->mt, v->size, v->display_mode, v->sh_deg, v->no_sh0,
+                       v->params, &m->fc);
+    m->preprocessed = m->sorted = m->counters_valid = m->binned = false;
+    HIPCHK(hipMemsetAsync(m->counters.p, 0, sizeof(Counters), v->stream));
+    {
+        ScopedPass t(v, GSX_PASS_PROJECT);
+        HIPCHK(launch_project(v->stream, m->fc, (uint32_t)m->n, m->pod(), m->has_sh, m->rec(),
+                              &m->counters.as<Counters>()->n_visible));
+        v->pass_launches[GSX_PASS_PROJECT] += m->n ? 1 : 0;
+    }
+    m->preprocessed = true;
+    return GSX_OK;
+}
+
+static gsx_status do_sort(gsx_viewer* v, Model* m) {
+    if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_sort('%s') before gsx_preprocess", m->key.c_str());
+    const uint32_t n = (uint32_t)m->n;
+    {
+        ScopedPass t(v, GSX_PASS_DEPTH_SORT);
+        RadixBuffers rb{m->key_buf.as<uint32_t>(), nullptr, m->sk_a.as<uint32_t>(), m->sv_a.as<uint32_t>(),
+                        m->sk_b.as<uint32_t>(), m->sv_b.as<uint32_t>(), m->table.as<uint32_t>()};
+        bool in_b = false;
+        HIPCHK(launch_radix_sort(v->stream, rb, n, 32, true, &in_b));
+        m->sorted_idx = in_b ? m->sv_b.as<uint32_t>() : m->sv_a.as<uint32_t>();
+        v->pass_launches[GSX_PASS_DEPTH_SORT] += n ? 4 : 0;
+    }
+    {
+        ScopedPass t(v, GSX_PASS_BIN);
+        Counters* dc = m->counters.as<Counters>();
+        HIPCHK(launch_tile_counts(v->stream, n, &dc->n_visible, m->sorted_idx, m->rec(), m->cnt.as<uint32_t>(),
+                                  m->block_sums.as<uint32_t>(), &dc->n_entries));
+    }
+    HIPCHK(hipMemcpyAsync(m->h_counters, m->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, v->stream));
+    m->sorted = true;
+    return GSX_OK;
+}
+
+static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool first) {
+    if (!m->sorted) return fail(GSX_ERR_INVALID_ARG, "gsx_render: model '%s' was not preprocessed+sorted", m->key.c_str());
+    if (m->fc.w_px != v->width || m->fc.h_px != v->height)
+        return fail(GSX_ERR_INVALID_ARG, "gsx_render: viewport changed since gsx_preprocess('%s')", m->key.c_str());
+    const uint32_t n_tiles = m->fc.tiles_x * m->fc.tiles_y;
+    const uint32_t D = m->n_entries;
+    {
+        ScopedPass t(v, GSX_PASS_BIN);
+        const size_t bytes = sizeof(uint32_t) * std::max<size_t>(D, 1);
+        HIPCHK(m->tk_src.ensure(bytes));
+        HIPCHK(m->tv_src.ensure(bytes));
+        HIPCHK(m->tk_a.ensure(bytes));
+        HIPCHK(m->tv_a.ensure(bytes));
+        HIPCHK(m->tk_b.ensure(bytes));
+        HIPCHK(m->tv_b.ensure(bytes));
+        HIPCHK(m->ttable.ensure(sizeof(uint32_t) * radix_table_entries(D)));
+        HIPCHK(m->ranges.ensure(sizeof(uint2) * (size_t)n_tiles));
+        HIPCHK(launch_tile_emit(v->stream, m->n_visible, m->sorted_idx, m->rec(), m->cnt.as<uint32_t>(),
+                                m->block_sums.as<uint32_t>(), m->fc.tiles_x, m->tk_src.as<uint32_t>(),
+                                m->tv_src.as<uint32_t>()));
+        v->pass_launches[GSX_PASS_BIN] += 1;
+    }
+    {
+        ScopedPass t(v, GSX_PASS_TILE_SORT);
+        RadixBuffers rb{m->tk_src.as<uint32_t>(), m->tv_src.as<uint32_t>(), m->tk_a.as<uint32_t>(), m->tv_a.as<uint32_t>(),
+                        m->tk_b.as<uint32_t>(), m->tv_b.as<uint32_t>(), m->ttable.as<uint32_t>()};
+        bool in_b = false;
+        const int bits = std::max<int>(1, (int)ceil_log2(n_tiles));
+        HIPCHK(launch_radix_sort(v->stream, rb, D, bits, false, &in_b));
+        if (D == 0) {
+            m->tile_keys = m->tk_src.as<uint32_t>();
+            m->tile_list = m->tv_src.as<uint32_t>();
+        } else {
+            m->tile_keys = in_b ? m->tk_b.as<uint32_t>() : m->tk_a.as<uint32_t>();
+            m->tile_list = in_b ? m->tv_b.as<uint32_t>() : m->tv_a.as<uint32_t>();
+        }
+        v->pass_launches[GSX_PASS_TILE_SORT] += D ? (bits + 7) / 8 : 0;
+    }
+    {
+        ScopedPass t(v, GSX_PASS_BIN);
+        HIPCHK(launch_tile_ranges(v->stream, D, m->tile_keys, n_tiles, m->ranges.as<uint2>()));
+    }
+    {
+        ScopedPass t(v, GSX_PASS_COMPOSITE);
+        HIPCHK(launch_composite(v->stream, m->fc, m->ranges.as<uint2>(), m->tile_list, m->rec(), v->fb.as<float4>(), first));
+        v->pass_launches[GSX_PASS_COMPOSITE] += 1;
+    }
+    m->binned = true;
+    return GSX_OK;
+}
+
+static gsx_status do_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys) {
+    gsx_status st = ensure_fb(v);
+    if (st) return st;
+    std::vector<Model*> order;
+    for (uint32_t i = 0; i < n_keys; ++i) {
+        Model* m = find_model(v, keys ? keys[i] : nullptr);
+        if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_render: no model '%s'", keys && keys[i] ? keys[i] : "(null)");
+        order.push_back(m);
+    }
+    if ((st = sync_counters(v))) return st;
+    if (order.empty()) {
+        HIPCHK(launch_clear_fb(v->stream, v->fb.as<float4>(), v->width * v->height));
+        return GSX_OK;
+    }
+    // the reference paints far -> near with "over"; front-to-back accumulation walks the same list backwards
+    bool first = true;
+    for (auto it = order.rbegin(); it != order.rend(); ++it) {
+        if ((st = do_bin_and_composite(v, *it, first))) return st;
+        first = false;
+    }
+    return GSX_OK;
+}
+
+}  // namespace gsx
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+const char* gsx_last_error_string(void) { return g_err.c_str(); }
+uint32_t gsx_abi_version(void) { return GSX_ABI_VERSION; }
+
+void gsx_spec_params_default(gsx_spec_params* p) {
+    if (!p) return;
+    p->max_std_dev = 3.0f;
+    p->cull_margin = 1.3f;
+    p->jacobian_clamp = 1.3f;
+    p->low_pass = 0.3f;
+    p->alpha_max = 1.0f;
+    p->alpha_min = 0.0f;
+    p->t_epsilon = 1e-4f;
+    p->point_radius = 2.0f;
+}
+
+gsx_status gsx_viewer_create(const gsx_viewer_desc* desc, gsx_viewer** out) {
+    if (!desc || !out) return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_create: null argument");
+    if (desc->abi_version != GSX_ABI_VERSION)
+        return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_create: ABI version %u, library is %u", desc->abi_version, GSX_ABI_VERSION);
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(GSX_ERR_NO_DEVICE, "gsx_viewer_create: no HIP device (%s); libgsx has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (desc->device < 0 || desc->device >= count)
+        return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_create: device %d out of range [0,%d)", desc->device, count);
+    HIPCHK(hipSetDevice(desc->device));
+    std::unique_ptr<gsx_viewer> v(new gsx_viewer());
+    v->device = desc->device;
+    if (desc->stream) {
+        v->stream = reinterpret_cast<hipStream_t>(desc->stream);
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
+        v->own_stream = true;
+    }
+    gsx_spec_params_default(&v->params);
+    v->width = std::max(1u, desc->width);
+    v->height = std::max(1u, desc->height);
+    static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    memcpy(v->view, ident, sizeof ident);
+    memcpy(v->proj, ident, sizeof ident);
+    *out = v.release();
+    return GSX_OK;
+}
+
+void gsx_viewer_destroy(gsx_viewer* v) {
+    if (!v) return;
+    (void)hipSetDevice(v->device);
+    (void)hipStreamSynchronize(v->stream);
+    for (auto& t : v->timers) {
+        (void)hipEventDestroy(t.start);
+        (void)hipEventDestroy(t.stop);
+    }
+    for (auto& p : v->event_pool) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    v->models.clear();
+    if (v->own_stream) (void)hipStreamDestroy(v->stream);
+    delete v;
+}
+
+gsx_status gsx_viewer_set_spec_params(gsx_viewer* v, const gsx_spec_params* p) {
+    if (!v || !p) return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_set_spec_params: null argument");
+    if (!(p->max_std_dev > 0.0f) || !(p->cull_margin > 0.0f) || !(p->alpha_max > 0.0f))
+        return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_set_spec_params: max_std_dev, cull_margin, alpha_max must be > 0");
+    v->params = *p;
+    return GSX_OK;
+}
+
+gsx_status gsx_model_create(gsx_viewer* v, const char* key, uint64_t count, gsx_sh_kind sh, gsx_cov3d_kind cov3d) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    if (!key) return fail(GSX_ERR_INVALID_ARG, "gsx_model_create: key is null");
+    if (count >= 0xFFFFFFF0ull) return fail(GSX_ERR_INVALID_ARG, "gsx_model_create: count %llu too large", (unsigned long long)count);
+    if (v->models.count(key)) return fail(GSX_ERR_INVALID_ARG, "gsx_model_create: model '%s' exists", key);
+    if (!((sh == GSX_SH_SINGLE || sh == GSX_SH_NONE) && cov3d == GSX_COV3D_SINGLE))
+        return fail(GSX_ERR_UNSUPPORTED, "gsx_model_create: pod Sh%d/Cov3d%d not implemented yet (Single/None x Single only)", (int)sh, (int)cov3d);
+    std::unique_ptr<Model> m(new Model());
+    m->key = key;
+    m->n = count;
+    m->sh_kind = sh;
+    m->cov_kind = cov3d;
+    m->has_sh = sh != GSX_SH_NONE;
+    const size_t n = std::max<uint64_t>(count, 1);
+    HIPCHK(m->pc.ensure(16 * n));
+    HIPCHK(m->cov_a.ensure(16 * n));
+    HIPCHK(m->cov_b.ensure(8 * n));
+    if (m->has_sh) {
+        HIPCHK(m->sh4.ensure(16 * n * kShPlanes4));
+        HIPCHK(m->sh1.ensure(4 * n));
+    }
+    HIPCHK(m->mask.ensure(4 * ((n + 31) / 32)));
+    HIPCHK(m->key_buf.ensure(4 * n));
+    HIPCHK(m->rec_a.ensure(16 * n));
+    HIPCHK(m->rec_b.ensure(16 * n));
+    HIPCHK(m->rec_c.ensure(16 * n));
+    HIPCHK(m->sk_a.ensure(4 * n));
+    HIPCHK(m->sk_b.ensure(4 * n));
+    HIPCHK(m->sv_a.ensure(4 * n));
+    HIPCHK(m->sv_b.ensure(4 * n));
+    HIPCHK(m->table.ensure(4 * radix_table_entries(n)));
+    HIPCHK(m->cnt.ensure(4 * n));
+    HIPCHK(m->block_sums.ensure(4 * (scan_blocks(n) + 1)));
+    HIPCHK(m->counters.ensure(sizeof(Counters)));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&m->h_counters), sizeof(Counters), hipHostMallocDefault));
+    // a fresh model is all-zero Gaussians (new_empty) and fully unmasked (MaskOpTree::Reset, scene.rs:2124-2131)
+    HIPCHK(hipMemsetAsync(m->pc.p, 0, 16 * n, v->stream));
+    HIPCHK(hipMemsetAsync(m->cov_a.p, 0, 16 * n, v->stream));
+    HIPCHK(hipMemsetAsync(m->cov_b.p, 0, 8 * n, v->stream));
+    if (m->has_sh) {
+        HIPCHK(hipMemsetAsync(m->sh4.p, 0, 16 * n * kShPlanes4, v->stream));
+        HIPCHK(hipMemsetAsync(m->sh1.p, 0, 4 * n, v->stream));
+    }
+    v->models[key] = std::move(m);
+    return GSX_OK;
+}
+
+gsx_status gsx_model_remove(gsx_viewer* v, const char* key) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_remove: no model '%s'", key ? key : "(null)");
+    HIPCHK(hipStreamSynchronize(v->stream));
+    v->models.erase(key);
+    return GSX_OK;
+}
+
+gsx_status gsx_model_len(gsx_viewer* v, const char* key, uint64_t* out_count) {
+    Model* m = find_model(v, key);
+    if (!m || !out_count) return fail(GSX_ERR_NOT_FOUND, "gsx_model_len: no model '%s'", key ? key : "(null)");
+    *out_count = m->n;
+    return GSX_OK;
+}
+
+gsx_status gsx_model_upload_range(gsx_viewer* v, const char* key, uint64_t start, const gsx_gaussian* src, uint64_t n) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_upload_range: no model '%s'", key ? key : "(null)");
+    if (n == 0) return GSX_OK;
+    if (!src) return fail(GSX_ERR_INVALID_ARG, "gsx_model_upload_range: src is null");
+    if (start > m->n || n > m->n - start)
+        return fail(GSX_ERR_INVALID_ARG, "gsx_model_upload_range: range [%llu,+%llu) exceeds model length %llu",
+                    (unsigned long long)start, (unsigned long long)n, (unsigned long long)m->n);
+    // stage in chunks so a multi-GB stream upload needs a bounded staging buffer
+    const uint64_t chunk = 1u << 20;
+    for (uint64_t off = 0; off < n; off += chunk) {
+        uint64_t c = std::min(chunk, n - off);
+        HIPCHK(v->staging.ensure(sizeof(gsx_gaussian) * c));
+        HIPCHK(hipMemcpyAsync(v->staging.p, src + off, sizeof(gsx_gaussian) * c, hipMemcpyHostToDevice, v->stream));
+        HIPCHK(launch_convert(v->stream, v->staging.as<gsx_gaussian>(), c, start + off, m->n, m->pod(), m->has_sh));
+        HIPCHK(hipStreamSynchronize(v->stream));  // the caller's memory may be reused after return
+    }
+    return GSX_OK;
+}
+
+gsx_status gsx_model_upload_pod_device(gsx_viewer* v, const char* key, uint64_t start, uint64_t n, const float* d_pos,
+                                       const uint32_t* d_color, const float* d_sh, const float* d_cov3d) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_upload_pod_device: no model '%s'", key ? key : "(null)");
+    if (n == 0) return GSX_OK;
+    if (!d_pos || !d_color || !d_cov3d || (m->has_sh && !d_sh))
+        return fail(GSX_ERR_INVALID_ARG, "gsx_model_upload_pod_device: null plane");
+    if (start > m->n || n > m->n - start) return fail(GSX_ERR_INVALID_ARG, "gsx_model_upload_pod_device: range exceeds model");
+    HIPCHK(launch_pack_pod(v->stream, d_pos, d_color, m->has_sh ? d_sh : nullptr, d_cov3d, n, start, m->n, m->pod()));
+    return GSX_OK;
+}
+
+gsx_status gsx_update_camera(gsx_viewer* v, const float view[16], const float proj[16], uint32_t width, uint32_t height) {
+    if (!v || !view || !proj) return fail(GSX_ERR_INVALID_ARG, "gsx_update_camera: null argument");
+    if (width == 0 || height == 0 || width > 65535u * GSX_TILE || height > 65535u * GSX_TILE)
+        return fail(GSX_ERR_INVALID_ARG, "gsx_update_camera: size %ux%u out of range", width, height);
+    memcpy(v->view, view, sizeof(float) * 16);
+    memcpy(v->proj, proj, sizeof(float) * 16);
+    v->width = width;
+    v->height = height;
+    return GSX_OK;
+}
+
+gsx_status gsx_update_model_transform(gsx_viewer* v, const char* key, const float pos[3], const float quat[4],
+                                      const float scale[3]) {
+    Model* m = find_model(v, key);
+    if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_update_model_transform: no model '%s'", key ? key : "(null)");
+    if (!pos || !quat || !scale) return fail(GSX_ERR_INVALID_ARG, "gsx_update_model_transform: null argument");
+    memcpy(m->mt.pos, pos, sizeof(float) * 3);
+    memcpy(m->mt.quat, quat, sizeof(float) * 4);
+    memcpy(m->mt.scale, scale, sizeof(float) * 3);
+    return GSX_OK;
+}
+
+gsx_status gsx_update_gaussian_transform(gsx_viewer* v, float size, gsx_display_mode mode, uint32_t sh_deg, uint32_t no_sh0) {
+    if (!v) return fail(GSX_ERR_INVALID_ARG, "gsx_update_gaussian_transform: viewer is null");
+    // GaussianShDegree::new returns None above 3 (transform.rs:139)
+    if (sh_deg > 3) return fail(GSX_ERR_INVALID_ARG, "gsx_update_gaussian_transform: sh_deg %u > 3", sh_deg);
+    if ((int)mode < 0 || (int)mode > GSX_DISPLAY_POINT) return fail(GSX_ERR_INVALID_ARG, "gsx_update_gaussian_transform: bad display mode");
+    v->size = size;
+    v->display_mode = (uint32_t)mode;
+    v->sh_deg = sh_deg;
+    v->no_sh0 = no_sh0 ? 1u : 0u;
+    return GSX_OK;
+}
+
+gsx_status gsx_model_upload_mask(gsx_viewer* v, const char* key, const uint32_t* words, uint64_t n_words) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_upload_mask: no model '%s'", key ? key : "(null)");
+    if (!words) {  // MaskOpTree::Reset
+        m->has_mask = false;
+        return GSX_OK;
+    }
+    if (n_words != (m->n + 31) / 32) return fail(GSX_ERR_INVALID_ARG, "gsx_model_upload_mask: expected %llu words", (unsigned long long)((m->n + 31) / 32));
+    HIPCHK(hipMemcpyAsync(m->mask.p, words, 4 * n_words, hipMemcpyHostToDevice, v->stream));
+    HIPCHK(hipStreamSynchronize(v->stream));
+    m->has_mask = true;
+    return GSX_OK;
+}
+
+gsx_status gsx_model_download_mask(gsx_viewer* v, const char* key, uint32_t* words, uint64_t n_words) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m || !words) return fail(GSX_ERR_NOT_FOUND, "gsx_model_download_mask: no model '%s'", key ? key : "(null)");
+    if (n_words != (m->n + 31) / 32) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_mask: expected %llu words", (unsigned long long)((m->n + 31) / 32));
+    if (!m->has_mask) {
+        memset(words, 0xFF, 4 * n_words);
+        return GSX_OK;
+    }
+    HIPCHK(hipStreamSynchronize(v->stream));
+    HIPCHK(hipMemcpy(words, m->mask.p, 4 * n_words, hipMemcpyDeviceToHost));
+    return GSX_OK;
+}
+
+gsx_status gsx_preprocess(gsx_viewer* v, const char* key) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_preprocess: no model '%s'", key ? key : "(null)");
+    return do_preprocess(v, m);
+}
+
+gsx_status gsx_sort(gsx_viewer* v, const char* key) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_sort: no model '%s'", key ? key : "(null)");
+    return do_sort(v, m);
+}
+
+gsx_status gsx_sync(gsx_viewer* v) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    HIPCHK(hipStreamSynchronize(v->stream));
+    return sync_counters(v);
+}
+
+gsx_status gsx_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    return do_render(v, keys, n_keys);
+}
+
+gsx_status gsx_render_frame(gsx_viewer* v, const char* const* keys, uint32_t n_keys) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    for (uint32_t i = 0; i < n_keys; ++i) {
+        Model* m = find_model(v, keys ? keys[i] : nullptr);
+        if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_render_frame: no model '%s'", keys && keys[i] ? keys[i] : "(null)");
+        if ((st = do_preprocess(v, m))) return st;
+        if ((st = do_sort(v, m))) return st;
+    }
+    return do_render(v, keys, n_keys);
+}
+
+gsx_status gsx_download_framebuffer(gsx_viewer* v, float* rgbt, uint64_t n_floats) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    const uint64_t need = 4ull * v->width * v->height;
+    if (!rgbt || n_floats != need) return fail(GSX_ERR_INVALID_ARG, "gsx_download_framebuffer: expected %llu floats", (unsigned long long)need);
+    if ((st = ensure_fb(v))) return st;
+    HIPCHK(hipStreamSynchronize(v->stream));
+    HIPCHK(hipMemcpy(rgbt, v->fb.p, sizeof(float) * need, hipMemcpyDeviceToHost));
+    return GSX_OK;
+}
+
+gsx_status gsx_download_rgba8(gsx_viewer* v, const float bg[3], uint8_t* rgba, uint64_t n_bytes) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    const uint64_t npx = (uint64_t)v->width * v->height;
+    if (!bg || !rgba || n_bytes != 4 * npx) return fail(GSX_ERR_INVALID_ARG, "gsx_download_rgba8: expected %llu bytes", (unsigned long long)(4 * npx));
+    if ((st = ensure_fb(v))) return st;
+    HIPCHK(v->scratch.ensure(4 * npx));
+    HIPCHK(launch_resolve_rgba8(v->stream, v->fb.as<float4>(), (uint32_t)npx, bg[0], bg[1], bg[2], v->scratch.as<uint32_t>()));
+    HIPCHK(hipStreamSynchronize(v->stream));
+    HIPCHK(hipMemcpy(rgba, v->scratch.p, 4 * npx, hipMemcpyDeviceToHost));
+    return GSX_OK;
+}
+
+gsx_status gsx_framebuffer_device_ptr(gsx_viewer* v, void** out_ptr, uint32_t* out_w, uint32_t* out_h) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    if (!out_ptr) return fail(GSX_ERR_INVALID_ARG, "gsx_framebuffer_device_ptr: null argument");
+    if ((st = ensure_fb(v))) return st;
+    *out_ptr = v->fb.p;
+    if (out_w) *out_w = v->width;
+    if (out_h) *out_h = v->height;
+    return GSX_OK;
+}
+
+gsx_status gsx_model_frame_stats(gsx_viewer* v, const char* key, gsx_frame_stats* out) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m || !out) return fail(GSX_ERR_NOT_FOUND, "gsx_model_frame_stats: no model '%s'", key ? key : "(null)");
+    if (!m->sorted) return fail(GSX_ERR_INVALID_ARG, "gsx_model_frame_stats: model '%s' not sorted this frame", key);
+    if ((st = sync_counters(v))) return st;
+    out->n_gaussians = m->n;
+    out->n_visible = m->n_visible;
+    out->n_tile_entries = m->n_entries;
+    return GSX_OK;
+}
+
+gsx_status gsx_model_download_projection(gsx_viewer* v, const char* key, uint32_t* depth_key, uint32_t* rect, float* mean2d,
+                                         float* conic_opacity, float* rgb) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_download_projection: no model '%s'", key ? key : "(null)");
+    if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_projection: model '%s' not preprocessed", key);
+    HIPCHK(hipStreamSynchronize(v->stream));
+    const size_t n = m->n;
+    std::vector<uint32_t> k(n);
+    std::vector<float4> a(n), b(n), c(n);
+    HIPCHK(hipMemcpy(k.data(), m->key_buf.p, 4 * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(a.data(), m->rec_a.p, 16 * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(b.data(), m->rec_b.p, 16 * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(c.data(), m->rec_c.p, 16 * n, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) {
+        const bool vis = k[i] != kCulledKey;
+        if (depth_key) depth_key[i] = k[i];
+        uint32_t rx, ry;
+        memcpy(&rx, &a[i].z, 4);
+        memcpy(&ry, &a[i].w, 4);
+        if (rect) {
+            rect[4 * i + 0] = vis ? (rx & 0xFFFFu) : 0;
+            rect[4 * i + 1] = vis ? (ry & 0xFFFFu) : 0;
+            rect[4 * i + 2] = vis ? (rx >> 16) : 0;
+            rect[4 * i + 3] = vis ? (ry >> 16) : 0;
+        }
+        if (mean2d) {
+            mean2d[2 * i] = vis ? a[i].x : 0.0f;
+            mean2d[2 * i + 1] = vis ? a[i].y : 0.0f;
+        }
+        if (conic_opacity) {
+            conic_opacity[4 * i] = vis ? b[i].x : 0.0f;
+            conic_opacity[4 * i + 1] = vis ? b[i].y : 0.0f;
+            conic_opacity[4 * i + 2] = vis ? b[i].z : 0.0f;
+            conic_opacity[4 * i + 3] = vis ? b[i].w : 0.0f;
+        }
+        if (rgb) {
+            rgb[3 * i] = vis ? c[i].x : 0.0f;
+            rgb[3 * i + 1] = vis ? c[i].y : 0.0f;
+            rgb[3 * i + 2] = vis ? c[i].z : 0.0f;
+        }
+    }
+    return GSX_OK;
+}
+
+gsx_status gsx_model_download_sorted(gsx_viewer* v, const char* key, uint32_t* indices, uint64_t capacity, uint64_t* out_n_visible) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_download_sorted: no model '%s'", key ? key : "(null)");
+    if (!m->sorted) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_sorted: model '%s' not sorted", key);
+    if ((st = sync_counters(v))) return st;
+    if (out_n_visible) *out_n_visible = m->n_visible;
+    if (indices) {
+        if (capacity < m->n_visible) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_sorted: capacity %llu < n_visible %u", (unsigned long long)capacity, m->n_visible);
+        HIPCHK(hipStreamSynchronize(v->stream));
+        if (m->n_visible) HIPCHK(hipMemcpy(indices, m->sorted_idx, 4ull * m->n_visible, hipMemcpyDeviceToHost));
+    }
+    return GSX_OK;
+}
+
+gsx_status gsx_model_download_tile_lists(gsx_viewer* v, const char* key, uint32_t* tile_offsets, uint64_t n_offsets,
+                                         uint32_t* list, uint64_t capacity) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_download_tile_lists: no model '%s'", key ? key : "(null)");
+    if (!m->binned) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_tile_lists: model '%s' not rendered this frame", key);
+    const uint32_t n_tiles = m->fc.tiles_x * m->fc.tiles_y;
+    if (n_offsets != (uint64_t)n_tiles + 1) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_tile_lists: expected %u offsets", n_tiles + 1);
+    HIPCHK(hipStreamSynchronize(v->stream));
+    std::vector<uint2> r(n_tiles);
+    HIPCHK(hipMemcpy(r.data(), m->ranges.p, sizeof(uint2) * n_tiles, hipMemcpyDeviceToHost));
+    uint32_t off = 0;
+    for (uint32_t t = 0; t < n_tiles; ++t) {
+        if (r[t].y > r[t].x && r[t].x != off)
+            return fail(GSX_ERR_HIP, "gsx_model_download_tile_lists: tile %u range [%u,%u) not contiguous at %u", t, r[t].x, r[t].y, off);
+        if (tile_offsets) tile_offsets[t] = off;
+        off += r[t].y - r[t].x;
+    }
+    if (tile_offsets) tile_offsets[n_tiles] = off;
+    if (off != m->n_entries) return fail(GSX_ERR_HIP, "gsx_model_download_tile_lists: ranges cover %u entries, D = %u", off, m->n_entries);
+    if (list) {
+        if (capacity < m->n_entries) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_tile_lists: capacity too small");
+        if (m->n_entries) HIPCHK(hipMemcpy(list, m->tile_list, 4ull * m->n_entries, hipMemcpyDeviceToHost));
+    }
+    return GSX_OK;
+}
+
+gsx_status gsx_model_download_pod(gsx_viewer* v, const char* key, float* pos, uint32_t* color, float* sh, float* cov3d) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_download_pod: no model '%s'", key ? key : "(null)");
+    if (!pos || !color || !cov3d) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_pod: null output");
+    const size_t n = m->n;
+    if (!n) return GSX_OK;
+    DevBuf dpos, dcol, dsh, dcov;
+    HIPCHK(dpos.ensure(12 * n));
+    HIPCHK(dcol.ensure(4 * n));
+    HIPCHK(dcov.ensure(24 * n));
+    if (sh) HIPCHK(dsh.ensure(180 * n));
+    HIPCHK(launch_unpack_pod(v->stream, m->pod(), n, dpos.as<float>(), dcol.as<uint32_t>(), sh ? dsh.as<float>() : nullptr,
+                             dcov.as<float>(), m->has_sh));
+    HIPCHK(hipStreamSynchronize(v->stream));
+    HIPCHK(hipMemcpy(pos, dpos.p, 12 * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(color, dcol.p, 4 * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cov3d, dcov.p, 24 * n, hipMemcpyDeviceToHost));
+    if (sh) HIPCHK(hipMemcpy(sh, dsh.p, 180 * n, hipMemcpyDeviceToHost));
+    return GSX_OK;
+}
+
+gsx_status gsx_set_pass_timing(gsx_viewer* v, uint32_t enabled) {
+    if (!v) return fail(GSX_ERR_INVALID_ARG, "gsx_set_pass_timing: viewer is null");
+    v->timing = enabled != 0;
+    return GSX_OK;
+}
+
+gsx_status gsx_get_pass_timing(gsx_viewer* v, float ms[GSX_PASS_COUNT], uint32_t launches[GSX_PASS_COUNT]) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    HIPCHK(hipStreamSynchronize(v->stream));
+    for (auto& t : v->timers) {
+        float e = 0.0f;
+        if (hipEventElapsedTime(&e, t.start, t.stop) == hipSuccess) v->pass_ms[t.pass] += e;
+        v->event_pool.push_back({t.start, t.stop});
+    }
+    v->timers.clear();
+    for (int i = 0; i < GSX_PASS_COUNT; ++i) {
+        if (ms) ms[i] = v->pass_ms[i];
+        if (launches) launches[i] = v->pass_launches[i];
+        v->pass_ms[i] = 0.0f;
+        v->pass_launches[i] = 0;
+    }
+    return GSX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+// gsx_internal.h — shared between the C-ABI host code (gsx_api.cpp) and the gfx950 kernels.
+// Everything here is build-internal; the public surface is include/gsx.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gsx.h"
+
+namespace gsx {
+
+constexpr int kTile = GSX_TILE;          // 16x16 px screen tiles
+constexpr int kShPlanes4 = 11;           // 45 SH floats = 11 float4 planes + 1 float plane
+constexpr uint32_t kCulledKey = 0xFFFFFFFFu;
+
+// Per-(camera, model, gaussian-transform) constants, derived once per preprocess on the host in
+// float32 with the operation order of spec/RENDER_SPEC.md §3 and passed to the kernels by value.
+struct FrameConsts {
+    float T[9];       // row-major 3x3: W * R_m * diag(s_m)
+    float vt[3];      // W * t_m + view translation
+    float P[16];      // projection, column-major
+    float cam_m[3];   // camera in unscaled model space
+    float s_m[3];     // model scale
+    float fx, fy, limx, limy;
+    float width, height;
+    float size2, k, k2;
+    float low_pass, cull_margin, alpha_max, alpha_min, point_radius, t_eps;
+    uint32_t w_px, h_px, tiles_x, tiles_y;
+    uint32_t sh_deg, no_sh0, display_mode;
+};
+
+struct ModelTransform {
+    float pos[3] = {0, 0, 0};
+    float quat[4] = {0, 0, 0, 1};
+    float scale[3] = {1, 1, 1};
+};
+
+void frame_consts_setup(const float view[16], const float proj[16], uint32_t width, uint32_t height,
+                        const ModelTransform& mt, float size, uint32_t display_mode, uint32_t sh_deg, uint32_t no_sh0,
+                        const gsx_spec_params& sp, FrameConsts* out);
+
+// Resident pod planes of one model (SoA, every plane contiguous over the model's N Gaussians).
+struct PodPlanes {
+    float4* pc;      // N   : x, y, z, bitcast(rgba8)
+    float4* cov_a;   // N   : xx, xy, xz, yy
+    float2* cov_b;   // N   : yz, zz
+    float4* sh4;     // 11*N: plane p holds SH floats 4p..4p+3 of every Gaussian (float index = 3*coeff + channel)
+    float* sh1;      // N   : SH float 44
+    uint32_t* mask;  // ceil(N/32) words, bit = keep (nullptr: keep all)
+};
+
+// Projected records of one model for the current frame (valid where key != kCulledKey).
+struct Records {
+    uint32_t* key;   // N : f32 bit pattern of view depth, kCulledKey when culled
+    float4* a;       // N : mean.x, mean.y, bitcast(x0 | x1<<16), bitcast(y0 | y1<<16)   (tile rect, max exclusive)
+    float4* b;       // N : conic a, b, c, opacity
+    float4* c;       // N : r, g, b, view depth
+};
+
+// ---- launch wrappers (one per kernel family); all enqueue on `s` and return the launch status ----
+hipError_t launch_convert(hipStream_t s, const gsx_gaussian* d_src, uint64_t n, uint64_t start, uint64_t model_n,
+                          const PodPlanes& pod, bool has_sh);
+hipError_t launch_pack_pod(hipStream_t s, const float* d_pos, const uint32_t* d_color, const float* d_sh,
+                           const float* d_cov, uint64_t n, uint64_t start, uint64_t model_n, const PodPlanes& pod);
+hipError_t launch_unpack_pod(hipStream_t s, const PodPlanes& pod, uint64_t model_n, float* d_pos, uint32_t* d_color,
+                             float* d_sh, float* d_cov, bool has_sh);
+hipError_t launch_project(hipStream_t s, const FrameConsts& f, uint32_t n, const PodPlanes& pod, bool has_sh,
+                          const Records& rec, uint32_t* d_n_visible);
+
+// Stable LSD radix sort of (key,value) u32 pairs, 8-bit digits.  `bits` = number of significant key bits.
+// Pass 0 reads (keys_src, vals_src) and never writes them; passes then ping-pong src -> a -> b -> a ...
+// iota_values: the value of element i is i (vals_src unused).  *result_in_b says where the result landed.
+struct RadixBuffers {
+    const uint32_t *keys_src, *vals_src;
+    uint32_t *keys_a, *vals_a, *keys_b, *vals_b;
+    uint32_t* table;  // 256 * nblocks(n) + 256 entries
+};
+size_t radix_table_entries(uint64_t n);
+hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n, int bits, bool iota_values,
+                             bool* result_in_b);
+
+// Tile binning.
+// n_upper bounds the launch (the model's N); the kernel reads the real N_vis from *d_n_vis.
+hipError_t launch_tile_counts(hipStream_t s, uint32_t n_upper, const uint32_t* d_n_vis, const uint32_t* sorted_idx,
+                              const Records& rec, uint32_t* cnt, uint32_t* block_sums, uint32_t* d_total /* D */);
+hipError_t launch_tile_emit(hipStream_t s, uint32_t n_vis, const uint32_t* sorted_idx, const Records& rec,
+                            const uint32_t* cnt, const uint32_t* block_sums, uint32_t tiles_x, uint32_t* tkey,
+                            uint32_t* tval);
+hipError_t launch_tile_ranges(hipStream_t s, uint32_t D, const uint32_t* tkey_sorted, uint32_t n_tiles,
+                              uint2* ranges);
+size_t scan_blocks(uint64_t n);
+
+// Compositing and resolve.
+hipError_t launch_composite(hipStream_t s, const FrameConsts& f, const uint2* ranges, const uint32_t* list,
+                            const Records& rec, float4* fb, bool first_model);
+hipError_t launch_clear_fb(hipStream_t s, float4* fb, uint32_t n_px);
+hipError_t launch_resolve_rgba8(hipStream_t s, const float4* fb, uint32_t n_px, float bg_r, float bg_g, float bg_b,
+                                uint32_t* out_rgba8);
+
+}  // namespace gsx

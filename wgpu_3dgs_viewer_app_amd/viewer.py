@@ -1,0 +1,336 @@
+"""Host-side mirror of the ``wgpu-3dgs-viewer`` (``gs::``) surface the app uses for the render path.
+
+The reference's host language is Rust (no toolchain in this image), so this mirror over the C ABI is
+Python; names, argument order and error behaviour follow the reference call sites so tests read like
+the app's frame loop (src/tab/scene.rs:699-874, 2263-2326):
+
+    viewer = MultiModelViewer(size=(1, 1))                      # MultiModelViewer::new_with   scene.rs:1969
+    viewer.add_model("a", count)                                # new_empty + BindGroups::new   scene.rs:2111
+    viewer.models["a"].gaussian_buffers.gaussians_buffer.update_range(start, gaussians)  # scene.rs:2083
+    viewer.update_camera(camera, (w, h))                        # scene.rs:795
+    viewer.update_model_transform("a", pos, quat, scale)        # scene.rs:796
+    viewer.update_gaussian_transform(1.0, Splat, GaussianShDegree.new(3), False)  # scene.rs:803
+    viewer.preprocessor.preprocess("a"); viewer.radix_sorter.sort("a")           # scene.rs:856, 865
+    viewer.poll()                                               # device.poll(Maintain::Wait)    scene.rs:873
+    viewer.renderer.render(keys_far_to_near)                    # render_with_pass loop          scene.rs:2302
+
+Every call goes into libgsx.so (HIP kernels); nothing here computes pixels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from typing import Iterable, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import GsxError, SpecParams  # noqa: F401  (re-exported)
+from .scene import GAUSSIAN_DTYPE
+
+
+class GaussianDisplayMode(enum.IntEnum):
+    """``gs::GaussianDisplayMode`` (src/app.rs:1147, src/tab/transform.rs:106-146)."""
+
+    Splat = 0
+    Ellipse = 1
+    Point = 2
+
+
+class GaussianShDegree:
+    """``gs::GaussianShDegree``: 0..=3; ``new`` returns ``None`` out of range (src/tab/transform.rs:139)."""
+
+    def __init__(self, deg: int):
+        self.deg = int(deg)
+
+    @classmethod
+    def new(cls, deg: int):
+        return cls(deg) if 0 <= int(deg) <= 3 else None
+
+    @classmethod
+    def new_unchecked(cls, deg: int) -> "GaussianShDegree":
+        return cls(deg)
+
+    def degree(self) -> int:
+        return self.deg
+
+
+class ShKind(enum.IntEnum):
+    """``GaussianSh{Single,Half,Norm8,None}Config`` (src/app.rs:386-403)."""
+
+    Single = 0
+    Half = 1
+    Norm8 = 2
+    Remove = 3
+
+
+class Cov3dKind(enum.IntEnum):
+    """``GaussianCov3d{Single,Half}Config`` (src/app.rs:405-418)."""
+
+    Single = 0
+    Half = 1
+
+
+def _f32p(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _u32p(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+class GaussiansBuffer:
+    """``gs::GaussiansBuffer<G>``: the model's resident pod planes in HBM."""
+
+    def __init__(self, viewer: "MultiModelViewer", key: str):
+        self._v, self._key = viewer, key
+
+    def len(self) -> int:
+        n = C.c_uint64()
+        _lib.check(self._v._L.gsx_model_len(self._v._h, self._key.encode(), C.byref(n)))
+        return int(n.value)
+
+    __len__ = len
+
+    def update_range(self, start: int, gaussians: np.ndarray) -> None:
+        """``gaussians_buffer.update_range(queue, start, &[gs::Gaussian])`` (src/tab/scene.rs:2083-2084)."""
+        g = np.ascontiguousarray(gaussians, dtype=GAUSSIAN_DTYPE)
+        _lib.check(self._v._L.gsx_model_upload_range(self._v._h, self._key.encode(), int(start), g.ctypes.data, g.shape[0]))
+
+    def update_range_pod_device(self, start: int, n: int, d_pos: int, d_color: int, d_sh: int, d_cov3d: int) -> None:
+        """Zero-copy upload of pod planes that already live in device memory (raw device pointers)."""
+        _lib.check(self._v._L.gsx_model_upload_pod_device(self._v._h, self._key.encode(), int(start), int(n), d_pos,
+                                                          d_color, d_sh, d_cov3d))
+
+    def download_pod(self):
+        n = self.len()
+        pos = np.empty((n, 3), np.float32)
+        color = np.empty(n, np.uint32)
+        sh = np.empty((n, 45), np.float32)
+        cov = np.empty((n, 6), np.float32)
+        _lib.check(self._v._L.gsx_model_download_pod(self._v._h, self._key.encode(), _f32p(pos), _u32p(color), _f32p(sh), _f32p(cov)))
+        return pos, color, sh, cov
+
+
+class MaskBuffer:
+    """``gs::MaskBuffer``: one bit per Gaussian, 1 = kept (src/tab/scene.rs:1851, src/app.rs:806-807)."""
+
+    def __init__(self, viewer: "MultiModelViewer", key: str):
+        self._v, self._key = viewer, key
+
+    def upload(self, words: np.ndarray | None) -> None:
+        if words is None:
+            _lib.check(self._v._L.gsx_model_upload_mask(self._v._h, self._key.encode(), None, 0))
+            return
+        w = np.ascontiguousarray(words, dtype=np.uint32)
+        _lib.check(self._v._L.gsx_model_upload_mask(self._v._h, self._key.encode(), _u32p(w), w.size))
+
+    def download(self) -> np.ndarray:
+        n = (self._v.models[self._key].gaussian_buffers.gaussians_buffer.len() + 31) // 32
+        w = np.empty(n, np.uint32)
+        _lib.check(self._v._L.gsx_model_download_mask(self._v._h, self._key.encode(), _u32p(w), n))
+        return w
+
+
+class MultiModelViewerGaussianBuffers:
+    """``gs::MultiModelViewerGaussianBuffers<G>`` (src/tab/scene.rs:2111-2112)."""
+
+    def __init__(self, viewer: "MultiModelViewer", key: str):
+        self.gaussians_buffer = GaussiansBuffer(viewer, key)
+        self.mask_buffer = MaskBuffer(viewer, key)
+
+
+class MultiModelViewerModel:
+    """``gs::MultiModelViewerModel {gaussian_buffers, bind_groups}`` (src/tab/scene.rs:2133-2139)."""
+
+    def __init__(self, viewer: "MultiModelViewer", key: str):
+        self.gaussian_buffers = MultiModelViewerGaussianBuffers(viewer, key)
+
+
+class _Preprocessor:
+    def __init__(self, v):
+        self._v = v
+
+    def preprocess(self, key: str) -> None:
+        """``preprocessor.preprocess(encoder, bind_group, gaussian_count)`` (src/tab/scene.rs:856-863)."""
+        _lib.check(self._v._L.gsx_preprocess(self._v._h, key.encode()))
+
+
+class _RadixSorter:
+    def __init__(self, v):
+        self._v = v
+
+    def sort(self, key: str) -> None:
+        """``radix_sorter.sort(encoder, bind_group, indirect_args)`` (src/tab/scene.rs:865-869)."""
+        _lib.check(self._v._L.gsx_sort(self._v._h, key.encode()))
+
+
+class _Renderer:
+    def __init__(self, v):
+        self._v = v
+
+    def render(self, model_render_keys: Sequence[str]) -> None:
+        """The ``render_with_pass`` loop over ``model_render_keys`` far -> near (src/tab/scene.rs:2302-2314)."""
+        keys = [k.encode() for k in model_render_keys]
+        arr = (C.c_char_p * max(len(keys), 1))(*keys)
+        _lib.check(self._v._L.gsx_render(self._v._h, arr, len(keys)))
+
+
+class MultiModelViewer:
+    """``gs::MultiModelViewer<G>`` over libgsx.so."""
+
+    def __init__(self, size=(1, 1), device: int = 0, stream: int | None = None, sh: ShKind = ShKind.Single,
+                 cov3d: Cov3dKind = Cov3dKind.Single):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        desc = _lib.ViewerDesc(_lib.GSX_ABI_VERSION, int(device), stream, int(size[0]), int(size[1]))
+        _lib.check(self._L.gsx_viewer_create(C.byref(desc), C.byref(self._h)))
+        self.sh, self.cov3d = ShKind(sh), Cov3dKind(cov3d)
+        self.models: dict[str, MultiModelViewerModel] = {}
+        self.preprocessor = _Preprocessor(self)
+        self.radix_sorter = _RadixSorter(self)
+        self.renderer = _Renderer(self)
+        self.size = (int(size[0]), int(size[1]))
+
+    # -- lifetime --
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.gsx_viewer_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- models --
+    def add_model(self, key: str, count: int) -> MultiModelViewerModel:
+        """``GaussianBuffers::new_empty(device, count)`` + ``BindGroups::new`` + ``models.insert`` (scene.rs:2111-2139)."""
+        _lib.check(self._L.gsx_model_create(self._h, key.encode(), int(count), int(self.sh), int(self.cov3d)))
+        self.models[key] = MultiModelViewerModel(self, key)
+        return self.models[key]
+
+    def remove_model(self, key: str) -> None:
+        """``viewer.remove_model(&key)`` (src/tab/scene.rs:2176)."""
+        _lib.check(self._L.gsx_model_remove(self._h, key.encode()))
+        self.models.pop(key, None)
+
+    # -- per-frame uniforms --
+    def update_camera(self, camera, size) -> None:
+        """``viewer.update_camera(queue, &impl CameraTrait, uvec2 size)`` (src/tab/scene.rs:795)."""
+        w, h = int(size[0]), int(size[1])
+        self.update_camera_with_matrices(camera.view(), camera.projection(w / h), (w, h))
+
+    def update_camera_with_matrices(self, view, proj, size) -> None:
+        v = np.ascontiguousarray(view, np.float32).reshape(16)
+        p = np.ascontiguousarray(proj, np.float32).reshape(16)
+        _lib.check(self._L.gsx_update_camera(self._h, _f32p(v), _f32p(p), int(size[0]), int(size[1])))
+        self.size = (int(size[0]), int(size[1]))
+
+    def update_model_transform(self, key: str, pos, quat, scale) -> None:
+        """``viewer.update_model_transform(queue, key, pos, quat, scale)`` (src/tab/scene.rs:796-802)."""
+        p = np.ascontiguousarray(pos, np.float32).reshape(3)
+        q = np.ascontiguousarray(quat, np.float32).reshape(4)
+        s = np.ascontiguousarray(scale, np.float32).reshape(3)
+        _lib.check(self._L.gsx_update_model_transform(self._h, key.encode(), _f32p(p), _f32p(q), _f32p(s)))
+
+    def update_gaussian_transform(self, size: float, display_mode: GaussianDisplayMode, sh_deg, no_sh0: bool) -> None:
+        """``viewer.update_gaussian_transform(queue, size, display_mode, sh_deg, no_sh0)`` (src/tab/scene.rs:803-809)."""
+        deg = sh_deg.degree() if isinstance(sh_deg, GaussianShDegree) else int(sh_deg)
+        _lib.check(self._L.gsx_update_gaussian_transform(self._h, float(size), int(display_mode), deg, 1 if no_sh0 else 0))
+
+    def set_spec_params(self, **kw) -> SpecParams:
+        sp = SpecParams()
+        self._L.gsx_spec_params_default(C.byref(sp))
+        for k, val in kw.items():
+            if not hasattr(sp, k):
+                raise KeyError(k)
+            setattr(sp, k, float(val))
+        _lib.check(self._L.gsx_viewer_set_spec_params(self._h, C.byref(sp)))
+        return sp
+
+    # -- frame execution --
+    def poll(self) -> None:
+        """``device.poll(wgpu::Maintain::Wait)`` (src/tab/scene.rs:614, 873)."""
+        _lib.check(self._L.gsx_sync(self._h))
+
+    def render_frame(self, model_render_keys: Sequence[str]) -> None:
+        """preprocess + sort every key, then render: the whole per-frame protocol in one call."""
+        keys = [k.encode() for k in model_render_keys]
+        arr = (C.c_char_p * max(len(keys), 1))(*keys)
+        _lib.check(self._L.gsx_render_frame(self._h, arr, len(keys)))
+
+    # -- readback --
+    def download_framebuffer(self) -> np.ndarray:
+        """float32 [H, W, 4]: premultiplied r,g,b and transmittance T."""
+        w, h = self.size
+        out = np.empty((h, w, 4), np.float32)
+        _lib.check(self._L.gsx_download_framebuffer(self._h, _f32p(out), out.size))
+        return out
+
+    def download_rgba8(self, background=(0.0, 0.0, 0.0)) -> np.ndarray:
+        w, h = self.size
+        out = np.empty((h, w, 4), np.uint8)
+        bg = np.ascontiguousarray(background, np.float32).reshape(3)
+        _lib.check(self._L.gsx_download_rgba8(self._h, _f32p(bg), out.ctypes.data_as(C.POINTER(C.c_uint8)), out.size))
+        return out
+
+    def framebuffer_device_ptr(self):
+        p, w, h = C.c_void_p(), C.c_uint32(), C.c_uint32()
+        _lib.check(self._L.gsx_framebuffer_device_ptr(self._h, C.byref(p), C.byref(w), C.byref(h)))
+        return p.value, int(w.value), int(h.value)
+
+    # -- parity / introspection --
+    def frame_stats(self, key: str) -> dict:
+        st = _lib.FrameStats()
+        _lib.check(self._L.gsx_model_frame_stats(self._h, key.encode(), C.byref(st)))
+        return dict(n_gaussians=int(st.n_gaussians), n_visible=int(st.n_visible), n_tile_entries=int(st.n_tile_entries))
+
+    def download_projection(self, key: str) -> dict:
+        n = self.models[key].gaussian_buffers.gaussians_buffer.len()
+        out = dict(key=np.empty(n, np.uint32), rect=np.empty((n, 4), np.uint32), mean2d=np.empty((n, 2), np.float32),
+                   conic_opacity=np.empty((n, 4), np.float32), rgb=np.empty((n, 3), np.float32))
+        _lib.check(self._L.gsx_model_download_projection(self._h, key.encode(), _u32p(out["key"]), _u32p(out["rect"]),
+                                                         _f32p(out["mean2d"]), _f32p(out["conic_opacity"]), _f32p(out["rgb"])))
+        out["n_visible"] = int(np.count_nonzero(out["key"] != 0xFFFFFFFF))
+        return out
+
+    def download_sorted(self, key: str) -> np.ndarray:
+        nv = C.c_uint64()
+        _lib.check(self._L.gsx_model_download_sorted(self._h, key.encode(), None, 0, C.byref(nv)))
+        idx = np.empty(max(int(nv.value), 1), np.uint32)
+        _lib.check(self._L.gsx_model_download_sorted(self._h, key.encode(), _u32p(idx), idx.size, C.byref(nv)))
+        return idx[: int(nv.value)]
+
+    def download_tile_lists(self, key: str):
+        st = self.frame_stats(key)
+        w, h = self.size
+        tiles = ((w + 15) // 16) * ((h + 15) // 16)
+        off = np.empty(tiles + 1, np.uint32)
+        lst = np.empty(max(st["n_tile_entries"], 1), np.uint32)
+        _lib.check(self._L.gsx_model_download_tile_lists(self._h, key.encode(), _u32p(off), off.size, _u32p(lst), lst.size))
+        return off, lst[: st["n_tile_entries"]]
+
+    # -- timing --
+    def set_pass_timing(self, enabled: bool) -> None:
+        _lib.check(self._L.gsx_set_pass_timing(self._h, 1 if enabled else 0))
+
+    def get_pass_timing(self) -> dict:
+        ms = (C.c_float * _lib.GSX_PASS_COUNT)()
+        launches = (C.c_uint32 * _lib.GSX_PASS_COUNT)()
+        _lib.check(self._L.gsx_get_pass_timing(self._h, ms, launches))
+        return {n: dict(ms=float(ms[i]), launches=int(launches[i])) for i, n in enumerate(_lib.GSX_PASS_NAMES)}
+
+
+def render_keys_far_to_near(viewer_models_centers: dict, camera_pos) -> list:
+    """``model_render_keys`` exactly as the app builds them (src/tab/scene.rs:533-558)."""
+    from .camera import model_render_order
+
+    return model_render_order(camera_pos, viewer_models_centers)
