@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py — frames/sec of the 3DGS render path on N MI355X (one process per GPU).
+
+A "step" is one frame: the whole hot path (projection -> depth sort -> tile binning -> tile sort ->
+composite [-> exchange/merge when N > 1]) over the resident synthetic scene at the next pose of the
+benchmark orbit.  Inputs are resident in HBM before the timed region starts.
+Prints ONE JSON line on rank 0.  The CPU oracle is used here only for the `cpu_baseline` leg.
+
+    python bench.py                       # N=1, cfg4 scene (10 M Gaussians, SH-3, 1920x1080)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=120)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="cfg4", help="cfg2 (1 M) | cfg3 (5.8 M) | cfg4 (10 M, headline)")
+    ap.add_argument("--gaussians", type=int, default=0, help="override the Gaussian count (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="Gaussians in the CPU baseline sample")
+    ap.add_argument("--force-dist", action="store_true", help="run the sharded exchange path even at N=1")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, n_sample, pose=0):
+    """Oracle (reference algorithm shape: cull -> global radix sort -> back-to-front splat-major raster) on the
+    host cores, one frame of a bounded sample of the same scene."""
+    import oracle
+    from wgpu_3dgs_viewer_app_amd import camera, scene
+
+    n, sh, w, h, seed = cfg
+    n_sample = min(n, n_sample)
+    g = scene.synthetic_gaussians(n, seed, sh, 0, n_sample)
+    pos, color, shc, cov = oracle.convert(g)
+    cam = camera.orbit_pose(pose)
+    f = oracle.frame_setup(cam.view(), cam.projection(w / h), w, h)
+    fb = oracle.new_framebuffer(f)
+    oracle.render_model(f, pos[:1000], color[:1000], shc[:1000], cov[:1000], fb)  # page in / thread start
+    fb = oracle.new_framebuffer(f)
+    t0 = time.perf_counter()
+    nvis = oracle.render_model(f, pos, color, shc, cov, fb)
+    dt = time.perf_counter() - t0
+    return dict(value=round(1.0 / dt, 4), unit="frames/s", cores=oracle.num_threads(), kind="port",
+                sample=f"1 frame (orbit pose {pose}) of the first {n_sample} of {n} Gaussians of the same scene at {w}x{h}, "
+                       f"N_vis={nvis}, {dt:.2f} s; oracle/gsx_oracle.c, OpenMP")
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    from wgpu_3dgs_viewer_app_amd import camera, parallel, scene
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libgsx has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    n, sh, w, h, seed = scene.CONFIGS[args.workload]
+    if args.gaussians:
+        n = args.gaussians
+    cfg = (n, sh, w, h, seed)
+
+    # --- resident scene: each rank generates and uploads only its index shard ---
+    start, count = parallel.shard_range(n, rank, world)
+    t0 = time.perf_counter()
+    g = scene.synthetic_gaussians(n, seed, sh, start, count)
+    t_gen = time.perf_counter() - t0
+    renderer = parallel.ShardedViewer(device=local_rank, world=world, rank=rank, use_dist=use_dist,
+                                      stream=torch.cuda.current_stream().cuda_stream)
+    t0 = time.perf_counter()
+    renderer.load_shard(g, start, n)
+    renderer.poll()
+    t_up = time.perf_counter() - t0
+    upload_gbs = g.nbytes / t_up / 1e9
+    del g
+
+    def frame(i):
+        renderer.render_frame(camera.orbit_pose(i), (w, h))
+
+    for i in range(args.warmup):
+        frame(i)
+    renderer.poll()
+    renderer.set_pass_timing(True)
+    renderer.get_pass_timing()  # reset accumulators
+
+    def fence():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        frame(args.warmup + i)
+    renderer.poll()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    timing = renderer.get_pass_timing()
+    stats = renderer.last_stats()
+    renderer.set_pass_timing(False)
+
+    # gather per-rank stats for the roofline of the projection pass (dominant HBM stream of the path)
+    local = torch.tensor([stats["n_gaussians"], stats["n_visible"], stats["n_tile_entries"],
+                          timing["project"]["ms"] * 1e3, timing["project"]["launches"]], dtype=torch.float64, device="cuda")
+    if use_dist:
+        allr = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(allr, local)
+    else:
+        allr = [local]
+    allr = torch.stack(allr).cpu().numpy()
+
+    if rank == 0:
+        fps = args.steps / elapsed
+        # projection kernel: ALGORITHMIC bytes per launch = N*220 + N_vis*40 (SH-3 f32 pod),
+        # N, N_vis of the last frame of rank 0's shard; duration = HIP-event average over the timed region.
+        n_loc, nvis_loc = allr[0][0], allr[0][1]
+        pod_bytes = 220 if sh > 0 else 40
+        proj_bytes = n_loc * pod_bytes + nvis_loc * 40
+        proj_us = allr[0][3] / max(allr[0][4], 1)
+        achieved = proj_bytes / (proj_us * 1e-6) / 1e9 if proj_us > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc)).get(f"{args.workload}:{world}:k_project")
+                traffic = rec["hbm_bytes_per_launch"] if rec else None
+            except Exception:
+                traffic = None
+        passes = {}
+        for name, tv in timing.items():
+            passes[name] = round(tv["ms"] / args.steps, 4)
+        out = {
+            "metric": "frames/sec @1920x1080, N-Gaussian SH3 scene, 1/2/4/8 MI355X; %HBM roofline",
+            "value": round(fps, 3),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: synthetic {n} Gaussians SH-deg-{sh}, {w}x{h}, orbit r=6 h=1.5 240 poses, seed {seed}",
+                "gaussians": n, "width": w, "height": h, "sh_degree": sh,
+                "sharding": f"splat-index shards x{world}" + (", tile-row exchange + gather" if use_dist else ""),
+                "n_visible_rank0": int(nvis_loc), "tile_entries_rank0": int(allr[0][2]),
+                "pass_ms_per_frame_rank0": passes,
+                "upload_GBps_pcie_inclusive": round(upload_gbs, 2), "scene_gen_s": round(t_gen, 1),
+            },
+            "roofline": {
+                "kernel": "k_project<3> (projection pass: SH-3 colour + cov2d + cull + depth key)",
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(proj_bytes), "avg_launch_us": round(proj_us, 2),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+
+    renderer.close()
+    if use_dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -167,6 +167,29 @@ gsx_status gsx_model_download_tile_lists(gsx_viewer* v, const char* key, uint32_
 gsx_status gsx_model_download_pod(gsx_viewer* v, const char* key, float* pos, uint32_t* color, float* sh,
                                   float* cov3d);
 
+/* ---- multi-GPU stage split.  No reference counterpart: the reference renders on one wgpu device
+ *      (src/main.rs:85-98).  One process per GPU holds an index shard of the Gaussians; tile row ty of
+ *      the screen belongs to rank ty % world.  Per frame and rank:
+ *        gsx_preprocess(key)                       project the resident shard
+ *        gsx_shard_pack(...)                       visible records grouped by destination rank
+ *        [RCCL all-to-all of the 48-byte records, done by the caller]
+ *        gsx_shard_import(...); gsx_sort(key)      received records become the frame's record set
+ *        gsx_render(&key, 1)                       bins + composites only this rank's tile rows
+ *        gsx_shard_pack_strip(...)                 this rank's rows, packed
+ *        [RCCL gather of the strips]  gsx_shard_unpack_strips(...) on the gathering rank ---- */
+#define GSX_RECORD_BYTES 48u /* mean.xy rect.xy | conic.abc opacity | rgb depth */
+/* counts[world] (host) = records per destination; d_send (device) receives them grouped by destination,
+ * ascending local index inside each group.  Synchronises. */
+gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, void* d_send, uint64_t capacity_records,
+                          uint64_t* counts);
+/* d_recv (device): n_records records ordered by (source rank, source index).  Replaces the model's
+ * projection results for this frame and restricts binning to tile rows with row % world == rank. */
+gsx_status gsx_shard_import(gsx_viewer* v, const char* key, const void* d_recv, uint64_t n_records, uint32_t world,
+                            uint32_t rank);
+gsx_status gsx_shard_strip_bytes(gsx_viewer* v, uint32_t world, uint64_t* out_bytes);
+gsx_status gsx_shard_pack_strip(gsx_viewer* v, uint32_t world, uint32_t rank, void* d_strip, uint64_t strip_bytes);
+gsx_status gsx_shard_unpack_strips(gsx_viewer* v, uint32_t world, const void* d_all, uint64_t bytes);
+
 /* ---- timing: HIP events recorded on the viewer's stream around each pass of the last frame ---- */
 typedef enum gsx_pass {
     GSX_PASS_PROJECT = 0,

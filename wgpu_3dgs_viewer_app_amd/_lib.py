@@ -26,6 +26,7 @@ EXPORTS = (
     "gsx_render_frame", "gsx_download_framebuffer", "gsx_download_rgba8", "gsx_framebuffer_device_ptr",
     "gsx_model_frame_stats", "gsx_model_download_projection", "gsx_model_download_sorted",
     "gsx_model_download_tile_lists", "gsx_model_download_pod", "gsx_set_pass_timing", "gsx_get_pass_timing",
+    "gsx_shard_pack", "gsx_shard_import", "gsx_shard_strip_bytes", "gsx_shard_pack_strip", "gsx_shard_unpack_strips",
 )
 
 
@@ -94,6 +95,11 @@ def load() -> C.CDLL:
         "gsx_model_download_sorted": ([vp, cp, u32p, u64, C.POINTER(u64)], C.c_int32),
         "gsx_model_download_tile_lists": ([vp, cp, u32p, u64, u32p, u64], C.c_int32),
         "gsx_model_download_pod": ([vp, cp, f32p, u32p, f32p, f32p], C.c_int32),
+        "gsx_shard_pack": ([vp, cp, u32, vp, u64, C.POINTER(u64)], C.c_int32),
+        "gsx_shard_import": ([vp, cp, vp, u64, u32, u32], C.c_int32),
+        "gsx_shard_strip_bytes": ([vp, u32, C.POINTER(u64)], C.c_int32),
+        "gsx_shard_pack_strip": ([vp, u32, u32, vp, u64], C.c_int32),
+        "gsx_shard_unpack_strips": ([vp, u32, vp, u64], C.c_int32),
         "gsx_set_pass_timing": ([vp, u32], C.c_int32),
         "gsx_get_pass_timing": ([vp, f32p, u32p], C.c_int32),
     }

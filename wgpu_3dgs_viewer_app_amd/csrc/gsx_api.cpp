@@ -83,6 +83,7 @@ struct Model {
     DevBuf key_buf, rec_a, rec_b, rec_c;
     DevBuf sk_a, sk_b, sv_a, sv_b, table;      // depth sort ping-pong + histogram table
     DevBuf cnt, block_sums;                     // tile counts in depth order + scan partials
+    DevBuf block_vis;                           // per-workgroup visible counts of the projection pass
     DevBuf tk_src, tv_src, tk_a, tk_b, tv_a, tv_b, ttable;  // tile pairs
     DevBuf ranges;
     DevBuf counters;
@@ -92,6 +93,11 @@ struct Model {
     uint32_t* tile_keys = nullptr;
     bool preprocessed = false, sorted = false, counters_valid = false, binned = false;
     uint32_t n_visible = 0, n_entries = 0;
+    // the per-frame record set: the model's own projection (rec_n == n) or records imported from the
+    // other ranks (gsx_shard_import); binning is restricted to tile rows row % row_world == row_rank
+    uint64_t rec_n = 0, rec_cap = 0;
+    uint32_t row_world = 1, row_rank = 0;
+    DevBuf pack_table;
 
     ~Model() {
         if (h_counters) (void)hipHostFree(h_counters);
@@ -207,24 +213,47 @@ static gsx_status sync_counters(gsx_viewer* v) {
     return GSX_OK;
 }
 
+static gsx_status ensure_record_capacity(Model* m, uint64_t count) {
+    if (count <= m->rec_cap) return GSX_OK;
+    const size_t n = std::max<uint64_t>(count, 1);
+    HIPCHK(m->key_buf.ensure(4 * n));
+    HIPCHK(m->rec_a.ensure(16 * n));
+    HIPCHK(m->rec_b.ensure(16 * n));
+    HIPCHK(m->rec_c.ensure(16 * n));
+    HIPCHK(m->sk_a.ensure(4 * n));
+    HIPCHK(m->sk_b.ensure(4 * n));
+    HIPCHK(m->sv_a.ensure(4 * n));
+    HIPCHK(m->sv_b.ensure(4 * n));
+    HIPCHK(m->table.ensure(4 * radix_table_entries(n)));
+    HIPCHK(m->cnt.ensure(4 * n));
+    HIPCHK(m->block_sums.ensure(4 * (scan_blocks(n) + 1)));
+    HIPCHK(m->block_vis.ensure(4 * (project_blocks(n) + 1)));
+    m->rec_cap = n;
+    return GSX_OK;
+}
+
 static gsx_status do_preprocess(gsx_viewer* v, Model* m) {
     frame_consts_setup(v->view, v->proj, v->width, v->height, m->mt, v->size, v->display_mode, v->sh_deg, v->no_sh0,
                        v->params, &m->fc);
     m->preprocessed = m->sorted = m->counters_valid = m->binned = false;
-    HIPCHK(hipMemsetAsync(m->counters.p, 0, sizeof(Counters), v->stream));
+    gsx_status st = ensure_record_capacity(m, m->n);
+    if (st) return st;
+    m->rec_n = m->n;
+    m->row_world = 1;
+    m->row_rank = 0;
     {
-        ScopedPass t(v, GSX_PASS_PROJECT);
-        HIPCHK(launch_project(v->stream, m->fc, (uint32_t)m->n, m->pod(), m->has_sh, m->rec(),
-                              &m->counters.as<Counters>()->n_visible));
+        ScopedPass t(v, GSX_PASS_PROJECT);  // brackets the projection kernel alone (bench.py's roofline kernel)
+        HIPCHK(launch_project(v->stream, m->fc, (uint32_t)m->n, m->pod(), m->has_sh, m->rec(), m->block_vis.as<uint32_t>()));
         v->pass_launches[GSX_PASS_PROJECT] += m->n ? 1 : 0;
     }
+    HIPCHK(launch_sum_counts(v->stream, m->block_vis.as<uint32_t>(), (uint32_t)m->n, &m->counters.as<Counters>()->n_visible));
     m->preprocessed = true;
     return GSX_OK;
 }
 
 static gsx_status do_sort(gsx_viewer* v, Model* m) {
     if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_sort('%s') before gsx_preprocess", m->key.c_str());
-    const uint32_t n = (uint32_t)m->n;
+    const uint32_t n = (uint32_t)m->rec_n;
     {
         ScopedPass t(v, GSX_PASS_DEPTH_SORT);
         RadixBuffers rb{m->key_buf.as<uint32_t>(), nullptr, m->sk_a.as<uint32_t>(), m->sv_a.as<uint32_t>(),
@@ -238,7 +267,7 @@ static gsx_status do_sort(gsx_viewer* v, Model* m) {
         ScopedPass t(v, GSX_PASS_BIN);
         Counters* dc = m->counters.as<Counters>();
         HIPCHK(launch_tile_counts(v->stream, n, &dc->n_visible, m->sorted_idx, m->rec(), m->cnt.as<uint32_t>(),
-                                  m->block_sums.as<uint32_t>(), &dc->n_entries));
+                                  m->block_sums.as<uint32_t>(), &dc->n_entries, m->row_world, m->row_rank));
     }
     HIPCHK(hipMemcpyAsync(m->h_counters, m->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, v->stream));
     m->sorted = true;
@@ -264,7 +293,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool first) {
         HIPCHK(m->ranges.ensure(sizeof(uint2) * (size_t)n_tiles));
         HIPCHK(launch_tile_emit(v->stream, m->n_visible, m->sorted_idx, m->rec(), m->cnt.as<uint32_t>(),
                                 m->block_sums.as<uint32_t>(), m->fc.tiles_x, m->tk_src.as<uint32_t>(),
-                                m->tv_src.as<uint32_t>()));
+                                m->tv_src.as<uint32_t>(), m->row_world, m->row_rank));
         v->pass_launches[GSX_PASS_BIN] += 1;
     }
     {
@@ -419,17 +448,10 @@ gsx_status gsx_model_create(gsx_viewer* v, const char* key, uint64_t count, gsx_
         HIPCHK(m->sh1.ensure(4 * n));
     }
     HIPCHK(m->mask.ensure(4 * ((n + 31) / 32)));
-    HIPCHK(m->key_buf.ensure(4 * n));
-    HIPCHK(m->rec_a.ensure(16 * n));
-    HIPCHK(m->rec_b.ensure(16 * n));
-    HIPCHK(m->rec_c.ensure(16 * n));
-    HIPCHK(m->sk_a.ensure(4 * n));
-    HIPCHK(m->sk_b.ensure(4 * n));
-    HIPCHK(m->sv_a.ensure(4 * n));
-    HIPCHK(m->sv_b.ensure(4 * n));
-    HIPCHK(m->table.ensure(4 * radix_table_entries(n)));
-    HIPCHK(m->cnt.ensure(4 * n));
-    HIPCHK(m->block_sums.ensure(4 * (scan_blocks(n) + 1)));
+    {
+        gsx_status rst = ensure_record_capacity(m.get(), n);
+        if (rst) return rst;
+    }
     HIPCHK(m->counters.ensure(sizeof(Counters)));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&m->h_counters), sizeof(Counters), hipHostMallocDefault));
     // a fresh model is all-zero Gaussians (new_empty) and fully unmasked (MaskOpTree::Reset, scene.rs:2124-2131)
@@ -659,7 +681,7 @@ gsx_status gsx_model_download_projection(gsx_viewer* v, const char* key, uint32_
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_download_projection: no model '%s'", key ? key : "(null)");
     if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_projection: model '%s' not preprocessed", key);
     HIPCHK(hipStreamSynchronize(v->stream));
-    const size_t n = m->n;
+    const size_t n = m->rec_n;  // == model length unless records were imported (gsx_shard_import)
     std::vector<uint32_t> k(n);
     std::vector<float4> a(n), b(n), c(n);
     HIPCHK(hipMemcpy(k.data(), m->key_buf.p, 4 * n, hipMemcpyDeviceToHost));
@@ -761,6 +783,97 @@ gsx_status gsx_model_download_pod(gsx_viewer* v, const char* key, float* pos, ui
     HIPCHK(hipMemcpy(color, dcol.p, 4 * n, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(cov3d, dcov.p, 24 * n, hipMemcpyDeviceToHost));
     if (sh) HIPCHK(hipMemcpy(sh, dsh.p, 180 * n, hipMemcpyDeviceToHost));
+    return GSX_OK;
+}
+
+// ---- multi-GPU stage split ----------------------------------------------------------------------
+gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, void* d_send, uint64_t capacity_records,
+                          uint64_t* counts) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_pack: no model '%s'", key ? key : "(null)");
+    if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack: model '%s' not preprocessed", key);
+    if (world == 0 || world > 64 || !counts) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack: world must be 1..64");
+    const uint32_t n = (uint32_t)m->rec_n;
+    const uint32_t nb = (uint32_t)pack_blocks(n);
+    HIPCHK(m->pack_table.ensure(4 * ((size_t)64 * std::max(nb, 1u) + 64)));
+    uint32_t* table = m->pack_table.as<uint32_t>();
+    uint32_t* totals = table + (size_t)64 * std::max(nb, 1u);
+    HIPCHK(hipMemsetAsync(totals, 0, 4 * 64, v->stream));
+    HIPCHK(launch_pack_count(v->stream, m->rec(), n, world, table));
+    if (nb) HIPCHK(launch_rowscan(v->stream, table, world, nb, totals));
+    uint32_t h_tot[64];
+    HIPCHK(hipMemcpyAsync(h_tot, totals, 4 * 64, hipMemcpyDeviceToHost, v->stream));
+    HIPCHK(hipStreamSynchronize(v->stream));
+    uint64_t sum = 0;
+    for (uint32_t g = 0; g < world; ++g) {
+        counts[g] = h_tot[g];
+        sum += h_tot[g];
+    }
+    if (sum > capacity_records)
+        return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack: %llu records exceed the send capacity %llu",
+                    (unsigned long long)sum, (unsigned long long)capacity_records);
+    if (sum && !d_send) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack: d_send is null");
+    HIPCHK(launch_pack_scatter(v->stream, m->rec(), n, world, table, totals, d_send, capacity_records));
+    return GSX_OK;
+}
+
+gsx_status gsx_shard_import(gsx_viewer* v, const char* key, const void* d_recv, uint64_t n_records, uint32_t world,
+                            uint32_t rank) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_import: no model '%s'", key ? key : "(null)");
+    if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import: model '%s' has no frame constants (gsx_preprocess first)", key);
+    if (world == 0 || world > 64 || rank >= world) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import: bad world/rank %u/%u", world, rank);
+    if (n_records >= 0xFFFFFFF0ull) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import: too many records");
+    if (n_records && !d_recv) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import: d_recv is null");
+    if ((st = ensure_record_capacity(m, n_records))) return st;
+    HIPCHK(launch_import_records(v->stream, d_recv, (uint32_t)n_records, m->rec()));
+    // every imported record is visible by construction
+    uint32_t nv = (uint32_t)n_records;
+    HIPCHK(hipMemcpyAsync(&m->counters.as<Counters>()->n_visible, &nv, 4, hipMemcpyHostToDevice, v->stream));
+    HIPCHK(hipStreamSynchronize(v->stream));
+    m->rec_n = n_records;
+    m->row_world = world;
+    m->row_rank = rank;
+    m->sorted = m->counters_valid = m->binned = false;
+    return GSX_OK;
+}
+
+static uint32_t rows_per_rank(const gsx_viewer* v, uint32_t world) {
+    uint32_t tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
+    return (tiles_y + world - 1) / world;
+}
+
+gsx_status gsx_shard_strip_bytes(gsx_viewer* v, uint32_t world, uint64_t* out_bytes) {
+    if (!v || !out_bytes || world == 0) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_strip_bytes: bad argument");
+    *out_bytes = (uint64_t)rows_per_rank(v, world) * GSX_TILE * v->width * sizeof(float4);
+    return GSX_OK;
+}
+
+gsx_status gsx_shard_pack_strip(gsx_viewer* v, uint32_t world, uint32_t rank, void* d_strip, uint64_t strip_bytes) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    if (world == 0 || rank >= world || !d_strip) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack_strip: bad argument");
+    const uint32_t rpr = rows_per_rank(v, world);
+    if (strip_bytes != (uint64_t)rpr * GSX_TILE * v->width * sizeof(float4))
+        return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack_strip: strip must be %llu bytes", (unsigned long long)((uint64_t)rpr * GSX_TILE * v->width * sizeof(float4)));
+    if ((st = ensure_fb(v))) return st;
+    HIPCHK(launch_pack_strip(v->stream, v->fb.as<float4>(), v->width, v->height, world, rank, rpr, d_strip));
+    return GSX_OK;
+}
+
+gsx_status gsx_shard_unpack_strips(gsx_viewer* v, uint32_t world, const void* d_all, uint64_t bytes) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    if (world == 0 || !d_all) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_unpack_strips: bad argument");
+    const uint32_t rpr = rows_per_rank(v, world);
+    if (bytes != (uint64_t)world * rpr * GSX_TILE * v->width * sizeof(float4))
+        return fail(GSX_ERR_INVALID_ARG, "gsx_shard_unpack_strips: expected %llu bytes", (unsigned long long)((uint64_t)world * rpr * GSX_TILE * v->width * sizeof(float4)));
+    if ((st = ensure_fb(v))) return st;
+    HIPCHK(launch_unpack_strips(v->stream, d_all, v->width, v->height, world, rpr, v->fb.as<float4>()));
     return GSX_OK;
 }
 

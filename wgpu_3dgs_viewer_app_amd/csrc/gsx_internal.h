@@ -63,8 +63,12 @@ hipError_t launch_pack_pod(hipStream_t s, const float* d_pos, const uint32_t* d_
                            const float* d_cov, uint64_t n, uint64_t start, uint64_t model_n, const PodPlanes& pod);
 hipError_t launch_unpack_pod(hipStream_t s, const PodPlanes& pod, uint64_t model_n, float* d_pos, uint32_t* d_color,
                              float* d_sh, float* d_cov, bool has_sh);
+// d_block_visible: one count per 256-Gaussian workgroup (project_blocks(n) entries); launch_sum_counts
+// reduces them into *d_n_visible.
 hipError_t launch_project(hipStream_t s, const FrameConsts& f, uint32_t n, const PodPlanes& pod, bool has_sh,
-                          const Records& rec, uint32_t* d_n_visible);
+                          const Records& rec, uint32_t* d_block_visible);
+hipError_t launch_sum_counts(hipStream_t s, const uint32_t* d_block_visible, uint32_t n, uint32_t* d_n_visible);
+size_t project_blocks(uint64_t n);
 
 // Stable LSD radix sort of (key,value) u32 pairs, 8-bit digits.  `bits` = number of significant key bits.
 // Pass 0 reads (keys_src, vals_src) and never writes them; passes then ping-pong src -> a -> b -> a ...
@@ -80,14 +84,28 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
 
 // Tile binning.
 // n_upper bounds the launch (the model's N); the kernel reads the real N_vis from *d_n_vis.
+// (world, rank): only tile rows with row % world == rank are binned (1, 0 = all rows).
 hipError_t launch_tile_counts(hipStream_t s, uint32_t n_upper, const uint32_t* d_n_vis, const uint32_t* sorted_idx,
-                              const Records& rec, uint32_t* cnt, uint32_t* block_sums, uint32_t* d_total /* D */);
+                              const Records& rec, uint32_t* cnt, uint32_t* block_sums, uint32_t* d_total /* D */,
+                              uint32_t world, uint32_t rank);
 hipError_t launch_tile_emit(hipStream_t s, uint32_t n_vis, const uint32_t* sorted_idx, const Records& rec,
                             const uint32_t* cnt, const uint32_t* block_sums, uint32_t tiles_x, uint32_t* tkey,
-                            uint32_t* tval);
+                            uint32_t* tval, uint32_t world, uint32_t rank);
 hipError_t launch_tile_ranges(hipStream_t s, uint32_t D, const uint32_t* tkey_sorted, uint32_t n_tiles,
                               uint2* ranges);
 size_t scan_blocks(uint64_t n);
+
+// Multi-GPU exchange support (kernels_shard.hip).
+hipError_t launch_rowscan(hipStream_t s, uint32_t* table, uint32_t nrows, uint32_t nblocks, uint32_t* totals);
+size_t pack_blocks(uint64_t n);
+hipError_t launch_pack_count(hipStream_t s, const Records& rec, uint32_t n, uint32_t world, uint32_t* table);
+hipError_t launch_pack_scatter(hipStream_t s, const Records& rec, uint32_t n, uint32_t world, const uint32_t* table,
+                               const uint32_t* totals, void* d_send, uint64_t capacity);
+hipError_t launch_import_records(hipStream_t s, const void* d_recv, uint32_t n, const Records& rec);
+hipError_t launch_pack_strip(hipStream_t s, const float4* fb, uint32_t w, uint32_t h, uint32_t world, uint32_t rank,
+                             uint32_t rows_per_rank, void* d_strip);
+hipError_t launch_unpack_strips(hipStream_t s, const void* d_all, uint32_t w, uint32_t h, uint32_t world,
+                                uint32_t rows_per_rank, float4* fb);
 
 // Compositing and resolve.
 hipError_t launch_composite(hipStream_t s, const FrameConsts& f, const uint2* ranges, const uint32_t* list,

@@ -17,9 +17,17 @@ constexpr int kScanTile = kScanThreads * kScanItems;  // 4096 entries per workgr
 
 size_t scan_blocks(uint64_t n) { return (size_t)((n + kScanTile - 1) / kScanTile); }
 
-__device__ inline uint32_t rect_area(float4 a) {
+// Multi-GPU: a rank bins only the tile rows it owns (row % world == rank); world = 1 owns every row.
+__device__ inline uint32_t first_owned_row(uint32_t y0, uint32_t world, uint32_t rank) {
+    return y0 + ((rank + world - (y0 % world)) % world);
+}
+
+__device__ inline uint32_t rect_area(float4 a, uint32_t world, uint32_t rank) {
     uint32_t rx = __float_as_uint(a.z), ry = __float_as_uint(a.w);
-    return ((rx >> 16) - (rx & 0xFFFFu)) * ((ry >> 16) - (ry & 0xFFFFu));
+    uint32_t y0 = ry & 0xFFFFu, y1 = ry >> 16;
+    uint32_t first = first_owned_row(y0, world, rank);
+    uint32_t rows = first < y1 ? (y1 - 1u - first) / world + 1u : 0u;
+    return ((rx >> 16) - (rx & 0xFFFFu)) * rows;
 }
 
 __device__ inline uint32_t block_reduce_sum(uint32_t v, uint32_t* smem4) {
@@ -35,7 +43,8 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_counts(const uint32_t* __
                                                                const uint32_t* __restrict__ sorted_idx,
                                                                const float4* __restrict__ rec_a,
                                                                uint32_t* __restrict__ cnt,
-                                                               uint32_t* __restrict__ block_sums) {
+                                                               uint32_t* __restrict__ block_sums, uint32_t world,
+                                                               uint32_t rank) {
     __shared__ uint32_t red[4];
     uint32_t sum = 0;
     const uint32_t n_vis = *d_n_vis;
@@ -44,7 +53,7 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_counts(const uint32_t* __
     for (int r = 0; r < kScanItems; ++r) {
         uint32_t j = base + r * kScanThreads + threadIdx.x;
         if (j < n_vis) {
-            uint32_t c = rect_area(rec_a[sorted_idx[j]]);
+            uint32_t c = rect_area(rec_a[sorted_idx[j]], world, rank);
             cnt[j] = c;
             sum += c;
         }
@@ -87,7 +96,8 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_emit(uint32_t n_vis, cons
                                                              const float4* __restrict__ rec_a,
                                                              const uint32_t* __restrict__ cnt,
                                                              const uint32_t* __restrict__ block_offs, uint32_t tiles_x,
-                                                             uint32_t* __restrict__ tkey, uint32_t* __restrict__ tval) {
+                                                             uint32_t* __restrict__ tkey, uint32_t* __restrict__ tval,
+                                                             uint32_t world, uint32_t rank) {
     __shared__ uint32_t wsum[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     // each lane owns kScanItems CONSECUTIVE entries so the local scan is a serial prefix + one block scan
@@ -119,7 +129,7 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_emit(uint32_t n_vis, cons
         uint32_t rx = __float_as_uint(a.z), ry = __float_as_uint(a.w);
         uint32_t x0 = rx & 0xFFFFu, x1 = rx >> 16, y0 = ry & 0xFFFFu, y1 = ry >> 16;
         uint32_t o = off;
-        for (uint32_t ty = y0; ty < y1; ++ty)
+        for (uint32_t ty = first_owned_row(y0, world, rank); ty < y1; ty += world)
             for (uint32_t tx = x0; tx < x1; ++tx) {
                 tkey[o] = ty * tiles_x + tx;
                 tval[o] = idx;
@@ -140,21 +150,23 @@ __global__ __launch_bounds__(256) void k_tile_ranges(uint32_t D, const uint32_t*
 }
 
 hipError_t launch_tile_counts(hipStream_t s, uint32_t n_upper, const uint32_t* d_n_vis, const uint32_t* sorted_idx,
-                              const Records& rec, uint32_t* cnt, uint32_t* block_sums, uint32_t* d_total) {
+                              const Records& rec, uint32_t* cnt, uint32_t* block_sums, uint32_t* d_total, uint32_t world,
+                              uint32_t rank) {
     uint32_t nb = (uint32_t)scan_blocks(n_upper);
     if (nb)
-        hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(kScanThreads), 0, s, d_n_vis, sorted_idx, rec.a, cnt, block_sums);
+        hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(kScanThreads), 0, s, d_n_vis, sorted_idx, rec.a, cnt, block_sums,
+                           world, rank);
     hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nb, d_total);
     return hipGetLastError();
 }
 
 hipError_t launch_tile_emit(hipStream_t s, uint32_t n_vis, const uint32_t* sorted_idx, const Records& rec,
                             const uint32_t* cnt, const uint32_t* block_sums, uint32_t tiles_x, uint32_t* tkey,
-                            uint32_t* tval) {
+                            uint32_t* tval, uint32_t world, uint32_t rank) {
     uint32_t nb = (uint32_t)scan_blocks(n_vis);
     if (!nb) return hipSuccess;
     hipLaunchKernelGGL(k_tile_emit, dim3(nb), dim3(kScanThreads), 0, s, n_vis, sorted_idx, rec.a, cnt, block_sums,
-                       tiles_x, tkey, tval);
+                       tiles_x, tkey, tval, world, rank);
     return hipGetLastError();
 }
 

@@ -10,6 +10,7 @@
 // Built with -ffp-contract=off: every operation that feeds an integer decision (cull, tile rectangle)
 // is written in the exact order of spec/RENDER_SPEC.md §4 so the CPU oracle reproduces it bit-for-bit.
 #include "gsx_internal.h"
+#include "project_math.h"
 
 namespace gsx {
 
@@ -159,19 +160,14 @@ __global__ __launch_bounds__(256) void k_unpack_pod(PodPlanes pod, uint64_t mode
 // ------------------------------------------------------------------------------------------------
 // projection pass.  One Gaussian per lane, 256 lanes per workgroup; N/256 workgroups (>> 256 CUs).
 // DEG = SH degree evaluated (0 = DC only, no SH planes touched).
+// Load schedule chosen by measurement (tools/bench_project.hip, 10 M Gaussians on MI355X): SoA planes
+// with survivor-only dependent loads reach 4.8 TB/s algorithmic; a 256-Gaussian chunked AoSoA layout
+// was slower (4.0 TB/s), and eager "all loads first" was no faster.  The visible count is reduced per
+// workgroup: one same-address atomic per wave serialises at ~12 ns each and alone cost 1.8 ms at 10 M.
 // ------------------------------------------------------------------------------------------------
-__device__ __constant__ const float kShC1 = 0.4886025119029199f;
-__device__ __constant__ const float kShC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
-                                               -1.0925484305920792f, 0.5462742152960396f};
-__device__ __constant__ const float kShC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
-                                               0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
-                                               -0.5900435899266435f};
-
-__device__ inline float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
-
 template <int DEG>
 __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint32_t n, const PodPlanes pod,
-                                                  const Records rec, uint32_t* __restrict__ n_visible) {
+                                                  const Records rec, uint32_t* __restrict__ block_visible) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     bool vis = i < n;
     float4 pc = make_float4(0, 0, 0, 0);
@@ -179,139 +175,58 @@ __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint
     if (vis && pod.mask) vis = (pod.mask[i >> 5] >> (i & 31)) & 1u;
     const uint32_t color = __float_as_uint(pc.w);
 
-    // view / clip space and the frustum cull (spec §4.1-4.2)
-    float pv0 = ddot3(f.T[0], f.T[1], f.T[2], pc.x, pc.y, pc.z) + f.vt[0];
-    float pv1 = ddot3(f.T[3], f.T[4], f.T[5], pc.x, pc.y, pc.z) + f.vt[1];
-    float pv2 = ddot3(f.T[6], f.T[7], f.T[8], pc.x, pc.y, pc.z) + f.vt[2];
-    float xc = ((f.P[0] * pv0 + f.P[4] * pv1) + f.P[8] * pv2) + f.P[12];
-    float yc = ((f.P[1] * pv0 + f.P[5] * pv1) + f.P[9] * pv2) + f.P[13];
-    float zc = ((f.P[2] * pv0 + f.P[6] * pv1) + f.P[10] * pv2) + f.P[14];
-    float wc = ((f.P[3] * pv0 + f.P[7] * pv1) + f.P[11] * pv2) + f.P[15];
-    float lim = f.cull_margin * wc;
-    float d = -pv2;
-    vis = vis && (wc > 0.0f) && (xc >= -lim && xc <= lim && yc >= -lim && yc <= lim && zc >= 0.0f && zc <= wc) &&
-          (d > 0.0f);
+    ViewClip vc;
+    vis = pm_view_cull(f, pc.x, pc.y, pc.z, vc) && vis;
 
-    float mx = 0, my = 0, con_a = 0, con_b = 0, con_c = 0;
-    uint32_t rx = 0, ry = 0;
-    if (vis) {
-        // the covariance planes are only fetched for Gaussians that survive the frustum test
-        float4 cva = pod.cov_a[i];
-        float2 cvb = pod.cov_b[i];
-        float inv_d = 1.0f / d;
-        float tx = clampf(pv0 * inv_d, -f.limx, f.limx);
-        float ty = clampf(pv1 * inv_d, -f.limy, f.limy);
-        float j00 = f.fx * inv_d, j02 = (f.fx * tx) * inv_d;
-        float j11 = -(f.fy * inv_d), j12 = -((f.fy * ty) * inv_d);
-        float a00 = j00 * f.T[0] + j02 * f.T[6], a01 = j00 * f.T[1] + j02 * f.T[7], a02 = j00 * f.T[2] + j02 * f.T[8];
-        float a10 = j11 * f.T[3] + j12 * f.T[6], a11 = j11 * f.T[4] + j12 * f.T[7], a12 = j11 * f.T[5] + j12 * f.T[8];
-        // Sigma rows: (xx xy xz) (xy yy yz) (xz yz zz)
-        float v00 = ddot3(cva.x, cva.y, cva.z, a00, a01, a02);
-        float v01 = ddot3(cva.y, cva.w, cvb.x, a00, a01, a02);
-        float v02 = ddot3(cva.z, cvb.x, cvb.y, a00, a01, a02);
-        float v10 = ddot3(cva.x, cva.y, cva.z, a10, a11, a12);
-        float v11 = ddot3(cva.y, cva.w, cvb.x, a10, a11, a12);
-        float v12 = ddot3(cva.z, cvb.x, cvb.y, a10, a11, a12);
-        float ca = ddot3(a00, a01, a02, v00, v01, v02);
-        float cb = ddot3(a10, a11, a12, v00, v01, v02);
-        float cc = ddot3(a10, a11, a12, v10, v11, v12);
-        if (f.display_mode == GSX_DISPLAY_POINT) {
-            float rp = f.point_radius / f.k;
-            ca = rp * rp - f.low_pass;
-            cb = 0.0f;
-            cc = rp * rp - f.low_pass;
-        }
-        ca = (ca + f.low_pass) * f.size2;
-        cb = cb * f.size2;
-        cc = (cc + f.low_pass) * f.size2;
-        float det = ca * cc - cb * cb;
-        vis = det > 0.0f;
-        float inv_det = 1.0f / det;
-        float inv_w = 1.0f / wc;
-        float ndcx = xc * inv_w, ndcy = yc * inv_w;
-        mx = (ndcx * 0.5f + 0.5f) * f.width;
-        my = (0.5f - ndcy * 0.5f) * f.height;
-        float ex = f.k * sqrtf(ca), ey = f.k * sqrtf(cc);
-        float x0f = ceilf((mx - ex) - 0.5f), x1f = floorf((mx + ex) - 0.5f);
-        float y0f = ceilf((my - ey) - 0.5f), y1f = floorf((my + ey) - 0.5f);
-        x0f = fmaxf(x0f, 0.0f);
-        y0f = fmaxf(y0f, 0.0f);
-        x1f = fminf(x1f, f.width - 1.0f);
-        y1f = fminf(y1f, f.height - 1.0f);
-        vis = vis && (x0f <= x1f && y0f <= y1f);
-        if (vis) {
-            uint32_t x0 = (uint32_t)(int)x0f, x1 = (uint32_t)(int)x1f, y0 = (uint32_t)(int)y0f, y1 = (uint32_t)(int)y1f;
-            rx = (x0 / kTile) | (((x1 / kTile) + 1u) << 16);
-            ry = (y0 / kTile) | (((y1 / kTile) + 1u) << 16);
-        }
-        con_a = cc * inv_det;
-        con_b = -(cb * inv_det);
-        con_c = ca * inv_det;
+    Splat2D sp{};
+    if (vis) {  // the covariance planes are only fetched for Gaussians that survive the frustum test
+        const float4 cva = pod.cov_a[i];
+        const float2 cvb = pod.cov_b[i];
+        vis = pm_cov2d_rect(f, vc, cva.x, cva.y, cva.z, cva.w, cvb.x, cvb.y, sp);
     }
 
     float r = 0, g = 0, b = 0;
-    if (vis) {
-        if (!f.no_sh0) {
-            r = (float)(color & 255u) * (1.0f / 255.0f);
-            g = (float)((color >> 8) & 255u) * (1.0f / 255.0f);
-            b = (float)((color >> 16) & 255u) * (1.0f / 255.0f);
-        }
-        if (DEG > 0) {
-            // SH planes: float index 3*coeff + channel; plane p = floats 4p..4p+3.  Loaded only for survivors.
-            constexpr int kFloats = DEG == 1 ? 9 : (DEG == 2 ? 24 : 45);
-            constexpr int kPlanes = (kFloats + 3) / 4 > kShPlanes4 ? kShPlanes4 : (kFloats + 3) / 4;
-            float s[48];
+    if (vis) {  // SH planes: loaded only for survivors, only the planes the degree needs
+        float s[48];
 #pragma unroll
-            for (int p = 0; p < kPlanes; ++p) {
-                float4 v = pod.sh4[(uint64_t)p * n + i];
-                s[4 * p] = v.x; s[4 * p + 1] = v.y; s[4 * p + 2] = v.z; s[4 * p + 3] = v.w;
-            }
-            if (DEG == 3) s[44] = pod.sh1[i];
-            float dx = f.s_m[0] * pc.x - f.cam_m[0];
-            float dy = f.s_m[1] * pc.y - f.cam_m[1];
-            float dz = f.s_m[2] * pc.z - f.cam_m[2];
-            float len = sqrtf((dx * dx + dy * dy) + dz * dz);
-            float il = 1.0f / len;
-            float x = dx * il, y = dy * il, z = dz * il;
-            float acc[3];
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                float v = -kShC1 * y * s[0 + ch] + kShC1 * z * s[3 + ch] - kShC1 * x * s[6 + ch];
-                if (DEG > 1) {
-                    float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                    v += kShC2[0] * xy * s[9 + ch] + kShC2[1] * yz * s[12 + ch] +
-                         kShC2[2] * (2.0f * zz - xx - yy) * s[15 + ch] + kShC2[3] * xz * s[18 + ch] +
-                         kShC2[4] * (xx - yy) * s[21 + ch];
-                    if (DEG > 2) {
-                        v += kShC3[0] * y * (3.0f * xx - yy) * s[24 + ch] + kShC3[1] * xy * z * s[27 + ch] +
-                             kShC3[2] * y * (4.0f * zz - xx - yy) * s[30 + ch] +
-                             kShC3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * s[33 + ch] +
-                             kShC3[4] * x * (4.0f * zz - xx - yy) * s[36 + ch] + kShC3[5] * z * (xx - yy) * s[39 + ch] +
-                             kShC3[6] * x * (xx - 3.0f * yy) * s[42 + ch];
-                    }
-                }
-                acc[ch] = v;
-            }
-            r += acc[0];
-            g += acc[1];
-            b += acc[2];
+        for (int p = 0; p < ShNeed<DEG>::planes4; ++p) {
+            const float4 v = pod.sh4[(uint64_t)p * n + i];
+            s[4 * p] = v.x; s[4 * p + 1] = v.y; s[4 * p + 2] = v.z; s[4 * p + 3] = v.w;
         }
-        r = fmaxf(r, 0.0f);
-        g = fmaxf(g, 0.0f);
-        b = fmaxf(b, 0.0f);
+        if (DEG == 3) s[44] = pod.sh1[i];
+        pm_color<DEG>(f, pc.x, pc.y, pc.z, color, s, r, g, b);
     }
 
     if (i < n) {
-        rec.key[i] = vis ? __float_as_uint(d) : kCulledKey;
+        rec.key[i] = vis ? __float_as_uint(vc.d) : kCulledKey;
         if (vis) {
-            rec.a[i] = make_float4(mx, my, __uint_as_float(rx), __uint_as_float(ry));
-            rec.b[i] = make_float4(con_a, con_b, con_c, (float)(color >> 24) * (1.0f / 255.0f));
-            rec.c[i] = make_float4(r, g, b, d);
+            rec.a[i] = make_float4(sp.mx, sp.my, __uint_as_float(sp.rx), __uint_as_float(sp.ry));
+            rec.b[i] = make_float4(sp.con_a, sp.con_b, sp.con_c, (float)(color >> 24) * (1.0f / 255.0f));
+            rec.c[i] = make_float4(r, g, b, vc.d);
         }
     }
-    // one atomic per wave: N_vis is order-independent, so this stays deterministic
-    unsigned long long bal = __ballot(vis);
-    if ((threadIdx.x & 63u) == 0 && bal) atomicAdd(n_visible, (uint32_t)__popcll(bal));
+    __shared__ uint32_t wave_cnt[4];
+    const unsigned long long bal = __ballot(vis);
+    if ((threadIdx.x & 63u) == 0) wave_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) block_visible[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+// N_vis = sum of the per-workgroup counts (single workgroup; <= 40 K entries at 10 M Gaussians)
+__global__ __launch_bounds__(1024) void k_sum_counts(const uint32_t* __restrict__ block_visible, uint32_t nblocks,
+                                                      uint32_t* __restrict__ n_visible) {
+    __shared__ uint32_t red[16];
+    uint32_t s = 0;
+    for (uint32_t b = threadIdx.x; b < nblocks; b += 1024) s += block_visible[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        *n_visible = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -339,6 +254,13 @@ hipError_t launch_unpack_pod(hipStream_t s, const PodPlanes& pod, uint64_t model
     if (model_n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_unpack_pod, dim3(blocks_for(model_n, 256)), dim3(256), 0, s, pod, model_n, d_pos, d_color, d_sh,
                        d_cov, has_sh ? 1 : 0);
+    return hipGetLastError();
+}
+
+size_t project_blocks(uint64_t n) { return (size_t)((n + 255) / 256); }
+
+hipError_t launch_sum_counts(hipStream_t s, const uint32_t* d_block_visible, uint32_t n, uint32_t* d_n_visible) {
+    hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(1024), 0, s, d_block_visible, (uint32_t)project_blocks(n), d_n_visible);
     return hipGetLastError();
 }
 

@@ -162,6 +162,11 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_scatter(const uint32_t*
     }
 }
 
+hipError_t launch_rowscan(hipStream_t s, uint32_t* table, uint32_t nrows, uint32_t nblocks, uint32_t* totals) {
+    if (nrows) hipLaunchKernelGGL(k_radix_rowscan, dim3(nrows), dim3(256), 0, s, table, nblocks, totals);
+    return hipGetLastError();
+}
+
 hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n, int bits, bool iota_values,
                              bool* result_in_b) {
     *result_in_b = false;

@@ -51,37 +51,56 @@ def gaussians_from_ply(ply: np.ndarray) -> np.ndarray:
     return g
 
 
-def synthetic_ply(n: int, seed: int, sh_degree: int = 3, start: int = 0, count: int | None = None) -> np.ndarray:
+def _ply_block(n: int, seed: int, sh_degree: int, b: int, centres: np.ndarray, block: int) -> np.ndarray:
+    lo, hi = b * block, min((b + 1) * block, n)
+    m = hi - lo
+    rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([seed, b + 1])))
+    v = np.zeros(m, dtype=PLY_DTYPE)
+    uniform = rng.uniform(-4.0, 4.0, size=(m, 3)).astype(np.float32)
+    which = rng.integers(0, 64, size=m)
+    clustered = centres[which] + np.float32(0.25) * rng.standard_normal((m, 3), dtype=np.float32)
+    in_cluster = rng.random(m) < 0.3
+    v["pos"] = np.where(in_cluster[:, None], clustered, uniform)
+    v["scale"] = np.clip(np.float32(-4.0) + np.float32(0.7) * rng.standard_normal((m, 3), dtype=np.float32), -7.0, -1.0)
+    v["rot"] = rng.standard_normal((m, 4), dtype=np.float32)
+    v["opacity"] = np.float32(0.5) + np.float32(1.5) * rng.standard_normal(m, dtype=np.float32)
+    v["f_dc"] = rng.standard_normal((m, 3), dtype=np.float32)
+    if sh_degree > 0:
+        v["f_rest"] = np.float32(0.15) * rng.standard_normal((m, 45), dtype=np.float32)
+    return v
+
+
+def synthetic_ply(n: int, seed: int, sh_degree: int = 3, start: int = 0, count: int | None = None,
+                  workers: int | None = None) -> np.ndarray:
     """PLY-domain synthetic scene.  ``start``/``count`` select a contiguous shard of the
-    same scene: the stream is consumed in fixed blocks of 65536 Gaussians so a shard costs only its
-    own blocks (every block b draws from ``PCG64(seed).jumped(b + 1)``; cluster centres from the
-    un-jumped stream)."""
+    same scene: the scene is defined in fixed blocks of 65536 Gaussians, block b drawn from
+    ``PCG64(SeedSequence([seed, b + 1]))`` and the 64 cluster centres from ``PCG64(seed)``, so a shard
+    costs only its own blocks and blocks generate in parallel (numpy releases the GIL)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
     if count is None:
         count = n - start
     block = 65536
     centres = np.random.Generator(np.random.PCG64(seed)).uniform(-3.0, 3.0, size=(64, 3)).astype(np.float32)
     out = np.zeros(count, dtype=PLY_DTYPE)
+    if count == 0:
+        return out
     b0, b1 = start // block, (start + count + block - 1) // block
-    for b in range(b0, b1):
+
+    def work(b):
+        v = _ply_block(n, seed, sh_degree, b, centres, block)
         lo, hi = b * block, min((b + 1) * block, n)
-        m = hi - lo
-        rng = np.random.Generator(np.random.PCG64(seed).jumped(b + 1))
-        v = np.zeros(m, dtype=PLY_DTYPE)
-        uniform = rng.uniform(-4.0, 4.0, size=(m, 3)).astype(np.float32)
-        which = rng.integers(0, 64, size=m)
-        clustered = centres[which] + np.float32(0.25) * rng.standard_normal((m, 3), dtype=np.float32)
-        in_cluster = rng.random(m) < 0.3
-        v["pos"] = np.where(in_cluster[:, None], clustered, uniform)
-        v["scale"] = np.clip(np.float32(-4.0) + np.float32(0.7) * rng.standard_normal((m, 3), dtype=np.float32), -7.0, -1.0)
-        v["rot"] = rng.standard_normal((m, 4), dtype=np.float32)
-        v["opacity"] = np.float32(0.5) + np.float32(1.5) * rng.standard_normal(m, dtype=np.float32)
-        v["f_dc"] = rng.standard_normal((m, 3), dtype=np.float32)
-        rest = np.float32(0.15) * rng.standard_normal((m, 45), dtype=np.float32)
-        if sh_degree == 0:
-            rest[:] = 0.0
-        v["f_rest"] = rest
         s, e = max(lo, start), min(hi, start + count)
         out[s - start : e - start] = v[s - lo : e - lo]
+
+    workers = workers or min(32, os.cpu_count() or 1)
+    if b1 - b0 == 1 or workers == 1:
+        for b in range(b0, b1):
+            work(b)
+    else:
+        with ThreadPoolExecutor(workers) as ex:
+            list(ex.map(work, range(b0, b1)))
     return out
 
 
