@@ -77,6 +77,18 @@ typedef struct gsx_spec_params {
     float point_radius;   /* GSX_DISPLAY_POINT dot radius in px at size 1       (default 2.0) */
 } gsx_spec_params;
 
+/* How gsx_render schedules one model's splats (build-internal; no reference counterpart).
+ * progressive = 1: the depth-sorted splats are binned and composited front to back in growing depth slabs
+ * [0, N_vis/first_slab_divisor), then `growth` times larger each; tiles whose every pixel has reached
+ * T < t_epsilon are flagged and receive no further tile entries.  Pixels are identical to progressive = 0
+ * (the per-pixel operation sequence is unchanged); only the work on hidden splats is skipped. */
+typedef struct gsx_render_options {
+    uint32_t progressive;        /* default 1 */
+    uint32_t first_slab_divisor; /* default 16 */
+    uint32_t min_slab;           /* models with N_vis <= min_slab use one slab; default 131072 */
+    uint32_t growth;             /* default 2 */
+} gsx_render_options;
+
 typedef struct gsx_viewer_desc {
     uint32_t abi_version; /* GSX_ABI_VERSION */
     int32_t device;       /* HIP device ordinal */
@@ -93,6 +105,8 @@ void gsx_spec_params_default(gsx_spec_params* out);
 gsx_status gsx_viewer_create(const gsx_viewer_desc* desc, gsx_viewer** out);
 void gsx_viewer_destroy(gsx_viewer* v);
 gsx_status gsx_viewer_set_spec_params(gsx_viewer* v, const gsx_spec_params* p);
+void gsx_render_options_default(gsx_render_options* out);
+gsx_status gsx_viewer_set_render_options(gsx_viewer* v, const gsx_render_options* o);
 
 /* ---- models: MultiModelViewerGaussianBuffers::new_empty + BindGroups::new + models.insert,
  *      scene.rs:2111-2139; viewer.remove_model(&key), scene.rs:2176 ---- */
@@ -148,7 +162,7 @@ gsx_status gsx_framebuffer_device_ptr(gsx_viewer* v, void** out_ptr, uint32_t* o
 typedef struct gsx_frame_stats {
     uint64_t n_gaussians; /* N of the model */
     uint64_t n_visible;   /* N_vis after cull */
-    uint64_t n_tile_entries; /* D = sum over visible splats of tiles touched */
+    uint64_t n_tile_entries; /* D = tile entries binned by the last gsx_render (all of them with progressive = 0) */
 } gsx_frame_stats;
 gsx_status gsx_model_frame_stats(gsx_viewer* v, const char* key, gsx_frame_stats* out);
 /* Per-Gaussian projection outputs of the last gsx_preprocess (host arrays of length N; any may be NULL):

@@ -244,6 +244,7 @@ def test_full_size_properties():
     g = scene.synthetic_gaussians(n, seed, sh)
     cam = camera.orbit_pose(0)
     with MultiModelViewer() as v:
+        v.set_render_options(progressive=0)  # complete tile lists are only kept without depth slabs
         run_gpu_model(v, "m", g, cam, w, h)
         pr = v.download_projection("m")
         order = v.download_sorted("m")
@@ -253,6 +254,13 @@ def test_full_size_properties():
         fb = v.download_framebuffer()
         v.render_frame(["m"])
         fb2 = v.download_framebuffer()
+        # progressive depth slabs: same pixels bit-for-bit, far fewer tile entries
+        v.set_render_options(progressive=1)
+        v.render_frame(["m"])
+        fb3 = v.download_framebuffer()
+        st3 = v.frame_stats("m")
+        with pytest.raises(GsxError):
+            v.download_tile_lists("m")
     vis = pr["key"] != 0xFFFFFFFF
     assert st["n_visible"] == vis.sum() == order.size
     # sortedness + permutation + tie-break
@@ -275,3 +283,33 @@ def test_full_size_properties():
     # framebuffer sanity + determinism (idempotence of the whole frame)
     assert np.isfinite(fb).all() and fb[..., 3].min() >= 0 and fb[..., 3].max() <= 1
     assert np.array_equal(fb, fb2)
+    assert np.array_equal(fb, fb3), "progressive slabs must not change a single pixel"
+    assert st3["n_visible"] == st["n_visible"] and st3["n_tile_entries"] < st["n_tile_entries"]
+
+
+@pytest.mark.parametrize("divisor,growth", [(8, 2), (3, 3), (64, 2)])
+def test_progressive_slabs_small(divisor, growth):
+    """Depth-slab scheduling on a scene small enough for the oracle: identical pixels, two layered models."""
+    w, h = 176, 128
+    cam = camera.orbit_pose(150)
+    ga, gb = common.small_scene(5000, 111, scale_mul=10.0), common.small_scene(3000, 112, scale_mul=10.0)
+    mtb = camera.ModelTransform(pos=np.array([0.2, 0.1, 2.0], np.float32))
+    keys = camera.model_render_order(cam.pos, {"a": camera.ModelTransform().world_center(), "b": mtb.world_center()})
+    fb_ref = None
+    for k in keys:
+        g, mt = (ga, None) if k == "a" else (gb, mtb)
+        _, _, _, _, fb_ref = common.oracle_model_frame(g, cam, w, h, mt, fb=fb_ref)
+    with MultiModelViewer() as v:
+        v.set_render_options(progressive=0)
+        run_gpu_model(v, "a", ga, cam, w, h)
+        run_gpu_model(v, "b", gb, cam, w, h, mtb)
+        v.renderer.render(keys)
+        full = v.download_framebuffer()
+        d_full = v.frame_stats("a")["n_tile_entries"] + v.frame_stats("b")["n_tile_entries"]
+        v.set_render_options(progressive=1, first_slab_divisor=divisor, min_slab=64, growth=growth)
+        v.render_frame(keys)
+        slab = v.download_framebuffer()
+        d_slab = v.frame_stats("a")["n_tile_entries"] + v.frame_stats("b")["n_tile_entries"]
+    assert np.array_equal(full, slab)
+    assert d_slab <= d_full
+    assert np.abs(full - fb_ref).max() <= 2e-4

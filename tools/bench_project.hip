@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <unistd.h>
 
 #include "project_math.h"
 
@@ -33,6 +34,7 @@ struct In {
     const float2* cov_b;
     const float* sh1;
     uint32_t n;
+    size_t sh_stride;  // float4 elements between consecutive SH planes (product: n)
 };
 struct Out {
     char* base;  // chunked
@@ -40,28 +42,40 @@ struct Out {
     uint32_t* key;
 };
 
+__device__ inline float4 nt4(const float4* p) {
+    return make_float4(__builtin_nontemporal_load(&p->x), __builtin_nontemporal_load(&p->y), __builtin_nontemporal_load(&p->z),
+                       __builtin_nontemporal_load(&p->w));
+}
+typedef float float4v __attribute__((ext_vector_type(4)));
+__device__ inline float4 nt4v(const float4* p) {
+    float4v v = __builtin_nontemporal_load((const float4v*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 template <int LAYOUT> __device__ inline float4 ld_pc(const In& in, uint32_t i) {
+    if (LAYOUT == 2) return nt4v(&in.pc[i]);
     if (LAYOUT == 0) return in.pc[i];
     return *(const float4*)(in.base + (size_t)(i >> 8) * kChunkBytes + (i & 255u) * 16u);
 }
 template <int LAYOUT> __device__ inline float4 ld_cova(const In& in, uint32_t i) {
+    if (LAYOUT == 2) return nt4v(&in.cov_a[i]);
     if (LAYOUT == 0) return in.cov_a[i];
     return *(const float4*)(in.base + (size_t)(i >> 8) * kChunkBytes + 4096u + (i & 255u) * 16u);
 }
 template <int LAYOUT> __device__ inline float2 ld_covb(const In& in, uint32_t i) {
-    if (LAYOUT == 0) return in.cov_b[i];
+    if (LAYOUT == 0 || LAYOUT == 2) return in.cov_b[i];
     return *(const float2*)(in.base + (size_t)(i >> 8) * kChunkBytes + 8192u + (i & 255u) * 8u);
 }
 template <int LAYOUT> __device__ inline float4 ld_sh4(const In& in, int p, uint32_t i) {
-    if (LAYOUT == 0) return in.sh4[(size_t)p * in.n + i];
+    if (LAYOUT == 2) return nt4v(&in.sh4[(size_t)p * in.sh_stride + i]);
+    if (LAYOUT == 0) return in.sh4[(size_t)p * in.sh_stride + i];
     return *(const float4*)(in.base + (size_t)(i >> 8) * kChunkBytes + 10240u + p * 4096u + (i & 255u) * 16u);
 }
 template <int LAYOUT> __device__ inline float ld_sh1(const In& in, uint32_t i) {
-    if (LAYOUT == 0) return in.sh1[i];
+    if (LAYOUT == 0 || LAYOUT == 2) return in.sh1[i];
     return *(const float*)(in.base + (size_t)(i >> 8) * kChunkBytes + 55296u + (i & 255u) * 4u);
 }
 template <int LAYOUT> __device__ inline void st_rec(const Out& o, uint32_t i, bool vis, uint32_t key, float4 a, float4 b, float4 c) {
-    if (LAYOUT == 0) {
+    if (LAYOUT == 0 || LAYOUT == 2) {
         o.key[i] = key;
         if (vis) { o.a[i] = a; o.b[i] = b; o.c[i] = c; }
     } else {
@@ -190,16 +204,18 @@ __global__ void k_fill(In soa, char* chunked, uint32_t n) {
     ((float2*)soa.cov_b)[i] = cb;
     char* c = chunked + (size_t)(i >> 8) * kChunkBytes;
     uint32_t l = i & 255u;
-    *(float4*)(c + l * 16) = pc;
-    *(float4*)(c + 4096 + l * 16) = ca;
-    *(float2*)(c + 8192 + l * 8) = cb;
+    if (chunked) {
+        *(float4*)(c + l * 16) = pc;
+        *(float4*)(c + 4096 + l * 16) = ca;
+        *(float2*)(c + 8192 + l * 8) = cb;
+    }
     for (int p = 0; p < 11; ++p) {
         float4 s = make_float4(v[6 + 4 * p] * 0.3f - 0.15f, v[7 + 4 * p] * 0.3f - 0.15f, v[8 + 4 * p] * 0.3f - 0.15f, v[9 + 4 * p] * 0.3f - 0.15f);
-        ((float4*)soa.sh4)[(size_t)p * n + i] = s;
-        *(float4*)(c + 10240 + p * 4096 + l * 16) = s;
+        ((float4*)soa.sh4)[(size_t)p * soa.sh_stride + i] = s;
+        if (chunked) *(float4*)(c + 10240 + p * 4096 + l * 16) = s;
     }
     ((float*)soa.sh1)[i] = v[50] * 0.3f - 0.15f;
-    *(float*)(c + 55296 + l * 4) = v[50] * 0.3f - 0.15f;
+    if (chunked) *(float*)(c + 55296 + l * 4) = v[50] * 0.3f - 0.15f;
 }
 
 static void look_at(const float e[3], float view[16]) {
@@ -215,6 +231,51 @@ static void look_at(const float e[3], float view[16]) {
                    -(e[0] * s[0] + e[1] * s[1] + e[2] * s[2]), -(e[0] * u[0] + e[1] * u[1] + e[2] * u[2]),
                    (e[0] * f[0] + e[1] * f[1] + e[2] * f[2]), 1};
     for (int i = 0; i < 16; ++i) view[i] = m[i];
+}
+
+// Placement sweep: the 15 input planes and 4 output planes carved from ONE slab, plane p starting at
+// p * (round_up(N*16, 2 MiB) + skew).  Shows how much the relative alignment of the 19 concurrent
+// streams matters for HBM channel balance.
+static void placement_sweep(uint32_t n, const FrameConsts& f, uint32_t* nvis, int rounds) {
+    const size_t plane = (((size_t)n * 16 + 255) >> 8) << 8;
+    const size_t r2m = ((((size_t)n * 16 + (2u << 20) - 1) >> 21) << 21) - plane;  // pad up to a 2 MiB multiple
+    const size_t skews[] = {0, 4096, r2m, r2m + 256};
+    char* slab;
+    const size_t max_skew = skews[sizeof(skews) / sizeof(skews[0]) - 1];
+    CK(hipMalloc((void**)&slab, 21 * (plane + max_skew)));
+    CK(hipMemset(slab, 0, 21 * (plane + max_skew)));
+    uint32_t nchunks = (n + 255) / 256;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    char* sep[20];
+    for (int p = 0; p < 20; ++p) CK(hipMalloc((void**)&sep[p], p == 4 ? 11 * plane : plane));
+    for (int mode = 0; mode < 3; ++mode)
+    for (size_t skew : skews) {
+        if (mode > 0 && skew != 0) continue;
+        auto at = [&](int p) { return mode == 0 ? slab + (size_t)p * (plane + skew) : sep[p]; };
+        In in{};
+        in.n = n;
+        in.pc = (const float4*)at(0); in.cov_a = (const float4*)at(1); in.cov_b = (const float2*)at(2);
+        in.sh1 = (const float*)at(3);
+        in.sh4 = (const float4*)at(4);
+        in.sh_stride = mode == 0 ? (plane + skew) / 16 : (mode == 1 ? plane / 16 : n);
+        Out out{nullptr, (float4*)at(16), (float4*)at(17), (float4*)at(18), (uint32_t*)at(19)};
+        if (mode) printf("separate hipMalloc per stream, sh stride %zu B: ", in.sh_stride * 16);
+        hipLaunchKernelGGL(k_fill, dim3(nchunks), dim3(256), 0, 0, in, (char*)nullptr, n);
+        CK(hipDeviceSynchronize());
+        std::vector<float> ms;
+        for (int r = 0; r < rounds + 2; ++r) {
+            if (getenv("GSX_SLEEP_US")) usleep(atoi(getenv("GSX_SLEEP_US")));
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL((k_var<0, 0, 1>), dim3(nchunks), dim3(256), 0, 0, f, in, out, nvis);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float t; CK(hipEventElapsedTime(&t, e0, e1));
+            if (r >= 2) ms.push_back(t);
+        }
+        std::sort(ms.begin(), ms.end());
+        printf("placement skew %8zu B: median %.3f ms  min %.3f ms\n", skew, ms[ms.size() / 2], ms[0]);
+    }
 }
 
 int main(int argc, char** argv) {
@@ -233,6 +294,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&nvis, 4 * (size_t)(nchunks + 1)));
     in.pc = (float4*)pc; in.cov_a = (float4*)ca; in.cov_b = (float2*)cb; in.sh4 = (float4*)sh4; in.sh1 = (float*)sh1;
     in.base = (char*)chunked;
+    in.sh_stride = n;
     Out out{(char*)rchunk, (float4*)ra, (float4*)rb, (float4*)rc, (uint32_t*)rk};
     hipLaunchKernelGGL(k_fill, dim3(nchunks), dim3(256), 0, 0, in, (char*)chunked, n);
     CK(hipDeviceSynchronize());
@@ -247,13 +309,16 @@ int main(int argc, char** argv) {
     ModelTransform mt;
     frame_consts_setup(view, proj, 1920, 1080, mt, 1.0f, 0, 3, 0, sp, &f);
 
+    if (argc > 3) {
+        placement_sweep(n, f, nvis, rounds);
+        return 0;
+    }
     struct Var { const char* name; void (*launch)(const FrameConsts&, In, Out, uint32_t*, uint32_t); };
 #define VAR(L, E, W)                                                                                           \
     Var{"layout=" #L " eager=" #E " lb=" #W, [](const FrameConsts& f, In in, Out out, uint32_t* nv, uint32_t nb) { \
             hipLaunchKernelGGL((k_var<L, E, W>), dim3(nb), dim3(256), 0, 0, f, in, out, nv);                        \
         }}
-    std::vector<Var> vars = {VAR(0, 0, 1), VAR(0, 1, 1), VAR(0, 2, 1), VAR(1, 0, 1), VAR(1, 1, 1), VAR(1, 2, 1),
-                             VAR(1, 1, 4), VAR(1, 2, 4), VAR(0, 1, 4)};
+    std::vector<Var> vars = {VAR(0, 0, 1), VAR(2, 0, 1), VAR(0, 1, 1), VAR(2, 1, 1), VAR(0, 0, 2), VAR(2, 0, 2), VAR(0, 0, 1), VAR(2, 0, 1)};
     std::vector<std::vector<float>> ms(vars.size() + 1);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -280,6 +345,25 @@ int main(int argc, char** argv) {
         CK(hipEventSynchronize(e1));
         float t; CK(hipEventElapsedTime(&t, e0, e1));
         if (r >= 2) ms[vars.size()].push_back(t);
+    }
+    {   // same arrays, tight back-to-back loop of variant 0, then with a streaming copy in between
+        for (int mode = 0; mode < 3; ++mode) {
+            std::vector<float> t;
+            for (int r = 0; r < rounds; ++r) {
+                if (mode == 1)
+                    hipLaunchKernelGGL(k_copy, dim3(256 * 8), dim3(256), 0, 0, (const float4*)chunked, (float4*)rchunk, (size_t)n * 3, (size_t)n * 3);
+                if (mode == 2) usleep(2000);
+                CK(hipEventRecord(e0));
+                vars[0].launch(f, in, out, nvis, nchunks);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float x; CK(hipEventElapsedTime(&x, e0, e1));
+                t.push_back(x);
+            }
+            std::sort(t.begin(), t.end());
+            printf("variant 0 on the same arrays, %s: median %.3f ms min %.3f\n",
+                   mode == 0 ? "back-to-back" : (mode == 1 ? "after a 480 MB streaming copy" : "after 2 ms idle"), t[t.size() / 2], t[0]);
+        }
     }
     auto med = [](std::vector<float> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
     auto mn = [](std::vector<float> v) { return *std::min_element(v.begin(), v.end()); };

@@ -26,13 +26,17 @@ EXPORTS = (
     "gsx_render_frame", "gsx_download_framebuffer", "gsx_download_rgba8", "gsx_framebuffer_device_ptr",
     "gsx_model_frame_stats", "gsx_model_download_projection", "gsx_model_download_sorted",
     "gsx_model_download_tile_lists", "gsx_model_download_pod", "gsx_set_pass_timing", "gsx_get_pass_timing",
-    "gsx_shard_pack", "gsx_shard_import", "gsx_shard_strip_bytes", "gsx_shard_pack_strip", "gsx_shard_unpack_strips",
+    "gsx_render_options_default", "gsx_viewer_set_render_options", "gsx_shard_pack", "gsx_shard_import", "gsx_shard_strip_bytes", "gsx_shard_pack_strip", "gsx_shard_unpack_strips",
 )
 
 
 class SpecParams(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("max_std_dev", "cull_margin", "jacobian_clamp", "low_pass", "alpha_max",
                                         "alpha_min", "t_epsilon", "point_radius")]
+
+
+class RenderOptions(C.Structure):
+    _fields_ = [("progressive", C.c_uint32), ("first_slab_divisor", C.c_uint32), ("min_slab", C.c_uint32), ("growth", C.c_uint32)]
 
 
 class ViewerDesc(C.Structure):
@@ -95,6 +99,8 @@ def load() -> C.CDLL:
         "gsx_model_download_sorted": ([vp, cp, u32p, u64, C.POINTER(u64)], C.c_int32),
         "gsx_model_download_tile_lists": ([vp, cp, u32p, u64, u32p, u64], C.c_int32),
         "gsx_model_download_pod": ([vp, cp, f32p, u32p, f32p, f32p], C.c_int32),
+        "gsx_render_options_default": ([C.POINTER(RenderOptions)], None),
+        "gsx_viewer_set_render_options": ([vp, C.POINTER(RenderOptions)], C.c_int32),
         "gsx_shard_pack": ([vp, cp, u32, vp, u64, C.POINTER(u64)], C.c_int32),
         "gsx_shard_import": ([vp, cp, vp, u64, u32, u32], C.c_int32),
         "gsx_shard_strip_bytes": ([vp, u32, C.POINTER(u64)], C.c_int32),

@@ -66,7 +66,8 @@ struct DevBuf {
 
 struct Counters {  // device + pinned host mirror
     uint32_t n_visible;
-    uint32_t n_entries;  // D
+    uint32_t n_entries;  // D of the current slab
+    uint32_t n_done;     // tiles that saturated while compositing this model
 };
 
 struct Model {
@@ -82,7 +83,7 @@ struct Model {
     DevBuf pc, cov_a, cov_b, sh4, sh1, mask;
     DevBuf key_buf, rec_a, rec_b, rec_c;
     DevBuf sk_a, sk_b, sv_a, sv_b, table;      // depth sort ping-pong + histogram table
-    DevBuf cnt, block_sums;                     // tile counts in depth order + scan partials
+    DevBuf cnt, block_sums, srect;              // per slab: tile counts in depth order, scan partials, tile rects
     DevBuf block_vis;                           // per-workgroup visible counts of the projection pass
     DevBuf tk_src, tv_src, tk_a, tk_b, tv_a, tv_b, ttable;  // tile pairs
     DevBuf ranges;
@@ -92,6 +93,7 @@ struct Model {
     uint32_t* tile_list = nullptr;              // -> tv_* after the tile sort
     uint32_t* tile_keys = nullptr;
     bool preprocessed = false, sorted = false, counters_valid = false, binned = false;
+    bool lists_complete = false;                // the tile lists of the last render cover the whole model (one slab)
     uint32_t n_visible = 0, n_entries = 0;
     // the per-frame record set: the model's own projection (rec_n == n) or records imported from the
     // other ranks (gsx_shard_import); binning is restricted to tile rows row % row_world == row_rank
@@ -141,7 +143,9 @@ struct gsx_viewer {
     float size = 1.0f;
     uint32_t display_mode = GSX_DISPLAY_SPLAT, sh_deg = 3, no_sh0 = 0;
     std::map<std::string, std::unique_ptr<Model>> models;
-    DevBuf fb, staging, scratch;
+    DevBuf fb, staging, scratch, done_bits;
+    uint32_t tiles_done = 0;  // host view of the saturated-tile count of the current frame
+    gsx_render_options options{1u, 16u, 131072u, 2u};
     bool timing = false;
     std::vector<PassTimer> timers;     // recorded, not yet read
     std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
@@ -206,7 +210,6 @@ static gsx_status sync_counters(gsx_viewer* v) {
         Model* m = kv.second.get();
         if (m->sorted && !m->counters_valid) {
             m->n_visible = m->h_counters->n_visible;
-            m->n_entries = m->h_counters->n_entries;
             m->counters_valid = true;
         }
     }
@@ -226,6 +229,7 @@ static gsx_status ensure_record_capacity(Model* m, uint64_t count) {
     HIPCHK(m->sv_b.ensure(4 * n));
     HIPCHK(m->table.ensure(4 * radix_table_entries(n)));
     HIPCHK(m->cnt.ensure(4 * n));
+    HIPCHK(m->srect.ensure(8 * n));
     HIPCHK(m->block_sums.ensure(4 * (scan_blocks(n) + 1)));
     HIPCHK(m->block_vis.ensure(4 * (project_blocks(n) + 1)));
     m->rec_cap = n;
@@ -263,65 +267,119 @@ static gsx_status do_sort(gsx_viewer* v, Model* m) {
         m->sorted_idx = in_b ? m->sv_b.as<uint32_t>() : m->sv_a.as<uint32_t>();
         v->pass_launches[GSX_PASS_DEPTH_SORT] += n ? 4 : 0;
     }
-    {
-        ScopedPass t(v, GSX_PASS_BIN);
-        Counters* dc = m->counters.as<Counters>();
-        HIPCHK(launch_tile_counts(v->stream, n, &dc->n_visible, m->sorted_idx, m->rec(), m->cnt.as<uint32_t>(),
-                                  m->block_sums.as<uint32_t>(), &dc->n_entries, m->row_world, m->row_rank));
-    }
-    HIPCHK(hipMemcpyAsync(m->h_counters, m->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, v->stream));
+    HIPCHK(hipMemcpyAsync(&m->h_counters->n_visible, &m->counters.as<Counters>()->n_visible, 4, hipMemcpyDeviceToHost,
+                          v->stream));
     m->sorted = true;
+    m->binned = false;
+    m->n_entries = 0;
     return GSX_OK;
 }
 
-static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool first) {
+// Depth slabs of the progressive mode: [0, n/div), then each slab `growth` times the previous one.
+static void plan_slabs(const gsx_render_options& o, uint32_t n_vis, std::vector<uint32_t>* bounds) {
+    bounds->clear();
+    bounds->push_back(0);
+    if (!o.progressive || n_vis <= o.min_slab) {
+        bounds->push_back(n_vis);
+        return;
+    }
+    uint64_t size = std::max<uint64_t>(o.min_slab, n_vis / std::max(1u, o.first_slab_divisor));
+    uint64_t at = 0;
+    while (at + size < n_vis) {
+        at += size;
+        bounds->push_back((uint32_t)at);
+        size *= std::max(2u, o.growth);
+    }
+    bounds->push_back(n_vis);
+}
+
+// One model: bin + tile-sort + composite, front to back in depth slabs.  carry: (C,T) already in the
+// framebuffer is in front of this model (nearer models were composited first).
+static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
     if (!m->sorted) return fail(GSX_ERR_INVALID_ARG, "gsx_render: model '%s' was not preprocessed+sorted", m->key.c_str());
     if (m->fc.w_px != v->width || m->fc.h_px != v->height)
         return fail(GSX_ERR_INVALID_ARG, "gsx_render: viewport changed since gsx_preprocess('%s')", m->key.c_str());
     const uint32_t n_tiles = m->fc.tiles_x * m->fc.tiles_y;
-    const uint32_t D = m->n_entries;
-    {
-        ScopedPass t(v, GSX_PASS_BIN);
-        const size_t bytes = sizeof(uint32_t) * std::max<size_t>(D, 1);
-        HIPCHK(m->tk_src.ensure(bytes));
-        HIPCHK(m->tv_src.ensure(bytes));
-        HIPCHK(m->tk_a.ensure(bytes));
-        HIPCHK(m->tv_a.ensure(bytes));
-        HIPCHK(m->tk_b.ensure(bytes));
-        HIPCHK(m->tv_b.ensure(bytes));
-        HIPCHK(m->ttable.ensure(sizeof(uint32_t) * radix_table_entries(D)));
-        HIPCHK(m->ranges.ensure(sizeof(uint2) * (size_t)n_tiles));
-        HIPCHK(launch_tile_emit(v->stream, m->n_visible, m->sorted_idx, m->rec(), m->cnt.as<uint32_t>(),
-                                m->block_sums.as<uint32_t>(), m->fc.tiles_x, m->tk_src.as<uint32_t>(),
-                                m->tv_src.as<uint32_t>(), m->row_world, m->row_rank));
-        v->pass_launches[GSX_PASS_BIN] += 1;
-    }
-    {
-        ScopedPass t(v, GSX_PASS_TILE_SORT);
-        RadixBuffers rb{m->tk_src.as<uint32_t>(), m->tv_src.as<uint32_t>(), m->tk_a.as<uint32_t>(), m->tv_a.as<uint32_t>(),
-                        m->tk_b.as<uint32_t>(), m->tv_b.as<uint32_t>(), m->ttable.as<uint32_t>()};
-        bool in_b = false;
-        const int bits = std::max<int>(1, (int)ceil_log2(n_tiles));
-        HIPCHK(launch_radix_sort(v->stream, rb, D, bits, false, &in_b));
-        if (D == 0) {
-            m->tile_keys = m->tk_src.as<uint32_t>();
-            m->tile_list = m->tv_src.as<uint32_t>();
-        } else {
-            m->tile_keys = in_b ? m->tk_b.as<uint32_t>() : m->tk_a.as<uint32_t>();
-            m->tile_list = in_b ? m->tv_b.as<uint32_t>() : m->tv_a.as<uint32_t>();
+    const uint32_t row_words = (m->fc.tiles_x + 31) / 32;
+    const bool progressive = v->options.progressive != 0;
+    uint32_t* done = progressive ? v->done_bits.as<uint32_t>() : nullptr;
+    std::vector<uint32_t> bounds;
+    plan_slabs(v->options, m->n_visible, &bounds);
+    Counters* dc = m->counters.as<Counters>();
+    m->n_entries = 0;
+    HIPCHK(m->ranges.ensure(sizeof(uint2) * (size_t)n_tiles));
+    HIPCHK(hipMemsetAsync(&dc->n_done, 0, 4, v->stream));
+    // tiles this rank composites: all of them, or its rows in the sharded path
+    uint32_t owned_rows = 0;
+    for (uint32_t ty = m->row_rank; ty < m->fc.tiles_y; ty += m->row_world) ++owned_rows;
+    const uint32_t owned_tiles = owned_rows * m->fc.tiles_x;
+    const uint32_t done_before = v->tiles_done;
+    for (size_t sl = 0; sl + 1 < bounds.size(); ++sl) {
+        if (progressive && v->tiles_done >= owned_tiles) break;  // every pixel is saturated: the rest is hidden
+        const uint32_t j0 = bounds[sl], j1 = bounds[sl + 1];
+        // the very first slab of the frame sees no saturated tile: plain rectangle areas
+        const uint32_t* done_in = (carry || sl > 0) ? done : nullptr;
+        {
+            ScopedPass t(v, GSX_PASS_BIN);
+            HIPCHK(launch_tile_counts(v->stream, j0, j1, &dc->n_visible, m->sorted_idx, m->rec(), m->srect.as<uint2>(),
+                                      m->cnt.as<uint32_t>(), m->block_sums.as<uint32_t>(), &dc->n_entries, m->row_world, m->row_rank, done_in,
+                                      row_words));
         }
-        v->pass_launches[GSX_PASS_TILE_SORT] += D ? (bits + 7) / 8 : 0;
+        HIPCHK(hipMemcpyAsync(&m->h_counters->n_entries, &dc->n_entries, 8, hipMemcpyDeviceToHost, v->stream));
+        HIPCHK(hipStreamSynchronize(v->stream));
+        const uint32_t D = m->h_counters->n_entries;
+        v->tiles_done = done_before + m->h_counters->n_done;  // as of the previous slab's composite
+        m->n_entries += D;
+        if (D == 0 && (carry || sl > 0)) continue;  // nothing new in this slab; the framebuffer already holds the state
+        {
+            ScopedPass t(v, GSX_PASS_BIN);
+            const size_t bytes = sizeof(uint32_t) * std::max<size_t>(D, 1);
+            HIPCHK(m->tk_src.ensure(bytes));
+            HIPCHK(m->tv_src.ensure(bytes));
+            HIPCHK(m->tk_a.ensure(bytes));
+            HIPCHK(m->tv_a.ensure(bytes));
+            HIPCHK(m->tk_b.ensure(bytes));
+            HIPCHK(m->tv_b.ensure(bytes));
+            HIPCHK(m->ttable.ensure(sizeof(uint32_t) * radix_table_entries(D)));
+            HIPCHK(launch_tile_emit(v->stream, j0, j1, m->sorted_idx, m->srect.as<uint2>(), m->cnt.as<uint32_t>(),
+                                    m->block_sums.as<uint32_t>(), m->fc.tiles_x, m->tk_src.as<uint32_t>(),
+                                    m->tv_src.as<uint32_t>(), m->row_world, m->row_rank, done_in, row_words));
+            v->pass_launches[GSX_PASS_BIN] += 1;
+        }
+        {
+            ScopedPass t(v, GSX_PASS_TILE_SORT);
+            RadixBuffers rb{m->tk_src.as<uint32_t>(), m->tv_src.as<uint32_t>(), m->tk_a.as<uint32_t>(), m->tv_a.as<uint32_t>(),
+                            m->tk_b.as<uint32_t>(), m->tv_b.as<uint32_t>(), m->ttable.as<uint32_t>()};
+            bool in_b = false;
+            const int bits = std::max<int>(1, (int)ceil_log2(n_tiles));
+            HIPCHK(launch_radix_sort(v->stream, rb, D, bits, false, &in_b));
+            if (D == 0) {
+                m->tile_keys = m->tk_src.as<uint32_t>();
+                m->tile_list = m->tv_src.as<uint32_t>();
+            } else {
+                m->tile_keys = in_b ? m->tk_b.as<uint32_t>() : m->tk_a.as<uint32_t>();
+                m->tile_list = in_b ? m->tv_b.as<uint32_t>() : m->tv_a.as<uint32_t>();
+            }
+            v->pass_launches[GSX_PASS_TILE_SORT] += D ? (bits + 7) / 8 : 0;
+        }
+        {
+            ScopedPass t(v, GSX_PASS_BIN);
+            HIPCHK(launch_tile_ranges(v->stream, D, m->tile_keys, n_tiles, m->ranges.as<uint2>()));
+        }
+        {
+            ScopedPass t(v, GSX_PASS_COMPOSITE);
+            HIPCHK(launch_composite(v->stream, m->fc, m->ranges.as<uint2>(), m->tile_list, m->rec(), v->fb.as<float4>(),
+                                    carry || sl > 0, done, row_words, &dc->n_done));
+            v->pass_launches[GSX_PASS_COMPOSITE] += 1;
+        }
     }
-    {
-        ScopedPass t(v, GSX_PASS_BIN);
-        HIPCHK(launch_tile_ranges(v->stream, D, m->tile_keys, n_tiles, m->ranges.as<uint2>()));
-    }
-    {
-        ScopedPass t(v, GSX_PASS_COMPOSITE);
-        HIPCHK(launch_composite(v->stream, m->fc, m->ranges.as<uint2>(), m->tile_list, m->rec(), v->fb.as<float4>(), first));
-        v->pass_launches[GSX_PASS_COMPOSITE] += 1;
+    if (progressive) {  // the last composite's saturated tiles count for the models behind this one
+        HIPCHK(hipMemcpyAsync(&m->h_counters->n_done, &dc->n_done, 4, hipMemcpyDeviceToHost, v->stream));
+        HIPCHK(hipStreamSynchronize(v->stream));
+        v->tiles_done = done_before + m->h_counters->n_done;
     }
     m->binned = true;
+    m->lists_complete = bounds.size() == 2 && !carry;
     return GSX_OK;
 }
 
@@ -339,11 +397,17 @@ static gsx_status do_render(gsx_viewer* v, const char* const* keys, uint32_t n_k
         HIPCHK(launch_clear_fb(v->stream, v->fb.as<float4>(), v->width * v->height));
         return GSX_OK;
     }
+    if (v->options.progressive) {
+        const uint32_t tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE, row_words = ((v->width + GSX_TILE - 1) / GSX_TILE + 31) / 32;
+        HIPCHK(v->done_bits.ensure(4 * (size_t)tiles_y * row_words));
+        HIPCHK(hipMemsetAsync(v->done_bits.p, 0, 4 * (size_t)tiles_y * row_words, v->stream));
+    }
+    v->tiles_done = 0;
     // the reference paints far -> near with "over"; front-to-back accumulation walks the same list backwards
-    bool first = true;
+    bool carry = false;
     for (auto it = order.rbegin(); it != order.rend(); ++it) {
-        if ((st = do_bin_and_composite(v, *it, first))) return st;
-        first = false;
+        if ((st = do_bin_and_composite(v, *it, carry))) return st;
+        carry = true;
     }
     return GSX_OK;
 }
@@ -415,6 +479,22 @@ void gsx_viewer_destroy(gsx_viewer* v) {
     v->models.clear();
     if (v->own_stream) (void)hipStreamDestroy(v->stream);
     delete v;
+}
+
+void gsx_render_options_default(gsx_render_options* o) {
+    if (!o) return;
+    o->progressive = 1;
+    o->first_slab_divisor = 16;
+    o->min_slab = 131072;
+    o->growth = 2;
+}
+
+gsx_status gsx_viewer_set_render_options(gsx_viewer* v, const gsx_render_options* o) {
+    if (!v || !o) return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_set_render_options: null argument");
+    if (o->first_slab_divisor == 0 || o->growth < 2 || o->min_slab == 0)
+        return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_set_render_options: first_slab_divisor >= 1, growth >= 2, min_slab >= 1");
+    v->options = *o;
+    return GSX_OK;
 }
 
 gsx_status gsx_viewer_set_spec_params(gsx_viewer* v, const gsx_spec_params* p) {
@@ -669,7 +749,7 @@ gsx_status gsx_model_frame_stats(gsx_viewer* v, const char* key, gsx_frame_stats
     if ((st = sync_counters(v))) return st;
     out->n_gaussians = m->n;
     out->n_visible = m->n_visible;
-    out->n_tile_entries = m->n_entries;
+    out->n_tile_entries = m->binned ? m->n_entries : 0;  // entries actually binned by the last gsx_render
     return GSX_OK;
 }
 
@@ -742,6 +822,9 @@ gsx_status gsx_model_download_tile_lists(gsx_viewer* v, const char* key, uint32_
     Model* m = find_model(v, key);
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_download_tile_lists: no model '%s'", key ? key : "(null)");
     if (!m->binned) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_tile_lists: model '%s' not rendered this frame", key);
+    if (!m->lists_complete)
+        return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_tile_lists: complete lists exist only for the front-most model "
+                    "rendered with gsx_render_options.progressive = 0 (model '%s' was rendered in depth slabs)", key);
     const uint32_t n_tiles = m->fc.tiles_x * m->fc.tiles_y;
     if (n_offsets != (uint64_t)n_tiles + 1) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_tile_lists: expected %u offsets", n_tiles + 1);
     HIPCHK(hipStreamSynchronize(v->stream));

@@ -83,14 +83,17 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
                              bool* result_in_b);
 
 // Tile binning.
-// n_upper bounds the launch (the model's N); the kernel reads the real N_vis from *d_n_vis.
+// Splats [j0, min(j1, *d_n_vis)) of the depth order; cnt / block_sums are indexed relative to j0.
 // (world, rank): only tile rows with row % world == rank are binned (1, 0 = all rows).
-hipError_t launch_tile_counts(hipStream_t s, uint32_t n_upper, const uint32_t* d_n_vis, const uint32_t* sorted_idx,
-                              const Records& rec, uint32_t* cnt, uint32_t* block_sums, uint32_t* d_total /* D */,
-                              uint32_t world, uint32_t rank);
-hipError_t launch_tile_emit(hipStream_t s, uint32_t n_vis, const uint32_t* sorted_idx, const Records& rec,
+// done (nullable): bitmap of saturated tiles (row_words u32 per tile row) that receive no more entries.
+// srect[j - j0]: the splat's packed tile rectangle, gathered once by the count pass and re-read by emit.
+hipError_t launch_tile_counts(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* d_n_vis, const uint32_t* sorted_idx,
+                              const Records& rec, uint2* srect, uint32_t* cnt, uint32_t* block_sums,
+                              uint32_t* d_total /* D */, uint32_t world, uint32_t rank, const uint32_t* done,
+                              uint32_t row_words);
+hipError_t launch_tile_emit(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* sorted_idx, const uint2* srect,
                             const uint32_t* cnt, const uint32_t* block_sums, uint32_t tiles_x, uint32_t* tkey,
-                            uint32_t* tval, uint32_t world, uint32_t rank);
+                            uint32_t* tval, uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words);
 hipError_t launch_tile_ranges(hipStream_t s, uint32_t D, const uint32_t* tkey_sorted, uint32_t n_tiles,
                               uint2* ranges);
 size_t scan_blocks(uint64_t n);
@@ -108,8 +111,11 @@ hipError_t launch_unpack_strips(hipStream_t s, const void* d_all, uint32_t w, ui
                                 uint32_t rows_per_rank, float4* fb);
 
 // Compositing and resolve.
+// carry: continue from the (C, T) already in fb (later slabs / models behind); done: saturated-tile bitmap
+// (read to skip tiles when carrying, updated when a tile saturates; nullable).
 hipError_t launch_composite(hipStream_t s, const FrameConsts& f, const uint2* ranges, const uint32_t* list,
-                            const Records& rec, float4* fb, bool first_model);
+                            const Records& rec, float4* fb, bool carry, uint32_t* done, uint32_t row_words,
+                            uint32_t* d_done_count);
 hipError_t launch_clear_fb(hipStream_t s, float4* fb, uint32_t n_px);
 hipError_t launch_resolve_rgba8(hipStream_t s, const float4* fb, uint32_t n_px, float bg_r, float bg_g, float bg_b,
                                 uint32_t* out_rgba8);

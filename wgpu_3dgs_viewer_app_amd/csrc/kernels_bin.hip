@@ -11,11 +11,9 @@
 
 namespace gsx {
 
-constexpr int kScanThreads = 256;
-constexpr int kScanItems = 16;
-constexpr int kScanTile = kScanThreads * kScanItems;  // 4096 entries per workgroup
+constexpr int kBinThreads = 256;  // one splat per lane
 
-size_t scan_blocks(uint64_t n) { return (size_t)((n + kScanTile - 1) / kScanTile); }
+size_t scan_blocks(uint64_t n) { return (size_t)((n + kBinThreads - 1) / kBinThreads); }
 
 // Multi-GPU: a rank bins only the tile rows it owns (row % world == rank); world = 1 owns every row.
 __device__ inline uint32_t first_owned_row(uint32_t y0, uint32_t world, uint32_t rank) {
@@ -30,6 +28,29 @@ __device__ inline uint32_t rect_area(float4 a, uint32_t world, uint32_t rank) {
     return ((rx >> 16) - (rx & 0xFFFFu)) * rows;
 }
 
+// Progressive slabs: tiles whose every pixel is already saturated (T < t_epsilon) are flagged in a bitmap
+// (one bit per tile, `row_words` 32-bit words per tile row) and receive no further entries.
+// Number of NOT-done tiles of row `ty` in [x0, x1).
+__device__ inline uint32_t live_tiles_in_row(const uint32_t* done, uint32_t row_words, uint32_t ty, uint32_t x0, uint32_t x1) {
+    uint32_t n = 0;
+    const uint32_t* row = done + ty * row_words;
+    for (uint32_t w = x0 >> 5; w <= ((x1 - 1u) >> 5); ++w) {
+        uint32_t lo = w == (x0 >> 5) ? (x0 & 31u) : 0u;
+        uint32_t hi = w == ((x1 - 1u) >> 5) ? ((x1 - 1u) & 31u) : 31u;
+        uint32_t mask = (hi == 31u ? 0xFFFFFFFFu : ((1u << (hi + 1u)) - 1u)) & ~((1u << lo) - 1u);
+        n += __popc(~row[w] & mask);
+    }
+    return n;
+}
+
+__device__ inline uint32_t rect_live_area(float4 a, uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words) {
+    uint32_t rx = __float_as_uint(a.z), ry = __float_as_uint(a.w);
+    uint32_t x0 = rx & 0xFFFFu, x1 = rx >> 16, y0 = ry & 0xFFFFu, y1 = ry >> 16;
+    uint32_t n = 0;
+    for (uint32_t ty = first_owned_row(y0, world, rank); ty < y1; ty += world) n += live_tiles_in_row(done, row_words, ty, x0, x1);
+    return n;
+}
+
 __device__ inline uint32_t block_reduce_sum(uint32_t v, uint32_t* smem4) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -38,27 +59,29 @@ __device__ inline uint32_t block_reduce_sum(uint32_t v, uint32_t* smem4) {
     return smem4[0] + smem4[1] + smem4[2] + smem4[3];
 }
 
-// tiles touched by the j-th splat in depth order -> cnt[j]; per-workgroup sums -> block_sums
-__global__ __launch_bounds__(kScanThreads) void k_tile_counts(const uint32_t* __restrict__ d_n_vis,
-                                                               const uint32_t* __restrict__ sorted_idx,
-                                                               const float4* __restrict__ rec_a,
-                                                               uint32_t* __restrict__ cnt,
-                                                               uint32_t* __restrict__ block_sums, uint32_t world,
-                                                               uint32_t rank) {
+// Slab splat j in [j0, min(j1, N_vis)): gather its tile rectangle once (-> srect[j - j0], reused by the
+// emit kernel), count its live tiles (-> cnt[j - j0]) and reduce per workgroup (-> block_sums).
+// One splat per lane and 256 per workgroup: the gather rec_a[sorted_idx[j]] is a dependent random
+// access, so the pass lives on memory-level parallelism (N/256 workgroups), not on per-lane loops.
+// done == nullptr: every tile is live.
+__global__ __launch_bounds__(kBinThreads) void k_tile_counts(const uint32_t* __restrict__ d_n_vis, uint32_t j0,
+                                                              uint32_t j1, const uint32_t* __restrict__ sorted_idx,
+                                                              const float4* __restrict__ rec_a,
+                                                              uint2* __restrict__ srect, uint32_t* __restrict__ cnt,
+                                                              uint32_t* __restrict__ block_sums, uint32_t world,
+                                                              uint32_t rank, const uint32_t* __restrict__ done,
+                                                              uint32_t row_words) {
     __shared__ uint32_t red[4];
-    uint32_t sum = 0;
-    const uint32_t n_vis = *d_n_vis;
-    const uint32_t base = blockIdx.x * kScanTile;
-#pragma unroll 4
-    for (int r = 0; r < kScanItems; ++r) {
-        uint32_t j = base + r * kScanThreads + threadIdx.x;
-        if (j < n_vis) {
-            uint32_t c = rect_area(rec_a[sorted_idx[j]], world, rank);
-            cnt[j] = c;
-            sum += c;
-        }
+    const uint32_t n_vis = min(*d_n_vis, j1);
+    const uint32_t j = j0 + blockIdx.x * kBinThreads + threadIdx.x;
+    uint32_t c = 0;
+    if (j < n_vis) {
+        const float4 a = rec_a[sorted_idx[j]];
+        c = done ? rect_live_area(a, world, rank, done, row_words) : rect_area(a, world, rank);
+        srect[j - j0] = make_uint2(__float_as_uint(a.z), __float_as_uint(a.w));
+        cnt[j - j0] = c;
     }
-    uint32_t tot = block_reduce_sum(sum, red);
+    uint32_t tot = block_reduce_sum(c, red);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
@@ -91,23 +114,20 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__
     if (tid == 0) *d_total = carry_s;
 }
 
-// emit (tile id, Gaussian index) pairs for the j-th splat at offset = block_sums[wg] + local exclusive scan
-__global__ __launch_bounds__(kScanThreads) void k_tile_emit(uint32_t n_vis, const uint32_t* __restrict__ sorted_idx,
-                                                             const float4* __restrict__ rec_a,
-                                                             const uint32_t* __restrict__ cnt,
-                                                             const uint32_t* __restrict__ block_offs, uint32_t tiles_x,
-                                                             uint32_t* __restrict__ tkey, uint32_t* __restrict__ tval,
-                                                             uint32_t world, uint32_t rank) {
+// emit (tile id, Gaussian index) pairs of slab splat j at offset = block_offs[workgroup] + exclusive scan
+// of cnt inside the workgroup.  Reads only sequential arrays (srect, cnt, sorted_idx).
+__global__ __launch_bounds__(kBinThreads) void k_tile_emit(uint32_t jbase, uint32_t n_vis,
+                                                            const uint32_t* __restrict__ sorted_idx,
+                                                            const uint2* __restrict__ srect,
+                                                            const uint32_t* __restrict__ cnt,
+                                                            const uint32_t* __restrict__ block_offs, uint32_t tiles_x,
+                                                            uint32_t* __restrict__ tkey, uint32_t* __restrict__ tval,
+                                                            uint32_t world, uint32_t rank,
+                                                            const uint32_t* __restrict__ done, uint32_t row_words) {
     __shared__ uint32_t wsum[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    // each lane owns kScanItems CONSECUTIVE entries so the local scan is a serial prefix + one block scan
-    const uint32_t j0 = blockIdx.x * kScanTile + tid * kScanItems;
-    uint32_t mine = 0;
-#pragma unroll
-    for (int r = 0; r < kScanItems; ++r) {
-        uint32_t j = j0 + r;
-        mine += j < n_vis ? cnt[j] : 0u;
-    }
+    const uint32_t j = jbase + blockIdx.x * kBinThreads + tid;
+    const uint32_t mine = j < n_vis ? cnt[j - jbase] : 0u;
     uint32_t x = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -116,27 +136,19 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_emit(uint32_t n_vis, cons
     }
     if (lane == 63) wsum[wave] = x;
     __syncthreads();
-    uint32_t off = block_offs[blockIdx.x] + x - mine;
-    for (uint32_t w = 0; w < wave; ++w) off += wsum[w];
-#pragma unroll 1
-    for (int r = 0; r < kScanItems; ++r) {
-        uint32_t j = j0 + r;
-        if (j >= n_vis) break;
-        const uint32_t cr = cnt[j];  // re-read (L1/L2 hit) instead of a runtime-indexed register array
-        if (cr == 0) continue;
-        uint32_t idx = sorted_idx[j];
-        float4 a = rec_a[idx];
-        uint32_t rx = __float_as_uint(a.z), ry = __float_as_uint(a.w);
-        uint32_t x0 = rx & 0xFFFFu, x1 = rx >> 16, y0 = ry & 0xFFFFu, y1 = ry >> 16;
-        uint32_t o = off;
-        for (uint32_t ty = first_owned_row(y0, world, rank); ty < y1; ty += world)
-            for (uint32_t tx = x0; tx < x1; ++tx) {
-                tkey[o] = ty * tiles_x + tx;
-                tval[o] = idx;
-                ++o;
-            }
-        off += cr;
-    }
+    if (mine == 0) return;
+    uint32_t o = block_offs[blockIdx.x] + x - mine;
+    for (uint32_t w = 0; w < wave; ++w) o += wsum[w];
+    const uint32_t idx = sorted_idx[j];
+    const uint2 r = srect[j - jbase];
+    const uint32_t x0 = r.x & 0xFFFFu, x1 = r.x >> 16, y0 = r.y & 0xFFFFu, y1 = r.y >> 16;
+    for (uint32_t ty = first_owned_row(y0, world, rank); ty < y1; ty += world)
+        for (uint32_t tx = x0; tx < x1; ++tx) {
+            if (done && ((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)) continue;
+            tkey[o] = ty * tiles_x + tx;
+            tval[o] = idx;
+            ++o;
+        }
 }
 
 // ranges[t] = [first, last+1) of tile t in the tile-sorted pair list (ranges pre-zeroed)
@@ -149,24 +161,24 @@ __global__ __launch_bounds__(256) void k_tile_ranges(uint32_t D, const uint32_t*
     if (e == D - 1 || tkey[e + 1] != t) ranges[t].y = e + 1;
 }
 
-hipError_t launch_tile_counts(hipStream_t s, uint32_t n_upper, const uint32_t* d_n_vis, const uint32_t* sorted_idx,
-                              const Records& rec, uint32_t* cnt, uint32_t* block_sums, uint32_t* d_total, uint32_t world,
-                              uint32_t rank) {
-    uint32_t nb = (uint32_t)scan_blocks(n_upper);
+hipError_t launch_tile_counts(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* d_n_vis, const uint32_t* sorted_idx,
+                              const Records& rec, uint2* srect, uint32_t* cnt, uint32_t* block_sums, uint32_t* d_total,
+                              uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words) {
+    uint32_t nb = (uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0);
     if (nb)
-        hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(kScanThreads), 0, s, d_n_vis, sorted_idx, rec.a, cnt, block_sums,
-                           world, rank);
+        hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(kBinThreads), 0, s, d_n_vis, j0, j1, sorted_idx, rec.a, srect, cnt,
+                           block_sums, world, rank, done, row_words);
     hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nb, d_total);
     return hipGetLastError();
 }
 
-hipError_t launch_tile_emit(hipStream_t s, uint32_t n_vis, const uint32_t* sorted_idx, const Records& rec,
+hipError_t launch_tile_emit(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* sorted_idx, const uint2* srect,
                             const uint32_t* cnt, const uint32_t* block_sums, uint32_t tiles_x, uint32_t* tkey,
-                            uint32_t* tval, uint32_t world, uint32_t rank) {
-    uint32_t nb = (uint32_t)scan_blocks(n_vis);
+                            uint32_t* tval, uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words) {
+    uint32_t nb = (uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0);
     if (!nb) return hipSuccess;
-    hipLaunchKernelGGL(k_tile_emit, dim3(nb), dim3(kScanThreads), 0, s, n_vis, sorted_idx, rec.a, cnt, block_sums,
-                       tiles_x, tkey, tval, world, rank);
+    hipLaunchKernelGGL(k_tile_emit, dim3(nb), dim3(kBinThreads), 0, s, j0, j1, sorted_idx, srect, cnt, block_sums,
+                       tiles_x, tkey, tval, world, rank, done, row_words);
     return hipGetLastError();
 }
 

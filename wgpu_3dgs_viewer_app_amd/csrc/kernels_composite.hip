@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConsts f, const ui
                                                     const uint32_t* __restrict__ list,
                                                     const float4* __restrict__ rec_a, const float4* __restrict__ rec_b,
                                                     const float4* __restrict__ rec_c, float4* __restrict__ fb,
-                                                    const int first_model) {
+                                                    const int carry, uint32_t* __restrict__ done_bits,
+                                                    const uint32_t row_words, uint32_t* __restrict__ done_count) {
     __shared__ float2 s_mean[kBatch];
     __shared__ float4 s_conic[kBatch];
     __shared__ float4 s_rgb[kBatch];
@@ -34,9 +35,17 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConsts f, const ui
     const bool inside = px < f.w_px && py < f.h_px;
     const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
     const uint2 range = ranges[tile];
+    const size_t fbo = (size_t)py * f.w_px + px;
 
+    // Later depth slabs / models behind continue from the (C, T) the framebuffer already holds; a tile
+    // with nothing new to blend, or already saturated, leaves it untouched.
+    if (carry && (range.x >= range.y || (done_bits && ((done_bits[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)))) return;
     float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
-    bool done = !inside;
+    if (carry && inside) {
+        const float4 p = fb[fbo];
+        C0 = p.x; C1 = p.y; C2 = p.z; T = p.w;
+    }
+    bool done = !inside || T < f.t_eps;
 
     for (uint32_t base = range.x; base < range.y; base += kBatch) {
         // vote + barrier: also protects the LDS batch of the previous iteration
@@ -74,15 +83,10 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConsts f, const ui
             }
         }
     }
-    if (inside) {
-        const size_t o = (size_t)py * f.w_px + px;
-        if (first_model) {
-            fb[o] = make_float4(C0, C1, C2, T);
-        } else {
-            // this model lies BEHIND what the framebuffer already holds (host walks near -> far)
-            const float4 p = fb[o];
-            fb[o] = make_float4(fmaf(p.w, C0, p.x), fmaf(p.w, C1, p.y), fmaf(p.w, C2, p.z), p.w * T);
-        }
+    if (inside) fb[fbo] = make_float4(C0, C1, C2, T);
+    if (done_bits && __syncthreads_and(done) && tid == 0) {
+        atomicOr(&done_bits[ty * row_words + (tx >> 5)], 1u << (tx & 31u));
+        atomicAdd(done_count, 1u);  // at most one per tile per frame
     }
 }
 
@@ -107,12 +111,13 @@ __global__ __launch_bounds__(256) void k_resolve_rgba8(const float4* __restrict_
 }
 
 hipError_t launch_composite(hipStream_t s, const FrameConsts& f, const uint2* ranges, const uint32_t* list,
-                            const Records& rec, float4* fb, bool first_model) {
+                            const Records& rec, float4* fb, bool carry, uint32_t* done, uint32_t row_words,
+                            uint32_t* d_done_count) {
     dim3 grid(f.tiles_x * f.tiles_y), block(256);
     if (f.display_mode == GSX_DISPLAY_SPLAT)
-        hipLaunchKernelGGL(k_composite<0>, grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, first_model ? 1 : 0);
+        hipLaunchKernelGGL(k_composite<0>, grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count);
     else
-        hipLaunchKernelGGL(k_composite<1>, grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, first_model ? 1 : 0);
+        hipLaunchKernelGGL(k_composite<1>, grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count);
     return hipGetLastError();
 }
 

@@ -256,6 +256,16 @@ class MultiModelViewer:
         _lib.check(self._L.gsx_viewer_set_spec_params(self._h, C.byref(sp)))
         return sp
 
+    def set_render_options(self, **kw) -> None:
+        """``gsx_render_options``: progressive depth slabs (default on), first_slab_divisor, min_slab, growth."""
+        o = _lib.RenderOptions()
+        self._L.gsx_render_options_default(C.byref(o))
+        for k, val in kw.items():
+            if not hasattr(o, k):
+                raise KeyError(k)
+            setattr(o, k, int(val))
+        _lib.check(self._L.gsx_viewer_set_render_options(self._h, C.byref(o)))
+
     # -- frame execution --
     def poll(self) -> None:
         """``device.poll(wgpu::Maintain::Wait)`` (src/tab/scene.rs:614, 873)."""
