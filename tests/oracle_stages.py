@@ -76,7 +76,11 @@ class OracleStages:
             if ty % world != rank:
                 fb[ty * 16:(ty + 1) * 16] = (0, 0, 0, 1)
         self._fb = fb
-        return dict(n_gaussians=pr["key"].size, n_visible=nvis, n_tile_entries=int(lst.size))
+        self._stats = dict(n_gaussians=pr["key"].size, n_visible=nvis, n_tile_entries=int(lst.size))
+        return self._stats
+
+    def stats(self, key):
+        return self._stats
 
     def render_local(self, key):
         pos, color, sh, cov = self.pod

@@ -20,7 +20,8 @@ def _single(g, cam, w, h):
     st = HipStages()
     st.load_shard("shard", g, 0, g.shape[0])
     st.set_uniforms("shard", cam, (w, h))
-    stats = st.render_local("shard")
+    st.render_local("shard")
+    stats = st.stats("shard")
     fb = st.framebuffer()
     st.close()
     return fb, stats
@@ -65,7 +66,8 @@ def test_emulated_world_matches_single_viewer(world):
             chunks.append(sends[src][off:off + counts[src][r]])
         recv = torch.cat(chunks) if chunks else sends[0][:0]
         with st.stream_ctx():
-            stats = st.render_records("shard", recv.contiguous(), recv.shape[0], world, r)
+            st.render_records("shard", recv.contiguous(), recv.shape[0], world, r)
+            stats = st.stats("shard")
             strips.append(st.own_strip(world, r).clone())
             st.poll()
         total_entries += stats["n_tile_entries"]

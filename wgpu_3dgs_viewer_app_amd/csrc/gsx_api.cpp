@@ -64,11 +64,7 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-struct Counters {  // device + pinned host mirror
-    uint32_t n_visible;
-    uint32_t n_entries;  // D of the current slab
-    uint32_t n_done;     // tiles that saturated while compositing this model
-};
+using Counters = SlabStats;  // device copy + pinned host mirror
 
 struct Model {
     std::string key;
@@ -93,8 +89,10 @@ struct Model {
     uint32_t* tile_list = nullptr;              // -> tv_* after the tile sort
     uint32_t* tile_keys = nullptr;
     bool preprocessed = false, sorted = false, counters_valid = false, binned = false;
+    bool stats_pending = false;                 // device statistics newer than the host mirror
     bool lists_complete = false;                // the tile lists of the last render cover the whole model (one slab)
     uint32_t n_visible = 0, n_entries = 0;
+    uint64_t tile_cap = 0;                      // capacity (entries) of the tile-pair buffers
     // the per-frame record set: the model's own projection (rec_n == n) or records imported from the
     // other ranks (gsx_shard_import); binning is restricted to tile rows row % row_world == row_rank
     uint64_t rec_n = 0, rec_cap = 0;
@@ -144,7 +142,8 @@ struct gsx_viewer {
     uint32_t display_mode = GSX_DISPLAY_SPLAT, sh_deg = 3, no_sh0 = 0;
     std::map<std::string, std::unique_ptr<Model>> models;
     DevBuf fb, staging, scratch, done_bits;
-    uint32_t tiles_done = 0;  // host view of the saturated-tile count of the current frame
+    DevBuf frame_done;        // u32: tiles saturated so far in the current frame (all models)
+    std::vector<std::string> last_keys;  // keys of the last gsx_render, for the overflow redo
     gsx_render_options options{1u, 16u, 131072u, 2u};
     bool timing = false;
     std::vector<PassTimer> timers;     // recorded, not yet read
@@ -201,20 +200,45 @@ static gsx_status ensure_fb(gsx_viewer* v) {
     return GSX_OK;
 }
 
-static gsx_status sync_counters(gsx_viewer* v) {
-    bool need = false;
-    for (auto& kv : v->models) need |= kv.second->sorted && !kv.second->counters_valid;
-    if (!need) return GSX_OK;
-    HIPCHK(hipStreamSynchronize(v->stream));
-    for (auto& kv : v->models) {
-        Model* m = kv.second.get();
-        if (m->sorted && !m->counters_valid) {
-            m->n_visible = m->h_counters->n_visible;
-            m->counters_valid = true;
+static gsx_status do_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys);
+
+// Frames are enqueued without any host round trip; this is where the host catches up: wait for the
+// stream, mirror the per-model statistics, and if a depth slab needed more tile-pair capacity than was
+// allocated, grow the buffers and redo the last gsx_render (rare: capacity starts at 16 entries/record).
+static gsx_status finish_frame(gsx_viewer* v) {
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        bool pending = false;
+        for (auto& kv : v->models) pending |= kv.second->stats_pending;
+        if (!pending) return GSX_OK;
+        for (auto& kv : v->models) {
+            Model* m = kv.second.get();
+            if (m->stats_pending)
+                HIPCHK(hipMemcpyAsync(m->h_counters, m->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, v->stream));
         }
+        HIPCHK(hipStreamSynchronize(v->stream));
+        bool redo = false;
+        for (auto& kv : v->models) {
+            Model* m = kv.second.get();
+            if (!m->stats_pending) continue;
+            m->stats_pending = false;
+            m->n_visible = m->h_counters->n_visible;
+            m->n_entries = m->h_counters->n_entries_total;
+            m->counters_valid = true;
+            if (m->h_counters->overflow && m->binned) {
+                m->tile_cap = std::max<uint64_t>(2 * m->tile_cap, (uint64_t)m->h_counters->max_needed + 1024);
+                redo = true;
+            }
+        }
+        if (!redo) return GSX_OK;
+        std::vector<const char*> keys;
+        for (auto& k : v->last_keys) keys.push_back(k.c_str());
+        gsx_status st = do_render(v, keys.data(), (uint32_t)keys.size());
+        if (st) return st;
     }
-    return GSX_OK;
+    return fail(GSX_ERR_OOM, "tile-pair buffers kept overflowing");
 }
+
+static gsx_status sync_counters(gsx_viewer* v) { return finish_frame(v); }
 
 static gsx_status ensure_record_capacity(Model* m, uint64_t count) {
     if (count <= m->rec_cap) return GSX_OK;
@@ -251,6 +275,7 @@ static gsx_status do_preprocess(gsx_viewer* v, Model* m) {
         v->pass_launches[GSX_PASS_PROJECT] += m->n ? 1 : 0;
     }
     HIPCHK(launch_sum_counts(v->stream, m->block_vis.as<uint32_t>(), (uint32_t)m->n, &m->counters.as<Counters>()->n_visible));
+    m->stats_pending = true;
     m->preprocessed = true;
     return GSX_OK;
 }
@@ -263,12 +288,11 @@ static gsx_status do_sort(gsx_viewer* v, Model* m) {
         RadixBuffers rb{m->key_buf.as<uint32_t>(), nullptr, m->sk_a.as<uint32_t>(), m->sv_a.as<uint32_t>(),
                         m->sk_b.as<uint32_t>(), m->sv_b.as<uint32_t>(), m->table.as<uint32_t>()};
         bool in_b = false;
-        HIPCHK(launch_radix_sort(v->stream, rb, n, 32, true, &in_b));
+        HIPCHK(launch_radix_sort(v->stream, rb, n, nullptr, 32, true, &in_b));
         m->sorted_idx = in_b ? m->sv_b.as<uint32_t>() : m->sv_a.as<uint32_t>();
         v->pass_launches[GSX_PASS_DEPTH_SORT] += n ? 4 : 0;
     }
-    HIPCHK(hipMemcpyAsync(&m->h_counters->n_visible, &m->counters.as<Counters>()->n_visible, 4, hipMemcpyDeviceToHost,
-                          v->stream));
+    m->stats_pending = true;
     m->sorted = true;
     m->binned = false;
     m->n_entries = 0;
@@ -293,8 +317,10 @@ static void plan_slabs(const gsx_render_options& o, uint32_t n_vis, std::vector<
     bounds->push_back(n_vis);
 }
 
-// One model: bin + tile-sort + composite, front to back in depth slabs.  carry: (C,T) already in the
-// framebuffer is in front of this model (nearer models were composited first).
+// One model: bin + tile-sort + composite, front to back in depth slabs, enqueued without host syncs.
+// Slab bounds are planned on the record count (an upper bound of N_vis; kernels clamp to the device-side
+// N_vis), slab entry counts stay on the device, and once every tile this rank owns is saturated the
+// remaining slabs' kernels fall through.  carry: the framebuffer already holds nearer models.
 static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
     if (!m->sorted) return fail(GSX_ERR_INVALID_ARG, "gsx_render: model '%s' was not preprocessed+sorted", m->key.c_str());
     if (m->fc.w_px != v->width || m->fc.h_px != v->height)
@@ -303,47 +329,48 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
     const uint32_t row_words = (m->fc.tiles_x + 31) / 32;
     const bool progressive = v->options.progressive != 0;
     uint32_t* done = progressive ? v->done_bits.as<uint32_t>() : nullptr;
+    uint32_t* done_count = v->frame_done.as<uint32_t>();
     std::vector<uint32_t> bounds;
-    plan_slabs(v->options, m->n_visible, &bounds);
+    plan_slabs(v->options, (uint32_t)m->rec_n, &bounds);
     Counters* dc = m->counters.as<Counters>();
-    m->n_entries = 0;
-    HIPCHK(m->ranges.ensure(sizeof(uint2) * (size_t)n_tiles));
-    HIPCHK(hipMemsetAsync(&dc->n_done, 0, 4, v->stream));
-    // tiles this rank composites: all of them, or its rows in the sharded path
     uint32_t owned_rows = 0;
     for (uint32_t ty = m->row_rank; ty < m->fc.tiles_y; ty += m->row_world) ++owned_rows;
     const uint32_t owned_tiles = owned_rows * m->fc.tiles_x;
-    const uint32_t done_before = v->tiles_done;
+
+    if (m->tile_cap == 0) m->tile_cap = std::max<uint64_t>(1u << 20, 16 * m->rec_n);
+    m->tile_cap = std::min<uint64_t>(m->tile_cap, 0xFFFFF000ull);
+    const uint32_t cap = (uint32_t)m->tile_cap;
+    {
+        const size_t bytes = sizeof(uint32_t) * (size_t)cap;
+        HIPCHK(m->tk_src.ensure(bytes));
+        HIPCHK(m->tv_src.ensure(bytes));
+        HIPCHK(m->tk_a.ensure(bytes));
+        HIPCHK(m->tv_a.ensure(bytes));
+        HIPCHK(m->tk_b.ensure(bytes));
+        HIPCHK(m->tv_b.ensure(bytes));
+        HIPCHK(m->ttable.ensure(sizeof(uint32_t) * radix_table_entries(cap)));
+        HIPCHK(m->ranges.ensure(sizeof(uint2) * (size_t)n_tiles));
+    }
+    // reset this model's per-frame totals (n_visible stays)
+    HIPCHK(hipMemsetAsync(&dc->n_entries, 0, sizeof(Counters) - offsetof(Counters, n_entries), v->stream));
+    const int bits = std::max<int>(1, (int)ceil_log2(n_tiles));
     for (size_t sl = 0; sl + 1 < bounds.size(); ++sl) {
-        if (progressive && v->tiles_done >= owned_tiles) break;  // every pixel is saturated: the rest is hidden
         const uint32_t j0 = bounds[sl], j1 = bounds[sl + 1];
         // the very first slab of the frame sees no saturated tile: plain rectangle areas
-        const uint32_t* done_in = (carry || sl > 0) ? done : nullptr;
+        const bool later = carry || sl > 0;
+        const uint32_t* done_in = later ? done : nullptr;
+        // a slab of S splats can produce at most S * n_tiles entries; size the sort launch by the smaller bound
+        const uint32_t slab_cap = (uint32_t)std::min<uint64_t>(cap, (uint64_t)(j1 - j0) * std::min<uint64_t>(owned_tiles, 1u << 16));
         {
             ScopedPass t(v, GSX_PASS_BIN);
             HIPCHK(launch_tile_counts(v->stream, j0, j1, &dc->n_visible, m->sorted_idx, m->rec(), m->srect.as<uint2>(),
-                                      m->cnt.as<uint32_t>(), m->block_sums.as<uint32_t>(), &dc->n_entries, m->row_world, m->row_rank, done_in,
-                                      row_words));
-        }
-        HIPCHK(hipMemcpyAsync(&m->h_counters->n_entries, &dc->n_entries, 8, hipMemcpyDeviceToHost, v->stream));
-        HIPCHK(hipStreamSynchronize(v->stream));
-        const uint32_t D = m->h_counters->n_entries;
-        v->tiles_done = done_before + m->h_counters->n_done;  // as of the previous slab's composite
-        m->n_entries += D;
-        if (D == 0 && (carry || sl > 0)) continue;  // nothing new in this slab; the framebuffer already holds the state
-        {
-            ScopedPass t(v, GSX_PASS_BIN);
-            const size_t bytes = sizeof(uint32_t) * std::max<size_t>(D, 1);
-            HIPCHK(m->tk_src.ensure(bytes));
-            HIPCHK(m->tv_src.ensure(bytes));
-            HIPCHK(m->tk_a.ensure(bytes));
-            HIPCHK(m->tv_a.ensure(bytes));
-            HIPCHK(m->tk_b.ensure(bytes));
-            HIPCHK(m->tv_b.ensure(bytes));
-            HIPCHK(m->ttable.ensure(sizeof(uint32_t) * radix_table_entries(D)));
+                                      m->cnt.as<uint32_t>(), m->block_sums.as<uint32_t>(), dc, cap, m->row_world,
+                                      m->row_rank, done_in, row_words, (progressive && later) ? done_count : nullptr,
+                                      owned_tiles));
             HIPCHK(launch_tile_emit(v->stream, j0, j1, m->sorted_idx, m->srect.as<uint2>(), m->cnt.as<uint32_t>(),
                                     m->block_sums.as<uint32_t>(), m->fc.tiles_x, m->tk_src.as<uint32_t>(),
-                                    m->tv_src.as<uint32_t>(), m->row_world, m->row_rank, done_in, row_words));
+                                    m->tv_src.as<uint32_t>(), m->row_world, m->row_rank, done_in, row_words, &dc->n_visible,
+                                    &dc->n_entries, cap));
             v->pass_launches[GSX_PASS_BIN] += 1;
         }
         {
@@ -351,34 +378,29 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
             RadixBuffers rb{m->tk_src.as<uint32_t>(), m->tv_src.as<uint32_t>(), m->tk_a.as<uint32_t>(), m->tv_a.as<uint32_t>(),
                             m->tk_b.as<uint32_t>(), m->tv_b.as<uint32_t>(), m->ttable.as<uint32_t>()};
             bool in_b = false;
-            const int bits = std::max<int>(1, (int)ceil_log2(n_tiles));
-            HIPCHK(launch_radix_sort(v->stream, rb, D, bits, false, &in_b));
-            if (D == 0) {
+            HIPCHK(launch_radix_sort(v->stream, rb, slab_cap, &dc->n_entries, bits, false, &in_b));
+            if (slab_cap == 0) {
                 m->tile_keys = m->tk_src.as<uint32_t>();
                 m->tile_list = m->tv_src.as<uint32_t>();
             } else {
                 m->tile_keys = in_b ? m->tk_b.as<uint32_t>() : m->tk_a.as<uint32_t>();
                 m->tile_list = in_b ? m->tv_b.as<uint32_t>() : m->tv_a.as<uint32_t>();
             }
-            v->pass_launches[GSX_PASS_TILE_SORT] += D ? (bits + 7) / 8 : 0;
+            v->pass_launches[GSX_PASS_TILE_SORT] += (bits + 7) / 8;
         }
         {
             ScopedPass t(v, GSX_PASS_BIN);
-            HIPCHK(launch_tile_ranges(v->stream, D, m->tile_keys, n_tiles, m->ranges.as<uint2>()));
+            HIPCHK(launch_tile_ranges(v->stream, slab_cap, &dc->n_entries, m->tile_keys, n_tiles, m->ranges.as<uint2>()));
         }
         {
             ScopedPass t(v, GSX_PASS_COMPOSITE);
             HIPCHK(launch_composite(v->stream, m->fc, m->ranges.as<uint2>(), m->tile_list, m->rec(), v->fb.as<float4>(),
-                                    carry || sl > 0, done, row_words, &dc->n_done));
+                                    later, done, row_words, done_count));
             v->pass_launches[GSX_PASS_COMPOSITE] += 1;
         }
     }
-    if (progressive) {  // the last composite's saturated tiles count for the models behind this one
-        HIPCHK(hipMemcpyAsync(&m->h_counters->n_done, &dc->n_done, 4, hipMemcpyDeviceToHost, v->stream));
-        HIPCHK(hipStreamSynchronize(v->stream));
-        v->tiles_done = done_before + m->h_counters->n_done;
-    }
     m->binned = true;
+    m->stats_pending = true;
     m->lists_complete = bounds.size() == 2 && !carry;
     return GSX_OK;
 }
@@ -387,22 +409,25 @@ static gsx_status do_render(gsx_viewer* v, const char* const* keys, uint32_t n_k
     gsx_status st = ensure_fb(v);
     if (st) return st;
     std::vector<Model*> order;
+    std::vector<std::string> key_copy;
     for (uint32_t i = 0; i < n_keys; ++i) {
         Model* m = find_model(v, keys ? keys[i] : nullptr);
         if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_render: no model '%s'", keys && keys[i] ? keys[i] : "(null)");
         order.push_back(m);
+        key_copy.push_back(keys[i]);
     }
-    if ((st = sync_counters(v))) return st;
+    v->last_keys = key_copy;
     if (order.empty()) {
         HIPCHK(launch_clear_fb(v->stream, v->fb.as<float4>(), v->width * v->height));
         return GSX_OK;
     }
+    HIPCHK(v->frame_done.ensure(4));
+    HIPCHK(hipMemsetAsync(v->frame_done.p, 0, 4, v->stream));
     if (v->options.progressive) {
         const uint32_t tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE, row_words = ((v->width + GSX_TILE - 1) / GSX_TILE + 31) / 32;
         HIPCHK(v->done_bits.ensure(4 * (size_t)tiles_y * row_words));
         HIPCHK(hipMemsetAsync(v->done_bits.p, 0, 4 * (size_t)tiles_y * row_words, v->stream));
     }
-    v->tiles_done = 0;
     // the reference paints far -> near with "over"; front-to-back accumulation walks the same list backwards
     bool carry = false;
     for (auto it = order.rbegin(); it != order.rend(); ++it) {
@@ -534,6 +559,7 @@ gsx_status gsx_model_create(gsx_viewer* v, const char* key, uint64_t count, gsx_
     }
     HIPCHK(m->counters.ensure(sizeof(Counters)));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&m->h_counters), sizeof(Counters), hipHostMallocDefault));
+    HIPCHK(hipMemsetAsync(m->counters.p, 0, sizeof(Counters), v->stream));
     // a fresh model is all-zero Gaussians (new_empty) and fully unmasked (MaskOpTree::Reset, scene.rs:2124-2131)
     HIPCHK(hipMemsetAsync(m->pc.p, 0, 16 * n, v->stream));
     HIPCHK(hipMemsetAsync(m->cov_a.p, 0, 16 * n, v->stream));
@@ -683,8 +709,10 @@ gsx_status gsx_sort(gsx_viewer* v, const char* key) {
 gsx_status gsx_sync(gsx_viewer* v) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
+    gsx_status fst = finish_frame(v);
+    if (fst) return fst;
     HIPCHK(hipStreamSynchronize(v->stream));
-    return sync_counters(v);
+    return GSX_OK;
 }
 
 gsx_status gsx_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys) {
@@ -711,6 +739,7 @@ gsx_status gsx_download_framebuffer(gsx_viewer* v, float* rgbt, uint64_t n_float
     const uint64_t need = 4ull * v->width * v->height;
     if (!rgbt || n_floats != need) return fail(GSX_ERR_INVALID_ARG, "gsx_download_framebuffer: expected %llu floats", (unsigned long long)need);
     if ((st = ensure_fb(v))) return st;
+    if ((st = finish_frame(v))) return st;
     HIPCHK(hipStreamSynchronize(v->stream));
     HIPCHK(hipMemcpy(rgbt, v->fb.p, sizeof(float) * need, hipMemcpyDeviceToHost));
     return GSX_OK;
@@ -722,6 +751,7 @@ gsx_status gsx_download_rgba8(gsx_viewer* v, const float bg[3], uint8_t* rgba, u
     const uint64_t npx = (uint64_t)v->width * v->height;
     if (!bg || !rgba || n_bytes != 4 * npx) return fail(GSX_ERR_INVALID_ARG, "gsx_download_rgba8: expected %llu bytes", (unsigned long long)(4 * npx));
     if ((st = ensure_fb(v))) return st;
+    if ((st = finish_frame(v))) return st;
     HIPCHK(v->scratch.ensure(4 * npx));
     HIPCHK(launch_resolve_rgba8(v->stream, v->fb.as<float4>(), (uint32_t)npx, bg[0], bg[1], bg[2], v->scratch.as<uint32_t>()));
     HIPCHK(hipStreamSynchronize(v->stream));
@@ -745,8 +775,8 @@ gsx_status gsx_model_frame_stats(gsx_viewer* v, const char* key, gsx_frame_stats
     if (st) return st;
     Model* m = find_model(v, key);
     if (!m || !out) return fail(GSX_ERR_NOT_FOUND, "gsx_model_frame_stats: no model '%s'", key ? key : "(null)");
-    if (!m->sorted) return fail(GSX_ERR_INVALID_ARG, "gsx_model_frame_stats: model '%s' not sorted this frame", key);
-    if ((st = sync_counters(v))) return st;
+    if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_model_frame_stats: model '%s' not preprocessed this frame", key);
+    if ((st = finish_frame(v))) return st;
     out->n_gaussians = m->n;
     out->n_visible = m->n_visible;
     out->n_tile_entries = m->binned ? m->n_entries : 0;  // entries actually binned by the last gsx_render
@@ -825,6 +855,7 @@ gsx_status gsx_model_download_tile_lists(gsx_viewer* v, const char* key, uint32_
     if (!m->lists_complete)
         return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_tile_lists: complete lists exist only for the front-most model "
                     "rendered with gsx_render_options.progressive = 0 (model '%s' was rendered in depth slabs)", key);
+    if ((st = finish_frame(v))) return st;
     const uint32_t n_tiles = m->fc.tiles_x * m->fc.tiles_y;
     if (n_offsets != (uint64_t)n_tiles + 1) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_tile_lists: expected %u offsets", n_tiles + 1);
     HIPCHK(hipStreamSynchronize(v->stream));
@@ -915,9 +946,9 @@ gsx_status gsx_shard_import(gsx_viewer* v, const char* key, const void* d_recv, 
     if ((st = ensure_record_capacity(m, n_records))) return st;
     HIPCHK(launch_import_records(v->stream, d_recv, (uint32_t)n_records, m->rec()));
     // every imported record is visible by construction
-    uint32_t nv = (uint32_t)n_records;
-    HIPCHK(hipMemcpyAsync(&m->counters.as<Counters>()->n_visible, &nv, 4, hipMemcpyHostToDevice, v->stream));
-    HIPCHK(hipStreamSynchronize(v->stream));
+    HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&m->counters.as<Counters>()->n_visible), (int)(uint32_t)n_records, 1,
+                             v->stream));
+    m->stats_pending = true;
     m->rec_n = n_records;
     m->row_world = world;
     m->row_rank = rank;
@@ -944,6 +975,7 @@ gsx_status gsx_shard_pack_strip(gsx_viewer* v, uint32_t world, uint32_t rank, vo
     if (strip_bytes != (uint64_t)rpr * GSX_TILE * v->width * sizeof(float4))
         return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack_strip: strip must be %llu bytes", (unsigned long long)((uint64_t)rpr * GSX_TILE * v->width * sizeof(float4)));
     if ((st = ensure_fb(v))) return st;
+    if ((st = finish_frame(v))) return st;  // a capacity overflow must be repaired before the strip leaves the GPU
     HIPCHK(launch_pack_strip(v->stream, v->fb.as<float4>(), v->width, v->height, world, rank, rpr, d_strip));
     return GSX_OK;
 }

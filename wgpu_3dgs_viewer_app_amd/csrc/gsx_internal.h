@@ -79,8 +79,18 @@ struct RadixBuffers {
     uint32_t* table;  // 256 * nblocks(n) + 256 entries
 };
 size_t radix_table_entries(uint64_t n);
-hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n, int bits, bool iota_values,
-                             bool* result_in_b);
+// n sizes the launch; d_n (nullable) is the real element count on the device (<= n).
+hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n, const uint32_t* d_n, int bits,
+                             bool iota_values, bool* result_in_b);
+
+// Device-resident per-model frame statistics; the host mirrors them lazily (no sync inside a frame).
+struct SlabStats {
+    uint32_t n_visible;        // N_vis (projection pass / import)
+    uint32_t n_entries;        // D of the slab being processed, clamped to the pair-buffer capacity
+    uint32_t n_entries_total;  // sum of slab D over the frame
+    uint32_t overflow;         // a slab needed more pair capacity than allocated: frame must be redone
+    uint32_t max_needed;       // largest slab D seen when overflowing
+};
 
 // Tile binning.
 // Splats [j0, min(j1, *d_n_vis)) of the depth order; cnt / block_sums are indexed relative to j0.
@@ -88,14 +98,15 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
 // done (nullable): bitmap of saturated tiles (row_words u32 per tile row) that receive no more entries.
 // srect[j - j0]: the splat's packed tile rectangle, gathered once by the count pass and re-read by emit.
 hipError_t launch_tile_counts(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* d_n_vis, const uint32_t* sorted_idx,
-                              const Records& rec, uint2* srect, uint32_t* cnt, uint32_t* block_sums,
-                              uint32_t* d_total /* D */, uint32_t world, uint32_t rank, const uint32_t* done,
-                              uint32_t row_words);
+                              const Records& rec, uint2* srect, uint32_t* cnt, uint32_t* block_sums, SlabStats* stats,
+                              uint32_t capacity, uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words,
+                              const uint32_t* d_done_count, uint32_t owned_tiles);
 hipError_t launch_tile_emit(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* sorted_idx, const uint2* srect,
                             const uint32_t* cnt, const uint32_t* block_sums, uint32_t tiles_x, uint32_t* tkey,
-                            uint32_t* tval, uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words);
-hipError_t launch_tile_ranges(hipStream_t s, uint32_t D, const uint32_t* tkey_sorted, uint32_t n_tiles,
-                              uint2* ranges);
+                            uint32_t* tval, uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words,
+                            const uint32_t* d_n_vis, const uint32_t* d_entries, uint32_t capacity);
+hipError_t launch_tile_ranges(hipStream_t s, uint32_t capacity, const uint32_t* d_n, const uint32_t* tkey_sorted,
+                              uint32_t n_tiles, uint2* ranges);
 size_t scan_blocks(uint64_t n);
 
 // Multi-GPU exchange support (kernels_shard.hip).

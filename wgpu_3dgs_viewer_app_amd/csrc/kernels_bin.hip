@@ -7,6 +7,8 @@
 // (kernels_sort.hip, 2 passes for <= 65536 tiles) leaves every tile's list depth-ordered.
 // Integer-only; must be bit-exact against oracle/gsx_oracle.c:gsxo_tile_lists.
 // Algorithmic bytes: N_vis*44 + D*12.
+#include <algorithm>
+
 #include "gsx_internal.h"
 
 namespace gsx {
@@ -70,8 +72,15 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_counts(const uint32_t* __r
                                                               uint2* __restrict__ srect, uint32_t* __restrict__ cnt,
                                                               uint32_t* __restrict__ block_sums, uint32_t world,
                                                               uint32_t rank, const uint32_t* __restrict__ done,
-                                                              uint32_t row_words) {
+                                                              uint32_t row_words,
+                                                              const uint32_t* __restrict__ d_done_count,
+                                                              uint32_t owned_tiles) {
     __shared__ uint32_t red[4];
+    // every tile this rank composites is saturated: whatever is left is hidden, skip the gather
+    if (d_done_count && *d_done_count >= owned_tiles) {
+        if (threadIdx.x == 0) block_sums[blockIdx.x] = 0;
+        return;
+    }
     const uint32_t n_vis = min(*d_n_vis, j1);
     const uint32_t j = j0 + blockIdx.x * kBinThreads + threadIdx.x;
     uint32_t c = 0;
@@ -85,9 +94,10 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_counts(const uint32_t* __r
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
-// single workgroup: exclusive scan of block_sums in place, grand total -> *d_total
+// single workgroup: exclusive scan of block_sums in place; slab total D -> stats->n_entries (clamped to the
+// pair-buffer capacity; an overflow is flagged for the host to grow the buffers and redo the frame)
 __global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__ sums, uint32_t nblocks,
-                                                           uint32_t* __restrict__ d_total) {
+                                                           SlabStats* __restrict__ stats, uint32_t capacity) {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry_s;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -111,20 +121,32 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__
         if (tid == 1023) carry_s = carry + woff + x;
         __syncthreads();
     }
-    if (tid == 0) *d_total = carry_s;
+    if (tid == 0) {
+        const uint32_t total = carry_s;
+        stats->n_entries = min(total, capacity);
+        stats->n_entries_total += total;
+        if (total > capacity) {
+            stats->overflow = 1;
+            stats->max_needed = max(stats->max_needed, total);
+        }
+    }
 }
 
 // emit (tile id, Gaussian index) pairs of slab splat j at offset = block_offs[workgroup] + exclusive scan
 // of cnt inside the workgroup.  Reads only sequential arrays (srect, cnt, sorted_idx).
-__global__ __launch_bounds__(kBinThreads) void k_tile_emit(uint32_t jbase, uint32_t n_vis,
+__global__ __launch_bounds__(kBinThreads) void k_tile_emit(uint32_t jbase, uint32_t n_vis /* upper bound j1 */,
                                                             const uint32_t* __restrict__ sorted_idx,
                                                             const uint2* __restrict__ srect,
                                                             const uint32_t* __restrict__ cnt,
                                                             const uint32_t* __restrict__ block_offs, uint32_t tiles_x,
                                                             uint32_t* __restrict__ tkey, uint32_t* __restrict__ tval,
                                                             uint32_t world, uint32_t rank,
-                                                            const uint32_t* __restrict__ done, uint32_t row_words) {
+                                                            const uint32_t* __restrict__ done, uint32_t row_words,
+                                                            const uint32_t* __restrict__ d_n_vis,
+                                                            const uint32_t* __restrict__ d_entries, uint32_t capacity) {
     __shared__ uint32_t wsum[4];
+    if (*d_entries == 0) return;  // empty slab (also: every tile already saturated)
+    n_vis = min(n_vis, *d_n_vis);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t j = jbase + blockIdx.x * kBinThreads + tid;
     const uint32_t mine = j < n_vis ? cnt[j - jbase] : 0u;
@@ -145,49 +167,55 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_emit(uint32_t jbase, uint3
     for (uint32_t ty = first_owned_row(y0, world, rank); ty < y1; ty += world)
         for (uint32_t tx = x0; tx < x1; ++tx) {
             if (done && ((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)) continue;
-            tkey[o] = ty * tiles_x + tx;
-            tval[o] = idx;
+            if (o < capacity) {
+                tkey[o] = ty * tiles_x + tx;
+                tval[o] = idx;
+            }
             ++o;
         }
 }
 
 // ranges[t] = [first, last+1) of tile t in the tile-sorted pair list (ranges pre-zeroed)
-__global__ __launch_bounds__(256) void k_tile_ranges(uint32_t D, const uint32_t* __restrict__ tkey,
+__global__ __launch_bounds__(256) void k_tile_ranges(const uint32_t* __restrict__ d_n, const uint32_t* __restrict__ tkey,
                                                       uint2* __restrict__ ranges) {
-    uint32_t e = blockIdx.x * 256u + threadIdx.x;
-    if (e >= D) return;
-    uint32_t t = tkey[e];
-    if (e == 0 || tkey[e - 1] != t) ranges[t].x = e;
-    if (e == D - 1 || tkey[e + 1] != t) ranges[t].y = e + 1;
+    const uint32_t D = *d_n;
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < D; e += gridDim.x * 256u) {
+        uint32_t t = tkey[e];
+        if (e == 0 || tkey[e - 1] != t) ranges[t].x = e;
+        if (e == D - 1 || tkey[e + 1] != t) ranges[t].y = e + 1;
+    }
 }
 
 hipError_t launch_tile_counts(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* d_n_vis, const uint32_t* sorted_idx,
-                              const Records& rec, uint2* srect, uint32_t* cnt, uint32_t* block_sums, uint32_t* d_total,
-                              uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words) {
+                              const Records& rec, uint2* srect, uint32_t* cnt, uint32_t* block_sums, SlabStats* stats,
+                              uint32_t capacity, uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words,
+                              const uint32_t* d_done_count, uint32_t owned_tiles) {
     uint32_t nb = (uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0);
     if (nb)
         hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(kBinThreads), 0, s, d_n_vis, j0, j1, sorted_idx, rec.a, srect, cnt,
-                           block_sums, world, rank, done, row_words);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nb, d_total);
+                           block_sums, world, rank, done, row_words, d_done_count, owned_tiles);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nb, stats, capacity);
     return hipGetLastError();
 }
 
 hipError_t launch_tile_emit(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* sorted_idx, const uint2* srect,
                             const uint32_t* cnt, const uint32_t* block_sums, uint32_t tiles_x, uint32_t* tkey,
-                            uint32_t* tval, uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words) {
+                            uint32_t* tval, uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words,
+                            const uint32_t* d_n_vis, const uint32_t* d_entries, uint32_t capacity) {
     uint32_t nb = (uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0);
     if (!nb) return hipSuccess;
     hipLaunchKernelGGL(k_tile_emit, dim3(nb), dim3(kBinThreads), 0, s, j0, j1, sorted_idx, srect, cnt, block_sums,
-                       tiles_x, tkey, tval, world, rank, done, row_words);
+                       tiles_x, tkey, tval, world, rank, done, row_words, d_n_vis, d_entries, capacity);
     return hipGetLastError();
 }
 
-hipError_t launch_tile_ranges(hipStream_t s, uint32_t D, const uint32_t* tkey_sorted, uint32_t n_tiles,
-                              uint2* ranges) {
+hipError_t launch_tile_ranges(hipStream_t s, uint32_t capacity, const uint32_t* d_n, const uint32_t* tkey_sorted,
+                              uint32_t n_tiles, uint2* ranges) {
     hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)n_tiles, s);
     if (e != hipSuccess) return e;
-    if (D == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_tile_ranges, dim3((D + 255) / 256), dim3(256), 0, s, D, tkey_sorted, ranges);
+    if (capacity == 0) return hipSuccess;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)capacity + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_tile_ranges, dim3(grid), dim3(256), 0, s, d_n, tkey_sorted, ranges);
     return hipGetLastError();
 }
 

@@ -54,8 +54,11 @@ class HipStages:
         self._size = (int(size[0]), int(size[1]))
 
     # -- single GPU --
-    def render_local(self, key: str) -> dict:
+    def render_local(self, key: str) -> None:
+        """Enqueue one whole frame; no host synchronisation (statistics are fetched lazily by ``stats``)."""
         self.viewer.render_frame([key])
+
+    def stats(self, key: str) -> dict:
         return self.viewer.frame_stats(key)
 
     # -- multi GPU (stage split of include/gsx.h) --
@@ -81,7 +84,6 @@ class HipStages:
         _lib.check(v._L.gsx_shard_import(v._h, key.encode(), recv.data_ptr() if n else None, n, world, rank))
         v.radix_sorter.sort(key)
         v.renderer.render([key])
-        return v.frame_stats(key)
 
     def own_strip(self, world: int, rank: int):
         import torch

@@ -61,7 +61,7 @@ class ShardedViewer:
         st = self.stages
         st.set_uniforms(self.KEY, camera, size, model_transform, gaussian_transform)
         if not self.use_dist:
-            self._stats = st.render_local(self.KEY)
+            st.render_local(self.KEY)
             return
         with st.stream_ctx():
             self._render_frame_dist()
@@ -83,7 +83,7 @@ class ShardedViewer:
         dist.all_to_all_single(recv, send[: sum(send_counts)], output_split_sizes=recv_counts,
                                input_split_sizes=[int(x) for x in send_counts], group=self.group)
         # stage C: sort + bin + composite this rank's tile rows
-        self._stats = st.render_records(self.KEY, recv, sum(recv_counts), world, rank)
+        st.render_records(self.KEY, recv, sum(recv_counts), world, rank)
         # stage M: gather the disjoint tile-row strips on rank 0
         strip = st.own_strip(world, rank)  # flat [rows_per_rank * 16 * W * 4]: the rows this rank owns, packed
         if rank == 0:
@@ -100,7 +100,8 @@ class ShardedViewer:
         self.stages.poll()
 
     def last_stats(self) -> dict:
-        return dict(self._stats)
+        """Statistics of the last frame (synchronises)."""
+        return dict(self.stages.stats(self.KEY))
 
     def set_pass_timing(self, on: bool) -> None:
         self.stages.set_pass_timing(on)
