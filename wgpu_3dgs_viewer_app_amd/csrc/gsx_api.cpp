@@ -78,10 +78,10 @@ struct Model {
 
     DevBuf pc, cov_a, cov_b, sh4, sh1, mask;
     DevBuf key_buf, rec_a, rec_b, rec_c;
-    DevBuf sk_a, sk_b, sv_a, sv_b, table;      // depth sort ping-pong + histogram table
+    DevBuf dp_a, dp_b, sk_out, sv_out, sort_ws; // depth sort: pair scratch, sorted keys / indices, workspace
     DevBuf cnt, block_sums, srect;              // per slab: tile counts in depth order, scan partials, tile rects
     DevBuf block_vis;                           // per-workgroup visible counts of the projection pass
-    DevBuf tk_src, tv_src, tk_a, tk_b, tv_a, tv_b, ttable;  // tile pairs
+    DevBuf tp_src, tp_a, tp_b, tk_out, tv_out, tsort_ws;  // tile pairs: emitted, scratch, sorted (split), workspace
     DevBuf ranges;
     DevBuf counters;
     Counters* h_counters = nullptr;             // pinned
@@ -93,6 +93,9 @@ struct Model {
     bool lists_complete = false;                // the tile lists of the last render cover the whole model (one slab)
     uint32_t n_visible = 0, n_entries = 0;
     uint64_t tile_cap = 0;                      // capacity (entries) of the tile-pair buffers
+    uint32_t slabs_hint = 0;                    // slabs the last observed frame needed (0 = unknown)
+    hipEvent_t stats_event = nullptr;           // completion of the asynchronous statistics copy
+    bool stats_copy_inflight = false;
     // the per-frame record set: the model's own projection (rec_n == n) or records imported from the
     // other ranks (gsx_shard_import); binning is restricted to tile rows row % row_world == row_rank
     uint64_t rec_n = 0, rec_cap = 0;
@@ -101,6 +104,7 @@ struct Model {
 
     ~Model() {
         if (h_counters) (void)hipHostFree(h_counters);
+        if (stats_event) (void)hipEventDestroy(stats_event);
     }
     PodPlanes pod() const {
         PodPlanes p;
@@ -224,6 +228,8 @@ static gsx_status finish_frame(gsx_viewer* v) {
             m->n_visible = m->h_counters->n_visible;
             m->n_entries = m->h_counters->n_entries_total;
             m->counters_valid = true;
+            if (m->binned) m->slabs_hint = m->h_counters->slabs_used;
+            m->stats_copy_inflight = false;
             if (m->h_counters->overflow && m->binned) {
                 m->tile_cap = std::max<uint64_t>(2 * m->tile_cap, (uint64_t)m->h_counters->max_needed + 1024);
                 redo = true;
@@ -247,11 +253,17 @@ static gsx_status ensure_record_capacity(Model* m, uint64_t count) {
     HIPCHK(m->rec_a.ensure(16 * n));
     HIPCHK(m->rec_b.ensure(16 * n));
     HIPCHK(m->rec_c.ensure(16 * n));
-    HIPCHK(m->sk_a.ensure(4 * n));
-    HIPCHK(m->sk_b.ensure(4 * n));
-    HIPCHK(m->sv_a.ensure(4 * n));
-    HIPCHK(m->sv_b.ensure(4 * n));
-    HIPCHK(m->table.ensure(4 * radix_table_entries(n)));
+    HIPCHK(m->dp_a.ensure(8 * n));
+    HIPCHK(m->dp_b.ensure(8 * n));
+    HIPCHK(m->sk_out.ensure(4 * n));
+    HIPCHK(m->sv_out.ensure(4 * n));
+    {
+        const size_t ws = 4 * radix_workspace_words(n);
+        if (ws > m->sort_ws.bytes) {
+            HIPCHK(m->sort_ws.ensure(ws));
+            HIPCHK(hipMemset(m->sort_ws.p, 0, m->sort_ws.bytes));  // status words must not alias a live epoch
+        }
+    }
     HIPCHK(m->cnt.ensure(4 * n));
     HIPCHK(m->srect.ensure(8 * n));
     HIPCHK(m->block_sums.ensure(4 * (scan_blocks(n) + 1)));
@@ -285,11 +297,10 @@ static gsx_status do_sort(gsx_viewer* v, Model* m) {
     const uint32_t n = (uint32_t)m->rec_n;
     {
         ScopedPass t(v, GSX_PASS_DEPTH_SORT);
-        RadixBuffers rb{m->key_buf.as<uint32_t>(), nullptr, m->sk_a.as<uint32_t>(), m->sv_a.as<uint32_t>(),
-                        m->sk_b.as<uint32_t>(), m->sv_b.as<uint32_t>(), m->table.as<uint32_t>()};
-        bool in_b = false;
-        HIPCHK(launch_radix_sort(v->stream, rb, n, nullptr, 32, true, &in_b));
-        m->sorted_idx = in_b ? m->sv_b.as<uint32_t>() : m->sv_a.as<uint32_t>();
+        RadixBuffers rb{m->key_buf.as<uint32_t>(), nullptr, nullptr, m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
+                        m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
+        HIPCHK(launch_radix_sort(v->stream, rb, n, nullptr, 32, true));
+        m->sorted_idx = m->sv_out.as<uint32_t>();
         v->pass_launches[GSX_PASS_DEPTH_SORT] += n ? 4 : 0;
     }
     m->stats_pending = true;
@@ -317,6 +328,20 @@ static void plan_slabs(const gsx_render_options& o, uint32_t n_vis, std::vector<
     bounds->push_back(n_vis);
 }
 
+// Frames are coherent: if the last observed frame saturated every tile after `used` slabs, the slabs
+// after used + 1 are merged into ONE remainder slab.  When the prediction holds that slab falls through
+// on the device (its count pass sees every tile done); when it does not, the remainder slab simply does
+// the work — the image is the same either way, only the number of empty launches changes.
+static void merge_tail_slabs(std::vector<uint32_t>* bounds, uint32_t used) {
+    if (used == 0) return;
+    const size_t keep = (size_t)used + 1;  // slabs kept as planned
+    if (bounds->size() > keep + 2) {
+        const uint32_t last = bounds->back();
+        bounds->resize(keep + 1);
+        bounds->push_back(last);
+    }
+}
+
 // One model: bin + tile-sort + composite, front to back in depth slabs, enqueued without host syncs.
 // Slab bounds are planned on the record count (an upper bound of N_vis; kernels clamp to the device-side
 // N_vis), slab entry counts stay on the device, and once every tile this rank owns is saturated the
@@ -332,6 +357,13 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
     uint32_t* done_count = v->frame_done.as<uint32_t>();
     std::vector<uint32_t> bounds;
     plan_slabs(v->options, (uint32_t)m->rec_n, &bounds);
+    if (progressive) {
+        if (m->stats_copy_inflight && hipEventQuery(m->stats_event) == hipSuccess) {
+            m->stats_copy_inflight = false;
+            m->slabs_hint = m->h_counters->slabs_used;
+        }
+        merge_tail_slabs(&bounds, m->slabs_hint);
+    }
     Counters* dc = m->counters.as<Counters>();
     uint32_t owned_rows = 0;
     for (uint32_t ty = m->row_rank; ty < m->fc.tiles_y; ty += m->row_world) ++owned_rows;
@@ -342,13 +374,16 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
     const uint32_t cap = (uint32_t)m->tile_cap;
     {
         const size_t bytes = sizeof(uint32_t) * (size_t)cap;
-        HIPCHK(m->tk_src.ensure(bytes));
-        HIPCHK(m->tv_src.ensure(bytes));
-        HIPCHK(m->tk_a.ensure(bytes));
-        HIPCHK(m->tv_a.ensure(bytes));
-        HIPCHK(m->tk_b.ensure(bytes));
-        HIPCHK(m->tv_b.ensure(bytes));
-        HIPCHK(m->ttable.ensure(sizeof(uint32_t) * radix_table_entries(cap)));
+        HIPCHK(m->tp_src.ensure(2 * bytes));
+        HIPCHK(m->tk_out.ensure(bytes));
+        HIPCHK(m->tv_out.ensure(bytes));
+        HIPCHK(m->tp_a.ensure(2 * bytes));
+        HIPCHK(m->tp_b.ensure(2 * bytes));
+        const size_t ws = 4 * radix_workspace_words(cap);
+        if (ws > m->tsort_ws.bytes) {
+            HIPCHK(m->tsort_ws.ensure(ws));
+            HIPCHK(hipMemsetAsync(m->tsort_ws.p, 0, m->tsort_ws.bytes, v->stream));
+        }
         HIPCHK(m->ranges.ensure(sizeof(uint2) * (size_t)n_tiles));
     }
     // reset this model's per-frame totals (n_visible stays)
@@ -366,26 +401,19 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
             HIPCHK(launch_tile_counts(v->stream, j0, j1, &dc->n_visible, m->sorted_idx, m->rec(), m->srect.as<uint2>(),
                                       m->cnt.as<uint32_t>(), m->block_sums.as<uint32_t>(), dc, cap, m->row_world,
                                       m->row_rank, done_in, row_words, (progressive && later) ? done_count : nullptr,
-                                      owned_tiles));
+                                      owned_tiles, (uint32_t)sl));
             HIPCHK(launch_tile_emit(v->stream, j0, j1, m->sorted_idx, m->srect.as<uint2>(), m->cnt.as<uint32_t>(),
-                                    m->block_sums.as<uint32_t>(), m->fc.tiles_x, m->tk_src.as<uint32_t>(),
-                                    m->tv_src.as<uint32_t>(), m->row_world, m->row_rank, done_in, row_words, &dc->n_visible,
-                                    &dc->n_entries, cap));
+                                    m->block_sums.as<uint32_t>(), m->fc.tiles_x, m->tp_src.as<uint2>(), m->row_world,
+                                    m->row_rank, done_in, row_words, &dc->n_visible, &dc->n_entries, cap));
             v->pass_launches[GSX_PASS_BIN] += 1;
         }
         {
             ScopedPass t(v, GSX_PASS_TILE_SORT);
-            RadixBuffers rb{m->tk_src.as<uint32_t>(), m->tv_src.as<uint32_t>(), m->tk_a.as<uint32_t>(), m->tv_a.as<uint32_t>(),
-                            m->tk_b.as<uint32_t>(), m->tv_b.as<uint32_t>(), m->ttable.as<uint32_t>()};
-            bool in_b = false;
-            HIPCHK(launch_radix_sort(v->stream, rb, slab_cap, &dc->n_entries, bits, false, &in_b));
-            if (slab_cap == 0) {
-                m->tile_keys = m->tk_src.as<uint32_t>();
-                m->tile_list = m->tv_src.as<uint32_t>();
-            } else {
-                m->tile_keys = in_b ? m->tk_b.as<uint32_t>() : m->tk_a.as<uint32_t>();
-                m->tile_list = in_b ? m->tv_b.as<uint32_t>() : m->tv_a.as<uint32_t>();
-            }
+            RadixBuffers rb{nullptr, nullptr, m->tp_src.as<uint2>(), m->tk_out.as<uint32_t>(), m->tv_out.as<uint32_t>(),
+                            m->tp_a.as<uint2>(), m->tp_b.as<uint2>(), m->tsort_ws.as<uint32_t>()};
+            HIPCHK(launch_radix_sort(v->stream, rb, slab_cap, &dc->n_entries, bits, false));
+            m->tile_keys = m->tk_out.as<uint32_t>();
+            m->tile_list = m->tv_out.as<uint32_t>();
             v->pass_launches[GSX_PASS_TILE_SORT] += (bits + 7) / 8;
         }
         {
@@ -398,6 +426,12 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
                                     later, done, row_words, done_count));
             v->pass_launches[GSX_PASS_COMPOSITE] += 1;
         }
+    }
+    if (progressive && !m->stats_copy_inflight) {  // feed the next frames' slab plan without waiting
+        if (!m->stats_event) HIPCHK(hipEventCreateWithFlags(&m->stats_event, hipEventDisableTiming));
+        HIPCHK(hipMemcpyAsync(m->h_counters, m->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, v->stream));
+        HIPCHK(hipEventRecord(m->stats_event, v->stream));
+        m->stats_copy_inflight = true;
     }
     m->binned = true;
     m->stats_pending = true;

@@ -70,18 +70,20 @@ hipError_t launch_project(hipStream_t s, const FrameConsts& f, uint32_t n, const
 hipError_t launch_sum_counts(hipStream_t s, const uint32_t* d_block_visible, uint32_t n, uint32_t* d_n_visible);
 size_t project_blocks(uint64_t n);
 
-// Stable LSD radix sort of (key,value) u32 pairs, 8-bit digits.  `bits` = number of significant key bits.
-// Pass 0 reads (keys_src, vals_src) and never writes them; passes then ping-pong src -> a -> b -> a ...
-// iota_values: the value of element i is i (vals_src unused).  *result_in_b says where the result landed.
+// Stable LSD radix sort of (key,value) u32 pairs, 8-bit digits (kernels_sort.hip).  `bits` = number of
+// significant key bits.  Reads (keys_src, vals_src) — never written; iota_values: the value of element i is
+// i — and leaves the sorted keys / values in (keys_out, vals_out).  pairs_a / pairs_b: interleaved scratch.
 struct RadixBuffers {
     const uint32_t *keys_src, *vals_src;
-    uint32_t *keys_a, *vals_a, *keys_b, *vals_b;
-    uint32_t* table;  // 256 * nblocks(n) + 256 entries
+    const uint2* pairs_src;  // alternative input: interleaved {key,value} pairs (then keys_src/vals_src unused)
+    uint32_t *keys_out, *vals_out;
+    uint2 *pairs_a, *pairs_b;
+    uint32_t* workspace;  // radix_workspace_words(n) u32, zero-initialised once at allocation
 };
-size_t radix_table_entries(uint64_t n);
+size_t radix_workspace_words(uint64_t n);
 // n sizes the launch; d_n (nullable) is the real element count on the device (<= n).
 hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n, const uint32_t* d_n, int bits,
-                             bool iota_values, bool* result_in_b);
+                             bool iota_values);
 
 // Device-resident per-model frame statistics; the host mirrors them lazily (no sync inside a frame).
 struct SlabStats {
@@ -90,6 +92,7 @@ struct SlabStats {
     uint32_t n_entries_total;  // sum of slab D over the frame
     uint32_t overflow;         // a slab needed more pair capacity than allocated: frame must be redone
     uint32_t max_needed;       // largest slab D seen when overflowing
+    uint32_t slabs_used;       // number of slabs that still found a live tile (progressive mode)
 };
 
 // Tile binning.
@@ -100,10 +103,10 @@ struct SlabStats {
 hipError_t launch_tile_counts(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* d_n_vis, const uint32_t* sorted_idx,
                               const Records& rec, uint2* srect, uint32_t* cnt, uint32_t* block_sums, SlabStats* stats,
                               uint32_t capacity, uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words,
-                              const uint32_t* d_done_count, uint32_t owned_tiles);
+                              const uint32_t* d_done_count, uint32_t owned_tiles, uint32_t slab_index);
 hipError_t launch_tile_emit(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* sorted_idx, const uint2* srect,
-                            const uint32_t* cnt, const uint32_t* block_sums, uint32_t tiles_x, uint32_t* tkey,
-                            uint32_t* tval, uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words,
+                            const uint32_t* cnt, const uint32_t* block_sums, uint32_t tiles_x, uint2* tpairs,
+                            uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words,
                             const uint32_t* d_n_vis, const uint32_t* d_entries, uint32_t capacity);
 hipError_t launch_tile_ranges(hipStream_t s, uint32_t capacity, const uint32_t* d_n, const uint32_t* tkey_sorted,
                               uint32_t n_tiles, uint2* ranges);

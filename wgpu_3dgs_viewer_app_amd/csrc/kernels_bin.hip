@@ -97,7 +97,9 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_counts(const uint32_t* __r
 // single workgroup: exclusive scan of block_sums in place; slab total D -> stats->n_entries (clamped to the
 // pair-buffer capacity; an overflow is flagged for the host to grow the buffers and redo the frame)
 __global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__ sums, uint32_t nblocks,
-                                                           SlabStats* __restrict__ stats, uint32_t capacity) {
+                                                           SlabStats* __restrict__ stats, uint32_t capacity,
+                                                           const uint32_t* __restrict__ d_done_count,
+                                                           uint32_t owned_tiles, uint32_t slab_index) {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry_s;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -125,6 +127,8 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__
         const uint32_t total = carry_s;
         stats->n_entries = min(total, capacity);
         stats->n_entries_total += total;
+        // the host sizes the next frame's slab plan from this (read lazily, never waited for)
+        if (!(d_done_count && *d_done_count >= owned_tiles)) stats->slabs_used = max(stats->slabs_used, slab_index + 1u);
         if (total > capacity) {
             stats->overflow = 1;
             stats->max_needed = max(stats->max_needed, total);
@@ -132,15 +136,31 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__
     }
 }
 
-// emit (tile id, Gaussian index) pairs of slab splat j at offset = block_offs[workgroup] + exclusive scan
-// of cnt inside the workgroup.  Reads only sequential arrays (srect, cnt, sorted_idx).
+// emit interleaved {tile id, Gaussian index} pairs of slab splat j at offset = block_offs[workgroup] +
+// exclusive scan of cnt inside the workgroup.  Reads only sequential arrays (srect, cnt, sorted_idx).
+// Splats touching up to kCoopThreshold live tiles are written by their own lane; the few large ones are
+// expanded cooperatively by the whole wave (lane l writes tiles l, l+64, ...), which removes the long
+// divergent tail a single lane would otherwise serialise.
+constexpr uint32_t kCoopThreshold = 24;
+
+__device__ inline void emit_rect(uint2* __restrict__ tpairs, uint32_t o, uint32_t capacity, uint32_t idx, uint2 r,
+                                 uint32_t tiles_x, uint32_t world, uint32_t rank, const uint32_t* __restrict__ done,
+                                 uint32_t row_words) {
+    const uint32_t x0 = r.x & 0xFFFFu, x1 = r.x >> 16, y0 = r.y & 0xFFFFu, y1 = r.y >> 16;
+    for (uint32_t ty = first_owned_row(y0, world, rank); ty < y1; ty += world)
+        for (uint32_t tx = x0; tx < x1; ++tx) {
+            if (done && ((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)) continue;
+            if (o < capacity) tpairs[o] = make_uint2(ty * tiles_x + tx, idx);
+            ++o;
+        }
+}
+
 __global__ __launch_bounds__(kBinThreads) void k_tile_emit(uint32_t jbase, uint32_t n_vis /* upper bound j1 */,
                                                             const uint32_t* __restrict__ sorted_idx,
                                                             const uint2* __restrict__ srect,
                                                             const uint32_t* __restrict__ cnt,
                                                             const uint32_t* __restrict__ block_offs, uint32_t tiles_x,
-                                                            uint32_t* __restrict__ tkey, uint32_t* __restrict__ tval,
-                                                            uint32_t world, uint32_t rank,
+                                                            uint2* __restrict__ tpairs, uint32_t world, uint32_t rank,
                                                             const uint32_t* __restrict__ done, uint32_t row_words,
                                                             const uint32_t* __restrict__ d_n_vis,
                                                             const uint32_t* __restrict__ d_entries, uint32_t capacity) {
@@ -158,21 +178,55 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_emit(uint32_t jbase, uint3
     }
     if (lane == 63) wsum[wave] = x;
     __syncthreads();
-    if (mine == 0) return;
     uint32_t o = block_offs[blockIdx.x] + x - mine;
     for (uint32_t w = 0; w < wave; ++w) o += wsum[w];
-    const uint32_t idx = sorted_idx[j];
-    const uint2 r = srect[j - jbase];
-    const uint32_t x0 = r.x & 0xFFFFu, x1 = r.x >> 16, y0 = r.y & 0xFFFFu, y1 = r.y >> 16;
-    for (uint32_t ty = first_owned_row(y0, world, rank); ty < y1; ty += world)
-        for (uint32_t tx = x0; tx < x1; ++tx) {
-            if (done && ((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)) continue;
-            if (o < capacity) {
-                tkey[o] = ty * tiles_x + tx;
-                tval[o] = idx;
+    uint32_t idx = 0;
+    uint2 r = make_uint2(0, 0);
+    if (mine) {
+        idx = sorted_idx[j];
+        r = srect[j - jbase];
+    }
+    if (mine && mine <= kCoopThreshold) emit_rect(tpairs, o, capacity, idx, r, tiles_x, world, rank, done, row_words);
+    // large splats: one at a time, all 64 lanes
+    unsigned long long big = __ballot(mine > kCoopThreshold);
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const uint32_t bo = __shfl(o, src, 64), bidx = __shfl(idx, src, 64);
+        const uint32_t rx = __shfl(r.x, src, 64), ry = __shfl(r.y, src, 64);
+        const uint32_t x0 = rx & 0xFFFFu, x1 = rx >> 16, y0 = ry & 0xFFFFu, y1 = ry >> 16;
+        const uint32_t w = x1 - x0;
+        if (!done) {
+            // no saturated tiles: the k-th entry is tile (first + (k / w) * world, x0 + k % w)
+            const uint32_t first = first_owned_row(y0, world, rank);
+            const uint32_t total = __shfl(mine, src, 64);
+            for (uint32_t k = lane; k < total; k += 64) {
+                const uint32_t ty = first + (k / w) * world, tx = x0 + k % w;
+                if (bo + k < capacity) tpairs[bo + k] = make_uint2(ty * tiles_x + tx, bidx);
             }
-            ++o;
+        } else {
+            // with a done bitmap the slots are not a closed form: lanes take whole rows, offsets by a wave scan
+            uint32_t row_o = bo;
+            for (uint32_t ty0 = first_owned_row(y0, world, rank); ty0 < y1; ty0 += 64 * world) {
+                const uint32_t ty = ty0 + lane * world;
+                const uint32_t live = ty < y1 ? live_tiles_in_row(done, row_words, ty, x0, x1) : 0u;
+                uint32_t incl = live;
+#pragma unroll
+                for (int s = 1; s < 64; s <<= 1) {
+                    uint32_t y = __shfl_up(incl, s, 64);
+                    if (lane >= (uint32_t)s) incl += y;
+                }
+                uint32_t oo = row_o + incl - live;
+                if (ty < y1)
+                    for (uint32_t tx = x0; tx < x1; ++tx) {
+                        if ((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u) continue;
+                        if (oo < capacity) tpairs[oo] = make_uint2(ty * tiles_x + tx, bidx);
+                        ++oo;
+                    }
+                row_o += __shfl(incl, 63, 64);
+            }
         }
+    }
 }
 
 // ranges[t] = [first, last+1) of tile t in the tile-sorted pair list (ranges pre-zeroed)
@@ -189,23 +243,24 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const uint32_t* __restrict_
 hipError_t launch_tile_counts(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* d_n_vis, const uint32_t* sorted_idx,
                               const Records& rec, uint2* srect, uint32_t* cnt, uint32_t* block_sums, SlabStats* stats,
                               uint32_t capacity, uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words,
-                              const uint32_t* d_done_count, uint32_t owned_tiles) {
+                              const uint32_t* d_done_count, uint32_t owned_tiles, uint32_t slab_index) {
     uint32_t nb = (uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0);
     if (nb)
         hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(kBinThreads), 0, s, d_n_vis, j0, j1, sorted_idx, rec.a, srect, cnt,
                            block_sums, world, rank, done, row_words, d_done_count, owned_tiles);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nb, stats, capacity);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nb, stats, capacity, d_done_count,
+                       owned_tiles, slab_index);
     return hipGetLastError();
 }
 
 hipError_t launch_tile_emit(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* sorted_idx, const uint2* srect,
-                            const uint32_t* cnt, const uint32_t* block_sums, uint32_t tiles_x, uint32_t* tkey,
-                            uint32_t* tval, uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words,
+                            const uint32_t* cnt, const uint32_t* block_sums, uint32_t tiles_x, uint2* tpairs,
+                            uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words,
                             const uint32_t* d_n_vis, const uint32_t* d_entries, uint32_t capacity) {
     uint32_t nb = (uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0);
     if (!nb) return hipSuccess;
     hipLaunchKernelGGL(k_tile_emit, dim3(nb), dim3(kBinThreads), 0, s, j0, j1, sorted_idx, srect, cnt, block_sums,
-                       tiles_x, tkey, tval, world, rank, done, row_words, d_n_vis, d_entries, capacity);
+                       tiles_x, tpairs, world, rank, done, row_words, d_n_vis, d_entries, capacity);
     return hipGetLastError();
 }
 

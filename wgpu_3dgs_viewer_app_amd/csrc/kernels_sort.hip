@@ -2,17 +2,28 @@
 //
 // Replaces the reference's K2 (`radix_sorter.sort(encoder, bind_group, indirect_args)`,
 // src/tab/scene.rs:865-869: key = depth, value = Gaussian index) and also orders the tile-binning
-// pairs (key = tile id).  Integer-only, HBM-bound: per 8-bit pass each element is read twice as a key
-// (histogram + scatter), once as a value, and written once: 20 B/element/pass.
+// pairs (key = tile id).  Integer-only, HBM-bound.
 //
-// Structure per pass (three launches, no inter-workgroup spinning):
-//   k_radix_hist    each workgroup histograms its 4096-element tile   -> table[digit][workgroup]
-//   k_radix_rowscan one workgroup per digit scans its table row        -> exclusive offsets + digit totals
-//   k_radix_scatter re-reads the tile, ranks every element stably inside the workgroup with
-//                   wave-level digit matching (8 ballots), and scatters to its final position.
-// Stability (and therefore determinism, ties broken by input order) comes from the ranking order
-// (wave, round, lane) == memory order inside a tile, tiles in workgroup order, digits in table order.
+// One launch per 8-bit digit ("onesweep" structure, written for CDNA4):
+//   k_radix_global_hist   one read of the keys builds the digit histograms of ALL passes.
+//   k_radix_onesweep      persistent workgroups take 4096-element tiles in ticket order; per tile:
+//                         stable ranks by wave-level digit matching (8 ballots) -> per-digit tile counts
+//                         -> published as one 64-bit {epoch|flag, count} word per (tile, digit);
+//                         thread d looks back over the preceding tiles' words of digit d (decoupled
+//                         look-back) to get the tile's global offset; the tile is reordered by digit in
+//                         LDS and written out so that consecutive lanes hit consecutive addresses.
+// Per pass every element is read once (8 B) and written once (8 B); intermediate passes move interleaved
+// {key,value} pairs, the last pass writes split key / value arrays for the consumers.
+// Inter-workgroup protocol (guide §6 G16, form R2 "the data IS the flag"): each status word is written by
+// ONE relaxed agent-scope 64-bit atomic store and polled with relaxed agent-scope loads; nothing else is
+// exchanged between workgroups, so no fence is needed.  Tickets guarantee that every tile a workgroup can
+// wait for is already held by a running workgroup (no dependence on dispatch order or XCD placement).
+// The status words carry an epoch (one per launch) so they never need clearing; the ticket counter is
+// reset by the last workgroup to finish.
+// The element count may live on the device (d_n: tile pairs of a depth slab) — no host round trip.
+// Stability (ties keep input order) makes the depth order deterministic: ties break by Gaussian index.
 #include <algorithm>
+#include <cstdlib>
 
 #include "gsx_internal.h"
 
@@ -20,14 +31,20 @@ namespace gsx {
 
 constexpr int kRadixThreads = 256;
 constexpr int kRadixWaves = kRadixThreads / 64;
-constexpr int kRadixRounds = 16;                                    // elements per lane
-constexpr int kRadixTile = kRadixThreads * kRadixRounds;            // 4096 elements per workgroup
-constexpr int kWaveChunk = 64 * kRadixRounds;                       // 1024 contiguous elements per wave
+constexpr int kRadixRounds = 16;                          // elements per lane
+constexpr int kRadixTile = kRadixThreads * kRadixRounds;  // 4096 elements per tile
+constexpr int kWaveChunk = 64 * kRadixRounds;             // 1024 contiguous elements per wave
+constexpr uint32_t kRadixGrid = 768;                      // persistent workgroups = resident capacity (3 per CU);
+                                                          // measured best of 128..1024 on MI355X
+constexpr uint32_t kMaxPasses = 4;
 
-constexpr uint32_t kRadixGrid = 1024;  // workgroups per pass at most (4 per CU); fixes the histogram table size
+constexpr unsigned long long kFlagAggregate = 1, kFlagPrefix = 2;
 
-static inline uint32_t radix_blocks(uint64_t n) { return (uint32_t)((n + kRadixTile - 1) / kRadixTile); }
-size_t radix_table_entries(uint64_t) { return (size_t)256 * kRadixGrid + 256; }
+static inline uint32_t radix_tiles(uint64_t n) { return (uint32_t)((n + kRadixTile - 1) / kRadixTile); }
+
+// workspace (u32 words): [0, 1024) global histograms of up to 4 passes | 1024 ticket | 1025 finished |
+// from 1032: 2 words (one 64-bit status) per (tile, digit)
+size_t radix_workspace_words(uint64_t n) { return 1032 + (size_t)radix_tiles(std::max<uint64_t>(n, 1)) * 256 * 2; }
 
 // lanes of this wave holding the same 8-bit digit (among `valid` lanes)
 __device__ inline unsigned long long wave_match8(uint32_t digit, bool valid) {
@@ -41,48 +58,44 @@ __device__ inline unsigned long long wave_match8(uint32_t digit, bool valid) {
     return m;
 }
 
-__device__ inline unsigned long long lanemask_lt() {
-    return (1ull << (threadIdx.x & 63u)) - 1ull;
-}
+__device__ inline unsigned long long lanemask_lt() { return (1ull << (threadIdx.x & 63u)) - 1ull; }
 
-// Work split: the ceil(n/4096) tiles are dealt to the workgroups in CONTIGUOUS runs (workgroup b owns tiles
-// [b*tpb, (b+1)*tpb)), so the grid and the histogram table have a fixed size (<= kRadixGrid) that does not
-// depend on n.  That lets n live on the device (d_n, the tile-pair count of a depth slab) with no host
-// round trip: n_cap only bounds the launch.
-__device__ inline void radix_my_tiles(uint32_t n, uint32_t& t0, uint32_t& t1) {
-    const uint32_t tiles = (n + kRadixTile - 1) / kRadixTile;
-    const uint32_t tpb = (tiles + gridDim.x - 1) / gridDim.x;
-    t0 = min(blockIdx.x * tpb, tiles);
-    t1 = min(t0 + tpb, tiles);
-}
-
-__global__ __launch_bounds__(kRadixThreads) void k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n_cap,
-                                                               const uint32_t* __restrict__ d_n, int shift,
-                                                               uint32_t* __restrict__ table) {
-    __shared__ uint32_t hist[256];
+// ---- histograms of every pass in one read of the keys ----
+template <int KEY_STRIDE /* 1: key array, 2: interleaved {key,value} pairs */>
+__global__ __launch_bounds__(kRadixThreads) void k_radix_global_hist(const uint32_t* __restrict__ keys, uint32_t n_cap,
+                                                                      const uint32_t* __restrict__ d_n, int passes,
+                                                                      uint32_t* __restrict__ ghist) {
+    __shared__ uint32_t hist[kMaxPasses][256];
     const uint32_t n = d_n ? min(*d_n, n_cap) : n_cap;
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    hist[tid] = 0;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    for (int p = 0; p < passes; ++p) hist[p][tid] = 0;
     __syncthreads();
-    uint32_t t0, t1;
-    radix_my_tiles(n, t0, t1);
-    for (uint32_t t = t0; t < t1; ++t) {
-        const uint32_t base = t * kRadixTile + wave * kWaveChunk;
-#pragma unroll 4
-        for (int r = 0; r < kRadixRounds; ++r) {
-            uint32_t e = base + r * 64 + lane;
-            bool valid = e < n;
-            uint32_t digit = valid ? (keys[e] >> shift) & 255u : 0u;
-            unsigned long long m = wave_match8(digit, valid);
-            // the lowest lane of every digit group adds the group's population
-            if (valid && (m & lanemask_lt()) == 0) atomicAdd(&hist[digit], (uint32_t)__popcll(m));
+    // wave-contiguous 64-element rounds, grid-strided
+    const uint32_t wave_global = blockIdx.x * kRadixWaves + (tid >> 6), waves_total = gridDim.x * kRadixWaves;
+    for (uint32_t base = wave_global * 64u; base < n; base += waves_total * 64u) {
+        const uint32_t e = base + lane;
+        const bool valid = e < n;
+        const uint32_t key = valid ? keys[(size_t)e * KEY_STRIDE] : 0u;
+        const unsigned long long vmask = __ballot(valid);
+        for (int p = 0; p < passes; ++p) {
+            const uint32_t digit = (key >> (8 * p)) & 255u;
+            // only counts are needed here: plain LDS atomics, except when the whole wave shares one digit
+            // (the exponent byte of depth keys), where 64 same-address atomics would serialise
+            const uint32_t first = __builtin_amdgcn_readfirstlane(digit);
+            if (__ballot(valid && digit != first) == 0) {
+                if (lane == (uint32_t)__ffsll((long long)vmask) - 1u) atomicAdd(&hist[p][first], (uint32_t)__popcll(vmask));
+            } else if (valid) {
+                atomicAdd(&hist[p][digit], 1u);
+            }
         }
     }
     __syncthreads();
-    table[tid * gridDim.x + blockIdx.x] = hist[tid];
+    for (int p = 0; p < passes; ++p)
+        if (hist[p][tid]) atomicAdd(&ghist[p * 256 + tid], hist[p][tid]);
 }
 
-// one workgroup per digit: exclusive scan of table[digit][0..nblocks) in place; total -> totals[digit]
+// one workgroup per row: exclusive scan of table[row][0..nblocks) in place; total -> totals[row]
+// (used by the multi-GPU pack, kernels_shard.hip)
 __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ table, uint32_t nblocks,
                                                         uint32_t* __restrict__ totals) {
     __shared__ uint32_t wsum[4];
@@ -94,7 +107,6 @@ __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ ta
     for (uint32_t base = 0; base < nblocks; base += 256) {
         uint32_t i = base + tid;
         uint32_t v = i < nblocks ? row[i] : 0u;
-        // inclusive wave scan
         uint32_t x = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -114,79 +126,173 @@ __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ ta
     if (tid == 0) totals[blockIdx.x] = carry_s;
 }
 
-template <bool IOTA>
-__global__ __launch_bounds__(kRadixThreads) void k_radix_scatter(const uint32_t* __restrict__ keys_in,
-                                                                  const uint32_t* __restrict__ vals_in,
-                                                                  uint32_t* __restrict__ keys_out,
-                                                                  uint32_t* __restrict__ vals_out, uint32_t n_cap,
-                                                                  const uint32_t* __restrict__ d_n, int shift,
-                                                                  const uint32_t* __restrict__ table,
-                                                                  const uint32_t* __restrict__ totals) {
-    __shared__ uint32_t cnt[kRadixWaves][256];  // per-wave digit counters, then absolute output offsets
-    __shared__ uint32_t wtot[4];
+// ---- one digit pass ----
+// IN : 0 = keys array, value = element index | 1 = split key / value arrays | 2 = interleaved pairs
+// OUT: 0 = interleaved pairs                 | 1 = split key / value arrays
+typedef unsigned long long u64;
+
+template <int IN, int OUT>
+__global__ __launch_bounds__(kRadixThreads) void k_radix_onesweep(const uint32_t* __restrict__ keys_in,
+                                                                   const uint32_t* __restrict__ vals_in,
+                                                                   const uint2* __restrict__ pairs_in,
+                                                                   uint32_t* __restrict__ keys_out,
+                                                                   uint32_t* __restrict__ vals_out,
+                                                                   uint2* __restrict__ pairs_out, uint32_t n_cap,
+                                                                   const uint32_t* __restrict__ d_n, int shift,
+                                                                   const uint32_t* __restrict__ ghist /* this pass */,
+                                                                   uint32_t* __restrict__ ticket /* [0] ticket, [1] finished */,
+                                                                   u64* __restrict__ status, uint32_t epoch) {
+    __shared__ uint2 s_pairs[kRadixTile];       // tile reordered by digit
+    __shared__ uint32_t cnt[kRadixWaves][256];  // per-wave digit counts, then per-wave local offsets
+    __shared__ uint32_t s_gbase[256];           // global slot of the tile's local slot 0, per digit
+    __shared__ uint32_t s_wtot[4];
+    __shared__ uint32_t s_tile;
+
     const uint32_t n = d_n ? min(*d_n, n_cap) : n_cap;
-    uint32_t t0, t1;
-    radix_my_tiles(n, t0, t1);
-    if (t0 >= t1) return;
+    const uint32_t n_tiles = (n + kRadixTile - 1) / kRadixTile;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    // thread = digit: running output offset of this digit for this workgroup
-    uint32_t run;
-    {   // exclusive scan of the 256 digit totals (each workgroup redoes this tiny scan)
-        uint32_t v = totals[tid], x = v;
+
+    // exclusive scan of this pass's global digit histogram: thread d -> first output slot of digit d
+    uint32_t dbase;
+    {
+        const uint32_t v = ghist[tid];
+        uint32_t x = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             uint32_t y = __shfl_up(x, o, 64);
             if (lane >= (uint32_t)o) x += y;
         }
-        if (lane == 63) wtot[wave] = x;
+        if (lane == 63) s_wtot[wave] = x;
         __syncthreads();
         uint32_t woff = 0;
-        for (uint32_t w = 0; w < wave; ++w) woff += wtot[w];
-        run = woff + x - v + table[tid * gridDim.x + blockIdx.x];
+        for (uint32_t w = 0; w < wave; ++w) woff += s_wtot[w];
+        dbase = woff + x - v;
+        __syncthreads();
     }
+
     volatile uint32_t* mycnt = cnt[wave];
-    for (uint32_t t = t0; t < t1; ++t) {
+    for (;;) {
+        // one tile per ticket: batching consecutive tiles would chain every workgroup behind the LAST tile
+        // of its predecessor and serialise the look-back
+        if (tid == 0) s_tile = atomicAdd(&ticket[0], 1u);
+        __syncthreads();
+        const uint32_t tile = s_tile;
+        if (tile >= n_tiles) break;
 #pragma unroll
         for (int w = 0; w < kRadixWaves; ++w) cnt[w][tid] = 0;
         __syncthreads();
-        const uint32_t base = t * kRadixTile + wave * kWaveChunk;
+
+        // load + stable ranks inside the wave's contiguous 1024-element chunk
+        const uint32_t base = tile * kRadixTile + wave * kWaveChunk;
         uint32_t key[kRadixRounds], val[kRadixRounds], rank[kRadixRounds];
 #pragma unroll
         for (int r = 0; r < kRadixRounds; ++r) {
-            uint32_t e = base + r * 64 + lane;
-            bool valid = e < n;
-            key[r] = valid ? keys_in[e] : 0xFFFFFFFFu;
-            val[r] = valid ? (IOTA ? e : vals_in[e]) : 0u;
-            uint32_t digit = (key[r] >> shift) & 255u;
-            unsigned long long m = wave_match8(digit, valid);
-            uint32_t before = (uint32_t)__popcll(m & lanemask_lt());
-            uint32_t old = valid ? mycnt[digit] : 0u;   // every lane of a digit group reads the same counter
+            const uint32_t e = base + r * 64 + lane;
+            const bool valid = e < n;
+            if (IN == 2) {
+                uint2 kv = valid ? pairs_in[e] : make_uint2(0xFFFFFFFFu, 0u);
+                key[r] = kv.x;
+                val[r] = kv.y;
+            } else {
+                key[r] = valid ? keys_in[e] : 0xFFFFFFFFu;
+                val[r] = valid ? (IN == 0 ? e : vals_in[e]) : 0u;
+            }
+            const uint32_t digit = (key[r] >> shift) & 255u;
+            const unsigned long long m = wave_match8(digit, valid);
+            const uint32_t before = (uint32_t)__popcll(m & lanemask_lt());
+            const uint32_t old = valid ? mycnt[digit] : 0u;  // every lane of a digit group reads the same counter
             rank[r] = old + before;
             __builtin_amdgcn_wave_barrier();
             if (valid && before == 0) mycnt[digit] = old + (uint32_t)__popcll(m);
             __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
-        {   // thread = digit: per-wave counts -> absolute output offsets; advance the running offset
+
+        // thread d: tile count of digit d, per-wave exclusive offsets, publish, look back
+        uint32_t tile_cnt = 0;
 #pragma unroll
-            for (int w = 0; w < kRadixWaves; ++w) {
-                uint32_t c = cnt[w][tid];
-                cnt[w][tid] = run;
-                run += c;
-            }
+        for (int w = 0; w < kRadixWaves; ++w) {
+            const uint32_t c = cnt[w][tid];
+            cnt[w][tid] = tile_cnt;  // exclusive offset of wave w inside digit d's run
+            tile_cnt += c;
         }
+        u64* my_status = status + ((size_t)tile * 256 + tid);
+        const u64 tag = (u64)epoch << 34;
+        __hip_atomic_store(my_status, tag | ((tile == 0 ? kFlagPrefix : kFlagAggregate) << 32) | (u64)tile_cnt,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // local exclusive scan over digits: first local slot of digit d in the reordered tile
+        uint32_t lstart;
+        {
+            uint32_t x = tile_cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                uint32_t y = __shfl_up(x, o, 64);
+                if (lane >= (uint32_t)o) x += y;
+            }
+            if (lane == 63) s_wtot[wave] = x;
+            __syncthreads();
+            uint32_t woff = 0;
+            for (uint32_t w = 0; w < wave; ++w) woff += s_wtot[w];
+            lstart = woff + x - tile_cnt;
+        }
+        uint32_t excl = 0;
+        if (tile > 0) {
+            int32_t k = (int32_t)tile - 1;
+            for (;;) {
+                const u64 s = __hip_atomic_load(status + ((size_t)k * 256 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t flag = (uint32_t)(s >> 32) & 3u;
+                if ((uint32_t)(s >> 34) != epoch || flag == 0) {  // not published yet in this launch
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                excl += (uint32_t)s;
+                if (flag == kFlagPrefix || k == 0) break;
+                --k;
+            }
+            __hip_atomic_store(my_status, tag | (kFlagPrefix << 32) | (u64)(excl + tile_cnt), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_gbase[tid] = dbase + excl - lstart;
+        // fold lstart into the per-wave offsets so that local slot = cnt[w][d] + rank
+#pragma unroll
+        for (int w = 0; w < kRadixWaves; ++w) cnt[w][tid] += lstart;
         __syncthreads();
+
+        // reorder the tile by digit in LDS
 #pragma unroll
         for (int r = 0; r < kRadixRounds; ++r) {
-            uint32_t e = base + r * 64 + lane;
+            const uint32_t e = base + r * 64 + lane;
             if (e < n) {
-                uint32_t digit = (key[r] >> shift) & 255u;
-                uint32_t o = cnt[wave][digit] + rank[r];
-                keys_out[o] = key[r];
-                vals_out[o] = val[r];
+                const uint32_t digit = (key[r] >> shift) & 255u;
+                s_pairs[cnt[wave][digit] + rank[r]] = make_uint2(key[r], val[r]);
             }
         }
         __syncthreads();
+        // write out: consecutive lanes -> consecutive addresses inside every digit run
+        const uint32_t tile_n = min((uint32_t)kRadixTile, n - tile * kRadixTile);
+#pragma unroll 4
+        for (int r = 0; r < kRadixRounds; ++r) {
+            const uint32_t slot = r * kRadixThreads + tid;
+            if (slot < tile_n) {
+                const uint2 kv = s_pairs[slot];
+                const uint32_t o = s_gbase[(kv.x >> shift) & 255u] + slot;
+                if (OUT == 0) {
+                    pairs_out[o] = kv;
+                } else {
+                    keys_out[o] = kv.x;
+                    vals_out[o] = kv.y;
+                }
+            }
+        }
+        __syncthreads();  // s_tile, cnt, s_pairs are reused by the next tile
+    }
+    // the last workgroup to leave re-arms the ticket for the next launch
+    if (tid == 0) {
+        const uint32_t fin = atomicAdd(&ticket[1], 1u);
+        if (fin == gridDim.x - 1) {
+            ticket[1] = 0;
+            __hip_atomic_store(&ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -195,30 +301,49 @@ hipError_t launch_rowscan(hipStream_t s, uint32_t* table, uint32_t nrows, uint32
     return hipGetLastError();
 }
 
+static uint32_t g_epoch = 1;  // distinguishes the status words of successive launches (any stream, any viewer)
+
 hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n, const uint32_t* d_n, int bits,
-                             bool iota_values, bool* result_in_b) {
-    *result_in_b = false;
+                             bool iota_values) {
     if (n == 0) return hipSuccess;
-    const uint32_t nb = std::min<uint32_t>(kRadixGrid, radix_blocks(n));
-    uint32_t* totals = buf.table + (size_t)256 * kRadixGrid;
     const int passes = (bits + 7) / 8;
-    const uint32_t *kin = buf.keys_src, *vin = buf.vals_src;
-    uint32_t *kout = buf.keys_a, *vout = buf.vals_a;
+    uint32_t* ghist = buf.workspace;
+    uint32_t* ticket = buf.workspace + 1024;
+    u64* status = reinterpret_cast<u64*>(buf.workspace + 1032);
+    const uint32_t tiles = radix_tiles(n);
+    static const uint32_t grid_limit = getenv("GSX_RADIX_GRID") ? (uint32_t)atoi(getenv("GSX_RADIX_GRID")) : kRadixGrid;
+    const uint32_t grid = std::min<uint32_t>(grid_limit, tiles);
+    hipError_t e = hipMemsetAsync(ghist, 0, sizeof(uint32_t) * 256 * passes, s);
+    if (e != hipSuccess) return e;
+    const uint32_t hgrid = std::min<uint32_t>(kRadixGrid, (tiles + 3) / 4);
+    if (buf.pairs_src)
+        hipLaunchKernelGGL(k_radix_global_hist<2>, dim3(hgrid), dim3(kRadixThreads), 0, s,
+                           reinterpret_cast<const uint32_t*>(buf.pairs_src), n, d_n, passes, ghist);
+    else
+        hipLaunchKernelGGL(k_radix_global_hist<1>, dim3(hgrid), dim3(kRadixThreads), 0, s, buf.keys_src, n, d_n, passes, ghist);
+    const uint2* pin = buf.pairs_src;
+    uint2* pout = buf.pairs_a;
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
-        hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(kRadixThreads), 0, s, kin, n, d_n, shift, buf.table);
-        hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(256), 0, s, buf.table, nb, totals);
-        if (p == 0 && iota_values)
-            hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nb), dim3(kRadixThreads), 0, s, kin, vin, kout, vout, n, d_n,
-                               shift, buf.table, totals);
-        else
-            hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nb), dim3(kRadixThreads), 0, s, kin, vin, kout, vout, n, d_n,
-                               shift, buf.table, totals);
-        *result_in_b = (kout == buf.keys_b);
-        kin = kout;
-        vin = vout;
-        kout = *result_in_b ? buf.keys_a : buf.keys_b;
-        vout = *result_in_b ? buf.vals_a : buf.vals_b;
+        const bool first = p == 0, last = p == passes - 1;
+        const uint32_t epoch = (g_epoch++ & 0x1FFFFFFFu) | (1u << 29);  // 30 bits, never 0
+#define GSX_SWEEP(IN, OUT)                                                                                              \
+    hipLaunchKernelGGL((k_radix_onesweep<IN, OUT>), dim3(grid), dim3(kRadixThreads), 0, s, buf.keys_src, buf.vals_src, pin, \
+                       buf.keys_out, buf.vals_out, pout, n, d_n, shift, ghist + 256 * p, ticket, status, epoch)
+        if (first && buf.pairs_src) {
+            if (last) GSX_SWEEP(2, 1); else GSX_SWEEP(2, 0);
+        } else if (first && last) {
+            if (iota_values) GSX_SWEEP(0, 1); else GSX_SWEEP(1, 1);
+        } else if (first) {
+            if (iota_values) GSX_SWEEP(0, 0); else GSX_SWEEP(1, 0);
+        } else if (last) {
+            GSX_SWEEP(2, 1);
+        } else {
+            GSX_SWEEP(2, 0);
+        }
+#undef GSX_SWEEP
+        pin = pout;
+        pout = (pout == buf.pairs_a) ? buf.pairs_b : buf.pairs_a;
     }
     return hipGetLastError();
 }
