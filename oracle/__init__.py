@@ -61,6 +61,8 @@ def lib():
         L.gsxo_frame_setup.restype = None
         L.gsxo_convert.argtypes = [vp, C.c_uint64, fp, u32p, fp, fp]
         L.gsxo_convert.restype = None
+        L.gsxo_quantize_roundtrip.argtypes = [C.c_int, C.c_int, C.c_uint64, fp, fp]
+        L.gsxo_quantize_roundtrip.restype = None
         L.gsxo_project.argtypes = [C.POINTER(Frame), C.c_uint64, fp, u32p, fp, fp, u32p, u32p, u32p, fp, fp, fp]
         L.gsxo_project.restype = C.c_uint64
         L.gsxo_depth_sort.argtypes = [C.c_uint64, u32p, u32p]
@@ -114,6 +116,14 @@ def convert(gaussians: np.ndarray):
     sh = np.empty((n, 45), np.float32)
     cov = np.empty((n, 6), np.float32)
     lib().gsxo_convert(g.ctypes.data_as(C.c_void_p), n, _fp(pos), _up(color), _fp(sh), _fp(cov))
+    return pos, color, sh, cov
+
+
+def convert_pod(gaussians: np.ndarray, sh_kind: int = 0, cov_kind: int = 0):
+    """Pod as the GPU computes with it: ``convert`` followed by the quantise -> dequantise round trip of the
+    compressed pod kinds (gsx_sh_kind: 0 Single, 1 Half, 2 Norm8, 3 None; gsx_cov3d_kind: 0 Single, 1 Half)."""
+    pos, color, sh, cov = convert(gaussians)
+    lib().gsxo_quantize_roundtrip(int(sh_kind), int(cov_kind), pos.shape[0], _fp(sh), _fp(cov))
     return pos, color, sh, cov
 
 

@@ -150,6 +150,67 @@ void gsxo_convert(const gsx_gaussian* g, uint64_t n, float* pos, uint32_t* color
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * Compressed pods (the reference's Sh{Half,Norm8} / Cov3d Half configs, app.rs:386-418): what the GPU
+ * stores is a quantised value and what it computes with is the exact dequantisation, so the oracle
+ * round-trips the float pod in place and then runs the ordinary float path.  spec §2b.
+ *   f16    : IEEE binary16, round to nearest even, overflow to infinity, subnormals kept.
+ *   snorm8 : q = floor(clamp(v,-1,1)*127 + 0.5) as int8, decode max(q/127, -1)  (WGSL unpack4x8snorm).
+ * ---------------------------------------------------------------------------------------------- */
+static uint16_t f32_to_f16_rne(float f) {
+    union { float f; uint32_t u; } v;
+    v.f = f;
+    uint32_t x = v.u, sign = (x >> 16) & 0x8000u, mant = x & 0x7FFFFFu;
+    int32_t e = (int32_t)((x >> 23) & 0xFF);
+    if (e == 255) return (uint16_t)(sign | 0x7C00u | (mant ? 0x200u : 0));
+    int32_t he = e - 127 + 15;
+    if (he >= 31) return (uint16_t)(sign | 0x7C00u);
+    if (he <= 0) {
+        if (he < -10) return (uint16_t)sign;
+        mant |= 0x800000u;
+        uint32_t shift = (uint32_t)(14 - he);
+        uint32_t hm = mant >> shift, rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (hm & 1u))) hm++;
+        return (uint16_t)(sign | hm);
+    }
+    uint32_t hm = mant >> 13, rem = mant & 0x1FFFu;
+    uint32_t h = (uint32_t)(he << 10) | hm;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+    return (uint16_t)(sign | h);
+}
+
+static float f16_to_f32(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3FFu;
+    union { float f; uint32_t u; } v;
+    if (e == 0) {
+        if (m == 0) { v.u = sign; return v.f; }
+        float r = (float)m * (1.0f / 16777216.0f); /* m * 2^-24 */
+        return sign ? -r : r;
+    }
+    if (e == 31) { v.u = sign | 0x7F800000u | (m << 13); return v.f; }
+    v.u = sign | ((e - 15 + 127) << 23) | (m << 13);
+    return v.f;
+}
+
+static float snorm8_roundtrip(float x) {
+    float c = fminf(fmaxf(x, -1.0f), 1.0f);
+    int q = (int)floorf(c * 127.0f + 0.5f);
+    return fmaxf((float)(signed char)q * (1.0f / 127.0f), -1.0f);
+}
+
+/* in place: sh (45 floats per Gaussian, may be NULL) and cov3d (6 floats per Gaussian) become what the GPU
+ * dequantises from a pod of the given kinds */
+void gsxo_quantize_roundtrip(int sh_kind, int cov_kind, uint64_t n, float* sh, float* cov3d) {
+    if (sh && sh_kind == GSX_SH_HALF)
+        for (uint64_t i = 0; i < 45 * n; ++i) sh[i] = f16_to_f32(f32_to_f16_rne(sh[i]));
+    if (sh && sh_kind == GSX_SH_NORM8)
+        for (uint64_t i = 0; i < 45 * n; ++i) sh[i] = snorm8_roundtrip(sh[i]);
+    if (sh && sh_kind == GSX_SH_NONE)
+        for (uint64_t i = 0; i < 45 * n; ++i) sh[i] = 0.0f;
+    if (cov_kind == GSX_COV3D_HALF)
+        for (uint64_t i = 0; i < 6 * n; ++i) cov3d[i] = f16_to_f32(f32_to_f16_rne(cov3d[i]));
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Projection of one Gaussian.  spec §4.  Returns 1 if visible.
  * ---------------------------------------------------------------------------------------------- */
 static const float SH_C1 = 0.4886025119029199f;

@@ -113,15 +113,16 @@ class OracleStages:
                 strip[r, : y1 - y0] = self._fb[y0:y1]
         return torch.from_numpy(strip.reshape(-1))
 
-    def gather_buffers(self, strip, world):
-        return [torch.empty_like(strip) for _ in range(world)]
+    def gather_buffer(self, strip, world):
+        return torch.empty(world * strip.numel(), dtype=strip.dtype)
 
-    def assemble(self, parts, world):
+    def assemble(self, gathered, world):
         w, h = self.size
         rpr = self._rows_per_rank(world)
         fb = np.zeros((h, w, 4), np.float32)
+        parts = gathered.numpy().reshape(world, -1)
         for g, p in enumerate(parts):
-            s = p.numpy().reshape(rpr, 16, w, 4)
+            s = p.reshape(rpr, 16, w, 4)
             for r in range(rpr):
                 ty = g + r * world
                 y0, y1 = ty * 16, min(ty * 16 + 16, h)

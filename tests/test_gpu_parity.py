@@ -313,3 +313,37 @@ def test_progressive_slabs_small(divisor, growth):
     assert np.array_equal(full, slab)
     assert d_slab <= d_full
     assert np.abs(full - fb_ref).max() <= 2e-4
+
+
+@pytest.mark.parametrize("sh_kind,cov_kind", [(0, 1), (1, 0), (1, 1), (2, 0), (2, 1), (3, 1)])
+def test_compressed_pods(sh_kind, cov_kind):
+    """The reference's 8-way pod choice (scene.rs:23-81; app default Norm8 + Half, app.rs:398-417): quantised
+    storage, exact dequantisation in the projection kernel -> same bit-exact integer parity as the f32 pod."""
+    from wgpu_3dgs_viewer_app_amd.viewer import Cov3dKind
+
+    n, w, h = 5000, 192, 128
+    g = common.small_scene(n, 121)
+    g["sh"] *= np.float32(4.0)  # push some coefficients past the snorm8 range
+    cam = camera.orbit_pose(201)
+    mt = common.odd_transform()
+    pos, color, sh, cov = oracle.convert_pod(g, sh_kind, cov_kind)
+    f = common.oracle_frame(cam, w, h, mt)
+    pr = oracle.project(f, pos, color, None if sh_kind == 3 else sh, cov)
+    idx, nvis = oracle.depth_sort(pr["key"])
+    fb_ref = oracle.new_framebuffer(f)
+    oracle.rasterize(f, pr, idx, nvis, fb_ref)
+    with MultiModelViewer(sh=ShKind(sh_kind), cov3d=Cov3dKind(cov_kind)) as v:
+        run_gpu_model(v, "m", g, cam, w, h, mt)
+        dpos, dcolor, dsh, dcov = v.models["m"].gaussian_buffers.gaussians_buffer.download_pod()
+        assert np.array_equal(dpos, pos) and np.array_equal(dcolor, color)
+        assert np.array_equal(dcov, cov), "cov3d quantisation differs"
+        assert np.array_equal(dsh, sh), "SH quantisation differs"
+        assert_projection_equal(v.download_projection("m"), pr)
+        assert np.array_equal(v.download_sorted("m"), idx[:nvis])
+        v.renderer.render(["m"])
+        fb = v.download_framebuffer()
+    # early termination leaves at most t_epsilon * (largest colour) behind; the scaled SH make colours > 1 here
+    assert np.abs(fb - fb_ref).max() <= 2e-4 * max(1.0, float(pr["rgb"].max()))
+    if sh_kind == 1 and cov_kind == 0:  # f16 SH alone keeps the frame close to full precision
+        full = common.oracle_model_frame(g, cam, w, h, mt)[4]
+        assert np.abs(fb_ref - full).max() <= 0.01

@@ -76,10 +76,9 @@ def test_emulated_world_matches_single_viewer(world):
 
     st0 = stages[0]
     with st0.stream_ctx():
-        parts = st0.gather_buffers(strips[0], world)
-        for p, s in zip(parts, strips):
-            p.copy_(s)
-        st0.assemble(parts, world)
+        gathered = st0.gather_buffer(strips[0], world)
+        gathered.view(world, -1).copy_(torch.stack(strips))
+        st0.assemble(gathered, world)
         st0.poll()
     fb = st0.framebuffer()
     for st in stages:

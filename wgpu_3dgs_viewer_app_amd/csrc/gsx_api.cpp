@@ -76,7 +76,7 @@ struct Model {
     ModelTransform mt;
     FrameConsts fc{};
 
-    DevBuf pc, cov_a, cov_b, sh4, sh1, mask;
+    DevBuf pc, cov_a, cov_b, sh4, sh1, sh_h, sh_q, cov_h, cov_h2, mask;
     DevBuf key_buf, rec_a, rec_b, rec_c;
     DevBuf dp_a, dp_b, sk_out, sv_out, sort_ws; // depth sort: pair scratch, sorted keys / indices, workspace
     DevBuf cnt, block_sums, srect;              // per slab: tile counts in depth order, scan partials, tile rects
@@ -113,6 +113,12 @@ struct Model {
         p.cov_b = cov_b.as<float2>();
         p.sh4 = sh4.as<float4>();
         p.sh1 = sh1.as<float>();
+        p.sh_h = sh_h.as<uint4>();
+        p.sh_q = sh_q.as<uint4>();
+        p.cov_h = cov_h.as<uint2>();
+        p.cov_h2 = cov_h2.as<uint32_t>();
+        p.sh_kind = (int)sh_kind;
+        p.cov_kind = (int)cov_kind;
         p.mask = has_mask ? mask.as<uint32_t>() : nullptr;
         return p;
     }
@@ -283,7 +289,7 @@ static gsx_status do_preprocess(gsx_viewer* v, Model* m) {
     m->row_rank = 0;
     {
         ScopedPass t(v, GSX_PASS_PROJECT);  // brackets the projection kernel alone (bench.py's roofline kernel)
-        HIPCHK(launch_project(v->stream, m->fc, (uint32_t)m->n, m->pod(), m->has_sh, m->rec(), m->block_vis.as<uint32_t>()));
+        HIPCHK(launch_project(v->stream, m->fc, (uint32_t)m->n, m->pod(), m->rec(), m->block_vis.as<uint32_t>()));
         v->pass_launches[GSX_PASS_PROJECT] += m->n ? 1 : 0;
     }
     HIPCHK(launch_sum_counts(v->stream, m->block_vis.as<uint32_t>(), (uint32_t)m->n, &m->counters.as<Counters>()->n_visible));
@@ -570,8 +576,8 @@ gsx_status gsx_model_create(gsx_viewer* v, const char* key, uint64_t count, gsx_
     if (!key) return fail(GSX_ERR_INVALID_ARG, "gsx_model_create: key is null");
     if (count >= 0xFFFFFFF0ull) return fail(GSX_ERR_INVALID_ARG, "gsx_model_create: count %llu too large", (unsigned long long)count);
     if (v->models.count(key)) return fail(GSX_ERR_INVALID_ARG, "gsx_model_create: model '%s' exists", key);
-    if (!((sh == GSX_SH_SINGLE || sh == GSX_SH_NONE) && cov3d == GSX_COV3D_SINGLE))
-        return fail(GSX_ERR_UNSUPPORTED, "gsx_model_create: pod Sh%d/Cov3d%d not implemented yet (Single/None x Single only)", (int)sh, (int)cov3d);
+    if ((int)sh < 0 || (int)sh > GSX_SH_NONE || (int)cov3d < 0 || (int)cov3d > GSX_COV3D_HALF)
+        return fail(GSX_ERR_INVALID_ARG, "gsx_model_create: unknown pod kind Sh%d/Cov3d%d", (int)sh, (int)cov3d);
     std::unique_ptr<Model> m(new Model());
     m->key = key;
     m->n = count;
@@ -580,11 +586,20 @@ gsx_status gsx_model_create(gsx_viewer* v, const char* key, uint64_t count, gsx_
     m->has_sh = sh != GSX_SH_NONE;
     const size_t n = std::max<uint64_t>(count, 1);
     HIPCHK(m->pc.ensure(16 * n));
-    HIPCHK(m->cov_a.ensure(16 * n));
-    HIPCHK(m->cov_b.ensure(8 * n));
-    if (m->has_sh) {
+    if (cov3d == GSX_COV3D_SINGLE) {
+        HIPCHK(m->cov_a.ensure(16 * n));
+        HIPCHK(m->cov_b.ensure(8 * n));
+    } else {
+        HIPCHK(m->cov_h.ensure(8 * n));
+        HIPCHK(m->cov_h2.ensure(4 * n));
+    }
+    if (sh == GSX_SH_SINGLE) {
         HIPCHK(m->sh4.ensure(16 * n * kShPlanes4));
         HIPCHK(m->sh1.ensure(4 * n));
+    } else if (sh == GSX_SH_HALF) {
+        HIPCHK(m->sh_h.ensure(16 * n * 6));
+    } else if (sh == GSX_SH_NORM8) {
+        HIPCHK(m->sh_q.ensure(16 * n * 3));
     }
     HIPCHK(m->mask.ensure(4 * ((n + 31) / 32)));
     {
@@ -595,13 +610,8 @@ gsx_status gsx_model_create(gsx_viewer* v, const char* key, uint64_t count, gsx_
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&m->h_counters), sizeof(Counters), hipHostMallocDefault));
     HIPCHK(hipMemsetAsync(m->counters.p, 0, sizeof(Counters), v->stream));
     // a fresh model is all-zero Gaussians (new_empty) and fully unmasked (MaskOpTree::Reset, scene.rs:2124-2131)
-    HIPCHK(hipMemsetAsync(m->pc.p, 0, 16 * n, v->stream));
-    HIPCHK(hipMemsetAsync(m->cov_a.p, 0, 16 * n, v->stream));
-    HIPCHK(hipMemsetAsync(m->cov_b.p, 0, 8 * n, v->stream));
-    if (m->has_sh) {
-        HIPCHK(hipMemsetAsync(m->sh4.p, 0, 16 * n * kShPlanes4, v->stream));
-        HIPCHK(hipMemsetAsync(m->sh1.p, 0, 4 * n, v->stream));
-    }
+    for (DevBuf* b : {&m->pc, &m->cov_a, &m->cov_b, &m->cov_h, &m->cov_h2, &m->sh4, &m->sh1, &m->sh_h, &m->sh_q})
+        if (b->p) HIPCHK(hipMemsetAsync(b->p, 0, b->bytes, v->stream));
     v->models[key] = std::move(m);
     return GSX_OK;
 }
@@ -639,7 +649,7 @@ gsx_status gsx_model_upload_range(gsx_viewer* v, const char* key, uint64_t start
         uint64_t c = std::min(chunk, n - off);
         HIPCHK(v->staging.ensure(sizeof(gsx_gaussian) * c));
         HIPCHK(hipMemcpyAsync(v->staging.p, src + off, sizeof(gsx_gaussian) * c, hipMemcpyHostToDevice, v->stream));
-        HIPCHK(launch_convert(v->stream, v->staging.as<gsx_gaussian>(), c, start + off, m->n, m->pod(), m->has_sh));
+        HIPCHK(launch_convert(v->stream, v->staging.as<gsx_gaussian>(), c, start + off, m->n, m->pod()));
         HIPCHK(hipStreamSynchronize(v->stream));  // the caller's memory may be reused after return
     }
     return GSX_OK;
@@ -925,7 +935,7 @@ gsx_status gsx_model_download_pod(gsx_viewer* v, const char* key, float* pos, ui
     HIPCHK(dcov.ensure(24 * n));
     if (sh) HIPCHK(dsh.ensure(180 * n));
     HIPCHK(launch_unpack_pod(v->stream, m->pod(), n, dpos.as<float>(), dcol.as<uint32_t>(), sh ? dsh.as<float>() : nullptr,
-                             dcov.as<float>(), m->has_sh));
+                             dcov.as<float>()));
     HIPCHK(hipStreamSynchronize(v->stream));
     HIPCHK(hipMemcpy(pos, dpos.p, 12 * n, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(color, dcol.p, 4 * n, hipMemcpyDeviceToHost));

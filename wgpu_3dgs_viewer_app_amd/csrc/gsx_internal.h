@@ -39,13 +39,24 @@ void frame_consts_setup(const float view[16], const float proj[16], uint32_t wid
                         const gsx_spec_params& sp, FrameConsts* out);
 
 // Resident pod planes of one model (SoA, every plane contiguous over the model's N Gaussians).
+// The reference's 8-way pod choice (scene.rs:23-81) selects which SH / cov3d planes exist:
+//   Sh Single : sh4 (11 float4 planes) + sh1          180 B     Cov3d Single: cov_a (float4) + cov_b (float2)  24 B
+//   Sh Half   : sh_h (6 uint4 planes = 48 f16, 3 pad)   96 B     Cov3d Half  : cov_h (uint2 = 4 f16) + cov_h2 (u32 = 2 f16)  12 B
+//   Sh Norm8  : sh_q (3 uint4 planes = 48 snorm8, 3 pad) 48 B
+//   Sh None   : nothing
 struct PodPlanes {
     float4* pc;      // N   : x, y, z, bitcast(rgba8)
     float4* cov_a;   // N   : xx, xy, xz, yy
     float2* cov_b;   // N   : yz, zz
     float4* sh4;     // 11*N: plane p holds SH floats 4p..4p+3 of every Gaussian (float index = 3*coeff + channel)
     float* sh1;      // N   : SH float 44
+    uint4* sh_h;     // 6*N : plane p holds SH floats 8p..8p+7 as f16
+    uint4* sh_q;     // 3*N : plane p holds SH floats 16p..16p+15 as snorm8
+    uint2* cov_h;    // N   : xx, xy, xz, yy as f16
+    uint32_t* cov_h2;  // N : yz, zz as f16
     uint32_t* mask;  // ceil(N/32) words, bit = keep (nullptr: keep all)
+    int sh_kind;     // gsx_sh_kind
+    int cov_kind;    // gsx_cov3d_kind
 };
 
 // Projected records of one model for the current frame (valid where key != kCulledKey).
@@ -58,15 +69,15 @@ struct Records {
 
 // ---- launch wrappers (one per kernel family); all enqueue on `s` and return the launch status ----
 hipError_t launch_convert(hipStream_t s, const gsx_gaussian* d_src, uint64_t n, uint64_t start, uint64_t model_n,
-                          const PodPlanes& pod, bool has_sh);
+                          const PodPlanes& pod);
 hipError_t launch_pack_pod(hipStream_t s, const float* d_pos, const uint32_t* d_color, const float* d_sh,
                            const float* d_cov, uint64_t n, uint64_t start, uint64_t model_n, const PodPlanes& pod);
 hipError_t launch_unpack_pod(hipStream_t s, const PodPlanes& pod, uint64_t model_n, float* d_pos, uint32_t* d_color,
-                             float* d_sh, float* d_cov, bool has_sh);
+                             float* d_sh, float* d_cov);
 // d_block_visible: one count per 256-Gaussian workgroup (project_blocks(n) entries); launch_sum_counts
 // reduces them into *d_n_visible.
-hipError_t launch_project(hipStream_t s, const FrameConsts& f, uint32_t n, const PodPlanes& pod, bool has_sh,
-                          const Records& rec, uint32_t* d_block_visible);
+hipError_t launch_project(hipStream_t s, const FrameConsts& f, uint32_t n, const PodPlanes& pod, const Records& rec,
+                          uint32_t* d_block_visible);
 hipError_t launch_sum_counts(hipStream_t s, const uint32_t* d_block_visible, uint32_t n, uint32_t* d_n_visible);
 size_t project_blocks(uint64_t n);
 

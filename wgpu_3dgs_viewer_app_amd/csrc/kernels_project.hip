@@ -9,6 +9,8 @@
 //
 // Built with -ffp-contract=off: every operation that feeds an integer decision (cull, tile rectangle)
 // is written in the exact order of spec/RENDER_SPEC.md §4 so the CPU oracle reproduces it bit-for-bit.
+#include <hip/hip_fp16.h>
+
 #include "gsx_internal.h"
 #include "project_math.h"
 
@@ -84,15 +86,106 @@ __device__ inline float ddot3(float a0, float a1, float a2, float b0, float b1, 
     return (a0 * b0 + a1 * b1) + a2 * b2;
 }
 
-__device__ inline void store_sh_planes(const PodPlanes& pod, uint64_t model_n, uint64_t i, const float* s45) {
+// ---- quantisation (spec/RENDER_SPEC.md §2b) ----
+// f16: IEEE binary16, round to nearest even (what `half::f16::from_f32` does; v_cvt_f16_f32).
+// snorm8: q = floor(clamp(v,-1,1) * 127 + 0.5) as int8; decode = max(q / 127, -1) (WGSL unpack4x8snorm).
+__device__ inline uint32_t pack_h2(float a, float b) {
+    return (uint32_t)__half_as_ushort(__float2half_rn(a)) | ((uint32_t)__half_as_ushort(__float2half_rn(b)) << 16);
+}
+__device__ inline float h_lo(uint32_t u) { return __half2float(__ushort_as_half((unsigned short)(u & 0xFFFFu))); }
+__device__ inline float h_hi(uint32_t u) { return __half2float(__ushort_as_half((unsigned short)(u >> 16))); }
+__device__ inline uint32_t q_snorm8(float v) {
+    float c = fminf(fmaxf(v, -1.0f), 1.0f);
+    return (uint32_t)(int)floorf(c * 127.0f + 0.5f) & 0xFFu;
+}
+__device__ inline float dq_snorm8(uint32_t word, int byte) {
+    int q = (int)(signed char)((word >> (8 * byte)) & 0xFFu);
+    return fmaxf((float)q * (1.0f / 127.0f), -1.0f);
+}
+
+__device__ inline void store_sh(const PodPlanes& pod, uint64_t model_n, uint64_t i, const float* s45) {
+    if (pod.sh_kind == GSX_SH_SINGLE) {
 #pragma unroll
-    for (int p = 0; p < kShPlanes4; ++p)
-        pod.sh4[(uint64_t)p * model_n + i] = make_float4(s45[4 * p], s45[4 * p + 1], s45[4 * p + 2], s45[4 * p + 3]);
-    pod.sh1[i] = s45[44];
+        for (int p = 0; p < kShPlanes4; ++p)
+            pod.sh4[(uint64_t)p * model_n + i] = make_float4(s45[4 * p], s45[4 * p + 1], s45[4 * p + 2], s45[4 * p + 3]);
+        pod.sh1[i] = s45[44];
+    } else if (pod.sh_kind == GSX_SH_HALF) {
+        for (int p = 0; p < 6; ++p) {
+            uint32_t w[4];
+            for (int k = 0; k < 4; ++k) {
+                int f0 = 8 * p + 2 * k, f1 = f0 + 1;
+                w[k] = pack_h2(f0 < 45 ? s45[f0] : 0.0f, f1 < 45 ? s45[f1] : 0.0f);
+            }
+            pod.sh_h[(uint64_t)p * model_n + i] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    } else if (pod.sh_kind == GSX_SH_NORM8) {
+        for (int p = 0; p < 3; ++p) {
+            uint32_t w[4];
+            for (int k = 0; k < 4; ++k) {
+                uint32_t v = 0;
+                for (int b = 0; b < 4; ++b) {
+                    int f = 16 * p + 4 * k + b;
+                    v |= (f < 45 ? q_snorm8(s45[f]) : 0u) << (8 * b);
+                }
+                w[k] = v;
+            }
+            pod.sh_q[(uint64_t)p * model_n + i] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+}
+
+__device__ inline void store_cov(const PodPlanes& pod, uint64_t i, float c0, float c1, float c2, float c3, float c4, float c5) {
+    if (pod.cov_kind == GSX_COV3D_SINGLE) {
+        pod.cov_a[i] = make_float4(c0, c1, c2, c3);
+        pod.cov_b[i] = make_float2(c4, c5);
+    } else {
+        pod.cov_h[i] = make_uint2(pack_h2(c0, c1), pack_h2(c2, c3));
+        pod.cov_h2[i] = pack_h2(c4, c5);
+    }
+}
+
+// dequantised SH floats [0, 48) of Gaussian i (zero when the pod has no SH)
+__device__ inline void load_sh_dq(const PodPlanes& pod, uint64_t model_n, uint64_t i, float* s48) {
+    for (int f = 0; f < 48; ++f) s48[f] = 0.0f;
+    if (pod.sh_kind == GSX_SH_SINGLE) {
+        for (int p = 0; p < kShPlanes4; ++p) {
+            float4 v = pod.sh4[(uint64_t)p * model_n + i];
+            s48[4 * p] = v.x; s48[4 * p + 1] = v.y; s48[4 * p + 2] = v.z; s48[4 * p + 3] = v.w;
+        }
+        s48[44] = pod.sh1[i];
+    } else if (pod.sh_kind == GSX_SH_HALF) {
+        for (int p = 0; p < 6; ++p) {
+            uint4 v = pod.sh_h[(uint64_t)p * model_n + i];
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            for (int k = 0; k < 4; ++k) {
+                s48[8 * p + 2 * k] = h_lo(w[k]);
+                s48[8 * p + 2 * k + 1] = h_hi(w[k]);
+            }
+        }
+    } else if (pod.sh_kind == GSX_SH_NORM8) {
+        for (int p = 0; p < 3; ++p) {
+            uint4 v = pod.sh_q[(uint64_t)p * model_n + i];
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            for (int k = 0; k < 4; ++k)
+                for (int b = 0; b < 4; ++b) s48[16 * p + 4 * k + b] = dq_snorm8(w[k], b);
+        }
+    }
+}
+
+__device__ inline void load_cov_dq(const PodPlanes& pod, uint64_t i, float* c6) {
+    if (pod.cov_kind == GSX_COV3D_SINGLE) {
+        float4 a = pod.cov_a[i];
+        float2 b = pod.cov_b[i];
+        c6[0] = a.x; c6[1] = a.y; c6[2] = a.z; c6[3] = a.w; c6[4] = b.x; c6[5] = b.y;
+    } else {
+        uint2 a = pod.cov_h[i];
+        uint32_t b = pod.cov_h2[i];
+        c6[0] = h_lo(a.x); c6[1] = h_hi(a.x); c6[2] = h_lo(a.y); c6[3] = h_hi(a.y); c6[4] = h_lo(b); c6[5] = h_hi(b);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_convert(const gsx_gaussian* __restrict__ src, uint64_t n, uint64_t start,
-                                                  uint64_t model_n, PodPlanes pod, int has_sh) {
+                                                  uint64_t model_n, PodPlanes pod) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const gsx_gaussian& g = src[t];
@@ -118,9 +211,8 @@ __global__ __launch_bounds__(256) void k_convert(const gsx_gaussian* __restrict_
     uint32_t col = (uint32_t)g.color[0] | ((uint32_t)g.color[1] << 8) | ((uint32_t)g.color[2] << 16) |
                    ((uint32_t)g.color[3] << 24);
     pod.pc[i] = make_float4(g.pos[0], g.pos[1], g.pos[2], __uint_as_float(col));
-    pod.cov_a[i] = make_float4(c0, c1, c2, c3);
-    pod.cov_b[i] = make_float2(c4, c5);
-    if (has_sh) store_sh_planes(pod, model_n, i, &g.sh[0][0]);
+    store_cov(pod, i, c0, c1, c2, c3, c4, c5);
+    store_sh(pod, model_n, i, &g.sh[0][0]);
 }
 
 // pod-ready planes (pos 3n, color n, sh 45n, cov 6n) -> resident float4 planes, and back (parity readback).
@@ -131,29 +223,26 @@ __global__ __launch_bounds__(256) void k_pack_pod(const float* __restrict__ pos,
     if (t >= n) return;
     uint64_t i = start + t;
     pod.pc[i] = make_float4(pos[3 * t], pos[3 * t + 1], pos[3 * t + 2], __uint_as_float(color[t]));
-    pod.cov_a[i] = make_float4(cov[6 * t], cov[6 * t + 1], cov[6 * t + 2], cov[6 * t + 3]);
-    pod.cov_b[i] = make_float2(cov[6 * t + 4], cov[6 * t + 5]);
-    if (sh) store_sh_planes(pod, model_n, i, sh + 45 * t);
+    store_cov(pod, i, cov[6 * t], cov[6 * t + 1], cov[6 * t + 2], cov[6 * t + 3], cov[6 * t + 4], cov[6 * t + 5]);
+    if (sh) store_sh(pod, model_n, i, sh + 45 * t);
 }
 
+// parity readback: the pod as the kernels see it, i.e. AFTER dequantisation
 __global__ __launch_bounds__(256) void k_unpack_pod(PodPlanes pod, uint64_t model_n, float* __restrict__ pos,
                                                      uint32_t* __restrict__ color, float* __restrict__ sh,
-                                                     float* __restrict__ cov, int has_sh) {
+                                                     float* __restrict__ cov) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= model_n) return;
     float4 pc = pod.pc[i];
-    float4 ca = pod.cov_a[i];
-    float2 cb = pod.cov_b[i];
     pos[3 * i] = pc.x; pos[3 * i + 1] = pc.y; pos[3 * i + 2] = pc.z;
     color[i] = __float_as_uint(pc.w);
-    cov[6 * i] = ca.x; cov[6 * i + 1] = ca.y; cov[6 * i + 2] = ca.z; cov[6 * i + 3] = ca.w;
-    cov[6 * i + 4] = cb.x; cov[6 * i + 5] = cb.y;
+    float c6[6];
+    load_cov_dq(pod, i, c6);
+    for (int k = 0; k < 6; ++k) cov[6 * i + k] = c6[k];
     if (sh) {
-        for (int p = 0; p < kShPlanes4; ++p) {
-            float4 v = has_sh ? pod.sh4[(uint64_t)p * model_n + i] : make_float4(0, 0, 0, 0);
-            sh[45 * i + 4 * p] = v.x; sh[45 * i + 4 * p + 1] = v.y; sh[45 * i + 4 * p + 2] = v.z; sh[45 * i + 4 * p + 3] = v.w;
-        }
-        sh[45 * i + 44] = has_sh ? pod.sh1[i] : 0.0f;
+        float s48[48];
+        load_sh_dq(pod, model_n, i, s48);
+        for (int k = 0; k < 45; ++k) sh[45 * i + k] = s48[k];
     }
 }
 
@@ -180,7 +269,22 @@ __device__ inline float2 ld_stream(const float2* p) {
 }
 __device__ inline float ld_stream(const float* p) { return __builtin_nontemporal_load(p); }
 
-template <int DEG>
+__device__ inline uint4 ld_stream(const uint4* p) {
+    typedef unsigned gsx_u4v __attribute__((ext_vector_type(4)));
+    gsx_u4v v = __builtin_nontemporal_load(reinterpret_cast<const gsx_u4v*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ inline uint2 ld_stream(const uint2* p) {
+    typedef unsigned gsx_u2v __attribute__((ext_vector_type(2)));
+    gsx_u2v v = __builtin_nontemporal_load(reinterpret_cast<const gsx_u2v*>(p));
+    return make_uint2(v.x, v.y);
+}
+__device__ inline uint32_t ld_stream(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+
+// SHK / COVK: storage of the SH and cov3d planes (gsx_sh_kind / gsx_cov3d_kind); dequantisation is exact
+// (f16 -> f32, snorm8 -> f32), so cull set and tile rectangles stay bit-exact against the oracle, which
+// projects the dequantised pod.
+template <int DEG, int SHK, int COVK>
 __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint32_t n, const PodPlanes pod,
                                                   const Records rec, uint32_t* __restrict__ block_visible) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -195,20 +299,48 @@ __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint
 
     Splat2D sp{};
     if (vis) {  // the covariance planes are only fetched for Gaussians that survive the frustum test
-        const float4 cva = ld_stream(&pod.cov_a[i]);
-        const float2 cvb = ld_stream(&pod.cov_b[i]);
-        vis = pm_cov2d_rect(f, vc, cva.x, cva.y, cva.z, cva.w, cvb.x, cvb.y, sp);
+        float c0, c1, c2, c3, c4, c5;
+        if (COVK == GSX_COV3D_SINGLE) {
+            const float4 cva = ld_stream(&pod.cov_a[i]);
+            const float2 cvb = ld_stream(&pod.cov_b[i]);
+            c0 = cva.x; c1 = cva.y; c2 = cva.z; c3 = cva.w; c4 = cvb.x; c5 = cvb.y;
+        } else {
+            const uint2 a = ld_stream(&pod.cov_h[i]);
+            const uint32_t b = ld_stream(&pod.cov_h2[i]);
+            c0 = h_lo(a.x); c1 = h_hi(a.x); c2 = h_lo(a.y); c3 = h_hi(a.y); c4 = h_lo(b); c5 = h_hi(b);
+        }
+        vis = pm_cov2d_rect(f, vc, c0, c1, c2, c3, c4, c5, sp);
     }
 
     float r = 0, g = 0, b = 0;
     if (vis) {  // SH planes: loaded only for survivors, only the planes the degree needs
         float s[48];
+        constexpr int kFloats = ShNeed<DEG>::floats;
+        if (SHK == GSX_SH_SINGLE) {
 #pragma unroll
-        for (int p = 0; p < ShNeed<DEG>::planes4; ++p) {
-            const float4 v = ld_stream(&pod.sh4[(uint64_t)p * n + i]);
-            s[4 * p] = v.x; s[4 * p + 1] = v.y; s[4 * p + 2] = v.z; s[4 * p + 3] = v.w;
+            for (int p = 0; p < ShNeed<DEG>::planes4; ++p) {
+                const float4 v = ld_stream(&pod.sh4[(uint64_t)p * n + i]);
+                s[4 * p] = v.x; s[4 * p + 1] = v.y; s[4 * p + 2] = v.z; s[4 * p + 3] = v.w;
+            }
+            if (DEG == 3) s[44] = ld_stream(&pod.sh1[i]);
+        } else if (SHK == GSX_SH_HALF) {
+#pragma unroll
+            for (int p = 0; p < (kFloats + 7) / 8; ++p) {
+                const uint4 v = ld_stream(&pod.sh_h[(uint64_t)p * n + i]);
+                s[8 * p] = h_lo(v.x); s[8 * p + 1] = h_hi(v.x); s[8 * p + 2] = h_lo(v.y); s[8 * p + 3] = h_hi(v.y);
+                s[8 * p + 4] = h_lo(v.z); s[8 * p + 5] = h_hi(v.z); s[8 * p + 6] = h_lo(v.w); s[8 * p + 7] = h_hi(v.w);
+            }
+        } else if (SHK == GSX_SH_NORM8) {
+#pragma unroll
+            for (int p = 0; p < (kFloats + 15) / 16; ++p) {
+                const uint4 v = ld_stream(&pod.sh_q[(uint64_t)p * n + i]);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int bb = 0; bb < 4; ++bb) s[16 * p + 4 * k + bb] = dq_snorm8(w[k], bb);
+            }
         }
-        if (DEG == 3) s[44] = ld_stream(&pod.sh1[i]);
         pm_color<DEG>(f, pc.x, pc.y, pc.z, color, s, r, g, b);
     }
 
@@ -250,9 +382,9 @@ __global__ __launch_bounds__(1024) void k_sum_counts(const uint32_t* __restrict_
 static inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
 
 hipError_t launch_convert(hipStream_t s, const gsx_gaussian* d_src, uint64_t n, uint64_t start, uint64_t model_n,
-                          const PodPlanes& pod, bool has_sh) {
+                          const PodPlanes& pod) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_convert, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_src, n, start, model_n, pod, has_sh ? 1 : 0);
+    hipLaunchKernelGGL(k_convert, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_src, n, start, model_n, pod);
     return hipGetLastError();
 }
 
@@ -265,10 +397,10 @@ hipError_t launch_pack_pod(hipStream_t s, const float* d_pos, const uint32_t* d_
 }
 
 hipError_t launch_unpack_pod(hipStream_t s, const PodPlanes& pod, uint64_t model_n, float* d_pos, uint32_t* d_color,
-                             float* d_sh, float* d_cov, bool has_sh) {
+                             float* d_sh, float* d_cov) {
     if (model_n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_unpack_pod, dim3(blocks_for(model_n, 256)), dim3(256), 0, s, pod, model_n, d_pos, d_color, d_sh,
-                       d_cov, has_sh ? 1 : 0);
+                       d_cov);
     return hipGetLastError();
 }
 
@@ -279,16 +411,37 @@ hipError_t launch_sum_counts(hipStream_t s, const uint32_t* d_block_visible, uin
     return hipGetLastError();
 }
 
-hipError_t launch_project(hipStream_t s, const FrameConsts& f, uint32_t n, const PodPlanes& pod, bool has_sh,
-                          const Records& rec, uint32_t* d_n_visible) {
-    if (n == 0) return hipSuccess;
-    dim3 grid(blocks_for(n, 256)), block(256);
-    int deg = has_sh ? (int)f.sh_deg : 0;
+template <int SHK, int COVK>
+static void launch_project_deg(hipStream_t s, dim3 grid, int deg, const FrameConsts& f, uint32_t n, const PodPlanes& pod,
+                               const Records& rec, uint32_t* bv) {
+    dim3 block(256);
     switch (deg) {
-        case 0: hipLaunchKernelGGL(k_project<0>, grid, block, 0, s, f, n, pod, rec, d_n_visible); break;
-        case 1: hipLaunchKernelGGL(k_project<1>, grid, block, 0, s, f, n, pod, rec, d_n_visible); break;
-        case 2: hipLaunchKernelGGL(k_project<2>, grid, block, 0, s, f, n, pod, rec, d_n_visible); break;
-        default: hipLaunchKernelGGL(k_project<3>, grid, block, 0, s, f, n, pod, rec, d_n_visible); break;
+        case 0: hipLaunchKernelGGL((k_project<0, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv); break;
+        case 1: hipLaunchKernelGGL((k_project<1, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv); break;
+        case 2: hipLaunchKernelGGL((k_project<2, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv); break;
+        default: hipLaunchKernelGGL((k_project<3, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv); break;
+    }
+}
+
+hipError_t launch_project(hipStream_t s, const FrameConsts& f, uint32_t n, const PodPlanes& pod, const Records& rec,
+                          uint32_t* d_block_visible) {
+    if (n == 0) return hipSuccess;
+    dim3 grid(blocks_for(n, 256));
+    const int deg = pod.sh_kind == GSX_SH_NONE ? 0 : (int)f.sh_deg;
+    const bool ch = pod.cov_kind == GSX_COV3D_HALF;
+    switch (pod.sh_kind) {
+        case GSX_SH_HALF:
+            if (ch) launch_project_deg<GSX_SH_HALF, GSX_COV3D_HALF>(s, grid, deg, f, n, pod, rec, d_block_visible);
+            else launch_project_deg<GSX_SH_HALF, GSX_COV3D_SINGLE>(s, grid, deg, f, n, pod, rec, d_block_visible);
+            break;
+        case GSX_SH_NORM8:
+            if (ch) launch_project_deg<GSX_SH_NORM8, GSX_COV3D_HALF>(s, grid, deg, f, n, pod, rec, d_block_visible);
+            else launch_project_deg<GSX_SH_NORM8, GSX_COV3D_SINGLE>(s, grid, deg, f, n, pod, rec, d_block_visible);
+            break;
+        default:  // Single, or None (deg 0 touches no SH plane)
+            if (ch) launch_project_deg<GSX_SH_SINGLE, GSX_COV3D_HALF>(s, grid, deg, f, n, pod, rec, d_block_visible);
+            else launch_project_deg<GSX_SH_SINGLE, GSX_COV3D_SINGLE>(s, grid, deg, f, n, pod, rec, d_block_visible);
+            break;
     }
     return hipGetLastError();
 }

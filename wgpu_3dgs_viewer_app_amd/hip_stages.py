@@ -12,13 +12,13 @@ import numpy as np
 
 from . import _lib
 from .camera import ModelTransform
-from .viewer import GaussianDisplayMode, GaussianShDegree, MultiModelViewer
+from .viewer import Cov3dKind, GaussianDisplayMode, GaussianShDegree, MultiModelViewer, ShKind
 
 RECORD_FLOATS = 12
 
 
 class HipStages:
-    def __init__(self, device: int = 0, stream=None, use_torch: bool = False):
+    def __init__(self, device: int = 0, stream=None, use_torch: bool = False, sh: int = 0, cov3d: int = 0):
         self.device = device
         self.torch_stream = None
         if use_torch:
@@ -27,7 +27,7 @@ class HipStages:
             # a dedicated non-default stream shared by torch (RCCL staging) and libgsx, so launch order = data order
             self.torch_stream = torch.cuda.Stream(device=device)
             stream = self.torch_stream.cuda_stream
-        self.viewer = MultiModelViewer(size=(1, 1), device=device, stream=stream)
+        self.viewer = MultiModelViewer(size=(1, 1), device=device, stream=stream, sh=ShKind(sh), cov3d=Cov3dKind(cov3d))
         self._size = (1, 1)
         self._send = None
         self._all = None
@@ -95,17 +95,17 @@ class HipStages:
         _lib.check(v._L.gsx_shard_pack_strip(v._h, world, rank, strip.data_ptr(), nbytes.value))
         return strip
 
-    def gather_buffers(self, strip, world: int):
-        """world contiguous strip-sized views RCCL can receive into directly."""
+    def gather_buffer(self, strip, world: int):
+        """One contiguous buffer of ``world`` strips that RCCL gathers into directly."""
         import torch
 
-        if self._all is None or self._all.shape != (world, strip.numel()):
-            self._all = torch.empty((world, strip.numel()), dtype=torch.float32, device=strip.device)
-        return list(self._all.unbind(0))
+        if self._all is None or self._all.numel() != world * strip.numel():
+            self._all = torch.empty(world * strip.numel(), dtype=torch.float32, device=strip.device)
+        return self._all
 
-    def assemble(self, parts, world: int) -> None:
+    def assemble(self, gathered, world: int) -> None:
         v = self.viewer
-        _lib.check(v._L.gsx_shard_unpack_strips(v._h, world, self._all.data_ptr(), self._all.numel() * 4))
+        _lib.check(v._L.gsx_shard_unpack_strips(v._h, world, gathered.data_ptr(), gathered.numel() * 4))
 
     # -- common --
     def framebuffer(self) -> np.ndarray:

@@ -10,7 +10,7 @@ path therefore has ONE real exchange step, sort-middle by screen rows:
   stage C  every rank depth-sorts what it received, bins it into ITS tile rows and composites them;
            received records arrive ordered by (source rank, local index) = global index, so the
            stable sort breaks depth ties exactly like the single-GPU path -> bit-identical pixels
-  stage M  the disjoint (rgb, T) tile-row strips are gathered into one framebuffer on rank 0.
+  stage M  the disjoint (rgb, T) tile-row strips are all-gathered and assembled into one framebuffer on rank 0.
 
 ``torch.distributed`` (backend nccl = RCCL) is plumbing only: it moves buffers the HIP kernels packed.
 The stage implementation is injectable (``stages=``) so the routing / merge logic is covered on CPU
@@ -42,12 +42,12 @@ class ShardedViewer:
     KEY = "shard"
 
     def __init__(self, device: int = 0, world: int = 1, rank: int = 0, use_dist: bool = False, stream=None,
-                 stages=None, group=None):
+                 stages=None, group=None, sh: int = 0, cov3d: int = 0):
         self.world, self.rank, self.use_dist, self.group = world, rank, use_dist, group
         if stages is None:
             from .hip_stages import HipStages  # the product path: libgsx.so, fails loudly if missing
 
-            stages = HipStages(device=device, stream=stream, use_torch=use_dist)
+            stages = HipStages(device=device, stream=stream, use_torch=use_dist, sh=sh, cov3d=cov3d)
         self.stages = stages
         self._stats = dict(n_gaussians=0, n_visible=0, n_tile_entries=0)
 
@@ -84,14 +84,12 @@ class ShardedViewer:
                                input_split_sizes=[int(x) for x in send_counts], group=self.group)
         # stage C: sort + bin + composite this rank's tile rows
         st.render_records(self.KEY, recv, sum(recv_counts), world, rank)
-        # stage M: gather the disjoint tile-row strips on rank 0
+        # stage M: the disjoint tile-row strips are all-gathered (every rank could present; rank 0 assembles)
         strip = st.own_strip(world, rank)  # flat [rows_per_rank * 16 * W * 4]: the rows this rank owns, packed
+        gathered = st.gather_buffer(strip, world)  # flat [world * strip]
+        dist.all_gather_into_tensor(gathered, strip, group=self.group)
         if rank == 0:
-            parts = st.gather_buffers(strip, world)
-            dist.gather(strip, parts, dst=0, group=self.group)
-            st.assemble(parts, world)
-        else:
-            dist.gather(strip, None, dst=0, group=self.group)
+            st.assemble(gathered, world)
 
     def framebuffer(self) -> np.ndarray:
         return self.stages.framebuffer()
