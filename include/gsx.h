@@ -136,6 +136,33 @@ gsx_status gsx_update_gaussian_transform(gsx_viewer* v, float size, gsx_display_
 gsx_status gsx_model_upload_mask(gsx_viewer* v, const char* key, const uint32_t* words, uint64_t n_words);
 gsx_status gsx_model_download_mask(gsx_viewer* v, const char* key, uint32_t* words, uint64_t n_words);
 
+/* gs::MaskEvaluator::evaluate(device, queue, &MaskOpTree, mask_buffer, model_transform_buffer, gaussians_buffer),
+ * scene.rs:2124-2131, 2201-2209.  The tree (app.rs:1815-1837: Union | Intersection | Difference |
+ * SymmetricDifference | Complement | Shape(&pod) | Reset) is passed in postfix order; n_ops == 0 is Reset
+ * (every bit set).  A Gaussian is inside a shape when its WORLD position (model transform applied), taken
+ * into the shape's frame (pos, rotation, scale), lies in the unit box |x|,|y|,|z| <= 1 or the unit ball.
+ * Result: the model's mask buffer, bit = 1 kept / rendered.  One HIP kernel, no readback. */
+typedef enum gsx_mask_shape_kind { GSX_MASK_BOX = 0, GSX_MASK_ELLIPSOID = 1 } gsx_mask_shape_kind;
+typedef struct gsx_mask_shape { /* gs::MaskOpShapePod (gs::MaskShape {kind, pos, rotation, scale, color}) */
+    uint32_t kind;
+    float pos[3];
+    float quat_xyzw[4];
+    float scale[3];
+} gsx_mask_shape;
+typedef enum gsx_mask_opcode {
+    GSX_MASK_OP_SHAPE = 0, /* push shape[arg] */
+    GSX_MASK_OP_UNION = 1,
+    GSX_MASK_OP_INTERSECTION = 2,
+    GSX_MASK_OP_DIFFERENCE = 3, /* a - b, a pushed first */
+    GSX_MASK_OP_SYMMETRIC_DIFFERENCE = 4,
+    GSX_MASK_OP_COMPLEMENT = 5
+} gsx_mask_opcode;
+typedef struct gsx_mask_op { uint32_t opcode; uint32_t arg; } gsx_mask_op;
+#define GSX_MASK_MAX_OPS 64u
+#define GSX_MASK_MAX_SHAPES 32u
+gsx_status gsx_mask_evaluate(gsx_viewer* v, const char* key, const gsx_mask_op* ops, uint32_t n_ops,
+                             const gsx_mask_shape* shapes, uint32_t n_shapes);
+
 /* ---- frame execution, split exactly like the reference's per-frame protocol (scene.rs:856-873, 2302-2314) ---- */
 /* preprocessor.preprocess(encoder, bind_group, N): cull + SH colour + 3D->2D covariance + depth key. scene.rs:856-863 */
 gsx_status gsx_preprocess(gsx_viewer* v, const char* key);

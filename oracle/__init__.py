@@ -75,6 +75,8 @@ def lib():
         L.gsxo_composite_tiles.restype = None
         L.gsxo_render_model.argtypes = [C.POINTER(Frame), C.c_uint64, fp, u32p, fp, fp, u32p, fp]
         L.gsxo_render_model.restype = C.c_uint64
+        L.gsxo_mask_evaluate.argtypes = [C.c_uint64, fp, fp, fp, fp, vp, C.c_uint32, vp, C.c_uint32, u32p]
+        L.gsxo_mask_evaluate.restype = None
         L.gsxo_num_threads.restype = C.c_int
         L.gsxo_frame_sizeof.restype = C.c_size_t
         assert L.gsxo_frame_sizeof() == C.sizeof(Frame), "gsxo_frame layout drifted"
@@ -180,3 +182,13 @@ def render_model(frame: Frame, pos, color, sh, cov3d, fb: np.ndarray, mask=None)
 
 def num_threads() -> int:
     return int(lib().gsxo_num_threads())
+
+
+def mask_evaluate(pos, m_pos, m_quat, m_scale, c_ops, n_ops, c_shapes, n_shapes) -> np.ndarray:
+    """Mask words (bit = kept) for a postfix program in the ``gsx_mask_op`` / ``gsx_mask_shape`` C layout."""
+    n = pos.shape[0]
+    words = np.zeros((n + 31) // 32, np.uint32)
+    mp, mq, ms = _f32(m_pos, 3), _f32(m_quat, 4), _f32(m_scale, 3)
+    lib().gsxo_mask_evaluate(n, _fp(np.ascontiguousarray(pos, np.float32)), _fp(mp), _fp(mq), _fp(ms),
+                             C.cast(c_ops, C.c_void_p), n_ops, C.cast(c_shapes, C.c_void_p), n_shapes, _up(words))
+    return words

@@ -532,6 +532,49 @@ uint64_t gsxo_render_model(const gsxo_frame* f, uint64_t n, const float* pos, co
     return nvis;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Mask evaluation (K5, gs::MaskEvaluator::evaluate, scene.rs:2124-2131): postfix set algebra over box /
+ * ellipsoid shapes on the world-space Gaussian position.  words: ceil(n/32) u32, bit = kept.
+ * ---------------------------------------------------------------------------------------------- */
+void gsxo_mask_evaluate(uint64_t n, const float* pos, const float m_pos[3], const float m_quat[4], const float m_scale[3],
+                        const gsx_mask_op* ops, uint32_t n_ops, const gsx_mask_shape* shapes, uint32_t n_shapes,
+                        uint32_t* words) {
+    float Rm[9], Rs[GSX_MASK_MAX_SHAPES][9];
+    quat_to_rows(m_quat, Rm);
+    for (uint32_t s = 0; s < n_shapes; ++s) quat_to_rows(shapes[s].quat_xyzw, Rs[s]);
+    memset(words, 0, sizeof(uint32_t) * ((n + 31) / 32));
+    for (uint64_t i = 0; i < n; ++i) {
+        float sp[3] = {m_scale[0] * pos[3 * i], m_scale[1] * pos[3 * i + 1], m_scale[2] * pos[3 * i + 2]};
+        float w[3];
+        for (int r = 0; r < 3; ++r) w[r] = dot3(&Rm[r * 3], sp) + m_pos[r];
+        uint32_t inside = 0;
+        for (uint32_t s = 0; s < n_shapes; ++s) {
+            float rel[3] = {w[0] - shapes[s].pos[0], w[1] - shapes[s].pos[1], w[2] - shapes[s].pos[2]};
+            float q[3];
+            for (int c = 0; c < 3; ++c) {
+                float col[3] = {Rs[s][0 * 3 + c], Rs[s][1 * 3 + c], Rs[s][2 * 3 + c]};
+                q[c] = dot3(col, rel) / shapes[s].scale[c];
+            }
+            int in = shapes[s].kind == GSX_MASK_BOX ? (fabsf(q[0]) <= 1.0f && fabsf(q[1]) <= 1.0f && fabsf(q[2]) <= 1.0f)
+                                                    : ((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2] <= 1.0f);
+            inside |= (uint32_t)(in ? 1 : 0) << s;
+        }
+        int stack[64], depth = 0;
+        for (uint32_t k = 0; k < n_ops; ++k) {
+            uint32_t op = ops[k].opcode;
+            if (op == GSX_MASK_OP_SHAPE) stack[depth++] = (int)((inside >> ops[k].arg) & 1u);
+            else if (op == GSX_MASK_OP_COMPLEMENT) stack[depth - 1] = !stack[depth - 1];
+            else {
+                int b = stack[--depth], a = stack[depth - 1];
+                stack[depth - 1] = op == GSX_MASK_OP_UNION ? (a | b) : op == GSX_MASK_OP_INTERSECTION ? (a & b)
+                                   : op == GSX_MASK_OP_DIFFERENCE ? (a & !b) : (a ^ b);
+            }
+        }
+        int keep = n_ops == 0 ? 1 : stack[0];
+        if (keep) words[i >> 5] |= 1u << (i & 31);
+    }
+}
+
 int gsxo_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

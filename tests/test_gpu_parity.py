@@ -347,3 +347,48 @@ def test_compressed_pods(sh_kind, cov_kind):
     if sh_kind == 1 and cov_kind == 0:  # f16 SH alone keeps the frame close to full precision
         full = common.oracle_model_frame(g, cam, w, h, mt)[4]
         assert np.abs(fb_ref - full).max() <= 0.01
+
+
+def test_mask_evaluator_parity_and_render():
+    """K5 on the GPU: `0 - 1` (box minus ellipsoid, cfg5's mask op) on a transformed model, bit-exact mask words,
+    and the masked frame against the oracle rendered with the same mask."""
+    from wgpu_3dgs_viewer_app_amd.mask import MaskEvaluator, MaskOp, MaskShape, MaskShapeKind, pack_program
+
+    n, w, h = 7000, 160, 112
+    g = common.small_scene(n, 131)
+    cam = camera.orbit_pose(120)
+    mt = common.odd_transform()
+    shapes = [MaskShape(MaskShapeKind.Box, pos=np.array([0.3, 0.0, 0.2], np.float32), scale=np.array([2.5, 2.0, 3.0], np.float32),
+                        rotation=camera.quat_from_euler_zyx(0.4, -0.3, 0.2)),
+              MaskShape(MaskShapeKind.Ellipsoid, pos=np.array([0.0, 0.3, 0.0], np.float32), scale=np.array([1.5, 1.2, 1.8], np.float32))]
+    pos = oracle.convert(g)[0]
+    with MultiModelViewer() as v:
+        v.add_model("m", n)
+        v.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g)
+        v.update_model_transform("m", mt.pos, mt.quat(), mt.scale)
+        ev = MaskEvaluator(v)
+        for expr in ("0 - 1", "0 | 1", "!(0 ^ 1) & 0", "1"):
+            op = MaskOp.parse(expr)
+            ev.evaluate(op, "m", shapes)
+            ref = oracle.mask_evaluate(pos, mt.pos, mt.quat(), mt.scale, *pack_program(op, shapes))
+            got = v.models["m"].gaussian_buffers.mask_buffer.download()
+            tail = (1 << (n & 31)) - 1 if n & 31 else 0xFFFFFFFF
+            got[-1] &= tail
+            ref[-1] &= tail
+            assert np.array_equal(got, ref), expr
+        op = MaskOp.parse("0 - 1")
+        ev.evaluate(op, "m", shapes)
+        mask = oracle.mask_evaluate(pos, mt.pos, mt.quat(), mt.scale, *pack_program(op, shapes))
+        kept = int(((mask[np.arange(n) >> 5] >> (np.arange(n) & 31).astype(np.uint32)) & 1).sum())
+        assert 0 < kept < n
+        f, pr, idx, nvis, fb_ref = common.oracle_model_frame(g, cam, w, h, mt, mask=mask)
+        v.update_camera(cam, (w, h))
+        v.update_gaussian_transform(1.0, GaussianDisplayMode.Splat, GaussianShDegree.new(3), False)
+        v.render_frame(["m"])
+        assert_projection_equal(v.download_projection("m"), pr)
+        assert np.abs(v.download_framebuffer() - fb_ref).max() <= 2e-4
+        with pytest.raises(GsxError):
+            ev.evaluate(MaskOp.parse("0 - 5"), "m", shapes)  # validate_shapes: index out of range
+        ev.evaluate(None, "m")  # MaskOpTree::Reset
+        v.render_frame(["m"])
+        assert v.frame_stats("m")["n_visible"] > nvis

@@ -26,7 +26,7 @@ EXPORTS = (
     "gsx_render_frame", "gsx_download_framebuffer", "gsx_download_rgba8", "gsx_framebuffer_device_ptr",
     "gsx_model_frame_stats", "gsx_model_download_projection", "gsx_model_download_sorted",
     "gsx_model_download_tile_lists", "gsx_model_download_pod", "gsx_set_pass_timing", "gsx_get_pass_timing",
-    "gsx_render_options_default", "gsx_viewer_set_render_options", "gsx_shard_pack", "gsx_shard_import", "gsx_shard_strip_bytes", "gsx_shard_pack_strip", "gsx_shard_unpack_strips",
+    "gsx_mask_evaluate", "gsx_render_options_default", "gsx_viewer_set_render_options", "gsx_shard_pack", "gsx_shard_import", "gsx_shard_strip_bytes", "gsx_shard_pack_strip", "gsx_shard_unpack_strips",
 )
 
 
@@ -86,6 +86,7 @@ def load() -> C.CDLL:
         "gsx_update_gaussian_transform": ([vp, C.c_float, C.c_int, u32, u32], C.c_int32),
         "gsx_model_upload_mask": ([vp, cp, u32p, u64], C.c_int32),
         "gsx_model_download_mask": ([vp, cp, u32p, u64], C.c_int32),
+        "gsx_mask_evaluate": ([vp, cp, vp, u32, vp, u32], C.c_int32),
         "gsx_preprocess": ([vp, cp], C.c_int32),
         "gsx_sort": ([vp, cp], C.c_int32),
         "gsx_sync": ([vp], C.c_int32),

@@ -734,6 +734,56 @@ gsx_status gsx_model_download_mask(gsx_viewer* v, const char* key, uint32_t* wor
     return GSX_OK;
 }
 
+gsx_status gsx_mask_evaluate(gsx_viewer* v, const char* key, const gsx_mask_op* ops, uint32_t n_ops,
+                             const gsx_mask_shape* shapes, uint32_t n_shapes) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_mask_evaluate: no model '%s'", key ? key : "(null)");
+    if (n_ops > GSX_MASK_MAX_OPS || n_shapes > GSX_MASK_MAX_SHAPES)
+        return fail(GSX_ERR_INVALID_ARG, "gsx_mask_evaluate: at most %u ops and %u shapes", GSX_MASK_MAX_OPS, GSX_MASK_MAX_SHAPES);
+    if ((n_ops && !ops) || (n_shapes && !shapes)) return fail(GSX_ERR_INVALID_ARG, "gsx_mask_evaluate: null argument");
+    // validate the postfix program: shape indices (validate_shapes, app.rs:1786-1813) and stack discipline
+    int depth = 0;
+    for (uint32_t k = 0; k < n_ops; ++k) {
+        switch (ops[k].opcode) {
+            case GSX_MASK_OP_SHAPE:
+                if (ops[k].arg >= n_shapes) return fail(GSX_ERR_INVALID_ARG, "gsx_mask_evaluate: shape index %u out of range", ops[k].arg);
+                if (++depth > 32) return fail(GSX_ERR_INVALID_ARG, "gsx_mask_evaluate: expression nests deeper than 32");
+                break;
+            case GSX_MASK_OP_COMPLEMENT:
+                if (depth < 1) return fail(GSX_ERR_INVALID_ARG, "gsx_mask_evaluate: malformed postfix program");
+                break;
+            case GSX_MASK_OP_UNION: case GSX_MASK_OP_INTERSECTION: case GSX_MASK_OP_DIFFERENCE: case GSX_MASK_OP_SYMMETRIC_DIFFERENCE:
+                if (depth < 2) return fail(GSX_ERR_INVALID_ARG, "gsx_mask_evaluate: malformed postfix program");
+                --depth;
+                break;
+            default: return fail(GSX_ERR_INVALID_ARG, "gsx_mask_evaluate: unknown opcode %u", ops[k].opcode);
+        }
+    }
+    if (n_ops && depth != 1) return fail(GSX_ERR_INVALID_ARG, "gsx_mask_evaluate: malformed postfix program");
+    if (n_ops == 0) {  // MaskOpTree::Reset
+        m->has_mask = false;
+        return GSX_OK;
+    }
+    MaskProgram prog{};
+    quat_to_rows(m->mt.quat, prog.m_rot);
+    memcpy(prog.m_pos, m->mt.pos, sizeof prog.m_pos);
+    memcpy(prog.m_scale, m->mt.scale, sizeof prog.m_scale);
+    prog.n_shapes = n_shapes;
+    prog.n_ops = n_ops;
+    for (uint32_t s = 0; s < n_shapes; ++s) {
+        prog.shapes[s].kind = shapes[s].kind;
+        memcpy(prog.shapes[s].pos, shapes[s].pos, sizeof(float) * 3);
+        quat_to_rows(shapes[s].quat_xyzw, prog.shapes[s].rot);
+        memcpy(prog.shapes[s].scale, shapes[s].scale, sizeof(float) * 3);
+    }
+    memcpy(prog.ops, ops, sizeof(gsx_mask_op) * n_ops);
+    HIPCHK(launch_mask_evaluate(v->stream, m->pc.as<float4>(), (uint32_t)m->n, prog, m->mask.as<uint32_t>()));
+    m->has_mask = true;
+    return GSX_OK;
+}
+
 gsx_status gsx_preprocess(gsx_viewer* v, const char* key) {
     gsx_status st = viewer_bind(v);
     if (st) return st;

@@ -135,6 +135,22 @@ hipError_t launch_pack_strip(hipStream_t s, const float4* fb, uint32_t w, uint32
 hipError_t launch_unpack_strips(hipStream_t s, const void* d_all, uint32_t w, uint32_t h, uint32_t world,
                                 uint32_t rows_per_rank, float4* fb);
 
+// Mask evaluation (kernels_mask.hip); passed to the kernel by value.
+struct MaskShapeConsts {
+    uint32_t kind;
+    float pos[3];
+    float rot[9];  // row-major rotation of the shape
+    float scale[3];
+};
+struct MaskProgram {
+    float m_rot[9], m_pos[3], m_scale[3];  // model transform
+    uint32_t n_shapes, n_ops;
+    MaskShapeConsts shapes[GSX_MASK_MAX_SHAPES];
+    gsx_mask_op ops[GSX_MASK_MAX_OPS];
+};
+hipError_t launch_mask_evaluate(hipStream_t s, const float4* pc, uint32_t n, const MaskProgram& prog, uint32_t* mask);
+void quat_to_rows(const float q[4], float r[9]);
+
 // Compositing and resolve.
 // carry: continue from the (C, T) already in fb (later slabs / models behind); done: saturated-tile bitmap
 // (read to skip tiles when carrying, updated when a tile saturates; nullable).

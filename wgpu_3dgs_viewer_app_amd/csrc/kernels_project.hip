@@ -19,7 +19,9 @@ namespace gsx {
 // ------------------------------------------------------------------------------------------------
 // host: frame constants (spec §3)
 // ------------------------------------------------------------------------------------------------
-static void quat_rows(const float q[4], float r[9]) {
+void quat_to_rows(const float q[4], float r[9]);
+static void quat_rows(const float q[4], float r[9]) { quat_to_rows(q, r); }
+void quat_to_rows(const float q[4], float r[9]) {
     float x = q[0], y = q[1], z = q[2], w = q[3];
     float x2 = x + x, y2 = y + y, z2 = z + z;
     float xx = x * x2, xy = x * y2, xz = x * z2;
