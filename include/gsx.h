@@ -231,6 +231,28 @@ gsx_status gsx_shard_strip_bytes(gsx_viewer* v, uint32_t world, uint64_t* out_by
 gsx_status gsx_shard_pack_strip(gsx_viewer* v, uint32_t world, uint32_t rank, void* d_strip, uint64_t strip_bytes);
 gsx_status gsx_shard_unpack_strips(gsx_viewer* v, uint32_t world, const void* d_all, uint64_t bytes);
 
+/* ---- PLY I/O (host side; no GPU needed).  gs::Gaussians::read_ply_header / PlyHeader::count /
+ *      read_ply_gaussians + gs::Gaussian::from(PlyGaussianPod) (app.rs:1053-1096) and write_ply (app.rs:897-947).
+ *      INRIA 3DGS vertex: x y z nx ny nz f_dc_0..2 f_rest_0..44 opacity scale_0..2 rot_0..3 (62 f32, 248 B;
+ *      properties are located by NAME, missing f_rest_* read as 0).  binary_little_endian and ascii. ---- */
+typedef struct gsx_ply_header {
+    uint64_t count;        /* element vertex N  (PlyHeader::count) */
+    uint64_t header_bytes; /* offset of the first vertex */
+    uint32_t vertex_bytes; /* stride of one binary vertex (0 for ascii) */
+    uint32_t is_ascii;
+    int32_t offsets[62];   /* byte offset (binary) / column (ascii) of each INRIA property, -1 if absent */
+} gsx_ply_header;
+/* data/size: the file contents (at least the header). */
+gsx_status gsx_ply_read_header(const void* data, uint64_t size, gsx_ply_header* out);
+/* Converts vertices [start, start+n) into gs::Gaussian records (rot normalised from w,x,y,z to x,y,z,w;
+ * scale = exp; colour = clamp(0.5 + C0*f_dc), alpha = sigmoid(opacity) as UNORM8; f_rest [3][15] -> [15][3]). */
+gsx_status gsx_ply_read_gaussians(const void* data, uint64_t size, const gsx_ply_header* header, uint64_t start,
+                                  uint64_t n, gsx_gaussian* out);
+/* Inverse conversion into a binary_little_endian INRIA PLY.  mask_words (nullable): only Gaussians whose bit
+ * is set are written (write_ply's mask iterator).  Call with out == NULL to get the size in *out_size. */
+gsx_status gsx_ply_write(const gsx_gaussian* gaussians, uint64_t n, const uint32_t* mask_words, void* out,
+                         uint64_t capacity, uint64_t* out_size);
+
 /* ---- timing: HIP events recorded on the viewer's stream around each pass of the last frame ---- */
 typedef enum gsx_pass {
     GSX_PASS_PROJECT = 0,

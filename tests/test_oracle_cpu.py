@@ -242,3 +242,60 @@ def test_mask_oracle_set_algebra():
     assert np.array_equal(run("0 - 1"), a & ~b) and np.array_equal(run("0 ^ 1"), a ^ b)
     assert np.array_equal(run("!0"), ~a) and np.array_equal(run("!(0 | 1) | 0&1"), ~(a | b) | (a & b))
     assert run("").all()  # Reset
+
+
+# ---- PLY I/O (host side of libgsx; src/app.rs:1053-1096, 897-947) ---------------------------------
+def _ply_bytes(ply, order=None, ascii_=False):
+    names = (["x", "y", "z", "nx", "ny", "nz"] + [f"f_dc_{i}" for i in range(3)] + [f"f_rest_{i}" for i in range(45)]
+             + ["opacity"] + [f"scale_{i}" for i in range(3)] + [f"rot_{i}" for i in range(4)])
+    flat = np.concatenate([ply["pos"], ply["n"], ply["f_dc"], ply["f_rest"], ply["opacity"][:, None], ply["scale"], ply["rot"]], 1).astype("<f4")
+    idx = list(range(62)) if order is None else order
+    head = "ply\nformat %s 1.0\ncomment test\nelement vertex %d\n" % ("ascii" if ascii_ else "binary_little_endian", flat.shape[0])
+    head += "".join(f"property float {names[i]}\n" for i in idx) + "end_header\n"
+    body = flat[:, idx]
+    if ascii_:
+        return head.encode() + "\n".join(" ".join(repr(float(v)) for v in row) for row in body).encode() + b"\n"
+    return head.encode() + np.ascontiguousarray(body).tobytes()
+
+
+def test_ply_read_matches_gaussian_from_ply_and_round_trips():
+    from wgpu_3dgs_viewer_app_amd.ply import Gaussians
+    from wgpu_3dgs_viewer_app_amd._lib import GsxError
+
+    ply = scene.synthetic_ply(3000, 77, 3)
+    ref = scene.gaussians_from_ply(ply)
+    for data in (_ply_bytes(ply), _ply_bytes(ply, order=list(reversed(range(62)))), _ply_bytes(ply[:200], ascii_=True)):
+        h = Gaussians.read_ply_header(data)
+        n = h.count()
+        got = Gaussians.read_ply(data).gaussians
+        assert got.shape[0] == n
+        r = ref[:n]
+        assert np.array_equal(got["pos"], r["pos"]) and np.array_equal(got["sh"], r["sh"])
+        np.testing.assert_allclose(got["rot"], r["rot"], atol=2e-7)
+        np.testing.assert_allclose(got["scale"], r["scale"], rtol=3e-7)
+        assert np.abs(got["color"].astype(int) - r["color"].astype(int)).max() <= 1  # exp / sigmoid last-bit rounding
+    # streaming batches like the app's loader (scene.rs:341-380)
+    data = _ply_bytes(ply)
+    h = Gaussians.read_ply_header(data)
+    parts = list(Gaussians.read_ply_gaussians(data, h, start=100, count=1000, batch=256))
+    assert [p.shape[0] for p in parts] == [256, 256, 256, 232]
+    assert np.array_equal(np.concatenate(parts)["pos"], ref["pos"][100:1100])
+    # write -> read round trip, with a mask (write_ply's mask iterator)
+    g = Gaussians(ref)
+    back = Gaussians.read_ply(g.write_ply()).gaussians
+    assert np.array_equal(back["pos"], ref["pos"]) and np.array_equal(back["color"], ref["color"]) and np.array_equal(back["sh"], ref["sh"])
+    np.testing.assert_allclose(back["scale"], ref["scale"], rtol=1e-6)
+    mask = np.random.default_rng(1).integers(0, 2**32, size=(3000 + 31) // 32, dtype=np.uint32)
+    kept = ((mask[np.arange(3000) >> 5] >> (np.arange(3000) & 31).astype(np.uint32)) & 1).astype(bool)
+    masked = Gaussians.read_ply(g.write_ply(mask)).gaussians
+    assert masked.shape[0] == kept.sum() and np.array_equal(masked["pos"], ref["pos"][kept])
+    # errors are gs::Error-style results, not crashes
+    for bad in (b"plx\n", b"ply\nformat binary_big_endian 1.0\nelement vertex 1\nend_header\n", data[:400],
+                b"ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nend_header\n0\n"):
+        with pytest.raises(GsxError):
+            Gaussians.read_ply(bad)
+    with pytest.raises(GsxError):
+        list(Gaussians.read_ply_gaussians(data[: h.raw.header_bytes + 248 * 10], h))  # truncated body -> Error::Io
+    # a PLY without f_rest (SH-0 export) reads zero SH
+    no_rest = _ply_bytes(ply[:50], order=[i for i in range(62) if not 9 <= i < 54])
+    assert not Gaussians.read_ply(no_rest).gaussians["sh"].any()

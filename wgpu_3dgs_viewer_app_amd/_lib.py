@@ -26,7 +26,7 @@ EXPORTS = (
     "gsx_render_frame", "gsx_download_framebuffer", "gsx_download_rgba8", "gsx_framebuffer_device_ptr",
     "gsx_model_frame_stats", "gsx_model_download_projection", "gsx_model_download_sorted",
     "gsx_model_download_tile_lists", "gsx_model_download_pod", "gsx_set_pass_timing", "gsx_get_pass_timing",
-    "gsx_mask_evaluate", "gsx_render_options_default", "gsx_viewer_set_render_options", "gsx_shard_pack", "gsx_shard_import", "gsx_shard_strip_bytes", "gsx_shard_pack_strip", "gsx_shard_unpack_strips",
+    "gsx_mask_evaluate", "gsx_ply_read_header", "gsx_ply_read_gaussians", "gsx_ply_write", "gsx_render_options_default", "gsx_viewer_set_render_options", "gsx_shard_pack", "gsx_shard_import", "gsx_shard_strip_bytes", "gsx_shard_pack_strip", "gsx_shard_unpack_strips",
 )
 
 
@@ -37,6 +37,11 @@ class SpecParams(C.Structure):
 
 class RenderOptions(C.Structure):
     _fields_ = [("progressive", C.c_uint32), ("first_slab_divisor", C.c_uint32), ("min_slab", C.c_uint32), ("growth", C.c_uint32)]
+
+
+class PlyHeader(C.Structure):
+    _fields_ = [("count", C.c_uint64), ("header_bytes", C.c_uint64), ("vertex_bytes", C.c_uint32), ("is_ascii", C.c_uint32),
+                ("offsets", C.c_int32 * 62)]
 
 
 class ViewerDesc(C.Structure):
@@ -87,6 +92,9 @@ def load() -> C.CDLL:
         "gsx_model_upload_mask": ([vp, cp, u32p, u64], C.c_int32),
         "gsx_model_download_mask": ([vp, cp, u32p, u64], C.c_int32),
         "gsx_mask_evaluate": ([vp, cp, vp, u32, vp, u32], C.c_int32),
+        "gsx_ply_read_header": ([vp, u64, C.POINTER(PlyHeader)], C.c_int32),
+        "gsx_ply_read_gaussians": ([vp, u64, C.POINTER(PlyHeader), u64, u64, vp], C.c_int32),
+        "gsx_ply_write": ([vp, u64, u32p, vp, u64, C.POINTER(u64)], C.c_int32),
         "gsx_preprocess": ([vp, cp], C.c_int32),
         "gsx_sort": ([vp, cp], C.c_int32),
         "gsx_sync": ([vp], C.c_int32),

@@ -30,6 +30,16 @@ static gsx_status fail(gsx_status st, const char* fmt, ...) {
     return st;
 }
 
+gsx_status ply_fail(gsx_status st, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return st;
+}
+
 #define HIPCHK(expr)                                                                                  \
     do {                                                                                              \
         hipError_t _e = (expr);                                                                       \

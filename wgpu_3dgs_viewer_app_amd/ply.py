@@ -1,0 +1,64 @@
+"""``gs::Gaussians`` PLY I/O over libgsx (csrc/gsx_ply.cpp): the reference's load path
+``read_ply_header -> header.count() -> read_ply_gaussians -> Gaussian::from`` (src/app.rs:1053-1096) and
+``write_ply(writer, edits, mask)`` (src/app.rs:897-947)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .scene import GAUSSIAN_DTYPE
+
+
+class PlyHeader:
+    def __init__(self, raw: _lib.PlyHeader):
+        self.raw = raw
+
+    def count(self) -> int:
+        """``PlyHeader::count`` (src/app.rs:1057)."""
+        return int(self.raw.count)
+
+
+class Gaussians:
+    """``gs::Gaussians {gaussians: Vec<Gaussian>}``."""
+
+    def __init__(self, gaussians: np.ndarray):
+        self.gaussians = np.ascontiguousarray(gaussians, dtype=GAUSSIAN_DTYPE)
+
+    @staticmethod
+    def read_ply_header(data: bytes) -> PlyHeader:
+        h = _lib.PlyHeader()
+        buf = (C.c_char * len(data)).from_buffer_copy(data) if not isinstance(data, (bytearray, memoryview)) else (C.c_char * len(data)).from_buffer(data)
+        _lib.check(_lib.load().gsx_ply_read_header(C.addressof(buf), len(data), C.byref(h)))
+        return PlyHeader(h)
+
+    @staticmethod
+    def read_ply_gaussians(data: bytes, header: PlyHeader, start: int = 0, count: int | None = None, batch: int = 1 << 16):
+        """Iterator of ``gs::Gaussian`` batches (the app streams them to the GPU in batches, scene.rs:341-380)."""
+        n = header.count() - start if count is None else count
+        buf = np.frombuffer(data, dtype=np.uint8)
+        L = _lib.load()
+        for s in range(start, start + n, batch):
+            m = min(batch, start + n - s)
+            out = np.zeros(m, dtype=GAUSSIAN_DTYPE)
+            _lib.check(L.gsx_ply_read_gaussians(buf.ctypes.data, buf.size, C.byref(header.raw), s, m, out.ctypes.data))
+            yield out
+
+    @classmethod
+    def read_ply(cls, data: bytes) -> "Gaussians":
+        h = cls.read_ply_header(data)
+        parts = list(cls.read_ply_gaussians(data, h))
+        return cls(np.concatenate(parts) if parts else np.zeros(0, GAUSSIAN_DTYPE))
+
+    def write_ply(self, mask_words: np.ndarray | None = None) -> bytes:
+        """``write_ply(writer, None, mask)``: binary little-endian INRIA PLY of the (masked) Gaussians."""
+        L = _lib.load()
+        g = self.gaussians
+        size = C.c_uint64()
+        mw = None if mask_words is None else np.ascontiguousarray(mask_words, np.uint32)
+        mp = None if mw is None else mw.ctypes.data_as(C.POINTER(C.c_uint32))
+        _lib.check(L.gsx_ply_write(g.ctypes.data, g.shape[0], mp, None, 0, C.byref(size)))
+        out = np.empty(size.value, np.uint8)
+        _lib.check(L.gsx_ply_write(g.ctypes.data, g.shape[0], mp, out.ctypes.data, out.size, C.byref(size)))
+        return out.tobytes()
