@@ -100,6 +100,7 @@ struct Model {
     uint32_t* tile_keys = nullptr;
     bool preprocessed = false, sorted = false, counters_valid = false, binned = false;
     bool stats_pending = false;                 // device statistics newer than the host mirror
+    bool ranges_clean = false;                  // the tile range table is known to be all-zero
     bool lists_complete = false;                // the tile lists of the last render cover the whole model (one slab)
     uint32_t n_visible = 0, n_entries = 0;
     uint64_t tile_cap = 0;                      // capacity (entries) of the tile-pair buffers
@@ -369,8 +370,8 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
     const uint32_t n_tiles = m->fc.tiles_x * m->fc.tiles_y;
     const uint32_t row_words = (m->fc.tiles_x + 31) / 32;
     const bool progressive = v->options.progressive != 0;
-    uint32_t* done = progressive ? v->done_bits.as<uint32_t>() : nullptr;
-    uint32_t* done_count = v->frame_done.as<uint32_t>();
+    uint32_t* done = progressive ? v->done_bits.as<uint32_t>() + 1 : nullptr;  // word 0 is the saturated-tile counter
+    uint32_t* done_count = v->done_bits.as<uint32_t>();
     std::vector<uint32_t> bounds;
     plan_slabs(v->options, (uint32_t)m->rec_n, &bounds);
     if (progressive) {
@@ -400,11 +401,14 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
             HIPCHK(m->tsort_ws.ensure(ws));
             HIPCHK(hipMemsetAsync(m->tsort_ws.p, 0, m->tsort_ws.bytes, v->stream));
         }
+        if (sizeof(uint2) * (size_t)n_tiles > m->ranges.bytes) m->ranges_clean = false;
         HIPCHK(m->ranges.ensure(sizeof(uint2) * (size_t)n_tiles));
     }
     // reset this model's per-frame totals (n_visible stays)
     HIPCHK(hipMemsetAsync(&dc->n_entries, 0, sizeof(Counters) - offsetof(Counters, n_entries), v->stream));
     const int bits = std::max<int>(1, (int)ceil_log2(n_tiles));
+    // a single-slab front model keeps its complete tile lists for gsx_model_download_tile_lists
+    const bool clear_ranges = progressive && !(bounds.size() == 2 && !carry);
     for (size_t sl = 0; sl + 1 < bounds.size(); ++sl) {
         const uint32_t j0 = bounds[sl], j1 = bounds[sl + 1];
         // the very first slab of the frame sees no saturated tile: plain rectangle areas
@@ -434,12 +438,14 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
         }
         {
             ScopedPass t(v, GSX_PASS_BIN);
-            HIPCHK(launch_tile_ranges(v->stream, slab_cap, &dc->n_entries, m->tile_keys, n_tiles, m->ranges.as<uint2>()));
+            HIPCHK(launch_tile_ranges(v->stream, slab_cap, &dc->n_entries, m->tile_keys, n_tiles, m->ranges.as<uint2>(),
+                                      m->ranges_clean));
         }
         {
             ScopedPass t(v, GSX_PASS_COMPOSITE);
             HIPCHK(launch_composite(v->stream, m->fc, m->ranges.as<uint2>(), m->tile_list, m->rec(), v->fb.as<float4>(),
-                                    later, done, row_words, done_count));
+                                    later, done, row_words, done_count, clear_ranges));
+            m->ranges_clean = clear_ranges;  // the compositor zeroed every range it consumed
             v->pass_launches[GSX_PASS_COMPOSITE] += 1;
         }
     }
@@ -471,12 +477,11 @@ static gsx_status do_render(gsx_viewer* v, const char* const* keys, uint32_t n_k
         HIPCHK(launch_clear_fb(v->stream, v->fb.as<float4>(), v->width * v->height));
         return GSX_OK;
     }
-    HIPCHK(v->frame_done.ensure(4));
-    HIPCHK(hipMemsetAsync(v->frame_done.p, 0, 4, v->stream));
-    if (v->options.progressive) {
+    {   // one memset: [saturated-tile counter | saturated-tile bitmap]
         const uint32_t tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE, row_words = ((v->width + GSX_TILE - 1) / GSX_TILE + 31) / 32;
-        HIPCHK(v->done_bits.ensure(4 * (size_t)tiles_y * row_words));
-        HIPCHK(hipMemsetAsync(v->done_bits.p, 0, 4 * (size_t)tiles_y * row_words, v->stream));
+        const size_t bytes = 4 * (1 + (size_t)tiles_y * row_words);
+        HIPCHK(v->done_bits.ensure(bytes));
+        HIPCHK(hipMemsetAsync(v->done_bits.p, 0, bytes, v->stream));
     }
     // the reference paints far -> near with "over"; front-to-back accumulation walks the same list backwards
     bool carry = false;

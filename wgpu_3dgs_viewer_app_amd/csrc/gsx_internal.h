@@ -119,8 +119,9 @@ hipError_t launch_tile_emit(hipStream_t s, uint32_t j0, uint32_t j1, const uint3
                             const uint32_t* cnt, const uint32_t* block_sums, uint32_t tiles_x, uint2* tpairs,
                             uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words,
                             const uint32_t* d_n_vis, const uint32_t* d_entries, uint32_t capacity);
+// ranges_clean: the table is already all-zero (the previous composite cleared what it used)
 hipError_t launch_tile_ranges(hipStream_t s, uint32_t capacity, const uint32_t* d_n, const uint32_t* tkey_sorted,
-                              uint32_t n_tiles, uint2* ranges);
+                              uint32_t n_tiles, uint2* ranges, bool ranges_clean);
 size_t scan_blocks(uint64_t n);
 
 // Multi-GPU exchange support (kernels_shard.hip).
@@ -154,9 +155,9 @@ void quat_to_rows(const float q[4], float r[9]);
 // Compositing and resolve.
 // carry: continue from the (C, T) already in fb (later slabs / models behind); done: saturated-tile bitmap
 // (read to skip tiles when carrying, updated when a tile saturates; nullable).
-hipError_t launch_composite(hipStream_t s, const FrameConsts& f, const uint2* ranges, const uint32_t* list,
+hipError_t launch_composite(hipStream_t s, const FrameConsts& f, uint2* ranges, const uint32_t* list,
                             const Records& rec, float4* fb, bool carry, uint32_t* done, uint32_t row_words,
-                            uint32_t* d_done_count);
+                            uint32_t* d_done_count, bool clear_ranges);
 hipError_t launch_clear_fb(hipStream_t s, float4* fb, uint32_t n_px);
 hipError_t launch_resolve_rgba8(hipStream_t s, const float4* fb, uint32_t n_px, float bg_r, float bg_g, float bg_b,
                                 uint32_t* out_rgba8);

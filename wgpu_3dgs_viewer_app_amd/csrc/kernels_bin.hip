@@ -265,9 +265,11 @@ hipError_t launch_tile_emit(hipStream_t s, uint32_t j0, uint32_t j1, const uint3
 }
 
 hipError_t launch_tile_ranges(hipStream_t s, uint32_t capacity, const uint32_t* d_n, const uint32_t* tkey_sorted,
-                              uint32_t n_tiles, uint2* ranges) {
-    hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)n_tiles, s);
-    if (e != hipSuccess) return e;
+                              uint32_t n_tiles, uint2* ranges, bool ranges_clean) {
+    if (!ranges_clean) {
+        hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)n_tiles, s);
+        if (e != hipSuccess) return e;
+    }
     if (capacity == 0) return hipSuccess;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)capacity + 255) / 256, 4096);
     hipLaunchKernelGGL(k_tile_ranges, dim3(grid), dim3(256), 0, s, d_n, tkey_sorted, ranges);

@@ -18,12 +18,13 @@ namespace gsx {
 constexpr int kBatch = 256;
 
 template <int MODE /* 0 splat (gaussian falloff), 1 constant alpha inside the cutoff */>
-__global__ __launch_bounds__(256) void k_composite(const FrameConsts f, const uint2* __restrict__ ranges,
+__global__ __launch_bounds__(256) void k_composite(const FrameConsts f, uint2* __restrict__ ranges,
                                                     const uint32_t* __restrict__ list,
                                                     const float4* __restrict__ rec_a, const float4* __restrict__ rec_b,
                                                     const float4* __restrict__ rec_c, float4* __restrict__ fb,
                                                     const int carry, uint32_t* __restrict__ done_bits,
-                                                    const uint32_t row_words, uint32_t* __restrict__ done_count) {
+                                                    const uint32_t row_words, uint32_t* __restrict__ done_count,
+                                                    const int clear_ranges) {
     __shared__ float2 s_mean[kBatch];
     __shared__ float4 s_conic[kBatch];
     __shared__ float4 s_rgb[kBatch];
@@ -36,6 +37,8 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConsts f, const ui
     const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
     const uint2 range = ranges[tile];
     const size_t fbo = (size_t)py * f.w_px + px;
+    // progressive mode: leave the range table clean for the next slab (saves a memset per slab)
+    if (clear_ranges && tid == 0 && range.y > range.x) ranges[tile] = make_uint2(0u, 0u);
 
     // Later depth slabs / models behind continue from the (C, T) the framebuffer already holds; a tile
     // with nothing new to blend, or already saturated, leaves it untouched.
@@ -47,18 +50,29 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConsts f, const ui
     }
     bool done = !inside || T < f.t_eps;
 
+    // software pipeline: the gather of batch b+1 (list -> three record planes, dependent random loads) is
+    // in flight while batch b is blended out of LDS
+    float4 pa = make_float4(0, 0, 0, 0), pb = pa, pc4 = pa;
+    if (range.x + tid < range.y) {
+        const uint32_t idx = list[range.x + tid];
+        pa = rec_a[idx];
+        pb = rec_b[idx];
+        pc4 = rec_c[idx];
+    }
     for (uint32_t base = range.x; base < range.y; base += kBatch) {
         // vote + barrier: also protects the LDS batch of the previous iteration
         if (__syncthreads_and(done)) break;
-        const uint32_t e = base + tid;
-        if (e < range.y) {
-            const uint32_t idx = list[e];
-            const float4 a = rec_a[idx];
-            s_mean[tid] = make_float2(a.x, a.y);
-            s_conic[tid] = rec_b[idx];
-            s_rgb[tid] = rec_c[idx];
-        }
+        s_mean[tid] = make_float2(pa.x, pa.y);
+        s_conic[tid] = pb;
+        s_rgb[tid] = pc4;
         __syncthreads();
+        const uint32_t nxt = base + kBatch + tid;
+        if (nxt < range.y) {
+            const uint32_t idx = list[nxt];
+            pa = rec_a[idx];
+            pb = rec_b[idx];
+            pc4 = rec_c[idx];
+        }
         const uint32_t cnt = min((uint32_t)kBatch, range.y - base);
         if (!done) {
             for (uint32_t j = 0; j < cnt; ++j) {
@@ -110,14 +124,16 @@ __global__ __launch_bounds__(256) void k_resolve_rgba8(const float4* __restrict_
     out[i] = R | (G << 8) | (B << 16) | (A << 24);
 }
 
-hipError_t launch_composite(hipStream_t s, const FrameConsts& f, const uint2* ranges, const uint32_t* list,
+hipError_t launch_composite(hipStream_t s, const FrameConsts& f, uint2* ranges, const uint32_t* list,
                             const Records& rec, float4* fb, bool carry, uint32_t* done, uint32_t row_words,
-                            uint32_t* d_done_count) {
+                            uint32_t* d_done_count, bool clear_ranges) {
     dim3 grid(f.tiles_x * f.tiles_y), block(256);
     if (f.display_mode == GSX_DISPLAY_SPLAT)
-        hipLaunchKernelGGL(k_composite<0>, grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count);
+        hipLaunchKernelGGL(k_composite<0>, grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count,
+                           clear_ranges ? 1 : 0);
     else
-        hipLaunchKernelGGL(k_composite<1>, grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count);
+        hipLaunchKernelGGL(k_composite<1>, grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count,
+                           clear_ranges ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -141,7 +141,9 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_onesweep(const uint32_t
                                                                    const uint32_t* __restrict__ d_n, int shift,
                                                                    const uint32_t* __restrict__ ghist /* this pass */,
                                                                    uint32_t* __restrict__ ticket /* [0] ticket, [1] finished */,
-                                                                   u64* __restrict__ status, uint32_t epoch) {
+                                                                   u64* __restrict__ status, uint32_t epoch,
+                                                                   uint32_t* __restrict__ ghist_clear /* last pass: all rows */,
+                                                                   uint32_t ghist_clear_words) {
     __shared__ uint2 s_pairs[kRadixTile];       // tile reordered by digit
     __shared__ uint32_t cnt[kRadixWaves][256];  // per-wave digit counts, then per-wave local offsets
     __shared__ uint32_t s_gbase[256];           // global slot of the tile's local slot 0, per digit
@@ -150,6 +152,10 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_onesweep(const uint32_t
 
     const uint32_t n = d_n ? min(*d_n, n_cap) : n_cap;
     const uint32_t n_tiles = (n + kRadixTile - 1) / kRadixTile;
+    // the launch is sized by n_cap; with a device-side n only min(grid, n_tiles) workgroups have anything to
+    // do — the others leave without touching the ticket (768 same-address atomics alone cost ~9 us)
+    const uint32_t participants = min(gridDim.x, n_tiles);
+    if (blockIdx.x >= participants) return;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
 
     // exclusive scan of this pass's global digit histogram: thread d -> first output slot of digit d
@@ -286,14 +292,19 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_onesweep(const uint32_t
         }
         __syncthreads();  // s_tile, cnt, s_pairs are reused by the next tile
     }
-    // the last workgroup to leave re-arms the ticket for the next launch
+    // the last workgroup to leave re-arms the ticket for the next launch and, after the final pass, clears the
+    // digit histograms so that the next sort on this workspace needs no memset
     if (tid == 0) {
         const uint32_t fin = atomicAdd(&ticket[1], 1u);
-        if (fin == gridDim.x - 1) {
+        s_tile = (fin == participants - 1) ? 1u : 0u;
+        if (s_tile) {
             ticket[1] = 0;
             __hip_atomic_store(&ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    __syncthreads();
+    if (s_tile)
+        for (uint32_t k = tid; k < ghist_clear_words; k += kRadixThreads) ghist_clear[k] = 0;
 }
 
 hipError_t launch_rowscan(hipStream_t s, uint32_t* table, uint32_t nrows, uint32_t nblocks, uint32_t* totals) {
@@ -313,8 +324,7 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
     const uint32_t tiles = radix_tiles(n);
     static const uint32_t grid_limit = getenv("GSX_RADIX_GRID") ? (uint32_t)atoi(getenv("GSX_RADIX_GRID")) : kRadixGrid;
     const uint32_t grid = std::min<uint32_t>(grid_limit, tiles);
-    hipError_t e = hipMemsetAsync(ghist, 0, sizeof(uint32_t) * 256 * passes, s);
-    if (e != hipSuccess) return e;
+    // ghist is zero here: the workspace is cleared at allocation and every sort's last pass clears it again
     const uint32_t hgrid = std::min<uint32_t>(kRadixGrid, (tiles + 3) / 4);
     if (buf.pairs_src)
         hipLaunchKernelGGL(k_radix_global_hist<2>, dim3(hgrid), dim3(kRadixThreads), 0, s,
@@ -329,7 +339,8 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
         const uint32_t epoch = (g_epoch++ & 0x1FFFFFFFu) | (1u << 29);  // 30 bits, never 0
 #define GSX_SWEEP(IN, OUT)                                                                                              \
     hipLaunchKernelGGL((k_radix_onesweep<IN, OUT>), dim3(grid), dim3(kRadixThreads), 0, s, buf.keys_src, buf.vals_src, pin, \
-                       buf.keys_out, buf.vals_out, pout, n, d_n, shift, ghist + 256 * p, ticket, status, epoch)
+                       buf.keys_out, buf.vals_out, pout, n, d_n, shift, ghist + 256 * p, ticket, status, epoch, ghist,         \
+                       last ? 256u * (uint32_t)passes : 0u)
         if (first && buf.pairs_src) {
             if (last) GSX_SWEEP(2, 1); else GSX_SWEEP(2, 0);
         } else if (first && last) {
