@@ -209,27 +209,54 @@ gsx_status gsx_model_download_pod(gsx_viewer* v, const char* key, float* pos, ui
                                   float* cov3d);
 
 /* ---- multi-GPU stage split.  No reference counterpart: the reference renders on one wgpu device
- *      (src/main.rs:85-98).  One process per GPU holds an index shard of the Gaussians; tile row ty of
- *      the screen belongs to rank ty % world.  Per frame and rank:
- *        gsx_preprocess(key)                       project the resident shard
- *        gsx_shard_pack(...)                       visible records grouped by destination rank
+ *      (src/main.rs:85-98).  One process per GPU holds an index shard of the Gaussians; the screen is cut into
+ *      `world` contiguous bands of tile rows, band g = rank g.  Per frame and rank:
+ *        gsx_preprocess(key)                              project the resident shard
+ *        gsx_shard_pack(key, world, windows, ..)          the records some tile's depth-key window [lo, hi) admits,
+ *                                                         grouped by destination (first frame: no windows = all)
  *        [RCCL all-to-all of the 48-byte records, done by the caller]
- *        gsx_shard_import(...); gsx_sort(key)      received records become the frame's record set
- *        gsx_render(&key, 1)                       bins + composites only this rank's tile rows
- *        gsx_shard_pack_strip(...)                 this rank's rows, packed
- *        [RCCL gather of the strips]  gsx_shard_unpack_strips(...) on the gathering rank ---- */
+ *        gsx_shard_import(.., windows); gsx_sort(key); gsx_render(&key, 1)   this rank's band, progressive slabs;
+ *                                                         a tile bins exactly the records its window admits
+ *        gsx_shard_feedback(..) -> per-tile saturation depth keys   one small all-gather: verification AND the
+ *                                                                   next frame's windows (caller's policy)
+ *        only if a tile with a bounded window is still open: gsx_shard_pack(key, world, windows2, ..) with
+ *        windows2 = [hi, inf) for those tiles and [0, 0) elsewhere -> all-to-all -> gsx_shard_import(.., windows2)
+ *        -> gsx_sort -> gsx_render_more(&key, 1)          (composited behind what the tiles hold)
+ *        [RCCL all-gather of the bands straight into the caller's padded framebuffer]
+ *      Pixels equal the single-GPU frame bit for bit whatever was predicted. ---- */
 #define GSX_RECORD_BYTES 48u /* mean.xy rect.xy | conic.abc opacity | rgb depth */
-/* counts[world] (host) = records per destination; d_send (device) receives them grouped by destination,
- * ascending local index inside each group.  Synchronises. */
-gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, void* d_send, uint64_t capacity_records,
-                          uint64_t* counts);
-/* d_recv (device): n_records records ordered by (source rank, source index).  Replaces the model's
- * projection results for this frame and restricts binning to tile rows with row % world == rank. */
+typedef struct gsx_shard_layout_t {
+    uint32_t rows_per_rank, row_lo, row_hi; /* band of this rank: tile rows [row_lo, row_hi) */
+    uint64_t band_bytes;                    /* rows_per_rank * 16 * width * 16: what every rank contributes */
+    uint64_t band_offset_bytes;             /* of this rank's band inside the framebuffer */
+    uint64_t padded_framebuffer_bytes;      /* world * band_bytes >= width * height * 16 */
+} gsx_shard_layout_t;
+gsx_status gsx_shard_layout(gsx_viewer* v, uint32_t world, uint32_t rank, gsx_shard_layout_t* out);
+/* Render into caller-owned DEVICE memory (row-major [height][width] float4; may be padded below). NULL restores
+ * the internal framebuffer. */
+gsx_status gsx_viewer_set_external_framebuffer(gsx_viewer* v, void* d_ptr, uint64_t bytes);
+/* Tile windows: d_tile_window (device, nullable, copied by the call) = one {uint32 lo, uint32 hi} pair per tile,
+ * row-major [height/16 rounded up][width/16 rounded up]; a tile admits a record iff lo <= depth key < hi.
+ * NULL = every tile admits everything.
+ *
+ * counts[world] (host) = records per destination; d_send (device) receives the travelling records grouped by
+ * destination, ascending local index inside each group.  A visible record travels to rank g if its tile rectangle
+ * holds, inside g's band, a tile that admits it.  Synchronises. */
+gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, const uint32_t* d_tile_window, void* d_send,
+                          uint64_t capacity_records, uint64_t* counts);
+/* d_recv (device): n_records records ordered by (source rank, source index).  They become the model's active
+ * record set for gsx_sort / gsx_render(_more); binning is restricted to this rank's band and to the tiles that
+ * admit the record (the receiving side of gsx_shard_pack's predicate, so that every tile composites a gap-free
+ * depth prefix in each round).  The model's own projection stays available for a second gsx_shard_pack. */
 gsx_status gsx_shard_import(gsx_viewer* v, const char* key, const void* d_recv, uint64_t n_records, uint32_t world,
-                            uint32_t rank);
-gsx_status gsx_shard_strip_bytes(gsx_viewer* v, uint32_t world, uint64_t* out_bytes);
-gsx_status gsx_shard_pack_strip(gsx_viewer* v, uint32_t world, uint32_t rank, void* d_strip, uint64_t strip_bytes);
-gsx_status gsx_shard_unpack_strips(gsx_viewer* v, uint32_t world, const void* d_all, uint64_t bytes);
+                            uint32_t rank, const uint32_t* d_tile_window);
+/* Enqueues the write of *out_words = rows_per_rank * (width/16 rounded up) u32 into DEVICE memory: for every tile of
+ * this rank's band, the depth key of the splat that saturated its last pixel this frame, 0 = still open (also for
+ * padding rows below the frame).  An all-gather over ranks is the map of the whole (padded) frame. */
+gsx_status gsx_shard_feedback_words(gsx_viewer* v, uint32_t world, uint32_t* out_words);
+gsx_status gsx_shard_feedback(gsx_viewer* v, const char* key, uint32_t world, uint32_t rank, void* d_out_u32);
+/* Second round of the same frame: like gsx_render but continues from the framebuffer / saturated-tile state. */
+gsx_status gsx_render_more(gsx_viewer* v, const char* const* keys, uint32_t n_keys);
 
 /* ---- PLY I/O (host side; no GPU needed).  gs::Gaussians::read_ply_header / PlyHeader::count /
  *      read_ply_gaussians + gs::Gaussian::from(PlyGaussianPod) (app.rs:1053-1096) and write_ply (app.rs:897-947).

@@ -37,3 +37,92 @@ def oracle_model_frame(g, cam, w, h, mt=None, fb=None, mask=None, **kw):
         fb = oracle.new_framebuffer(f)
     oracle.rasterize(f, pr, idx, nvis, fb)
     return f, pr, idx, nvis, fb
+
+
+class ThreadHub:
+    """Shared state of ``ThreadComm``: `world` ranks of ONE process (threads), each with its own viewer + stream."""
+
+    def __init__(self, world, timeout=120.0):
+        import threading
+
+        self.world = world
+        self.barrier = threading.Barrier(world, timeout=timeout)
+        self.slots = [None] * world
+
+
+class ThreadComm:
+    """Stand-in for ``parallel.TorchComm`` that lets `world` ranks run the real exchange protocol on one device:
+    the collectives are device-to-device copies between the ranks' buffers, delivered exactly in the order
+    ``all_to_all_single`` / ``all_gather_into_tensor`` deliver them (by source rank).  TEST ONLY."""
+
+    def __init__(self, hub, rank):
+        self.hub, self.rank = hub, rank
+        self.bytes_sent = 0
+
+    @staticmethod
+    def _sync(t):
+        import torch
+
+        if t.is_cuda:
+            torch.cuda.current_stream().synchronize()
+
+    def all_to_all_counts(self, counts, device):
+        h = self.hub
+        h.slots[self.rank] = list(counts)
+        h.barrier.wait()
+        out = [int(h.slots[src][self.rank]) for src in range(h.world)]
+        h.barrier.wait()
+        return out
+
+    def all_to_all_records(self, recv, send, recv_counts, send_counts):
+        h = self.hub
+        self._sync(send)
+        h.slots[self.rank] = (send, list(send_counts))
+        self.bytes_sent += sum(c for g, c in enumerate(send_counts) if g != self.rank) * send.shape[1] * 4
+        h.barrier.wait()
+        o = 0
+        for src in range(h.world):
+            s, sc = h.slots[src]
+            off, n = sum(sc[: self.rank]), sc[self.rank]
+            assert n == recv_counts[src]
+            if n:
+                recv[o:o + n].copy_(s[off:off + n])
+            o += n
+        self._sync(recv)
+        h.barrier.wait()
+
+    def all_gather(self, out, inp):
+        h = self.hub
+        self._sync(inp)
+        h.slots[self.rank] = inp
+        h.barrier.wait()
+        n = inp.numel()
+        for src in range(h.world):
+            out[src * n:(src + 1) * n].copy_(h.slots[src])
+        self._sync(out)
+        h.barrier.wait()
+
+
+def run_ranks(world, fn):
+    """Run fn(rank, comm) on `world` threads; re-raises the first failure (and releases the others)."""
+    import threading
+
+    hub = ThreadHub(world)
+    errors, results = [], [None] * world
+
+    def body(r):
+        try:
+            results[r] = fn(r, ThreadComm(hub, r))
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+            hub.barrier.abort()
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    real = [e for e in errors if not isinstance(e, threading.BrokenBarrierError)]
+    if real or errors:
+        raise (real or errors)[0]
+    return results

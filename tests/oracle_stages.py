@@ -25,14 +25,23 @@ def records_from_projection(pr):
     return rec, rect
 
 
-def pack_by_destination(pr, world):
-    """Records grouped by destination rank (tile row % world), ascending index inside each group."""
+def pack_by_destination(pr, world, tiles_x, tiles_y, window=None):
+    """``gsx_shard_pack`` restated: a visible record goes to rank g (band = tile rows [g*rpr, (g+1)*rpr)) if its
+    rectangle holds, inside the band, a tile whose window [lo, hi) (uint32 [tiles_y, tiles_x, 2]; None = everything)
+    contains the record's depth key.  Groups in rank order, ascending index."""
     rec, rect = records_from_projection(pr)
-    y0, y1 = rect[:, 1].astype(np.int64), rect[:, 3].astype(np.int64)
+    keys = np.ascontiguousarray(rec[:, 11]).view(np.uint32).astype(np.int64)
+    rpr = (tiles_y + world - 1) // world
     groups, counts = [], []
     for g in range(world):
-        first = y0 + ((g - y0) % world)
-        sel = first < y1
+        y0 = np.maximum(rect[:, 1].astype(np.int64), g * rpr)
+        y1 = np.minimum(rect[:, 3].astype(np.int64), (g + 1) * rpr)
+        sel = y0 < y1
+        if window is not None:
+            lo, hi = window[..., 0].astype(np.int64), window[..., 1].astype(np.int64)
+            for i in np.nonzero(sel)[0]:
+                sl = (slice(y0[i], y1[i]), slice(rect[i, 0], rect[i, 2]))
+                sel[i] = bool(((lo[sl] <= keys[i]) & (keys[i] < hi[sl])).any())
         groups.append(rec[sel])
         counts.append(int(sel.sum()))
     return (np.concatenate(groups) if groups else rec[:0]), counts
@@ -66,16 +75,43 @@ class OracleStages:
         self.frame = oracle.frame_setup(cam.view(), cam.projection(w / h), w, h, mt.pos, mt.quat(), mt.scale)
         self.size = (w, h)
 
-    def _render_projection(self, pr, world=1, rank=0):
+    def _band(self, world, rank):
+        rpr = (self.frame.tiles_y + world - 1) // world
+        return rpr, min(rank * rpr, self.frame.tiles_y), min((rank + 1) * rpr, self.frame.tiles_y)
+
+    def _render_projection(self, pr, world=1, rank=0, more=False, window=None):
         f = self.frame
         idx, nvis = oracle.depth_sort(pr["key"])
         off, lst = oracle.tile_lists(f, idx, nvis, pr["rect"])
-        fb = oracle.new_framebuffer(f)
-        oracle.composite_tiles(f, pr, off, lst, fb)
-        for ty in range(f.tiles_y):
-            if ty % world != rank:
-                fb[ty * 16:(ty + 1) * 16] = (0, 0, 0, 1)
+        tile_of = np.repeat(np.arange(off.size - 1), np.diff(off).astype(np.int64))
+        if window is not None:  # a tile bins only the records its window admits
+            k = pr["key"][lst].astype(np.int64)
+            w = window.reshape(-1, 2).astype(np.int64)
+            keep = (w[tile_of, 0] <= k) & (k < w[tile_of, 1])
+            lst = np.ascontiguousarray(lst[keep])
+            tile_of = tile_of[keep]
+            cnt = np.bincount(tile_of, minlength=off.size - 1)
+            off = np.concatenate([[0], np.cumsum(cnt)]).astype(off.dtype)
+        # deepest key binned into each tile: an upper bound of the depth at which a saturated tile saturated
+        deepest = np.zeros(off.size - 1, np.uint32)
+        np.maximum.at(deepest, tile_of, pr["key"][lst])
+        deepest = deepest.reshape(f.tiles_y, f.tiles_x)
+        self._deepest = np.maximum(self._deepest, deepest) if more else deepest
+        # this set lies BEHIND what the framebuffer holds: composite it alone, then put the old frame in front
+        back = oracle.new_framebuffer(f)
+        oracle.composite_tiles(f, pr, off, lst, back)
+        if more:
+            front = self._fb
+            fb = np.empty_like(front)
+            fb[..., :3] = front[..., :3] + front[..., 3:4] * back[..., :3]
+            fb[..., 3] = front[..., 3] * back[..., 3]
+        else:
+            fb = back
+        _, lo, hi = self._band(world, rank)
+        fb[: lo * 16] = (0, 0, 0, 1)
+        fb[hi * 16:] = (0, 0, 0, 1)
         self._fb = fb
+        self._band_rows = (lo, hi)
         self._stats = dict(n_gaussians=pr["key"].size, n_visible=nvis, n_tile_entries=int(lst.size))
         return self._stats
 
@@ -86,51 +122,52 @@ class OracleStages:
         pos, color, sh, cov = self.pod
         return self._render_projection(oracle.project(self.frame, pos, color, sh, cov))
 
-    def project_and_pack(self, key, world):
+    def begin_frame(self, key, world, rank):
         pos, color, sh, cov = self.pod
-        pr = oracle.project(self.frame, pos, color, sh, cov)
-        send, counts = pack_by_destination(pr, world)
+        self._pr = oracle.project(self.frame, pos, color, sh, cov)
+
+    def pack(self, key, world, window=None):
+        send, counts = pack_by_destination(self._pr, world, self.frame.tiles_x, self.frame.tiles_y, window)
         return torch.from_numpy(np.ascontiguousarray(send)), counts
 
     def alloc_records(self, n):
         return torch.empty((n, 12), dtype=torch.float32)
 
-    def render_records(self, key, recv, n, world, rank):
-        return self._render_projection(projection_from_records(recv.numpy()[:n]), world, rank)
+    def render_records(self, key, recv, n, world, rank, more=False, window=None):
+        self._world, self._rank = world, rank
+        return self._render_projection(projection_from_records(recv.numpy()[:n]), world, rank, more, window)
 
-    def _rows_per_rank(self, world):
-        return (self.frame.tiles_y + world - 1) // world
+    def feedback(self, key, world, rank):
+        """Saturation depth keys of this rank's band (rows_per_rank x tiles_x, 0 = open): a tile is saturated when all
+        its pixels have T < 1e-4; its key is the deepest one binned into it."""
+        f = self.frame
+        rpr, lo, hi = self._band(world, rank)
+        out = np.zeros((rpr, f.tiles_x), np.uint32)
+        for ty in range(lo, hi):
+            for tx in range(f.tiles_x):
+                tile = self._fb[ty * 16: ty * 16 + 16, tx * 16: tx * 16 + 16, 3]
+                if tile.size and bool((tile < 1e-4).all()):
+                    out[ty - lo, tx] = max(int(self._deepest[ty, tx]), 1)
+        return torch.from_numpy(out.view(np.int32).reshape(-1).copy())
 
-    def own_strip(self, world, rank):
+    def own_band(self):
         w, h = self.size
-        rpr = self._rows_per_rank(world)
-        strip = np.zeros((rpr, 16, w, 4), np.float32)
-        strip[..., 3] = 1
-        for r in range(rpr):
-            ty = rank + r * world
-            y0, y1 = ty * 16, min(ty * 16 + 16, h)
-            if y0 < h:
-                strip[r, : y1 - y0] = self._fb[y0:y1]
-        return torch.from_numpy(strip.reshape(-1))
+        rpr, lo, hi = self._band(self._world, self._rank)
+        band = np.zeros((rpr * 16, w, 4), np.float32)
+        rows = self._fb[lo * 16: min(hi * 16, h)]
+        band[: rows.shape[0]] = rows
+        return torch.from_numpy(band.reshape(-1))
 
-    def gather_buffer(self, strip, world):
-        return torch.empty(world * strip.numel(), dtype=strip.dtype)
-
-    def assemble(self, gathered, world):
+    def gather_target(self):
         w, h = self.size
-        rpr = self._rows_per_rank(world)
-        fb = np.zeros((h, w, 4), np.float32)
-        parts = gathered.numpy().reshape(world, -1)
-        for g, p in enumerate(parts):
-            s = p.reshape(rpr, 16, w, 4)
-            for r in range(rpr):
-                ty = g + r * world
-                y0, y1 = ty * 16, min(ty * 16 + 16, h)
-                if y0 < h:
-                    fb[y0:y1] = s[r, : y1 - y0]
-        self._fb = fb
+        rpr, _, _ = self._band(self._world, self._rank)
+        self._gather = torch.zeros(self._world * rpr * 16 * w * 4, dtype=torch.float32)
+        return self._gather
 
     def framebuffer(self):
+        if getattr(self, "_gather", None) is not None:
+            w, h = self.size
+            return self._gather.numpy().reshape(-1, w, 4)[:h].copy()
         return self._fb
 
     def poll(self):

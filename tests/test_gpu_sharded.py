@@ -1,7 +1,9 @@
-"""GPU: the multi-GPU stage kernels (pack by destination, import, row-restricted binning, strip pack /
-unpack) emulated on ONE device: `world` viewers each hold an index shard, records are exchanged by plain
-device copies in the order RCCL's all-to-all would deliver them, and the assembled frame must equal the
-single-viewer frame bit-for-bit.  The pack kernel is also checked against the oracle's routing."""
+"""GPU: the multi-GPU path on ONE device.  `world` ranks run as threads, each with its own viewer, stream and index
+shard, and execute the REAL protocol of ``parallel.ShardedViewer`` (pack by destination band -> exchange -> import
+with the tile filter -> sort -> band-restricted progressive compositing -> feedback -> optional verified second
+exchange -> band all-gather); only the collectives are replaced by device copies in the order RCCL delivers them
+(tests/common.py ThreadComm).  Every rank's assembled frame must equal the single-viewer frame BIT FOR BIT whatever
+the prediction was.  The pack kernel is also checked against the oracle's routing."""
 import ctypes as C
 
 import numpy as np
@@ -14,76 +16,122 @@ from wgpu_3dgs_viewer_app_amd import _lib, camera, parallel
 from wgpu_3dgs_viewer_app_amd.hip_stages import HipStages
 
 pytestmark = pytest.mark.gpu
+KEY_ALL = parallel.KEY_ALL
+N, W, H = 9000, 208, 152
+POSES = (57, 58, 61, 90)
 
 
-def _single(g, cam, w, h):
+def _scene():
+    return common.small_scene(N, 91, scale_mul=14.0)  # opaque enough that tiles saturate
+
+
+def _single_frames(g):
+    out = []
     st = HipStages()
     st.load_shard("shard", g, 0, g.shape[0])
-    st.set_uniforms("shard", cam, (w, h))
-    st.render_local("shard")
-    stats = st.stats("shard")
-    fb = st.framebuffer()
+    for pose in POSES:
+        st.set_uniforms("shard", camera.orbit_pose(pose), (W, H))
+        st.render_local("shard")
+        out.append((st.framebuffer().copy(), dict(st.stats("shard"))))
     st.close()
-    return fb, stats
+    return out
 
 
-@pytest.mark.parametrize("world", [2, 3, 8])
-def test_emulated_world_matches_single_viewer(world):
+@pytest.mark.parametrize("world,mode", [(2, "off"), (3, "natural"), (8, "natural"), (2, "all_saturated"), (5, "all_open"),
+                                        (4, "stale")])
+def test_threaded_world_matches_single_viewer(world, mode):
+    g = _scene()
+    ref = _single_frames(g)
+    tiles = ((H + 15) // 16, (W + 15) // 16)
+    assert ref[0][0][..., 3].min() < 1e-4, "the scene must saturate some pixels"
+
+    def rank_main(rank, comm):
+        s0, c = parallel.shard_range(N, rank, world)
+        v = parallel.ShardedViewer(world=world, rank=rank, use_dist=True, comm=comm)
+        v.load_shard(g[s0:s0 + c], s0, N)
+        frames, rounds = [], []
+        rng = np.random.default_rng(5)
+        for pose in POSES:
+            if mode == "all_saturated":   # every tile refuses all but the nearest records: verified second exchange
+                v._limit = np.full(tiles, 0x40400000, np.uint32)
+            elif mode == "all_open":
+                v._limit = np.full(tiles, KEY_ALL, np.uint32)
+            elif mode == "stale":   # limits unrelated to the frame (same on every rank): random depths 2..8, a third unbounded
+                lim = rng.uniform(2.0, 8.0, tiles).astype(np.float32).view(np.uint32)
+                v._limit = np.where(rng.random(tiles) < 0.33, np.uint32(KEY_ALL), lim).astype(np.uint32)
+            elif mode == "off":
+                v.speculate = False
+            v.render_frame(camera.orbit_pose(pose), (W, H))
+            v.poll()
+            frames.append(v.framebuffer().copy())
+            rounds.append(v.rounds)
+        sent = comm.bytes_sent
+        v.close()
+        return frames, rounds, sent
+
+    res = common.run_ranks(world, rank_main)
+    for rank, (frames, rounds, _) in enumerate(res):
+        for k, fb in enumerate(frames):
+            assert np.array_equal(fb, ref[k][0]), (f"rank {rank} frame {k} ({mode}) differs from the single-GPU frame: "
+                                                   f"L-inf {np.abs(fb - ref[k][0]).max()}")
+        if mode in ("off", "all_open"):
+            assert rounds == [1] * len(POSES)
+        elif mode == "all_saturated":
+            assert rounds == [2] * len(POSES)
+        elif mode == "natural":
+            assert rounds[0] == 1  # no prediction yet: one full exchange
+    print(mode, "rounds", res[0][1], "bytes sent by rank 0", res[0][2])
+
+
+def test_speculation_sends_fewer_records():
+    """The point of the prediction: with it, fewer bytes cross the links than with one full exchange."""
+    g = _scene()
+    world = 4
+
+    def run(speculate):
+        def rank_main(rank, comm):
+            s0, c = parallel.shard_range(N, rank, world)
+            v = parallel.ShardedViewer(world=world, rank=rank, use_dist=True, comm=comm)
+            v.speculate = speculate
+            v.load_shard(g[s0:s0 + c], s0, N)
+            for pose in (57, 57, 57, 58):
+                v.render_frame(camera.orbit_pose(pose), (W, H))
+                v.poll()
+            v.close()
+            return comm.bytes_sent
+        return sum(common.run_ranks(world, rank_main))
+
+    full, spec = run(False), run(True)
+    assert spec < full, (spec, full)
+
+
+def test_pack_matches_oracle_routing():
     import torch
 
-    n, w, h = 9000, 208, 152
-    g = common.small_scene(n, 91)
+    world = 3
     cam = camera.orbit_pose(57)
-    ref, ref_stats = _single(g, cam, w, h)
-
-    stages = []
-    sends, counts = [], []
-    for r in range(world):
-        s0, c = parallel.shard_range(n, r, world)
+    g = _scene()
+    f = common.oracle_frame(cam, W, H)
+    rng = np.random.default_rng(3)
+    tiles = ((H + 15) // 16, (W + 15) // 16)
+    lim = np.where(rng.random(tiles) < 0.4, np.uint32(KEY_ALL), rng.uniform(2.0, 8.0, tiles).astype(np.float32).view(np.uint32)).astype(np.uint32)
+    need = rng.random(tiles) < 0.3
+    for rank in range(world):
+        s0, c = parallel.shard_range(N, rank, world)
         st = HipStages(use_torch=True)
-        st.load_shard("shard", g[s0:s0 + c], s0, n)
-        st.set_uniforms("shard", cam, (w, h))
-        with st.stream_ctx():
-            send, cnt = st.project_and_pack("shard", world)
-            st.poll()
-        # routing parity with the oracle on this shard
-        f = common.oracle_frame(cam, w, h)
+        st.load_shard("shard", g[s0:s0 + c], s0, N)
+        st.set_uniforms("shard", cam, (W, H))
         pr = oracle.project(f, *oracle.convert(g[s0:s0 + c]))
-        rsend, rcnt = pack_by_destination(pr, world)
-        assert cnt == rcnt
-        assert np.array_equal(send[: sum(cnt)].cpu().numpy().view(np.uint32), rsend.view(np.uint32)), "packed records differ"
-        stages.append(st)
-        sends.append(send[: sum(cnt)].clone())
-        counts.append(cnt)
-    torch.cuda.synchronize()
-
-    strips, total_entries = [], 0
-    for r, st in enumerate(stages):
-        # what all_to_all_single delivers to rank r: from every source rank, its group for destination r
-        chunks = []
-        for src in range(world):
-            off = sum(counts[src][:r])
-            chunks.append(sends[src][off:off + counts[src][r]])
-        recv = torch.cat(chunks) if chunks else sends[0][:0]
         with st.stream_ctx():
-            st.render_records("shard", recv.contiguous(), recv.shape[0], world, r)
-            stats = st.stats("shard")
-            strips.append(st.own_strip(world, r).clone())
-            st.poll()
-        total_entries += stats["n_tile_entries"]
-    torch.cuda.synchronize()
-    assert total_entries == ref_stats["n_tile_entries"], "row ownership must partition the tile entries"
-
-    st0 = stages[0]
-    with st0.stream_ctx():
-        gathered = st0.gather_buffer(strips[0], world)
-        gathered.view(world, -1).copy_(torch.stack(strips))
-        st0.assemble(gathered, world)
-        st0.poll()
-    fb = st0.framebuffer()
-    for st in stages:
+            st.begin_frame("shard", world, rank)
+            for window in (None, parallel.windows_first(lim), parallel.windows_second(lim, need)):
+                send, cnt = st.pack("shard", world, window)
+                st.poll()
+                torch.cuda.synchronize()
+                rsend, rcnt = pack_by_destination(pr, world, f.tiles_x, f.tiles_y, window)
+                assert cnt == rcnt, (cnt, rcnt)
+                assert np.array_equal(send[: sum(cnt)].cpu().numpy().view(np.uint32), rsend.view(np.uint32)), "packed records differ"
         st.close()
-    assert np.array_equal(fb, ref), f"sharded frame differs from single-GPU frame: L-inf {np.abs(fb - ref).max()}"
 
 
 def test_pack_capacity_error():
@@ -98,5 +146,5 @@ def test_pack_capacity_error():
     small = torch.empty((4, 12), dtype=torch.float32, device="cuda")
     counts = (C.c_uint64 * 2)()
     with pytest.raises(_lib.GsxError):
-        _lib.check(v._L.gsx_shard_pack(v._h, b"shard", 2, small.data_ptr(), 4, counts))
+        _lib.check(v._L.gsx_shard_pack(v._h, b"shard", 2, None, small.data_ptr(), 4, counts))
     st.close()

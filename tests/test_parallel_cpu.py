@@ -25,41 +25,99 @@ def _free_port():
     return p
 
 
-def _single_frame():
-    g = common.small_scene(N, SEED)
-    st = OracleStages()
-    v = parallel.ShardedViewer(world=1, rank=0, use_dist=False, stages=st)
-    v.load_shard(g, 0, N)
-    v.render_frame(camera.orbit_pose(POSE), (W, H))
-    return v.framebuffer().copy()
-
-
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        g = common.small_scene(N, SEED)
+        g = common.small_scene(N, SEED, scale_mul=14.0)  # opaque enough that many tiles saturate
         start, count = parallel.shard_range(N, rank, world)
         v = parallel.ShardedViewer(world=world, rank=rank, use_dist=True, stages=OracleStages())
         v.load_shard(g[start:start + count], start, N)
-        for pose in (POSE, POSE):  # twice: buffers are reused across frames
+        tiles = ((H + 15) // 16, (W + 15) // 16)
+        rounds, frames = [], []
+        for i, pose in enumerate(POSES):
+            if mode == "all_saturated":      # worst limits: every tile refuses all but the nearest records -> verified second exchange
+                v._limit = np.full(tiles, 0x40400000, np.uint32)
+            elif mode == "all_open":         # unbounded windows on every tile -> everything travels in one exchange
+                v._limit = np.full(tiles, parallel.KEY_ALL, np.uint32)
+            elif mode == "off":
+                v.speculate = False
             v.render_frame(camera.orbit_pose(pose), (W, H))
+            rounds.append(v.rounds)
+            if rank == 0:
+                frames.append(v.framebuffer())
         if rank == 0:
-            np.save(out_path, v.framebuffer())
+            np.save(out_path, np.stack(frames))
+            np.save(out_path + ".rounds.npy", np.array(rounds))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_frame_equals_single_process(world, tmp_path):
-    ref = _single_frame()
+POSES = (33, 36, 60)
+
+
+def _single_frames():
+    g = common.small_scene(N, SEED, scale_mul=14.0)
+    out = []
+    for pose in POSES:
+        v = parallel.ShardedViewer(world=1, rank=0, use_dist=False, stages=OracleStages())
+        v.load_shard(g, 0, N)
+        v.render_frame(camera.orbit_pose(pose), (W, H))
+        out.append(v.framebuffer().copy())
+    return np.stack(out)
+
+
+@pytest.mark.parametrize("world,mode", [(2, "off"), (3, "natural"), (2, "all_saturated"), (3, "all_open"), (2, "natural")])
+def test_sharded_frames_equal_single_process(world, mode, tmp_path):
+    """Index shards + band routing + (speculative) exchange + band gather reproduce the single-process oracle frames,
+    whatever the prediction: off = one full exchange; natural = frame k uses frame k-1's feedback; all_saturated forces
+    the verified second exchange; all_open sends every record in one exchange."""
+    ref = _single_frames()
     out = str(tmp_path / "fb.npy")
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, mode), nprocs=world, join=True)
     fb = np.load(out)
+    rounds = list(np.load(out + ".rounds.npy"))
     assert fb.shape == ref.shape
-    assert np.array_equal(fb, ref), f"sharded frame differs: L-inf {np.abs(fb - ref).max()}"
+    if mode in ("off", "all_open"):
+        assert rounds == [1, 1, 1]
+        assert np.array_equal(fb, ref), f"sharded frames differ: L-inf {np.abs(fb - ref).max()}"
+    else:
+        if mode == "all_saturated":
+            assert rounds == [2, 2, 2]
+        else:
+            print("natural rounds", rounds)
+            assert rounds[0] == 1  # the first frame has no prediction: one full exchange
+        # a saturated tile (every pixel T < t_epsilon = 1e-4) takes no deeper record, exactly like the product's early
+        # termination: such pixels differ from the untruncated oracle frame by < t_epsilon x colour; every other pixel
+        # matches up to the one extra float32 multiply-add of this adapter's (front) over (back) merge
+        err = np.abs(fb - ref).max(axis=-1)
+        open_px = ref[..., 3] >= 1e-4
+        assert err[open_px].max() <= 2e-6
+        assert err.max() <= 1e-4 * max(1.0, float(ref[..., :3].max()))
+    assert ref[..., 3].min() < 1e-4, "the test scene must saturate some pixels"
+
+
+def test_limit_policy():
+    import struct
+
+    bits = lambda x: struct.unpack("<I", struct.pack("<f", x))[0]
+    sat = np.zeros((6, 7), np.uint32)            # 0 = open
+    sat[1:5, 1:6] = bits(4.0)
+    sat[2, 3] = bits(8.0)
+    lim = parallel.next_limits(sat, 0.25, 1)
+    assert lim[0, 0] == parallel.KEY_ALL and lim[1, 1] == parallel.KEY_ALL      # an open neighbour: unbounded
+    assert lim[3, 3] == bits(10.0) and lim[2, 3] == bits(10.0)                  # 1.25 x the deepest neighbour
+    assert lim[3, 1] == parallel.KEY_ALL and lim[2, 5] == parallel.KEY_ALL
+    full = np.full((3, 3), bits(4.0), np.uint32)
+    assert (parallel.next_limits(full, 0.25, 2) == bits(5.0)).all()             # outside the frame counts as nothing
+    w1 = parallel.windows_first(lim)
+    assert (w1[..., 0] == 0).all() and np.array_equal(w1[..., 1], lim)
+    need = np.zeros_like(lim, bool)
+    need[3, 3] = True
+    w2 = parallel.windows_second(lim, need)
+    assert tuple(w2[3, 3]) == (bits(10.0), parallel.KEY_ALL) and w2.reshape(-1, 2).any(1).sum() == 1
 
 
 def test_shard_ranges_cover():
@@ -82,11 +140,20 @@ def test_pack_routes_every_touched_row():
     pr = oracle.project(f, *oracle.convert(g))
     vis = pr["key"] != 0xFFFFFFFF
     for world in (1, 2, 5, 8):
-        send, counts = pack_by_destination(pr, world)
+        send, counts = pack_by_destination(pr, world, f.tiles_x, f.tiles_y)
         assert send.shape[0] == sum(counts)
         rows = [set(range(r[1], r[3])) for r in pr["rect"][vis]]
+        rpr = (f.tiles_y + world - 1) // world
         for gdst in range(world):
-            expect = sum(1 for rs in rows if any(ty % world == gdst for ty in rs))
+            expect = sum(1 for rs in rows if any(ty // rpr == gdst for ty in rs))
             assert counts[gdst] == expect
+        # uniform windows split the set by depth: [0, mid) + [mid, inf) = everything, disjoint
+        mid = int(np.median(pr["key"][vis]))
+        lim = np.full((f.tiles_y, f.tiles_x), mid, np.uint32)
+        front = pack_by_destination(pr, world, f.tiles_x, f.tiles_y, parallel.windows_first(lim))[1]
+        back = pack_by_destination(pr, world, f.tiles_x, f.tiles_y, parallel.windows_second(lim, np.ones(lim.shape, bool)))[1]
+        assert [a + b for a, b in zip(front, back)] == counts
+        assert pack_by_destination(pr, world, f.tiles_x, f.tiles_y, parallel.windows_first(np.full_like(lim, parallel.KEY_ALL)))[1] == counts
+        assert pack_by_destination(pr, world, f.tiles_x, f.tiles_y, parallel.windows_second(lim, np.zeros(lim.shape, bool)))[1] == [0] * world
         if world == 1:
             assert counts[0] == vis.sum()

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Run the real N-rank exchange protocol (parallel.ShardedViewer) on ONE GPU: N ranks as threads, each with an index
+shard of the scene, collectives replaced by device copies (tests/common.py ThreadComm).  Reports what decides the
+multi-GPU frame rate and cannot be seen on a 1-GPU box otherwise: bytes every rank puts on the links per frame, how
+often the verified second exchange is needed, and the per-pass GPU time of each rank (event-timed; the ranks share
+the device here, so passes that overlap are inflated — read them as upper bounds).  Dev tool, not part of the product."""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from tests import common  # noqa: E402
+from wgpu_3dgs_viewer_app_amd import camera, parallel, scene  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--world", type=int, default=8)
+ap.add_argument("--frames", type=int, default=30)
+ap.add_argument("--first", type=int, default=0, help="first orbit pose")
+ap.add_argument("--workload", default="cfg4")
+ap.add_argument("--no-speculate", action="store_true")
+ap.add_argument("--margin", type=float, default=0.5)
+ap.add_argument("--radius", type=int, default=3)
+args = ap.parse_args()
+n, sh, w, h, seed = scene.CONFIGS[args.workload]
+world = args.world
+
+
+def rank_main(rank, comm):
+    s0, c = parallel.shard_range(n, rank, world)
+    v = parallel.ShardedViewer(world=world, rank=rank, use_dist=True, comm=comm)
+    v.speculate = not args.no_speculate
+    v.margin = args.margin
+    v.radius = args.radius
+    v.debug = rank == 0
+    v.load_shard(scene.synthetic_gaussians(n, seed, sh, s0, c), s0, n)
+    v.poll()
+    rounds, sent = [], []
+    for f in range(args.frames + 2):
+        if f == 2:
+            v.set_pass_timing(True)
+            v.get_pass_timing()
+        b0 = comm.bytes_sent
+        v.render_frame(camera.orbit_pose(args.first + f), (w, h))
+        v.poll()
+        if f >= 2:
+            rounds.append(v.rounds)
+            sent.append(comm.bytes_sent - b0)
+    t = v.get_pass_timing()
+    stats = v.last_stats()
+    if rank == 0:
+        for d in v.debug_log:
+            print("need", d)
+    v.close()
+    return dict(rank=rank, rounds=rounds, sent_MB=float(np.mean(sent)) / 1e6, sent_max_MB=float(np.max(sent)) / 1e6,
+                pass_ms={k: round(x["ms"] / args.frames, 4) for k, x in t.items()}, stats=stats)
+
+
+res = common.run_ranks(world, rank_main)
+for r in res:
+    print(json.dumps(r))
+two = float(np.mean([x == 2 for x in res[0]["rounds"]]))
+print(f"world {world} {args.workload} speculate={not args.no_speculate} margin={args.margin} radius={args.radius}: mean MB sent per rank per frame "
+      f"{np.mean([r['sent_MB'] for r in res]):.2f} (max rank {max(r['sent_MB'] for r in res):.2f}), "
+      f"frames needing the second exchange: {100 * two:.0f} %")

@@ -26,7 +26,8 @@ EXPORTS = (
     "gsx_render_frame", "gsx_download_framebuffer", "gsx_download_rgba8", "gsx_framebuffer_device_ptr",
     "gsx_model_frame_stats", "gsx_model_download_projection", "gsx_model_download_sorted",
     "gsx_model_download_tile_lists", "gsx_model_download_pod", "gsx_set_pass_timing", "gsx_get_pass_timing",
-    "gsx_mask_evaluate", "gsx_ply_read_header", "gsx_ply_read_gaussians", "gsx_ply_write", "gsx_render_options_default", "gsx_viewer_set_render_options", "gsx_shard_pack", "gsx_shard_import", "gsx_shard_strip_bytes", "gsx_shard_pack_strip", "gsx_shard_unpack_strips",
+    "gsx_mask_evaluate", "gsx_ply_read_header", "gsx_ply_read_gaussians", "gsx_ply_write", "gsx_render_options_default", "gsx_viewer_set_render_options", "gsx_shard_layout", "gsx_viewer_set_external_framebuffer", "gsx_shard_pack", "gsx_shard_import", "gsx_shard_feedback_words", "gsx_shard_feedback",
+    "gsx_render_more", 
 )
 
 
@@ -42,6 +43,11 @@ class RenderOptions(C.Structure):
 class PlyHeader(C.Structure):
     _fields_ = [("count", C.c_uint64), ("header_bytes", C.c_uint64), ("vertex_bytes", C.c_uint32), ("is_ascii", C.c_uint32),
                 ("offsets", C.c_int32 * 62)]
+
+
+class ShardLayout(C.Structure):
+    _fields_ = [("rows_per_rank", C.c_uint32), ("row_lo", C.c_uint32), ("row_hi", C.c_uint32), ("band_bytes", C.c_uint64),
+                ("band_offset_bytes", C.c_uint64), ("padded_framebuffer_bytes", C.c_uint64)]
 
 
 class ViewerDesc(C.Structure):
@@ -110,11 +116,13 @@ def load() -> C.CDLL:
         "gsx_model_download_pod": ([vp, cp, f32p, u32p, f32p, f32p], C.c_int32),
         "gsx_render_options_default": ([C.POINTER(RenderOptions)], None),
         "gsx_viewer_set_render_options": ([vp, C.POINTER(RenderOptions)], C.c_int32),
-        "gsx_shard_pack": ([vp, cp, u32, vp, u64, C.POINTER(u64)], C.c_int32),
-        "gsx_shard_import": ([vp, cp, vp, u64, u32, u32], C.c_int32),
-        "gsx_shard_strip_bytes": ([vp, u32, C.POINTER(u64)], C.c_int32),
-        "gsx_shard_pack_strip": ([vp, u32, u32, vp, u64], C.c_int32),
-        "gsx_shard_unpack_strips": ([vp, u32, vp, u64], C.c_int32),
+        "gsx_shard_layout": ([vp, u32, u32, C.POINTER(ShardLayout)], C.c_int32),
+        "gsx_viewer_set_external_framebuffer": ([vp, vp, u64], C.c_int32),
+        "gsx_shard_pack": ([vp, cp, u32, vp, vp, u64, C.POINTER(u64)], C.c_int32),
+        "gsx_shard_import": ([vp, cp, vp, u64, u32, u32, vp], C.c_int32),
+        "gsx_shard_feedback_words": ([vp, u32, C.POINTER(u32)], C.c_int32),
+        "gsx_shard_feedback": ([vp, cp, u32, u32, vp], C.c_int32),
+        "gsx_render_more": ([vp, C.POINTER(cp), u32], C.c_int32),
         "gsx_set_pass_timing": ([vp, u32], C.c_int32),
         "gsx_get_pass_timing": ([vp, f32p, u32p], C.c_int32),
     }

@@ -87,7 +87,10 @@ struct Model {
     FrameConsts fc{};
 
     DevBuf pc, cov_a, cov_b, sh4, sh1, sh_h, sh_q, cov_h, cov_h2, mask;
-    DevBuf key_buf, rec_a, rec_b, rec_c;
+    DevBuf key_buf, rec_a, rec_b, rec_c;        // projection records of the model's own Gaussians
+    DevBuf imp_key, imp_a, imp_b, imp_c;        // records imported from other ranks (kept apart: a frame may pack twice)
+    bool use_imported = false;
+    uint64_t sortbin_cap = 0, imp_cap = 0;
     DevBuf dp_a, dp_b, sk_out, sv_out, sort_ws; // depth sort: pair scratch, sorted keys / indices, workspace
     DevBuf cnt, block_sums, srect;              // per slab: tile counts in depth order, scan partials, tile rects
     DevBuf block_vis;                           // per-workgroup visible counts of the projection pass
@@ -108,10 +111,13 @@ struct Model {
     hipEvent_t stats_event = nullptr;           // completion of the asynchronous statistics copy
     bool stats_copy_inflight = false;
     // the per-frame record set: the model's own projection (rec_n == n) or records imported from the
-    // other ranks (gsx_shard_import); binning is restricted to tile rows row % row_world == row_rank
+    // other ranks (gsx_shard_import); binning is restricted to the band of tile rows [row_lo, row_hi)
     uint64_t rec_n = 0, rec_cap = 0;
-    uint32_t row_world = 1, row_rank = 0;
+    uint32_t row_lo = 0, row_hi = 0xFFFFFFFFu;  // band of tile rows this viewer bins (clamped to tiles_y)
     DevBuf pack_table;
+    DevBuf pack_masks;             // destination bit mask per record (gsx_shard_pack)
+    DevBuf window, pack_window;    // per-tile depth-key windows [lo, hi): of the imported set / of the pack in flight
+    bool has_window = false;
 
     ~Model() {
         if (h_counters) (void)hipHostFree(h_counters);
@@ -133,7 +139,7 @@ struct Model {
         p.mask = has_mask ? mask.as<uint32_t>() : nullptr;
         return p;
     }
-    Records rec() const {
+    Records proj_rec() const {
         Records r;
         r.key = key_buf.as<uint32_t>();
         r.a = rec_a.as<float4>();
@@ -141,6 +147,15 @@ struct Model {
         r.c = rec_c.as<float4>();
         return r;
     }
+    Records imp_rec() const {
+        Records r;
+        r.key = imp_key.as<uint32_t>();
+        r.a = imp_a.as<float4>();
+        r.b = imp_b.as<float4>();
+        r.c = imp_c.as<float4>();
+        return r;
+    }
+    Records rec() const { return use_imported ? imp_rec() : proj_rec(); }  // the frame's active record set
 };
 
 struct PassTimer {
@@ -165,6 +180,9 @@ struct gsx_viewer {
     DevBuf fb, staging, scratch, done_bits;
     DevBuf frame_done;        // u32: tiles saturated so far in the current frame (all models)
     std::vector<std::string> last_keys;  // keys of the last gsx_render, for the overflow redo
+    bool last_render_cont = false;
+    void* ext_fb = nullptr;              // caller-owned framebuffer (multi-GPU: the RCCL gather target)
+    uint64_t ext_fb_bytes = 0;
     gsx_render_options options{1u, 16u, 131072u, 2u};
     bool timing = false;
     std::vector<PassTimer> timers;     // recorded, not yet read
@@ -217,11 +235,17 @@ static gsx_status viewer_bind(gsx_viewer* v) {
 }
 
 static gsx_status ensure_fb(gsx_viewer* v) {
+    if (v->ext_fb) {
+        if (v->ext_fb_bytes < sizeof(float4) * (size_t)v->width * v->height)
+            return fail(GSX_ERR_INVALID_ARG, "external framebuffer of %llu bytes is too small for %ux%u", (unsigned long long)v->ext_fb_bytes, v->width, v->height);
+        return GSX_OK;
+    }
     HIPCHK(v->fb.ensure(sizeof(float4) * (size_t)v->width * v->height));
     return GSX_OK;
 }
+static float4* fb_ptr(gsx_viewer* v) { return v->ext_fb ? static_cast<float4*>(v->ext_fb) : reinterpret_cast<float4*>(v->fb.p); }
 
-static gsx_status do_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys);
+static gsx_status do_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys, bool cont = false);
 
 // Frames are enqueued without any host round trip; this is where the host catches up: wait for the
 // stream, mirror the per-model statistics, and if a depth slab needed more tile-pair capacity than was
@@ -249,6 +273,9 @@ static gsx_status finish_frame(gsx_viewer* v) {
             m->stats_copy_inflight = false;
             if (m->h_counters->overflow && m->binned) {
                 m->tile_cap = std::max<uint64_t>(2 * m->tile_cap, (uint64_t)m->h_counters->max_needed + 1024);
+                if (v->last_render_cont || m->rec_n != m->n)
+                    return fail(GSX_ERR_OOM, "tile-pair capacity overflow in a sharded frame (model '%s'); capacity grown for the "
+                                "next frame, this frame is incomplete", m->key.c_str());
                 redo = true;
             }
         }
@@ -263,6 +290,7 @@ static gsx_status finish_frame(gsx_viewer* v) {
 
 static gsx_status sync_counters(gsx_viewer* v) { return finish_frame(v); }
 
+// buffers sized by the model (projection outputs)
 static gsx_status ensure_record_capacity(Model* m, uint64_t count) {
     if (count <= m->rec_cap) return GSX_OK;
     const size_t n = std::max<uint64_t>(count, 1);
@@ -270,6 +298,15 @@ static gsx_status ensure_record_capacity(Model* m, uint64_t count) {
     HIPCHK(m->rec_a.ensure(16 * n));
     HIPCHK(m->rec_b.ensure(16 * n));
     HIPCHK(m->rec_c.ensure(16 * n));
+    HIPCHK(m->block_vis.ensure(4 * (project_blocks(n) + 1)));
+    m->rec_cap = n;
+    return GSX_OK;
+}
+
+// buffers sized by the frame's active record set (depth sort + per-slab binning)
+static gsx_status ensure_sortbin_capacity(Model* m, uint64_t count) {
+    if (count <= m->sortbin_cap) return GSX_OK;
+    const size_t n = std::max<uint64_t>(count + count / 8, 1);
     HIPCHK(m->dp_a.ensure(8 * n));
     HIPCHK(m->dp_b.ensure(8 * n));
     HIPCHK(m->sk_out.ensure(4 * n));
@@ -284,9 +321,20 @@ static gsx_status ensure_record_capacity(Model* m, uint64_t count) {
     HIPCHK(m->cnt.ensure(4 * n));
     HIPCHK(m->srect.ensure(8 * n));
     HIPCHK(m->block_sums.ensure(4 * (scan_blocks(n) + 1)));
-    HIPCHK(m->block_vis.ensure(4 * (project_blocks(n) + 1)));
-    m->rec_cap = n;
+    m->sortbin_cap = n;
     return GSX_OK;
+}
+
+static gsx_status ensure_import_capacity(Model* m, uint64_t count) {
+    if (count > m->imp_cap) {
+        const size_t n = std::max<uint64_t>(count + count / 8, 1);
+        HIPCHK(m->imp_key.ensure(4 * n));
+        HIPCHK(m->imp_a.ensure(16 * n));
+        HIPCHK(m->imp_b.ensure(16 * n));
+        HIPCHK(m->imp_c.ensure(16 * n));
+        m->imp_cap = n;
+    }
+    return ensure_sortbin_capacity(m, count);
 }
 
 static gsx_status do_preprocess(gsx_viewer* v, Model* m) {
@@ -295,12 +343,14 @@ static gsx_status do_preprocess(gsx_viewer* v, Model* m) {
     m->preprocessed = m->sorted = m->counters_valid = m->binned = false;
     gsx_status st = ensure_record_capacity(m, m->n);
     if (st) return st;
+    if ((st = ensure_sortbin_capacity(m, m->n))) return st;
+    m->use_imported = false;
     m->rec_n = m->n;
-    m->row_world = 1;
-    m->row_rank = 0;
+    m->row_lo = 0;
+    m->row_hi = 0xFFFFFFFFu;
     {
         ScopedPass t(v, GSX_PASS_PROJECT);  // brackets the projection kernel alone (bench.py's roofline kernel)
-        HIPCHK(launch_project(v->stream, m->fc, (uint32_t)m->n, m->pod(), m->rec(), m->block_vis.as<uint32_t>()));
+        HIPCHK(launch_project(v->stream, m->fc, (uint32_t)m->n, m->pod(), m->proj_rec(), m->block_vis.as<uint32_t>()));
         v->pass_launches[GSX_PASS_PROJECT] += m->n ? 1 : 0;
     }
     HIPCHK(launch_sum_counts(v->stream, m->block_vis.as<uint32_t>(), (uint32_t)m->n, &m->counters.as<Counters>()->n_visible));
@@ -314,7 +364,7 @@ static gsx_status do_sort(gsx_viewer* v, Model* m) {
     const uint32_t n = (uint32_t)m->rec_n;
     {
         ScopedPass t(v, GSX_PASS_DEPTH_SORT);
-        RadixBuffers rb{m->key_buf.as<uint32_t>(), nullptr, nullptr, m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
+        RadixBuffers rb{m->rec().key, nullptr, nullptr, m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
                         m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
         HIPCHK(launch_radix_sort(v->stream, rb, n, nullptr, 32, true));
         m->sorted_idx = m->sv_out.as<uint32_t>();
@@ -382,9 +432,10 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
         merge_tail_slabs(&bounds, m->slabs_hint);
     }
     Counters* dc = m->counters.as<Counters>();
-    uint32_t owned_rows = 0;
-    for (uint32_t ty = m->row_rank; ty < m->fc.tiles_y; ty += m->row_world) ++owned_rows;
-    const uint32_t owned_tiles = owned_rows * m->fc.tiles_x;
+    const uint32_t row_lo = std::min(m->row_lo, m->fc.tiles_y), row_hi = std::min(m->row_hi, m->fc.tiles_y);
+    const uint32_t owned_tiles = (row_hi > row_lo ? row_hi - row_lo : 0) * m->fc.tiles_x;
+    const uint2* window = (m->use_imported && m->has_window) ? m->window.as<uint2>() : nullptr;
+    uint32_t* tile_sat = progressive ? done + row_words * m->fc.tiles_y : nullptr;  // [count | bitmap | saturation keys]
 
     if (m->tile_cap == 0) m->tile_cap = std::max<uint64_t>(1u << 20, 16 * m->rec_n);
     m->tile_cap = std::min<uint64_t>(m->tile_cap, 0xFFFFF000ull);
@@ -419,12 +470,12 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
         {
             ScopedPass t(v, GSX_PASS_BIN);
             HIPCHK(launch_tile_counts(v->stream, j0, j1, &dc->n_visible, m->sorted_idx, m->rec(), m->srect.as<uint2>(),
-                                      m->cnt.as<uint32_t>(), m->block_sums.as<uint32_t>(), dc, cap, m->row_world,
-                                      m->row_rank, done_in, row_words, (progressive && later) ? done_count : nullptr,
-                                      owned_tiles, (uint32_t)sl));
+                                      m->cnt.as<uint32_t>(), m->block_sums.as<uint32_t>(), dc, cap, row_lo, row_hi, done_in,
+                                      row_words, (progressive && later) ? done_count : nullptr, owned_tiles, (uint32_t)sl,
+                                      window, m->sk_out.as<uint32_t>(), m->fc.tiles_x));
             HIPCHK(launch_tile_emit(v->stream, j0, j1, m->sorted_idx, m->srect.as<uint2>(), m->cnt.as<uint32_t>(),
-                                    m->block_sums.as<uint32_t>(), m->fc.tiles_x, m->tp_src.as<uint2>(), m->row_world,
-                                    m->row_rank, done_in, row_words, &dc->n_visible, &dc->n_entries, cap));
+                                    m->block_sums.as<uint32_t>(), m->fc.tiles_x, m->tp_src.as<uint2>(), row_lo, row_hi,
+                                    done_in, row_words, &dc->n_visible, &dc->n_entries, cap, window, m->sk_out.as<uint32_t>()));
             v->pass_launches[GSX_PASS_BIN] += 1;
         }
         {
@@ -443,8 +494,8 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
         }
         {
             ScopedPass t(v, GSX_PASS_COMPOSITE);
-            HIPCHK(launch_composite(v->stream, m->fc, m->ranges.as<uint2>(), m->tile_list, m->rec(), v->fb.as<float4>(),
-                                    later, done, row_words, done_count, clear_ranges));
+            HIPCHK(launch_composite(v->stream, m->fc, m->ranges.as<uint2>(), m->tile_list, m->rec(), fb_ptr(v),
+                                    later, done, row_words, done_count, clear_ranges, tile_sat));
             m->ranges_clean = clear_ranges;  // the compositor zeroed every range it consumed
             v->pass_launches[GSX_PASS_COMPOSITE] += 1;
         }
@@ -461,7 +512,9 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
     return GSX_OK;
 }
 
-static gsx_status do_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys) {
+// cont: a second round of the same frame (multi-GPU back set): keep the framebuffer, the saturated-tile state
+// and carry (C, T) into the first model.
+static gsx_status do_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys, bool cont) {
     gsx_status st = ensure_fb(v);
     if (st) return st;
     std::vector<Model*> order;
@@ -473,18 +526,21 @@ static gsx_status do_render(gsx_viewer* v, const char* const* keys, uint32_t n_k
         key_copy.push_back(keys[i]);
     }
     v->last_keys = key_copy;
+    v->last_render_cont = cont;
     if (order.empty()) {
-        HIPCHK(launch_clear_fb(v->stream, v->fb.as<float4>(), v->width * v->height));
+        if (cont) return GSX_OK;
+        HIPCHK(launch_clear_fb(v->stream, fb_ptr(v), v->width * v->height));
         return GSX_OK;
     }
-    {   // one memset: [saturated-tile counter | saturated-tile bitmap]
-        const uint32_t tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE, row_words = ((v->width + GSX_TILE - 1) / GSX_TILE + 31) / 32;
-        const size_t bytes = 4 * (1 + (size_t)tiles_y * row_words);
+    if (!cont) {   // one memset: [saturated-tile counter | saturated-tile bitmap | per-tile saturation depth keys]
+        const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
+        const uint32_t row_words = (tiles_x + 31) / 32;
+        const size_t bytes = 4 * (1 + (size_t)tiles_y * row_words + (size_t)tiles_y * tiles_x);
         HIPCHK(v->done_bits.ensure(bytes));
         HIPCHK(hipMemsetAsync(v->done_bits.p, 0, bytes, v->stream));
     }
     // the reference paints far -> near with "over"; front-to-back accumulation walks the same list backwards
-    bool carry = false;
+    bool carry = cont;
     for (auto it = order.rbegin(); it != order.rend(); ++it) {
         if ((st = do_bin_and_composite(v, *it, carry))) return st;
         carry = true;
@@ -620,6 +676,7 @@ gsx_status gsx_model_create(gsx_viewer* v, const char* key, uint64_t count, gsx_
     {
         gsx_status rst = ensure_record_capacity(m.get(), n);
         if (rst) return rst;
+        if ((rst = ensure_sortbin_capacity(m.get(), n))) return rst;
     }
     HIPCHK(m->counters.ensure(sizeof(Counters)));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&m->h_counters), sizeof(Counters), hipHostMallocDefault));
@@ -850,7 +907,7 @@ gsx_status gsx_download_framebuffer(gsx_viewer* v, float* rgbt, uint64_t n_float
     if ((st = ensure_fb(v))) return st;
     if ((st = finish_frame(v))) return st;
     HIPCHK(hipStreamSynchronize(v->stream));
-    HIPCHK(hipMemcpy(rgbt, v->fb.p, sizeof(float) * need, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rgbt, fb_ptr(v), sizeof(float) * need, hipMemcpyDeviceToHost));
     return GSX_OK;
 }
 
@@ -862,7 +919,7 @@ gsx_status gsx_download_rgba8(gsx_viewer* v, const float bg[3], uint8_t* rgba, u
     if ((st = ensure_fb(v))) return st;
     if ((st = finish_frame(v))) return st;
     HIPCHK(v->scratch.ensure(4 * npx));
-    HIPCHK(launch_resolve_rgba8(v->stream, v->fb.as<float4>(), (uint32_t)npx, bg[0], bg[1], bg[2], v->scratch.as<uint32_t>()));
+    HIPCHK(launch_resolve_rgba8(v->stream, fb_ptr(v), (uint32_t)npx, bg[0], bg[1], bg[2], v->scratch.as<uint32_t>()));
     HIPCHK(hipStreamSynchronize(v->stream));
     HIPCHK(hipMemcpy(rgba, v->scratch.p, 4 * npx, hipMemcpyDeviceToHost));
     return GSX_OK;
@@ -873,7 +930,7 @@ gsx_status gsx_framebuffer_device_ptr(gsx_viewer* v, void** out_ptr, uint32_t* o
     if (st) return st;
     if (!out_ptr) return fail(GSX_ERR_INVALID_ARG, "gsx_framebuffer_device_ptr: null argument");
     if ((st = ensure_fb(v))) return st;
-    *out_ptr = v->fb.p;
+    *out_ptr = fb_ptr(v);
     if (out_w) *out_w = v->width;
     if (out_h) *out_h = v->height;
     return GSX_OK;
@@ -903,10 +960,13 @@ gsx_status gsx_model_download_projection(gsx_viewer* v, const char* key, uint32_
     const size_t n = m->rec_n;  // == model length unless records were imported (gsx_shard_import)
     std::vector<uint32_t> k(n);
     std::vector<float4> a(n), b(n), c(n);
-    HIPCHK(hipMemcpy(k.data(), m->key_buf.p, 4 * n, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(a.data(), m->rec_a.p, 16 * n, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(b.data(), m->rec_b.p, 16 * n, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(c.data(), m->rec_c.p, 16 * n, hipMemcpyDeviceToHost));
+    const Records rr = m->rec();
+    if (n) {
+        HIPCHK(hipMemcpy(k.data(), rr.key, 4 * n, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(a.data(), rr.a, 16 * n, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(b.data(), rr.b, 16 * n, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(c.data(), rr.c, 16 * n, hipMemcpyDeviceToHost));
+    }
     for (size_t i = 0; i < n; ++i) {
         const bool vis = k[i] != kCulledKey;
         if (depth_key) depth_key[i] = k[i];
@@ -1010,21 +1070,60 @@ gsx_status gsx_model_download_pod(gsx_viewer* v, const char* key, float* pos, ui
 }
 
 // ---- multi-GPU stage split ----------------------------------------------------------------------
-gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, void* d_send, uint64_t capacity_records,
-                          uint64_t* counts) {
+static uint32_t rows_per_rank(const gsx_viewer* v, uint32_t world) {
+    uint32_t tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
+    return (tiles_y + world - 1) / world;
+}
+
+gsx_status gsx_shard_layout(gsx_viewer* v, uint32_t world, uint32_t rank, gsx_shard_layout_t* out) {
+    if (!v || !out || world == 0 || world > 64 || rank >= world) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_layout: bad argument");
+    const uint32_t tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE, rpr = rows_per_rank(v, world);
+    out->rows_per_rank = rpr;
+    out->row_lo = std::min(rank * rpr, tiles_y);
+    out->row_hi = std::min((rank + 1) * rpr, tiles_y);
+    out->band_bytes = (uint64_t)rpr * GSX_TILE * v->width * sizeof(float4);
+    out->band_offset_bytes = (uint64_t)rank * out->band_bytes;
+    out->padded_framebuffer_bytes = (uint64_t)world * out->band_bytes;
+    return GSX_OK;
+}
+
+gsx_status gsx_viewer_set_external_framebuffer(gsx_viewer* v, void* d_ptr, uint64_t bytes) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    if ((st = finish_frame(v))) return st;
+    v->ext_fb = d_ptr;
+    v->ext_fb_bytes = d_ptr ? bytes : 0;
+    return GSX_OK;
+}
+
+static size_t window_bytes(const gsx_viewer* v) {
+    return sizeof(uint2) * (size_t)((v->width + GSX_TILE - 1) / GSX_TILE) * ((v->height + GSX_TILE - 1) / GSX_TILE);
+}
+
+gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, const uint32_t* d_tile_window, void* d_send,
+                          uint64_t capacity_records, uint64_t* counts) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
     Model* m = find_model(v, key);
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_pack: no model '%s'", key ? key : "(null)");
-    if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack: model '%s' not preprocessed", key);
+    if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack: model '%s' has no projection this frame (gsx_preprocess first)", key);
     if (world == 0 || world > 64 || !counts) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack: world must be 1..64");
-    const uint32_t n = (uint32_t)m->rec_n;
-    const uint32_t nb = (uint32_t)pack_blocks(n);
+    const uint32_t n = (uint32_t)m->n;
+    const uint32_t nb = (uint32_t)pack_blocks(n), rpr = rows_per_rank(v, world);
+    const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE;
     HIPCHK(m->pack_table.ensure(4 * ((size_t)64 * std::max(nb, 1u) + 64)));
+    HIPCHK(m->pack_masks.ensure(8 * (size_t)std::max(n, 1u)));
+    const uint2* window = nullptr;
+    if (d_tile_window) {  // own copy: the caller's map need not outlive this call
+        HIPCHK(m->pack_window.ensure(window_bytes(v)));
+        HIPCHK(hipMemcpyAsync(m->pack_window.p, d_tile_window, window_bytes(v), hipMemcpyDeviceToDevice, v->stream));
+        window = m->pack_window.as<uint2>();
+    }
     uint32_t* table = m->pack_table.as<uint32_t>();
     uint32_t* totals = table + (size_t)64 * std::max(nb, 1u);
+    unsigned long long* masks = m->pack_masks.as<unsigned long long>();
     HIPCHK(hipMemsetAsync(totals, 0, 4 * 64, v->stream));
-    HIPCHK(launch_pack_count(v->stream, m->rec(), n, world, table));
+    HIPCHK(launch_pack_count(v->stream, m->proj_rec(), n, world, rpr, window, tiles_x, masks, table));
     if (nb) HIPCHK(launch_rowscan(v->stream, table, world, nb, totals));
     uint32_t h_tot[64];
     HIPCHK(hipMemcpyAsync(h_tot, totals, 4 * 64, hipMemcpyDeviceToHost, v->stream));
@@ -1038,12 +1137,12 @@ gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, void* 
         return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack: %llu records exceed the send capacity %llu",
                     (unsigned long long)sum, (unsigned long long)capacity_records);
     if (sum && !d_send) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack: d_send is null");
-    HIPCHK(launch_pack_scatter(v->stream, m->rec(), n, world, table, totals, d_send, capacity_records));
+    HIPCHK(launch_pack_scatter(v->stream, m->proj_rec(), n, world, masks, table, totals, d_send, capacity_records));
     return GSX_OK;
 }
 
 gsx_status gsx_shard_import(gsx_viewer* v, const char* key, const void* d_recv, uint64_t n_records, uint32_t world,
-                            uint32_t rank) {
+                            uint32_t rank, const uint32_t* d_tile_window) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
     Model* m = find_model(v, key);
@@ -1052,53 +1151,62 @@ gsx_status gsx_shard_import(gsx_viewer* v, const char* key, const void* d_recv, 
     if (world == 0 || world > 64 || rank >= world) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import: bad world/rank %u/%u", world, rank);
     if (n_records >= 0xFFFFFFF0ull) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import: too many records");
     if (n_records && !d_recv) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import: d_recv is null");
-    if ((st = ensure_record_capacity(m, n_records))) return st;
-    HIPCHK(launch_import_records(v->stream, d_recv, (uint32_t)n_records, m->rec()));
+    if ((st = ensure_import_capacity(m, n_records))) return st;
+    HIPCHK(launch_import_records(v->stream, d_recv, (uint32_t)n_records, m->imp_rec()));
     // every imported record is visible by construction
     HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&m->counters.as<Counters>()->n_visible), (int)(uint32_t)n_records, 1,
                              v->stream));
     m->stats_pending = true;
     m->rec_n = n_records;
-    m->row_world = world;
-    m->row_rank = rank;
+    m->use_imported = true;
+    const uint32_t rpr = rows_per_rank(v, world);
+    m->row_lo = rank * rpr;
+    m->row_hi = (rank + 1) * rpr;
+    m->has_window = d_tile_window != nullptr;
+    if (d_tile_window) {
+        HIPCHK(m->window.ensure(window_bytes(v)));
+        HIPCHK(hipMemcpyAsync(m->window.p, d_tile_window, window_bytes(v), hipMemcpyDeviceToDevice, v->stream));
+    }
     m->sorted = m->counters_valid = m->binned = false;
     return GSX_OK;
 }
 
-static uint32_t rows_per_rank(const gsx_viewer* v, uint32_t world) {
-    uint32_t tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
-    return (tiles_y + world - 1) / world;
+// this rank's band of the per-tile saturation keys; rows below the frame read 0 (= open)
+__global__ void k_shard_feedback(const uint32_t* __restrict__ tile_sat, uint32_t tiles_x, uint32_t tiles_y, uint32_t row_lo,
+                                 uint32_t n_words, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_words) return;
+    const uint32_t ty = row_lo + i / tiles_x;
+    out[i] = ty < tiles_y ? tile_sat[ty * tiles_x + i % tiles_x] : 0u;
 }
 
-gsx_status gsx_shard_strip_bytes(gsx_viewer* v, uint32_t world, uint64_t* out_bytes) {
-    if (!v || !out_bytes || world == 0) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_strip_bytes: bad argument");
-    *out_bytes = (uint64_t)rows_per_rank(v, world) * GSX_TILE * v->width * sizeof(float4);
+gsx_status gsx_shard_feedback_words(gsx_viewer* v, uint32_t world, uint32_t* out_words) {
+    if (!v || !out_words || world == 0 || world > 64) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_feedback_words: bad argument");
+    *out_words = rows_per_rank(v, world) * ((v->width + GSX_TILE - 1) / GSX_TILE);
     return GSX_OK;
 }
 
-gsx_status gsx_shard_pack_strip(gsx_viewer* v, uint32_t world, uint32_t rank, void* d_strip, uint64_t strip_bytes) {
+gsx_status gsx_shard_feedback(gsx_viewer* v, const char* key, uint32_t world, uint32_t rank, void* d_out_u32) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
-    if (world == 0 || rank >= world || !d_strip) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack_strip: bad argument");
-    const uint32_t rpr = rows_per_rank(v, world);
-    if (strip_bytes != (uint64_t)rpr * GSX_TILE * v->width * sizeof(float4))
-        return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack_strip: strip must be %llu bytes", (unsigned long long)((uint64_t)rpr * GSX_TILE * v->width * sizeof(float4)));
-    if ((st = ensure_fb(v))) return st;
-    if ((st = finish_frame(v))) return st;  // a capacity overflow must be repaired before the strip leaves the GPU
-    HIPCHK(launch_pack_strip(v->stream, v->fb.as<float4>(), v->width, v->height, world, rank, rpr, d_strip));
+    Model* m = find_model(v, key);
+    if (!m || !d_out_u32) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_feedback: no model '%s'", key ? key : "(null)");
+    if (!m->binned) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_feedback: model '%s' not rendered this frame", key);
+    if (!v->options.progressive) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_feedback needs gsx_render_options.progressive = 1");
+    if (world == 0 || world > 64 || rank >= world) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_feedback: bad world/rank %u/%u", world, rank);
+    const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
+    const uint32_t row_words = (tiles_x + 31) / 32, rpr = rows_per_rank(v, world), n_words = rpr * tiles_x;
+    const uint32_t* tile_sat = v->done_bits.as<uint32_t>() + 1 + (size_t)row_words * tiles_y;
+    hipLaunchKernelGGL(k_shard_feedback, dim3((n_words + 255) / 256), dim3(256), 0, v->stream, tile_sat, tiles_x, tiles_y,
+                       rank * rpr, n_words, static_cast<uint32_t*>(d_out_u32));
+    HIPCHK(hipGetLastError());
     return GSX_OK;
 }
 
-gsx_status gsx_shard_unpack_strips(gsx_viewer* v, uint32_t world, const void* d_all, uint64_t bytes) {
+gsx_status gsx_render_more(gsx_viewer* v, const char* const* keys, uint32_t n_keys) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
-    if (world == 0 || !d_all) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_unpack_strips: bad argument");
-    const uint32_t rpr = rows_per_rank(v, world);
-    if (bytes != (uint64_t)world * rpr * GSX_TILE * v->width * sizeof(float4))
-        return fail(GSX_ERR_INVALID_ARG, "gsx_shard_unpack_strips: expected %llu bytes", (unsigned long long)((uint64_t)world * rpr * GSX_TILE * v->width * sizeof(float4)));
-    if ((st = ensure_fb(v))) return st;
-    HIPCHK(launch_unpack_strips(v->stream, d_all, v->width, v->height, world, rpr, v->fb.as<float4>()));
-    return GSX_OK;
+    return do_render(v, keys, n_keys, true);
 }
 
 gsx_status gsx_set_pass_timing(gsx_viewer* v, uint32_t enabled) {

@@ -108,17 +108,19 @@ struct SlabStats {
 
 // Tile binning.
 // Splats [j0, min(j1, *d_n_vis)) of the depth order; cnt / block_sums are indexed relative to j0.
-// (world, rank): only tile rows with row % world == rank are binned (1, 0 = all rows).
+// [row_lo, row_hi): the band of tile rows this rank bins (0, tiles_y on one GPU).
 // done (nullable): bitmap of saturated tiles (row_words u32 per tile row) that receive no more entries.
 // srect[j - j0]: the splat's packed tile rectangle, gathered once by the count pass and re-read by emit.
 hipError_t launch_tile_counts(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* d_n_vis, const uint32_t* sorted_idx,
                               const Records& rec, uint2* srect, uint32_t* cnt, uint32_t* block_sums, SlabStats* stats,
-                              uint32_t capacity, uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words,
-                              const uint32_t* d_done_count, uint32_t owned_tiles, uint32_t slab_index);
+                              uint32_t capacity, uint32_t row_lo, uint32_t row_hi, const uint32_t* done, uint32_t row_words,
+                              const uint32_t* d_done_count, uint32_t owned_tiles, uint32_t slab_index,
+                              const uint2* window, const uint32_t* sorted_keys, uint32_t tiles_x);
 hipError_t launch_tile_emit(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* sorted_idx, const uint2* srect,
                             const uint32_t* cnt, const uint32_t* block_sums, uint32_t tiles_x, uint2* tpairs,
-                            uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words,
-                            const uint32_t* d_n_vis, const uint32_t* d_entries, uint32_t capacity);
+                            uint32_t row_lo, uint32_t row_hi, const uint32_t* done, uint32_t row_words,
+                            const uint32_t* d_n_vis, const uint32_t* d_entries, uint32_t capacity,
+                            const uint2* window, const uint32_t* sorted_keys);
 // ranges_clean: the table is already all-zero (the previous composite cleared what it used)
 hipError_t launch_tile_ranges(hipStream_t s, uint32_t capacity, const uint32_t* d_n, const uint32_t* tkey_sorted,
                               uint32_t n_tiles, uint2* ranges, bool ranges_clean);
@@ -127,14 +129,15 @@ size_t scan_blocks(uint64_t n);
 // Multi-GPU exchange support (kernels_shard.hip).
 hipError_t launch_rowscan(hipStream_t s, uint32_t* table, uint32_t nrows, uint32_t nblocks, uint32_t* totals);
 size_t pack_blocks(uint64_t n);
-hipError_t launch_pack_count(hipStream_t s, const Records& rec, uint32_t n, uint32_t world, uint32_t* table);
-hipError_t launch_pack_scatter(hipStream_t s, const Records& rec, uint32_t n, uint32_t world, const uint32_t* table,
-                               const uint32_t* totals, void* d_send, uint64_t capacity);
+// rows_per_rank: rank g owns tile rows [g*rpr, min((g+1)*rpr, tiles_y)).  A record travels to g if its rectangle
+// touches g's band and (key < key_front_hi, or key >= key_back_lo and it touches a tile whose bit in open_map is 0).
+// window: uint2 [lo, hi) depth-key window per tile (tiles_y * tiles_x, row-major) or nullptr = every tile takes everything
+hipError_t launch_pack_count(hipStream_t s, const Records& rec, uint32_t n, uint32_t world, uint32_t rows_per_rank,
+                             const uint2* window, uint32_t tiles_x, unsigned long long* masks, uint32_t* table);
+hipError_t launch_pack_scatter(hipStream_t s, const Records& rec, uint32_t n, uint32_t world,
+                               const unsigned long long* masks, const uint32_t* table, const uint32_t* totals, void* d_send,
+                               uint64_t capacity);
 hipError_t launch_import_records(hipStream_t s, const void* d_recv, uint32_t n, const Records& rec);
-hipError_t launch_pack_strip(hipStream_t s, const float4* fb, uint32_t w, uint32_t h, uint32_t world, uint32_t rank,
-                             uint32_t rows_per_rank, void* d_strip);
-hipError_t launch_unpack_strips(hipStream_t s, const void* d_all, uint32_t w, uint32_t h, uint32_t world,
-                                uint32_t rows_per_rank, float4* fb);
 
 // Mask evaluation (kernels_mask.hip); passed to the kernel by value.
 struct MaskShapeConsts {
@@ -155,9 +158,10 @@ void quat_to_rows(const float q[4], float r[9]);
 // Compositing and resolve.
 // carry: continue from the (C, T) already in fb (later slabs / models behind); done: saturated-tile bitmap
 // (read to skip tiles when carrying, updated when a tile saturates; nullable).
+// depth feedback (nullable): when a tile saturates, *depth_needed = max(., sorted_keys[min(slab_end, *d_n_vis) - 1])
 hipError_t launch_composite(hipStream_t s, const FrameConsts& f, uint2* ranges, const uint32_t* list,
                             const Records& rec, float4* fb, bool carry, uint32_t* done, uint32_t row_words,
-                            uint32_t* d_done_count, bool clear_ranges);
+                            uint32_t* d_done_count, bool clear_ranges, uint32_t* tile_sat);
 hipError_t launch_clear_fb(hipStream_t s, float4* fb, uint32_t n_px);
 hipError_t launch_resolve_rgba8(hipStream_t s, const float4* fb, uint32_t n_px, float bg_r, float bg_g, float bg_b,
                                 uint32_t* out_rgba8);

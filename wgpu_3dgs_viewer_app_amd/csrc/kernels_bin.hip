@@ -17,16 +17,12 @@ constexpr int kBinThreads = 256;  // one splat per lane
 
 size_t scan_blocks(uint64_t n) { return (size_t)((n + kBinThreads - 1) / kBinThreads); }
 
-// Multi-GPU: a rank bins only the tile rows it owns (row % world == rank); world = 1 owns every row.
-__device__ inline uint32_t first_owned_row(uint32_t y0, uint32_t world, uint32_t rank) {
-    return y0 + ((rank + world - (y0 % world)) % world);
-}
+// Multi-GPU: a rank bins only the band of tile rows it owns, [row_lo, row_hi); one GPU owns [0, tiles_y).
 
-__device__ inline uint32_t rect_area(float4 a, uint32_t world, uint32_t rank) {
+__device__ inline uint32_t rect_area(float4 a, uint32_t row_lo, uint32_t row_hi) {
     uint32_t rx = __float_as_uint(a.z), ry = __float_as_uint(a.w);
-    uint32_t y0 = ry & 0xFFFFu, y1 = ry >> 16;
-    uint32_t first = first_owned_row(y0, world, rank);
-    uint32_t rows = first < y1 ? (y1 - 1u - first) / world + 1u : 0u;
+    uint32_t first = max(ry & 0xFFFFu, row_lo), last = min(ry >> 16, row_hi);
+    uint32_t rows = first < last ? last - first : 0u;
     return ((rx >> 16) - (rx & 0xFFFFu)) * rows;
 }
 
@@ -45,11 +41,34 @@ __device__ inline uint32_t live_tiles_in_row(const uint32_t* done, uint32_t row_
     return n;
 }
 
-__device__ inline uint32_t rect_live_area(float4 a, uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words) {
+__device__ inline uint32_t rect_live_area(float4 a, uint32_t row_lo, uint32_t row_hi, const uint32_t* done, uint32_t row_words) {
     uint32_t rx = __float_as_uint(a.z), ry = __float_as_uint(a.w);
-    uint32_t x0 = rx & 0xFFFFu, x1 = rx >> 16, y0 = ry & 0xFFFFu, y1 = ry >> 16;
+    uint32_t x0 = rx & 0xFFFFu, x1 = rx >> 16;
     uint32_t n = 0;
-    for (uint32_t ty = first_owned_row(y0, world, rank); ty < y1; ty += world) n += live_tiles_in_row(done, row_words, ty, x0, x1);
+    for (uint32_t ty = max(ry & 0xFFFFu, row_lo), last = min(ry >> 16, row_hi); ty < last; ++ty)
+        n += live_tiles_in_row(done, row_words, ty, x0, x1);
+    return n;
+}
+
+// Multi-GPU speculation (kernels_shard.hip): every tile has a depth-key window [lo, hi); a tile takes a record only
+// if the record's key lies inside it (and the tile is not saturated).  window == nullptr on one GPU.
+struct TileWindow {
+    const uint2* win;             // [tiles_y * tiles_x] or nullptr
+    const uint32_t* sorted_keys;  // key of depth-order position j
+    uint32_t tiles_x;
+};
+
+__device__ inline bool tile_takes(const uint32_t* done, uint32_t row_words, const uint2* win, uint32_t tiles_x, uint32_t tx,
+                                  uint32_t ty, uint32_t key) {
+    if (done && ((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)) return false;
+    const uint2 w = win[ty * tiles_x + tx];
+    return key >= w.x && key < w.y;
+}
+
+__device__ inline uint32_t window_tiles_in_row(const uint32_t* done, uint32_t row_words, const uint2* win, uint32_t tiles_x,
+                                               uint32_t ty, uint32_t x0, uint32_t x1, uint32_t key) {
+    uint32_t n = 0;
+    for (uint32_t tx = x0; tx < x1; ++tx) n += tile_takes(done, row_words, win, tiles_x, tx, ty, key) ? 1u : 0u;
     return n;
 }
 
@@ -70,11 +89,11 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_counts(const uint32_t* __r
                                                               uint32_t j1, const uint32_t* __restrict__ sorted_idx,
                                                               const float4* __restrict__ rec_a,
                                                               uint2* __restrict__ srect, uint32_t* __restrict__ cnt,
-                                                              uint32_t* __restrict__ block_sums, uint32_t world,
-                                                              uint32_t rank, const uint32_t* __restrict__ done,
+                                                              uint32_t* __restrict__ block_sums, uint32_t row_lo,
+                                                              uint32_t row_hi, const uint32_t* __restrict__ done,
                                                               uint32_t row_words,
                                                               const uint32_t* __restrict__ d_done_count,
-                                                              uint32_t owned_tiles) {
+                                                              uint32_t owned_tiles, TileWindow tw) {
     __shared__ uint32_t red[4];
     // every tile this rank composites is saturated: whatever is left is hidden, skip the gather
     if (d_done_count && *d_done_count >= owned_tiles) {
@@ -86,7 +105,13 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_counts(const uint32_t* __r
     uint32_t c = 0;
     if (j < n_vis) {
         const float4 a = rec_a[sorted_idx[j]];
-        c = done ? rect_live_area(a, world, rank, done, row_words) : rect_area(a, world, rank);
+        if (tw.win) {
+            const uint32_t rx = __float_as_uint(a.z), ry = __float_as_uint(a.w), key = tw.sorted_keys[j];
+            for (uint32_t ty = max(ry & 0xFFFFu, row_lo), last = min(ry >> 16, row_hi); ty < last; ++ty)
+                c += window_tiles_in_row(done, row_words, tw.win, tw.tiles_x, ty, rx & 0xFFFFu, rx >> 16, key);
+        } else {
+            c = done ? rect_live_area(a, row_lo, row_hi, done, row_words) : rect_area(a, row_lo, row_hi);
+        }
         srect[j - j0] = make_uint2(__float_as_uint(a.z), __float_as_uint(a.w));
         cnt[j - j0] = c;
     }
@@ -144,12 +169,16 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__
 constexpr uint32_t kCoopThreshold = 24;
 
 __device__ inline void emit_rect(uint2* __restrict__ tpairs, uint32_t o, uint32_t capacity, uint32_t idx, uint2 r,
-                                 uint32_t tiles_x, uint32_t world, uint32_t rank, const uint32_t* __restrict__ done,
-                                 uint32_t row_words) {
+                                 uint32_t tiles_x, uint32_t row_lo, uint32_t row_hi, const uint32_t* __restrict__ done,
+                                 uint32_t row_words, const uint2* __restrict__ win, uint32_t key) {
     const uint32_t x0 = r.x & 0xFFFFu, x1 = r.x >> 16, y0 = r.y & 0xFFFFu, y1 = r.y >> 16;
-    for (uint32_t ty = first_owned_row(y0, world, rank); ty < y1; ty += world)
+    for (uint32_t ty = max(y0, row_lo), last = min(y1, row_hi); ty < last; ++ty)
         for (uint32_t tx = x0; tx < x1; ++tx) {
-            if (done && ((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)) continue;
+            if (win) {
+                if (!tile_takes(done, row_words, win, tiles_x, tx, ty, key)) continue;
+            } else if (done && ((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)) {
+                continue;
+            }
             if (o < capacity) tpairs[o] = make_uint2(ty * tiles_x + tx, idx);
             ++o;
         }
@@ -160,10 +189,11 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_emit(uint32_t jbase, uint3
                                                             const uint2* __restrict__ srect,
                                                             const uint32_t* __restrict__ cnt,
                                                             const uint32_t* __restrict__ block_offs, uint32_t tiles_x,
-                                                            uint2* __restrict__ tpairs, uint32_t world, uint32_t rank,
+                                                            uint2* __restrict__ tpairs, uint32_t row_lo, uint32_t row_hi,
                                                             const uint32_t* __restrict__ done, uint32_t row_words,
                                                             const uint32_t* __restrict__ d_n_vis,
-                                                            const uint32_t* __restrict__ d_entries, uint32_t capacity) {
+                                                            const uint32_t* __restrict__ d_entries, uint32_t capacity,
+                                                            TileWindow tw) {
     __shared__ uint32_t wsum[4];
     if (*d_entries == 0) return;  // empty slab (also: every tile already saturated)
     n_vis = min(n_vis, *d_n_vis);
@@ -182,11 +212,13 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_emit(uint32_t jbase, uint3
     for (uint32_t w = 0; w < wave; ++w) o += wsum[w];
     uint32_t idx = 0;
     uint2 r = make_uint2(0, 0);
+    uint32_t key = 0;
     if (mine) {
         idx = sorted_idx[j];
         r = srect[j - jbase];
+        if (tw.win) key = tw.sorted_keys[j];
     }
-    if (mine && mine <= kCoopThreshold) emit_rect(tpairs, o, capacity, idx, r, tiles_x, world, rank, done, row_words);
+    if (mine && mine <= kCoopThreshold) emit_rect(tpairs, o, capacity, idx, r, tiles_x, row_lo, row_hi, done, row_words, tw.win, key);
     // large splats: one at a time, all 64 lanes
     unsigned long long big = __ballot(mine > kCoopThreshold);
     while (big) {
@@ -196,20 +228,25 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_emit(uint32_t jbase, uint3
         const uint32_t rx = __shfl(r.x, src, 64), ry = __shfl(r.y, src, 64);
         const uint32_t x0 = rx & 0xFFFFu, x1 = rx >> 16, y0 = ry & 0xFFFFu, y1 = ry >> 16;
         const uint32_t w = x1 - x0;
-        if (!done) {
-            // no saturated tiles: the k-th entry is tile (first + (k / w) * world, x0 + k % w)
-            const uint32_t first = first_owned_row(y0, world, rank);
+        const uint32_t bkey = __shfl(key, src, 64);
+        if (!done && !tw.win) {
+            // no saturated tiles: the k-th entry is tile (first + k / w, x0 + k % w)
+            const uint32_t first = max(y0, row_lo);
             const uint32_t total = __shfl(mine, src, 64);
             for (uint32_t k = lane; k < total; k += 64) {
-                const uint32_t ty = first + (k / w) * world, tx = x0 + k % w;
+                const uint32_t ty = first + k / w, tx = x0 + k % w;
                 if (bo + k < capacity) tpairs[bo + k] = make_uint2(ty * tiles_x + tx, bidx);
             }
         } else {
             // with a done bitmap the slots are not a closed form: lanes take whole rows, offsets by a wave scan
             uint32_t row_o = bo;
-            for (uint32_t ty0 = first_owned_row(y0, world, rank); ty0 < y1; ty0 += 64 * world) {
-                const uint32_t ty = ty0 + lane * world;
-                const uint32_t live = ty < y1 ? live_tiles_in_row(done, row_words, ty, x0, x1) : 0u;
+            const uint32_t ylast = min(y1, row_hi);
+            for (uint32_t ty0 = max(y0, row_lo); ty0 < ylast; ty0 += 64) {
+                const uint32_t ty = ty0 + lane;
+                uint32_t live = 0;
+                if (ty < ylast)
+                    live = tw.win ? window_tiles_in_row(done, row_words, tw.win, tiles_x, ty, x0, x1, bkey)
+                                  : live_tiles_in_row(done, row_words, ty, x0, x1);
                 uint32_t incl = live;
 #pragma unroll
                 for (int s = 1; s < 64; s <<= 1) {
@@ -217,9 +254,13 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_emit(uint32_t jbase, uint3
                     if (lane >= (uint32_t)s) incl += y;
                 }
                 uint32_t oo = row_o + incl - live;
-                if (ty < y1)
+                if (ty < ylast)
                     for (uint32_t tx = x0; tx < x1; ++tx) {
-                        if ((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u) continue;
+                        if (tw.win) {
+                            if (!tile_takes(done, row_words, tw.win, tiles_x, tx, ty, bkey)) continue;
+                        } else if ((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u) {
+                            continue;
+                        }
                         if (oo < capacity) tpairs[oo] = make_uint2(ty * tiles_x + tx, bidx);
                         ++oo;
                     }
@@ -242,12 +283,14 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const uint32_t* __restrict_
 
 hipError_t launch_tile_counts(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* d_n_vis, const uint32_t* sorted_idx,
                               const Records& rec, uint2* srect, uint32_t* cnt, uint32_t* block_sums, SlabStats* stats,
-                              uint32_t capacity, uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words,
-                              const uint32_t* d_done_count, uint32_t owned_tiles, uint32_t slab_index) {
+                              uint32_t capacity, uint32_t row_lo, uint32_t row_hi, const uint32_t* done, uint32_t row_words,
+                              const uint32_t* d_done_count, uint32_t owned_tiles, uint32_t slab_index,
+                              const uint2* window, const uint32_t* sorted_keys, uint32_t tiles_x) {
     uint32_t nb = (uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0);
+    TileWindow tw{window, sorted_keys, tiles_x};
     if (nb)
         hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(kBinThreads), 0, s, d_n_vis, j0, j1, sorted_idx, rec.a, srect, cnt,
-                           block_sums, world, rank, done, row_words, d_done_count, owned_tiles);
+                           block_sums, row_lo, row_hi, done, row_words, d_done_count, owned_tiles, tw);
     hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nb, stats, capacity, d_done_count,
                        owned_tiles, slab_index);
     return hipGetLastError();
@@ -255,12 +298,14 @@ hipError_t launch_tile_counts(hipStream_t s, uint32_t j0, uint32_t j1, const uin
 
 hipError_t launch_tile_emit(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* sorted_idx, const uint2* srect,
                             const uint32_t* cnt, const uint32_t* block_sums, uint32_t tiles_x, uint2* tpairs,
-                            uint32_t world, uint32_t rank, const uint32_t* done, uint32_t row_words,
-                            const uint32_t* d_n_vis, const uint32_t* d_entries, uint32_t capacity) {
+                            uint32_t row_lo, uint32_t row_hi, const uint32_t* done, uint32_t row_words,
+                            const uint32_t* d_n_vis, const uint32_t* d_entries, uint32_t capacity,
+                            const uint2* window, const uint32_t* sorted_keys) {
     uint32_t nb = (uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0);
     if (!nb) return hipSuccess;
+    TileWindow tw{window, sorted_keys, tiles_x};
     hipLaunchKernelGGL(k_tile_emit, dim3(nb), dim3(kBinThreads), 0, s, j0, j1, sorted_idx, srect, cnt, block_sums,
-                       tiles_x, tpairs, world, rank, done, row_words, d_n_vis, d_entries, capacity);
+                       tiles_x, tpairs, row_lo, row_hi, done, row_words, d_n_vis, d_entries, capacity, tw);
     return hipGetLastError();
 }
 

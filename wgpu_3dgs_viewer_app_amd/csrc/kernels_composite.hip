@@ -24,8 +24,9 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConsts f, uint2* _
                                                     const float4* __restrict__ rec_c, float4* __restrict__ fb,
                                                     const int carry, uint32_t* __restrict__ done_bits,
                                                     const uint32_t row_words, uint32_t* __restrict__ done_count,
-                                                    const int clear_ranges) {
+                                                    const int clear_ranges, uint32_t* __restrict__ tile_sat) {
     __shared__ float2 s_mean[kBatch];
+    __shared__ uint32_t s_sat;
     __shared__ float4 s_conic[kBatch];
     __shared__ float4 s_rgb[kBatch];
 
@@ -49,6 +50,8 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConsts f, uint2* _
         C0 = p.x; C1 = p.y; C2 = p.z; T = p.w;
     }
     bool done = !inside || T < f.t_eps;
+    uint32_t stop_key = 0;  // depth key of the splat that saturated this pixel (in this launch)
+    if (tid == 0) s_sat = 0;
 
     // software pipeline: the gather of batch b+1 (list -> three record planes, dependent random loads) is
     // in flight while batch b is blended out of LDS
@@ -92,15 +95,24 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConsts f, uint2* _
                 T = T * (1.0f - alpha);
                 if (T < f.t_eps) {
                     done = true;
+                    stop_key = __float_as_uint(c.w);
                     break;
                 }
             }
         }
     }
     if (inside) fb[fbo] = make_float4(C0, C1, C2, T);
-    if (done_bits && __syncthreads_and(done) && tid == 0) {
-        atomicOr(&done_bits[ty * row_words + (tx >> 5)], 1u << (tx & 31u));
-        atomicAdd(done_count, 1u);  // at most one per tile per frame
+    if (done_bits && __syncthreads_and(done)) {
+        // the tile saturated in this launch: its last pixels stopped here, behind everything blended earlier
+        if (tile_sat) {
+            if (stop_key) atomicMax(&s_sat, stop_key);
+            __syncthreads();
+        }
+        if (tid == 0) {
+            atomicOr(&done_bits[ty * row_words + (tx >> 5)], 1u << (tx & 31u));
+            atomicAdd(done_count, 1u);  // at most one per tile per frame
+            if (tile_sat) tile_sat[tile] = max(s_sat, 1u);  // saturation depth key (multi-GPU speculation); 0 = open
+        }
     }
 }
 
@@ -126,14 +138,14 @@ __global__ __launch_bounds__(256) void k_resolve_rgba8(const float4* __restrict_
 
 hipError_t launch_composite(hipStream_t s, const FrameConsts& f, uint2* ranges, const uint32_t* list,
                             const Records& rec, float4* fb, bool carry, uint32_t* done, uint32_t row_words,
-                            uint32_t* d_done_count, bool clear_ranges) {
+                            uint32_t* d_done_count, bool clear_ranges, uint32_t* tile_sat) {
     dim3 grid(f.tiles_x * f.tiles_y), block(256);
     if (f.display_mode == GSX_DISPLAY_SPLAT)
         hipLaunchKernelGGL(k_composite<0>, grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count,
-                           clear_ranges ? 1 : 0);
+                           clear_ranges ? 1 : 0, tile_sat);
     else
         hipLaunchKernelGGL(k_composite<1>, grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count,
-                           clear_ranges ? 1 : 0);
+                           clear_ranges ? 1 : 0, tile_sat);
     return hipGetLastError();
 }
 

@@ -2,10 +2,16 @@
 // rank, and import received records as a rank's per-frame record set.
 //
 // No reference counterpart (the reference is single-device, src/main.rs:85-98).  The Gaussian array is
-// sharded by splat index; tile row ty of the screen belongs to rank ty % world.  After the projection
+// sharded by splat index; the screen is cut into `world` contiguous bands of tile rows, band g = rank g.  After the projection
 // pass each rank sends every visible record to the rank(s) whose tile rows its rectangle touches
 // (RCCL all-to-all, done by the host layer), so that compositing — which is order dependent per
 // pixel — happens with ALL splats of a pixel on one GPU, in global depth order.
+// The exchange is speculative: every tile has a depth-key WINDOW [lo, hi) (host layer: hi = a margin behind the
+// depth at which the tile's neighbourhood saturated last frame, unbounded for tiles expected to stay open); a
+// record travels to a band only if some tile it touches there has its key inside the window, and the importing
+// side bins it into exactly those tiles (kernels_bin.hip, same predicate).  A verification step sends what a
+// wrongly predicted tile still misses as a second set of windows [hi, inf).  Whatever the windows, every tile
+// composites a gap-free depth prefix, so the pixels come out identical.
 // Packing is an order-preserving multi-destination stream compaction (records keep ascending local
 // index inside every destination group), which keeps the depth-tie order = global Gaussian index.
 // Record = 48 bytes: {mean.x, mean.y, rect.x, rect.y | conic a, b, c, opacity | r, g, b, depth}.
@@ -21,16 +27,39 @@ constexpr int kMaxWorld = 64;
 
 size_t pack_blocks(uint64_t n) { return (size_t)((n + kPackTile - 1) / kPackTile); }
 
-// does the half-open tile-row range [y0, y1) contain a row owned by `dest` (row % world == dest)?
-__device__ inline bool rows_touch(uint32_t y0, uint32_t y1, uint32_t world, uint32_t dest) {
-    uint32_t first = y0 + ((dest + world - (y0 % world)) % world);
-    return first < y1;
+// destinations of a record (key, tile rect): bit g set iff band g (tile rows [g*rpr, (g+1)*rpr)) holds a tile of the
+// rectangle whose window contains the key (window == nullptr: every touched band)
+__device__ inline unsigned long long dest_mask(const uint2* __restrict__ window, uint32_t tiles_x, uint32_t key,
+                                               uint32_t rx, uint32_t ry, uint32_t rpr, uint32_t world) {
+    const uint32_t x0 = rx & 0xFFFFu, x1 = rx >> 16, y0 = ry & 0xFFFFu, y1 = ry >> 16;
+    unsigned long long m = 0;
+    if (y0 >= y1 || x0 >= x1) return 0;
+    const uint32_t g0 = y0 / rpr, g1 = min((y1 - 1u) / rpr, world - 1u);
+    for (uint32_t g = g0; g <= g1; ++g) {
+        bool hit = window == nullptr;
+        if (!hit) {
+            const uint32_t ya = max(y0, g * rpr), yb = min(y1, (g + 1u) * rpr);
+            for (uint32_t ty = ya; ty < yb && !hit; ++ty)
+                for (uint32_t tx = x0; tx < x1; ++tx) {
+                    const uint2 w = window[ty * tiles_x + tx];
+                    if (key >= w.x && key < w.y) {
+                        hit = true;
+                        break;
+                    }
+                }
+        }
+        if (hit) m |= 1ull << g;
+    }
+    return m;
 }
 
+// per record: destination mask (stored for the scatter pass); per workgroup and destination: record count
 __global__ __launch_bounds__(kPackThreads) void k_pack_count(const uint32_t* __restrict__ key,
                                                               const float4* __restrict__ rec_a, uint32_t n,
-                                                              uint32_t world, uint32_t* __restrict__ table,
-                                                              uint32_t nblocks) {
+                                                              uint32_t world, uint32_t rpr,
+                                                              const uint2* __restrict__ window, uint32_t tiles_x,
+                                                              unsigned long long* __restrict__ masks,
+                                                              uint32_t* __restrict__ table, uint32_t nblocks) {
     __shared__ uint32_t cnt[kMaxWorld];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     if (tid < kMaxWorld) cnt[tid] = 0;
@@ -38,15 +67,16 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_count(const uint32_t* __r
     const uint32_t base = blockIdx.x * kPackTile + wave * kPackWaveChunk;
     for (int r = 0; r < kPackRounds; ++r) {
         uint32_t e = base + r * 64 + lane;
-        bool vis = e < n && key[e] != kCulledKey;
-        uint32_t y0 = 0, y1 = 0;
-        if (vis) {
-            uint32_t ry = __float_as_uint(rec_a[e].w);
-            y0 = ry & 0xFFFFu;
-            y1 = ry >> 16;
+        uint32_t kk = kCulledKey;
+        if (e < n) kk = key[e];
+        unsigned long long m = 0;
+        if (kk != kCulledKey) {
+            const float4 a = rec_a[e];
+            m = dest_mask(window, tiles_x, kk, __float_as_uint(a.z), __float_as_uint(a.w), rpr, world);
         }
+        if (e < n) masks[e] = m;
         for (uint32_t g = 0; g < world; ++g) {
-            unsigned long long bal = __ballot(vis && rows_touch(y0, y1, world, g));
+            unsigned long long bal = __ballot((m >> g) & 1ull);
             if (lane == 0 && bal) atomicAdd(&cnt[g], (uint32_t)__popcll(bal));
         }
     }
@@ -55,7 +85,7 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_count(const uint32_t* __r
 }
 
 // table rows were scanned exclusively in place (k_radix_rowscan), totals[g] = records for destination g
-__global__ __launch_bounds__(kPackThreads) void k_pack_scatter(const uint32_t* __restrict__ key,
+__global__ __launch_bounds__(kPackThreads) void k_pack_scatter(const unsigned long long* __restrict__ masks,
                                                                 const float4* __restrict__ rec_a,
                                                                 const float4* __restrict__ rec_b,
                                                                 const float4* __restrict__ rec_c, uint32_t n,
@@ -77,15 +107,9 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_scatter(const uint32_t* _
     // pass 1: per-wave counts
     for (int r = 0; r < kPackRounds; ++r) {
         uint32_t e = base + r * 64 + lane;
-        bool vis = e < n && key[e] != kCulledKey;
-        uint32_t y0 = 0, y1 = 0;
-        if (vis) {
-            uint32_t ry = __float_as_uint(rec_a[e].w);
-            y0 = ry & 0xFFFFu;
-            y1 = ry >> 16;
-        }
+        const unsigned long long m = e < n ? masks[e] : 0ull;
         for (uint32_t g = 0; g < world; ++g) {
-            unsigned long long bal = __ballot(vis && rows_touch(y0, y1, world, g));
+            unsigned long long bal = __ballot((m >> g) & 1ull);
             if (lane == 0) run[wave][g] += (uint32_t)__popcll(bal);
         }
     }
@@ -103,23 +127,19 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_scatter(const uint32_t* _
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (int r = 0; r < kPackRounds; ++r) {
         uint32_t e = base + r * 64 + lane;
-        bool vis = e < n && key[e] != kCulledKey;
+        const unsigned long long m = e < n ? masks[e] : 0ull;
         float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
-        uint32_t y0 = 0, y1 = 0;
-        if (vis) {
+        if (m) {
             a = rec_a[e];
             b = rec_b[e];
             c = rec_c[e];
-            uint32_t ry = __float_as_uint(a.w);
-            y0 = ry & 0xFFFFu;
-            y1 = ry >> 16;
         }
         for (uint32_t g = 0; g < world; ++g) {
-            bool m = vis && rows_touch(y0, y1, world, g);
-            unsigned long long bal = __ballot(m);
+            const bool hit = (m >> g) & 1ull;
+            unsigned long long bal = __ballot(hit);
             uint32_t o = run[wave][g];
             __builtin_amdgcn_wave_barrier();
-            if (m) {
+            if (hit) {
                 uint64_t pos = (uint64_t)o + (uint32_t)__popcll(bal & lt);
                 if (pos < capacity) {
                     send[3 * pos + 0] = a;
@@ -144,63 +164,27 @@ __global__ __launch_bounds__(256) void k_import_records(const float4* __restrict
     rec.key[i] = __float_as_uint(c.w);
 }
 
-// the rows of the framebuffer a rank owns, packed: strip[r][16][W] <- fb[(rank + r*world)*16 + y][x], zero padded
-__global__ __launch_bounds__(256) void k_pack_strip(const float4* __restrict__ fb, uint32_t w, uint32_t h, uint32_t world,
-                                                     uint32_t rank, uint32_t rows_per_rank, float4* __restrict__ strip) {
-    uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    uint64_t total = (uint64_t)rows_per_rank * kTile * w;
-    if (i >= total) return;
-    uint32_t x = (uint32_t)(i % w);
-    uint32_t yy = (uint32_t)(i / w);
-    uint32_t y = (rank + (yy / kTile) * world) * kTile + (yy % kTile);
-    strip[i] = y < h ? fb[(size_t)y * w + x] : make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-}
-
-// inverse on the gathering rank: all[g][r][16][W] -> fb
-__global__ __launch_bounds__(256) void k_unpack_strips(const float4* __restrict__ all, uint32_t w, uint32_t h, uint32_t world,
-                                                        uint32_t rows_per_rank, float4* __restrict__ fb) {
-    uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (i >= (uint64_t)w * h) return;
-    uint32_t x = (uint32_t)(i % w), y = (uint32_t)(i / w);
-    uint32_t trow = y / kTile, g = trow % world, r = trow / world;
-    fb[i] = all[(((size_t)g * rows_per_rank + r) * kTile + (y % kTile)) * w + x];
-}
-
-hipError_t launch_pack_count(hipStream_t s, const Records& rec, uint32_t n, uint32_t world, uint32_t* table) {
+hipError_t launch_pack_count(hipStream_t s, const Records& rec, uint32_t n, uint32_t world, uint32_t rows_per_rank,
+                             const uint2* window, uint32_t tiles_x, unsigned long long* masks, uint32_t* table) {
     uint32_t nb = (uint32_t)pack_blocks(n);
-    if (nb) hipLaunchKernelGGL(k_pack_count, dim3(nb), dim3(kPackThreads), 0, s, rec.key, rec.a, n, world, table, nb);
+    if (nb)
+        hipLaunchKernelGGL(k_pack_count, dim3(nb), dim3(kPackThreads), 0, s, rec.key, rec.a, n, world, rows_per_rank, window,
+                           tiles_x, masks, table, nb);
     return hipGetLastError();
 }
 
-hipError_t launch_pack_scatter(hipStream_t s, const Records& rec, uint32_t n, uint32_t world, const uint32_t* table,
-                               const uint32_t* totals, void* d_send, uint64_t capacity) {
+hipError_t launch_pack_scatter(hipStream_t s, const Records& rec, uint32_t n, uint32_t world,
+                               const unsigned long long* masks, const uint32_t* table, const uint32_t* totals, void* d_send,
+                               uint64_t capacity) {
     uint32_t nb = (uint32_t)pack_blocks(n);
     if (nb)
-        hipLaunchKernelGGL(k_pack_scatter, dim3(nb), dim3(kPackThreads), 0, s, rec.key, rec.a, rec.b, rec.c, n, world, table,
-                           nb, totals, reinterpret_cast<float4*>(d_send), capacity);
+        hipLaunchKernelGGL(k_pack_scatter, dim3(nb), dim3(kPackThreads), 0, s, masks, rec.a, rec.b, rec.c, n, world, table, nb,
+                           totals, reinterpret_cast<float4*>(d_send), capacity);
     return hipGetLastError();
 }
 
 hipError_t launch_import_records(hipStream_t s, const void* d_recv, uint32_t n, const Records& rec) {
     if (n) hipLaunchKernelGGL(k_import_records, dim3((n + 255) / 256), dim3(256), 0, s, reinterpret_cast<const float4*>(d_recv), n, rec);
-    return hipGetLastError();
-}
-
-hipError_t launch_pack_strip(hipStream_t s, const float4* fb, uint32_t w, uint32_t h, uint32_t world, uint32_t rank,
-                             uint32_t rows_per_rank, void* d_strip) {
-    uint64_t total = (uint64_t)rows_per_rank * kTile * w;
-    if (total)
-        hipLaunchKernelGGL(k_pack_strip, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, fb, w, h, world, rank,
-                           rows_per_rank, reinterpret_cast<float4*>(d_strip));
-    return hipGetLastError();
-}
-
-hipError_t launch_unpack_strips(hipStream_t s, const void* d_all, uint32_t w, uint32_t h, uint32_t world,
-                                uint32_t rows_per_rank, float4* fb) {
-    uint64_t total = (uint64_t)w * h;
-    if (total)
-        hipLaunchKernelGGL(k_unpack_strips, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                           reinterpret_cast<const float4*>(d_all), w, h, world, rows_per_rank, fb);
     return hipGetLastError();
 }
 

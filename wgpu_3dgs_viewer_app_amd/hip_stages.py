@@ -30,7 +30,8 @@ class HipStages:
         self.viewer = MultiModelViewer(size=(1, 1), device=device, stream=stream, sh=ShKind(sh), cov3d=Cov3dKind(cov3d))
         self._size = (1, 1)
         self._send = None
-        self._all = None
+        self._fb_t = None
+        self._fbk = None
 
     def stream_ctx(self):
         if self.torch_stream is None:
@@ -62,16 +63,50 @@ class HipStages:
         return self.viewer.frame_stats(key)
 
     # -- multi GPU (stage split of include/gsx.h) --
-    def project_and_pack(self, key: str, world: int):
+    def begin_frame(self, key: str, world: int, rank: int) -> None:
+        """Project the resident shard and make sure the library renders into the padded framebuffer RCCL gathers into."""
         import torch
 
         v = self.viewer
+        lay = _lib.ShardLayout()
+        _lib.check(v._L.gsx_shard_layout(v._h, world, rank, C.byref(lay)))
+        n_floats = lay.padded_framebuffer_bytes // 4
+        if self._fb_t is None or self._fb_t.numel() != n_floats:
+            self._fb_t = torch.zeros(n_floats, dtype=torch.float32, device=f"cuda:{self.device}")
+            self._band_t = torch.empty(lay.band_bytes // 4, dtype=torch.float32, device=f"cuda:{self.device}")
+            self._fbk = None
+            _lib.check(v._L.gsx_viewer_set_external_framebuffer(v._h, self._fb_t.data_ptr(), lay.padded_framebuffer_bytes))
+        self._lay = lay
         v.preprocessor.preprocess(key)
-        cap = max(self._n_local * world, 1)  # worst case: every record touches every rank's rows
+
+    def _window_ptr(self, window, slot):
+        """numpy uint32 [tiles_y, tiles_x, 2] -> device pointer (the library copies it, the tensor is kept until reused)."""
+        import torch
+
+        if window is None:
+            return None
+        t = torch.from_numpy(np.ascontiguousarray(window, np.uint32).view(np.int32)).to(f"cuda:{self.device}", non_blocking=True)
+        setattr(self, slot, t)
+        return t.data_ptr()
+
+    def pack(self, key: str, world: int, window=None):
+        """``gsx_shard_pack``; ``window``: per-tile depth-key windows, numpy uint32 [tiles_y, tiles_x, 2] or None = all."""
+        import torch
+
+        v = self.viewer
+        cap = max(self._n_local * min(world, 3), 1)  # a record reaches every band its rectangle touches; 3 is generous
         if self._send is None or self._send.shape[0] < cap:
             self._send = torch.empty((cap, RECORD_FLOATS), dtype=torch.float32, device=f"cuda:{self.device}")
+        d_win = self._window_ptr(window, "_pack_win_t")
         counts = (C.c_uint64 * world)()
-        _lib.check(v._L.gsx_shard_pack(v._h, key.encode(), world, self._send.data_ptr(), cap, counts))
+        try:
+            _lib.check(v._L.gsx_shard_pack(v._h, key.encode(), world, d_win, self._send.data_ptr(), cap, counts))
+        except _lib.GsxError:
+            need = sum(int(c) for c in counts)
+            if need <= cap:
+                raise
+            self._send = torch.empty((need, RECORD_FLOATS), dtype=torch.float32, device=f"cuda:{self.device}")
+            _lib.check(v._L.gsx_shard_pack(v._h, key.encode(), world, d_win, self._send.data_ptr(), need, counts))
         return self._send, [int(c) for c in counts]
 
     def alloc_records(self, n: int):
@@ -79,33 +114,38 @@ class HipStages:
 
         return torch.empty((n, RECORD_FLOATS), dtype=torch.float32, device=f"cuda:{self.device}")
 
-    def render_records(self, key: str, recv, n: int, world: int, rank: int) -> dict:
+    def render_records(self, key: str, recv, n: int, world: int, rank: int, more: bool = False, window=None) -> None:
+        """``gsx_shard_import`` + sort + render; ``window``: the same per-tile windows that were given to ``pack``."""
         v = self.viewer
-        _lib.check(v._L.gsx_shard_import(v._h, key.encode(), recv.data_ptr() if n else None, n, world, rank))
+        d_win = self._window_ptr(window, "_imp_win_t")
+        _lib.check(v._L.gsx_shard_import(v._h, key.encode(), recv.data_ptr() if n else None, n, world, rank, d_win))
         v.radix_sorter.sort(key)
-        v.renderer.render([key])
+        arr = (C.c_char_p * 1)(key.encode())
+        _lib.check((v._L.gsx_render_more if more else v._L.gsx_render)(v._h, arr, 1))
 
-    def own_strip(self, world: int, rank: int):
+    def feedback(self, key: str, world: int, rank: int):
+        """Device tensor int32[rows_per_rank * tiles_x] (u32 bit patterns): saturation depth key of every tile of this
+        rank's band, 0 = open."""
         import torch
 
         v = self.viewer
-        nbytes = C.c_uint64()
-        _lib.check(v._L.gsx_shard_strip_bytes(v._h, world, C.byref(nbytes)))
-        strip = torch.empty(nbytes.value // 4, dtype=torch.float32, device=f"cuda:{self.device}")
-        _lib.check(v._L.gsx_shard_pack_strip(v._h, world, rank, strip.data_ptr(), nbytes.value))
-        return strip
+        nw = C.c_uint32()
+        _lib.check(v._L.gsx_shard_feedback_words(v._h, world, C.byref(nw)))
+        if self._fbk is None or self._fbk.numel() != nw.value:
+            self._fbk = torch.zeros(nw.value, dtype=torch.int32, device=f"cuda:{self.device}")
+        _lib.check(v._L.gsx_shard_feedback(v._h, key.encode(), world, rank, self._fbk.data_ptr()))
+        return self._fbk
 
-    def gather_buffer(self, strip, world: int):
-        """One contiguous buffer of ``world`` strips that RCCL gathers into directly."""
-        import torch
+    def own_band(self):
+        """This rank's band of the framebuffer, copied out so the all-gather never aliases its own output."""
+        lay = self._lay
+        lo = lay.band_offset_bytes // 4
+        self._band_t.copy_(self._fb_t[lo: lo + lay.band_bytes // 4])
+        return self._band_t
 
-        if self._all is None or self._all.numel() != world * strip.numel():
-            self._all = torch.empty(world * strip.numel(), dtype=torch.float32, device=strip.device)
-        return self._all
-
-    def assemble(self, gathered, world: int) -> None:
-        v = self.viewer
-        _lib.check(v._L.gsx_shard_unpack_strips(v._h, world, gathered.data_ptr(), gathered.numel() * 4))
+    def gather_target(self):
+        """The padded framebuffer itself: RCCL all-gathers every rank's band into place."""
+        return self._fb_t
 
     # -- common --
     def framebuffer(self) -> np.ndarray:

@@ -5,12 +5,21 @@ dependent per pixel, so per-GPU images of index shards cannot simply be summed (
 path therefore has ONE real exchange step, sort-middle by screen rows:
 
   stage P  every rank projects / culls / colours its resident shard          (no communication)
-  stage X  projected 48-byte records are routed to the rank(s) that own the tile rows they touch
-           (tile row ty belongs to rank ty % world): RCCL all-to-all over xGMI, all 7 links busy
-  stage C  every rank depth-sorts what it received, bins it into ITS tile rows and composites them;
-           received records arrive ordered by (source rank, local index) = global index, so the
-           stable sort breaks depth ties exactly like the single-GPU path -> bit-identical pixels
-  stage M  the disjoint (rgb, T) tile-row strips are all-gathered and assembled into one framebuffer on rank 0.
+  stage X  projected 48-byte records are routed to the rank(s) owning the tile rows they touch (the screen
+           is cut into `world` contiguous bands of tile rows): RCCL all-to-all over xGMI, all 7 links busy
+  stage C  every rank depth-sorts what it received, bins it into ITS band and composites it in
+           progressive depth slabs; received records arrive ordered by (source rank, local index) =
+           global index, so the stable sort breaks depth ties exactly like the single-GPU path
+  stage M  the disjoint (rgb, T) bands are all-gathered straight into every rank's padded framebuffer.
+
+Opaque scenes hide most splats, so stage X is speculative: every 16x16 tile has a depth-key limit — (1 + margin) x
+the deepest depth at which its neighbourhood saturated last frame, unbounded where a neighbour stayed open — and a
+record travels to a band only if some tile it touches there still takes it; the importing rank bins it into exactly
+those tiles.  One small all-gather of the per-tile saturation depths verifies the limits and yields the next frame's;
+only if a limited tile is still open do the records it was refused travel in a second exchange (`gsx_render_more`
+composites them behind).  Whatever the limits, every tile composites a gap-free depth prefix, so the pixels are
+bit-identical to the single-GPU frame; the limits only decide how many bytes cross xGMI (one link per GPU pair: at
+2 GPUs the full 110 MB per frame would take ~2 ms).
 
 ``torch.distributed`` (backend nccl = RCCL) is plumbing only: it moves buffers the HIP kernels packed.
 The stage implementation is injectable (``stages=``) so the routing / merge logic is covered on CPU
@@ -21,6 +30,40 @@ from __future__ import annotations
 import numpy as np
 
 RECORD_FLOATS = 12  # mean.xy, rect.xy (bits), conic.abc, opacity, rgb, depth  = 48 bytes
+KEY_ALL = 0xFFFFFFFF  # exclusive upper bound of every valid depth key
+
+
+def next_limits(sat: np.ndarray, margin: float, radius: int) -> np.ndarray:
+    """Next frame's per-tile depth-key limit from this frame's saturation keys (uint32 [tiles_y, tiles_x], 0 = open):
+    (1 + margin) x the deepest saturation depth in the tile's (2 radius + 1)^2 neighbourhood — the camera moves —
+    and KEY_ALL (unbounded) if any tile of the neighbourhood stayed open.  Outside the frame counts as nothing."""
+    sat = np.asarray(sat, np.uint32)
+    d = np.where(sat != 0, sat.view(np.float32), np.float32(np.inf)).astype(np.float32)
+    p = np.pad(d, radius, constant_values=np.float32(0.0))
+    m = np.zeros_like(d)
+    ty, tx = d.shape
+    for dy in range(2 * radius + 1):
+        for dx in range(2 * radius + 1):
+            np.maximum(m, p[dy: dy + ty, dx: dx + tx], out=m)
+    lim = (m * np.float32(1.0 + margin)).astype(np.float32)
+    out = lim.view(np.uint32).copy()
+    out[~np.isfinite(lim)] = KEY_ALL
+    return np.maximum(out, 1)
+
+
+def windows_first(limit: np.ndarray) -> np.ndarray:
+    """Round 1: tile t admits the keys [0, limit[t])."""
+    w = np.zeros(limit.shape + (2,), np.uint32)
+    w[..., 1] = limit
+    return w
+
+
+def windows_second(limit: np.ndarray, need: np.ndarray) -> np.ndarray:
+    """Round 2: the tiles in `need` admit what they were refused, [limit[t], KEY_ALL); every other tile nothing."""
+    w = np.zeros(limit.shape + (2,), np.uint32)
+    w[..., 0] = np.where(need, limit, 0)
+    w[..., 1] = np.where(need, KEY_ALL, 0)
+    return w
 
 
 def shard_range(n: int, rank: int, world: int):
@@ -30,9 +73,30 @@ def shard_range(n: int, rank: int, world: int):
     return start, base + (1 if rank < rem else 0)
 
 
-def rows_owned(tiles_y: int, rank: int, world: int) -> np.ndarray:
-    """Tile rows owned by a rank: ty % world == rank."""
-    return np.arange(rank, tiles_y, world)
+class TorchComm:
+    """The three collectives of the path on ``torch.distributed`` (nccl = RCCL over xGMI; gloo in the CPU tests)."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def all_to_all_counts(self, counts, device):
+        import torch
+        import torch.distributed as dist
+
+        sc = torch.as_tensor(counts, dtype=torch.int64, device=device)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc, group=self.group)
+        return [int(x) for x in rc.tolist()]
+
+    def all_to_all_records(self, recv, send, recv_counts, send_counts):
+        import torch.distributed as dist
+
+        dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=self.group)
+
+    def all_gather(self, out, inp):
+        import torch.distributed as dist
+
+        dist.all_gather_into_tensor(out, inp, group=self.group)
 
 
 class ShardedViewer:
@@ -42,14 +106,23 @@ class ShardedViewer:
     KEY = "shard"
 
     def __init__(self, device: int = 0, world: int = 1, rank: int = 0, use_dist: bool = False, stream=None,
-                 stages=None, group=None, sh: int = 0, cov3d: int = 0):
-        self.world, self.rank, self.use_dist, self.group = world, rank, use_dist, group
+                 stages=None, group=None, sh: int = 0, cov3d: int = 0, comm=None):
+        self.world, self.rank, self.use_dist = world, rank, use_dist
+        self.comm = comm if comm is not None else TorchComm(group)  # injectable: tests drive `world` ranks as threads
         if stages is None:
             from .hip_stages import HipStages  # the product path: libgsx.so, fails loudly if missing
 
             stages = HipStages(device=device, stream=stream, use_torch=use_dist, sh=sh, cov3d=cov3d)
         self.stages = stages
-        self._stats = dict(n_gaussians=0, n_visible=0, n_tile_entries=0)
+        self._limit = None  # uint32 [tiles_y, tiles_x]: per-tile depth-key limit of the next frame; None = everything travels
+        self.speculate = True
+        # measured on cfg4 at 8 ranks (tools/emulate_ranks.py): margin 0.5 / radius 3 moves 3.6 MB per rank and frame instead
+        # of 51.6 MB and needs the second exchange in 18 % of the frames (tiles that open up from nothing: unpredictable)
+        self.margin = 0.5   # how far behind last frame's saturation depth a tile still takes records
+        self.radius = 3     # tiles; neighbourhood over which the saturation depth is maximised (camera motion)
+        self.rounds = 0
+        self.debug, self.debug_log = False, []
+        self._size = (1, 1)
 
     # -- scene --
     def load_shard(self, gaussians: np.ndarray, start: int, n_total: int) -> None:
@@ -60,36 +133,68 @@ class ShardedViewer:
         """One frame.  On rank 0 ``self.stages.framebuffer()`` afterwards holds the complete (rgb, T) image."""
         st = self.stages
         st.set_uniforms(self.KEY, camera, size, model_transform, gaussian_transform)
+        self._size = (int(size[0]), int(size[1]))
         if not self.use_dist:
             st.render_local(self.KEY)
             return
         with st.stream_ctx():
             self._render_frame_dist()
 
-    def _render_frame_dist(self):
-        import torch
-        import torch.distributed as dist
+    def _exchange(self, send, send_counts):
+        """counts, then the 48-byte records with exact split sizes (two all-to-alls)."""
+        st = self.stages
+        send_counts = [int(x) for x in send_counts]
+        recv_counts = self.comm.all_to_all_counts(send_counts, send.device)
+        recv = st.alloc_records(sum(recv_counts))
+        self.comm.all_to_all_records(recv, send[: sum(send_counts)], recv_counts, send_counts)
+        return recv, sum(recv_counts)
 
+    def _feedback(self, tiles_x, tiles_y):
+        """Saturation depth key of every tile of the frame (0 = open): each rank contributes its band, one small
+        all-gather; the result is identical on every rank."""
+        import torch
+
+        mine = self.stages.feedback(self.KEY, self.world, self.rank)
+        allw = torch.empty(self.world * mine.numel(), dtype=mine.dtype, device=mine.device)
+        self.comm.all_gather(allw, mine)
+        return allw.cpu().numpy().view(np.uint32).reshape(-1, tiles_x)[:tiles_y]
+
+    def _render_frame_dist(self):
         st = self.stages
         world, rank = self.world, self.rank
-        # stage P + pack: records grouped by destination rank, ascending local index inside each group
-        send, send_counts = st.project_and_pack(self.KEY, world)
-        # stage X: counts first (tiny), then the records with exact split sizes
-        sc = torch.as_tensor(send_counts, dtype=torch.int64, device=send.device)
-        rc = torch.empty_like(sc)
-        dist.all_to_all_single(rc, sc, group=self.group)
-        recv_counts = [int(x) for x in rc.tolist()]
-        recv = st.alloc_records(sum(recv_counts))
-        dist.all_to_all_single(recv, send[: sum(send_counts)], output_split_sizes=recv_counts,
-                               input_split_sizes=[int(x) for x in send_counts], group=self.group)
-        # stage C: sort + bin + composite this rank's tile rows
-        st.render_records(self.KEY, recv, sum(recv_counts), world, rank)
-        # stage M: the disjoint tile-row strips are all-gathered (every rank could present; rank 0 assembles)
-        strip = st.own_strip(world, rank)  # flat [rows_per_rank * 16 * W * 4]: the rows this rank owns, packed
-        gathered = st.gather_buffer(strip, world)  # flat [world * strip]
-        dist.all_gather_into_tensor(gathered, strip, group=self.group)
-        if rank == 0:
-            st.assemble(gathered, world)
+        tiles_x, tiles_y = (self._size[0] + 15) // 16, (self._size[1] + 15) // 16
+        # stage P: project the resident shard
+        st.begin_frame(self.KEY, world, rank)
+        # stage X/C: every tile takes the records in front of its limit (first frame / speculation off: everything)
+        limit = self._limit if self.speculate else None
+        if limit is not None and limit.shape != (tiles_y, tiles_x):
+            limit = None
+        win = windows_first(limit) if limit is not None else None
+        send, counts = st.pack(self.KEY, world, win)
+        recv, n = self._exchange(send, counts)
+        st.render_records(self.KEY, recv, n, world, rank, more=False, window=win)
+        # verification + next frame's limits from one collective
+        sat = self._feedback(tiles_x, tiles_y)
+        self.rounds = 1
+        if limit is not None:
+            need = (limit < KEY_ALL) & (sat == 0)  # refused its deep records but still open
+            if need.any():
+                win2 = windows_second(limit, need)
+                send, counts = st.pack(self.KEY, world, win2)
+                recv, n = self._exchange(send, counts)
+                st.render_records(self.KEY, recv, n, world, rank, more=True, window=win2)
+                sat = self._feedback(tiles_x, tiles_y)
+                self.rounds = 2
+                if self.debug:  # what the wrong limits looked like (dev tool)
+                    s2 = sat[need]
+                    lim_d = limit[need].view(np.float32)
+                    ratio = np.where(s2 != 0, s2.view(np.float32) / lim_d, np.float32(np.inf))
+                    self.debug_log.append(dict(need=int(need.sum()), stayed_open=int((s2 == 0).sum()),
+                                               ratio_median=float(np.median(ratio)), ratio_max=float(ratio[np.isfinite(ratio)].max(initial=0)),
+                                               rows=np.unique(np.nonzero(need)[0]).tolist()))
+        self._limit = next_limits(sat, self.margin, self.radius)
+        # stage M: the disjoint bands of tile rows are all-gathered straight into the framebuffer
+        self.comm.all_gather(st.gather_target(), st.own_band())
 
     def framebuffer(self) -> np.ndarray:
         return self.stages.framebuffer()
