@@ -37,6 +37,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="Gaussians in the CPU baseline sample")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded exchange path even at N=1")
+    ap.add_argument("--host-profile", action="store_true", help="print host wall time per exchange-protocol section (adds syncs; debug)")
     ap.add_argument("--pod", default="single/single", help="pod storage sh/cov3d: single|half|norm8|none / single|half "
                     "(reference default is norm8/half; the headline metric is quoted on the f32 pod)")
     return ap.parse_args()
@@ -114,6 +115,8 @@ def main():
     renderer.poll()
     renderer.set_pass_timing(True)
     renderer.get_pass_timing()  # reset accumulators
+    if args.host_profile and use_dist:
+        renderer.profile = {}
 
     def fence():
         torch.cuda.synchronize()
@@ -134,6 +137,8 @@ def main():
         elapsed = float(t.item())
 
     timing = renderer.get_pass_timing()
+    if args.host_profile and use_dist and rank == 0:
+        print("host ms/frame by section:", {k: round(1e3 * x / args.steps, 4) for k, x in renderer.profile.items()}, file=sys.stderr)
     stats = renderer.last_stats()
     renderer.set_pass_timing(False)
 

@@ -318,7 +318,7 @@ int main(int argc, char** argv) {
     Var{"layout=" #L " eager=" #E " lb=" #W, [](const FrameConsts& f, In in, Out out, uint32_t* nv, uint32_t nb) { \
             hipLaunchKernelGGL((k_var<L, E, W>), dim3(nb), dim3(256), 0, 0, f, in, out, nv);                        \
         }}
-    std::vector<Var> vars = {VAR(0, 0, 1), VAR(2, 0, 1), VAR(0, 1, 1), VAR(2, 1, 1), VAR(0, 0, 2), VAR(2, 0, 2), VAR(0, 0, 1), VAR(2, 0, 1)};
+    std::vector<Var> vars = {VAR(0, 0, 1), VAR(2, 0, 1), VAR(1, 0, 1), VAR(2, 1, 1), VAR(1, 1, 1), VAR(2, 0, 2), VAR(1, 0, 2), VAR(2, 0, 1)};
     std::vector<std::vector<float>> ms(vars.size() + 1);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

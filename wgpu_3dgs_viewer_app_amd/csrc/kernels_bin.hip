@@ -14,6 +14,7 @@
 namespace gsx {
 
 constexpr int kBinThreads = 256;  // one splat per lane
+constexpr uint32_t kCoopThreshold = 24;  // rectangles with more tiles are expanded by the whole wave
 
 size_t scan_blocks(uint64_t n) { return (size_t)((n + kBinThreads - 1) / kBinThreads); }
 
@@ -102,19 +103,41 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_counts(const uint32_t* __r
     }
     const uint32_t n_vis = min(*d_n_vis, j1);
     const uint32_t j = j0 + blockIdx.x * kBinThreads + threadIdx.x;
-    uint32_t c = 0;
+    uint32_t c = 0, rx = 0, ry = 0, key = 0, area = 0;
     if (j < n_vis) {
         const float4 a = rec_a[sorted_idx[j]];
+        rx = __float_as_uint(a.z);
+        ry = __float_as_uint(a.w);
         if (tw.win) {
-            const uint32_t rx = __float_as_uint(a.z), ry = __float_as_uint(a.w), key = tw.sorted_keys[j];
-            for (uint32_t ty = max(ry & 0xFFFFu, row_lo), last = min(ry >> 16, row_hi); ty < last; ++ty)
-                c += window_tiles_in_row(done, row_words, tw.win, tw.tiles_x, ty, rx & 0xFFFFu, rx >> 16, key);
+            key = tw.sorted_keys[j];
+            area = rect_area(a, row_lo, row_hi);
+            if (area <= kCoopThreshold)
+                for (uint32_t ty = max(ry & 0xFFFFu, row_lo), last = min(ry >> 16, row_hi); ty < last; ++ty)
+                    c += window_tiles_in_row(done, row_words, tw.win, tw.tiles_x, ty, rx & 0xFFFFu, rx >> 16, key);
         } else {
             c = done ? rect_live_area(a, row_lo, row_hi, done, row_words) : rect_area(a, row_lo, row_hi);
         }
-        srect[j - j0] = make_uint2(__float_as_uint(a.z), __float_as_uint(a.w));
-        cnt[j - j0] = c;
+        srect[j - j0] = make_uint2(rx, ry);
     }
+    if (tw.win) {
+        // large rectangles: the whole wave evaluates the window predicate, lane l takes tiles l, l + 64, ...
+        unsigned long long big = __ballot(area > kCoopThreshold);
+        const uint32_t lane = threadIdx.x & 63u;
+        while (big) {
+            const int src = __ffsll((long long)big) - 1;
+            big &= big - 1;
+            const uint32_t brx = __shfl(rx, src, 64), bry = __shfl(ry, src, 64), bkey = __shfl(key, src, 64);
+            const uint32_t total = __shfl(area, src, 64);
+            const uint32_t x0 = brx & 0xFFFFu, w = (brx >> 16) - x0, first = max(bry & 0xFFFFu, row_lo);
+            uint32_t n = 0;
+            for (uint32_t k = lane; k < total; k += 64)
+                n += tile_takes(done, row_words, tw.win, tw.tiles_x, x0 + k % w, first + k / w, bkey) ? 1u : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+            if ((int)lane == src) c = n;
+        }
+    }
+    if (j < n_vis) cnt[j - j0] = c;
     uint32_t tot = block_reduce_sum(c, red);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
@@ -166,8 +189,6 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__
 // Splats touching up to kCoopThreshold live tiles are written by their own lane; the few large ones are
 // expanded cooperatively by the whole wave (lane l writes tiles l, l+64, ...), which removes the long
 // divergent tail a single lane would otherwise serialise.
-constexpr uint32_t kCoopThreshold = 24;
-
 __device__ inline void emit_rect(uint2* __restrict__ tpairs, uint32_t o, uint32_t capacity, uint32_t idx, uint2 r,
                                  uint32_t tiles_x, uint32_t row_lo, uint32_t row_hi, const uint32_t* __restrict__ done,
                                  uint32_t row_words, const uint2* __restrict__ win, uint32_t key) {

@@ -24,6 +24,7 @@ constexpr int kPackRounds = 16;
 constexpr int kPackTile = kPackThreads * kPackRounds;  // 4096 records per workgroup
 constexpr int kPackWaveChunk = 64 * kPackRounds;
 constexpr int kMaxWorld = 64;
+constexpr uint32_t kPackCoop = 32;  // rectangles with more tiles are tested against the windows by the whole wave
 
 size_t pack_blocks(uint64_t n) { return (size_t)((n + kPackTile - 1) / kPackTile); }
 
@@ -70,9 +71,39 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_count(const uint32_t* __r
         uint32_t kk = kCulledKey;
         if (e < n) kk = key[e];
         unsigned long long m = 0;
+        uint32_t rx = 0, ry = 0, area = 0;
         if (kk != kCulledKey) {
             const float4 a = rec_a[e];
-            m = dest_mask(window, tiles_x, kk, __float_as_uint(a.z), __float_as_uint(a.w), rpr, world);
+            rx = __float_as_uint(a.z);
+            ry = __float_as_uint(a.w);
+            area = ((rx >> 16) - (rx & 0xFFFFu)) * ((ry >> 16) - (ry & 0xFFFFu));
+            if (!window || area <= kPackCoop) m = dest_mask(window, tiles_x, kk, rx, ry, rpr, world);
+        }
+        if (window) {
+            // large rectangles (mostly hidden background splats that no tile admits): the whole wave scans the tiles
+            unsigned long long big = __ballot(area > kPackCoop);
+            while (big) {
+                const int src = __ffsll((long long)big) - 1;
+                big &= big - 1;
+                const uint32_t brx = __shfl(rx, src, 64), bry = __shfl(ry, src, 64), bkey = __shfl(kk, src, 64);
+                const uint32_t total = __shfl(area, src, 64);
+                const uint32_t x0 = brx & 0xFFFFu, w = (brx >> 16) - x0, y0 = bry & 0xFFFFu;
+                uint32_t lo = 0, hi = 0;  // destination bits 0..31 / 32..63
+                for (uint32_t k = lane; k < total; k += 64) {
+                    const uint32_t ty = y0 + k / w;
+                    const uint2 ww = window[ty * tiles_x + x0 + k % w];
+                    if (bkey >= ww.x && bkey < ww.y) {
+                        const uint32_t g = min(ty / rpr, world - 1u);
+                        if (g < 32u) lo |= 1u << g; else hi |= 1u << (g - 32u);
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    lo |= __shfl_xor(lo, o, 64);
+                    hi |= __shfl_xor(hi, o, 64);
+                }
+                if ((int)lane == src) m = ((unsigned long long)hi << 32) | lo;
+            }
         }
         if (e < n) masks[e] = m;
         for (uint32_t g = 0; g < world; ++g) {

@@ -39,12 +39,14 @@ def next_limits(sat: np.ndarray, margin: float, radius: int) -> np.ndarray:
     and KEY_ALL (unbounded) if any tile of the neighbourhood stayed open.  Outside the frame counts as nothing."""
     sat = np.asarray(sat, np.uint32)
     d = np.where(sat != 0, sat.view(np.float32), np.float32(np.inf)).astype(np.float32)
-    p = np.pad(d, radius, constant_values=np.float32(0.0))
-    m = np.zeros_like(d)
     ty, tx = d.shape
+    p = np.pad(d, ((radius, radius), (0, 0)), constant_values=np.float32(0.0))   # separable max filter: rows, then columns
+    m = p[radius: radius + ty].copy()
     for dy in range(2 * radius + 1):
-        for dx in range(2 * radius + 1):
-            np.maximum(m, p[dy: dy + ty, dx: dx + tx], out=m)
+        np.maximum(m, p[dy: dy + ty], out=m)
+    p = np.pad(m, ((0, 0), (radius, radius)), constant_values=np.float32(0.0))
+    for dx in range(2 * radius + 1):
+        np.maximum(m, p[:, dx: dx + tx], out=m)
     lim = (m * np.float32(1.0 + margin)).astype(np.float32)
     out = lim.view(np.uint32).copy()
     out[~np.isfinite(lim)] = KEY_ALL
@@ -122,6 +124,7 @@ class ShardedViewer:
         self.radius = 3     # tiles; neighbourhood over which the saturation depth is maximised (camera motion)
         self.rounds = 0
         self.debug, self.debug_log = False, []
+        self.profile = None  # set to {} to collect host wall time per protocol section (adds device syncs)
         self._size = (1, 1)
 
     # -- scene --
@@ -159,22 +162,43 @@ class ShardedViewer:
         self.comm.all_gather(allw, mine)
         return allw.cpu().numpy().view(np.uint32).reshape(-1, tiles_x)[:tiles_y]
 
+    def _tick(self, name):
+        """Dev aid (self.profile = {}): host wall time per protocol section, with a device sync at every boundary."""
+        if self.profile is None:
+            return
+        import time
+
+        self.stages.poll()
+        now = time.perf_counter()
+        self.profile[name] = self.profile.get(name, 0.0) + (now - self._t_last)
+        self._t_last = now
+
     def _render_frame_dist(self):
         st = self.stages
         world, rank = self.world, self.rank
         tiles_x, tiles_y = (self._size[0] + 15) // 16, (self._size[1] + 15) // 16
+        if self.profile is not None:
+            import time
+
+            st.poll()
+            self._t_last = time.perf_counter()
         # stage P: project the resident shard
         st.begin_frame(self.KEY, world, rank)
+        self._tick("project")
         # stage X/C: every tile takes the records in front of its limit (first frame / speculation off: everything)
         limit = self._limit if self.speculate else None
         if limit is not None and limit.shape != (tiles_y, tiles_x):
             limit = None
         win = windows_first(limit) if limit is not None else None
         send, counts = st.pack(self.KEY, world, win)
+        self._tick("pack")
         recv, n = self._exchange(send, counts)
+        self._tick("exchange")
         st.render_records(self.KEY, recv, n, world, rank, more=False, window=win)
+        self._tick("import_sort_render")
         # verification + next frame's limits from one collective
         sat = self._feedback(tiles_x, tiles_y)
+        self._tick("feedback")
         self.rounds = 1
         if limit is not None:
             need = (limit < KEY_ALL) & (sat == 0)  # refused its deep records but still open
@@ -185,6 +209,7 @@ class ShardedViewer:
                 st.render_records(self.KEY, recv, n, world, rank, more=True, window=win2)
                 sat = self._feedback(tiles_x, tiles_y)
                 self.rounds = 2
+                self._tick("second_round")
                 if self.debug:  # what the wrong limits looked like (dev tool)
                     s2 = sat[need]
                     lim_d = limit[need].view(np.float32)
@@ -193,8 +218,10 @@ class ShardedViewer:
                                                ratio_median=float(np.median(ratio)), ratio_max=float(ratio[np.isfinite(ratio)].max(initial=0)),
                                                rows=np.unique(np.nonzero(need)[0]).tolist()))
         self._limit = next_limits(sat, self.margin, self.radius)
+        self._tick("policy")
         # stage M: the disjoint bands of tile rows are all-gathered straight into the framebuffer
         self.comm.all_gather(st.gather_target(), st.own_band())
+        self._tick("gather")
 
     def framebuffer(self) -> np.ndarray:
         return self.stages.framebuffer()
