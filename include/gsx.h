@@ -208,6 +208,69 @@ gsx_status gsx_model_download_tile_lists(gsx_viewer* v, const char* key, uint32_
 gsx_status gsx_model_download_pod(gsx_viewer* v, const char* key, float* pos, uint32_t* color, float* sh,
                                   float* cov3d);
 
+/* ---- selection, per-Gaussian edits, queries.  The app builds the pods and calls
+ *      the crate (src/tab/scene.rs:740-835, 601-614, 651-657; app.rs:1479-1564); the arithmetic is the build's,
+ *      spec/RENDER_SPEC.md §7 [BUILD-SPEC].  None of this costs anything while no selection / edit / query exists. ---- */
+#define GSX_EDIT_ENABLED 1u        /* gs::GaussianEditFlag::ENABLED        (app.rs:1546-1552) */
+#define GSX_EDIT_HIDDEN 2u         /* gs::GaussianEditFlag::HIDDEN */
+#define GSX_EDIT_OVERRIDE_COLOR 4u /* gs::GaussianEditFlag::OVERRIDE_COLOR: color is RGB, otherwise an HSV edit */
+/* gs::GaussianEditPod::new(flag, color, contrast, exposure, gamma, alpha) (app.rs:1553-1562); 32 bytes */
+typedef struct gsx_gaussian_edit {
+    uint32_t flag;
+    float color[3]; /* HSV edit: hue shift [0,1], saturation factor, brightness factor; or the override RGB */
+    float contrast, exposure, gamma, alpha;
+} gsx_gaussian_edit;
+void gsx_gaussian_edit_default(gsx_gaussian_edit* e); /* gs::GaussianEditPod::default(): flag 0, (0,1,1), 0, 0, 1, 1 */
+
+typedef enum gsx_query_kind {  /* gs::QueryNonePod / QueryHitPod / the QueryToolset's rect, brush and texture queries */
+    GSX_QUERY_NONE = 0, GSX_QUERY_HIT = 1, GSX_QUERY_RECT = 2, GSX_QUERY_BRUSH = 3, GSX_QUERY_TEXTURE = 4
+} gsx_query_kind;
+typedef enum gsx_selection_op { GSX_SELECTION_SET = 0, GSX_SELECTION_ADD = 1, GSX_SELECTION_REMOVE = 2 } gsx_selection_op;
+typedef struct gsx_query {  /* coordinates in viewport pixels, origin top-left */
+    uint32_t kind;         /* gsx_query_kind */
+    uint32_t selection_op; /* gsx_selection_op (gs::QuerySelectionOp, scene.rs:1605), applied by gsx_postprocess */
+    float p0[2];           /* Hit: the point; Rect: one corner; Brush: stroke start */
+    float p1[2];           /* Rect: the opposite corner; Brush: stroke end */
+    float radius;          /* Brush */
+    uint32_t reserved;
+} gsx_query;
+typedef struct gsx_query_hit { uint32_t index; float depth; float alpha; uint32_t reserved; } gsx_query_hit; /* gs::QueryHitResultPod */
+#define GSX_QUERY_MAX_HITS 65536u
+
+/* viewer.update_query(queue, &pod) (scene.rs:785): the query every following gsx_preprocess evaluates. */
+gsx_status gsx_update_query(gsx_viewer* v, const gsx_query* q);
+/* The query texture the toolset paints its strokes into (viewer.update_query_texture_size + QueryToolset::render,
+ * scene.rs:740, 791): width*height bytes from HOST memory, non-zero = selected; must match the viewport. */
+gsx_status gsx_update_query_texture(gsx_viewer* v, const uint8_t* texels, uint32_t width, uint32_t height);
+/* viewer.update_selection_highlight(queue, rgba) / _with_pod (scene.rs:816-829); alpha 0 = no highlight. */
+gsx_status gsx_update_selection_highlight(gsx_viewer* v, const float rgba[4]);
+/* viewer.update_selection_edit_with_pod(queue, &pod) (scene.rs:815, 821, 848): while ENABLED, every preprocess writes
+ * it into the edit records of the selected Gaussians. */
+gsx_status gsx_update_selection_edit(gsx_viewer* v, const gsx_gaussian_edit* e);
+/* The "unedited model" bind group (scene.rs:856-863): on != 0 renders the model ignoring (and not touching) edits. */
+gsx_status gsx_model_show_unedited(gsx_viewer* v, const char* key, uint32_t on);
+/* postprocessor.postprocess(...) (scene.rs:601-611): applies the selection op of a Rect/Brush/Texture query evaluated
+ * by the last gsx_preprocess(key) to the model's selection. */
+gsx_status gsx_postprocess(gsx_viewer* v, const char* key);
+/* Selection bitset, ceil(len/32) words, bit i = Gaussian i selected. */
+gsx_status gsx_model_upload_selection(gsx_viewer* v, const char* key, const uint32_t* words, uint64_t n_words);
+gsx_status gsx_model_download_selection(gsx_viewer* v, const char* key, uint32_t* words, uint64_t n_words);
+/* gaussians_edit_buffer.download() (app.rs:789): len records; Gaussians never edited read as the default pod. */
+gsx_status gsx_model_download_edits(gsx_viewer* v, const char* key, gsx_gaussian_edit* out, uint64_t n);
+gsx_status gsx_model_upload_edits(gsx_viewer* v, const char* key, const gsx_gaussian_edit* edits, uint64_t n);
+/* gs::query::download(count_buffer, results_buffer) (scene.rs:651-657): hits of the last Hit query on `key`, sorted by
+ * (depth, index). */
+gsx_status gsx_query_download_hits(gsx_viewer* v, const char* key, gsx_query_hit* out, uint64_t capacity, uint64_t* out_n);
+/* gs::query::hit_pos_by_closest / hit_pos_by_alpha_range (scene.rs:660-679), host arithmetic: world position on the
+ * pixel ray through `coords` at the chosen hit's depth.  view/proj column-major as in gsx_update_camera.
+ * GSX_ERR_NOT_FOUND when there is no hit. */
+gsx_status gsx_query_hit_pos_by_closest(const gsx_query_hit* hits, uint64_t n, const float view[16], const float proj[16],
+                                        uint32_t width, uint32_t height, const float coords[2], uint32_t* out_index,
+                                        float out_pos[3]);
+gsx_status gsx_query_hit_pos_by_alpha_range(const gsx_query_hit* hits, uint64_t n, const float view[16], const float proj[16],
+                                            uint32_t width, uint32_t height, const float coords[2], float range,
+                                            uint32_t* out_index, float* out_alpha, float out_pos[3]);
+
 /* ---- multi-GPU stage split.  No reference counterpart: the reference renders on one wgpu device
  *      (src/main.rs:85-98).  One process per GPU holds an index shard of the Gaussians; the screen is cut into
  *      `world` contiguous bands of tile rows, band g = rank g.  Per frame and rank:
@@ -276,9 +339,11 @@ gsx_status gsx_ply_read_header(const void* data, uint64_t size, gsx_ply_header* 
 gsx_status gsx_ply_read_gaussians(const void* data, uint64_t size, const gsx_ply_header* header, uint64_t start,
                                   uint64_t n, gsx_gaussian* out);
 /* Inverse conversion into a binary_little_endian INRIA PLY.  mask_words (nullable): only Gaussians whose bit
- * is set are written (write_ply's mask iterator).  Call with out == NULL to get the size in *out_size. */
-gsx_status gsx_ply_write(const gsx_gaussian* gaussians, uint64_t n, const uint32_t* mask_words, void* out,
-                         uint64_t capacity, uint64_t* out_size);
+ * is set are written (write_ply's mask iterator).  edits (nullable, n records; write_ply's Option<&[GaussianEditPod]>,
+ * app.rs:908-940): ENABLED+HIDDEN Gaussians are dropped, the other ENABLED edits are baked into f_dc / opacity
+ * (spec §7 Export).  Call with out == NULL to get the size in *out_size. */
+gsx_status gsx_ply_write(const gsx_gaussian* gaussians, uint64_t n, const uint32_t* mask_words,
+                         const gsx_gaussian_edit* edits, void* out, uint64_t capacity, uint64_t* out_size);
 
 /* ---- timing: HIP events recorded on the viewer's stream around each pass of the last frame ---- */
 typedef enum gsx_pass {

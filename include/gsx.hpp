@@ -106,13 +106,57 @@ public:
     }
     void update_range(size_t start, const std::vector<Gaussian>& g) { update_range(start, g.data(), g.size()); }
 };
-struct MultiModelViewerGaussianBuffers { GaussiansBuffer gaussians_buffer; };
+class MaskBuffer {  // gs::MaskBuffer (scene.rs:1851, app.rs:806-807): bit = kept
+    gsx_viewer* v_;
+    std::string key_;
+public:
+    MaskBuffer(gsx_viewer* v, std::string key) : v_(v), key_(std::move(key)) {}
+    void upload(const std::vector<uint32_t>& words) { check(gsx_model_upload_mask(v_, key_.c_str(), words.data(), words.size())); }
+    std::vector<uint32_t> download(size_t n_gaussians) {
+        std::vector<uint32_t> w((n_gaussians + 31) / 32);
+        check(gsx_model_download_mask(v_, key_.c_str(), w.data(), w.size()));
+        return w;
+    }
+};
+class SelectionBuffer {  // gs::SelectionBuffer (scene.rs:1846-1850): bit = selected
+    gsx_viewer* v_;
+    std::string key_;
+public:
+    SelectionBuffer(gsx_viewer* v, std::string key) : v_(v), key_(std::move(key)) {}
+    void upload(const std::vector<uint32_t>& words) { check(gsx_model_upload_selection(v_, key_.c_str(), words.data(), words.size())); }
+    void clear() { check(gsx_model_upload_selection(v_, key_.c_str(), nullptr, 0)); }
+    std::vector<uint32_t> download(size_t n_gaussians) {
+        std::vector<uint32_t> w((n_gaussians + 31) / 32);
+        check(gsx_model_download_selection(v_, key_.c_str(), w.data(), w.size()));
+        return w;
+    }
+};
+using GaussianEditPod = gsx_gaussian_edit;  // gs::GaussianEditPod (app.rs:1553-1562)
+class GaussiansEditBuffer {  // gs::GaussiansEditBuffer (scene.rs:1816-1830, app.rs:789)
+    gsx_viewer* v_;
+    std::string key_;
+public:
+    GaussiansEditBuffer(gsx_viewer* v, std::string key) : v_(v), key_(std::move(key)) {}
+    std::vector<GaussianEditPod> download(size_t n_gaussians) {
+        std::vector<GaussianEditPod> e(n_gaussians);
+        check(gsx_model_download_edits(v_, key_.c_str(), e.data(), e.size()));
+        return e;
+    }
+    void upload(const std::vector<GaussianEditPod>& e) { check(gsx_model_upload_edits(v_, key_.c_str(), e.data(), e.size())); }
+};
+struct MultiModelViewerGaussianBuffers {
+    GaussiansBuffer gaussians_buffer;
+    MaskBuffer mask_buffer;
+    SelectionBuffer selection_buffer;
+    GaussiansEditBuffer gaussians_edit_buffer;
+};
 struct MultiModelViewerModel { MultiModelViewerGaussianBuffers gaussian_buffers; };
 
 class MultiModelViewer {
     gsx_viewer* v_ = nullptr;
     struct Pre { gsx_viewer*& v; void preprocess(const std::string& key) { check(gsx_preprocess(v, key.c_str())); } };
     struct Sort { gsx_viewer*& v; void sort(const std::string& key) { check(gsx_sort(v, key.c_str())); } };
+    struct Post { gsx_viewer*& v; void postprocess(const std::string& key) { check(gsx_postprocess(v, key.c_str())); } };  // scene.rs:601-611
     struct Ren {
         gsx_viewer*& v;
         void render(const std::vector<std::string>& model_render_keys) {  // far -> near, scene.rs:533-558
@@ -126,6 +170,7 @@ public:
     Pre preprocessor{v_};
     Sort radix_sorter{v_};
     Ren renderer{v_};
+    Post postprocessor{v_};
     ShCompression sh;
     Cov3dCompression cov3d;
     UVec2 size{1, 1};
@@ -147,7 +192,8 @@ public:
 
     MultiModelViewerModel& add_model(const std::string& key, size_t count) {  // new_empty + BindGroups::new + insert
         check(gsx_model_create(v_, key.c_str(), count, (gsx_sh_kind)sh, (gsx_cov3d_kind)cov3d));
-        return models.emplace(key, MultiModelViewerModel{{GaussiansBuffer(v_, key)}}).first->second;
+        return models.emplace(key, MultiModelViewerModel{{GaussiansBuffer(v_, key), MaskBuffer(v_, key), SelectionBuffer(v_, key),
+                                                            GaussiansEditBuffer(v_, key)}}).first->second;
     }
     void remove_model(const std::string& key) {  // scene.rs:2176
         check(gsx_model_remove(v_, key.c_str()));
@@ -163,6 +209,20 @@ public:
     }
     void update_gaussian_transform(float sz, GaussianDisplayMode mode, GaussianShDegree sh_deg, bool no_sh0) {  // scene.rs:803-809
         check(gsx_update_gaussian_transform(v_, sz, (gsx_display_mode)mode, sh_deg.degree(), no_sh0 ? 1u : 0u));
+    }
+    void update_query(const gsx_query& pod) { check(gsx_update_query(v_, &pod)); }  // scene.rs:785
+    void update_query_texture(const std::vector<uint8_t>& texels, UVec2 sz) {  // scene.rs:740, 791
+        check(gsx_update_query_texture(v_, texels.data(), sz.x, sz.y));
+    }
+    void update_selection_highlight(std::array<float, 4> rgba) { check(gsx_update_selection_highlight(v_, rgba.data())); }  // scene.rs:816-829
+    void update_selection_edit_with_pod(const GaussianEditPod& pod) { check(gsx_update_selection_edit(v_, &pod)); }   // scene.rs:815
+    void show_unedited(const std::string& key, bool on) { check(gsx_model_show_unedited(v_, key.c_str(), on ? 1u : 0u)); }  // scene.rs:856-863
+    std::vector<gsx_query_hit> download_query_hits(const std::string& key) {  // gs::query::download, scene.rs:651-657
+        std::vector<gsx_query_hit> h(GSX_QUERY_MAX_HITS);
+        uint64_t n = 0;
+        check(gsx_query_download_hits(v_, key.c_str(), h.data(), h.size(), &n));
+        h.resize((size_t)n);
+        return h;
     }
     void poll() { check(gsx_sync(v_)); }  // device.poll(Maintain::Wait)
     std::vector<float> download_framebuffer() {

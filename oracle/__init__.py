@@ -192,3 +192,59 @@ def mask_evaluate(pos, m_pos, m_quat, m_scale, c_ops, n_ops, c_shapes, n_shapes)
     lib().gsxo_mask_evaluate(n, _fp(np.ascontiguousarray(pos, np.float32)), _fp(mp), _fp(mq), _fp(ms),
                              C.cast(c_ops, C.c_void_p), n_ops, C.cast(c_shapes, C.c_void_p), n_shapes, _up(words))
     return words
+
+
+# ---- selection / edits / queries (spec §7) ----
+def _edit_records(edits):
+    from wgpu_3dgs_viewer_app_amd.query import EDIT_DTYPE
+
+    return np.ascontiguousarray(edits, EDIT_DTYPE)
+
+
+def edit_pass(proj: dict, selection, edits, sel_edit, highlight=(0, 0, 0, 0)) -> int:
+    """In place on an oracle projection: persist the selection edit, cull HIDDEN, colour ops, highlight.  ``edits`` is an
+    EDIT_DTYPE array (updated in place), ``sel_edit`` a ``query.GaussianEditPod``.  Returns n_visible."""
+    n = proj["key"].shape[0]
+    assert edits.flags["C_CONTIGUOUS"] and edits.itemsize == 32
+    raw = sel_edit.raw()
+    hl = _f32(highlight, 4)
+    fn = lib().gsxo_edit_pass
+    fn.restype = C.c_uint64
+    nv = fn(C.c_uint64(n), None if selection is None else _up(np.ascontiguousarray(selection, np.uint32)),
+            C.c_void_p(edits.ctypes.data), C.byref(raw), _fp(hl), _up(proj["key"]), _up(proj["rect"]), _fp(proj["mean2d"]),
+            _fp(proj["conic_opacity"]), _fp(proj["rgb"]))
+    proj["n_visible"] = int(nv)
+    return int(nv)
+
+
+def query_flags(proj: dict, query_pod, texture=None) -> np.ndarray:
+    n = proj["key"].shape[0]
+    flags = np.zeros((n + 31) // 32, np.uint32)
+    raw = query_pod.raw()
+    tw = th = 0
+    tp = None
+    if texture is not None:
+        texture = np.ascontiguousarray(texture, np.uint8)
+        th, tw = texture.shape
+        tp = C.c_void_p(texture.ctypes.data)
+    lib().gsxo_query_flags(C.c_uint64(n), _up(proj["key"]), _fp(proj["mean2d"]), C.byref(raw), tp, C.c_uint32(tw), C.c_uint32(th),
+                           _up(flags))
+    return flags
+
+
+def query_hits(frame: Frame, proj: dict, coords) -> np.ndarray:
+    from wgpu_3dgs_viewer_app_amd.query import HIT_DTYPE
+
+    n = proj["key"].shape[0]
+    out = np.zeros(65536, HIT_DTYPE)
+    fn = lib().gsxo_query_hits
+    fn.restype = C.c_uint64
+    cnt = fn(C.byref(frame), C.c_uint64(n), _up(proj["key"]), _fp(proj["mean2d"]), _fp(proj["conic_opacity"]), _fp(_f32(coords, 2)),
+             C.c_void_p(out.ctypes.data), C.c_uint64(out.size))
+    return out[: min(int(cnt), out.size)].copy()
+
+
+def selection_op(op: int, flags: np.ndarray, selection: np.ndarray) -> np.ndarray:
+    sel = np.ascontiguousarray(selection, np.uint32).copy()
+    lib().gsxo_selection_op(C.c_uint64(sel.size), C.c_uint32(int(op)), _up(np.ascontiguousarray(flags, np.uint32)), _up(sel))
+    return sel

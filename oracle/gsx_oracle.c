@@ -575,6 +575,154 @@ void gsxo_mask_evaluate(uint64_t n, const float* pos, const float m_pos[3], cons
     }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Selection, edits, queries (spec §7).  Call sites in the reference: viewer.update_query / update_selection_* /
+ * postprocessor.postprocess / gs::query::download (src/tab/scene.rs:785-835, 601-611, 651-657); the arithmetic is the
+ * build's [BUILD-SPEC].  Restated here as passes over the projection arrays.
+ * ---------------------------------------------------------------------------------------------- */
+static void o_rgb_to_hsv(float r, float g, float b, float* h, float* s, float* v) {
+    float mx = fmaxf(r, fmaxf(g, b)), mn = fminf(r, fminf(g, b)), d = mx - mn;
+    *v = mx;
+    *s = mx > 0.0f ? d / mx : 0.0f;
+    float hh;
+    if (!(d > 0.0f)) hh = 0.0f;
+    else if (mx == r) { hh = (g - b) / d; if (hh < 0.0f) hh += 6.0f; }
+    else if (mx == g) hh = (b - r) / d + 2.0f;
+    else hh = (r - g) / d + 4.0f;
+    *h = hh / 6.0f;
+}
+
+static void o_hsv_to_rgb(float h, float s, float v, float* r, float* g, float* b) {
+    float k = h * 6.0f, fl = floorf(k), f = k - fl;
+    int sec = (int)fl;
+    if (sec < 0 || sec > 5) sec = 0;
+    float p = v * (1.0f - s), q = v * (1.0f - s * f), t = v * (1.0f - s * (1.0f - f));
+    switch (sec) {
+        case 0: *r = v; *g = t; *b = p; break;
+        case 1: *r = q; *g = v; *b = p; break;
+        case 2: *r = p; *g = v; *b = t; break;
+        case 3: *r = p; *g = q; *b = v; break;
+        case 4: *r = t; *g = p; *b = v; break;
+        default: *r = v; *g = p; *b = q; break;
+    }
+}
+
+/* colour ops 1-5 of spec §7; e has ENABLED */
+void gsxo_apply_edit(const gsx_gaussian_edit* e, float rgb[3], float* opacity) {
+    float r = rgb[0], g = rgb[1], b = rgb[2];
+    if (e->flag & GSX_EDIT_OVERRIDE_COLOR) {
+        r = e->color[0]; g = e->color[1]; b = e->color[2];
+    } else {
+        float h, s, v;
+        o_rgb_to_hsv(r, g, b, &h, &s, &v);
+        h = h + e->color[0];
+        h = h - floorf(h);
+        s = clampf(s * e->color[1], 0.0f, 1.0f);
+        v = v * e->color[2];
+        o_hsv_to_rgb(h, s, v, &r, &g, &b);
+    }
+    if (e->contrast != 0.0f) {
+        float c = 1.0f + e->contrast;
+        r = (r - 0.5f) * c + 0.5f; g = (g - 0.5f) * c + 0.5f; b = (b - 0.5f) * c + 0.5f;
+    }
+    if (e->exposure != 0.0f) {
+        float m = exp2f(e->exposure);
+        r *= m; g *= m; b *= m;
+    }
+    r = fmaxf(r, 0.0f); g = fmaxf(g, 0.0f); b = fmaxf(b, 0.0f);
+    if (e->gamma != 1.0f) { r = powf(r, e->gamma); g = powf(g, e->gamma); b = powf(b, e->gamma); }
+    rgb[0] = r; rgb[1] = g; rgb[2] = b;
+    *opacity = clampf(*opacity * e->alpha, 0.0f, 1.0f);
+}
+
+/* Preprocess-time edit handling over a finished projection: persists the selection edit into the selected
+ * Gaussians' records (visible or not), culls HIDDEN ones, applies colour ops and the highlight.  selection may be
+ * NULL; edits has n records (in/out).  Returns the new n_visible. */
+uint64_t gsxo_edit_pass(uint64_t n, const uint32_t* selection, gsx_gaussian_edit* edits, const gsx_gaussian_edit* sel_edit,
+                        const float highlight[4], uint32_t* key, uint32_t* rect, float* mean2d, float* conic_op,
+                        float* rgb) {
+    uint64_t nvis = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        int sel = selection ? (int)((selection[i >> 5] >> (i & 31)) & 1u) : 0;
+        if (sel && (sel_edit->flag & GSX_EDIT_ENABLED)) edits[i] = *sel_edit;
+        const gsx_gaussian_edit* e = &edits[i];
+        if (key[i] == 0xFFFFFFFFu) continue;
+        if ((e->flag & GSX_EDIT_ENABLED) && (e->flag & GSX_EDIT_HIDDEN)) {
+            key[i] = 0xFFFFFFFFu;
+            memset(rect + 4 * i, 0, 16); memset(mean2d + 2 * i, 0, 8); memset(conic_op + 4 * i, 0, 16); memset(rgb + 3 * i, 0, 12);
+            continue;
+        }
+        if (e->flag & GSX_EDIT_ENABLED) gsxo_apply_edit(e, rgb + 3 * i, conic_op + 4 * i + 3);
+        if (sel && highlight[3] > 0.0f)
+            for (int c = 0; c < 3; ++c) rgb[3 * i + c] = rgb[3 * i + c] + (highlight[c] - rgb[3 * i + c]) * highlight[3];
+        nvis += 1;
+    }
+    return nvis;
+}
+
+/* Rect / Brush / Texture query -> one flag bit per Gaussian */
+void gsxo_query_flags(uint64_t n, const uint32_t* key, const float* mean2d, const gsx_query* q, const uint8_t* texture,
+                      uint32_t tex_w, uint32_t tex_h, uint32_t* flags) {
+    memset(flags, 0, 4 * ((n + 31) / 32));
+    for (uint64_t i = 0; i < n; ++i) {
+        if (key[i] == 0xFFFFFFFFu) continue;
+        float mx = mean2d[2 * i], my = mean2d[2 * i + 1];
+        int f = 0;
+        if (q->kind == GSX_QUERY_RECT) {
+            float x0 = fminf(q->p0[0], q->p1[0]), x1 = fmaxf(q->p0[0], q->p1[0]);
+            float y0 = fminf(q->p0[1], q->p1[1]), y1 = fmaxf(q->p0[1], q->p1[1]);
+            f = mx >= x0 && mx <= x1 && my >= y0 && my <= y1;
+        } else if (q->kind == GSX_QUERY_BRUSH) {
+            float ax = q->p0[0], ay = q->p0[1], dx = q->p1[0] - ax, dy = q->p1[1] - ay;
+            float len2 = dx * dx + dy * dy, t = 0.0f;
+            if (len2 > 0.0f) t = clampf(((mx - ax) * dx + (my - ay) * dy) / len2, 0.0f, 1.0f);
+            float ex = mx - (ax + t * dx), ey = my - (ay + t * dy);
+            f = ex * ex + ey * ey <= q->radius * q->radius;
+        } else if (q->kind == GSX_QUERY_TEXTURE) {
+            float fx = floorf(mx), fy = floorf(my);
+            if (texture && fx >= 0.0f && fy >= 0.0f && fx < (float)tex_w && fy < (float)tex_h)
+                f = texture[(size_t)fy * tex_w + (size_t)fx] != 0;
+        }
+        if (f) flags[i >> 5] |= 1u << (i & 31);
+    }
+}
+
+static int hit_cmp(const void* a, const void* b) {
+    const gsx_query_hit *x = (const gsx_query_hit*)a, *y = (const gsx_query_hit*)b;
+    if (x->depth != y->depth) return x->depth < y->depth ? -1 : 1;
+    return x->index < y->index ? -1 : (x->index > y->index ? 1 : 0);
+}
+
+/* Hit query at p0: (index, view depth, alpha) of every visible Gaussian covering the point, sorted by (depth, index) */
+uint64_t gsxo_query_hits(const gsxo_frame* f, uint64_t n, const uint32_t* key, const float* mean2d, const float* conic_op,
+                         const float p0[2], gsx_query_hit* out, uint64_t capacity) {
+    uint64_t cnt = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (key[i] == 0xFFFFFFFFu) continue;
+        const float* co = conic_op + 4 * i;
+        float dx = p0[0] - mean2d[2 * i], dy = p0[1] - mean2d[2 * i + 1];
+        float q = fmaf(co[0] * dx, dx, fmaf(co[2] * dy, dy, ((2.0f * co[1]) * dx) * dy));
+        if (!(q <= f->k2) || q < 0.0f) continue;
+        float w = (f->display_mode == GSX_DISPLAY_SPLAT) ? expf(-0.5f * q) : 1.0f;
+        float a = fminf(f->alpha_max, co[3] * w);
+        if (!(a >= 1.0f / 255.0f)) continue;
+        if (cnt < capacity) {
+            union { uint32_t u; float f; } d;
+            d.u = key[i];
+            out[cnt].index = (uint32_t)i; out[cnt].depth = d.f; out[cnt].alpha = a; out[cnt].reserved = 0;
+        }
+        cnt += 1;
+    }
+    qsort(out, cnt < capacity ? cnt : capacity, sizeof *out, hit_cmp);
+    return cnt;
+}
+
+/* K4: selection = op(selection, flags) */
+void gsxo_selection_op(uint64_t n_words, uint32_t op, const uint32_t* flags, uint32_t* selection) {
+    for (uint64_t w = 0; w < n_words; ++w)
+        selection[w] = op == GSX_SELECTION_SET ? flags[w] : (op == GSX_SELECTION_ADD ? (selection[w] | flags[w]) : (selection[w] & ~flags[w]));
+}
+
 int gsxo_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -27,8 +27,24 @@ EXPORTS = (
     "gsx_model_frame_stats", "gsx_model_download_projection", "gsx_model_download_sorted",
     "gsx_model_download_tile_lists", "gsx_model_download_pod", "gsx_set_pass_timing", "gsx_get_pass_timing",
     "gsx_mask_evaluate", "gsx_ply_read_header", "gsx_ply_read_gaussians", "gsx_ply_write", "gsx_render_options_default", "gsx_viewer_set_render_options", "gsx_shard_layout", "gsx_viewer_set_external_framebuffer", "gsx_shard_pack", "gsx_shard_import", "gsx_shard_feedback_words", "gsx_shard_feedback",
-    "gsx_render_more", 
+    "gsx_render_more",
+    "gsx_gaussian_edit_default", "gsx_update_query", "gsx_update_query_texture", "gsx_update_selection_highlight",
+    "gsx_update_selection_edit", "gsx_model_show_unedited", "gsx_postprocess", "gsx_model_upload_selection",
+    "gsx_model_download_selection", "gsx_model_download_edits", "gsx_model_upload_edits", "gsx_query_download_hits",
+    "gsx_query_hit_pos_by_closest", "gsx_query_hit_pos_by_alpha_range",
 )
+
+
+class GaussianEdit(C.Structure):
+    """``gsx_gaussian_edit`` = gs::GaussianEditPod (32 bytes)."""
+    _fields_ = [("flag", C.c_uint32), ("color", C.c_float * 3), ("contrast", C.c_float), ("exposure", C.c_float),
+                ("gamma", C.c_float), ("alpha", C.c_float)]
+
+
+class Query(C.Structure):
+    """``gsx_query``."""
+    _fields_ = [("kind", C.c_uint32), ("selection_op", C.c_uint32), ("p0", C.c_float * 2), ("p1", C.c_float * 2),
+                ("radius", C.c_float), ("reserved", C.c_uint32)]
 
 
 class SpecParams(C.Structure):
@@ -100,7 +116,21 @@ def load() -> C.CDLL:
         "gsx_mask_evaluate": ([vp, cp, vp, u32, vp, u32], C.c_int32),
         "gsx_ply_read_header": ([vp, u64, C.POINTER(PlyHeader)], C.c_int32),
         "gsx_ply_read_gaussians": ([vp, u64, C.POINTER(PlyHeader), u64, u64, vp], C.c_int32),
-        "gsx_ply_write": ([vp, u64, u32p, vp, u64, C.POINTER(u64)], C.c_int32),
+        "gsx_ply_write": ([vp, u64, u32p, vp, vp, u64, C.POINTER(u64)], C.c_int32),
+        "gsx_gaussian_edit_default": ([vp], None),
+        "gsx_update_query": ([vp, vp], C.c_int32),
+        "gsx_update_query_texture": ([vp, vp, u32, u32], C.c_int32),
+        "gsx_update_selection_highlight": ([vp, f32p], C.c_int32),
+        "gsx_update_selection_edit": ([vp, vp], C.c_int32),
+        "gsx_model_show_unedited": ([vp, cp, u32], C.c_int32),
+        "gsx_postprocess": ([vp, cp], C.c_int32),
+        "gsx_model_upload_selection": ([vp, cp, u32p, u64], C.c_int32),
+        "gsx_model_download_selection": ([vp, cp, u32p, u64], C.c_int32),
+        "gsx_model_download_edits": ([vp, cp, vp, u64], C.c_int32),
+        "gsx_model_upload_edits": ([vp, cp, vp, u64], C.c_int32),
+        "gsx_query_download_hits": ([vp, cp, vp, u64, C.POINTER(u64)], C.c_int32),
+        "gsx_query_hit_pos_by_closest": ([vp, u64, f32p, f32p, u32, u32, f32p, u32p, f32p], C.c_int32),
+        "gsx_query_hit_pos_by_alpha_range": ([vp, u64, f32p, f32p, u32, u32, f32p, C.c_float, u32p, f32p, f32p], C.c_int32),
         "gsx_preprocess": ([vp, cp], C.c_int32),
         "gsx_sort": ([vp, cp], C.c_int32),
         "gsx_sync": ([vp], C.c_int32),

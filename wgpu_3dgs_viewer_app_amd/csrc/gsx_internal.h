@@ -126,6 +126,16 @@ hipError_t launch_tile_ranges(hipStream_t s, uint32_t capacity, const uint32_t* 
                               uint32_t n_tiles, uint2* ranges, bool ranges_clean);
 size_t scan_blocks(uint64_t n);
 
+// Selection / edits / queries (kernels_edit.hip).
+hipError_t launch_edit_prepare(hipStream_t s, uint32_t n, const uint32_t* selection, uint32_t* edited, float4* edit_a,
+                               float4* edit_b, const gsx_gaussian_edit& sel_edit, const uint32_t* mask, uint32_t* keep);
+hipError_t launch_edit_apply(hipStream_t s, uint32_t n, const Records& rec, const uint32_t* selection, const uint32_t* edited,
+                             const float4* edit_a, const float4* edit_b, const float highlight[4]);
+hipError_t launch_query(hipStream_t s, uint32_t n, const Records& rec, const gsx_query& q, const uint8_t* texture, uint32_t tex_w,
+                        uint32_t tex_h, const FrameConsts& f, uint32_t* flags, gsx_query_hit* hits, uint32_t* hit_count,
+                        uint32_t hit_capacity);
+hipError_t launch_selection_op(hipStream_t s, uint32_t n_words, uint32_t op, const uint32_t* flags, uint32_t* selection);
+
 // Multi-GPU exchange support (kernels_shard.hip).
 hipError_t launch_rowscan(hipStream_t s, uint32_t* table, uint32_t nrows, uint32_t nblocks, uint32_t* totals);
 size_t pack_blocks(uint64_t n);

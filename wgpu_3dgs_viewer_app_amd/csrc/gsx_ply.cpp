@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/gsx.h"
+#include "edit_math.h"
 
 namespace gsx {
 gsx_status ply_fail(gsx_status st, const char* fmt, ...);
@@ -182,11 +183,16 @@ gsx_status gsx_ply_read_gaussians(const void* data, uint64_t size, const gsx_ply
     return GSX_OK;
 }
 
-gsx_status gsx_ply_write(const gsx_gaussian* g, uint64_t n, const uint32_t* mask, void* out, uint64_t capacity, uint64_t* out_size) {
+gsx_status gsx_ply_write(const gsx_gaussian* g, uint64_t n, const uint32_t* mask, const gsx_gaussian_edit* edits, void* out,
+                         uint64_t capacity, uint64_t* out_size) {
     using gsx::ply_fail;
     if ((n && !g) || !out_size) return ply_fail(GSX_ERR_INVALID_ARG, "gsx_ply_write: null argument");
+    auto keep = [&](uint64_t i) {
+        if (mask && !((mask[i >> 5] >> (i & 31)) & 1u)) return false;
+        return !(edits && (edits[i].flag & GSX_EDIT_ENABLED) && (edits[i].flag & GSX_EDIT_HIDDEN));
+    };
     uint64_t kept = 0;
-    for (uint64_t i = 0; i < n; ++i) kept += !mask || ((mask[i >> 5] >> (i & 31)) & 1u);
+    for (uint64_t i = 0; i < n; ++i) kept += keep(i);
     std::string header = "ply\nformat binary_little_endian 1.0\nelement vertex " + std::to_string(kept) + "\n";
     for (int k = 0; k < 62; ++k) header += std::string("property float ") + kProps[k] + "\n";
     header += "end_header\n";
@@ -198,8 +204,18 @@ gsx_status gsx_ply_write(const gsx_gaussian* g, uint64_t n, const uint32_t* mask
     p += header.size();
     float v[62];
     for (uint64_t i = 0; i < n; ++i) {
-        if (mask && !((mask[i >> 5] >> (i & 31)) & 1u)) continue;
+        if (!keep(i)) continue;
         gaussian_to_vertex(g + i, v);
+        if (edits && (edits[i].flag & GSX_EDIT_ENABLED)) {  // spec §7 Export: the colour ops baked into the DC colour and opacity
+            float r = (float)g[i].color[0] / 255.0f, gg = (float)g[i].color[1] / 255.0f, b = (float)g[i].color[2] / 255.0f;
+            float a = (float)g[i].color[3] / 255.0f;
+            gsx::em_apply_edit(edits[i], r, gg, b, a);
+            v[P_FDC] = (r - 0.5f) / kShC0;
+            v[P_FDC + 1] = (gg - 0.5f) / kShC0;
+            v[P_FDC + 2] = (b - 0.5f) / kShC0;
+            a = std::min(std::max(a, 1e-6f), 1.0f - 1e-6f);
+            v[P_OPACITY] = std::log(a / (1.0f - a));
+        }
         memcpy(p, v, 248);
         p += 248;
     }

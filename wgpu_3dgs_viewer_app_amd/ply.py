@@ -51,14 +51,22 @@ class Gaussians:
         parts = list(cls.read_ply_gaussians(data, h))
         return cls(np.concatenate(parts) if parts else np.zeros(0, GAUSSIAN_DTYPE))
 
-    def write_ply(self, mask_words: np.ndarray | None = None) -> bytes:
-        """``write_ply(writer, None, mask)``: binary little-endian INRIA PLY of the (masked) Gaussians."""
+    def write_ply(self, mask_words: np.ndarray | None = None, edits: np.ndarray | None = None) -> bytes:
+        """``write_ply(writer, edits, mask)`` (app.rs:908-940): binary little-endian INRIA PLY of the (masked, edited) Gaussians."""
         L = _lib.load()
         g = self.gaussians
         size = C.c_uint64()
         mw = None if mask_words is None else np.ascontiguousarray(mask_words, np.uint32)
         mp = None if mw is None else mw.ctypes.data_as(C.POINTER(C.c_uint32))
-        _lib.check(L.gsx_ply_write(g.ctypes.data, g.shape[0], mp, None, 0, C.byref(size)))
+        ep = None
+        if edits is not None:
+            from .query import EDIT_DTYPE
+
+            ed = np.ascontiguousarray(edits, EDIT_DTYPE)
+            if ed.shape[0] != g.shape[0]:
+                raise ValueError("one edit record per Gaussian")
+            ep = ed.ctypes.data
+        _lib.check(L.gsx_ply_write(g.ctypes.data, g.shape[0], mp, ep, None, 0, C.byref(size)))
         out = np.empty(size.value, np.uint8)
-        _lib.check(L.gsx_ply_write(g.ctypes.data, g.shape[0], mp, out.ctypes.data, out.size, C.byref(size)))
+        _lib.check(L.gsx_ply_write(g.ctypes.data, g.shape[0], mp, ep, out.ctypes.data, out.size, C.byref(size)))
         return out.tobytes()

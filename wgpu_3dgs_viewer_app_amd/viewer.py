@@ -132,12 +132,58 @@ class MaskBuffer:
         return w
 
 
+class SelectionBuffer:
+    """``gs::SelectionBuffer``: one bit per Gaussian, 1 = selected (src/tab/scene.rs:1846-1850)."""
+
+    def __init__(self, viewer: "MultiModelViewer", key: str):
+        self._v, self._key = viewer, key
+
+    def upload(self, words: np.ndarray | None) -> None:
+        if words is None:
+            _lib.check(self._v._L.gsx_model_upload_selection(self._v._h, self._key.encode(), None, 0))
+            return
+        w = np.ascontiguousarray(words, dtype=np.uint32)
+        _lib.check(self._v._L.gsx_model_upload_selection(self._v._h, self._key.encode(), _u32p(w), w.size))
+
+    def download(self) -> np.ndarray:
+        n = (self._v.models[self._key].gaussian_buffers.gaussians_buffer.len() + 31) // 32
+        w = np.empty(n, np.uint32)
+        _lib.check(self._v._L.gsx_model_download_selection(self._v._h, self._key.encode(), _u32p(w), n))
+        return w
+
+
+class GaussiansEditBuffer:
+    """``gs::GaussiansEditBuffer``: one ``GaussianEditPod`` per Gaussian (src/tab/scene.rs:1816-1830, app.rs:789)."""
+
+    def __init__(self, viewer: "MultiModelViewer", key: str):
+        self._v, self._key = viewer, key
+
+    def download(self) -> np.ndarray:
+        from .query import EDIT_DTYPE
+
+        n = self._v.models[self._key].gaussian_buffers.gaussians_buffer.len()
+        out = np.zeros(n, EDIT_DTYPE)
+        _lib.check(self._v._L.gsx_model_download_edits(self._v._h, self._key.encode(), out.ctypes.data, n))
+        return out
+
+    def upload(self, edits: np.ndarray | None) -> None:
+        from .query import EDIT_DTYPE
+
+        if edits is None:
+            _lib.check(self._v._L.gsx_model_upload_edits(self._v._h, self._key.encode(), None, 0))
+            return
+        e = np.ascontiguousarray(edits, EDIT_DTYPE)
+        _lib.check(self._v._L.gsx_model_upload_edits(self._v._h, self._key.encode(), e.ctypes.data, e.size))
+
+
 class MultiModelViewerGaussianBuffers:
     """``gs::MultiModelViewerGaussianBuffers<G>`` (src/tab/scene.rs:2111-2112)."""
 
     def __init__(self, viewer: "MultiModelViewer", key: str):
         self.gaussians_buffer = GaussiansBuffer(viewer, key)
         self.mask_buffer = MaskBuffer(viewer, key)
+        self.selection_buffer = SelectionBuffer(viewer, key)
+        self.gaussians_edit_buffer = GaussiansEditBuffer(viewer, key)
 
 
 class MultiModelViewerModel:
@@ -154,6 +200,15 @@ class _Preprocessor:
     def preprocess(self, key: str) -> None:
         """``preprocessor.preprocess(encoder, bind_group, gaussian_count)`` (src/tab/scene.rs:856-863)."""
         _lib.check(self._v._L.gsx_preprocess(self._v._h, key.encode()))
+
+
+class _Postprocessor:
+    def __init__(self, v):
+        self._v = v
+
+    def postprocess(self, key: str) -> None:
+        """``postprocessor.postprocess(encoder, bg0, bg1, gaussian_count, indirect_args)`` (src/tab/scene.rs:601-611)."""
+        _lib.check(self._v._L.gsx_postprocess(self._v._h, key.encode()))
 
 
 class _RadixSorter:
@@ -190,6 +245,7 @@ class MultiModelViewer:
         self.preprocessor = _Preprocessor(self)
         self.radix_sorter = _RadixSorter(self)
         self.renderer = _Renderer(self)
+        self.postprocessor = _Postprocessor(self)
         self.size = (int(size[0]), int(size[1]))
 
     # -- lifetime --
@@ -245,6 +301,40 @@ class MultiModelViewer:
         """``viewer.update_gaussian_transform(queue, size, display_mode, sh_deg, no_sh0)`` (src/tab/scene.rs:803-809)."""
         deg = sh_deg.degree() if isinstance(sh_deg, GaussianShDegree) else int(sh_deg)
         _lib.check(self._L.gsx_update_gaussian_transform(self._h, float(size), int(display_mode), deg, 1 if no_sh0 else 0))
+
+    # -- selection / edits / queries (spec §7) --
+    def update_query(self, pod) -> None:
+        """``viewer.update_query(queue, &query_pod)`` (src/tab/scene.rs:785)."""
+        raw = pod.raw()
+        _lib.check(self._L.gsx_update_query(self._h, C.byref(raw)))
+
+    def update_query_texture(self, texels: np.ndarray) -> None:
+        """``viewer.update_query_texture_size`` + ``query_toolset.render(.., &query_texture)`` (scene.rs:740, 791)."""
+        t = np.ascontiguousarray(texels, np.uint8)
+        _lib.check(self._L.gsx_update_query_texture(self._h, t.ctypes.data, t.shape[1], t.shape[0]))
+
+    def update_selection_highlight(self, rgba) -> None:
+        """``viewer.update_selection_highlight(queue, vec4)`` / ``_with_pod`` (src/tab/scene.rs:816-829)."""
+        c = np.ascontiguousarray(rgba, np.float32).reshape(4)
+        _lib.check(self._L.gsx_update_selection_highlight(self._h, _f32p(c)))
+
+    def update_selection_edit_with_pod(self, pod) -> None:
+        """``viewer.update_selection_edit_with_pod(queue, &gs::GaussianEditPod)`` (src/tab/scene.rs:815, 821, 848)."""
+        raw = pod.raw()
+        _lib.check(self._L.gsx_update_selection_edit(self._h, C.byref(raw)))
+
+    def show_unedited(self, key: str, on: bool) -> None:
+        """Preprocess with the unedited model's bind group (src/tab/scene.rs:856-863)."""
+        _lib.check(self._L.gsx_model_show_unedited(self._h, key.encode(), 1 if on else 0))
+
+    def download_query_hits(self, key: str) -> np.ndarray:
+        """``gs::query::download(&device, &queue, &count_buffer, &results_buffer)`` (src/tab/scene.rs:651-657)."""
+        from .query import HIT_DTYPE
+
+        n = C.c_uint64()
+        out = np.zeros(65536, HIT_DTYPE)
+        _lib.check(self._L.gsx_query_download_hits(self._h, key.encode(), out.ctypes.data, out.size, C.byref(n)))
+        return out[: int(n.value)].copy()
 
     def set_spec_params(self, **kw) -> SpecParams:
         sp = SpecParams()
