@@ -60,6 +60,11 @@ def projection_from_records(rec):
 class OracleStages:
     def __init__(self):
         self._fb = None
+        self.pods, self.frames, self._prs, self._imp = {}, {}, {}, {}
+
+    @property
+    def frame(self):  # tile grid / viewport are the same for every model
+        return next(iter(self.frames.values()))
 
     def stream_ctx(self):
         import contextlib
@@ -67,20 +72,21 @@ class OracleStages:
         return contextlib.nullcontext()
 
     def load_shard(self, key, gaussians, start, n_total):
-        self.pod = oracle.convert(gaussians)
+        self.pods[key] = oracle.convert(gaussians)
 
     def set_uniforms(self, key, cam, size, model_transform=None, gaussian_transform=None):
         mt = model_transform or camera.ModelTransform()
         w, h = size
-        self.frame = oracle.frame_setup(cam.view(), cam.projection(w / h), w, h, mt.pos, mt.quat(), mt.scale)
+        self.frames[key] = oracle.frame_setup(cam.view(), cam.projection(w / h), w, h, mt.pos, mt.quat(), mt.scale)
         self.size = (w, h)
 
     def _band(self, world, rank):
         rpr = (self.frame.tiles_y + world - 1) // world
         return rpr, min(rank * rpr, self.frame.tiles_y), min((rank + 1) * rpr, self.frame.tiles_y)
 
-    def _render_projection(self, pr, world=1, rank=0, more=False, window=None):
-        f = self.frame
+    def _lists(self, key, pr, window=None):
+        """(projection, tile offsets, tile list) of a record set, window-filtered"""
+        f = self.frames[key]
         idx, nvis = oracle.depth_sort(pr["key"])
         off, lst = oracle.tile_lists(f, idx, nvis, pr["rect"])
         tile_of = np.repeat(np.arange(off.size - 1), np.diff(off).astype(np.int64))
@@ -95,47 +101,68 @@ class OracleStages:
         # deepest key binned into each tile: an upper bound of the depth at which a saturated tile saturated
         deepest = np.zeros(off.size - 1, np.uint32)
         np.maximum.at(deepest, tile_of, pr["key"][lst])
-        deepest = deepest.reshape(f.tiles_y, f.tiles_x)
-        self._deepest = np.maximum(self._deepest, deepest) if more else deepest
-        # this set lies BEHIND what the framebuffer holds: composite it alone, then put the old frame in front
-        back = oracle.new_framebuffer(f)
-        oracle.composite_tiles(f, pr, off, lst, back)
-        if more:
+        return dict(pr=pr, off=off, lst=lst, nvis=nvis, deepest=deepest.reshape(f.tiles_y, f.tiles_x))
+
+    def _composite(self, keys, world=1, rank=0, more=False):
+        """layers far -> near: each model is composited IN FRONT of what the framebuffer holds (composite_tiles)"""
+        f = self.frame
+        layer = oracle.new_framebuffer(f)
+        for key in keys:
+            L = self._imp[key]
+            oracle.composite_tiles(self.frames[key], L["pr"], L["off"], L["lst"], layer)
+        near = self._imp[keys[-1]]
+        if more:  # this set lies BEHIND what the framebuffer holds
             front = self._fb
             fb = np.empty_like(front)
-            fb[..., :3] = front[..., :3] + front[..., 3:4] * back[..., :3]
-            fb[..., 3] = front[..., 3] * back[..., 3]
+            fb[..., :3] = front[..., :3] + front[..., 3:4] * layer[..., :3]
+            fb[..., 3] = front[..., 3] * layer[..., 3]
+            self._deepest = np.maximum(self._deepest, near["deepest"])
         else:
-            fb = back
+            fb = layer
+            self._deepest = near["deepest"]
         _, lo, hi = self._band(world, rank)
         fb[: lo * 16] = (0, 0, 0, 1)
         fb[hi * 16:] = (0, 0, 0, 1)
         self._fb = fb
-        self._band_rows = (lo, hi)
-        self._stats = dict(n_gaussians=pr["key"].size, n_visible=nvis, n_tile_entries=int(lst.size))
-        return self._stats
+        self._stats = {k: dict(n_gaussians=self._imp[k]["pr"]["key"].size, n_visible=self._imp[k]["nvis"],
+                               n_tile_entries=int(self._imp[k]["lst"].size)) for k in keys}
 
     def stats(self, key):
-        return self._stats
+        return self._stats[key]
+
+    def _project(self, key):
+        pos, color, sh, cov = self.pods[key]
+        return oracle.project(self.frames[key], pos, color, sh, cov)
 
     def render_local(self, key):
-        pos, color, sh, cov = self.pod
-        return self._render_projection(oracle.project(self.frame, pos, color, sh, cov))
+        self.render_local_keys([key])
+
+    def render_local_keys(self, keys):
+        for k in keys:
+            self._imp[k] = self._lists(k, self._project(k))
+        self._world, self._rank = 1, 0
+        self._composite(keys)
 
     def begin_frame(self, key, world, rank):
-        pos, color, sh, cov = self.pod
-        self._pr = oracle.project(self.frame, pos, color, sh, cov)
+        self._prs[key] = self._project(key)
 
     def pack(self, key, world, window=None):
-        send, counts = pack_by_destination(self._pr, world, self.frame.tiles_x, self.frame.tiles_y, window)
+        send, counts = pack_by_destination(self._prs[key], world, self.frame.tiles_x, self.frame.tiles_y, window)
         return torch.from_numpy(np.ascontiguousarray(send)), counts
 
     def alloc_records(self, n):
         return torch.empty((n, 12), dtype=torch.float32)
 
-    def render_records(self, key, recv, n, world, rank, more=False, window=None):
+    def import_records(self, key, recv, n, world, rank, window=None):
         self._world, self._rank = world, rank
-        return self._render_projection(projection_from_records(recv.numpy()[:n]), world, rank, more, window)
+        self._imp[key] = self._lists(key, projection_from_records(recv.numpy()[:n]), window)
+
+    def render_keys(self, keys, more=False):
+        self._composite(list(keys), self._world, self._rank, more)
+
+    def render_records(self, key, recv, n, world, rank, more=False, window=None):
+        self.import_records(key, recv, n, world, rank, window)
+        self.render_keys([key], more)
 
     def feedback(self, key, world, rank):
         """Saturation depth keys of this rank's band (rows_per_rank x tiles_x, 0 = open): a tile is saturated when all

@@ -148,3 +148,67 @@ def test_pack_capacity_error():
     with pytest.raises(_lib.GsxError):
         _lib.check(v._L.gsx_shard_pack(v._h, b"shard", 2, None, small.data_ptr(), 4, counts))
     st.close()
+
+
+def test_cfg5_like_layered_models_mask_selection_edit():
+    """cfg5's shape at test size: several models with their own TRS, a `0 - 1` mask op, a rect selection with an HSV
+    edit, sharded over 3 ranks: every rank's frame equals the single-viewer frame bit for bit (the per-Gaussian state —
+    mask, selection, edits — lives with the shard; queries are evaluated per shard)."""
+    from wgpu_3dgs_viewer_app_amd import query
+    from wgpu_3dgs_viewer_app_amd.mask import MaskEvaluator, MaskOp, MaskShape, MaskShapeKind
+
+    world, w, h = 3, 240, 160
+    models = {"a": (4000, 11, camera.ModelTransform(pos=np.array([0.0, 0.0, 1.5], np.float32))),
+              "b": (3000, 12, common.odd_transform()),
+              "c": (2500, 13, camera.ModelTransform(pos=np.array([-1.0, 0.3, -2.0], np.float32), rot=np.array([0, 40, 0], np.float32))),
+              "d": (2000, 14, camera.ModelTransform(pos=np.array([1.5, -0.2, 0.0], np.float32), scale=np.array([0.8, 0.8, 0.8], np.float32)))}
+    scenes = {k: common.small_scene(n, seed, scale_mul=8.0) for k, (n, seed, _) in models.items()}
+    tr = {k: mt for k, (_, _, mt) in models.items()}
+    shapes = [MaskShape(MaskShapeKind.Box, pos=np.array([0.0, 0.0, 0.5], np.float32), scale=np.array([3.0, 2.5, 3.0], np.float32)),
+              MaskShape(MaskShapeKind.Ellipsoid, pos=np.array([0.2, 0.1, 0.8], np.float32), scale=np.array([1.2, 1.0, 1.4], np.float32))]
+    rect = query.QueryPod.rect((60.0, 40.0), (180.0, 120.0), query.QuerySelectionOp.Set)
+    edit = query.GaussianEditPod(query.GaussianEditFlag.ENABLED, (0.45, 1.2, 0.9), 0.1, 0.3, 1.0, 0.8)
+    poses = (30, 31)
+
+    def drive(v, raw):
+        """the app's sequence: mask the model 'b', select by rectangle in every model, edit the selection"""
+        for k, mt in tr.items():
+            raw.update_model_transform(k, mt.pos, mt.quat(), mt.scale)
+        MaskEvaluator(raw).evaluate(MaskOp.parse("0 - 1"), "b", shapes)
+        frames = []
+        for step, pose in enumerate(poses):
+            cam = camera.orbit_pose(pose)
+            raw.update_query(rect if step == 0 else query.QueryPod.none())
+            if step == 1:
+                raw.update_selection_edit_with_pod(edit)
+                raw.update_selection_highlight((1.0, 0.0, 1.0, 0.3))
+            v.render_frame(cam, (w, h), keys=parallel.model_render_keys(cam.pos, tr), transforms=tr)
+            for k in tr:
+                raw.postprocessor.postprocess(k)
+            v.poll()
+            frames.append(v.framebuffer().copy())
+        nsel = sum(int(np.unpackbits(raw.models[k].gaussian_buffers.selection_buffer.download().view(np.uint8)).sum()) for k in tr)
+        return frames, nsel
+
+    single = parallel.ShardedViewer(world=1, rank=0, use_dist=False)
+    for k, g in scenes.items():
+        single.load_shard(g, 0, g.shape[0], key=k)
+    ref, nsel_ref = drive(single, single.stages.viewer)
+    single.close()
+    assert nsel_ref > 100 and not np.array_equal(ref[0], ref[1])
+
+    def rank_main(rank, comm):
+        v = parallel.ShardedViewer(world=world, rank=rank, use_dist=True, comm=comm)
+        for k, g in scenes.items():
+            s0, c = parallel.shard_range(g.shape[0], rank, world)
+            v.load_shard(g[s0:s0 + c], s0, g.shape[0], key=k)
+        with v.stages.stream_ctx():
+            out = drive(v, v.stages.viewer)
+        v.close()
+        return out
+
+    res = common.run_ranks(world, rank_main)
+    assert sum(r[1] for r in res) == nsel_ref, "the shards' selections partition the single-viewer selection"
+    for rank, (frames, _) in enumerate(res):
+        for i, fb in enumerate(frames):
+            assert np.array_equal(fb, ref[i]), f"rank {rank} frame {i}: L-inf {np.abs(fb - ref[i]).max()}"

@@ -44,7 +44,7 @@ class HipStages:
     def load_shard(self, key: str, gaussians: np.ndarray, start: int, n_total: int) -> None:
         self.viewer.add_model(key, gaussians.shape[0])
         self.viewer.models[key].gaussian_buffers.gaussians_buffer.update_range(0, gaussians)
-        self._n_local = gaussians.shape[0]
+        self._n_local = max(getattr(self, "_n_local", 0), gaussians.shape[0])  # sizes the shared send buffer
 
     def set_uniforms(self, key, camera, size, model_transform=None, gaussian_transform=None) -> None:
         mt = model_transform or ModelTransform()
@@ -58,6 +58,9 @@ class HipStages:
     def render_local(self, key: str) -> None:
         """Enqueue one whole frame; no host synchronisation (statistics are fetched lazily by ``stats``)."""
         self.viewer.render_frame([key])
+
+    def render_local_keys(self, keys) -> None:
+        self.viewer.render_frame(list(keys))
 
     def stats(self, key: str) -> dict:
         return self.viewer.frame_stats(key)
@@ -114,14 +117,22 @@ class HipStages:
 
         return torch.empty((n, RECORD_FLOATS), dtype=torch.float32, device=f"cuda:{self.device}")
 
-    def render_records(self, key: str, recv, n: int, world: int, rank: int, more: bool = False, window=None) -> None:
-        """``gsx_shard_import`` + sort + render; ``window``: the same per-tile windows that were given to ``pack``."""
+    def import_records(self, key: str, recv, n: int, world: int, rank: int, window=None) -> None:
+        """``gsx_shard_import`` + ``gsx_sort``; ``window``: the same per-tile windows that were given to ``pack``."""
         v = self.viewer
         d_win = self._window_ptr(window, "_imp_win_t")
         _lib.check(v._L.gsx_shard_import(v._h, key.encode(), recv.data_ptr() if n else None, n, world, rank, d_win))
         v.radix_sorter.sort(key)
-        arr = (C.c_char_p * 1)(key.encode())
-        _lib.check((v._L.gsx_render_more if more else v._L.gsx_render)(v._h, arr, 1))
+
+    def render_keys(self, keys, more: bool = False) -> None:
+        """``gsx_render`` / ``gsx_render_more`` over the imported record sets, ``keys`` far -> near (scene.rs:533-558)."""
+        v = self.viewer
+        arr = (C.c_char_p * len(keys))(*[k.encode() for k in keys])
+        _lib.check((v._L.gsx_render_more if more else v._L.gsx_render)(v._h, arr, len(keys)))
+
+    def render_records(self, key: str, recv, n: int, world: int, rank: int, more: bool = False, window=None) -> None:
+        self.import_records(key, recv, n, world, rank, window)
+        self.render_keys([key], more)
 
     def feedback(self, key: str, world: int, rank: int):
         """Device tensor int32[rows_per_rank * tiles_x] (u32 bit patterns): saturation depth key of every tile of this

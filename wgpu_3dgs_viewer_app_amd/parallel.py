@@ -68,6 +68,14 @@ def windows_second(limit: np.ndarray, need: np.ndarray) -> np.ndarray:
     return w
 
 
+def model_render_keys(camera_pos, transforms: dict) -> list:
+    """The app's far -> near model order: descending squared distance from the camera to each model's world centre,
+    which is the model position (scene.rs:533-558, app.rs:1038-1046: `center` stays Vec3::ZERO)."""
+    cp = np.asarray(camera_pos, np.float32)
+    d = {k: float(((np.asarray(mt.pos, np.float32) - cp) ** 2).sum()) for k, mt in transforms.items()}
+    return sorted(d, key=lambda k: -d[k])
+
+
 def shard_range(n: int, rank: int, world: int):
     """Contiguous index shard [start, start+count) of rank; sizes differ by at most one."""
     base, rem = divmod(n, world)
@@ -123,25 +131,61 @@ class ShardedViewer:
         self.margin = 0.5   # how far behind last frame's saturation depth a tile still takes records
         self.radius = 3     # tiles; neighbourhood over which the saturation depth is maximised (camera motion)
         self.rounds = 0
+        self.keys = []      # models in load order
         self.debug, self.debug_log = False, []
         self.profile = None  # set to {} to collect host wall time per protocol section (adds device syncs)
         self._size = (1, 1)
 
     # -- scene --
-    def load_shard(self, gaussians: np.ndarray, start: int, n_total: int) -> None:
-        self.stages.load_shard(self.KEY, gaussians, start, n_total)
+    def load_shard(self, gaussians: np.ndarray, start: int, n_total: int, key: str | None = None) -> None:
+        """This rank's index shard [start, start + len) of model ``key`` (several models: call once per key)."""
+        key = key or self.KEY
+        self.stages.load_shard(key, gaussians, start, n_total)
+        if key not in self.keys:
+            self.keys.append(key)
 
     # -- frame --
-    def render_frame(self, camera, size, model_transform=None, gaussian_transform=None):
-        """One frame.  On rank 0 ``self.stages.framebuffer()`` afterwards holds the complete (rgb, T) image."""
+    def render_frame(self, camera, size, model_transform=None, gaussian_transform=None, keys=None, transforms=None):
+        """One frame; afterwards ``framebuffer()`` holds the complete (rgb, T) image on every rank.
+
+        One model: ``model_transform`` is its TRS.  Several models: ``keys`` lists them far -> near — the app's
+        ``model_render_keys`` (scene.rs:533-558), see ``model_render_keys`` below — and ``transforms[key]`` their TRS;
+        models are layered, never merged, exactly as on one GPU."""
         st = self.stages
-        st.set_uniforms(self.KEY, camera, size, model_transform, gaussian_transform)
+        keys = list(keys) if keys is not None else list(self.keys[:1] or [self.KEY])
+        transforms = dict(transforms or {})
+        if model_transform is not None and len(keys) == 1:
+            transforms.setdefault(keys[0], model_transform)
+        for k in keys:
+            st.set_uniforms(k, camera, size, transforms.get(k), gaussian_transform)
         self._size = (int(size[0]), int(size[1]))
         if not self.use_dist:
-            st.render_local(self.KEY)
+            if len(keys) == 1:
+                st.render_local(keys[0])
+            else:
+                st.render_local_keys(keys)
             return
         with st.stream_ctx():
-            self._render_frame_dist()
+            if len(keys) == 1:
+                self._render_frame_dist(keys[0])
+            else:
+                self._render_frame_dist_layers(keys)
+
+    def _render_frame_dist_layers(self, keys):
+        """Several layered models: every model's records travel once to the bands they touch (no windows — a tile's
+        saturation depth is a per-model quantity), each rank composites the layers of its band front to back."""
+        st = self.stages
+        world, rank = self.world, self.rank
+        for k in keys:
+            st.begin_frame(k, world, rank)
+        for k in keys:
+            send, counts = st.pack(k, world, None)
+            recv, n = self._exchange(send, counts)
+            st.import_records(k, recv, n, world, rank, None)
+        st.render_keys(keys, more=False)
+        self.rounds = 1
+        self._limit = None
+        self.comm.all_gather(st.gather_target(), st.own_band())
 
     def _exchange(self, send, send_counts):
         """counts, then the 48-byte records with exact split sizes (two all-to-alls)."""
@@ -152,12 +196,12 @@ class ShardedViewer:
         self.comm.all_to_all_records(recv, send[: sum(send_counts)], recv_counts, send_counts)
         return recv, sum(recv_counts)
 
-    def _feedback(self, tiles_x, tiles_y):
+    def _feedback(self, key, tiles_x, tiles_y):
         """Saturation depth key of every tile of the frame (0 = open): each rank contributes its band, one small
         all-gather; the result is identical on every rank."""
         import torch
 
-        mine = self.stages.feedback(self.KEY, self.world, self.rank)
+        mine = self.stages.feedback(key, self.world, self.rank)
         allw = torch.empty(self.world * mine.numel(), dtype=mine.dtype, device=mine.device)
         self.comm.all_gather(allw, mine)
         return allw.cpu().numpy().view(np.uint32).reshape(-1, tiles_x)[:tiles_y]
@@ -173,7 +217,7 @@ class ShardedViewer:
         self.profile[name] = self.profile.get(name, 0.0) + (now - self._t_last)
         self._t_last = now
 
-    def _render_frame_dist(self):
+    def _render_frame_dist(self, key):
         st = self.stages
         world, rank = self.world, self.rank
         tiles_x, tiles_y = (self._size[0] + 15) // 16, (self._size[1] + 15) // 16
@@ -183,31 +227,31 @@ class ShardedViewer:
             st.poll()
             self._t_last = time.perf_counter()
         # stage P: project the resident shard
-        st.begin_frame(self.KEY, world, rank)
+        st.begin_frame(key, world, rank)
         self._tick("project")
         # stage X/C: every tile takes the records in front of its limit (first frame / speculation off: everything)
         limit = self._limit if self.speculate else None
         if limit is not None and limit.shape != (tiles_y, tiles_x):
             limit = None
         win = windows_first(limit) if limit is not None else None
-        send, counts = st.pack(self.KEY, world, win)
+        send, counts = st.pack(key, world, win)
         self._tick("pack")
         recv, n = self._exchange(send, counts)
         self._tick("exchange")
-        st.render_records(self.KEY, recv, n, world, rank, more=False, window=win)
+        st.render_records(key, recv, n, world, rank, more=False, window=win)
         self._tick("import_sort_render")
         # verification + next frame's limits from one collective
-        sat = self._feedback(tiles_x, tiles_y)
+        sat = self._feedback(key, tiles_x, tiles_y)
         self._tick("feedback")
         self.rounds = 1
         if limit is not None:
             need = (limit < KEY_ALL) & (sat == 0)  # refused its deep records but still open
             if need.any():
                 win2 = windows_second(limit, need)
-                send, counts = st.pack(self.KEY, world, win2)
+                send, counts = st.pack(key, world, win2)
                 recv, n = self._exchange(send, counts)
-                st.render_records(self.KEY, recv, n, world, rank, more=True, window=win2)
-                sat = self._feedback(tiles_x, tiles_y)
+                st.render_records(key, recv, n, world, rank, more=True, window=win2)
+                sat = self._feedback(key, tiles_x, tiles_y)
                 self.rounds = 2
                 self._tick("second_round")
                 if self.debug:  # what the wrong limits looked like (dev tool)
@@ -229,9 +273,9 @@ class ShardedViewer:
     def poll(self) -> None:
         self.stages.poll()
 
-    def last_stats(self) -> dict:
+    def last_stats(self, key: str | None = None) -> dict:
         """Statistics of the last frame (synchronises)."""
-        return dict(self.stages.stats(self.KEY))
+        return dict(self.stages.stats(key or (self.keys[0] if self.keys else self.KEY)))
 
     def set_pass_timing(self, on: bool) -> None:
         self.stages.set_pass_timing(on)
