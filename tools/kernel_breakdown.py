@@ -6,7 +6,7 @@ import glob
 import sys
 
 d, frames = sys.argv[1], float(sys.argv[2])
-f = glob.glob(d + "/*/*_kernel_trace.csv")[0]
+f = (glob.glob(d + "/*/*_kernel_trace.csv") + glob.glob(d + "/*_kernel_trace.csv"))[0]
 acc = collections.defaultdict(list)
 t0, t1 = None, None
 for r in csv.DictReader(open(f)):

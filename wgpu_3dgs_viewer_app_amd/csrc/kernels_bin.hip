@@ -15,6 +15,7 @@ namespace gsx {
 
 constexpr int kBinThreads = 256;  // one splat per lane
 constexpr uint32_t kCoopThreshold = 24;  // rectangles with more tiles are expanded by the whole wave
+constexpr uint32_t kBinGrid = 256 * 24;  // workgroups of the chunk-striding kernels: 24 per CU keeps the gathers in flight
 
 size_t scan_blocks(uint64_t n) { return (size_t)((n + kBinThreads - 1) / kBinThreads); }
 
@@ -82,9 +83,10 @@ __device__ inline uint32_t block_reduce_sum(uint32_t v, uint32_t* smem4) {
 }
 
 // Slab splat j in [j0, min(j1, N_vis)): gather its tile rectangle once (-> srect[j - j0], reused by the
-// emit kernel), count its live tiles (-> cnt[j - j0]) and reduce per workgroup (-> block_sums).
-// One splat per lane and 256 per workgroup: the gather rec_a[sorted_idx[j]] is a dependent random
-// access, so the pass lives on memory-level parallelism (N/256 workgroups), not on per-lane loops.
+// emit kernel), count its live tiles (-> cnt[j - j0]) and reduce per 256-splat chunk (-> block_sums[chunk]).
+// One splat per lane: the gather rec_a[sorted_idx[j]] is a dependent random access, so the pass lives on
+// memory-level parallelism.  Workgroups stride over the chunks that exist ON THE DEVICE (N_vis is only known
+// there), so a slab bound far above N_vis — the host plans slabs from an upper bound — costs nothing.
 // done == nullptr: every tile is live.
 __global__ __launch_bounds__(kBinThreads) void k_tile_counts(const uint32_t* __restrict__ d_n_vis, uint32_t j0,
                                                               uint32_t j1, const uint32_t* __restrict__ sorted_idx,
@@ -96,61 +98,69 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_counts(const uint32_t* __r
                                                               const uint32_t* __restrict__ d_done_count,
                                                               uint32_t owned_tiles, TileWindow tw) {
     __shared__ uint32_t red[4];
-    // every tile this rank composites is saturated: whatever is left is hidden, skip the gather
-    if (d_done_count && *d_done_count >= owned_tiles) {
-        if (threadIdx.x == 0) block_sums[blockIdx.x] = 0;
-        return;
-    }
     const uint32_t n_vis = min(*d_n_vis, j1);
-    const uint32_t j = j0 + blockIdx.x * kBinThreads + threadIdx.x;
-    uint32_t c = 0, rx = 0, ry = 0, key = 0, area = 0;
-    if (j < n_vis) {
-        const float4 a = rec_a[sorted_idx[j]];
-        rx = __float_as_uint(a.z);
-        ry = __float_as_uint(a.w);
+    const uint32_t chunks = n_vis > j0 ? (n_vis - j0 + kBinThreads - 1) / kBinThreads : 0u;
+    // every tile this rank composites is saturated: whatever is left is hidden, skip the gather
+    const bool all_done = d_done_count && *d_done_count >= owned_tiles;
+    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        if (all_done) {
+            if (threadIdx.x == 0) block_sums[chunk] = 0;
+            continue;
+        }
+        const uint32_t j = j0 + chunk * kBinThreads + threadIdx.x;
+        uint32_t c = 0, rx = 0, ry = 0, key = 0, area = 0;
+        if (j < n_vis) {
+            const float4 a = rec_a[sorted_idx[j]];
+            rx = __float_as_uint(a.z);
+            ry = __float_as_uint(a.w);
+            if (tw.win) {
+                key = tw.sorted_keys[j];
+                area = rect_area(a, row_lo, row_hi);
+                if (area <= kCoopThreshold)
+                    for (uint32_t ty = max(ry & 0xFFFFu, row_lo), last = min(ry >> 16, row_hi); ty < last; ++ty)
+                        c += window_tiles_in_row(done, row_words, tw.win, tw.tiles_x, ty, rx & 0xFFFFu, rx >> 16, key);
+            } else {
+                c = done ? rect_live_area(a, row_lo, row_hi, done, row_words) : rect_area(a, row_lo, row_hi);
+            }
+            srect[j - j0] = make_uint2(rx, ry);
+        }
         if (tw.win) {
-            key = tw.sorted_keys[j];
-            area = rect_area(a, row_lo, row_hi);
-            if (area <= kCoopThreshold)
-                for (uint32_t ty = max(ry & 0xFFFFu, row_lo), last = min(ry >> 16, row_hi); ty < last; ++ty)
-                    c += window_tiles_in_row(done, row_words, tw.win, tw.tiles_x, ty, rx & 0xFFFFu, rx >> 16, key);
-        } else {
-            c = done ? rect_live_area(a, row_lo, row_hi, done, row_words) : rect_area(a, row_lo, row_hi);
-        }
-        srect[j - j0] = make_uint2(rx, ry);
-    }
-    if (tw.win) {
-        // large rectangles: the whole wave evaluates the window predicate, lane l takes tiles l, l + 64, ...
-        unsigned long long big = __ballot(area > kCoopThreshold);
-        const uint32_t lane = threadIdx.x & 63u;
-        while (big) {
-            const int src = __ffsll((long long)big) - 1;
-            big &= big - 1;
-            const uint32_t brx = __shfl(rx, src, 64), bry = __shfl(ry, src, 64), bkey = __shfl(key, src, 64);
-            const uint32_t total = __shfl(area, src, 64);
-            const uint32_t x0 = brx & 0xFFFFu, w = (brx >> 16) - x0, first = max(bry & 0xFFFFu, row_lo);
-            uint32_t n = 0;
-            for (uint32_t k = lane; k < total; k += 64)
-                n += tile_takes(done, row_words, tw.win, tw.tiles_x, x0 + k % w, first + k / w, bkey) ? 1u : 0u;
+            // large rectangles: the whole wave evaluates the window predicate, lane l takes tiles l, l + 64, ...
+            unsigned long long big = __ballot(area > kCoopThreshold);
+            const uint32_t lane = threadIdx.x & 63u;
+            while (big) {
+                const int src = __ffsll((long long)big) - 1;
+                big &= big - 1;
+                const uint32_t brx = __shfl(rx, src, 64), bry = __shfl(ry, src, 64), bkey = __shfl(key, src, 64);
+                const uint32_t total = __shfl(area, src, 64);
+                const uint32_t x0 = brx & 0xFFFFu, w = (brx >> 16) - x0, first = max(bry & 0xFFFFu, row_lo);
+                uint32_t n = 0;
+                for (uint32_t k = lane; k < total; k += 64)
+                    n += tile_takes(done, row_words, tw.win, tw.tiles_x, x0 + k % w, first + k / w, bkey) ? 1u : 0u;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
-            if ((int)lane == src) c = n;
+                for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+                if ((int)lane == src) c = n;
+            }
         }
+        if (j < n_vis) cnt[j - j0] = c;
+        const uint32_t tot = block_reduce_sum(c, red);
+        if (threadIdx.x == 0) block_sums[chunk] = tot;
+        __syncthreads();  // red[] is reused by the next chunk
     }
-    if (j < n_vis) cnt[j - j0] = c;
-    uint32_t tot = block_reduce_sum(c, red);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
 // single workgroup: exclusive scan of block_sums in place; slab total D -> stats->n_entries (clamped to the
 // pair-buffer capacity; an overflow is flagged for the host to grow the buffers and redo the frame)
-__global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__ sums, uint32_t nblocks,
+__global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__ sums, uint32_t j0, uint32_t j1,
+                                                           const uint32_t* __restrict__ d_n_vis,
                                                            SlabStats* __restrict__ stats, uint32_t capacity,
                                                            const uint32_t* __restrict__ d_done_count,
                                                            uint32_t owned_tiles, uint32_t slab_index) {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry_s;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n_vis = min(*d_n_vis, j1);
+    const uint32_t nblocks = n_vis > j0 ? (n_vis - j0 + kBinThreads - 1) / kBinThreads : 0u;  // chunks that exist
     if (tid == 0) carry_s = 0;
     __syncthreads();
     for (uint32_t base = 0; base < nblocks; base += 1024) {
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__
         stats->n_entries = min(total, capacity);
         stats->n_entries_total += total;
         // the host sizes the next frame's slab plan from this (read lazily, never waited for)
-        if (!(d_done_count && *d_done_count >= owned_tiles)) stats->slabs_used = max(stats->slabs_used, slab_index + 1u);
+        if (nblocks && !(d_done_count && *d_done_count >= owned_tiles)) stats->slabs_used = max(stats->slabs_used, slab_index + 1u);
         if (total > capacity) {
             stats->overflow = 1;
             stats->max_needed = max(stats->max_needed, total);
@@ -219,7 +229,9 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_emit(uint32_t jbase, uint3
     if (*d_entries == 0) return;  // empty slab (also: every tile already saturated)
     n_vis = min(n_vis, *d_n_vis);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t j = jbase + blockIdx.x * kBinThreads + tid;
+    const uint32_t chunks = n_vis > jbase ? (n_vis - jbase + kBinThreads - 1) / kBinThreads : 0u;
+    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+    const uint32_t j = jbase + chunk * kBinThreads + tid;
     const uint32_t mine = j < n_vis ? cnt[j - jbase] : 0u;
     uint32_t x = mine;
 #pragma unroll
@@ -229,7 +241,7 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_emit(uint32_t jbase, uint3
     }
     if (lane == 63) wsum[wave] = x;
     __syncthreads();
-    uint32_t o = block_offs[blockIdx.x] + x - mine;
+    uint32_t o = block_offs[chunk] + x - mine;
     for (uint32_t w = 0; w < wave; ++w) o += wsum[w];
     uint32_t idx = 0;
     uint2 r = make_uint2(0, 0);
@@ -289,6 +301,8 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_emit(uint32_t jbase, uint3
             }
         }
     }
+    __syncthreads();  // wsum[] is reused by the next chunk
+    }
 }
 
 // ranges[t] = [first, last+1) of tile t in the tile-sorted pair list (ranges pre-zeroed)
@@ -307,12 +321,12 @@ hipError_t launch_tile_counts(hipStream_t s, uint32_t j0, uint32_t j1, const uin
                               uint32_t capacity, uint32_t row_lo, uint32_t row_hi, const uint32_t* done, uint32_t row_words,
                               const uint32_t* d_done_count, uint32_t owned_tiles, uint32_t slab_index,
                               const uint2* window, const uint32_t* sorted_keys, uint32_t tiles_x) {
-    uint32_t nb = (uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0);
+    const uint32_t nb = std::min<uint32_t>((uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0), kBinGrid);
     TileWindow tw{window, sorted_keys, tiles_x};
     if (nb)
         hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(kBinThreads), 0, s, d_n_vis, j0, j1, sorted_idx, rec.a, srect, cnt,
                            block_sums, row_lo, row_hi, done, row_words, d_done_count, owned_tiles, tw);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nb, stats, capacity, d_done_count,
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, j0, j1, d_n_vis, stats, capacity, d_done_count,
                        owned_tiles, slab_index);
     return hipGetLastError();
 }
@@ -322,7 +336,7 @@ hipError_t launch_tile_emit(hipStream_t s, uint32_t j0, uint32_t j1, const uint3
                             uint32_t row_lo, uint32_t row_hi, const uint32_t* done, uint32_t row_words,
                             const uint32_t* d_n_vis, const uint32_t* d_entries, uint32_t capacity,
                             const uint2* window, const uint32_t* sorted_keys) {
-    uint32_t nb = (uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0);
+    const uint32_t nb = std::min<uint32_t>((uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0), kBinGrid);
     if (!nb) return hipSuccess;
     TileWindow tw{window, sorted_keys, tiles_x};
     hipLaunchKernelGGL(k_tile_emit, dim3(nb), dim3(kBinThreads), 0, s, j0, j1, sorted_idx, srect, cnt, block_sums,
