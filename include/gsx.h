@@ -81,12 +81,21 @@ typedef struct gsx_spec_params {
  * progressive = 1: the depth-sorted splats are binned and composited front to back in growing depth slabs
  * [0, N_vis/first_slab_divisor), then `growth` times larger each; tiles whose every pixel has reached
  * T < t_epsilon are flagged and receive no further tile entries.  Pixels are identical to progressive = 0
- * (the per-pixel operation sequence is unchanged); only the work on hidden splats is skipped. */
+ * (the per-pixel operation sequence is unchanged); only the work on hidden splats is skipped.
+ * speculative = 1 (needs progressive): temporal occlusion speculation.  Every tile remembers the depth at which it
+ * saturated in the model's previous frame; only the records in front of (1 + spec_margin) x that depth, maximised over
+ * the tile's (2 spec_radius + 1)^2 neighbourhood, enter this frame's depth sort and binning.  The compositor verifies
+ * the assumption on the device and a second round hands the tiles that are still open the records they were refused,
+ * composited behind — pixels stay identical to speculative = 0 whatever the camera does; a wrong guess only costs
+ * time.  After such a frame gsx_model_download_sorted returns the second round's (possibly empty) order. */
 typedef struct gsx_render_options {
     uint32_t progressive;        /* default 1 */
     uint32_t first_slab_divisor; /* default 16 */
     uint32_t min_slab;           /* models with N_vis <= min_slab use one slab; default 131072 */
     uint32_t growth;             /* default 2 */
+    uint32_t speculative;        /* default 1 */
+    float spec_margin;           /* default 0.5 */
+    uint32_t spec_radius;        /* default 3 (tiles) */
 } gsx_render_options;
 
 typedef struct gsx_viewer_desc {
@@ -190,6 +199,11 @@ typedef struct gsx_frame_stats {
     uint64_t n_gaussians; /* N of the model */
     uint64_t n_visible;   /* N_vis after cull */
     uint64_t n_tile_entries; /* D = tile entries binned by the last gsx_render (all of them with progressive = 0) */
+    uint64_t n_sorted;       /* records that entered the depth sort (= n_visible unless the frame was speculated) */
+    uint64_t n_repair_tiles; /* speculated frame: tiles that needed the repair round */
+    uint64_t n_repair_sorted; /* speculated frame: records that entered the repair round's depth sort */
+    uint32_t speculated;     /* 1 if the last gsx_render of this model used last frame's windows */
+    uint32_t reserved;
 } gsx_frame_stats;
 gsx_status gsx_model_frame_stats(gsx_viewer* v, const char* key, gsx_frame_stats* out);
 /* Per-Gaussian projection outputs of the last gsx_preprocess (host arrays of length N; any may be NULL):

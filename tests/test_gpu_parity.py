@@ -189,7 +189,8 @@ def test_edge_cases_empty_culled_huge():
         # empty model
         v.add_model("empty", 0)
         v.render_frame(["empty"])
-        assert v.frame_stats("empty") == dict(n_gaussians=0, n_visible=0, n_tile_entries=0)
+        st = v.frame_stats("empty")
+        assert (st["n_gaussians"], st["n_visible"], st["n_tile_entries"], st["n_sorted"]) == (0, 0, 0, 0)
         assert np.all(v.download_framebuffer()[..., 3] == 1)
         # everything behind the camera: all culled
         g = common.small_scene(500, 61)

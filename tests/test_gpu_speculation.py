@@ -1,0 +1,163 @@
+"""GPU: temporal occlusion speculation (gsx_render_options.speculative, kernels_spec.hip / kernels_admit.hip).
+
+The claim under test: whatever the windows inherited from the previous frame — a smooth orbit, a camera jump, a model
+that changed underneath (mask, edit, transform), several layered models — the speculated frame is BIT-IDENTICAL to the
+frame rendered with speculative = 0, and both stay within the framebuffer tolerance of the oracle.  The statistics
+show the speculation engaged (fewer records sorted) and that the repair round ran when it had to."""
+import numpy as np
+import pytest
+
+import oracle
+from tests import common
+from tests.test_gpu_parity import FB_TOL
+from wgpu_3dgs_viewer_app_amd import camera, query
+from wgpu_3dgs_viewer_app_amd.viewer import GaussianDisplayMode, GaussianShDegree, MultiModelViewer
+
+pytestmark = pytest.mark.gpu
+W, H = 256, 176
+
+
+def _viewer(speculative, **opts):
+    v = MultiModelViewer()
+    v.set_render_options(speculative=1 if speculative else 0, min_slab=2048, **opts)
+    return v
+
+
+def _load(v, key, g, mt=None):
+    v.add_model(key, g.shape[0])
+    v.models[key].gaussian_buffers.gaussians_buffer.update_range(0, g)
+    if mt is not None:
+        v.update_model_transform(key, mt.pos, mt.quat(), mt.scale)
+
+
+def _frame(v, cam, keys, size=(W, H)):
+    v.update_camera(cam, size)
+    v.update_gaussian_transform(1.0, GaussianDisplayMode.Splat, GaussianShDegree.new(3), False)
+    v.render_frame(keys)
+    v.poll()
+    return v.download_framebuffer()
+
+
+@pytest.mark.parametrize("margin,radius", [(0.5, 3), (0.0, 0), (2.0, 1)])
+def test_orbit_with_jumps_bit_identical(margin, radius):
+    g = common.small_scene(30000, 201, scale_mul=10.0)  # opaque enough that most tiles saturate
+    poses = [10, 11, 12, 13, 14, 130, 131, 132, 60, 61, 61, 61, 200]  # smooth runs, jumps, a still camera
+    spec, plain = _viewer(True, spec_margin=margin, spec_radius=radius), _viewer(False)
+    _load(spec, "m", g)
+    _load(plain, "m", g)
+    engaged = repaired = 0
+    for k, pose in enumerate(poses):
+        cam = camera.orbit_pose(pose)
+        a, b = _frame(spec, cam, ["m"]), _frame(plain, cam, ["m"])
+        assert np.array_equal(a, b), f"pose {pose} (frame {k}): speculated frame differs, L-inf {np.abs(a - b).max()}"
+        st, sp = spec.frame_stats("m"), plain.frame_stats("m")
+        assert st["n_visible"] == sp["n_visible"] and not sp["speculated"] and sp["n_sorted"] == sp["n_visible"]
+        assert st["speculated"] == (k > 0)
+        if st["speculated"]:
+            engaged += st["n_sorted"] < 0.8 * st["n_visible"]
+            repaired += st["n_repair_tiles"] > 0
+            assert (st["n_repair_sorted"] > 0) == (st["n_repair_tiles"] > 0) or st["n_repair_tiles"] > 0
+    if margin <= 0.5:
+        assert engaged >= 6, "the speculation never reduced the sorted set: the test scene is not opaque enough"
+    if margin == 0.0:
+        assert repaired >= 3, "zero margin / radius must mispredict on a moving camera, or the repair round is untested"
+    # and the oracle agrees with the last frame
+    _, _, _, _, fb_ref = common.oracle_model_frame(g, camera.orbit_pose(poses[-1]), W, H)
+    assert np.abs(a - fb_ref).max() <= FB_TOL
+    spec.close()
+    plain.close()
+
+
+def test_scene_changes_under_the_windows():
+    """mask, hidden edit, model transform, Gaussian size, viewport: every change invalidates the inherited windows in
+    some tiles; the repair round must make up for all of it."""
+    from wgpu_3dgs_viewer_app_amd.mask import MaskEvaluator, MaskOp, MaskShape, MaskShapeKind
+
+    g = common.small_scene(25000, 202, scale_mul=10.0)
+    spec, plain = _viewer(True), _viewer(False)
+    for v in (spec, plain):
+        _load(v, "m", g)
+    cam = camera.orbit_pose(40)
+    rng = np.random.default_rng(3)
+    sel = rng.integers(0, 2 ** 32, (g.shape[0] + 31) // 32, dtype=np.uint64).astype(np.uint32)
+    shapes = [MaskShape(MaskShapeKind.Ellipsoid, pos=np.array([0.0, 0.0, 0.0], np.float32), scale=np.array([2.5, 2.5, 2.5], np.float32))]
+
+    def both(fn, size=(W, H)):
+        out = []
+        for v in (spec, plain):
+            fn(v)
+            out.append(_frame(v, cam, ["m"], size))
+        assert np.array_equal(out[0], out[1]), f"L-inf {np.abs(out[0] - out[1]).max()}"
+        return spec.frame_stats("m")
+
+    both(lambda v: None)
+    both(lambda v: None)
+    st = both(lambda v: MaskEvaluator(v).evaluate(MaskOp.parse("0"), "m", shapes))   # everything in front of the core disappears
+    assert st["speculated"] and st["n_repair_tiles"] > 0
+    both(lambda v: MaskEvaluator(v).evaluate(None, "m"))                               # and comes back
+    both(lambda v: (v.models["m"].gaussian_buffers.selection_buffer.upload(sel),
+                    v.update_selection_edit_with_pod(query.GaussianEditPod(query.GaussianEditFlag.ENABLED | query.GaussianEditFlag.HIDDEN))))
+    both(lambda v: v.update_selection_edit_with_pod(query.GaussianEditPod(query.GaussianEditFlag.ENABLED, (0.2, 1.0, 1.0), 0, 0, 1.0, 0.3)))
+    mt = common.odd_transform()
+    both(lambda v: v.update_model_transform("m", mt.pos, mt.quat(), mt.scale))
+    both(lambda v: None, size=(W - 40, H + 24))   # another tile grid: the windows do not apply, the frame is unspeculated
+    assert not spec.frame_stats("m")["speculated"]
+    st = both(lambda v: None, size=(W - 40, H + 24))
+    assert st["speculated"]
+    spec.close()
+    plain.close()
+
+
+def test_layered_models_speculate_per_model():
+    scenes = {"a": (common.small_scene(12000, 203, scale_mul=10.0), camera.ModelTransform(pos=np.array([0.0, 0.0, 2.0], np.float32))),
+              "b": (common.small_scene(15000, 204, scale_mul=10.0), common.odd_transform()),
+              "c": (common.small_scene(9000, 205, scale_mul=10.0), camera.ModelTransform(pos=np.array([-1.5, 0.2, -2.0], np.float32)))}
+    spec, plain = _viewer(True), _viewer(False)
+    for v in (spec, plain):
+        for k, (g, mt) in scenes.items():
+            _load(v, k, g, mt)
+    from wgpu_3dgs_viewer_app_amd import parallel
+
+    tr = {k: mt for k, (_, mt) in scenes.items()}
+    orders = set()
+    for i, pose in enumerate([20, 21, 22, 100, 101, 102, 103, 180]):
+        cam = camera.orbit_pose(pose)
+        keys = parallel.model_render_keys(cam.pos, tr)
+        orders.add(tuple(keys))
+        a, b = _frame(spec, cam, keys), _frame(plain, cam, keys)
+        assert np.array_equal(a, b), f"pose {pose}: layered speculated frame differs, L-inf {np.abs(a - b).max()}"
+        if i:
+            assert all(spec.frame_stats(k)["speculated"] for k in keys)
+    assert len(orders) > 1, "the layer order must change along the path for the test to cover it"
+    # a model leaves the frame and comes back with stale windows
+    cam = camera.orbit_pose(180)
+    for keys in (["a", "c"], ["c", "b", "a"], ["b"]):
+        assert np.array_equal(_frame(spec, cam, keys), _frame(plain, cam, keys))
+    spec.close()
+    plain.close()
+
+
+def test_split_protocol_and_statistics():
+    """preprocess / sort / render called one by one (the app's protocol) speculate exactly like render_frame; the depth
+    order exposed after a speculated frame is the repair round's."""
+    g = common.small_scene(20000, 206, scale_mul=10.0)
+    cam0, cam1 = camera.orbit_pose(70), camera.orbit_pose(71)
+    with _viewer(True) as v, _viewer(False) as p:
+        _load(v, "m", g)
+        _load(p, "m", g)
+        for cam in (cam0, cam1, cam1):
+            for x in (v, p):
+                x.update_camera(cam, (W, H))
+                x.update_gaussian_transform(1.0, GaussianDisplayMode.Splat, GaussianShDegree.new(3), False)
+                x.preprocessor.preprocess("m")
+                x.radix_sorter.sort("m")
+                x.renderer.render(["m"])
+                x.poll()
+            assert np.array_equal(v.download_framebuffer(), p.download_framebuffer())
+        st = v.frame_stats("m")
+        assert st["speculated"] and st["n_sorted"] < st["n_visible"]
+        assert v.download_sorted("m").size == st["n_repair_sorted"]
+        # the projection download is untouched by the speculation
+        gp, pp = v.download_projection("m"), p.download_projection("m")
+        assert all(np.array_equal(gp[k], pp[k]) for k in ("key", "rect", "mean2d", "conic_opacity", "rgb"))
+        assert np.array_equal(np.sort(p.download_sorted("m")), np.nonzero(pp["key"] != 0xFFFFFFFF)[0])

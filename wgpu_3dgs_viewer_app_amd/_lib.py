@@ -53,7 +53,8 @@ class SpecParams(C.Structure):
 
 
 class RenderOptions(C.Structure):
-    _fields_ = [("progressive", C.c_uint32), ("first_slab_divisor", C.c_uint32), ("min_slab", C.c_uint32), ("growth", C.c_uint32)]
+    _fields_ = [("progressive", C.c_uint32), ("first_slab_divisor", C.c_uint32), ("min_slab", C.c_uint32), ("growth", C.c_uint32),
+                ("speculative", C.c_uint32), ("spec_margin", C.c_float), ("spec_radius", C.c_uint32)]
 
 
 class PlyHeader(C.Structure):
@@ -72,7 +73,8 @@ class ViewerDesc(C.Structure):
 
 
 class FrameStats(C.Structure):
-    _fields_ = [("n_gaussians", C.c_uint64), ("n_visible", C.c_uint64), ("n_tile_entries", C.c_uint64)]
+    _fields_ = [("n_gaussians", C.c_uint64), ("n_visible", C.c_uint64), ("n_tile_entries", C.c_uint64), ("n_sorted", C.c_uint64),
+                ("n_repair_tiles", C.c_uint64), ("n_repair_sorted", C.c_uint64), ("speculated", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class GsxError(RuntimeError):

@@ -105,7 +105,7 @@ struct Model {
     bool stats_pending = false;                 // device statistics newer than the host mirror
     bool ranges_clean = false;                  // the tile range table is known to be all-zero
     bool lists_complete = false;                // the tile lists of the last render cover the whole model (one slab)
-    uint32_t n_visible = 0, n_entries = 0;
+    uint32_t n_visible = 0, n_entries = 0, n_sorted = 0, n_sorted2 = 0;
     uint64_t tile_cap = 0;                      // capacity (entries) of the tile-pair buffers
     uint32_t slabs_hint = 0;                    // slabs the last observed frame needed (0 = unknown)
     hipEvent_t stats_event = nullptr;           // completion of the asynchronous statistics copy
@@ -119,6 +119,12 @@ struct Model {
     DevBuf selection, edited, edit_a, edit_b, keep, query_flags, hits, hit_count;
     bool has_selection = false, has_edits = false, show_unedited = false;
     uint32_t flags_kind = GSX_QUERY_NONE, flags_op = GSX_SELECTION_SET;  // what the last preprocess evaluated
+    // temporal occlusion speculation (kernels_spec.hip): this model's per-tile windows for its next frame, the repair
+    // windows of the current one, the saturated-tile bitmap as it was before this model was composited
+    DevBuf spec_win, spec_win2, spec_done_before, spec_need, spec_coarse;
+    bool spec_valid = false, spec_round1 = false;
+    uint32_t spec_tiles_x = 0, spec_tiles_y = 0;
+    DevBuf adm_pairs, adm_ballots, adm_counts;  // admission pass: compacted (key, index) pairs, per-wave ballots, per-workgroup counts
     DevBuf pack_masks;             // destination bit mask per record (gsx_shard_pack)
     DevBuf window, pack_window;    // per-tile depth-key windows [lo, hi): of the imported set / of the pack in flight
     bool has_window = false;
@@ -192,7 +198,7 @@ struct gsx_viewer {
     gsx_gaussian_edit sel_edit{0u, {0.0f, 1.0f, 1.0f}, 0.0f, 0.0f, 1.0f, 1.0f};
     void* ext_fb = nullptr;              // caller-owned framebuffer (multi-GPU: the RCCL gather target)
     uint64_t ext_fb_bytes = 0;
-    gsx_render_options options{1u, 16u, 131072u, 2u};
+    gsx_render_options options{1u, 16u, 131072u, 2u, 1u, 0.5f, 3u};
     bool timing = false;
     std::vector<PassTimer> timers;     // recorded, not yet read
     std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
@@ -255,6 +261,7 @@ static gsx_status ensure_fb(gsx_viewer* v) {
 static float4* fb_ptr(gsx_viewer* v) { return v->ext_fb ? static_cast<float4*>(v->ext_fb) : reinterpret_cast<float4*>(v->fb.p); }
 
 static gsx_status do_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys, bool cont = false);
+static gsx_status do_sort(gsx_viewer* v, Model* m);
 
 // Frames are enqueued without any host round trip; this is where the host catches up: wait for the
 // stream, mirror the per-model statistics, and if a depth slab needed more tile-pair capacity than was
@@ -276,6 +283,8 @@ static gsx_status finish_frame(gsx_viewer* v) {
             if (!m->stats_pending) continue;
             m->stats_pending = false;
             m->n_visible = m->h_counters->n_visible;
+            m->n_sorted = m->h_counters->n_sorted;
+            m->n_sorted2 = m->h_counters->n_sorted2;
             m->n_entries = m->h_counters->n_entries_total;
             m->counters_valid = true;
             if (m->binned) m->slabs_hint = m->h_counters->slabs_used;
@@ -291,6 +300,14 @@ static gsx_status finish_frame(gsx_viewer* v) {
         if (!redo) return GSX_OK;
         std::vector<const char*> keys;
         for (auto& k : v->last_keys) keys.push_back(k.c_str());
+        for (auto& k : v->last_keys) {  // a speculated frame is redone unspeculated: its depth order was consumed
+            Model* m = find_model(v, k.c_str());
+            if (m && m->spec_round1) {
+                m->spec_valid = false;
+                gsx_status st2 = do_sort(v, m);
+                if (st2) return st2;
+            }
+        }
         gsx_status st = do_render(v, keys.data(), (uint32_t)keys.size());
         if (st) return st;
     }
@@ -428,11 +445,30 @@ static gsx_status do_preprocess(gsx_viewer* v, Model* m) {
 static gsx_status do_sort(gsx_viewer* v, Model* m) {
     if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_sort('%s') before gsx_preprocess", m->key.c_str());
     const uint32_t n = (uint32_t)m->rec_n;
+    Counters* dc = m->counters.as<Counters>();
     {
         ScopedPass t(v, GSX_PASS_DEPTH_SORT);
-        RadixBuffers rb{m->rec().key, nullptr, nullptr, m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
-                        m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
-        HIPCHK(launch_radix_sort(v->stream, rb, n, nullptr, 32, true));
+        m->spec_round1 = false;
+        if (m->use_imported) {  // every imported record is visible: sort the keys as they lie
+            RadixBuffers rb{m->rec().key, nullptr, nullptr, m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
+                            m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
+            HIPCHK(launch_radix_sort(v->stream, rb, n, nullptr, 32, true));
+        } else {
+            // admission: compact the (key, index) pairs of the records that take part, then sort only those
+            const size_t nb = std::max<size_t>(admit_blocks(n), 1);
+            HIPCHK(m->adm_pairs.ensure(8 * std::max<size_t>(n, 1)));
+            HIPCHK(m->adm_ballots.ensure(8 * ((std::max<size_t>(n, 1) + 63) / 64)));
+            HIPCHK(m->adm_counts.ensure(4 * nb));
+            m->spec_round1 = v->options.progressive && v->options.speculative && m->spec_valid &&
+                             m->spec_tiles_x == m->fc.tiles_x && m->spec_tiles_y == m->fc.tiles_y;
+            WindowPyramid pyr{};
+            if (m->spec_round1) pyr = window_pyramid_layout(m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse.as<uint32_t>());
+            HIPCHK(launch_admit(v->stream, m->proj_rec(), n, nullptr, m->fc.tiles_x, nullptr, 0, pyr, nullptr, m->adm_ballots.as<unsigned long long>(), m->adm_counts.as<uint32_t>(), &dc->n_sorted,
+                                m->adm_pairs.as<uint2>()));
+            RadixBuffers rb{nullptr, nullptr, m->adm_pairs.as<uint2>(), m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
+                            m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
+            HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted, 32, false));
+        }
         m->sorted_idx = m->sv_out.as<uint32_t>();
         v->pass_launches[GSX_PASS_DEPTH_SORT] += n ? 4 : 0;
     }
@@ -488,19 +524,27 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
     const bool progressive = v->options.progressive != 0;
     uint32_t* done = progressive ? v->done_bits.as<uint32_t>() + 1 : nullptr;  // word 0 is the saturated-tile counter
     uint32_t* done_count = v->done_bits.as<uint32_t>();
+    const bool speculate = progressive && v->options.speculative && !m->use_imported;
+    if (progressive && m->stats_copy_inflight && hipEventQuery(m->stats_event) == hipSuccess) {
+        m->stats_copy_inflight = false;
+        m->slabs_hint = m->h_counters->slabs_used;
+        m->n_sorted = m->h_counters->n_sorted;
+    }
     std::vector<uint32_t> bounds;
-    plan_slabs(v->options, (uint32_t)m->rec_n, &bounds);
-    if (progressive) {
-        if (m->stats_copy_inflight && hipEventQuery(m->stats_event) == hipSuccess) {
-            m->stats_copy_inflight = false;
-            m->slabs_hint = m->h_counters->slabs_used;
-        }
-        merge_tail_slabs(&bounds, m->slabs_hint);
+    if (m->spec_round1 && m->n_sorted && m->n_sorted < m->rec_n) {
+        // the admitted set is a small front part of the model: plan the slabs on its last known size, and let the last
+        // one run to the record count (the kernels stride over what exists on the device, so that costs nothing)
+        plan_slabs(v->options, m->n_sorted, &bounds);
+        bounds.back() = (uint32_t)m->rec_n;
+    } else {
+        plan_slabs(v->options, (uint32_t)m->rec_n, &bounds);
+        if (progressive) merge_tail_slabs(&bounds, m->slabs_hint);
     }
     Counters* dc = m->counters.as<Counters>();
     const uint32_t row_lo = std::min(m->row_lo, m->fc.tiles_y), row_hi = std::min(m->row_hi, m->fc.tiles_y);
     const uint32_t owned_tiles = (row_hi > row_lo ? row_hi - row_lo : 0) * m->fc.tiles_x;
     const uint2* window = (m->use_imported && m->has_window) ? m->window.as<uint2>() : nullptr;
+    if (m->spec_round1) window = m->spec_win.as<uint2>();
     uint32_t* tile_sat = progressive ? done + row_words * m->fc.tiles_y : nullptr;  // [count | bitmap | saturation keys]
 
     if (m->tile_cap == 0) m->tile_cap = std::max<uint64_t>(1u << 20, 16 * m->rec_n);
@@ -521,27 +565,37 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
         if (sizeof(uint2) * (size_t)n_tiles > m->ranges.bytes) m->ranges_clean = false;
         HIPCHK(m->ranges.ensure(sizeof(uint2) * (size_t)n_tiles));
     }
-    // reset this model's per-frame totals (n_visible stays)
+    // reset this model's per-frame totals (n_visible and n_sorted stay)
     HIPCHK(hipMemsetAsync(&dc->n_entries, 0, sizeof(Counters) - offsetof(Counters, n_entries), v->stream));
+    const uint32_t* done_before = nullptr;
+    if (speculate) {
+        const size_t bm = 4 * (size_t)row_words * m->fc.tiles_y;
+        HIPCHK(m->spec_win.ensure(sizeof(uint2) * (size_t)n_tiles));
+        HIPCHK(m->spec_win2.ensure(sizeof(uint2) * (size_t)n_tiles));
+        if (carry) {  // nearer models already saturated some tiles: remember which, they say nothing about this model
+            HIPCHK(m->spec_done_before.ensure(bm));
+            HIPCHK(hipMemcpyAsync(m->spec_done_before.p, done, bm, hipMemcpyDeviceToDevice, v->stream));
+            done_before = m->spec_done_before.as<uint32_t>();
+        }
+    }
     const int bits = std::max<int>(1, (int)ceil_log2(n_tiles));
     // a single-slab front model keeps its complete tile lists for gsx_model_download_tile_lists
-    const bool clear_ranges = progressive && !(bounds.size() == 2 && !carry);
-    for (size_t sl = 0; sl + 1 < bounds.size(); ++sl) {
-        const uint32_t j0 = bounds[sl], j1 = bounds[sl + 1];
+    const bool clear_ranges = progressive && !(bounds.size() == 2 && !carry && !m->spec_round1);
+    // one depth slab [j0, j1) of the current depth order: bin -> tile sort -> ranges -> composite
+    auto run_slab = [&](uint32_t j0, uint32_t j1, bool later, const uint2* win, const uint32_t* d_n, uint32_t slab_index) -> gsx_status {
         // the very first slab of the frame sees no saturated tile: plain rectangle areas
-        const bool later = carry || sl > 0;
         const uint32_t* done_in = later ? done : nullptr;
         // a slab of S splats can produce at most S * n_tiles entries; size the sort launch by the smaller bound
         const uint32_t slab_cap = (uint32_t)std::min<uint64_t>(cap, (uint64_t)(j1 - j0) * std::min<uint64_t>(owned_tiles, 1u << 16));
         {
             ScopedPass t(v, GSX_PASS_BIN);
-            HIPCHK(launch_tile_counts(v->stream, j0, j1, &dc->n_visible, m->sorted_idx, m->rec(), m->srect.as<uint2>(),
+            HIPCHK(launch_tile_counts(v->stream, j0, j1, d_n, m->sorted_idx, m->rec(), m->srect.as<uint2>(),
                                       m->cnt.as<uint32_t>(), m->block_sums.as<uint32_t>(), dc, cap, row_lo, row_hi, done_in,
-                                      row_words, (progressive && later) ? done_count : nullptr, owned_tiles, (uint32_t)sl,
-                                      window, m->sk_out.as<uint32_t>(), m->fc.tiles_x));
+                                      row_words, (progressive && later) ? done_count : nullptr, owned_tiles, slab_index,
+                                      win, m->sk_out.as<uint32_t>(), m->fc.tiles_x));
             HIPCHK(launch_tile_emit(v->stream, j0, j1, m->sorted_idx, m->srect.as<uint2>(), m->cnt.as<uint32_t>(),
                                     m->block_sums.as<uint32_t>(), m->fc.tiles_x, m->tp_src.as<uint2>(), row_lo, row_hi,
-                                    done_in, row_words, &dc->n_visible, &dc->n_entries, cap, window, m->sk_out.as<uint32_t>()));
+                                    done_in, row_words, d_n, &dc->n_entries, cap, win, m->sk_out.as<uint32_t>()));
             v->pass_launches[GSX_PASS_BIN] += 1;
         }
         {
@@ -565,6 +619,39 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
             m->ranges_clean = clear_ranges;  // the compositor zeroed every range it consumed
             v->pass_launches[GSX_PASS_COMPOSITE] += 1;
         }
+        return GSX_OK;
+    };
+    gsx_status st = GSX_OK;
+    for (size_t sl = 0; sl + 1 < bounds.size(); ++sl)
+        if ((st = run_slab(bounds[sl], bounds[sl + 1], carry || sl > 0, window, &dc->n_sorted, (uint32_t)sl))) return st;
+    if (m->spec_round1) {
+        // verification on the device: tiles with a bounded window that are still open get, in one more round, exactly
+        // the records they were refused, composited behind what they hold.  Nothing to repair: the kernels fall through.
+        const uint32_t n = (uint32_t)m->rec_n;
+        {
+            ScopedPass t(v, GSX_PASS_DEPTH_SORT);
+            HIPCHK(m->spec_need.ensure(4 * (size_t)row_words * m->fc.tiles_y));
+            HIPCHK(launch_spec_verify(v->stream, m->spec_win.as<uint2>(), done, row_words, m->fc.tiles_x, m->fc.tiles_y,
+                                      m->spec_win2.as<uint2>(), m->spec_need.as<uint32_t>(), &dc->spec_need));
+            HIPCHK(launch_admit(v->stream, m->proj_rec(), n, m->spec_win2.as<uint2>(), m->fc.tiles_x, m->spec_need.as<uint32_t>(),
+                                row_words, WindowPyramid{}, &dc->spec_need,
+                                m->adm_ballots.as<unsigned long long>(), m->adm_counts.as<uint32_t>(), &dc->n_sorted2,
+                                m->adm_pairs.as<uint2>()));
+            RadixBuffers rb{nullptr, nullptr, m->adm_pairs.as<uint2>(), m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
+                            m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
+            HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted2, 32, false));
+        }
+        if ((st = run_slab(0, n, true, m->spec_win2.as<uint2>(), &dc->n_sorted2, (uint32_t)bounds.size()))) return st;
+    }
+    if (speculate) {  // this model's windows for its next frame
+        ScopedPass t(v, GSX_PASS_COMPOSITE);
+        HIPCHK(launch_spec_next(v->stream, tile_sat, done, done_before, row_words, m->fc.tiles_x, m->fc.tiles_y,
+                                v->options.spec_margin, v->options.spec_radius, m->spec_win.as<uint2>()));
+        HIPCHK(m->spec_coarse.ensure(4 * window_pyramid_words(m->fc.tiles_x, m->fc.tiles_y)));
+        HIPCHK(launch_window_pyramid(v->stream, m->spec_win.as<uint2>(), m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse.as<uint32_t>()));
+        m->spec_valid = true;
+        m->spec_tiles_x = m->fc.tiles_x;
+        m->spec_tiles_y = m->fc.tiles_y;
     }
     if (progressive && !m->stats_copy_inflight) {  // feed the next frames' slab plan without waiting
         if (!m->stats_event) HIPCHK(hipEventCreateWithFlags(&m->stats_event, hipEventDisableTiming));
@@ -574,7 +661,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
     }
     m->binned = true;
     m->stats_pending = true;
-    m->lists_complete = bounds.size() == 2 && !carry;
+    m->lists_complete = bounds.size() == 2 && !carry && !m->spec_round1;
     return GSX_OK;
 }
 
@@ -689,12 +776,17 @@ void gsx_render_options_default(gsx_render_options* o) {
     o->first_slab_divisor = 16;
     o->min_slab = 131072;
     o->growth = 2;
+    o->speculative = 1;
+    o->spec_margin = 0.5f;
+    o->spec_radius = 3;
 }
 
 gsx_status gsx_viewer_set_render_options(gsx_viewer* v, const gsx_render_options* o) {
     if (!v || !o) return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_set_render_options: null argument");
     if (o->first_slab_divisor == 0 || o->growth < 2 || o->min_slab == 0)
         return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_set_render_options: first_slab_divisor >= 1, growth >= 2, min_slab >= 1");
+    if (!(o->spec_margin >= 0.0f) || o->spec_radius > 16)
+        return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_set_render_options: spec_margin >= 0, spec_radius <= 16");
     v->options = *o;
     return GSX_OK;
 }
@@ -1012,6 +1104,11 @@ gsx_status gsx_model_frame_stats(gsx_viewer* v, const char* key, gsx_frame_stats
     out->n_gaussians = m->n;
     out->n_visible = m->n_visible;
     out->n_tile_entries = m->binned ? m->n_entries : 0;  // entries actually binned by the last gsx_render
+    out->n_sorted = m->n_sorted;
+    out->speculated = m->binned && m->spec_round1 ? 1u : 0u;
+    out->n_repair_tiles = out->speculated ? m->h_counters->spec_need : 0;
+    out->n_repair_sorted = out->speculated ? m->n_sorted2 : 0;
+    out->reserved = 0;
     return GSX_OK;
 }
 
@@ -1071,11 +1168,12 @@ gsx_status gsx_model_download_sorted(gsx_viewer* v, const char* key, uint32_t* i
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_download_sorted: no model '%s'", key ? key : "(null)");
     if (!m->sorted) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_sorted: model '%s' not sorted", key);
     if ((st = sync_counters(v))) return st;
-    if (out_n_visible) *out_n_visible = m->n_visible;
+    const uint32_t n_order = m->spec_round1 && m->binned ? m->n_sorted2 : m->n_sorted;  // a speculated frame leaves its repair order
+    if (out_n_visible) *out_n_visible = n_order;
     if (indices) {
-        if (capacity < m->n_visible) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_sorted: capacity %llu < n_visible %u", (unsigned long long)capacity, m->n_visible);
+        if (capacity < n_order) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_sorted: capacity %llu < %u sorted records", (unsigned long long)capacity, n_order);
         HIPCHK(hipStreamSynchronize(v->stream));
-        if (m->n_visible) HIPCHK(hipMemcpy(indices, m->sorted_idx, 4ull * m->n_visible, hipMemcpyDeviceToHost));
+        if (n_order) HIPCHK(hipMemcpy(indices, m->sorted_idx, 4ull * n_order, hipMemcpyDeviceToHost));
     }
     return GSX_OK;
 }
@@ -1431,8 +1529,8 @@ gsx_status gsx_shard_import(gsx_viewer* v, const char* key, const void* d_recv, 
     if ((st = ensure_import_capacity(m, n_records))) return st;
     HIPCHK(launch_import_records(v->stream, d_recv, (uint32_t)n_records, m->imp_rec()));
     // every imported record is visible by construction
-    HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&m->counters.as<Counters>()->n_visible), (int)(uint32_t)n_records, 1,
-                             v->stream));
+    HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&m->counters.as<Counters>()->n_visible), (int)(uint32_t)n_records, 2,
+                             v->stream));  // n_visible and n_sorted
     m->stats_pending = true;
     m->rec_n = n_records;
     m->use_imported = true;

@@ -99,11 +99,14 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
 // Device-resident per-model frame statistics; the host mirrors them lazily (no sync inside a frame).
 struct SlabStats {
     uint32_t n_visible;        // N_vis (projection pass / import)
+    uint32_t n_sorted;         // records in the depth order of this frame (admission pass / import); <= n_visible
     uint32_t n_entries;        // D of the slab being processed, clamped to the pair-buffer capacity
     uint32_t n_entries_total;  // sum of slab D over the frame
     uint32_t overflow;         // a slab needed more pair capacity than allocated: frame must be redone
     uint32_t max_needed;       // largest slab D seen when overflowing
     uint32_t slabs_used;       // number of slabs that still found a live tile (progressive mode)
+    uint32_t n_sorted2;        // speculation: records admitted in the repair round
+    uint32_t spec_need;        // speculation: tiles that needed the repair round
 };
 
 // Tile binning.
@@ -135,6 +138,35 @@ hipError_t launch_query(hipStream_t s, uint32_t n, const Records& rec, const gsx
                         uint32_t tex_h, const FrameConsts& f, uint32_t* flags, gsx_query_hit* hits, uint32_t* hit_count,
                         uint32_t hit_capacity);
 hipError_t launch_selection_op(hipStream_t s, uint32_t n_words, uint32_t op, const uint32_t* flags, uint32_t* selection);
+
+// Max-pyramid over the per-tile window ends (launch_window_pyramid): level l holds, per cell of 2^l x 2^l tiles, the
+// largest end.  A rectangle of extent <= 2^l tiles lies under at most 2x2 cells of level l, so four loads bound the
+// largest window end under it from above: a conservative admission test (a hierarchical-Z test on depth keys).
+struct WindowPyramid {
+    const uint32_t* data;  // nullptr: no pyramid
+    uint32_t off[9];       // first element of level l
+    uint32_t wx[9], wy[9]; // cells per row / column of level l
+    uint32_t levels;       // level (levels - 1) is a single cell
+};
+WindowPyramid window_pyramid_layout(uint32_t tiles_x, uint32_t tiles_y, const uint32_t* data);  // total words: off[levels]... see .hip
+size_t window_pyramid_words(uint32_t tiles_x, uint32_t tiles_y);
+hipError_t launch_window_pyramid(hipStream_t s, const uint2* window, uint32_t tiles_x, uint32_t tiles_y, uint32_t* data);
+
+// Admission pass (kernels_admit.hip): compacts the (key, index) pairs of the records the depth sort takes, ascending
+// index; window == nullptr admits every visible record.  *d_total = number of pairs.  d_skip (nullable): when it
+// points at 0 nothing is admitted (verification round with nothing to repair).  gate (nullable): tile bitmap; records
+// whose rectangle holds no gated tile are refused before the windows are looked at.  pyramid (data != nullptr): the
+// windows are [0, hi) and admission is CONSERVATIVE — every record some tile admits is admitted, plus a few more; the
+// binning applies the exact per-tile windows, so the surplus only rides through the depth sort.
+size_t admit_blocks(uint64_t n);
+hipError_t launch_admit(hipStream_t s, const Records& rec, uint32_t n, const uint2* window, uint32_t tiles_x,
+                        const uint32_t* gate, uint32_t row_words, const WindowPyramid& pyramid, const uint32_t* d_skip, unsigned long long* ballots, uint32_t* counts, uint32_t* d_total, uint2* pairs);
+
+// Temporal occlusion speculation (kernels_spec.hip): verification of this frame's windows, windows of the next frame.
+hipError_t launch_spec_verify(hipStream_t s, const uint2* win1, const uint32_t* done, uint32_t row_words, uint32_t tiles_x,
+                              uint32_t tiles_y, uint2* win2, uint32_t* need_bits, uint32_t* d_need);
+hipError_t launch_spec_next(hipStream_t s, const uint32_t* tile_sat, const uint32_t* done, const uint32_t* done_before,
+                            uint32_t row_words, uint32_t tiles_x, uint32_t tiles_y, float margin, uint32_t radius, uint2* win_next);
 
 // Multi-GPU exchange support (kernels_shard.hip).
 hipError_t launch_rowscan(hipStream_t s, uint32_t* table, uint32_t nrows, uint32_t nblocks, uint32_t* totals);

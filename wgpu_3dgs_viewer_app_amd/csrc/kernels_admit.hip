@@ -1,0 +1,92 @@
+// kernels_admit.hip — admission pass for gfx950: compacts the (depth key, Gaussian index) pairs of the records that
+// take part in this frame's depth sort, in ascending index order (so the stable sort breaks depth ties by index).
+//
+// No reference counterpart: the reference sorts every surviving Gaussian (radix_sorter.sort, src/tab/scene.rs:865-869).
+// Without windows every visible record is admitted, and the sort then moves N_vis pairs instead of N keys.  With
+// per-tile depth-key windows (temporal occlusion speculation, gsx_api.cpp) a record is admitted only if some tile of
+// its rectangle still takes it; the rest stay in the record planes, untouched, for the verification round.
+// Order-preserving stream compaction: per-wave ballots + per-workgroup counts, a row scan, then a scatter.
+#include "gsx_internal.h"
+#include "window_scan.h"
+
+namespace gsx {
+
+constexpr int kAdmitThreads = 256;
+constexpr int kAdmitRounds = 16;
+constexpr int kAdmitTile = kAdmitThreads * kAdmitRounds;  // 4096 records per workgroup
+constexpr int kAdmitWaveChunk = 64 * kAdmitRounds;
+
+size_t admit_blocks(uint64_t n) { return (size_t)((n + kAdmitTile - 1) / kAdmitTile); }
+
+// ballots[e / 64] = admitted lanes of the 64 records e..e+63; counts[workgroup] = admitted records
+__global__ __launch_bounds__(kAdmitThreads) void k_admit_count(const uint32_t* __restrict__ key, const float4* __restrict__ rec_a,
+                                                                uint32_t n, const uint2* __restrict__ window, uint32_t tiles_x,
+                                                                const uint32_t* __restrict__ gate, uint32_t row_words,
+                                                                const WindowPyramid pyr,
+                                                                const uint32_t* __restrict__ d_skip,
+                                                                unsigned long long* __restrict__ ballots,
+                                                                uint32_t* __restrict__ counts) {
+    __shared__ uint32_t wcnt[kAdmitThreads / 64];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const bool skip = d_skip && *d_skip == 0;  // verification round with nothing to repair: admit nothing
+    const uint32_t base = blockIdx.x * kAdmitTile + wave * kAdmitWaveChunk;
+    uint32_t c = 0;
+    for (int r = 0; r < kAdmitRounds; ++r) {
+        const uint32_t e = base + r * 64 + lane;
+        uint32_t kk = kCulledKey, rx = 0, ry = 0;
+        if (!skip && e < n) kk = key[e];
+        if ((window || pyr.data) && kk != kCulledKey) {
+            const float4 a = rec_a[e];
+            rx = __float_as_uint(a.z);
+            ry = __float_as_uint(a.w);
+        }
+        bool adm;
+        if (pyr.data) adm = kk != kCulledKey && pyramid_admits(pyr, kk, rx, ry);
+        else if (window) adm = wave_dest_mask(window, tiles_x, kk, rx, ry, 0x10000u, 1u, gate, row_words) & 1ull;
+        else adm = kk != kCulledKey;
+        const unsigned long long bal = __ballot(adm);
+        if (lane == 0 && base + r * 64 < n) ballots[(base + r * 64) >> 6] = bal;
+        c += (uint32_t)__popcll(bal);
+    }
+    if (lane == 0) wcnt[wave] = c;
+    __syncthreads();
+    if (tid == 0) counts[blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+}
+
+// counts were scanned exclusively in place; pairs[offset ..] = (key, index) of the admitted records of the workgroup
+__global__ __launch_bounds__(kAdmitThreads) void k_admit_scatter(const uint32_t* __restrict__ key, uint32_t n,
+                                                                  const unsigned long long* __restrict__ ballots,
+                                                                  const uint32_t* __restrict__ offsets,
+                                                                  uint2* __restrict__ pairs) {
+    __shared__ uint32_t wcnt[kAdmitThreads / 64];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t base = blockIdx.x * kAdmitTile + wave * kAdmitWaveChunk;
+    uint32_t c = 0;
+    for (int r = 0; r < kAdmitRounds; ++r)
+        if (base + r * 64 < n) c += (uint32_t)__popcll(ballots[(base + r * 64) >> 6]);
+    if (lane == 0) wcnt[wave] = c;
+    __syncthreads();
+    uint32_t o = offsets[blockIdx.x];
+    for (uint32_t w = 0; w < wave; ++w) o += wcnt[w];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int r = 0; r < kAdmitRounds; ++r) {
+        const uint32_t e0 = base + r * 64;
+        if (e0 >= n) break;
+        const unsigned long long bal = ballots[e0 >> 6];
+        if ((bal >> lane) & 1ull) pairs[o + (uint32_t)__popcll(bal & lt)] = make_uint2(key[e0 + lane], e0 + lane);
+        o += (uint32_t)__popcll(bal);
+    }
+}
+
+hipError_t launch_admit(hipStream_t s, const Records& rec, uint32_t n, const uint2* window, uint32_t tiles_x,
+                        const uint32_t* gate, uint32_t row_words, const WindowPyramid& pyramid, const uint32_t* d_skip, unsigned long long* ballots, uint32_t* counts, uint32_t* d_total, uint2* pairs) {
+    const uint32_t nb = (uint32_t)admit_blocks(n);
+    if (!nb) return hipMemsetAsync(d_total, 0, 4, s);
+    hipLaunchKernelGGL(k_admit_count, dim3(nb), dim3(kAdmitThreads), 0, s, rec.key, rec.a, n, window, tiles_x, gate, row_words, pyramid, d_skip, ballots, counts);
+    hipError_t e = launch_rowscan(s, counts, 1, nb, d_total);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_admit_scatter, dim3(nb), dim3(kAdmitThreads), 0, s, rec.key, n, ballots, counts, pairs);
+    return hipGetLastError();
+}
+
+}  // namespace gsx

@@ -251,9 +251,15 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_emit(uint32_t jbase, uint3
         r = srect[j - jbase];
         if (tw.win) key = tw.sorted_keys[j];
     }
-    if (mine && mine <= kCoopThreshold) emit_rect(tpairs, o, capacity, idx, r, tiles_x, row_lo, row_hi, done, row_words, tw.win, key);
+    // a lane walks its own rectangle only if that is short; large rectangles (even with few takers left) go to the wave
+    uint32_t area = 0;
+    if (mine) {
+        const uint32_t ya = max(r.y & 0xFFFFu, row_lo), yb = min(r.y >> 16, row_hi);
+        area = ((r.x >> 16) - (r.x & 0xFFFFu)) * (yb > ya ? yb - ya : 0u);
+    }
+    if (mine && area <= kCoopThreshold) emit_rect(tpairs, o, capacity, idx, r, tiles_x, row_lo, row_hi, done, row_words, tw.win, key);
     // large splats: one at a time, all 64 lanes
-    unsigned long long big = __ballot(mine > kCoopThreshold);
+    unsigned long long big = __ballot(area > kCoopThreshold);
     while (big) {
         const int src = __ffsll((long long)big) - 1;
         big &= big - 1;
@@ -271,33 +277,28 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_emit(uint32_t jbase, uint3
                 if (bo + k < capacity) tpairs[bo + k] = make_uint2(ty * tiles_x + tx, bidx);
             }
         } else {
-            // with a done bitmap the slots are not a closed form: lanes take whole rows, offsets by a wave scan
-            uint32_t row_o = bo;
-            const uint32_t ylast = min(y1, row_hi);
-            for (uint32_t ty0 = max(y0, row_lo); ty0 < ylast; ty0 += 64) {
-                const uint32_t ty = ty0 + lane;
-                uint32_t live = 0;
-                if (ty < ylast)
-                    live = tw.win ? window_tiles_in_row(done, row_words, tw.win, tiles_x, ty, x0, x1, bkey)
-                                  : live_tiles_in_row(done, row_words, ty, x0, x1);
-                uint32_t incl = live;
-#pragma unroll
-                for (int s = 1; s < 64; s <<= 1) {
-                    uint32_t y = __shfl_up(incl, s, 64);
-                    if (lane >= (uint32_t)s) incl += y;
+            // with saturated tiles / windows the slots are not a closed form: lanes stride over the rectangle's tiles,
+            // a ballot gives every taker its slot (the order of one splat's entries is irrelevant: the tile sort keys
+            // on the tile id and each (tile, splat) pair is unique)
+            const uint32_t first = max(y0, row_lo), rows = min(y1, row_hi) - first, total = w * rows;
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            uint32_t base = bo;
+            for (uint32_t k0 = 0; k0 < total; k0 += 64) {
+                const uint32_t k = k0 + lane;
+                bool take = false;
+                uint32_t tx = 0, ty = 0;
+                if (k < total) {
+                    ty = first + k / w;
+                    tx = x0 + k % w;
+                    take = tw.win ? tile_takes(done, row_words, tw.win, tiles_x, tx, ty, bkey)
+                                  : !((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u);
                 }
-                uint32_t oo = row_o + incl - live;
-                if (ty < ylast)
-                    for (uint32_t tx = x0; tx < x1; ++tx) {
-                        if (tw.win) {
-                            if (!tile_takes(done, row_words, tw.win, tiles_x, tx, ty, bkey)) continue;
-                        } else if ((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u) {
-                            continue;
-                        }
-                        if (oo < capacity) tpairs[oo] = make_uint2(ty * tiles_x + tx, bidx);
-                        ++oo;
-                    }
-                row_o += __shfl(incl, 63, 64);
+                const unsigned long long bal = __ballot(take);
+                if (take) {
+                    const uint32_t oo = base + (uint32_t)__popcll(bal & lt);
+                    if (oo < capacity) tpairs[oo] = make_uint2(ty * tiles_x + tx, bidx);
+                }
+                base += (uint32_t)__popcll(bal);
             }
         }
     }

@@ -16,6 +16,7 @@
 // index inside every destination group), which keeps the depth-tie order = global Gaussian index.
 // Record = 48 bytes: {mean.x, mean.y, rect.x, rect.y | conic a, b, c, opacity | r, g, b, depth}.
 #include "gsx_internal.h"
+#include "window_scan.h"
 
 namespace gsx {
 
@@ -24,35 +25,8 @@ constexpr int kPackRounds = 16;
 constexpr int kPackTile = kPackThreads * kPackRounds;  // 4096 records per workgroup
 constexpr int kPackWaveChunk = 64 * kPackRounds;
 constexpr int kMaxWorld = 64;
-constexpr uint32_t kPackCoop = 32;  // rectangles with more tiles are tested against the windows by the whole wave
 
 size_t pack_blocks(uint64_t n) { return (size_t)((n + kPackTile - 1) / kPackTile); }
-
-// destinations of a record (key, tile rect): bit g set iff band g (tile rows [g*rpr, (g+1)*rpr)) holds a tile of the
-// rectangle whose window contains the key (window == nullptr: every touched band)
-__device__ inline unsigned long long dest_mask(const uint2* __restrict__ window, uint32_t tiles_x, uint32_t key,
-                                               uint32_t rx, uint32_t ry, uint32_t rpr, uint32_t world) {
-    const uint32_t x0 = rx & 0xFFFFu, x1 = rx >> 16, y0 = ry & 0xFFFFu, y1 = ry >> 16;
-    unsigned long long m = 0;
-    if (y0 >= y1 || x0 >= x1) return 0;
-    const uint32_t g0 = y0 / rpr, g1 = min((y1 - 1u) / rpr, world - 1u);
-    for (uint32_t g = g0; g <= g1; ++g) {
-        bool hit = window == nullptr;
-        if (!hit) {
-            const uint32_t ya = max(y0, g * rpr), yb = min(y1, (g + 1u) * rpr);
-            for (uint32_t ty = ya; ty < yb && !hit; ++ty)
-                for (uint32_t tx = x0; tx < x1; ++tx) {
-                    const uint2 w = window[ty * tiles_x + tx];
-                    if (key >= w.x && key < w.y) {
-                        hit = true;
-                        break;
-                    }
-                }
-        }
-        if (hit) m |= 1ull << g;
-    }
-    return m;
-}
 
 // per record: destination mask (stored for the scatter pass); per workgroup and destination: record count
 __global__ __launch_bounds__(kPackThreads) void k_pack_count(const uint32_t* __restrict__ key,
@@ -70,41 +44,13 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_count(const uint32_t* __r
         uint32_t e = base + r * 64 + lane;
         uint32_t kk = kCulledKey;
         if (e < n) kk = key[e];
-        unsigned long long m = 0;
-        uint32_t rx = 0, ry = 0, area = 0;
+        uint32_t rx = 0, ry = 0;
         if (kk != kCulledKey) {
             const float4 a = rec_a[e];
             rx = __float_as_uint(a.z);
             ry = __float_as_uint(a.w);
-            area = ((rx >> 16) - (rx & 0xFFFFu)) * ((ry >> 16) - (ry & 0xFFFFu));
-            if (!window || area <= kPackCoop) m = dest_mask(window, tiles_x, kk, rx, ry, rpr, world);
         }
-        if (window) {
-            // large rectangles (mostly hidden background splats that no tile admits): the whole wave scans the tiles
-            unsigned long long big = __ballot(area > kPackCoop);
-            while (big) {
-                const int src = __ffsll((long long)big) - 1;
-                big &= big - 1;
-                const uint32_t brx = __shfl(rx, src, 64), bry = __shfl(ry, src, 64), bkey = __shfl(kk, src, 64);
-                const uint32_t total = __shfl(area, src, 64);
-                const uint32_t x0 = brx & 0xFFFFu, w = (brx >> 16) - x0, y0 = bry & 0xFFFFu;
-                uint32_t lo = 0, hi = 0;  // destination bits 0..31 / 32..63
-                for (uint32_t k = lane; k < total; k += 64) {
-                    const uint32_t ty = y0 + k / w;
-                    const uint2 ww = window[ty * tiles_x + x0 + k % w];
-                    if (bkey >= ww.x && bkey < ww.y) {
-                        const uint32_t g = min(ty / rpr, world - 1u);
-                        if (g < 32u) lo |= 1u << g; else hi |= 1u << (g - 32u);
-                    }
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    lo |= __shfl_xor(lo, o, 64);
-                    hi |= __shfl_xor(hi, o, 64);
-                }
-                if ((int)lane == src) m = ((unsigned long long)hi << 32) | lo;
-            }
-        }
+        const unsigned long long m = wave_dest_mask(window, tiles_x, kk, rx, ry, rpr, world);
         if (e < n) masks[e] = m;
         for (uint32_t g = 0; g < world; ++g) {
             unsigned long long bal = __ballot((m >> g) & 1ull);

@@ -1,0 +1,126 @@
+// kernels_spec.hip — temporal occlusion speculation on one GPU (gfx950): the device-side policy kernels.
+//
+// No reference counterpart (the reference sorts and draws every surviving Gaussian, src/tab/scene.rs:865-869,
+// 2302-2314).  An opaque scene hides most visible splats, and which ones barely changes between two frames.  Every
+// 16x16 tile therefore carries a depth-key window [0, hi): hi = (1 + margin) x the deepest depth at which the tile's
+// (2 radius + 1)^2 neighbourhood saturated in the model's previous frame, unbounded where a neighbour stayed open.  Only
+// records some tile admits enter the depth sort and the binning (kernels_admit.hip, kernels_bin.hip).  After
+// compositing, k_spec_verify finds the tiles that had a bounded window and are still open; a second round gives
+// exactly those tiles the records they were refused, [hi, inf), composited behind — so every tile always blends a
+// gap-free depth prefix and the frame is bit-identical to the unspeculated one.  Everything stays on the device: no
+// host round trip, the second round's kernels fall through when nothing needs repair.
+#include "gsx_internal.h"
+
+namespace gsx {
+
+constexpr uint32_t kKeyAll = 0xFFFFFFFFu;
+
+// need[t] = bounded window && still open  ->  win2[t] = [hi, inf) for those tiles, [0, 0) for the rest; *d_need = count
+__global__ __launch_bounds__(256) void k_spec_verify(const uint2* __restrict__ win1, const uint32_t* __restrict__ done,
+                                                      uint32_t row_words, uint32_t tiles_x, uint32_t n_tiles,
+                                                      uint2* __restrict__ win2, uint32_t* __restrict__ need_bits,
+                                                      uint32_t* __restrict__ d_need) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    bool need = false;
+    if (t < n_tiles) {
+        const uint32_t tx = t % tiles_x, ty = t / tiles_x;
+        const uint2 w = win1[t];
+        need = w.y != kKeyAll && !((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u);
+        win2[t] = need ? make_uint2(w.y, kKeyAll) : make_uint2(0u, 0u);
+        if (need) atomicOr(&need_bits[ty * row_words + (tx >> 5)], 1u << (tx & 31u));  // rare: a handful of tiles per frame
+    }
+    const unsigned long long bal = __ballot(need);
+    if ((threadIdx.x & 63u) == 0 && bal) atomicAdd(d_need, (uint32_t)__popcll(bal));
+}
+
+// the model's windows for its next frame.  A tile that was saturated before this model was composited (done_before,
+// nearer models) says nothing about this model's depths; a tile still open afterwards makes its neighbourhood unbounded.
+__global__ __launch_bounds__(256) void k_spec_next(const uint32_t* __restrict__ tile_sat, const uint32_t* __restrict__ done,
+                                                    const uint32_t* __restrict__ done_before, uint32_t row_words,
+                                                    uint32_t tiles_x, uint32_t tiles_y, float gain, int radius,
+                                                    uint2* __restrict__ win_next) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= tiles_x * tiles_y) return;
+    const int tx = (int)(t % tiles_x), ty = (int)(t / tiles_x);
+    float deepest = 0.0f;
+    bool open = false;
+    for (int y = max(ty - radius, 0); y <= min(ty + radius, (int)tiles_y - 1); ++y)
+        for (int x = max(tx - radius, 0); x <= min(tx + radius, (int)tiles_x - 1); ++x) {
+            const uint32_t w = (uint32_t)y * row_words + ((uint32_t)x >> 5), b = (uint32_t)x & 31u;
+            if (!((done[w] >> b) & 1u)) {
+                open = true;
+            } else if (!(done_before && ((done_before[w] >> b) & 1u))) {
+                deepest = fmaxf(deepest, __uint_as_float(tile_sat[(uint32_t)y * tiles_x + (uint32_t)x]));
+            }
+        }
+    uint32_t hi = kKeyAll;
+    if (!open) {
+        const float lim = deepest * gain;
+        hi = (lim < 3.0e38f) ? max(__float_as_uint(lim), 1u) : kKeyAll;
+    }
+    win_next[t] = make_uint2(0u, hi);
+}
+
+WindowPyramid window_pyramid_layout(uint32_t tiles_x, uint32_t tiles_y, const uint32_t* data) {
+    WindowPyramid p{};
+    p.data = data;
+    uint32_t wx = tiles_x, wy = tiles_y, off = 0, l = 0;
+    for (;;) {
+        p.off[l] = off;
+        p.wx[l] = wx;
+        p.wy[l] = wy;
+        off += wx * wy;
+        ++l;
+        if ((wx == 1 && wy == 1) || l == 9) break;
+        wx = (wx + 1) / 2;
+        wy = (wy + 1) / 2;
+    }
+    p.levels = l;
+    return p;
+}
+
+size_t window_pyramid_words(uint32_t tiles_x, uint32_t tiles_y) {
+    const WindowPyramid p = window_pyramid_layout(tiles_x, tiles_y, nullptr);
+    return (size_t)p.off[p.levels - 1] + (size_t)p.wx[p.levels - 1] * p.wy[p.levels - 1];
+}
+
+// one workgroup builds every level (11 k words at 1080p): level 0 = the window ends, level l = 2x2 max of level l-1
+__global__ __launch_bounds__(1024) void k_window_pyramid(const uint2* __restrict__ window, WindowPyramid p, uint32_t* __restrict__ data) {
+    for (uint32_t i = threadIdx.x; i < p.wx[0] * p.wy[0]; i += 1024) data[i] = window[i].y;
+    for (uint32_t l = 1; l < p.levels; ++l) {
+        __syncthreads();
+        const uint32_t wx = p.wx[l], wy = p.wy[l], px = p.wx[l - 1], py = p.wy[l - 1];
+        const uint32_t* src = data + p.off[l - 1];
+        uint32_t* dst = data + p.off[l];
+        for (uint32_t i = threadIdx.x; i < wx * wy; i += 1024) {
+            const uint32_t x = 2u * (i % wx), y = 2u * (i / wx), x1 = min(x + 1u, px - 1u), y1 = min(y + 1u, py - 1u);
+            dst[i] = max(max(src[y * px + x], src[y * px + x1]), max(src[y1 * px + x], src[y1 * px + x1]));
+        }
+    }
+}
+
+hipError_t launch_window_pyramid(hipStream_t s, const uint2* window, uint32_t tiles_x, uint32_t tiles_y, uint32_t* data) {
+    hipLaunchKernelGGL(k_window_pyramid, dim3(1), dim3(1024), 0, s, window, window_pyramid_layout(tiles_x, tiles_y, data), data);
+    return hipGetLastError();
+}
+
+hipError_t launch_spec_verify(hipStream_t s, const uint2* win1, const uint32_t* done, uint32_t row_words, uint32_t tiles_x,
+                              uint32_t tiles_y, uint2* win2, uint32_t* need_bits, uint32_t* d_need) {
+    // *d_need is zero here (the frame's counters are reset before the first slab)
+    hipError_t e = hipMemsetAsync(need_bits, 0, 4 * (size_t)row_words * tiles_y, s);
+    if (e != hipSuccess) return e;
+    const uint32_t n_tiles = tiles_x * tiles_y;
+    hipLaunchKernelGGL(k_spec_verify, dim3((n_tiles + 255) / 256), dim3(256), 0, s, win1, done, row_words, tiles_x, n_tiles, win2,
+                       need_bits, d_need);
+    return hipGetLastError();
+}
+
+hipError_t launch_spec_next(hipStream_t s, const uint32_t* tile_sat, const uint32_t* done, const uint32_t* done_before,
+                            uint32_t row_words, uint32_t tiles_x, uint32_t tiles_y, float margin, uint32_t radius, uint2* win_next) {
+    const uint32_t n_tiles = tiles_x * tiles_y;
+    hipLaunchKernelGGL(k_spec_next, dim3((n_tiles + 255) / 256), dim3(256), 0, s, tile_sat, done, done_before, row_words, tiles_x,
+                       tiles_y, 1.0f + margin, (int)radius, win_next);
+    return hipGetLastError();
+}
+
+}  // namespace gsx

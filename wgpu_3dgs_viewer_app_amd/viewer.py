@@ -353,7 +353,7 @@ class MultiModelViewer:
         for k, val in kw.items():
             if not hasattr(o, k):
                 raise KeyError(k)
-            setattr(o, k, int(val))
+            setattr(o, k, float(val) if k == "spec_margin" else int(val))
         _lib.check(self._L.gsx_viewer_set_render_options(self._h, C.byref(o)))
 
     # -- frame execution --
@@ -391,7 +391,9 @@ class MultiModelViewer:
     def frame_stats(self, key: str) -> dict:
         st = _lib.FrameStats()
         _lib.check(self._L.gsx_model_frame_stats(self._h, key.encode(), C.byref(st)))
-        return dict(n_gaussians=int(st.n_gaussians), n_visible=int(st.n_visible), n_tile_entries=int(st.n_tile_entries))
+        return dict(n_gaussians=int(st.n_gaussians), n_visible=int(st.n_visible), n_tile_entries=int(st.n_tile_entries),
+                    n_sorted=int(st.n_sorted), n_repair_tiles=int(st.n_repair_tiles), n_repair_sorted=int(st.n_repair_sorted),
+                    speculated=bool(st.speculated))
 
     def download_projection(self, key: str) -> dict:
         n = self.models[key].gaussian_buffers.gaussians_buffer.len()
