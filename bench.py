@@ -37,6 +37,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="Gaussians in the CPU baseline sample")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded exchange path even at N=1")
+    ap.add_argument("--render-options", default="", help="gsx_render_options overrides, e.g. speculative=0,min_slab=1000000 (experiments)")
     ap.add_argument("--host-profile", action="store_true", help="print host wall time per exchange-protocol section (adds syncs; debug)")
     ap.add_argument("--pod", default="single/single", help="pod storage sh/cov3d: single|half|norm8|none / single|half "
                     "(reference default is norm8/half; the headline metric is quoted on the f32 pod)")
@@ -100,6 +101,9 @@ def main():
     sh_kind = {"single": 0, "half": 1, "norm8": 2, "none": 3}[args.pod.split("/")[0]]
     cov_kind = {"single": 0, "half": 1}[args.pod.split("/")[1]]
     renderer = parallel.ShardedViewer(device=local_rank, world=world, rank=rank, use_dist=use_dist, sh=sh_kind, cov3d=cov_kind)
+    if args.render_options:
+        renderer.stages.viewer.set_render_options(**{k: float(x) if "." in x else int(x) for k, x in
+                                                     (kv.split("=") for kv in args.render_options.split(","))})
     t0 = time.perf_counter()
     renderer.load_shard(g, start, n)
     renderer.poll()

@@ -94,7 +94,7 @@ typedef struct gsx_render_options {
     uint32_t min_slab;           /* models with N_vis <= min_slab use one slab; default 131072 */
     uint32_t growth;             /* default 2 */
     uint32_t speculative;        /* default 1 */
-    float spec_margin;           /* default 0.5 */
+    float spec_margin;           /* default 0.25 */
     uint32_t spec_radius;        /* default 3 (tiles) */
 } gsx_render_options;
 

@@ -198,7 +198,7 @@ struct gsx_viewer {
     gsx_gaussian_edit sel_edit{0u, {0.0f, 1.0f, 1.0f}, 0.0f, 0.0f, 1.0f, 1.0f};
     void* ext_fb = nullptr;              // caller-owned framebuffer (multi-GPU: the RCCL gather target)
     uint64_t ext_fb_bytes = 0;
-    gsx_render_options options{1u, 16u, 131072u, 2u, 1u, 0.5f, 3u};
+    gsx_render_options options{1u, 16u, 131072u, 2u, 1u, 0.25f, 3u};
     bool timing = false;
     std::vector<PassTimer> timers;     // recorded, not yet read
     std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
@@ -261,7 +261,7 @@ static gsx_status ensure_fb(gsx_viewer* v) {
 static float4* fb_ptr(gsx_viewer* v) { return v->ext_fb ? static_cast<float4*>(v->ext_fb) : reinterpret_cast<float4*>(v->fb.p); }
 
 static gsx_status do_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys, bool cont = false);
-static gsx_status do_sort(gsx_viewer* v, Model* m);
+static gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full = false);
 
 // Frames are enqueued without any host round trip; this is where the host catches up: wait for the
 // stream, mirror the per-model statistics, and if a depth slab needed more tile-pair capacity than was
@@ -304,7 +304,7 @@ static gsx_status finish_frame(gsx_viewer* v) {
             Model* m = find_model(v, k.c_str());
             if (m && m->spec_round1) {
                 m->spec_valid = false;
-                gsx_status st2 = do_sort(v, m);
+                gsx_status st2 = do_sort(v, m, true);
                 if (st2) return st2;
             }
         }
@@ -410,9 +410,19 @@ static gsx_status do_preprocess(gsx_viewer* v, Model* m) {
         m->has_edits = true;
         pod.mask = m->keep.as<uint32_t>();
     }
+    // admission is decided inside the projection kernel: every visible Gaussian, or — when this model has windows from
+    // its previous frame — the conservative max-pyramid test of the temporal occlusion speculation
+    m->spec_round1 = v->options.progressive && v->options.speculative && m->spec_valid && m->spec_tiles_x == m->fc.tiles_x &&
+                     m->spec_tiles_y == m->fc.tiles_y;
+    ProjectAdmission adm{};
+    HIPCHK(m->adm_ballots.ensure(8 * ((std::max<size_t>(m->n, 1) + 63) / 64 + 4)));
+    HIPCHK(m->adm_counts.ensure(4 * std::max<size_t>(std::max(admit_blocks(m->n), (size_t)(m->n + 255) / 256), 1)));
+    if (m->spec_round1) adm.pyramid = window_pyramid_layout(m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse.as<uint32_t>());
+    adm.ballots = m->adm_ballots.as<unsigned long long>();
+    adm.block_counts = m->adm_counts.as<uint32_t>();
     {
         ScopedPass t(v, GSX_PASS_PROJECT);  // brackets the projection kernel alone (bench.py's roofline kernel)
-        HIPCHK(launch_project(v->stream, m->fc, n32, pod, m->proj_rec(), m->block_vis.as<uint32_t>()));
+        HIPCHK(launch_project(v->stream, m->fc, n32, pod, m->proj_rec(), m->block_vis.as<uint32_t>(), adm));
         v->pass_launches[GSX_PASS_PROJECT] += m->n ? 1 : 0;
     }
     HIPCHK(launch_sum_counts(v->stream, m->block_vis.as<uint32_t>(), n32, &m->counters.as<Counters>()->n_visible));
@@ -442,29 +452,30 @@ static gsx_status do_preprocess(gsx_viewer* v, Model* m) {
     return GSX_OK;
 }
 
-static gsx_status do_sort(gsx_viewer* v, Model* m) {
+// force_full: ignore the admission the projection pass made (a speculated frame being redone) and sort every visible record
+static gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
     if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_sort('%s') before gsx_preprocess", m->key.c_str());
     const uint32_t n = (uint32_t)m->rec_n;
     Counters* dc = m->counters.as<Counters>();
     {
         ScopedPass t(v, GSX_PASS_DEPTH_SORT);
-        m->spec_round1 = false;
         if (m->use_imported) {  // every imported record is visible: sort the keys as they lie
+            m->spec_round1 = false;
             RadixBuffers rb{m->rec().key, nullptr, nullptr, m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
                             m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
             HIPCHK(launch_radix_sort(v->stream, rb, n, nullptr, 32, true));
         } else {
-            // admission: compact the (key, index) pairs of the records that take part, then sort only those
-            const size_t nb = std::max<size_t>(admit_blocks(n), 1);
+            // compact the (key, index) pairs the projection pass admitted, then sort only those
             HIPCHK(m->adm_pairs.ensure(8 * std::max<size_t>(n, 1)));
-            HIPCHK(m->adm_ballots.ensure(8 * ((std::max<size_t>(n, 1) + 63) / 64)));
-            HIPCHK(m->adm_counts.ensure(4 * nb));
-            m->spec_round1 = v->options.progressive && v->options.speculative && m->spec_valid &&
-                             m->spec_tiles_x == m->fc.tiles_x && m->spec_tiles_y == m->fc.tiles_y;
-            WindowPyramid pyr{};
-            if (m->spec_round1) pyr = window_pyramid_layout(m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse.as<uint32_t>());
-            HIPCHK(launch_admit(v->stream, m->proj_rec(), n, nullptr, m->fc.tiles_x, nullptr, 0, pyr, nullptr, m->adm_ballots.as<unsigned long long>(), m->adm_counts.as<uint32_t>(), &dc->n_sorted,
-                                m->adm_pairs.as<uint2>()));
+            if (force_full) {
+                m->spec_round1 = false;
+                HIPCHK(launch_admit(v->stream, m->proj_rec(), n, nullptr, m->fc.tiles_x, nullptr, 0, WindowPyramid{}, nullptr,
+                                    m->adm_ballots.as<unsigned long long>(), m->adm_counts.as<uint32_t>(), &dc->n_sorted,
+                                    m->adm_pairs.as<uint2>()));
+            } else {
+                HIPCHK(launch_admit_from_project(v->stream, m->proj_rec().key, n, m->adm_ballots.as<unsigned long long>(),
+                                                 m->adm_counts.as<uint32_t>(), &dc->n_sorted, m->adm_pairs.as<uint2>()));
+            }
             RadixBuffers rb{nullptr, nullptr, m->adm_pairs.as<uint2>(), m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
                             m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
             HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted, 32, false));
@@ -531,11 +542,11 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
         m->n_sorted = m->h_counters->n_sorted;
     }
     std::vector<uint32_t> bounds;
-    if (m->spec_round1 && m->n_sorted && m->n_sorted < m->rec_n) {
-        // the admitted set is a small front part of the model: plan the slabs on its last known size, and let the last
-        // one run to the record count (the kernels stride over what exists on the device, so that costs nothing)
-        plan_slabs(v->options, m->n_sorted, &bounds);
-        bounds.back() = (uint32_t)m->rec_n;
+    if (m->spec_round1) {
+        // a speculated round is ONE slab: the windows already bound what every tile takes to little more than it needs,
+        // and the compositor stops a saturated tile by itself; more slabs only add launches (measured on cfg4: 551 fps
+        // with one slab, 487 with three).  The kernels stride over what exists on the device, so the bound is free.
+        bounds = {0u, (uint32_t)m->rec_n};
     } else {
         plan_slabs(v->options, (uint32_t)m->rec_n, &bounds);
         if (progressive) merge_tail_slabs(&bounds, m->slabs_hint);
@@ -777,7 +788,7 @@ void gsx_render_options_default(gsx_render_options* o) {
     o->min_slab = 131072;
     o->growth = 2;
     o->speculative = 1;
-    o->spec_margin = 0.5f;
+    o->spec_margin = 0.25f;
     o->spec_radius = 3;
 }
 

@@ -74,10 +74,26 @@ hipError_t launch_pack_pod(hipStream_t s, const float* d_pos, const uint32_t* d_
                            const float* d_cov, uint64_t n, uint64_t start, uint64_t model_n, const PodPlanes& pod);
 hipError_t launch_unpack_pod(hipStream_t s, const PodPlanes& pod, uint64_t model_n, float* d_pos, uint32_t* d_color,
                              float* d_sh, float* d_cov);
+// Max-pyramid over the per-tile window ends (launch_window_pyramid): level l holds, per cell of 2^l x 2^l tiles, the
+// largest end.  A rectangle of extent <= 2^l tiles lies under at most 2x2 cells of level l, so four loads bound the
+// largest window end under it from above: a conservative admission test (a hierarchical-Z test on depth keys).
+struct WindowPyramid {
+    const uint32_t* data;  // nullptr: no pyramid
+    uint32_t off[9];       // first element of level l
+    uint32_t wx[9], wy[9]; // cells per row / column of level l
+    uint32_t levels;       // level (levels - 1) is a single cell
+};
+// What the projection kernel needs to decide admission in place (see kernels_admit.hip): ballots[i / 64] = admitted
+// lanes of Gaussians i..i+63, block_counts[i / 256] = admitted per workgroup.
+struct ProjectAdmission {
+    WindowPyramid pyramid;        // data == nullptr: every visible Gaussian is admitted
+    unsigned long long* ballots;  // ceil(N / 64) words
+    uint32_t* block_counts;       // ceil(N / 256) words
+};
 // d_block_visible: one count per 256-Gaussian workgroup (project_blocks(n) entries); launch_sum_counts
 // reduces them into *d_n_visible.
 hipError_t launch_project(hipStream_t s, const FrameConsts& f, uint32_t n, const PodPlanes& pod, const Records& rec,
-                          uint32_t* d_block_visible);
+                          uint32_t* d_block_visible, const ProjectAdmission& adm);
 hipError_t launch_sum_counts(hipStream_t s, const uint32_t* d_block_visible, uint32_t n, uint32_t* d_n_visible);
 size_t project_blocks(uint64_t n);
 
@@ -139,18 +155,14 @@ hipError_t launch_query(hipStream_t s, uint32_t n, const Records& rec, const gsx
                         uint32_t hit_capacity);
 hipError_t launch_selection_op(hipStream_t s, uint32_t n_words, uint32_t op, const uint32_t* flags, uint32_t* selection);
 
-// Max-pyramid over the per-tile window ends (launch_window_pyramid): level l holds, per cell of 2^l x 2^l tiles, the
-// largest end.  A rectangle of extent <= 2^l tiles lies under at most 2x2 cells of level l, so four loads bound the
-// largest window end under it from above: a conservative admission test (a hierarchical-Z test on depth keys).
-struct WindowPyramid {
-    const uint32_t* data;  // nullptr: no pyramid
-    uint32_t off[9];       // first element of level l
-    uint32_t wx[9], wy[9]; // cells per row / column of level l
-    uint32_t levels;       // level (levels - 1) is a single cell
-};
 WindowPyramid window_pyramid_layout(uint32_t tiles_x, uint32_t tiles_y, const uint32_t* data);  // total words: off[levels]... see .hip
 size_t window_pyramid_words(uint32_t tiles_x, uint32_t tiles_y);
 hipError_t launch_window_pyramid(hipStream_t s, const uint2* window, uint32_t tiles_x, uint32_t tiles_y, uint32_t* data);
+
+// exclusive scan of the projection pass's per-workgroup counts (total -> *d_total), then the compaction of the admitted
+// (key, index) pairs in ascending index order
+hipError_t launch_admit_from_project(hipStream_t s, const uint32_t* key, uint32_t n, const unsigned long long* ballots,
+                                     uint32_t* block_counts, uint32_t* d_total, uint2* pairs);
 
 // Admission pass (kernels_admit.hip): compacts the (key, index) pairs of the records the depth sort takes, ascending
 // index; window == nullptr admits every visible record.  *d_total = number of pairs.  d_skip (nullable): when it

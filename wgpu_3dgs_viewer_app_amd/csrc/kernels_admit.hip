@@ -78,6 +78,53 @@ __global__ __launch_bounds__(kAdmitThreads) void k_admit_scatter(const uint32_t*
     }
 }
 
+// ---- compaction straight from the projection pass (its ballots: one word per wave, counts per 256-Gaussian workgroup) ----
+// one workgroup: exclusive scan of counts[0..nblocks) in place, total -> *d_total
+__global__ __launch_bounds__(1024) void k_admit_scan(uint32_t* __restrict__ counts, uint32_t nblocks, uint32_t* __restrict__ d_total) {
+    __shared__ uint32_t wsum[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t per = (nblocks + 1023u) / 1024u, lo = min(tid * per, nblocks), hi = min(lo + per, nblocks);
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i) s += counts[i];
+    uint32_t x = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o, 64);
+        if (lane >= (uint32_t)o) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    uint32_t off = x - s;
+    for (uint32_t w = 0; w < wave; ++w) off += wsum[w];
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t c = counts[i];
+        counts[i] = off;
+        off += c;
+    }
+    if (tid == 1023) *d_total = off;
+}
+
+__global__ __launch_bounds__(256) void k_admit_scatter256(const uint32_t* __restrict__ key, uint32_t n,
+                                                           const unsigned long long* __restrict__ ballots,
+                                                           const uint32_t* __restrict__ offsets, uint2* __restrict__ pairs) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const unsigned long long* b = ballots + blockIdx.x * 4u;
+    const unsigned long long mine = b[wave];
+    if (!((mine >> lane) & 1ull)) return;
+    uint32_t o = offsets[blockIdx.x];
+    for (uint32_t w = 0; w < wave; ++w) o += (uint32_t)__popcll(b[w]);
+    pairs[o + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))] = make_uint2(key[i], i);
+}
+
+hipError_t launch_admit_from_project(hipStream_t s, const uint32_t* key, uint32_t n, const unsigned long long* ballots,
+                                     uint32_t* block_counts, uint32_t* d_total, uint2* pairs) {
+    const uint32_t nb = (n + 255) / 256;
+    if (!nb) return hipMemsetAsync(d_total, 0, 4, s);
+    hipLaunchKernelGGL(k_admit_scan, dim3(1), dim3(1024), 0, s, block_counts, nb, d_total);
+    hipLaunchKernelGGL(k_admit_scatter256, dim3(nb), dim3(256), 0, s, key, n, ballots, block_counts, pairs);
+    return hipGetLastError();
+}
+
 hipError_t launch_admit(hipStream_t s, const Records& rec, uint32_t n, const uint2* window, uint32_t tiles_x,
                         const uint32_t* gate, uint32_t row_words, const WindowPyramid& pyramid, const uint32_t* d_skip, unsigned long long* ballots, uint32_t* counts, uint32_t* d_total, uint2* pairs) {
     const uint32_t nb = (uint32_t)admit_blocks(n);

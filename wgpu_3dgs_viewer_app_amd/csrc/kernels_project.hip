@@ -13,6 +13,7 @@
 
 #include "gsx_internal.h"
 #include "project_math.h"
+#include "window_scan.h"
 
 namespace gsx {
 
@@ -286,9 +287,13 @@ __device__ inline uint32_t ld_stream(const uint32_t* p) { return __builtin_nonte
 // SHK / COVK: storage of the SH and cov3d planes (gsx_sh_kind / gsx_cov3d_kind); dequantisation is exact
 // (f16 -> f32, snorm8 -> f32), so cull set and tile rectangles stay bit-exact against the oracle, which
 // projects the dequantised pod.
+// Admission (kernels_admit.hip) is decided here, where key and rectangle are still in registers: adm.pyramid.data ==
+// nullptr admits every visible Gaussian; otherwise the conservative max-pyramid test of the temporal occlusion
+// speculation (window_scan.h).  One ballot word per wave + one count per workgroup feed the compaction.
 template <int DEG, int SHK, int COVK>
 __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint32_t n, const PodPlanes pod,
-                                                  const Records rec, uint32_t* __restrict__ block_visible) {
+                                                  const Records rec, uint32_t* __restrict__ block_visible,
+                                                  const ProjectAdmission adm) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     bool vis = i < n;
     float4 pc = make_float4(0, 0, 0, 0);
@@ -354,11 +359,21 @@ __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint
             rec.c[i] = make_float4(r, g, b, vc.d);
         }
     }
-    __shared__ uint32_t wave_cnt[4];
+    __shared__ uint32_t wave_cnt[4], wave_adm[4];
     const unsigned long long bal = __ballot(vis);
-    if ((threadIdx.x & 63u) == 0) wave_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
+    bool take = vis;
+    if (adm.pyramid.data && vis) take = pyramid_admits(adm.pyramid, __float_as_uint(vc.d), sp.rx, sp.ry);
+    const unsigned long long bal_adm = __ballot(take);
+    if ((threadIdx.x & 63u) == 0) {
+        wave_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
+        wave_adm[threadIdx.x >> 6] = (uint32_t)__popcll(bal_adm);
+        adm.ballots[blockIdx.x * 4u + (threadIdx.x >> 6)] = bal_adm;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) block_visible[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    if (threadIdx.x == 0) {
+        block_visible[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        adm.block_counts[blockIdx.x] = wave_adm[0] + wave_adm[1] + wave_adm[2] + wave_adm[3];
+    }
 }
 
 // N_vis = sum of the per-workgroup counts (single workgroup; <= 40 K entries at 10 M Gaussians)
@@ -415,34 +430,34 @@ hipError_t launch_sum_counts(hipStream_t s, const uint32_t* d_block_visible, uin
 
 template <int SHK, int COVK>
 static void launch_project_deg(hipStream_t s, dim3 grid, int deg, const FrameConsts& f, uint32_t n, const PodPlanes& pod,
-                               const Records& rec, uint32_t* bv) {
+                               const Records& rec, uint32_t* bv, const ProjectAdmission& adm) {
     dim3 block(256);
     switch (deg) {
-        case 0: hipLaunchKernelGGL((k_project<0, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv); break;
-        case 1: hipLaunchKernelGGL((k_project<1, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv); break;
-        case 2: hipLaunchKernelGGL((k_project<2, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv); break;
-        default: hipLaunchKernelGGL((k_project<3, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv); break;
+        case 0: hipLaunchKernelGGL((k_project<0, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv, adm); break;
+        case 1: hipLaunchKernelGGL((k_project<1, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv, adm); break;
+        case 2: hipLaunchKernelGGL((k_project<2, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv, adm); break;
+        default: hipLaunchKernelGGL((k_project<3, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv, adm); break;
     }
 }
 
 hipError_t launch_project(hipStream_t s, const FrameConsts& f, uint32_t n, const PodPlanes& pod, const Records& rec,
-                          uint32_t* d_block_visible) {
+                          uint32_t* d_block_visible, const ProjectAdmission& adm) {
     if (n == 0) return hipSuccess;
     dim3 grid(blocks_for(n, 256));
     const int deg = pod.sh_kind == GSX_SH_NONE ? 0 : (int)f.sh_deg;
     const bool ch = pod.cov_kind == GSX_COV3D_HALF;
     switch (pod.sh_kind) {
         case GSX_SH_HALF:
-            if (ch) launch_project_deg<GSX_SH_HALF, GSX_COV3D_HALF>(s, grid, deg, f, n, pod, rec, d_block_visible);
-            else launch_project_deg<GSX_SH_HALF, GSX_COV3D_SINGLE>(s, grid, deg, f, n, pod, rec, d_block_visible);
+            if (ch) launch_project_deg<GSX_SH_HALF, GSX_COV3D_HALF>(s, grid, deg, f, n, pod, rec, d_block_visible, adm);
+            else launch_project_deg<GSX_SH_HALF, GSX_COV3D_SINGLE>(s, grid, deg, f, n, pod, rec, d_block_visible, adm);
             break;
         case GSX_SH_NORM8:
-            if (ch) launch_project_deg<GSX_SH_NORM8, GSX_COV3D_HALF>(s, grid, deg, f, n, pod, rec, d_block_visible);
-            else launch_project_deg<GSX_SH_NORM8, GSX_COV3D_SINGLE>(s, grid, deg, f, n, pod, rec, d_block_visible);
+            if (ch) launch_project_deg<GSX_SH_NORM8, GSX_COV3D_HALF>(s, grid, deg, f, n, pod, rec, d_block_visible, adm);
+            else launch_project_deg<GSX_SH_NORM8, GSX_COV3D_SINGLE>(s, grid, deg, f, n, pod, rec, d_block_visible, adm);
             break;
         default:  // Single, or None (deg 0 touches no SH plane)
-            if (ch) launch_project_deg<GSX_SH_SINGLE, GSX_COV3D_HALF>(s, grid, deg, f, n, pod, rec, d_block_visible);
-            else launch_project_deg<GSX_SH_SINGLE, GSX_COV3D_SINGLE>(s, grid, deg, f, n, pod, rec, d_block_visible);
+            if (ch) launch_project_deg<GSX_SH_SINGLE, GSX_COV3D_HALF>(s, grid, deg, f, n, pod, rec, d_block_visible, adm);
+            else launch_project_deg<GSX_SH_SINGLE, GSX_COV3D_SINGLE>(s, grid, deg, f, n, pod, rec, d_block_visible, adm);
             break;
     }
     return hipGetLastError();
