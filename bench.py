@@ -37,6 +37,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="Gaussians in the CPU baseline sample")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded exchange path even at N=1")
+    ap.add_argument("--pass-timing", default="project", help="project (the roofline kernel only; default) | all (every pass, adds "
+                    "a few microseconds of stream gap per pass boundary)")
     ap.add_argument("--render-options", default="", help="gsx_render_options overrides, e.g. speculative=0,min_slab=1000000 (experiments)")
     ap.add_argument("--host-profile", action="store_true", help="print host wall time per exchange-protocol section (adds syncs; debug)")
     ap.add_argument("--pod", default="single/single", help="pod storage sh/cov3d: single|half|norm8|none / single|half "
@@ -117,7 +119,7 @@ def main():
     for i in range(args.warmup):
         frame(i)
     renderer.poll()
-    renderer.set_pass_timing(True)
+    renderer.set_pass_timing(True, None if args.pass_timing == "all" else ["project"])
     renderer.get_pass_timing()  # reset accumulators
     if args.host_profile and use_dist:
         renderer.profile = {}
@@ -175,7 +177,8 @@ def main():
                 traffic = None
         passes = {}
         for name, tv in timing.items():
-            passes[name] = round(tv["ms"] / args.steps, 4)
+            if args.pass_timing == "all" or name == "project":
+                passes[name] = round(tv["ms"] / args.steps, 4)
         out = {
             "metric": "frames/sec @1920x1080, N-Gaussian SH3 scene, 1/2/4/8 MI355X; %HBM roofline",
             "value": round(fps, 3),

@@ -368,6 +368,8 @@ typedef enum gsx_pass {
     GSX_PASS_COMPOSITE = 4,
     GSX_PASS_COUNT = 5
 } gsx_pass;
+/* enabled: 0 = off, 1 = every pass, otherwise a mask with bit (p + 1) set for each pass p to bracket with events
+ * (an event pair costs a few microseconds of stream gap: time only what is being measured). */
 gsx_status gsx_set_pass_timing(gsx_viewer* v, uint32_t enabled);
 /* milliseconds of each pass accumulated over all models since the last call (resets accumulators);
  * synchronises. launches[i] = kernel launches of the dominant kernel of pass i. */

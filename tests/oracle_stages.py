@@ -200,7 +200,7 @@ class OracleStages:
     def poll(self):
         pass
 
-    def set_pass_timing(self, on):
+    def set_pass_timing(self, on, passes=None):
         pass
 
     def get_pass_timing(self):

@@ -199,7 +199,7 @@ struct gsx_viewer {
     void* ext_fb = nullptr;              // caller-owned framebuffer (multi-GPU: the RCCL gather target)
     uint64_t ext_fb_bytes = 0;
     gsx_render_options options{1u, 16u, 131072u, 2u, 1u, 0.25f, 3u};
-    bool timing = false;
+    uint32_t timing = 0;  // bit p: bracket pass p with events
     std::vector<PassTimer> timers;     // recorded, not yet read
     std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
     float pass_ms[GSX_PASS_COUNT]{};
@@ -219,7 +219,7 @@ struct ScopedPass {
     int pass;
     hipEvent_t a = nullptr, b = nullptr;
     ScopedPass(gsx_viewer* v_, int pass_) : v(v_), pass(pass_) {
-        if (!v->timing) return;
+        if (!((v->timing >> pass) & 1u)) return;
         if (!v->event_pool.empty()) {
             a = v->event_pool.back().first;
             b = v->event_pool.back().second;
@@ -577,7 +577,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
         HIPCHK(m->ranges.ensure(sizeof(uint2) * (size_t)n_tiles));
     }
     // reset this model's per-frame totals (n_visible and n_sorted stay)
-    HIPCHK(hipMemsetAsync(&dc->n_entries, 0, sizeof(Counters) - offsetof(Counters, n_entries), v->stream));
+    HIPCHK(launch_zero_words(v->stream, &dc->n_entries, (uint32_t)((sizeof(Counters) - offsetof(Counters, n_entries)) / 4), nullptr, 0));
     const uint32_t* done_before = nullptr;
     if (speculate) {
         const size_t bm = 4 * (size_t)row_words * m->fc.tiles_y;
@@ -701,7 +701,7 @@ static gsx_status do_render(gsx_viewer* v, const char* const* keys, uint32_t n_k
         const uint32_t row_words = (tiles_x + 31) / 32;
         const size_t bytes = 4 * (1 + (size_t)tiles_y * row_words + (size_t)tiles_y * tiles_x);
         HIPCHK(v->done_bits.ensure(bytes));
-        HIPCHK(hipMemsetAsync(v->done_bits.p, 0, bytes, v->stream));
+        HIPCHK(launch_zero_words(v->stream, v->done_bits.as<uint32_t>(), (uint32_t)(bytes / 4), nullptr, 0));
     }
     // the reference paints far -> near with "over"; front-to-back accumulation walks the same list backwards
     bool carry = cont;
@@ -1597,7 +1597,7 @@ gsx_status gsx_render_more(gsx_viewer* v, const char* const* keys, uint32_t n_ke
 
 gsx_status gsx_set_pass_timing(gsx_viewer* v, uint32_t enabled) {
     if (!v) return fail(GSX_ERR_INVALID_ARG, "gsx_set_pass_timing: viewer is null");
-    v->timing = enabled != 0;
+    v->timing = enabled == 1u ? 0xFFFFFFFFu : (enabled >> 1);  // 1 = every pass; otherwise bit (p + 1) selects pass p
     return GSX_OK;
 }
 

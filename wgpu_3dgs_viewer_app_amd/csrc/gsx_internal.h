@@ -177,6 +177,7 @@ hipError_t launch_admit(hipStream_t s, const Records& rec, uint32_t n, const uin
 // Temporal occlusion speculation (kernels_spec.hip): verification of this frame's windows, windows of the next frame.
 hipError_t launch_spec_verify(hipStream_t s, const uint2* win1, const uint32_t* done, uint32_t row_words, uint32_t tiles_x,
                               uint32_t tiles_y, uint2* win2, uint32_t* need_bits, uint32_t* d_need);
+hipError_t launch_zero_words(hipStream_t s, uint32_t* a, uint32_t na, uint32_t* b, uint32_t nb);
 hipError_t launch_spec_next(hipStream_t s, const uint32_t* tile_sat, const uint32_t* done, const uint32_t* done_before,
                             uint32_t row_words, uint32_t tiles_x, uint32_t tiles_y, float margin, uint32_t radius, uint2* win_next);
 

@@ -82,26 +82,30 @@ __global__ __launch_bounds__(kAdmitThreads) void k_admit_scatter(const uint32_t*
 // one workgroup: exclusive scan of counts[0..nblocks) in place, total -> *d_total
 __global__ __launch_bounds__(1024) void k_admit_scan(uint32_t* __restrict__ counts, uint32_t nblocks, uint32_t* __restrict__ d_total) {
     __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t per = (nblocks + 1023u) / 1024u, lo = min(tid * per, nblocks), hi = min(lo + per, nblocks);
-    uint32_t s = 0;
-    for (uint32_t i = lo; i < hi; ++i) s += counts[i];
-    uint32_t x = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = __shfl_up(x, o, 64);
-        if (lane >= (uint32_t)o) x += y;
-    }
-    if (lane == 63) wsum[wave] = x;
+    if (tid == 0) carry_s = 0;
     __syncthreads();
-    uint32_t off = x - s;
-    for (uint32_t w = 0; w < wave; ++w) off += wsum[w];
-    for (uint32_t i = lo; i < hi; ++i) {
-        const uint32_t c = counts[i];
-        counts[i] = off;
-        off += c;
+    for (uint32_t base = 0; base < nblocks; base += 1024) {  // coalesced 1024-wide tiles, carry between them
+        const uint32_t i = base + tid;
+        const uint32_t v = i < nblocks ? counts[i] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= (uint32_t)o) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t w = 0; w < wave; ++w) woff += wsum[w];
+        const uint32_t carry = carry_s;
+        if (i < nblocks) counts[i] = carry + woff + x - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + x;
+        __syncthreads();
     }
-    if (tid == 1023) *d_total = off;
+    if (tid == 0) *d_total = carry_s;
 }
 
 __global__ __launch_bounds__(256) void k_admit_scatter256(const uint32_t* __restrict__ key, uint32_t n,

@@ -15,19 +15,40 @@ namespace gsx {
 
 constexpr uint32_t kKeyAll = 0xFFFFFFFFu;
 
+// replaces hipMemsetAsync for small, oddly sized ranges (the runtime splits those into several fill kernels)
+__global__ __launch_bounds__(256) void k_zero_words(uint32_t* __restrict__ a, uint32_t na, uint32_t* __restrict__ b, uint32_t nb) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < na) a[i] = 0u;
+    if (i < nb) b[i] = 0u;
+}
+
+hipError_t launch_zero_words(hipStream_t s, uint32_t* a, uint32_t na, uint32_t* b, uint32_t nb) {
+    const uint32_t n = na > nb ? na : nb;
+    if (n) hipLaunchKernelGGL(k_zero_words, dim3((n + 255) / 256), dim3(256), 0, s, a, na, b, nb);
+    return hipGetLastError();
+}
+
 // need[t] = bounded window && still open  ->  win2[t] = [hi, inf) for those tiles, [0, 0) for the rest; *d_need = count
 __global__ __launch_bounds__(256) void k_spec_verify(const uint2* __restrict__ win1, const uint32_t* __restrict__ done,
                                                       uint32_t row_words, uint32_t tiles_x, uint32_t n_tiles,
                                                       uint2* __restrict__ win2, uint32_t* __restrict__ need_bits,
                                                       uint32_t* __restrict__ d_need) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    // the need bitmap, one thread per word (no clear, no atomics): bit = bounded window && still open
+    const uint32_t tiles_y = n_tiles / tiles_x;
+    if (t < row_words * tiles_y) {
+        const uint32_t ty = t / row_words, x0 = (t % row_words) * 32u;
+        uint32_t bits = 0;
+        for (uint32_t b = 0; b < 32u && x0 + b < tiles_x; ++b)
+            if (win1[ty * tiles_x + x0 + b].y != kKeyAll) bits |= 1u << b;
+        need_bits[t] = bits & ~done[t];
+    }
     bool need = false;
     if (t < n_tiles) {
         const uint32_t tx = t % tiles_x, ty = t / tiles_x;
         const uint2 w = win1[t];
         need = w.y != kKeyAll && !((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u);
         win2[t] = need ? make_uint2(w.y, kKeyAll) : make_uint2(0u, 0u);
-        if (need) atomicOr(&need_bits[ty * row_words + (tx >> 5)], 1u << (tx & 31u));  // rare: a handful of tiles per frame
     }
     const unsigned long long bal = __ballot(need);
     if ((threadIdx.x & 63u) == 0 && bal) atomicAdd(d_need, (uint32_t)__popcll(bal));
@@ -107,8 +128,6 @@ hipError_t launch_window_pyramid(hipStream_t s, const uint2* window, uint32_t ti
 hipError_t launch_spec_verify(hipStream_t s, const uint2* win1, const uint32_t* done, uint32_t row_words, uint32_t tiles_x,
                               uint32_t tiles_y, uint2* win2, uint32_t* need_bits, uint32_t* d_need) {
     // *d_need is zero here (the frame's counters are reset before the first slab)
-    hipError_t e = hipMemsetAsync(need_bits, 0, 4 * (size_t)row_words * tiles_y, s);
-    if (e != hipSuccess) return e;
     const uint32_t n_tiles = tiles_x * tiles_y;
     hipLaunchKernelGGL(k_spec_verify, dim3((n_tiles + 255) / 256), dim3(256), 0, s, win1, done, row_words, tiles_x, n_tiles, win2,
                        need_bits, d_need);

@@ -165,8 +165,8 @@ class HipStages:
     def poll(self) -> None:
         self.viewer.poll()
 
-    def set_pass_timing(self, on: bool) -> None:
-        self.viewer.set_pass_timing(on)
+    def set_pass_timing(self, on: bool, passes=None) -> None:
+        self.viewer.set_pass_timing(on, passes)
 
     def get_pass_timing(self) -> dict:
         return self.viewer.get_pass_timing()

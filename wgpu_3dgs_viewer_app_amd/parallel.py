@@ -277,8 +277,8 @@ class ShardedViewer:
         """Statistics of the last frame (synchronises)."""
         return dict(self.stages.stats(key or (self.keys[0] if self.keys else self.KEY)))
 
-    def set_pass_timing(self, on: bool) -> None:
-        self.stages.set_pass_timing(on)
+    def set_pass_timing(self, on: bool, passes=None) -> None:
+        self.stages.set_pass_timing(on, passes)
 
     def get_pass_timing(self) -> dict:
         return self.stages.get_pass_timing()

@@ -421,8 +421,12 @@ class MultiModelViewer:
         return off, lst[: st["n_tile_entries"]]
 
     # -- timing --
-    def set_pass_timing(self, enabled: bool) -> None:
-        _lib.check(self._L.gsx_set_pass_timing(self._h, 1 if enabled else 0))
+    def set_pass_timing(self, enabled, passes=None) -> None:
+        """``passes``: names from ``_lib.GSX_PASS_NAMES`` to bracket with events (default: all)."""
+        code = 0
+        if enabled:
+            code = 1 if passes is None else sum(1 << (_lib.GSX_PASS_NAMES.index(p) + 1) for p in passes)
+        _lib.check(self._L.gsx_set_pass_timing(self._h, code))
 
     def get_pass_timing(self) -> dict:
         ms = (C.c_float * _lib.GSX_PASS_COUNT)()
