@@ -124,6 +124,9 @@ struct Model {
     DevBuf spec_win, spec_win2, spec_done_before, spec_need, spec_coarse;
     bool spec_valid = false, spec_round1 = false;
     uint32_t spec_tiles_x = 0, spec_tiles_y = 0;
+    DevBuf adm_ballots2;           // the repair round's ballots (the first round's stay: they say which records are shaded)
+    bool lazy = false;             // this frame's projection shaded only the admitted Gaussians
+    uint32_t* last_pod_mask = nullptr;  // the keep-bitset the projection pass used (mask, or mask & ~hidden)
     DevBuf adm_pairs, adm_ballots, adm_counts;  // admission pass: compacted (key, index) pairs, per-wave ballots, per-workgroup counts
     DevBuf pack_masks;             // destination bit mask per record (gsx_shard_pack)
     DevBuf window, pack_window;    // per-tile depth-key windows [lo, hi): of the imported set / of the pack in flight
@@ -262,6 +265,7 @@ static float4* fb_ptr(gsx_viewer* v) { return v->ext_fb ? static_cast<float4*>(v
 
 static gsx_status do_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys, bool cont = false);
 static gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full = false);
+static gsx_status complete_records(gsx_viewer* v, Model* m);
 
 // Frames are enqueued without any host round trip; this is where the host catches up: wait for the
 // stream, mirror the per-model statistics, and if a depth slab needed more tile-pair capacity than was
@@ -420,6 +424,10 @@ static gsx_status do_preprocess(gsx_viewer* v, Model* m) {
     if (m->spec_round1) adm.pyramid = window_pyramid_layout(m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse.as<uint32_t>());
     adm.ballots = m->adm_ballots.as<unsigned long long>();
     adm.block_counts = m->adm_counts.as<uint32_t>();
+    // lazy shading: nothing else reads the conic / colour records of this frame (no edit, highlight or query pass)
+    m->lazy = m->spec_round1 && !edits_on && !highlight_on && v->query.kind == GSX_QUERY_NONE;
+    adm.lazy = m->lazy ? 1u : 0u;
+    m->last_pod_mask = pod.mask;
     {
         ScopedPass t(v, GSX_PASS_PROJECT);  // brackets the projection kernel alone (bench.py's roofline kernel)
         HIPCHK(launch_project(v->stream, m->fc, n32, pod, m->proj_rec(), m->block_vis.as<uint32_t>(), adm));
@@ -452,6 +460,22 @@ static gsx_status do_preprocess(gsx_viewer* v, Model* m) {
     return GSX_OK;
 }
 
+// A lazily shaded frame left the conic / colour records of the refused Gaussians unwritten; whoever needs all of them
+// (parity download, multi-GPU pack, a redone frame) gets them by running the projection again, unlazily: same values.
+static gsx_status complete_records(gsx_viewer* v, Model* m) {
+    if (!m->lazy || !m->preprocessed) return GSX_OK;
+    ProjectAdmission adm{};
+    adm.pyramid = window_pyramid_layout(m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse.as<uint32_t>());
+    adm.ballots = m->adm_ballots.as<unsigned long long>();
+    HIPCHK(m->block_sums.ensure(4 * std::max<size_t>((m->n + 255) / 256, 1)));
+    adm.block_counts = m->block_sums.as<uint32_t>();  // scratch: the admission counts were consumed by the compaction
+    PodPlanes pod = m->pod();
+    pod.mask = m->last_pod_mask;
+    HIPCHK(launch_project(v->stream, m->fc, (uint32_t)m->n, pod, m->proj_rec(), m->block_vis.as<uint32_t>(), adm));
+    m->lazy = false;
+    return GSX_OK;
+}
+
 // force_full: ignore the admission the projection pass made (a speculated frame being redone) and sort every visible record
 static gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
     if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_sort('%s') before gsx_preprocess", m->key.c_str());
@@ -468,6 +492,8 @@ static gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
             // compact the (key, index) pairs the projection pass admitted, then sort only those
             HIPCHK(m->adm_pairs.ensure(8 * std::max<size_t>(n, 1)));
             if (force_full) {
+                gsx_status stc = complete_records(v, m);
+                if (stc) return stc;
                 m->spec_round1 = false;
                 HIPCHK(launch_admit(v->stream, m->proj_rec(), n, nullptr, m->fc.tiles_x, nullptr, 0, WindowPyramid{}, nullptr,
                                     m->adm_ballots.as<unsigned long long>(), m->adm_counts.as<uint32_t>(), &dc->n_sorted,
@@ -644,10 +670,17 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
             HIPCHK(m->spec_need.ensure(4 * (size_t)row_words * m->fc.tiles_y));
             HIPCHK(launch_spec_verify(v->stream, m->spec_win.as<uint2>(), done, row_words, m->fc.tiles_x, m->fc.tiles_y,
                                       m->spec_win2.as<uint2>(), m->spec_need.as<uint32_t>(), &dc->spec_need));
+            HIPCHK(m->adm_ballots2.ensure(8 * ((std::max<size_t>(n, 1) + 63) / 64)));
             HIPCHK(launch_admit(v->stream, m->proj_rec(), n, m->spec_win2.as<uint2>(), m->fc.tiles_x, m->spec_need.as<uint32_t>(),
                                 row_words, WindowPyramid{}, &dc->spec_need,
-                                m->adm_ballots.as<unsigned long long>(), m->adm_counts.as<uint32_t>(), &dc->n_sorted2,
+                                m->adm_ballots2.as<unsigned long long>(), m->adm_counts.as<uint32_t>(), &dc->n_sorted2,
                                 m->adm_pairs.as<uint2>()));
+            if (m->lazy) {  // the repair round needs records the lazy projection did not shade
+                PodPlanes pod = m->pod();
+                pod.mask = m->last_pod_mask;
+                HIPCHK(launch_project_late(v->stream, m->fc, n, pod, m->proj_rec(),
+                                           LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>()}));
+            }
             RadixBuffers rb{nullptr, nullptr, m->adm_pairs.as<uint2>(), m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
                             m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
             HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted2, 32, false));
@@ -1130,6 +1163,7 @@ gsx_status gsx_model_download_projection(gsx_viewer* v, const char* key, uint32_
     Model* m = find_model(v, key);
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_download_projection: no model '%s'", key ? key : "(null)");
     if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_projection: model '%s' not preprocessed", key);
+    if ((st = complete_records(v, m))) return st;
     HIPCHK(hipStreamSynchronize(v->stream));
     const size_t n = m->rec_n;  // == model length unless records were imported (gsx_shard_import)
     std::vector<uint32_t> k(n);
@@ -1494,6 +1528,7 @@ gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, const 
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_pack: no model '%s'", key ? key : "(null)");
     if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack: model '%s' has no projection this frame (gsx_preprocess first)", key);
     if (world == 0 || world > 64 || !counts) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack: world must be 1..64");
+    if ((st = complete_records(v, m))) return st;
     const uint32_t n = (uint32_t)m->n;
     const uint32_t nb = (uint32_t)pack_blocks(n), rpr = rows_per_rank(v, world);
     const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE;

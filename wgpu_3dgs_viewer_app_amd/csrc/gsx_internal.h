@@ -89,11 +89,20 @@ struct ProjectAdmission {
     WindowPyramid pyramid;        // data == nullptr: every visible Gaussian is admitted
     unsigned long long* ballots;  // ceil(N / 64) words
     uint32_t* block_counts;       // ceil(N / 256) words
+    uint32_t lazy;                // 1: shade (SH planes, conic / colour records) only the admitted Gaussians
+};
+// the records a repair round admitted; those not shaded by the (lazy) projection pass are completed
+struct LateProjection {
+    const uint2* pairs;                 // (key, index)
+    const uint32_t* d_n;                // number of pairs, on the device
+    const unsigned long long* shaded;   // the projection pass's admission ballots
 };
 // d_block_visible: one count per 256-Gaussian workgroup (project_blocks(n) entries); launch_sum_counts
 // reduces them into *d_n_visible.
 hipError_t launch_project(hipStream_t s, const FrameConsts& f, uint32_t n, const PodPlanes& pod, const Records& rec,
                           uint32_t* d_block_visible, const ProjectAdmission& adm);
+hipError_t launch_project_late(hipStream_t s, const FrameConsts& f, uint32_t n, const PodPlanes& pod, const Records& rec,
+                               const LateProjection& late);
 hipError_t launch_sum_counts(hipStream_t s, const uint32_t* d_block_visible, uint32_t n, uint32_t* d_n_visible);
 size_t project_blocks(uint64_t n);
 

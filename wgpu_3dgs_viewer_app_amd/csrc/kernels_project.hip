@@ -290,6 +290,58 @@ __device__ inline uint32_t ld_stream(const uint32_t* p) { return __builtin_nonte
 // Admission (kernels_admit.hip) is decided here, where key and rectangle are still in registers: adm.pyramid.data ==
 // nullptr admits every visible Gaussian; otherwise the conservative max-pyramid test of the temporal occlusion
 // speculation (window_scan.h).  One ballot word per wave + one count per workgroup feed the compaction.
+// covariance planes of Gaussian i -> cov2d, screen position, tile rectangle (false: culled)
+template <int COVK>
+__device__ inline bool load_cov2d_rect(const FrameConsts& f, const PodPlanes& pod, uint32_t i, const ViewClip& vc, Splat2D& sp) {
+    float c0, c1, c2, c3, c4, c5;
+    if (COVK == GSX_COV3D_SINGLE) {
+        const float4 cva = ld_stream(&pod.cov_a[i]);
+        const float2 cvb = ld_stream(&pod.cov_b[i]);
+        c0 = cva.x; c1 = cva.y; c2 = cva.z; c3 = cva.w; c4 = cvb.x; c5 = cvb.y;
+    } else {
+        const uint2 a = ld_stream(&pod.cov_h[i]);
+        const uint32_t b = ld_stream(&pod.cov_h2[i]);
+        c0 = h_lo(a.x); c1 = h_hi(a.x); c2 = h_lo(a.y); c3 = h_hi(a.y); c4 = h_lo(b); c5 = h_hi(b);
+    }
+    return pm_cov2d_rect(f, vc, c0, c1, c2, c3, c4, c5, sp);
+}
+
+// SH planes of Gaussian i (only the planes the degree needs) -> colour
+template <int DEG, int SHK>
+__device__ inline void load_shade(const FrameConsts& f, const PodPlanes& pod, uint32_t n, uint32_t i, const float4& pc,
+                                  float& r, float& g, float& b) {
+    float s[48];
+    constexpr int kFloats = ShNeed<DEG>::floats;
+    if (SHK == GSX_SH_SINGLE) {
+#pragma unroll
+        for (int p = 0; p < ShNeed<DEG>::planes4; ++p) {
+            const float4 v = ld_stream(&pod.sh4[(uint64_t)p * n + i]);
+            s[4 * p] = v.x; s[4 * p + 1] = v.y; s[4 * p + 2] = v.z; s[4 * p + 3] = v.w;
+        }
+        if (DEG == 3) s[44] = ld_stream(&pod.sh1[i]);
+    } else if (SHK == GSX_SH_HALF) {
+#pragma unroll
+        for (int p = 0; p < (kFloats + 7) / 8; ++p) {
+            const uint4 v = ld_stream(&pod.sh_h[(uint64_t)p * n + i]);
+            s[8 * p] = h_lo(v.x); s[8 * p + 1] = h_hi(v.x); s[8 * p + 2] = h_lo(v.y); s[8 * p + 3] = h_hi(v.y);
+            s[8 * p + 4] = h_lo(v.z); s[8 * p + 5] = h_hi(v.z); s[8 * p + 6] = h_lo(v.w); s[8 * p + 7] = h_hi(v.w);
+        }
+    } else if (SHK == GSX_SH_NORM8) {
+#pragma unroll
+        for (int p = 0; p < (kFloats + 15) / 16; ++p) {
+            const uint4 v = ld_stream(&pod.sh_q[(uint64_t)p * n + i]);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) s[16 * p + 4 * k + bb] = dq_snorm8(w[k], bb);
+        }
+    }
+    pm_color<DEG>(f, pc.x, pc.y, pc.z, __float_as_uint(pc.w), s, r, g, b);
+}
+
+// adm.lazy: a refused Gaussian is not shaded — its SH planes (180 of the pod's 220 bytes) are never read and its conic /
+// colour records never written; k_project_late completes the few that the repair round turns out to need.
 template <int DEG, int SHK, int COVK>
 __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint32_t n, const PodPlanes pod,
                                                   const Records rec, uint32_t* __restrict__ block_visible,
@@ -305,64 +357,26 @@ __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint
     vis = pm_view_cull(f, pc.x, pc.y, pc.z, vc) && vis;
 
     Splat2D sp{};
-    if (vis) {  // the covariance planes are only fetched for Gaussians that survive the frustum test
-        float c0, c1, c2, c3, c4, c5;
-        if (COVK == GSX_COV3D_SINGLE) {
-            const float4 cva = ld_stream(&pod.cov_a[i]);
-            const float2 cvb = ld_stream(&pod.cov_b[i]);
-            c0 = cva.x; c1 = cva.y; c2 = cva.z; c3 = cva.w; c4 = cvb.x; c5 = cvb.y;
-        } else {
-            const uint2 a = ld_stream(&pod.cov_h[i]);
-            const uint32_t b = ld_stream(&pod.cov_h2[i]);
-            c0 = h_lo(a.x); c1 = h_hi(a.x); c2 = h_lo(a.y); c3 = h_hi(a.y); c4 = h_lo(b); c5 = h_hi(b);
-        }
-        vis = pm_cov2d_rect(f, vc, c0, c1, c2, c3, c4, c5, sp);
-    }
+    // the covariance planes are only fetched for Gaussians that survive the frustum test
+    if (vis) vis = load_cov2d_rect<COVK>(f, pod, i, vc, sp);
+
+    bool take = vis;
+    if (adm.pyramid.data && vis) take = pyramid_admits(adm.pyramid, __float_as_uint(vc.d), sp.rx, sp.ry);
+    const bool shade = vis && (take || !adm.lazy);
 
     float r = 0, g = 0, b = 0;
-    if (vis) {  // SH planes: loaded only for survivors, only the planes the degree needs
-        float s[48];
-        constexpr int kFloats = ShNeed<DEG>::floats;
-        if (SHK == GSX_SH_SINGLE) {
-#pragma unroll
-            for (int p = 0; p < ShNeed<DEG>::planes4; ++p) {
-                const float4 v = ld_stream(&pod.sh4[(uint64_t)p * n + i]);
-                s[4 * p] = v.x; s[4 * p + 1] = v.y; s[4 * p + 2] = v.z; s[4 * p + 3] = v.w;
-            }
-            if (DEG == 3) s[44] = ld_stream(&pod.sh1[i]);
-        } else if (SHK == GSX_SH_HALF) {
-#pragma unroll
-            for (int p = 0; p < (kFloats + 7) / 8; ++p) {
-                const uint4 v = ld_stream(&pod.sh_h[(uint64_t)p * n + i]);
-                s[8 * p] = h_lo(v.x); s[8 * p + 1] = h_hi(v.x); s[8 * p + 2] = h_lo(v.y); s[8 * p + 3] = h_hi(v.y);
-                s[8 * p + 4] = h_lo(v.z); s[8 * p + 5] = h_hi(v.z); s[8 * p + 6] = h_lo(v.w); s[8 * p + 7] = h_hi(v.w);
-            }
-        } else if (SHK == GSX_SH_NORM8) {
-#pragma unroll
-            for (int p = 0; p < (kFloats + 15) / 16; ++p) {
-                const uint4 v = ld_stream(&pod.sh_q[(uint64_t)p * n + i]);
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int bb = 0; bb < 4; ++bb) s[16 * p + 4 * k + bb] = dq_snorm8(w[k], bb);
-            }
-        }
-        pm_color<DEG>(f, pc.x, pc.y, pc.z, color, s, r, g, b);
-    }
+    if (shade) load_shade<DEG, SHK>(f, pod, n, i, pc, r, g, b);  // SH planes: survivors (lazy: admitted ones) only
 
     if (i < n) {
         rec.key[i] = vis ? __float_as_uint(vc.d) : kCulledKey;
-        if (vis) {
-            rec.a[i] = make_float4(sp.mx, sp.my, __uint_as_float(sp.rx), __uint_as_float(sp.ry));
+        if (vis) rec.a[i] = make_float4(sp.mx, sp.my, __uint_as_float(sp.rx), __uint_as_float(sp.ry));
+        if (shade) {
             rec.b[i] = make_float4(sp.con_a, sp.con_b, sp.con_c, (float)(color >> 24) * (1.0f / 255.0f));
             rec.c[i] = make_float4(r, g, b, vc.d);
         }
     }
     __shared__ uint32_t wave_cnt[4], wave_adm[4];
     const unsigned long long bal = __ballot(vis);
-    bool take = vis;
-    if (adm.pyramid.data && vis) take = pyramid_admits(adm.pyramid, __float_as_uint(vc.d), sp.rx, sp.ry);
     const unsigned long long bal_adm = __ballot(take);
     if ((threadIdx.x & 63u) == 0) {
         wave_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
@@ -373,6 +387,27 @@ __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint
     if (threadIdx.x == 0) {
         block_visible[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
         adm.block_counts[blockIdx.x] = wave_adm[0] + wave_adm[1] + wave_adm[2] + wave_adm[3];
+    }
+}
+
+// Repair round of a lazily shaded frame: pairs[0 .. *d_n) are the records the round admitted; those the projection pass
+// did not shade (bit clear in its ballots) get their conic / colour records now — same code, same values.
+template <int DEG, int SHK, int COVK>
+__global__ __launch_bounds__(256) void k_project_late(const FrameConsts f, const uint32_t n, const PodPlanes pod, const Records rec,
+                                                       const uint2* __restrict__ pairs, const uint32_t* __restrict__ d_n,
+                                                       const unsigned long long* __restrict__ shaded) {
+    const uint32_t count = *d_n;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < count; j += gridDim.x * 256u) {
+        const uint32_t i = pairs[j].y;
+        if ((shaded[i >> 6] >> (i & 63u)) & 1ull) continue;
+        const float4 pc = pod.pc[i];
+        ViewClip vc;
+        Splat2D sp{};
+        if (!pm_view_cull(f, pc.x, pc.y, pc.z, vc) || !load_cov2d_rect<COVK>(f, pod, i, vc, sp)) continue;  // cannot happen: it is visible
+        float r, g, b;
+        load_shade<DEG, SHK>(f, pod, n, i, pc, r, g, b);
+        rec.b[i] = make_float4(sp.con_a, sp.con_b, sp.con_c, (float)(__float_as_uint(pc.w) >> 24) * (1.0f / 255.0f));
+        rec.c[i] = make_float4(r, g, b, vc.d);
     }
 }
 
@@ -430,37 +465,53 @@ hipError_t launch_sum_counts(hipStream_t s, const uint32_t* d_block_visible, uin
 
 template <int SHK, int COVK>
 static void launch_project_deg(hipStream_t s, dim3 grid, int deg, const FrameConsts& f, uint32_t n, const PodPlanes& pod,
-                               const Records& rec, uint32_t* bv, const ProjectAdmission& adm) {
+                               const Records& rec, uint32_t* bv, const ProjectAdmission& adm, const LateProjection* late) {
     dim3 block(256);
+#define GSX_PROJECT(D)                                                                                                       \
+    if (late)                                                                                                                \
+        hipLaunchKernelGGL((k_project_late<D, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, late->pairs, late->d_n, late->shaded); \
+    else                                                                                                                     \
+        hipLaunchKernelGGL((k_project<D, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv, adm)
     switch (deg) {
-        case 0: hipLaunchKernelGGL((k_project<0, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv, adm); break;
-        case 1: hipLaunchKernelGGL((k_project<1, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv, adm); break;
-        case 2: hipLaunchKernelGGL((k_project<2, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv, adm); break;
-        default: hipLaunchKernelGGL((k_project<3, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv, adm); break;
+        case 0: GSX_PROJECT(0); break;
+        case 1: GSX_PROJECT(1); break;
+        case 2: GSX_PROJECT(2); break;
+        default: GSX_PROJECT(3); break;
     }
+#undef GSX_PROJECT
+}
+
+static hipError_t dispatch_project(hipStream_t s, dim3 grid, const FrameConsts& f, uint32_t n, const PodPlanes& pod, const Records& rec,
+                                   uint32_t* d_block_visible, const ProjectAdmission& adm, const LateProjection* late) {
+    const int deg = pod.sh_kind == GSX_SH_NONE ? 0 : (int)f.sh_deg;
+    const bool ch = pod.cov_kind == GSX_COV3D_HALF;
+    switch (pod.sh_kind) {
+        case GSX_SH_HALF:
+            if (ch) launch_project_deg<GSX_SH_HALF, GSX_COV3D_HALF>(s, grid, deg, f, n, pod, rec, d_block_visible, adm, late);
+            else launch_project_deg<GSX_SH_HALF, GSX_COV3D_SINGLE>(s, grid, deg, f, n, pod, rec, d_block_visible, adm, late);
+            break;
+        case GSX_SH_NORM8:
+            if (ch) launch_project_deg<GSX_SH_NORM8, GSX_COV3D_HALF>(s, grid, deg, f, n, pod, rec, d_block_visible, adm, late);
+            else launch_project_deg<GSX_SH_NORM8, GSX_COV3D_SINGLE>(s, grid, deg, f, n, pod, rec, d_block_visible, adm, late);
+            break;
+        default:  // Single, or None (deg 0 touches no SH plane)
+            if (ch) launch_project_deg<GSX_SH_SINGLE, GSX_COV3D_HALF>(s, grid, deg, f, n, pod, rec, d_block_visible, adm, late);
+            else launch_project_deg<GSX_SH_SINGLE, GSX_COV3D_SINGLE>(s, grid, deg, f, n, pod, rec, d_block_visible, adm, late);
+            break;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_project(hipStream_t s, const FrameConsts& f, uint32_t n, const PodPlanes& pod, const Records& rec,
                           uint32_t* d_block_visible, const ProjectAdmission& adm) {
     if (n == 0) return hipSuccess;
-    dim3 grid(blocks_for(n, 256));
-    const int deg = pod.sh_kind == GSX_SH_NONE ? 0 : (int)f.sh_deg;
-    const bool ch = pod.cov_kind == GSX_COV3D_HALF;
-    switch (pod.sh_kind) {
-        case GSX_SH_HALF:
-            if (ch) launch_project_deg<GSX_SH_HALF, GSX_COV3D_HALF>(s, grid, deg, f, n, pod, rec, d_block_visible, adm);
-            else launch_project_deg<GSX_SH_HALF, GSX_COV3D_SINGLE>(s, grid, deg, f, n, pod, rec, d_block_visible, adm);
-            break;
-        case GSX_SH_NORM8:
-            if (ch) launch_project_deg<GSX_SH_NORM8, GSX_COV3D_HALF>(s, grid, deg, f, n, pod, rec, d_block_visible, adm);
-            else launch_project_deg<GSX_SH_NORM8, GSX_COV3D_SINGLE>(s, grid, deg, f, n, pod, rec, d_block_visible, adm);
-            break;
-        default:  // Single, or None (deg 0 touches no SH plane)
-            if (ch) launch_project_deg<GSX_SH_SINGLE, GSX_COV3D_HALF>(s, grid, deg, f, n, pod, rec, d_block_visible, adm);
-            else launch_project_deg<GSX_SH_SINGLE, GSX_COV3D_SINGLE>(s, grid, deg, f, n, pod, rec, d_block_visible, adm);
-            break;
-    }
-    return hipGetLastError();
+    return dispatch_project(s, dim3(blocks_for(n, 256)), f, n, pod, rec, d_block_visible, adm, nullptr);
+}
+
+hipError_t launch_project_late(hipStream_t s, const FrameConsts& f, uint32_t n, const PodPlanes& pod, const Records& rec,
+                               const LateProjection& late) {
+    if (n == 0) return hipSuccess;
+    return dispatch_project(s, dim3(256), f, n, pod, rec, nullptr, ProjectAdmission{}, &late);  // repairs are few: 64 k lanes stride over them
 }
 
 }  // namespace gsx
