@@ -145,12 +145,23 @@ def main():
     timing = renderer.get_pass_timing()
     if args.host_profile and use_dist and rank == 0:
         print("host ms/frame by section:", {k: round(1e3 * x / args.steps, 4) for k, x in renderer.profile.items()}, file=sys.stderr)
-    stats = renderer.last_stats()
     renderer.set_pass_timing(False)
 
-    # gather per-rank stats for the roofline of the projection pass (dominant HBM stream of the path)
-    local = torch.tensor([stats["n_gaussians"], stats["n_visible"], stats["n_tile_entries"],
-                          timing["project"]["ms"] * 1e3, timing["project"]["launches"]], dtype=torch.float64, device="cuda")
+    # Untimed accounting pass over the same poses: per-frame counts for the projection kernel's algorithmic bytes (the
+    # statistics live on the device; reading them costs a sync per frame, which the timed loop must not pay).
+    renderer.profile = None
+    acct = []
+    for i in range(min(args.steps, 64)):
+        frame(args.warmup + i)
+        st = renderer.last_stats()
+        acct.append((st["n_gaussians"], st["n_visible"], st.get("n_sorted", st["n_visible"]), 1 if st.get("speculated") else 0,
+                     st.get("n_repair_tiles", 0), st["n_tile_entries"]))
+    acct = np.asarray(acct, np.float64)
+    stats = renderer.last_stats()
+
+    # gather per-rank numbers for the roofline of the projection pass (dominant HBM stream of the path)
+    local = torch.tensor([acct[:, 0].mean(), acct[:, 1].mean(), acct[:, 2].mean(), acct[:, 3].mean(), float((acct[:, 4] > 0).mean()),
+                          acct[:, 5].mean(), timing["project"]["ms"] * 1e3, timing["project"]["launches"]], dtype=torch.float64, device="cuda")
     if use_dist:
         allr = [torch.zeros_like(local) for _ in range(world)]
         dist.all_gather(allr, local)
@@ -160,18 +171,27 @@ def main():
 
     if rank == 0:
         fps = args.steps / elapsed
-        # projection kernel: ALGORITHMIC bytes per launch = N*pod_bytes + N_vis*40 (220 for the SH-3 f32 pod),
-        # N, N_vis of the last frame of rank 0's shard; duration = HIP-event average over the timed region.
-        n_loc, nvis_loc = allr[0][0], allr[0][1]
-        pod_bytes = 16 + {0: 180, 1: 96, 2: 48, 3: 0}[sh_kind if sh > 0 else 3] + {0: 24, 1: 12}[cov_kind]
-        proj_bytes = n_loc * pod_bytes + nvis_loc * 40
-        proj_us = allr[0][3] / max(allr[0][4], 1)
+        # Projection kernel, ALGORITHMIC bytes per launch (means over the accounting frames of rank 0's shard):
+        #   every frame      reads N*16 (pos + rgba8) + N_vis*cov, writes N*4 (depth key) + N_vis*16 (mean, tile rect) + N/8 (ballots)
+        #   shaded Gaussians read the SH planes and write conic/opacity + colour/depth: + N_shaded*(sh + 32)
+        # An unspeculated frame shades every visible Gaussian in this kernel: that is SURVEY 8d's N*pod + N_vis*40 up to
+        # bookkeeping.  A speculated frame's projection pass is geometry only — the few admitted Gaussians are shaded by
+        # k_shade afterwards — so the kernel moves fewer bytes BY DESIGN and is priced on what it has to move.
+        n_loc, nvis_loc, nsort_loc, spec_frac, repair_frac, entries = allr[0][:6]
+        sh_bytes = {0: 180, 1: 96, 2: 48, 3: 0}[sh_kind if sh > 0 else 3]
+        cov_bytes = {0: 24, 1: 12}[cov_kind]
+        pod_bytes = 16 + sh_bytes + cov_bytes
+        n_shaded = (1.0 - spec_frac) * nvis_loc  # a speculated frame's projection pass is geometry only (k_shade does the rest)
+        proj_bytes = n_loc * 16 + nvis_loc * cov_bytes + n_loc * 4 + nvis_loc * 16 + n_loc / 8 + n_shaded * (sh_bytes + 32)
+        survey_bytes = n_loc * pod_bytes + nvis_loc * 40
+        proj_us = allr[0][6] / max(allr[0][7], 1)
         achieved = proj_bytes / (proj_us * 1e-6) / 1e9 if proj_us > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and args.pod == "single/single":
+        variant = "lazy" if spec_frac > 0.5 else "full"
+        if os.path.exists(pmc) and args.pod == "single/single" and not args.render_options:
             try:
-                rec = json.load(open(pmc)).get(f"{args.workload}:{world}:k_project")
+                rec = json.load(open(pmc)).get(f"{args.workload}:{world}:k_project:{variant}")
                 traffic = rec["hbm_bytes_per_launch"] if rec else None
             except Exception:
                 traffic = None
@@ -196,7 +216,8 @@ def main():
                 "workload": f"{args.workload}: synthetic {n} Gaussians SH-deg-{sh}, {w}x{h}, orbit r=6 h=1.5 240 poses, seed {seed}",
                 "gaussians": n, "width": w, "height": h, "sh_degree": sh, "pod": args.pod, "pod_bytes": pod_bytes,
                 "sharding": f"splat-index shards x{world}" + (", tile-row exchange + gather" if use_dist else ""),
-                "n_visible_rank0": int(nvis_loc), "tile_entries_rank0": int(allr[0][2]),
+                "n_visible_rank0": int(nvis_loc), "n_depth_sorted_rank0": int(nsort_loc), "tile_entries_rank0": int(entries),
+                "speculated_frames": round(float(spec_frac), 3), "frames_with_repair_round": round(float(repair_frac), 3),
                 "pass_ms_per_frame_rank0": passes,
                 "upload_GBps_pcie_inclusive": round(upload_gbs, 2), "scene_gen_s": round(t_gen, 1),
             },
@@ -205,6 +226,9 @@ def main():
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(proj_bytes), "avg_launch_us": round(proj_us, 2),
+                "bytes_definition": ("geometry-only projection of a speculated frame: N*20.125 + N_vis*(16+cov)" if variant == "lazy" else
+                                     "N*20.125 + N_vis*(16+cov+sh+32) (= SURVEY 8d up to bookkeeping)"),
+                "survey_8d_bytes_per_launch": int(survey_bytes),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

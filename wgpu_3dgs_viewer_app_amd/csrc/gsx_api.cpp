@@ -86,7 +86,7 @@ struct Model {
     ModelTransform mt;
     FrameConsts fc{};
 
-    DevBuf pc, cov_a, cov_b, sh4, sh1, sh_h, sh_q, cov_h, cov_h2, mask;
+    DevBuf pc, cov_a, cov_b, sh4, sh1, sh_h, sh_q, sh_aos, cov_h, cov_h2, mask;
     DevBuf key_buf, rec_a, rec_b, rec_c;        // projection records of the model's own Gaussians
     DevBuf imp_key, imp_a, imp_b, imp_c;        // records imported from other ranks (kept apart: a frame may pack twice)
     bool use_imported = false;
@@ -145,6 +145,7 @@ struct Model {
         p.sh1 = sh1.as<float>();
         p.sh_h = sh_h.as<uint4>();
         p.sh_q = sh_q.as<uint4>();
+        p.sh_aos = sh_aos.as<uint4>();
         p.cov_h = cov_h.as<uint2>();
         p.cov_h2 = cov_h2.as<uint32_t>();
         p.sh_kind = (int)sh_kind;
@@ -501,6 +502,11 @@ static gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
             } else {
                 HIPCHK(launch_admit_from_project(v->stream, m->proj_rec().key, n, m->adm_ballots.as<unsigned long long>(),
                                                  m->adm_counts.as<uint32_t>(), &dc->n_sorted, m->adm_pairs.as<uint2>()));
+                if (m->lazy) {  // the projection pass was geometry only: shade what it admitted
+                    PodPlanes pod = m->pod();
+                    pod.mask = m->last_pod_mask;
+                    HIPCHK(launch_shade(v->stream, m->fc, n, pod, m->proj_rec(), LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted, nullptr}));
+                }
             }
             RadixBuffers rb{nullptr, nullptr, m->adm_pairs.as<uint2>(), m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
                             m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
@@ -678,8 +684,8 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
             if (m->lazy) {  // the repair round needs records the lazy projection did not shade
                 PodPlanes pod = m->pod();
                 pod.mask = m->last_pod_mask;
-                HIPCHK(launch_project_late(v->stream, m->fc, n, pod, m->proj_rec(),
-                                           LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>()}));
+                HIPCHK(launch_shade(v->stream, m->fc, n, pod, m->proj_rec(),
+                                    LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>()}));
             }
             RadixBuffers rb{nullptr, nullptr, m->adm_pairs.as<uint2>(), m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
                             m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
@@ -866,13 +872,18 @@ gsx_status gsx_model_create(gsx_viewer* v, const char* key, uint64_t count, gsx_
         HIPCHK(m->cov_h.ensure(8 * n));
         HIPCHK(m->cov_h2.ensure(4 * n));
     }
+    // SH twice: streaming planes for frames that shade every survivor, a per-Gaussian record copy for the sparse shading
+    // of speculated frames (288 GB of HBM: 1.9 GB more at 10 M Gaussians buys whole-line gathers)
     if (sh == GSX_SH_SINGLE) {
         HIPCHK(m->sh4.ensure(16 * n * kShPlanes4));
         HIPCHK(m->sh1.ensure(4 * n));
+        HIPCHK(m->sh_aos.ensure(16 * n * 12));
     } else if (sh == GSX_SH_HALF) {
         HIPCHK(m->sh_h.ensure(16 * n * 6));
+        HIPCHK(m->sh_aos.ensure(16 * n * 6));
     } else if (sh == GSX_SH_NORM8) {
         HIPCHK(m->sh_q.ensure(16 * n * 3));
+        HIPCHK(m->sh_aos.ensure(16 * n * 3));
     }
     HIPCHK(m->mask.ensure(4 * ((n + 31) / 32)));
     {

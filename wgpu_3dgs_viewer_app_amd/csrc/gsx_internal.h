@@ -52,6 +52,8 @@ struct PodPlanes {
     float* sh1;      // N   : SH float 44
     uint4* sh_h;     // 6*N : plane p holds SH floats 8p..8p+7 as f16
     uint4* sh_q;     // 3*N : plane p holds SH floats 16p..16p+15 as snorm8
+    uint4* sh_aos;   // P*N : record copy of the SH planes, P = 12 / 6 / 3 consecutive words per Gaussian (plane order; f32: word 11 =
+                     //       {float 44, 0, 0, 0}); nullptr for Sh None.  Read by the sparse shading pass, where whole lines count.
     uint2* cov_h;    // N   : xx, xy, xz, yy as f16
     uint32_t* cov_h2;  // N : yz, zz as f16
     uint32_t* mask;  // ceil(N/32) words, bit = keep (nullptr: keep all)
@@ -89,20 +91,20 @@ struct ProjectAdmission {
     WindowPyramid pyramid;        // data == nullptr: every visible Gaussian is admitted
     unsigned long long* ballots;  // ceil(N / 64) words
     uint32_t* block_counts;       // ceil(N / 256) words
-    uint32_t lazy;                // 1: shade (SH planes, conic / colour records) only the admitted Gaussians
+    uint32_t lazy;                // 1: geometry only; launch_shade writes the conic / colour records of the admitted Gaussians
 };
 // the records a repair round admitted; those not shaded by the (lazy) projection pass are completed
 struct LateProjection {
     const uint2* pairs;                 // (key, index)
     const uint32_t* d_n;                // number of pairs, on the device
-    const unsigned long long* shaded;   // the projection pass's admission ballots
+    const unsigned long long* shaded;   // nullable: ballots of the records to skip (shaded already)
 };
 // d_block_visible: one count per 256-Gaussian workgroup (project_blocks(n) entries); launch_sum_counts
 // reduces them into *d_n_visible.
 hipError_t launch_project(hipStream_t s, const FrameConsts& f, uint32_t n, const PodPlanes& pod, const Records& rec,
                           uint32_t* d_block_visible, const ProjectAdmission& adm);
-hipError_t launch_project_late(hipStream_t s, const FrameConsts& f, uint32_t n, const PodPlanes& pod, const Records& rec,
-                               const LateProjection& late);
+hipError_t launch_shade(hipStream_t s, const FrameConsts& f, uint32_t n, const PodPlanes& pod, const Records& rec,
+                        const LateProjection& late);
 hipError_t launch_sum_counts(hipStream_t s, const uint32_t* d_block_visible, uint32_t n, uint32_t* d_n_visible);
 size_t project_blocks(uint64_t n);
 

@@ -109,9 +109,13 @@ __device__ inline float dq_snorm8(uint32_t word, int byte) {
 __device__ inline void store_sh(const PodPlanes& pod, uint64_t model_n, uint64_t i, const float* s45) {
     if (pod.sh_kind == GSX_SH_SINGLE) {
 #pragma unroll
-        for (int p = 0; p < kShPlanes4; ++p)
-            pod.sh4[(uint64_t)p * model_n + i] = make_float4(s45[4 * p], s45[4 * p + 1], s45[4 * p + 2], s45[4 * p + 3]);
+        for (int p = 0; p < kShPlanes4; ++p) {
+            const float4 v = make_float4(s45[4 * p], s45[4 * p + 1], s45[4 * p + 2], s45[4 * p + 3]);
+            pod.sh4[(uint64_t)p * model_n + i] = v;
+            if (pod.sh_aos) pod.sh_aos[i * 12 + p] = make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w));
+        }
         pod.sh1[i] = s45[44];
+        if (pod.sh_aos) pod.sh_aos[i * 12 + 11] = make_uint4(__float_as_uint(s45[44]), 0u, 0u, 0u);
     } else if (pod.sh_kind == GSX_SH_HALF) {
         for (int p = 0; p < 6; ++p) {
             uint32_t w[4];
@@ -120,6 +124,7 @@ __device__ inline void store_sh(const PodPlanes& pod, uint64_t model_n, uint64_t
                 w[k] = pack_h2(f0 < 45 ? s45[f0] : 0.0f, f1 < 45 ? s45[f1] : 0.0f);
             }
             pod.sh_h[(uint64_t)p * model_n + i] = make_uint4(w[0], w[1], w[2], w[3]);
+            if (pod.sh_aos) pod.sh_aos[i * 6 + p] = make_uint4(w[0], w[1], w[2], w[3]);
         }
     } else if (pod.sh_kind == GSX_SH_NORM8) {
         for (int p = 0; p < 3; ++p) {
@@ -133,6 +138,7 @@ __device__ inline void store_sh(const PodPlanes& pod, uint64_t model_n, uint64_t
                 w[k] = v;
             }
             pod.sh_q[(uint64_t)p * model_n + i] = make_uint4(w[0], w[1], w[2], w[3]);
+            if (pod.sh_aos) pod.sh_aos[i * 3 + p] = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
 }
@@ -306,8 +312,10 @@ __device__ inline bool load_cov2d_rect(const FrameConsts& f, const PodPlanes& po
     return pm_cov2d_rect(f, vc, c0, c1, c2, c3, c4, c5, sp);
 }
 
-// SH planes of Gaussian i (only the planes the degree needs) -> colour
-template <int DEG, int SHK>
+// SH planes of Gaussian i (only the planes the degree needs) -> colour.  AOS = false: the streaming SoA planes (every
+// lane of the wave shades, non-temporal loads); AOS = true: the per-Gaussian record copy (sh_aos: the same words, P
+// consecutive uint4 per Gaussian), for the sparse shading of admitted Gaussians — whole cache lines are used.
+template <int DEG, int SHK, bool AOS>
 __device__ inline void load_shade(const FrameConsts& f, const PodPlanes& pod, uint32_t n, uint32_t i, const float4& pc,
                                   float& r, float& g, float& b) {
     float s[48];
@@ -315,21 +323,27 @@ __device__ inline void load_shade(const FrameConsts& f, const PodPlanes& pod, ui
     if (SHK == GSX_SH_SINGLE) {
 #pragma unroll
         for (int p = 0; p < ShNeed<DEG>::planes4; ++p) {
-            const float4 v = ld_stream(&pod.sh4[(uint64_t)p * n + i]);
-            s[4 * p] = v.x; s[4 * p + 1] = v.y; s[4 * p + 2] = v.z; s[4 * p + 3] = v.w;
+            if (AOS) {
+                const uint4 v = pod.sh_aos[(uint64_t)i * 12 + p];
+                s[4 * p] = __uint_as_float(v.x); s[4 * p + 1] = __uint_as_float(v.y);
+                s[4 * p + 2] = __uint_as_float(v.z); s[4 * p + 3] = __uint_as_float(v.w);
+            } else {
+                const float4 v = ld_stream(&pod.sh4[(uint64_t)p * n + i]);
+                s[4 * p] = v.x; s[4 * p + 1] = v.y; s[4 * p + 2] = v.z; s[4 * p + 3] = v.w;
+            }
         }
-        if (DEG == 3) s[44] = ld_stream(&pod.sh1[i]);
+        if (DEG == 3) s[44] = AOS ? __uint_as_float(pod.sh_aos[(uint64_t)i * 12 + 11].x) : ld_stream(&pod.sh1[i]);
     } else if (SHK == GSX_SH_HALF) {
 #pragma unroll
         for (int p = 0; p < (kFloats + 7) / 8; ++p) {
-            const uint4 v = ld_stream(&pod.sh_h[(uint64_t)p * n + i]);
+            const uint4 v = AOS ? pod.sh_aos[(uint64_t)i * 6 + p] : ld_stream(&pod.sh_h[(uint64_t)p * n + i]);
             s[8 * p] = h_lo(v.x); s[8 * p + 1] = h_hi(v.x); s[8 * p + 2] = h_lo(v.y); s[8 * p + 3] = h_hi(v.y);
             s[8 * p + 4] = h_lo(v.z); s[8 * p + 5] = h_hi(v.z); s[8 * p + 6] = h_lo(v.w); s[8 * p + 7] = h_hi(v.w);
         }
     } else if (SHK == GSX_SH_NORM8) {
 #pragma unroll
         for (int p = 0; p < (kFloats + 15) / 16; ++p) {
-            const uint4 v = ld_stream(&pod.sh_q[(uint64_t)p * n + i]);
+            const uint4 v = AOS ? pod.sh_aos[(uint64_t)i * 3 + p] : ld_stream(&pod.sh_q[(uint64_t)p * n + i]);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -340,8 +354,9 @@ __device__ inline void load_shade(const FrameConsts& f, const PodPlanes& pod, ui
     pm_color<DEG>(f, pc.x, pc.y, pc.z, __float_as_uint(pc.w), s, r, g, b);
 }
 
-// adm.lazy: a refused Gaussian is not shaded — its SH planes (180 of the pod's 220 bytes) are never read and its conic /
-// colour records never written; k_project_late completes the few that the repair round turns out to need.
+// adm.lazy: geometry only — nobody is shaded here: the SH planes (180 of the pod's 220 bytes) are not read and no conic /
+// colour record is written; k_shade does that for the Gaussians the admission let through (a few per cent of the
+// visible ones), and later for the few more the repair round turns out to need.
 template <int DEG, int SHK, int COVK>
 __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint32_t n, const PodPlanes pod,
                                                   const Records rec, uint32_t* __restrict__ block_visible,
@@ -362,10 +377,10 @@ __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint
 
     bool take = vis;
     if (adm.pyramid.data && vis) take = pyramid_admits(adm.pyramid, __float_as_uint(vc.d), sp.rx, sp.ry);
-    const bool shade = vis && (take || !adm.lazy);
+    const bool shade = vis && !adm.lazy;
 
     float r = 0, g = 0, b = 0;
-    if (shade) load_shade<DEG, SHK>(f, pod, n, i, pc, r, g, b);  // SH planes: survivors (lazy: admitted ones) only
+    if (shade) load_shade<DEG, SHK, false>(f, pod, n, i, pc, r, g, b);  // SH planes: survivors only
 
     if (i < n) {
         rec.key[i] = vis ? __float_as_uint(vc.d) : kCulledKey;
@@ -390,22 +405,24 @@ __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint
     }
 }
 
-// Repair round of a lazily shaded frame: pairs[0 .. *d_n) are the records the round admitted; those the projection pass
-// did not shade (bit clear in its ballots) get their conic / colour records now — same code, same values.
+// Shading of a lazily projected frame: pairs[0 .. *d_n) are admitted records; each gets its conic / colour records —
+// same code, same values as the unlazy projection.  skip (nullable): ballots of the records that are shaded already
+// (repair round: what the first round admitted).  One record per lane, gathered: position, covariance, and the SH
+// record copy whose cache lines are used whole.
 template <int DEG, int SHK, int COVK>
-__global__ __launch_bounds__(256) void k_project_late(const FrameConsts f, const uint32_t n, const PodPlanes pod, const Records rec,
-                                                       const uint2* __restrict__ pairs, const uint32_t* __restrict__ d_n,
-                                                       const unsigned long long* __restrict__ shaded) {
+__global__ __launch_bounds__(256) void k_shade(const FrameConsts f, const uint32_t n, const PodPlanes pod, const Records rec,
+                                                const uint2* __restrict__ pairs, const uint32_t* __restrict__ d_n,
+                                                const unsigned long long* __restrict__ skip) {
     const uint32_t count = *d_n;
     for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < count; j += gridDim.x * 256u) {
         const uint32_t i = pairs[j].y;
-        if ((shaded[i >> 6] >> (i & 63u)) & 1ull) continue;
+        if (skip && ((skip[i >> 6] >> (i & 63u)) & 1ull)) continue;
         const float4 pc = pod.pc[i];
         ViewClip vc;
         Splat2D sp{};
         if (!pm_view_cull(f, pc.x, pc.y, pc.z, vc) || !load_cov2d_rect<COVK>(f, pod, i, vc, sp)) continue;  // cannot happen: it is visible
         float r, g, b;
-        load_shade<DEG, SHK>(f, pod, n, i, pc, r, g, b);
+        load_shade<DEG, SHK, true>(f, pod, n, i, pc, r, g, b);
         rec.b[i] = make_float4(sp.con_a, sp.con_b, sp.con_c, (float)(__float_as_uint(pc.w) >> 24) * (1.0f / 255.0f));
         rec.c[i] = make_float4(r, g, b, vc.d);
     }
@@ -469,7 +486,7 @@ static void launch_project_deg(hipStream_t s, dim3 grid, int deg, const FrameCon
     dim3 block(256);
 #define GSX_PROJECT(D)                                                                                                       \
     if (late)                                                                                                                \
-        hipLaunchKernelGGL((k_project_late<D, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, late->pairs, late->d_n, late->shaded); \
+        hipLaunchKernelGGL((k_shade<D, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, late->pairs, late->d_n, late->shaded); \
     else                                                                                                                     \
         hipLaunchKernelGGL((k_project<D, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv, adm)
     switch (deg) {
@@ -508,10 +525,10 @@ hipError_t launch_project(hipStream_t s, const FrameConsts& f, uint32_t n, const
     return dispatch_project(s, dim3(blocks_for(n, 256)), f, n, pod, rec, d_block_visible, adm, nullptr);
 }
 
-hipError_t launch_project_late(hipStream_t s, const FrameConsts& f, uint32_t n, const PodPlanes& pod, const Records& rec,
-                               const LateProjection& late) {
+hipError_t launch_shade(hipStream_t s, const FrameConsts& f, uint32_t n, const PodPlanes& pod, const Records& rec,
+                        const LateProjection& late) {
     if (n == 0) return hipSuccess;
-    return dispatch_project(s, dim3(256), f, n, pod, rec, nullptr, ProjectAdmission{}, &late);  // repairs are few: 64 k lanes stride over them
+    return dispatch_project(s, dim3(1024), f, n, pod, rec, nullptr, ProjectAdmission{}, &late);  // 256 k lanes stride over the admitted records
 }
 
 }  // namespace gsx
