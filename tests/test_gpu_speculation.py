@@ -161,3 +161,36 @@ def test_split_protocol_and_statistics():
         gp, pp = v.download_projection("m"), p.download_projection("m")
         assert all(np.array_equal(gp[k], pp[k]) for k in ("key", "rect", "mean2d", "conic_opacity", "rgb"))
         assert np.array_equal(np.sort(p.download_sorted("m")), np.nonzero(pp["key"] != 0xFFFFFFFF)[0])
+
+
+@pytest.mark.parametrize("sh_kind,cov_kind,sh_deg", [(0, 0, 2), (0, 1, 1), (1, 0, 3), (1, 1, 2), (2, 0, 3), (2, 1, 1), (3, 0, 3), (0, 0, 0)])
+def test_lazy_shading_all_pod_kinds(sh_kind, cov_kind, sh_deg):
+    """A speculated frame projects geometry only and shades the admitted Gaussians from the SH record copy (k_shade);
+    every pod kind and SH degree must give the very pixels of the unspeculated frame, and the completed projection
+    records must equal the unlazy ones."""
+    from wgpu_3dgs_viewer_app_amd.viewer import Cov3dKind, ShKind
+
+    g = common.small_scene(20000, 207, scale_mul=10.0)
+    spec = MultiModelViewer(sh=ShKind(sh_kind), cov3d=Cov3dKind(cov_kind))
+    plain = MultiModelViewer(sh=ShKind(sh_kind), cov3d=Cov3dKind(cov_kind))
+    spec.set_render_options(speculative=1, min_slab=2048)
+    plain.set_render_options(speculative=0, min_slab=2048)
+    _load(spec, "m", g)
+    _load(plain, "m", g)
+    for k, pose in enumerate([90, 91, 92, 150, 151]):
+        cam = camera.orbit_pose(pose)
+        out = []
+        for v in (spec, plain):
+            v.update_camera(cam, (W, H))
+            v.update_gaussian_transform(1.0, GaussianDisplayMode.Splat, GaussianShDegree.new(sh_deg), False)
+            v.render_frame(["m"])
+            v.poll()
+            out.append(v.download_framebuffer())
+        assert np.array_equal(out[0], out[1]), f"pose {pose}: L-inf {np.abs(out[0] - out[1]).max()}"
+        if k:
+            st = spec.frame_stats("m")
+            assert st["speculated"] and st["n_sorted"] < st["n_visible"]
+    gp, pp = spec.download_projection("m"), plain.download_projection("m")  # completes the lazily shaded records
+    assert all(np.array_equal(gp[k], pp[k]) for k in ("key", "rect", "mean2d", "conic_opacity", "rgb"))
+    spec.close()
+    plain.close()
