@@ -77,26 +77,32 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConsts f, uint2* _
             pc4 = rec_c[idx];
         }
         const uint32_t cnt = min((uint32_t)kBatch, range.y - base);
-        if (!done) {
-            for (uint32_t j = 0; j < cnt; ++j) {
+        // Straight-line body, one predicated region per splat: a saturated pixel simply stops hitting (`done` is part of
+        // the support predicate) instead of leaving the loop, which keeps the wave's control flow to one skip branch per
+        // splat; a wave whose pixels are all saturated leaves the batch (checked every 4 splats).
+        for (uint32_t j0 = 0; j0 < cnt; j0 += 4) {
+            if (!__ballot(!done)) break;
+            const uint32_t j1 = min(j0 + 4u, cnt);
+            for (uint32_t j = j0; j < j1; ++j) {
                 const float2 m = s_mean[j];
                 const float4 co = s_conic[j];
                 const float dx = pxf - m.x, dy = pyf - m.y;
                 const float q = fmaf(co.x * dx, dx, fmaf(co.z * dy, dy, ((2.0f * co.y) * dx) * dy));
-                if (!(q <= f.k2) || q < 0.0f) continue;
-                const float w = MODE == 0 ? __expf(-0.5f * q) : 1.0f;
-                const float alpha = fminf(f.alpha_max, co.w * w);
-                if (alpha < f.alpha_min) continue;
-                const float4 c = s_rgb[j];
-                const float wgt = T * alpha;
-                C0 = fmaf(wgt, c.x, C0);
-                C1 = fmaf(wgt, c.y, C1);
-                C2 = fmaf(wgt, c.z, C2);
-                T = T * (1.0f - alpha);
-                if (T < f.t_eps) {
-                    done = true;
-                    stop_key = __float_as_uint(c.w);
-                    break;
+                if (!done && q <= f.k2 && q >= 0.0f) {
+                    const float w = MODE == 0 ? __expf(-0.5f * q) : 1.0f;
+                    const float alpha = fminf(f.alpha_max, co.w * w);
+                    if (!(alpha < f.alpha_min)) {
+                        const float4 c = s_rgb[j];
+                        const float wgt = T * alpha;
+                        C0 = fmaf(wgt, c.x, C0);
+                        C1 = fmaf(wgt, c.y, C1);
+                        C2 = fmaf(wgt, c.z, C2);
+                        T = T * (1.0f - alpha);
+                        if (T < f.t_eps) {
+                            done = true;
+                            stop_key = __float_as_uint(c.w);
+                        }
+                    }
                 }
             }
         }
