@@ -357,7 +357,9 @@ __device__ inline void load_shade(const FrameConsts& f, const PodPlanes& pod, ui
 // adm.lazy: geometry only — nobody is shaded here: the SH planes (180 of the pod's 220 bytes) are not read and no conic /
 // colour record is written; k_shade does that for the Gaussians the admission let through (a few per cent of the
 // visible ones), and later for the few more the repair round turns out to need.
-template <int DEG, int SHK, int COVK>
+// LAZY is a template parameter so that the geometry-only variant carries no SH registers (higher occupancy: the kernel
+// is a chain of three dependent loads — position, covariance, pyramid — and lives on waves in flight).
+template <int DEG, int SHK, int COVK, bool LAZY>
 __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint32_t n, const PodPlanes pod,
                                                   const Records rec, uint32_t* __restrict__ block_visible,
                                                   const ProjectAdmission adm) {
@@ -377,10 +379,10 @@ __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint
 
     bool take = vis;
     if (adm.pyramid.data && vis) take = pyramid_admits(adm.pyramid, __float_as_uint(vc.d), sp.rx, sp.ry);
-    const bool shade = vis && !adm.lazy;
+    const bool shade = vis && !LAZY;
 
     float r = 0, g = 0, b = 0;
-    if (shade) load_shade<DEG, SHK, false>(f, pod, n, i, pc, r, g, b);  // SH planes: survivors only
+    if (!LAZY && shade) load_shade<DEG, SHK, false>(f, pod, n, i, pc, r, g, b);  // SH planes: survivors only
 
     if (i < n) {
         rec.key[i] = vis ? __float_as_uint(vc.d) : kCulledKey;
@@ -487,8 +489,10 @@ static void launch_project_deg(hipStream_t s, dim3 grid, int deg, const FrameCon
 #define GSX_PROJECT(D)                                                                                                       \
     if (late)                                                                                                                \
         hipLaunchKernelGGL((k_shade<D, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, late->pairs, late->d_n, late->shaded); \
+    else if (adm.lazy)                                                                                                       \
+        hipLaunchKernelGGL((k_project<0, GSX_SH_SINGLE, COVK, true>), grid, block, 0, s, f, n, pod, rec, bv, adm);           \
     else                                                                                                                     \
-        hipLaunchKernelGGL((k_project<D, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv, adm)
+        hipLaunchKernelGGL((k_project<D, SHK, COVK, false>), grid, block, 0, s, f, n, pod, rec, bv, adm)
     switch (deg) {
         case 0: GSX_PROJECT(0); break;
         case 1: GSX_PROJECT(1); break;
