@@ -288,6 +288,7 @@ gsx_status gsx_query_hit_pos_by_alpha_range(const gsx_query_hit* hits, uint64_t 
 /* ---- multi-GPU stage split.  No reference counterpart: the reference renders on one wgpu device
  *      (src/main.rs:85-98).  One process per GPU holds an index shard of the Gaussians; the screen is cut into
  *      `world` contiguous bands of tile rows, band g = rank g.  Per frame and rank:
+ *        [gsx_shard_set_windows(key, windows)]            optional: lets the projection skip what cannot travel
  *        gsx_preprocess(key)                              project the resident shard
  *        gsx_shard_pack(key, world, windows, ..)          the records some tile's depth-key window [lo, hi) admits,
  *                                                         grouped by destination (first frame: no windows = all)
@@ -321,6 +322,13 @@ gsx_status gsx_viewer_set_external_framebuffer(gsx_viewer* v, void* d_ptr, uint6
  * holds, inside g's band, a tile that admits it.  Synchronises. */
 gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, const uint32_t* d_tile_window, void* d_send,
                           uint64_t capacity_records, uint64_t* counts);
+/* Optional, BEFORE gsx_preprocess: the windows [0, hi) the coming exchange will use (NULL clears).  The projection
+ * pass then is geometry only, admits candidates against a max-pyramid of the window ends (a conservative superset of the
+ * travellers), and only those get their conic / colour records; gsx_shard_pack(.., d_tile_window = NULL, ..) packs
+ * from that candidate list with the exact windows given here — nothing else of the shard is looked at.  A later
+ * gsx_shard_pack with explicit windows (the repair exchange) scans the whole shard and shades the travellers the
+ * first round did not. */
+gsx_status gsx_shard_set_windows(gsx_viewer* v, const char* key, const uint32_t* d_tile_window);
 /* d_recv (device): n_records records ordered by (source rank, source index).  They become the model's active
  * record set for gsx_sort / gsx_render(_more); binning is restricted to this rank's band and to the tiles that
  * admit the record (the receiving side of gsx_shard_pack's predicate, so that every tile composites a gap-free

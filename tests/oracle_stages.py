@@ -143,10 +143,13 @@ class OracleStages:
         self._world, self._rank = 1, 0
         self._composite(keys)
 
-    def begin_frame(self, key, world, rank):
+    def begin_frame(self, key, world, rank, window=None):
         self._prs[key] = self._project(key)
+        self._set_win = window
 
     def pack(self, key, world, window=None):
+        if window is None:
+            window = self._set_win  # the windows announced at begin_frame
         send, counts = pack_by_destination(self._prs[key], world, self.frame.tiles_x, self.frame.tiles_y, window)
         return torch.from_numpy(np.ascontiguousarray(send)), counts
 

@@ -131,6 +131,17 @@ def test_pack_matches_oracle_routing():
                 rsend, rcnt = pack_by_destination(pr, world, f.tiles_x, f.tiles_y, window)
                 assert cnt == rcnt, (cnt, rcnt)
                 assert np.array_equal(send[: sum(cnt)].cpu().numpy().view(np.uint32), rsend.view(np.uint32)), "packed records differ"
+            # windows announced before the projection: geometry-only projection, candidates, sparse shading; the packed
+            # records must be the very same, and so must the repair exchange's (travellers shaded on demand)
+            w1, w2 = parallel.windows_first(lim), parallel.windows_second(lim, need)
+            st.begin_frame("shard", world, rank, w1)
+            for window, ref_window in ((None, w1), (w2, w2)):
+                send, cnt = st.pack("shard", world, window)
+                st.poll()
+                torch.cuda.synchronize()
+                rsend, rcnt = pack_by_destination(pr, world, f.tiles_x, f.tiles_y, ref_window)
+                assert cnt == rcnt, (cnt, rcnt)
+                assert np.array_equal(send[: sum(cnt)].cpu().numpy().view(np.uint32), rsend.view(np.uint32)), "lazily packed records differ"
         st.close()
 
 

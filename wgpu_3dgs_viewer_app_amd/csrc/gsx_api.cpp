@@ -123,9 +123,14 @@ struct Model {
     // windows of the current one, the saturated-tile bitmap as it was before this model was composited
     DevBuf spec_win, spec_win2, spec_done_before, spec_need, spec_coarse;
     bool spec_valid = false, spec_round1 = false;
-    uint32_t spec_tiles_x = 0, spec_tiles_y = 0;
+    uint32_t spec_tiles_x = 0, spec_tiles_y = 0, shard_tiles_x = 0, shard_tiles_y = 0;
+    // lazily projected shard (gsx_shard_set_windows): the windows of the coming exchange, their max-pyramid, and whether the
+    // last preprocess left a candidate list in adm_pairs
+    DevBuf shard_win, shard_pyr, trav_ballots, trav_counts;
+    bool shard_win_set = false, cand_valid = false;
     DevBuf adm_ballots2;           // the repair round's ballots (the first round's stay: they say which records are shaded)
     bool lazy = false;             // this frame's projection shaded only the admitted Gaussians
+    const uint32_t* last_pyramid = nullptr;  // the admission pyramid the projection pass used
     uint32_t* last_pod_mask = nullptr;  // the keep-bitset the projection pass used (mask, or mask & ~hidden)
     DevBuf adm_pairs, adm_ballots, adm_counts;  // admission pass: compacted (key, index) pairs, per-wave ballots, per-workgroup counts
     DevBuf pack_masks;             // destination bit mask per record (gsx_shard_pack)
@@ -422,19 +427,34 @@ static gsx_status do_preprocess(gsx_viewer* v, Model* m) {
     ProjectAdmission adm{};
     HIPCHK(m->adm_ballots.ensure(8 * ((std::max<size_t>(m->n, 1) + 63) / 64 + 4)));
     HIPCHK(m->adm_counts.ensure(4 * std::max<size_t>(std::max(admit_blocks(m->n), (size_t)(m->n + 255) / 256), 1)));
+    const bool shard_lazy = m->shard_win_set && m->shard_tiles_x == m->fc.tiles_x && m->shard_tiles_y == m->fc.tiles_y;
+    if (shard_lazy) m->spec_round1 = false;  // a sharded frame: the windows come from the caller, not from this viewer's last frame
     if (m->spec_round1) adm.pyramid = window_pyramid_layout(m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse.as<uint32_t>());
+    if (shard_lazy) adm.pyramid = window_pyramid_layout(m->fc.tiles_x, m->fc.tiles_y, m->shard_pyr.as<uint32_t>());
     adm.ballots = m->adm_ballots.as<unsigned long long>();
     adm.block_counts = m->adm_counts.as<uint32_t>();
     // lazy shading: nothing else reads the conic / colour records of this frame (no edit, highlight or query pass)
-    m->lazy = m->spec_round1 && !edits_on && !highlight_on && v->query.kind == GSX_QUERY_NONE;
+    m->lazy = (m->spec_round1 || shard_lazy) && !edits_on && !highlight_on && v->query.kind == GSX_QUERY_NONE;
+    m->cand_valid = false;
     adm.lazy = m->lazy ? 1u : 0u;
     m->last_pod_mask = pod.mask;
+    m->last_pyramid = adm.pyramid.data;
     {
         ScopedPass t(v, GSX_PASS_PROJECT);  // brackets the projection kernel alone (bench.py's roofline kernel)
         HIPCHK(launch_project(v->stream, m->fc, n32, pod, m->proj_rec(), m->block_vis.as<uint32_t>(), adm));
         v->pass_launches[GSX_PASS_PROJECT] += m->n ? 1 : 0;
     }
     HIPCHK(launch_sum_counts(v->stream, m->block_vis.as<uint32_t>(), n32, &m->counters.as<Counters>()->n_visible));
+    if (shard_lazy) {
+        // the candidates of the coming exchange (a conservative superset of the travellers): compact them and give
+        // exactly those their conic / colour records; gsx_shard_pack then looks at nothing else
+        Counters* dcx = m->counters.as<Counters>();
+        HIPCHK(m->adm_pairs.ensure(8 * std::max<size_t>(m->n, 1)));
+        HIPCHK(launch_admit_from_project(v->stream, m->proj_rec().key, n32, m->adm_ballots.as<unsigned long long>(),
+                                         m->adm_counts.as<uint32_t>(), &dcx->n_candidates, m->adm_pairs.as<uint2>()));
+        if (m->lazy) HIPCHK(launch_shade(v->stream, m->fc, n32, pod, m->proj_rec(), LateProjection{m->adm_pairs.as<uint2>(), &dcx->n_candidates, nullptr}));
+        m->cand_valid = true;
+    }
     if (edits_on || highlight_on)
         HIPCHK(launch_edit_apply(v->stream, n32, m->proj_rec(), highlight_on ? m->selection.as<uint32_t>() : nullptr,
                                  edits_on ? m->edited.as<uint32_t>() : nullptr, m->edit_a.as<float4>(), m->edit_b.as<float4>(),
@@ -466,7 +486,7 @@ static gsx_status do_preprocess(gsx_viewer* v, Model* m) {
 static gsx_status complete_records(gsx_viewer* v, Model* m) {
     if (!m->lazy || !m->preprocessed) return GSX_OK;
     ProjectAdmission adm{};
-    adm.pyramid = window_pyramid_layout(m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse.as<uint32_t>());
+    adm.pyramid = window_pyramid_layout(m->fc.tiles_x, m->fc.tiles_y, m->last_pyramid);
     adm.ballots = m->adm_ballots.as<unsigned long long>();
     HIPCHK(m->block_sums.ensure(4 * std::max<size_t>((m->n + 255) / 256, 1)));
     adm.block_counts = m->block_sums.as<uint32_t>();  // scratch: the admission counts were consumed by the compaction
@@ -1539,24 +1559,51 @@ gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, const 
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_pack: no model '%s'", key ? key : "(null)");
     if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack: model '%s' has no projection this frame (gsx_preprocess first)", key);
     if (world == 0 || world > 64 || !counts) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack: world must be 1..64");
-    if ((st = complete_records(v, m))) return st;
     const uint32_t n = (uint32_t)m->n;
     const uint32_t nb = (uint32_t)pack_blocks(n), rpr = rows_per_rank(v, world);
     const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE;
     HIPCHK(m->pack_table.ensure(4 * ((size_t)64 * std::max(nb, 1u) + 64)));
     HIPCHK(m->pack_masks.ensure(8 * (size_t)std::max(n, 1u)));
     const uint2* window = nullptr;
+    const uint2* list = nullptr;
+    const uint32_t* d_list_n = nullptr;
+    unsigned long long* travellers = nullptr;
+    uint32_t* trav_counts = nullptr;
+    Counters* dc = m->counters.as<Counters>();
     if (d_tile_window) {  // own copy: the caller's map need not outlive this call
         HIPCHK(m->pack_window.ensure(window_bytes(v)));
         HIPCHK(hipMemcpyAsync(m->pack_window.p, d_tile_window, window_bytes(v), hipMemcpyDeviceToDevice, v->stream));
         window = m->pack_window.as<uint2>();
+        if (m->lazy) {  // explicit windows on a lazily projected shard (the repair exchange): travellers may be unshaded
+            HIPCHK(m->trav_ballots.ensure(8 * ((std::max<size_t>(n, 1) + 63) / 64)));
+            HIPCHK(m->trav_counts.ensure(4 * std::max<size_t>(nb, 1)));
+            travellers = m->trav_ballots.as<unsigned long long>();
+            trav_counts = m->trav_counts.as<uint32_t>();
+        }
+    } else if (m->shard_win_set && m->cand_valid) {  // the windows given to gsx_shard_set_windows: only the candidates are looked at
+        window = m->shard_win.as<uint2>();
+        list = m->adm_pairs.as<uint2>();
+        d_list_n = &dc->n_candidates;
+    } else if (m->lazy) {
+        if ((st = complete_records(v, m))) return st;  // everything travels: every record must be whole
     }
     uint32_t* table = m->pack_table.as<uint32_t>();
     uint32_t* totals = table + (size_t)64 * std::max(nb, 1u);
     unsigned long long* masks = m->pack_masks.as<unsigned long long>();
     HIPCHK(hipMemsetAsync(totals, 0, 4 * 64, v->stream));
-    HIPCHK(launch_pack_count(v->stream, m->proj_rec(), n, world, rpr, window, tiles_x, masks, table));
+    HIPCHK(launch_pack_count(v->stream, m->proj_rec(), n, world, rpr, window, tiles_x, masks, table, list, d_list_n, travellers, trav_counts));
     if (nb) HIPCHK(launch_rowscan(v->stream, table, world, nb, totals));
+    if (travellers && nb) {
+        // shade the travellers the first round did not: compact their indices, k_shade skips what is shaded already
+        HIPCHK(m->adm_pairs.ensure(8 * std::max<size_t>(n, 1)));
+        HIPCHK(launch_rowscan(v->stream, trav_counts, 1, nb, &dc->n_sorted2));
+        HIPCHK(launch_admit_scatter(v->stream, m->proj_rec().key, n, travellers, trav_counts, m->adm_pairs.as<uint2>()));
+        PodPlanes pod = m->pod();
+        pod.mask = m->last_pod_mask;
+        HIPCHK(launch_shade(v->stream, m->fc, n, pod, m->proj_rec(),
+                            LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>()}));
+        m->cand_valid = false;  // adm_pairs now holds the repair travellers
+    }
     uint32_t h_tot[64];
     HIPCHK(hipMemcpyAsync(h_tot, totals, 4 * 64, hipMemcpyDeviceToHost, v->stream));
     HIPCHK(hipStreamSynchronize(v->stream));
@@ -1569,7 +1616,24 @@ gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, const 
         return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack: %llu records exceed the send capacity %llu",
                     (unsigned long long)sum, (unsigned long long)capacity_records);
     if (sum && !d_send) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack: d_send is null");
-    HIPCHK(launch_pack_scatter(v->stream, m->proj_rec(), n, world, masks, table, totals, d_send, capacity_records));
+    HIPCHK(launch_pack_scatter(v->stream, m->proj_rec(), n, world, masks, table, totals, d_send, capacity_records, list, d_list_n));
+    return GSX_OK;
+}
+
+gsx_status gsx_shard_set_windows(gsx_viewer* v, const char* key, const uint32_t* d_tile_window) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_set_windows: no model '%s'", key ? key : "(null)");
+    m->shard_win_set = d_tile_window != nullptr;
+    if (!d_tile_window) return GSX_OK;
+    const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
+    HIPCHK(m->shard_win.ensure(window_bytes(v)));
+    HIPCHK(hipMemcpyAsync(m->shard_win.p, d_tile_window, window_bytes(v), hipMemcpyDeviceToDevice, v->stream));
+    HIPCHK(m->shard_pyr.ensure(4 * window_pyramid_words(tiles_x, tiles_y)));
+    HIPCHK(launch_window_pyramid(v->stream, m->shard_win.as<uint2>(), tiles_x, tiles_y, m->shard_pyr.as<uint32_t>()));
+    m->shard_tiles_x = tiles_x;
+    m->shard_tiles_y = tiles_y;
     return GSX_OK;
 }
 

@@ -127,6 +127,7 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
 struct SlabStats {
     uint32_t n_visible;        // N_vis (projection pass / import)
     uint32_t n_sorted;         // records in the depth order of this frame (admission pass / import); <= n_visible
+    uint32_t n_candidates;     // lazily projected shard: records the admission let through (gsx_shard_set_windows)
     uint32_t n_entries;        // D of the slab being processed, clamped to the pair-buffer capacity
     uint32_t n_entries_total;  // sum of slab D over the frame
     uint32_t overflow;         // a slab needed more pair capacity than allocated: frame must be redone
@@ -182,6 +183,9 @@ hipError_t launch_admit_from_project(hipStream_t s, const uint32_t* key, uint32_
 // windows are [0, hi) and admission is CONSERVATIVE — every record some tile admits is admitted, plus a few more; the
 // binning applies the exact per-tile windows, so the surplus only rides through the depth sort.
 size_t admit_blocks(uint64_t n);
+// compaction from ballots over 4096-record workgroups (offsets = exclusively scanned per-workgroup counts)
+hipError_t launch_admit_scatter(hipStream_t s, const uint32_t* key, uint32_t n, const unsigned long long* ballots,
+                                const uint32_t* offsets, uint2* pairs);
 hipError_t launch_admit(hipStream_t s, const Records& rec, uint32_t n, const uint2* window, uint32_t tiles_x,
                         const uint32_t* gate, uint32_t row_words, const WindowPyramid& pyramid, const uint32_t* d_skip, unsigned long long* ballots, uint32_t* counts, uint32_t* d_total, uint2* pairs);
 
@@ -197,12 +201,15 @@ hipError_t launch_rowscan(hipStream_t s, uint32_t* table, uint32_t nrows, uint32
 size_t pack_blocks(uint64_t n);
 // rows_per_rank: rank g owns tile rows [g*rpr, min((g+1)*rpr, tiles_y)).  A record travels to g if its rectangle
 // touches g's band and (key < key_front_hi, or key >= key_back_lo and it touches a tile whose bit in open_map is 0).
-// window: uint2 [lo, hi) depth-key window per tile (tiles_y * tiles_x, row-major) or nullptr = every tile takes everything
+// window: uint2 [lo, hi) depth-key window per tile (tiles_y * tiles_x, row-major) or nullptr = every tile takes everything.
+// list / d_list_n (nullable): pack only these (key, index) candidates; the per-element arrays are then indexed by list position.
+// travellers / traveller_counts (nullable): ballots + per-workgroup counts of the elements that travel anywhere.
 hipError_t launch_pack_count(hipStream_t s, const Records& rec, uint32_t n, uint32_t world, uint32_t rows_per_rank,
-                             const uint2* window, uint32_t tiles_x, unsigned long long* masks, uint32_t* table);
+                             const uint2* window, uint32_t tiles_x, unsigned long long* masks, uint32_t* table,
+                             const uint2* list, const uint32_t* d_list_n, unsigned long long* travellers, uint32_t* traveller_counts);
 hipError_t launch_pack_scatter(hipStream_t s, const Records& rec, uint32_t n, uint32_t world,
                                const unsigned long long* masks, const uint32_t* table, const uint32_t* totals, void* d_send,
-                               uint64_t capacity);
+                               uint64_t capacity, const uint2* list, const uint32_t* d_list_n);
 hipError_t launch_import_records(hipStream_t s, const void* d_recv, uint32_t n, const Records& rec);
 
 // Mask evaluation (kernels_mask.hip); passed to the kernel by value.

@@ -129,6 +129,13 @@ hipError_t launch_admit_from_project(hipStream_t s, const uint32_t* key, uint32_
     return hipGetLastError();
 }
 
+hipError_t launch_admit_scatter(hipStream_t s, const uint32_t* key, uint32_t n, const unsigned long long* ballots,
+                                const uint32_t* offsets, uint2* pairs) {
+    const uint32_t nb = (uint32_t)admit_blocks(n);
+    if (nb) hipLaunchKernelGGL(k_admit_scatter, dim3(nb), dim3(kAdmitThreads), 0, s, key, n, ballots, offsets, pairs);
+    return hipGetLastError();
+}
+
 hipError_t launch_admit(hipStream_t s, const Records& rec, uint32_t n, const uint2* window, uint32_t tiles_x,
                         const uint32_t* gate, uint32_t row_words, const WindowPyramid& pyramid, const uint32_t* d_skip, unsigned long long* ballots, uint32_t* counts, uint32_t* d_total, uint2* pairs) {
     const uint32_t nb = (uint32_t)admit_blocks(n);

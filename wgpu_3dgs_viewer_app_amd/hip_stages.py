@@ -66,8 +66,10 @@ class HipStages:
         return self.viewer.frame_stats(key)
 
     # -- multi GPU (stage split of include/gsx.h) --
-    def begin_frame(self, key: str, world: int, rank: int) -> None:
-        """Project the resident shard and make sure the library renders into the padded framebuffer RCCL gathers into."""
+    def begin_frame(self, key: str, world: int, rank: int, window=None) -> None:
+        """Project the resident shard and make sure the library renders into the padded framebuffer RCCL gathers into.
+        ``window``: the windows of the coming exchange (``gsx_shard_set_windows``): the projection then shades only what can
+        travel, and ``pack(key, world, None)`` packs from that candidate list."""
         import torch
 
         v = self.viewer
@@ -80,6 +82,7 @@ class HipStages:
             self._fbk = None
             _lib.check(v._L.gsx_viewer_set_external_framebuffer(v._h, self._fb_t.data_ptr(), lay.padded_framebuffer_bytes))
         self._lay = lay
+        _lib.check(v._L.gsx_shard_set_windows(v._h, key.encode(), self._window_ptr(window, "_set_win_t")))
         v.preprocessor.preprocess(key)
 
     def _window_ptr(self, window, slot):
@@ -93,7 +96,8 @@ class HipStages:
         return t.data_ptr()
 
     def pack(self, key: str, world: int, window=None):
-        """``gsx_shard_pack``; ``window``: per-tile depth-key windows, numpy uint32 [tiles_y, tiles_x, 2] or None = all."""
+        """``gsx_shard_pack``; ``window``: per-tile depth-key windows, numpy uint32 [tiles_y, tiles_x, 2]; None = the windows
+        given to ``begin_frame`` (candidate list), or everything if there were none."""
         import torch
 
         v = self.viewer

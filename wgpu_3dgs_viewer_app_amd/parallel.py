@@ -226,15 +226,16 @@ class ShardedViewer:
 
             st.poll()
             self._t_last = time.perf_counter()
-        # stage P: project the resident shard
-        st.begin_frame(key, world, rank)
-        self._tick("project")
-        # stage X/C: every tile takes the records in front of its limit (first frame / speculation off: everything)
+        # every tile takes the records in front of its limit (first frame / speculation off: everything)
         limit = self._limit if self.speculate else None
         if limit is not None and limit.shape != (tiles_y, tiles_x):
             limit = None
         win = windows_first(limit) if limit is not None else None
-        send, counts = st.pack(key, world, win)
+        # stage P: project the resident shard; knowing the windows, it shades only what can travel
+        st.begin_frame(key, world, rank, win)
+        self._tick("project")
+        # stage X/C
+        send, counts = st.pack(key, world, None)
         self._tick("pack")
         recv, n = self._exchange(send, counts)
         self._tick("exchange")
