@@ -426,7 +426,7 @@ static gsx_status do_preprocess(gsx_viewer* v, Model* m) {
                      m->spec_tiles_y == m->fc.tiles_y;
     ProjectAdmission adm{};
     HIPCHK(m->adm_ballots.ensure(8 * ((std::max<size_t>(m->n, 1) + 63) / 64 + 4)));
-    HIPCHK(m->adm_counts.ensure(4 * std::max<size_t>(std::max(admit_blocks(m->n), (size_t)(m->n + 255) / 256), 1)));
+    HIPCHK(m->adm_counts.ensure(4 * (std::max<size_t>(std::max(admit_blocks(m->n), (size_t)(m->n + 255) / 256), 1) + 4)));
     const bool shard_lazy = m->shard_win_set && m->shard_tiles_x == m->fc.tiles_x && m->shard_tiles_y == m->fc.tiles_y;
     if (shard_lazy) m->spec_round1 = false;  // a sharded frame: the windows come from the caller, not from this viewer's last frame
     if (m->spec_round1) adm.pyramid = window_pyramid_layout(m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse.as<uint32_t>());

@@ -86,10 +86,16 @@ __global__ __launch_bounds__(1024) void k_admit_scan(uint32_t* __restrict__ coun
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < nblocks; base += 1024) {  // coalesced 1024-wide tiles, carry between them
-        const uint32_t i = base + tid;
-        const uint32_t v = i < nblocks ? counts[i] : 0u;
-        uint32_t x = v;
+    // coalesced 4096-wide tiles (one uint4 per lane; the buffer is padded to a multiple of 4), carry between them
+    for (uint32_t base = 0; base < nblocks; base += 4096) {
+        const uint32_t i = base + 4u * tid;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i < nblocks) v = *reinterpret_cast<const uint4*>(counts + i);
+        if (i + 1 >= nblocks) v.y = 0;
+        if (i + 2 >= nblocks) v.z = 0;
+        if (i + 3 >= nblocks) v.w = 0;
+        const uint32_t s4 = v.x + v.y + v.z + v.w;
+        uint32_t x = s4;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t y = __shfl_up(x, o, 64);
@@ -97,12 +103,20 @@ __global__ __launch_bounds__(1024) void k_admit_scan(uint32_t* __restrict__ coun
         }
         if (lane == 63) wsum[wave] = x;
         __syncthreads();
-        uint32_t woff = 0;
-        for (uint32_t w = 0; w < wave; ++w) woff += wsum[w];
-        const uint32_t carry = carry_s;
-        if (i < nblocks) counts[i] = carry + woff + x - v;
+        uint32_t off = carry_s + x - s4;
+        for (uint32_t w = 0; w < wave; ++w) off += wsum[w];
+        if (i < nblocks) {
+            const uint4 o4 = make_uint4(off, off + v.x, off + v.x + v.y, off + v.x + v.y + v.z);
+            if (i + 3 < nblocks) {
+                *reinterpret_cast<uint4*>(counts + i) = o4;
+            } else {
+                counts[i] = o4.x;
+                if (i + 1 < nblocks) counts[i + 1] = o4.y;
+                if (i + 2 < nblocks) counts[i + 2] = o4.z;
+            }
+        }
         __syncthreads();
-        if (tid == 1023) carry_s = carry + woff + x;
+        if (tid == 1023) carry_s = off + s4;
         __syncthreads();
     }
     if (tid == 0) *d_total = carry_s;
