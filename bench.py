@@ -37,6 +37,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="Gaussians in the CPU baseline sample")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded exchange path even at N=1")
+    ap.add_argument("--shard-mode", default="screen", help="N > 1: screen = whole scene on every GPU, rank g renders band g of "
+                    "tile rows, one all-gather (default) | index = splat-index shards + speculative record exchange")
     ap.add_argument("--pass-timing", default="project", help="project (the roofline kernel only; default) | all (every pass, adds "
                     "a few microseconds of stream gap per pass boundary)")
     ap.add_argument("--render-options", default="", help="gsx_render_options overrides, e.g. speculative=0,min_slab=1000000 (experiments)")
@@ -96,13 +98,14 @@ def main():
     cfg = (n, sh, w, h, seed)
 
     # --- resident scene: each rank generates and uploads only its index shard ---
-    start, count = parallel.shard_range(n, rank, world)
+    start, count = parallel.shard_range(n, rank, world) if args.shard_mode == "index" else (0, n)
     t0 = time.perf_counter()
     g = scene.synthetic_gaussians(n, seed, sh, start, count)
     t_gen = time.perf_counter() - t0
     sh_kind = {"single": 0, "half": 1, "norm8": 2, "none": 3}[args.pod.split("/")[0]]
     cov_kind = {"single": 0, "half": 1}[args.pod.split("/")[1]]
-    renderer = parallel.ShardedViewer(device=local_rank, world=world, rank=rank, use_dist=use_dist, sh=sh_kind, cov3d=cov_kind)
+    renderer = parallel.ShardedViewer(device=local_rank, world=world, rank=rank, use_dist=use_dist, sh=sh_kind, cov3d=cov_kind,
+                                      mode=args.shard_mode)
     if args.render_options:
         renderer.stages.viewer.set_render_options(**{k: float(x) if "." in x else int(x) for k, x in
                                                      (kv.split("=") for kv in args.render_options.split(","))})
@@ -215,7 +218,10 @@ def main():
             "config": {
                 "workload": f"{args.workload}: synthetic {n} Gaussians SH-deg-{sh}, {w}x{h}, orbit r=6 h=1.5 240 poses, seed {seed}",
                 "gaussians": n, "width": w, "height": h, "sh_degree": sh, "pod": args.pod, "pod_bytes": pod_bytes,
-                "sharding": f"splat-index shards x{world}" + (", tile-row exchange + gather" if use_dist else ""),
+                "sharding": ("one GPU" if not use_dist else
+                             (f"splat-index shards x{world}, speculative record exchange by tile-row band + band all-gather"
+                              if args.shard_mode == "index" else
+                              f"scene resident on each of {world} GPUs, rank g renders band g of tile rows, band all-gather")),
                 "n_visible_rank0": int(nvis_loc), "n_depth_sorted_rank0": int(nsort_loc), "tile_entries_rank0": int(entries),
                 "speculated_frames": round(float(spec_frac), 3), "frames_with_repair_round": round(float(repair_frac), 3),
                 "pass_ms_per_frame_rank0": passes,

@@ -310,6 +310,11 @@ typedef struct gsx_shard_layout_t {
     uint64_t padded_framebuffer_bytes;      /* world * band_bytes >= width * height * 16 */
 } gsx_shard_layout_t;
 gsx_status gsx_shard_layout(gsx_viewer* v, uint32_t world, uint32_t rank, gsx_shard_layout_t* out);
+/* Screen-band rendering: this viewer composites only the tile rows [row_lo, row_hi) (clamped to the frame); Gaussians
+ * whose tile rectangle misses the band are culled by gsx_preprocess, the other rows of the framebuffer are not touched.
+ * With the whole scene resident on every GPU (10 M Gaussians = 8 GB of 288 GB) rank g renders band g of
+ * gsx_shard_layout and the bands are all-gathered: no record exchange at all.  Default: every row. */
+gsx_status gsx_viewer_set_band(gsx_viewer* v, uint32_t row_lo, uint32_t row_hi);
 /* Render into caller-owned DEVICE memory (row-major [height][width] float4; may be padded below). NULL restores
  * the internal framebuffer. */
 gsx_status gsx_viewer_set_external_framebuffer(gsx_viewer* v, void* d_ptr, uint64_t bytes);

@@ -143,6 +143,13 @@ class OracleStages:
         self._world, self._rank = 1, 0
         self._composite(keys)
 
+    def render_band(self, keys, world, rank):
+        """screen-band mode: the whole scene is here; composite only this rank's band of tile rows"""
+        for k in keys:
+            self._imp[k] = self._lists(k, self._project(k))
+        self._world, self._rank = world, rank
+        self._composite(list(keys), world, rank)
+
     def begin_frame(self, key, world, rank, window=None):
         self._prs[key] = self._project(key)
         self._set_win = window

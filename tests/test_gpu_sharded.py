@@ -223,3 +223,36 @@ def test_cfg5_like_layered_models_mask_selection_edit():
     for rank, (frames, _) in enumerate(res):
         for i, fb in enumerate(frames):
             assert np.array_equal(fb, ref[i]), f"rank {rank} frame {i}: L-inf {np.abs(fb - ref[i]).max()}"
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_screen_band_mode_matches_single_viewer(world):
+    """mode="screen": whole scene on every rank, rank g renders band g (speculation per band included), bands gathered:
+    every rank's frame equals the single-viewer frame bit for bit, along a path with a camera jump."""
+    g = _scene()
+    poses = (57, 58, 59, 150, 151)
+    single = parallel.ShardedViewer(world=1, rank=0, use_dist=False)
+    single.load_shard(g, 0, N)
+    ref = []
+    for pose in poses:
+        single.render_frame(camera.orbit_pose(pose), (W, H))
+        single.poll()
+        ref.append(single.framebuffer().copy())
+    single.close()
+
+    def rank_main(rank, comm):
+        v = parallel.ShardedViewer(world=world, rank=rank, use_dist=True, comm=comm, mode="screen")
+        v.load_shard(g, 0, N)
+        frames, spec = [], []
+        for pose in poses:
+            v.render_frame(camera.orbit_pose(pose), (W, H))
+            v.poll()
+            frames.append(v.framebuffer().copy())
+            spec.append(v.last_stats()["speculated"])
+        v.close()
+        return frames, spec
+
+    for rank, (frames, spec) in enumerate(common.run_ranks(world, rank_main)):
+        assert spec == [False] + [True] * (len(poses) - 1)
+        for k, fb in enumerate(frames):
+            assert np.array_equal(fb, ref[k]), f"rank {rank} frame {k}: L-inf {np.abs(fb - ref[k]).max()}"

@@ -148,6 +148,39 @@ def test_sharded_layered_models_equal_single_process(world, tmp_path):
     assert not np.array_equal(single.framebuffer(), ref)
 
 
+def _screen_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        v = parallel.ShardedViewer(world=world, rank=rank, use_dist=True, stages=OracleStages(), mode="screen")
+        for key, (n, seed, _) in LAYERS.items():
+            v.load_shard(common.small_scene(n, seed, scale_mul=9.0), 0, n, key=key)  # the whole model on every rank
+        cam = camera.orbit_pose(21)
+        tr = {k: mt for k, (_, _, mt) in LAYERS.items()}
+        v.render_frame(cam, (W, H), keys=parallel.model_render_keys(cam.pos, tr), transforms=tr)
+        if rank == world - 1:
+            np.save(out_path, v.framebuffer())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_screen_band_mode_equals_single_process(world, tmp_path):
+    """mode="screen": every rank holds the whole scene and composites one band; the gathered frame is the single frame."""
+    cam = camera.orbit_pose(21)
+    tr = {k: mt for k, (_, _, mt) in LAYERS.items()}
+    keys = parallel.model_render_keys(cam.pos, tr)
+    single = parallel.ShardedViewer(world=1, rank=0, use_dist=False, stages=OracleStages())
+    for key, (n, seed, _) in LAYERS.items():
+        single.load_shard(common.small_scene(n, seed, scale_mul=9.0), 0, n, key=key)
+    single.render_frame(cam, (W, H), keys=keys, transforms=tr)
+    out = str(tmp_path / "fb.npy")
+    mp.spawn(_screen_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert np.array_equal(np.load(out), single.framebuffer())
+
+
 def test_limit_policy():
     import struct
 

@@ -21,6 +21,7 @@ ap.add_argument("--frames", type=int, default=30)
 ap.add_argument("--first", type=int, default=0, help="first orbit pose")
 ap.add_argument("--workload", default="cfg4")
 ap.add_argument("--no-speculate", action="store_true")
+ap.add_argument("--mode", default="index", help="index | screen")
 ap.add_argument("--margin", type=float, default=0.5)
 ap.add_argument("--radius", type=int, default=3)
 args = ap.parse_args()
@@ -28,14 +29,20 @@ n, sh, w, h, seed = scene.CONFIGS[args.workload]
 world = args.world
 
 
+whole = scene.synthetic_gaussians(n, seed, sh) if args.mode == "screen" else None
+
+
 def rank_main(rank, comm):
     s0, c = parallel.shard_range(n, rank, world)
-    v = parallel.ShardedViewer(world=world, rank=rank, use_dist=True, comm=comm)
+    v = parallel.ShardedViewer(world=world, rank=rank, use_dist=True, comm=comm, mode=args.mode)
     v.speculate = not args.no_speculate
     v.margin = args.margin
     v.radius = args.radius
     v.debug = rank == 0
-    v.load_shard(scene.synthetic_gaussians(n, seed, sh, s0, c), s0, n)
+    if args.mode == "screen":
+        v.load_shard(whole, 0, n)
+    else:
+        v.load_shard(scene.synthetic_gaussians(n, seed, sh, s0, c), s0, n)
     v.poll()
     rounds, sent = [], []
     for f in range(args.frames + 2):
@@ -62,6 +69,6 @@ res = common.run_ranks(world, rank_main)
 for r in res:
     print(json.dumps(r))
 two = float(np.mean([x == 2 for x in res[0]["rounds"]]))
-print(f"world {world} {args.workload} speculate={not args.no_speculate} margin={args.margin} radius={args.radius}: mean MB sent per rank per frame "
+print(f"mode {args.mode} world {world} {args.workload} speculate={not args.no_speculate} margin={args.margin} radius={args.radius}: mean MB sent per rank per frame "
       f"{np.mean([r['sent_MB'] for r in res]):.2f} (max rank {max(r['sent_MB'] for r in res):.2f}), "
       f"frames needing the second exchange: {100 * two:.0f} %")

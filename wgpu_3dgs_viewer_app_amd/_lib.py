@@ -26,7 +26,7 @@ EXPORTS = (
     "gsx_render_frame", "gsx_download_framebuffer", "gsx_download_rgba8", "gsx_framebuffer_device_ptr",
     "gsx_model_frame_stats", "gsx_model_download_projection", "gsx_model_download_sorted",
     "gsx_model_download_tile_lists", "gsx_model_download_pod", "gsx_set_pass_timing", "gsx_get_pass_timing",
-    "gsx_mask_evaluate", "gsx_ply_read_header", "gsx_ply_read_gaussians", "gsx_ply_write", "gsx_render_options_default", "gsx_viewer_set_render_options", "gsx_shard_layout", "gsx_viewer_set_external_framebuffer", "gsx_shard_pack", "gsx_shard_import", "gsx_shard_feedback_words", "gsx_shard_feedback", "gsx_shard_set_windows",
+    "gsx_mask_evaluate", "gsx_ply_read_header", "gsx_ply_read_gaussians", "gsx_ply_write", "gsx_render_options_default", "gsx_viewer_set_render_options", "gsx_shard_layout", "gsx_viewer_set_external_framebuffer", "gsx_shard_pack", "gsx_shard_import", "gsx_shard_feedback_words", "gsx_shard_feedback", "gsx_shard_set_windows", "gsx_viewer_set_band",
     "gsx_render_more",
     "gsx_gaussian_edit_default", "gsx_update_query", "gsx_update_query_texture", "gsx_update_selection_highlight",
     "gsx_update_selection_edit", "gsx_model_show_unedited", "gsx_postprocess", "gsx_model_upload_selection",
@@ -153,6 +153,7 @@ def load() -> C.CDLL:
         "gsx_shard_pack": ([vp, cp, u32, vp, vp, u64, C.POINTER(u64)], C.c_int32),
         "gsx_shard_import": ([vp, cp, vp, u64, u32, u32, vp], C.c_int32),
         "gsx_shard_set_windows": ([vp, cp, vp], C.c_int32),
+        "gsx_viewer_set_band": ([vp, u32, u32], C.c_int32),
         "gsx_shard_feedback_words": ([vp, u32, C.POINTER(u32)], C.c_int32),
         "gsx_shard_feedback": ([vp, cp, u32, u32, vp], C.c_int32),
         "gsx_render_more": ([vp, C.POINTER(cp), u32], C.c_int32),

@@ -200,6 +200,7 @@ struct gsx_viewer {
     DevBuf frame_done;        // u32: tiles saturated so far in the current frame (all models)
     std::vector<std::string> last_keys;  // keys of the last gsx_render, for the overflow redo
     bool last_render_cont = false;
+    uint32_t band_lo = 0, band_hi = 0xFFFFFFFFu;  // tile rows this viewer renders (gsx_viewer_set_band)
     gsx_query query{};                   // GSX_QUERY_NONE
     DevBuf query_texture;
     uint32_t query_tex_w = 0, query_tex_h = 0;
@@ -397,14 +398,16 @@ static gsx_status ensure_edit_buffers(gsx_viewer* v, Model* m) {
 static gsx_status do_preprocess(gsx_viewer* v, Model* m) {
     frame_consts_setup(v->view, v->proj, v->width, v->height, m->mt, v->size, v->display_mode, v->sh_deg, v->no_sh0,
                        v->params, &m->fc);
+    m->fc.band_lo = std::min(v->band_lo, m->fc.tiles_y);
+    m->fc.band_hi = std::min(v->band_hi, m->fc.tiles_y);
     m->preprocessed = m->sorted = m->counters_valid = m->binned = false;
     gsx_status st = ensure_record_capacity(m, m->n);
     if (st) return st;
     if ((st = ensure_sortbin_capacity(m, m->n))) return st;
     m->use_imported = false;
     m->rec_n = m->n;
-    m->row_lo = 0;
-    m->row_hi = 0xFFFFFFFFu;
+    m->row_lo = m->fc.band_lo;
+    m->row_hi = m->fc.band_hi;
     // selection edit / stored edits / highlight: only when something of the kind exists (spec §7)
     const uint32_t n32 = (uint32_t)m->n;
     const size_t words = ((size_t)m->n + 31) / 32;
@@ -695,7 +698,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
             ScopedPass t(v, GSX_PASS_DEPTH_SORT);
             HIPCHK(m->spec_need.ensure(4 * (size_t)row_words * m->fc.tiles_y));
             HIPCHK(launch_spec_verify(v->stream, m->spec_win.as<uint2>(), done, row_words, m->fc.tiles_x, m->fc.tiles_y,
-                                      m->spec_win2.as<uint2>(), m->spec_need.as<uint32_t>(), &dc->spec_need));
+                                      m->spec_win2.as<uint2>(), m->spec_need.as<uint32_t>(), &dc->spec_need, row_lo, row_hi));
             HIPCHK(m->adm_ballots2.ensure(8 * ((std::max<size_t>(n, 1) + 63) / 64)));
             HIPCHK(launch_admit(v->stream, m->proj_rec(), n, m->spec_win2.as<uint2>(), m->fc.tiles_x, m->spec_need.as<uint32_t>(),
                                 row_words, WindowPyramid{}, &dc->spec_need,
@@ -716,7 +719,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
     if (speculate) {  // this model's windows for its next frame
         ScopedPass t(v, GSX_PASS_COMPOSITE);
         HIPCHK(launch_spec_next(v->stream, tile_sat, done, done_before, row_words, m->fc.tiles_x, m->fc.tiles_y,
-                                v->options.spec_margin, v->options.spec_radius, m->spec_win.as<uint2>()));
+                                v->options.spec_margin, v->options.spec_radius, m->spec_win.as<uint2>(), row_lo, row_hi));
         HIPCHK(m->spec_coarse.ensure(4 * window_pyramid_words(m->fc.tiles_x, m->fc.tiles_y)));
         HIPCHK(launch_window_pyramid(v->stream, m->spec_win.as<uint2>(), m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse.as<uint32_t>()));
         m->spec_valid = true;
@@ -1617,6 +1620,14 @@ gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, const 
                     (unsigned long long)sum, (unsigned long long)capacity_records);
     if (sum && !d_send) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack: d_send is null");
     HIPCHK(launch_pack_scatter(v->stream, m->proj_rec(), n, world, masks, table, totals, d_send, capacity_records, list, d_list_n));
+    return GSX_OK;
+}
+
+gsx_status gsx_viewer_set_band(gsx_viewer* v, uint32_t row_lo, uint32_t row_hi) {
+    if (!v) return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_set_band: viewer is null");
+    if (row_lo > row_hi) return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_set_band: row_lo %u > row_hi %u", row_lo, row_hi);
+    v->band_lo = row_lo;
+    v->band_hi = row_hi;
     return GSX_OK;
 }
 

@@ -26,6 +26,8 @@ struct FrameConsts {
     float low_pass, cull_margin, alpha_max, alpha_min, point_radius, t_eps;
     uint32_t w_px, h_px, tiles_x, tiles_y;
     uint32_t sh_deg, no_sh0, display_mode;
+    uint32_t band_lo, band_hi;  // tile rows this viewer renders (gsx_viewer_set_band; 0 .. tiles_y = everything): a Gaussian
+                                // whose rectangle misses the band is culled
 };
 
 struct ModelTransform {
@@ -191,10 +193,11 @@ hipError_t launch_admit(hipStream_t s, const Records& rec, uint32_t n, const uin
 
 // Temporal occlusion speculation (kernels_spec.hip): verification of this frame's windows, windows of the next frame.
 hipError_t launch_spec_verify(hipStream_t s, const uint2* win1, const uint32_t* done, uint32_t row_words, uint32_t tiles_x,
-                              uint32_t tiles_y, uint2* win2, uint32_t* need_bits, uint32_t* d_need);
+                              uint32_t tiles_y, uint2* win2, uint32_t* need_bits, uint32_t* d_need, uint32_t band_lo, uint32_t band_hi);
 hipError_t launch_zero_words(hipStream_t s, uint32_t* a, uint32_t na, uint32_t* b, uint32_t nb);
 hipError_t launch_spec_next(hipStream_t s, const uint32_t* tile_sat, const uint32_t* done, const uint32_t* done_before,
-                            uint32_t row_words, uint32_t tiles_x, uint32_t tiles_y, float margin, uint32_t radius, uint2* win_next);
+                            uint32_t row_words, uint32_t tiles_x, uint32_t tiles_y, float margin, uint32_t radius, uint2* win_next,
+                            uint32_t band_lo, uint32_t band_hi);
 
 // Multi-GPU exchange support (kernels_shard.hip).
 hipError_t launch_rowscan(hipStream_t s, uint32_t* table, uint32_t nrows, uint32_t nblocks, uint32_t* totals);

@@ -40,6 +40,8 @@ static inline float hdot3(float a0, float a1, float a2, float b0, float b1, floa
 void frame_consts_setup(const float view[16], const float proj[16], uint32_t width, uint32_t height,
                         const ModelTransform& mt, float size, uint32_t display_mode, uint32_t sh_deg, uint32_t no_sh0,
                         const gsx_spec_params& sp, FrameConsts* f) {
+    f->band_lo = 0;
+    f->band_hi = (height + GSX_TILE - 1) / GSX_TILE;
     float R[9], W[9], WR[9];
     quat_rows(mt.quat, R);
     for (int r = 0; r < 3; ++r)
@@ -376,6 +378,8 @@ __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint
     Splat2D sp{};
     // the covariance planes are only fetched for Gaussians that survive the frustum test
     if (vis) vis = load_cov2d_rect<COVK>(f, pod, i, vc, sp);
+    // screen-band rendering (one band of tile rows per GPU over a replicated scene): what misses the band is culled
+    if (vis && ((sp.ry >> 16) <= f.band_lo || (sp.ry & 0xFFFFu) >= f.band_hi)) vis = false;
 
     bool take = vis;
     if (adm.pyramid.data && vis) take = pyramid_admits(adm.pyramid, __float_as_uint(vc.d), sp.rx, sp.ry);

@@ -9,6 +9,8 @@
 // exactly those tiles the records they were refused, [hi, inf), composited behind — so every tile always blends a
 // gap-free depth prefix and the frame is bit-identical to the unspeculated one.  Everything stays on the device: no
 // host round trip, the second round's kernels fall through when nothing needs repair.
+#include <algorithm>
+
 #include "gsx_internal.h"
 
 namespace gsx {
@@ -32,7 +34,7 @@ hipError_t launch_zero_words(hipStream_t s, uint32_t* a, uint32_t na, uint32_t* 
 __global__ __launch_bounds__(256) void k_spec_verify(const uint2* __restrict__ win1, const uint32_t* __restrict__ done,
                                                       uint32_t row_words, uint32_t tiles_x, uint32_t n_tiles,
                                                       uint2* __restrict__ win2, uint32_t* __restrict__ need_bits,
-                                                      uint32_t* __restrict__ d_need) {
+                                                      uint32_t* __restrict__ d_need, uint32_t band_lo, uint32_t band_hi) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     // the need bitmap, one thread per word (no clear, no atomics): bit = bounded window && still open
     const uint32_t tiles_y = n_tiles / tiles_x;
@@ -41,13 +43,13 @@ __global__ __launch_bounds__(256) void k_spec_verify(const uint2* __restrict__ w
         uint32_t bits = 0;
         for (uint32_t b = 0; b < 32u && x0 + b < tiles_x; ++b)
             if (win1[ty * tiles_x + x0 + b].y != kKeyAll) bits |= 1u << b;
-        need_bits[t] = bits & ~done[t];
+        need_bits[t] = (ty >= band_lo && ty < band_hi) ? (bits & ~done[t]) : 0u;
     }
     bool need = false;
     if (t < n_tiles) {
         const uint32_t tx = t % tiles_x, ty = t / tiles_x;
         const uint2 w = win1[t];
-        need = w.y != kKeyAll && !((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u);
+        need = ty >= band_lo && ty < band_hi && w.y != kKeyAll && !((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u);
         win2[t] = need ? make_uint2(w.y, kKeyAll) : make_uint2(0u, 0u);
     }
     const unsigned long long bal = __ballot(need);
@@ -59,13 +61,18 @@ __global__ __launch_bounds__(256) void k_spec_verify(const uint2* __restrict__ w
 __global__ __launch_bounds__(256) void k_spec_next(const uint32_t* __restrict__ tile_sat, const uint32_t* __restrict__ done,
                                                     const uint32_t* __restrict__ done_before, uint32_t row_words,
                                                     uint32_t tiles_x, uint32_t tiles_y, float gain, int radius,
-                                                    uint2* __restrict__ win_next) {
+                                                    uint2* __restrict__ win_next, int band_lo, int band_hi) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= tiles_x * tiles_y) return;
     const int tx = (int)(t % tiles_x), ty = (int)(t / tiles_x);
+    if (ty < band_lo || ty >= band_hi) {  // not this viewer's band: takes nothing
+        win_next[t] = make_uint2(0u, 0u);
+        return;
+    }
     float deepest = 0.0f;
     bool open = false;
-    for (int y = max(ty - radius, 0); y <= min(ty + radius, (int)tiles_y - 1); ++y)
+    // the neighbourhood is clipped to the band: tiles outside are never composited here and say nothing
+    for (int y = max(ty - radius, band_lo); y <= min(ty + radius, band_hi - 1); ++y)
         for (int x = max(tx - radius, 0); x <= min(tx + radius, (int)tiles_x - 1); ++x) {
             const uint32_t w = (uint32_t)y * row_words + ((uint32_t)x >> 5), b = (uint32_t)x & 31u;
             if (!((done[w] >> b) & 1u)) {
@@ -126,19 +133,20 @@ hipError_t launch_window_pyramid(hipStream_t s, const uint2* window, uint32_t ti
 }
 
 hipError_t launch_spec_verify(hipStream_t s, const uint2* win1, const uint32_t* done, uint32_t row_words, uint32_t tiles_x,
-                              uint32_t tiles_y, uint2* win2, uint32_t* need_bits, uint32_t* d_need) {
+                              uint32_t tiles_y, uint2* win2, uint32_t* need_bits, uint32_t* d_need, uint32_t band_lo, uint32_t band_hi) {
     // *d_need is zero here (the frame's counters are reset before the first slab)
     const uint32_t n_tiles = tiles_x * tiles_y;
     hipLaunchKernelGGL(k_spec_verify, dim3((n_tiles + 255) / 256), dim3(256), 0, s, win1, done, row_words, tiles_x, n_tiles, win2,
-                       need_bits, d_need);
+                       need_bits, d_need, band_lo, band_hi);
     return hipGetLastError();
 }
 
 hipError_t launch_spec_next(hipStream_t s, const uint32_t* tile_sat, const uint32_t* done, const uint32_t* done_before,
-                            uint32_t row_words, uint32_t tiles_x, uint32_t tiles_y, float margin, uint32_t radius, uint2* win_next) {
+                            uint32_t row_words, uint32_t tiles_x, uint32_t tiles_y, float margin, uint32_t radius, uint2* win_next,
+                            uint32_t band_lo, uint32_t band_hi) {
     const uint32_t n_tiles = tiles_x * tiles_y;
     hipLaunchKernelGGL(k_spec_next, dim3((n_tiles + 255) / 256), dim3(256), 0, s, tile_sat, done, done_before, row_words, tiles_x,
-                       tiles_y, 1.0f + margin, (int)radius, win_next);
+                       tiles_y, 1.0f + margin, (int)radius, win_next, (int)std::min(band_lo, tiles_y), (int)std::min(band_hi, tiles_y));
     return hipGetLastError();
 }
 

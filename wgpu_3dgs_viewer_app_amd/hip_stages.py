@@ -85,6 +85,23 @@ class HipStages:
         _lib.check(v._L.gsx_shard_set_windows(v._h, key.encode(), self._window_ptr(window, "_set_win_t")))
         v.preprocessor.preprocess(key)
 
+    def render_band(self, keys, world: int, rank: int) -> None:
+        """Screen-band mode (the whole scene is resident on every GPU): render band `rank` of `world` into the padded
+        framebuffer the bands are all-gathered into.  No record exchange; enqueued without host synchronisation."""
+        import torch
+
+        v = self.viewer
+        lay = _lib.ShardLayout()
+        _lib.check(v._L.gsx_shard_layout(v._h, world, rank, C.byref(lay)))
+        n_floats = lay.padded_framebuffer_bytes // 4
+        if self._fb_t is None or self._fb_t.numel() != n_floats:
+            self._fb_t = torch.zeros(n_floats, dtype=torch.float32, device=f"cuda:{self.device}")
+            self._band_t = torch.empty(lay.band_bytes // 4, dtype=torch.float32, device=f"cuda:{self.device}")
+            _lib.check(v._L.gsx_viewer_set_external_framebuffer(v._h, self._fb_t.data_ptr(), lay.padded_framebuffer_bytes))
+        self._lay = lay
+        _lib.check(v._L.gsx_viewer_set_band(v._h, lay.row_lo, lay.row_hi))
+        v.render_frame(list(keys))
+
     def _window_ptr(self, window, slot):
         """numpy uint32 [tiles_y, tiles_x, 2] -> device pointer (the library copies it, the tensor is kept until reused)."""
         import torch
