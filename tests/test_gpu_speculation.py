@@ -219,3 +219,63 @@ def test_full_size_bit_identity():
     assert a[..., 3].min() < 1e-4  # the scene saturates: there is something to speculate on
     spec.close()
     plain.close()
+
+
+def test_cfg5_full_size_layered_models():
+    """BASELINE.json configs[4] at full size: 4 models x 6 M Gaussians (24 M), each with its own TRS, a `0 - 1` mask op on one
+    of them, a rect selection with an HSV edit on another, 3840x2160.  No oracle finishes this; the properties checked:
+    speculated frames equal unspeculated ones bit for bit, layering order matters, the mask and the edit take effect."""
+    from wgpu_3dgs_viewer_app_amd import parallel, scene
+    from wgpu_3dgs_viewer_app_amd.mask import MaskEvaluator, MaskOp, MaskShape, MaskShapeKind
+
+    n_total, sh, w, h, seed = scene.CONFIGS["cfg5"]
+    n = n_total // 4
+    tr = {"a": camera.ModelTransform(pos=np.array([0.0, 0.0, 2.5], np.float32)),
+          "b": camera.ModelTransform(pos=np.array([2.0, 0.2, -1.0], np.float32), rot=np.array([0, 35, 0], np.float32)),
+          "c": camera.ModelTransform(pos=np.array([-2.5, -0.1, -0.5], np.float32), scale=np.array([0.9, 0.9, 0.9], np.float32)),
+          "d": common.odd_transform()}
+    spec, plain = MultiModelViewer(), MultiModelViewer()
+    plain.set_render_options(speculative=0)
+    for i, k in enumerate(tr):
+        g = scene.synthetic_gaussians(n, seed + i, sh)
+        for v in (spec, plain):
+            _load(v, k, g, tr[k])
+        del g
+    shapes = [MaskShape(MaskShapeKind.Box, pos=np.array([0.0, 0.0, 2.5], np.float32), scale=np.array([3.0, 3.0, 3.0], np.float32)),
+              MaskShape(MaskShapeKind.Ellipsoid, pos=np.array([0.0, 0.0, 2.5], np.float32), scale=np.array([1.5, 1.5, 1.5], np.float32))]
+    rect = query.QueryPod.rect((1200.0, 600.0), (2600.0, 1500.0), query.QuerySelectionOp.Set)
+    edit = query.GaussianEditPod(query.GaussianEditFlag.ENABLED, (0.5, 1.0, 1.2), 0.1, 0.2, 1.0, 0.9)
+    frames = []
+    for step, pose in enumerate([10, 11, 12, 13]):
+        cam = camera.orbit_pose(pose)
+        keys = parallel.model_render_keys(cam.pos, tr)
+        out = []
+        for v in (spec, plain):
+            if step == 1:
+                MaskEvaluator(v).evaluate(MaskOp.parse("0 - 1"), "a", shapes)
+            v.update_query(rect if step == 2 else query.QueryPod.none())
+            if step == 3:
+                v.update_selection_edit_with_pod(edit)
+            out.append(_frame(v, cam, keys, (w, h)))
+            for k in keys:
+                v.postprocessor.postprocess(k)
+            v.poll()
+        if not np.array_equal(out[0], out[1]):
+            d = np.abs(out[0] - out[1]).max(-1)
+            ys, xs = np.nonzero(d)
+            raise AssertionError(f"step {step}: L-inf {d.max()}, {ys.size} px, rows {ys.min()}..{ys.max()}, cols {xs.min()}..{xs.max()}, "
+                                 f"spec {[spec.frame_stats(k) for k in keys]} plain {[plain.frame_stats(k) for k in keys]}")
+        frames.append(out[0])
+        if step:
+            assert any(spec.frame_stats(k)["speculated"] for k in keys)
+    nsel = sum(int(np.unpackbits(spec.models[k].gaussian_buffers.selection_buffer.download().view(np.uint8)).sum()) for k in tr)
+    assert nsel > 1000, "the rectangle must select something"
+    assert sum(spec.frame_stats(k)["n_visible"] for k in tr) > 5_000_000
+    kept = int(np.unpackbits(spec.models["a"].gaussian_buffers.mask_buffer.download().view(np.uint8)).sum())
+    assert 0 < kept < n
+    # layering matters at this size too
+    cam = camera.orbit_pose(13)
+    keys = parallel.model_render_keys(cam.pos, tr)
+    assert not np.array_equal(_frame(plain, cam, keys[::-1], (w, h)), frames[-1])
+    spec.close()
+    plain.close()

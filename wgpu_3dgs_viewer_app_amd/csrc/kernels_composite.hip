@@ -38,12 +38,19 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConsts f, uint2* _
     const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
     const uint2 range = ranges[tile];
     const size_t fbo = (size_t)py * f.w_px + px;
-    // progressive mode: leave the range table clean for the next slab (saves a memset per slab)
-    if (clear_ranges && tid == 0 && range.y > range.x) ranges[tile] = make_uint2(0u, 0u);
+    // Progressive mode leaves the range table clean for the next slab (saves a memset per slab).  EVERY lane reads
+    // ranges[tile] itself, so the entry may only be zeroed once all four waves have read it: on the early-return path
+    // that is harmless (a wave that reads the zeroed entry returns as well), on the main path it happens after the
+    // list loop, whose barriers every wave has passed by then.  (Zeroing it up front lost whole waves of pixels whenever
+    // wave 0 ran a memory round trip ahead of the others — seen on the first frame of a 24 M-Gaussian 4K scene.)
+    const bool had_entries = range.y > range.x;
 
     // Later depth slabs / models behind continue from the (C, T) the framebuffer already holds; a tile
     // with nothing new to blend, or already saturated, leaves it untouched.
-    if (carry && (range.x >= range.y || (done_bits && ((done_bits[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)))) return;
+    if (carry && (range.x >= range.y || (done_bits && ((done_bits[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)))) {
+        if (clear_ranges && tid == 0 && had_entries) ranges[tile] = make_uint2(0u, 0u);
+        return;
+    }
     float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     if (carry && inside) {
         const float4 p = fb[fbo];
@@ -108,6 +115,7 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConsts f, uint2* _
         }
     }
     if (inside) fb[fbo] = make_float4(C0, C1, C2, T);
+    if (clear_ranges && tid == 0 && had_entries) ranges[tile] = make_uint2(0u, 0u);
     if (done_bits && __syncthreads_and(done)) {
         // the tile saturated in this launch: its last pixels stopped here, behind everything blended earlier
         if (tile_sat) {
