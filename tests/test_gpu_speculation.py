@@ -204,21 +204,28 @@ def test_full_size_bit_identity():
 
     n, sh, w, h, seed = scene.CONFIGS["cfg4"]
     g = scene.synthetic_gaussians(n, seed, sh)
-    spec, plain = MultiModelViewer(), MultiModelViewer()
+    spec, plain, flat = MultiModelViewer(), MultiModelViewer(), MultiModelViewer()
     plain.set_render_options(speculative=0)
+    flat.set_render_options(speculative=0, progressive=0)   # one pass over every tile entry: the plainest schedule
     _load(spec, "m", g)
     _load(plain, "m", g)
+    _load(flat, "m", g)
     del g
     for k, pose in enumerate([0, 1, 2, 3, 120, 121]):
         cam = camera.orbit_pose(pose)
         a, b = _frame(spec, cam, ["m"], (w, h)), _frame(plain, cam, ["m"], (w, h))
         assert np.array_equal(a, b), f"pose {pose}: L-inf {np.abs(a - b).max()}"
+        if pose in (0, 120):  # includes every viewer's very first frame
+            c = _frame(flat, cam, ["m"], (w, h))
+            assert np.array_equal(a, c), f"pose {pose}: slabbed / speculated frame differs from the one-pass frame, L-inf {np.abs(a - c).max()}"
+            assert flat.frame_stats("m")["n_tile_entries"] > 3 * plain.frame_stats("m")["n_tile_entries"]
         st = spec.frame_stats("m")
         if k:
             assert st["speculated"] and st["n_sorted"] < 0.15 * st["n_visible"], st
     assert a[..., 3].min() < 1e-4  # the scene saturates: there is something to speculate on
     spec.close()
     plain.close()
+    flat.close()
 
 
 def test_cfg5_full_size_layered_models():
