@@ -121,7 +121,7 @@ struct Model {
     uint32_t flags_kind = GSX_QUERY_NONE, flags_op = GSX_SELECTION_SET;  // what the last preprocess evaluated
     // temporal occlusion speculation (kernels_spec.hip): this model's per-tile windows for its next frame, the repair
     // windows of the current one, the saturated-tile bitmap as it was before this model was composited
-    DevBuf spec_win, spec_win2, spec_done_before, spec_need, spec_coarse;
+    DevBuf spec_win, spec_win2, spec_done_before, spec_need, spec_coarse, spec_coarse2;
     bool spec_valid = false, spec_round1 = false;
     uint32_t spec_tiles_x = 0, spec_tiles_y = 0, shard_tiles_x = 0, shard_tiles_y = 0;
     // lazily projected shard (gsx_shard_set_windows): the windows of the coming exchange, their max-pyramid, and whether the
@@ -700,8 +700,14 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
             HIPCHK(launch_spec_verify(v->stream, m->spec_win.as<uint2>(), done, row_words, m->fc.tiles_x, m->fc.tiles_y,
                                       m->spec_win2.as<uint2>(), m->spec_need.as<uint32_t>(), &dc->spec_need, row_lo, row_hi));
             HIPCHK(m->adm_ballots2.ensure(8 * ((std::max<size_t>(n, 1) + 63) / 64)));
-            HIPCHK(launch_admit(v->stream, m->proj_rec(), n, m->spec_win2.as<uint2>(), m->fc.tiles_x, m->spec_need.as<uint32_t>(),
-                                row_words, WindowPyramid{}, &dc->spec_need,
+            // conservative admission against the min-pyramid of the repair windows' starts (four loads per record; the
+            // binning applies the exact windows): an exact per-tile scan of every visible record cost 260-350 us here
+            HIPCHK(m->spec_coarse2.ensure(4 * window_pyramid_words(m->fc.tiles_x, m->fc.tiles_y)));
+            HIPCHK(launch_window_pyramid(v->stream, m->spec_win2.as<uint2>(), m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse2.as<uint32_t>(), true, &dc->spec_need));
+            WindowPyramid pyr2 = window_pyramid_layout(m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse2.as<uint32_t>());
+            pyr2.min_of_starts = 1;
+            HIPCHK(launch_admit(v->stream, m->proj_rec(), n, nullptr, m->fc.tiles_x, nullptr,
+                                row_words, pyr2, &dc->spec_need,
                                 m->adm_ballots2.as<unsigned long long>(), m->adm_counts.as<uint32_t>(), &dc->n_sorted2,
                                 m->adm_pairs.as<uint2>()));
             if (m->lazy) {  // the repair round needs records the lazy projection did not shade

@@ -86,6 +86,8 @@ struct WindowPyramid {
     uint32_t off[9];       // first element of level l
     uint32_t wx[9], wy[9]; // cells per row / column of level l
     uint32_t levels;       // level (levels - 1) is a single cell
+    uint32_t min_of_starts; // 0: cells hold the largest window END (admit key < it); 1: the smallest START among non-empty
+                            // windows, KEY_ALL if none (admit key >= it) — the repair round's windows [hi, inf)
 };
 // What the projection kernel needs to decide admission in place (see kernels_admit.hip): ballots[i / 64] = admitted
 // lanes of Gaussians i..i+63, block_counts[i / 256] = admitted per workgroup.
@@ -171,7 +173,8 @@ hipError_t launch_selection_op(hipStream_t s, uint32_t n_words, uint32_t op, con
 
 WindowPyramid window_pyramid_layout(uint32_t tiles_x, uint32_t tiles_y, const uint32_t* data);  // total words: off[levels]... see .hip
 size_t window_pyramid_words(uint32_t tiles_x, uint32_t tiles_y);
-hipError_t launch_window_pyramid(hipStream_t s, const uint2* window, uint32_t tiles_x, uint32_t tiles_y, uint32_t* data);
+hipError_t launch_window_pyramid(hipStream_t s, const uint2* window, uint32_t tiles_x, uint32_t tiles_y, uint32_t* data,
+                                 bool min_of_starts = false, const uint32_t* d_skip = nullptr);
 
 // exclusive scan of the projection pass's per-workgroup counts (total -> *d_total), then the compaction of the admitted
 // (key, index) pairs in ascending index order

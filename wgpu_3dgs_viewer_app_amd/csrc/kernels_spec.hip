@@ -113,8 +113,13 @@ size_t window_pyramid_words(uint32_t tiles_x, uint32_t tiles_y) {
 }
 
 // one workgroup builds every level (11 k words at 1080p): level 0 = the window ends, level l = 2x2 max of level l-1
-__global__ __launch_bounds__(1024) void k_window_pyramid(const uint2* __restrict__ window, WindowPyramid p, uint32_t* __restrict__ data) {
-    for (uint32_t i = threadIdx.x; i < p.wx[0] * p.wy[0]; i += 1024) data[i] = window[i].y;
+__global__ __launch_bounds__(1024) void k_window_pyramid(const uint2* __restrict__ window, WindowPyramid p, uint32_t* __restrict__ data,
+                                                         const uint32_t* __restrict__ d_skip) {
+    if (d_skip && *d_skip == 0) return;  // repair round with nothing to repair
+    for (uint32_t i = threadIdx.x; i < p.wx[0] * p.wy[0]; i += 1024) {
+        const uint2 w = window[i];
+        data[i] = p.min_of_starts ? (w.y > w.x ? w.x : 0xFFFFFFFFu) : w.y;
+    }
     for (uint32_t l = 1; l < p.levels; ++l) {
         __syncthreads();
         const uint32_t wx = p.wx[l], wy = p.wy[l], px = p.wx[l - 1], py = p.wy[l - 1];
@@ -122,13 +127,17 @@ __global__ __launch_bounds__(1024) void k_window_pyramid(const uint2* __restrict
         uint32_t* dst = data + p.off[l];
         for (uint32_t i = threadIdx.x; i < wx * wy; i += 1024) {
             const uint32_t x = 2u * (i % wx), y = 2u * (i / wx), x1 = min(x + 1u, px - 1u), y1 = min(y + 1u, py - 1u);
-            dst[i] = max(max(src[y * px + x], src[y * px + x1]), max(src[y1 * px + x], src[y1 * px + x1]));
+            const uint32_t a = src[y * px + x], b = src[y * px + x1], c = src[y1 * px + x], d = src[y1 * px + x1];
+            dst[i] = p.min_of_starts ? min(min(a, b), min(c, d)) : max(max(a, b), max(c, d));
         }
     }
 }
 
-hipError_t launch_window_pyramid(hipStream_t s, const uint2* window, uint32_t tiles_x, uint32_t tiles_y, uint32_t* data) {
-    hipLaunchKernelGGL(k_window_pyramid, dim3(1), dim3(1024), 0, s, window, window_pyramid_layout(tiles_x, tiles_y, data), data);
+hipError_t launch_window_pyramid(hipStream_t s, const uint2* window, uint32_t tiles_x, uint32_t tiles_y, uint32_t* data,
+                                 bool min_of_starts, const uint32_t* d_skip) {
+    WindowPyramid p = window_pyramid_layout(tiles_x, tiles_y, data);
+    p.min_of_starts = min_of_starts ? 1u : 0u;
+    hipLaunchKernelGGL(k_window_pyramid, dim3(1), dim3(1024), 0, s, window, p, data, d_skip);
     return hipGetLastError();
 }
 

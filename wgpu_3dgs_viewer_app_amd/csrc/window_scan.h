@@ -115,8 +115,9 @@ __device__ inline bool pyramid_admits(const WindowPyramid& p, uint32_t key, uint
     const uint32_t* L = p.data + p.off[l];
     const uint32_t wx = p.wx[l];
     const uint32_t cx0 = x0 >> l, cx1 = min(xb >> l, wx - 1u), cy0 = y0 >> l, cy1 = min(yb >> l, p.wy[l] - 1u);
-    const uint32_t u = max(max(L[cy0 * wx + cx0], L[cy0 * wx + cx1]), max(L[cy1 * wx + cx0], L[cy1 * wx + cx1]));
-    return key < u;
+    const uint32_t a = L[cy0 * wx + cx0], b = L[cy0 * wx + cx1], c = L[cy1 * wx + cx0], d = L[cy1 * wx + cx1];
+    if (p.min_of_starts) return key >= min(min(a, b), min(c, d));
+    return key < max(max(a, b), max(c, d));
 }
 
 }  // namespace gsx
