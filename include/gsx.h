@@ -87,7 +87,9 @@ typedef struct gsx_spec_params {
  * the tile's (2 spec_radius + 1)^2 neighbourhood, enter this frame's depth sort and binning.  The compositor verifies
  * the assumption on the device and a second round hands the tiles that are still open the records they were refused,
  * composited behind — pixels stay identical to speculative = 0 whatever the camera does; a wrong guess only costs
- * time.  After such a frame gsx_model_download_sorted returns the second round's (possibly empty) order. */
+ * time.  After such a frame gsx_model_download_sorted returns the second round's (possibly empty) order, and the model
+ * must go through gsx_preprocess + gsx_sort again before it is rendered once more (the app does so every frame;
+ * gsx_render refuses otherwise: the frame's admission belongs to windows the frame has replaced). */
 typedef struct gsx_render_options {
     uint32_t progressive;        /* default 1 */
     uint32_t first_slab_divisor; /* default 16 */

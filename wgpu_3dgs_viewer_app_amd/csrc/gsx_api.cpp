@@ -123,6 +123,7 @@ struct Model {
     // windows of the current one, the saturated-tile bitmap as it was before this model was composited
     DevBuf spec_win, spec_win2, spec_done_before, spec_need, spec_coarse, spec_coarse2;
     bool spec_valid = false, spec_round1 = false;
+    bool order_consumed = false;   // a speculated render overwrote the depth order with its repair round's
     uint32_t spec_tiles_x = 0, spec_tiles_y = 0, shard_tiles_x = 0, shard_tiles_y = 0;
     // lazily projected shard (gsx_shard_set_windows): the windows of the coming exchange, their max-pyramid, and whether the
     // last preprocess left a candidate list in adm_pairs
@@ -132,6 +133,7 @@ struct Model {
     bool lazy = false;             // this frame's projection shaded only the admitted Gaussians
     const uint32_t* last_pyramid = nullptr;  // the admission pyramid the projection pass used
     uint32_t* last_pod_mask = nullptr;  // the keep-bitset the projection pass used (mask, or mask & ~hidden)
+    DevBuf adm_offsets, adm_counts2;  // scan output of adm_counts; counts of the admission passes that run outside the projection
     DevBuf adm_pairs, adm_ballots, adm_counts;  // admission pass: compacted (key, index) pairs, per-wave ballots, per-workgroup counts
     DevBuf pack_masks;             // destination bit mask per record (gsx_shard_pack)
     DevBuf window, pack_window;    // per-tile depth-key windows [lo, hi): of the imported set / of the pack in flight
@@ -401,6 +403,7 @@ static gsx_status do_preprocess(gsx_viewer* v, Model* m) {
     m->fc.band_lo = std::min(v->band_lo, m->fc.tiles_y);
     m->fc.band_hi = std::min(v->band_hi, m->fc.tiles_y);
     m->preprocessed = m->sorted = m->counters_valid = m->binned = false;
+    m->order_consumed = false;
     gsx_status st = ensure_record_capacity(m, m->n);
     if (st) return st;
     if ((st = ensure_sortbin_capacity(m, m->n))) return st;
@@ -453,8 +456,10 @@ static gsx_status do_preprocess(gsx_viewer* v, Model* m) {
         // exactly those their conic / colour records; gsx_shard_pack then looks at nothing else
         Counters* dcx = m->counters.as<Counters>();
         HIPCHK(m->adm_pairs.ensure(8 * std::max<size_t>(m->n, 1)));
+        HIPCHK(m->adm_offsets.ensure(m->adm_counts.bytes));
         HIPCHK(launch_admit_from_project(v->stream, m->proj_rec().key, n32, m->adm_ballots.as<unsigned long long>(),
-                                         m->adm_counts.as<uint32_t>(), &dcx->n_candidates, m->adm_pairs.as<uint2>()));
+                                         m->adm_counts.as<uint32_t>(), m->adm_offsets.as<uint32_t>(), &dcx->n_candidates,
+                                         m->adm_pairs.as<uint2>()));
         if (m->lazy) HIPCHK(launch_shade(v->stream, m->fc, n32, pod, m->proj_rec(), LateProjection{m->adm_pairs.as<uint2>(), &dcx->n_candidates, nullptr}));
         m->cand_valid = true;
     }
@@ -519,12 +524,16 @@ static gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
                 gsx_status stc = complete_records(v, m);
                 if (stc) return stc;
                 m->spec_round1 = false;
+                HIPCHK(m->adm_ballots2.ensure(8 * ((std::max<size_t>(n, 1) + 63) / 64)));
+                HIPCHK(m->adm_counts2.ensure(4 * (std::max<size_t>(admit_blocks(n), 1) + 4)));
                 HIPCHK(launch_admit(v->stream, m->proj_rec(), n, nullptr, m->fc.tiles_x, nullptr, 0, WindowPyramid{}, nullptr,
-                                    m->adm_ballots.as<unsigned long long>(), m->adm_counts.as<uint32_t>(), &dc->n_sorted,
+                                    m->adm_ballots2.as<unsigned long long>(), m->adm_counts2.as<uint32_t>(), &dc->n_sorted,
                                     m->adm_pairs.as<uint2>()));
             } else {
+                HIPCHK(m->adm_offsets.ensure(m->adm_counts.bytes));
                 HIPCHK(launch_admit_from_project(v->stream, m->proj_rec().key, n, m->adm_ballots.as<unsigned long long>(),
-                                                 m->adm_counts.as<uint32_t>(), &dc->n_sorted, m->adm_pairs.as<uint2>()));
+                                                 m->adm_counts.as<uint32_t>(), m->adm_offsets.as<uint32_t>(), &dc->n_sorted,
+                                                 m->adm_pairs.as<uint2>()));
                 if (m->lazy) {  // the projection pass was geometry only: shade what it admitted
                     PodPlanes pod = m->pod();
                     pod.mask = m->last_pod_mask;
@@ -540,6 +549,7 @@ static gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
     }
     m->stats_pending = true;
     m->sorted = true;
+    if (force_full) m->order_consumed = false;  // an unspeculated order over every visible record: renderable again
     m->binned = false;
     m->n_entries = 0;
     return GSX_OK;
@@ -583,6 +593,10 @@ static void merge_tail_slabs(std::vector<uint32_t>* bounds, uint32_t used) {
 // remaining slabs' kernels fall through.  carry: the framebuffer already holds nearer models.
 static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
     if (!m->sorted) return fail(GSX_ERR_INVALID_ARG, "gsx_render: model '%s' was not preprocessed+sorted", m->key.c_str());
+    if (m->order_consumed)
+        return fail(GSX_ERR_INVALID_ARG, "gsx_render: the depth order of '%s' was consumed by a speculated frame's repair round; "
+                    "call gsx_preprocess + gsx_sort('%s') again before rendering it once more (its admission belongs to the windows "
+                    "that frame replaced)", m->key.c_str(), m->key.c_str());
     if (m->fc.w_px != v->width || m->fc.h_px != v->height)
         return fail(GSX_ERR_INVALID_ARG, "gsx_render: viewport changed since gsx_preprocess('%s')", m->key.c_str());
     const uint32_t n_tiles = m->fc.tiles_x * m->fc.tiles_y;
@@ -700,6 +714,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
             HIPCHK(launch_spec_verify(v->stream, m->spec_win.as<uint2>(), done, row_words, m->fc.tiles_x, m->fc.tiles_y,
                                       m->spec_win2.as<uint2>(), m->spec_need.as<uint32_t>(), &dc->spec_need, row_lo, row_hi));
             HIPCHK(m->adm_ballots2.ensure(8 * ((std::max<size_t>(n, 1) + 63) / 64)));
+            HIPCHK(m->adm_counts2.ensure(4 * (std::max<size_t>(admit_blocks(n), 1) + 4)));
             // conservative admission against the min-pyramid of the repair windows' starts (four loads per record; the
             // binning applies the exact windows): an exact per-tile scan of every visible record cost 260-350 us here
             HIPCHK(m->spec_coarse2.ensure(4 * window_pyramid_words(m->fc.tiles_x, m->fc.tiles_y)));
@@ -708,7 +723,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
             pyr2.min_of_starts = 1;
             HIPCHK(launch_admit(v->stream, m->proj_rec(), n, nullptr, m->fc.tiles_x, nullptr,
                                 row_words, pyr2, &dc->spec_need,
-                                m->adm_ballots2.as<unsigned long long>(), m->adm_counts.as<uint32_t>(), &dc->n_sorted2,
+                                m->adm_ballots2.as<unsigned long long>(), m->adm_counts2.as<uint32_t>(), &dc->n_sorted2,
                                 m->adm_pairs.as<uint2>()));
             if (m->lazy) {  // the repair round needs records the lazy projection did not shade
                 PodPlanes pod = m->pod();
@@ -721,6 +736,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
             HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted2, 32, false));
         }
         if ((st = run_slab(0, n, true, m->spec_win2.as<uint2>(), &dc->n_sorted2, (uint32_t)bounds.size()))) return st;
+        m->order_consumed = true;
     }
     if (speculate) {  // this model's windows for its next frame
         ScopedPass t(v, GSX_PASS_COMPOSITE);

@@ -80,7 +80,9 @@ __global__ __launch_bounds__(kAdmitThreads) void k_admit_scatter(const uint32_t*
 
 // ---- compaction straight from the projection pass (its ballots: one word per wave, counts per 256-Gaussian workgroup) ----
 // one workgroup: exclusive scan of counts[0..nblocks) in place, total -> *d_total
-__global__ __launch_bounds__(1024) void k_admit_scan(uint32_t* __restrict__ counts, uint32_t nblocks, uint32_t* __restrict__ d_total) {
+// (counts stay as the projection pass wrote them: a model may be sorted again without being projected again)
+__global__ __launch_bounds__(1024) void k_admit_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets, uint32_t nblocks,
+                                                     uint32_t* __restrict__ d_total) {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry_s;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -108,11 +110,11 @@ __global__ __launch_bounds__(1024) void k_admit_scan(uint32_t* __restrict__ coun
         if (i < nblocks) {
             const uint4 o4 = make_uint4(off, off + v.x, off + v.x + v.y, off + v.x + v.y + v.z);
             if (i + 3 < nblocks) {
-                *reinterpret_cast<uint4*>(counts + i) = o4;
+                *reinterpret_cast<uint4*>(offsets + i) = o4;
             } else {
-                counts[i] = o4.x;
-                if (i + 1 < nblocks) counts[i + 1] = o4.y;
-                if (i + 2 < nblocks) counts[i + 2] = o4.z;
+                offsets[i] = o4.x;
+                if (i + 1 < nblocks) offsets[i + 1] = o4.y;
+                if (i + 2 < nblocks) offsets[i + 2] = o4.z;
             }
         }
         __syncthreads();
@@ -135,11 +137,11 @@ __global__ __launch_bounds__(256) void k_admit_scatter256(const uint32_t* __rest
 }
 
 hipError_t launch_admit_from_project(hipStream_t s, const uint32_t* key, uint32_t n, const unsigned long long* ballots,
-                                     uint32_t* block_counts, uint32_t* d_total, uint2* pairs) {
+                                     const uint32_t* block_counts, uint32_t* block_offsets, uint32_t* d_total, uint2* pairs) {
     const uint32_t nb = (n + 255) / 256;
     if (!nb) return hipMemsetAsync(d_total, 0, 4, s);
-    hipLaunchKernelGGL(k_admit_scan, dim3(1), dim3(1024), 0, s, block_counts, nb, d_total);
-    hipLaunchKernelGGL(k_admit_scatter256, dim3(nb), dim3(256), 0, s, key, n, ballots, block_counts, pairs);
+    hipLaunchKernelGGL(k_admit_scan, dim3(1), dim3(1024), 0, s, block_counts, block_offsets, nb, d_total);
+    hipLaunchKernelGGL(k_admit_scatter256, dim3(nb), dim3(256), 0, s, key, n, ballots, block_offsets, pairs);
     return hipGetLastError();
 }
 

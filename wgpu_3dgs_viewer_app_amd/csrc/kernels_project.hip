@@ -536,7 +536,7 @@ hipError_t launch_project(hipStream_t s, const FrameConsts& f, uint32_t n, const
 hipError_t launch_shade(hipStream_t s, const FrameConsts& f, uint32_t n, const PodPlanes& pod, const Records& rec,
                         const LateProjection& late) {
     if (n == 0) return hipSuccess;
-    return dispatch_project(s, dim3(1024), f, n, pod, rec, nullptr, ProjectAdmission{}, &late);  // 256 k lanes stride over the admitted records
+    return dispatch_project(s, dim3(4096), f, n, pod, rec, nullptr, ProjectAdmission{}, &late);  // 1 M lanes stride over the admitted records
 }
 
 }  // namespace gsx
