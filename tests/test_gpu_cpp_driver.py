@@ -1,5 +1,6 @@
 """GPU: the C++ gs:: facade (include/gsx.hpp) driven by tools/frame_driver.cpp replays the app's frame protocol;
-the same LCG scene pushed through the Python mirror must give the bit-identical framebuffer (FNV-1a checksum)."""
+the same LCG scene pushed through the Python mirror must give the same frame (to the ulps of the two host-side camera
+restatements), the same cull counts, paint order and selection."""
 import os
 import re
 import subprocess
@@ -74,10 +75,29 @@ def test_cpp_facade_matches_python_mirror(tmp_path):
         v.renderer.render(keys)
         fb = v.download_framebuffer()
         va, vb = v.frame_stats("a")["n_visible"], v.frame_stats("b")["n_visible"]
+        # the second frame of the driver: rect selection through the same protocol
+        from wgpu_3dgs_viewer_app_amd import query
+
+        v.update_query(query.QueryPod.rect((60.0, 40.0), (250.0, 160.0), query.QuerySelectionOp.Set))
+        v.update_selection_highlight((1.0, 0.0, 1.0, 0.5))
+        for key in ("a", "b"):
+            v.preprocessor.preprocess(key)
+            v.radix_sorter.sort(key)
+        v.renderer.render(keys)
+        for key in ("a", "b"):
+            v.postprocessor.postprocess(key)
+        v.poll()
+        selected = sum(int(np.unpackbits(v.models[k].gaussian_buffers.selection_buffer.download().view(np.uint8)).sum()) for k in ("a", "b"))
     assert [m.group(4), m.group(5)] == keys
     assert (int(m.group(1)), int(m.group(3))) == (va, vb)
     cpp = np.fromfile(dump, np.float32).reshape(h, w, 4)
     assert int(m.group(6), 16) == fnv1a(cpp.tobytes())
+    # glam's look_at_rh / perspective_rh / from_euler are restated twice on the host (C++ float32 vs numpy float32, different
+    # operation order): the matrices agree to an ulp or two, so do the frames — not bit for bit
+    err = float(np.abs(cpp - fb).max())
+    assert err <= 2e-4, f"the C++ facade's frame differs from the Python mirror's: L-inf {err}"
+    ms = re.search(r"selected=(\d+)", out.stdout)
+    assert ms and int(ms.group(1)) == selected and selected > 50, (out.stdout, selected)
     # camera matrices / the model quaternion are float32 on both sides but come from different libm calls (last-bit
     # differences), so the frames agree to rounding rather than bit-for-bit
     assert np.abs(cpp - fb).max() <= 2e-4

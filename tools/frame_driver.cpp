@@ -71,6 +71,24 @@ int main(int argc, char** argv) {
         printf("frame_driver n_a=%llu vis_a=%llu n_b=%llu vis_b=%llu order=%s,%s fnv=%016llx\n", (unsigned long long)sa.n_gaussians,
                (unsigned long long)sa.n_visible, (unsigned long long)sb.n_gaussians, (unsigned long long)sb.n_visible, keys[0].c_str(),
                keys[1].c_str(), (unsigned long long)hash);
+        // a second frame through the selection protocol (scene.rs:785-835, 601-611): rect query -> postprocess -> selection bits
+        gsx_query q{};
+        q.kind = GSX_QUERY_RECT;
+        q.selection_op = GSX_SELECTION_SET;
+        q.p0[0] = 60.0f; q.p0[1] = 40.0f; q.p1[0] = 250.0f; q.p1[1] = 160.0f;
+        viewer.update_query(q);
+        viewer.update_selection_highlight({1.0f, 0.0f, 1.0f, 0.5f});
+        for (auto& m : models) {
+            viewer.preprocessor.preprocess(m.key);
+            viewer.radix_sorter.sort(m.key);
+        }
+        viewer.renderer.render(keys);
+        for (auto& m : models) viewer.postprocessor.postprocess(m.key);
+        viewer.poll();
+        size_t selected = 0;
+        for (auto& m : models)
+            for (uint32_t word : viewer.models.at(m.key).gaussian_buffers.selection_buffer.download(m.g->size())) selected += (size_t)__builtin_popcount(word);
+        printf("frame_driver selected=%zu\n", selected);
         // error convention: a missing model is a gs::Error, not a crash
         try { viewer.preprocessor.preprocess("missing"); return 2; } catch (const gs::Error& e) { if (e.status != GSX_ERR_NOT_FOUND) return 3; }
         if (gs::GaussianShDegree::new_(4)) return 4;
