@@ -1,0 +1,552 @@
+// gsx_frame.cpp — frame scheduling of libgsx.so: what gsx_preprocess / gsx_sort / gsx_render enqueue on the viewer's stream.
+//
+// Mirrors the per-frame protocol the app drives (src/tab/scene.rs:699-874 and 2263-2326): per visible model preprocess (K1)
+// + radix sort (K2), then the far -> near render loop (K3).  Nothing here waits for the device: counts stay in HBM, the host
+// plans upper bounds, overflow and statistics are looked at lazily (finish_frame).
+#include "gsx_state.h"
+
+namespace gsx {
+
+thread_local std::string g_err;
+
+gsx_status fail(gsx_status st, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return st;
+}
+
+gsx_status ply_fail(gsx_status st, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return st;
+}
+
+
+// Frames are enqueued without any host round trip; this is where the host catches up: wait for the
+// stream, mirror the per-model statistics, and if a depth slab needed more tile-pair capacity than was
+// allocated, grow the buffers and redo the last gsx_render (rare: capacity starts at 16 entries/record).
+gsx_status finish_frame(gsx_viewer* v) {
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        bool pending = false;
+        for (auto& kv : v->models) pending |= kv.second->stats_pending;
+        if (!pending) return GSX_OK;
+        for (auto& kv : v->models) {
+            Model* m = kv.second.get();
+            if (m->stats_pending)
+                HIPCHK(hipMemcpyAsync(m->h_counters, m->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, v->stream));
+        }
+        HIPCHK(hipStreamSynchronize(v->stream));
+        bool redo = false;
+        for (auto& kv : v->models) {
+            Model* m = kv.second.get();
+            if (!m->stats_pending) continue;
+            m->stats_pending = false;
+            m->n_visible = m->h_counters->n_visible;
+            m->n_sorted = m->h_counters->n_sorted;
+            m->n_sorted2 = m->h_counters->n_sorted2;
+            m->n_entries = m->h_counters->n_entries_total;
+            m->counters_valid = true;
+            if (m->binned) m->slabs_hint = m->h_counters->slabs_used;
+            m->stats_copy_inflight = false;
+            if (m->h_counters->overflow && m->binned) {
+                m->tile_cap = std::max<uint64_t>(2 * m->tile_cap, (uint64_t)m->h_counters->max_needed + 1024);
+                if (v->last_render_cont || m->rec_n != m->n)
+                    return fail(GSX_ERR_OOM, "tile-pair capacity overflow in a sharded frame (model '%s'); capacity grown for the "
+                                "next frame, this frame is incomplete", m->key.c_str());
+                redo = true;
+            }
+        }
+        if (!redo) return GSX_OK;
+        std::vector<const char*> keys;
+        for (auto& k : v->last_keys) keys.push_back(k.c_str());
+        for (auto& k : v->last_keys) {  // a speculated frame is redone unspeculated: its depth order was consumed
+            Model* m = find_model(v, k.c_str());
+            if (m && m->spec_round1) {
+                m->spec_valid = false;
+                gsx_status st2 = do_sort(v, m, true);
+                if (st2) return st2;
+            }
+        }
+        gsx_status st = do_render(v, keys.data(), (uint32_t)keys.size());
+        if (st) return st;
+    }
+    return fail(GSX_ERR_OOM, "tile-pair buffers kept overflowing");
+}
+
+
+// buffers sized by the model (projection outputs)
+gsx_status ensure_record_capacity(Model* m, uint64_t count) {
+    if (count <= m->rec_cap) return GSX_OK;
+    const size_t n = std::max<uint64_t>(count, 1);
+    HIPCHK(m->key_buf.ensure(4 * n));
+    HIPCHK(m->rec_a.ensure(16 * n));
+    HIPCHK(m->rec_b.ensure(16 * n));
+    HIPCHK(m->rec_c.ensure(16 * n));
+    HIPCHK(m->block_vis.ensure(4 * (project_blocks(n) + 1)));
+    m->rec_cap = n;
+    return GSX_OK;
+}
+
+// buffers sized by the frame's active record set (depth sort + per-slab binning)
+gsx_status ensure_sortbin_capacity(Model* m, uint64_t count) {
+    if (count <= m->sortbin_cap) return GSX_OK;
+    const size_t n = std::max<uint64_t>(count + count / 8, 1);
+    HIPCHK(m->dp_a.ensure(8 * n));
+    HIPCHK(m->dp_b.ensure(8 * n));
+    HIPCHK(m->sk_out.ensure(4 * n));
+    HIPCHK(m->sv_out.ensure(4 * n));
+    {
+        const size_t ws = 4 * radix_workspace_words(n);
+        if (ws > m->sort_ws.bytes) {
+            HIPCHK(m->sort_ws.ensure(ws));
+            HIPCHK(hipMemset(m->sort_ws.p, 0, m->sort_ws.bytes));  // status words must not alias a live epoch
+        }
+    }
+    HIPCHK(m->cnt.ensure(4 * n));
+    HIPCHK(m->srect.ensure(8 * n));
+    HIPCHK(m->block_sums.ensure(4 * (scan_blocks(n) + 1)));
+    m->sortbin_cap = n;
+    return GSX_OK;
+}
+
+gsx_status ensure_import_capacity(Model* m, uint64_t count) {
+    if (count > m->imp_cap) {
+        const size_t n = std::max<uint64_t>(count + count / 8, 1);
+        HIPCHK(m->imp_key.ensure(4 * n));
+        HIPCHK(m->imp_a.ensure(16 * n));
+        HIPCHK(m->imp_b.ensure(16 * n));
+        HIPCHK(m->imp_c.ensure(16 * n));
+        m->imp_cap = n;
+    }
+    return ensure_sortbin_capacity(m, count);
+}
+
+gsx_status ensure_selection(gsx_viewer* v, Model* m) {
+    const size_t bytes = 4 * std::max<size_t>(((size_t)m->n + 31) / 32, 1);
+    if (m->selection.bytes < bytes) {
+        HIPCHK(m->selection.ensure(bytes));
+        HIPCHK(hipMemsetAsync(m->selection.p, 0, bytes, v->stream));
+    }
+    return GSX_OK;
+}
+
+gsx_status ensure_edit_buffers(gsx_viewer* v, Model* m) {
+    const size_t words = std::max<size_t>(((size_t)m->n + 31) / 32, 1), n = std::max<size_t>(m->n, 1);
+    if (m->edited.bytes < 4 * words) {
+        HIPCHK(m->edited.ensure(4 * words));
+        HIPCHK(hipMemsetAsync(m->edited.p, 0, 4 * words, v->stream));
+        HIPCHK(m->keep.ensure(4 * words));
+        HIPCHK(m->edit_a.ensure(16 * n));
+        HIPCHK(m->edit_b.ensure(16 * n));
+    }
+    return GSX_OK;
+}
+
+gsx_status do_preprocess(gsx_viewer* v, Model* m) {
+    frame_consts_setup(v->view, v->proj, v->width, v->height, m->mt, v->size, v->display_mode, v->sh_deg, v->no_sh0,
+                       v->params, &m->fc);
+    m->fc.band_lo = std::min(v->band_lo, m->fc.tiles_y);
+    m->fc.band_hi = std::min(v->band_hi, m->fc.tiles_y);
+    m->preprocessed = m->sorted = m->counters_valid = m->binned = false;
+    m->order_consumed = false;
+    gsx_status st = ensure_record_capacity(m, m->n);
+    if (st) return st;
+    if ((st = ensure_sortbin_capacity(m, m->n))) return st;
+    m->use_imported = false;
+    m->rec_n = m->n;
+    m->row_lo = m->fc.band_lo;
+    m->row_hi = m->fc.band_hi;
+    // selection edit / stored edits / highlight: only when something of the kind exists (spec §7)
+    const uint32_t n32 = (uint32_t)m->n;
+    const size_t words = ((size_t)m->n + 31) / 32;
+    const bool sel_edit_on = m->has_selection && (v->sel_edit.flag & GSX_EDIT_ENABLED);
+    const bool edits_on = !m->show_unedited && (m->has_edits || sel_edit_on);
+    const bool highlight_on = m->has_selection && v->highlight[3] > 0.0f;
+    PodPlanes pod = m->pod();
+    if (edits_on) {
+        if ((st = ensure_edit_buffers(v, m))) return st;
+        HIPCHK(launch_edit_prepare(v->stream, n32, m->has_selection ? m->selection.as<uint32_t>() : nullptr,
+                                   m->edited.as<uint32_t>(), m->edit_a.as<float4>(), m->edit_b.as<float4>(), v->sel_edit, pod.mask,
+                                   m->keep.as<uint32_t>()));
+        m->has_edits = true;
+        pod.mask = m->keep.as<uint32_t>();
+    }
+    // admission is decided inside the projection kernel: every visible Gaussian, or — when this model has windows from
+    // its previous frame — the conservative max-pyramid test of the temporal occlusion speculation
+    m->spec_round1 = v->options.progressive && v->options.speculative && m->spec_valid && m->spec_tiles_x == m->fc.tiles_x &&
+                     m->spec_tiles_y == m->fc.tiles_y;
+    ProjectAdmission adm{};
+    HIPCHK(m->adm_ballots.ensure(8 * ((std::max<size_t>(m->n, 1) + 63) / 64 + 4)));
+    HIPCHK(m->adm_counts.ensure(4 * (std::max<size_t>(std::max(admit_blocks(m->n), (size_t)(m->n + 255) / 256), 1) + 4)));
+    const bool shard_lazy = m->shard_win_set && m->shard_tiles_x == m->fc.tiles_x && m->shard_tiles_y == m->fc.tiles_y;
+    if (shard_lazy) m->spec_round1 = false;  // a sharded frame: the windows come from the caller, not from this viewer's last frame
+    if (m->spec_round1) adm.pyramid = window_pyramid_layout(m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse.as<uint32_t>());
+    if (shard_lazy) adm.pyramid = window_pyramid_layout(m->fc.tiles_x, m->fc.tiles_y, m->shard_pyr.as<uint32_t>());
+    adm.ballots = m->adm_ballots.as<unsigned long long>();
+    adm.block_counts = m->adm_counts.as<uint32_t>();
+    // lazy shading: nothing else reads the conic / colour records of this frame (no edit, highlight or query pass)
+    m->lazy = (m->spec_round1 || shard_lazy) && !edits_on && !highlight_on && v->query.kind == GSX_QUERY_NONE;
+    m->cand_valid = false;
+    adm.lazy = m->lazy ? 1u : 0u;
+    m->last_pod_mask = pod.mask;
+    m->last_pyramid = adm.pyramid.data;
+    {
+        ScopedPass t(v, GSX_PASS_PROJECT);  // brackets the projection kernel alone (bench.py's roofline kernel)
+        HIPCHK(launch_project(v->stream, m->fc, n32, pod, m->proj_rec(), m->block_vis.as<uint32_t>(), adm));
+        v->pass_launches[GSX_PASS_PROJECT] += m->n ? 1 : 0;
+    }
+    HIPCHK(launch_sum_counts(v->stream, m->block_vis.as<uint32_t>(), n32, &m->counters.as<Counters>()->n_visible));
+    if (shard_lazy) {
+        // the candidates of the coming exchange (a conservative superset of the travellers): compact them and give
+        // exactly those their conic / colour records; gsx_shard_pack then looks at nothing else
+        Counters* dcx = m->counters.as<Counters>();
+        HIPCHK(m->adm_pairs.ensure(8 * std::max<size_t>(m->n, 1)));
+        HIPCHK(m->adm_offsets.ensure(m->adm_counts.bytes));
+        HIPCHK(launch_admit_from_project(v->stream, m->proj_rec().key, n32, m->adm_ballots.as<unsigned long long>(),
+                                         m->adm_counts.as<uint32_t>(), m->adm_offsets.as<uint32_t>(), &dcx->n_candidates,
+                                         m->adm_pairs.as<uint2>()));
+        if (m->lazy) HIPCHK(launch_shade(v->stream, m->fc, n32, pod, m->proj_rec(), LateProjection{m->adm_pairs.as<uint2>(), &dcx->n_candidates, nullptr}));
+        m->cand_valid = true;
+    }
+    if (edits_on || highlight_on)
+        HIPCHK(launch_edit_apply(v->stream, n32, m->proj_rec(), highlight_on ? m->selection.as<uint32_t>() : nullptr,
+                                 edits_on ? m->edited.as<uint32_t>() : nullptr, m->edit_a.as<float4>(), m->edit_b.as<float4>(),
+                                 v->highlight));
+    m->flags_kind = GSX_QUERY_NONE;
+    if (v->query.kind != GSX_QUERY_NONE) {
+        if (v->query.kind == GSX_QUERY_HIT) {
+            HIPCHK(m->hits.ensure(sizeof(gsx_query_hit) * (size_t)GSX_QUERY_MAX_HITS));
+            HIPCHK(m->hit_count.ensure(4));
+            HIPCHK(hipMemsetAsync(m->hit_count.p, 0, 4, v->stream));
+        } else {
+            HIPCHK(m->query_flags.ensure(4 * std::max<size_t>(words, 1)));
+            if (v->query.kind == GSX_QUERY_TEXTURE && (v->query_tex_w != v->width || v->query_tex_h != v->height))
+                return fail(GSX_ERR_INVALID_ARG, "gsx_preprocess: texture query without a viewport-sized query texture (gsx_update_query_texture)");
+        }
+        HIPCHK(launch_query(v->stream, n32, m->proj_rec(), v->query, v->query_texture.as<uint8_t>(), v->query_tex_w, v->query_tex_h,
+                            m->fc, m->query_flags.as<uint32_t>(), m->hits.as<gsx_query_hit>(), m->hit_count.as<uint32_t>(),
+                            GSX_QUERY_MAX_HITS));
+        m->flags_kind = v->query.kind;
+        m->flags_op = v->query.selection_op;
+    }
+    m->stats_pending = true;
+    m->preprocessed = true;
+    return GSX_OK;
+}
+
+// A lazily shaded frame left the conic / colour records of the refused Gaussians unwritten; whoever needs all of them
+// (parity download, multi-GPU pack, a redone frame) gets them by running the projection again, unlazily: same values.
+gsx_status complete_records(gsx_viewer* v, Model* m) {
+    if (!m->lazy || !m->preprocessed) return GSX_OK;
+    ProjectAdmission adm{};
+    adm.pyramid = window_pyramid_layout(m->fc.tiles_x, m->fc.tiles_y, m->last_pyramid);
+    adm.ballots = m->adm_ballots.as<unsigned long long>();
+    HIPCHK(m->block_sums.ensure(4 * std::max<size_t>((m->n + 255) / 256, 1)));
+    adm.block_counts = m->block_sums.as<uint32_t>();  // scratch: the admission counts were consumed by the compaction
+    PodPlanes pod = m->pod();
+    pod.mask = m->last_pod_mask;
+    HIPCHK(launch_project(v->stream, m->fc, (uint32_t)m->n, pod, m->proj_rec(), m->block_vis.as<uint32_t>(), adm));
+    m->lazy = false;
+    return GSX_OK;
+}
+
+// force_full: ignore the admission the projection pass made (a speculated frame being redone) and sort every visible record
+gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
+    if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_sort('%s') before gsx_preprocess", m->key.c_str());
+    const uint32_t n = (uint32_t)m->rec_n;
+    Counters* dc = m->counters.as<Counters>();
+    {
+        ScopedPass t(v, GSX_PASS_DEPTH_SORT);
+        if (m->use_imported) {  // every imported record is visible: sort the keys as they lie
+            m->spec_round1 = false;
+            RadixBuffers rb{m->rec().key, nullptr, nullptr, m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
+                            m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
+            HIPCHK(launch_radix_sort(v->stream, rb, n, nullptr, 32, true));
+        } else {
+            // compact the (key, index) pairs the projection pass admitted, then sort only those
+            HIPCHK(m->adm_pairs.ensure(8 * std::max<size_t>(n, 1)));
+            if (force_full) {
+                gsx_status stc = complete_records(v, m);
+                if (stc) return stc;
+                m->spec_round1 = false;
+                HIPCHK(m->adm_ballots2.ensure(8 * ((std::max<size_t>(n, 1) + 63) / 64)));
+                HIPCHK(m->adm_counts2.ensure(4 * (std::max<size_t>(admit_blocks(n), 1) + 4)));
+                HIPCHK(launch_admit(v->stream, m->proj_rec(), n, nullptr, m->fc.tiles_x, nullptr, 0, WindowPyramid{}, nullptr,
+                                    m->adm_ballots2.as<unsigned long long>(), m->adm_counts2.as<uint32_t>(), &dc->n_sorted,
+                                    m->adm_pairs.as<uint2>()));
+            } else {
+                HIPCHK(m->adm_offsets.ensure(m->adm_counts.bytes));
+                HIPCHK(launch_admit_from_project(v->stream, m->proj_rec().key, n, m->adm_ballots.as<unsigned long long>(),
+                                                 m->adm_counts.as<uint32_t>(), m->adm_offsets.as<uint32_t>(), &dc->n_sorted,
+                                                 m->adm_pairs.as<uint2>()));
+                if (m->lazy) {  // the projection pass was geometry only: shade what it admitted
+                    PodPlanes pod = m->pod();
+                    pod.mask = m->last_pod_mask;
+                    HIPCHK(launch_shade(v->stream, m->fc, n, pod, m->proj_rec(), LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted, nullptr}));
+                }
+            }
+            RadixBuffers rb{nullptr, nullptr, m->adm_pairs.as<uint2>(), m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
+                            m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
+            HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted, 32, false));
+        }
+        m->sorted_idx = m->sv_out.as<uint32_t>();
+        v->pass_launches[GSX_PASS_DEPTH_SORT] += n ? 4 : 0;
+    }
+    m->stats_pending = true;
+    m->sorted = true;
+    if (force_full) m->order_consumed = false;  // an unspeculated order over every visible record: renderable again
+    m->binned = false;
+    m->n_entries = 0;
+    return GSX_OK;
+}
+
+// Depth slabs of the progressive mode: [0, n/div), then each slab `growth` times the previous one.
+static void plan_slabs(const gsx_render_options& o, uint32_t n_vis, std::vector<uint32_t>* bounds) {
+    bounds->clear();
+    bounds->push_back(0);
+    if (!o.progressive || n_vis <= o.min_slab) {
+        bounds->push_back(n_vis);
+        return;
+    }
+    uint64_t size = std::max<uint64_t>(o.min_slab, n_vis / std::max(1u, o.first_slab_divisor));
+    uint64_t at = 0;
+    while (at + size < n_vis) {
+        at += size;
+        bounds->push_back((uint32_t)at);
+        size *= std::max(2u, o.growth);
+    }
+    bounds->push_back(n_vis);
+}
+
+// Frames are coherent: if the last observed frame saturated every tile after `used` slabs, the slabs
+// after used + 1 are merged into ONE remainder slab.  When the prediction holds that slab falls through
+// on the device (its count pass sees every tile done); when it does not, the remainder slab simply does
+// the work — the image is the same either way, only the number of empty launches changes.
+static void merge_tail_slabs(std::vector<uint32_t>* bounds, uint32_t used) {
+    if (used == 0) return;
+    const size_t keep = (size_t)used + 1;  // slabs kept as planned
+    if (bounds->size() > keep + 2) {
+        const uint32_t last = bounds->back();
+        bounds->resize(keep + 1);
+        bounds->push_back(last);
+    }
+}
+
+// One model: bin + tile-sort + composite, front to back in depth slabs, enqueued without host syncs.
+// Slab bounds are planned on the record count (an upper bound of N_vis; kernels clamp to the device-side
+// N_vis), slab entry counts stay on the device, and once every tile this rank owns is saturated the
+// remaining slabs' kernels fall through.  carry: the framebuffer already holds nearer models.
+static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
+    if (!m->sorted) return fail(GSX_ERR_INVALID_ARG, "gsx_render: model '%s' was not preprocessed+sorted", m->key.c_str());
+    if (m->order_consumed)
+        return fail(GSX_ERR_INVALID_ARG, "gsx_render: the depth order of '%s' was consumed by a speculated frame's repair round; "
+                    "call gsx_preprocess + gsx_sort('%s') again before rendering it once more (its admission belongs to the windows "
+                    "that frame replaced)", m->key.c_str(), m->key.c_str());
+    if (m->fc.w_px != v->width || m->fc.h_px != v->height)
+        return fail(GSX_ERR_INVALID_ARG, "gsx_render: viewport changed since gsx_preprocess('%s')", m->key.c_str());
+    const uint32_t n_tiles = m->fc.tiles_x * m->fc.tiles_y;
+    const uint32_t row_words = (m->fc.tiles_x + 31) / 32;
+    const bool progressive = v->options.progressive != 0;
+    uint32_t* done = progressive ? v->done_bits.as<uint32_t>() + 1 : nullptr;  // word 0 is the saturated-tile counter
+    uint32_t* done_count = v->done_bits.as<uint32_t>();
+    const bool speculate = progressive && v->options.speculative && !m->use_imported;
+    if (progressive && m->stats_copy_inflight && hipEventQuery(m->stats_event) == hipSuccess) {
+        m->stats_copy_inflight = false;
+        m->slabs_hint = m->h_counters->slabs_used;
+        m->n_sorted = m->h_counters->n_sorted;
+    }
+    std::vector<uint32_t> bounds;
+    if (m->spec_round1) {
+        // a speculated round is ONE slab: the windows already bound what every tile takes to little more than it needs,
+        // and the compositor stops a saturated tile by itself; more slabs only add launches (measured on cfg4: 551 fps
+        // with one slab, 487 with three).  The kernels stride over what exists on the device, so the bound is free.
+        bounds = {0u, (uint32_t)m->rec_n};
+    } else {
+        plan_slabs(v->options, (uint32_t)m->rec_n, &bounds);
+        if (progressive) merge_tail_slabs(&bounds, m->slabs_hint);
+    }
+    Counters* dc = m->counters.as<Counters>();
+    const uint32_t row_lo = std::min(m->row_lo, m->fc.tiles_y), row_hi = std::min(m->row_hi, m->fc.tiles_y);
+    const uint32_t owned_tiles = (row_hi > row_lo ? row_hi - row_lo : 0) * m->fc.tiles_x;
+    const uint2* window = (m->use_imported && m->has_window) ? m->window.as<uint2>() : nullptr;
+    if (m->spec_round1) window = m->spec_win.as<uint2>();
+    uint32_t* tile_sat = progressive ? done + row_words * m->fc.tiles_y : nullptr;  // [count | bitmap | saturation keys]
+
+    if (m->tile_cap == 0) m->tile_cap = std::max<uint64_t>(1u << 20, 16 * m->rec_n);
+    m->tile_cap = std::min<uint64_t>(m->tile_cap, 0xFFFFF000ull);
+    const uint32_t cap = (uint32_t)m->tile_cap;
+    {
+        const size_t bytes = sizeof(uint32_t) * (size_t)cap;
+        HIPCHK(m->tp_src.ensure(2 * bytes));
+        HIPCHK(m->tk_out.ensure(bytes));
+        HIPCHK(m->tv_out.ensure(bytes));
+        HIPCHK(m->tp_a.ensure(2 * bytes));
+        HIPCHK(m->tp_b.ensure(2 * bytes));
+        const size_t ws = 4 * radix_workspace_words(cap);
+        if (ws > m->tsort_ws.bytes) {
+            HIPCHK(m->tsort_ws.ensure(ws));
+            HIPCHK(hipMemsetAsync(m->tsort_ws.p, 0, m->tsort_ws.bytes, v->stream));
+        }
+        if (sizeof(uint2) * (size_t)n_tiles > m->ranges.bytes) m->ranges_clean = false;
+        HIPCHK(m->ranges.ensure(sizeof(uint2) * (size_t)n_tiles));
+    }
+    // reset this model's per-frame totals (n_visible and n_sorted stay)
+    HIPCHK(launch_zero_words(v->stream, &dc->n_entries, (uint32_t)((sizeof(Counters) - offsetof(Counters, n_entries)) / 4), nullptr, 0));
+    const uint32_t* done_before = nullptr;
+    if (speculate) {
+        const size_t bm = 4 * (size_t)row_words * m->fc.tiles_y;
+        HIPCHK(m->spec_win.ensure(sizeof(uint2) * (size_t)n_tiles));
+        HIPCHK(m->spec_win2.ensure(sizeof(uint2) * (size_t)n_tiles));
+        if (carry) {  // nearer models already saturated some tiles: remember which, they say nothing about this model
+            HIPCHK(m->spec_done_before.ensure(bm));
+            HIPCHK(hipMemcpyAsync(m->spec_done_before.p, done, bm, hipMemcpyDeviceToDevice, v->stream));
+            done_before = m->spec_done_before.as<uint32_t>();
+        }
+    }
+    const int bits = std::max<int>(1, (int)ceil_log2(n_tiles));
+    // a single-slab front model keeps its complete tile lists for gsx_model_download_tile_lists
+    const bool clear_ranges = progressive && !(bounds.size() == 2 && !carry && !m->spec_round1);
+    // one depth slab [j0, j1) of the current depth order: bin -> tile sort -> ranges -> composite
+    auto run_slab = [&](uint32_t j0, uint32_t j1, bool later, const uint2* win, const uint32_t* d_n, uint32_t slab_index) -> gsx_status {
+        // the very first slab of the frame sees no saturated tile: plain rectangle areas
+        const uint32_t* done_in = later ? done : nullptr;
+        // a slab of S splats can produce at most S * n_tiles entries; size the sort launch by the smaller bound
+        const uint32_t slab_cap = (uint32_t)std::min<uint64_t>(cap, (uint64_t)(j1 - j0) * std::min<uint64_t>(owned_tiles, 1u << 16));
+        {
+            ScopedPass t(v, GSX_PASS_BIN);
+            HIPCHK(launch_tile_counts(v->stream, j0, j1, d_n, m->sorted_idx, m->rec(), m->srect.as<uint2>(),
+                                      m->cnt.as<uint32_t>(), m->block_sums.as<uint32_t>(), dc, cap, row_lo, row_hi, done_in,
+                                      row_words, (progressive && later) ? done_count : nullptr, owned_tiles, slab_index,
+                                      win, m->sk_out.as<uint32_t>(), m->fc.tiles_x));
+            HIPCHK(launch_tile_emit(v->stream, j0, j1, m->sorted_idx, m->srect.as<uint2>(), m->cnt.as<uint32_t>(),
+                                    m->block_sums.as<uint32_t>(), m->fc.tiles_x, m->tp_src.as<uint2>(), row_lo, row_hi,
+                                    done_in, row_words, d_n, &dc->n_entries, cap, win, m->sk_out.as<uint32_t>()));
+            v->pass_launches[GSX_PASS_BIN] += 1;
+        }
+        {
+            ScopedPass t(v, GSX_PASS_TILE_SORT);
+            RadixBuffers rb{nullptr, nullptr, m->tp_src.as<uint2>(), m->tk_out.as<uint32_t>(), m->tv_out.as<uint32_t>(),
+                            m->tp_a.as<uint2>(), m->tp_b.as<uint2>(), m->tsort_ws.as<uint32_t>()};
+            HIPCHK(launch_radix_sort(v->stream, rb, slab_cap, &dc->n_entries, bits, false));
+            m->tile_keys = m->tk_out.as<uint32_t>();
+            m->tile_list = m->tv_out.as<uint32_t>();
+            v->pass_launches[GSX_PASS_TILE_SORT] += (bits + 7) / 8;
+        }
+        {
+            ScopedPass t(v, GSX_PASS_BIN);
+            HIPCHK(launch_tile_ranges(v->stream, slab_cap, &dc->n_entries, m->tile_keys, n_tiles, m->ranges.as<uint2>(),
+                                      m->ranges_clean));
+        }
+        {
+            ScopedPass t(v, GSX_PASS_COMPOSITE);
+            HIPCHK(launch_composite(v->stream, m->fc, m->ranges.as<uint2>(), m->tile_list, m->rec(), fb_ptr(v),
+                                    later, done, row_words, done_count, clear_ranges, tile_sat));
+            m->ranges_clean = clear_ranges;  // the compositor zeroed every range it consumed
+            v->pass_launches[GSX_PASS_COMPOSITE] += 1;
+        }
+        return GSX_OK;
+    };
+    gsx_status st = GSX_OK;
+    for (size_t sl = 0; sl + 1 < bounds.size(); ++sl)
+        if ((st = run_slab(bounds[sl], bounds[sl + 1], carry || sl > 0, window, &dc->n_sorted, (uint32_t)sl))) return st;
+    if (m->spec_round1) {
+        // verification on the device: tiles with a bounded window that are still open get, in one more round, exactly
+        // the records they were refused, composited behind what they hold.  Nothing to repair: the kernels fall through.
+        const uint32_t n = (uint32_t)m->rec_n;
+        {
+            ScopedPass t(v, GSX_PASS_DEPTH_SORT);
+            HIPCHK(m->spec_need.ensure(4 * (size_t)row_words * m->fc.tiles_y));
+            HIPCHK(launch_spec_verify(v->stream, m->spec_win.as<uint2>(), done, row_words, m->fc.tiles_x, m->fc.tiles_y,
+                                      m->spec_win2.as<uint2>(), m->spec_need.as<uint32_t>(), &dc->spec_need, row_lo, row_hi));
+            HIPCHK(m->adm_ballots2.ensure(8 * ((std::max<size_t>(n, 1) + 63) / 64)));
+            HIPCHK(m->adm_counts2.ensure(4 * (std::max<size_t>(admit_blocks(n), 1) + 4)));
+            // conservative admission against the min-pyramid of the repair windows' starts (four loads per record; the
+            // binning applies the exact windows): an exact per-tile scan of every visible record cost 260-350 us here
+            HIPCHK(m->spec_coarse2.ensure(4 * window_pyramid_words(m->fc.tiles_x, m->fc.tiles_y)));
+            HIPCHK(launch_window_pyramid(v->stream, m->spec_win2.as<uint2>(), m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse2.as<uint32_t>(), true, &dc->spec_need));
+            WindowPyramid pyr2 = window_pyramid_layout(m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse2.as<uint32_t>());
+            pyr2.min_of_starts = 1;
+            HIPCHK(launch_admit(v->stream, m->proj_rec(), n, nullptr, m->fc.tiles_x, nullptr,
+                                row_words, pyr2, &dc->spec_need,
+                                m->adm_ballots2.as<unsigned long long>(), m->adm_counts2.as<uint32_t>(), &dc->n_sorted2,
+                                m->adm_pairs.as<uint2>()));
+            if (m->lazy) {  // the repair round needs records the lazy projection did not shade
+                PodPlanes pod = m->pod();
+                pod.mask = m->last_pod_mask;
+                HIPCHK(launch_shade(v->stream, m->fc, n, pod, m->proj_rec(),
+                                    LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>()}));
+            }
+            RadixBuffers rb{nullptr, nullptr, m->adm_pairs.as<uint2>(), m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
+                            m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
+            HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted2, 32, false));
+        }
+        if ((st = run_slab(0, n, true, m->spec_win2.as<uint2>(), &dc->n_sorted2, (uint32_t)bounds.size()))) return st;
+        m->order_consumed = true;
+    }
+    if (speculate) {  // this model's windows for its next frame
+        ScopedPass t(v, GSX_PASS_COMPOSITE);
+        HIPCHK(launch_spec_next(v->stream, tile_sat, done, done_before, row_words, m->fc.tiles_x, m->fc.tiles_y,
+                                v->options.spec_margin, v->options.spec_radius, m->spec_win.as<uint2>(), row_lo, row_hi));
+        HIPCHK(m->spec_coarse.ensure(4 * window_pyramid_words(m->fc.tiles_x, m->fc.tiles_y)));
+        HIPCHK(launch_window_pyramid(v->stream, m->spec_win.as<uint2>(), m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse.as<uint32_t>()));
+        m->spec_valid = true;
+        m->spec_tiles_x = m->fc.tiles_x;
+        m->spec_tiles_y = m->fc.tiles_y;
+    }
+    if (progressive && !m->stats_copy_inflight) {  // feed the next frames' slab plan without waiting
+        if (!m->stats_event) HIPCHK(hipEventCreateWithFlags(&m->stats_event, hipEventDisableTiming));
+        HIPCHK(hipMemcpyAsync(m->h_counters, m->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, v->stream));
+        HIPCHK(hipEventRecord(m->stats_event, v->stream));
+        m->stats_copy_inflight = true;
+    }
+    m->binned = true;
+    m->stats_pending = true;
+    m->lists_complete = bounds.size() == 2 && !carry && !m->spec_round1;
+    return GSX_OK;
+}
+
+// cont: a second round of the same frame (multi-GPU back set): keep the framebuffer, the saturated-tile state
+// and carry (C, T) into the first model.
+gsx_status do_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys, bool cont) {
+    gsx_status st = ensure_fb(v);
+    if (st) return st;
+    std::vector<Model*> order;
+    std::vector<std::string> key_copy;
+    for (uint32_t i = 0; i < n_keys; ++i) {
+        Model* m = find_model(v, keys ? keys[i] : nullptr);
+        if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_render: no model '%s'", keys && keys[i] ? keys[i] : "(null)");
+        order.push_back(m);
+        key_copy.push_back(keys[i]);
+    }
+    v->last_keys = key_copy;
+    v->last_render_cont = cont;
+    if (order.empty()) {
+        if (cont) return GSX_OK;
+        HIPCHK(launch_clear_fb(v->stream, fb_ptr(v), v->width * v->height));
+        return GSX_OK;
+    }
+    if (!cont) {   // one memset: [saturated-tile counter | saturated-tile bitmap | per-tile saturation depth keys]
+        const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
+        const uint32_t row_words = (tiles_x + 31) / 32;
+        const size_t bytes = 4 * (1 + (size_t)tiles_y * row_words + (size_t)tiles_y * tiles_x);
+        HIPCHK(v->done_bits.ensure(bytes));
+        HIPCHK(launch_zero_words(v->stream, v->done_bits.as<uint32_t>(), (uint32_t)(bytes / 4), nullptr, 0));
+    }
+    // the reference paints far -> near with "over"; front-to-back accumulation walks the same list backwards
+    bool carry = cont;
+    for (auto it = order.rbegin(); it != order.rend(); ++it) {
+        if ((st = do_bin_and_composite(v, *it, carry))) return st;
+        carry = true;
+    }
+    return GSX_OK;
+}
+
+}  // namespace gsx

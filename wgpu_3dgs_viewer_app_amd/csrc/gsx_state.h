@@ -1,0 +1,277 @@
+// gsx_state.h — host-side state of libgsx.so shared by its translation units: device buffers, the per-model and
+// per-viewer records, and the frame scheduling entry points (gsx_frame.cpp) the C ABI files call.
+// Build-internal; the public surface is include/gsx.h.
+#pragma once
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "gsx_internal.h"
+
+namespace gsx {
+
+extern thread_local std::string g_err;  // gsx_last_error_string()
+gsx_status fail(gsx_status st, const char* fmt, ...);
+
+#define HIPCHK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess)                                                                         \
+            return fail(_e == hipErrorOutOfMemory ? GSX_ERR_OOM : GSX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(_e), __FILE__, __LINE__);                                   \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    // grow-only; contents are NOT preserved
+    hipError_t ensure(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        release();
+        size_t want = need + need / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            e = hipMalloc(&p, need);
+            want = need;
+        }
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+using Counters = SlabStats;  // device copy + pinned host mirror
+
+struct Model {
+    std::string key;
+    uint64_t n = 0;
+    gsx_sh_kind sh_kind = GSX_SH_SINGLE;
+    gsx_cov3d_kind cov_kind = GSX_COV3D_SINGLE;
+    bool has_sh = true;
+    bool has_mask = false;
+    ModelTransform mt;
+    FrameConsts fc{};
+
+    DevBuf pc, cov_a, cov_b, sh4, sh1, sh_h, sh_q, sh_aos, cov_h, cov_h2, mask;
+    DevBuf key_buf, rec_a, rec_b, rec_c;        // projection records of the model's own Gaussians
+    DevBuf imp_key, imp_a, imp_b, imp_c;        // records imported from other ranks (kept apart: a frame may pack twice)
+    bool use_imported = false;
+    uint64_t sortbin_cap = 0, imp_cap = 0;
+    DevBuf dp_a, dp_b, sk_out, sv_out, sort_ws; // depth sort: pair scratch, sorted keys / indices, workspace
+    DevBuf cnt, block_sums, srect;              // per slab: tile counts in depth order, scan partials, tile rects
+    DevBuf block_vis;                           // per-workgroup visible counts of the projection pass
+    DevBuf tp_src, tp_a, tp_b, tk_out, tv_out, tsort_ws;  // tile pairs: emitted, scratch, sorted (split), workspace
+    DevBuf ranges;
+    DevBuf counters;
+    Counters* h_counters = nullptr;             // pinned
+    uint32_t* sorted_idx = nullptr;             // -> sv_a or sv_b after the depth sort
+    uint32_t* tile_list = nullptr;              // -> tv_* after the tile sort
+    uint32_t* tile_keys = nullptr;
+    bool preprocessed = false, sorted = false, counters_valid = false, binned = false;
+    bool stats_pending = false;                 // device statistics newer than the host mirror
+    bool ranges_clean = false;                  // the tile range table is known to be all-zero
+    bool lists_complete = false;                // the tile lists of the last render cover the whole model (one slab)
+    uint32_t n_visible = 0, n_entries = 0, n_sorted = 0, n_sorted2 = 0;
+    uint64_t tile_cap = 0;                      // capacity (entries) of the tile-pair buffers
+    uint32_t slabs_hint = 0;                    // slabs the last observed frame needed (0 = unknown)
+    hipEvent_t stats_event = nullptr;           // completion of the asynchronous statistics copy
+    bool stats_copy_inflight = false;
+    // the per-frame record set: the model's own projection (rec_n == n) or records imported from the
+    // other ranks (gsx_shard_import); binning is restricted to the band of tile rows [row_lo, row_hi)
+    uint64_t rec_n = 0, rec_cap = 0;
+    uint32_t row_lo = 0, row_hi = 0xFFFFFFFFu;  // band of tile rows this viewer bins (clamped to tiles_y)
+    DevBuf pack_table;
+    // selection / edits / query (kernels_edit.hip); all allocated on first use
+    DevBuf selection, edited, edit_a, edit_b, keep, query_flags, hits, hit_count;
+    bool has_selection = false, has_edits = false, show_unedited = false;
+    uint32_t flags_kind = GSX_QUERY_NONE, flags_op = GSX_SELECTION_SET;  // what the last preprocess evaluated
+    // temporal occlusion speculation (kernels_spec.hip): this model's per-tile windows for its next frame, the repair
+    // windows of the current one, the saturated-tile bitmap as it was before this model was composited
+    DevBuf spec_win, spec_win2, spec_done_before, spec_need, spec_coarse, spec_coarse2;
+    bool spec_valid = false, spec_round1 = false;
+    bool order_consumed = false;   // a speculated render overwrote the depth order with its repair round's
+    uint32_t spec_tiles_x = 0, spec_tiles_y = 0, shard_tiles_x = 0, shard_tiles_y = 0;
+    // lazily projected shard (gsx_shard_set_windows): the windows of the coming exchange, their max-pyramid, and whether the
+    // last preprocess left a candidate list in adm_pairs
+    DevBuf shard_win, shard_pyr, trav_ballots, trav_counts;
+    bool shard_win_set = false, cand_valid = false;
+    DevBuf adm_ballots2;           // the repair round's ballots (the first round's stay: they say which records are shaded)
+    bool lazy = false;             // this frame's projection shaded only the admitted Gaussians
+    const uint32_t* last_pyramid = nullptr;  // the admission pyramid the projection pass used
+    uint32_t* last_pod_mask = nullptr;  // the keep-bitset the projection pass used (mask, or mask & ~hidden)
+    DevBuf adm_offsets, adm_counts2;  // scan output of adm_counts; counts of the admission passes that run outside the projection
+    DevBuf adm_pairs, adm_ballots, adm_counts;  // admission pass: compacted (key, index) pairs, per-wave ballots, per-workgroup counts
+    DevBuf pack_masks;             // destination bit mask per record (gsx_shard_pack)
+    DevBuf window, pack_window;    // per-tile depth-key windows [lo, hi): of the imported set / of the pack in flight
+    bool has_window = false;
+
+    ~Model() {
+        if (h_counters) (void)hipHostFree(h_counters);
+        if (stats_event) (void)hipEventDestroy(stats_event);
+    }
+    PodPlanes pod() const {
+        PodPlanes p;
+        p.pc = pc.as<float4>();
+        p.cov_a = cov_a.as<float4>();
+        p.cov_b = cov_b.as<float2>();
+        p.sh4 = sh4.as<float4>();
+        p.sh1 = sh1.as<float>();
+        p.sh_h = sh_h.as<uint4>();
+        p.sh_q = sh_q.as<uint4>();
+        p.sh_aos = sh_aos.as<uint4>();
+        p.cov_h = cov_h.as<uint2>();
+        p.cov_h2 = cov_h2.as<uint32_t>();
+        p.sh_kind = (int)sh_kind;
+        p.cov_kind = (int)cov_kind;
+        p.mask = has_mask ? mask.as<uint32_t>() : nullptr;
+        return p;
+    }
+    Records proj_rec() const {
+        Records r;
+        r.key = key_buf.as<uint32_t>();
+        r.a = rec_a.as<float4>();
+        r.b = rec_b.as<float4>();
+        r.c = rec_c.as<float4>();
+        return r;
+    }
+    Records imp_rec() const {
+        Records r;
+        r.key = imp_key.as<uint32_t>();
+        r.a = imp_a.as<float4>();
+        r.b = imp_b.as<float4>();
+        r.c = imp_c.as<float4>();
+        return r;
+    }
+    Records rec() const { return use_imported ? imp_rec() : proj_rec(); }  // the frame's active record set
+};
+
+struct PassTimer {
+    hipEvent_t start, stop;
+    int pass;
+};
+
+}  // namespace gsx
+
+using namespace gsx;
+
+struct gsx_viewer {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    gsx_spec_params params{};
+    float view[16]{}, proj[16]{};
+    uint32_t width = 1, height = 1;
+    float size = 1.0f;
+    uint32_t display_mode = GSX_DISPLAY_SPLAT, sh_deg = 3, no_sh0 = 0;
+    std::map<std::string, std::unique_ptr<Model>> models;
+    DevBuf fb, staging, scratch, done_bits;
+    DevBuf frame_done;        // u32: tiles saturated so far in the current frame (all models)
+    std::vector<std::string> last_keys;  // keys of the last gsx_render, for the overflow redo
+    bool last_render_cont = false;
+    uint32_t band_lo = 0, band_hi = 0xFFFFFFFFu;  // tile rows this viewer renders (gsx_viewer_set_band)
+    gsx_query query{};                   // GSX_QUERY_NONE
+    DevBuf query_texture;
+    uint32_t query_tex_w = 0, query_tex_h = 0;
+    float highlight[4]{0, 0, 0, 0};
+    gsx_gaussian_edit sel_edit{0u, {0.0f, 1.0f, 1.0f}, 0.0f, 0.0f, 1.0f, 1.0f};
+    void* ext_fb = nullptr;              // caller-owned framebuffer (multi-GPU: the RCCL gather target)
+    uint64_t ext_fb_bytes = 0;
+    gsx_render_options options{1u, 16u, 131072u, 2u, 1u, 0.25f, 3u};
+    uint32_t timing = 0;  // bit p: bracket pass p with events
+    std::vector<PassTimer> timers;     // recorded, not yet read
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
+    float pass_ms[GSX_PASS_COUNT]{};
+    uint32_t pass_launches[GSX_PASS_COUNT]{};
+};
+
+namespace gsx {
+
+inline Model* find_model(gsx_viewer* v, const char* key) {
+    if (!v || !key) return nullptr;
+    auto it = v->models.find(key);
+    return it == v->models.end() ? nullptr : it->second.get();
+}
+
+struct ScopedPass {
+    gsx_viewer* v;
+    int pass;
+    hipEvent_t a = nullptr, b = nullptr;
+    ScopedPass(gsx_viewer* v_, int pass_) : v(v_), pass(pass_) {
+        if (!((v->timing >> pass) & 1u)) return;
+        if (!v->event_pool.empty()) {
+            a = v->event_pool.back().first;
+            b = v->event_pool.back().second;
+            v->event_pool.pop_back();
+        } else {
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+        }
+        (void)hipEventRecord(a, v->stream);
+    }
+    ~ScopedPass() {
+        if (!a) return;
+        (void)hipEventRecord(b, v->stream);
+        v->timers.push_back({a, b, pass});
+    }
+};
+
+inline uint32_t ceil_log2(uint32_t x) {
+    uint32_t b = 0;
+    while ((1ull << b) < x) ++b;
+    return b;
+}
+
+inline gsx_status viewer_bind(gsx_viewer* v) {
+    if (!v) return fail(GSX_ERR_INVALID_ARG, "viewer is null");
+    HIPCHK(hipSetDevice(v->device));
+    return GSX_OK;
+}
+
+inline gsx_status ensure_fb(gsx_viewer* v) {
+    if (v->ext_fb) {
+        if (v->ext_fb_bytes < sizeof(float4) * (size_t)v->width * v->height)
+            return fail(GSX_ERR_INVALID_ARG, "external framebuffer of %llu bytes is too small for %ux%u", (unsigned long long)v->ext_fb_bytes, v->width, v->height);
+        return GSX_OK;
+    }
+    HIPCHK(v->fb.ensure(sizeof(float4) * (size_t)v->width * v->height));
+    return GSX_OK;
+}
+inline float4* fb_ptr(gsx_viewer* v) { return v->ext_fb ? static_cast<float4*>(v->ext_fb) : reinterpret_cast<float4*>(v->fb.p); }
+
+// ---- frame scheduling (gsx_frame.cpp) ----
+gsx_status do_preprocess(gsx_viewer* v, Model* m);
+// force_full: ignore the admission the projection pass made (a speculated frame being redone) and sort every visible record
+gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full = false);
+// cont: a second round of the same frame (multi-GPU repair exchange): keep the framebuffer and the saturated-tile state
+gsx_status do_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys, bool cont = false);
+gsx_status finish_frame(gsx_viewer* v);
+inline gsx_status sync_counters(gsx_viewer* v) { return finish_frame(v); }
+gsx_status complete_records(gsx_viewer* v, Model* m);
+gsx_status ensure_record_capacity(Model* m, uint64_t count);
+gsx_status ensure_sortbin_capacity(Model* m, uint64_t count);
+gsx_status ensure_import_capacity(Model* m, uint64_t count);
+gsx_status ensure_selection(gsx_viewer* v, Model* m);
+gsx_status ensure_edit_buffers(gsx_viewer* v, Model* m);
+
+// tile rows per rank of the multi-GPU layout, bytes of a per-tile window map
+inline uint32_t rows_per_rank(const gsx_viewer* v, uint32_t world) {
+    const uint32_t tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
+    return (tiles_y + world - 1) / world;
+}
+inline size_t window_bytes(const gsx_viewer* v) {
+    return sizeof(uint2) * (size_t)((v->width + GSX_TILE - 1) / GSX_TILE) * ((v->height + GSX_TILE - 1) / GSX_TILE);
+}
+
+}  // namespace gsx
