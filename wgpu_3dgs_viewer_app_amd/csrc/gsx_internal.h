@@ -1,4 +1,4 @@
-// gsx_internal.h — shared between the C-ABI host code (gsx_api.cpp) and the gfx950 kernels.
+// gsx_internal.h — shared between the host code (gsx_frame.cpp, gsx_api*.cpp) and the gfx950 kernels.
 // Everything here is build-internal; the public surface is include/gsx.h.
 #pragma once
 #include <hip/hip_runtime.h>

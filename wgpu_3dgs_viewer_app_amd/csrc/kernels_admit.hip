@@ -3,7 +3,7 @@
 //
 // No reference counterpart: the reference sorts every surviving Gaussian (radix_sorter.sort, src/tab/scene.rs:865-869).
 // Without windows every visible record is admitted, and the sort then moves N_vis pairs instead of N keys.  With
-// per-tile depth-key windows (temporal occlusion speculation, gsx_api.cpp) a record is admitted only if some tile of
+// per-tile depth-key windows (temporal occlusion speculation, gsx_frame.cpp) a record is admitted only if some tile of
 // its rectangle still takes it; the rest stay in the record planes, untouched, for the verification round.
 // Order-preserving stream compaction: per-wave ballots + per-workgroup counts, a row scan, then a scatter.
 #include "gsx_internal.h"
