@@ -119,6 +119,10 @@ def main():
     def frame(i):
         renderer.render_frame(camera.orbit_pose(i), (w, h))
 
+    # working buffers (records, sort and tile-pair buffers: sized by the scene) are allocated by the first frame a model is
+    # rendered in; that belongs to loading the scene, not to a step
+    frame(0)
+    renderer.poll()
     for i in range(args.warmup):
         frame(i)
     renderer.poll()
