@@ -381,3 +381,28 @@ def test_fuzz_operation_sequences(seed):
     assert speculated > 15
     spec.close()
     plain.close()
+
+
+def test_speculation_pauses_when_it_gains_nothing():
+    """A sparse scene whose few saturating tiles keep changing (zero margin and radius, moving camera): the windows admit
+    nearly everything and most frames still need the repair round.  The statistics that reach the host notice it and the
+    viewer renders unspeculated frames for a while, then tries again — same pixels throughout."""
+    g = common.small_scene(100000, 208, scale_mul=1.0)
+    spec, plain = _viewer(True, spec_margin=0.0, spec_radius=0), _viewer(False)
+    _load(spec, "m", g)
+    _load(plain, "m", g)
+    flags, repairs = [], []
+    for k in range(90):
+        cam = camera.orbit_pose(3 * k)
+        a, b = _frame(spec, cam, ["m"]), _frame(plain, cam, ["m"])
+        assert np.array_equal(a, b), f"frame {k}"
+        st = spec.frame_stats("m")
+        flags.append(bool(st["speculated"]))
+        repairs.append(st["n_repair_tiles"] > 0)
+    assert sum(repairs) >= 7, f"the setup must make the speculation fail, or nothing is tested: {repairs}"
+    first_pause = flags[1:].index(False) + 1
+    assert first_pause < 40, f"the speculation never paused: {flags}"
+    assert not any(flags[first_pause:first_pause + 48]), "a pause lasts 48 frames"
+    assert any(flags[first_pause + 48:]), "and it must come back"
+    spec.close()
+    plain.close()

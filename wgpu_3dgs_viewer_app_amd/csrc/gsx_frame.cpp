@@ -30,6 +30,22 @@ gsx_status ply_fail(gsx_status st, const char* fmt, ...) {
 }
 
 
+// A sample of how the speculation is doing (whenever statistics reach the host; never waited for).  A frame that needed
+// the repair round although its windows admitted more than 7/8 of what was visible gained nothing from speculating
+// (sparse scenes whose tiles hover around saturation: cfg2 admits 93 % and repairs 94 % of its frames, and the plain
+// progressive path is 6 % faster there; cfg3/cfg4 admit 76 % / 40 % and win 1.4x / 1.8x even when they repair).  When
+// 7 of the last 8 samples were like that, render 48 frames without, then try again.  The windows are kept up to date
+// meanwhile, and either path gives the same pixels.
+static void note_speculation_outcome(Model* m, bool repaired) {
+    const bool useless = repaired && (uint64_t)m->h_counters->n_sorted * 8 > (uint64_t)m->h_counters->n_visible * 7;
+    m->spec_repair_history = (m->spec_repair_history << 1) | (useless ? 1u : 0u);
+    if (__builtin_popcount(m->spec_repair_history & 0xFFu) >= 7) {
+        m->spec_pause = 48;
+        m->spec_repair_history = 0;
+    }
+}
+
+
 // Frames are enqueued without any host round trip; this is where the host catches up: wait for the
 // stream, mirror the per-model statistics, and if a depth slab needed more tile-pair capacity than was
 // allocated, grow the buffers and redo the last gsx_render (rare: capacity starts at 16 entries/record).
@@ -56,6 +72,7 @@ gsx_status finish_frame(gsx_viewer* v) {
             m->counters_valid = true;
             if (m->binned) m->slabs_hint = m->h_counters->slabs_used;
             m->stats_copy_inflight = false;
+            if (m->binned && m->spec_round1 && !m->use_imported) note_speculation_outcome(m, m->h_counters->spec_need != 0);
             if (m->h_counters->overflow && m->binned) {
                 m->tile_cap = std::max<uint64_t>(2 * m->tile_cap, (uint64_t)m->h_counters->max_needed + 1024);
                 if (v->last_render_cont || m->rec_n != m->n)
@@ -183,6 +200,10 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m) {
     // its previous frame — the conservative max-pyramid test of the temporal occlusion speculation
     m->spec_round1 = v->options.progressive && v->options.speculative && m->spec_valid && m->spec_tiles_x == m->fc.tiles_x &&
                      m->spec_tiles_y == m->fc.tiles_y;
+    if (m->spec_pause) {  // the speculation kept repairing: plain frames for a while (the windows stay up to date meanwhile)
+        m->spec_pause -= 1;
+        m->spec_round1 = false;
+    }
     ProjectAdmission adm{};
     HIPCHK(m->adm_ballots.ensure(8 * ((std::max<size_t>(m->n, 1) + 63) / 64 + 4)));
     HIPCHK(m->adm_counts.ensure(4 * (std::max<size_t>(std::max(admit_blocks(m->n), (size_t)(m->n + 255) / 256), 1) + 4)));
@@ -362,6 +383,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
         m->stats_copy_inflight = false;
         m->slabs_hint = m->h_counters->slabs_used;
         m->n_sorted = m->h_counters->n_sorted;
+        if (m->stats_copy_speculated) note_speculation_outcome(m, m->h_counters->spec_need != 0);
     }
     std::vector<uint32_t> bounds;
     if (m->spec_round1) {
@@ -506,6 +528,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
         HIPCHK(hipMemcpyAsync(m->h_counters, m->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, v->stream));
         HIPCHK(hipEventRecord(m->stats_event, v->stream));
         m->stats_copy_inflight = true;
+        m->stats_copy_speculated = m->spec_round1;
     }
     m->binned = true;
     m->stats_pending = true;

@@ -88,6 +88,7 @@ struct Model {
     uint32_t slabs_hint = 0;                    // slabs the last observed frame needed (0 = unknown)
     hipEvent_t stats_event = nullptr;           // completion of the asynchronous statistics copy
     bool stats_copy_inflight = false;
+    bool stats_copy_speculated = false;         // the frame whose statistics are in flight was speculated
     // the per-frame record set: the model's own projection (rec_n == n) or records imported from the
     // other ranks (gsx_shard_import); binning is restricted to the band of tile rows [row_lo, row_hi)
     uint64_t rec_n = 0, rec_cap = 0;
@@ -101,6 +102,10 @@ struct Model {
     // windows of the current one, the saturated-tile bitmap as it was before this model was composited
     DevBuf spec_win, spec_win2, spec_done_before, spec_need, spec_coarse, spec_coarse2;
     bool spec_valid = false, spec_round1 = false;
+    // speculation that keeps repairing does not pay (sparse scenes whose tiles hover around saturation): the lazily read
+    // statistics keep a history of "this frame needed the repair round"; too many -> unspeculated frames for a while
+    uint32_t spec_repair_history = 0;  // bit k: the k-th latest sampled speculated frame repaired although it admitted nearly everything
+    uint32_t spec_pause = 0;           // frames left to render unspeculated
     bool order_consumed = false;   // a speculated render overwrote the depth order with its repair round's
     uint32_t spec_tiles_x = 0, spec_tiles_y = 0, shard_tiles_x = 0, shard_tiles_y = 0;
     // lazily projected shard (gsx_shard_set_windows): the windows of the coming exchange, their max-pyramid, and whether the
