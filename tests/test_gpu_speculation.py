@@ -406,3 +406,25 @@ def test_speculation_pauses_when_it_gains_nothing():
     assert any(flags[first_pause + 48:]), "and it must come back"
     spec.close()
     plain.close()
+
+
+def test_viewport_resizes_with_validation(monkeypatch):
+    """Viewport sizes going up and down (the tile tables are allocated with slack and reused): every frame equals the frame
+    of a fresh viewer, and the library's own pre-composite validation (GSX_VALIDATE, read when a viewer is created) finds
+    no tile range or list index out of bounds.  Regression: a range table zeroed only up to a smaller frame's tile count."""
+    monkeypatch.setenv("GSX_VALIDATE", "1")
+    g = common.small_scene(20000, 77, scale_mul=8.0)
+    sizes = [(224, 192), (256, 208), (200, 120), (256, 208), (256, 192), (224, 192), (320, 240), (200, 120), (320, 240)]
+    viewers = [_viewer(True), _viewer(False)]
+    for v in viewers:
+        _load(v, "m", g)
+    for k, size in enumerate(sizes * 2):
+        cam = camera.orbit_pose(2 * k)
+        fresh = _viewer(False)
+        _load(fresh, "m", g)
+        ref = _frame(fresh, cam, ["m"], size)
+        fresh.close()
+        for v in viewers:
+            assert np.array_equal(_frame(v, cam, ["m"], size), ref), f"frame {k} at {size}"
+    for v in viewers:
+        v.close()

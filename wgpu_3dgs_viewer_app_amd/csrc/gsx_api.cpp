@@ -2,6 +2,7 @@
 // (Selection / edits / queries: gsx_api_edit.cpp; multi-GPU: gsx_api_shard.cpp; what a frame enqueues: gsx_frame.cpp.)
 // There is NO CPU fallback: without a HIP device every entry point fails with GSX_ERR_NO_DEVICE.
 #include "gsx_state.h"
+#include <cstdlib>
 
 using namespace gsx;
 
@@ -36,6 +37,7 @@ gsx_status gsx_viewer_create(const gsx_viewer_desc* desc, gsx_viewer** out) {
         return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_create: device %d out of range [0,%d)", desc->device, count);
     HIPCHK(hipSetDevice(desc->device));
     std::unique_ptr<gsx_viewer> v(new gsx_viewer());
+    v->validate = getenv("GSX_VALIDATE") != nullptr;
     v->device = desc->device;
     if (desc->stream) {
         v->stream = reinterpret_cast<hipStream_t>(desc->stream);

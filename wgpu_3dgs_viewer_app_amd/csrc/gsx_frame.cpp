@@ -4,6 +4,7 @@
 // + radix sort (K2), then the far -> near render loop (K3).  Nothing here waits for the device: counts stay in HBM, the host
 // plans upper bounds, overflow and statistics are looked at lazily (finish_frame).
 #include "gsx_state.h"
+#include <cstdlib>
 
 namespace gsx {
 
@@ -464,8 +465,23 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
         }
         {
             ScopedPass t(v, GSX_PASS_BIN);
-            HIPCHK(launch_tile_ranges(v->stream, slab_cap, &dc->n_entries, m->tile_keys, n_tiles, m->ranges.as<uint2>(),
-                                      m->ranges_clean));
+            HIPCHK(launch_tile_ranges(v->stream, slab_cap, &dc->n_entries, m->tile_keys, (uint32_t)(m->ranges.bytes / sizeof(uint2)),
+                                      m->ranges.as<uint2>(), m->ranges_clean));
+        }
+        if (v->validate) {  // debug: check what the compositor will dereference, on the host, before it runs
+            HIPCHK(v->scratch.ensure(64));
+            HIPCHK(hipMemsetAsync(v->scratch.p, 0, 64, v->stream));
+            HIPCHK(launch_validate_tiles(v->stream, m->ranges.as<uint2>(), n_tiles, m->tile_list, &dc->n_entries, slab_cap, (uint32_t)m->rec_n,
+                                         v->scratch.as<uint32_t>()));
+            uint32_t rep[8];
+            HIPCHK(hipMemcpyAsync(rep, v->scratch.p, 32, hipMemcpyDeviceToHost, v->stream));
+            HIPCHK(hipStreamSynchronize(v->stream));
+            if (rep[0])
+                return fail(GSX_ERR_HIP, "GSX_VALIDATE: model '%s' slab %u: %s (tile %u: %u, %u, %u); n_tiles %u, tiles %ux%u, ranges_clean %d, "
+                            "clear_ranges %d, speculated %d, later %d, slab_cap %u, rec_n %llu", m->key.c_str(), slab_index,
+                            rep[0] == 1 ? "tile range outside the sorted entries" : "list index outside the records", rep[1], rep[2], rep[3], rep[4],
+                            n_tiles, m->fc.tiles_x, m->fc.tiles_y, (int)m->ranges_clean, (int)clear_ranges, (int)m->spec_round1, (int)later, slab_cap,
+                            (unsigned long long)m->rec_n);
         }
         {
             ScopedPass t(v, GSX_PASS_COMPOSITE);

@@ -156,9 +156,10 @@ hipError_t launch_tile_emit(hipStream_t s, uint32_t j0, uint32_t j1, const uint3
                             uint32_t row_lo, uint32_t row_hi, const uint32_t* done, uint32_t row_words,
                             const uint32_t* d_n_vis, const uint32_t* d_entries, uint32_t capacity,
                             const uint2* window, const uint32_t* sorted_keys);
-// ranges_clean: the table is already all-zero (the previous composite cleared what it used)
+// ranges_clean: the whole table (table_tiles entries = its allocation) is already all-zero (the previous composite
+// cleared what it used); otherwise it is zeroed here, all of it
 hipError_t launch_tile_ranges(hipStream_t s, uint32_t capacity, const uint32_t* d_n, const uint32_t* tkey_sorted,
-                              uint32_t n_tiles, uint2* ranges, bool ranges_clean);
+                              uint32_t table_tiles, uint2* ranges, bool ranges_clean);
 size_t scan_blocks(uint64_t n);
 
 // Selection / edits / queries (kernels_edit.hip).
@@ -198,6 +199,8 @@ hipError_t launch_admit(hipStream_t s, const Records& rec, uint32_t n, const uin
 hipError_t launch_spec_verify(hipStream_t s, const uint2* win1, const uint32_t* done, uint32_t row_words, uint32_t tiles_x,
                               uint32_t tiles_y, uint2* win2, uint32_t* need_bits, uint32_t* d_need, uint32_t band_lo, uint32_t band_hi);
 hipError_t launch_zero_words(hipStream_t s, uint32_t* a, uint32_t na, uint32_t* b, uint32_t nb);
+hipError_t launch_validate_tiles(hipStream_t s, const uint2* ranges, uint32_t n_tiles, const uint32_t* list, const uint32_t* d_entries,
+                                 uint32_t capacity, uint32_t n_records, uint32_t* report);
 hipError_t launch_spec_next(hipStream_t s, const uint32_t* tile_sat, const uint32_t* done, const uint32_t* done_before,
                             uint32_t row_words, uint32_t tiles_x, uint32_t tiles_y, float margin, uint32_t radius, uint2* win_next,
                             uint32_t band_lo, uint32_t band_hi);

@@ -185,6 +185,7 @@ struct gsx_viewer {
     DevBuf frame_done;        // u32: tiles saturated so far in the current frame (all models)
     std::vector<std::string> last_keys;  // keys of the last gsx_render, for the overflow redo
     bool last_render_cont = false;
+    bool validate = false;  // GSX_VALIDATE was set when the viewer was created: check tile ranges / lists before compositing (debug, synchronous)
     uint32_t band_lo = 0, band_hi = 0xFFFFFFFFu;  // tile rows this viewer renders (gsx_viewer_set_band)
     gsx_query query{};                   // GSX_QUERY_NONE
     DevBuf query_texture;

@@ -346,9 +346,12 @@ hipError_t launch_tile_emit(hipStream_t s, uint32_t j0, uint32_t j1, const uint3
 }
 
 hipError_t launch_tile_ranges(hipStream_t s, uint32_t capacity, const uint32_t* d_n, const uint32_t* tkey_sorted,
-                              uint32_t n_tiles, uint2* ranges, bool ranges_clean) {
+                              uint32_t table_tiles, uint2* ranges, bool ranges_clean) {
     if (!ranges_clean) {
-        hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)n_tiles, s);
+        // the WHOLE allocation, not this frame's tile count: "clean" is a statement about every entry a later, larger
+        // viewport may read (a table allocated with slack and zeroed up to a smaller frame's tile count handed stale
+        // ranges to the compositor after a resize — found by the API fuzz test)
+        hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)table_tiles, s);
         if (e != hipSuccess) return e;
     }
     if (capacity == 0) return hipSuccess;

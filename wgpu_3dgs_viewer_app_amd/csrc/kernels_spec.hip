@@ -30,6 +30,34 @@ hipError_t launch_zero_words(hipStream_t s, uint32_t* a, uint32_t na, uint32_t* 
     return hipGetLastError();
 }
 
+// Debug aid (GSX_VALIDATE=1, gsx_frame.cpp): everything the compositor is about to dereference, checked before it runs.
+// report[0] = first error code (1 range outside the sorted entries, 2 list index outside the records), [1] tile, [2..3] detail.
+__global__ __launch_bounds__(256) void k_validate_tiles(const uint2* __restrict__ ranges, uint32_t n_tiles,
+                                                         const uint32_t* __restrict__ list, const uint32_t* __restrict__ d_entries,
+                                                         uint32_t capacity, uint32_t n_records, uint32_t* __restrict__ report) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_tiles) return;
+    const uint32_t D = min(*d_entries, capacity);
+    const uint2 r = ranges[t];
+    if (r.x > r.y || r.y > D) {
+        if (atomicCAS(&report[0], 0u, 1u) == 0u) { report[1] = t; report[2] = r.x; report[3] = r.y; report[4] = D; }
+        return;
+    }
+    for (uint32_t e = r.x; e < r.y; ++e) {
+        const uint32_t idx = list[e];
+        if (idx >= n_records) {
+            if (atomicCAS(&report[0], 0u, 2u) == 0u) { report[1] = t; report[2] = e; report[3] = idx; report[4] = n_records; }
+            return;
+        }
+    }
+}
+
+hipError_t launch_validate_tiles(hipStream_t s, const uint2* ranges, uint32_t n_tiles, const uint32_t* list, const uint32_t* d_entries,
+                                 uint32_t capacity, uint32_t n_records, uint32_t* report) {
+    hipLaunchKernelGGL(k_validate_tiles, dim3((n_tiles + 255) / 256), dim3(256), 0, s, ranges, n_tiles, list, d_entries, capacity, n_records, report);
+    return hipGetLastError();
+}
+
 // need[t] = bounded window && still open  ->  win2[t] = [hi, inf) for those tiles, [0, 0) for the rest; *d_need = count
 __global__ __launch_bounds__(256) void k_spec_verify(const uint2* __restrict__ win1, const uint32_t* __restrict__ done,
                                                       uint32_t row_words, uint32_t tiles_x, uint32_t n_tiles,
