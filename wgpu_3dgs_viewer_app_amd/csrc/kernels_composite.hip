@@ -2,7 +2,7 @@
 //
 // Replaces the raster half of the reference's K3 (`renderer.render_with_pass`, instanced quads with
 // fixed-function "over" blending in back-to-front order, src/tab/scene.rs:2302-2314).  Here one
-// 256-lane workgroup owns one 16x16 px tile and walks the tile's depth-ordered splat list FRONT to
+// 128-lane workgroup owns one 16x16 px tile (two pixels per lane) and walks the tile's depth-ordered splat list FRONT to
 // back:  C += T*alpha*c ; T *= 1-alpha   — algebraically the same premultiplied "over" result.
 // The list is staged through LDS 256 records at a time (one gather per lane, then every lane reads
 // all 256 records as LDS broadcasts); waves vote (`__syncthreads_and`) to stop once every pixel of the
@@ -17,8 +17,20 @@ namespace gsx {
 
 constexpr int kBatch = 256;
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f splat2(float x) { return v2f{x, x}; }
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }  // v_pk_fma_f32
+
+// One 128-lane workgroup (two waves) per 16x16 tile; every lane owns the two vertically adjacent pixels
+// (x, 2r) and (x, 2r+1), so wave w covers rows 8w..8w+7.  Two pixels per lane because the loop is bound by VALU
+// issue and by the LDS return path (every splat record is broadcast to all lanes): gfx950's packed fp32
+// instructions (v_pk_fma/mul/add_f32) blend both pixels in one issue slot, dx and the dx-only products are shared,
+// and each LDS broadcast now feeds two pixels.  Per pixel the operation sequence is exactly the oracle's (spec §6;
+// packed ops round like their scalar forms), a pixel that is not hit takes alpha = 0, which leaves (C, T) unchanged
+// bit for bit for finite colour records.
 template <int MODE /* 0 splat (gaussian falloff), 1 constant alpha inside the cutoff */>
-__global__ __launch_bounds__(256) void k_composite(const FrameConsts f, uint2* __restrict__ ranges,
+__global__ __launch_bounds__(128) void k_composite(const FrameConsts f, uint2* __restrict__ ranges,
                                                     const uint32_t* __restrict__ list,
                                                     const float4* __restrict__ rec_a, const float4* __restrict__ rec_b,
                                                     const float4* __restrict__ rec_c, float4* __restrict__ fb,
@@ -27,19 +39,20 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConsts f, uint2* _
                                                     const int clear_ranges, uint32_t* __restrict__ tile_sat) {
     __shared__ float2 s_mean[kBatch];
     __shared__ uint32_t s_sat;
-    __shared__ float4 s_conic[kBatch];
+    __shared__ float4 s_conic[kBatch];  // (a, 2b, c, opacity)
     __shared__ float4 s_rgb[kBatch];
 
     const uint32_t tile = blockIdx.x;
     const uint32_t tx = tile % f.tiles_x, ty = tile / f.tiles_x;
     const uint32_t tid = threadIdx.x;
-    const uint32_t px = tx * kTile + (tid & 15u), py = ty * kTile + (tid >> 4);
-    const bool inside = px < f.w_px && py < f.h_px;
-    const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
+    const uint32_t px = tx * kTile + (tid & 15u), py = ty * kTile + 2u * (tid >> 4);
+    const bool in0 = px < f.w_px && py < f.h_px, in1 = px < f.w_px && py + 1u < f.h_px;
+    const float pxf = (float)px + 0.5f;
+    const v2f pyf = v2f{(float)py + 0.5f, (float)(py + 1u) + 0.5f};
     const uint2 range = ranges[tile];
     const size_t fbo = (size_t)py * f.w_px + px;
     // Progressive mode leaves the range table clean for the next slab (saves a memset per slab).  EVERY lane reads
-    // ranges[tile] itself, so the entry may only be zeroed once all four waves have read it: on the early-return path
+    // ranges[tile] itself, so the entry may only be zeroed once both waves have read it: on the early-return path
     // that is harmless (a wave that reads the zeroed entry returns as well), on the main path it happens after the
     // list loop, whose barriers every wave has passed by then.  (Zeroing it up front lost whole waves of pixels whenever
     // wave 0 ran a memory round trip ahead of the others — seen on the first frame of a 24 M-Gaussian 4K scene.)
@@ -51,72 +64,120 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConsts f, uint2* _
         if (clear_ranges && tid == 0 && had_entries) ranges[tile] = make_uint2(0u, 0u);
         return;
     }
-    float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
-    if (carry && inside) {
-        const float4 p = fb[fbo];
-        C0 = p.x; C1 = p.y; C2 = p.z; T = p.w;
+    v2f T = splat2(1.0f), C0 = splat2(0.0f), C1 = C0, C2 = C0;
+    if (carry) {
+        if (in0) {
+            const float4 p = fb[fbo];
+            C0.x = p.x; C1.x = p.y; C2.x = p.z; T.x = p.w;
+        }
+        if (in1) {
+            const float4 p = fb[fbo + f.w_px];
+            C0.y = p.x; C1.y = p.y; C2.y = p.z; T.y = p.w;
+        }
     }
-    bool done = !inside || T < f.t_eps;
-    uint32_t stop_key = 0;  // depth key of the splat that saturated this pixel (in this launch)
+    // The support test `!done && 0 <= q <= k2` as ONE unsigned compare per pixel: non-negative floats order like their bit
+    // patterns, negative values and NaN have larger patterns than any finite k2, so it is `bits(q) < lim` with
+    // lim = bits(k2) + 1 while the pixel is live and 0 once it is saturated (or outside the image).  This keeps the
+    // predicate logic off the scalar unit, which was busier than the vector ALU in this loop (110 M vs 77 M instructions).
+    const uint32_t live = f.k2 > 0.0f ? __float_as_uint(f.k2) + 1u : (f.k2 == 0.0f ? 1u : 0u);
+    uint32_t lim0 = (in0 && !(T.x < f.t_eps)) ? live : 0u, lim1 = (in1 && !(T.y < f.t_eps)) ? live : 0u;
+    uint32_t stop_key = 0;  // depth key of this lane's last hit: once both its pixels are saturated, the key of the splat
+                            // that saturated the later one (keys ascend along the list)
     if (tid == 0) s_sat = 0;
 
-    // software pipeline: the gather of batch b+1 (list -> three record planes, dependent random loads) is
-    // in flight while batch b is blended out of LDS
-    float4 pa = make_float4(0, 0, 0, 0), pb = pa, pc4 = pa;
-    if (range.x + tid < range.y) {
-        const uint32_t idx = list[range.x + tid];
-        pa = rec_a[idx];
-        pb = rec_b[idx];
-        pc4 = rec_c[idx];
+    // software pipeline: the gather of batch b+1 (list -> three record planes, dependent random loads; two records per
+    // lane) is in flight while batch b is blended out of LDS.  Slots past the end of the list hold a record no pixel
+    // supports (q = +inf), so the blend loop can run in fixed groups of four.
+    const float4 pad_a = make_float4(3.0e38f, 3.0e38f, 0.0f, 0.0f), pad_b = make_float4(1.0f, 0.0f, 1.0f, 0.0f);
+    float4 pa[2], pb[2], pc4[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        pa[k] = pad_a;
+        pb[k] = pad_b;
+        pc4[k] = make_float4(0, 0, 0, 0);
+        const uint32_t at = range.x + tid + 128u * k;
+        if (at < range.y) {
+            const uint32_t idx = list[at];
+            pa[k] = rec_a[idx];
+            pb[k] = rec_b[idx];
+            pc4[k] = rec_c[idx];
+        }
     }
     for (uint32_t base = range.x; base < range.y; base += kBatch) {
         // vote + barrier: also protects the LDS batch of the previous iteration
-        if (__syncthreads_and(done)) break;
-        s_mean[tid] = make_float2(pa.x, pa.y);
-        s_conic[tid] = pb;
-        s_rgb[tid] = pc4;
+        if (__syncthreads_and((lim0 | lim1) == 0u)) break;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            s_mean[tid + 128u * k] = make_float2(pa[k].x, pa[k].y);
+            s_conic[tid + 128u * k] = make_float4(pb[k].x, 2.0f * pb[k].y, pb[k].z, pb[k].w);
+            s_rgb[tid + 128u * k] = pc4[k];
+        }
         __syncthreads();
-        const uint32_t nxt = base + kBatch + tid;
-        if (nxt < range.y) {
-            const uint32_t idx = list[nxt];
-            pa = rec_a[idx];
-            pb = rec_b[idx];
-            pc4 = rec_c[idx];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t nxt = base + kBatch + tid + 128u * k;
+            pa[k] = pad_a;
+            pb[k] = pad_b;
+            if (nxt < range.y) {
+                const uint32_t idx = list[nxt];
+                pa[k] = rec_a[idx];
+                pb[k] = rec_b[idx];
+                pc4[k] = rec_c[idx];
+            }
         }
         const uint32_t cnt = min((uint32_t)kBatch, range.y - base);
-        // Straight-line body, one predicated region per splat: a saturated pixel simply stops hitting (`done` is part of
-        // the support predicate) instead of leaving the loop, which keeps the wave's control flow to one skip branch per
-        // splat; a wave whose pixels are all saturated leaves the batch (checked every 4 splats).
+        // Groups of four splats, straight-line, one skip branch per splat; a wave whose pixels are all saturated leaves the
+        // batch at the next group.
         for (uint32_t j0 = 0; j0 < cnt; j0 += 4) {
-            if (!__ballot(!done)) break;
-            const uint32_t j1 = min(j0 + 4u, cnt);
-            for (uint32_t j = j0; j < j1; ++j) {
-                const float2 m = s_mean[j];
-                const float4 co = s_conic[j];
-                const float dx = pxf - m.x, dy = pyf - m.y;
-                const float q = fmaf(co.x * dx, dx, fmaf(co.z * dy, dy, ((2.0f * co.y) * dx) * dy));
-                if (!done && q <= f.k2 && q >= 0.0f) {
-                    const float w = MODE == 0 ? __expf(-0.5f * q) : 1.0f;
-                    const float alpha = fminf(f.alpha_max, co.w * w);
-                    if (!(alpha < f.alpha_min)) {
-                        const float4 c = s_rgb[j];
-                        const float wgt = T * alpha;
-                        C0 = fmaf(wgt, c.x, C0);
-                        C1 = fmaf(wgt, c.y, C1);
-                        C2 = fmaf(wgt, c.z, C2);
-                        T = T * (1.0f - alpha);
-                        if (T < f.t_eps) {
-                            done = true;
-                            stop_key = __float_as_uint(c.w);
-                        }
+            if (!__ballot((lim0 | lim1) != 0u)) break;
+            // the group's records first, so the LDS round trips overlap instead of each splat waiting for its own
+            float2 gm[4];
+            float4 gc[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                gm[u] = s_mean[j0 + u];
+                gc[u] = s_conic[j0 + u];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const uint32_t j = j0 + u;
+                const float2 m = gm[u];
+                const float4 co = gc[u];
+                const float dx = pxf - m.x;
+                const v2f dy = pyf - splat2(m.y);
+                // q = fma(a*dx, dx, fma(c*dy, dy, ((2b)*dx)*dy))
+                const v2f q = fma2(splat2(co.x * dx), splat2(dx), fma2(splat2(co.z) * dy, dy, splat2(co.y * dx) * dy));
+                const bool h0 = __float_as_uint(q.x) < lim0, h1 = __float_as_uint(q.y) < lim1;
+                if (h0 || h1) {
+                    v2f alpha;
+                    if (MODE == 0) {
+                        const v2f e = splat2(-0.5f) * q;
+                        alpha = splat2(co.w) * v2f{__expf(e.x), __expf(e.y)};
+                    } else {
+                        alpha = splat2(co.w * 1.0f);
                     }
+                    alpha.x = fminf(f.alpha_max, alpha.x);
+                    alpha.y = fminf(f.alpha_max, alpha.y);
+                    alpha.x = (h0 && !(alpha.x < f.alpha_min)) ? alpha.x : 0.0f;
+                    alpha.y = (h1 && !(alpha.y < f.alpha_min)) ? alpha.y : 0.0f;
+                    const float4 c = s_rgb[j];
+                    const v2f wgt = T * alpha;
+                    C0 = fma2(wgt, splat2(c.x), C0);
+                    C1 = fma2(wgt, splat2(c.y), C1);
+                    C2 = fma2(wgt, splat2(c.z), C2);
+                    T = T * (splat2(1.0f) - alpha);
+                    // only a blend lowers T, so T < t_eps here means saturated now or before
+                    lim0 = T.x < f.t_eps ? 0u : lim0;
+                    lim1 = T.y < f.t_eps ? 0u : lim1;
+                    stop_key = __float_as_uint(c.w);
                 }
             }
         }
     }
-    if (inside) fb[fbo] = make_float4(C0, C1, C2, T);
+    if (in0) fb[fbo] = make_float4(C0.x, C1.x, C2.x, T.x);
+    if (in1) fb[fbo + f.w_px] = make_float4(C0.y, C1.y, C2.y, T.y);
     if (clear_ranges && tid == 0 && had_entries) ranges[tile] = make_uint2(0u, 0u);
-    if (done_bits && __syncthreads_and(done)) {
+    if (done_bits && __syncthreads_and((lim0 | lim1) == 0u)) {
         // the tile saturated in this launch: its last pixels stopped here, behind everything blended earlier
         if (tile_sat) {
             if (stop_key) atomicMax(&s_sat, stop_key);
@@ -153,7 +214,7 @@ __global__ __launch_bounds__(256) void k_resolve_rgba8(const float4* __restrict_
 hipError_t launch_composite(hipStream_t s, const FrameConsts& f, uint2* ranges, const uint32_t* list,
                             const Records& rec, float4* fb, bool carry, uint32_t* done, uint32_t row_words,
                             uint32_t* d_done_count, bool clear_ranges, uint32_t* tile_sat) {
-    dim3 grid(f.tiles_x * f.tiles_y), block(256);
+    dim3 grid(f.tiles_x * f.tiles_y), block(128);
     if (f.display_mode == GSX_DISPLAY_SPLAT)
         hipLaunchKernelGGL(k_composite<0>, grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count,
                            clear_ranges ? 1 : 0, tile_sat);
