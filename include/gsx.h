@@ -89,7 +89,14 @@ typedef struct gsx_spec_params {
  * composited behind — pixels stay identical to speculative = 0 whatever the camera does; a wrong guess only costs
  * time.  After such a frame gsx_model_download_sorted returns the second round's (possibly empty) order, and the model
  * must go through gsx_preprocess + gsx_sort again before it is rendered once more (the app does so every frame;
- * gsx_render refuses otherwise: the frame's admission belongs to windows the frame has replaced). */
+ * gsx_render refuses otherwise: the frame's admission belongs to windows the frame has replaced).
+ * host_verify = 1: the device verification posts its verdict (how many tiles need the second round) into pinned host
+ * memory and gsx_render waits for that one word before it returns: when nothing needs repairing — most frames — the
+ * second round's ~20 kernel launches are not enqueued at all (they fall through, but each costs ~4 us of stream time).
+ * The next frame's windows are enqueued before the wait.  Worth it only for a host that prepares a frame in well under
+ * 100 us: the host can no longer run ahead of the device, so its per-frame time is no longer hidden (measured from
+ * Python, cfg4: 992 vs 995 fps; cfg2, which repairs 94 % of its frames: 856 vs 1269).
+ * host_verify = 0 (default): gsx_render never waits for the device; the second round is always enqueued. */
 typedef struct gsx_render_options {
     uint32_t progressive;        /* default 1 */
     uint32_t first_slab_divisor; /* default 16 */
@@ -98,6 +105,7 @@ typedef struct gsx_render_options {
     uint32_t speculative;        /* default 1 */
     float spec_margin;           /* default 0.25 */
     uint32_t spec_radius;        /* default 3 (tiles) */
+    uint32_t host_verify;        /* default 0 */
 } gsx_render_options;
 
 typedef struct gsx_viewer_desc {

@@ -54,7 +54,7 @@ class SpecParams(C.Structure):
 
 class RenderOptions(C.Structure):
     _fields_ = [("progressive", C.c_uint32), ("first_slab_divisor", C.c_uint32), ("min_slab", C.c_uint32), ("growth", C.c_uint32),
-                ("speculative", C.c_uint32), ("spec_margin", C.c_float), ("spec_radius", C.c_uint32)]
+                ("speculative", C.c_uint32), ("spec_margin", C.c_float), ("spec_radius", C.c_uint32), ("host_verify", C.c_uint32)]
 
 
 class PlyHeader(C.Structure):
@@ -92,11 +92,12 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("GSX_LIB", LIB_PATH)  # development: A/B a differently built library on the same box
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            f"{path} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
             "There is no CPU fallback for the render path.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, u32, u64, f32p, u32p, cp = C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_char_p
     sig = {
         "gsx_last_error_string": ([], C.c_char_p),

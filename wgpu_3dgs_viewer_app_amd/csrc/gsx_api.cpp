@@ -68,6 +68,7 @@ void gsx_viewer_destroy(gsx_viewer* v) {
         (void)hipEventDestroy(p.second);
     }
     v->models.clear();
+    if (v->h_verdict) (void)hipHostFree(v->h_verdict);
     if (v->own_stream) (void)hipStreamDestroy(v->stream);
     delete v;
 }
@@ -81,6 +82,7 @@ void gsx_render_options_default(gsx_render_options* o) {
     o->speculative = 1;
     o->spec_margin = 0.25f;
     o->spec_radius = 3;
+    o->host_verify = 0;
 }
 
 gsx_status gsx_viewer_set_render_options(gsx_viewer* v, const gsx_render_options* o) {

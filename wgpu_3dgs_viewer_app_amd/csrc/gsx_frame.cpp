@@ -31,6 +31,30 @@ gsx_status ply_fail(gsx_status st, const char* fmt, ...) {
 }
 
 
+// host_verify: spin on the pinned verdict word until k_spec_verify of this frame has posted {seq, need}.  The wait is
+// bounded by the stream itself: if the stream drains (or fails) and the word still is not there, something upstream
+// went wrong and that is reported instead of spinning forever.
+static gsx_status wait_verdict(gsx_viewer* v, uint32_t seq, uint32_t* need) {
+    for (uint64_t spin = 1;; ++spin) {
+        const unsigned long long w = __atomic_load_n(v->h_verdict, __ATOMIC_ACQUIRE);
+        if ((uint32_t)(w >> 32) == seq) {
+            *need = (uint32_t)w;
+            return GSX_OK;
+        }
+        if ((spin & 0x3FFFu) == 0) {
+            const hipError_t e = hipStreamQuery(v->stream);
+            if (e == hipSuccess) {
+                const unsigned long long w2 = __atomic_load_n(v->h_verdict, __ATOMIC_ACQUIRE);
+                if ((uint32_t)(w2 >> 32) == seq) continue;
+                return fail(GSX_ERR_HIP, "speculation verdict %u never arrived (stream idle)", seq);
+            }
+            if (e != hipErrorNotReady) return fail(GSX_ERR_HIP, "stream failed while waiting for the speculation verdict: %s", hipGetErrorString(e));
+        }
+        __builtin_ia32_pause();
+    }
+}
+
+
 // A sample of how the speculation is doing (whenever statistics reach the host; never waited for).  A frame that needed
 // the repair round although its windows admitted more than 7/8 of what was visible gained nothing from speculating
 // (sparse scenes whose tiles hover around saturation: cfg2 admits 93 % and repairs 94 % of its frames, and the plain
@@ -495,15 +519,49 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
     gsx_status st = GSX_OK;
     for (size_t sl = 0; sl + 1 < bounds.size(); ++sl)
         if ((st = run_slab(bounds[sl], bounds[sl + 1], carry || sl > 0, window, &dc->n_sorted, (uint32_t)sl))) return st;
+    bool windows_enqueued = false;
+    auto enqueue_next_windows = [&]() -> gsx_status {  // this model's windows for its next frame
+        ScopedPass t(v, GSX_PASS_COMPOSITE);
+        HIPCHK(launch_spec_next(v->stream, tile_sat, done, done_before, row_words, m->fc.tiles_x, m->fc.tiles_y,
+                                v->options.spec_margin, v->options.spec_radius, m->spec_win.as<uint2>(), row_lo, row_hi));
+        HIPCHK(m->spec_coarse.ensure(4 * window_pyramid_words(m->fc.tiles_x, m->fc.tiles_y)));
+        HIPCHK(launch_window_pyramid(v->stream, m->spec_win.as<uint2>(), m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse.as<uint32_t>()));
+        m->spec_valid = true;
+        m->spec_tiles_x = m->fc.tiles_x;
+        m->spec_tiles_y = m->fc.tiles_y;
+        return GSX_OK;
+    };
     if (m->spec_round1) {
         // verification on the device: tiles with a bounded window that are still open get, in one more round, exactly
-        // the records they were refused, composited behind what they hold.  Nothing to repair: the kernels fall through.
+        // the records they were refused, composited behind what they hold.
         const uint32_t n = (uint32_t)m->rec_n;
+        bool repair = true;
         {
             ScopedPass t(v, GSX_PASS_DEPTH_SORT);
+            const bool ask = v->options.host_verify != 0;
+            if (ask && !v->h_verdict) {
+                HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&v->h_verdict), 64, hipHostMallocDefault));
+                *v->h_verdict = 0;
+            }
+            const uint32_t seq = ask ? ++v->verify_seq : 0;
             HIPCHK(m->spec_need.ensure(4 * (size_t)row_words * m->fc.tiles_y));
             HIPCHK(launch_spec_verify(v->stream, m->spec_win.as<uint2>(), done, row_words, m->fc.tiles_x, m->fc.tiles_y,
-                                      m->spec_win2.as<uint2>(), m->spec_need.as<uint32_t>(), &dc->spec_need, row_lo, row_hi));
+                                      m->spec_win2.as<uint2>(), m->spec_need.as<uint32_t>(), &dc->spec_need, row_lo, row_hi,
+                                      &dc->verify_ticket, ask ? v->h_verdict : nullptr, seq));
+            if (ask) {
+                // Nothing to repair (most frames): the ~20 launches of the second round would all fall through, at a few
+                // microseconds of stream time each.  So the verdict comes to the host: one pinned word, written by the
+                // verification kernel.  The next frame's windows are enqueued first — they are what follows when there is
+                // nothing to repair, and they keep the stream busy while the word travels; after a repair they are redone.
+                if ((st = enqueue_next_windows())) return st;
+                uint32_t need = 0;
+                if ((st = wait_verdict(v, seq, &need))) return st;
+                repair = need != 0;
+                windows_enqueued = !repair;
+            }
+        }
+        if (repair) {
+            ScopedPass t(v, GSX_PASS_DEPTH_SORT);
             HIPCHK(m->adm_ballots2.ensure(8 * ((std::max<size_t>(n, 1) + 63) / 64)));
             HIPCHK(m->adm_counts2.ensure(4 * (std::max<size_t>(admit_blocks(n), 1) + 4)));
             // conservative admission against the min-pyramid of the repair windows' starts (four loads per record; the
@@ -526,19 +584,10 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
                             m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
             HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted2, 32, false));
         }
-        if ((st = run_slab(0, n, true, m->spec_win2.as<uint2>(), &dc->n_sorted2, (uint32_t)bounds.size()))) return st;
+        if (repair && (st = run_slab(0, n, true, m->spec_win2.as<uint2>(), &dc->n_sorted2, (uint32_t)bounds.size()))) return st;
         m->order_consumed = true;
     }
-    if (speculate) {  // this model's windows for its next frame
-        ScopedPass t(v, GSX_PASS_COMPOSITE);
-        HIPCHK(launch_spec_next(v->stream, tile_sat, done, done_before, row_words, m->fc.tiles_x, m->fc.tiles_y,
-                                v->options.spec_margin, v->options.spec_radius, m->spec_win.as<uint2>(), row_lo, row_hi));
-        HIPCHK(m->spec_coarse.ensure(4 * window_pyramid_words(m->fc.tiles_x, m->fc.tiles_y)));
-        HIPCHK(launch_window_pyramid(v->stream, m->spec_win.as<uint2>(), m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse.as<uint32_t>()));
-        m->spec_valid = true;
-        m->spec_tiles_x = m->fc.tiles_x;
-        m->spec_tiles_y = m->fc.tiles_y;
-    }
+    if (speculate && !windows_enqueued && (st = enqueue_next_windows())) return st;
     if (progressive && !m->stats_copy_inflight) {  // feed the next frames' slab plan without waiting
         if (!m->stats_event) HIPCHK(hipEventCreateWithFlags(&m->stats_event, hipEventDisableTiming));
         HIPCHK(hipMemcpyAsync(m->h_counters, m->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, v->stream));

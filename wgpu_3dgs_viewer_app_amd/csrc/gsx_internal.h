@@ -139,6 +139,7 @@ struct SlabStats {
     uint32_t slabs_used;       // number of slabs that still found a live tile (progressive mode)
     uint32_t n_sorted2;        // speculation: records admitted in the repair round
     uint32_t spec_need;        // speculation: tiles that needed the repair round
+    uint32_t verify_ticket;    // k_spec_verify: blocks that have added their share of spec_need (the last one posts the verdict)
 };
 
 // Tile binning.
@@ -197,7 +198,8 @@ hipError_t launch_admit(hipStream_t s, const Records& rec, uint32_t n, const uin
 
 // Temporal occlusion speculation (kernels_spec.hip): verification of this frame's windows, windows of the next frame.
 hipError_t launch_spec_verify(hipStream_t s, const uint2* win1, const uint32_t* done, uint32_t row_words, uint32_t tiles_x,
-                              uint32_t tiles_y, uint2* win2, uint32_t* need_bits, uint32_t* d_need, uint32_t band_lo, uint32_t band_hi);
+                              uint32_t tiles_y, uint2* win2, uint32_t* need_bits, uint32_t* d_need, uint32_t band_lo, uint32_t band_hi,
+                              uint32_t* d_ticket, unsigned long long* host_verdict /* pinned host word or null */, uint32_t seq);
 hipError_t launch_zero_words(hipStream_t s, uint32_t* a, uint32_t na, uint32_t* b, uint32_t nb);
 hipError_t launch_validate_tiles(hipStream_t s, const uint2* ranges, uint32_t n_tiles, const uint32_t* list, const uint32_t* d_entries,
                                  uint32_t capacity, uint32_t n_records, uint32_t* report);

@@ -185,6 +185,8 @@ struct gsx_viewer {
     DevBuf frame_done;        // u32: tiles saturated so far in the current frame (all models)
     std::vector<std::string> last_keys;  // keys of the last gsx_render, for the overflow redo
     bool last_render_cont = false;
+    unsigned long long* h_verdict = nullptr;  // pinned: {seq << 32 | tiles needing repair}, posted by k_spec_verify (host_verify)
+    uint32_t verify_seq = 0;
     bool validate = false;  // GSX_VALIDATE was set when the viewer was created: check tile ranges / lists before compositing (debug, synchronous)
     uint32_t band_lo = 0, band_hi = 0xFFFFFFFFu;  // tile rows this viewer renders (gsx_viewer_set_band)
     gsx_query query{};                   // GSX_QUERY_NONE
@@ -194,7 +196,7 @@ struct gsx_viewer {
     gsx_gaussian_edit sel_edit{0u, {0.0f, 1.0f, 1.0f}, 0.0f, 0.0f, 1.0f, 1.0f};
     void* ext_fb = nullptr;              // caller-owned framebuffer (multi-GPU: the RCCL gather target)
     uint64_t ext_fb_bytes = 0;
-    gsx_render_options options{1u, 16u, 131072u, 2u, 1u, 0.25f, 3u};
+    gsx_render_options options{1u, 16u, 131072u, 2u, 1u, 0.25f, 3u, 0u};  // = gsx_render_options_default
     uint32_t timing = 0;  // bit p: bracket pass p with events
     std::vector<PassTimer> timers;     // recorded, not yet read
     std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;

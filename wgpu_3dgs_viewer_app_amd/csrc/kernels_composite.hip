@@ -15,7 +15,15 @@
 
 namespace gsx {
 
-constexpr int kBatch = 256;
+#ifndef GSX_VAR_COMP_BATCH
+#define GSX_VAR_COMP_BATCH 128
+#endif
+#ifndef GSX_VAR_COMP_GROUP
+#define GSX_VAR_COMP_GROUP 4
+#endif
+constexpr int kBatch = GSX_VAR_COMP_BATCH;   // splat records staged through LDS per barrier pair
+constexpr int kGroup = GSX_VAR_COMP_GROUP;   // splats blended between two wave-level exit checks (tools/build_variant.sh)
+constexpr int kPerLane = kBatch / 128;
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -89,9 +97,9 @@ __global__ __launch_bounds__(128) void k_composite(const FrameConsts f, uint2* _
     // lane) is in flight while batch b is blended out of LDS.  Slots past the end of the list hold a record no pixel
     // supports (q = +inf), so the blend loop can run in fixed groups of four.
     const float4 pad_a = make_float4(3.0e38f, 3.0e38f, 0.0f, 0.0f), pad_b = make_float4(1.0f, 0.0f, 1.0f, 0.0f);
-    float4 pa[2], pb[2], pc4[2];
+    float4 pa[kPerLane], pb[kPerLane], pc4[kPerLane];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < kPerLane; ++k) {
         pa[k] = pad_a;
         pb[k] = pad_b;
         pc4[k] = make_float4(0, 0, 0, 0);
@@ -107,14 +115,14 @@ __global__ __launch_bounds__(128) void k_composite(const FrameConsts f, uint2* _
         // vote + barrier: also protects the LDS batch of the previous iteration
         if (__syncthreads_and((lim0 | lim1) == 0u)) break;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < kPerLane; ++k) {
             s_mean[tid + 128u * k] = make_float2(pa[k].x, pa[k].y);
             s_conic[tid + 128u * k] = make_float4(pb[k].x, 2.0f * pb[k].y, pb[k].z, pb[k].w);
             s_rgb[tid + 128u * k] = pc4[k];
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < kPerLane; ++k) {
             const uint32_t nxt = base + kBatch + tid + 128u * k;
             pa[k] = pad_a;
             pb[k] = pad_b;
@@ -128,18 +136,18 @@ __global__ __launch_bounds__(128) void k_composite(const FrameConsts f, uint2* _
         const uint32_t cnt = min((uint32_t)kBatch, range.y - base);
         // Groups of four splats, straight-line, one skip branch per splat; a wave whose pixels are all saturated leaves the
         // batch at the next group.
-        for (uint32_t j0 = 0; j0 < cnt; j0 += 4) {
+        for (uint32_t j0 = 0; j0 < cnt; j0 += kGroup) {
             if (!__ballot((lim0 | lim1) != 0u)) break;
             // the group's records first, so the LDS round trips overlap instead of each splat waiting for its own
-            float2 gm[4];
-            float4 gc[4];
+            float2 gm[kGroup];
+            float4 gc[kGroup];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) {
+            for (uint32_t u = 0; u < kGroup; ++u) {
                 gm[u] = s_mean[j0 + u];
                 gc[u] = s_conic[j0 + u];
             }
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) {
+            for (uint32_t u = 0; u < kGroup; ++u) {
                 const uint32_t j = j0 + u;
                 const float2 m = gm[u];
                 const float4 co = gc[u];

@@ -62,7 +62,12 @@ hipError_t launch_validate_tiles(hipStream_t s, const uint2* ranges, uint32_t n_
 __global__ __launch_bounds__(256) void k_spec_verify(const uint2* __restrict__ win1, const uint32_t* __restrict__ done,
                                                       uint32_t row_words, uint32_t tiles_x, uint32_t n_tiles,
                                                       uint2* __restrict__ win2, uint32_t* __restrict__ need_bits,
-                                                      uint32_t* __restrict__ d_need, uint32_t band_lo, uint32_t band_hi) {
+                                                      uint32_t* __restrict__ d_need, uint32_t band_lo, uint32_t band_hi,
+                                                      uint32_t* __restrict__ ticket, unsigned long long* __restrict__ host_verdict,
+                                                      uint32_t seq) {
+    __shared__ uint32_t s_need;
+    if (threadIdx.x == 0) s_need = 0;
+    __syncthreads();
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     // the need bitmap, one thread per word (no clear, no atomics): bit = bounded window && still open
     const uint32_t tiles_y = n_tiles / tiles_x;
@@ -81,7 +86,20 @@ __global__ __launch_bounds__(256) void k_spec_verify(const uint2* __restrict__ w
         win2[t] = need ? make_uint2(w.y, kKeyAll) : make_uint2(0u, 0u);
     }
     const unsigned long long bal = __ballot(need);
-    if ((threadIdx.x & 63u) == 0 && bal) atomicAdd(d_need, (uint32_t)__popcll(bal));
+    if ((threadIdx.x & 63u) == 0 && bal) atomicAdd(&s_need, (uint32_t)__popcll(bal));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_need) atomicAdd(d_need, s_need);
+        if (host_verdict) {
+            // the last block to get here posts {seq, tiles that need the repair round} to pinned host memory: one
+            // system-scope 64-bit store, polled by gsx_render (host_verify).  Ticket pattern: add, fence, take a ticket.
+            __threadfence();
+            if (atomicAdd(ticket, 1u) == gridDim.x - 1u) {
+                const uint32_t total = __hip_atomic_load(d_need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(host_verdict, ((unsigned long long)seq << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
 // the model's windows for its next frame.  A tile that was saturated before this model was composited (done_before,
@@ -170,11 +188,12 @@ hipError_t launch_window_pyramid(hipStream_t s, const uint2* window, uint32_t ti
 }
 
 hipError_t launch_spec_verify(hipStream_t s, const uint2* win1, const uint32_t* done, uint32_t row_words, uint32_t tiles_x,
-                              uint32_t tiles_y, uint2* win2, uint32_t* need_bits, uint32_t* d_need, uint32_t band_lo, uint32_t band_hi) {
-    // *d_need is zero here (the frame's counters are reset before the first slab)
+                              uint32_t tiles_y, uint2* win2, uint32_t* need_bits, uint32_t* d_need, uint32_t band_lo, uint32_t band_hi,
+                              uint32_t* d_ticket, unsigned long long* host_verdict, uint32_t seq) {
+    // *d_need and *d_ticket are zero here (the frame's counters are reset before the first slab)
     const uint32_t n_tiles = tiles_x * tiles_y;
     hipLaunchKernelGGL(k_spec_verify, dim3((n_tiles + 255) / 256), dim3(256), 0, s, win1, done, row_words, tiles_x, n_tiles, win2,
-                       need_bits, d_need, band_lo, band_hi);
+                       need_bits, d_need, band_lo, band_hi, d_ticket, host_verdict, seq);
     return hipGetLastError();
 }
 
