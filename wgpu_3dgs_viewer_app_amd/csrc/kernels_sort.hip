@@ -37,6 +37,10 @@ constexpr int kWaveChunk = 64 * kRadixRounds;             // 1024 contiguous ele
 constexpr uint32_t kRadixGrid = 768;                      // persistent workgroups = resident capacity (3 per CU);
                                                           // measured best of 128..1024 on MI355X
 constexpr uint32_t kMaxPasses = 4;
+#ifndef GSX_VAR_LOOK
+#define GSX_VAR_LOOK 8
+#endif
+constexpr int kLook = GSX_VAR_LOOK;                       // predecessors examined per look-back round trip
 
 constexpr unsigned long long kFlagAggregate = 1, kFlagPrefix = 2;
 
@@ -63,7 +67,7 @@ __device__ inline unsigned long long lanemask_lt() { return (1ull << (threadIdx.
 // ---- histograms of every pass in one read of the keys ----
 template <int KEY_STRIDE /* 1: key array, 2: interleaved {key,value} pairs */>
 __global__ __launch_bounds__(kRadixThreads) void k_radix_global_hist(const uint32_t* __restrict__ keys, uint32_t n_cap,
-                                                                      const uint32_t* __restrict__ d_n, int passes,
+                                                                      const uint32_t* __restrict__ d_n, int passes, int dbits,
                                                                       uint32_t* __restrict__ ghist) {
     __shared__ uint32_t hist[kMaxPasses][256];
     const uint32_t n = d_n ? min(*d_n, n_cap) : n_cap;
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_global_hist(const uint3
         const uint32_t key = valid ? keys[(size_t)e * KEY_STRIDE] : 0u;
         const unsigned long long vmask = __ballot(valid);
         for (int p = 0; p < passes; ++p) {
-            const uint32_t digit = (key >> (8 * p)) & 255u;
+            const uint32_t digit = (key >> (dbits * p)) & ((1u << dbits) - 1u);
             // only counts are needed here: plain LDS atomics, except when the whole wave shares one digit
             // (the exponent byte of depth keys), where 64 same-address atomics would serialise
             const uint32_t first = __builtin_amdgcn_readfirstlane(digit);
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_onesweep(const uint32_t
                                                                    uint32_t* __restrict__ keys_out,
                                                                    uint32_t* __restrict__ vals_out,
                                                                    uint2* __restrict__ pairs_out, uint32_t n_cap,
-                                                                   const uint32_t* __restrict__ d_n, int shift,
+                                                                   const uint32_t* __restrict__ d_n, int shift, uint32_t dmask,
                                                                    const uint32_t* __restrict__ ghist /* this pass */,
                                                                    uint32_t* __restrict__ ticket /* [0] ticket, [1] finished */,
                                                                    u64* __restrict__ status, uint32_t epoch,
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_onesweep(const uint32_t
                 key[r] = valid ? keys_in[e] : 0xFFFFFFFFu;
                 val[r] = valid ? (IN == 0 ? e : vals_in[e]) : 0u;
             }
-            const uint32_t digit = (key[r] >> shift) & 255u;
+            const uint32_t digit = (key[r] >> shift) & dmask;
             const unsigned long long m = wave_match8(digit, valid);
             const uint32_t before = (uint32_t)__popcll(m & lanemask_lt());
             const uint32_t old = valid ? mycnt[digit] : 0u;  // every lane of a digit group reads the same counter
@@ -224,8 +228,10 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_onesweep(const uint32_t
         }
         u64* my_status = status + ((size_t)tile * 256 + tid);
         const u64 tag = (u64)epoch << 34;
-        __hip_atomic_store(my_status, tag | ((tile == 0 ? kFlagPrefix : kFlagAggregate) << 32) | (u64)tile_cnt,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool live = tid <= dmask;  // digits this pass can produce: the others have nothing to publish or look up
+        if (live)
+            __hip_atomic_store(my_status, tag | ((tile == 0 ? kFlagPrefix : kFlagAggregate) << 32) | (u64)tile_cnt,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // local exclusive scan over digits: first local slot of digit d in the reordered tile
         uint32_t lstart;
         {
@@ -242,18 +248,34 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_onesweep(const uint32_t
             lstart = woff + x - tile_cnt;
         }
         uint32_t excl = 0;
-        if (tile > 0) {
+        if (tile > 0 && live) {
+            // Look-back, kLook predecessors per round trip: the status loads of a batch are independent and issued
+            // together (one load at a time made every predecessor a full L2 round trip: with hundreds of tiles in flight
+            // the look-back, not the data movement, set the pass time).  Words are consumed nearest first; an
+            // unpublished one ends the batch and is polled again.
             int32_t k = (int32_t)tile - 1;
-            for (;;) {
-                const u64 s = __hip_atomic_load(status + ((size_t)k * 256 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t flag = (uint32_t)(s >> 32) & 3u;
-                if ((uint32_t)(s >> 34) != epoch || flag == 0) {  // not published yet in this launch
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
+            bool found = false;
+            while (!found) {
+                u64 w[kLook];
+#pragma unroll
+                for (int i = 0; i < kLook; ++i) {
+                    const int32_t kk = max(k - i, 0);
+                    w[i] = __hip_atomic_load(status + ((size_t)kk * 256 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                excl += (uint32_t)s;
-                if (flag == kFlagPrefix || k == 0) break;
-                --k;
+                int32_t used = 0;
+#pragma unroll
+                for (int i = 0; i < kLook; ++i) {
+                    if (!found && used == i && k - i >= 0) {
+                        const uint32_t flag = (uint32_t)(w[i] >> 32) & 3u;
+                        if ((uint32_t)(w[i] >> 34) == epoch && flag != 0) {  // published in this launch
+                            excl += (uint32_t)w[i];
+                            used = i + 1;
+                            found = flag == kFlagPrefix || k - i == 0;
+                        }
+                    }
+                }
+                k -= used;
+                if (!found && used == 0) __builtin_amdgcn_s_sleep(1);
             }
             __hip_atomic_store(my_status, tag | (kFlagPrefix << 32) | (u64)(excl + tile_cnt), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -269,7 +291,7 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_onesweep(const uint32_t
         for (int r = 0; r < kRadixRounds; ++r) {
             const uint32_t e = base + r * 64 + lane;
             if (e < n) {
-                const uint32_t digit = (key[r] >> shift) & 255u;
+                const uint32_t digit = (key[r] >> shift) & dmask;
                 s_pairs[cnt[wave][digit] + rank[r]] = make_uint2(key[r], val[r]);
             }
         }
@@ -281,7 +303,7 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_onesweep(const uint32_t
             const uint32_t slot = r * kRadixThreads + tid;
             if (slot < tile_n) {
                 const uint2 kv = s_pairs[slot];
-                const uint32_t o = s_gbase[(kv.x >> shift) & 255u] + slot;
+                const uint32_t o = s_gbase[(kv.x >> shift) & dmask] + slot;
                 if (OUT == 0) {
                     pairs_out[o] = kv;
                 } else {
@@ -318,6 +340,10 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
                              bool iota_values) {
     if (n == 0) return hipSuccess;
     const int passes = (bits + 7) / 8;
+    // equal digit widths (13 tile-key bits sort as 7 + 6, not 8 + 5): fewer digits mean shorter status rows to publish
+    // and look back over, and longer runs per digit in the scattered writes
+    const int dbits = (bits + passes - 1) / passes;
+    const uint32_t dmask = (1u << dbits) - 1u;
     uint32_t* ghist = buf.workspace;
     uint32_t* ticket = buf.workspace + 1024;
     u64* status = reinterpret_cast<u64*>(buf.workspace + 1032);
@@ -328,18 +354,18 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
     const uint32_t hgrid = std::min<uint32_t>(kRadixGrid, (tiles + 3) / 4);
     if (buf.pairs_src)
         hipLaunchKernelGGL(k_radix_global_hist<2>, dim3(hgrid), dim3(kRadixThreads), 0, s,
-                           reinterpret_cast<const uint32_t*>(buf.pairs_src), n, d_n, passes, ghist);
+                           reinterpret_cast<const uint32_t*>(buf.pairs_src), n, d_n, passes, dbits, ghist);
     else
-        hipLaunchKernelGGL(k_radix_global_hist<1>, dim3(hgrid), dim3(kRadixThreads), 0, s, buf.keys_src, n, d_n, passes, ghist);
+        hipLaunchKernelGGL(k_radix_global_hist<1>, dim3(hgrid), dim3(kRadixThreads), 0, s, buf.keys_src, n, d_n, passes, dbits, ghist);
     const uint2* pin = buf.pairs_src;
     uint2* pout = buf.pairs_a;
     for (int p = 0; p < passes; ++p) {
-        const int shift = 8 * p;
+        const int shift = dbits * p;
         const bool first = p == 0, last = p == passes - 1;
         const uint32_t epoch = (g_epoch++ & 0x1FFFFFFFu) | (1u << 29);  // 30 bits, never 0
 #define GSX_SWEEP(IN, OUT)                                                                                              \
     hipLaunchKernelGGL((k_radix_onesweep<IN, OUT>), dim3(grid), dim3(kRadixThreads), 0, s, buf.keys_src, buf.vals_src, pin, \
-                       buf.keys_out, buf.vals_out, pout, n, d_n, shift, ghist + 256 * p, ticket, status, epoch, ghist,         \
+                       buf.keys_out, buf.vals_out, pout, n, d_n, shift, dmask, ghist + 256 * p, ticket, status, epoch, ghist,         \
                        last ? 256u * (uint32_t)passes : 0u)
         if (first && buf.pairs_src) {
             if (last) GSX_SWEEP(2, 1); else GSX_SWEEP(2, 0);
