@@ -38,6 +38,7 @@ gsx_status gsx_viewer_create(const gsx_viewer_desc* desc, gsx_viewer** out) {
     HIPCHK(hipSetDevice(desc->device));
     std::unique_ptr<gsx_viewer> v(new gsx_viewer());
     v->validate = getenv("GSX_VALIDATE") != nullptr;
+    (void)radix_lane_ordered_adds();  // probes the device once per process
     v->device = desc->device;
     if (desc->stream) {
         v->stream = reinterpret_cast<hipStream_t>(desc->stream);

@@ -123,6 +123,9 @@ struct RadixBuffers {
     uint32_t* workspace;  // radix_workspace_words(n) u32, zero-initialised once at allocation
 };
 size_t radix_workspace_words(uint64_t n);
+// One-time probe (synchronous, current device): may the sort take its stable ranks from returning LDS adds?  Until it has
+// been called the sort uses the ballot-matching ranks.  GSX_RADIX_MATCH_RANKS=1 forces those.
+bool radix_lane_ordered_adds();
 // n sizes the launch; d_n (nullable) is the real element count on the device (<= n).
 hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n, const uint32_t* d_n, int bits,
                              bool iota_values);
