@@ -462,7 +462,8 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
     // a single-slab front model keeps its complete tile lists for gsx_model_download_tile_lists
     const bool clear_ranges = progressive && !(bounds.size() == 2 && !carry && !m->spec_round1);
     // one depth slab [j0, j1) of the current depth order: bin -> tile sort -> ranges -> composite
-    auto run_slab = [&](uint32_t j0, uint32_t j1, bool later, const uint2* win, const uint32_t* d_n, uint32_t slab_index) -> gsx_status {
+    auto run_slab = [&](uint32_t j0, uint32_t j1, bool later, const uint2* win, const uint32_t* d_n, uint32_t slab_index,
+                        const WindowPyramid* min_ends = nullptr) -> gsx_status {
         // the very first slab of the frame sees no saturated tile: plain rectangle areas
         const uint32_t* done_in = later ? done : nullptr;
         // a slab of S splats can produce at most S * n_tiles entries; size the sort launch by the smaller bound
@@ -472,7 +473,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
             HIPCHK(launch_tile_counts(v->stream, j0, j1, d_n, m->sorted_idx, m->rec(), m->srect.as<uint2>(),
                                       m->cnt.as<uint32_t>(), m->block_sums.as<uint32_t>(), dc, cap, row_lo, row_hi, done_in,
                                       row_words, (progressive && later) ? done_count : nullptr, owned_tiles, slab_index,
-                                      win, m->sk_out.as<uint32_t>(), m->fc.tiles_x));
+                                      win, m->sk_out.as<uint32_t>(), m->fc.tiles_x, min_ends));
             HIPCHK(launch_tile_emit(v->stream, j0, j1, m->sorted_idx, m->srect.as<uint2>(), m->cnt.as<uint32_t>(),
                                     m->block_sums.as<uint32_t>(), m->fc.tiles_x, m->tp_src.as<uint2>(), row_lo, row_hi,
                                     done_in, row_words, d_n, &dc->n_entries, cap, win, m->sk_out.as<uint32_t>()));
@@ -517,15 +518,26 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
         return GSX_OK;
     };
     gsx_status st = GSX_OK;
+    // a speculated round's windows all start at 0 and come with the min-pyramid of their ends (enqueue_next_windows)
+    WindowPyramid min_ends{};
+    if (m->spec_round1) {
+        const size_t pw = window_pyramid_words(m->fc.tiles_x, m->fc.tiles_y);
+        min_ends = window_pyramid_layout(m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse.as<uint32_t>() + pw);
+    }
     for (size_t sl = 0; sl + 1 < bounds.size(); ++sl)
-        if ((st = run_slab(bounds[sl], bounds[sl + 1], carry || sl > 0, window, &dc->n_sorted, (uint32_t)sl))) return st;
+        if ((st = run_slab(bounds[sl], bounds[sl + 1], carry || sl > 0, window, &dc->n_sorted, (uint32_t)sl,
+                           m->spec_round1 ? &min_ends : nullptr)))
+            return st;
     bool windows_enqueued = false;
     auto enqueue_next_windows = [&]() -> gsx_status {  // this model's windows for its next frame
         ScopedPass t(v, GSX_PASS_COMPOSITE);
         HIPCHK(launch_spec_next(v->stream, tile_sat, done, done_before, row_words, m->fc.tiles_x, m->fc.tiles_y,
                                 v->options.spec_margin, v->options.spec_radius, m->spec_win.as<uint2>(), row_lo, row_hi));
-        HIPCHK(m->spec_coarse.ensure(4 * window_pyramid_words(m->fc.tiles_x, m->fc.tiles_y)));
-        HIPCHK(launch_window_pyramid(v->stream, m->spec_win.as<uint2>(), m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse.as<uint32_t>()));
+        // [max-pyramid of the window ends: admission in k_project | min-pyramid: "every tile takes it" in the binning]
+        const size_t pw = window_pyramid_words(m->fc.tiles_x, m->fc.tiles_y);
+        HIPCHK(m->spec_coarse.ensure(8 * pw));
+        HIPCHK(launch_window_pyramid(v->stream, m->spec_win.as<uint2>(), m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse.as<uint32_t>(), false,
+                                     nullptr, m->spec_coarse.as<uint32_t>() + pw));
         m->spec_valid = true;
         m->spec_tiles_x = m->fc.tiles_x;
         m->spec_tiles_y = m->fc.tiles_y;

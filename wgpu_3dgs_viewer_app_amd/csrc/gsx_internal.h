@@ -154,7 +154,8 @@ hipError_t launch_tile_counts(hipStream_t s, uint32_t j0, uint32_t j1, const uin
                               const Records& rec, uint2* srect, uint32_t* cnt, uint32_t* block_sums, SlabStats* stats,
                               uint32_t capacity, uint32_t row_lo, uint32_t row_hi, const uint32_t* done, uint32_t row_words,
                               const uint32_t* d_done_count, uint32_t owned_tiles, uint32_t slab_index,
-                              const uint2* window, const uint32_t* sorted_keys, uint32_t tiles_x);
+                              const uint2* window, const uint32_t* sorted_keys, uint32_t tiles_x,
+                              const WindowPyramid* min_ends = nullptr /* of `window`, when every window starts at 0 */);
 hipError_t launch_tile_emit(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* sorted_idx, const uint2* srect,
                             const uint32_t* cnt, const uint32_t* block_sums, uint32_t tiles_x, uint2* tpairs,
                             uint32_t row_lo, uint32_t row_hi, const uint32_t* done, uint32_t row_words,
@@ -179,7 +180,7 @@ hipError_t launch_selection_op(hipStream_t s, uint32_t n_words, uint32_t op, con
 WindowPyramid window_pyramid_layout(uint32_t tiles_x, uint32_t tiles_y, const uint32_t* data);  // total words: off[levels]... see .hip
 size_t window_pyramid_words(uint32_t tiles_x, uint32_t tiles_y);
 hipError_t launch_window_pyramid(hipStream_t s, const uint2* window, uint32_t tiles_x, uint32_t tiles_y, uint32_t* data,
-                                 bool min_of_starts = false, const uint32_t* d_skip = nullptr);
+                                 bool min_of_starts = false, const uint32_t* d_skip = nullptr, uint32_t* min_ends = nullptr);
 
 // exclusive scan of the projection pass's per-workgroup counts (total -> *d_total), then the compaction of the admitted
 // (key, index) pairs in ascending index order

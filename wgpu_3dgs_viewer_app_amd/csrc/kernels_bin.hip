@@ -58,7 +58,23 @@ struct TileWindow {
     const uint2* win;             // [tiles_y * tiles_x] or nullptr
     const uint32_t* sorted_keys;  // key of depth-order position j
     uint32_t tiles_x;
+    WindowPyramid min_ends;       // .data nullable: min-pyramid of the window ends (every window starts at 0)
 };
+
+// srect.x bit 31 (set by k_tile_counts, read by k_tile_emit): every tile of the rectangle takes the splat — no per-tile test
+constexpr uint32_t kAllTake = 0x80000000u;
+
+// true if EVERY tile of the (band-clipped, non-empty) rectangle [x0, xb] x [y0, yb] has a window end above `key`: the
+// rectangle lies under at most 2x2 cells of the level its extent selects, and a cell holds the minimum over its tiles
+__device__ inline bool pyramid_all_take(const WindowPyramid& p, uint32_t key, uint32_t x0, uint32_t xb, uint32_t y0, uint32_t yb) {
+    const uint32_t ext = max(xb - x0, yb - y0);  // extent - 1
+    const uint32_t l = ext ? 32u - (uint32_t)__clz((int)ext) : 0u;
+    if (l >= p.levels) return false;
+    const uint32_t* L = p.data + p.off[l];
+    const uint32_t wx = p.wx[l];
+    const uint32_t cx0 = x0 >> l, cx1 = min(xb >> l, wx - 1u), cy0 = y0 >> l, cy1 = min(yb >> l, p.wy[l] - 1u);
+    return key < min(min(L[cy0 * wx + cx0], L[cy0 * wx + cx1]), min(L[cy1 * wx + cx0], L[cy1 * wx + cx1]));
+}
 
 __device__ inline bool tile_takes(const uint32_t* done, uint32_t row_words, const uint2* win, uint32_t tiles_x, uint32_t tx,
                                   uint32_t ty, uint32_t key) {
@@ -116,7 +132,15 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_counts(const uint32_t* __r
             if (tw.win) {
                 key = tw.sorted_keys[j];
                 area = rect_area(a, row_lo, row_hi);
-                if (area <= kCoopThreshold)
+                // most splats of a speculated round lie in front of every window end under them: four pyramid loads
+                // instead of one dependent load per tile (the per-tile tests are bound by the L1's line rate: 64 lanes,
+                // 64 different lines per instruction)
+                if (area && !done && tw.min_ends.data &&
+                    pyramid_all_take(tw.min_ends, key, rx & 0xFFFFu, (rx >> 16) - 1u, max(ry & 0xFFFFu, row_lo), min(ry >> 16, row_hi) - 1u)) {
+                    c = area;
+                    area = 0;  // nothing left to test
+                    rx |= kAllTake;
+                } else if (area <= kCoopThreshold)
                     for (uint32_t ty = max(ry & 0xFFFFu, row_lo), last = min(ry >> 16, row_hi); ty < last; ++ty)
                         c += window_tiles_in_row(done, row_words, tw.win, tw.tiles_x, ty, rx & 0xFFFFu, rx >> 16, key);
             } else {
@@ -246,10 +270,13 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_emit(uint32_t jbase, uint3
     uint32_t idx = 0;
     uint2 r = make_uint2(0, 0);
     uint32_t key = 0;
+    bool all = false;  // k_tile_counts found every tile of the rectangle taking it (kAllTake; implies no saturation bitmap)
     if (mine) {
         idx = sorted_idx[j];
         r = srect[j - jbase];
-        if (tw.win) key = tw.sorted_keys[j];
+        all = (r.x & kAllTake) != 0u;
+        r.x &= ~kAllTake;
+        if (tw.win && !all) key = tw.sorted_keys[j];
     }
     // a lane walks its own rectangle only if that is short; large rectangles (even with few takers left) go to the wave
     uint32_t area = 0;
@@ -257,7 +284,8 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_emit(uint32_t jbase, uint3
         const uint32_t ya = max(r.y & 0xFFFFu, row_lo), yb = min(r.y >> 16, row_hi);
         area = ((r.x >> 16) - (r.x & 0xFFFFu)) * (yb > ya ? yb - ya : 0u);
     }
-    if (mine && area <= kCoopThreshold) emit_rect(tpairs, o, capacity, idx, r, tiles_x, row_lo, row_hi, done, row_words, tw.win, key);
+    if (mine && area <= kCoopThreshold)
+        emit_rect(tpairs, o, capacity, idx, r, tiles_x, row_lo, row_hi, done, row_words, all ? nullptr : tw.win, key);
     // large splats: one at a time, all 64 lanes
     unsigned long long big = __ballot(area > kCoopThreshold);
     while (big) {
@@ -268,7 +296,8 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_emit(uint32_t jbase, uint3
         const uint32_t x0 = rx & 0xFFFFu, x1 = rx >> 16, y0 = ry & 0xFFFFu, y1 = ry >> 16;
         const uint32_t w = x1 - x0;
         const uint32_t bkey = __shfl(key, src, 64);
-        if (!done && !tw.win) {
+        const bool ball = __shfl((int)all, src, 64) != 0;
+        if (!done && (!tw.win || ball)) {
             // no saturated tiles: the k-th entry is tile (first + k / w, x0 + k % w)
             const uint32_t first = max(y0, row_lo);
             const uint32_t total = __shfl(mine, src, 64);
@@ -321,9 +350,9 @@ hipError_t launch_tile_counts(hipStream_t s, uint32_t j0, uint32_t j1, const uin
                               const Records& rec, uint2* srect, uint32_t* cnt, uint32_t* block_sums, SlabStats* stats,
                               uint32_t capacity, uint32_t row_lo, uint32_t row_hi, const uint32_t* done, uint32_t row_words,
                               const uint32_t* d_done_count, uint32_t owned_tiles, uint32_t slab_index,
-                              const uint2* window, const uint32_t* sorted_keys, uint32_t tiles_x) {
+                              const uint2* window, const uint32_t* sorted_keys, uint32_t tiles_x, const WindowPyramid* min_ends) {
     const uint32_t nb = std::min<uint32_t>((uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0), kBinGrid);
-    TileWindow tw{window, sorted_keys, tiles_x};
+    TileWindow tw{window, sorted_keys, tiles_x, min_ends ? *min_ends : WindowPyramid{}};
     if (nb)
         hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(kBinThreads), 0, s, d_n_vis, j0, j1, sorted_idx, rec.a, srect, cnt,
                            block_sums, row_lo, row_hi, done, row_words, d_done_count, owned_tiles, tw);
@@ -339,7 +368,7 @@ hipError_t launch_tile_emit(hipStream_t s, uint32_t j0, uint32_t j1, const uint3
                             const uint2* window, const uint32_t* sorted_keys) {
     const uint32_t nb = std::min<uint32_t>((uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0), kBinGrid);
     if (!nb) return hipSuccess;
-    TileWindow tw{window, sorted_keys, tiles_x};
+    TileWindow tw{window, sorted_keys, tiles_x, WindowPyramid{}};
     hipLaunchKernelGGL(k_tile_emit, dim3(nb), dim3(kBinThreads), 0, s, j0, j1, sorted_idx, srect, cnt, block_sums,
                        tiles_x, tpairs, row_lo, row_hi, done, row_words, d_n_vis, d_entries, capacity, tw);
     return hipGetLastError();

@@ -442,7 +442,10 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
     static const uint32_t grid_limit = getenv("GSX_RADIX_GRID") ? (uint32_t)atoi(getenv("GSX_RADIX_GRID")) : kRadixGrid;
     const uint32_t grid = std::min<uint32_t>(grid_limit, tiles);
     // ghist is zero here: the workspace is cleared at allocation and every sort's last pass clears it again
-    const uint32_t hgrid = std::min<uint32_t>(kRadixGrid, (tiles + 3) / 4);
+    // histogram workgroups: ~one per 1024..4096 elements up to the persistent grid (sorts of a few hundred thousand elements
+    // are latency-bound: 300 k keys took 89 us with 4096 x 4 elements per workgroup, 67 us with 4096)
+    static const uint32_t hper = getenv("GSX_RADIX_HPER") ? (uint32_t)atoi(getenv("GSX_RADIX_HPER")) : 4096u;
+    const uint32_t hgrid = std::max<uint32_t>(1u, std::min<uint32_t>(kRadixGrid, (uint32_t)(((uint64_t)n + hper - 1) / hper)));
     if (buf.pairs_src)
         hipLaunchKernelGGL(k_radix_global_hist<2>, dim3(hgrid), dim3(kRadixThreads), 0, s,
                            reinterpret_cast<const uint32_t*>(buf.pairs_src), n, d_n, passes, dbits, ghist);

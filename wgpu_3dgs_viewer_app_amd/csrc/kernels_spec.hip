@@ -158,13 +158,16 @@ size_t window_pyramid_words(uint32_t tiles_x, uint32_t tiles_y) {
     return (size_t)p.off[p.levels - 1] + (size_t)p.wx[p.levels - 1] * p.wy[p.levels - 1];
 }
 
-// one workgroup builds every level (11 k words at 1080p): level 0 = the window ends, level l = 2x2 max of level l-1
+// one workgroup builds every level (11 k words at 1080p): level 0 = the window ends, level l = 2x2 max of level l-1.
+// min_ends (nullable): a second pyramid, the MIN of the window ends — "every tile under this rectangle takes this key"
+// for windows that start at 0 (the binning's fast path, kernels_bin.hip).
 __global__ __launch_bounds__(1024) void k_window_pyramid(const uint2* __restrict__ window, WindowPyramid p, uint32_t* __restrict__ data,
-                                                         const uint32_t* __restrict__ d_skip) {
+                                                         const uint32_t* __restrict__ d_skip, uint32_t* __restrict__ min_ends) {
     if (d_skip && *d_skip == 0) return;  // repair round with nothing to repair
     for (uint32_t i = threadIdx.x; i < p.wx[0] * p.wy[0]; i += 1024) {
         const uint2 w = window[i];
         data[i] = p.min_of_starts ? (w.y > w.x ? w.x : 0xFFFFFFFFu) : w.y;
+        if (min_ends) min_ends[i] = w.x == 0u ? w.y : 0u;  // a window that does not start at 0 promises nothing
     }
     for (uint32_t l = 1; l < p.levels; ++l) {
         __syncthreads();
@@ -175,15 +178,19 @@ __global__ __launch_bounds__(1024) void k_window_pyramid(const uint2* __restrict
             const uint32_t x = 2u * (i % wx), y = 2u * (i / wx), x1 = min(x + 1u, px - 1u), y1 = min(y + 1u, py - 1u);
             const uint32_t a = src[y * px + x], b = src[y * px + x1], c = src[y1 * px + x], d = src[y1 * px + x1];
             dst[i] = p.min_of_starts ? min(min(a, b), min(c, d)) : max(max(a, b), max(c, d));
+            if (min_ends) {
+                const uint32_t* ms = min_ends + p.off[l - 1];
+                min_ends[p.off[l] + i] = min(min(ms[y * px + x], ms[y * px + x1]), min(ms[y1 * px + x], ms[y1 * px + x1]));
+            }
         }
     }
 }
 
 hipError_t launch_window_pyramid(hipStream_t s, const uint2* window, uint32_t tiles_x, uint32_t tiles_y, uint32_t* data,
-                                 bool min_of_starts, const uint32_t* d_skip) {
+                                 bool min_of_starts, const uint32_t* d_skip, uint32_t* min_ends) {
     WindowPyramid p = window_pyramid_layout(tiles_x, tiles_y, data);
     p.min_of_starts = min_of_starts ? 1u : 0u;
-    hipLaunchKernelGGL(k_window_pyramid, dim3(1), dim3(1024), 0, s, window, p, data, d_skip);
+    hipLaunchKernelGGL(k_window_pyramid, dim3(1), dim3(1024), 0, s, window, p, data, d_skip, min_ends);
     return hipGetLastError();
 }
 
