@@ -132,7 +132,7 @@ gsx_status gsx_model_create(gsx_viewer* v, const char* key, uint64_t count, gsx_
     if (sh == GSX_SH_SINGLE) {
         HIPCHK(m->sh4.ensure(16 * n * kShPlanes4));
         HIPCHK(m->sh1.ensure(4 * n));
-        HIPCHK(m->sh_aos.ensure(16 * n * 12));
+        HIPCHK(m->sh_aos.ensure(16 * n * (cov3d == GSX_COV3D_SINGLE ? 16 : 12)));
     } else if (sh == GSX_SH_HALF) {
         HIPCHK(m->sh_h.ensure(16 * n * 6));
         HIPCHK(m->sh_aos.ensure(16 * n * 6));

@@ -54,8 +54,11 @@ struct PodPlanes {
     float* sh1;      // N   : SH float 44
     uint4* sh_h;     // 6*N : plane p holds SH floats 8p..8p+7 as f16
     uint4* sh_q;     // 3*N : plane p holds SH floats 16p..16p+15 as snorm8
-    uint4* sh_aos;   // P*N : record copy of the SH planes, P = 12 / 6 / 3 consecutive words per Gaussian (plane order; f32: word 11 =
-                     //       {float 44, 0, 0, 0}); nullptr for Sh None.  Read by the sparse shading pass, where whole lines count.
+    uint4* sh_aos;   // P*N : record copy of the SH planes, P = aos_stride consecutive words per Gaussian (plane order; f32: word
+                     //       11 = {float 44, 0, 0, 0}); nullptr for Sh None.  Read by the sparse shading pass, where whole lines
+                     //       count.  f32 SH + f32 covariance: P = 16, a 256-byte record that also carries word 12 = pc, 13 = cov_a,
+                     //       14 = {cov_b, 0, 0} — everything k_shade reads about a Gaussian, in two 128-byte lines.
+    uint32_t aos_stride;  // 16 (full record) | 12 / 6 / 3 (SH only: f32 / f16 / snorm8)
     uint2* cov_h;    // N   : xx, xy, xz, yy as f16
     uint32_t* cov_h2;  // N : yz, zz as f16
     uint32_t* mask;  // ceil(N/32) words, bit = keep (nullptr: keep all)

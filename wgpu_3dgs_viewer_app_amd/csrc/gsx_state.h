@@ -136,6 +136,7 @@ struct Model {
         p.sh_h = sh_h.as<uint4>();
         p.sh_q = sh_q.as<uint4>();
         p.sh_aos = sh_aos.as<uint4>();
+        p.aos_stride = sh_kind == GSX_SH_SINGLE ? (cov_kind == GSX_COV3D_SINGLE ? 16u : 12u) : sh_kind == GSX_SH_HALF ? 6u : sh_kind == GSX_SH_NORM8 ? 3u : 0u;
         p.cov_h = cov_h.as<uint2>();
         p.cov_h2 = cov_h2.as<uint32_t>();
         p.sh_kind = (int)sh_kind;

@@ -114,10 +114,10 @@ __device__ inline void store_sh(const PodPlanes& pod, uint64_t model_n, uint64_t
         for (int p = 0; p < kShPlanes4; ++p) {
             const float4 v = make_float4(s45[4 * p], s45[4 * p + 1], s45[4 * p + 2], s45[4 * p + 3]);
             pod.sh4[(uint64_t)p * model_n + i] = v;
-            if (pod.sh_aos) pod.sh_aos[i * 12 + p] = make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w));
+            if (pod.sh_aos) pod.sh_aos[i * pod.aos_stride + p] = make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w));
         }
         pod.sh1[i] = s45[44];
-        if (pod.sh_aos) pod.sh_aos[i * 12 + 11] = make_uint4(__float_as_uint(s45[44]), 0u, 0u, 0u);
+        if (pod.sh_aos) pod.sh_aos[i * pod.aos_stride + 11] = make_uint4(__float_as_uint(s45[44]), 0u, 0u, 0u);
     } else if (pod.sh_kind == GSX_SH_HALF) {
         for (int p = 0; p < 6; ++p) {
             uint32_t w[4];
@@ -143,6 +143,16 @@ __device__ inline void store_sh(const PodPlanes& pod, uint64_t model_n, uint64_t
             if (pod.sh_aos) pod.sh_aos[i * 3 + p] = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
+}
+
+// full 256-byte shade record (aos_stride 16): position + colour word and the covariance beside the SH words
+__device__ inline void store_aos_geometry(const PodPlanes& pod, uint64_t i, float4 pc, float c0, float c1, float c2, float c3, float c4,
+                                          float c5) {
+    if (!pod.sh_aos || pod.aos_stride != 16u) return;
+    uint4* r = pod.sh_aos + i * 16u;
+    r[12] = make_uint4(__float_as_uint(pc.x), __float_as_uint(pc.y), __float_as_uint(pc.z), __float_as_uint(pc.w));
+    r[13] = make_uint4(__float_as_uint(c0), __float_as_uint(c1), __float_as_uint(c2), __float_as_uint(c3));
+    r[14] = make_uint4(__float_as_uint(c4), __float_as_uint(c5), 0u, 0u);
 }
 
 __device__ inline void store_cov(const PodPlanes& pod, uint64_t i, float c0, float c1, float c2, float c3, float c4, float c5) {
@@ -223,6 +233,7 @@ __global__ __launch_bounds__(256) void k_convert(const gsx_gaussian* __restrict_
                    ((uint32_t)g.color[3] << 24);
     pod.pc[i] = make_float4(g.pos[0], g.pos[1], g.pos[2], __uint_as_float(col));
     store_cov(pod, i, c0, c1, c2, c3, c4, c5);
+    store_aos_geometry(pod, i, make_float4(g.pos[0], g.pos[1], g.pos[2], __uint_as_float(col)), c0, c1, c2, c3, c4, c5);
     store_sh(pod, model_n, i, &g.sh[0][0]);
 }
 
@@ -235,6 +246,8 @@ __global__ __launch_bounds__(256) void k_pack_pod(const float* __restrict__ pos,
     uint64_t i = start + t;
     pod.pc[i] = make_float4(pos[3 * t], pos[3 * t + 1], pos[3 * t + 2], __uint_as_float(color[t]));
     store_cov(pod, i, cov[6 * t], cov[6 * t + 1], cov[6 * t + 2], cov[6 * t + 3], cov[6 * t + 4], cov[6 * t + 5]);
+    store_aos_geometry(pod, i, make_float4(pos[3 * t], pos[3 * t + 1], pos[3 * t + 2], __uint_as_float(color[t])), cov[6 * t], cov[6 * t + 1],
+                       cov[6 * t + 2], cov[6 * t + 3], cov[6 * t + 4], cov[6 * t + 5]);
     if (sh) store_sh(pod, model_n, i, sh + 45 * t);
 }
 
@@ -326,7 +339,7 @@ __device__ inline void load_shade(const FrameConsts& f, const PodPlanes& pod, ui
 #pragma unroll
         for (int p = 0; p < ShNeed<DEG>::planes4; ++p) {
             if (AOS) {
-                const uint4 v = pod.sh_aos[(uint64_t)i * 12 + p];
+                const uint4 v = pod.sh_aos[(uint64_t)i * pod.aos_stride + p];
                 s[4 * p] = __uint_as_float(v.x); s[4 * p + 1] = __uint_as_float(v.y);
                 s[4 * p + 2] = __uint_as_float(v.z); s[4 * p + 3] = __uint_as_float(v.w);
             } else {
@@ -334,7 +347,7 @@ __device__ inline void load_shade(const FrameConsts& f, const PodPlanes& pod, ui
                 s[4 * p] = v.x; s[4 * p + 1] = v.y; s[4 * p + 2] = v.z; s[4 * p + 3] = v.w;
             }
         }
-        if (DEG == 3) s[44] = AOS ? __uint_as_float(pod.sh_aos[(uint64_t)i * 12 + 11].x) : ld_stream(&pod.sh1[i]);
+        if (DEG == 3) s[44] = AOS ? __uint_as_float(pod.sh_aos[(uint64_t)i * pod.aos_stride + 11].x) : ld_stream(&pod.sh1[i]);
     } else if (SHK == GSX_SH_HALF) {
 #pragma unroll
         for (int p = 0; p < (kFloats + 7) / 8; ++p) {
@@ -423,10 +436,26 @@ __global__ __launch_bounds__(256) void k_shade(const FrameConsts f, const uint32
     for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < count; j += gridDim.x * 256u) {
         const uint32_t i = pairs[j].y;
         if (skip && ((skip[i >> 6] >> (i & 63u)) & 1ull)) continue;
-        const float4 pc = pod.pc[i];
+        // 256-byte record: no other gather (Sh None models run the f32 instantiation without a record copy)
+        const bool full = COVK == GSX_COV3D_SINGLE && SHK == GSX_SH_SINGLE && pod.sh_aos != nullptr && pod.aos_stride == 16u;
+        float4 pc;
+        if (full) {
+            const uint4 w = pod.sh_aos[(uint64_t)i * 16u + 12u];
+            pc = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+        } else {
+            pc = pod.pc[i];
+        }
         ViewClip vc;
         Splat2D sp{};
-        if (!pm_view_cull(f, pc.x, pc.y, pc.z, vc) || !load_cov2d_rect<COVK>(f, pod, i, vc, sp)) continue;  // cannot happen: it is visible
+        if (!pm_view_cull(f, pc.x, pc.y, pc.z, vc)) continue;  // cannot happen: it is visible
+        if (full) {
+            const uint4 a = pod.sh_aos[(uint64_t)i * 16u + 13u], b2 = pod.sh_aos[(uint64_t)i * 16u + 14u];
+            if (!pm_cov2d_rect(f, vc, __uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
+                               __uint_as_float(b2.x), __uint_as_float(b2.y), sp))
+                continue;
+        } else if (!load_cov2d_rect<COVK>(f, pod, i, vc, sp)) {
+            continue;
+        }
         float r, g, b;
         load_shade<DEG, SHK, true>(f, pod, n, i, pc, r, g, b);
         rec.b[i] = make_float4(sp.con_a, sp.con_b, sp.con_c, (float)(__float_as_uint(pc.w) >> 24) * (1.0f / 255.0f));
