@@ -124,16 +124,23 @@ __global__ __launch_bounds__(1024) void k_admit_scan(const uint32_t* __restrict_
     if (tid == 0) *d_total = carry_s;
 }
 
-__global__ __launch_bounds__(256) void k_admit_scatter256(const uint32_t* __restrict__ key, uint32_t n,
+// One lane per ballot word (64 Gaussians, one wave of k_project): a few per cent of the Gaussians are admitted, so a
+// thread per Gaussian mostly dispatched workgroups that had nothing to do (39 K workgroups at 10 M: 27 us of dispatch).
+// words = ceil(n / 64); word w belongs to projection workgroup w / 4, whose first output slot is offsets[w / 4].
+__global__ __launch_bounds__(256) void k_admit_scatter256(const uint32_t* __restrict__ key, uint32_t words,
                                                            const unsigned long long* __restrict__ ballots,
                                                            const uint32_t* __restrict__ offsets, uint2* __restrict__ pairs) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const unsigned long long* b = ballots + blockIdx.x * 4u;
-    const unsigned long long mine = b[wave];
-    if (!((mine >> lane) & 1ull)) return;
-    uint32_t o = offsets[blockIdx.x];
-    for (uint32_t w = 0; w < wave; ++w) o += (uint32_t)__popcll(b[w]);
-    pairs[o + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))] = make_uint2(key[i], i);
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    if (w >= words) return;
+    unsigned long long mine = ballots[w];
+    if (!mine) return;
+    uint32_t o = offsets[w >> 2];
+    for (uint32_t q = w & ~3u; q < w; ++q) o += (uint32_t)__popcll(ballots[q]);
+    while (mine) {  // ascending lanes: index order inside the word
+        const uint32_t i = w * 64u + (uint32_t)__ffsll((long long)mine) - 1u;
+        mine &= mine - 1ull;
+        pairs[o++] = make_uint2(key[i], i);
+    }
 }
 
 hipError_t launch_admit_from_project(hipStream_t s, const uint32_t* key, uint32_t n, const unsigned long long* ballots,
@@ -141,7 +148,8 @@ hipError_t launch_admit_from_project(hipStream_t s, const uint32_t* key, uint32_
     const uint32_t nb = (n + 255) / 256;
     if (!nb) return hipMemsetAsync(d_total, 0, 4, s);
     hipLaunchKernelGGL(k_admit_scan, dim3(1), dim3(1024), 0, s, block_counts, block_offsets, nb, d_total);
-    hipLaunchKernelGGL(k_admit_scatter256, dim3(nb), dim3(256), 0, s, key, n, ballots, block_offsets, pairs);
+    const uint32_t words = (n + 63) / 64;
+    hipLaunchKernelGGL(k_admit_scatter256, dim3((words + 255) / 256), dim3(256), 0, s, key, words, ballots, block_offsets, pairs);
     return hipGetLastError();
 }
 
