@@ -424,6 +424,91 @@ __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint
     }
 }
 
+// Geometry-only projection (the lazy variant of k_project: same values, same outputs), written so that a lane can carry
+// PER Gaussians, 256 apart, with all loads of a stage issued before any is consumed.  Measured on cfg4 (10 M): PER = 1
+// 118-120 us, 2: 122, 4: 127 — the pass is not waiting on its chain of dependent loads (position -> covariance ->
+// pyramid cells), it moves 600 MB at ~5.1 TB/s, which is what a plain streaming copy reaches on this part; PER stays 1.
+// What the straight-line form (no branch around the covariance loads: culled lanes read element 0) buys over the
+// LAZY instantiation of k_project is ~5 %.  A workgroup covers PER consecutive 256-Gaussian groups and writes their
+// ballots / counts exactly where PER workgroups of k_project would.
+#ifndef GSX_VAR_PROJ_PER
+#define GSX_VAR_PROJ_PER 1
+#endif
+template <int COVK, int PER>
+__global__ __launch_bounds__(256) void k_project_geom(const FrameConsts f, const uint32_t n, const PodPlanes pod,
+                                                       const Records rec, uint32_t* __restrict__ block_visible,
+                                                       const ProjectAdmission adm) {
+    const uint32_t base = blockIdx.x * (256u * PER) + threadIdx.x;
+    float4 pc[PER];
+    bool vis[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t i = base + 256u * k;
+        vis[k] = i < n;
+        pc[k] = ld_stream(&pod.pc[vis[k] ? i : 0u]);
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t i = base + 256u * k;
+        if (vis[k] && pod.mask) vis[k] = (pod.mask[i >> 5] >> (i & 31)) & 1u;
+    }
+    ViewClip vc[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) vis[k] = pm_view_cull(f, pc[k].x, pc[k].y, pc[k].z, vc[k]) && vis[k];
+    // covariance: every load first (culled lanes read element 0: one line per wave, no branch around the load)
+    float cv[PER][6];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t i = vis[k] ? base + 256u * k : 0u;
+        if (COVK == GSX_COV3D_SINGLE) {
+            const float4 a = ld_stream(&pod.cov_a[i]);
+            const float2 b = ld_stream(&pod.cov_b[i]);
+            cv[k][0] = a.x; cv[k][1] = a.y; cv[k][2] = a.z; cv[k][3] = a.w; cv[k][4] = b.x; cv[k][5] = b.y;
+        } else {
+            const uint2 a = ld_stream(&pod.cov_h[i]);
+            const uint32_t b = ld_stream(&pod.cov_h2[i]);
+            cv[k][0] = h_lo(a.x); cv[k][1] = h_hi(a.x); cv[k][2] = h_lo(a.y); cv[k][3] = h_hi(a.y); cv[k][4] = h_lo(b); cv[k][5] = h_hi(b);
+        }
+    }
+    Splat2D sp[PER];
+    bool take[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        sp[k] = Splat2D{};
+        if (vis[k]) vis[k] = pm_cov2d_rect(f, vc[k], cv[k][0], cv[k][1], cv[k][2], cv[k][3], cv[k][4], cv[k][5], sp[k]);
+        if (vis[k] && ((sp[k].ry >> 16) <= f.band_lo || (sp[k].ry & 0xFFFFu) >= f.band_hi)) vis[k] = false;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        take[k] = vis[k];
+        if (adm.pyramid.data && vis[k]) take[k] = pyramid_admits(adm.pyramid, __float_as_uint(vc[k].d), sp[k].rx, sp[k].ry);
+    }
+    __shared__ uint32_t wave_cnt[PER][4], wave_adm[PER][4];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t i = base + 256u * k;
+        if (i < n) {
+            rec.key[i] = vis[k] ? __float_as_uint(vc[k].d) : kCulledKey;
+            if (vis[k]) rec.a[i] = make_float4(sp[k].mx, sp[k].my, __uint_as_float(sp[k].rx), __uint_as_float(sp[k].ry));
+        }
+        const unsigned long long bal = __ballot(vis[k]);
+        const unsigned long long bal_adm = __ballot(take[k]);
+        if ((threadIdx.x & 63u) == 0) {
+            wave_cnt[k][threadIdx.x >> 6] = (uint32_t)__popcll(bal);
+            wave_adm[k][threadIdx.x >> 6] = (uint32_t)__popcll(bal_adm);
+            if ((blockIdx.x * PER + k) * 256u < n) adm.ballots[(blockIdx.x * PER + k) * 4u + (threadIdx.x >> 6)] = bal_adm;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < PER) {
+        const uint32_t k = threadIdx.x, g = blockIdx.x * PER + k;
+        if (g * 256u < n) {  // groups past the end belong to nobody (the buffers are sized by ceil(n / 256))
+            block_visible[g] = wave_cnt[k][0] + wave_cnt[k][1] + wave_cnt[k][2] + wave_cnt[k][3];
+            adm.block_counts[g] = wave_adm[k][0] + wave_adm[k][1] + wave_adm[k][2] + wave_adm[k][3];
+        }
+    }
+}
+
 // Shading of a lazily projected frame: pairs[0 .. *d_n) are admitted records; each gets its conic / colour records —
 // same code, same values as the unlazy projection.  skip (nullable): ballots of the records that are shaded already
 // (repair round: what the first round admitted).  One record per lane, gathered: position, covariance, and the SH
@@ -523,7 +608,8 @@ static void launch_project_deg(hipStream_t s, dim3 grid, int deg, const FrameCon
     if (late)                                                                                                                \
         hipLaunchKernelGGL((k_shade<D, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, late->pairs, late->d_n, late->shaded); \
     else if (adm.lazy)                                                                                                       \
-        hipLaunchKernelGGL((k_project<0, GSX_SH_SINGLE, COVK, true>), grid, block, 0, s, f, n, pod, rec, bv, adm);           \
+        hipLaunchKernelGGL((k_project_geom<COVK, GSX_VAR_PROJ_PER>), dim3((grid.x + GSX_VAR_PROJ_PER - 1) / GSX_VAR_PROJ_PER), \
+                           block, 0, s, f, n, pod, rec, bv, adm);                                                            \
     else                                                                                                                     \
         hipLaunchKernelGGL((k_project<D, SHK, COVK, false>), grid, block, 0, s, f, n, pod, rec, bv, adm)
     switch (deg) {
