@@ -39,6 +39,9 @@ def parse_args():
     ap.add_argument("--force-dist", action="store_true", help="run the sharded exchange path even at N=1")
     ap.add_argument("--shard-mode", default="screen", help="N > 1: screen = whole scene on every GPU, rank g renders band g of "
                     "tile rows, one all-gather (default) | index = splat-index shards + speculative record exchange")
+    ap.add_argument("--gather", default="rgba8", help="N > 1, screen mode: rgba8 = every rank resolves its band (the app's blit to its "
+                    "Rgba8Unorm surface) and 4 bytes a pixel are all-gathered on a second stream, under the next frame | float = the "
+                    "(rgb, T) bands, 16 bytes a pixel, in stream order")
     ap.add_argument("--pass-timing", default="project", help="project (the roofline kernel only; default) | all (every pass, adds "
                     "a few microseconds of stream gap per pass boundary)")
     ap.add_argument("--render-options", default="", help="gsx_render_options overrides, e.g. speculative=0,min_slab=1000000 (experiments)")
@@ -104,8 +107,9 @@ def main():
     t_gen = time.perf_counter() - t0
     sh_kind = {"single": 0, "half": 1, "norm8": 2, "none": 3}[args.pod.split("/")[0]]
     cov_kind = {"single": 0, "half": 1}[args.pod.split("/")[1]]
+    gather = args.gather if (use_dist and args.shard_mode == "screen") else "float"
     renderer = parallel.ShardedViewer(device=local_rank, world=world, rank=rank, use_dist=use_dist, sh=sh_kind, cov3d=cov_kind,
-                                      mode=args.shard_mode)
+                                      mode=args.shard_mode, gather=gather, overlap_gather=gather == "rgba8")
     if args.render_options:
         renderer.stages.viewer.set_render_options(**{k: float(x) if "." in x else int(x) for k, x in
                                                      (kv.split("=") for kv in args.render_options.split(","))})
@@ -225,14 +229,17 @@ def main():
                 "sharding": ("one GPU" if not use_dist else
                              (f"splat-index shards x{world}, speculative record exchange by tile-row band + band all-gather"
                               if args.shard_mode == "index" else
-                              f"scene resident on each of {world} GPUs, rank g renders band g of tile rows, band all-gather")),
+                              f"scene resident on each of {world} GPUs, rank g renders band g of tile rows, band all-gather "
+                              + ("of RGBA8 pixels (resolved per band) on a second stream" if gather == "rgba8" else "of (rgb, T) float4 pixels"))),
                 "n_visible_rank0": int(nvis_loc), "n_depth_sorted_rank0": int(nsort_loc), "tile_entries_rank0": int(entries),
                 "speculated_frames": round(float(spec_frac), 3), "frames_with_repair_round": round(float(repair_frac), 3),
                 "pass_ms_per_frame_rank0": passes,
                 "upload_GBps_pcie_inclusive": round(upload_gbs, 2), "scene_gen_s": round(t_gen, 1),
             },
             "roofline": {
-                "kernel": f"k_project<{sh},{sh_kind},{cov_kind}> (projection pass: SH colour + cov2d + cull + depth key)",
+                "kernel": (f"k_project_geom<{cov_kind},1> (projection pass of a speculated frame: cov2d + cull + depth key + admission; "
+                           "SH colour is evaluated by k_shade for the admitted Gaussians only)" if variant == "lazy" else
+                           f"k_project<{sh},{sh_kind},{cov_kind}> (projection pass: SH colour + cov2d + cull + depth key)"),
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(proj_bytes), "avg_launch_us": round(proj_us, 2),

@@ -328,6 +328,11 @@ gsx_status gsx_viewer_set_band(gsx_viewer* v, uint32_t row_lo, uint32_t row_hi);
 /* Render into caller-owned DEVICE memory (row-major [height][width] float4; may be padded below). NULL restores
  * the internal framebuffer. */
 gsx_status gsx_viewer_set_external_framebuffer(gsx_viewer* v, void* d_ptr, uint64_t bytes);
+/* Resolve the pixel rows [y0, y1) of the (rgb, T) framebuffer against a background colour into RGBA8 in caller-owned
+ * DEVICE memory ((y1 - y0) * width uint32, R in the low byte) — the app's final blit to its Rgba8Unorm surface, per band:
+ * what the screen-band mode all-gathers (4 bytes a pixel instead of 16).  Enqueued on the viewer's stream, no host
+ * synchronisation.  Rows below the image (the padding of an external framebuffer) may be included. */
+gsx_status gsx_resolve_rgba8_device(gsx_viewer* v, const float background_rgb[3], uint32_t y0, uint32_t y1, void* d_rgba);
 /* Tile windows: d_tile_window (device, nullable, copied by the call) = one {uint32 lo, uint32 hi} pair per tile,
  * row-major [height/16 rounded up][width/16 rounded up]; a tile admits a record iff lo <= depth key < hi.
  * NULL = every tile admits everything.

@@ -195,6 +195,37 @@ class OracleStages:
         band[: rows.shape[0]] = rows
         return torch.from_numpy(band.reshape(-1))
 
+    @staticmethod
+    def resolve_rgba8(fb, background):
+        """(rgb, T) over a background -> RGBA8 words: fma(T, bg, C) clamped, alpha = 1 - T, round half up (k_resolve_rgba8)"""
+        p = fb.astype(np.float64)
+        out = np.zeros(fb.shape[:-1], np.uint32)
+        for c in range(3):
+            v = np.clip((p[..., 3] * np.float64(np.float32(background[c])) + p[..., c]).astype(np.float32), 0.0, 1.0)
+            out |= np.floor(v * np.float32(255.0) + np.float32(0.5)).astype(np.uint32) << np.uint32(8 * c)
+        a = np.clip(np.float32(1.0) - fb[..., 3], 0.0, 1.0).astype(np.float32)
+        out |= np.floor(a * np.float32(255.0) + np.float32(0.5)).astype(np.uint32) << np.uint32(24)
+        return out
+
+    def own_band_rgba8(self, background=(0.0, 0.0, 0.0), slot=0):
+        w, h = self.size
+        rpr, lo, hi = self._band(self._world, self._rank)
+        band = np.zeros((rpr * 16, w, 4), np.float32)
+        band[..., 3] = 0.0  # padding rows: the device framebuffer is zero-initialised there
+        rows = self._fb[lo * 16: min(hi * 16, h)]
+        band[: rows.shape[0]] = rows
+        return torch.from_numpy(self.resolve_rgba8(band, background).view(np.int32).reshape(-1).copy())
+
+    def gather_target_rgba8(self):
+        w, h = self.size
+        rpr, _, _ = self._band(self._world, self._rank)
+        self._gather8 = torch.zeros(self._world * rpr * 16 * w, dtype=torch.int32)
+        return self._gather8
+
+    def frame_rgba8(self):
+        w, h = self.size
+        return self._gather8.numpy().view(np.uint8).reshape(-1, w, 4)[:h].copy()
+
     def gather_target(self):
         w, h = self.size
         rpr, _, _ = self._band(self._world, self._rank)

@@ -258,6 +258,43 @@ def test_screen_band_mode_matches_single_viewer(world):
             assert np.array_equal(fb, ref[k]), f"rank {rank} frame {k}: L-inf {np.abs(fb - ref[k]).max()}"
 
 
+@pytest.mark.parametrize("world,overlap", [(2, False), (4, True), (3, True)])
+def test_screen_band_mode_rgba8_gather(world, overlap):
+    """gather="rgba8": every rank resolves its band on the device (gsx_resolve_rgba8_device) and the bands travel as 4 bytes
+    a pixel, with ``overlap`` on a second stream under the next frame; the gathered frame equals the single viewer's
+    gsx_download_rgba8 of the same frame, byte for byte, on every rank and for every frame of an un-synchronised run."""
+    from wgpu_3dgs_viewer_app_amd.viewer import MultiModelViewer
+
+    g = _scene()
+    poses = (57, 58, 59, 150, 151, 152)
+    bg = (0.25, 0.5, 0.75)
+    single = MultiModelViewer()
+    single.add_model("m", N)
+    single.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g)
+    ref = []
+    for pose in poses:
+        single.update_camera(camera.orbit_pose(pose), (W, H))
+        single.render_frame(["m"])
+        ref.append(single.download_rgba8(bg).reshape(H, W, 4).copy())
+    single.close()
+
+    def rank_main(rank, comm):
+        v = parallel.ShardedViewer(world=world, rank=rank, use_dist=True, comm=comm, mode="screen", gather="rgba8",
+                                   overlap_gather=overlap, background=bg)
+        v.load_shard(g, 0, N)
+        frames = []
+        for k, pose in enumerate(poses):
+            v.render_frame(camera.orbit_pose(pose), (W, H))
+            if k >= 3:                      # the first frames run ahead without any host synchronisation
+                frames.append((k, v.frame_rgba8()))
+        v.close()
+        return frames
+
+    for rank, frames in enumerate(common.run_ranks(world, rank_main)):
+        for k, fb in frames:
+            assert fb.shape == ref[k].shape and np.array_equal(fb, ref[k]), f"rank {rank} frame {k} (world {world}, overlap {overlap})"
+
+
 @pytest.mark.parametrize("mode,world", [("index", 4), ("screen", 4)])
 def test_full_size_sharded_frames(mode, world):
     """BASELINE.json's headline scene (10 M Gaussians, 1920x1080) through both multi-GPU partitionings with 4 ranks as

@@ -148,22 +148,40 @@ def test_sharded_layered_models_equal_single_process(world, tmp_path):
     assert not np.array_equal(single.framebuffer(), ref)
 
 
-def _screen_worker(rank, world, port, out_path):
+def _screen_worker(rank, world, port, out_path, gather="float"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        v = parallel.ShardedViewer(world=world, rank=rank, use_dist=True, stages=OracleStages(), mode="screen")
+        v = parallel.ShardedViewer(world=world, rank=rank, use_dist=True, stages=OracleStages(), mode="screen", gather=gather,
+                                   background=(0.2, 0.4, 0.6))
         for key, (n, seed, _) in LAYERS.items():
             v.load_shard(common.small_scene(n, seed, scale_mul=9.0), 0, n, key=key)  # the whole model on every rank
         cam = camera.orbit_pose(21)
         tr = {k: mt for k, (_, _, mt) in LAYERS.items()}
         v.render_frame(cam, (W, H), keys=parallel.model_render_keys(cam.pos, tr), transforms=tr)
         if rank == world - 1:
-            np.save(out_path, v.framebuffer())
+            np.save(out_path, v.framebuffer() if gather == "float" else v.frame_rgba8())
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def test_screen_band_mode_rgba8_gather(tmp_path):
+    """gather="rgba8": the bands travel resolved against the background; the gathered frame is the single frame resolved."""
+    cam = camera.orbit_pose(21)
+    tr = {k: mt for k, (_, _, mt) in LAYERS.items()}
+    keys = parallel.model_render_keys(cam.pos, tr)
+    single = parallel.ShardedViewer(world=1, rank=0, use_dist=False, stages=OracleStages())
+    for key, (n, seed, _) in LAYERS.items():
+        single.load_shard(common.small_scene(n, seed, scale_mul=9.0), 0, n, key=key)
+    single.render_frame(cam, (W, H), keys=keys, transforms=tr)
+    ref = OracleStages.resolve_rgba8(single.framebuffer(), (0.2, 0.4, 0.6)).view(np.uint8).reshape(H, W, 4)
+    out = str(tmp_path / "fb8.npy")
+    mp.spawn(_screen_worker, args=(2, _free_port(), out, "rgba8"), nprocs=2, join=True)
+    got = np.load(out)
+    assert got.dtype == np.uint8 and np.array_equal(got, ref)
+    assert got[..., 3].max() == 255 and got[..., :3].max() > 0
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -26,7 +26,7 @@ EXPORTS = (
     "gsx_render_frame", "gsx_download_framebuffer", "gsx_download_rgba8", "gsx_framebuffer_device_ptr",
     "gsx_model_frame_stats", "gsx_model_download_projection", "gsx_model_download_sorted",
     "gsx_model_download_tile_lists", "gsx_model_download_pod", "gsx_set_pass_timing", "gsx_get_pass_timing",
-    "gsx_mask_evaluate", "gsx_ply_read_header", "gsx_ply_read_gaussians", "gsx_ply_write", "gsx_render_options_default", "gsx_viewer_set_render_options", "gsx_shard_layout", "gsx_viewer_set_external_framebuffer", "gsx_shard_pack", "gsx_shard_import", "gsx_shard_feedback_words", "gsx_shard_feedback", "gsx_shard_set_windows", "gsx_viewer_set_band",
+    "gsx_mask_evaluate", "gsx_ply_read_header", "gsx_ply_read_gaussians", "gsx_ply_write", "gsx_render_options_default", "gsx_viewer_set_render_options", "gsx_shard_layout", "gsx_viewer_set_external_framebuffer", "gsx_shard_pack", "gsx_shard_import", "gsx_shard_feedback_words", "gsx_shard_feedback", "gsx_shard_set_windows", "gsx_viewer_set_band", "gsx_resolve_rgba8_device",
     "gsx_render_more",
     "gsx_gaussian_edit_default", "gsx_update_query", "gsx_update_query_texture", "gsx_update_selection_highlight",
     "gsx_update_selection_edit", "gsx_model_show_unedited", "gsx_postprocess", "gsx_model_upload_selection",
@@ -141,6 +141,7 @@ def load() -> C.CDLL:
         "gsx_render_frame": ([vp, C.POINTER(cp), u32], C.c_int32),
         "gsx_download_framebuffer": ([vp, f32p, u64], C.c_int32),
         "gsx_download_rgba8": ([vp, f32p, C.POINTER(C.c_uint8), u64], C.c_int32),
+        "gsx_resolve_rgba8_device": ([vp, f32p, u32, u32, vp], C.c_int32),
         "gsx_framebuffer_device_ptr": ([vp, C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)], C.c_int32),
         "gsx_model_frame_stats": ([vp, cp, C.POINTER(FrameStats)], C.c_int32),
         "gsx_model_download_projection": ([vp, cp, u32p, u32p, f32p, f32p, f32p], C.c_int32),

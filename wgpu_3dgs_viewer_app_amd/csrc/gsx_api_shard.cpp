@@ -30,6 +30,18 @@ gsx_status gsx_viewer_set_external_framebuffer(gsx_viewer* v, void* d_ptr, uint6
 }
 
 
+gsx_status gsx_resolve_rgba8_device(gsx_viewer* v, const float bg[3], uint32_t y0, uint32_t y1, void* d_rgba) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    if (!bg || !d_rgba || y1 < y0) return fail(GSX_ERR_INVALID_ARG, "gsx_resolve_rgba8_device: null argument or y1 < y0");
+    if ((st = ensure_fb(v))) return st;
+    const uint64_t rows_avail = v->ext_fb ? v->ext_fb_bytes / (sizeof(float4) * (uint64_t)v->width) : v->height;
+    if (y1 > rows_avail) return fail(GSX_ERR_INVALID_ARG, "gsx_resolve_rgba8_device: rows [%u, %u) of a %llu-row framebuffer", y0, y1, (unsigned long long)rows_avail);
+    const uint64_t npx = (uint64_t)(y1 - y0) * v->width;
+    HIPCHK(launch_resolve_rgba8(v->stream, fb_ptr(v) + (size_t)y0 * v->width, (uint32_t)npx, bg[0], bg[1], bg[2], static_cast<uint32_t*>(d_rgba)));
+    return GSX_OK;
+}
+
 gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, const uint32_t* d_tile_window, void* d_send,
                           uint64_t capacity_records, uint64_t* counts) {
     gsx_status st = viewer_bind(v);

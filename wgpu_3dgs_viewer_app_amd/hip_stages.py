@@ -168,6 +168,38 @@ class HipStages:
         _lib.check(v._L.gsx_shard_feedback(v._h, key.encode(), world, rank, self._fbk.data_ptr()))
         return self._fbk
 
+    # -- screen-band mode, RGBA8 delivery: the bands travel resolved (4 bytes a pixel instead of 16) --
+    def own_band_rgba8(self, background=(0.0, 0.0, 0.0), slot: int = 0):
+        """Resolve this rank's band (``gsx_resolve_rgba8_device``) into one of two band buffers (`slot`: the caller
+        alternates them so that a gather still in flight on another stream keeps its source).  Enqueued, no sync.
+        int32 tensor [rows_per_rank * 16 * width], one RGBA8 pixel per word."""
+        import torch
+
+        v, lay = self.viewer, self._lay
+        w = self._size[0]
+        rows = lay.rows_per_rank * 16
+        if getattr(self, "_band8", None) is None or self._band8[0].numel() != rows * w:
+            self._band8 = [torch.zeros(rows * w, dtype=torch.int32, device=f"cuda:{self.device}") for _ in range(2)]
+            self._frame8 = None
+        bg = (C.c_float * 3)(*[float(x) for x in background])
+        y0 = lay.band_offset_bytes // (16 * w)
+        _lib.check(v._L.gsx_resolve_rgba8_device(v._h, bg, y0, y0 + rows, self._band8[slot].data_ptr()))
+        return self._band8[slot]
+
+    def gather_target_rgba8(self):
+        """int32 tensor [world * rows_per_rank * 16 * width]: every rank's resolved band, in place."""
+        import torch
+
+        n = self._lay.padded_framebuffer_bytes // 16
+        if getattr(self, "_frame8", None) is None or self._frame8.numel() != n:
+            self._frame8 = torch.zeros(n, dtype=torch.int32, device=f"cuda:{self.device}")
+        return self._frame8
+
+    def frame_rgba8(self) -> np.ndarray:
+        """(height, width, 4) uint8 of the gathered frame (synchronises the caller's streams first)."""
+        w, h = self._size
+        return self._frame8.cpu().numpy().view(np.uint8).reshape(-1, w, 4)[:h].copy()
+
     def own_band(self):
         """This rank's band of the framebuffer, copied out so the all-gather never aliases its own output."""
         lay = self._lay

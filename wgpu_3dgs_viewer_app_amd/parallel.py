@@ -121,13 +121,23 @@ class ShardedViewer:
     KEY = "shard"
 
     def __init__(self, device: int = 0, world: int = 1, rank: int = 0, use_dist: bool = False, stream=None,
-                 stages=None, group=None, sh: int = 0, cov3d: int = 0, comm=None, mode: str = "index"):
+                 stages=None, group=None, sh: int = 0, cov3d: int = 0, comm=None, mode: str = "index",
+                 gather: str = "float", overlap_gather: bool = False, background=(0.0, 0.0, 0.0)):
         """mode "index": every rank holds an index shard of the Gaussians, projected records are exchanged (module doc).
         mode "screen": every rank holds the WHOLE scene (``load_shard(all, 0, n)``) and renders one band of tile rows;
-        the only collective is the all-gather of the bands."""
+        the only collective is the all-gather of the bands.
+        gather (screen mode): "float" — the (rgb, T) bands, 16 bytes a pixel, ``framebuffer()`` as on one GPU; "rgba8" — every
+        rank resolves its band against ``background`` first (the app's blit to its Rgba8Unorm surface) and 4 bytes a pixel
+        travel; the frame is ``frame_rgba8()``.  overlap_gather (rgba8): the all-gather runs on a second stream, under the
+        next frame's projection and sorting — the gathered frame is complete after ``poll()``."""
         if mode not in ("index", "screen"):
             raise ValueError(mode)
-        self.mode = mode
+        if gather not in ("float", "rgba8") or (gather == "rgba8" and mode != "screen"):
+            raise ValueError(f"gather={gather!r} with mode={mode!r}")
+        self.mode, self.gather, self.overlap_gather, self.background = mode, gather, bool(overlap_gather), tuple(background)
+        self._frame_no = 0
+        self._comm_stream = None
+        self._gather_done = [None, None]
         self.world, self.rank, self.use_dist = world, rank, use_dist
         self.comm = comm if comm is not None else TorchComm(group)  # injectable: tests drive `world` ranks as threads
         if stages is None:
@@ -182,7 +192,10 @@ class ShardedViewer:
                 # nothing waits on the host (speculation, layered models, edits: all as on one GPU, per band)
                 st.render_band(keys, self.world, self.rank)
                 self.rounds = 0
-                self.comm.all_gather(st.gather_target(), st.own_band())
+                if self.gather == "rgba8":
+                    self._gather_rgba8()
+                else:
+                    self.comm.all_gather(st.gather_target(), st.own_band())
             elif len(keys) == 1:
                 self._render_frame_dist(keys[0])
             else:
@@ -285,11 +298,47 @@ class ShardedViewer:
         self.comm.all_gather(st.gather_target(), st.own_band())
         self._tick("gather")
 
+    def _gather_rgba8(self):
+        """Resolve this rank's band and all-gather the RGBA8 bands; with ``overlap_gather`` on a second stream, so that the
+        links work under the next frame's projection (two band buffers: a band is rewritten two frames later, after the
+        gather that read it)."""
+        st = self.stages
+        slot = self._frame_no & 1
+        self._frame_no += 1
+        overlap = self.overlap_gather and getattr(st, "torch_stream", None) is not None
+        if not overlap:
+            self.comm.all_gather(st.gather_target_rgba8(), st.own_band_rgba8(self.background, slot))
+            return
+        import torch
+
+        main = st.torch_stream
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=st.device)
+        if self._gather_done[slot] is not None:
+            main.wait_event(self._gather_done[slot])   # the gather of two frames ago has read this band buffer
+        band = st.own_band_rgba8(self.background, slot)
+        out = st.gather_target_rgba8()
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self._comm_stream):
+            self._comm_stream.wait_event(ready)
+            self.comm.all_gather(out, band)
+            done = torch.cuda.Event()
+            done.record(self._comm_stream)
+        self._gather_done[slot] = done
+
     def framebuffer(self) -> np.ndarray:
         return self.stages.framebuffer()
 
+    def frame_rgba8(self) -> np.ndarray:
+        """(height, width, 4) uint8: the gathered frame of ``gather="rgba8"`` (synchronises)."""
+        self.poll()
+        return self.stages.frame_rgba8()
+
     def poll(self) -> None:
         self.stages.poll()
+        if self._comm_stream is not None:
+            self._comm_stream.synchronize()
 
     def last_stats(self, key: str | None = None) -> dict:
         """Statistics of the last frame (synchronises)."""
