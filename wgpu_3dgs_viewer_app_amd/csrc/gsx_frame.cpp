@@ -258,7 +258,7 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m) {
         HIPCHK(m->adm_offsets.ensure(m->adm_counts.bytes));
         HIPCHK(launch_admit_from_project(v->stream, m->proj_rec().key, n32, m->adm_ballots.as<unsigned long long>(),
                                          m->adm_counts.as<uint32_t>(), m->adm_offsets.as<uint32_t>(), &dcx->n_candidates,
-                                         m->adm_pairs.as<uint2>()));
+                                         m->adm_pairs.as<uint2>(), true));
         if (m->lazy) HIPCHK(launch_shade(v->stream, m->fc, n32, pod, m->proj_rec(), LateProjection{m->adm_pairs.as<uint2>(), &dcx->n_candidates, nullptr}));
         m->cand_valid = true;
     }
@@ -332,7 +332,7 @@ gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
                 HIPCHK(m->adm_offsets.ensure(m->adm_counts.bytes));
                 HIPCHK(launch_admit_from_project(v->stream, m->proj_rec().key, n, m->adm_ballots.as<unsigned long long>(),
                                                  m->adm_counts.as<uint32_t>(), m->adm_offsets.as<uint32_t>(), &dc->n_sorted,
-                                                 m->adm_pairs.as<uint2>()));
+                                                 m->adm_pairs.as<uint2>(), m->spec_round1));
                 if (m->lazy) {  // the projection pass was geometry only: shade what it admitted
                     PodPlanes pod = m->pod();
                     pod.mask = m->last_pod_mask;

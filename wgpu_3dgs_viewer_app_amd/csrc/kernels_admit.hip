@@ -143,13 +143,31 @@ __global__ __launch_bounds__(256) void k_admit_scatter256(const uint32_t* __rest
     }
 }
 
+// dense admission (unspeculated frames: every visible Gaussian): one thread per Gaussian, coalesced key reads and pair
+// writes — a lane walking the 64 bits of a full ballot word writes 64 scattered pairs one after the other (205 vs ~30 us)
+__global__ __launch_bounds__(256) void k_admit_scatter_dense(const uint32_t* __restrict__ key, uint32_t n,
+                                                              const unsigned long long* __restrict__ ballots,
+                                                              const uint32_t* __restrict__ offsets, uint2* __restrict__ pairs) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const unsigned long long* b = ballots + blockIdx.x * 4u;
+    const unsigned long long mine = b[wave];
+    if (!((mine >> lane) & 1ull)) return;
+    uint32_t o = offsets[blockIdx.x];
+    for (uint32_t w = 0; w < wave; ++w) o += (uint32_t)__popcll(b[w]);
+    pairs[o + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))] = make_uint2(key[i], i);
+}
+
 hipError_t launch_admit_from_project(hipStream_t s, const uint32_t* key, uint32_t n, const unsigned long long* ballots,
-                                     const uint32_t* block_counts, uint32_t* block_offsets, uint32_t* d_total, uint2* pairs) {
+                                     const uint32_t* block_counts, uint32_t* block_offsets, uint32_t* d_total, uint2* pairs,
+                                     bool sparse) {
     const uint32_t nb = (n + 255) / 256;
     if (!nb) return hipMemsetAsync(d_total, 0, 4, s);
     hipLaunchKernelGGL(k_admit_scan, dim3(1), dim3(1024), 0, s, block_counts, block_offsets, nb, d_total);
     const uint32_t words = (n + 63) / 64;
-    hipLaunchKernelGGL(k_admit_scatter256, dim3((words + 255) / 256), dim3(256), 0, s, key, words, ballots, block_offsets, pairs);
+    if (sparse)
+        hipLaunchKernelGGL(k_admit_scatter256, dim3((words + 255) / 256), dim3(256), 0, s, key, words, ballots, block_offsets, pairs);
+    else
+        hipLaunchKernelGGL(k_admit_scatter_dense, dim3(nb), dim3(256), 0, s, key, n, ballots, block_offsets, pairs);
     return hipGetLastError();
 }
 
