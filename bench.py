@@ -37,8 +37,11 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="Gaussians in the CPU baseline sample")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded exchange path even at N=1")
-    ap.add_argument("--shard-mode", default="screen", help="N > 1: screen = whole scene on every GPU, rank g renders band g of "
-                    "tile rows, one all-gather (default) | index = splat-index shards + speculative record exchange")
+    ap.add_argument("--shard-mode", default="frames", help="N > 1: frames = whole scene on every GPU, rank g renders every N-th frame "
+                    "(frame-parallel; RGBA8 frames all-gathered) | screen = whole scene on every GPU, rank g renders band g of "
+                    "tile rows, one all-gather | index = splat-index shards + speculative record exchange")
+    ap.add_argument("--pose-stride", type=int, default=1, help="N = 1 experiment: render every S-th pose of the orbit — what one rank of "
+                    "the frame-parallel mode at S GPUs sees (its speculation looks S poses back)")
     ap.add_argument("--gather", default="rgba8", help="N > 1, screen mode: rgba8 = every rank resolves its band (the app's blit to its "
                     "Rgba8Unorm surface) and 4 bytes a pixel are all-gathered on a second stream, under the next frame | float = the "
                     "(rgb, T) bands, 16 bytes a pixel, in stream order")
@@ -107,9 +110,12 @@ def main():
     t_gen = time.perf_counter() - t0
     sh_kind = {"single": 0, "half": 1, "norm8": 2, "none": 3}[args.pod.split("/")[0]]
     cov_kind = {"single": 0, "half": 1}[args.pod.split("/")[1]]
-    gather = args.gather if (use_dist and args.shard_mode == "screen") else "float"
+    afr = use_dist and args.shard_mode == "frames"   # frame-parallel: a step is still ONE frame of the orbit; N ranks render N per round
+    if afr and (args.steps % world or args.warmup % world):
+        raise SystemExit(f"--shard-mode frames: --steps and --warmup must be multiples of the GPU count ({world})")
+    gather = "rgba8" if afr else (args.gather if (use_dist and args.shard_mode == "screen") else "float")
     renderer = parallel.ShardedViewer(device=local_rank, world=world, rank=rank, use_dist=use_dist, sh=sh_kind, cov3d=cov_kind,
-                                      mode=args.shard_mode, gather=gather, overlap_gather=gather == "rgba8")
+                                      mode=args.shard_mode if use_dist else "index", gather=gather, overlap_gather=gather == "rgba8")
     if args.render_options:
         renderer.stages.viewer.set_render_options(**{k: float(x) if "." in x else int(x) for k, x in
                                                      (kv.split("=") for kv in args.render_options.split(","))})
@@ -121,13 +127,21 @@ def main():
     del g
 
     def frame(i):
-        renderer.render_frame(camera.orbit_pose(i), (w, h))
+        renderer.render_frame(camera.orbit_pose(i * args.pose_stride), (w, h))
+
+    if afr:
+        # round j of the orbit = frames j * world .. j * world + world - 1; this rank renders frame j * world + rank
+        one_frame = frame
+
+        def frame(j):  # noqa: F811
+            one_frame(j * world + rank)
 
     # working buffers (records, sort and tile-pair buffers: sized by the scene) are allocated by the first frame a model is
     # rendered in; that belongs to loading the scene, not to a step
     frame(0)
     renderer.poll()
-    for i in range(args.warmup):
+    per = world if afr else 1     # frames of the orbit per loop iteration
+    for i in range(args.warmup // per):
         frame(i)
     renderer.poll()
     renderer.set_pass_timing(True, None if args.pass_timing == "all" else ["project"])
@@ -143,8 +157,8 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        frame(args.warmup + i)
+    for i in range(args.steps // per):
+        frame(args.warmup // per + i)
     renderer.poll()
     fence()
     elapsed = time.perf_counter() - t0
@@ -162,8 +176,8 @@ def main():
     # statistics live on the device; reading them costs a sync per frame, which the timed loop must not pay).
     renderer.profile = None
     acct = []
-    for i in range(min(args.steps, 64)):
-        frame(args.warmup + i)
+    for i in range(min(args.steps // per, 64)):
+        frame(args.warmup // per + i)
         st = renderer.last_stats()
         acct.append((st["n_gaussians"], st["n_visible"], st.get("n_sorted", st["n_visible"]), 1 if st.get("speculated") else 0,
                      st.get("n_repair_tiles", 0), st["n_tile_entries"]))
@@ -209,7 +223,7 @@ def main():
         passes = {}
         for name, tv in timing.items():
             if args.pass_timing == "all" or name == "project":
-                passes[name] = round(tv["ms"] / args.steps, 4)
+                passes[name] = round(tv["ms"] / (args.steps // per), 4)
         out = {
             "metric": "frames/sec @1920x1080, N-Gaussian SH3 scene, 1/2/4/8 MI355X; %HBM roofline",
             "value": round(fps, 3),
@@ -227,6 +241,8 @@ def main():
                 "workload": f"{args.workload}: synthetic {n} Gaussians SH-deg-{sh}, {w}x{h}, orbit r=6 h=1.5 240 poses, seed {seed}",
                 "gaussians": n, "width": w, "height": h, "sh_degree": sh, "pod": args.pod, "pod_bytes": pod_bytes,
                 "sharding": ("one GPU" if not use_dist else
+                             f"frame-parallel x{world}: scene resident on each GPU, rank g renders frame j*{world}+g of the orbit "
+                             "(one-frame latency as on one GPU), RGBA8 frames all-gathered on a second stream" if afr else
                              (f"splat-index shards x{world}, speculative record exchange by tile-row band + band all-gather"
                               if args.shard_mode == "index" else
                               f"scene resident on each of {world} GPUs, rank g renders band g of tile rows, band all-gather "

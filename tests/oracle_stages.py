@@ -216,6 +216,18 @@ class OracleStages:
         band[: rows.shape[0]] = rows
         return torch.from_numpy(self.resolve_rgba8(band, background).view(np.int32).reshape(-1).copy())
 
+    def own_frame_rgba8(self, background=(0.0, 0.0, 0.0), slot=0):
+        return torch.from_numpy(self.resolve_rgba8(self._fb, background).view(np.int32).reshape(-1).copy())
+
+    def gather_target_frames_rgba8(self, world):
+        w, h = self.size
+        self._frames8 = torch.zeros(world * w * h, dtype=torch.int32)
+        return self._frames8
+
+    def frames_rgba8(self):
+        w, h = self.size
+        return self._frames8.numpy().view(np.uint8).reshape(-1, h, w, 4).copy()
+
     def gather_target_rgba8(self):
         w, h = self.size
         rpr, _, _ = self._band(self._world, self._rank)

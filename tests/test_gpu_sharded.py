@@ -295,6 +295,45 @@ def test_screen_band_mode_rgba8_gather(world, overlap):
             assert fb.shape == ref[k].shape and np.array_equal(fb, ref[k]), f"rank {rank} frame {k} (world {world}, overlap {overlap})"
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_frame_parallel_mode(world):
+    """mode="frames": rank g renders frame r * world + g of the orbit (whole frames; its speculation looks `world` poses
+    back), the resolved frames of a round are all-gathered on the second stream: every slot of every round equals the
+    single viewer's gsx_download_rgba8 at that pose, on every rank, without host synchronisation between rounds."""
+    from wgpu_3dgs_viewer_app_amd.viewer import MultiModelViewer
+
+    g = _scene()
+    rounds, first, bg = 4, 40, (0.1, 0.2, 0.3)
+    single = MultiModelViewer()
+    single.add_model("m", N)
+    single.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g)
+    ref = []
+    for f in range(rounds * world):
+        single.update_camera(camera.orbit_pose(first + f), (W, H))
+        single.render_frame(["m"])
+        ref.append(single.download_rgba8(bg).reshape(H, W, 4).copy())
+    single.close()
+
+    def rank_main(rank, comm):
+        v = parallel.ShardedViewer(world=world, rank=rank, use_dist=True, comm=comm, mode="frames", overlap_gather=True, background=bg)
+        v.load_shard(g, 0, N)
+        got = []
+        for r in range(rounds):
+            v.render_frame(camera.orbit_pose(first + r * world + rank), (W, H))
+            if r >= 2:
+                got.append((r, v.frames_rgba8()))
+        spec = v.last_stats()["speculated"]
+        v.close()
+        return got, spec
+
+    for rank, (got, spec) in enumerate(common.run_ranks(world, rank_main)):
+        assert spec
+        for r, frames in got:
+            assert frames.shape == (world, H, W, 4)
+            for slot in range(world):
+                assert np.array_equal(frames[slot], ref[r * world + slot]), f"rank {rank} round {r} slot {slot}"
+
+
 @pytest.mark.parametrize("mode,world", [("index", 4), ("screen", 4)])
 def test_full_size_sharded_frames(mode, world):
     """BASELINE.json's headline scene (10 M Gaussians, 1920x1080) through both multi-GPU partitionings with 4 ranks as

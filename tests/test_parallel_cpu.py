@@ -167,6 +167,44 @@ def _screen_worker(rank, world, port, out_path, gather="float"):
         dist.destroy_process_group()
 
 
+def _frames_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        v = parallel.ShardedViewer(world=world, rank=rank, use_dist=True, stages=OracleStages(), mode="frames", background=(0.2, 0.4, 0.6))
+        n, seed, _ = LAYERS["b"]
+        v.load_shard(common.small_scene(n, seed, scale_mul=9.0), 0, n)
+        rounds = []
+        for r in range(2):                      # two rounds of `world` consecutive frames: rank g renders frame r * world + g
+            v.render_frame(camera.orbit_pose(30 + r * world + rank), (W, H))
+            rounds.append(v.frames_rgba8())
+        if rank == 0:
+            np.save(out_path, np.stack(rounds))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frame_parallel_mode(tmp_path):
+    """mode="frames": every rank renders whole frames of its own, the resolved frames of a round are all-gathered: frame
+    r * world + g of the orbit is slot g of round r, equal to the single process's frame at that pose."""
+    world = 2
+    n, seed, _ = LAYERS["b"]
+    single = parallel.ShardedViewer(world=1, rank=0, use_dist=False, stages=OracleStages())
+    single.load_shard(common.small_scene(n, seed, scale_mul=9.0), 0, n)
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_frames_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    assert got.shape == (2, world, H, W, 4)
+    for r in range(2):
+        for g in range(world):
+            single.render_frame(camera.orbit_pose(30 + r * world + g), (W, H))
+            ref = OracleStages.resolve_rgba8(single.framebuffer(), (0.2, 0.4, 0.6)).view(np.uint8).reshape(H, W, 4)
+            assert np.array_equal(got[r, g], ref), f"round {r} rank {g}"
+    assert not np.array_equal(got[0, 0], got[0, 1])
+
+
 def test_screen_band_mode_rgba8_gather(tmp_path):
     """gather="rgba8": the bands travel resolved against the background; the gathered frame is the single frame resolved."""
     cam = camera.orbit_pose(21)

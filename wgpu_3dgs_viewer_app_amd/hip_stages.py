@@ -200,6 +200,34 @@ class HipStages:
         w, h = self._size
         return self._frame8.cpu().numpy().view(np.uint8).reshape(-1, w, 4)[:h].copy()
 
+    # -- frame-parallel mode: this rank renders whole frames; the resolved frames of all ranks are all-gathered --
+    def own_frame_rgba8(self, background=(0.0, 0.0, 0.0), slot: int = 0):
+        """Resolve the whole frame into one of two frame buffers (int32 [height * width]).  Enqueued, no sync."""
+        import torch
+
+        v = self.viewer
+        w, h = self._size
+        if getattr(self, "_own8", None) is None or self._own8[0].numel() != w * h:
+            self._own8 = [torch.zeros(w * h, dtype=torch.int32, device=f"cuda:{self.device}") for _ in range(2)]
+            self._frames8 = None
+        bg = (C.c_float * 3)(*[float(x) for x in background])
+        _lib.check(v._L.gsx_resolve_rgba8_device(v._h, bg, 0, h, self._own8[slot].data_ptr()))
+        return self._own8[slot]
+
+    def gather_target_frames_rgba8(self, world: int):
+        """int32 tensor [world * height * width]: the frames the ranks rendered in this round, by rank."""
+        import torch
+
+        w, h = self._size
+        if getattr(self, "_frames8", None) is None or self._frames8.numel() != world * w * h:
+            self._frames8 = torch.zeros(world * w * h, dtype=torch.int32, device=f"cuda:{self.device}")
+        return self._frames8
+
+    def frames_rgba8(self) -> np.ndarray:
+        """(world, height, width, 4) uint8 of the last gathered round."""
+        w, h = self._size
+        return self._frames8.cpu().numpy().view(np.uint8).reshape(-1, h, w, 4).copy()
+
     def own_band(self):
         """This rank's band of the framebuffer, copied out so the all-gather never aliases its own output."""
         lay = self._lay

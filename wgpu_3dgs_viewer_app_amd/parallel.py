@@ -129,10 +129,17 @@ class ShardedViewer:
         gather (screen mode): "float" — the (rgb, T) bands, 16 bytes a pixel, ``framebuffer()`` as on one GPU; "rgba8" — every
         rank resolves its band against ``background`` first (the app's blit to its Rgba8Unorm surface) and 4 bytes a pixel
         travel; the frame is ``frame_rgba8()``.  overlap_gather (rgba8): the all-gather runs on a second stream, under the
-        next frame's projection and sorting — the gathered frame is complete after ``poll()``."""
-        if mode not in ("index", "screen"):
+        next frame's projection and sorting — the gathered frame is complete after ``poll()``.
+        mode "frames" (frame-parallel): the whole scene on every rank, and every rank renders WHOLE frames — in a round of
+        ``world`` consecutive frames rank g renders frame g (``render_frame`` gets this rank's own camera).  The resolved
+        RGBA8 frames of the round are all-gathered (``frames_rgba8()``: any rank, e.g. the one that owns the display, has
+        every frame).  Throughput scales with the GPU count, the latency of one frame stays that of one GPU; the temporal
+        speculation of a rank looks ``world`` frames back instead of one."""
+        if mode not in ("index", "screen", "frames"):
             raise ValueError(mode)
-        if gather not in ("float", "rgba8") or (gather == "rgba8" and mode != "screen"):
+        if mode == "frames":
+            gather = "rgba8"
+        if gather not in ("float", "rgba8") or (gather == "rgba8" and mode == "index"):
             raise ValueError(f"gather={gather!r} with mode={mode!r}")
         self.mode, self.gather, self.overlap_gather, self.background = mode, gather, bool(overlap_gather), tuple(background)
         self._frame_no = 0
@@ -145,6 +152,10 @@ class ShardedViewer:
 
             stages = HipStages(device=device, stream=stream, use_torch=use_dist, sh=sh, cov3d=cov3d)
         self.stages = stages
+        if mode == "frames" and world >= 4 and hasattr(stages, "viewer"):
+            # a rank's previous frame is `world` poses back: wider windows (measured on cfg4, one GPU rendering every 8th / 4th
+            # pose: margin 0.25 / radius 3 -> 638 / 869 fps, every frame needs the repair round at 8; 0.5 / 6 -> 765 / 936)
+            stages.viewer.set_render_options(spec_margin=0.5, spec_radius=6)
         self._limit = None  # uint32 [tiles_y, tiles_x]: per-tile depth-key limit of the next frame; None = everything travels
         self.speculate = True
         # measured on cfg4 at 8 ranks (tools/emulate_ranks.py): margin 0.5 / radius 3 moves 3.6 MB per rank and frame instead
@@ -187,7 +198,11 @@ class ShardedViewer:
                 st.render_local_keys(keys)
             return
         with st.stream_ctx():
-            if self.mode == "screen":
+            if self.mode == "frames":
+                st.render_local_keys(keys)
+                self.rounds = 0
+                self._gather_rgba8()
+            elif self.mode == "screen":
                 # every rank has every Gaussian: render band `rank`, gather the bands — nothing else crosses the links and
                 # nothing waits on the host (speculation, layered models, edits: all as on one GPU, per band)
                 st.render_band(keys, self.world, self.rank)
@@ -306,8 +321,11 @@ class ShardedViewer:
         slot = self._frame_no & 1
         self._frame_no += 1
         overlap = self.overlap_gather and getattr(st, "torch_stream", None) is not None
+        frames = self.mode == "frames"
+        own = (lambda: st.own_frame_rgba8(self.background, slot)) if frames else (lambda: st.own_band_rgba8(self.background, slot))
+        target = (lambda: st.gather_target_frames_rgba8(self.world)) if frames else st.gather_target_rgba8
         if not overlap:
-            self.comm.all_gather(st.gather_target_rgba8(), st.own_band_rgba8(self.background, slot))
+            self.comm.all_gather(target(), own())
             return
         import torch
 
@@ -316,8 +334,8 @@ class ShardedViewer:
             self._comm_stream = torch.cuda.Stream(device=st.device)
         if self._gather_done[slot] is not None:
             main.wait_event(self._gather_done[slot])   # the gather of two frames ago has read this band buffer
-        band = st.own_band_rgba8(self.background, slot)
-        out = st.gather_target_rgba8()
+        band = own()
+        out = target()
         ready = torch.cuda.Event()
         ready.record(main)
         with torch.cuda.stream(self._comm_stream):
@@ -334,6 +352,11 @@ class ShardedViewer:
         """(height, width, 4) uint8: the gathered frame of ``gather="rgba8"`` (synchronises)."""
         self.poll()
         return self.stages.frame_rgba8()
+
+    def frames_rgba8(self) -> np.ndarray:
+        """mode "frames": (world, height, width, 4) uint8, the frames of the last round by rank (synchronises)."""
+        self.poll()
+        return self.stages.frames_rgba8()
 
     def poll(self) -> None:
         self.stages.poll()
