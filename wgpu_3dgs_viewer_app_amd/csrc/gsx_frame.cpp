@@ -390,7 +390,7 @@ static void merge_tail_slabs(std::vector<uint32_t>* bounds, uint32_t used) {
 // Slab bounds are planned on the record count (an upper bound of N_vis; kernels clamp to the device-side
 // N_vis), slab entry counts stay on the device, and once every tile this rank owns is saturated the
 // remaining slabs' kernels fall through.  carry: the framebuffer already holds nearer models.
-static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
+static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool counters_zeroed = false) {
     if (!m->sorted) return fail(GSX_ERR_INVALID_ARG, "gsx_render: model '%s' was not preprocessed+sorted", m->key.c_str());
     if (m->order_consumed)
         return fail(GSX_ERR_INVALID_ARG, "gsx_render: the depth order of '%s' was consumed by a speculated frame's repair round; "
@@ -446,7 +446,8 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
         HIPCHK(m->ranges.ensure(sizeof(uint2) * (size_t)n_tiles));
     }
     // reset this model's per-frame totals (n_visible and n_sorted stay)
-    HIPCHK(launch_zero_words(v->stream, &dc->n_entries, (uint32_t)((sizeof(Counters) - offsetof(Counters, n_entries)) / 4), nullptr, 0));
+    if (!counters_zeroed)  // (the frame's first model: done together with the saturation state, one launch)
+        HIPCHK(launch_zero_words(v->stream, &dc->n_entries, (uint32_t)((sizeof(Counters) - offsetof(Counters, n_entries)) / 4), nullptr, 0));
     const uint32_t* done_before = nullptr;
     if (speculate) {
         const size_t bm = 4 * (size_t)row_words * m->fc.tiles_y;
@@ -600,7 +601,8 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry) {
         m->order_consumed = true;
     }
     if (speculate && !windows_enqueued && (st = enqueue_next_windows())) return st;
-    if (progressive && !m->stats_copy_inflight) {  // feed the next frames' slab plan without waiting
+    // feed the next frames' slab plan without waiting — every fourth frame is plenty (the copy is two runtime kernels)
+    if (progressive && !m->stats_copy_inflight && (m->stats_copy_tick++ & 3u) == 0) {
         if (!m->stats_event) HIPCHK(hipEventCreateWithFlags(&m->stats_event, hipEventDisableTiming));
         HIPCHK(hipMemcpyAsync(m->h_counters, m->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, v->stream));
         HIPCHK(hipEventRecord(m->stats_event, v->stream));
@@ -638,12 +640,15 @@ gsx_status do_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys, bo
         const uint32_t row_words = (tiles_x + 31) / 32;
         const size_t bytes = 4 * (1 + (size_t)tiles_y * row_words + (size_t)tiles_y * tiles_x);
         HIPCHK(v->done_bits.ensure(bytes));
-        HIPCHK(launch_zero_words(v->stream, v->done_bits.as<uint32_t>(), (uint32_t)(bytes / 4), nullptr, 0));
+        // ... and, in the same launch, the per-frame totals of the model composited first
+        Counters* dc0 = order.back()->counters.as<Counters>();
+        HIPCHK(launch_zero_words(v->stream, v->done_bits.as<uint32_t>(), (uint32_t)(bytes / 4), &dc0->n_entries,
+                                 (uint32_t)((sizeof(Counters) - offsetof(Counters, n_entries)) / 4)));
     }
     // the reference paints far -> near with "over"; front-to-back accumulation walks the same list backwards
     bool carry = cont;
     for (auto it = order.rbegin(); it != order.rend(); ++it) {
-        if ((st = do_bin_and_composite(v, *it, carry))) return st;
+        if ((st = do_bin_and_composite(v, *it, carry, !cont && it == order.rbegin()))) return st;
         carry = true;
     }
     return GSX_OK;

@@ -88,6 +88,7 @@ struct Model {
     uint32_t slabs_hint = 0;                    // slabs the last observed frame needed (0 = unknown)
     hipEvent_t stats_event = nullptr;           // completion of the asynchronous statistics copy
     bool stats_copy_inflight = false;
+    uint32_t stats_copy_tick = 0;
     bool stats_copy_speculated = false;         // the frame whose statistics are in flight was speculated
     // the per-frame record set: the model's own projection (rec_n == n) or records imported from the
     // other ranks (gsx_shard_import); binning is restricted to the band of tile rows [row_lo, row_hi)
