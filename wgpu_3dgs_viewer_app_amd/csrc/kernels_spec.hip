@@ -104,29 +104,65 @@ __global__ __launch_bounds__(256) void k_spec_verify(const uint2* __restrict__ w
 
 // the model's windows for its next frame.  A tile that was saturated before this model was composited (done_before,
 // nearer models) says nothing about this model's depths; a tile still open afterwards makes its neighbourhood unbounded.
+// One workgroup per 16x16 block of tiles: the block's neighbourhood (radius <= 16) is staged in LDS once and the
+// (2r+1)^2 maximum is taken separably — rows, then columns — instead of (2r+1)^2 global loads per tile (169 at the radius
+// the frame-parallel mode uses: 40 us; 14 us at radius 3).
+constexpr int kNextBlock = 16, kNextMaxR = 16, kNextSpan = kNextBlock + 2 * kNextMaxR;
 __global__ __launch_bounds__(256) void k_spec_next(const uint32_t* __restrict__ tile_sat, const uint32_t* __restrict__ done,
                                                     const uint32_t* __restrict__ done_before, uint32_t row_words,
                                                     uint32_t tiles_x, uint32_t tiles_y, float gain, int radius,
                                                     uint2* __restrict__ win_next, int band_lo, int band_hi) {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= tiles_x * tiles_y) return;
-    const int tx = (int)(t % tiles_x), ty = (int)(t / tiles_x);
+    // per staged tile: depth (0 = contributes nothing) and an "open" flag; outside the band / image: neither
+    __shared__ float s_deep[kNextSpan][kNextSpan + 1];
+    __shared__ unsigned char s_open[kNextSpan][kNextSpan + 1];
+    __shared__ float s_hdeep[kNextSpan][kNextBlock + 1];
+    __shared__ unsigned char s_hopen[kNextSpan][kNextBlock + 1];
+    const int bx = (int)blockIdx.x * kNextBlock, by = (int)blockIdx.y * kNextBlock;
+    const int span = kNextBlock + 2 * radius;
+    for (int i = (int)threadIdx.x; i < span * span; i += 256) {
+        const int ly = i / span, lx = i - ly * span;
+        const int x = bx - radius + lx, y = by - radius + ly;
+        float deep = 0.0f;
+        unsigned char open = 0;
+        if (x >= 0 && x < (int)tiles_x && y >= band_lo && y < band_hi) {
+            const uint32_t w = (uint32_t)y * row_words + ((uint32_t)x >> 5), bit = (uint32_t)x & 31u;
+            if (!((done[w] >> bit) & 1u)) {
+                open = 1;
+            } else if (!(done_before && ((done_before[w] >> bit) & 1u))) {
+                deep = __uint_as_float(tile_sat[(uint32_t)y * tiles_x + (uint32_t)x]);
+            }
+        }
+        s_deep[ly][lx] = deep;
+        s_open[ly][lx] = open;
+    }
+    __syncthreads();
+    // rows: for every staged row and every column of the block, max / any over [x - r, x + r]
+    for (int i = (int)threadIdx.x; i < span * kNextBlock; i += 256) {
+        const int ly = i / kNextBlock, cx = i - ly * kNextBlock;
+        float deep = 0.0f;
+        unsigned char open = 0;
+        for (int d = 0; d <= 2 * radius; ++d) {
+            deep = fmaxf(deep, s_deep[ly][cx + d]);
+            open |= s_open[ly][cx + d];
+        }
+        s_hdeep[ly][cx] = deep;
+        s_hopen[ly][cx] = open;
+    }
+    __syncthreads();
+    const int cx = (int)threadIdx.x & 15, cy = (int)threadIdx.x >> 4;
+    const int tx = bx + cx, ty = by + cy;
+    if (tx >= (int)tiles_x || ty >= (int)tiles_y) return;
+    const uint32_t t = (uint32_t)ty * tiles_x + (uint32_t)tx;
     if (ty < band_lo || ty >= band_hi) {  // not this viewer's band: takes nothing
         win_next[t] = make_uint2(0u, 0u);
         return;
     }
     float deepest = 0.0f;
-    bool open = false;
-    // the neighbourhood is clipped to the band: tiles outside are never composited here and say nothing
-    for (int y = max(ty - radius, band_lo); y <= min(ty + radius, band_hi - 1); ++y)
-        for (int x = max(tx - radius, 0); x <= min(tx + radius, (int)tiles_x - 1); ++x) {
-            const uint32_t w = (uint32_t)y * row_words + ((uint32_t)x >> 5), b = (uint32_t)x & 31u;
-            if (!((done[w] >> b) & 1u)) {
-                open = true;
-            } else if (!(done_before && ((done_before[w] >> b) & 1u))) {
-                deepest = fmaxf(deepest, __uint_as_float(tile_sat[(uint32_t)y * tiles_x + (uint32_t)x]));
-            }
-        }
+    unsigned char open = 0;
+    for (int d = 0; d <= 2 * radius; ++d) {
+        deepest = fmaxf(deepest, s_hdeep[cy + d][cx]);
+        open |= s_hopen[cy + d][cx];
+    }
     uint32_t hi = kKeyAll;
     if (!open) {
         const float lim = deepest * gain;
@@ -207,9 +243,9 @@ hipError_t launch_spec_verify(hipStream_t s, const uint2* win1, const uint32_t* 
 hipError_t launch_spec_next(hipStream_t s, const uint32_t* tile_sat, const uint32_t* done, const uint32_t* done_before,
                             uint32_t row_words, uint32_t tiles_x, uint32_t tiles_y, float margin, uint32_t radius, uint2* win_next,
                             uint32_t band_lo, uint32_t band_hi) {
-    const uint32_t n_tiles = tiles_x * tiles_y;
-    hipLaunchKernelGGL(k_spec_next, dim3((n_tiles + 255) / 256), dim3(256), 0, s, tile_sat, done, done_before, row_words, tiles_x,
-                       tiles_y, 1.0f + margin, (int)radius, win_next, (int)std::min(band_lo, tiles_y), (int)std::min(band_hi, tiles_y));
+    hipLaunchKernelGGL(k_spec_next, dim3((tiles_x + kNextBlock - 1) / kNextBlock, (tiles_y + kNextBlock - 1) / kNextBlock), dim3(256), 0, s,
+                       tile_sat, done, done_before, row_words, tiles_x, tiles_y, 1.0f + margin, (int)std::min<uint32_t>(radius, kNextMaxR), win_next,
+                       (int)std::min(band_lo, tiles_y), (int)std::min(band_hi, tiles_y));
     return hipGetLastError();
 }
 
