@@ -111,8 +111,6 @@ def main():
     sh_kind = {"single": 0, "half": 1, "norm8": 2, "none": 3}[args.pod.split("/")[0]]
     cov_kind = {"single": 0, "half": 1}[args.pod.split("/")[1]]
     afr = use_dist and args.shard_mode == "frames"   # frame-parallel: a step is still ONE frame of the orbit; N ranks render N per round
-    if afr and (args.steps % world or args.warmup % world):
-        raise SystemExit(f"--shard-mode frames: --steps and --warmup must be multiples of the GPU count ({world})")
     gather = "rgba8" if afr else (args.gather if (use_dist and args.shard_mode == "screen") else "float")
     renderer = parallel.ShardedViewer(device=local_rank, world=world, rank=rank, use_dist=use_dist, sh=sh_kind, cov3d=cov_kind,
                                       mode=args.shard_mode if use_dist else "index", gather=gather, overlap_gather=gather == "rgba8")
@@ -133,15 +131,19 @@ def main():
         # round j of the orbit = frames j * world .. j * world + world - 1; this rank renders frame j * world + rank
         one_frame = frame
 
-        def frame(j):  # noqa: F811
-            one_frame(j * world + rank)
+        def frame(j, limit=None):  # noqa: F811 — limit: frames of the orbit that exist in this loop (the last round may be partial)
+            if limit is None or j * world + rank < limit:
+                one_frame(j * world + rank)
+            else:
+                renderer.skip_frame()
 
     # working buffers (records, sort and tile-pair buffers: sized by the scene) are allocated by the first frame a model is
     # rendered in; that belongs to loading the scene, not to a step
     frame(0)
     renderer.poll()
     per = world if afr else 1     # frames of the orbit per loop iteration
-    for i in range(args.warmup // per):
+    rounds = lambda k: (k + per - 1) // per  # noqa: E731
+    for i in range(rounds(args.warmup)):
         frame(i)
     renderer.poll()
     renderer.set_pass_timing(True, None if args.pass_timing == "all" else ["project"])
@@ -157,8 +159,13 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps // per):
-        frame(args.warmup // per + i)
+    if afr:   # exactly args.steps frames of the orbit, dealt round-robin; ranks without a frame in the last round only gather
+        first = rounds(args.warmup)
+        for i in range(rounds(args.steps)):
+            frame(first + i, limit=first * world + args.steps)
+    else:
+        for i in range(args.steps):
+            frame(args.warmup + i)
     renderer.poll()
     fence()
     elapsed = time.perf_counter() - t0
@@ -176,8 +183,8 @@ def main():
     # statistics live on the device; reading them costs a sync per frame, which the timed loop must not pay).
     renderer.profile = None
     acct = []
-    for i in range(min(args.steps // per, 64)):
-        frame(args.warmup // per + i)
+    for i in range(min(rounds(args.steps), 64)):
+        frame(rounds(args.warmup) + i)
         st = renderer.last_stats()
         acct.append((st["n_gaussians"], st["n_visible"], st.get("n_sorted", st["n_visible"]), 1 if st.get("speculated") else 0,
                      st.get("n_repair_tiles", 0), st["n_tile_entries"]))
@@ -223,7 +230,7 @@ def main():
         passes = {}
         for name, tv in timing.items():
             if args.pass_timing == "all" or name == "project":
-                passes[name] = round(tv["ms"] / (args.steps // per), 4)
+                passes[name] = round(tv["ms"] / max(rounds(args.steps), 1), 4)
         out = {
             "metric": "frames/sec @1920x1080, N-Gaussian SH3 scene, 1/2/4/8 MI355X; %HBM roofline",
             "value": round(fps, 3),

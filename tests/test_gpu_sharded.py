@@ -308,7 +308,7 @@ def test_frame_parallel_mode(world):
     single.add_model("m", N)
     single.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g)
     ref = []
-    for f in range(rounds * world):
+    for f in range(rounds * world + 1):
         single.update_camera(camera.orbit_pose(first + f), (W, H))
         single.render_frame(["m"])
         ref.append(single.download_rgba8(bg).reshape(H, W, 4).copy())
@@ -323,11 +323,20 @@ def test_frame_parallel_mode(world):
             if r >= 2:
                 got.append((r, v.frames_rgba8()))
         spec = v.last_stats()["speculated"]
+        # a last, partial round: only rank 0 has a frame, the others join the gather with the frame they rendered last
+        if rank == 0:
+            v.render_frame(camera.orbit_pose(first + rounds * world), (W, H))
+        else:
+            v.skip_frame()
+        tail = v.frames_rgba8()
         v.close()
-        return got, spec
+        return got, spec, tail
 
-    for rank, (got, spec) in enumerate(common.run_ranks(world, rank_main)):
+    for rank, (got, spec, tail) in enumerate(common.run_ranks(world, rank_main)):
         assert spec
+        assert np.array_equal(tail[0], ref[rounds * world]), f"rank {rank}: partial round, slot 0"
+        for slot in range(1, world):
+            assert np.array_equal(tail[slot], ref[(rounds - 1) * world + slot]), f"rank {rank}: partial round, slot {slot}"
         for r, frames in got:
             assert frames.shape == (world, H, W, 4)
             for slot in range(world):

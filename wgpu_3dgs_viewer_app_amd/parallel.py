@@ -313,6 +313,14 @@ class ShardedViewer:
         self.comm.all_gather(st.gather_target(), st.own_band())
         self._tick("gather")
 
+    def skip_frame(self) -> None:
+        """mode "frames": this rank has no frame in the round (the job's frame count is not a multiple of the GPU count) but
+        the round's gather is a collective: join it with the frame this rank rendered last."""
+        if self.mode != "frames" or not self.use_dist:
+            return
+        with self.stages.stream_ctx():
+            self._gather_rgba8()
+
     def _gather_rgba8(self):
         """Resolve this rank's band and all-gather the RGBA8 bands; with ``overlap_gather`` on a second stream, so that the
         links work under the next frame's projection (two band buffers: a band is rewritten two frames later, after the
