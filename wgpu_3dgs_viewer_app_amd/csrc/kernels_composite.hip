@@ -4,11 +4,11 @@
 // fixed-function "over" blending in back-to-front order, src/tab/scene.rs:2302-2314).  Here one
 // 128-lane workgroup owns one 16x16 px tile (two pixels per lane) and walks the tile's depth-ordered splat list FRONT to
 // back:  C += T*alpha*c ; T *= 1-alpha   — algebraically the same premultiplied "over" result.
-// The list is staged through LDS 256 records at a time (one gather per lane, then every lane reads
-// all 256 records as LDS broadcasts); waves vote (`__syncthreads_and`) to stop once every pixel of the
-// tile has T < t_epsilon.  Models are layered by carrying (C,T) in the framebuffer: the host walks
+// The list is staged through LDS 128 records at a time (one gather per lane, in flight while the previous batch is
+// blended; every lane then reads all records as LDS broadcasts); waves vote (`__syncthreads_and`) to stop once every
+// pixel of the tile has T < t_epsilon.  Models are layered by carrying (C,T) in the framebuffer: the host walks
 // the reference's far->near key list (scene.rs:533-558) in reverse.
-// LDS/latency bound, not HBM bound; algorithmic bytes D*40 + W*H*16.
+// VALU / LDS bound, not HBM bound; algorithmic bytes D*40 + W*H*16.
 //
 // The support decision uses exactly the oracle's operation order (spec §6): explicit fmaf, no contraction.
 #include "gsx_internal.h"

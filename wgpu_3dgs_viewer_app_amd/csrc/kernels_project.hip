@@ -369,12 +369,10 @@ __device__ inline void load_shade(const FrameConsts& f, const PodPlanes& pod, ui
     pm_color<DEG>(f, pc.x, pc.y, pc.z, __float_as_uint(pc.w), s, r, g, b);
 }
 
-// adm.lazy: geometry only — nobody is shaded here: the SH planes (180 of the pod's 220 bytes) are not read and no conic /
-// colour record is written; k_shade does that for the Gaussians the admission let through (a few per cent of the
-// visible ones), and later for the few more the repair round turns out to need.
-// LAZY is a template parameter so that the geometry-only variant carries no SH registers (higher occupancy: the kernel
-// is a chain of three dependent loads — position, covariance, pyramid — and lives on waves in flight).
-template <int DEG, int SHK, int COVK, bool LAZY>
+// (adm.lazy — geometry only, nobody shaded here: the SH planes, 180 of the pod's 220 bytes, are not read and no conic /
+// colour record is written — is a kernel of its own, k_project_geom below; k_shade then shades the Gaussians the admission
+// let through, a few per cent of the visible ones, and later the few more the repair round turns out to need.)
+template <int DEG, int SHK, int COVK>
 __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint32_t n, const PodPlanes pod,
                                                   const Records rec, uint32_t* __restrict__ block_visible,
                                                   const ProjectAdmission adm) {
@@ -396,10 +394,10 @@ __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint
 
     bool take = vis;
     if (adm.pyramid.data && vis) take = pyramid_admits(adm.pyramid, __float_as_uint(vc.d), sp.rx, sp.ry);
-    const bool shade = vis && !LAZY;
+    const bool shade = vis;
 
     float r = 0, g = 0, b = 0;
-    if (!LAZY && shade) load_shade<DEG, SHK, false>(f, pod, n, i, pc, r, g, b);  // SH planes: survivors only
+    if (shade) load_shade<DEG, SHK, false>(f, pod, n, i, pc, r, g, b);  // SH planes: survivors only
 
     if (i < n) {
         rec.key[i] = vis ? __float_as_uint(vc.d) : kCulledKey;
@@ -429,7 +427,7 @@ __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint
 // 118-120 us, 2: 122, 4: 127 — the pass is not waiting on its chain of dependent loads (position -> covariance ->
 // pyramid cells), it moves 600 MB at ~5.1 TB/s, which is what a plain streaming copy reaches on this part; PER stays 1.
 // What the straight-line form (no branch around the covariance loads: culled lanes read element 0) buys over the
-// LAZY instantiation of k_project is ~5 %.  A workgroup covers PER consecutive 256-Gaussian groups and writes their
+// geometry-only instantiation k_project used to have is ~5 %.  A workgroup covers PER consecutive 256-Gaussian groups and writes their
 // ballots / counts exactly where PER workgroups of k_project would.
 #ifndef GSX_VAR_PROJ_PER
 #define GSX_VAR_PROJ_PER 1
@@ -611,7 +609,7 @@ static void launch_project_deg(hipStream_t s, dim3 grid, int deg, const FrameCon
         hipLaunchKernelGGL((k_project_geom<COVK, GSX_VAR_PROJ_PER>), dim3((grid.x + GSX_VAR_PROJ_PER - 1) / GSX_VAR_PROJ_PER), \
                            block, 0, s, f, n, pod, rec, bv, adm);                                                            \
     else                                                                                                                     \
-        hipLaunchKernelGGL((k_project<D, SHK, COVK, false>), grid, block, 0, s, f, n, pod, rec, bv, adm)
+        hipLaunchKernelGGL((k_project<D, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv, adm)
     switch (deg) {
         case 0: GSX_PROJECT(0); break;
         case 1: GSX_PROJECT(1); break;

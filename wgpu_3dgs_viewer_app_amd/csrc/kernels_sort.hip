@@ -31,7 +31,10 @@ namespace gsx {
 
 constexpr int kRadixThreads = 256;
 constexpr int kRadixWaves = kRadixThreads / 64;
-constexpr int kRadixRounds = 16;                          // elements per lane
+#ifndef GSX_VAR_RADIX_ROUNDS
+#define GSX_VAR_RADIX_ROUNDS 16
+#endif
+constexpr int kRadixRounds = GSX_VAR_RADIX_ROUNDS;        // elements per lane
 constexpr int kRadixTile = kRadixThreads * kRadixRounds;  // 4096 elements per tile
 constexpr int kWaveChunk = 64 * kRadixRounds;             // 1024 contiguous elements per wave
 constexpr uint32_t kRadixGrid = 768;                      // persistent workgroups = resident capacity (3 per CU);
