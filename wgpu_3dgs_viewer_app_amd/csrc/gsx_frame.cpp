@@ -4,6 +4,8 @@
 // + radix sort (K2), then the far -> near render loop (K3).  Nothing here waits for the device: counts stay in HBM, the host
 // plans upper bounds, overflow and statistics are looked at lazily (finish_frame).
 #include "gsx_state.h"
+#include <chrono>
+#include <thread>
 #include <cstdlib>
 
 namespace gsx {
@@ -41,7 +43,7 @@ static gsx_status wait_verdict(gsx_viewer* v, uint32_t seq, uint32_t* need) {
             *need = (uint32_t)w;
             return GSX_OK;
         }
-        if ((spin & 0x3FFFu) == 0) {
+        if ((spin & 0xFFFu) == 0) {
             const hipError_t e = hipStreamQuery(v->stream);
             if (e == hipSuccess) {
                 const unsigned long long w2 = __atomic_load_n(v->h_verdict, __ATOMIC_ACQUIRE);
@@ -50,7 +52,11 @@ static gsx_status wait_verdict(gsx_viewer* v, uint32_t seq, uint32_t* need) {
             }
             if (e != hipErrorNotReady) return fail(GSX_ERR_HIP, "stream failed while waiting for the speculation verdict: %s", hipGetErrorString(e));
         }
-        __builtin_ia32_pause();
+        if (spin > 4096) {
+            std::this_thread::sleep_for(std::chrono::microseconds(20));  // a long wait (the host was frames ahead): yield
+        } else {
+            __builtin_ia32_pause();
+        }
     }
 }
 
@@ -62,6 +68,7 @@ static gsx_status wait_verdict(gsx_viewer* v, uint32_t seq, uint32_t* need) {
 // 7 of the last 8 samples were like that, render 48 frames without, then try again.  The windows are kept up to date
 // meanwhile, and either path gives the same pixels.
 static void note_speculation_outcome(Model* m, bool repaired) {
+
     const bool useless = repaired && (uint64_t)m->h_counters->n_sorted * 8 > (uint64_t)m->h_counters->n_visible * 7;
     m->spec_repair_history = (m->spec_repair_history << 1) | (useless ? 1u : 0u);
     if (__builtin_popcount(m->spec_repair_history & 0xFFu) >= 7) {
@@ -551,16 +558,31 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
         bool repair = true;
         {
             ScopedPass t(v, GSX_PASS_DEPTH_SORT);
-            const bool ask = v->options.host_verify != 0;
-            if (ask && !v->h_verdict) {
+            // auto (2): ask while repairs are rare.  While they are not, the verdicts are still posted and the host merely
+            // LOOKS at the latest one each frame (it lags by the frames in flight, and costs nothing): eight repair-free
+            // verdicts in a row and the host asks again.  (A blocking probe here cost milliseconds: a host that does not wait
+            // is ~10 frames ahead of the device.)
+            const bool automatic = v->options.host_verify == 2;
+            if (automatic && !m->hv_active && v->h_verdict) {
+                const unsigned long long w = __atomic_load_n(v->h_verdict, __ATOMIC_ACQUIRE);
+                const uint32_t wseq = (uint32_t)(w >> 32);
+                if (wseq != 0 && wseq != m->hv_seen_seq) {
+                    m->hv_seen_seq = wseq;
+                    m->hv_quiet = (uint32_t)w == 0u ? m->hv_quiet + 1u : 0u;
+                    if (m->hv_quiet >= 8) m->hv_active = true;
+                }
+            }
+            const bool ask = v->options.host_verify == 1 || (automatic && m->hv_active);
+            const bool post = ask || automatic;
+            if (post && !v->h_verdict) {
                 HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&v->h_verdict), 64, hipHostMallocDefault));
                 *v->h_verdict = 0;
             }
-            const uint32_t seq = ask ? ++v->verify_seq : 0;
+            const uint32_t seq = post ? ++v->verify_seq : 0;
             HIPCHK(m->spec_need.ensure(4 * (size_t)row_words * m->fc.tiles_y));
             HIPCHK(launch_spec_verify(v->stream, m->spec_win.as<uint2>(), done, row_words, m->fc.tiles_x, m->fc.tiles_y,
                                       m->spec_win2.as<uint2>(), m->spec_need.as<uint32_t>(), &dc->spec_need, row_lo, row_hi,
-                                      &dc->verify_ticket, ask ? v->h_verdict : nullptr, seq));
+                                      &dc->verify_ticket, post ? v->h_verdict : nullptr, seq));
             if (ask) {
                 // Nothing to repair (most frames): the ~20 launches of the second round would all fall through, at a few
                 // microseconds of stream time each.  So the verdict comes to the host: one pinned word, written by the
@@ -571,6 +593,14 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
                 if ((st = wait_verdict(v, seq, &need))) return st;
                 repair = need != 0;
                 windows_enqueued = !repair;
+                // auto: a frame that repairs costs more with the wait than without (the host enqueues the second round
+                // while the device idles); stop asking when half of the last eight frames repaired
+                m->hv_history = (m->hv_history << 1) | (repair ? 1u : 0u);
+                if (automatic && __builtin_popcount(m->hv_history & 0xFFu) >= 6) {
+                    m->hv_active = false;
+                    m->hv_history = 0;
+                    m->hv_quiet = 0;
+                }
             }
         }
         if (repair) {

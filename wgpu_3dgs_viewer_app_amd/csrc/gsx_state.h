@@ -107,6 +107,11 @@ struct Model {
     // statistics keep a history of "this frame needed the repair round"; too many -> unspeculated frames for a while
     uint32_t spec_repair_history = 0;  // bit k: the k-th latest sampled speculated frame repaired although it admitted nearly everything
     uint32_t spec_pause = 0;           // frames left to render unspeculated
+    // host_verify = 2 (auto): ask the device for its verdict only while repairs are rare
+    bool hv_active = true;             // currently asking
+    uint32_t hv_history = 0;           // bit k: the k-th latest verdict needed the repair round
+    uint32_t hv_quiet = 0;             // while not asking: consecutive probes / sampled frames without a repair
+    uint32_t hv_seen_seq = 0;          // while not asking: the last verdict the host has looked at
     bool order_consumed = false;   // a speculated render overwrote the depth order with its repair round's
     uint32_t spec_tiles_x = 0, spec_tiles_y = 0, shard_tiles_x = 0, shard_tiles_y = 0;
     // lazily projected shard (gsx_shard_set_windows): the windows of the coming exchange, their max-pyramid, and whether the
