@@ -21,7 +21,7 @@ ap.add_argument("--frames", type=int, default=30)
 ap.add_argument("--first", type=int, default=0, help="first orbit pose")
 ap.add_argument("--workload", default="cfg4")
 ap.add_argument("--no-speculate", action="store_true")
-ap.add_argument("--mode", default="index", help="index | screen")
+ap.add_argument("--mode", default="index", help="index | screen | frames")
 ap.add_argument("--margin", type=float, default=0.5)
 ap.add_argument("--radius", type=int, default=3)
 args = ap.parse_args()
@@ -29,7 +29,7 @@ n, sh, w, h, seed = scene.CONFIGS[args.workload]
 world = args.world
 
 
-whole = scene.synthetic_gaussians(n, seed, sh) if args.mode == "screen" else None
+whole = scene.synthetic_gaussians(n, seed, sh) if args.mode in ("screen", "frames") else None
 
 
 def rank_main(rank, comm):
@@ -39,7 +39,7 @@ def rank_main(rank, comm):
     v.margin = args.margin
     v.radius = args.radius
     v.debug = rank == 0
-    if args.mode == "screen":
+    if args.mode in ("screen", "frames"):
         v.load_shard(whole, 0, n)
     else:
         v.load_shard(scene.synthetic_gaussians(n, seed, sh, s0, c), s0, n)
@@ -50,7 +50,8 @@ def rank_main(rank, comm):
             v.set_pass_timing(True)
             v.get_pass_timing()
         b0 = comm.bytes_sent
-        v.render_frame(camera.orbit_pose(args.first + f), (w, h))
+        # frames mode: round f of the orbit, this rank renders frame f * world + rank
+        v.render_frame(camera.orbit_pose(args.first + (f * world + rank if args.mode == "frames" else f)), (w, h))
         v.poll()
         if f >= 2:
             rounds.append(v.rounds)
