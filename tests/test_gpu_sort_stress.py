@@ -21,6 +21,7 @@ CASES = [("6000000", "32", "depth"), ("8400000", "32", "depth"), ("12000000", "3
 def test_sort_matches_stable_sort(case, ranks):
     assert os.path.exists(EXE), "tools/bench_sort missing: run __graft_entry__.build()"
     env = dict(os.environ)
+    env.pop("GSX_RADIX_MATCH_RANKS", None)
     if ranks == "match":
         env["GSX_RADIX_MATCH_RANKS"] = "1"
     p = subprocess.run([EXE, *case], capture_output=True, text=True, timeout=60, env=env)
