@@ -427,7 +427,9 @@ __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint
 // 118-120 us, 2: 122, 4: 127 — the pass is not waiting on its chain of dependent loads (position -> covariance ->
 // pyramid cells), it moves 600 MB at ~5.1 TB/s, which is what a plain streaming copy reaches on this part; PER stays 1.
 // What the straight-line form (no branch around the covariance loads: culled lanes read element 0) buys over the
-// geometry-only instantiation k_project used to have is ~5 %.  A workgroup covers PER consecutive 256-Gaussian groups and writes their
+// geometry-only instantiation k_project used to have is ~5 %.  (A fixed grid striding over the groups instead of one workgroup per group — an empty
+// 39 K-workgroup launch costs 9 us of dispatch — was slower: 131-166 us at 2048-16384 workgroups; the dispatcher streams
+// workgroups better than a loop with a barrier per group.)  A workgroup covers PER consecutive 256-Gaussian groups and writes their
 // ballots / counts exactly where PER workgroups of k_project would.
 #ifndef GSX_VAR_PROJ_PER
 #define GSX_VAR_PROJ_PER 1
