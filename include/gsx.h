@@ -217,7 +217,8 @@ typedef struct gsx_frame_stats {
     uint64_t n_repair_tiles; /* speculated frame: tiles that needed the repair round */
     uint64_t n_repair_sorted; /* speculated frame: records that entered the repair round's depth sort */
     uint32_t speculated;     /* 1 if the last gsx_render of this model used last frame's windows */
-    uint32_t reserved;
+    uint32_t overflow_slabs; /* depth slabs, over the model's lifetime, whose tile entries exceeded the pair buffers: their tails
+                              * were composited pair-free on the device (complete pixels, slower) and the buffers grown */
 } gsx_frame_stats;
 gsx_status gsx_model_frame_stats(gsx_viewer* v, const char* key, gsx_frame_stats* out);
 /* Per-Gaussian projection outputs of the last gsx_preprocess (host arrays of length N; any may be NULL):
@@ -390,6 +391,12 @@ gsx_status gsx_ply_read_gaussians(const void* data, uint64_t size, const gsx_ply
  * (spec §7 Export).  Call with out == NULL to get the size in *out_size. */
 gsx_status gsx_ply_write(const gsx_gaussian* gaussians, uint64_t n, const uint32_t* mask_words,
                          const gsx_gaussian_edit* edits, void* out, uint64_t capacity, uint64_t* out_size);
+
+/* ---- debug: which stable-rank path the radix sort uses.  -1 (default): per device, decided by a start-up probe; 0: wave
+ *      ballot matching (documented hardware behaviour only); 1: one returning LDS add per element (relies on same-address
+ *      LDS adds of one instruction being served in ascending lane order — what the probe checks).  Process-wide.  Both give
+ *      the same order; tests/test_gpu_sort_stress.py and test_gpu_parity.py assert it at full size. ---- */
+void gsx_debug_set_radix_rank_mode(int32_t mode);
 
 /* ---- timing: HIP events recorded on the viewer's stream around each pass of the last frame ---- */
 typedef enum gsx_pass {

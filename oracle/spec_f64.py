@@ -63,9 +63,104 @@ def sh_color(dirs, sh, deg):
     return r
 
 
+def quantise_pod(sh, cov3d, sh_kind=0, cov_kind=0):
+    """spec 2b: what a compressed pod holds, i.e. the EXACT dequantisation of the stored value, as float32 arrays.
+    sh_kind 0 Single | 1 Half (binary16, round to nearest even) | 2 Norm8 (snorm8) | 3 None; cov_kind 0 Single | 1 Half.
+    Written with numpy's own float16 conversion, not with the oracle's bit twiddling."""
+    sh = np.asarray(sh, np.float32)
+    cov = np.asarray(cov3d, np.float32)
+    if sh_kind == 1:
+        with np.errstate(over="ignore"):
+            sh = sh.astype(np.float16).astype(np.float32)
+    elif sh_kind == 2:
+        q = np.floor(np.clip(sh.astype(np.float64), -1.0, 1.0) * 127.0 + 0.5)
+        # the decode is ONE float32 multiply by the float32 constant 1/127 (unpack4x8snorm), then max(-1)
+        sh = np.maximum(q.astype(np.float32) * np.float32(1.0 / 127.0), np.float32(-1.0)).astype(np.float32)
+    elif sh_kind == 3:
+        sh = np.zeros_like(sh)
+    if cov_kind == 1:
+        with np.errstate(over="ignore"):
+            cov = cov.astype(np.float16).astype(np.float32)
+    return sh, cov
+
+
+def mask_evaluate(pos, tree, shapes, m_pos=(0, 0, 0), m_quat=(0, 0, 0, 1), m_scale=(1, 1, 1)):
+    """spec 2c in float64.  tree: nested tuples ("shape", i) | ("not", a) | (op, a, b) with op in "|&-^" (mask.MaskOp.tree);
+    shapes: list of dict(kind 0 box | 1 ellipsoid, pos, quat, scale).  Returns (bool[n] kept, float[n] margin) — margin =
+    the smallest distance of any shape's decision value from its boundary, so a fixture can assert that no Gaussian sits
+    within float32 rounding of a boundary."""
+    pos = np.asarray(pos, np.float64)
+    pw = (pos * np.asarray(m_scale, np.float64)) @ quat_to_mat(m_quat).T + np.asarray(m_pos, np.float64)
+    margin = np.full(pos.shape[0], np.inf)
+    inside = []
+    for sh in shapes:
+        q = ((pw - np.asarray(sh["pos"], np.float64)) @ quat_to_mat(sh["quat"])) / np.asarray(sh["scale"], np.float64)
+        if int(sh["kind"]) == 0:
+            val = np.abs(q).max(axis=1)
+        else:
+            val = (q * q).sum(axis=1)
+        inside.append(val <= 1.0)
+        margin = np.minimum(margin, np.abs(val - 1.0))
+
+    def ev(t):
+        if t[0] == "shape":
+            return inside[t[1]]
+        if t[0] == "not":
+            return ~ev(t[1])
+        a, b = ev(t[1]), ev(t[2])
+        return {"|": a | b, "&": a & b, "-": a & ~b, "^": a ^ b}[t[0]]
+
+    return ev(tree), margin
+
+
+def mask_words(bits):
+    """bool[n] -> uint32 words, bit i of word i >> 5 (tail bits of the last word set: they belong to no Gaussian)."""
+    n = bits.shape[0]
+    w = np.zeros((n + 31) // 32, np.uint32)
+    idx = np.nonzero(bits)[0]
+    np.bitwise_or.at(w, idx >> 5, (np.uint32(1) << (idx & 31).astype(np.uint32)))
+    if n & 31:
+        w[-1] |= np.uint32((0xFFFFFFFF << (n & 31)) & 0xFFFFFFFF)
+    return w
+
+
+def edit_colour_ops(rgb, opacity, edit):
+    """spec 7 colour ops in float64 for ONE edit record applied to arrays rgb[n,3], opacity[n].  edit: dict(flag, color,
+    contrast, exposure, gamma, alpha).  HSV by the textbook piecewise formulas (not the oracle's branch order)."""
+    rgb = np.asarray(rgb, np.float64).copy()
+    flag = int(edit["flag"])
+    c = [float(x) for x in edit["color"]]
+    if flag & 4:
+        rgb[:] = c
+    else:
+        mx, mn = rgb.max(axis=1), rgb.min(axis=1)
+        d = mx - mn
+        r, g, b = rgb[:, 0], rgb[:, 1], rgb[:, 2]
+        with np.errstate(all="ignore"):
+            h = np.where(d == 0, 0.0, np.where(mx == r, ((g - b) / d) % 6.0, np.where(mx == g, (b - r) / d + 2.0, (r - g) / d + 4.0))) / 6.0
+            s = np.where(mx > 0, d / mx, 0.0)
+        h = (h + c[0]) % 1.0
+        s = np.clip(s * c[1], 0.0, 1.0)
+        v = mx * c[2]
+        k = lambda n_: (n_ + h * 6.0) % 6.0  # noqa: E731
+        f = lambda n_: v - v * s * np.clip(np.minimum(k(n_), 4.0 - k(n_)), 0.0, 1.0)  # noqa: E731
+        rgb = np.stack([f(5.0), f(3.0), f(1.0)], 1)
+    if float(edit["contrast"]) != 0:
+        rgb = (rgb - 0.5) * (1.0 + float(edit["contrast"])) + 0.5
+    if float(edit["exposure"]) != 0:
+        rgb = rgb * 2.0 ** float(edit["exposure"])
+    rgb = np.maximum(rgb, 0.0)
+    if float(edit["gamma"]) != 1:
+        rgb = rgb ** float(edit["gamma"])
+    return rgb, np.clip(np.asarray(opacity, np.float64) * float(edit["alpha"]), 0.0, 1.0)
+
+
 def project(view, proj, width, height, pos, color_u32, sh, cov3d, m_pos=(0, 0, 0), m_quat=(0, 0, 0, 1),
-            m_scale=(1, 1, 1), size=1.0, display_mode=0, sh_deg=3, no_sh0=0, params=None, mask=None):
-    """Per-Gaussian projection in float64.  Returns dict(visible, depth, mean2d, cov2d, conic, opacity, rgb)."""
+            m_scale=(1, 1, 1), size=1.0, display_mode=0, sh_deg=3, no_sh0=0, params=None, mask=None,
+            selection=None, sel_edit=None, highlight=None):
+    """Per-Gaussian projection in float64.  Returns dict(visible, depth, mean2d, cov2d, conic, opacity, rgb).
+    selection (bool[n]) + sel_edit (dict, spec 7): the selected Gaussians carry that edit (HIDDEN culls them, otherwise the
+    colour ops apply); highlight (r, g, b, a): blended over the selected Gaussians' colour."""
     P_ = dict(DEFAULT_PARAMS)
     P_.update(params or {})
     k = P_["max_std_dev"]
@@ -144,6 +239,18 @@ def project(view, proj, width, height, pos, color_u32, sh, cov3d, m_pos=(0, 0, 0
         dm = dw @ Rm  # R_m^T applied to each direction
         rgb = rgb + sh_color(dm, np.asarray(sh, np.float64).reshape(n, 15, 3), sh_deg)
     rgb = np.maximum(rgb, 0.0)
+    if selection is not None:
+        sel = np.asarray(selection, bool)
+        if sel_edit is not None and int(sel_edit["flag"]) & 1:
+            if int(sel_edit["flag"]) & 2:
+                vis = vis & ~sel
+            else:
+                e_rgb, e_op = edit_colour_ops(rgb[sel], opacity[sel], sel_edit)
+                rgb[sel] = e_rgb
+                opacity[sel] = e_op
+        if highlight is not None and float(highlight[3]) > 0:
+            hl = np.asarray(highlight, np.float64)
+            rgb[sel] = rgb[sel] + (hl[:3] - rgb[sel]) * hl[3]
     return dict(visible=vis, depth=d, mean2d=np.stack([mx, my], 1), cov2d=np.stack([a, b, cc], 1), conic=conic,
                 opacity=opacity, rgb=rgb, pix_aabb=np.stack([x0, y0, x1, y1], 1))
 
@@ -162,7 +269,8 @@ def render(view, proj, width, height, models, size=1.0, display_mode=0, sh_deg=3
     for mdl in reversed(models):  # front-to-back across models: nearest model first
         pr = project(view, proj, width, height, mdl["pos"], mdl["color"], mdl.get("sh"), mdl["cov3d"],
                      mdl.get("m_pos", (0, 0, 0)), mdl.get("m_quat", (0, 0, 0, 1)), mdl.get("m_scale", (1, 1, 1)),
-                     size, display_mode, sh_deg, no_sh0, params, mdl.get("mask"))
+                     size, display_mode, sh_deg, no_sh0, params, mdl.get("mask"), mdl.get("selection"), mdl.get("sel_edit"),
+                     mdl.get("highlight"))
         idx = np.nonzero(pr["visible"])[0]
         # float32 depth key order (the key is the f32 bit pattern of d), ties by index
         order = idx[np.lexsort((idx, pr["depth"][idx].astype(np.float32)))]

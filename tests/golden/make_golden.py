@@ -5,6 +5,16 @@ PARITY UNPINNED: the reference holds no golden vectors for this path and its imp
 wgpu-3dgs-viewer 0.2.0) is neither vendored nor buildable here, so these fixtures pin the WRITTEN SPEC
 (spec/RENDER_SPEC.md), not the reference.  Inputs are stored next to the expected outputs so the
 fixtures stay valid if the scene generator changes.  Run from the repo root:  python tests/golden/make_golden.py
+
+Fixture keys (i = model index in load order):
+  view, proj, size, n_models, paint_order        camera (column-major), viewport, far -> near model order
+  g{i}, cov{i}, mt{i}                            gs::Gaussian records, float64-derived cov3d (as f32), model TRS (pos3 quat4 scale3)
+  visible{i}, mean2d{i}, conic{i}, rgb{i}, depth{i}, opacity{i}    float64 projection
+  frame                                          float32 [H, W, 4] premultiplied rgb + T
+  kw_*                                           gaussian-transform arguments (size, sh_deg, display_mode, no_sh0)
+  pod_kind = (sh_kind, cov_kind), sh_q{i}, cov_q{i}   compressed pod: the exact dequantisation of what is stored
+  mask_expr, mask_shapes [k, 11] = kind pos3 quat4 scale3, mask_words{i}, mask_margin{i}
+  selection_words{i}, sel_edit = flag color3 contrast exposure gamma alpha, highlight = r g b a
 """
 import os
 import sys
@@ -16,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 from oracle import spec_f64  # noqa: E402
 from wgpu_3dgs_viewer_app_amd import camera, scene  # noqa: E402
+from wgpu_3dgs_viewer_app_amd.mask import MaskOp  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -28,22 +39,55 @@ def pod_f64(g):
     return g["pos"].copy(), color, g["sh"].reshape(-1, 45).copy(), cov
 
 
-def make(name, models, cam, w, h, **kw):
+def make(name, models, cam, w, h, pod=None, mask=None, selection=None, sel_edit=None, highlight=None, **kw):
+    """pod = (sh_kind, cov_kind); mask = (expression, [dict(kind, pos, quat, scale)]) applied to every model;
+    selection = seed of a random selection bitset (every model); sel_edit = dict(flag, color, contrast, exposure, gamma, alpha);
+    highlight = (r, g, b, a); kw: size, display_mode, sh_deg, no_sh0."""
     view, proj = cam.view(), cam.projection(w / h)
     out = dict(view=view, proj=proj, size=np.array([w, h]), n_models=np.array(len(models)))
+    if pod:
+        out["pod_kind"] = np.array(pod)
+    if mask:
+        out["mask_expr"] = np.array(mask[0])
+        out["mask_shapes"] = np.array([[s["kind"], *s["pos"], *s["quat"], *s["scale"]] for s in mask[1]], np.float32)
+    if sel_edit:
+        out["sel_edit"] = np.array([sel_edit["flag"], *sel_edit["color"], sel_edit["contrast"], sel_edit["exposure"],
+                                    sel_edit["gamma"], sel_edit["alpha"]], np.float32)
+    if highlight:
+        out["highlight"] = np.array(highlight, np.float32)
     spec_models = []
     for i, (g, mt) in enumerate(models):
         pos, color, sh, cov = pod_f64(g)
         out[f"g{i}"] = g
         out[f"cov{i}"] = cov
         out[f"mt{i}"] = np.concatenate([mt.pos, mt.quat(), mt.scale]).astype(np.float32)
-        spec_models.append(dict(pos=pos, color=color, sh=sh, cov3d=cov, m_pos=mt.pos, m_quat=mt.quat(), m_scale=mt.scale))
-        pr = spec_f64.project(view, proj, w, h, pos, color, sh, cov, mt.pos, mt.quat(), mt.scale, **kw)
+        if pod:
+            # the upload computes cov3d in float32 and quantises THAT; the float64-derived cov agrees to ~1e-7 relative, far
+            # inside a binary16 rounding interval for all but a vanishing fraction of values — the fixture keeps what the
+            # float64 statement says and the tests compare the quantised planes with a one-ulp16 tolerance on cov, exactly on sh
+            sh, cov = spec_f64.quantise_pod(sh, cov, *pod)
+            out[f"sh_q{i}"], out[f"cov_q{i}"] = sh, cov
+        mdl = dict(pos=pos, color=color, sh=None if (pod and pod[0] == 3) else sh, cov3d=cov, m_pos=mt.pos, m_quat=mt.quat(), m_scale=mt.scale)
+        if mask:
+            kept, margin = spec_f64.mask_evaluate(pos, MaskOp.parse(mask[0]).tree, mask[1], mt.pos, mt.quat(), mt.scale)
+            assert margin.min() > 1e-4, f"{name}: a Gaussian sits within {margin.min():.2e} of a mask shape boundary; pick another seed"
+            assert 0 < kept.sum() < kept.size
+            mdl["mask"] = spec_f64.mask_words(kept)
+            out[f"mask_words{i}"] = mdl["mask"]
+            out[f"mask_margin{i}"] = np.array(margin.min())
+        if selection is not None:
+            bits = np.random.default_rng(selection + i).random(pos.shape[0]) < 0.4
+            mdl["selection"], mdl["sel_edit"], mdl["highlight"] = bits, sel_edit, highlight
+            out[f"selection_words{i}"] = _sel_words(bits)
+        spec_models.append(mdl)
+        pr = spec_f64.project(view, proj, w, h, pos, color, mdl["sh"], cov, mt.pos, mt.quat(), mt.scale, mask=mdl.get("mask"),
+                              selection=mdl.get("selection"), sel_edit=mdl.get("sel_edit"), highlight=mdl.get("highlight"), **kw)
         out[f"visible{i}"] = pr["visible"]
         out[f"mean2d{i}"] = pr["mean2d"]
         out[f"conic{i}"] = pr["conic"]
         out[f"rgb{i}"] = pr["rgb"]
         out[f"depth{i}"] = pr["depth"]
+        out[f"opacity{i}"] = pr["opacity"]
     # paint order far -> near by centre distance (scene.rs:533-558)
     keys = camera.model_render_order(cam.pos, {i: mt.world_center() for i, (_, mt) in enumerate(models)})
     out["paint_order"] = np.array(keys)
@@ -53,7 +97,16 @@ def make(name, models, cam, w, h, **kw):
         out[f"kw_{k}"] = np.array(v)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k in ("frame", "g0")},
-          "mean T", float(frame[..., 3].mean()))
+          "mean T", float(frame[..., 3].mean()), "visible", [int(out[f"visible{i}"].sum()) for i in range(len(models))])
+
+
+def _sel_words(bits):
+    """selection bitset: bit i of word i >> 5; tail bits clear."""
+    n = bits.shape[0]
+    w = np.zeros((n + 31) // 32, np.uint32)
+    idx = np.nonzero(bits)[0]
+    np.bitwise_or.at(w, idx >> 5, (np.uint32(1) << (idx & 31).astype(np.uint32)))
+    return w
 
 
 def scene_small(n, seed, sh_degree=3, mul=6.0):
@@ -66,9 +119,41 @@ if __name__ == "__main__":
     ident = camera.ModelTransform()
     odd = camera.ModelTransform(pos=np.array([0.3, -0.2, 0.5], np.float32), rot=np.array([20, -35, 50], np.float32),
                                 scale=np.array([1.2, 0.9, 1.1], np.float32))
-    make("frame_sh3_identity_96x64_n600_seed101", [(scene_small(600, 101), ident)], camera.orbit_pose(17), 96, 64)
-    make("frame_sh3_trs_2models_112x80_n500_seed102",
-         [(scene_small(500, 102), odd), (scene_small(400, 103), camera.ModelTransform(pos=np.array([0, 0, 1.5], np.float32)))],
-         camera.orbit_pose(200), 112, 80)
-    make("frame_sh0_nosh_size_80x48_n400_seed104", [(scene_small(400, 104, 0), ident)], camera.orbit_pose(90), 80, 48,
-         size=1.5, sh_deg=0)
+    only = sys.argv[1:]
+
+    def want(name):
+        return not only or any(o in name for o in only)
+
+    if want("sh3_identity"):
+        make("frame_sh3_identity_96x64_n600_seed101", [(scene_small(600, 101), ident)], camera.orbit_pose(17), 96, 64)
+    if want("2models"):
+        make("frame_sh3_trs_2models_112x80_n500_seed102",
+             [(scene_small(500, 102), odd), (scene_small(400, 103), camera.ModelTransform(pos=np.array([0, 0, 1.5], np.float32)))],
+             camera.orbit_pose(200), 112, 80)
+    if want("sh0_nosh"):
+        make("frame_sh0_nosh_size_80x48_n400_seed104", [(scene_small(400, 104, 0), ident)], camera.orbit_pose(90), 80, 48,
+             size=1.5, sh_deg=0)
+    # round 2: one fixture per feature either side of the plain path
+    if want("norm8_half"):
+        g = scene_small(600, 105)
+        g["sh"] *= np.float32(4.0)  # push a good part of the coefficients past the snorm8 range
+        make("frame_pod_norm8_half_96x64_n600_seed105", [(g, odd)], camera.orbit_pose(33), 96, 64, pod=(2, 1))  # the app's default pod
+    if want("half_single"):
+        make("frame_pod_half_single_80x48_n400_seed106", [(scene_small(400, 106), ident)], camera.orbit_pose(140), 80, 48, pod=(1, 0))
+    if want("mask"):
+        shapes = [dict(kind=0, pos=(0.3, 0.0, 0.2), quat=tuple(camera.quat_from_euler_zyx(0.4, -0.3, 0.2)), scale=(2.5, 2.0, 3.0)),
+                  dict(kind=1, pos=(0.0, 0.3, 0.0), quat=(0.0, 0.0, 0.0, 1.0), scale=(1.5, 1.2, 1.8))]
+        make("frame_mask_box_minus_ellipsoid_96x64_n700_seed107", [(scene_small(700, 107), odd)], camera.orbit_pose(120), 96, 64,
+             mask=("0 - 1", shapes))
+    if want("hsv_edit"):
+        make("frame_hsv_edit_highlight_96x64_n600_seed108", [(scene_small(600, 108), ident)], camera.orbit_pose(60), 96, 64,
+             selection=7, sel_edit=dict(flag=1, color=(0.37, 1.4, 0.7), contrast=0.3, exposure=-0.75, gamma=1.8, alpha=0.6),
+             highlight=(1.0, 0.5, 0.0, 0.25))
+    if want("hidden_edit"):
+        make("frame_hidden_edit_80x48_n400_seed109", [(scene_small(400, 109), ident)], camera.orbit_pose(75), 80, 48,
+             selection=9, sel_edit=dict(flag=3, color=(0.0, 1.0, 1.0), contrast=0.0, exposure=0.0, gamma=1.0, alpha=1.0))
+    if want("ellipse"):
+        make("frame_ellipse_mode_80x48_n400_seed110", [(scene_small(400, 110), ident)], camera.orbit_pose(150), 80, 48, display_mode=1)
+    if want("point"):
+        make("frame_point_mode_size15_80x48_n500_seed111", [(scene_small(500, 111), odd)], camera.orbit_pose(210), 80, 48,
+             display_mode=2, size=1.5)

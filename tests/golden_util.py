@@ -1,0 +1,96 @@
+"""Reading tests/golden/*.npz (float64 spec fixtures, tests/golden/make_golden.py) and comparing an implementation's
+projection / frame with them.  Used by the CPU suite (C oracle vs fixtures) and by the GPU suite (HIP path vs the SAME
+float64 arrays — the only formulation of the spec that is not a transliteration of the kernels)."""
+import glob
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz")))
+IDS = [os.path.basename(p)[:-4] for p in GOLDEN]
+
+FRAME_TOL = 1e-3  # north_star: per-channel L-inf
+
+
+class Fixture:
+    def __init__(self, path):
+        z = np.load(path)
+        self.z = z
+        self.name = os.path.basename(path)[:-4]
+        self.w, self.h = [int(x) for x in z["size"]]
+        self.view, self.proj = z["view"], z["proj"]
+        self.n_models = int(z["n_models"])
+        self.paint_order = [int(k) for k in z["paint_order"]]  # far -> near
+        self.size = float(z["kw_size"]) if "kw_size" in z else 1.0
+        self.sh_deg = int(z["kw_sh_deg"]) if "kw_sh_deg" in z else 3
+        self.display_mode = int(z["kw_display_mode"]) if "kw_display_mode" in z else 0
+        self.no_sh0 = int(z["kw_no_sh0"]) if "kw_no_sh0" in z else 0
+        self.pod = tuple(int(x) for x in z["pod_kind"]) if "pod_kind" in z else (0, 0)
+        self.mask_expr = str(z["mask_expr"]) if "mask_expr" in z else None
+        self.sel_edit = z["sel_edit"] if "sel_edit" in z else None
+        self.highlight = z["highlight"] if "highlight" in z else None
+        self.frame = z["frame"]
+
+    def gaussians(self, k):
+        return self.z[f"g{k}"]
+
+    def transform(self, k):
+        v = self.z[f"mt{k}"]
+        return v[:3], v[3:7], v[7:10]
+
+    def mask_shapes(self):
+        from wgpu_3dgs_viewer_app_amd.mask import MaskShape, MaskShapeKind
+
+        return [MaskShape(MaskShapeKind(int(r[0])), pos=r[1:4].copy(), rotation=r[4:8].copy(), scale=r[8:11].copy()) for r in self.z["mask_shapes"]]
+
+    def mask_words(self, k):
+        return self.z[f"mask_words{k}"] if f"mask_words{k}" in self.z else None
+
+    def selection_words(self, k):
+        return self.z[f"selection_words{k}"] if f"selection_words{k}" in self.z else None
+
+    def edit_pod(self):
+        from wgpu_3dgs_viewer_app_amd.query import GaussianEditPod
+
+        if self.sel_edit is None:
+            return None
+        e = self.sel_edit
+        return GaussianEditPod(int(e[0]), tuple(float(x) for x in e[1:4]), float(e[4]), float(e[5]), float(e[6]), float(e[7]))
+
+    # ---- comparisons against the float64 arrays ----
+    def check_pod(self, k, pos, color, sh, cov):
+        """Quantised pod planes (what the kernels compute with) against the float64 statement of spec 2b."""
+        z = self.z
+        if f"sh_q{k}" not in z:
+            np.testing.assert_allclose(cov, z[f"cov{k}"], rtol=2e-6, atol=1e-7)  # float32 (RS)(RS)^T vs float64
+            return
+        if self.pod[0] != 3:
+            assert np.array_equal(sh, z[f"sh_q{k}"]), "SH quantisation differs from the float64 statement"
+        if self.pod[1] == 1:
+            # cov3d is computed in float32 before it is rounded to binary16: a value within float32 rounding of a binary16
+            # tie may land on the neighbouring half — allowed for a handful of entries, never by more than one binary16 step
+            a, b = cov.astype(np.float16), z[f"cov_q{k}"].astype(np.float16)
+            step = np.abs(a.view(np.int16).astype(np.int32) - b.view(np.int16).astype(np.int32))
+            assert step.max() <= 1 and np.count_nonzero(step) <= 2, f"cov3d binary16 planes differ in {np.count_nonzero(step)} entries"
+        else:
+            np.testing.assert_allclose(cov, z[f"cov_q{k}"], rtol=2e-6, atol=1e-7)
+
+    def check_projection(self, k, pr):
+        """pr: dict(key, mean2d, conic_opacity, rgb) of model k as an implementation computed it."""
+        z = self.z
+        vis = pr["key"] != 0xFFFFFFFF
+        assert np.array_equal(vis, z[f"visible{k}"]), f"{self.name}: cull set differs from the float64 spec"
+        np.testing.assert_allclose(pr["mean2d"][vis], z[f"mean2d{k}"][vis], atol=2e-3)
+        np.testing.assert_allclose(pr["conic_opacity"][vis, :3], z[f"conic{k}"][vis], rtol=5e-3, atol=1e-6)
+        rgb_tol = 1e-5 if self.sel_edit is None else 2e-5 * max(1.0, float(np.abs(z[f"rgb{k}"][vis]).max()))  # exp2 / pow in the edit ops
+        np.testing.assert_allclose(pr["rgb"][vis], z[f"rgb{k}"][vis], atol=rgb_tol, rtol=2e-5)
+        np.testing.assert_allclose(pr["key"][vis].view(np.float32), z[f"depth{k}"][vis], rtol=1e-5)
+        if f"opacity{k}" in z:
+            np.testing.assert_allclose(pr["conic_opacity"][vis, 3], z[f"opacity{k}"][vis], atol=1e-6)
+
+    def check_frame(self, fb, tight):
+        err = float(np.abs(fb - self.frame).max())
+        assert err <= FRAME_TOL, f"{self.name}: frame L-inf {err} > {FRAME_TOL}"
+        assert err <= tight, f"{self.name}: frame L-inf {err}: drifted from the float64 spec (expected <= {tight})"
+        return err

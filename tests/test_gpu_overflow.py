@@ -1,0 +1,266 @@
+"""GPU: tile-pair capacity overflow inside loops that never synchronise with the host.
+
+The pair buffers have a fixed capacity; a depth slab that needs more is CUT on the device (k_scan_block_sums) and its
+tail composited pair-free by k_composite_spill, so every frame that leaves the GPU is complete — also the frames a
+free-running loop hands to a device-side consumer (gsx_resolve_rgba8_device -> all-gather) long before the host learns
+that anything overflowed.  GSX_TILE_CAP pins a capacity that overflows on purpose and never grows (every frame spills).
+
+Reference for each frame: a viewer with the default (ample) capacity — frames must be equal bit for bit / byte for byte.
+Also here: a partially uploaded model under speculation (uninitialised shade records), and scheduling options
+changed between gsx_preprocess and gsx_render (must be refused, not crash)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import common
+from wgpu_3dgs_viewer_app_amd import _lib, camera, parallel
+from wgpu_3dgs_viewer_app_amd.viewer import GaussianDisplayMode, GaussianShDegree, GsxError, MultiModelViewer
+
+pytestmark = pytest.mark.gpu
+W, H = 256, 176
+N = 30000
+
+
+def _scene():
+    return common.small_scene(N, 301, scale_mul=10.0)
+
+
+def _load(v, g, key="m", n=None):
+    v.add_model(key, g.shape[0] if n is None else n)
+    v.models[key].gaussian_buffers.gaussians_buffer.update_range(0, g)
+    v.update_gaussian_transform(1.0, GaussianDisplayMode.Splat, GaussianShDegree.new(3), False)
+
+
+def _resolve_into(v, tensor, bg):
+    bgc = (C.c_float * 3)(*bg)
+    _lib.check(v._L.gsx_resolve_rgba8_device(v._h, bgc, 0, H, tensor.data_ptr()))
+
+
+@pytest.mark.parametrize("speculative,progressive,cap", [(1, 1, 4096), (0, 1, 4096), (0, 0, 20000), (1, 1, 300), (0, 1, 1)])
+def test_free_running_loop_with_overflow_delivers_complete_frames(monkeypatch, speculative, progressive, cap):
+    """10 frames enqueued back to back, each resolved on the device into its own slot — no host synchronisation before the
+    last frame is enqueued; every slot must equal the frame of a viewer whose buffers never overflow."""
+    import torch
+
+    g = _scene()
+    poses = [20, 21, 22, 23, 24, 140, 141, 142, 143, 144]
+    bg = (0.2, 0.4, 0.6)
+    monkeypatch.setenv("GSX_TILE_CAP", "16000000")  # the reference: one pass over every tile entry, ample room
+    ref = []
+    with MultiModelViewer() as v:
+        v.set_render_options(speculative=0, progressive=0)
+        _load(v, g)
+        for pose in poses:
+            v.update_camera(camera.orbit_pose(pose), (W, H))
+            v.render_frame(["m"])
+            ref.append(v.download_rgba8(bg).copy())
+        assert v.frame_stats("m")["overflow_slabs"] == 0
+        d_full = v.frame_stats("m")["n_tile_entries"]
+    assert d_full > 8 * cap, "the test scene must overflow the pinned capacity many times over"
+
+    monkeypatch.setenv("GSX_TILE_CAP", str(cap))
+    stream = torch.cuda.Stream()
+    with MultiModelViewer(stream=stream.cuda_stream) as v:
+        v.set_render_options(speculative=speculative, progressive=progressive, min_slab=2048)
+        _load(v, g)
+        slots = torch.zeros((len(poses), H * W), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()  # the slots were zeroed on torch's stream, the viewer enqueues on its own
+        for k, pose in enumerate(poses):
+            v.update_camera(camera.orbit_pose(pose), (W, H))
+            v.render_frame(["m"])
+            _resolve_into(v, slots[k], bg)
+        stream.synchronize()
+        got = slots.cpu().numpy().view(np.uint8).reshape(len(poses), H, W, 4)
+        st = v.frame_stats("m")
+        fb_last = v.download_rgba8(bg)
+    for k in range(len(poses)):
+        assert np.array_equal(got[k], ref[k]), f"frame {k} (pose {poses[k]}) left the GPU incomplete: {np.abs(got[k].astype(int) - ref[k]).max()}"
+    assert np.array_equal(fb_last, ref[-1])
+    assert st["overflow_slabs"] >= len(poses) - 4, "the pinned capacity did not overflow: the spill path was not exercised"
+    if speculative:
+        assert st["speculated"]
+
+
+def test_overflow_float_frames_bit_identical_and_capacity_grows(monkeypatch):
+    """Without the pin: a model whose first frame overflows (huge splats: 16 entries per record are not enough) renders it
+    completely anyway, the host grows the buffers when the statistics arrive, later frames no longer spill.  Reference: a
+    viewer with an ample pinned capacity (bit-identical), and the oracle (tolerance) for the frame that spilled."""
+    n = 20000
+    g = common.small_scene(n, 302, scale_mul=1.0)
+    g["scale"][:] = np.float32(1.5)           # every splat covers the whole frame: 176 tiles each, D = 3.5 M > 1 M entries
+    g["pos"] *= np.float32(0.2)
+    g["color"][:, 3] = 3                      # nearly transparent: tiles saturate late, most entries are needed
+    cams = [camera.orbit_pose(k) for k in (30, 31, 32, 33, 34, 35)]
+    monkeypatch.setenv("GSX_TILE_CAP", "8000000")
+    ref_v = MultiModelViewer()
+    monkeypatch.delenv("GSX_TILE_CAP")
+    v = MultiModelViewer()
+    try:
+        ref_v.set_render_options(speculative=0, progressive=0)
+        v.set_render_options(speculative=0, progressive=1, min_slab=4096)
+        for x in (ref_v, v):
+            _load(x, g)
+        spilled = []
+        for k, cam in enumerate(cams):
+            for x in (ref_v, v):
+                x.update_camera(cam, (W, H))
+            ref_v.render_frame(["m"])
+            v.render_frame(["m"])
+            a, b = v.download_framebuffer(), ref_v.download_framebuffer()
+            assert np.array_equal(a, b), f"frame {k}: L-inf {np.abs(a - b).max()}"
+            spilled.append(v.frame_stats("m")["overflow_slabs"])
+            if k == 0:
+                fb_ref = common.oracle_model_frame(g, cam, W, H)[4]
+                assert np.abs(a - fb_ref).max() <= 2e-4
+        assert ref_v.frame_stats("m")["overflow_slabs"] == 0
+    finally:
+        ref_v.close()
+        v.close()
+    assert spilled[0] > 0, "the first frame must have overflowed the initial capacity (16 entries per record)"
+    assert spilled[-1] == spilled[-2] == spilled[-3], f"capacity never caught up: {spilled}"
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_frame_parallel_mode_with_overflow(monkeypatch, world):
+    """mode="frames" (whole frames per rank, RGBA8 all-gather on a second stream, no host synchronisation between rounds)
+    with a pair capacity that overflows in every frame: every slot of every round equals the single viewer's frame."""
+    g = _scene()
+    rounds, first, bg = 4, 40, (0.1, 0.2, 0.3)
+    monkeypatch.delenv("GSX_TILE_CAP", raising=False)
+    ref = []
+    with MultiModelViewer() as single:
+        _load(single, g)
+        for f in range(rounds * world):
+            single.update_camera(camera.orbit_pose(first + f), (W, H))
+            single.render_frame(["m"])
+            ref.append(single.download_rgba8(bg).reshape(H, W, 4).copy())
+    monkeypatch.setenv("GSX_TILE_CAP", "5000")
+
+    def rank_main(rank, comm):
+        v = parallel.ShardedViewer(world=world, rank=rank, use_dist=True, comm=comm, mode="frames", overlap_gather=True, background=bg)
+        v.load_shard(g, 0, N)
+        got = []
+        for r in range(rounds):
+            v.render_frame(camera.orbit_pose(first + r * world + rank), (W, H))
+            if r >= 2:
+                got.append((r, v.frames_rgba8()))
+        st = v.last_stats()
+        v.close()
+        return got, st
+
+    for rank, (got, st) in enumerate(common.run_ranks(world, rank_main)):
+        assert st["overflow_slabs"] > 0
+        for r, frames in got:
+            for slot in range(world):
+                assert np.array_equal(frames[slot], ref[r * world + slot]), f"rank {rank} round {r} slot {slot}"
+
+
+@pytest.mark.parametrize("mode", ["index", "screen"])
+def test_sharded_modes_with_overflow(monkeypatch, mode):
+    """Index-sharded (imported records, windows, repair exchange) and screen-band frames with a capacity that overflows:
+    the gathered float frame equals the single viewer's bit for bit (was: GSX_ERR_OOM 'this frame is incomplete')."""
+    g = _scene()
+    world = 3
+    poses = (57, 58, 59, 150, 151)
+    monkeypatch.delenv("GSX_TILE_CAP", raising=False)
+    single = parallel.ShardedViewer(world=1, rank=0, use_dist=False)
+    single.load_shard(g, 0, N)
+    ref = []
+    for pose in poses:
+        single.render_frame(camera.orbit_pose(pose), (W, H))
+        single.poll()
+        ref.append(single.framebuffer().copy())
+    single.close()
+    monkeypatch.setenv("GSX_TILE_CAP", "3000")
+
+    def rank_main(rank, comm):
+        v = parallel.ShardedViewer(world=world, rank=rank, use_dist=True, comm=comm, mode=mode)
+        if mode == "screen":
+            v.load_shard(g, 0, N)
+        else:
+            s0, c = parallel.shard_range(N, rank, world)
+            v.load_shard(g[s0:s0 + c], s0, N)
+        out = []
+        for pose in poses:
+            v.render_frame(camera.orbit_pose(pose), (W, H))
+            v.poll()
+            out.append(v.framebuffer().copy())
+        st = v.last_stats()
+        v.close()
+        return out, st
+
+    for rank, (frames, st) in enumerate(common.run_ranks(world, rank_main)):
+        assert st["overflow_slabs"] > 0
+        for k, fb in enumerate(frames):
+            assert np.array_equal(fb, ref[k]), f"{mode} rank {rank} frame {k}: L-inf {np.abs(fb - ref[k]).max()}"
+
+
+@pytest.mark.parametrize("sh_kind,cov_kind", [(0, 0), (2, 1), (1, 0)])
+def test_partially_uploaded_model_speculates_identically(sh_kind, cov_kind):
+    """The app creates a model with new_empty and streams update_range into it over many frames (scene.rs:341-380,
+    2084/2112): a partially loaded model is drawn routinely.  Its not-yet-uploaded Gaussians are all-zero records; a lazily
+    shaded speculated frame reads their shade records (sh_aos), which must be zero too — speculated == unspeculated."""
+    from wgpu_3dgs_viewer_app_amd.viewer import Cov3dKind, ShKind
+
+    g = _scene()
+    part = N // 3
+    viewers = [MultiModelViewer(sh=ShKind(sh_kind), cov3d=Cov3dKind(cov_kind)) for _ in range(2)]
+    spec, plain = viewers
+    spec.set_render_options(speculative=1, min_slab=2048)
+    plain.set_render_options(speculative=0, min_slab=2048)
+    try:
+        for v in viewers:
+            # dirty the allocator first: a buffer that is freed and reallocated comes back with its old contents
+            v.add_model("junk", N)
+            v.models["junk"].gaussian_buffers.gaussians_buffer.update_range(0, g)
+            v.update_camera(camera.orbit_pose(0), (W, H))
+            v.render_frame(["junk"])
+            v.poll()
+            v.remove_model("junk")
+            _load(v, g[:part], n=N)                      # model of N, only the first third uploaded
+        loaded = part
+        for k, pose in enumerate([10, 11, 12, 13, 14, 15]):
+            cam = camera.orbit_pose(pose)
+            frames = []
+            for v in viewers:
+                v.update_camera(cam, (W, H))
+                v.render_frame(["m"])
+                frames.append(v.download_framebuffer())
+            assert np.isfinite(frames[0]).all()
+            assert np.array_equal(frames[0], frames[1]), f"frame {k}: speculated != unspeculated on a partially loaded model"
+            if k:
+                assert spec.frame_stats("m")["speculated"]
+            if k == 2:                                   # the loader delivers another batch mid-way
+                for v in viewers:
+                    v.models["m"].gaussian_buffers.gaussians_buffer.update_range(loaded, g[loaded:loaded + 5000])
+                loaded += 5000
+    finally:
+        for v in viewers:
+            v.close()
+
+
+def test_options_changed_between_preprocess_and_render_are_refused():
+    """gsx_preprocess decides speculated / lazy from the options it sees; switching them off before gsx_render used to leave
+    a speculated round without its saturation bitmap (a null dereference on the device).  Now: a clean error."""
+    g = _scene()
+    with MultiModelViewer() as v:
+        v.set_render_options(speculative=1, min_slab=2048)
+        _load(v, g)
+        for pose in (5, 6):
+            v.update_camera(camera.orbit_pose(pose), (W, H))
+            v.render_frame(["m"])
+        v.update_camera(camera.orbit_pose(7), (W, H))
+        v.preprocessor.preprocess("m")
+        v.radix_sorter.sort("m")
+        v.set_render_options(speculative=0, progressive=0)
+        with pytest.raises(GsxError):
+            v.renderer.render(["m"])
+        v.render_frame(["m"])                            # the whole protocol again: fine
+        a = v.download_framebuffer()
+    with MultiModelViewer() as v:
+        v.set_render_options(speculative=0, progressive=0)
+        _load(v, g)
+        v.update_camera(camera.orbit_pose(7), (W, H))
+        v.render_frame(["m"])
+        assert np.array_equal(a, v.download_framebuffer())

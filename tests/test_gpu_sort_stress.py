@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tools", "bench_sort")
 
 CASES = [("6000000", "32", "depth"), ("8400000", "32", "depth"), ("12000000", "32", "depth"), ("300000", "32", "depth"),
-         ("5300000", "13"), ("4096", "32"), ("4097", "13"), ("3145728", "32"), ("3145729", "32", "depth"), ("1", "32")]
+         ("8400000", "32", "dup"), ("300000", "32", "dup"), ("5300000", "13"), ("4096", "32"), ("4097", "13"), ("3145728", "32"), ("3145729", "32", "depth"), ("1", "32")]
 
 
 @pytest.mark.parametrize("ranks", ["lane_ordered", "match"])

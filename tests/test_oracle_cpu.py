@@ -13,41 +13,47 @@ from oracle import spec_f64
 from tests import common
 from wgpu_3dgs_viewer_app_amd import _lib, camera, scene
 
+from tests import golden_util
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GOLDEN = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz")))
+GOLDEN = golden_util.GOLDEN
 
 
-def _mt(v):
-    return v[:3], v[3:7], v[7:10]
-
-
-@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+@pytest.mark.parametrize("path", GOLDEN, ids=golden_util.IDS)
 def test_c_oracle_matches_golden_fixture(path):
-    """float32 C restatement vs the float64 spec fixture: projection fields and the frame (<= 1e-3 L-inf)."""
-    z = np.load(path)
-    w, h = [int(x) for x in z["size"]]
-    kw = dict(size=float(z["kw_size"]) if "kw_size" in z else 1.0, sh_deg=int(z["kw_sh_deg"]) if "kw_sh_deg" in z else 3)
+    """float32 C restatement vs the float64 spec fixture: quantised pods, mask words, projection fields (after edits) and the
+    frame (<= 1e-3 L-inf).  tests/test_gpu_golden.py runs the HIP path against the same float64 arrays."""
+    from wgpu_3dgs_viewer_app_amd.mask import MaskOp, pack_program
+    from wgpu_3dgs_viewer_app_amd.query import default_edits
+
+    fx = golden_util.Fixture(path)
     fb = None
-    for k in z["paint_order"]:
-        g = z[f"g{k}"]
-        pos, color, sh, cov = oracle.convert(g)
-        np.testing.assert_allclose(cov, z[f"cov{k}"], rtol=2e-6, atol=1e-7)  # float32 (RS)(RS)^T vs float64
-        mp, mq, ms = _mt(z[f"mt{k}"])
-        f = oracle.frame_setup(z["view"], z["proj"], w, h, mp, mq, ms, **kw)
-        pr = oracle.project(f, pos, color, sh, cov)
-        vis = pr["key"] != 0xFFFFFFFF
-        assert np.array_equal(vis, z[f"visible{k}"]), "cull set differs from the float64 spec"
-        np.testing.assert_allclose(pr["mean2d"][vis], z[f"mean2d{k}"][vis], atol=2e-3)
-        np.testing.assert_allclose(pr["conic_opacity"][vis, :3], z[f"conic{k}"][vis], rtol=5e-3, atol=1e-6)
-        np.testing.assert_allclose(pr["rgb"][vis], z[f"rgb{k}"][vis], atol=1e-5)
-        np.testing.assert_allclose(pr["key"][vis].view(np.float32), z[f"depth{k}"][vis], rtol=1e-5)
+    for k in fx.paint_order:
+        g = fx.gaussians(k)
+        n = g.shape[0]
+        pos, color, sh, cov = oracle.convert_pod(g, *fx.pod)
+        fx.check_pod(k, pos, color, sh, cov)
+        mp, mq, ms = fx.transform(k)
+        mask = None
+        if fx.mask_expr:
+            mask = oracle.mask_evaluate(pos, mp, mq, ms, *pack_program(MaskOp.parse(fx.mask_expr), fx.mask_shapes()))
+            tail = np.uint32((1 << (n & 31)) - 1 if n & 31 else 0xFFFFFFFF)
+            ref = fx.mask_words(k).copy()
+            ref[-1] &= tail
+            got = mask.copy()
+            got[-1] &= tail
+            assert np.array_equal(got, ref), "mask words differ from the float64 spec"
+        f = oracle.frame_setup(fx.view, fx.proj, fx.w, fx.h, mp, mq, ms, size=fx.size, display_mode=fx.display_mode,
+                               sh_deg=fx.sh_deg, no_sh0=fx.no_sh0)
+        pr = oracle.project(f, pos, color, None if fx.pod[0] == 3 else sh, cov, mask)
+        if fx.selection_words(k) is not None:
+            oracle.edit_pass(pr, fx.selection_words(k), default_edits(n), fx.edit_pod(), fx.highlight if fx.highlight is not None else (0, 0, 0, 0))
+        fx.check_projection(k, pr)
         idx, nvis = oracle.depth_sort(pr["key"])
         if fb is None:
             fb = oracle.new_framebuffer(f)
         oracle.rasterize(f, pr, idx, nvis, fb)
-    err = np.abs(fb - z["frame"]).max()
-    assert err <= 1e-3, f"frame L-inf {err}"
-    assert err <= 5e-5, f"frame L-inf {err}: float32 restatement drifted from the float64 spec"
+    fx.check_frame(fb, tight=5e-5)
 
 
 def test_back_to_front_equals_front_to_back_tiles():

@@ -29,10 +29,11 @@ int main(int argc, char** argv) {
     std::mt19937 rng(7);
     std::vector<uint2> h(n);
     const bool depth = argc > 3;  // third argument: keys are float bits of depths in [0.2, 12) (one or two exponent bytes)
+    const bool dup = argc > 3 && !strcmp(argv[3], "dup");  // "dup": only 997 distinct depths -> every key is shared by thousands
     for (uint32_t i = 0; i < n; ++i) {
         uint32_t k = bits >= 32 ? rng() : rng() % ((1u << bits) - 31u);
         if (depth) {
-            const float f = 0.2f + 11.8f * (float)(rng() >> 8) / 16777216.0f;
+            const float f = dup ? 0.2f + 11.8f * (float)(rng() % 997u) / 997.0f : 0.2f + 11.8f * (float)(rng() >> 8) / 16777216.0f;
             memcpy(&k, &f, 4);
         }
         h[i] = make_uint2(k, i);

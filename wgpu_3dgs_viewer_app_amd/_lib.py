@@ -27,7 +27,7 @@ EXPORTS = (
     "gsx_model_frame_stats", "gsx_model_download_projection", "gsx_model_download_sorted",
     "gsx_model_download_tile_lists", "gsx_model_download_pod", "gsx_set_pass_timing", "gsx_get_pass_timing",
     "gsx_mask_evaluate", "gsx_ply_read_header", "gsx_ply_read_gaussians", "gsx_ply_write", "gsx_render_options_default", "gsx_viewer_set_render_options", "gsx_shard_layout", "gsx_viewer_set_external_framebuffer", "gsx_shard_pack", "gsx_shard_import", "gsx_shard_feedback_words", "gsx_shard_feedback", "gsx_shard_set_windows", "gsx_viewer_set_band", "gsx_resolve_rgba8_device",
-    "gsx_render_more",
+    "gsx_render_more", "gsx_debug_set_radix_rank_mode",
     "gsx_gaussian_edit_default", "gsx_update_query", "gsx_update_query_texture", "gsx_update_selection_highlight",
     "gsx_update_selection_edit", "gsx_model_show_unedited", "gsx_postprocess", "gsx_model_upload_selection",
     "gsx_model_download_selection", "gsx_model_download_edits", "gsx_model_upload_edits", "gsx_query_download_hits",
@@ -74,7 +74,7 @@ class ViewerDesc(C.Structure):
 
 class FrameStats(C.Structure):
     _fields_ = [("n_gaussians", C.c_uint64), ("n_visible", C.c_uint64), ("n_tile_entries", C.c_uint64), ("n_sorted", C.c_uint64),
-                ("n_repair_tiles", C.c_uint64), ("n_repair_sorted", C.c_uint64), ("speculated", C.c_uint32), ("reserved", C.c_uint32)]
+                ("n_repair_tiles", C.c_uint64), ("n_repair_sorted", C.c_uint64), ("speculated", C.c_uint32), ("overflow_slabs", C.c_uint32)]
 
 
 class GsxError(RuntimeError):
@@ -159,6 +159,7 @@ def load() -> C.CDLL:
         "gsx_shard_feedback_words": ([vp, u32, C.POINTER(u32)], C.c_int32),
         "gsx_shard_feedback": ([vp, cp, u32, u32, vp], C.c_int32),
         "gsx_render_more": ([vp, C.POINTER(cp), u32], C.c_int32),
+        "gsx_debug_set_radix_rank_mode": ([C.c_int32], None),
         "gsx_set_pass_timing": ([vp, u32], C.c_int32),
         "gsx_get_pass_timing": ([vp, f32p, u32p], C.c_int32),
     }

@@ -38,7 +38,8 @@ gsx_status gsx_viewer_create(const gsx_viewer_desc* desc, gsx_viewer** out) {
     HIPCHK(hipSetDevice(desc->device));
     std::unique_ptr<gsx_viewer> v(new gsx_viewer());
     v->validate = getenv("GSX_VALIDATE") != nullptr;
-    (void)radix_lane_ordered_adds();  // probes the device once per process
+    if (const char* tc = getenv("GSX_TILE_CAP")) v->tile_cap_fixed = std::max<long long>(atoll(tc), 1);
+    (void)radix_lane_ordered_adds();  // probes THIS device once per process (the answer is kept per device)
     v->device = desc->device;
     if (desc->stream) {
         v->stream = reinterpret_cast<hipStream_t>(desc->stream);
@@ -86,12 +87,21 @@ void gsx_render_options_default(gsx_render_options* o) {
     o->host_verify = 0;
 }
 
+void gsx_debug_set_radix_rank_mode(int32_t mode) { radix_set_rank_override(mode); }
+
 gsx_status gsx_viewer_set_render_options(gsx_viewer* v, const gsx_render_options* o) {
     if (!v || !o) return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_set_render_options: null argument");
     if (o->first_slab_divisor == 0 || o->growth < 2 || o->min_slab == 0)
         return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_set_render_options: first_slab_divisor >= 1, growth >= 2, min_slab >= 1");
     if (!(o->spec_margin >= 0.0f) || o->spec_radius > 16 || o->host_verify > 2)
         return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_set_render_options: spec_margin >= 0, spec_radius <= 16, host_verify 0 | 1 | 2");
+    // what gsx_preprocess decided (speculated round, lazy shading) belongs to the options it saw: a model preprocessed under
+    // other scheduling options must go through gsx_preprocess + gsx_sort again before it is rendered
+    if (o->progressive != v->options.progressive || o->speculative != v->options.speculative)
+        for (auto& kv : v->models) {
+            kv.second->sorted = false;
+            kv.second->spec_round1 = false;
+        }
     v->options = *o;
     return GSX_OK;
 }
@@ -150,7 +160,7 @@ gsx_status gsx_model_create(gsx_viewer* v, const char* key, uint64_t count, gsx_
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&m->h_counters), sizeof(Counters), hipHostMallocDefault));
     HIPCHK(hipMemsetAsync(m->counters.p, 0, sizeof(Counters), v->stream));
     // a fresh model is all-zero Gaussians (new_empty) and fully unmasked (MaskOpTree::Reset, scene.rs:2124-2131)
-    for (DevBuf* b : {&m->pc, &m->cov_a, &m->cov_b, &m->cov_h, &m->cov_h2, &m->sh4, &m->sh1, &m->sh_h, &m->sh_q})
+    for (DevBuf* b : {&m->pc, &m->cov_a, &m->cov_b, &m->cov_h, &m->cov_h2, &m->sh4, &m->sh1, &m->sh_h, &m->sh_q, &m->sh_aos})
         if (b->p) HIPCHK(hipMemsetAsync(b->p, 0, b->bytes, v->stream));
     v->models[key] = std::move(m);
     return GSX_OK;
@@ -418,7 +428,7 @@ gsx_status gsx_model_frame_stats(gsx_viewer* v, const char* key, gsx_frame_stats
     out->speculated = m->binned && m->spec_round1 ? 1u : 0u;
     out->n_repair_tiles = out->speculated ? m->h_counters->spec_need : 0;
     out->n_repair_sorted = out->speculated ? m->n_sorted2 : 0;
-    out->reserved = 0;
+    out->overflow_slabs = (uint32_t)std::min<uint64_t>(m->overflow_slabs, 0xFFFFFFFFull);
     return GSX_OK;
 }
 

@@ -78,9 +78,19 @@ static void note_speculation_outcome(Model* m, bool repaired) {
 }
 
 
+// The host's view of the device-side overflow bookkeeping (SlabStats::overflow_events / max_needed_ever never reset): when
+// slabs spilled since the last look, the pair buffers grow for the frames to come.  The frames that spilled were composited
+// completely on the device (k_composite_spill) — this is about speed, not correctness.
+static void note_overflow(Model* m) {
+    const uint32_t ev = m->h_counters->overflow_events;
+    if (ev == m->overflow_seen) return;
+    m->overflow_slabs += ev - m->overflow_seen;
+    m->overflow_seen = ev;
+    m->tile_cap = std::max<uint64_t>(2 * m->tile_cap, (uint64_t)m->h_counters->max_needed_ever + 1024);
+}
+
 // Frames are enqueued without any host round trip; this is where the host catches up: wait for the
-// stream, mirror the per-model statistics, and if a depth slab needed more tile-pair capacity than was
-// allocated, grow the buffers and redo the last gsx_render (rare: capacity starts at 16 entries/record).
+// stream and mirror the per-model statistics.
 gsx_status finish_frame(gsx_viewer* v) {
     for (int attempt = 0; attempt < 8; ++attempt) {
         bool pending = false;
@@ -105,13 +115,11 @@ gsx_status finish_frame(gsx_viewer* v) {
             if (m->binned) m->slabs_hint = m->h_counters->slabs_used;
             m->stats_copy_inflight = false;
             if (m->binned && m->spec_round1 && !m->use_imported) note_speculation_outcome(m, m->h_counters->spec_need != 0);
-            if (m->h_counters->overflow && m->binned) {
-                m->tile_cap = std::max<uint64_t>(2 * m->tile_cap, (uint64_t)m->h_counters->max_needed + 1024);
-                if (v->last_render_cont || m->rec_n != m->n)
-                    return fail(GSX_ERR_OOM, "tile-pair capacity overflow in a sharded frame (model '%s'); capacity grown for the "
-                                "next frame, this frame is incomplete", m->key.c_str());
+            note_overflow(m);
+            // The pixels of a frame that spilled are complete (k_composite_spill); only its tile LISTS are not, and only a
+            // single-slab frame promises those (gsx_model_download_tile_lists): that one is redone with the grown buffers.
+            if (m->h_counters->overflow && m->binned && m->lists_complete && !v->tile_cap_fixed && !v->last_render_cont && m->rec_n == m->n)
                 redo = true;
-            }
         }
         if (!redo) return GSX_OK;
         std::vector<const char*> keys;
@@ -411,11 +419,14 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
     uint32_t* done = progressive ? v->done_bits.as<uint32_t>() + 1 : nullptr;  // word 0 is the saturated-tile counter
     uint32_t* done_count = v->done_bits.as<uint32_t>();
     const bool speculate = progressive && v->options.speculative && !m->use_imported;
-    if (progressive && m->stats_copy_inflight && hipEventQuery(m->stats_event) == hipSuccess) {
+    if (m->stats_copy_inflight && hipEventQuery(m->stats_event) == hipSuccess) {
         m->stats_copy_inflight = false;
-        m->slabs_hint = m->h_counters->slabs_used;
-        m->n_sorted = m->h_counters->n_sorted;
-        if (m->stats_copy_speculated) note_speculation_outcome(m, m->h_counters->spec_need != 0);
+        if (progressive) {
+            m->slabs_hint = m->h_counters->slabs_used;
+            m->n_sorted = m->h_counters->n_sorted;
+            if (m->stats_copy_speculated) note_speculation_outcome(m, m->h_counters->spec_need != 0);
+        }
+        note_overflow(m);  // a free-running loop learns here that some earlier frame spilled: larger pair buffers from now on
     }
     std::vector<uint32_t> bounds;
     if (m->spec_round1) {
@@ -435,6 +446,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
     uint32_t* tile_sat = progressive ? done + row_words * m->fc.tiles_y : nullptr;  // [count | bitmap | saturation keys]
 
     if (m->tile_cap == 0) m->tile_cap = std::max<uint64_t>(1u << 20, 16 * m->rec_n);
+    if (v->tile_cap_fixed) m->tile_cap = v->tile_cap_fixed;  // GSX_TILE_CAP (tests): a capacity that overflows on purpose
     m->tile_cap = std::min<uint64_t>(m->tile_cap, 0xFFFFF000ull);
     const uint32_t cap = (uint32_t)m->tile_cap;
     {
@@ -484,7 +496,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
                                       win, m->sk_out.as<uint32_t>(), m->fc.tiles_x, min_ends));
             HIPCHK(launch_tile_emit(v->stream, j0, j1, m->sorted_idx, m->srect.as<uint2>(), m->cnt.as<uint32_t>(),
                                     m->block_sums.as<uint32_t>(), m->fc.tiles_x, m->tp_src.as<uint2>(), row_lo, row_hi,
-                                    done_in, row_words, d_n, &dc->n_entries, cap, win, m->sk_out.as<uint32_t>()));
+                                    done_in, row_words, d_n, &dc->n_entries, cap, win, m->sk_out.as<uint32_t>(), &dc->slab_cut));
             v->pass_launches[GSX_PASS_BIN] += 1;
         }
         {
@@ -522,6 +534,10 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
                                     later, done, row_words, done_count, clear_ranges, tile_sat));
             m->ranges_clean = clear_ranges;  // the compositor zeroed every range it consumed
             v->pass_launches[GSX_PASS_COMPOSITE] += 1;
+            // the slab's entries did not fit the pair buffers (decided on the device): its tail is composited pair-free, so
+            // the frame is complete without a host round trip; otherwise this launch falls through
+            HIPCHK(launch_composite_spill(v->stream, m->fc, dc, j1, d_n, m->sorted_idx, m->sk_out.as<uint32_t>(), m->rec(), fb_ptr(v),
+                                          done, row_words, done_count, tile_sat, row_lo, row_hi, win));
         }
         return GSX_OK;
     };
@@ -632,7 +648,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
     }
     if (speculate && !windows_enqueued && (st = enqueue_next_windows())) return st;
     // feed the next frames' slab plan without waiting — every fourth frame is plenty (the copy is two runtime kernels)
-    if (progressive && !m->stats_copy_inflight && (m->stats_copy_tick++ & 3u) == 0) {
+    if (!m->stats_copy_inflight && (m->stats_copy_tick++ & 3u) == 0) {
         if (!m->stats_event) HIPCHK(hipEventCreateWithFlags(&m->stats_event, hipEventDisableTiming));
         HIPCHK(hipMemcpyAsync(m->h_counters, m->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, v->stream));
         HIPCHK(hipEventRecord(m->stats_event, v->stream));

@@ -129,6 +129,7 @@ size_t radix_workspace_words(uint64_t n);
 // One-time probe (synchronous, current device): may the sort take its stable ranks from returning LDS adds?  Until it has
 // been called the sort uses the ballot-matching ranks.  GSX_RADIX_MATCH_RANKS=1 forces those.
 bool radix_lane_ordered_adds();
+void radix_set_rank_override(int mode);  // -1 none | 0 ballot matching | 1 lane-ordered LDS adds (debug: gsx_debug_set_radix_rank_mode)
 // n sizes the launch; d_n (nullable) is the real element count on the device (<= n).
 hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n, const uint32_t* d_n, int bits,
                              bool iota_values);
@@ -138,14 +139,20 @@ struct SlabStats {
     uint32_t n_visible;        // N_vis (projection pass / import)
     uint32_t n_sorted;         // records in the depth order of this frame (admission pass / import); <= n_visible
     uint32_t n_candidates;     // lazily projected shard: records the admission let through (gsx_shard_set_windows)
-    uint32_t n_entries;        // D of the slab being processed, clamped to the pair-buffer capacity
-    uint32_t n_entries_total;  // sum of slab D over the frame
-    uint32_t overflow;         // a slab needed more pair capacity than allocated: frame must be redone
-    uint32_t max_needed;       // largest slab D seen when overflowing
+    uint32_t overflow_events;  // slabs, over the model's lifetime, whose tile entries did not fit the pair buffers (never reset:
+                               // the host compares with the count it has seen and grows the buffers for the frames to come)
+    uint32_t max_needed_ever;  // largest slab D ever seen
+    // ---- from here on: zeroed at the start of every frame ----
+    uint32_t n_entries;        // D of the slab being processed: what was binned into the pair buffers (<= their capacity)
+    uint32_t n_entries_total;  // sum of slab D over the frame (including entries the spill compositor handled without pairs)
+    uint32_t overflow;         // a slab of THIS frame needed more pair capacity than allocated (its tail went to the spill compositor)
+    uint32_t max_needed;       // largest slab D of this frame
     uint32_t slabs_used;       // number of slabs that still found a live tile (progressive mode)
     uint32_t n_sorted2;        // speculation: records admitted in the repair round
     uint32_t spec_need;        // speculation: tiles that needed the repair round
     uint32_t verify_ticket;    // k_spec_verify: blocks that have added their share of spec_need (the last one posts the verdict)
+    uint32_t slab_cut;         // depth-order position up to which the current slab was binned into pairs: the whole slab unless
+                               // its entries overflowed the pair buffers; k_composite_spill composites [slab_cut, slab end)
 };
 
 // Tile binning.
@@ -163,7 +170,7 @@ hipError_t launch_tile_emit(hipStream_t s, uint32_t j0, uint32_t j1, const uint3
                             const uint32_t* cnt, const uint32_t* block_sums, uint32_t tiles_x, uint2* tpairs,
                             uint32_t row_lo, uint32_t row_hi, const uint32_t* done, uint32_t row_words,
                             const uint32_t* d_n_vis, const uint32_t* d_entries, uint32_t capacity,
-                            const uint2* window, const uint32_t* sorted_keys);
+                            const uint2* window, const uint32_t* sorted_keys, const uint32_t* d_cut /* SlabStats::slab_cut */);
 // ranges_clean: the whole table (table_tiles entries = its allocation) is already all-zero (the previous composite
 // cleared what it used); otherwise it is zeroed here, all of it
 hipError_t launch_tile_ranges(hipStream_t s, uint32_t capacity, const uint32_t* d_n, const uint32_t* tkey_sorted,
@@ -254,6 +261,13 @@ void quat_to_rows(const float q[4], float r[9]);
 hipError_t launch_composite(hipStream_t s, const FrameConsts& f, uint2* ranges, const uint32_t* list,
                             const Records& rec, float4* fb, bool carry, uint32_t* done, uint32_t row_words,
                             uint32_t* d_done_count, bool clear_ranges, uint32_t* tile_sat);
+// The splats [stats->slab_cut, min(j1, *d_n)) of the depth order, composited WITHOUT tile pairs (an overflowing slab's tail):
+// one workgroup per live tile scans them, keeps those whose rectangle (and window) takes the tile, blends them like
+// k_composite.  Falls through when the slab was not cut.
+hipError_t launch_composite_spill(hipStream_t s, const FrameConsts& f, const SlabStats* stats, uint32_t j1, const uint32_t* d_n,
+                                  const uint32_t* sorted_idx, const uint32_t* sorted_keys, const Records& rec, float4* fb,
+                                  uint32_t* done, uint32_t row_words, uint32_t* d_done_count, uint32_t* tile_sat, uint32_t row_lo,
+                                  uint32_t row_hi, const uint2* window);
 hipError_t launch_clear_fb(hipStream_t s, float4* fb, uint32_t n_px);
 hipError_t launch_resolve_rgba8(hipStream_t s, const float4* fb, uint32_t n_px, float bg_r, float bg_g, float bg_b,
                                 uint32_t* out_rgba8);

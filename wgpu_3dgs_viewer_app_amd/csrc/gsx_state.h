@@ -85,6 +85,8 @@ struct Model {
     bool lists_complete = false;                // the tile lists of the last render cover the whole model (one slab)
     uint32_t n_visible = 0, n_entries = 0, n_sorted = 0, n_sorted2 = 0;
     uint64_t tile_cap = 0;                      // capacity (entries) of the tile-pair buffers
+    uint32_t overflow_seen = 0;                 // SlabStats::overflow_events as last mirrored
+    uint64_t overflow_slabs = 0;                // slabs that spilled over the model's lifetime (gsx_frame_stats)
     uint32_t slabs_hint = 0;                    // slabs the last observed frame needed (0 = unknown)
     hipEvent_t stats_event = nullptr;           // completion of the asynchronous statistics copy
     bool stats_copy_inflight = false;
@@ -194,6 +196,7 @@ struct gsx_viewer {
     bool last_render_cont = false;
     unsigned long long* h_verdict = nullptr;  // pinned: {seq << 32 | tiles needing repair}, posted by k_spec_verify (host_verify)
     uint32_t verify_seq = 0;
+    uint64_t tile_cap_fixed = 0;  // GSX_TILE_CAP was set when the viewer was created: pair-buffer capacity that never grows (tests of the spill path)
     bool validate = false;  // GSX_VALIDATE was set when the viewer was created: check tile ranges / lists before compositing (debug, synchronous)
     uint32_t band_lo = 0, band_hi = 0xFFFFFFFFu;  // tile rows this viewer renders (gsx_viewer_set_band)
     gsx_query query{};                   // GSX_QUERY_NONE

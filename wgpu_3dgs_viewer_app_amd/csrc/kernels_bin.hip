@@ -173,8 +173,8 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_counts(const uint32_t* __r
     }
 }
 
-// single workgroup: exclusive scan of block_sums in place; slab total D -> stats->n_entries (clamped to the
-// pair-buffer capacity; an overflow is flagged for the host to grow the buffers and redo the frame)
+// single workgroup: exclusive scan of block_sums in place; slab total D -> stats->n_entries (what fits the pair buffers:
+// see the cut below)
 __global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__ sums, uint32_t j0, uint32_t j1,
                                                            const uint32_t* __restrict__ d_n_vis,
                                                            SlabStats* __restrict__ stats, uint32_t capacity,
@@ -205,15 +205,34 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__
         if (tid == 1023) carry_s = carry + woff + x;
         __syncthreads();
     }
+    // More entries than the pair buffers hold: the slab is CUT after the last 256-splat chunk whose entries still fit.  The
+    // chunks before the cut are binned, tile-sorted and composited as usual; k_composite_spill then composites the splats
+    // behind the cut straight from the depth order (slow, pair-free, same per-pixel operation sequence), so the frame is
+    // complete whatever the capacity — the host only learns (lazily) that it should grow the buffers.
+    __shared__ uint32_t fit_s;
+    const uint32_t total = carry_s;
+    if (tid == 0) fit_s = 0;
+    __syncthreads();
+    if (total > capacity) {
+        for (uint32_t i = tid; i < nblocks; i += 1024) {
+            const uint32_t incl = i + 1 < nblocks ? sums[i + 1] : total;  // inclusive prefix of chunk i (monotone in i)
+            if (incl <= capacity) atomicMax(&fit_s, i + 1u);
+        }
+    }
+    __syncthreads();
     if (tid == 0) {
-        const uint32_t total = carry_s;
-        stats->n_entries = min(total, capacity);
+        const bool over = total > capacity;
+        const uint32_t fit = over ? fit_s : nblocks;
+        stats->n_entries = over ? (fit < nblocks ? sums[fit] : total) : total;
+        stats->slab_cut = over ? min(j0 + fit * (uint32_t)kBinThreads, n_vis) : max(n_vis, j0);
         stats->n_entries_total += total;
+        stats->max_needed = max(stats->max_needed, total);
         // the host sizes the next frame's slab plan from this (read lazily, never waited for)
         if (nblocks && !(d_done_count && *d_done_count >= owned_tiles)) stats->slabs_used = max(stats->slabs_used, slab_index + 1u);
-        if (total > capacity) {
+        if (over) {
             stats->overflow = 1;
-            stats->max_needed = max(stats->max_needed, total);
+            stats->overflow_events += 1;
+            stats->max_needed_ever = max(stats->max_needed_ever, total);
         }
     }
 }
@@ -248,10 +267,10 @@ __global__ __launch_bounds__(kBinThreads) void k_tile_emit(uint32_t jbase, uint3
                                                             const uint32_t* __restrict__ done, uint32_t row_words,
                                                             const uint32_t* __restrict__ d_n_vis,
                                                             const uint32_t* __restrict__ d_entries, uint32_t capacity,
-                                                            TileWindow tw) {
+                                                            TileWindow tw, const uint32_t* __restrict__ d_cut) {
     __shared__ uint32_t wsum[4];
     if (*d_entries == 0) return;  // empty slab (also: every tile already saturated)
-    n_vis = min(n_vis, *d_n_vis);
+    n_vis = min(min(n_vis, *d_n_vis), *d_cut);  // an overflowing slab is binned up to its cut (k_scan_block_sums)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chunks = n_vis > jbase ? (n_vis - jbase + kBinThreads - 1) / kBinThreads : 0u;
     for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
@@ -365,12 +384,12 @@ hipError_t launch_tile_emit(hipStream_t s, uint32_t j0, uint32_t j1, const uint3
                             const uint32_t* cnt, const uint32_t* block_sums, uint32_t tiles_x, uint2* tpairs,
                             uint32_t row_lo, uint32_t row_hi, const uint32_t* done, uint32_t row_words,
                             const uint32_t* d_n_vis, const uint32_t* d_entries, uint32_t capacity,
-                            const uint2* window, const uint32_t* sorted_keys) {
+                            const uint2* window, const uint32_t* sorted_keys, const uint32_t* d_cut) {
     const uint32_t nb = std::min<uint32_t>((uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0), kBinGrid);
     if (!nb) return hipSuccess;
     TileWindow tw{window, sorted_keys, tiles_x, WindowPyramid{}};
     hipLaunchKernelGGL(k_tile_emit, dim3(nb), dim3(kBinThreads), 0, s, j0, j1, sorted_idx, srect, cnt, block_sums,
-                       tiles_x, tpairs, row_lo, row_hi, done, row_words, d_n_vis, d_entries, capacity, tw);
+                       tiles_x, tpairs, row_lo, row_hi, done, row_words, d_n_vis, d_entries, capacity, tw, d_cut);
     return hipGetLastError();
 }
 

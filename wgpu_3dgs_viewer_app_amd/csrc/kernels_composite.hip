@@ -30,6 +30,60 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f splat2(float x) { return v2f{x, x}; }
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }  // v_pk_fma_f32
 
+// Blends the first `cnt` records of the LDS batch (slots up to the next multiple of kGroup must hold records no pixel
+// supports) into this lane's two pixels.  Groups of kGroup splats, straight-line, one skip branch per splat; a wave whose
+// pixels are all saturated leaves the batch at the next group.
+template <int MODE>
+__device__ __forceinline__ void blend_batch(const FrameConsts& f, const uint32_t cnt, const float2* s_mean, const float4* s_conic,
+                                            const float4* s_rgb, const float pxf, const v2f pyf, uint32_t& lim0, uint32_t& lim1,
+                                            v2f& T, v2f& C0, v2f& C1, v2f& C2, uint32_t& stop_key) {
+    for (uint32_t j0 = 0; j0 < cnt; j0 += kGroup) {
+        if (!__ballot((lim0 | lim1) != 0u)) break;
+        // the group's records first, so the LDS round trips overlap instead of each splat waiting for its own
+        float2 gm[kGroup];
+        float4 gc[kGroup];
+#pragma unroll
+        for (uint32_t u = 0; u < kGroup; ++u) {
+            gm[u] = s_mean[j0 + u];
+            gc[u] = s_conic[j0 + u];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kGroup; ++u) {
+            const uint32_t j = j0 + u;
+            const float2 m = gm[u];
+            const float4 co = gc[u];
+            const float dx = pxf - m.x;
+            const v2f dy = pyf - splat2(m.y);
+            // q = fma(a*dx, dx, fma(c*dy, dy, ((2b)*dx)*dy))
+            const v2f q = fma2(splat2(co.x * dx), splat2(dx), fma2(splat2(co.z) * dy, dy, splat2(co.y * dx) * dy));
+            const bool h0 = __float_as_uint(q.x) < lim0, h1 = __float_as_uint(q.y) < lim1;
+            if (h0 || h1) {
+                v2f alpha;
+                if (MODE == 0) {
+                    const v2f e = splat2(-0.5f) * q;
+                    alpha = splat2(co.w) * v2f{__expf(e.x), __expf(e.y)};
+                } else {
+                    alpha = splat2(co.w * 1.0f);
+                }
+                alpha.x = fminf(f.alpha_max, alpha.x);
+                alpha.y = fminf(f.alpha_max, alpha.y);
+                alpha.x = (h0 && !(alpha.x < f.alpha_min)) ? alpha.x : 0.0f;
+                alpha.y = (h1 && !(alpha.y < f.alpha_min)) ? alpha.y : 0.0f;
+                const float4 c = s_rgb[j];
+                const v2f wgt = T * alpha;
+                C0 = fma2(wgt, splat2(c.x), C0);
+                C1 = fma2(wgt, splat2(c.y), C1);
+                C2 = fma2(wgt, splat2(c.z), C2);
+                T = T * (splat2(1.0f) - alpha);
+                // only a blend lowers T, so T < t_eps here means saturated now or before
+                lim0 = T.x < f.t_eps ? 0u : lim0;
+                lim1 = T.y < f.t_eps ? 0u : lim1;
+                stop_key = __float_as_uint(c.w);
+            }
+        }
+    }
+}
+
 // One 128-lane workgroup (two waves) per 16x16 tile; every lane owns the two vertically adjacent pixels
 // (x, 2r) and (x, 2r+1), so wave w covers rows 8w..8w+7.  Two pixels per lane because the loop is bound by VALU
 // issue and by the LDS return path (every splat record is broadcast to all lanes): gfx950's packed fp32
@@ -134,53 +188,7 @@ __global__ __launch_bounds__(128) void k_composite(const FrameConsts f, uint2* _
             }
         }
         const uint32_t cnt = min((uint32_t)kBatch, range.y - base);
-        // Groups of four splats, straight-line, one skip branch per splat; a wave whose pixels are all saturated leaves the
-        // batch at the next group.
-        for (uint32_t j0 = 0; j0 < cnt; j0 += kGroup) {
-            if (!__ballot((lim0 | lim1) != 0u)) break;
-            // the group's records first, so the LDS round trips overlap instead of each splat waiting for its own
-            float2 gm[kGroup];
-            float4 gc[kGroup];
-#pragma unroll
-            for (uint32_t u = 0; u < kGroup; ++u) {
-                gm[u] = s_mean[j0 + u];
-                gc[u] = s_conic[j0 + u];
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < kGroup; ++u) {
-                const uint32_t j = j0 + u;
-                const float2 m = gm[u];
-                const float4 co = gc[u];
-                const float dx = pxf - m.x;
-                const v2f dy = pyf - splat2(m.y);
-                // q = fma(a*dx, dx, fma(c*dy, dy, ((2b)*dx)*dy))
-                const v2f q = fma2(splat2(co.x * dx), splat2(dx), fma2(splat2(co.z) * dy, dy, splat2(co.y * dx) * dy));
-                const bool h0 = __float_as_uint(q.x) < lim0, h1 = __float_as_uint(q.y) < lim1;
-                if (h0 || h1) {
-                    v2f alpha;
-                    if (MODE == 0) {
-                        const v2f e = splat2(-0.5f) * q;
-                        alpha = splat2(co.w) * v2f{__expf(e.x), __expf(e.y)};
-                    } else {
-                        alpha = splat2(co.w * 1.0f);
-                    }
-                    alpha.x = fminf(f.alpha_max, alpha.x);
-                    alpha.y = fminf(f.alpha_max, alpha.y);
-                    alpha.x = (h0 && !(alpha.x < f.alpha_min)) ? alpha.x : 0.0f;
-                    alpha.y = (h1 && !(alpha.y < f.alpha_min)) ? alpha.y : 0.0f;
-                    const float4 c = s_rgb[j];
-                    const v2f wgt = T * alpha;
-                    C0 = fma2(wgt, splat2(c.x), C0);
-                    C1 = fma2(wgt, splat2(c.y), C1);
-                    C2 = fma2(wgt, splat2(c.z), C2);
-                    T = T * (splat2(1.0f) - alpha);
-                    // only a blend lowers T, so T < t_eps here means saturated now or before
-                    lim0 = T.x < f.t_eps ? 0u : lim0;
-                    lim1 = T.y < f.t_eps ? 0u : lim1;
-                    stop_key = __float_as_uint(c.w);
-                }
-            }
-        }
+        blend_batch<MODE>(f, cnt, s_mean, s_conic, s_rgb, pxf, pyf, lim0, lim1, T, C0, C1, C2, stop_key);
     }
     if (in0) fb[fbo] = make_float4(C0.x, C1.x, C2.x, T.x);
     if (in1) fb[fbo + f.w_px] = make_float4(C0.y, C1.y, C2.y, T.y);
@@ -195,6 +203,101 @@ __global__ __launch_bounds__(128) void k_composite(const FrameConsts f, uint2* _
             atomicOr(&done_bits[ty * row_words + (tx >> 5)], 1u << (tx & 31u));
             atomicAdd(done_count, 1u);  // at most one per tile per frame
             if (tile_sat) tile_sat[tile] = max(s_sat, 1u);  // saturation depth key (multi-GPU speculation); 0 = open
+        }
+    }
+}
+
+// An overflowing slab's tail: the splats [stats->slab_cut, min(j1, *d_n)) of the depth order never reached the tile-pair
+// buffers (k_scan_block_sums cut the slab where they were full).  One workgroup per tile that is still open scans them 128
+// at a time, keeps — in depth order — those whose tile rectangle (and depth-key window) takes this tile, and blends them
+// with the compositor's own code: the per-pixel operation sequence is that of a frame with larger buffers, so the pixels are
+// the same.  O(tiles x tail) rectangle tests: a rare path that trades speed for never delivering an incomplete frame; the
+// host grows the buffers as soon as it learns of the overflow.  A slab that was not cut: two loads, then return.
+template <int MODE>
+__global__ __launch_bounds__(128) void k_composite_spill(const FrameConsts f, const SlabStats* __restrict__ stats, const uint32_t j1,
+                                                          const uint32_t* __restrict__ d_n, const uint32_t* __restrict__ sorted_idx,
+                                                          const uint32_t* __restrict__ sorted_keys, const float4* __restrict__ rec_a,
+                                                          const float4* __restrict__ rec_b, const float4* __restrict__ rec_c,
+                                                          float4* __restrict__ fb, uint32_t* __restrict__ done_bits,
+                                                          const uint32_t row_words, uint32_t* __restrict__ done_count,
+                                                          uint32_t* __restrict__ tile_sat, const uint32_t row_lo, const uint32_t row_hi,
+                                                          const uint2* __restrict__ window) {
+    const uint32_t end = min(j1, *d_n), cut = stats->slab_cut;
+    if (cut >= end) return;
+    __shared__ float2 s_mean[128 + kGroup];
+    __shared__ float4 s_conic[128 + kGroup];
+    __shared__ float4 s_rgb[128 + kGroup];
+    __shared__ uint32_t s_sat, s_w[2];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tx = tile % f.tiles_x, ty = tile / f.tiles_x;
+    if (ty < row_lo || ty >= row_hi) return;
+    if (done_bits && ((done_bits[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)) return;
+    const uint2 win = window ? window[tile] : make_uint2(0u, 0xFFFFFFFFu);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t px = tx * kTile + (tid & 15u), py = ty * kTile + 2u * (tid >> 4);
+    const bool in0 = px < f.w_px && py < f.h_px, in1 = px < f.w_px && py + 1u < f.h_px;
+    const float pxf = (float)px + 0.5f;
+    const v2f pyf = v2f{(float)py + 0.5f, (float)(py + 1u) + 0.5f};
+    const size_t fbo = (size_t)py * f.w_px + px;
+    v2f T = splat2(1.0f), C0 = splat2(0.0f), C1 = C0, C2 = C0;
+    if (in0) {  // the slab's k_composite has run: the framebuffer holds every pixel
+        const float4 p = fb[fbo];
+        C0.x = p.x; C1.x = p.y; C2.x = p.z; T.x = p.w;
+    }
+    if (in1) {
+        const float4 p = fb[fbo + f.w_px];
+        C0.y = p.x; C1.y = p.y; C2.y = p.z; T.y = p.w;
+    }
+    const uint32_t live = f.k2 > 0.0f ? __float_as_uint(f.k2) + 1u : (f.k2 == 0.0f ? 1u : 0u);
+    uint32_t lim0 = (in0 && !(T.x < f.t_eps)) ? live : 0u, lim1 = (in1 && !(T.y < f.t_eps)) ? live : 0u;
+    uint32_t stop_key = 0;
+    if (tid == 0) s_sat = 0;
+    for (uint32_t base = cut; base < end; base += 128u) {
+        if (__syncthreads_and((lim0 | lim1) == 0u)) break;  // also protects the LDS batch of the previous iteration
+        const uint32_t j = base + tid;
+        bool hit = false;
+        uint32_t idx = 0;
+        float4 a = make_float4(0, 0, 0, 0);
+        if (j < end) {
+            idx = sorted_idx[j];
+            a = rec_a[idx];
+            const uint32_t rx = __float_as_uint(a.z), ry = __float_as_uint(a.w);
+            hit = tx >= (rx & 0xFFFFu) && tx < (rx >> 16) && ty >= (ry & 0xFFFFu) && ty < (ry >> 16);
+            if (hit && window) {
+                const uint32_t key = sorted_keys[j];
+                hit = key >= win.x && key < win.y;
+            }
+        }
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) s_w[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        const uint32_t cnt = s_w[0] + s_w[1];
+        const uint32_t slot = (wave ? s_w[0] : 0u) + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (hit) {
+            const float4 b = rec_b[idx];
+            s_mean[slot] = make_float2(a.x, a.y);
+            s_conic[slot] = make_float4(b.x, 2.0f * b.y, b.z, b.w);
+            s_rgb[slot] = rec_c[idx];
+        }
+        if (tid < (uint32_t)kGroup) {  // the blend loop runs in whole groups: records no pixel supports behind the last hit
+            s_mean[cnt + tid] = make_float2(3.0e38f, 3.0e38f);
+            s_conic[cnt + tid] = make_float4(1.0f, 0.0f, 1.0f, 0.0f);
+            s_rgb[cnt + tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        __syncthreads();
+        blend_batch<MODE>(f, cnt, s_mean, s_conic, s_rgb, pxf, pyf, lim0, lim1, T, C0, C1, C2, stop_key);
+    }
+    if (in0) fb[fbo] = make_float4(C0.x, C1.x, C2.x, T.x);
+    if (in1) fb[fbo + f.w_px] = make_float4(C0.y, C1.y, C2.y, T.y);
+    if (done_bits && __syncthreads_and((lim0 | lim1) == 0u)) {
+        if (tile_sat) {
+            if (stop_key) atomicMax(&s_sat, stop_key);
+            __syncthreads();
+        }
+        if (tid == 0) {
+            atomicOr(&done_bits[ty * row_words + (tx >> 5)], 1u << (tx & 31u));
+            atomicAdd(done_count, 1u);
+            if (tile_sat) tile_sat[tile] = max(s_sat, 1u);
         }
     }
 }
@@ -229,6 +332,20 @@ hipError_t launch_composite(hipStream_t s, const FrameConsts& f, uint2* ranges, 
     else
         hipLaunchKernelGGL(k_composite<1>, grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count,
                            clear_ranges ? 1 : 0, tile_sat);
+    return hipGetLastError();
+}
+
+hipError_t launch_composite_spill(hipStream_t s, const FrameConsts& f, const SlabStats* stats, uint32_t j1, const uint32_t* d_n,
+                                  const uint32_t* sorted_idx, const uint32_t* sorted_keys, const Records& rec, float4* fb,
+                                  uint32_t* done, uint32_t row_words, uint32_t* d_done_count, uint32_t* tile_sat, uint32_t row_lo,
+                                  uint32_t row_hi, const uint2* window) {
+    dim3 grid(f.tiles_x * f.tiles_y), block(128);
+    if (f.display_mode == GSX_DISPLAY_SPLAT)
+        hipLaunchKernelGGL(k_composite_spill<0>, grid, block, 0, s, f, stats, j1, d_n, sorted_idx, sorted_keys, rec.a, rec.b, rec.c, fb, done,
+                           row_words, d_done_count, tile_sat, row_lo, row_hi, window);
+    else
+        hipLaunchKernelGGL(k_composite_spill<1>, grid, block, 0, s, f, stats, j1, d_n, sorted_idx, sorted_keys, rec.a, rec.b, rec.c, fb, done,
+                           row_words, d_done_count, tile_sat, row_lo, row_hi, window);
     return hipGetLastError();
 }
 

@@ -23,6 +23,7 @@
 // The element count may live on the device (d_n: tile pairs of a depth slab) — no host round trip.
 // Stability (ties keep input order) makes the depth order deterministic: ties break by Gaussian index.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include "gsx_internal.h"
@@ -71,6 +72,17 @@ __device__ inline unsigned long long wave_match8(uint32_t digit, bool valid) {
         bool bit = (digit >> b) & 1u;
         unsigned long long bal = __ballot(bit);
         m &= bit ? bal : ~bal;
+    }
+    return m;
+}
+
+// lanes whose `theirs` equals THIS lane's `mine` (8-bit values)
+__device__ inline unsigned long long wave_match8_pair(uint32_t theirs, uint32_t mine) {
+    unsigned long long m = ~0ull;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const unsigned long long bal = __ballot((theirs >> b) & 1u);
+        m &= ((mine >> b) & 1u) ? bal : ~bal;
     }
     return m;
 }
@@ -395,49 +407,91 @@ hipError_t launch_rowscan(hipStream_t s, uint32_t* table, uint32_t nrows, uint32
     return hipGetLastError();
 }
 
-static uint32_t g_epoch = 1;  // distinguishes the status words of successive launches (any stream, any viewer)
+static std::atomic<uint32_t> g_epoch{1};  // distinguishes the status words of successive launches (any stream, any viewer, any thread)
 
 // ---- is a returning LDS add served in ascending lane order?  (see k_radix_onesweep<.., LANE_ORDERED>) ----
-__global__ __launch_bounds__(64) void k_lane_order_probe(uint32_t seed, uint32_t rounds, uint32_t* __restrict__ violations) {
-    __shared__ uint32_t c[256];
-    const uint32_t lane = threadIdx.x;
+// The probe has the shape of the kernel that relies on the answer: 256-thread workgroups (four waves sharing the LDS), every
+// lane issuing kRadixRounds back-to-back returning adds on its wave's 256 counters, one workgroup per resident slot of the
+// persistent sort grid (three per CU) so the LDS is contended the way it is in production, and address patterns from "no
+// two lanes collide" to "all 64 lanes on one counter".  Expected value of each add: the counter before the instruction
+// (the wave's earlier rounds, tracked by ballot matching — the documented path) plus the number of LOWER lanes that hit
+// the same counter in the same instruction.
+__global__ __launch_bounds__(kRadixThreads) void k_lane_order_probe(uint32_t seed, uint32_t iterations, uint32_t* __restrict__ violations) {
+    __shared__ uint32_t c[kRadixWaves][256];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t bad = 0;
-    for (uint32_t r = 0; r < rounds; ++r) {
-        for (uint32_t i = lane; i < 256; i += 64) c[i] = 0;
+    for (uint32_t it = 0; it < iterations; ++it) {
+#pragma unroll
+        for (int w = 0; w < kRadixWaves; ++w) c[w][tid] = 0;
         __syncthreads();
-        // address patterns from no collisions to all 64 lanes on one counter
-        uint32_t x = (seed + blockIdx.x * 9781u + r * 6271u) * 2654435761u + lane * 40503u;
-        x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
-        const uint32_t span = 1u << ((blockIdx.x + r) % 9u);  // 1, 2, 4 ... 256 distinct addresses
-        const uint32_t a = x & (span - 1u);
-        const uint32_t old = atomicAdd(&c[a], 1u);
-        // expected: the number of lower lanes with the same address
-        uint32_t expect = 0;
-        for (uint32_t l = 0; l < 64; ++l) {
-            const uint32_t al = __shfl((int)a, (int)l, 64);
-            expect += (l < lane && al == a) ? 1u : 0u;
+        const uint32_t span = 1u << ((blockIdx.x + it + wave) % 9u);  // 1, 2, 4 ... 256 distinct counters
+        uint32_t a[kRadixRounds], got[kRadixRounds];
+#pragma unroll
+        for (int r = 0; r < kRadixRounds; ++r) {
+            uint32_t x = (seed + blockIdx.x * 9781u + it * 6271u + (uint32_t)r * 7919u + wave * 104729u) * 2654435761u + lane * 40503u;
+            x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+            a[r] = x & (span - 1u);
         }
-        bad += old != expect;
+#pragma unroll
+        for (int r = 0; r < kRadixRounds; ++r) got[r] = atomicAdd(&c[wave][a[r]], 1u);  // chained, like the ranking loop
+        // reference ranks: per round, lower lanes with the same counter + that counter's total over the earlier rounds
+#pragma unroll
+        for (int r = 0; r < kRadixRounds; ++r) {
+            const unsigned long long m = wave_match8(a[r], true);
+            uint32_t earlier = 0;
+            for (int q = 0; q < r; ++q) earlier += (uint32_t)__popcll(wave_match8_pair(a[q], a[r]));
+            bad += got[r] != earlier + (uint32_t)__popcll(m & lanemask_lt());
+        }
         __syncthreads();
     }
     if (bad) atomicAdd(violations, bad);
 }
 
-static int g_lane_ordered = -1;  // -1 not probed yet (the ballot-matching ranks are used), 0 no, 1 yes
+// One answer per device (the property belongs to the silicon a viewer runs on): -1 not probed yet (the ballot-matching ranks
+// are used), 0 no, 1 yes.  Probed on the CURRENT device; gsx_viewer_create calls it after hipSetDevice.
+constexpr int kMaxDevices = 64;
+static std::atomic<int> g_lane_ordered[kMaxDevices];
+static std::atomic<bool> g_lane_init{false};
+static std::atomic<int> g_rank_override{-1};  // gsx_debug_set_radix_rank_mode: -1 none, 0 force matching, 1 force lane-ordered
+
+static int lane_ordered_slot(int* dev_out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = -1;
+    *dev_out = dev;
+    bool expected = false;
+    if (g_lane_init.compare_exchange_strong(expected, true))
+        for (auto& x : g_lane_ordered) x.store(-1);
+    return dev < 0 ? 0 : g_lane_ordered[dev].load();
+}
 
 bool radix_lane_ordered_adds() {
-    if (g_lane_ordered >= 0) return g_lane_ordered == 1;
-    if (getenv("GSX_RADIX_MATCH_RANKS")) return (g_lane_ordered = 0) == 1;  // force the documented-behaviour path
+    int dev;
+    const int known = lane_ordered_slot(&dev);
+    if (dev < 0) return false;
+    if (known >= 0) return known == 1;
+    if (getenv("GSX_RADIX_MATCH_RANKS")) {  // force the documented-behaviour path
+        g_lane_ordered[dev].store(0);
+        return false;
+    }
     uint32_t* d = nullptr;
     uint32_t h = 1;
     bool ok = hipMalloc(&d, 4) == hipSuccess && hipMemset(d, 0, 4) == hipSuccess;
     if (ok) {
-        hipLaunchKernelGGL(k_lane_order_probe, dim3(512), dim3(64), 0, 0, 12345u, 32u, d);
+        hipLaunchKernelGGL(k_lane_order_probe, dim3(kRadixGrid), dim3(kRadixThreads), 0, 0, 12345u, 8u, d);
         ok = hipGetLastError() == hipSuccess && hipMemcpy(&h, d, 4, hipMemcpyDeviceToHost) == hipSuccess;
     }
     if (d) (void)hipFree(d);
-    g_lane_ordered = (ok && h == 0) ? 1 : 0;
-    return g_lane_ordered == 1;
+    g_lane_ordered[dev].store((ok && h == 0) ? 1 : 0);
+    return ok && h == 0;
+}
+
+void radix_set_rank_override(int mode) { g_rank_override.store(mode < 0 ? -1 : (mode ? 1 : 0)); }
+
+static bool use_lane_ordered() {
+    const int o = g_rank_override.load(std::memory_order_relaxed);
+    if (o >= 0) return o == 1;
+    int dev;
+    return lane_ordered_slot(&dev) == 1;
 }
 
 hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n, const uint32_t* d_n, int bits,
@@ -466,13 +520,14 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
         hipLaunchKernelGGL(k_radix_global_hist<1>, dim3(hgrid), dim3(kRadixThreads), 0, s, buf.keys_src, n, d_n, passes, dbits, ghist);
     const uint2* pin = buf.pairs_src;
     uint2* pout = buf.pairs_a;
+    const bool lane_ordered = use_lane_ordered();
     for (int p = 0; p < passes; ++p) {
         const int shift = dbits * p;
         const bool first = p == 0, last = p == passes - 1;
-        const uint32_t epoch = (g_epoch++ & 0x1FFFFFFFu) | (1u << 29);  // 30 bits, never 0
+        const uint32_t epoch = (g_epoch.fetch_add(1, std::memory_order_relaxed) & 0x1FFFFFFFu) | (1u << 29);  // 30 bits, never 0
 #define GSX_SWEEP(IN, OUT)                                                                                              \
     do {                                                                                                                \
-        if (g_lane_ordered == 1)                                                                                        \
+        if (lane_ordered)                                                                                               \
             hipLaunchKernelGGL((k_radix_onesweep<IN, OUT, true>), dim3(grid), dim3(kRadixThreads), 0, s, buf.keys_src,  \
                                buf.vals_src, pin, buf.keys_out, buf.vals_out, pout, n, d_n, shift, dmask, ghist + 256 * p, \
                                ticket, status, epoch, ghist, last ? 256u * (uint32_t)passes : 0u);                       \

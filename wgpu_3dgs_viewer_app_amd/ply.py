@@ -29,8 +29,8 @@ class Gaussians:
     @staticmethod
     def read_ply_header(data: bytes) -> PlyHeader:
         h = _lib.PlyHeader()
-        buf = (C.c_char * len(data)).from_buffer_copy(data) if not isinstance(data, (bytearray, memoryview)) else (C.c_char * len(data)).from_buffer(data)
-        _lib.check(_lib.load().gsx_ply_read_header(C.addressof(buf), len(data), C.byref(h)))
+        buf = np.frombuffer(data, dtype=np.uint8)  # zero-copy view (bytes, bytearray, memoryview, ndarray): a garden-sized file is 1.4 GB
+        _lib.check(_lib.load().gsx_ply_read_header(buf.ctypes.data, buf.size, C.byref(h)))
         return PlyHeader(h)
 
     @staticmethod
@@ -53,6 +53,10 @@ class Gaussians:
 
     def write_ply(self, mask_words: np.ndarray | None = None, edits: np.ndarray | None = None) -> bytes:
         """``write_ply(writer, edits, mask)`` (app.rs:908-940): binary little-endian INRIA PLY of the (masked, edited) Gaussians."""
+        return self.write_ply_array(mask_words, edits).tobytes()
+
+    def write_ply_array(self, mask_words: np.ndarray | None = None, edits: np.ndarray | None = None) -> np.ndarray:
+        """``write_ply`` into a uint8 array (no second copy of a multi-GB file)."""
         L = _lib.load()
         g = self.gaussians
         size = C.c_uint64()
@@ -69,4 +73,4 @@ class Gaussians:
         _lib.check(L.gsx_ply_write(g.ctypes.data, g.shape[0], mp, ep, None, 0, C.byref(size)))
         out = np.empty(size.value, np.uint8)
         _lib.check(L.gsx_ply_write(g.ctypes.data, g.shape[0], mp, ep, out.ctypes.data, out.size, C.byref(size)))
-        return out.tobytes()
+        return out

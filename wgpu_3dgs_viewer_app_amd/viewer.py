@@ -393,7 +393,7 @@ class MultiModelViewer:
         _lib.check(self._L.gsx_model_frame_stats(self._h, key.encode(), C.byref(st)))
         return dict(n_gaussians=int(st.n_gaussians), n_visible=int(st.n_visible), n_tile_entries=int(st.n_tile_entries),
                     n_sorted=int(st.n_sorted), n_repair_tiles=int(st.n_repair_tiles), n_repair_sorted=int(st.n_repair_sorted),
-                    speculated=bool(st.speculated))
+                    speculated=bool(st.speculated), overflow_slabs=int(st.overflow_slabs))
 
     def download_projection(self, key: str) -> dict:
         n = self.models[key].gaussian_buffers.gaussians_buffer.len()
