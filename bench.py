@@ -9,13 +9,31 @@ Prints ONE JSON line on rank 0.  The CPU oracle is used here only for the `cpu_b
     python bench.py                       # N=1, cfg4 scene (10 M Gaussians, SH-3, 1920x1080)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus 8 --steps K --warmup W
+
+What one N=1 run measures, all in the same process on the same resident scene (nothing is read from profiles/):
+  value                 fps of K frames in the default schedule (progressive slabs + temporal occlusion speculation)
+  value_unspeculated    fps of K frames with speculative = 0 (what every first frame / incoherent pose costs)
+  roofline              k_project<3,0,0> — the projection pass SURVEY 8d prices (SH colour + cov2d + cull + depth key),
+                        HIP events around that kernel alone over the unspeculated timed loop, N*pod + N_vis*40 bytes
+  roofline_speculated   k_project_geom — the geometry-only projection of the speculated loop, priced on what IT has to move
+  roofline*.traffic     HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate passes) that this
+                        script runs on short child invocations of itself before it touches the GPU (null if rocprofv3 is
+                        missing or fails; --no-pmc skips them)
+  frame_check           the last timed speculated frame, re-rendered with speculative = 0 and progressive = 0, must be
+                        bit-identical; overflow_slabs must be 0 (no frame took the slow pair-free path)
+  cpu_baseline          oracle/gsx_oracle.c, one frame of the WHOLE scene on all host cores
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -25,6 +43,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+METRIC = "frames/sec @1920x1080, N-Gaussian SH3 scene, 1/2/4/8 MI355X; %HBM roofline"
 
 
 def parse_args():
@@ -35,13 +54,18 @@ def parse_args():
     ap.add_argument("--workload", default="cfg4", help="cfg2 (1 M) | cfg3 (5.8 M) | cfg4 (10 M, headline)")
     ap.add_argument("--gaussians", type=int, default=0, help="override the Gaussian count (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="Gaussians in the CPU baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="Gaussians in the CPU baseline (0 = the whole scene)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC child passes (roofline.traffic = null)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # internal: the run rocprofv3 wraps
     ap.add_argument("--force-dist", action="store_true", help="run the sharded exchange path even at N=1")
-    ap.add_argument("--shard-mode", default="frames", help="N > 1: frames = whole scene on every GPU, rank g renders every N-th frame "
-                    "(frame-parallel; RGBA8 frames all-gathered) | screen = whole scene on every GPU, rank g renders band g of "
-                    "tile rows, one all-gather | index = splat-index shards + speculative record exchange")
+    ap.add_argument("--shard-mode", default="index", help="N > 1: index = splat-index shards + speculative record exchange by screen "
+                    "band (north_star's partition; the headline) | screen = whole scene on every GPU, rank g renders band g of tile "
+                    "rows, one all-gather | frames = whole scene on every GPU, rank g renders every N-th frame (replicated, "
+                    "frame-parallel; RGBA8 frames all-gathered)")
     ap.add_argument("--pose-stride", type=int, default=1, help="N = 1 experiment: render every S-th pose of the orbit — what one rank of "
                     "the frame-parallel mode at S GPUs sees (its speculation looks S poses back)")
+    ap.add_argument("--pose-order", default="orbit", help="orbit | random (the same 240 poses in a seeded random order: no temporal "
+                    "coherence, the speculation's worst case)")
     ap.add_argument("--gather", default="rgba8", help="N > 1, screen mode: rgba8 = every rank resolves its band (the app's blit to its "
                     "Rgba8Unorm surface) and 4 bytes a pixel are all-gathered on a second stream, under the next frame | float = the "
                     "(rgb, T) bands, 16 bytes a pixel, in stream order")
@@ -56,14 +80,15 @@ def parse_args():
 
 def cpu_baseline(cfg, n_sample, pose=0):
     """Oracle (reference algorithm shape: cull -> global radix sort -> back-to-front splat-major raster) on the
-    host cores, one frame of a bounded sample of the same scene."""
+    host cores: one frame of the same scene (the whole scene unless --cpu-sample bounds it)."""
     import oracle
     from wgpu_3dgs_viewer_app_amd import camera, scene
 
     n, sh, w, h, seed = cfg
-    n_sample = min(n, n_sample)
+    n_sample = min(n, n_sample) if n_sample else n
     g = scene.synthetic_gaussians(n, seed, sh, 0, n_sample)
     pos, color, shc, cov = oracle.convert(g)
+    del g
     cam = camera.orbit_pose(pose)
     f = oracle.frame_setup(cam.view(), cam.projection(w / h), w, h)
     fb = oracle.new_framebuffer(f)
@@ -72,23 +97,82 @@ def cpu_baseline(cfg, n_sample, pose=0):
     t0 = time.perf_counter()
     nvis = oracle.render_model(f, pos, color, shc, cov, fb)
     dt = time.perf_counter() - t0
+    what = "the whole scene" if n_sample == n else f"the first {n_sample} of {n} Gaussians of the same scene"
     return dict(value=round(1.0 / dt, 4), unit="frames/s", cores=oracle.num_threads(), kind="port",
-                sample=f"1 frame (orbit pose {pose}) of the first {n_sample} of {n} Gaussians of the same scene at {w}x{h}, "
-                       f"N_vis={nvis}, {dt:.2f} s; oracle/gsx_oracle.c, OpenMP")
+                sample=f"1 frame (orbit pose {pose}) of {what} ({n_sample} Gaussians) at {w}x{h}, N_vis={nvis}, {dt:.2f} s; "
+                       "oracle/gsx_oracle.c (cull -> LSD radix sort -> back-to-front splat-major 'over'), OpenMP")
+
+
+# ------------------------------------------------------------------------------------------------
+# HBM traffic of the projection kernels from PMC counters, measured by THIS run: rocprofv3 wraps two short child
+# invocations of this script (FETCH_SIZE and WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md "rocprofv3 PMC slots")
+# before the parent touches the GPU.  gfx950 correction per the guide: FETCH_SIZE tallies a wide coalesced streaming read
+# at half its bytes -> doubled; WRITE_SIZE taken as reported.
+# ------------------------------------------------------------------------------------------------
+def pmc_traffic(args):
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="gsx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload, "--pod", args.pod,
+                   "--steps", "4", "--warmup", "3"]
+            if args.gaussians:
+                cmd += ["--gaussians", str(args.gaussians)]
+            p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            if p.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} exited {p.returncode}: {p.stderr.decode(errors='replace')[-200:]}"
+            files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+            if not files:
+                return None, f"rocprofv3 --pmc {counter}: no counter_collection.csv"
+            per = {}
+            for r in csv.DictReader(open(files[0])):
+                if r.get("Counter_Name") != counter:
+                    continue
+                k = r["Kernel_Name"]
+                if "k_project" not in k:
+                    continue
+                variant = "speculated" if "k_project_geom" in k else "full"
+                per.setdefault(variant, []).append(float(r["Counter_Value"]))
+            for variant, vals in per.items():
+                out.setdefault(variant, {})[counter] = (1024.0 * sum(vals) / len(vals), len(vals))  # KiB -> bytes per dispatch
+    except Exception as e:  # noqa: BLE001 — the bench line must not die on a profiler problem
+        return None, f"PMC pass failed: {e!r}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {}
+    for variant, c in out.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            res[variant] = dict(hbm_bytes_per_launch=2.0 * c["FETCH_SIZE"][0] + c["WRITE_SIZE"][0], fetch_size_bytes_raw=c["FETCH_SIZE"][0],
+                                write_size_bytes=c["WRITE_SIZE"][0], dispatches=c["FETCH_SIZE"][1])
+    return (res or None), ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on child runs of this script, same scene; "
+                           "bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: wide coalesced reads are tallied at half their bytes)")
 
 
 def main():
     args = parse_args()
-    import torch
-    import torch.distributed as dist
-
-    from wgpu_3dgs_viewer_app_amd import camera, parallel, scene
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    # PMC child passes first: nothing in this process has initialised the GPU yet
+    traffic, traffic_note = None, "skipped"
+    single = world == 1 and not args.force_dist
+    if single and not args.no_pmc and not args.pmc_child and not args.render_options:
+        traffic, traffic_note = pmc_traffic(args)
+
+    import torch
+    import torch.distributed as dist
+
+    from wgpu_3dgs_viewer_app_amd import camera, parallel, scene
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libgsx has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -104,7 +188,7 @@ def main():
     cfg = (n, sh, w, h, seed)
 
     # --- resident scene: each rank generates and uploads only its index shard ---
-    start, count = parallel.shard_range(n, rank, world) if args.shard_mode == "index" else (0, n)
+    start, count = parallel.shard_range(n, rank, world) if (use_dist and args.shard_mode == "index") else (0, n)
     t0 = time.perf_counter()
     g = scene.synthetic_gaussians(n, seed, sh, start, count)
     t_gen = time.perf_counter() - t0
@@ -114,9 +198,10 @@ def main():
     gather = "rgba8" if afr else (args.gather if (use_dist and args.shard_mode == "screen") else "float")
     renderer = parallel.ShardedViewer(device=local_rank, world=world, rank=rank, use_dist=use_dist, sh=sh_kind, cov3d=cov_kind,
                                       mode=args.shard_mode if use_dist else "index", gather=gather, overlap_gather=gather == "rgba8")
-    if args.render_options:
-        renderer.stages.viewer.set_render_options(**{k: float(x) if "." in x else int(x) for k, x in
-                                                     (kv.split("=") for kv in args.render_options.split(","))})
+    viewer = renderer.stages.viewer
+    overrides = {k: float(x) if "." in x else int(x) for k, x in (kv.split("=") for kv in args.render_options.split(","))} if args.render_options else {}
+    if overrides:
+        viewer.set_render_options(**overrides)
     t0 = time.perf_counter()
     renderer.load_shard(g, start, n)
     renderer.poll()
@@ -127,9 +212,12 @@ def main():
     # the orbit's cameras (inputs of the path) are prepared before the clock starts: look_at / perspective in numpy cost
     # ~30 us a pose, which an un-synchronised frame loop hides but a host that waits for the device (host_verify) does not
     orbit = [camera.PrecomputedCamera(camera.orbit_pose(k), w / h) for k in range(240)]
+    pose_of = list(range(240))
+    if args.pose_order == "random":
+        pose_of = [int(x) for x in np.random.default_rng(2024).permutation(240)]
 
     def frame(i):
-        renderer.render_frame(orbit[(i * args.pose_stride) % 240], (w, h))
+        renderer.render_frame(orbit[pose_of[(i * args.pose_stride) % 240]], (w, h))
 
     if afr:
         # round j of the orbit = frames j * world .. j * world + world - 1; this rank renders frame j * world + rank
@@ -141,19 +229,8 @@ def main():
             else:
                 renderer.skip_frame()
 
-    # working buffers (records, sort and tile-pair buffers: sized by the scene) are allocated by the first frame a model is
-    # rendered in; that belongs to loading the scene, not to a step
-    frame(0)
-    renderer.poll()
     per = world if afr else 1     # frames of the orbit per loop iteration
     rounds = lambda k: (k + per - 1) // per  # noqa: E731
-    for i in range(rounds(args.warmup)):
-        frame(i)
-    renderer.poll()
-    renderer.set_pass_timing(True, None if args.pass_timing == "all" else ["project"])
-    renderer.get_pass_timing()  # reset accumulators
-    if args.host_profile and use_dist:
-        renderer.profile = {}
 
     def fence():
         torch.cuda.synchronize()
@@ -161,42 +238,100 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    if afr:   # exactly args.steps frames of the orbit, dealt round-robin; ranks without a frame in the last round only gather
-        first = rounds(args.warmup)
-        for i in range(rounds(args.steps)):
-            frame(first + i, limit=first * world + args.steps)
-    else:
-        for i in range(args.steps):
-            frame(args.warmup + i)
-    renderer.poll()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_loop(first_round):
+        """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize fences; max over ranks.
+        Returns (seconds, project-pass timing, index of the last frame rendered)."""
+        for i in range(rounds(args.warmup)):
+            frame(first_round + i)
+        renderer.poll()
+        renderer.set_pass_timing(True, None if args.pass_timing == "all" else ["project"])
+        renderer.get_pass_timing()  # reset accumulators
+        first = first_round + rounds(args.warmup)
+        fence()
+        t0 = time.perf_counter()
+        if afr:   # exactly args.steps frames of the orbit, dealt round-robin; ranks without a frame in the last round only gather
+            for i in range(rounds(args.steps)):
+                frame(first + i, limit=first * world + args.steps)
+        else:
+            for i in range(args.steps):
+                frame(first + i)
+        renderer.poll()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        timing = renderer.get_pass_timing()
+        renderer.set_pass_timing(False)
+        return elapsed, timing, first + rounds(args.steps) - 1
 
-    timing = renderer.get_pass_timing()
+    def accounting(first_round, frames=32):
+        """Untimed pass over the same poses: per-frame device counts (reading them costs a sync per frame)."""
+        acct = []
+        for i in range(min(rounds(args.steps), frames)):
+            frame(first_round + i)
+            st = renderer.last_stats()
+            acct.append((st["n_gaussians"], st["n_visible"], st.get("n_sorted", st["n_visible"]), 1 if st.get("speculated") else 0,
+                         1 if st.get("n_repair_tiles", 0) > 0 else 0, st["n_tile_entries"], st.get("overflow_slabs", 0)))
+        return np.asarray(acct, np.float64)
+
+    # working buffers (records, sort and tile-pair buffers: sized by the scene) are allocated by the first frame a model is
+    # rendered in; that belongs to loading the scene, not to a step
+    frame(0)
+    renderer.poll()
+
+    if args.pmc_child:
+        # the run rocprofv3 wraps for the PMC passes: a few speculated frames, then a few unspeculated ones; no output
+        for i in range(args.warmup + args.steps):
+            frame(i)
+        renderer.poll()
+        viewer.set_render_options(**dict(overrides, speculative=0))
+        for i in range(args.warmup + args.steps):
+            frame(i)
+        renderer.poll()
+        renderer.close()
+        return
+
+    if args.host_profile and use_dist:
+        renderer.profile = {}
+    elapsed, timing, last_idx = timed_loop(0)
     if args.host_profile and use_dist and rank == 0:
         print("host ms/frame by section:", {k: round(1e3 * x / args.steps, 4) for k, x in renderer.profile.items()}, file=sys.stderr)
-    renderer.set_pass_timing(False)
-
-    # Untimed accounting pass over the same poses: per-frame counts for the projection kernel's algorithmic bytes (the
-    # statistics live on the device; reading them costs a sync per frame, which the timed loop must not pay).
     renderer.profile = None
-    acct = []
-    for i in range(min(rounds(args.steps), 64)):
-        frame(rounds(args.warmup) + i)
-        st = renderer.last_stats()
-        acct.append((st["n_gaussians"], st["n_visible"], st.get("n_sorted", st["n_visible"]), 1 if st.get("speculated") else 0,
-                     st.get("n_repair_tiles", 0), st["n_tile_entries"]))
-    acct = np.asarray(acct, np.float64)
-    stats = renderer.last_stats()
+
+    # ---- the last timed frame is still in the framebuffer: keep it for the frame check ----
+    frame_check = None
+    fb_last = None
+    if single:
+        renderer.poll()
+        fb_last = renderer.framebuffer().copy()
+    acct = accounting(rounds(args.warmup))
+
+    # ---- N = 1: the unspeculated loop of the same run (value_unspeculated + the SURVEY 8d projection roofline) ----
+    elapsed_u = timing_u = acct_u = None
+    if single and "speculative" not in overrides:
+        viewer.set_render_options(**dict(overrides, speculative=0))
+        elapsed_u, timing_u, _ = timed_loop(0)
+        acct_u = accounting(rounds(args.warmup))
+        # frame check: the pose of the last timed speculated frame through the plainest schedule (no slabs, no speculation)
+        viewer.set_render_options(**dict(overrides, speculative=0, progressive=0))
+        frame(last_idx)
+        renderer.poll()
+        fb_plain = renderer.framebuffer()
+        equal = bool(np.array_equal(fb_last, fb_plain))
+        frame_check = dict(pose=pose_of[(last_idx * args.pose_stride) % 240], equal_to_unspeculated_single_pass=equal,
+                           max_abs_diff=float(np.abs(fb_last - fb_plain).max()),
+                           checksum=int(np.frombuffer(fb_last.tobytes(), np.uint32).astype(np.uint64).sum() & 0xFFFFFFFFFFFF))
+        viewer.set_render_options(**overrides) if overrides else viewer.set_render_options()
+        if not equal:
+            raise SystemExit(f"bench.py: the last timed frame differs from the speculative=0, progressive=0 frame: {frame_check}")
+    overflow_slabs = int(max(acct[:, 6].max(), acct_u[:, 6].max() if acct_u is not None else 0))
+    if overflow_slabs:
+        raise SystemExit(f"bench.py: {overflow_slabs} depth slabs overflowed the tile-pair buffers during the run (slow pair-free path)")
 
     # gather per-rank numbers for the roofline of the projection pass (dominant HBM stream of the path)
-    local = torch.tensor([acct[:, 0].mean(), acct[:, 1].mean(), acct[:, 2].mean(), acct[:, 3].mean(), float((acct[:, 4] > 0).mean()),
+    local = torch.tensor([acct[:, 0].mean(), acct[:, 1].mean(), acct[:, 2].mean(), acct[:, 3].mean(), acct[:, 4].mean(),
                           acct[:, 5].mean(), timing["project"]["ms"] * 1e3, timing["project"]["launches"]], dtype=torch.float64, device="cuda")
     if use_dist:
         allr = [torch.zeros_like(local) for _ in range(world)]
@@ -207,36 +342,55 @@ def main():
 
     if rank == 0:
         fps = args.steps / elapsed
-        # Projection kernel, ALGORITHMIC bytes per launch (means over the accounting frames of rank 0's shard):
-        #   every frame      reads N*16 (pos + rgba8) + N_vis*cov, writes N*4 (depth key) + N_vis*16 (mean, tile rect) + N/8 (ballots)
-        #   shaded Gaussians read the SH planes and write conic/opacity + colour/depth: + N_shaded*(sh + 32)
-        # An unspeculated frame shades every visible Gaussian in this kernel: that is SURVEY 8d's N*pod + N_vis*40 up to
-        # bookkeeping.  A speculated frame's projection pass is geometry only — the few admitted Gaussians are shaded by
-        # k_shade afterwards — so the kernel moves fewer bytes BY DESIGN and is priced on what it has to move.
-        n_loc, nvis_loc, nsort_loc, spec_frac, repair_frac, entries = allr[0][:6]
         sh_bytes = {0: 180, 1: 96, 2: 48, 3: 0}[sh_kind if sh > 0 else 3]
         cov_bytes = {0: 24, 1: 12}[cov_kind]
         pod_bytes = 16 + sh_bytes + cov_bytes
-        n_shaded = (1.0 - spec_frac) * nvis_loc  # a speculated frame's projection pass is geometry only (k_shade does the rest)
-        proj_bytes = n_loc * 16 + nvis_loc * cov_bytes + n_loc * 4 + nvis_loc * 16 + n_loc / 8 + n_shaded * (sh_bytes + 32)
-        survey_bytes = n_loc * pod_bytes + nvis_loc * 40
-        proj_us = allr[0][6] / max(allr[0][7], 1)
-        achieved = proj_bytes / (proj_us * 1e-6) / 1e9 if proj_us > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        variant = "lazy" if spec_frac > 0.5 else "full"
-        if os.path.exists(pmc) and args.pod == "single/single" and not args.render_options:
-            try:
-                rec = json.load(open(pmc)).get(f"{args.workload}:{world}:k_project:{variant}")
-                traffic = rec["hbm_bytes_per_launch"] if rec else None
-            except Exception:
-                traffic = None
+
+        def roofline_of(ac, tm, label_full):
+            """Projection kernel of one timed loop.  ALGORITHMIC bytes per launch (means over the accounting frames):
+            full kernel (every visible Gaussian shaded in the kernel): SURVEY 8d, N*pod + N_vis*40;
+            geometry-only kernel of speculated frames: N*(16 pos+rgba8 + 4 key + 1/8 ballot) + N_vis*(cov + 16 mean/rect) — the
+            SH planes and the conic / colour records are k_shade's, for the few admitted Gaussians."""
+            n_loc, nvis_loc, spec_frac = ac[:, 0].mean(), ac[:, 1].mean(), ac[:, 3].mean()
+            lazy = spec_frac > 0.5
+            if lazy:
+                b = n_loc * 20.125 + nvis_loc * (16 + cov_bytes)
+                kernel = (f"k_project_geom<{cov_kind},1> (projection of a speculated frame: cov2d + cull + depth key + admission; SH colour "
+                          "is evaluated by k_shade for the admitted Gaussians only)")
+                definition = "geometry-only projection: N*20.125 + N_vis*(16+cov)"
+            else:
+                b = n_loc * pod_bytes + nvis_loc * 40
+                kernel = f"k_project<{sh},{sh_kind},{cov_kind}> ({label_full})"
+                definition = f"SURVEY 8d: N*{pod_bytes} + N_vis*40"
+            us = tm["project"]["ms"] * 1e3 / max(tm["project"]["launches"], 1)
+            ach = b / (us * 1e-6) / 1e9 if us > 0 else 0.0
+            tr = (traffic or {}).get("speculated" if lazy else "full")
+            return {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+                    "algorithmic_bytes_per_launch": int(b), "avg_launch_us": round(us, 2), "launches_timed": int(tm["project"]["launches"]),
+                    "bytes_definition": definition, "n": int(n_loc), "n_visible": int(nvis_loc),
+                    "traffic_source": traffic_note if tr else (traffic_note if traffic is None else "no dispatch of this kernel in the PMC passes"),
+                    "traffic_detail": tr}
+
+        n_loc, nvis_loc, nsort_loc, spec_frac, repair_frac, entries = allr[0][:6]
         passes = {}
         for name, tv in timing.items():
             if args.pass_timing == "all" or name == "project":
                 passes[name] = round(tv["ms"] / max(rounds(args.steps), 1), 4)
+        if not use_dist:
+            sharding, scaling = "one GPU", "strong"
+        elif afr:
+            sharding = (f"REPLICATED, frame-parallel x{world}: scene resident on each GPU, rank g renders frame j*{world}+g of the orbit "
+                        "(one-frame latency as on one GPU), RGBA8 frames all-gathered on a second stream")
+            scaling = "weak"   # every GPU holds and renders the whole scene: throughput scales, one frame does not
+        elif args.shard_mode == "index":
+            sharding, scaling = f"splat-index shards x{world}, speculative record exchange by tile-row band + band all-gather", "strong"
+        else:
+            sharding = (f"scene resident on each of {world} GPUs, rank g renders band g of tile rows, band all-gather "
+                        + ("of RGBA8 pixels (resolved per band) on a second stream" if gather == "rgba8" else "of (rgb, T) float4 pixels"))
+            scaling = "strong"
         out = {
-            "metric": "frames/sec @1920x1080, N-Gaussian SH3 scene, 1/2/4/8 MI355X; %HBM roofline",
+            "metric": METRIC,
             "value": round(fps, 3),
             "unit": "frames/s",
             "n_gpus": world,
@@ -244,37 +398,33 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}: synthetic {n} Gaussians SH-deg-{sh}, {w}x{h}, orbit r=6 h=1.5 240 poses, seed {seed}",
+                "workload": f"{args.workload}: synthetic {n} Gaussians SH-deg-{sh}, {w}x{h}, orbit r=6 h=1.5 240 poses"
+                            + (" in seeded random order" if args.pose_order == "random" else "") + f", seed {seed}",
                 "gaussians": n, "width": w, "height": h, "sh_degree": sh, "pod": args.pod, "pod_bytes": pod_bytes,
-                "sharding": ("one GPU" if not use_dist else
-                             f"frame-parallel x{world}: scene resident on each GPU, rank g renders frame j*{world}+g of the orbit "
-                             "(one-frame latency as on one GPU), RGBA8 frames all-gathered on a second stream" if afr else
-                             (f"splat-index shards x{world}, speculative record exchange by tile-row band + band all-gather"
-                              if args.shard_mode == "index" else
-                              f"scene resident on each of {world} GPUs, rank g renders band g of tile rows, band all-gather "
-                              + ("of RGBA8 pixels (resolved per band) on a second stream" if gather == "rgba8" else "of (rgb, T) float4 pixels"))),
+                "sharding": sharding, "schedule": "progressive depth slabs + temporal occlusion speculation (gsx_render_options defaults)"
+                if not overrides else f"overrides: {args.render_options}",
                 "n_visible_rank0": int(nvis_loc), "n_depth_sorted_rank0": int(nsort_loc), "tile_entries_rank0": int(entries),
                 "speculated_frames": round(float(spec_frac), 3), "frames_with_repair_round": round(float(repair_frac), 3),
                 "pass_ms_per_frame_rank0": passes,
                 "upload_GBps_pcie_inclusive": round(upload_gbs, 2), "scene_gen_s": round(t_gen, 1),
             },
-            "roofline": {
-                "kernel": (f"k_project_geom<{cov_kind},1> (projection pass of a speculated frame: cov2d + cull + depth key + admission; "
-                           "SH colour is evaluated by k_shade for the admitted Gaussians only)" if variant == "lazy" else
-                           f"k_project<{sh},{sh_kind},{cov_kind}> (projection pass: SH colour + cov2d + cull + depth key)"),
-                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": int(proj_bytes), "avg_launch_us": round(proj_us, 2),
-                "bytes_definition": ("geometry-only projection of a speculated frame: N*20.125 + N_vis*(16+cov)" if variant == "lazy" else
-                                     "N*20.125 + N_vis*(16+cov+sh+32) (= SURVEY 8d up to bookkeeping)"),
-                "survey_8d_bytes_per_launch": int(survey_bytes),
-            },
+            "overflow_slabs": overflow_slabs,
         }
+        if timing_u is not None:
+            out["value_unspeculated"] = round(args.steps / elapsed_u, 3)
+            out["ms_per_step_unspeculated"] = round(1e3 * elapsed_u / args.steps, 4)
+            out["frame_check"] = frame_check
+            out["roofline"] = roofline_of(acct_u, timing_u, "projection pass: SH colour + cov2d + cull + depth key; measured on the "
+                                          "unspeculated timed loop of this run")
+            out["roofline_speculated"] = roofline_of(acct, timing, "projection pass")
+            out["config"]["tile_entries_unspeculated"] = int(acct_u[:, 5].mean())
+        else:
+            out["roofline"] = roofline_of(acct, timing, "projection pass: SH colour + cov2d + cull + depth key")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample)
         print(json.dumps(out), flush=True)

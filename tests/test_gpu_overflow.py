@@ -98,7 +98,7 @@ def test_overflow_float_frames_bit_identical_and_capacity_grows(monkeypatch):
     v = MultiModelViewer()
     try:
         ref_v.set_render_options(speculative=0, progressive=0)
-        v.set_render_options(speculative=0, progressive=1, min_slab=4096)
+        v.set_render_options(speculative=0, progressive=1, min_slab=16384)  # first slab: 16384 splats x 176 tiles = 2.9 M entries
         for x in (ref_v, v):
             _load(x, g)
         spilled = []
