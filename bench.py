@@ -21,6 +21,10 @@ What one N=1 run measures, all in the same process on the same resident scene (n
                         missing or fails; --no-pmc skips them)
   frame_check           the last timed speculated frame, re-rendered with speculative = 0 and progressive = 0, must be
                         bit-identical; overflow_slabs must be 0 (no frame took the slow pair-free path)
+  robustness            how much of `value` is the coherent orbit over an occluding scene: the same K-frame loops (a) with the
+                        240 poses in a seeded random order — no temporal coherence — and (b) on the scene with an open sky (a
+                        mask box keeps only the Gaussians below y = 0.5: the upper part of the screen never saturates), each
+                        speculated and unspeculated, with the fraction of frames that needed the repair round
   cpu_baseline          oracle/gsx_oracle.c, one frame of the WHOLE scene on all host cores
 """
 from __future__ import annotations
@@ -56,6 +60,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="Gaussians in the CPU baseline (0 = the whole scene)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC child passes (roofline.traffic = null)")
+    ap.add_argument("--no-robustness", action="store_true", help="skip the speculation-robustness legs (random pose order, open sky)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # internal: the run rocprofv3 wraps
     ap.add_argument("--force-dist", action="store_true", help="run the sharded exchange path even at N=1")
     ap.add_argument("--shard-mode", default="index", help="N > 1: index = splat-index shards + speculative record exchange by screen "
@@ -326,6 +331,37 @@ def main():
         viewer.set_render_options(**overrides) if overrides else viewer.set_render_options()
         if not equal:
             raise SystemExit(f"bench.py: the last timed frame differs from the speculative=0, progressive=0 frame: {frame_check}")
+    # ---- N = 1: speculation robustness legs (same process, same resident scene) ----
+    robustness = None
+    if single and not overrides and not args.no_robustness and not args.pose_stride > 1 and args.pose_order == "orbit":
+        from wgpu_3dgs_viewer_app_amd.mask import MaskEvaluator, MaskOp, MaskShape, MaskShapeKind
+
+        def leg():
+            res = {}
+            for name, spec in (("speculated", 1), ("unspeculated", 0)):
+                viewer.set_render_options(speculative=spec)
+                el, _, _ = timed_loop(0)
+                ac = accounting(rounds(args.warmup))
+                res[name] = dict(fps=round(args.steps / el, 1), ms_per_step=round(1e3 * el / args.steps, 4),
+                                 speculated_frames=round(float(ac[:, 3].mean()), 3), frames_with_repair_round=round(float(ac[:, 4].mean()), 3),
+                                 n_visible=int(ac[:, 1].mean()), n_depth_sorted=int(ac[:, 2].mean()), tile_entries=int(ac[:, 5].mean()))
+            viewer.set_render_options()
+            res["speculated_over_unspeculated"] = round(res["speculated"]["fps"] / res["unspeculated"]["fps"], 3)
+            return res
+
+        robustness = {}
+        saved = pose_of[:]
+        pose_of[:] = [int(x) for x in np.random.default_rng(2024).permutation(240)]
+        robustness["random_pose_order"] = leg()
+        pose_of[:] = saved
+        ev = MaskEvaluator(viewer)
+        sky = [MaskShape(MaskShapeKind.Box, pos=np.array([0.0, -4.5, 0.0], np.float32), scale=np.array([10.0, 5.0, 10.0], np.float32))]
+        ev.evaluate(MaskOp.parse("0"), renderer.KEY, sky)
+        robustness["open_sky"] = leg()
+        robustness["open_sky"]["scene"] = "mask box keeps the Gaussians with y <= 0.5 (gsx_mask_evaluate): the screen above the horizon stays open"
+        ev.evaluate(None, renderer.KEY)   # MaskOpTree::Reset
+        robustness["note"] = ("speculated frames are bit-identical to unspeculated ones whatever the poses (tests/test_gpu_speculation.py); "
+                              "the viewer pauses speculation by itself when it keeps repairing without admitting less (gsx_frame.cpp)")
     overflow_slabs = int(max(acct[:, 6].max(), acct_u[:, 6].max() if acct_u is not None else 0))
     if overflow_slabs:
         raise SystemExit(f"bench.py: {overflow_slabs} depth slabs overflowed the tile-pair buffers during the run (slow pair-free path)")
@@ -425,6 +461,8 @@ def main():
             out["config"]["tile_entries_unspeculated"] = int(acct_u[:, 5].mean())
         else:
             out["roofline"] = roofline_of(acct, timing, "projection pass: SH colour + cov2d + cull + depth key")
+        if robustness is not None:
+            out["robustness"] = robustness
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample)
         print(json.dumps(out), flush=True)

@@ -4,7 +4,10 @@ ARGS=$1; shift
 for rep in 1 2 3; do
   for v in "$@"; do
     if [ "$v" = base ]; then unset GSX_LIB; else export GSX_LIB=$PWD/wgpu_3dgs_viewer_app_amd/variants/libgsx_$v.so; fi
-    r=$(python bench.py --no-cpu-baseline $ARGS 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['config'].get('pass_ms_per_frame_rank0',''))")
+    r=$(python bench.py --no-cpu-baseline --no-pmc $ARGS 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('fps', d['value'], 'unspec', d.get('value_unspeculated'), 'project_us', d['roofline']['avg_launch_us'], 'geom_us', d.get('roofline_speculated',{}).get('avg_launch_us'), 'check', d.get('frame_check',{}).get('equal_to_unspeculated_single_pass'))")
     echo "rep $rep $v: $r"
   done
 done

@@ -15,6 +15,19 @@
 #include "project_math.h"
 #include "window_scan.h"
 
+#ifndef GSX_VAR_SH_STREAM
+#define GSX_VAR_SH_STREAM 1
+#endif
+#ifndef GSX_VAR_NT_STORE
+#define GSX_VAR_NT_STORE 1
+#endif
+#ifndef GSX_VAR_FULLW
+#define GSX_VAR_FULLW 1
+#endif
+#ifndef GSX_VAR_PROJ_WAVES
+#define GSX_VAR_PROJ_WAVES 0
+#endif
+
 namespace gsx {
 
 // ------------------------------------------------------------------------------------------------
@@ -305,6 +318,27 @@ __device__ inline uint2 ld_stream(const uint2* p) {
 }
 __device__ inline uint32_t ld_stream(const uint32_t* p) { return __builtin_nontemporal_load(p); }
 
+// Streaming stores of the projection records: written once, 440 MB per frame at 10 M Gaussians, read back sparsely much
+// later.  tools/bench_hbm.hip (14 planes read + 3 written, this pass's shape): 0.500 ms with default stores, 0.462 ms with
+// non-temporal ones — a write costs this part about twice a read, and write-allocating L2 / Infinity Cache lines for data
+// nobody reads soon makes it worse.  And every lane stores (GSX_VAR_FULLW): culled Gaussians write a record nobody reads
+// (key = kCulledKey marks it), so that a wave always writes whole 128-byte lines — with ~15 % of the lanes masked nearly
+// every line was a partial write: k_project<3,0,0> 516 -> 471 us on cfg4 (A/B on one box), at 8 % more bytes written.
+__device__ inline void st_stream(float4* p, float4 v) {
+#if GSX_VAR_NT_STORE
+    __builtin_nontemporal_store(gsx_f4v{v.x, v.y, v.z, v.w}, reinterpret_cast<gsx_f4v*>(p));
+#else
+    *p = v;
+#endif
+}
+__device__ inline void st_stream(uint32_t* p, uint32_t v) {
+#if GSX_VAR_NT_STORE
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // SHK / COVK: storage of the SH and cov3d planes (gsx_sh_kind / gsx_cov3d_kind); dequantisation is exact
 // (f16 -> f32, snorm8 -> f32), so cull set and tile rectangles stay bit-exact against the oracle, which
 // projects the dequantised pod.
@@ -333,8 +367,57 @@ __device__ inline bool load_cov2d_rect(const FrameConsts& f, const PodPlanes& po
 template <int DEG, int SHK, bool AOS>
 __device__ inline void load_shade(const FrameConsts& f, const PodPlanes& pod, uint32_t n, uint32_t i, const float4& pc,
                                   float& r, float& g, float& b) {
-    float s[48];
     constexpr int kFloats = ShNeed<DEG>::floats;
+#if GSX_VAR_SH_STREAM
+    // every SH float is consumed as it arrives (ShStream, project_math.h): same value as pm_color, 45 fewer live registers
+    ShStream<DEG> st;
+    st.begin(f, pc.x, pc.y, pc.z, __float_as_uint(pc.w));
+    if (SHK == GSX_SH_SINGLE) {
+        float4 v[ShNeed<DEG>::planes4 ? ShNeed<DEG>::planes4 : 1];
+        float last = 0.0f;
+#pragma unroll
+        for (int p = 0; p < ShNeed<DEG>::planes4; ++p) {
+            if (AOS) {
+                const uint4 w = pod.sh_aos[(uint64_t)i * pod.aos_stride + p];
+                v[p] = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+            } else {
+                v[p] = ld_stream(&pod.sh4[(uint64_t)p * n + i]);
+            }
+        }
+        if (DEG == 3) last = AOS ? __uint_as_float(pod.sh_aos[(uint64_t)i * pod.aos_stride + 11].x) : ld_stream(&pod.sh1[i]);
+#pragma unroll
+        for (int p = 0; p < ShNeed<DEG>::planes4; ++p) {
+            st.feed(4 * p, v[p].x); st.feed(4 * p + 1, v[p].y); st.feed(4 * p + 2, v[p].z); st.feed(4 * p + 3, v[p].w);
+        }
+        if (DEG == 3) st.feed(44, last);
+    } else if (SHK == GSX_SH_HALF) {
+        constexpr int kP = (kFloats + 7) / 8;
+        uint4 v[kP ? kP : 1];
+#pragma unroll
+        for (int p = 0; p < kP; ++p) v[p] = AOS ? pod.sh_aos[(uint64_t)i * 6 + p] : ld_stream(&pod.sh_h[(uint64_t)p * n + i]);
+#pragma unroll
+        for (int p = 0; p < kP; ++p) {
+            st.feed(8 * p, h_lo(v[p].x)); st.feed(8 * p + 1, h_hi(v[p].x)); st.feed(8 * p + 2, h_lo(v[p].y)); st.feed(8 * p + 3, h_hi(v[p].y));
+            st.feed(8 * p + 4, h_lo(v[p].z)); st.feed(8 * p + 5, h_hi(v[p].z)); st.feed(8 * p + 6, h_lo(v[p].w)); st.feed(8 * p + 7, h_hi(v[p].w));
+        }
+    } else if (SHK == GSX_SH_NORM8) {
+        constexpr int kP = (kFloats + 15) / 16;
+        uint4 v[kP ? kP : 1];
+#pragma unroll
+        for (int p = 0; p < kP; ++p) v[p] = AOS ? pod.sh_aos[(uint64_t)i * 3 + p] : ld_stream(&pod.sh_q[(uint64_t)p * n + i]);
+#pragma unroll
+        for (int p = 0; p < kP; ++p) {
+            const uint32_t w[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) st.feed(16 * p + 4 * k + bb, dq_snorm8(w[k], bb));
+        }
+    }
+    st.finish(r, g, b);
+    return;
+#endif
+    float s[48];
     if (SHK == GSX_SH_SINGLE) {
 #pragma unroll
         for (int p = 0; p < ShNeed<DEG>::planes4; ++p) {
@@ -372,8 +455,13 @@ __device__ inline void load_shade(const FrameConsts& f, const PodPlanes& pod, ui
 // (adm.lazy — geometry only, nobody shaded here: the SH planes, 180 of the pod's 220 bytes, are not read and no conic /
 // colour record is written — is a kernel of its own, k_project_geom below; k_shade then shades the Gaussians the admission
 // let through, a few per cent of the visible ones, and later the few more the repair round turns out to need.)
+#if GSX_VAR_PROJ_WAVES
+#define GSX_PROJ_ATTR __attribute__((amdgpu_waves_per_eu(GSX_VAR_PROJ_WAVES, GSX_VAR_PROJ_WAVES)))
+#else
+#define GSX_PROJ_ATTR
+#endif
 template <int DEG, int SHK, int COVK>
-__global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint32_t n, const PodPlanes pod,
+__global__ __launch_bounds__(256) GSX_PROJ_ATTR void k_project(const FrameConsts f, const uint32_t n, const PodPlanes pod,
                                                   const Records rec, uint32_t* __restrict__ block_visible,
                                                   const ProjectAdmission adm) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -400,11 +488,11 @@ __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint
     if (shade) load_shade<DEG, SHK, false>(f, pod, n, i, pc, r, g, b);  // SH planes: survivors only
 
     if (i < n) {
-        rec.key[i] = vis ? __float_as_uint(vc.d) : kCulledKey;
-        if (vis) rec.a[i] = make_float4(sp.mx, sp.my, __uint_as_float(sp.rx), __uint_as_float(sp.ry));
-        if (shade) {
-            rec.b[i] = make_float4(sp.con_a, sp.con_b, sp.con_c, (float)(color >> 24) * (1.0f / 255.0f));
-            rec.c[i] = make_float4(r, g, b, vc.d);
+        st_stream(&rec.key[i], vis ? __float_as_uint(vc.d) : kCulledKey);
+        if (vis || GSX_VAR_FULLW) st_stream(&rec.a[i], make_float4(sp.mx, sp.my, __uint_as_float(sp.rx), __uint_as_float(sp.ry)));
+        if (shade || GSX_VAR_FULLW) {
+            st_stream(&rec.b[i], make_float4(sp.con_a, sp.con_b, sp.con_c, (float)(color >> 24) * (1.0f / 255.0f)));
+            st_stream(&rec.c[i], make_float4(r, g, b, vc.d));
         }
     }
     __shared__ uint32_t wave_cnt[4], wave_adm[4];
@@ -488,8 +576,8 @@ __global__ __launch_bounds__(256) void k_project_geom(const FrameConsts f, const
     for (int k = 0; k < PER; ++k) {
         const uint32_t i = base + 256u * k;
         if (i < n) {
-            rec.key[i] = vis[k] ? __float_as_uint(vc[k].d) : kCulledKey;
-            if (vis[k]) rec.a[i] = make_float4(sp[k].mx, sp[k].my, __uint_as_float(sp[k].rx), __uint_as_float(sp[k].ry));
+            st_stream(&rec.key[i], vis[k] ? __float_as_uint(vc[k].d) : kCulledKey);
+            if (vis[k] || GSX_VAR_FULLW) st_stream(&rec.a[i], make_float4(sp[k].mx, sp[k].my, __uint_as_float(sp[k].rx), __uint_as_float(sp[k].ry)));
         }
         const unsigned long long bal = __ballot(vis[k]);
         const unsigned long long bal_adm = __ballot(take[k]);

@@ -148,6 +148,88 @@ __device__ inline void pm_color(const FrameConsts& f, float x_, float y_, float 
     b = fmaxf(b, 0.0f);
 }
 
+// The same colour, evaluated as the SH floats ARRIVE (one float4 plane at a time) instead of from an array of 45: the 15 basis
+// factors come first (they need only the position), every loaded float is consumed by one multiply-add, and nothing but the
+// loads still in flight occupies registers (pm_color keeps all 45 floats live: 84 VGPRs, 5 waves per SIMD).  Bit-identical to
+// pm_color by construction: per channel the spec's expression is three left-to-right chains — degree 1, then "v += (degree-2
+// terms)", then "v += (degree-3 terms)" — and each term is ((constant * polynomial) * s), so a chain per degree fed in
+// coefficient order, joined at the end, performs the same float32 operations in the same order.
+template <int DEG> struct ShStream {
+    float basis[15];
+    float g1[3], g2[3], g3[3];
+    float dc[3];
+
+    __device__ inline void begin(const FrameConsts& f, float x_, float y_, float z_, uint32_t color) {
+        constexpr float C1 = 0.4886025119029199f;
+        constexpr float C2_0 = 1.0925484305920792f, C2_1 = -1.0925484305920792f, C2_2 = 0.31539156525252005f,
+                        C2_3 = -1.0925484305920792f, C2_4 = 0.5462742152960396f;
+        constexpr float C3_0 = -0.5900435899266435f, C3_1 = 2.890611442640554f, C3_2 = -0.4570457994644658f,
+                        C3_3 = 0.3731763325901154f, C3_4 = -0.4570457994644658f, C3_5 = 1.445305721320277f,
+                        C3_6 = -0.5900435899266435f;
+        dc[0] = dc[1] = dc[2] = 0.0f;
+        if (!f.no_sh0) {
+            dc[0] = (float)(color & 255u) * (1.0f / 255.0f);
+            dc[1] = (float)((color >> 8) & 255u) * (1.0f / 255.0f);
+            dc[2] = (float)((color >> 16) & 255u) * (1.0f / 255.0f);
+        }
+        if (DEG > 0) {
+            float dx = f.s_m[0] * x_ - f.cam_m[0];
+            float dy = f.s_m[1] * y_ - f.cam_m[1];
+            float dz = f.s_m[2] * z_ - f.cam_m[2];
+            float len = sqrtf((dx * dx + dy * dy) + dz * dz);
+            float il = 1.0f / len;
+            float x = dx * il, y = dy * il, z = dz * il;
+            basis[0] = -C1 * y;
+            basis[1] = C1 * z;
+            basis[2] = -(C1 * x);  // "- C1 * x * s": a - b*s == a + (-b)*s exactly
+            if (DEG > 1) {
+                float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                basis[3] = C2_0 * xy;
+                basis[4] = C2_1 * yz;
+                basis[5] = C2_2 * (2.0f * zz - xx - yy);
+                basis[6] = C2_3 * xz;
+                basis[7] = C2_4 * (xx - yy);
+                if (DEG > 2) {
+                    basis[8] = C3_0 * y * (3.0f * xx - yy);
+                    basis[9] = C3_1 * xy * z;
+                    basis[10] = C3_2 * y * (4.0f * zz - xx - yy);
+                    basis[11] = C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                    basis[12] = C3_4 * x * (4.0f * zz - xx - yy);
+                    basis[13] = C3_5 * z * (xx - yy);
+                    basis[14] = C3_6 * x * (xx - 3.0f * yy);
+                }
+            }
+        }
+    }
+    // SH float F (= 3 * coefficient + channel; a compile-time constant once the caller's loops are unrolled) has arrived
+    __device__ __forceinline__ void feed(const int F, float s) {
+        const int c = F / 3, ch = F % 3;
+        if (c >= (DEG == 1 ? 3 : (DEG == 2 ? 8 : 15))) return;
+        const float t = basis[c] * s;
+        if (c == 0) g1[ch] = t;
+        else if (c < 3) g1[ch] = g1[ch] + t;
+        else if (c == 3) g2[ch] = t;
+        else if (c < 8) g2[ch] = g2[ch] + t;
+        else if (c == 8) g3[ch] = t;
+        else g3[ch] = g3[ch] + t;
+    }
+    __device__ inline void finish(float& r, float& g, float& b) const {
+        float o[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float v = dc[ch];
+            if (DEG > 0) {
+                float a = g1[ch];
+                if (DEG > 1) a += g2[ch];
+                if (DEG > 2) a += g3[ch];
+                v += a;
+            }
+            o[ch] = fmaxf(v, 0.0f);
+        }
+        r = o[0]; g = o[1]; b = o[2];
+    }
+};
+
 // number of SH floats / float4 planes needed for a degree
 template <int DEG> struct ShNeed {
     static constexpr int floats = DEG == 0 ? 0 : (DEG == 1 ? 9 : (DEG == 2 ? 24 : 45));
