@@ -161,6 +161,10 @@ def pmc_traffic(args):
 
 def main():
     args = parse_args()
+    # stdout carries ONE JSON line and nothing else: libraries that print banners on fd 1 (RCCL's version block) go to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -202,7 +206,8 @@ def main():
     afr = use_dist and args.shard_mode == "frames"   # frame-parallel: a step is still ONE frame of the orbit; N ranks render N per round
     gather = "rgba8" if afr else (args.gather if (use_dist and args.shard_mode == "screen") else "float")
     renderer = parallel.ShardedViewer(device=local_rank, world=world, rank=rank, use_dist=use_dist, sh=sh_kind, cov3d=cov_kind,
-                                      mode=args.shard_mode if use_dist else "index", gather=gather, overlap_gather=gather == "rgba8")
+                                      mode=args.shard_mode if use_dist else "index", gather=gather, overlap_gather=gather == "rgba8",
+                                      comm="lib" if (use_dist and args.shard_mode == "index") else None)  # index mode: collectives inside libgsx (RCCL)
     viewer = renderer.stages.viewer
     overrides = {k: float(x) if "." in x else int(x) for k, x in (kv.split("=") for kv in args.render_options.split(","))} if args.render_options else {}
     if overrides:
@@ -420,7 +425,10 @@ def main():
                         "(one-frame latency as on one GPU), RGBA8 frames all-gathered on a second stream")
             scaling = "weak"   # every GPU holds and renders the whole scene: throughput scales, one frame does not
         elif args.shard_mode == "index":
-            sharding, scaling = f"splat-index shards x{world}, speculative record exchange by tile-row band + band all-gather", "strong"
+            sharding = (f"splat-index shards x{world}: gsx_shard_render_frame — projection of the resident shard, speculative exchange of "
+                        "fixed record slots by tile-row band (RCCL point-to-point inside libgsx, counts on the device), verification + "
+                        "repair round, in-place all-gather of the bands; no host round trip inside a frame")
+            scaling = "strong"
         else:
             sharding = (f"scene resident on each of {world} GPUs, rank g renders band g of tile rows, band all-gather "
                         + ("of RGBA8 pixels (resolved per band) on a second stream" if gather == "rgba8" else "of (rgb, T) float4 pixels"))
@@ -465,7 +473,8 @@ def main():
             out["robustness"] = robustness
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
     renderer.close()
     if use_dist:

@@ -368,6 +368,71 @@ gsx_status gsx_shard_feedback(gsx_viewer* v, const char* key, uint32_t world, ui
 /* Second round of the same frame: like gsx_render but continues from the framebuffer / saturated-tile state. */
 gsx_status gsx_render_more(gsx_viewer* v, const char* const* keys, uint32_t n_keys);
 
+/* ---- multi-GPU, device-resident protocol.  Windows, verification, the repair round's windows, next frame's limits and every
+ *      record count stay on the device; the exchange moves fixed-size SLOTS whose headers carry the counts (buffer of a round
+ *      = `world` slots of (1 + T) records of GSX_RECORD_BYTES; record 0 of slot g = {u32 records the sender had for g, u32
+ *      records sent = min(that, T)}); the host waits for ONE thing per frame, the verdict of round 0 — two words in pinned
+ *      memory that the verification kernel derives from globally gathered data, so that every rank reads the same verdict
+ *      and takes the same decision.  Per frame and rank (gsx_shard_render_frame is exactly this sequence over RCCL;
+ *      wgpu_3dgs_viewer_app_amd/parallel.py runs the same stage calls with an injectable transport so that the tests can
+ *      put `world` ranks on one GPU, or on CPU over gloo):
+ *        gsx_shard_frame_begin(key, world, rank, speculate, NULL)      windows [0, limit) from last frame's limits -> projection
+ *        gsx_shard_slot_records(key, world, max_shard, &T)             round-0 slot size (2x what the last verdict reported)
+ *        gsx_shard_pack_slots(key, world, 0, d_send, T)
+ *        all-to-all of the slots, (1 + T) * 48 bytes per peer          gsx_comm_all_to_all
+ *        gsx_shard_import_slots(key, d_recv, world, rank, 0, T)        import + depth sort + render this rank's band
+ *        gsx_shard_feedback(key, world, rank, d_band) + all-gather     saturation depth key of every tile + slot statistics
+ *        gsx_shard_verify(key, world, d_sat_all, &seq)                 repair windows on the device; posts the verdict
+ *        gsx_shard_next_windows(..) ; all-gather of the bands          enqueued before the wait: what follows when all is well
+ *        gsx_shard_wait_verdict(key, seq, &verdict)
+ *          verdict.overflow: round 0 once more with T = max_shard (always fits), verify + wait again
+ *          verdict.need_tiles > 0: gsx_shard_repair_count(d_4words) + all-gather + gsx_shard_post_counts(&seq) + wait -> T1
+ *                                  (exact); pack_slots(.., 1, T1) -> all-to-all -> import_slots(.., 1, T1) -> feedback +
+ *                                  all-gather -> next_windows + the band all-gather again (they replace the early ones)
+ *        gsx_shard_frame_end(key)                                      the limits computed last become the next frame's
+ *      Whatever the verdict, the frame that leaves the GPU is complete and equals the single-GPU frame bit for bit. ---- */
+typedef struct gsx_shard_verdict {
+    uint32_t need_tiles;   /* tiles of the frame with a bounded window that are still open (0 after gsx_shard_post_counts) */
+    uint32_t overflow;     /* some rank had more records for a destination than the slot held: round 0 must be redone */
+    uint32_t max_records;  /* records the busiest (rank, destination) pair wanted: next frame's slot hint / the repair round's T */
+    uint32_t reserved;
+} gsx_shard_verdict;
+gsx_status gsx_shard_frame_begin(gsx_viewer* v, const char* key, uint32_t world, uint32_t rank, uint32_t speculate,
+                                 const uint32_t* d_limit_override /* nullable: device u32 per tile, replaces the limits the last frame left */);
+/* shard_records_max: the size of the model's LARGEST shard over all ranks (the caller's partition; ceil(N / world) for equal
+ * shards).  Every rank gets the same answer: the policy uses only that and the last verdict's global figure. */
+gsx_status gsx_shard_slot_records(gsx_viewer* v, const char* key, uint32_t world, uint32_t shard_records_max, uint32_t* out_records);
+gsx_status gsx_shard_pack_slots(gsx_viewer* v, const char* key, uint32_t world, uint32_t round, void* d_send, uint32_t slot_records);
+gsx_status gsx_shard_import_slots(gsx_viewer* v, const char* key, const void* d_recv, uint32_t world, uint32_t rank, uint32_t round,
+                                  uint32_t slot_records);
+/* d_sat_all: the all-gathered gsx_shard_feedback bands: per rank gsx_shard_feedback_words() words = its band of saturation keys
+ * (rows_per_rank tile rows) followed by 4 statistics words {records wanted for its busiest destination, slot overflowed, 0, 0} */
+gsx_status gsx_shard_verify(gsx_viewer* v, const char* key, uint32_t world, const void* d_sat_all, uint32_t* out_seq);
+gsx_status gsx_shard_wait_verdict(gsx_viewer* v, const char* key, uint32_t seq, gsx_shard_verdict* out);
+/* repair round sizing: d_out4 (device, 4 u32) = {records this rank has for its busiest destination under the repair windows, 0,0,0};
+ * all-gather those (16 bytes per rank), then gsx_shard_post_counts posts the global maximum as a verdict (max_records) */
+gsx_status gsx_shard_repair_count(gsx_viewer* v, const char* key, uint32_t world, void* d_out4);
+gsx_status gsx_shard_post_counts(gsx_viewer* v, uint32_t world, const void* d_counts_all, uint32_t* out_seq);
+gsx_status gsx_shard_next_windows(gsx_viewer* v, const char* key, uint32_t world, const void* d_sat_all, float margin, uint32_t radius);
+gsx_status gsx_shard_frame_end(gsx_viewer* v, const char* key);
+/* parity / introspection: the per-tile limits the next frame will use (u32 per tile; 0xFFFFFFFF = unbounded). Synchronises. */
+gsx_status gsx_shard_download_limits(gsx_viewer* v, const char* key, uint32_t* limits, uint64_t n_words);
+
+/* ---- the collectives, inside the library over RCCL (xGMI): one communicator per viewer, enqueued on the viewer's stream.
+ *      RCCL is loaded at run time; missing / failing RCCL -> GSX_ERR_RCCL.  Bootstrap like any NCCL program: one rank calls
+ *      gsx_comm_unique_id, the 128 bytes reach the other ranks by the host's own means, every rank calls gsx_viewer_comm_init
+ *      (collective: returns when all `world` ranks have joined). ---- */
+gsx_status gsx_comm_unique_id(uint8_t out_id[128]);
+gsx_status gsx_viewer_comm_init(gsx_viewer* v, uint32_t world, uint32_t rank, const uint8_t id[128]);
+gsx_status gsx_viewer_comm_destroy(gsx_viewer* v);
+/* slot p of d_send goes to rank p, slot p of d_recv comes from rank p (grouped point-to-point: all xGMI links at once) */
+gsx_status gsx_comm_all_to_all(gsx_viewer* v, const void* d_send, void* d_recv, uint64_t bytes_per_peer);
+/* d_recv = world * bytes_per_rank; in place when d_send == d_recv + rank * bytes_per_rank */
+gsx_status gsx_comm_all_gather(gsx_viewer* v, const void* d_send, void* d_recv, uint64_t bytes_per_rank);
+/* One whole index-sharded frame of model `key` on this rank (needs gsx_viewer_comm_init): the sequence above, into a padded
+ * framebuffer the library owns; after gsx_sync, gsx_download_framebuffer returns the complete frame on every rank. */
+gsx_status gsx_shard_render_frame(gsx_viewer* v, const char* key, uint32_t shard_records_max, uint32_t speculate, float margin, uint32_t radius);
+
 /* ---- PLY I/O (host side; no GPU needed).  gs::Gaussians::read_ply_header / PlyHeader::count /
  *      read_ply_gaussians + gs::Gaussian::from(PlyGaussianPod) (app.rs:1053-1096) and write_ply (app.rs:897-947).
  *      INRIA 3DGS vertex: x y z nx ny nz f_dc_0..2 f_rest_0..44 opacity scale_0..2 rot_0..3 (62 f32, 248 B;

@@ -91,6 +91,24 @@ class ThreadComm:
         self._sync(recv)
         h.barrier.wait()
 
+    def all_to_all_slots(self, recv, send):
+        """Fixed-size slots [world, 1 + T, 12]: slot p of `send` goes to rank p.  ``bytes_sent`` counts the PAYLOAD the
+        headers announce (word 1 of a slot's first record = records sent), not the slot size."""
+        import numpy as np
+
+        h = self.hub
+        self._sync(send)
+        h.slots[self.rank] = send
+        sent = send[:, 0, 1].cpu().numpy().view(np.uint32)
+        self.bytes_sent += int(sum(int(c) for g, c in enumerate(sent) if g != self.rank)) * send.shape[2] * 4
+        h.barrier.wait()
+        for src in range(h.world):
+            s = h.slots[src]
+            assert s.shape == send.shape, f"rank {src} sized its slots {tuple(s.shape)}, rank {self.rank} {tuple(send.shape)}"
+            recv[src].copy_(s[self.rank])
+        self._sync(recv)
+        h.barrier.wait()
+
     def all_gather(self, out, inp):
         h = self.hub
         self._sync(inp)

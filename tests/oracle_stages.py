@@ -128,7 +128,110 @@ class OracleStages:
                                n_tile_entries=int(self._imp[k]["lst"].size)) for k in keys}
 
     def stats(self, key):
-        return self._stats[key]
+        return dict(self._stats[key], n_repair_tiles=getattr(self, "_need_count", 0))
+
+    # ---- device-resident protocol of the product (include/gsx.h), restated on the host: fixed slots whose headers carry
+    #      the counts, windows / verification / next limits kept by the stage backend ----
+    EXTRA = 4  # statistics words behind every rank's band of saturation keys
+
+    def frame_begin(self, key, world, rank, speculate=True, limit=None):
+        from wgpu_3dgs_viewer_app_amd import parallel
+
+        f = self.frame
+        if limit is not None:
+            self._limit = np.array(limit, np.uint32)
+        lim = getattr(self, "_limit", None)
+        self._limited = bool(speculate and lim is not None and lim.shape == (f.tiles_y, f.tiles_x))
+        self._win1 = parallel.windows_first(lim) if self._limited else None
+        self._win2 = np.zeros((f.tiles_y, f.tiles_x, 2), np.uint32)
+        self._prs[key] = self._project(key)
+        self._world, self._rank = world, rank
+        self._slot_max, self._slot_over = [0, 0], [0, 0]
+        self._need_count = 0
+
+    def slot_records(self, key, world, shard_max):
+        return int(shard_max)   # no adaptive policy here: the safe size, identical on every rank
+
+    def pack_slots(self, key, world, rnd, slot):
+        window = self._win1 if rnd == 0 else self._win2
+        send, counts = pack_by_destination(self._prs[key], world, self.frame.tiles_x, self.frame.tiles_y, window)
+        out = np.zeros((world, slot + 1, 12), np.float32)
+        o = 0
+        for g, c in enumerate(counts):
+            sent = min(c, slot)
+            out[g, 0, 0:2] = np.array([c, sent], np.uint32).view(np.float32)
+            out[g, 1:1 + sent] = send[o:o + sent]
+            o += c
+        self._slot_max[rnd] = max(counts) if counts else 0
+        self._slot_over[rnd] = int(self._slot_max[rnd] > slot)
+        return torch.from_numpy(out)
+
+    def alloc_slots(self, world, slot, rnd):
+        return torch.zeros((world, slot + 1, 12), dtype=torch.float32)
+
+    def import_slots(self, key, recv, world, rank, rnd, slot):
+        r = recv.numpy()
+        parts = []
+        for s in range(world):
+            sent = int(r[s, 0, 1:2].view(np.uint32)[0])
+            parts.append(r[s, 1:1 + sent])
+        recs = np.ascontiguousarray(np.concatenate(parts)) if parts else np.zeros((0, 12), np.float32)
+        window = self._win1 if rnd == 0 else self._win2
+        self._world, self._rank = world, rank
+        self._imp[key] = self._lists(key, projection_from_records(recs), window)
+        self._composite([key], world, rank, more=(rnd == 1))
+
+    def alloc_sat(self, world, mine):
+        return torch.zeros(world * mine.numel(), dtype=torch.int32)
+
+    def _sat_map(self, sat_all, world):
+        f = self.frame
+        rpr = (f.tiles_y + world - 1) // world
+        a = sat_all.numpy().view(np.uint32).reshape(world, rpr * f.tiles_x + self.EXTRA)
+        return a[:, : rpr * f.tiles_x].reshape(world * rpr, f.tiles_x)[: f.tiles_y], a[:, rpr * f.tiles_x:]
+
+    def verify(self, key, world, sat_all):
+        from wgpu_3dgs_viewer_app_amd import parallel
+
+        sat, extra = self._sat_map(sat_all, world)
+        if self._limited:
+            need = (self._limit < parallel.KEY_ALL) & (sat == 0)
+            self._win2 = parallel.windows_second(self._limit, need)
+            self._need_count = int(need.sum())
+        else:
+            self._win2 = np.zeros(sat.shape + (2,), np.uint32)
+            self._need_count = 0
+        self._seq = getattr(self, "_seq", 0) + 1
+        self._verdicts = getattr(self, "_verdicts", {})
+        self._verdicts[self._seq] = dict(need_tiles=self._need_count, overflow=bool(extra[:, 1].any()), max_records=int(extra[:, 0].max()))
+        return self._seq
+
+    def wait_verdict(self, key, seq):
+        return self._verdicts.pop(seq)
+
+    def repair_count(self, key, world):
+        _, counts = pack_by_destination(self._prs[key], world, self.frame.tiles_x, self.frame.tiles_y, self._win2)
+        return torch.tensor([max(counts) if counts else 0, 0, 0, 0], dtype=torch.int32)
+
+    def alloc_counts(self, world):
+        return torch.zeros(4 * world, dtype=torch.int32)
+
+    def post_counts(self, world, counts_all):
+        self._seq = getattr(self, "_seq", 0) + 1
+        self._verdicts[self._seq] = dict(need_tiles=0, overflow=False, max_records=int(counts_all.numpy().reshape(world, 4)[:, 0].max()))
+        return self._seq
+
+    def next_windows(self, key, world, sat_all, margin, radius):
+        from wgpu_3dgs_viewer_app_amd import parallel
+
+        sat, _ = self._sat_map(sat_all, world)
+        self._limit_next = parallel.next_limits(sat, margin, radius)
+
+    def frame_end(self, key):
+        self._limit = self._limit_next
+
+    def limits(self, key):
+        return self._limit
 
     def _project(self, key):
         pos, color, sh, cov = self.pods[key]
@@ -185,7 +288,9 @@ class OracleStages:
                 tile = self._fb[ty * 16: ty * 16 + 16, tx * 16: tx * 16 + 16, 3]
                 if tile.size and bool((tile < 1e-4).all()):
                     out[ty - lo, tx] = max(int(self._deepest[ty, tx]), 1)
-        return torch.from_numpy(out.view(np.int32).reshape(-1).copy())
+        extra = np.zeros(self.EXTRA, np.uint32)
+        extra[0], extra[1] = getattr(self, "_slot_max", [0, 0])[0], getattr(self, "_slot_over", [0, 0])[0]
+        return torch.from_numpy(np.concatenate([out.reshape(-1), extra]).view(np.int32).copy())
 
     def own_band(self):
         w, h = self.size

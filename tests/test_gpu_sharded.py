@@ -38,7 +38,7 @@ def _single_frames(g):
 
 
 @pytest.mark.parametrize("world,mode", [(2, "off"), (3, "natural"), (8, "natural"), (2, "all_saturated"), (5, "all_open"),
-                                        (4, "stale")])
+                                        (4, "stale"), (3, "tiny_slots")])
 def test_threaded_world_matches_single_viewer(world, mode):
     g = _scene()
     ref = _single_frames(g)
@@ -61,7 +61,11 @@ def test_threaded_world_matches_single_viewer(world, mode):
                 v._limit = np.where(rng.random(tiles) < 0.33, np.uint32(KEY_ALL), lim).astype(np.uint32)
             elif mode == "off":
                 v.speculate = False
+            elif mode == "tiny_slots":   # round 0's slots hold 64 records: the verdict reports the overflow, round 0 is redone
+                v.force_slot = 64
             v.render_frame(camera.orbit_pose(pose), (W, H))
+            if mode == "tiny_slots":
+                assert v.last_verdict["overflow"] is False and v.last_verdict["max_records"] > 64
             v.poll()
             frames.append(v.framebuffer().copy())
             rounds.append(v.rounds)
@@ -383,3 +387,62 @@ def test_full_size_sharded_frames(mode, world):
     for rank, (bad, rounds) in enumerate(res):
         assert not bad, f"{mode} rank {rank}: frames differ from the single-GPU frames: {bad}"
     print(mode, "rounds", res[0][1])
+
+
+def test_library_transport_world1_over_rccl():
+    """The product transport: the collectives inside libgsx over RCCL (gsx_viewer_comm_init, gsx_comm_all_to_all /
+    _all_gather) and the whole frame as ONE library call (gsx_shard_render_frame).  A 1-GPU box has one rank, which is enough
+    to run every code path of the protocol for real — slots, headers, device-side counts, verification, repair round,
+    next limits, the in-place band gather — through RCCL's own send / recv / all-gather.  Frames must equal the single
+    viewer's bit for bit, with the library call and with the stage calls driven from Python over the same communicator."""
+    g = _scene()
+    ref = _single_frames(g)
+    tiles = ((H + 15) // 16, (W + 15) // 16)
+    for drive in ("library", "stages", "stages_refusing"):
+        v = parallel.ShardedViewer(world=1, rank=0, use_dist=True, comm="lib")
+        assert isinstance(v.comm, parallel.LibComm)
+        v.load_shard(g, 0, N)
+        rounds = []
+        for k, pose in enumerate(POSES):
+            if drive == "stages":
+                v.profile = {}          # the per-section profiler takes the Python-driven path over the same transport
+            if drive == "stages_refusing":
+                v._limit = np.full(tiles, 0x40400000, np.uint32)   # every tile refuses all but the nearest records: repair round
+            v.render_frame(camera.orbit_pose(pose), (W, H))
+            v.poll()
+            fb = v.framebuffer()
+            assert np.array_equal(fb, ref[k][0]), f"{drive}: frame {k} differs, L-inf {np.abs(fb - ref[k][0]).max()}"
+            rounds.append(v.rounds)
+        if drive == "stages_refusing":
+            assert rounds == [2] * len(POSES)
+        else:
+            assert rounds[0] == 1
+        lim = v.stages.limits(v.KEY)
+        assert lim.shape == tiles and (lim >= 1).all()
+        v.close()
+
+
+def test_verdict_reports_a_slot_that_was_too_small():
+    """Stage level: a slot smaller than what the rank has for a destination -> the header says so, the verdict's overflow
+    flag is set and max_records is what was wanted (ShardedViewer / gsx_shard_render_frame then redo round 0 with the
+    whole-shard slot size: test_threaded_world_matches_single_viewer[tiny_slots])."""
+    import torch
+
+    g = _scene()
+    st = HipStages(use_torch=True)
+    st.load_shard("shard", g, 0, N)
+    st.set_uniforms("shard", camera.orbit_pose(57), (W, H))
+    with st.stream_ctx():
+        st.frame_begin("shard", 1, 0, True, None)
+        assert st.slot_records("shard", 1, N) == N          # no windows, no history: the whole-shard size
+        send = st.pack_slots("shard", 1, 0, 64)              # 64 records where thousands are visible
+        st.import_slots("shard", send, 1, 0, 0, 64)
+        mine = st.feedback("shard", 1, 0)
+        seq = st.verify("shard", 1, mine)
+        verdict = st.wait_verdict("shard", seq)
+        hdr = send[0, 0, :2].cpu().numpy().view(np.uint32)
+    assert hdr[0] > 64 and hdr[1] == 64
+    assert verdict["overflow"] and verdict["max_records"] == int(hdr[0]) and verdict["need_tiles"] == 0
+    st.poll()
+    st.close()
+    torch.cuda.synchronize()

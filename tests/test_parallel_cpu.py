@@ -43,7 +43,11 @@ def _worker(rank, world, port, out_path, mode):
                 v._limit = np.full(tiles, parallel.KEY_ALL, np.uint32)
             elif mode == "off":
                 v.speculate = False
+            elif mode == "tiny_slots":       # round 0's slots hold 40 records: the verdict reports the overflow, round 0 is redone
+                v.force_slot = 40
             v.render_frame(camera.orbit_pose(pose), (W, H))
+            if mode == "tiny_slots":
+                assert v.last_verdict["overflow"] is False and v.last_verdict["max_records"] > 40
             rounds.append(v.rounds)
             if rank == 0:
                 frames.append(v.framebuffer())
@@ -69,7 +73,7 @@ def _single_frames():
     return np.stack(out)
 
 
-@pytest.mark.parametrize("world,mode", [(2, "off"), (3, "natural"), (2, "all_saturated"), (3, "all_open"), (2, "natural")])
+@pytest.mark.parametrize("world,mode", [(2, "off"), (3, "natural"), (2, "all_saturated"), (3, "all_open"), (2, "natural"), (2, "tiny_slots")])
 def test_sharded_frames_equal_single_process(world, mode, tmp_path):
     """Index shards + band routing + (speculative) exchange + band gather reproduce the single-process oracle frames,
     whatever the prediction: off = one full exchange; natural = frame k uses frame k-1's feedback; all_saturated forces

@@ -21,5 +21,5 @@ for f in $(grep '^SRCS' $SRC/Makefile | cut -d= -f2); do
   objs="$objs $o"
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/wgpu_3dgs_viewer_app_amd/variants/libgsx_$NAME.so $objs
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/wgpu_3dgs_viewer_app_amd/variants/libgsx_$NAME.so $objs -ldl
 echo built $ROOT/wgpu_3dgs_viewer_app_amd/variants/libgsx_$NAME.so

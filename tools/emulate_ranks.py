@@ -22,7 +22,7 @@ ap.add_argument("--first", type=int, default=0, help="first orbit pose")
 ap.add_argument("--workload", default="cfg4")
 ap.add_argument("--no-speculate", action="store_true")
 ap.add_argument("--mode", default="index", help="index | screen | frames")
-ap.add_argument("--margin", type=float, default=0.5)
+ap.add_argument("--margin", type=float, default=0.25)
 ap.add_argument("--radius", type=int, default=3)
 args = ap.parse_args()
 n, sh, w, h, seed = scene.CONFIGS[args.workload]
@@ -38,7 +38,6 @@ def rank_main(rank, comm):
     v.speculate = not args.no_speculate
     v.margin = args.margin
     v.radius = args.radius
-    v.debug = rank == 0
     if args.mode in ("screen", "frames"):
         v.load_shard(whole, 0, n)
     else:
@@ -58,9 +57,6 @@ def rank_main(rank, comm):
             sent.append(comm.bytes_sent - b0)
     t = v.get_pass_timing()
     stats = v.last_stats()
-    if rank == 0:
-        for d in v.debug_log:
-            print("need", d)
     v.close()
     return dict(rank=rank, rounds=rounds, sent_MB=float(np.mean(sent)) / 1e6, sent_max_MB=float(np.max(sent)) / 1e6,
                 pass_ms={k: round(x["ms"] / args.frames, 4) for k, x in t.items()}, stats=stats)

@@ -28,6 +28,10 @@ EXPORTS = (
     "gsx_model_download_tile_lists", "gsx_model_download_pod", "gsx_set_pass_timing", "gsx_get_pass_timing",
     "gsx_mask_evaluate", "gsx_ply_read_header", "gsx_ply_read_gaussians", "gsx_ply_write", "gsx_render_options_default", "gsx_viewer_set_render_options", "gsx_shard_layout", "gsx_viewer_set_external_framebuffer", "gsx_shard_pack", "gsx_shard_import", "gsx_shard_feedback_words", "gsx_shard_feedback", "gsx_shard_set_windows", "gsx_viewer_set_band", "gsx_resolve_rgba8_device",
     "gsx_render_more", "gsx_debug_set_radix_rank_mode",
+    "gsx_shard_frame_begin", "gsx_shard_slot_records", "gsx_shard_pack_slots", "gsx_shard_import_slots", "gsx_shard_verify",
+    "gsx_shard_wait_verdict", "gsx_shard_repair_count", "gsx_shard_post_counts", "gsx_shard_frame_end",
+    "gsx_shard_next_windows", "gsx_shard_download_limits", "gsx_comm_unique_id", "gsx_viewer_comm_init", "gsx_viewer_comm_destroy",
+    "gsx_comm_all_to_all", "gsx_comm_all_gather", "gsx_shard_render_frame",
     "gsx_gaussian_edit_default", "gsx_update_query", "gsx_update_query_texture", "gsx_update_selection_highlight",
     "gsx_update_selection_edit", "gsx_model_show_unedited", "gsx_postprocess", "gsx_model_upload_selection",
     "gsx_model_download_selection", "gsx_model_download_edits", "gsx_model_upload_edits", "gsx_query_download_hits",
@@ -75,6 +79,11 @@ class ViewerDesc(C.Structure):
 class FrameStats(C.Structure):
     _fields_ = [("n_gaussians", C.c_uint64), ("n_visible", C.c_uint64), ("n_tile_entries", C.c_uint64), ("n_sorted", C.c_uint64),
                 ("n_repair_tiles", C.c_uint64), ("n_repair_sorted", C.c_uint64), ("speculated", C.c_uint32), ("overflow_slabs", C.c_uint32)]
+
+
+class ShardVerdict(C.Structure):
+    """``gsx_shard_verdict``."""
+    _fields_ = [("need_tiles", C.c_uint32), ("overflow", C.c_uint32), ("max_records", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class GsxError(RuntimeError):
@@ -160,6 +169,23 @@ def load() -> C.CDLL:
         "gsx_shard_feedback": ([vp, cp, u32, u32, vp], C.c_int32),
         "gsx_render_more": ([vp, C.POINTER(cp), u32], C.c_int32),
         "gsx_debug_set_radix_rank_mode": ([C.c_int32], None),
+        "gsx_shard_frame_begin": ([vp, cp, u32, u32, u32, vp], C.c_int32),
+        "gsx_shard_slot_records": ([vp, cp, u32, u32, C.POINTER(u32)], C.c_int32),
+        "gsx_shard_wait_verdict": ([vp, cp, u32, C.POINTER(ShardVerdict)], C.c_int32),
+        "gsx_shard_repair_count": ([vp, cp, u32, vp], C.c_int32),
+        "gsx_shard_post_counts": ([vp, u32, vp, C.POINTER(u32)], C.c_int32),
+        "gsx_shard_frame_end": ([vp, cp], C.c_int32),
+        "gsx_shard_pack_slots": ([vp, cp, u32, u32, vp, u32], C.c_int32),
+        "gsx_shard_import_slots": ([vp, cp, vp, u32, u32, u32, u32], C.c_int32),
+        "gsx_shard_verify": ([vp, cp, u32, vp, C.POINTER(u32)], C.c_int32),
+        "gsx_shard_next_windows": ([vp, cp, u32, vp, C.c_float, u32], C.c_int32),
+        "gsx_shard_download_limits": ([vp, cp, u32p, u64], C.c_int32),
+        "gsx_comm_unique_id": ([vp], C.c_int32),
+        "gsx_viewer_comm_init": ([vp, u32, u32, vp], C.c_int32),
+        "gsx_viewer_comm_destroy": ([vp], C.c_int32),
+        "gsx_comm_all_to_all": ([vp, vp, vp, u64], C.c_int32),
+        "gsx_comm_all_gather": ([vp, vp, vp, u64], C.c_int32),
+        "gsx_shard_render_frame": ([vp, cp, u32, u32, C.c_float, u32], C.c_int32),
         "gsx_set_pass_timing": ([vp, u32], C.c_int32),
         "gsx_get_pass_timing": ([vp, f32p, u32p], C.c_int32),
     }

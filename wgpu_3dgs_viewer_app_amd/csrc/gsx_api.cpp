@@ -61,6 +61,8 @@ void gsx_viewer_destroy(gsx_viewer* v) {
     if (!v) return;
     (void)hipSetDevice(v->device);
     (void)hipStreamSynchronize(v->stream);
+    (void)gsx_viewer_comm_destroy(v);
+    if (v->h_shard_verdict) (void)hipHostFree(v->h_shard_verdict);
     for (auto& t : v->timers) {
         (void)hipEventDestroy(t.start);
         (void)hipEventDestroy(t.stop);
@@ -426,7 +428,7 @@ gsx_status gsx_model_frame_stats(gsx_viewer* v, const char* key, gsx_frame_stats
     out->n_tile_entries = m->binned ? m->n_entries : 0;  // entries actually binned by the last gsx_render
     out->n_sorted = m->n_sorted;
     out->speculated = m->binned && m->spec_round1 ? 1u : 0u;
-    out->n_repair_tiles = out->speculated ? m->h_counters->spec_need : 0;
+    out->n_repair_tiles = out->speculated ? m->h_counters->spec_need : (m->use_imported ? m->h_counters->shard_need : 0);
     out->n_repair_sorted = out->speculated ? m->n_sorted2 : 0;
     out->overflow_slabs = (uint32_t)std::min<uint64_t>(m->overflow_slabs, 0xFFFFFFFFull);
     return GSX_OK;

@@ -158,6 +158,8 @@ gsx_status gsx_shard_import(gsx_viewer* v, const char* key, const void* d_recv, 
     m->row_lo = rank * rpr;
     m->row_hi = (rank + 1) * rpr;
     m->has_window = d_tile_window != nullptr;
+    m->window_ptr = nullptr;
+    m->import_min_ends = nullptr;
     if (d_tile_window) {
         HIPCHK(m->window.ensure(window_bytes(v)));
         HIPCHK(hipMemcpyAsync(m->window.p, d_tile_window, window_bytes(v), hipMemcpyDeviceToDevice, v->stream));
@@ -167,17 +169,23 @@ gsx_status gsx_shard_import(gsx_viewer* v, const char* key, const void* d_recv, 
 }
 
 // this rank's band of the per-tile saturation keys; rows below the frame read 0 (= open)
+// ... followed by kShardExtraWords statistics words (the all-gather that verifies the frame also tells every rank how large
+// the slots have to be and whether one was too small)
 __global__ void k_shard_feedback(const uint32_t* __restrict__ tile_sat, uint32_t tiles_x, uint32_t tiles_y, uint32_t row_lo,
-                                 uint32_t n_words, uint32_t* __restrict__ out) {
+                                 uint32_t n_words, uint32_t* __restrict__ out, const SlabStats* __restrict__ stats) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_words) return;
+    if (i >= n_words + kShardExtraWords) return;
+    if (i >= n_words) {  // round 0's figures: what this rank wanted to send to its busiest destination, and whether the slot held it
+        out[i] = i - n_words == 0u ? stats->slot_max[0] : (i - n_words == 1u ? stats->slot_over[0] : 0u);
+        return;
+    }
     const uint32_t ty = row_lo + i / tiles_x;
     out[i] = ty < tiles_y ? tile_sat[ty * tiles_x + i % tiles_x] : 0u;
 }
 
 gsx_status gsx_shard_feedback_words(gsx_viewer* v, uint32_t world, uint32_t* out_words) {
     if (!v || !out_words || world == 0 || world > 64) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_feedback_words: bad argument");
-    *out_words = rows_per_rank(v, world) * ((v->width + GSX_TILE - 1) / GSX_TILE);
+    *out_words = rows_per_rank(v, world) * ((v->width + GSX_TILE - 1) / GSX_TILE) + kShardExtraWords;
     return GSX_OK;
 }
 
@@ -192,8 +200,8 @@ gsx_status gsx_shard_feedback(gsx_viewer* v, const char* key, uint32_t world, ui
     const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
     const uint32_t row_words = (tiles_x + 31) / 32, rpr = rows_per_rank(v, world), n_words = rpr * tiles_x;
     const uint32_t* tile_sat = v->done_bits.as<uint32_t>() + 1 + (size_t)row_words * tiles_y;
-    hipLaunchKernelGGL(k_shard_feedback, dim3((n_words + 255) / 256), dim3(256), 0, v->stream, tile_sat, tiles_x, tiles_y,
-                       rank * rpr, n_words, static_cast<uint32_t*>(d_out_u32));
+    hipLaunchKernelGGL(k_shard_feedback, dim3((n_words + kShardExtraWords + 255) / 256), dim3(256), 0, v->stream, tile_sat, tiles_x, tiles_y,
+                       rank * rpr, n_words, static_cast<uint32_t*>(d_out_u32), m->counters.as<Counters>());
     HIPCHK(hipGetLastError());
     return GSX_OK;
 }
@@ -202,6 +210,346 @@ gsx_status gsx_render_more(gsx_viewer* v, const char* const* keys, uint32_t n_ke
     gsx_status st = viewer_bind(v);
     if (st) return st;
     return do_render(v, keys, n_keys, true);
+}
+
+}  // extern "C"
+
+// =====================================================================================================================
+// Device-resident exchange protocol: the index-sharded frame with windows, verification, repair windows, next frame's limits
+// and every record count ON THE DEVICE, fixed-size exchange slots whose headers carry the counts, and ONE thing the host
+// waits for per frame: the verdict of round 0 (two words in pinned memory, written by the verification kernel from globally
+// gathered data — every rank reads the same verdict and takes the same decision):
+//
+//   gsx_shard_frame_begin(key, world, rank, speculate)        windows [0, limit) from last frame's limits -> projection
+//   gsx_shard_slot_records(key, world, max_shard, &T)         round-0 slot size: 2x what the LAST frame's busiest (rank,
+//                                                             destination) pair wanted (a global figure from its verdict)
+//   gsx_shard_pack_slots(key, world, 0, d_send, T)            world slots of (1 + T) records, header = counts
+//   all-to-all of the slots                                   gsx_comm_all_to_all
+//   gsx_shard_import_slots(key, d_recv, world, rank, 0, T)    import + depth sort + render this rank's band
+//   gsx_shard_feedback(..) + all-gather                       saturation depth key of every tile + the ranks' slot statistics
+//   gsx_shard_verify(key, world, d_sat_all, &seq)             repair windows on the device; posts the verdict
+//   gsx_shard_next_windows(..); all-gather of the bands       enqueued BEFORE the wait: what follows when nothing is wrong
+//   gsx_shard_wait_verdict(seq, &verdict)                     {tiles needing repair, a slot overflowed somewhere, busiest pair}
+//     verdict.overflow: round 0 again with T = max_shard (a destination can be sent at most a whole shard: always fits)
+//     verdict.need > 0: the repair round, sized EXACTLY — gsx_shard_repair_count + all-gather + gsx_shard_post_counts +
+//                       wait -> T1; pack_slots(.., 1, T1) -> all-to-all -> import_slots(.., 1, T1) -> feedback + all-gather,
+//                       then next_windows and the band all-gather once more (they replace the early ones)
+// Common case (no repair, no overflow): one short wait that overlaps the band all-gather; nothing else ever blocks.
+// Whatever happens the frame that leaves the GPU is complete, and equal to the single-GPU frame bit for bit.
+// =====================================================================================================================
+namespace {
+
+// The two halves of a round's pack.  pack_count: which records travel where (destination masks, per-workgroup tables,
+// per-destination totals; with explicit windows on a lazily projected shard also the travellers' ballots).  window ==
+// nullptr: the windows announced to the projection (its candidate list), or everything.  gate (nullable): bitmap of tiles;
+// a record whose rectangle holds none of them is refused before any window is looked at (the repair round: few tiles).
+gsx_status pack_count(gsx_viewer* v, Model* m, uint32_t world, const uint2* explicit_window, const uint32_t* gate, const WindowPyramid* pyramid) {
+    const uint32_t n = (uint32_t)m->n;
+    const uint32_t nb = (uint32_t)pack_blocks(n), rpr = rows_per_rank(v, world);
+    const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE;
+    HIPCHK(m->pack_table.ensure(4 * ((size_t)64 * std::max(nb, 1u) + 64)));
+    HIPCHK(m->pack_masks.ensure(8 * (size_t)std::max(n, 1u)));
+    m->pack_list = false;
+    m->pack_travellers = false;
+    const uint2* window = nullptr;
+    const uint2* list = nullptr;
+    const uint32_t* d_list_n = nullptr;
+    unsigned long long* travellers = nullptr;
+    uint32_t* trav_counts = nullptr;
+    Counters* dc = m->counters.as<Counters>();
+    gsx_status st;
+    if (explicit_window) {
+        window = explicit_window;
+        if (m->lazy) {  // explicit windows on a lazily projected shard (the repair exchange): travellers may be unshaded
+            HIPCHK(m->trav_ballots.ensure(8 * ((std::max<size_t>(n, 1) + 63) / 64)));
+            HIPCHK(m->trav_counts.ensure(4 * std::max<size_t>(nb, 1)));
+            travellers = m->trav_ballots.as<unsigned long long>();
+            trav_counts = m->trav_counts.as<uint32_t>();
+            m->pack_travellers = true;
+        }
+    } else if (m->shard_win_set && m->cand_valid) {
+        window = m->shard_win.as<uint2>();
+        list = m->adm_pairs.as<uint2>();
+        d_list_n = &dc->n_candidates;
+        m->pack_list = true;
+    } else if (m->lazy) {
+        if ((st = complete_records(v, m))) return st;
+    }
+    uint32_t* table = m->pack_table.as<uint32_t>();
+    uint32_t* totals = table + (size_t)64 * std::max(nb, 1u);
+    HIPCHK(launch_zero_words(v->stream, totals, 64, nullptr, 0));
+    HIPCHK(launch_pack_count(v->stream, m->proj_rec(), n, world, rpr, window, tiles_x, m->pack_masks.as<unsigned long long>(), table, list, d_list_n,
+                             travellers, trav_counts, gate, (tiles_x + 31) / 32, window ? pyramid : nullptr));
+    if (nb) HIPCHK(launch_rowscan(v->stream, table, world, nb, totals));
+    return GSX_OK;
+}
+
+// pack_write: shade the travellers the lazy projection skipped, slot headers, the records into their slots
+gsx_status pack_write(gsx_viewer* v, Model* m, uint32_t world, void* d_send, uint32_t slot_stride, uint32_t slot_cap, uint32_t round) {
+    const uint32_t n = (uint32_t)m->n;
+    const uint32_t nb = (uint32_t)pack_blocks(n);
+    Counters* dc = m->counters.as<Counters>();
+    uint32_t* table = m->pack_table.as<uint32_t>();
+    uint32_t* totals = table + (size_t)64 * std::max(nb, 1u);
+    if (m->pack_travellers && nb) {
+        HIPCHK(m->adm_pairs.ensure(8 * std::max<size_t>(n, 1)));
+        HIPCHK(launch_rowscan(v->stream, m->trav_counts.as<uint32_t>(), 1, nb, &dc->n_sorted2));
+        HIPCHK(launch_admit_scatter(v->stream, m->proj_rec().key, n, m->trav_ballots.as<unsigned long long>(), m->trav_counts.as<uint32_t>(),
+                                    m->adm_pairs.as<uint2>()));
+        PodPlanes pod = m->pod();
+        pod.mask = m->last_pod_mask;
+        HIPCHK(launch_shade(v->stream, m->fc, n, pod, m->proj_rec(),
+                            LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>()}));
+        m->cand_valid = false;
+        m->pack_travellers = false;
+    }
+    HIPCHK(launch_pack_headers(v->stream, totals, world, slot_stride, slot_cap, d_send, dc, round));
+    HIPCHK(launch_pack_scatter(v->stream, m->proj_rec(), n, world, m->pack_masks.as<unsigned long long>(), table, totals, d_send,
+                               (uint64_t)world * slot_stride, m->pack_list ? m->adm_pairs.as<uint2>() : nullptr,
+                               m->pack_list ? &dc->n_candidates : nullptr, slot_stride, slot_cap));
+    m->stats_pending = true;
+    return GSX_OK;
+}
+
+// the repair round's count: windows [limit, inf) on the tiles that need it, nothing elsewhere; decided by the min-pyramid of
+// the window starts (KEY_ALL where no tile needs anything), built here — only frames that repair pay for it
+gsx_status repair_pack_count(gsx_viewer* v, Model* m, uint32_t world) {
+    const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
+    HIPCHK(m->shard_pyr2.ensure(4 * window_pyramid_words(tiles_x, tiles_y)));
+    HIPCHK(launch_window_pyramid(v->stream, m->shard_win2.as<uint2>(), tiles_x, tiles_y, m->shard_pyr2.as<uint32_t>(), true));
+    WindowPyramid pyr2 = window_pyramid_layout(tiles_x, tiles_y, m->shard_pyr2.as<uint32_t>());
+    pyr2.min_of_starts = 1;
+    return pack_count(v, m, world, m->shard_win2.as<uint2>(), nullptr, &pyr2);
+}
+
+gsx_status ensure_verdict(gsx_viewer* v) {
+    if (!v->h_shard_verdict) {
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&v->h_shard_verdict), 64, hipHostMallocDefault));
+        v->h_shard_verdict[0] = v->h_shard_verdict[1] = 0;
+    }
+    return GSX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+gsx_status gsx_shard_frame_begin(gsx_viewer* v, const char* key, uint32_t world, uint32_t rank, uint32_t speculate, const uint32_t* d_limit_override) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_frame_begin: no model '%s'", key ? key : "(null)");
+    if (world == 0 || world > 64 || rank >= world) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_frame_begin: bad world/rank %u/%u", world, rank);
+    const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE, n_tiles = tiles_x * tiles_y;
+    if (d_limit_override) {  // tests / a caller with its own policy: these limits instead of the ones the last frame left
+        HIPCHK(m->shard_limit.ensure(4 * (size_t)n_tiles));
+        HIPCHK(hipMemcpyAsync(m->shard_limit.p, d_limit_override, 4 * (size_t)n_tiles, hipMemcpyDeviceToDevice, v->stream));
+        m->shard_limit_valid = true;
+        m->shard_limit_tx = tiles_x;
+        m->shard_limit_ty = tiles_y;
+        m->slot_hint = 0;  // nothing is known about what THESE limits let through: the safe slot size
+    }
+    m->shard_frame_limited = speculate && m->shard_limit_valid && m->shard_limit_tx == tiles_x && m->shard_limit_ty == tiles_y;
+    m->shard_win_set = false;
+    if (m->shard_frame_limited) {
+        HIPCHK(m->shard_win.ensure(window_bytes(v)));
+        HIPCHK(launch_limits_to_windows(v->stream, m->shard_limit.as<uint32_t>(), n_tiles, m->shard_win.as<uint2>()));
+        // [max-pyramid of the window ends: admission in the projection kernel | min-pyramid: "every tile takes it" in the binning]
+        const size_t pw = window_pyramid_words(tiles_x, tiles_y);
+        HIPCHK(m->shard_pyr.ensure(8 * pw));
+        HIPCHK(launch_window_pyramid(v->stream, m->shard_win.as<uint2>(), tiles_x, tiles_y, m->shard_pyr.as<uint32_t>(), false, nullptr,
+                                     m->shard_pyr.as<uint32_t>() + pw));
+        m->shard_tiles_x = tiles_x;
+        m->shard_tiles_y = tiles_y;
+        m->shard_win_set = true;
+    }
+    m->repair_counted = false;
+    return do_preprocess(v, m);
+}
+
+gsx_status gsx_shard_slot_records(gsx_viewer* v, const char* key, uint32_t world, uint32_t shard_records_max, uint32_t* out_records) {
+    Model* m = find_model(v, key);
+    if (!m || !out_records) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_slot_records: no model '%s' / bad argument", key ? key : "(null)");
+    if (shard_records_max < m->n) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_slot_records: shard_records_max %u < this shard's %llu records",
+                                              shard_records_max, (unsigned long long)m->n);
+    // EVERY rank must arrive at the same number (the all-to-all moves equal slots), so nothing rank-local enters it:
+    // shard_records_max is the largest shard of the model (the caller's partition), slot_hint is the global figure of the last
+    // verdict.  Without windows every visible record travels: a destination can be sent at most a whole shard, which
+    // always fits.  With windows: twice what the busiest pair wanted last frame; should that still be too small, the
+    // verdict says so and round 0 is redone with the safe size.
+    const uint32_t n = std::max<uint32_t>(shard_records_max, 1u);
+    uint32_t t = n;
+    if (m->shard_frame_limited && m->slot_hint) t = std::min<uint32_t>(n, std::max<uint32_t>(2u * m->slot_hint + 4096u, 8192u));
+    *out_records = t;
+    (void)world;
+    return GSX_OK;
+}
+
+gsx_status gsx_shard_pack_slots(gsx_viewer* v, const char* key, uint32_t world, uint32_t round, void* d_send, uint32_t slot_records) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_pack_slots: no model '%s'", key ? key : "(null)");
+    if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack_slots: model '%s' has no projection this frame (gsx_shard_frame_begin first)", key);
+    if (world == 0 || world > 64 || round > 1 || !d_send || slot_records == 0) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack_slots: bad argument");
+    if (round == 1) {
+        if (m->shard_win2.bytes < window_bytes(v)) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack_slots: round 1 before gsx_shard_verify");
+        // the repair round is counted once (gsx_shard_repair_count sized it); packing without it counts here
+        if (!m->repair_counted && (st = repair_pack_count(v, m, world))) return st;
+        m->repair_counted = false;
+    } else {
+        // the senders decide by the max-pyramid of the window ends, per destination band (a conservative superset; the
+        // receiver bins by the exact windows)
+        WindowPyramid pyr = window_pyramid_layout(m->shard_tiles_x, m->shard_tiles_y, m->shard_pyr.as<uint32_t>());
+        if ((st = pack_count(v, m, world, nullptr, nullptr, m->shard_win_set ? &pyr : nullptr))) return st;
+    }
+    return pack_write(v, m, world, d_send, slot_records + 1u, slot_records, round);
+}
+
+gsx_status gsx_shard_repair_count(gsx_viewer* v, const char* key, uint32_t world, void* d_out4) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m || !d_out4) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_repair_count: no model '%s' / null output", key ? key : "(null)");
+    if (!m->preprocessed || m->shard_win2.bytes < window_bytes(v)) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_repair_count: before gsx_shard_verify");
+    if ((st = repair_pack_count(v, m, world))) return st;
+    m->repair_counted = true;
+    const uint32_t* totals = m->pack_table.as<uint32_t>() + (size_t)64 * std::max<uint32_t>((uint32_t)pack_blocks(m->n), 1u);
+    HIPCHK(launch_shard_max_count(v->stream, totals, world, static_cast<uint32_t*>(d_out4)));
+    return GSX_OK;
+}
+
+gsx_status gsx_shard_post_counts(gsx_viewer* v, uint32_t world, const void* d_counts_all, uint32_t* out_seq) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    if (!d_counts_all || !out_seq || world == 0 || world > 64) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_post_counts: bad argument");
+    if ((st = ensure_verdict(v))) return st;
+    *out_seq = ++v->shard_seq;
+    HIPCHK(launch_shard_post_counts(v->stream, static_cast<const uint32_t*>(d_counts_all), world, v->h_shard_verdict, *out_seq));
+    return GSX_OK;
+}
+
+gsx_status gsx_shard_import_slots(gsx_viewer* v, const char* key, const void* d_recv, uint32_t world, uint32_t rank, uint32_t round,
+                                  uint32_t slot_records) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_import_slots: no model '%s'", key ? key : "(null)");
+    if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import_slots: model '%s' has no frame constants (gsx_shard_frame_begin first)", key);
+    if (world == 0 || world > 64 || rank >= world || round > 1 || !d_recv || slot_records == 0)
+        return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import_slots: bad argument");
+    const uint64_t cap = (uint64_t)world * slot_records;
+    if (cap >= 0xFFFFFFF0ull) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import_slots: too many records");
+    if ((st = ensure_import_capacity(m, cap))) return st;
+    HIPCHK(launch_import_slots(v->stream, d_recv, world, slot_records + 1u, slot_records, m->imp_rec(), m->counters.as<Counters>()));
+    m->stats_pending = true;
+    m->rec_n = cap;  // an upper bound: the count is on the device (Counters::n_sorted)
+    m->use_imported = true;
+    const uint32_t rpr = rows_per_rank(v, world);
+    m->row_lo = rank * rpr;
+    m->row_hi = (rank + 1) * rpr;
+    // the receiving side of the pack predicate: a tile bins exactly the records its window admits
+    const uint2* win = round == 0 ? (m->shard_frame_limited ? m->shard_win.as<uint2>() : nullptr) : m->shard_win2.as<uint2>();
+    m->has_window = win != nullptr;
+    m->import_min_ends = nullptr;
+    m->window_ptr = win;  // the model's own maps (shard_win / shard_win2) stay put until the next frame: no copy
+    if (win) {
+        if (round == 0) m->import_min_ends = m->shard_pyr.as<uint32_t>() + window_pyramid_words((v->width + GSX_TILE - 1) / GSX_TILE, (v->height + GSX_TILE - 1) / GSX_TILE);
+    }
+    m->sorted = m->counters_valid = m->binned = false;
+    if ((st = do_sort(v, m))) return st;
+    const char* keys[1] = {m->key.c_str()};
+    return do_render(v, keys, 1, round == 1);
+}
+
+gsx_status gsx_shard_verify(gsx_viewer* v, const char* key, uint32_t world, const void* d_sat_all, uint32_t* out_seq) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m || !d_sat_all || !out_seq) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_verify: no model '%s' / null argument", key ? key : "(null)");
+    if (world == 0 || world > 64) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_verify: world must be 1..64");
+    const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
+    HIPCHK(m->shard_win2.ensure(window_bytes(v)));
+    HIPCHK(m->shard_need_bits.ensure(4 * (size_t)((tiles_x + 31) / 32) * tiles_y));
+    if ((st = ensure_verdict(v))) return st;
+    Counters* dc = m->counters.as<Counters>();
+    HIPCHK(launch_zero_words(v->stream, &dc->shard_need, 2, m->shard_need_bits.as<uint32_t>(), ((tiles_x + 31) / 32) * tiles_y));  // shard_need + shard_ticket | bitmap
+    *out_seq = ++v->shard_seq;
+    HIPCHK(launch_shard_verify(v->stream, m->shard_frame_limited ? m->shard_limit.as<uint32_t>() : nullptr, static_cast<const uint32_t*>(d_sat_all),
+                               tiles_x, tiles_y, rows_per_rank(v, world), world, m->shard_win2.as<uint2>(), &dc->shard_need, &dc->shard_ticket,
+                               v->h_shard_verdict, *out_seq, m->shard_need_bits.as<uint32_t>()));
+    m->repair_counted = false;
+    m->stats_pending = true;
+    return GSX_OK;
+}
+
+// Spins on the pinned verdict words until the kernel that posts `seq` has run.  Bounded by the stream itself: if the stream
+// drains (or fails) and the words still are not there, that is reported instead of spinning forever.
+gsx_status gsx_shard_wait_verdict(gsx_viewer* v, const char* key, uint32_t seq, gsx_shard_verdict* out) {
+    if (!v || !out || !v->h_shard_verdict) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_wait_verdict: nothing was posted");
+    for (uint64_t spin = 1;; ++spin) {
+        const unsigned long long w = __atomic_load_n(&v->h_shard_verdict[0], __ATOMIC_ACQUIRE);
+        if ((uint32_t)(w >> 32) == seq) {
+            const unsigned long long d = __atomic_load_n(&v->h_shard_verdict[1], __ATOMIC_RELAXED);
+            out->need_tiles = (uint32_t)w;
+            out->overflow = (uint32_t)(d & 1ull);
+            out->max_records = (uint32_t)(d >> 32);
+            if (Model* m = find_model(v, key)) m->slot_hint = out->max_records;  // next frame's round-0 slots (global: same on every rank)
+            return GSX_OK;
+        }
+        if ((spin & 0xFFFu) == 0) {
+            const hipError_t e = hipStreamQuery(v->stream);
+            if (e == hipSuccess) {
+                const unsigned long long w2 = __atomic_load_n(&v->h_shard_verdict[0], __ATOMIC_ACQUIRE);
+                if ((uint32_t)(w2 >> 32) == seq) continue;
+                return fail(GSX_ERR_HIP, "gsx_shard_wait_verdict: verdict %u never arrived (stream idle)", seq);
+            }
+            if (e != hipErrorNotReady) return fail(GSX_ERR_HIP, "stream failed while waiting for the exchange verdict: %s", hipGetErrorString(e));
+        }
+        __builtin_ia32_pause();
+    }
+}
+
+gsx_status gsx_shard_next_windows(gsx_viewer* v, const char* key, uint32_t world, const void* d_sat_all, float margin, uint32_t radius) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m || !d_sat_all) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_next_windows: no model '%s' / null map", key ? key : "(null)");
+    if (!(margin >= 0.0f) || radius > 16 || world == 0 || world > 64) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_next_windows: margin >= 0, radius <= 16, world 1..64");
+    const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
+    // the limits of the frame in flight must survive until its verdict is in (a repair round reads them): double buffer
+    DevBuf& next = m->shard_limit_next;
+    HIPCHK(next.ensure(4 * (size_t)tiles_x * tiles_y));
+    HIPCHK(launch_shard_next_limits(v->stream, static_cast<const uint32_t*>(d_sat_all), tiles_x, tiles_y, margin, radius, next.as<uint32_t>(),
+                                    rows_per_rank(v, world)));
+    m->shard_next_valid = true;
+    m->shard_limit_tx = tiles_x;
+    m->shard_limit_ty = tiles_y;
+    return GSX_OK;
+}
+
+gsx_status gsx_shard_frame_end(gsx_viewer* v, const char* key) {
+    Model* m = find_model(v, key);
+    if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_frame_end: no model '%s'", key ? key : "(null)");
+    if (m->shard_next_valid) {  // the limits gsx_shard_next_windows computed become the next frame's
+        std::swap(m->shard_limit.p, m->shard_limit_next.p);
+        std::swap(m->shard_limit.bytes, m->shard_limit_next.bytes);
+        m->shard_limit_valid = true;
+        m->shard_next_valid = false;
+    }
+    return GSX_OK;
+}
+
+gsx_status gsx_shard_download_limits(gsx_viewer* v, const char* key, uint32_t* limits, uint64_t n_words) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m || !limits) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_download_limits: no model '%s'", key ? key : "(null)");
+    const uint64_t n_tiles = (uint64_t)m->shard_limit_tx * m->shard_limit_ty;
+    if (!m->shard_limit_valid || n_words < n_tiles) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_download_limits: no limits yet, or buffer too small");
+    HIPCHK(hipMemcpyAsync(limits, m->shard_limit.p, 4 * n_tiles, hipMemcpyDeviceToHost, v->stream));
+    HIPCHK(hipStreamSynchronize(v->stream));
+    return GSX_OK;
 }
 
 }  // extern "C"

@@ -330,7 +330,7 @@ gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
             m->spec_round1 = false;
             RadixBuffers rb{m->rec().key, nullptr, nullptr, m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
                             m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
-            HIPCHK(launch_radix_sort(v->stream, rb, n, nullptr, 32, true));
+            HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted, 32, true));  // n: an upper bound (slot import); the count is on the device
         } else {
             // compact the (key, index) pairs the projection pass admitted, then sort only those
             HIPCHK(m->adm_pairs.ensure(8 * std::max<size_t>(n, 1)));
@@ -429,10 +429,12 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
         note_overflow(m);  // a free-running loop learns here that some earlier frame spilled: larger pair buffers from now on
     }
     std::vector<uint32_t> bounds;
-    if (m->spec_round1) {
+    const bool imported_windows = m->use_imported && m->has_window && progressive;
+    if (m->spec_round1 || imported_windows) {
         // a speculated round is ONE slab: the windows already bound what every tile takes to little more than it needs,
         // and the compositor stops a saturated tile by itself; more slabs only add launches (measured on cfg4: 551 fps
         // with one slab, 487 with three).  The kernels stride over what exists on the device, so the bound is free.
+        // (Same for the imported records of an index-sharded frame whose exchange was windowed.)
         bounds = {0u, (uint32_t)m->rec_n};
     } else {
         plan_slabs(v->options, (uint32_t)m->rec_n, &bounds);
@@ -441,7 +443,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
     Counters* dc = m->counters.as<Counters>();
     const uint32_t row_lo = std::min(m->row_lo, m->fc.tiles_y), row_hi = std::min(m->row_hi, m->fc.tiles_y);
     const uint32_t owned_tiles = (row_hi > row_lo ? row_hi - row_lo : 0) * m->fc.tiles_x;
-    const uint2* window = (m->use_imported && m->has_window) ? m->window.as<uint2>() : nullptr;
+    const uint2* window = (m->use_imported && m->has_window) ? (m->window_ptr ? m->window_ptr : m->window.as<uint2>()) : nullptr;
     if (m->spec_round1) window = m->spec_win.as<uint2>();
     uint32_t* tile_sat = progressive ? done + row_words * m->fc.tiles_y : nullptr;  // [count | bitmap | saturation keys]
 
@@ -480,7 +482,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
     }
     const int bits = std::max<int>(1, (int)ceil_log2(n_tiles));
     // a single-slab front model keeps its complete tile lists for gsx_model_download_tile_lists
-    const bool clear_ranges = progressive && !(bounds.size() == 2 && !carry && !m->spec_round1);
+    const bool clear_ranges = progressive && !(bounds.size() == 2 && !carry && !m->spec_round1 && !imported_windows);
     // one depth slab [j0, j1) of the current depth order: bin -> tile sort -> ranges -> composite
     auto run_slab = [&](uint32_t j0, uint32_t j1, bool later, const uint2* win, const uint32_t* d_n, uint32_t slab_index,
                         const WindowPyramid* min_ends = nullptr) -> gsx_status {
@@ -544,13 +546,18 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
     gsx_status st = GSX_OK;
     // a speculated round's windows all start at 0 and come with the min-pyramid of their ends (enqueue_next_windows)
     WindowPyramid min_ends{};
+    bool have_min_ends = false;
     if (m->spec_round1) {
         const size_t pw = window_pyramid_words(m->fc.tiles_x, m->fc.tiles_y);
         min_ends = window_pyramid_layout(m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse.as<uint32_t>() + pw);
+        have_min_ends = true;
+    } else if (imported_windows && m->import_min_ends) {  // round 0 of an index-sharded frame: windows [0, limit), pyramid built at frame begin
+        min_ends = window_pyramid_layout(m->fc.tiles_x, m->fc.tiles_y, m->import_min_ends);
+        have_min_ends = true;
     }
     for (size_t sl = 0; sl + 1 < bounds.size(); ++sl)
         if ((st = run_slab(bounds[sl], bounds[sl + 1], carry || sl > 0, window, &dc->n_sorted, (uint32_t)sl,
-                           m->spec_round1 ? &min_ends : nullptr)))
+                           have_min_ends ? &min_ends : nullptr)))
             return st;
     bool windows_enqueued = false;
     auto enqueue_next_windows = [&]() -> gsx_status {  // this model's windows for its next frame
@@ -657,7 +664,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
     }
     m->binned = true;
     m->stats_pending = true;
-    m->lists_complete = bounds.size() == 2 && !carry && !m->spec_round1;
+    m->lists_complete = bounds.size() == 2 && !carry && !m->spec_round1 && !imported_windows;
     return GSX_OK;
 }
 

@@ -142,6 +142,10 @@ struct SlabStats {
     uint32_t overflow_events;  // slabs, over the model's lifetime, whose tile entries did not fit the pair buffers (never reset:
                                // the host compares with the count it has seen and grows the buffers for the frames to come)
     uint32_t max_needed_ever;  // largest slab D ever seen
+    uint32_t slot_max[2];      // device-resident exchange: most records this rank had for ONE destination in the last round 0 / 1
+    uint32_t slot_over[2];     // ... and whether that exceeded the slot (the verdict tells every rank; round 0 is then redone)
+    uint32_t shard_need;       // tiles of the whole frame that needed the repair round (gsx_shard_verify)
+    uint32_t shard_ticket;     // k_shard_verify: blocks done (the last one posts the verdict): tiles of the whole frame that needed the repair round (gsx_shard_verify)
     // ---- from here on: zeroed at the start of every frame ----
     uint32_t n_entries;        // D of the slab being processed: what was binned into the pair buffers (<= their capacity)
     uint32_t n_entries_total;  // sum of slab D over the frame (including entries the spill compositor handled without pairs)
@@ -232,10 +236,29 @@ size_t pack_blocks(uint64_t n);
 // travellers / traveller_counts (nullable): ballots + per-workgroup counts of the elements that travel anywhere.
 hipError_t launch_pack_count(hipStream_t s, const Records& rec, uint32_t n, uint32_t world, uint32_t rows_per_rank,
                              const uint2* window, uint32_t tiles_x, unsigned long long* masks, uint32_t* table,
-                             const uint2* list, const uint32_t* d_list_n, unsigned long long* travellers, uint32_t* traveller_counts);
+                             const uint2* list, const uint32_t* d_list_n, unsigned long long* travellers, uint32_t* traveller_counts,
+                             const uint32_t* gate = nullptr /* tile bitmap: records whose rectangle holds no gated tile go nowhere */,
+                             uint32_t gate_row_words = 0,
+                             const WindowPyramid* pyramid = nullptr /* decide by the windows' pyramid alone: a conservative superset */);
 hipError_t launch_pack_scatter(hipStream_t s, const Records& rec, uint32_t n, uint32_t world,
                                const unsigned long long* masks, const uint32_t* table, const uint32_t* totals, void* d_send,
-                               uint64_t capacity, const uint2* list, const uint32_t* d_list_n);
+                               uint64_t capacity, const uint2* list, const uint32_t* d_list_n, uint32_t slot_stride = 0,
+                               uint32_t slot_cap = 0 /* > 0: fixed slots of slot_stride records, header first, at most slot_cap records each */);
+// device-resident exchange (kernels_shard.hip): slot headers, import from slots, windows / verification / next limits
+hipError_t launch_pack_headers(hipStream_t s, const uint32_t* totals, uint32_t world, uint32_t slot_stride, uint32_t slot_cap, void* d_send,
+                               SlabStats* stats, uint32_t round);
+hipError_t launch_import_slots(hipStream_t s, const void* d_recv, uint32_t world, uint32_t slot_stride, uint32_t slot_cap, const Records& rec,
+                               SlabStats* stats);
+hipError_t launch_limits_to_windows(hipStream_t s, const uint32_t* limit, uint32_t n_tiles, uint2* win);
+// sat: the all-gathered feedback = per rank (rpr * tiles_x + kShardExtraWords) words
+constexpr uint32_t kShardExtraWords = 4;  // {records wanted for the busiest destination, slot overflowed?, 0, 0} behind every rank's band
+hipError_t launch_shard_verify(hipStream_t s, const uint32_t* limit, const uint32_t* sat, uint32_t tiles_x, uint32_t tiles_y, uint32_t rpr,
+                               uint32_t world, uint2* win2, uint32_t* d_need, uint32_t* d_ticket, unsigned long long* host_verdict, uint32_t seq,
+                               uint32_t* need_bits /* zeroed; bit per tile that needs the repair round */);
+hipError_t launch_shard_post_counts(hipStream_t s, const uint32_t* counts_all, uint32_t world, unsigned long long* host_verdict, uint32_t seq);
+hipError_t launch_shard_max_count(hipStream_t s, const uint32_t* totals, uint32_t world, uint32_t* out4);
+hipError_t launch_shard_next_limits(hipStream_t s, const uint32_t* sat, uint32_t tiles_x, uint32_t tiles_y, float margin, uint32_t radius,
+                                    uint32_t* limit, uint32_t rpr);
 hipError_t launch_import_records(hipStream_t s, const void* d_recv, uint32_t n, const Records& rec);
 
 // Mask evaluation (kernels_mask.hip); passed to the kernel by value.

@@ -120,6 +120,13 @@ struct Model {
     // last preprocess left a candidate list in adm_pairs
     DevBuf shard_win, shard_pyr, trav_ballots, trav_counts;
     bool shard_win_set = false, cand_valid = false;
+    // device-resident exchange (gsx_shard_frame_begin ... gsx_shard_next_windows): next frame's per-tile limits, the
+    // repair round's windows, and what the host knows (late, never waited for) about how full the exchange slots get
+    DevBuf shard_limit, shard_limit_next, shard_win2;
+    bool shard_limit_valid = false, shard_next_valid = false, shard_frame_limited = false;
+    uint32_t shard_limit_tx = 0, shard_limit_ty = 0;
+    uint32_t slot_hint = 0;                    // records the busiest (rank, destination) pair wanted in round 0 of the last frame: a GLOBAL
+                                               // figure from that frame's verdict, so every rank sizes the next slots identically; 0 = unknown
     DevBuf adm_ballots2;           // the repair round's ballots (the first round's stay: they say which records are shaded)
     bool lazy = false;             // this frame's projection shaded only the admitted Gaussians
     const uint32_t* last_pyramid = nullptr;  // the admission pyramid the projection pass used
@@ -129,6 +136,12 @@ struct Model {
     DevBuf pack_masks;             // destination bit mask per record (gsx_shard_pack)
     DevBuf window, pack_window;    // per-tile depth-key windows [lo, hi): of the imported set / of the pack in flight
     bool has_window = false;
+    const uint2* window_ptr = nullptr;          // != nullptr: the imported set's windows live here (no copy in `window`)
+    const uint32_t* import_min_ends = nullptr;  // min-pyramid of the imported set's window ends (every window starts at 0), or nullptr
+    DevBuf shard_pyr2;             // min-pyramid of the repair windows' starts (the repair round's conservative pack test)
+    DevBuf shard_need_bits;        // device-resident exchange: bitmap of the tiles that need the repair round (gates its pack)
+    bool repair_counted = false;
+    bool pack_list = false, pack_travellers = false;  // how the last pack_count addressed the records / whether it left travellers to shade   // gsx_shard_repair_count has left masks / table / travellers for the repair pack
 
     ~Model() {
         if (h_counters) (void)hipHostFree(h_counters);
@@ -204,6 +217,11 @@ struct gsx_viewer {
     uint32_t query_tex_w = 0, query_tex_h = 0;
     float highlight[4]{0, 0, 0, 0};
     gsx_gaussian_edit sel_edit{0u, {0.0f, 1.0f, 1.0f}, 0.0f, 0.0f, 1.0f, 1.0f};
+    unsigned long long* h_shard_verdict = nullptr;  // pinned, 2 words: {seq | need}, {busiest pair's records | overflow} (k_shard_verify / k_shard_post_counts)
+    uint32_t shard_seq = 0;
+    void* comm = nullptr;                // ncclComm_t (gsx_viewer_comm_init); RCCL is loaded at run time (gsx_comm.cpp)
+    uint32_t comm_world = 0, comm_rank = 0;
+    DevBuf shard_fb, shard_send, shard_recv, shard_sat_band, shard_sat_all, shard_counts;  // gsx_shard_render_frame's own buffers
     void* ext_fb = nullptr;              // caller-owned framebuffer (multi-GPU: the RCCL gather target)
     uint64_t ext_fb_bytes = 0;
     gsx_render_options options{1u, 16u, 131072u, 2u, 1u, 0.25f, 3u, 0u};  // = gsx_render_options_default

@@ -15,6 +15,8 @@
 // Packing is an order-preserving multi-destination stream compaction (records keep ascending local
 // index inside every destination group), which keeps the depth-tie order = global Gaussian index.
 // Record = 48 bytes: {mean.x, mean.y, rect.x, rect.y | conic a, b, c, opacity | r, g, b, depth}.
+#include <algorithm>
+
 #include "gsx_internal.h"
 #include "window_scan.h"
 
@@ -41,7 +43,9 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_count(const uint32_t* __r
                                                               uint32_t* __restrict__ table, uint32_t nblocks,
                                                               const uint2* __restrict__ list, const uint32_t* __restrict__ d_list_n,
                                                               unsigned long long* __restrict__ travellers,
-                                                              uint32_t* __restrict__ traveller_counts) {
+                                                              uint32_t* __restrict__ traveller_counts,
+                                                              const uint32_t* __restrict__ gate, uint32_t gate_row_words,
+                                                              const WindowPyramid pyr) {
     __shared__ uint32_t cnt[kMaxWorld];
     __shared__ uint32_t tcnt[kPackThreads / 64];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
@@ -49,26 +53,46 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_count(const uint32_t* __r
     __syncthreads();
     if (list) n = min(n, *d_list_n);
     const uint32_t base = blockIdx.x * kPackTile + wave * kPackWaveChunk;
+    if (blockIdx.x * kPackTile >= n) {  // (uniform per workgroup) nothing here — a candidate list is a small fraction of the shard: a zero table column
+        if (tid < world) table[tid * nblocks + blockIdx.x] = 0u;
+        if (travellers && tid == 0) traveller_counts[blockIdx.x] = 0u;
+        return;
+    }
     uint32_t tc = 0;
+    // The loads of all rounds are issued before any is consumed: keys / list entries, then the rectangles they point at.  With
+    // one round at a time a wave paid three dependent memory round trips per round, sixteen times over — and a candidate list
+    // (a few per cent of the shard) leaves too few waves on the chip to hide any of it: 200-270 us for 0.7 M candidates.
+    uint32_t kks[kPackRounds], srcs[kPackRounds], rxs[kPackRounds], rys[kPackRounds];
+#pragma unroll
     for (int r = 0; r < kPackRounds; ++r) {
-        uint32_t e = base + r * 64 + lane;
-        uint32_t kk = kCulledKey, src = e;
+        const uint32_t e = base + r * 64 + lane;
+        kks[r] = kCulledKey;
+        srcs[r] = e;
         if (e < n) {
             if (list) {
                 const uint2 p = list[e];
-                kk = p.x;
-                src = p.y;
+                kks[r] = p.x;
+                srcs[r] = p.y;
             } else {
-                kk = key[e];
+                kks[r] = key[e];
             }
         }
-        uint32_t rx = 0, ry = 0;
-        if (kk != kCulledKey) {
-            const float4 a = rec_a[src];
-            rx = __float_as_uint(a.z);
-            ry = __float_as_uint(a.w);
+    }
+#pragma unroll
+    for (int r = 0; r < kPackRounds; ++r) {
+        rxs[r] = rys[r] = 0;
+        if (kks[r] != kCulledKey) {
+            const float4 a = rec_a[srcs[r]];
+            rxs[r] = __float_as_uint(a.z);
+            rys[r] = __float_as_uint(a.w);
         }
-        const unsigned long long m = wave_dest_mask(window, tiles_x, kk, rx, ry, rpr, world);
+    }
+#pragma unroll
+    for (int r = 0; r < kPackRounds; ++r) {
+        const uint32_t e = base + r * 64 + lane;
+        const uint32_t kk = kks[r], rx = rxs[r], ry = rys[r];
+        const unsigned long long m = pyr.data ? dest_mask_pyramid(pyr, kk, rx, ry, rpr, world)
+                                              : wave_dest_mask(window, tiles_x, kk, rx, ry, rpr, world, gate, gate_row_words);
         if (e < n) masks[e] = m;
         if (travellers) {
             const unsigned long long any = __ballot(m != 0ull);
@@ -94,24 +118,39 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_scatter(const unsigned lo
                                                                 uint32_t world, const uint32_t* __restrict__ table,
                                                                 uint32_t nblocks, const uint32_t* __restrict__ totals,
                                                                 float4* __restrict__ send, uint64_t capacity,
-                                                                const uint2* __restrict__ list, const uint32_t* __restrict__ d_list_n) {
+                                                                const uint2* __restrict__ list, const uint32_t* __restrict__ d_list_n,
+                                                                uint32_t slot_stride, uint32_t slot_cap) {
     __shared__ uint32_t run[kPackThreads / 64][kMaxWorld];  // per-wave running counts -> absolute offsets
     __shared__ uint32_t dbase[kMaxWorld];
+    __shared__ uint32_t dend[kMaxWorld];   // first position past what destination g may hold
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     if (tid < kMaxWorld) {
-        uint32_t b = 0;
-        for (uint32_t g = 0; g < tid && g < world; ++g) b += totals[g];
-        dbase[tid] = b;
+        if (slot_stride) {  // fixed slots (device-resident exchange): slot g = [header | slot_cap records]
+            dbase[tid] = tid * slot_stride + 1u;
+            dend[tid] = tid * slot_stride + 1u + slot_cap;
+        } else {            // packed groups in rank order (exact split sizes known to the host)
+            uint32_t b = 0;
+            for (uint32_t g = 0; g < tid && g < world; ++g) b += totals[g];
+            dbase[tid] = b;
+            dend[tid] = 0xFFFFFFFFu;
+        }
     }
     for (int w = 0; w < kPackThreads / 64; ++w)
         if (tid < kMaxWorld) run[w][tid] = 0;
     __syncthreads();
     if (list) n = min(n, *d_list_n);
+    if (blockIdx.x * kPackTile >= n) return;  // uniform per workgroup (before any barrier that matters: the ones above were passed)
     const uint32_t base = blockIdx.x * kPackTile + wave * kPackWaveChunk;
-    // pass 1: per-wave counts
+    // the destination masks of all rounds first (independent loads), then pass 1: per-wave counts
+    unsigned long long ms[kPackRounds];
+#pragma unroll
     for (int r = 0; r < kPackRounds; ++r) {
-        uint32_t e = base + r * 64 + lane;
-        const unsigned long long m = e < n ? masks[e] : 0ull;
+        const uint32_t e = base + r * 64 + lane;
+        ms[r] = e < n ? masks[e] : 0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < kPackRounds; ++r) {
+        const unsigned long long m = ms[r];
         for (uint32_t g = 0; g < world; ++g) {
             unsigned long long bal = __ballot((m >> g) & 1ull);
             if (lane == 0) run[wave][g] += (uint32_t)__popcll(bal);
@@ -129,9 +168,10 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_scatter(const unsigned lo
     __syncthreads();
     // pass 2: ranks inside the wave, in (round, lane) = memory order
     const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
     for (int r = 0; r < kPackRounds; ++r) {
         uint32_t e = base + r * 64 + lane;
-        const unsigned long long m = e < n ? masks[e] : 0ull;
+        const unsigned long long m = ms[r];
         float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
         if (m) {
             const uint32_t src = list ? list[e].y : e;
@@ -146,7 +186,7 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_scatter(const unsigned lo
             __builtin_amdgcn_wave_barrier();
             if (hit) {
                 uint64_t pos = (uint64_t)o + (uint32_t)__popcll(bal & lt);
-                if (pos < capacity) {
+                if (pos < capacity && pos < dend[g]) {
                     send[3 * pos + 0] = a;
                     send[3 * pos + 1] = b;
                     send[3 * pos + 2] = c;
@@ -171,21 +211,223 @@ __global__ __launch_bounds__(256) void k_import_records(const float4* __restrict
 
 hipError_t launch_pack_count(hipStream_t s, const Records& rec, uint32_t n, uint32_t world, uint32_t rows_per_rank,
                              const uint2* window, uint32_t tiles_x, unsigned long long* masks, uint32_t* table,
-                             const uint2* list, const uint32_t* d_list_n, unsigned long long* travellers, uint32_t* traveller_counts) {
+                             const uint2* list, const uint32_t* d_list_n, unsigned long long* travellers, uint32_t* traveller_counts,
+                             const uint32_t* gate, uint32_t gate_row_words, const WindowPyramid* pyramid) {
     uint32_t nb = (uint32_t)pack_blocks(n);
     if (nb)
         hipLaunchKernelGGL(k_pack_count, dim3(nb), dim3(kPackThreads), 0, s, rec.key, rec.a, n, world, rows_per_rank, window,
-                           tiles_x, masks, table, nb, list, d_list_n, travellers, traveller_counts);
+                           tiles_x, masks, table, nb, list, d_list_n, travellers, traveller_counts, gate, gate_row_words,
+                           pyramid ? *pyramid : WindowPyramid{});
     return hipGetLastError();
 }
 
 hipError_t launch_pack_scatter(hipStream_t s, const Records& rec, uint32_t n, uint32_t world,
                                const unsigned long long* masks, const uint32_t* table, const uint32_t* totals, void* d_send,
-                               uint64_t capacity, const uint2* list, const uint32_t* d_list_n) {
+                               uint64_t capacity, const uint2* list, const uint32_t* d_list_n, uint32_t slot_stride, uint32_t slot_cap) {
     uint32_t nb = (uint32_t)pack_blocks(n);
     if (nb)
         hipLaunchKernelGGL(k_pack_scatter, dim3(nb), dim3(kPackThreads), 0, s, masks, rec.a, rec.b, rec.c, n, world, table, nb,
-                           totals, reinterpret_cast<float4*>(d_send), capacity, list, d_list_n);
+                           totals, reinterpret_cast<float4*>(d_send), capacity, list, d_list_n, slot_stride, slot_cap);
+    return hipGetLastError();
+}
+
+// ---- device-resident exchange: fixed slots, counts in the slot headers (no host round trip) ----
+// send / recv buffer of a round: `world` slots of (1 + T) records of 48 bytes; record 0 of a slot is its header:
+// word 0 = records the sender HAD for this destination, word 1 = records it sent = min(word 0, T).
+__global__ __launch_bounds__(64) void k_pack_headers(const uint32_t* __restrict__ totals, uint32_t world, uint32_t slot_stride,
+                                                      uint32_t slot_cap, float4* __restrict__ send, SlabStats* __restrict__ stats,
+                                                      uint32_t round) {
+    const uint32_t g = threadIdx.x;
+    uint32_t cnt = g < world ? totals[g] : 0u;
+    if (g < world) {
+        float4* h = send + 3ull * (size_t)g * slot_stride;
+        h[0] = make_float4(__uint_as_float(cnt), __uint_as_float(min(cnt, slot_cap)), 0.0f, 0.0f);
+        h[1] = make_float4(0, 0, 0, 0);
+        h[2] = make_float4(0, 0, 0, 0);
+    }
+    uint32_t mx = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    if (g == 0) {
+        stats->slot_max[round & 1u] = mx;           // what this rank WANTED to send to its busiest destination
+        stats->slot_over[round & 1u] = mx > slot_cap ? 1u : 0u;
+    }
+}
+
+// received slots -> the record planes of the model, compacted in (source rank, source index) order = global Gaussian
+// index order (what makes the stable depth sort break ties exactly as on one GPU); the record count stays on the device
+__global__ __launch_bounds__(256) void k_import_slots(const float4* __restrict__ recv, uint32_t world, uint32_t slot_stride,
+                                                       uint32_t slot_cap, Records rec, SlabStats* __restrict__ stats) {
+    __shared__ uint32_t pre[kMaxWorld + 1];
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t s = 0; s < world; ++s) {
+            pre[s] = acc;
+            acc += min(__float_as_uint(recv[3ull * (size_t)s * slot_stride].y), slot_cap);
+        }
+        pre[world] = acc;
+        if (blockIdx.x == 0) {
+            stats->n_visible = acc;  // every imported record is visible by construction
+            stats->n_sorted = acc;
+        }
+    }
+    __syncthreads();
+    const uint64_t e = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint32_t s = (uint32_t)(e / slot_cap), j = (uint32_t)(e % slot_cap);
+    if (s >= world || j >= pre[s + 1] - pre[s]) return;
+    const float4* r = recv + 3ull * ((size_t)s * slot_stride + 1u + j);
+    const uint32_t i = pre[s] + j;
+    const float4 a = r[0], b = r[1], c = r[2];
+    rec.a[i] = a;
+    rec.b[i] = b;
+    rec.c[i] = c;
+    rec.key[i] = __float_as_uint(c.w);
+}
+
+// per-tile limits -> round-1 windows [0, limit)
+__global__ __launch_bounds__(256) void k_limits_to_windows(const uint32_t* __restrict__ limit, uint32_t n_tiles, uint2* __restrict__ win) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < n_tiles) win[t] = make_uint2(0u, limit[t]);
+}
+
+// Verification on the device, from the all-gathered saturation map (sat: one word per tile of the PADDED frame, 0 = still
+// open): a tile whose window was bounded and that is still open gets, in the second exchange, what it was refused:
+// [limit, inf); every other tile nothing.  limit == nullptr (the round had no windows): nothing to repair.
+// (the gathered map: per rank its band of rpr tile rows followed by kShardExtraWords statistics words)
+__device__ inline uint32_t sat_at(const uint32_t* __restrict__ sat, uint32_t tx, uint32_t ty, uint32_t tiles_x, uint32_t rpr) {
+    const uint32_t g = ty / rpr;
+    return sat[(size_t)g * (rpr * tiles_x + kShardExtraWords) + (ty - g * rpr) * tiles_x + tx];
+}
+
+__global__ __launch_bounds__(256) void k_shard_verify(const uint32_t* __restrict__ limit, const uint32_t* __restrict__ sat, uint32_t n_tiles,
+                                                       uint32_t tiles_x, uint32_t rpr, uint32_t world, uint2* __restrict__ win2,
+                                                       uint32_t* __restrict__ d_need, uint32_t* __restrict__ ticket,
+                                                       unsigned long long* __restrict__ host_verdict, uint32_t seq,
+                                                       uint32_t* __restrict__ need_bits) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    bool need = false;
+    if (t < n_tiles) {
+        const uint32_t lim = limit ? limit[t] : 0xFFFFFFFFu;
+        const uint32_t tx = t % tiles_x, ty = t / tiles_x;
+        need = lim < 0xFFFFFFFFu && sat_at(sat, tx, ty, tiles_x, rpr) == 0u;
+        win2[t] = need ? make_uint2(lim, 0xFFFFFFFFu) : make_uint2(0u, 0u);
+        if (need) atomicOr(&need_bits[ty * ((tiles_x + 31u) / 32u) + (tx >> 5)], 1u << (tx & 31u));
+    }
+    __shared__ uint32_t s_need;
+    if (threadIdx.x == 0) s_need = 0;
+    __syncthreads();
+    const unsigned long long bal = __ballot(need);
+    if ((threadIdx.x & 63u) == 0 && bal) atomicAdd(&s_need, (uint32_t)__popcll(bal));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_need) atomicAdd(d_need, s_need);
+        // The last block posts the verdict of round 0 to pinned host memory — the ONE thing the host waits for in a frame:
+        //   word 1 = {largest per-destination record count over all ranks | any rank's slot overflowed}
+        //   word 0 = {seq | tiles that need the repair round}     (release store: the host polls this one)
+        // Every input is globally gathered, so every rank posts the same verdict and takes the same decision.
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1u) {
+            const uint32_t total = __hip_atomic_load(d_need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t gmax = 0, over = 0;
+            for (uint32_t g = 0; g < world; ++g) {
+                const uint32_t* x = sat + (size_t)g * (rpr * tiles_x + kShardExtraWords) + rpr * tiles_x;
+                gmax = max(gmax, x[0]);
+                over |= x[1];
+            }
+            __hip_atomic_store(host_verdict + 1, ((unsigned long long)gmax << 32) | (over ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_verdict, ((unsigned long long)seq << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            *ticket = 0;
+        }
+    }
+}
+
+// Sizing the repair exchange: counts_all = per rank {records it has for its busiest destination, 0, 0, 0} (all-gathered);
+// the global maximum goes to the host — the exact slot size of the repair round, the same on every rank.
+__global__ __launch_bounds__(64) void k_shard_post_counts(const uint32_t* __restrict__ counts_all, uint32_t world,
+                                                           unsigned long long* __restrict__ host_verdict, uint32_t seq) {
+    uint32_t mx = threadIdx.x < world ? counts_all[4u * threadIdx.x] : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(host_verdict + 1, (unsigned long long)mx << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_verdict, (unsigned long long)seq << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// local maximum of the per-destination totals -> out[0..3] = {max, 0, 0, 0}
+__global__ __launch_bounds__(64) void k_shard_max_count(const uint32_t* __restrict__ totals, uint32_t world, uint32_t* __restrict__ out) {
+    uint32_t mx = threadIdx.x < world ? totals[threadIdx.x] : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    if (threadIdx.x < 4) out[threadIdx.x] = threadIdx.x == 0 ? mx : 0u;
+}
+
+// Next frame's per-tile depth-key limit from this frame's saturation keys: (1 + margin) x the deepest saturation depth in
+// the tile's (2 radius + 1)^2 neighbourhood — the camera moves — and unbounded if any tile of the neighbourhood stayed open
+// (parallel.next_limits is the numpy statement of the same policy).  Outside the frame counts as nothing.
+__global__ __launch_bounds__(256) void k_shard_next_limits(const uint32_t* __restrict__ sat, uint32_t tiles_x, uint32_t tiles_y, float gain,
+                                                            int radius, uint32_t* __restrict__ limit, uint32_t rpr) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= tiles_x * tiles_y) return;
+    const int tx = (int)(t % tiles_x), ty = (int)(t / tiles_x);
+    float deepest = 0.0f;
+    bool open = false;
+    for (int y = max(ty - radius, 0); y <= min(ty + radius, (int)tiles_y - 1); ++y)
+        for (int x = max(tx - radius, 0); x <= min(tx + radius, (int)tiles_x - 1); ++x) {
+            const uint32_t s = sat_at(sat, (uint32_t)x, (uint32_t)y, tiles_x, rpr);
+            if (s == 0u) open = true;
+            else deepest = fmaxf(deepest, __uint_as_float(s));
+        }
+    uint32_t out = 0xFFFFFFFFu;
+    if (!open) {
+        const float lim = deepest * gain;
+        out = (lim < 3.0e38f) ? max(__float_as_uint(lim), 1u) : 0xFFFFFFFFu;
+    }
+    limit[t] = out;
+}
+
+hipError_t launch_pack_headers(hipStream_t s, const uint32_t* totals, uint32_t world, uint32_t slot_stride, uint32_t slot_cap, void* d_send,
+                               SlabStats* stats, uint32_t round) {
+    hipLaunchKernelGGL(k_pack_headers, dim3(1), dim3(64), 0, s, totals, world, slot_stride, slot_cap, reinterpret_cast<float4*>(d_send), stats, round);
+    return hipGetLastError();
+}
+
+hipError_t launch_import_slots(hipStream_t s, const void* d_recv, uint32_t world, uint32_t slot_stride, uint32_t slot_cap, const Records& rec,
+                               SlabStats* stats) {
+    const uint64_t total = (uint64_t)world * slot_cap;
+    hipLaunchKernelGGL(k_import_slots, dim3((unsigned)std::max<uint64_t>((total + 255) / 256, 1)), dim3(256), 0, s,
+                       reinterpret_cast<const float4*>(d_recv), world, slot_stride, slot_cap, rec, stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_limits_to_windows(hipStream_t s, const uint32_t* limit, uint32_t n_tiles, uint2* win) {
+    hipLaunchKernelGGL(k_limits_to_windows, dim3((n_tiles + 255) / 256), dim3(256), 0, s, limit, n_tiles, win);
+    return hipGetLastError();
+}
+
+hipError_t launch_shard_verify(hipStream_t s, const uint32_t* limit, const uint32_t* sat, uint32_t tiles_x, uint32_t tiles_y, uint32_t rpr,
+                               uint32_t world, uint2* win2, uint32_t* d_need, uint32_t* d_ticket, unsigned long long* host_verdict, uint32_t seq,
+                               uint32_t* need_bits) {
+    const uint32_t n_tiles = tiles_x * tiles_y;
+    hipLaunchKernelGGL(k_shard_verify, dim3((n_tiles + 255) / 256), dim3(256), 0, s, limit, sat, n_tiles, tiles_x, rpr, world, win2, d_need,
+                       d_ticket, host_verdict, seq, need_bits);
+    return hipGetLastError();
+}
+
+hipError_t launch_shard_post_counts(hipStream_t s, const uint32_t* counts_all, uint32_t world, unsigned long long* host_verdict, uint32_t seq) {
+    hipLaunchKernelGGL(k_shard_post_counts, dim3(1), dim3(64), 0, s, counts_all, world, host_verdict, seq);
+    return hipGetLastError();
+}
+
+hipError_t launch_shard_max_count(hipStream_t s, const uint32_t* totals, uint32_t world, uint32_t* out4) {
+    hipLaunchKernelGGL(k_shard_max_count, dim3(1), dim3(64), 0, s, totals, world, out4);
+    return hipGetLastError();
+}
+
+hipError_t launch_shard_next_limits(hipStream_t s, const uint32_t* sat, uint32_t tiles_x, uint32_t tiles_y, float margin, uint32_t radius,
+                                    uint32_t* limit, uint32_t rpr) {
+    hipLaunchKernelGGL(k_shard_next_limits, dim3((tiles_x * tiles_y + 255) / 256), dim3(256), 0, s, sat, tiles_x, tiles_y, 1.0f + margin,
+                       (int)std::min<uint32_t>(radius, 16u), limit, rpr);
     return hipGetLastError();
 }
 

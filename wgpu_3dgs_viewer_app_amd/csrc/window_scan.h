@@ -120,4 +120,22 @@ __device__ inline bool pyramid_admits(const WindowPyramid& p, uint32_t key, uint
     return key < max(max(a, b), max(c, d));
 }
 
+// Destinations of a record by the pyramid alone: bit g set iff the part of the rectangle inside band g MAY hold a tile that
+// admits the key (four loads per band the rectangle touches, no walk over tiles).  A conservative superset of dest_mask —
+// allowed on the sending side of the exchange: the receiver bins every record by the exact per-tile windows, so a record
+// that travels in vain costs link bytes, never a pixel.  (The exact walk was the slowest kernel of a sharded frame: large
+// rectangles are scanned by the whole wave, one after the other.)
+__device__ inline unsigned long long dest_mask_pyramid(const WindowPyramid& p, uint32_t key, uint32_t rx, uint32_t ry, uint32_t rpr,
+                                                       uint32_t world) {
+    const uint32_t x0 = rx & 0xFFFFu, x1 = rx >> 16, y0 = ry & 0xFFFFu, y1 = ry >> 16;
+    if (key == kCulledKey || y0 >= y1 || x0 >= x1) return 0ull;
+    unsigned long long m = 0;
+    const uint32_t g0 = y0 / rpr, g1 = min((y1 - 1u) / rpr, world - 1u);
+    for (uint32_t g = g0; g <= g1; ++g) {
+        const uint32_t ya = max(y0, g * rpr), yb = min(y1, (g + 1u) * rpr);
+        if (ya < yb && pyramid_admits(p, key, rx, ya | (yb << 16))) m |= 1ull << g;
+    }
+    return m;
+}
+
 }  // namespace gsx

@@ -96,6 +96,126 @@ class HipStages:
         _lib.check(v._L.gsx_shard_set_windows(v._h, key.encode(), self._window_ptr(window, "_set_win_t")))
         v.preprocessor.preprocess(key)
 
+    # -- multi GPU, device-resident protocol (include/gsx.h): nothing below waits for the device or reads a count --
+    def _padded_framebuffer(self, world: int, rank: int):
+        import torch
+
+        v = self.viewer
+        lay = _lib.ShardLayout()
+        _lib.check(v._L.gsx_shard_layout(v._h, world, rank, C.byref(lay)))
+        n_floats = lay.padded_framebuffer_bytes // 4
+        if self._fb_t is None or self._fb_t.numel() != n_floats:
+            self._fb_t = torch.zeros(n_floats, dtype=torch.float32, device=f"cuda:{self.device}")
+            self._band_t = torch.empty(lay.band_bytes // 4, dtype=torch.float32, device=f"cuda:{self.device}")
+            self._fbk = None
+            _lib.check(v._L.gsx_viewer_set_external_framebuffer(v._h, self._fb_t.data_ptr(), lay.padded_framebuffer_bytes))
+        self._lay = lay
+
+    def frame_begin(self, key: str, world: int, rank: int, speculate: bool = True, limit=None) -> None:
+        """``gsx_shard_frame_begin``: windows from the limits the last frame left on the device (``limit``: numpy uint32
+        [tiles_y, tiles_x] to use instead — tests), then the projection of the resident shard."""
+        import torch
+
+        self._padded_framebuffer(world, rank)
+        v = self.viewer
+        d_lim = None
+        if limit is not None:
+            self._lim_t = torch.from_numpy(np.ascontiguousarray(limit, np.uint32).view(np.int32)).to(f"cuda:{self.device}", non_blocking=True)
+            d_lim = self._lim_t.data_ptr()
+        _lib.check(v._L.gsx_shard_frame_begin(v._h, key.encode(), world, rank, 1 if speculate else 0, d_lim))
+
+    def slot_records(self, key: str, world: int, shard_max: int) -> int:
+        """``gsx_shard_slot_records``: round 0's slot size — the same number on every rank (``shard_max`` = the largest shard
+        of the model; the figure behind the policy is the last verdict's global maximum)."""
+        t = C.c_uint32()
+        _lib.check(self.viewer._L.gsx_shard_slot_records(self.viewer._h, key.encode(), world, int(shard_max), C.byref(t)))
+        return int(t.value)
+
+    def pack_slots(self, key: str, world: int, rnd: int, slot: int):
+        """``gsx_shard_pack_slots`` -> float32 tensor [world, 1 + slot, 12]: slot g for rank g, header first."""
+        import torch
+
+        pool = self.__dict__.setdefault("_send_slots", {})
+        if pool.get(rnd) is None or pool[rnd].shape != (world, slot + 1, RECORD_FLOATS):
+            pool[rnd] = torch.empty((world, slot + 1, RECORD_FLOATS), dtype=torch.float32, device=f"cuda:{self.device}")
+        t = pool[rnd]
+        _lib.check(self.viewer._L.gsx_shard_pack_slots(self.viewer._h, key.encode(), world, rnd, t.data_ptr(), slot))
+        return t
+
+    def alloc_slots(self, world: int, slot: int, rnd: int):
+        import torch
+
+        pool = self.__dict__.setdefault("_recv_slots", {})
+        if pool.get(rnd) is None or pool[rnd].shape != (world, slot + 1, RECORD_FLOATS):
+            pool[rnd] = torch.empty((world, slot + 1, RECORD_FLOATS), dtype=torch.float32, device=f"cuda:{self.device}")
+        return pool[rnd]
+
+    def import_slots(self, key: str, recv, world: int, rank: int, rnd: int, slot: int) -> None:
+        """``gsx_shard_import_slots``: import (counts from the slot headers, on the device) + depth sort + render."""
+        _lib.check(self.viewer._L.gsx_shard_import_slots(self.viewer._h, key.encode(), recv.data_ptr(), world, rank, rnd, slot))
+
+    def alloc_sat(self, world: int, mine):
+        import torch
+
+        if getattr(self, "_sat_all", None) is None or self._sat_all.numel() != world * mine.numel():
+            self._sat_all = torch.zeros(world * mine.numel(), dtype=mine.dtype, device=mine.device)
+        return self._sat_all
+
+    def verify(self, key: str, world: int, sat_all) -> int:
+        """``gsx_shard_verify``: repair windows on the device; returns the sequence number of the verdict it will post."""
+        seq = C.c_uint32()
+        _lib.check(self.viewer._L.gsx_shard_verify(self.viewer._h, key.encode(), world, sat_all.data_ptr(), C.byref(seq)))
+        return int(seq.value)
+
+    def wait_verdict(self, key, seq: int) -> dict:
+        """``gsx_shard_wait_verdict``: the one host wait of a frame (two pinned words; no stream synchronisation)."""
+        out = _lib.ShardVerdict()
+        _lib.check(self.viewer._L.gsx_shard_wait_verdict(self.viewer._h, key.encode() if key else None, int(seq), C.byref(out)))
+        return dict(need_tiles=int(out.need_tiles), overflow=bool(out.overflow), max_records=int(out.max_records))
+
+    def repair_count(self, key: str, world: int):
+        """``gsx_shard_repair_count`` -> int32 tensor [4]: {records for this rank's busiest destination under the repair windows, 0, 0, 0}"""
+        import torch
+
+        if getattr(self, "_cnt4", None) is None:
+            self._cnt4 = torch.zeros(4, dtype=torch.int32, device=f"cuda:{self.device}")
+        _lib.check(self.viewer._L.gsx_shard_repair_count(self.viewer._h, key.encode(), world, self._cnt4.data_ptr()))
+        return self._cnt4
+
+    def alloc_counts(self, world: int):
+        import torch
+
+        if getattr(self, "_cnt_all", None) is None or self._cnt_all.numel() != 4 * world:
+            self._cnt_all = torch.zeros(4 * world, dtype=torch.int32, device=f"cuda:{self.device}")
+        return self._cnt_all
+
+    def post_counts(self, world: int, counts_all) -> int:
+        seq = C.c_uint32()
+        _lib.check(self.viewer._L.gsx_shard_post_counts(self.viewer._h, world, counts_all.data_ptr(), C.byref(seq)))
+        return int(seq.value)
+
+    def frame_end(self, key: str) -> None:
+        _lib.check(self.viewer._L.gsx_shard_frame_end(self.viewer._h, key.encode()))
+
+    def next_windows(self, key: str, world: int, sat_all, margin: float, radius: int) -> None:
+        _lib.check(self.viewer._L.gsx_shard_next_windows(self.viewer._h, key.encode(), world, sat_all.data_ptr(), float(margin), int(radius)))
+
+    def limits(self, key: str) -> np.ndarray:
+        """The per-tile limits the next frame will use (parity / debugging; synchronises)."""
+        w, h = self._size
+        tx, ty = (w + 15) // 16, (h + 15) // 16
+        out = np.empty((ty, tx), np.uint32)
+        _lib.check(self.viewer._L.gsx_shard_download_limits(self.viewer._h, key.encode(), out.ctypes.data_as(C.POINTER(C.c_uint32)), out.size))
+        return out
+
+    def render_frame_lib(self, key: str, shard_max: int, speculate: bool, margin: float, radius: int) -> None:
+        """``gsx_shard_render_frame``: the whole index-sharded frame inside the library (collectives over RCCL)."""
+        v = self.viewer
+        if self._fb_t is not None:   # the library gathers into a padded framebuffer of its own
+            _lib.check(v._L.gsx_viewer_set_external_framebuffer(v._h, None, 0))
+            self._fb_t = None
+        _lib.check(v._L.gsx_shard_render_frame(v._h, key.encode(), int(shard_max), 1 if speculate else 0, float(margin), int(radius)))
+
     def render_band(self, keys, world: int, rank: int) -> None:
         """Screen-band mode (the whole scene is resident on every GPU): render band `rank` of `world` into the padded
         framebuffer the bands are all-gathered into.  No record exchange; enqueued without host synchronisation."""

@@ -108,10 +108,62 @@ class TorchComm:
 
         dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=self.group)
 
+    def all_to_all_slots(self, recv, send):
+        """Fixed-size slots, equal split: slot p of `send` goes to rank p, slot p of `recv` comes from rank p."""
+        import torch.distributed as dist
+
+        dist.all_to_all_single(recv, send, group=self.group)
+
     def all_gather(self, out, inp):
         import torch.distributed as dist
 
         dist.all_gather_into_tensor(out, inp, group=self.group)
+
+
+class LibComm(TorchComm):
+    """The product transport: the collectives of the index-sharded frame run INSIDE libgsx over RCCL
+    (``gsx_comm_all_to_all`` / ``gsx_comm_all_gather``, include/gsx.h), one communicator per viewer, bootstrapped like any
+    NCCL program — rank 0 draws the unique id, ``torch.distributed`` only carries those 128 bytes to the other ranks.
+    With it ``ShardedViewer`` renders an index-sharded frame through ONE library call, ``gsx_shard_render_frame``."""
+
+    def __init__(self, stages, world, rank, group=None):
+        super().__init__(group)
+        import ctypes as C
+
+        from . import _lib
+
+        self._v = stages.viewer
+        self._stream = stages.torch_stream
+        L = self._v._L
+        ident = [None]
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            _lib.check(L.gsx_comm_unique_id(buf))
+            ident[0] = bytes(buf)
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.broadcast_object_list(ident, src=0, group=group)
+        buf = (C.c_uint8 * 128).from_buffer_copy(ident[0])
+        _lib.check(L.gsx_viewer_comm_init(self._v._h, world, rank, buf))
+
+    def _on_viewer_stream(self):
+        import torch
+
+        return self._stream is None or torch.cuda.current_stream().cuda_stream == self._stream.cuda_stream
+
+    def all_to_all_slots(self, recv, send):
+        from . import _lib
+
+        per_peer = send.numel() * send.element_size() // send.shape[0]
+        _lib.check(self._v._L.gsx_comm_all_to_all(self._v._h, send.data_ptr(), recv.data_ptr(), per_peer))
+
+    def all_gather(self, out, inp):
+        from . import _lib
+
+        if not self._on_viewer_stream():   # an overlapped gather on the caller's second stream: torch's communicator
+            return super().all_gather(out, inp)
+        _lib.check(self._v._L.gsx_comm_all_gather(self._v._h, inp.data_ptr(), out.data_ptr(), inp.numel() * inp.element_size()))
 
 
 class ShardedViewer:
@@ -146,25 +198,30 @@ class ShardedViewer:
         self._comm_stream = None
         self._gather_done = [None, None]
         self.world, self.rank, self.use_dist = world, rank, use_dist
-        self.comm = comm if comm is not None else TorchComm(group)  # injectable: tests drive `world` ranks as threads
         if stages is None:
             from .hip_stages import HipStages  # the product path: libgsx.so, fails loudly if missing
 
             stages = HipStages(device=device, stream=stream, use_torch=use_dist, sh=sh, cov3d=cov3d)
         self.stages = stages
+        # the transport is injectable (tests drive `world` ranks as threads of one process, or over gloo on CPU); "lib" = the
+        # collectives inside libgsx over RCCL, the index-sharded frame as one library call
+        self.comm = LibComm(stages, world, rank, group) if comm == "lib" else (comm if comm is not None else TorchComm(group))
         if mode == "frames" and world >= 4 and hasattr(stages, "viewer"):
             # a rank's previous frame is `world` poses back: wider windows (measured on cfg4, one GPU rendering every 8th / 4th
             # pose: margin 0.25 / radius 3 -> 638 / 869 fps, every frame needs the repair round at 8; 0.5 / 6 -> 765 / 936)
             stages.viewer.set_render_options(spec_margin=0.5, spec_radius=6)
-        self._limit = None  # uint32 [tiles_y, tiles_x]: per-tile depth-key limit of the next frame; None = everything travels
+        self._limit = None  # uint32 [tiles_y, tiles_x]: limits to use INSTEAD of the ones the last frame left on the device (tests); consumed by the next frame
         self.speculate = True
         # measured on cfg4 at 8 ranks (tools/emulate_ranks.py): margin 0.5 / radius 3 moves 3.6 MB per rank and frame instead
         # of 51.6 MB and needs the second exchange in 18 % of the frames (tiles that open up from nothing: unpredictable)
-        self.margin = 0.5   # how far behind last frame's saturation depth a tile still takes records
+        self.margin = 0.25  # how far behind last frame's saturation depth a tile still takes records (world 1 over RCCL, cfg4:
+                            # 962 / 1044 / 1066 fps at 0.5 / 0.35 / 0.25 — the repair round is sized exactly, so a tighter
+                            # window costs a repair now and then, never a truncated slot)
         self.radius = 3     # tiles; neighbourhood over which the saturation depth is maximised (camera motion)
-        self.rounds = 0
+        self._rounds_host = None
+        self.force_slot = None   # tests: a round-0 slot size instead of the library's policy (to provoke the overflow redo)
+        self.last_verdict = None
         self.keys = []      # models in load order
-        self.debug, self.debug_log = False, []
         self.profile = None  # set to {} to collect host wall time per protocol section (adds device syncs)
         self._size = (1, 1)
 
@@ -172,6 +229,8 @@ class ShardedViewer:
     def load_shard(self, gaussians: np.ndarray, start: int, n_total: int, key: str | None = None) -> None:
         """This rank's index shard [start, start + len) of model ``key`` (several models: call once per key)."""
         key = key or self.KEY
+        self._shard_max = getattr(self, "_shard_max", {})
+        self._shard_max[key] = (int(n_total) + self.world - 1) // self.world if self.mode == "index" else int(n_total)
         self.stages.load_shard(key, gaussians, start, n_total)
         if key not in self.keys:
             self.keys.append(key)
@@ -241,16 +300,6 @@ class ShardedViewer:
         self.comm.all_to_all_records(recv, send[: sum(send_counts)], recv_counts, send_counts)
         return recv, sum(recv_counts)
 
-    def _feedback(self, key, tiles_x, tiles_y):
-        """Saturation depth key of every tile of the frame (0 = open): each rank contributes its band, one small
-        all-gather; the result is identical on every rank."""
-        import torch
-
-        mine = self.stages.feedback(key, self.world, self.rank)
-        allw = torch.empty(self.world * mine.numel(), dtype=mine.dtype, device=mine.device)
-        self.comm.all_gather(allw, mine)
-        return allw.cpu().numpy().view(np.uint32).reshape(-1, tiles_x)[:tiles_y]
-
     def _tick(self, name):
         """Dev aid (self.profile = {}): host wall time per protocol section, with a device sync at every boundary."""
         if self.profile is None:
@@ -263,55 +312,83 @@ class ShardedViewer:
         self._t_last = now
 
     def _render_frame_dist(self, key):
-        st = self.stages
+        """One index-sharded frame, device-resident protocol (include/gsx.h "multi-GPU, device-resident protocol"): every stage
+        call enqueues, every collective moves fixed-size buffers, and the host waits for ONE thing — the verdict of round 0,
+        two pinned words every rank derives from the same gathered data — while the band all-gather is already running.
+        With the library transport the whole sequence is ONE call, gsx_shard_render_frame, which runs exactly these steps."""
+        st, comm = self.stages, self.comm
         world, rank = self.world, self.rank
-        tiles_x, tiles_y = (self._size[0] + 15) // 16, (self._size[1] + 15) // 16
         if self.profile is not None:
             import time
 
             st.poll()
             self._t_last = time.perf_counter()
-        # every tile takes the records in front of its limit (first frame / speculation off: everything)
-        limit = self._limit if self.speculate else None
-        if limit is not None and limit.shape != (tiles_y, tiles_x):
-            limit = None
-        win = windows_first(limit) if limit is not None else None
-        # stage P: project the resident shard; knowing the windows, it shades only what can travel
-        st.begin_frame(key, world, rank, win)
+        limit, self._limit = self._limit, None
+        self._rounds_host = None
+        shard_max = self._shard_max[key]
+        if isinstance(comm, LibComm) and limit is None and self.profile is None and self.force_slot is None:
+            st.render_frame_lib(key, shard_max, self.speculate, self.margin, self.radius)
+            return
+
+        def exchange_round(rnd, slot):
+            send = st.pack_slots(key, world, rnd, slot)
+            self._tick("pack")
+            recv = st.alloc_slots(world, slot, rnd)
+            comm.all_to_all_slots(recv, send)                # stage X: fixed slots, the counts ride in the headers
+            self._tick("exchange")
+            st.import_slots(key, recv, world, rank, rnd, slot)   # stage C: import + depth sort + this rank's band
+            self._tick("import_sort_render")
+            mine = st.feedback(key, world, rank)
+            sat_all = st.alloc_sat(world, mine)
+            comm.all_gather(sat_all, mine)                   # verification AND the source of the next frame's limits
+            self._tick("feedback")
+            return sat_all
+
+        def finish(sat_all):
+            st.next_windows(key, world, sat_all, self.margin, self.radius)
+            # stage M: the disjoint bands of tile rows are all-gathered straight into the framebuffer
+            comm.all_gather(st.gather_target(), st.own_band())
+            self._tick("gather")
+
+        # stage P: windows [0, limit) from last frame's limits (first frame / speculation off: none), project the shard
+        st.frame_begin(key, world, rank, self.speculate, limit)
         self._tick("project")
-        # stage X/C
-        send, counts = st.pack(key, world, None)
-        self._tick("pack")
-        recv, n = self._exchange(send, counts)
-        self._tick("exchange")
-        st.render_records(key, recv, n, world, rank, more=False, window=win)
-        self._tick("import_sort_render")
-        # verification + next frame's limits from one collective
-        sat = self._feedback(key, tiles_x, tiles_y)
-        self._tick("feedback")
-        self.rounds = 1
-        if limit is not None:
-            need = (limit < KEY_ALL) & (sat == 0)  # refused its deep records but still open
-            if need.any():
-                win2 = windows_second(limit, need)
-                send, counts = st.pack(key, world, win2)
-                recv, n = self._exchange(send, counts)
-                st.render_records(key, recv, n, world, rank, more=True, window=win2)
-                sat = self._feedback(key, tiles_x, tiles_y)
-                self.rounds = 2
-                self._tick("second_round")
-                if self.debug:  # what the wrong limits looked like (dev tool)
-                    s2 = sat[need]
-                    lim_d = limit[need].view(np.float32)
-                    ratio = np.where(s2 != 0, s2.view(np.float32) / lim_d, np.float32(np.inf))
-                    self.debug_log.append(dict(need=int(need.sum()), stayed_open=int((s2 == 0).sum()),
-                                               ratio_median=float(np.median(ratio)), ratio_max=float(ratio[np.isfinite(ratio)].max(initial=0)),
-                                               rows=np.unique(np.nonzero(need)[0]).tolist()))
-        self._limit = next_limits(sat, self.margin, self.radius)
-        self._tick("policy")
-        # stage M: the disjoint bands of tile rows are all-gathered straight into the framebuffer
-        self.comm.all_gather(st.gather_target(), st.own_band())
-        self._tick("gather")
+        slot = self.force_slot if self.force_slot is not None else st.slot_records(key, world, shard_max)
+        for attempt in (0, 1):
+            sat_all = exchange_round(0, slot)
+            seq = st.verify(key, world, sat_all)             # repair windows on the device; posts the verdict
+            finish(sat_all)                                  # enqueued BEFORE the wait: what follows when all is well
+            verdict = st.wait_verdict(key, seq)              # the frame's one host wait
+            if not verdict["overflow"]:
+                break
+            if attempt == 1:
+                raise RuntimeError(f"an exchange slot of {slot} records (a whole shard) overflowed")
+            slot = shard_max                                 # a destination can be sent at most a whole shard: always fits
+        self.last_verdict = verdict
+        if verdict["need_tiles"]:
+            mine = st.repair_count(key, world)               # the repair round is sized exactly: count, gather, post, wait
+            counts_all = st.alloc_counts(world)
+            comm.all_gather(counts_all, mine)
+            sized = st.wait_verdict(None, st.post_counts(world, counts_all))
+            sat_all = exchange_round(1, max(sized["max_records"], 1))
+            finish(sat_all)
+            self._rounds_host = 2
+        else:
+            self._rounds_host = 1
+        st.frame_end(key)
+
+    @property
+    def rounds(self):
+        """Exchange rounds of the last index-sharded frame (the library call does not tell the host: statistics, synchronises)."""
+        if not self.use_dist or self.mode != "index":
+            return 0
+        if self._rounds_host is not None:
+            return self._rounds_host
+        return 2 if self.last_stats().get("n_repair_tiles", 0) > 0 else 1
+
+    @rounds.setter
+    def rounds(self, value):
+        self._rounds_host = value if value else None
 
     def skip_frame(self) -> None:
         """mode "frames": this rank has no frame in the round (the job's frame count is not a multiple of the GPU count) but
