@@ -373,7 +373,7 @@ gsx_status gsx_render_frame(gsx_viewer* v, const char* const* keys, uint32_t n_k
     for (uint32_t i = 0; i < n_keys; ++i) {
         Model* m = find_model(v, keys ? keys[i] : nullptr);
         if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_render_frame: no model '%s'", keys && keys[i] ? keys[i] : "(null)");
-        if ((st = do_preprocess(v, m))) return st;
+        if ((st = do_preprocess(v, m, true))) return st;  // the sort's admission scan sums N_vis: one launch less
         if ((st = do_sort(v, m))) return st;
     }
     return do_render(v, keys, n_keys);

@@ -64,16 +64,24 @@ static gsx_status wait_verdict(gsx_viewer* v, uint32_t seq, uint32_t* need) {
 // A sample of how the speculation is doing (whenever statistics reach the host; never waited for).  A frame that needed
 // the repair round although its windows admitted more than 7/8 of what was visible gained nothing from speculating
 // (sparse scenes whose tiles hover around saturation: cfg2 admits 93 % and repairs 94 % of its frames, and the plain
-// progressive path is 6 % faster there; cfg3/cfg4 admit 76 % / 40 % and win 1.4x / 1.8x even when they repair).  When
-// 7 of the last 8 samples were like that, render 48 frames without, then try again.  The windows are kept up to date
-// meanwhile, and either path gives the same pixels.
+// progressive path is faster there; cfg3/cfg4 admit 76 % / 40 % and win 1.4x / 1.8x even when they repair).  When
+// four samples in a row were like that, render 48 frames without, then try again — 96, 192 ... if the retry fails as well.
+// The windows are kept up to date meanwhile, and either path gives the same pixels.
 static void note_speculation_outcome(Model* m, bool repaired) {
 
     const bool useless = repaired && (uint64_t)m->h_counters->n_sorted * 8 > (uint64_t)m->h_counters->n_visible * 7;
     m->spec_repair_history = (m->spec_repair_history << 1) | (useless ? 1u : 0u);
-    if (__builtin_popcount(m->spec_repair_history & 0xFFu) >= 7) {
-        m->spec_pause = 48;
+    m->spec_samples += 1;
+    // (samples arrive every fourth frame: four in a row are sixteen frames at a loss already.  The pause doubles while the
+    // retries keep failing — 48, 96, ... 1536 frames — and starts over once speculating pays again: a scene like cfg2 spent
+    // 40 % of its frames speculating at a loss with a fixed 7-of-8 / 48-frame rule.)
+    if (m->spec_samples >= 4 && (m->spec_repair_history & 0xFu) == 0xFu) {
+        m->spec_pause = m->spec_pause_len;
+        m->spec_pause_len = std::min<uint32_t>(2 * m->spec_pause_len, 1536u);
         m->spec_repair_history = 0;
+        m->spec_samples = 0;
+    } else if (!useless) {
+        m->spec_pause_len = 48;
     }
 }
 
@@ -110,6 +118,7 @@ gsx_status finish_frame(gsx_viewer* v) {
             m->n_visible = m->h_counters->n_visible;
             m->n_sorted = m->h_counters->n_sorted;
             m->n_sorted2 = m->h_counters->n_sorted2;
+
             m->n_entries = m->h_counters->n_entries_total;
             m->counters_valid = true;
             if (m->binned) m->slabs_hint = m->h_counters->slabs_used;
@@ -207,7 +216,7 @@ gsx_status ensure_edit_buffers(gsx_viewer* v, Model* m) {
     return GSX_OK;
 }
 
-gsx_status do_preprocess(gsx_viewer* v, Model* m) {
+gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
     frame_consts_setup(v->view, v->proj, v->width, v->height, m->mt, v->size, v->display_mode, v->sh_deg, v->no_sh0,
                        v->params, &m->fc);
     m->fc.band_lo = std::min(v->band_lo, m->fc.tiles_y);
@@ -264,7 +273,9 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m) {
         HIPCHK(launch_project(v->stream, m->fc, n32, pod, m->proj_rec(), m->block_vis.as<uint32_t>(), adm));
         v->pass_launches[GSX_PASS_PROJECT] += m->n ? 1 : 0;
     }
-    HIPCHK(launch_sum_counts(v->stream, m->block_vis.as<uint32_t>(), n32, &m->counters.as<Counters>()->n_visible));
+    // N_vis: summed by the admission scan when a compaction follows anyway (gsx_render_frame, a lazily projected shard)
+    m->visible_count_pending = defer_visible_count || shard_lazy;
+    if (!m->visible_count_pending) HIPCHK(launch_sum_counts(v->stream, m->block_vis.as<uint32_t>(), n32, &m->counters.as<Counters>()->n_visible));
     if (shard_lazy) {
         // the candidates of the coming exchange (a conservative superset of the travellers): compact them and give
         // exactly those their conic / colour records; gsx_shard_pack then looks at nothing else
@@ -273,7 +284,8 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m) {
         HIPCHK(m->adm_offsets.ensure(m->adm_counts.bytes));
         HIPCHK(launch_admit_from_project(v->stream, m->proj_rec().key, n32, m->adm_ballots.as<unsigned long long>(),
                                          m->adm_counts.as<uint32_t>(), m->adm_offsets.as<uint32_t>(), &dcx->n_candidates,
-                                         m->adm_pairs.as<uint2>(), true));
+                                         m->adm_pairs.as<uint2>(), true, m->block_vis.as<uint32_t>(), &dcx->n_visible));
+        m->visible_count_pending = false;
         if (m->lazy) HIPCHK(launch_shade(v->stream, m->fc, n32, pod, m->proj_rec(), LateProjection{m->adm_pairs.as<uint2>(), &dcx->n_candidates, nullptr}));
         m->cand_valid = true;
     }
@@ -319,6 +331,11 @@ gsx_status complete_records(gsx_viewer* v, Model* m) {
     return GSX_OK;
 }
 
+// (A single-launch depth sort for the ~0.3 M pairs of a speculated frame — one persistent grid, device-wide barriers between
+// the digit passes — was built and measured this round: 146 us against 66 us for one launch per digit at 0.3 M pairs, 499
+// against 95 at 1 M.  Seven grid barriers plus the per-tile offset lookups cost more than the five kernel boundaries they
+// replace, and a persistent grid that needs every workgroup resident is a deadlock risk next to other streams.  Not shipped.)
+
 // force_full: ignore the admission the projection pass made (a speculated frame being redone) and sort every visible record
 gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
     if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_sort('%s') before gsx_preprocess", m->key.c_str());
@@ -333,10 +350,17 @@ gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
             HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted, 32, true));  // n: an upper bound (slot import); the count is on the device
         } else {
             // compact the (key, index) pairs the projection pass admitted, then sort only those
+            // (counting the sort's digit histograms inside the compaction / tile-emit kernels — LDS atomics where the pairs are
+            // written, one flush per workgroup — removes two histogram launches per frame and was measured: 1200 vs 1198 fps
+            // speculated, 602 vs 613 unspeculated on cfg4; the counting costs what the histogram kernels cost.  Not kept.)
             HIPCHK(m->adm_pairs.ensure(8 * std::max<size_t>(n, 1)));
             if (force_full) {
                 gsx_status stc = complete_records(v, m);
                 if (stc) return stc;
+                if (m->visible_count_pending) {
+                    HIPCHK(launch_sum_counts(v->stream, m->block_vis.as<uint32_t>(), n, &dc->n_visible));
+                    m->visible_count_pending = false;
+                }
                 m->spec_round1 = false;
                 HIPCHK(m->adm_ballots2.ensure(8 * ((std::max<size_t>(n, 1) + 63) / 64)));
                 HIPCHK(m->adm_counts2.ensure(4 * (std::max<size_t>(admit_blocks(n), 1) + 4)));
@@ -347,7 +371,9 @@ gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
                 HIPCHK(m->adm_offsets.ensure(m->adm_counts.bytes));
                 HIPCHK(launch_admit_from_project(v->stream, m->proj_rec().key, n, m->adm_ballots.as<unsigned long long>(),
                                                  m->adm_counts.as<uint32_t>(), m->adm_offsets.as<uint32_t>(), &dc->n_sorted,
-                                                 m->adm_pairs.as<uint2>(), m->spec_round1));
+                                                 m->adm_pairs.as<uint2>(), m->spec_round1,
+                                                 m->visible_count_pending ? m->block_vis.as<uint32_t>() : nullptr, &dc->n_visible));
+                m->visible_count_pending = false;
                 if (m->lazy) {  // the projection pass was geometry only: shade what it admitted
                     PodPlanes pod = m->pod();
                     pod.mask = m->last_pod_mask;

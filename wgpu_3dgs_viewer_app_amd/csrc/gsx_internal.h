@@ -200,7 +200,9 @@ hipError_t launch_window_pyramid(hipStream_t s, const uint2* window, uint32_t ti
 // (key, index) pairs in ascending index order
 hipError_t launch_admit_from_project(hipStream_t s, const uint32_t* key, uint32_t n, const unsigned long long* ballots,
                                      const uint32_t* block_counts, uint32_t* block_offsets, uint32_t* d_total, uint2* pairs,
-                                     bool sparse /* a few per cent admitted (windows): one lane per ballot word */);
+                                     bool sparse /* a few per cent admitted (windows): one lane per ballot word */,
+                                     const uint32_t* block_visible = nullptr /* + sum these into *d_n_visible (saves k_sum_counts) */,
+                                     uint32_t* d_n_visible = nullptr);
 
 // Admission pass (kernels_admit.hip): compacts the (key, index) pairs of the records the depth sort takes, ascending
 // index; window == nullptr admits every visible record.  *d_total = number of pairs.  d_skip (nullable): when it

@@ -109,6 +109,8 @@ struct Model {
     // statistics keep a history of "this frame needed the repair round"; too many -> unspeculated frames for a while
     uint32_t spec_repair_history = 0;  // bit k: the k-th latest sampled speculated frame repaired although it admitted nearly everything
     uint32_t spec_pause = 0;           // frames left to render unspeculated
+    uint32_t spec_pause_len = 48;      // length of the next pause (doubles while the retries keep failing)
+    uint32_t spec_samples = 0;         // samples since the last pause
     // host_verify = 2 (auto): ask the device for its verdict only while repairs are rare
     bool hv_active = true;             // currently asking
     uint32_t hv_history = 0;           // bit k: the k-th latest verdict needed the repair round
@@ -129,6 +131,7 @@ struct Model {
                                                // figure from that frame's verdict, so every rank sizes the next slots identically; 0 = unknown
     DevBuf adm_ballots2;           // the repair round's ballots (the first round's stay: they say which records are shaded)
     bool lazy = false;             // this frame's projection shaded only the admitted Gaussians
+    bool visible_count_pending = false;  // N_vis of this projection has not been summed yet (the admission scan will)
     const uint32_t* last_pyramid = nullptr;  // the admission pyramid the projection pass used
     uint32_t* last_pod_mask = nullptr;  // the keep-bitset the projection pass used (mask, or mask & ~hidden)
     DevBuf adm_offsets, adm_counts2;  // scan output of adm_counts; counts of the admission passes that run outside the projection
@@ -287,7 +290,8 @@ inline gsx_status ensure_fb(gsx_viewer* v) {
 inline float4* fb_ptr(gsx_viewer* v) { return v->ext_fb ? static_cast<float4*>(v->ext_fb) : reinterpret_cast<float4*>(v->fb.p); }
 
 // ---- frame scheduling (gsx_frame.cpp) ----
-gsx_status do_preprocess(gsx_viewer* v, Model* m);
+// defer_visible_count: a gsx_sort of this model follows at once (gsx_render_frame): its admission scan sums N_vis
+gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count = false);
 // force_full: ignore the admission the projection pass made (a speculated frame being redone) and sort every visible record
 gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full = false);
 // cont: a second round of the same frame (multi-GPU repair exchange): keep the framebuffer and the saturated-tile state

@@ -81,13 +81,29 @@ __global__ __launch_bounds__(kAdmitThreads) void k_admit_scatter(const uint32_t*
 // ---- compaction straight from the projection pass (its ballots: one word per wave, counts per 256-Gaussian workgroup) ----
 // one workgroup: exclusive scan of counts[0..nblocks) in place, total -> *d_total
 // (counts stay as the projection pass wrote them: a model may be sorted again without being projected again)
+// visible / d_n_visible (nullable): the projection pass's per-workgroup VISIBLE counts are summed on the way (N_vis is a
+// statistic only; when a sort follows the projection this saves k_sum_counts' launch)
 __global__ __launch_bounds__(1024) void k_admit_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets, uint32_t nblocks,
-                                                     uint32_t* __restrict__ d_total) {
+                                                     uint32_t* __restrict__ d_total, const uint32_t* __restrict__ visible,
+                                                     uint32_t* __restrict__ d_n_visible) {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry_s;
+    __shared__ uint32_t vis_s[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid == 0) carry_s = 0;
+    if (visible) {
+        uint32_t s = 0;
+        for (uint32_t b = tid; b < nblocks; b += 1024) s += visible[b];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (lane == 0) vis_s[wave] = s;
+    }
     __syncthreads();
+    if (visible && tid == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < 16; ++w) t += vis_s[w];
+        *d_n_visible = t;
+    }
     // coalesced 4096-wide tiles (one uint4 per lane; the buffer is padded to a multiple of 4), carry between them
     for (uint32_t base = 0; base < nblocks; base += 4096) {
         const uint32_t i = base + 4u * tid;
@@ -159,10 +175,13 @@ __global__ __launch_bounds__(256) void k_admit_scatter_dense(const uint32_t* __r
 
 hipError_t launch_admit_from_project(hipStream_t s, const uint32_t* key, uint32_t n, const unsigned long long* ballots,
                                      const uint32_t* block_counts, uint32_t* block_offsets, uint32_t* d_total, uint2* pairs,
-                                     bool sparse) {
+                                     bool sparse, const uint32_t* block_visible, uint32_t* d_n_visible) {
     const uint32_t nb = (n + 255) / 256;
-    if (!nb) return hipMemsetAsync(d_total, 0, 4, s);
-    hipLaunchKernelGGL(k_admit_scan, dim3(1), dim3(1024), 0, s, block_counts, block_offsets, nb, d_total);
+    if (!nb) {
+        if (block_visible) (void)hipMemsetAsync(d_n_visible, 0, 4, s);
+        return hipMemsetAsync(d_total, 0, 4, s);
+    }
+    hipLaunchKernelGGL(k_admit_scan, dim3(1), dim3(1024), 0, s, block_counts, block_offsets, nb, d_total, block_visible, d_n_visible);
     const uint32_t words = (n + 63) / 64;
     if (sparse)
         hipLaunchKernelGGL(k_admit_scatter256, dim3((words + 255) / 256), dim3(256), 0, s, key, words, ballots, block_offsets, pairs);

@@ -11,6 +11,8 @@
 // VALU / LDS bound, not HBM bound; algorithmic bytes D*40 + W*H*16.
 //
 // The support decision uses exactly the oracle's operation order (spec §6): explicit fmaf, no contraction.
+#include <algorithm>
+
 #include "gsx_internal.h"
 
 namespace gsx {
@@ -228,10 +230,13 @@ __global__ __launch_bounds__(128) void k_composite_spill(const FrameConsts f, co
     __shared__ float4 s_conic[128 + kGroup];
     __shared__ float4 s_rgb[128 + kGroup];
     __shared__ uint32_t s_sat, s_w[2];
-    const uint32_t tile = blockIdx.x;
+    // a fixed, small grid strides over the tiles: the launch that finds nothing to do (every frame but the rare one that
+    // overflowed) costs a kernel boundary, not the dispatch of one workgroup per tile (4.5 -> ~3 us at 1080p)
+    for (uint32_t tile = blockIdx.x; tile < f.tiles_x * f.tiles_y; tile += gridDim.x) {
+    __syncthreads();  // the previous tile's LDS batch and s_sat are done with
     const uint32_t tx = tile % f.tiles_x, ty = tile / f.tiles_x;
-    if (ty < row_lo || ty >= row_hi) return;
-    if (done_bits && ((done_bits[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)) return;
+    if (ty < row_lo || ty >= row_hi) continue;
+    if (done_bits && ((done_bits[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)) continue;
     const uint2 win = window ? window[tile] : make_uint2(0u, 0xFFFFFFFFu);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t px = tx * kTile + (tid & 15u), py = ty * kTile + 2u * (tid >> 4);
@@ -300,6 +305,7 @@ __global__ __launch_bounds__(128) void k_composite_spill(const FrameConsts f, co
             if (tile_sat) tile_sat[tile] = max(s_sat, 1u);
         }
     }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_clear_fb(float4* __restrict__ fb, uint32_t n) {
@@ -339,7 +345,7 @@ hipError_t launch_composite_spill(hipStream_t s, const FrameConsts& f, const Sla
                                   const uint32_t* sorted_idx, const uint32_t* sorted_keys, const Records& rec, float4* fb,
                                   uint32_t* done, uint32_t row_words, uint32_t* d_done_count, uint32_t* tile_sat, uint32_t row_lo,
                                   uint32_t row_hi, const uint2* window) {
-    dim3 grid(f.tiles_x * f.tiles_y), block(128);
+    dim3 grid(std::min<uint32_t>(f.tiles_x * f.tiles_y, 2048u)), block(128);
     if (f.display_mode == GSX_DISPLAY_SPLAT)
         hipLaunchKernelGGL(k_composite_spill<0>, grid, block, 0, s, f, stats, j1, d_n, sorted_idx, sorted_keys, rec.a, rec.b, rec.c, fb, done,
                            row_words, d_done_count, tile_sat, row_lo, row_hi, window);
