@@ -390,15 +390,16 @@ def main():
         def roofline_of(ac, tm, label_full):
             """Projection kernel of one timed loop.  ALGORITHMIC bytes per launch (means over the accounting frames):
             full kernel (every visible Gaussian shaded in the kernel): SURVEY 8d, N*pod + N_vis*40;
-            geometry-only kernel of speculated frames: N*(16 pos+rgba8 + 4 key + 1/8 ballot) + N_vis*(cov + 16 mean/rect) — the
-            SH planes and the conic / colour records are k_shade's, for the few admitted Gaussians."""
+            geometry-only kernel of speculated frames: N*(16 pos+rgba8 + 4 key + 4 packed tile rectangle + 1/8 ballot) + N_vis*cov —
+            the SH planes and the mean / conic / colour records are k_shade's, for the few admitted Gaussians."""
             n_loc, nvis_loc, spec_frac = ac[:, 0].mean(), ac[:, 1].mean(), ac[:, 3].mean()
             lazy = spec_frac > 0.5
             if lazy:
-                b = n_loc * 20.125 + nvis_loc * (16 + cov_bytes)
+                rect8 = (w + 15) // 16 <= 255 and (h + 15) // 16 <= 255   # packed 4-byte rectangles (Records::rect8) up to 255 x 255 tiles
+                b = n_loc * 24.125 + nvis_loc * cov_bytes if rect8 else n_loc * 20.125 + nvis_loc * (16 + cov_bytes)
                 kernel = (f"k_project_geom<{cov_kind},1> (projection of a speculated frame: cov2d + cull + depth key + admission; SH colour "
                           "is evaluated by k_shade for the admitted Gaussians only)")
-                definition = "geometry-only projection: N*20.125 + N_vis*(16+cov)"
+                definition = "geometry-only projection: N*24.125 + N_vis*cov" if rect8 else "geometry-only projection: N*20.125 + N_vis*(16+cov)"
             else:
                 b = n_loc * pod_bytes + nvis_loc * 40
                 kernel = f"k_project<{sh},{sh_kind},{cov_kind}> ({label_full})"

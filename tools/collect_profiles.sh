@@ -1,27 +1,33 @@
 #!/bin/bash
 # Collects the per-round evidence under gpurun_out/<round>/ on the GPU box (run through gpurun); copy the summaries into
-# profiles/ afterwards (tools/collect_profiles.sh r01 && cp ...).  rocprofv3 wraps python3 directly (no env / bash hop).
+# profiles/ afterwards.  rocprofv3 wraps python3 directly (no env / bash hop).  usage: tools/collect_profiles.sh r02
 set -u
-R=${1:-r01}
+R=${1:-r02}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-# 1. kernel trace + stats of the default bench command (speculated steady state) and of the unspeculated path
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/kt_bench.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_nospec -o kt -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --render-options speculative=0 > $OUT/kt_nospec_bench.log 2>&1
-# 2. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (they do not fit one), kernel trace only
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o p -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline > $OUT/pmc_$c.log 2>&1
-done
-python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_summary.csv $OUT/pmc_traffic.json cfg4:1:k_project
-cp $OUT/pmc_traffic.json profiles/pmc_traffic.json
-# 3. the bench lines
+# 1. the bench line exactly as the driver runs it (PMC child passes, both timed loops, frame check, robustness legs, full CPU baseline)
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
-python3 bench.py --no-cpu-baseline --pass-timing all > $OUT/bench_all_passes.json 2>> $OUT/bench.err
-python3 bench.py --no-cpu-baseline --render-options speculative=0 --pass-timing all > $OUT/bench_nospec.json 2>> $OUT/bench.err
-for w in cfg2 cfg3; do python3 bench.py --workload $w --no-cpu-baseline > $OUT/bench_$w.json 2>> $OUT/bench.err; done
-python3 bench.py --pod half/half --no-cpu-baseline > $OUT/bench_half_half.json 2>> $OUT/bench.err
-python3 bench.py --pod norm8/half --no-cpu-baseline > $OUT/bench_norm8_half.json 2>> $OUT/bench.err
-python3 tools/kernel_breakdown.py $OUT/kt 174 > $OUT/kt_breakdown.txt
-python3 tools/kernel_breakdown.py $OUT/kt_nospec 174 > $OUT/kt_nospec_breakdown.txt
-tail -n +1 $OUT/bench.json | cut -c1-400
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2>> $OUT/bench.err
+# 2. kernel trace + stats of the same command (both timed loops are in it: k_project<3,0,0> and k_project_geom averages must agree
+#    with roofline.avg_launch_us / roofline_speculated.avg_launch_us of the line above)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --no-cpu-baseline --no-pmc > $OUT/kt_bench.log 2>&1
+# 3. per-frame kernel breakdowns of the speculated and of the unspeculated loop alone
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_spec -o kt -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-pmc --render-options speculative=1 > $OUT/kt_spec.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_nospec -o kt -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-pmc --render-options speculative=0 > $OUT/kt_nospec.log 2>&1
+python3 tools/kernel_breakdown.py $OUT/kt_spec 143 > $OUT/kt_spec_breakdown.txt
+python3 tools/kernel_breakdown.py $OUT/kt_nospec 143 > $OUT/kt_nospec_breakdown.txt
+# 4. HBM traffic, separate PMC passes (what bench.py's child passes do, kept here as raw per-kernel averages)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o p -- python3 bench.py --pmc-child --steps 4 --warmup 3 > $OUT/pmc_$c.log 2>&1
+done
+python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_summary.csv
+# 5. the other workloads / pods / the index-sharded path on one rank over real RCCL
+for w in cfg2 cfg3; do python3 bench.py --workload $w --no-cpu-baseline --no-pmc > $OUT/bench_$w.json 2>> $OUT/bench.err; done
+python3 bench.py --pod half/half --no-cpu-baseline --no-pmc --no-robustness > $OUT/bench_half_half.json 2>> $OUT/bench.err
+python3 bench.py --pod norm8/half --no-cpu-baseline --no-pmc --no-robustness > $OUT/bench_norm8_half.json 2>> $OUT/bench.err
+python3 bench.py --force-dist --no-cpu-baseline --no-pmc > $OUT/bench_index_world1_rccl.json 2>> $OUT/bench.err
+tools/bench_hbm > $OUT/bench_hbm.txt 2>&1
+python3 tools/emulate_ranks.py --world 8 --frames 30 > $OUT/emulate_world8.txt 2>&1
+python3 tools/emulate_ranks.py --world 2 --frames 30 > $OUT/emulate_world2.txt 2>&1
+for f in $OUT/bench.json $OUT/bench_driver_args.json $OUT/bench_index_world1_rccl.json; do cut -c1-300 $f; done

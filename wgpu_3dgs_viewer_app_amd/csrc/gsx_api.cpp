@@ -427,9 +427,11 @@ gsx_status gsx_model_frame_stats(gsx_viewer* v, const char* key, gsx_frame_stats
     out->n_visible = m->n_visible;
     out->n_tile_entries = m->binned ? m->n_entries : 0;  // entries actually binned by the last gsx_render
     out->n_sorted = m->n_sorted;
-    out->speculated = m->binned && m->spec_round1 ? 1u : 0u;
-    out->n_repair_tiles = out->speculated ? m->h_counters->spec_need : (m->use_imported ? m->h_counters->shard_need : 0);
-    out->n_repair_sorted = out->speculated ? m->n_sorted2 : 0;
+    const bool spec_local = m->binned && m->spec_round1;
+    // (an index-sharded frame whose exchange was windowed by last frame's limits is speculated in the same sense)
+    out->speculated = spec_local || (m->binned && m->use_imported && m->shard_frame_limited) ? 1u : 0u;
+    out->n_repair_tiles = spec_local ? m->h_counters->spec_need : (m->use_imported ? m->h_counters->shard_need : 0);
+    out->n_repair_sorted = spec_local ? m->n_sorted2 : 0;
     out->overflow_slabs = (uint32_t)std::min<uint64_t>(m->overflow_slabs, 0xFFFFFFFFull);
     return GSX_OK;
 }

@@ -92,7 +92,7 @@ gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, const 
         PodPlanes pod = m->pod();
         pod.mask = m->last_pod_mask;
         HIPCHK(launch_shade(v->stream, m->fc, n, pod, m->proj_rec(),
-                            LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>()}));
+                            LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>(), m->rect8_active}));
         m->cand_valid = false;  // adm_pairs now holds the repair travellers
     }
     uint32_t h_tot[64];
@@ -299,7 +299,7 @@ gsx_status pack_write(gsx_viewer* v, Model* m, uint32_t world, void* d_send, uin
         PodPlanes pod = m->pod();
         pod.mask = m->last_pod_mask;
         HIPCHK(launch_shade(v->stream, m->fc, n, pod, m->proj_rec(),
-                            LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>()}));
+                            LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>(), m->rect8_active}));
         m->cand_valid = false;
         m->pack_travellers = false;
     }

@@ -266,6 +266,9 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
     m->lazy = (m->spec_round1 || shard_lazy) && !edits_on && !highlight_on && v->query.kind == GSX_QUERY_NONE;
     m->cand_valid = false;
     adm.lazy = m->lazy ? 1u : 0u;
+    // a lazy projection writes four bytes of tile rectangle per Gaussian instead of the 16-byte `a` record (grids up to 255 x 255 tiles)
+    m->rect8_active = m->lazy && m->fc.tiles_x <= 255u && m->fc.tiles_y <= 255u;
+    if (m->rect8_active) HIPCHK(m->rect8.ensure(4 * std::max<size_t>(m->n, 1)));
     m->last_pod_mask = pod.mask;
     m->last_pyramid = adm.pyramid.data;
     {
@@ -286,7 +289,7 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
                                          m->adm_counts.as<uint32_t>(), m->adm_offsets.as<uint32_t>(), &dcx->n_candidates,
                                          m->adm_pairs.as<uint2>(), true, m->block_vis.as<uint32_t>(), &dcx->n_visible));
         m->visible_count_pending = false;
-        if (m->lazy) HIPCHK(launch_shade(v->stream, m->fc, n32, pod, m->proj_rec(), LateProjection{m->adm_pairs.as<uint2>(), &dcx->n_candidates, nullptr}));
+        if (m->lazy) HIPCHK(launch_shade(v->stream, m->fc, n32, pod, m->proj_rec(), LateProjection{m->adm_pairs.as<uint2>(), &dcx->n_candidates, nullptr, m->rect8_active}));
         m->cand_valid = true;
     }
     if (edits_on || highlight_on)
@@ -326,6 +329,7 @@ gsx_status complete_records(gsx_viewer* v, Model* m) {
     adm.block_counts = m->block_sums.as<uint32_t>();  // scratch: the admission counts were consumed by the compaction
     PodPlanes pod = m->pod();
     pod.mask = m->last_pod_mask;
+    m->rect8_active = false;  // the unlazy kernel writes every record whole
     HIPCHK(launch_project(v->stream, m->fc, (uint32_t)m->n, pod, m->proj_rec(), m->block_vis.as<uint32_t>(), adm));
     m->lazy = false;
     return GSX_OK;
@@ -377,7 +381,7 @@ gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
                 if (m->lazy) {  // the projection pass was geometry only: shade what it admitted
                     PodPlanes pod = m->pod();
                     pod.mask = m->last_pod_mask;
-                    HIPCHK(launch_shade(v->stream, m->fc, n, pod, m->proj_rec(), LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted, nullptr}));
+                    HIPCHK(launch_shade(v->stream, m->fc, n, pod, m->proj_rec(), LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted, nullptr, m->rect8_active}));
                 }
             }
             RadixBuffers rb{nullptr, nullptr, m->adm_pairs.as<uint2>(), m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
@@ -670,7 +674,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
                 PodPlanes pod = m->pod();
                 pod.mask = m->last_pod_mask;
                 HIPCHK(launch_shade(v->stream, m->fc, n, pod, m->proj_rec(),
-                                    LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>()}));
+                                    LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>(), m->rect8_active}));
             }
             RadixBuffers rb{nullptr, nullptr, m->adm_pairs.as<uint2>(), m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
                             m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
@@ -680,8 +684,11 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
         m->order_consumed = true;
     }
     if (speculate && !windows_enqueued && (st = enqueue_next_windows())) return st;
-    // feed the next frames' slab plan without waiting — every fourth frame is plenty (the copy is two runtime kernels)
-    if (!m->stats_copy_inflight && (m->stats_copy_tick++ & 3u) == 0) {
+    // feed the next frames' slab plan without waiting — every fourth frame is plenty (the copy is two runtime kernels), every
+    // frame while a freshly (re)started speculation has not shown yet whether it pays (so that a scene it does not pay on
+    // is back on the plain path after half a dozen frames, not after twenty)
+    const bool probing = m->spec_round1 && m->spec_samples < 4;
+    if (!m->stats_copy_inflight && (((m->stats_copy_tick++ & 3u) == 0) || probing)) {
         if (!m->stats_event) HIPCHK(hipEventCreateWithFlags(&m->stats_event, hipEventDisableTiming));
         HIPCHK(hipMemcpyAsync(m->h_counters, m->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, v->stream));
         HIPCHK(hipEventRecord(m->stats_event, v->stream));

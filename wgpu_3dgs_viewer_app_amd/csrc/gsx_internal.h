@@ -72,7 +72,24 @@ struct Records {
     float4* a;       // N : mean.x, mean.y, bitcast(x0 | x1<<16), bitcast(y0 | y1<<16)   (tile rect, max exclusive)
     float4* b;       // N : conic a, b, c, opacity
     float4* c;       // N : r, g, b, view depth
+    uint32_t* rect8; // N or nullptr.  Non-null in a LAZILY projected frame on a grid of at most 255 x 255 tiles: the geometry-only
+                     // projection wrote the tile rectangle of EVERY Gaussian here as four bytes x0 | y0<<8 | x1<<16 | y1<<24 (0 =
+                     // culled) instead of the 16-byte `a` record — a write costs this part twice a read — and `a` (like b, c) then
+                     // exists only for the Gaussians k_shade has visited.  Whoever needs the rectangle of an arbitrary visible
+                     // Gaussian (the repair admission, the repair exchange's pack) reads it through rec_rect().
 };
+// tile rectangle of record i in the packed (x0 | x1<<16, y0 | y1<<16) form
+__device__ inline void rec_rect(const float4* __restrict__ rec_a, const uint32_t* __restrict__ rect8, uint32_t i, uint32_t& rx, uint32_t& ry) {
+    if (rect8) {
+        const uint32_t p = rect8[i];
+        rx = (p & 0xFFu) | ((p >> 16 & 0xFFu) << 16);
+        ry = (p >> 8 & 0xFFu) | ((p >> 24) << 16);
+    } else {
+        const float4 a = rec_a[i];
+        rx = __float_as_uint(a.z);
+        ry = __float_as_uint(a.w);
+    }
+}
 
 // ---- launch wrappers (one per kernel family); all enqueue on `s` and return the launch status ----
 hipError_t launch_convert(hipStream_t s, const gsx_gaussian* d_src, uint64_t n, uint64_t start, uint64_t model_n,
@@ -105,6 +122,7 @@ struct LateProjection {
     const uint2* pairs;                 // (key, index)
     const uint32_t* d_n;                // number of pairs, on the device
     const unsigned long long* shaded;   // nullable: ballots of the records to skip (shaded already)
+    bool write_a = false;               // the projection left no `a` record (Records::rect8 mode): k_shade writes it as well
 };
 // d_block_visible: one count per 256-Gaussian workgroup (project_blocks(n) entries); launch_sum_counts
 // reduces them into *d_n_visible.
@@ -214,6 +232,7 @@ size_t admit_blocks(uint64_t n);
 // compaction from ballots over 4096-record workgroups (offsets = exclusively scanned per-workgroup counts)
 hipError_t launch_admit_scatter(hipStream_t s, const uint32_t* key, uint32_t n, const unsigned long long* ballots,
                                 const uint32_t* offsets, uint2* pairs);
+// (rec.rect8 != nullptr: rectangles are read from the packed plane)
 hipError_t launch_admit(hipStream_t s, const Records& rec, uint32_t n, const uint2* window, uint32_t tiles_x,
                         const uint32_t* gate, uint32_t row_words, const WindowPyramid& pyramid, const uint32_t* d_skip, unsigned long long* ballots, uint32_t* counts, uint32_t* d_total, uint2* pairs);
 

@@ -66,6 +66,8 @@ struct Model {
 
     DevBuf pc, cov_a, cov_b, sh4, sh1, sh_h, sh_q, sh_aos, cov_h, cov_h2, mask;
     DevBuf key_buf, rec_a, rec_b, rec_c;        // projection records of the model's own Gaussians
+    DevBuf rect8;                               // packed tile rectangles of a lazily projected frame (Records::rect8)
+    bool rect8_active = false;                  // this frame's projection wrote rect8 instead of the `a` records
     DevBuf imp_key, imp_a, imp_b, imp_c;        // records imported from other ranks (kept apart: a frame may pack twice)
     bool use_imported = false;
     uint64_t sortbin_cap = 0, imp_cap = 0;
@@ -174,6 +176,7 @@ struct Model {
         r.a = rec_a.as<float4>();
         r.b = rec_b.as<float4>();
         r.c = rec_c.as<float4>();
+        r.rect8 = rect8_active ? rect8.as<uint32_t>() : nullptr;
         return r;
     }
     Records imp_rec() const {
@@ -182,6 +185,7 @@ struct Model {
         r.a = imp_a.as<float4>();
         r.b = imp_b.as<float4>();
         r.c = imp_c.as<float4>();
+        r.rect8 = nullptr;
         return r;
     }
     Records rec() const { return use_imported ? imp_rec() : proj_rec(); }  // the frame's active record set

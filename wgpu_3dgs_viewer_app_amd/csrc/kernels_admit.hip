@@ -25,7 +25,7 @@ __global__ __launch_bounds__(kAdmitThreads) void k_admit_count(const uint32_t* _
                                                                 const WindowPyramid pyr,
                                                                 const uint32_t* __restrict__ d_skip,
                                                                 unsigned long long* __restrict__ ballots,
-                                                                uint32_t* __restrict__ counts) {
+                                                                uint32_t* __restrict__ counts, const uint32_t* __restrict__ rect8) {
     __shared__ uint32_t wcnt[kAdmitThreads / 64];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const bool skip = d_skip && *d_skip == 0;  // verification round with nothing to repair: admit nothing
@@ -35,11 +35,7 @@ __global__ __launch_bounds__(kAdmitThreads) void k_admit_count(const uint32_t* _
         const uint32_t e = base + r * 64 + lane;
         uint32_t kk = kCulledKey, rx = 0, ry = 0;
         if (!skip && e < n) kk = key[e];
-        if ((window || pyr.data) && kk != kCulledKey) {
-            const float4 a = rec_a[e];
-            rx = __float_as_uint(a.z);
-            ry = __float_as_uint(a.w);
-        }
+        if ((window || pyr.data) && kk != kCulledKey) rec_rect(rec_a, rect8, e, rx, ry);
         bool adm;
         if (pyr.data) adm = kk != kCulledKey && pyramid_admits(pyr, kk, rx, ry);
         else if (window) adm = wave_dest_mask(window, tiles_x, kk, rx, ry, 0x10000u, 1u, gate, row_words) & 1ull;
@@ -201,7 +197,7 @@ hipError_t launch_admit(hipStream_t s, const Records& rec, uint32_t n, const uin
                         const uint32_t* gate, uint32_t row_words, const WindowPyramid& pyramid, const uint32_t* d_skip, unsigned long long* ballots, uint32_t* counts, uint32_t* d_total, uint2* pairs) {
     const uint32_t nb = (uint32_t)admit_blocks(n);
     if (!nb) return hipMemsetAsync(d_total, 0, 4, s);
-    hipLaunchKernelGGL(k_admit_count, dim3(nb), dim3(kAdmitThreads), 0, s, rec.key, rec.a, n, window, tiles_x, gate, row_words, pyramid, d_skip, ballots, counts);
+    hipLaunchKernelGGL(k_admit_count, dim3(nb), dim3(kAdmitThreads), 0, s, rec.key, rec.a, n, window, tiles_x, gate, row_words, pyramid, d_skip, ballots, counts, rec.rect8);
     hipError_t e = launch_rowscan(s, counts, 1, nb, d_total);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_admit_scatter, dim3(nb), dim3(kAdmitThreads), 0, s, rec.key, n, ballots, counts, pairs);

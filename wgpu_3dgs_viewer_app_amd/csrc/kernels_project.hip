@@ -577,7 +577,12 @@ __global__ __launch_bounds__(256) void k_project_geom(const FrameConsts f, const
         const uint32_t i = base + 256u * k;
         if (i < n) {
             st_stream(&rec.key[i], vis[k] ? __float_as_uint(vc[k].d) : kCulledKey);
-            if (vis[k] || GSX_VAR_FULLW) st_stream(&rec.a[i], make_float4(sp[k].mx, sp[k].my, __uint_as_float(sp[k].rx), __uint_as_float(sp[k].ry)));
+            if (rec.rect8) {  // four bytes instead of sixteen: k_shade writes the `a` record of the Gaussians it visits
+                const uint32_t rx = sp[k].rx, ry = sp[k].ry;
+                st_stream(&rec.rect8[i], vis[k] ? ((rx & 0xFFu) | ((ry & 0xFFu) << 8) | ((rx >> 16) << 16) | ((ry >> 16) << 24)) : 0u);
+            } else if (vis[k] || GSX_VAR_FULLW) {
+                st_stream(&rec.a[i], make_float4(sp[k].mx, sp[k].my, __uint_as_float(sp[k].rx), __uint_as_float(sp[k].ry)));
+            }
         }
         const unsigned long long bal = __ballot(vis[k]);
         const unsigned long long bal_adm = __ballot(take[k]);
@@ -604,7 +609,7 @@ __global__ __launch_bounds__(256) void k_project_geom(const FrameConsts f, const
 template <int DEG, int SHK, int COVK>
 __global__ __launch_bounds__(256) void k_shade(const FrameConsts f, const uint32_t n, const PodPlanes pod, const Records rec,
                                                 const uint2* __restrict__ pairs, const uint32_t* __restrict__ d_n,
-                                                const unsigned long long* __restrict__ skip) {
+                                                const unsigned long long* __restrict__ skip, const int write_a) {
     const uint32_t count = *d_n;
     for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < count; j += gridDim.x * 256u) {
         const uint32_t i = pairs[j].y;
@@ -631,6 +636,7 @@ __global__ __launch_bounds__(256) void k_shade(const FrameConsts f, const uint32
         }
         float r, g, b;
         load_shade<DEG, SHK, true>(f, pod, n, i, pc, r, g, b);
+        if (write_a) rec.a[i] = make_float4(sp.mx, sp.my, __uint_as_float(sp.rx), __uint_as_float(sp.ry));
         rec.b[i] = make_float4(sp.con_a, sp.con_b, sp.con_c, (float)(__float_as_uint(pc.w) >> 24) * (1.0f / 255.0f));
         rec.c[i] = make_float4(r, g, b, vc.d);
     }
@@ -694,7 +700,7 @@ static void launch_project_deg(hipStream_t s, dim3 grid, int deg, const FrameCon
     dim3 block(256);
 #define GSX_PROJECT(D)                                                                                                       \
     if (late)                                                                                                                \
-        hipLaunchKernelGGL((k_shade<D, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, late->pairs, late->d_n, late->shaded); \
+        hipLaunchKernelGGL((k_shade<D, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, late->pairs, late->d_n, late->shaded, late->write_a ? 1 : 0); \
     else if (adm.lazy)                                                                                                       \
         hipLaunchKernelGGL((k_project_geom<COVK, GSX_VAR_PROJ_PER>), dim3((grid.x + GSX_VAR_PROJ_PER - 1) / GSX_VAR_PROJ_PER), \
                            block, 0, s, f, n, pod, rec, bv, adm);                                                            \

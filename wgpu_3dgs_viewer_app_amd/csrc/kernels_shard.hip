@@ -45,7 +45,7 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_count(const uint32_t* __r
                                                               unsigned long long* __restrict__ travellers,
                                                               uint32_t* __restrict__ traveller_counts,
                                                               const uint32_t* __restrict__ gate, uint32_t gate_row_words,
-                                                              const WindowPyramid pyr) {
+                                                              const WindowPyramid pyr, const uint32_t* __restrict__ rect8) {
     __shared__ uint32_t cnt[kMaxWorld];
     __shared__ uint32_t tcnt[kPackThreads / 64];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
@@ -81,11 +81,7 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_count(const uint32_t* __r
 #pragma unroll
     for (int r = 0; r < kPackRounds; ++r) {
         rxs[r] = rys[r] = 0;
-        if (kks[r] != kCulledKey) {
-            const float4 a = rec_a[srcs[r]];
-            rxs[r] = __float_as_uint(a.z);
-            rys[r] = __float_as_uint(a.w);
-        }
+        if (kks[r] != kCulledKey) rec_rect(rec_a, rect8, srcs[r], rxs[r], rys[r]);
     }
 #pragma unroll
     for (int r = 0; r < kPackRounds; ++r) {
@@ -217,7 +213,7 @@ hipError_t launch_pack_count(hipStream_t s, const Records& rec, uint32_t n, uint
     if (nb)
         hipLaunchKernelGGL(k_pack_count, dim3(nb), dim3(kPackThreads), 0, s, rec.key, rec.a, n, world, rows_per_rank, window,
                            tiles_x, masks, table, nb, list, d_list_n, travellers, traveller_counts, gate, gate_row_words,
-                           pyramid ? *pyramid : WindowPyramid{});
+                           pyramid ? *pyramid : WindowPyramid{}, rec.rect8);
     return hipGetLastError();
 }
 
