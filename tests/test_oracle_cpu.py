@@ -183,6 +183,26 @@ def test_library_exports_every_declared_symbol():
     assert all(getattr(sp, n) == pytest.approx(getattr(d, n)) for n, _ in _lib.SpecParams._fields_)
 
 
+def test_rust_sys_covers_every_symbol():
+    """rust/gsx-sys/src/lib.rs (uncompiled binding source) declares every function include/gsx.h exports, and is
+    what tools/gen_rust_sys.py generates from the current header (not a stale copy)."""
+    hdr = open(os.path.join(ROOT, "include", "gsx.h")).read()
+    declared = set(re.findall(r"^(?:gsx_status|void|uint32_t|const char\*)\s+(gsx_\w+)\s*\(", re.sub(r"/\*.*?\*/", "", hdr, flags=re.S), flags=re.M))
+    assert declared == set(_lib.EXPORTS)
+    path = os.path.join(ROOT, "rust", "gsx-sys", "src", "lib.rs")
+    rs = open(path).read()
+    in_rust = set(re.findall(r"pub fn (gsx_\w+)\(", rs))
+    assert in_rust == declared, (declared - in_rust, in_rust - declared)
+    before = rs
+    subprocess.run(["python3", os.path.join(ROOT, "tools", "gen_rust_sys.py")], check=True, capture_output=True)
+    assert open(path).read() == before, "rust/gsx-sys/src/lib.rs is stale: run tools/gen_rust_sys.py"
+    facade = open(os.path.join(ROOT, "rust", "gsx", "src", "lib.rs")).read()
+    for name in ("MultiModelViewer", "new_with", "update_range", "preprocess", "radix_sorter", "render", "postprocess", "update_camera",
+                 "update_model_transform", "update_gaussian_transform", "update_query", "update_selection_highlight",
+                 "update_selection_edit_with_pod", "GaussianShDegree", "remove_model", "read_ply", "write_ply", "shard_render_frame"):
+        assert name in facade, name
+
+
 def test_no_cpu_fallback_without_a_device():
     import torch
 

@@ -204,6 +204,7 @@ gsx_status gsx_model_upload_range(gsx_viewer* v, const char* key, uint64_t start
         HIPCHK(launch_convert(v->stream, v->staging.as<gsx_gaussian>(), c, start + off, m->n, m->pod()));
         HIPCHK(hipStreamSynchronize(v->stream));  // the caller's memory may be reused after return
     }
+    m->tuner.reset();
     return GSX_OK;
 }
 
@@ -218,6 +219,7 @@ gsx_status gsx_model_upload_pod_device(gsx_viewer* v, const char* key, uint64_t 
         return fail(GSX_ERR_INVALID_ARG, "gsx_model_upload_pod_device: null plane");
     if (start > m->n || n > m->n - start) return fail(GSX_ERR_INVALID_ARG, "gsx_model_upload_pod_device: range exceeds model");
     HIPCHK(launch_pack_pod(v->stream, d_pos, d_color, m->has_sh ? d_sh : nullptr, d_cov3d, n, start, m->n, m->pod()));
+    m->tuner.reset();
     return GSX_OK;
 }
 
@@ -261,13 +263,17 @@ gsx_status gsx_model_upload_mask(gsx_viewer* v, const char* key, const uint32_t*
     Model* m = find_model(v, key);
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_upload_mask: no model '%s'", key ? key : "(null)");
     if (!words) {  // MaskOpTree::Reset
+        if (m->has_mask) m->tuner.reset();
         m->has_mask = false;
+        m->mask_program_hash = 0;
         return GSX_OK;
     }
     if (n_words != (m->n + 31) / 32) return fail(GSX_ERR_INVALID_ARG, "gsx_model_upload_mask: expected %llu words", (unsigned long long)((m->n + 31) / 32));
     HIPCHK(hipMemcpyAsync(m->mask.p, words, 4 * n_words, hipMemcpyHostToDevice, v->stream));
     HIPCHK(hipStreamSynchronize(v->stream));
     m->has_mask = true;
+    m->mask_program_hash = 0;
+    m->tuner.reset();
     return GSX_OK;
 }
 
@@ -315,7 +321,9 @@ gsx_status gsx_mask_evaluate(gsx_viewer* v, const char* key, const gsx_mask_op* 
     }
     if (n_ops && depth != 1) return fail(GSX_ERR_INVALID_ARG, "gsx_mask_evaluate: malformed postfix program");
     if (n_ops == 0) {  // MaskOpTree::Reset
+        if (m->has_mask) m->tuner.reset();
         m->has_mask = false;
+        m->mask_program_hash = 0;
         return GSX_OK;
     }
     MaskProgram prog{};
@@ -332,6 +340,13 @@ gsx_status gsx_mask_evaluate(gsx_viewer* v, const char* key, const gsx_mask_op* 
     }
     memcpy(prog.ops, ops, sizeof(gsx_mask_op) * n_ops);
     HIPCHK(launch_mask_evaluate(v->stream, m->pc.as<float4>(), (uint32_t)m->n, prog, m->mask.as<uint32_t>()));
+    // another mask is another scene as far as the speculation tuner's timings go (an app that re-evaluates the same
+    // program every frame keeps them)
+    uint64_t h = 1469598103934665603ull;
+    for (size_t b = 0; b < sizeof prog; ++b) h = (h ^ reinterpret_cast<const unsigned char*>(&prog)[b]) * 1099511628211ull;
+    h |= 1;
+    if (!m->has_mask || h != m->mask_program_hash) m->tuner.reset();
+    m->mask_program_hash = h;
     m->has_mask = true;
     return GSX_OK;
 }

@@ -61,30 +61,113 @@ static gsx_status wait_verdict(gsx_viewer* v, uint32_t seq, uint32_t* need) {
 }
 
 
-// A sample of how the speculation is doing (whenever statistics reach the host; never waited for).  A frame that needed
-// the repair round although its windows admitted more than 7/8 of what was visible gained nothing from speculating
-// (sparse scenes whose tiles hover around saturation: cfg2 admits 93 % and repairs 94 % of its frames, and the plain
-// progressive path is faster there; cfg3/cfg4 admit 76 % / 40 % and win 1.4x / 1.8x even when they repair).  When
-// four samples in a row were like that, render 48 frames without, then try again — 96, 192 ... if the retry fails as well.
-// The windows are kept up to date meanwhile, and either path gives the same pixels.
-static void note_speculation_outcome(Model* m, bool repaired) {
+// ---- does speculating pay on THIS scene, along THIS camera path?  Measured, not guessed. ----
+// Temporal occlusion speculation wins when frames are coherent and the scene occludes (cfg4: 2x), and loses when most frames
+// need the repair round anyway (cfg2: 1 M sparse Gaussians, 90 % of the frames repair; random camera poses).  Either path
+// gives the same pixels, so the viewer simply times them: some frames are bracketed by a pair of HIP events (recorded on the
+// stream, read back when they have completed — never waited for), one running mean per mode, and a four-phase cycle per model:
+//   SPEC (len_spec frames) -> PROBE_PLAIN (5 frames, unspeculated; the windows keep being updated) -> SETTLE (speculated
+//   frames until the probe's timings have arrived) -> decide;   PLAIN -> PROBE_SPEC -> SETTLE -> decide likewise.
+// A decision that confirms the current mode doubles its phase (64 ... 2048 frames: the probes then cost < 1 %), one that
+// flips it starts over at 64.  By construction the result stays within a few per cent of the better of the two paths.
+constexpr uint32_t kProbeFrames = 5;   // the first is not timed (the switch itself is atypical), the other four are
+constexpr uint32_t kSettleFrames = 64; // at most this many frames between a probe and the decision it feeds (normally: until its timings are in)
 
-    const bool useless = repaired && (uint64_t)m->h_counters->n_sorted * 8 > (uint64_t)m->h_counters->n_visible * 7;
-    m->spec_repair_history = (m->spec_repair_history << 1) | (useless ? 1u : 0u);
-    m->spec_samples += 1;
-    // (samples arrive every fourth frame: four in a row are sixteen frames at a loss already.  The pause doubles while the
-    // retries keep failing — 48, 96, ... 1536 frames — and starts over once speculating pays again: a scene like cfg2 spent
-    // 40 % of its frames speculating at a loss with a fixed 7-of-8 / 48-frame rule.)
-    if (m->spec_samples >= 4 && (m->spec_repair_history & 0xFu) == 0xFu) {
-        m->spec_pause = m->spec_pause_len;
-        m->spec_pause_len = std::min<uint32_t>(2 * m->spec_pause_len, 1536u);
-        m->spec_repair_history = 0;
-        m->spec_samples = 0;
-    } else if (!useless) {
-        m->spec_pause_len = 48;
+static void tuner_collect(Model* m) {
+    SpecTuner& t = m->tuner;
+    for (auto& s : t.slots) {
+        if (s.state < 2 || hipEventQuery(s.stop) != hipSuccess) continue;
+        if (s.state == 3) {  // bracketed before a reset()
+            s.state = 0;
+            continue;
+        }
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, s.start, s.stop) == hipSuccess && ms > 0.0f) {
+            double& mean = s.spec ? t.mean_spec : t.mean_plain;
+            uint32_t& n = s.spec ? t.n_spec : t.n_plain;
+            mean = n == 0 ? ms : mean + 0.25 * (ms - mean);
+            n += 1;
+        }
+        if (s.probe && t.probe_pending) t.probe_pending -= 1;
+        s.state = 0;
     }
 }
 
+// called once per gsx_preprocess of a model that could speculate; returns whether this frame should
+static bool tuner_wants_speculation(Model* m) {
+    SpecTuner& t = m->tuner;
+    tuner_collect(m);
+    static const bool debug = getenv("GSX_SPEC_DEBUG") != nullptr;
+    // a settle phase ends as soon as the probe's timings are in (or after kSettleFrames at the latest)
+    if ((t.phase == SpecTuner::SETTLE_SPEC || t.phase == SpecTuner::SETTLE_PLAIN) && t.probe_pending == 0) t.left = 0;
+    if (t.left == 0) {
+        switch (t.phase) {
+            case SpecTuner::SPEC:
+                t.phase = SpecTuner::PROBE_PLAIN; t.left = kProbeFrames;
+                break;
+            case SpecTuner::PLAIN:
+                t.phase = SpecTuner::PROBE_SPEC; t.left = kProbeFrames;
+                break;
+            // a host that does not wait for the device is several frames ahead of it: the probe's timings arrive while the
+            // frames after it are being enqueued, so the decision is taken a dozen frames later, in the old mode meanwhile
+            case SpecTuner::PROBE_PLAIN:
+                t.phase = SpecTuner::SETTLE_SPEC; t.left = kSettleFrames;
+                break;
+            case SpecTuner::PROBE_SPEC:
+                t.phase = SpecTuner::SETTLE_PLAIN; t.left = kSettleFrames;
+                break;
+            case SpecTuner::SETTLE_SPEC:
+            case SpecTuner::SETTLE_PLAIN: {
+                const bool was_spec = t.phase == SpecTuner::SETTLE_SPEC;
+                const bool have = t.n_spec >= 2 && t.n_plain >= 2;  // (running means over every bracketed frame so far, newest weighted most)
+                const bool spec_better = have ? (was_spec ? t.mean_spec <= 1.03 * t.mean_plain : t.mean_spec < 0.97 * t.mean_plain) : was_spec;
+                if (debug) fprintf(stderr, "[gsx spec] model '%s' frame %u: speculated %.3f ms (%u samples), plain %.3f ms (%u) -> %s\n", m->key.c_str(),
+                                   t.frame_no, t.mean_spec, t.n_spec, t.mean_plain, t.n_plain, spec_better ? "speculate" : "plain");
+                if (spec_better) {
+                    t.len_spec = was_spec ? std::min<uint32_t>(2 * t.len_spec, 2048u) : 64u;
+                    t.len_plain = 64;
+                    t.phase = SpecTuner::SPEC; t.left = t.len_spec;
+                } else {
+                    t.len_plain = was_spec ? 64u : std::min<uint32_t>(2 * t.len_plain, 2048u);
+                    t.len_spec = 64;
+                    t.phase = SpecTuner::PLAIN; t.left = t.len_plain;
+                }
+                break;
+            }
+        }
+    }
+    t.left -= 1;
+    t.frame_no += 1;
+    return t.phase == SpecTuner::SPEC || t.phase == SpecTuner::PROBE_SPEC || t.phase == SpecTuner::SETTLE_SPEC;
+}
+
+// bracket this model's frame with events?  every frame of a probe but its first (the switch itself is atypical), every
+// fourth frame otherwise (an event pair costs a few microseconds of stream gap)
+static void tuner_frame_begin(gsx_viewer* v, Model* m, bool speculated) {
+    SpecTuner& t = m->tuner;
+    t.active = nullptr;
+    const bool probe = t.phase == SpecTuner::PROBE_PLAIN || t.phase == SpecTuner::PROBE_SPEC;
+    if (probe ? t.left == kProbeFrames - 1 : (t.frame_no & 3u) != 0) return;
+    for (auto& s : t.slots) {
+        if (s.state != 0) continue;
+        if (!s.start && (hipEventCreate(&s.start) != hipSuccess || hipEventCreate(&s.stop) != hipSuccess)) return;
+        if (hipEventRecord(s.start, v->stream) != hipSuccess) return;
+        s.spec = speculated;
+        s.probe = probe;
+        s.state = 1;
+        if (probe) t.probe_pending += 1;
+        t.active = &s;
+        return;
+    }
+}
+
+static void tuner_frame_end(gsx_viewer* v, Model* m) {
+    SpecTuner& t = m->tuner;
+    if (!t.active) return;
+    t.active->state = hipEventRecord(t.active->stop, v->stream) == hipSuccess ? 2 : 0;
+    if (t.active->state == 0 && t.active->probe && t.probe_pending) t.probe_pending -= 1;
+    t.active = nullptr;
+}
 
 // The host's view of the device-side overflow bookkeeping (SlabStats::overflow_events / max_needed_ever never reset): when
 // slabs spilled since the last look, the pair buffers grow for the frames to come.  The frames that spilled were composited
@@ -123,7 +206,6 @@ gsx_status finish_frame(gsx_viewer* v) {
             m->counters_valid = true;
             if (m->binned) m->slabs_hint = m->h_counters->slabs_used;
             m->stats_copy_inflight = false;
-            if (m->binned && m->spec_round1 && !m->use_imported) note_speculation_outcome(m, m->h_counters->spec_need != 0);
             note_overflow(m);
             // The pixels of a frame that spilled are complete (k_composite_spill); only its tile LISTS are not, and only a
             // single-slab frame promises those (gsx_model_download_tile_lists): that one is redone with the grown buffers.
@@ -249,10 +331,11 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
     // its previous frame — the conservative max-pyramid test of the temporal occlusion speculation
     m->spec_round1 = v->options.progressive && v->options.speculative && m->spec_valid && m->spec_tiles_x == m->fc.tiles_x &&
                      m->spec_tiles_y == m->fc.tiles_y;
-    if (m->spec_pause) {  // the speculation kept repairing: plain frames for a while (the windows stay up to date meanwhile)
-        m->spec_pause -= 1;
-        m->spec_round1 = false;
-    }
+    // ... and whether speculating pays here is measured (SpecTuner): plain frames while it does not, windows kept up to date
+    const bool could_speculate = v->options.progressive && v->options.speculative && !(m->shard_win_set && m->shard_tiles_x == m->fc.tiles_x && m->shard_tiles_y == m->fc.tiles_y);
+    if (could_speculate && !tuner_wants_speculation(m)) m->spec_round1 = false;
+    // deep inside a plain phase nobody reads the windows this frame would leave behind (its last frame does: a probe follows)
+    m->windows_unwanted = could_speculate && m->tuner.phase == SpecTuner::PLAIN && m->tuner.left > 0;
     ProjectAdmission adm{};
     HIPCHK(m->adm_ballots.ensure(8 * ((std::max<size_t>(m->n, 1) + 63) / 64 + 4)));
     HIPCHK(m->adm_counts.ensure(4 * (std::max<size_t>(std::max(admit_blocks(m->n), (size_t)(m->n + 255) / 256), 1) + 4)));
@@ -271,6 +354,7 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
     if (m->rect8_active) HIPCHK(m->rect8.ensure(4 * std::max<size_t>(m->n, 1)));
     m->last_pod_mask = pod.mask;
     m->last_pyramid = adm.pyramid.data;
+    if (could_speculate && !m->use_imported) tuner_frame_begin(v, m, m->spec_round1);
     {
         ScopedPass t(v, GSX_PASS_PROJECT);  // brackets the projection kernel alone (bench.py's roofline kernel)
         HIPCHK(launch_project(v->stream, m->fc, n32, pod, m->proj_rec(), m->block_vis.as<uint32_t>(), adm));
@@ -454,7 +538,6 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
         if (progressive) {
             m->slabs_hint = m->h_counters->slabs_used;
             m->n_sorted = m->h_counters->n_sorted;
-            if (m->stats_copy_speculated) note_speculation_outcome(m, m->h_counters->spec_need != 0);
         }
         note_overflow(m);  // a free-running loop learns here that some earlier frame spilled: larger pair buffers from now on
     }
@@ -683,18 +766,17 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
         if (repair && (st = run_slab(0, n, true, m->spec_win2.as<uint2>(), &dc->n_sorted2, (uint32_t)bounds.size()))) return st;
         m->order_consumed = true;
     }
-    if (speculate && !windows_enqueued && (st = enqueue_next_windows())) return st;
-    // feed the next frames' slab plan without waiting — every fourth frame is plenty (the copy is two runtime kernels), every
-    // frame while a freshly (re)started speculation has not shown yet whether it pays (so that a scene it does not pay on
-    // is back on the plain path after half a dozen frames, not after twenty)
-    const bool probing = m->spec_round1 && m->spec_samples < 4;
-    if (!m->stats_copy_inflight && (((m->stats_copy_tick++ & 3u) == 0) || probing)) {
+    if (speculate && m->windows_unwanted) m->spec_valid = false;
+    else if (speculate && !windows_enqueued && (st = enqueue_next_windows())) return st;
+    // feed the next frames' slab plan without waiting — every fourth frame is plenty (the copy is two runtime kernels)
+    if (!m->stats_copy_inflight && (m->stats_copy_tick++ & 3u) == 0) {
         if (!m->stats_event) HIPCHK(hipEventCreateWithFlags(&m->stats_event, hipEventDisableTiming));
         HIPCHK(hipMemcpyAsync(m->h_counters, m->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, v->stream));
         HIPCHK(hipEventRecord(m->stats_event, v->stream));
         m->stats_copy_inflight = true;
         m->stats_copy_speculated = m->spec_round1;
     }
+    tuner_frame_end(v, m);
     m->binned = true;
     m->stats_pending = true;
     m->lists_complete = bounds.size() == 2 && !carry && !m->spec_round1 && !imported_windows;

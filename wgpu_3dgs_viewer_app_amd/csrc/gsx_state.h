@@ -54,6 +54,36 @@ struct DevBuf {
 
 using Counters = SlabStats;  // device copy + pinned host mirror
 
+// Per model: which of the two equivalent schedules (speculated / plain progressive) is faster here — see gsx_frame.cpp.
+struct SpecTuner {
+    enum Phase { SPEC, PROBE_PLAIN, SETTLE_SPEC, PLAIN, PROBE_SPEC, SETTLE_PLAIN } phase = SPEC;
+    uint32_t left = 32;                 // frames left in the phase (the first SPEC phase is short: decide early)
+    uint32_t len_spec = 64, len_plain = 64, frame_no = 0;
+    double mean_spec = 0.0, mean_plain = 0.0;  // running means of the bracketed frames, milliseconds
+    uint32_t n_spec = 0, n_plain = 0;
+    struct Slot {
+        hipEvent_t start = nullptr, stop = nullptr;
+        bool spec = false;
+        int state = 0;  // 0 free, 1 start recorded, 2 stop recorded (in flight), 3 in flight but stale (reset() since)
+        bool probe = false;  // a frame of a probe phase: the decision waits for these
+    } slots[16];
+    Slot* active = nullptr;
+    uint32_t probe_pending = 0;         // probe frames whose timings have not arrived yet
+    // the scene changed under the model (another mask, new Gaussians): what was measured belongs to the old scene
+    void reset() {
+        phase = SPEC; left = 32; len_spec = len_plain = 64;
+        n_spec = n_plain = 0; mean_spec = mean_plain = 0.0; probe_pending = 0;
+        for (auto& s : slots)
+            if (s.state == 2) s.state = 3;
+    }
+    ~SpecTuner() {
+        for (auto& s : slots) {
+            if (s.start) (void)hipEventDestroy(s.start);
+            if (s.stop) (void)hipEventDestroy(s.stop);
+        }
+    }
+};
+
 struct Model {
     std::string key;
     uint64_t n = 0;
@@ -109,10 +139,9 @@ struct Model {
     bool spec_valid = false, spec_round1 = false;
     // speculation that keeps repairing does not pay (sparse scenes whose tiles hover around saturation): the lazily read
     // statistics keep a history of "this frame needed the repair round"; too many -> unspeculated frames for a while
-    uint32_t spec_repair_history = 0;  // bit k: the k-th latest sampled speculated frame repaired although it admitted nearly everything
-    uint32_t spec_pause = 0;           // frames left to render unspeculated
-    uint32_t spec_pause_len = 48;      // length of the next pause (doubles while the retries keep failing)
-    uint32_t spec_samples = 0;         // samples since the last pause
+    uint64_t mask_program_hash = 0;    // of the last gsx_mask_evaluate program (0: none / uploaded words)
+    bool windows_unwanted = false;     // this frame need not leave windows for the next (SpecTuner: a plain phase)
+    SpecTuner tuner;                   // speculate or not? decided by timing both paths (gsx_frame.cpp)
     // host_verify = 2 (auto): ask the device for its verdict only while repairs are rare
     bool hv_active = true;             // currently asking
     uint32_t hv_history = 0;           // bit k: the k-th latest verdict needed the repair round
