@@ -76,6 +76,11 @@ def parse_args():
                     "(rgb, T) bands, 16 bytes a pixel, in stream order")
     ap.add_argument("--pass-timing", default="project", help="project (the roofline kernel only; default) | all (every pass, adds "
                     "a few microseconds of stream gap per pass boundary)")
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="gsx_render_options.frames_in_flight of the headline loop at N=1 (the one-in-flight rate is reported beside it)")
+    ap.add_argument("--unspeculated-in-flight", action="store_true",
+                    help="N=1: also time the unspeculated loop with --frames-in-flight lanes (off by default: its contended k_project "
+                         "launches would blur the kernel-trace average the roofline is checked against)")
     ap.add_argument("--render-options", default="", help="gsx_render_options overrides, e.g. speculative=0,min_slab=1000000 (experiments)")
     ap.add_argument("--host-profile", action="store_true", help="print host wall time per exchange-protocol section (adds syncs; debug)")
     ap.add_argument("--pod", default="single/single", help="pod storage sh/cov3d: single|half|norm8|none / single|half "
@@ -305,6 +310,15 @@ def main():
 
     if args.host_profile and use_dist:
         renderer.profile = {}
+    # N = 1: the headline loop keeps --frames-in-flight frames in flight (lanes inside libgsx: own stream and per-frame buffers,
+    # shared scene); the same loop with one frame in flight follows, and the kernel rooflines are measured there, uncontended
+    lanes = args.frames_in_flight if (single and not overrides) else 1
+
+    def set_opts(**kw):
+        viewer.set_render_options(**dict(overrides, **kw))
+
+    if lanes > 1:
+        set_opts(frames_in_flight=lanes)
     elapsed, timing, last_idx = timed_loop(0)
     if args.host_profile and use_dist and rank == 0:
         print("host ms/frame by section:", {k: round(1e3 * x / args.steps, 4) for k, x in renderer.profile.items()}, file=sys.stderr)
@@ -317,6 +331,11 @@ def main():
         renderer.poll()
         fb_last = renderer.framebuffer().copy()
     acct = accounting(rounds(args.warmup))
+    elapsed_1 = elapsed_ul = None
+    if lanes > 1:
+        set_opts()
+        elapsed_1, timing, _ = timed_loop(0)
+        acct = accounting(rounds(args.warmup))
 
     # ---- N = 1: the unspeculated loop of the same run (value_unspeculated + the SURVEY 8d projection roofline) ----
     elapsed_u = timing_u = acct_u = None
@@ -324,6 +343,9 @@ def main():
         viewer.set_render_options(**dict(overrides, speculative=0))
         elapsed_u, timing_u, _ = timed_loop(0)
         acct_u = accounting(rounds(args.warmup))
+        if lanes > 1 and args.unspeculated_in_flight:
+            set_opts(speculative=0, frames_in_flight=lanes)
+            elapsed_ul, _, _ = timed_loop(0)
         # frame check: the pose of the last timed speculated frame through the plainest schedule (no slabs, no speculation)
         viewer.set_render_options(**dict(overrides, speculative=0, progressive=0))
         frame(last_idx)
@@ -453,6 +475,7 @@ def main():
                 "gaussians": n, "width": w, "height": h, "sh_degree": sh, "pod": args.pod, "pod_bytes": pod_bytes,
                 "sharding": sharding, "schedule": "progressive depth slabs + temporal occlusion speculation (gsx_render_options defaults)"
                 if not overrides else f"overrides: {args.render_options}",
+                "frames_in_flight": lanes,
                 "n_visible_rank0": int(nvis_loc), "n_depth_sorted_rank0": int(nsort_loc), "tile_entries_rank0": int(entries),
                 "speculated_frames": round(float(spec_frac), 3), "frames_with_repair_round": round(float(repair_frac), 3),
                 "pass_ms_per_frame_rank0": passes,
@@ -460,6 +483,17 @@ def main():
             },
             "overflow_slabs": overflow_slabs,
         }
+        if elapsed_1 is not None:
+            out["value_one_frame_in_flight"] = round(args.steps / elapsed_1, 3)
+            out["ms_per_step_one_frame_in_flight"] = round(1e3 * elapsed_1 / args.steps, 4)
+            out["frames_in_flight_note"] = (
+                f"value: gsx_render_options.frames_in_flight = {lanes} — consecutive frames go round-robin to {lanes} lanes inside libgsx (own "
+                "stream, records, sort / tile buffers, framebuffer and speculation windows; the scene is shared), so the device overlaps one "
+                "frame's latency-bound tail with the next frame's bandwidth-bound projection; every frame is bit-identical to the one-lane "
+                "frame (tests/test_gpu_inflight.py, and frame_check below is taken from this loop).  value_one_frame_in_flight, "
+                "value_unspeculated, both rooflines and the robustness legs run with ONE frame in flight (kernel times uncontended).")
+        if elapsed_ul is not None:
+            out["value_unspeculated_in_flight"] = round(args.steps / elapsed_ul, 3)
         if timing_u is not None:
             out["value_unspeculated"] = round(args.steps / elapsed_u, 3)
             out["ms_per_step_unspeculated"] = round(1e3 * elapsed_u / args.steps, 4)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSX_ABI_VERSION 1u
+#define GSX_ABI_VERSION 2u
 #define GSX_TILE 16u /* screen tile edge in pixels (build-internal; the reference has no tiles) */
 #define GSX_SH_COEFFS 15u /* SH degree 1..3 coefficients, each an RGB triple (gs::Gaussian::sh) */
 
@@ -100,7 +100,16 @@ typedef struct gsx_spec_params {
  * enqueues the second round while the device idles).
  * 2: ask only while repairs are rare — stop when six of the last eight verdicts needed the second round; the verdicts
  * keep being posted and the host looks at the latest one without waiting: eight repair-free ones in a row and it asks
- * again.  (Conservative: on cfg4, whose repairs come in bursts, it mostly stays off.) */
+ * again.  (Conservative: on cfg4, whose repairs come in bursts, it mostly stays off.)
+ * frames_in_flight = L > 1: gsx_render_frame deals consecutive frames round-robin to L lanes, each with its own stream and
+ * per-frame buffers (records, sort and tile buffers, framebuffer, speculation windows: a lane speculates from ITS last
+ * frame, L poses back); the Gaussian data is shared.  The device then overlaps the latency-bound tail of one frame with
+ * the bandwidth-bound projection of the next: more frames per second, each taking longer from first to last kernel.
+ * Frames still complete in order per lane and every frame is the same frame bit for bit.  Readback calls
+ * (gsx_download_framebuffer, gsx_model_frame_stats, gsx_framebuffer_device_ptr ...) refer to the newest frame; a
+ * framebuffer pointer stays valid until the same lane renders again (L frames later).  Calls that touch model data
+ * (uploads, masks, selection / edits) are ordered after every frame in flight.  Frames with a query, an edit or a
+ * selection, a band (gsx_viewer_set_band), an external framebuffer or a sharded model run on the viewer itself, one at a time. */
 typedef struct gsx_render_options {
     uint32_t progressive;        /* default 1 */
     uint32_t first_slab_divisor; /* default 16 */
@@ -110,6 +119,7 @@ typedef struct gsx_render_options {
     float spec_margin;           /* default 0.25 */
     uint32_t spec_radius;        /* default 3 (tiles) */
     uint32_t host_verify;        /* default 0 */
+    uint32_t frames_in_flight;   /* default 1; 1 .. 4 — see below */
 } gsx_render_options;
 
 typedef struct gsx_viewer_desc {

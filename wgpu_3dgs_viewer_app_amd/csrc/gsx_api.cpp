@@ -6,6 +6,102 @@
 
 using namespace gsx;
 
+// ---- frames in flight (gsx_render_options::frames_in_flight) ----
+// A lane is a gsx_viewer of its own — stream, framebuffer, per-model records / sort / tile buffers, speculation windows —
+// created by the viewer it belongs to; its models are shadows that VIEW the owner's Gaussian data (DevBuf::borrow).
+// gsx_render_frame deals frames round-robin to the viewer and its lanes; nothing else in the library knows about lanes
+// except viewer_bind (gsx_state.h), which orders the viewer's stream after the lanes' frames before any other call.
+static uint64_t g_model_serial = 0;
+
+static gsx_viewer* result_lane(gsx_viewer* v) { return v->latest ? v->latest : v; }
+
+static gsx_status lane_create(gsx_viewer* v, gsx_viewer** out) {
+    std::unique_ptr<gsx_viewer> l(new gsx_viewer());
+    l->device = v->device;
+    l->parent = v;
+    l->validate = v->validate;
+    l->tile_cap_fixed = v->tile_cap_fixed;
+    HIPCHK(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
+    l->own_stream = true;
+    HIPCHK(hipEventCreateWithFlags(&l->lane_event, hipEventDisableTiming));
+    *out = l.release();
+    return GSX_OK;
+}
+
+// may this frame go to a lane?  (anything interactive — query, selection, edits — and everything multi-GPU stays on the viewer)
+static bool frame_may_overlap(gsx_viewer* v, const char* const* keys, uint32_t n_keys) {
+    if (v->parent || v->options.frames_in_flight < 2 || v->query.kind != GSX_QUERY_NONE || v->ext_fb || v->band_lo != 0 ||
+        v->band_hi != 0xFFFFFFFFu || v->highlight[3] > 0.0f)
+        return false;
+    for (uint32_t i = 0; i < n_keys; ++i) {
+        Model* m = find_model(v, keys ? keys[i] : nullptr);
+        if (!m || m->has_selection || m->has_edits || m->shard_win_set || m->shard_limit_valid || m->shard_next_valid) return false;
+    }
+    return n_keys > 0;
+}
+
+// bring lane l up to date with viewer v for a frame of `keys`: uniforms, options, and a shadow of every model
+static gsx_status lane_sync(gsx_viewer* v, gsx_viewer* l, const char* const* keys, uint32_t n_keys) {
+    l->params = v->params;
+    memcpy(l->view, v->view, sizeof l->view);
+    memcpy(l->proj, v->proj, sizeof l->proj);
+    l->width = v->width;
+    l->height = v->height;
+    l->size = v->size;
+    l->display_mode = v->display_mode;
+    l->sh_deg = v->sh_deg;
+    l->no_sh0 = v->no_sh0;
+    memcpy(l->highlight, v->highlight, sizeof l->highlight);
+    l->sel_edit = v->sel_edit;
+    if (l->options.progressive != v->options.progressive || l->options.speculative != v->options.speculative)
+        for (auto& kv : l->models) kv.second->spec_round1 = kv.second->sorted = false;
+    l->options = v->options;
+    l->options.frames_in_flight = 1;
+    l->timing = v->timing;
+    for (uint32_t i = 0; i < n_keys; ++i) {
+        Model* pm = find_model(v, keys[i]);
+        Model* sm = find_model(l, keys[i]);
+        if (sm && sm->shadow_of != pm->serial) {  // the key names another model now
+            HIPCHK(hipStreamSynchronize(l->stream));
+            l->models.erase(keys[i]);
+            sm = nullptr;
+        }
+        if (!sm) {
+            std::unique_ptr<Model> m(new Model());
+            m->key = pm->key;
+            m->shadow_of = pm->serial;
+            m->n = pm->n;
+            m->sh_kind = pm->sh_kind;
+            m->cov_kind = pm->cov_kind;
+            m->has_sh = pm->has_sh;
+            HIPCHK(m->counters.ensure(sizeof(Counters)));
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&m->h_counters), sizeof(Counters), hipHostMallocDefault));
+            memset(m->h_counters, 0, sizeof(Counters));
+            HIPCHK(hipMemsetAsync(m->counters.p, 0, sizeof(Counters), l->stream));
+            sm = m.get();
+            l->models[pm->key] = std::move(m);
+        }
+        for (auto pr : {std::make_pair(&sm->pc, &pm->pc), std::make_pair(&sm->cov_a, &pm->cov_a), std::make_pair(&sm->cov_b, &pm->cov_b),
+                        std::make_pair(&sm->sh4, &pm->sh4), std::make_pair(&sm->sh1, &pm->sh1), std::make_pair(&sm->sh_h, &pm->sh_h),
+                        std::make_pair(&sm->sh_q, &pm->sh_q), std::make_pair(&sm->sh_aos, &pm->sh_aos), std::make_pair(&sm->cov_h, &pm->cov_h),
+                        std::make_pair(&sm->cov_h2, &pm->cov_h2), std::make_pair(&sm->mask, &pm->mask)})
+            pr.first->borrow(*pr.second);
+        if (sm->has_mask != pm->has_mask || sm->mask_program_hash != pm->mask_program_hash) sm->tuner.reset();
+        sm->has_mask = pm->has_mask;
+        sm->mask_program_hash = pm->mask_program_hash;
+        sm->mt = pm->mt;
+        sm->show_unedited = pm->show_unedited;
+    }
+    // whatever the caller enqueued on the viewer's stream since this lane's last frame (uploads, masks) comes first
+    if (l->seen_epoch != v->epoch) {
+        if (!v->lane_event) HIPCHK(hipEventCreateWithFlags(&v->lane_event, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(v->lane_event, v->stream));
+        HIPCHK(hipStreamWaitEvent(l->stream, v->lane_event, 0));
+        l->seen_epoch = v->epoch;
+    }
+    return GSX_OK;
+}
+
 extern "C" {
 
 
@@ -60,7 +156,10 @@ gsx_status gsx_viewer_create(const gsx_viewer_desc* desc, gsx_viewer** out) {
 void gsx_viewer_destroy(gsx_viewer* v) {
     if (!v) return;
     (void)hipSetDevice(v->device);
+    for (gsx_viewer* l : v->lanes) gsx_viewer_destroy(l);  // (synchronises the lane's stream first)
+    v->lanes.clear();
     (void)hipStreamSynchronize(v->stream);
+    if (v->lane_event) (void)hipEventDestroy(v->lane_event);
     (void)gsx_viewer_comm_destroy(v);
     if (v->h_shard_verdict) (void)hipHostFree(v->h_shard_verdict);
     for (auto& t : v->timers) {
@@ -87,6 +186,7 @@ void gsx_render_options_default(gsx_render_options* o) {
     o->spec_margin = 0.25f;
     o->spec_radius = 3;
     o->host_verify = 0;
+    o->frames_in_flight = 1;
 }
 
 void gsx_debug_set_radix_rank_mode(int32_t mode) { radix_set_rank_override(mode); }
@@ -97,6 +197,12 @@ gsx_status gsx_viewer_set_render_options(gsx_viewer* v, const gsx_render_options
         return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_set_render_options: first_slab_divisor >= 1, growth >= 2, min_slab >= 1");
     if (!(o->spec_margin >= 0.0f) || o->spec_radius > 16 || o->host_verify > 2)
         return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_set_render_options: spec_margin >= 0, spec_radius <= 16, host_verify 0 | 1 | 2");
+    if (o->frames_in_flight < 1 || o->frames_in_flight > 4)
+        return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_set_render_options: frames_in_flight 1 .. 4");
+    {
+        gsx_status bst = viewer_bind(v);  // frames in flight finish under the options they were enqueued with
+        if (bst) return bst;
+    }
     // what gsx_preprocess decided (speculated round, lazy shading) belongs to the options it saw: a model preprocessed under
     // other scheduling options must go through gsx_preprocess + gsx_sort again before it is rendered
     if (o->progressive != v->options.progressive || o->speculative != v->options.speculative)
@@ -126,6 +232,7 @@ gsx_status gsx_model_create(gsx_viewer* v, const char* key, uint64_t count, gsx_
         return fail(GSX_ERR_INVALID_ARG, "gsx_model_create: unknown pod kind Sh%d/Cov3d%d", (int)sh, (int)cov3d);
     std::unique_ptr<Model> m(new Model());
     m->key = key;
+    m->serial = ++g_model_serial;
     m->n = count;
     m->sh_kind = sh;
     m->cov_kind = cov3d;
@@ -173,7 +280,8 @@ gsx_status gsx_model_remove(gsx_viewer* v, const char* key) {
     if (st) return st;
     Model* m = find_model(v, key);
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_remove: no model '%s'", key ? key : "(null)");
-    HIPCHK(hipStreamSynchronize(v->stream));
+    HIPCHK(hipStreamSynchronize(v->stream));  // (ordered after the lanes' frames by viewer_bind)
+    for (gsx_viewer* l : v->lanes) l->models.erase(key);
     v->models.erase(key);
     return GSX_OK;
 }
@@ -356,6 +464,7 @@ gsx_status gsx_preprocess(gsx_viewer* v, const char* key) {
     if (st) return st;
     Model* m = find_model(v, key);
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_preprocess: no model '%s'", key ? key : "(null)");
+    v->latest = nullptr;
     return do_preprocess(v, m);
 }
 
@@ -370,6 +479,10 @@ gsx_status gsx_sort(gsx_viewer* v, const char* key) {
 gsx_status gsx_sync(gsx_viewer* v) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
+    for (gsx_viewer* l : v->lanes) {
+        if ((st = finish_frame(l))) return st;
+        HIPCHK(hipStreamSynchronize(l->stream));
+    }
     gsx_status fst = finish_frame(v);
     if (fst) return fst;
     HIPCHK(hipStreamSynchronize(v->stream));
@@ -379,24 +492,48 @@ gsx_status gsx_sync(gsx_viewer* v) {
 gsx_status gsx_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
+    v->latest = nullptr;
     return do_render(v, keys, n_keys);
 }
 
 gsx_status gsx_render_frame(gsx_viewer* v, const char* const* keys, uint32_t n_keys) {
-    gsx_status st = viewer_bind(v);
-    if (st) return st;
-    for (uint32_t i = 0; i < n_keys; ++i) {
-        Model* m = find_model(v, keys ? keys[i] : nullptr);
-        if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_render_frame: no model '%s'", keys && keys[i] ? keys[i] : "(null)");
-        if ((st = do_preprocess(v, m, true))) return st;  // the sort's admission scan sums N_vis: one launch less
-        if ((st = do_sort(v, m))) return st;
+    if (!v) return fail(GSX_ERR_INVALID_ARG, "viewer is null");
+    gsx_status st = GSX_OK;
+    gsx_viewer* lane = v;
+    if (frame_may_overlap(v, keys, n_keys)) {
+        HIPCHK(hipSetDevice(v->device));  // NOT viewer_bind: frames in flight stay in flight
+        const uint32_t turn = v->lane_turn++ % v->options.frames_in_flight;
+        if (turn > 0) {
+            while (v->lanes.size() < turn) {
+                gsx_viewer* l = nullptr;
+                if ((st = lane_create(v, &l))) return st;
+                v->lanes.push_back(l);
+            }
+            lane = v->lanes[turn - 1];
+            if ((st = lane_sync(v, lane, keys, n_keys))) return st;
+        }
+    } else if ((st = viewer_bind(v))) {
+        return st;
     }
-    return do_render(v, keys, n_keys);
+    for (uint32_t i = 0; i < n_keys; ++i) {
+        Model* m = find_model(lane, keys ? keys[i] : nullptr);
+        if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_render_frame: no model '%s'", keys && keys[i] ? keys[i] : "(null)");
+        if ((st = do_preprocess(lane, m, true))) return st;  // the sort's admission scan sums N_vis: one launch less
+        if ((st = do_sort(lane, m))) return st;
+    }
+    if ((st = do_render(lane, keys, n_keys))) return st;
+    if (lane != v) {
+        HIPCHK(hipEventRecord(lane->lane_event, lane->stream));
+        lane->lane_busy = true;
+    }
+    v->latest = lane == v ? nullptr : lane;
+    return GSX_OK;
 }
 
 gsx_status gsx_download_framebuffer(gsx_viewer* v, float* rgbt, uint64_t n_floats) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
+    v = result_lane(v);  // the newest frame may be a lane's
     const uint64_t need = 4ull * v->width * v->height;
     if (!rgbt || n_floats != need) return fail(GSX_ERR_INVALID_ARG, "gsx_download_framebuffer: expected %llu floats", (unsigned long long)need);
     if ((st = ensure_fb(v))) return st;
@@ -409,6 +546,7 @@ gsx_status gsx_download_framebuffer(gsx_viewer* v, float* rgbt, uint64_t n_float
 gsx_status gsx_download_rgba8(gsx_viewer* v, const float bg[3], uint8_t* rgba, uint64_t n_bytes) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
+    v = result_lane(v);  // the newest frame may be a lane's
     const uint64_t npx = (uint64_t)v->width * v->height;
     if (!bg || !rgba || n_bytes != 4 * npx) return fail(GSX_ERR_INVALID_ARG, "gsx_download_rgba8: expected %llu bytes", (unsigned long long)(4 * npx));
     if ((st = ensure_fb(v))) return st;
@@ -423,6 +561,7 @@ gsx_status gsx_download_rgba8(gsx_viewer* v, const float bg[3], uint8_t* rgba, u
 gsx_status gsx_framebuffer_device_ptr(gsx_viewer* v, void** out_ptr, uint32_t* out_w, uint32_t* out_h) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
+    v = result_lane(v);  // the newest frame may be a lane's
     if (!out_ptr) return fail(GSX_ERR_INVALID_ARG, "gsx_framebuffer_device_ptr: null argument");
     if ((st = ensure_fb(v))) return st;
     *out_ptr = fb_ptr(v);
@@ -434,6 +573,7 @@ gsx_status gsx_framebuffer_device_ptr(gsx_viewer* v, void** out_ptr, uint32_t* o
 gsx_status gsx_model_frame_stats(gsx_viewer* v, const char* key, gsx_frame_stats* out) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
+    v = result_lane(v);  // the newest frame may be a lane's
     Model* m = find_model(v, key);
     if (!m || !out) return fail(GSX_ERR_NOT_FOUND, "gsx_model_frame_stats: no model '%s'", key ? key : "(null)");
     if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_model_frame_stats: model '%s' not preprocessed this frame", key);
@@ -455,6 +595,7 @@ gsx_status gsx_model_download_projection(gsx_viewer* v, const char* key, uint32_
                                          float* conic_opacity, float* rgb) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
+    v = result_lane(v);  // the newest frame may be a lane's
     Model* m = find_model(v, key);
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_download_projection: no model '%s'", key ? key : "(null)");
     if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_projection: model '%s' not preprocessed", key);
@@ -504,6 +645,7 @@ gsx_status gsx_model_download_projection(gsx_viewer* v, const char* key, uint32_
 gsx_status gsx_model_download_sorted(gsx_viewer* v, const char* key, uint32_t* indices, uint64_t capacity, uint64_t* out_n_visible) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
+    v = result_lane(v);  // the newest frame may be a lane's
     Model* m = find_model(v, key);
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_download_sorted: no model '%s'", key ? key : "(null)");
     if (!m->sorted) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_sorted: model '%s' not sorted", key);
@@ -522,6 +664,7 @@ gsx_status gsx_model_download_tile_lists(gsx_viewer* v, const char* key, uint32_
                                          uint32_t* list, uint64_t capacity) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
+    v = result_lane(v);  // the newest frame may be a lane's
     Model* m = find_model(v, key);
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_download_tile_lists: no model '%s'", key ? key : "(null)");
     if (!m->binned) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_tile_lists: model '%s' not rendered this frame", key);
@@ -583,12 +726,21 @@ gsx_status gsx_get_pass_timing(gsx_viewer* v, float ms[GSX_PASS_COUNT], uint32_t
     gsx_status st = viewer_bind(v);
     if (st) return st;
     HIPCHK(hipStreamSynchronize(v->stream));
-    for (auto& t : v->timers) {
-        float e = 0.0f;
-        if (hipEventElapsedTime(&e, t.start, t.stop) == hipSuccess) v->pass_ms[t.pass] += e;
-        v->event_pool.push_back({t.start, t.stop});
+    std::vector<gsx_viewer*> all{v};
+    all.insert(all.end(), v->lanes.begin(), v->lanes.end());
+    for (gsx_viewer* l : all) {
+        for (auto& t : l->timers) {
+            float e = 0.0f;
+            if (hipEventElapsedTime(&e, t.start, t.stop) == hipSuccess) v->pass_ms[t.pass] += e;
+            l->event_pool.push_back({t.start, t.stop});
+        }
+        l->timers.clear();
+        if (l != v)
+            for (int i = 0; i < GSX_PASS_COUNT; ++i) {
+                v->pass_launches[i] += l->pass_launches[i];
+                l->pass_launches[i] = 0;
+            }
     }
-    v->timers.clear();
     for (int i = 0; i < GSX_PASS_COUNT; ++i) {
         if (ms) ms[i] = v->pass_ms[i];
         if (launches) launches[i] = v->pass_launches[i];

@@ -29,15 +29,24 @@ gsx_status fail(gsx_status st, const char* fmt, ...);
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    bool borrowed = false;  // p belongs to another DevBuf (a lane's view of the model data, gsx_api.cpp)
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && !borrowed) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
+        borrowed = false;
+    }
+    void borrow(const DevBuf& o) {
+        if (!borrowed) release();
+        p = o.p;
+        bytes = o.bytes;
+        borrowed = o.p != nullptr;
     }
     // grow-only; contents are NOT preserved
     hipError_t ensure(size_t need) {
         if (need <= bytes) return hipSuccess;
+        if (borrowed) return hipErrorInvalidValue;  // a view never grows what it does not own
         release();
         size_t want = need + need / 4 + 256;
         hipError_t e = hipMalloc(&p, want);
@@ -86,6 +95,8 @@ struct SpecTuner {
 
 struct Model {
     std::string key;
+    uint64_t serial = 0;                        // unique per gsx_model_create (a lane's shadow model remembers whose data it views)
+    uint64_t shadow_of = 0;                     // != 0: this is a lane's shadow of the model with that serial
     uint64_t n = 0;
     gsx_sh_kind sh_kind = GSX_SH_SINGLE;
     gsx_cov3d_kind cov_kind = GSX_COV3D_SINGLE;
@@ -233,6 +244,16 @@ struct gsx_viewer {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // frames in flight (gsx_render_options::frames_in_flight = L > 1): gsx_render_frame deals frames round-robin to this
+    // viewer and L - 1 lanes — viewers of their own (stream, records, sort and tile buffers, framebuffer, speculation
+    // state) whose models VIEW this viewer's Gaussian data.  See gsx_api.cpp.
+    std::vector<gsx_viewer*> lanes;      // owned
+    gsx_viewer* parent = nullptr;        // set in a lane
+    gsx_viewer* latest = nullptr;        // the lane that rendered the newest frame (nullptr: this viewer itself)
+    uint32_t lane_turn = 0;
+    hipEvent_t lane_event = nullptr;     // lane: end of its last frame; parent: "everything enqueued so far" for the lanes to wait on
+    bool lane_busy = false;              // lane: it has a frame the parent's stream has not been ordered after
+    uint64_t epoch = 1, seen_epoch = 0;  // parent: bumped by every call that may touch model data; lane: the epoch it has waited for
     gsx_spec_params params{};
     float view[16]{}, proj[16]{};
     uint32_t width = 1, height = 1;
@@ -260,7 +281,7 @@ struct gsx_viewer {
     DevBuf shard_fb, shard_send, shard_recv, shard_sat_band, shard_sat_all, shard_counts;  // gsx_shard_render_frame's own buffers
     void* ext_fb = nullptr;              // caller-owned framebuffer (multi-GPU: the RCCL gather target)
     uint64_t ext_fb_bytes = 0;
-    gsx_render_options options{1u, 16u, 131072u, 2u, 1u, 0.25f, 3u, 0u};  // = gsx_render_options_default
+    gsx_render_options options{1u, 16u, 131072u, 2u, 1u, 0.25f, 3u, 0u, 1u};  // = gsx_render_options_default
     uint32_t timing = 0;  // bit p: bracket pass p with events
     std::vector<PassTimer> timers;     // recorded, not yet read
     std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
@@ -305,9 +326,20 @@ inline uint32_t ceil_log2(uint32_t x) {
     return b;
 }
 
+// Every entry point but gsx_render_frame and the uniform setters comes through here.  With frames in flight, the caller
+// may be about to read results or to change model data the lanes are still reading: the viewer's stream is ordered after
+// the lanes' frames (no host wait), and the lanes' next frames after whatever the caller enqueues (epoch).
 inline gsx_status viewer_bind(gsx_viewer* v) {
     if (!v) return fail(GSX_ERR_INVALID_ARG, "viewer is null");
     HIPCHK(hipSetDevice(v->device));
+    if (!v->lanes.empty()) {
+        for (gsx_viewer* l : v->lanes)
+            if (l->lane_busy) {
+                HIPCHK(hipStreamWaitEvent(v->stream, l->lane_event, 0));
+                l->lane_busy = false;
+            }
+        v->epoch += 1;
+    }
     return GSX_OK;
 }
 
