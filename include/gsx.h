@@ -480,7 +480,9 @@ typedef enum gsx_pass {
     GSX_PASS_BIN = 2,
     GSX_PASS_TILE_SORT = 3,
     GSX_PASS_COMPOSITE = 4,
-    GSX_PASS_COUNT = 5
+    GSX_PASS_PROJECT_GEOM = 5, /* the geometry-only projection of a lazily shaded (speculated / sharded) frame: another kernel,
+                                  other bytes — timed apart from GSX_PASS_PROJECT so that each average is one kernel's */
+    GSX_PASS_COUNT = 6
 } gsx_pass;
 /* enabled: 0 = off, 1 = every pass, otherwise a mask with bit (p + 1) set for each pass p to bracket with events
  * (an event pair costs a few microseconds of stream gap: time only what is being measured). */

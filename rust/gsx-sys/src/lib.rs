@@ -107,8 +107,8 @@ pub struct gsx_shard_verdict { pub need_tiles: u32, pub overflow: u32, pub max_r
 #[repr(C)]
 #[derive(Clone, Copy)]
 pub struct gsx_ply_header { pub count: u64, pub header_bytes: u64, pub vertex_bytes: u32, pub is_ascii: u32, pub offsets: [i32; 62] }
-pub type gsx_pass = u32; // 0 project, 1 depth sort, 2 bin, 3 tile sort, 4 composite
-pub const GSX_PASS_COUNT: usize = 5;
+pub type gsx_pass = u32; // 0 project, 1 depth sort, 2 bin, 3 tile sort, 4 composite, 5 project (geometry only)
+pub const GSX_PASS_COUNT: usize = 6;
 
 #[link(name = "gsx")]
 extern "C" {

@@ -27,6 +27,10 @@ for w in cfg2 cfg3; do python3 bench.py --workload $w --no-cpu-baseline --no-pmc
 python3 bench.py --pod half/half --no-cpu-baseline --no-pmc --no-robustness > $OUT/bench_half_half.json 2>> $OUT/bench.err
 python3 bench.py --pod norm8/half --no-cpu-baseline --no-pmc --no-robustness > $OUT/bench_norm8_half.json 2>> $OUT/bench.err
 python3 bench.py --force-dist --no-cpu-baseline --no-pmc > $OUT/bench_index_world1_rccl.json 2>> $OUT/bench.err
+# 6. frames in flight: the unspeculated loop with two lanes too, and one / three lanes for the headline loop
+python3 bench.py --no-cpu-baseline --no-pmc --no-robustness --unspeculated-in-flight > $OUT/bench_inflight2_both.json 2>> $OUT/bench.err
+python3 bench.py --no-cpu-baseline --no-pmc --no-robustness --frames-in-flight 1 > $OUT/bench_inflight1.json 2>> $OUT/bench.err
+python3 bench.py --no-cpu-baseline --no-pmc --no-robustness --frames-in-flight 3 > $OUT/bench_inflight3.json 2>> $OUT/bench.err
 tools/bench_hbm > $OUT/bench_hbm.txt 2>&1
 python3 tools/emulate_ranks.py --world 8 --frames 30 > $OUT/emulate_world8.txt 2>&1
 python3 tools/emulate_ranks.py --world 2 --frames 30 > $OUT/emulate_world2.txt 2>&1

@@ -356,9 +356,10 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
     m->last_pyramid = adm.pyramid.data;
     if (could_speculate && !m->use_imported) tuner_frame_begin(v, m, m->spec_round1);
     {
-        ScopedPass t(v, GSX_PASS_PROJECT);  // brackets the projection kernel alone (bench.py's roofline kernel)
+        const int pass = m->lazy ? GSX_PASS_PROJECT_GEOM : GSX_PASS_PROJECT;  // two kernels, two averages
+        ScopedPass t(v, pass);  // brackets the projection kernel alone (bench.py's roofline kernel)
         HIPCHK(launch_project(v->stream, m->fc, n32, pod, m->proj_rec(), m->block_vis.as<uint32_t>(), adm));
-        v->pass_launches[GSX_PASS_PROJECT] += m->n ? 1 : 0;
+        v->pass_launches[pass] += m->n ? 1 : 0;
     }
     // N_vis: summed by the admission scan when a compaction follows anyway (gsx_render_frame, a lazily projected shard)
     m->visible_count_pending = defer_visible_count || shard_lazy;
