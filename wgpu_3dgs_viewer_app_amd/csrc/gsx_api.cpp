@@ -21,6 +21,7 @@ static gsx_status lane_create(gsx_viewer* v, gsx_viewer** out) {
     l->parent = v;
     l->validate = v->validate;
     l->tile_cap_fixed = v->tile_cap_fixed;
+    l->bin_mode = v->bin_mode;
     HIPCHK(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
     l->own_stream = true;
     HIPCHK(hipEventCreateWithFlags(&l->lane_event, hipEventDisableTiming));
@@ -135,6 +136,7 @@ gsx_status gsx_viewer_create(const gsx_viewer_desc* desc, gsx_viewer** out) {
     std::unique_ptr<gsx_viewer> v(new gsx_viewer());
     v->validate = getenv("GSX_VALIDATE") != nullptr;
     if (const char* tc = getenv("GSX_TILE_CAP")) v->tile_cap_fixed = std::max<long long>(atoll(tc), 1);
+    if (const char* bm = getenv("GSX_BIN")) v->bin_mode = atoi(bm) ? 1 : 0;
     (void)radix_lane_ordered_adds();  // probes THIS device once per process (the answer is kept per device)
     v->device = desc->device;
     if (desc->stream) {

@@ -259,7 +259,7 @@ gsx_status ensure_sortbin_capacity(Model* m, uint64_t count) {
         }
     }
     HIPCHK(m->cnt.ensure(4 * n));
-    HIPCHK(m->srect.ensure(8 * n));
+    HIPCHK(m->srect.ensure(16 * n));  // uint2 tile rectangles (tile lists) or uint4 {rect, key, index} (block lists)
     HIPCHK(m->block_sums.ensure(4 * (scan_blocks(n) + 1)));
     m->sortbin_cap = n;
     return GSX_OK;
@@ -578,7 +578,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
             HIPCHK(hipMemsetAsync(m->tsort_ws.p, 0, m->tsort_ws.bytes, v->stream));
         }
         if (sizeof(uint2) * (size_t)n_tiles > m->ranges.bytes) m->ranges_clean = false;
-        HIPCHK(m->ranges.ensure(sizeof(uint2) * (size_t)n_tiles));
+        HIPCHK(m->ranges.ensure(sizeof(uint2) * (size_t)std::max<uint32_t>(n_tiles, 256u)));  // (block lists: up to 256 block ranges)
     }
     // reset this model's per-frame totals (n_visible and n_sorted stay)
     if (!counters_zeroed)  // (the frame's first model: done together with the saturation state, one launch)
@@ -595,6 +595,17 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
         }
     }
     const int bits = std::max<int>(1, (int)ceil_log2(n_tiles));
+    // Progressive frames bin by BLOCKS of tiles (<= 256 of them: one 8-bit sort pass) and let the compositor decide per tile
+    // (kernels_bin.hip "block lists").
+    // a single-slab front model keeps complete per-tile lists (gsx_model_download_tile_lists): that frame bins by tile
+    const bool lists_wanted = bounds.size() == 2 && !carry && !m->spec_round1 && !imported_windows;
+    const bool blocks = progressive && v->bin_mode == 1 && !lists_wanted;
+    uint32_t bsx = 0, bsy = 0;
+    if (blocks) {
+        auto count = [&]() { return (uint64_t)((m->fc.tiles_x + (1u << bsx) - 1u) >> bsx) * ((m->fc.tiles_y + (1u << bsy) - 1u) >> bsy); };
+        while (count() > 256u) (bsx <= bsy ? bsx : bsy) += 1;
+        HIPCHK(m->block_table.ensure(sizeof(uint4) * 256));
+    }
     // a single-slab front model keeps its complete tile lists for gsx_model_download_tile_lists
     const bool clear_ranges = progressive && !(bounds.size() == 2 && !carry && !m->spec_round1 && !imported_windows);
     // one depth slab [j0, j1) of the current depth order: bin -> tile sort -> ranges -> composite
@@ -604,32 +615,56 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
         const uint32_t* done_in = later ? done : nullptr;
         // a slab of S splats can produce at most S * n_tiles entries; size the sort launch by the smaller bound
         const uint32_t slab_cap = (uint32_t)std::min<uint64_t>(cap, (uint64_t)(j1 - j0) * std::min<uint64_t>(owned_tiles, 1u << 16));
-        {
-            ScopedPass t(v, GSX_PASS_BIN);
-            HIPCHK(launch_tile_counts(v->stream, j0, j1, d_n, m->sorted_idx, m->rec(), m->srect.as<uint2>(),
-                                      m->cnt.as<uint32_t>(), m->block_sums.as<uint32_t>(), dc, cap, row_lo, row_hi, done_in,
-                                      row_words, (progressive && later) ? done_count : nullptr, owned_tiles, slab_index,
-                                      win, m->sk_out.as<uint32_t>(), m->fc.tiles_x, min_ends));
-            HIPCHK(launch_tile_emit(v->stream, j0, j1, m->sorted_idx, m->srect.as<uint2>(), m->cnt.as<uint32_t>(),
-                                    m->block_sums.as<uint32_t>(), m->fc.tiles_x, m->tp_src.as<uint2>(), row_lo, row_hi,
-                                    done_in, row_words, d_n, &dc->n_entries, cap, win, m->sk_out.as<uint32_t>(), &dc->slab_cut));
-            v->pass_launches[GSX_PASS_BIN] += 1;
+        if (blocks) {
+            {
+                ScopedPass t(v, GSX_PASS_BIN);
+                HIPCHK(launch_block_bin(v->stream, j0, j1, d_n, m->sorted_idx, m->rec(), m->sk_out.as<uint32_t>(), m->srect.as<uint4>(),
+                                        m->cnt.as<uint32_t>(), m->block_sums.as<uint32_t>(), dc, cap, row_lo, row_hi, done_in, row_words,
+                                        (progressive && later) ? done_count : nullptr, owned_tiles, slab_index, win, m->fc.tiles_x,
+                                        m->fc.tiles_y, bsx, bsy, m->block_table.as<uint4>(), m->tp_src.as<uint2>()));
+                v->pass_launches[GSX_PASS_BIN] += 1;
+            }
+            {
+                ScopedPass t(v, GSX_PASS_TILE_SORT);
+                RadixBuffers rb{nullptr, nullptr, m->tp_src.as<uint2>(), m->tk_out.as<uint32_t>(), m->tv_out.as<uint32_t>(),
+                                m->tp_a.as<uint2>(), m->tp_b.as<uint2>(), m->tsort_ws.as<uint32_t>()};
+                const uint32_t block_cap = (uint32_t)std::min<uint64_t>(cap, (uint64_t)(j1 - j0) * 256u);
+                HIPCHK(launch_radix_sort(v->stream, rb, block_cap, &dc->n_entries, 8, false));
+                m->tile_keys = m->tk_out.as<uint32_t>();
+                m->tile_list = m->tv_out.as<uint32_t>();
+                v->pass_launches[GSX_PASS_TILE_SORT] += 1;
+                ScopedPass t2(v, GSX_PASS_BIN);
+                HIPCHK(launch_tile_ranges(v->stream, block_cap, &dc->n_entries, m->tile_keys, 256u, m->ranges.as<uint2>(), false));
+                m->ranges_clean = false;
+            }
+        } else {
+            {
+                ScopedPass t(v, GSX_PASS_BIN);
+                HIPCHK(launch_tile_counts(v->stream, j0, j1, d_n, m->sorted_idx, m->rec(), m->srect.as<uint2>(),
+                                          m->cnt.as<uint32_t>(), m->block_sums.as<uint32_t>(), dc, cap, row_lo, row_hi, done_in,
+                                          row_words, (progressive && later) ? done_count : nullptr, owned_tiles, slab_index,
+                                          win, m->sk_out.as<uint32_t>(), m->fc.tiles_x, min_ends));
+                HIPCHK(launch_tile_emit(v->stream, j0, j1, m->sorted_idx, m->srect.as<uint2>(), m->cnt.as<uint32_t>(),
+                                        m->block_sums.as<uint32_t>(), m->fc.tiles_x, m->tp_src.as<uint2>(), row_lo, row_hi,
+                                        done_in, row_words, d_n, &dc->n_entries, cap, win, m->sk_out.as<uint32_t>(), &dc->slab_cut));
+                v->pass_launches[GSX_PASS_BIN] += 1;
+            }
+            {
+                ScopedPass t(v, GSX_PASS_TILE_SORT);
+                RadixBuffers rb{nullptr, nullptr, m->tp_src.as<uint2>(), m->tk_out.as<uint32_t>(), m->tv_out.as<uint32_t>(),
+                                m->tp_a.as<uint2>(), m->tp_b.as<uint2>(), m->tsort_ws.as<uint32_t>()};
+                HIPCHK(launch_radix_sort(v->stream, rb, slab_cap, &dc->n_entries, bits, false));
+                m->tile_keys = m->tk_out.as<uint32_t>();
+                m->tile_list = m->tv_out.as<uint32_t>();
+                v->pass_launches[GSX_PASS_TILE_SORT] += (bits + 7) / 8;
+            }
+            {
+                ScopedPass t(v, GSX_PASS_BIN);
+                HIPCHK(launch_tile_ranges(v->stream, slab_cap, &dc->n_entries, m->tile_keys, (uint32_t)(m->ranges.bytes / sizeof(uint2)),
+                                          m->ranges.as<uint2>(), m->ranges_clean));
+            }
         }
-        {
-            ScopedPass t(v, GSX_PASS_TILE_SORT);
-            RadixBuffers rb{nullptr, nullptr, m->tp_src.as<uint2>(), m->tk_out.as<uint32_t>(), m->tv_out.as<uint32_t>(),
-                            m->tp_a.as<uint2>(), m->tp_b.as<uint2>(), m->tsort_ws.as<uint32_t>()};
-            HIPCHK(launch_radix_sort(v->stream, rb, slab_cap, &dc->n_entries, bits, false));
-            m->tile_keys = m->tk_out.as<uint32_t>();
-            m->tile_list = m->tv_out.as<uint32_t>();
-            v->pass_launches[GSX_PASS_TILE_SORT] += (bits + 7) / 8;
-        }
-        {
-            ScopedPass t(v, GSX_PASS_BIN);
-            HIPCHK(launch_tile_ranges(v->stream, slab_cap, &dc->n_entries, m->tile_keys, (uint32_t)(m->ranges.bytes / sizeof(uint2)),
-                                      m->ranges.as<uint2>(), m->ranges_clean));
-        }
-        if (v->validate) {  // debug: check what the compositor will dereference, on the host, before it runs
+        if (v->validate && !blocks) {  // debug: check what the compositor will dereference, on the host, before it runs
             HIPCHK(v->scratch.ensure(64));
             HIPCHK(hipMemsetAsync(v->scratch.p, 0, 64, v->stream));
             HIPCHK(launch_validate_tiles(v->stream, m->ranges.as<uint2>(), n_tiles, m->tile_list, &dc->n_entries, slab_cap, (uint32_t)m->rec_n,
@@ -646,9 +681,14 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
         }
         {
             ScopedPass t(v, GSX_PASS_COMPOSITE);
-            HIPCHK(launch_composite(v->stream, m->fc, m->ranges.as<uint2>(), m->tile_list, m->rec(), fb_ptr(v),
-                                    later, done, row_words, done_count, clear_ranges, tile_sat));
-            m->ranges_clean = clear_ranges;  // the compositor zeroed every range it consumed
+            if (blocks) {
+                HIPCHK(launch_composite_blocks(v->stream, m->fc, m->ranges.as<uint2>(), m->tile_list, m->srect.as<uint4>(), m->rec(), fb_ptr(v),
+                                               later, done, row_words, done_count, tile_sat, win, row_lo, row_hi, bsx, bsy));
+            } else {
+                HIPCHK(launch_composite(v->stream, m->fc, m->ranges.as<uint2>(), m->tile_list, m->rec(), fb_ptr(v),
+                                        later, done, row_words, done_count, clear_ranges, tile_sat));
+                m->ranges_clean = clear_ranges;  // the compositor zeroed every range it consumed
+            }
             v->pass_launches[GSX_PASS_COMPOSITE] += 1;
             // the slab's entries did not fit the pair buffers (decided on the device): its tail is composited pair-free, so
             // the frame is complete without a host round trip; otherwise this launch falls through

@@ -117,6 +117,7 @@ struct Model {
     DevBuf block_vis;                           // per-workgroup visible counts of the projection pass
     DevBuf tp_src, tp_a, tp_b, tk_out, tv_out, tsort_ws;  // tile pairs: emitted, scratch, sorted (split), workspace
     DevBuf ranges;
+    DevBuf block_table;                         // block lists: per block {min window start, max window end, live}
     DevBuf counters;
     Counters* h_counters = nullptr;             // pinned
     uint32_t* sorted_idx = nullptr;             // -> sv_a or sv_b after the depth sort
@@ -266,6 +267,7 @@ struct gsx_viewer {
     bool last_render_cont = false;
     unsigned long long* h_verdict = nullptr;  // pinned: {seq << 32 | tiles needing repair}, posted by k_spec_verify (host_verify)
     uint32_t verify_seq = 0;
+    int bin_mode = 1;             // GSX_BIN: 1 block lists for progressive frames (default), 0 per-tile lists always
     uint64_t tile_cap_fixed = 0;  // GSX_TILE_CAP was set when the viewer was created: pair-buffer capacity that never grows (tests of the spill path)
     bool validate = false;  // GSX_VALIDATE was set when the viewer was created: check tile ranges / lists before compositing (debug, synchronous)
     uint32_t band_lo = 0, band_hi = 0xFFFFFFFFu;  // tile rows this viewer renders (gsx_viewer_set_band)

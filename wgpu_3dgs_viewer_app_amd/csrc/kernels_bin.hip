@@ -365,6 +365,172 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const uint32_t* __restrict_
     }
 }
 
+// ---- block lists: binning by BLOCKS of tiles (progressive frames) ----
+// The screen's tiles are grouped into at most 256 blocks of 2^bsx x 2^bsy tiles (1920x1080: 15 x 17 blocks of 8 x 4 tiles).
+// A slab's records are binned by block — a record makes one entry per block its rectangle touches, a few instead of one per
+// tile — the entries are sorted by block id in ONE 8-bit radix pass, and the compositor of a tile walks its block's list and
+// keeps the records whose rectangle and depth-key window take the tile (k_composite_blocks).  The per-tile predicate thus
+// costs one register compare where the list is consumed instead of one dependent load per (record, tile) where it is
+// built, and the sort moves 1/4 of the entries once instead of all of them twice.  Block-level tests here are
+// CONSERVATIVE (a block takes a record unless all its tiles are saturated / outside the band, or no window of its tiles
+// can contain the key); the exact decision is the compositor's.  Entry value = the record's position in the slab;
+// brec[position] = {rect x, rect y, depth key, record index}.
+struct BlockGrid {
+    uint32_t bsx, bsy;       // log2 of the block size in tiles
+    uint32_t blocks_x, blocks_y;
+};
+
+// table[b] = {min window start, max window end (of the non-empty windows of the block's live tiles), live}
+__global__ __launch_bounds__(256) void k_block_table(BlockGrid g, uint32_t tiles_x, uint32_t tiles_y, uint32_t row_lo, uint32_t row_hi,
+                                                     const uint32_t* __restrict__ done, uint32_t row_words,
+                                                     const uint2* __restrict__ win, uint4* __restrict__ table) {
+    const uint32_t b = threadIdx.x;
+    if (b >= g.blocks_x * g.blocks_y) return;
+    const uint32_t bx = b % g.blocks_x, by = b / g.blocks_x;
+    const uint32_t x0 = bx << g.bsx, x1 = min(x0 + (1u << g.bsx), tiles_x);
+    const uint32_t y0 = max(by << g.bsy, row_lo), y1 = min(min((by + 1u) << g.bsy, tiles_y), row_hi);
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u, live = 0u;
+    for (uint32_t ty = y0; ty < y1; ++ty)
+        for (uint32_t tx = x0; tx < x1; ++tx) {
+            if (done && ((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)) continue;
+            if (win) {
+                const uint2 w = win[ty * tiles_x + tx];
+                if (w.x >= w.y) continue;
+                lo = min(lo, w.x);
+                hi = max(hi, w.y);
+            }
+            live = 1u;
+        }
+    if (!win) {
+        lo = 0u;
+        hi = 0xFFFFFFFFu;
+    }
+    table[b] = make_uint4(lo, hi, live, 0u);
+}
+
+__device__ inline bool block_takes(const uint4* tab, uint32_t b, uint32_t key, bool keyed) {
+    const uint4 t = tab[b];
+    return t.z != 0u && (!keyed || (key >= t.x && key < t.y));
+}
+
+// blocks touched by the band-clipped tile rectangle: [bx0, bx1) x [by0, by1); false if none
+__device__ inline bool block_rect(const BlockGrid& g, uint32_t rx, uint32_t ry, uint32_t row_lo, uint32_t row_hi, uint32_t& bx0,
+                                  uint32_t& bx1, uint32_t& by0, uint32_t& by1) {
+    const uint32_t x0 = rx & 0xFFFFu, x1 = rx >> 16, y0 = max(ry & 0xFFFFu, row_lo), y1 = min(ry >> 16, row_hi);
+    if (x0 >= x1 || y0 >= y1) return false;
+    bx0 = x0 >> g.bsx;
+    bx1 = ((x1 - 1u) >> g.bsx) + 1u;
+    by0 = y0 >> g.bsy;
+    by1 = ((y1 - 1u) >> g.bsy) + 1u;
+    return true;
+}
+
+__global__ __launch_bounds__(kBinThreads) void k_block_counts(const uint32_t* __restrict__ d_n_vis, uint32_t j0, uint32_t j1,
+                                                               const uint32_t* __restrict__ sorted_idx,
+                                                               const float4* __restrict__ rec_a,
+                                                               const uint32_t* __restrict__ sorted_keys, uint4* __restrict__ brec,
+                                                               uint32_t* __restrict__ cnt, uint32_t* __restrict__ block_sums,
+                                                               uint32_t row_lo, uint32_t row_hi,
+                                                               const uint32_t* __restrict__ d_done_count, uint32_t owned_tiles,
+                                                               BlockGrid g, const uint4* __restrict__ table, int keyed) {
+    __shared__ uint32_t red[4];
+    __shared__ uint4 tab[256];
+    const uint32_t n_vis = min(*d_n_vis, j1);
+    const uint32_t chunks = n_vis > j0 ? (n_vis - j0 + kBinThreads - 1) / kBinThreads : 0u;
+    const bool all_done = d_done_count && *d_done_count >= owned_tiles;
+    if (!all_done && blockIdx.x < chunks) {
+        tab[threadIdx.x] = threadIdx.x < g.blocks_x * g.blocks_y ? table[threadIdx.x] : make_uint4(0, 0, 0, 0);
+        __syncthreads();
+    }
+    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        if (all_done) {
+            if (threadIdx.x == 0) block_sums[chunk] = 0;
+            continue;
+        }
+        const uint32_t j = j0 + chunk * kBinThreads + threadIdx.x;
+        uint32_t c = 0;
+        if (j < n_vis) {
+            const uint32_t idx = sorted_idx[j];
+            const float4 a = rec_a[idx];
+            const uint32_t rx = __float_as_uint(a.z), ry = __float_as_uint(a.w);
+            const uint32_t key = sorted_keys[j];
+            brec[j - j0] = make_uint4(rx, ry, key, idx);
+            uint32_t bx0, bx1, by0, by1;
+            if (block_rect(g, rx, ry, row_lo, row_hi, bx0, bx1, by0, by1))
+                for (uint32_t by = by0; by < by1; ++by)
+                    for (uint32_t bx = bx0; bx < bx1; ++bx) c += block_takes(tab, by * g.blocks_x + bx, key, keyed != 0) ? 1u : 0u;
+            cnt[j - j0] = c;
+        }
+        const uint32_t tot = block_reduce_sum(c, red);
+        if (threadIdx.x == 0) block_sums[chunk] = tot;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kBinThreads) void k_block_emit(uint32_t jbase, uint32_t j1, const uint4* __restrict__ brec,
+                                                             const uint32_t* __restrict__ cnt,
+                                                             const uint32_t* __restrict__ block_offs, uint2* __restrict__ pairs,
+                                                             uint32_t row_lo, uint32_t row_hi, const uint32_t* __restrict__ d_n_vis,
+                                                             const uint32_t* __restrict__ d_entries, uint32_t capacity,
+                                                             const uint32_t* __restrict__ d_cut, BlockGrid g,
+                                                             const uint4* __restrict__ table, int keyed) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint4 tab[256];
+    if (*d_entries == 0) return;
+    const uint32_t n_vis = min(min(j1, *d_n_vis), *d_cut);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t chunks = n_vis > jbase ? (n_vis - jbase + kBinThreads - 1) / kBinThreads : 0u;
+    if (blockIdx.x < chunks) tab[tid] = tid < g.blocks_x * g.blocks_y ? table[tid] : make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        const uint32_t j = jbase + chunk * kBinThreads + tid;
+        const uint32_t mine = j < n_vis ? cnt[j - jbase] : 0u;
+        uint32_t x = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= (uint32_t)o) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint32_t o = block_offs[chunk] + x - mine;
+        for (uint32_t w = 0; w < wave; ++w) o += wsum[w];
+        if (mine) {
+            const uint4 r = brec[j - jbase];
+            uint32_t bx0, bx1, by0, by1;
+            if (block_rect(g, r.x, r.y, row_lo, row_hi, bx0, bx1, by0, by1))
+                for (uint32_t by = by0; by < by1; ++by)
+                    for (uint32_t bx = bx0; bx < bx1; ++bx) {
+                        const uint32_t b = by * g.blocks_x + bx;
+                        if (!block_takes(tab, b, r.z, keyed != 0)) continue;
+                        if (o < capacity) pairs[o] = make_uint2(b, j - jbase);
+                        ++o;
+                    }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_block_bin(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* d_n_vis, const uint32_t* sorted_idx,
+                            const Records& rec, const uint32_t* sorted_keys, uint4* brec, uint32_t* cnt, uint32_t* block_sums,
+                            SlabStats* stats, uint32_t capacity, uint32_t row_lo, uint32_t row_hi, const uint32_t* done,
+                            uint32_t row_words, const uint32_t* d_done_count, uint32_t owned_tiles, uint32_t slab_index,
+                            const uint2* window, uint32_t tiles_x, uint32_t tiles_y, uint32_t bsx, uint32_t bsy, uint4* table,
+                            uint2* pairs) {
+    const uint32_t nb = std::min<uint32_t>((uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0), kBinGrid);
+    BlockGrid g{bsx, bsy, (tiles_x + (1u << bsx) - 1u) >> bsx, (tiles_y + (1u << bsy) - 1u) >> bsy};
+    hipLaunchKernelGGL(k_block_table, dim3(1), dim3(256), 0, s, g, tiles_x, tiles_y, row_lo, row_hi, done, row_words, window, table);
+    if (nb)
+        hipLaunchKernelGGL(k_block_counts, dim3(nb), dim3(kBinThreads), 0, s, d_n_vis, j0, j1, sorted_idx, rec.a, sorted_keys, brec, cnt,
+                           block_sums, row_lo, row_hi, d_done_count, owned_tiles, g, table, window ? 1 : 0);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, j0, j1, d_n_vis, stats, capacity, d_done_count,
+                       owned_tiles, slab_index);
+    if (nb)
+        hipLaunchKernelGGL(k_block_emit, dim3(nb), dim3(kBinThreads), 0, s, j0, j1, brec, cnt, block_sums, pairs, row_lo, row_hi,
+                           d_n_vis, &stats->n_entries, capacity, &stats->slab_cut, g, table, window ? 1 : 0);
+    return hipGetLastError();
+}
+
 hipError_t launch_tile_counts(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* d_n_vis, const uint32_t* sorted_idx,
                               const Records& rec, uint2* srect, uint32_t* cnt, uint32_t* block_sums, SlabStats* stats,
                               uint32_t capacity, uint32_t row_lo, uint32_t row_hi, const uint32_t* done, uint32_t row_words,

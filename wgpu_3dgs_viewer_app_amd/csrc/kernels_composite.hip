@@ -209,6 +209,122 @@ __global__ __launch_bounds__(128) void k_composite(const FrameConsts f, uint2* _
     }
 }
 
+// Block lists (kernels_bin.hip): the tile's BLOCK has one depth-ordered list of slab positions; brec[position] = {rect x, rect y,
+// depth key, record index}.  The workgroup walks it 128 candidates at a time and keeps, in order, those whose rectangle
+// covers this tile and whose key lies in the tile's window — the exact per-tile decision, a handful of register compares.
+// Software pipeline, one stage deeper than k_composite's: while the takers of chunk c are blended out of LDS, the record
+// gathers of chunk c + 1's takers and the candidate loads of chunk c + 2 are in flight.
+template <int MODE>
+__global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, const uint2* __restrict__ ranges,
+                                                           const uint32_t* __restrict__ list, const uint4* __restrict__ brec,
+                                                           const float4* __restrict__ rec_a, const float4* __restrict__ rec_b,
+                                                           const float4* __restrict__ rec_c, float4* __restrict__ fb,
+                                                           const int carry, uint32_t* __restrict__ done_bits,
+                                                           const uint32_t row_words, uint32_t* __restrict__ done_count,
+                                                           uint32_t* __restrict__ tile_sat, const uint2* __restrict__ window,
+                                                           const uint32_t row_lo, const uint32_t row_hi, const uint32_t bsx,
+                                                           const uint32_t bsy, const uint32_t blocks_x) {
+    __shared__ float2 s_mean[128 + kGroup];
+    __shared__ float4 s_conic[128 + kGroup];
+    __shared__ float4 s_rgb[128 + kGroup];
+    __shared__ uint32_t s_sat, s_w[2];
+
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tx = tile % f.tiles_x, ty = tile / f.tiles_x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t px = tx * kTile + (tid & 15u), py = ty * kTile + 2u * (tid >> 4);
+    const bool in0 = px < f.w_px && py < f.h_px, in1 = px < f.w_px && py + 1u < f.h_px;
+    const float pxf = (float)px + 0.5f;
+    const v2f pyf = v2f{(float)py + 0.5f, (float)(py + 1u) + 0.5f};
+    const size_t fbo = (size_t)py * f.w_px + px;
+    uint2 range = ranges[(ty >> bsy) * blocks_x + (tx >> bsx)];
+    const uint2 win = window ? window[tile] : make_uint2(0u, 0xFFFFFFFFu);
+    if (ty < row_lo || ty >= row_hi || win.x >= win.y) range = make_uint2(0u, 0u);  // not this rank's tile / takes nothing
+    if (carry && (range.x >= range.y || (done_bits && ((done_bits[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)))) return;
+    v2f T = splat2(1.0f), C0 = splat2(0.0f), C1 = C0, C2 = C0;
+    if (carry) {
+        if (in0) {
+            const float4 p = fb[fbo];
+            C0.x = p.x; C1.x = p.y; C2.x = p.z; T.x = p.w;
+        }
+        if (in1) {
+            const float4 p = fb[fbo + f.w_px];
+            C0.y = p.x; C1.y = p.y; C2.y = p.z; T.y = p.w;
+        }
+    }
+    const uint32_t live = f.k2 > 0.0f ? __float_as_uint(f.k2) + 1u : (f.k2 == 0.0f ? 1u : 0u);
+    uint32_t lim0 = (in0 && !(T.x < f.t_eps)) ? live : 0u, lim1 = (in1 && !(T.y < f.t_eps)) ? live : 0u;
+    uint32_t stop_key = 0;
+    if (tid == 0) s_sat = 0;
+
+    // stage 1 registers: the next chunk's candidates; stage 2 registers: the gathered takers of the chunk before
+    uint4 cand = make_uint4(0u, 0u, 0u, 0u);
+    bool cand_ok = false;
+    {
+        const uint32_t at = range.x + tid;
+        if (at < range.y) {
+            cand = brec[list[at]];
+            cand_ok = true;
+        }
+    }
+    bool g_take = false;
+    uint32_t g_my = 0, g_cnt = 0;
+    float4 pa = make_float4(0, 0, 0, 0), pb = pa, pc4 = pa;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // iteration i: write the takers gathered in iteration i - 1 to LDS, filter chunk i and start its gathers, prefetch the
+    // candidates of chunk i + 1, blend; one more iteration drains the pipeline
+    for (uint32_t base = range.x; base < range.y + 128u; base += 128u) {
+        if (lane == 0) s_w[wave] = g_cnt;
+        // vote + barrier: also protects the LDS batch of the previous iteration and publishes s_w
+        if (__syncthreads_and((lim0 | lim1) == 0u)) break;
+        const uint32_t cnt = s_w[0] + s_w[1];
+        if (g_take) {
+            const uint32_t slot = (wave ? s_w[0] : 0u) + g_my;
+            s_mean[slot] = make_float2(pa.x, pa.y);
+            s_conic[slot] = make_float4(pb.x, 2.0f * pb.y, pb.z, pb.w);
+            s_rgb[slot] = pc4;
+        }
+        if (tid < (uint32_t)kGroup) {  // the blend loop runs in whole groups
+            s_mean[cnt + tid] = make_float2(3.0e38f, 3.0e38f);
+            s_conic[cnt + tid] = make_float4(1.0f, 0.0f, 1.0f, 0.0f);
+            s_rgb[cnt + tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        __syncthreads();
+        // filter this chunk's candidates (already in registers) and start the gathers of its takers
+        g_take = cand_ok && tx >= (cand.x & 0xFFFFu) && tx < (cand.x >> 16) && ty >= (cand.y & 0xFFFFu) && ty < (cand.y >> 16) &&
+                 cand.z >= win.x && cand.z < win.y;
+        const unsigned long long bal = __ballot(g_take);
+        g_my = (uint32_t)__popcll(bal & lt);
+        g_cnt = (uint32_t)__popcll(bal);
+        if (g_take) {
+            pa = rec_a[cand.w];
+            pb = rec_b[cand.w];
+            pc4 = rec_c[cand.w];
+        }
+        // candidates of the chunk after
+        cand_ok = false;
+        const uint32_t nxt = base + 128u + tid;
+        if (nxt < range.y) {
+            cand = brec[list[nxt]];
+            cand_ok = true;
+        }
+        if (cnt) blend_batch<MODE>(f, cnt, s_mean, s_conic, s_rgb, pxf, pyf, lim0, lim1, T, C0, C1, C2, stop_key);
+    }
+    if (in0) fb[fbo] = make_float4(C0.x, C1.x, C2.x, T.x);
+    if (in1) fb[fbo + f.w_px] = make_float4(C0.y, C1.y, C2.y, T.y);
+    if (done_bits && __syncthreads_and((lim0 | lim1) == 0u)) {
+        if (tile_sat) {
+            if (stop_key) atomicMax(&s_sat, stop_key);
+            __syncthreads();
+        }
+        if (tid == 0) {
+            atomicOr(&done_bits[ty * row_words + (tx >> 5)], 1u << (tx & 31u));
+            atomicAdd(done_count, 1u);
+            if (tile_sat) tile_sat[tile] = max(s_sat, 1u);
+        }
+    }
+}
+
 // An overflowing slab's tail: the splats [stats->slab_cut, min(j1, *d_n)) of the depth order never reached the tile-pair
 // buffers (k_scan_block_sums cut the slab where they were full).  One workgroup per tile that is still open scans them 128
 // at a time, keeps — in depth order — those whose tile rectangle (and depth-key window) takes this tile, and blends them
@@ -338,6 +454,21 @@ hipError_t launch_composite(hipStream_t s, const FrameConsts& f, uint2* ranges, 
     else
         hipLaunchKernelGGL(k_composite<1>, grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count,
                            clear_ranges ? 1 : 0, tile_sat);
+    return hipGetLastError();
+}
+
+hipError_t launch_composite_blocks(hipStream_t s, const FrameConsts& f, const uint2* ranges, const uint32_t* list, const uint4* brec,
+                                   const Records& rec, float4* fb, bool carry, uint32_t* done, uint32_t row_words,
+                                   uint32_t* d_done_count, uint32_t* tile_sat, const uint2* window, uint32_t row_lo,
+                                   uint32_t row_hi, uint32_t bsx, uint32_t bsy) {
+    dim3 grid(f.tiles_x * f.tiles_y), block(128);
+    const uint32_t blocks_x = (f.tiles_x + (1u << bsx) - 1u) >> bsx;
+    if (f.display_mode == GSX_DISPLAY_SPLAT)
+        hipLaunchKernelGGL(k_composite_blocks<0>, grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
+                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x);
+    else
+        hipLaunchKernelGGL(k_composite_blocks<1>, grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
+                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x);
     return hipGetLastError();
 }
 
