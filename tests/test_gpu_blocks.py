@@ -1,0 +1,72 @@
+"""GPU: block lists (kernels_bin.hip / k_composite_blocks) against per-tile lists (GSX_BIN=0), frame for frame.
+
+Progressive frames bin by blocks of tiles (at most 256 blocks: one 8-bit sort pass) and the compositor decides per tile;
+GSX_BIN=0 keeps the per-tile binning + two-pass tile sort for every frame.  Both must give the same pixels bit for bit:
+viewports whose grid is below 256 tiles (block = tile), 1080p (8 x 4 tiles per block), 4K (16 x 8), sizes that are not a
+multiple of the tile, depth slabs with saturated tiles, speculated frames with windows and repair rounds, layered models."""
+import numpy as np
+import pytest
+
+from tests import common
+from wgpu_3dgs_viewer_app_amd import camera
+from wgpu_3dgs_viewer_app_amd.viewer import GaussianDisplayMode, GaussianShDegree, MultiModelViewer
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(monkeypatch, **opts):
+    monkeypatch.setenv("GSX_BIN", "0")
+    tiles = MultiModelViewer()
+    monkeypatch.delenv("GSX_BIN")
+    blocks = MultiModelViewer()
+    for v in (tiles, blocks):
+        v.set_render_options(**opts)
+    return tiles, blocks
+
+
+def _frame(v, pose, keys, size, mode=GaussianDisplayMode.Splat):
+    v.update_camera(camera.orbit_pose(pose), size)
+    v.update_gaussian_transform(1.0, mode, GaussianShDegree.new(3), False)
+    v.render_frame(keys)
+    return v.download_framebuffer()
+
+
+@pytest.mark.parametrize("size", [(256, 176), (200, 136), (1920, 1080), (3840, 2160), (1000, 40)])
+@pytest.mark.parametrize("speculative", [0, 1])
+def test_block_lists_equal_tile_lists(monkeypatch, size, speculative):
+    g = common.small_scene(40000, 401, scale_mul=8.0 if size[0] < 1000 else 30.0)
+    tiles, blocks = _pair(monkeypatch, speculative=speculative, min_slab=4096)  # several depth slabs
+    for v in (tiles, blocks):
+        v.add_model("m", g.shape[0])
+        v.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g)
+    fewer = 0
+    for k, pose in enumerate([3, 4, 5, 6, 120, 121, 122, 122, 40]):
+        a, b = _frame(blocks, pose, ["m"], size), _frame(tiles, pose, ["m"], size)
+        assert np.array_equal(a, b), f"{size} frame {k}: L-inf {np.abs(a - b).max()}"
+        sa, sb = blocks.frame_stats("m"), tiles.frame_stats("m")
+        assert sa["n_visible"] == sb["n_visible"] and sa["n_sorted"] == sb["n_sorted"] and sa["speculated"] == sb["speculated"]
+        assert sa["n_repair_tiles"] == sb["n_repair_tiles"]
+        assert sa["n_tile_entries"] <= sb["n_tile_entries"]
+        fewer += sa["n_tile_entries"] < sb["n_tile_entries"]
+    tiles_n = ((size[0] + 15) // 16) * ((size[1] + 15) // 16)
+    if tiles_n > 256:
+        assert fewer >= 6, "blocks of several tiles must need fewer entries than tiles"
+    tiles.close()
+    blocks.close()
+
+
+def test_block_lists_layered_models_and_display_modes(monkeypatch):
+    ga = common.small_scene(20000, 402, scale_mul=10.0)
+    gb = common.small_scene(15000, 403, scale_mul=10.0)
+    tiles, blocks = _pair(monkeypatch, min_slab=2048)
+    for v in (tiles, blocks):
+        for key, g in (("far", ga), ("near", gb)):
+            v.add_model(key, g.shape[0])
+            v.models[key].gaussian_buffers.gaussians_buffer.update_range(0, g)
+    for k, (pose, mode) in enumerate([(10, GaussianDisplayMode.Splat), (11, GaussianDisplayMode.Splat), (12, GaussianDisplayMode.Ellipse),
+                                      (13, GaussianDisplayMode.Point), (14, GaussianDisplayMode.Splat), (15, GaussianDisplayMode.Splat)]):
+        a = _frame(blocks, pose, ["far", "near"], (640, 360), mode)
+        b = _frame(tiles, pose, ["far", "near"], (640, 360), mode)
+        assert np.array_equal(a, b), f"frame {k}"
+    tiles.close()
+    blocks.close()

@@ -7,7 +7,7 @@ for rep in 1 2 3; do
     r=$(python bench.py --no-cpu-baseline --no-pmc $ARGS 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-print('fps', d['value'], 'unspec', d.get('value_unspeculated'), 'project_us', d['roofline']['avg_launch_us'], 'geom_us', d.get('roofline_speculated',{}).get('avg_launch_us'), 'check', d.get('frame_check',{}).get('equal_to_unspeculated_single_pass'))")
+print('fps', d['value'], 'one', d.get('value_one_frame_in_flight'), 'unspec', d.get('value_unspeculated'), 'project_us', d['roofline']['avg_launch_us'], 'geom_us', d.get('roofline_speculated',{}).get('avg_launch_us'), 'check', d.get('frame_check',{}).get('equal_to_unspeculated_single_pass'))")
     echo "rep $rep $v: $r"
   done
 done

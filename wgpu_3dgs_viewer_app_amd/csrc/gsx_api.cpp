@@ -22,6 +22,7 @@ static gsx_status lane_create(gsx_viewer* v, gsx_viewer** out) {
     l->validate = v->validate;
     l->tile_cap_fixed = v->tile_cap_fixed;
     l->bin_mode = v->bin_mode;
+    l->blocks_max = v->blocks_max;
     HIPCHK(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
     l->own_stream = true;
     HIPCHK(hipEventCreateWithFlags(&l->lane_event, hipEventDisableTiming));
@@ -137,6 +138,7 @@ gsx_status gsx_viewer_create(const gsx_viewer_desc* desc, gsx_viewer** out) {
     v->validate = getenv("GSX_VALIDATE") != nullptr;
     if (const char* tc = getenv("GSX_TILE_CAP")) v->tile_cap_fixed = std::max<long long>(atoll(tc), 1);
     if (const char* bm = getenv("GSX_BIN")) v->bin_mode = atoi(bm) ? 1 : 0;
+    if (const char* bx = getenv("GSX_BLOCKS_MAX")) v->blocks_max = (uint32_t)std::max(16, std::min(1024, atoi(bx)));
     (void)radix_lane_ordered_adds();  // probes THIS device once per process (the answer is kept per device)
     v->device = desc->device;
     if (desc->stream) {

@@ -578,7 +578,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
             HIPCHK(hipMemsetAsync(m->tsort_ws.p, 0, m->tsort_ws.bytes, v->stream));
         }
         if (sizeof(uint2) * (size_t)n_tiles > m->ranges.bytes) m->ranges_clean = false;
-        HIPCHK(m->ranges.ensure(sizeof(uint2) * (size_t)std::max<uint32_t>(n_tiles, 256u)));  // (block lists: up to 256 block ranges)
+        HIPCHK(m->ranges.ensure(sizeof(uint2) * (size_t)std::max<uint32_t>(n_tiles, 1024u)));  // (block lists: up to 1024 block ranges)
     }
     // reset this model's per-frame totals (n_visible and n_sorted stay)
     if (!counters_zeroed)  // (the frame's first model: done together with the saturation state, one launch)
@@ -603,8 +603,8 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
     uint32_t bsx = 0, bsy = 0;
     if (blocks) {
         auto count = [&]() { return (uint64_t)((m->fc.tiles_x + (1u << bsx) - 1u) >> bsx) * ((m->fc.tiles_y + (1u << bsy) - 1u) >> bsy); };
-        while (count() > 256u) (bsx <= bsy ? bsx : bsy) += 1;
-        HIPCHK(m->block_table.ensure(sizeof(uint4) * 256));
+        while (count() > v->blocks_max) (bsx <= bsy ? bsx : bsy) += 1;
+        HIPCHK(m->block_table.ensure(sizeof(uint4) * 1024));
     }
     // a single-slab front model keeps its complete tile lists for gsx_model_download_tile_lists
     const bool clear_ranges = progressive && !(bounds.size() == 2 && !carry && !m->spec_round1 && !imported_windows);
@@ -621,7 +621,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
                 HIPCHK(launch_block_bin(v->stream, j0, j1, d_n, m->sorted_idx, m->rec(), m->sk_out.as<uint32_t>(), m->srect.as<uint4>(),
                                         m->cnt.as<uint32_t>(), m->block_sums.as<uint32_t>(), dc, cap, row_lo, row_hi, done_in, row_words,
                                         (progressive && later) ? done_count : nullptr, owned_tiles, slab_index, win, m->fc.tiles_x,
-                                        m->fc.tiles_y, bsx, bsy, m->block_table.as<uint4>(), m->tp_src.as<uint2>()));
+                                        m->fc.tiles_y, bsx, bsy, m->block_table.as<uint4>(), m->tp_src.as<uint2>(), m->ranges.as<uint2>()));
                 v->pass_launches[GSX_PASS_BIN] += 1;
             }
             {
@@ -629,12 +629,12 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
                 RadixBuffers rb{nullptr, nullptr, m->tp_src.as<uint2>(), m->tk_out.as<uint32_t>(), m->tv_out.as<uint32_t>(),
                                 m->tp_a.as<uint2>(), m->tp_b.as<uint2>(), m->tsort_ws.as<uint32_t>()};
                 const uint32_t block_cap = (uint32_t)std::min<uint64_t>(cap, (uint64_t)(j1 - j0) * 256u);
-                HIPCHK(launch_radix_sort(v->stream, rb, block_cap, &dc->n_entries, 8, false));
+                HIPCHK(launch_radix_sort(v->stream, rb, block_cap, &dc->n_entries, (int)std::max<uint32_t>(1u, ceil_log2(v->blocks_max)), false));
                 m->tile_keys = m->tk_out.as<uint32_t>();
                 m->tile_list = m->tv_out.as<uint32_t>();
                 v->pass_launches[GSX_PASS_TILE_SORT] += 1;
                 ScopedPass t2(v, GSX_PASS_BIN);
-                HIPCHK(launch_tile_ranges(v->stream, block_cap, &dc->n_entries, m->tile_keys, 256u, m->ranges.as<uint2>(), false));
+                HIPCHK(launch_tile_ranges(v->stream, block_cap, &dc->n_entries, m->tile_keys, 1024u, m->ranges.as<uint2>(), true));  // (k_block_table zeroed the block ranges)
                 m->ranges_clean = false;
             }
         } else {

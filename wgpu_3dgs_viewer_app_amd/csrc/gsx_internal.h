@@ -199,13 +199,14 @@ hipError_t launch_tile_ranges(hipStream_t s, uint32_t capacity, const uint32_t* 
                               uint32_t table_tiles, uint2* ranges, bool ranges_clean);
 size_t scan_blocks(uint64_t n);
 // Block lists (progressive frames): bin by blocks of 2^bsx x 2^bsy tiles (<= 256 blocks), one 8-bit sort pass, and
-// k_composite_blocks applies the exact per-tile decision.  brec: uint4 per slab record; table: 256 uint4.
+// k_composite_blocks applies the exact per-tile decision.  brec: uint4 per slab record; table: 1024 uint4; ranges: the block
+// range table (zeroed here, filled by launch_tile_ranges).
 hipError_t launch_block_bin(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* d_n_vis, const uint32_t* sorted_idx,
                             const Records& rec, const uint32_t* sorted_keys, uint4* brec, uint32_t* cnt, uint32_t* block_sums,
                             SlabStats* stats, uint32_t capacity, uint32_t row_lo, uint32_t row_hi, const uint32_t* done,
                             uint32_t row_words, const uint32_t* d_done_count, uint32_t owned_tiles, uint32_t slab_index,
                             const uint2* window, uint32_t tiles_x, uint32_t tiles_y, uint32_t bsx, uint32_t bsy, uint4* table,
-                            uint2* pairs);
+                            uint2* pairs, uint2* ranges);
 hipError_t launch_composite_blocks(hipStream_t s, const FrameConsts& f, const uint2* ranges, const uint32_t* list, const uint4* brec,
                                    const Records& rec, float4* fb, bool carry, uint32_t* done, uint32_t row_words,
                                    uint32_t* d_done_count, uint32_t* tile_sat, const uint2* window, uint32_t row_lo,

@@ -267,6 +267,7 @@ struct gsx_viewer {
     bool last_render_cont = false;
     unsigned long long* h_verdict = nullptr;  // pinned: {seq << 32 | tiles needing repair}, posted by k_spec_verify (host_verify)
     uint32_t verify_seq = 0;
+    uint32_t blocks_max = 256;    // GSX_BLOCKS_MAX: most blocks of a block-list frame (256: one 8-bit sort pass)
     int bin_mode = 1;             // GSX_BIN: 1 block lists for progressive frames (default), 0 per-tile lists always
     uint64_t tile_cap_fixed = 0;  // GSX_TILE_CAP was set when the viewer was created: pair-buffer capacity that never grows (tests of the spill path)
     bool validate = false;  // GSX_VALIDATE was set when the viewer was created: check tile ranges / lists before compositing (debug, synchronous)

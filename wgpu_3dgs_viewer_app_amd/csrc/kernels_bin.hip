@@ -383,9 +383,11 @@ struct BlockGrid {
 // table[b] = {min window start, max window end (of the non-empty windows of the block's live tiles), live}
 __global__ __launch_bounds__(256) void k_block_table(BlockGrid g, uint32_t tiles_x, uint32_t tiles_y, uint32_t row_lo, uint32_t row_hi,
                                                      const uint32_t* __restrict__ done, uint32_t row_words,
-                                                     const uint2* __restrict__ win, uint4* __restrict__ table) {
-    const uint32_t b = threadIdx.x;
+                                                     const uint2* __restrict__ win, uint4* __restrict__ table,
+                                                     uint2* __restrict__ ranges) {
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
     if (b >= g.blocks_x * g.blocks_y) return;
+    ranges[b] = make_uint2(0u, 0u);  // k_tile_ranges fills in the blocks that have entries
     const uint32_t bx = b % g.blocks_x, by = b / g.blocks_x;
     const uint32_t x0 = bx << g.bsx, x1 = min(x0 + (1u << g.bsx), tiles_x);
     const uint32_t y0 = max(by << g.bsy, row_lo), y1 = min(min((by + 1u) << g.bsy, tiles_y), row_hi);
@@ -434,12 +436,12 @@ __global__ __launch_bounds__(kBinThreads) void k_block_counts(const uint32_t* __
                                                                const uint32_t* __restrict__ d_done_count, uint32_t owned_tiles,
                                                                BlockGrid g, const uint4* __restrict__ table, int keyed) {
     __shared__ uint32_t red[4];
-    __shared__ uint4 tab[256];
+    __shared__ uint4 tab[1024];
     const uint32_t n_vis = min(*d_n_vis, j1);
     const uint32_t chunks = n_vis > j0 ? (n_vis - j0 + kBinThreads - 1) / kBinThreads : 0u;
     const bool all_done = d_done_count && *d_done_count >= owned_tiles;
     if (!all_done && blockIdx.x < chunks) {
-        tab[threadIdx.x] = threadIdx.x < g.blocks_x * g.blocks_y ? table[threadIdx.x] : make_uint4(0, 0, 0, 0);
+        for (uint32_t b = threadIdx.x; b < g.blocks_x * g.blocks_y; b += kBinThreads) tab[b] = table[b];
         __syncthreads();
     }
     for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
@@ -475,12 +477,13 @@ __global__ __launch_bounds__(kBinThreads) void k_block_emit(uint32_t jbase, uint
                                                              const uint32_t* __restrict__ d_cut, BlockGrid g,
                                                              const uint4* __restrict__ table, int keyed) {
     __shared__ uint32_t wsum[4];
-    __shared__ uint4 tab[256];
+    __shared__ uint4 tab[1024];
     if (*d_entries == 0) return;
     const uint32_t n_vis = min(min(j1, *d_n_vis), *d_cut);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chunks = n_vis > jbase ? (n_vis - jbase + kBinThreads - 1) / kBinThreads : 0u;
-    if (blockIdx.x < chunks) tab[tid] = tid < g.blocks_x * g.blocks_y ? table[tid] : make_uint4(0, 0, 0, 0);
+    if (blockIdx.x < chunks)
+        for (uint32_t b = tid; b < g.blocks_x * g.blocks_y; b += kBinThreads) tab[b] = table[b];
     __syncthreads();
     for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
         const uint32_t j = jbase + chunk * kBinThreads + tid;
@@ -516,10 +519,11 @@ hipError_t launch_block_bin(hipStream_t s, uint32_t j0, uint32_t j1, const uint3
                             SlabStats* stats, uint32_t capacity, uint32_t row_lo, uint32_t row_hi, const uint32_t* done,
                             uint32_t row_words, const uint32_t* d_done_count, uint32_t owned_tiles, uint32_t slab_index,
                             const uint2* window, uint32_t tiles_x, uint32_t tiles_y, uint32_t bsx, uint32_t bsy, uint4* table,
-                            uint2* pairs) {
+                            uint2* pairs, uint2* ranges) {
     const uint32_t nb = std::min<uint32_t>((uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0), kBinGrid);
     BlockGrid g{bsx, bsy, (tiles_x + (1u << bsx) - 1u) >> bsx, (tiles_y + (1u << bsy) - 1u) >> bsy};
-    hipLaunchKernelGGL(k_block_table, dim3(1), dim3(256), 0, s, g, tiles_x, tiles_y, row_lo, row_hi, done, row_words, window, table);
+    hipLaunchKernelGGL(k_block_table, dim3((g.blocks_x * g.blocks_y + 255u) / 256u), dim3(256), 0, s, g, tiles_x, tiles_y, row_lo, row_hi, done,
+                       row_words, window, table, ranges);
     if (nb)
         hipLaunchKernelGGL(k_block_counts, dim3(nb), dim3(kBinThreads), 0, s, d_n_vis, j0, j1, sorted_idx, rec.a, sorted_keys, brec, cnt,
                            block_sums, row_lo, row_hi, d_done_count, owned_tiles, g, table, window ? 1 : 0);

@@ -214,6 +214,12 @@ __global__ __launch_bounds__(128) void k_composite(const FrameConsts f, uint2* _
 // covers this tile and whose key lies in the tile's window — the exact per-tile decision, a handful of register compares.
 // Software pipeline, one stage deeper than k_composite's: while the takers of chunk c are blended out of LDS, the record
 // gathers of chunk c + 1's takers and the candidate loads of chunk c + 2 are in flight.
+#ifndef GSX_VAR_BLK_CAND
+#define GSX_VAR_BLK_CAND 1
+#endif
+constexpr int kCand = GSX_VAR_BLK_CAND;          // candidates per lane and iteration
+constexpr uint32_t kChunk = 128u * kCand;
+
 template <int MODE>
 __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, const uint2* __restrict__ ranges,
                                                            const uint32_t* __restrict__ list, const uint4* __restrict__ brec,
@@ -224,10 +230,10 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
                                                            uint32_t* __restrict__ tile_sat, const uint2* __restrict__ window,
                                                            const uint32_t row_lo, const uint32_t row_hi, const uint32_t bsx,
                                                            const uint32_t bsy, const uint32_t blocks_x) {
-    __shared__ float2 s_mean[128 + kGroup];
-    __shared__ float4 s_conic[128 + kGroup];
-    __shared__ float4 s_rgb[128 + kGroup];
-    __shared__ uint32_t s_sat, s_w[2];
+    __shared__ float2 s_mean[kChunk + kGroup];
+    __shared__ float4 s_conic[kChunk + kGroup];
+    __shared__ float4 s_rgb[kChunk + kGroup];
+    __shared__ uint32_t s_sat, s_w[2][kCand];
 
     const uint32_t tile = blockIdx.x;
     const uint32_t tx = tile % f.tiles_x, ty = tile / f.tiles_x;
@@ -257,32 +263,55 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
     uint32_t stop_key = 0;
     if (tid == 0) s_sat = 0;
 
+    // Candidate k of a chunk sits at list position chunk + 128 k + tid: sub-chunk k (128 consecutive candidates) comes before
+    // sub-chunk k + 1, inside one the waves in order, inside a wave the lanes — LDS slots are handed out in that order.
     // stage 1 registers: the next chunk's candidates; stage 2 registers: the gathered takers of the chunk before
-    uint4 cand = make_uint4(0u, 0u, 0u, 0u);
-    bool cand_ok = false;
-    {
-        const uint32_t at = range.x + tid;
-        if (at < range.y) {
-            cand = brec[list[at]];
-            cand_ok = true;
-        }
+    // (the list -> brec chain is split over two iterations: a load whose address is another load's result would stall the
+    // wave before the blend it is meant to hide under)
+    uint4 cand[kCand];
+    bool cand_ok[kCand];
+    uint32_t ent[kCand];   // list entries of the chunk after the candidates'
+    bool ent_ok[kCand];
+#pragma unroll
+    for (int k = 0; k < kCand; ++k) {
+        const uint32_t at = range.x + 128u * k + tid;
+        cand_ok[k] = at < range.y;
+        cand[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (cand_ok[k]) cand[k] = brec[list[at]];
+        ent_ok[k] = at + kChunk < range.y;
+        ent[k] = 0;
+        if (ent_ok[k]) ent[k] = list[at + kChunk];
     }
-    bool g_take = false;
-    uint32_t g_my = 0, g_cnt = 0;
-    float4 pa = make_float4(0, 0, 0, 0), pb = pa, pc4 = pa;
+    bool g_take[kCand];
+    uint32_t g_my[kCand], g_cnt[kCand];
+    float4 pa[kCand], pb[kCand], pc4[kCand];
+#pragma unroll
+    for (int k = 0; k < kCand; ++k) {
+        g_take[k] = false;
+        g_my[k] = g_cnt[k] = 0;
+        pa[k] = pb[k] = pc4[k] = make_float4(0, 0, 0, 0);
+    }
     const unsigned long long lt = (1ull << lane) - 1ull;
     // iteration i: write the takers gathered in iteration i - 1 to LDS, filter chunk i and start its gathers, prefetch the
     // candidates of chunk i + 1, blend; one more iteration drains the pipeline
-    for (uint32_t base = range.x; base < range.y + 128u; base += 128u) {
-        if (lane == 0) s_w[wave] = g_cnt;
+    for (uint32_t base = range.x; base < range.y + kChunk; base += kChunk) {
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < kCand; ++k) s_w[wave][k] = g_cnt[k];
+        }
         // vote + barrier: also protects the LDS batch of the previous iteration and publishes s_w
         if (__syncthreads_and((lim0 | lim1) == 0u)) break;
-        const uint32_t cnt = s_w[0] + s_w[1];
-        if (g_take) {
-            const uint32_t slot = (wave ? s_w[0] : 0u) + g_my;
-            s_mean[slot] = make_float2(pa.x, pa.y);
-            s_conic[slot] = make_float4(pb.x, 2.0f * pb.y, pb.z, pb.w);
-            s_rgb[slot] = pc4;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int k = 0; k < kCand; ++k) {
+            const uint32_t w0 = s_w[0][k], w1 = s_w[1][k];
+            if (g_take[k]) {
+                const uint32_t slot = cnt + (wave ? w0 : 0u) + g_my[k];
+                s_mean[slot] = make_float2(pa[k].x, pa[k].y);
+                s_conic[slot] = make_float4(pb[k].x, 2.0f * pb[k].y, pb[k].z, pb[k].w);
+                s_rgb[slot] = pc4[k];
+            }
+            cnt += w0 + w1;
         }
         if (tid < (uint32_t)kGroup) {  // the blend loop runs in whole groups
             s_mean[cnt + tid] = make_float2(3.0e38f, 3.0e38f);
@@ -291,22 +320,28 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
         }
         __syncthreads();
         // filter this chunk's candidates (already in registers) and start the gathers of its takers
-        g_take = cand_ok && tx >= (cand.x & 0xFFFFu) && tx < (cand.x >> 16) && ty >= (cand.y & 0xFFFFu) && ty < (cand.y >> 16) &&
-                 cand.z >= win.x && cand.z < win.y;
-        const unsigned long long bal = __ballot(g_take);
-        g_my = (uint32_t)__popcll(bal & lt);
-        g_cnt = (uint32_t)__popcll(bal);
-        if (g_take) {
-            pa = rec_a[cand.w];
-            pb = rec_b[cand.w];
-            pc4 = rec_c[cand.w];
+#pragma unroll
+        for (int k = 0; k < kCand; ++k) {
+            const uint4 c = cand[k];
+            g_take[k] = cand_ok[k] && tx >= (c.x & 0xFFFFu) && tx < (c.x >> 16) && ty >= (c.y & 0xFFFFu) && ty < (c.y >> 16) &&
+                        c.z >= win.x && c.z < win.y;
+            const unsigned long long bal = __ballot(g_take[k]);
+            g_my[k] = (uint32_t)__popcll(bal & lt);
+            g_cnt[k] = (uint32_t)__popcll(bal);
+            if (g_take[k]) {
+                pa[k] = rec_a[c.w];
+                pb[k] = rec_b[c.w];
+                pc4[k] = rec_c[c.w];
+            }
         }
-        // candidates of the chunk after
-        cand_ok = false;
-        const uint32_t nxt = base + 128u + tid;
-        if (nxt < range.y) {
-            cand = brec[list[nxt]];
-            cand_ok = true;
+        // candidates of the chunk after (their list entries arrived an iteration ago), list entries of the chunk after that
+#pragma unroll
+        for (int k = 0; k < kCand; ++k) {
+            cand_ok[k] = ent_ok[k];
+            if (cand_ok[k]) cand[k] = brec[ent[k]];
+            const uint32_t nn = base + 2u * kChunk + 128u * k + tid;
+            ent_ok[k] = nn < range.y;
+            if (ent_ok[k]) ent[k] = list[nn];
         }
         if (cnt) blend_batch<MODE>(f, cnt, s_mean, s_conic, s_rgb, pxf, pyf, lim0, lim1, T, C0, C1, C2, stop_key);
     }
