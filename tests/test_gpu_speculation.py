@@ -320,7 +320,8 @@ def test_fuzz_operation_sequences(seed):
               for i, k in enumerate("abc")}
     tr = {k: camera.ModelTransform(pos=rng.uniform(-2.0, 2.0, 3).astype(np.float32), rot=rng.uniform(-40, 40, 3).astype(np.float32),
                                    scale=rng.uniform(0.7, 1.3, 3).astype(np.float32)) for k in scenes}
-    spec, plain = _viewer(True, host_verify=seed % 3), _viewer(False)
+    lanes = 1 + seed % 3  # frames in flight: consecutive frames of the speculating viewer alternate between lanes
+    spec, plain = _viewer(True, host_verify=seed % 3, frames_in_flight=lanes), _viewer(False)
     for v in (spec, plain):
         for k, g in scenes.items():
             _load(v, k, g, tr[k])
@@ -367,7 +368,7 @@ def test_fuzz_operation_sequences(seed):
             both(lambda v: v.update_model_transform(k, tr[k].pos, tr[k].quat(), tr[k].scale))
         else:
             spec.set_render_options(speculative=1, min_slab=2048, spec_margin=float(rng.choice([0.0, 0.25, 1.0])), spec_radius=int(rng.integers(0, 5)),
-                                    host_verify=int(rng.integers(0, 3)))
+                                    host_verify=int(rng.integers(0, 3)), frames_in_flight=lanes)
         cam = camera.orbit_pose(pose)
         keys = [k for k in parallel.model_render_keys(cam.pos, tr) if k in visible]
         out = []
@@ -381,7 +382,7 @@ def test_fuzz_operation_sequences(seed):
             out.append(v.download_framebuffer())
         assert np.array_equal(out[0], out[1]), f"seed {seed} step {step} op {op}: L-inf {np.abs(out[0] - out[1]).max()}"
         speculated += any(spec.frame_stats(k)["speculated"] for k in keys)
-    assert speculated > 15
+    assert speculated > (15 if lanes == 1 else 8)
     spec.close()
     plain.close()
 
