@@ -88,7 +88,7 @@ static gsx_status lane_sync(gsx_viewer* v, gsx_viewer* l, const char* const* key
                         std::make_pair(&sm->sh_q, &pm->sh_q), std::make_pair(&sm->sh_aos, &pm->sh_aos), std::make_pair(&sm->cov_h, &pm->cov_h),
                         std::make_pair(&sm->cov_h2, &pm->cov_h2), std::make_pair(&sm->mask, &pm->mask)})
             pr.first->borrow(*pr.second);
-        if (sm->has_mask != pm->has_mask || sm->mask_program_hash != pm->mask_program_hash) sm->tuner.reset();
+        sm->tuner_ref = &pm->tuner;  // one speculate-or-not cycle per model, whichever lane renders the frame
         sm->has_mask = pm->has_mask;
         sm->mask_program_hash = pm->mask_program_hash;
         sm->mt = pm->mt;

@@ -74,7 +74,7 @@ constexpr uint32_t kProbeFrames = 5;   // the first is not timed (the switch its
 constexpr uint32_t kSettleFrames = 64; // at most this many frames between a probe and the decision it feeds (normally: until its timings are in)
 
 static void tuner_collect(Model* m) {
-    SpecTuner& t = m->tuner;
+    SpecTuner& t = m->tuner_ref ? *m->tuner_ref : m->tuner;
     for (auto& s : t.slots) {
         if (s.state < 2 || hipEventQuery(s.stop) != hipSuccess) continue;
         if (s.state == 3) {  // bracketed before a reset()
@@ -95,7 +95,7 @@ static void tuner_collect(Model* m) {
 
 // called once per gsx_preprocess of a model that could speculate; returns whether this frame should
 static bool tuner_wants_speculation(Model* m) {
-    SpecTuner& t = m->tuner;
+    SpecTuner& t = m->tuner_ref ? *m->tuner_ref : m->tuner;
     tuner_collect(m);
     static const bool debug = getenv("GSX_SPEC_DEBUG") != nullptr;
     // a settle phase ends as soon as the probe's timings are in (or after kSettleFrames at the latest)
@@ -144,7 +144,7 @@ static bool tuner_wants_speculation(Model* m) {
 // bracket this model's frame with events?  every frame of a probe but its first (the switch itself is atypical), every
 // fourth frame otherwise (an event pair costs a few microseconds of stream gap)
 static void tuner_frame_begin(gsx_viewer* v, Model* m, bool speculated) {
-    SpecTuner& t = m->tuner;
+    SpecTuner& t = m->tuner_ref ? *m->tuner_ref : m->tuner;
     t.active = nullptr;
     const bool probe = t.phase == SpecTuner::PROBE_PLAIN || t.phase == SpecTuner::PROBE_SPEC;
     if (probe ? t.left == kProbeFrames - 1 : (t.frame_no & 3u) != 0) return;
@@ -162,7 +162,7 @@ static void tuner_frame_begin(gsx_viewer* v, Model* m, bool speculated) {
 }
 
 static void tuner_frame_end(gsx_viewer* v, Model* m) {
-    SpecTuner& t = m->tuner;
+    SpecTuner& t = m->tuner_ref ? *m->tuner_ref : m->tuner;
     if (!t.active) return;
     t.active->state = hipEventRecord(t.active->stop, v->stream) == hipSuccess ? 2 : 0;
     if (t.active->state == 0 && t.active->probe && t.probe_pending) t.probe_pending -= 1;
@@ -335,7 +335,12 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
     const bool could_speculate = v->options.progressive && v->options.speculative && !(m->shard_win_set && m->shard_tiles_x == m->fc.tiles_x && m->shard_tiles_y == m->fc.tiles_y);
     if (could_speculate && !tuner_wants_speculation(m)) m->spec_round1 = false;
     // deep inside a plain phase nobody reads the windows this frame would leave behind (its last frame does: a probe follows)
-    m->windows_unwanted = could_speculate && m->tuner.phase == SpecTuner::PLAIN && m->tuner.left > 0;
+    {
+        // (with frames in flight every lane needs ITS windows for the probe: the last L frames of the phase keep them)
+        const SpecTuner& tn = m->tuner_ref ? *m->tuner_ref : m->tuner;
+        const uint32_t lanes = v->parent ? v->parent->options.frames_in_flight : v->options.frames_in_flight;
+        m->windows_unwanted = could_speculate && tn.phase == SpecTuner::PLAIN && tn.left >= lanes;
+    }
     ProjectAdmission adm{};
     HIPCHK(m->adm_ballots.ensure(8 * ((std::max<size_t>(m->n, 1) + 63) / 64 + 4)));
     HIPCHK(m->adm_counts.ensure(4 * (std::max<size_t>(std::max(admit_blocks(m->n), (size_t)(m->n + 255) / 256), 1) + 4)));

@@ -153,6 +153,7 @@ struct Model {
     // statistics keep a history of "this frame needed the repair round"; too many -> unspeculated frames for a while
     uint64_t mask_program_hash = 0;    // of the last gsx_mask_evaluate program (0: none / uploaded words)
     bool windows_unwanted = false;     // this frame need not leave windows for the next (SpecTuner: a plain phase)
+    SpecTuner* tuner_ref = nullptr;    // a lane's shadow model: the owner's tuner decides for every lane (one phase cycle per model)
     SpecTuner tuner;                   // speculate or not? decided by timing both paths (gsx_frame.cpp)
     // host_verify = 2 (auto): ask the device for its verdict only while repairs are rare
     bool hv_active = true;             // currently asking
