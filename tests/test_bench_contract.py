@@ -73,3 +73,9 @@ def test_profiled_kernel_time_agrees_with_bench():
     assert rows, "the kernel-trace summary holds the projection kernel"
     avg_ns = float(rows[0].rsplit('",', 1)[1].split(",")[2])
     assert abs(avg_ns / 1e3 - us) / us < 0.10, (avg_ns / 1e3, us)
+    # and the line the PROFILED run printed itself (same process as the trace: no run-to-run variance in between) within 5 %
+    own = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cfg4_kernel_stats_bench_line.json")))
+    if own:
+        o = json.loads(open(own[-1]).read().strip())
+        us_own = o["roofline"]["avg_launch_us"]
+        assert abs(avg_ns / 1e3 - us_own) / us_own < 0.05, (avg_ns / 1e3, us_own)
