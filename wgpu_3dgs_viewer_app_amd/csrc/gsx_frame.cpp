@@ -238,7 +238,7 @@ gsx_status ensure_record_capacity(Model* m, uint64_t count) {
     HIPCHK(m->rec_a.ensure(16 * n));
     HIPCHK(m->rec_b.ensure(16 * n));
     HIPCHK(m->rec_c.ensure(16 * n));
-    HIPCHK(m->block_vis.ensure(4 * (project_blocks(n) + 1)));
+    HIPCHK(m->block_vis.ensure(4 * (project_blocks(n) + 4)));  // (k_admit_scan reads it in uint4 steps)
     m->rec_cap = n;
     return GSX_OK;
 }

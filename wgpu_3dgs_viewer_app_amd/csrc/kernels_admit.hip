@@ -87,29 +87,35 @@ __global__ __launch_bounds__(1024) void k_admit_scan(const uint32_t* __restrict_
     __shared__ uint32_t vis_s[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid == 0) carry_s = 0;
-    if (visible) {
-        uint32_t s = 0;
-        for (uint32_t b = tid; b < nblocks; b += 1024) s += visible[b];
+    // Super-tiles of 1024 x kPer values, a contiguous run of kPer per thread, ALL of a thread's loads issued before the first
+    // is used (one workgroup: the kernel is a chain of memory round trips otherwise — 10 serial tiles cost 19 us at 39 K
+    // counts; this form: one round trip per 40 K).  The buffers are padded to a multiple of 4.
+    constexpr uint32_t kPer = 40, kVec = kPer / 4;
+    uint32_t vis = 0;
+    for (uint32_t base = 0; base < nblocks; base += 1024u * kPer) {
+        const uint32_t first = base + tid * kPer;
+        uint4 v[kVec], q[kVec];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-        if (lane == 0) vis_s[wave] = s;
-    }
-    __syncthreads();
-    if (visible && tid == 0) {
-        uint32_t t = 0;
-        for (int w = 0; w < 16; ++w) t += vis_s[w];
-        *d_n_visible = t;
-    }
-    // coalesced 4096-wide tiles (one uint4 per lane; the buffer is padded to a multiple of 4), carry between them
-    for (uint32_t base = 0; base < nblocks; base += 4096) {
-        const uint32_t i = base + 4u * tid;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (i < nblocks) v = *reinterpret_cast<const uint4*>(counts + i);
-        if (i + 1 >= nblocks) v.y = 0;
-        if (i + 2 >= nblocks) v.z = 0;
-        if (i + 3 >= nblocks) v.w = 0;
-        const uint32_t s4 = v.x + v.y + v.z + v.w;
-        uint32_t x = s4;
+        for (uint32_t k = 0; k < kVec; ++k) {
+            const uint32_t i = first + 4u * k;
+            v[k] = make_uint4(0, 0, 0, 0);
+            q[k] = make_uint4(0, 0, 0, 0);
+            if (i < nblocks) {
+                v[k] = *reinterpret_cast<const uint4*>(counts + i);
+                if (visible) q[k] = *reinterpret_cast<const uint4*>(visible + i);
+            }
+        }
+        uint32_t own = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kVec; ++k) {
+            const uint32_t i = first + 4u * k;
+            if (i + 1 >= nblocks) v[k].y = q[k].y = 0;
+            if (i + 2 >= nblocks) v[k].z = q[k].z = 0;
+            if (i + 3 >= nblocks) v[k].w = q[k].w = 0;
+            own += v[k].x + v[k].y + v[k].z + v[k].w;
+            vis += q[k].x + q[k].y + q[k].z + q[k].w;
+        }
+        uint32_t x = own;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t y = __shfl_up(x, o, 64);
@@ -117,21 +123,37 @@ __global__ __launch_bounds__(1024) void k_admit_scan(const uint32_t* __restrict_
         }
         if (lane == 63) wsum[wave] = x;
         __syncthreads();
-        uint32_t off = carry_s + x - s4;
+        uint32_t off = carry_s + x - own;
         for (uint32_t w = 0; w < wave; ++w) off += wsum[w];
-        if (i < nblocks) {
-            const uint4 o4 = make_uint4(off, off + v.x, off + v.x + v.y, off + v.x + v.y + v.z);
-            if (i + 3 < nblocks) {
-                *reinterpret_cast<uint4*>(offsets + i) = o4;
-            } else {
-                offsets[i] = o4.x;
-                if (i + 1 < nblocks) offsets[i + 1] = o4.y;
-                if (i + 2 < nblocks) offsets[i + 2] = o4.z;
+#pragma unroll
+        for (uint32_t k = 0; k < kVec; ++k) {
+            const uint32_t i = first + 4u * k;
+            if (i < nblocks) {
+                const uint4 o4 = make_uint4(off, off + v[k].x, off + v[k].x + v[k].y, off + v[k].x + v[k].y + v[k].z);
+                if (i + 3 < nblocks) {
+                    *reinterpret_cast<uint4*>(offsets + i) = o4;
+                } else {
+                    offsets[i] = o4.x;
+                    if (i + 1 < nblocks) offsets[i + 1] = o4.y;
+                    if (i + 2 < nblocks) offsets[i + 2] = o4.z;
+                }
             }
+            off += v[k].x + v[k].y + v[k].z + v[k].w;
         }
         __syncthreads();
-        if (tid == 1023) carry_s = off + s4;
+        if (tid == 1023) carry_s = off;
         __syncthreads();
+    }
+    if (visible) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vis += __shfl_down(vis, o, 64);
+        if (lane == 0) vis_s[wave] = vis;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t t = 0;
+            for (int w = 0; w < 16; ++w) t += vis_s[w];
+            *d_n_visible = t;
+        }
     }
     if (tid == 0) *d_total = carry_s;
 }

@@ -380,34 +380,44 @@ struct BlockGrid {
     uint32_t blocks_x, blocks_y;
 };
 
-// table[b] = {min window start, max window end (of the non-empty windows of the block's live tiles), live}
+// table[b] = {min window start, max window end (of the non-empty windows of the block's live tiles), live}; also zeroes the
+// block's range (k_tile_ranges fills in the blocks that have entries).  One wave per block, a lane per tile.
 __global__ __launch_bounds__(256) void k_block_table(BlockGrid g, uint32_t tiles_x, uint32_t tiles_y, uint32_t row_lo, uint32_t row_hi,
                                                      const uint32_t* __restrict__ done, uint32_t row_words,
                                                      const uint2* __restrict__ win, uint4* __restrict__ table,
                                                      uint2* __restrict__ ranges) {
-    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, b = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (b >= g.blocks_x * g.blocks_y) return;
-    ranges[b] = make_uint2(0u, 0u);  // k_tile_ranges fills in the blocks that have entries
     const uint32_t bx = b % g.blocks_x, by = b / g.blocks_x;
     const uint32_t x0 = bx << g.bsx, x1 = min(x0 + (1u << g.bsx), tiles_x);
     const uint32_t y0 = max(by << g.bsy, row_lo), y1 = min(min((by + 1u) << g.bsy, tiles_y), row_hi);
     uint32_t lo = 0xFFFFFFFFu, hi = 0u, live = 0u;
-    for (uint32_t ty = y0; ty < y1; ++ty)
-        for (uint32_t tx = x0; tx < x1; ++tx) {
-            if (done && ((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)) continue;
-            if (win) {
-                const uint2 w = win[ty * tiles_x + tx];
-                if (w.x >= w.y) continue;
-                lo = min(lo, w.x);
-                hi = max(hi, w.y);
-            }
-            live = 1u;
+    const uint32_t w = x1 - x0, total = y1 > y0 ? w * (y1 - y0) : 0u;
+    for (uint32_t k = lane; k < total; k += 64) {
+        const uint32_t tx = x0 + k % w, ty = y0 + k / w;
+        if (done && ((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)) continue;
+        if (win) {
+            const uint2 ww = win[ty * tiles_x + tx];
+            if (ww.x >= ww.y) continue;
+            lo = min(lo, ww.x);
+            hi = max(hi, ww.y);
         }
+        live = 1u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor(lo, o, 64));
+        hi = max(hi, (uint32_t)__shfl_xor(hi, o, 64));
+        live |= (uint32_t)__shfl_xor(live, o, 64);
+    }
     if (!win) {
         lo = 0u;
         hi = 0xFFFFFFFFu;
     }
-    table[b] = make_uint4(lo, hi, live, 0u);
+    if (lane == 0) {
+        table[b] = make_uint4(lo, hi, live, 0u);
+        ranges[b] = make_uint2(0u, 0u);
+    }
 }
 
 __device__ inline bool block_takes(const uint4* tab, uint32_t b, uint32_t key, bool keyed) {
@@ -522,7 +532,7 @@ hipError_t launch_block_bin(hipStream_t s, uint32_t j0, uint32_t j1, const uint3
                             uint2* pairs, uint2* ranges) {
     const uint32_t nb = std::min<uint32_t>((uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0), kBinGrid);
     BlockGrid g{bsx, bsy, (tiles_x + (1u << bsx) - 1u) >> bsx, (tiles_y + (1u << bsy) - 1u) >> bsy};
-    hipLaunchKernelGGL(k_block_table, dim3((g.blocks_x * g.blocks_y + 255u) / 256u), dim3(256), 0, s, g, tiles_x, tiles_y, row_lo, row_hi, done,
+    hipLaunchKernelGGL(k_block_table, dim3((g.blocks_x * g.blocks_y + 3u) / 4u), dim3(256), 0, s, g, tiles_x, tiles_y, row_lo, row_hi, done,
                        row_words, window, table, ranges);
     if (nb)
         hipLaunchKernelGGL(k_block_counts, dim3(nb), dim3(kBinThreads), 0, s, d_n_vis, j0, j1, sorted_idx, rec.a, sorted_keys, brec, cnt,
