@@ -222,7 +222,9 @@ gsx_status gsx_framebuffer_device_ptr(gsx_viewer* v, void** out_ptr, uint32_t* o
 typedef struct gsx_frame_stats {
     uint64_t n_gaussians; /* N of the model */
     uint64_t n_visible;   /* N_vis after cull */
-    uint64_t n_tile_entries; /* D = tile entries binned by the last gsx_render (all of them with progressive = 0) */
+    uint64_t n_tile_entries; /* D = list entries binned by the last gsx_render: (Gaussian, tile) pairs for a frame that keeps
+                                per-tile lists (progressive = 0, or a single-slab front model: all of them), (Gaussian, block of
+                                tiles) pairs for the depth slabs of a progressive frame (fewer: see DESIGN.md, block lists) */
     uint64_t n_sorted;       /* records that entered the depth sort (= n_visible unless the frame was speculated) */
     uint64_t n_repair_tiles; /* speculated frame: tiles that needed the repair round */
     uint64_t n_repair_sorted; /* speculated frame: records that entered the repair round's depth sort */
