@@ -669,11 +669,13 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
                                           m->ranges.as<uint2>(), m->ranges_clean));
             }
         }
-        if (v->validate && !blocks) {  // debug: check what the compositor will dereference, on the host, before it runs
+        if (v->validate) {  // debug: check what the compositor will dereference, on the host, before it runs
             HIPCHK(v->scratch.ensure(64));
             HIPCHK(hipMemsetAsync(v->scratch.p, 0, 64, v->stream));
-            HIPCHK(launch_validate_tiles(v->stream, m->ranges.as<uint2>(), n_tiles, m->tile_list, &dc->n_entries, slab_cap, (uint32_t)m->rec_n,
-                                         v->scratch.as<uint32_t>()));
+            // (block lists: one range per block, list values are positions in the slab)
+            const uint32_t n_ranges = blocks ? ((m->fc.tiles_x + (1u << bsx) - 1u) >> bsx) * ((m->fc.tiles_y + (1u << bsy) - 1u) >> bsy) : n_tiles;
+            HIPCHK(launch_validate_tiles(v->stream, m->ranges.as<uint2>(), n_ranges, m->tile_list, &dc->n_entries, blocks ? cap : slab_cap,
+                                         blocks ? j1 - j0 : (uint32_t)m->rec_n, v->scratch.as<uint32_t>()));
             uint32_t rep[8];
             HIPCHK(hipMemcpyAsync(rep, v->scratch.p, 32, hipMemcpyDeviceToHost, v->stream));
             HIPCHK(hipStreamSynchronize(v->stream));
