@@ -78,6 +78,7 @@ def parse_args():
                     "a few microseconds of stream gap per pass boundary)")
     ap.add_argument("--frames-in-flight", type=int, default=2,
                     help="gsx_render_options.frames_in_flight of the headline loop at N=1 (the one-in-flight rate is reported beside it)")
+    ap.add_argument("--dist-frames-in-flight", type=int, default=1, help="frames_in_flight of gsx_shard_render_frame (N > 1 / --force-dist)")
     ap.add_argument("--unspeculated-in-flight", action="store_true",
                     help="N=1: also time the unspeculated loop with --frames-in-flight lanes (off by default: its contended k_project "
                          "launches would blur the kernel-trace average the roofline is checked against)")
@@ -312,7 +313,11 @@ def main():
         renderer.profile = {}
     # N = 1: the headline loop keeps --frames-in-flight frames in flight (lanes inside libgsx: own stream and per-frame buffers,
     # shared scene); the same loop with one frame in flight follows, and the kernel rooflines are measured there, uncontended
-    lanes = args.frames_in_flight if (single and not overrides) else 1
+    # (N > 1 / --force-dist: gsx_shard_render_frame accepts frames_in_flight too — the verdict of frame k is then read after
+    # frame k + 1 is enqueued — but with every collective on one in-order stream frame k + 1's exchange queues behind frame k's
+    # band gather: 1230 -> 1015 fps at world 1.  --dist-frames-in-flight L runs it anyway.)
+    lib_index = use_dist and args.shard_mode == "index"
+    lanes = args.frames_in_flight if (single and not overrides) else (args.dist_frames_in_flight if lib_index else 1)
 
     def set_opts(**kw):
         viewer.set_render_options(**dict(overrides, **kw))
@@ -332,7 +337,7 @@ def main():
         fb_last = renderer.framebuffer().copy()
     acct = accounting(rounds(args.warmup))
     elapsed_1 = elapsed_ul = None
-    if lanes > 1:
+    if lanes > 1 and (single or world == 1):   # (N > 1: one timed loop, as the contract says)
         set_opts()
         elapsed_1, timing, _ = timed_loop(0)
         acct = accounting(rounds(args.warmup))

@@ -422,6 +422,46 @@ def test_library_transport_world1_over_rccl():
         v.close()
 
 
+@pytest.mark.parametrize("lanes", [2, 3])
+def test_library_transport_with_frames_in_flight(lanes):
+    """gsx_shard_render_frame with gsx_render_options.frames_in_flight > 1: frame k is enqueued on lane k mod L before the verdict
+    of the frame before is looked at; every collective goes through one stream in program order.  One rank over real RCCL:
+    every frame, read back right away or after a run of un-synchronised calls, equals the single viewer's."""
+    g = _scene()
+    ref = _single_frames(g)
+    v = parallel.ShardedViewer(world=1, rank=0, use_dist=True, comm="lib")
+    v.stages.viewer.set_render_options(frames_in_flight=lanes)
+    v.load_shard(g, 0, N)
+    for k, pose in enumerate(POSES):           # readback after every frame: completes the frame just enqueued
+        v.render_frame(camera.orbit_pose(pose), (W, H))
+        fb = v.framebuffer()
+        assert np.array_equal(fb, ref[k][0]), f"lanes {lanes}: frame {k} differs, L-inf {np.abs(fb - ref[k][0]).max()}"
+    for rep in range(3):                       # runs without a host wait: the verdict of a frame is read a call later
+        for k, pose in enumerate(POSES):
+            v.render_frame(camera.orbit_pose(pose), (W, H))
+        v.poll()
+        fb = v.framebuffer()
+        assert np.array_equal(fb, ref[len(POSES) - 1][0]), f"lanes {lanes}: run {rep}"
+        st = v.stages.viewer.frame_stats(v.KEY)
+        assert st["n_gaussians"] == N and st["overflow_slabs"] == 0
+    # a change of the model data between frames reaches every lane (mask: half the Gaussians disappear, then come back)
+    from wgpu_3dgs_viewer_app_amd.mask import MaskEvaluator, MaskOp, MaskShape, MaskShapeKind
+
+    shapes = [MaskShape(MaskShapeKind.Box, pos=np.array([0.0, -5.0, 0.0], np.float32), scale=np.array([10.0, 5.0, 10.0], np.float32))]
+    MaskEvaluator(v.stages.viewer).evaluate(MaskOp.parse("0"), v.KEY, shapes)
+    masked = []
+    for pose in POSES[:4]:
+        v.render_frame(camera.orbit_pose(pose), (W, H))
+        masked.append(v.framebuffer())
+    MaskEvaluator(v.stages.viewer).evaluate(None, v.KEY)
+    for k, pose in enumerate(POSES[:4]):
+        v.render_frame(camera.orbit_pose(pose), (W, H))
+        fb = v.framebuffer()
+        assert np.array_equal(fb, ref[k][0]), f"lanes {lanes}: after the mask reset, frame {k}"
+        assert not np.array_equal(fb, masked[k]), "the mask must have changed the frames"
+    v.close()
+
+
 def test_verdict_reports_a_slot_that_was_too_small():
     """Stage level: a slot smaller than what the rank has for a destination -> the header says so, the verdict's overflow
     flag is set and max_records is what was wanted (ShardedViewer / gsx_shard_render_frame then redo round 0 with the

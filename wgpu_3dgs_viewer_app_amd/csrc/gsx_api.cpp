@@ -55,6 +55,8 @@ static gsx_status lane_sync(gsx_viewer* v, gsx_viewer* l, const char* const* key
     l->no_sh0 = v->no_sh0;
     memcpy(l->highlight, v->highlight, sizeof l->highlight);
     l->sel_edit = v->sel_edit;
+    l->band_lo = v->band_lo;
+    l->band_hi = v->band_hi;
     if (l->options.progressive != v->options.progressive || l->options.speculative != v->options.speculative)
         for (auto& kv : l->models) kv.second->spec_round1 = kv.second->sorted = false;
     l->options = v->options;
@@ -103,6 +105,21 @@ static gsx_status lane_sync(gsx_viewer* v, gsx_viewer* l, const char* const* key
     }
     return GSX_OK;
 }
+
+namespace gsx {
+gsx_status lane_acquire(gsx_viewer* v, uint32_t index, const char* const* keys, uint32_t n_keys, gsx_viewer** out) {
+    *out = v;
+    if (index == 0) return GSX_OK;
+    gsx_status st = GSX_OK;
+    while (v->lanes.size() < index) {
+        gsx_viewer* l = nullptr;
+        if ((st = lane_create(v, &l))) return st;
+        v->lanes.push_back(l);
+    }
+    *out = v->lanes[index - 1];
+    return lane_sync(v, *out, keys, n_keys);
+}
+}  // namespace gsx
 
 extern "C" {
 
@@ -164,6 +181,12 @@ void gsx_viewer_destroy(gsx_viewer* v) {
     v->lanes.clear();
     (void)hipStreamSynchronize(v->stream);
     if (v->lane_event) (void)hipEventDestroy(v->lane_event);
+    if (v->comm_ev_in) (void)hipEventDestroy(v->comm_ev_in);
+    if (v->comm_ev_out) (void)hipEventDestroy(v->comm_ev_out);
+    if (v->comm_stream) {
+        (void)hipStreamSynchronize(v->comm_stream);
+        (void)hipStreamDestroy(v->comm_stream);
+    }
     (void)gsx_viewer_comm_destroy(v);
     if (v->h_shard_verdict) (void)hipHostFree(v->h_shard_verdict);
     for (auto& t : v->timers) {
@@ -507,15 +530,7 @@ gsx_status gsx_render_frame(gsx_viewer* v, const char* const* keys, uint32_t n_k
     if (frame_may_overlap(v, keys, n_keys)) {
         HIPCHK(hipSetDevice(v->device));  // NOT viewer_bind: frames in flight stay in flight
         const uint32_t turn = v->lane_turn++ % v->options.frames_in_flight;
-        if (turn > 0) {
-            while (v->lanes.size() < turn) {
-                gsx_viewer* l = nullptr;
-                if ((st = lane_create(v, &l))) return st;
-                v->lanes.push_back(l);
-            }
-            lane = v->lanes[turn - 1];
-            if ((st = lane_sync(v, lane, keys, n_keys))) return st;
-        }
+        if ((st = lane_acquire(v, turn, keys, n_keys, &lane))) return st;
     } else if ((st = viewer_bind(v))) {
         return st;
     }

@@ -1,5 +1,7 @@
 // gsx_api_shard.cpp — C ABI for multi-GPU rendering: band layout, external framebuffer, screen bands, and the stage split of
 // the index-sharded exchange (pack / import / feedback / second round).  No reference counterpart (src/main.rs:85-98).
+#include <chrono>
+
 #include "gsx_state.h"
 
 using namespace gsx;
@@ -487,6 +489,9 @@ gsx_status gsx_shard_verify(gsx_viewer* v, const char* key, uint32_t world, cons
 // drains (or fails) and the words still are not there, that is reported instead of spinning forever.
 gsx_status gsx_shard_wait_verdict(gsx_viewer* v, const char* key, uint32_t seq, gsx_shard_verdict* out) {
     if (!v || !out || !v->h_shard_verdict) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_wait_verdict: nothing was posted");
+    // a verdict that does not come within a minute is a collective that cannot complete (a rank died, or the ranks disagree
+    // about what to exchange): an error the caller can report, not a process that spins for ever
+    const auto t_start = std::chrono::steady_clock::now();
     for (uint64_t spin = 1;; ++spin) {
         const unsigned long long w = __atomic_load_n(&v->h_shard_verdict[0], __ATOMIC_ACQUIRE);
         if ((uint32_t)(w >> 32) == seq) {
@@ -505,6 +510,8 @@ gsx_status gsx_shard_wait_verdict(gsx_viewer* v, const char* key, uint32_t seq, 
                 return fail(GSX_ERR_HIP, "gsx_shard_wait_verdict: verdict %u never arrived (stream idle)", seq);
             }
             if (e != hipErrorNotReady) return fail(GSX_ERR_HIP, "stream failed while waiting for the exchange verdict: %s", hipGetErrorString(e));
+            if ((spin & 0xFFFFFu) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(60))
+                return fail(GSX_ERR_RCCL, "gsx_shard_wait_verdict: verdict %u did not arrive within 60 s (a collective is stuck)", seq);
         }
         __builtin_ia32_pause();
     }

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <string>
@@ -242,6 +243,14 @@ struct PassTimer {
 
 using namespace gsx;
 
+// an index-sharded frame whose round 0 is enqueued and whose verdict has not been looked at yet (gsx_comm.cpp)
+struct ShardPending {
+    gsx_viewer* lane = nullptr;
+    std::string key;
+    uint32_t seq = 0, slot_records = 0, shard_records_max = 0, speculate = 0, radius = 0;
+    float margin = 0.0f;
+};
+
 struct gsx_viewer {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -256,6 +265,13 @@ struct gsx_viewer {
     hipEvent_t lane_event = nullptr;     // lane: end of its last frame; parent: "everything enqueued so far" for the lanes to wait on
     bool lane_busy = false;              // lane: it has a frame the parent's stream has not been ordered after
     uint64_t epoch = 1, seen_epoch = 0;  // parent: bumped by every call that may touch model data; lane: the epoch it has waited for
+    // sharded frames in flight (gsx_shard_render_frame with frames_in_flight > 1, gsx_comm.cpp): every collective of every
+    // lane goes through ONE stream in program order (one communicator, the same order on every rank)
+    hipStream_t comm_stream = nullptr;   // owner only
+    hipEvent_t comm_ev_in = nullptr, comm_ev_out = nullptr;  // this viewer's hand-over to / from the comm stream
+    std::deque<ShardPending> shard_pending;  // owner only: oldest first
+    bool shard_busy = false;             // gsx_shard_render_frame is enqueueing / completing: viewer_bind must not complete frames
+    uint32_t shard_turn = 0;
     gsx_spec_params params{};
     float view[16]{}, proj[16]{};
     uint32_t width = 1, height = 1;
@@ -333,10 +349,16 @@ inline uint32_t ceil_log2(uint32_t x) {
 // Every entry point but gsx_render_frame and the uniform setters comes through here.  With frames in flight, the caller
 // may be about to read results or to change model data the lanes are still reading: the viewer's stream is ordered after
 // the lanes' frames (no host wait), and the lanes' next frames after whatever the caller enqueues (epoch).
+gsx_status shard_complete_pending(gsx_viewer* v);  // gsx_comm.cpp: verdicts, redo / repair rounds of the sharded frames in flight
+
 inline gsx_status viewer_bind(gsx_viewer* v) {
     if (!v) return fail(GSX_ERR_INVALID_ARG, "viewer is null");
     HIPCHK(hipSetDevice(v->device));
-    if (!v->lanes.empty()) {
+    if (!v->shard_pending.empty() && !v->shard_busy) {
+        gsx_status pst = shard_complete_pending(v);
+        if (pst) return pst;
+    }
+    if (!v->lanes.empty() && !v->shard_busy) {  // (inside gsx_shard_render_frame the lanes' frames stay in flight)
         for (gsx_viewer* l : v->lanes)
             if (l->lane_busy) {
                 HIPCHK(hipStreamWaitEvent(v->stream, l->lane_event, 0));
@@ -357,6 +379,9 @@ inline gsx_status ensure_fb(gsx_viewer* v) {
     return GSX_OK;
 }
 inline float4* fb_ptr(gsx_viewer* v) { return v->ext_fb ? static_cast<float4*>(v->ext_fb) : reinterpret_cast<float4*>(v->fb.p); }
+
+// lane `index` (0 = the viewer itself) brought up to date for a frame of `keys` (gsx_api.cpp)
+gsx_status lane_acquire(gsx_viewer* v, uint32_t index, const char* const* keys, uint32_t n_keys, gsx_viewer** out);
 
 // ---- frame scheduling (gsx_frame.cpp) ----
 // defer_visible_count: a gsx_sort of this model follows at once (gsx_render_frame): its admission scan sums N_vis
