@@ -31,11 +31,25 @@ __global__ __launch_bounds__(kAdmitThreads) void k_admit_count(const uint32_t* _
     const bool skip = d_skip && *d_skip == 0;  // verification round with nothing to repair: admit nothing
     const uint32_t base = blockIdx.x * kAdmitTile + wave * kAdmitWaveChunk;
     uint32_t c = 0;
+    // every key and rectangle of the wave's 16 rounds first: the loop below is a chain of dependent loads per round otherwise
+    // (key -> rectangle -> four pyramid cells), and a wave that walks 16 such chains one after the other is latency, not
+    // bandwidth (70 us for 80 MB at 10 M records)
+    uint32_t kks[kAdmitRounds], rxs[kAdmitRounds], rys[kAdmitRounds];
+#pragma unroll
     for (int r = 0; r < kAdmitRounds; ++r) {
         const uint32_t e = base + r * 64 + lane;
-        uint32_t kk = kCulledKey, rx = 0, ry = 0;
-        if (!skip && e < n) kk = key[e];
-        if ((window || pyr.data) && kk != kCulledKey) rec_rect(rec_a, rect8, e, rx, ry);
+        kks[r] = kCulledKey;
+        if (!skip && e < n) kks[r] = key[e];
+    }
+#pragma unroll
+    for (int r = 0; r < kAdmitRounds; ++r) {
+        const uint32_t e = base + r * 64 + lane;
+        rxs[r] = rys[r] = 0;
+        if ((window || pyr.data) && !skip && e < n) rec_rect(rec_a, rect8, e, rxs[r], rys[r]);  // (culled records too: no wait for the key)
+    }
+#pragma unroll
+    for (int r = 0; r < kAdmitRounds; ++r) {
+        const uint32_t kk = kks[r], rx = rxs[r], ry = rys[r];
         bool adm;
         if (pyr.data) adm = kk != kCulledKey && pyramid_admits(pyr, kk, rx, ry);
         else if (window) adm = wave_dest_mask(window, tiles_x, kk, rx, ry, 0x10000u, 1u, gate, row_words) & 1ull;
