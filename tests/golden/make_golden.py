@@ -157,3 +157,19 @@ if __name__ == "__main__":
     if want("point"):
         make("frame_point_mode_size15_80x48_n500_seed111", [(scene_small(500, 111), odd)], camera.orbit_pose(210), 80, 48,
              display_mode=2, size=1.5)
+    # more of round 2: the SH degrees in between, no_sh0, a union mask on a Half/Half pod, three layered models
+    if want("sh1"):
+        make("frame_sh1_80x48_n400_seed112", [(scene_small(400, 112), odd)], camera.orbit_pose(5), 80, 48, sh_deg=1)
+    if want("sh2_nosh0"):
+        make("frame_sh2_nosh0_80x48_n400_seed113", [(scene_small(400, 113), ident)], camera.orbit_pose(100), 80, 48, sh_deg=2, no_sh0=1)
+    if want("half_half_union"):
+        shapes = [dict(kind=1, pos=(0.8, 0.0, 0.0), quat=(0.0, 0.0, 0.0, 1.0), scale=(1.2, 2.0, 1.2)),
+                  dict(kind=0, pos=(-0.8, 0.2, 0.1), quat=tuple(camera.quat_from_euler_zyx(0.1, 0.7, -0.2)), scale=(1.0, 1.5, 2.0))]
+        make("frame_pod_half_half_mask_union_96x64_n600_seed114", [(scene_small(600, 114), ident)], camera.orbit_pose(45), 96, 64,
+             pod=(1, 1), mask=("0 | 1", shapes))
+    if want("3models"):
+        make("frame_sh3_3models_layered_112x80_seed115",
+             [(scene_small(350, 115), odd), (scene_small(300, 116), camera.ModelTransform(pos=np.array([0.0, 0.4, -1.2], np.float32))),
+              (scene_small(300, 117), camera.ModelTransform(pos=np.array([1.0, 0.0, 1.0], np.float32), scale=np.array([0.8, 0.8, 0.8], np.float32)))],
+             camera.orbit_pose(180), 112, 80, pod=(2, 1))
+
