@@ -31,6 +31,8 @@ python3 bench.py --force-dist --no-cpu-baseline --no-pmc > $OUT/bench_index_worl
 python3 bench.py --no-cpu-baseline --no-pmc --no-robustness --unspeculated-in-flight > $OUT/bench_inflight2_both.json 2>> $OUT/bench.err
 python3 bench.py --no-cpu-baseline --no-pmc --no-robustness --frames-in-flight 1 > $OUT/bench_inflight1.json 2>> $OUT/bench.err
 python3 bench.py --no-cpu-baseline --no-pmc --no-robustness --frames-in-flight 3 > $OUT/bench_inflight3.json 2>> $OUT/bench.err
+# 7. BASELINE configs[4] on one GPU: 4 x 6 M Gaussians at 3840x2160, with and without the stored selection + edit
+(python3 tools/bench_cfg5.py; python3 tools/bench_cfg5.py --edit 0) 2>> $OUT/bench.err | grep '^{' > $OUT/bench_cfg5.json
 tools/bench_hbm > $OUT/bench_hbm.txt 2>&1
 python3 tools/emulate_ranks.py --world 8 --frames 30 > $OUT/emulate_world8.txt 2>&1
 python3 tools/emulate_ranks.py --world 2 --frames 30 > $OUT/emulate_world2.txt 2>&1
