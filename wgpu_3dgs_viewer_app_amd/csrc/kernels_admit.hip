@@ -96,22 +96,23 @@ __global__ __launch_bounds__(kAdmitThreads) void k_admit_scatter(const uint32_t*
 __global__ __launch_bounds__(1024) void k_admit_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets, uint32_t nblocks,
                                                      uint32_t* __restrict__ d_total, const uint32_t* __restrict__ visible,
                                                      uint32_t* __restrict__ d_n_visible) {
-    __shared__ uint32_t wsum[16];
+    constexpr uint32_t kTiles = 10;
+    __shared__ uint32_t wtot[kTiles][16], wpre[kTiles][16];
     __shared__ uint32_t carry_s;
     __shared__ uint32_t vis_s[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid == 0) carry_s = 0;
-    // Super-tiles of 1024 x kPer values, a contiguous run of kPer per thread, ALL of a thread's loads issued before the first
-    // is used (one workgroup: the kernel is a chain of memory round trips otherwise — 10 serial tiles cost 19 us at 39 K
-    // counts; this form: one round trip per 40 K).  The buffers are padded to a multiple of 4.
-    constexpr uint32_t kPer = 40, kVec = kPer / 4;
+    __syncthreads();
+    // Super-tiles of kTiles coalesced 4096-wide tiles (one uint4 per lane each; the buffers are padded to a multiple of 4):
+    // ALL loads of a super-tile are issued before the first is used — one memory round trip per 40 K counts instead of one
+    // per tile (the kernel is a single workgroup: ten serial round trips and thirty barriers were its 19 us).  (A contiguous
+    // run per thread instead of coalesced tiles moved 10x the cache lines through the one CU and was no faster.)
     uint32_t vis = 0;
-    for (uint32_t base = 0; base < nblocks; base += 1024u * kPer) {
-        const uint32_t first = base + tid * kPer;
-        uint4 v[kVec], q[kVec];
+    for (uint32_t base = 0; base < nblocks; base += 4096u * kTiles) {
+        uint4 v[kTiles], q[kTiles];
 #pragma unroll
-        for (uint32_t k = 0; k < kVec; ++k) {
-            const uint32_t i = first + 4u * k;
+        for (uint32_t k = 0; k < kTiles; ++k) {
+            const uint32_t i = base + 4096u * k + 4u * tid;
             v[k] = make_uint4(0, 0, 0, 0);
             q[k] = make_uint4(0, 0, 0, 0);
             if (i < nblocks) {
@@ -119,30 +120,39 @@ __global__ __launch_bounds__(1024) void k_admit_scan(const uint32_t* __restrict_
                 if (visible) q[k] = *reinterpret_cast<const uint4*>(visible + i);
             }
         }
-        uint32_t own = 0;
+        // every tile's wave-level scans first (registers + shuffles), ONE exchange of the 10 x 16 wave totals through LDS, then
+        // the offsets: three barriers per super-tile instead of three per tile
+        uint32_t x[kTiles], s4[kTiles];
 #pragma unroll
-        for (uint32_t k = 0; k < kVec; ++k) {
-            const uint32_t i = first + 4u * k;
+        for (uint32_t k = 0; k < kTiles; ++k) {
+            const uint32_t i = base + 4096u * k + 4u * tid;
             if (i + 1 >= nblocks) v[k].y = q[k].y = 0;
             if (i + 2 >= nblocks) v[k].z = q[k].z = 0;
             if (i + 3 >= nblocks) v[k].w = q[k].w = 0;
-            own += v[k].x + v[k].y + v[k].z + v[k].w;
             vis += q[k].x + q[k].y + q[k].z + q[k].w;
-        }
-        uint32_t x = own;
+            s4[k] = v[k].x + v[k].y + v[k].z + v[k].w;
+            uint32_t y = s4[k];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t y = __shfl_up(x, o, 64);
-            if (lane >= (uint32_t)o) x += y;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t z = __shfl_up(y, o, 64);
+                if (lane >= (uint32_t)o) y += z;
+            }
+            x[k] = y;
+            if (lane == 63) wtot[k][wave] = y;
         }
-        if (lane == 63) wsum[wave] = x;
         __syncthreads();
-        uint32_t off = carry_s + x - own;
-        for (uint32_t w = 0; w < wave; ++w) off += wsum[w];
+        if (tid < kTiles * 16u) {  // exclusive prefix of the wave totals in (tile, wave) order
+            uint32_t p = 0;
+            for (uint32_t j = 0; j < tid; ++j) p += wtot[j >> 4][j & 15u];
+            wpre[tid >> 4][tid & 15u] = p;
+        }
+        __syncthreads();
+        const uint32_t carry = carry_s;
 #pragma unroll
-        for (uint32_t k = 0; k < kVec; ++k) {
-            const uint32_t i = first + 4u * k;
+        for (uint32_t k = 0; k < kTiles; ++k) {
+            const uint32_t i = base + 4096u * k + 4u * tid;
             if (i < nblocks) {
+                const uint32_t off = carry + wpre[k][wave] + x[k] - s4[k];
                 const uint4 o4 = make_uint4(off, off + v[k].x, off + v[k].x + v[k].y, off + v[k].x + v[k].y + v[k].z);
                 if (i + 3 < nblocks) {
                     *reinterpret_cast<uint4*>(offsets + i) = o4;
@@ -152,10 +162,9 @@ __global__ __launch_bounds__(1024) void k_admit_scan(const uint32_t* __restrict_
                     if (i + 2 < nblocks) offsets[i + 2] = o4.z;
                 }
             }
-            off += v[k].x + v[k].y + v[k].z + v[k].w;
         }
         __syncthreads();
-        if (tid == 1023) carry_s = off;
+        if (tid == 1023) carry_s = carry + wpre[kTiles - 1][15] + wtot[kTiles - 1][15];
         __syncthreads();
     }
     if (visible) {
