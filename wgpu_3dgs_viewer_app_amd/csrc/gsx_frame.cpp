@@ -566,7 +566,14 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
     if (m->spec_round1) window = m->spec_win.as<uint2>();
     uint32_t* tile_sat = progressive ? done + row_words * m->fc.tiles_y : nullptr;  // [count | bitmap | saturation keys]
 
-    if (m->tile_cap == 0) m->tile_cap = std::max<uint64_t>(1u << 20, 16 * m->rec_n);
+    // pair capacity to begin with: 16 entries per record for small models (per-tile lists), 6 for large ones (block lists need
+    // ~3 per record on speculated frames, 0.2 on depth slabs; a frame that wants more spills on the device and the host grows
+    // the buffers when it learns of it) — 32 bytes of pair / sort buffers per entry
+    // (a frame without depth slabs keeps per-tile lists of the whole model: 16 as well)
+    {
+        const uint64_t per_record = (!progressive || m->rec_n <= (1u << 18)) ? 16u : 6u;
+        m->tile_cap = std::max<uint64_t>(m->tile_cap, std::max<uint64_t>(1u << 20, per_record * m->rec_n));
+    }
     if (v->tile_cap_fixed) m->tile_cap = v->tile_cap_fixed;  // GSX_TILE_CAP (tests): a capacity that overflows on purpose
     m->tile_cap = std::min<uint64_t>(m->tile_cap, 0xFFFFF000ull);
     const uint32_t cap = (uint32_t)m->tile_cap;
