@@ -4,6 +4,8 @@ The claim under test: whatever the windows inherited from the previous frame —
 that changed underneath (mask, edit, transform), several layered models — the speculated frame is BIT-IDENTICAL to the
 frame rendered with speculative = 0, and both stay within the framebuffer tolerance of the oracle.  The statistics
 show the speculation engaged (fewer records sorted) and that the repair round ran when it had to."""
+import os
+
 import numpy as np
 import pytest
 
@@ -307,7 +309,7 @@ def test_cfg5_full_size_layered_models():
     plain.close()
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("seed", [int(x) for x in os.environ.get("GSX_FUZZ_SEEDS", "1,2,3,4,5,6,7,8").split(",")])
 def test_fuzz_operation_sequences(seed):
     """Seeded random walks through the API — camera steps and jumps, viewport changes, models shown / hidden / re-ordered,
     masks, selections, edits, highlight, display mode, Gaussian size, speculation parameters — applied to a speculating and
@@ -338,7 +340,7 @@ def test_fuzz_operation_sequences(seed):
         elif op == 5:
             pose = int(rng.integers(0, 240))                                    # a jump
         elif op == 6:
-            size = [(W, H), (W - 32, H), (W, H + 16), (200, 120)][int(rng.integers(0, 4))]
+            size = [(W, H), (W - 32, H), (W, H + 16), (200, 120), (640, 368), (1000, 200)][int(rng.integers(0, 6))]  # the last two: blocks of several tiles
         elif op == 7:
             visible = [k for k in "abc" if rng.random() < 0.7] or ["b"]
         elif op == 8:
