@@ -68,8 +68,8 @@ static gsx_status wait_verdict(gsx_viewer* v, uint32_t seq, uint32_t* need) {
 // stream, read back when they have completed — never waited for), one running mean per mode, and a four-phase cycle per model:
 //   SPEC (len_spec frames) -> PROBE_PLAIN (5 frames, unspeculated; the windows keep being updated) -> SETTLE (speculated
 //   frames until the probe's timings have arrived) -> decide;   PLAIN -> PROBE_SPEC -> SETTLE -> decide likewise.
-// A decision that confirms the current mode doubles its phase (64 ... 2048 frames: the probes then cost < 1 %), one that
-// flips it starts over at 64.  By construction the result stays within a few per cent of the better of the two paths.
+// A decision that confirms the current mode doubles its phase — quadruples it when the verdict is clear — (64 ... 2048
+// frames: the probes then cost < 1 %), one that flips it starts over at 64.  By construction the result stays within a few per cent of the better of the two paths.
 constexpr uint32_t kProbeFrames = 5;   // the first is not timed (the switch itself is atypical), the other four are
 constexpr uint32_t kSettleFrames = 64; // at most this many frames between a probe and the decision it feeds (normally: until its timings are in)
 
@@ -123,12 +123,16 @@ static bool tuner_wants_speculation(Model* m) {
                 const bool spec_better = have ? (was_spec ? t.mean_spec <= 1.03 * t.mean_plain : t.mean_spec < 0.97 * t.mean_plain) : was_spec;
                 if (debug) fprintf(stderr, "[gsx spec] model '%s' frame %u: speculated %.3f ms (%u samples), plain %.3f ms (%u) -> %s\n", m->key.c_str(),
                                    t.frame_no, t.mean_spec, t.n_spec, t.mean_plain, t.n_plain, spec_better ? "speculate" : "plain");
+                // a clear verdict (the other path costs half as much again, or more) is asked for again four times later, a close
+                // one twice later: on cfg4 a probe is five frames at twice the cost, on cfg2 the two paths are within 5 %
+                const double ratio = !have ? 1.0 : (spec_better ? t.mean_plain / std::max(t.mean_spec, 1e-6) : t.mean_spec / std::max(t.mean_plain, 1e-6));
+                const uint32_t grow = ratio >= 1.5 ? 4u : 2u;
                 if (spec_better) {
-                    t.len_spec = was_spec ? std::min<uint32_t>(2 * t.len_spec, 2048u) : 64u;
+                    t.len_spec = was_spec ? std::min<uint32_t>(grow * t.len_spec, 2048u) : 64u;
                     t.len_plain = 64;
                     t.phase = SpecTuner::SPEC; t.left = t.len_spec;
                 } else {
-                    t.len_plain = was_spec ? 64u : std::min<uint32_t>(2 * t.len_plain, 2048u);
+                    t.len_plain = was_spec ? 64u : std::min<uint32_t>(grow * t.len_plain, 2048u);
                     t.len_spec = 64;
                     t.phase = SpecTuner::PLAIN; t.left = t.len_plain;
                 }
