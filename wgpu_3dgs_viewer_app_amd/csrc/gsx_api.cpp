@@ -2,6 +2,7 @@
 // (Selection / edits / queries: gsx_api_edit.cpp; multi-GPU: gsx_api_shard.cpp; what a frame enqueues: gsx_frame.cpp.)
 // There is NO CPU fallback: without a HIP device every entry point fails with GSX_ERR_NO_DEVICE.
 #include "gsx_state.h"
+#include <atomic>
 #include <cstdlib>
 
 using namespace gsx;
@@ -11,7 +12,7 @@ using namespace gsx;
 // created by the viewer it belongs to; its models are shadows that VIEW the owner's Gaussian data (DevBuf::borrow).
 // gsx_render_frame deals frames round-robin to the viewer and its lanes; nothing else in the library knows about lanes
 // except viewer_bind (gsx_state.h), which orders the viewer's stream after the lanes' frames before any other call.
-static uint64_t g_model_serial = 0;
+static std::atomic<uint64_t> g_model_serial{0};  // (viewers of different host threads create models concurrently)
 
 static gsx_viewer* result_lane(gsx_viewer* v) { return v->latest ? v->latest : v; }
 
@@ -259,7 +260,7 @@ gsx_status gsx_model_create(gsx_viewer* v, const char* key, uint64_t count, gsx_
         return fail(GSX_ERR_INVALID_ARG, "gsx_model_create: unknown pod kind Sh%d/Cov3d%d", (int)sh, (int)cov3d);
     std::unique_ptr<Model> m(new Model());
     m->key = key;
-    m->serial = ++g_model_serial;
+    m->serial = g_model_serial.fetch_add(1) + 1;
     m->n = count;
     m->sh_kind = sh;
     m->cov_kind = cov3d;
