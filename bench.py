@@ -497,7 +497,10 @@ def main():
                 "stream, records, sort / tile buffers, framebuffer and speculation windows; the scene is shared), so the device overlaps one "
                 "frame's latency-bound tail with the next frame's bandwidth-bound projection; every frame is bit-identical to the one-lane "
                 "frame (tests/test_gpu_inflight.py, and frame_check below is taken from this loop).  value_one_frame_in_flight, "
-                "value_unspeculated, both rooflines and the robustness legs run with ONE frame in flight (kernel times uncontended).")
+                "value_unspeculated, both rooflines and the robustness legs run with ONE frame in flight (kernel times uncontended).  "
+                f"Throughput, not latency: with {lanes} frames in flight a frame spends about {lanes} x ms_per_step on the device from its first "
+                "kernel to its last (ms_per_step_one_frame_in_flight is the latency of a frame that has the device to itself).")
+            out["frame_latency_ms_estimate"] = round(lanes * 1e3 * elapsed / args.steps, 4)
         if elapsed_ul is not None:
             out["value_unspeculated_in_flight"] = round(args.steps / elapsed_ul, 3)
         if timing_u is not None:
