@@ -145,3 +145,48 @@ def test_spilled_slabs_with_frames_in_flight(monkeypatch):
     assert v.frame_stats("m")["overflow_slabs"] > 0
     v.close()
     ref.close()
+
+
+def test_staged_calls_between_overlapped_frames_and_close_without_sync():
+    """gsx_preprocess / gsx_sort / gsx_render (the reference's own three-call frame) mixed into a run of gsx_render_frame calls
+    with frames in flight: the staged frame runs on the viewer itself after the lanes' frames, reads back as the newest frame,
+    and the overlapped frames after it are unaffected.  The viewer is then destroyed with frames still in flight."""
+    g = common.small_scene(30000, 308, scale_mul=10.0)
+    ref, v = _viewer(1), _viewer(3)
+    _load(ref, "m", g)
+    _load(v, "m", g)
+    for k in range(12):
+        pose = 70 + k
+        if k % 4 == 3:  # the three-call frame
+            for x in (v, ref):
+                x.update_camera(camera.orbit_pose(pose), (W, H))
+                x.update_gaussian_transform(1.0, GaussianDisplayMode.Splat, GaussianShDegree.new(3), False)
+                x.preprocessor.preprocess("m")
+                x.radix_sorter.sort("m")
+                x.poll()
+                x.renderer.render(["m"])
+            a, b = v.download_framebuffer(), ref.download_framebuffer()
+        else:
+            a, b = _frame(v, pose, ["m"]), _frame(ref, pose, ["m"])
+        assert np.array_equal(a, b), f"frame {k}"
+    for k in range(7):  # seven frames enqueued, none waited for, then the viewer goes away
+        _enqueue(v, 90 + k, ["m"])
+    v.close()
+    ref.close()
+
+
+def test_viewport_change_with_frames_in_flight_unsynchronised():
+    g = common.small_scene(30000, 309, scale_mul=10.0)
+    ref, v = _viewer(1), _viewer(2)
+    _load(ref, "m", g)
+    _load(v, "m", g)
+    sizes = [(W, H)] * 5 + [(640, 368)] * 5 + [(200, 120)] * 4 + [(W, H)] * 3
+    for k, size in enumerate(sizes):
+        _enqueue(v, 110 + k, ["m"], size)   # no host wait anywhere in the run
+    a = v.download_framebuffer()
+    for k, size in enumerate(sizes):
+        b = _frame(ref, 110 + k, ["m"], size)
+    assert a.shape == b.shape and np.array_equal(a, b)
+    v.close()
+    ref.close()
+
