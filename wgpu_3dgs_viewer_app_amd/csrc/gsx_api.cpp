@@ -15,6 +15,12 @@ using namespace gsx;
 static std::atomic<uint64_t> g_model_serial{0};  // (viewers of different host threads create models concurrently)
 
 static gsx_viewer* result_lane(gsx_viewer* v) { return v->latest ? v->latest : v; }
+// per-model results: the lane that rendered the newest frame — unless that frame did not include the model (a key that was
+// last rendered in an earlier frame lives where that frame ran; the viewer itself is the best answer left)
+static gsx_viewer* result_lane_of(gsx_viewer* v, const char* key) {
+    gsx_viewer* l = result_lane(v);
+    return (l != v && !find_model(l, key)) ? v : l;
+}
 
 static gsx_status lane_create(gsx_viewer* v, gsx_viewer** out) {
     std::unique_ptr<gsx_viewer> l(new gsx_viewer());
@@ -593,7 +599,7 @@ gsx_status gsx_framebuffer_device_ptr(gsx_viewer* v, void** out_ptr, uint32_t* o
 gsx_status gsx_model_frame_stats(gsx_viewer* v, const char* key, gsx_frame_stats* out) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
-    v = result_lane(v);  // the newest frame may be a lane's
+    v = result_lane_of(v, key);  // the newest frame may be a lane's
     Model* m = find_model(v, key);
     if (!m || !out) return fail(GSX_ERR_NOT_FOUND, "gsx_model_frame_stats: no model '%s'", key ? key : "(null)");
     if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_model_frame_stats: model '%s' not preprocessed this frame", key);
@@ -615,7 +621,7 @@ gsx_status gsx_model_download_projection(gsx_viewer* v, const char* key, uint32_
                                          float* conic_opacity, float* rgb) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
-    v = result_lane(v);  // the newest frame may be a lane's
+    v = result_lane_of(v, key);  // the newest frame may be a lane's
     Model* m = find_model(v, key);
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_download_projection: no model '%s'", key ? key : "(null)");
     if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_projection: model '%s' not preprocessed", key);
@@ -665,7 +671,7 @@ gsx_status gsx_model_download_projection(gsx_viewer* v, const char* key, uint32_
 gsx_status gsx_model_download_sorted(gsx_viewer* v, const char* key, uint32_t* indices, uint64_t capacity, uint64_t* out_n_visible) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
-    v = result_lane(v);  // the newest frame may be a lane's
+    v = result_lane_of(v, key);  // the newest frame may be a lane's
     Model* m = find_model(v, key);
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_download_sorted: no model '%s'", key ? key : "(null)");
     if (!m->sorted) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_sorted: model '%s' not sorted", key);
@@ -684,7 +690,7 @@ gsx_status gsx_model_download_tile_lists(gsx_viewer* v, const char* key, uint32_
                                          uint32_t* list, uint64_t capacity) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
-    v = result_lane(v);  // the newest frame may be a lane's
+    v = result_lane_of(v, key);  // the newest frame may be a lane's
     Model* m = find_model(v, key);
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_download_tile_lists: no model '%s'", key ? key : "(null)");
     if (!m->binned) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_tile_lists: model '%s' not rendered this frame", key);
