@@ -43,7 +43,6 @@ class HipStages:
     # -- scene --
     def load_shard(self, key: str, gaussians: np.ndarray, start: int, n_total: int) -> None:
         self.viewer.add_model(key, gaussians.shape[0])
-        self.__dict__.setdefault("_sent_uniforms", {}).pop(("m", key), None)   # a new model starts from the default transform
         self.viewer.models[key].gaussian_buffers.gaussians_buffer.update_range(0, gaussians)
         self._n_local = max(getattr(self, "_n_local", 0), gaussians.shape[0])  # sizes the shared send buffer
 
@@ -51,18 +50,9 @@ class HipStages:
         mt = model_transform or ModelTransform()
         gt = gaussian_transform or (1.0, GaussianDisplayMode.Splat, GaussianShDegree.new(3), False)
         self.viewer.update_camera(camera, size)
-        # the library keeps both transforms: write them again only when they changed (the app updates them every frame,
-        # scene.rs:796-809; here that is two ctypes round trips per model of an un-synchronised frame loop)
-        sig_m = (tuple(np.asarray(mt.pos, np.float32).tolist()), tuple(np.asarray(mt.rot, np.float32).tolist()),
-                 tuple(np.asarray(mt.scale, np.float32).tolist()))
-        sent = self.__dict__.setdefault("_sent_uniforms", {})
-        if sent.get(("m", key)) != sig_m:
-            self.viewer.update_model_transform(key, mt.pos, mt.quat(), mt.scale)
-            sent[("m", key)] = sig_m
-        sig_g = (float(gt[0]), int(gt[1]), int(getattr(gt[2], "deg", gt[2])), bool(gt[3]))
-        if sent.get("g") != sig_g:
-            self.viewer.update_gaussian_transform(*gt)
-            sent["g"] = sig_g
+        # every frame, like the app (scene.rs:796-809): three host-side setters, no device work
+        self.viewer.update_model_transform(key, mt.pos, mt.quat(), mt.scale)
+        self.viewer.update_gaussian_transform(*gt)
         self._size = (int(size[0]), int(size[1]))
 
     # -- single GPU --
