@@ -65,12 +65,14 @@ static gsx_status wait_verdict(gsx_viewer* v, uint32_t seq, uint32_t* need) {
 // Temporal occlusion speculation wins when frames are coherent and the scene occludes (cfg4: 2x), and loses when most frames
 // need the repair round anyway (cfg2: 1 M sparse Gaussians, 90 % of the frames repair; random camera poses).  Either path
 // gives the same pixels, so the viewer simply times them: some frames are bracketed by a pair of HIP events (recorded on the
-// stream, read back when they have completed — never waited for), one running mean per mode, and a four-phase cycle per model:
+// stream, read back when they have completed; the host waits for none of them except a probe's, eight frames after it —
+// kSettleWait), one running mean per mode, and a four-phase cycle per model:
 //   SPEC (len_spec frames) -> PROBE_PLAIN (5 frames, unspeculated; the windows keep being updated) -> SETTLE (speculated
 //   frames until the probe's timings have arrived) -> decide;   PLAIN -> PROBE_SPEC -> SETTLE -> decide likewise.
 // A decision that confirms the current mode doubles its phase — quadruples it when the verdict is clear — (64 ... 2048
 // frames: the probes then cost < 1 %), one that flips it starts over at 64.  By construction the result stays within a few per cent of the better of the two paths.
 constexpr uint32_t kProbeFrames = 5;   // the first is not timed (the switch itself is atypical), the other four are
+constexpr uint32_t kSettleWait = 8;    // frames enqueued behind a probe before the host waits for its timings
 constexpr uint32_t kSettleFrames = 64; // at most this many frames between a probe and the decision it feeds (normally: until its timings are in)
 
 static void tuner_collect(Model* m) {
@@ -98,8 +100,17 @@ static bool tuner_wants_speculation(Model* m) {
     SpecTuner& t = m->tuner_ref ? *m->tuner_ref : m->tuner;
     tuner_collect(m);
     static const bool debug = getenv("GSX_SPEC_DEBUG") != nullptr;
-    // a settle phase ends as soon as the probe's timings are in (or after kSettleFrames at the latest)
-    if ((t.phase == SpecTuner::SETTLE_SPEC || t.phase == SpecTuner::SETTLE_PLAIN) && t.probe_pending == 0) t.left = 0;
+    // a settle phase ends as soon as the probe's timings are in.  Eight frames after the probe the host stops running ahead
+    // until they are: it waits for the probe's last event — with eight frames queued behind it the device never idles, and a
+    // host that is dozens of short frames ahead (a 1 M-Gaussian scene on two lanes) would otherwise spend that long in the
+    // mode it is about to leave
+    const bool settling = t.phase == SpecTuner::SETTLE_SPEC || t.phase == SpecTuner::SETTLE_PLAIN;
+    if (settling && t.probe_pending && kSettleFrames - t.left >= kSettleWait) {
+        for (auto& s : t.slots)
+            if (s.state == 2 && s.probe) (void)hipEventSynchronize(s.stop);
+        tuner_collect(m);
+    }
+    if (settling && t.probe_pending == 0) t.left = 0;
     if (t.left == 0) {
         switch (t.phase) {
             case SpecTuner::SPEC:
