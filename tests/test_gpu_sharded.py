@@ -389,7 +389,7 @@ def test_full_size_sharded_frames(mode, world):
     print(mode, "rounds", res[0][1])
 
 
-def test_library_transport_world1_over_rccl():
+def test_library_transport_world1_over_rccl(monkeypatch):
     """The product transport: the collectives inside libgsx over RCCL (gsx_viewer_comm_init, gsx_comm_all_to_all /
     _all_gather) and the whole frame as ONE library call (gsx_shard_render_frame).  A 1-GPU box has one rank, which is enough
     to run every code path of the protocol for real — slots, headers, device-side counts, verification, repair round,
@@ -398,7 +398,12 @@ def test_library_transport_world1_over_rccl():
     g = _scene()
     ref = _single_frames(g)
     tiles = ((H + 15) // 16, (W + 15) // 16)
-    for drive in ("library", "stages", "stages_refusing"):
+    for drive in ("library", "library_self_copy", "stages", "stages_refusing"):
+        # a rank's own slot is a device copy by default; here it goes through ncclSend / ncclRecv like a peer's, except in one leg
+        if drive == "library_self_copy":
+            monkeypatch.delenv("GSX_COMM_SELF_VIA_RCCL", raising=False)
+        else:
+            monkeypatch.setenv("GSX_COMM_SELF_VIA_RCCL", "1")
         v = parallel.ShardedViewer(world=1, rank=0, use_dist=True, comm="lib")
         assert isinstance(v.comm, parallel.LibComm)
         v.load_shard(g, 0, N)
@@ -423,12 +428,13 @@ def test_library_transport_world1_over_rccl():
 
 
 @pytest.mark.parametrize("lanes", [2, 3])
-def test_library_transport_with_frames_in_flight(lanes):
+def test_library_transport_with_frames_in_flight(lanes, monkeypatch):
     """gsx_shard_render_frame with gsx_render_options.frames_in_flight > 1: frame k is enqueued on lane k mod L before the verdict
     of the frame before is looked at; every collective goes through one stream in program order.  One rank over real RCCL:
     every frame, read back right away or after a run of un-synchronised calls, equals the single viewer's."""
     g = _scene()
     ref = _single_frames(g)
+    monkeypatch.setenv("GSX_COMM_SELF_VIA_RCCL", "1")   # the rank's own slot through ncclSend / ncclRecv (the comm stream's hand-overs)
     v = parallel.ShardedViewer(world=1, rank=0, use_dist=True, comm="lib")
     v.stages.viewer.set_render_options(frames_in_flight=lanes)
     v.load_shard(g, 0, N)

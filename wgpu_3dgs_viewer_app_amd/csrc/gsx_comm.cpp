@@ -136,6 +136,7 @@ gsx_status gsx_viewer_comm_init(gsx_viewer* v, uint32_t world, uint32_t rank, co
     v->comm = c;
     v->comm_world = world;
     v->comm_rank = rank;
+    v->comm_self_via_rccl = getenv("GSX_COMM_SELF_VIA_RCCL") != nullptr;
     return GSX_OK;
 }
 
@@ -161,10 +162,21 @@ gsx_status gsx_comm_all_to_all(gsx_viewer* v, const void* d_send, void* d_recv, 
     if (!o->comm) return fail(GSX_ERR_RCCL, "gsx_comm_all_to_all: no communicator (gsx_viewer_comm_init)");
     if (!d_send || !d_recv) return fail(GSX_ERR_INVALID_ARG, "gsx_comm_all_to_all: null buffer");
     if (bytes_per_peer == 0) return GSX_OK;
+    // what this rank keeps for itself does not travel: a device copy on the viewer's own stream, beside the exchange
+    // (GSX_COMM_SELF_VIA_RCCL, read by gsx_viewer_comm_init: send it to oneself through RCCL like everything else — the
+    // one-rank tests on a one-GPU box exercise ncclSend / ncclRecv that way)
+    const bool bypass = !o->comm_self_via_rccl;
+    if (bypass) {
+        const size_t self_off = (size_t)o->comm_rank * bytes_per_peer;
+        HIPCHK(hipMemcpyAsync(static_cast<char*>(d_recv) + self_off, static_cast<const char*>(d_send) + self_off, bytes_per_peer,
+                              hipMemcpyDeviceToDevice, v->stream));
+        if (o->comm_world == 1) return GSX_OK;
+    }
     hipStream_t cs;
     if ((st = route_begin(v, &cs))) return st;
     RCCLCHK(g_rccl.GroupStart());
     for (uint32_t p = 0; p < o->comm_world; ++p) {
+        if (bypass && p == o->comm_rank) continue;
         RCCLCHK(g_rccl.Send(static_cast<const char*>(d_send) + (size_t)p * bytes_per_peer, bytes_per_peer, kNcclChar, (int)p, comm_of(v), cs));
         RCCLCHK(g_rccl.Recv(static_cast<char*>(d_recv) + (size_t)p * bytes_per_peer, bytes_per_peer, kNcclChar, (int)p, comm_of(v), cs));
     }

@@ -298,6 +298,7 @@ struct gsx_viewer {
     uint32_t shard_seq = 0;
     void* comm = nullptr;                // ncclComm_t (gsx_viewer_comm_init); RCCL is loaded at run time (gsx_comm.cpp)
     uint32_t comm_world = 0, comm_rank = 0;
+    bool comm_self_via_rccl = false;     // GSX_COMM_SELF_VIA_RCCL at gsx_viewer_comm_init: a rank's own exchange slot goes through RCCL too
     DevBuf shard_fb, shard_send, shard_recv, shard_sat_band, shard_sat_all, shard_counts;  // gsx_shard_render_frame's own buffers
     void* ext_fb = nullptr;              // caller-owned framebuffer (multi-GPU: the RCCL gather target)
     uint64_t ext_fb_bytes = 0;
