@@ -190,3 +190,29 @@ def test_viewport_change_with_frames_in_flight_unsynchronised():
     v.close()
     ref.close()
 
+
+
+def test_device_side_resolve_sees_the_newest_frame_on_a_lane():
+    """gsx_resolve_rgba8_device must resolve the framebuffer of the lane that rendered the newest frame (an odd
+    frame count with two lanes leaves it on a lane, not on the viewer itself)."""
+    import ctypes as C
+
+    import torch
+
+    from wgpu_3dgs_viewer_app_amd import _lib
+
+    g = common.small_scene(20000, 305, scale_mul=10.0)
+    v = _viewer(2)
+    _load(v, "m", g)
+    bg = (0.25, 0.5, 0.75)
+    out = torch.zeros(W * H, dtype=torch.int32, device="cuda:0")
+    for n_frames in (1, 2, 3, 4, 5):
+        for k in range(n_frames):
+            _enqueue(v, 20 + k, ["m"])
+        cbg = (C.c_float * 3)(*bg)
+        _lib.check(v._L.gsx_resolve_rgba8_device(v._h, cbg, 0, H, out.data_ptr()))
+        v.poll()
+        got = out.cpu().numpy().view(np.uint8).reshape(H, W, 4)
+        want = v.download_rgba8(bg)
+        assert np.array_equal(got, want), f"after {n_frames} frames the device-side resolve shows another frame"
+    v.close()

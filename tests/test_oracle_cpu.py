@@ -4,6 +4,7 @@ import glob
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -235,6 +236,18 @@ def test_no_cpu_fallback_without_a_device():
     with pytest.raises(GsxError) as e:
         MultiModelViewer()
     assert e.value.status == _lib.GSX_ERR_NO_DEVICE
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """a host without librccl gets GSX_ERR_RCCL from the first collective call (the loader's error string used to
+    be built from a second dlerror() call = NULL: a segfault).  Own process: the library is looked up once per process."""
+    code = ("import ctypes as C, sys; L = C.CDLL(sys.argv[1]); L.gsx_last_error_string.restype = C.c_char_p; "
+            "b = (C.c_uint8 * 128)(); st = L.gsx_comm_unique_id(b); print(st, L.gsx_last_error_string().decode())")
+    env = dict(os.environ, GSX_RCCL_LIBRARY="/nonexistent/librccl.so.1")
+    r = subprocess.run([sys.executable, "-c", code, os.environ.get("GSX_LIB", _lib.LIB_PATH)], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    st, msg = r.stdout.split(" ", 1)
+    assert int(st) == _lib.GSX_ERR_RCCL and "librccl not found" in msg and "/nonexistent/librccl.so.1" in msg
 
 
 def test_product_package_never_imports_the_oracle():

@@ -14,7 +14,6 @@ using namespace gsx;
 // except viewer_bind (gsx_state.h), which orders the viewer's stream after the lanes' frames before any other call.
 static std::atomic<uint64_t> g_model_serial{0};  // (viewers of different host threads create models concurrently)
 
-static gsx_viewer* result_lane(gsx_viewer* v) { return v->latest ? v->latest : v; }
 // per-model results: the lane that rendered the newest frame — unless that frame did not include the model (a key that was
 // last rendered in an earlier frame lives where that frame ran; the viewer itself is the best answer left)
 static gsx_viewer* result_lane_of(gsx_viewer* v, const char* key) {
@@ -187,14 +186,16 @@ void gsx_viewer_destroy(gsx_viewer* v) {
     for (gsx_viewer* l : v->lanes) gsx_viewer_destroy(l);  // (synchronises the lane's stream first)
     v->lanes.clear();
     (void)hipStreamSynchronize(v->stream);
+    (void)gsx_viewer_comm_destroy(v);  // first: it drains the lanes' streams and the comm stream, then destroys the communicator
     if (v->lane_event) (void)hipEventDestroy(v->lane_event);
     if (v->comm_ev_in) (void)hipEventDestroy(v->comm_ev_in);
     if (v->comm_ev_out) (void)hipEventDestroy(v->comm_ev_out);
+    v->comm_ev_in = v->comm_ev_out = nullptr;
     if (v->comm_stream) {
         (void)hipStreamSynchronize(v->comm_stream);
         (void)hipStreamDestroy(v->comm_stream);
+        v->comm_stream = nullptr;
     }
-    (void)gsx_viewer_comm_destroy(v);
     if (v->h_shard_verdict) (void)hipHostFree(v->h_shard_verdict);
     for (auto& t : v->timers) {
         (void)hipEventDestroy(t.start);

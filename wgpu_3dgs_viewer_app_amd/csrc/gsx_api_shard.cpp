@@ -36,11 +36,14 @@ gsx_status gsx_resolve_rgba8_device(gsx_viewer* v, const float bg[3], uint32_t y
     gsx_status st = viewer_bind(v);
     if (st) return st;
     if (!bg || !d_rgba || y1 < y0) return fail(GSX_ERR_INVALID_ARG, "gsx_resolve_rgba8_device: null argument or y1 < y0");
-    if ((st = ensure_fb(v))) return st;
-    const uint64_t rows_avail = v->ext_fb ? v->ext_fb_bytes / (sizeof(float4) * (uint64_t)v->width) : v->height;
+    // the newest frame may be a lane's: ITS framebuffer, resolved on the viewer's own stream — viewer_bind has ordered that
+    // stream after the lane's frame, and the lane's next frame waits for what is enqueued here (epoch)
+    gsx_viewer* src = result_lane(v);
+    if ((st = ensure_fb(src))) return st;
+    const uint64_t rows_avail = src->ext_fb ? src->ext_fb_bytes / (sizeof(float4) * (uint64_t)src->width) : src->height;
     if (y1 > rows_avail) return fail(GSX_ERR_INVALID_ARG, "gsx_resolve_rgba8_device: rows [%u, %u) of a %llu-row framebuffer", y0, y1, (unsigned long long)rows_avail);
-    const uint64_t npx = (uint64_t)(y1 - y0) * v->width;
-    HIPCHK(launch_resolve_rgba8(v->stream, fb_ptr(v) + (size_t)y0 * v->width, (uint32_t)npx, bg[0], bg[1], bg[2], static_cast<uint32_t*>(d_rgba)));
+    const uint64_t npx = (uint64_t)(y1 - y0) * src->width;
+    HIPCHK(launch_resolve_rgba8(v->stream, fb_ptr(src) + (size_t)y0 * src->width, (uint32_t)npx, bg[0], bg[1], bg[2], static_cast<uint32_t*>(d_rgba)));
     return GSX_OK;
 }
 

@@ -41,16 +41,26 @@ std::once_flag g_rccl_once;
 
 void load_rccl() {
     // a copy the process already holds (PyTorch ships one) is reused; otherwise the ROCm installation's
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // GSX_RCCL_LIBRARY (read once, at the first collective call of the process): this file instead of the search list
+    const char* forced = getenv("GSX_RCCL_LIBRARY");
+    const char* defaults[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    std::vector<const char*> names;
+    if (forced && *forced) names.push_back(forced);
+    else names.assign(std::begin(defaults), std::end(defaults));
     void* h = nullptr;
     for (const char* n : names)
         if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    std::string why;
     for (const char* n : names) {
         if (h) break;
         h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!h) {
+            const char* e = dlerror();  // (one call: dlerror clears what it returns)
+            why = e ? e : "?";
+        }
     }
     if (!h) {
-        g_rccl.error = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?");
+        g_rccl.error = std::string("librccl not found: ") + (why.empty() ? "?" : why);
         return;
     }
     g_rccl.handle = h;

@@ -160,7 +160,13 @@ static bool tuner_wants_speculation(Model* m) {
 // fourth frame otherwise (an event pair costs a few microseconds of stream gap)
 static void tuner_frame_begin(gsx_viewer* v, Model* m, bool speculated) {
     SpecTuner& t = m->tuner_ref ? *m->tuner_ref : m->tuner;
-    t.active = nullptr;
+    if (t.active) {  // the last bracket was never closed (a gsx_preprocess without its gsx_render): take the slot back
+        if (t.active->state == 1) {
+            t.active->state = 0;
+            if (t.active->probe && t.probe_pending) t.probe_pending -= 1;
+        }
+        t.active = nullptr;
+    }
     const bool probe = t.phase == SpecTuner::PROBE_PLAIN || t.phase == SpecTuner::PROBE_SPEC;
     if (probe ? t.left == kProbeFrames - 1 : (t.frame_no & 3u) != 0) return;
     for (auto& s : t.slots) {

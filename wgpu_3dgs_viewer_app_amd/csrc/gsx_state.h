@@ -83,8 +83,11 @@ struct SpecTuner {
     void reset() {
         phase = SPEC; left = 32; len_spec = len_plain = 64;
         n_spec = n_plain = 0; mean_spec = mean_plain = 0.0; probe_pending = 0;
-        for (auto& s : slots)
+        for (auto& s : slots) {
             if (s.state == 2) s.state = 3;
+            if (s.state == 1) s.state = 0;  // bracket opened, never closed (the frame was not rendered): nothing in flight
+        }
+        active = nullptr;
     }
     ~SpecTuner() {
         for (auto& s : slots) {
@@ -379,6 +382,8 @@ inline gsx_status ensure_fb(gsx_viewer* v) {
     HIPCHK(v->fb.ensure(sizeof(float4) * (size_t)v->width * v->height));
     return GSX_OK;
 }
+// readback entry points refer to the newest frame, whichever lane rendered it
+inline gsx_viewer* result_lane(gsx_viewer* v) { return v->latest ? v->latest : v; }
 inline float4* fb_ptr(gsx_viewer* v) { return v->ext_fb ? static_cast<float4*>(v->ext_fb) : reinterpret_cast<float4*>(v->fb.p); }
 
 // lane `index` (0 = the viewer itself) brought up to date for a frame of `keys` (gsx_api.cpp)
