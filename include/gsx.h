@@ -441,9 +441,47 @@ gsx_status gsx_viewer_comm_destroy(gsx_viewer* v);
 gsx_status gsx_comm_all_to_all(gsx_viewer* v, const void* d_send, void* d_recv, uint64_t bytes_per_peer);
 /* d_recv = world * bytes_per_rank; in place when d_send == d_recv + rank * bytes_per_rank */
 gsx_status gsx_comm_all_gather(gsx_viewer* v, const void* d_send, void* d_recv, uint64_t bytes_per_rank);
-/* One whole index-sharded frame of model `key` on this rank (needs gsx_viewer_comm_init): the sequence above, into a padded
- * framebuffer the library owns; after gsx_sync, gsx_download_framebuffer returns the complete frame on every rank. */
+/* One whole index-sharded frame of model `key` on this rank (needs a communicator: gsx_viewer_comm_init, _init_group or
+ * _init_custom): the sequence above, into a padded framebuffer the library owns; after gsx_sync, gsx_download_framebuffer
+ * returns the complete frame on every rank. */
 gsx_status gsx_shard_render_frame(gsx_viewer* v, const char* key, uint32_t shard_records_max, uint32_t speculate, float margin, uint32_t radius);
+
+/* ---- other transports under the same frame loop.  gsx_shard_render_frame only ever calls "all-to-all of equal slots" and
+ *      "all-gather of equal pieces"; RCCL is one provider of the two.
+ *      (a) in-process group: ONE host process drives several GPUs, one host thread and one viewer per GPU — what a
+ *          single-process host such as the egui app (src/main.rs:85-98: one process, one event loop) would do.  The collectives are
+ *          device-to-device copies ordered by HIP events (peer-to-peer over xGMI between devices), delivered in RCCL's order
+ *          (by source rank); ranks meet at a host rendezvous inside every collective, which gives up after timeout_ms
+ *          (0 = 60 s): every rank of the group then gets GSX_ERR_RCCL instead of a hang.  Also how the tests put `world`
+ *          ranks on ONE GPU and run the real frame loop.
+ *      (b) custom: the caller's own two functions (MPI, a test double ...).  They ENQUEUE on `hip_stream` like
+ *          ncclSend / ncclRecv do and return 0 or a gsx_status; slot p of d_send goes to rank p, slot p of d_recv comes from
+ *          rank p; the all-gather is in place when d_send == d_recv + rank * bytes_per_rank. ---- */
+typedef struct gsx_comm_group gsx_comm_group;
+gsx_status gsx_comm_group_create(uint32_t world, uint32_t timeout_ms, gsx_comm_group** out);
+void gsx_comm_group_destroy(gsx_comm_group* g); /* after every viewer of the group called gsx_viewer_comm_destroy / _destroy */
+gsx_status gsx_viewer_comm_init_group(gsx_viewer* v, gsx_comm_group* g, uint32_t rank);
+typedef gsx_status (*gsx_comm_all_to_all_fn)(void* ctx, const void* d_send, void* d_recv, uint64_t bytes_per_peer, void* hip_stream);
+typedef gsx_status (*gsx_comm_all_gather_fn)(void* ctx, const void* d_send, void* d_recv, uint64_t bytes_per_rank, void* hip_stream);
+gsx_status gsx_viewer_comm_init_custom(gsx_viewer* v, uint32_t world, uint32_t rank, gsx_comm_all_to_all_fn all_to_all,
+                                       gsx_comm_all_gather_fn all_gather, void* ctx);
+
+/* A caller with its own exchange policy (and the tests): per-tile limits the NEXT sharded frame of `key` uses instead of the ones
+ * the last frame left (host or device memory, u32 per tile, 0xFFFFFFFF = unbounded; copied by the call), and a fixed round-0 slot size
+ * (records; 0 = the library's policy).  Every rank must set the same values. */
+gsx_status gsx_shard_set_limits(gsx_viewer* v, const char* key, const uint32_t* limits);
+gsx_status gsx_shard_set_slot_records(gsx_viewer* v, const char* key, uint32_t records);
+/* What the sharded frames of this viewer did since the last reset (host-side bookkeeping; never synchronises). */
+typedef struct gsx_shard_stats {
+    uint64_t frames;          /* gsx_shard_render_frame calls completed */
+    uint64_t redo_frames;     /* frames whose round 0 was redone with whole-shard slots (a slot overflowed) */
+    uint64_t repair_frames;   /* frames that needed the repair exchange */
+    uint64_t exchange_rounds; /* all-to-all rounds in total */
+    uint64_t wire_bytes;      /* bytes this rank sent to OTHER ranks: slots (fixed size, whatever they hold), feedback and band gathers */
+    uint64_t verdict_wait_ns; /* host time spent waiting for verdicts */
+    uint32_t last_slot_records, last_repair_slot_records;
+} gsx_shard_stats;
+gsx_status gsx_shard_get_stats(gsx_viewer* v, gsx_shard_stats* out, uint32_t reset);
 
 /* ---- PLY I/O (host side; no GPU needed).  gs::Gaussians::read_ply_header / PlyHeader::count /
  *      read_ply_gaussians + gs::Gaussian::from(PlyGaussianPod) (app.rs:1053-1096) and write_ply (app.rs:897-947).

@@ -107,6 +107,20 @@ pub struct gsx_shard_verdict { pub need_tiles: u32, pub overflow: u32, pub max_r
 #[repr(C)]
 #[derive(Clone, Copy)]
 pub struct gsx_ply_header { pub count: u64, pub header_bytes: u64, pub vertex_bytes: u32, pub is_ascii: u32, pub offsets: [i32; 62] }
+/// opaque: an in-process group of viewers, one per GPU (gsx_comm_group_create)
+#[repr(C)]
+pub struct gsx_comm_group {
+    _private: [u8; 0],
+}
+/// the two collectives of a caller-supplied transport: they ENQUEUE on `hip_stream` and return 0 or a gsx_status
+pub type gsx_comm_all_to_all_fn = Option<unsafe extern "C" fn(ctx: *mut c_void, d_send: *const c_void, d_recv: *mut c_void, bytes_per_peer: u64, hip_stream: *mut c_void) -> gsx_status>;
+pub type gsx_comm_all_gather_fn = Option<unsafe extern "C" fn(ctx: *mut c_void, d_send: *const c_void, d_recv: *mut c_void, bytes_per_rank: u64, hip_stream: *mut c_void) -> gsx_status>;
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct gsx_shard_stats {
+    pub frames: u64, pub redo_frames: u64, pub repair_frames: u64, pub exchange_rounds: u64,
+    pub wire_bytes: u64, pub verdict_wait_ns: u64, pub last_slot_records: u32, pub last_repair_slot_records: u32,
+}
 pub type gsx_pass = u32; // 0 project, 1 depth sort, 2 bin, 3 tile sort, 4 composite, 5 project (geometry only)
 pub const GSX_PASS_COUNT: usize = 6;
 
@@ -185,6 +199,13 @@ extern "C" {
     pub fn gsx_comm_all_to_all(v: *mut gsx_viewer, d_send: *const c_void, d_recv: *mut c_void, bytes_per_peer: u64) -> gsx_status;
     pub fn gsx_comm_all_gather(v: *mut gsx_viewer, d_send: *const c_void, d_recv: *mut c_void, bytes_per_rank: u64) -> gsx_status;
     pub fn gsx_shard_render_frame(v: *mut gsx_viewer, key: *const c_char, shard_records_max: u32, speculate: u32, margin: f32, radius: u32) -> gsx_status;
+    pub fn gsx_comm_group_create(world: u32, timeout_ms: u32, out: *mut *mut gsx_comm_group) -> gsx_status;
+    pub fn gsx_comm_group_destroy(g: *mut gsx_comm_group);
+    pub fn gsx_viewer_comm_init_group(v: *mut gsx_viewer, g: *mut gsx_comm_group, rank: u32) -> gsx_status;
+    pub fn gsx_viewer_comm_init_custom(v: *mut gsx_viewer, world: u32, rank: u32, all_to_all: gsx_comm_all_to_all_fn, all_gather: gsx_comm_all_gather_fn, ctx: *mut c_void) -> gsx_status;
+    pub fn gsx_shard_set_limits(v: *mut gsx_viewer, key: *const c_char, limits: *const u32) -> gsx_status;
+    pub fn gsx_shard_set_slot_records(v: *mut gsx_viewer, key: *const c_char, records: u32) -> gsx_status;
+    pub fn gsx_shard_get_stats(v: *mut gsx_viewer, out: *mut gsx_shard_stats, reset: u32) -> gsx_status;
     pub fn gsx_ply_read_header(data: *const c_void, size: u64, out: *mut gsx_ply_header) -> gsx_status;
     pub fn gsx_ply_read_gaussians(data: *const c_void, size: u64, header: *const gsx_ply_header, start: u64, n: u64, out: *mut gsx_gaussian) -> gsx_status;
     pub fn gsx_ply_write(gaussians: *const gsx_gaussian, n: u64, mask_words: *const u32, edits: *const gsx_gaussian_edit, out: *mut c_void, capacity: u64, out_size: *mut u64) -> gsx_status;

@@ -155,6 +155,20 @@ pub struct gsx_shard_verdict { pub need_tiles: u32, pub overflow: u32, pub max_r
 #[repr(C)]
 #[derive(Clone, Copy)]
 pub struct gsx_ply_header { pub count: u64, pub header_bytes: u64, pub vertex_bytes: u32, pub is_ascii: u32, pub offsets: [i32; 62] }
+/// opaque: an in-process group of viewers, one per GPU (gsx_comm_group_create)
+#[repr(C)]
+pub struct gsx_comm_group {
+    _private: [u8; 0],
+}
+/// the two collectives of a caller-supplied transport: they ENQUEUE on `hip_stream` and return 0 or a gsx_status
+pub type gsx_comm_all_to_all_fn = Option<unsafe extern "C" fn(ctx: *mut c_void, d_send: *const c_void, d_recv: *mut c_void, bytes_per_peer: u64, hip_stream: *mut c_void) -> gsx_status>;
+pub type gsx_comm_all_gather_fn = Option<unsafe extern "C" fn(ctx: *mut c_void, d_send: *const c_void, d_recv: *mut c_void, bytes_per_rank: u64, hip_stream: *mut c_void) -> gsx_status>;
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct gsx_shard_stats {
+    pub frames: u64, pub redo_frames: u64, pub repair_frames: u64, pub exchange_rounds: u64,
+    pub wire_bytes: u64, pub verdict_wait_ns: u64, pub last_slot_records: u32, pub last_repair_slot_records: u32,
+}
 pub type gsx_pass = u32; // 0 project, 1 depth sort, 2 bin, 3 tile sort, 4 composite, 5 project (geometry only)
 pub const GSX_PASS_COUNT: usize = 6;
 

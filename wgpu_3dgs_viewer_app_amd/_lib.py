@@ -32,6 +32,8 @@ EXPORTS = (
     "gsx_shard_wait_verdict", "gsx_shard_repair_count", "gsx_shard_post_counts", "gsx_shard_frame_end",
     "gsx_shard_next_windows", "gsx_shard_download_limits", "gsx_comm_unique_id", "gsx_viewer_comm_init", "gsx_viewer_comm_destroy",
     "gsx_comm_all_to_all", "gsx_comm_all_gather", "gsx_shard_render_frame",
+    "gsx_comm_group_create", "gsx_comm_group_destroy", "gsx_viewer_comm_init_group", "gsx_viewer_comm_init_custom",
+    "gsx_shard_set_limits", "gsx_shard_set_slot_records", "gsx_shard_get_stats",
     "gsx_gaussian_edit_default", "gsx_update_query", "gsx_update_query_texture", "gsx_update_selection_highlight",
     "gsx_update_selection_edit", "gsx_model_show_unedited", "gsx_postprocess", "gsx_model_upload_selection",
     "gsx_model_download_selection", "gsx_model_download_edits", "gsx_model_upload_edits", "gsx_query_download_hits",
@@ -85,6 +87,17 @@ class FrameStats(C.Structure):
 class ShardVerdict(C.Structure):
     """``gsx_shard_verdict``."""
     _fields_ = [("need_tiles", C.c_uint32), ("overflow", C.c_uint32), ("max_records", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class ShardStats(C.Structure):
+    """``gsx_shard_stats``."""
+    _fields_ = [("frames", C.c_uint64), ("redo_frames", C.c_uint64), ("repair_frames", C.c_uint64), ("exchange_rounds", C.c_uint64),
+                ("wire_bytes", C.c_uint64), ("verdict_wait_ns", C.c_uint64), ("last_slot_records", C.c_uint32),
+                ("last_repair_slot_records", C.c_uint32)]
+
+
+#: gsx_comm_all_to_all_fn / gsx_comm_all_gather_fn: (ctx, d_send, d_recv, bytes, hip_stream) -> gsx_status
+COMM_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
 
 
 class GsxError(RuntimeError):
@@ -187,6 +200,13 @@ def load() -> C.CDLL:
         "gsx_comm_all_to_all": ([vp, vp, vp, u64], C.c_int32),
         "gsx_comm_all_gather": ([vp, vp, vp, u64], C.c_int32),
         "gsx_shard_render_frame": ([vp, cp, u32, u32, C.c_float, u32], C.c_int32),
+        "gsx_comm_group_create": ([u32, u32, C.POINTER(vp)], C.c_int32),
+        "gsx_comm_group_destroy": ([vp], None),
+        "gsx_viewer_comm_init_group": ([vp, vp, u32], C.c_int32),
+        "gsx_viewer_comm_init_custom": ([vp, u32, u32, COMM_FN, COMM_FN, vp], C.c_int32),
+        "gsx_shard_set_limits": ([vp, cp, vp], C.c_int32),
+        "gsx_shard_set_slot_records": ([vp, cp, u32], C.c_int32),
+        "gsx_shard_get_stats": ([vp, C.POINTER(ShardStats), u32], C.c_int32),
         "gsx_set_pass_timing": ([vp, u32], C.c_int32),
         "gsx_get_pass_timing": ([vp, f32p, u32p], C.c_int32),
     }

@@ -385,6 +385,7 @@ gsx_status gsx_shard_slot_records(gsx_viewer* v, const char* key, uint32_t world
     const uint32_t n = std::max<uint32_t>(shard_records_max, 1u);
     uint32_t t = n;
     if (m->shard_frame_limited && m->slot_hint) t = std::min<uint32_t>(n, std::max<uint32_t>(2u * m->slot_hint + 4096u, 8192u));
+    if (m->slot_force) t = std::min<uint32_t>(n, m->slot_force);  // gsx_shard_set_slot_records (the same on every rank, by contract)
     *out_records = t;
     (void)world;
     return GSX_OK;
@@ -547,6 +548,56 @@ gsx_status gsx_shard_frame_end(gsx_viewer* v, const char* key) {
         m->shard_limit_valid = true;
         m->shard_next_valid = false;
     }
+    return GSX_OK;
+}
+
+gsx_status gsx_shard_set_limits(gsx_viewer* v, const char* key, const uint32_t* d_limits) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m || !d_limits) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_set_limits: no model '%s' / null limits", key ? key : "(null)");
+    const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
+    HIPCHK(m->shard_limit.ensure(4 * (size_t)tiles_x * tiles_y));
+    // host or device memory: a host array is staged through the viewer's scratch so that every copy below is device to device
+    hipPointerAttribute_t attr{};
+    const bool on_device = hipPointerGetAttributes(&attr, d_limits) == hipSuccess && attr.type == hipMemoryTypeDevice;
+    if (!on_device) {
+        (void)hipGetLastError();
+        HIPCHK(v->scratch.ensure(4 * (size_t)tiles_x * tiles_y));
+        HIPCHK(hipStreamSynchronize(v->stream));
+        HIPCHK(hipMemcpy(v->scratch.p, d_limits, 4 * (size_t)tiles_x * tiles_y, hipMemcpyHostToDevice));
+        d_limits = v->scratch.as<uint32_t>();
+    }
+    HIPCHK(hipMemcpyAsync(m->shard_limit.p, d_limits, 4 * (size_t)tiles_x * tiles_y, hipMemcpyDeviceToDevice, v->stream));
+    m->shard_limit_valid = true;
+    m->shard_limit_tx = tiles_x;
+    m->shard_limit_ty = tiles_y;
+    m->slot_hint = 0;  // nothing is known about what THESE limits let through: the safe slot size
+    for (gsx_viewer* l : v->lanes)  // (frames in flight: every lane's next frame of this model starts from these limits)
+        if (Model* sm = find_model(l, key)) {
+            HIPCHK(sm->shard_limit.ensure(4 * (size_t)tiles_x * tiles_y));
+            HIPCHK(hipMemcpyAsync(sm->shard_limit.p, d_limits, 4 * (size_t)tiles_x * tiles_y, hipMemcpyDeviceToDevice, v->stream));
+            sm->shard_limit_valid = true;
+            sm->shard_limit_tx = tiles_x;
+            sm->shard_limit_ty = tiles_y;
+            sm->slot_hint = 0;
+        }
+    return GSX_OK;
+}
+
+gsx_status gsx_shard_set_slot_records(gsx_viewer* v, const char* key, uint32_t records) {
+    Model* m = find_model(v, key);
+    if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_set_slot_records: no model '%s'", key ? key : "(null)");
+    m->slot_force = records;
+    for (gsx_viewer* l : v->lanes)
+        if (Model* sm = find_model(l, key)) sm->slot_force = records;
+    return GSX_OK;
+}
+
+gsx_status gsx_shard_get_stats(gsx_viewer* v, gsx_shard_stats* out, uint32_t reset) {
+    if (!v || !out) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_get_stats: null argument");
+    *out = v->shard_stats;
+    if (reset) v->shard_stats = gsx_shard_stats{};
     return GSX_OK;
 }
 

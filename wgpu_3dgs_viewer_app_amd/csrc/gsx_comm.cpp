@@ -11,6 +11,8 @@
 // round trip inside it.
 #include <dlfcn.h>
 
+#include <chrono>
+
 #include <mutex>
 
 #include "gsx_state.h"
@@ -137,7 +139,7 @@ gsx_status gsx_viewer_comm_init(gsx_viewer* v, uint32_t world, uint32_t rank, co
     gsx_status st = viewer_bind(v);
     if (st) return st;
     if (!id || world == 0 || world > 64 || rank >= world) return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_comm_init: bad world/rank %u/%u", world, rank);
-    if (v->comm) return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_comm_init: this viewer already has a communicator");
+    if (has_comm(v)) return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_comm_init: this viewer already has a communicator");
     if ((st = rccl_ready())) return st;
     ncclUniqueId_ uid;
     memcpy(uid.internal, id, 128);
@@ -150,17 +152,39 @@ gsx_status gsx_viewer_comm_init(gsx_viewer* v, uint32_t world, uint32_t rank, co
     return GSX_OK;
 }
 
+gsx_status gsx_viewer_comm_init_custom(gsx_viewer* v, uint32_t world, uint32_t rank, gsx_comm_all_to_all_fn all_to_all,
+                                       gsx_comm_all_gather_fn all_gather, void* ctx) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    if (!all_to_all || !all_gather || world == 0 || world > 64 || rank >= world)
+        return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_comm_init_custom: null function or bad world/rank %u/%u", world, rank);
+    if (has_comm(v)) return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_comm_init_custom: this viewer already has a communicator");
+    v->comm_a2a_fn = all_to_all;
+    v->comm_ag_fn = all_gather;
+    v->comm_ctx = ctx;
+    v->comm_world = world;
+    v->comm_rank = rank;
+    return GSX_OK;
+}
+
 gsx_status gsx_viewer_comm_destroy(gsx_viewer* v) {
     if (!v) return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_comm_destroy: viewer is null");
-    if (!v->comm) return GSX_OK;
+    if (!has_comm(v)) return GSX_OK;
     (void)hipSetDevice(v->device);
     v->shard_pending.clear();  // frames in flight die with the communicator
     for (gsx_viewer* l : v->lanes) (void)hipStreamSynchronize(l->stream);
     if (v->comm_stream) (void)hipStreamSynchronize(v->comm_stream);
     (void)hipStreamSynchronize(v->stream);
+    v->comm_world = 0;
+    if (v->comm_a2a_fn) {
+        if (v->comm_group) group_leave(v);
+        v->comm_a2a_fn = nullptr;
+        v->comm_ag_fn = nullptr;
+        v->comm_ctx = nullptr;
+        return GSX_OK;
+    }
     ncclComm_t c = comm_of(v);
     v->comm = nullptr;
-    v->comm_world = 0;
     RCCLCHK(g_rccl.CommDestroy(c));
     return GSX_OK;
 }
@@ -169,9 +193,18 @@ gsx_status gsx_comm_all_to_all(gsx_viewer* v, const void* d_send, void* d_recv, 
     gsx_status st = viewer_bind(v);
     if (st) return st;
     gsx_viewer* o = owner_of(v);
-    if (!o->comm) return fail(GSX_ERR_RCCL, "gsx_comm_all_to_all: no communicator (gsx_viewer_comm_init)");
+    if (!has_comm(o)) return fail(GSX_ERR_RCCL, "gsx_comm_all_to_all: no communicator (gsx_viewer_comm_init)");
     if (!d_send || !d_recv) return fail(GSX_ERR_INVALID_ARG, "gsx_comm_all_to_all: null buffer");
     if (bytes_per_peer == 0) return GSX_OK;
+    o->shard_stats.wire_bytes += (uint64_t)(o->comm_world - 1u) * bytes_per_peer;
+    if (o->comm_a2a_fn) {  // the caller's transport (or the in-process group): the whole exchange, own slot included
+        hipStream_t ts;
+        if ((st = route_begin(v, &ts))) return st;
+        g_err.clear();
+        if ((st = o->comm_a2a_fn(o->comm_ctx, d_send, d_recv, bytes_per_peer, ts)))
+            return g_err.empty() ? fail(st, "gsx_comm_all_to_all: the custom transport failed with status %d", (int)st) : st;
+        return route_end(v);
+    }
     // what this rank keeps for itself does not travel: a device copy on the viewer's own stream, beside the exchange
     // (GSX_COMM_SELF_VIA_RCCL, read by gsx_viewer_comm_init: send it to oneself through RCCL like everything else — the
     // one-rank tests on a one-GPU box exercise ncclSend / ncclRecv that way)
@@ -198,11 +231,18 @@ gsx_status gsx_comm_all_gather(gsx_viewer* v, const void* d_send, void* d_recv, 
     gsx_status st = viewer_bind(v);
     if (st) return st;
     gsx_viewer* o = owner_of(v);
-    if (!o->comm) return fail(GSX_ERR_RCCL, "gsx_comm_all_gather: no communicator (gsx_viewer_comm_init)");
+    if (!has_comm(o)) return fail(GSX_ERR_RCCL, "gsx_comm_all_gather: no communicator (gsx_viewer_comm_init)");
     if (!d_send || !d_recv) return fail(GSX_ERR_INVALID_ARG, "gsx_comm_all_gather: null buffer");
     if (bytes_per_rank == 0) return GSX_OK;
+    o->shard_stats.wire_bytes += (uint64_t)(o->comm_world - 1u) * bytes_per_rank;
     hipStream_t cs;
     if ((st = route_begin(v, &cs))) return st;
+    if (o->comm_ag_fn) {
+        g_err.clear();
+        if ((st = o->comm_ag_fn(o->comm_ctx, d_send, d_recv, bytes_per_rank, cs)))
+            return g_err.empty() ? fail(st, "gsx_comm_all_gather: the custom transport failed with status %d", (int)st) : st;
+        return route_end(v);
+    }
     RCCLCHK(g_rccl.AllGather(d_send, d_recv, bytes_per_rank, kNcclChar, comm_of(v), cs));
     return route_end(v);
 }
@@ -242,6 +282,11 @@ gsx_status frame_buffers(ShardFrame& f) {
 gsx_status exchange_round(ShardFrame& f, uint32_t round, uint32_t T) {
     gsx_viewer* v = f.l;
     const uint64_t per_peer = (uint64_t)(T + 1u) * GSX_RECORD_BYTES;
+    {
+        gsx_shard_stats& ss = (v->parent ? v->parent : v)->shard_stats;
+        ss.exchange_rounds += 1;
+        (round == 0 ? ss.last_slot_records : ss.last_repair_slot_records) = T;
+    }
     HIPCHK(v->shard_send.ensure(per_peer * f.world));
     HIPCHK(v->shard_recv.ensure(per_peer * f.world));
     gsx_status s2;
@@ -279,9 +324,17 @@ gsx_status frame_complete(gsx_viewer* owner, ShardPending& p) {
     gsx_status st = frame_buffers(f);
     if (st) return st;
     gsx_shard_verdict verdict{};
+    gsx_shard_stats& ss = owner->shard_stats;
+    auto timed_wait = [&](gsx_viewer* wv, const char* wkey, uint32_t seq, gsx_shard_verdict* out) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const gsx_status ws = gsx_shard_wait_verdict(wv, wkey, seq, out);
+        ss.verdict_wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        return ws;
+    };
     for (int attempt = 0;; ++attempt) {
-        if ((st = gsx_shard_wait_verdict(f.l, f.key, p.seq, &verdict))) return st;
+        if ((st = timed_wait(f.l, f.key, p.seq, &verdict))) return st;
         if (!verdict.overflow) break;
+        if (attempt == 0) ss.redo_frames += 1;
         if (attempt == 1)
             return fail(GSX_ERR_OOM, "gsx_shard_render_frame: an exchange slot of %u records (a whole shard) overflowed: shard_records_max is wrong",
                         p.slot_records);
@@ -290,7 +343,9 @@ gsx_status frame_complete(gsx_viewer* owner, ShardPending& p) {
         if ((st = gsx_shard_verify(f.l, f.key, f.world, f.l->shard_sat_all.p, &p.seq))) return st;
         if ((st = finish_round(f, p.margin, p.radius))) return st;
     }
+    ss.frames += 1;
     if (verdict.need_tiles) {
+        ss.repair_frames += 1;
         gsx_viewer* v = f.l;
         HIPCHK(v->shard_counts.ensure(16 * (size_t)(f.world + 1)));
         char* cnt = static_cast<char*>(v->shard_counts.p);
@@ -299,7 +354,7 @@ gsx_status frame_complete(gsx_viewer* owner, ShardPending& p) {
         uint32_t seq = 0;
         if ((st = gsx_shard_post_counts(v, f.world, cnt, &seq))) return st;
         gsx_shard_verdict sized{};
-        if ((st = gsx_shard_wait_verdict(v, nullptr, seq, &sized))) return st;
+        if ((st = timed_wait(v, nullptr, seq, &sized))) return st;
         if ((st = exchange_round(f, 1, std::max<uint32_t>(sized.max_records, 1u)))) return st;
         if ((st = finish_round(f, p.margin, p.radius))) return st;
     }
@@ -348,7 +403,7 @@ gsx_status gsx_shard_render_frame(gsx_viewer* v, const char* key, uint32_t shard
     if (!v || !key) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_render_frame: null argument");
     if (v->parent) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_render_frame: called on a lane");
     HIPCHK(hipSetDevice(v->device));
-    if (!v->comm) return fail(GSX_ERR_RCCL, "gsx_shard_render_frame: no communicator (gsx_viewer_comm_init)");
+    if (!has_comm(v)) return fail(GSX_ERR_RCCL, "gsx_shard_render_frame: no communicator (gsx_viewer_comm_init)");
     if (!find_model(v, key)) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_render_frame: no model '%s'", key);
     BusyGuard guard(v);
     gsx_status st = GSX_OK;

@@ -1,0 +1,201 @@
+// gsx_comm_group.cpp — the in-process transport of the multi-GPU path: one host process, one host thread + one viewer per
+// GPU (or, in the tests, several viewers on ONE GPU), the two collectives of the sharded frame as device-to-device copies
+// ordered by HIP events.  No reference counterpart (src/main.rs:85-98: one wgpu device); a single-process host like the egui
+// app would drive its GPUs this way, and it is how tests/test_gpu_shard_lib.py runs gsx_shard_render_frame's own control flow
+// with 2 ... 8 ranks on a one-GPU box.  Implemented on the custom-transport interface of include/gsx.h (two functions that
+// enqueue on a stream), like any transport a caller could bring.
+//
+// A collective, seen from rank r (every rank runs the same sequence, gsx_comm.cpp guarantees one order of collectives):
+//   record `ready` on r's stream, publish {send, recv, bytes}          -- what r contributes exists once `ready` fires
+//   host rendezvous A                                                  -- everybody has published; sizes are compared
+//   for every source p, in rank order: wait for p's `ready`, copy p's piece for r into r's receive buffer   (on r's stream)
+//   record `done` on r's stream; host rendezvous B; wait for every peer's `done`
+//                                                                      -- r's send buffer may be reused: every reader is behind
+// The host threads meet twice per collective; the DEVICE never waits for a host (copies and waits are enqueued).  A rendezvous
+// that is not complete after timeout_ms aborts the group: every rank's call — the waiting one and all later ones — returns
+// GSX_ERR_RCCL with the reason.  Nothing hangs.
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+
+#include "gsx_state.h"
+
+namespace {
+
+enum Op : int { OP_NONE = 0, OP_ALL_TO_ALL = 1, OP_ALL_GATHER = 2 };
+
+struct Seat {
+    gsx_comm_group* group = nullptr;
+    uint32_t rank = 0;
+    bool taken = false;
+    int device = 0;
+    hipEvent_t ready = nullptr, done = nullptr;
+    // published for the collective in flight
+    const char* send = nullptr;
+    char* recv = nullptr;
+    uint64_t bytes = 0;
+    int op = OP_NONE;
+};
+
+}  // namespace
+
+struct gsx_comm_group {
+    uint32_t world = 0;
+    uint32_t timeout_ms = 60000;
+    std::mutex mu;
+    std::condition_variable cv;
+    uint32_t arrived = 0;
+    uint64_t generation = 0;
+    bool aborted = false;
+    std::string why;
+    Seat seats[64];
+};
+
+namespace {
+
+gsx_status group_abort(gsx_comm_group* g, const std::string& why) {  // (mu held)
+    if (!g->aborted) {
+        g->aborted = true;
+        g->why = why;
+    }
+    g->cv.notify_all();
+    return fail(GSX_ERR_RCCL, "in-process group: %s", g->why.c_str());
+}
+
+// all `world` ranks, or GSX_ERR_RCCL for everybody
+gsx_status rendezvous(gsx_comm_group* g, uint32_t rank, const char* what) {
+    std::unique_lock<std::mutex> lk(g->mu);
+    if (g->aborted) return fail(GSX_ERR_RCCL, "in-process group: %s", g->why.c_str());
+    const uint64_t gen = g->generation;
+    if (++g->arrived == g->world) {
+        g->arrived = 0;
+        g->generation += 1;
+        g->cv.notify_all();
+        return GSX_OK;
+    }
+    const bool ok = g->cv.wait_for(lk, std::chrono::milliseconds(g->timeout_ms), [&] { return g->generation != gen || g->aborted; });
+    if (g->generation != gen) return GSX_OK;  // complete (whatever happened to the group a moment later)
+    if (g->aborted) return fail(GSX_ERR_RCCL, "in-process group: %s", g->why.c_str());
+    if (!ok) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "rank %u waited %u ms for its peers in %s (a rank left the frame loop, or the ranks disagree about the "
+                 "sequence of collectives)", rank, g->timeout_ms, what);
+        return group_abort(g, buf);
+    }
+    return GSX_OK;
+}
+
+gsx_status collective(Seat* me, int op, const void* d_send, void* d_recv, uint64_t bytes, hipStream_t stream) {
+    gsx_comm_group* g = me->group;
+    const char* what = op == OP_ALL_TO_ALL ? "an all-to-all" : "an all-gather";
+    HIPCHK(hipEventRecord(me->ready, stream));
+    me->send = static_cast<const char*>(d_send);
+    me->recv = static_cast<char*>(d_recv);
+    me->bytes = bytes;
+    me->op = op;
+    gsx_status st = rendezvous(g, me->rank, what);
+    if (st) return st;
+    // every rank compares the same published values and comes to the same conclusion
+    for (uint32_t p = 0; p < g->world; ++p)
+        if (g->seats[p].op != op || g->seats[p].bytes != bytes) {
+            std::unique_lock<std::mutex> lk(g->mu);
+            char buf[256];
+            snprintf(buf, sizeof buf, "ranks disagree: rank %u is in %s of %llu bytes per rank, rank %u in op %d of %llu", me->rank, what,
+                     (unsigned long long)bytes, p, g->seats[p].op, (unsigned long long)g->seats[p].bytes);
+            return group_abort(g, buf);
+        }
+    for (uint32_t p = 0; p < g->world; ++p) {  // delivery by source rank, like ncclRecv from p / ncclAllGather
+        const Seat& src = g->seats[p];
+        const char* from = op == OP_ALL_TO_ALL ? src.send + (size_t)me->rank * bytes : src.send;
+        char* to = me->recv + (size_t)p * bytes;
+        if (from == to) continue;  // an in-place all-gather's own piece
+        if (p != me->rank) HIPCHK(hipStreamWaitEvent(stream, src.ready, 0));
+        HIPCHK(hipMemcpyAsync(to, from, bytes, hipMemcpyDefault, stream));
+    }
+    HIPCHK(hipEventRecord(me->done, stream));
+    if ((st = rendezvous(g, me->rank, what))) return st;
+    for (uint32_t p = 0; p < g->world; ++p)
+        if (p != me->rank) HIPCHK(hipStreamWaitEvent(stream, g->seats[p].done, 0));
+    return GSX_OK;
+}
+
+gsx_status group_all_to_all(void* ctx, const void* d_send, void* d_recv, uint64_t bytes_per_peer, void* hip_stream) {
+    return collective(static_cast<Seat*>(ctx), OP_ALL_TO_ALL, d_send, d_recv, bytes_per_peer, static_cast<hipStream_t>(hip_stream));
+}
+
+gsx_status group_all_gather(void* ctx, const void* d_send, void* d_recv, uint64_t bytes_per_rank, void* hip_stream) {
+    return collective(static_cast<Seat*>(ctx), OP_ALL_GATHER, d_send, d_recv, bytes_per_rank, static_cast<hipStream_t>(hip_stream));
+}
+
+}  // namespace
+
+void gsx::group_leave(gsx_viewer* v) {
+    gsx_comm_group* g = v->comm_group;
+    Seat* me = static_cast<Seat*>(v->comm_ctx);
+    if (!g || !me) return;
+    std::unique_lock<std::mutex> lk(g->mu);
+    if (me->ready) (void)hipEventDestroy(me->ready);
+    if (me->done) (void)hipEventDestroy(me->done);
+    me->ready = me->done = nullptr;
+    me->taken = false;
+    // a rank that leaves while the others still render: they find out at their next rendezvous, at once
+    if (!g->aborted) {
+        g->aborted = true;
+        g->why = "rank " + std::to_string(me->rank) + " destroyed its communicator";
+    }
+    g->cv.notify_all();
+    v->comm_group = nullptr;
+}
+
+extern "C" {
+
+gsx_status gsx_comm_group_create(uint32_t world, uint32_t timeout_ms, gsx_comm_group** out) {
+    if (!out || world == 0 || world > 64) return fail(GSX_ERR_INVALID_ARG, "gsx_comm_group_create: world must be 1..64");
+    gsx_comm_group* g = new gsx_comm_group();
+    g->world = world;
+    g->timeout_ms = timeout_ms ? timeout_ms : 60000u;
+    for (uint32_t r = 0; r < world; ++r) {
+        g->seats[r].group = g;
+        g->seats[r].rank = r;
+    }
+    *out = g;
+    return GSX_OK;
+}
+
+void gsx_comm_group_destroy(gsx_comm_group* g) { delete g; }
+
+gsx_status gsx_viewer_comm_init_group(gsx_viewer* v, gsx_comm_group* g, uint32_t rank) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    if (!g || rank >= g->world) return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_comm_init_group: null group or rank %u out of range", rank);
+    if (has_comm(v)) return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_comm_init_group: this viewer already has a communicator");
+    Seat* me = &g->seats[rank];
+    {
+        std::unique_lock<std::mutex> lk(g->mu);
+        if (me->taken) return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_comm_init_group: rank %u of this group is taken", rank);
+        if (g->aborted) return fail(GSX_ERR_RCCL, "in-process group: %s", g->why.c_str());
+        me->taken = true;
+    }
+    me->device = v->device;
+    HIPCHK(hipEventCreateWithFlags(&me->ready, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&me->done, hipEventDisableTiming));
+    // several devices in one process: direct peer copies over xGMI where the platform allows (otherwise the runtime stages them)
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) == hipSuccess)
+        for (int d = 0; d < n_dev; ++d) {
+            int can = 0;
+            if (d != v->device && hipDeviceCanAccessPeer(&can, v->device, d) == hipSuccess && can) {
+                const hipError_t e = hipDeviceEnablePeerAccess(d, 0);
+                if (e != hipSuccess) (void)hipGetLastError();  // already enabled: fine
+            }
+        }
+    if ((st = gsx_viewer_comm_init_custom(v, g->world, rank, group_all_to_all, group_all_gather, me))) {
+        std::unique_lock<std::mutex> lk(g->mu);
+        me->taken = false;
+        return st;
+    }
+    v->comm_group = g;
+    return GSX_OK;
+}
+
+}  // extern "C"

@@ -175,6 +175,7 @@ struct Model {
     DevBuf shard_limit, shard_limit_next, shard_win2;
     bool shard_limit_valid = false, shard_next_valid = false, shard_frame_limited = false;
     uint32_t shard_limit_tx = 0, shard_limit_ty = 0;
+    uint32_t slot_force = 0;                   // gsx_shard_set_slot_records: round-0 slot size instead of the policy's (0 = policy)
     uint32_t slot_hint = 0;                    // records the busiest (rank, destination) pair wanted in round 0 of the last frame: a GLOBAL
                                                // figure from that frame's verdict, so every rank sizes the next slots identically; 0 = unknown
     DevBuf adm_ballots2;           // the repair round's ballots (the first round's stay: they say which records are shaded)
@@ -302,6 +303,12 @@ struct gsx_viewer {
     void* comm = nullptr;                // ncclComm_t (gsx_viewer_comm_init); RCCL is loaded at run time (gsx_comm.cpp)
     uint32_t comm_world = 0, comm_rank = 0;
     bool comm_self_via_rccl = false;     // GSX_COMM_SELF_VIA_RCCL at gsx_viewer_comm_init: a rank's own exchange slot goes through RCCL too
+    // a transport other than RCCL (gsx_viewer_comm_init_custom / _init_group): the two collectives as functions that enqueue
+    gsx_comm_all_to_all_fn comm_a2a_fn = nullptr;
+    gsx_comm_all_gather_fn comm_ag_fn = nullptr;
+    void* comm_ctx = nullptr;
+    gsx_comm_group* comm_group = nullptr;  // != nullptr: comm_ctx is this viewer's seat in that group (gsx_comm_group.cpp)
+    gsx_shard_stats shard_stats{};       // host-side bookkeeping of the sharded frames (gsx_shard_get_stats)
     DevBuf shard_fb, shard_send, shard_recv, shard_sat_band, shard_sat_all, shard_counts;  // gsx_shard_render_frame's own buffers
     void* ext_fb = nullptr;              // caller-owned framebuffer (multi-GPU: the RCCL gather target)
     uint64_t ext_fb_bytes = 0;
@@ -354,6 +361,8 @@ inline uint32_t ceil_log2(uint32_t x) {
 // may be about to read results or to change model data the lanes are still reading: the viewer's stream is ordered after
 // the lanes' frames (no host wait), and the lanes' next frames after whatever the caller enqueues (epoch).
 gsx_status shard_complete_pending(gsx_viewer* v);  // gsx_comm.cpp: verdicts, redo / repair rounds of the sharded frames in flight
+inline bool has_comm(const gsx_viewer* v) { return v->comm != nullptr || v->comm_a2a_fn != nullptr; }
+void group_leave(gsx_viewer* v);  // gsx_comm_group.cpp: give this viewer's seat in its in-process group back
 
 inline gsx_status viewer_bind(gsx_viewer* v) {
     if (!v) return fail(GSX_ERR_INVALID_ARG, "viewer is null");

@@ -231,6 +231,21 @@ class _Renderer:
         _lib.check(self._v._L.gsx_render(self._v._h, arr, len(keys)))
 
 
+class CommGroup:
+    """``gsx_comm_group``: the in-process transport for `world` viewers of ONE process (one host thread each)."""
+
+    def __init__(self, world: int, timeout_ms: int = 0):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        self.world = int(world)
+        _lib.check(self._L.gsx_comm_group_create(self.world, int(timeout_ms), C.byref(self._h)))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.gsx_comm_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+
 class MultiModelViewer:
     """``gs::MultiModelViewer<G>`` over libgsx.so."""
 
@@ -366,6 +381,48 @@ class MultiModelViewer:
         keys = [k.encode() for k in model_render_keys]
         arr = (C.c_char_p * max(len(keys), 1))(*keys)
         _lib.check(self._L.gsx_render_frame(self._h, arr, len(keys)))
+
+    # -- several GPUs: the index-sharded frame as one library call (include/gsx.h "multi-GPU"; no reference counterpart) --
+    def comm_init_group(self, group: "CommGroup", rank: int) -> None:
+        """Seat `rank` of an in-process group: one host thread + one viewer per GPU, collectives as peer copies."""
+        _lib.check(self._L.gsx_viewer_comm_init_group(self._h, group._h, int(rank)))
+        self._group = group  # keeps the group alive as long as the viewer
+
+    def comm_init_rccl(self, world: int, rank: int, unique_id: bytes) -> None:
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _lib.check(self._L.gsx_viewer_comm_init(self._h, int(world), int(rank), buf))
+
+    def comm_init_custom(self, world: int, rank: int, all_to_all, all_gather) -> None:
+        """A transport of the caller's own: two callables (d_send, d_recv, bytes, hip_stream) -> gsx_status that enqueue."""
+        self._comm_fns = (_lib.COMM_FN(lambda ctx, s, r, b, st: int(all_to_all(s, r, b, st) or 0)),
+                          _lib.COMM_FN(lambda ctx, s, r, b, st: int(all_gather(s, r, b, st) or 0)))
+        _lib.check(self._L.gsx_viewer_comm_init_custom(self._h, int(world), int(rank), self._comm_fns[0], self._comm_fns[1], None))
+
+    def comm_destroy(self) -> None:
+        _lib.check(self._L.gsx_viewer_comm_destroy(self._h))
+
+    def shard_render_frame(self, key: str, shard_records_max: int, speculate: bool = True, margin: float = 0.25, radius: int = 3) -> None:
+        """One whole index-sharded frame of this rank (``gsx_shard_render_frame``)."""
+        _lib.check(self._L.gsx_shard_render_frame(self._h, key.encode(), int(shard_records_max), 1 if speculate else 0, float(margin), int(radius)))
+
+    def shard_set_limits(self, key: str, limits: np.ndarray) -> None:
+        """Per-tile depth-key limits (uint32 [tiles_y, tiles_x]) the next sharded frame uses instead of the last frame's."""
+        a = np.ascontiguousarray(limits, np.uint32)
+        _lib.check(self._L.gsx_shard_set_limits(self._h, key.encode(), a.ctypes.data))
+
+    def shard_set_slot_records(self, key: str, records: int) -> None:
+        _lib.check(self._L.gsx_shard_set_slot_records(self._h, key.encode(), int(records)))
+
+    def shard_download_limits(self, key: str) -> np.ndarray:
+        w, h = self.size
+        out = np.empty(((h + 15) // 16, (w + 15) // 16), np.uint32)
+        _lib.check(self._L.gsx_shard_download_limits(self._h, key.encode(), _u32p(out), out.size))
+        return out
+
+    def shard_stats(self, reset: bool = False) -> dict:
+        st = _lib.ShardStats()
+        _lib.check(self._L.gsx_shard_get_stats(self._h, C.byref(st), 1 if reset else 0))
+        return {n: int(getattr(st, n)) for n, _ in _lib.ShardStats._fields_}
 
     # -- readback --
     def download_framebuffer(self) -> np.ndarray:
