@@ -415,6 +415,10 @@ gsx_status gsx_shard_frame_begin(gsx_viewer* v, const char* key, uint32_t world,
  * shards).  Every rank gets the same answer: the policy uses only that and the last verdict's global figure. */
 gsx_status gsx_shard_slot_records(gsx_viewer* v, const char* key, uint32_t world, uint32_t shard_records_max, uint32_t* out_records);
 gsx_status gsx_shard_pack_slots(gsx_viewer* v, const char* key, uint32_t world, uint32_t round, void* d_send, uint32_t slot_records);
+/* round: 0 or 1, | GSX_SHARD_BEHIND for a model of a LAYERED frame that is not the nearest one: its records are composited
+ * behind what the nearer models of this frame left in the framebuffer (scene.rs:533-558, 2302-2314: models are painted far ->
+ * near and never merged), and its feedback ignores the tiles those models had saturated already. */
+#define GSX_SHARD_BEHIND 2u
 gsx_status gsx_shard_import_slots(gsx_viewer* v, const char* key, const void* d_recv, uint32_t world, uint32_t rank, uint32_t round,
                                   uint32_t slot_records);
 /* d_sat_all: the all-gathered gsx_shard_feedback bands: per rank gsx_shard_feedback_words() words = its band of saturation keys
@@ -430,7 +434,8 @@ gsx_status gsx_shard_frame_end(gsx_viewer* v, const char* key);
 /* parity / introspection: the per-tile limits the next frame will use (u32 per tile; 0xFFFFFFFF = unbounded). Synchronises. */
 gsx_status gsx_shard_download_limits(gsx_viewer* v, const char* key, uint32_t* limits, uint64_t n_words);
 
-/* ---- the collectives, inside the library over RCCL (xGMI): one communicator per viewer, enqueued on the viewer's stream.
+/* ---- the collectives, inside the library over RCCL (xGMI): one communicator per viewer (with frames_in_flight = L sharded
+ *      frames: L, the others created by the library on first use — a collective step), enqueued on the viewer's stream.
  *      RCCL is loaded at run time; missing / failing RCCL -> GSX_ERR_RCCL.  Bootstrap like any NCCL program: one rank calls
  *      gsx_comm_unique_id, the 128 bytes reach the other ranks by the host's own means, every rank calls gsx_viewer_comm_init
  *      (collective: returns when all `world` ranks have joined). ---- */
@@ -445,6 +450,13 @@ gsx_status gsx_comm_all_gather(gsx_viewer* v, const void* d_send, void* d_recv, 
  * _init_custom): the sequence above, into a padded framebuffer the library owns; after gsx_sync, gsx_download_framebuffer
  * returns the complete frame on every rank. */
 gsx_status gsx_shard_render_frame(gsx_viewer* v, const char* key, uint32_t shard_records_max, uint32_t speculate, float margin, uint32_t radius);
+/* The same for several LAYERED models — the reference paints `model_render_keys` far -> near and never merges models
+ * (src/tab/scene.rs:533-558, 2302-2314), gsx_render does the same on one GPU.  Every model is index-sharded over the ranks
+ * (shard_records_max[i] = largest shard of keys_far_to_near[i]); each keeps its own per-tile limits from frame to frame.  Per
+ * model: exchange -> composite into this rank's band behind the nearer models -> verification -> (repair); one band
+ * all-gather at the end.  Pixels equal gsx_render(keys_far_to_near) on one GPU bit for bit. */
+gsx_status gsx_shard_render_frame_keys(gsx_viewer* v, const char* const* keys_far_to_near, uint32_t n_keys,
+                                       const uint32_t* shard_records_max, uint32_t speculate, float margin, uint32_t radius);
 
 /* ---- other transports under the same frame loop.  gsx_shard_render_frame only ever calls "all-to-all of equal slots" and
  *      "all-gather of equal pieces"; RCCL is one provider of the two.

@@ -199,6 +199,7 @@ extern "C" {
     pub fn gsx_comm_all_to_all(v: *mut gsx_viewer, d_send: *const c_void, d_recv: *mut c_void, bytes_per_peer: u64) -> gsx_status;
     pub fn gsx_comm_all_gather(v: *mut gsx_viewer, d_send: *const c_void, d_recv: *mut c_void, bytes_per_rank: u64) -> gsx_status;
     pub fn gsx_shard_render_frame(v: *mut gsx_viewer, key: *const c_char, shard_records_max: u32, speculate: u32, margin: f32, radius: u32) -> gsx_status;
+    pub fn gsx_shard_render_frame_keys(v: *mut gsx_viewer, keys_far_to_near: *const *const c_char, n_keys: u32, shard_records_max: *const u32, speculate: u32, margin: f32, radius: u32) -> gsx_status;
     pub fn gsx_comm_group_create(world: u32, timeout_ms: u32, out: *mut *mut gsx_comm_group) -> gsx_status;
     pub fn gsx_comm_group_destroy(g: *mut gsx_comm_group);
     pub fn gsx_viewer_comm_init_group(v: *mut gsx_viewer, g: *mut gsx_comm_group, rank: u32) -> gsx_status;

@@ -66,31 +66,6 @@ class ThreadComm:
         if t.is_cuda:
             torch.cuda.current_stream().synchronize()
 
-    def all_to_all_counts(self, counts, device):
-        h = self.hub
-        h.slots[self.rank] = list(counts)
-        h.barrier.wait()
-        out = [int(h.slots[src][self.rank]) for src in range(h.world)]
-        h.barrier.wait()
-        return out
-
-    def all_to_all_records(self, recv, send, recv_counts, send_counts):
-        h = self.hub
-        self._sync(send)
-        h.slots[self.rank] = (send, list(send_counts))
-        self.bytes_sent += sum(c for g, c in enumerate(send_counts) if g != self.rank) * send.shape[1] * 4
-        h.barrier.wait()
-        o = 0
-        for src in range(h.world):
-            s, sc = h.slots[src]
-            off, n = sum(sc[: self.rank]), sc[self.rank]
-            assert n == recv_counts[src]
-            if n:
-                recv[o:o + n].copy_(s[off:off + n])
-            o += n
-        self._sync(recv)
-        h.barrier.wait()
-
     def all_to_all_slots(self, recv, send):
         """Fixed-size slots [world, 1 + T, 12]: slot p of `send` goes to rank p.  ``bytes_sent`` counts the PAYLOAD the
         headers announce (word 1 of a slot's first record = records sent), not the slot size."""

@@ -134,26 +134,33 @@ class OracleStages:
     #      the counts, windows / verification / next limits kept by the stage backend ----
     EXTRA = 4  # statistics words behind every rank's band of saturation keys
 
+    def _m(self, key):
+        """per-model protocol state (limits, windows, slot figures): models are exchanged one after the other"""
+        self._ms = getattr(self, "_ms", {})
+        return self._ms.setdefault(key, {})
+
     def frame_begin(self, key, world, rank, speculate=True, limit=None):
         from wgpu_3dgs_viewer_app_amd import parallel
 
         f = self.frame
+        m = self._m(key)
         if limit is not None:
-            self._limit = np.array(limit, np.uint32)
-        lim = getattr(self, "_limit", None)
-        self._limited = bool(speculate and lim is not None and lim.shape == (f.tiles_y, f.tiles_x))
-        self._win1 = parallel.windows_first(lim) if self._limited else None
-        self._win2 = np.zeros((f.tiles_y, f.tiles_x, 2), np.uint32)
+            m["limit"] = np.array(limit, np.uint32)
+        lim = m.get("limit")
+        m["limited"] = bool(speculate and lim is not None and lim.shape == (f.tiles_y, f.tiles_x))
+        m["win1"] = parallel.windows_first(lim) if m["limited"] else None
+        m["win2"] = np.zeros((f.tiles_y, f.tiles_x, 2), np.uint32)
         self._prs[key] = self._project(key)
         self._world, self._rank = world, rank
-        self._slot_max, self._slot_over = [0, 0], [0, 0]
+        m["slot_max"], m["slot_over"] = [0, 0], [0, 0]
         self._need_count = 0
 
     def slot_records(self, key, world, shard_max):
         return int(shard_max)   # no adaptive policy here: the safe size, identical on every rank
 
     def pack_slots(self, key, world, rnd, slot):
-        window = self._win1 if rnd == 0 else self._win2
+        m = self._m(key)
+        window = m["win1"] if rnd == 0 else m["win2"]
         send, counts = pack_by_destination(self._prs[key], world, self.frame.tiles_x, self.frame.tiles_y, window)
         out = np.zeros((world, slot + 1, 12), np.float32)
         o = 0
@@ -162,24 +169,39 @@ class OracleStages:
             out[g, 0, 0:2] = np.array([c, sent], np.uint32).view(np.float32)
             out[g, 1:1 + sent] = send[o:o + sent]
             o += c
-        self._slot_max[rnd] = max(counts) if counts else 0
-        self._slot_over[rnd] = int(self._slot_max[rnd] > slot)
+        m["slot_max"][rnd] = max(counts) if counts else 0
+        m["slot_over"][rnd] = int(m["slot_max"][rnd] > slot)
         return torch.from_numpy(out)
 
     def alloc_slots(self, world, slot, rnd):
         return torch.zeros((world, slot + 1, 12), dtype=torch.float32)
 
-    def import_slots(self, key, recv, world, rank, rnd, slot):
+    def _saturated(self):
+        """bool [tiles_y, tiles_x]: every pixel of the tile has T < 1e-4 (padding pixels do not exist: partial tiles count
+        their real pixels)"""
+        f = self.frame
+        out = np.zeros((f.tiles_y, f.tiles_x), bool)
+        for ty in range(f.tiles_y):
+            for tx in range(f.tiles_x):
+                tile = self._fb[ty * 16: ty * 16 + 16, tx * 16: tx * 16 + 16, 3]
+                out[ty, tx] = bool(tile.size) and bool((tile < 1e-4).all())
+        return out
+
+    def import_slots(self, key, recv, world, rank, rnd, slot, behind=False):
         r = recv.numpy()
         parts = []
         for s in range(world):
             sent = int(r[s, 0, 1:2].view(np.uint32)[0])
             parts.append(r[s, 1:1 + sent])
         recs = np.ascontiguousarray(np.concatenate(parts)) if parts else np.zeros((0, 12), np.float32)
-        window = self._win1 if rnd == 0 else self._win2
+        m = self._m(key)
+        window = m["win1"] if rnd == 0 else m["win2"]
         self._world, self._rank = world, rank
         self._imp[key] = self._lists(key, projection_from_records(recs), window)
-        self._composite([key], world, rank, more=(rnd == 1))
+        if rnd == 0:  # a layered frame: the tiles nearer models saturated say nothing about this model's depths
+            m["done_before"] = self._saturated() if behind else None
+        self._fb_key = key
+        self._composite([key], world, rank, more=(rnd == 1 or behind))
 
     def alloc_sat(self, world, mine):
         return torch.zeros(world * mine.numel(), dtype=torch.int32)
@@ -194,12 +216,13 @@ class OracleStages:
         from wgpu_3dgs_viewer_app_amd import parallel
 
         sat, extra = self._sat_map(sat_all, world)
-        if self._limited:
-            need = (self._limit < parallel.KEY_ALL) & (sat == 0)
-            self._win2 = parallel.windows_second(self._limit, need)
+        m = self._m(key)
+        if m["limited"]:
+            need = (m["limit"] < parallel.KEY_ALL) & (sat == 0)
+            m["win2"] = parallel.windows_second(m["limit"], need)
             self._need_count = int(need.sum())
         else:
-            self._win2 = np.zeros(sat.shape + (2,), np.uint32)
+            m["win2"] = np.zeros(sat.shape + (2,), np.uint32)
             self._need_count = 0
         self._seq = getattr(self, "_seq", 0) + 1
         self._verdicts = getattr(self, "_verdicts", {})
@@ -210,7 +233,7 @@ class OracleStages:
         return self._verdicts.pop(seq)
 
     def repair_count(self, key, world):
-        _, counts = pack_by_destination(self._prs[key], world, self.frame.tiles_x, self.frame.tiles_y, self._win2)
+        _, counts = pack_by_destination(self._prs[key], world, self.frame.tiles_x, self.frame.tiles_y, self._m(key)["win2"])
         return torch.tensor([max(counts) if counts else 0, 0, 0, 0], dtype=torch.int32)
 
     def alloc_counts(self, world):
@@ -225,13 +248,14 @@ class OracleStages:
         from wgpu_3dgs_viewer_app_amd import parallel
 
         sat, _ = self._sat_map(sat_all, world)
-        self._limit_next = parallel.next_limits(sat, margin, radius)
+        self._m(key)["limit_next"] = parallel.next_limits(sat, margin, radius)
 
     def frame_end(self, key):
-        self._limit = self._limit_next
+        m = self._m(key)
+        m["limit"] = m["limit_next"]
 
     def limits(self, key):
-        return self._limit
+        return self._m(key)["limit"]
 
     def _project(self, key):
         pos, color, sh, cov = self.pods[key]
@@ -283,13 +307,15 @@ class OracleStages:
         f = self.frame
         rpr, lo, hi = self._band(world, rank)
         out = np.zeros((rpr, f.tiles_x), np.uint32)
+        m = self._m(key)
+        before = m.get("done_before")
+        sat = self._saturated()
         for ty in range(lo, hi):
             for tx in range(f.tiles_x):
-                tile = self._fb[ty * 16: ty * 16 + 16, tx * 16: tx * 16 + 16, 3]
-                if tile.size and bool((tile < 1e-4).all()):
-                    out[ty - lo, tx] = max(int(self._deepest[ty, tx]), 1)
+                if sat[ty, tx]:
+                    out[ty - lo, tx] = 1 if (before is not None and before[ty, tx]) else max(int(self._deepest[ty, tx]), 1)
         extra = np.zeros(self.EXTRA, np.uint32)
-        extra[0], extra[1] = getattr(self, "_slot_max", [0, 0])[0], getattr(self, "_slot_over", [0, 0])[0]
+        extra[0], extra[1] = m.get("slot_max", [0, 0])[0], m.get("slot_over", [0, 0])[0]
         return torch.from_numpy(np.concatenate([out.reshape(-1), extra]).view(np.int32).copy())
 
     def own_band(self):

@@ -283,3 +283,228 @@ def test_full_size_cfg4_world4_through_the_library():
     for rank, (bad, stats) in enumerate(res):
         assert not bad, f"rank {rank}: frames differ from the single-GPU frames: {bad}"
     print("cfg4 world 4:", res[0][1])
+
+
+# ---- layered models inside the library call: gsx_shard_render_frame_keys ---------------------------------
+
+LAYERS = {"a": (4000, 11, camera.ModelTransform(pos=np.array([0.0, 0.0, 1.5], np.float32))),
+          "b": (3000, 12, common.odd_transform()),
+          "c": (2500, 13, camera.ModelTransform(pos=np.array([-1.0, 0.3, -2.0], np.float32), rot=np.array([0, 40, 0], np.float32))),
+          "d": (2000, 14, camera.ModelTransform(pos=np.array([1.5, -0.2, 0.0], np.float32), scale=np.array([0.8, 0.8, 0.8], np.float32)))}
+LW, LH = 240, 160
+LTILES = ((LH + 15) // 16, (LW + 15) // 16)
+LPOSES = (30, 31, 32, 150, 151, 90)   # the far -> near order of the four models changes along the way
+
+
+def _layer_scenes():
+    return {k: common.small_scene(n, seed, scale_mul=8.0) for k, (n, seed, _) in LAYERS.items()}
+
+
+def _layer_keys(pose):
+    return parallel.model_render_keys(camera.orbit_pose(pose).pos, {k: mt for k, (_, _, mt) in LAYERS.items()})
+
+
+def _layer_viewer(scenes, rank, world, group=None, lanes=1):
+    v = MultiModelViewer()
+    v.set_render_options(frames_in_flight=lanes)
+    for k, g in scenes.items():
+        s0, c = parallel.shard_range(g.shape[0], rank, world)
+        v.add_model(k, c)
+        v.models[k].gaussian_buffers.gaussians_buffer.update_range(0, g[s0:s0 + c])
+        mt = LAYERS[k][2]
+        v.update_model_transform(k, mt.pos, mt.quat(), mt.scale)
+    if group is not None:
+        v.comm_init_group(group, rank)
+    return v
+
+
+def _layer_reference(scenes, poses=LPOSES):
+    out = []
+    v = _layer_viewer(scenes, 0, 1)
+    for pose in poses:
+        _uniforms(v, pose, (LW, LH))
+        v.render_frame(_layer_keys(pose))
+        out.append(v.download_framebuffer().copy())
+    v.close()
+    return out
+
+
+@pytest.mark.parametrize("world,mode,lanes", [(2, "natural", 1), (4, "natural", 1), (3, "all_refusing", 1), (4, "tiny_slots", 1),
+                                              (3, "off", 1), (2, "natural", 2), (4, "all_refusing", 2)])
+def test_layered_models_inside_the_library_call(world, mode, lanes):
+    """Four models with their own TRS, layered far -> near in an order that changes with the camera, every model
+    index-sharded over `world` ranks, ONE C-ABI call per frame and rank: equal to gsx_render_frame(keys) on one GPU."""
+    scenes = _layer_scenes()
+    ref = _layer_reference(scenes)
+    assert len({tuple(_layer_keys(p)) for p in LPOSES}) >= 2, "the layer order must change along the path"
+    assert not np.array_equal(ref[0], ref[3])
+
+    def body(rank, group):
+        v = _layer_viewer(scenes, rank, world, group, lanes)
+        shard_max = {k: (g.shape[0] + world - 1) // world for k, g in scenes.items()}
+        bad = []
+        for rep in range(2 if lanes > 1 else 1):
+            for k, pose in enumerate(LPOSES):
+                _uniforms(v, pose, (LW, LH))
+                keys = _layer_keys(pose)
+                for key in keys:
+                    if mode == "all_refusing":
+                        v.shard_set_limits(key, np.full(LTILES, 0x40400000, np.uint32))
+                    elif mode == "tiny_slots":
+                        v.shard_set_slot_records(key, 32)
+                v.shard_render_frame_keys(keys, [shard_max[x] for x in keys], speculate=mode != "off")
+                if rep == 0 or k == len(LPOSES) - 1:   # second pass (frames in flight): free-running, read the last frame only
+                    fb = v.download_framebuffer()
+                    if not np.array_equal(fb, ref[k]):
+                        bad.append((rep, k, float(np.abs(fb - ref[k]).max())))
+        stats = v.shard_stats()
+        v.close()
+        return bad, stats
+
+    res = run_group(world, body)
+    for rank, (bad, stats) in enumerate(res):
+        assert not bad, f"rank {rank} ({mode}, {lanes} lanes): {bad}"
+        if mode == "all_refusing":
+            assert stats["repair_frames"] == stats["frames"]
+        if mode == "tiny_slots":
+            assert stats["redo_frames"] == stats["frames"]
+        if mode == "off":
+            assert stats["exchange_rounds"] == 4 * stats["frames"] and stats["repair_frames"] == 0
+    print("layered", mode, world, lanes, res[0][1])
+
+
+def test_cfg5_shape_mask_selection_edit_inside_the_library_call():
+    """cfg5's shape at test size through gsx_shard_render_frame_keys: four models with TRS, a `0 - 1` mask on one, a rect
+    selection evaluated on the sharded frame (gsx_postprocess per shard) and an HSV edit + highlight of what it selected —
+    every rank's frame equals the single-viewer frame, the shards' selections partition the single viewer's."""
+    from wgpu_3dgs_viewer_app_amd import query
+    from wgpu_3dgs_viewer_app_amd.mask import MaskEvaluator, MaskOp, MaskShape, MaskShapeKind
+
+    world = 3
+    scenes = _layer_scenes()
+    shapes = [MaskShape(MaskShapeKind.Box, pos=np.array([0.0, 0.0, 0.5], np.float32), scale=np.array([3.0, 2.5, 3.0], np.float32)),
+              MaskShape(MaskShapeKind.Ellipsoid, pos=np.array([0.2, 0.1, 0.8], np.float32), scale=np.array([1.2, 1.0, 1.4], np.float32))]
+    rect = query.QueryPod.rect((60.0, 40.0), (180.0, 120.0), query.QuerySelectionOp.Set)
+    edit = query.GaussianEditPod(query.GaussianEditFlag.ENABLED, (0.45, 1.2, 0.9), 0.1, 0.3, 1.0, 0.8)
+    poses = (30, 31, 32)
+
+    def drive(v, render):
+        MaskEvaluator(v).evaluate(MaskOp.parse("0 - 1"), "b", shapes)
+        frames = []
+        for step, pose in enumerate(poses):
+            _uniforms(v, pose, (LW, LH))
+            v.update_query(rect if step == 0 else query.QueryPod.none())
+            if step == 1:
+                v.update_selection_edit_with_pod(edit)
+                v.update_selection_highlight((1.0, 0.0, 1.0, 0.3))
+            render(v, _layer_keys(pose))
+            for k in LAYERS:
+                v.postprocessor.postprocess(k)
+            frames.append(v.download_framebuffer().copy())
+        nsel = sum(int(np.unpackbits(v.models[k].gaussian_buffers.selection_buffer.download().view(np.uint8)).sum()) for k in LAYERS)
+        return frames, nsel
+
+    single = _layer_viewer(scenes, 0, 1)
+    ref, nsel_ref = drive(single, lambda v, keys: v.render_frame(keys))
+    single.close()
+    assert nsel_ref > 100 and not np.array_equal(ref[0], ref[1])
+
+    def body(rank, group):
+        v = _layer_viewer(scenes, rank, world, group)
+        shard_max = {k: (g.shape[0] + world - 1) // world for k, g in scenes.items()}
+        out = drive(v, lambda vv, keys: vv.shard_render_frame_keys(keys, [shard_max[x] for x in keys]))
+        v.close()
+        return out
+
+    res = run_group(world, body)
+    assert sum(r[1] for r in res) == nsel_ref, "the shards' selections partition the single-viewer selection"
+    for rank, (frames, _) in enumerate(res):
+        for i, fb in enumerate(frames):
+            assert np.array_equal(fb, ref[i]), f"rank {rank} frame {i}: L-inf {np.abs(fb - ref[i]).max()}"
+
+
+def _cfg5_setup(v, rank, world, scenes, tr):
+    from wgpu_3dgs_viewer_app_amd.mask import MaskEvaluator, MaskOp, MaskShape, MaskShapeKind
+
+    for k, g in scenes.items():
+        s0, c = parallel.shard_range(g.shape[0], rank, world)
+        v.add_model(k, c)
+        v.models[k].gaussian_buffers.gaussians_buffer.update_range(0, g[s0:s0 + c])
+        v.update_model_transform(k, tr[k].pos, tr[k].quat(), tr[k].scale)
+    shapes = [MaskShape(MaskShapeKind.Box, pos=np.array([0.0, 0.0, 2.5], np.float32), scale=np.array([3.0, 3.0, 3.0], np.float32)),
+              MaskShape(MaskShapeKind.Ellipsoid, pos=np.array([0.0, 0.0, 2.5], np.float32), scale=np.array([1.5, 1.5, 1.5], np.float32))]
+    MaskEvaluator(v).evaluate(MaskOp.parse("0 - 1"), "a", shapes)
+
+
+def test_full_size_cfg5_world4_and_rccl_world1_through_the_library():
+    """BASELINE.json configs[4]: 4 models x 6 M Gaussians (24 M, SH-3), TRS per model, `0 - 1` mask on one, a rect selection
+    with an HSV edit, 3840x2160 — ONE gsx_shard_render_frame_keys call per frame: 4 ranks as threads over the in-process
+    group, and one rank over real RCCL.  Equal to gsx_render_frame(keys) on one GPU, bit for bit."""
+    from wgpu_3dgs_viewer_app_amd import query, scene
+
+    n_total, sh, w, h, seed = scene.CONFIGS["cfg5"]
+    n = n_total // 4
+    tr = {"a": camera.ModelTransform(pos=np.array([0.0, 0.0, 2.5], np.float32)),
+          "b": camera.ModelTransform(pos=np.array([2.0, 0.2, -1.0], np.float32), rot=np.array([0, 35, 0], np.float32)),
+          "c": camera.ModelTransform(pos=np.array([-2.5, -0.1, -0.5], np.float32), scale=np.array([0.9, 0.9, 0.9], np.float32)),
+          "d": camera.ModelTransform(pos=np.array([0.3, -0.2, 0.5], np.float32), rot=np.array([20, -35, 50], np.float32),
+                                     scale=np.array([1.2, 0.9, 1.1], np.float32))}
+    scenes = {k: scene.synthetic_gaussians(n, seed + i, sh) for i, k in enumerate(tr)}
+    poses = (0, 1, 2, 100, 101)
+    rect = query.QueryPod.rect((1200.0, 600.0), (2600.0, 1500.0), query.QuerySelectionOp.Set)
+    edit = query.GaussianEditPod(query.GaussianEditFlag.ENABLED, (0.5, 1.0, 1.2), 0.1, 0.2, 1.0, 0.9)
+
+    def drive(v, render):
+        frames = []
+        for step, pose in enumerate(poses):
+            _uniforms(v, pose, (w, h))
+            keys = parallel.model_render_keys(camera.orbit_pose(pose).pos, tr)
+            v.update_query(rect if step == 1 else query.QueryPod.none())
+            if step == 2:
+                v.update_selection_edit_with_pod(edit)
+            render(v, keys)
+            if step == 1:
+                for k in keys:
+                    v.postprocessor.postprocess(k)
+            frames.append(v.download_framebuffer().copy())
+        return frames
+
+    single = MultiModelViewer()
+    _cfg5_setup(single, 0, 1, scenes, tr)
+    ref = drive(single, lambda v, keys: v.render_frame(keys))
+    single.close()
+    assert not np.array_equal(ref[1], ref[2]), "the edit must change the frame"
+
+    # one rank over real RCCL (send / recv to itself, like the world-1 tests of tests/test_gpu_sharded.py)
+    import os
+
+    os.environ["GSX_COMM_SELF_VIA_RCCL"] = "1"
+    try:
+        v = MultiModelViewer()
+        _cfg5_setup(v, 0, 1, scenes, tr)
+        uid = (C.c_uint8 * 128)()
+        _lib.check(v._L.gsx_comm_unique_id(uid))
+        v.comm_init_rccl(1, 0, bytes(uid))
+        got = drive(v, lambda vv, keys: vv.shard_render_frame_keys(keys, [n] * len(keys)))
+        v.close()
+    finally:
+        del os.environ["GSX_COMM_SELF_VIA_RCCL"]
+    for i, fb in enumerate(got):
+        assert np.array_equal(fb, ref[i]), f"RCCL world 1, frame {i}: L-inf {np.abs(fb - ref[i]).max()}"
+
+    world = 4
+
+    def body(rank, group):
+        v = MultiModelViewer()
+        _cfg5_setup(v, rank, world, scenes, tr)
+        v.comm_init_group(group, rank)
+        frames = drive(v, lambda vv, keys: vv.shard_render_frame_keys(keys, [(n + world - 1) // world] * len(keys)))
+        bad = [(i, float(np.abs(fb - ref[i]).max())) for i, fb in enumerate(frames) if not np.array_equal(fb, ref[i])]
+        stats = v.shard_stats()
+        v.close()
+        return bad, stats
+
+    res = run_group(world, body, timeout_ms=180000)
+    for rank, (bad, stats) in enumerate(res):
+        assert not bad, f"cfg5 rank {rank}: frames differ from the single-GPU frames: {bad}"
+    print("cfg5 world 4:", res[0][1])

@@ -130,8 +130,10 @@ LAYERS = {"a": (1500, 5, camera.ModelTransform(pos=np.array([0.0, 0.0, 1.5], np.
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_layered_models_equal_single_process(world, tmp_path):
-    """Several models, each with its own TRS, layered far -> near (scene.rs:533-558): the sharded frame equals the
-    single-process oracle frame bit for bit."""
+    """Several models, each with its own TRS, layered far -> near (scene.rs:533-558), through the slot / verdict protocol
+    model by model (nearest first, each behind the ones before it): the sharded frame equals the single-process oracle frame
+    up to the one extra float32 multiply-add of this adapter's (front) over (back) merge — the HIP path composites behind in
+    place and is held to bit-identity on the GPU (tests/test_gpu_shard_lib.py)."""
     cam = camera.orbit_pose(21)
     tr = {k: mt for k, (_, _, mt) in LAYERS.items()}
     keys = parallel.model_render_keys(cam.pos, tr)
@@ -146,7 +148,9 @@ def test_sharded_layered_models_equal_single_process(world, tmp_path):
     out = str(tmp_path / "fb.npy")
     mp.spawn(_layers_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     fb = np.load(out)
-    assert np.array_equal(fb, ref), f"layered sharded frame differs: L-inf {np.abs(fb - ref).max()}"
+    err = np.abs(fb - ref).max(axis=-1)
+    open_px = ref[..., 3] >= 1e-4
+    assert err[open_px].max() <= 2e-6 and err.max() <= 1e-4 * max(1.0, float(ref[..., :3].max())), f"layered sharded frame differs: L-inf {err.max()}"
     # the layering matters: another order gives another image
     single.render_frame(cam, (W, H), keys=keys[::-1], transforms=tr)
     assert not np.array_equal(single.framebuffer(), ref)

@@ -31,7 +31,7 @@ EXPORTS = (
     "gsx_shard_frame_begin", "gsx_shard_slot_records", "gsx_shard_pack_slots", "gsx_shard_import_slots", "gsx_shard_verify",
     "gsx_shard_wait_verdict", "gsx_shard_repair_count", "gsx_shard_post_counts", "gsx_shard_frame_end",
     "gsx_shard_next_windows", "gsx_shard_download_limits", "gsx_comm_unique_id", "gsx_viewer_comm_init", "gsx_viewer_comm_destroy",
-    "gsx_comm_all_to_all", "gsx_comm_all_gather", "gsx_shard_render_frame",
+    "gsx_comm_all_to_all", "gsx_comm_all_gather", "gsx_shard_render_frame", "gsx_shard_render_frame_keys",
     "gsx_comm_group_create", "gsx_comm_group_destroy", "gsx_viewer_comm_init_group", "gsx_viewer_comm_init_custom",
     "gsx_shard_set_limits", "gsx_shard_set_slot_records", "gsx_shard_get_stats",
     "gsx_gaussian_edit_default", "gsx_update_query", "gsx_update_query_texture", "gsx_update_selection_highlight",
@@ -200,6 +200,7 @@ def load() -> C.CDLL:
         "gsx_comm_all_to_all": ([vp, vp, vp, u64], C.c_int32),
         "gsx_comm_all_gather": ([vp, vp, vp, u64], C.c_int32),
         "gsx_shard_render_frame": ([vp, cp, u32, u32, C.c_float, u32], C.c_int32),
+        "gsx_shard_render_frame_keys": ([vp, C.POINTER(cp), u32, u32p, u32, C.c_float, u32], C.c_int32),
         "gsx_comm_group_create": ([u32, u32, C.POINTER(vp)], C.c_int32),
         "gsx_comm_group_destroy": ([vp], None),
         "gsx_viewer_comm_init_group": ([vp, vp, u32], C.c_int32),

@@ -121,6 +121,7 @@ gsx_status lane_acquire(gsx_viewer* v, uint32_t index, const char* const* keys, 
         gsx_viewer* l = nullptr;
         if ((st = lane_create(v, &l))) return st;
         v->lanes.push_back(l);
+        l->lane_index = (uint32_t)v->lanes.size();
     }
     *out = v->lanes[index - 1];
     return lane_sync(v, *out, keys, n_keys);
@@ -183,19 +184,11 @@ gsx_status gsx_viewer_create(const gsx_viewer_desc* desc, gsx_viewer** out) {
 void gsx_viewer_destroy(gsx_viewer* v) {
     if (!v) return;
     (void)hipSetDevice(v->device);
+    (void)gsx_viewer_comm_destroy(v);  // first: it drains the lanes' streams, then destroys the communicators (a lane has none of its own)
     for (gsx_viewer* l : v->lanes) gsx_viewer_destroy(l);  // (synchronises the lane's stream first)
     v->lanes.clear();
     (void)hipStreamSynchronize(v->stream);
-    (void)gsx_viewer_comm_destroy(v);  // first: it drains the lanes' streams and the comm stream, then destroys the communicator
     if (v->lane_event) (void)hipEventDestroy(v->lane_event);
-    if (v->comm_ev_in) (void)hipEventDestroy(v->comm_ev_in);
-    if (v->comm_ev_out) (void)hipEventDestroy(v->comm_ev_out);
-    v->comm_ev_in = v->comm_ev_out = nullptr;
-    if (v->comm_stream) {
-        (void)hipStreamSynchronize(v->comm_stream);
-        (void)hipStreamDestroy(v->comm_stream);
-        v->comm_stream = nullptr;
-    }
     if (v->h_shard_verdict) (void)hipHostFree(v->h_shard_verdict);
     for (auto& t : v->timers) {
         (void)hipEventDestroy(t.start);

@@ -176,16 +176,22 @@ gsx_status gsx_shard_import(gsx_viewer* v, const char* key, const void* d_recv, 
 // this rank's band of the per-tile saturation keys; rows below the frame read 0 (= open)
 // ... followed by kShardExtraWords statistics words (the all-gather that verifies the frame also tells every rank how large
 // the slots have to be and whether one was too small)
+// done_before (nullable; layered models): the tiles nearer models had saturated before this model was composited.  They say
+// nothing about THIS model's depths: reported as saturated at the smallest depth key, so that the model's next limit there
+// is whatever its neighbourhood needs and nothing more (the single-GPU rule, k_spec_next).
 __global__ void k_shard_feedback(const uint32_t* __restrict__ tile_sat, uint32_t tiles_x, uint32_t tiles_y, uint32_t row_lo,
-                                 uint32_t n_words, uint32_t* __restrict__ out, const SlabStats* __restrict__ stats) {
+                                 uint32_t n_words, uint32_t* __restrict__ out, const SlabStats* __restrict__ stats,
+                                 const uint32_t* __restrict__ done_before, uint32_t row_words) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_words + kShardExtraWords) return;
     if (i >= n_words) {  // round 0's figures: what this rank wanted to send to its busiest destination, and whether the slot held it
         out[i] = i - n_words == 0u ? stats->slot_max[0] : (i - n_words == 1u ? stats->slot_over[0] : 0u);
         return;
     }
-    const uint32_t ty = row_lo + i / tiles_x;
-    out[i] = ty < tiles_y ? tile_sat[ty * tiles_x + i % tiles_x] : 0u;
+    const uint32_t ty = row_lo + i / tiles_x, tx = i % tiles_x;
+    uint32_t s = ty < tiles_y ? tile_sat[ty * tiles_x + tx] : 0u;
+    if (done_before && ty < tiles_y && ((done_before[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)) s = 1u;
+    out[i] = s;
 }
 
 gsx_status gsx_shard_feedback_words(gsx_viewer* v, uint32_t world, uint32_t* out_words) {
@@ -206,7 +212,8 @@ gsx_status gsx_shard_feedback(gsx_viewer* v, const char* key, uint32_t world, ui
     const uint32_t row_words = (tiles_x + 31) / 32, rpr = rows_per_rank(v, world), n_words = rpr * tiles_x;
     const uint32_t* tile_sat = v->done_bits.as<uint32_t>() + 1 + (size_t)row_words * tiles_y;
     hipLaunchKernelGGL(k_shard_feedback, dim3((n_words + kShardExtraWords + 255) / 256), dim3(256), 0, v->stream, tile_sat, tiles_x, tiles_y,
-                       rank * rpr, n_words, static_cast<uint32_t*>(d_out_u32), m->counters.as<Counters>());
+                       rank * rpr, n_words, static_cast<uint32_t*>(d_out_u32), m->counters.as<Counters>(),
+                       m->shard_behind ? m->spec_done_before.as<uint32_t>() : nullptr, row_words);
     HIPCHK(hipGetLastError());
     return GSX_OK;
 }
@@ -435,14 +442,16 @@ gsx_status gsx_shard_post_counts(gsx_viewer* v, uint32_t world, const void* d_co
     return GSX_OK;
 }
 
-gsx_status gsx_shard_import_slots(gsx_viewer* v, const char* key, const void* d_recv, uint32_t world, uint32_t rank, uint32_t round,
+gsx_status gsx_shard_import_slots(gsx_viewer* v, const char* key, const void* d_recv, uint32_t world, uint32_t rank, uint32_t round_flags,
                                   uint32_t slot_records) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
     Model* m = find_model(v, key);
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_import_slots: no model '%s'", key ? key : "(null)");
     if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import_slots: model '%s' has no frame constants (gsx_shard_frame_begin first)", key);
-    if (world == 0 || world > 64 || rank >= world || round > 1 || !d_recv || slot_records == 0)
+    const uint32_t round = round_flags & 1u;
+    const bool behind = (round_flags & GSX_SHARD_BEHIND) != 0;  // a layered frame: nearer models are in the framebuffer already
+    if (world == 0 || world > 64 || rank >= world || round_flags > 3u || !d_recv || slot_records == 0)
         return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import_slots: bad argument");
     const uint64_t cap = (uint64_t)world * slot_records;
     if (cap >= 0xFFFFFFF0ull) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import_slots: too many records");
@@ -464,8 +473,18 @@ gsx_status gsx_shard_import_slots(gsx_viewer* v, const char* key, const void* d_
     }
     m->sorted = m->counters_valid = m->binned = false;
     if ((st = do_sort(v, m))) return st;
+    if (round == 0) {
+        m->shard_behind = behind;
+        if (behind) {  // which tiles the nearer models had saturated: this model's feedback must not take their depths for its own
+            const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
+            const size_t bm = 4 * (size_t)((tiles_x + 31) / 32) * tiles_y;
+            if (v->done_bits.bytes < 4 + bm) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import_slots: GSX_SHARD_BEHIND without a nearer model in this frame");
+            HIPCHK(m->spec_done_before.ensure(bm));
+            HIPCHK(hipMemcpyAsync(m->spec_done_before.p, v->done_bits.as<uint32_t>() + 1, bm, hipMemcpyDeviceToDevice, v->stream));
+        }
+    }
     const char* keys[1] = {m->key.c_str()};
-    return do_render(v, keys, 1, round == 1);
+    return do_render(v, keys, 1, round == 1 || behind);
 }
 
 gsx_status gsx_shard_verify(gsx_viewer* v, const char* key, uint32_t world, const void* d_sat_all, uint32_t* out_seq) {
@@ -551,37 +570,25 @@ gsx_status gsx_shard_frame_end(gsx_viewer* v, const char* key) {
     return GSX_OK;
 }
 
-gsx_status gsx_shard_set_limits(gsx_viewer* v, const char* key, const uint32_t* d_limits) {
+gsx_status gsx_shard_set_limits(gsx_viewer* v, const char* key, const uint32_t* limits) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
     Model* m = find_model(v, key);
-    if (!m || !d_limits) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_set_limits: no model '%s' / null limits", key ? key : "(null)");
+    if (!m || !limits) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_set_limits: no model '%s' / null limits", key ? key : "(null)");
     const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
-    HIPCHK(m->shard_limit.ensure(4 * (size_t)tiles_x * tiles_y));
-    // host or device memory: a host array is staged through the viewer's scratch so that every copy below is device to device
+    const size_t bytes = 4 * (size_t)tiles_x * tiles_y;
+    // kept with the model until its next sharded frame picks it up — on whichever lane that frame runs (gsx_shard_frame.cpp)
+    HIPCHK(m->shard_limit_override.ensure(bytes));
     hipPointerAttribute_t attr{};
-    const bool on_device = hipPointerGetAttributes(&attr, d_limits) == hipSuccess && attr.type == hipMemoryTypeDevice;
-    if (!on_device) {
+    const bool on_device = hipPointerGetAttributes(&attr, limits) == hipSuccess && attr.type == hipMemoryTypeDevice;
+    if (on_device) {
+        HIPCHK(hipMemcpyAsync(m->shard_limit_override.p, limits, bytes, hipMemcpyDeviceToDevice, v->stream));
+    } else {
         (void)hipGetLastError();
-        HIPCHK(v->scratch.ensure(4 * (size_t)tiles_x * tiles_y));
         HIPCHK(hipStreamSynchronize(v->stream));
-        HIPCHK(hipMemcpy(v->scratch.p, d_limits, 4 * (size_t)tiles_x * tiles_y, hipMemcpyHostToDevice));
-        d_limits = v->scratch.as<uint32_t>();
+        HIPCHK(hipMemcpy(m->shard_limit_override.p, limits, bytes, hipMemcpyHostToDevice));
     }
-    HIPCHK(hipMemcpyAsync(m->shard_limit.p, d_limits, 4 * (size_t)tiles_x * tiles_y, hipMemcpyDeviceToDevice, v->stream));
-    m->shard_limit_valid = true;
-    m->shard_limit_tx = tiles_x;
-    m->shard_limit_ty = tiles_y;
-    m->slot_hint = 0;  // nothing is known about what THESE limits let through: the safe slot size
-    for (gsx_viewer* l : v->lanes)  // (frames in flight: every lane's next frame of this model starts from these limits)
-        if (Model* sm = find_model(l, key)) {
-            HIPCHK(sm->shard_limit.ensure(4 * (size_t)tiles_x * tiles_y));
-            HIPCHK(hipMemcpyAsync(sm->shard_limit.p, d_limits, 4 * (size_t)tiles_x * tiles_y, hipMemcpyDeviceToDevice, v->stream));
-            sm->shard_limit_valid = true;
-            sm->shard_limit_tx = tiles_x;
-            sm->shard_limit_ty = tiles_y;
-            sm->slot_hint = 0;
-        }
+    m->shard_override_tiles = tiles_x * tiles_y;
     return GSX_OK;
 }
 

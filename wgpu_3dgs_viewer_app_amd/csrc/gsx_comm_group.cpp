@@ -5,6 +5,9 @@
 // with 2 ... 8 ranks on a one-GPU box.  Implemented on the custom-transport interface of include/gsx.h (two functions that
 // enqueue on a stream), like any transport a caller could bring.
 //
+// Frames in flight: a viewer and its lanes share one seat; the host issues their collectives one after the other (one thread),
+// each on the stream of the lane whose frame it serves, so frames on different lanes overlap on the device.
+//
 // A collective, seen from rank r (every rank runs the same sequence, gsx_comm.cpp guarantees one order of collectives):
 //   record `ready` on r's stream, publish {send, recv, bytes}          -- what r contributes exists once `ready` fires
 //   host rendezvous A                                                  -- everybody has published; sizes are compared
@@ -16,6 +19,7 @@
 // GSX_ERR_RCCL with the reason.  Nothing hangs.
 #include <chrono>
 #include <condition_variable>
+#include <map>
 #include <mutex>
 
 #include "gsx_state.h"
@@ -29,8 +33,10 @@ struct Seat {
     uint32_t rank = 0;
     bool taken = false;
     int device = 0;
-    hipEvent_t ready = nullptr, done = nullptr;
+    // one event pair per stream this seat has issued collectives on (a viewer and its lanes: frames in flight)
+    std::map<hipStream_t, std::pair<hipEvent_t, hipEvent_t>> events;
     // published for the collective in flight
+    hipEvent_t ready = nullptr, done = nullptr;
     const char* send = nullptr;
     char* recv = nullptr;
     uint64_t bytes = 0;
@@ -88,6 +94,15 @@ gsx_status rendezvous(gsx_comm_group* g, uint32_t rank, const char* what) {
 gsx_status collective(Seat* me, int op, const void* d_send, void* d_recv, uint64_t bytes, hipStream_t stream) {
     gsx_comm_group* g = me->group;
     const char* what = op == OP_ALL_TO_ALL ? "an all-to-all" : "an all-gather";
+    auto ev = me->events.find(stream);
+    if (ev == me->events.end()) {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        ev = me->events.emplace(stream, std::make_pair(a, b)).first;
+    }
+    me->ready = ev->second.first;
+    me->done = ev->second.second;
     HIPCHK(hipEventRecord(me->ready, stream));
     me->send = static_cast<const char*>(d_send);
     me->recv = static_cast<char*>(d_recv);
@@ -134,8 +149,11 @@ void gsx::group_leave(gsx_viewer* v) {
     Seat* me = static_cast<Seat*>(v->comm_ctx);
     if (!g || !me) return;
     std::unique_lock<std::mutex> lk(g->mu);
-    if (me->ready) (void)hipEventDestroy(me->ready);
-    if (me->done) (void)hipEventDestroy(me->done);
+    for (auto& kv : me->events) {
+        (void)hipEventDestroy(kv.second.first);
+        (void)hipEventDestroy(kv.second.second);
+    }
+    me->events.clear();
     me->ready = me->done = nullptr;
     me->taken = false;
     // a rank that leaves while the others still render: they find out at their next rendezvous, at once
@@ -177,8 +195,6 @@ gsx_status gsx_viewer_comm_init_group(gsx_viewer* v, gsx_comm_group* g, uint32_t
         me->taken = true;
     }
     me->device = v->device;
-    HIPCHK(hipEventCreateWithFlags(&me->ready, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&me->done, hipEventDisableTiming));
     // several devices in one process: direct peer copies over xGMI where the platform allows (otherwise the runtime stages them)
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) == hipSuccess)

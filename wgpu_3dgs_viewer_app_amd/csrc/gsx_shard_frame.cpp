@@ -1,0 +1,276 @@
+// gsx_shard_frame.cpp — gsx_shard_render_frame / gsx_shard_render_frame_keys: one index-sharded frame of this rank as ONE call
+// of the C ABI, strung together from the stage calls of gsx_api_shard.cpp and the collectives of gsx_comm.cpp.  No reference
+// counterpart (src/main.rs:85-98: one wgpu device); what it must reproduce is the single-GPU frame — for several models the
+// reference's layering: painted far -> near, never merged (src/tab/scene.rs:533-558, 2302-2314).
+//
+// The frame, per model in COMPOSITING order (nearest first; the far -> near key list walked backwards, as gsx_render does):
+//   front   gsx_shard_frame_begin of every model (projection; windows from the model's own limits of its last frame), then
+//           for each model: round 0 = pack -> all-to-all of fixed slots -> import + depth sort + composite into this rank's
+//           band (behind the nearer models) -> feedback -> all-gather of the saturation map -> verify (posts the model's
+//           verdict) -> next limits.  Between two models the host looks at the verdict: the repair round of a model has to be
+//           composited before the next model's records are (order matters per pixel), so for layered frames that one wait per
+//           model boundary is on the critical path; the LAST model's verdict is not looked at here.
+//   back    the last model's verdict: a slot overflowed -> the whole frame again with whole-shard slots (cannot overflow);
+//           tiles need a repair -> count, size exactly, exchange, composite behind.  Then the in-place band all-gather and
+//           gsx_shard_frame_end of every model.
+// With one frame in flight front and back run in the same call (the band gather is enqueued before the wait: that is what
+// follows in the usual frame).  With gsx_render_options.frames_in_flight = L > 1 a call enqueues the front of frame k on lane
+// k mod L and then runs the back of frame k - L + 1: its verdict arrived while the host was enqueueing, so nothing waits,
+// and the device always has L - 1 other frames queued.  Every lane has its own communicator and stream (gsx_comm.cpp), so
+// one frame's exchange never queues behind another frame's gather.
+//
+// Every branch below is taken on data that was gathered from all ranks (the verdict words), so every rank takes the same
+// branches and issues the same collectives in the same order: nothing can cross.
+#include <chrono>
+
+#include "gsx_state.h"
+
+namespace {
+
+struct Ctx {
+    gsx_viewer* owner;   // holds the communicator(s) and the statistics
+    gsx_viewer* l;       // the lane this frame runs on (the owner itself with one frame in flight)
+    ShardPending* p;
+    uint32_t world, rank;
+    gsx_shard_layout_t lay;
+    uint32_t sat_words;
+};
+
+// the padded framebuffer the bands are gathered into (owned by the library, per lane) and the saturation-map buffers
+gsx_status frame_buffers(Ctx& c) {
+    gsx_viewer* v = c.l;
+    gsx_status st = gsx_shard_layout(v, c.world, c.rank, &c.lay);
+    if (st) return st;
+    if (v->ext_fb != v->shard_fb.p || v->shard_fb.bytes < c.lay.padded_framebuffer_bytes) {
+        HIPCHK(hipStreamSynchronize(v->stream));
+        if (v->shard_fb.bytes < c.lay.padded_framebuffer_bytes) {
+            HIPCHK(v->shard_fb.ensure(c.lay.padded_framebuffer_bytes));
+            HIPCHK(hipMemsetAsync(v->shard_fb.p, 0, v->shard_fb.bytes, v->stream));
+        }
+        v->ext_fb = v->shard_fb.p;
+        v->ext_fb_bytes = v->shard_fb.bytes;
+    }
+    if ((st = gsx_shard_feedback_words(v, c.world, &c.sat_words))) return st;
+    HIPCHK(v->shard_sat_band.ensure(4 * (size_t)c.sat_words + 16));
+    HIPCHK(v->shard_sat_all.ensure((4 * (size_t)c.sat_words + 16) * c.world));
+    return GSX_OK;
+}
+
+// one exchange round of model i: pack -> all-to-all -> import + sort + composite -> feedback -> all-gather
+gsx_status exchange_round(Ctx& c, size_t i, uint32_t round, uint32_t T) {
+    gsx_viewer* v = c.l;
+    const char* key = c.p->order[i].c_str();
+    const uint64_t per_peer = (uint64_t)(T + 1u) * GSX_RECORD_BYTES;
+    gsx_shard_stats& ss = c.owner->shard_stats;
+    ss.exchange_rounds += 1;
+    (round == 0 ? ss.last_slot_records : ss.last_repair_slot_records) = T;
+    HIPCHK(v->shard_send.ensure(per_peer * c.world));
+    HIPCHK(v->shard_recv.ensure(per_peer * c.world));
+    gsx_status st;
+    if ((st = gsx_shard_pack_slots(v, key, c.world, round, v->shard_send.p, T))) return st;
+    if ((st = gsx_comm_all_to_all(v, v->shard_send.p, v->shard_recv.p, per_peer))) return st;
+    if ((st = gsx_shard_import_slots(v, key, v->shard_recv.p, c.world, c.rank, round | (i > 0 ? GSX_SHARD_BEHIND : 0u), T))) return st;
+    if ((st = gsx_shard_feedback(v, key, c.world, c.rank, v->shard_sat_band.p))) return st;
+    return gsx_comm_all_gather(v, v->shard_sat_band.p, v->shard_sat_all.p, 4 * (uint64_t)c.sat_words);
+}
+
+gsx_status next_limits(Ctx& c, size_t i) {
+    return gsx_shard_next_windows(c.l, c.p->order[i].c_str(), c.world, c.l->shard_sat_all.p, c.p->margin, c.p->radius);
+}
+
+// the bands, in place: every rank's band lands where it belongs in every rank's framebuffer
+gsx_status band_gather(Ctx& c) {
+    char* fb = static_cast<char*>(c.l->ext_fb);
+    gsx_status st = gsx_comm_all_gather(c.l, fb + c.lay.band_offset_bytes, fb, c.lay.band_bytes);
+    c.p->gathered = st == GSX_OK;
+    return st;
+}
+
+gsx_status round0(Ctx& c, size_t i) {
+    gsx_status st = exchange_round(c, i, 0, c.p->slot[i]);
+    if (st) return st;
+    if ((st = gsx_shard_verify(c.l, c.p->order[i].c_str(), c.world, c.l->shard_sat_all.p, &c.p->seq))) return st;
+    return next_limits(c, i);  // what follows when nothing needs a repair (redone after one)
+}
+
+gsx_status timed_wait(Ctx& c, const char* key, uint32_t seq, gsx_shard_verdict* out) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const gsx_status st = gsx_shard_wait_verdict(c.l, key, seq, out);
+    c.owner->shard_stats.verdict_wait_ns +=
+        (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    return st;
+}
+
+// the verdict of model i's round 0 and what it asks for; *overflow: a slot was too small, the frame has to be redone
+gsx_status settle(Ctx& c, size_t i, bool* overflow) {
+    gsx_viewer* v = c.l;
+    const char* key = c.p->order[i].c_str();
+    gsx_shard_verdict verdict{};
+    gsx_status st = timed_wait(c, key, c.p->seq, &verdict);
+    if (st) return st;
+    *overflow = verdict.overflow != 0;
+    if (*overflow || !verdict.need_tiles) return GSX_OK;
+    // the repair round, sized exactly: what each destination is owed is counted, the maximum gathered and posted
+    c.p->repaired = true;
+    HIPCHK(v->shard_counts.ensure(16 * (size_t)(c.world + 1)));
+    char* cnt = static_cast<char*>(v->shard_counts.p);
+    if ((st = gsx_shard_repair_count(v, key, c.world, cnt + 16 * (size_t)c.world))) return st;
+    if ((st = gsx_comm_all_gather(v, cnt + 16 * (size_t)c.world, cnt, 16))) return st;
+    uint32_t seq = 0;
+    if ((st = gsx_shard_post_counts(v, c.world, cnt, &seq))) return st;
+    gsx_shard_verdict sized{};
+    if ((st = timed_wait(c, nullptr, seq, &sized))) return st;
+    if ((st = exchange_round(c, i, 1, std::max<uint32_t>(sized.max_records, 1u)))) return st;
+    c.p->gathered = false;
+    return next_limits(c, i);
+}
+
+// the whole frame once more with slots of a whole shard each: nothing can overflow, every verdict is dealt with at once
+gsx_status redo_safe(Ctx& c) {
+    c.owner->shard_stats.redo_frames += 1;
+    c.p->gathered = false;
+    for (size_t i = 0; i < c.p->order.size(); ++i) c.p->slot[i] = std::max<uint32_t>(c.p->shard_max[i], 1u);
+    for (size_t i = 0; i < c.p->order.size(); ++i) {
+        gsx_status st = round0(c, i);  // (model 0 is not "behind": it starts from a cleared band)
+        if (st) return st;
+        bool overflow = false;
+        if ((st = settle(c, i, &overflow))) return st;
+        if (overflow)
+            return fail(GSX_ERR_OOM, "gsx_shard_render_frame: an exchange slot of %u records (a whole shard of '%s') overflowed: shard_records_max is wrong",
+                        c.p->slot[i], c.p->order[i].c_str());
+    }
+    c.p->settled = true;
+    return GSX_OK;
+}
+
+// everything of a frame up to (not including) the look at its LAST verdict
+gsx_status frame_front(Ctx& c, bool eager_gather) {
+    gsx_status st = frame_buffers(c);
+    if (st) return st;
+    ShardPending& p = *c.p;
+    const size_t n = p.order.size();
+    const uint32_t n_tiles = ((c.l->width + GSX_TILE - 1) / GSX_TILE) * ((c.l->height + GSX_TILE - 1) / GSX_TILE);
+    for (size_t i = 0; i < n; ++i) {  // every model's projection first: independent of everything that follows
+        // limits the caller set for this frame (gsx_shard_set_limits) live with the owner's model, whichever lane renders
+        Model* om = find_model(c.owner, p.order[i].c_str());
+        const uint32_t* override_limits = om && om->shard_override_tiles == n_tiles ? om->shard_limit_override.as<uint32_t>() : nullptr;
+        if (om) om->shard_override_tiles = 0;
+        if ((st = gsx_shard_frame_begin(c.l, p.order[i].c_str(), c.world, c.rank, p.speculate, override_limits))) return st;
+    }
+    p.slot.resize(n);
+    for (size_t i = 0; i < n; ++i)
+        if ((st = gsx_shard_slot_records(c.l, p.order[i].c_str(), c.world, p.shard_max[i], &p.slot[i]))) return st;
+    for (size_t i = 0; i < n; ++i) {
+        if ((st = round0(c, i))) return st;
+        if (i + 1 == n) break;  // the last model's verdict belongs to frame_back
+        bool overflow = false;  // a layered frame: model i's repair has to be in the framebuffer before model i + 1 is composited
+        if ((st = settle(c, i, &overflow))) return st;
+        if (overflow) {
+            if ((st = redo_safe(c))) return st;
+            break;
+        }
+    }
+    return eager_gather ? band_gather(c) : GSX_OK;
+}
+
+gsx_status frame_back(gsx_viewer* owner, ShardPending& p) {
+    Ctx c{owner, p.lane, &p, owner->comm_world, owner->comm_rank, {}, 0};
+    gsx_status st = frame_buffers(c);
+    if (st) return st;
+    if (!p.settled) {
+        bool overflow = false;
+        if ((st = settle(c, p.order.size() - 1, &overflow))) return st;
+        if (overflow && (st = redo_safe(c))) return st;
+    }
+    if (!p.gathered && (st = band_gather(c))) return st;
+    gsx_shard_stats& ss = owner->shard_stats;
+    ss.frames += 1;
+    if (p.repaired) ss.repair_frames += 1;
+    for (const std::string& k : p.order)
+        if ((st = gsx_shard_frame_end(p.lane, k.c_str()))) return st;
+    if (p.lane != owner) {  // model-changing calls on the owner's stream come after this lane's frame (viewer_bind)
+        HIPCHK(hipEventRecord(p.lane->lane_event, p.lane->stream));
+        p.lane->lane_busy = true;
+    }
+    owner->latest = p.lane == owner ? nullptr : p.lane;
+    return GSX_OK;
+}
+
+struct BusyGuard {
+    gsx_viewer* v;
+    explicit BusyGuard(gsx_viewer* v_) : v(v_) { v->shard_busy = true; }
+    ~BusyGuard() { v->shard_busy = false; }
+};
+
+}  // namespace
+
+// viewer_bind (gsx_state.h): any other entry point first finishes the sharded frames in flight (on every rank alike: an
+// SPMD host makes the same calls in the same order)
+gsx_status gsx::shard_complete_pending(gsx_viewer* v) {
+    BusyGuard guard(v);
+    while (!v->shard_pending.empty()) {
+        gsx_status st = frame_back(v, v->shard_pending.front());
+        v->shard_pending.pop_front();
+        if (st) {
+            v->shard_pending.clear();
+            return st;
+        }
+    }
+    return GSX_OK;
+}
+
+extern "C" {
+
+gsx_status gsx_shard_render_frame_keys(gsx_viewer* v, const char* const* keys_far_to_near, uint32_t n_keys, const uint32_t* shard_records_max,
+                                       uint32_t speculate, float margin, uint32_t radius) {
+    if (!v || !keys_far_to_near || !shard_records_max || n_keys == 0 || n_keys > 1024)
+        return fail(GSX_ERR_INVALID_ARG, "gsx_shard_render_frame_keys: null argument or no keys");
+    if (v->parent) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_render_frame_keys: called on a lane");
+    HIPCHK(hipSetDevice(v->device));
+    if (!has_comm(v)) return fail(GSX_ERR_RCCL, "gsx_shard_render_frame: no communicator (gsx_viewer_comm_init / _init_group / _init_custom)");
+    for (uint32_t i = 0; i < n_keys; ++i) {
+        if (!find_model(v, keys_far_to_near[i])) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_render_frame: no model '%s'", keys_far_to_near[i] ? keys_far_to_near[i] : "(null)");
+        for (uint32_t j = 0; j < i; ++j)
+            if (!strcmp(keys_far_to_near[i], keys_far_to_near[j])) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_render_frame_keys: model '%s' listed twice", keys_far_to_near[i]);
+    }
+    BusyGuard guard(v);
+    gsx_status st = GSX_OK;
+    const uint32_t lanes = std::max(1u, std::min(v->options.frames_in_flight, 4u));
+    if ((st = comm_ensure_lanes(v, lanes))) return st;
+    gsx_viewer* lane = v;
+    if (lanes > 1 && (st = lane_acquire(v, v->shard_turn++ % lanes, keys_far_to_near, n_keys, &lane))) return st;
+    v->shard_pending.emplace_back();
+    ShardPending& p = v->shard_pending.back();
+    p.lane = lane;
+    for (uint32_t i = n_keys; i-- > 0;) {  // compositing order: nearest model first
+        p.order.emplace_back(keys_far_to_near[i]);
+        p.shard_max.push_back(shard_records_max[i]);
+    }
+    p.speculate = speculate;
+    p.margin = margin;
+    p.radius = radius;
+    Ctx c{v, lane, &p, v->comm_world, v->comm_rank, {}, 0};
+    if ((st = frame_front(c, lanes == 1))) {
+        v->shard_pending.clear();
+        return st;
+    }
+    while (v->shard_pending.size() > lanes - 1u) {
+        st = frame_back(v, v->shard_pending.front());
+        v->shard_pending.pop_front();
+        if (st) {
+            v->shard_pending.clear();
+            return st;
+        }
+    }
+    return GSX_OK;
+}
+
+// One model: what a host without Python calls once per frame after gsx_update_camera / gsx_update_model_transform.  Afterwards
+// (gsx_sync) gsx_download_framebuffer returns the whole frame on every rank.
+gsx_status gsx_shard_render_frame(gsx_viewer* v, const char* key, uint32_t shard_records_max, uint32_t speculate, float margin, uint32_t radius) {
+    if (!key) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_render_frame: null argument");
+    const char* keys[1] = {key};
+    return gsx_shard_render_frame_keys(v, keys, 1, &shard_records_max, speculate, margin, radius);
+}
+
+}  // extern "C"

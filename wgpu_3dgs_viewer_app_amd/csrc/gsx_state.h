@@ -173,7 +173,10 @@ struct Model {
     // device-resident exchange (gsx_shard_frame_begin ... gsx_shard_next_windows): next frame's per-tile limits, the
     // repair round's windows, and what the host knows (late, never waited for) about how full the exchange slots get
     DevBuf shard_limit, shard_limit_next, shard_win2;
+    DevBuf shard_limit_override;               // gsx_shard_set_limits: limits for the model's NEXT sharded frame (whichever lane renders it)
+    uint32_t shard_override_tiles = 0;         // != 0: an override is waiting, made for a grid of that many tiles
     bool shard_limit_valid = false, shard_next_valid = false, shard_frame_limited = false;
+    bool shard_behind = false;                 // this frame's imported records were composited behind nearer models (spec_done_before holds their tiles)
     uint32_t shard_limit_tx = 0, shard_limit_ty = 0;
     uint32_t slot_force = 0;                   // gsx_shard_set_slot_records: round-0 slot size instead of the policy's (0 = policy)
     uint32_t slot_hint = 0;                    // records the busiest (rank, destination) pair wanted in round 0 of the last frame: a GLOBAL
@@ -247,12 +250,17 @@ struct PassTimer {
 
 using namespace gsx;
 
-// an index-sharded frame whose round 0 is enqueued and whose verdict has not been looked at yet (gsx_comm.cpp)
+// an index-sharded frame whose rounds 0 are enqueued and whose last verdict has not been looked at yet (gsx_shard_frame.cpp)
 struct ShardPending {
     gsx_viewer* lane = nullptr;
-    std::string key;
-    uint32_t seq = 0, slot_records = 0, shard_records_max = 0, speculate = 0, radius = 0;
+    std::vector<std::string> order;           // the frame's models in COMPOSITING order: nearest first (keys_far_to_near reversed)
+    std::vector<uint32_t> shard_max, slot;    // per model: largest shard over the ranks, round-0 slot size in use
+    uint32_t seq = 0;                         // verdict of the last model's round 0
+    uint32_t speculate = 0, radius = 0;
     float margin = 0.0f;
+    bool gathered = false;                    // the band gather that is enqueued shows the final frame
+    bool settled = false;                     // every model's verdict has been dealt with already (a frame redone with safe slots)
+    bool repaired = false;                    // some model needed its repair exchange
 };
 
 struct gsx_viewer {
@@ -269,10 +277,10 @@ struct gsx_viewer {
     hipEvent_t lane_event = nullptr;     // lane: end of its last frame; parent: "everything enqueued so far" for the lanes to wait on
     bool lane_busy = false;              // lane: it has a frame the parent's stream has not been ordered after
     uint64_t epoch = 1, seen_epoch = 0;  // parent: bumped by every call that may touch model data; lane: the epoch it has waited for
-    // sharded frames in flight (gsx_shard_render_frame with frames_in_flight > 1, gsx_comm.cpp): every collective of every
-    // lane goes through ONE stream in program order (one communicator, the same order on every rank)
-    hipStream_t comm_stream = nullptr;   // owner only
-    hipEvent_t comm_ev_in = nullptr, comm_ev_out = nullptr;  // this viewer's hand-over to / from the comm stream
+    uint32_t lane_index = 0;             // 0: the viewer itself; lane i of its parent otherwise
+    // sharded frames in flight (gsx_shard_render_frame with frames_in_flight > 1): every lane has a communicator of its own
+    // and runs its collectives on its own stream (gsx_comm.cpp)
+    std::vector<void*> lane_comms;       // owner only: ncclComm_t of lane 1, 2, ... (lane 0 uses `comm`)
     std::deque<ShardPending> shard_pending;  // owner only: oldest first
     bool shard_busy = false;             // gsx_shard_render_frame is enqueueing / completing: viewer_bind must not complete frames
     uint32_t shard_turn = 0;
@@ -363,6 +371,7 @@ inline uint32_t ceil_log2(uint32_t x) {
 gsx_status shard_complete_pending(gsx_viewer* v);  // gsx_comm.cpp: verdicts, redo / repair rounds of the sharded frames in flight
 inline bool has_comm(const gsx_viewer* v) { return v->comm != nullptr || v->comm_a2a_fn != nullptr; }
 void group_leave(gsx_viewer* v);  // gsx_comm_group.cpp: give this viewer's seat in its in-process group back
+gsx_status comm_ensure_lanes(gsx_viewer* v, uint32_t lanes);  // gsx_comm.cpp: one RCCL communicator per lane (collective)
 
 inline gsx_status viewer_bind(gsx_viewer* v) {
     if (!v) return fail(GSX_ERR_INVALID_ARG, "viewer is null");

@@ -140,9 +140,10 @@ class HipStages:
             pool[rnd] = torch.empty((world, slot + 1, RECORD_FLOATS), dtype=torch.float32, device=f"cuda:{self.device}")
         return pool[rnd]
 
-    def import_slots(self, key: str, recv, world: int, rank: int, rnd: int, slot: int) -> None:
-        """``gsx_shard_import_slots``: import (counts from the slot headers, on the device) + depth sort + render."""
-        _lib.check(self.viewer._L.gsx_shard_import_slots(self.viewer._h, key.encode(), recv.data_ptr(), world, rank, rnd, slot))
+    def import_slots(self, key: str, recv, world: int, rank: int, rnd: int, slot: int, behind: bool = False) -> None:
+        """``gsx_shard_import_slots``: import (counts from the slot headers, on the device) + depth sort + render; ``behind``:
+        a layered frame's model that is not the nearest (GSX_SHARD_BEHIND)."""
+        _lib.check(self.viewer._L.gsx_shard_import_slots(self.viewer._h, key.encode(), recv.data_ptr(), world, rank, rnd | (2 if behind else 0), slot))
 
     def alloc_sat(self, world: int, mine):
         import torch
@@ -198,13 +199,14 @@ class HipStages:
         _lib.check(self.viewer._L.gsx_shard_download_limits(self.viewer._h, key.encode(), out.ctypes.data_as(C.POINTER(C.c_uint32)), out.size))
         return out
 
-    def render_frame_lib(self, key: str, shard_max: int, speculate: bool, margin: float, radius: int) -> None:
-        """``gsx_shard_render_frame``: the whole index-sharded frame inside the library (collectives over RCCL)."""
+    def render_frame_lib(self, keys, shard_max, speculate: bool, margin: float, radius: int) -> None:
+        """``gsx_shard_render_frame_keys``: the whole index-sharded frame inside the library (collectives over RCCL or the
+        in-process group); ``keys`` far -> near, ``shard_max`` per key."""
         v = self.viewer
         if self._fb_t is not None:   # the library gathers into a padded framebuffer of its own
             _lib.check(v._L.gsx_viewer_set_external_framebuffer(v._h, None, 0))
             self._fb_t = None
-        _lib.check(v._L.gsx_shard_render_frame(v._h, key.encode(), int(shard_max), 1 if speculate else 0, float(margin), int(radius)))
+        v.shard_render_frame_keys(list(keys), list(shard_max), speculate, margin, radius)
 
     def render_band(self, keys, world: int, rank: int) -> None:
         """Screen-band mode (the whole scene is resident on every GPU): render band `rank` of `world` into the padded

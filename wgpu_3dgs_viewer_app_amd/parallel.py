@@ -94,20 +94,6 @@ class TorchComm:
     def __init__(self, group=None):
         self.group = group
 
-    def all_to_all_counts(self, counts, device):
-        import torch
-        import torch.distributed as dist
-
-        sc = torch.as_tensor(counts, dtype=torch.int64, device=device)
-        rc = torch.empty_like(sc)
-        dist.all_to_all_single(rc, sc, group=self.group)
-        return [int(x) for x in rc.tolist()]
-
-    def all_to_all_records(self, recv, send, recv_counts, send_counts):
-        import torch.distributed as dist
-
-        dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=self.group)
-
     def all_to_all_slots(self, recv, send):
         """Fixed-size slots, equal split: slot p of `send` goes to rank p, slot p of `recv` comes from rank p."""
         import torch.distributed as dist
@@ -166,6 +152,28 @@ class LibComm(TorchComm):
         _lib.check(self._v._L.gsx_comm_all_gather(self._v._h, inp.data_ptr(), out.data_ptr(), inp.numel() * inp.element_size()))
 
 
+class GroupComm(TorchComm):
+    """The in-process transport of the library (``gsx_comm_group_*``, csrc/gsx_comm_group.cpp): `world` ranks of ONE process,
+    one host thread and one viewer each; collectives are device copies inside libgsx.  ``group``: a ``viewer.CommGroup``
+    shared by the ranks."""
+
+    def __init__(self, stages, group, rank):
+        super().__init__(None)
+        self._v = stages.viewer
+        self._v.comm_init_group(group, rank)
+
+    def all_to_all_slots(self, recv, send):
+        from . import _lib
+
+        per_peer = send.numel() * send.element_size() // send.shape[0]
+        _lib.check(self._v._L.gsx_comm_all_to_all(self._v._h, send.data_ptr(), recv.data_ptr(), per_peer))
+
+    def all_gather(self, out, inp):
+        from . import _lib
+
+        _lib.check(self._v._L.gsx_comm_all_gather(self._v._h, inp.data_ptr(), out.data_ptr(), inp.numel() * inp.element_size()))
+
+
 class ShardedViewer:
     """One rank's view of a scene rendered by ``world`` GPUs.  With world == 1 (and use_dist False) this is
     exactly the single-GPU ``MultiModelViewer`` protocol."""
@@ -205,7 +213,12 @@ class ShardedViewer:
         self.stages = stages
         # the transport is injectable (tests drive `world` ranks as threads of one process, or over gloo on CPU); "lib" = the
         # collectives inside libgsx over RCCL, the index-sharded frame as one library call
-        self.comm = LibComm(stages, world, rank, group) if comm == "lib" else (comm if comm is not None else TorchComm(group))
+        if comm == "lib":
+            self.comm = LibComm(stages, world, rank, group)
+        elif hasattr(comm, "_h") and hasattr(comm, "world"):   # a viewer.CommGroup: the library's in-process transport
+            self.comm = GroupComm(stages, comm, rank)
+        else:
+            self.comm = comm if comm is not None else TorchComm(group)
         if mode == "frames" and world >= 4 and hasattr(stages, "viewer"):
             # a rank's previous frame is `world` poses back: wider windows (measured on cfg4, one GPU rendering every 8th / 4th
             # pose: margin 0.25 / radius 3 -> 638 / 869 fps, every frame needs the repair round at 8; 0.5 / 6 -> 765 / 936)
@@ -270,35 +283,8 @@ class ShardedViewer:
                     self._gather_rgba8()
                 else:
                     self.comm.all_gather(st.gather_target(), st.own_band())
-            elif len(keys) == 1:
-                self._render_frame_dist(keys[0])
             else:
-                self._render_frame_dist_layers(keys)
-
-    def _render_frame_dist_layers(self, keys):
-        """Several layered models: every model's records travel once to the bands they touch (no windows — a tile's
-        saturation depth is a per-model quantity), each rank composites the layers of its band front to back."""
-        st = self.stages
-        world, rank = self.world, self.rank
-        for k in keys:
-            st.begin_frame(k, world, rank)
-        for k in keys:
-            send, counts = st.pack(k, world, None)
-            recv, n = self._exchange(send, counts)
-            st.import_records(k, recv, n, world, rank, None)
-        st.render_keys(keys, more=False)
-        self.rounds = 1
-        self._limit = None
-        self.comm.all_gather(st.gather_target(), st.own_band())
-
-    def _exchange(self, send, send_counts):
-        """counts, then the 48-byte records with exact split sizes (two all-to-alls)."""
-        st = self.stages
-        send_counts = [int(x) for x in send_counts]
-        recv_counts = self.comm.all_to_all_counts(send_counts, send.device)
-        recv = st.alloc_records(sum(recv_counts))
-        self.comm.all_to_all_records(recv, send[: sum(send_counts)], recv_counts, send_counts)
-        return recv, sum(recv_counts)
+                self._render_frame_dist(keys)
 
     def _tick(self, name):
         """Dev aid (self.profile = {}): host wall time per protocol section, with a device sync at every boundary."""
@@ -311,11 +297,13 @@ class ShardedViewer:
         self.profile[name] = self.profile.get(name, 0.0) + (now - self._t_last)
         self._t_last = now
 
-    def _render_frame_dist(self, key):
+    def _render_frame_dist(self, keys):
         """One index-sharded frame, device-resident protocol (include/gsx.h "multi-GPU, device-resident protocol"): every stage
-        call enqueues, every collective moves fixed-size buffers, and the host waits for ONE thing — the verdict of round 0,
-        two pinned words every rank derives from the same gathered data — while the band all-gather is already running.
-        With the library transport the whole sequence is ONE call, gsx_shard_render_frame, which runs exactly these steps."""
+        call enqueues, every collective moves fixed-size buffers, and what the host waits for is one verdict per model — two
+        pinned words every rank derives from the same gathered data.  ``keys`` far -> near; models are layered, never merged
+        (scene.rs:533-558, 2302-2314): they are exchanged and composited nearest first, each behind the ones before it, and a
+        model's repair round comes before the next model's records.  With the library transport the whole sequence is ONE
+        call, gsx_shard_render_frame_keys (csrc/gsx_shard_frame.cpp), which this method mirrors step for step."""
         st, comm = self.stages, self.comm
         world, rank = self.world, self.rank
         if self.profile is not None:
@@ -325,18 +313,20 @@ class ShardedViewer:
             self._t_last = time.perf_counter()
         limit, self._limit = self._limit, None
         self._rounds_host = None
-        shard_max = self._shard_max[key]
-        if isinstance(comm, LibComm) and limit is None and self.profile is None and self.force_slot is None:
-            st.render_frame_lib(key, shard_max, self.speculate, self.margin, self.radius)
+        order = list(reversed(keys))                         # compositing order: nearest model first
+        shard_max = [self._shard_max[k] for k in order]
+        if isinstance(comm, (LibComm, GroupComm)) and limit is None and self.profile is None and self.force_slot is None:
+            st.render_frame_lib(list(keys), [self._shard_max[k] for k in keys], self.speculate, self.margin, self.radius)
             return
 
-        def exchange_round(rnd, slot):
+        def exchange_round(i, rnd, slot):
+            key = order[i]
             send = st.pack_slots(key, world, rnd, slot)
             self._tick("pack")
             recv = st.alloc_slots(world, slot, rnd)
             comm.all_to_all_slots(recv, send)                # stage X: fixed slots, the counts ride in the headers
             self._tick("exchange")
-            st.import_slots(key, recv, world, rank, rnd, slot)   # stage C: import + depth sort + this rank's band
+            st.import_slots(key, recv, world, rank, rnd, slot, behind=i > 0)   # stage C: import + depth sort + this rank's band
             self._tick("import_sort_render")
             mine = st.feedback(key, world, rank)
             sat_all = st.alloc_sat(world, mine)
@@ -344,38 +334,50 @@ class ShardedViewer:
             self._tick("feedback")
             return sat_all
 
-        def finish(sat_all):
-            st.next_windows(key, world, sat_all, self.margin, self.radius)
-            # stage M: the disjoint bands of tile rows are all-gathered straight into the framebuffer
-            comm.all_gather(st.gather_target(), st.own_band())
-            self._tick("gather")
+        def round0(i, slot):
+            sat_all = exchange_round(i, 0, slot)
+            seq = st.verify(order[i], world, sat_all)        # repair windows on the device; posts the verdict
+            st.next_windows(order[i], world, sat_all, self.margin, self.radius)   # enqueued BEFORE the wait: what follows when all is well
+            return seq
 
-        # stage P: windows [0, limit) from last frame's limits (first frame / speculation off: none), project the shard
-        st.frame_begin(key, world, rank, self.speculate, limit)
+        def settle(i, seq):
+            """the verdict of model i's round 0: True = a slot overflowed; a needed repair round is run here"""
+            verdict = st.wait_verdict(order[i], seq)
+            self.last_verdict = verdict
+            if verdict["overflow"]:
+                return True
+            if verdict["need_tiles"]:
+                mine = st.repair_count(order[i], world)      # the repair round is sized exactly: count, gather, post, wait
+                counts_all = st.alloc_counts(world)
+                comm.all_gather(counts_all, mine)
+                sized = st.wait_verdict(None, st.post_counts(world, counts_all))
+                sat_all = exchange_round(i, 1, max(sized["max_records"], 1))
+                st.next_windows(order[i], world, sat_all, self.margin, self.radius)
+                self._rounds_host = 2
+            return False
+
+        # stage P: windows [0, limit) from each model's last frame (first frame / speculation off: none), project the shards
+        for k in order:
+            st.frame_begin(k, world, rank, self.speculate, limit.get(k) if isinstance(limit, dict) else limit)
         self._tick("project")
-        slot = self.force_slot if self.force_slot is not None else st.slot_records(key, world, shard_max)
+        slots = [self.force_slot if self.force_slot is not None else st.slot_records(k, world, m) for k, m in zip(order, shard_max)]
+        self._rounds_host = 1
         for attempt in (0, 1):
-            sat_all = exchange_round(0, slot)
-            seq = st.verify(key, world, sat_all)             # repair windows on the device; posts the verdict
-            finish(sat_all)                                  # enqueued BEFORE the wait: what follows when all is well
-            verdict = st.wait_verdict(key, seq)              # the frame's one host wait
-            if not verdict["overflow"]:
+            overflow = False
+            for i in range(len(order)):
+                overflow = settle(i, round0(i, slots[i]))
+                if overflow:
+                    break
+            if not overflow:
                 break
             if attempt == 1:
-                raise RuntimeError(f"an exchange slot of {slot} records (a whole shard) overflowed")
-            slot = shard_max                                 # a destination can be sent at most a whole shard: always fits
-        self.last_verdict = verdict
-        if verdict["need_tiles"]:
-            mine = st.repair_count(key, world)               # the repair round is sized exactly: count, gather, post, wait
-            counts_all = st.alloc_counts(world)
-            comm.all_gather(counts_all, mine)
-            sized = st.wait_verdict(None, st.post_counts(world, counts_all))
-            sat_all = exchange_round(1, max(sized["max_records"], 1))
-            finish(sat_all)
-            self._rounds_host = 2
-        else:
-            self._rounds_host = 1
-        st.frame_end(key)
+                raise RuntimeError(f"an exchange slot of {slots} records (whole shards) overflowed")
+            slots = list(shard_max)                          # a destination can be sent at most a whole shard: always fits
+        # stage M: the disjoint bands of tile rows are all-gathered straight into the framebuffer
+        comm.all_gather(st.gather_target(), st.own_band())
+        self._tick("gather")
+        for k in order:
+            st.frame_end(k)
 
     @property
     def rounds(self):

@@ -405,6 +405,14 @@ class MultiModelViewer:
         """One whole index-sharded frame of this rank (``gsx_shard_render_frame``)."""
         _lib.check(self._L.gsx_shard_render_frame(self._h, key.encode(), int(shard_records_max), 1 if speculate else 0, float(margin), int(radius)))
 
+    def shard_render_frame_keys(self, model_render_keys: Sequence[str], shard_records_max: Sequence[int], speculate: bool = True,
+                                margin: float = 0.25, radius: int = 3) -> None:
+        """Layered models, far -> near like ``renderer.render`` (``gsx_shard_render_frame_keys``)."""
+        keys = [k.encode() for k in model_render_keys]
+        arr = (C.c_char_p * len(keys))(*keys)
+        mx = (C.c_uint32 * len(keys))(*[int(x) for x in shard_records_max])
+        _lib.check(self._L.gsx_shard_render_frame_keys(self._h, arr, len(keys), mx, 1 if speculate else 0, float(margin), int(radius)))
+
     def shard_set_limits(self, key: str, limits: np.ndarray) -> None:
         """Per-tile depth-key limits (uint32 [tiles_y, tiles_x]) the next sharded frame uses instead of the last frame's."""
         a = np.ascontiguousarray(limits, np.uint32)
