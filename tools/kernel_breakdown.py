@@ -13,6 +13,6 @@ for r in csv.DictReader(open(f)):
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     acc[r["Kernel_Name"].split("(")[0][-40:]].append((e - s) / 1e3)
 rows = [(sum(v) / frames, k, len(v) / frames, sum(v) / len(v)) for k, v in acc.items()]
-for r in sorted(rows, reverse=True)[:18]:
+for r in sorted(rows, reverse=True)[: int(sys.argv[3]) if len(sys.argv) > 3 else 18]:
     print("per-frame %7.1f us  %-42s calls/frame=%5.1f avg=%7.1f us" % r)
 print("sum per frame us %.1f" % sum(r[0] for r in rows))

@@ -56,7 +56,9 @@ gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, const 
     if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack: model '%s' has no projection this frame (gsx_preprocess first)", key);
     if (world == 0 || world > 64 || !counts) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack: world must be 1..64");
     const uint32_t n = (uint32_t)m->n;
-    const uint32_t nb = (uint32_t)pack_blocks(n), rpr = rows_per_rank(v, world);
+    const bool from_list = !d_tile_window && m->shard_win_set && m->cand_valid;
+    const uint32_t rounds = pack_rounds(from_list), tile = 256u * rounds;
+    const uint32_t nb = (uint32_t)pack_blocks(n, rounds), rpr = rows_per_rank(v, world);
     const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE;
     HIPCHK(m->pack_table.ensure(4 * ((size_t)64 * std::max(nb, 1u) + 64)));
     HIPCHK(m->pack_masks.ensure(8 * (size_t)std::max(n, 1u)));
@@ -88,7 +90,7 @@ gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, const 
     unsigned long long* masks = m->pack_masks.as<unsigned long long>();
     HIPCHK(hipMemsetAsync(totals, 0, 4 * 64, v->stream));
     HIPCHK(launch_pack_count(v->stream, m->proj_rec(), n, world, rpr, window, tiles_x, masks, table, list, d_list_n, travellers, trav_counts));
-    if (nb) HIPCHK(launch_rowscan(v->stream, table, world, nb, totals));
+    if (nb) HIPCHK(launch_rowscan(v->stream, table, world, nb, totals, d_list_n, tile));
     if (travellers && nb) {
         // shade the travellers the first round did not: compact their indices, k_shade skips what is shaded already
         HIPCHK(m->adm_pairs.ensure(8 * std::max<size_t>(n, 1)));
@@ -257,11 +259,12 @@ namespace {
 // a record whose rectangle holds none of them is refused before any window is looked at (the repair round: few tiles).
 gsx_status pack_count(gsx_viewer* v, Model* m, uint32_t world, const uint2* explicit_window, const uint32_t* gate, const WindowPyramid* pyramid) {
     const uint32_t n = (uint32_t)m->n;
-    const uint32_t nb = (uint32_t)pack_blocks(n), rpr = rows_per_rank(v, world);
+    m->pack_list = !explicit_window && m->shard_win_set && m->cand_valid;
+    m->pack_rounds = pack_rounds(m->pack_list);
+    const uint32_t nb = (uint32_t)pack_blocks(n, m->pack_rounds), rpr = rows_per_rank(v, world);
     const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE;
     HIPCHK(m->pack_table.ensure(4 * ((size_t)64 * std::max(nb, 1u) + 64)));
     HIPCHK(m->pack_masks.ensure(8 * (size_t)std::max(n, 1u)));
-    m->pack_list = false;
     m->pack_travellers = false;
     const uint2* window = nullptr;
     const uint2* list = nullptr;
@@ -279,11 +282,10 @@ gsx_status pack_count(gsx_viewer* v, Model* m, uint32_t world, const uint2* expl
             trav_counts = m->trav_counts.as<uint32_t>();
             m->pack_travellers = true;
         }
-    } else if (m->shard_win_set && m->cand_valid) {
+    } else if (m->pack_list) {
         window = m->shard_win.as<uint2>();
         list = m->adm_pairs.as<uint2>();
         d_list_n = &dc->n_candidates;
-        m->pack_list = true;
     } else if (m->lazy) {
         if ((st = complete_records(v, m))) return st;
     }
@@ -292,14 +294,14 @@ gsx_status pack_count(gsx_viewer* v, Model* m, uint32_t world, const uint2* expl
     HIPCHK(launch_zero_words(v->stream, totals, 64, nullptr, 0));
     HIPCHK(launch_pack_count(v->stream, m->proj_rec(), n, world, rpr, window, tiles_x, m->pack_masks.as<unsigned long long>(), table, list, d_list_n,
                              travellers, trav_counts, gate, (tiles_x + 31) / 32, window ? pyramid : nullptr));
-    if (nb) HIPCHK(launch_rowscan(v->stream, table, world, nb, totals));
+    if (nb) HIPCHK(launch_rowscan(v->stream, table, world, nb, totals, d_list_n, 256u * m->pack_rounds));
     return GSX_OK;
 }
 
 // pack_write: shade the travellers the lazy projection skipped, slot headers, the records into their slots
 gsx_status pack_write(gsx_viewer* v, Model* m, uint32_t world, void* d_send, uint32_t slot_stride, uint32_t slot_cap, uint32_t round) {
     const uint32_t n = (uint32_t)m->n;
-    const uint32_t nb = (uint32_t)pack_blocks(n);
+    const uint32_t nb = (uint32_t)pack_blocks(n, m->pack_rounds);
     Counters* dc = m->counters.as<Counters>();
     uint32_t* table = m->pack_table.as<uint32_t>();
     uint32_t* totals = table + (size_t)64 * std::max(nb, 1u);
@@ -427,7 +429,7 @@ gsx_status gsx_shard_repair_count(gsx_viewer* v, const char* key, uint32_t world
     if (!m->preprocessed || m->shard_win2.bytes < window_bytes(v)) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_repair_count: before gsx_shard_verify");
     if ((st = repair_pack_count(v, m, world))) return st;
     m->repair_counted = true;
-    const uint32_t* totals = m->pack_table.as<uint32_t>() + (size_t)64 * std::max<uint32_t>((uint32_t)pack_blocks(m->n), 1u);
+    const uint32_t* totals = m->pack_table.as<uint32_t>() + (size_t)64 * std::max<uint32_t>((uint32_t)pack_blocks(m->n, m->pack_rounds), 1u);
     HIPCHK(launch_shard_max_count(v->stream, totals, world, static_cast<uint32_t*>(d_out4)));
     return GSX_OK;
 }

@@ -195,8 +195,6 @@ gsx_status gsx_comm_all_to_all(gsx_viewer* v, const void* d_send, void* d_recv, 
             return g_err.empty() ? fail(st, "gsx_comm_all_to_all: the custom transport failed with status %d", (int)st) : st;
         return GSX_OK;
     }
-    ncclComm_t comm = comm_of(v);
-    if (!comm) return fail(GSX_ERR_RCCL, "gsx_comm_all_to_all: lane %u has no communicator", v->lane_index);
     // what this rank keeps for itself does not travel: a device copy on the viewer's own stream, beside the exchange
     // (GSX_COMM_SELF_VIA_RCCL, read by gsx_viewer_comm_init: send it to oneself through RCCL like everything else — the
     // one-rank tests on a one-GPU box exercise ncclSend / ncclRecv that way)
@@ -207,6 +205,8 @@ gsx_status gsx_comm_all_to_all(gsx_viewer* v, const void* d_send, void* d_recv, 
                               hipMemcpyDeviceToDevice, v->stream));
         if (o->comm_world == 1) return GSX_OK;
     }
+    ncclComm_t comm = comm_of(v);
+    if (!comm) return fail(GSX_ERR_RCCL, "gsx_comm_all_to_all: lane %u has no communicator", v->lane_index);
     RCCLCHK(g_rccl.GroupStart());
     for (uint32_t p = 0; p < o->comm_world; ++p) {
         if (bypass && p == o->comm_rank) continue;
@@ -231,6 +231,10 @@ gsx_status gsx_comm_all_gather(gsx_viewer* v, const void* d_send, void* d_recv, 
             return g_err.empty() ? fail(st, "gsx_comm_all_gather: the custom transport failed with status %d", (int)st) : st;
         return GSX_OK;
     }
+    if (o->comm_world == 1 && !o->comm_self_via_rccl) {  // one rank: its own piece is all there is, and it does not travel
+        if (d_send != d_recv) HIPCHK(hipMemcpyAsync(d_recv, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, v->stream));
+        return GSX_OK;
+    }
     ncclComm_t comm = comm_of(v);
     if (!comm) return fail(GSX_ERR_RCCL, "gsx_comm_all_gather: lane %u has no communicator", v->lane_index);
     RCCLCHK(g_rccl.AllGather(d_send, d_recv, bytes_per_rank, kNcclChar, comm, v->stream));
@@ -243,6 +247,10 @@ gsx_status gsx_comm_all_gather(gsx_viewer* v, const void* d_send, void* d_recv, 
 // it follows from gsx_render_options.frames_in_flight, which an SPMD host sets alike everywhere.
 gsx_status gsx::comm_ensure_lanes(gsx_viewer* v, uint32_t lanes) {
     if (!v->comm || lanes <= 1) return GSX_OK;  // a custom transport serves every lane with the same two functions
+    // one rank: nothing of a frame goes through RCCL (own slot and own pieces are device copies), so no lane needs a communicator.
+    // (Measured with ROCm 7.2's RCCL 2.27.7: a second communicator in the process costs 1413 -> 1214 fps at world 1 although no
+    // RCCL call is made in the loop; the 2.26.6 that ships with PyTorch does not show it.)
+    if (v->comm_world == 1 && !v->comm_self_via_rccl) return GSX_OK;
     gsx_status st = rccl_ready();
     if (st) return st;
     while (v->lane_comms.size() + 1 < lanes) {

@@ -261,8 +261,11 @@ hipError_t launch_spec_next(hipStream_t s, const uint32_t* tile_sat, const uint3
                             uint32_t band_lo, uint32_t band_hi);
 
 // Multi-GPU exchange support (kernels_shard.hip).
-hipError_t launch_rowscan(hipStream_t s, uint32_t* table, uint32_t nrows, uint32_t nblocks, uint32_t* totals);
-size_t pack_blocks(uint64_t n);
+// d_n (nullable) / tile: only the first ceil(*d_n / tile) columns of every row hold anything (a candidate list shorter than the grid)
+hipError_t launch_rowscan(hipStream_t s, uint32_t* table, uint32_t nrows, uint32_t nblocks, uint32_t* totals, const uint32_t* d_n = nullptr,
+                          uint32_t tile = 1);
+size_t pack_blocks(uint64_t n, uint32_t rounds);  // workgroups of a pack pass whose tiles hold 256 x rounds records
+uint32_t pack_rounds(bool candidate_list);
 // rows_per_rank: rank g owns tile rows [g*rpr, min((g+1)*rpr, tiles_y)).  A record travels to g if its rectangle
 // touches g's band and (key < key_front_hi, or key >= key_back_lo and it touches a tile whose bit in open_map is 0).
 // window: uint2 [lo, hi) depth-key window per tile (tiles_y * tiles_x, row-major) or nullptr = every tile takes everything.

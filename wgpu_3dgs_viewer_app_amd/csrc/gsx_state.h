@@ -196,6 +196,7 @@ struct Model {
     DevBuf shard_pyr2;             // min-pyramid of the repair windows' starts (the repair round's conservative pack test)
     DevBuf shard_need_bits;        // device-resident exchange: bitmap of the tiles that need the repair round (gates its pack)
     bool repair_counted = false;
+    uint32_t pack_rounds = 16;     // tile size (x 256 records) of the last pack_count: its table layout (kernels_shard.hip)
     bool pack_list = false, pack_travellers = false;  // how the last pack_count addressed the records / whether it left travellers to shade   // gsx_shard_repair_count has left masks / table / travellers for the repair pack
 
     ~Model() {

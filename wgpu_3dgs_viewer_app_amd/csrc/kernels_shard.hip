@@ -23,18 +23,22 @@
 namespace gsx {
 
 constexpr int kPackThreads = 256;
-constexpr int kPackRounds = 16;
-constexpr int kPackTile = kPackThreads * kPackRounds;  // 4096 records per workgroup
-constexpr int kPackWaveChunk = 64 * kPackRounds;
 constexpr int kMaxWorld = 64;
+// Records per workgroup = 256 x ROUNDS.  16 rounds (4096 records) when the whole shard is scanned; 2 rounds (512) when only a
+// candidate list is — a few per cent of the shard, compacted at the front: with 4096-record tiles 0.3 M candidates kept 73
+// workgroups busy on 256 CUs (47 + 51 us for count + scatter); the grid is sized for the shard, the workgroups past the list
+// return at once.
+constexpr uint32_t kPackRoundsFull = 16, kPackRoundsList = 2;
 
-size_t pack_blocks(uint64_t n) { return (size_t)((n + kPackTile - 1) / kPackTile); }
+size_t pack_blocks(uint64_t n, uint32_t rounds) { return (size_t)((n + kPackThreads * rounds - 1) / (kPackThreads * rounds)); }
+uint32_t pack_rounds(bool candidate_list) { return candidate_list ? kPackRoundsList : kPackRoundsFull; }
 
 // per record: destination mask (stored for the scatter pass); per workgroup and destination: record count
 // list (nullable): pack only the candidates list[0 .. *d_list_n) = (key, index) pairs (the records a lazily projected
 // shard admitted); element e of every per-record array below then refers to list position e.
 // travellers (nullable): ballots of the elements that travel anywhere + their count per workgroup (feeds the shading of
 // a lazily projected shard's repair round).
+template <int kPackRounds>
 __global__ __launch_bounds__(kPackThreads) void k_pack_count(const uint32_t* __restrict__ key,
                                                               const float4* __restrict__ rec_a, uint32_t n,
                                                               uint32_t world, uint32_t rpr,
@@ -48,6 +52,7 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_count(const uint32_t* __r
                                                               const WindowPyramid pyr, const uint32_t* __restrict__ rect8) {
     __shared__ uint32_t cnt[kMaxWorld];
     __shared__ uint32_t tcnt[kPackThreads / 64];
+    constexpr uint32_t kPackTile = kPackThreads * kPackRounds, kPackWaveChunk = 64 * kPackRounds;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     if (tid < kMaxWorld) cnt[tid] = 0;
     __syncthreads();
@@ -107,6 +112,7 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_count(const uint32_t* __r
 }
 
 // table rows were scanned exclusively in place (k_radix_rowscan), totals[g] = records for destination g
+template <int kPackRounds>
 __global__ __launch_bounds__(kPackThreads) void k_pack_scatter(const unsigned long long* __restrict__ masks,
                                                                 const float4* __restrict__ rec_a,
                                                                 const float4* __restrict__ rec_b,
@@ -119,6 +125,7 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_scatter(const unsigned lo
     __shared__ uint32_t run[kPackThreads / 64][kMaxWorld];  // per-wave running counts -> absolute offsets
     __shared__ uint32_t dbase[kMaxWorld];
     __shared__ uint32_t dend[kMaxWorld];   // first position past what destination g may hold
+    constexpr uint32_t kPackTile = kPackThreads * kPackRounds, kPackWaveChunk = 64 * kPackRounds;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     if (tid < kMaxWorld) {
         if (slot_stride) {  // fixed slots (device-resident exchange): slot g = [header | slot_cap records]
@@ -209,21 +216,25 @@ hipError_t launch_pack_count(hipStream_t s, const Records& rec, uint32_t n, uint
                              const uint2* window, uint32_t tiles_x, unsigned long long* masks, uint32_t* table,
                              const uint2* list, const uint32_t* d_list_n, unsigned long long* travellers, uint32_t* traveller_counts,
                              const uint32_t* gate, uint32_t gate_row_words, const WindowPyramid* pyramid) {
-    uint32_t nb = (uint32_t)pack_blocks(n);
-    if (nb)
-        hipLaunchKernelGGL(k_pack_count, dim3(nb), dim3(kPackThreads), 0, s, rec.key, rec.a, n, world, rows_per_rank, window,
+    const uint32_t rounds = pack_rounds(list != nullptr), nb = (uint32_t)pack_blocks(n, rounds);
+    if (nb) {
+        auto kernel = rounds == kPackRoundsList ? k_pack_count<(int)kPackRoundsList> : k_pack_count<(int)kPackRoundsFull>;
+        hipLaunchKernelGGL(kernel, dim3(nb), dim3(kPackThreads), 0, s, rec.key, rec.a, n, world, rows_per_rank, window,
                            tiles_x, masks, table, nb, list, d_list_n, travellers, traveller_counts, gate, gate_row_words,
                            pyramid ? *pyramid : WindowPyramid{}, rec.rect8);
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_pack_scatter(hipStream_t s, const Records& rec, uint32_t n, uint32_t world,
                                const unsigned long long* masks, const uint32_t* table, const uint32_t* totals, void* d_send,
                                uint64_t capacity, const uint2* list, const uint32_t* d_list_n, uint32_t slot_stride, uint32_t slot_cap) {
-    uint32_t nb = (uint32_t)pack_blocks(n);
-    if (nb)
-        hipLaunchKernelGGL(k_pack_scatter, dim3(nb), dim3(kPackThreads), 0, s, masks, rec.a, rec.b, rec.c, n, world, table, nb,
+    const uint32_t rounds = pack_rounds(list != nullptr), nb = (uint32_t)pack_blocks(n, rounds);
+    if (nb) {
+        auto kernel = rounds == kPackRoundsList ? k_pack_scatter<(int)kPackRoundsList> : k_pack_scatter<(int)kPackRoundsFull>;
+        hipLaunchKernelGGL(kernel, dim3(nb), dim3(kPackThreads), 0, s, masks, rec.a, rec.b, rec.c, n, world, table, nb,
                            totals, reinterpret_cast<float4*>(d_send), capacity, list, d_list_n, slot_stride, slot_cap);
+    }
     return hipGetLastError();
 }
 
