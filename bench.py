@@ -13,6 +13,12 @@ Prints ONE JSON line on rank 0.  The CPU oracle is used here only for the `cpu_b
 What one N=1 run measures, all in the same process on the same resident scene (nothing is read from profiles/):
   value                 fps of K frames in the default schedule (progressive slabs + temporal occlusion speculation)
   value_unspeculated    fps of K frames with speculative = 0 (what every first frame / incoherent pose costs)
+  value_synchronised    fps of K frames when the host waits for every frame: gsx_render_frame + gsx_sync (SURVEY 8d's definition of
+                        the metric), and value_reference_protocol: the app's own sequence with its two blocking waits per frame —
+                        preprocess + sort, poll, render, poll (src/tab/scene.rs:856-873, 613-614)
+  steady_state          the headline loop again over >= 240 frames (a whole orbit), whatever --steps is
+  passes                every pass of both schedules bracketed with HIP events in a loop of its own: microseconds per frame,
+                        algorithmic bytes (BASELINE.md 4 / SURVEY 8d formulas, stated per pass), GB/s and fraction of 8 TB/s
   roofline              k_project<3,0,0> — the projection pass SURVEY 8d prices (SH colour + cov2d + cull + depth key),
                         HIP events around that kernel alone over the unspeculated timed loop, N*pod + N_vis*40 bytes
   roofline_speculated   k_project_geom — the geometry-only projection of the speculated loop, priced on what IT has to move
@@ -78,7 +84,9 @@ def parse_args():
                     "a few microseconds of stream gap per pass boundary)")
     ap.add_argument("--frames-in-flight", type=int, default=2,
                     help="gsx_render_options.frames_in_flight of the headline loop at N=1 (the one-in-flight rate is reported beside it)")
-    ap.add_argument("--dist-frames-in-flight", type=int, default=1, help="frames_in_flight of gsx_shard_render_frame (N > 1 / --force-dist)")
+    ap.add_argument("--dist-frames-in-flight", type=int, default=2, help="frames_in_flight of gsx_shard_render_frame (N > 1 / --force-dist): "
+                    "every lane has its own communicator and stream, the verdict of a frame is read one call later")
+    ap.add_argument("--no-extra-legs", action="store_true", help="N=1: skip the synchronised / steady-state / per-pass legs")
     ap.add_argument("--unspeculated-in-flight", action="store_true",
                     help="N=1: also time the unspeculated loop with --frames-in-flight lanes (off by default: its contended k_project "
                          "launches would blur the kernel-trace average the roofline is checked against)")
@@ -324,7 +332,10 @@ def main():
 
     if lanes > 1:
         set_opts(frames_in_flight=lanes)
+    if lib_index:
+        viewer.shard_stats(reset=True)
     elapsed, timing, last_idx = timed_loop(0)
+    shard_stats_timed = viewer.shard_stats(reset=True) if lib_index else None
     if args.host_profile and use_dist and rank == 0:
         print("host ms/frame by section:", {k: round(1e3 * x / args.steps, 4) for k, x in renderer.profile.items()}, file=sys.stderr)
     renderer.profile = None
@@ -363,6 +374,67 @@ def main():
         viewer.set_render_options(**overrides) if overrides else viewer.set_render_options()
         if not equal:
             raise SystemExit(f"bench.py: the last timed frame differs from the speculative=0, progressive=0 frame: {frame_check}")
+    # ---- N = 1: what a host that WAITS gets, a whole-orbit figure, and every pass against its bytes ----
+    extra = None
+    if single and not overrides and not args.no_extra_legs and not args.pose_stride > 1 and args.pose_order == "orbit":
+        extra = {}
+        key = renderer.KEY
+
+        def host_sync_loop(protocol):
+            """K frames, the host waiting for each: 'frame' = gsx_render_frame + gsx_sync; 'reference' = the app's sequence
+            preprocess + sort, poll, render, poll (scene.rs:856-873, 613-614)."""
+            st = renderer.stages
+
+            def one(i):
+                st.set_uniforms(key, orbit[pose_of[i % 240]], (w, h))
+                if protocol == "frame":
+                    viewer.render_frame([key])
+                else:
+                    viewer.preprocessor.preprocess(key)
+                    viewer.radix_sorter.sort(key)
+                    viewer.poll()
+                    viewer.renderer.render([key])
+                viewer.poll()
+
+            for i in range(args.warmup):
+                one(i)
+            fence()
+            t0 = time.perf_counter()
+            for i in range(args.warmup, args.warmup + args.steps):
+                one(i)
+            fence()
+            return time.perf_counter() - t0
+
+        set_opts()
+        extra["sync_frame"] = host_sync_loop("frame")
+        extra["sync_reference"] = host_sync_loop("reference")
+        set_opts(speculative=0)
+        extra["sync_frame_unspeculated"] = host_sync_loop("frame")
+        # the headline schedule over a whole orbit (>= 240 frames): the tuner's probes and every part of the path are in it
+        steady_frames = max(240, args.steps)
+        set_opts(frames_in_flight=lanes)
+        for i in range(args.warmup):
+            frame(i)
+        renderer.poll()
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.warmup, args.warmup + steady_frames):
+            frame(i)
+        renderer.poll()
+        fence()
+        extra["steady"] = (steady_frames, time.perf_counter() - t0)
+        # every pass bracketed (a loop of its own: each bracket costs a few microseconds of stream gap), one frame in flight
+        saved_timing, args.pass_timing = args.pass_timing, "all"
+        set_opts()
+        el_p, tm_p, _ = timed_loop(0)
+        ac_p = accounting(rounds(args.warmup))
+        set_opts(speculative=0)
+        el_pu, tm_pu, _ = timed_loop(0)
+        ac_pu = accounting(rounds(args.warmup))
+        args.pass_timing = saved_timing
+        extra["passes_raw"] = dict(speculated=(el_p, tm_p, ac_p), unspeculated=(el_pu, tm_pu, ac_pu))
+        set_opts()
+
     # ---- N = 1: speculation robustness legs (same process, same resident scene) ----
     robustness = None
     if single and not overrides and not args.no_robustness and not args.pose_stride > 1 and args.pose_order == "orbit":
@@ -407,6 +479,37 @@ def main():
     else:
         allr = [local]
     allr = torch.stack(allr).cpu().numpy()
+
+    # ---- N > 1 (index shards): what every rank did, so that a scaling run can be read — the library's own bookkeeping of the
+    #      timed loop (gsx_shard_get_stats: host side, never synchronises) and a second, short loop with every pass bracketed ----
+    per_rank = None
+    if lib_index:
+        frames_stats = max(shard_stats_timed["frames"], 1)
+        renderer.set_pass_timing(True, None)
+        renderer.get_pass_timing()
+        n_prof = min(args.steps, 40)
+        for i in range(n_prof):
+            frame(i)
+        renderer.poll()
+        tm_all = renderer.get_pass_timing()
+        renderer.set_pass_timing(False)
+        mine = torch.tensor([shard_stats_timed["wire_bytes"] / frames_stats, shard_stats_timed["repair_frames"] / frames_stats,
+                             shard_stats_timed["redo_frames"] / frames_stats, shard_stats_timed["verdict_wait_ns"] / 1e3 / frames_stats,
+                             shard_stats_timed["exchange_rounds"] / frames_stats, shard_stats_timed["last_slot_records"],
+                             count] + [tm_all[name]["ms"] * 1e3 / n_prof for name in ("project", "project_geom", "depth_sort", "bin", "tile_sort", "composite")],
+                            dtype=torch.float64, device="cuda")
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        g_all = torch.stack(gathered).cpu().numpy()
+        per_rank = dict(
+            note="per rank, in rank order; wire bytes = what the rank put on the links (fixed-size slots to every peer, feedback and band "
+                 "gathers); pass times from a second loop of %d frames with every pass bracketed by events" % n_prof,
+            shard_gaussians=[int(x) for x in g_all[:, 6]], wire_bytes_per_frame=[int(x) for x in g_all[:, 0]],
+            frames_with_repair_round=[round(float(x), 3) for x in g_all[:, 1]], frames_redone_with_whole_shard_slots=[round(float(x), 3) for x in g_all[:, 2]],
+            verdict_wait_us_per_frame=[round(float(x), 1) for x in g_all[:, 3]], exchange_rounds_per_frame=[round(float(x), 3) for x in g_all[:, 4]],
+            slot_records_last_frame=[int(x) for x in g_all[:, 5]],
+            pass_us_per_frame={name: [round(float(x), 1) for x in g_all[:, 7 + k]]
+                               for k, name in enumerate(("project", "project_geom", "depth_sort", "bin", "tile_sort", "composite"))})
 
     if rank == 0:
         fps = args.steps / elapsed
@@ -513,6 +616,62 @@ def main():
             out["config"]["tile_entries_unspeculated"] = int(acct_u[:, 5].mean())
         else:
             out["roofline"] = roofline_of(acct, timing, "projection pass: SH colour + cov2d + cull + depth key")
+        if out.get("roofline") is not None:
+            out["roofline"]["belongs_to"] = ("value_unspeculated: that loop runs this kernel once per frame; the headline loop (`value`) "
+                                             "projects with roofline_speculated's kernel and shades only the admitted Gaussians (k_shade)"
+                                             if timing_u is not None else "value")
+        if extra is not None:
+            out["value_synchronised"] = round(args.steps / extra["sync_frame"], 3)
+            out["ms_per_step_synchronised"] = round(1e3 * extra["sync_frame"] / args.steps, 4)
+            out["value_reference_protocol"] = round(args.steps / extra["sync_reference"], 3)
+            out["value_synchronised_unspeculated"] = round(args.steps / extra["sync_frame_unspeculated"], 3)
+            out["synchronised_note"] = ("the host waits for every frame, as the app does: value_synchronised = gsx_render_frame + gsx_sync per frame "
+                                        "(SURVEY 8d's definition of the metric); value_reference_protocol = the app's own sequence with its TWO "
+                                        "blocking waits per frame — gsx_preprocess + gsx_sort, gsx_sync, gsx_render, gsx_sync "
+                                        "(src/tab/scene.rs:856-873, 613-614); default schedule, one frame in flight; `value` is the same frames "
+                                        "enqueued back to back without a host wait")
+            sf, st_el = extra["steady"]
+            out["steady_state"] = dict(frames=sf, value=round(sf / st_el, 3), ms_per_step=round(1e3 * st_el / sf, 4),
+                                       note=f"the headline loop (frames_in_flight = {lanes}) over a whole orbit, timed like `value`")
+
+            def passes_of(el, tm, ac, speculated):
+                """every pass against its algorithmic bytes; means over the accounting frames of that loop"""
+                n_a, nvis, nsort, _, _, d_ent = [float(ac[:, k].mean()) for k in range(6)]
+                tiles = ((w + 15) // 16) * ((h + 15) // 16)
+                p_tile = max(1, -(-max(1, (tiles - 1).bit_length()) // 8))
+                lazy = speculated and float(ac[:, 3].mean()) > 0.5
+                rows = {}
+                proj_name = "project_geom" if lazy else "project"
+                proj_bytes = (n_a * 24.125 + nvis * cov_bytes) if lazy else (n_a * pod_bytes + nvis * 40)
+                defs = {
+                    proj_name: (proj_bytes, "geometry-only projection: N*24.125 + N_vis*cov" if lazy else f"SURVEY 8d projection: N*{pod_bytes} + N_vis*40"),
+                    "depth_sort": (nsort * 68, "SURVEY 8d K2: N_sorted*68 (four 8-bit passes of 8-byte pairs, read + write, + 4 B): the records that "
+                                               "enter the depth sort — all visible ones unspeculated, the admitted ones speculated; the pass also holds "
+                                               "the admission compaction and, on speculated frames, k_shade and the repair round's sort"),
+                    "bin": (nsort * 44 + d_ent * 12, "BASELINE 4 binning: N_sorted*44 + D*12, D = list entries actually binned (block entries on "
+                                                     "progressive frames)"),
+                    "tile_sort": (d_ent * 24 + d_ent * 8, "BASELINE 4 sort: D*24*p + D*8 with p = 1 (block lists: one 8-bit pass over "
+                                                                                   "the block ids; per-tile lists would need p = %d)" % p_tile),
+                    "composite": (d_ent * 40 + w * h * 16, "BASELINE 4 composite: D*40 + W*H*16 (VALU / LDS bound: reported against HBM bytes as 8d asks)"),
+                }
+                for name, (b, definition) in defs.items():
+                    t = tm.get(name)
+                    if not t or t["ms"] <= 0:
+                        continue
+                    us = t["ms"] * 1e3 / args.steps
+                    gbs = b / (us * 1e-6) / 1e9
+                    rows[name] = dict(us_per_frame=round(us, 1), algorithmic_bytes=int(b), GBps=round(gbs, 1), frac_of_8TBps=round(gbs / HBM_PEAK_GBS, 4),
+                                      bytes_definition=definition)
+                rows["frame_ms_with_every_pass_bracketed"] = round(1e3 * el / args.steps, 4)
+                rows["n_visible"], rows["n_depth_sorted"], rows["list_entries"] = int(nvis), int(nsort), int(d_ent)
+                return rows
+
+            pr = extra["passes_raw"]
+            out["passes"] = dict(speculated=passes_of(*pr["speculated"], True), unspeculated=passes_of(*pr["unspeculated"], False),
+                                 note="one frame in flight, every pass bracketed with a pair of HIP events on the viewer's stream (each bracket costs a "
+                                      "few microseconds of stream gap: the frame is slower than value_one_frame_in_flight)")
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if robustness is not None:
             out["robustness"] = robustness
         if world == 1 and not args.no_cpu_baseline:

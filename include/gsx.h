@@ -312,6 +312,22 @@ gsx_status gsx_query_hit_pos_by_alpha_range(const gsx_query_hit* hits, uint64_t 
                                             uint32_t width, uint32_t height, const float coords[2], float range,
                                             uint32_t* out_index, float* out_alpha, float out_pos[3]);
 
+/* ---- ref-counted buffer handles for readback off the owner's thread.  gs:: buffers are cheaply `Clone`: the export path clones
+ *      every model's edit and mask buffer, moves the clones into two spawned threads and downloads there while the UI thread
+ *      keeps rendering (app.rs:769-816, scene.rs:635-648).  gsx_model_buffer_retain (owner thread; enqueues a device-side
+ *      snapshot on the viewer's stream: the contents as of this call, what a clone + download reads in wgpu's submission
+ *      order) returns a handle; gsx_buffer_download runs on ANY thread, concurrently with frames, uploads, gsx_model_remove
+ *      and even gsx_viewer_destroy — it touches only the handle.  gsx_buffer_retain adds a reference (a clone),
+ *      gsx_buffer_release drops one; the snapshot is freed with the last.  Elements: GSX_BUFFER_EDITS -> gsx_gaussian_edit x
+ *      len (never-edited Gaussians read as the default pod); GSX_BUFFER_MASK / _SELECTION -> uint32 x ceil(len / 32). ---- */
+typedef struct gsx_buffer gsx_buffer;
+typedef enum gsx_buffer_kind { GSX_BUFFER_MASK = 0, GSX_BUFFER_EDITS = 1, GSX_BUFFER_SELECTION = 2 } gsx_buffer_kind;
+gsx_status gsx_model_buffer_retain(gsx_viewer* v, const char* key, gsx_buffer_kind kind, gsx_buffer** out);
+gsx_status gsx_buffer_retain(gsx_buffer* b);
+void gsx_buffer_release(gsx_buffer* b);
+gsx_status gsx_buffer_len(gsx_buffer* b, uint64_t* out_elements);
+gsx_status gsx_buffer_download(gsx_buffer* b, void* out, uint64_t n_elements);
+
 /* ---- multi-GPU stage split.  No reference counterpart: the reference renders on one wgpu device
  *      (src/main.rs:85-98).  One process per GPU holds an index shard of the Gaussians; the screen is cut into
  *      `world` contiguous bands of tile rows, band g = rank g.  Per frame and rank:

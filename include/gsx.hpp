@@ -106,6 +106,25 @@ public:
     }
     void update_range(size_t start, const std::vector<Gaussian>& g) { update_range(start, g.data(), g.size()); }
 };
+// A cloned buffer (`edit_buffer.clone()` / `mask_buffer.clone()`, app.rs:769-780): copyable, shares one device-side snapshot
+// taken at clone time; download() may run on any thread while the viewer renders (gsx_buffer_*).
+template <class T>
+class BufferClone {
+    gsx_buffer* h_ = nullptr;
+public:
+    BufferClone(gsx_viewer* v, const std::string& key, gsx_buffer_kind kind) { check(gsx_model_buffer_retain(v, key.c_str(), kind, &h_)); }
+    BufferClone(const BufferClone& o) : h_(o.h_) { if (h_) check(gsx_buffer_retain(h_)); }
+    BufferClone(BufferClone&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    BufferClone& operator=(BufferClone o) noexcept { std::swap(h_, o.h_); return *this; }
+    ~BufferClone() { gsx_buffer_release(h_); }
+    std::vector<T> download() const {
+        uint64_t n = 0;
+        check(gsx_buffer_len(h_, &n));
+        std::vector<T> out(n);
+        check(gsx_buffer_download(h_, out.data(), n));
+        return out;
+    }
+};
 class MaskBuffer {  // gs::MaskBuffer (scene.rs:1851, app.rs:806-807): bit = kept
     gsx_viewer* v_;
     std::string key_;
@@ -117,6 +136,7 @@ public:
         check(gsx_model_download_mask(v_, key_.c_str(), w.data(), w.size()));
         return w;
     }
+    BufferClone<uint32_t> clone() const { return BufferClone<uint32_t>(v_, key_, GSX_BUFFER_MASK); }  // app.rs:775
 };
 class SelectionBuffer {  // gs::SelectionBuffer (scene.rs:1846-1850): bit = selected
     gsx_viewer* v_;
@@ -130,6 +150,7 @@ public:
         check(gsx_model_download_selection(v_, key_.c_str(), w.data(), w.size()));
         return w;
     }
+    BufferClone<uint32_t> clone() const { return BufferClone<uint32_t>(v_, key_, GSX_BUFFER_SELECTION); }
 };
 using GaussianEditPod = gsx_gaussian_edit;  // gs::GaussianEditPod (app.rs:1553-1562)
 class GaussiansEditBuffer {  // gs::GaussiansEditBuffer (scene.rs:1816-1830, app.rs:789)
@@ -143,6 +164,7 @@ public:
         return e;
     }
     void upload(const std::vector<GaussianEditPod>& e) { check(gsx_model_upload_edits(v_, key_.c_str(), e.data(), e.size())); }
+    BufferClone<GaussianEditPod> clone() const { return BufferClone<GaussianEditPod>(v_, key_, GSX_BUFFER_EDITS); }  // app.rs:772
 };
 struct MultiModelViewerGaussianBuffers {
     GaussiansBuffer gaussians_buffer;

@@ -112,6 +112,14 @@ pub struct gsx_ply_header { pub count: u64, pub header_bytes: u64, pub vertex_by
 pub struct gsx_comm_group {
     _private: [u8; 0],
 }
+/// opaque: a ref-counted handle on a snapshot of one of a model's per-Gaussian buffers (gs:: buffers are `Clone`, src/app.rs:769-780)
+#[repr(C)]
+pub struct gsx_buffer {
+    _private: [u8; 0],
+}
+#[repr(i32)]
+#[derive(Clone, Copy, PartialEq, Eq)]
+pub enum gsx_buffer_kind { Mask = 0, Edits = 1, Selection = 2 }
 /// the two collectives of a caller-supplied transport: they ENQUEUE on `hip_stream` and return 0 or a gsx_status
 pub type gsx_comm_all_to_all_fn = Option<unsafe extern "C" fn(ctx: *mut c_void, d_send: *const c_void, d_recv: *mut c_void, bytes_per_peer: u64, hip_stream: *mut c_void) -> gsx_status>;
 pub type gsx_comm_all_gather_fn = Option<unsafe extern "C" fn(ctx: *mut c_void, d_send: *const c_void, d_recv: *mut c_void, bytes_per_rank: u64, hip_stream: *mut c_void) -> gsx_status>;
@@ -172,6 +180,11 @@ extern "C" {
     pub fn gsx_query_download_hits(v: *mut gsx_viewer, key: *const c_char, out: *mut gsx_query_hit, capacity: u64, out_n: *mut u64) -> gsx_status;
     pub fn gsx_query_hit_pos_by_closest(hits: *const gsx_query_hit, n: u64, view: *const f32, proj: *const f32, width: u32, height: u32, coords: *const f32, out_index: *mut u32, out_pos: *mut f32) -> gsx_status;
     pub fn gsx_query_hit_pos_by_alpha_range(hits: *const gsx_query_hit, n: u64, view: *const f32, proj: *const f32, width: u32, height: u32, coords: *const f32, range: f32, out_index: *mut u32, out_alpha: *mut f32, out_pos: *mut f32) -> gsx_status;
+    pub fn gsx_model_buffer_retain(v: *mut gsx_viewer, key: *const c_char, kind: gsx_buffer_kind, out: *mut *mut gsx_buffer) -> gsx_status;
+    pub fn gsx_buffer_retain(b: *mut gsx_buffer) -> gsx_status;
+    pub fn gsx_buffer_release(b: *mut gsx_buffer);
+    pub fn gsx_buffer_len(b: *mut gsx_buffer, out_elements: *mut u64) -> gsx_status;
+    pub fn gsx_buffer_download(b: *mut gsx_buffer, out: *mut c_void, n_elements: u64) -> gsx_status;
     pub fn gsx_shard_layout(v: *mut gsx_viewer, world: u32, rank: u32, out: *mut gsx_shard_layout_t) -> gsx_status;
     pub fn gsx_viewer_set_band(v: *mut gsx_viewer, row_lo: u32, row_hi: u32) -> gsx_status;
     pub fn gsx_viewer_set_external_framebuffer(v: *mut gsx_viewer, d_ptr: *mut c_void, bytes: u64) -> gsx_status;

@@ -96,6 +96,30 @@ impl GaussiansBuffer {
         n as usize
     }
 }
+/// What `buffer.clone()` gives in the app (app.rs:769-780: the clones are moved into spawned download threads): a handle on a
+/// device-side snapshot of the buffer taken at clone time.  `Clone` adds a reference, `Drop` releases it, `download` may run on
+/// any thread while the viewer renders (`gsx_buffer_*` in include/gsx.h).
+pub struct BufferClone<T> { h: *mut sys::gsx_buffer, _t: std::marker::PhantomData<T> }
+unsafe impl<T: Send> Send for BufferClone<T> {}
+impl<T> Clone for BufferClone<T> {
+    fn clone(&self) -> Self { unsafe { sys::gsx_buffer_retain(self.h) }; Self { h: self.h, _t: std::marker::PhantomData } }
+}
+impl<T> Drop for BufferClone<T> { fn drop(&mut self) { unsafe { sys::gsx_buffer_release(self.h) } } }
+impl<T: Copy> BufferClone<T> {
+    fn retain(v: *mut sys::gsx_viewer, key: &CString, kind: sys::gsx_buffer_kind) -> Result<Self, Error> {
+        let mut h = std::ptr::null_mut();
+        check(unsafe { sys::gsx_model_buffer_retain(v, key.as_ptr(), kind, &mut h) })?;
+        Ok(Self { h, _t: std::marker::PhantomData })
+    }
+    pub async fn download<D, Q>(&self, _device: &D, _queue: &Q) -> Result<Vec<T>, Error> {
+        let mut n = 0u64;
+        check(unsafe { sys::gsx_buffer_len(self.h, &mut n) })?;
+        let mut out: Vec<T> = Vec::with_capacity(n as usize);
+        check(unsafe { sys::gsx_buffer_download(self.h, out.as_mut_ptr() as *mut std::os::raw::c_void, n) })?;
+        unsafe { out.set_len(n as usize) };
+        Ok(out)
+    }
+}
 /// `gs::MaskBuffer` / `gs::SelectionBuffer` / `gs::GaussiansEditBuffer`: `download::<T>(&device, &queue).await` (app.rs:789, 806).
 pub struct MaskBuffer { v: *mut sys::gsx_viewer, key: CString, words: usize }
 impl MaskBuffer {
@@ -104,6 +128,8 @@ impl MaskBuffer {
         check(unsafe { sys::gsx_model_download_mask(self.v, self.key.as_ptr(), w.as_mut_ptr(), w.len() as u64) })?;
         Ok(w)
     }
+    /// `mask_buffer.clone()` (app.rs:775)
+    pub fn clone_handle(&self) -> Result<BufferClone<u32>, Error> { BufferClone::retain(self.v, &self.key, sys::gsx_buffer_kind::Mask) }
 }
 pub struct GaussiansEditBuffer { v: *mut sys::gsx_viewer, key: CString, n: usize }
 impl GaussiansEditBuffer {
@@ -113,6 +139,8 @@ impl GaussiansEditBuffer {
         unsafe { e.set_len(self.n) };
         Ok(e)
     }
+    /// `gaussians_edit_buffer.clone()` (app.rs:772)
+    pub fn clone_handle(&self) -> Result<BufferClone<GaussianEditPod>, Error> { BufferClone::retain(self.v, &self.key, sys::gsx_buffer_kind::Edits) }
 }
 /// `gs::MultiModelViewerGaussianBuffers<G>::new_empty(&device, count)` (scene.rs:2111-2112)
 pub struct MultiModelViewerGaussianBuffers {
@@ -235,6 +263,16 @@ impl<G: GaussianPod> MultiModelViewer<G> {
         let k = CString::new(key).unwrap();
         check(unsafe { sys::gsx_shard_render_frame(self.handle.0, k.as_ptr(), shard_records_max, speculate as u32, margin, radius) })
     }
+}
+impl<G: GaussianPod> MultiModelViewer<G> {
+    /// Layered models far -> near like `renderer.render` (scene.rs:2302-2314), every model index-sharded over the ranks.
+    pub fn shard_render_frame_keys(&mut self, model_render_keys: &[String], shard_records_max: &[u32], speculate: bool, margin: f32, radius: u32) -> Result<(), Error> {
+        let ks: Vec<CString> = model_render_keys.iter().map(|k| CString::new(k.as_str()).unwrap()).collect();
+        let ps: Vec<*const std::os::raw::c_char> = ks.iter().map(|k| k.as_ptr()).collect();
+        check(unsafe { sys::gsx_shard_render_frame_keys(self.handle.0, ps.as_ptr(), ps.len() as u32, shard_records_max.as_ptr(), speculate as u32, margin, radius) })
+    }
+    /// One process, one thread + one viewer per GPU: seat `rank` of an in-process group (`sys::gsx_comm_group_create`).
+    pub fn comm_init_group(&mut self, group: *mut sys::gsx_comm_group, rank: u32) -> Result<(), Error> { check(unsafe { sys::gsx_viewer_comm_init_group(self.handle.0, group, rank) }) }
 }
 pub fn comm_unique_id() -> Result<[u8; 128], Error> {
     let mut id = [0u8; 128];

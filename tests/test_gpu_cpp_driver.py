@@ -98,6 +98,7 @@ def test_cpp_facade_matches_python_mirror(tmp_path):
     assert err <= 2e-4, f"the C++ facade's frame differs from the Python mirror's: L-inf {err}"
     ms = re.search(r"selected=(\d+)", out.stdout)
     assert ms and int(ms.group(1)) == selected and selected > 50, (out.stdout, selected)
+    assert "frame_driver clones=ok" in out.stdout, out.stdout   # cloned buffer handles downloaded on spawned threads (app.rs:769-816)
     # camera matrices / the model quaternion are float32 on both sides but come from different libm calls (last-bit
     # differences), so the frames agree to rounding rather than bit-for-bit
     assert np.abs(cpp - fb).max() <= 2e-4

@@ -254,3 +254,86 @@ def test_texture_query_needs_a_texture():
             v.preprocessor.preprocess(KEY)
         with pytest.raises(GsxError):
             v.update_query_texture(np.zeros((H + 1, W), np.uint8))
+
+
+def test_cloned_buffer_handles_download_on_other_threads_while_frames_run():
+    """SURVEY 8(b) ownership: the export path clones every model's edit and mask buffer, moves the clones into two spawned
+    threads and downloads there while the UI thread keeps rendering (src/app.rs:769-816, scene.rs:635-648).  Here: handles
+    taken between frames of an un-synchronised loop (two frames in flight), downloaded by two threads while the loop goes on
+    changing the very buffers (another mask, more edits); every download equals the buffer as it was when its handle was
+    taken; a handle outlives gsx_model_remove and gsx_viewer_destroy."""
+    import threading
+
+    from wgpu_3dgs_viewer_app_amd.mask import MaskEvaluator, MaskOp, MaskShape, MaskShapeKind
+
+    n = 60000
+    g = common.small_scene(n, 77, scale_mul=8.0)
+    v = MultiModelViewer()
+    v.set_render_options(frames_in_flight=2)
+    v.add_model("m", n)
+    v.add_model("other", 1000)
+    v.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g)
+    bufs = v.models["m"].gaussian_buffers
+
+    def frame(pose):
+        v.update_camera(camera.orbit_pose(pose), (W, H))
+        v.update_gaussian_transform(1.0, GaussianDisplayMode.Splat, GaussianShDegree.new(3), False)
+        v.render_frame(["m"])
+
+    shapes = [MaskShape(MaskShapeKind.Box, pos=np.array([0.0, 0.0, 0.0], np.float32), scale=np.array([2.0, 2.0, 2.0], np.float32)),
+              MaskShape(MaskShapeKind.Ellipsoid, pos=np.array([0.5, 0.0, 0.0], np.float32), scale=np.array([1.0, 1.5, 1.0], np.float32))]
+    # untouched buffers: the gs:: defaults, without a copy
+    h0 = bufs.mask_buffer.clone(), bufs.gaussians_edit_buffer.clone(), bufs.selection_buffer.clone()
+    assert (h0[0].download() == 0xFFFFFFFF).all() and not h0[2].download().any()
+    assert (h0[1].download()["flag"] == 0).all() and h0[1].len() == n and h0[0].len() == (n + 31) // 32
+    # state A: mask `0 - 1`, a rect selection, an HSV edit of what it selected
+    MaskEvaluator(v).evaluate(MaskOp.parse("0 - 1"), "m", shapes)
+    v.update_query(query.QueryPod.rect((40.0, 30.0), (200.0, 130.0), query.QuerySelectionOp.Set))
+    frame(10)
+    v.postprocessor.postprocess("m")
+    v.update_query(query.QueryPod.none())
+    v.update_selection_edit_with_pod(query.GaussianEditPod(query.GaussianEditFlag.ENABLED, (0.3, 1.1, 0.9), 0.1, 0.2, 1.0, 0.7))
+    frame(11)
+    want_a = bufs.mask_buffer.download(), bufs.gaussians_edit_buffer.download(), bufs.selection_buffer.download()
+    assert (want_a[1]["flag"] != 0).sum() > 50 and want_a[2].any() and not (want_a[0] == 0xFFFFFFFF).all()
+    handles_a = bufs.mask_buffer.clone(), bufs.gaussians_edit_buffer.clone(), bufs.selection_buffer.clone()
+    handles_a2 = tuple(h.clone() for h in handles_a)   # a clone of a clone: one more reference on the same snapshot
+    got, errors = {}, []
+
+    def downloader(name, handles):
+        try:
+            for rep in range(3):
+                got[(name, rep)] = tuple(h.download() for h in handles)
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=downloader, args=("t1", handles_a)), threading.Thread(target=downloader, args=("t2", handles_a2))]
+    for t in threads:
+        t.start()
+    # meanwhile the owner keeps going and CHANGES all three buffers: state B
+    for k in range(12):
+        if k == 3:
+            MaskEvaluator(v).evaluate(MaskOp.parse("0 | 1"), "m", shapes)
+        if k == 5:
+            v.update_query(query.QueryPod.rect((10.0, 10.0), (120.0, 90.0), query.QuerySelectionOp.Add))
+        if k == 6:
+            v.postprocessor.postprocess("m")
+            v.update_query(query.QueryPod.none())
+            v.update_selection_edit_with_pod(query.GaussianEditPod(query.GaussianEditFlag.ENABLED | query.GaussianEditFlag.HIDDEN, (0.0, 1.0, 1.0), 0.0, 0.0, 1.0, 1.0))
+        frame(20 + k)
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for key, (mask, edits, sel) in got.items():
+        assert np.array_equal(mask, want_a[0]) and np.array_equal(sel, want_a[2]), key
+        assert edits.tobytes() == want_a[1].tobytes(), key
+    want_b = bufs.mask_buffer.download(), bufs.gaussians_edit_buffer.download(), bufs.selection_buffer.download()
+    assert not np.array_equal(want_b[0], want_a[0]) and want_b[1].tobytes() != want_a[1].tobytes()
+    handles_b = bufs.mask_buffer.clone(), bufs.gaussians_edit_buffer.clone()
+    v.remove_model("m")                       # the handles own their snapshots
+    assert np.array_equal(handles_b[0].download(), want_b[0])
+    v.close()                                 # ... and need no viewer
+    assert handles_b[1].download().tobytes() == want_b[1].tobytes()
+    assert np.array_equal(handles_a[0].download(), want_a[0])
+    for h in handles_a + handles_a2 + handles_b + h0:
+        h.release()

@@ -5,6 +5,7 @@
 // and requires the identical checksum.
 #include <cstdio>
 #include <cstring>
+#include <thread>
 
 #include "../include/gsx.hpp"
 
@@ -89,6 +90,37 @@ int main(int argc, char** argv) {
         for (auto& m : models)
             for (uint32_t word : viewer.models.at(m.key).gaussian_buffers.selection_buffer.download(m.g->size())) selected += (size_t)__builtin_popcount(word);
         printf("frame_driver selected=%zu\n", selected);
+        // the export path (app.rs:769-816): clone the selection / mask buffers, download the clones on spawned threads while this
+        // thread renders one more frame that CHANGES the selection — the clones still hold what was there when they were taken
+        {
+            auto& bufs = viewer.models.at("a").gaussian_buffers;
+            const std::vector<uint32_t> want_sel = bufs.selection_buffer.download(models[0].g->size());
+            std::vector<uint32_t> got_sel, got_sel2, got_mask;
+            {
+                auto sel_clone = bufs.selection_buffer.clone();
+                auto mask_clone = bufs.mask_buffer.clone();
+                auto sel_clone2 = sel_clone;  // Clone of a clone
+                std::thread t1([&] { got_sel = sel_clone.download(); got_mask = mask_clone.download(); });
+                std::thread t2([&] { got_sel2 = sel_clone2.download(); });
+                struct Join { std::thread& a; std::thread& b; ~Join() { a.join(); b.join(); } } join{t1, t2};
+                q.selection_op = GSX_SELECTION_REMOVE;  // meanwhile: a frame that takes the rectangle OUT of the selection again
+                viewer.update_query(q);
+                for (auto& m : models) {
+                    viewer.preprocessor.preprocess(m.key);
+                    viewer.radix_sorter.sort(m.key);
+                }
+                viewer.renderer.render(keys);
+                for (auto& m : models) viewer.postprocessor.postprocess(m.key);
+                viewer.poll();
+            }
+            size_t left = 0;
+            for (uint32_t word : bufs.selection_buffer.download(models[0].g->size())) left += (size_t)__builtin_popcount(word);
+            bool mask_all_ones = !got_mask.empty();
+            for (uint32_t wd : got_mask) mask_all_ones = mask_all_ones && wd == 0xFFFFFFFFu;
+            const bool ok = left == 0 && got_sel == want_sel && got_sel2 == want_sel && mask_all_ones;
+            printf("frame_driver clones=%s\n", ok ? "ok" : "MISMATCH");
+            if (!ok) return 6;
+        }
         // error convention: a missing model is a gs::Error, not a crash
         try { viewer.preprocessor.preprocess("missing"); return 2; } catch (const gs::Error& e) { if (e.status != GSX_ERR_NOT_FOUND) return 3; }
         if (gs::GaussianShDegree::new_(4)) return 4;

@@ -12,7 +12,7 @@ code = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
 protos = re.findall(r"^(gsx_status|void|uint32_t|const char\*)\s+(gsx_\w+)\s*\(([^;]*?)\);", code, flags=re.M | re.S)
 
 SCALAR = {"uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64", "int32_t": "i32", "float": "f32", "char": "c_char", "void": "c_void",
-          "gsx_sh_kind": "gsx_sh_kind", "gsx_cov3d_kind": "gsx_cov3d_kind", "gsx_display_mode": "gsx_display_mode", "gsx_status": "gsx_status"}
+          "gsx_sh_kind": "gsx_sh_kind", "gsx_cov3d_kind": "gsx_cov3d_kind", "gsx_display_mode": "gsx_display_mode", "gsx_status": "gsx_status", "gsx_buffer_kind": "gsx_buffer_kind"}
 
 
 def rust_type(ctype: str) -> str:
@@ -160,6 +160,14 @@ pub struct gsx_ply_header { pub count: u64, pub header_bytes: u64, pub vertex_by
 pub struct gsx_comm_group {
     _private: [u8; 0],
 }
+/// opaque: a ref-counted handle on a snapshot of one of a model's per-Gaussian buffers (gs:: buffers are `Clone`, src/app.rs:769-780)
+#[repr(C)]
+pub struct gsx_buffer {
+    _private: [u8; 0],
+}
+#[repr(i32)]
+#[derive(Clone, Copy, PartialEq, Eq)]
+pub enum gsx_buffer_kind { Mask = 0, Edits = 1, Selection = 2 }
 /// the two collectives of a caller-supplied transport: they ENQUEUE on `hip_stream` and return 0 or a gsx_status
 pub type gsx_comm_all_to_all_fn = Option<unsafe extern "C" fn(ctx: *mut c_void, d_send: *const c_void, d_recv: *mut c_void, bytes_per_peer: u64, hip_stream: *mut c_void) -> gsx_status>;
 pub type gsx_comm_all_gather_fn = Option<unsafe extern "C" fn(ctx: *mut c_void, d_send: *const c_void, d_recv: *mut c_void, bytes_per_rank: u64, hip_stream: *mut c_void) -> gsx_status>;

@@ -41,7 +41,7 @@ v = MultiModelViewer()
 v.add_model("m", n)
 v.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g)
 v.update_gaussian_transform(1.0, GaussianDisplayMode.Splat, GaussianShDegree.new(3), False)
-for lanes in (1, 2, 3):
+for lanes in (() if os.environ.get("NO_SINGLE") else (1, 2, 3)):
     print("single ", run(v, lambda vv: vv.render_frame(["m"]), lanes), flush=True)
 v.close()
 from wgpu_3dgs_viewer_app_amd.viewer import CommGroup  # noqa: E402
@@ -58,8 +58,9 @@ for transport in (os.environ.get("TRANSPORTS", "group,rccl").split(",")):
     else:
         grp = CommGroup(1)
         v.comm_init_group(grp, 0)
+    margin, radius = float(os.environ.get("MARGIN", "0.25")), int(os.environ.get("RADIUS", "3"))
     for lanes in (1, 2, 3):
-        r = run(v, lambda vv: vv.shard_render_frame("m", n), lanes)
+        r = run(v, lambda vv: vv.shard_render_frame("m", n, True, margin, radius), lanes)
         st = v.shard_stats(reset=True)
         r.update(repair_frac=round(st["repair_frames"] / max(st["frames"], 1), 3), verdict_wait_ms_per_frame=round(st["verdict_wait_ns"] / 1e6 / max(st["frames"], 1), 4),
                  slot=st["last_slot_records"])

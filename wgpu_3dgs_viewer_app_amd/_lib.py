@@ -34,6 +34,7 @@ EXPORTS = (
     "gsx_comm_all_to_all", "gsx_comm_all_gather", "gsx_shard_render_frame", "gsx_shard_render_frame_keys",
     "gsx_comm_group_create", "gsx_comm_group_destroy", "gsx_viewer_comm_init_group", "gsx_viewer_comm_init_custom",
     "gsx_shard_set_limits", "gsx_shard_set_slot_records", "gsx_shard_get_stats",
+    "gsx_model_buffer_retain", "gsx_buffer_retain", "gsx_buffer_release", "gsx_buffer_len", "gsx_buffer_download",
     "gsx_gaussian_edit_default", "gsx_update_query", "gsx_update_query_texture", "gsx_update_selection_highlight",
     "gsx_update_selection_edit", "gsx_model_show_unedited", "gsx_postprocess", "gsx_model_upload_selection",
     "gsx_model_download_selection", "gsx_model_download_edits", "gsx_model_upload_edits", "gsx_query_download_hits",
@@ -208,6 +209,11 @@ def load() -> C.CDLL:
         "gsx_shard_set_limits": ([vp, cp, vp], C.c_int32),
         "gsx_shard_set_slot_records": ([vp, cp, u32], C.c_int32),
         "gsx_shard_get_stats": ([vp, C.POINTER(ShardStats), u32], C.c_int32),
+        "gsx_model_buffer_retain": ([vp, cp, C.c_int, C.POINTER(vp)], C.c_int32),
+        "gsx_buffer_retain": ([vp], C.c_int32),
+        "gsx_buffer_release": ([vp], None),
+        "gsx_buffer_len": ([vp, C.POINTER(u64)], C.c_int32),
+        "gsx_buffer_download": ([vp, vp, u64], C.c_int32),
         "gsx_set_pass_timing": ([vp, u32], C.c_int32),
         "gsx_get_pass_timing": ([vp, f32p, u32p], C.c_int32),
     }

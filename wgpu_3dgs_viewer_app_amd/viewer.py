@@ -112,6 +112,50 @@ class GaussiansBuffer:
         return pos, color, sh, cov
 
 
+class BufferHandle:
+    """A cloned buffer handle (``buffer.clone()`` in the app, src/app.rs:769-780): owns a device-side snapshot of the buffer as
+    of the clone; ``download()`` may run on any thread while the viewer keeps rendering (``gsx_buffer_*``)."""
+
+    KINDS = {"mask": 0, "edits": 1, "selection": 2}
+
+    def __init__(self, viewer: "MultiModelViewer", key: str, kind: str):
+        self._L, self.kind = viewer._L, kind
+        self._h = C.c_void_p()
+        _lib.check(self._L.gsx_model_buffer_retain(viewer._h, key.encode(), self.KINDS[kind], C.byref(self._h)))
+
+    def clone(self) -> "BufferHandle":
+        other = object.__new__(BufferHandle)
+        other._L, other.kind, other._h = self._L, self.kind, C.c_void_p(self._h.value)
+        _lib.check(self._L.gsx_buffer_retain(self._h))
+        return other
+
+    def len(self) -> int:
+        n = C.c_uint64()
+        _lib.check(self._L.gsx_buffer_len(self._h, C.byref(n)))
+        return int(n.value)
+
+    def download(self) -> np.ndarray:
+        if self.kind == "edits":
+            from .query import EDIT_DTYPE
+
+            out = np.zeros(self.len(), EDIT_DTYPE)
+        else:
+            out = np.empty(self.len(), np.uint32)
+        _lib.check(self._L.gsx_buffer_download(self._h, out.ctypes.data, out.size))
+        return out
+
+    def release(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.gsx_buffer_release(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
 class MaskBuffer:
     """``gs::MaskBuffer``: one bit per Gaussian, 1 = kept (src/tab/scene.rs:1851, src/app.rs:806-807)."""
 
@@ -130,6 +174,10 @@ class MaskBuffer:
         w = np.empty(n, np.uint32)
         _lib.check(self._v._L.gsx_model_download_mask(self._v._h, self._key.encode(), _u32p(w), n))
         return w
+
+    def clone(self) -> BufferHandle:
+        """``mask_buffer.clone()`` (src/app.rs:775): a handle for a download on another thread."""
+        return BufferHandle(self._v, self._key, "mask")
 
 
 class SelectionBuffer:
@@ -151,6 +199,9 @@ class SelectionBuffer:
         _lib.check(self._v._L.gsx_model_download_selection(self._v._h, self._key.encode(), _u32p(w), n))
         return w
 
+    def clone(self) -> BufferHandle:
+        return BufferHandle(self._v, self._key, "selection")
+
 
 class GaussiansEditBuffer:
     """``gs::GaussiansEditBuffer``: one ``GaussianEditPod`` per Gaussian (src/tab/scene.rs:1816-1830, app.rs:789)."""
@@ -165,6 +216,10 @@ class GaussiansEditBuffer:
         out = np.zeros(n, EDIT_DTYPE)
         _lib.check(self._v._L.gsx_model_download_edits(self._v._h, self._key.encode(), out.ctypes.data, n))
         return out
+
+    def clone(self) -> BufferHandle:
+        """``gaussians_edit_buffer.clone()`` (src/app.rs:772): a handle for a download on another thread."""
+        return BufferHandle(self._v, self._key, "edits")
 
     def upload(self, edits: np.ndarray | None) -> None:
         from .query import EDIT_DTYPE
