@@ -255,15 +255,22 @@ def project(view, proj, width, height, pos, color_u32, sh, cov3d, m_pos=(0, 0, 0
                 opacity=opacity, rgb=rgb, pix_aabb=np.stack([x0, y0, x1, y1], 1))
 
 
-def render(view, proj, width, height, models, size=1.0, display_mode=0, sh_deg=3, no_sh0=0, params=None):
+def render(view, proj, width, height, models, size=1.0, display_mode=0, sh_deg=3, no_sh0=0, params=None, ambiguity_tol=None):
     """Full frame.  ``models`` = list of dicts(pos,color,sh,cov3d[,m_pos,m_quat,m_scale,mask]) in the
     reference's paint order FAR -> NEAR (src/tab/scene.rs:533-558).  Returns float64 [H,W,4] =
-    premultiplied rgb + transmittance."""
+    premultiplied rgb + transmittance.
+
+    ambiguity_tol (optional): also returns, per pixel, how much of the frame hangs on support decisions `q <= k^2` that are
+    closer than ``ambiguity_tol`` to the cut.  The cut is a discontinuity of the spec itself: a contribution of
+    opacity x exp(-k^2 / 2) (1.1 % at k = 3) is in or out, and an implementation in another precision may decide a pair that
+    close the other way.  Per such pair the pixel's allowance grows by 2 x T x alpha x max(1, |rgb|) — its own contribution plus
+    what the changed transmittance does to everything behind it."""
     P_ = dict(DEFAULT_PARAMS)
     P_.update(params or {})
     k2 = P_["max_std_dev"] ** 2
     C = np.zeros((height, width, 3))
     T = np.ones((height, width))
+    amb = np.zeros((height, width)) if ambiguity_tol is not None else None
     ys, xs = np.mgrid[0:height, 0:width]
     px, py = xs + 0.5, ys + 0.5
     for mdl in reversed(models):  # front-to-back across models: nearest model first
@@ -289,6 +296,52 @@ def render(view, proj, width, height, models, size=1.0, display_mode=0, sh_deg=3
             al = np.minimum(P_["alpha_max"], pr["opacity"][i] * wgt)
             al = np.where((q <= k2) & (al >= P_["alpha_min"]), al, 0.0)
             Tl = T[y0:y1, x0:x1]
+            if amb is not None:
+                edge = np.abs(q - k2) < ambiguity_tol
+                if edge.any():
+                    a_edge = np.minimum(P_["alpha_max"], pr["opacity"][i] * wgt)
+                    amb[y0:y1, x0:x1] += np.where(edge, 2.0 * Tl * a_edge * max(1.0, float(np.abs(pr["rgb"][i]).max())), 0.0)
             C[y0:y1, x0:x1] += (Tl * al)[..., None] * pr["rgb"][i]
             T[y0:y1, x0:x1] = Tl * (1 - al)
-    return np.concatenate([C, T[..., None]], 2)
+    frame = np.concatenate([C, T[..., None]], 2)
+    return (frame, amb) if amb is not None else frame
+
+
+def alpha_min_margin(view, proj, width, height, models, size=1.0, display_mode=0, sh_deg=3, no_sh0=0, params=None):
+    """Smallest relative distance |alpha / alpha_min - 1| over the contributions that matter (T x colour above 1e-4 at that
+    pixel) of the frame ``render`` would produce: how safely a float32 implementation reproduces the `alpha >= alpha_min`
+    decisions (tests/golden/make_golden.py keeps a fixture only if this is comfortably above float32 rounding)."""
+    P_ = dict(DEFAULT_PARAMS)
+    P_.update(params or {})
+    k2 = P_["max_std_dev"] ** 2
+    T = np.ones((height, width))
+    ys, xs = np.mgrid[0:height, 0:width]
+    px, py = xs + 0.5, ys + 0.5
+    best = np.inf
+    for mdl in reversed(models):
+        pr = project(view, proj, width, height, mdl["pos"], mdl["color"], mdl.get("sh"), mdl["cov3d"],
+                     mdl.get("m_pos", (0, 0, 0)), mdl.get("m_quat", (0, 0, 0, 1)), mdl.get("m_scale", (1, 1, 1)),
+                     size, display_mode, sh_deg, no_sh0, params, mdl.get("mask"), mdl.get("selection"), mdl.get("sel_edit"),
+                     mdl.get("highlight"))
+        idx = np.nonzero(pr["visible"])[0]
+        order = idx[np.lexsort((idx, pr["depth"][idx].astype(np.float32)))]
+        for i in order:
+            mx, my = pr["mean2d"][i]
+            a, b, c = pr["cov2d"][i]
+            ex, ey = np.sqrt(k2 * a), np.sqrt(k2 * c)
+            x0, x1 = int(max(np.floor(mx - ex - 1), 0)), int(min(np.ceil(mx + ex + 1), width))
+            y0, y1 = int(max(np.floor(my - ey - 1), 0)), int(min(np.ceil(my + ey + 1), height))
+            if x0 >= x1 or y0 >= y1:
+                continue
+            dx, dy = px[y0:y1, x0:x1] - mx, py[y0:y1, x0:x1] - my
+            ca, cb, cc = pr["conic"][i]
+            q = ca * dx * dx + cc * dy * dy + 2 * cb * dx * dy
+            wgt = np.exp(-0.5 * q) if display_mode == 0 else np.ones_like(q)
+            raw = np.minimum(P_["alpha_max"], pr["opacity"][i] * wgt)
+            Tl = T[y0:y1, x0:x1]
+            matters = (q <= k2) & (Tl * max(float(np.abs(pr["rgb"][i]).max()), 1.0) * P_["alpha_min"] > 1e-4)
+            if matters.any():
+                best = min(best, float(np.abs(raw[matters] / P_["alpha_min"] - 1.0).min()))
+            al = np.where((q <= k2) & (raw >= P_["alpha_min"]), raw, 0.0)
+            T[y0:y1, x0:x1] = Tl * (1 - al)
+    return best

@@ -15,6 +15,11 @@ Fixture keys (i = model index in load order):
   pod_kind = (sh_kind, cov_kind), sh_q{i}, cov_q{i}   compressed pod: the exact dequantisation of what is stored
   mask_expr, mask_shapes [k, 11] = kind pos3 quat4 scale3, mask_words{i}, mask_margin{i}
   selection_words{i}, sel_edit = flag color3 contrast exposure gamma alpha, highlight = r g b a
+  params_<name>                                  gsx_spec_params that differ from the defaults (spec/RENDER_SPEC.md [BUILD-SPEC] constants)
+  frame_ambiguity, ambiguity_tol                 (large fixtures) per pixel: how much of the value hangs on support decisions q <= k^2 closer
+                                                 than ambiguity_tol to the cut — a discontinuity of the spec (oracle/spec_f64.render)
+  prior_view, prior_proj                         (large fixtures) another camera: a frame rendered from it first leaves windows that are
+                                                 wrong for this one, so the speculated frame needs its repair round
 """
 import os
 import sys
@@ -39,7 +44,8 @@ def pod_f64(g):
     return g["pos"].copy(), color, g["sh"].reshape(-1, 45).copy(), cov
 
 
-def make(name, models, cam, w, h, pod=None, mask=None, selection=None, sel_edit=None, highlight=None, **kw):
+def make(name, models, cam, w, h, pod=None, mask=None, selection=None, sel_edit=None, highlight=None, params=None, prior_cam=None,
+         ambiguity_tol=None, **kw):
     """pod = (sh_kind, cov_kind); mask = (expression, [dict(kind, pos, quat, scale)]) applied to every model;
     selection = seed of a random selection bitset (every model); sel_edit = dict(flag, color, contrast, exposure, gamma, alpha);
     highlight = (r, g, b, a); kw: size, display_mode, sh_deg, no_sh0."""
@@ -55,6 +61,12 @@ def make(name, models, cam, w, h, pod=None, mask=None, selection=None, sel_edit=
                                     sel_edit["gamma"], sel_edit["alpha"]], np.float32)
     if highlight:
         out["highlight"] = np.array(highlight, np.float32)
+    if params:
+        kw = dict(kw, params=params)
+        for k, v in params.items():
+            out[f"params_{k}"] = np.array(v, np.float32)
+    if prior_cam is not None:
+        out["prior_view"], out["prior_proj"] = prior_cam.view(), prior_cam.projection(w / h)
     spec_models = []
     for i, (g, mt) in enumerate(models):
         pos, color, sh, cov = pod_f64(g)
@@ -91,10 +103,25 @@ def make(name, models, cam, w, h, pod=None, mask=None, selection=None, sel_edit=
     # paint order far -> near by centre distance (scene.rs:533-558)
     keys = camera.model_render_order(cam.pos, {i: mt.world_center() for i, (_, mt) in enumerate(models)})
     out["paint_order"] = np.array(keys)
-    frame = spec_f64.render(view, proj, w, h, [spec_models[k] for k in keys], **kw)
+    if ambiguity_tol is not None:
+        frame, amb = spec_f64.render(view, proj, w, h, [spec_models[k] for k in keys], ambiguity_tol=ambiguity_tol, **kw)
+        out["frame_ambiguity"] = amb.astype(np.float32)
+        out["ambiguity_tol"] = np.array(ambiguity_tol)
+        print(name, "pixels whose value hangs on a support decision within", ambiguity_tol, "of the cut by more than 1e-4:",
+              int((amb > 1e-4).sum()), "of", amb.size, "max allowance", float(amb.max()))
+    else:
+        frame = spec_f64.render(view, proj, w, h, [spec_models[k] for k in keys], **kw)
     out["frame"] = frame.astype(np.float32)
     for k, v in kw.items():
-        out[f"kw_{k}"] = np.array(v)
+        if k != "params":
+            out[f"kw_{k}"] = np.array(v)
+    if params and params.get("alpha_min", 0.0) > 0.0:
+        # alpha_min > 0 makes a visibility decision depend on exp(): a float32 implementation may decide a contribution that sits
+        # within its rounding of the threshold the other way (up to alpha_min x colour on that pixel).  The fixture is only kept
+        # if no contribution that matters comes that close.
+        margin = spec_f64.alpha_min_margin(view, proj, w, h, [spec_models[k] for k in keys], **kw)
+        assert margin > 3e-5, f"{name}: a contribution lies within {margin:.1e} (relative) of alpha_min; pick another seed"
+        out["alpha_min_margin"] = np.array(margin)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k in ("frame", "g0")},
           "mean T", float(frame[..., 3].mean()), "visible", [int(out[f"visible{i}"].sum()) for i in range(len(models))])
@@ -167,6 +194,17 @@ if __name__ == "__main__":
                   dict(kind=0, pos=(-0.8, 0.2, 0.1), quat=tuple(camera.quat_from_euler_zyx(0.1, 0.7, -0.2)), scale=(1.0, 1.5, 2.0))]
         make("frame_pod_half_half_mask_union_96x64_n600_seed114", [(scene_small(600, 114), ident)], camera.orbit_pose(45), 96, 64,
              pod=(1, 1), mask=("0 | 1", shapes))
+    # round 3: a fixture the DEFAULT pipeline meets at full strength — 320 x 240 = 300 tiles (> 256: blocks of several tiles),
+    # two layered models, opaque enough that most tiles saturate (speculation, depth slabs, and — rendered after a frame from
+    # `prior_cam` — a repair round); and one on INRIA-convention constants (alpha_max 0.99, alpha_min 1/255, k = 3), the values
+    # SURVEY 8c expects the real crate to use, so that a later reconciliation has a float64 anchor
+    if want("large"):
+        make("frame_large_2models_320x240_seed201",
+             [(scene_small(5500, 201, 3, 8.0), odd), (scene_small(4500, 202, 3, 8.0), camera.ModelTransform(pos=np.array([0.4, 0.1, 1.2], np.float32)))],
+             camera.orbit_pose(40), 320, 240, prior_cam=camera.orbit_pose(100), ambiguity_tol=1e-3)
+    if want("inria_params"):
+        make("frame_inria_params_96x64_n600_seed204", [(scene_small(600, 204), odd)], camera.orbit_pose(25), 96, 64,
+             params=dict(alpha_max=0.99, alpha_min=1.0 / 255.0, max_std_dev=3.0))
     if want("3models"):
         make("frame_sh3_3models_layered_112x80_seed115",
              [(scene_small(350, 115), odd), (scene_small(300, 116), camera.ModelTransform(pos=np.array([0.0, 0.4, -1.2], np.float32))),

@@ -31,6 +31,13 @@ class Fixture:
         self.sel_edit = z["sel_edit"] if "sel_edit" in z else None
         self.highlight = z["highlight"] if "highlight" in z else None
         self.frame = z["frame"]
+        # gsx_spec_params that differ from the defaults (spec/RENDER_SPEC.md [BUILD-SPEC] constants), e.g. the INRIA conventions
+        self.params = {k[len("params_"):]: float(z[k]) for k in z.files if k.startswith("params_")}
+        self.prior = (z["prior_view"], z["prior_proj"]) if "prior_view" in z else None
+        # large fixtures: per-pixel allowance for support decisions q <= k^2 that lie within ambiguity_tol of the cut — the cut is
+        # a discontinuity of the spec (1.1 % of opacity x colour at k = 3), decided differently by implementations of different
+        # precision for pairs that close (oracle/spec_f64.render); None for the small fixtures, which hold no such pair that matters
+        self.ambiguity = z["frame_ambiguity"] if "frame_ambiguity" in z else None
 
     def gaussians(self, k):
         return self.z[f"g{k}"]
@@ -90,7 +97,11 @@ class Fixture:
             np.testing.assert_allclose(pr["conic_opacity"][vis, 3], z[f"opacity{k}"][vis], atol=1e-6)
 
     def check_frame(self, fb, tight):
-        err = float(np.abs(fb - self.frame).max())
+        diff = np.abs(fb - self.frame)
+        if self.ambiguity is not None:
+            assert (self.ambiguity > 1e-4).mean() < 0.02, "too much of the fixture hangs on near-cut support decisions"
+            diff = np.maximum(diff - self.ambiguity[..., None], 0.0)
+        err = float(diff.max())
         assert err <= FRAME_TOL, f"{self.name}: frame L-inf {err} > {FRAME_TOL}"
         assert err <= tight, f"{self.name}: frame L-inf {err}: drifted from the float64 spec (expected <= {tight})"
         return err

@@ -44,8 +44,13 @@ def test_c_oracle_matches_golden_fixture(path):
             got = mask.copy()
             got[-1] &= tail
             assert np.array_equal(got, ref), "mask words differ from the float64 spec"
+        params = None
+        if fx.params:
+            params = oracle.SpecParams.default()
+            for name, val in fx.params.items():
+                setattr(params, name, val)
         f = oracle.frame_setup(fx.view, fx.proj, fx.w, fx.h, mp, mq, ms, size=fx.size, display_mode=fx.display_mode,
-                               sh_deg=fx.sh_deg, no_sh0=fx.no_sh0)
+                               sh_deg=fx.sh_deg, no_sh0=fx.no_sh0, params=params)
         pr = oracle.project(f, pos, color, None if fx.pod[0] == 3 else sh, cov, mask)
         if fx.selection_words(k) is not None:
             oracle.edit_pass(pr, fx.selection_words(k), default_edits(n), fx.edit_pod(), fx.highlight if fx.highlight is not None else (0, 0, 0, 0))
