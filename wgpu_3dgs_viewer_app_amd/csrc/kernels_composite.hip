@@ -17,14 +17,11 @@
 
 namespace gsx {
 
-#ifndef GSX_VAR_COMP_BATCH
-#define GSX_VAR_COMP_BATCH 128
-#endif
 #ifndef GSX_VAR_COMP_GROUP
 #define GSX_VAR_COMP_GROUP 4
 #endif
-constexpr int kBatch = GSX_VAR_COMP_BATCH;   // splat records staged through LDS per barrier pair
-constexpr int kGroup = GSX_VAR_COMP_GROUP;   // splats blended between two wave-level exit checks (tools/build_variant.sh)
+constexpr int kBatch = 128;                  // splat records staged through LDS per barrier pair (256 measured: no gain)
+constexpr int kGroup = GSX_VAR_COMP_GROUP;   // splats blended between two wave-level exit checks (A/B: tools/build_variant.sh)
 constexpr int kPerLane = kBatch / 128;
 
 typedef float v2f __attribute__((ext_vector_type(2)));

@@ -15,19 +15,6 @@
 #include "project_math.h"
 #include "window_scan.h"
 
-#ifndef GSX_VAR_SH_STREAM
-#define GSX_VAR_SH_STREAM 1
-#endif
-#ifndef GSX_VAR_NT_STORE
-#define GSX_VAR_NT_STORE 1
-#endif
-#ifndef GSX_VAR_FULLW
-#define GSX_VAR_FULLW 1
-#endif
-#ifndef GSX_VAR_PROJ_WAVES
-#define GSX_VAR_PROJ_WAVES 0
-#endif
-
 namespace gsx {
 
 // ------------------------------------------------------------------------------------------------
@@ -321,22 +308,14 @@ __device__ inline uint32_t ld_stream(const uint32_t* p) { return __builtin_nonte
 // Streaming stores of the projection records: written once, 440 MB per frame at 10 M Gaussians, read back sparsely much
 // later.  tools/bench_hbm.hip (14 planes read + 3 written, this pass's shape): 0.500 ms with default stores, 0.462 ms with
 // non-temporal ones — a write costs this part about twice a read, and write-allocating L2 / Infinity Cache lines for data
-// nobody reads soon makes it worse.  And every lane stores (GSX_VAR_FULLW): culled Gaussians write a record nobody reads
+// nobody reads soon makes it worse.  And every lane stores: culled Gaussians write a record nobody reads
 // (key = kCulledKey marks it), so that a wave always writes whole 128-byte lines — with ~15 % of the lanes masked nearly
 // every line was a partial write: k_project<3,0,0> 516 -> 471 us on cfg4 (A/B on one box), at 8 % more bytes written.
 __device__ inline void st_stream(float4* p, float4 v) {
-#if GSX_VAR_NT_STORE
     __builtin_nontemporal_store(gsx_f4v{v.x, v.y, v.z, v.w}, reinterpret_cast<gsx_f4v*>(p));
-#else
-    *p = v;
-#endif
 }
 __device__ inline void st_stream(uint32_t* p, uint32_t v) {
-#if GSX_VAR_NT_STORE
     __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
 }
 
 // SHK / COVK: storage of the SH and cov3d planes (gsx_sh_kind / gsx_cov3d_kind); dequantisation is exact
@@ -368,7 +347,6 @@ template <int DEG, int SHK, bool AOS>
 __device__ inline void load_shade(const FrameConsts& f, const PodPlanes& pod, uint32_t n, uint32_t i, const float4& pc,
                                   float& r, float& g, float& b) {
     constexpr int kFloats = ShNeed<DEG>::floats;
-#if GSX_VAR_SH_STREAM
     // every SH float is consumed as it arrives (ShStream, project_math.h): same value as pm_color, 45 fewer live registers
     ShStream<DEG> st;
     st.begin(f, pc.x, pc.y, pc.z, __float_as_uint(pc.w));
@@ -415,53 +393,13 @@ __device__ inline void load_shade(const FrameConsts& f, const PodPlanes& pod, ui
         }
     }
     st.finish(r, g, b);
-    return;
-#endif
-    float s[48];
-    if (SHK == GSX_SH_SINGLE) {
-#pragma unroll
-        for (int p = 0; p < ShNeed<DEG>::planes4; ++p) {
-            if (AOS) {
-                const uint4 v = pod.sh_aos[(uint64_t)i * pod.aos_stride + p];
-                s[4 * p] = __uint_as_float(v.x); s[4 * p + 1] = __uint_as_float(v.y);
-                s[4 * p + 2] = __uint_as_float(v.z); s[4 * p + 3] = __uint_as_float(v.w);
-            } else {
-                const float4 v = ld_stream(&pod.sh4[(uint64_t)p * n + i]);
-                s[4 * p] = v.x; s[4 * p + 1] = v.y; s[4 * p + 2] = v.z; s[4 * p + 3] = v.w;
-            }
-        }
-        if (DEG == 3) s[44] = AOS ? __uint_as_float(pod.sh_aos[(uint64_t)i * pod.aos_stride + 11].x) : ld_stream(&pod.sh1[i]);
-    } else if (SHK == GSX_SH_HALF) {
-#pragma unroll
-        for (int p = 0; p < (kFloats + 7) / 8; ++p) {
-            const uint4 v = AOS ? pod.sh_aos[(uint64_t)i * 6 + p] : ld_stream(&pod.sh_h[(uint64_t)p * n + i]);
-            s[8 * p] = h_lo(v.x); s[8 * p + 1] = h_hi(v.x); s[8 * p + 2] = h_lo(v.y); s[8 * p + 3] = h_hi(v.y);
-            s[8 * p + 4] = h_lo(v.z); s[8 * p + 5] = h_hi(v.z); s[8 * p + 6] = h_lo(v.w); s[8 * p + 7] = h_hi(v.w);
-        }
-    } else if (SHK == GSX_SH_NORM8) {
-#pragma unroll
-        for (int p = 0; p < (kFloats + 15) / 16; ++p) {
-            const uint4 v = AOS ? pod.sh_aos[(uint64_t)i * 3 + p] : ld_stream(&pod.sh_q[(uint64_t)p * n + i]);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int bb = 0; bb < 4; ++bb) s[16 * p + 4 * k + bb] = dq_snorm8(w[k], bb);
-        }
-    }
-    pm_color<DEG>(f, pc.x, pc.y, pc.z, __float_as_uint(pc.w), s, r, g, b);
 }
 
 // (adm.lazy — geometry only, nobody shaded here: the SH planes, 180 of the pod's 220 bytes, are not read and no conic /
 // colour record is written — is a kernel of its own, k_project_geom below; k_shade then shades the Gaussians the admission
 // let through, a few per cent of the visible ones, and later the few more the repair round turns out to need.)
-#if GSX_VAR_PROJ_WAVES
-#define GSX_PROJ_ATTR __attribute__((amdgpu_waves_per_eu(GSX_VAR_PROJ_WAVES, GSX_VAR_PROJ_WAVES)))
-#else
-#define GSX_PROJ_ATTR
-#endif
 template <int DEG, int SHK, int COVK>
-__global__ __launch_bounds__(256) GSX_PROJ_ATTR void k_project(const FrameConsts f, const uint32_t n, const PodPlanes pod,
+__global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint32_t n, const PodPlanes pod,
                                                   const Records rec, uint32_t* __restrict__ block_visible,
                                                   const ProjectAdmission adm) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -489,11 +427,9 @@ __global__ __launch_bounds__(256) GSX_PROJ_ATTR void k_project(const FrameConsts
 
     if (i < n) {
         st_stream(&rec.key[i], vis ? __float_as_uint(vc.d) : kCulledKey);
-        if (vis || GSX_VAR_FULLW) st_stream(&rec.a[i], make_float4(sp.mx, sp.my, __uint_as_float(sp.rx), __uint_as_float(sp.ry)));
-        if (shade || GSX_VAR_FULLW) {
-            st_stream(&rec.b[i], make_float4(sp.con_a, sp.con_b, sp.con_c, (float)(color >> 24) * (1.0f / 255.0f)));
-            st_stream(&rec.c[i], make_float4(r, g, b, vc.d));
-        }
+        st_stream(&rec.a[i], make_float4(sp.mx, sp.my, __uint_as_float(sp.rx), __uint_as_float(sp.ry)));
+        st_stream(&rec.b[i], make_float4(sp.con_a, sp.con_b, sp.con_c, (float)(color >> 24) * (1.0f / 255.0f)));
+        st_stream(&rec.c[i], make_float4(r, g, b, vc.d));
     }
     __shared__ uint32_t wave_cnt[4], wave_adm[4];
     const unsigned long long bal = __ballot(vis);
@@ -519,9 +455,7 @@ __global__ __launch_bounds__(256) GSX_PROJ_ATTR void k_project(const FrameConsts
 // 39 K-workgroup launch costs 9 us of dispatch — was slower: 131-166 us at 2048-16384 workgroups; the dispatcher streams
 // workgroups better than a loop with a barrier per group.)  A workgroup covers PER consecutive 256-Gaussian groups and writes their
 // ballots / counts exactly where PER workgroups of k_project would.
-#ifndef GSX_VAR_PROJ_PER
-#define GSX_VAR_PROJ_PER 1
-#endif
+constexpr int kProjGeomPer = 1;  // Gaussians per lane of the geometry-only kernel (2 and 4 measured: no gain)
 template <int COVK, int PER>
 __global__ __launch_bounds__(256) void k_project_geom(const FrameConsts f, const uint32_t n, const PodPlanes pod,
                                                        const Records rec, uint32_t* __restrict__ block_visible,
@@ -580,7 +514,7 @@ __global__ __launch_bounds__(256) void k_project_geom(const FrameConsts f, const
             if (rec.rect8) {  // four bytes instead of sixteen: k_shade writes the `a` record of the Gaussians it visits
                 const uint32_t rx = sp[k].rx, ry = sp[k].ry;
                 st_stream(&rec.rect8[i], vis[k] ? ((rx & 0xFFu) | ((ry & 0xFFu) << 8) | ((rx >> 16) << 16) | ((ry >> 16) << 24)) : 0u);
-            } else if (vis[k] || GSX_VAR_FULLW) {
+            } else {
                 st_stream(&rec.a[i], make_float4(sp[k].mx, sp[k].my, __uint_as_float(sp[k].rx), __uint_as_float(sp[k].ry)));
             }
         }
@@ -702,7 +636,7 @@ static void launch_project_deg(hipStream_t s, dim3 grid, int deg, const FrameCon
     if (late)                                                                                                                \
         hipLaunchKernelGGL((k_shade<D, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, late->pairs, late->d_n, late->shaded, late->write_a ? 1 : 0); \
     else if (adm.lazy)                                                                                                       \
-        hipLaunchKernelGGL((k_project_geom<COVK, GSX_VAR_PROJ_PER>), dim3((grid.x + GSX_VAR_PROJ_PER - 1) / GSX_VAR_PROJ_PER), \
+        hipLaunchKernelGGL((k_project_geom<COVK, kProjGeomPer>), dim3((grid.x + kProjGeomPer - 1) / kProjGeomPer), \
                            block, 0, s, f, n, pod, rec, bv, adm);                                                            \
     else                                                                                                                     \
         hipLaunchKernelGGL((k_project<D, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv, adm)

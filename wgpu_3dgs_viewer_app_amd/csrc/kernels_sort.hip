@@ -32,19 +32,13 @@ namespace gsx {
 
 constexpr int kRadixThreads = 256;
 constexpr int kRadixWaves = kRadixThreads / 64;
-#ifndef GSX_VAR_RADIX_ROUNDS
-#define GSX_VAR_RADIX_ROUNDS 16
-#endif
-constexpr int kRadixRounds = GSX_VAR_RADIX_ROUNDS;        // elements per lane
+constexpr int kRadixRounds = 16;                          // elements per lane
 constexpr int kRadixTile = kRadixThreads * kRadixRounds;  // 4096 elements per tile
 constexpr int kWaveChunk = 64 * kRadixRounds;             // 1024 contiguous elements per wave
 constexpr uint32_t kRadixGrid = 768;                      // persistent workgroups = resident capacity (3 per CU);
                                                           // measured best of 128..1024 on MI355X
 constexpr uint32_t kMaxPasses = 4;
-#ifndef GSX_VAR_LOOK
-#define GSX_VAR_LOOK 4
-#endif
-constexpr int kLook = GSX_VAR_LOOK;                       // predecessors examined per look-back round trip
+constexpr int kLook = 4;                                  // predecessors examined per look-back round trip (2 and 8 measured)
 
 constexpr unsigned long long kFlagAggregate = 1, kFlagPrefix = 2;
 
