@@ -95,7 +95,7 @@ int main(int argc, char** argv) {
         t1 = std::max(t1, hp[8ull * t + 5]);
         for (int p = 0; p < 5; ++p) ph[p] += (double)(hp[8ull * t + p + 1] - hp[8ull * t + p]);
     }
-    printf("last pass: %u tiles, span %.1f us; mean per tile (us): load+rank %.2f, publish %.2f, look-back %.2f, LDS reorder %.2f, write %.2f\n",
+    printf("last pass: %u tiles, span %.1f us; mean per tile (us): load+rank %.2f, publish %.2f, LDS reorder %.2f, look-back %.2f, write %.2f\n",
            tiles, (t1 - t0) / 100.0, ph[0] / tiles / 100, ph[1] / tiles / 100, ph[2] / tiles / 100, ph[3] / tiles / 100, ph[4] / tiles / 100);
     for (uint32_t t : {0u, 1u, tiles / 4, tiles / 2, tiles - 1}) {
         printf("  tile %5u: start +%.1f us:", t, (hp[8ull * t] - t0) / 100.0);

@@ -21,7 +21,11 @@ namespace gsx {
 #define GSX_VAR_COMP_GROUP 4
 #endif
 constexpr int kBatch = 128;                  // splat records staged through LDS per barrier pair (256 measured: no gain)
-constexpr int kGroup = GSX_VAR_COMP_GROUP;   // splats blended between two wave-level exit checks (A/B: tools/build_variant.sh)
+constexpr int kGroupTiles = GSX_VAR_COMP_GROUP;  // splats blended between two wave-level exit checks, per-tile lists (A/B: tools/build_variant.sh)
+#ifndef GSX_VAR_BLK_GROUP
+#define GSX_VAR_BLK_GROUP 4
+#endif
+constexpr int kGroupBlocks = GSX_VAR_BLK_GROUP;  // ... block lists
 constexpr int kPerLane = kBatch / 128;
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -32,7 +36,7 @@ __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elem
 // Blends the first `cnt` records of the LDS batch (slots up to the next multiple of kGroup must hold records no pixel
 // supports) into this lane's two pixels.  Groups of kGroup splats, straight-line, one skip branch per splat; a wave whose
 // pixels are all saturated leaves the batch at the next group.
-template <int MODE>
+template <int MODE, int kGroup>
 __device__ __forceinline__ void blend_batch(const FrameConsts& f, const uint32_t cnt, const float2* s_mean, const float4* s_conic,
                                             const float4* s_rgb, const float pxf, const v2f pyf, uint32_t& lim0, uint32_t& lim1,
                                             v2f& T, v2f& C0, v2f& C1, v2f& C2, uint32_t& stop_key) {
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(128) void k_composite(const FrameConsts f, uint2* _
             }
         }
         const uint32_t cnt = min((uint32_t)kBatch, range.y - base);
-        blend_batch<MODE>(f, cnt, s_mean, s_conic, s_rgb, pxf, pyf, lim0, lim1, T, C0, C1, C2, stop_key);
+        blend_batch<MODE, kGroupTiles>(f, cnt, s_mean, s_conic, s_rgb, pxf, pyf, lim0, lim1, T, C0, C1, C2, stop_key);
     }
     if (in0) fb[fbo] = make_float4(C0.x, C1.x, C2.x, T.x);
     if (in1) fb[fbo + f.w_px] = make_float4(C0.y, C1.y, C2.y, T.y);
@@ -228,9 +232,9 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
                                                            uint32_t* __restrict__ tile_sat, const uint2* __restrict__ window,
                                                            const uint32_t row_lo, const uint32_t row_hi, const uint32_t bsx,
                                                            const uint32_t bsy, const uint32_t blocks_x) {
-    __shared__ float2 s_mean[kChunk + kGroup];
-    __shared__ float4 s_conic[kChunk + kGroup];
-    __shared__ float4 s_rgb[kChunk + kGroup];
+    __shared__ float2 s_mean[kChunk + kGroupBlocks];
+    __shared__ float4 s_conic[kChunk + kGroupBlocks];
+    __shared__ float4 s_rgb[kChunk + kGroupBlocks];
     __shared__ uint32_t s_sat, s_w[2][kCand];
 
     const uint32_t tile = blockIdx.x;
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
             }
             cnt += w0 + w1;
         }
-        if (tid < (uint32_t)kGroup) {  // the blend loop runs in whole groups
+        if (tid < (uint32_t)kGroupBlocks) {  // the blend loop runs in whole groups
             s_mean[cnt + tid] = make_float2(3.0e38f, 3.0e38f);
             s_conic[cnt + tid] = make_float4(1.0f, 0.0f, 1.0f, 0.0f);
             s_rgb[cnt + tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
             ent_ok[k] = nn < range.y;
             if (ent_ok[k]) ent[k] = list[nn];
         }
-        if (cnt) blend_batch<MODE>(f, cnt, s_mean, s_conic, s_rgb, pxf, pyf, lim0, lim1, T, C0, C1, C2, stop_key);
+        if (cnt) blend_batch<MODE, kGroupBlocks>(f, cnt, s_mean, s_conic, s_rgb, pxf, pyf, lim0, lim1, T, C0, C1, C2, stop_key);
     }
     if (in0) fb[fbo] = make_float4(C0.x, C1.x, C2.x, T.x);
     if (in1) fb[fbo + f.w_px] = make_float4(C0.y, C1.y, C2.y, T.y);
@@ -372,9 +376,9 @@ __global__ __launch_bounds__(128) void k_composite_spill(const FrameConsts f, co
                                                           const uint2* __restrict__ window) {
     const uint32_t end = min(j1, *d_n), cut = stats->slab_cut;
     if (cut >= end) return;
-    __shared__ float2 s_mean[128 + kGroup];
-    __shared__ float4 s_conic[128 + kGroup];
-    __shared__ float4 s_rgb[128 + kGroup];
+    __shared__ float2 s_mean[128 + kGroupTiles];
+    __shared__ float4 s_conic[128 + kGroupTiles];
+    __shared__ float4 s_rgb[128 + kGroupTiles];
     __shared__ uint32_t s_sat, s_w[2];
     // a fixed, small grid strides over the tiles: the launch that finds nothing to do (every frame but the rare one that
     // overflowed) costs a kernel boundary, not the dispatch of one workgroup per tile (4.5 -> ~3 us at 1080p)
@@ -430,13 +434,13 @@ __global__ __launch_bounds__(128) void k_composite_spill(const FrameConsts f, co
             s_conic[slot] = make_float4(b.x, 2.0f * b.y, b.z, b.w);
             s_rgb[slot] = rec_c[idx];
         }
-        if (tid < (uint32_t)kGroup) {  // the blend loop runs in whole groups: records no pixel supports behind the last hit
+        if (tid < (uint32_t)kGroupTiles) {  // the blend loop runs in whole groups: records no pixel supports behind the last hit
             s_mean[cnt + tid] = make_float2(3.0e38f, 3.0e38f);
             s_conic[cnt + tid] = make_float4(1.0f, 0.0f, 1.0f, 0.0f);
             s_rgb[cnt + tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
         __syncthreads();
-        blend_batch<MODE>(f, cnt, s_mean, s_conic, s_rgb, pxf, pyf, lim0, lim1, T, C0, C1, C2, stop_key);
+        blend_batch<MODE, kGroupTiles>(f, cnt, s_mean, s_conic, s_rgb, pxf, pyf, lim0, lim1, T, C0, C1, C2, stop_key);
     }
     if (in0) fb[fbo] = make_float4(C0.x, C1.x, C2.x, T.x);
     if (in1) fb[fbo + f.w_px] = make_float4(C0.y, C1.y, C2.y, T.y);

@@ -6,7 +6,7 @@
 //
 // One launch per 8-bit digit ("onesweep" structure, written for CDNA4):
 //   k_radix_global_hist   one read of the keys builds the digit histograms of ALL passes.
-//   k_radix_onesweep      persistent workgroups take 4096-element tiles in ticket order; per tile:
+//   k_radix_onesweep      persistent workgroups take 8192-element tiles in ticket order; per tile:
 //                         stable ranks by wave-level digit matching (8 ballots) -> per-digit tile counts
 //                         -> published as one 64-bit {epoch|flag, count} word per (tile, digit);
 //                         thread d looks back over the preceding tiles' words of digit d (decoupled
@@ -30,13 +30,18 @@
 
 namespace gsx {
 
-constexpr int kRadixThreads = 256;
+constexpr int kRadixThreads = 256;                        // histogram / scan kernels
 constexpr int kRadixWaves = kRadixThreads / 64;
+// The digit pass runs 512-thread workgroups (8 waves), one 8192-element tile each; threads 0..255 also own one digit each.
+// What bounds a pass at millions of pairs is the chain of tile prefixes: ~40 tiles per microsecond whatever a tile holds
+// (1024 / 2048 / 4096 / 8192 / 16384 elements per tile: 190 / 105 / 67 / 56 / 54 us per pass at 8.46 M pairs; a 16384-element
+// tile needs 1024 threads and costs the small sorts 15 %).  tools/bench_sort.hip, round 3.
+constexpr int kSweepThreads = 512;
+constexpr int kSweepWaves = kSweepThreads / 64;
 constexpr int kRadixRounds = 16;                          // elements per lane
-constexpr int kRadixTile = kRadixThreads * kRadixRounds;  // 4096 elements per tile
+constexpr int kRadixTile = kSweepThreads * kRadixRounds;  // 8192 elements per tile
 constexpr int kWaveChunk = 64 * kRadixRounds;             // 1024 contiguous elements per wave
-constexpr uint32_t kRadixGrid = 768;                      // persistent workgroups = resident capacity (3 per CU);
-                                                          // measured best of 128..1024 on MI355X
+constexpr uint32_t kRadixGrid = 512;                      // persistent workgroups = resident capacity (73 KB of LDS each: 2 per CU)
 constexpr uint32_t kMaxPasses = 4;
 constexpr int kLook = 4;                                  // predecessors examined per look-back round trip (2 and 8 measured)
 
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ ta
 typedef unsigned long long u64;
 
 template <int IN, int OUT, bool LANE_ORDERED>
-__global__ __launch_bounds__(kRadixThreads) void k_radix_onesweep(const uint32_t* __restrict__ keys_in,
+__global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t* __restrict__ keys_in,
                                                                    const uint32_t* __restrict__ vals_in,
                                                                    const uint2* __restrict__ pairs_in,
                                                                    uint32_t* __restrict__ keys_out,
@@ -179,9 +184,9 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_onesweep(const uint32_t
                                                                    uint32_t* __restrict__ ghist_clear /* last pass: all rows */,
                                                                    uint32_t ghist_clear_words) {
     __shared__ uint2 s_pairs[kRadixTile];       // tile reordered by digit
-    __shared__ uint32_t cnt[kRadixWaves][256];  // per-wave digit counts, then per-wave local offsets
+    __shared__ uint32_t cnt[kSweepWaves][256];  // per-wave digit counts, then per-wave local offsets
     __shared__ uint32_t s_gbase[256];           // global slot of the tile's local slot 0, per digit
-    __shared__ uint32_t s_wtot[4];
+    __shared__ uint32_t s_wtot[kSweepWaves];
     __shared__ uint32_t s_tile;
     __shared__ uint32_t s_last;
 
@@ -192,11 +197,12 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_onesweep(const uint32_t
     const uint32_t participants = min(gridDim.x, n_tiles);
     if (blockIdx.x >= participants) return;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const bool dig = tid < 256u;  // this thread also owns digit `tid` (the scans below run over the first four waves; the others add 0)
 
     // exclusive scan of this pass's global digit histogram: thread d -> first output slot of digit d
     uint32_t dbase;
     {
-        const uint32_t v = ghist[tid];
+        const uint32_t v = dig ? ghist[tid] : 0u;
         uint32_t x = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -219,8 +225,7 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_onesweep(const uint32_t
         const uint32_t tile = s_tile;
         if (tile >= n_tiles) break;
         GSX_PROF(0);
-#pragma unroll
-        for (int w = 0; w < kRadixWaves; ++w) cnt[w][tid] = 0;
+        for (uint32_t i = tid; i < (uint32_t)kSweepWaves * 256u; i += kSweepThreads) (&cnt[0][0])[i] = 0;
         __syncthreads();
 
         // load + stable ranks inside the wave's contiguous 1024-element chunk
@@ -282,15 +287,17 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_onesweep(const uint32_t
 
         // thread d: tile count of digit d, per-wave exclusive offsets, publish, look back
         uint32_t tile_cnt = 0;
+        if (dig) {
 #pragma unroll
-        for (int w = 0; w < kRadixWaves; ++w) {
-            const uint32_t c = cnt[w][tid];
-            cnt[w][tid] = tile_cnt;  // exclusive offset of wave w inside digit d's run
-            tile_cnt += c;
+            for (int w = 0; w < kSweepWaves; ++w) {
+                const uint32_t c = cnt[w][tid];
+                cnt[w][tid] = tile_cnt;  // exclusive offset of wave w inside digit d's run
+                tile_cnt += c;
+            }
         }
         u64* my_status = status + ((size_t)tile * 256 + tid);
         const u64 tag = (u64)epoch << 34;
-        const bool live = tid <= dmask;  // digits this pass can produce: the others have nothing to publish or look up
+        const bool live = dig && tid <= dmask;  // digits this pass can produce: the others have nothing to publish or look up
         if (live)
             __hip_atomic_store(my_status, tag | ((tile == 0 ? kFlagPrefix : kFlagAggregate) << 32) | (u64)tile_cnt,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -310,6 +317,25 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_onesweep(const uint32_t
             lstart = woff + x - tile_cnt;
         }
         GSX_PROF(2);
+        // The tile is reordered by digit in LDS BEFORE the look-back: the reorder needs local offsets only, and the 2 us it
+        // takes are 2 us the predecessors have had to publish (measured: 329 -> 320 us per 8.46 M-pair sort).  What the
+        // look-back costs on this part is not the walk but visibility: an agent-scope store of one XCD reaches a reader on
+        // another after ~3 us, and a tile needs one or two such hops — a two-level (grouped) look-back that reads 10x fewer
+        // status words and polling back-offs of 30 ns ... 3 us all left its 7.5 us per tile unchanged (tools/bench_sort.hip).
+        if (dig) {
+#pragma unroll
+            for (int w = 0; w < kSweepWaves; ++w) cnt[w][tid] += lstart;  // local slot = cnt[w][d] + rank
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kRadixRounds; ++r) {
+            const uint32_t e = base + r * 64 + lane;
+            if (e < n) {
+                const uint32_t digit = (key[r] >> shift) & dmask;
+                s_pairs[cnt[wave][digit] + rank[r]] = make_uint2(key[r], val[r]);
+            }
+        }
+        GSX_PROF(3);
         uint32_t excl = 0;
         if (tile > 0 && live) {
             // Look-back, kLook predecessors per round trip: the status loads of a batch are independent and issued
@@ -343,29 +369,14 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_onesweep(const uint32_t
             __hip_atomic_store(my_status, tag | (kFlagPrefix << 32) | (u64)(excl + tile_cnt), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         }
-        GSX_PROF(3);
-        s_gbase[tid] = dbase + excl - lstart;
-        // fold lstart into the per-wave offsets so that local slot = cnt[w][d] + rank
-#pragma unroll
-        for (int w = 0; w < kRadixWaves; ++w) cnt[w][tid] += lstart;
-        __syncthreads();
-
-        // reorder the tile by digit in LDS
-#pragma unroll
-        for (int r = 0; r < kRadixRounds; ++r) {
-            const uint32_t e = base + r * 64 + lane;
-            if (e < n) {
-                const uint32_t digit = (key[r] >> shift) & dmask;
-                s_pairs[cnt[wave][digit] + rank[r]] = make_uint2(key[r], val[r]);
-            }
-        }
+        if (dig) s_gbase[tid] = dbase + excl - lstart;
         __syncthreads();
         GSX_PROF(4);
         // write out: consecutive lanes -> consecutive addresses inside every digit run
         const uint32_t tile_n = min((uint32_t)kRadixTile, n - tile * kRadixTile);
 #pragma unroll 4
         for (int r = 0; r < kRadixRounds; ++r) {
-            const uint32_t slot = r * kRadixThreads + tid;
+            const uint32_t slot = r * kSweepThreads + tid;
             if (slot < tile_n) {
                 const uint2 kv = s_pairs[slot];
                 const uint32_t o = s_gbase[(kv.x >> shift) & dmask] + slot;
@@ -394,7 +405,7 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_onesweep(const uint32_t
     }
     __syncthreads();
     if (s_last)
-        for (uint32_t k = tid; k < ghist_clear_words; k += kRadixThreads) ghist_clear[k] = 0;
+        for (uint32_t k = tid; k < ghist_clear_words; k += kSweepThreads) ghist_clear[k] = 0;
 }
 
 hipError_t launch_rowscan(hipStream_t s, uint32_t* table, uint32_t nrows, uint32_t nblocks, uint32_t* totals, const uint32_t* d_n, uint32_t tile) {
@@ -405,19 +416,18 @@ hipError_t launch_rowscan(hipStream_t s, uint32_t* table, uint32_t nrows, uint32
 static std::atomic<uint32_t> g_epoch{1};  // distinguishes the status words of successive launches (any stream, any viewer, any thread)
 
 // ---- is a returning LDS add served in ascending lane order?  (see k_radix_onesweep<.., LANE_ORDERED>) ----
-// The probe has the shape of the kernel that relies on the answer: 256-thread workgroups (four waves sharing the LDS), every
+// The probe has the shape of the kernel that relies on the answer: 512-thread workgroups (eight waves sharing the LDS), every
 // lane issuing kRadixRounds back-to-back returning adds on its wave's 256 counters, one workgroup per resident slot of the
-// persistent sort grid (three per CU) so the LDS is contended the way it is in production, and address patterns from "no
+// persistent sort grid (two per CU) so the LDS is contended the way it is in production, and address patterns from "no
 // two lanes collide" to "all 64 lanes on one counter".  Expected value of each add: the counter before the instruction
 // (the wave's earlier rounds, tracked by ballot matching — the documented path) plus the number of LOWER lanes that hit
 // the same counter in the same instruction.
-__global__ __launch_bounds__(kRadixThreads) void k_lane_order_probe(uint32_t seed, uint32_t iterations, uint32_t* __restrict__ violations) {
-    __shared__ uint32_t c[kRadixWaves][256];
+__global__ __launch_bounds__(kSweepThreads) void k_lane_order_probe(uint32_t seed, uint32_t iterations, uint32_t* __restrict__ violations) {
+    __shared__ uint32_t c[kSweepWaves][256];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t bad = 0;
     for (uint32_t it = 0; it < iterations; ++it) {
-#pragma unroll
-        for (int w = 0; w < kRadixWaves; ++w) c[w][tid] = 0;
+        for (uint32_t i = tid; i < (uint32_t)kSweepWaves * 256u; i += kSweepThreads) (&c[0][0])[i] = 0;
         __syncthreads();
         const uint32_t span = 1u << ((blockIdx.x + it + wave) % 9u);  // 1, 2, 4 ... 256 distinct counters
         uint32_t a[kRadixRounds], got[kRadixRounds];
@@ -472,7 +482,7 @@ bool radix_lane_ordered_adds() {
     uint32_t h = 1;
     bool ok = hipMalloc(&d, 4) == hipSuccess && hipMemset(d, 0, 4) == hipSuccess;
     if (ok) {
-        hipLaunchKernelGGL(k_lane_order_probe, dim3(kRadixGrid), dim3(kRadixThreads), 0, 0, 12345u, 8u, d);
+        hipLaunchKernelGGL(k_lane_order_probe, dim3(kRadixGrid), dim3(kSweepThreads), 0, 0, 12345u, 8u, d);
         ok = hipGetLastError() == hipSuccess && hipMemcpy(&h, d, 4, hipMemcpyDeviceToHost) == hipSuccess;
     }
     if (d) (void)hipFree(d);
@@ -507,7 +517,7 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
     // histogram workgroups: ~one per 1024..4096 elements up to the persistent grid (sorts of a few hundred thousand elements
     // are latency-bound: 300 k keys took 89 us with 4096 x 4 elements per workgroup, 67 us with 4096)
     static const uint32_t hper = getenv("GSX_RADIX_HPER") ? (uint32_t)atoi(getenv("GSX_RADIX_HPER")) : 4096u;
-    const uint32_t hgrid = std::max<uint32_t>(1u, std::min<uint32_t>(kRadixGrid, (uint32_t)(((uint64_t)n + hper - 1) / hper)));
+    const uint32_t hgrid = std::max<uint32_t>(1u, std::min<uint32_t>(768u, (uint32_t)(((uint64_t)n + hper - 1) / hper)));
     if (buf.pairs_src)
         hipLaunchKernelGGL(k_radix_global_hist<2>, dim3(hgrid), dim3(kRadixThreads), 0, s,
                            reinterpret_cast<const uint32_t*>(buf.pairs_src), n, d_n, passes, dbits, ghist);
@@ -523,11 +533,11 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
 #define GSX_SWEEP(IN, OUT)                                                                                              \
     do {                                                                                                                \
         if (lane_ordered)                                                                                               \
-            hipLaunchKernelGGL((k_radix_onesweep<IN, OUT, true>), dim3(grid), dim3(kRadixThreads), 0, s, buf.keys_src,  \
+            hipLaunchKernelGGL((k_radix_onesweep<IN, OUT, true>), dim3(grid), dim3(kSweepThreads), 0, s, buf.keys_src,  \
                                buf.vals_src, pin, buf.keys_out, buf.vals_out, pout, n, d_n, shift, dmask, ghist + 256 * p, \
                                ticket, status, epoch, ghist, last ? 256u * (uint32_t)passes : 0u);                       \
         else                                                                                                            \
-            hipLaunchKernelGGL((k_radix_onesweep<IN, OUT, false>), dim3(grid), dim3(kRadixThreads), 0, s, buf.keys_src, \
+            hipLaunchKernelGGL((k_radix_onesweep<IN, OUT, false>), dim3(grid), dim3(kSweepThreads), 0, s, buf.keys_src, \
                                buf.vals_src, pin, buf.keys_out, buf.vals_out, pout, n, d_n, shift, dmask, ghist + 256 * p, \
                                ticket, status, epoch, ghist, last ? 256u * (uint32_t)passes : 0u);                       \
     } while (0)
