@@ -1,39 +1,43 @@
 #!/bin/bash
 # Collects the per-round evidence under gpurun_out/<round>/ on the GPU box (run through gpurun); copy the summaries into
-# profiles/ afterwards.  rocprofv3 wraps python3 directly (no env / bash hop).  usage: tools/collect_profiles.sh r02
+# profiles/ afterwards.  rocprofv3 wraps python3 directly (no env / bash hop).  usage: tools/collect_profiles.sh r03
 set -u
-R=${1:-r02}
+R=${1:-r03}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-# 1. the bench line exactly as the driver runs it (PMC child passes, both timed loops, frame check, robustness legs, full CPU baseline)
+# 1. the bench line exactly as the driver runs it (PMC child passes, every timed loop, frame check, synchronised / steady / per-pass
+#    legs, robustness legs, full CPU baseline), and with the driver's short window
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2>> $OUT/bench.err
-# 2. kernel trace + stats of the same command (both timed loops are in it: k_project<3,0,0> and k_project_geom averages must agree
-#    with roofline.avg_launch_us / roofline_speculated.avg_launch_us of the line above)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --no-cpu-baseline --no-pmc > $OUT/kt_bench.log 2>&1
-# 3. per-frame kernel breakdowns of the speculated and of the unspeculated loop alone
+# 2. kernel trace + stats of the same command (the timed loops are in it: k_project<3,0,0> and k_project_geom averages must agree
+#    with roofline.avg_launch_us / roofline_speculated.avg_launch_us of the line it prints itself)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --no-cpu-baseline --no-pmc --no-extra-legs --no-robustness > $OUT/kt_bench.log 2>&1
+# 3. per-frame kernel breakdowns of the speculated and of the unspeculated loop alone, and of the sharded frame at world 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_spec -o kt -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-pmc --render-options speculative=1 > $OUT/kt_spec.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_nospec -o kt -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-pmc --render-options speculative=0 > $OUT/kt_nospec.log 2>&1
-python3 tools/kernel_breakdown.py $OUT/kt_spec 143 > $OUT/kt_spec_breakdown.txt
-python3 tools/kernel_breakdown.py $OUT/kt_nospec 143 > $OUT/kt_nospec_breakdown.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_dist -o kt -- python3 bench.py --force-dist --steps 100 --warmup 10 --no-cpu-baseline --no-pmc --dist-frames-in-flight 1 > $OUT/kt_dist.log 2>&1
+python3 tools/kernel_breakdown.py $OUT/kt_spec 143 40 > $OUT/kt_spec_breakdown.txt
+python3 tools/kernel_breakdown.py $OUT/kt_nospec 143 40 > $OUT/kt_nospec_breakdown.txt
+python3 tools/kernel_breakdown.py $OUT/kt_dist 143 40 > $OUT/kt_dist_breakdown.txt
 # 4. HBM traffic, separate PMC passes (what bench.py's child passes do, kept here as raw per-kernel averages)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o p -- python3 bench.py --pmc-child --steps 4 --warmup 3 > $OUT/pmc_$c.log 2>&1
 done
 python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_summary.csv
-# 5. the other workloads / pods / the index-sharded path on one rank over real RCCL
+# 5. the other workloads / pods / the index-sharded path on one rank (frames in flight 1, 2, 3)
 for w in cfg2 cfg3; do python3 bench.py --workload $w --no-cpu-baseline --no-pmc > $OUT/bench_$w.json 2>> $OUT/bench.err; done
-python3 bench.py --pod half/half --no-cpu-baseline --no-pmc --no-robustness > $OUT/bench_half_half.json 2>> $OUT/bench.err
-python3 bench.py --pod norm8/half --no-cpu-baseline --no-pmc --no-robustness > $OUT/bench_norm8_half.json 2>> $OUT/bench.err
-python3 bench.py --force-dist --no-cpu-baseline --no-pmc > $OUT/bench_index_world1_rccl.json 2>> $OUT/bench.err
-# 6. frames in flight: the unspeculated loop with two lanes too, and one / three lanes for the headline loop
-python3 bench.py --no-cpu-baseline --no-pmc --no-robustness --unspeculated-in-flight > $OUT/bench_inflight2_both.json 2>> $OUT/bench.err
-python3 bench.py --no-cpu-baseline --no-pmc --no-robustness --frames-in-flight 1 > $OUT/bench_inflight1.json 2>> $OUT/bench.err
-python3 bench.py --no-cpu-baseline --no-pmc --no-robustness --frames-in-flight 3 > $OUT/bench_inflight3.json 2>> $OUT/bench.err
+python3 bench.py --pod half/half --no-cpu-baseline --no-pmc --no-robustness --no-extra-legs > $OUT/bench_half_half.json 2>> $OUT/bench.err
+python3 bench.py --pod norm8/half --no-cpu-baseline --no-pmc --no-robustness --no-extra-legs > $OUT/bench_norm8_half.json 2>> $OUT/bench.err
+for L in 1 2 3; do python3 bench.py --force-dist --no-cpu-baseline --no-pmc --dist-frames-in-flight $L > $OUT/bench_index_world1_inflight$L.json 2>> $OUT/bench.err; done
+# 6. frames in flight on the single-GPU path: one / three lanes for the headline loop
+python3 bench.py --no-cpu-baseline --no-pmc --no-robustness --no-extra-legs --frames-in-flight 1 > $OUT/bench_inflight1.json 2>> $OUT/bench.err
+python3 bench.py --no-cpu-baseline --no-pmc --no-robustness --no-extra-legs --frames-in-flight 3 > $OUT/bench_inflight3.json 2>> $OUT/bench.err
 # 7. BASELINE configs[4] on one GPU: 4 x 6 M Gaussians at 3840x2160, with and without the stored selection + edit
 (python3 tools/bench_cfg5.py; python3 tools/bench_cfg5.py --edit 0) 2>> $OUT/bench.err | grep '^{' > $OUT/bench_cfg5.json
 tools/bench_hbm > $OUT/bench_hbm.txt 2>&1
-python3 tools/emulate_ranks.py --world 8 --frames 30 > $OUT/emulate_world8.txt 2>&1
-python3 tools/emulate_ranks.py --world 2 --frames 30 > $OUT/emulate_world2.txt 2>&1
-for f in $OUT/bench.json $OUT/bench_driver_args.json $OUT/bench_index_world1_rccl.json; do cut -c1-300 $f; done
+tools/bench_sort 8460000 32 depth > $OUT/bench_sort.txt 2>&1
+tools/bench_sort 310000 32 depth >> $OUT/bench_sort.txt 2>&1
+tools/bench_sort 870000 8 >> $OUT/bench_sort.txt 2>&1
+python3 tools/shard_host_time.py > $OUT/shard_host_time.txt 2>&1
+for f in $OUT/bench.json $OUT/bench_driver_args.json $OUT/bench_index_world1_inflight2.json; do cut -c1-300 $f; done

