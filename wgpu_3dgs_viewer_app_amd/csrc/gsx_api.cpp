@@ -21,6 +21,38 @@ static gsx_viewer* result_lane_of(gsx_viewer* v, const char* key) {
     return (l != v && !find_model(l, key)) ? v : l;
 }
 
+// Does work on `candidate` run while each of `busy` is occupied?  HIP multiplexes its streams onto a few hardware queues
+// (GPU_MAX_HW_QUEUES, 4 by default) in creation order; two streams on one queue execute one after the other, and a lane that
+// shares its queue with the viewer (or with another lane) overlaps nothing: measured on cfg4 with a second RCCL communicator in
+// the process (its streams shifted the lane onto the viewer's queue): 1729 -> 1245 fps with two frames in flight.
+// Probe: occupy every busy stream with a spinning wave, run an empty kernel on the candidate, and see whether it completed
+// while all the spinners were still at it.
+static gsx_status stream_runs_beside(hipStream_t candidate, const std::vector<hipStream_t>& busy, bool* out) {
+    *out = true;
+    std::vector<hipEvent_t> ev(busy.size() + 1, nullptr);
+    gsx_status st = GSX_OK;
+    auto run = [&]() -> gsx_status {
+        for (auto& e : ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (hipStream_t b : busy) HIPCHK(hipStreamSynchronize(b));
+        HIPCHK(hipStreamSynchronize(candidate));
+        for (size_t i = 0; i < busy.size(); ++i) {
+            HIPCHK(launch_spin(busy[i], 400));
+            HIPCHK(hipEventRecord(ev[i], busy[i]));
+        }
+        HIPCHK(launch_spin(candidate, 1));
+        HIPCHK(hipEventRecord(ev.back(), candidate));
+        HIPCHK(hipEventSynchronize(ev.back()));
+        for (size_t i = 0; i < busy.size(); ++i)
+            if (hipEventQuery(ev[i]) == hipSuccess) *out = false;  // that spinner finished first: the candidate waited behind it
+        for (hipStream_t b : busy) HIPCHK(hipStreamSynchronize(b));
+        return GSX_OK;
+    };
+    st = run();
+    for (auto& e : ev)
+        if (e) (void)hipEventDestroy(e);
+    return st;
+}
+
 static gsx_status lane_create(gsx_viewer* v, gsx_viewer** out) {
     std::unique_ptr<gsx_viewer> l(new gsx_viewer());
     l->device = v->device;
@@ -29,7 +61,22 @@ static gsx_status lane_create(gsx_viewer* v, gsx_viewer** out) {
     l->tile_cap_fixed = v->tile_cap_fixed;
     l->bin_mode = v->bin_mode;
     l->blocks_max = v->blocks_max;
-    HIPCHK(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
+    // a stream that does not share its hardware queue with the viewer's or another lane's: streams that do are kept (parked)
+    // until the viewer goes, so that the next one created lands on the next queue
+    std::vector<hipStream_t> busy{v->stream};
+    for (gsx_viewer* o : v->lanes) busy.push_back(o->stream);
+    static const bool probe = getenv("GSX_NO_QUEUE_PROBE") == nullptr;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        HIPCHK(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
+        bool beside = true;
+        if (probe) {
+            const gsx_status pst = stream_runs_beside(l->stream, busy, &beside);
+            if (pst) return pst;
+        }
+        if (beside || attempt == 7) break;  // (eight tries without luck: fewer hardware queues than lanes — frames still come out right)
+        v->parked_streams.push_back(l->stream);
+        l->stream = nullptr;
+    }
     l->own_stream = true;
     HIPCHK(hipEventCreateWithFlags(&l->lane_event, hipEventDisableTiming));
     *out = l.release();
@@ -189,6 +236,7 @@ void gsx_viewer_destroy(gsx_viewer* v) {
     v->lanes.clear();
     (void)hipStreamSynchronize(v->stream);
     if (v->lane_event) (void)hipEventDestroy(v->lane_event);
+    for (hipStream_t ps : v->parked_streams) (void)hipStreamDestroy(ps);
     if (v->h_shard_verdict) (void)hipHostFree(v->h_shard_verdict);
     for (auto& t : v->timers) {
         (void)hipEventDestroy(t.start);

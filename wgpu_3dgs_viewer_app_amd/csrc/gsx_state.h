@@ -278,6 +278,7 @@ struct gsx_viewer {
     hipEvent_t lane_event = nullptr;     // lane: end of its last frame; parent: "everything enqueued so far" for the lanes to wait on
     bool lane_busy = false;              // lane: it has a frame the parent's stream has not been ordered after
     uint64_t epoch = 1, seen_epoch = 0;  // parent: bumped by every call that may touch model data; lane: the epoch it has waited for
+    std::vector<hipStream_t> parked_streams;  // owner only: streams that turned out to share a hardware queue with a lane (lane_create)
     uint32_t lane_index = 0;             // 0: the viewer itself; lane i of its parent otherwise
     // sharded frames in flight (gsx_shard_render_frame with frames_in_flight > 1): every lane has a communicator of its own
     // and runs its collectives on its own stream (gsx_comm.cpp)

@@ -30,6 +30,20 @@ hipError_t launch_zero_words(hipStream_t s, uint32_t* a, uint32_t na, uint32_t* 
     return hipGetLastError();
 }
 
+// Occupies a stream for `ticks` of the 100 MHz wall clock (one wave, no memory traffic): gsx_api.cpp uses it once per lane to
+// find out whether two HIP streams share a hardware queue.
+__global__ __launch_bounds__(64) void k_spin(unsigned long long ticks, uint32_t* __restrict__ sink) {
+    const unsigned long long t0 = wall_clock64();
+    unsigned long long now = t0;
+    while (now - t0 < ticks) now = wall_clock64();
+    if (sink && threadIdx.x == 0 && now == 0ull) *sink = 1u;  // never true: keeps the loop from being optimised away
+}
+
+hipError_t launch_spin(hipStream_t s, uint32_t microseconds) {
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, 100ull * microseconds, static_cast<uint32_t*>(nullptr));
+    return hipGetLastError();
+}
+
 // Debug aid (GSX_VALIDATE=1, gsx_frame.cpp): everything the compositor is about to dereference, checked before it runs.
 // report[0] = first error code (1 range outside the sorted entries, 2 list index outside the records), [1] tile, [2..3] detail.
 __global__ __launch_bounds__(256) void k_validate_tiles(const uint2* __restrict__ ranges, uint32_t n_tiles,
