@@ -34,7 +34,7 @@ for L in 1 2 3; do python3 bench.py --force-dist --no-cpu-baseline --no-pmc --di
 python3 bench.py --no-cpu-baseline --no-pmc --no-robustness --no-extra-legs --frames-in-flight 1 > $OUT/bench_inflight1.json 2>> $OUT/bench.err
 python3 bench.py --no-cpu-baseline --no-pmc --no-robustness --no-extra-legs --frames-in-flight 3 > $OUT/bench_inflight3.json 2>> $OUT/bench.err
 # 7. BASELINE configs[4] on one GPU: 4 x 6 M Gaussians at 3840x2160, with and without the stored selection + edit
-(python3 tools/bench_cfg5.py; python3 tools/bench_cfg5.py --edit 0) 2>> $OUT/bench.err | grep '^{' > $OUT/bench_cfg5.json
+(python3 tools/bench_cfg5.py; python3 tools/bench_cfg5.py --edit 0; python3 tools/bench_cfg5.py --edit 0 --shard 1) 2>> $OUT/bench.err | grep '^{' > $OUT/bench_cfg5.json
 tools/bench_hbm > $OUT/bench_hbm.txt 2>&1
 tools/bench_sort 8460000 32 depth > $OUT/bench_sort.txt 2>&1
 tools/bench_sort 310000 32 depth >> $OUT/bench_sort.txt 2>&1
