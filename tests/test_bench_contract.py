@@ -58,6 +58,24 @@ def test_bench_line_contract(name, d):
         assert "whole scene" in c["sample"]
         assert 0 < d["value_unspeculated"] < d["value"]
         assert "k_project_geom" in d["roofline_speculated"]["kernel"]
+    if "passes" in d:  # round 3 onwards: what a host that waits gets, a whole-orbit figure, every pass against its bytes
+        assert 0 < d["value_synchronised_unspeculated"] < d["value_synchronised"] <= 1.1 * d["value_one_frame_in_flight"]
+        assert 0 < d["value_reference_protocol"] <= 1.1 * d["value_synchronised"]
+        assert abs(d["value_synchronised"] - 1e3 / d["ms_per_step_synchronised"]) / d["value_synchronised"] < 1e-2
+        assert d["steady_state"]["frames"] >= 240 and 0.7 * d["value"] < d["steady_state"]["value"] < 1.3 * d["value"]
+        assert "value_unspeculated" in d["roofline"]["belongs_to"]
+        for schedule, proj in (("speculated", "project_geom"), ("unspeculated", "project")):
+            ps = d["passes"][schedule]
+            for name in (proj, "depth_sort", "bin", "tile_sort", "composite"):
+                row = ps[name]
+                assert row["us_per_frame"] > 0 and row["algorithmic_bytes"] > 0 and "bytes_definition" in row
+                assert abs(row["GBps"] - row["algorithmic_bytes"] / (row["us_per_frame"] * 1e-6) / 1e9) / row["GBps"] < 2e-2
+                assert abs(row["frac_of_8TBps"] - row["GBps"] / 8000.0) < 1e-3
+            # the bracketed passes account for the frame they were measured in (event brackets leave gaps: not more than the frame)
+            total = sum(ps[n]["us_per_frame"] for n in (proj, "depth_sort", "bin", "tile_sort", "composite"))
+            assert 0.7 * ps["frame_ms_with_every_pass_bracketed"] * 1e3 < total <= 1.05 * ps["frame_ms_with_every_pass_bracketed"] * 1e3
+        # the projection pass of the `passes` loop and the roofline kernel of the unspeculated timed loop are the same kernel
+        assert abs(d["passes"]["unspeculated"]["project"]["us_per_frame"] - d["roofline"]["avg_launch_us"]) / d["roofline"]["avg_launch_us"] < 0.15
 
 
 def test_profiled_kernel_time_agrees_with_bench():
