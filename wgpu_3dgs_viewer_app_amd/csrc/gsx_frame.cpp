@@ -464,25 +464,29 @@ gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
                             m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
             HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted, 32, true));  // n: an upper bound (slot import); the count is on the device
         } else {
-            // compact the (key, index) pairs the projection pass admitted, then sort only those
+            // speculated frames: compact the (key, index) pairs the projection pass admitted, then sort only those
             // (counting the sort's digit histograms inside the compaction / tile-emit kernels — LDS atomics where the pairs are
             // written, one flush per workgroup — removes two histogram launches per frame and was measured: 1200 vs 1198 fps
             // speculated, 602 vs 613 unspeculated on cfg4; the counting costs what the histogram kernels cost.  Not kept.)
-            HIPCHK(m->adm_pairs.ensure(8 * std::max<size_t>(n, 1)));
             if (force_full) {
                 gsx_status stc = complete_records(v, m);
                 if (stc) return stc;
+                m->spec_round1 = false;
+            }
+            // every visible record enters the sort (an unspeculated frame, a redone one): the first radix pass reads the
+            // projection's key plane as it lies and skips the culled records — no compaction pass in front of the sort
+            // (k_admit_scan + k_admit_scatter_dense: 55 us and 176 MB at 10 M Gaussians)
+            const bool dense = force_full || (!m->spec_round1 && !m->lazy && m->last_pyramid == nullptr);
+            if (dense) {
                 if (m->visible_count_pending) {
                     HIPCHK(launch_sum_counts(v->stream, m->block_vis.as<uint32_t>(), n, &dc->n_visible));
                     m->visible_count_pending = false;
                 }
-                m->spec_round1 = false;
-                HIPCHK(m->adm_ballots2.ensure(8 * ((std::max<size_t>(n, 1) + 63) / 64)));
-                HIPCHK(m->adm_counts2.ensure(4 * (std::max<size_t>(admit_blocks(n), 1) + 4)));
-                HIPCHK(launch_admit(v->stream, m->proj_rec(), n, nullptr, m->fc.tiles_x, nullptr, 0, WindowPyramid{}, nullptr,
-                                    m->adm_ballots2.as<unsigned long long>(), m->adm_counts2.as<uint32_t>(), &dc->n_sorted,
-                                    m->adm_pairs.as<uint2>()));
+                RadixBuffers rb{m->proj_rec().key, nullptr, nullptr, m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
+                                m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
+                HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted, 32, true, true));
             } else {
+                HIPCHK(m->adm_pairs.ensure(8 * std::max<size_t>(n, 1)));
                 HIPCHK(m->adm_offsets.ensure(m->adm_counts.bytes));
                 HIPCHK(launch_admit_from_project(v->stream, m->proj_rec().key, n, m->adm_ballots.as<unsigned long long>(),
                                                  m->adm_counts.as<uint32_t>(), m->adm_offsets.as<uint32_t>(), &dc->n_sorted,
@@ -494,10 +498,10 @@ gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
                     pod.mask = m->last_pod_mask;
                     HIPCHK(launch_shade(v->stream, m->fc, n, pod, m->proj_rec(), LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted, nullptr, m->rect8_active}));
                 }
+                RadixBuffers rb{nullptr, nullptr, m->adm_pairs.as<uint2>(), m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
+                                m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
+                HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted, 32, false));
             }
-            RadixBuffers rb{nullptr, nullptr, m->adm_pairs.as<uint2>(), m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
-                            m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
-            HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted, 32, false));
         }
         m->sorted_idx = m->sv_out.as<uint32_t>();
         v->pass_launches[GSX_PASS_DEPTH_SORT] += n ? 4 : 0;

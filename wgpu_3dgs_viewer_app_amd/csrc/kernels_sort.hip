@@ -89,10 +89,11 @@ __device__ inline unsigned long long wave_match8_pair(uint32_t theirs, uint32_t 
 __device__ inline unsigned long long lanemask_lt() { return (1ull << (threadIdx.x & 63u)) - 1ull; }
 
 // ---- histograms of every pass in one read of the keys ----
+// skip_key: elements whose key is 0xFFFFFFFF do not exist (a projection's culled records: the sort compacts on the way)
 template <int KEY_STRIDE /* 1: key array, 2: interleaved {key,value} pairs */>
 __global__ __launch_bounds__(kRadixThreads) void k_radix_global_hist(const uint32_t* __restrict__ keys, uint32_t n_cap,
                                                                       const uint32_t* __restrict__ d_n, int passes, int dbits,
-                                                                      uint32_t* __restrict__ ghist) {
+                                                                      uint32_t* __restrict__ ghist, int skip_key) {
     __shared__ uint32_t hist[kMaxPasses][256];
     const uint32_t n = d_n ? min(*d_n, n_cap) : n_cap;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_global_hist(const uint3
 #pragma unroll
         for (int u = 0; u < kHistUnroll; ++u) {
             const uint32_t e = base + u * 64u + lane;
-            const bool valid = e < n;
+            const bool valid = e < n && !(skip_key && key[u] == 0xFFFFFFFFu);
             const unsigned long long vmask = __ballot(valid);
             for (int p = 0; p < passes; ++p) {
                 const uint32_t digit = (key[u] >> (dbits * p)) & ((1u << dbits) - 1u);
@@ -170,7 +171,11 @@ __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ ta
 // OUT: 0 = interleaved pairs                 | 1 = split key / value arrays
 typedef unsigned long long u64;
 
-template <int IN, int OUT, bool LANE_ORDERED>
+// SKIP (IN == 0 only): input elements whose key is 0xFFFFFFFF do not exist — the first pass of a depth sort reads the
+// projection's key plane as it lies (culled records carry that key) and writes dense pairs: no compaction pass before the
+// sort (the unspeculated frame paid 40 MB + 68 MB + 68 MB for one).  The number of elements that do exist is the sum of this
+// pass's histogram; workgroup 0 writes it to *d_n_out, which is the element count of the passes that follow.
+template <int IN, int OUT, bool LANE_ORDERED, bool SKIP = false>
 __global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t* __restrict__ keys_in,
                                                                    const uint32_t* __restrict__ vals_in,
                                                                    const uint2* __restrict__ pairs_in,
@@ -182,8 +187,9 @@ __global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t
                                                                    uint32_t* __restrict__ ticket /* [0] ticket, [1] finished */,
                                                                    u64* __restrict__ status, uint32_t epoch,
                                                                    uint32_t* __restrict__ ghist_clear /* last pass: all rows */,
-                                                                   uint32_t ghist_clear_words) {
+                                                                   uint32_t ghist_clear_words, uint32_t* __restrict__ d_n_out) {
     __shared__ uint2 s_pairs[kRadixTile];       // tile reordered by digit
+    __shared__ uint32_t s_tile_n;               // elements of the tile that exist (SKIP)
     __shared__ uint32_t cnt[kSweepWaves][256];  // per-wave digit counts, then per-wave local offsets
     __shared__ uint32_t s_gbase[256];           // global slot of the tile's local slot 0, per digit
     __shared__ uint32_t s_wtot[kSweepWaves];
@@ -214,6 +220,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t
         uint32_t woff = 0;
         for (uint32_t w = 0; w < wave; ++w) woff += s_wtot[w];
         dbase = woff + x - v;
+        if (SKIP && blockIdx.x == 0 && tid == 255u && d_n_out) *d_n_out = woff + x;  // the histogram's total: what exists
         __syncthreads();
     }
 
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t
             // 1024-element chunk.  (The ballot-matching path below spends ~7 us per tile here, this one well under 1.)
 #pragma unroll
             for (int r = 0; r < kRadixRounds; ++r) {
-                const bool valid = base + r * 64 + lane < n;
+                const bool valid = SKIP ? key[r] != 0xFFFFFFFFu : base + r * 64 + lane < n;
                 rank[r] = valid ? atomicAdd(&cnt[wave][(key[r] >> shift) & dmask], 1u) : 0u;
             }
         } else {
@@ -266,12 +273,12 @@ __global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t
             unsigned long long mm[kRadixRounds];
 #pragma unroll
             for (int r = 0; r < kRadixRounds; ++r) {
-                const bool valid = base + r * 64 + lane < n;
+                const bool valid = SKIP ? key[r] != 0xFFFFFFFFu : base + r * 64 + lane < n;
                 mm[r] = wave_match8((key[r] >> shift) & dmask, valid);
             }
 #pragma unroll
             for (int r = 0; r < kRadixRounds; ++r) {
-                const bool valid = base + r * 64 + lane < n;
+                const bool valid = SKIP ? key[r] != 0xFFFFFFFFu : base + r * 64 + lane < n;
                 const uint32_t before = (uint32_t)__popcll(mm[r] & lanemask_lt());
                 rank[r] = 0;
                 if (valid && before == 0) rank[r] = atomicAdd(&cnt[wave][(key[r] >> shift) & dmask], (uint32_t)__popcll(mm[r]));
@@ -315,6 +322,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t
             uint32_t woff = 0;
             for (uint32_t w = 0; w < wave; ++w) woff += s_wtot[w];
             lstart = woff + x - tile_cnt;
+            if (SKIP && tid == 255u) s_tile_n = woff + x;  // (threads past the 256 digits add nothing: this is the tile's total)
         }
         GSX_PROF(2);
         // The tile is reordered by digit in LDS BEFORE the look-back: the reorder needs local offsets only, and the 2 us it
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t
 #pragma unroll
         for (int r = 0; r < kRadixRounds; ++r) {
             const uint32_t e = base + r * 64 + lane;
-            if (e < n) {
+            if (SKIP ? key[r] != 0xFFFFFFFFu : e < n) {
                 const uint32_t digit = (key[r] >> shift) & dmask;
                 s_pairs[cnt[wave][digit] + rank[r]] = make_uint2(key[r], val[r]);
             }
@@ -373,7 +381,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t
         __syncthreads();
         GSX_PROF(4);
         // write out: consecutive lanes -> consecutive addresses inside every digit run
-        const uint32_t tile_n = min((uint32_t)kRadixTile, n - tile * kRadixTile);
+        const uint32_t tile_n = SKIP ? s_tile_n : min((uint32_t)kRadixTile, n - tile * kRadixTile);
 #pragma unroll 4
         for (int r = 0; r < kRadixRounds; ++r) {
             const uint32_t slot = r * kSweepThreads + tid;
@@ -499,8 +507,8 @@ static bool use_lane_ordered() {
     return lane_ordered_slot(&dev) == 1;
 }
 
-hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n, const uint32_t* d_n, int bits,
-                             bool iota_values) {
+hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n, uint32_t* d_n, int bits, bool iota_values,
+                             bool skip_culled) {
     if (n == 0) return hipSuccess;
     const int passes = (bits + 7) / 8;
     // equal digit widths (13 tile-key bits sort as 7 + 6, not 8 + 5): fewer digits mean shorter status rows to publish
@@ -513,6 +521,9 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
     const uint32_t tiles = radix_tiles(n);
     static const uint32_t grid_limit = getenv("GSX_RADIX_GRID") ? (uint32_t)atoi(getenv("GSX_RADIX_GRID")) : kRadixGrid;
     const uint32_t grid = std::min<uint32_t>(grid_limit, tiles);
+    // skip_culled: the keys are a projection's key plane (iota values); records whose key is 0xFFFFFFFF do not exist.  The
+    // histogram and the first pass run over all n of them, *d_n receives how many exist, the later passes run over those.
+    const bool skip = skip_culled && buf.keys_src && !buf.pairs_src && iota_values && passes > 1 && d_n;
     // ghist is zero here: the workspace is cleared at allocation and every sort's last pass clears it again
     // histogram workgroups: ~one per 1024..4096 elements up to the persistent grid (sorts of a few hundred thousand elements
     // are latency-bound: 300 k keys took 89 us with 4096 x 4 elements per workgroup, 67 us with 4096)
@@ -520,9 +531,10 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
     const uint32_t hgrid = std::max<uint32_t>(1u, std::min<uint32_t>(768u, (uint32_t)(((uint64_t)n + hper - 1) / hper)));
     if (buf.pairs_src)
         hipLaunchKernelGGL(k_radix_global_hist<2>, dim3(hgrid), dim3(kRadixThreads), 0, s,
-                           reinterpret_cast<const uint32_t*>(buf.pairs_src), n, d_n, passes, dbits, ghist);
+                           reinterpret_cast<const uint32_t*>(buf.pairs_src), n, d_n, passes, dbits, ghist, 0);
     else
-        hipLaunchKernelGGL(k_radix_global_hist<1>, dim3(hgrid), dim3(kRadixThreads), 0, s, buf.keys_src, n, d_n, passes, dbits, ghist);
+        hipLaunchKernelGGL(k_radix_global_hist<1>, dim3(hgrid), dim3(kRadixThreads), 0, s, buf.keys_src, n, skip ? nullptr : d_n, passes, dbits,
+                           ghist, skip ? 1 : 0);
     const uint2* pin = buf.pairs_src;
     uint2* pout = buf.pairs_a;
     const bool lane_ordered = use_lane_ordered();
@@ -530,18 +542,22 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
         const int shift = dbits * p;
         const bool first = p == 0, last = p == passes - 1;
         const uint32_t epoch = (g_epoch.fetch_add(1, std::memory_order_relaxed) & 0x1FFFFFFFu) | (1u << 29);  // 30 bits, never 0
-#define GSX_SWEEP(IN, OUT)                                                                                              \
-    do {                                                                                                                \
-        if (lane_ordered)                                                                                               \
-            hipLaunchKernelGGL((k_radix_onesweep<IN, OUT, true>), dim3(grid), dim3(kSweepThreads), 0, s, buf.keys_src,  \
-                               buf.vals_src, pin, buf.keys_out, buf.vals_out, pout, n, d_n, shift, dmask, ghist + 256 * p, \
-                               ticket, status, epoch, ghist, last ? 256u * (uint32_t)passes : 0u);                       \
-        else                                                                                                            \
-            hipLaunchKernelGGL((k_radix_onesweep<IN, OUT, false>), dim3(grid), dim3(kSweepThreads), 0, s, buf.keys_src, \
-                               buf.vals_src, pin, buf.keys_out, buf.vals_out, pout, n, d_n, shift, dmask, ghist + 256 * p, \
-                               ticket, status, epoch, ghist, last ? 256u * (uint32_t)passes : 0u);                       \
+#define GSX_SWEEP_ARGS(DN, DNOUT)                                                                                        \
+    dim3(grid), dim3(kSweepThreads), 0, s, buf.keys_src, buf.vals_src, pin, buf.keys_out, buf.vals_out, pout, n, DN, shift, dmask, \
+        ghist + 256 * p, ticket, status, epoch, ghist, last ? 256u * (uint32_t)passes : 0u, DNOUT
+#define GSX_SWEEP(IN, OUT)                                                                                               \
+    do {                                                                                                                 \
+        if (lane_ordered)                                                                                                \
+            hipLaunchKernelGGL((k_radix_onesweep<IN, OUT, true>), GSX_SWEEP_ARGS(d_n, nullptr));                          \
+        else                                                                                                             \
+            hipLaunchKernelGGL((k_radix_onesweep<IN, OUT, false>), GSX_SWEEP_ARGS(d_n, nullptr));                         \
     } while (0)
-        if (first && buf.pairs_src) {
+        if (first && skip) {  // (more than one pass: the first one writes interleaved pairs)
+            if (lane_ordered)
+                hipLaunchKernelGGL((k_radix_onesweep<0, 0, true, true>), GSX_SWEEP_ARGS(nullptr, d_n));
+            else
+                hipLaunchKernelGGL((k_radix_onesweep<0, 0, false, true>), GSX_SWEEP_ARGS(nullptr, d_n));
+        } else if (first && buf.pairs_src) {
             if (last) GSX_SWEEP(2, 1); else GSX_SWEEP(2, 0);
         } else if (first && last) {
             if (iota_values) GSX_SWEEP(0, 1); else GSX_SWEEP(1, 1);
@@ -553,6 +569,7 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
             GSX_SWEEP(2, 0);
         }
 #undef GSX_SWEEP
+#undef GSX_SWEEP_ARGS
         pin = pout;
         pout = (pout == buf.pairs_a) ? buf.pairs_b : buf.pairs_a;
     }
