@@ -99,21 +99,26 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_global_hist(const uint3
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     for (int p = 0; p < passes; ++p) hist[p][tid] = 0;
     __syncthreads();
-    // wave-contiguous 64-element rounds, grid-strided, four rounds per trip with their loads issued together: one load in
-    // flight per wave made the kernel a chain of memory round trips (27 per wave at 5.3 M keys: 28 us for 42 MB)
+    // Every workgroup takes ONE contiguous share of the keys, at least 4096 of them: the launch is sized by an upper bound, and
+    // with the elements dealt round-robin every one of 768 workgroups held a few of a 0.4 M-entry block sort's keys and flushed
+    // ~250 bins each — 100 K global atomics on 256 addresses were most of that kernel's 14 us.  Inside its share a wave takes
+    // 64-element rounds, four per trip with their loads issued together (one load in flight per wave made the kernel a chain
+    // of memory round trips).
     constexpr int kHistUnroll = 4;
-    const uint32_t wave_global = blockIdx.x * kRadixWaves + (tid >> 6), waves_total = gridDim.x * kRadixWaves;
-    for (uint32_t base = wave_global * (64u * kHistUnroll); base < n; base += waves_total * (64u * kHistUnroll)) {
+    const uint32_t share = max(4096u, (((n + gridDim.x - 1u) / gridDim.x) + 1023u) & ~1023u);
+    const uint32_t lo = blockIdx.x * share, hi = min(n, lo + share);
+    if (lo >= n) return;  // (uniform per workgroup, nothing to flush)
+    for (uint32_t base = lo + (tid >> 6) * (64u * kHistUnroll); base < hi; base += kRadixWaves * (64u * kHistUnroll)) {
         uint32_t key[kHistUnroll];
 #pragma unroll
         for (int u = 0; u < kHistUnroll; ++u) {
             const uint32_t e = base + u * 64u + lane;
-            key[u] = e < n ? keys[(size_t)e * KEY_STRIDE] : 0u;
+            key[u] = e < hi ? keys[(size_t)e * KEY_STRIDE] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < kHistUnroll; ++u) {
             const uint32_t e = base + u * 64u + lane;
-            const bool valid = e < n && !(skip_key && key[u] == 0xFFFFFFFFu);
+            const bool valid = e < hi && !(skip_key && key[u] == 0xFFFFFFFFu);
             const unsigned long long vmask = __ballot(valid);
             for (int p = 0; p < passes; ++p) {
                 const uint32_t digit = (key[u] >> (dbits * p)) & ((1u << dbits) - 1u);
