@@ -480,11 +480,12 @@ __global__ __launch_bounds__(kBinThreads) void k_block_counts(const uint32_t* __
             const float4 a = rec_a[idx];
             const uint32_t rx = __float_as_uint(a.z), ry = __float_as_uint(a.w);
             const uint32_t key = sorted_keys[j];
-            brec[j - j0] = make_uint4(rx, ry, key, idx);
             uint32_t bx0, bx1, by0, by1;
             if (block_rect(g, rx, ry, row_lo, row_hi, bx0, bx1, by0, by1))
                 for (uint32_t by = by0; by < by1; ++by)
                     for (uint32_t bx = bx0; bx < bx1; ++bx) c += block_takes(tab, by * g.blocks_x + bx, key, keyed != 0) ? 1u : 0u;
+            if (c)  // (only records that make an entry are ever looked up: later slabs mostly hit saturated blocks)
+                brec[j - j0] = make_uint4(rx, ry, key, idx);
             cnt[j - j0] = c;
         }
         const uint32_t tot = block_reduce_sum(c, red);
