@@ -255,6 +255,43 @@ def test_missing_rccl_is_an_error_code_not_a_crash():
     assert int(st) == _lib.GSX_ERR_RCCL and "librccl not found" in msg and "/nonexistent/librccl.so.1" in msg
 
 
+def test_new_entry_points_reject_bad_arguments_without_a_device():
+    """The round-3 additions of the C ABI (transports, layered shard call, buffer handles, statistics) check their arguments
+    before they touch a device: status codes and messages, nothing aborts.  (What they compute is tested under -m gpu.)"""
+    import ctypes as C
+
+    L = _lib.load()
+    g = C.c_void_p()
+    assert L.gsx_comm_group_create(0, 0, C.byref(g)) == _lib.GSX_ERR_INVALID_ARG and b"world" in L.gsx_last_error_string()
+    assert L.gsx_comm_group_create(65, 0, C.byref(g)) == _lib.GSX_ERR_INVALID_ARG
+    assert L.gsx_comm_group_create(3, 0, None) == _lib.GSX_ERR_INVALID_ARG
+    assert L.gsx_comm_group_create(3, 250, C.byref(g)) == _lib.GSX_OK and g.value
+    assert L.gsx_viewer_comm_init_group(None, g, 0) == _lib.GSX_ERR_INVALID_ARG          # no viewer
+    L.gsx_comm_group_destroy(g)
+    L.gsx_comm_group_destroy(None)                                                       # a no-op, like free(NULL)
+    n = C.c_uint64()
+    assert L.gsx_buffer_retain(None) == _lib.GSX_ERR_INVALID_ARG
+    assert L.gsx_buffer_len(None, C.byref(n)) == _lib.GSX_ERR_INVALID_ARG
+    assert L.gsx_buffer_download(None, None, 0) == _lib.GSX_ERR_INVALID_ARG
+    L.gsx_buffer_release(None)
+    h = C.c_void_p()
+    assert L.gsx_model_buffer_retain(None, b"m", 0, C.byref(h)) == _lib.GSX_ERR_INVALID_ARG
+    st = _lib.ShardStats()
+    assert L.gsx_shard_get_stats(None, C.byref(st), 0) == _lib.GSX_ERR_INVALID_ARG
+    assert L.gsx_shard_set_slot_records(None, b"m", 64) == _lib.GSX_ERR_NOT_FOUND
+    keys = (C.c_char_p * 1)(b"m")
+    mx = (C.c_uint32 * 1)(10)
+    assert L.gsx_shard_render_frame_keys(None, keys, 1, mx, 1, 0.25, 3) == _lib.GSX_ERR_INVALID_ARG
+    assert L.gsx_shard_render_frame(None, None, 0, 1, 0.25, 3) == _lib.GSX_ERR_INVALID_ARG
+    fn = _lib.COMM_FN(lambda *a: 0)
+    assert L.gsx_viewer_comm_init_custom(None, 2, 0, fn, fn, None) == _lib.GSX_ERR_INVALID_ARG
+    assert C.sizeof(_lib.ShardStats) == 56
+    hdr = open(os.path.join(ROOT, "include", "gsx.h")).read()
+    body = hdr[hdr.index("typedef struct gsx_shard_stats {"):hdr.index("} gsx_shard_stats;")]
+    fields = re.findall(r"(\w+)\s*(?:,\s*(\w+))?;", re.sub(r"/\*.*?\*/", "", body, flags=re.S).split("{", 1)[1])
+    assert [x for pair in fields for x in pair if x] == [f[0] for f in _lib.ShardStats._fields_]
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "wgpu_3dgs_viewer_app_amd")
     for path in glob.glob(os.path.join(pkg, "**", "*"), recursive=True):
