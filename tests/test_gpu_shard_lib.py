@@ -508,3 +508,130 @@ def test_full_size_cfg5_world4_and_rccl_world1_through_the_library():
     for rank, (bad, stats) in enumerate(res):
         assert not bad, f"cfg5 rank {rank}: frames differ from the single-GPU frames: {bad}"
     print("cfg5 world 4:", res[0][1])
+
+
+# ---- seeded random walks through the API, sharded against single (the multi-GPU twin of test_fuzz_operation_sequences) --------
+
+def _fuzz_ops(seed, steps=40):
+    """The walk is drawn up front: every rank (and the single viewer) replays the same list."""
+    rng = np.random.default_rng(7000 + seed)
+    ops, pose, size, visible = [], int(rng.integers(0, 240)), (LW, LH), list(LAYERS)
+    state = dict(size=1.0, mode=0, deg=3, speculate=True)
+    for _ in range(steps):
+        op = int(rng.integers(0, 16))
+        extra = None
+        if op <= 4:
+            pose = (pose + int(rng.integers(1, 3))) % 240
+        elif op == 5:
+            pose = int(rng.integers(0, 240))
+        elif op == 6:
+            size = [(LW, LH), (LW - 32, LH), (LW, LH + 16), (200, 120), (640, 368)][int(rng.integers(0, 5))]
+        elif op == 7:
+            visible = [k for k in LAYERS if rng.random() < 0.7] or ["b"]
+        elif op == 8:
+            extra = ("mask", "abcd"[int(rng.integers(0, 4))], [None, "0", "!1", "0 - 1", "0 | 1"][int(rng.integers(0, 5))])
+        elif op == 9:
+            extra = ("rect", tuple(float(x) for x in rng.uniform(0, 120, 2)), tuple(float(x) for x in rng.uniform(100, 240, 2)),
+                     int(rng.integers(0, 3)))
+        elif op == 10:
+            extra = ("edit", [0, 1, 3, 5][int(rng.integers(0, 4))], tuple(float(x) for x in rng.uniform(0, 1, 3)),
+                     float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-1, 1)), float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.3, 1.5)),
+                     float(rng.choice([0.0, 0.4])))
+        elif op == 11:
+            state.update(mode=int(rng.integers(0, 3)), size=float(rng.choice([0.6, 1.0, 1.5])), deg=int(rng.integers(0, 4)))
+        elif op == 12:
+            k = "abcd"[int(rng.integers(0, 4))]
+            extra = ("trs", k, rng.uniform(-2.0, 2.0, 3).astype(np.float32), rng.uniform(-40, 40, 3).astype(np.float32),
+                     rng.uniform(0.7, 1.3, 3).astype(np.float32))
+        elif op == 13:
+            extra = ("limits", int(rng.integers(0, 1 << 30)), float(rng.uniform(0.2, 0.9)))   # seed of a limit map, share of bounded tiles
+        elif op == 14:
+            extra = ("slots", int(rng.choice([0, 16, 64, 100000])))
+        else:
+            state["speculate"] = bool(rng.random() < 0.8)
+        ops.append(dict(pose=pose, size=size, visible=list(visible), state=dict(state), extra=extra))
+    return ops
+
+
+def _fuzz_replay(v, ops, render, world, on_frame):
+    """Applies the walk to viewer v (a rank's, or the single one: world = 1, render = gsx_render_frame)."""
+    from wgpu_3dgs_viewer_app_amd import query
+    from wgpu_3dgs_viewer_app_amd.mask import MaskEvaluator, MaskOp, MaskShape, MaskShapeKind
+
+    shapes = [MaskShape(MaskShapeKind.Box, pos=np.zeros(3, np.float32), scale=np.array([2.0, 2.0, 2.0], np.float32)),
+              MaskShape(MaskShapeKind.Ellipsoid, pos=np.array([0.5, 0.0, 0.5], np.float32), scale=np.array([1.5, 1.2, 1.5], np.float32))]
+    tr = {k: mt for k, (_, _, mt) in LAYERS.items()}
+    slots = 0
+    for step, o in enumerate(ops):
+        e = o["extra"]
+        query_on = False
+        limits = None
+        if e and e[0] == "mask":
+            mt = tr[e[1]]
+            v.update_model_transform(e[1], mt.pos, mt.quat(), mt.scale)
+            MaskEvaluator(v).evaluate(MaskOp.parse(e[2]) if e[2] else None, e[1], shapes)
+        elif e and e[0] == "rect":
+            v.update_query(query.QueryPod.rect(e[1], e[2], [query.QuerySelectionOp.Set, query.QuerySelectionOp.Add, query.QuerySelectionOp.Remove][e[3]]))
+            query_on = True
+        elif e and e[0] == "edit":
+            v.update_selection_edit_with_pod(query.GaussianEditPod(e[1], e[2], e[3], e[4], e[5], e[6]))
+            v.update_selection_highlight((1.0, 0.0, 1.0, e[7]))
+        elif e and e[0] == "trs":
+            tr[e[1]] = camera.ModelTransform(pos=e[2], rot=e[3], scale=e[4])
+            v.update_model_transform(e[1], tr[e[1]].pos, tr[e[1]].quat(), tr[e[1]].scale)
+        elif e and e[0] == "limits":
+            limits = e
+        elif e and e[0] == "slots":
+            slots = e[1]
+        w, h = o["size"]
+        cam = camera.orbit_pose(o["pose"])
+        keys = [k for k in parallel.model_render_keys(cam.pos, tr) if k in o["visible"]]
+        v.update_camera(cam, (w, h))
+        v.update_gaussian_transform(o["state"]["size"], GaussianDisplayMode(o["state"]["mode"]), GaussianShDegree.new(o["state"]["deg"]), False)
+        if world > 1:
+            tiles = ((h + 15) // 16, (w + 15) // 16)
+            for k in keys:
+                v.shard_set_slot_records(k, slots)
+                if limits is not None:   # the same map on every rank (limits are a global input)
+                    r = np.random.default_rng(limits[1])
+                    lim = r.uniform(2.0, 9.0, tiles).astype(np.float32).view(np.uint32)
+                    v.shard_set_limits(k, np.where(r.random(tiles) < limits[2], lim, np.uint32(KEY_ALL)).astype(np.uint32))
+        render(v, keys, o["state"]["speculate"])
+        for k in keys:
+            v.postprocessor.postprocess(k)
+        if query_on:
+            v.update_query(query.QueryPod.none())
+        on_frame(step, o, v.download_framebuffer())
+
+
+@pytest.mark.parametrize("seed,world,lanes", [(1, 2, 1), (2, 3, 2), (3, 4, 1), (4, 2, 2), (5, 3, 1)])
+def test_fuzz_sharded_against_single(seed, world, lanes):
+    """Random walks — camera steps and jumps, viewports (also grids of more than 256 tiles), models shown / hidden, masks, rect
+    selections + postprocess, edits + highlight, display mode / size / SH degree, model transforms, imposed limit maps, slot
+    sizes from 16 records to ample, speculation on / off — through gsx_shard_render_frame_keys on `world` ranks (threads) and
+    through gsx_render_frame on one viewer: every frame of every rank is the same bytes."""
+    scenes = _layer_scenes()
+    ops = _fuzz_ops(seed)
+    ref = {}
+    single = _layer_viewer(scenes, 0, 1)
+    _fuzz_replay(single, ops, lambda v, keys, spec: v.render_frame(keys), 1, lambda step, o, fb: ref.__setitem__(step, fb.copy()))
+    single.close()
+    assert len({o["extra"][0] for o in ops if o["extra"]}) >= 4, "the walk must mix kinds of operations"
+
+    def body(rank, group):
+        v = _layer_viewer(scenes, rank, world, group, lanes)
+        shard_max = {k: (g.shape[0] + world - 1) // world for k, g in scenes.items()}
+        bad = []
+
+        def check(step, o, fb):
+            if not np.array_equal(fb, ref[step]):
+                bad.append((step, o["extra"][0] if o["extra"] else None, float(np.abs(fb - ref[step]).max())))
+
+        _fuzz_replay(v, ops, lambda vv, keys, spec: vv.shard_render_frame_keys(keys, [shard_max[k] for k in keys], speculate=spec), world, check)
+        stats = v.shard_stats()
+        v.close()
+        return bad, stats
+
+    for rank, (bad, stats) in enumerate(run_group(world, body, timeout_ms=60000)):
+        assert not bad, f"seed {seed} rank {rank}: {bad[:5]}"
+        assert stats["frames"] == len(ops)

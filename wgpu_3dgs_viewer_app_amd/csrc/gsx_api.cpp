@@ -160,6 +160,18 @@ static gsx_status lane_sync(gsx_viewer* v, gsx_viewer* l, const char* const* key
 }
 
 namespace gsx {
+// May an index-sharded frame of these models run on a lane?  A lane's shadow models view the Gaussian data, the mask and the
+// transform; selections, edit records, the query and the highlight live with the viewer itself (as for gsx_render_frame:
+// frame_may_overlap).  tests/test_gpu_shard_lib.py::test_fuzz_sharded_against_single found the hole.
+bool shard_frame_may_use_lanes(gsx_viewer* v, const char* const* keys, uint32_t n_keys) {
+    if (v->query.kind != GSX_QUERY_NONE || v->highlight[3] > 0.0f) return false;
+    for (uint32_t i = 0; i < n_keys; ++i) {
+        Model* m = find_model(v, keys[i]);
+        if (!m || m->has_selection || m->has_edits) return false;
+    }
+    return true;
+}
+
 gsx_status lane_acquire(gsx_viewer* v, uint32_t index, const char* const* keys, uint32_t n_keys, gsx_viewer** out) {
     *out = v;
     if (index == 0) return GSX_OK;

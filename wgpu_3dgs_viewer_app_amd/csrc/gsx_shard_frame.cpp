@@ -235,8 +235,21 @@ gsx_status gsx_shard_render_frame_keys(gsx_viewer* v, const char* const* keys_fa
     }
     BusyGuard guard(v);
     gsx_status st = GSX_OK;
-    const uint32_t lanes = std::max(1u, std::min(v->options.frames_in_flight, 4u));
+    uint32_t lanes = std::max(1u, std::min(v->options.frames_in_flight, 4u));
     if ((st = comm_ensure_lanes(v, lanes))) return st;
+    if (lanes > 1 && !shard_frame_may_use_lanes(v, keys_far_to_near, n_keys)) {
+        // a frame with a query, a selection, edits or a highlight runs on the viewer itself, alone: whatever is in flight
+        // completes first (in order), then this frame's front and back run in this call
+        while (!v->shard_pending.empty()) {
+            st = frame_back(v, v->shard_pending.front());
+            v->shard_pending.pop_front();
+            if (st) {
+                v->shard_pending.clear();
+                return st;
+            }
+        }
+        lanes = 1;
+    }
     gsx_viewer* lane = v;
     if (lanes > 1 && (st = lane_acquire(v, v->shard_turn++ % lanes, keys_far_to_near, n_keys, &lane))) return st;
     v->shard_pending.emplace_back();

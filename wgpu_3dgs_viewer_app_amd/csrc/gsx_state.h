@@ -408,6 +408,7 @@ inline float4* fb_ptr(gsx_viewer* v) { return v->ext_fb ? static_cast<float4*>(v
 
 // lane `index` (0 = the viewer itself) brought up to date for a frame of `keys` (gsx_api.cpp)
 gsx_status lane_acquire(gsx_viewer* v, uint32_t index, const char* const* keys, uint32_t n_keys, gsx_viewer** out);
+bool shard_frame_may_use_lanes(gsx_viewer* v, const char* const* keys, uint32_t n_keys);  // gsx_api.cpp
 
 // ---- frame scheduling (gsx_frame.cpp) ----
 // defer_visible_count: a gsx_sort of this model follows at once (gsx_render_frame): its admission scan sums N_vis
