@@ -185,6 +185,14 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
 
+    # GSX_BENCH_ONE_DEVICE=1 (test aid, tests/test_gpu_bench_ranks.py): every rank uses device 0 and carries a host identity of its
+    # own, so RCCL accepts N ranks on ONE GPU and connects them over its socket transport on `lo`.  The N > 1 code of this file and
+    # of libgsx then runs for real, between processes; the rate it prints measures nothing and the line says so.
+    one_device = world > 1 and os.environ.get("GSX_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        os.environ.update({"NCCL_HOSTID": f"gsx-bench-rank-{rank}", "NCCL_SOCKET_IFNAME": "lo", "NCCL_IB_DISABLE": "1", "NCCL_NET": "Socket"})
+        local_rank = 0
+
     # PMC child passes first: nothing in this process has initialised the GPU yet
     traffic, traffic_note = None, "skipped"
     single = world == 1 and not args.force_dist
@@ -672,6 +680,9 @@ def main():
                                       "few microseconds of stream gap: the frame is slower than value_one_frame_in_flight)")
         if per_rank is not None:
             out["per_rank"] = per_rank
+        if one_device:
+            out["one_device_emulation"] = (f"GSX_BENCH_ONE_DEVICE=1: the {world} ranks are processes sharing ONE GPU, RCCL over sockets on lo — the N > 1 "
+                                           "code ran for real, `value` measures nothing")
         if robustness is not None:
             out["robustness"] = robustness
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,116 @@
+"""One rank of tests/test_gpu_rccl_peers.py: a PROCESS of its own that renders index-sharded frames through the library's frame loop
+(gsx_shard_render_frame) over a real RCCL communicator of `world` ranks — every rank on the box's one GPU.
+
+RCCL refuses two ranks of one communicator on the same device of the same host; NCCL_HOSTID (set by the test, one value per
+rank) makes every rank look like a host of its own, so the ranks talk through RCCL's network transport (sockets on `lo`): real
+ncclSend / ncclRecv to a PEER, real all-gathers, two processes, the library's own control flow on both sides.  Nothing here
+re-states the protocol; the worker uploads its shard, calls the library and compares what comes back with the single-viewer
+frame of the whole scene, bit for bit.
+
+usage: rccl_peer_worker.py <rank> <world> <uid file> <mode> <lanes>      exit 0 = frames identical, 77 = no communicator here"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from tests import common  # noqa: E402
+from wgpu_3dgs_viewer_app_amd import _lib, camera, parallel  # noqa: E402
+from wgpu_3dgs_viewer_app_amd.viewer import GaussianDisplayMode, GaussianShDegree, GsxError, MultiModelViewer  # noqa: E402
+
+N, W, H = 9000, 208, 152
+POSES = (57, 58, 61, 90, 91, 200)
+TILES = ((H + 15) // 16, (W + 15) // 16)
+
+
+def uniforms(v, pose):
+    v.update_camera(camera.orbit_pose(pose), (W, H))
+    v.update_gaussian_transform(1.0, GaussianDisplayMode.Splat, GaussianShDegree.new(3), False)
+
+
+def main():
+    rank, world, uid_path, mode, lanes = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], int(sys.argv[5])
+    g = common.small_scene(N, 91, scale_mul=14.0)
+    ref = []
+    with MultiModelViewer() as v:
+        v.add_model("m", N)
+        v.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g)
+        for pose in POSES:
+            uniforms(v, pose)
+            v.render_frame(["m"])
+            ref.append(v.download_framebuffer().copy())
+
+    s0, c = parallel.shard_range(N, rank, world)
+    v = MultiModelViewer()
+    v.set_render_options(frames_in_flight=lanes)
+    v.add_model("m", c)
+    v.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g[s0:s0 + c])
+    # the unique id travels through a file: rank 0 draws it, the others wait for it
+    if rank == 0:
+        uid = (C.c_uint8 * 128)()
+        try:
+            _lib.check(v._L.gsx_comm_unique_id(uid))
+        except GsxError as e:
+            print(f"rank {rank}: no RCCL here: {e}", flush=True)
+            return 77
+        with open(uid_path + ".tmp", "wb") as f:
+            f.write(bytes(uid))
+        os.replace(uid_path + ".tmp", uid_path)
+        uid = bytes(uid)
+    else:
+        t0 = time.time()
+        while not os.path.exists(uid_path):
+            if time.time() - t0 > 60:
+                print(f"rank {rank}: no unique id after 60 s", flush=True)
+                return 77
+            time.sleep(0.05)
+        uid = open(uid_path, "rb").read()
+    try:
+        v.comm_init_rccl(world, rank, uid)
+    except GsxError as e:
+        print(f"rank {rank}: communicator of {world} ranks on one GPU refused: {e}", flush=True)
+        return 77
+    print(f"rank {rank}: communicator up", flush=True)
+
+    shard_max = (N + world - 1) // world
+    frames = []
+    for pose in POSES:
+        uniforms(v, pose)
+        if mode == "all_refusing":   # verdict -> exactly sized repair round over the links
+            v.shard_set_limits("m", np.full(TILES, 0x40400000, np.uint32))
+        elif mode == "tiny_slots":   # overflow verdict -> round 0 redone with whole-shard slots
+            v.shard_set_slot_records("m", 64)
+        v.shard_render_frame("m", shard_max)
+        if lanes == 1:
+            frames.append(v.download_framebuffer().copy())
+    if lanes > 1:  # frames in flight: the last frame is what the viewer holds after a sync
+        frames = [None] * (len(POSES) - 1) + [v.download_framebuffer().copy()]
+    stats = v.shard_stats()
+    v.close()
+    bad = [k for k, fb in enumerate(frames) if fb is not None and not np.array_equal(fb, ref[k])]
+    print(f"rank {rank}: stats {stats}", flush=True)
+    if bad:
+        print(f"rank {rank}: frames {bad} differ from the single-viewer frames (L-inf {max(np.abs(frames[k] - ref[k]).max() for k in bad)})", flush=True)
+        return 1
+    if stats["frames"] != len(POSES):
+        print(f"rank {rank}: {stats['frames']} frames counted", flush=True)
+        return 1
+    if world > 1 and stats["wire_bytes"] == 0:
+        print(f"rank {rank}: nothing went over the links", flush=True)
+        return 1
+    if mode == "all_refusing" and stats["repair_frames"] == 0:
+        print(f"rank {rank}: no repair round ran", flush=True)
+        return 1
+    if mode == "tiny_slots" and stats["redo_frames"] == 0:
+        print(f"rank {rank}: no frame was redone", flush=True)
+        return 1
+    print(f"rank {rank}: OK ({mode}, {lanes} lane(s), {stats['wire_bytes']} bytes on the links)", flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,58 @@
+"""GPU: the library's sharded frame loop over REAL RCCL with a PEER — two (three) processes, one communicator, one GPU.
+
+Everything else that runs `gsx_shard_render_frame` with more than one rank in this suite uses the in-process group transport
+(tests/test_gpu_shard_lib.py); RCCL itself had only ever run at world 1, where a rank's exchange is a device copy.  Here
+every rank is a process (tests/rccl_peer_worker.py) with its own viewer and shard on the box's single GPU; NCCL_HOSTID gives
+each rank a host identity of its own, so RCCL accepts them on one device and connects them through its socket transport on
+`lo`: ncclSend / ncclRecv between peers, the all-gathers, the unique-id broadcast that creates a lane's communicator, the
+library's verdict / repair / redo control flow on both sides.  The frames must equal the single-viewer frames bit for bit.
+
+If RCCL cannot build such a communicator on this box (no loopback networking, a refusal of the duplicate device) the
+workers say so with exit code 77 and the test is skipped — it is an environment probe then, not a parity statement."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "rccl_peer_worker.py")
+
+
+def _run(world, mode, lanes, timeout=240):
+    with tempfile.TemporaryDirectory() as tmp:
+        uid = os.path.join(tmp, "uid")
+        procs = []
+        for rank in range(world):
+            env = dict(os.environ)
+            env.update({"NCCL_HOSTID": f"gsx-peer-test-{rank}", "NCCL_SOCKET_IFNAME": "lo", "NCCL_IB_DISABLE": "1", "NCCL_NET": "Socket",
+                        "NCCL_DEBUG": env.get("NCCL_DEBUG", "WARN"), "HSA_ENABLE_IPC_MODE_LEGACY": "0", "PYTHONPATH": ROOT})
+            procs.append(subprocess.Popen([sys.executable, WORKER, str(rank), str(world), uid, mode, str(lanes)], env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=ROOT))
+        outs, codes = [], []
+        try:
+            for p in procs:
+                out, _ = p.communicate(timeout=timeout)
+                outs.append(out)
+                codes.append(p.returncode)
+        except subprocess.TimeoutExpired:
+            for p in procs:   # exactly the processes started here
+                if p.poll() is None:
+                    p.kill()
+            outs = [p.communicate()[0] for p in procs]
+            pytest.fail(f"world {world} ({mode}, {lanes} lanes) did not finish in {timeout} s:\n" + "\n----\n".join(o[-3000:] for o in outs))
+        report = "\n----\n".join(o[-3000:] for o in outs)
+        if any(c == 77 for c in codes):
+            pytest.skip("RCCL would not build a communicator of several ranks on one GPU here:\n" + report[-1500:])
+        assert all(c == 0 for c in codes), f"exit codes {codes}:\n{report}"
+        return outs
+
+
+@pytest.mark.parametrize("world,mode,lanes", [(2, "natural", 1), (2, "all_refusing", 1), (2, "tiny_slots", 1), (2, "natural", 2), (3, "natural", 1)])
+def test_sharded_frames_over_rccl_between_processes(world, mode, lanes):
+    outs = _run(world, mode, lanes)
+    for rank, o in enumerate(outs):
+        assert f"rank {rank}: OK" in o, o[-2000:]
+        print(o.strip().splitlines()[-1])
