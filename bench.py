@@ -333,6 +333,8 @@ def main():
     # frame k + 1 is enqueued — but with every collective on one in-order stream frame k + 1's exchange queues behind frame k's
     # band gather: 1230 -> 1015 fps at world 1.  --dist-frames-in-flight L runs it anyway.)
     lib_index = use_dist and args.shard_mode == "index"
+    if lib_index:
+        viewer.shard_set_gather_root(0)   # north_star: "into one framebuffer" — rank 0's; the other ranks send their band and receive none
     lanes = args.frames_in_flight if (single and not overrides) else (args.dist_frames_in_flight if lib_index else 1)
 
     def set_opts(**kw):
@@ -354,6 +356,28 @@ def main():
     if single:
         renderer.poll()
         fb_last = renderer.framebuffer().copy()
+    if lib_index and world > 1:
+        # N > 1: rank 0 holds the last timed frame (the bands were gathered to it); it renders that pose once more from the WHOLE
+        # scene with the plainest single-GPU schedule and the two must be equal bit for bit.  The other ranks wait at the barrier.
+        renderer.poll()
+        if rank == 0:
+            fb_dist = renderer.framebuffer().copy()
+            plain = parallel.ShardedViewer(device=local_rank, world=1, rank=0, use_dist=False, sh=sh_kind, cov3d=cov_kind)
+            plain.stages.viewer.set_render_options(speculative=0, progressive=0)
+            plain.load_shard(scene.synthetic_gaussians(n, seed, sh, 0, n), 0, n)
+            plain.render_frame(orbit[pose_of[(last_idx * args.pose_stride) % 240]], (w, h))
+            plain.poll()
+            fb_plain = plain.framebuffer()
+            equal = bool(np.array_equal(fb_dist, fb_plain))
+            frame_check = dict(pose=pose_of[(last_idx * args.pose_stride) % 240], equal_to_single_gpu_single_pass_frame=equal,
+                               max_abs_diff=float(np.abs(fb_dist - fb_plain).max()),
+                               checksum=int(np.frombuffer(fb_dist.tobytes(), np.uint32).astype(np.uint64).sum() & 0xFFFFFFFFFFFF),
+                               note=f"rank 0's gathered frame of the last timed step ({world} index shards) against the whole scene rendered "
+                                    "on rank 0 alone with speculative = 0, progressive = 0")
+            plain.close()
+            if not equal:
+                raise SystemExit(f"bench.py: the sharded frame differs from the single-GPU frame: {frame_check}")
+        dist.barrier()
     acct = accounting(rounds(args.warmup))
     elapsed_1 = elapsed_ul = None
     if lanes > 1 and (single or world == 1):   # (N > 1: one timed loop, as the contract says)
@@ -567,7 +591,7 @@ def main():
         elif args.shard_mode == "index":
             sharding = (f"splat-index shards x{world}: gsx_shard_render_frame — projection of the resident shard, speculative exchange of "
                         "fixed record slots by tile-row band (RCCL point-to-point inside libgsx, counts on the device), verification + "
-                        "repair round, in-place all-gather of the bands; no host round trip inside a frame")
+                        "repair round, the finished bands gathered into rank 0's framebuffer (gsx_shard_set_gather_root); no host round trip inside a frame")
             scaling = "strong"
         else:
             sharding = (f"scene resident on each of {world} GPUs, rank g renders band g of tile rows, band all-gather "
@@ -680,6 +704,8 @@ def main():
                                       "few microseconds of stream gap: the frame is slower than value_one_frame_in_flight)")
         if per_rank is not None:
             out["per_rank"] = per_rank
+        if frame_check is not None and "frame_check" not in out:
+            out["frame_check"] = frame_check
         if one_device:
             out["one_device_emulation"] = (f"GSX_BENCH_ONE_DEVICE=1: the {world} ranks are processes sharing ONE GPU, RCCL over sockets on lo — the N > 1 "
                                            "code ran for real, `value` measures nothing")

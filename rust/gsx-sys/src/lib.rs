@@ -220,6 +220,7 @@ extern "C" {
     pub fn gsx_shard_set_limits(v: *mut gsx_viewer, key: *const c_char, limits: *const u32) -> gsx_status;
     pub fn gsx_shard_set_slot_records(v: *mut gsx_viewer, key: *const c_char, records: u32) -> gsx_status;
     pub fn gsx_shard_get_stats(v: *mut gsx_viewer, out: *mut gsx_shard_stats, reset: u32) -> gsx_status;
+    pub fn gsx_shard_set_gather_root(v: *mut gsx_viewer, root: i32) -> gsx_status;
     pub fn gsx_ply_read_header(data: *const c_void, size: u64, out: *mut gsx_ply_header) -> gsx_status;
     pub fn gsx_ply_read_gaussians(data: *const c_void, size: u64, header: *const gsx_ply_header, start: u64, n: u64, out: *mut gsx_gaussian) -> gsx_status;
     pub fn gsx_ply_write(gaussians: *const gsx_gaussian, n: u64, mask_words: *const u32, edits: *const gsx_gaussian_edit, out: *mut c_void, capacity: u64, out_size: *mut u64) -> gsx_status;

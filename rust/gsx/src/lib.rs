@@ -271,6 +271,8 @@ impl<G: GaussianPod> MultiModelViewer<G> {
         let ps: Vec<*const std::os::raw::c_char> = ks.iter().map(|k| k.as_ptr()).collect();
         check(unsafe { sys::gsx_shard_render_frame_keys(self.handle.0, ps.as_ptr(), ps.len() as u32, shard_records_max.as_ptr(), speculate as u32, margin, radius) })
     }
+    /// Where a sharded frame's bands go: `None` = every rank ends up with the whole frame (default), `Some(r)` = only rank `r`.
+    pub fn shard_set_gather_root(&mut self, root: Option<u32>) -> Result<(), Error> { check(unsafe { sys::gsx_shard_set_gather_root(self.handle.0, root.map(|r| r as i32).unwrap_or(-1)) }) }
     /// One process, one thread + one viewer per GPU: seat `rank` of an in-process group (`sys::gsx_comm_group_create`).
     pub fn comm_init_group(&mut self, group: *mut sys::gsx_comm_group, rank: u32) -> Result<(), Error> { check(unsafe { sys::gsx_viewer_comm_init_group(self.handle.0, group, rank) }) }
 }

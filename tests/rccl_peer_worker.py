@@ -76,6 +76,8 @@ def main():
         return 77
     print(f"rank {rank}: communicator up", flush=True)
 
+    if mode == "root_gather":
+        v.shard_set_gather_root(0)
     shard_max = (N + world - 1) // world
     frames = []
     for pose in POSES:
@@ -91,6 +93,11 @@ def main():
         frames = [None] * (len(POSES) - 1) + [v.download_framebuffer().copy()]
     stats = v.shard_stats()
     v.close()
+    if mode == "root_gather" and rank != 0:   # only rank 0 holds the frame; this rank still holds its own band of tile rows
+        rows = 16 * ((TILES[0] + world - 1) // world)
+        lo, hi = min(rank * rows, H), min((rank + 1) * rows, H)
+        frames = [None if fb is None else fb[lo:hi] for fb in frames]
+        ref = [fb[lo:hi] for fb in ref]
     bad = [k for k, fb in enumerate(frames) if fb is not None and not np.array_equal(fb, ref[k])]
     print(f"rank {rank}: stats {stats}", flush=True)
     if bad:

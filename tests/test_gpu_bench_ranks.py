@@ -48,3 +48,4 @@ def test_bench_with_ranks_as_processes(world, extra):
         assert len(pr["shard_gaussians"]) == world and sum(pr["shard_gaussians"]) == 400000
         assert all(b > 0 for b in pr["wire_bytes_per_frame"]), "every rank put records on the links"
         assert all(r >= 1.0 for r in pr["exchange_rounds_per_frame"])
+        assert d["frame_check"]["equal_to_single_gpu_single_pass_frame"] is True, d["frame_check"]

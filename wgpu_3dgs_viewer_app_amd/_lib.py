@@ -33,7 +33,7 @@ EXPORTS = (
     "gsx_shard_next_windows", "gsx_shard_download_limits", "gsx_comm_unique_id", "gsx_viewer_comm_init", "gsx_viewer_comm_destroy",
     "gsx_comm_all_to_all", "gsx_comm_all_gather", "gsx_shard_render_frame", "gsx_shard_render_frame_keys",
     "gsx_comm_group_create", "gsx_comm_group_destroy", "gsx_viewer_comm_init_group", "gsx_viewer_comm_init_custom",
-    "gsx_shard_set_limits", "gsx_shard_set_slot_records", "gsx_shard_get_stats",
+    "gsx_shard_set_limits", "gsx_shard_set_slot_records", "gsx_shard_get_stats", "gsx_shard_set_gather_root",
     "gsx_model_buffer_retain", "gsx_buffer_retain", "gsx_buffer_release", "gsx_buffer_len", "gsx_buffer_download",
     "gsx_gaussian_edit_default", "gsx_update_query", "gsx_update_query_texture", "gsx_update_selection_highlight",
     "gsx_update_selection_edit", "gsx_model_show_unedited", "gsx_postprocess", "gsx_model_upload_selection",
@@ -208,6 +208,7 @@ def load() -> C.CDLL:
         "gsx_viewer_comm_init_custom": ([vp, u32, u32, COMM_FN, COMM_FN, vp], C.c_int32),
         "gsx_shard_set_limits": ([vp, cp, vp], C.c_int32),
         "gsx_shard_set_slot_records": ([vp, cp, u32], C.c_int32),
+        "gsx_shard_set_gather_root": ([vp, C.c_int32], C.c_int32),
         "gsx_shard_get_stats": ([vp, C.POINTER(ShardStats), u32], C.c_int32),
         "gsx_model_buffer_retain": ([vp, cp, C.c_int, C.POINTER(vp)], C.c_int32),
         "gsx_buffer_retain": ([vp], C.c_int32),

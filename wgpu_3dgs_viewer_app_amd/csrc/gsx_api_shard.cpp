@@ -610,6 +610,15 @@ gsx_status gsx_shard_get_stats(gsx_viewer* v, gsx_shard_stats* out, uint32_t res
     return GSX_OK;
 }
 
+gsx_status gsx_shard_set_gather_root(gsx_viewer* v, int32_t root) {
+    gsx_status st = viewer_bind(v);  // (finishes the sharded frames in flight: they were promised the old destination)
+    if (st) return st;
+    if (v->parent) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_set_gather_root: called on a lane");
+    if (root < -1 || root >= 64) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_set_gather_root: root %d (-1 = every rank, else a rank)", (int)root);
+    v->shard_gather_root = root;
+    return GSX_OK;
+}
+
 gsx_status gsx_shard_download_limits(gsx_viewer* v, const char* key, uint32_t* limits, uint64_t n_words) {
     gsx_status st = viewer_bind(v);
     if (st) return st;

@@ -243,6 +243,30 @@ gsx_status gsx_comm_all_gather(gsx_viewer* v, const void* d_send, void* d_recv, 
 
 }  // extern "C"
 
+// The bands of a frame to ONE rank: everybody else sends its piece, the root receives world - 1 of them side by side (its own
+// is in place already, or copied on the device).  Transports without point-to-point calls fall back to their all-gather.
+gsx_status gsx::comm_gather_to_root(gsx_viewer* v, const void* d_send, void* d_recv, uint64_t bytes_per_rank, uint32_t root) {
+    gsx_viewer* o = owner_of(v);
+    if (!has_comm(o)) return fail(GSX_ERR_RCCL, "gather to root: no communicator (gsx_viewer_comm_init)");
+    if (root >= o->comm_world) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_set_gather_root: root %u of %u ranks", root, o->comm_world);
+    if (o->comm_ag_fn || (o->comm_world == 1 && !o->comm_self_via_rccl)) return gsx_comm_all_gather(v, d_send, d_recv, bytes_per_rank);
+    if (bytes_per_rank == 0) return GSX_OK;
+    ncclComm_t comm = comm_of(v);
+    if (!comm) return fail(GSX_ERR_RCCL, "gather to root: lane %u has no communicator", v->lane_index);
+    if (o->comm_rank != root) {
+        o->shard_stats.wire_bytes += bytes_per_rank;
+        RCCLCHK(g_rccl.Send(d_send, bytes_per_rank, kNcclChar, (int)root, comm, v->stream));
+        return GSX_OK;
+    }
+    char* own = static_cast<char*>(d_recv) + (size_t)root * bytes_per_rank;
+    if (own != d_send) HIPCHK(hipMemcpyAsync(own, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, v->stream));
+    RCCLCHK(g_rccl.GroupStart());
+    for (uint32_t p = 0; p < o->comm_world; ++p)
+        if (p != root) RCCLCHK(g_rccl.Recv(static_cast<char*>(d_recv) + (size_t)p * bytes_per_rank, bytes_per_rank, kNcclChar, (int)p, comm, v->stream));
+    RCCLCHK(g_rccl.GroupEnd());
+    return GSX_OK;
+}
+
 // One communicator per lane (see the head of this file).  Collective: every rank calls it with the same `lanes` — they do,
 // it follows from gsx_render_options.frames_in_flight, which an SPMD host sets alike everywhere.
 gsx_status gsx::comm_ensure_lanes(gsx_viewer* v, uint32_t lanes) {

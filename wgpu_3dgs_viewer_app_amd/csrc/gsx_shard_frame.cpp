@@ -81,7 +81,9 @@ gsx_status next_limits(Ctx& c, size_t i) {
 // the bands, in place: every rank's band lands where it belongs in every rank's framebuffer
 gsx_status band_gather(Ctx& c) {
     char* fb = static_cast<char*>(c.l->ext_fb);
-    gsx_status st = gsx_comm_all_gather(c.l, fb + c.lay.band_offset_bytes, fb, c.lay.band_bytes);
+    const int32_t root = c.owner->shard_gather_root;
+    gsx_status st = root < 0 ? gsx_comm_all_gather(c.l, fb + c.lay.band_offset_bytes, fb, c.lay.band_bytes)
+                             : comm_gather_to_root(c.l, fb + c.lay.band_offset_bytes, fb, c.lay.band_bytes, (uint32_t)root);
     c.p->gathered = st == GSX_OK;
     return st;
 }

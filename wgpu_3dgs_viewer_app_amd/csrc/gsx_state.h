@@ -319,6 +319,7 @@ struct gsx_viewer {
     void* comm_ctx = nullptr;
     gsx_comm_group* comm_group = nullptr;  // != nullptr: comm_ctx is this viewer's seat in that group (gsx_comm_group.cpp)
     gsx_shard_stats shard_stats{};       // host-side bookkeeping of the sharded frames (gsx_shard_get_stats)
+    int32_t shard_gather_root = -1;  // gsx_shard_set_gather_root: -1 every rank receives every band, >= 0 only that rank
     DevBuf shard_fb, shard_send, shard_recv, shard_sat_band, shard_sat_all, shard_counts;  // gsx_shard_render_frame's own buffers
     void* ext_fb = nullptr;              // caller-owned framebuffer (multi-GPU: the RCCL gather target)
     uint64_t ext_fb_bytes = 0;
@@ -373,6 +374,7 @@ inline uint32_t ceil_log2(uint32_t x) {
 gsx_status shard_complete_pending(gsx_viewer* v);  // gsx_comm.cpp: verdicts, redo / repair rounds of the sharded frames in flight
 inline bool has_comm(const gsx_viewer* v) { return v->comm != nullptr || v->comm_a2a_fn != nullptr; }
 void group_leave(gsx_viewer* v);  // gsx_comm_group.cpp: give this viewer's seat in its in-process group back
+gsx_status comm_gather_to_root(gsx_viewer* v, const void* d_send, void* d_recv, uint64_t bytes_per_rank, uint32_t root);  // gsx_comm.cpp
 gsx_status comm_ensure_lanes(gsx_viewer* v, uint32_t lanes);  // gsx_comm.cpp: one RCCL communicator per lane (collective)
 
 inline gsx_status viewer_bind(gsx_viewer* v) {

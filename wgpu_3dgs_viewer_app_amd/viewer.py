@@ -476,6 +476,10 @@ class MultiModelViewer:
     def shard_set_slot_records(self, key: str, records: int) -> None:
         _lib.check(self._L.gsx_shard_set_slot_records(self._h, key.encode(), int(records)))
 
+    def shard_set_gather_root(self, root: int) -> None:
+        """-1: every rank's framebuffer holds the whole frame after a sharded frame (default); r >= 0: only rank r's does."""
+        _lib.check(self._L.gsx_shard_set_gather_root(self._h, int(root)))
+
     def shard_download_limits(self, key: str) -> np.ndarray:
         w, h = self.size
         out = np.empty(((h + 15) // 16, (w + 15) // 16), np.uint32)
