@@ -32,24 +32,8 @@ def uniforms(v, pose):
     v.update_gaussian_transform(1.0, GaussianDisplayMode.Splat, GaussianShDegree.new(3), False)
 
 
-def main():
-    rank, world, uid_path, mode, lanes = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], int(sys.argv[5])
-    g = common.small_scene(N, 91, scale_mul=14.0)
-    ref = []
-    with MultiModelViewer() as v:
-        v.add_model("m", N)
-        v.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g)
-        for pose in POSES:
-            uniforms(v, pose)
-            v.render_frame(["m"])
-            ref.append(v.download_framebuffer().copy())
-
-    s0, c = parallel.shard_range(N, rank, world)
-    v = MultiModelViewer()
-    v.set_render_options(frames_in_flight=lanes)
-    v.add_model("m", c)
-    v.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g[s0:s0 + c])
-    # the unique id travels through a file: rank 0 draws it, the others wait for it
+def connect(v, rank, world, uid_path):
+    """the unique id travels through a file: rank 0 draws it, the others wait for it; 77 = no communicator to be had here"""
     if rank == 0:
         uid = (C.c_uint8 * 128)()
         try:
@@ -75,6 +59,64 @@ def main():
         print(f"rank {rank}: communicator of {world} ranks on one GPU refused: {e}", flush=True)
         return 77
     print(f"rank {rank}: communicator up", flush=True)
+    return 0
+
+
+def layered(rank, world, uid_path, mode, lanes):
+    """four models with their own TRS, layered far -> near in an order that changes with the camera (gsx_shard_render_frame_keys)"""
+    from tests import test_gpu_shard_lib as T
+
+    scenes = T._layer_scenes()
+    ref = T._layer_reference(scenes)
+    v = T._layer_viewer(scenes, rank, world, None, lanes)
+    rc = connect(v, rank, world, uid_path)
+    if rc:
+        return rc
+    shard_max = {k: (g.shape[0] + world - 1) // world for k, g in scenes.items()}
+    bad = []
+    for k, pose in enumerate(T.LPOSES):
+        T._uniforms(v, pose, (T.LW, T.LH))
+        keys = T._layer_keys(pose)
+        if mode == "layered_refusing":
+            for key in keys:
+                v.shard_set_limits(key, np.full(T.LTILES, 0x40400000, np.uint32))
+        v.shard_render_frame_keys(keys, [shard_max[x] for x in keys])
+        if lanes == 1 or k == len(T.LPOSES) - 1:
+            fb = v.download_framebuffer()
+            if not np.array_equal(fb, ref[k]):
+                bad.append((k, float(np.abs(fb - ref[k]).max())))
+    stats = v.shard_stats()
+    v.close()
+    print(f"rank {rank}: stats {stats}", flush=True)
+    if bad or stats["wire_bytes"] == 0 or (mode == "layered_refusing" and stats["repair_frames"] != stats["frames"]):
+        print(f"rank {rank}: layered frames differ / nothing sent / no repair: {bad}", flush=True)
+        return 1
+    print(f"rank {rank}: OK ({mode}, {lanes} lane(s), {stats['wire_bytes']} bytes on the links)", flush=True)
+    return 0
+
+
+def main():
+    rank, world, uid_path, mode, lanes = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], int(sys.argv[5])
+    if mode.startswith("layered"):
+        return layered(rank, world, uid_path, mode, lanes)
+    g = common.small_scene(N, 91, scale_mul=14.0)
+    ref = []
+    with MultiModelViewer() as v:
+        v.add_model("m", N)
+        v.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g)
+        for pose in POSES:
+            uniforms(v, pose)
+            v.render_frame(["m"])
+            ref.append(v.download_framebuffer().copy())
+
+    s0, c = parallel.shard_range(N, rank, world)
+    v = MultiModelViewer()
+    v.set_render_options(frames_in_flight=lanes)
+    v.add_model("m", c)
+    v.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g[s0:s0 + c])
+    rc = connect(v, rank, world, uid_path)
+    if rc:
+        return rc
 
     if mode == "root_gather":
         v.shard_set_gather_root(0)
