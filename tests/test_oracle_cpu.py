@@ -279,6 +279,7 @@ def test_new_entry_points_reject_bad_arguments_without_a_device():
     st = _lib.ShardStats()
     assert L.gsx_shard_get_stats(None, C.byref(st), 0) == _lib.GSX_ERR_INVALID_ARG
     assert L.gsx_shard_set_slot_records(None, b"m", 64) == _lib.GSX_ERR_NOT_FOUND
+    assert L.gsx_shard_set_gather_root(None, 0) == _lib.GSX_ERR_INVALID_ARG
     keys = (C.c_char_p * 1)(b"m")
     mx = (C.c_uint32 * 1)(10)
     assert L.gsx_shard_render_frame_keys(None, keys, 1, mx, 1, 0.25, 3) == _lib.GSX_ERR_INVALID_ARG
