@@ -35,10 +35,13 @@ def _launch(world, extra, port, timeout=420):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("world,extra", [(2, []), (2, ["--dist-frames-in-flight", "1"]), (3, []), (2, ["--shard-mode", "frames"]),
-                                         (2, ["--shard-mode", "screen"])])
-def test_bench_with_ranks_as_processes(world, extra):
-    d = _launch(world, extra, 29530 + world + 7 * len(extra))
+CASES = [(2, []), (2, ["--dist-frames-in-flight", "1"]), (3, []), (2, ["--shard-mode", "frames"]), (2, ["--shard-mode", "screen"])]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)), ids=[f"world{w}" + "".join(x.replace("--", "-") for x in e) for w, e in CASES])
+def test_bench_with_ranks_as_processes(case):
+    world, extra = CASES[case]
+    d = _launch(world, extra, 29531 + 3 * case + (os.getpid() % 200))   # a rendezvous port of its own per case and per pytest process
     assert d["n_gpus"] == world and d["steps"] == 12 and d["warmup"] == 4 and d["value"] > 0
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 1e-2
     assert "one_device_emulation" in d and d["overflow_slabs"] == 0
