@@ -72,6 +72,53 @@ def test_orbit_with_jumps_bit_identical(margin, radius, host_verify):
     plain.close()
 
 
+@pytest.mark.parametrize("what", ["edit", "highlight", "both", "stored"])
+def test_lazy_shading_with_colour_ops(what):
+    """A selection edit / highlight / stored edits no longer switch lazy shading off: a speculated frame shades only what it
+    admits and applies the colour ops to exactly those records (shade_admitted) — in the main round, in the repair round (camera
+    jumps) and after a full re-projection (download_projection).  Frame for frame equal to the unspeculated viewer's."""
+    from wgpu_3dgs_viewer_app_amd.query import GaussianEditFlag as F
+
+    n = 30000
+    g = common.small_scene(n, 207, scale_mul=10.0)
+    rng = np.random.default_rng(17)
+    sel = rng.integers(0, 2 ** 32, (n + 31) // 32, dtype=np.uint64).astype(np.uint32)
+    sel[-1] &= np.uint32((1 << (n % 32)) - 1) if n % 32 else np.uint32(0xFFFFFFFF)
+    edit = query.GaussianEditPod(F.ENABLED, (0.3, 1.5, 0.8), 0.25, -0.75, 2.2, 0.6)   # colour AND opacity change
+    spec, plain = _viewer(True, spec_margin=0.1, spec_radius=1), _viewer(False, progressive=0)
+    for v in (spec, plain):
+        _load(v, "m", g)
+        v.models["m"].gaussian_buffers.selection_buffer.upload(sel)
+        if what in ("edit", "both", "stored"):
+            v.update_selection_edit_with_pod(edit)
+        if what in ("highlight", "both"):
+            v.update_selection_highlight((1.0, 0.0, 1.0, 0.5))
+    engaged = repaired = 0
+    for k, pose in enumerate([10, 11, 12, 13, 130, 131, 132, 60, 61, 61, 200, 201]):
+        cam = camera.orbit_pose(pose)
+        if what == "stored" and k == 3:   # leave edit mode: the edits stored so far keep rendering, no selection
+            for v in (spec, plain):
+                v.models["m"].gaussian_buffers.selection_buffer.upload(None)
+                v.update_selection_edit_with_pod(query.GaussianEditPod.default())
+        a, b = _frame(spec, cam, ["m"]), _frame(plain, cam, ["m"])
+        assert np.array_equal(a, b), f"{what}: pose {pose} (frame {k}): L-inf {np.abs(a - b).max()}"
+        st = spec.frame_stats("m")
+        if st["speculated"]:
+            engaged += st["n_sorted"] < 0.8 * st["n_visible"]
+            repaired += st["n_repair_tiles"] > 0
+        if k in (5, 9):   # every record, edited: the lazily shaded frame completes itself
+            pa, pb = spec.download_projection("m"), plain.download_projection("m")
+            for name in ("key", "rect", "rgb", "conic_opacity"):
+                assert np.array_equal(pa[name], pb[name]), (what, k, name)
+    assert engaged >= 6 and repaired >= 2, (engaged, repaired)
+    unedited = common.small_scene(n, 207, scale_mul=10.0)
+    with MultiModelViewer() as u:
+        _load(u, "m", unedited)
+        assert not np.array_equal(_frame(u, cam, ["m"]), a), "the colour ops must be visible in the frame"
+    spec.close()
+    plain.close()
+
+
 def test_scene_changes_under_the_windows():
     """mask, hidden edit, model transform, Gaussian size, viewport: every change invalidates the inherited windows in
     some tiles; the repair round must make up for all of it."""
@@ -310,10 +357,12 @@ def test_cfg5_full_size_layered_models():
 
 
 @pytest.mark.parametrize("seed", [int(x) for x in os.environ.get("GSX_FUZZ_SEEDS", "1,2,3,4,5,6,7,8").split(",")])
-def test_fuzz_operation_sequences(seed):
+def test_fuzz_operation_sequences(seed, monkeypatch):
     """Seeded random walks through the API — camera steps and jumps, viewport changes, models shown / hidden / re-ordered,
-    masks, selections, edits, highlight, display mode, Gaussian size, speculation parameters — applied to a speculating and
-    a non-speculating viewer in lock-step: every frame must be the same bytes."""
+    masks, selections (uploaded, and made by rectangle queries + postprocess), selection edits, stored edits uploaded and
+    dropped, the unedited view, highlight, display mode, Gaussian size, speculation parameters — applied to a speculating and
+    a non-speculating viewer in lock-step: every frame must be the same bytes.  The plain viewer also runs k_edit_prepare every
+    frame (GSX_NO_EDIT_CACHE) while the speculating one skips it when none of its inputs changed."""
     from wgpu_3dgs_viewer_app_amd import parallel
     from wgpu_3dgs_viewer_app_amd.mask import MaskEvaluator, MaskOp, MaskShape, MaskShapeKind
 
@@ -323,17 +372,22 @@ def test_fuzz_operation_sequences(seed):
     tr = {k: camera.ModelTransform(pos=rng.uniform(-2.0, 2.0, 3).astype(np.float32), rot=rng.uniform(-40, 40, 3).astype(np.float32),
                                    scale=rng.uniform(0.7, 1.3, 3).astype(np.float32)) for k in scenes}
     lanes = 1 + seed % 3  # frames in flight: consecutive frames of the speculating viewer alternate between lanes
-    spec, plain = _viewer(True, host_verify=seed % 3, frames_in_flight=lanes), _viewer(False)
+    spec = _viewer(True, host_verify=seed % 3, frames_in_flight=lanes)
+    monkeypatch.setenv("GSX_NO_EDIT_CACHE", "1")
+    plain = _viewer(False)
+    monkeypatch.delenv("GSX_NO_EDIT_CACHE")
     for v in (spec, plain):
         for k, g in scenes.items():
             _load(v, k, g, tr[k])
+    unedited = {k: False for k in scenes}
     shapes = [MaskShape(MaskShapeKind.Box, pos=np.zeros(3, np.float32), scale=np.array([2.0, 2.0, 2.0], np.float32)),
               MaskShape(MaskShapeKind.Ellipsoid, pos=np.array([0.5, 0.0, 0.5], np.float32), scale=np.array([1.5, 1.2, 1.5], np.float32))]
     pose, size, visible = int(rng.integers(0, 240)), (W, H), ["a", "b", "c"]
     state = dict(size=1.0, mode=GaussianDisplayMode.Splat, deg=3)
     speculated = 0
     for step in range(60):
-        op = int(rng.integers(0, 14))
+        op = int(rng.integers(0, 17))
+        qpod = None
         both = lambda fn: [fn(v) for v in (spec, plain)]  # noqa: E731
         if op <= 4:
             pose = (pose + int(rng.integers(1, 3))) % 240                       # a camera step
@@ -368,20 +422,43 @@ def test_fuzz_operation_sequences(seed):
             tr[k] = camera.ModelTransform(pos=rng.uniform(-2.0, 2.0, 3).astype(np.float32), rot=rng.uniform(-40, 40, 3).astype(np.float32),
                                           scale=rng.uniform(0.7, 1.3, 3).astype(np.float32))
             both(lambda v: v.update_model_transform(k, tr[k].pos, tr[k].quat(), tr[k].scale))
-        else:
+        elif op == 13:
             spec.set_render_options(speculative=1, min_slab=2048, spec_margin=float(rng.choice([0.0, 0.25, 1.0])), spec_radius=int(rng.integers(0, 5)),
                                     host_verify=int(rng.integers(0, 3)), frames_in_flight=lanes)
+        elif op == 14:   # stored edits from the host (a loaded session), or dropped
+            k = "abc"[int(rng.integers(0, 3))]
+            edits = None
+            if rng.random() < 0.7:
+                edits = query.default_edits(scenes[k].shape[0])
+                on = rng.random(edits.shape[0]) < 0.3
+                edits["flag"][on] = rng.choice([1, 3, 5], int(on.sum()))
+                edits["color"][on] = rng.uniform(0, 1, (int(on.sum()), 3))
+                edits["alpha"][on] = rng.uniform(0.3, 1.5, int(on.sum()))
+            both(lambda v: v.models[k].gaussian_buffers.gaussians_edit_buffer.upload(edits))
+        elif op == 15:   # a rectangle query this frame: postprocess applies its selection op
+            x0, y0 = float(rng.uniform(0, size[0] * 0.6)), float(rng.uniform(0, size[1] * 0.6))
+            sop = [query.QuerySelectionOp.Set, query.QuerySelectionOp.Add, query.QuerySelectionOp.Remove][int(rng.integers(0, 3))]
+            qpod = query.QueryPod.rect((x0, y0), (x0 + float(rng.uniform(10, size[0] * 0.4)), y0 + float(rng.uniform(10, size[1] * 0.4))), sop)
+        else:
+            k = "abc"[int(rng.integers(0, 3))]
+            unedited[k] = not unedited[k]
+            both(lambda v: v.show_unedited(k, unedited[k]))
         cam = camera.orbit_pose(pose)
         keys = [k for k in parallel.model_render_keys(cam.pos, tr) if k in visible]
         out = []
         for v in (spec, plain):
             v.update_camera(cam, size)
             v.update_gaussian_transform(state["size"], state["mode"], GaussianShDegree.new(state["deg"]), False)
+            v.update_query(qpod if qpod is not None else query.QueryPod.none())
             v.render_frame(keys)
             for k in keys:
                 v.postprocessor.postprocess(k)
             v.poll()
             out.append(v.download_framebuffer())
+        if qpod is not None:
+            for k in keys:
+                assert np.array_equal(spec.models[k].gaussian_buffers.selection_buffer.download(),
+                                      plain.models[k].gaussian_buffers.selection_buffer.download()), f"seed {seed} step {step}: selections differ"
         assert np.array_equal(out[0], out[1]), f"seed {seed} step {step} op {op}: L-inf {np.abs(out[0] - out[1]).max()}"
         speculated += any(spec.frame_stats(k)["speculated"] for k in keys)
     assert speculated > (15 if lanes == 1 else 8)

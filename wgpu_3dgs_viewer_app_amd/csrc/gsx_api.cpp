@@ -60,6 +60,7 @@ static gsx_status lane_create(gsx_viewer* v, gsx_viewer** out) {
     l->validate = v->validate;
     l->tile_cap_fixed = v->tile_cap_fixed;
     l->bin_mode = v->bin_mode;
+    l->edit_cache = v->edit_cache;
     l->blocks_max = v->blocks_max;
     // a stream that does not share its hardware queue with the viewer's or another lane's: streams that do are kept (parked)
     // until the viewer goes, so that the next one created lands on the next queue
@@ -221,6 +222,7 @@ gsx_status gsx_viewer_create(const gsx_viewer_desc* desc, gsx_viewer** out) {
     v->validate = getenv("GSX_VALIDATE") != nullptr;
     if (const char* tc = getenv("GSX_TILE_CAP")) v->tile_cap_fixed = std::max<long long>(atoll(tc), 1);
     if (const char* bm = getenv("GSX_BIN")) v->bin_mode = atoi(bm) ? 1 : 0;
+    v->edit_cache = getenv("GSX_NO_EDIT_CACHE") == nullptr;
     if (const char* bx = getenv("GSX_BLOCKS_MAX")) v->blocks_max = (uint32_t)std::max(16, std::min(1024, atoi(bx)));
     (void)radix_lane_ordered_adds();  // probes THIS device once per process (the answer is kept per device)
     v->device = desc->device;
@@ -458,6 +460,7 @@ gsx_status gsx_model_upload_mask(gsx_viewer* v, const char* key, const uint32_t*
     if (st) return st;
     Model* m = find_model(v, key);
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_upload_mask: no model '%s'", key ? key : "(null)");
+    m->edit_epoch += 1;
     if (!words) {  // MaskOpTree::Reset
         if (m->has_mask) m->tuner.reset();
         m->has_mask = false;
@@ -516,6 +519,7 @@ gsx_status gsx_mask_evaluate(gsx_viewer* v, const char* key, const gsx_mask_op* 
         }
     }
     if (n_ops && depth != 1) return fail(GSX_ERR_INVALID_ARG, "gsx_mask_evaluate: malformed postfix program");
+    m->edit_epoch += 1;
     if (n_ops == 0) {  // MaskOpTree::Reset
         if (m->has_mask) m->tuner.reset();
         m->has_mask = false;

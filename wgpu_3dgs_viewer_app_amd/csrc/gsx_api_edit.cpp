@@ -61,6 +61,7 @@ gsx_status gsx_postprocess(gsx_viewer* v, const char* key) {
         HIPCHK(launch_selection_op(v->stream, (uint32_t)(((size_t)m->n + 31) / 32), m->flags_op, m->query_flags.as<uint32_t>(),
                                    m->selection.as<uint32_t>()));
         m->has_selection = true;
+        m->edit_epoch += 1;
         m->flags_kind = GSX_QUERY_NONE;  // consumed: one selection op per evaluated query
     }
     return GSX_OK;
@@ -71,6 +72,7 @@ gsx_status gsx_model_upload_selection(gsx_viewer* v, const char* key, const uint
     if (st) return st;
     Model* m = find_model(v, key);
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_upload_selection: no model '%s'", key ? key : "(null)");
+    m->edit_epoch += 1;
     if (!words) {  // clear
         m->has_selection = false;
         if (m->selection.p) HIPCHK(hipMemsetAsync(m->selection.p, 0, m->selection.bytes, v->stream));
@@ -130,6 +132,7 @@ gsx_status gsx_model_upload_edits(gsx_viewer* v, const char* key, const gsx_gaus
     if (st) return st;
     Model* m = find_model(v, key);
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_upload_edits: no model '%s'", key ? key : "(null)");
+    m->edit_epoch += 1;
     if (!edits) {  // drop every stored edit
         m->has_edits = false;
         if (m->edited.p) HIPCHK(hipMemsetAsync(m->edited.p, 0, m->edited.bytes, v->stream));

@@ -96,10 +96,7 @@ gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, const 
         HIPCHK(m->adm_pairs.ensure(8 * std::max<size_t>(n, 1)));
         HIPCHK(launch_rowscan(v->stream, trav_counts, 1, nb, &dc->n_sorted2));
         HIPCHK(launch_admit_scatter(v->stream, m->proj_rec().key, n, travellers, trav_counts, m->adm_pairs.as<uint2>()));
-        PodPlanes pod = m->pod();
-        pod.mask = m->last_pod_mask;
-        HIPCHK(launch_shade(v->stream, m->fc, n, pod, m->proj_rec(),
-                            LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>(), m->rect8_active}));
+        if ((st = shade_admitted(v, m, LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>(), m->rect8_active}))) return st;
         m->cand_valid = false;  // adm_pairs now holds the repair travellers
     }
     uint32_t h_tot[64];
@@ -310,10 +307,8 @@ gsx_status pack_write(gsx_viewer* v, Model* m, uint32_t world, void* d_send, uin
         HIPCHK(launch_rowscan(v->stream, m->trav_counts.as<uint32_t>(), 1, nb, &dc->n_sorted2));
         HIPCHK(launch_admit_scatter(v->stream, m->proj_rec().key, n, m->trav_ballots.as<unsigned long long>(), m->trav_counts.as<uint32_t>(),
                                     m->adm_pairs.as<uint2>()));
-        PodPlanes pod = m->pod();
-        pod.mask = m->last_pod_mask;
-        HIPCHK(launch_shade(v->stream, m->fc, n, pod, m->proj_rec(),
-                            LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>(), m->rect8_active}));
+        gsx_status sst = shade_admitted(v, m, LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>(), m->rect8_active});
+        if (sst) return sst;
         m->cand_valid = false;
         m->pack_travellers = false;
     }

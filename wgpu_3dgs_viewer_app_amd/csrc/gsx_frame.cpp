@@ -315,6 +315,7 @@ gsx_status ensure_edit_buffers(gsx_viewer* v, Model* m) {
         HIPCHK(m->keep.ensure(4 * words));
         HIPCHK(m->edit_a.ensure(16 * n));
         HIPCHK(m->edit_b.ensure(16 * n));
+        m->prep_epoch = 0;  // new buffers: nothing prepared
     }
     return GSX_OK;
 }
@@ -342,9 +343,17 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
     PodPlanes pod = m->pod();
     if (edits_on) {
         if ((st = ensure_edit_buffers(v, m))) return st;
-        HIPCHK(launch_edit_prepare(v->stream, n32, m->has_selection ? m->selection.as<uint32_t>() : nullptr,
-                                   m->edited.as<uint32_t>(), m->edit_a.as<float4>(), m->edit_b.as<float4>(), v->sel_edit, pod.mask,
-                                   m->keep.as<uint32_t>()));
+        const bool prepared = v->edit_cache && m->prep_epoch == m->edit_epoch && m->prep_has_selection == m->has_selection &&
+                              m->prep_mask == pod.mask && memcmp(&m->prep_sel_edit, &v->sel_edit, sizeof v->sel_edit) == 0;
+        if (!prepared) {
+            HIPCHK(launch_edit_prepare(v->stream, n32, m->has_selection ? m->selection.as<uint32_t>() : nullptr,
+                                       m->edited.as<uint32_t>(), m->edit_a.as<float4>(), m->edit_b.as<float4>(), v->sel_edit, pod.mask,
+                                       m->keep.as<uint32_t>()));
+            m->prep_epoch = m->edit_epoch;
+            m->prep_has_selection = m->has_selection;
+            m->prep_mask = pod.mask;
+            m->prep_sel_edit = v->sel_edit;
+        }
         m->has_edits = true;
         pod.mask = m->keep.as<uint32_t>();
     }
@@ -372,7 +381,10 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
     adm.ballots = m->adm_ballots.as<unsigned long long>();
     adm.block_counts = m->adm_counts.as<uint32_t>();
     // lazy shading: nothing else reads the conic / colour records of this frame (no edit, highlight or query pass)
-    m->lazy = (m->spec_round1 || shard_lazy) && !edits_on && !highlight_on && v->query.kind == GSX_QUERY_NONE;
+    // (edits and the highlight are colour ops on shaded records: shade_admitted applies them to what k_shade writes)
+    m->lazy = (m->spec_round1 || shard_lazy) && v->query.kind == GSX_QUERY_NONE;
+    m->frame_edits = edits_on;
+    m->frame_highlight = highlight_on;
     m->cand_valid = false;
     adm.lazy = m->lazy ? 1u : 0u;
     // a lazy projection writes four bytes of tile rectangle per Gaussian instead of the 16-byte `a` record (grids up to 255 x 255 tiles)
@@ -400,10 +412,10 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
                                          m->adm_counts.as<uint32_t>(), m->adm_offsets.as<uint32_t>(), &dcx->n_candidates,
                                          m->adm_pairs.as<uint2>(), true, m->block_vis.as<uint32_t>(), &dcx->n_visible));
         m->visible_count_pending = false;
-        if (m->lazy) HIPCHK(launch_shade(v->stream, m->fc, n32, pod, m->proj_rec(), LateProjection{m->adm_pairs.as<uint2>(), &dcx->n_candidates, nullptr, m->rect8_active}));
+        if (m->lazy && (st = shade_admitted(v, m, LateProjection{m->adm_pairs.as<uint2>(), &dcx->n_candidates, nullptr, m->rect8_active}))) return st;
         m->cand_valid = true;
     }
-    if (edits_on || highlight_on)
+    if ((edits_on || highlight_on) && !m->lazy)
         HIPCHK(launch_edit_apply(v->stream, n32, m->proj_rec(), highlight_on ? m->selection.as<uint32_t>() : nullptr,
                                  edits_on ? m->edited.as<uint32_t>() : nullptr, m->edit_a.as<float4>(), m->edit_b.as<float4>(),
                                  v->highlight));
@@ -443,6 +455,23 @@ gsx_status complete_records(gsx_viewer* v, Model* m) {
     m->rect8_active = false;  // the unlazy kernel writes every record whole
     HIPCHK(launch_project(v->stream, m->fc, (uint32_t)m->n, pod, m->proj_rec(), m->block_vis.as<uint32_t>(), adm));
     m->lazy = false;
+    if (m->frame_edits || m->frame_highlight)  // every record was written again: the frame's colour ops on all of them
+        HIPCHK(launch_edit_apply(v->stream, (uint32_t)m->n, m->proj_rec(), m->frame_highlight ? m->selection.as<uint32_t>() : nullptr,
+                                 m->frame_edits ? m->edited.as<uint32_t>() : nullptr, m->edit_a.as<float4>(), m->edit_b.as<float4>(),
+                                 v->highlight));
+    return GSX_OK;
+}
+
+gsx_status shade_admitted(gsx_viewer* v, Model* m, const LateProjection& late) {
+    PodPlanes pod = m->pod();
+    pod.mask = m->last_pod_mask;
+    const uint32_t n = (uint32_t)m->n;
+    HIPCHK(launch_shade(v->stream, m->fc, n, pod, m->proj_rec(), late));
+    if (m->frame_edits || m->frame_highlight)
+        HIPCHK(launch_edit_apply_list(v->stream, n, m->proj_rec(), late.pairs, late.d_n, late.shaded,
+                                      m->frame_highlight ? m->selection.as<uint32_t>() : nullptr,
+                                      m->frame_edits ? m->edited.as<uint32_t>() : nullptr, m->edit_a.as<float4>(), m->edit_b.as<float4>(),
+                                      v->highlight));
     return GSX_OK;
 }
 
@@ -494,9 +523,8 @@ gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
                                                  m->visible_count_pending ? m->block_vis.as<uint32_t>() : nullptr, &dc->n_visible));
                 m->visible_count_pending = false;
                 if (m->lazy) {  // the projection pass was geometry only: shade what it admitted
-                    PodPlanes pod = m->pod();
-                    pod.mask = m->last_pod_mask;
-                    HIPCHK(launch_shade(v->stream, m->fc, n, pod, m->proj_rec(), LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted, nullptr, m->rect8_active}));
+                    gsx_status sst = shade_admitted(v, m, LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted, nullptr, m->rect8_active});
+                    if (sst) return sst;
                 }
                 RadixBuffers rb{nullptr, nullptr, m->adm_pairs.as<uint2>(), m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
                                 m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
@@ -834,10 +862,8 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
                                 m->adm_ballots2.as<unsigned long long>(), m->adm_counts2.as<uint32_t>(), &dc->n_sorted2,
                                 m->adm_pairs.as<uint2>()));
             if (m->lazy) {  // the repair round needs records the lazy projection did not shade
-                PodPlanes pod = m->pod();
-                pod.mask = m->last_pod_mask;
-                HIPCHK(launch_shade(v->stream, m->fc, n, pod, m->proj_rec(),
-                                    LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>(), m->rect8_active}));
+                gsx_status sst = shade_admitted(v, m, LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>(), m->rect8_active});
+                if (sst) return sst;
             }
             RadixBuffers rb{nullptr, nullptr, m->adm_pairs.as<uint2>(), m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
                             m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};

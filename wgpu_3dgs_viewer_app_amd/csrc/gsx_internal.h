@@ -217,6 +217,9 @@ hipError_t launch_edit_prepare(hipStream_t s, uint32_t n, const uint32_t* select
                                float4* edit_b, const gsx_gaussian_edit& sel_edit, const uint32_t* mask, uint32_t* keep);
 hipError_t launch_edit_apply(hipStream_t s, uint32_t n, const Records& rec, const uint32_t* selection, const uint32_t* edited,
                              const float4* edit_a, const float4* edit_b, const float highlight[4]);
+hipError_t launch_edit_apply_list(hipStream_t s, uint32_t n, const Records& rec, const uint2* pairs, const uint32_t* d_n,
+                                  const unsigned long long* skip, const uint32_t* selection, const uint32_t* edited, const float4* edit_a,
+                                  const float4* edit_b, const float highlight[4]);
 hipError_t launch_query(hipStream_t s, uint32_t n, const Records& rec, const gsx_query& q, const uint8_t* texture, uint32_t tex_w,
                         uint32_t tex_h, const FrameConsts& f, uint32_t* flags, gsx_query_hit* hits, uint32_t* hit_count,
                         uint32_t hit_capacity);

@@ -183,6 +183,13 @@ struct Model {
                                                // figure from that frame's verdict, so every rank sizes the next slots identically; 0 = unknown
     DevBuf adm_ballots2;           // the repair round's ballots (the first round's stay: they say which records are shaded)
     bool lazy = false;             // this frame's projection shaded only the admitted Gaussians
+    // k_edit_prepare is a function of (selection, stored edits, mask, the viewer's selection edit) and idempotent: it runs again
+    // only after one of them changed (edit_epoch: bumped by every call that writes one of the buffers)
+    uint64_t edit_epoch = 1, prep_epoch = 0;
+    gsx_gaussian_edit prep_sel_edit{};
+    bool prep_has_selection = false;
+    const uint32_t* prep_mask = nullptr;
+    bool frame_edits = false, frame_highlight = false;  // this frame applies stored / selection edits, the selection highlight (to whatever gets shaded)
     bool visible_count_pending = false;  // N_vis of this projection has not been summed yet (the admission scan will)
     const uint32_t* last_pyramid = nullptr;  // the admission pyramid the projection pass used
     uint32_t* last_pod_mask = nullptr;  // the keep-bitset the projection pass used (mask, or mask & ~hidden)
@@ -300,6 +307,7 @@ struct gsx_viewer {
     uint32_t verify_seq = 0;
     uint32_t blocks_max = 256;    // GSX_BLOCKS_MAX: most blocks of a block-list frame (256: one 8-bit sort pass)
     int bin_mode = 1;             // GSX_BIN: 1 block lists for progressive frames (default), 0 per-tile lists always
+    bool edit_cache = true;       // GSX_NO_EDIT_CACHE: run k_edit_prepare every frame (tests compare the two)
     uint64_t tile_cap_fixed = 0;  // GSX_TILE_CAP was set when the viewer was created: pair-buffer capacity that never grows (tests of the spill path)
     bool validate = false;  // GSX_VALIDATE was set when the viewer was created: check tile ranges / lists before compositing (debug, synchronous)
     uint32_t band_lo = 0, band_hi = 0xFFFFFFFFu;  // tile rows this viewer renders (gsx_viewer_set_band)
@@ -422,6 +430,8 @@ gsx_status do_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys, bo
 gsx_status finish_frame(gsx_viewer* v);
 inline gsx_status sync_counters(gsx_viewer* v) { return finish_frame(v); }
 gsx_status complete_records(gsx_viewer* v, Model* m);
+// k_shade over a list of admitted records of a lazily projected frame, then the frame's colour ops on exactly those (gsx_frame.cpp)
+gsx_status shade_admitted(gsx_viewer* v, Model* m, const LateProjection& late);
 gsx_status ensure_record_capacity(Model* m, uint64_t count);
 gsx_status ensure_sortbin_capacity(Model* m, uint64_t count);
 gsx_status ensure_import_capacity(Model* m, uint64_t count);

@@ -8,6 +8,8 @@
 // already honours (the mask), colour ops and the highlight rewrite the projected records afterwards.
 // All bitsets are one bit per Gaussian; a 64-lane wave owns exactly two words, so no atomics are needed.
 #include "edit_math.h"
+#include <algorithm>
+
 #include "gsx_internal.h"
 
 namespace gsx {
@@ -81,6 +83,38 @@ __global__ __launch_bounds__(256) void k_edit_apply(uint32_t n, const uint32_t* 
     rec_c[i] = c;
 }
 
+// The same ops over a list of (key, index) pairs: the records k_shade has just written on a lazily projected frame (skip = the
+// ballots of the records an earlier round shaded — and edited — already: the same bits k_shade skips).
+__global__ __launch_bounds__(256) void k_edit_apply_list(const uint2* __restrict__ pairs, const uint32_t* __restrict__ d_n,
+                                                          const unsigned long long* __restrict__ skip, float4* __restrict__ rec_b,
+                                                          float4* __restrict__ rec_c, const uint32_t* __restrict__ selection,
+                                                          const uint32_t* __restrict__ edited, const float4* __restrict__ edit_a,
+                                                          const float4* __restrict__ edit_b, float4 highlight) {
+    const uint32_t count = *d_n;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < count; j += gridDim.x * 256u) {
+        const uint32_t i = pairs[j].y;
+        if (skip && ((skip[i >> 6] >> (i & 63u)) & 1ull)) continue;
+        const bool sel = selection && highlight.w > 0.0f && ((selection[i >> 5] >> (i & 31u)) & 1u);
+        const bool has = edited && ((edited[i >> 5] >> (i & 31u)) & 1u);
+        if (!sel && !has) continue;
+        float4 c = rec_c[i];
+        if (has) {
+            const gsx_gaussian_edit e = load_edit(edit_a, edit_b, i);
+            if (e.flag & GSX_EDIT_ENABLED) {
+                float4 b = rec_b[i];
+                em_apply_edit(e, c.x, c.y, c.z, b.w);
+                rec_b[i] = b;
+            }
+        }
+        if (sel) {
+            c.x = c.x + (highlight.x - c.x) * highlight.w;
+            c.y = c.y + (highlight.y - c.y) * highlight.w;
+            c.z = c.z + (highlight.z - c.z) * highlight.w;
+        }
+        rec_c[i] = c;
+    }
+}
+
 // K1 query: Rect / Brush / Texture set one flag bit per Gaussian; Hit appends (index, depth, alpha) results.
 __global__ __launch_bounds__(256) void k_query(uint32_t n, const uint32_t* __restrict__ key, const float4* __restrict__ rec_a,
                                                 const float4* __restrict__ rec_b, const float4* __restrict__ rec_c,
@@ -138,6 +172,15 @@ hipError_t launch_edit_apply(hipStream_t s, uint32_t n, const Records& rec, cons
     if (n)
         hipLaunchKernelGGL(k_edit_apply, dim3((n + 255) / 256), dim3(256), 0, s, n, rec.key, rec.b, rec.c, selection, edited, edit_a,
                            edit_b, make_float4(highlight[0], highlight[1], highlight[2], highlight[3]));
+    return hipGetLastError();
+}
+
+hipError_t launch_edit_apply_list(hipStream_t s, uint32_t n, const Records& rec, const uint2* pairs, const uint32_t* d_n,
+                                  const unsigned long long* skip, const uint32_t* selection, const uint32_t* edited, const float4* edit_a,
+                                  const float4* edit_b, const float highlight[4]) {
+    if (n)  // (n: an upper bound of the list length; the count is on the device)
+        hipLaunchKernelGGL(k_edit_apply_list, dim3(std::min<uint32_t>((n + 255) / 256, 2048u)), dim3(256), 0, s, pairs, d_n, skip, rec.b, rec.c,
+                           selection, edited, edit_a, edit_b, make_float4(highlight[0], highlight[1], highlight[2], highlight[3]));
     return hipGetLastError();
 }
 
