@@ -3,7 +3,8 @@
 gsx_render_frame deals consecutive frames to L lanes — own stream, own per-frame buffers and speculation windows, shared
 Gaussian data.  Under test: every frame is bit-identical to the frame of a one-lane viewer; readback calls see the newest
 frame whichever lane rendered it; model data changed between frames (mask, upload, remove + create) reaches every lane;
-frames that cannot overlap (query, selection) fall back to the viewer itself; un-synchronised loops deliver complete frames."""
+frames that cannot overlap (a query) fall back to the viewer itself; frames with a selection, edits or the highlight DO overlap
+(the lanes view the owner's edit buffers, prepared on the owner's stream); un-synchronised loops deliver complete frames."""
 import numpy as np
 import pytest
 
@@ -216,3 +217,66 @@ def test_device_side_resolve_sees_the_newest_frame_on_a_lane():
         want = v.download_rgba8(bg)
         assert np.array_equal(got, want), f"after {n_frames} frames the device-side resolve shows another frame"
     v.close()
+
+
+@pytest.mark.parametrize("lanes", [2, 3])
+def test_colour_ops_with_frames_in_flight_unsynchronised(lanes, monkeypatch):
+    """A selection edit, stored edits and the highlight on frames in flight, the loop never waiting: the selection, the
+    selection edit (a host-side setter: nothing orders it but the library) and the mask change in mid-flight.  Every checked
+    frame equals the frame of a one-lane viewer that runs k_edit_prepare every frame."""
+    from wgpu_3dgs_viewer_app_amd import query
+    from wgpu_3dgs_viewer_app_amd.query import GaussianEditFlag as F
+
+    n = 30000
+    g = common.small_scene(n, 311, scale_mul=10.0)
+    rng = np.random.default_rng(23)
+    words = (n + 31) // 32
+    monkeypatch.setenv("GSX_NO_EDIT_CACHE", "1")
+    ref = _viewer(1)
+    monkeypatch.delenv("GSX_NO_EDIT_CACHE")
+    v = _viewer(lanes)
+    for x in (ref, v):
+        _load(x, "m", g)
+    steps = []
+    for k in range(40):
+        change = None
+        if k in (3, 17, 29):
+            sel = rng.integers(0, 2 ** 32, words, dtype=np.uint64).astype(np.uint32)
+            change = ("selection", sel if k != 29 else None)
+        elif k in (5, 11, 23, 33):
+            change = ("edit", query.GaussianEditPod([F.ENABLED, F.ENABLED | F.OVERRIDE_COLOR, F.ENABLED | F.HIDDEN, 0][(k // 6) % 4],
+                                                    tuple(rng.uniform(0, 1, 3)), 0.1, -0.4, 1.6, float(rng.uniform(0.4, 1.3))))
+        elif k in (8, 20):
+            change = ("highlight", (1.0, 0.2, 0.0, 0.5 if k == 8 else 0.0))
+        elif k == 26:
+            change = ("mask", rng.integers(0, 2 ** 32, words, dtype=np.uint64).astype(np.uint32))
+        steps.append((60 + k, change))
+
+    def run(x, check_at):
+        out = {}
+        for k, (pose, change) in enumerate(steps):
+            if change:
+                kind, val = change
+                if kind == "selection":
+                    x.models["m"].gaussian_buffers.selection_buffer.upload(val)
+                elif kind == "edit":
+                    x.update_selection_edit_with_pod(val)
+                elif kind == "highlight":
+                    x.update_selection_highlight(val)
+                else:
+                    x.models["m"].gaussian_buffers.mask_buffer.upload(val)
+            _enqueue(x, pose, ["m"])
+            if k in check_at:
+                out[k] = x.download_framebuffer().copy()
+        return out
+
+    check = {4, 6, 7, 12, 18, 19, 24, 27, 30, 34, 39}
+    a, b = run(v, check), run(ref, set(range(len(steps))))
+    for k in sorted(check):
+        assert np.array_equal(a[k], b[k]), f"{lanes} lanes, frame {k}: L-inf {np.abs(a[k] - b[k]).max()}"
+    assert not np.array_equal(b[4], b[2]) and not np.array_equal(b[12], b[10])
+    edits_v = v.models["m"].gaussian_buffers.gaussians_edit_buffer.download()
+    edits_r = ref.models["m"].gaussian_buffers.gaussians_edit_buffer.download()
+    assert edits_v.tobytes() == edits_r.tobytes(), "the stored edits are the same whichever lane rendered"
+    v.close()
+    ref.close()

@@ -84,16 +84,43 @@ static gsx_status lane_create(gsx_viewer* v, gsx_viewer** out) {
     return GSX_OK;
 }
 
-// may this frame go to a lane?  (anything interactive — query, selection, edits — and everything multi-GPU stays on the viewer)
+// may this frame go to a lane?  (a frame with a query — its flags feed gsx_postprocess — and everything multi-GPU stays on the
+// viewer; selections, edits and the highlight travel: a lane's shadow models view the owner's selection and edit buffers, which
+// the owner prepares before the frame is dealt out, prepare_edits_for_lanes)
 static bool frame_may_overlap(gsx_viewer* v, const char* const* keys, uint32_t n_keys) {
     if (v->parent || v->options.frames_in_flight < 2 || v->query.kind != GSX_QUERY_NONE || v->ext_fb || v->band_lo != 0 ||
-        v->band_hi != 0xFFFFFFFFu || v->highlight[3] > 0.0f)
+        v->band_hi != 0xFFFFFFFFu)
         return false;
     for (uint32_t i = 0; i < n_keys; ++i) {
         Model* m = find_model(v, keys ? keys[i] : nullptr);
-        if (!m || m->has_selection || m->has_edits || m->shard_win_set || m->shard_limit_valid || m->shard_next_valid) return false;
+        if (!m || m->shard_win_set || m->shard_limit_valid || m->shard_next_valid) return false;
     }
     return n_keys > 0;
+}
+
+// The edit records and the keep-bitset of the frame's models live with the owner and are read by whichever lane renders a
+// frame.  When k_edit_prepare has to run again (a selection, mask, edit or selection-edit change since it last did) it runs on
+// the owner's stream, AFTER every frame in flight that still reads the old state and BEFORE every later frame on any lane.
+static gsx_status prepare_edits_for_lanes(gsx_viewer* v, const char* const* keys, uint32_t n_keys) {
+    for (uint32_t i = 0; i < n_keys; ++i) {
+        Model* m = find_model(v, keys[i]);
+        if (!m) continue;
+        const bool sel_edit_on = m->has_selection && (v->sel_edit.flag & GSX_EDIT_ENABLED);
+        if (m->show_unedited || !(m->has_edits || sel_edit_on)) continue;
+        const uint32_t* mask = m->has_mask ? m->mask.as<uint32_t>() : nullptr;
+        const bool prepared = v->edit_cache && m->edited.p && m->prep_epoch == m->edit_epoch && m->prep_has_selection == m->has_selection &&
+                              m->prep_mask == mask && memcmp(&m->prep_sel_edit, &v->sel_edit, sizeof v->sel_edit) == 0;
+        if (prepared) continue;
+        for (gsx_viewer* l : v->lanes)
+            if (l->lane_busy) {
+                HIPCHK(hipStreamWaitEvent(v->stream, l->lane_event, 0));
+                l->lane_busy = false;
+            }
+        gsx_status st = prepare_edits(v, m, nullptr);
+        if (st) return st;
+        v->epoch += 1;  // every lane's next frame waits for the owner's stream (lane_sync)
+    }
+    return GSX_OK;
 }
 
 // bring lane l up to date with viewer v for a frame of `keys`: uniforms, options, and a shadow of every model
@@ -142,8 +169,12 @@ static gsx_status lane_sync(gsx_viewer* v, gsx_viewer* l, const char* const* key
         for (auto pr : {std::make_pair(&sm->pc, &pm->pc), std::make_pair(&sm->cov_a, &pm->cov_a), std::make_pair(&sm->cov_b, &pm->cov_b),
                         std::make_pair(&sm->sh4, &pm->sh4), std::make_pair(&sm->sh1, &pm->sh1), std::make_pair(&sm->sh_h, &pm->sh_h),
                         std::make_pair(&sm->sh_q, &pm->sh_q), std::make_pair(&sm->sh_aos, &pm->sh_aos), std::make_pair(&sm->cov_h, &pm->cov_h),
-                        std::make_pair(&sm->cov_h2, &pm->cov_h2), std::make_pair(&sm->mask, &pm->mask)})
+                        std::make_pair(&sm->cov_h2, &pm->cov_h2), std::make_pair(&sm->mask, &pm->mask),
+                        std::make_pair(&sm->selection, &pm->selection), std::make_pair(&sm->edited, &pm->edited),
+                        std::make_pair(&sm->edit_a, &pm->edit_a), std::make_pair(&sm->edit_b, &pm->edit_b), std::make_pair(&sm->keep, &pm->keep)})
             pr.first->borrow(*pr.second);
+        sm->has_selection = pm->has_selection;
+        sm->has_edits = pm->has_edits;
         sm->tuner_ref = &pm->tuner;  // one speculate-or-not cycle per model, whichever lane renders the frame
         sm->has_mask = pm->has_mask;
         sm->mask_program_hash = pm->mask_program_hash;
@@ -594,6 +625,7 @@ gsx_status gsx_render_frame(gsx_viewer* v, const char* const* keys, uint32_t n_k
     gsx_viewer* lane = v;
     if (frame_may_overlap(v, keys, n_keys)) {
         HIPCHK(hipSetDevice(v->device));  // NOT viewer_bind: frames in flight stay in flight
+        if ((st = prepare_edits_for_lanes(v, keys, n_keys))) return st;
         const uint32_t turn = v->lane_turn++ % v->options.frames_in_flight;
         if ((st = lane_acquire(v, turn, keys, n_keys, &lane))) return st;
     } else if ((st = viewer_bind(v))) {

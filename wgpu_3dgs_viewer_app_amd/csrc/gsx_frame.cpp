@@ -320,6 +320,30 @@ gsx_status ensure_edit_buffers(gsx_viewer* v, Model* m) {
     return GSX_OK;
 }
 
+// k_edit_prepare for this model if its inputs changed since it last ran (Model::edit_epoch; idempotent otherwise): persists the
+// selection edit into the selected Gaussians' edit records and derives keep = mask & ~hidden.  *launched: it ran.
+gsx_status prepare_edits(gsx_viewer* v, Model* m, bool* launched) {
+    if (launched) *launched = false;
+    const bool sel_edit_on = m->has_selection && (v->sel_edit.flag & GSX_EDIT_ENABLED);
+    if (m->show_unedited || !(m->has_edits || sel_edit_on)) return GSX_OK;
+    const bool fresh_buffers = m->edited.bytes < 4 * std::max<size_t>(((size_t)m->n + 31) / 32, 1);
+    gsx_status st = ensure_edit_buffers(v, m);
+    if (st) return st;
+    const uint32_t* mask = m->has_mask ? m->mask.as<uint32_t>() : nullptr;
+    const bool prepared = v->edit_cache && !fresh_buffers && m->prep_epoch == m->edit_epoch && m->prep_has_selection == m->has_selection &&
+                          m->prep_mask == mask && memcmp(&m->prep_sel_edit, &v->sel_edit, sizeof v->sel_edit) == 0;
+    if (prepared) return GSX_OK;
+    HIPCHK(launch_edit_prepare(v->stream, (uint32_t)m->n, m->has_selection ? m->selection.as<uint32_t>() : nullptr, m->edited.as<uint32_t>(),
+                               m->edit_a.as<float4>(), m->edit_b.as<float4>(), v->sel_edit, mask, m->keep.as<uint32_t>()));
+    m->prep_epoch = m->edit_epoch;
+    m->prep_has_selection = m->has_selection;
+    m->prep_mask = mask;
+    m->prep_sel_edit = v->sel_edit;
+    m->has_edits = true;
+    if (launched) *launched = true;
+    return GSX_OK;
+}
+
 gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
     frame_consts_setup(v->view, v->proj, v->width, v->height, m->mt, v->size, v->display_mode, v->sh_deg, v->no_sh0,
                        v->params, &m->fc);
@@ -342,18 +366,8 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
     const bool highlight_on = m->has_selection && v->highlight[3] > 0.0f;
     PodPlanes pod = m->pod();
     if (edits_on) {
-        if ((st = ensure_edit_buffers(v, m))) return st;
-        const bool prepared = v->edit_cache && m->prep_epoch == m->edit_epoch && m->prep_has_selection == m->has_selection &&
-                              m->prep_mask == pod.mask && memcmp(&m->prep_sel_edit, &v->sel_edit, sizeof v->sel_edit) == 0;
-        if (!prepared) {
-            HIPCHK(launch_edit_prepare(v->stream, n32, m->has_selection ? m->selection.as<uint32_t>() : nullptr,
-                                       m->edited.as<uint32_t>(), m->edit_a.as<float4>(), m->edit_b.as<float4>(), v->sel_edit, pod.mask,
-                                       m->keep.as<uint32_t>()));
-            m->prep_epoch = m->edit_epoch;
-            m->prep_has_selection = m->has_selection;
-            m->prep_mask = pod.mask;
-            m->prep_sel_edit = v->sel_edit;
-        }
+        // (a lane's shadow model views the owner's edit buffers: the owner prepared them before the frame was dealt out, gsx_render_frame)
+        if (!v->parent && (st = prepare_edits(v, m, nullptr))) return st;
         m->has_edits = true;
         pod.mask = m->keep.as<uint32_t>();
     }
