@@ -108,8 +108,10 @@ typedef struct gsx_spec_params {
  * Frames still complete in order per lane and every frame is the same frame bit for bit.  Readback calls
  * (gsx_download_framebuffer, gsx_model_frame_stats, gsx_framebuffer_device_ptr ...) refer to the newest frame; a
  * framebuffer pointer stays valid until the same lane renders again (L frames later).  Calls that touch model data
- * (uploads, masks, selection / edits) are ordered after every frame in flight.  Frames with a query, an edit or a
- * selection, a band (gsx_viewer_set_band), an external framebuffer or a sharded model run on the viewer itself, one at a time. */
+ * (uploads, masks, selection / edits) are ordered after every frame in flight.  Frames with a selection, stored edits or the
+ * highlight overlap like any other (the lanes read the viewer's selection and edit records; the per-frame preparation of those
+ * runs only after one of its inputs changed, ordered between the frames in flight).  Frames with a query, a band
+ * (gsx_viewer_set_band), an external framebuffer or a sharded model run on the viewer itself, one at a time. */
 typedef struct gsx_render_options {
     uint32_t progressive;        /* default 1 */
     uint32_t first_slab_divisor; /* default 16 */
