@@ -104,13 +104,7 @@ static bool frame_may_overlap(gsx_viewer* v, const char* const* keys, uint32_t n
 static gsx_status prepare_edits_for_lanes(gsx_viewer* v, const char* const* keys, uint32_t n_keys) {
     for (uint32_t i = 0; i < n_keys; ++i) {
         Model* m = find_model(v, keys[i]);
-        if (!m) continue;
-        const bool sel_edit_on = m->has_selection && (v->sel_edit.flag & GSX_EDIT_ENABLED);
-        if (m->show_unedited || !(m->has_edits || sel_edit_on)) continue;
-        const uint32_t* mask = m->has_mask ? m->mask.as<uint32_t>() : nullptr;
-        const bool prepared = v->edit_cache && m->edited.p && m->prep_epoch == m->edit_epoch && m->prep_has_selection == m->has_selection &&
-                              m->prep_mask == mask && memcmp(&m->prep_sel_edit, &v->sel_edit, sizeof v->sel_edit) == 0;
-        if (prepared) continue;
+        if (!m || !edits_need_prepare(v, m)) continue;
         for (gsx_viewer* l : v->lanes)
             if (l->lane_busy) {
                 HIPCHK(hipStreamWaitEvent(v->stream, l->lane_event, 0));

@@ -322,17 +322,21 @@ gsx_status ensure_edit_buffers(gsx_viewer* v, Model* m) {
 
 // k_edit_prepare for this model if its inputs changed since it last ran (Model::edit_epoch; idempotent otherwise): persists the
 // selection edit into the selected Gaussians' edit records and derives keep = mask & ~hidden.  *launched: it ran.
+bool edits_need_prepare(const gsx_viewer* v, const Model* m) {
+    const bool sel_edit_on = m->has_selection && (v->sel_edit.flag & GSX_EDIT_ENABLED);
+    if (m->show_unedited || !(m->has_edits || sel_edit_on)) return false;  // no edit pass this frame
+    const uint32_t* mask = m->has_mask ? m->mask.as<uint32_t>() : nullptr;
+    const bool buffers = m->edited.bytes >= 4 * std::max<size_t>(((size_t)m->n + 31) / 32, 1);
+    return !(v->edit_cache && buffers && m->prep_epoch == m->edit_epoch && m->prep_has_selection == m->has_selection && m->prep_mask == mask &&
+             memcmp(&m->prep_sel_edit, &v->sel_edit, sizeof v->sel_edit) == 0);
+}
+
 gsx_status prepare_edits(gsx_viewer* v, Model* m, bool* launched) {
     if (launched) *launched = false;
-    const bool sel_edit_on = m->has_selection && (v->sel_edit.flag & GSX_EDIT_ENABLED);
-    if (m->show_unedited || !(m->has_edits || sel_edit_on)) return GSX_OK;
-    const bool fresh_buffers = m->edited.bytes < 4 * std::max<size_t>(((size_t)m->n + 31) / 32, 1);
+    if (!edits_need_prepare(v, m)) return GSX_OK;
     gsx_status st = ensure_edit_buffers(v, m);
     if (st) return st;
     const uint32_t* mask = m->has_mask ? m->mask.as<uint32_t>() : nullptr;
-    const bool prepared = v->edit_cache && !fresh_buffers && m->prep_epoch == m->edit_epoch && m->prep_has_selection == m->has_selection &&
-                          m->prep_mask == mask && memcmp(&m->prep_sel_edit, &v->sel_edit, sizeof v->sel_edit) == 0;
-    if (prepared) return GSX_OK;
     HIPCHK(launch_edit_prepare(v->stream, (uint32_t)m->n, m->has_selection ? m->selection.as<uint32_t>() : nullptr, m->edited.as<uint32_t>(),
                                m->edit_a.as<float4>(), m->edit_b.as<float4>(), v->sel_edit, mask, m->keep.as<uint32_t>()));
     m->prep_epoch = m->edit_epoch;
