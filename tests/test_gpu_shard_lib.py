@@ -635,3 +635,54 @@ def test_fuzz_sharded_against_single(seed, world, lanes):
     for rank, (bad, stats) in enumerate(run_group(world, body, timeout_ms=60000)):
         assert not bad, f"seed {seed} rank {rank}: {bad[:5]}"
         assert stats["frames"] == len(ops)
+
+
+@pytest.mark.parametrize("world,lanes", [(2, 2), (3, 3)])
+def test_selection_edit_set_in_mid_flight_of_sharded_frames(world, lanes):
+    """Sharded frames in flight on lanes, nothing read back in between, and the host changes the selection edit with a plain setter
+    (gsx_update_selection_edit orders nothing by itself): the library completes the frames that still read the old edit records
+    before it prepares the new ones.  Checked frames equal the single viewer's."""
+    from wgpu_3dgs_viewer_app_amd import query
+    from wgpu_3dgs_viewer_app_amd.query import GaussianEditFlag as F
+
+    g = _scene()
+    rng = np.random.default_rng(31)
+    sel = rng.integers(0, 2 ** 32, (N + 31) // 32, dtype=np.uint64).astype(np.uint32)
+    sel[-1] &= np.uint32((1 << (N % 32)) - 1) if N % 32 else np.uint32(0xFFFFFFFF)
+    pods = {0: query.GaussianEditPod(F.ENABLED, (0.3, 1.5, 0.8), 0.25, -0.75, 2.2, 0.6),
+            5: query.GaussianEditPod(F.ENABLED | F.OVERRIDE_COLOR, (0.9, 0.2, 0.1), -0.5, 1.5, 0.45, 1.7),
+            9: query.GaussianEditPod(F.ENABLED | F.HIDDEN)}
+    poses = [57 + k for k in range(14)]
+    check = {4, 8, 13}
+
+    def drive(v, render, sel_words):
+        v.models["m"].gaussian_buffers.selection_buffer.upload(sel_words)
+        v.update_selection_highlight((1.0, 0.0, 1.0, 0.4))
+        out = {}
+        for k, pose in enumerate(poses):
+            if k in pods:
+                v.update_selection_edit_with_pod(pods[k])
+            _uniforms(v, pose)
+            render(v)
+            if k in check:
+                out[k] = v.download_framebuffer().copy()
+        return out
+
+    with MultiModelViewer() as s:
+        s.add_model("m", N)
+        s.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g)
+        ref = drive(s, lambda v: v.render_frame(["m"]), sel)
+
+    def body(rank, group):
+        v, shard_max = _rank_viewer(g, N, rank, world, group, lanes=lanes)
+        s0, c = parallel.shard_range(N, rank, world)
+        bits = np.unpackbits(sel.view(np.uint8), bitorder="little")[:N][s0:s0 + c]
+        words = np.packbits(np.concatenate([bits, np.zeros((-c) % 32, np.uint8)]), bitorder="little").view(np.uint32)
+        out = drive(v, lambda vv: vv.shard_render_frame("m", shard_max), words)
+        v.close()
+        return out
+
+    for rank, out in enumerate(run_group(world, body)):
+        for k in sorted(check):
+            assert np.array_equal(out[k], ref[k]), f"rank {rank} frame {k}: L-inf {np.abs(out[k] - ref[k]).max()}"
+    assert not np.array_equal(ref[4], ref[8])

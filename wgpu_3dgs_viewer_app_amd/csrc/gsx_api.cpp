@@ -101,7 +101,8 @@ static bool frame_may_overlap(gsx_viewer* v, const char* const* keys, uint32_t n
 // The edit records and the keep-bitset of the frame's models live with the owner and are read by whichever lane renders a
 // frame.  When k_edit_prepare has to run again (a selection, mask, edit or selection-edit change since it last did) it runs on
 // the owner's stream, AFTER every frame in flight that still reads the old state and BEFORE every later frame on any lane.
-static gsx_status prepare_edits_for_lanes(gsx_viewer* v, const char* const* keys, uint32_t n_keys) {
+namespace gsx {
+gsx_status prepare_edits_for_lanes(gsx_viewer* v, const char* const* keys, uint32_t n_keys) {
     for (uint32_t i = 0; i < n_keys; ++i) {
         Model* m = find_model(v, keys[i]);
         if (!m || !edits_need_prepare(v, m)) continue;
@@ -116,6 +117,7 @@ static gsx_status prepare_edits_for_lanes(gsx_viewer* v, const char* const* keys
     }
     return GSX_OK;
 }
+}  // namespace gsx
 
 // bring lane l up to date with viewer v for a frame of `keys`: uniforms, options, and a shadow of every model
 static gsx_status lane_sync(gsx_viewer* v, gsx_viewer* l, const char* const* keys, uint32_t n_keys) {
@@ -186,15 +188,14 @@ static gsx_status lane_sync(gsx_viewer* v, gsx_viewer* l, const char* const* key
 }
 
 namespace gsx {
-// May an index-sharded frame of these models run on a lane?  A lane's shadow models view the Gaussian data, the mask and the
-// transform; selections, edit records, the query and the highlight live with the viewer itself (as for gsx_render_frame:
-// frame_may_overlap).  tests/test_gpu_shard_lib.py::test_fuzz_sharded_against_single found the hole.
+// May an index-sharded frame of these models run on a lane?  A lane's shadow models view the Gaussian data, the mask, the
+// transform and the owner's selection / edit records (prepare_edits_for_lanes); a query's flags live with the viewer itself (as
+// for gsx_render_frame: frame_may_overlap).  tests/test_gpu_shard_lib.py::test_fuzz_sharded_against_single found the hole when
+// lanes did not see selections and edits at all.
 bool shard_frame_may_use_lanes(gsx_viewer* v, const char* const* keys, uint32_t n_keys) {
-    if (v->query.kind != GSX_QUERY_NONE || v->highlight[3] > 0.0f) return false;
-    for (uint32_t i = 0; i < n_keys; ++i) {
-        Model* m = find_model(v, keys[i]);
-        if (!m || m->has_selection || m->has_edits) return false;
-    }
+    if (v->query.kind != GSX_QUERY_NONE) return false;
+    for (uint32_t i = 0; i < n_keys; ++i)
+        if (!find_model(v, keys[i])) return false;
     return true;
 }
 

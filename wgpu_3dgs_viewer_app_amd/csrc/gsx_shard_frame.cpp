@@ -239,20 +239,31 @@ gsx_status gsx_shard_render_frame_keys(gsx_viewer* v, const char* const* keys_fa
     gsx_status st = GSX_OK;
     uint32_t lanes = std::max(1u, std::min(v->options.frames_in_flight, 4u));
     if ((st = comm_ensure_lanes(v, lanes))) return st;
-    if (lanes > 1 && !shard_frame_may_use_lanes(v, keys_far_to_near, n_keys)) {
-        // a frame with a query, a selection, edits or a highlight runs on the viewer itself, alone: whatever is in flight
-        // completes first (in order), then this frame's front and back run in this call
+    auto complete_all = [&]() -> gsx_status {  // whatever is in flight completes, in order
         while (!v->shard_pending.empty()) {
-            st = frame_back(v, v->shard_pending.front());
+            const gsx_status cst = frame_back(v, v->shard_pending.front());
             v->shard_pending.pop_front();
-            if (st) {
+            if (cst) {
                 v->shard_pending.clear();
-                return st;
+                return cst;
             }
         }
+        return GSX_OK;
+    };
+    if (lanes > 1 && !shard_frame_may_use_lanes(v, keys_far_to_near, n_keys)) {
+        // a frame with a query runs on the viewer itself, alone: this frame's front and back run in this call
+        if ((st = complete_all())) return st;
         lanes = 1;
     }
     gsx_viewer* lane = v;
+    if (lanes > 1) {
+        // the models' edit records are shared by the lanes: when they have to be prepared again (a selection edit set by the host
+        // since the last frame: nothing else has ordered it), the frames in flight — which read the old ones — complete first
+        bool again = false;
+        for (uint32_t i = 0; i < n_keys; ++i) again = again || edits_need_prepare(v, find_model(v, keys_far_to_near[i]));
+        if (again && (st = complete_all())) return st;
+        if ((st = prepare_edits_for_lanes(v, keys_far_to_near, n_keys))) return st;
+    }
     if (lanes > 1 && (st = lane_acquire(v, v->shard_turn++ % lanes, keys_far_to_near, n_keys, &lane))) return st;
     v->shard_pending.emplace_back();
     ShardPending& p = v->shard_pending.back();

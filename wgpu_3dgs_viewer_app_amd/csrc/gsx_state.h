@@ -430,6 +430,7 @@ gsx_status do_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys, bo
 gsx_status finish_frame(gsx_viewer* v);
 inline gsx_status sync_counters(gsx_viewer* v) { return finish_frame(v); }
 gsx_status complete_records(gsx_viewer* v, Model* m);
+gsx_status prepare_edits_for_lanes(gsx_viewer* v, const char* const* keys, uint32_t n_keys);  // gsx_api.cpp: before a frame is dealt to a lane
 bool edits_need_prepare(const gsx_viewer* v, const Model* m);          // gsx_frame.cpp: this frame runs an edit pass and k_edit_prepare's inputs changed
 gsx_status prepare_edits(gsx_viewer* v, Model* m, bool* launched);  // gsx_frame.cpp
 // k_shade over a list of admitted records of a lazily projected frame, then the frame's colour ops on exactly those (gsx_frame.cpp)
