@@ -403,3 +403,27 @@ def test_ply_read_matches_gaussian_from_ply_and_round_trips():
     # a PLY without f_rest (SH-0 export) reads zero SH
     no_rest = _ply_bytes(ply[:50], order=[i for i in range(62) if not 9 <= i < 54])
     assert not Gaussians.read_ply(no_rest).gaussians["sh"].any()
+
+
+def test_ply_large_range_converted_by_several_threads_equals_small_batches():
+    """gsx_ply_read_gaussians splits a range of >= 2 x 131072 vertices over host threads: same bytes as the app's 1000-vertex batches."""
+    import ctypes as C
+
+    from wgpu_3dgs_viewer_app_amd import scene
+    from wgpu_3dgs_viewer_app_amd.ply import Gaussians
+
+    n = 3 * 131072 + 777
+    g = scene.synthetic_gaussians(n, 5, 3, 0, n)
+    data = Gaussians(g).write_ply_array()
+    L = _lib.load()
+    h = Gaussians.read_ply_header(data[:4096].tobytes())
+    whole, parts = np.zeros(n, g.dtype), np.zeros(n, g.dtype)
+    _lib.check(L.gsx_ply_read_gaussians(data.ctypes.data, data.size, C.byref(h.raw), 0, n, whole.ctypes.data))
+    for s in range(0, n, 1000):
+        m = min(1000, n - s)
+        _lib.check(L.gsx_ply_read_gaussians(data.ctypes.data, data.size, C.byref(h.raw), s, m, parts[s:].ctypes.data))
+    assert whole.tobytes() == parts.tobytes()
+    # and a range that starts in the middle
+    mid = np.zeros(2 * 131072 + 5, g.dtype)
+    _lib.check(L.gsx_ply_read_gaussians(data.ctypes.data, data.size, C.byref(h.raw), 1234, mid.shape[0], mid.ctypes.data))
+    assert mid.tobytes() == parts[1234:1234 + mid.shape[0]].tobytes()

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/gsx.h"
@@ -154,13 +155,28 @@ gsx_status gsx_ply_read_gaussians(const void* data, uint64_t size, const gsx_ply
     if (!h->is_ascii) {
         const uint64_t need = h->header_bytes + (start + n) * (uint64_t)h->vertex_bytes;
         if (need > size) return ply_fail(GSX_ERR_IO, "PLY data truncated: need %llu bytes, have %llu", (unsigned long long)need, (unsigned long long)size);
-        for (uint64_t i = 0; i < n; ++i) {
-            const char* row = p + h->header_bytes + (start + i) * (uint64_t)h->vertex_bytes;
-            for (int k = 0; k < 62; ++k) {
-                if (h->offsets[k] >= 0) memcpy(&v[k], row + h->offsets[k], 4); else v[k] = 0.0f;
+        auto convert = [&](uint64_t i0, uint64_t i1) {
+            float w[62];
+            for (uint64_t i = i0; i < i1; ++i) {
+                const char* row = p + h->header_bytes + (start + i) * (uint64_t)h->vertex_bytes;
+                for (int k = 0; k < 62; ++k) {
+                    if (h->offsets[k] >= 0) memcpy(&w[k], row + h->offsets[k], 4); else w[k] = 0.0f;
+                }
+                vertex_to_gaussian(w, out + i);
             }
-            vertex_to_gaussian(v, out + i);
+        };
+        // rows are independent: a large range is converted by several host threads (a 5.8 M-vertex file: 0.53 s on one core)
+        const unsigned hw = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+        const uint64_t per = 1u << 17;
+        const unsigned workers = (unsigned)std::min<uint64_t>(hw, n / per);
+        if (workers <= 1) {
+            convert(0, n);
+            return GSX_OK;
         }
+        std::vector<std::thread> pool;
+        pool.reserve(workers);
+        for (unsigned t = 0; t < workers; ++t) pool.emplace_back(convert, n * t / workers, n * (t + 1) / workers);
+        for (std::thread& t : pool) t.join();
         return GSX_OK;
     }
     // ascii: one vertex per line, whitespace separated
