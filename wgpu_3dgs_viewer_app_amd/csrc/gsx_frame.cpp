@@ -399,8 +399,16 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
     adm.ballots = m->adm_ballots.as<unsigned long long>();
     adm.block_counts = m->adm_counts.as<uint32_t>();
     // lazy shading: nothing else reads the conic / colour records of this frame (no edit, highlight or query pass)
-    // (edits and the highlight are colour ops on shaded records: shade_admitted applies them to what k_shade writes)
-    m->lazy = (m->spec_round1 || shard_lazy) && v->query.kind == GSX_QUERY_NONE;
+    // (edits and the highlight are colour ops on shaded records: shade_admitted applies them to what k_shade writes; a rect /
+    // brush / texture query is answered by the geometry-only kernel itself from the projected centre; a hit query reads conics)
+    const bool geometric_query = v->query.kind == GSX_QUERY_RECT || v->query.kind == GSX_QUERY_BRUSH || v->query.kind == GSX_QUERY_TEXTURE;
+    m->lazy = (m->spec_round1 || shard_lazy) && (v->query.kind == GSX_QUERY_NONE || geometric_query);
+    if (m->lazy && geometric_query) {
+        HIPCHK(m->query_flags.ensure(4 * std::max<size_t>(words, 1)));
+        if (v->query.kind == GSX_QUERY_TEXTURE && (v->query_tex_w != v->width || v->query_tex_h != v->height))
+            return fail(GSX_ERR_INVALID_ARG, "gsx_preprocess: texture query without a viewport-sized query texture (gsx_update_query_texture)");
+        adm.query = ProjectQuery{v->query, v->query_texture.as<uint8_t>(), v->query_tex_w, v->query_tex_h, m->query_flags.as<uint32_t>()};
+    }
     m->frame_edits = edits_on;
     m->frame_highlight = highlight_on;
     m->cand_valid = false;
@@ -438,7 +446,10 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
                                  edits_on ? m->edited.as<uint32_t>() : nullptr, m->edit_a.as<float4>(), m->edit_b.as<float4>(),
                                  v->highlight));
     m->flags_kind = GSX_QUERY_NONE;
-    if (v->query.kind != GSX_QUERY_NONE) {
+    if (adm.query.flags) {  // answered by the projection kernel
+        m->flags_kind = v->query.kind;
+        m->flags_op = v->query.selection_op;
+    } else if (v->query.kind != GSX_QUERY_NONE) {
         if (v->query.kind == GSX_QUERY_HIT) {
             HIPCHK(m->hits.ensure(sizeof(gsx_query_hit) * (size_t)GSX_QUERY_MAX_HITS));
             HIPCHK(m->hit_count.ensure(4));

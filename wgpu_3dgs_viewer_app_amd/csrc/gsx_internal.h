@@ -111,11 +111,21 @@ struct WindowPyramid {
 };
 // What the projection kernel needs to decide admission in place (see kernels_admit.hip): ballots[i / 64] = admitted
 // lanes of Gaussians i..i+63, block_counts[i / 256] = admitted per workgroup.
+// A rect / brush / texture query answered inside the geometry-only projection (the reference's K1 answers its query in the
+// preprocess pass too, scene.rs:856-863): one flag bit per Gaussian from the projected centre the kernel holds anyway, so a
+// frame with such a query (every frame while a selection tool is dragged) stays a lazily shaded frame.
+struct ProjectQuery {
+    gsx_query q;
+    const uint8_t* texture;  // GSX_QUERY_TEXTURE: viewport-sized, non-zero = inside
+    uint32_t tex_w, tex_h;
+    uint32_t* flags;         // ceil(N / 32) words; nullptr: no query in this launch
+};
 struct ProjectAdmission {
     WindowPyramid pyramid;        // data == nullptr: every visible Gaussian is admitted
     unsigned long long* ballots;  // ceil(N / 64) words
     uint32_t* block_counts;       // ceil(N / 256) words
     uint32_t lazy;                // 1: geometry only; launch_shade writes the conic / colour records of the admitted Gaussians
+    ProjectQuery query;           // lazy launches only
 };
 // the records a repair round admitted; those not shaded by the (lazy) projection pass are completed
 struct LateProjection {

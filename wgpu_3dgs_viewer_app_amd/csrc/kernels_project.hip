@@ -11,6 +11,7 @@
 // is written in the exact order of spec/RENDER_SPEC.md §4 so the CPU oracle reproduces it bit-for-bit.
 #include <hip/hip_fp16.h>
 
+#include "edit_math.h"
 #include "gsx_internal.h"
 #include "project_math.h"
 #include "window_scan.h"
@@ -456,7 +457,8 @@ __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint
 // workgroups better than a loop with a barrier per group.)  A workgroup covers PER consecutive 256-Gaussian groups and writes their
 // ballots / counts exactly where PER workgroups of k_project would.
 constexpr int kProjGeomPer = 1;  // Gaussians per lane of the geometry-only kernel (2 and 4 measured: no gain)
-template <int COVK, int PER>
+// QUERY: also answer adm.query (rect / brush / texture) from the projected centre: the flag words k_query would write
+template <int COVK, int PER, bool QUERY>
 __global__ __launch_bounds__(256) void k_project_geom(const FrameConsts f, const uint32_t n, const PodPlanes pod,
                                                        const Records rec, uint32_t* __restrict__ block_visible,
                                                        const ProjectAdmission adm) {
@@ -504,6 +506,29 @@ __global__ __launch_bounds__(256) void k_project_geom(const FrameConsts f, const
     for (int k = 0; k < PER; ++k) {
         take[k] = vis[k];
         if (adm.pyramid.data && vis[k]) take[k] = pyramid_admits(adm.pyramid, __float_as_uint(vc[k].d), sp[k].rx, sp[k].ry);
+    }
+    if (QUERY) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const uint32_t i = base + 256u * k;
+            const gsx_query& q = adm.query.q;
+            bool flag = false;
+            if (vis[k]) {
+                const float mx = sp[k].mx, my = sp[k].my;
+                if (q.kind == GSX_QUERY_RECT) {
+                    flag = em_in_rect(mx, my, q);
+                } else if (q.kind == GSX_QUERY_BRUSH) {
+                    flag = em_in_brush(mx, my, q);
+                } else {  // GSX_QUERY_TEXTURE
+                    const float fx = floorf(mx), fy = floorf(my);
+                    if (adm.query.texture && fx >= 0.0f && fy >= 0.0f && fx < (float)adm.query.tex_w && fy < (float)adm.query.tex_h)
+                        flag = adm.query.texture[(size_t)fy * adm.query.tex_w + (size_t)fx] != 0;
+                }
+            }
+            const unsigned long long qb = __ballot(flag);
+            const uint32_t lane = threadIdx.x & 63u;
+            if ((lane & 31u) == 0 && i < n) adm.query.flags[i >> 5] = (uint32_t)(qb >> lane);
+        }
     }
     __shared__ uint32_t wave_cnt[PER][4], wave_adm[PER][4];
 #pragma unroll
@@ -635,8 +660,11 @@ static void launch_project_deg(hipStream_t s, dim3 grid, int deg, const FrameCon
 #define GSX_PROJECT(D)                                                                                                       \
     if (late)                                                                                                                \
         hipLaunchKernelGGL((k_shade<D, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, late->pairs, late->d_n, late->shaded, late->write_a ? 1 : 0); \
+    else if (adm.lazy && adm.query.flags)                                                                                    \
+        hipLaunchKernelGGL((k_project_geom<COVK, kProjGeomPer, true>), dim3((grid.x + kProjGeomPer - 1) / kProjGeomPer),     \
+                           block, 0, s, f, n, pod, rec, bv, adm);                                                            \
     else if (adm.lazy)                                                                                                       \
-        hipLaunchKernelGGL((k_project_geom<COVK, kProjGeomPer>), dim3((grid.x + kProjGeomPer - 1) / kProjGeomPer), \
+        hipLaunchKernelGGL((k_project_geom<COVK, kProjGeomPer, false>), dim3((grid.x + kProjGeomPer - 1) / kProjGeomPer),    \
                            block, 0, s, f, n, pod, rec, bv, adm);                                                            \
     else                                                                                                                     \
         hipLaunchKernelGGL((k_project<D, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv, adm)
