@@ -3,7 +3,7 @@
   mask        gsx_mask_evaluate ('0 - 1', box minus ellipsoid): one pass over the positions
   query       a rect query riding on the projection pass + gsx_postprocess (selection Set)
   edit frame  a frame while a selection edit is active (k_edit_prepare / k_edit_apply, unlazy projection)
-  PLY         gsx_ply_write / gsx_ply_read_gaussians on the host (1 M Gaussians; single thread)
+  PLY         gsx_ply_write (one thread) / gsx_ply_read_gaussians (one call for the file: several host threads) on the host, 1 M Gaussians
 One JSON line.  usage: python tools/bench_rows.py"""
 import json
 import os

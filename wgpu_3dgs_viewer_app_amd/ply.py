@@ -41,15 +41,16 @@ class Gaussians:
         L = _lib.load()
         for s in range(start, start + n, batch):
             m = min(batch, start + n - s)
-            out = np.zeros(m, dtype=GAUSSIAN_DTYPE)
+            out = np.empty(m, dtype=GAUSSIAN_DTYPE)  # every byte is written by the library (no padding in gs::Gaussian)
             _lib.check(L.gsx_ply_read_gaussians(buf.ctypes.data, buf.size, C.byref(header.raw), s, m, out.ctypes.data))
             yield out
 
     @classmethod
     def read_ply(cls, data: bytes) -> "Gaussians":
+        """The whole file in ONE library call: a large range is converted on several host threads (csrc/gsx_ply.cpp)."""
         h = cls.read_ply_header(data)
-        parts = list(cls.read_ply_gaussians(data, h))
-        return cls(np.concatenate(parts) if parts else np.zeros(0, GAUSSIAN_DTYPE))
+        parts = list(cls.read_ply_gaussians(data, h, batch=max(h.count(), 1)))
+        return cls(parts[0] if parts else np.zeros(0, GAUSSIAN_DTYPE))
 
     def write_ply(self, mask_words: np.ndarray | None = None, edits: np.ndarray | None = None) -> bytes:
         """``write_ply(writer, edits, mask)`` (app.rs:908-940): binary little-endian INRIA PLY of the (masked, edited) Gaussians."""
