@@ -723,12 +723,17 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
                 RadixBuffers rb{nullptr, nullptr, m->tp_src.as<uint2>(), m->tk_out.as<uint32_t>(), m->tv_out.as<uint32_t>(),
                                 m->tp_a.as<uint2>(), m->tp_b.as<uint2>(), m->tsort_ws.as<uint32_t>()};
                 const uint32_t block_cap = (uint32_t)std::min<uint64_t>(cap, (uint64_t)(j1 - j0) * 256u);
-                HIPCHK(launch_radix_sort(v->stream, rb, block_cap, &dc->n_entries, (int)std::max<uint32_t>(1u, ceil_log2(v->blocks_max)), false));
+                // (<= 256 blocks: ONE digit, and the block ranges are the scan of its histogram — no k_tile_ranges launch;
+                //  k_block_table zeroed the ranges, which is what stays when the slab made no entry at all)
+                const int block_bits = (int)std::max<uint32_t>(1u, ceil_log2(v->blocks_max));
+                HIPCHK(launch_radix_sort(v->stream, rb, block_cap, &dc->n_entries, block_bits, false, false, block_bits <= 8 ? m->ranges.as<uint2>() : nullptr));
                 m->tile_keys = m->tk_out.as<uint32_t>();
                 m->tile_list = m->tv_out.as<uint32_t>();
                 v->pass_launches[GSX_PASS_TILE_SORT] += 1;
-                ScopedPass t2(v, GSX_PASS_BIN);
-                HIPCHK(launch_tile_ranges(v->stream, block_cap, &dc->n_entries, m->tile_keys, 1024u, m->ranges.as<uint2>(), true));  // (k_block_table zeroed the block ranges)
+                if (block_bits > 8) {  // GSX_BLOCKS_MAX above 256: two digits, ranges from the sorted keys
+                    ScopedPass t2(v, GSX_PASS_BIN);
+                    HIPCHK(launch_tile_ranges(v->stream, block_cap, &dc->n_entries, m->tile_keys, 1024u, m->ranges.as<uint2>(), true));
+                }
                 m->ranges_clean = false;
             }
         } else {

@@ -159,8 +159,9 @@ size_t radix_workspace_words(uint64_t n);
 bool radix_lane_ordered_adds();
 void radix_set_rank_override(int mode);  // -1 none | 0 ballot matching | 1 lane-ordered LDS adds (debug: gsx_debug_set_radix_rank_mode)
 // n sizes the launch; d_n (nullable) is the real element count on the device (<= n).
+// ranges_out (one-digit sorts only: bits <= 8): [first, end) of every key value in the sorted output, (0, 0) for absent ones
 hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n, uint32_t* d_n, int bits, bool iota_values,
-                             bool skip_culled = false);  // skip_culled: keys == 0xFFFFFFFF do not exist; *d_n receives the count that do
+                             bool skip_culled = false, uint2* ranges_out = nullptr);  // skip_culled: keys == 0xFFFFFFFF do not exist; *d_n receives the count that do
 
 // Device-resident per-model frame statistics; the host mirrors them lazily (no sync inside a frame).
 struct SlabStats {

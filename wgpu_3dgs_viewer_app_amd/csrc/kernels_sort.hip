@@ -192,7 +192,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t
                                                                    uint32_t* __restrict__ ticket /* [0] ticket, [1] finished */,
                                                                    u64* __restrict__ status, uint32_t epoch,
                                                                    uint32_t* __restrict__ ghist_clear /* last pass: all rows */,
-                                                                   uint32_t ghist_clear_words, uint32_t* __restrict__ d_n_out) {
+                                                                   uint32_t ghist_clear_words, uint32_t* __restrict__ d_n_out,
+                                                                   uint2* __restrict__ ranges_out) {
     __shared__ uint2 s_pairs[kRadixTile];       // tile reordered by digit
     __shared__ uint32_t s_tile_n;               // elements of the tile that exist (SKIP)
     __shared__ uint32_t cnt[kSweepWaves][256];  // per-wave digit counts, then per-wave local offsets
@@ -226,6 +227,9 @@ __global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t
         for (uint32_t w = 0; w < wave; ++w) woff += s_wtot[w];
         dbase = woff + x - v;
         if (SKIP && blockIdx.x == 0 && tid == 255u && d_n_out) *d_n_out = woff + x;  // the histogram's total: what exists
+        // a one-pass sort (the block sort: the digit IS the key): [first slot, end) of every key is the scan just made —
+        // what a k_tile_ranges launch over the sorted keys would find
+        if (ranges_out && blockIdx.x == 0 && dig) ranges_out[tid] = v ? make_uint2(dbase, dbase + v) : make_uint2(0u, 0u);
         __syncthreads();
     }
 
@@ -513,9 +517,10 @@ static bool use_lane_ordered() {
 }
 
 hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n, uint32_t* d_n, int bits, bool iota_values,
-                             bool skip_culled) {
+                             bool skip_culled, uint2* ranges_out) {
     if (n == 0) return hipSuccess;
     const int passes = (bits + 7) / 8;
+    if (ranges_out && passes != 1) return hipErrorInvalidValue;  // key ranges fall out of a ONE-digit sort only
     // equal digit widths (13 tile-key bits sort as 7 + 6, not 8 + 5): fewer digits mean shorter status rows to publish
     // and look back over, and longer runs per digit in the scattered writes
     const int dbits = (bits + passes - 1) / passes;
@@ -549,7 +554,7 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
         const uint32_t epoch = (g_epoch.fetch_add(1, std::memory_order_relaxed) & 0x1FFFFFFFu) | (1u << 29);  // 30 bits, never 0
 #define GSX_SWEEP_ARGS(DN, DNOUT)                                                                                        \
     dim3(grid), dim3(kSweepThreads), 0, s, buf.keys_src, buf.vals_src, pin, buf.keys_out, buf.vals_out, pout, n, DN, shift, dmask, \
-        ghist + 256 * p, ticket, status, epoch, ghist, last ? 256u * (uint32_t)passes : 0u, DNOUT
+        ghist + 256 * p, ticket, status, epoch, ghist, last ? 256u * (uint32_t)passes : 0u, DNOUT, ranges_out
 #define GSX_SWEEP(IN, OUT)                                                                                               \
     do {                                                                                                                 \
         if (lane_ordered)                                                                                                \
