@@ -121,6 +121,37 @@ def main():
     if mode == "root_gather":
         v.shard_set_gather_root(0)
     shard_max = (N + world - 1) // world
+    if mode == "long":   # hundreds of frames in flight with jumps (repairs, redone frames), compared at a few points
+        rng = np.random.default_rng(77)
+        walk, pose = [], 57
+        for k in range(240):
+            pose = int(rng.integers(0, 240)) if rng.random() < 0.08 else (pose + 1) % 240
+            walk.append(pose)
+        check = {59, 119, 179, 239}
+        with MultiModelViewer() as s1:
+            s1.add_model("m", N)
+            s1.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g)
+            want = {}
+            for k in check:
+                uniforms(s1, walk[k])
+                s1.render_frame(["m"])
+                want[k] = s1.download_framebuffer().copy()
+        bad = []
+        for k, pz in enumerate(walk):
+            uniforms(v, pz)
+            if k % 37 == 5:
+                v.shard_set_slot_records("m", 64)   # now and then a slot that overflows: the frame is redone
+            v.shard_render_frame("m", shard_max)
+            if k in check and not np.array_equal(v.download_framebuffer(), want[k]):
+                bad.append(k)
+        stats = v.shard_stats()
+        v.close()
+        print(f"rank {rank}: stats {stats}", flush=True)
+        if bad or stats["frames"] != len(walk) or stats["repair_frames"] == 0 or stats["redo_frames"] == 0:
+            print(f"rank {rank}: long run: frames {bad} differ, or no repair / redo happened", flush=True)
+            return 1
+        print(f"rank {rank}: OK ({mode}, {lanes} lane(s), {stats['wire_bytes']} bytes on the links)", flush=True)
+        return 0
     frames = []
     for pose in POSES:
         uniforms(v, pose)

@@ -51,7 +51,7 @@ def _run(world, mode, lanes, timeout=240):
 
 
 @pytest.mark.parametrize("world,mode,lanes", [(2, "natural", 1), (2, "all_refusing", 1), (2, "tiny_slots", 1), (2, "natural", 2), (3, "natural", 1), (3, "root_gather", 1), (2, "root_gather", 2),
-                                              (2, "layered", 1), (3, "layered_refusing", 1), (2, "layered", 2)])
+                                              (2, "layered", 1), (3, "layered_refusing", 1), (2, "layered", 2), (3, "long", 2), (2, "long", 3)])
 def test_sharded_frames_over_rccl_between_processes(world, mode, lanes):
     outs = _run(world, mode, lanes)
     for rank, o in enumerate(outs):
