@@ -108,6 +108,11 @@ struct WindowPyramid {
     uint32_t levels;       // level (levels - 1) is a single cell
     uint32_t min_of_starts; // 0: cells hold the largest window END (admit key < it); 1: the smallest START among non-empty
                             // windows, KEY_ALL if none (admit key >= it) — the repair round's windows [hi, inf)
+    // min_of_starts pyramids also carry ONE 64-bit word behind their levels: bit (cy * 8 + cx) of an 8 x 8 grid of screen cells
+    // (tile >> cell_sx, tile >> cell_sy) is set iff some tile of the cell has a non-empty window.  A repair touches few tiles:
+    // most records are refused by this word — shifts and an AND in registers — before any pyramid cell is loaded.
+    uint32_t cells_off;     // word offset of that (8-byte aligned) word in `data`
+    uint32_t cell_sx, cell_sy;
 };
 // What the projection kernel needs to decide admission in place (see kernels_admit.hip): ballots[i / 64] = admitted
 // lanes of Gaussians i..i+63, block_counts[i / 256] = admitted per workgroup.

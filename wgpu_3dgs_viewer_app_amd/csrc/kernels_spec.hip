@@ -200,12 +200,16 @@ WindowPyramid window_pyramid_layout(uint32_t tiles_x, uint32_t tiles_y, const ui
         wy = (wy + 1) / 2;
     }
     p.levels = l;
+    p.cells_off = (off + 1u) & ~1u;
+    auto shift = [](uint32_t tiles) { uint32_t s = 0; while (((tiles - 1u) >> s) > 7u) ++s; return s; };  // (tiles - 1) >> s <= 7
+    p.cell_sx = shift(std::max(tiles_x, 1u));
+    p.cell_sy = shift(std::max(tiles_y, 1u));
     return p;
 }
 
 size_t window_pyramid_words(uint32_t tiles_x, uint32_t tiles_y) {
     const WindowPyramid p = window_pyramid_layout(tiles_x, tiles_y, nullptr);
-    return (size_t)p.off[p.levels - 1] + (size_t)p.wx[p.levels - 1] * p.wy[p.levels - 1];
+    return (size_t)p.cells_off + 2;  // the levels, then the 64-bit cell word of a min-of-starts pyramid
 }
 
 // one workgroup builds every level (11 k words at 1080p): level 0 = the window ends, level l = 2x2 max of level l-1.
@@ -214,10 +218,20 @@ size_t window_pyramid_words(uint32_t tiles_x, uint32_t tiles_y) {
 __global__ __launch_bounds__(1024) void k_window_pyramid(const uint2* __restrict__ window, WindowPyramid p, uint32_t* __restrict__ data,
                                                          const uint32_t* __restrict__ d_skip, uint32_t* __restrict__ min_ends) {
     if (d_skip && *d_skip == 0) return;  // repair round with nothing to repair
+    __shared__ unsigned long long s_cells;
+    if (threadIdx.x == 0) s_cells = 0ull;
+    __syncthreads();
+    unsigned long long cells = 0ull;
     for (uint32_t i = threadIdx.x; i < p.wx[0] * p.wy[0]; i += 1024) {
         const uint2 w = window[i];
         data[i] = p.min_of_starts ? (w.y > w.x ? w.x : 0xFFFFFFFFu) : w.y;
         if (min_ends) min_ends[i] = w.x == 0u ? w.y : 0u;  // a window that does not start at 0 promises nothing
+        if (p.min_of_starts && w.y > w.x) cells |= 1ull << ((((i / p.wx[0]) >> p.cell_sy) << 3) | ((i % p.wx[0]) >> p.cell_sx));
+    }
+    if (p.min_of_starts) {
+        if (cells) atomicOr(&s_cells, cells);
+        __syncthreads();
+        if (threadIdx.x == 0) *reinterpret_cast<unsigned long long*>(data + p.cells_off) = s_cells;
     }
     for (uint32_t l = 1; l < p.levels; ++l) {
         __syncthreads();

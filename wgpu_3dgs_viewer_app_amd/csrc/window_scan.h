@@ -109,6 +109,16 @@ __device__ inline unsigned long long wave_dest_mask(const uint2* __restrict__ wi
 // conservative admission against the max-pyramid of the window ends: true if SOME tile under the rectangle may admit
 __device__ inline bool pyramid_admits(const WindowPyramid& p, uint32_t key, uint32_t rx, uint32_t ry) {
     const uint32_t x0 = rx & 0xFFFFu, xb = (rx >> 16) - 1u, y0 = ry & 0xFFFFu, yb = (ry >> 16) - 1u;
+    if (p.min_of_starts) {
+        // no tile with a window anywhere near the rectangle (an 8 x 8 grid of screen cells, one bit each): every cell the walk
+        // below would load holds KEY_ALL — the same answer without a load
+        const unsigned long long need = *reinterpret_cast<const unsigned long long*>(p.data + p.cells_off);
+        const uint32_t cx0 = x0 >> p.cell_sx, cx1 = min(xb >> p.cell_sx, 7u), cy0 = y0 >> p.cell_sy, cy1 = min(yb >> p.cell_sy, 7u);
+        const unsigned long long row = ((2ull << (cx1 - cx0)) - 1ull) << cx0;
+        const uint32_t rows = cy1 - cy0 + 1u;
+        const unsigned long long sel = (rows >= 8u ? ~0ull : ((1ull << (8u * rows)) - 1ull)) << (8u * cy0);
+        if (((row * 0x0101010101010101ull) & sel & need) == 0ull) return false;
+    }
     const uint32_t ext = max(xb - x0, yb - y0);  // extent - 1
     const uint32_t l = ext ? 32u - (uint32_t)__clz((int)ext) : 0u;
     if (l >= p.levels) return true;  // wider than the pyramid's top cell (viewports beyond 4096 px): take it
