@@ -283,7 +283,7 @@ hipError_t launch_spec_next(hipStream_t s, const uint32_t* tile_sat, const uint3
 // d_n (nullable) / tile: only the first ceil(*d_n / tile) columns of every row hold anything (a candidate list shorter than the grid)
 hipError_t launch_spin(hipStream_t s, uint32_t microseconds);  // one wave that does nothing for that long (stream / queue probe)
 hipError_t launch_rowscan(hipStream_t s, uint32_t* table, uint32_t nrows, uint32_t nblocks, uint32_t* totals, const uint32_t* d_n = nullptr,
-                          uint32_t tile = 1);
+                          uint32_t tile = 1, const uint32_t* d_skip = nullptr /* points at 0: the totals are 0, nothing is read */);
 size_t pack_blocks(uint64_t n, uint32_t rounds);  // workgroups of a pack pass whose tiles hold 256 x rounds records
 uint32_t pack_rounds(bool candidate_list);
 // rows_per_rank: rank g owns tile rows [g*rpr, min((g+1)*rpr, tiles_y)).  A record travels to g if its rectangle

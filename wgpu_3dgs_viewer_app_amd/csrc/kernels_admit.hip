@@ -29,6 +29,7 @@ __global__ __launch_bounds__(kAdmitThreads) void k_admit_count(const uint32_t* _
     __shared__ uint32_t wcnt[kAdmitThreads / 64];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const bool skip = d_skip && *d_skip == 0;  // verification round with nothing to repair: admit nothing
+    if (skip) return;  // (uniform) the scan and the scatter behind look at the same word: total 0, no ballot read
     const uint32_t base = blockIdx.x * kAdmitTile + wave * kAdmitWaveChunk;
     uint32_t c = 0;
     // every key and rectangle of the wave's 16 rounds first: the loop below is a chain of dependent loads per round otherwise
@@ -67,8 +68,9 @@ __global__ __launch_bounds__(kAdmitThreads) void k_admit_count(const uint32_t* _
 __global__ __launch_bounds__(kAdmitThreads) void k_admit_scatter(const uint32_t* __restrict__ key, uint32_t n,
                                                                   const unsigned long long* __restrict__ ballots,
                                                                   const uint32_t* __restrict__ offsets,
-                                                                  uint2* __restrict__ pairs) {
+                                                                  uint2* __restrict__ pairs, const uint32_t* __restrict__ d_skip) {
     __shared__ uint32_t wcnt[kAdmitThreads / 64];
+    if (d_skip && *d_skip == 0) return;  // nothing was admitted and no ballot was written (k_admit_count)
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const uint32_t base = blockIdx.x * kAdmitTile + wave * kAdmitWaveChunk;
     uint32_t c = 0;
@@ -234,7 +236,7 @@ hipError_t launch_admit_from_project(hipStream_t s, const uint32_t* key, uint32_
 hipError_t launch_admit_scatter(hipStream_t s, const uint32_t* key, uint32_t n, const unsigned long long* ballots,
                                 const uint32_t* offsets, uint2* pairs) {
     const uint32_t nb = (uint32_t)admit_blocks(n);
-    if (nb) hipLaunchKernelGGL(k_admit_scatter, dim3(nb), dim3(kAdmitThreads), 0, s, key, n, ballots, offsets, pairs);
+    if (nb) hipLaunchKernelGGL(k_admit_scatter, dim3(nb), dim3(kAdmitThreads), 0, s, key, n, ballots, offsets, pairs, nullptr);
     return hipGetLastError();
 }
 
@@ -243,9 +245,9 @@ hipError_t launch_admit(hipStream_t s, const Records& rec, uint32_t n, const uin
     const uint32_t nb = (uint32_t)admit_blocks(n);
     if (!nb) return hipMemsetAsync(d_total, 0, 4, s);
     hipLaunchKernelGGL(k_admit_count, dim3(nb), dim3(kAdmitThreads), 0, s, rec.key, rec.a, n, window, tiles_x, gate, row_words, pyramid, d_skip, ballots, counts, rec.rect8);
-    hipError_t e = launch_rowscan(s, counts, 1, nb, d_total);
+    hipError_t e = launch_rowscan(s, counts, 1, nb, d_total, nullptr, 1, d_skip);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_admit_scatter, dim3(nb), dim3(kAdmitThreads), 0, s, rec.key, n, ballots, counts, pairs);
+    hipLaunchKernelGGL(k_admit_scatter, dim3(nb), dim3(kAdmitThreads), 0, s, rec.key, n, ballots, counts, pairs, d_skip);
     return hipGetLastError();
 }
 

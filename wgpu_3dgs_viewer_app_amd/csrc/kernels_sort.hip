@@ -141,11 +141,13 @@ __global__ __launch_bounds__(kRadixThreads) void k_radix_global_hist(const uint3
 // one workgroup per row: exclusive scan of table[row][0..nblocks) in place; total -> totals[row]
 // (used by the multi-GPU pack, kernels_shard.hip)
 __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ table, uint32_t nblocks,
-                                                        uint32_t* __restrict__ totals, const uint32_t* __restrict__ d_n, uint32_t tile) {
+                                                        uint32_t* __restrict__ totals, const uint32_t* __restrict__ d_n, uint32_t tile,
+                                                        const uint32_t* __restrict__ d_skip) {
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t carry_s;
     uint32_t* row = table + (size_t)blockIdx.x * nblocks;  // (the row stride stays the full grid's)
     if (d_n) nblocks = min(nblocks, (*d_n + tile - 1u) / tile);
+    if (d_skip && *d_skip == 0u) nblocks = 0;  // the producer wrote nothing (or zeros): the total is 0
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
@@ -425,8 +427,9 @@ __global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t
         for (uint32_t k = tid; k < ghist_clear_words; k += kSweepThreads) ghist_clear[k] = 0;
 }
 
-hipError_t launch_rowscan(hipStream_t s, uint32_t* table, uint32_t nrows, uint32_t nblocks, uint32_t* totals, const uint32_t* d_n, uint32_t tile) {
-    if (nrows) hipLaunchKernelGGL(k_radix_rowscan, dim3(nrows), dim3(256), 0, s, table, nblocks, totals, d_n, tile);
+hipError_t launch_rowscan(hipStream_t s, uint32_t* table, uint32_t nrows, uint32_t nblocks, uint32_t* totals, const uint32_t* d_n, uint32_t tile,
+                          const uint32_t* d_skip) {
+    if (nrows) hipLaunchKernelGGL(k_radix_rowscan, dim3(nrows), dim3(256), 0, s, table, nblocks, totals, d_n, tile, d_skip);
     return hipGetLastError();
 }
 
