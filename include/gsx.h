@@ -516,8 +516,8 @@ gsx_status gsx_shard_get_stats(gsx_viewer* v, gsx_shard_stats* out, uint32_t res
  * framebuffer holds the whole frame ((world - 1) / world of W x H x 16 bytes INTO every rank: 29 MB per rank and frame at
  * 1920x1080 on 8 ranks).  root >= 0: only that rank's does — north_star's "into one framebuffer"; every other rank sends its
  * band there (4 MB each in the same case, arriving on 7 links side by side) and the rest of its own framebuffer is undefined.
- * Every rank must set the same root.  A custom transport (gsx_viewer_comm_init_custom) and the in-process group have no
- * rooted gather and keep delivering every band to every rank. */
+ * Every rank must set the same root (ranks that disagree fail the frame).  RCCL and the in-process group gather to the
+ * root; a custom transport (gsx_viewer_comm_init_custom) has only its two functions and keeps delivering every band to every rank. */
 gsx_status gsx_shard_set_gather_root(gsx_viewer* v, int32_t root);
 
 /* ---- PLY I/O (host side; no GPU needed).  gs::Gaussians::read_ply_header / PlyHeader::count /

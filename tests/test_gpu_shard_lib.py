@@ -686,3 +686,42 @@ def test_selection_edit_set_in_mid_flight_of_sharded_frames(world, lanes):
         for k in sorted(check):
             assert np.array_equal(out[k], ref[k]), f"rank {rank} frame {k}: L-inf {np.abs(out[k] - ref[k]).max()}"
     assert not np.array_equal(ref[4], ref[8])
+
+
+@pytest.mark.parametrize("world,root,lanes", [(3, 1, 1), (4, 0, 2)])
+def test_bands_gathered_to_one_rank_over_the_group(world, root, lanes):
+    """gsx_shard_set_gather_root over the in-process group: the root's framebuffer holds every frame whole, every other rank
+    keeps (at least) its own band of tile rows and receives nothing; ranks that name different roots fail the frame."""
+    g = _scene()
+    ref = _single_frames(g)
+
+    def body(rank, group):
+        v, shard_max = _rank_viewer(g, N, rank, world, group, lanes=lanes)
+        v.shard_set_gather_root(root)
+        frames = []
+        for pose in POSES:
+            _uniforms(v, pose)
+            v.shard_render_frame("m", shard_max)
+            frames.append(v.download_framebuffer().copy())
+        v.close()
+        return frames
+
+    rows = 16 * ((TILES[0] + world - 1) // world)
+    for rank, frames in enumerate(run_group(world, body)):
+        lo, hi = (0, H) if rank == root else (min(rank * rows, H), min((rank + 1) * rows, H))
+        for k, fb in enumerate(frames):
+            assert np.array_equal(fb[lo:hi], ref[k][lo:hi]), f"rank {rank} frame {k}"
+
+    def disagree(rank, group):
+        v, shard_max = _rank_viewer(g, N, rank, world, group)
+        v.shard_set_gather_root(rank % 2)
+        _uniforms(v, POSES[0])
+        try:
+            v.shard_render_frame("m", shard_max)
+            v.poll()
+        finally:
+            v.close()
+
+    with pytest.raises(GsxError) as e:
+        run_group(world, disagree, timeout_ms=2000)
+    assert e.value.status == _lib.GSX_ERR_RCCL

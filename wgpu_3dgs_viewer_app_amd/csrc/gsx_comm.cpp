@@ -249,6 +249,12 @@ gsx_status gsx::comm_gather_to_root(gsx_viewer* v, const void* d_send, void* d_r
     gsx_viewer* o = owner_of(v);
     if (!has_comm(o)) return fail(GSX_ERR_RCCL, "gather to root: no communicator (gsx_viewer_comm_init)");
     if (root >= o->comm_world) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_set_gather_root: root %u of %u ranks", root, o->comm_world);
+    if (o->comm_group && o->comm_world > 1) {  // the in-process group: the root copies the pieces, nobody else receives
+        gsx_status bst = viewer_bind(v);
+        if (bst) return bst;
+        if (o->comm_rank != root) o->shard_stats.wire_bytes += bytes_per_rank;
+        return bytes_per_rank ? group_gather_to_root(o, d_send, d_recv, bytes_per_rank, root, v->stream) : GSX_OK;
+    }
     if (o->comm_ag_fn || (o->comm_world == 1 && !o->comm_self_via_rccl)) return gsx_comm_all_gather(v, d_send, d_recv, bytes_per_rank);
     if (bytes_per_rank == 0) return GSX_OK;
     ncclComm_t comm = comm_of(v);

@@ -26,7 +26,7 @@
 
 namespace {
 
-enum Op : int { OP_NONE = 0, OP_ALL_TO_ALL = 1, OP_ALL_GATHER = 2 };
+enum Op : int { OP_NONE = 0, OP_ALL_TO_ALL = 1, OP_ALL_GATHER = 2, OP_GATHER = 3 /* + root << 8 */ };
 
 struct Seat {
     gsx_comm_group* group = nullptr;
@@ -93,7 +93,9 @@ gsx_status rendezvous(gsx_comm_group* g, uint32_t rank, const char* what) {
 
 gsx_status collective(Seat* me, int op, const void* d_send, void* d_recv, uint64_t bytes, hipStream_t stream) {
     gsx_comm_group* g = me->group;
-    const char* what = op == OP_ALL_TO_ALL ? "an all-to-all" : "an all-gather";
+    const int kind = op & 0xFF;
+    const uint32_t root = (uint32_t)op >> 8;  // OP_GATHER: the only rank that receives
+    const char* what = kind == OP_ALL_TO_ALL ? "an all-to-all" : (kind == OP_GATHER ? "a gather" : "an all-gather");
     auto ev = me->events.find(stream);
     if (ev == me->events.end()) {
         hipEvent_t a = nullptr, b = nullptr;
@@ -120,8 +122,9 @@ gsx_status collective(Seat* me, int op, const void* d_send, void* d_recv, uint64
             return group_abort(g, buf);
         }
     for (uint32_t p = 0; p < g->world; ++p) {  // delivery by source rank, like ncclRecv from p / ncclAllGather
+        if (kind == OP_GATHER && me->rank != root) break;  // a rank that is not the root sends (the root copies) and receives nothing
         const Seat& src = g->seats[p];
-        const char* from = op == OP_ALL_TO_ALL ? src.send + (size_t)me->rank * bytes : src.send;
+        const char* from = kind == OP_ALL_TO_ALL ? src.send + (size_t)me->rank * bytes : src.send;
         char* to = me->recv + (size_t)p * bytes;
         if (from == to) continue;  // an in-place all-gather's own piece
         if (p != me->rank) HIPCHK(hipStreamWaitEvent(stream, src.ready, 0));
@@ -143,6 +146,11 @@ gsx_status group_all_gather(void* ctx, const void* d_send, void* d_recv, uint64_
 }
 
 }  // namespace
+
+// every rank's piece into the root's buffer only (gsx_shard_set_gather_root over the in-process group)
+gsx_status gsx::group_gather_to_root(gsx_viewer* owner, const void* d_send, void* d_recv, uint64_t bytes_per_rank, uint32_t root, hipStream_t stream) {
+    return collective(static_cast<Seat*>(owner->comm_ctx), OP_GATHER | (int)(root << 8), d_send, d_recv, bytes_per_rank, stream);
+}
 
 void gsx::group_leave(gsx_viewer* v) {
     gsx_comm_group* g = v->comm_group;

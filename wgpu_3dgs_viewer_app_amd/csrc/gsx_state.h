@@ -381,6 +381,7 @@ inline uint32_t ceil_log2(uint32_t x) {
 // the lanes' frames (no host wait), and the lanes' next frames after whatever the caller enqueues (epoch).
 gsx_status shard_complete_pending(gsx_viewer* v);  // gsx_comm.cpp: verdicts, redo / repair rounds of the sharded frames in flight
 inline bool has_comm(const gsx_viewer* v) { return v->comm != nullptr || v->comm_a2a_fn != nullptr; }
+gsx_status group_gather_to_root(gsx_viewer* owner, const void* d_send, void* d_recv, uint64_t bytes_per_rank, uint32_t root, hipStream_t stream);  // gsx_comm_group.cpp
 void group_leave(gsx_viewer* v);  // gsx_comm_group.cpp: give this viewer's seat in its in-process group back
 gsx_status comm_gather_to_root(gsx_viewer* v, const void* d_send, void* d_recv, uint64_t bytes_per_rank, uint32_t root);  // gsx_comm.cpp
 gsx_status comm_ensure_lanes(gsx_viewer* v, uint32_t lanes);  // gsx_comm.cpp: one RCCL communicator per lane (collective)
