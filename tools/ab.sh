@@ -3,7 +3,7 @@
 ARGS=$1; shift
 for rep in 1 2 3; do
   for v in "$@"; do
-    if [ "$v" = base ]; then unset GSX_LIB; else export GSX_LIB=$PWD/wgpu_3dgs_viewer_app_amd/variants/libgsx_$v.so; fi
+    if [ "$v" = base ]; then unset GSX_LIB; else export GSX_LIB=$PWD/build_variants/libgsx_$v.so; fi
     r=$(python bench.py --no-cpu-baseline --no-pmc $ARGS 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Hardware counters of one kernel over a short bench run, one rocprofv3 pass per counter group (never with sys-trace).
+# (--no-pmc: the profiled process must not start rocprofv3 children of its own once its GPU is initialised)
 # usage: tools/pmc_kernel.sh <out dir under gpurun_out> <kernel substring> [bench args...]
 OUT=gpurun_out/$1; K=$2; shift 2
 mkdir -p $OUT
@@ -8,7 +9,7 @@ for grp in "SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_ACTIVE_INS
            "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU" "SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD" \
            "GRBM_GUI_ACTIVE SQ_LEVEL_WAVES SQ_INSTS_VALU_TRANS_F32 SQ_THREAD_CYCLES_VALU"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/g$i -o p -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline "$@" > $OUT/g$i.log 2>&1
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/g$i -o p -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-pmc "$@" > $OUT/g$i.log 2>&1
 done
 python3 - "$OUT" "$K" <<'PY'
 import csv, glob, sys, collections

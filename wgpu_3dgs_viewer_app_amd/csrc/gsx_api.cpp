@@ -13,6 +13,7 @@ using namespace gsx;
 // gsx_render_frame deals frames round-robin to the viewer and its lanes; nothing else in the library knows about lanes
 // except viewer_bind (gsx_state.h), which orders the viewer's stream after the lanes' frames before any other call.
 static std::atomic<uint64_t> g_model_serial{0};  // (viewers of different host threads create models concurrently)
+static std::atomic<int> g_viewers_on_device[64];  // live top-level viewers of this process per device (lane_create's probe asks)
 
 // per-model results: the lane that rendered the newest frame — unless that frame did not include the model (a key that was
 // last rendered in an earlier frame lives where that frame ran; the viewer itself is the best answer left)
@@ -66,11 +67,17 @@ static gsx_status lane_create(gsx_viewer* v, gsx_viewer** out) {
     // until the viewer goes, so that the next one created lands on the next queue
     std::vector<hipStream_t> busy{v->stream};
     for (gsx_viewer* o : v->lanes) busy.push_back(o->stream);
-    static const bool probe = getenv("GSX_NO_QUEUE_PROBE") == nullptr;
+    static const bool probe_env = getenv("GSX_NO_QUEUE_PROBE") == nullptr;
+    // The probe decides from timing: with other viewers at work on the same device (ranks as threads of one process, several
+    // processes per GPU) their kernels delay the candidate and the verdict is noise — every false "shares a queue" would park a
+    // stream for the viewer's lifetime and spin 400 us on every busy stream.  So: only while this is the one viewer with lanes on
+    // its device, and never more than kMaxParked parked streams per viewer.
+    constexpr size_t kMaxParked = 8;
+    const bool probe = probe_env && g_viewers_on_device[v->device & 63].load() <= 1;
     for (int attempt = 0; attempt < 8; ++attempt) {
         HIPCHK(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
         bool beside = true;
-        if (probe) {
+        if (probe && v->parked_streams.size() < kMaxParked) {
             const gsx_status pst = stream_runs_beside(l->stream, busy, &beside);
             if (pst) return pst;
         }
@@ -176,6 +183,7 @@ static gsx_status lane_sync(gsx_viewer* v, gsx_viewer* l, const char* const* key
         sm->mask_program_hash = pm->mask_program_hash;
         sm->mt = pm->mt;
         sm->show_unedited = pm->show_unedited;
+        sm->slot_force = pm->slot_force;  // gsx_shard_set_slot_records may have been called before this lane (or this shadow) existed
     }
     // whatever the caller enqueued on the viewer's stream since this lane's last frame (uploads, masks) comes first
     if (l->seen_epoch != v->epoch) {
@@ -264,6 +272,7 @@ gsx_status gsx_viewer_create(const gsx_viewer_desc* desc, gsx_viewer** out) {
     static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     memcpy(v->view, ident, sizeof ident);
     memcpy(v->proj, ident, sizeof ident);
+    g_viewers_on_device[v->device & 63].fetch_add(1);
     *out = v.release();
     return GSX_OK;
 }
@@ -289,6 +298,7 @@ void gsx_viewer_destroy(gsx_viewer* v) {
     v->models.clear();
     if (v->h_verdict) (void)hipHostFree(v->h_verdict);
     if (v->own_stream) (void)hipStreamDestroy(v->stream);
+    if (!v->parent) g_viewers_on_device[v->device & 63].fetch_sub(1);
     delete v;
 }
 

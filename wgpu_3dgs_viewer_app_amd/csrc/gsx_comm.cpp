@@ -103,6 +103,31 @@ gsx_status rccl_ready() {
         if (_r != 0) return fail(GSX_ERR_RCCL, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(_r), __FILE__, __LINE__); \
     } while (0)
 
+// Inside an open ncclGroupStart nothing may return: the group has to be closed whatever a Send / Recv answered, or every later
+// RCCL call of the thread lands in a group nobody ends.  GROUPED remembers the first failure and skips the rest; group_end
+// closes the group and reports it.
+struct RcclGroup {
+    ncclResult_t first = 0;
+    const char* what = nullptr;
+    int line = 0;
+};
+#define GROUPED(grp, expr)                                   \
+    do {                                                     \
+        if ((grp).first == 0) {                              \
+            (grp).first = (expr);                            \
+            if ((grp).first != 0) {                          \
+                (grp).what = #expr;                          \
+                (grp).line = __LINE__;                       \
+            }                                                \
+        }                                                    \
+    } while (0)
+inline gsx_status group_end(RcclGroup& grp) {
+    const ncclResult_t e = g_rccl.GroupEnd();
+    if (grp.first != 0) return fail(GSX_ERR_RCCL, "%s failed: %s (%s:%d)", grp.what, g_rccl.GetErrorString(grp.first), __FILE__, grp.line);
+    if (e != 0) return fail(GSX_ERR_RCCL, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(e));
+    return GSX_OK;
+}
+
 inline gsx_viewer* owner_of(gsx_viewer* v) { return v->parent ? v->parent : v; }
 // the communicator of a viewer (lane 0) or of one of its lanes
 inline ncclComm_t comm_of(gsx_viewer* v) {
@@ -208,13 +233,13 @@ gsx_status gsx_comm_all_to_all(gsx_viewer* v, const void* d_send, void* d_recv, 
     ncclComm_t comm = comm_of(v);
     if (!comm) return fail(GSX_ERR_RCCL, "gsx_comm_all_to_all: lane %u has no communicator", v->lane_index);
     RCCLCHK(g_rccl.GroupStart());
+    RcclGroup grp;
     for (uint32_t p = 0; p < o->comm_world; ++p) {
         if (bypass && p == o->comm_rank) continue;
-        RCCLCHK(g_rccl.Send(static_cast<const char*>(d_send) + (size_t)p * bytes_per_peer, bytes_per_peer, kNcclChar, (int)p, comm, v->stream));
-        RCCLCHK(g_rccl.Recv(static_cast<char*>(d_recv) + (size_t)p * bytes_per_peer, bytes_per_peer, kNcclChar, (int)p, comm, v->stream));
+        GROUPED(grp, g_rccl.Send(static_cast<const char*>(d_send) + (size_t)p * bytes_per_peer, bytes_per_peer, kNcclChar, (int)p, comm, v->stream));
+        GROUPED(grp, g_rccl.Recv(static_cast<char*>(d_recv) + (size_t)p * bytes_per_peer, bytes_per_peer, kNcclChar, (int)p, comm, v->stream));
     }
-    RCCLCHK(g_rccl.GroupEnd());
-    return GSX_OK;
+    return group_end(grp);
 }
 
 gsx_status gsx_comm_all_gather(gsx_viewer* v, const void* d_send, void* d_recv, uint64_t bytes_per_rank) {
@@ -267,10 +292,10 @@ gsx_status gsx::comm_gather_to_root(gsx_viewer* v, const void* d_send, void* d_r
     char* own = static_cast<char*>(d_recv) + (size_t)root * bytes_per_rank;
     if (own != d_send) HIPCHK(hipMemcpyAsync(own, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, v->stream));
     RCCLCHK(g_rccl.GroupStart());
+    RcclGroup grp;
     for (uint32_t p = 0; p < o->comm_world; ++p)
-        if (p != root) RCCLCHK(g_rccl.Recv(static_cast<char*>(d_recv) + (size_t)p * bytes_per_rank, bytes_per_rank, kNcclChar, (int)p, comm, v->stream));
-    RCCLCHK(g_rccl.GroupEnd());
-    return GSX_OK;
+        if (p != root) GROUPED(grp, g_rccl.Recv(static_cast<char*>(d_recv) + (size_t)p * bytes_per_rank, bytes_per_rank, kNcclChar, (int)p, comm, v->stream));
+    return group_end(grp);
 }
 
 // One communicator per lane (see the head of this file).  Collective: every rank calls it with the same `lanes` — they do,

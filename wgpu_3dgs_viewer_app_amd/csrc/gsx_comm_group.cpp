@@ -12,7 +12,7 @@
 //   record `ready` on r's stream, publish {send, recv, bytes}          -- what r contributes exists once `ready` fires
 //   host rendezvous A                                                  -- everybody has published; sizes are compared
 //   for every source p, in rank order: wait for p's `ready`, copy p's piece for r into r's receive buffer   (on r's stream)
-//   record `done` on r's stream; host rendezvous B; wait for every peer's `done`
+//   record `done` on r's stream; host rendezvous B; wait for every peer's `done` (the event handles are read BEFORE B)
 //                                                                      -- r's send buffer may be reused: every reader is behind
 // The host threads meet twice per collective; the DEVICE never waits for a host (copies and waits are enqueued).  A rendezvous
 // that is not complete after timeout_ms aborts the group: every rank's call — the waiting one and all later ones — returns
@@ -121,6 +121,10 @@ gsx_status collective(Seat* me, int op, const void* d_send, void* d_recv, uint64
                      (unsigned long long)bytes, p, g->seats[p].op, (unsigned long long)g->seats[p].bytes);
             return group_abort(g, buf);
         }
+    // the peers' `done` events of THIS collective, taken while the published fields are stable (between the two rendezvous): after
+    // rendezvous B a faster peer may already be publishing its next collective, on another lane's stream with that lane's event pair
+    hipEvent_t peer_done[64];
+    for (uint32_t p = 0; p < g->world; ++p) peer_done[p] = g->seats[p].done;
     for (uint32_t p = 0; p < g->world; ++p) {  // delivery by source rank, like ncclRecv from p / ncclAllGather
         if (kind == OP_GATHER && me->rank != root) break;  // a rank that is not the root sends (the root copies) and receives nothing
         const Seat& src = g->seats[p];
@@ -133,7 +137,7 @@ gsx_status collective(Seat* me, int op, const void* d_send, void* d_recv, uint64
     HIPCHK(hipEventRecord(me->done, stream));
     if ((st = rendezvous(g, me->rank, what))) return st;
     for (uint32_t p = 0; p < g->world; ++p)
-        if (p != me->rank) HIPCHK(hipStreamWaitEvent(stream, g->seats[p].done, 0));
+        if (p != me->rank) HIPCHK(hipStreamWaitEvent(stream, peer_done[p], 0));
     return GSX_OK;
 }
 

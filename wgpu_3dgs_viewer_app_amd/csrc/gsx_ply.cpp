@@ -173,9 +173,16 @@ gsx_status gsx_ply_read_gaussians(const void* data, uint64_t size, const gsx_ply
             convert(0, n);
             return GSX_OK;
         }
+        // nothing may leave an extern "C" function by exception: a thread that cannot be created (pid limits) or an allocation
+        // that fails ends the pool where it is, what was started is joined, and the calling thread converts the rest
         std::vector<std::thread> pool;
-        pool.reserve(workers);
-        for (unsigned t = 0; t < workers; ++t) pool.emplace_back(convert, n * t / workers, n * (t + 1) / workers);
+        unsigned started = 0;
+        try {
+            pool.reserve(workers);
+            for (; started < workers; ++started) pool.emplace_back(convert, n * started / workers, n * (started + 1) / workers);
+        } catch (...) {
+        }
+        if (started < workers) convert(n * started / workers, n);
         for (std::thread& t : pool) t.join();
         return GSX_OK;
     }

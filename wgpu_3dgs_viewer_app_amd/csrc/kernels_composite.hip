@@ -17,15 +17,9 @@
 
 namespace gsx {
 
-#ifndef GSX_VAR_COMP_GROUP
-#define GSX_VAR_COMP_GROUP 4
-#endif
 constexpr int kBatch = 128;                  // splat records staged through LDS per barrier pair (256 measured: no gain)
-constexpr int kGroupTiles = GSX_VAR_COMP_GROUP;  // splats blended between two wave-level exit checks, per-tile lists (A/B: tools/build_variant.sh)
-#ifndef GSX_VAR_BLK_GROUP
-#define GSX_VAR_BLK_GROUP 4
-#endif
-constexpr int kGroupBlocks = GSX_VAR_BLK_GROUP;  // ... block lists
+constexpr int kGroupTiles = 4;               // splats blended between two wave-level exit checks, per-tile lists (2 / 3 / 4 measured alike, round 3)
+constexpr int kGroupBlocks = 4;              // ... block lists
 constexpr int kPerLane = kBatch / 128;
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -216,10 +210,7 @@ __global__ __launch_bounds__(128) void k_composite(const FrameConsts f, uint2* _
 // Software pipeline: while the takers of chunk c are blended out of LDS, the candidate loads of chunk c + 1 (brec) and c + 2
 // (list) are in flight.  The takers' 48-byte records are gathered when their LDS slots are written, NOT held across the blend:
 // twelve registers less is one more wave per SIMD (84 -> 74 VGPRs, occupancy 5 -> 6), worth more than the overlap (+1.2 %).
-#ifndef GSX_VAR_BLK_CAND
-#define GSX_VAR_BLK_CAND 1
-#endif
-constexpr int kCand = GSX_VAR_BLK_CAND;          // candidates per lane and iteration
+constexpr int kCand = 1;                         // candidates per lane and iteration (1 / 2 / 3 measured alike, round 2)
 constexpr uint32_t kChunk = 128u * kCand;
 
 template <int MODE>
