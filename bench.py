@@ -203,6 +203,7 @@ def main():
     import torch.distributed as dist
 
     from wgpu_3dgs_viewer_app_amd import camera, parallel, scene
+    from wgpu_3dgs_viewer_app_amd import viewer as viewer_mod
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libgsx has no CPU fallback")
@@ -280,6 +281,7 @@ def main():
         renderer.get_pass_timing()  # reset accumulators
         first = first_round + rounds(args.warmup)
         fence()
+        launches0 = viewer_mod.launch_count()
         t0 = time.perf_counter()
         if afr:   # exactly args.steps frames of the orbit, dealt round-robin; ranks without a frame in the last round only gather
             for i in range(rounds(args.steps)):
@@ -296,7 +298,10 @@ def main():
             elapsed = float(t.item())
         timing = renderer.get_pass_timing()
         renderer.set_pass_timing(False)
+        launches["per_frame"] = round((viewer_mod.launch_count() - launches0) / max(args.steps, 1), 2)   # kernel launches the library asked for
         return elapsed, timing, first + rounds(args.steps) - 1
+
+    launches = {}
 
     def accounting(first_round, frames=32):
         """Untimed pass over the same poses: per-frame device counts (reading them costs a sync per frame)."""
@@ -383,6 +388,7 @@ def main():
     if lanes > 1 and (single or world == 1):   # (N > 1: one timed loop, as the contract says)
         set_opts()
         elapsed_1, timing, _ = timed_loop(0)
+        launches["speculated_one_frame_in_flight"] = launches["per_frame"]
         acct = accounting(rounds(args.warmup))
 
     # ---- N = 1: the unspeculated loop of the same run (value_unspeculated + the SURVEY 8d projection roofline) ----
@@ -390,6 +396,7 @@ def main():
     if single and "speculative" not in overrides:
         viewer.set_render_options(**dict(overrides, speculative=0))
         elapsed_u, timing_u, _ = timed_loop(0)
+        launches["unspeculated"] = launches["per_frame"]
         acct_u = accounting(rounds(args.warmup))
         if lanes > 1 and args.unspeculated_in_flight:
             set_opts(speculative=0, frames_in_flight=lanes)
@@ -442,6 +449,48 @@ def main():
         extra["sync_reference"] = host_sync_loop("reference")
         set_opts(speculative=0)
         extra["sync_frame_unspeculated"] = host_sync_loop("frame")
+        # the same loops with every launch submitted on its own (gsx_debug_set_launch_graphs(0)): what the cached, patched HIP graphs
+        # of csrc/gsx_launch.h are worth, same process, same resident scene
+        def host_us_per_call():
+            """host time inside gsx_render_frame, free-running loop, one frame in flight"""
+            st = renderer.stages
+            spent = 0.0
+            for i in range(args.warmup + 60):
+                st.set_uniforms(key, orbit[pose_of[i % 240]], (w, h))
+                t_a = time.perf_counter()
+                viewer.render_frame([key])
+                if i >= args.warmup:
+                    spent += time.perf_counter() - t_a
+            viewer.poll()
+            return round(1e6 * spent / 60.0, 1)
+
+        set_opts()
+        viewer.launch_stats(reset=True)
+        el_g, _, _ = timed_loop(0)
+        graph_stats = viewer.launch_stats(reset=True)
+        host_g = host_us_per_call()
+        viewer_mod.set_launch_graphs(False)
+        el_d, _, _ = timed_loop(0)
+        host_d = host_us_per_call()
+        sync_d = host_sync_loop("frame")
+        sync_ref_d = host_sync_loop("reference")
+        set_opts(speculative=0)
+        el_ud, _, _ = timed_loop(0)
+        viewer_mod.set_launch_graphs(True)
+        el_ug, _, _ = timed_loop(0)
+        set_opts()
+        extra["launch_graphs"] = dict(
+            one_frame_in_flight=dict(graphs=round(args.steps / el_g, 1), direct=round(args.steps / el_d, 1)),
+            synchronised=dict(graphs=round(args.steps / extra["sync_frame"], 1), direct=round(args.steps / sync_d, 1)),
+            reference_protocol=dict(graphs=round(args.steps / extra["sync_reference"], 1), direct=round(args.steps / sync_ref_d, 1)),
+            unspeculated=dict(graphs=round(args.steps / el_ug, 1), direct=round(args.steps / el_ud, 1)),
+            host_us_inside_gsx_render_frame=dict(graphs=host_g, direct=host_d),
+            stats_of_the_graph_loop={k: v for k, v in graph_stats.items()},
+            note="fps, one frame in flight, same process and scene; 'graphs' (default): while its stream is busy gsx_render_frame records its "
+                 "launches and submits them as cached HIP graphs whose nodes are patched to the frame's arguments — that saves HOST time "
+                 "(host_us_inside_gsx_render_frame); the device runs the same kernels at the same pace, and an entry point that finds its "
+                 "stream idle (the synchronised loops) submits launch by launch so that the first kernel starts at once; 'direct': "
+                 "gsx_debug_set_launch_graphs(0).  Same kernels, same arguments, same order: frames are bit-identical (tests/test_gpu_graph.py)")
         # the headline schedule over a whole orbit (>= 240 frames): the tuner's probes and every part of the path are in it
         steady_frames = max(240, args.steps)
         set_opts(frames_in_flight=lanes)
@@ -709,6 +758,10 @@ def main():
         if one_device:
             out["one_device_emulation"] = (f"GSX_BENCH_ONE_DEVICE=1: the {world} ranks are processes sharing ONE GPU, RCCL over sockets on lo — the N > 1 "
                                            "code ran for real, `value` measures nothing")
+        if launches:
+            out["launches_per_frame"] = {k: v for k, v in launches.items() if k != "per_frame"}
+        if extra and "launch_graphs" in extra:
+            out["launch_graphs"] = extra["launch_graphs"]
         if robustness is not None:
             out["robustness"] = robustness
         if world == 1 and not args.no_cpu_baseline:

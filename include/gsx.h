@@ -550,6 +550,28 @@ gsx_status gsx_ply_write(const gsx_gaussian* gaussians, uint64_t n, const uint32
  *      the same order; tests/test_gpu_sort_stress.py and test_gpu_parity.py assert it at full size. ---- */
 void gsx_debug_set_radix_rank_mode(int32_t mode);
 
+/* ---- how a frame's kernel launches reach the device.  gsx_preprocess / gsx_sort / gsx_render / gsx_render_frame record their
+ *      launches and submit them as cached HIP graphs whose nodes are patched to the frame's arguments (a dependent kernel boundary
+ *      costs 1.75 us inside a graph, 3.3 us on a stream; csrc/gsx_launch.h).  The reference records a wgpu CommandEncoder per frame
+ *      and submits it once (scene.rs:856-873): same shape.  What a graph saves is HOST time (cfg4: 112 -> 37 us per frame); the
+ *      device runs the same kernels at the same pace, and a graph only leaves when its last launch is recorded — so an entry point
+ *      that finds its stream idle (a host that waits for every frame) submits launch by launch: the first kernel starts at once.
+ *      enabled = 0: every launch is submitted at once; 1 (default, or GSX_GRAPH in the environment): as described; 2: record even
+ *      when the stream is idle (tests).  Process-wide.  Either way the same kernels run with the same arguments in the same order:
+ *      frames are bit-identical (tests/test_gpu_graph.py). ---- */
+void gsx_debug_set_launch_graphs(int32_t enabled);
+uint64_t gsx_debug_launch_count(void); /* kernel launches this process has asked for so far (recorded or submitted) */
+typedef struct gsx_launch_stats {
+    uint64_t graph_launches;  /* hipGraphLaunch calls */
+    uint64_t graph_nodes;     /* kernel launches that left inside a graph */
+    uint64_t nodes_patched;   /* graph nodes whose grid / arguments had changed since the graph last ran */
+    uint64_t direct_launches; /* kernel launches of recorded segments too short for a graph, submitted one by one */
+    uint64_t graphs_built;    /* graphs instantiated (a kernel sequence seen for the first time at its position) */
+    uint64_t broken;          /* != 0: a graph call failed on this viewer, it launches directly since (frames stay right) */
+    uint64_t idle_direct_scopes; /* entry points that found their stream idle and submitted launch by launch (the device was waiting) */
+} gsx_launch_stats;
+gsx_status gsx_viewer_launch_stats(gsx_viewer* v, gsx_launch_stats* out, uint32_t reset);
+
 /* ---- timing: HIP events recorded on the viewer's stream around each pass of the last frame ---- */
 typedef enum gsx_pass {
     GSX_PASS_PROJECT = 0,

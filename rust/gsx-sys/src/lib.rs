@@ -129,6 +129,11 @@ pub struct gsx_shard_stats {
     pub frames: u64, pub redo_frames: u64, pub repair_frames: u64, pub exchange_rounds: u64,
     pub wire_bytes: u64, pub verdict_wait_ns: u64, pub last_slot_records: u32, pub last_repair_slot_records: u32,
 }
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct gsx_launch_stats {
+    pub graph_launches: u64, pub graph_nodes: u64, pub nodes_patched: u64, pub direct_launches: u64, pub graphs_built: u64, pub broken: u64, pub idle_direct_scopes: u64,
+}
 pub type gsx_pass = u32; // 0 project, 1 depth sort, 2 bin, 3 tile sort, 4 composite, 5 project (geometry only)
 pub const GSX_PASS_COUNT: usize = 6;
 
@@ -225,6 +230,9 @@ extern "C" {
     pub fn gsx_ply_read_gaussians(data: *const c_void, size: u64, header: *const gsx_ply_header, start: u64, n: u64, out: *mut gsx_gaussian) -> gsx_status;
     pub fn gsx_ply_write(gaussians: *const gsx_gaussian, n: u64, mask_words: *const u32, edits: *const gsx_gaussian_edit, out: *mut c_void, capacity: u64, out_size: *mut u64) -> gsx_status;
     pub fn gsx_debug_set_radix_rank_mode(mode: i32);
+    pub fn gsx_debug_set_launch_graphs(enabled: i32);
+    pub fn gsx_debug_launch_count() -> u64;
+    pub fn gsx_viewer_launch_stats(v: *mut gsx_viewer, out: *mut gsx_launch_stats, reset: u32) -> gsx_status;
     pub fn gsx_set_pass_timing(v: *mut gsx_viewer, enabled: u32) -> gsx_status;
     pub fn gsx_get_pass_timing(v: *mut gsx_viewer, ms: *mut f32, launches: *mut u32) -> gsx_status;
 }

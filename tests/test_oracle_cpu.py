@@ -215,7 +215,7 @@ def test_rust_sys_covers_every_symbol():
     """rust/gsx-sys/src/lib.rs (uncompiled binding source) declares every function include/gsx.h exports, and is
     what tools/gen_rust_sys.py generates from the current header (not a stale copy)."""
     hdr = open(os.path.join(ROOT, "include", "gsx.h")).read()
-    declared = set(re.findall(r"^(?:gsx_status|void|uint32_t|const char\*)\s+(gsx_\w+)\s*\(", re.sub(r"/\*.*?\*/", "", hdr, flags=re.S), flags=re.M))
+    declared = set(re.findall(r"^(?:gsx_status|void|uint32_t|uint64_t|const char\*)\s+(gsx_\w+)\s*\(", re.sub(r"/\*.*?\*/", "", hdr, flags=re.S), flags=re.M))
     assert declared == set(_lib.EXPORTS)
     path = os.path.join(ROOT, "rust", "gsx-sys", "src", "lib.rs")
     rs = open(path).read()
@@ -427,3 +427,22 @@ def test_ply_large_range_converted_by_several_threads_equals_small_batches():
     mid = np.zeros(2 * 131072 + 5, g.dtype)
     _lib.check(L.gsx_ply_read_gaussians(data.ctypes.data, data.size, C.byref(h.raw), 1234, mid.shape[0], mid.ctypes.data))
     assert mid.tobytes() == parts[1234:1234 + mid.shape[0]].tobytes()
+
+
+def test_no_raw_stream_calls_in_the_library():
+    """csrc/gsx_launch.h: a frame-level entry point may be RECORDING its kernel launches (they leave as a HIP graph when the segment
+    closes), so every other stream operation, every host wait for the device and every free of device memory must close the
+    segment first — the gsx::op wrappers do.  A raw hipMemcpyAsync / hipEventRecord / hipStreamSynchronize / ... in the library
+    would be reordered against launches that are still in a trace; raw hipLaunchKernelGGL would bypass the trace."""
+    csrc = os.path.join(ROOT, "wgpu_3dgs_viewer_app_amd", "csrc")
+    raw = re.compile(r"(?<![A-Za-z0-9_:])hip(MemcpyAsync|Memcpy|MemsetAsync|Memset|MemsetD32Async|EventRecord|StreamWaitEvent|StreamSynchronize|"
+                     r"StreamQuery|EventSynchronize|Free|LaunchKernelGGL|DeviceSynchronize)\(")
+    bad = []
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".cpp", ".hip", ".h")) or name in ("gsx_launch.h", "gsx_graph.cpp"):
+            continue
+        for ln, line in enumerate(open(os.path.join(csrc, name)), 1):
+            code = line.split("//")[0]
+            if raw.search(code):
+                bad.append(f"{name}:{ln}: {line.strip()}")
+    assert not bad, "\n".join(bad)

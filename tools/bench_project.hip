@@ -3,6 +3,7 @@
 // measurement (within-process interleaved A/B, same arithmetic from csrc/project_math.h).
 //   hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 tools/bench_project.hip \
 //         -Iwgpu_3dgs_viewer_app_amd/csrc -Lwgpu_3dgs_viewer_app_amd -lgsx -Wl,-rpath,'$ORIGIN/../wgpu_3dgs_viewer_app_amd' -o tools/bench_project
+#define GSX_LAUNCH_STANDALONE 1  // csrc/gsx_launch.h: launches submit at once, nothing of libgsx is linked
 #include <algorithm>
 #include <cmath>
 #include <cstdio>

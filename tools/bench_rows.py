@@ -46,6 +46,9 @@ for name, (shk, covk) in {"single/single": (0, 0), "norm8/half": (2, 1)}.items()
               MaskShape(MaskShapeKind.Ellipsoid, pos=np.zeros(3, np.float32), scale=np.array([1.5, 1.5, 1.5], np.float32))]
     ev = MaskEvaluator(v)
     s = timed(lambda: (ev.evaluate(MaskOp.parse("0 - 1"), "m", shapes), v.poll()))
+    res["mask_evaluate_call_and_wait_us"] = round(1e6 * s, 1)   # one call + the host's wait for it (launch latency and Python included)
+    prog = MaskOp.parse("0 - 1")
+    s = timed(lambda: ([ev.evaluate(prog, "m", shapes) for _ in range(50)], v.poll())) / 50.0   # 50 calls enqueued back to back: the kernel
     res["mask_evaluate_us"] = round(1e6 * s, 1)
     res["mask_evaluate_GBps_of_positions"] = round(16.0 * n / s / 1e9, 1)
     ev.evaluate(None, "m")

@@ -3,6 +3,7 @@
 //   hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -DGSX_SORT_PROFILE tools/bench_sort.hip \
 //         -Iwgpu_3dgs_viewer_app_amd/csrc -Iinclude -o tools/bench_sort
 //   tools/bench_sort [n=5300000] [bits=13]
+#define GSX_LAUNCH_STANDALONE 1  // csrc/gsx_launch.h: launches submit at once, nothing of libgsx is linked
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>

@@ -9,7 +9,7 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = open(os.path.join(ROOT, "include", "gsx.h")).read()
 code = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-protos = re.findall(r"^(gsx_status|void|uint32_t|const char\*)\s+(gsx_\w+)\s*\(([^;]*?)\);", code, flags=re.M | re.S)
+protos = re.findall(r"^(gsx_status|void|uint32_t|uint64_t|const char\*)\s+(gsx_\w+)\s*\(([^;]*?)\);", code, flags=re.M | re.S)
 
 SCALAR = {"uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64", "int32_t": "i32", "float": "f32", "char": "c_char", "void": "c_void",
           "gsx_sh_kind": "gsx_sh_kind", "gsx_cov3d_kind": "gsx_cov3d_kind", "gsx_display_mode": "gsx_display_mode", "gsx_status": "gsx_status", "gsx_buffer_kind": "gsx_buffer_kind"}
@@ -43,7 +43,7 @@ def param(p: str):
 out = []
 for ret, name, args in protos:
     ps = [x for x in (param(a) for a in args.split(",")) if x]
-    r = {"gsx_status": " -> gsx_status", "void": "", "uint32_t": " -> u32", "const char*": " -> *const c_char"}[ret]
+    r = {"gsx_status": " -> gsx_status", "void": "", "uint32_t": " -> u32", "uint64_t": " -> u64", "const char*": " -> *const c_char"}[ret]
     out.append(f"    pub fn {name}({', '.join(ps)}){r};")
 
 HEAD = '''//! gsx-sys — raw FFI over `include/gsx.h` (libgsx.so, the MI355X-native 3DGS render path).
@@ -176,6 +176,11 @@ pub type gsx_comm_all_gather_fn = Option<unsafe extern "C" fn(ctx: *mut c_void, 
 pub struct gsx_shard_stats {
     pub frames: u64, pub redo_frames: u64, pub repair_frames: u64, pub exchange_rounds: u64,
     pub wire_bytes: u64, pub verdict_wait_ns: u64, pub last_slot_records: u32, pub last_repair_slot_records: u32,
+}
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct gsx_launch_stats {
+    pub graph_launches: u64, pub graph_nodes: u64, pub nodes_patched: u64, pub direct_launches: u64, pub graphs_built: u64, pub broken: u64, pub idle_direct_scopes: u64,
 }
 pub type gsx_pass = u32; // 0 project, 1 depth sort, 2 bin, 3 tile sort, 4 composite, 5 project (geometry only)
 pub const GSX_PASS_COUNT: usize = 6;

@@ -39,6 +39,7 @@ EXPORTS = (
     "gsx_update_selection_edit", "gsx_model_show_unedited", "gsx_postprocess", "gsx_model_upload_selection",
     "gsx_model_download_selection", "gsx_model_download_edits", "gsx_model_upload_edits", "gsx_query_download_hits",
     "gsx_query_hit_pos_by_closest", "gsx_query_hit_pos_by_alpha_range",
+    "gsx_debug_set_launch_graphs", "gsx_debug_launch_count", "gsx_viewer_launch_stats",
 )
 
 
@@ -52,6 +53,11 @@ class Query(C.Structure):
     """``gsx_query``."""
     _fields_ = [("kind", C.c_uint32), ("selection_op", C.c_uint32), ("p0", C.c_float * 2), ("p1", C.c_float * 2),
                 ("radius", C.c_float), ("reserved", C.c_uint32)]
+
+
+class LaunchStats(C.Structure):
+    """``gsx_launch_stats``."""
+    _fields_ = [(n, C.c_uint64) for n in ("graph_launches", "graph_nodes", "nodes_patched", "direct_launches", "graphs_built", "broken", "idle_direct_scopes")]
 
 
 class SpecParams(C.Structure):
@@ -215,6 +221,9 @@ def load() -> C.CDLL:
         "gsx_buffer_release": ([vp], None),
         "gsx_buffer_len": ([vp, C.POINTER(u64)], C.c_int32),
         "gsx_buffer_download": ([vp, vp, u64], C.c_int32),
+        "gsx_debug_set_launch_graphs": ([C.c_int32], None),
+        "gsx_debug_launch_count": ([], C.c_uint64),
+        "gsx_viewer_launch_stats": ([vp, C.POINTER(LaunchStats), u32], C.c_int32),
         "gsx_set_pass_timing": ([vp, u32], C.c_int32),
         "gsx_get_pass_timing": ([vp, f32p, u32p], C.c_int32),
     }

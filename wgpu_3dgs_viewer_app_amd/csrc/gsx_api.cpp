@@ -34,18 +34,18 @@ static gsx_status stream_runs_beside(hipStream_t candidate, const std::vector<hi
     gsx_status st = GSX_OK;
     auto run = [&]() -> gsx_status {
         for (auto& e : ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for (hipStream_t b : busy) HIPCHK(hipStreamSynchronize(b));
-        HIPCHK(hipStreamSynchronize(candidate));
+        for (hipStream_t b : busy) HIPCHK(gsx::op::StreamSynchronize(b));
+        HIPCHK(gsx::op::StreamSynchronize(candidate));
         for (size_t i = 0; i < busy.size(); ++i) {
             HIPCHK(launch_spin(busy[i], 400));
-            HIPCHK(hipEventRecord(ev[i], busy[i]));
+            HIPCHK(gsx::op::EventRecord(ev[i], busy[i]));
         }
         HIPCHK(launch_spin(candidate, 1));
-        HIPCHK(hipEventRecord(ev.back(), candidate));
-        HIPCHK(hipEventSynchronize(ev.back()));
+        HIPCHK(gsx::op::EventRecord(ev.back(), candidate));
+        HIPCHK(gsx::op::EventSynchronize(ev.back()));
         for (size_t i = 0; i < busy.size(); ++i)
             if (hipEventQuery(ev[i]) == hipSuccess) *out = false;  // that spinner finished first: the candidate waited behind it
-        for (hipStream_t b : busy) HIPCHK(hipStreamSynchronize(b));
+        for (hipStream_t b : busy) HIPCHK(gsx::op::StreamSynchronize(b));
         return GSX_OK;
     };
     st = run();
@@ -115,7 +115,7 @@ gsx_status prepare_edits_for_lanes(gsx_viewer* v, const char* const* keys, uint3
         if (!m || !edits_need_prepare(v, m)) continue;
         for (gsx_viewer* l : v->lanes)
             if (l->lane_busy) {
-                HIPCHK(hipStreamWaitEvent(v->stream, l->lane_event, 0));
+                HIPCHK(gsx::op::StreamWaitEvent(v->stream, l->lane_event, 0));
                 l->lane_busy = false;
             }
         gsx_status st = prepare_edits(v, m, nullptr);
@@ -150,7 +150,7 @@ static gsx_status lane_sync(gsx_viewer* v, gsx_viewer* l, const char* const* key
         Model* pm = find_model(v, keys[i]);
         Model* sm = find_model(l, keys[i]);
         if (sm && sm->shadow_of != pm->serial) {  // the key names another model now
-            HIPCHK(hipStreamSynchronize(l->stream));
+            HIPCHK(gsx::op::StreamSynchronize(l->stream));
             l->models.erase(keys[i]);
             sm = nullptr;
         }
@@ -165,7 +165,7 @@ static gsx_status lane_sync(gsx_viewer* v, gsx_viewer* l, const char* const* key
             HIPCHK(m->counters.ensure(sizeof(Counters)));
             HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&m->h_counters), sizeof(Counters), hipHostMallocDefault));
             memset(m->h_counters, 0, sizeof(Counters));
-            HIPCHK(hipMemsetAsync(m->counters.p, 0, sizeof(Counters), l->stream));
+            HIPCHK(gsx::op::MemsetAsync(m->counters.p, 0, sizeof(Counters), l->stream));
             sm = m.get();
             l->models[pm->key] = std::move(m);
         }
@@ -188,8 +188,8 @@ static gsx_status lane_sync(gsx_viewer* v, gsx_viewer* l, const char* const* key
     // whatever the caller enqueued on the viewer's stream since this lane's last frame (uploads, masks) comes first
     if (l->seen_epoch != v->epoch) {
         if (!v->lane_event) HIPCHK(hipEventCreateWithFlags(&v->lane_event, hipEventDisableTiming));
-        HIPCHK(hipEventRecord(v->lane_event, v->stream));
-        HIPCHK(hipStreamWaitEvent(l->stream, v->lane_event, 0));
+        HIPCHK(gsx::op::EventRecord(v->lane_event, v->stream));
+        HIPCHK(gsx::op::StreamWaitEvent(l->stream, v->lane_event, 0));
         l->seen_epoch = v->epoch;
     }
     return GSX_OK;
@@ -283,7 +283,7 @@ void gsx_viewer_destroy(gsx_viewer* v) {
     (void)gsx_viewer_comm_destroy(v);  // first: it drains the lanes' streams, then destroys the communicators (a lane has none of its own)
     for (gsx_viewer* l : v->lanes) gsx_viewer_destroy(l);  // (synchronises the lane's stream first)
     v->lanes.clear();
-    (void)hipStreamSynchronize(v->stream);
+    (void)gsx::op::StreamSynchronize(v->stream);
     if (v->lane_event) (void)hipEventDestroy(v->lane_event);
     for (hipStream_t ps : v->parked_streams) (void)hipStreamDestroy(ps);
     if (v->h_shard_verdict) (void)hipHostFree(v->h_shard_verdict);
@@ -296,6 +296,7 @@ void gsx_viewer_destroy(gsx_viewer* v) {
         (void)hipEventDestroy(p.second);
     }
     v->models.clear();
+    trace_destroy(v->trace);
     if (v->h_verdict) (void)hipHostFree(v->h_verdict);
     if (v->own_stream) (void)hipStreamDestroy(v->stream);
     if (!v->parent) g_viewers_on_device[v->device & 63].fetch_sub(1);
@@ -393,10 +394,10 @@ gsx_status gsx_model_create(gsx_viewer* v, const char* key, uint64_t count, gsx_
     }
     HIPCHK(m->counters.ensure(sizeof(Counters)));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&m->h_counters), sizeof(Counters), hipHostMallocDefault));
-    HIPCHK(hipMemsetAsync(m->counters.p, 0, sizeof(Counters), v->stream));
+    HIPCHK(gsx::op::MemsetAsync(m->counters.p, 0, sizeof(Counters), v->stream));
     // a fresh model is all-zero Gaussians (new_empty) and fully unmasked (MaskOpTree::Reset, scene.rs:2124-2131)
     for (DevBuf* b : {&m->pc, &m->cov_a, &m->cov_b, &m->cov_h, &m->cov_h2, &m->sh4, &m->sh1, &m->sh_h, &m->sh_q, &m->sh_aos})
-        if (b->p) HIPCHK(hipMemsetAsync(b->p, 0, b->bytes, v->stream));
+        if (b->p) HIPCHK(gsx::op::MemsetAsync(b->p, 0, b->bytes, v->stream));
     v->models[key] = std::move(m);
     return GSX_OK;
 }
@@ -406,7 +407,7 @@ gsx_status gsx_model_remove(gsx_viewer* v, const char* key) {
     if (st) return st;
     Model* m = find_model(v, key);
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_remove: no model '%s'", key ? key : "(null)");
-    HIPCHK(hipStreamSynchronize(v->stream));  // (ordered after the lanes' frames by viewer_bind)
+    HIPCHK(gsx::op::StreamSynchronize(v->stream));  // (ordered after the lanes' frames by viewer_bind)
     for (gsx_viewer* l : v->lanes) l->models.erase(key);
     v->models.erase(key);
     return GSX_OK;
@@ -434,9 +435,9 @@ gsx_status gsx_model_upload_range(gsx_viewer* v, const char* key, uint64_t start
     for (uint64_t off = 0; off < n; off += chunk) {
         uint64_t c = std::min(chunk, n - off);
         HIPCHK(v->staging.ensure(sizeof(gsx_gaussian) * c));
-        HIPCHK(hipMemcpyAsync(v->staging.p, src + off, sizeof(gsx_gaussian) * c, hipMemcpyHostToDevice, v->stream));
+        HIPCHK(gsx::op::MemcpyAsync(v->staging.p, src + off, sizeof(gsx_gaussian) * c, hipMemcpyHostToDevice, v->stream));
         HIPCHK(launch_convert(v->stream, v->staging.as<gsx_gaussian>(), c, start + off, m->n, m->pod()));
-        HIPCHK(hipStreamSynchronize(v->stream));  // the caller's memory may be reused after return
+        HIPCHK(gsx::op::StreamSynchronize(v->stream));  // the caller's memory may be reused after return
     }
     m->tuner.reset();
     return GSX_OK;
@@ -504,8 +505,8 @@ gsx_status gsx_model_upload_mask(gsx_viewer* v, const char* key, const uint32_t*
         return GSX_OK;
     }
     if (n_words != (m->n + 31) / 32) return fail(GSX_ERR_INVALID_ARG, "gsx_model_upload_mask: expected %llu words", (unsigned long long)((m->n + 31) / 32));
-    HIPCHK(hipMemcpyAsync(m->mask.p, words, 4 * n_words, hipMemcpyHostToDevice, v->stream));
-    HIPCHK(hipStreamSynchronize(v->stream));
+    HIPCHK(gsx::op::MemcpyAsync(m->mask.p, words, 4 * n_words, hipMemcpyHostToDevice, v->stream));
+    HIPCHK(gsx::op::StreamSynchronize(v->stream));
     m->has_mask = true;
     m->mask_program_hash = 0;
     m->tuner.reset();
@@ -522,8 +523,8 @@ gsx_status gsx_model_download_mask(gsx_viewer* v, const char* key, uint32_t* wor
         memset(words, 0xFF, 4 * n_words);
         return GSX_OK;
     }
-    HIPCHK(hipStreamSynchronize(v->stream));
-    HIPCHK(hipMemcpy(words, m->mask.p, 4 * n_words, hipMemcpyDeviceToHost));
+    HIPCHK(gsx::op::StreamSynchronize(v->stream));
+    HIPCHK(gsx::op::Memcpy(words, m->mask.p, 4 * n_words, hipMemcpyDeviceToHost));
     return GSX_OK;
 }
 
@@ -593,6 +594,7 @@ gsx_status gsx_preprocess(gsx_viewer* v, const char* key) {
     Model* m = find_model(v, key);
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_preprocess: no model '%s'", key ? key : "(null)");
     v->latest = nullptr;
+    TraceScope trace(v, TRACE_PREPROCESS);
     return do_preprocess(v, m);
 }
 
@@ -601,6 +603,7 @@ gsx_status gsx_sort(gsx_viewer* v, const char* key) {
     if (st) return st;
     Model* m = find_model(v, key);
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_sort: no model '%s'", key ? key : "(null)");
+    TraceScope trace(v, TRACE_SORT);
     return do_sort(v, m);
 }
 
@@ -609,11 +612,11 @@ gsx_status gsx_sync(gsx_viewer* v) {
     if (st) return st;
     for (gsx_viewer* l : v->lanes) {
         if ((st = finish_frame(l))) return st;
-        HIPCHK(hipStreamSynchronize(l->stream));
+        HIPCHK(gsx::op::StreamSynchronize(l->stream));
     }
     gsx_status fst = finish_frame(v);
     if (fst) return fst;
-    HIPCHK(hipStreamSynchronize(v->stream));
+    HIPCHK(gsx::op::StreamSynchronize(v->stream));
     return GSX_OK;
 }
 
@@ -621,6 +624,7 @@ gsx_status gsx_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
     v->latest = nullptr;
+    TraceScope trace(v, TRACE_RENDER);
     return do_render(v, keys, n_keys);
 }
 
@@ -636,15 +640,18 @@ gsx_status gsx_render_frame(gsx_viewer* v, const char* const* keys, uint32_t n_k
     } else if ((st = viewer_bind(v))) {
         return st;
     }
-    for (uint32_t i = 0; i < n_keys; ++i) {
-        Model* m = find_model(lane, keys ? keys[i] : nullptr);
-        if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_render_frame: no model '%s'", keys && keys[i] ? keys[i] : "(null)");
-        if ((st = do_preprocess(lane, m, true))) return st;  // the sort's admission scan sums N_vis: one launch less
-        if ((st = do_sort(lane, m))) return st;
+    {
+        TraceScope trace(lane, TRACE_RENDER_FRAME);  // the frame's launches leave as (cached, patched) HIP graphs when the scope ends
+        for (uint32_t i = 0; i < n_keys; ++i) {
+            Model* m = find_model(lane, keys ? keys[i] : nullptr);
+            if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_render_frame: no model '%s'", keys && keys[i] ? keys[i] : "(null)");
+            if ((st = do_preprocess(lane, m, true))) return st;  // the sort's admission scan sums N_vis: one launch less
+            if ((st = do_sort(lane, m))) return st;
+        }
+        if ((st = do_render(lane, keys, n_keys))) return st;
     }
-    if ((st = do_render(lane, keys, n_keys))) return st;
     if (lane != v) {
-        HIPCHK(hipEventRecord(lane->lane_event, lane->stream));
+        HIPCHK(gsx::op::EventRecord(lane->lane_event, lane->stream));
         lane->lane_busy = true;
     }
     v->latest = lane == v ? nullptr : lane;
@@ -659,8 +666,8 @@ gsx_status gsx_download_framebuffer(gsx_viewer* v, float* rgbt, uint64_t n_float
     if (!rgbt || n_floats != need) return fail(GSX_ERR_INVALID_ARG, "gsx_download_framebuffer: expected %llu floats", (unsigned long long)need);
     if ((st = ensure_fb(v))) return st;
     if ((st = finish_frame(v))) return st;
-    HIPCHK(hipStreamSynchronize(v->stream));
-    HIPCHK(hipMemcpy(rgbt, fb_ptr(v), sizeof(float) * need, hipMemcpyDeviceToHost));
+    HIPCHK(gsx::op::StreamSynchronize(v->stream));
+    HIPCHK(gsx::op::Memcpy(rgbt, fb_ptr(v), sizeof(float) * need, hipMemcpyDeviceToHost));
     return GSX_OK;
 }
 
@@ -674,8 +681,8 @@ gsx_status gsx_download_rgba8(gsx_viewer* v, const float bg[3], uint8_t* rgba, u
     if ((st = finish_frame(v))) return st;
     HIPCHK(v->scratch.ensure(4 * npx));
     HIPCHK(launch_resolve_rgba8(v->stream, fb_ptr(v), (uint32_t)npx, bg[0], bg[1], bg[2], v->scratch.as<uint32_t>()));
-    HIPCHK(hipStreamSynchronize(v->stream));
-    HIPCHK(hipMemcpy(rgba, v->scratch.p, 4 * npx, hipMemcpyDeviceToHost));
+    HIPCHK(gsx::op::StreamSynchronize(v->stream));
+    HIPCHK(gsx::op::Memcpy(rgba, v->scratch.p, 4 * npx, hipMemcpyDeviceToHost));
     return GSX_OK;
 }
 
@@ -721,16 +728,16 @@ gsx_status gsx_model_download_projection(gsx_viewer* v, const char* key, uint32_
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_model_download_projection: no model '%s'", key ? key : "(null)");
     if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_projection: model '%s' not preprocessed", key);
     if ((st = complete_records(v, m))) return st;
-    HIPCHK(hipStreamSynchronize(v->stream));
+    HIPCHK(gsx::op::StreamSynchronize(v->stream));
     const size_t n = m->rec_n;  // == model length unless records were imported (gsx_shard_import)
     std::vector<uint32_t> k(n);
     std::vector<float4> a(n), b(n), c(n);
     const Records rr = m->rec();
     if (n) {
-        HIPCHK(hipMemcpy(k.data(), rr.key, 4 * n, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(a.data(), rr.a, 16 * n, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(b.data(), rr.b, 16 * n, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(c.data(), rr.c, 16 * n, hipMemcpyDeviceToHost));
+        HIPCHK(gsx::op::Memcpy(k.data(), rr.key, 4 * n, hipMemcpyDeviceToHost));
+        HIPCHK(gsx::op::Memcpy(a.data(), rr.a, 16 * n, hipMemcpyDeviceToHost));
+        HIPCHK(gsx::op::Memcpy(b.data(), rr.b, 16 * n, hipMemcpyDeviceToHost));
+        HIPCHK(gsx::op::Memcpy(c.data(), rr.c, 16 * n, hipMemcpyDeviceToHost));
     }
     for (size_t i = 0; i < n; ++i) {
         const bool vis = k[i] != kCulledKey;
@@ -775,8 +782,8 @@ gsx_status gsx_model_download_sorted(gsx_viewer* v, const char* key, uint32_t* i
     if (out_n_visible) *out_n_visible = n_order;
     if (indices) {
         if (capacity < n_order) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_sorted: capacity %llu < %u sorted records", (unsigned long long)capacity, n_order);
-        HIPCHK(hipStreamSynchronize(v->stream));
-        if (n_order) HIPCHK(hipMemcpy(indices, m->sorted_idx, 4ull * n_order, hipMemcpyDeviceToHost));
+        HIPCHK(gsx::op::StreamSynchronize(v->stream));
+        if (n_order) HIPCHK(gsx::op::Memcpy(indices, m->sorted_idx, 4ull * n_order, hipMemcpyDeviceToHost));
     }
     return GSX_OK;
 }
@@ -795,9 +802,9 @@ gsx_status gsx_model_download_tile_lists(gsx_viewer* v, const char* key, uint32_
     if ((st = finish_frame(v))) return st;
     const uint32_t n_tiles = m->fc.tiles_x * m->fc.tiles_y;
     if (n_offsets != (uint64_t)n_tiles + 1) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_tile_lists: expected %u offsets", n_tiles + 1);
-    HIPCHK(hipStreamSynchronize(v->stream));
+    HIPCHK(gsx::op::StreamSynchronize(v->stream));
     std::vector<uint2> r(n_tiles);
-    HIPCHK(hipMemcpy(r.data(), m->ranges.p, sizeof(uint2) * n_tiles, hipMemcpyDeviceToHost));
+    HIPCHK(gsx::op::Memcpy(r.data(), m->ranges.p, sizeof(uint2) * n_tiles, hipMemcpyDeviceToHost));
     uint32_t off = 0;
     for (uint32_t t = 0; t < n_tiles; ++t) {
         if (r[t].y > r[t].x && r[t].x != off)
@@ -809,7 +816,7 @@ gsx_status gsx_model_download_tile_lists(gsx_viewer* v, const char* key, uint32_
     if (off != m->n_entries) return fail(GSX_ERR_HIP, "gsx_model_download_tile_lists: ranges cover %u entries, D = %u", off, m->n_entries);
     if (list) {
         if (capacity < m->n_entries) return fail(GSX_ERR_INVALID_ARG, "gsx_model_download_tile_lists: capacity too small");
-        if (m->n_entries) HIPCHK(hipMemcpy(list, m->tile_list, 4ull * m->n_entries, hipMemcpyDeviceToHost));
+        if (m->n_entries) HIPCHK(gsx::op::Memcpy(list, m->tile_list, 4ull * m->n_entries, hipMemcpyDeviceToHost));
     }
     return GSX_OK;
 }
@@ -829,11 +836,11 @@ gsx_status gsx_model_download_pod(gsx_viewer* v, const char* key, float* pos, ui
     if (sh) HIPCHK(dsh.ensure(180 * n));
     HIPCHK(launch_unpack_pod(v->stream, m->pod(), n, dpos.as<float>(), dcol.as<uint32_t>(), sh ? dsh.as<float>() : nullptr,
                              dcov.as<float>()));
-    HIPCHK(hipStreamSynchronize(v->stream));
-    HIPCHK(hipMemcpy(pos, dpos.p, 12 * n, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(color, dcol.p, 4 * n, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(cov3d, dcov.p, 24 * n, hipMemcpyDeviceToHost));
-    if (sh) HIPCHK(hipMemcpy(sh, dsh.p, 180 * n, hipMemcpyDeviceToHost));
+    HIPCHK(gsx::op::StreamSynchronize(v->stream));
+    HIPCHK(gsx::op::Memcpy(pos, dpos.p, 12 * n, hipMemcpyDeviceToHost));
+    HIPCHK(gsx::op::Memcpy(color, dcol.p, 4 * n, hipMemcpyDeviceToHost));
+    HIPCHK(gsx::op::Memcpy(cov3d, dcov.p, 24 * n, hipMemcpyDeviceToHost));
+    if (sh) HIPCHK(gsx::op::Memcpy(sh, dsh.p, 180 * n, hipMemcpyDeviceToHost));
     return GSX_OK;
 }
 
@@ -846,7 +853,7 @@ gsx_status gsx_set_pass_timing(gsx_viewer* v, uint32_t enabled) {
 gsx_status gsx_get_pass_timing(gsx_viewer* v, float ms[GSX_PASS_COUNT], uint32_t launches[GSX_PASS_COUNT]) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
-    HIPCHK(hipStreamSynchronize(v->stream));
+    HIPCHK(gsx::op::StreamSynchronize(v->stream));
     std::vector<gsx_viewer*> all{v};
     all.insert(all.end(), v->lanes.begin(), v->lanes.end());
     for (gsx_viewer* l : all) {

@@ -42,16 +42,16 @@ gsx_status gsx_model_buffer_retain(gsx_viewer* v, const char* key, gsx_buffer_ki
     if (b->present && bits->bytes < 4 * words) b->present = false;
     if (b->present) {
         HIPCHK(b->words.ensure(4 * words));
-        HIPCHK(hipMemcpyAsync(b->words.p, bits->p, 4 * words, hipMemcpyDeviceToDevice, v->stream));
+        HIPCHK(gsx::op::MemcpyAsync(b->words.p, bits->p, 4 * words, hipMemcpyDeviceToDevice, v->stream));
         if (kind == GSX_BUFFER_EDITS) {
             HIPCHK(b->a.ensure(16 * n));
             HIPCHK(b->b.ensure(16 * n));
-            HIPCHK(hipMemcpyAsync(b->a.p, m->edit_a.p, 16 * n, hipMemcpyDeviceToDevice, v->stream));
-            HIPCHK(hipMemcpyAsync(b->b.p, m->edit_b.p, 16 * n, hipMemcpyDeviceToDevice, v->stream));
+            HIPCHK(gsx::op::MemcpyAsync(b->a.p, m->edit_a.p, 16 * n, hipMemcpyDeviceToDevice, v->stream));
+            HIPCHK(gsx::op::MemcpyAsync(b->b.p, m->edit_b.p, 16 * n, hipMemcpyDeviceToDevice, v->stream));
         }
     }
     HIPCHK(hipEventCreateWithFlags(&b->ready, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(b->ready, v->stream));
+    HIPCHK(gsx::op::EventRecord(b->ready, v->stream));
     *out = b.release();
     return GSX_OK;
 }
@@ -66,7 +66,7 @@ void gsx_buffer_release(gsx_buffer* b) {
     if (!b || b->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
     (void)hipSetDevice(b->device);
     if (b->ready) {
-        (void)hipEventSynchronize(b->ready);  // the snapshot copies read and write memory this handle is about to free
+        (void)gsx::op::EventSynchronize(b->ready);  // the snapshot copies read and write memory this handle is about to free
         (void)hipEventDestroy(b->ready);
     }
     delete b;
@@ -98,18 +98,18 @@ gsx_status gsx_buffer_download(gsx_buffer* b, void* out, uint64_t n_elements) {
     HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     gsx_status st = GSX_OK;
     auto run = [&]() -> gsx_status {
-        HIPCHK(hipStreamWaitEvent(s, b->ready, 0));
+        HIPCHK(gsx::op::StreamWaitEvent(s, b->ready, 0));
         if (b->kind != GSX_BUFFER_EDITS) {
-            HIPCHK(hipMemcpyAsync(out, b->words.p, 4 * words, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(gsx::op::MemcpyAsync(out, b->words.p, 4 * words, hipMemcpyDeviceToHost, s));
+            HIPCHK(gsx::op::StreamSynchronize(s));
             return GSX_OK;
         }
         std::vector<uint32_t> bits(std::max<uint64_t>(words, 1));
         std::vector<float4> pa(std::max<uint64_t>(b->n, 1)), pb(std::max<uint64_t>(b->n, 1));
-        HIPCHK(hipMemcpyAsync(bits.data(), b->words.p, 4 * words, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(pa.data(), b->a.p, 16 * b->n, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(pb.data(), b->b.p, 16 * b->n, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(gsx::op::MemcpyAsync(bits.data(), b->words.p, 4 * words, hipMemcpyDeviceToHost, s));
+        HIPCHK(gsx::op::MemcpyAsync(pa.data(), b->a.p, 16 * b->n, hipMemcpyDeviceToHost, s));
+        HIPCHK(gsx::op::MemcpyAsync(pb.data(), b->b.p, 16 * b->n, hipMemcpyDeviceToHost, s));
+        HIPCHK(gsx::op::StreamSynchronize(s));
         gsx_gaussian_edit def;
         gsx_gaussian_edit_default(&def);
         gsx_gaussian_edit* o = static_cast<gsx_gaussian_edit*>(out);

@@ -25,8 +25,8 @@ gsx_status gsx_update_query_texture(gsx_viewer* v, const uint8_t* texels, uint32
     if (!texels || width != v->width || height != v->height)
         return fail(GSX_ERR_INVALID_ARG, "gsx_update_query_texture: need %ux%u texels (the viewport)", v->width, v->height);
     HIPCHK(v->query_texture.ensure((size_t)width * height));
-    HIPCHK(hipMemcpyAsync(v->query_texture.p, texels, (size_t)width * height, hipMemcpyHostToDevice, v->stream));
-    HIPCHK(hipStreamSynchronize(v->stream));
+    HIPCHK(gsx::op::MemcpyAsync(v->query_texture.p, texels, (size_t)width * height, hipMemcpyHostToDevice, v->stream));
+    HIPCHK(gsx::op::StreamSynchronize(v->stream));
     v->query_tex_w = width;
     v->query_tex_h = height;
     return GSX_OK;
@@ -75,13 +75,13 @@ gsx_status gsx_model_upload_selection(gsx_viewer* v, const char* key, const uint
     m->edit_epoch += 1;
     if (!words) {  // clear
         m->has_selection = false;
-        if (m->selection.p) HIPCHK(hipMemsetAsync(m->selection.p, 0, m->selection.bytes, v->stream));
+        if (m->selection.p) HIPCHK(gsx::op::MemsetAsync(m->selection.p, 0, m->selection.bytes, v->stream));
         return GSX_OK;
     }
     if (n_words != (m->n + 31) / 32) return fail(GSX_ERR_INVALID_ARG, "gsx_model_upload_selection: expected %llu words", (unsigned long long)((m->n + 31) / 32));
     if ((st = ensure_selection(v, m))) return st;
-    HIPCHK(hipMemcpyAsync(m->selection.p, words, 4 * n_words, hipMemcpyHostToDevice, v->stream));
-    HIPCHK(hipStreamSynchronize(v->stream));
+    HIPCHK(gsx::op::MemcpyAsync(m->selection.p, words, 4 * n_words, hipMemcpyHostToDevice, v->stream));
+    HIPCHK(gsx::op::StreamSynchronize(v->stream));
     m->has_selection = true;
     return GSX_OK;
 }
@@ -96,8 +96,8 @@ gsx_status gsx_model_download_selection(gsx_viewer* v, const char* key, uint32_t
         memset(words, 0, 4 * n_words);
         return GSX_OK;
     }
-    HIPCHK(hipStreamSynchronize(v->stream));
-    HIPCHK(hipMemcpy(words, m->selection.p, 4 * n_words, hipMemcpyDeviceToHost));
+    HIPCHK(gsx::op::StreamSynchronize(v->stream));
+    HIPCHK(gsx::op::Memcpy(words, m->selection.p, 4 * n_words, hipMemcpyDeviceToHost));
     return GSX_OK;
 }
 
@@ -114,10 +114,10 @@ gsx_status gsx_model_download_edits(gsx_viewer* v, const char* key, gsx_gaussian
     const size_t words = ((size_t)n + 31) / 32;
     std::vector<uint32_t> bits(words);
     std::vector<float4> a(n), b(n);
-    HIPCHK(hipStreamSynchronize(v->stream));
-    HIPCHK(hipMemcpy(bits.data(), m->edited.p, 4 * words, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(a.data(), m->edit_a.p, 16 * n, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(b.data(), m->edit_b.p, 16 * n, hipMemcpyDeviceToHost));
+    HIPCHK(gsx::op::StreamSynchronize(v->stream));
+    HIPCHK(gsx::op::Memcpy(bits.data(), m->edited.p, 4 * words, hipMemcpyDeviceToHost));
+    HIPCHK(gsx::op::Memcpy(a.data(), m->edit_a.p, 16 * n, hipMemcpyDeviceToHost));
+    HIPCHK(gsx::op::Memcpy(b.data(), m->edit_b.p, 16 * n, hipMemcpyDeviceToHost));
     for (uint64_t i = 0; i < n; ++i) {
         if (!((bits[i >> 5] >> (i & 31)) & 1u)) continue;
         memcpy(&out[i].flag, &a[i].x, 4);
@@ -135,7 +135,7 @@ gsx_status gsx_model_upload_edits(gsx_viewer* v, const char* key, const gsx_gaus
     m->edit_epoch += 1;
     if (!edits) {  // drop every stored edit
         m->has_edits = false;
-        if (m->edited.p) HIPCHK(hipMemsetAsync(m->edited.p, 0, m->edited.bytes, v->stream));
+        if (m->edited.p) HIPCHK(gsx::op::MemsetAsync(m->edited.p, 0, m->edited.bytes, v->stream));
         return GSX_OK;
     }
     if (n != m->n) return fail(GSX_ERR_INVALID_ARG, "gsx_model_upload_edits: expected %llu records", (unsigned long long)m->n);
@@ -149,10 +149,10 @@ gsx_status gsx_model_upload_edits(gsx_viewer* v, const char* key, const gsx_gaus
         b[i] = make_float4(edits[i].contrast, edits[i].exposure, edits[i].gamma, edits[i].alpha);
         if (edits[i].flag & GSX_EDIT_ENABLED) bits[i >> 5] |= 1u << (i & 31);
     }
-    HIPCHK(hipMemcpyAsync(m->edited.p, bits.data(), 4 * words, hipMemcpyHostToDevice, v->stream));
-    HIPCHK(hipMemcpyAsync(m->edit_a.p, a.data(), 16 * n, hipMemcpyHostToDevice, v->stream));
-    HIPCHK(hipMemcpyAsync(m->edit_b.p, b.data(), 16 * n, hipMemcpyHostToDevice, v->stream));
-    HIPCHK(hipStreamSynchronize(v->stream));
+    HIPCHK(gsx::op::MemcpyAsync(m->edited.p, bits.data(), 4 * words, hipMemcpyHostToDevice, v->stream));
+    HIPCHK(gsx::op::MemcpyAsync(m->edit_a.p, a.data(), 16 * n, hipMemcpyHostToDevice, v->stream));
+    HIPCHK(gsx::op::MemcpyAsync(m->edit_b.p, b.data(), 16 * n, hipMemcpyHostToDevice, v->stream));
+    HIPCHK(gsx::op::StreamSynchronize(v->stream));
     m->has_edits = true;
     return GSX_OK;
 }
@@ -165,11 +165,11 @@ gsx_status gsx_query_download_hits(gsx_viewer* v, const char* key, gsx_query_hit
     *out_n = 0;
     if (m->flags_kind != GSX_QUERY_HIT) return GSX_OK;
     uint32_t cnt = 0;
-    HIPCHK(hipStreamSynchronize(v->stream));
-    HIPCHK(hipMemcpy(&cnt, m->hit_count.p, 4, hipMemcpyDeviceToHost));
+    HIPCHK(gsx::op::StreamSynchronize(v->stream));
+    HIPCHK(gsx::op::Memcpy(&cnt, m->hit_count.p, 4, hipMemcpyDeviceToHost));
     cnt = std::min<uint32_t>(cnt, GSX_QUERY_MAX_HITS);
     std::vector<gsx_query_hit> h(cnt);
-    if (cnt) HIPCHK(hipMemcpy(h.data(), m->hits.p, sizeof(gsx_query_hit) * cnt, hipMemcpyDeviceToHost));
+    if (cnt) HIPCHK(gsx::op::Memcpy(h.data(), m->hits.p, sizeof(gsx_query_hit) * cnt, hipMemcpyDeviceToHost));
     std::sort(h.begin(), h.end(), [](const gsx_query_hit& x, const gsx_query_hit& y) {
         return x.depth != y.depth ? x.depth < y.depth : x.index < y.index;
     });

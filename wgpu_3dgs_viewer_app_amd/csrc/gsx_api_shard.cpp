@@ -70,7 +70,7 @@ gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, const 
     Counters* dc = m->counters.as<Counters>();
     if (d_tile_window) {  // own copy: the caller's map need not outlive this call
         HIPCHK(m->pack_window.ensure(window_bytes(v)));
-        HIPCHK(hipMemcpyAsync(m->pack_window.p, d_tile_window, window_bytes(v), hipMemcpyDeviceToDevice, v->stream));
+        HIPCHK(gsx::op::MemcpyAsync(m->pack_window.p, d_tile_window, window_bytes(v), hipMemcpyDeviceToDevice, v->stream));
         window = m->pack_window.as<uint2>();
         if (m->lazy) {  // explicit windows on a lazily projected shard (the repair exchange): travellers may be unshaded
             HIPCHK(m->trav_ballots.ensure(8 * ((std::max<size_t>(n, 1) + 63) / 64)));
@@ -88,7 +88,7 @@ gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, const 
     uint32_t* table = m->pack_table.as<uint32_t>();
     uint32_t* totals = table + (size_t)64 * std::max(nb, 1u);
     unsigned long long* masks = m->pack_masks.as<unsigned long long>();
-    HIPCHK(hipMemsetAsync(totals, 0, 4 * 64, v->stream));
+    HIPCHK(gsx::op::MemsetAsync(totals, 0, 4 * 64, v->stream));
     HIPCHK(launch_pack_count(v->stream, m->proj_rec(), n, world, rpr, window, tiles_x, masks, table, list, d_list_n, travellers, trav_counts));
     if (nb) HIPCHK(launch_rowscan(v->stream, table, world, nb, totals, d_list_n, tile));
     if (travellers && nb) {
@@ -100,8 +100,8 @@ gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, const 
         m->cand_valid = false;  // adm_pairs now holds the repair travellers
     }
     uint32_t h_tot[64];
-    HIPCHK(hipMemcpyAsync(h_tot, totals, 4 * 64, hipMemcpyDeviceToHost, v->stream));
-    HIPCHK(hipStreamSynchronize(v->stream));
+    HIPCHK(gsx::op::MemcpyAsync(h_tot, totals, 4 * 64, hipMemcpyDeviceToHost, v->stream));
+    HIPCHK(gsx::op::StreamSynchronize(v->stream));
     uint64_t sum = 0;
     for (uint32_t g = 0; g < world; ++g) {
         counts[g] = h_tot[g];
@@ -132,7 +132,7 @@ gsx_status gsx_shard_set_windows(gsx_viewer* v, const char* key, const uint32_t*
     if (!d_tile_window) return GSX_OK;
     const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
     HIPCHK(m->shard_win.ensure(window_bytes(v)));
-    HIPCHK(hipMemcpyAsync(m->shard_win.p, d_tile_window, window_bytes(v), hipMemcpyDeviceToDevice, v->stream));
+    HIPCHK(gsx::op::MemcpyAsync(m->shard_win.p, d_tile_window, window_bytes(v), hipMemcpyDeviceToDevice, v->stream));
     HIPCHK(m->shard_pyr.ensure(4 * window_pyramid_words(tiles_x, tiles_y)));
     HIPCHK(launch_window_pyramid(v->stream, m->shard_win.as<uint2>(), tiles_x, tiles_y, m->shard_pyr.as<uint32_t>()));
     m->shard_tiles_x = tiles_x;
@@ -153,7 +153,7 @@ gsx_status gsx_shard_import(gsx_viewer* v, const char* key, const void* d_recv, 
     if ((st = ensure_import_capacity(m, n_records))) return st;
     HIPCHK(launch_import_records(v->stream, d_recv, (uint32_t)n_records, m->imp_rec()));
     // every imported record is visible by construction
-    HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&m->counters.as<Counters>()->n_visible), (int)(uint32_t)n_records, 2,
+    HIPCHK(gsx::op::MemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&m->counters.as<Counters>()->n_visible), (int)(uint32_t)n_records, 2,
                              v->stream));  // n_visible and n_sorted
     m->stats_pending = true;
     m->rec_n = n_records;
@@ -166,7 +166,7 @@ gsx_status gsx_shard_import(gsx_viewer* v, const char* key, const void* d_recv, 
     m->import_min_ends = nullptr;
     if (d_tile_window) {
         HIPCHK(m->window.ensure(window_bytes(v)));
-        HIPCHK(hipMemcpyAsync(m->window.p, d_tile_window, window_bytes(v), hipMemcpyDeviceToDevice, v->stream));
+        HIPCHK(gsx::op::MemcpyAsync(m->window.p, d_tile_window, window_bytes(v), hipMemcpyDeviceToDevice, v->stream));
     }
     m->sorted = m->counters_valid = m->binned = false;
     return GSX_OK;
@@ -210,7 +210,7 @@ gsx_status gsx_shard_feedback(gsx_viewer* v, const char* key, uint32_t world, ui
     const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
     const uint32_t row_words = (tiles_x + 31) / 32, rpr = rows_per_rank(v, world), n_words = rpr * tiles_x;
     const uint32_t* tile_sat = v->done_bits.as<uint32_t>() + 1 + (size_t)row_words * tiles_y;
-    hipLaunchKernelGGL(k_shard_feedback, dim3((n_words + kShardExtraWords + 255) / 256), dim3(256), 0, v->stream, tile_sat, tiles_x, tiles_y,
+    GSX_LAUNCH(k_shard_feedback, dim3((n_words + kShardExtraWords + 255) / 256), dim3(256), 0, v->stream, tile_sat, tiles_x, tiles_y,
                        rank * rpr, n_words, static_cast<uint32_t*>(d_out_u32), m->counters.as<Counters>(),
                        m->shard_behind ? m->spec_done_before.as<uint32_t>() : nullptr, row_words);
     HIPCHK(hipGetLastError());
@@ -352,7 +352,7 @@ gsx_status gsx_shard_frame_begin(gsx_viewer* v, const char* key, uint32_t world,
     const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE, n_tiles = tiles_x * tiles_y;
     if (d_limit_override) {  // tests / a caller with its own policy: these limits instead of the ones the last frame left
         HIPCHK(m->shard_limit.ensure(4 * (size_t)n_tiles));
-        HIPCHK(hipMemcpyAsync(m->shard_limit.p, d_limit_override, 4 * (size_t)n_tiles, hipMemcpyDeviceToDevice, v->stream));
+        HIPCHK(gsx::op::MemcpyAsync(m->shard_limit.p, d_limit_override, 4 * (size_t)n_tiles, hipMemcpyDeviceToDevice, v->stream));
         m->shard_limit_valid = true;
         m->shard_limit_tx = tiles_x;
         m->shard_limit_ty = tiles_y;
@@ -477,7 +477,7 @@ gsx_status gsx_shard_import_slots(gsx_viewer* v, const char* key, const void* d_
             const size_t bm = 4 * (size_t)((tiles_x + 31) / 32) * tiles_y;
             if (v->done_bits.bytes < 4 + bm) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import_slots: GSX_SHARD_BEHIND without a nearer model in this frame");
             HIPCHK(m->spec_done_before.ensure(bm));
-            HIPCHK(hipMemcpyAsync(m->spec_done_before.p, v->done_bits.as<uint32_t>() + 1, bm, hipMemcpyDeviceToDevice, v->stream));
+            HIPCHK(gsx::op::MemcpyAsync(m->spec_done_before.p, v->done_bits.as<uint32_t>() + 1, bm, hipMemcpyDeviceToDevice, v->stream));
         }
     }
     const char* keys[1] = {m->key.c_str()};
@@ -512,6 +512,7 @@ gsx_status gsx_shard_wait_verdict(gsx_viewer* v, const char* key, uint32_t seq, 
     // a verdict that does not come within a minute is a collective that cannot complete (a rank died, or the ranks disagree
     // about what to exchange): an error the caller can report, not a process that spins for ever
     const auto t_start = std::chrono::steady_clock::now();
+    trace_flush();  // the kernel that posts the words may still be in a recorded segment
     for (uint64_t spin = 1;; ++spin) {
         const unsigned long long w = __atomic_load_n(&v->h_shard_verdict[0], __ATOMIC_ACQUIRE);
         if ((uint32_t)(w >> 32) == seq) {
@@ -523,7 +524,7 @@ gsx_status gsx_shard_wait_verdict(gsx_viewer* v, const char* key, uint32_t seq, 
             return GSX_OK;
         }
         if ((spin & 0xFFFu) == 0) {
-            const hipError_t e = hipStreamQuery(v->stream);
+            const hipError_t e = gsx::op::StreamQuery(v->stream);
             if (e == hipSuccess) {
                 const unsigned long long w2 = __atomic_load_n(&v->h_shard_verdict[0], __ATOMIC_ACQUIRE);
                 if ((uint32_t)(w2 >> 32) == seq) continue;
@@ -579,11 +580,11 @@ gsx_status gsx_shard_set_limits(gsx_viewer* v, const char* key, const uint32_t* 
     hipPointerAttribute_t attr{};
     const bool on_device = hipPointerGetAttributes(&attr, limits) == hipSuccess && attr.type == hipMemoryTypeDevice;
     if (on_device) {
-        HIPCHK(hipMemcpyAsync(m->shard_limit_override.p, limits, bytes, hipMemcpyDeviceToDevice, v->stream));
+        HIPCHK(gsx::op::MemcpyAsync(m->shard_limit_override.p, limits, bytes, hipMemcpyDeviceToDevice, v->stream));
     } else {
         (void)hipGetLastError();
-        HIPCHK(hipStreamSynchronize(v->stream));
-        HIPCHK(hipMemcpy(m->shard_limit_override.p, limits, bytes, hipMemcpyHostToDevice));
+        HIPCHK(gsx::op::StreamSynchronize(v->stream));
+        HIPCHK(gsx::op::Memcpy(m->shard_limit_override.p, limits, bytes, hipMemcpyHostToDevice));
     }
     m->shard_override_tiles = tiles_x * tiles_y;
     return GSX_OK;
@@ -621,8 +622,8 @@ gsx_status gsx_shard_download_limits(gsx_viewer* v, const char* key, uint32_t* l
     if (!m || !limits) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_download_limits: no model '%s'", key ? key : "(null)");
     const uint64_t n_tiles = (uint64_t)m->shard_limit_tx * m->shard_limit_ty;
     if (!m->shard_limit_valid || n_words < n_tiles) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_download_limits: no limits yet, or buffer too small");
-    HIPCHK(hipMemcpyAsync(limits, m->shard_limit.p, 4 * n_tiles, hipMemcpyDeviceToHost, v->stream));
-    HIPCHK(hipStreamSynchronize(v->stream));
+    HIPCHK(gsx::op::MemcpyAsync(limits, m->shard_limit.p, 4 * n_tiles, hipMemcpyDeviceToHost, v->stream));
+    HIPCHK(gsx::op::StreamSynchronize(v->stream));
     return GSX_OK;
 }
 

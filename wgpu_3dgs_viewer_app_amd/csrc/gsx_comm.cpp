@@ -187,8 +187,8 @@ gsx_status gsx_viewer_comm_destroy(gsx_viewer* v) {
     if (!has_comm(v)) return GSX_OK;
     (void)hipSetDevice(v->device);
     v->shard_pending.clear();  // frames in flight die with the communicator
-    for (gsx_viewer* l : v->lanes) (void)hipStreamSynchronize(l->stream);
-    (void)hipStreamSynchronize(v->stream);
+    for (gsx_viewer* l : v->lanes) (void)gsx::op::StreamSynchronize(l->stream);
+    (void)gsx::op::StreamSynchronize(v->stream);
     v->comm_world = 0;
     if (v->comm_a2a_fn) {
         if (v->comm_group) group_leave(v);
@@ -226,7 +226,7 @@ gsx_status gsx_comm_all_to_all(gsx_viewer* v, const void* d_send, void* d_recv, 
     const bool bypass = !o->comm_self_via_rccl;
     if (bypass) {
         const size_t self_off = (size_t)o->comm_rank * bytes_per_peer;
-        HIPCHK(hipMemcpyAsync(static_cast<char*>(d_recv) + self_off, static_cast<const char*>(d_send) + self_off, bytes_per_peer,
+        HIPCHK(gsx::op::MemcpyAsync(static_cast<char*>(d_recv) + self_off, static_cast<const char*>(d_send) + self_off, bytes_per_peer,
                               hipMemcpyDeviceToDevice, v->stream));
         if (o->comm_world == 1) return GSX_OK;
     }
@@ -257,7 +257,7 @@ gsx_status gsx_comm_all_gather(gsx_viewer* v, const void* d_send, void* d_recv, 
         return GSX_OK;
     }
     if (o->comm_world == 1 && !o->comm_self_via_rccl) {  // one rank: its own piece is all there is, and it does not travel
-        if (d_send != d_recv) HIPCHK(hipMemcpyAsync(d_recv, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, v->stream));
+        if (d_send != d_recv) HIPCHK(gsx::op::MemcpyAsync(d_recv, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, v->stream));
         return GSX_OK;
     }
     ncclComm_t comm = comm_of(v);
@@ -290,7 +290,7 @@ gsx_status gsx::comm_gather_to_root(gsx_viewer* v, const void* d_send, void* d_r
         return GSX_OK;
     }
     char* own = static_cast<char*>(d_recv) + (size_t)root * bytes_per_rank;
-    if (own != d_send) HIPCHK(hipMemcpyAsync(own, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, v->stream));
+    if (own != d_send) HIPCHK(gsx::op::MemcpyAsync(own, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, v->stream));
     RCCLCHK(g_rccl.GroupStart());
     RcclGroup grp;
     for (uint32_t p = 0; p < o->comm_world; ++p)
@@ -313,11 +313,11 @@ gsx_status gsx::comm_ensure_lanes(gsx_viewer* v, uint32_t lanes) {
         HIPCHK(v->scratch.ensure(128));
         if (v->comm_rank == 0) {
             RCCLCHK(g_rccl.GetUniqueId(&uid));
-            HIPCHK(hipMemcpyAsync(v->scratch.p, uid.internal, 128, hipMemcpyHostToDevice, v->stream));
+            HIPCHK(gsx::op::MemcpyAsync(v->scratch.p, uid.internal, 128, hipMemcpyHostToDevice, v->stream));
         }
         RCCLCHK(g_rccl.Broadcast(v->scratch.p, v->scratch.p, 128, kNcclChar, 0, static_cast<ncclComm_t>(v->comm), v->stream));
-        HIPCHK(hipMemcpyAsync(uid.internal, v->scratch.p, 128, hipMemcpyDeviceToHost, v->stream));
-        HIPCHK(hipStreamSynchronize(v->stream));
+        HIPCHK(gsx::op::MemcpyAsync(uid.internal, v->scratch.p, 128, hipMemcpyDeviceToHost, v->stream));
+        HIPCHK(gsx::op::StreamSynchronize(v->stream));
         ncclComm_t c = nullptr;
         RCCLCHK(g_rccl.CommInitRank(&c, (int)v->comm_world, uid, (int)v->comm_rank));
         v->lane_comms.push_back(c);

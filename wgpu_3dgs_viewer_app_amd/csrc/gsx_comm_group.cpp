@@ -105,7 +105,7 @@ gsx_status collective(Seat* me, int op, const void* d_send, void* d_recv, uint64
     }
     me->ready = ev->second.first;
     me->done = ev->second.second;
-    HIPCHK(hipEventRecord(me->ready, stream));
+    HIPCHK(gsx::op::EventRecord(me->ready, stream));
     me->send = static_cast<const char*>(d_send);
     me->recv = static_cast<char*>(d_recv);
     me->bytes = bytes;
@@ -131,13 +131,13 @@ gsx_status collective(Seat* me, int op, const void* d_send, void* d_recv, uint64
         const char* from = kind == OP_ALL_TO_ALL ? src.send + (size_t)me->rank * bytes : src.send;
         char* to = me->recv + (size_t)p * bytes;
         if (from == to) continue;  // an in-place all-gather's own piece
-        if (p != me->rank) HIPCHK(hipStreamWaitEvent(stream, src.ready, 0));
-        HIPCHK(hipMemcpyAsync(to, from, bytes, hipMemcpyDefault, stream));
+        if (p != me->rank) HIPCHK(gsx::op::StreamWaitEvent(stream, src.ready, 0));
+        HIPCHK(gsx::op::MemcpyAsync(to, from, bytes, hipMemcpyDefault, stream));
     }
-    HIPCHK(hipEventRecord(me->done, stream));
+    HIPCHK(gsx::op::EventRecord(me->done, stream));
     if ((st = rendezvous(g, me->rank, what))) return st;
     for (uint32_t p = 0; p < g->world; ++p)
-        if (p != me->rank) HIPCHK(hipStreamWaitEvent(stream, peer_done[p], 0));
+        if (p != me->rank) HIPCHK(gsx::op::StreamWaitEvent(stream, peer_done[p], 0));
     return GSX_OK;
 }
 

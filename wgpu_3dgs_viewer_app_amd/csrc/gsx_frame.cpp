@@ -37,6 +37,7 @@ gsx_status ply_fail(gsx_status st, const char* fmt, ...) {
 // bounded by the stream itself: if the stream drains (or fails) and the word still is not there, something upstream
 // went wrong and that is reported instead of spinning forever.
 static gsx_status wait_verdict(gsx_viewer* v, uint32_t seq, uint32_t* need) {
+    trace_flush();  // the kernel that posts the word may still be in a recorded segment
     for (uint64_t spin = 1;; ++spin) {
         const unsigned long long w = __atomic_load_n(v->h_verdict, __ATOMIC_ACQUIRE);
         if ((uint32_t)(w >> 32) == seq) {
@@ -44,7 +45,7 @@ static gsx_status wait_verdict(gsx_viewer* v, uint32_t seq, uint32_t* need) {
             return GSX_OK;
         }
         if ((spin & 0xFFFu) == 0) {
-            const hipError_t e = hipStreamQuery(v->stream);
+            const hipError_t e = gsx::op::StreamQuery(v->stream);
             if (e == hipSuccess) {
                 const unsigned long long w2 = __atomic_load_n(v->h_verdict, __ATOMIC_ACQUIRE);
                 if ((uint32_t)(w2 >> 32) == seq) continue;
@@ -107,7 +108,7 @@ static bool tuner_wants_speculation(Model* m) {
     const bool settling = t.phase == SpecTuner::SETTLE_SPEC || t.phase == SpecTuner::SETTLE_PLAIN;
     if (settling && t.probe_pending && kSettleFrames - t.left >= kSettleWait) {
         for (auto& s : t.slots)
-            if (s.state == 2 && s.probe) (void)hipEventSynchronize(s.stop);
+            if (s.state == 2 && s.probe) (void)gsx::op::EventSynchronize(s.stop);
         tuner_collect(m);
     }
     if (settling && t.probe_pending == 0) t.left = 0;
@@ -172,7 +173,7 @@ static void tuner_frame_begin(gsx_viewer* v, Model* m, bool speculated) {
     for (auto& s : t.slots) {
         if (s.state != 0) continue;
         if (!s.start && (hipEventCreate(&s.start) != hipSuccess || hipEventCreate(&s.stop) != hipSuccess)) return;
-        if (hipEventRecord(s.start, v->stream) != hipSuccess) return;
+        if (gsx::op::EventRecord(s.start, v->stream) != hipSuccess) return;
         s.spec = speculated;
         s.probe = probe;
         s.state = 1;
@@ -185,7 +186,7 @@ static void tuner_frame_begin(gsx_viewer* v, Model* m, bool speculated) {
 static void tuner_frame_end(gsx_viewer* v, Model* m) {
     SpecTuner& t = m->tuner_ref ? *m->tuner_ref : m->tuner;
     if (!t.active) return;
-    t.active->state = hipEventRecord(t.active->stop, v->stream) == hipSuccess ? 2 : 0;
+    t.active->state = gsx::op::EventRecord(t.active->stop, v->stream) == hipSuccess ? 2 : 0;
     if (t.active->state == 0 && t.active->probe && t.probe_pending) t.probe_pending -= 1;
     t.active = nullptr;
 }
@@ -211,9 +212,9 @@ gsx_status finish_frame(gsx_viewer* v) {
         for (auto& kv : v->models) {
             Model* m = kv.second.get();
             if (m->stats_pending)
-                HIPCHK(hipMemcpyAsync(m->h_counters, m->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, v->stream));
+                HIPCHK(gsx::op::MemcpyAsync(m->h_counters, m->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, v->stream));
         }
-        HIPCHK(hipStreamSynchronize(v->stream));
+        HIPCHK(gsx::op::StreamSynchronize(v->stream));
         bool redo = false;
         for (auto& kv : v->models) {
             Model* m = kv.second.get();
@@ -276,7 +277,7 @@ gsx_status ensure_sortbin_capacity(Model* m, uint64_t count) {
         const size_t ws = 4 * radix_workspace_words(n);
         if (ws > m->sort_ws.bytes) {
             HIPCHK(m->sort_ws.ensure(ws));
-            HIPCHK(hipMemset(m->sort_ws.p, 0, m->sort_ws.bytes));  // status words must not alias a live epoch
+            HIPCHK(gsx::op::Memset(m->sort_ws.p, 0, m->sort_ws.bytes));  // status words must not alias a live epoch
         }
     }
     HIPCHK(m->cnt.ensure(4 * n));
@@ -302,7 +303,7 @@ gsx_status ensure_selection(gsx_viewer* v, Model* m) {
     const size_t bytes = 4 * std::max<size_t>(((size_t)m->n + 31) / 32, 1);
     if (m->selection.bytes < bytes) {
         HIPCHK(m->selection.ensure(bytes));
-        HIPCHK(hipMemsetAsync(m->selection.p, 0, bytes, v->stream));
+        HIPCHK(gsx::op::MemsetAsync(m->selection.p, 0, bytes, v->stream));
     }
     return GSX_OK;
 }
@@ -311,7 +312,7 @@ gsx_status ensure_edit_buffers(gsx_viewer* v, Model* m) {
     const size_t words = std::max<size_t>(((size_t)m->n + 31) / 32, 1), n = std::max<size_t>(m->n, 1);
     if (m->edited.bytes < 4 * words) {
         HIPCHK(m->edited.ensure(4 * words));
-        HIPCHK(hipMemsetAsync(m->edited.p, 0, 4 * words, v->stream));
+        HIPCHK(gsx::op::MemsetAsync(m->edited.p, 0, 4 * words, v->stream));
         HIPCHK(m->keep.ensure(4 * words));
         HIPCHK(m->edit_a.ensure(16 * n));
         HIPCHK(m->edit_b.ensure(16 * n));
@@ -453,7 +454,7 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
         if (v->query.kind == GSX_QUERY_HIT) {
             HIPCHK(m->hits.ensure(sizeof(gsx_query_hit) * (size_t)GSX_QUERY_MAX_HITS));
             HIPCHK(m->hit_count.ensure(4));
-            HIPCHK(hipMemsetAsync(m->hit_count.p, 0, 4, v->stream));
+            HIPCHK(gsx::op::MemsetAsync(m->hit_count.p, 0, 4, v->stream));
         } else {
             HIPCHK(m->query_flags.ensure(4 * std::max<size_t>(words, 1)));
             if (v->query.kind == GSX_QUERY_TEXTURE && (v->query_tex_w != v->width || v->query_tex_h != v->height))
@@ -669,7 +670,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
         const size_t ws = 4 * radix_workspace_words(cap);
         if (ws > m->tsort_ws.bytes) {
             HIPCHK(m->tsort_ws.ensure(ws));
-            HIPCHK(hipMemsetAsync(m->tsort_ws.p, 0, m->tsort_ws.bytes, v->stream));
+            HIPCHK(gsx::op::MemsetAsync(m->tsort_ws.p, 0, m->tsort_ws.bytes, v->stream));
         }
         if (sizeof(uint2) * (size_t)n_tiles > m->ranges.bytes) m->ranges_clean = false;
         HIPCHK(m->ranges.ensure(sizeof(uint2) * (size_t)std::max<uint32_t>(n_tiles, 1024u)));  // (block lists: up to 1024 block ranges)
@@ -684,7 +685,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
         HIPCHK(m->spec_win2.ensure(sizeof(uint2) * (size_t)n_tiles));
         if (carry) {  // nearer models already saturated some tiles: remember which, they say nothing about this model
             HIPCHK(m->spec_done_before.ensure(bm));
-            HIPCHK(hipMemcpyAsync(m->spec_done_before.p, done, bm, hipMemcpyDeviceToDevice, v->stream));
+            HIPCHK(gsx::op::MemcpyAsync(m->spec_done_before.p, done, bm, hipMemcpyDeviceToDevice, v->stream));
             done_before = m->spec_done_before.as<uint32_t>();
         }
     }
@@ -765,14 +766,14 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
         }
         if (v->validate) {  // debug: check what the compositor will dereference, on the host, before it runs
             HIPCHK(v->scratch.ensure(64));
-            HIPCHK(hipMemsetAsync(v->scratch.p, 0, 64, v->stream));
+            HIPCHK(gsx::op::MemsetAsync(v->scratch.p, 0, 64, v->stream));
             // (block lists: one range per block, list values are positions in the slab)
             const uint32_t n_ranges = blocks ? ((m->fc.tiles_x + (1u << bsx) - 1u) >> bsx) * ((m->fc.tiles_y + (1u << bsy) - 1u) >> bsy) : n_tiles;
             HIPCHK(launch_validate_tiles(v->stream, m->ranges.as<uint2>(), n_ranges, m->tile_list, &dc->n_entries, blocks ? cap : slab_cap,
                                          blocks ? j1 - j0 : (uint32_t)m->rec_n, v->scratch.as<uint32_t>()));
             uint32_t rep[8];
-            HIPCHK(hipMemcpyAsync(rep, v->scratch.p, 32, hipMemcpyDeviceToHost, v->stream));
-            HIPCHK(hipStreamSynchronize(v->stream));
+            HIPCHK(gsx::op::MemcpyAsync(rep, v->scratch.p, 32, hipMemcpyDeviceToHost, v->stream));
+            HIPCHK(gsx::op::StreamSynchronize(v->stream));
             if (rep[0])
                 return fail(GSX_ERR_HIP, "GSX_VALIDATE: model '%s' slab %u: %s (tile %u: %u, %u, %u); n_tiles %u, tiles %ux%u, ranges_clean %d, "
                             "clear_ranges %d, speculated %d, later %d, slab_cap %u, rec_n %llu", m->key.c_str(), slab_index,
@@ -911,8 +912,8 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
     // feed the next frames' slab plan without waiting — every fourth frame is plenty (the copy is two runtime kernels)
     if (!m->stats_copy_inflight && (m->stats_copy_tick++ & 3u) == 0) {
         if (!m->stats_event) HIPCHK(hipEventCreateWithFlags(&m->stats_event, hipEventDisableTiming));
-        HIPCHK(hipMemcpyAsync(m->h_counters, m->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, v->stream));
-        HIPCHK(hipEventRecord(m->stats_event, v->stream));
+        HIPCHK(gsx::op::MemcpyAsync(m->h_counters, m->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, v->stream));
+        HIPCHK(gsx::op::EventRecord(m->stats_event, v->stream));
         m->stats_copy_inflight = true;
         m->stats_copy_speculated = m->spec_round1;
     }

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/gsx.h"
+#include "gsx_launch.h"
 
 namespace gsx {
 

@@ -42,10 +42,10 @@ gsx_status frame_buffers(Ctx& c) {
     gsx_status st = gsx_shard_layout(v, c.world, c.rank, &c.lay);
     if (st) return st;
     if (v->ext_fb != v->shard_fb.p || v->shard_fb.bytes < c.lay.padded_framebuffer_bytes) {
-        HIPCHK(hipStreamSynchronize(v->stream));
+        HIPCHK(gsx::op::StreamSynchronize(v->stream));
         if (v->shard_fb.bytes < c.lay.padded_framebuffer_bytes) {
             HIPCHK(v->shard_fb.ensure(c.lay.padded_framebuffer_bytes));
-            HIPCHK(hipMemsetAsync(v->shard_fb.p, 0, v->shard_fb.bytes, v->stream));
+            HIPCHK(gsx::op::MemsetAsync(v->shard_fb.p, 0, v->shard_fb.bytes, v->stream));
         }
         v->ext_fb = v->shard_fb.p;
         v->ext_fb_bytes = v->shard_fb.bytes;
@@ -191,7 +191,7 @@ gsx_status frame_back(gsx_viewer* owner, ShardPending& p) {
     for (const std::string& k : p.order)
         if ((st = gsx_shard_frame_end(p.lane, k.c_str()))) return st;
     if (p.lane != owner) {  // model-changing calls on the owner's stream come after this lane's frame (viewer_bind)
-        HIPCHK(hipEventRecord(p.lane->lane_event, p.lane->stream));
+        HIPCHK(gsx::op::EventRecord(p.lane->lane_event, p.lane->stream));
         p.lane->lane_busy = true;
     }
     owner->latest = p.lane == owner ? nullptr : p.lane;

@@ -33,7 +33,7 @@ struct DevBuf {
     bool borrowed = false;  // p belongs to another DevBuf (a lane's view of the model data, gsx_api.cpp)
     ~DevBuf() { release(); }
     void release() {
-        if (p && !borrowed) (void)hipFree(p);
+        if (p && !borrowed) (void)gsx::op::Free(p);
         p = nullptr;
         bytes = 0;
         borrowed = false;
@@ -249,6 +249,20 @@ struct Model {
     Records rec() const { return use_imported ? imp_rec() : proj_rec(); }  // the frame's active record set
 };
 
+// A frame-level entry point records its kernel launches and submits them as cached, patched HIP graphs (gsx_launch.h,
+// gsx_graph.cpp).  scope_id: which entry point (the cache is per entry point and segment position).
+enum : uint32_t { TRACE_PREPROCESS = 1, TRACE_SORT = 2, TRACE_RENDER = 3, TRACE_RENDER_FRAME = 4, TRACE_SHARD = 5 };
+struct TraceScope {
+    LaunchTrace* mine = nullptr;
+    TraceScope(gsx_viewer* v, uint32_t scope_id);
+    ~TraceScope();
+    TraceScope(const TraceScope&) = delete;
+    TraceScope& operator=(const TraceScope&) = delete;
+};
+bool launch_graphs_enabled();
+void trace_destroy(LaunchTrace* t);
+void trace_stats(const LaunchTrace* t, gsx_launch_stats* out);
+
 struct PassTimer {
     hipEvent_t start, stop;
     int pass;
@@ -337,6 +351,7 @@ struct gsx_viewer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
     float pass_ms[GSX_PASS_COUNT]{};
     uint32_t pass_launches[GSX_PASS_COUNT]{};
+    gsx::LaunchTrace* trace = nullptr;  // owned; created by the first TraceScope on this viewer (gsx_graph.cpp)
 };
 
 namespace gsx {
@@ -361,11 +376,11 @@ struct ScopedPass {
             (void)hipEventCreate(&a);
             (void)hipEventCreate(&b);
         }
-        (void)hipEventRecord(a, v->stream);
+        (void)gsx::op::EventRecord(a, v->stream);
     }
     ~ScopedPass() {
         if (!a) return;
-        (void)hipEventRecord(b, v->stream);
+        (void)gsx::op::EventRecord(b, v->stream);
         v->timers.push_back({a, b, pass});
     }
 };
@@ -396,7 +411,7 @@ inline gsx_status viewer_bind(gsx_viewer* v) {
     if (!v->lanes.empty() && !v->shard_busy) {  // (inside gsx_shard_render_frame the lanes' frames stay in flight)
         for (gsx_viewer* l : v->lanes)
             if (l->lane_busy) {
-                HIPCHK(hipStreamWaitEvent(v->stream, l->lane_event, 0));
+                HIPCHK(gsx::op::StreamWaitEvent(v->stream, l->lane_event, 0));
                 l->lane_busy = false;
             }
         v->epoch += 1;

@@ -221,33 +221,33 @@ hipError_t launch_admit_from_project(hipStream_t s, const uint32_t* key, uint32_
                                      bool sparse, const uint32_t* block_visible, uint32_t* d_n_visible) {
     const uint32_t nb = (n + 255) / 256;
     if (!nb) {
-        if (block_visible) (void)hipMemsetAsync(d_n_visible, 0, 4, s);
-        return hipMemsetAsync(d_total, 0, 4, s);
+        if (block_visible) (void)gsx::op::MemsetAsync(d_n_visible, 0, 4, s);
+        return gsx::op::MemsetAsync(d_total, 0, 4, s);
     }
-    hipLaunchKernelGGL(k_admit_scan, dim3(1), dim3(1024), 0, s, block_counts, block_offsets, nb, d_total, block_visible, d_n_visible);
+    GSX_LAUNCH(k_admit_scan, dim3(1), dim3(1024), 0, s, block_counts, block_offsets, nb, d_total, block_visible, d_n_visible);
     const uint32_t words = (n + 63) / 64;
     if (sparse)
-        hipLaunchKernelGGL(k_admit_scatter256, dim3((words + 255) / 256), dim3(256), 0, s, key, words, ballots, block_offsets, pairs);
+        GSX_LAUNCH(k_admit_scatter256, dim3((words + 255) / 256), dim3(256), 0, s, key, words, ballots, block_offsets, pairs);
     else
-        hipLaunchKernelGGL(k_admit_scatter_dense, dim3(nb), dim3(256), 0, s, key, n, ballots, block_offsets, pairs);
+        GSX_LAUNCH(k_admit_scatter_dense, dim3(nb), dim3(256), 0, s, key, n, ballots, block_offsets, pairs);
     return hipGetLastError();
 }
 
 hipError_t launch_admit_scatter(hipStream_t s, const uint32_t* key, uint32_t n, const unsigned long long* ballots,
                                 const uint32_t* offsets, uint2* pairs) {
     const uint32_t nb = (uint32_t)admit_blocks(n);
-    if (nb) hipLaunchKernelGGL(k_admit_scatter, dim3(nb), dim3(kAdmitThreads), 0, s, key, n, ballots, offsets, pairs, nullptr);
+    if (nb) GSX_LAUNCH(k_admit_scatter, dim3(nb), dim3(kAdmitThreads), 0, s, key, n, ballots, offsets, pairs, nullptr);
     return hipGetLastError();
 }
 
 hipError_t launch_admit(hipStream_t s, const Records& rec, uint32_t n, const uint2* window, uint32_t tiles_x,
                         const uint32_t* gate, uint32_t row_words, const WindowPyramid& pyramid, const uint32_t* d_skip, unsigned long long* ballots, uint32_t* counts, uint32_t* d_total, uint2* pairs) {
     const uint32_t nb = (uint32_t)admit_blocks(n);
-    if (!nb) return hipMemsetAsync(d_total, 0, 4, s);
-    hipLaunchKernelGGL(k_admit_count, dim3(nb), dim3(kAdmitThreads), 0, s, rec.key, rec.a, n, window, tiles_x, gate, row_words, pyramid, d_skip, ballots, counts, rec.rect8);
+    if (!nb) return gsx::op::MemsetAsync(d_total, 0, 4, s);
+    GSX_LAUNCH(k_admit_count, dim3(nb), dim3(kAdmitThreads), 0, s, rec.key, rec.a, n, window, tiles_x, gate, row_words, pyramid, d_skip, ballots, counts, rec.rect8);
     hipError_t e = launch_rowscan(s, counts, 1, nb, d_total, nullptr, 1, d_skip);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_admit_scatter, dim3(nb), dim3(kAdmitThreads), 0, s, rec.key, n, ballots, counts, pairs, d_skip);
+    GSX_LAUNCH(k_admit_scatter, dim3(nb), dim3(kAdmitThreads), 0, s, rec.key, n, ballots, counts, pairs, d_skip);
     return hipGetLastError();
 }
 

@@ -547,15 +547,15 @@ hipError_t launch_block_bin(hipStream_t s, uint32_t j0, uint32_t j1, const uint3
                             uint2* pairs, uint2* ranges) {
     const uint32_t nb = std::min<uint32_t>((uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0), kBinGrid);
     BlockGrid g{bsx, bsy, (tiles_x + (1u << bsx) - 1u) >> bsx, (tiles_y + (1u << bsy) - 1u) >> bsy};
-    hipLaunchKernelGGL(k_block_table, dim3((g.blocks_x * g.blocks_y + 3u) / 4u), dim3(256), 0, s, g, tiles_x, tiles_y, row_lo, row_hi, done,
+    GSX_LAUNCH(k_block_table, dim3((g.blocks_x * g.blocks_y + 3u) / 4u), dim3(256), 0, s, g, tiles_x, tiles_y, row_lo, row_hi, done,
                        row_words, window, table, ranges);
     if (nb)
-        hipLaunchKernelGGL(k_block_counts, dim3(nb), dim3(kBinThreads), 0, s, d_n_vis, j0, j1, sorted_idx, rec.a, sorted_keys, brec, cnt,
+        GSX_LAUNCH(k_block_counts, dim3(nb), dim3(kBinThreads), 0, s, d_n_vis, j0, j1, sorted_idx, rec.a, sorted_keys, brec, cnt,
                            block_sums, row_lo, row_hi, d_done_count, owned_tiles, g, table, window ? 1 : 0);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, j0, j1, d_n_vis, stats, capacity, d_done_count,
+    GSX_LAUNCH(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, j0, j1, d_n_vis, stats, capacity, d_done_count,
                        owned_tiles, slab_index);
     if (nb)
-        hipLaunchKernelGGL(k_block_emit, dim3(nb), dim3(kBinThreads), 0, s, j0, j1, brec, cnt, block_sums, pairs, row_lo, row_hi,
+        GSX_LAUNCH(k_block_emit, dim3(nb), dim3(kBinThreads), 0, s, j0, j1, brec, cnt, block_sums, pairs, row_lo, row_hi,
                            d_n_vis, &stats->n_entries, capacity, &stats->slab_cut, g, table, window ? 1 : 0);
     return hipGetLastError();
 }
@@ -568,9 +568,9 @@ hipError_t launch_tile_counts(hipStream_t s, uint32_t j0, uint32_t j1, const uin
     const uint32_t nb = std::min<uint32_t>((uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0), kBinGrid);
     TileWindow tw{window, sorted_keys, tiles_x, min_ends ? *min_ends : WindowPyramid{}};
     if (nb)
-        hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(kBinThreads), 0, s, d_n_vis, j0, j1, sorted_idx, rec.a, srect, cnt,
+        GSX_LAUNCH(k_tile_counts, dim3(nb), dim3(kBinThreads), 0, s, d_n_vis, j0, j1, sorted_idx, rec.a, srect, cnt,
                            block_sums, row_lo, row_hi, done, row_words, d_done_count, owned_tiles, tw);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, j0, j1, d_n_vis, stats, capacity, d_done_count,
+    GSX_LAUNCH(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, j0, j1, d_n_vis, stats, capacity, d_done_count,
                        owned_tiles, slab_index);
     return hipGetLastError();
 }
@@ -583,7 +583,7 @@ hipError_t launch_tile_emit(hipStream_t s, uint32_t j0, uint32_t j1, const uint3
     const uint32_t nb = std::min<uint32_t>((uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0), kBinGrid);
     if (!nb) return hipSuccess;
     TileWindow tw{window, sorted_keys, tiles_x, WindowPyramid{}};
-    hipLaunchKernelGGL(k_tile_emit, dim3(nb), dim3(kBinThreads), 0, s, j0, j1, sorted_idx, srect, cnt, block_sums,
+    GSX_LAUNCH(k_tile_emit, dim3(nb), dim3(kBinThreads), 0, s, j0, j1, sorted_idx, srect, cnt, block_sums,
                        tiles_x, tpairs, row_lo, row_hi, done, row_words, d_n_vis, d_entries, capacity, tw, d_cut);
     return hipGetLastError();
 }
@@ -594,12 +594,12 @@ hipError_t launch_tile_ranges(hipStream_t s, uint32_t capacity, const uint32_t* 
         // the WHOLE allocation, not this frame's tile count: "clean" is a statement about every entry a later, larger
         // viewport may read (a table allocated with slack and zeroed up to a smaller frame's tile count handed stale
         // ranges to the compositor after a resize — found by the API fuzz test)
-        hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)table_tiles, s);
+        hipError_t e = gsx::op::MemsetAsync(ranges, 0, sizeof(uint2) * (size_t)table_tiles, s);
         if (e != hipSuccess) return e;
     }
     if (capacity == 0) return hipSuccess;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)capacity + 255) / 256, 4096);
-    hipLaunchKernelGGL(k_tile_ranges, dim3(grid), dim3(256), 0, s, d_n, tkey_sorted, ranges);
+    GSX_LAUNCH(k_tile_ranges, dim3(grid), dim3(256), 0, s, d_n, tkey_sorted, ranges);
     return hipGetLastError();
 }
 

@@ -474,10 +474,10 @@ hipError_t launch_composite(hipStream_t s, const FrameConsts& f, uint2* ranges, 
                             uint32_t* d_done_count, bool clear_ranges, uint32_t* tile_sat) {
     dim3 grid(f.tiles_x * f.tiles_y), block(128);
     if (f.display_mode == GSX_DISPLAY_SPLAT)
-        hipLaunchKernelGGL(k_composite<0>, grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count,
+        GSX_LAUNCH(k_composite<0>, grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count,
                            clear_ranges ? 1 : 0, tile_sat);
     else
-        hipLaunchKernelGGL(k_composite<1>, grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count,
+        GSX_LAUNCH(k_composite<1>, grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count,
                            clear_ranges ? 1 : 0, tile_sat);
     return hipGetLastError();
 }
@@ -489,10 +489,10 @@ hipError_t launch_composite_blocks(hipStream_t s, const FrameConsts& f, const ui
     dim3 grid(f.tiles_x * f.tiles_y), block(128);
     const uint32_t blocks_x = (f.tiles_x + (1u << bsx) - 1u) >> bsx;
     if (f.display_mode == GSX_DISPLAY_SPLAT)
-        hipLaunchKernelGGL(k_composite_blocks<0>, grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
+        GSX_LAUNCH(k_composite_blocks<0>, grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
                            row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x);
     else
-        hipLaunchKernelGGL(k_composite_blocks<1>, grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
+        GSX_LAUNCH(k_composite_blocks<1>, grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
                            row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x);
     return hipGetLastError();
 }
@@ -503,24 +503,24 @@ hipError_t launch_composite_spill(hipStream_t s, const FrameConsts& f, const Sla
                                   uint32_t row_hi, const uint2* window) {
     dim3 grid(std::min<uint32_t>(f.tiles_x * f.tiles_y, 2048u)), block(128);
     if (f.display_mode == GSX_DISPLAY_SPLAT)
-        hipLaunchKernelGGL(k_composite_spill<0>, grid, block, 0, s, f, stats, j1, d_n, sorted_idx, sorted_keys, rec.a, rec.b, rec.c, fb, done,
+        GSX_LAUNCH(k_composite_spill<0>, grid, block, 0, s, f, stats, j1, d_n, sorted_idx, sorted_keys, rec.a, rec.b, rec.c, fb, done,
                            row_words, d_done_count, tile_sat, row_lo, row_hi, window);
     else
-        hipLaunchKernelGGL(k_composite_spill<1>, grid, block, 0, s, f, stats, j1, d_n, sorted_idx, sorted_keys, rec.a, rec.b, rec.c, fb, done,
+        GSX_LAUNCH(k_composite_spill<1>, grid, block, 0, s, f, stats, j1, d_n, sorted_idx, sorted_keys, rec.a, rec.b, rec.c, fb, done,
                            row_words, d_done_count, tile_sat, row_lo, row_hi, window);
     return hipGetLastError();
 }
 
 hipError_t launch_clear_fb(hipStream_t s, float4* fb, uint32_t n_px) {
     if (!n_px) return hipSuccess;
-    hipLaunchKernelGGL(k_clear_fb, dim3((n_px + 255) / 256), dim3(256), 0, s, fb, n_px);
+    GSX_LAUNCH(k_clear_fb, dim3((n_px + 255) / 256), dim3(256), 0, s, fb, n_px);
     return hipGetLastError();
 }
 
 hipError_t launch_resolve_rgba8(hipStream_t s, const float4* fb, uint32_t n_px, float bg_r, float bg_g, float bg_b,
                                 uint32_t* out_rgba8) {
     if (!n_px) return hipSuccess;
-    hipLaunchKernelGGL(k_resolve_rgba8, dim3((n_px + 255) / 256), dim3(256), 0, s, fb, n_px, bg_r, bg_g, bg_b, out_rgba8);
+    GSX_LAUNCH(k_resolve_rgba8, dim3((n_px + 255) / 256), dim3(256), 0, s, fb, n_px, bg_r, bg_g, bg_b, out_rgba8);
     return hipGetLastError();
 }
 

@@ -163,14 +163,14 @@ __global__ __launch_bounds__(256) void k_selection_op(uint32_t n_words, uint32_t
 
 hipError_t launch_edit_prepare(hipStream_t s, uint32_t n, const uint32_t* selection, uint32_t* edited, float4* edit_a,
                                float4* edit_b, const gsx_gaussian_edit& sel_edit, const uint32_t* mask, uint32_t* keep) {
-    if (n) hipLaunchKernelGGL(k_edit_prepare, dim3((n + 255) / 256), dim3(256), 0, s, n, selection, edited, edit_a, edit_b, sel_edit, mask, keep);
+    if (n) GSX_LAUNCH(k_edit_prepare, dim3((n + 255) / 256), dim3(256), 0, s, n, selection, edited, edit_a, edit_b, sel_edit, mask, keep);
     return hipGetLastError();
 }
 
 hipError_t launch_edit_apply(hipStream_t s, uint32_t n, const Records& rec, const uint32_t* selection, const uint32_t* edited,
                              const float4* edit_a, const float4* edit_b, const float highlight[4]) {
     if (n)
-        hipLaunchKernelGGL(k_edit_apply, dim3((n + 255) / 256), dim3(256), 0, s, n, rec.key, rec.b, rec.c, selection, edited, edit_a,
+        GSX_LAUNCH(k_edit_apply, dim3((n + 255) / 256), dim3(256), 0, s, n, rec.key, rec.b, rec.c, selection, edited, edit_a,
                            edit_b, make_float4(highlight[0], highlight[1], highlight[2], highlight[3]));
     return hipGetLastError();
 }
@@ -179,7 +179,7 @@ hipError_t launch_edit_apply_list(hipStream_t s, uint32_t n, const Records& rec,
                                   const unsigned long long* skip, const uint32_t* selection, const uint32_t* edited, const float4* edit_a,
                                   const float4* edit_b, const float highlight[4]) {
     if (n)  // (n: an upper bound of the list length; the count is on the device)
-        hipLaunchKernelGGL(k_edit_apply_list, dim3(std::min<uint32_t>((n + 255) / 256, 2048u)), dim3(256), 0, s, pairs, d_n, skip, rec.b, rec.c,
+        GSX_LAUNCH(k_edit_apply_list, dim3(std::min<uint32_t>((n + 255) / 256, 2048u)), dim3(256), 0, s, pairs, d_n, skip, rec.b, rec.c,
                            selection, edited, edit_a, edit_b, make_float4(highlight[0], highlight[1], highlight[2], highlight[3]));
     return hipGetLastError();
 }
@@ -188,13 +188,13 @@ hipError_t launch_query(hipStream_t s, uint32_t n, const Records& rec, const gsx
                         uint32_t tex_h, const FrameConsts& f, uint32_t* flags, gsx_query_hit* hits, uint32_t* hit_count,
                         uint32_t hit_capacity) {
     if (n)
-        hipLaunchKernelGGL(k_query, dim3((n + 255) / 256), dim3(256), 0, s, n, rec.key, rec.a, rec.b, rec.c, q, texture, tex_w, tex_h,
+        GSX_LAUNCH(k_query, dim3((n + 255) / 256), dim3(256), 0, s, n, rec.key, rec.a, rec.b, rec.c, q, texture, tex_w, tex_h,
                            f.k2, f.alpha_max, f.display_mode, flags, hits, hit_count, hit_capacity);
     return hipGetLastError();
 }
 
 hipError_t launch_selection_op(hipStream_t s, uint32_t n_words, uint32_t op, const uint32_t* flags, uint32_t* selection) {
-    if (n_words) hipLaunchKernelGGL(k_selection_op, dim3((n_words + 255) / 256), dim3(256), 0, s, n_words, op, flags, selection);
+    if (n_words) GSX_LAUNCH(k_selection_op, dim3((n_words + 255) / 256), dim3(256), 0, s, n_words, op, flags, selection);
     return hipGetLastError();
 }
 

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_mask_evaluate(const float4* __restrict_
 
 hipError_t launch_mask_evaluate(hipStream_t s, const float4* pc, uint32_t n, const MaskProgram& prog, uint32_t* mask) {
     const uint32_t per = 256u * kMaskPerLane;
-    if (n) hipLaunchKernelGGL(k_mask_evaluate, dim3((n + per - 1) / per), dim3(256), 0, s, pc, n, prog, mask);
+    if (n) GSX_LAUNCH(k_mask_evaluate, dim3((n + per - 1) / per), dim3(256), 0, s, pc, n, prog, mask);
     return hipGetLastError();
 }
 

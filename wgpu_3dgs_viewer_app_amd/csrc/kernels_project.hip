@@ -626,14 +626,14 @@ static inline unsigned blocks_for(uint64_t n, unsigned per) { return (unsigned)(
 hipError_t launch_convert(hipStream_t s, const gsx_gaussian* d_src, uint64_t n, uint64_t start, uint64_t model_n,
                           const PodPlanes& pod) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_convert, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_src, n, start, model_n, pod);
+    GSX_LAUNCH(k_convert, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_src, n, start, model_n, pod);
     return hipGetLastError();
 }
 
 hipError_t launch_pack_pod(hipStream_t s, const float* d_pos, const uint32_t* d_color, const float* d_sh,
                            const float* d_cov, uint64_t n, uint64_t start, uint64_t model_n, const PodPlanes& pod) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_pack_pod, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_pos, d_color, d_sh, d_cov, n, start,
+    GSX_LAUNCH(k_pack_pod, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_pos, d_color, d_sh, d_cov, n, start,
                        model_n, pod);
     return hipGetLastError();
 }
@@ -641,7 +641,7 @@ hipError_t launch_pack_pod(hipStream_t s, const float* d_pos, const uint32_t* d_
 hipError_t launch_unpack_pod(hipStream_t s, const PodPlanes& pod, uint64_t model_n, float* d_pos, uint32_t* d_color,
                              float* d_sh, float* d_cov) {
     if (model_n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_unpack_pod, dim3(blocks_for(model_n, 256)), dim3(256), 0, s, pod, model_n, d_pos, d_color, d_sh,
+    GSX_LAUNCH(k_unpack_pod, dim3(blocks_for(model_n, 256)), dim3(256), 0, s, pod, model_n, d_pos, d_color, d_sh,
                        d_cov);
     return hipGetLastError();
 }
@@ -649,7 +649,7 @@ hipError_t launch_unpack_pod(hipStream_t s, const PodPlanes& pod, uint64_t model
 size_t project_blocks(uint64_t n) { return (size_t)((n + 255) / 256); }
 
 hipError_t launch_sum_counts(hipStream_t s, const uint32_t* d_block_visible, uint32_t n, uint32_t* d_n_visible) {
-    hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(1024), 0, s, d_block_visible, (uint32_t)project_blocks(n), d_n_visible);
+    GSX_LAUNCH(k_sum_counts, dim3(1), dim3(1024), 0, s, d_block_visible, (uint32_t)project_blocks(n), d_n_visible);
     return hipGetLastError();
 }
 
@@ -659,15 +659,15 @@ static void launch_project_deg(hipStream_t s, dim3 grid, int deg, const FrameCon
     dim3 block(256);
 #define GSX_PROJECT(D)                                                                                                       \
     if (late)                                                                                                                \
-        hipLaunchKernelGGL((k_shade<D, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, late->pairs, late->d_n, late->shaded, late->write_a ? 1 : 0); \
+        GSX_LAUNCH((k_shade<D, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, late->pairs, late->d_n, late->shaded, late->write_a ? 1 : 0); \
     else if (adm.lazy && adm.query.flags)                                                                                    \
-        hipLaunchKernelGGL((k_project_geom<COVK, kProjGeomPer, true>), dim3((grid.x + kProjGeomPer - 1) / kProjGeomPer),     \
+        GSX_LAUNCH((k_project_geom<COVK, kProjGeomPer, true>), dim3((grid.x + kProjGeomPer - 1) / kProjGeomPer),     \
                            block, 0, s, f, n, pod, rec, bv, adm);                                                            \
     else if (adm.lazy)                                                                                                       \
-        hipLaunchKernelGGL((k_project_geom<COVK, kProjGeomPer, false>), dim3((grid.x + kProjGeomPer - 1) / kProjGeomPer),    \
+        GSX_LAUNCH((k_project_geom<COVK, kProjGeomPer, false>), dim3((grid.x + kProjGeomPer - 1) / kProjGeomPer),    \
                            block, 0, s, f, n, pod, rec, bv, adm);                                                            \
     else                                                                                                                     \
-        hipLaunchKernelGGL((k_project<D, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv, adm)
+        GSX_LAUNCH((k_project<D, SHK, COVK>), grid, block, 0, s, f, n, pod, rec, bv, adm)
     switch (deg) {
         case 0: GSX_PROJECT(0); break;
         case 1: GSX_PROJECT(1); break;

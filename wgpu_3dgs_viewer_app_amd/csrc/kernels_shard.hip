@@ -219,7 +219,7 @@ hipError_t launch_pack_count(hipStream_t s, const Records& rec, uint32_t n, uint
     const uint32_t rounds = pack_rounds(list != nullptr), nb = (uint32_t)pack_blocks(n, rounds);
     if (nb) {
         auto kernel = rounds == kPackRoundsList ? k_pack_count<(int)kPackRoundsList> : k_pack_count<(int)kPackRoundsFull>;
-        hipLaunchKernelGGL(kernel, dim3(nb), dim3(kPackThreads), 0, s, rec.key, rec.a, n, world, rows_per_rank, window,
+        GSX_LAUNCH(kernel, dim3(nb), dim3(kPackThreads), 0, s, rec.key, rec.a, n, world, rows_per_rank, window,
                            tiles_x, masks, table, nb, list, d_list_n, travellers, traveller_counts, gate, gate_row_words,
                            pyramid ? *pyramid : WindowPyramid{}, rec.rect8);
     }
@@ -232,7 +232,7 @@ hipError_t launch_pack_scatter(hipStream_t s, const Records& rec, uint32_t n, ui
     const uint32_t rounds = pack_rounds(list != nullptr), nb = (uint32_t)pack_blocks(n, rounds);
     if (nb) {
         auto kernel = rounds == kPackRoundsList ? k_pack_scatter<(int)kPackRoundsList> : k_pack_scatter<(int)kPackRoundsFull>;
-        hipLaunchKernelGGL(kernel, dim3(nb), dim3(kPackThreads), 0, s, masks, rec.a, rec.b, rec.c, n, world, table, nb,
+        GSX_LAUNCH(kernel, dim3(nb), dim3(kPackThreads), 0, s, masks, rec.a, rec.b, rec.c, n, world, table, nb,
                            totals, reinterpret_cast<float4*>(d_send), capacity, list, d_list_n, slot_stride, slot_cap);
     }
     return hipGetLastError();
@@ -395,20 +395,20 @@ __global__ __launch_bounds__(256) void k_shard_next_limits(const uint32_t* __res
 
 hipError_t launch_pack_headers(hipStream_t s, const uint32_t* totals, uint32_t world, uint32_t slot_stride, uint32_t slot_cap, void* d_send,
                                SlabStats* stats, uint32_t round) {
-    hipLaunchKernelGGL(k_pack_headers, dim3(1), dim3(64), 0, s, totals, world, slot_stride, slot_cap, reinterpret_cast<float4*>(d_send), stats, round);
+    GSX_LAUNCH(k_pack_headers, dim3(1), dim3(64), 0, s, totals, world, slot_stride, slot_cap, reinterpret_cast<float4*>(d_send), stats, round);
     return hipGetLastError();
 }
 
 hipError_t launch_import_slots(hipStream_t s, const void* d_recv, uint32_t world, uint32_t slot_stride, uint32_t slot_cap, const Records& rec,
                                SlabStats* stats) {
     const uint64_t total = (uint64_t)world * slot_cap;
-    hipLaunchKernelGGL(k_import_slots, dim3((unsigned)std::max<uint64_t>((total + 255) / 256, 1)), dim3(256), 0, s,
+    GSX_LAUNCH(k_import_slots, dim3((unsigned)std::max<uint64_t>((total + 255) / 256, 1)), dim3(256), 0, s,
                        reinterpret_cast<const float4*>(d_recv), world, slot_stride, slot_cap, rec, stats);
     return hipGetLastError();
 }
 
 hipError_t launch_limits_to_windows(hipStream_t s, const uint32_t* limit, uint32_t n_tiles, uint2* win) {
-    hipLaunchKernelGGL(k_limits_to_windows, dim3((n_tiles + 255) / 256), dim3(256), 0, s, limit, n_tiles, win);
+    GSX_LAUNCH(k_limits_to_windows, dim3((n_tiles + 255) / 256), dim3(256), 0, s, limit, n_tiles, win);
     return hipGetLastError();
 }
 
@@ -416,30 +416,30 @@ hipError_t launch_shard_verify(hipStream_t s, const uint32_t* limit, const uint3
                                uint32_t world, uint2* win2, uint32_t* d_need, uint32_t* d_ticket, unsigned long long* host_verdict, uint32_t seq,
                                uint32_t* need_bits) {
     const uint32_t n_tiles = tiles_x * tiles_y;
-    hipLaunchKernelGGL(k_shard_verify, dim3((n_tiles + 255) / 256), dim3(256), 0, s, limit, sat, n_tiles, tiles_x, rpr, world, win2, d_need,
+    GSX_LAUNCH(k_shard_verify, dim3((n_tiles + 255) / 256), dim3(256), 0, s, limit, sat, n_tiles, tiles_x, rpr, world, win2, d_need,
                        d_ticket, host_verdict, seq, need_bits);
     return hipGetLastError();
 }
 
 hipError_t launch_shard_post_counts(hipStream_t s, const uint32_t* counts_all, uint32_t world, unsigned long long* host_verdict, uint32_t seq) {
-    hipLaunchKernelGGL(k_shard_post_counts, dim3(1), dim3(64), 0, s, counts_all, world, host_verdict, seq);
+    GSX_LAUNCH(k_shard_post_counts, dim3(1), dim3(64), 0, s, counts_all, world, host_verdict, seq);
     return hipGetLastError();
 }
 
 hipError_t launch_shard_max_count(hipStream_t s, const uint32_t* totals, uint32_t world, uint32_t* out4) {
-    hipLaunchKernelGGL(k_shard_max_count, dim3(1), dim3(64), 0, s, totals, world, out4);
+    GSX_LAUNCH(k_shard_max_count, dim3(1), dim3(64), 0, s, totals, world, out4);
     return hipGetLastError();
 }
 
 hipError_t launch_shard_next_limits(hipStream_t s, const uint32_t* sat, uint32_t tiles_x, uint32_t tiles_y, float margin, uint32_t radius,
                                     uint32_t* limit, uint32_t rpr) {
-    hipLaunchKernelGGL(k_shard_next_limits, dim3((tiles_x * tiles_y + 255) / 256), dim3(256), 0, s, sat, tiles_x, tiles_y, 1.0f + margin,
+    GSX_LAUNCH(k_shard_next_limits, dim3((tiles_x * tiles_y + 255) / 256), dim3(256), 0, s, sat, tiles_x, tiles_y, 1.0f + margin,
                        (int)std::min<uint32_t>(radius, 16u), limit, rpr);
     return hipGetLastError();
 }
 
 hipError_t launch_import_records(hipStream_t s, const void* d_recv, uint32_t n, const Records& rec) {
-    if (n) hipLaunchKernelGGL(k_import_records, dim3((n + 255) / 256), dim3(256), 0, s, reinterpret_cast<const float4*>(d_recv), n, rec);
+    if (n) GSX_LAUNCH(k_import_records, dim3((n + 255) / 256), dim3(256), 0, s, reinterpret_cast<const float4*>(d_recv), n, rec);
     return hipGetLastError();
 }
 

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t
 
 hipError_t launch_rowscan(hipStream_t s, uint32_t* table, uint32_t nrows, uint32_t nblocks, uint32_t* totals, const uint32_t* d_n, uint32_t tile,
                           const uint32_t* d_skip) {
-    if (nrows) hipLaunchKernelGGL(k_radix_rowscan, dim3(nrows), dim3(256), 0, s, table, nblocks, totals, d_n, tile, d_skip);
+    if (nrows) GSX_LAUNCH(k_radix_rowscan, dim3(nrows), dim3(256), 0, s, table, nblocks, totals, d_n, tile, d_skip);
     return hipGetLastError();
 }
 
@@ -500,12 +500,12 @@ bool radix_lane_ordered_adds() {
     }
     uint32_t* d = nullptr;
     uint32_t h = 1;
-    bool ok = hipMalloc(&d, 4) == hipSuccess && hipMemset(d, 0, 4) == hipSuccess;
+    bool ok = hipMalloc(&d, 4) == hipSuccess && gsx::op::Memset(d, 0, 4) == hipSuccess;
     if (ok) {
-        hipLaunchKernelGGL(k_lane_order_probe, dim3(kRadixGrid), dim3(kSweepThreads), 0, 0, 12345u, 8u, d);
-        ok = hipGetLastError() == hipSuccess && hipMemcpy(&h, d, 4, hipMemcpyDeviceToHost) == hipSuccess;
+        GSX_LAUNCH(k_lane_order_probe, dim3(kRadixGrid), dim3(kSweepThreads), 0, 0, 12345u, 8u, d);
+        ok = hipGetLastError() == hipSuccess && gsx::op::Memcpy(&h, d, 4, hipMemcpyDeviceToHost) == hipSuccess;
     }
-    if (d) (void)hipFree(d);
+    if (d) (void)gsx::op::Free(d);
     g_lane_ordered[dev].store((ok && h == 0) ? 1 : 0);
     return ok && h == 0;
 }
@@ -543,10 +543,10 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
     static const uint32_t hper = getenv("GSX_RADIX_HPER") ? (uint32_t)atoi(getenv("GSX_RADIX_HPER")) : 4096u;
     const uint32_t hgrid = std::max<uint32_t>(1u, std::min<uint32_t>(768u, (uint32_t)(((uint64_t)n + hper - 1) / hper)));
     if (buf.pairs_src)
-        hipLaunchKernelGGL(k_radix_global_hist<2>, dim3(hgrid), dim3(kRadixThreads), 0, s,
+        GSX_LAUNCH(k_radix_global_hist<2>, dim3(hgrid), dim3(kRadixThreads), 0, s,
                            reinterpret_cast<const uint32_t*>(buf.pairs_src), n, d_n, passes, dbits, ghist, 0);
     else
-        hipLaunchKernelGGL(k_radix_global_hist<1>, dim3(hgrid), dim3(kRadixThreads), 0, s, buf.keys_src, n, skip ? nullptr : d_n, passes, dbits,
+        GSX_LAUNCH(k_radix_global_hist<1>, dim3(hgrid), dim3(kRadixThreads), 0, s, buf.keys_src, n, skip ? nullptr : d_n, passes, dbits,
                            ghist, skip ? 1 : 0);
     const uint2* pin = buf.pairs_src;
     uint2* pout = buf.pairs_a;
@@ -561,15 +561,15 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
 #define GSX_SWEEP(IN, OUT)                                                                                               \
     do {                                                                                                                 \
         if (lane_ordered)                                                                                                \
-            hipLaunchKernelGGL((k_radix_onesweep<IN, OUT, true>), GSX_SWEEP_ARGS(d_n, nullptr));                          \
+            GSX_LAUNCH((k_radix_onesweep<IN, OUT, true>), GSX_SWEEP_ARGS(d_n, nullptr));                          \
         else                                                                                                             \
-            hipLaunchKernelGGL((k_radix_onesweep<IN, OUT, false>), GSX_SWEEP_ARGS(d_n, nullptr));                         \
+            GSX_LAUNCH((k_radix_onesweep<IN, OUT, false>), GSX_SWEEP_ARGS(d_n, nullptr));                         \
     } while (0)
         if (first && skip) {  // (more than one pass: the first one writes interleaved pairs)
             if (lane_ordered)
-                hipLaunchKernelGGL((k_radix_onesweep<0, 0, true, true>), GSX_SWEEP_ARGS(nullptr, d_n));
+                GSX_LAUNCH((k_radix_onesweep<0, 0, true, true>), GSX_SWEEP_ARGS(nullptr, d_n));
             else
-                hipLaunchKernelGGL((k_radix_onesweep<0, 0, false, true>), GSX_SWEEP_ARGS(nullptr, d_n));
+                GSX_LAUNCH((k_radix_onesweep<0, 0, false, true>), GSX_SWEEP_ARGS(nullptr, d_n));
         } else if (first && buf.pairs_src) {
             if (last) GSX_SWEEP(2, 1); else GSX_SWEEP(2, 0);
         } else if (first && last) {

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void k_zero_words(uint32_t* __restrict__ a, ui
 
 hipError_t launch_zero_words(hipStream_t s, uint32_t* a, uint32_t na, uint32_t* b, uint32_t nb) {
     const uint32_t n = na > nb ? na : nb;
-    if (n) hipLaunchKernelGGL(k_zero_words, dim3((n + 255) / 256), dim3(256), 0, s, a, na, b, nb);
+    if (n) GSX_LAUNCH(k_zero_words, dim3((n + 255) / 256), dim3(256), 0, s, a, na, b, nb);
     return hipGetLastError();
 }
 
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(64) void k_spin(unsigned long long ticks, uint32_t*
 }
 
 hipError_t launch_spin(hipStream_t s, uint32_t microseconds) {
-    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, 100ull * microseconds, static_cast<uint32_t*>(nullptr));
+    GSX_LAUNCH(k_spin, dim3(1), dim3(64), 0, s, 100ull * microseconds, static_cast<uint32_t*>(nullptr));
     return hipGetLastError();
 }
 
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_validate_tiles(const uint2* __restrict_
 
 hipError_t launch_validate_tiles(hipStream_t s, const uint2* ranges, uint32_t n_tiles, const uint32_t* list, const uint32_t* d_entries,
                                  uint32_t capacity, uint32_t n_records, uint32_t* report) {
-    hipLaunchKernelGGL(k_validate_tiles, dim3((n_tiles + 255) / 256), dim3(256), 0, s, ranges, n_tiles, list, d_entries, capacity, n_records, report);
+    GSX_LAUNCH(k_validate_tiles, dim3((n_tiles + 255) / 256), dim3(256), 0, s, ranges, n_tiles, list, d_entries, capacity, n_records, report);
     return hipGetLastError();
 }
 
@@ -289,7 +289,7 @@ hipError_t launch_window_pyramid(hipStream_t s, const uint2* window, uint32_t ti
                                  bool min_of_starts, const uint32_t* d_skip, uint32_t* min_ends) {
     WindowPyramid p = window_pyramid_layout(tiles_x, tiles_y, data);
     p.min_of_starts = min_of_starts ? 1u : 0u;
-    hipLaunchKernelGGL(k_window_pyramid, dim3(1), dim3(1024), 0, s, window, p, data, d_skip, min_ends);
+    GSX_LAUNCH(k_window_pyramid, dim3(1), dim3(1024), 0, s, window, p, data, d_skip, min_ends);
     return hipGetLastError();
 }
 
@@ -298,7 +298,7 @@ hipError_t launch_spec_verify(hipStream_t s, const uint2* win1, const uint32_t* 
                               uint32_t* d_ticket, unsigned long long* host_verdict, uint32_t seq) {
     // *d_need and *d_ticket are zero here (the frame's counters are reset before the first slab)
     const uint32_t n_tiles = tiles_x * tiles_y;
-    hipLaunchKernelGGL(k_spec_verify, dim3((n_tiles + 255) / 256), dim3(256), 0, s, win1, done, row_words, tiles_x, n_tiles, win2,
+    GSX_LAUNCH(k_spec_verify, dim3((n_tiles + 255) / 256), dim3(256), 0, s, win1, done, row_words, tiles_x, n_tiles, win2,
                        need_bits, d_need, band_lo, band_hi, d_ticket, host_verdict, seq);
     return hipGetLastError();
 }
@@ -306,7 +306,7 @@ hipError_t launch_spec_verify(hipStream_t s, const uint2* win1, const uint32_t* 
 hipError_t launch_spec_next(hipStream_t s, const uint32_t* tile_sat, const uint32_t* done, const uint32_t* done_before,
                             uint32_t row_words, uint32_t tiles_x, uint32_t tiles_y, float margin, uint32_t radius, uint2* win_next,
                             uint32_t band_lo, uint32_t band_hi) {
-    hipLaunchKernelGGL(k_spec_next, dim3((tiles_x + kNextBlock - 1) / kNextBlock, (tiles_y + kNextBlock - 1) / kNextBlock), dim3(256), 0, s,
+    GSX_LAUNCH(k_spec_next, dim3((tiles_x + kNextBlock - 1) / kNextBlock, (tiles_y + kNextBlock - 1) / kNextBlock), dim3(256), 0, s,
                        tile_sat, done, done_before, row_words, tiles_x, tiles_y, 1.0f + margin, (int)std::min<uint32_t>(radius, kNextMaxR), win_next,
                        (int)std::min(band_lo, tiles_y), (int)std::min(band_hi, tiles_y));
     return hipGetLastError();

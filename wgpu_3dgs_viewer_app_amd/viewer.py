@@ -545,6 +545,12 @@ class MultiModelViewer:
         return off, lst[: st["n_tile_entries"]]
 
     # -- timing --
+    def launch_stats(self, reset: bool = False) -> dict:
+        """How this viewer's (and its lanes') kernel launches reached the device: ``gsx_launch_stats`` (csrc/gsx_launch.h)."""
+        ls = _lib.LaunchStats()
+        _lib.check(self._L.gsx_viewer_launch_stats(self._h, C.byref(ls), 1 if reset else 0))
+        return {n: int(getattr(ls, n)) for n, _ in ls._fields_}
+
     def set_pass_timing(self, enabled, passes=None) -> None:
         """``passes``: names from ``_lib.GSX_PASS_NAMES`` to bracket with events (default: all)."""
         code = 0
@@ -557,6 +563,17 @@ class MultiModelViewer:
         launches = (C.c_uint32 * _lib.GSX_PASS_COUNT)()
         _lib.check(self._L.gsx_get_pass_timing(self._h, ms, launches))
         return {n: dict(ms=float(ms[i]), launches=int(launches[i])) for i, n in enumerate(_lib.GSX_PASS_NAMES)}
+
+
+def set_launch_graphs(enabled) -> None:
+    """Process-wide: frame-level entry points submit their launches as cached HIP graphs while their stream is busy (True / 1, the
+    default), always (2: tests) or never (False / 0)."""
+    _lib.load().gsx_debug_set_launch_graphs(int(enabled))
+
+
+def launch_count() -> int:
+    """Kernel launches this process has asked libgsx for so far."""
+    return int(_lib.load().gsx_debug_launch_count())
 
 
 def render_keys_far_to_near(viewer_models_centers: dict, camera_pos) -> list:
