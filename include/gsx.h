@@ -349,10 +349,10 @@ gsx_status gsx_buffer_download(gsx_buffer* b, void* out, uint64_t n_elements);
  *      Pixels equal the single-GPU frame bit for bit whatever was predicted. ---- */
 #define GSX_RECORD_BYTES 48u /* mean.xy rect.xy | conic.abc opacity | rgb depth */
 typedef struct gsx_shard_layout_t {
-    uint32_t rows_per_rank, row_lo, row_hi; /* band of this rank: tile rows [row_lo, row_hi) */
-    uint64_t band_bytes;                    /* rows_per_rank * 16 * width * 16: what every rank contributes */
+    uint32_t rows_per_rank, row_lo, row_hi; /* tallest band of the layout; band of this rank: tile rows [row_lo, row_hi) */
+    uint64_t band_bytes;                    /* this rank's band: rows * 16 * width * 16 (equal bands: rows_per_rank rows for every rank) */
     uint64_t band_offset_bytes;             /* of this rank's band inside the framebuffer */
-    uint64_t padded_framebuffer_bytes;      /* world * band_bytes >= width * height * 16 */
+    uint64_t padded_framebuffer_bytes;      /* whole tile rows of every band >= width * height * 16 */
 } gsx_shard_layout_t;
 gsx_status gsx_shard_layout(gsx_viewer* v, uint32_t world, uint32_t rank, gsx_shard_layout_t* out);
 /* Screen-band rendering: this viewer composites only the tile rows [row_lo, row_hi) (clamped to the frame); Gaussians
@@ -495,6 +495,27 @@ typedef gsx_status (*gsx_comm_all_to_all_fn)(void* ctx, const void* d_send, void
 typedef gsx_status (*gsx_comm_all_gather_fn)(void* ctx, const void* d_send, void* d_recv, uint64_t bytes_per_rank, void* hip_stream);
 gsx_status gsx_viewer_comm_init_custom(gsx_viewer* v, uint32_t world, uint32_t rank, gsx_comm_all_to_all_fn all_to_all,
                                        gsx_comm_all_gather_fn all_gather, void* ctx);
+/* A transport that moves pieces of UNEQUAL size (arrays of `world` byte offsets / sizes; a size may be 0): what RCCL's grouped
+ * ncclSend / ncclRecv and the in-process group do.  all_to_all_v: send_bytes[p] bytes at d_send + send_offsets[p] go to rank p, what
+ * rank p sends lands at d_recv + recv_offsets[p] (recv_bytes[p] bytes: the ranks derive the sizes from gathered data, they agree).
+ * gather_v: this rank's send_bytes bytes to every rank (root < 0) or to `root` only; rank p's piece lands at d_recv + recv_offsets[p];
+ * d_send may be d_recv + recv_offsets[rank] (in place).  Both ENQUEUE on hip_stream and return 0 or a gsx_status.
+ * With such a transport gsx_shard_render_frame balances the bands by the previous frame's per-row work and sizes the exchange slots
+ * pair by pair; with the equal-piece functions of gsx_viewer_comm_init_custom the bands stay equal and the slots uniform. */
+typedef gsx_status (*gsx_comm_all_to_all_v_fn)(void* ctx, const void* d_send, const uint64_t* send_offsets, const uint64_t* send_bytes,
+                                               void* d_recv, const uint64_t* recv_offsets, const uint64_t* recv_bytes, void* hip_stream);
+typedef gsx_status (*gsx_comm_gather_v_fn)(void* ctx, const void* d_send, uint64_t send_bytes, void* d_recv, const uint64_t* recv_offsets,
+                                           const uint64_t* recv_bytes, int32_t root, void* hip_stream);
+gsx_status gsx_viewer_comm_init_custom_v(gsx_viewer* v, uint32_t world, uint32_t rank, gsx_comm_all_to_all_v_fn all_to_all_v,
+                                         gsx_comm_gather_v_fn gather_v, void* ctx);
+/* Band layout of the sharded frames: rank g owns the tile rows [edges[g], edges[g + 1]) (edges[0] = 0, edges[world] >= tiles_y, non-decreasing;
+ * a band may be empty).  gsx_shard_set_band_edges: these edges for every following frame and stage call (NULL: back to the
+ * library's own — equal bands, or, in gsx_shard_render_frame over a transport that moves unequal pieces, bands balanced by the previous
+ * frame's per-row work; gsx_shard_set_balance(0) keeps those equal too).  Every rank must set the same.  gsx_shard_get_band_edges: the
+ * layout the last sharded frame used. */
+gsx_status gsx_shard_set_band_edges(gsx_viewer* v, uint32_t world, const uint32_t* edges);
+gsx_status gsx_shard_get_band_edges(gsx_viewer* v, uint32_t world, uint32_t* out_edges);
+gsx_status gsx_shard_set_balance(gsx_viewer* v, uint32_t enabled);
 
 /* A caller with its own exchange policy (and the tests): per-tile limits the NEXT sharded frame of `key` uses instead of the ones
  * the last frame left (host or device memory, u32 per tile, 0xFFFFFFFF = unbounded; copied by the call), and a fixed round-0 slot size
@@ -510,6 +531,10 @@ typedef struct gsx_shard_stats {
     uint64_t wire_bytes;      /* bytes this rank sent to OTHER ranks: slots (fixed size, whatever they hold), feedback and band gathers */
     uint64_t verdict_wait_ns; /* host time spent waiting for verdicts */
     uint32_t last_slot_records, last_repair_slot_records;
+    uint32_t last_entries_sum, last_entries_max; /* list entries all ranks / the busiest rank binned in the last frame whose verdict was read
+                                                    (balance of the bands: max * world / sum) */
+    uint32_t last_work_permille, reserved0;      /* list entries the busiest rank's tiles WALKED x world x 1000 / all ranks': what the bands
+                                                    are balanced by (1000 = perfectly even) */
 } gsx_shard_stats;
 gsx_status gsx_shard_get_stats(gsx_viewer* v, gsx_shard_stats* out, uint32_t reset);
 /* Where a sharded frame's finished bands go.  root = -1 (default): an all-gather — after gsx_shard_render_frame every rank's

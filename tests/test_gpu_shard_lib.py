@@ -702,14 +702,14 @@ def test_bands_gathered_to_one_rank_over_the_group(world, root, lanes):
         for pose in POSES:
             _uniforms(v, pose)
             v.shard_render_frame("m", shard_max)
-            frames.append(v.download_framebuffer().copy())
+            fb = v.download_framebuffer().copy()
+            frames.append((fb, v.shard_get_band_edges(world).copy()))   # (the bands are balanced: the layout moves from frame to frame)
         v.close()
         return frames
 
-    rows = 16 * ((TILES[0] + world - 1) // world)
     for rank, frames in enumerate(run_group(world, body)):
-        lo, hi = (0, H) if rank == root else (min(rank * rows, H), min((rank + 1) * rows, H))
-        for k, fb in enumerate(frames):
+        for k, (fb, edges) in enumerate(frames):
+            lo, hi = (0, H) if rank == root else (min(16 * int(edges[rank]), H), min(16 * int(edges[rank + 1]), H))
             assert np.array_equal(fb[lo:hi], ref[k][lo:hi]), f"rank {rank} frame {k}"
 
     def disagree(rank, group):
@@ -722,6 +722,105 @@ def test_bands_gathered_to_one_rank_over_the_group(world, root, lanes):
         finally:
             v.close()
 
+    # the feedback all-gather carries every rank's root; the verdict says whether they agree, BEFORE any rank gathers (over RCCL a
+    # Send nobody receives would hang): every rank fails with the same message
     with pytest.raises(GsxError) as e:
         run_group(world, disagree, timeout_ms=2000)
-    assert e.value.status == _lib.GSX_ERR_RCCL
+    assert e.value.status == _lib.GSX_ERR_INVALID_ARG and "different gather roots" in str(e.value)
+
+
+# ---- band layout: balanced by the previous frame's per-row work (SURVEY 8e "load-balanced") ----
+def _open_sky_scene(n=30000):
+    """Everything below the horizon: the upper half of the screen stays empty — equal bands would leave the top ranks idle."""
+    g = common.small_scene(n, 93, scale_mul=14.0)
+    g["pos"][:, 1] = -np.abs(g["pos"][:, 1]) - 0.3
+    return g
+
+
+def test_bands_are_balanced_by_the_previous_frames_work():
+    world, size = 8, (640, 480)           # 40 x 30 tiles
+    g = _open_sky_scene()
+    poses = (10, 11, 12, 13, 14, 15, 16, 130, 131, 132)   # (a jump: the work moves, the edges follow)
+    ref = _single_frames(g, poses, size)
+
+    def body(rank, group):
+        v, shard_max = _rank_viewer(g, g.shape[0], rank, world, group)
+        frames, edges, stats = [], [], []
+        for pose in poses:
+            _uniforms(v, pose, size)
+            v.shard_render_frame("m", shard_max)
+            frames.append(v.download_framebuffer().copy())
+            edges.append(v.shard_get_band_edges(world).copy())
+            stats.append(v.shard_stats())
+        v.close()
+        return frames, edges, stats
+
+    res = run_group(world, body)
+    for rank, (frames, edges, stats) in enumerate(res):
+        for k, fb in enumerate(frames):
+            assert np.array_equal(fb, ref[k]), f"rank {rank} frame {k}: L-inf {np.abs(fb - ref[k]).max()}"
+        for k in range(len(poses)):
+            assert np.array_equal(edges[k], res[0][1][k]), "every rank derives the same edges"
+    edges = res[0][1]
+    assert np.array_equal(edges[0], np.arange(world + 1) * 4), "first frame: equal bands (nothing is known yet)"
+    assert any(not np.array_equal(edges[k], edges[k + 1]) for k in range(1, len(poses) - 1)), "the edges move with the work"
+    assert edges[-1][1] > 4, f"the empty sky must go to few ranks: {edges[-1]}"
+    stats = res[0][2]
+    work = [st["last_work_permille"] / 1000.0 for st in stats]            # busiest rank's walked entries / mean, frame by frame
+    entries = [st["last_entries_max"] * world / max(st["last_entries_sum"], 1) for st in stats]
+    print("edges", [e.tolist() for e in edges], "work max/mean", work, "entries max/mean", [round(x, 2) for x in entries])
+    # frame 0 ran on equal bands (its verdict is stats[0]); the steady frames on bands balanced by the frame before
+    assert work[0] > 1.5, f"equal bands on this scene: {work[0]}"
+    assert max(work[3:7]) <= 1.25, f"balanced bands: busiest rank / mean of the work = {work[3:7]}"
+    assert max(entries[3:7]) < entries[0], (entries[0], entries[3:7])
+
+
+@pytest.mark.parametrize("edges", [(0, 1, 1, 9, 10), (0, 0, 5, 5, 10), (0, 10, 10, 10, 10)])
+def test_forced_band_edges_with_empty_and_uneven_bands(edges):
+    world = 4
+    g = _scene()
+    ref = _single_frames(g)
+
+    def body(rank, group):
+        v, shard_max = _rank_viewer(g, N, rank, world, group)
+        v.shard_set_band_edges(world, np.array(edges, np.uint32))
+        frames = []
+        for pose in POSES:
+            _uniforms(v, pose)
+            v.shard_render_frame("m", shard_max)
+            frames.append(v.download_framebuffer().copy())
+        got = v.shard_get_band_edges(world)
+        v.close()
+        return frames, got
+
+    for rank, (frames, got) in enumerate(run_group(world, body)):
+        assert tuple(got) == edges
+        for k, fb in enumerate(frames):
+            assert np.array_equal(fb, ref[k]), f"rank {rank} frame {k}: L-inf {np.abs(fb - ref[k]).max()}"
+
+
+def test_balanced_bands_gathered_to_one_rank_with_frames_in_flight():
+    world, lanes, size = 4, 2, (640, 480)
+    g = _open_sky_scene(20000)
+    poses = tuple(range(20, 32))
+    ref = _single_frames(g, poses, size)
+
+    def body(rank, group):
+        v, shard_max = _rank_viewer(g, g.shape[0], rank, world, group, lanes=lanes)
+        v.shard_set_gather_root(1)
+        frames = []
+        for pose in poses:
+            _uniforms(v, pose, size)
+            v.shard_render_frame("m", shard_max)
+            if rank == 1:
+                frames.append(v.download_framebuffer().copy())
+            else:
+                v.poll()
+        edges = v.shard_get_band_edges(world)
+        v.close()
+        return frames, edges
+
+    res = run_group(world, body)
+    for k, fb in enumerate(res[1][0]):
+        assert np.array_equal(fb, ref[k]), f"root frame {k}: L-inf {np.abs(fb - ref[k]).max()}"
+    assert not np.array_equal(res[0][1], np.arange(world + 1) * 8), "balanced edges were in use"

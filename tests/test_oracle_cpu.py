@@ -286,7 +286,13 @@ def test_new_entry_points_reject_bad_arguments_without_a_device():
     assert L.gsx_shard_render_frame(None, None, 0, 1, 0.25, 3) == _lib.GSX_ERR_INVALID_ARG
     fn = _lib.COMM_FN(lambda *a: 0)
     assert L.gsx_viewer_comm_init_custom(None, 2, 0, fn, fn, None) == _lib.GSX_ERR_INVALID_ARG
-    assert C.sizeof(_lib.ShardStats) == 56
+    assert C.sizeof(_lib.ShardStats) == 72
+    fa, fg = _lib.COMM_A2A_V_FN(lambda *a: 0), _lib.COMM_GATHER_V_FN(lambda *a: 0)
+    assert L.gsx_viewer_comm_init_custom_v(None, 2, 0, fa, fg, None) == _lib.GSX_ERR_INVALID_ARG
+    e = (C.c_uint32 * 3)(0, 1, 2)
+    assert L.gsx_shard_set_band_edges(None, 2, e) == _lib.GSX_ERR_INVALID_ARG
+    assert L.gsx_shard_get_band_edges(None, 2, e) == _lib.GSX_ERR_INVALID_ARG
+    assert L.gsx_shard_set_balance(None, 1) == _lib.GSX_ERR_INVALID_ARG
     hdr = open(os.path.join(ROOT, "include", "gsx.h")).read()
     body = hdr[hdr.index("typedef struct gsx_shard_stats {"):hdr.index("} gsx_shard_stats;")]
     fields = re.findall(r"(\w+)\s*(?:,\s*(\w+))?;", re.sub(r"/\*.*?\*/", "", body, flags=re.S).split("{", 1)[1])

@@ -171,11 +171,15 @@ pub enum gsx_buffer_kind { Mask = 0, Edits = 1, Selection = 2 }
 /// the two collectives of a caller-supplied transport: they ENQUEUE on `hip_stream` and return 0 or a gsx_status
 pub type gsx_comm_all_to_all_fn = Option<unsafe extern "C" fn(ctx: *mut c_void, d_send: *const c_void, d_recv: *mut c_void, bytes_per_peer: u64, hip_stream: *mut c_void) -> gsx_status>;
 pub type gsx_comm_all_gather_fn = Option<unsafe extern "C" fn(ctx: *mut c_void, d_send: *const c_void, d_recv: *mut c_void, bytes_per_rank: u64, hip_stream: *mut c_void) -> gsx_status>;
+/// ... and of a transport that moves pieces of unequal size (arrays of `world` byte offsets / sizes)
+pub type gsx_comm_all_to_all_v_fn = Option<unsafe extern "C" fn(ctx: *mut c_void, d_send: *const c_void, send_offsets: *const u64, send_bytes: *const u64, d_recv: *mut c_void, recv_offsets: *const u64, recv_bytes: *const u64, hip_stream: *mut c_void) -> gsx_status>;
+pub type gsx_comm_gather_v_fn = Option<unsafe extern "C" fn(ctx: *mut c_void, d_send: *const c_void, send_bytes: u64, d_recv: *mut c_void, recv_offsets: *const u64, recv_bytes: *const u64, root: i32, hip_stream: *mut c_void) -> gsx_status>;
 #[repr(C)]
 #[derive(Clone, Copy, Default)]
 pub struct gsx_shard_stats {
     pub frames: u64, pub redo_frames: u64, pub repair_frames: u64, pub exchange_rounds: u64,
     pub wire_bytes: u64, pub verdict_wait_ns: u64, pub last_slot_records: u32, pub last_repair_slot_records: u32,
+    pub last_entries_sum: u32, pub last_entries_max: u32, pub last_work_permille: u32, pub reserved0: u32,
 }
 #[repr(C)]
 #[derive(Clone, Copy, Default)]

@@ -40,6 +40,7 @@ EXPORTS = (
     "gsx_model_download_selection", "gsx_model_download_edits", "gsx_model_upload_edits", "gsx_query_download_hits",
     "gsx_query_hit_pos_by_closest", "gsx_query_hit_pos_by_alpha_range",
     "gsx_debug_set_launch_graphs", "gsx_debug_launch_count", "gsx_viewer_launch_stats",
+    "gsx_viewer_comm_init_custom_v", "gsx_shard_set_band_edges", "gsx_shard_get_band_edges", "gsx_shard_set_balance",
 )
 
 
@@ -100,11 +101,17 @@ class ShardStats(C.Structure):
     """``gsx_shard_stats``."""
     _fields_ = [("frames", C.c_uint64), ("redo_frames", C.c_uint64), ("repair_frames", C.c_uint64), ("exchange_rounds", C.c_uint64),
                 ("wire_bytes", C.c_uint64), ("verdict_wait_ns", C.c_uint64), ("last_slot_records", C.c_uint32),
-                ("last_repair_slot_records", C.c_uint32)]
+                ("last_repair_slot_records", C.c_uint32), ("last_entries_sum", C.c_uint32), ("last_entries_max", C.c_uint32),
+                ("last_work_permille", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 #: gsx_comm_all_to_all_fn / gsx_comm_all_gather_fn: (ctx, d_send, d_recv, bytes, hip_stream) -> gsx_status
 COMM_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+#: gsx_comm_all_to_all_v_fn(ctx, d_send, send_offsets, send_bytes, d_recv, recv_offsets, recv_bytes, hip_stream)
+COMM_A2A_V_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64),
+                            C.POINTER(C.c_uint64), C.c_void_p)
+#: gsx_comm_gather_v_fn(ctx, d_send, send_bytes, d_recv, recv_offsets, recv_bytes, root, hip_stream)
+COMM_GATHER_V_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32, C.c_void_p)
 
 
 class GsxError(RuntimeError):
@@ -212,6 +219,10 @@ def load() -> C.CDLL:
         "gsx_comm_group_destroy": ([vp], None),
         "gsx_viewer_comm_init_group": ([vp, vp, u32], C.c_int32),
         "gsx_viewer_comm_init_custom": ([vp, u32, u32, COMM_FN, COMM_FN, vp], C.c_int32),
+        "gsx_viewer_comm_init_custom_v": ([vp, u32, u32, COMM_A2A_V_FN, COMM_GATHER_V_FN, vp], C.c_int32),
+        "gsx_shard_set_band_edges": ([vp, u32, u32p], C.c_int32),
+        "gsx_shard_get_band_edges": ([vp, u32, u32p], C.c_int32),
+        "gsx_shard_set_balance": ([vp, u32], C.c_int32),
         "gsx_shard_set_limits": ([vp, cp, vp], C.c_int32),
         "gsx_shard_set_slot_records": ([vp, cp, u32], C.c_int32),
         "gsx_shard_set_gather_root": ([vp, C.c_int32], C.c_int32),

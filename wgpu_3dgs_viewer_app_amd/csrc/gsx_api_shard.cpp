@@ -12,13 +12,15 @@ extern "C" {
 
 gsx_status gsx_shard_layout(gsx_viewer* v, uint32_t world, uint32_t rank, gsx_shard_layout_t* out) {
     if (!v || !out || world == 0 || world > 64 || rank >= world) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_layout: bad argument");
-    const uint32_t tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE, rpr = rows_per_rank(v, world);
-    out->rows_per_rank = rpr;
-    out->row_lo = std::min(rank * rpr, tiles_y);
-    out->row_hi = std::min((rank + 1) * rpr, tiles_y);
-    out->band_bytes = (uint64_t)rpr * GSX_TILE * v->width * sizeof(float4);
-    out->band_offset_bytes = (uint64_t)rank * out->band_bytes;
-    out->padded_framebuffer_bytes = (uint64_t)world * out->band_bytes;
+    const uint32_t tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
+    const BandEdges b = bands_of(v, world);
+    const uint64_t row_bytes = (uint64_t)GSX_TILE * v->width * sizeof(float4);
+    out->rows_per_rank = band_rows_max(b);  // (equal bands: what it always was)
+    out->row_lo = std::min(b.e[rank], tiles_y);
+    out->row_hi = std::min(b.e[rank + 1], tiles_y);
+    out->band_bytes = (uint64_t)(b.e[rank + 1] - b.e[rank]) * row_bytes;
+    out->band_offset_bytes = (uint64_t)b.e[rank] * row_bytes;
+    out->padded_framebuffer_bytes = (uint64_t)std::max(b.e[world], tiles_y) * row_bytes;
     return GSX_OK;
 }
 
@@ -58,7 +60,8 @@ gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, const 
     const uint32_t n = (uint32_t)m->n;
     const bool from_list = !d_tile_window && m->shard_win_set && m->cand_valid;
     const uint32_t rounds = pack_rounds(from_list), tile = 256u * rounds;
-    const uint32_t nb = (uint32_t)pack_blocks(n, rounds), rpr = rows_per_rank(v, world);
+    const uint32_t nb = (uint32_t)pack_blocks(n, rounds);
+    const BandEdges bands = bands_of(v, world);
     const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE;
     HIPCHK(m->pack_table.ensure(4 * ((size_t)64 * std::max(nb, 1u) + 64)));
     HIPCHK(m->pack_masks.ensure(8 * (size_t)std::max(n, 1u)));
@@ -89,7 +92,7 @@ gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, const 
     uint32_t* totals = table + (size_t)64 * std::max(nb, 1u);
     unsigned long long* masks = m->pack_masks.as<unsigned long long>();
     HIPCHK(gsx::op::MemsetAsync(totals, 0, 4 * 64, v->stream));
-    HIPCHK(launch_pack_count(v->stream, m->proj_rec(), n, world, rpr, window, tiles_x, masks, table, list, d_list_n, travellers, trav_counts));
+    HIPCHK(launch_pack_count(v->stream, m->proj_rec(), n, bands, window, tiles_x, masks, table, list, d_list_n, travellers, trav_counts));
     if (nb) HIPCHK(launch_rowscan(v->stream, table, world, nb, totals, d_list_n, tile));
     if (travellers && nb) {
         // shade the travellers the first round did not: compact their indices, k_shade skips what is shaded already
@@ -158,9 +161,11 @@ gsx_status gsx_shard_import(gsx_viewer* v, const char* key, const void* d_recv, 
     m->stats_pending = true;
     m->rec_n = n_records;
     m->use_imported = true;
-    const uint32_t rpr = rows_per_rank(v, world);
-    m->row_lo = rank * rpr;
-    m->row_hi = (rank + 1) * rpr;
+    {
+        const BandEdges b = bands_of(v, world);
+        m->row_lo = b.e[rank];
+        m->row_hi = b.e[rank + 1];
+    }
     m->has_window = d_tile_window != nullptr;
     m->window_ptr = nullptr;
     m->import_min_ends = nullptr;
@@ -172,30 +177,10 @@ gsx_status gsx_shard_import(gsx_viewer* v, const char* key, const void* d_recv, 
     return GSX_OK;
 }
 
-// this rank's band of the per-tile saturation keys; rows below the frame read 0 (= open)
-// ... followed by kShardExtraWords statistics words (the all-gather that verifies the frame also tells every rank how large
-// the slots have to be and whether one was too small)
-// done_before (nullable; layered models): the tiles nearer models had saturated before this model was composited.  They say
-// nothing about THIS model's depths: reported as saturated at the smallest depth key, so that the model's next limit there
-// is whatever its neighbourhood needs and nothing more (the single-GPU rule, k_spec_next).
-__global__ void k_shard_feedback(const uint32_t* __restrict__ tile_sat, uint32_t tiles_x, uint32_t tiles_y, uint32_t row_lo,
-                                 uint32_t n_words, uint32_t* __restrict__ out, const SlabStats* __restrict__ stats,
-                                 const uint32_t* __restrict__ done_before, uint32_t row_words) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_words + kShardExtraWords) return;
-    if (i >= n_words) {  // round 0's figures: what this rank wanted to send to its busiest destination, and whether the slot held it
-        out[i] = i - n_words == 0u ? stats->slot_max[0] : (i - n_words == 1u ? stats->slot_over[0] : 0u);
-        return;
-    }
-    const uint32_t ty = row_lo + i / tiles_x, tx = i % tiles_x;
-    uint32_t s = ty < tiles_y ? tile_sat[ty * tiles_x + tx] : 0u;
-    if (done_before && ty < tiles_y && ((done_before[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)) s = 1u;
-    out[i] = s;
-}
-
 gsx_status gsx_shard_feedback_words(gsx_viewer* v, uint32_t world, uint32_t* out_words) {
     if (!v || !out_words || world == 0 || world > 64) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_feedback_words: bad argument");
-    *out_words = rows_per_rank(v, world) * ((v->width + GSX_TILE - 1) / GSX_TILE) + kShardExtraWords;
+    // the common stride of the gathered pieces (gsx_internal.h, feedback_*): statistics + the tallest band's keys + its rows' work
+    *out_words = feedback_stride(bands_of(v, world), (v->width + GSX_TILE - 1) / GSX_TILE);
     return GSX_OK;
 }
 
@@ -208,12 +193,13 @@ gsx_status gsx_shard_feedback(gsx_viewer* v, const char* key, uint32_t world, ui
     if (!v->options.progressive) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_feedback needs gsx_render_options.progressive = 1");
     if (world == 0 || world > 64 || rank >= world) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_feedback: bad world/rank %u/%u", world, rank);
     const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
-    const uint32_t row_words = (tiles_x + 31) / 32, rpr = rows_per_rank(v, world), n_words = rpr * tiles_x;
+    const uint32_t row_words = (tiles_x + 31) / 32;
     const uint32_t* tile_sat = v->done_bits.as<uint32_t>() + 1 + (size_t)row_words * tiles_y;
-    GSX_LAUNCH(k_shard_feedback, dim3((n_words + kShardExtraWords + 255) / 256), dim3(256), 0, v->stream, tile_sat, tiles_x, tiles_y,
-                       rank * rpr, n_words, static_cast<uint32_t*>(d_out_u32), m->counters.as<Counters>(),
-                       m->shard_behind ? m->spec_done_before.as<uint32_t>() : nullptr, row_words);
-    HIPCHK(hipGetLastError());
+    const uint32_t* row_work = tile_sat + (size_t)tiles_x * tiles_y;  // (do_render: behind the saturation keys)
+    const gsx_viewer* o = v->parent ? v->parent : v;
+    HIPCHK(launch_shard_feedback(v->stream, tile_sat, row_work, tiles_x, tiles_y, bands_of(v, world), rank, static_cast<uint32_t*>(d_out_u32),
+                                 m->counters.as<Counters>(), m->shard_behind ? m->spec_done_before.as<uint32_t>() : nullptr, row_words,
+                                 (uint32_t)(o->shard_gather_root + 1)));
     return GSX_OK;
 }
 
@@ -258,7 +244,7 @@ gsx_status pack_count(gsx_viewer* v, Model* m, uint32_t world, const uint2* expl
     const uint32_t n = (uint32_t)m->n;
     m->pack_list = !explicit_window && m->shard_win_set && m->cand_valid;
     m->pack_rounds = pack_rounds(m->pack_list);
-    const uint32_t nb = (uint32_t)pack_blocks(n, m->pack_rounds), rpr = rows_per_rank(v, world);
+    const uint32_t nb = (uint32_t)pack_blocks(n, m->pack_rounds);
     const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE;
     HIPCHK(m->pack_table.ensure(4 * ((size_t)64 * std::max(nb, 1u) + 64)));
     HIPCHK(m->pack_masks.ensure(8 * (size_t)std::max(n, 1u)));
@@ -289,7 +275,7 @@ gsx_status pack_count(gsx_viewer* v, Model* m, uint32_t world, const uint2* expl
     uint32_t* table = m->pack_table.as<uint32_t>();
     uint32_t* totals = table + (size_t)64 * std::max(nb, 1u);
     HIPCHK(launch_zero_words(v->stream, totals, 64, nullptr, 0));
-    HIPCHK(launch_pack_count(v->stream, m->proj_rec(), n, world, rpr, window, tiles_x, m->pack_masks.as<unsigned long long>(), table, list, d_list_n,
+    HIPCHK(launch_pack_count(v->stream, m->proj_rec(), n, bands_of(v, world), window, tiles_x, m->pack_masks.as<unsigned long long>(), table, list, d_list_n,
                              travellers, trav_counts, gate, (tiles_x + 31) / 32, window ? pyramid : nullptr));
     if (nb) HIPCHK(launch_rowscan(v->stream, table, world, nb, totals, d_list_n, 256u * m->pack_rounds));
     return GSX_OK;
@@ -333,8 +319,8 @@ gsx_status repair_pack_count(gsx_viewer* v, Model* m, uint32_t world) {
 
 gsx_status ensure_verdict(gsx_viewer* v) {
     if (!v->h_shard_verdict) {
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&v->h_shard_verdict), 64, hipHostMallocDefault));
-        v->h_shard_verdict[0] = v->h_shard_verdict[1] = 0;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&v->h_shard_verdict), 4 * (size_t)kVerdictWords, hipHostMallocDefault));
+        memset(v->h_shard_verdict, 0, 4 * (size_t)kVerdictWords);
     }
     return GSX_OK;
 }
@@ -457,9 +443,11 @@ gsx_status gsx_shard_import_slots(gsx_viewer* v, const char* key, const void* d_
     m->stats_pending = true;
     m->rec_n = cap;  // an upper bound: the count is on the device (Counters::n_sorted)
     m->use_imported = true;
-    const uint32_t rpr = rows_per_rank(v, world);
-    m->row_lo = rank * rpr;
-    m->row_hi = (rank + 1) * rpr;
+    {
+        const BandEdges b = bands_of(v, world);
+        m->row_lo = b.e[rank];
+        m->row_hi = b.e[rank + 1];
+    }
     // the receiving side of the pack predicate: a tile bins exactly the records its window admits
     const uint2* win = round == 0 ? (m->shard_frame_limited ? m->shard_win.as<uint2>() : nullptr) : m->shard_win2.as<uint2>();
     m->has_window = win != nullptr;
@@ -497,9 +485,10 @@ gsx_status gsx_shard_verify(gsx_viewer* v, const char* key, uint32_t world, cons
     Counters* dc = m->counters.as<Counters>();
     HIPCHK(launch_zero_words(v->stream, &dc->shard_need, 2, m->shard_need_bits.as<uint32_t>(), ((tiles_x + 31) / 32) * tiles_y));  // shard_need + shard_ticket | bitmap
     *out_seq = ++v->shard_seq;
+    const gsx_viewer* o = v->parent ? v->parent : v;
     HIPCHK(launch_shard_verify(v->stream, m->shard_frame_limited ? m->shard_limit.as<uint32_t>() : nullptr, static_cast<const uint32_t*>(d_sat_all),
-                               tiles_x, tiles_y, rows_per_rank(v, world), world, m->shard_win2.as<uint2>(), &dc->shard_need, &dc->shard_ticket,
-                               v->h_shard_verdict, *out_seq, m->shard_need_bits.as<uint32_t>()));
+                               tiles_x, tiles_y, bands_of(v, world), m->shard_win2.as<uint2>(), &dc->shard_need, &dc->shard_ticket,
+                               v->h_shard_verdict, *out_seq, m->shard_need_bits.as<uint32_t>(), o->shard_balance ? 1u : 0u));
     m->repair_counted = false;
     m->stats_pending = true;
     return GSX_OK;
@@ -549,7 +538,7 @@ gsx_status gsx_shard_next_windows(gsx_viewer* v, const char* key, uint32_t world
     DevBuf& next = m->shard_limit_next;
     HIPCHK(next.ensure(4 * (size_t)tiles_x * tiles_y));
     HIPCHK(launch_shard_next_limits(v->stream, static_cast<const uint32_t*>(d_sat_all), tiles_x, tiles_y, margin, radius, next.as<uint32_t>(),
-                                    rows_per_rank(v, world)));
+                                    bands_of(v, world)));
     m->shard_next_valid = true;
     m->shard_limit_tx = tiles_x;
     m->shard_limit_ty = tiles_y;
@@ -610,8 +599,51 @@ gsx_status gsx_shard_set_gather_root(gsx_viewer* v, int32_t root) {
     gsx_status st = viewer_bind(v);  // (finishes the sharded frames in flight: they were promised the old destination)
     if (st) return st;
     if (v->parent) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_set_gather_root: called on a lane");
-    if (root < -1 || root >= 64) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_set_gather_root: root %d (-1 = every rank, else a rank)", (int)root);
+    if (root < -1 || root >= 64 || (v->comm_world && root >= (int32_t)v->comm_world))
+        return fail(GSX_ERR_INVALID_ARG, "gsx_shard_set_gather_root: root %d (-1 = every rank, else a rank of the %u)", (int)root, v->comm_world);
     v->shard_gather_root = root;
+    v->shard_root_confirmed = false;  // the next frame's verdict tells whether every rank named the same root; it gathers only then
+    return GSX_OK;
+}
+
+gsx_status gsx_shard_set_band_edges(gsx_viewer* v, uint32_t world, const uint32_t* edges) {
+    gsx_status st = viewer_bind(v);  // (frames in flight keep the layout they were enqueued with)
+    if (st) return st;
+    if (v->parent) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_set_band_edges: called on a lane");
+    if (!edges) {
+        v->band_edges_forced.clear();
+        v->band_edges.clear();
+        return GSX_OK;
+    }
+    if (world == 0 || world > 64) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_set_band_edges: world must be 1..64");
+    const uint32_t tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
+    if (edges[0] != 0 || edges[world] < tiles_y || edges[world] > 0xFFFFu)
+        return fail(GSX_ERR_INVALID_ARG, "gsx_shard_set_band_edges: edges[0] must be 0 and edges[world] = %u must cover the %u tile rows", edges[world], tiles_y);
+    for (uint32_t g = 0; g < world; ++g)
+        if (edges[g] > edges[g + 1]) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_set_band_edges: edges must not decrease (edge %u)", g + 1);
+    v->band_edges_forced.assign(edges, edges + world + 1);
+    v->band_edges = v->band_edges_forced;  // the stage calls read the viewer's layout
+    return GSX_OK;
+}
+
+gsx_status gsx_shard_get_band_edges(gsx_viewer* v, uint32_t world, uint32_t* out_edges) {
+    if (!v || !out_edges || world == 0 || world > 64) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_get_band_edges: bad argument");
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    if (v->last_edges.size() == (size_t)world + 1u) {
+        for (uint32_t g = 0; g <= world; ++g) out_edges[g] = v->last_edges[g];
+    } else {
+        const BandEdges b = bands_of(v, world);
+        for (uint32_t g = 0; g <= world; ++g) out_edges[g] = b.e[g];
+    }
+    return GSX_OK;
+}
+
+gsx_status gsx_shard_set_balance(gsx_viewer* v, uint32_t enabled) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    if (v->parent) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_set_balance: called on a lane");
+    v->shard_balance = enabled != 0;
     return GSX_OK;
 }
 

@@ -182,6 +182,21 @@ gsx_status gsx_viewer_comm_init_custom(gsx_viewer* v, uint32_t world, uint32_t r
     return GSX_OK;
 }
 
+gsx_status gsx_viewer_comm_init_custom_v(gsx_viewer* v, uint32_t world, uint32_t rank, gsx_comm_all_to_all_v_fn all_to_all_v,
+                                         gsx_comm_gather_v_fn gather_v, void* ctx) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    if (!all_to_all_v || !gather_v || world == 0 || world > 64 || rank >= world)
+        return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_comm_init_custom_v: null function or bad world/rank %u/%u", world, rank);
+    if (has_comm(v)) return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_comm_init_custom_v: this viewer already has a communicator");
+    v->comm_a2a_v_fn = all_to_all_v;
+    v->comm_gather_v_fn = gather_v;
+    v->comm_ctx = ctx;
+    v->comm_world = world;
+    v->comm_rank = rank;
+    return GSX_OK;
+}
+
 gsx_status gsx_viewer_comm_destroy(gsx_viewer* v) {
     if (!v) return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_comm_destroy: viewer is null");
     if (!has_comm(v)) return GSX_OK;
@@ -190,10 +205,12 @@ gsx_status gsx_viewer_comm_destroy(gsx_viewer* v) {
     for (gsx_viewer* l : v->lanes) (void)gsx::op::StreamSynchronize(l->stream);
     (void)gsx::op::StreamSynchronize(v->stream);
     v->comm_world = 0;
-    if (v->comm_a2a_fn) {
+    if (v->comm_a2a_fn || v->comm_a2a_v_fn) {
         if (v->comm_group) group_leave(v);
         v->comm_a2a_fn = nullptr;
         v->comm_ag_fn = nullptr;
+        v->comm_a2a_v_fn = nullptr;
+        v->comm_gather_v_fn = nullptr;
         v->comm_ctx = nullptr;
         return GSX_OK;
     }
@@ -213,6 +230,14 @@ gsx_status gsx_comm_all_to_all(gsx_viewer* v, const void* d_send, void* d_recv, 
     if (!has_comm(o)) return fail(GSX_ERR_RCCL, "gsx_comm_all_to_all: no communicator (gsx_viewer_comm_init)");
     if (!d_send || !d_recv) return fail(GSX_ERR_INVALID_ARG, "gsx_comm_all_to_all: null buffer");
     if (bytes_per_peer == 0) return GSX_OK;
+    if (!o->comm && !o->comm_a2a_fn) {  // a transport of unequal pieces only: equal ones are a case of those
+        PeerSpans sp{};
+        for (uint32_t p = 0; p < o->comm_world; ++p) {
+            sp.off[p] = (uint64_t)p * bytes_per_peer;
+            sp.bytes[p] = bytes_per_peer;
+        }
+        return comm_all_to_all_v(v, d_send, sp, d_recv, sp);
+    }
     o->shard_stats.wire_bytes += (uint64_t)(o->comm_world - 1u) * bytes_per_peer;
     if (o->comm_a2a_fn) {  // the caller's transport (or the in-process group): the whole exchange, own slot included
         g_err.clear();
@@ -232,6 +257,7 @@ gsx_status gsx_comm_all_to_all(gsx_viewer* v, const void* d_send, void* d_recv, 
     }
     ncclComm_t comm = comm_of(v);
     if (!comm) return fail(GSX_ERR_RCCL, "gsx_comm_all_to_all: lane %u has no communicator", v->lane_index);
+    trace_flush();  // (RCCL enqueues on the stream itself)
     RCCLCHK(g_rccl.GroupStart());
     RcclGroup grp;
     for (uint32_t p = 0; p < o->comm_world; ++p) {
@@ -249,6 +275,14 @@ gsx_status gsx_comm_all_gather(gsx_viewer* v, const void* d_send, void* d_recv, 
     if (!has_comm(o)) return fail(GSX_ERR_RCCL, "gsx_comm_all_gather: no communicator (gsx_viewer_comm_init)");
     if (!d_send || !d_recv) return fail(GSX_ERR_INVALID_ARG, "gsx_comm_all_gather: null buffer");
     if (bytes_per_rank == 0) return GSX_OK;
+    if (!o->comm && !o->comm_ag_fn) {
+        PeerSpans sp{};
+        for (uint32_t p = 0; p < o->comm_world; ++p) {
+            sp.off[p] = (uint64_t)p * bytes_per_rank;
+            sp.bytes[p] = bytes_per_rank;
+        }
+        return comm_gather_v(v, d_send, bytes_per_rank, d_recv, sp, -1);
+    }
     o->shard_stats.wire_bytes += (uint64_t)(o->comm_world - 1u) * bytes_per_rank;
     if (o->comm_ag_fn) {
         g_err.clear();
@@ -262,39 +296,91 @@ gsx_status gsx_comm_all_gather(gsx_viewer* v, const void* d_send, void* d_recv, 
     }
     ncclComm_t comm = comm_of(v);
     if (!comm) return fail(GSX_ERR_RCCL, "gsx_comm_all_gather: lane %u has no communicator", v->lane_index);
+    trace_flush();
     RCCLCHK(g_rccl.AllGather(d_send, d_recv, bytes_per_rank, kNcclChar, comm, v->stream));
     return GSX_OK;
 }
 
 }  // extern "C"
 
-// The bands of a frame to ONE rank: everybody else sends its piece, the root receives world - 1 of them side by side (its own
-// is in place already, or copied on the device).  Transports without point-to-point calls fall back to their all-gather.
-gsx_status gsx::comm_gather_to_root(gsx_viewer* v, const void* d_send, void* d_recv, uint64_t bytes_per_rank, uint32_t root) {
+// ---- pieces of unequal size: balanced bands, slots sized pair by pair (gsx_shard_frame.cpp) ----
+// Over RCCL both are grouped ncclSend / ncclRecv — point-to-point, every xGMI link of the GPU busy at once, each message as long
+// as its piece; what a rank keeps for itself is a device copy beside the exchange.
+gsx_status gsx::comm_all_to_all_v(gsx_viewer* v, const void* d_send, const PeerSpans& snd, void* d_recv, const PeerSpans& rcv) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
     gsx_viewer* o = owner_of(v);
-    if (!has_comm(o)) return fail(GSX_ERR_RCCL, "gather to root: no communicator (gsx_viewer_comm_init)");
-    if (root >= o->comm_world) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_set_gather_root: root %u of %u ranks", root, o->comm_world);
-    if (o->comm_group && o->comm_world > 1) {  // the in-process group: the root copies the pieces, nobody else receives
-        gsx_status bst = viewer_bind(v);
-        if (bst) return bst;
-        if (o->comm_rank != root) o->shard_stats.wire_bytes += bytes_per_rank;
-        return bytes_per_rank ? group_gather_to_root(o, d_send, d_recv, bytes_per_rank, root, v->stream) : GSX_OK;
-    }
-    if (o->comm_ag_fn || (o->comm_world == 1 && !o->comm_self_via_rccl)) return gsx_comm_all_gather(v, d_send, d_recv, bytes_per_rank);
-    if (bytes_per_rank == 0) return GSX_OK;
-    ncclComm_t comm = comm_of(v);
-    if (!comm) return fail(GSX_ERR_RCCL, "gather to root: lane %u has no communicator", v->lane_index);
-    if (o->comm_rank != root) {
-        o->shard_stats.wire_bytes += bytes_per_rank;
-        RCCLCHK(g_rccl.Send(d_send, bytes_per_rank, kNcclChar, (int)root, comm, v->stream));
+    if (!has_comm(o)) return fail(GSX_ERR_RCCL, "all-to-all: no communicator (gsx_viewer_comm_init)");
+    if (!d_send || !d_recv) return fail(GSX_ERR_INVALID_ARG, "all-to-all: null buffer");
+    const uint32_t world = o->comm_world, me = o->comm_rank;
+    for (uint32_t p = 0; p < world; ++p)
+        if (p != me) o->shard_stats.wire_bytes += snd.bytes[p];
+    if (o->comm_a2a_v_fn) {
+        g_err.clear();
+        if ((st = o->comm_a2a_v_fn(o->comm_ctx, d_send, snd.off, snd.bytes, d_recv, rcv.off, rcv.bytes, v->stream)))
+            return g_err.empty() ? fail(st, "all-to-all: the custom transport failed with status %d", (int)st) : st;
         return GSX_OK;
     }
-    char* own = static_cast<char*>(d_recv) + (size_t)root * bytes_per_rank;
-    if (own != d_send) HIPCHK(gsx::op::MemcpyAsync(own, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, v->stream));
+    if (!o->comm) return fail(GSX_ERR_UNSUPPORTED, "all-to-all of unequal slots: this transport moves equal pieces only (gsx_viewer_comm_init_custom_v)");
+    const bool bypass = !o->comm_self_via_rccl;
+    if (bypass) {
+        if (snd.bytes[me] != rcv.bytes[me]) return fail(GSX_ERR_INVALID_ARG, "all-to-all: own slot of %llu bytes sent, %llu expected", (unsigned long long)snd.bytes[me], (unsigned long long)rcv.bytes[me]);
+        if (snd.bytes[me])
+            HIPCHK(gsx::op::MemcpyAsync(static_cast<char*>(d_recv) + rcv.off[me], static_cast<const char*>(d_send) + snd.off[me], snd.bytes[me], hipMemcpyDeviceToDevice, v->stream));
+        if (world == 1) return GSX_OK;
+    }
+    ncclComm_t comm = comm_of(v);
+    if (!comm) return fail(GSX_ERR_RCCL, "all-to-all: lane %u has no communicator", v->lane_index);
+    trace_flush();
     RCCLCHK(g_rccl.GroupStart());
     RcclGroup grp;
-    for (uint32_t p = 0; p < o->comm_world; ++p)
-        if (p != root) GROUPED(grp, g_rccl.Recv(static_cast<char*>(d_recv) + (size_t)p * bytes_per_rank, bytes_per_rank, kNcclChar, (int)p, comm, v->stream));
+    for (uint32_t p = 0; p < world; ++p) {
+        if (bypass && p == me) continue;
+        if (snd.bytes[p]) GROUPED(grp, g_rccl.Send(static_cast<const char*>(d_send) + snd.off[p], snd.bytes[p], kNcclChar, (int)p, comm, v->stream));
+        if (rcv.bytes[p]) GROUPED(grp, g_rccl.Recv(static_cast<char*>(d_recv) + rcv.off[p], rcv.bytes[p], kNcclChar, (int)p, comm, v->stream));
+    }
+    return group_end(grp);
+}
+
+gsx_status gsx::comm_gather_v(gsx_viewer* v, const void* d_send, uint64_t send_bytes, void* d_recv, const PeerSpans& rcv, int32_t root) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    gsx_viewer* o = owner_of(v);
+    if (!has_comm(o)) return fail(GSX_ERR_RCCL, "gather: no communicator (gsx_viewer_comm_init)");
+    if (!d_send || !d_recv) return fail(GSX_ERR_INVALID_ARG, "gather: null buffer");
+    const uint32_t world = o->comm_world, me = o->comm_rank;
+    if (root >= (int32_t)world) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_set_gather_root: root %d of %u ranks", (int)root, world);
+    if (rcv.bytes[me] != send_bytes) return fail(GSX_ERR_INVALID_ARG, "gather: own piece of %llu bytes sent, %llu expected", (unsigned long long)send_bytes, (unsigned long long)rcv.bytes[me]);
+    o->shard_stats.wire_bytes += root < 0 ? (uint64_t)(world - 1u) * send_bytes : ((uint32_t)root == me ? 0u : send_bytes);
+    if (o->comm_gather_v_fn) {
+        g_err.clear();
+        if ((st = o->comm_gather_v_fn(o->comm_ctx, d_send, send_bytes, d_recv, rcv.off, rcv.bytes, root, v->stream)))
+            return g_err.empty() ? fail(st, "gather: the custom transport failed with status %d", (int)st) : st;
+        return GSX_OK;
+    }
+    if (!o->comm) {  // equal pieces only: the transport's all-gather, when the pieces happen to be equal and in rank order
+        for (uint32_t p = 0; p < world; ++p)
+            if (rcv.bytes[p] != send_bytes || rcv.off[p] != (uint64_t)p * send_bytes)
+                return fail(GSX_ERR_UNSUPPORTED, "gather of unequal pieces: this transport moves equal pieces only (gsx_viewer_comm_init_custom_v)");
+        o->shard_stats.wire_bytes -= root < 0 ? (uint64_t)(world - 1u) * send_bytes : ((uint32_t)root == me ? 0u : send_bytes);  // (counted by the call below)
+        return gsx_comm_all_gather(v, d_send, d_recv, send_bytes);
+    }
+    char* own = static_cast<char*>(d_recv) + rcv.off[me];
+    const bool receives = root < 0 || (uint32_t)root == me;
+    const bool self_copy = !o->comm_self_via_rccl || root >= 0;
+    if (receives && self_copy && own != d_send && send_bytes) HIPCHK(gsx::op::MemcpyAsync(own, d_send, send_bytes, hipMemcpyDeviceToDevice, v->stream));
+    if (world == 1 && self_copy) return GSX_OK;
+    ncclComm_t comm = comm_of(v);
+    if (!comm) return fail(GSX_ERR_RCCL, "gather: lane %u has no communicator", v->lane_index);
+    trace_flush();
+    RCCLCHK(g_rccl.GroupStart());
+    RcclGroup grp;
+    for (uint32_t p = 0; p < world; ++p) {
+        if (p == me && self_copy) continue;
+        const bool p_receives = root < 0 || (uint32_t)root == p;
+        if (p_receives && send_bytes) GROUPED(grp, g_rccl.Send(d_send, send_bytes, kNcclChar, (int)p, comm, v->stream));
+        if (receives && rcv.bytes[p]) GROUPED(grp, g_rccl.Recv(static_cast<char*>(d_recv) + rcv.off[p], rcv.bytes[p], kNcclChar, (int)p, comm, v->stream));
+    }
     return group_end(grp);
 }
 
@@ -315,6 +401,7 @@ gsx_status gsx::comm_ensure_lanes(gsx_viewer* v, uint32_t lanes) {
             RCCLCHK(g_rccl.GetUniqueId(&uid));
             HIPCHK(gsx::op::MemcpyAsync(v->scratch.p, uid.internal, 128, hipMemcpyHostToDevice, v->stream));
         }
+        trace_flush();
         RCCLCHK(g_rccl.Broadcast(v->scratch.p, v->scratch.p, 128, kNcclChar, 0, static_cast<ncclComm_t>(v->comm), v->stream));
         HIPCHK(gsx::op::MemcpyAsync(uid.internal, v->scratch.p, 128, hipMemcpyDeviceToHost, v->stream));
         HIPCHK(gsx::op::StreamSynchronize(v->stream));

@@ -2,14 +2,14 @@
 // GPU (or, in the tests, several viewers on ONE GPU), the two collectives of the sharded frame as device-to-device copies
 // ordered by HIP events.  No reference counterpart (src/main.rs:85-98: one wgpu device); a single-process host like the egui
 // app would drive its GPUs this way, and it is how tests/test_gpu_shard_lib.py runs gsx_shard_render_frame's own control flow
-// with 2 ... 8 ranks on a one-GPU box.  Implemented on the custom-transport interface of include/gsx.h (two functions that
-// enqueue on a stream), like any transport a caller could bring.
+// with 2 ... 8 ranks on a one-GPU box.  Implemented on the custom-transport interface of include/gsx.h for pieces of unequal size
+// (gsx_viewer_comm_init_custom_v: two functions that enqueue on a stream), like any transport a caller could bring.
 //
 // Frames in flight: a viewer and its lanes share one seat; the host issues their collectives one after the other (one thread),
 // each on the stream of the lane whose frame it serves, so frames on different lanes overlap on the device.
 //
 // A collective, seen from rank r (every rank runs the same sequence, gsx_comm.cpp guarantees one order of collectives):
-//   record `ready` on r's stream, publish {send, recv, bytes}          -- what r contributes exists once `ready` fires
+//   record `ready` on r's stream, publish {send, per-peer spans}       -- what r contributes exists once `ready` fires
 //   host rendezvous A                                                  -- everybody has published; sizes are compared
 //   for every source p, in rank order: wait for p's `ready`, copy p's piece for r into r's receive buffer   (on r's stream)
 //   record `done` on r's stream; host rendezvous B; wait for every peer's `done` (the event handles are read BEFORE B)
@@ -26,7 +26,7 @@
 
 namespace {
 
-enum Op : int { OP_NONE = 0, OP_ALL_TO_ALL = 1, OP_ALL_GATHER = 2, OP_GATHER = 3 /* + root << 8 */ };
+enum Op : int { OP_NONE = 0, OP_ALL_TO_ALL = 1, OP_GATHER = 2 /* + (root + 1) << 8: 0 = every rank receives */ };
 
 struct Seat {
     gsx_comm_group* group = nullptr;
@@ -38,8 +38,7 @@ struct Seat {
     // published for the collective in flight
     hipEvent_t ready = nullptr, done = nullptr;
     const char* send = nullptr;
-    char* recv = nullptr;
-    uint64_t bytes = 0;
+    uint64_t send_off[64]{}, send_bytes[64]{};  // what this rank has for every peer (a gather: the same piece for everybody)
     int op = OP_NONE;
 };
 
@@ -91,11 +90,15 @@ gsx_status rendezvous(gsx_comm_group* g, uint32_t rank, const char* what) {
     return GSX_OK;
 }
 
-gsx_status collective(Seat* me, int op, const void* d_send, void* d_recv, uint64_t bytes, hipStream_t stream) {
+// snd: what this rank has for peer p (bytes at an offset of d_send); rcv: where peer p's piece for this rank goes and how long the
+// ranks agreed it is (a peer that publishes another length aborts the group: sizes are derived from gathered data, they cannot
+// differ unless the ranks ran different frames)
+gsx_status collective(Seat* me, int op, const void* d_send, const uint64_t* snd_off, const uint64_t* snd_bytes, void* d_recv, const uint64_t* rcv_off,
+                      const uint64_t* rcv_bytes, hipStream_t stream) {
     gsx_comm_group* g = me->group;
     const int kind = op & 0xFF;
-    const uint32_t root = (uint32_t)op >> 8;  // OP_GATHER: the only rank that receives
-    const char* what = kind == OP_ALL_TO_ALL ? "an all-to-all" : (kind == OP_GATHER ? "a gather" : "an all-gather");
+    const int32_t root = (int32_t)((uint32_t)op >> 8) - 1;  // OP_GATHER: the only rank that receives (-1: every rank)
+    const char* what = kind == OP_ALL_TO_ALL ? "an all-to-all" : "a gather";
     auto ev = me->events.find(stream);
     if (ev == me->events.end()) {
         hipEvent_t a = nullptr, b = nullptr;
@@ -107,32 +110,34 @@ gsx_status collective(Seat* me, int op, const void* d_send, void* d_recv, uint64
     me->done = ev->second.second;
     HIPCHK(gsx::op::EventRecord(me->ready, stream));
     me->send = static_cast<const char*>(d_send);
-    me->recv = static_cast<char*>(d_recv);
-    me->bytes = bytes;
+    for (uint32_t p = 0; p < g->world; ++p) {
+        me->send_off[p] = snd_off[p];
+        me->send_bytes[p] = snd_bytes[p];
+    }
     me->op = op;
     gsx_status st = rendezvous(g, me->rank, what);
     if (st) return st;
-    // every rank compares the same published values and comes to the same conclusion
+    // every rank compares what its peers published with what it expects of them
+    const bool receives = kind == OP_ALL_TO_ALL || root < 0 || (uint32_t)root == me->rank;
     for (uint32_t p = 0; p < g->world; ++p)
-        if (g->seats[p].op != op || g->seats[p].bytes != bytes) {
+        if (g->seats[p].op != op || (receives && g->seats[p].send_bytes[me->rank] != rcv_bytes[p])) {
             std::unique_lock<std::mutex> lk(g->mu);
             char buf[256];
-            snprintf(buf, sizeof buf, "ranks disagree: rank %u is in %s of %llu bytes per rank, rank %u in op %d of %llu", me->rank, what,
-                     (unsigned long long)bytes, p, g->seats[p].op, (unsigned long long)g->seats[p].bytes);
+            snprintf(buf, sizeof buf, "ranks disagree: rank %u is in %s and expects %llu bytes of rank %u, which is in op %d with %llu for it", me->rank, what,
+                     (unsigned long long)rcv_bytes[p], p, g->seats[p].op, (unsigned long long)g->seats[p].send_bytes[me->rank]);
             return group_abort(g, buf);
         }
     // the peers' `done` events of THIS collective, taken while the published fields are stable (between the two rendezvous): after
     // rendezvous B a faster peer may already be publishing its next collective, on another lane's stream with that lane's event pair
     hipEvent_t peer_done[64];
     for (uint32_t p = 0; p < g->world; ++p) peer_done[p] = g->seats[p].done;
-    for (uint32_t p = 0; p < g->world; ++p) {  // delivery by source rank, like ncclRecv from p / ncclAllGather
-        if (kind == OP_GATHER && me->rank != root) break;  // a rank that is not the root sends (the root copies) and receives nothing
+    for (uint32_t p = 0; receives && p < g->world; ++p) {  // delivery by source rank, like ncclRecv from p
         const Seat& src = g->seats[p];
-        const char* from = kind == OP_ALL_TO_ALL ? src.send + (size_t)me->rank * bytes : src.send;
-        char* to = me->recv + (size_t)p * bytes;
-        if (from == to) continue;  // an in-place all-gather's own piece
+        const char* from = src.send + src.send_off[me->rank];
+        char* to = static_cast<char*>(d_recv) + rcv_off[p];
+        if (from == to || rcv_bytes[p] == 0) continue;  // an in-place gather's own piece / nothing to move
         if (p != me->rank) HIPCHK(gsx::op::StreamWaitEvent(stream, src.ready, 0));
-        HIPCHK(gsx::op::MemcpyAsync(to, from, bytes, hipMemcpyDefault, stream));
+        HIPCHK(gsx::op::MemcpyAsync(to, from, rcv_bytes[p], hipMemcpyDefault, stream));
     }
     HIPCHK(gsx::op::EventRecord(me->done, stream));
     if ((st = rendezvous(g, me->rank, what))) return st;
@@ -141,20 +146,23 @@ gsx_status collective(Seat* me, int op, const void* d_send, void* d_recv, uint64
     return GSX_OK;
 }
 
-gsx_status group_all_to_all(void* ctx, const void* d_send, void* d_recv, uint64_t bytes_per_peer, void* hip_stream) {
-    return collective(static_cast<Seat*>(ctx), OP_ALL_TO_ALL, d_send, d_recv, bytes_per_peer, static_cast<hipStream_t>(hip_stream));
+gsx_status group_all_to_all_v(void* ctx, const void* d_send, const uint64_t* send_offsets, const uint64_t* send_bytes, void* d_recv, const uint64_t* recv_offsets,
+                              const uint64_t* recv_bytes, void* hip_stream) {
+    return collective(static_cast<Seat*>(ctx), OP_ALL_TO_ALL, d_send, send_offsets, send_bytes, d_recv, recv_offsets, recv_bytes, static_cast<hipStream_t>(hip_stream));
 }
 
-gsx_status group_all_gather(void* ctx, const void* d_send, void* d_recv, uint64_t bytes_per_rank, void* hip_stream) {
-    return collective(static_cast<Seat*>(ctx), OP_ALL_GATHER, d_send, d_recv, bytes_per_rank, static_cast<hipStream_t>(hip_stream));
+gsx_status group_gather_v(void* ctx, const void* d_send, uint64_t send_bytes, void* d_recv, const uint64_t* recv_offsets, const uint64_t* recv_bytes, int32_t root,
+                          void* hip_stream) {
+    Seat* me = static_cast<Seat*>(ctx);
+    uint64_t off[64], bytes[64];
+    for (uint32_t p = 0; p < me->group->world; ++p) {  // the same piece for every rank that receives
+        off[p] = 0;
+        bytes[p] = (root < 0 || (uint32_t)root == p) ? send_bytes : 0;
+    }
+    return collective(me, OP_GATHER | (int)((uint32_t)(root + 1) << 8), d_send, off, bytes, d_recv, recv_offsets, recv_bytes, static_cast<hipStream_t>(hip_stream));
 }
 
 }  // namespace
-
-// every rank's piece into the root's buffer only (gsx_shard_set_gather_root over the in-process group)
-gsx_status gsx::group_gather_to_root(gsx_viewer* owner, const void* d_send, void* d_recv, uint64_t bytes_per_rank, uint32_t root, hipStream_t stream) {
-    return collective(static_cast<Seat*>(owner->comm_ctx), OP_GATHER | (int)(root << 8), d_send, d_recv, bytes_per_rank, stream);
-}
 
 void gsx::group_leave(gsx_viewer* v) {
     gsx_comm_group* g = v->comm_group;
@@ -217,7 +225,7 @@ gsx_status gsx_viewer_comm_init_group(gsx_viewer* v, gsx_comm_group* g, uint32_t
                 if (e != hipSuccess) (void)hipGetLastError();  // already enabled: fine
             }
         }
-    if ((st = gsx_viewer_comm_init_custom(v, g->world, rank, group_all_to_all, group_all_gather, me))) {
+    if ((st = gsx_viewer_comm_init_custom_v(v, g->world, rank, group_all_to_all_v, group_gather_v, me))) {
         std::unique_lock<std::mutex> lk(g->mu);
         me->taken = false;
         return st;

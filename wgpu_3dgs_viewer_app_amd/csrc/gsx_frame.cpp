@@ -647,7 +647,9 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
     const uint32_t owned_tiles = (row_hi > row_lo ? row_hi - row_lo : 0) * m->fc.tiles_x;
     const uint2* window = (m->use_imported && m->has_window) ? (m->window_ptr ? m->window_ptr : m->window.as<uint2>()) : nullptr;
     if (m->spec_round1) window = m->spec_win.as<uint2>();
-    uint32_t* tile_sat = progressive ? done + row_words * m->fc.tiles_y : nullptr;  // [count | bitmap | saturation keys]
+    uint32_t* tile_sat = progressive ? done + row_words * m->fc.tiles_y : nullptr;  // [count | bitmap | saturation keys | row work]
+    // multi-GPU: what the tiles of every tile row walked, summed — the next frame's bands are balanced by it (gsx_shard_frame.cpp)
+    uint32_t* row_work = (progressive && m->use_imported) ? tile_sat + (size_t)n_tiles : nullptr;
 
     // pair capacity to begin with: 16 entries per record for small models (per-tile lists), 6 for large ones (block lists need
     // ~3 per record on speculated frames, 0.2 on depth slabs; a frame that wants more spills on the device and the host grows
@@ -785,10 +787,10 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
             ScopedPass t(v, GSX_PASS_COMPOSITE);
             if (blocks) {
                 HIPCHK(launch_composite_blocks(v->stream, m->fc, m->ranges.as<uint2>(), m->tile_list, m->srect.as<uint4>(), m->rec(), fb_ptr(v),
-                                               later, done, row_words, done_count, tile_sat, win, row_lo, row_hi, bsx, bsy));
+                                               later, done, row_words, done_count, tile_sat, win, row_lo, row_hi, bsx, bsy, row_work));
             } else {
                 HIPCHK(launch_composite(v->stream, m->fc, m->ranges.as<uint2>(), m->tile_list, m->rec(), fb_ptr(v),
-                                        later, done, row_words, done_count, clear_ranges, tile_sat));
+                                        later, done, row_words, done_count, clear_ranges, tile_sat, row_work));
                 m->ranges_clean = clear_ranges;  // the compositor zeroed every range it consumed
             }
             v->pass_launches[GSX_PASS_COMPOSITE] += 1;
@@ -944,10 +946,10 @@ gsx_status do_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys, bo
         HIPCHK(launch_clear_fb(v->stream, fb_ptr(v), v->width * v->height));
         return GSX_OK;
     }
-    if (!cont) {   // one memset: [saturated-tile counter | saturated-tile bitmap | per-tile saturation depth keys]
+    if (!cont) {   // one memset: [saturated-tile counter | saturated-tile bitmap | per-tile saturation depth keys | per-row work]
         const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
         const uint32_t row_words = (tiles_x + 31) / 32;
-        const size_t bytes = 4 * (1 + (size_t)tiles_y * row_words + (size_t)tiles_y * tiles_x);
+        const size_t bytes = 4 * (1 + (size_t)tiles_y * row_words + (size_t)tiles_y * tiles_x + tiles_y);
         HIPCHK(v->done_bits.ensure(bytes));
         // ... and, in the same launch, the per-frame totals of the model composited first
         Counters* dc0 = order.back()->counters.as<Counters>();

@@ -41,6 +41,41 @@ void frame_consts_setup(const float view[16], const float proj[16], uint32_t wid
                         const ModelTransform& mt, float size, uint32_t display_mode, uint32_t sh_deg, uint32_t no_sh0,
                         const gsx_spec_params& sp, FrameConsts* out);
 
+// Multi-GPU: the screen is cut into `world` contiguous bands of tile rows, band g = rank g: rows [e[g], e[g + 1]).  e[0] = 0,
+// e[world] >= tiles_y (rows past the frame hold nothing); a band may be empty.  Equal bands (e[g] = g * ceil(tiles_y / world)) or
+// bands balanced by the previous frame's per-row work (gsx_shard_frame.cpp).  Passed to the kernels by value: every frame in
+// flight carries the edges it was enqueued with.
+constexpr uint32_t kMaxRanks = 64;
+struct BandEdges {
+    uint32_t world;
+    uint32_t e[kMaxRanks + 1];
+};
+__host__ __device__ inline uint32_t band_of(const BandEdges& b, uint32_t ty) {  // owner of tile row ty (rows past the last edge: the last rank)
+    uint32_t g = 0;
+    while (g + 1u < b.world && ty >= b.e[g + 1u]) ++g;
+    return g;
+}
+__host__ __device__ inline uint32_t band_rows_max(const BandEdges& b) {
+    uint32_t m = 0;
+    for (uint32_t g = 0; g < b.world; ++g) m = b.e[g + 1u] - b.e[g] > m ? b.e[g + 1u] - b.e[g] : m;
+    return m;
+}
+// One rank's feedback after a round (gsx_shard_feedback), in u32 words:
+//   [0] records it wanted to send to its busiest destination   [1] a slot overflowed   [2] gather root + 1 (0: every rank receives)
+//   [3] list entries it binned this round   [4..7] 0   [8 + d] records it wanted to send to destination d (round 0)
+//   then rows x tiles_x saturation depth keys of its band (0 = open), then rows words of per-tile-row work (list entries its
+//   tiles walked + kTileWork per tile: what the next frame's bands are balanced by); rows = its band's height.
+// The pieces are gathered at a common stride (the tallest band's piece); a rank sends only what its own band needs.
+constexpr uint32_t kShardExtraWords = 8 + kMaxRanks;
+constexpr uint32_t kTileWork = 8;  // what a tile costs before it has walked a single list entry, in list entries (band balancing)
+__host__ __device__ inline uint32_t feedback_stride(const BandEdges& b, uint32_t tiles_x) { return kShardExtraWords + band_rows_max(b) * (tiles_x + 1u); }
+__host__ __device__ inline uint32_t feedback_words(const BandEdges& b, uint32_t tiles_x, uint32_t g) { return kShardExtraWords + (b.e[g + 1u] - b.e[g]) * (tiles_x + 1u); }
+// The verdict block in pinned host memory (u32 words; words 0..3 are the two 64-bit verdict words the host polls):
+//   [4] the ranks disagree about the gather root   [5] list entries of all ranks   [6] largest of any rank   [7] work of the busiest
+//   rank x world x 1000 / work of all (how evenly this frame's bands shared it)   [8 .. 8 + world] band edges for
+//   the next frame   [80 + s * world + d] records rank s wanted to send to rank d in round 0
+constexpr uint32_t kVerdictEdges = 8, kVerdictMatrix = 80, kVerdictWords = kVerdictMatrix + kMaxRanks * kMaxRanks;
+
 // Resident pod planes of one model (SoA, every plane contiguous over the model's N Gaussians).
 // The reference's 8-way pod choice (scene.rs:23-81) selects which SH / cov3d planes exist:
 //   Sh Single : sh4 (11 float4 planes) + sh1          180 B     Cov3d Single: cov_a (float4) + cov_b (float2)  24 B
@@ -180,6 +215,8 @@ struct SlabStats {
     uint32_t slot_max[2];      // device-resident exchange: most records this rank had for ONE destination in the last round 0 / 1
     uint32_t slot_over[2];     // ... and whether that exceeded the slot (the verdict tells every rank; round 0 is then redone)
     uint32_t shard_need;       // tiles of the whole frame that needed the repair round (gsx_shard_verify)
+    uint32_t slot_want[64];    // records this rank wanted to send to each destination in the last round 0 (k_pack_headers): the
+                               // gathered count matrix sizes the next frame's slots per (source, destination) pair
     uint32_t shard_ticket;     // k_shard_verify: blocks done (the last one posts the verdict): tiles of the whole frame that needed the repair round (gsx_shard_verify)
     // ---- from here on: zeroed at the start of every frame ----
     uint32_t n_entries;        // D of the slab being processed: what was binned into the pair buffers (<= their capacity)
@@ -227,7 +264,7 @@ hipError_t launch_block_bin(hipStream_t s, uint32_t j0, uint32_t j1, const uint3
 hipError_t launch_composite_blocks(hipStream_t s, const FrameConsts& f, const uint2* ranges, const uint32_t* list, const uint4* brec,
                                    const Records& rec, float4* fb, bool carry, uint32_t* done, uint32_t row_words,
                                    uint32_t* d_done_count, uint32_t* tile_sat, const uint2* window, uint32_t row_lo,
-                                   uint32_t row_hi, uint32_t bsx, uint32_t bsy);
+                                   uint32_t row_hi, uint32_t bsx, uint32_t bsy, uint32_t* row_work = nullptr /* as launch_composite */);
 
 // Selection / edits / queries (kernels_edit.hip).
 hipError_t launch_edit_prepare(hipStream_t s, uint32_t n, const uint32_t* selection, uint32_t* edited, float4* edit_a,
@@ -287,12 +324,12 @@ hipError_t launch_rowscan(hipStream_t s, uint32_t* table, uint32_t nrows, uint32
                           uint32_t tile = 1, const uint32_t* d_skip = nullptr /* points at 0: the totals are 0, nothing is read */);
 size_t pack_blocks(uint64_t n, uint32_t rounds);  // workgroups of a pack pass whose tiles hold 256 x rounds records
 uint32_t pack_rounds(bool candidate_list);
-// rows_per_rank: rank g owns tile rows [g*rpr, min((g+1)*rpr, tiles_y)).  A record travels to g if its rectangle
-// touches g's band and (key < key_front_hi, or key >= key_back_lo and it touches a tile whose bit in open_map is 0).
+// bands: rank g owns the tile rows [bands.e[g], bands.e[g + 1]).  A record travels to g if its rectangle touches g's band and some
+// tile of it there has the record's key inside its window.
 // window: uint2 [lo, hi) depth-key window per tile (tiles_y * tiles_x, row-major) or nullptr = every tile takes everything.
 // list / d_list_n (nullable): pack only these (key, index) candidates; the per-element arrays are then indexed by list position.
 // travellers / traveller_counts (nullable): ballots + per-workgroup counts of the elements that travel anywhere.
-hipError_t launch_pack_count(hipStream_t s, const Records& rec, uint32_t n, uint32_t world, uint32_t rows_per_rank,
+hipError_t launch_pack_count(hipStream_t s, const Records& rec, uint32_t n, const BandEdges& bands,
                              const uint2* window, uint32_t tiles_x, unsigned long long* masks, uint32_t* table,
                              const uint2* list, const uint32_t* d_list_n, unsigned long long* travellers, uint32_t* traveller_counts,
                              const uint32_t* gate = nullptr /* tile bitmap: records whose rectangle holds no gated tile go nowhere */,
@@ -308,15 +345,17 @@ hipError_t launch_pack_headers(hipStream_t s, const uint32_t* totals, uint32_t w
 hipError_t launch_import_slots(hipStream_t s, const void* d_recv, uint32_t world, uint32_t slot_stride, uint32_t slot_cap, const Records& rec,
                                SlabStats* stats);
 hipError_t launch_limits_to_windows(hipStream_t s, const uint32_t* limit, uint32_t n_tiles, uint2* win);
-// sat: the all-gathered feedback = per rank (rpr * tiles_x + kShardExtraWords) words
-constexpr uint32_t kShardExtraWords = 4;  // {records wanted for the busiest destination, slot overflowed?, 0, 0} behind every rank's band
-hipError_t launch_shard_verify(hipStream_t s, const uint32_t* limit, const uint32_t* sat, uint32_t tiles_x, uint32_t tiles_y, uint32_t rpr,
-                               uint32_t world, uint2* win2, uint32_t* d_need, uint32_t* d_ticket, unsigned long long* host_verdict, uint32_t seq,
-                               uint32_t* need_bits /* zeroed; bit per tile that needs the repair round */);
+// sat: the all-gathered feedback, piece g at word g * feedback_stride(bands, tiles_x) (layout: feedback_* below)
+hipError_t launch_shard_verify(hipStream_t s, const uint32_t* limit, const uint32_t* sat, uint32_t tiles_x, uint32_t tiles_y, const BandEdges& bands,
+                               uint2* win2, uint32_t* d_need, uint32_t* d_ticket, unsigned long long* host_verdict, uint32_t seq,
+                               uint32_t* need_bits /* zeroed; bit per tile that needs the repair round */, uint32_t balance /* post balanced edges for the next frame */);
 hipError_t launch_shard_post_counts(hipStream_t s, const uint32_t* counts_all, uint32_t world, unsigned long long* host_verdict, uint32_t seq);
 hipError_t launch_shard_max_count(hipStream_t s, const uint32_t* totals, uint32_t world, uint32_t* out4);
 hipError_t launch_shard_next_limits(hipStream_t s, const uint32_t* sat, uint32_t tiles_x, uint32_t tiles_y, float margin, uint32_t radius,
-                                    uint32_t* limit, uint32_t rpr);
+                                    uint32_t* limit, const BandEdges& bands);
+// this rank's feedback piece (layout: feedback_* above)
+hipError_t launch_shard_feedback(hipStream_t s, const uint32_t* tile_sat, const uint32_t* row_work, uint32_t tiles_x, uint32_t tiles_y, const BandEdges& bands,
+                                 uint32_t rank, uint32_t* out, const SlabStats* stats, const uint32_t* done_before, uint32_t row_words, uint32_t gather_root_plus1);
 hipError_t launch_import_records(hipStream_t s, const void* d_recv, uint32_t n, const Records& rec);
 
 // Mask evaluation (kernels_mask.hip); passed to the kernel by value.
@@ -341,7 +380,7 @@ void quat_to_rows(const float q[4], float r[9]);
 // depth feedback (nullable): when a tile saturates, *depth_needed = max(., sorted_keys[min(slab_end, *d_n_vis) - 1])
 hipError_t launch_composite(hipStream_t s, const FrameConsts& f, uint2* ranges, const uint32_t* list,
                             const Records& rec, float4* fb, bool carry, uint32_t* done, uint32_t row_words,
-                            uint32_t* d_done_count, bool clear_ranges, uint32_t* tile_sat);
+                            uint32_t* d_done_count, bool clear_ranges, uint32_t* tile_sat, uint32_t* row_work = nullptr /* per tile row: += list entries walked */);
 // The splats [stats->slab_cut, min(j1, *d_n)) of the depth order, composited WITHOUT tile pairs (an overflowing slab's tail):
 // one workgroup per live tile scans them, keeps those whose rectangle (and window) takes the tile, blends them like
 // k_composite.  Falls through when the slab was not cut.

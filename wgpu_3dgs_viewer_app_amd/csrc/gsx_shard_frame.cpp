@@ -33,18 +33,40 @@ struct Ctx {
     ShardPending* p;
     uint32_t world, rank;
     gsx_shard_layout_t lay;
-    uint32_t sat_words;
+    uint32_t sat_words;  // stride of the gathered feedback pieces
+    BandEdges bands;     // this frame's layout (ShardPending::edges; the lane's band_edges while the frame is worked on)
+    uint32_t tiles_x, tiles_y;
 };
+
+// The frame's band layout.  Equal bands unless the transport moves pieces of unequal size; then the edges the caller forced
+// (gsx_shard_set_band_edges), or the ones the last COMPLETED frame's verdict posted — balanced by that frame's per-row work, the
+// same on every rank because the verdict is derived from gathered data and every rank completes its frames in the same order.
+void choose_edges(gsx_viewer* owner, ShardPending& p, uint32_t world, uint32_t tiles_y) {
+    p.edges.clear();
+    if (!comm_moves_unequal(owner)) return;
+    if (owner->band_edges_forced.size() == (size_t)world + 1u) {
+        p.edges = owner->band_edges_forced;
+    } else if (owner->shard_balance && owner->next_edges.size() == (size_t)world + 1u && owner->next_edges_tiles_y == tiles_y) {
+        p.edges = owner->next_edges;
+    }
+}
 
 // the padded framebuffer the bands are gathered into (owned by the library, per lane) and the saturation-map buffers
 gsx_status frame_buffers(Ctx& c) {
     gsx_viewer* v = c.l;
+    v->band_edges = c.p->edges;  // (empty: equal bands) — every stage call below reads the layout from the viewer it runs on
+    c.tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE;
+    c.tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
+    c.bands = bands_of(v, c.world);
     gsx_status st = gsx_shard_layout(v, c.world, c.rank, &c.lay);
     if (st) return st;
-    if (v->ext_fb != v->shard_fb.p || v->shard_fb.bytes < c.lay.padded_framebuffer_bytes) {
+    // (whole tile rows of the equal layout AND of any balanced one: the layout may change from frame to frame, the buffer stays)
+    const uint64_t fb_bytes = std::max<uint64_t>(c.lay.padded_framebuffer_bytes,
+                                                 (uint64_t)std::max(c.world * rows_per_rank(v, c.world), c.tiles_y) * GSX_TILE * v->width * sizeof(float4));
+    if (v->ext_fb != v->shard_fb.p || v->shard_fb.bytes < fb_bytes) {
         HIPCHK(gsx::op::StreamSynchronize(v->stream));
-        if (v->shard_fb.bytes < c.lay.padded_framebuffer_bytes) {
-            HIPCHK(v->shard_fb.ensure(c.lay.padded_framebuffer_bytes));
+        if (v->shard_fb.bytes < fb_bytes) {
+            HIPCHK(v->shard_fb.ensure(fb_bytes));
             HIPCHK(gsx::op::MemsetAsync(v->shard_fb.p, 0, v->shard_fb.bytes, v->stream));
         }
         v->ext_fb = v->shard_fb.p;
@@ -54,6 +76,18 @@ gsx_status frame_buffers(Ctx& c) {
     HIPCHK(v->shard_sat_band.ensure(4 * (size_t)c.sat_words + 16));
     HIPCHK(v->shard_sat_all.ensure((4 * (size_t)c.sat_words + 16) * c.world));
     return GSX_OK;
+}
+
+// every rank's feedback piece to every rank: at the common stride, each as long as its band needs
+gsx_status feedback_gather(Ctx& c) {
+    gsx_viewer* v = c.l;
+    if (!comm_moves_unequal(c.owner)) return gsx_comm_all_gather(v, v->shard_sat_band.p, v->shard_sat_all.p, 4 * (uint64_t)c.sat_words);
+    PeerSpans sp{};
+    for (uint32_t g = 0; g < c.world; ++g) {
+        sp.off[g] = 4ull * g * c.sat_words;
+        sp.bytes[g] = 4ull * feedback_words(c.bands, c.tiles_x, g);
+    }
+    return comm_gather_v(v, v->shard_sat_band.p, sp.bytes[c.rank], v->shard_sat_all.p, sp, -1);
 }
 
 // one exchange round of model i: pack -> all-to-all -> import + sort + composite -> feedback -> all-gather
@@ -71,21 +105,48 @@ gsx_status exchange_round(Ctx& c, size_t i, uint32_t round, uint32_t T) {
     if ((st = gsx_comm_all_to_all(v, v->shard_send.p, v->shard_recv.p, per_peer))) return st;
     if ((st = gsx_shard_import_slots(v, key, v->shard_recv.p, c.world, c.rank, round | (i > 0 ? GSX_SHARD_BEHIND : 0u), T))) return st;
     if ((st = gsx_shard_feedback(v, key, c.world, c.rank, v->shard_sat_band.p))) return st;
-    return gsx_comm_all_gather(v, v->shard_sat_band.p, v->shard_sat_all.p, 4 * (uint64_t)c.sat_words);
+    return feedback_gather(c);
 }
 
 gsx_status next_limits(Ctx& c, size_t i) {
     return gsx_shard_next_windows(c.l, c.p->order[i].c_str(), c.world, c.l->shard_sat_all.p, c.p->margin, c.p->radius);
 }
 
-// the bands, in place: every rank's band lands where it belongs in every rank's framebuffer
+// the bands, in place: every rank's band lands where it belongs in every rank's framebuffer (or in the root's only)
 gsx_status band_gather(Ctx& c) {
     char* fb = static_cast<char*>(c.l->ext_fb);
     const int32_t root = c.owner->shard_gather_root;
-    gsx_status st = root < 0 ? gsx_comm_all_gather(c.l, fb + c.lay.band_offset_bytes, fb, c.lay.band_bytes)
-                             : comm_gather_to_root(c.l, fb + c.lay.band_offset_bytes, fb, c.lay.band_bytes, (uint32_t)root);
+    gsx_status st;
+    if (!comm_moves_unequal(c.owner)) {  // equal pieces only: the transport's all-gather, whatever the root
+        st = gsx_comm_all_gather(c.l, fb + c.lay.band_offset_bytes, fb, c.lay.band_bytes);
+    } else {
+        const uint64_t row_bytes = (uint64_t)GSX_TILE * c.l->width * sizeof(float4);
+        PeerSpans sp{};
+        for (uint32_t g = 0; g < c.world; ++g) {
+            sp.off[g] = c.bands.e[g] * row_bytes;
+            sp.bytes[g] = (c.bands.e[g + 1] - c.bands.e[g]) * row_bytes;
+        }
+        st = comm_gather_v(c.l, fb + sp.off[c.rank], sp.bytes[c.rank], fb, sp, root);
+    }
     c.p->gathered = st == GSX_OK;
     return st;
+}
+
+// what a round-0 verdict carries besides its two words (kernels_shard.hip, k_shard_verify): do the ranks agree about the gather
+// root, the band edges for the frames to come, the count matrix of the exchange
+gsx_status read_verdict_extras(Ctx& c) {
+    const uint32_t* hv = reinterpret_cast<const uint32_t*>(c.l->h_shard_verdict);
+    gsx_viewer* o = c.owner;
+    if (hv[4]) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_render_frame: the ranks name different gather roots (gsx_shard_set_gather_root: this rank %d)", (int)o->shard_gather_root);
+    o->shard_root_confirmed = true;
+    o->next_edges.assign(hv + kVerdictEdges, hv + kVerdictEdges + c.world + 1);
+    o->next_edges_tiles_y = c.tiles_y;
+    o->pair_counts.assign(hv + kVerdictMatrix, hv + kVerdictMatrix + (size_t)c.world * c.world);
+    o->pair_world = c.world;
+    o->shard_stats.last_entries_sum = hv[5];
+    o->shard_stats.last_entries_max = hv[6];
+    o->shard_stats.last_work_permille = hv[7];
+    return GSX_OK;
 }
 
 gsx_status round0(Ctx& c, size_t i) {
@@ -110,6 +171,7 @@ gsx_status settle(Ctx& c, size_t i, bool* overflow) {
     gsx_shard_verdict verdict{};
     gsx_status st = timed_wait(c, key, c.p->seq, &verdict);
     if (st) return st;
+    if ((st = read_verdict_extras(c))) return st;
     *overflow = verdict.overflow != 0;
     if (*overflow || !verdict.need_tiles) return GSX_OK;
     // the repair round, sized exactly: what each destination is owed is counted, the maximum gathered and posted
@@ -147,6 +209,7 @@ gsx_status redo_safe(Ctx& c) {
 
 // everything of a frame up to (not including) the look at its LAST verdict
 gsx_status frame_front(Ctx& c, bool eager_gather) {
+    choose_edges(c.owner, *c.p, c.world, (c.l->height + GSX_TILE - 1) / GSX_TILE);
     gsx_status st = frame_buffers(c);
     if (st) return st;
     ShardPending& p = *c.p;
@@ -172,11 +235,13 @@ gsx_status frame_front(Ctx& c, bool eager_gather) {
             break;
         }
     }
-    return eager_gather ? band_gather(c) : GSX_OK;
+    // (a gather to ONE rank over RCCL hangs if the ranks name different roots: the first frame after gsx_shard_set_gather_root
+    //  gathers only when its verdict has confirmed that they agree)
+    return eager_gather && (c.owner->shard_gather_root < 0 || c.owner->shard_root_confirmed) ? band_gather(c) : GSX_OK;
 }
 
 gsx_status frame_back(gsx_viewer* owner, ShardPending& p) {
-    Ctx c{owner, p.lane, &p, owner->comm_world, owner->comm_rank, {}, 0};
+    Ctx c{owner, p.lane, &p, owner->comm_world, owner->comm_rank, {}, 0, {}, 0, 0};
     gsx_status st = frame_buffers(c);
     if (st) return st;
     if (!p.settled) {
@@ -190,6 +255,8 @@ gsx_status frame_back(gsx_viewer* owner, ShardPending& p) {
     if (p.repaired) ss.repair_frames += 1;
     for (const std::string& k : p.order)
         if ((st = gsx_shard_frame_end(p.lane, k.c_str()))) return st;
+    owner->last_edges.assign(c.bands.e, c.bands.e + c.world + 1);
+    p.lane->band_edges = owner->band_edges_forced;  // stage calls between frames see the caller's layout (or equal bands), not this frame's
     if (p.lane != owner) {  // model-changing calls on the owner's stream come after this lane's frame (viewer_bind)
         HIPCHK(gsx::op::EventRecord(p.lane->lane_event, p.lane->stream));
         p.lane->lane_busy = true;
@@ -275,7 +342,7 @@ gsx_status gsx_shard_render_frame_keys(gsx_viewer* v, const char* const* keys_fa
     p.speculate = speculate;
     p.margin = margin;
     p.radius = radius;
-    Ctx c{v, lane, &p, v->comm_world, v->comm_rank, {}, 0};
+    Ctx c{v, lane, &p, v->comm_world, v->comm_rank, {}, 0, {}, 0, 0};
     if ((st = frame_front(c, lanes == 1))) {
         v->shard_pending.clear();
         return st;

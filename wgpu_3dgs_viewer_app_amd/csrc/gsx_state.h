@@ -283,6 +283,7 @@ struct ShardPending {
     bool gathered = false;                    // the band gather that is enqueued shows the final frame
     bool settled = false;                     // every model's verdict has been dealt with already (a frame redone with safe slots)
     bool repaired = false;                    // some model needed its repair exchange
+    std::vector<uint32_t> edges;              // the frame's band layout (world + 1 tile rows; empty: equal bands)
 };
 
 struct gsx_viewer {
@@ -339,9 +340,24 @@ struct gsx_viewer {
     gsx_comm_all_to_all_fn comm_a2a_fn = nullptr;
     gsx_comm_all_gather_fn comm_ag_fn = nullptr;
     void* comm_ctx = nullptr;
+    // ... and, where the transport can move pieces of unequal size (gsx_viewer_comm_init_custom_v, the in-process group): then the
+    // bands may be balanced and the exchange slots sized pair by pair
+    gsx_comm_all_to_all_v_fn comm_a2a_v_fn = nullptr;
+    gsx_comm_gather_v_fn comm_gather_v_fn = nullptr;
     gsx_comm_group* comm_group = nullptr;  // != nullptr: comm_ctx is this viewer's seat in that group (gsx_comm_group.cpp)
     gsx_shard_stats shard_stats{};       // host-side bookkeeping of the sharded frames (gsx_shard_get_stats)
     int32_t shard_gather_root = -1;  // gsx_shard_set_gather_root: -1 every rank receives every band, >= 0 only that rank
+    // band layout of the sharded frames (BandEdges, gsx_internal.h).  band_edges: world + 1 tile rows, or empty = equal bands.
+    // gsx_shard_render_frame sets it per frame — from next_edges, which the last completed frame's verdict posted (balanced by
+    // that frame's per-row work) — when the transport moves pieces of unequal size; gsx_shard_set_band_edges sets it for callers
+    // of the stage functions.
+    std::vector<uint32_t> band_edges, next_edges, band_edges_forced, last_edges;
+    bool shard_root_confirmed = false;   // a verdict since the last gsx_shard_set_gather_root has shown that every rank names the same root
+    uint32_t next_edges_tiles_y = 0;     // the grid next_edges was made for
+    bool shard_balance = true;           // gsx_shard_set_balance
+    // per (source, destination) records of the last completed frame's round 0 (the verdict's count matrix; empty: unknown)
+    std::vector<uint32_t> pair_counts;
+    uint32_t pair_world = 0;
     DevBuf shard_fb, shard_send, shard_recv, shard_sat_band, shard_sat_all, shard_counts;  // gsx_shard_render_frame's own buffers
     void* ext_fb = nullptr;              // caller-owned framebuffer (multi-GPU: the RCCL gather target)
     uint64_t ext_fb_bytes = 0;
@@ -395,10 +411,17 @@ inline uint32_t ceil_log2(uint32_t x) {
 // may be about to read results or to change model data the lanes are still reading: the viewer's stream is ordered after
 // the lanes' frames (no host wait), and the lanes' next frames after whatever the caller enqueues (epoch).
 gsx_status shard_complete_pending(gsx_viewer* v);  // gsx_comm.cpp: verdicts, redo / repair rounds of the sharded frames in flight
-inline bool has_comm(const gsx_viewer* v) { return v->comm != nullptr || v->comm_a2a_fn != nullptr; }
-gsx_status group_gather_to_root(gsx_viewer* owner, const void* d_send, void* d_recv, uint64_t bytes_per_rank, uint32_t root, hipStream_t stream);  // gsx_comm_group.cpp
+inline bool has_comm(const gsx_viewer* v) { return v->comm != nullptr || v->comm_a2a_fn != nullptr || v->comm_a2a_v_fn != nullptr; }
 void group_leave(gsx_viewer* v);  // gsx_comm_group.cpp: give this viewer's seat in its in-process group back
-gsx_status comm_gather_to_root(gsx_viewer* v, const void* d_send, void* d_recv, uint64_t bytes_per_rank, uint32_t root);  // gsx_comm.cpp
+// The collectives of a sharded frame with pieces of unequal size (gsx_comm.cpp): per peer p, `bytes[p]` bytes at `off[p]`.
+struct PeerSpans {
+    uint64_t off[kMaxRanks], bytes[kMaxRanks];
+};
+inline bool comm_moves_unequal(const gsx_viewer* owner) { return owner->comm != nullptr || owner->comm_a2a_v_fn != nullptr; }
+// slot p of the send buffer (snd) goes to rank p, what rank p sends lands in slot p of the receive buffer (rcv)
+gsx_status comm_all_to_all_v(gsx_viewer* v, const void* d_send, const PeerSpans& snd, void* d_recv, const PeerSpans& rcv);
+// every rank's piece (send_bytes of it; rank p's lands at rcv.off[p]) to every rank (root < 0) or to `root` only
+gsx_status comm_gather_v(gsx_viewer* v, const void* d_send, uint64_t send_bytes, void* d_recv, const PeerSpans& rcv, int32_t root);
 gsx_status comm_ensure_lanes(gsx_viewer* v, uint32_t lanes);  // gsx_comm.cpp: one RCCL communicator per lane (collective)
 
 inline gsx_status viewer_bind(gsx_viewer* v) {
@@ -457,10 +480,22 @@ gsx_status ensure_import_capacity(Model* m, uint64_t count);
 gsx_status ensure_selection(gsx_viewer* v, Model* m);
 gsx_status ensure_edit_buffers(gsx_viewer* v, Model* m);
 
-// tile rows per rank of the multi-GPU layout, bytes of a per-tile window map
+// tile rows per rank of the multi-GPU layout with equal bands, the layout in force, bytes of a per-tile window map
 inline uint32_t rows_per_rank(const gsx_viewer* v, uint32_t world) {
     const uint32_t tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
     return (tiles_y + world - 1) / world;
+}
+inline BandEdges bands_of(const gsx_viewer* v, uint32_t world) {
+    BandEdges b{};
+    b.world = world;
+    // (a lane renders with the layout its owner's frame was given: gsx_shard_frame.cpp copies it)
+    if (v->band_edges.size() == (size_t)world + 1u) {
+        for (uint32_t g = 0; g <= world; ++g) b.e[g] = v->band_edges[g];
+    } else {
+        const uint32_t rpr = rows_per_rank(v, world);
+        for (uint32_t g = 0; g <= world; ++g) b.e[g] = g * rpr;
+    }
+    return b;
 }
 inline size_t window_bytes(const gsx_viewer* v) {
     return sizeof(uint2) * (size_t)((v->width + GSX_TILE - 1) / GSX_TILE) * ((v->height + GSX_TILE - 1) / GSX_TILE);

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kAdmitThreads) void k_admit_count(const uint32_t* _
         const uint32_t kk = kks[r], rx = rxs[r], ry = rys[r];
         bool adm;
         if (pyr.data) adm = kk != kCulledKey && pyramid_admits(pyr, kk, rx, ry);
-        else if (window) adm = wave_dest_mask(window, tiles_x, kk, rx, ry, 0x10000u, 1u, gate, row_words) & 1ull;
+        else if (window) adm = wave_dest_mask(window, tiles_x, kk, rx, ry, one_band(), gate, row_words) & 1ull;
         else adm = kk != kCulledKey;
         const unsigned long long bal = __ballot(adm);
         if (lane == 0 && base + r * 64 < n) ballots[(base + r * 64) >> 6] = bal;

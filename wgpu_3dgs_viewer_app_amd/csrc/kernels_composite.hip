@@ -95,7 +95,8 @@ __global__ __launch_bounds__(128) void k_composite(const FrameConsts f, uint2* _
                                                     const float4* __restrict__ rec_c, float4* __restrict__ fb,
                                                     const int carry, uint32_t* __restrict__ done_bits,
                                                     const uint32_t row_words, uint32_t* __restrict__ done_count,
-                                                    const int clear_ranges, uint32_t* __restrict__ tile_sat) {
+                                                    const int clear_ranges, uint32_t* __restrict__ tile_sat,
+                                                    uint32_t* __restrict__ row_work) {
     __shared__ float2 s_mean[kBatch];
     __shared__ uint32_t s_sat;
     __shared__ float4 s_conic[kBatch];  // (a, 2b, c, opacity)
@@ -162,7 +163,8 @@ __global__ __launch_bounds__(128) void k_composite(const FrameConsts f, uint2* _
             pc4[k] = rec_c[idx];
         }
     }
-    for (uint32_t base = range.x; base < range.y; base += kBatch) {
+    uint32_t base = range.x;
+    for (; base < range.y; base += kBatch) {
         // vote + barrier: also protects the LDS batch of the previous iteration
         if (__syncthreads_and((lim0 | lim1) == 0u)) break;
 #pragma unroll
@@ -190,6 +192,9 @@ __global__ __launch_bounds__(128) void k_composite(const FrameConsts f, uint2* _
     if (in0) fb[fbo] = make_float4(C0.x, C1.x, C2.x, T.x);
     if (in1) fb[fbo + f.w_px] = make_float4(C0.y, C1.y, C2.y, T.y);
     if (clear_ranges && tid == 0 && had_entries) ranges[tile] = make_uint2(0u, 0u);
+    // multi-GPU: what this tile cost — list entries walked plus a constant for the tile itself; the next frame's bands are balanced
+    // by the rows' sums (gsx_shard_frame.cpp, k_shard_verify)
+    if (row_work && tid == 0) atomicAdd(&row_work[ty], kTileWork + min(base, range.y) - range.x);
     if (done_bits && __syncthreads_and((lim0 | lim1) == 0u)) {
         // the tile saturated in this launch: its last pixels stopped here, behind everything blended earlier
         if (tile_sat) {
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
                                                            const uint32_t row_words, uint32_t* __restrict__ done_count,
                                                            uint32_t* __restrict__ tile_sat, const uint2* __restrict__ window,
                                                            const uint32_t row_lo, const uint32_t row_hi, const uint32_t bsx,
-                                                           const uint32_t bsy, const uint32_t blocks_x) {
+                                                           const uint32_t bsy, const uint32_t blocks_x, uint32_t* __restrict__ row_work) {
     __shared__ float2 s_mean[kChunk + kGroupBlocks];
     __shared__ float4 s_conic[kChunk + kGroupBlocks];
     __shared__ float4 s_rgb[kChunk + kGroupBlocks];
@@ -287,7 +292,8 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
     const unsigned long long lt = (1ull << lane) - 1ull;
     // iteration i: write the takers gathered in iteration i - 1 to LDS, filter chunk i and start its gathers, prefetch the
     // candidates of chunk i + 1, blend; one more iteration drains the pipeline
-    for (uint32_t base = range.x; base < range.y + kChunk; base += kChunk) {
+    uint32_t base = range.x;
+    for (; base < range.y + kChunk; base += kChunk) {
         if (lane == 0) {
 #pragma unroll
             for (int k = 0; k < kCand; ++k) s_w[wave][k] = g_cnt[k];
@@ -337,6 +343,7 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
     }
     if (in0) fb[fbo] = make_float4(C0.x, C1.x, C2.x, T.x);
     if (in1) fb[fbo + f.w_px] = make_float4(C0.y, C1.y, C2.y, T.y);
+    if (row_work && tid == 0) atomicAdd(&row_work[ty], kTileWork + min(base, range.y) - range.x);  // (as k_composite)
     if (done_bits && __syncthreads_and((lim0 | lim1) == 0u)) {
         if (tile_sat) {
             if (stop_key) atomicMax(&s_sat, stop_key);
@@ -471,29 +478,29 @@ __global__ __launch_bounds__(256) void k_resolve_rgba8(const float4* __restrict_
 
 hipError_t launch_composite(hipStream_t s, const FrameConsts& f, uint2* ranges, const uint32_t* list,
                             const Records& rec, float4* fb, bool carry, uint32_t* done, uint32_t row_words,
-                            uint32_t* d_done_count, bool clear_ranges, uint32_t* tile_sat) {
+                            uint32_t* d_done_count, bool clear_ranges, uint32_t* tile_sat, uint32_t* row_work) {
     dim3 grid(f.tiles_x * f.tiles_y), block(128);
     if (f.display_mode == GSX_DISPLAY_SPLAT)
         GSX_LAUNCH(k_composite<0>, grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count,
-                           clear_ranges ? 1 : 0, tile_sat);
+                           clear_ranges ? 1 : 0, tile_sat, row_work);
     else
         GSX_LAUNCH(k_composite<1>, grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count,
-                           clear_ranges ? 1 : 0, tile_sat);
+                           clear_ranges ? 1 : 0, tile_sat, row_work);
     return hipGetLastError();
 }
 
 hipError_t launch_composite_blocks(hipStream_t s, const FrameConsts& f, const uint2* ranges, const uint32_t* list, const uint4* brec,
                                    const Records& rec, float4* fb, bool carry, uint32_t* done, uint32_t row_words,
                                    uint32_t* d_done_count, uint32_t* tile_sat, const uint2* window, uint32_t row_lo,
-                                   uint32_t row_hi, uint32_t bsx, uint32_t bsy) {
+                                   uint32_t row_hi, uint32_t bsx, uint32_t bsy, uint32_t* row_work) {
     dim3 grid(f.tiles_x * f.tiles_y), block(128);
     const uint32_t blocks_x = (f.tiles_x + (1u << bsx) - 1u) >> bsx;
     if (f.display_mode == GSX_DISPLAY_SPLAT)
         GSX_LAUNCH(k_composite_blocks<0>, grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
-                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x);
+                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work);
     else
         GSX_LAUNCH(k_composite_blocks<1>, grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
-                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x);
+                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work);
     return hipGetLastError();
 }
 

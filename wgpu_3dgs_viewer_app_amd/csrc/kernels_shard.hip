@@ -2,7 +2,8 @@
 // rank, and import received records as a rank's per-frame record set.
 //
 // No reference counterpart (the reference is single-device, src/main.rs:85-98).  The Gaussian array is
-// sharded by splat index; the screen is cut into `world` contiguous bands of tile rows, band g = rank g.  After the projection
+// sharded by splat index; the screen is cut into `world` contiguous bands of tile rows, band g = rank g (BandEdges: equal, or
+// balanced by the previous frame's per-row work).  After the projection
 // pass each rank sends every visible record to the rank(s) whose tile rows its rectangle touches
 // (RCCL all-to-all, done by the host layer), so that compositing — which is order dependent per
 // pixel — happens with ALL splats of a pixel on one GPU, in global depth order.
@@ -41,7 +42,7 @@ uint32_t pack_rounds(bool candidate_list) { return candidate_list ? kPackRoundsL
 template <int kPackRounds>
 __global__ __launch_bounds__(kPackThreads) void k_pack_count(const uint32_t* __restrict__ key,
                                                               const float4* __restrict__ rec_a, uint32_t n,
-                                                              uint32_t world, uint32_t rpr,
+                                                              const BandEdges bands,
                                                               const uint2* __restrict__ window, uint32_t tiles_x,
                                                               unsigned long long* __restrict__ masks,
                                                               uint32_t* __restrict__ table, uint32_t nblocks,
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_count(const uint32_t* __r
     __shared__ uint32_t tcnt[kPackThreads / 64];
     constexpr uint32_t kPackTile = kPackThreads * kPackRounds, kPackWaveChunk = 64 * kPackRounds;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t world = bands.world;
     if (tid < kMaxWorld) cnt[tid] = 0;
     __syncthreads();
     if (list) n = min(n, *d_list_n);
@@ -92,8 +94,8 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_count(const uint32_t* __r
     for (int r = 0; r < kPackRounds; ++r) {
         const uint32_t e = base + r * 64 + lane;
         const uint32_t kk = kks[r], rx = rxs[r], ry = rys[r];
-        const unsigned long long m = pyr.data ? dest_mask_pyramid(pyr, kk, rx, ry, rpr, world)
-                                              : wave_dest_mask(window, tiles_x, kk, rx, ry, rpr, world, gate, gate_row_words);
+        const unsigned long long m = pyr.data ? dest_mask_pyramid(pyr, kk, rx, ry, bands)
+                                              : wave_dest_mask(window, tiles_x, kk, rx, ry, bands, gate, gate_row_words);
         if (e < n) masks[e] = m;
         if (travellers) {
             const unsigned long long any = __ballot(m != 0ull);
@@ -212,14 +214,14 @@ __global__ __launch_bounds__(256) void k_import_records(const float4* __restrict
     rec.key[i] = __float_as_uint(c.w);
 }
 
-hipError_t launch_pack_count(hipStream_t s, const Records& rec, uint32_t n, uint32_t world, uint32_t rows_per_rank,
+hipError_t launch_pack_count(hipStream_t s, const Records& rec, uint32_t n, const BandEdges& bands,
                              const uint2* window, uint32_t tiles_x, unsigned long long* masks, uint32_t* table,
                              const uint2* list, const uint32_t* d_list_n, unsigned long long* travellers, uint32_t* traveller_counts,
                              const uint32_t* gate, uint32_t gate_row_words, const WindowPyramid* pyramid) {
     const uint32_t rounds = pack_rounds(list != nullptr), nb = (uint32_t)pack_blocks(n, rounds);
     if (nb) {
         auto kernel = rounds == kPackRoundsList ? k_pack_count<(int)kPackRoundsList> : k_pack_count<(int)kPackRoundsFull>;
-        GSX_LAUNCH(kernel, dim3(nb), dim3(kPackThreads), 0, s, rec.key, rec.a, n, world, rows_per_rank, window,
+        GSX_LAUNCH(kernel, dim3(nb), dim3(kPackThreads), 0, s, rec.key, rec.a, n, bands, window,
                            tiles_x, masks, table, nb, list, d_list_n, travellers, traveller_counts, gate, gate_row_words,
                            pyramid ? *pyramid : WindowPyramid{}, rec.rect8);
     }
@@ -252,6 +254,7 @@ __global__ __launch_bounds__(64) void k_pack_headers(const uint32_t* __restrict_
         h[1] = make_float4(0, 0, 0, 0);
         h[2] = make_float4(0, 0, 0, 0);
     }
+    if (round == 0u) stats->slot_want[g] = cnt;     // (the gathered count matrix sizes the next frame's slots pair by pair)
     uint32_t mx = cnt;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
@@ -297,26 +300,63 @@ __global__ __launch_bounds__(256) void k_limits_to_windows(const uint32_t* __res
     if (t < n_tiles) win[t] = make_uint2(0u, limit[t]);
 }
 
-// Verification on the device, from the all-gathered saturation map (sat: one word per tile of the PADDED frame, 0 = still
-// open): a tile whose window was bounded and that is still open gets, in the second exchange, what it was refused:
-// [limit, inf); every other tile nothing.  limit == nullptr (the round had no windows): nothing to repair.
-// (the gathered map: per rank its band of rpr tile rows followed by kShardExtraWords statistics words)
-__device__ inline uint32_t sat_at(const uint32_t* __restrict__ sat, uint32_t tx, uint32_t ty, uint32_t tiles_x, uint32_t rpr) {
-    const uint32_t g = ty / rpr;
-    return sat[(size_t)g * (rpr * tiles_x + kShardExtraWords) + (ty - g * rpr) * tiles_x + tx];
+// Verification on the device, from the all-gathered feedback (layout: gsx_internal.h, feedback_*): a tile whose window was
+// bounded and that is still open gets, in the second exchange, what it was refused: [limit, inf); every other tile nothing.
+// limit == nullptr (the round had no windows): nothing to repair.
+__device__ inline uint32_t sat_at(const uint32_t* __restrict__ sat, uint32_t tx, uint32_t ty, uint32_t tiles_x, const BandEdges& bands, uint32_t stride) {
+    const uint32_t g = band_of(bands, ty);
+    return sat[(size_t)g * stride + kShardExtraWords + (ty - bands.e[g]) * tiles_x + tx];
+}
+__device__ inline uint32_t work_at(const uint32_t* __restrict__ sat, uint32_t ty, uint32_t tiles_x, const BandEdges& bands, uint32_t stride) {
+    const uint32_t g = band_of(bands, ty);
+    return sat[(size_t)g * stride + kShardExtraWords + (bands.e[g + 1u] - bands.e[g]) * tiles_x + (ty - bands.e[g])];
+}
+
+// this rank's feedback piece: statistics, the saturation keys of its band, the work of its tile rows.
+// done_before (nullable; layered models): the tiles nearer models had saturated before this model was composited.  They say
+// nothing about THIS model's depths: reported as saturated at the smallest depth key, so that the model's next limit there
+// is whatever its neighbourhood needs and nothing more (the single-GPU rule, k_spec_next).
+__global__ __launch_bounds__(256) void k_shard_feedback(const uint32_t* __restrict__ tile_sat, const uint32_t* __restrict__ row_work, uint32_t tiles_x,
+                                                         uint32_t tiles_y, uint32_t row_lo, uint32_t rows, uint32_t* __restrict__ out,
+                                                         const SlabStats* __restrict__ stats, const uint32_t* __restrict__ done_before,
+                                                         uint32_t row_words, uint32_t gather_root_plus1) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_sat = rows * tiles_x;
+    if (i >= kShardExtraWords + n_sat + rows) return;
+    if (i < kShardExtraWords) {  // round 0's figures (k_pack_headers) + what this rank binned
+        uint32_t x = 0;
+        if (i == 0u) x = stats->slot_max[0];
+        else if (i == 1u) x = stats->slot_over[0];
+        else if (i == 2u) x = gather_root_plus1;
+        else if (i == 3u) x = stats->n_entries_total;
+        else if (i >= 8u) x = stats->slot_want[i - 8u];
+        out[i] = x;
+        return;
+    }
+    if (i >= kShardExtraWords + n_sat) {
+        const uint32_t ty = row_lo + (i - kShardExtraWords - n_sat);
+        out[i] = (row_work && ty < tiles_y) ? row_work[ty] : 0u;
+        return;
+    }
+    const uint32_t k = i - kShardExtraWords;
+    const uint32_t ty = row_lo + k / tiles_x, tx = k % tiles_x;
+    uint32_t s = ty < tiles_y ? tile_sat[ty * tiles_x + tx] : 0u;
+    if (done_before && ty < tiles_y && ((done_before[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)) s = 1u;
+    out[i] = s;
 }
 
 __global__ __launch_bounds__(256) void k_shard_verify(const uint32_t* __restrict__ limit, const uint32_t* __restrict__ sat, uint32_t n_tiles,
-                                                       uint32_t tiles_x, uint32_t rpr, uint32_t world, uint2* __restrict__ win2,
+                                                       uint32_t tiles_x, const BandEdges bands, uint32_t stride, uint2* __restrict__ win2,
                                                        uint32_t* __restrict__ d_need, uint32_t* __restrict__ ticket,
                                                        unsigned long long* __restrict__ host_verdict, uint32_t seq,
-                                                       uint32_t* __restrict__ need_bits) {
+                                                       uint32_t* __restrict__ need_bits, uint32_t balance) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t world = bands.world;
     bool need = false;
     if (t < n_tiles) {
         const uint32_t lim = limit ? limit[t] : 0xFFFFFFFFu;
         const uint32_t tx = t % tiles_x, ty = t / tiles_x;
-        need = lim < 0xFFFFFFFFu && sat_at(sat, tx, ty, tiles_x, rpr) == 0u;
+        need = lim < 0xFFFFFFFFu && sat_at(sat, tx, ty, tiles_x, bands, stride) == 0u;
         win2[t] = need ? make_uint2(lim, 0xFFFFFFFFu) : make_uint2(0u, 0u);
         if (need) atomicOr(&need_bits[ty * ((tiles_x + 31u) / 32u) + (tx >> 5)], 1u << (tx & 31u));
     }
@@ -328,18 +368,60 @@ __global__ __launch_bounds__(256) void k_shard_verify(const uint32_t* __restrict
     __syncthreads();
     if (threadIdx.x == 0) {
         if (s_need) atomicAdd(d_need, s_need);
-        // The last block posts the verdict of round 0 to pinned host memory — the ONE thing the host waits for in a frame:
+        // The last block posts the verdict of round 0 to pinned host memory — the ONE thing the host waits for in a frame
+        // (layout: gsx_internal.h, kVerdict*):
         //   word 1 = {largest per-destination record count over all ranks | any rank's slot overflowed}
         //   word 0 = {seq | tiles that need the repair round}     (release store: the host polls this one)
-        // Every input is globally gathered, so every rank posts the same verdict and takes the same decision.
+        //   and behind them: the count matrix (slot sizes of the next frame, pair by pair), the band edges of the next frame
+        //   (balanced by the rows' work), whether the ranks agree about the gather root, the ranks' list entries.
+        // Every input is globally gathered, so every rank posts the same verdict and takes the same decisions.
         __threadfence();
         if (atomicAdd(ticket, 1u) == gridDim.x - 1u) {
             const uint32_t total = __hip_atomic_load(d_need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t gmax = 0, over = 0;
+            uint32_t* hv = reinterpret_cast<uint32_t*>(host_verdict);
+            uint32_t gmax = 0, over = 0, root_bad = 0, ent_sum = 0, ent_max = 0;
+            const uint32_t root0 = sat[2];
             for (uint32_t g = 0; g < world; ++g) {
-                const uint32_t* x = sat + (size_t)g * (rpr * tiles_x + kShardExtraWords) + rpr * tiles_x;
+                const uint32_t* x = sat + (size_t)g * stride;
                 gmax = max(gmax, x[0]);
                 over |= x[1];
+                root_bad |= x[2] != root0 ? 1u : 0u;
+                ent_sum += x[3];
+                ent_max = max(ent_max, x[3]);
+                for (uint32_t d = 0; d < world; ++d) hv[kVerdictMatrix + g * world + d] = x[8u + d];
+            }
+            hv[4] = root_bad;
+            hv[5] = ent_sum;
+            hv[6] = ent_max;
+            {   // how evenly THIS frame's bands shared the work: busiest rank x world x 1000 / all
+                unsigned long long all = 0, busiest = 0;
+                for (uint32_t g = 0; g < world; ++g) {
+                    unsigned long long wg = 0;
+                    for (uint32_t ty = bands.e[g]; ty < bands.e[g + 1u] && ty < n_tiles / tiles_x; ++ty) wg += work_at(sat, ty, tiles_x, bands, stride);
+                    all += wg;
+                    busiest = wg > busiest ? wg : busiest;
+                }
+                hv[7] = all ? (uint32_t)(busiest * world * 1000ull / all) : 1000u;
+            }
+            // next frame's bands: contiguous runs of tile rows of (as nearly as rows allow) equal work.  A row weighs what its tiles
+            // walked this frame plus kTileWork per tile (a tile that blends nothing still reads and writes its pixels).
+            const uint32_t tiles_y = n_tiles / tiles_x;
+            if (balance) {
+                unsigned long long W = 0;
+                for (uint32_t ty = 0; ty < tiles_y; ++ty) W += (unsigned long long)work_at(sat, ty, tiles_x, bands, stride) + kTileWork * tiles_x;
+                unsigned long long acc = 0;
+                uint32_t g = 1;
+                hv[kVerdictEdges] = 0u;
+                for (uint32_t ty = 0; ty < tiles_y; ++ty) {
+                    const unsigned long long w = (unsigned long long)work_at(sat, ty, tiles_x, bands, stride) + kTileWork * tiles_x;
+                    // edge g goes in front of row ty if that is at least as close to g / world of the work as behind it
+                    while (g < world && (acc * world >= g * W || 2ull * (g * W - acc * world) <= w * world)) hv[kVerdictEdges + g++] = ty;
+                    acc += w;
+                }
+                while (g < world) hv[kVerdictEdges + g++] = tiles_y;
+                hv[kVerdictEdges + world] = tiles_y;
+            } else {
+                for (uint32_t g = 0; g <= world; ++g) hv[kVerdictEdges + g] = bands.e[g];
             }
             __hip_atomic_store(host_verdict + 1, ((unsigned long long)gmax << 32) | (over ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(host_verdict, ((unsigned long long)seq << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -373,7 +455,7 @@ __global__ __launch_bounds__(64) void k_shard_max_count(const uint32_t* __restri
 // the tile's (2 radius + 1)^2 neighbourhood — the camera moves — and unbounded if any tile of the neighbourhood stayed open
 // (parallel.next_limits is the numpy statement of the same policy).  Outside the frame counts as nothing.
 __global__ __launch_bounds__(256) void k_shard_next_limits(const uint32_t* __restrict__ sat, uint32_t tiles_x, uint32_t tiles_y, float gain,
-                                                            int radius, uint32_t* __restrict__ limit, uint32_t rpr) {
+                                                            int radius, uint32_t* __restrict__ limit, const BandEdges bands, uint32_t stride) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= tiles_x * tiles_y) return;
     const int tx = (int)(t % tiles_x), ty = (int)(t / tiles_x);
@@ -381,7 +463,7 @@ __global__ __launch_bounds__(256) void k_shard_next_limits(const uint32_t* __res
     bool open = false;
     for (int y = max(ty - radius, 0); y <= min(ty + radius, (int)tiles_y - 1); ++y)
         for (int x = max(tx - radius, 0); x <= min(tx + radius, (int)tiles_x - 1); ++x) {
-            const uint32_t s = sat_at(sat, (uint32_t)x, (uint32_t)y, tiles_x, rpr);
+            const uint32_t s = sat_at(sat, (uint32_t)x, (uint32_t)y, tiles_x, bands, stride);
             if (s == 0u) open = true;
             else deepest = fmaxf(deepest, __uint_as_float(s));
         }
@@ -412,12 +494,20 @@ hipError_t launch_limits_to_windows(hipStream_t s, const uint32_t* limit, uint32
     return hipGetLastError();
 }
 
-hipError_t launch_shard_verify(hipStream_t s, const uint32_t* limit, const uint32_t* sat, uint32_t tiles_x, uint32_t tiles_y, uint32_t rpr,
-                               uint32_t world, uint2* win2, uint32_t* d_need, uint32_t* d_ticket, unsigned long long* host_verdict, uint32_t seq,
-                               uint32_t* need_bits) {
+hipError_t launch_shard_verify(hipStream_t s, const uint32_t* limit, const uint32_t* sat, uint32_t tiles_x, uint32_t tiles_y, const BandEdges& bands,
+                               uint2* win2, uint32_t* d_need, uint32_t* d_ticket, unsigned long long* host_verdict, uint32_t seq,
+                               uint32_t* need_bits, uint32_t balance) {
     const uint32_t n_tiles = tiles_x * tiles_y;
-    GSX_LAUNCH(k_shard_verify, dim3((n_tiles + 255) / 256), dim3(256), 0, s, limit, sat, n_tiles, tiles_x, rpr, world, win2, d_need,
-                       d_ticket, host_verdict, seq, need_bits);
+    GSX_LAUNCH(k_shard_verify, dim3((n_tiles + 255) / 256), dim3(256), 0, s, limit, sat, n_tiles, tiles_x, bands, feedback_stride(bands, tiles_x), win2,
+               d_need, d_ticket, host_verdict, seq, need_bits, balance);
+    return hipGetLastError();
+}
+
+hipError_t launch_shard_feedback(hipStream_t s, const uint32_t* tile_sat, const uint32_t* row_work, uint32_t tiles_x, uint32_t tiles_y, const BandEdges& bands,
+                                 uint32_t rank, uint32_t* out, const SlabStats* stats, const uint32_t* done_before, uint32_t row_words, uint32_t gather_root_plus1) {
+    const uint32_t rows = bands.e[rank + 1u] - bands.e[rank], n = feedback_words(bands, tiles_x, rank);
+    GSX_LAUNCH(k_shard_feedback, dim3((n + 255) / 256), dim3(256), 0, s, tile_sat, row_work, tiles_x, tiles_y, bands.e[rank], rows, out, stats, done_before,
+               row_words, gather_root_plus1);
     return hipGetLastError();
 }
 
@@ -432,9 +522,9 @@ hipError_t launch_shard_max_count(hipStream_t s, const uint32_t* totals, uint32_
 }
 
 hipError_t launch_shard_next_limits(hipStream_t s, const uint32_t* sat, uint32_t tiles_x, uint32_t tiles_y, float margin, uint32_t radius,
-                                    uint32_t* limit, uint32_t rpr) {
+                                    uint32_t* limit, const BandEdges& bands) {
     GSX_LAUNCH(k_shard_next_limits, dim3((tiles_x * tiles_y + 255) / 256), dim3(256), 0, s, sat, tiles_x, tiles_y, 1.0f + margin,
-                       (int)std::min<uint32_t>(radius, 16u), limit, rpr);
+                       (int)std::min<uint32_t>(radius, 16u), limit, bands, feedback_stride(bands, tiles_x));
     return hipGetLastError();
 }
 

@@ -7,18 +7,28 @@ namespace gsx {
 
 constexpr uint32_t kWindowCoop = 32;  // rectangles with more tiles are tested against the windows by the whole wave
 
-// destinations of a record (key, tile rect): bit g set iff band g (tile rows [g*rpr, (g+1)*rpr)) holds a tile of the
+// the whole screen as one band (the single-GPU admission passes ask "does ANY tile admit it")
+__device__ inline BandEdges one_band() {
+    BandEdges b;
+    b.world = 1u;
+    b.e[0] = 0u;
+    b.e[1] = 0x10000u;
+    return b;
+}
+
+// destinations of a record (key, tile rect): bit g set iff band g (tile rows [bands.e[g], bands.e[g + 1])) holds a tile of the
 // rectangle whose window contains the key (window == nullptr: every touched band)
 __device__ inline unsigned long long dest_mask(const uint2* __restrict__ window, uint32_t tiles_x, uint32_t key,
-                                               uint32_t rx, uint32_t ry, uint32_t rpr, uint32_t world) {
+                                               uint32_t rx, uint32_t ry, const BandEdges& bands) {
     const uint32_t x0 = rx & 0xFFFFu, x1 = rx >> 16, y0 = ry & 0xFFFFu, y1 = ry >> 16;
     unsigned long long m = 0;
     if (y0 >= y1 || x0 >= x1) return 0;
-    const uint32_t g0 = y0 / rpr, g1 = min((y1 - 1u) / rpr, world - 1u);
+    const uint32_t g0 = band_of(bands, y0), g1 = band_of(bands, y1 - 1u);
     for (uint32_t g = g0; g <= g1; ++g) {
         bool hit = window == nullptr;
+        const uint32_t ya = max(y0, bands.e[g]), yb = g == g1 ? y1 : min(y1, bands.e[g + 1u]);
+        if (ya >= yb) continue;  // an empty band between two others
         if (!hit) {
-            const uint32_t ya = max(y0, g * rpr), yb = min(y1, (g + 1u) * rpr);
             for (uint32_t ty = ya; ty < yb && !hit; ++ty)
                 for (uint32_t tx = x0; tx < x1; ++tx) {
                     const uint2 w = window[ty * tiles_x + tx];
@@ -51,8 +61,9 @@ __device__ inline bool rect_hits_bitmap(const uint32_t* __restrict__ bits, uint3
 // whose rectangle holds no gated tile is refused without looking at the windows (repair round: the tiles in need).
 // Must be called by the whole wave.
 __device__ inline unsigned long long wave_dest_mask(const uint2* __restrict__ window, uint32_t tiles_x, uint32_t kk,
-                                                    uint32_t rx, uint32_t ry, uint32_t rpr, uint32_t world,
+                                                    uint32_t rx, uint32_t ry, const BandEdges& bands,
                                                     const uint32_t* __restrict__ gate = nullptr, uint32_t row_words = 0) {
+    const uint32_t world = bands.world;
     const uint32_t lane = threadIdx.x & 63u;
     unsigned long long m = 0;
     uint32_t area = 0;
@@ -61,17 +72,17 @@ __device__ inline unsigned long long wave_dest_mask(const uint2* __restrict__ wi
         const uint32_t x0 = rx & 0xFFFFu, x1 = rx >> 16, y0 = ry & 0xFFFFu, y1 = ry >> 16;
         area = (x1 - x0) * (y1 - y0);
         if (!window) {
-            m = dest_mask(window, tiles_x, kk, rx, ry, rpr, world);
+            m = dest_mask(window, tiles_x, kk, rx, ry, bands);
         } else if (x1 - x0 <= 2u && y1 - y0 <= 2u) {
             const uint32_t xb = x1 - 1u, yb = y1 - 1u;  // == x0 / y0 for a one-tile extent: the duplicates cost nothing
             const uint2 w00 = window[y0 * tiles_x + x0], w01 = window[y0 * tiles_x + xb];
             const uint2 w10 = window[yb * tiles_x + x0], w11 = window[yb * tiles_x + xb];
-            const uint32_t g0 = min(y0 / rpr, world - 1u), g1 = min(yb / rpr, world - 1u);
+            const uint32_t g0 = band_of(bands, y0), g1 = band_of(bands, yb);
             if ((kk >= w00.x && kk < w00.y) || (kk >= w01.x && kk < w01.y)) m |= 1ull << g0;
             if ((kk >= w10.x && kk < w10.y) || (kk >= w11.x && kk < w11.y)) m |= 1ull << g1;
             area = 0;
         } else if (area <= kWindowCoop) {
-            m = dest_mask(window, tiles_x, kk, rx, ry, rpr, world);
+            m = dest_mask(window, tiles_x, kk, rx, ry, bands);
         }
     }
     if (window) {
@@ -89,7 +100,7 @@ __device__ inline unsigned long long wave_dest_mask(const uint2* __restrict__ wi
                     const uint32_t ty = y0 + k / w;
                     const uint2 ww = window[ty * tiles_x + x0 + k % w];
                     if (bkey >= ww.x && bkey < ww.y) {
-                        const uint32_t g = min(ty / rpr, world - 1u);
+                        const uint32_t g = band_of(bands, ty);
                         if (g < 32u) lo |= 1u << g; else hi |= 1u << (g - 32u);
                     }
                 }
@@ -135,15 +146,14 @@ __device__ inline bool pyramid_admits(const WindowPyramid& p, uint32_t key, uint
 // allowed on the sending side of the exchange: the receiver bins every record by the exact per-tile windows, so a record
 // that travels in vain costs link bytes, never a pixel.  (The exact walk was the slowest kernel of a sharded frame: large
 // rectangles are scanned by the whole wave, one after the other.)
-__device__ inline unsigned long long dest_mask_pyramid(const WindowPyramid& p, uint32_t key, uint32_t rx, uint32_t ry, uint32_t rpr,
-                                                       uint32_t world) {
+__device__ inline unsigned long long dest_mask_pyramid(const WindowPyramid& p, uint32_t key, uint32_t rx, uint32_t ry, const BandEdges& bands) {
     const uint32_t x0 = rx & 0xFFFFu, x1 = rx >> 16, y0 = ry & 0xFFFFu, y1 = ry >> 16;
     if (key == kCulledKey || y0 >= y1 || x0 >= x1) return 0ull;
-    if (world == 1u) return pyramid_admits(p, key, rx, ry) ? 1ull : 0ull;  // one band: no integer divisions (96 -> 40 us over 10 M records)
+    if (bands.world == 1u) return pyramid_admits(p, key, rx, ry) ? 1ull : 0ull;  // one band: nothing to look up (96 -> 40 us over 10 M records)
     unsigned long long m = 0;
-    const uint32_t g0 = y0 / rpr, g1 = min((y1 - 1u) / rpr, world - 1u);
+    const uint32_t g0 = band_of(bands, y0), g1 = band_of(bands, y1 - 1u);
     for (uint32_t g = g0; g <= g1; ++g) {
-        const uint32_t ya = max(y0, g * rpr), yb = min(y1, (g + 1u) * rpr);
+        const uint32_t ya = max(y0, bands.e[g]), yb = g == g1 ? y1 : min(y1, bands.e[g + 1u]);
         if (ya < yb && pyramid_admits(p, key, rx, ya | (yb << 16))) m |= 1ull << g;
     }
     return m;

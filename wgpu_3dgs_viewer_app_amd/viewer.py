@@ -453,6 +453,22 @@ class MultiModelViewer:
                           _lib.COMM_FN(lambda ctx, s, r, b, st: int(all_gather(s, r, b, st) or 0)))
         _lib.check(self._L.gsx_viewer_comm_init_custom(self._h, int(world), int(rank), self._comm_fns[0], self._comm_fns[1], None))
 
+    def comm_init_custom_v(self, world: int, rank: int, all_to_all_v, gather_v) -> None:
+        """A transport of the caller's own that moves pieces of UNEQUAL size (``gsx_viewer_comm_init_custom_v``):
+        ``all_to_all_v(d_send, send_offsets, send_bytes, d_recv, recv_offsets, recv_bytes, hip_stream)`` and
+        ``gather_v(d_send, send_bytes, d_recv, recv_offsets, recv_bytes, root, hip_stream)`` -> gsx_status; the offset / size
+        arguments arrive as lists of `world` ints.  Both enqueue on ``hip_stream``."""
+        w = int(world)
+
+        def a2a(ctx, s, so, sb, r, ro, rb, st):
+            return int(all_to_all_v(s, [so[i] for i in range(w)], [sb[i] for i in range(w)], r, [ro[i] for i in range(w)], [rb[i] for i in range(w)], st) or 0)
+
+        def gat(ctx, s, n, r, ro, rb, root, st):
+            return int(gather_v(s, n, r, [ro[i] for i in range(w)], [rb[i] for i in range(w)], root, st) or 0)
+
+        self._comm_fns = (_lib.COMM_A2A_V_FN(a2a), _lib.COMM_GATHER_V_FN(gat))
+        _lib.check(self._L.gsx_viewer_comm_init_custom_v(self._h, w, int(rank), self._comm_fns[0], self._comm_fns[1], None))
+
     def comm_destroy(self) -> None:
         _lib.check(self._L.gsx_viewer_comm_destroy(self._h))
 
@@ -479,6 +495,25 @@ class MultiModelViewer:
     def shard_set_gather_root(self, root: int) -> None:
         """-1: every rank's framebuffer holds the whole frame after a sharded frame (default); r >= 0: only rank r's does."""
         _lib.check(self._L.gsx_shard_set_gather_root(self._h, int(root)))
+
+    def shard_set_band_edges(self, world: int, edges) -> None:
+        """Rank g owns the tile rows [edges[g], edges[g + 1]) in every following sharded frame (None: the library's own layout)."""
+        if edges is None:
+            _lib.check(self._L.gsx_shard_set_band_edges(self._h, int(world), None))
+            return
+        a = np.ascontiguousarray(edges, np.uint32)
+        assert a.size == world + 1
+        _lib.check(self._L.gsx_shard_set_band_edges(self._h, int(world), _u32p(a)))
+
+    def shard_get_band_edges(self, world: int) -> np.ndarray:
+        """The band layout the last sharded frame used (uint32 [world + 1] tile rows)."""
+        out = np.empty(world + 1, np.uint32)
+        _lib.check(self._L.gsx_shard_get_band_edges(self._h, int(world), _u32p(out)))
+        return out
+
+    def shard_set_balance(self, enabled: bool) -> None:
+        """Balance the bands by the previous frame's per-row work (default, where the transport moves unequal pieces) or keep them equal."""
+        _lib.check(self._L.gsx_shard_set_balance(self._h, 1 if enabled else 0))
 
     def shard_download_limits(self, key: str) -> np.ndarray:
         w, h = self.size
