@@ -128,6 +128,27 @@ def cpu_baseline(cfg, n_sample, pose=0):
 # before the parent touches the GPU.  gfx950 correction per the guide: FETCH_SIZE tallies a wide coalesced streaming read
 # at half its bytes -> doubled; WRITE_SIZE taken as reported.
 # ------------------------------------------------------------------------------------------------
+def predicted_for(world, workload):
+    """What tools/rank_alone.py predicted for this world size from a ONE-GPU box (every rank of an N-rank frame replayed alone on the GPU
+    against the pieces it received; profiles/r04_rank_alone.json, committed): the number this line's `value` can prove wrong."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_rank_alone.json")
+    try:
+        with open(path) as f:
+            table = json.loads(f.read().strip().splitlines()[-1])
+    except (OSError, ValueError):
+        return None
+    if table.get("workload") != workload:
+        return None
+    rows = {}
+    for r in table["runs"]:
+        if r["world"] == world and r["scene"] == "orbit":
+            rows[f"speculate={r['speculate']} frames_in_flight={r['frames_in_flight']}"] = dict(
+                fps=r["predicted_fps"], slowest_rank_ms_alone=r["slowest_rank_ms"], fastest_rank_ms_alone=r["fastest_rank_ms"],
+                wire_ms_at_7x153GBps=r["wire_ms_at_7x153GBps"])
+    return dict(source="profiles/r04_rank_alone.json (tools/rank_alone.py on a one-GPU box; read from that file, not measured in this run)",
+                method=table.get("method"), single_gpu_fps_in_that_run=table.get("single_gpu_fps"), by_schedule=rows) if rows else None
+
+
 def pmc_traffic(args):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
@@ -384,6 +405,20 @@ def main():
                 raise SystemExit(f"bench.py: the sharded frame differs from the single-GPU frame: {frame_check}")
         dist.barrier()
     acct = accounting(rounds(args.warmup))
+    # N > 1 (index shards): the same K steps with the exchange unfiltered and every shard projected and shaded in full
+    # (gsx_shard_render_frame(speculate = 0)) — the schedule whose dominant pass shards 1 / N; read it against the N = 1 line's
+    # value_unspeculated
+    elapsed_dist_u = None
+    shard_stats_unspec = None
+    if lib_index and world > 1 and not args.no_extra_legs:
+        renderer.speculate = False
+        viewer.shard_stats(reset=True)
+        elapsed_dist_u, _, _ = timed_loop(0)
+        shard_stats_unspec = viewer.shard_stats(reset=True)
+        renderer.speculate = True
+        for i in range(rounds(args.warmup)):   # (the limits of the frames that follow come from speculated frames again)
+            frame(i)
+        renderer.poll()
     elapsed_1 = elapsed_ul = None
     if lanes > 1 and (single or world == 1):   # (N > 1: one timed loop, as the contract says)
         set_opts()
@@ -574,10 +609,13 @@ def main():
         renderer.poll()
         tm_all = renderer.get_pass_timing()
         renderer.set_pass_timing(False)
+        edges_now = [int(x) for x in viewer.shard_get_band_edges(world)]
         mine = torch.tensor([shard_stats_timed["wire_bytes"] / frames_stats, shard_stats_timed["repair_frames"] / frames_stats,
                              shard_stats_timed["redo_frames"] / frames_stats, shard_stats_timed["verdict_wait_ns"] / 1e3 / frames_stats,
                              shard_stats_timed["exchange_rounds"] / frames_stats, shard_stats_timed["last_slot_records"],
-                             count] + [tm_all[name]["ms"] * 1e3 / n_prof for name in ("project", "project_geom", "depth_sort", "bin", "tile_sort", "composite")],
+                             count] + [tm_all[name]["ms"] * 1e3 / n_prof for name in ("project", "project_geom", "depth_sort", "bin", "tile_sort", "composite")]
+                            + [acct[:, 5].mean(), edges_now[rank + 1] - edges_now[rank],
+                               (shard_stats_unspec["wire_bytes"] / max(shard_stats_unspec["frames"], 1)) if shard_stats_unspec else 0.0],
                             dtype=torch.float64, device="cuda")
         gathered = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
@@ -590,7 +628,15 @@ def main():
             verdict_wait_us_per_frame=[round(float(x), 1) for x in g_all[:, 3]], exchange_rounds_per_frame=[round(float(x), 3) for x in g_all[:, 4]],
             slot_records_last_frame=[int(x) for x in g_all[:, 5]],
             pass_us_per_frame={name: [round(float(x), 1) for x in g_all[:, 7 + k]]
-                               for k, name in enumerate(("project", "project_geom", "depth_sort", "bin", "tile_sort", "composite"))})
+                               for k, name in enumerate(("project", "project_geom", "depth_sort", "bin", "tile_sort", "composite"))},
+            list_entries_per_frame=[int(x) for x in g_all[:, 13]],
+            list_entries_max_over_mean=round(float(g_all[:, 13].max() * world / max(g_all[:, 13].sum(), 1.0)), 3),
+            band_rows=[int(x) for x in g_all[:, 14]], band_edges=edges_now,
+            work_busiest_rank_over_mean=round(shard_stats_timed["last_work_permille"] / 1000.0, 3),
+            bands="tile rows [band_edges[g], band_edges[g + 1]) belong to rank g; cut by the previous frame's per-row work (list entries the "
+                  "compositor's tiles walked, all-gathered with the saturation map): work_busiest_rank_over_mean is that measure for the last "
+                  "timed frame, list_entries_max_over_mean the ranks' binned entries",
+            wire_bytes_per_frame_unspeculated=[int(x) for x in g_all[:, 15]] if shard_stats_unspec else None)
 
     if rank == 0:
         fps = args.steps / elapsed
@@ -751,8 +797,14 @@ def main():
             out["passes"] = dict(speculated=passes_of(*pr["speculated"], True), unspeculated=passes_of(*pr["unspeculated"], False),
                                  note="one frame in flight, every pass bracketed with a pair of HIP events on the viewer's stream (each bracket costs a "
                                       "few microseconds of stream gap: the frame is slower than value_one_frame_in_flight)")
+        if elapsed_dist_u is not None:
+            out["value_unspeculated"] = round(args.steps / elapsed_dist_u, 3)
+            out["value_unspeculated_note"] = ("the same K steps through gsx_shard_render_frame(speculate = 0): every shard projected and shaded in "
+                                              "full, the exchange unfiltered (whole-shard slots); compare with value_unspeculated of the N = 1 line")
         if per_rank is not None:
             out["per_rank"] = per_rank
+        if lib_index and world > 1:
+            out["predicted"] = predicted_for(world, args.workload)
         if frame_check is not None and "frame_check" not in out:
             out["frame_check"] = frame_check
         if one_device:

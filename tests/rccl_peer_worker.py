@@ -152,7 +152,7 @@ def main():
             return 1
         print(f"rank {rank}: OK ({mode}, {lanes} lane(s), {stats['wire_bytes']} bytes on the links)", flush=True)
         return 0
-    frames = []
+    frames, bands = [], []
     for pose in POSES:
         uniforms(v, pose)
         if mode == "all_refusing":   # verdict -> exactly sized repair round over the links
@@ -162,15 +162,16 @@ def main():
         v.shard_render_frame("m", shard_max)
         if lanes == 1:
             frames.append(v.download_framebuffer().copy())
+            bands.append(v.shard_get_band_edges(world).copy())   # (balanced bands: the layout moves from frame to frame)
     if lanes > 1:  # frames in flight: the last frame is what the viewer holds after a sync
         frames = [None] * (len(POSES) - 1) + [v.download_framebuffer().copy()]
+        bands = [None] * (len(POSES) - 1) + [v.shard_get_band_edges(world).copy()]
     stats = v.shard_stats()
     v.close()
     if mode == "root_gather" and rank != 0:   # only rank 0 holds the frame; this rank still holds its own band of tile rows
-        rows = 16 * ((TILES[0] + world - 1) // world)
-        lo, hi = min(rank * rows, H), min((rank + 1) * rows, H)
-        frames = [None if fb is None else fb[lo:hi] for fb in frames]
-        ref = [fb[lo:hi] for fb in ref]
+        cut = [None if e is None else (min(16 * int(e[rank]), H), min(16 * int(e[rank + 1]), H)) for e in bands]
+        frames = [None if fb is None else fb[cut[k][0]:cut[k][1]] for k, fb in enumerate(frames)]
+        ref = [fb if cut[k] is None else fb[cut[k][0]:cut[k][1]] for k, fb in enumerate(ref)]
     bad = [k for k, fb in enumerate(frames) if fb is not None and not np.array_equal(fb, ref[k])]
     print(f"rank {rank}: stats {stats}", flush=True)
     if bad:

@@ -1,0 +1,314 @@
+"""What would ONE rank of an N-GPU sharded frame cost if it had a GPU to itself?  (a falsifiable prediction
+of the 2 / 4 / 8-GPU rate from a one-GPU box.)
+
+No reference counterpart (the reference renders on one wgpu device, src/main.rs:85-98); the design is SURVEY.md 8(e).
+
+Phase 1, record: `world` ranks run as host threads on the one GPU, each with its index shard, each calling the library's own
+frame loop (gsx_shard_render_frame) over a transport of THIS file (gsx_viewer_comm_init_custom_v: device copies between the ranks'
+buffers, delivered in rank order like RCCL).  Besides delivering, the transport keeps, per rank, every piece that rank RECEIVED in
+every collective of every frame — slots, feedback, repair counts, bands.
+Phase 2, replay: one rank at a time, ALONE on the GPU, runs the same frames through the same library call; its transport now
+serves the recorded pieces as device copies (the rank's own pieces are copied as the library asks).  Its behaviour is that of the
+N-rank run — same shard, same limits, same slots, same verdicts, same band — and the frames it renders are compared with the
+recording's (band checksums).  What is timed is the rank's wall time per frame with nothing else on the device: projection of
+its shard, pack, import, sort, bin, composite of its band, verification — everything but the time the bytes spend on the links,
+which is added as wire bytes / (7 links x 153 GB/s) (MI355X_MICROARCH.md: xGMI point-to-point).
+
+Output: one JSON object — per world, scene and schedule: every rank's ms per frame alone, its wire bytes, list entries, the
+band edges; and predicted fps = 1 / (max over ranks (ms alone) + max wire time).  The driver's 8-GPU SCALE run can prove it wrong.
+
+usage: python tools/rank_alone.py [--worlds 2,4,8] [--frames 40] [--workload cfg4] [--scenes orbit,open_sky] [--out file.json]"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wgpu_3dgs_viewer_app_amd import camera, parallel, scene  # noqa: E402
+from wgpu_3dgs_viewer_app_amd.mask import MaskEvaluator, MaskOp, MaskShape, MaskShapeKind  # noqa: E402
+from wgpu_3dgs_viewer_app_amd.viewer import GaussianDisplayMode, GaussianShDegree, MultiModelViewer  # noqa: E402
+
+XGMI_LINK_GBPS, XGMI_LINKS = 153.0, 7
+hip = C.CDLL("libamdhip64.so")
+hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+hip.hipFree.argtypes = [C.c_void_p]
+D2D = 3
+
+
+def dmalloc(n):
+    p = C.c_void_p()
+    assert hip.hipMalloc(C.byref(p), max(int(n), 1)) == 0
+    return p.value
+
+
+class Hub:
+    """Phase 1: the ranks' meeting point (host threads of one process)."""
+
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world, timeout=300.0)
+        self.pub = [None] * world
+        self.log = [[] for _ in range(world)]   # per rank: [(kind, [(offset, bytes, device copy of the piece) per source])]
+
+
+class RecordingTransport:
+    def __init__(self, hub, rank):
+        self.hub, self.rank = hub, rank
+
+    def _meet(self, stream, item):
+        hip.hipStreamSynchronize(stream)   # what this rank contributes exists
+        self.hub.pub[self.rank] = item
+        self.hub.barrier.wait()
+
+    def all_to_all_v(self, d_send, so, sb, d_recv, ro, rb, stream):
+        h, me = self.hub, self.rank
+        self._meet(stream, (d_send, so, sb))
+        pieces = []
+        for p in range(h.world):
+            ps, pso, psb = h.pub[p]
+            assert psb[me] == rb[p], f"rank {p} has {psb[me]} bytes for rank {me}, which expects {rb[p]}"
+            keep = dmalloc(rb[p])
+            if rb[p]:
+                hip.hipMemcpyAsync(d_recv + ro[p], ps + pso[me], rb[p], D2D, stream)
+                hip.hipMemcpyAsync(keep, ps + pso[me], rb[p], D2D, stream)
+            pieces.append((ro[p], rb[p], keep))
+        hip.hipStreamSynchronize(stream)
+        h.log[me].append(("a2a", pieces))
+        h.barrier.wait()   # every reader is done with the peers' send buffers
+        return 0
+
+    def gather_v(self, d_send, n, d_recv, ro, rb, root, stream):
+        h, me = self.hub, self.rank
+        self._meet(stream, (d_send, n))
+        pieces = []
+        if root < 0 or root == me:
+            for p in range(h.world):
+                ps, pn = h.pub[p]
+                assert pn == rb[p]
+                keep = dmalloc(rb[p])
+                if rb[p]:
+                    if ps != d_recv + ro[p]:
+                        hip.hipMemcpyAsync(d_recv + ro[p], ps, rb[p], D2D, stream)
+                    hip.hipMemcpyAsync(keep, ps, rb[p], D2D, stream)
+                pieces.append((ro[p], rb[p], keep))
+            hip.hipStreamSynchronize(stream)
+        h.log[me].append(("gather", pieces))
+        h.barrier.wait()
+        return 0
+
+
+class ReplayTransport:
+    """Phase 2: the recorded pieces of ONE rank, served in the order the library asks for them."""
+
+    def __init__(self, world, rank, log):
+        self.world, self.rank, self.log, self.at = world, rank, log, 0
+        self.wire = 0
+
+    def _next(self, kind):
+        k, pieces = self.log[self.at]
+        assert k == kind, f"replay out of step: call {self.at} was recorded as {k}, the library now asks for {kind}"
+        self.at += 1
+        return pieces
+
+    def all_to_all_v(self, d_send, so, sb, d_recv, ro, rb, stream):
+        for p, (off, n, keep) in enumerate(self._next("a2a")):
+            assert off == ro[p] and n == rb[p], "replay: the rank sizes its slots differently from the recording"
+            if p == self.rank:
+                if n:
+                    hip.hipMemcpyAsync(d_recv + off, d_send + so[p], n, D2D, stream)   # its own slot: a device copy, as over RCCL
+            elif n:
+                hip.hipMemcpyAsync(d_recv + off, keep, n, D2D, stream)
+        self.wire += sum(b for p, b in enumerate(sb) if p != self.rank)
+        return 0
+
+    def gather_v(self, d_send, n, d_recv, ro, rb, root, stream):
+        pieces = self._next("gather")
+        if root < 0 or root == self.rank:
+            for p, (off, m, keep) in enumerate(pieces):
+                assert off == ro[p] and m == rb[p]
+                if p == self.rank:
+                    if m and d_send != d_recv + off:
+                        hip.hipMemcpyAsync(d_recv + off, d_send, m, D2D, stream)
+                elif m:
+                    hip.hipMemcpyAsync(d_recv + off, keep, m, D2D, stream)
+        self.wire += (self.world - 1) * n if root < 0 else (0 if root == self.rank else n)
+        return 0
+
+
+SHARDS = {}   # (world, rank) -> the shard's Gaussians (generated once per world)
+
+
+def make_viewer(cfg, rank, world, open_sky, lanes=1):
+    n, sh, w, h, seed = cfg
+    s0, c = parallel.shard_range(n, rank, world)
+    if (world, rank) not in SHARDS:
+        SHARDS[(world, rank)] = scene.synthetic_gaussians(n, seed, sh, s0, c)
+    g = SHARDS[(world, rank)]
+    v = MultiModelViewer()
+    v.set_render_options(frames_in_flight=lanes)
+    v.add_model("m", c)
+    v.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g)
+    if open_sky:   # bench.py's robustness scene: the Gaussians with y <= 0.5 (the screen above the horizon stays open)
+        sky = [MaskShape(MaskShapeKind.Box, pos=np.array([0.0, -4.5, 0.0], np.float32), scale=np.array([10.0, 5.0, 10.0], np.float32))]
+        MaskEvaluator(v).evaluate(MaskOp.parse("0"), "m", sky)
+    v.update_gaussian_transform(1.0, GaussianDisplayMode.Splat, GaussianShDegree.new(sh), False)
+    v.shard_set_gather_root(0)
+    return v, (n + world - 1) // world
+
+
+def band_checksum(v, world, rank):
+    e = v.shard_get_band_edges(world)
+    fb = v.download_framebuffer()
+    lo, hi = 16 * int(e[rank]), min(16 * int(e[rank + 1]), fb.shape[0])
+    return int(np.frombuffer(fb[lo:hi].tobytes(), np.uint32).astype(np.uint64).sum() & 0xFFFFFFFFFFFF), e.tolist()
+
+
+def run(cfg, world, frames, open_sky, speculate, orbit, lanes):
+    n, sh, w, h, seed = cfg
+    hub = Hub(world)
+    out = [None] * world
+    errors = []
+
+    def record(rank):
+        try:
+            v, shard_max = make_viewer(cfg, rank, world, open_sky, lanes)
+            v.comm_init_custom_v(world, rank, RecordingTransport(hub, rank).all_to_all_v, RecordingTransport(hub, rank).gather_v)
+            marks, sums = [], []
+            warm = max(1, min(10, frames // 4))
+            for i in range(frames):
+                if i == warm:
+                    v.poll()   # (the replay starts its clock here: with frames in flight that completes them — the same calls in both phases)
+                v.update_camera(orbit[i % 240], (w, h))
+                marks.append(len(hub.log[rank]))
+                v.shard_render_frame("m", shard_max, speculate=bool(speculate))
+                # (frames in flight: a readback completes them — it would change the order of the collectives; only the last
+                #  frame is compared then)
+                sums.append(band_checksum(v, world, rank) if lanes == 1 or i == frames - 1 else None)
+            st = v.shard_stats()
+            entries = v.frame_stats("m")["n_tile_entries"]
+            v.close()
+            out[rank] = dict(marks=marks, sums=sums, stats=st, entries=entries, shard_max=shard_max)
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+            hub.barrier.abort()
+
+    th = [threading.Thread(target=record, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    if errors:
+        raise [e for e in errors if not isinstance(e, threading.BrokenBarrierError)][0] if any(
+            not isinstance(e, threading.BrokenBarrierError) for e in errors) else errors[0]
+
+    ranks = []
+    warm = max(1, min(10, frames // 4))
+    for rank in range(world):   # phase 2: one rank at a time, nothing else on the GPU
+        v, shard_max = make_viewer(cfg, rank, world, open_sky, lanes)
+        tr = ReplayTransport(world, rank, hub.log[rank])
+        v.comm_init_custom_v(world, rank, tr.all_to_all_v, tr.gather_v)
+        same = True
+        t_mark = wire_mark = None
+        for i in range(frames):
+            if i == warm:
+                v.poll()
+                t_mark, wire_mark = time.perf_counter(), tr.wire
+            v.update_camera(orbit[i % 240], (w, h))
+            v.shard_render_frame("m", shard_max, speculate=bool(speculate))
+            if i < warm and lanes == 1:   # (checking costs a readback: only untimed frames are checked, the last one after the clock stops)
+                v.poll()
+                same = same and band_checksum(v, world, rank) == out[rank]["sums"][i]
+        v.poll()
+        elapsed = time.perf_counter() - t_mark
+        same = same and band_checksum(v, world, rank) == out[rank]["sums"][frames - 1]
+        st = v.shard_stats()
+        timed = frames - warm
+        ranks.append(dict(rank=rank, ms_per_frame_alone=round(1e3 * elapsed / timed, 4), wire_bytes_per_frame=int((tr.wire - wire_mark) / timed),
+                          frames_equal_to_the_recording=bool(same), list_entries_last_frame=int(out[rank]["entries"]),
+                          repair_frames=round(out[rank]["stats"]["repair_frames"] / frames, 3), redo_frames=round(out[rank]["stats"]["redo_frames"] / frames, 3),
+                          band_rows_last_frame=[out[rank]["sums"][-1][1][rank], out[rank]["sums"][-1][1][rank + 1]]))
+        v.close()
+    for lg in hub.log:
+        for _, pieces in lg:
+            for _, _, keep in pieces:
+                hip.hipFree(keep)
+    slowest = max(r["ms_per_frame_alone"] for r in ranks)
+    wire_ms = max(r["wire_bytes_per_frame"] for r in ranks) / (XGMI_LINKS * XGMI_LINK_GBPS * 1e9) * 1e3
+    ent = [r["list_entries_last_frame"] for r in ranks]
+    return dict(world=world, scene="open_sky" if open_sky else "orbit", speculate=int(speculate), frames_in_flight=lanes, frames_timed=frames - warm, ranks=ranks,
+                slowest_rank_ms=round(slowest, 4), fastest_rank_ms=round(min(r["ms_per_frame_alone"] for r in ranks), 4),
+                wire_ms_at_7x153GBps=round(wire_ms, 4), predicted_fps=round(1e3 / (slowest + wire_ms), 1),
+                list_entries_max_over_mean=round(max(ent) * world / max(sum(ent), 1), 3),
+                band_edges_last_frame=out[0]["sums"][-1][1], all_frames_equal_to_the_recording=all(r["frames_equal_to_the_recording"] for r in ranks))
+
+
+def single_gpu(cfg, frames, open_sky, speculate, orbit, lanes):
+    """the same scene on the single-GPU path, same process: what N = 1 means in the table"""
+    n, sh, w, h, seed = cfg
+    v, _ = make_viewer(cfg, 0, 1, open_sky)
+    v.set_render_options(speculative=int(speculate), frames_in_flight=lanes)
+    for i in range(10):
+        v.update_camera(orbit[i % 240], (w, h))
+        v.render_frame(["m"])
+    v.poll()
+    t0 = time.perf_counter()
+    for i in range(10, 10 + frames):
+        v.update_camera(orbit[i % 240], (w, h))
+        v.render_frame(["m"])
+    v.poll()
+    el = time.perf_counter() - t0
+    v.close()
+    return round(frames / el, 1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--worlds", default="2,4,8")
+    ap.add_argument("--frames", type=int, default=40)
+    ap.add_argument("--workload", default="cfg4")
+    ap.add_argument("--scenes", default="orbit,open_sky")
+    ap.add_argument("--unspeculated-frames", type=int, default=8)
+    ap.add_argument("--lanes", default="1,2", help="frames in flight of the replayed rank (and of the recording)")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    cfg = scene.CONFIGS[a.workload]
+    n, sh, w, h, seed = cfg
+    orbit = [camera.PrecomputedCamera(camera.orbit_pose(k), w / h) for k in range(240)]
+    res = dict(tool="tools/rank_alone.py", workload=a.workload, gaussians=n, size=[w, h],
+               method="every rank of an N-rank gsx_shard_render_frame run replayed ALONE on the GPU against the pieces it received in the "
+                      "N-rank run (threads, one GPU); predicted fps = 1 / (slowest rank's ms alone + busiest rank's wire bytes / (7 x 153 GB/s)); "
+                      "the transport's callbacks are Python (their host time is inside ms_per_frame_alone — an upper bound — and hides behind the "
+                      "other frame's device work with two frames in flight)",
+               single_gpu_fps={}, runs=[])
+    lanes_list = [int(x) for x in a.lanes.split(",")]
+    for sc in a.scenes.split(","):
+        for spec in (1, 0):
+            for lanes in lanes_list:
+                res["single_gpu_fps"][f"{sc} speculate={spec} frames_in_flight={lanes}"] = single_gpu(cfg, max(a.frames, 120), sc == "open_sky", spec, orbit, lanes)
+    SHARDS.clear()
+    for world in [int(x) for x in a.worlds.split(",")]:
+        SHARDS.clear()
+        for sc in a.scenes.split(","):
+            for spec, lanes in [(s, l) for s in (1, 0) for l in lanes_list]:
+                # (speculate = 0: every visible record travels and a slot holds a whole shard — 60 MB x 8 x 8 per frame at world 8 on
+                #  cfg4: the recording keeps fewer frames)
+                frames = a.frames if spec else min(a.frames, a.unspeculated_frames)
+                r = run(cfg, world, frames, sc == "open_sky", spec, orbit, lanes)
+                res["runs"].append(r)
+                print(f"world {world} {sc} speculate={spec} lanes={lanes}: predicted {r['predicted_fps']} fps (slowest rank {r['slowest_rank_ms']} ms, fastest "
+                      f"{r['fastest_rank_ms']}, wire {r['wire_ms_at_7x153GBps']} ms, entries max/mean {r['list_entries_max_over_mean']}, equal "
+                      f"{r['all_frames_equal_to_the_recording']})", file=sys.stderr, flush=True)
+    txt = json.dumps(res)
+    if a.out:
+        with open(a.out, "w") as f:
+            f.write(txt + "\n")
+    print(txt)
+
+
+if __name__ == "__main__":
+    main()

@@ -282,7 +282,7 @@ gsx_status pack_count(gsx_viewer* v, Model* m, uint32_t world, const uint2* expl
 }
 
 // pack_write: shade the travellers the lazy projection skipped, slot headers, the records into their slots
-gsx_status pack_write(gsx_viewer* v, Model* m, uint32_t world, void* d_send, uint32_t slot_stride, uint32_t slot_cap, uint32_t round) {
+gsx_status pack_write(gsx_viewer* v, Model* m, uint32_t world, void* d_send, const SlotSpans& slots, uint32_t round) {
     const uint32_t n = (uint32_t)m->n;
     const uint32_t nb = (uint32_t)pack_blocks(n, m->pack_rounds);
     Counters* dc = m->counters.as<Counters>();
@@ -298,10 +298,12 @@ gsx_status pack_write(gsx_viewer* v, Model* m, uint32_t world, void* d_send, uin
         m->cand_valid = false;
         m->pack_travellers = false;
     }
-    HIPCHK(launch_pack_headers(v->stream, totals, world, slot_stride, slot_cap, d_send, dc, round));
+    HIPCHK(launch_pack_headers(v->stream, totals, world, slots, d_send, dc, round));
+    uint64_t send_records = 0;
+    for (uint32_t p = 0; p < world; ++p) send_records = std::max<uint64_t>(send_records, (uint64_t)slots.off[p] + 1u + slots.cap[p]);
     HIPCHK(launch_pack_scatter(v->stream, m->proj_rec(), n, world, m->pack_masks.as<unsigned long long>(), table, totals, d_send,
-                               (uint64_t)world * slot_stride, m->pack_list ? m->adm_pairs.as<uint2>() : nullptr,
-                               m->pack_list ? &dc->n_candidates : nullptr, slot_stride, slot_cap));
+                               send_records, m->pack_list ? m->adm_pairs.as<uint2>() : nullptr,
+                               m->pack_list ? &dc->n_candidates : nullptr, &slots));
     m->stats_pending = true;
     return GSX_OK;
 }
@@ -382,12 +384,20 @@ gsx_status gsx_shard_slot_records(gsx_viewer* v, const char* key, uint32_t world
 }
 
 gsx_status gsx_shard_pack_slots(gsx_viewer* v, const char* key, uint32_t world, uint32_t round, void* d_send, uint32_t slot_records) {
+    if (world == 0 || world > 64 || slot_records == 0) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack_slots: bad argument");
+    return shard_pack_slots(v, key, world, round, d_send, uniform_slots(world, slot_records));
+}
+
+}  // extern "C"
+
+// slots: where the records for every destination go (sizes that both ends of every pair agree on: gsx_shard_frame.cpp)
+gsx_status gsx::shard_pack_slots(gsx_viewer* v, const char* key, uint32_t world, uint32_t round, void* d_send, const SlotSpans& slots) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
     Model* m = find_model(v, key);
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_pack_slots: no model '%s'", key ? key : "(null)");
     if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack_slots: model '%s' has no projection this frame (gsx_shard_frame_begin first)", key);
-    if (world == 0 || world > 64 || round > 1 || !d_send || slot_records == 0) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack_slots: bad argument");
+    if (world == 0 || world > 64 || round > 1 || !d_send) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack_slots: bad argument");
     if (round == 1) {
         if (m->shard_win2.bytes < window_bytes(v)) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack_slots: round 1 before gsx_shard_verify");
         // the repair round is counted once (gsx_shard_repair_count sized it); packing without it counts here
@@ -399,8 +409,10 @@ gsx_status gsx_shard_pack_slots(gsx_viewer* v, const char* key, uint32_t world, 
         WindowPyramid pyr = window_pyramid_layout(m->shard_tiles_x, m->shard_tiles_y, m->shard_pyr.as<uint32_t>());
         if ((st = pack_count(v, m, world, nullptr, nullptr, m->shard_win_set ? &pyr : nullptr))) return st;
     }
-    return pack_write(v, m, world, d_send, slot_records + 1u, slot_records, round);
+    return pack_write(v, m, world, d_send, slots, round);
 }
+
+extern "C" {
 
 gsx_status gsx_shard_repair_count(gsx_viewer* v, const char* key, uint32_t world, void* d_out4) {
     gsx_status st = viewer_bind(v);
@@ -427,6 +439,15 @@ gsx_status gsx_shard_post_counts(gsx_viewer* v, uint32_t world, const void* d_co
 
 gsx_status gsx_shard_import_slots(gsx_viewer* v, const char* key, const void* d_recv, uint32_t world, uint32_t rank, uint32_t round_flags,
                                   uint32_t slot_records) {
+    if (world == 0 || world > 64 || slot_records == 0) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import_slots: bad argument");
+    return shard_import_slots(v, key, d_recv, world, rank, round_flags, uniform_slots(world, slot_records));
+}
+
+}  // extern "C"
+
+// slots: where every source's records lie in d_recv
+gsx_status gsx::shard_import_slots(gsx_viewer* v, const char* key, const void* d_recv, uint32_t world, uint32_t rank, uint32_t round_flags,
+                                   const SlotSpans& slots) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
     Model* m = find_model(v, key);
@@ -434,12 +455,13 @@ gsx_status gsx_shard_import_slots(gsx_viewer* v, const char* key, const void* d_
     if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import_slots: model '%s' has no frame constants (gsx_shard_frame_begin first)", key);
     const uint32_t round = round_flags & 1u;
     const bool behind = (round_flags & GSX_SHARD_BEHIND) != 0;  // a layered frame: nearer models are in the framebuffer already
-    if (world == 0 || world > 64 || rank >= world || round_flags > 3u || !d_recv || slot_records == 0)
+    if (world == 0 || world > 64 || rank >= world || round_flags > 3u || !d_recv)
         return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import_slots: bad argument");
-    const uint64_t cap = (uint64_t)world * slot_records;
+    uint64_t cap = 0;
+    for (uint32_t p = 0; p < world; ++p) cap += slots.cap[p];
     if (cap >= 0xFFFFFFF0ull) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import_slots: too many records");
-    if ((st = ensure_import_capacity(m, cap))) return st;
-    HIPCHK(launch_import_slots(v->stream, d_recv, world, slot_records + 1u, slot_records, m->imp_rec(), m->counters.as<Counters>()));
+    if ((st = ensure_import_capacity(m, std::max<uint64_t>(cap, 1)))) return st;
+    HIPCHK(launch_import_slots(v->stream, d_recv, world, slots, m->imp_rec(), m->counters.as<Counters>()));
     m->stats_pending = true;
     m->rec_n = cap;  // an upper bound: the count is on the device (Counters::n_sorted)
     m->use_imported = true;
@@ -471,6 +493,8 @@ gsx_status gsx_shard_import_slots(gsx_viewer* v, const char* key, const void* d_
     const char* keys[1] = {m->key.c_str()};
     return do_render(v, keys, 1, round == 1 || behind);
 }
+
+extern "C" {
 
 gsx_status gsx_shard_verify(gsx_viewer* v, const char* key, uint32_t world, const void* d_sat_all, uint32_t* out_seq) {
     gsx_status st = viewer_bind(v);

@@ -608,7 +608,9 @@ static void merge_tail_slabs(std::vector<uint32_t>* bounds, uint32_t used) {
 // Slab bounds are planned on the record count (an upper bound of N_vis; kernels clamp to the device-side
 // N_vis), slab entry counts stay on the device, and once every tile this rank owns is saturated the
 // remaining slabs' kernels fall through.  carry: the framebuffer already holds nearer models.
-static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool counters_zeroed = false) {
+// frame_zero (nullable; the frame's first model): the frame's saturation state, to be zeroed together with this model's per-frame
+// totals before anything of the frame reads them — folded into the first slab's block-table kernel where there is one.
+static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, const ZeroJob* frame_zero = nullptr) {
     if (!m->sorted) return fail(GSX_ERR_INVALID_ARG, "gsx_render: model '%s' was not preprocessed+sorted", m->key.c_str());
     if (m->order_consumed)
         return fail(GSX_ERR_INVALID_ARG, "gsx_render: the depth order of '%s' was consumed by a speculated frame's repair round; "
@@ -677,9 +679,14 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
         if (sizeof(uint2) * (size_t)n_tiles > m->ranges.bytes) m->ranges_clean = false;
         HIPCHK(m->ranges.ensure(sizeof(uint2) * (size_t)std::max<uint32_t>(n_tiles, 1024u)));  // (block lists: up to 1024 block ranges)
     }
-    // reset this model's per-frame totals (n_visible and n_sorted stay)
-    if (!counters_zeroed)  // (the frame's first model: done together with the saturation state, one launch)
-        HIPCHK(launch_zero_words(v->stream, &dc->n_entries, (uint32_t)((sizeof(Counters) - offsetof(Counters, n_entries)) / 4), nullptr, 0));
+    // reset this model's per-frame totals (n_visible and n_sorted stay) — and, for the frame's first model, the frame's saturation
+    // state: one launch, or none where the first slab's block-table kernel can do it on its way (below)
+    ZeroJob zero{&dc->n_entries, (uint32_t)((sizeof(Counters) - offsetof(Counters, n_entries)) / 4), nullptr, 0};
+    if (frame_zero) {
+        zero.b = frame_zero->a;
+        zero.nb = frame_zero->na;
+    }
+    bool zero_pending = true;
     const uint32_t* done_before = nullptr;
     if (speculate) {
         const size_t bm = 4 * (size_t)row_words * m->fc.tiles_y;
@@ -697,6 +704,10 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
     // a single-slab front model keeps complete per-tile lists (gsx_model_download_tile_lists): that frame bins by tile
     const bool lists_wanted = bounds.size() == 2 && !carry && !m->spec_round1 && !imported_windows;
     const bool blocks = progressive && v->bin_mode == 1 && !lists_wanted;
+    if (!blocks || bounds.size() < 2 || bounds[1] == bounds[0]) {  // no block-table kernel ahead (or no slab at all): zero here
+        HIPCHK(launch_zero_words(v->stream, zero.a, zero.na, zero.b, zero.nb));
+        zero_pending = false;
+    }
     uint32_t bsx = 0, bsy = 0;
     if (blocks) {
         auto count = [&]() { return (uint64_t)((m->fc.tiles_x + (1u << bsx) - 1u) >> bsx) * ((m->fc.tiles_y + (1u << bsy) - 1u) >> bsy); };
@@ -707,7 +718,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
     const bool clear_ranges = progressive && !(bounds.size() == 2 && !carry && !m->spec_round1 && !imported_windows);
     // one depth slab [j0, j1) of the current depth order: bin -> tile sort -> ranges -> composite
     auto run_slab = [&](uint32_t j0, uint32_t j1, bool later, const uint2* win, const uint32_t* d_n, uint32_t slab_index,
-                        const WindowPyramid* min_ends = nullptr) -> gsx_status {
+                        const WindowPyramid* min_ends = nullptr, bool table_ready = false) -> gsx_status {
         // the very first slab of the frame sees no saturated tile: plain rectangle areas
         const uint32_t* done_in = later ? done : nullptr;
         // a slab of S splats can produce at most S * n_tiles entries; size the sort launch by the smaller bound
@@ -718,7 +729,9 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
                 HIPCHK(launch_block_bin(v->stream, j0, j1, d_n, m->sorted_idx, m->rec(), m->sk_out.as<uint32_t>(), m->srect.as<uint4>(),
                                         m->cnt.as<uint32_t>(), m->block_sums.as<uint32_t>(), dc, cap, row_lo, row_hi, done_in, row_words,
                                         (progressive && later) ? done_count : nullptr, owned_tiles, slab_index, win, m->fc.tiles_x,
-                                        m->fc.tiles_y, bsx, bsy, m->block_table.as<uint4>(), m->tp_src.as<uint2>(), m->ranges.as<uint2>()));
+                                        m->fc.tiles_y, bsx, bsy, m->block_table.as<uint4>(), m->tp_src.as<uint2>(), m->ranges.as<uint2>(),
+                                        zero_pending ? zero : ZeroJob{}, table_ready));
+                zero_pending = false;
                 v->pass_launches[GSX_PASS_BIN] += 1;
             }
             {
@@ -820,13 +833,13 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
     bool windows_enqueued = false;
     auto enqueue_next_windows = [&]() -> gsx_status {  // this model's windows for its next frame
         ScopedPass t(v, GSX_PASS_COMPOSITE);
-        HIPCHK(launch_spec_next(v->stream, tile_sat, done, done_before, row_words, m->fc.tiles_x, m->fc.tiles_y,
-                                v->options.spec_margin, v->options.spec_radius, m->spec_win.as<uint2>(), row_lo, row_hi));
+        // the windows and, by the last workgroup of the same launch, their two pyramids:
         // [max-pyramid of the window ends: admission in k_project | min-pyramid: "every tile takes it" in the binning]
         const size_t pw = window_pyramid_words(m->fc.tiles_x, m->fc.tiles_y);
         HIPCHK(m->spec_coarse.ensure(8 * pw));
-        HIPCHK(launch_window_pyramid(v->stream, m->spec_win.as<uint2>(), m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse.as<uint32_t>(), false,
-                                     nullptr, m->spec_coarse.as<uint32_t>() + pw));
+        HIPCHK(launch_spec_next(v->stream, tile_sat, done, done_before, row_words, m->fc.tiles_x, m->fc.tiles_y,
+                                v->options.spec_margin, v->options.spec_radius, m->spec_win.as<uint2>(), row_lo, row_hi, &dc->verify_ticket,
+                                m->spec_coarse.as<uint32_t>(), m->spec_coarse.as<uint32_t>() + pw));
         m->spec_valid = true;
         m->spec_tiles_x = m->fc.tiles_x;
         m->spec_tiles_y = m->fc.tiles_y;
@@ -861,9 +874,15 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
             }
             const uint32_t seq = post ? ++v->verify_seq : 0;
             HIPCHK(m->spec_need.ensure(4 * (size_t)row_words * m->fc.tiles_y));
+            // ... and in the same launch, when something needs repair: the min-pyramid of the repair windows' starts (the repair
+            // round's conservative admission test: four loads per record; an exact per-tile scan of every visible record cost
+            // 260-350 us here) and the repair slab's block table
+            HIPCHK(m->spec_coarse2.ensure(4 * window_pyramid_words(m->fc.tiles_x, m->fc.tiles_y)));
+            const BlockGrid grid{bsx, bsy, (m->fc.tiles_x + (1u << bsx) - 1u) >> bsx, (m->fc.tiles_y + (1u << bsy) - 1u) >> bsy};
             HIPCHK(launch_spec_verify(v->stream, m->spec_win.as<uint2>(), done, row_words, m->fc.tiles_x, m->fc.tiles_y,
                                       m->spec_win2.as<uint2>(), m->spec_need.as<uint32_t>(), &dc->spec_need, row_lo, row_hi,
-                                      &dc->verify_ticket, post ? v->h_verdict : nullptr, seq));
+                                      post ? v->h_verdict : nullptr, seq, m->spec_coarse2.as<uint32_t>(), blocks ? &grid : nullptr,
+                                      blocks ? m->block_table.as<uint4>() : nullptr, blocks ? m->ranges.as<uint2>() : nullptr));
             if (ask) {
                 // Nothing to repair (most frames): the ~20 launches of the second round would all fall through, at a few
                 // microseconds of stream time each.  So the verdict comes to the host: one pinned word, written by the
@@ -888,10 +907,8 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
             ScopedPass t(v, GSX_PASS_DEPTH_SORT);
             HIPCHK(m->adm_ballots2.ensure(8 * ((std::max<size_t>(n, 1) + 63) / 64)));
             HIPCHK(m->adm_counts2.ensure(4 * (std::max<size_t>(admit_blocks(n), 1) + 4)));
-            // conservative admission against the min-pyramid of the repair windows' starts (four loads per record; the
-            // binning applies the exact windows): an exact per-tile scan of every visible record cost 260-350 us here
-            HIPCHK(m->spec_coarse2.ensure(4 * window_pyramid_words(m->fc.tiles_x, m->fc.tiles_y)));
-            HIPCHK(launch_window_pyramid(v->stream, m->spec_win2.as<uint2>(), m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse2.as<uint32_t>(), true, &dc->spec_need));
+            // conservative admission against the min-pyramid of the repair windows' starts (launch_spec_verify built it; the
+            // binning applies the exact windows)
             WindowPyramid pyr2 = window_pyramid_layout(m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse2.as<uint32_t>());
             pyr2.min_of_starts = 1;
             HIPCHK(launch_admit(v->stream, m->proj_rec(), n, nullptr, m->fc.tiles_x, nullptr,
@@ -906,7 +923,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, bool
                             m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
             HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted2, 32, false));
         }
-        if (repair && (st = run_slab(0, n, true, m->spec_win2.as<uint2>(), &dc->n_sorted2, (uint32_t)bounds.size()))) return st;
+        if (repair && (st = run_slab(0, n, true, m->spec_win2.as<uint2>(), &dc->n_sorted2, (uint32_t)bounds.size(), nullptr, blocks))) return st;
         m->order_consumed = true;
     }
     if (speculate && m->windows_unwanted) m->spec_valid = false;
@@ -946,20 +963,19 @@ gsx_status do_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys, bo
         HIPCHK(launch_clear_fb(v->stream, fb_ptr(v), v->width * v->height));
         return GSX_OK;
     }
+    ZeroJob frame_zero{};
     if (!cont) {   // one memset: [saturated-tile counter | saturated-tile bitmap | per-tile saturation depth keys | per-row work]
         const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
         const uint32_t row_words = (tiles_x + 31) / 32;
         const size_t bytes = 4 * (1 + (size_t)tiles_y * row_words + (size_t)tiles_y * tiles_x + tiles_y);
         HIPCHK(v->done_bits.ensure(bytes));
-        // ... and, in the same launch, the per-frame totals of the model composited first
-        Counters* dc0 = order.back()->counters.as<Counters>();
-        HIPCHK(launch_zero_words(v->stream, v->done_bits.as<uint32_t>(), (uint32_t)(bytes / 4), &dc0->n_entries,
-                                 (uint32_t)((sizeof(Counters) - offsetof(Counters, n_entries)) / 4)));
+        // ... zeroed together with the per-frame totals of the model composited first (do_bin_and_composite)
+        frame_zero = ZeroJob{v->done_bits.as<uint32_t>(), (uint32_t)(bytes / 4), nullptr, 0};
     }
     // the reference paints far -> near with "over"; front-to-back accumulation walks the same list backwards
     bool carry = cont;
     for (auto it = order.rbegin(); it != order.rend(); ++it) {
-        if ((st = do_bin_and_composite(v, *it, carry, !cont && it == order.rbegin()))) return st;
+        if ((st = do_bin_and_composite(v, *it, carry, (!cont && it == order.rbegin()) ? &frame_zero : nullptr))) return st;
         carry = true;
     }
     return GSX_OK;

@@ -63,8 +63,8 @@ __host__ __device__ inline uint32_t band_rows_max(const BandEdges& b) {
 // One rank's feedback after a round (gsx_shard_feedback), in u32 words:
 //   [0] records it wanted to send to its busiest destination   [1] a slot overflowed   [2] gather root + 1 (0: every rank receives)
 //   [3] list entries it binned this round   [4..7] 0   [8 + d] records it wanted to send to destination d (round 0)
-//   then rows x tiles_x saturation depth keys of its band (0 = open), then rows words of per-tile-row work (list entries its
-//   tiles walked + kTileWork per tile: what the next frame's bands are balanced by); rows = its band's height.
+//   then rows x tiles_x saturation depth keys of its band (0 = open), then rows words of per-tile-row work (per tile: list entries
+//   walked + list length + kTileWork: what the next frame's bands are balanced by); rows = its band's height.
 // The pieces are gathered at a common stride (the tallest band's piece); a rank sends only what its own band needs.
 constexpr uint32_t kShardExtraWords = 8 + kMaxRanks;
 constexpr uint32_t kTileWork = 8;  // what a tile costs before it has walked a single list entry, in list entries (band balancing)
@@ -231,6 +231,60 @@ struct SlabStats {
                                // its entries overflowed the pair buffers; k_composite_spill composites [slab_cut, slab end)
 };
 
+// Two runs of words some kernel of the frame zeroes on its way (the frame's saturation state + the first model's counters:
+// folded into the first slab's block-table kernel instead of a launch of their own).
+struct ZeroJob {
+    uint32_t* a = nullptr;
+    uint32_t na = 0;
+    uint32_t* b = nullptr;
+    uint32_t nb = 0;
+};
+
+// Block lists (kernels_bin.hip): the screen's tiles in at most 256 blocks of 2^bsx x 2^bsy tiles.
+struct BlockGrid {
+    uint32_t bsx, bsy;       // log2 of the block size in tiles
+    uint32_t blocks_x, blocks_y;
+};
+#ifdef __HIPCC__
+// One WAVE computes table[b] = {min window start, max window end (of the non-empty windows of the block's live tiles), live} and
+// zeroes ranges[b]; a lane per tile.  done (nullable): saturated tiles are not live; win (nullable): no windows = takes every key.
+__device__ inline void wave_block_table_entry(const BlockGrid& g, uint32_t b, uint32_t tiles_x, uint32_t tiles_y, uint32_t row_lo, uint32_t row_hi,
+                                              const uint32_t* __restrict__ done, uint32_t row_words, const uint2* __restrict__ win,
+                                              uint4* __restrict__ table, uint2* __restrict__ ranges) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t bx = b % g.blocks_x, by = b / g.blocks_x;
+    const uint32_t x0 = bx << g.bsx, x1 = min(x0 + (1u << g.bsx), tiles_x);
+    const uint32_t y0 = max(by << g.bsy, row_lo), y1 = min(min((by + 1u) << g.bsy, tiles_y), row_hi);
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u, live = 0u;
+    const uint32_t w = x1 - x0, total = y1 > y0 ? w * (y1 - y0) : 0u;
+    for (uint32_t k = lane; k < total; k += 64) {
+        const uint32_t tx = x0 + k % w, ty = y0 + k / w;
+        if (done && ((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)) continue;
+        if (win) {
+            const uint2 ww = win[ty * tiles_x + tx];
+            if (ww.x >= ww.y) continue;
+            lo = min(lo, ww.x);
+            hi = max(hi, ww.y);
+        }
+        live = 1u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor(lo, o, 64));
+        hi = max(hi, (uint32_t)__shfl_xor(hi, o, 64));
+        live |= (uint32_t)__shfl_xor(live, o, 64);
+    }
+    if (!win) {
+        lo = 0u;
+        hi = 0xFFFFFFFFu;
+    }
+    if (lane == 0) {
+        table[b] = make_uint4(lo, hi, live, 0u);
+        ranges[b] = make_uint2(0u, 0u);
+    }
+}
+#endif
+
 // Tile binning.
 // Splats [j0, min(j1, *d_n_vis)) of the depth order; cnt / block_sums are indexed relative to j0.
 // [row_lo, row_hi): the band of tile rows this rank bins (0, tiles_y on one GPU).
@@ -260,7 +314,8 @@ hipError_t launch_block_bin(hipStream_t s, uint32_t j0, uint32_t j1, const uint3
                             SlabStats* stats, uint32_t capacity, uint32_t row_lo, uint32_t row_hi, const uint32_t* done,
                             uint32_t row_words, const uint32_t* d_done_count, uint32_t owned_tiles, uint32_t slab_index,
                             const uint2* window, uint32_t tiles_x, uint32_t tiles_y, uint32_t bsx, uint32_t bsy, uint4* table,
-                            uint2* pairs, uint2* ranges);
+                            uint2* pairs, uint2* ranges, const ZeroJob& zero = ZeroJob{} /* words the table kernel zeroes on the way */,
+                            bool table_ready = false /* table and ranges are in place already (launch_spec_verify built them) */);
 hipError_t launch_composite_blocks(hipStream_t s, const FrameConsts& f, const uint2* ranges, const uint32_t* list, const uint4* brec,
                                    const Records& rec, float4* fb, bool carry, uint32_t* done, uint32_t row_words,
                                    uint32_t* d_done_count, uint32_t* tile_sat, const uint2* window, uint32_t row_lo,
@@ -307,15 +362,20 @@ hipError_t launch_admit(hipStream_t s, const Records& rec, uint32_t n, const uin
                         const uint32_t* gate, uint32_t row_words, const WindowPyramid& pyramid, const uint32_t* d_skip, unsigned long long* ballots, uint32_t* counts, uint32_t* d_total, uint2* pairs);
 
 // Temporal occlusion speculation (kernels_spec.hip): verification of this frame's windows, windows of the next frame.
+// pyr2_data (nullable): + the min-pyramid of the repair windows' starts; grid / table / ranges (nullable): + the repair slab's block
+// table, its ranges zeroed — both only when some tile needs the repair round (k_spec_verify_fused)
 hipError_t launch_spec_verify(hipStream_t s, const uint2* win1, const uint32_t* done, uint32_t row_words, uint32_t tiles_x,
                               uint32_t tiles_y, uint2* win2, uint32_t* need_bits, uint32_t* d_need, uint32_t band_lo, uint32_t band_hi,
-                              uint32_t* d_ticket, unsigned long long* host_verdict /* pinned host word or null */, uint32_t seq);
+                              unsigned long long* host_verdict /* pinned host word or null */, uint32_t seq, uint32_t* pyr2_data,
+                              const BlockGrid* grid, uint4* table, uint2* ranges);
 hipError_t launch_zero_words(hipStream_t s, uint32_t* a, uint32_t na, uint32_t* b, uint32_t nb);
 hipError_t launch_validate_tiles(hipStream_t s, const uint2* ranges, uint32_t n_tiles, const uint32_t* list, const uint32_t* d_entries,
                                  uint32_t capacity, uint32_t n_records, uint32_t* report);
+// d_ticket: a zero word (left zero); pyr_data / pyr_min_ends (nullable): + the windows' max-pyramid / min-pyramid, built by the
+// last workgroup to finish
 hipError_t launch_spec_next(hipStream_t s, const uint32_t* tile_sat, const uint32_t* done, const uint32_t* done_before,
                             uint32_t row_words, uint32_t tiles_x, uint32_t tiles_y, float margin, uint32_t radius, uint2* win_next,
-                            uint32_t band_lo, uint32_t band_hi);
+                            uint32_t band_lo, uint32_t band_hi, uint32_t* d_ticket, uint32_t* pyr_data, uint32_t* pyr_min_ends);
 
 // Multi-GPU exchange support (kernels_shard.hip).
 // d_n (nullable) / tile: only the first ceil(*d_n / tile) columns of every row hold anything (a candidate list shorter than the grid)
@@ -335,15 +395,25 @@ hipError_t launch_pack_count(hipStream_t s, const Records& rec, uint32_t n, cons
                              const uint32_t* gate = nullptr /* tile bitmap: records whose rectangle holds no gated tile go nowhere */,
                              uint32_t gate_row_words = 0,
                              const WindowPyramid* pyramid = nullptr /* decide by the windows' pyramid alone: a conservative superset */);
+// The slots of an exchange buffer, in records: slot p = one header record at off[p], then up to cap[p] records.
+struct SlotSpans {
+    uint32_t off[kMaxRanks], cap[kMaxRanks];
+};
+inline SlotSpans uniform_slots(uint32_t world, uint32_t cap) {
+    SlotSpans sp{};
+    for (uint32_t p = 0; p < world; ++p) {
+        sp.off[p] = p * (cap + 1u);
+        sp.cap[p] = cap;
+    }
+    return sp;
+}
 hipError_t launch_pack_scatter(hipStream_t s, const Records& rec, uint32_t n, uint32_t world,
                                const unsigned long long* masks, const uint32_t* table, const uint32_t* totals, void* d_send,
-                               uint64_t capacity, const uint2* list, const uint32_t* d_list_n, uint32_t slot_stride = 0,
-                               uint32_t slot_cap = 0 /* > 0: fixed slots of slot_stride records, header first, at most slot_cap records each */);
+                               uint64_t capacity, const uint2* list, const uint32_t* d_list_n,
+                               const SlotSpans* slots = nullptr /* != nullptr: into these slots, headers first, at most cap[p] records each */);
 // device-resident exchange (kernels_shard.hip): slot headers, import from slots, windows / verification / next limits
-hipError_t launch_pack_headers(hipStream_t s, const uint32_t* totals, uint32_t world, uint32_t slot_stride, uint32_t slot_cap, void* d_send,
-                               SlabStats* stats, uint32_t round);
-hipError_t launch_import_slots(hipStream_t s, const void* d_recv, uint32_t world, uint32_t slot_stride, uint32_t slot_cap, const Records& rec,
-                               SlabStats* stats);
+hipError_t launch_pack_headers(hipStream_t s, const uint32_t* totals, uint32_t world, const SlotSpans& slots, void* d_send, SlabStats* stats, uint32_t round);
+hipError_t launch_import_slots(hipStream_t s, const void* d_recv, uint32_t world, const SlotSpans& slots, const Records& rec, SlabStats* stats);
 hipError_t launch_limits_to_windows(hipStream_t s, const uint32_t* limit, uint32_t n_tiles, uint2* win);
 // sat: the all-gathered feedback, piece g at word g * feedback_stride(bands, tiles_x) (layout: feedback_* below)
 hipError_t launch_shard_verify(hipStream_t s, const uint32_t* limit, const uint32_t* sat, uint32_t tiles_x, uint32_t tiles_y, const BandEdges& bands,

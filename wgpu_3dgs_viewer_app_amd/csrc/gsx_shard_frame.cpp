@@ -90,22 +90,71 @@ gsx_status feedback_gather(Ctx& c) {
     return comm_gather_v(v, v->shard_sat_band.p, sp.bytes[c.rank], v->shard_sat_all.p, sp, -1);
 }
 
-// one exchange round of model i: pack -> all-to-all -> import + sort + composite -> feedback -> all-gather
-gsx_status exchange_round(Ctx& c, size_t i, uint32_t round, uint32_t T) {
+// one exchange round of model i: pack -> all-to-all -> import + sort + composite -> feedback -> all-gather.
+// T: uniform slots of T records; caps (round 0, nullable): caps[s * world + d] = records the slot of the pair (s, d) holds — sized
+// pair by pair from the count matrix of the model's last frame, the same table on every rank.
+gsx_status exchange_round(Ctx& c, size_t i, uint32_t round, uint32_t T, const std::vector<uint32_t>* caps = nullptr) {
     gsx_viewer* v = c.l;
     const char* key = c.p->order[i].c_str();
-    const uint64_t per_peer = (uint64_t)(T + 1u) * GSX_RECORD_BYTES;
     gsx_shard_stats& ss = c.owner->shard_stats;
     ss.exchange_rounds += 1;
+    SlotSpans snd = uniform_slots(c.world, T), rcv = snd;
+    if (caps && caps->size() == (size_t)c.world * c.world) {
+        uint32_t so = 0, ro = 0;
+        T = 0;
+        for (uint32_t p = 0; p < c.world; ++p) {
+            snd.off[p] = so;
+            snd.cap[p] = (*caps)[(size_t)c.rank * c.world + p];
+            so += snd.cap[p] + 1u;
+            rcv.off[p] = ro;
+            rcv.cap[p] = (*caps)[(size_t)p * c.world + c.rank];
+            ro += rcv.cap[p] + 1u;
+            T = std::max(T, snd.cap[p]);
+        }
+    }
     (round == 0 ? ss.last_slot_records : ss.last_repair_slot_records) = T;
-    HIPCHK(v->shard_send.ensure(per_peer * c.world));
-    HIPCHK(v->shard_recv.ensure(per_peer * c.world));
+    const uint32_t last = c.world - 1u;
+    HIPCHK(v->shard_send.ensure((uint64_t)(snd.off[last] + snd.cap[last] + 1u) * GSX_RECORD_BYTES));
+    HIPCHK(v->shard_recv.ensure((uint64_t)(rcv.off[last] + rcv.cap[last] + 1u) * GSX_RECORD_BYTES));
     gsx_status st;
-    if ((st = gsx_shard_pack_slots(v, key, c.world, round, v->shard_send.p, T))) return st;
-    if ((st = gsx_comm_all_to_all(v, v->shard_send.p, v->shard_recv.p, per_peer))) return st;
-    if ((st = gsx_shard_import_slots(v, key, v->shard_recv.p, c.world, c.rank, round | (i > 0 ? GSX_SHARD_BEHIND : 0u), T))) return st;
+    if ((st = shard_pack_slots(v, key, c.world, round, v->shard_send.p, snd))) return st;
+    if (comm_moves_unequal(c.owner)) {
+        PeerSpans bs{}, br{};
+        for (uint32_t p = 0; p < c.world; ++p) {
+            bs.off[p] = (uint64_t)snd.off[p] * GSX_RECORD_BYTES;
+            bs.bytes[p] = (uint64_t)(snd.cap[p] + 1u) * GSX_RECORD_BYTES;
+            br.off[p] = (uint64_t)rcv.off[p] * GSX_RECORD_BYTES;
+            br.bytes[p] = (uint64_t)(rcv.cap[p] + 1u) * GSX_RECORD_BYTES;
+        }
+        st = comm_all_to_all_v(v, v->shard_send.p, bs, v->shard_recv.p, br);
+    } else {
+        st = gsx_comm_all_to_all(v, v->shard_send.p, v->shard_recv.p, (uint64_t)(T + 1u) * GSX_RECORD_BYTES);
+    }
+    if (st) return st;
+    if ((st = shard_import_slots(v, key, v->shard_recv.p, c.world, c.rank, round | (i > 0 ? GSX_SHARD_BEHIND : 0u), rcv))) return st;
     if ((st = gsx_shard_feedback(v, key, c.world, c.rank, v->shard_sat_band.p))) return st;
     return feedback_gather(c);
+}
+
+// Slots pair by pair: what the pair (s, d) wanted in round 0 of the model's last frame, a quarter more, and 512 records (the
+// orbit moves the counts by a few per cent a frame; a camera jump overflows a slot, the verdict says so and the frame is redone
+// with whole-shard slots — the same frame, the same pixels).  Uniform slots hold the BUSIEST pair's count x 2 for every pair:
+// 19.4 MB per rank and frame on the links at 8 ranks on cfg4, of which 2.7 MB were records somebody wanted.  Needs a transport
+// that moves unequal pieces and a matrix from a frame of the same kind (both limited by windows, or both not).
+void plan_pair_slots(Ctx& c, size_t i) {
+    ShardPending& p = *c.p;
+    p.pair_caps[i].clear();
+    gsx_viewer* o = c.owner;
+    if (!comm_moves_unequal(o) || !o->shard_pair_slots || c.world < 2) return;
+    const Model* om = find_model(o, p.order[i].c_str());
+    const Model* lm = find_model(c.l, p.order[i].c_str());
+    if (!om || !lm || om->slot_force || om->pair_counts.size() != (size_t)c.world * c.world || om->pair_limited != lm->shard_frame_limited) return;
+    const uint32_t n = std::max<uint32_t>(p.shard_max[i], 1u);
+    p.pair_caps[i].resize((size_t)c.world * c.world);
+    for (size_t k = 0; k < p.pair_caps[i].size(); ++k) {
+        const uint64_t want = om->pair_counts[k];
+        p.pair_caps[i][k] = (uint32_t)std::min<uint64_t>(n, want + want / 4u + 512u);
+    }
 }
 
 gsx_status next_limits(Ctx& c, size_t i) {
@@ -134,15 +183,18 @@ gsx_status band_gather(Ctx& c) {
 
 // what a round-0 verdict carries besides its two words (kernels_shard.hip, k_shard_verify): do the ranks agree about the gather
 // root, the band edges for the frames to come, the count matrix of the exchange
-gsx_status read_verdict_extras(Ctx& c) {
+gsx_status read_verdict_extras(Ctx& c, size_t i) {
     const uint32_t* hv = reinterpret_cast<const uint32_t*>(c.l->h_shard_verdict);
     gsx_viewer* o = c.owner;
     if (hv[4]) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_render_frame: the ranks name different gather roots (gsx_shard_set_gather_root: this rank %d)", (int)o->shard_gather_root);
     o->shard_root_confirmed = true;
     o->next_edges.assign(hv + kVerdictEdges, hv + kVerdictEdges + c.world + 1);
     o->next_edges_tiles_y = c.tiles_y;
-    o->pair_counts.assign(hv + kVerdictMatrix, hv + kVerdictMatrix + (size_t)c.world * c.world);
-    o->pair_world = c.world;
+    if (Model* om = find_model(o, c.p->order[i].c_str())) {
+        om->pair_counts.assign(hv + kVerdictMatrix, hv + kVerdictMatrix + (size_t)c.world * c.world);
+        const Model* lm = find_model(c.l, c.p->order[i].c_str());
+        om->pair_limited = lm && lm->shard_frame_limited;
+    }
     o->shard_stats.last_entries_sum = hv[5];
     o->shard_stats.last_entries_max = hv[6];
     o->shard_stats.last_work_permille = hv[7];
@@ -150,7 +202,7 @@ gsx_status read_verdict_extras(Ctx& c) {
 }
 
 gsx_status round0(Ctx& c, size_t i) {
-    gsx_status st = exchange_round(c, i, 0, c.p->slot[i]);
+    gsx_status st = exchange_round(c, i, 0, c.p->slot[i], &c.p->pair_caps[i]);
     if (st) return st;
     if ((st = gsx_shard_verify(c.l, c.p->order[i].c_str(), c.world, c.l->shard_sat_all.p, &c.p->seq))) return st;
     return next_limits(c, i);  // what follows when nothing needs a repair (redone after one)
@@ -171,7 +223,7 @@ gsx_status settle(Ctx& c, size_t i, bool* overflow) {
     gsx_shard_verdict verdict{};
     gsx_status st = timed_wait(c, key, c.p->seq, &verdict);
     if (st) return st;
-    if ((st = read_verdict_extras(c))) return st;
+    if ((st = read_verdict_extras(c, i))) return st;
     *overflow = verdict.overflow != 0;
     if (*overflow || !verdict.need_tiles) return GSX_OK;
     // the repair round, sized exactly: what each destination is owed is counted, the maximum gathered and posted
@@ -193,7 +245,10 @@ gsx_status settle(Ctx& c, size_t i, bool* overflow) {
 gsx_status redo_safe(Ctx& c) {
     c.owner->shard_stats.redo_frames += 1;
     c.p->gathered = false;
-    for (size_t i = 0; i < c.p->order.size(); ++i) c.p->slot[i] = std::max<uint32_t>(c.p->shard_max[i], 1u);
+    for (size_t i = 0; i < c.p->order.size(); ++i) {
+        c.p->slot[i] = std::max<uint32_t>(c.p->shard_max[i], 1u);
+        c.p->pair_caps[i].clear();
+    }
     for (size_t i = 0; i < c.p->order.size(); ++i) {
         gsx_status st = round0(c, i);  // (model 0 is not "behind": it starts from a cleared band)
         if (st) return st;
@@ -223,8 +278,11 @@ gsx_status frame_front(Ctx& c, bool eager_gather) {
         if ((st = gsx_shard_frame_begin(c.l, p.order[i].c_str(), c.world, c.rank, p.speculate, override_limits))) return st;
     }
     p.slot.resize(n);
-    for (size_t i = 0; i < n; ++i)
+    p.pair_caps.assign(n, {});
+    for (size_t i = 0; i < n; ++i) {
         if ((st = gsx_shard_slot_records(c.l, p.order[i].c_str(), c.world, p.shard_max[i], &p.slot[i]))) return st;
+        plan_pair_slots(c, i);
+    }
     for (size_t i = 0; i < n; ++i) {
         if ((st = round0(c, i))) return st;
         if (i + 1 == n) break;  // the last model's verdict belongs to frame_back

@@ -178,6 +178,9 @@ struct Model {
     bool shard_limit_valid = false, shard_next_valid = false, shard_frame_limited = false;
     bool shard_behind = false;                 // this frame's imported records were composited behind nearer models (spec_done_before holds their tiles)
     uint32_t shard_limit_tx = 0, shard_limit_ty = 0;
+    std::vector<uint32_t> pair_counts;         // owner's model: records rank s wanted to send to rank d in round 0 of the model's last frame
+                                               // whose verdict was read ([s * world + d]; empty: unknown) — next frame's slots, pair by pair
+    bool pair_limited = false;                 // ... and whether that frame's exchange was limited by windows
     uint32_t slot_force = 0;                   // gsx_shard_set_slot_records: round-0 slot size instead of the policy's (0 = policy)
     uint32_t slot_hint = 0;                    // records the busiest (rank, destination) pair wanted in round 0 of the last frame: a GLOBAL
                                                // figure from that frame's verdict, so every rank sizes the next slots identically; 0 = unknown
@@ -284,6 +287,7 @@ struct ShardPending {
     bool settled = false;                     // every model's verdict has been dealt with already (a frame redone with safe slots)
     bool repaired = false;                    // some model needed its repair exchange
     std::vector<uint32_t> edges;              // the frame's band layout (world + 1 tile rows; empty: equal bands)
+    std::vector<std::vector<uint32_t>> pair_caps;  // per model: round-0 slot sizes pair by pair ([s * world + d]; empty: uniform `slot`)
 };
 
 struct gsx_viewer {
@@ -355,9 +359,7 @@ struct gsx_viewer {
     bool shard_root_confirmed = false;   // a verdict since the last gsx_shard_set_gather_root has shown that every rank names the same root
     uint32_t next_edges_tiles_y = 0;     // the grid next_edges was made for
     bool shard_balance = true;           // gsx_shard_set_balance
-    // per (source, destination) records of the last completed frame's round 0 (the verdict's count matrix; empty: unknown)
-    std::vector<uint32_t> pair_counts;
-    uint32_t pair_world = 0;
+    bool shard_pair_slots = true;        // size the exchange slots pair by pair (where the transport moves unequal pieces); GSX_SHARD_UNIFORM_SLOTS
     DevBuf shard_fb, shard_send, shard_recv, shard_sat_band, shard_sat_all, shard_counts;  // gsx_shard_render_frame's own buffers
     void* ext_fb = nullptr;              // caller-owned framebuffer (multi-GPU: the RCCL gather target)
     uint64_t ext_fb_bytes = 0;
@@ -418,6 +420,9 @@ struct PeerSpans {
     uint64_t off[kMaxRanks], bytes[kMaxRanks];
 };
 inline bool comm_moves_unequal(const gsx_viewer* owner) { return owner->comm != nullptr || owner->comm_a2a_v_fn != nullptr; }
+// the slot-based stage calls with slots of any size (gsx_api_shard.cpp; the exported ones pass uniform slots)
+gsx_status shard_pack_slots(gsx_viewer* v, const char* key, uint32_t world, uint32_t round, void* d_send, const SlotSpans& slots);
+gsx_status shard_import_slots(gsx_viewer* v, const char* key, const void* d_recv, uint32_t world, uint32_t rank, uint32_t round_flags, const SlotSpans& slots);
 // slot p of the send buffer (snd) goes to rank p, what rank p sends lands in slot p of the receive buffer (rcv)
 gsx_status comm_all_to_all_v(gsx_viewer* v, const void* d_send, const PeerSpans& snd, void* d_recv, const PeerSpans& rcv);
 // every rank's piece (send_bytes of it; rank p's lands at rcv.off[p]) to every rank (root < 0) or to `root` only

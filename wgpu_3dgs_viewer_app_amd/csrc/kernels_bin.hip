@@ -389,49 +389,23 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const uint32_t* __restrict_
 // CONSERVATIVE (a block takes a record unless all its tiles are saturated / outside the band, or no window of its tiles
 // can contain the key); the exact decision is the compositor's.  Entry value = the record's position in the slab;
 // brec[position] = {rect x, rect y, depth key, record index}.
-struct BlockGrid {
-    uint32_t bsx, bsy;       // log2 of the block size in tiles
-    uint32_t blocks_x, blocks_y;
-};
-
+// (BlockGrid, wave_block_table_entry: gsx_internal.h — kernels_spec.hip builds the repair round's table in its verification kernel)
 // table[b] = {min window start, max window end (of the non-empty windows of the block's live tiles), live}; also zeroes the
-// block's range (k_tile_ranges fills in the blocks that have entries).  One wave per block, a lane per tile.
+// block's range (the block sort fills in the blocks that have entries).  One wave per block, a lane per tile
+// (wave_block_table_entry, gsx_internal.h).  za / zb: words to zero on the way — the frame's saturation state and counters, when
+// this is the first slab of the frame (one launch less: k_zero_words).
 __global__ __launch_bounds__(256) void k_block_table(BlockGrid g, uint32_t tiles_x, uint32_t tiles_y, uint32_t row_lo, uint32_t row_hi,
                                                      const uint32_t* __restrict__ done, uint32_t row_words,
                                                      const uint2* __restrict__ win, uint4* __restrict__ table,
-                                                     uint2* __restrict__ ranges) {
-    const uint32_t lane = threadIdx.x & 63u, b = blockIdx.x * 4u + (threadIdx.x >> 6);
+                                                     uint2* __restrict__ ranges, uint32_t* __restrict__ za, uint32_t nza,
+                                                     uint32_t* __restrict__ zb, uint32_t nzb) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < max(nza, nzb); i += gridDim.x * 256u) {
+        if (i < nza) za[i] = 0u;
+        if (i < nzb) zb[i] = 0u;
+    }
+    const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (b >= g.blocks_x * g.blocks_y) return;
-    const uint32_t bx = b % g.blocks_x, by = b / g.blocks_x;
-    const uint32_t x0 = bx << g.bsx, x1 = min(x0 + (1u << g.bsx), tiles_x);
-    const uint32_t y0 = max(by << g.bsy, row_lo), y1 = min(min((by + 1u) << g.bsy, tiles_y), row_hi);
-    uint32_t lo = 0xFFFFFFFFu, hi = 0u, live = 0u;
-    const uint32_t w = x1 - x0, total = y1 > y0 ? w * (y1 - y0) : 0u;
-    for (uint32_t k = lane; k < total; k += 64) {
-        const uint32_t tx = x0 + k % w, ty = y0 + k / w;
-        if (done && ((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)) continue;
-        if (win) {
-            const uint2 ww = win[ty * tiles_x + tx];
-            if (ww.x >= ww.y) continue;
-            lo = min(lo, ww.x);
-            hi = max(hi, ww.y);
-        }
-        live = 1u;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        lo = min(lo, (uint32_t)__shfl_xor(lo, o, 64));
-        hi = max(hi, (uint32_t)__shfl_xor(hi, o, 64));
-        live |= (uint32_t)__shfl_xor(live, o, 64);
-    }
-    if (!win) {
-        lo = 0u;
-        hi = 0xFFFFFFFFu;
-    }
-    if (lane == 0) {
-        table[b] = make_uint4(lo, hi, live, 0u);
-        ranges[b] = make_uint2(0u, 0u);
-    }
+    wave_block_table_entry(g, b, tiles_x, tiles_y, row_lo, row_hi, done, row_words, win, table, ranges);
 }
 
 __device__ inline bool block_takes(const uint4* tab, uint32_t b, uint32_t key, bool keyed) {
@@ -544,11 +518,12 @@ hipError_t launch_block_bin(hipStream_t s, uint32_t j0, uint32_t j1, const uint3
                             SlabStats* stats, uint32_t capacity, uint32_t row_lo, uint32_t row_hi, const uint32_t* done,
                             uint32_t row_words, const uint32_t* d_done_count, uint32_t owned_tiles, uint32_t slab_index,
                             const uint2* window, uint32_t tiles_x, uint32_t tiles_y, uint32_t bsx, uint32_t bsy, uint4* table,
-                            uint2* pairs, uint2* ranges) {
+                            uint2* pairs, uint2* ranges, const ZeroJob& zero, bool table_ready) {
     const uint32_t nb = std::min<uint32_t>((uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0), kBinGrid);
     BlockGrid g{bsx, bsy, (tiles_x + (1u << bsx) - 1u) >> bsx, (tiles_y + (1u << bsy) - 1u) >> bsy};
-    GSX_LAUNCH(k_block_table, dim3((g.blocks_x * g.blocks_y + 3u) / 4u), dim3(256), 0, s, g, tiles_x, tiles_y, row_lo, row_hi, done,
-                       row_words, window, table, ranges);
+    if (!table_ready)  // (the repair round of a speculated frame: k_spec_verify_fused has built the table and zeroed the ranges)
+        GSX_LAUNCH(k_block_table, dim3((g.blocks_x * g.blocks_y + 3u) / 4u), dim3(256), 0, s, g, tiles_x, tiles_y, row_lo, row_hi, done,
+                   row_words, window, table, ranges, zero.a, zero.na, zero.b, zero.nb);
     if (nb)
         GSX_LAUNCH(k_block_counts, dim3(nb), dim3(kBinThreads), 0, s, d_n_vis, j0, j1, sorted_idx, rec.a, sorted_keys, brec, cnt,
                            block_sums, row_lo, row_hi, d_done_count, owned_tiles, g, table, window ? 1 : 0);

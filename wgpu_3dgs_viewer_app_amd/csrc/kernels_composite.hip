@@ -192,9 +192,10 @@ __global__ __launch_bounds__(128) void k_composite(const FrameConsts f, uint2* _
     if (in0) fb[fbo] = make_float4(C0.x, C1.x, C2.x, T.x);
     if (in1) fb[fbo + f.w_px] = make_float4(C0.y, C1.y, C2.y, T.y);
     if (clear_ranges && tid == 0 && had_entries) ranges[tile] = make_uint2(0u, 0u);
-    // multi-GPU: what this tile cost — list entries walked plus a constant for the tile itself; the next frame's bands are balanced
-    // by the rows' sums (gsx_shard_frame.cpp, k_shard_verify)
-    if (row_work && tid == 0) atomicAdd(&row_work[ty], kTileWork + min(base, range.y) - range.x);
+    // multi-GPU: what this tile cost — the list entries it walked, the length of its list (an entry costs its share of the depth sort,
+    // the binning and the list sort before any tile walks it: together about what the compositor costs) and a constant for the tile
+    // itself; the next frame's bands are balanced by the rows' sums (gsx_shard_frame.cpp, k_shard_verify)
+    if (row_work && tid == 0) atomicAdd(&row_work[ty], kTileWork + (min(base, range.y) - range.x) + (range.y - range.x));
     if (done_bits && __syncthreads_and((lim0 | lim1) == 0u)) {
         // the tile saturated in this launch: its last pixels stopped here, behind everything blended earlier
         if (tile_sat) {
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
     }
     if (in0) fb[fbo] = make_float4(C0.x, C1.x, C2.x, T.x);
     if (in1) fb[fbo + f.w_px] = make_float4(C0.y, C1.y, C2.y, T.y);
-    if (row_work && tid == 0) atomicAdd(&row_work[ty], kTileWork + min(base, range.y) - range.x);  // (as k_composite)
+    if (row_work && tid == 0) atomicAdd(&row_work[ty], kTileWork + (min(base, range.y) - range.x) + (range.y - range.x));  // (as k_composite)
     if (done_bits && __syncthreads_and((lim0 | lim1) == 0u)) {
         if (tile_sat) {
             if (stop_key) atomicMax(&s_sat, stop_key);

@@ -123,16 +123,16 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_scatter(const unsigned lo
                                                                 uint32_t nblocks, const uint32_t* __restrict__ totals,
                                                                 float4* __restrict__ send, uint64_t capacity,
                                                                 const uint2* __restrict__ list, const uint32_t* __restrict__ d_list_n,
-                                                                uint32_t slot_stride, uint32_t slot_cap) {
+                                                                const SlotSpans sp, uint32_t slotted) {
     __shared__ uint32_t run[kPackThreads / 64][kMaxWorld];  // per-wave running counts -> absolute offsets
     __shared__ uint32_t dbase[kMaxWorld];
     __shared__ uint32_t dend[kMaxWorld];   // first position past what destination g may hold
     constexpr uint32_t kPackTile = kPackThreads * kPackRounds, kPackWaveChunk = 64 * kPackRounds;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     if (tid < kMaxWorld) {
-        if (slot_stride) {  // fixed slots (device-resident exchange): slot g = [header | slot_cap records]
-            dbase[tid] = tid * slot_stride + 1u;
-            dend[tid] = tid * slot_stride + 1u + slot_cap;
+        if (slotted) {      // slots (device-resident exchange): slot g = [header | up to sp.cap[g] records] at record sp.off[g]
+            dbase[tid] = sp.off[tid] + 1u;
+            dend[tid] = sp.off[tid] + 1u + sp.cap[tid];
         } else {            // packed groups in rank order (exact split sizes known to the host)
             uint32_t b = 0;
             for (uint32_t g = 0; g < tid && g < world; ++g) b += totals[g];
@@ -230,52 +230,62 @@ hipError_t launch_pack_count(hipStream_t s, const Records& rec, uint32_t n, cons
 
 hipError_t launch_pack_scatter(hipStream_t s, const Records& rec, uint32_t n, uint32_t world,
                                const unsigned long long* masks, const uint32_t* table, const uint32_t* totals, void* d_send,
-                               uint64_t capacity, const uint2* list, const uint32_t* d_list_n, uint32_t slot_stride, uint32_t slot_cap) {
+                               uint64_t capacity, const uint2* list, const uint32_t* d_list_n, const SlotSpans* slots) {
     const uint32_t rounds = pack_rounds(list != nullptr), nb = (uint32_t)pack_blocks(n, rounds);
     if (nb) {
         auto kernel = rounds == kPackRoundsList ? k_pack_scatter<(int)kPackRoundsList> : k_pack_scatter<(int)kPackRoundsFull>;
         GSX_LAUNCH(kernel, dim3(nb), dim3(kPackThreads), 0, s, masks, rec.a, rec.b, rec.c, n, world, table, nb,
-                           totals, reinterpret_cast<float4*>(d_send), capacity, list, d_list_n, slot_stride, slot_cap);
+                           totals, reinterpret_cast<float4*>(d_send), capacity, list, d_list_n, slots ? *slots : SlotSpans{}, slots ? 1u : 0u);
     }
     return hipGetLastError();
 }
 
-// ---- device-resident exchange: fixed slots, counts in the slot headers (no host round trip) ----
-// send / recv buffer of a round: `world` slots of (1 + T) records of 48 bytes; record 0 of a slot is its header:
-// word 0 = records the sender HAD for this destination, word 1 = records it sent = min(word 0, T).
-__global__ __launch_bounds__(64) void k_pack_headers(const uint32_t* __restrict__ totals, uint32_t world, uint32_t slot_stride,
-                                                      uint32_t slot_cap, float4* __restrict__ send, SlabStats* __restrict__ stats,
-                                                      uint32_t round) {
+// ---- device-resident exchange: slots, counts in the slot headers (no host round trip) ----
+// send / recv buffer of a round: `world` slots; slot p = a header record followed by up to cap[p] records of 48 bytes, at record
+// off[p] (SlotSpans, gsx_internal.h).  The sizes are the same on both ends of a pair because every rank derives them from gathered
+// data (uniform: the busiest pair of the last frame; pair by pair: the last frame's count matrix).  Header: word 0 = records the
+// sender HAD for this destination, word 1 = records it sent = min(word 0, cap).
+__global__ __launch_bounds__(64) void k_pack_headers(const uint32_t* __restrict__ totals, uint32_t world, const SlotSpans sp,
+                                                      float4* __restrict__ send, SlabStats* __restrict__ stats, uint32_t round) {
     const uint32_t g = threadIdx.x;
     uint32_t cnt = g < world ? totals[g] : 0u;
+    uint32_t over = 0u;
     if (g < world) {
-        float4* h = send + 3ull * (size_t)g * slot_stride;
-        h[0] = make_float4(__uint_as_float(cnt), __uint_as_float(min(cnt, slot_cap)), 0.0f, 0.0f);
+        float4* h = send + 3ull * (size_t)sp.off[g];
+        h[0] = make_float4(__uint_as_float(cnt), __uint_as_float(min(cnt, sp.cap[g])), 0.0f, 0.0f);
         h[1] = make_float4(0, 0, 0, 0);
         h[2] = make_float4(0, 0, 0, 0);
+        over = cnt > sp.cap[g] ? 1u : 0u;
+        if (round == 0u) stats->slot_want[g] = cnt;     // (the gathered count matrix sizes the next frame's slots pair by pair)
     }
-    if (round == 0u) stats->slot_want[g] = cnt;     // (the gathered count matrix sizes the next frame's slots pair by pair)
     uint32_t mx = cnt;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+        over |= (uint32_t)__shfl_xor((int)over, o, 64);
+    }
     if (g == 0) {
         stats->slot_max[round & 1u] = mx;           // what this rank WANTED to send to its busiest destination
-        stats->slot_over[round & 1u] = mx > slot_cap ? 1u : 0u;
+        stats->slot_over[round & 1u] = over;        // ... and whether some destination's slot was too small for what it was owed
     }
 }
 
 // received slots -> the record planes of the model, compacted in (source rank, source index) order = global Gaussian
 // index order (what makes the stable depth sort break ties exactly as on one GPU); the record count stays on the device
-__global__ __launch_bounds__(256) void k_import_slots(const float4* __restrict__ recv, uint32_t world, uint32_t slot_stride,
-                                                       uint32_t slot_cap, Records rec, SlabStats* __restrict__ stats) {
-    __shared__ uint32_t pre[kMaxWorld + 1];
+__global__ __launch_bounds__(256) void k_import_slots(const float4* __restrict__ recv, uint32_t world, const SlotSpans sp, Records rec,
+                                                       SlabStats* __restrict__ stats) {
+    __shared__ uint32_t pre[kMaxWorld + 1];    // records imported from the sources before s
+    __shared__ uint32_t capre[kMaxWorld + 1];  // thread index space: capacities of the sources before s
     if (threadIdx.x == 0) {
-        uint32_t acc = 0;
+        uint32_t acc = 0, cacc = 0;
         for (uint32_t s = 0; s < world; ++s) {
             pre[s] = acc;
-            acc += min(__float_as_uint(recv[3ull * (size_t)s * slot_stride].y), slot_cap);
+            capre[s] = cacc;
+            acc += min(__float_as_uint(recv[3ull * (size_t)sp.off[s]].y), sp.cap[s]);
+            cacc += sp.cap[s];
         }
         pre[world] = acc;
+        capre[world] = cacc;
         if (blockIdx.x == 0) {
             stats->n_visible = acc;  // every imported record is visible by construction
             stats->n_sorted = acc;
@@ -283,9 +293,12 @@ __global__ __launch_bounds__(256) void k_import_slots(const float4* __restrict__
     }
     __syncthreads();
     const uint64_t e = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    const uint32_t s = (uint32_t)(e / slot_cap), j = (uint32_t)(e % slot_cap);
-    if (s >= world || j >= pre[s + 1] - pre[s]) return;
-    const float4* r = recv + 3ull * ((size_t)s * slot_stride + 1u + j);
+    if (e >= capre[world]) return;
+    uint32_t s = 0;
+    while (s + 1u < world && e >= capre[s + 1u]) ++s;
+    const uint32_t j = (uint32_t)(e - capre[s]);
+    if (j >= pre[s + 1] - pre[s]) return;
+    const float4* r = recv + 3ull * ((size_t)sp.off[s] + 1u + j);
     const uint32_t i = pre[s] + j;
     const float4 a = r[0], b = r[1], c = r[2];
     rec.a[i] = a;
@@ -475,17 +488,16 @@ __global__ __launch_bounds__(256) void k_shard_next_limits(const uint32_t* __res
     limit[t] = out;
 }
 
-hipError_t launch_pack_headers(hipStream_t s, const uint32_t* totals, uint32_t world, uint32_t slot_stride, uint32_t slot_cap, void* d_send,
-                               SlabStats* stats, uint32_t round) {
-    GSX_LAUNCH(k_pack_headers, dim3(1), dim3(64), 0, s, totals, world, slot_stride, slot_cap, reinterpret_cast<float4*>(d_send), stats, round);
+hipError_t launch_pack_headers(hipStream_t s, const uint32_t* totals, uint32_t world, const SlotSpans& slots, void* d_send, SlabStats* stats, uint32_t round) {
+    GSX_LAUNCH(k_pack_headers, dim3(1), dim3(64), 0, s, totals, world, slots, reinterpret_cast<float4*>(d_send), stats, round);
     return hipGetLastError();
 }
 
-hipError_t launch_import_slots(hipStream_t s, const void* d_recv, uint32_t world, uint32_t slot_stride, uint32_t slot_cap, const Records& rec,
-                               SlabStats* stats) {
-    const uint64_t total = (uint64_t)world * slot_cap;
+hipError_t launch_import_slots(hipStream_t s, const void* d_recv, uint32_t world, const SlotSpans& slots, const Records& rec, SlabStats* stats) {
+    uint64_t total = 0;
+    for (uint32_t p = 0; p < world; ++p) total += slots.cap[p];
     GSX_LAUNCH(k_import_slots, dim3((unsigned)std::max<uint64_t>((total + 255) / 256, 1)), dim3(256), 0, s,
-                       reinterpret_cast<const float4*>(d_recv), world, slot_stride, slot_cap, rec, stats);
+               reinterpret_cast<const float4*>(d_recv), world, slots, rec, stats);
     return hipGetLastError();
 }
 

@@ -72,68 +72,178 @@ hipError_t launch_validate_tiles(hipStream_t s, const uint2* ranges, uint32_t n_
     return hipGetLastError();
 }
 
-// need[t] = bounded window && still open  ->  win2[t] = [hi, inf) for those tiles, [0, 0) for the rest; *d_need = count
-__global__ __launch_bounds__(256) void k_spec_verify(const uint2* __restrict__ win1, const uint32_t* __restrict__ done,
-                                                      uint32_t row_words, uint32_t tiles_x, uint32_t n_tiles,
-                                                      uint2* __restrict__ win2, uint32_t* __restrict__ need_bits,
-                                                      uint32_t* __restrict__ d_need, uint32_t band_lo, uint32_t band_hi,
-                                                      uint32_t* __restrict__ ticket, unsigned long long* __restrict__ host_verdict,
-                                                      uint32_t seq) {
+// one workgroup builds every level (11 k words at 1080p): level 0 = the window ends, level l = 2x2 max of level l-1.
+// min_ends (nullable): a second pyramid, the MIN of the window ends — "every tile under this rectangle takes this key"
+// for windows that start at 0 (the binning's fast path, kernels_bin.hip).
+// Levels that fit kPyrLds words are kept in LDS as well: the level above is built from there instead of from global words this
+// workgroup has just written (a round trip through L2 per level, 7 of them at 1080p: 12 us for 11 k words).  Level 1 comes
+// straight from the windows, so that it does not wait for level 0 either.
+constexpr uint32_t kPyrLds = 2304;  // 1920x1080: level 1 = 60 x 34 = 2040 cells
+struct PyramidLds {
+    unsigned long long cells;
+    uint32_t a[2][kPyrLds], m[2][kPyrLds];
+};
+// every thread of ONE workgroup (NT threads); `window` may have been written by this workgroup (barrier before the call)
+template <uint32_t NT>
+__device__ inline void build_window_pyramid(const uint2* __restrict__ window, const WindowPyramid& p, uint32_t* __restrict__ data,
+                                            uint32_t* __restrict__ min_ends, PyramidLds& lds) {
+    if (threadIdx.x == 0) lds.cells = 0ull;
+    __syncthreads();
+    const uint32_t mos = p.min_of_starts;
+    auto leaf = [&](const uint2 w) -> uint32_t { return mos ? (w.y > w.x ? w.x : 0xFFFFFFFFu) : w.y; };
+    auto leaf_min = [](const uint2 w) -> uint32_t { return w.x == 0u ? w.y : 0u; };  // a window that does not start at 0 promises nothing
+    auto join = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) -> uint32_t { return mos ? min(min(a, b), min(c, d)) : max(max(a, b), max(c, d)); };
+    unsigned long long cells = 0ull;
+    for (uint32_t i = threadIdx.x; i < p.wx[0] * p.wy[0]; i += NT) {
+        const uint2 w = window[i];
+        data[i] = leaf(w);
+        if (min_ends) min_ends[i] = leaf_min(w);
+        if (mos && w.y > w.x) cells |= 1ull << ((((i / p.wx[0]) >> p.cell_sy) << 3) | ((i % p.wx[0]) >> p.cell_sx));
+    }
+    if (mos) {
+        if (cells) atomicOr(&lds.cells, cells);
+        __syncthreads();
+        if (threadIdx.x == 0) *reinterpret_cast<unsigned long long*>(data + p.cells_off) = lds.cells;
+    }
+    uint32_t l = 1, cur = 0;
+    bool prev_lds = false;
+    if (p.levels > 1 && p.wx[1] * p.wy[1] <= kPyrLds) {  // level 1 from the windows themselves
+        const uint32_t wx = p.wx[1], px = p.wx[0], py = p.wy[0];
+        for (uint32_t i = threadIdx.x; i < wx * p.wy[1]; i += NT) {
+            const uint32_t x = 2u * (i % wx), y = 2u * (i / wx), x1 = min(x + 1u, px - 1u), y1 = min(y + 1u, py - 1u);
+            const uint2 a = window[y * px + x], b = window[y * px + x1], c = window[y1 * px + x], d = window[y1 * px + x1];
+            const uint32_t v = join(leaf(a), leaf(b), leaf(c), leaf(d));
+            data[p.off[1] + i] = v;
+            lds.a[0][i] = v;
+            if (min_ends) {
+                const uint32_t mv = min(min(leaf_min(a), leaf_min(b)), min(leaf_min(c), leaf_min(d)));
+                min_ends[p.off[1] + i] = mv;
+                lds.m[0][i] = mv;
+            }
+        }
+        prev_lds = true;
+        l = 2;
+    }
+    for (; l < p.levels; ++l) {
+        __syncthreads();
+        const uint32_t wx = p.wx[l], wy = p.wy[l], px = p.wx[l - 1], py = p.wy[l - 1];
+        const uint32_t* src = prev_lds ? lds.a[cur] : data + p.off[l - 1];
+        const uint32_t* msrc = prev_lds ? lds.m[cur] : (min_ends ? min_ends + p.off[l - 1] : nullptr);
+        uint32_t* dst = data + p.off[l];
+        const bool keep = wx * wy <= kPyrLds;
+        const uint32_t wbuf = prev_lds ? cur ^ 1u : 0u;  // (never the buffer this level is read from)
+        for (uint32_t i = threadIdx.x; i < wx * wy; i += NT) {
+            const uint32_t x = 2u * (i % wx), y = 2u * (i / wx), x1 = min(x + 1u, px - 1u), y1 = min(y + 1u, py - 1u);
+            const uint32_t v = join(src[y * px + x], src[y * px + x1], src[y1 * px + x], src[y1 * px + x1]);
+            dst[i] = v;
+            if (keep) lds.a[wbuf][i] = v;
+            if (min_ends) {
+                const uint32_t mv = min(min(msrc[y * px + x], msrc[y * px + x1]), min(msrc[y1 * px + x], msrc[y1 * px + x1]));
+                min_ends[p.off[l] + i] = mv;
+                if (keep) lds.m[wbuf][i] = mv;
+            }
+        }
+        if (keep) cur = wbuf;
+        prev_lds = keep;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_window_pyramid(const uint2* __restrict__ window, WindowPyramid p, uint32_t* __restrict__ data,
+                                                         const uint32_t* __restrict__ d_skip, uint32_t* __restrict__ min_ends) {
+    if (d_skip && *d_skip == 0) return;  // repair round with nothing to repair
+    __shared__ PyramidLds lds;
+    build_window_pyramid<1024>(window, p, data, min_ends, lds);
+}
+
+// Verification of a speculated round, ONE workgroup (8 k tiles at 1080p: eight a thread):
+//   need[t] = bounded window && still open  ->  win2[t] = [hi, inf) for those tiles, [0, 0) for the rest; *d_need = count;
+//   the verdict to pinned host memory (host_verify);
+//   and, when something needs repair, what the repair round's first kernels would otherwise be launched for: the min-pyramid
+//   of the repair windows' starts (the conservative admission test of k_admit_count) and — block lists — the repair slab's block
+//   table {min window start, max window end, live} with its ranges zeroed (k_block_table).  Two launches less per frame, and
+//   nothing at all behind the count when nothing needs repair.
+struct VerifyTables {
+    WindowPyramid pyr2;          // of win2's starts (min_of_starts = 1); data == nullptr: none
+    uint32_t* pyr2_data;
+    BlockGrid grid;              // block lists of the repair slab; table == nullptr: none (per-tile lists)
+    uint4* table;
+    uint2* ranges;
+};
+__global__ __launch_bounds__(1024) void k_spec_verify_fused(const uint2* __restrict__ win1, const uint32_t* __restrict__ done,
+                                                             uint32_t row_words, uint32_t tiles_x, uint32_t n_tiles,
+                                                             uint2* __restrict__ win2, uint32_t* __restrict__ need_bits,
+                                                             uint32_t* __restrict__ d_need, uint32_t band_lo, uint32_t band_hi,
+                                                             unsigned long long* __restrict__ host_verdict, uint32_t seq, VerifyTables vt) {
     __shared__ uint32_t s_need;
+    __shared__ PyramidLds lds;
     if (threadIdx.x == 0) s_need = 0;
     __syncthreads();
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    // the need bitmap, one thread per word (no clear, no atomics): bit = bounded window && still open
     const uint32_t tiles_y = n_tiles / tiles_x;
-    if (t < row_words * tiles_y) {
+    // the need bitmap, one thread per word (no clear, no atomics): bit = bounded window && still open
+    for (uint32_t t = threadIdx.x; t < row_words * tiles_y; t += 1024u) {
         const uint32_t ty = t / row_words, x0 = (t % row_words) * 32u;
         uint32_t bits = 0;
         for (uint32_t b = 0; b < 32u && x0 + b < tiles_x; ++b)
             if (win1[ty * tiles_x + x0 + b].y != kKeyAll) bits |= 1u << b;
         need_bits[t] = (ty >= band_lo && ty < band_hi) ? (bits & ~done[t]) : 0u;
     }
-    bool need = false;
-    if (t < n_tiles) {
+    uint32_t mine = 0;
+    for (uint32_t t = threadIdx.x; t < n_tiles; t += 1024u) {
         const uint32_t tx = t % tiles_x, ty = t / tiles_x;
         const uint2 w = win1[t];
-        need = ty >= band_lo && ty < band_hi && w.y != kKeyAll && !((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u);
+        const bool need = ty >= band_lo && ty < band_hi && w.y != kKeyAll && !((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u);
         win2[t] = need ? make_uint2(w.y, kKeyAll) : make_uint2(0u, 0u);
+        mine += need ? 1u : 0u;
     }
-    const unsigned long long bal = __ballot(need);
-    if ((threadIdx.x & 63u) == 0 && bal) atomicAdd(&s_need, (uint32_t)__popcll(bal));
-    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+    if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(&s_need, mine);
+    __syncthreads();  // (also: win2 is complete and visible to this workgroup)
+    const uint32_t total = s_need;
     if (threadIdx.x == 0) {
-        if (s_need) atomicAdd(d_need, s_need);
-        if (host_verdict) {
-            // the last block to get here posts {seq, tiles that need the repair round} to pinned host memory: one
-            // system-scope 64-bit store, polled by gsx_render (host_verify).  Ticket pattern: add, fence, take a ticket.
-            __threadfence();
-            if (atomicAdd(ticket, 1u) == gridDim.x - 1u) {
-                const uint32_t total = __hip_atomic_load(d_need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(host_verdict, ((unsigned long long)seq << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
+        *d_need = total;
+        // {seq, tiles that need the repair round} to pinned host memory: one system-scope 64-bit store, polled by gsx_render
+        if (host_verdict) __hip_atomic_store(host_verdict, ((unsigned long long)seq << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (total == 0) return;  // the repair round's kernels fall through on *d_need == 0
+    if (vt.pyr2_data) build_window_pyramid<1024>(win2, vt.pyr2, vt.pyr2_data, nullptr, lds);
+    if (vt.table) {
+        const uint32_t n_blocks = vt.grid.blocks_x * vt.grid.blocks_y;
+        for (uint32_t b = threadIdx.x >> 6; b < n_blocks; b += 16u)
+            wave_block_table_entry(vt.grid, b, tiles_x, tiles_y, band_lo, band_hi, done, row_words, win2, vt.table, vt.ranges);
     }
 }
 
 // the model's windows for its next frame.  A tile that was saturated before this model was composited (done_before,
 // nearer models) says nothing about this model's depths; a tile still open afterwards makes its neighbourhood unbounded.
-// One workgroup per 16x16 block of tiles: the block's neighbourhood (radius <= 16) is staged in LDS once and the
+// One workgroup per 32x32 block of tiles: the block's neighbourhood (radius <= 16) is staged in LDS once and the
 // (2r+1)^2 maximum is taken separably — rows, then columns — instead of (2r+1)^2 global loads per tile (169 at the radius
 // the frame-parallel mode uses: 40 us; 14 us at radius 3).
-constexpr int kNextBlock = 16, kNextMaxR = 16, kNextSpan = kNextBlock + 2 * kNextMaxR;
-__global__ __launch_bounds__(256) void k_spec_next(const uint32_t* __restrict__ tile_sat, const uint32_t* __restrict__ done,
+// The LAST workgroup to finish (a ticket: a dozen workgroups at 1080p) goes on to build the two pyramids of the new windows —
+// the max-pyramid of their ends (admission in the projection kernel) and the min-pyramid (binning) — which used to be a launch
+// of their own behind this one.
+constexpr int kNextBlock = 32, kNextMaxR = 16, kNextSpan = kNextBlock + 2 * kNextMaxR;
+struct NextLds {
+    float deep[kNextSpan][kNextSpan + 1];
+    unsigned char open[kNextSpan][kNextSpan + 1];
+    float hdeep[kNextSpan][kNextBlock + 1];
+    unsigned char hopen[kNextSpan][kNextBlock + 1];
+};
+__global__ __launch_bounds__(1024) void k_spec_next(const uint32_t* __restrict__ tile_sat, const uint32_t* __restrict__ done,
                                                     const uint32_t* __restrict__ done_before, uint32_t row_words,
                                                     uint32_t tiles_x, uint32_t tiles_y, float gain, int radius,
-                                                    uint2* __restrict__ win_next, int band_lo, int band_hi) {
+                                                    uint2* __restrict__ win_next, int band_lo, int band_hi,
+                                                    uint32_t* __restrict__ ticket, WindowPyramid pyr, uint32_t* __restrict__ pyr_data,
+                                                    uint32_t* __restrict__ pyr_min_ends) {
     // per staged tile: depth (0 = contributes nothing) and an "open" flag; outside the band / image: neither
-    __shared__ float s_deep[kNextSpan][kNextSpan + 1];
-    __shared__ unsigned char s_open[kNextSpan][kNextSpan + 1];
-    __shared__ float s_hdeep[kNextSpan][kNextBlock + 1];
-    __shared__ unsigned char s_hopen[kNextSpan][kNextBlock + 1];
+    __shared__ union {
+        NextLds n;
+        PyramidLds p;
+    } lds;
+    __shared__ uint32_t s_last;
     const int bx = (int)blockIdx.x * kNextBlock, by = (int)blockIdx.y * kNextBlock;
     const int span = kNextBlock + 2 * radius;
-    for (int i = (int)threadIdx.x; i < span * span; i += 256) {
+    for (int i = (int)threadIdx.x; i < span * span; i += 1024) {
         const int ly = i / span, lx = i - ly * span;
         const int x = bx - radius + lx, y = by - radius + ly;
         float deep = 0.0f;
@@ -146,43 +256,59 @@ __global__ __launch_bounds__(256) void k_spec_next(const uint32_t* __restrict__ 
                 deep = __uint_as_float(tile_sat[(uint32_t)y * tiles_x + (uint32_t)x]);
             }
         }
-        s_deep[ly][lx] = deep;
-        s_open[ly][lx] = open;
+        lds.n.deep[ly][lx] = deep;
+        lds.n.open[ly][lx] = open;
     }
     __syncthreads();
     // rows: for every staged row and every column of the block, max / any over [x - r, x + r]
-    for (int i = (int)threadIdx.x; i < span * kNextBlock; i += 256) {
+    for (int i = (int)threadIdx.x; i < span * kNextBlock; i += 1024) {
         const int ly = i / kNextBlock, cx = i - ly * kNextBlock;
         float deep = 0.0f;
         unsigned char open = 0;
         for (int d = 0; d <= 2 * radius; ++d) {
-            deep = fmaxf(deep, s_deep[ly][cx + d]);
-            open |= s_open[ly][cx + d];
+            deep = fmaxf(deep, lds.n.deep[ly][cx + d]);
+            open |= lds.n.open[ly][cx + d];
         }
-        s_hdeep[ly][cx] = deep;
-        s_hopen[ly][cx] = open;
+        lds.n.hdeep[ly][cx] = deep;
+        lds.n.hopen[ly][cx] = open;
     }
     __syncthreads();
-    const int cx = (int)threadIdx.x & 15, cy = (int)threadIdx.x >> 4;
-    const int tx = bx + cx, ty = by + cy;
-    if (tx >= (int)tiles_x || ty >= (int)tiles_y) return;
-    const uint32_t t = (uint32_t)ty * tiles_x + (uint32_t)tx;
-    if (ty < band_lo || ty >= band_hi) {  // not this viewer's band: takes nothing
-        win_next[t] = make_uint2(0u, 0u);
-        return;
+    {
+        const int cx = (int)threadIdx.x & 31, cy = (int)threadIdx.x >> 5;
+        const int tx = bx + cx, ty = by + cy;
+        if (tx < (int)tiles_x && ty < (int)tiles_y) {
+            const uint32_t t = (uint32_t)ty * tiles_x + (uint32_t)tx;
+            if (ty < band_lo || ty >= band_hi) {  // not this viewer's band: takes nothing
+                win_next[t] = make_uint2(0u, 0u);
+            } else {
+                float deepest = 0.0f;
+                unsigned char open = 0;
+                for (int d = 0; d <= 2 * radius; ++d) {
+                    deepest = fmaxf(deepest, lds.n.hdeep[cy + d][cx]);
+                    open |= lds.n.hopen[cy + d][cx];
+                }
+                uint32_t hi = kKeyAll;
+                if (!open) {
+                    const float lim = deepest * gain;
+                    hi = (lim < 3.0e38f) ? max(__float_as_uint(lim), 1u) : kKeyAll;
+                }
+                win_next[t] = make_uint2(0u, hi);
+            }
+        }
     }
-    float deepest = 0.0f;
-    unsigned char open = 0;
-    for (int d = 0; d <= 2 * radius; ++d) {
-        deepest = fmaxf(deepest, s_hdeep[cy + d][cx]);
-        open |= s_hopen[cy + d][cx];
+    if (!pyr_data) return;
+    // ticket: this workgroup's windows are visible device-wide before it draws; the one that draws the last number sees them all
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t n_wg = gridDim.x * gridDim.y;
+        s_last = atomicAdd(ticket, 1u) == n_wg - 1u ? 1u : 0u;
+        if (s_last) *ticket = 0u;  // (the next launch of this kernel starts from zero again)
     }
-    uint32_t hi = kKeyAll;
-    if (!open) {
-        const float lim = deepest * gain;
-        hi = (lim < 3.0e38f) ? max(__float_as_uint(lim), 1u) : kKeyAll;
-    }
-    win_next[t] = make_uint2(0u, hi);
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    build_window_pyramid<1024>(win_next, pyr, pyr_data, pyr_min_ends, lds.p);
 }
 
 WindowPyramid window_pyramid_layout(uint32_t tiles_x, uint32_t tiles_y, const uint32_t* data) {
@@ -212,79 +338,6 @@ size_t window_pyramid_words(uint32_t tiles_x, uint32_t tiles_y) {
     return (size_t)p.cells_off + 2;  // the levels, then the 64-bit cell word of a min-of-starts pyramid
 }
 
-// one workgroup builds every level (11 k words at 1080p): level 0 = the window ends, level l = 2x2 max of level l-1.
-// min_ends (nullable): a second pyramid, the MIN of the window ends — "every tile under this rectangle takes this key"
-// for windows that start at 0 (the binning's fast path, kernels_bin.hip).
-// Levels that fit kPyrLds words are kept in LDS as well: the level above is built from there instead of from global words this
-// workgroup has just written (a round trip through L2 per level, 7 of them at 1080p: 12 us for 11 k words).  Level 1 comes
-// straight from the windows, so that it does not wait for level 0 either.
-constexpr uint32_t kPyrLds = 2304;  // 1920x1080: level 1 = 60 x 34 = 2040 cells
-__global__ __launch_bounds__(1024) void k_window_pyramid(const uint2* __restrict__ window, WindowPyramid p, uint32_t* __restrict__ data,
-                                                         const uint32_t* __restrict__ d_skip, uint32_t* __restrict__ min_ends) {
-    if (d_skip && *d_skip == 0) return;  // repair round with nothing to repair
-    __shared__ unsigned long long s_cells;
-    __shared__ uint32_t s_a[2][kPyrLds], s_m[2][kPyrLds];
-    if (threadIdx.x == 0) s_cells = 0ull;
-    __syncthreads();
-    const uint32_t mos = p.min_of_starts;
-    auto leaf = [&](const uint2 w) -> uint32_t { return mos ? (w.y > w.x ? w.x : 0xFFFFFFFFu) : w.y; };
-    auto leaf_min = [](const uint2 w) -> uint32_t { return w.x == 0u ? w.y : 0u; };  // a window that does not start at 0 promises nothing
-    auto join = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) -> uint32_t { return mos ? min(min(a, b), min(c, d)) : max(max(a, b), max(c, d)); };
-    unsigned long long cells = 0ull;
-    for (uint32_t i = threadIdx.x; i < p.wx[0] * p.wy[0]; i += 1024) {
-        const uint2 w = window[i];
-        data[i] = leaf(w);
-        if (min_ends) min_ends[i] = leaf_min(w);
-        if (mos && w.y > w.x) cells |= 1ull << ((((i / p.wx[0]) >> p.cell_sy) << 3) | ((i % p.wx[0]) >> p.cell_sx));
-    }
-    if (mos) {
-        if (cells) atomicOr(&s_cells, cells);
-        __syncthreads();
-        if (threadIdx.x == 0) *reinterpret_cast<unsigned long long*>(data + p.cells_off) = s_cells;
-    }
-    uint32_t l = 1, cur = 0;
-    bool prev_lds = false;
-    if (p.levels > 1 && p.wx[1] * p.wy[1] <= kPyrLds) {  // level 1 from the windows themselves
-        const uint32_t wx = p.wx[1], px = p.wx[0], py = p.wy[0];
-        for (uint32_t i = threadIdx.x; i < wx * p.wy[1]; i += 1024) {
-            const uint32_t x = 2u * (i % wx), y = 2u * (i / wx), x1 = min(x + 1u, px - 1u), y1 = min(y + 1u, py - 1u);
-            const uint2 a = window[y * px + x], b = window[y * px + x1], c = window[y1 * px + x], d = window[y1 * px + x1];
-            const uint32_t v = join(leaf(a), leaf(b), leaf(c), leaf(d));
-            data[p.off[1] + i] = v;
-            s_a[0][i] = v;
-            if (min_ends) {
-                const uint32_t mv = min(min(leaf_min(a), leaf_min(b)), min(leaf_min(c), leaf_min(d)));
-                min_ends[p.off[1] + i] = mv;
-                s_m[0][i] = mv;
-            }
-        }
-        prev_lds = true;
-        l = 2;
-    }
-    for (; l < p.levels; ++l) {
-        __syncthreads();
-        const uint32_t wx = p.wx[l], wy = p.wy[l], px = p.wx[l - 1], py = p.wy[l - 1];
-        const uint32_t* src = prev_lds ? s_a[cur] : data + p.off[l - 1];
-        const uint32_t* msrc = prev_lds ? s_m[cur] : (min_ends ? min_ends + p.off[l - 1] : nullptr);
-        uint32_t* dst = data + p.off[l];
-        const bool keep = wx * wy <= kPyrLds;
-        const uint32_t wbuf = prev_lds ? cur ^ 1u : 0u;  // (never the buffer this level is read from)
-        for (uint32_t i = threadIdx.x; i < wx * wy; i += 1024) {
-            const uint32_t x = 2u * (i % wx), y = 2u * (i / wx), x1 = min(x + 1u, px - 1u), y1 = min(y + 1u, py - 1u);
-            const uint32_t v = join(src[y * px + x], src[y * px + x1], src[y1 * px + x], src[y1 * px + x1]);
-            dst[i] = v;
-            if (keep) s_a[wbuf][i] = v;
-            if (min_ends) {
-                const uint32_t mv = min(min(msrc[y * px + x], msrc[y * px + x1]), min(msrc[y1 * px + x], msrc[y1 * px + x1]));
-                min_ends[p.off[l] + i] = mv;
-                if (keep) s_m[wbuf][i] = mv;
-            }
-        }
-        if (keep) cur = wbuf;
-        prev_lds = keep;
-    }
-}
-
 hipError_t launch_window_pyramid(hipStream_t s, const uint2* window, uint32_t tiles_x, uint32_t tiles_y, uint32_t* data,
                                  bool min_of_starts, const uint32_t* d_skip, uint32_t* min_ends) {
     WindowPyramid p = window_pyramid_layout(tiles_x, tiles_y, data);
@@ -295,20 +348,32 @@ hipError_t launch_window_pyramid(hipStream_t s, const uint2* window, uint32_t ti
 
 hipError_t launch_spec_verify(hipStream_t s, const uint2* win1, const uint32_t* done, uint32_t row_words, uint32_t tiles_x,
                               uint32_t tiles_y, uint2* win2, uint32_t* need_bits, uint32_t* d_need, uint32_t band_lo, uint32_t band_hi,
-                              uint32_t* d_ticket, unsigned long long* host_verdict, uint32_t seq) {
-    // *d_need and *d_ticket are zero here (the frame's counters are reset before the first slab)
+                              unsigned long long* host_verdict, uint32_t seq, uint32_t* pyr2_data, const BlockGrid* grid, uint4* table,
+                              uint2* ranges) {
     const uint32_t n_tiles = tiles_x * tiles_y;
-    GSX_LAUNCH(k_spec_verify, dim3((n_tiles + 255) / 256), dim3(256), 0, s, win1, done, row_words, tiles_x, n_tiles, win2,
-                       need_bits, d_need, band_lo, band_hi, d_ticket, host_verdict, seq);
+    VerifyTables vt{};
+    vt.pyr2_data = pyr2_data;
+    if (pyr2_data) {
+        vt.pyr2 = window_pyramid_layout(tiles_x, tiles_y, pyr2_data);
+        vt.pyr2.min_of_starts = 1u;
+    }
+    if (grid && table) {
+        vt.grid = *grid;
+        vt.table = table;
+        vt.ranges = ranges;
+    }
+    GSX_LAUNCH(k_spec_verify_fused, dim3(1), dim3(1024), 0, s, win1, done, row_words, tiles_x, n_tiles, win2, need_bits, d_need,
+               std::min(band_lo, tiles_y), std::min(band_hi, tiles_y), host_verdict, seq, vt);
     return hipGetLastError();
 }
 
 hipError_t launch_spec_next(hipStream_t s, const uint32_t* tile_sat, const uint32_t* done, const uint32_t* done_before,
                             uint32_t row_words, uint32_t tiles_x, uint32_t tiles_y, float margin, uint32_t radius, uint2* win_next,
-                            uint32_t band_lo, uint32_t band_hi) {
-    GSX_LAUNCH(k_spec_next, dim3((tiles_x + kNextBlock - 1) / kNextBlock, (tiles_y + kNextBlock - 1) / kNextBlock), dim3(256), 0, s,
-                       tile_sat, done, done_before, row_words, tiles_x, tiles_y, 1.0f + margin, (int)std::min<uint32_t>(radius, kNextMaxR), win_next,
-                       (int)std::min(band_lo, tiles_y), (int)std::min(band_hi, tiles_y));
+                            uint32_t band_lo, uint32_t band_hi, uint32_t* d_ticket, uint32_t* pyr_data, uint32_t* pyr_min_ends) {
+    const WindowPyramid pyr = window_pyramid_layout(tiles_x, tiles_y, pyr_data);
+    GSX_LAUNCH(k_spec_next, dim3((tiles_x + kNextBlock - 1) / kNextBlock, (tiles_y + kNextBlock - 1) / kNextBlock), dim3(1024), 0, s,
+               tile_sat, done, done_before, row_words, tiles_x, tiles_y, 1.0f + margin, (int)std::min<uint32_t>(radius, kNextMaxR), win_next,
+               (int)std::min(band_lo, tiles_y), (int)std::min(band_hi, tiles_y), d_ticket, pyr, pyr_data, pyr_min_ends);
     return hipGetLastError();
 }
 
