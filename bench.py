@@ -86,6 +86,7 @@ def parse_args():
                     help="gsx_render_options.frames_in_flight of the headline loop at N=1 (the one-in-flight rate is reported beside it)")
     ap.add_argument("--dist-frames-in-flight", type=int, default=2, help="frames_in_flight of gsx_shard_render_frame (N > 1 / --force-dist): "
                     "every lane has its own communicator and stream, the verdict of a frame is read one call later")
+    ap.add_argument("--no-scene-legs", action="store_true", help="robustness: skip the legs that upload another scene (translucent, surfaces)")
     ap.add_argument("--no-extra-legs", action="store_true", help="N=1: skip the synchronised / steady-state / per-pass legs")
     ap.add_argument("--unspeculated-in-flight", action="store_true",
                     help="N=1: also time the unspeculated loop with --frames-in-flight lanes (off by default: its contended k_project "
@@ -564,7 +565,8 @@ def main():
                 ac = accounting(rounds(args.warmup))
                 res[name] = dict(fps=round(args.steps / el, 1), ms_per_step=round(1e3 * el / args.steps, 4),
                                  speculated_frames=round(float(ac[:, 3].mean()), 3), frames_with_repair_round=round(float(ac[:, 4].mean()), 3),
-                                 n_visible=int(ac[:, 1].mean()), n_depth_sorted=int(ac[:, 2].mean()), tile_entries=int(ac[:, 5].mean()))
+                                 n_visible=int(ac[:, 1].mean()), n_depth_sorted=int(ac[:, 2].mean()), tile_entries=int(ac[:, 5].mean()),
+                                 overflow_slabs=int(ac[:, 6].max()))
             viewer.set_render_options()
             res["speculated_over_unspeculated"] = round(res["speculated"]["fps"] / res["unspeculated"]["fps"], 3)
             return res
@@ -580,6 +582,27 @@ def main():
         robustness["open_sky"] = leg()
         robustness["open_sky"]["scene"] = "mask box keeps the Gaussians with y <= 0.5 (gsx_mask_evaluate): the screen above the horizon stays open"
         ev.evaluate(None, renderer.KEY)   # MaskOpTree::Reset
+
+        def scene_leg(variant, what):
+            """the same loops on ANOTHER resident scene of the same size (scene.VARIANTS), uploaded in place of the benchmark scene; a long
+            warm-up: the viewer needs ~50 frames to time both schedules and settle on the faster one (SpecTuner, gsx_frame.cpp)"""
+            g2 = scene.synthetic_gaussians(n, seed, sh, 0, n, variant=variant)
+            renderer.load_shard(g2, 0, n)
+            renderer.poll()
+            del g2
+            saved_w, args.warmup = args.warmup, max(args.warmup, 100)
+            res = leg()
+            args.warmup = saved_w
+            res["scene"] = what
+            res["list_entries_per_visible_gaussian"] = round(res["unspeculated"]["tile_entries"] / max(res["unspeculated"]["n_visible"], 1), 3)
+            return res
+
+        if not args.no_scene_legs:
+            robustness["translucent"] = scene_leg("translucent", "the benchmark scene with opacity logits N(-5.5, 1.5) (median opacity 0.004): next to no tile ever "
+                                                  "saturates, there is nothing to speculate on — the viewer must find that out and stop (speculated_over_unspeculated ~ 1)")
+            robustness["surfaces"] = scene_leg("surfaces", "a captured-scene stand-in (the INRIA garden PLY is not in the image): Gaussians on six planes and four "
+                                               "spheres, flattened along the normal, log-scales N(-3, 1.2) clamped to [-7, 1] — a heavy tail, the widest splats "
+                                               "cover hundreds of tiles — opacity logits N(2, 1.5)")
         robustness["note"] = ("speculated frames are bit-identical to unspeculated ones whatever the poses (tests/test_gpu_speculation.py); "
                               "the viewer pauses speculation by itself when it keeps repairing without admitting less (gsx_frame.cpp)")
     overflow_slabs = int(max(acct[:, 6].max(), acct_u[:, 6].max() if acct_u is not None else 0))

@@ -533,8 +533,10 @@ typedef struct gsx_shard_stats {
     uint32_t last_slot_records, last_repair_slot_records;
     uint32_t last_entries_sum, last_entries_max; /* list entries all ranks / the busiest rank binned in the last frame whose verdict was read
                                                     (balance of the bands: max * world / sum) */
-    uint32_t last_work_permille, reserved0;      /* list entries the busiest rank's tiles WALKED x world x 1000 / all ranks': what the bands
-                                                    are balanced by (1000 = perfectly even) */
+    uint32_t last_work_permille;                 /* work of the busiest rank's tiles x world x 1000 / all ranks': what the bands are balanced
+                                                    by (1000 = perfectly even) */
+    uint32_t redo_fallbacks;                     /* redone frames whose exactly sized slots overflowed again and that were redone with
+                                                    whole-shard slots */
 } gsx_shard_stats;
 gsx_status gsx_shard_get_stats(gsx_viewer* v, gsx_shard_stats* out, uint32_t reset);
 /* Where a sharded frame's finished bands go.  root = -1 (default): an all-gather — after gsx_shard_render_frame every rank's

@@ -182,6 +182,7 @@ def run(cfg, world, frames, open_sky, speculate, orbit, lanes):
             v.comm_init_custom_v(world, rank, RecordingTransport(hub, rank).all_to_all_v, RecordingTransport(hub, rank).gather_v)
             marks, sums = [], []
             warm = max(1, min(10, frames // 4))
+            per_frame = []
             for i in range(frames):
                 if i == warm:
                     v.poll()   # (the replay starts its clock here: with frames in flight that completes them — the same calls in both phases)
@@ -191,10 +192,15 @@ def run(cfg, world, frames, open_sky, speculate, orbit, lanes):
                 # (frames in flight: a readback completes them — it would change the order of the collectives; only the last
                 #  frame is compared then)
                 sums.append(band_checksum(v, world, rank) if lanes == 1 or i == frames - 1 else None)
+                if rank == 0 and lanes == 1:
+                    stf = v.shard_stats()
+                    per_frame.append(dict(slot_records_max=stf["last_slot_records"], redo=stf["redo_frames"], repair=stf["repair_frames"],
+                                          wire_MB=round(stf["wire_bytes"] / 1e6, 2), work_busiest_over_mean=stf["last_work_permille"] / 1000.0,
+                                          edges=sums[-1][1]))
             st = v.shard_stats()
             entries = v.frame_stats("m")["n_tile_entries"]
             v.close()
-            out[rank] = dict(marks=marks, sums=sums, stats=st, entries=entries, shard_max=shard_max)
+            out[rank] = dict(marks=marks, sums=sums, stats=st, entries=entries, shard_max=shard_max, per_frame=per_frame)
         except BaseException as e:  # noqa: BLE001
             errors.append(e)
             hub.barrier.abort()
@@ -228,7 +234,21 @@ def run(cfg, world, frames, open_sky, speculate, orbit, lanes):
         same = same and band_checksum(v, world, rank) == out[rank]["sums"][frames - 1]
         st = v.shard_stats()
         timed = frames - warm
-        ranks.append(dict(rank=rank, ms_per_frame_alone=round(1e3 * elapsed / timed, 4), wire_bytes_per_frame=int((tr.wire - wire_mark) / timed),
+        v.close()
+        # once more with every pass bracketed by events (costs a few microseconds of stream gap per bracket): where the rank's time goes
+        v, shard_max = make_viewer(cfg, rank, world, open_sky, lanes)
+        tr2 = ReplayTransport(world, rank, hub.log[rank])
+        v.comm_init_custom_v(world, rank, tr2.all_to_all_v, tr2.gather_v)
+        for i in range(frames):
+            if i == warm:
+                v.poll()
+                v.set_pass_timing(True)
+                v.get_pass_timing()
+            v.update_camera(orbit[i % 240], (w, h))
+            v.shard_render_frame("m", shard_max, speculate=bool(speculate))
+        v.poll()
+        passes = {k: round(1e3 * t["ms"] / timed, 1) for k, t in v.get_pass_timing().items() if t["ms"] > 0}
+        ranks.append(dict(rank=rank, ms_per_frame_alone=round(1e3 * elapsed / timed, 4), pass_us_per_frame=passes, wire_bytes_per_frame=int((tr.wire - wire_mark) / timed),
                           frames_equal_to_the_recording=bool(same), list_entries_last_frame=int(out[rank]["entries"]),
                           repair_frames=round(out[rank]["stats"]["repair_frames"] / frames, 3), redo_frames=round(out[rank]["stats"]["redo_frames"] / frames, 3),
                           band_rows_last_frame=[out[rank]["sums"][-1][1][rank], out[rank]["sums"][-1][1][rank + 1]]))
@@ -244,7 +264,7 @@ def run(cfg, world, frames, open_sky, speculate, orbit, lanes):
                 slowest_rank_ms=round(slowest, 4), fastest_rank_ms=round(min(r["ms_per_frame_alone"] for r in ranks), 4),
                 wire_ms_at_7x153GBps=round(wire_ms, 4), predicted_fps=round(1e3 / (slowest + wire_ms), 1),
                 list_entries_max_over_mean=round(max(ent) * world / max(sum(ent), 1), 3),
-                band_edges_last_frame=out[0]["sums"][-1][1], all_frames_equal_to_the_recording=all(r["frames_equal_to_the_recording"] for r in ranks))
+                band_edges_last_frame=out[0]["sums"][-1][1], rank0_frame_by_frame_cumulative=out[0]["per_frame"], all_frames_equal_to_the_recording=all(r["frames_equal_to_the_recording"] for r in ranks))
 
 
 def single_gpu(cfg, frames, open_sky, speculate, orbit, lanes):

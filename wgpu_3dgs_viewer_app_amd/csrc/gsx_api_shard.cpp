@@ -376,7 +376,7 @@ gsx_status gsx_shard_slot_records(gsx_viewer* v, const char* key, uint32_t world
     // verdict says so and round 0 is redone with the safe size.
     const uint32_t n = std::max<uint32_t>(shard_records_max, 1u);
     uint32_t t = n;
-    if (m->shard_frame_limited && m->slot_hint) t = std::min<uint32_t>(n, std::max<uint32_t>(2u * m->slot_hint + 4096u, 8192u));
+    if (m->shard_frame_limited && m->slot_hint && m->slot_hint_limited) t = std::min<uint32_t>(n, std::max<uint32_t>(2u * m->slot_hint + 4096u, 8192u));
     if (m->slot_force) t = std::min<uint32_t>(n, m->slot_force);  // gsx_shard_set_slot_records (the same on every rank, by contract)
     *out_records = t;
     (void)world;
@@ -533,7 +533,10 @@ gsx_status gsx_shard_wait_verdict(gsx_viewer* v, const char* key, uint32_t seq, 
             out->need_tiles = (uint32_t)w;
             out->overflow = (uint32_t)(d & 1ull);
             out->max_records = (uint32_t)(d >> 32);
-            if (Model* m = find_model(v, key)) m->slot_hint = out->max_records;  // next frame's round-0 slots (global: same on every rank)
+            if (Model* m = find_model(v, key)) {  // next frame's round-0 slots (global: same on every rank)
+                m->slot_hint = out->max_records;
+                m->slot_hint_limited = m->shard_frame_limited;
+            }
             return GSX_OK;
         }
         if ((spin & 0xFFFu) == 0) {

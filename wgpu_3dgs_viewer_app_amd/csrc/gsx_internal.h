@@ -64,10 +64,19 @@ __host__ __device__ inline uint32_t band_rows_max(const BandEdges& b) {
 //   [0] records it wanted to send to its busiest destination   [1] a slot overflowed   [2] gather root + 1 (0: every rank receives)
 //   [3] list entries it binned this round   [4..7] 0   [8 + d] records it wanted to send to destination d (round 0)
 //   then rows x tiles_x saturation depth keys of its band (0 = open), then rows words of per-tile-row work (per tile: list entries
-//   walked + list length + kTileWork: what the next frame's bands are balanced by); rows = its band's height.
+//   tile_work(): what the next frame's bands are balanced by); rows = its band's height.
 // The pieces are gathered at a common stride (the tallest band's piece); a rank sends only what its own band needs.
 constexpr uint32_t kShardExtraWords = 8 + kMaxRanks;
-constexpr uint32_t kTileWork = 8;  // what a tile costs before it has walked a single list entry, in list entries (band balancing)
+constexpr uint32_t kBalanceKeepPermille = 1150;  // bands whose busiest rank carries at most 1.15 x the mean work are left alone
+// Band balancing: what a tile cost this frame, in units of one list candidate looked at and passed by.  By the block compositor's
+// instruction counts a candidate that is TAKEN (blended into 256 pixels) costs ~50 of those; an entry of the tile's list has cost its
+// share of the depth sort, the binning and the list sort before any tile looks at it (cfg4: ~300 us for 0.87 M block entries against
+// 223 us for the compositor's ~20 M candidates and ~5 M takers: ~440 units an entry, spread over the tiles that share the list); a
+// tile that finds nothing still reads and writes its pixels.
+constexpr uint32_t kTileWork = 256;
+__host__ __device__ inline uint32_t tile_work(uint32_t walked, uint32_t taken, uint32_t list_len, uint32_t tiles_per_list) {
+    return kTileWork + walked + 50u * taken + (440u * list_len) / (tiles_per_list ? tiles_per_list : 1u);
+}
 __host__ __device__ inline uint32_t feedback_stride(const BandEdges& b, uint32_t tiles_x) { return kShardExtraWords + band_rows_max(b) * (tiles_x + 1u); }
 __host__ __device__ inline uint32_t feedback_words(const BandEdges& b, uint32_t tiles_x, uint32_t g) { return kShardExtraWords + (b.e[g + 1u] - b.e[g]) * (tiles_x + 1u); }
 // The verdict block in pinned host memory (u32 words; words 0..3 are the two 64-bit verdict words the host polls):
@@ -215,9 +224,9 @@ struct SlabStats {
     uint32_t slot_max[2];      // device-resident exchange: most records this rank had for ONE destination in the last round 0 / 1
     uint32_t slot_over[2];     // ... and whether that exceeded the slot (the verdict tells every rank; round 0 is then redone)
     uint32_t shard_need;       // tiles of the whole frame that needed the repair round (gsx_shard_verify)
+    uint32_t shard_ticket;     // k_shard_verify: blocks done (the last one posts the verdict); directly behind shard_need: zeroed together
     uint32_t slot_want[64];    // records this rank wanted to send to each destination in the last round 0 (k_pack_headers): the
                                // gathered count matrix sizes the next frame's slots per (source, destination) pair
-    uint32_t shard_ticket;     // k_shard_verify: blocks done (the last one posts the verdict): tiles of the whole frame that needed the repair round (gsx_shard_verify)
     // ---- from here on: zeroed at the start of every frame ----
     uint32_t n_entries;        // D of the slab being processed: what was binned into the pair buffers (<= their capacity)
     uint32_t n_entries_total;  // sum of slab D over the frame (including entries the spill compositor handled without pairs)

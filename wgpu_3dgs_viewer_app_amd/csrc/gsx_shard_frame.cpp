@@ -140,7 +140,8 @@ gsx_status exchange_round(Ctx& c, size_t i, uint32_t round, uint32_t T, const st
 // orbit moves the counts by a few per cent a frame; a camera jump overflows a slot, the verdict says so and the frame is redone
 // with whole-shard slots — the same frame, the same pixels).  Uniform slots hold the BUSIEST pair's count x 2 for every pair:
 // 19.4 MB per rank and frame on the links at 8 ranks on cfg4, of which 2.7 MB were records somebody wanted.  Needs a transport
-// that moves unequal pieces and a matrix from a frame of the same kind (both limited by windows, or both not).
+// that moves unequal pieces and a matrix from a frame of the same kind (both limited by windows, or both not) and the same bands
+// (a frame whose bands have just moved falls back to uniform slots once).
 void plan_pair_slots(Ctx& c, size_t i) {
     ShardPending& p = *c.p;
     p.pair_caps[i].clear();
@@ -149,6 +150,7 @@ void plan_pair_slots(Ctx& c, size_t i) {
     const Model* om = find_model(o, p.order[i].c_str());
     const Model* lm = find_model(c.l, p.order[i].c_str());
     if (!om || !lm || om->slot_force || om->pair_counts.size() != (size_t)c.world * c.world || om->pair_limited != lm->shard_frame_limited) return;
+    if (om->pair_edges.size() != (size_t)c.world + 1u || !std::equal(om->pair_edges.begin(), om->pair_edges.end(), c.bands.e)) return;  // counted under other bands
     const uint32_t n = std::max<uint32_t>(p.shard_max[i], 1u);
     p.pair_caps[i].resize((size_t)c.world * c.world);
     for (size_t k = 0; k < p.pair_caps[i].size(); ++k) {
@@ -194,6 +196,7 @@ gsx_status read_verdict_extras(Ctx& c, size_t i) {
         om->pair_counts.assign(hv + kVerdictMatrix, hv + kVerdictMatrix + (size_t)c.world * c.world);
         const Model* lm = find_model(c.l, c.p->order[i].c_str());
         om->pair_limited = lm && lm->shard_frame_limited;
+        om->pair_edges.assign(c.bands.e, c.bands.e + c.world + 1);
     }
     o->shard_stats.last_entries_sum = hv[5];
     o->shard_stats.last_entries_max = hv[6];
@@ -224,6 +227,7 @@ gsx_status settle(Ctx& c, size_t i, bool* overflow) {
     gsx_status st = timed_wait(c, key, c.p->seq, &verdict);
     if (st) return st;
     if ((st = read_verdict_extras(c, i))) return st;
+    c.p->counted[i] = true;
     *overflow = verdict.overflow != 0;
     if (*overflow || !verdict.need_tiles) return GSX_OK;
     // the repair round, sized exactly: what each destination is owed is counted, the maximum gathered and posted
@@ -241,22 +245,45 @@ gsx_status settle(Ctx& c, size_t i, bool* overflow) {
     return next_limits(c, i);
 }
 
-// the whole frame once more with slots of a whole shard each: nothing can overflow, every verdict is dealt with at once
+// The whole frame once more with slots that cannot overflow; every verdict is dealt with at once.  Slots of a whole shard always
+// fit — and move 420 MB per rank at 8 ranks on cfg4.  But the verdict that reported the overflow also carries what every pair WANTED
+// in this very round (the count matrix), the redo packs the same records through the same windows, so where the transport moves
+// unequal pieces the redo's slots are exactly that: a few megabytes.
 gsx_status redo_safe(Ctx& c) {
     c.owner->shard_stats.redo_frames += 1;
-    c.p->gathered = false;
-    for (size_t i = 0; i < c.p->order.size(); ++i) {
-        c.p->slot[i] = std::max<uint32_t>(c.p->shard_max[i], 1u);
-        c.p->pair_caps[i].clear();
-    }
-    for (size_t i = 0; i < c.p->order.size(); ++i) {
-        gsx_status st = round0(c, i);  // (model 0 is not "behind": it starts from a cleared band)
-        if (st) return st;
-        bool overflow = false;
-        if ((st = settle(c, i, &overflow))) return st;
-        if (overflow)
-            return fail(GSX_ERR_OOM, "gsx_shard_render_frame: an exchange slot of %u records (a whole shard of '%s') overflowed: shard_records_max is wrong",
-                        c.p->slot[i], c.p->order[i].c_str());
+    // attempt 0: exact slots where this frame's counts are known; attempt 1: slots of a whole shard (they cannot overflow)
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        c.p->gathered = false;
+        bool any_exact = false;
+        for (size_t i = 0; i < c.p->order.size(); ++i) {
+            c.p->slot[i] = std::max<uint32_t>(c.p->shard_max[i], 1u);
+            c.p->pair_caps[i].clear();
+            const Model* om = find_model(c.owner, c.p->order[i].c_str());
+            // (models behind the one that overflowed have not been exchanged in this frame yet: nothing is known about them)
+            if (attempt == 0 && comm_moves_unequal(c.owner) && c.owner->shard_pair_slots && om && !om->slot_force && c.p->counted[i] &&
+                om->pair_counts.size() == (size_t)c.world * c.world) {
+                c.p->pair_caps[i] = om->pair_counts;
+                any_exact = true;
+            }
+        }
+        if (attempt == 0 && !any_exact) continue;
+        bool again = false;
+        for (size_t i = 0; i < c.p->order.size() && !again; ++i) {
+            gsx_status st = round0(c, i);  // (model 0 is not "behind": it starts from a cleared band)
+            if (st) return st;
+            bool overflow = false;
+            if ((st = settle(c, i, &overflow))) return st;
+            if (overflow) {
+                if (attempt == 0) {  // (the counts moved between the two attempts: the safe size, once more)
+                    c.owner->shard_stats.redo_fallbacks += 1;
+                    again = true;
+                } else {
+                    return fail(GSX_ERR_OOM, "gsx_shard_render_frame: an exchange slot of %u records (a whole shard of '%s') overflowed: shard_records_max is wrong",
+                                c.p->slot[i], c.p->order[i].c_str());
+                }
+            }
+        }
+        if (!again) break;
     }
     c.p->settled = true;
     return GSX_OK;
@@ -279,6 +306,7 @@ gsx_status frame_front(Ctx& c, bool eager_gather) {
     }
     p.slot.resize(n);
     p.pair_caps.assign(n, {});
+    p.counted.assign(n, false);
     for (size_t i = 0; i < n; ++i) {
         if ((st = gsx_shard_slot_records(c.l, p.order[i].c_str(), c.world, p.shard_max[i], &p.slot[i]))) return st;
         plan_pair_slots(c, i);

@@ -181,9 +181,11 @@ struct Model {
     std::vector<uint32_t> pair_counts;         // owner's model: records rank s wanted to send to rank d in round 0 of the model's last frame
                                                // whose verdict was read ([s * world + d]; empty: unknown) — next frame's slots, pair by pair
     bool pair_limited = false;                 // ... and whether that frame's exchange was limited by windows
+    std::vector<uint32_t> pair_edges;          // ... and the band edges it ran with
     uint32_t slot_force = 0;                   // gsx_shard_set_slot_records: round-0 slot size instead of the policy's (0 = policy)
     uint32_t slot_hint = 0;                    // records the busiest (rank, destination) pair wanted in round 0 of the last frame: a GLOBAL
                                                // figure from that frame's verdict, so every rank sizes the next slots identically; 0 = unknown
+    bool slot_hint_limited = false;            // ... of a frame whose exchange was limited by windows
     DevBuf adm_ballots2;           // the repair round's ballots (the first round's stay: they say which records are shaded)
     bool lazy = false;             // this frame's projection shaded only the admitted Gaussians
     // k_edit_prepare is a function of (selection, stored edits, mask, the viewer's selection edit) and idempotent: it runs again
@@ -288,6 +290,7 @@ struct ShardPending {
     bool repaired = false;                    // some model needed its repair exchange
     std::vector<uint32_t> edges;              // the frame's band layout (world + 1 tile rows; empty: equal bands)
     std::vector<std::vector<uint32_t>> pair_caps;  // per model: round-0 slot sizes pair by pair ([s * world + d]; empty: uniform `slot`)
+    std::vector<bool> counted;                // per model: its round 0 of THIS frame has been counted (its verdict read: Model::pair_counts)
 };
 
 struct gsx_viewer {

@@ -192,10 +192,9 @@ __global__ __launch_bounds__(128) void k_composite(const FrameConsts f, uint2* _
     if (in0) fb[fbo] = make_float4(C0.x, C1.x, C2.x, T.x);
     if (in1) fb[fbo + f.w_px] = make_float4(C0.y, C1.y, C2.y, T.y);
     if (clear_ranges && tid == 0 && had_entries) ranges[tile] = make_uint2(0u, 0u);
-    // multi-GPU: what this tile cost — the list entries it walked, the length of its list (an entry costs its share of the depth sort,
-    // the binning and the list sort before any tile walks it: together about what the compositor costs) and a constant for the tile
-    // itself; the next frame's bands are balanced by the rows' sums (gsx_shard_frame.cpp, k_shard_verify)
-    if (row_work && tid == 0) atomicAdd(&row_work[ty], kTileWork + (min(base, range.y) - range.x) + (range.y - range.x));
+    // multi-GPU: what this tile cost (tile_work, gsx_internal.h: here every entry walked is blended); the next frame's bands are
+    // balanced by the rows' sums (gsx_shard_frame.cpp, k_shard_verify)
+    if (row_work && tid == 0) atomicAdd(&row_work[ty], tile_work(min(base, range.y) - range.x, min(base, range.y) - range.x, range.y - range.x, 1u));
     if (done_bits && __syncthreads_and((lim0 | lim1) == 0u)) {
         // the tile saturated in this launch: its last pixels stopped here, behind everything blended earlier
         if (tile_sat) {
@@ -293,7 +292,7 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
     const unsigned long long lt = (1ull << lane) - 1ull;
     // iteration i: write the takers gathered in iteration i - 1 to LDS, filter chunk i and start its gathers, prefetch the
     // candidates of chunk i + 1, blend; one more iteration drains the pipeline
-    uint32_t base = range.x;
+    uint32_t base = range.x, taken = 0;
     for (; base < range.y + kChunk; base += kChunk) {
         if (lane == 0) {
 #pragma unroll
@@ -340,11 +339,13 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
             ent_ok[k] = nn < range.y;
             if (ent_ok[k]) ent[k] = list[nn];
         }
+        taken += cnt;
         if (cnt) blend_batch<MODE, kGroupBlocks>(f, cnt, s_mean, s_conic, s_rgb, pxf, pyf, lim0, lim1, T, C0, C1, C2, stop_key);
     }
     if (in0) fb[fbo] = make_float4(C0.x, C1.x, C2.x, T.x);
     if (in1) fb[fbo + f.w_px] = make_float4(C0.y, C1.y, C2.y, T.y);
-    if (row_work && tid == 0) atomicAdd(&row_work[ty], kTileWork + (min(base, range.y) - range.x) + (range.y - range.x));  // (as k_composite)
+    if (row_work && tid == 0)  // (as k_composite; a block's list is shared by its tiles)
+        atomicAdd(&row_work[ty], tile_work(min(base, range.y) - range.x, taken, range.y - range.x, 1u << (bsx + bsy)));
     if (done_bits && __syncthreads_and((lim0 | lim1) == 0u)) {
         if (tile_sat) {
             if (stop_key) atomicMax(&s_sat, stop_key);

@@ -447,16 +447,20 @@ __global__ __launch_bounds__(256) void k_project(const FrameConsts f, const uint
     }
 }
 
-// Geometry-only projection (the lazy variant of k_project: same values, same outputs), written so that a lane can carry
-// PER Gaussians, 256 apart, with all loads of a stage issued before any is consumed.  Measured on cfg4 (10 M): PER = 1
-// 118-120 us, 2: 122, 4: 127 — the pass is not waiting on its chain of dependent loads (position -> covariance ->
-// pyramid cells), it moves 600 MB at ~5.1 TB/s, which is what a plain streaming copy reaches on this part; PER stays 1.
-// What the straight-line form (no branch around the covariance loads: culled lanes read element 0) buys over the
-// geometry-only instantiation k_project used to have is ~5 %.  (A fixed grid striding over the groups instead of one workgroup per group — an empty
-// 39 K-workgroup launch costs 9 us of dispatch — was slower: 131-166 us at 2048-16384 workgroups; the dispatcher streams
-// workgroups better than a loop with a barrier per group.)  A workgroup covers PER consecutive 256-Gaussian groups and writes their
-// ballots / counts exactly where PER workgroups of k_project would.
-constexpr int kProjGeomPer = 1;  // Gaussians per lane of the geometry-only kernel (2 and 4 measured: no gain)
+// Geometry-only projection (the lazy variant of k_project: same values, same outputs).  A lane carries PER Gaussians, 256 apart,
+// and every load of a stage is issued before any is consumed; the covariance loads do not wait for the cull (a culled lane
+// reads its own element: the lines are fetched for its neighbours anyway), key and rectangle are stored before the admission
+// test's pyramid cells are waited for.  Round 4, A/B on one box (tools/ab.sh, profiles/r04_ab_geom.txt), cfg4: PER = 1 with
+// covariance loads behind the cull 100.0 us; loads ahead of the cull 100.5; + early stores 102; PER = 2: 95.1 / 94.2 / 92.9;
+// PER = 4: 101.  The pass moves 480 MB in 93 us (5.2 TB/s) and is NOT waiting for memory: by the ISA a wave of 64 Gaussians
+// issues 362 vector and 206 scalar instructions (the 3x3 products, J W S W^T J^T, three correctly rounded divisions, the tile
+// rectangle: the spec's operation order, -ffp-contract=off) = 1450 cycles of its SIMD; 152 waves per SIMD at 10 M Gaussians are
+// 220 k cycles = 91 us at 2.4 GHz.  The kernel sits on its vector issue rate; HBM would allow ~66 us (tools/bench_hbm).
+// (A fixed grid striding over the groups instead of one workgroup per group — an empty 39 K-workgroup launch costs 9 us of
+// dispatch — was slower: 131-166 us at 2048-16384 workgroups; the dispatcher streams workgroups better than a loop with a
+// barrier per group.)  A workgroup covers PER consecutive 256-Gaussian groups and writes their ballots / counts exactly where
+// PER workgroups of k_project would.
+constexpr int kProjGeomPer = 2;  // Gaussians per lane of the geometry-only kernel
 // QUERY: also answer adm.query (rect / brush / texture) from the projected centre: the flag words k_query would write
 template <int COVK, int PER, bool QUERY>
 __global__ __launch_bounds__(256) void k_project_geom(const FrameConsts f, const uint32_t n, const PodPlanes pod,
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(256) void k_project_geom(const FrameConsts f, const
     float cv[PER][6];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const uint32_t i = vis[k] ? base + 256u * k : 0u;
+        const uint32_t i = min(base + 256u * k, n - 1u);   // its own element whatever the cull says: the address does not wait for the position
         if (COVK == GSX_COV3D_SINGLE) {
             const float4 a = ld_stream(&pod.cov_a[i]);
             const float2 b = ld_stream(&pod.cov_b[i]);
@@ -501,6 +505,19 @@ __global__ __launch_bounds__(256) void k_project_geom(const FrameConsts f, const
         sp[k] = Splat2D{};
         if (vis[k]) vis[k] = pm_cov2d_rect(f, vc[k], cv[k][0], cv[k][1], cv[k][2], cv[k][3], cv[k][4], cv[k][5], sp[k]);
         if (vis[k] && ((sp[k].ry >> 16) <= f.band_lo || (sp[k].ry & 0xFFFFu) >= f.band_hi)) vis[k] = false;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {  // key and rectangle leave before the admission test's loads are waited for
+        const uint32_t i = base + 256u * k;
+        if (i < n) {
+            st_stream(&rec.key[i], vis[k] ? __float_as_uint(vc[k].d) : kCulledKey);
+            if (rec.rect8) {
+                const uint32_t rx = sp[k].rx, ry = sp[k].ry;
+                st_stream(&rec.rect8[i], vis[k] ? ((rx & 0xFFu) | ((ry & 0xFFu) << 8) | ((rx >> 16) << 16) | ((ry >> 16) << 24)) : 0u);
+            } else {
+                st_stream(&rec.a[i], make_float4(sp[k].mx, sp[k].my, __uint_as_float(sp[k].rx), __uint_as_float(sp[k].ry)));
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
@@ -533,16 +550,6 @@ __global__ __launch_bounds__(256) void k_project_geom(const FrameConsts f, const
     __shared__ uint32_t wave_cnt[PER][4], wave_adm[PER][4];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const uint32_t i = base + 256u * k;
-        if (i < n) {
-            st_stream(&rec.key[i], vis[k] ? __float_as_uint(vc[k].d) : kCulledKey);
-            if (rec.rect8) {  // four bytes instead of sixteen: k_shade writes the `a` record of the Gaussians it visits
-                const uint32_t rx = sp[k].rx, ry = sp[k].ry;
-                st_stream(&rec.rect8[i], vis[k] ? ((rx & 0xFFu) | ((ry & 0xFFu) << 8) | ((rx >> 16) << 16) | ((ry >> 16) << 24)) : 0u);
-            } else {
-                st_stream(&rec.a[i], make_float4(sp[k].mx, sp[k].my, __uint_as_float(sp[k].rx), __uint_as_float(sp[k].ry)));
-            }
-        }
         const unsigned long long bal = __ballot(vis[k]);
         const unsigned long long bal_adm = __ballot(take[k]);
         if ((threadIdx.x & 63u) == 0) {

@@ -417,25 +417,46 @@ __global__ __launch_bounds__(256) void k_shard_verify(const uint32_t* __restrict
                 hv[7] = all ? (uint32_t)(busiest * world * 1000ull / all) : 1000u;
             }
             // next frame's bands: contiguous runs of tile rows of (as nearly as rows allow) equal work.  A row weighs what its tiles
-            // walked this frame plus kTileWork per tile (a tile that blends nothing still reads and writes its pixels).
+            // cost this frame (tile_work, gsx_internal.h) plus kTileWork for every tile (the ones that were not composited at all).
             const uint32_t tiles_y = n_tiles / tiles_x;
-            if (balance) {
+            // Hysteresis: an edge that moves shifts what every pair exchanges (the slots sized pair by pair from this frame's counts
+            // would overflow for nothing), and bands a few rows tall cannot be tuned finer than a row.  New edges are adopted only
+            // when the busiest rank carries more than kBalanceKeep x the mean AND they would have shared THIS frame's work at
+            // least a tenth better.
+            uint32_t* ne = hv + kVerdictEdges;
+            bool adopt = false;
+            if (balance && hv[7] > kBalanceKeepPermille) {
                 unsigned long long W = 0;
-                for (uint32_t ty = 0; ty < tiles_y; ++ty) W += (unsigned long long)work_at(sat, ty, tiles_x, bands, stride) + kTileWork * tiles_x;
-                unsigned long long acc = 0;
+                for (uint32_t ty = 0; ty < tiles_y; ++ty) W += (unsigned long long)work_at(sat, ty, tiles_x, bands, stride) + (unsigned long long)kTileWork * tiles_x;
+                unsigned long long acc = 0, band_w = 0, worst = 0;
                 uint32_t g = 1;
-                hv[kVerdictEdges] = 0u;
+                ne[0] = 0u;
                 for (uint32_t ty = 0; ty < tiles_y; ++ty) {
-                    const unsigned long long w = (unsigned long long)work_at(sat, ty, tiles_x, bands, stride) + kTileWork * tiles_x;
+                    const unsigned long long w = (unsigned long long)work_at(sat, ty, tiles_x, bands, stride) + (unsigned long long)kTileWork * tiles_x;
                     // edge g goes in front of row ty if that is at least as close to g / world of the work as behind it
-                    while (g < world && (acc * world >= g * W || 2ull * (g * W - acc * world) <= w * world)) hv[kVerdictEdges + g++] = ty;
+                    while (g < world && (acc * world >= g * W || 2ull * (g * W - acc * world) <= w * world)) {
+                        ne[g++] = ty;
+                        worst = band_w > worst ? band_w : worst;
+                        band_w = 0;
+                    }
                     acc += w;
+                    band_w += w;
                 }
-                while (g < world) hv[kVerdictEdges + g++] = tiles_y;
-                hv[kVerdictEdges + world] = tiles_y;
-            } else {
-                for (uint32_t g = 0; g <= world; ++g) hv[kVerdictEdges + g] = bands.e[g];
+                worst = band_w > worst ? band_w : worst;
+                while (g < world) ne[g++] = tiles_y;
+                ne[world] = tiles_y;
+                // the same measure for the bands in force (rows' weights as above)
+                unsigned long long cur_worst = 0;
+                for (uint32_t gg = 0; gg < world; ++gg) {
+                    unsigned long long wg = 0;
+                    for (uint32_t ty = bands.e[gg]; ty < bands.e[gg + 1u] && ty < tiles_y; ++ty)
+                        wg += (unsigned long long)work_at(sat, ty, tiles_x, bands, stride) + (unsigned long long)kTileWork * tiles_x;
+                    cur_worst = wg > cur_worst ? wg : cur_worst;
+                }
+                adopt = worst * 10ull <= cur_worst * 9ull;
             }
+            if (!adopt)
+                for (uint32_t g = 0; g <= world; ++g) ne[g] = bands.e[g];
             __hip_atomic_store(host_verdict + 1, ((unsigned long long)gmax << 32) | (over ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(host_verdict, ((unsigned long long)seq << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             *ticket = 0;

@@ -51,11 +51,72 @@ def gaussians_from_ply(ply: np.ndarray) -> np.ndarray:
     return g
 
 
-def _ply_block(n: int, seed: int, sh_degree: int, b: int, centres: np.ndarray, block: int) -> np.ndarray:
+#: scene variants (``synthetic_ply(variant=...)``).  "default" is the benchmark generator of BASELINE.md §3.  The other two exist to
+#: put the temporal occlusion speculation where it does NOT shine (bench.py ``robustness``, tests/test_gpu_speculation.py):
+#:   "translucent"  the default scene with the opacity logits drawn from N(-5.5, 1.5) instead of N(0.5, 1.5): median opacity 0.004,
+#:                  next to no tile of a 1080p frame ever saturates — nothing to speculate on, the viewer must notice and stop trying
+#:   "surfaces"     a captured-scene stand-in (the INRIA garden PLY is not in the image): Gaussians ON a handful of large surfaces —
+#:                  six planes through the cube and four spheres — flattened along the surface normal, log-scales N(-3, 1.2)
+#:                  clamped to [-7, 1] (a heavy tail: a few splats are metres wide and cover hundreds of tiles), opacity logits
+#:                  N(2, 1.5) (surfaces are mostly opaque); list entries per visible Gaussian are ~10x the default scene's
+VARIANTS = ("default", "translucent", "surfaces")
+
+
+def _surface_points(rng, m: int, seed: int):
+    """positions on six planes / four spheres (which ones: a function of `seed` alone) + the surface normal at each"""
+    geo = np.random.Generator(np.random.PCG64(np.random.SeedSequence([seed, 0x5AFE])))
+    normals = geo.standard_normal((6, 3)).astype(np.float32)
+    normals /= np.linalg.norm(normals, axis=1, keepdims=True)
+    offsets = geo.uniform(-2.5, 2.5, 6).astype(np.float32)
+    centres = geo.uniform(-2.5, 2.5, (4, 3)).astype(np.float32)
+    radii = geo.uniform(0.6, 1.6, 4).astype(np.float32)
+    which = rng.integers(0, 10, size=m)
+    pos = np.zeros((m, 3), np.float32)
+    nrm = np.zeros((m, 3), np.float32)
+    p = rng.uniform(-4.0, 4.0, size=(m, 3)).astype(np.float32)
+    d = rng.standard_normal((m, 3), dtype=np.float32)
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), np.float32(1e-6))
+    for k in range(6):
+        sel = which == k
+        nk = normals[k]
+        pos[sel] = p[sel] - ((p[sel] @ nk) - offsets[k])[:, None] * nk   # projected onto the plane n.x = offset
+        nrm[sel] = nk
+    for k in range(4):
+        sel = which == 6 + k
+        pos[sel] = centres[k] + radii[k] * d[sel]
+        nrm[sel] = d[sel]
+    return pos, nrm
+
+
+def _quat_z_to(nrm: np.ndarray) -> np.ndarray:
+    """w, x, y, z (the PLY's order) of the shortest rotation that takes +z to `nrm`"""
+    z = np.array([0.0, 0.0, 1.0], np.float32)
+    w = np.float32(1.0) + nrm @ z
+    xyz = np.cross(np.broadcast_to(z, nrm.shape), nrm).astype(np.float32)
+    flip = w < 1e-6                                   # opposite: any axis perpendicular to z
+    xyz[flip] = np.array([1.0, 0.0, 0.0], np.float32)
+    w = np.where(flip, np.float32(0.0), w)
+    q = np.concatenate([w[:, None], xyz], axis=1).astype(np.float32)
+    return q / np.linalg.norm(q, axis=1, keepdims=True)
+
+
+def _ply_block(n: int, seed: int, sh_degree: int, b: int, centres: np.ndarray, block: int, variant: str = "default") -> np.ndarray:
     lo, hi = b * block, min((b + 1) * block, n)
     m = hi - lo
     rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([seed, b + 1])))
     v = np.zeros(m, dtype=PLY_DTYPE)
+    if variant == "surfaces":
+        pos, nrm = _surface_points(rng, m, seed)
+        v["pos"] = pos + np.float32(0.01) * rng.standard_normal((m, 3), dtype=np.float32)
+        ls = np.clip(np.float32(-3.0) + np.float32(1.2) * rng.standard_normal((m, 3), dtype=np.float32), -7.0, 1.0)
+        ls[:, 2] = np.minimum(ls[:, 2], np.float32(-5.0))         # thin along the normal
+        v["scale"] = ls
+        v["rot"] = _quat_z_to(nrm)
+        v["opacity"] = np.float32(2.0) + np.float32(1.5) * rng.standard_normal(m, dtype=np.float32)
+        v["f_dc"] = rng.standard_normal((m, 3), dtype=np.float32)
+        if sh_degree > 0:
+            v["f_rest"] = np.float32(0.15) * rng.standard_normal((m, 45), dtype=np.float32)
+        return v
     uniform = rng.uniform(-4.0, 4.0, size=(m, 3)).astype(np.float32)
     which = rng.integers(0, 64, size=m)
     clustered = centres[which] + np.float32(0.25) * rng.standard_normal((m, 3), dtype=np.float32)
@@ -63,7 +124,7 @@ def _ply_block(n: int, seed: int, sh_degree: int, b: int, centres: np.ndarray, b
     v["pos"] = np.where(in_cluster[:, None], clustered, uniform)
     v["scale"] = np.clip(np.float32(-4.0) + np.float32(0.7) * rng.standard_normal((m, 3), dtype=np.float32), -7.0, -1.0)
     v["rot"] = rng.standard_normal((m, 4), dtype=np.float32)
-    v["opacity"] = np.float32(0.5) + np.float32(1.5) * rng.standard_normal(m, dtype=np.float32)
+    v["opacity"] = np.float32(-5.5 if variant == "translucent" else 0.5) + np.float32(1.5) * rng.standard_normal(m, dtype=np.float32)
     v["f_dc"] = rng.standard_normal((m, 3), dtype=np.float32)
     if sh_degree > 0:
         v["f_rest"] = np.float32(0.15) * rng.standard_normal((m, 45), dtype=np.float32)
@@ -71,7 +132,7 @@ def _ply_block(n: int, seed: int, sh_degree: int, b: int, centres: np.ndarray, b
 
 
 def synthetic_ply(n: int, seed: int, sh_degree: int = 3, start: int = 0, count: int | None = None,
-                  workers: int | None = None) -> np.ndarray:
+                  workers: int | None = None, variant: str = "default") -> np.ndarray:
     """PLY-domain synthetic scene.  ``start``/``count`` select a contiguous shard of the
     same scene: the scene is defined in fixed blocks of 65536 Gaussians, block b drawn from
     ``PCG64(SeedSequence([seed, b + 1]))`` and the 64 cluster centres from ``PCG64(seed)``, so a shard
@@ -79,6 +140,8 @@ def synthetic_ply(n: int, seed: int, sh_degree: int = 3, start: int = 0, count: 
     import os
     from concurrent.futures import ThreadPoolExecutor
 
+    if variant not in VARIANTS:
+        raise ValueError(f"variant {variant!r}: one of {VARIANTS}")
     if count is None:
         count = n - start
     block = 65536
@@ -89,7 +152,7 @@ def synthetic_ply(n: int, seed: int, sh_degree: int = 3, start: int = 0, count: 
     b0, b1 = start // block, (start + count + block - 1) // block
 
     def work(b):
-        v = _ply_block(n, seed, sh_degree, b, centres, block)
+        v = _ply_block(n, seed, sh_degree, b, centres, block, variant)
         lo, hi = b * block, min((b + 1) * block, n)
         s, e = max(lo, start), min(hi, start + count)
         out[s - start : e - start] = v[s - lo : e - lo]
@@ -104,9 +167,10 @@ def synthetic_ply(n: int, seed: int, sh_degree: int = 3, start: int = 0, count: 
     return out
 
 
-def synthetic_gaussians(n: int, seed: int, sh_degree: int = 3, start: int = 0, count: int | None = None) -> np.ndarray:
+def synthetic_gaussians(n: int, seed: int, sh_degree: int = 3, start: int = 0, count: int | None = None,
+                        variant: str = "default") -> np.ndarray:
     """Render-ready ``gs::Gaussian`` array of the synthetic scene (or of the shard [start, start+count))."""
-    return gaussians_from_ply(synthetic_ply(n, seed, sh_degree, start, count))
+    return gaussians_from_ply(synthetic_ply(n, seed, sh_degree, start, count, variant=variant))
 
 
 #: benchmark configs of BASELINE.json / BASELINE.md §3: name -> (N, sh_degree, width, height, seed)
