@@ -587,7 +587,7 @@ def main():
             """the same loops on ANOTHER resident scene of the same size (scene.VARIANTS), uploaded in place of the benchmark scene; a long
             warm-up: the viewer needs ~50 frames to time both schedules and settle on the faster one (SpecTuner, gsx_frame.cpp)"""
             g2 = scene.synthetic_gaussians(n, seed, sh, 0, n, variant=variant)
-            renderer.load_shard(g2, 0, n)
+            viewer.models[renderer.KEY].gaussian_buffers.gaussians_buffer.update_range(0, g2)   # (gsx_model_upload_range: in place)
             renderer.poll()
             del g2
             saved_w, args.warmup = args.warmup, max(args.warmup, 100)

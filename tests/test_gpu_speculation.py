@@ -329,7 +329,8 @@ def test_full_size_bit_identity_on_scenes_the_speculation_does_not_like(variant)
         tiles = (big[:, 2].astype(np.int64) - big[:, 0]) * (big[:, 3].astype(np.int64) - big[:, 1])   # rect = x0, y0, x1, y1 in tiles
         assert (tiles > 500).sum() > 100, "some splats must cover more than 500 tiles"
     else:
-        assert (a[..., 3] < 1e-4).mean() < 0.01, "the translucent scene must saturate next to nothing (a dense cluster on a ray may)"
+        # (median opacity 0.004: only rays through the dense clusters pile up enough to saturate)
+        assert (a[..., 3] < 1e-4).mean() < 0.25, f"the translucent scene saturates {100 * (a[..., 3] < 1e-4).mean():.1f} % of the pixels"
     for v in (spec, plain, flat):
         v.close()
 
