@@ -724,6 +724,11 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
         // a slab of S splats can produce at most S * n_tiles entries; size the sort launch by the smaller bound
         const uint32_t slab_cap = (uint32_t)std::min<uint64_t>(cap, (uint64_t)(j1 - j0) * std::min<uint64_t>(owned_tiles, 1u << 16));
         if (blocks) {
+            // (the block sort's one-digit histogram — entries per block — counted by the emit kernel on its way instead of by a launch of
+            //  its own was measured, round 4: two launches less per frame, and slower — every emit workgroup flushes up to 256 bins to
+            //  the same 256 addresses: binning 69 -> 86 us against block sort 37 -> 25 on a speculated cfg4 frame, 218 -> 327 against
+            //  69 -> 45 unspeculated.  Not kept.)
+            const int block_bits = (int)std::max<uint32_t>(1u, ceil_log2(v->blocks_max));
             {
                 ScopedPass t(v, GSX_PASS_BIN);
                 HIPCHK(launch_block_bin(v->stream, j0, j1, d_n, m->sorted_idx, m->rec(), m->sk_out.as<uint32_t>(), m->srect.as<uint4>(),
@@ -741,7 +746,6 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
                 const uint32_t block_cap = (uint32_t)std::min<uint64_t>(cap, (uint64_t)(j1 - j0) * 256u);
                 // (<= 256 blocks: ONE digit, and the block ranges are the scan of its histogram — no k_tile_ranges launch;
                 //  k_block_table zeroed the ranges, which is what stays when the slab made no entry at all)
-                const int block_bits = (int)std::max<uint32_t>(1u, ceil_log2(v->blocks_max));
                 HIPCHK(launch_radix_sort(v->stream, rb, block_cap, &dc->n_entries, block_bits, false, false, block_bits <= 8 ? m->ranges.as<uint2>() : nullptr));
                 m->tile_keys = m->tk_out.as<uint32_t>();
                 m->tile_list = m->tv_out.as<uint32_t>();
@@ -799,18 +803,22 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
         {
             ScopedPass t(v, GSX_PASS_COMPOSITE);
             if (blocks) {
+                // (a slab whose entries did not fit the pair buffers — decided on the device — has its tail composited pair-free by the
+                //  same launch: the frame is complete without a host round trip)
                 HIPCHK(launch_composite_blocks(v->stream, m->fc, m->ranges.as<uint2>(), m->tile_list, m->srect.as<uint4>(), m->rec(), fb_ptr(v),
-                                               later, done, row_words, done_count, tile_sat, win, row_lo, row_hi, bsx, bsy, row_work));
+                                               later, done, row_words, done_count, tile_sat, win, row_lo, row_hi, bsx, bsy, row_work, dc, j1,
+                                               d_n, m->sorted_idx, m->sk_out.as<uint32_t>()));
             } else {
                 HIPCHK(launch_composite(v->stream, m->fc, m->ranges.as<uint2>(), m->tile_list, m->rec(), fb_ptr(v),
                                         later, done, row_words, done_count, clear_ranges, tile_sat, row_work));
                 m->ranges_clean = clear_ranges;  // the compositor zeroed every range it consumed
             }
             v->pass_launches[GSX_PASS_COMPOSITE] += 1;
-            // the slab's entries did not fit the pair buffers (decided on the device): its tail is composited pair-free, so
-            // the frame is complete without a host round trip; otherwise this launch falls through
-            HIPCHK(launch_composite_spill(v->stream, m->fc, dc, j1, d_n, m->sorted_idx, m->sk_out.as<uint32_t>(), m->rec(), fb_ptr(v),
-                                          done, row_words, done_count, tile_sat, row_lo, row_hi, win));
+            // per-tile lists: the slab's entries did not fit the pair buffers (decided on the device): its tail is composited
+            // pair-free, so the frame is complete without a host round trip; otherwise this launch falls through
+            if (!blocks)
+                HIPCHK(launch_composite_spill(v->stream, m->fc, dc, j1, d_n, m->sorted_idx, m->sk_out.as<uint32_t>(), m->rec(), fb_ptr(v),
+                                              done, row_words, done_count, tile_sat, row_lo, row_hi, win));
         }
         return GSX_OK;
     };

@@ -64,21 +64,42 @@ __global__ __launch_bounds__(kAdmitThreads) void k_admit_count(const uint32_t* _
     if (tid == 0) counts[blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
 }
 
-// counts were scanned exclusively in place; pairs[offset ..] = (key, index) of the admitted records of the workgroup
+// pairs[offset ..] = (key, index) of the admitted records of the workgroup.  offsets: the per-workgroup counts scanned exclusively
+// (d_total == nullptr), or — d_total != nullptr — the RAW counts: every workgroup sums the counts in front of it itself (a few
+// thousand L2-resident words at most) and the last one writes the total: the single-workgroup scan in between was a launch of
+// its own on the critical path of every speculated frame's repair round.
 __global__ __launch_bounds__(kAdmitThreads) void k_admit_scatter(const uint32_t* __restrict__ key, uint32_t n,
                                                                   const unsigned long long* __restrict__ ballots,
                                                                   const uint32_t* __restrict__ offsets,
-                                                                  uint2* __restrict__ pairs, const uint32_t* __restrict__ d_skip) {
+                                                                  uint2* __restrict__ pairs, const uint32_t* __restrict__ d_skip,
+                                                                  uint32_t* __restrict__ d_total) {
     __shared__ uint32_t wcnt[kAdmitThreads / 64];
-    if (d_skip && *d_skip == 0) return;  // nothing was admitted and no ballot was written (k_admit_count)
+    __shared__ uint32_t wpre[kAdmitThreads / 64];
+    if (d_skip && *d_skip == 0) {  // nothing was admitted and no ballot was written (k_admit_count)
+        if (d_total && blockIdx.x == gridDim.x - 1u && threadIdx.x == 0) *d_total = 0u;
+        return;
+    }
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    uint32_t before = 0;
+    if (d_total) {
+        uint32_t x = 0;
+        for (uint32_t i = tid; i < blockIdx.x; i += kAdmitThreads) x += offsets[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+        if (lane == 0) wpre[wave] = x;
+        __syncthreads();
+        for (uint32_t w = 0; w < kAdmitThreads / 64; ++w) before += wpre[w];
+        if (blockIdx.x == gridDim.x - 1u && tid == 0) *d_total = before + offsets[blockIdx.x];
+    } else {
+        before = offsets[blockIdx.x];
+    }
     const uint32_t base = blockIdx.x * kAdmitTile + wave * kAdmitWaveChunk;
     uint32_t c = 0;
     for (int r = 0; r < kAdmitRounds; ++r)
         if (base + r * 64 < n) c += (uint32_t)__popcll(ballots[(base + r * 64) >> 6]);
     if (lane == 0) wcnt[wave] = c;
     __syncthreads();
-    uint32_t o = offsets[blockIdx.x];
+    uint32_t o = before;
     for (uint32_t w = 0; w < wave; ++w) o += wcnt[w];
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (int r = 0; r < kAdmitRounds; ++r) {
@@ -236,7 +257,7 @@ hipError_t launch_admit_from_project(hipStream_t s, const uint32_t* key, uint32_
 hipError_t launch_admit_scatter(hipStream_t s, const uint32_t* key, uint32_t n, const unsigned long long* ballots,
                                 const uint32_t* offsets, uint2* pairs) {
     const uint32_t nb = (uint32_t)admit_blocks(n);
-    if (nb) GSX_LAUNCH(k_admit_scatter, dim3(nb), dim3(kAdmitThreads), 0, s, key, n, ballots, offsets, pairs, nullptr);
+    if (nb) GSX_LAUNCH(k_admit_scatter, dim3(nb), dim3(kAdmitThreads), 0, s, key, n, ballots, offsets, pairs, nullptr, nullptr);
     return hipGetLastError();
 }
 
@@ -245,9 +266,7 @@ hipError_t launch_admit(hipStream_t s, const Records& rec, uint32_t n, const uin
     const uint32_t nb = (uint32_t)admit_blocks(n);
     if (!nb) return gsx::op::MemsetAsync(d_total, 0, 4, s);
     GSX_LAUNCH(k_admit_count, dim3(nb), dim3(kAdmitThreads), 0, s, rec.key, rec.a, n, window, tiles_x, gate, row_words, pyramid, d_skip, ballots, counts, rec.rect8);
-    hipError_t e = launch_rowscan(s, counts, 1, nb, d_total, nullptr, 1, d_skip);
-    if (e != hipSuccess) return e;
-    GSX_LAUNCH(k_admit_scatter, dim3(nb), dim3(kAdmitThreads), 0, s, rec.key, n, ballots, counts, pairs, d_skip);
+    GSX_LAUNCH(k_admit_scatter, dim3(nb), dim3(kAdmitThreads), 0, s, rec.key, n, ballots, counts, pairs, d_skip, d_total);  // (scans the raw counts itself)
     return hipGetLastError();
 }
 

@@ -227,7 +227,10 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
                                                            const uint32_t row_words, uint32_t* __restrict__ done_count,
                                                            uint32_t* __restrict__ tile_sat, const uint2* __restrict__ window,
                                                            const uint32_t row_lo, const uint32_t row_hi, const uint32_t bsx,
-                                                           const uint32_t bsy, const uint32_t blocks_x, uint32_t* __restrict__ row_work) {
+                                                           const uint32_t bsy, const uint32_t blocks_x, uint32_t* __restrict__ row_work,
+                                                           const SlabStats* __restrict__ stats, const uint32_t j1,
+                                                           const uint32_t* __restrict__ d_n, const uint32_t* __restrict__ sorted_idx,
+                                                           const uint32_t* __restrict__ sorted_keys) {
     __shared__ float2 s_mean[kChunk + kGroupBlocks];
     __shared__ float4 s_conic[kChunk + kGroupBlocks];
     __shared__ float4 s_rgb[kChunk + kGroupBlocks];
@@ -243,8 +246,18 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
     const size_t fbo = (size_t)py * f.w_px + px;
     uint2 range = ranges[(ty >> bsy) * blocks_x + (tx >> bsx)];
     const uint2 win = window ? window[tile] : make_uint2(0u, 0xFFFFFFFFu);
-    if (ty < row_lo || ty >= row_hi || win.x >= win.y) range = make_uint2(0u, 0u);  // not this rank's tile / takes nothing
-    if (carry && (range.x >= range.y || (done_bits && ((done_bits[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)))) return;
+    const bool owned = ty >= row_lo && ty < row_hi;
+    if (!owned || win.x >= win.y) range = make_uint2(0u, 0u);  // not this rank's tile / takes nothing
+    // The slab's entries did not fit the pair buffers (k_scan_block_sums cut it: rare, the host grows the buffers when it learns of
+    // it): the splats [cut, end) of the depth order never reached the lists.  The tile composites them itself, BEHIND its list,
+    // pair-free — it scans them 128 at a time and keeps those whose rectangle and window take it; the per-pixel operation sequence
+    // is that of a frame with larger buffers.  (Until round 4 a launch of its own behind every compositor launch: k_composite_spill,
+    // which the per-tile-list compositor still uses.)
+    const uint32_t spill_end = stats ? min(j1, *d_n) : 0u, spill_cut = stats ? stats->slab_cut : 0u;
+    const bool tile_done = done_bits && ((done_bits[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u);
+    const bool spill = spill_cut < spill_end && owned && !tile_done;
+    if (carry && (range.x >= range.y || tile_done) && !spill) return;
+    if (tile_done) range = make_uint2(0u, 0u);
     v2f T = splat2(1.0f), C0 = splat2(0.0f), C1 = C0, C2 = C0;
     if (carry) {
         if (in0) {
@@ -341,6 +354,43 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
         }
         taken += cnt;
         if (cnt) blend_batch<MODE, kGroupBlocks>(f, cnt, s_mean, s_conic, s_rgb, pxf, pyf, lim0, lim1, T, C0, C1, C2, stop_key);
+    }
+    if (spill) {
+        for (uint32_t sb = spill_cut; sb < spill_end; sb += 128u) {
+            if (__syncthreads_and((lim0 | lim1) == 0u)) break;  // (also protects the LDS batch of the previous iteration)
+            const uint32_t j = sb + tid;
+            bool hit = false;
+            uint32_t idx = 0;
+            float4 a = make_float4(0, 0, 0, 0);
+            if (j < spill_end) {
+                idx = sorted_idx[j];
+                a = rec_a[idx];
+                const uint32_t rx = __float_as_uint(a.z), ry = __float_as_uint(a.w);
+                hit = tx >= (rx & 0xFFFFu) && tx < (rx >> 16) && ty >= (ry & 0xFFFFu) && ty < (ry >> 16);
+                if (hit && window) {
+                    const uint32_t key = sorted_keys[j];
+                    hit = key >= win.x && key < win.y;
+                }
+            }
+            const unsigned long long bal = __ballot(hit);
+            if (lane == 0) s_w[wave][0] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            const uint32_t cnt = s_w[0][0] + s_w[1][0];
+            const uint32_t slot = (wave ? s_w[0][0] : 0u) + (uint32_t)__popcll(bal & lt);
+            if (hit) {
+                const float4 b = rec_b[idx];
+                s_mean[slot] = make_float2(a.x, a.y);
+                s_conic[slot] = make_float4(b.x, 2.0f * b.y, b.z, b.w);
+                s_rgb[slot] = rec_c[idx];
+            }
+            if (tid < (uint32_t)kGroupBlocks) {
+                s_mean[cnt + tid] = make_float2(3.0e38f, 3.0e38f);
+                s_conic[cnt + tid] = make_float4(1.0f, 0.0f, 1.0f, 0.0f);
+                s_rgb[cnt + tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            __syncthreads();
+            if (cnt) blend_batch<MODE, kGroupBlocks>(f, cnt, s_mean, s_conic, s_rgb, pxf, pyf, lim0, lim1, T, C0, C1, C2, stop_key);
+        }
     }
     if (in0) fb[fbo] = make_float4(C0.x, C1.x, C2.x, T.x);
     if (in1) fb[fbo + f.w_px] = make_float4(C0.y, C1.y, C2.y, T.y);
@@ -494,15 +544,16 @@ hipError_t launch_composite(hipStream_t s, const FrameConsts& f, uint2* ranges, 
 hipError_t launch_composite_blocks(hipStream_t s, const FrameConsts& f, const uint2* ranges, const uint32_t* list, const uint4* brec,
                                    const Records& rec, float4* fb, bool carry, uint32_t* done, uint32_t row_words,
                                    uint32_t* d_done_count, uint32_t* tile_sat, const uint2* window, uint32_t row_lo,
-                                   uint32_t row_hi, uint32_t bsx, uint32_t bsy, uint32_t* row_work) {
+                                   uint32_t row_hi, uint32_t bsx, uint32_t bsy, uint32_t* row_work, const SlabStats* stats, uint32_t j1,
+                                   const uint32_t* d_n, const uint32_t* sorted_idx, const uint32_t* sorted_keys) {
     dim3 grid(f.tiles_x * f.tiles_y), block(128);
     const uint32_t blocks_x = (f.tiles_x + (1u << bsx) - 1u) >> bsx;
     if (f.display_mode == GSX_DISPLAY_SPLAT)
         GSX_LAUNCH(k_composite_blocks<0>, grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
-                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work);
+                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work, stats, j1, d_n, sorted_idx, sorted_keys);
     else
         GSX_LAUNCH(k_composite_blocks<1>, grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
-                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work);
+                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work, stats, j1, d_n, sorted_idx, sorted_keys);
     return hipGetLastError();
 }
 
