@@ -501,32 +501,35 @@ def main():
             return round(1e6 * spent / 60.0, 1)
 
         set_opts()
+        viewer_mod.set_launch_graphs(True)
         viewer.launch_stats(reset=True)
         el_g, _, _ = timed_loop(0)
         graph_stats = viewer.launch_stats(reset=True)
         host_g = host_us_per_call()
-        viewer_mod.set_launch_graphs(False)
+        sync_g = host_sync_loop("frame")
+        sync_ref_g = host_sync_loop("reference")
+        set_opts(speculative=0)
+        el_ug, _, _ = timed_loop(0)
+        viewer_mod.set_launch_graphs(False)   # (the default)
+        el_ud, _, _ = timed_loop(0)
+        set_opts()
         el_d, _, _ = timed_loop(0)
         host_d = host_us_per_call()
-        sync_d = host_sync_loop("frame")
-        sync_ref_d = host_sync_loop("reference")
-        set_opts(speculative=0)
-        el_ud, _, _ = timed_loop(0)
-        viewer_mod.set_launch_graphs(True)
-        el_ug, _, _ = timed_loop(0)
-        set_opts()
         extra["launch_graphs"] = dict(
             one_frame_in_flight=dict(graphs=round(args.steps / el_g, 1), direct=round(args.steps / el_d, 1)),
-            synchronised=dict(graphs=round(args.steps / extra["sync_frame"], 1), direct=round(args.steps / sync_d, 1)),
-            reference_protocol=dict(graphs=round(args.steps / extra["sync_reference"], 1), direct=round(args.steps / sync_ref_d, 1)),
+            synchronised=dict(graphs=round(args.steps / sync_g, 1), direct=round(args.steps / extra["sync_frame"], 1)),
+            reference_protocol=dict(graphs=round(args.steps / sync_ref_g, 1), direct=round(args.steps / extra["sync_reference"], 1)),
             unspeculated=dict(graphs=round(args.steps / el_ug, 1), direct=round(args.steps / el_ud, 1)),
             host_us_inside_gsx_render_frame=dict(graphs=host_g, direct=host_d),
             stats_of_the_graph_loop={k: v for k, v in graph_stats.items()},
-            note="fps, one frame in flight, same process and scene; 'graphs' (default): while its stream is busy gsx_render_frame records its "
-                 "launches and submits them as cached HIP graphs whose nodes are patched to the frame's arguments — that saves HOST time "
-                 "(host_us_inside_gsx_render_frame); the device runs the same kernels at the same pace, and an entry point that finds its "
-                 "stream idle (the synchronised loops) submits launch by launch so that the first kernel starts at once; 'direct': "
-                 "gsx_debug_set_launch_graphs(0).  Same kernels, same arguments, same order: frames are bit-identical (tests/test_gpu_graph.py)")
+            note="fps, one frame in flight, same process and scene; 'direct' (the default): every launch submitted on its own; 'graphs' "
+                 "(gsx_debug_set_launch_graphs(1) / GSX_GRAPH=1): while its stream is busy gsx_render_frame records its launches and submits "
+                 "them as cached HIP graphs whose nodes are patched to the frame's arguments — that saves HOST time "
+                 "(host_us_inside_gsx_render_frame) and nothing on the device: a real kernel boundary costs the same inside a graph as on a "
+                 "stream (tools/bench_launch.hip's 3.3 -> 1.75 us is the command processor's rate for EMPTY kernels), and a frame that is one "
+                 "graph launch starts ~10 us later than one whose first kernel is already queued; an entry point that finds its stream "
+                 "idle (the synchronised loops) submits launch by launch in either mode.  Same kernels, same arguments, same order: "
+                 "frames are bit-identical (tests/test_gpu_graph.py)")
         # the headline schedule over a whole orbit (>= 240 frames): the tuner's probes and every part of the path are in it
         steady_frames = max(240, args.steps)
         set_opts(frames_in_flight=lanes)

@@ -583,8 +583,10 @@ void gsx_debug_set_radix_rank_mode(int32_t mode);
  *      and submits it once (scene.rs:856-873): same shape.  What a graph saves is HOST time (cfg4: 112 -> 37 us per frame); the
  *      device runs the same kernels at the same pace, and a graph only leaves when its last launch is recorded — so an entry point
  *      that finds its stream idle (a host that waits for every frame) submits launch by launch: the first kernel starts at once.
- *      enabled = 0: every launch is submitted at once; 1 (default, or GSX_GRAPH in the environment): as described; 2: record even
- *      when the stream is idle (tests).  Process-wide.  Either way the same kernels run with the same arguments in the same order:
+ *      And the device gains nothing (a real kernel boundary costs the same in a graph as on a stream; a frame that is one graph launch
+ *      starts a few microseconds later): 1607 vs 1633 frames/s on cfg4 with one frame in flight.  So the default is
+ *      enabled = 0: every launch is submitted at once; 1 (or GSX_GRAPH=1 in the environment): as described — for hosts whose time is what
+ *      counts; 2: record even when the stream is idle (tests).  Process-wide.  Either way the same kernels run with the same arguments in the same order:
  *      frames are bit-identical (tests/test_gpu_graph.py). ---- */
 void gsx_debug_set_launch_graphs(int32_t enabled);
 uint64_t gsx_debug_launch_count(void); /* kernel launches this process has asked for so far (recorded or submitted) */

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _graphs_back_on():
     yield
-    viewer_mod.set_launch_graphs(1)
+    viewer_mod.set_launch_graphs(0)
 
 
 def _load(v, key, g):

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collects the per-round evidence under gpurun_out/<round>/ on the GPU box (run through gpurun); copy the summaries into
-# profiles/ afterwards.  rocprofv3 wraps python3 directly (no env / bash hop).  usage: tools/collect_profiles.sh r03
+# profiles/ afterwards.  rocprofv3 wraps python3 directly (no env / bash hop).  usage: tools/collect_profiles.sh r04
 set -u
-R=${1:-r03}
+R=${1:-r04}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -40,4 +40,12 @@ tools/bench_sort 8460000 32 depth > $OUT/bench_sort.txt 2>&1
 tools/bench_sort 310000 32 depth >> $OUT/bench_sort.txt 2>&1
 tools/bench_sort 870000 8 >> $OUT/bench_sort.txt 2>&1
 python3 tools/shard_host_time.py > $OUT/shard_host_time.txt 2>&1
+# 8. round 4: what a kernel boundary costs on a stream / in a graph, what the launch traces do to a frame, every rank of an
+#    N-rank frame alone on the GPU (the predicted 2 / 4 / 8-GPU rates), the bench as the driver launches it with N ranks on one GPU
+tools/bench_launch > $OUT/bench_launch.txt 2>&1
+python3 tools/graph_probe.py 200 > $OUT/graph_probe.txt 2>> $OUT/bench.err
+python3 tools/rank_alone.py --out $OUT/rank_alone.json > /dev/null 2> $OUT/rank_alone.err
+for N in 2 8; do
+  GSX_BENCH_ONE_DEVICE=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29600+N)) bench.py --gpus $N --steps 20 --warmup 5 > $OUT/bench_ranks_on_one_gpu_world$N.json 2>> $OUT/bench.err
+done
 for f in $OUT/bench.json $OUT/bench_driver_args.json $OUT/bench_index_world1_inflight2.json; do cut -c1-300 $f; done

@@ -17,7 +17,7 @@ namespace {
 constexpr size_t kMinGraphNodes = 3;   // shorter segments are launched directly (a graph launch costs the host ~5 us)
 constexpr size_t kMaxVariants = 6;     // cached graphs per (entry point, segment position): speculated / plain / repairing ...
 
-std::atomic<int> g_graphs_enabled{-1};  // -1: not decided (GSX_GRAPH, default on)
+std::atomic<int> g_graphs_enabled{-1};  // -1: not decided (GSX_GRAPH, default off: see TraceScope)
 
 struct Launch {
     const void* fn;
@@ -191,7 +191,7 @@ bool launch_graphs_enabled() {
     int e = g_graphs_enabled.load(std::memory_order_relaxed);
     if (e < 0) {
         const char* s = getenv("GSX_GRAPH");
-        e = (s && *s) ? std::max(0, std::min(2, atoi(s))) : 1;  // 2: record even when the stream is idle (tests)
+        e = (s && *s) ? std::max(0, std::min(2, atoi(s))) : 0;  // 1: record while the stream is busy; 2: record even when it is idle (tests)
         g_graphs_enabled.store(e, std::memory_order_relaxed);
     }
     return e != 0;
@@ -222,13 +222,15 @@ TraceScope::TraceScope(gsx_viewer* v, uint32_t scope_id) {
     if (!v->trace) v->trace = new LaunchTrace();
     LaunchTrace* t = v->trace;
     if (t->broken) return;
-    // Recording buys HOST time (cfg4: 112 -> 37 us inside gsx_render_frame); on the device a real kernel boundary costs the same
+    // Recording buys HOST time (cfg4: 95 -> 42 us inside gsx_render_frame); on the device a real kernel boundary costs the same
     // inside a graph as on a stream (the 3.3 -> 1.75 us of tools/bench_launch.hip is the command processor's rate for EMPTY
-    // kernels: a frame's kernels run long enough for the next packet to be fetched meanwhile; tools/graph_probe.py: 597 vs 594 us per
-    // free-running frame).  And a graph reaches the device only when the whole segment has been recorded: a host that WAITS for
-    // every frame (the app's own protocol) would leave the device idle for those 37 us (661 vs 616 us per synchronised frame).
-    // So: record while the device still has work of this stream queued — the host is ahead, its time is what counts — and
-    // submit launch by launch when the stream is idle, the first kernel starts at once.
+    // kernels: a frame's kernels run long enough for the next packet to be fetched meanwhile), and a frame that arrives as one
+    // graph launch starts a few microseconds later than one whose first kernel is already queued (profiles/r04_bench.json,
+    // launch_graphs: 1607 vs 1633 fps with one frame in flight) — which is why the recording is OFF by default and a switch for
+    // hosts whose time is what counts (gsx_debug_set_launch_graphs(1) / GSX_GRAPH=1).  And a graph reaches the device only when
+    // the whole segment has been recorded: a host that WAITS for every frame (the app's own protocol) would leave the device idle
+    // meanwhile (661 vs 616 us per synchronised frame, tools/graph_probe.py).  So, when switched on: record while the device
+    // still has work of this stream queued, submit launch by launch when the stream is idle, the first kernel starts at once.
     if (g_graphs_enabled.load(std::memory_order_relaxed) != 2 && hipStreamQuery(v->stream) == hipSuccess) {
         t->stats.idle_direct_scopes += 1;
         return;

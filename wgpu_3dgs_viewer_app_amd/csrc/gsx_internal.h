@@ -382,11 +382,9 @@ hipError_t launch_spec_verify(hipStream_t s, const uint2* win1, const uint32_t* 
 hipError_t launch_zero_words(hipStream_t s, uint32_t* a, uint32_t na, uint32_t* b, uint32_t nb);
 hipError_t launch_validate_tiles(hipStream_t s, const uint2* ranges, uint32_t n_tiles, const uint32_t* list, const uint32_t* d_entries,
                                  uint32_t capacity, uint32_t n_records, uint32_t* report);
-// d_ticket: a zero word (left zero); pyr_data / pyr_min_ends (nullable): + the windows' max-pyramid / min-pyramid, built by the
-// last workgroup to finish
 hipError_t launch_spec_next(hipStream_t s, const uint32_t* tile_sat, const uint32_t* done, const uint32_t* done_before,
                             uint32_t row_words, uint32_t tiles_x, uint32_t tiles_y, float margin, uint32_t radius, uint2* win_next,
-                            uint32_t band_lo, uint32_t band_hi, uint32_t* d_ticket, uint32_t* pyr_data, uint32_t* pyr_min_ends);
+                            uint32_t band_lo, uint32_t band_hi);
 
 // Multi-GPU exchange support (kernels_shard.hip).
 // d_n (nullable) / tile: only the first ceil(*d_n / tile) columns of every row hold anything (a candidate list shorter than the grid)

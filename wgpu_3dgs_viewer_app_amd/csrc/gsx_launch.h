@@ -18,8 +18,14 @@
 //
 // Every frame therefore executes exactly the launches its host logic asked for, with exactly those arguments; the graph only
 // changes how they reach the device.  The host pays one pass of its own logic + memcmp + a handful of patches + one
-// hipGraphLaunch instead of ~40 hipLaunchKernel calls (113 -> ~25 us).  gsx_debug_set_launch_graphs(0) / GSX_GRAPH=0: every
-// GSX_LAUNCH submits at once, as before.
+// hipGraphLaunch instead of ~30 hipLaunchKernel calls (95 -> 42 us per cfg4 frame).
+//
+// What round 4 measured next (bench.py `launch_graphs`, tools/graph_probe.py): that is ALL it buys.  A real kernel boundary costs the
+// same inside a graph as on a stream — the 3.3 -> 1.75 us above is the command processor's rate for EMPTY kernels; a frame's
+// kernels run long enough for the next packet to be fetched meanwhile — and a frame that arrives as one graph launch starts a few
+// microseconds later than one whose first kernel is already queued: 1607 vs 1633 frames/s with one frame in flight.  So the recording
+// is OFF by default (every GSX_LAUNCH submits at once) and a switch for hosts whose time is what counts:
+// gsx_debug_set_launch_graphs(1) / GSX_GRAPH=1.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

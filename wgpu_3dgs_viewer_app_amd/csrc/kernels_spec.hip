@@ -216,34 +216,22 @@ __global__ __launch_bounds__(1024) void k_spec_verify_fused(const uint2* __restr
 
 // the model's windows for its next frame.  A tile that was saturated before this model was composited (done_before,
 // nearer models) says nothing about this model's depths; a tile still open afterwards makes its neighbourhood unbounded.
-// One workgroup per 32x32 block of tiles: the block's neighbourhood (radius <= 16) is staged in LDS once and the
+// One workgroup per 16x16 block of tiles: the block's neighbourhood (radius <= 16) is staged in LDS once and the
 // (2r+1)^2 maximum is taken separably — rows, then columns — instead of (2r+1)^2 global loads per tile (169 at the radius
 // the frame-parallel mode uses: 40 us; 14 us at radius 3).
-// The LAST workgroup to finish (a ticket: a dozen workgroups at 1080p) goes on to build the two pyramids of the new windows —
-// the max-pyramid of their ends (admission in the projection kernel) and the min-pyramid (binning) — which used to be a launch
-// of their own behind this one.
-constexpr int kNextBlock = 32, kNextMaxR = 16, kNextSpan = kNextBlock + 2 * kNextMaxR;
-struct NextLds {
-    float deep[kNextSpan][kNextSpan + 1];
-    unsigned char open[kNextSpan][kNextSpan + 1];
-    float hdeep[kNextSpan][kNextBlock + 1];
-    unsigned char hopen[kNextSpan][kNextBlock + 1];
-};
-__global__ __launch_bounds__(1024) void k_spec_next(const uint32_t* __restrict__ tile_sat, const uint32_t* __restrict__ done,
+constexpr int kNextBlock = 16, kNextMaxR = 16, kNextSpan = kNextBlock + 2 * kNextMaxR;
+__global__ __launch_bounds__(256) void k_spec_next(const uint32_t* __restrict__ tile_sat, const uint32_t* __restrict__ done,
                                                     const uint32_t* __restrict__ done_before, uint32_t row_words,
                                                     uint32_t tiles_x, uint32_t tiles_y, float gain, int radius,
-                                                    uint2* __restrict__ win_next, int band_lo, int band_hi,
-                                                    uint32_t* __restrict__ ticket, WindowPyramid pyr, uint32_t* __restrict__ pyr_data,
-                                                    uint32_t* __restrict__ pyr_min_ends) {
+                                                    uint2* __restrict__ win_next, int band_lo, int band_hi) {
     // per staged tile: depth (0 = contributes nothing) and an "open" flag; outside the band / image: neither
-    __shared__ union {
-        NextLds n;
-        PyramidLds p;
-    } lds;
-    __shared__ uint32_t s_last;
+    __shared__ float s_deep[kNextSpan][kNextSpan + 1];
+    __shared__ unsigned char s_open[kNextSpan][kNextSpan + 1];
+    __shared__ float s_hdeep[kNextSpan][kNextBlock + 1];
+    __shared__ unsigned char s_hopen[kNextSpan][kNextBlock + 1];
     const int bx = (int)blockIdx.x * kNextBlock, by = (int)blockIdx.y * kNextBlock;
     const int span = kNextBlock + 2 * radius;
-    for (int i = (int)threadIdx.x; i < span * span; i += 1024) {
+    for (int i = (int)threadIdx.x; i < span * span; i += 256) {
         const int ly = i / span, lx = i - ly * span;
         const int x = bx - radius + lx, y = by - radius + ly;
         float deep = 0.0f;
@@ -256,59 +244,43 @@ __global__ __launch_bounds__(1024) void k_spec_next(const uint32_t* __restrict__
                 deep = __uint_as_float(tile_sat[(uint32_t)y * tiles_x + (uint32_t)x]);
             }
         }
-        lds.n.deep[ly][lx] = deep;
-        lds.n.open[ly][lx] = open;
+        s_deep[ly][lx] = deep;
+        s_open[ly][lx] = open;
     }
     __syncthreads();
     // rows: for every staged row and every column of the block, max / any over [x - r, x + r]
-    for (int i = (int)threadIdx.x; i < span * kNextBlock; i += 1024) {
+    for (int i = (int)threadIdx.x; i < span * kNextBlock; i += 256) {
         const int ly = i / kNextBlock, cx = i - ly * kNextBlock;
         float deep = 0.0f;
         unsigned char open = 0;
         for (int d = 0; d <= 2 * radius; ++d) {
-            deep = fmaxf(deep, lds.n.deep[ly][cx + d]);
-            open |= lds.n.open[ly][cx + d];
+            deep = fmaxf(deep, s_deep[ly][cx + d]);
+            open |= s_open[ly][cx + d];
         }
-        lds.n.hdeep[ly][cx] = deep;
-        lds.n.hopen[ly][cx] = open;
+        s_hdeep[ly][cx] = deep;
+        s_hopen[ly][cx] = open;
     }
     __syncthreads();
-    {
-        const int cx = (int)threadIdx.x & 31, cy = (int)threadIdx.x >> 5;
-        const int tx = bx + cx, ty = by + cy;
-        if (tx < (int)tiles_x && ty < (int)tiles_y) {
-            const uint32_t t = (uint32_t)ty * tiles_x + (uint32_t)tx;
-            if (ty < band_lo || ty >= band_hi) {  // not this viewer's band: takes nothing
-                win_next[t] = make_uint2(0u, 0u);
-            } else {
-                float deepest = 0.0f;
-                unsigned char open = 0;
-                for (int d = 0; d <= 2 * radius; ++d) {
-                    deepest = fmaxf(deepest, lds.n.hdeep[cy + d][cx]);
-                    open |= lds.n.hopen[cy + d][cx];
-                }
-                uint32_t hi = kKeyAll;
-                if (!open) {
-                    const float lim = deepest * gain;
-                    hi = (lim < 3.0e38f) ? max(__float_as_uint(lim), 1u) : kKeyAll;
-                }
-                win_next[t] = make_uint2(0u, hi);
-            }
-        }
+    const int cx = (int)threadIdx.x & 15, cy = (int)threadIdx.x >> 4;
+    const int tx = bx + cx, ty = by + cy;
+    if (tx >= (int)tiles_x || ty >= (int)tiles_y) return;
+    const uint32_t t = (uint32_t)ty * tiles_x + (uint32_t)tx;
+    if (ty < band_lo || ty >= band_hi) {  // not this viewer's band: takes nothing
+        win_next[t] = make_uint2(0u, 0u);
+        return;
     }
-    if (!pyr_data) return;
-    // ticket: this workgroup's windows are visible device-wide before it draws; the one that draws the last number sees them all
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t n_wg = gridDim.x * gridDim.y;
-        s_last = atomicAdd(ticket, 1u) == n_wg - 1u ? 1u : 0u;
-        if (s_last) *ticket = 0u;  // (the next launch of this kernel starts from zero again)
+    float deepest = 0.0f;
+    unsigned char open = 0;
+    for (int d = 0; d <= 2 * radius; ++d) {
+        deepest = fmaxf(deepest, s_hdeep[cy + d][cx]);
+        open |= s_hopen[cy + d][cx];
     }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    build_window_pyramid<1024>(win_next, pyr, pyr_data, pyr_min_ends, lds.p);
+    uint32_t hi = kKeyAll;
+    if (!open) {
+        const float lim = deepest * gain;
+        hi = (lim < 3.0e38f) ? max(__float_as_uint(lim), 1u) : kKeyAll;
+    }
+    win_next[t] = make_uint2(0u, hi);
 }
 
 WindowPyramid window_pyramid_layout(uint32_t tiles_x, uint32_t tiles_y, const uint32_t* data) {
@@ -369,11 +341,10 @@ hipError_t launch_spec_verify(hipStream_t s, const uint2* win1, const uint32_t* 
 
 hipError_t launch_spec_next(hipStream_t s, const uint32_t* tile_sat, const uint32_t* done, const uint32_t* done_before,
                             uint32_t row_words, uint32_t tiles_x, uint32_t tiles_y, float margin, uint32_t radius, uint2* win_next,
-                            uint32_t band_lo, uint32_t band_hi, uint32_t* d_ticket, uint32_t* pyr_data, uint32_t* pyr_min_ends) {
-    const WindowPyramid pyr = window_pyramid_layout(tiles_x, tiles_y, pyr_data);
-    GSX_LAUNCH(k_spec_next, dim3((tiles_x + kNextBlock - 1) / kNextBlock, (tiles_y + kNextBlock - 1) / kNextBlock), dim3(1024), 0, s,
-               tile_sat, done, done_before, row_words, tiles_x, tiles_y, 1.0f + margin, (int)std::min<uint32_t>(radius, kNextMaxR), win_next,
-               (int)std::min(band_lo, tiles_y), (int)std::min(band_hi, tiles_y), d_ticket, pyr, pyr_data, pyr_min_ends);
+                            uint32_t band_lo, uint32_t band_hi) {
+    GSX_LAUNCH(k_spec_next, dim3((tiles_x + kNextBlock - 1) / kNextBlock, (tiles_y + kNextBlock - 1) / kNextBlock), dim3(256), 0, s,
+                       tile_sat, done, done_before, row_words, tiles_x, tiles_y, 1.0f + margin, (int)std::min<uint32_t>(radius, kNextMaxR), win_next,
+                       (int)std::min(band_lo, tiles_y), (int)std::min(band_hi, tiles_y));
     return hipGetLastError();
 }
 

@@ -601,8 +601,8 @@ class MultiModelViewer:
 
 
 def set_launch_graphs(enabled) -> None:
-    """Process-wide: frame-level entry points submit their launches as cached HIP graphs while their stream is busy (True / 1, the
-    default), always (2: tests) or never (False / 0)."""
+    """Process-wide: frame-level entry points submit their launches as cached HIP graphs while their stream is busy (True / 1), always
+    (2: tests) or never (False / 0, the default: the graphs save host time, not device time — csrc/gsx_launch.h)."""
     _lib.load().gsx_debug_set_launch_graphs(int(enabled))
 
 
