@@ -258,6 +258,7 @@ gsx_status gsx_viewer_create(const gsx_viewer_desc* desc, gsx_viewer** out) {
     if (const char* bm = getenv("GSX_BIN")) v->bin_mode = atoi(bm) ? 1 : 0;
     v->edit_cache = getenv("GSX_NO_EDIT_CACHE") == nullptr;
     v->shard_pair_slots = getenv("GSX_SHARD_UNIFORM_SLOTS") == nullptr;
+    v->tile_profile = getenv("GSX_TILE_PROFILE") != nullptr;
     if (const char* bx = getenv("GSX_BLOCKS_MAX")) v->blocks_max = (uint32_t)std::max(16, std::min(1024, atoi(bx)));
     (void)radix_lane_ordered_adds();  // probes THIS device once per process (the answer is kept per device)
     v->device = desc->device;

@@ -713,6 +713,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
         auto count = [&]() { return (uint64_t)((m->fc.tiles_x + (1u << bsx) - 1u) >> bsx) * ((m->fc.tiles_y + (1u << bsy) - 1u) >> bsy); };
         while (count() > v->blocks_max) (bsx <= bsy ? bsx : bsy) += 1;
         HIPCHK(m->block_table.ensure(sizeof(uint4) * 1024));
+        if (v->tile_profile) HIPCHK(v->tile_prof.ensure(sizeof(uint4) * (size_t)n_tiles));
     }
     // a single-slab front model keeps its complete tile lists for gsx_model_download_tile_lists
     const bool clear_ranges = progressive && !(bounds.size() == 2 && !carry && !m->spec_round1 && !imported_windows);
@@ -807,7 +808,8 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
                 //  same launch: the frame is complete without a host round trip)
                 HIPCHK(launch_composite_blocks(v->stream, m->fc, m->ranges.as<uint2>(), m->tile_list, m->srect.as<uint4>(), m->rec(), fb_ptr(v),
                                                later, done, row_words, done_count, tile_sat, win, row_lo, row_hi, bsx, bsy, row_work, dc, j1,
-                                               d_n, m->sorted_idx, m->sk_out.as<uint32_t>()));
+                                               d_n, m->sorted_idx, m->sk_out.as<uint32_t>(),
+                                               (v->tile_profile && slab_index == 0) ? v->tile_prof.as<uint4>() : nullptr));
             } else {
                 HIPCHK(launch_composite(v->stream, m->fc, m->ranges.as<uint2>(), m->tile_list, m->rec(), fb_ptr(v),
                                         later, done, row_words, done_count, clear_ranges, tile_sat, row_work));

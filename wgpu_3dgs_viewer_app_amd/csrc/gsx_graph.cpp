@@ -267,6 +267,17 @@ extern "C" {
 
 uint64_t gsx_debug_launch_count(void) { return gsx::g_launch_count.load(); }
 
+gsx_status gsx_debug_tile_profile(gsx_viewer* v, uint32_t* out4, uint64_t n_tiles) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    gsx_viewer* l = result_lane(v);
+    if (!out4 || !l->tile_profile || l->tile_prof.bytes < 16 * n_tiles)
+        return fail(GSX_ERR_INVALID_ARG, "gsx_debug_tile_profile: the viewer was not created under GSX_TILE_PROFILE=1, or no block-list frame yet");
+    HIPCHK(gsx::op::MemcpyAsync(out4, l->tile_prof.p, 16 * n_tiles, hipMemcpyDeviceToHost, l->stream));
+    HIPCHK(gsx::op::StreamSynchronize(l->stream));
+    return GSX_OK;
+}
+
 void gsx_debug_set_launch_graphs(int32_t enabled) { gsx::g_graphs_enabled.store(enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled)); }
 
 gsx_status gsx_viewer_launch_stats(gsx_viewer* v, gsx_launch_stats* out, uint32_t reset) {

@@ -330,7 +330,8 @@ hipError_t launch_composite_blocks(hipStream_t s, const FrameConsts& f, const ui
                                    uint32_t* d_done_count, uint32_t* tile_sat, const uint2* window, uint32_t row_lo,
                                    uint32_t row_hi, uint32_t bsx, uint32_t bsy, uint32_t* row_work /* as launch_composite */,
                                    const SlabStats* stats, uint32_t j1, const uint32_t* d_n, const uint32_t* sorted_idx,
-                                   const uint32_t* sorted_keys /* the slab's tail behind stats->slab_cut is composited pair-free by the same launch */);
+                                   const uint32_t* sorted_keys /* the slab's tail behind stats->slab_cut is composited pair-free by the same launch */,
+                                   uint4* tile_prof = nullptr /* development: per tile {start, duration (10 ns ticks), chunks walked | list chunks << 16, takers} */);
 
 // Selection / edits / queries (kernels_edit.hip).
 hipError_t launch_edit_prepare(hipStream_t s, uint32_t n, const uint32_t* selection, uint32_t* edited, float4* edit_a,

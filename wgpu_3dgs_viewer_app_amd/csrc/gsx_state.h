@@ -372,6 +372,8 @@ struct gsx_viewer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
     float pass_ms[GSX_PASS_COUNT]{};
     uint32_t pass_launches[GSX_PASS_COUNT]{};
+    DevBuf tile_prof;                    // GSX_TILE_PROFILE: what every tile of the LAST block-compositor launch of a frame's first slab cost
+    bool tile_profile = false;
     gsx::LaunchTrace* trace = nullptr;  // owned; created by the first TraceScope on this viewer (gsx_graph.cpp)
 };
 

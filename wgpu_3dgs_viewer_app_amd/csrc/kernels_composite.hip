@@ -30,7 +30,11 @@ __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elem
 // Blends the first `cnt` records of the LDS batch (slots up to the next multiple of kGroup must hold records no pixel
 // supports) into this lane's two pixels.  Groups of kGroup splats, straight-line, one skip branch per splat; a wave whose
 // pixels are all saturated leaves the batch at the next group.
-template <int MODE, int kGroup>
+// CLAMP: alpha_max < 1 or alpha_min > 0.  With the default constants (alpha_max = 1, alpha_min = 0) min(alpha_max, opacity x weight)
+// and the alpha_min test change nothing — opacity <= 1 and exp(-q / 2) <= 1, so their product is <= 1 and >= 0 — and the loop is
+// bound by vector issue: six instructions of the ~26 a hit costs are left out (same values, bit for bit; the INRIA-constants
+// fixture and every test that sets gsx_spec_params run the clamping instantiation).
+template <int MODE, int kGroup, bool CLAMP>
 __device__ __forceinline__ void blend_batch(const FrameConsts& f, const uint32_t cnt, const float2* s_mean, const float4* s_conic,
                                             const float4* s_rgb, const float pxf, const v2f pyf, uint32_t& lim0, uint32_t& lim1,
                                             v2f& T, v2f& C0, v2f& C1, v2f& C2, uint32_t& stop_key) {
@@ -57,15 +61,22 @@ __device__ __forceinline__ void blend_batch(const FrameConsts& f, const uint32_t
             if (h0 || h1) {
                 v2f alpha;
                 if (MODE == 0) {
-                    const v2f e = splat2(-0.5f) * q;
-                    alpha = splat2(co.w) * v2f{__expf(e.x), __expf(e.y)};
+                    // exp(-q / 2) as ONE packed multiply and two v_exp_f32: 2^(q x (-log2(e) / 2)) (__expf(-0.5f * q) is a multiply by
+                    // -0.5, a multiply by log2(e) and the same v_exp_f32 per pixel; the argument differs by at most an ulp)
+                    const v2f e = splat2(-0.72134752044448170368f) * q;
+                    alpha = splat2(co.w) * v2f{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
                 } else {
                     alpha = splat2(co.w * 1.0f);
                 }
-                alpha.x = fminf(f.alpha_max, alpha.x);
-                alpha.y = fminf(f.alpha_max, alpha.y);
-                alpha.x = (h0 && !(alpha.x < f.alpha_min)) ? alpha.x : 0.0f;
-                alpha.y = (h1 && !(alpha.y < f.alpha_min)) ? alpha.y : 0.0f;
+                if (CLAMP) {
+                    alpha.x = fminf(f.alpha_max, alpha.x);
+                    alpha.y = fminf(f.alpha_max, alpha.y);
+                    alpha.x = (h0 && !(alpha.x < f.alpha_min)) ? alpha.x : 0.0f;
+                    alpha.y = (h1 && !(alpha.y < f.alpha_min)) ? alpha.y : 0.0f;
+                } else {
+                    alpha.x = h0 ? alpha.x : 0.0f;
+                    alpha.y = h1 ? alpha.y : 0.0f;
+                }
                 const float4 c = s_rgb[j];
                 const v2f wgt = T * alpha;
                 C0 = fma2(wgt, splat2(c.x), C0);
@@ -88,7 +99,7 @@ __device__ __forceinline__ void blend_batch(const FrameConsts& f, const uint32_t
 // and each LDS broadcast now feeds two pixels.  Per pixel the operation sequence is exactly the oracle's (spec §6;
 // packed ops round like their scalar forms), a pixel that is not hit takes alpha = 0, which leaves (C, T) unchanged
 // bit for bit for finite colour records.
-template <int MODE /* 0 splat (gaussian falloff), 1 constant alpha inside the cutoff */>
+template <int MODE /* 0 splat (gaussian falloff), 1 constant alpha inside the cutoff */, bool CLAMP /* blend_batch */>
 __global__ __launch_bounds__(128) void k_composite(const FrameConsts f, uint2* __restrict__ ranges,
                                                     const uint32_t* __restrict__ list,
                                                     const float4* __restrict__ rec_a, const float4* __restrict__ rec_b,
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(128) void k_composite(const FrameConsts f, uint2* _
             }
         }
         const uint32_t cnt = min((uint32_t)kBatch, range.y - base);
-        blend_batch<MODE, kGroupTiles>(f, cnt, s_mean, s_conic, s_rgb, pxf, pyf, lim0, lim1, T, C0, C1, C2, stop_key);
+        blend_batch<MODE, kGroupTiles, CLAMP>(f, cnt, s_mean, s_conic, s_rgb, pxf, pyf, lim0, lim1, T, C0, C1, C2, stop_key);
     }
     if (in0) fb[fbo] = make_float4(C0.x, C1.x, C2.x, T.x);
     if (in1) fb[fbo + f.w_px] = make_float4(C0.y, C1.y, C2.y, T.y);
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(128) void k_composite(const FrameConsts f, uint2* _
 constexpr int kCand = 1;                         // candidates per lane and iteration (1 / 2 / 3 measured alike, round 2)
 constexpr uint32_t kChunk = 128u * kCand;
 
-template <int MODE>
+template <int MODE, bool CLAMP>
 __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, const uint2* __restrict__ ranges,
                                                            const uint32_t* __restrict__ list, const uint4* __restrict__ brec,
                                                            const float4* __restrict__ rec_a, const float4* __restrict__ rec_b,
@@ -230,7 +241,8 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
                                                            const uint32_t bsy, const uint32_t blocks_x, uint32_t* __restrict__ row_work,
                                                            const SlabStats* __restrict__ stats, const uint32_t j1,
                                                            const uint32_t* __restrict__ d_n, const uint32_t* __restrict__ sorted_idx,
-                                                           const uint32_t* __restrict__ sorted_keys) {
+                                                           const uint32_t* __restrict__ sorted_keys, uint4* __restrict__ tile_prof) {
+    const unsigned long long t_start = tile_prof ? wall_clock64() : 0ull;  // (development: gsx_debug_tile_profile)
     __shared__ float2 s_mean[kChunk + kGroupBlocks];
     __shared__ float4 s_conic[kChunk + kGroupBlocks];
     __shared__ float4 s_rgb[kChunk + kGroupBlocks];
@@ -353,7 +365,7 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
             if (ent_ok[k]) ent[k] = list[nn];
         }
         taken += cnt;
-        if (cnt) blend_batch<MODE, kGroupBlocks>(f, cnt, s_mean, s_conic, s_rgb, pxf, pyf, lim0, lim1, T, C0, C1, C2, stop_key);
+        if (cnt) blend_batch<MODE, kGroupBlocks, CLAMP>(f, cnt, s_mean, s_conic, s_rgb, pxf, pyf, lim0, lim1, T, C0, C1, C2, stop_key);
     }
     if (spill) {
         for (uint32_t sb = spill_cut; sb < spill_end; sb += 128u) {
@@ -389,13 +401,16 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
                 s_rgb[cnt + tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
             __syncthreads();
-            if (cnt) blend_batch<MODE, kGroupBlocks>(f, cnt, s_mean, s_conic, s_rgb, pxf, pyf, lim0, lim1, T, C0, C1, C2, stop_key);
+            if (cnt) blend_batch<MODE, kGroupBlocks, CLAMP>(f, cnt, s_mean, s_conic, s_rgb, pxf, pyf, lim0, lim1, T, C0, C1, C2, stop_key);
         }
     }
     if (in0) fb[fbo] = make_float4(C0.x, C1.x, C2.x, T.x);
     if (in1) fb[fbo + f.w_px] = make_float4(C0.y, C1.y, C2.y, T.y);
     if (row_work && tid == 0)  // (as k_composite; a block's list is shared by its tiles)
         atomicAdd(&row_work[ty], tile_work(min(base, range.y) - range.x, taken, range.y - range.x, 1u << (bsx + bsy)));
+    if (tile_prof && tid == 0)  // {start, duration in 10 ns ticks, list entries walked | list length << 16 (in chunks), takers blended}
+        tile_prof[tile] = make_uint4((uint32_t)t_start, (uint32_t)(wall_clock64() - t_start),
+                                     ((min(base, range.y) - range.x + kChunk - 1u) / kChunk) | (((range.y - range.x + kChunk - 1u) / kChunk) << 16), taken);
     if (done_bits && __syncthreads_and((lim0 | lim1) == 0u)) {
         if (tile_sat) {
             if (stop_key) atomicMax(&s_sat, stop_key);
@@ -415,7 +430,7 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
 // with the compositor's own code: the per-pixel operation sequence is that of a frame with larger buffers, so the pixels are
 // the same.  O(tiles x tail) rectangle tests: a rare path that trades speed for never delivering an incomplete frame; the
 // host grows the buffers as soon as it learns of the overflow.  A slab that was not cut: two loads, then return.
-template <int MODE>
+template <int MODE, bool CLAMP>
 __global__ __launch_bounds__(128) void k_composite_spill(const FrameConsts f, const SlabStats* __restrict__ stats, const uint32_t j1,
                                                           const uint32_t* __restrict__ d_n, const uint32_t* __restrict__ sorted_idx,
                                                           const uint32_t* __restrict__ sorted_keys, const float4* __restrict__ rec_a,
@@ -490,7 +505,7 @@ __global__ __launch_bounds__(128) void k_composite_spill(const FrameConsts f, co
             s_rgb[cnt + tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
         __syncthreads();
-        blend_batch<MODE, kGroupTiles>(f, cnt, s_mean, s_conic, s_rgb, pxf, pyf, lim0, lim1, T, C0, C1, C2, stop_key);
+        blend_batch<MODE, kGroupTiles, CLAMP>(f, cnt, s_mean, s_conic, s_rgb, pxf, pyf, lim0, lim1, T, C0, C1, C2, stop_key);
     }
     if (in0) fb[fbo] = make_float4(C0.x, C1.x, C2.x, T.x);
     if (in1) fb[fbo + f.w_px] = make_float4(C0.y, C1.y, C2.y, T.y);
@@ -532,12 +547,18 @@ hipError_t launch_composite(hipStream_t s, const FrameConsts& f, uint2* ranges, 
                             const Records& rec, float4* fb, bool carry, uint32_t* done, uint32_t row_words,
                             uint32_t* d_done_count, bool clear_ranges, uint32_t* tile_sat, uint32_t* row_work) {
     dim3 grid(f.tiles_x * f.tiles_y), block(128);
-    if (f.display_mode == GSX_DISPLAY_SPLAT)
-        GSX_LAUNCH(k_composite<0>, grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count,
+    const bool clamp = f.alpha_max < 1.0f || f.alpha_min > 0.0f;  // (blend_batch: the default constants need no clamping)
+    if (f.display_mode == GSX_DISPLAY_SPLAT) {
+        if (clamp) GSX_LAUNCH((k_composite<0, true>), grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count,
                            clear_ranges ? 1 : 0, tile_sat, row_work);
-    else
-        GSX_LAUNCH(k_composite<1>, grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count,
+        else GSX_LAUNCH((k_composite<0, false>), grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count,
                            clear_ranges ? 1 : 0, tile_sat, row_work);
+    } else {
+        if (clamp) GSX_LAUNCH((k_composite<1, true>), grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count,
+                           clear_ranges ? 1 : 0, tile_sat, row_work);
+        else GSX_LAUNCH((k_composite<1, false>), grid, block, 0, s, f, ranges, list, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, d_done_count,
+                           clear_ranges ? 1 : 0, tile_sat, row_work);
+    }
     return hipGetLastError();
 }
 
@@ -545,15 +566,21 @@ hipError_t launch_composite_blocks(hipStream_t s, const FrameConsts& f, const ui
                                    const Records& rec, float4* fb, bool carry, uint32_t* done, uint32_t row_words,
                                    uint32_t* d_done_count, uint32_t* tile_sat, const uint2* window, uint32_t row_lo,
                                    uint32_t row_hi, uint32_t bsx, uint32_t bsy, uint32_t* row_work, const SlabStats* stats, uint32_t j1,
-                                   const uint32_t* d_n, const uint32_t* sorted_idx, const uint32_t* sorted_keys) {
+                                   const uint32_t* d_n, const uint32_t* sorted_idx, const uint32_t* sorted_keys, uint4* tile_prof) {
     dim3 grid(f.tiles_x * f.tiles_y), block(128);
     const uint32_t blocks_x = (f.tiles_x + (1u << bsx) - 1u) >> bsx;
-    if (f.display_mode == GSX_DISPLAY_SPLAT)
-        GSX_LAUNCH(k_composite_blocks<0>, grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
-                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work, stats, j1, d_n, sorted_idx, sorted_keys);
-    else
-        GSX_LAUNCH(k_composite_blocks<1>, grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
-                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work, stats, j1, d_n, sorted_idx, sorted_keys);
+    const bool clamp = f.alpha_max < 1.0f || f.alpha_min > 0.0f;  // (blend_batch: the default constants need no clamping)
+    if (f.display_mode == GSX_DISPLAY_SPLAT) {
+        if (clamp) GSX_LAUNCH((k_composite_blocks<0, true>), grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
+                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work, stats, j1, d_n, sorted_idx, sorted_keys, tile_prof);
+        else GSX_LAUNCH((k_composite_blocks<0, false>), grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
+                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work, stats, j1, d_n, sorted_idx, sorted_keys, tile_prof);
+    } else {
+        if (clamp) GSX_LAUNCH((k_composite_blocks<1, true>), grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
+                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work, stats, j1, d_n, sorted_idx, sorted_keys, tile_prof);
+        else GSX_LAUNCH((k_composite_blocks<1, false>), grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
+                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work, stats, j1, d_n, sorted_idx, sorted_keys, tile_prof);
+    }
     return hipGetLastError();
 }
 
@@ -562,12 +589,18 @@ hipError_t launch_composite_spill(hipStream_t s, const FrameConsts& f, const Sla
                                   uint32_t* done, uint32_t row_words, uint32_t* d_done_count, uint32_t* tile_sat, uint32_t row_lo,
                                   uint32_t row_hi, const uint2* window) {
     dim3 grid(std::min<uint32_t>(f.tiles_x * f.tiles_y, 2048u)), block(128);
-    if (f.display_mode == GSX_DISPLAY_SPLAT)
-        GSX_LAUNCH(k_composite_spill<0>, grid, block, 0, s, f, stats, j1, d_n, sorted_idx, sorted_keys, rec.a, rec.b, rec.c, fb, done,
+    const bool clamp = f.alpha_max < 1.0f || f.alpha_min > 0.0f;  // (blend_batch: the default constants need no clamping)
+    if (f.display_mode == GSX_DISPLAY_SPLAT) {
+        if (clamp) GSX_LAUNCH((k_composite_spill<0, true>), grid, block, 0, s, f, stats, j1, d_n, sorted_idx, sorted_keys, rec.a, rec.b, rec.c, fb, done,
                            row_words, d_done_count, tile_sat, row_lo, row_hi, window);
-    else
-        GSX_LAUNCH(k_composite_spill<1>, grid, block, 0, s, f, stats, j1, d_n, sorted_idx, sorted_keys, rec.a, rec.b, rec.c, fb, done,
+        else GSX_LAUNCH((k_composite_spill<0, false>), grid, block, 0, s, f, stats, j1, d_n, sorted_idx, sorted_keys, rec.a, rec.b, rec.c, fb, done,
                            row_words, d_done_count, tile_sat, row_lo, row_hi, window);
+    } else {
+        if (clamp) GSX_LAUNCH((k_composite_spill<1, true>), grid, block, 0, s, f, stats, j1, d_n, sorted_idx, sorted_keys, rec.a, rec.b, rec.c, fb, done,
+                           row_words, d_done_count, tile_sat, row_lo, row_hi, window);
+        else GSX_LAUNCH((k_composite_spill<1, false>), grid, block, 0, s, f, stats, j1, d_n, sorted_idx, sorted_keys, rec.a, rec.b, rec.c, fb, done,
+                           row_words, d_done_count, tile_sat, row_lo, row_hi, window);
+    }
     return hipGetLastError();
 }
 
