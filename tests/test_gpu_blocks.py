@@ -70,3 +70,32 @@ def test_block_lists_layered_models_and_display_modes(monkeypatch):
         assert np.array_equal(a, b), f"frame {k}"
     tiles.close()
     blocks.close()
+
+
+@pytest.mark.parametrize("speculative", [0, 1])
+def test_dispatch_order_is_a_schedule_not_data(monkeypatch, speculative):
+    """The block compositor takes its tiles expensive-first (tile_order_job: last frame's cost per tile, two classes, made by one more
+    workgroup of the first slab's k_block_counts); GSX_TILE_ORDER=0 keeps index order.  Same pixels bit for bit — a scene whose cost
+    is concentrated in part of the screen so that both classes are populated, a viewport change (the order is rebuilt), layered
+    models (tiles that return early under `carry`), frames in flight (every lane has an order of its own)."""
+    rng = np.random.default_rng(77)
+    g = common.small_scene(60000, 404, scale_mul=20.0)
+    g2 = common.small_scene(20000, 405, scale_mul=10.0)
+    monkeypatch.setenv("GSX_TILE_ORDER", "0")
+    plain = MultiModelViewer()
+    monkeypatch.delenv("GSX_TILE_ORDER")
+    ordered = MultiModelViewer()
+    for v in (plain, ordered):
+        v.set_render_options(speculative=speculative, min_slab=8192, frames_in_flight=2)
+        v.add_model("m", g.shape[0])
+        v.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g)
+        v.add_model("near", g2.shape[0])
+        v.models["near"].gaussian_buffers.gaussians_buffer.update_range(0, g2)
+    poses = [int(p) for p in rng.integers(0, 200, 4)]
+    plan = [((1920, 1080), ["m"], p) for p in (7, 8, 9, 10, 11, 12)] + [((1000, 600), ["m"], p) for p in (12, 13, 14)] + \
+           [((1920, 1080), ["m", "near"], p) for p in (20, 21, 22, 23)] + [((1920, 1080), ["m"], p) for p in poses]
+    for k, (size, keys, pose) in enumerate(plan):
+        a, b = _frame(ordered, pose, keys, size), _frame(plain, pose, keys, size)
+        assert np.array_equal(a, b), f"frame {k} ({size}, {keys}, pose {pose}): L-inf {np.abs(a - b).max()}"
+    plain.close()
+    ordered.close()

@@ -38,7 +38,31 @@ for spec in (1, 0):
         print(f"   p{q}: duration {np.percentile(dur, q):7.1f} us, chunks walked {np.percentile(walked, q):6.0f} of {np.percentile(listc, q):6.0f} in the list, takers {np.percentile(taken, q):7.0f}")
     worst = np.argsort(-dur)[:8]
     print("   slowest tiles (x, y: us, chunks walked / in list, takers, start us):", [(int(t % tx), int(t // tx), round(float(dur[t]), 1), int(walked[t]), int(listc[t]), int(taken[t]), round(float(((start[t] - t0) & 0xFFFFFFFF) * 0.01), 1)) for t in worst])
+    # list scheduling of the measured durations on 256 x 12 slots: the order the dispatcher uses (tile index) against longest first
+    import heapq
+
+    def makespan(order):
+        slots = [0.0] * (256 * 12)
+        heapq.heapify(slots)
+        end_ = 0.0
+        for t in order:
+            s0 = heapq.heappop(slots)
+            e0 = s0 + dur[t]
+            end_ = max(end_, e0)
+            heapq.heappush(slots, e0)
+        return end_
+
+    ran = np.nonzero(dur > 0)[0]
+    if os.environ.get("GSX_TILE_PROFILE_DUMP"):
+        np.savez_compressed(os.environ["GSX_TILE_PROFILE_DUMP"] + f"_{spec}.npz", out=out)
+    print(f"   list scheduling of these durations on 3072 slots: index order {makespan(ran):.1f} us, longest first {makespan(ran[np.argsort(-dur[ran])]):.1f} us,"
+          f" by takers (what a previous frame would know) {makespan(ran[np.argsort(-(taken[ran].astype(np.int64) * 4 + walked[ran] * 128), kind='stable')]):.1f} us")
     # how late do the slow tiles START?  (the dispatcher hands out tiles in index order)
+    rel = ((start - t0) & 0xFFFFFFFF) * 0.01
+    hist, _ = np.histogram(rel[dur > 0], bins=np.arange(0, 200, 10))
+    print("   tiles starting per 10 us:", hist.tolist())
+    hist, _ = np.histogram(end[dur > 0], bins=np.arange(0, 200, 10))
+    print("   tiles ending per 10 us:  ", hist.tolist())
     late = dur > np.percentile(dur, 99)
     print(f"   the slowest 1 % of the tiles start at {np.percentile((((start - t0) & 0xFFFFFFFF) * 0.01)[late], [0, 50, 100])} us (min / median / max)")
 v.close()

@@ -610,7 +610,7 @@ static void merge_tail_slabs(std::vector<uint32_t>* bounds, uint32_t used) {
 // remaining slabs' kernels fall through.  carry: the framebuffer already holds nearer models.
 // frame_zero (nullable; the frame's first model): the frame's saturation state, to be zeroed together with this model's per-frame
 // totals before anything of the frame reads them — folded into the first slab's block-table kernel where there is one.
-static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, const ZeroJob* frame_zero = nullptr) {
+static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, const ZeroJob* frame_zero = nullptr, bool cont = false) {
     if (!m->sorted) return fail(GSX_ERR_INVALID_ARG, "gsx_render: model '%s' was not preprocessed+sorted", m->key.c_str());
     if (m->order_consumed)
         return fail(GSX_ERR_INVALID_ARG, "gsx_render: the depth order of '%s' was consumed by a speculated frame's repair round; "
@@ -715,6 +715,21 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
         HIPCHK(m->block_table.ensure(sizeof(uint4) * 1024));
         if (v->tile_profile) HIPCHK(v->tile_prof.ensure(sizeof(uint4) * (size_t)n_tiles));
     }
+    // Block compositor: the tiles that were expensive in the model's frame before are dispatched first (k_composite_blocks; a
+    // schedule, not data).  The order is made by one more workgroup of the frame's first block-table kernel; a second round of the
+    // same frame (cont) keeps the first round's, and what it costs counts towards the next frame's.
+    uint32_t* order_buf = nullptr;
+    bool order_build = false;
+    if (blocks && v->tile_order_on && n_tiles <= kTileOrderMax && bounds.size() >= 2 && bounds[1] > bounds[0]) {
+        if (m->tile_order_tiles != n_tiles) {
+            HIPCHK(m->tile_order.ensure(4 * (1 + 2 * (size_t)n_tiles)));
+            HIPCHK(gsx::op::MemsetAsync(m->tile_order.p, 0, 4 * (1 + (size_t)n_tiles), v->stream));
+            m->tile_order_tiles = n_tiles;
+            m->tile_order_valid = false;
+        }
+        order_buf = m->tile_order.as<uint32_t>();
+        order_build = !cont || !m->tile_order_valid;
+    }
     // a single-slab front model keeps its complete tile lists for gsx_model_download_tile_lists
     const bool clear_ranges = progressive && !(bounds.size() == 2 && !carry && !m->spec_round1 && !imported_windows);
     // one depth slab [j0, j1) of the current depth order: bin -> tile sort -> ranges -> composite
@@ -730,13 +745,20 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
             //  the same 256 addresses: binning 69 -> 86 us against block sort 37 -> 25 on a speculated cfg4 frame, 218 -> 327 against
             //  69 -> 45 unspeculated.  Not kept.)
             const int block_bits = (int)std::max<uint32_t>(1u, ceil_log2(v->blocks_max));
+            ZeroJob jobs = zero_pending ? zero : ZeroJob{};
+            if (order_build && !table_ready) {
+                jobs.order_buf = order_buf;
+                jobs.order_tiles = n_tiles;
+                m->tile_order_valid = true;
+                order_build = false;
+            }
             {
                 ScopedPass t(v, GSX_PASS_BIN);
                 HIPCHK(launch_block_bin(v->stream, j0, j1, d_n, m->sorted_idx, m->rec(), m->sk_out.as<uint32_t>(), m->srect.as<uint4>(),
                                         m->cnt.as<uint32_t>(), m->block_sums.as<uint32_t>(), dc, cap, row_lo, row_hi, done_in, row_words,
                                         (progressive && later) ? done_count : nullptr, owned_tiles, slab_index, win, m->fc.tiles_x,
                                         m->fc.tiles_y, bsx, bsy, m->block_table.as<uint4>(), m->tp_src.as<uint2>(), m->ranges.as<uint2>(),
-                                        zero_pending ? zero : ZeroJob{}, table_ready));
+                                        jobs, table_ready));
                 zero_pending = false;
                 v->pass_launches[GSX_PASS_BIN] += 1;
             }
@@ -809,7 +831,9 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
                 HIPCHK(launch_composite_blocks(v->stream, m->fc, m->ranges.as<uint2>(), m->tile_list, m->srect.as<uint4>(), m->rec(), fb_ptr(v),
                                                later, done, row_words, done_count, tile_sat, win, row_lo, row_hi, bsx, bsy, row_work, dc, j1,
                                                d_n, m->sorted_idx, m->sk_out.as<uint32_t>(),
-                                               (v->tile_profile && slab_index == 0) ? v->tile_prof.as<uint4>() : nullptr));
+                                               (v->tile_profile && slab_index == 0) ? v->tile_prof.as<uint4>() : nullptr,
+                                               (order_buf && m->tile_order_valid) ? order_buf + 1 + n_tiles : nullptr,
+                                               order_buf ? order_buf + 1 : nullptr));
             } else {
                 HIPCHK(launch_composite(v->stream, m->fc, m->ranges.as<uint2>(), m->tile_list, m->rec(), fb_ptr(v),
                                         later, done, row_words, done_count, clear_ranges, tile_sat, row_work));
@@ -987,7 +1011,7 @@ gsx_status do_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys, bo
     // the reference paints far -> near with "over"; front-to-back accumulation walks the same list backwards
     bool carry = cont;
     for (auto it = order.rbegin(); it != order.rend(); ++it) {
-        if ((st = do_bin_and_composite(v, *it, carry, (!cont && it == order.rbegin()) ? &frame_zero : nullptr))) return st;
+        if ((st = do_bin_and_composite(v, *it, carry, (!cont && it == order.rbegin()) ? &frame_zero : nullptr, cont))) return st;
         carry = true;
     }
     return GSX_OK;

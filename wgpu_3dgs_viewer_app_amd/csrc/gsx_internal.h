@@ -247,7 +247,94 @@ struct ZeroJob {
     uint32_t na = 0;
     uint32_t* b = nullptr;
     uint32_t nb = 0;
+    // ... and the block compositor's dispatch order, as one more workgroup of the slab's k_block_counts (tile_order_job):
+    // order_buf = {threshold, tile_cost[order_tiles], tile_order[order_tiles]}
+    uint32_t* order_buf = nullptr;
+    uint32_t order_tiles = 0;
 };
+constexpr uint32_t kTileOrderMax = 65536;   // tiles (tile_order_job keeps 3 words of LDS per 64 tiles: within k_block_counts' 4096)
+constexpr uint32_t tile_order_lds_words(uint32_t n_tiles) { return 3u * ((n_tiles + 63u) / 64u) + 32u; }
+
+#ifdef __HIPCC__
+// The block compositor's dispatch order (k_composite_blocks): the tiles whose cost in the model's frame before (tile_cost, summed over
+// that frame's compositor launches; zeroed here) was above that frame's threshold come first, the others after, each class in index
+// order (neighbours share block lists and records: they still run together).  threshold <- this frame's average cost.
+// One workgroup of THREADS lanes; a wave takes 64 consecutive tiles at a time: one coalesced load, one ballot, no second look at memory.
+template <uint32_t THREADS>
+__device__ __forceinline__ void tile_order_job(uint32_t* __restrict__ order_buf, const uint32_t n_tiles, uint32_t* __restrict__ lds /* tile_order_lds_words(n_tiles), 8-byte aligned */) {
+    constexpr uint32_t kWaves = THREADS / 64u, kBatch = 16u;
+    const uint32_t groups = (n_tiles + 63u) / 64u;
+    unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(lds);   // bit l of group g: tile 64 g + l is expensive
+    uint32_t* s_before = lds + 2u * groups;                                     // expensive tiles in the groups before g
+    uint32_t *s_sum = s_before + groups, *s_cnt = s_sum + kWaves;
+    uint32_t* __restrict__ tile_cost = order_buf + 1;
+    uint32_t* __restrict__ tile_order = tile_cost + n_tiles;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t thr = order_buf[0];
+    uint32_t sum = 0;
+    for (uint32_t gb = wave; gb < groups; gb += kBatch * kWaves) {  // kBatch loads in flight per lane (one workgroup: latency is all there is)
+        uint32_t c[kBatch];
+#pragma unroll
+        for (uint32_t k = 0; k < kBatch; ++k) {
+            const uint32_t tile = (gb + k * kWaves) * 64u + lane;
+            c[k] = tile < n_tiles ? tile_cost[tile] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kBatch; ++k) {
+            const uint32_t g = gb + k * kWaves, tile = g * 64u + lane;
+            if (tile < n_tiles) tile_cost[tile] = 0u;
+            sum += c[k];
+            const unsigned long long m = __ballot(c[k] > thr);
+            if (lane == 0u && g < groups) s_mask[g] = m;
+        }
+    }
+#pragma unroll
+    for (uint32_t d = 32u; d; d >>= 1) sum += __shfl_xor(sum, d);
+    if (lane == 0u) s_sum[wave] = sum;
+    __syncthreads();
+    // exclusive scan of the groups' counts: every lane a contiguous run of groups, then the runs
+    const uint32_t per = (groups + THREADS - 1u) / THREADS, g0 = min(tid * per, groups), g1 = min(g0 + per, groups);
+    uint32_t mine = 0;
+    for (uint32_t g = g0; g < g1; ++g) mine += (uint32_t)__popcll(s_mask[g]);
+    uint32_t incl = mine;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63u) s_cnt[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - mine, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kWaves; ++w) {
+        run += w < wave ? s_cnt[w] : 0u;
+        total += s_cnt[w];
+    }
+    for (uint32_t g = g0; g < g1; ++g) {
+        s_before[g] = run;
+        run += (uint32_t)__popcll(s_mask[g]);
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (uint32_t g = wave; g < groups; g += kWaves) {
+        const uint32_t tile = g * 64u + lane;
+        const unsigned long long m = s_mask[g];
+        const uint32_t before = s_before[g];
+        if (tile < n_tiles) {
+            const bool exp_ = (m >> lane) & 1ull;
+            // (a cheap tile: after all the expensive ones, behind the cheap tiles of the groups before and of this group's lower lanes)
+            const uint32_t at = exp_ ? before + (uint32_t)__popcll(m & lt) : total + (g * 64u - before) + (uint32_t)__popcll(~m & lt);
+            tile_order[at] = tile;
+        }
+    }
+    if (tid == 0u) {
+        uint32_t all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kWaves; ++w) all += s_sum[w];
+        order_buf[0] = all / n_tiles;
+    }
+}
+#endif
 
 // Block lists (kernels_bin.hip): the screen's tiles in at most 256 blocks of 2^bsx x 2^bsy tiles.
 struct BlockGrid {
@@ -331,7 +418,9 @@ hipError_t launch_composite_blocks(hipStream_t s, const FrameConsts& f, const ui
                                    uint32_t row_hi, uint32_t bsx, uint32_t bsy, uint32_t* row_work /* as launch_composite */,
                                    const SlabStats* stats, uint32_t j1, const uint32_t* d_n, const uint32_t* sorted_idx,
                                    const uint32_t* sorted_keys /* the slab's tail behind stats->slab_cut is composited pair-free by the same launch */,
-                                   uint4* tile_prof = nullptr /* development: per tile {start, duration (10 ns ticks), chunks walked | list chunks << 16, takers} */);
+                                   uint4* tile_prof = nullptr /* development: per tile {start, duration (10 ns ticks), chunks walked | list chunks << 16, takers} */,
+                                   const uint32_t* tile_order = nullptr /* the tile workgroup i composites (nullptr: tile i) */,
+                                   uint32_t* tile_cost = nullptr /* += what each tile cost: tile_order_job's input for the model's next frame */);
 
 // Selection / edits / queries (kernels_edit.hip).
 hipError_t launch_edit_prepare(hipStream_t s, uint32_t n, const uint32_t* selection, uint32_t* edited, float4* edit_a,

@@ -121,6 +121,9 @@ struct Model {
     DevBuf block_vis;                           // per-workgroup visible counts of the projection pass
     DevBuf tp_src, tp_a, tp_b, tk_out, tv_out, tsort_ws;  // tile pairs: emitted, scratch, sorted (split), workspace
     DevBuf ranges;
+    DevBuf tile_order;                          // block compositor's dispatch order: {threshold, tile_cost[n_tiles], tile_order[n_tiles]} (tile_order_job)
+    uint32_t tile_order_tiles = 0;              // the tile count it is laid out for
+    bool tile_order_valid = false;              // tile_order holds a permutation
     DevBuf block_table;                         // block lists: per block {min window start, max window end, live}
     DevBuf counters;
     Counters* h_counters = nullptr;             // pinned
@@ -374,6 +377,7 @@ struct gsx_viewer {
     uint32_t pass_launches[GSX_PASS_COUNT]{};
     DevBuf tile_prof;                    // GSX_TILE_PROFILE: what every tile of the LAST block-compositor launch of a frame's first slab cost
     bool tile_profile = false;
+    bool tile_order_on = true;           // GSX_TILE_ORDER=0: the block compositor takes its tiles in index order (A/B)
     gsx::LaunchTrace* trace = nullptr;  // owned; created by the first TraceScope on this viewer (gsx_graph.cpp)
 };
 

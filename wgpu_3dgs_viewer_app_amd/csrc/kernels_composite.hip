@@ -34,6 +34,9 @@ __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elem
 // and the alpha_min test change nothing — opacity <= 1 and exp(-q / 2) <= 1, so their product is <= 1 and >= 0 — and the loop is
 // bound by vector issue: six instructions of the ~26 a hit costs are left out (same values, bit for bit; the INRIA-constants
 // fixture and every test that sets gsx_spec_params run the clamping instantiation).
+// Measured on cfg4 (a counting build, round 4): 60 % of the (record, wave) evaluations hit a pixel — the rest leave after the ten
+// instructions of q and the two compares — and a hit covers 65 % of the wave's 128 pixels; ~144 evaluations and ~87 hits per wave
+// and tile, 80 % of the kernel's vector instructions.
 template <int MODE, int kGroup, bool CLAMP>
 __device__ __forceinline__ void blend_batch(const FrameConsts& f, const uint32_t cnt, const float2* s_mean, const float4* s_conic,
                                             const float4* s_rgb, const float pxf, const v2f pyf, uint32_t& lim0, uint32_t& lim1,
@@ -226,6 +229,10 @@ __global__ __launch_bounds__(128) void k_composite(const FrameConsts f, uint2* _
 // Software pipeline: while the takers of chunk c are blended out of LDS, the candidate loads of chunk c + 1 (brec) and c + 2
 // (list) are in flight.  The takers' 48-byte records are gathered when their LDS slots are written, NOT held across the blend:
 // twelve registers less is one more wave per SIMD (84 -> 74 VGPRs, occupancy 5 -> 6), worth more than the overlap (+1.2 %).
+// What a tile cost, in the units the dispatch order is decided by (tile_order_job): measured on cfg4 (tools/tile_profile.py), a tile's time under a full chip is
+// ~16 us + 0.95 us per list chunk walked + 0.11 us per taker blended; one unit = 0.44 us.
+__device__ __forceinline__ uint32_t tile_cost_units(uint32_t chunks, uint32_t taken) { return (9u * chunks + taken) >> 2; }
+
 constexpr int kCand = 1;                         // candidates per lane and iteration (1 / 2 / 3 measured alike, round 2)
 constexpr uint32_t kChunk = 128u * kCand;
 
@@ -241,14 +248,21 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
                                                            const uint32_t bsy, const uint32_t blocks_x, uint32_t* __restrict__ row_work,
                                                            const SlabStats* __restrict__ stats, const uint32_t j1,
                                                            const uint32_t* __restrict__ d_n, const uint32_t* __restrict__ sorted_idx,
-                                                           const uint32_t* __restrict__ sorted_keys, uint4* __restrict__ tile_prof) {
+                                                           const uint32_t* __restrict__ sorted_keys, uint4* __restrict__ tile_prof,
+                                                           const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ tile_cost) {
     const unsigned long long t_start = tile_prof ? wall_clock64() : 0ull;  // (development: gsx_debug_tile_profile)
     __shared__ float2 s_mean[kChunk + kGroupBlocks];
     __shared__ float4 s_conic[kChunk + kGroupBlocks];
     __shared__ float4 s_rgb[kChunk + kGroupBlocks];
     __shared__ uint32_t s_sat, s_w[2][kCand];
 
-    const uint32_t tile = blockIdx.x;
+    // The launch is as slow as its tail: the dispatcher hands out workgroups in index order, twelve a CU, and a tile takes 15 to
+    // 100 us — measured (tools/tile_profile.py, cfg4): the last 55 of 187 us ran with under a sixth of the slots occupied, and
+    // list scheduling of the same durations with the expensive half first ends 35 us earlier (finer classes gain nothing: what a
+    // tile cost a frame ago predicts its time only roughly).  So workgroup i composites tile_order[i] — the tiles that cost more
+    // than the average in the model's frame before, then the others, each class in index order (tile_order_job, gsx_internal.h:
+    // one more workgroup of the frame's first block-table kernel).  A schedule, not data: any permutation renders the same pixels.
+    const uint32_t tile = tile_order ? tile_order[blockIdx.x] : blockIdx.x;
     const uint32_t tx = tile % f.tiles_x, ty = tile / f.tiles_x;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t px = tx * kTile + (tid & 15u), py = ty * kTile + 2u * (tid >> 4);
@@ -408,6 +422,7 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
     if (in1) fb[fbo + f.w_px] = make_float4(C0.y, C1.y, C2.y, T.y);
     if (row_work && tid == 0)  // (as k_composite; a block's list is shared by its tiles)
         atomicAdd(&row_work[ty], tile_work(min(base, range.y) - range.x, taken, range.y - range.x, 1u << (bsx + bsy)));
+    if (tile_cost && tid == 0) tile_cost[tile] += tile_cost_units((min(base, range.y) - range.x + kChunk - 1u) / kChunk, taken);
     if (tile_prof && tid == 0)  // {start, duration in 10 ns ticks, list entries walked | list length << 16 (in chunks), takers blended}
         tile_prof[tile] = make_uint4((uint32_t)t_start, (uint32_t)(wall_clock64() - t_start),
                                      ((min(base, range.y) - range.x + kChunk - 1u) / kChunk) | (((range.y - range.x + kChunk - 1u) / kChunk) << 16), taken);
@@ -566,20 +581,21 @@ hipError_t launch_composite_blocks(hipStream_t s, const FrameConsts& f, const ui
                                    const Records& rec, float4* fb, bool carry, uint32_t* done, uint32_t row_words,
                                    uint32_t* d_done_count, uint32_t* tile_sat, const uint2* window, uint32_t row_lo,
                                    uint32_t row_hi, uint32_t bsx, uint32_t bsy, uint32_t* row_work, const SlabStats* stats, uint32_t j1,
-                                   const uint32_t* d_n, const uint32_t* sorted_idx, const uint32_t* sorted_keys, uint4* tile_prof) {
+                                   const uint32_t* d_n, const uint32_t* sorted_idx, const uint32_t* sorted_keys, uint4* tile_prof,
+                                   const uint32_t* tile_order, uint32_t* tile_cost) {
     dim3 grid(f.tiles_x * f.tiles_y), block(128);
     const uint32_t blocks_x = (f.tiles_x + (1u << bsx) - 1u) >> bsx;
     const bool clamp = f.alpha_max < 1.0f || f.alpha_min > 0.0f;  // (blend_batch: the default constants need no clamping)
     if (f.display_mode == GSX_DISPLAY_SPLAT) {
         if (clamp) GSX_LAUNCH((k_composite_blocks<0, true>), grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
-                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work, stats, j1, d_n, sorted_idx, sorted_keys, tile_prof);
+                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work, stats, j1, d_n, sorted_idx, sorted_keys, tile_prof, tile_order, tile_cost);
         else GSX_LAUNCH((k_composite_blocks<0, false>), grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
-                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work, stats, j1, d_n, sorted_idx, sorted_keys, tile_prof);
+                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work, stats, j1, d_n, sorted_idx, sorted_keys, tile_prof, tile_order, tile_cost);
     } else {
         if (clamp) GSX_LAUNCH((k_composite_blocks<1, true>), grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
-                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work, stats, j1, d_n, sorted_idx, sorted_keys, tile_prof);
+                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work, stats, j1, d_n, sorted_idx, sorted_keys, tile_prof, tile_order, tile_cost);
         else GSX_LAUNCH((k_composite_blocks<1, false>), grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
-                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work, stats, j1, d_n, sorted_idx, sorted_keys, tile_prof);
+                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work, stats, j1, d_n, sorted_idx, sorted_keys, tile_prof, tile_order, tile_cost);
     }
     return hipGetLastError();
 }
