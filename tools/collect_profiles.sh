@@ -48,4 +48,11 @@ python3 tools/rank_alone.py --out $OUT/rank_alone.json > /dev/null 2> $OUT/rank_
 for N in 2 8; do
   GSX_BENCH_ONE_DEVICE=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29600+N)) bench.py --gpus $N --steps 20 --warmup 5 > $OUT/bench_ranks_on_one_gpu_world$N.json 2>> $OUT/bench.err
 done
+
+# 9. round 4: per-tile profile of the block compositor (index order against expensive-first), the A/B of that order on the bench
+#    line, what atomics on one address cost
+python3 tools/tile_profile.py > $OUT/tile_profile.txt 2>> $OUT/bench.err
+GSX_TILE_ORDER=0 python3 tools/tile_profile.py > $OUT/tile_profile_index_order.txt 2>> $OUT/bench.err
+tools/ab_env.sh GSX_TILE_ORDER=0 GSX_TILE_ORDER=1 GSX_TILE_ORDER=0 GSX_TILE_ORDER=1 > $OUT/ab_tile_order.txt 2>&1
+tools/bench_atomic > $OUT/bench_atomic.txt 2>&1
 for f in $OUT/bench.json $OUT/bench_driver_args.json $OUT/bench_index_world1_inflight2.json; do cut -c1-300 $f; done
