@@ -82,7 +82,7 @@ def parse_args():
                     "(rgb, T) bands, 16 bytes a pixel, in stream order")
     ap.add_argument("--pass-timing", default="project", help="project (the roofline kernel only; default) | all (every pass, adds "
                     "a few microseconds of stream gap per pass boundary)")
-    ap.add_argument("--frames-in-flight", type=int, default=2,
+    ap.add_argument("--frames-in-flight", type=int, default=None,
                     help="gsx_render_options.frames_in_flight of the headline loop at N=1 (the one-in-flight rate is reported beside it)")
     ap.add_argument("--dist-frames-in-flight", type=int, default=2, help="frames_in_flight of gsx_shard_render_frame (N > 1 / --force-dist): "
                     "every lane has its own communicator and stream, the verdict of a frame is read one call later")
@@ -95,7 +95,11 @@ def parse_args():
     ap.add_argument("--host-profile", action="store_true", help="print host wall time per exchange-protocol section (adds syncs; debug)")
     ap.add_argument("--pod", default="single/single", help="pod storage sh/cov3d: single|half|norm8|none / single|half "
                     "(reference default is norm8/half; the headline metric is quoted on the f32 pod)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    a.frames_in_flight_given = a.frames_in_flight is not None   # (an explicit value is taken as it is: no probe)
+    if a.frames_in_flight is None:
+        a.frames_in_flight = 2
+    return a
 
 
 def cpu_baseline(cfg, n_sample, pose=0):
@@ -367,7 +371,28 @@ def main():
     def set_opts(**kw):
         viewer.set_render_options(**dict(overrides, **kw))
 
-    if lanes > 1:
+    lanes_probe = None
+    if lanes > 1 and single and not args.frames_in_flight_given:
+        # Untimed probe, like the library's own speculation tuner: frames in flight pay when the device runs two hardware queues side
+        # by side.  One box of the pool (round 4) ran the two-lane loop at 0.6 frames/s and the one-lane loop at 1750 in the same
+        # process — whatever held its second queue, a run that lands on such a box should report what the path does with one
+        # frame in flight and say so, not that.  48 frames each way; the default stays when it is not clearly slower.
+        def probe(l):
+            set_opts(frames_in_flight=l)
+            for i in range(16):
+                frame(i)
+            renderer.poll()
+            t0 = time.perf_counter()
+            for i in range(16, 64):
+                frame(i)
+            renderer.poll()
+            return 48.0 / (time.perf_counter() - t0)
+        lanes_probe = {"frames_in_flight_1": round(probe(1), 1), f"frames_in_flight_{lanes}": round(probe(lanes), 1)}
+        if lanes_probe[f"frames_in_flight_{lanes}"] < 0.85 * lanes_probe["frames_in_flight_1"]:
+            lanes_probe["decision"] = f"this device does not overlap two streams ({lanes} frames in flight slower than one): the headline loop runs with ONE frame in flight"
+            lanes = 1
+        set_opts(frames_in_flight=lanes)
+    elif lanes > 1:
         set_opts(frames_in_flight=lanes)
     if lib_index:
         viewer.shard_stats(reset=True)
@@ -757,6 +782,9 @@ def main():
                 f"Throughput, not latency: with {lanes} frames in flight a frame spends about {lanes} x ms_per_step on the device from its first "
                 "kernel to its last (ms_per_step_one_frame_in_flight is the latency of a frame that has the device to itself).")
             out["frame_latency_ms_estimate"] = round(lanes * 1e3 * elapsed / args.steps, 4)
+            if lanes_probe is not None:
+                out["frames_in_flight_probe"] = dict(lanes_probe, note="untimed, before the timed region: 48 frames with one frame in flight and 48 "
+                                                     "with the default; the headline loop keeps the default unless it is below 0.85 x the one-lane rate")
         if elapsed_ul is not None:
             out["value_unspeculated_in_flight"] = round(args.steps / elapsed_ul, 3)
         if timing_u is not None:

@@ -393,3 +393,44 @@ def test_mask_evaluator_parity_and_render():
         ev.evaluate(None, "m")  # MaskOpTree::Reset
         v.render_frame(["m"])
         assert v.frame_stats("m")["n_visible"] > nvis
+
+
+def test_mask_box_without_division_on_the_boundary():
+    """k_mask_evaluate decides a box axis as |d| <= |scale| instead of |d / scale| <= 1 (mask_box_limit, gsx_internal.h): the same
+    verdict as the oracle's division on Gaussians placed exactly ON the faces, one ulp inside and outside, for scales that are
+    powers of two, just below one, denormal, negative, zero and infinite (identity rotations: d is the position itself)."""
+    from wgpu_3dgs_viewer_app_amd.mask import MaskEvaluator, MaskOp, MaskShape, MaskShapeKind, pack_program
+
+    scales = np.array([1.0, 0.99999994, 3.0, 2.5e-39, 1.1754944e-38, -2.0, 1.5, 0.0, np.inf, 6.5e37], np.float32)
+    pos_list = []
+    for s in scales:
+        a = np.abs(s)
+        for d in (a, np.nextafter(a, np.float32(np.inf)), np.nextafter(a, np.float32(0)), -a, -np.nextafter(a, np.float32(np.inf)), np.float32(0), np.float32(3e38)):
+            pos_list.append(d)
+    d = np.array([x for x in pos_list if np.isfinite(x)], np.float32)
+    n = d.size * 3
+    g = common.small_scene(n, 5)
+    with MultiModelViewer() as v:
+        v.add_model("m", n)
+        for axis in range(3):  # the boundary value on one axis, zero on the others
+            g["pos"][axis * d.size:(axis + 1) * d.size] = 0
+            g["pos"][axis * d.size:(axis + 1) * d.size, axis] = d
+        v.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g)
+        pos = oracle.convert(g)[0]
+        ev = MaskEvaluator(v)
+        mt_pos, mt_quat, mt_scale = np.zeros(3, np.float32), np.array([0, 0, 0, 1], np.float32), np.ones(3, np.float32)
+        v.update_model_transform("m", mt_pos, mt_quat, mt_scale)
+        differing = 0
+        for s in scales:
+            shapes = [MaskShape(MaskShapeKind.Box, pos=np.zeros(3, np.float32), scale=np.array([s, s, s], np.float32))]
+            op = MaskOp.parse("0")
+            ev.evaluate(op, "m", shapes)
+            ref = oracle.mask_evaluate(pos, mt_pos, mt_quat, mt_scale, *pack_program(op, shapes))
+            got = v.models["m"].gaussian_buffers.mask_buffer.download()
+            tail = (1 << (n & 31)) - 1 if n & 31 else 0xFFFFFFFF
+            got[-1] &= tail
+            ref[-1] &= tail
+            assert np.array_equal(got, ref), f"scale {s!r}: {np.flatnonzero(got != ref)}"
+            bits = (ref[np.arange(n) >> 5] >> (np.arange(n) & 31).astype(np.uint32)) & 1
+            differing += int(0 < int(bits.sum()) < n)
+        assert differing >= 5, "the cases must fall on both sides of the faces"

@@ -452,3 +452,31 @@ def test_no_raw_stream_calls_in_the_library():
             if raw.search(code):
                 bad.append(f"{name}:{ln}: {line.strip()}")
     assert not bad, "\n".join(bad)
+
+
+def test_box_mask_without_division_is_the_same_verdict():
+    """k_mask_evaluate decides |d / s| <= 1 as |d| <= mask_box_limit(s) (csrc/gsx_internal.h): correctly rounded float32 division,
+    as the oracle and the reference's shader do it, gives the same verdict on, next to and far from the faces — normal, denormal,
+    negative, zero, infinite and NaN scales."""
+    rng = np.random.default_rng(11)
+
+    def limit(s):  # restatement of mask_box_limit
+        out = np.abs(s)
+        out = np.where(np.isnan(s) | (s == 0), np.float32(-1), out)
+        return np.where(np.isinf(out), np.float32(3.402823466e+38), out).astype(np.float32)
+
+    s = (rng.standard_normal(400000).astype(np.float32) * np.float32(10) ** rng.integers(-44, 38, 400000).astype(np.float32)).astype(np.float32)
+    s = np.concatenate([s, np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, 2.0 ** -126, 2.0 ** -149, 3.4028235e38], np.float32)])
+    lim = limit(s)
+    a = np.abs(s)
+    with np.errstate(all="ignore"):
+        for k in (-3, -1, 0, 1, 3, None):
+            d = a.copy() if k is not None else (rng.standard_normal(s.size).astype(np.float32) * np.float32(2) ** rng.integers(-20, 20, s.size).astype(np.float32)).astype(np.float32)
+            for _ in range(abs(k or 0)):
+                d = np.nextafter(d, np.float32(np.inf) if k > 0 else np.float32(0))
+            for sign in (1, -1):
+                dd = (d * np.float32(sign)).astype(np.float32)
+                want = np.abs(dd / s) <= 1
+                got = np.abs(dd) <= lim
+                bad = np.flatnonzero(want != got)
+                assert bad.size == 0, (k, s[bad[:4]], dd[bad[:4]])

@@ -3,9 +3,12 @@
 # profiles/ afterwards.  rocprofv3 wraps python3 directly (no env / bash hop).  usage: tools/collect_profiles.sh r04
 set -u
 R=${1:-r04}
+PART=${2:-all}
+want() { [ "$PART" = all ] || [ "$PART" = "$1" ]; }
 OUT=gpurun_out/$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+if want A; then
 # 1. the bench line exactly as the driver runs it (PMC child passes, every timed loop, frame check, synchronised / steady / per-pass
 #    legs, robustness legs, full CPU baseline), and with the driver's short window
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
@@ -25,6 +28,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o p -- python3 bench.py --pmc-child --steps 4 --warmup 3 > $OUT/pmc_$c.log 2>&1
 done
 python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_summary.csv
+fi
+if want B; then
 # 5. the other workloads / pods / the index-sharded path on one rank (frames in flight 1, 2, 3)
 for w in cfg2 cfg3; do python3 bench.py --workload $w --no-cpu-baseline --no-pmc > $OUT/bench_$w.json 2>> $OUT/bench.err; done
 python3 bench.py --pod half/half --no-cpu-baseline --no-pmc --no-robustness --no-extra-legs > $OUT/bench_half_half.json 2>> $OUT/bench.err
@@ -40,6 +45,9 @@ tools/bench_sort 8460000 32 depth > $OUT/bench_sort.txt 2>&1
 tools/bench_sort 310000 32 depth >> $OUT/bench_sort.txt 2>&1
 tools/bench_sort 870000 8 >> $OUT/bench_sort.txt 2>&1
 python3 tools/shard_host_time.py > $OUT/shard_host_time.txt 2>&1
+python3 tools/bench_rows.py > $OUT/rows.json 2> $OUT/rows.err
+fi
+if want C; then
 # 8. round 4: what a kernel boundary costs on a stream / in a graph, what the launch traces do to a frame, every rank of an
 #    N-rank frame alone on the GPU (the predicted 2 / 4 / 8-GPU rates), the bench as the driver launches it with N ranks on one GPU
 tools/bench_launch > $OUT/bench_launch.txt 2>&1
@@ -55,4 +63,6 @@ python3 tools/tile_profile.py > $OUT/tile_profile.txt 2>> $OUT/bench.err
 GSX_TILE_ORDER=0 python3 tools/tile_profile.py > $OUT/tile_profile_index_order.txt 2>> $OUT/bench.err
 tools/ab_env.sh GSX_TILE_ORDER=0 GSX_TILE_ORDER=1 GSX_TILE_ORDER=0 GSX_TILE_ORDER=1 > $OUT/ab_tile_order.txt 2>&1
 tools/bench_atomic > $OUT/bench_atomic.txt 2>&1
-for f in $OUT/bench.json $OUT/bench_driver_args.json $OUT/bench_index_world1_inflight2.json; do cut -c1-300 $f; done
+python3 tools/rank_alone.py --worlds 8 --scenes open_sky --lanes 1 --balance 0 --out $OUT/rank_alone_equal_bands.json > /dev/null 2>> $OUT/rank_alone.err
+fi
+for f in $OUT/bench.json $OUT/bench_driver_args.json $OUT/bench_index_world1_inflight2.json; do [ -s $f ] && cut -c1-300 $f; done

@@ -142,6 +142,7 @@ class ReplayTransport:
         return 0
 
 
+BALANCE = True   # --balance 0: equal bands (the A/B of the balanced ones)
 SHARDS = {}   # (world, rank) -> the shard's Gaussians (generated once per world)
 
 
@@ -160,6 +161,8 @@ def make_viewer(cfg, rank, world, open_sky, lanes=1):
         MaskEvaluator(v).evaluate(MaskOp.parse("0"), "m", sky)
     v.update_gaussian_transform(1.0, GaussianDisplayMode.Splat, GaussianShDegree.new(sh), False)
     v.shard_set_gather_root(0)
+    if not BALANCE:
+        v.shard_set_balance(False)   # the A/B: equal bands of tile rows, as until round 3
     return v, (n + world - 1) // world
 
 
@@ -295,7 +298,10 @@ def main():
     ap.add_argument("--unspeculated-frames", type=int, default=8)
     ap.add_argument("--lanes", default="1,2", help="frames in flight of the replayed rank (and of the recording)")
     ap.add_argument("--out", default="")
+    ap.add_argument("--balance", type=int, default=1, help="0: equal bands of tile rows (gsx_shard_set_balance(0)) — the A/B of the balanced bands")
     a = ap.parse_args()
+    global BALANCE
+    BALANCE = bool(a.balance)
     cfg = scene.CONFIGS[a.workload]
     n, sh, w, h, seed = cfg
     orbit = [camera.PrecomputedCamera(camera.orbit_pose(k), w / h) for k in range(240)]
@@ -304,7 +310,7 @@ def main():
                       "N-rank run (threads, one GPU); predicted fps = 1 / (slowest rank's ms alone + busiest rank's wire bytes / (7 x 153 GB/s)); "
                       "the transport's callbacks are Python (their host time is inside ms_per_frame_alone — an upper bound — and hides behind the "
                       "other frame's device work with two frames in flight)",
-               single_gpu_fps={}, runs=[])
+               balanced_bands=bool(a.balance), single_gpu_fps={}, runs=[])
     lanes_list = [int(x) for x in a.lanes.split(",")]
     for sc in a.scenes.split(","):
         for spec in (1, 0):

@@ -579,6 +579,7 @@ gsx_status gsx_mask_evaluate(gsx_viewer* v, const char* key, const gsx_mask_op* 
         memcpy(prog.shapes[s].pos, shapes[s].pos, sizeof(float) * 3);
         quat_to_rows(shapes[s].quat_xyzw, prog.shapes[s].rot);
         memcpy(prog.shapes[s].scale, shapes[s].scale, sizeof(float) * 3);
+        for (int c = 0; c < 3; ++c) prog.shapes[s].box_lim[c] = mask_box_limit(shapes[s].scale[c]);
     }
     memcpy(prog.ops, ops, sizeof(gsx_mask_op) * n_ops);
     HIPCHK(launch_mask_evaluate(v->stream, m->pc.as<float4>(), (uint32_t)m->n, prog, m->mask.as<uint32_t>()));

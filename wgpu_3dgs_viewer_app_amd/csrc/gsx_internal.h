@@ -533,7 +533,17 @@ struct MaskShapeConsts {
     float pos[3];
     float rot[9];  // row-major rotation of the shape
     float scale[3];
+    float box_lim[3];  // box: |d / scale| <= 1 decided without the division (mask_box_limit)
 };
+// The box test of the reference's mask (|d / s| <= 1 per axis, d / s correctly rounded) as ONE compare |d| <= lim:
+// RN(|d| / |s|) <= 1  <=>  |d| / |s| <= 1 + 2^-24 (the tie rounds to even, 1.0)  <=>  |d| <= |s|, because the float next above |s| is
+// |s| + ulp(|s|) with ulp(|s|) / |s| > 2^-24 (denormal |s| included).  s = 0 or NaN: the quotient is inf or NaN, never inside (-1);
+// s = +-inf: every finite d gives 0, inside (FLT_MAX; d = inf gives NaN: outside either way).
+inline float mask_box_limit(float s) {
+    if (s != s || s == 0.0f) return -1.0f;
+    const float a = s < 0.0f ? -s : s;
+    return a > 3.402823466e+38f ? 3.402823466e+38f : a;
+}
 struct MaskProgram {
     float m_rot[9], m_pos[3], m_scale[3];  // model transform
     uint32_t n_shapes, n_ops;

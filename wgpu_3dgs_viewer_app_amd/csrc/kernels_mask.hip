@@ -27,11 +27,18 @@ __device__ inline bool mk_keep(const float4 p, const MaskProgram& prog) {
         const MaskShapeConsts& sh = prog.shapes[s];
         const float rx = wx - sh.pos[0], ry = wy - sh.pos[1], rz = wz - sh.pos[2];
         // inverse rotation = transpose: local_c = column c of R . rel
-        const float q0 = mk_dot3(sh.rot[0], sh.rot[3], sh.rot[6], rx, ry, rz) / sh.scale[0];
-        const float q1 = mk_dot3(sh.rot[1], sh.rot[4], sh.rot[7], rx, ry, rz) / sh.scale[1];
-        const float q2 = mk_dot3(sh.rot[2], sh.rot[5], sh.rot[8], rx, ry, rz) / sh.scale[2];
-        bool in = sh.kind == GSX_MASK_BOX ? (fabsf(q0) <= 1.0f && fabsf(q1) <= 1.0f && fabsf(q2) <= 1.0f)
-                                          : ((q0 * q0 + q1 * q1) + q2 * q2 <= 1.0f);
+        const float d0 = mk_dot3(sh.rot[0], sh.rot[3], sh.rot[6], rx, ry, rz);
+        const float d1 = mk_dot3(sh.rot[1], sh.rot[4], sh.rot[7], rx, ry, rz);
+        const float d2 = mk_dot3(sh.rot[2], sh.rot[5], sh.rot[8], rx, ry, rz);
+        bool in;
+        if (sh.kind == GSX_MASK_BOX) {
+            // |d / scale| <= 1 without the division — the same verdict bit for bit (mask_box_limit, gsx_internal.h); the kernel is
+            // bound by vector issue as much as by HBM, and an IEEE division is ten instructions
+            in = fabsf(d0) <= sh.box_lim[0] && fabsf(d1) <= sh.box_lim[1] && fabsf(d2) <= sh.box_lim[2];
+        } else {
+            const float q0 = d0 / sh.scale[0], q1 = d1 / sh.scale[1], q2 = d2 / sh.scale[2];
+            in = (q0 * q0 + q1 * q1) + q2 * q2 <= 1.0f;
+        }
         inside |= (in ? 1u : 0u) << s;
     }
     // postfix evaluation, the stack is a bit string (depth <= 32)
