@@ -99,3 +99,36 @@ def test_dispatch_order_is_a_schedule_not_data(monkeypatch, speculative):
         assert np.array_equal(a, b), f"frame {k} ({size}, {keys}, pose {pose}): L-inf {np.abs(a - b).max()}"
     plain.close()
     ordered.close()
+
+
+@pytest.mark.parametrize("speculative", [0, 1])
+def test_records_carried_through_the_block_sort_change_nothing(monkeypatch, speculative):
+    """Models whose block lists are long have the lists' {rect, key, index} records carried through the block sort's write-out, and the
+    compositor reads its candidates side by side (k_composite_blocks<.., SORTED>); GSX_SORTED_RECORDS=1 / 0 forces / forbids it.
+    Same pixels bit for bit: depth slabs, the repair round, layered models, a translucent scene (nothing saturates: the case the path is
+    for), and the viewer that decides by itself from the statistics of earlier frames."""
+    g = common.small_scene(60000, 406, scale_mul=20.0)
+    thin = g.copy()
+    thin["color"][:, 3] = 3   # next to transparent: lists stay long, nothing saturates
+    g2 = common.small_scene(20000, 407, scale_mul=10.0)
+    viewers = []
+    for env in ("0", "1", None):
+        if env is None:
+            monkeypatch.delenv("GSX_SORTED_RECORDS", raising=False)
+        else:
+            monkeypatch.setenv("GSX_SORTED_RECORDS", env)
+        v = MultiModelViewer()
+        v.set_render_options(speculative=speculative, min_slab=8192)
+        for key, data in (("m", g), ("thin", thin), ("near", g2)):
+            v.add_model(key, data.shape[0])
+            v.models[key].gaussian_buffers.gaussians_buffer.update_range(0, data)
+        viewers.append(v)
+    monkeypatch.delenv("GSX_SORTED_RECORDS", raising=False)
+    plan = [((1920, 1080), ["m"], p) for p in (7, 8, 9, 10)] + [((1920, 1080), ["thin"], p) for p in (10, 11, 12, 13, 14, 15, 16, 17, 18)] + \
+           [((1000, 600), ["m", "near"], p) for p in (20, 21, 22)] + [((1920, 1080), ["thin", "near"], p) for p in (30, 31, 90)]
+    for k, (size, keys, pose) in enumerate(plan):
+        frames = [_frame(v, pose, keys, size) for v in viewers]
+        assert np.array_equal(frames[0], frames[1]), f"frame {k} ({size}, {keys}, pose {pose}): L-inf {np.abs(frames[0] - frames[1]).max()}"
+        assert np.array_equal(frames[0], frames[2]), f"frame {k}: the viewer that decides by itself"
+    for v in viewers:
+        v.close()

@@ -12,13 +12,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from wgpu_3dgs_viewer_app_amd import _lib, camera, scene  # noqa: E402
 from wgpu_3dgs_viewer_app_amd.viewer import GaussianDisplayMode, GaussianShDegree, MultiModelViewer  # noqa: E402
 
-n, sh, w, h, seed = scene.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "cfg4"]
+n, sh, w, h, seed = scene.CONFIGS[sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] != "open_sky" else "cfg4"]
 g = scene.synthetic_gaussians(n, seed, sh)
 v = MultiModelViewer()
 v.add_model("m", n)
 v.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g)
 del g
 v.update_gaussian_transform(1.0, GaussianDisplayMode.Splat, GaussianShDegree.new(sh), False)
+if "open_sky" in sys.argv[1:]:   # bench.py's robustness scene: a mask box keeps the Gaussians with y <= 0.5, the screen above the horizon stays open
+    from wgpu_3dgs_viewer_app_amd.mask import MaskEvaluator, MaskOp, MaskShape, MaskShapeKind
+    MaskEvaluator(v).evaluate(MaskOp.parse("0"), "m", [MaskShape(MaskShapeKind.Box, pos=np.array([0.0, -4.5, 0.0], np.float32), scale=np.array([10.0, 5.0, 10.0], np.float32))])
 tx, ty = (w + 15) // 16, (h + 15) // 16
 for spec in (1, 0):
     v.set_render_options(speculative=spec)
@@ -63,6 +66,8 @@ for spec in (1, 0):
     print("   tiles starting per 10 us:", hist.tolist())
     hist, _ = np.histogram(end[dur > 0], bins=np.arange(0, 200, 10))
     print("   tiles ending per 10 us:  ", hist.tolist())
+    rows = [(int(r), round(float(dur[r * tx:(r + 1) * tx].max()), 1), int(walked[r * tx:(r + 1) * tx].max()), int(taken[r * tx:(r + 1) * tx].max())) for r in range(ty)]
+    print("   per tile row (row, slowest tile us, most chunks walked, most takers):", [r for r in rows if r[1] > 60])
     late = dur > np.percentile(dur, 99)
     print(f"   the slowest 1 % of the tiles start at {np.percentile((((start - t0) & 0xFFFFFFFF) * 0.01)[late], [0, 50, 100])} us (min / median / max)")
 v.close()

@@ -631,6 +631,10 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
             m->n_sorted = m->h_counters->n_sorted;
         }
         note_overflow(m);  // a free-running loop learns here that some earlier frame spilled: larger pair buffers from now on
+        // long block lists (a scene where little saturates): the block sort carries the lists' records along (k_composite_blocks
+        // SORTED); with hysteresis, from whatever frame's statistics arrived last — either way the pixels are the same
+        const uint64_t per_tile = (uint64_t)m->h_counters->n_entries_total / std::max<uint32_t>(n_tiles, 1u);
+        m->lists_long = m->lists_long ? per_tile > 500u : per_tile > 900u;
     }
     std::vector<uint32_t> bounds;
     const bool imported_windows = m->use_imported && m->has_window && progressive;
@@ -737,6 +741,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
                         const WindowPyramid* min_ends = nullptr, bool table_ready = false) -> gsx_status {
         // the very first slab of the frame sees no saturated tile: plain rectangle areas
         const uint32_t* done_in = later ? done : nullptr;
+        bool sorted_records = false;  // block lists: the compositor's candidates travel through the block sort (long lists)
         // a slab of S splats can produce at most S * n_tiles entries; size the sort launch by the smaller bound
         const uint32_t slab_cap = (uint32_t)std::min<uint64_t>(cap, (uint64_t)(j1 - j0) * std::min<uint64_t>(owned_tiles, 1u << 16));
         if (blocks) {
@@ -769,7 +774,13 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
                 const uint32_t block_cap = (uint32_t)std::min<uint64_t>(cap, (uint64_t)(j1 - j0) * 256u);
                 // (<= 256 blocks: ONE digit, and the block ranges are the scan of its histogram — no k_tile_ranges launch;
                 //  k_block_table zeroed the ranges, which is what stays when the slab made no entry at all)
-                HIPCHK(launch_radix_sort(v->stream, rb, block_cap, &dc->n_entries, block_bits, false, false, block_bits <= 8 ? m->ranges.as<uint2>() : nullptr));
+                // (<= 256 blocks: ONE digit, and the block ranges are the scan of its histogram — no k_tile_ranges launch;
+                //  k_block_table zeroed the ranges, which is what stays when the slab made no entry at all)
+                // sorted_records: the write-out also carries every entry's {rect, key, index} record along
+                sorted_records = block_bits <= 8 && (v->sorted_records >= 0 ? v->sorted_records == 1 : m->lists_long);
+                if (sorted_records) HIPCHK(m->brec_sorted.ensure(sizeof(uint4) * (size_t)cap));
+                HIPCHK(launch_radix_sort(v->stream, rb, block_cap, &dc->n_entries, block_bits, false, false, block_bits <= 8 ? m->ranges.as<uint2>() : nullptr,
+                                         sorted_records ? m->srect.as<uint4>() : nullptr, sorted_records ? m->brec_sorted.as<uint4>() : nullptr));
                 m->tile_keys = m->tk_out.as<uint32_t>();
                 m->tile_list = m->tv_out.as<uint32_t>();
                 v->pass_launches[GSX_PASS_TILE_SORT] += 1;
@@ -828,7 +839,8 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
             if (blocks) {
                 // (a slab whose entries did not fit the pair buffers — decided on the device — has its tail composited pair-free by the
                 //  same launch: the frame is complete without a host round trip)
-                HIPCHK(launch_composite_blocks(v->stream, m->fc, m->ranges.as<uint2>(), m->tile_list, m->srect.as<uint4>(), m->rec(), fb_ptr(v),
+                HIPCHK(launch_composite_blocks(v->stream, m->fc, m->ranges.as<uint2>(), sorted_records ? nullptr : m->tile_list,
+                                               sorted_records ? m->brec_sorted.as<uint4>() : m->srect.as<uint4>(), m->rec(), fb_ptr(v),
                                                later, done, row_words, done_count, tile_sat, win, row_lo, row_hi, bsx, bsy, row_work, dc, j1,
                                                d_n, m->sorted_idx, m->sk_out.as<uint32_t>(),
                                                (v->tile_profile && slab_index == 0) ? v->tile_prof.as<uint4>() : nullptr,

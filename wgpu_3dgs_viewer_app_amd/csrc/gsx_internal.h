@@ -211,7 +211,8 @@ void radix_set_rank_override(int mode);  // -1 none | 0 ballot matching | 1 lane
 // n sizes the launch; d_n (nullable) is the real element count on the device (<= n).
 // ranges_out (one-digit sorts only: bits <= 8): [first, end) of every key value in the sorted output, (0, 0) for absent ones
 hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n, uint32_t* d_n, int bits, bool iota_values,
-                             bool skip_culled = false, uint2* ranges_out = nullptr);  // skip_culled: keys == 0xFFFFFFFF do not exist; *d_n receives the count that do
+                             bool skip_culled = false, uint2* ranges_out = nullptr,  // skip_culled: keys == 0xFFFFFFFF do not exist; *d_n receives the count that do
+                             const uint4* payload_in = nullptr, uint4* payload_out = nullptr);  // the last pass also writes payload_out[sorted position] = payload_in[value]
 
 // Device-resident per-model frame statistics; the host mirrors them lazily (no sync inside a frame).
 struct SlabStats {
@@ -412,7 +413,7 @@ hipError_t launch_block_bin(hipStream_t s, uint32_t j0, uint32_t j1, const uint3
                             const uint2* window, uint32_t tiles_x, uint32_t tiles_y, uint32_t bsx, uint32_t bsy, uint4* table,
                             uint2* pairs, uint2* ranges, const ZeroJob& zero = ZeroJob{} /* words the table kernel zeroes on the way */,
                             bool table_ready = false /* table and ranges are in place already (launch_spec_verify built them) */);
-hipError_t launch_composite_blocks(hipStream_t s, const FrameConsts& f, const uint2* ranges, const uint32_t* list, const uint4* brec,
+hipError_t launch_composite_blocks(hipStream_t s, const FrameConsts& f, const uint2* ranges, const uint32_t* list /* nullptr: brec is in list order */, const uint4* brec,
                                    const Records& rec, float4* fb, bool carry, uint32_t* done, uint32_t row_words,
                                    uint32_t* d_done_count, uint32_t* tile_sat, const uint2* window, uint32_t row_lo,
                                    uint32_t row_hi, uint32_t bsx, uint32_t bsy, uint32_t* row_work /* as launch_composite */,

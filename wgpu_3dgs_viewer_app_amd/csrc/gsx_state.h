@@ -120,6 +120,8 @@ struct Model {
     DevBuf cnt, block_sums, srect;              // per slab: tile counts in depth order, scan partials, tile rects
     DevBuf block_vis;                           // per-workgroup visible counts of the projection pass
     DevBuf tp_src, tp_a, tp_b, tk_out, tv_out, tsort_ws;  // tile pairs: emitted, scratch, sorted (split), workspace
+    DevBuf brec_sorted;                         // block lists: the {rect, key, index} records in list order (the block sort's write-out gathers them)
+    bool lists_long = false;                    // ... for models whose lists are long (decided from the last frame statistics that arrived)
     DevBuf ranges;
     DevBuf tile_order;                          // block compositor's dispatch order: {threshold, tile_cost[n_tiles], tile_order[n_tiles]} (tile_order_job)
     uint32_t tile_order_tiles = 0;              // the tile count it is laid out for
@@ -378,6 +380,7 @@ struct gsx_viewer {
     DevBuf tile_prof;                    // GSX_TILE_PROFILE: what every tile of the LAST block-compositor launch of a frame's first slab cost
     bool tile_profile = false;
     bool tile_order_on = true;           // GSX_TILE_ORDER=0: the block compositor takes its tiles in index order (A/B)
+    int sorted_records = -1;             // GSX_SORTED_RECORDS=0 / 1: never / always carry the block lists' records through the block sort (-1: by list length)
     gsx::LaunchTrace* trace = nullptr;  // owned; created by the first TraceScope on this viewer (gsx_graph.cpp)
 };
 

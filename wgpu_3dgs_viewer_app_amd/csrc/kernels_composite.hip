@@ -236,7 +236,7 @@ __device__ __forceinline__ uint32_t tile_cost_units(uint32_t chunks, uint32_t ta
 constexpr int kCand = 1;                         // candidates per lane and iteration (1 / 2 / 3 measured alike, round 2)
 constexpr uint32_t kChunk = 128u * kCand;
 
-template <int MODE, bool CLAMP>
+template <int MODE, bool CLAMP, bool SORTED /* brec is in list order (below) */>
 __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, const uint2* __restrict__ ranges,
                                                            const uint32_t* __restrict__ list, const uint4* __restrict__ brec,
                                                            const float4* __restrict__ rec_a, const float4* __restrict__ rec_b,
@@ -305,6 +305,10 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
     // stage 1 registers: the next chunk's candidates; stage 2 registers: the gathered takers of the chunk before
     // (the list -> brec chain is split over two iterations: a load whose address is another load's result would stall the
     // wave before the blend it is meant to hide under)
+    // SORTED: brec is in LIST order — the block sort's write-out carried the records along (kernels_sort.hip), a chunk's candidates
+    // are 2 KB side by side, no list -> brec chain.  The frame chooses it for models whose lists are long (gsx_frame.cpp): a scene
+    // where nothing saturates walks ~1700 entries per tile, one dependent 64-byte line each (translucent leg: 84 -> 112 fps);
+    // on cfg4's ~110 per tile the 16 bytes more per entry the sort then moves cost what the compositor gains.
     uint4 cand[kCand];
     bool cand_ok[kCand];
     uint32_t ent[kCand];   // list entries of the chunk after the candidates'
@@ -314,10 +318,15 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
         const uint32_t at = range.x + 128u * k + tid;
         cand_ok[k] = at < range.y;
         cand[k] = make_uint4(0u, 0u, 0u, 0u);
-        if (cand_ok[k]) cand[k] = brec[list[at]];
-        ent_ok[k] = at + kChunk < range.y;
+        ent_ok[k] = false;
         ent[k] = 0;
-        if (ent_ok[k]) ent[k] = list[at + kChunk];
+        if (SORTED) {
+            if (cand_ok[k]) cand[k] = brec[at];
+        } else {
+            if (cand_ok[k]) cand[k] = brec[list[at]];
+            ent_ok[k] = at + kChunk < range.y;
+            if (ent_ok[k]) ent[k] = list[at + kChunk];
+        }
     }
     bool g_take[kCand];
     uint32_t g_my[kCand], g_cnt[kCand];
@@ -372,11 +381,17 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
         // candidates of the chunk after (their list entries arrived an iteration ago), list entries of the chunk after that
 #pragma unroll
         for (int k = 0; k < kCand; ++k) {
-            cand_ok[k] = ent_ok[k];
-            if (cand_ok[k]) cand[k] = brec[ent[k]];
-            const uint32_t nn = base + 2u * kChunk + 128u * k + tid;
-            ent_ok[k] = nn < range.y;
-            if (ent_ok[k]) ent[k] = list[nn];
+            if (SORTED) {
+                const uint32_t nn = base + kChunk + 128u * k + tid;
+                cand_ok[k] = nn < range.y;
+                if (cand_ok[k]) cand[k] = brec[nn];
+            } else {
+                cand_ok[k] = ent_ok[k];
+                if (cand_ok[k]) cand[k] = brec[ent[k]];
+                const uint32_t nn = base + 2u * kChunk + 128u * k + tid;
+                ent_ok[k] = nn < range.y;
+                if (ent_ok[k]) ent[k] = list[nn];
+            }
         }
         taken += cnt;
         if (cnt) blend_batch<MODE, kGroupBlocks, CLAMP>(f, cnt, s_mean, s_conic, s_rgb, pxf, pyf, lim0, lim1, T, C0, C1, C2, stop_key);
@@ -586,17 +601,19 @@ hipError_t launch_composite_blocks(hipStream_t s, const FrameConsts& f, const ui
     dim3 grid(f.tiles_x * f.tiles_y), block(128);
     const uint32_t blocks_x = (f.tiles_x + (1u << bsx) - 1u) >> bsx;
     const bool clamp = f.alpha_max < 1.0f || f.alpha_min > 0.0f;  // (blend_batch: the default constants need no clamping)
+    const bool sorted = list == nullptr;                          // brec in list order (the block sort gathered it)
+#define GSX_CB(M, C, S)                                                                                                              \
+    GSX_LAUNCH((k_composite_blocks<M, C, S>), grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, \
+               d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work, stats, j1, d_n, sorted_idx, sorted_keys, tile_prof,    \
+               tile_order, tile_cost)
     if (f.display_mode == GSX_DISPLAY_SPLAT) {
-        if (clamp) GSX_LAUNCH((k_composite_blocks<0, true>), grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
-                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work, stats, j1, d_n, sorted_idx, sorted_keys, tile_prof, tile_order, tile_cost);
-        else GSX_LAUNCH((k_composite_blocks<0, false>), grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
-                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work, stats, j1, d_n, sorted_idx, sorted_keys, tile_prof, tile_order, tile_cost);
+        if (clamp) { if (sorted) GSX_CB(0, true, true); else GSX_CB(0, true, false); }
+        else { if (sorted) GSX_CB(0, false, true); else GSX_CB(0, false, false); }
     } else {
-        if (clamp) GSX_LAUNCH((k_composite_blocks<1, true>), grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
-                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work, stats, j1, d_n, sorted_idx, sorted_keys, tile_prof, tile_order, tile_cost);
-        else GSX_LAUNCH((k_composite_blocks<1, false>), grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done,
-                           row_words, d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work, stats, j1, d_n, sorted_idx, sorted_keys, tile_prof, tile_order, tile_cost);
+        if (clamp) { if (sorted) GSX_CB(1, true, true); else GSX_CB(1, true, false); }
+        else { if (sorted) GSX_CB(1, false, true); else GSX_CB(1, false, false); }
     }
+#undef GSX_CB
     return hipGetLastError();
 }
 

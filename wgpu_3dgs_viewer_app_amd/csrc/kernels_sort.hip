@@ -195,7 +195,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t
                                                                    u64* __restrict__ status, uint32_t epoch,
                                                                    uint32_t* __restrict__ ghist_clear /* last pass: all rows */,
                                                                    uint32_t ghist_clear_words, uint32_t* __restrict__ d_n_out,
-                                                                   uint2* __restrict__ ranges_out) {
+                                                                   uint2* __restrict__ ranges_out,
+                                                                   const uint4* __restrict__ payload_in, uint4* __restrict__ payload_out) {
     __shared__ uint2 s_pairs[kRadixTile];       // tile reordered by digit
     __shared__ uint32_t s_tile_n;               // elements of the tile that exist (SKIP)
     __shared__ uint32_t cnt[kSweepWaves][256];  // per-wave digit counts, then per-wave local offsets
@@ -404,6 +405,9 @@ __global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t
                 } else {
                     keys_out[o] = kv.x;
                     vals_out[o] = kv.y;
+                    // (the block sort: the 16-byte record its value names travels with it, so that whoever walks the sorted list
+                    //  reads records side by side instead of one dependent gather per entry — k_composite_blocks)
+                    if (payload_out) payload_out[o] = payload_in[kv.y];
                 }
             }
         }
@@ -520,7 +524,7 @@ static bool use_lane_ordered() {
 }
 
 hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n, uint32_t* d_n, int bits, bool iota_values,
-                             bool skip_culled, uint2* ranges_out) {
+                             bool skip_culled, uint2* ranges_out, const uint4* payload_in, uint4* payload_out) {
     if (n == 0) return hipSuccess;
     const int passes = (bits + 7) / 8;
     if (ranges_out && passes != 1) return hipErrorInvalidValue;  // key ranges fall out of a ONE-digit sort only
@@ -557,7 +561,8 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
         const uint32_t epoch = (g_epoch.fetch_add(1, std::memory_order_relaxed) & 0x1FFFFFFFu) | (1u << 29);  // 30 bits, never 0
 #define GSX_SWEEP_ARGS(DN, DNOUT)                                                                                        \
     dim3(grid), dim3(kSweepThreads), 0, s, buf.keys_src, buf.vals_src, pin, buf.keys_out, buf.vals_out, pout, n, DN, shift, dmask, \
-        ghist + 256 * p, ticket, status, epoch, ghist, last ? 256u * (uint32_t)passes : 0u, DNOUT, ranges_out
+        ghist + 256 * p, ticket, status, epoch, ghist, last ? 256u * (uint32_t)passes : 0u, DNOUT, ranges_out,                  \
+        last ? payload_in : nullptr, last ? payload_out : nullptr
 #define GSX_SWEEP(IN, OUT)                                                                                               \
     do {                                                                                                                 \
         if (lane_ordered)                                                                                                \
