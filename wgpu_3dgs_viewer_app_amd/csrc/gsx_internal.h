@@ -68,14 +68,21 @@ __host__ __device__ inline uint32_t band_rows_max(const BandEdges& b) {
 // The pieces are gathered at a common stride (the tallest band's piece); a rank sends only what its own band needs.
 constexpr uint32_t kShardExtraWords = 8 + kMaxRanks;
 constexpr uint32_t kBalanceKeepPermille = 1150;  // bands whose busiest rank carries at most 1.15 x the mean work are left alone
-// Band balancing: what a tile cost this frame, in units of one list candidate looked at and passed by.  By the block compositor's
-// instruction counts a candidate that is TAKEN (blended into 256 pixels) costs ~50 of those; an entry of the tile's list has cost its
-// share of the depth sort, the binning and the list sort before any tile looks at it (cfg4: ~300 us for 0.87 M block entries against
-// 223 us for the compositor's ~20 M candidates and ~5 M takers: ~440 units an entry, spread over the tiles that share the list); a
-// tile that finds nothing still reads and writes its pixels.
+// Band balancing: what a tile cost this frame.  Unit: one list candidate looked at and passed by, in whole-chip throughput — by the
+// block compositor's instruction counts a candidate that is TAKEN (blended into 256 pixels) costs ~50 of those; an entry of the tile's
+// list has cost its share of the depth sort, the binning and the list sort before any tile looks at it (cfg4: ~300 us for 0.87 M block
+// entries against 223 us for the compositor's ~20 M candidates and ~5 M takers: ~440 units an entry, spread over the tiles that share
+// the list); a tile that finds nothing still reads and writes its pixels.  But a band is not done when its share of the chip's
+// throughput is used up: it is done when its LONGEST tile is, and a tile's walk is serial (0.95 us per 128 candidates against 0.11 us
+// per taker, tools/tile_profile.py).  So the walk counts kWalkWork times: the rows whose tiles walk long lists and take little (an open
+// horizon) then weigh what they cost in time, the cut goes through them, and a band cut through a block row has shorter lists
+// (entries are clipped to the band).  Measured with every rank alone on the GPU (tools/rank_alone.py, world 8, open sky): slowest
+// rank 1.11 ms with kWalkWork = 1 (worse than equal bands: 0.94), 0.96-0.97 with 12, 0.91 / 1.08 with 24 / 48; unspeculated
+// 1.37 -> 0.96 ms (equal bands: 1.39).
 constexpr uint32_t kTileWork = 256;
+constexpr uint32_t kWalkWork = 12;
 __host__ __device__ inline uint32_t tile_work(uint32_t walked, uint32_t taken, uint32_t list_len, uint32_t tiles_per_list) {
-    return kTileWork + walked + 50u * taken + (440u * list_len) / (tiles_per_list ? tiles_per_list : 1u);
+    return kTileWork + kWalkWork * walked + 50u * taken + (440u * list_len) / (tiles_per_list ? tiles_per_list : 1u);
 }
 __host__ __device__ inline uint32_t feedback_stride(const BandEdges& b, uint32_t tiles_x) { return kShardExtraWords + band_rows_max(b) * (tiles_x + 1u); }
 __host__ __device__ inline uint32_t feedback_words(const BandEdges& b, uint32_t tiles_x, uint32_t g) { return kShardExtraWords + (b.e[g + 1u] - b.e[g]) * (tiles_x + 1u); }
