@@ -260,7 +260,10 @@ struct ZeroJob {
     uint32_t* order_buf = nullptr;
     uint32_t order_tiles = 0;
 };
-constexpr uint32_t kTileOrderMax = 65536;   // tiles (tile_order_job keeps 3 words of LDS per 64 tiles: within k_block_counts' 4096)
+// Frames of more tiles keep index order: at 3840 x 2160 (32 400 tiles: ten dispatch rounds, the tail is a smaller share of the launch) the
+// order gains little and the job's one workgroup takes ~20 us per model — cfg5 (four models) measured 6 % slower with it.
+// (tile_order_job keeps 3 words of LDS per 64 tiles: within k_block_counts' 4096)
+constexpr uint32_t kTileOrderMax = 16384;
 constexpr uint32_t tile_order_lds_words(uint32_t n_tiles) { return 3u * ((n_tiles + 63u) / 64u) + 32u; }
 
 #ifdef __HIPCC__
