@@ -132,3 +132,19 @@ def test_records_carried_through_the_block_sort_change_nothing(monkeypatch, spec
         assert np.array_equal(frames[0], frames[2]), f"frame {k}: the viewer that decides by itself"
     for v in viewers:
         v.close()
+
+
+def test_block_lists_under_the_library_validator(monkeypatch):
+    """GSX_VALIDATE=1 (read when a viewer is created) checks every range and list index the compositor will dereference before each
+    launch.  Speculated frames with depth slabs and repair rounds that find nothing to repair: the repair slab's ranges must not keep
+    the main round's (regression, round 4: the fused verification left them when no tile needed a repair)."""
+    monkeypatch.setenv("GSX_VALIDATE", "1")
+    g = common.small_scene(40000, 401, scale_mul=8.0)
+    v = MultiModelViewer()
+    v.set_render_options(speculative=1, min_slab=4096)
+    v.add_model("m", g.shape[0])
+    v.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g)
+    for size in ((256, 176), (1920, 1080)):
+        for pose in (3, 4, 5, 6, 120, 121, 122, 122, 40):
+            _frame(v, pose, ["m"], size)
+    v.close()

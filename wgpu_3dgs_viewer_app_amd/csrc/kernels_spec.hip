@@ -216,7 +216,13 @@ __global__ __launch_bounds__(1024) void k_spec_verify_fused(const uint2* __restr
         // {seq, tiles that need the repair round} to pinned host memory: one system-scope 64-bit store, polled by gsx_render
         if (host_verdict) __hip_atomic_store(host_verdict, ((unsigned long long)seq << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (total == 0) return;  // the repair round's kernels fall through on *d_need == 0
+    if (total == 0) {  // the repair round's kernels fall through on *d_need == 0
+        // (nothing will rebuild the repair slab's block table; its ranges must not keep the main round's — every tile's repair window
+        //  is empty, so nothing would be read through them, but GSX_VALIDATE checks what is there)
+        if (vt.table)
+            for (uint32_t b = threadIdx.x; b < vt.grid.blocks_x * vt.grid.blocks_y; b += 1024u) vt.ranges[b] = make_uint2(0u, 0u);
+        return;
+    }
     if (vt.pyr2_data) build_window_pyramid<1024>(win2, vt.pyr2, vt.pyr2_data, nullptr, lds);
     if (vt.table) {
         const uint32_t n_blocks = vt.grid.blocks_x * vt.grid.blocks_y;
