@@ -41,7 +41,14 @@ CASES = [(2, []), (2, ["--dist-frames-in-flight", "1"]), (3, []), (2, ["--shard-
 @pytest.mark.parametrize("case", range(len(CASES)), ids=[f"world{w}" + "".join(x.replace("--", "-") for x in e) for w, e in CASES])
 def test_bench_with_ranks_as_processes(case):
     world, extra = CASES[case]
-    d = _launch(world, extra, 29531 + 3 * case + (os.getpid() % 200))   # a rendezvous port of its own per case and per pytest process
+    port = 29531 + 3 * case + (os.getpid() % 200)   # a rendezvous port of its own per case and per pytest process
+    try:
+        d = _launch(world, extra, port)
+    except BaseException as e:  # noqa: BLE001 — the launcher did not come up / did not finish (N processes on one GPU, sockets on `lo`)
+        if isinstance(e, pytest.skip.Exception):
+            raise
+        print(f"first attempt failed ({type(e).__name__}): one more, on another port\n{str(e)[-1500:]}")
+        d = _launch(world, extra, port + 1000)   # (what the line SAYS — frame_check, counts — is asserted below, on whichever attempt printed it)
     assert d["n_gpus"] == world and d["steps"] == 12 and d["warmup"] == 4 and d["value"] > 0
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 1e-2
     assert "one_device_emulation" in d and d["overflow_slabs"] == 0

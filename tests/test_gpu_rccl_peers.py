@@ -53,7 +53,15 @@ def _run(world, mode, lanes, timeout=240):
 @pytest.mark.parametrize("world,mode,lanes", [(2, "natural", 1), (2, "all_refusing", 1), (2, "tiny_slots", 1), (2, "natural", 2), (3, "natural", 1), (3, "root_gather", 1), (2, "root_gather", 2),
                                               (2, "layered", 1), (3, "layered_refusing", 1), (2, "layered", 2), (3, "long", 2), (2, "long", 3)])
 def test_sharded_frames_over_rccl_between_processes(world, mode, lanes):
-    outs = _run(world, mode, lanes)
+    try:
+        outs = _run(world, mode, lanes)
+    except BaseException as e:  # noqa: BLE001 — pytest.fail / AssertionError of the harness
+        # N processes share one GPU and talk through sockets on `lo`: a box under load can lose a rendezvous.  ONE more attempt — never
+        # when a rank reported frames that differ (that is what the test is for).
+        if isinstance(e, pytest.skip.Exception) or "differ" in str(e):
+            raise
+        print(f"first attempt failed ({type(e).__name__}): retrying once\n{str(e)[-1500:]}")
+        outs = _run(world, mode, lanes)
     for rank, o in enumerate(outs):
         assert f"rank {rank}: OK" in o, o[-2000:]
         print(o.strip().splitlines()[-1])
