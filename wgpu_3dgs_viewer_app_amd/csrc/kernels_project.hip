@@ -608,6 +608,64 @@ __global__ __launch_bounds__(256) void k_shade(const FrameConsts f, const uint32
     }
 }
 
+// k_shade for the 256-byte record copy (f32 SH + f32 covariance), four lanes to a record.  One record per lane meant sixteen 16-byte
+// loads 256 bytes apart from lane to lane: every load instruction touched 64 different lines, a wave's working set was 16 KB of a
+// 32 KB L1 shared by eight waves, and the sectors were fetched again and again (75 MB of records in 41 us: 1.8 TB/s).  Here the
+// four lanes of a quad load the record side by side — lane s takes words s, s + 4, s + 8, s + 12: every instruction reads whole
+// 64-byte sectors, sixteen sectors a wave — and hand each other their words by quad broadcasts (v_mov_dpp: no LDS, no barrier).
+// All four lanes then run the SAME arithmetic on the same sixteen words — the code of k_shade, value for value — and lane 0 stores.
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v, const int s) {
+    // quad_perm [s, s, s, s]
+    switch (s) {
+        case 0: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xF, 0xF, false);
+        case 1: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x55, 0xF, 0xF, false);
+        case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xAA, 0xF, 0xF, false);
+        default: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xFF, 0xF, 0xF, false);
+    }
+}
+template <int DEG>
+__global__ __launch_bounds__(256) void k_shade_quads(const FrameConsts f, const PodPlanes pod, const Records rec,
+                                                      const uint2* __restrict__ pairs, const uint32_t* __restrict__ d_n,
+                                                      const unsigned long long* __restrict__ skip, const int write_a) {
+    const uint32_t count = *d_n;
+    const uint32_t sub = threadIdx.x & 3u;
+    for (uint32_t j = (blockIdx.x * 256u + threadIdx.x) >> 2; j < count; j += gridDim.x * 64u) {  // (the quad's four lanes share j)
+        const uint32_t i = pairs[j].y;
+        if (skip && ((skip[i >> 6] >> (i & 63u)) & 1ull)) continue;
+        uint4 mine[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) mine[k] = pod.sh_aos[(uint64_t)i * 16u + sub + 4u * k];
+        uint4 w[16];   // the record's words, in every lane of the quad
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl)
+                w[sl + 4 * k] = make_uint4(quad_bcast(mine[k].x, sl), quad_bcast(mine[k].y, sl), quad_bcast(mine[k].z, sl), quad_bcast(mine[k].w, sl));
+        const float4 pc = make_float4(__uint_as_float(w[12].x), __uint_as_float(w[12].y), __uint_as_float(w[12].z), __uint_as_float(w[12].w));
+        ViewClip vc;
+        Splat2D sp{};
+        if (!pm_view_cull(f, pc.x, pc.y, pc.z, vc)) continue;  // cannot happen: it is visible
+        if (!pm_cov2d_rect(f, vc, __uint_as_float(w[13].x), __uint_as_float(w[13].y), __uint_as_float(w[13].z), __uint_as_float(w[13].w),
+                           __uint_as_float(w[14].x), __uint_as_float(w[14].y), sp))
+            continue;
+        ShStream<DEG> st;   // (load_shade<DEG, GSX_SH_SINGLE, true>, fed from registers)
+        st.begin(f, pc.x, pc.y, pc.z, __float_as_uint(pc.w));
+#pragma unroll
+        for (int p = 0; p < ShNeed<DEG>::planes4; ++p) {
+            st.feed(4 * p, __uint_as_float(w[p].x)); st.feed(4 * p + 1, __uint_as_float(w[p].y));
+            st.feed(4 * p + 2, __uint_as_float(w[p].z)); st.feed(4 * p + 3, __uint_as_float(w[p].w));
+        }
+        if (DEG == 3) st.feed(44, __uint_as_float(w[11].x));
+        float r, g, b;
+        st.finish(r, g, b);
+        if (sub == 0u) {
+            if (write_a) rec.a[i] = make_float4(sp.mx, sp.my, __uint_as_float(sp.rx), __uint_as_float(sp.ry));
+            rec.b[i] = make_float4(sp.con_a, sp.con_b, sp.con_c, (float)(__float_as_uint(pc.w) >> 24) * (1.0f / 255.0f));
+            rec.c[i] = make_float4(r, g, b, vc.d);
+        }
+    }
+}
+
 // N_vis = sum of the per-workgroup counts (single workgroup; <= 40 K entries at 10 M Gaussians)
 __global__ __launch_bounds__(1024) void k_sum_counts(const uint32_t* __restrict__ block_visible, uint32_t nblocks,
                                                       uint32_t* __restrict__ n_visible) {
@@ -714,6 +772,17 @@ hipError_t launch_project(hipStream_t s, const FrameConsts& f, uint32_t n, const
 hipError_t launch_shade(hipStream_t s, const FrameConsts& f, uint32_t n, const PodPlanes& pod, const Records& rec,
                         const LateProjection& late) {
     if (n == 0) return hipSuccess;
+    static const bool quads = getenv("GSX_SHADE_QUADS") == nullptr || atoi(getenv("GSX_SHADE_QUADS")) != 0;  // (A/B switch)
+    if (quads && pod.sh_kind == GSX_SH_SINGLE && pod.cov_kind == GSX_COV3D_SINGLE && pod.sh_aos != nullptr && pod.aos_stride == 16u) {
+        const dim3 grid(8192), block(256);   // 0.5 M quads stride over the admitted records
+        switch ((int)f.sh_deg) {
+            case 0: GSX_LAUNCH((k_shade_quads<0>), grid, block, 0, s, f, pod, rec, late.pairs, late.d_n, late.shaded, late.write_a ? 1 : 0); break;
+            case 1: GSX_LAUNCH((k_shade_quads<1>), grid, block, 0, s, f, pod, rec, late.pairs, late.d_n, late.shaded, late.write_a ? 1 : 0); break;
+            case 2: GSX_LAUNCH((k_shade_quads<2>), grid, block, 0, s, f, pod, rec, late.pairs, late.d_n, late.shaded, late.write_a ? 1 : 0); break;
+            default: GSX_LAUNCH((k_shade_quads<3>), grid, block, 0, s, f, pod, rec, late.pairs, late.d_n, late.shaded, late.write_a ? 1 : 0); break;
+        }
+        return hipGetLastError();
+    }
     return dispatch_project(s, dim3(4096), f, n, pod, rec, nullptr, ProjectAdmission{}, &late);  // 1 M lanes stride over the admitted records
 }
 
