@@ -78,6 +78,30 @@ def test_bench_line_contract(name, d):
         assert abs(d["passes"]["unspeculated"]["project"]["us_per_frame"] - d["roofline"]["avg_launch_us"]) / d["roofline"]["avg_launch_us"] < 0.15
 
 
+    if "summary" in d:  # round 5 onwards: `value` is a whole-orbit rate and the side-by-side figures are the last keys of the line
+        assert d["steps_timed"] >= 240 and d["steps_timed"] >= d["steps"]
+        keys = list(d)
+        assert keys[-2:] == ["summary", "cpu_baseline"] or keys[-1] == "summary"
+        sm = d["summary"]
+        assert sm["value"] == d["value"] and sm["steps_timed"] == d["steps_timed"]
+        for k in ("value_one_frame_in_flight", "value_synchronised", "value_reference_protocol", "value_unspeculated"):
+            if k in d:
+                assert sm[k] == d[k], k
+        if "steady_state" in d:
+            assert sm["steady_state_value"] == d["steady_state"]["value"]
+            assert 0.85 * d["value"] < d["steady_state"]["value"] < 1.15 * d["value"]  # two whole-orbit samples of one loop
+        assert sm["roofline_frac"] == d["roofline"]["frac"]
+
+
+def test_bench_source_prints_the_summary_last():
+    """bench.py assigns out["summary"] directly before out["cpu_baseline"], the last key of the line (CPU check of the source)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    i, j = src.index('out["summary"] = summary'), src.index('out["cpu_baseline"] = cpu_baseline(')
+    assert i < j and 'out["' not in src[i + len('out["summary"] = summary'):j].replace('out["cpu_baseline"]', "")
+    assert src.index("os.write(real_stdout") > j
+    assert "args.steps = max(args.steps, args.min_steps)" in src and '"--min-steps", type=int, default=240' in src
+
+
 def test_profiled_kernel_time_agrees_with_bench():
     """profiles/: the rocprofv3 average of the roofline kernel agrees with the HIP-event time in the kept bench line (+-10 %)."""
     kept = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")))

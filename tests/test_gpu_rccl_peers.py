@@ -10,7 +10,9 @@ library's verdict / repair / redo control flow on both sides.  The frames must e
 If RCCL cannot build such a communicator on this box (no loopback networking, a refusal of the duplicate device) the
 workers say so with exit code 77 and the test is skipped — it is an environment probe then, not a parity statement."""
 import os
+import re
 import subprocess
+import warnings
 import sys
 import tempfile
 
@@ -46,8 +48,19 @@ def _run(world, mode, lanes, timeout=240):
         report = "\n----\n".join(o[-3000:] for o in outs)
         if any(c == 77 for c in codes):
             pytest.skip("RCCL would not build a communicator of several ranks on one GPU here:\n" + report[-1500:])
+        if any(c != 0 for c in codes) and RENDEZVOUS.search(report) and not RANK_ERROR.search(report):
+            raise RendezvousError(report[-3000:])
         assert all(c == 0 for c in codes), f"exit codes {codes}:\n{report}"
         return outs
+
+
+class RendezvousError(Exception):
+    """RCCL's bootstrap (sockets on `lo`) did not come up: the one failure that is retried"""
+
+
+RENDEZVOUS = re.compile(r"bootstrap|Bootstrap|socketStartConnect|socketProgress|Connection refused|connection refused|Address already in use|"
+                        r"ncclSystemError|ncclRemoteError|unhandled system error")
+RANK_ERROR = re.compile(r"differ|GSX_ERR_(?!RCCL)|AssertionError")
 
 
 @pytest.mark.parametrize("world,mode,lanes", [(2, "natural", 1), (2, "all_refusing", 1), (2, "tiny_slots", 1), (2, "natural", 2), (3, "natural", 1), (3, "root_gather", 1), (2, "root_gather", 2),
@@ -55,12 +68,11 @@ def _run(world, mode, lanes, timeout=240):
 def test_sharded_frames_over_rccl_between_processes(world, mode, lanes):
     try:
         outs = _run(world, mode, lanes)
-    except BaseException as e:  # noqa: BLE001 — pytest.fail / AssertionError of the harness
-        # N processes share one GPU and talk through sockets on `lo`: a box under load can lose a rendezvous.  ONE more attempt — never
-        # when a rank reported frames that differ (that is what the test is for).
-        if isinstance(e, pytest.skip.Exception) or "differ" in str(e):
-            raise
-        print(f"first attempt failed ({type(e).__name__}): retrying once\n{str(e)[-1500:]}")
+    except RendezvousError as e:
+        # N processes share one GPU and talk through sockets on `lo`: a box under load can lose the bootstrap rendezvous.  ONE more
+        # attempt, and only for that: a timeout, a rank that exits non-zero for another reason, a rank-reported error or frames that
+        # differ are never retried (they are what the test is for).
+        warnings.warn(f"RCCL bootstrap did not rendezvous: retrying once\n{str(e)[-800:]}")
         outs = _run(world, mode, lanes)
     for rank, o in enumerate(outs):
         assert f"rank {rank}: OK" in o, o[-2000:]

@@ -799,6 +799,34 @@ def test_forced_band_edges_with_empty_and_uneven_bands(edges):
             assert np.array_equal(fb, ref[k]), f"rank {rank} frame {k}: L-inf {np.abs(fb - ref[k]).max()}"
 
 
+def test_forced_band_edges_that_no_longer_cover_the_viewport_fail_the_frame():
+    """gsx_shard_set_band_edges validates against the viewport of the moment; a later, taller viewport must not be rendered with
+    bottom tile rows nobody owns: the frame fails with GSX_ERR_INVALID_ARG on every rank until the edges are set again."""
+    world = 2
+    g = _scene()
+    tall = (W, 2 * H)
+    ref = _single_frames(g, POSES[:1], tall)
+
+    def body(rank, group):
+        v, shard_max = _rank_viewer(g, N, rank, world, group)
+        _uniforms(v, POSES[0])
+        v.shard_set_band_edges(world, np.array([0, 4, TILES[0]], np.uint32))
+        v.shard_render_frame("m", shard_max)
+        v.poll()
+        _uniforms(v, POSES[0], tall)
+        with pytest.raises(GsxError) as ei:
+            v.shard_render_frame("m", shard_max)
+        assert ei.value.status == _lib.GSX_ERR_INVALID_ARG and "band edges" in str(ei.value)
+        v.shard_set_band_edges(world, np.array([0, 4, (tall[1] + 15) // 16], np.uint32))
+        v.shard_render_frame("m", shard_max)
+        fb = v.download_framebuffer().copy()
+        v.close()
+        return fb
+
+    for rank, fb in enumerate(run_group(world, body)):
+        assert np.array_equal(fb, ref[0]), f"rank {rank}: L-inf {np.abs(fb - ref[0]).max()}"
+
+
 def test_balanced_bands_gathered_to_one_rank_with_frames_in_flight():
     world, lanes, size = 4, 2, (640, 480)
     g = _open_sky_scene(20000)

@@ -224,6 +224,10 @@ def test_rust_sys_covers_every_symbol():
     before = rs
     subprocess.run(["python3", os.path.join(ROOT, "tools", "gen_rust_sys.py")], check=True, capture_output=True)
     assert open(path).read() == before, "rust/gsx-sys/src/lib.rs is stale: run tools/gen_rust_sys.py"
+    # the documents quote the count: it is the header's
+    for doc in ("INTEGRATION.md", "DESIGN.md"):
+        for quoted in re.findall(r"all\s+\**(\d+)\**\s+(?:functions|symbols)", open(os.path.join(ROOT, doc)).read()):
+            assert int(quoted) == len(declared), f"{doc} says {quoted} functions, include/gsx.h declares {len(declared)}"
     facade = open(os.path.join(ROOT, "rust", "gsx", "src", "lib.rs")).read()
     for name in ("MultiModelViewer", "new_with", "update_range", "preprocess", "radix_sorter", "render", "postprocess", "update_camera",
                  "update_model_transform", "update_gaussian_transform", "update_query", "update_selection_highlight",

@@ -17,9 +17,9 @@ python3 bench.py --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2>> $OUT/be
 #    with roofline.avg_launch_us / roofline_speculated.avg_launch_us of the line it prints itself)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --no-cpu-baseline --no-pmc --no-extra-legs --no-robustness > $OUT/kt_bench.log 2>&1
 # 3. per-frame kernel breakdowns of the speculated and of the unspeculated loop alone, and of the sharded frame at world 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_spec -o kt -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-pmc --render-options speculative=1 > $OUT/kt_spec.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_nospec -o kt -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-pmc --render-options speculative=0 > $OUT/kt_nospec.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_dist -o kt -- python3 bench.py --force-dist --steps 100 --warmup 10 --no-cpu-baseline --no-pmc --dist-frames-in-flight 1 > $OUT/kt_dist.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_spec -o kt -- python3 bench.py --steps 100 --warmup 10 --min-steps 0 --no-cpu-baseline --no-pmc --render-options speculative=1 > $OUT/kt_spec.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_nospec -o kt -- python3 bench.py --steps 100 --warmup 10 --min-steps 0 --no-cpu-baseline --no-pmc --render-options speculative=0 > $OUT/kt_nospec.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_dist -o kt -- python3 bench.py --force-dist --steps 100 --warmup 10 --min-steps 0 --no-cpu-baseline --no-pmc --dist-frames-in-flight 1 > $OUT/kt_dist.log 2>&1
 python3 tools/kernel_breakdown.py $OUT/kt_spec 143 40 > $OUT/kt_spec_breakdown.txt
 python3 tools/kernel_breakdown.py $OUT/kt_nospec 143 40 > $OUT/kt_nospec_breakdown.txt
 python3 tools/kernel_breakdown.py $OUT/kt_dist 143 40 > $OUT/kt_dist_breakdown.txt

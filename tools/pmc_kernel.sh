@@ -9,7 +9,7 @@ for grp in "SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_ACTIVE_INS
            "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU" "SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD" \
            "GRBM_GUI_ACTIVE SQ_LEVEL_WAVES SQ_INSTS_VALU_TRANS_F32 SQ_THREAD_CYCLES_VALU"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/g$i -o p -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-pmc "$@" > $OUT/g$i.log 2>&1
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/g$i -o p -- python3 bench.py --steps 6 --warmup 3 --min-steps 0 --no-cpu-baseline --no-pmc "$@" > $OUT/g$i.log 2>&1
 done
 python3 - "$OUT" "$K" <<'PY'
 import csv, glob, sys, collections

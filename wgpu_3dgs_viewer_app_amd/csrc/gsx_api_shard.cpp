@@ -13,6 +13,7 @@ extern "C" {
 gsx_status gsx_shard_layout(gsx_viewer* v, uint32_t world, uint32_t rank, gsx_shard_layout_t* out) {
     if (!v || !out || world == 0 || world > 64 || rank >= world) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_layout: bad argument");
     const uint32_t tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
+    if (gsx_status cst = check_bands(v, world, "gsx_shard_layout")) return cst;
     const BandEdges b = bands_of(v, world);
     const uint64_t row_bytes = (uint64_t)GSX_TILE * v->width * sizeof(float4);
     out->rows_per_rank = band_rows_max(b);  // (equal bands: what it always was)
@@ -57,6 +58,7 @@ gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, const 
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_pack: no model '%s'", key ? key : "(null)");
     if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack: model '%s' has no projection this frame (gsx_preprocess first)", key);
     if (world == 0 || world > 64 || !counts) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack: world must be 1..64");
+    if ((st = check_bands(v, world, "gsx_shard_pack"))) return st;
     const uint32_t n = (uint32_t)m->n;
     const bool from_list = !d_tile_window && m->shard_win_set && m->cand_valid;
     const uint32_t rounds = pack_rounds(from_list), tile = 256u * rounds;
@@ -153,6 +155,7 @@ gsx_status gsx_shard_import(gsx_viewer* v, const char* key, const void* d_recv, 
     if (world == 0 || world > 64 || rank >= world) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import: bad world/rank %u/%u", world, rank);
     if (n_records >= 0xFFFFFFF0ull) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import: too many records");
     if (n_records && !d_recv) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import: d_recv is null");
+    if ((st = check_bands(v, world, "gsx_shard_import"))) return st;
     if ((st = ensure_import_capacity(m, n_records))) return st;
     HIPCHK(launch_import_records(v->stream, d_recv, (uint32_t)n_records, m->imp_rec()));
     // every imported record is visible by construction
@@ -192,6 +195,7 @@ gsx_status gsx_shard_feedback(gsx_viewer* v, const char* key, uint32_t world, ui
     if (!m->binned) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_feedback: model '%s' not rendered this frame", key);
     if (!v->options.progressive) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_feedback needs gsx_render_options.progressive = 1");
     if (world == 0 || world > 64 || rank >= world) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_feedback: bad world/rank %u/%u", world, rank);
+    if ((st = check_bands(v, world, "gsx_shard_feedback"))) return st;
     const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
     const uint32_t row_words = (tiles_x + 31) / 32;
     const uint32_t* tile_sat = v->done_bits.as<uint32_t>() + 1 + (size_t)row_words * tiles_y;
@@ -398,6 +402,7 @@ gsx_status gsx::shard_pack_slots(gsx_viewer* v, const char* key, uint32_t world,
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_pack_slots: no model '%s'", key ? key : "(null)");
     if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack_slots: model '%s' has no projection this frame (gsx_shard_frame_begin first)", key);
     if (world == 0 || world > 64 || round > 1 || !d_send) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack_slots: bad argument");
+    if ((st = check_bands(v, world, "gsx_shard_pack_slots"))) return st;
     if (round == 1) {
         if (m->shard_win2.bytes < window_bytes(v)) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack_slots: round 1 before gsx_shard_verify");
         // the repair round is counted once (gsx_shard_repair_count sized it); packing without it counts here
@@ -457,6 +462,7 @@ gsx_status gsx::shard_import_slots(gsx_viewer* v, const char* key, const void* d
     const bool behind = (round_flags & GSX_SHARD_BEHIND) != 0;  // a layered frame: nearer models are in the framebuffer already
     if (world == 0 || world > 64 || rank >= world || round_flags > 3u || !d_recv)
         return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import_slots: bad argument");
+    if ((st = check_bands(v, world, "gsx_shard_import_slots"))) return st;
     uint64_t cap = 0;
     for (uint32_t p = 0; p < world; ++p) cap += slots.cap[p];
     if (cap >= 0xFFFFFFF0ull) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_import_slots: too many records");
@@ -502,6 +508,7 @@ gsx_status gsx_shard_verify(gsx_viewer* v, const char* key, uint32_t world, cons
     Model* m = find_model(v, key);
     if (!m || !d_sat_all || !out_seq) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_verify: no model '%s' / null argument", key ? key : "(null)");
     if (world == 0 || world > 64) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_verify: world must be 1..64");
+    if ((st = check_bands(v, world, "gsx_shard_verify"))) return st;
     const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
     HIPCHK(m->shard_win2.ensure(window_bytes(v)));
     HIPCHK(m->shard_need_bits.ensure(4 * (size_t)((tiles_x + 31) / 32) * tiles_y));
@@ -560,6 +567,7 @@ gsx_status gsx_shard_next_windows(gsx_viewer* v, const char* key, uint32_t world
     Model* m = find_model(v, key);
     if (!m || !d_sat_all) return fail(GSX_ERR_NOT_FOUND, "gsx_shard_next_windows: no model '%s' / null map", key ? key : "(null)");
     if (!(margin >= 0.0f) || radius > 16 || world == 0 || world > 64) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_next_windows: margin >= 0, radius <= 16, world 1..64");
+    if ((st = check_bands(v, world, "gsx_shard_next_windows"))) return st;
     const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
     // the limits of the frame in flight must survive until its verdict is in (a repair round reads them): double buffer
     DevBuf& next = m->shard_limit_next;

@@ -45,7 +45,7 @@ void choose_edges(gsx_viewer* owner, ShardPending& p, uint32_t world, uint32_t t
     p.edges.clear();
     if (!comm_moves_unequal(owner)) return;
     if (owner->band_edges_forced.size() == (size_t)world + 1u) {
-        p.edges = owner->band_edges_forced;
+        p.edges = owner->band_edges_forced;  // (a layout that no longer covers the viewport fails the frame: check_bands in frame_buffers)
     } else if (owner->shard_balance && owner->next_edges.size() == (size_t)world + 1u && owner->next_edges_tiles_y == tiles_y) {
         p.edges = owner->next_edges;
     }

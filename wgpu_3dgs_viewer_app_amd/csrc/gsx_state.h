@@ -514,6 +514,16 @@ inline BandEdges bands_of(const gsx_viewer* v, uint32_t world) {
     }
     return b;
 }
+// A band layout set for another viewport (gsx_shard_set_band_edges validates against the height at call time; gsx_update_camera may
+// enlarge the viewport later): the last edge must still cover every tile row, or no rank would own the bottom rows and the gathered
+// frame would silently keep stale pixels there.  Every stage call that reads the layout checks it.
+inline gsx_status check_bands(const gsx_viewer* v, uint32_t world, const char* who) {
+    const uint32_t tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
+    if (v->band_edges.size() == (size_t)world + 1u && v->band_edges[world] < tiles_y)
+        return fail(GSX_ERR_INVALID_ARG, "%s: the band edges in force end at tile row %u but the viewport has %u rows (gsx_shard_set_band_edges was called "
+                    "for a smaller viewport: set them again, or clear them with edges = NULL)", who, v->band_edges[world], tiles_y);
+    return GSX_OK;
+}
 inline size_t window_bytes(const gsx_viewer* v) {
     return sizeof(uint2) * (size_t)((v->width + GSX_TILE - 1) / GSX_TILE) * ((v->height + GSX_TILE - 1) / GSX_TILE);
 }
