@@ -688,7 +688,8 @@ def main():
                              shard_stats_timed["exchange_rounds"] / frames_stats, shard_stats_timed["last_slot_records"],
                              count] + [tm_all[name]["ms"] * 1e3 / n_prof for name in ("project", "project_geom", "depth_sort", "bin", "tile_sort", "composite")]
                             + [acct[:, 5].mean(), edges_now[rank + 1] - edges_now[rank],
-                               (shard_stats_unspec["wire_bytes"] / max(shard_stats_unspec["frames"], 1)) if shard_stats_unspec else 0.0],
+                               (shard_stats_unspec["wire_bytes"] / max(shard_stats_unspec["frames"], 1)) if shard_stats_unspec else 0.0,
+                               shard_stats_timed["redo_fallbacks"], shard_stats_timed["last_repair_slot_records"]],
                             dtype=torch.float64, device="cuda")
         gathered = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
@@ -709,7 +710,12 @@ def main():
             bands="tile rows [band_edges[g], band_edges[g + 1]) belong to rank g; cut by the previous frame's per-row work (list entries the "
                   "compositor's tiles walked, all-gathered with the saturation map): work_busiest_rank_over_mean is that measure for the last "
                   "timed frame, list_entries_max_over_mean the ranks' binned entries",
-            wire_bytes_per_frame_unspeculated=[int(x) for x in g_all[:, 15]] if shard_stats_unspec else None)
+            wire_bytes_per_frame_unspeculated=[int(x) for x in g_all[:, 15]] if shard_stats_unspec else None,
+            redone_frames_redone_again_with_whole_shard_slots=[int(x) for x in g_all[:, 16]], repair_slot_records_last_frame=[int(x) for x in g_all[:, 17]],
+            protocol="every frame is enqueued whole — both exchange rounds of every model, the repair round deciding on the device whether it has "
+                     "anything to do — and its verdict is read when the frame is retired (frames in flight: after the next frame is enqueued; "
+                     "verdict_wait_us_per_frame is what the host waited then); a frame whose slots overflowed is redone at its retirement, before "
+                     "its lane is used again and before anybody can read it (frames_redone_with_whole_shard_slots)")
 
     if rank == 0:
         fps = args.steps / elapsed

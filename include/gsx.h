@@ -537,6 +537,9 @@ typedef struct gsx_shard_stats {
                                                     by (1000 = perfectly even) */
     uint32_t redo_fallbacks;                     /* redone frames whose exactly sized slots overflowed again and that were redone with
                                                     whole-shard slots */
+    uint32_t last_repair_records;                /* most records any rank had for one destination in the repair round of the last frame
+                                                    whose verdict was read */
+    uint32_t reserved0;
 } gsx_shard_stats;
 gsx_status gsx_shard_get_stats(gsx_viewer* v, gsx_shard_stats* out, uint32_t reset);
 /* Where a sharded frame's finished bands go.  root = -1 (default): an all-gather — after gsx_shard_render_frame every rank's

@@ -132,6 +132,7 @@ pub struct gsx_shard_stats {
     pub frames: u64, pub redo_frames: u64, pub repair_frames: u64, pub exchange_rounds: u64,
     pub wire_bytes: u64, pub verdict_wait_ns: u64, pub last_slot_records: u32, pub last_repair_slot_records: u32,
     pub last_entries_sum: u32, pub last_entries_max: u32, pub last_work_permille: u32, pub redo_fallbacks: u32,
+    pub last_repair_records: u32, pub reserved0: u32,
 }
 #[repr(C)]
 #[derive(Clone, Copy, Default)]

@@ -290,7 +290,7 @@ def test_new_entry_points_reject_bad_arguments_without_a_device():
     assert L.gsx_shard_render_frame(None, None, 0, 1, 0.25, 3) == _lib.GSX_ERR_INVALID_ARG
     fn = _lib.COMM_FN(lambda *a: 0)
     assert L.gsx_viewer_comm_init_custom(None, 2, 0, fn, fn, None) == _lib.GSX_ERR_INVALID_ARG
-    assert C.sizeof(_lib.ShardStats) == 72
+    assert C.sizeof(_lib.ShardStats) == 80
     fa, fg = _lib.COMM_A2A_V_FN(lambda *a: 0), _lib.COMM_GATHER_V_FN(lambda *a: 0)
     assert L.gsx_viewer_comm_init_custom_v(None, 2, 0, fa, fg, None) == _lib.GSX_ERR_INVALID_ARG
     e = (C.c_uint32 * 3)(0, 1, 2)

@@ -118,7 +118,8 @@ int main(int argc, char** argv) {
     for (uint32_t i = 0; i < n; ++i) bad += (ref[i].x != k[i]) || (ref[i].y != v[i]);
     printf("mismatches vs std::stable_sort: %zu\n", bad);
     // phase profile of one sort (all passes write the same slots: the last pass remains)
-    const uint32_t tiles = (n + kRadixTile - 1) / kRadixTile;
+    const uint32_t tile_elems = n <= radix_small_n() ? kRadixTileSmall : kRadixTile;
+    const uint32_t tiles = (n + tile_elems - 1) / tile_elems;
     long long* prof;
     CK(hipMalloc(&prof, 64ull * tiles));
     CK(hipMemset(prof, 0, 64ull * tiles));

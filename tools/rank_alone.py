@@ -104,8 +104,56 @@ class RecordingTransport:
         return 0
 
 
+_RT = None
+
+
+def replay_lib():
+    """tools/libreplay_transport.so (tools/replay_transport.cpp, built by __graft_entry__.build()): the replay transport as native code"""
+    global _RT
+    if _RT is None:
+        _RT = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libreplay_transport.so"))
+        _RT.rt_create.restype = C.c_void_p
+        _RT.rt_create.argtypes = [C.c_uint32, C.c_uint32]
+        _RT.rt_destroy.argtypes = [C.c_void_p]
+        _RT.rt_add_call.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        _RT.rt_rewind.argtypes = [C.c_void_p]
+        _RT.rt_wire.restype = C.c_uint64
+        _RT.rt_wire.argtypes = [C.c_void_p]
+        _RT.rt_position.restype = C.c_uint64
+        _RT.rt_position.argtypes = [C.c_void_p]
+        _RT.rt_failed.argtypes = [C.c_void_p]
+    return _RT
+
+
+class NativeReplay:
+    """Phase 2, native: the recorded pieces of ONE rank handed to tools/replay_transport.cpp; the library calls its two C functions
+    directly (gsx_viewer_comm_init_custom_v) — no Python inside the timed rank."""
+
+    def __init__(self, world, rank, log):
+        self.lib = replay_lib()
+        self.ctx = self.lib.rt_create(world, rank)
+        for kind, pieces in log:
+            n = len(pieces)
+            off = (C.c_uint64 * max(n, 1))(*[p[0] for p in pieces])
+            nb = (C.c_uint64 * max(n, 1))(*[p[1] for p in pieces])
+            keep = (C.c_uint64 * max(n, 1))(*[p[2] or 0 for p in pieces])
+            self.lib.rt_add_call(self.ctx, 0 if kind == "a2a" else 1, n, off, nb, keep)
+
+    def attach(self, v, world, rank):
+        self.lib.rt_rewind(self.ctx)
+        v.comm_init_custom_v_native(world, rank, self.lib.rt_all_to_all_v, self.lib.rt_gather_v, self.ctx)
+
+    @property
+    def wire(self):
+        return int(self.lib.rt_wire(self.ctx))
+
+    def close(self):
+        self.lib.rt_destroy(self.ctx)
+
+
 class ReplayTransport:
-    """Phase 2: the recorded pieces of ONE rank, served in the order the library asks for them."""
+    """Phase 2 in Python (--python-replay: the A/B of the native transport): the recorded pieces of ONE rank, served in the order the
+    library asks for them."""
 
     def __init__(self, world, rank, log):
         self.world, self.rank, self.log, self.at = world, rank, log, 0
@@ -143,27 +191,70 @@ class ReplayTransport:
 
 
 BALANCE = True   # --balance 0: equal bands (the A/B of the balanced ones)
+ORBIT, KEYS_OF = [], []
 SHARDS = {}   # (world, rank) -> the shard's Gaussians (generated once per world)
 
 
+CFG5_TRS = {"a": camera.ModelTransform(pos=np.array([0.0, 0.0, 2.5], np.float32)),
+            "b": camera.ModelTransform(pos=np.array([2.0, 0.2, -1.0], np.float32), rot=np.array([0, 35, 0], np.float32)),
+            "c": camera.ModelTransform(pos=np.array([-2.5, -0.1, -0.5], np.float32), scale=np.array([0.9, 0.9, 0.9], np.float32)),
+            "d": camera.ModelTransform(pos=np.array([0.3, -0.2, 0.5], np.float32), rot=np.array([20, -35, 50], np.float32),
+                                       scale=np.array([1.2, 0.9, 1.1], np.float32))}   # tools/bench_cfg5.py's scene (BASELINE.json configs[4])
+WORKLOAD = "cfg4"
+PYTHON_REPLAY = False
+
+
 def make_viewer(cfg, rank, world, open_sky, lanes=1):
+    """-> (viewer, frame(i, speculate, sharded=True), models): the rank's index shard(s) resident, uniforms set by frame()."""
     n, sh, w, h, seed = cfg
-    s0, c = parallel.shard_range(n, rank, world)
-    if (world, rank) not in SHARDS:
-        SHARDS[(world, rank)] = scene.synthetic_gaussians(n, seed, sh, s0, c)
-    g = SHARDS[(world, rank)]
     v = MultiModelViewer()
     v.set_render_options(frames_in_flight=lanes)
-    v.add_model("m", c)
-    v.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g)
-    if open_sky:   # bench.py's robustness scene: the Gaussians with y <= 0.5 (the screen above the horizon stays open)
-        sky = [MaskShape(MaskShapeKind.Box, pos=np.array([0.0, -4.5, 0.0], np.float32), scale=np.array([10.0, 5.0, 10.0], np.float32))]
-        MaskEvaluator(v).evaluate(MaskOp.parse("0"), "m", sky)
+    orbit = ORBIT
+    if WORKLOAD == "cfg5":   # 4 layered models x n / 4 Gaussians, each index-sharded over the ranks; TRS per model, `0 - 1` mask on one
+        nm = n // 4
+        s0, c = parallel.shard_range(nm, rank, world)
+        for i, k in enumerate(CFG5_TRS):
+            if (world, rank, k) not in SHARDS:
+                SHARDS[(world, rank, k)] = scene.synthetic_gaussians(nm, seed + i, sh, s0, c)
+            v.add_model(k, c)
+            v.models[k].gaussian_buffers.gaussians_buffer.update_range(0, SHARDS[(world, rank, k)])
+            v.update_model_transform(k, CFG5_TRS[k].pos, CFG5_TRS[k].quat(), CFG5_TRS[k].scale)
+        shapes = [MaskShape(MaskShapeKind.Box, pos=np.array([0.0, 0.0, 2.5], np.float32), scale=np.array([3.0, 3.0, 3.0], np.float32)),
+                  MaskShape(MaskShapeKind.Ellipsoid, pos=np.array([0.0, 0.0, 2.5], np.float32), scale=np.array([1.5, 1.5, 1.5], np.float32))]
+        MaskEvaluator(v).evaluate(MaskOp.parse("0 - 1"), "a", shapes)
+        keys_of = KEYS_OF
+        shard_max = [(nm + world - 1) // world] * 4
+        models = list(CFG5_TRS)
+
+        def frame(i, speculate, sharded=True):
+            v.update_camera(orbit[i % 240], (w, h))
+            if sharded:
+                v.shard_render_frame_keys(keys_of[i % 240], shard_max, speculate=bool(speculate))
+            else:
+                v.render_frame(keys_of[i % 240])
+    else:
+        s0, c = parallel.shard_range(n, rank, world)
+        if (world, rank) not in SHARDS:
+            SHARDS[(world, rank)] = scene.synthetic_gaussians(n, seed, sh, s0, c)
+        v.add_model("m", c)
+        v.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, SHARDS[(world, rank)])
+        if open_sky:   # bench.py's robustness scene: the Gaussians with y <= 0.5 (the screen above the horizon stays open)
+            sky = [MaskShape(MaskShapeKind.Box, pos=np.array([0.0, -4.5, 0.0], np.float32), scale=np.array([10.0, 5.0, 10.0], np.float32))]
+            MaskEvaluator(v).evaluate(MaskOp.parse("0"), "m", sky)
+        shard_max = (n + world - 1) // world
+        models = ["m"]
+
+        def frame(i, speculate, sharded=True):
+            v.update_camera(orbit[i % 240], (w, h))
+            if sharded:
+                v.shard_render_frame("m", shard_max, speculate=bool(speculate))
+            else:
+                v.render_frame(["m"])
     v.update_gaussian_transform(1.0, GaussianDisplayMode.Splat, GaussianShDegree.new(sh), False)
     v.shard_set_gather_root(0)
     if not BALANCE:
         v.shard_set_balance(False)   # the A/B: equal bands of tile rows, as until round 3
-    return v, (n + world - 1) // world
+    return v, frame, models
 
 
 def band_checksum(v, world, rank):
@@ -178,32 +269,31 @@ def run(cfg, world, frames, open_sky, speculate, orbit, lanes):
     hub = Hub(world)
     out = [None] * world
     errors = []
+    warm = max(1, min(10, frames // 4))
+    # frames that are LOOKED at (a readback completes the frames in flight, and redoes a frame whose slots overflowed): the same ones in
+    # the recording and in the replay, or the two would issue different collectives — the untimed ones (one frame in flight) and the last
+    looked_at = lambda i: (lanes == 1 and i < warm) or i == frames - 1  # noqa: E731
 
     def record(rank):
         try:
-            v, shard_max = make_viewer(cfg, rank, world, open_sky, lanes)
+            v, frame, models = make_viewer(cfg, rank, world, open_sky, lanes)
             v.comm_init_custom_v(world, rank, RecordingTransport(hub, rank).all_to_all_v, RecordingTransport(hub, rank).gather_v)
-            marks, sums = [], []
-            warm = max(1, min(10, frames // 4))
+            sums = []
             per_frame = []
             for i in range(frames):
                 if i == warm:
-                    v.poll()   # (the replay starts its clock here: with frames in flight that completes them — the same calls in both phases)
-                v.update_camera(orbit[i % 240], (w, h))
-                marks.append(len(hub.log[rank]))
-                v.shard_render_frame("m", shard_max, speculate=bool(speculate))
-                # (frames in flight: a readback completes them — it would change the order of the collectives; only the last
-                #  frame is compared then)
-                sums.append(band_checksum(v, world, rank) if lanes == 1 or i == frames - 1 else None)
-                if rank == 0 and lanes == 1:
-                    stf = v.shard_stats()
-                    per_frame.append(dict(slot_records_max=stf["last_slot_records"], redo=stf["redo_frames"], repair=stf["repair_frames"],
-                                          wire_MB=round(stf["wire_bytes"] / 1e6, 2), work_busiest_over_mean=stf["last_work_permille"] / 1000.0,
-                                          edges=sums[-1][1]))
+                    v.poll()   # (the replay starts its clock here: that completes the frames in flight — the same calls in both phases)
+                frame(i, speculate)
+                sums.append(band_checksum(v, world, rank) if looked_at(i) else None)
+                if rank == 0:
+                    stf = v.shard_stats()   # (host-side bookkeeping of the frames retired so far: it lags the loop by a frame or two)
+                    per_frame.append(dict(slot_records_max=stf["last_slot_records"], repair_slot_records=stf["last_repair_slot_records"], redo=stf["redo_frames"],
+                                          repair=stf["repair_frames"], wire_MB=round(stf["wire_bytes"] / 1e6, 2),
+                                          work_busiest_over_mean=stf["last_work_permille"] / 1000.0))
             st = v.shard_stats()
-            entries = v.frame_stats("m")["n_tile_entries"]
+            entries = sum(v.frame_stats(k)["n_tile_entries"] for k in models)
             v.close()
-            out[rank] = dict(marks=marks, sums=sums, stats=st, entries=entries, shard_max=shard_max, per_frame=per_frame)
+            out[rank] = dict(sums=sums, stats=st, entries=entries, per_frame=per_frame)
         except BaseException as e:  # noqa: BLE001
             errors.append(e)
             hub.barrier.abort()
@@ -215,47 +305,62 @@ def run(cfg, world, frames, open_sky, speculate, orbit, lanes):
         raise [e for e in errors if not isinstance(e, threading.BrokenBarrierError)][0] if any(
             not isinstance(e, threading.BrokenBarrierError) for e in errors) else errors[0]
 
+    def attach(v, rank):
+        if PYTHON_REPLAY:
+            tr = ReplayTransport(world, rank, hub.log[rank])
+            v.comm_init_custom_v(world, rank, tr.all_to_all_v, tr.gather_v)
+        else:
+            tr = NativeReplay(world, rank, hub.log[rank])
+            tr.attach(v, world, rank)
+        return tr
+
     ranks = []
-    warm = max(1, min(10, frames // 4))
     for rank in range(world):   # phase 2: one rank at a time, nothing else on the GPU
-        v, shard_max = make_viewer(cfg, rank, world, open_sky, lanes)
-        tr = ReplayTransport(world, rank, hub.log[rank])
-        v.comm_init_custom_v(world, rank, tr.all_to_all_v, tr.gather_v)
+        v, frame, models = make_viewer(cfg, rank, world, open_sky, lanes)
+        tr = attach(v, rank)
         same = True
         t_mark = wire_mark = None
         for i in range(frames):
             if i == warm:
                 v.poll()
                 t_mark, wire_mark = time.perf_counter(), tr.wire
-            v.update_camera(orbit[i % 240], (w, h))
-            v.shard_render_frame("m", shard_max, speculate=bool(speculate))
-            if i < warm and lanes == 1:   # (checking costs a readback: only untimed frames are checked, the last one after the clock stops)
-                v.poll()
+            frame(i, speculate)
+            if looked_at(i) and i < frames - 1:   # (checking costs a readback: only untimed frames are checked, the last one after the clock stops)
                 same = same and band_checksum(v, world, rank) == out[rank]["sums"][i]
         v.poll()
         elapsed = time.perf_counter() - t_mark
+        wire_timed = tr.wire - wire_mark
         same = same and band_checksum(v, world, rank) == out[rank]["sums"][frames - 1]
         st = v.shard_stats()
         timed = frames - warm
+        launches = None
         v.close()
-        # once more with every pass bracketed by events (costs a few microseconds of stream gap per bracket): where the rank's time goes
-        v, shard_max = make_viewer(cfg, rank, world, open_sky, lanes)
-        tr2 = ReplayTransport(world, rank, hub.log[rank])
-        v.comm_init_custom_v(world, rank, tr2.all_to_all_v, tr2.gather_v)
+        # once more with every pass bracketed by events (costs a few microseconds of stream gap per bracket): where the rank's time goes;
+        # and the kernel launches the library asks for per frame (GSX_LAUNCH counter)
+        from wgpu_3dgs_viewer_app_amd import viewer as viewer_mod
+        v, frame, models = make_viewer(cfg, rank, world, open_sky, lanes)
+        tr2 = attach(v, rank)
+        l0 = 0
         for i in range(frames):
             if i == warm:
                 v.poll()
                 v.set_pass_timing(True)
                 v.get_pass_timing()
-            v.update_camera(orbit[i % 240], (w, h))
-            v.shard_render_frame("m", shard_max, speculate=bool(speculate))
+                l0 = viewer_mod.launch_count()
+            frame(i, speculate)
+        launches = round((viewer_mod.launch_count() - l0) / timed, 1)
         v.poll()
         passes = {k: round(1e3 * t["ms"] / timed, 1) for k, t in v.get_pass_timing().items() if t["ms"] > 0}
-        ranks.append(dict(rank=rank, ms_per_frame_alone=round(1e3 * elapsed / timed, 4), pass_us_per_frame=passes, wire_bytes_per_frame=int((tr.wire - wire_mark) / timed),
-                          frames_equal_to_the_recording=bool(same), list_entries_last_frame=int(out[rank]["entries"]),
-                          repair_frames=round(out[rank]["stats"]["repair_frames"] / frames, 3), redo_frames=round(out[rank]["stats"]["redo_frames"] / frames, 3),
+        ranks.append(dict(rank=rank, ms_per_frame_alone=round(1e3 * elapsed / timed, 4), pass_us_per_frame=passes, launches_per_frame=launches,
+                          wire_bytes_per_frame=int(wire_timed / timed), frames_equal_to_the_recording=bool(same),
+                          list_entries_last_frame=int(out[rank]["entries"]),
+                          repair_frames=round(st["repair_frames"] / max(st["frames"], 1), 3), redo_frames=round(st["redo_frames"] / max(st["frames"], 1), 3),
+                          verdict_wait_us_per_frame=round(st["verdict_wait_ns"] / 1e3 / max(st["frames"], 1), 1),
                           band_rows_last_frame=[out[rank]["sums"][-1][1][rank], out[rank]["sums"][-1][1][rank + 1]]))
         v.close()
+        for t in (tr, tr2):
+            if hasattr(t, "close"):
+                t.close()
     for lg in hub.log:
         for _, pieces in lg:
             for _, _, keep in pieces:
@@ -272,17 +377,14 @@ def run(cfg, world, frames, open_sky, speculate, orbit, lanes):
 
 def single_gpu(cfg, frames, open_sky, speculate, orbit, lanes):
     """the same scene on the single-GPU path, same process: what N = 1 means in the table"""
-    n, sh, w, h, seed = cfg
-    v, _ = make_viewer(cfg, 0, 1, open_sky)
+    v, frame, _ = make_viewer(cfg, 0, 1, open_sky)
     v.set_render_options(speculative=int(speculate), frames_in_flight=lanes)
     for i in range(10):
-        v.update_camera(orbit[i % 240], (w, h))
-        v.render_frame(["m"])
+        frame(i, speculate, sharded=False)
     v.poll()
     t0 = time.perf_counter()
     for i in range(10, 10 + frames):
-        v.update_camera(orbit[i % 240], (w, h))
-        v.render_frame(["m"])
+        frame(i, speculate, sharded=False)
     v.poll()
     el = time.perf_counter() - t0
     v.close()
@@ -299,17 +401,24 @@ def main():
     ap.add_argument("--lanes", default="1,2", help="frames in flight of the replayed rank (and of the recording)")
     ap.add_argument("--out", default="")
     ap.add_argument("--balance", type=int, default=1, help="0: equal bands of tile rows (gsx_shard_set_balance(0)) — the A/B of the balanced bands")
+    ap.add_argument("--python-replay", action="store_true", help="serve the replay from Python callbacks (rounds 4's transport: the A/B of the native one)")
     a = ap.parse_args()
-    global BALANCE
+    global BALANCE, WORKLOAD, PYTHON_REPLAY, ORBIT, KEYS_OF
     BALANCE = bool(a.balance)
+    WORKLOAD = a.workload
+    PYTHON_REPLAY = a.python_replay
     cfg = scene.CONFIGS[a.workload]
     n, sh, w, h, seed = cfg
     orbit = [camera.PrecomputedCamera(camera.orbit_pose(k), w / h) for k in range(240)]
+    ORBIT = orbit
+    KEYS_OF = [parallel.model_render_keys(camera.orbit_pose(k).pos, CFG5_TRS) for k in range(240)]
+    if a.workload == "cfg5":
+        a.scenes = "orbit"
     res = dict(tool="tools/rank_alone.py", workload=a.workload, gaussians=n, size=[w, h],
                method="every rank of an N-rank gsx_shard_render_frame run replayed ALONE on the GPU against the pieces it received in the "
                       "N-rank run (threads, one GPU); predicted fps = 1 / (slowest rank's ms alone + busiest rank's wire bytes / (7 x 153 GB/s)); "
-                      "the transport's callbacks are Python (their host time is inside ms_per_frame_alone — an upper bound — and hides behind the "
-                      "other frame's device work with two frames in flight)",
+                      + ("the replay transport's callbacks are Python (--python-replay)" if a.python_replay else
+                         "the replay transport is native code (tools/replay_transport.cpp): no Python inside the timed rank"),
                balanced_bands=bool(a.balance), single_gpu_fps={}, runs=[])
     lanes_list = [int(x) for x in a.lanes.split(",")]
     for sc in a.scenes.split(","):

@@ -102,7 +102,8 @@ class ShardStats(C.Structure):
     _fields_ = [("frames", C.c_uint64), ("redo_frames", C.c_uint64), ("repair_frames", C.c_uint64), ("exchange_rounds", C.c_uint64),
                 ("wire_bytes", C.c_uint64), ("verdict_wait_ns", C.c_uint64), ("last_slot_records", C.c_uint32),
                 ("last_repair_slot_records", C.c_uint32), ("last_entries_sum", C.c_uint32), ("last_entries_max", C.c_uint32),
-                ("last_work_permille", C.c_uint32), ("redo_fallbacks", C.c_uint32)]
+                ("last_work_permille", C.c_uint32), ("redo_fallbacks", C.c_uint32),
+                ("last_repair_records", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 #: gsx_comm_all_to_all_fn / gsx_comm_all_gather_fn: (ctx, d_send, d_recv, bytes, hip_stream) -> gsx_status

@@ -63,6 +63,7 @@ static gsx_status lane_create(gsx_viewer* v, gsx_viewer** out) {
     l->bin_mode = v->bin_mode;
     l->edit_cache = v->edit_cache;
     l->blocks_max = v->blocks_max;
+    l->blocks_adaptive = v->blocks_adaptive;
     l->tile_order_on = v->tile_order_on;
     l->sorted_records = v->sorted_records;
     l->tile_profile = v->tile_profile;
@@ -264,7 +265,10 @@ gsx_status gsx_viewer_create(const gsx_viewer_desc* desc, gsx_viewer** out) {
     v->tile_profile = getenv("GSX_TILE_PROFILE") != nullptr;
     if (const char* e = getenv("GSX_TILE_ORDER")) v->tile_order_on = atoi(e) != 0;
     if (const char* e = getenv("GSX_SORTED_RECORDS")) v->sorted_records = atoi(e) != 0 ? 1 : 0;
-    if (const char* bx = getenv("GSX_BLOCKS_MAX")) v->blocks_max = (uint32_t)std::max(16, std::min(1024, atoi(bx)));
+    if (const char* bx = getenv("GSX_BLOCKS_MAX")) {
+        v->blocks_max = (uint32_t)std::max(16, std::min(1024, atoi(bx)));
+        v->blocks_adaptive = false;
+    }
     (void)radix_lane_ordered_adds();  // probes THIS device once per process (the answer is kept per device)
     v->device = desc->device;
     if (desc->stream) {
@@ -294,6 +298,7 @@ void gsx_viewer_destroy(gsx_viewer* v) {
     if (v->lane_event) (void)hipEventDestroy(v->lane_event);
     for (hipStream_t ps : v->parked_streams) (void)hipStreamDestroy(ps);
     if (v->h_shard_verdict) (void)hipHostFree(v->h_shard_verdict);
+    if (v->h_verdict_ring) (void)hipHostFree(v->h_verdict_ring);
     for (auto& t : v->timers) {
         (void)hipEventDestroy(t.start);
         (void)hipEventDestroy(t.stop);
@@ -385,13 +390,13 @@ gsx_status gsx_model_create(gsx_viewer* v, const char* key, uint64_t count, gsx_
     if (sh == GSX_SH_SINGLE) {
         HIPCHK(m->sh4.ensure(16 * n * kShPlanes4));
         HIPCHK(m->sh1.ensure(4 * n));
-        HIPCHK(m->sh_aos.ensure(16 * n * (cov3d == GSX_COV3D_SINGLE ? 16 : 12)));
+        HIPCHK(m->sh_aos.ensure(16 * n * 16));
     } else if (sh == GSX_SH_HALF) {
         HIPCHK(m->sh_h.ensure(16 * n * 6));
-        HIPCHK(m->sh_aos.ensure(16 * n * 6));
+        HIPCHK(m->sh_aos.ensure(16 * n * (cov3d == GSX_COV3D_SINGLE ? 12 : 8)));
     } else if (sh == GSX_SH_NORM8) {
         HIPCHK(m->sh_q.ensure(16 * n * 3));
-        HIPCHK(m->sh_aos.ensure(16 * n * 3));
+        HIPCHK(m->sh_aos.ensure(16 * n * 8));
     }
     HIPCHK(m->mask.ensure(4 * ((n + 31) / 32)));
     {

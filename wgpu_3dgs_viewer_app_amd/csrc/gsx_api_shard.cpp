@@ -1,6 +1,7 @@
 // gsx_api_shard.cpp — C ABI for multi-GPU rendering: band layout, external framebuffer, screen bands, and the stage split of
 // the index-sharded exchange (pack / import / feedback / second round).  No reference counterpart (src/main.rs:85-98).
 #include <chrono>
+#include <thread>
 
 #include "gsx_state.h"
 
@@ -137,6 +138,7 @@ gsx_status gsx_shard_set_windows(gsx_viewer* v, const char* key, const uint32_t*
     if (!d_tile_window) return GSX_OK;
     const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
     HIPCHK(m->shard_win.ensure(window_bytes(v)));
+    m->shard_win_current = false;  // (no longer the windows of the model's own limits)
     HIPCHK(gsx::op::MemcpyAsync(m->shard_win.p, d_tile_window, window_bytes(v), hipMemcpyDeviceToDevice, v->stream));
     HIPCHK(m->shard_pyr.ensure(4 * window_pyramid_words(tiles_x, tiles_y)));
     HIPCHK(launch_window_pyramid(v->stream, m->shard_win.as<uint2>(), tiles_x, tiles_y, m->shard_pyr.as<uint32_t>()));
@@ -201,9 +203,12 @@ gsx_status gsx_shard_feedback(gsx_viewer* v, const char* key, uint32_t world, ui
     const uint32_t* tile_sat = v->done_bits.as<uint32_t>() + 1 + (size_t)row_words * tiles_y;
     const uint32_t* row_work = tile_sat + (size_t)tiles_x * tiles_y;  // (do_render: behind the saturation keys)
     const gsx_viewer* o = v->parent ? v->parent : v;
+    // how this rank sizes slots and bands travels with the feedback: ranks that disagree would exchange slots of different sizes
+    // (over RCCL: a hang or silent truncation) — the verification posts the disagreement and the frame fails first
+    const uint32_t policy = (o->shard_balance ? kPolicyBalance : 0u) | (o->shard_pair_slots ? kPolicyPairSlots : 0u) | (m->slot_force << 8);
     HIPCHK(launch_shard_feedback(v->stream, tile_sat, row_work, tiles_x, tiles_y, bands_of(v, world), rank, static_cast<uint32_t*>(d_out_u32),
                                  m->counters.as<Counters>(), m->shard_behind ? m->spec_done_before.as<uint32_t>() : nullptr, row_words,
-                                 (uint32_t)(o->shard_gather_root + 1)));
+                                 (uint32_t)(o->shard_gather_root + 1), policy));
     return GSX_OK;
 }
 
@@ -244,7 +249,9 @@ namespace {
 // per-destination totals; with explicit windows on a lazily projected shard also the travellers' ballots).  window ==
 // nullptr: the windows announced to the projection (its candidate list), or everything.  gate (nullable): bitmap of tiles;
 // a record whose rectangle holds none of them is refused before any window is looked at (the repair round: few tiles).
-gsx_status pack_count(gsx_viewer* v, Model* m, uint32_t world, const uint2* explicit_window, const uint32_t* gate, const WindowPyramid* pyramid) {
+// d_skip (nullable): a device word; 0 = nothing travels in this round (an always-enqueued repair round that has nothing to repair)
+gsx_status pack_count(gsx_viewer* v, Model* m, uint32_t world, const uint2* explicit_window, const uint32_t* gate, const WindowPyramid* pyramid,
+                      const uint32_t* d_skip = nullptr) {
     const uint32_t n = (uint32_t)m->n;
     m->pack_list = !explicit_window && m->shard_win_set && m->cand_valid;
     m->pack_rounds = pack_rounds(m->pack_list);
@@ -278,15 +285,16 @@ gsx_status pack_count(gsx_viewer* v, Model* m, uint32_t world, const uint2* expl
     }
     uint32_t* table = m->pack_table.as<uint32_t>();
     uint32_t* totals = table + (size_t)64 * std::max(nb, 1u);
-    HIPCHK(launch_zero_words(v->stream, totals, 64, nullptr, 0));
+    // (the row scan writes every total — 0 when the round is skipped —: no zeroing launch in front)
     HIPCHK(launch_pack_count(v->stream, m->proj_rec(), n, bands_of(v, world), window, tiles_x, m->pack_masks.as<unsigned long long>(), table, list, d_list_n,
-                             travellers, trav_counts, gate, (tiles_x + 31) / 32, window ? pyramid : nullptr));
-    if (nb) HIPCHK(launch_rowscan(v->stream, table, world, nb, totals, d_list_n, 256u * m->pack_rounds));
+                             travellers, trav_counts, gate, (tiles_x + 31) / 32, window ? pyramid : nullptr, d_skip));
+    if (nb) HIPCHK(launch_rowscan(v->stream, table, world, nb, totals, d_list_n, 256u * m->pack_rounds, d_skip));
+    else HIPCHK(launch_zero_words(v->stream, totals, 64, nullptr, 0));
     return GSX_OK;
 }
 
 // pack_write: shade the travellers the lazy projection skipped, slot headers, the records into their slots
-gsx_status pack_write(gsx_viewer* v, Model* m, uint32_t world, void* d_send, const SlotSpans& slots, uint32_t round) {
+gsx_status pack_write(gsx_viewer* v, Model* m, uint32_t world, void* d_send, const SlotSpans& slots, uint32_t round, const uint32_t* d_skip = nullptr) {
     const uint32_t n = (uint32_t)m->n;
     const uint32_t nb = (uint32_t)pack_blocks(n, m->pack_rounds);
     Counters* dc = m->counters.as<Counters>();
@@ -294,33 +302,33 @@ gsx_status pack_write(gsx_viewer* v, Model* m, uint32_t world, void* d_send, con
     uint32_t* totals = table + (size_t)64 * std::max(nb, 1u);
     if (m->pack_travellers && nb) {
         HIPCHK(m->adm_pairs.ensure(8 * std::max<size_t>(n, 1)));
-        HIPCHK(launch_rowscan(v->stream, m->trav_counts.as<uint32_t>(), 1, nb, &dc->n_sorted2));
+        // (the scatter sums the raw per-workgroup counts itself and leaves the total: no scan launch in between)
         HIPCHK(launch_admit_scatter(v->stream, m->proj_rec().key, n, m->trav_ballots.as<unsigned long long>(), m->trav_counts.as<uint32_t>(),
-                                    m->adm_pairs.as<uint2>()));
+                                    m->adm_pairs.as<uint2>(), d_skip, &dc->n_sorted2));
         gsx_status sst = shade_admitted(v, m, LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>(), m->rect8_active});
         if (sst) return sst;
         m->cand_valid = false;
         m->pack_travellers = false;
     }
-    HIPCHK(launch_pack_headers(v->stream, totals, world, slots, d_send, dc, round));
+    HIPCHK(launch_pack_headers(v->stream, totals, world, slots, d_send, dc, round, d_skip));
     uint64_t send_records = 0;
     for (uint32_t p = 0; p < world; ++p) send_records = std::max<uint64_t>(send_records, (uint64_t)slots.off[p] + 1u + slots.cap[p]);
     HIPCHK(launch_pack_scatter(v->stream, m->proj_rec(), n, world, m->pack_masks.as<unsigned long long>(), table, totals, d_send,
                                send_records, m->pack_list ? m->adm_pairs.as<uint2>() : nullptr,
-                               m->pack_list ? &dc->n_candidates : nullptr, &slots));
+                               m->pack_list ? &dc->n_candidates : nullptr, &slots, d_skip));
     m->stats_pending = true;
     return GSX_OK;
 }
 
 // the repair round's count: windows [limit, inf) on the tiles that need it, nothing elsewhere; decided by the min-pyramid of
 // the window starts (KEY_ALL where no tile needs anything), built here — only frames that repair pay for it
-gsx_status repair_pack_count(gsx_viewer* v, Model* m, uint32_t world) {
+gsx_status repair_pack_count(gsx_viewer* v, Model* m, uint32_t world, const uint32_t* d_skip = nullptr) {
     const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
     HIPCHK(m->shard_pyr2.ensure(4 * window_pyramid_words(tiles_x, tiles_y)));
-    HIPCHK(launch_window_pyramid(v->stream, m->shard_win2.as<uint2>(), tiles_x, tiles_y, m->shard_pyr2.as<uint32_t>(), true));
+    HIPCHK(launch_window_pyramid(v->stream, m->shard_win2.as<uint2>(), tiles_x, tiles_y, m->shard_pyr2.as<uint32_t>(), true, d_skip));
     WindowPyramid pyr2 = window_pyramid_layout(tiles_x, tiles_y, m->shard_pyr2.as<uint32_t>());
     pyr2.min_of_starts = 1;
-    return pack_count(v, m, world, m->shard_win2.as<uint2>(), nullptr, &pyr2);
+    return pack_count(v, m, world, m->shard_win2.as<uint2>(), nullptr, &pyr2, d_skip);
 }
 
 gsx_status ensure_verdict(gsx_viewer* v) {
@@ -349,12 +357,20 @@ gsx_status gsx_shard_frame_begin(gsx_viewer* v, const char* key, uint32_t world,
         m->shard_limit_tx = tiles_x;
         m->shard_limit_ty = tiles_y;
         m->slot_hint = 0;  // nothing is known about what THESE limits let through: the safe slot size
+        m->slot_hint_known = false;
+        if (v->parent)
+            if (Model* om = find_model(v->parent, key)) om->slot_hint_known = false;
     }
     m->shard_frame_limited = speculate && m->shard_limit_valid && m->shard_limit_tx == tiles_x && m->shard_limit_ty == tiles_y;
     m->shard_win_set = false;
+    if (d_limit_override) m->shard_win_current = false;
     if (m->shard_frame_limited) {
         HIPCHK(m->shard_win.ensure(window_bytes(v)));
-        HIPCHK(launch_limits_to_windows(v->stream, m->shard_limit.as<uint32_t>(), n_tiles, m->shard_win.as<uint2>()));
+        // (the kernel that computed these limits wrote their windows too — shard_next_windows_post — unless they came from outside)
+        if (!m->shard_win_current || m->shard_win_tiles != n_tiles)
+            HIPCHK(launch_limits_to_windows(v->stream, m->shard_limit.as<uint32_t>(), n_tiles, m->shard_win.as<uint2>()));
+        m->shard_win_current = true;
+        m->shard_win_tiles = n_tiles;
         // [max-pyramid of the window ends: admission in the projection kernel | min-pyramid: "every tile takes it" in the binning]
         const size_t pw = window_pyramid_words(tiles_x, tiles_y);
         HIPCHK(m->shard_pyr.ensure(8 * pw));
@@ -380,8 +396,12 @@ gsx_status gsx_shard_slot_records(gsx_viewer* v, const char* key, uint32_t world
     // verdict says so and round 0 is redone with the safe size.
     const uint32_t n = std::max<uint32_t>(shard_records_max, 1u);
     uint32_t t = n;
-    if (m->shard_frame_limited && m->slot_hint && m->slot_hint_limited) t = std::min<uint32_t>(n, std::max<uint32_t>(2u * m->slot_hint + 4096u, 8192u));
-    if (m->slot_force) t = std::min<uint32_t>(n, m->slot_force);  // gsx_shard_set_slot_records (the same on every rank, by contract)
+    // (the figures of the last verdict live with the OWNER's model: whichever lane rendered that frame, whichever renders this one)
+    const Model* hm = m;
+    if (v->parent)
+        if (const Model* om = find_model(v->parent, key)) hm = om;
+    if (m->shard_frame_limited && hm->slot_hint_known && hm->slot_hint_limited) t = std::min<uint32_t>(n, std::max<uint32_t>(2u * hm->slot_hint + 4096u, 8192u));
+    if (hm->slot_force) t = std::min<uint32_t>(n, hm->slot_force);  // gsx_shard_set_slot_records (the same on every rank, by contract)
     *out_records = t;
     (void)world;
     return GSX_OK;
@@ -395,7 +415,7 @@ gsx_status gsx_shard_pack_slots(gsx_viewer* v, const char* key, uint32_t world, 
 }  // extern "C"
 
 // slots: where the records for every destination go (sizes that both ends of every pair agree on: gsx_shard_frame.cpp)
-gsx_status gsx::shard_pack_slots(gsx_viewer* v, const char* key, uint32_t world, uint32_t round, void* d_send, const SlotSpans& slots) {
+gsx_status gsx::shard_pack_slots(gsx_viewer* v, const char* key, uint32_t world, uint32_t round, void* d_send, const SlotSpans& slots, bool gated) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
     Model* m = find_model(v, key);
@@ -406,8 +426,12 @@ gsx_status gsx::shard_pack_slots(gsx_viewer* v, const char* key, uint32_t world,
     if (round == 1) {
         if (m->shard_win2.bytes < window_bytes(v)) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_pack_slots: round 1 before gsx_shard_verify");
         // the repair round is counted once (gsx_shard_repair_count sized it); packing without it counts here
-        if (!m->repair_counted && (st = repair_pack_count(v, m, world))) return st;
+        // gated: the round was enqueued without asking whether any tile needs it (gsx_shard_frame.cpp); its kernels look at the
+        // verification's count on the device and fall through when it is 0
+        const uint32_t* d_skip = gated ? &m->counters.as<Counters>()->shard_need : nullptr;
+        if (!m->repair_counted && (st = repair_pack_count(v, m, world, d_skip))) return st;
         m->repair_counted = false;
+        return pack_write(v, m, world, d_send, slots, round, d_skip);
     } else {
         // the senders decide by the max-pyramid of the window ends, per destination band (a conservative superset; the
         // receiver bins by the exact windows)
@@ -525,6 +549,95 @@ gsx_status gsx_shard_verify(gsx_viewer* v, const char* key, uint32_t world, cons
     return GSX_OK;
 }
 
+}  // extern "C"
+
+// ---- verdicts that are read late: the device-decided frame (gsx_shard_frame.cpp) ----
+// verdicts_outstanding: how many verdicts may be posted before the oldest is read (models per frame x frames that stay unretired)
+gsx_status gsx::shard_ensure_ring(gsx_viewer* v, uint32_t verdicts_outstanding) {
+    const uint32_t want = std::max<uint32_t>(8u, verdicts_outstanding + 2u);
+    if (v->h_verdict_ring && v->ring_slots >= want) return GSX_OK;
+    HIPCHK(gsx::op::StreamSynchronize(v->stream));  // (nothing in flight posts into the old ring any more)
+    uint32_t* ring = nullptr;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ring), 4 * (size_t)kVerdictWords * want, hipHostMallocDefault));
+    memset(ring, 0, 4 * (size_t)kVerdictWords * want);
+    // verdicts already posted and not read yet keep their slots' contents only if the slot index survives: it does not when the ring
+    // grows, so the caller grows it only between frames whose verdicts have all been read (frame_front: before anything is enqueued)
+    if (v->h_verdict_ring) (void)hipHostFree(v->h_verdict_ring);
+    v->h_verdict_ring = ring;
+    v->ring_slots = want;
+    HIPCHK(v->verdict_stage.ensure(4 * (size_t)kVerdictWords));
+    return GSX_OK;
+}
+
+gsx_status gsx::shard_verify_staged(gsx_viewer* v, const char* key, uint32_t world, const void* d_sat_all) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m || !d_sat_all) return fail(GSX_ERR_NOT_FOUND, "shard_verify_staged: no model '%s' / null argument", key ? key : "(null)");
+    if ((st = check_bands(v, world, "gsx_shard_render_frame"))) return st;
+    const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
+    HIPCHK(m->shard_win2.ensure(window_bytes(v)));
+    HIPCHK(m->shard_need_bits.ensure(4 * (size_t)((tiles_x + 31) / 32) * tiles_y));
+    HIPCHK(v->verdict_stage.ensure(4 * (size_t)kVerdictWords));
+    Counters* dc = m->counters.as<Counters>();
+    HIPCHK(launch_zero_words(v->stream, &dc->shard_need, 2, m->shard_need_bits.as<uint32_t>(), ((tiles_x + 31) / 32) * tiles_y));
+    const gsx_viewer* o = v->parent ? v->parent : v;
+    // the verdict block goes to DEVICE memory: nobody waits for it; k_shard_post_verdict posts it behind the repair round
+    HIPCHK(launch_shard_verify(v->stream, m->shard_frame_limited ? m->shard_limit.as<uint32_t>() : nullptr, static_cast<const uint32_t*>(d_sat_all),
+                               tiles_x, tiles_y, bands_of(v, world), m->shard_win2.as<uint2>(), &dc->shard_need, &dc->shard_ticket,
+                               v->verdict_stage.as<unsigned long long>(), 0u, m->shard_need_bits.as<uint32_t>(), o->shard_balance ? 1u : 0u));
+    m->repair_counted = false;
+    m->stats_pending = true;
+    return GSX_OK;
+}
+
+gsx_status gsx::shard_post_verdict(gsx_viewer* v, uint32_t world, const void* d_sat_after_repair, uint32_t* out_seq) {
+    if (!v->h_verdict_ring || !v->ring_slots) return fail(GSX_ERR_INVALID_ARG, "shard_post_verdict: no verdict ring");
+    *out_seq = ++v->ring_seq;
+    if (*out_seq == 0) *out_seq = ++v->ring_seq;  // (0 = "nothing posted yet" in a fresh slot)
+    uint32_t* block = v->h_verdict_ring + (size_t)(*out_seq % v->ring_slots) * kVerdictWords;
+    const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE;
+    HIPCHK(launch_shard_post_verdict(v->stream, v->verdict_stage.as<uint32_t>(), static_cast<const uint32_t*>(d_sat_after_repair), world,
+                                     feedback_stride(bands_of(v, world), tiles_x), block, *out_seq));
+    return GSX_OK;
+}
+
+// Spins on slot seq % ring of the pinned ring until the kernel that posts `seq` has run (normally it has: the frame was enqueued a
+// call or two ago).  Bounded like gsx_shard_wait_verdict.  *block: the whole verdict block (kVerdict* layout).
+gsx_status gsx::shard_wait_ring(gsx_viewer* v, uint32_t seq, gsx_shard_verdict* out, const uint32_t** block) {
+    if (!v || !out || !v->h_verdict_ring) return fail(GSX_ERR_INVALID_ARG, "shard_wait_ring: nothing was posted");
+    const uint32_t* b = v->h_verdict_ring + (size_t)(seq % v->ring_slots) * kVerdictWords;
+    const unsigned long long* w64 = reinterpret_cast<const unsigned long long*>(b);
+    const auto t_start = std::chrono::steady_clock::now();
+    trace_flush();
+    for (uint64_t spin = 1;; ++spin) {
+        const unsigned long long w = __atomic_load_n(&w64[0], __ATOMIC_ACQUIRE);
+        if ((uint32_t)(w >> 32) == seq) {
+            const unsigned long long d = __atomic_load_n(&w64[1], __ATOMIC_RELAXED);
+            out->need_tiles = (uint32_t)w;
+            out->overflow = (uint32_t)(d & 1ull);
+            out->max_records = (uint32_t)(d >> 32);
+            if (block) *block = b;
+            return GSX_OK;
+        }
+        if ((spin & 0xFFFu) == 0) {
+            const hipError_t e = gsx::op::StreamQuery(v->stream);
+            if (e == hipSuccess) {
+                const unsigned long long w2 = __atomic_load_n(&w64[0], __ATOMIC_ACQUIRE);
+                if ((uint32_t)(w2 >> 32) == seq) continue;
+                return fail(GSX_ERR_HIP, "sharded frame: verdict %u never arrived (stream idle)", seq);
+            }
+            if (e != hipErrorNotReady) return fail(GSX_ERR_HIP, "stream failed while waiting for a sharded frame's verdict: %s", hipGetErrorString(e));
+            if ((spin & 0xFFFFFu) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(60))
+                return fail(GSX_ERR_RCCL, "sharded frame: verdict %u did not arrive within 60 s (a collective is stuck)", seq);
+        }
+        if (spin > 4096) std::this_thread::sleep_for(std::chrono::microseconds(5));  // a long wait (the device is a frame behind): yield
+        else __builtin_ia32_pause();
+    }
+}
+
+extern "C" {
+
 // Spins on the pinned verdict words until the kernel that posts `seq` has run.  Bounded by the stream itself: if the stream
 // drains (or fails) and the words still are not there, that is reported instead of spinning forever.
 gsx_status gsx_shard_wait_verdict(gsx_viewer* v, const char* key, uint32_t seq, gsx_shard_verdict* out) {
@@ -541,8 +654,12 @@ gsx_status gsx_shard_wait_verdict(gsx_viewer* v, const char* key, uint32_t seq, 
             out->overflow = (uint32_t)(d & 1ull);
             out->max_records = (uint32_t)(d >> 32);
             if (Model* m = find_model(v, key)) {  // next frame's round-0 slots (global: same on every rank)
-                m->slot_hint = out->max_records;
-                m->slot_hint_limited = m->shard_frame_limited;
+                Model* hm = m;
+                if (v->parent)
+                    if (Model* om = find_model(v->parent, key)) hm = om;
+                hm->slot_hint = out->max_records;
+                hm->slot_hint_known = true;
+                hm->slot_hint_limited = m->shard_frame_limited;
             }
             return GSX_OK;
         }
@@ -575,10 +692,42 @@ gsx_status gsx_shard_next_windows(gsx_viewer* v, const char* key, uint32_t world
     HIPCHK(launch_shard_next_limits(v->stream, static_cast<const uint32_t*>(d_sat_all), tiles_x, tiles_y, margin, radius, next.as<uint32_t>(),
                                     bands_of(v, world)));
     m->shard_next_valid = true;
+    m->shard_win_next_valid = false;  // (these limits come without their windows: whatever shard_win_next holds belongs to older ones)
     m->shard_limit_tx = tiles_x;
     m->shard_limit_ty = tiles_y;
     return GSX_OK;
 }
+
+}  // extern "C"
+
+// gsx_shard_next_windows for the frames of gsx_shard_frame.cpp: the same limits, plus — in the same launch — the windows [0, limit) of the
+// model's next frame and the frame's verdict (what shard_post_verdict does as a launch of its own)
+gsx_status gsx::shard_next_windows_post(gsx_viewer* v, const char* key, uint32_t world, const void* d_sat_all, float margin, uint32_t radius,
+                                        const void* d_sat_after_repair, uint32_t* out_seq) {
+    gsx_status st = viewer_bind(v);
+    if (st) return st;
+    Model* m = find_model(v, key);
+    if (!m || !d_sat_all || !out_seq) return fail(GSX_ERR_NOT_FOUND, "shard_next_windows_post: no model '%s' / null argument", key ? key : "(null)");
+    if (!(margin >= 0.0f) || radius > 16 || world == 0 || world > 64) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_render_frame: margin >= 0, radius <= 16, world 1..64");
+    if ((st = check_bands(v, world, "gsx_shard_render_frame"))) return st;
+    if (!v->h_verdict_ring || !v->ring_slots) return fail(GSX_ERR_INVALID_ARG, "shard_next_windows_post: no verdict ring");
+    const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE, tiles_y = (v->height + GSX_TILE - 1) / GSX_TILE;
+    HIPCHK(m->shard_limit_next.ensure(4 * (size_t)tiles_x * tiles_y));
+    HIPCHK(m->shard_win_next.ensure(window_bytes(v)));
+    *out_seq = ++v->ring_seq;
+    if (*out_seq == 0) *out_seq = ++v->ring_seq;
+    uint32_t* block = v->h_verdict_ring + (size_t)(*out_seq % v->ring_slots) * kVerdictWords;
+    HIPCHK(launch_shard_next_limits(v->stream, static_cast<const uint32_t*>(d_sat_all), tiles_x, tiles_y, margin, radius, m->shard_limit_next.as<uint32_t>(),
+                                    bands_of(v, world), m->shard_win_next.as<uint2>(), v->verdict_stage.as<uint32_t>(),
+                                    static_cast<const uint32_t*>(d_sat_after_repair), block, *out_seq));
+    m->shard_next_valid = true;
+    m->shard_win_next_valid = true;
+    m->shard_limit_tx = tiles_x;
+    m->shard_limit_ty = tiles_y;
+    return GSX_OK;
+}
+
+extern "C" {
 
 gsx_status gsx_shard_frame_end(gsx_viewer* v, const char* key) {
     Model* m = find_model(v, key);
@@ -588,6 +737,14 @@ gsx_status gsx_shard_frame_end(gsx_viewer* v, const char* key) {
         std::swap(m->shard_limit.bytes, m->shard_limit_next.bytes);
         m->shard_limit_valid = true;
         m->shard_next_valid = false;
+        // ... and their windows, where the same kernel wrote them
+        m->shard_win_current = false;
+        if (m->shard_win_next_valid) {
+            std::swap(m->shard_win.p, m->shard_win_next.p);
+            std::swap(m->shard_win.bytes, m->shard_win_next.bytes);
+            m->shard_win_current = true;
+            m->shard_win_next_valid = false;
+        }
     }
     return GSX_OK;
 }

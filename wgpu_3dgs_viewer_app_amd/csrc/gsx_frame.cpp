@@ -72,6 +72,7 @@ static gsx_status wait_verdict(gsx_viewer* v, uint32_t seq, uint32_t* need) {
 //   frames until the probe's timings have arrived) -> decide;   PLAIN -> PROBE_SPEC -> SETTLE -> decide likewise.
 // A decision that confirms the current mode doubles its phase — quadruples it when the verdict is clear — (64 ... 2048
 // frames: the probes then cost < 1 %), one that flips it starts over at 64.  By construction the result stays within a few per cent of the better of the two paths.
+constexpr uint32_t kWalkFineOn = 160, kWalkFineOff = 30;  // chunks of 128 candidates: finer blocks above / coarse blocks again below (measured under the finer ones)
 constexpr uint32_t kProbeFrames = 5;   // the first is not timed (the switch itself is atypical), the other four are
 constexpr uint32_t kSettleWait = 8;    // frames enqueued behind a probe before the host waits for its timings
 constexpr uint32_t kSettleFrames = 64; // at most this many frames between a probe and the decision it feeds (normally: until its timings are in)
@@ -635,6 +636,13 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
         // SORTED); with hysteresis, from whatever frame's statistics arrived last — either way the pixels are the same
         const uint64_t per_tile = (uint64_t)m->h_counters->n_entries_total / std::max<uint32_t>(n_tiles, 1u);
         m->lists_long = m->lists_long ? per_tile > 500u : per_tile > 900u;
+        // a tile that never saturates walks its block's whole list, 128 candidates per ~1.5 us, and the launch is as slow as that tile
+        // (an open horizon: 425 chunks for 1900 takers with blocks of 8 x 4 tiles).  Blocks of a quarter the size cut the walk ~3.5x
+        // and cost a second digit in the block sort and ~2x the entries: - 12 % on cfg4's orbit, + 16 % under an open sky
+        // (tools/ab_blocks.py, round 5).  So the block size follows the longest walk of an earlier frame (SlabStats::walk_max, left
+        // by tile_order_job), with hysteresis; either way the pixels are the same.
+        const uint32_t walk = m->h_counters->walk_max;
+        m->blocks_fine = m->blocks_fine ? walk > kWalkFineOff : walk > kWalkFineOn;
     }
     std::vector<uint32_t> bounds;
     const bool imported_windows = m->use_imported && m->has_window && progressive;
@@ -713,9 +721,11 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
         zero_pending = false;
     }
     uint32_t bsx = 0, bsy = 0;
+    // most blocks of this frame: GSX_BLOCKS_MAX when it was given, otherwise 256 (one 8-bit sort pass) — or 1024 while some tile's walk is long
+    const uint32_t blocks_max = v->blocks_adaptive && m->blocks_fine ? 1024u : v->blocks_max;
     if (blocks) {
         auto count = [&]() { return (uint64_t)((m->fc.tiles_x + (1u << bsx) - 1u) >> bsx) * ((m->fc.tiles_y + (1u << bsy) - 1u) >> bsy); };
-        while (count() > v->blocks_max) (bsx <= bsy ? bsx : bsy) += 1;
+        while (count() > blocks_max) (bsx <= bsy ? bsx : bsy) += 1;
         HIPCHK(m->block_table.ensure(sizeof(uint4) * 1024));
         if (v->tile_profile) HIPCHK(v->tile_prof.ensure(sizeof(uint4) * (size_t)n_tiles));
     }
@@ -749,7 +759,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
             //  its own was measured, round 4: two launches less per frame, and slower — every emit workgroup flushes up to 256 bins to
             //  the same 256 addresses: binning 69 -> 86 us against block sort 37 -> 25 on a speculated cfg4 frame, 218 -> 327 against
             //  69 -> 45 unspeculated.  Not kept.)
-            const int block_bits = (int)std::max<uint32_t>(1u, ceil_log2(v->blocks_max));
+            const int block_bits = (int)std::max<uint32_t>(1u, ceil_log2(blocks_max));
             ZeroJob jobs = zero_pending ? zero : ZeroJob{};
             if (order_build && !table_ready) {
                 jobs.order_buf = order_buf;
@@ -777,7 +787,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
                 // (<= 256 blocks: ONE digit, and the block ranges are the scan of its histogram — no k_tile_ranges launch;
                 //  k_block_table zeroed the ranges, which is what stays when the slab made no entry at all)
                 // sorted_records: the write-out also carries every entry's {rect, key, index} record along
-                sorted_records = block_bits <= 8 && (v->sorted_records >= 0 ? v->sorted_records == 1 : m->lists_long);
+                sorted_records = v->sorted_records >= 0 ? v->sorted_records == 1 : m->lists_long;  // (the LAST digit pass carries them)
                 if (sorted_records) HIPCHK(m->brec_sorted.ensure(sizeof(uint4) * (size_t)cap));
                 HIPCHK(launch_radix_sort(v->stream, rb, block_cap, &dc->n_entries, block_bits, false, false, block_bits <= 8 ? m->ranges.as<uint2>() : nullptr,
                                          sorted_records ? m->srect.as<uint4>() : nullptr, sorted_records ? m->brec_sorted.as<uint4>() : nullptr));

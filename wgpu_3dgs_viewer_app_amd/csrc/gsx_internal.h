@@ -62,7 +62,8 @@ __host__ __device__ inline uint32_t band_rows_max(const BandEdges& b) {
 }
 // One rank's feedback after a round (gsx_shard_feedback), in u32 words:
 //   [0] records it wanted to send to its busiest destination   [1] a slot overflowed   [2] gather root + 1 (0: every rank receives)
-//   [3] list entries it binned this round   [4..7] 0   [8 + d] records it wanted to send to destination d (round 0)
+//   [3] list entries it binned this round   [4] / [5] the same as [0] / [1] for the repair round   [6] policy flags (how it sizes slots
+//   and bands: kPolicy*)   [7] 0   [8 + d] records it wanted to send to destination d (round 0)
 //   then rows x tiles_x saturation depth keys of its band (0 = open), then rows words of per-tile-row work (per tile: list entries
 //   tile_work(): what the next frame's bands are balanced by); rows = its band's height.
 // The pieces are gathered at a common stride (the tallest band's piece); a rank sends only what its own band needs.
@@ -90,7 +91,9 @@ __host__ __device__ inline uint32_t feedback_words(const BandEdges& b, uint32_t 
 //   [4] the ranks disagree about the gather root   [5] list entries of all ranks   [6] largest of any rank   [7] work of the busiest
 //   rank x world x 1000 / work of all (how evenly this frame's bands shared it)   [8 .. 8 + world] band edges for
 //   the next frame   [80 + s * world + d] records rank s wanted to send to rank d in round 0
-constexpr uint32_t kVerdictEdges = 8, kVerdictMatrix = 80, kVerdictWords = kVerdictMatrix + kMaxRanks * kMaxRanks;
+//   [76] (frames whose repair round is always enqueued) most records any rank had for ONE destination in the repair round
+//   [77] ... and whether a repair slot overflowed
+constexpr uint32_t kVerdictEdges = 8, kVerdictRepairMax = 76, kVerdictRepairOver = 77, kVerdictMatrix = 80, kVerdictWords = kVerdictMatrix + kMaxRanks * kMaxRanks;
 
 // Resident pod planes of one model (SoA, every plane contiguous over the model's N Gaussians).
 // The reference's 8-way pod choice (scene.rs:23-81) selects which SH / cov3d planes exist:
@@ -106,17 +109,29 @@ struct PodPlanes {
     float* sh1;      // N   : SH float 44
     uint4* sh_h;     // 6*N : plane p holds SH floats 8p..8p+7 as f16
     uint4* sh_q;     // 3*N : plane p holds SH floats 16p..16p+15 as snorm8
-    uint4* sh_aos;   // P*N : record copy of the SH planes, P = aos_stride consecutive words per Gaussian (plane order; f32: word
-                     //       11 = {float 44, 0, 0, 0}); nullptr for Sh None.  Read by the sparse shading pass, where whole lines
-                     //       count.  f32 SH + f32 covariance: P = 16, a 256-byte record that also carries word 12 = pc, 13 = cov_a,
-                     //       14 = {cov_b, 0, 0} — everything k_shade reads about a Gaussian, in two 128-byte lines.
-    uint32_t aos_stride;  // 16 (full record) | 12 / 6 / 3 (SH only: f32 / f16 / snorm8)
+    uint4* sh_aos;   // P*N : the shade record, P = aos_stride consecutive words per Gaussian: the SH words in plane order (f32: 12, word
+                     //       11 = {float 44, 0, 0, 0}; f16: 6; snorm8: 3), then pc and the covariance (aos_geo) — everything the sparse
+                     //       shading pass reads about a Gaussian, in whole cache lines: 256 B (f32 SH), 192 / 128 B (f16 SH with f32 / f16
+                     //       covariance), 128 B (snorm8 SH).  nullptr for Sh None.
+    uint32_t aos_stride;  // words (uint4) per record: aos_layout()
+    uint32_t aos_geo;     // word of the record that holds pc; the covariance follows (f32: two words {xx,xy,xz,yy} {yz,zz,0,0}; f16: one
+                          // word {xx|xy, xz|yy, yz|zz, 0}).  The record holds EVERYTHING the sparse shading reads about a Gaussian.
     uint2* cov_h;    // N   : xx, xy, xz, yy as f16
     uint32_t* cov_h2;  // N : yz, zz as f16
     uint32_t* mask;  // ceil(N/32) words, bit = keep (nullptr: keep all)
     int sh_kind;     // gsx_sh_kind
     int cov_kind;    // gsx_cov3d_kind
 };
+
+// words per shade record and the word that holds pc, by pod kind (PodPlanes::sh_aos)
+inline void aos_layout(int sh_kind, int cov_kind, uint32_t* stride, uint32_t* geo) {
+    switch (sh_kind) {
+        case GSX_SH_SINGLE: *stride = 16u; *geo = 12u; break;
+        case GSX_SH_HALF: *stride = cov_kind == GSX_COV3D_SINGLE ? 12u : 8u; *geo = 6u; break;
+        case GSX_SH_NORM8: *stride = 8u; *geo = 3u; break;
+        default: *stride = 0u; *geo = 0u; break;
+    }
+}
 
 // Projected records of one model for the current frame (valid where key != kCulledKey).
 struct Records {
@@ -235,6 +250,8 @@ struct SlabStats {
     uint32_t shard_ticket;     // k_shard_verify: blocks done (the last one posts the verdict); directly behind shard_need: zeroed together
     uint32_t slot_want[64];    // records this rank wanted to send to each destination in the last round 0 (k_pack_headers): the
                                // gathered count matrix sizes the next frame's slots per (source, destination) pair
+    uint32_t walk_max;         // block compositor: the longest walk of any tile in the model's frame BEFORE the one that wrote it, in chunks
+                               // of 128 list candidates (tile_order_job) — the host picks the block size by it (gsx_frame.cpp)
     // ---- from here on: zeroed at the start of every frame ----
     uint32_t n_entries;        // D of the slab being processed: what was binned into the pair buffers (<= their capacity)
     uint32_t n_entries_total;  // sum of slab D over the frame (including entries the spill compositor handled without pairs)
@@ -272,7 +289,8 @@ constexpr uint32_t tile_order_lds_words(uint32_t n_tiles) { return 3u * ((n_tile
 // order (neighbours share block lists and records: they still run together).  threshold <- this frame's average cost.
 // One workgroup of THREADS lanes; a wave takes 64 consecutive tiles at a time: one coalesced load, one ballot, no second look at memory.
 template <uint32_t THREADS>
-__device__ __forceinline__ void tile_order_job(uint32_t* __restrict__ order_buf, const uint32_t n_tiles, uint32_t* __restrict__ lds /* tile_order_lds_words(n_tiles), 8-byte aligned */) {
+__device__ __forceinline__ void tile_order_job(uint32_t* __restrict__ order_buf, const uint32_t n_tiles, uint32_t* __restrict__ lds /* tile_order_lds_words(n_tiles), 8-byte aligned */,
+                                               uint32_t* __restrict__ walk_max_out /* <- the longest walk of any tile in that frame, in chunks (SlabStats::walk_max) */) {
     constexpr uint32_t kWaves = THREADS / 64u, kBatch = 16u;
     const uint32_t groups = (n_tiles + 63u) / 64u;
     unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(lds);   // bit l of group g: tile 64 g + l is expensive
@@ -282,13 +300,18 @@ __device__ __forceinline__ void tile_order_job(uint32_t* __restrict__ order_buf,
     uint32_t* __restrict__ tile_order = tile_cost + n_tiles;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t thr = order_buf[0];
-    uint32_t sum = 0;
+    uint32_t sum = 0, walk = 0;
     for (uint32_t gb = wave; gb < groups; gb += kBatch * kWaves) {  // kBatch loads in flight per lane (one workgroup: latency is all there is)
         uint32_t c[kBatch];
 #pragma unroll
         for (uint32_t k = 0; k < kBatch; ++k) {
             const uint32_t tile = (gb + k * kWaves) * 64u + lane;
             c[k] = tile < n_tiles ? tile_cost[tile] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kBatch; ++k) {  // {chunks walked << 16 | takers} (summed over the frame's launches) -> the cost the order is made by
+            walk = max(walk, c[k] >> 16);
+            c[k] = (9u * (c[k] >> 16) + (c[k] & 0xFFFFu)) >> 2;
         }
 #pragma unroll
         for (uint32_t k = 0; k < kBatch; ++k) {
@@ -300,8 +323,21 @@ __device__ __forceinline__ void tile_order_job(uint32_t* __restrict__ order_buf,
         }
     }
 #pragma unroll
-    for (uint32_t d = 32u; d; d >>= 1) sum += __shfl_xor(sum, d);
-    if (lane == 0u) s_sum[wave] = sum;
+    for (uint32_t d = 32u; d; d >>= 1) {
+        sum += __shfl_xor(sum, d);
+        walk = max(walk, (uint32_t)__shfl_xor(walk, d));
+    }
+    if (lane == 0u) {
+        s_sum[wave] = sum;
+        s_cnt[wave] = walk;  // (s_cnt is written again only behind the next barrier)
+    }
+    __syncthreads();
+    if (tid == 0u && walk_max_out) {
+        uint32_t w = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kWaves; ++k) w = max(w, s_cnt[k]);
+        *walk_max_out = w;
+    }
     __syncthreads();
     // exclusive scan of the groups' counts: every lane a contiguous run of groups, then the runs
     const uint32_t per = (groups + THREADS - 1u) / THREADS, g0 = min(tid * per, groups), g1 = min(g0 + per, groups);
@@ -467,8 +503,10 @@ hipError_t launch_admit_from_project(hipStream_t s, const uint32_t* key, uint32_
 // binning applies the exact per-tile windows, so the surplus only rides through the depth sort.
 size_t admit_blocks(uint64_t n);
 // compaction from ballots over 4096-record workgroups (offsets = exclusively scanned per-workgroup counts)
+// d_total != nullptr: `offsets` holds the RAW per-workgroup counts — every workgroup sums the ones in front of it itself and the last
+// writes the total (no scan launch in between)
 hipError_t launch_admit_scatter(hipStream_t s, const uint32_t* key, uint32_t n, const unsigned long long* ballots,
-                                const uint32_t* offsets, uint2* pairs);
+                                const uint32_t* offsets, uint2* pairs, const uint32_t* d_skip = nullptr, uint32_t* d_total = nullptr);
 // (rec.rect8 != nullptr: rectangles are read from the packed plane)
 hipError_t launch_admit(hipStream_t s, const Records& rec, uint32_t n, const uint2* window, uint32_t tiles_x,
                         const uint32_t* gate, uint32_t row_words, const WindowPyramid& pyramid, const uint32_t* d_skip, unsigned long long* ballots, uint32_t* counts, uint32_t* d_total, uint2* pairs);
@@ -504,7 +542,8 @@ hipError_t launch_pack_count(hipStream_t s, const Records& rec, uint32_t n, cons
                              const uint2* list, const uint32_t* d_list_n, unsigned long long* travellers, uint32_t* traveller_counts,
                              const uint32_t* gate = nullptr /* tile bitmap: records whose rectangle holds no gated tile go nowhere */,
                              uint32_t gate_row_words = 0,
-                             const WindowPyramid* pyramid = nullptr /* decide by the windows' pyramid alone: a conservative superset */);
+                             const WindowPyramid* pyramid = nullptr /* decide by the windows' pyramid alone: a conservative superset */,
+                             const uint32_t* d_skip = nullptr /* points at 0: nothing travels, nothing is read or written (an always-enqueued repair round) */);
 // The slots of an exchange buffer, in records: slot p = one header record at off[p], then up to cap[p] records.
 struct SlotSpans {
     uint32_t off[kMaxRanks], cap[kMaxRanks];
@@ -520,9 +559,14 @@ inline SlotSpans uniform_slots(uint32_t world, uint32_t cap) {
 hipError_t launch_pack_scatter(hipStream_t s, const Records& rec, uint32_t n, uint32_t world,
                                const unsigned long long* masks, const uint32_t* table, const uint32_t* totals, void* d_send,
                                uint64_t capacity, const uint2* list, const uint32_t* d_list_n,
-                               const SlotSpans* slots = nullptr /* != nullptr: into these slots, headers first, at most cap[p] records each */);
+                               const SlotSpans* slots = nullptr /* != nullptr: into these slots, headers first, at most cap[p] records each */,
+                               const uint32_t* d_skip = nullptr);
 // device-resident exchange (kernels_shard.hip): slot headers, import from slots, windows / verification / next limits
-hipError_t launch_pack_headers(hipStream_t s, const uint32_t* totals, uint32_t world, const SlotSpans& slots, void* d_send, SlabStats* stats, uint32_t round);
+hipError_t launch_pack_headers(hipStream_t s, const uint32_t* totals, uint32_t world, const SlotSpans& slots, void* d_send, SlabStats* stats, uint32_t round,
+                               const uint32_t* d_skip = nullptr);
+// staged: the round-0 verdict block in device memory (launch_shard_verify with a device pointer); sat (nullable): the feedback gathered
+// after the repair round; host_block: the frame's slot of the pinned ring
+hipError_t launch_shard_post_verdict(hipStream_t s, const uint32_t* staged, const uint32_t* sat, uint32_t world, uint32_t stride, uint32_t* host_block, uint32_t seq);
 hipError_t launch_import_slots(hipStream_t s, const void* d_recv, uint32_t world, const SlotSpans& slots, const Records& rec, SlabStats* stats);
 hipError_t launch_limits_to_windows(hipStream_t s, const uint32_t* limit, uint32_t n_tiles, uint2* win);
 // sat: the all-gathered feedback, piece g at word g * feedback_stride(bands, tiles_x) (layout: feedback_* below)
@@ -531,11 +575,16 @@ hipError_t launch_shard_verify(hipStream_t s, const uint32_t* limit, const uint3
                                uint32_t* need_bits /* zeroed; bit per tile that needs the repair round */, uint32_t balance /* post balanced edges for the next frame */);
 hipError_t launch_shard_post_counts(hipStream_t s, const uint32_t* counts_all, uint32_t world, unsigned long long* host_verdict, uint32_t seq);
 hipError_t launch_shard_max_count(hipStream_t s, const uint32_t* totals, uint32_t world, uint32_t* out4);
+// win_next (nullable): also the next frame's round-0 windows [0, limit); staged + host_block (nullable): block 0 posts the frame's verdict on
+// its way (what launch_shard_post_verdict does as a launch of its own; sat_verdict: the feedback gathered after the repair round, or nullptr)
 hipError_t launch_shard_next_limits(hipStream_t s, const uint32_t* sat, uint32_t tiles_x, uint32_t tiles_y, float margin, uint32_t radius,
-                                    uint32_t* limit, const BandEdges& bands);
+                                    uint32_t* limit, const BandEdges& bands, uint2* win_next = nullptr, const uint32_t* staged = nullptr,
+                                    const uint32_t* sat_verdict = nullptr, uint32_t* host_block = nullptr, uint32_t seq = 0);
 // this rank's feedback piece (layout: feedback_* above)
 hipError_t launch_shard_feedback(hipStream_t s, const uint32_t* tile_sat, const uint32_t* row_work, uint32_t tiles_x, uint32_t tiles_y, const BandEdges& bands,
-                                 uint32_t rank, uint32_t* out, const SlabStats* stats, const uint32_t* done_before, uint32_t row_words, uint32_t gather_root_plus1);
+                                 uint32_t rank, uint32_t* out, const SlabStats* stats, const uint32_t* done_before, uint32_t row_words, uint32_t gather_root_plus1,
+                                 uint32_t policy_flags = 0);
+constexpr uint32_t kPolicyBalance = 1u, kPolicyPairSlots = 2u;  // feedback word [6]; bits 8.. : the model's forced slot size (gsx_shard_set_slot_records)
 hipError_t launch_import_records(hipStream_t s, const void* d_recv, uint32_t n, const Records& rec);
 
 // Mask evaluation (kernels_mask.hip); passed to the kernel by value.

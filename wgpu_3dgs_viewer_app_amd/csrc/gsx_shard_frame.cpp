@@ -3,25 +3,37 @@
 // counterpart (src/main.rs:85-98: one wgpu device); what it must reproduce is the single-GPU frame — for several models the
 // reference's layering: painted far -> near, never merged (src/tab/scene.rs:533-558, 2302-2314).
 //
-// The frame, per model in COMPOSITING order (nearest first; the far -> near key list walked backwards, as gsx_render does):
-//   front   gsx_shard_frame_begin of every model (projection; windows from the model's own limits of its last frame), then
-//           for each model: round 0 = pack -> all-to-all of fixed slots -> import + depth sort + composite into this rank's
-//           band (behind the nearer models) -> feedback -> all-gather of the saturation map -> verify (posts the model's
-//           verdict) -> next limits.  Between two models the host looks at the verdict: the repair round of a model has to be
-//           composited before the next model's records are (order matters per pixel), so for layered frames that one wait per
-//           model boundary is on the critical path; the LAST model's verdict is not looked at here.
-//   back    the last model's verdict: a slot overflowed -> the whole frame again with whole-shard slots (cannot overflow);
-//           tiles need a repair -> count, size exactly, exchange, composite behind.  Then the in-place band all-gather and
-//           gsx_shard_frame_end of every model.
-// With one frame in flight front and back run in the same call (the band gather is enqueued before the wait: that is what
-// follows in the usual frame).  With gsx_render_options.frames_in_flight = L > 1 a call enqueues the front of frame k on lane
-// k mod L and then runs the back of frame k - L + 1: its verdict arrived while the host was enqueueing, so nothing waits,
-// and the device always has L - 1 other frames queued.  Every lane has its own communicator and stream (gsx_comm.cpp), so
-// one frame's exchange never queues behind another frame's gather.
+// The frame, per model in COMPOSITING order (nearest first; the far -> near key list walked backwards, as gsx_render does).  The
+// call ENQUEUES all of it and returns; nothing in it waits for the device (round 5 — until then the host read a verdict per
+// model and decided about the repair round):
+//   gsx_shard_frame_begin of every model (projection; windows from the model's own limits of its last frame), then for each model:
+//   round 0   pack -> all-to-all of fixed slots -> import + depth sort + composite into this rank's band (behind the nearer
+//             models) -> feedback -> all-gather of the saturation map -> verification: which tiles were refused records they
+//             still need, their repair windows, the count — all on the device (the verdict block staged in device memory).
+//   round 1   the repair exchange, ALWAYS enqueued when the frame was limited by windows, with slots of a fixed size R (twice what
+//             the busiest pair had in the last repair round whose verdict was read): its kernels look at the verification's count
+//             and fall through when no tile needs anything; the all-to-all moves the (empty) slots regardless.  What it
+//             delivers is composited behind what the tiles hold; feedback + all-gather once more.
+//   verdict   one kernel posts the model's verdict block — tiles that needed the repair, a slot of either round overflowed, the
+//             count matrix, next frame's band edges — into slot (seq mod ring) of a pinned ring; next limits from the last
+//             gathered saturation map.  The next model follows at once: its records are composited behind a finished model.
+//   then the in-place band gather.
+// The verdicts are read when the frame is RETIRED: after frame k is enqueued, every frame but the newest L - 1 is retired
+// (L = gsx_render_options.frames_in_flight), on every rank alike — what they say (slot sizes pair by pair, band edges, the repair
+// slot size) is what every rank plans the next frame with.  With L >= 2 the verdict of frame k - L + 1 arrived while frame k was
+// being enqueued and the device has L - 1 frames queued meanwhile: nothing waits.  With L = 1 the call waits for its own frame's
+// verdict — once per frame, whatever the number of models and whether or not anything was repaired (until round 5: once per model,
+// twice where a repair was sized).
+// A slot that overflowed (round 0: the camera jumped; round 1: more repairs than R — on cfg4's orbit they come in bursts: a few
+// hundred tiles looking through a hole want 1.5 M records behind their limits, five frames after 5 000 were plenty) leaves the frame
+// incomplete; its retirement redoes it, synchronously, by the host-decided path of rounds 2-4 (the whole frame with exactly sized or
+// whole-shard slots, an exactly sized repair round) on its own lane, with its own uniforms and limits — a lane is never reused, and
+// no frame is ever read (viewer_bind retires the frames in flight), before its frame is complete.
 //
 // Every branch below is taken on data that was gathered from all ranks (the verdict words), so every rank takes the same
 // branches and issues the same collectives in the same order: nothing can cross.
 #include <chrono>
+#include <cstdlib>
 
 #include "gsx_state.h"
 
@@ -93,7 +105,7 @@ gsx_status feedback_gather(Ctx& c) {
 // one exchange round of model i: pack -> all-to-all -> import + sort + composite -> feedback -> all-gather.
 // T: uniform slots of T records; caps (round 0, nullable): caps[s * world + d] = records the slot of the pair (s, d) holds — sized
 // pair by pair from the count matrix of the model's last frame, the same table on every rank.
-gsx_status exchange_round(Ctx& c, size_t i, uint32_t round, uint32_t T, const std::vector<uint32_t>* caps = nullptr) {
+gsx_status exchange_round(Ctx& c, size_t i, uint32_t round, uint32_t T, const std::vector<uint32_t>* caps = nullptr, bool gated = false) {
     gsx_viewer* v = c.l;
     const char* key = c.p->order[i].c_str();
     gsx_shard_stats& ss = c.owner->shard_stats;
@@ -117,7 +129,7 @@ gsx_status exchange_round(Ctx& c, size_t i, uint32_t round, uint32_t T, const st
     HIPCHK(v->shard_send.ensure((uint64_t)(snd.off[last] + snd.cap[last] + 1u) * GSX_RECORD_BYTES));
     HIPCHK(v->shard_recv.ensure((uint64_t)(rcv.off[last] + rcv.cap[last] + 1u) * GSX_RECORD_BYTES));
     gsx_status st;
-    if ((st = shard_pack_slots(v, key, c.world, round, v->shard_send.p, snd))) return st;
+    if ((st = shard_pack_slots(v, key, c.world, round, v->shard_send.p, snd, gated))) return st;
     if (comm_moves_unequal(c.owner)) {
         PeerSpans bs{}, br{};
         for (uint32_t p = 0; p < c.world; ++p) {
@@ -149,7 +161,7 @@ void plan_pair_slots(Ctx& c, size_t i) {
     if (!comm_moves_unequal(o) || !o->shard_pair_slots || c.world < 2) return;
     const Model* om = find_model(o, p.order[i].c_str());
     const Model* lm = find_model(c.l, p.order[i].c_str());
-    if (!om || !lm || om->slot_force || om->pair_counts.size() != (size_t)c.world * c.world || om->pair_limited != lm->shard_frame_limited) return;
+    if (!om || !lm || om->slot_force || om->pair_counts.size() != (size_t)c.world * c.world || om->pair_limited != (p.limited[i] != 0)) return;
     if (om->pair_edges.size() != (size_t)c.world + 1u || !std::equal(om->pair_edges.begin(), om->pair_edges.end(), c.bands.e)) return;  // counted under other bands
     const uint32_t n = std::max<uint32_t>(p.shard_max[i], 1u);
     p.pair_caps[i].resize((size_t)c.world * c.world);
@@ -183,19 +195,19 @@ gsx_status band_gather(Ctx& c) {
     return st;
 }
 
-// what a round-0 verdict carries besides its two words (kernels_shard.hip, k_shard_verify): do the ranks agree about the gather
-// root, the band edges for the frames to come, the count matrix of the exchange
-gsx_status read_verdict_extras(Ctx& c, size_t i) {
-    const uint32_t* hv = reinterpret_cast<const uint32_t*>(c.l->h_shard_verdict);
+// what a verdict block carries besides its two words (kernels_shard.hip, k_shard_verify / k_shard_post_verdict): do the ranks agree
+// about the gather root and about how they size slots and bands, the band edges for the frames to come, the count matrix of the exchange
+gsx_status read_block(Ctx& c, size_t i, const uint32_t* hv) {
     gsx_viewer* o = c.owner;
-    if (hv[4]) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_render_frame: the ranks name different gather roots (gsx_shard_set_gather_root: this rank %d)", (int)o->shard_gather_root);
+    if (hv[4] & 1u) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_render_frame: the ranks name different gather roots (gsx_shard_set_gather_root: this rank %d)", (int)o->shard_gather_root);
+    if (hv[4] & 2u) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_render_frame: the ranks size their exchange slots or bands differently (gsx_shard_set_balance, "
+                                "GSX_SHARD_UNIFORM_SLOTS, gsx_shard_set_slot_records must be the same on every rank)");
     o->shard_root_confirmed = true;
     o->next_edges.assign(hv + kVerdictEdges, hv + kVerdictEdges + c.world + 1);
     o->next_edges_tiles_y = c.tiles_y;
     if (Model* om = find_model(o, c.p->order[i].c_str())) {
         om->pair_counts.assign(hv + kVerdictMatrix, hv + kVerdictMatrix + (size_t)c.world * c.world);
-        const Model* lm = find_model(c.l, c.p->order[i].c_str());
-        om->pair_limited = lm && lm->shard_frame_limited;
+        om->pair_limited = c.p->limited[i] != 0;
         om->pair_edges.assign(c.bands.e, c.bands.e + c.world + 1);
     }
     o->shard_stats.last_entries_sum = hv[5];
@@ -204,7 +216,8 @@ gsx_status read_verdict_extras(Ctx& c, size_t i) {
     return GSX_OK;
 }
 
-gsx_status round0(Ctx& c, size_t i) {
+// ---- the synchronous path: a frame somebody is looking at whose slots overflowed is redone with the host deciding ----
+gsx_status round0_sync(Ctx& c, size_t i) {
     gsx_status st = exchange_round(c, i, 0, c.p->slot[i], &c.p->pair_caps[i]);
     if (st) return st;
     if ((st = gsx_shard_verify(c.l, c.p->order[i].c_str(), c.world, c.l->shard_sat_all.p, &c.p->seq))) return st;
@@ -226,7 +239,10 @@ gsx_status settle(Ctx& c, size_t i, bool* overflow) {
     gsx_shard_verdict verdict{};
     gsx_status st = timed_wait(c, key, c.p->seq, &verdict);
     if (st) return st;
-    if ((st = read_verdict_extras(c, i))) return st;
+    if ((st = read_block(c, i, reinterpret_cast<const uint32_t*>(c.l->h_shard_verdict)))) return st;
+    if (getenv("GSX_SHARD_DEBUG"))
+        fprintf(stderr, "[gsx shard] rank %u   redo: model '%s' (slot %u): need %u, overflow %u, busiest pair wanted %u, entries %u\n", c.rank, key, c.p->slot[i],
+                verdict.need_tiles, verdict.overflow, verdict.max_records, reinterpret_cast<const uint32_t*>(c.l->h_shard_verdict)[5]);
     c.p->counted[i] = true;
     *overflow = verdict.overflow != 0;
     if (*overflow || !verdict.need_tiles) return GSX_OK;
@@ -240,6 +256,7 @@ gsx_status settle(Ctx& c, size_t i, bool* overflow) {
     if ((st = gsx_shard_post_counts(v, c.world, cnt, &seq))) return st;
     gsx_shard_verdict sized{};
     if ((st = timed_wait(c, nullptr, seq, &sized))) return st;
+    if (getenv("GSX_SHARD_DEBUG")) fprintf(stderr, "[gsx shard] rank %u   redo: model '%s' repair sized %u\n", c.rank, key, sized.max_records);
     if ((st = exchange_round(c, i, 1, std::max<uint32_t>(sized.max_records, 1u)))) return st;
     c.p->gathered = false;
     return next_limits(c, i);
@@ -269,7 +286,7 @@ gsx_status redo_safe(Ctx& c) {
         if (attempt == 0 && !any_exact) continue;
         bool again = false;
         for (size_t i = 0; i < c.p->order.size() && !again; ++i) {
-            gsx_status st = round0(c, i);  // (model 0 is not "behind": it starts from a cleared band)
+            gsx_status st = round0_sync(c, i);  // (model 0 is not "behind": it starts from a cleared band)
             if (st) return st;
             bool overflow = false;
             if ((st = settle(c, i, &overflow))) return st;
@@ -289,7 +306,66 @@ gsx_status redo_safe(Ctx& c) {
     return GSX_OK;
 }
 
-// everything of a frame up to (not including) the look at its LAST verdict
+// ---- the frame: everything enqueued, nothing waited for ----
+
+void snapshot_uniforms(const gsx_viewer* v, ShardPending& p) {
+    ShardUniforms& u = p.uniforms;
+    memcpy(u.view, v->view, sizeof u.view);
+    memcpy(u.proj, v->proj, sizeof u.proj);
+    u.width = v->width;
+    u.height = v->height;
+    u.size = v->size;
+    u.display_mode = v->display_mode;
+    u.sh_deg = v->sh_deg;
+    u.no_sh0 = v->no_sh0;
+    u.params = v->params;
+    u.mt.clear();
+    for (const std::string& k : p.order) {
+        const Model* m = find_model(const_cast<gsx_viewer*>(v), k.c_str());
+        u.mt.push_back(m ? m->mt : ModelTransform{});
+    }
+}
+
+// the lane's uniforms <-> the frame's (a frame that is redone after the caller moved the camera on: redone as it was asked for)
+void swap_uniforms(gsx_viewer* v, ShardPending& p) {
+    ShardUniforms& u = p.uniforms;
+    for (int k = 0; k < 16; ++k) {
+        std::swap(u.view[k], v->view[k]);
+        std::swap(u.proj[k], v->proj[k]);
+    }
+    std::swap(u.width, v->width);
+    std::swap(u.height, v->height);
+    std::swap(u.size, v->size);
+    std::swap(u.display_mode, v->display_mode);
+    std::swap(u.sh_deg, v->sh_deg);
+    std::swap(u.no_sh0, v->no_sh0);
+    std::swap(u.params, v->params);
+    for (size_t i = 0; i < p.order.size() && i < u.mt.size(); ++i)
+        if (Model* m = find_model(v, p.order[i].c_str())) std::swap(u.mt[i], m->mt);
+}
+
+// Slot size of the always-enqueued repair round: twice the most the busiest (rank, destination) pair had in the repair rounds of the
+// last frames (a maximum that decays by a sixteenth per frame), and 4096 — a GLOBAL figure (every rank reads the same verdicts in the same order), never more than a
+// shard.  A frame that needs more (a camera jump: thousands of tiles repair at once) overflows, says so in its verdict and is redone
+// by the host-decided path if anybody looks at it; its verdict also raises the hint.
+uint32_t repair_slot_policy(const Model* om, uint32_t shard_max) {
+    const uint64_t want = std::max<uint64_t>(8192u, 2ull * (om ? om->repair_hint : 0u) + 4096u);
+    return (uint32_t)std::min<uint64_t>(std::max<uint32_t>(shard_max, 1u), want);
+}
+
+// the frame is enqueued on its lane: results refer to it, model-changing calls on the owner's stream come after it (viewer_bind)
+// (newest: the frame is the newest one enqueued — a frame that is redone at its retirement while a newer one is in flight on another lane
+//  gets its lane's event again, but results keep referring to the newer frame)
+gsx_status lane_mark(gsx_viewer* owner, ShardPending& p, bool newest) {
+    p.lane->band_edges = owner->band_edges_forced;  // stage calls between frames see the caller's layout (or equal bands), not this frame's
+    if (p.lane != owner) {
+        HIPCHK(gsx::op::EventRecord(p.lane->lane_event, p.lane->stream));
+        p.lane->lane_busy = true;
+    }
+    if (newest) owner->latest = p.lane == owner ? nullptr : p.lane;
+    return GSX_OK;
+}
+
 gsx_status frame_front(Ctx& c, bool eager_gather) {
     choose_edges(c.owner, *c.p, c.world, (c.l->height + GSX_TILE - 1) / GSX_TILE);
     gsx_status st = frame_buffers(c);
@@ -297,7 +373,10 @@ gsx_status frame_front(Ctx& c, bool eager_gather) {
     ShardPending& p = *c.p;
     const size_t n = p.order.size();
     const uint32_t n_tiles = ((c.l->width + GSX_TILE - 1) / GSX_TILE) * ((c.l->height + GSX_TILE - 1) / GSX_TILE);
+    snapshot_uniforms(c.l, p);
     for (size_t i = 0; i < n; ++i) {  // every model's projection first: independent of everything that follows
+        // the limits this lane's last frame computed become this frame's (kept apart until now: a redo of that frame wanted its own)
+        if ((st = gsx_shard_frame_end(c.l, p.order[i].c_str()))) return st;
         // limits the caller set for this frame (gsx_shard_set_limits) live with the owner's model, whichever lane renders
         Model* om = find_model(c.owner, p.order[i].c_str());
         const uint32_t* override_limits = om && om->shard_override_tiles == n_tiles ? om->shard_limit_override.as<uint32_t>() : nullptr;
@@ -307,47 +386,100 @@ gsx_status frame_front(Ctx& c, bool eager_gather) {
     p.slot.resize(n);
     p.pair_caps.assign(n, {});
     p.counted.assign(n, false);
+    p.vseq.assign(n, 0u);
+    p.repair_slot.assign(n, 0u);
+    p.limited.assign(n, 0);
     for (size_t i = 0; i < n; ++i) {
         if ((st = gsx_shard_slot_records(c.l, p.order[i].c_str(), c.world, p.shard_max[i], &p.slot[i]))) return st;
+        const Model* lm = find_model(c.l, p.order[i].c_str());
+        p.limited[i] = lm && lm->shard_frame_limited ? 1 : 0;
         plan_pair_slots(c, i);
+        // only a frame whose exchange was limited by windows can have refused a tile anything
+        if (p.limited[i]) p.repair_slot[i] = repair_slot_policy(find_model(c.owner, p.order[i].c_str()), p.shard_max[i]);
     }
     for (size_t i = 0; i < n; ++i) {
-        if ((st = round0(c, i))) return st;
-        if (i + 1 == n) break;  // the last model's verdict belongs to frame_back
-        bool overflow = false;  // a layered frame: model i's repair has to be in the framebuffer before model i + 1 is composited
-        if ((st = settle(c, i, &overflow))) return st;
-        if (overflow) {
-            if ((st = redo_safe(c))) return st;
-            break;
-        }
+        const char* key = p.order[i].c_str();
+        if ((st = exchange_round(c, i, 0, p.slot[i], &p.pair_caps[i]))) return st;
+        if ((st = shard_verify_staged(c.l, key, c.world, c.l->shard_sat_all.p))) return st;
+        // the repair round: enqueued without asking; its kernels fall through when the verification counted no tile in need
+        if (p.repair_slot[i] && (st = exchange_round(c, i, 1, p.repair_slot[i], nullptr, true))) return st;
+        // the model's next limits and their windows + the frame's verdict for this model: one launch
+        if ((st = shard_next_windows_post(c.l, key, c.world, c.l->shard_sat_all.p, p.margin, p.radius, p.repair_slot[i] ? c.l->shard_sat_all.p : nullptr, &p.vseq[i])))
+            return st;
     }
+    c.l->shard_frames_enqueued += 1;
+    p.lane_frame = c.l->shard_frames_enqueued;
     // (a gather to ONE rank over RCCL hangs if the ranks name different roots: the first frame after gsx_shard_set_gather_root
-    //  gathers only when its verdict has confirmed that they agree)
-    return eager_gather && (c.owner->shard_gather_root < 0 || c.owner->shard_root_confirmed) ? band_gather(c) : GSX_OK;
+    //  gathers only when its verdict has confirmed that they agree — the caller retires it at once)
+    if (eager_gather && (st = band_gather(c))) return st;
+    return lane_mark(c.owner, p, true);
 }
 
-gsx_status frame_back(gsx_viewer* owner, ShardPending& p) {
+// The frame's verdicts, read (with frames in flight they arrived while the next frame was being enqueued); a frame whose slots
+// overflowed is redone here, before its lane is used again and before anybody can read it.
+gsx_status frame_retire(gsx_viewer* owner, ShardPending& p) {
     Ctx c{owner, p.lane, &p, owner->comm_world, owner->comm_rank, {}, 0, {}, 0, 0};
-    gsx_status st = frame_buffers(c);
-    if (st) return st;
-    if (!p.settled) {
-        bool overflow = false;
-        if ((st = settle(c, p.order.size() - 1, &overflow))) return st;
-        if (overflow && (st = redo_safe(c))) return st;
-    }
-    if (!p.gathered && (st = band_gather(c))) return st;
+    // (the lane may be running a newer frame by now — with one frame in flight it is the owner itself: the frame's own geometry)
+    c.tiles_x = (p.uniforms.width + GSX_TILE - 1) / GSX_TILE;
+    c.tiles_y = (p.uniforms.height + GSX_TILE - 1) / GSX_TILE;
+    c.bands.world = c.world;
+    for (uint32_t g = 0; g <= c.world; ++g)
+        c.bands.e[g] = p.edges.size() == (size_t)c.world + 1u ? p.edges[g] : g * ((c.tiles_y + c.world - 1) / c.world);
+    gsx_status st = GSX_OK;
     gsx_shard_stats& ss = owner->shard_stats;
+    bool overflow = false;
+    if (!p.settled) {
+        for (size_t i = 0; i < p.order.size(); ++i) {
+            gsx_shard_verdict verdict{};
+            const uint32_t* block = nullptr;
+            const auto t0 = std::chrono::steady_clock::now();
+            st = shard_wait_ring(p.lane, p.vseq[i], &verdict, &block);
+            ss.verdict_wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (st) return st;
+            if ((st = read_block(c, i, block))) return st;
+            p.counted[i] = true;
+            if (Model* om = find_model(owner, p.order[i].c_str())) {  // next frame's slots (global figures: the same on every rank)
+                om->slot_hint = verdict.max_records;
+                om->slot_hint_known = true;
+                om->slot_hint_limited = p.limited[i] != 0;
+                if (p.repair_slot[i]) {
+                    // (a third of cfg4's orbit frames repair, a few thousand records each, the others nothing: the hint is a maximum
+                    //  that decays by a sixteenth per frame — a slot sized by the last frame alone overflowed in 8 % of the frames)
+                    om->repair_hint = std::max(block[kVerdictRepairMax], om->repair_hint - om->repair_hint / 16u);
+                    ss.last_repair_records = block[kVerdictRepairMax];
+                }
+            }
+            static const bool debug = getenv("GSX_SHARD_DEBUG") != nullptr;
+            if (debug)
+                fprintf(stderr, "[gsx shard] rank %u frame %llu model '%s': need %u, slot %u (busiest pair wanted %u, overflow %u), repair slot %u (busiest pair had %u, overflow %u)%s\n",
+                        c.rank, (unsigned long long)p.lane_frame, p.order[i].c_str(), verdict.need_tiles, p.slot[i], verdict.max_records, verdict.overflow, p.repair_slot[i],
+                        block[kVerdictRepairMax], block[kVerdictRepairOver], "");
+            if (verdict.need_tiles && p.repair_slot[i]) p.repaired = true;
+            overflow = overflow || verdict.overflow != 0 || block[kVerdictRepairOver] != 0;
+        }
+    }
+    if (overflow) {
+        const bool own = p.lane == owner;
+        if (own) swap_uniforms(p.lane, p);  // (a lane keeps the uniforms its frame was enqueued with until it is acquired again)
+        st = frame_buffers(c);
+        if (!st) st = redo_safe(c);
+        if (!st && !p.gathered) st = band_gather(c);
+        if (!st) st = lane_mark(owner, p, !owner->shard_pending.empty() && &owner->shard_pending.back() == &p);
+        if (own) swap_uniforms(p.lane, p);
+        if (st) return st;
+    } else if (!p.gathered) {
+        st = frame_buffers(c);
+        if (!st) st = band_gather(c);
+        if (!st) st = lane_mark(owner, p, !owner->shard_pending.empty() && &owner->shard_pending.back() == &p);
+        if (st) return st;
+    }
     ss.frames += 1;
     if (p.repaired) ss.repair_frames += 1;
-    for (const std::string& k : p.order)
-        if ((st = gsx_shard_frame_end(p.lane, k.c_str()))) return st;
+    // this frame's next limits become the models' limits now — unless the lane has begun a newer frame, which took them over already
+    if (p.lane->shard_frames_enqueued == p.lane_frame)
+        for (const std::string& k : p.order)
+            if ((st = gsx_shard_frame_end(p.lane, k.c_str()))) return st;
     owner->last_edges.assign(c.bands.e, c.bands.e + c.world + 1);
-    p.lane->band_edges = owner->band_edges_forced;  // stage calls between frames see the caller's layout (or equal bands), not this frame's
-    if (p.lane != owner) {  // model-changing calls on the owner's stream come after this lane's frame (viewer_bind)
-        HIPCHK(gsx::op::EventRecord(p.lane->lane_event, p.lane->stream));
-        p.lane->lane_busy = true;
-    }
-    owner->latest = p.lane == owner ? nullptr : p.lane;
     return GSX_OK;
 }
 
@@ -357,14 +489,10 @@ struct BusyGuard {
     ~BusyGuard() { v->shard_busy = false; }
 };
 
-}  // namespace
-
-// viewer_bind (gsx_state.h): any other entry point first finishes the sharded frames in flight (on every rank alike: an
-// SPMD host makes the same calls in the same order)
-gsx_status gsx::shard_complete_pending(gsx_viewer* v) {
-    BusyGuard guard(v);
+// whatever is in flight is retired, in order
+gsx_status retire_all(gsx_viewer* v) {
     while (!v->shard_pending.empty()) {
-        gsx_status st = frame_back(v, v->shard_pending.front());
+        const gsx_status st = frame_retire(v, v->shard_pending.front());
         v->shard_pending.pop_front();
         if (st) {
             v->shard_pending.clear();
@@ -372,6 +500,15 @@ gsx_status gsx::shard_complete_pending(gsx_viewer* v) {
         }
     }
     return GSX_OK;
+}
+
+}  // namespace
+
+// viewer_bind (gsx_state.h): any other entry point first finishes the sharded frames in flight (on every rank alike: an
+// SPMD host makes the same calls in the same order)
+gsx_status gsx::shard_complete_pending(gsx_viewer* v) {
+    BusyGuard guard(v);
+    return retire_all(v);
 }
 
 extern "C" {
@@ -392,32 +529,34 @@ gsx_status gsx_shard_render_frame_keys(gsx_viewer* v, const char* const* keys_fa
     gsx_status st = GSX_OK;
     uint32_t lanes = std::max(1u, std::min(v->options.frames_in_flight, 4u));
     if ((st = comm_ensure_lanes(v, lanes))) return st;
-    auto complete_all = [&]() -> gsx_status {  // whatever is in flight completes, in order
-        while (!v->shard_pending.empty()) {
-            const gsx_status cst = frame_back(v, v->shard_pending.front());
-            v->shard_pending.pop_front();
-            if (cst) {
-                v->shard_pending.clear();
-                return cst;
-            }
-        }
-        return GSX_OK;
-    };
     if (lanes > 1 && !shard_frame_may_use_lanes(v, keys_far_to_near, n_keys)) {
-        // a frame with a query runs on the viewer itself, alone: this frame's front and back run in this call
-        if ((st = complete_all())) return st;
+        // a frame with a query runs on the viewer itself, alone
+        if ((st = retire_all(v))) return st;
         lanes = 1;
     }
-    gsx_viewer* lane = v;
     if (lanes > 1) {
         // the models' edit records are shared by the lanes: when they have to be prepared again (a selection edit set by the host
         // since the last frame: nothing else has ordered it), the frames in flight — which read the old ones — complete first
         bool again = false;
         for (uint32_t i = 0; i < n_keys; ++i) again = again || edits_need_prepare(v, find_model(v, keys_far_to_near[i]));
-        if (again && (st = complete_all())) return st;
+        if (again && (st = retire_all(v))) return st;
         if ((st = prepare_edits_for_lanes(v, keys_far_to_near, n_keys))) return st;
     }
+    while (v->shard_pending.size() > lanes - 1u) {  // (fewer lanes than the frames before: they complete first)
+        st = frame_retire(v, v->shard_pending.front());
+        v->shard_pending.pop_front();
+        if (st) {
+            v->shard_pending.clear();
+            return st;
+        }
+    }
+    gsx_viewer* lane = v;
     if (lanes > 1 && (st = lane_acquire(v, v->shard_turn++ % lanes, keys_far_to_near, n_keys, &lane))) return st;
+    // verdict ring of the lane: a verdict per model and frame (a lane's frame is retired before the lane is used again)
+    if (!lane->h_verdict_ring || lane->ring_slots < 2u * n_keys + 2u) {
+        if ((st = retire_all(v))) return st;  // (a ring is only ever replaced while none of its verdicts is unread)
+        if ((st = shard_ensure_ring(lane, 2u * n_keys))) return st;
+    }
     v->shard_pending.emplace_back();
     ShardPending& p = v->shard_pending.back();
     p.lane = lane;
@@ -429,12 +568,16 @@ gsx_status gsx_shard_render_frame_keys(gsx_viewer* v, const char* const* keys_fa
     p.margin = margin;
     p.radius = radius;
     Ctx c{v, lane, &p, v->comm_world, v->comm_rank, {}, 0, {}, 0, 0};
-    if ((st = frame_front(c, lanes == 1))) {
+    const bool eager_gather = v->shard_gather_root < 0 || v->shard_root_confirmed;
+    if ((st = frame_front(c, eager_gather))) {
         v->shard_pending.clear();
         return st;
     }
+    if (!eager_gather && (st = retire_all(v))) return st;  // (its verdict says whether the ranks agree about the root; then the gather)
+    // the frames in flight: every frame but the newest L - 1 is retired — with L >= 2 its verdict arrived while this frame was being
+    // enqueued (and the device has this one queued); with one frame in flight the call waits for its own frame
     while (v->shard_pending.size() > lanes - 1u) {
-        st = frame_back(v, v->shard_pending.front());
+        st = frame_retire(v, v->shard_pending.front());
         v->shard_pending.pop_front();
         if (st) {
             v->shard_pending.clear();

@@ -121,6 +121,7 @@ struct Model {
     DevBuf block_vis;                           // per-workgroup visible counts of the projection pass
     DevBuf tp_src, tp_a, tp_b, tk_out, tv_out, tsort_ws;  // tile pairs: emitted, scratch, sorted (split), workspace
     DevBuf brec_sorted;                         // block lists: the {rect, key, index} records in list order (the block sort's write-out gathers them)
+    bool blocks_fine = false;                   // models some tile of which walks a long list: blocks of a quarter the size (1024 instead of 256; gsx_frame.cpp)
     bool lists_long = false;                    // ... for models whose lists are long (decided from the last frame statistics that arrived)
     DevBuf ranges;
     DevBuf tile_order;                          // block compositor's dispatch order: {threshold, tile_cost[n_tiles], tile_order[n_tiles]} (tile_order_job)
@@ -178,6 +179,9 @@ struct Model {
     // device-resident exchange (gsx_shard_frame_begin ... gsx_shard_next_windows): next frame's per-tile limits, the
     // repair round's windows, and what the host knows (late, never waited for) about how full the exchange slots get
     DevBuf shard_limit, shard_limit_next, shard_win2;
+    DevBuf shard_win_next;                     // the windows [0, limit) of shard_limit_next, where the kernel that made the limits wrote them too
+    bool shard_win_current = false, shard_win_next_valid = false;  // shard_win holds the windows of shard_limit / shard_win_next those of shard_limit_next
+    uint32_t shard_win_tiles = 0;
     DevBuf shard_limit_override;               // gsx_shard_set_limits: limits for the model's NEXT sharded frame (whichever lane renders it)
     uint32_t shard_override_tiles = 0;         // != 0: an override is waiting, made for a grid of that many tiles
     bool shard_limit_valid = false, shard_next_valid = false, shard_frame_limited = false;
@@ -188,9 +192,12 @@ struct Model {
     bool pair_limited = false;                 // ... and whether that frame's exchange was limited by windows
     std::vector<uint32_t> pair_edges;          // ... and the band edges it ran with
     uint32_t slot_force = 0;                   // gsx_shard_set_slot_records: round-0 slot size instead of the policy's (0 = policy)
+    uint32_t repair_hint = 0;                  // most records any (rank, destination) pair had in the repair round of the last frame whose verdict was read
+    bool repair_overflowed = false;            // ... and whether a repair slot was too small for them
     uint32_t slot_hint = 0;                    // records the busiest (rank, destination) pair wanted in round 0 of the last frame: a GLOBAL
                                                // figure from that frame's verdict, so every rank sizes the next slots identically; 0 = unknown
     bool slot_hint_limited = false;            // ... of a frame whose exchange was limited by windows
+    bool slot_hint_known = false;              // a verdict has been read since the limits were last replaced from outside (0 wanted is a figure too)
     DevBuf adm_ballots2;           // the repair round's ballots (the first round's stay: they say which records are shaded)
     bool lazy = false;             // this frame's projection shaded only the admitted Gaussians
     // k_edit_prepare is a function of (selection, stored edits, mask, the viewer's selection edit) and idempotent: it runs again
@@ -230,7 +237,7 @@ struct Model {
         p.sh_h = sh_h.as<uint4>();
         p.sh_q = sh_q.as<uint4>();
         p.sh_aos = sh_aos.as<uint4>();
-        p.aos_stride = sh_kind == GSX_SH_SINGLE ? (cov_kind == GSX_COV3D_SINGLE ? 16u : 12u) : sh_kind == GSX_SH_HALF ? 6u : sh_kind == GSX_SH_NORM8 ? 3u : 0u;
+        aos_layout((int)sh_kind, (int)cov_kind, &p.aos_stride, &p.aos_geo);
         p.cov_h = cov_h.as<uint2>();
         p.cov_h2 = cov_h2.as<uint32_t>();
         p.sh_kind = (int)sh_kind;
@@ -282,17 +289,34 @@ struct PassTimer {
 
 using namespace gsx;
 
-// an index-sharded frame whose rounds 0 are enqueued and whose last verdict has not been looked at yet (gsx_shard_frame.cpp)
+// What a frame was rendered with (the uniform setters do not complete frames in flight): a frame that has to be redone after the
+// caller moved the camera on is redone with ITS uniforms.
+struct ShardUniforms {
+    float view[16], proj[16];
+    uint32_t width, height;
+    float size;
+    uint32_t display_mode, sh_deg, no_sh0;
+    gsx_spec_params params;
+    std::vector<ModelTransform> mt;  // per model, in ShardPending::order
+};
+
+// An index-sharded frame that is enqueued — every round of every model, the repair rounds included (they decide on the device whether
+// they have anything to do) — and whose verdicts have not been read yet (gsx_shard_frame.cpp).
 struct ShardPending {
     gsx_viewer* lane = nullptr;
     std::vector<std::string> order;           // the frame's models in COMPOSITING order: nearest first (keys_far_to_near reversed)
     std::vector<uint32_t> shard_max, slot;    // per model: largest shard over the ranks, round-0 slot size in use
-    uint32_t seq = 0;                         // verdict of the last model's round 0
+    std::vector<uint32_t> vseq;               // per model: its verdict in the lane's ring (shard_post_verdict)
+    std::vector<uint32_t> repair_slot;        // per model: slot size of its always-enqueued repair round (0: the frame had none — not limited by windows)
+    std::vector<uint8_t> limited;             // per model: the exchange was limited by windows
+    uint32_t seq = 0;                         // (the synchronous path: verdict of the model last verified)
     uint32_t speculate = 0, radius = 0;
     float margin = 0.0f;
     bool gathered = false;                    // the band gather that is enqueued shows the final frame
     bool settled = false;                     // every model's verdict has been dealt with already (a frame redone with safe slots)
     bool repaired = false;                    // some model needed its repair exchange
+    uint64_t lane_frame = 0;                  // the lane's sharded-frame counter when this frame was enqueued (is it still the lane's newest?)
+    ShardUniforms uniforms;
     std::vector<uint32_t> edges;              // the frame's band layout (world + 1 tile rows; empty: equal bands)
     std::vector<std::vector<uint32_t>> pair_caps;  // per model: round-0 slot sizes pair by pair ([s * world + d]; empty: uniform `slot`)
     std::vector<bool> counted;                // per model: its round 0 of THIS frame has been counted (its verdict read: Model::pair_counts)
@@ -320,6 +344,7 @@ struct gsx_viewer {
     std::deque<ShardPending> shard_pending;  // owner only: oldest first
     bool shard_busy = false;             // gsx_shard_render_frame is enqueueing / completing: viewer_bind must not complete frames
     uint32_t shard_turn = 0;
+    uint64_t shard_frames_enqueued = 0;  // lane (or owner as lane 0): sharded frames enqueued on it so far
     gsx_spec_params params{};
     float view[16]{}, proj[16]{};
     uint32_t width = 1, height = 1;
@@ -333,6 +358,7 @@ struct gsx_viewer {
     unsigned long long* h_verdict = nullptr;  // pinned: {seq << 32 | tiles needing repair}, posted by k_spec_verify (host_verify)
     uint32_t verify_seq = 0;
     uint32_t blocks_max = 256;    // GSX_BLOCKS_MAX: most blocks of a block-list frame (256: one 8-bit sort pass)
+    bool blocks_adaptive = true;  // no GSX_BLOCKS_MAX given: 256, or 1024 for models some tile of which walks a long list (Model::blocks_fine)
     int bin_mode = 1;             // GSX_BIN: 1 block lists for progressive frames (default), 0 per-tile lists always
     bool edit_cache = true;       // GSX_NO_EDIT_CACHE: run k_edit_prepare every frame (tests compare the two)
     uint64_t tile_cap_fixed = 0;  // GSX_TILE_CAP was set when the viewer was created: pair-buffer capacity that never grows (tests of the spill path)
@@ -345,6 +371,11 @@ struct gsx_viewer {
     gsx_gaussian_edit sel_edit{0u, {0.0f, 1.0f, 1.0f}, 0.0f, 0.0f, 1.0f, 1.0f};
     unsigned long long* h_shard_verdict = nullptr;  // pinned, 2 words: {seq | need}, {busiest pair's records | overflow} (k_shard_verify / k_shard_post_counts)
     uint32_t shard_seq = 0;
+    // frames that never ask the host inside a frame (gsx_shard_frame.cpp): every model of every frame posts ONE verdict block, into
+    // slot (seq % ring_slots) of a pinned ring — read when the frame is retired, a call or two later
+    uint32_t* h_verdict_ring = nullptr;  // pinned: ring_slots x kVerdictWords u32
+    uint32_t ring_slots = 0, ring_seq = 0;
+    DevBuf verdict_stage;                // device: the round-0 verdict block (k_shard_verify), merged and posted by k_shard_post_verdict
     void* comm = nullptr;                // ncclComm_t (gsx_viewer_comm_init); RCCL is loaded at run time (gsx_comm.cpp)
     uint32_t comm_world = 0, comm_rank = 0;
     bool comm_self_via_rccl = false;     // GSX_COMM_SELF_VIA_RCCL at gsx_viewer_comm_init: a rank's own exchange slot goes through RCCL too
@@ -433,7 +464,15 @@ struct PeerSpans {
 };
 inline bool comm_moves_unequal(const gsx_viewer* owner) { return owner->comm != nullptr || owner->comm_a2a_v_fn != nullptr; }
 // the slot-based stage calls with slots of any size (gsx_api_shard.cpp; the exported ones pass uniform slots)
-gsx_status shard_pack_slots(gsx_viewer* v, const char* key, uint32_t world, uint32_t round, void* d_send, const SlotSpans& slots);
+gsx_status shard_pack_slots(gsx_viewer* v, const char* key, uint32_t world, uint32_t round, void* d_send, const SlotSpans& slots, bool gated = false);
+// a frame that decides its repair round on the device (gsx_shard_frame.cpp): the round-0 verdict staged in device memory, then — behind
+// the always-enqueued repair round — posted to slot seq % ring of the viewer's pinned verdict ring
+gsx_status shard_verify_staged(gsx_viewer* v, const char* key, uint32_t world, const void* d_sat_all);
+gsx_status shard_post_verdict(gsx_viewer* v, uint32_t world, const void* d_sat_after_repair /* nullable */, uint32_t* out_seq);
+gsx_status shard_next_windows_post(gsx_viewer* v, const char* key, uint32_t world, const void* d_sat_all, float margin, uint32_t radius,
+                                   const void* d_sat_after_repair /* nullable */, uint32_t* out_seq);
+gsx_status shard_wait_ring(gsx_viewer* v, uint32_t seq, gsx_shard_verdict* out, const uint32_t** block);  // spins on the ring slot of seq
+gsx_status shard_ensure_ring(gsx_viewer* v, uint32_t verdicts_outstanding);
 gsx_status shard_import_slots(gsx_viewer* v, const char* key, const void* d_recv, uint32_t world, uint32_t rank, uint32_t round_flags, const SlotSpans& slots);
 // slot p of the send buffer (snd) goes to rank p, what rank p sends lands in slot p of the receive buffer (rcv)
 gsx_status comm_all_to_all_v(gsx_viewer* v, const void* d_send, const PeerSpans& snd, void* d_recv, const PeerSpans& rcv);

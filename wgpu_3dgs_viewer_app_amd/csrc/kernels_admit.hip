@@ -255,9 +255,9 @@ hipError_t launch_admit_from_project(hipStream_t s, const uint32_t* key, uint32_
 }
 
 hipError_t launch_admit_scatter(hipStream_t s, const uint32_t* key, uint32_t n, const unsigned long long* ballots,
-                                const uint32_t* offsets, uint2* pairs) {
+                                const uint32_t* offsets, uint2* pairs, const uint32_t* d_skip, uint32_t* d_total) {
     const uint32_t nb = (uint32_t)admit_blocks(n);
-    if (nb) GSX_LAUNCH(k_admit_scatter, dim3(nb), dim3(kAdmitThreads), 0, s, key, n, ballots, offsets, pairs, nullptr, nullptr);
+    if (nb) GSX_LAUNCH(k_admit_scatter, dim3(nb), dim3(kAdmitThreads), 0, s, key, n, ballots, offsets, pairs, d_skip, d_total);
     return hipGetLastError();
 }
 

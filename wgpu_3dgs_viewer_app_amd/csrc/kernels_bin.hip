@@ -433,14 +433,14 @@ __global__ __launch_bounds__(kBinThreads) void k_block_counts(const uint32_t* __
                                                                uint32_t row_lo, uint32_t row_hi,
                                                                const uint32_t* __restrict__ d_done_count, uint32_t owned_tiles,
                                                                BlockGrid g, const uint4* __restrict__ table, int keyed,
-                                                               uint32_t* __restrict__ order_buf, uint32_t order_tiles) {
+                                                               uint32_t* __restrict__ order_buf, uint32_t order_tiles, uint32_t* __restrict__ walk_max_out) {
     __shared__ uint32_t red[4];
     __shared__ uint4 tab[1024];
     // the launch's one extra workgroup (the first, so that it starts at once): the block compositor's dispatch order, made while the
     // others count (tile_order_job, gsx_internal.h — ~8 us of one workgroup's latency chain, hidden here; as a launch of its own: 11)
     const uint32_t extra = order_buf ? 1u : 0u, workers = gridDim.x - extra, worker = blockIdx.x - extra;
     if (extra && blockIdx.x == 0u) {
-        tile_order_job<kBinThreads>(order_buf, order_tiles, reinterpret_cast<uint32_t*>(tab));
+        tile_order_job<kBinThreads>(order_buf, order_tiles, reinterpret_cast<uint32_t*>(tab), walk_max_out);
         return;
     }
     const uint32_t n_vis = min(*d_n_vis, j1);
@@ -534,7 +534,8 @@ hipError_t launch_block_bin(hipStream_t s, uint32_t j0, uint32_t j1, const uint3
                    row_words, window, table, ranges, zero.a, zero.na, zero.b, zero.nb);
     if (nb)
         GSX_LAUNCH(k_block_counts, dim3(nb + (zero.order_buf ? 1u : 0u)), dim3(kBinThreads), 0, s, d_n_vis, j0, j1, sorted_idx, rec.a, sorted_keys,
-                   brec, cnt, block_sums, row_lo, row_hi, d_done_count, owned_tiles, g, table, window ? 1 : 0, zero.order_buf, zero.order_tiles);
+                   brec, cnt, block_sums, row_lo, row_hi, d_done_count, owned_tiles, g, table, window ? 1 : 0, zero.order_buf, zero.order_tiles,
+                   zero.order_buf ? &stats->walk_max : nullptr);
     GSX_LAUNCH(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, j0, j1, d_n_vis, stats, capacity, d_done_count,
                        owned_tiles, slab_index);
     if (nb)

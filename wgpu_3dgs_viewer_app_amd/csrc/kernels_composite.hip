@@ -231,7 +231,9 @@ __global__ __launch_bounds__(128) void k_composite(const FrameConsts f, uint2* _
 // twelve registers less is one more wave per SIMD (84 -> 74 VGPRs, occupancy 5 -> 6), worth more than the overlap (+1.2 %).
 // What a tile cost, in the units the dispatch order is decided by (tile_order_job): measured on cfg4 (tools/tile_profile.py), a tile's time under a full chip is
 // ~16 us + 0.95 us per list chunk walked + 0.11 us per taker blended; one unit = 0.44 us.
-__device__ __forceinline__ uint32_t tile_cost_units(uint32_t chunks, uint32_t taken) { return (9u * chunks + taken) >> 2; }
+// what a tile cost, as the compositor leaves it in tile_cost: chunks walked << 16 | candidates taken (tile_order_job weighs the two —
+// (9 chunks + takers) / 4, fitted to the tile profile — and keeps the longest walk for the host: gsx_internal.h)
+__device__ __forceinline__ uint32_t tile_cost_units(uint32_t chunks, uint32_t taken) { return (min(chunks, 0x7FFFu) << 16) | min(taken, 0xFFFFu); }
 
 constexpr int kCand = 1;                         // candidates per lane and iteration (1 / 2 / 3 measured alike, round 2)
 constexpr uint32_t kChunk = 128u * kCand;

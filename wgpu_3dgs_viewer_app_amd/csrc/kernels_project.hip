@@ -127,7 +127,7 @@ __device__ inline void store_sh(const PodPlanes& pod, uint64_t model_n, uint64_t
                 w[k] = pack_h2(f0 < 45 ? s45[f0] : 0.0f, f1 < 45 ? s45[f1] : 0.0f);
             }
             pod.sh_h[(uint64_t)p * model_n + i] = make_uint4(w[0], w[1], w[2], w[3]);
-            if (pod.sh_aos) pod.sh_aos[i * 6 + p] = make_uint4(w[0], w[1], w[2], w[3]);
+            if (pod.sh_aos) pod.sh_aos[i * pod.aos_stride + p] = make_uint4(w[0], w[1], w[2], w[3]);
         }
     } else if (pod.sh_kind == GSX_SH_NORM8) {
         for (int p = 0; p < 3; ++p) {
@@ -141,19 +141,23 @@ __device__ inline void store_sh(const PodPlanes& pod, uint64_t model_n, uint64_t
                 w[k] = v;
             }
             pod.sh_q[(uint64_t)p * model_n + i] = make_uint4(w[0], w[1], w[2], w[3]);
-            if (pod.sh_aos) pod.sh_aos[i * 3 + p] = make_uint4(w[0], w[1], w[2], w[3]);
+            if (pod.sh_aos) pod.sh_aos[i * pod.aos_stride + p] = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
 }
 
-// full 256-byte shade record (aos_stride 16): position + colour word and the covariance beside the SH words
+// the shade record's geometry words: position + colour word and the covariance (as the pod stores it) beside the SH words
 __device__ inline void store_aos_geometry(const PodPlanes& pod, uint64_t i, float4 pc, float c0, float c1, float c2, float c3, float c4,
                                           float c5) {
-    if (!pod.sh_aos || pod.aos_stride != 16u) return;
-    uint4* r = pod.sh_aos + i * 16u;
-    r[12] = make_uint4(__float_as_uint(pc.x), __float_as_uint(pc.y), __float_as_uint(pc.z), __float_as_uint(pc.w));
-    r[13] = make_uint4(__float_as_uint(c0), __float_as_uint(c1), __float_as_uint(c2), __float_as_uint(c3));
-    r[14] = make_uint4(__float_as_uint(c4), __float_as_uint(c5), 0u, 0u);
+    if (!pod.sh_aos || !pod.aos_geo) return;
+    uint4* r = pod.sh_aos + i * pod.aos_stride + pod.aos_geo;
+    r[0] = make_uint4(__float_as_uint(pc.x), __float_as_uint(pc.y), __float_as_uint(pc.z), __float_as_uint(pc.w));
+    if (pod.cov_kind == GSX_COV3D_SINGLE) {
+        r[1] = make_uint4(__float_as_uint(c0), __float_as_uint(c1), __float_as_uint(c2), __float_as_uint(c3));
+        r[2] = make_uint4(__float_as_uint(c4), __float_as_uint(c5), 0u, 0u);
+    } else {
+        r[1] = make_uint4(pack_h2(c0, c1), pack_h2(c2, c3), pack_h2(c4, c5), 0u);  // (the same halves store_cov writes)
+    }
 }
 
 __device__ inline void store_cov(const PodPlanes& pod, uint64_t i, float c0, float c1, float c2, float c3, float c4, float c5) {
@@ -373,7 +377,7 @@ __device__ inline void load_shade(const FrameConsts& f, const PodPlanes& pod, ui
         constexpr int kP = (kFloats + 7) / 8;
         uint4 v[kP ? kP : 1];
 #pragma unroll
-        for (int p = 0; p < kP; ++p) v[p] = AOS ? pod.sh_aos[(uint64_t)i * 6 + p] : ld_stream(&pod.sh_h[(uint64_t)p * n + i]);
+        for (int p = 0; p < kP; ++p) v[p] = AOS ? pod.sh_aos[(uint64_t)i * pod.aos_stride + p] : ld_stream(&pod.sh_h[(uint64_t)p * n + i]);
 #pragma unroll
         for (int p = 0; p < kP; ++p) {
             st.feed(8 * p, h_lo(v[p].x)); st.feed(8 * p + 1, h_hi(v[p].x)); st.feed(8 * p + 2, h_lo(v[p].y)); st.feed(8 * p + 3, h_hi(v[p].y));
@@ -383,7 +387,7 @@ __device__ inline void load_shade(const FrameConsts& f, const PodPlanes& pod, ui
         constexpr int kP = (kFloats + 15) / 16;
         uint4 v[kP ? kP : 1];
 #pragma unroll
-        for (int p = 0; p < kP; ++p) v[p] = AOS ? pod.sh_aos[(uint64_t)i * 3 + p] : ld_stream(&pod.sh_q[(uint64_t)p * n + i]);
+        for (int p = 0; p < kP; ++p) v[p] = AOS ? pod.sh_aos[(uint64_t)i * pod.aos_stride + p] : ld_stream(&pod.sh_q[(uint64_t)p * n + i]);
 #pragma unroll
         for (int p = 0; p < kP; ++p) {
             const uint32_t w[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
@@ -580,11 +584,12 @@ __global__ __launch_bounds__(256) void k_shade(const FrameConsts f, const uint32
     for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < count; j += gridDim.x * 256u) {
         const uint32_t i = pairs[j].y;
         if (skip && ((skip[i >> 6] >> (i & 63u)) & 1ull)) continue;
-        // 256-byte record: no other gather (Sh None models run the f32 instantiation without a record copy)
-        const bool full = COVK == GSX_COV3D_SINGLE && SHK == GSX_SH_SINGLE && pod.sh_aos != nullptr && pod.aos_stride == 16u;
+        // the shade record holds position and covariance too: no other gather (Sh None models run the f32 instantiation without a record)
+        const bool full = pod.sh_aos != nullptr && pod.aos_geo != 0u;
+        const uint4* __restrict__ geo = pod.sh_aos + (uint64_t)i * pod.aos_stride + pod.aos_geo;
         float4 pc;
         if (full) {
-            const uint4 w = pod.sh_aos[(uint64_t)i * 16u + 12u];
+            const uint4 w = geo[0];
             pc = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
         } else {
             pc = pod.pc[i];
@@ -592,11 +597,14 @@ __global__ __launch_bounds__(256) void k_shade(const FrameConsts f, const uint32
         ViewClip vc;
         Splat2D sp{};
         if (!pm_view_cull(f, pc.x, pc.y, pc.z, vc)) continue;  // cannot happen: it is visible
-        if (full) {
-            const uint4 a = pod.sh_aos[(uint64_t)i * 16u + 13u], b2 = pod.sh_aos[(uint64_t)i * 16u + 14u];
+        if (full && COVK == GSX_COV3D_SINGLE) {
+            const uint4 a = geo[1], b2 = geo[2];
             if (!pm_cov2d_rect(f, vc, __uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
                                __uint_as_float(b2.x), __uint_as_float(b2.y), sp))
                 continue;
+        } else if (full) {
+            const uint4 a = geo[1];
+            if (!pm_cov2d_rect(f, vc, h_lo(a.x), h_hi(a.x), h_lo(a.y), h_hi(a.y), h_lo(a.z), h_hi(a.z), sp)) continue;
         } else if (!load_cov2d_rect<COVK>(f, pod, i, vc, sp)) {
             continue;
         }
@@ -623,39 +631,75 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v, const int s) {
         default: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xFF, 0xF, 0xF, false);
     }
 }
-template <int DEG>
-__global__ __launch_bounds__(256) void k_shade_quads(const FrameConsts f, const PodPlanes pod, const Records rec,
-                                                      const uint2* __restrict__ pairs, const uint32_t* __restrict__ d_n,
-                                                      const unsigned long long* __restrict__ skip, const int write_a) {
-    const uint32_t count = *d_n;
-    const uint32_t sub = threadIdx.x & 3u;
-    for (uint32_t j = (blockIdx.x * 256u + threadIdx.x) >> 2; j < count; j += gridDim.x * 64u) {  // (the quad's four lanes share j)
-        const uint32_t i = pairs[j].y;
-        if (skip && ((skip[i >> 6] >> (i & 63u)) & 1ull)) continue;
-        uint4 mine[4];
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) mine[k] = pod.sh_aos[(uint64_t)i * 16u + sub + 4u * k];
-        uint4 w[16];   // the record's words, in every lane of the quad
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int sl = 0; sl < 4; ++sl)
-                w[sl + 4 * k] = make_uint4(quad_bcast(mine[k].x, sl), quad_bcast(mine[k].y, sl), quad_bcast(mine[k].z, sl), quad_bcast(mine[k].w, sl));
-        const float4 pc = make_float4(__uint_as_float(w[12].x), __uint_as_float(w[12].y), __uint_as_float(w[12].z), __uint_as_float(w[12].w));
-        ViewClip vc;
-        Splat2D sp{};
-        if (!pm_view_cull(f, pc.x, pc.y, pc.z, vc)) continue;  // cannot happen: it is visible
-        if (!pm_cov2d_rect(f, vc, __uint_as_float(w[13].x), __uint_as_float(w[13].y), __uint_as_float(w[13].z), __uint_as_float(w[13].w),
-                           __uint_as_float(w[14].x), __uint_as_float(w[14].y), sp))
-            continue;
-        ShStream<DEG> st;   // (load_shade<DEG, GSX_SH_SINGLE, true>, fed from registers)
-        st.begin(f, pc.x, pc.y, pc.z, __float_as_uint(pc.w));
+// the SH words of a shade record (plane order, as the pod stores them) -> the stream's floats: what load_shade<.., AOS = true> feeds
+template <int DEG, int SHK>
+__device__ __forceinline__ void feed_record_words(ShStream<DEG>& st, const uint4* w) {
+    constexpr int kFloats = ShNeed<DEG>::floats;
+    if (SHK == GSX_SH_SINGLE) {
 #pragma unroll
         for (int p = 0; p < ShNeed<DEG>::planes4; ++p) {
             st.feed(4 * p, __uint_as_float(w[p].x)); st.feed(4 * p + 1, __uint_as_float(w[p].y));
             st.feed(4 * p + 2, __uint_as_float(w[p].z)); st.feed(4 * p + 3, __uint_as_float(w[p].w));
         }
         if (DEG == 3) st.feed(44, __uint_as_float(w[11].x));
+    } else if (SHK == GSX_SH_HALF) {
+        constexpr int kP = (kFloats + 7) / 8;
+#pragma unroll
+        for (int p = 0; p < kP; ++p) {
+            st.feed(8 * p, h_lo(w[p].x)); st.feed(8 * p + 1, h_hi(w[p].x)); st.feed(8 * p + 2, h_lo(w[p].y)); st.feed(8 * p + 3, h_hi(w[p].y));
+            st.feed(8 * p + 4, h_lo(w[p].z)); st.feed(8 * p + 5, h_hi(w[p].z)); st.feed(8 * p + 6, h_lo(w[p].w)); st.feed(8 * p + 7, h_hi(w[p].w));
+        }
+    } else {
+        constexpr int kP = (kFloats + 15) / 16;
+#pragma unroll
+        for (int p = 0; p < kP; ++p) {
+            const uint32_t q[4] = {w[p].x, w[p].y, w[p].z, w[p].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) st.feed(16 * p + 4 * k + bb, dq_snorm8(q[k], bb));
+        }
+    }
+}
+
+// Four lanes to a shade record, every pod kind (round 5; f32 pods since round 4): the quad loads the record side by side — STRIDE / 4
+// coalesced 16-byte loads per lane, whole 64-byte sectors — and every lane gets every word by quad broadcasts.
+template <int DEG, int SHK, int COVK>
+__global__ __launch_bounds__(256) void k_shade_quads(const FrameConsts f, const PodPlanes pod, const Records rec,
+                                                      const uint2* __restrict__ pairs, const uint32_t* __restrict__ d_n,
+                                                      const unsigned long long* __restrict__ skip, const int write_a) {
+    constexpr uint32_t kStride = SHK == GSX_SH_SINGLE ? 16u : (SHK == GSX_SH_HALF ? (COVK == GSX_COV3D_SINGLE ? 12u : 8u) : 8u);
+    constexpr uint32_t kGeo = SHK == GSX_SH_SINGLE ? 12u : (SHK == GSX_SH_HALF ? 6u : 3u);
+    constexpr int kLoads = (int)(kStride / 4u);
+    const uint32_t count = *d_n;
+    const uint32_t sub = threadIdx.x & 3u;
+    for (uint32_t j = (blockIdx.x * 256u + threadIdx.x) >> 2; j < count; j += gridDim.x * 64u) {  // (the quad's four lanes share j)
+        const uint32_t i = pairs[j].y;
+        if (skip && ((skip[i >> 6] >> (i & 63u)) & 1ull)) continue;
+        uint4 mine[kLoads];
+#pragma unroll
+        for (int k = 0; k < kLoads; ++k) mine[k] = pod.sh_aos[(uint64_t)i * kStride + sub + 4u * (uint32_t)k];
+        uint4 w[kStride];   // the record's words, in every lane of the quad
+#pragma unroll
+        for (int k = 0; k < kLoads; ++k)
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl)
+                w[sl + 4 * k] = make_uint4(quad_bcast(mine[k].x, sl), quad_bcast(mine[k].y, sl), quad_bcast(mine[k].z, sl), quad_bcast(mine[k].w, sl));
+        const float4 pc = make_float4(__uint_as_float(w[kGeo].x), __uint_as_float(w[kGeo].y), __uint_as_float(w[kGeo].z), __uint_as_float(w[kGeo].w));
+        ViewClip vc;
+        Splat2D sp{};
+        if (!pm_view_cull(f, pc.x, pc.y, pc.z, vc)) continue;  // cannot happen: it is visible
+        if (COVK == GSX_COV3D_SINGLE) {
+            if (!pm_cov2d_rect(f, vc, __uint_as_float(w[kGeo + 1].x), __uint_as_float(w[kGeo + 1].y), __uint_as_float(w[kGeo + 1].z), __uint_as_float(w[kGeo + 1].w),
+                               __uint_as_float(w[kGeo + 2].x), __uint_as_float(w[kGeo + 2].y), sp))
+                continue;
+        } else {
+            const uint4 a = w[kGeo + 1];
+            if (!pm_cov2d_rect(f, vc, h_lo(a.x), h_hi(a.x), h_lo(a.y), h_hi(a.y), h_lo(a.z), h_hi(a.z), sp)) continue;
+        }
+        ShStream<DEG> st;   // (load_shade<DEG, SHK, true>, fed from registers)
+        st.begin(f, pc.x, pc.y, pc.z, __float_as_uint(pc.w));
+        feed_record_words<DEG, SHK>(st, w);
         float r, g, b;
         st.finish(r, g, b);
         if (sub == 0u) {
@@ -773,14 +817,24 @@ hipError_t launch_shade(hipStream_t s, const FrameConsts& f, uint32_t n, const P
                         const LateProjection& late) {
     if (n == 0) return hipSuccess;
     static const bool quads = getenv("GSX_SHADE_QUADS") == nullptr || atoi(getenv("GSX_SHADE_QUADS")) != 0;  // (A/B switch)
-    if (quads && pod.sh_kind == GSX_SH_SINGLE && pod.cov_kind == GSX_COV3D_SINGLE && pod.sh_aos != nullptr && pod.aos_stride == 16u) {
+    if (quads && pod.sh_kind != GSX_SH_NONE && pod.sh_aos != nullptr && pod.aos_geo != 0u) {
         const dim3 grid(8192), block(256);   // 0.5 M quads stride over the admitted records
-        switch ((int)f.sh_deg) {
-            case 0: GSX_LAUNCH((k_shade_quads<0>), grid, block, 0, s, f, pod, rec, late.pairs, late.d_n, late.shaded, late.write_a ? 1 : 0); break;
-            case 1: GSX_LAUNCH((k_shade_quads<1>), grid, block, 0, s, f, pod, rec, late.pairs, late.d_n, late.shaded, late.write_a ? 1 : 0); break;
-            case 2: GSX_LAUNCH((k_shade_quads<2>), grid, block, 0, s, f, pod, rec, late.pairs, late.d_n, late.shaded, late.write_a ? 1 : 0); break;
-            default: GSX_LAUNCH((k_shade_quads<3>), grid, block, 0, s, f, pod, rec, late.pairs, late.d_n, late.shaded, late.write_a ? 1 : 0); break;
+#define GSX_QUADS(SHK, COVK)                                                                                                                      \
+    switch ((int)f.sh_deg) {                                                                                                                      \
+        case 0: GSX_LAUNCH((k_shade_quads<0, SHK, COVK>), grid, block, 0, s, f, pod, rec, late.pairs, late.d_n, late.shaded, late.write_a ? 1 : 0); break; \
+        case 1: GSX_LAUNCH((k_shade_quads<1, SHK, COVK>), grid, block, 0, s, f, pod, rec, late.pairs, late.d_n, late.shaded, late.write_a ? 1 : 0); break; \
+        case 2: GSX_LAUNCH((k_shade_quads<2, SHK, COVK>), grid, block, 0, s, f, pod, rec, late.pairs, late.d_n, late.shaded, late.write_a ? 1 : 0); break; \
+        default: GSX_LAUNCH((k_shade_quads<3, SHK, COVK>), grid, block, 0, s, f, pod, rec, late.pairs, late.d_n, late.shaded, late.write_a ? 1 : 0); break; \
+    }
+        const bool ch = pod.cov_kind == GSX_COV3D_HALF;
+        if (pod.sh_kind == GSX_SH_SINGLE) {
+            if (ch) { GSX_QUADS(GSX_SH_SINGLE, GSX_COV3D_HALF) } else { GSX_QUADS(GSX_SH_SINGLE, GSX_COV3D_SINGLE) }
+        } else if (pod.sh_kind == GSX_SH_HALF) {
+            if (ch) { GSX_QUADS(GSX_SH_HALF, GSX_COV3D_HALF) } else { GSX_QUADS(GSX_SH_HALF, GSX_COV3D_SINGLE) }
+        } else {
+            if (ch) { GSX_QUADS(GSX_SH_NORM8, GSX_COV3D_HALF) } else { GSX_QUADS(GSX_SH_NORM8, GSX_COV3D_SINGLE) }
         }
+#undef GSX_QUADS
         return hipGetLastError();
     }
     return dispatch_project(s, dim3(4096), f, n, pod, rec, nullptr, ProjectAdmission{}, &late);  // 1 M lanes stride over the admitted records

@@ -50,12 +50,16 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_count(const uint32_t* __r
                                                               unsigned long long* __restrict__ travellers,
                                                               uint32_t* __restrict__ traveller_counts,
                                                               const uint32_t* __restrict__ gate, uint32_t gate_row_words,
-                                                              const WindowPyramid pyr, const uint32_t* __restrict__ rect8) {
+                                                              const WindowPyramid pyr, const uint32_t* __restrict__ rect8,
+                                                              const uint32_t* __restrict__ d_skip) {
     __shared__ uint32_t cnt[kMaxWorld];
     __shared__ uint32_t tcnt[kPackThreads / 64];
     constexpr uint32_t kPackTile = kPackThreads * kPackRounds, kPackWaveChunk = 64 * kPackRounds;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const uint32_t world = bands.world;
+    // an always-enqueued repair round with nothing to repair (*d_skip == 0: no tile needs anything): nothing is read, nothing
+    // written — the row scan, the headers and the scatter behind look at the same word and take every total for 0
+    if (d_skip && *d_skip == 0u) return;
     if (tid < kMaxWorld) cnt[tid] = 0;
     __syncthreads();
     if (list) n = min(n, *d_list_n);
@@ -123,7 +127,8 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_scatter(const unsigned lo
                                                                 uint32_t nblocks, const uint32_t* __restrict__ totals,
                                                                 float4* __restrict__ send, uint64_t capacity,
                                                                 const uint2* __restrict__ list, const uint32_t* __restrict__ d_list_n,
-                                                                const SlotSpans sp, uint32_t slotted) {
+                                                                const SlotSpans sp, uint32_t slotted, const uint32_t* __restrict__ d_skip) {
+    if (d_skip && *d_skip == 0u) return;  // (uniform) nothing was counted: the masks are stale
     __shared__ uint32_t run[kPackThreads / 64][kMaxWorld];  // per-wave running counts -> absolute offsets
     __shared__ uint32_t dbase[kMaxWorld];
     __shared__ uint32_t dend[kMaxWorld];   // first position past what destination g may hold
@@ -217,25 +222,25 @@ __global__ __launch_bounds__(256) void k_import_records(const float4* __restrict
 hipError_t launch_pack_count(hipStream_t s, const Records& rec, uint32_t n, const BandEdges& bands,
                              const uint2* window, uint32_t tiles_x, unsigned long long* masks, uint32_t* table,
                              const uint2* list, const uint32_t* d_list_n, unsigned long long* travellers, uint32_t* traveller_counts,
-                             const uint32_t* gate, uint32_t gate_row_words, const WindowPyramid* pyramid) {
+                             const uint32_t* gate, uint32_t gate_row_words, const WindowPyramid* pyramid, const uint32_t* d_skip) {
     const uint32_t rounds = pack_rounds(list != nullptr), nb = (uint32_t)pack_blocks(n, rounds);
     if (nb) {
         auto kernel = rounds == kPackRoundsList ? k_pack_count<(int)kPackRoundsList> : k_pack_count<(int)kPackRoundsFull>;
         GSX_LAUNCH(kernel, dim3(nb), dim3(kPackThreads), 0, s, rec.key, rec.a, n, bands, window,
                            tiles_x, masks, table, nb, list, d_list_n, travellers, traveller_counts, gate, gate_row_words,
-                           pyramid ? *pyramid : WindowPyramid{}, rec.rect8);
+                           pyramid ? *pyramid : WindowPyramid{}, rec.rect8, d_skip);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_pack_scatter(hipStream_t s, const Records& rec, uint32_t n, uint32_t world,
                                const unsigned long long* masks, const uint32_t* table, const uint32_t* totals, void* d_send,
-                               uint64_t capacity, const uint2* list, const uint32_t* d_list_n, const SlotSpans* slots) {
+                               uint64_t capacity, const uint2* list, const uint32_t* d_list_n, const SlotSpans* slots, const uint32_t* d_skip) {
     const uint32_t rounds = pack_rounds(list != nullptr), nb = (uint32_t)pack_blocks(n, rounds);
     if (nb) {
         auto kernel = rounds == kPackRoundsList ? k_pack_scatter<(int)kPackRoundsList> : k_pack_scatter<(int)kPackRoundsFull>;
         GSX_LAUNCH(kernel, dim3(nb), dim3(kPackThreads), 0, s, masks, rec.a, rec.b, rec.c, n, world, table, nb,
-                           totals, reinterpret_cast<float4*>(d_send), capacity, list, d_list_n, slots ? *slots : SlotSpans{}, slots ? 1u : 0u);
+                           totals, reinterpret_cast<float4*>(d_send), capacity, list, d_list_n, slots ? *slots : SlotSpans{}, slots ? 1u : 0u, d_skip);
     }
     return hipGetLastError();
 }
@@ -246,9 +251,11 @@ hipError_t launch_pack_scatter(hipStream_t s, const Records& rec, uint32_t n, ui
 // data (uniform: the busiest pair of the last frame; pair by pair: the last frame's count matrix).  Header: word 0 = records the
 // sender HAD for this destination, word 1 = records it sent = min(word 0, cap).
 __global__ __launch_bounds__(64) void k_pack_headers(const uint32_t* __restrict__ totals, uint32_t world, const SlotSpans sp,
-                                                      float4* __restrict__ send, SlabStats* __restrict__ stats, uint32_t round) {
+                                                      float4* __restrict__ send, SlabStats* __restrict__ stats, uint32_t round,
+                                                      const uint32_t* __restrict__ d_skip) {
     const uint32_t g = threadIdx.x;
-    uint32_t cnt = g < world ? totals[g] : 0u;
+    const bool skip = d_skip && *d_skip == 0u;  // an always-enqueued repair round with nothing to repair: empty slots
+    uint32_t cnt = (g < world && !skip) ? totals[g] : 0u;
     uint32_t over = 0u;
     if (g < world) {
         float4* h = send + 3ull * (size_t)sp.off[g];
@@ -332,7 +339,7 @@ __device__ inline uint32_t work_at(const uint32_t* __restrict__ sat, uint32_t ty
 __global__ __launch_bounds__(256) void k_shard_feedback(const uint32_t* __restrict__ tile_sat, const uint32_t* __restrict__ row_work, uint32_t tiles_x,
                                                          uint32_t tiles_y, uint32_t row_lo, uint32_t rows, uint32_t* __restrict__ out,
                                                          const SlabStats* __restrict__ stats, const uint32_t* __restrict__ done_before,
-                                                         uint32_t row_words, uint32_t gather_root_plus1) {
+                                                         uint32_t row_words, uint32_t gather_root_plus1, uint32_t policy_flags) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_sat = rows * tiles_x;
     if (i >= kShardExtraWords + n_sat + rows) return;
@@ -342,6 +349,9 @@ __global__ __launch_bounds__(256) void k_shard_feedback(const uint32_t* __restri
         else if (i == 1u) x = stats->slot_over[0];
         else if (i == 2u) x = gather_root_plus1;
         else if (i == 3u) x = stats->n_entries_total;
+        else if (i == 4u) x = stats->slot_max[1];    // the repair round's figures (meaningful in the feedback gathered AFTER that round)
+        else if (i == 5u) x = stats->slot_over[1];
+        else if (i == 6u) x = policy_flags;          // how this rank sizes slots and bands: ranks that disagree must not exchange
         else if (i >= 8u) x = stats->slot_want[i - 8u];
         out[i] = x;
         return;
@@ -393,12 +403,13 @@ __global__ __launch_bounds__(256) void k_shard_verify(const uint32_t* __restrict
             const uint32_t total = __hip_atomic_load(d_need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint32_t* hv = reinterpret_cast<uint32_t*>(host_verdict);
             uint32_t gmax = 0, over = 0, root_bad = 0, ent_sum = 0, ent_max = 0;
-            const uint32_t root0 = sat[2];
+            const uint32_t root0 = sat[2], flags0 = sat[6];
             for (uint32_t g = 0; g < world; ++g) {
                 const uint32_t* x = sat + (size_t)g * stride;
                 gmax = max(gmax, x[0]);
                 over |= x[1];
                 root_bad |= x[2] != root0 ? 1u : 0u;
+                root_bad |= x[6] != flags0 ? 2u : 0u;  // (bit 1: the ranks size their slots / bands by different policies)
                 ent_sum += x[3];
                 ent_max = max(ent_max, x[3]);
                 for (uint32_t d = 0; d < world; ++d) hv[kVerdictMatrix + g * world + d] = x[8u + d];
@@ -464,6 +475,8 @@ __global__ __launch_bounds__(256) void k_shard_verify(const uint32_t* __restrict
     }
 }
 
+__device__ inline unsigned long long need_of_staged(const uint32_t* __restrict__ staged) { return (unsigned long long)staged[0]; }  // low half of word 0
+
 // Sizing the repair exchange: counts_all = per rank {records it has for its busiest destination, 0, 0, 0} (all-gathered);
 // the global maximum goes to the host — the exact slot size of the repair round, the same on every rank.
 __global__ __launch_bounds__(64) void k_shard_post_counts(const uint32_t* __restrict__ counts_all, uint32_t world,
@@ -477,6 +490,14 @@ __global__ __launch_bounds__(64) void k_shard_post_counts(const uint32_t* __rest
     }
 }
 
+// The verdict of a frame whose repair round was enqueued unasked (gsx_shard_frame.cpp: no host look inside a frame).  k_shard_verify
+// left the round-0 verdict in DEVICE memory (staged: same layout as the host block); this kernel, behind the repair round's feedback
+// gather (sat: piece g at word g * stride; nullptr: the frame had no repair round), adds what that round reports — the largest count
+// any rank had for one destination, whether a repair slot overflowed — and posts the whole block to the frame's slot of the host ring.
+// Every input is gathered data: every rank posts the same block.
+__global__ __launch_bounds__(256) void k_shard_post_verdict(const uint32_t* __restrict__ staged, const uint32_t* __restrict__ sat, uint32_t world,
+                                                             uint32_t stride, uint32_t* __restrict__ host_block, uint32_t seq);
+
 // local maximum of the per-destination totals -> out[0..3] = {max, 0, 0, 0}
 __global__ __launch_bounds__(64) void k_shard_max_count(const uint32_t* __restrict__ totals, uint32_t world, uint32_t* __restrict__ out) {
     uint32_t mx = threadIdx.x < world ? totals[threadIdx.x] : 0u;
@@ -488,8 +509,42 @@ __global__ __launch_bounds__(64) void k_shard_max_count(const uint32_t* __restri
 // Next frame's per-tile depth-key limit from this frame's saturation keys: (1 + margin) x the deepest saturation depth in
 // the tile's (2 radius + 1)^2 neighbourhood — the camera moves — and unbounded if any tile of the neighbourhood stayed open
 // (parallel.next_limits is the numpy statement of the same policy).  Outside the frame counts as nothing.
+// win_next (nullable): also the next frame's round-0 windows [0, limit) (saves that frame a launch); staged / host_block (nullable): block 0
+// posts the frame's verdict on its way (post_verdict_body: what k_shard_post_verdict does as a launch of its own)
+__device__ inline void post_verdict_body(const uint32_t* __restrict__ staged, const uint32_t* __restrict__ sat, uint32_t world, uint32_t stride,
+                                         uint32_t* __restrict__ host_block, uint32_t seq) {
+    const uint32_t n = kVerdictMatrix + world * world;
+    for (uint32_t i = 4u + threadIdx.x; i < n; i += 256u)
+        if (i != kVerdictRepairMax && i != kVerdictRepairOver) host_block[i] = staged[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t mx = 0, over = 0;
+        const unsigned long long need = need_of_staged(staged);
+        if (sat && need)  // (a round that repaired nothing left its statistics untouched: the previous frame's)
+            for (uint32_t g = 0; g < world; ++g) {
+                mx = max(mx, sat[(size_t)g * stride + 4u]);
+                over |= sat[(size_t)g * stride + 5u];
+            }
+        host_block[kVerdictRepairMax] = mx;
+        host_block[kVerdictRepairOver] = over;
+        __threadfence_system();
+        unsigned long long* hv = reinterpret_cast<unsigned long long*>(host_block);
+        const unsigned long long* sv = reinterpret_cast<const unsigned long long*>(staged);
+        __hip_atomic_store(hv + 1, sv[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(hv, ((unsigned long long)seq << 32) | need, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_shard_post_verdict(const uint32_t* __restrict__ staged, const uint32_t* __restrict__ sat, uint32_t world,
+                                                             uint32_t stride, uint32_t* __restrict__ host_block, uint32_t seq) {
+    post_verdict_body(staged, sat, world, stride, host_block, seq);
+}
+
 __global__ __launch_bounds__(256) void k_shard_next_limits(const uint32_t* __restrict__ sat, uint32_t tiles_x, uint32_t tiles_y, float gain,
-                                                            int radius, uint32_t* __restrict__ limit, const BandEdges bands, uint32_t stride) {
+                                                            int radius, uint32_t* __restrict__ limit, const BandEdges bands, uint32_t stride,
+                                                            uint2* __restrict__ win_next, const uint32_t* __restrict__ staged,
+                                                            const uint32_t* __restrict__ sat_verdict, uint32_t* __restrict__ host_block, uint32_t seq) {
+    if (host_block && blockIdx.x == 0) post_verdict_body(staged, sat_verdict, bands.world, stride, host_block, seq);
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= tiles_x * tiles_y) return;
     const int tx = (int)(t % tiles_x), ty = (int)(t / tiles_x);
@@ -507,10 +562,12 @@ __global__ __launch_bounds__(256) void k_shard_next_limits(const uint32_t* __res
         out = (lim < 3.0e38f) ? max(__float_as_uint(lim), 1u) : 0xFFFFFFFFu;
     }
     limit[t] = out;
+    if (win_next) win_next[t] = make_uint2(0u, out);
 }
 
-hipError_t launch_pack_headers(hipStream_t s, const uint32_t* totals, uint32_t world, const SlotSpans& slots, void* d_send, SlabStats* stats, uint32_t round) {
-    GSX_LAUNCH(k_pack_headers, dim3(1), dim3(64), 0, s, totals, world, slots, reinterpret_cast<float4*>(d_send), stats, round);
+hipError_t launch_pack_headers(hipStream_t s, const uint32_t* totals, uint32_t world, const SlotSpans& slots, void* d_send, SlabStats* stats, uint32_t round,
+                               const uint32_t* d_skip) {
+    GSX_LAUNCH(k_pack_headers, dim3(1), dim3(64), 0, s, totals, world, slots, reinterpret_cast<float4*>(d_send), stats, round, d_skip);
     return hipGetLastError();
 }
 
@@ -537,15 +594,21 @@ hipError_t launch_shard_verify(hipStream_t s, const uint32_t* limit, const uint3
 }
 
 hipError_t launch_shard_feedback(hipStream_t s, const uint32_t* tile_sat, const uint32_t* row_work, uint32_t tiles_x, uint32_t tiles_y, const BandEdges& bands,
-                                 uint32_t rank, uint32_t* out, const SlabStats* stats, const uint32_t* done_before, uint32_t row_words, uint32_t gather_root_plus1) {
+                                 uint32_t rank, uint32_t* out, const SlabStats* stats, const uint32_t* done_before, uint32_t row_words, uint32_t gather_root_plus1,
+                                 uint32_t policy_flags) {
     const uint32_t rows = bands.e[rank + 1u] - bands.e[rank], n = feedback_words(bands, tiles_x, rank);
     GSX_LAUNCH(k_shard_feedback, dim3((n + 255) / 256), dim3(256), 0, s, tile_sat, row_work, tiles_x, tiles_y, bands.e[rank], rows, out, stats, done_before,
-               row_words, gather_root_plus1);
+               row_words, gather_root_plus1, policy_flags);
     return hipGetLastError();
 }
 
 hipError_t launch_shard_post_counts(hipStream_t s, const uint32_t* counts_all, uint32_t world, unsigned long long* host_verdict, uint32_t seq) {
     GSX_LAUNCH(k_shard_post_counts, dim3(1), dim3(64), 0, s, counts_all, world, host_verdict, seq);
+    return hipGetLastError();
+}
+
+hipError_t launch_shard_post_verdict(hipStream_t s, const uint32_t* staged, const uint32_t* sat, uint32_t world, uint32_t stride, uint32_t* host_block, uint32_t seq) {
+    GSX_LAUNCH(k_shard_post_verdict, dim3(1), dim3(256), 0, s, staged, sat, world, stride, host_block, seq);
     return hipGetLastError();
 }
 
@@ -555,9 +618,10 @@ hipError_t launch_shard_max_count(hipStream_t s, const uint32_t* totals, uint32_
 }
 
 hipError_t launch_shard_next_limits(hipStream_t s, const uint32_t* sat, uint32_t tiles_x, uint32_t tiles_y, float margin, uint32_t radius,
-                                    uint32_t* limit, const BandEdges& bands) {
+                                    uint32_t* limit, const BandEdges& bands, uint2* win_next, const uint32_t* staged, const uint32_t* sat_verdict,
+                                    uint32_t* host_block, uint32_t seq) {
     GSX_LAUNCH(k_shard_next_limits, dim3((tiles_x * tiles_y + 255) / 256), dim3(256), 0, s, sat, tiles_x, tiles_y, 1.0f + margin,
-                       (int)std::min<uint32_t>(radius, 16u), limit, bands, feedback_stride(bands, tiles_x));
+                       (int)std::min<uint32_t>(radius, 16u), limit, bands, feedback_stride(bands, tiles_x), win_next, staged, sat_verdict, host_block, seq);
     return hipGetLastError();
 }
 

@@ -40,7 +40,14 @@ constexpr int kSweepThreads = 512;
 constexpr int kSweepWaves = kSweepThreads / 64;
 constexpr int kRadixRounds = 16;                          // elements per lane
 constexpr int kRadixTile = kSweepThreads * kRadixRounds;  // 8192 elements per tile
-constexpr int kWaveChunk = 64 * kRadixRounds;             // 1024 contiguous elements per wave
+// Small sorts (the ~0.3 M admitted pairs of a speculated frame, its repair round, the block lists): a few dozen 8192-element tiles
+// leave most of the chip idle and every tile is a 16-round chain per lane — the pass is one tile's latency.  At or below
+// kRadixSmallN elements (decided ON THE DEVICE from *d_n: the host only knows an upper bound) a pass runs 2048-element tiles,
+// four rounds per lane: four times the workgroups, a quarter of the chain each.  Same ranks, same order (tile boundaries are not
+// part of the result).  tools/bench_sort.hip sweeps the threshold (GSX_RADIX_SMALL).
+constexpr int kRadixRoundsSmall = 4;
+constexpr int kRadixTileSmall = kSweepThreads * kRadixRoundsSmall;  // 2048
+constexpr uint32_t kRadixSmallN = 1u << 19;
 constexpr uint32_t kRadixGrid = 512;                      // persistent workgroups = resident capacity (73 KB of LDS each: 2 per CU)
 constexpr uint32_t kMaxPasses = 4;
 constexpr int kLook = 4;                                  // predecessors examined per look-back round trip (2 and 8 measured)
@@ -57,7 +64,16 @@ __device__ long long* g_sort_prof = nullptr;
 #define GSX_PROF(ph)
 #endif
 
-static inline uint32_t radix_tiles(uint64_t n) { return (uint32_t)((n + kRadixTile - 1) / kRadixTile); }
+static uint32_t radix_small_n() {
+    static const uint32_t v = getenv("GSX_RADIX_SMALL") ? (uint32_t)atoll(getenv("GSX_RADIX_SMALL")) : kRadixSmallN;
+    return v;
+}
+// tiles a pass over at most n elements may use (status words, grid): the larger of the two tilings
+static inline uint32_t radix_tiles(uint64_t n) {
+    const uint64_t big = (n + kRadixTile - 1) / kRadixTile;
+    const uint64_t small_ = (std::min<uint64_t>(n, radix_small_n()) + kRadixTileSmall - 1) / kRadixTileSmall;
+    return (uint32_t)std::max(big, small_);
+}
 
 // workspace (u32 words): [0, 1024) global histograms of up to 4 passes | 1024 ticket | 1025 finished |
 // from 1032: 2 words (one 64-bit status) per (tile, digit)
@@ -182,32 +198,30 @@ typedef unsigned long long u64;
 // projection's key plane as it lies (culled records carry that key) and writes dense pairs: no compaction pass before the
 // sort (the unspeculated frame paid 40 MB + 68 MB + 68 MB for one).  The number of elements that do exist is the sum of this
 // pass's histogram; workgroup 0 writes it to *d_n_out, which is the element count of the passes that follow.
-template <int IN, int OUT, bool LANE_ORDERED, bool SKIP = false>
-__global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t* __restrict__ keys_in,
+template <int IN, int OUT, bool LANE_ORDERED, bool SKIP, int ROUNDS>
+__device__ __forceinline__ void radix_sweep_tiles(const uint32_t* __restrict__ keys_in,
                                                                    const uint32_t* __restrict__ vals_in,
                                                                    const uint2* __restrict__ pairs_in,
                                                                    uint32_t* __restrict__ keys_out,
                                                                    uint32_t* __restrict__ vals_out,
-                                                                   uint2* __restrict__ pairs_out, uint32_t n_cap,
-                                                                   const uint32_t* __restrict__ d_n, int shift, uint32_t dmask,
-                                                                   const uint32_t* __restrict__ ghist /* this pass */,
-                                                                   uint32_t* __restrict__ ticket /* [0] ticket, [1] finished */,
-                                                                   u64* __restrict__ status, uint32_t epoch,
-                                                                   uint32_t* __restrict__ ghist_clear /* last pass: all rows */,
-                                                                   uint32_t ghist_clear_words, uint32_t* __restrict__ d_n_out,
-                                                                   uint2* __restrict__ ranges_out,
-                                                                   const uint4* __restrict__ payload_in, uint4* __restrict__ payload_out) {
-    __shared__ uint2 s_pairs[kRadixTile];       // tile reordered by digit
-    __shared__ uint32_t s_tile_n;               // elements of the tile that exist (SKIP)
-    __shared__ uint32_t cnt[kSweepWaves][256];  // per-wave digit counts, then per-wave local offsets
-    __shared__ uint32_t s_gbase[256];           // global slot of the tile's local slot 0, per digit
-    __shared__ uint32_t s_wtot[kSweepWaves];
-    __shared__ uint32_t s_tile;
-    __shared__ uint32_t s_last;
-
-    const uint32_t n = d_n ? min(*d_n, n_cap) : n_cap;
-    const uint32_t n_tiles = (n + kRadixTile - 1) / kRadixTile;
-    // the launch is sized by n_cap; with a device-side n only min(grid, n_tiles) workgroups have anything to
+                                                          uint2* __restrict__ pairs_out, const uint32_t n, int shift, uint32_t dmask,
+                                                          const uint32_t* __restrict__ ghist /* this pass */,
+                                                          uint32_t* __restrict__ ticket /* [0] ticket, [1] finished */,
+                                                          u64* __restrict__ status, uint32_t epoch,
+                                                          uint32_t* __restrict__ ghist_clear /* last pass: all rows */,
+                                                          uint32_t ghist_clear_words, uint32_t* __restrict__ d_n_out,
+                                                          uint2* __restrict__ ranges_out,
+                                                          const uint4* __restrict__ payload_in, uint4* __restrict__ payload_out,
+                                                          uint2* __restrict__ s_pairs /* LDS: kRadixTile */, uint32_t (*__restrict__ cnt)[256] /* LDS: [kSweepWaves][256] */,
+                                                          uint32_t* __restrict__ s_gbase /* LDS: 256 */, uint32_t* __restrict__ s_wtot /* LDS: kSweepWaves */,
+                                                          uint32_t* __restrict__ s_misc /* LDS: [0] tile, [1] last, [2] tile_n */) {
+    constexpr int kTile = kSweepThreads * ROUNDS;  // elements per tile
+    constexpr int kChunk = 64 * ROUNDS;            // contiguous elements per wave
+    uint32_t& s_tile = s_misc[0];
+    uint32_t& s_last = s_misc[1];
+    uint32_t& s_tile_n = s_misc[2];               // elements of the tile that exist (SKIP)
+    const uint32_t n_tiles = (n + kTile - 1) / kTile;
+    // the launch is sized by an upper bound; with a device-side n only min(grid, n_tiles) workgroups have anything to
     // do — the others leave without touching the ticket (768 same-address atomics alone cost ~9 us)
     const uint32_t participants = min(gridDim.x, n_tiles);
     if (blockIdx.x >= participants) return;
@@ -248,12 +262,12 @@ __global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t
         __syncthreads();
 
         // load + stable ranks inside the wave's contiguous 1024-element chunk
-        const uint32_t base = tile * kRadixTile + wave * kWaveChunk;
-        uint32_t key[kRadixRounds], val[kRadixRounds], rank[kRadixRounds];
+        const uint32_t base = tile * kTile + wave * kChunk;
+        uint32_t key[ROUNDS], val[ROUNDS], rank[ROUNDS];
         // all of the lane's loads first: inside the ranking loop (LDS counters, wave barriers) the compiler kept every load
         // next to its use, and a tile paid 16 serial memory round trips (10-12 us of its ~24)
 #pragma unroll
-        for (int r = 0; r < kRadixRounds; ++r) {
+        for (int r = 0; r < ROUNDS; ++r) {
             const uint32_t e = base + r * 64 + lane;
             const bool valid = e < n;
             if (IN == 2) {
@@ -272,7 +286,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t
             // executes a wave's instructions in order, so the old value IS the element's rank among the wave's
             // 1024-element chunk.  (The ballot-matching path below spends ~7 us per tile here, this one well under 1.)
 #pragma unroll
-            for (int r = 0; r < kRadixRounds; ++r) {
+            for (int r = 0; r < ROUNDS; ++r) {
                 const bool valid = SKIP ? key[r] != 0xFFFFFFFFu : base + r * 64 + lane < n;
                 rank[r] = valid ? atomicAdd(&cnt[wave][(key[r] >> shift) & dmask], 1u) : 0u;
             }
@@ -282,21 +296,21 @@ __global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t
             // rounds, independent of each other; (b) one returning LDS add per digit group and round, issued back to back by
             // the group's first lane — the LDS executes a wave's operations in order, which is exactly the sequential
             // semantics the counters need; (c) the group's base handed to its other lanes by a lane permute.
-            unsigned long long mm[kRadixRounds];
+            unsigned long long mm[ROUNDS];
 #pragma unroll
-            for (int r = 0; r < kRadixRounds; ++r) {
+            for (int r = 0; r < ROUNDS; ++r) {
                 const bool valid = SKIP ? key[r] != 0xFFFFFFFFu : base + r * 64 + lane < n;
                 mm[r] = wave_match8((key[r] >> shift) & dmask, valid);
             }
 #pragma unroll
-            for (int r = 0; r < kRadixRounds; ++r) {
+            for (int r = 0; r < ROUNDS; ++r) {
                 const bool valid = SKIP ? key[r] != 0xFFFFFFFFu : base + r * 64 + lane < n;
                 const uint32_t before = (uint32_t)__popcll(mm[r] & lanemask_lt());
                 rank[r] = 0;
                 if (valid && before == 0) rank[r] = atomicAdd(&cnt[wave][(key[r] >> shift) & dmask], (uint32_t)__popcll(mm[r]));
             }
 #pragma unroll
-            for (int r = 0; r < kRadixRounds; ++r) {
+            for (int r = 0; r < ROUNDS; ++r) {
                 const uint32_t first = ((uint32_t)__ffsll((long long)mm[r]) - 1u) & 63u;
                 rank[r] = (uint32_t)__shfl((int)rank[r], (int)first, 64) + (uint32_t)__popcll(mm[r] & lanemask_lt());
             }
@@ -348,7 +362,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < kRadixRounds; ++r) {
+        for (int r = 0; r < ROUNDS; ++r) {
             const uint32_t e = base + r * 64 + lane;
             if (SKIP ? key[r] != 0xFFFFFFFFu : e < n) {
                 const uint32_t digit = (key[r] >> shift) & dmask;
@@ -393,9 +407,9 @@ __global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t
         __syncthreads();
         GSX_PROF(4);
         // write out: consecutive lanes -> consecutive addresses inside every digit run
-        const uint32_t tile_n = SKIP ? s_tile_n : min((uint32_t)kRadixTile, n - tile * kRadixTile);
+        const uint32_t tile_n = SKIP ? s_tile_n : min((uint32_t)kTile, n - tile * kTile);
 #pragma unroll 4
-        for (int r = 0; r < kRadixRounds; ++r) {
+        for (int r = 0; r < ROUNDS; ++r) {
             const uint32_t slot = r * kSweepThreads + tid;
             if (slot < tile_n) {
                 const uint2 kv = s_pairs[slot];
@@ -429,6 +443,33 @@ __global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t
     __syncthreads();
     if (s_last)
         for (uint32_t k = tid; k < ghist_clear_words; k += kSweepThreads) ghist_clear[k] = 0;
+}
+
+// The pass as a kernel: tile size chosen from the element count that exists on the device.
+template <int IN, int OUT, bool LANE_ORDERED, bool SKIP = false>
+__global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                                   const uint2* __restrict__ pairs_in, uint32_t* __restrict__ keys_out,
+                                                                   uint32_t* __restrict__ vals_out, uint2* __restrict__ pairs_out, uint32_t n_cap,
+                                                                   const uint32_t* __restrict__ d_n, int shift, uint32_t dmask,
+                                                                   const uint32_t* __restrict__ ghist, uint32_t* __restrict__ ticket,
+                                                                   u64* __restrict__ status, uint32_t epoch, uint32_t* __restrict__ ghist_clear,
+                                                                   uint32_t ghist_clear_words, uint32_t* __restrict__ d_n_out,
+                                                                   uint2* __restrict__ ranges_out, const uint4* __restrict__ payload_in,
+                                                                   uint4* __restrict__ payload_out, uint32_t small_n) {
+    __shared__ uint2 s_pairs[kRadixTile];       // tile reordered by digit
+    __shared__ uint32_t cnt[kSweepWaves][256];  // per-wave digit counts, then per-wave local offsets
+    __shared__ uint32_t s_gbase[256];           // global slot of the tile's local slot 0, per digit
+    __shared__ uint32_t s_wtot[kSweepWaves];
+    __shared__ uint32_t s_misc[4];
+    const uint32_t n = d_n ? min(*d_n, n_cap) : n_cap;
+    if (!SKIP && n <= small_n)
+        radix_sweep_tiles<IN, OUT, LANE_ORDERED, SKIP, kRadixRoundsSmall>(keys_in, vals_in, pairs_in, keys_out, vals_out, pairs_out, n, shift, dmask, ghist, ticket,
+                                                                           status, epoch, ghist_clear, ghist_clear_words, d_n_out, ranges_out, payload_in,
+                                                                           payload_out, s_pairs, cnt, s_gbase, s_wtot, s_misc);
+    else
+        radix_sweep_tiles<IN, OUT, LANE_ORDERED, SKIP, kRadixRounds>(keys_in, vals_in, pairs_in, keys_out, vals_out, pairs_out, n, shift, dmask, ghist, ticket,
+                                                                      status, epoch, ghist_clear, ghist_clear_words, d_n_out, ranges_out, payload_in, payload_out,
+                                                                      s_pairs, cnt, s_gbase, s_wtot, s_misc);
 }
 
 hipError_t launch_rowscan(hipStream_t s, uint32_t* table, uint32_t nrows, uint32_t nblocks, uint32_t* totals, const uint32_t* d_n, uint32_t tile,
@@ -562,7 +603,7 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
 #define GSX_SWEEP_ARGS(DN, DNOUT)                                                                                        \
     dim3(grid), dim3(kSweepThreads), 0, s, buf.keys_src, buf.vals_src, pin, buf.keys_out, buf.vals_out, pout, n, DN, shift, dmask, \
         ghist + 256 * p, ticket, status, epoch, ghist, last ? 256u * (uint32_t)passes : 0u, DNOUT, ranges_out,                  \
-        last ? payload_in : nullptr, last ? payload_out : nullptr
+        last ? payload_in : nullptr, last ? payload_out : nullptr, radix_small_n()
 #define GSX_SWEEP(IN, OUT)                                                                                               \
     do {                                                                                                                 \
         if (lane_ordered)                                                                                                \

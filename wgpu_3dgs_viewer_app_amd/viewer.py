@@ -469,6 +469,14 @@ class MultiModelViewer:
         self._comm_fns = (_lib.COMM_A2A_V_FN(a2a), _lib.COMM_GATHER_V_FN(gat))
         _lib.check(self._L.gsx_viewer_comm_init_custom_v(self._h, w, int(rank), self._comm_fns[0], self._comm_fns[1], None))
 
+    def comm_init_custom_v_native(self, world: int, rank: int, all_to_all_v_ptr, gather_v_ptr, ctx) -> None:
+        """The same with two NATIVE functions (addresses or ctypes function objects of a shared library) and their context pointer:
+        nothing of the transport runs in Python (tools/replay_transport.cpp)."""
+        a = C.cast(all_to_all_v_ptr, _lib.COMM_A2A_V_FN)
+        g = C.cast(gather_v_ptr, _lib.COMM_GATHER_V_FN)
+        self._comm_fns = (a, g)
+        _lib.check(self._L.gsx_viewer_comm_init_custom_v(self._h, int(world), int(rank), a, g, C.c_void_p(ctx)))
+
     def comm_destroy(self) -> None:
         _lib.check(self._L.gsx_viewer_comm_destroy(self._h))
 
