@@ -403,9 +403,11 @@ gsx_status gsx_render_more(gsx_viewer* v, const char* const* keys, uint32_t n_ke
  *      = `world` slots of (1 + T) records of GSX_RECORD_BYTES; record 0 of slot g = {u32 records the sender had for g, u32
  *      records sent = min(that, T)}); the host waits for ONE thing per frame, the verdict of round 0 — two words in pinned
  *      memory that the verification kernel derives from globally gathered data, so that every rank reads the same verdict
- *      and takes the same decision.  Per frame and rank (gsx_shard_render_frame is exactly this sequence over RCCL;
- *      wgpu_3dgs_viewer_app_amd/parallel.py runs the same stage calls with an injectable transport so that the tests can
- *      put `world` ranks on one GPU, or on CPU over gloo):
+ *      and takes the same decision.  Per frame and rank (the STAGE calls below, for a caller that strings the protocol together
+ *      itself: wgpu_3dgs_viewer_app_amd/parallel.py runs them with an injectable transport so that the tests can put `world` ranks
+ *      on one GPU, or on CPU over gloo.  gsx_shard_render_frame runs the same stages without a host look inside the frame: its
+ *      repair rounds are enqueued unasked and decide on the device, except the last model's, which — like a frame whose slots
+ *      overflowed — is dealt with when the frame is retired; its verdicts go to a pinned ring that is read then):
  *        gsx_shard_frame_begin(key, world, rank, speculate, NULL)      windows [0, limit) from last frame's limits -> projection
  *        gsx_shard_slot_records(key, world, max_shard, &T)             round-0 slot size (2x what the last verdict reported)
  *        gsx_shard_pack_slots(key, world, 0, d_send, T)
@@ -471,8 +473,9 @@ gsx_status gsx_shard_render_frame(gsx_viewer* v, const char* key, uint32_t shard
 /* The same for several LAYERED models — the reference paints `model_render_keys` far -> near and never merges models
  * (src/tab/scene.rs:533-558, 2302-2314), gsx_render does the same on one GPU.  Every model is index-sharded over the ranks
  * (shard_records_max[i] = largest shard of keys_far_to_near[i]); each keeps its own per-tile limits from frame to frame.  Per
- * model: exchange -> composite into this rank's band behind the nearer models -> verification -> (repair); one band
- * all-gather at the end.  Pixels equal gsx_render(keys_far_to_near) on one GPU bit for bit. */
+ * model: exchange -> composite into this rank's band behind the nearer models -> verification -> repair exchange (always
+ * enqueued with fixed-size slots, decided on the device: nothing waits between two models; the last model's is decided when the
+ * frame is retired); one band all-gather at the end.  Pixels equal gsx_render(keys_far_to_near) on one GPU bit for bit. */
 gsx_status gsx_shard_render_frame_keys(gsx_viewer* v, const char* const* keys_far_to_near, uint32_t n_keys,
                                        const uint32_t* shard_records_max, uint32_t speculate, float margin, uint32_t radius);
 

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collects the per-round evidence under gpurun_out/<round>/ on the GPU box (run through gpurun); copy the summaries into
-# profiles/ afterwards.  rocprofv3 wraps python3 directly (no env / bash hop).  usage: tools/collect_profiles.sh r04
+# profiles/ afterwards.  rocprofv3 wraps python3 directly (no env / bash hop).  usage: tools/collect_profiles.sh r05 [A|B|C|D]
 set -u
-R=${1:-r04}
+R=${1:-r05}
 PART=${2:-all}
 want() { [ "$PART" = all ] || [ "$PART" = "$1" ]; }
 OUT=gpurun_out/$R
@@ -64,5 +64,18 @@ GSX_TILE_ORDER=0 python3 tools/tile_profile.py > $OUT/tile_profile_index_order.t
 tools/ab_env.sh GSX_TILE_ORDER=0 GSX_TILE_ORDER=1 GSX_TILE_ORDER=0 GSX_TILE_ORDER=1 > $OUT/ab_tile_order.txt 2>&1
 tools/bench_atomic > $OUT/bench_atomic.txt 2>&1
 python3 tools/rank_alone.py --worlds 8 --scenes open_sky --lanes 1 --balance 0 --out $OUT/rank_alone_equal_bands.json > /dev/null 2>> $OUT/rank_alone.err
+fi
+if want D; then
+# 10. round 5: every rank of an N-rank frame alone on the GPU over the native replay transport, cfg4 and cfg5; the sharded frame and
+#     cfg5 against the round-4 protocol (build_variants/libgsx_base.so) on this box; the block size A/B; the radix tile size A/B
+python3 tools/rank_alone.py --out $OUT/rank_alone.json > /dev/null 2> $OUT/rank_alone.err
+python3 tools/rank_alone.py --workload cfg5 --worlds 8 --scenes orbit --out $OUT/rank_alone_cfg5.json > /dev/null 2>> $OUT/rank_alone.err
+python3 tools/rank_alone.py --worlds 8 --scenes orbit --lanes 1 --python-replay --out $OUT/rank_alone_python_replay.json > /dev/null 2>> $OUT/rank_alone.err
+[ -f build_variants/libgsx_base.so ] && tools/ab_shard.sh base new > $OUT/ab_shard.txt 2>&1
+python3 tools/ab_blocks.py > $OUT/ab_blocks.txt 2>> $OUT/bench.err
+for n in 100000 310000 870000; do
+  echo "== n=$n, 2048-element tiles off" >> $OUT/ab_radix_small.txt; GSX_RADIX_SMALL=0 tools/bench_sort $n 32 depth >> $OUT/ab_radix_small.txt 2>&1
+  echo "== n=$n, default" >> $OUT/ab_radix_small.txt; tools/bench_sort $n 32 depth >> $OUT/ab_radix_small.txt 2>&1
+done
 fi
 for f in $OUT/bench.json $OUT/bench_driver_args.json $OUT/bench_index_world1_inflight2.json; do [ -s $f ] && cut -c1-300 $f; done

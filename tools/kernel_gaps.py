@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where a frame's time goes between its kernels, from a rocprofv3 --kernel-trace CSV: the frames are cut at the projection
 kernel, and for the last <frames> of them the kernel time, the gaps between consecutive kernels (end -> next start) and the gap
-after each kernel (by kernel name) are averaged.  usage: kernel_gaps.py <dir> <frames> [project-kernel substring]"""
+after each kernel (by kernel name) are averaged.  usage: kernel_gaps.py <dir> <frames> [project-kernel substring] [timeline]"""
 import collections
 import csv
 import glob
@@ -29,3 +29,9 @@ span = (rows[starts[-1]][0] - rows[starts[0]][0]) / 1e3 / nf
 print(f"{nf} frames: {span:.1f} us per frame = {busy / nf:.1f} us in kernels + {gap / nf:.1f} us between them; {n_k / nf:.1f} kernels per frame, {gap / max(n_k, 1):.2f} us per boundary")
 for name, v in sorted(after.items(), key=lambda kv: -sum(kv[1]))[:14]:
     print(f"  after {name:46s} {sum(v) / nf:7.1f} us per frame  ({len(v) / nf:4.1f} x {sum(v) / len(v):6.2f} us)")
+if len(sys.argv) > 4 and sys.argv[4] == "timeline":   # the last whole frame, kernel by kernel: start offset, duration, gap to the next
+    a, b = starts[-2], starts[-1]
+    t0 = rows[a][0]
+    for i in range(a, b):
+        s, e, name = rows[i]
+        print(f"  +{(s - t0) / 1e3:8.1f} us  {(e - s) / 1e3:7.1f} us  gap {(rows[i + 1][0] - e) / 1e3:6.1f}  {name}")

@@ -33,6 +33,12 @@ from wgpu_3dgs_viewer_app_amd import camera, parallel, scene  # noqa: E402
 from wgpu_3dgs_viewer_app_amd.mask import MaskEvaluator, MaskOp, MaskShape, MaskShapeKind  # noqa: E402
 from wgpu_3dgs_viewer_app_amd.viewer import GaussianDisplayMode, GaussianShDegree, MultiModelViewer  # noqa: E402
 
+# The block size of the block lists is pinned for both phases: left to itself the library picks it per model from the longest walk of an
+# earlier frame (gsx_frame.cpp), i.e. from statistics that arrive when the device gets to them — at other frames in an 8-thread recording
+# than in a solo replay — and the per-row work the bands are balanced by depends on it: the replayed rank would plan other band edges than
+# the recording and ask its transport for pieces that were never recorded.  (A real N-GPU run needs no such pin: every rank reads the same
+# gathered figures whatever each rank's block size was.)
+os.environ.setdefault("GSX_BLOCKS_MAX", "256")
 XGMI_LINK_GBPS, XGMI_LINKS = 153.0, 7
 hip = C.CDLL("libamdhip64.so")
 hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
@@ -202,6 +208,7 @@ CFG5_TRS = {"a": camera.ModelTransform(pos=np.array([0.0, 0.0, 2.5], np.float32)
                                        scale=np.array([1.2, 0.9, 1.1], np.float32))}   # tools/bench_cfg5.py's scene (BASELINE.json configs[4])
 WORKLOAD = "cfg4"
 PYTHON_REPLAY = False
+PASS_REPLAY = True
 
 
 def make_viewer(cfg, rank, world, open_sky, lanes=1):
@@ -337,29 +344,32 @@ def run(cfg, world, frames, open_sky, speculate, orbit, lanes):
         v.close()
         # once more with every pass bracketed by events (costs a few microseconds of stream gap per bracket): where the rank's time goes;
         # and the kernel launches the library asks for per frame (GSX_LAUNCH counter)
-        from wgpu_3dgs_viewer_app_amd import viewer as viewer_mod
-        v, frame, models = make_viewer(cfg, rank, world, open_sky, lanes)
-        tr2 = attach(v, rank)
-        l0 = 0
-        for i in range(frames):
-            if i == warm:
-                v.poll()
-                v.set_pass_timing(True)
-                v.get_pass_timing()
-                l0 = viewer_mod.launch_count()
-            frame(i, speculate)
-        launches = round((viewer_mod.launch_count() - l0) / timed, 1)
-        v.poll()
-        passes = {k: round(1e3 * t["ms"] / timed, 1) for k, t in v.get_pass_timing().items() if t["ms"] > 0}
+        passes, tr2 = {}, None
+        if PASS_REPLAY:
+            from wgpu_3dgs_viewer_app_amd import viewer as viewer_mod
+            v, frame, models = make_viewer(cfg, rank, world, open_sky, lanes)
+            tr2 = attach(v, rank)
+            l0 = 0
+            for i in range(frames):
+                if i == warm:
+                    v.poll()
+                    v.set_pass_timing(True)
+                    v.get_pass_timing()
+                    l0 = viewer_mod.launch_count()
+                frame(i, speculate)
+            launches = round((viewer_mod.launch_count() - l0) / timed, 1)
+            v.poll()
+            passes = {k: round(1e3 * t["ms"] / timed, 1) for k, t in v.get_pass_timing().items() if t["ms"] > 0}
         ranks.append(dict(rank=rank, ms_per_frame_alone=round(1e3 * elapsed / timed, 4), pass_us_per_frame=passes, launches_per_frame=launches,
                           wire_bytes_per_frame=int(wire_timed / timed), frames_equal_to_the_recording=bool(same),
                           list_entries_last_frame=int(out[rank]["entries"]),
                           repair_frames=round(st["repair_frames"] / max(st["frames"], 1), 3), redo_frames=round(st["redo_frames"] / max(st["frames"], 1), 3),
                           verdict_wait_us_per_frame=round(st["verdict_wait_ns"] / 1e3 / max(st["frames"], 1), 1),
                           band_rows_last_frame=[out[rank]["sums"][-1][1][rank], out[rank]["sums"][-1][1][rank + 1]]))
-        v.close()
+        if PASS_REPLAY:
+            v.close()
         for t in (tr, tr2):
-            if hasattr(t, "close"):
+            if t is not None and hasattr(t, "close"):
                 t.close()
     for lg in hub.log:
         for _, pieces in lg:
@@ -397,16 +407,20 @@ def main():
     ap.add_argument("--frames", type=int, default=40)
     ap.add_argument("--workload", default="cfg4")
     ap.add_argument("--scenes", default="orbit,open_sky")
-    ap.add_argument("--unspeculated-frames", type=int, default=8)
+    ap.add_argument("--unspeculated-frames", type=int, default=14)
     ap.add_argument("--lanes", default="1,2", help="frames in flight of the replayed rank (and of the recording)")
     ap.add_argument("--out", default="")
     ap.add_argument("--balance", type=int, default=1, help="0: equal bands of tile rows (gsx_shard_set_balance(0)) — the A/B of the balanced bands")
+    ap.add_argument("--speculate", default="1,0", help="which schedules to run")
+    ap.add_argument("--no-pass-replay", action="store_true", help="skip the second replay with the passes bracketed by events (for a kernel trace whose tail is the timed replay)")
     ap.add_argument("--python-replay", action="store_true", help="serve the replay from Python callbacks (rounds 4's transport: the A/B of the native one)")
     a = ap.parse_args()
-    global BALANCE, WORKLOAD, PYTHON_REPLAY, ORBIT, KEYS_OF
+    global BALANCE, WORKLOAD, PYTHON_REPLAY, ORBIT, KEYS_OF, PASS_REPLAY
     BALANCE = bool(a.balance)
     WORKLOAD = a.workload
     PYTHON_REPLAY = a.python_replay
+    PASS_REPLAY = not a.no_pass_replay
+    specs = [int(x) for x in a.speculate.split(",")]
     cfg = scene.CONFIGS[a.workload]
     n, sh, w, h, seed = cfg
     orbit = [camera.PrecomputedCamera(camera.orbit_pose(k), w / h) for k in range(240)]
@@ -422,14 +436,14 @@ def main():
                balanced_bands=bool(a.balance), single_gpu_fps={}, runs=[])
     lanes_list = [int(x) for x in a.lanes.split(",")]
     for sc in a.scenes.split(","):
-        for spec in (1, 0):
+        for spec in specs:
             for lanes in lanes_list:
                 res["single_gpu_fps"][f"{sc} speculate={spec} frames_in_flight={lanes}"] = single_gpu(cfg, max(a.frames, 120), sc == "open_sky", spec, orbit, lanes)
     SHARDS.clear()
     for world in [int(x) for x in a.worlds.split(",")]:
         SHARDS.clear()
         for sc in a.scenes.split(","):
-            for spec, lanes in [(s, l) for s in (1, 0) for l in lanes_list]:
+            for spec, lanes in [(s, l) for s in specs for l in lanes_list]:
                 # (speculate = 0: every visible record travels and a slot holds a whole shard — 60 MB x 8 x 8 per frame at world 8 on
                 #  cfg4: the recording keeps fewer frames)
                 frames = a.frames if spec else min(a.frames, a.unspeculated_frames)

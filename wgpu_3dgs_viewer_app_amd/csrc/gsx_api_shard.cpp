@@ -1,6 +1,7 @@
 // gsx_api_shard.cpp — C ABI for multi-GPU rendering: band layout, external framebuffer, screen bands, and the stage split of
 // the index-sharded exchange (pack / import / feedback / second round).  No reference counterpart (src/main.rs:85-98).
 #include <chrono>
+#include <sched.h>
 #include <thread>
 
 #include "gsx_state.h"
@@ -190,6 +191,14 @@ gsx_status gsx_shard_feedback_words(gsx_viewer* v, uint32_t world, uint32_t* out
 }
 
 gsx_status gsx_shard_feedback(gsx_viewer* v, const char* key, uint32_t world, uint32_t rank, void* d_out_u32) {
+    return shard_feedback(v, key, world, rank, d_out_u32, false);
+}
+
+}  // extern "C"
+
+// zero_verify_state: the kernel also zeroes what the verification behind the gather accumulates into (its counter, its ticket, the need
+// bitmap): shard_verify_staged then launches nothing in front of its kernel
+gsx_status gsx::shard_feedback(gsx_viewer* v, const char* key, uint32_t world, uint32_t rank, void* d_out_u32, bool zero_verify_state) {
     gsx_status st = viewer_bind(v);
     if (st) return st;
     Model* m = find_model(v, key);
@@ -206,11 +215,23 @@ gsx_status gsx_shard_feedback(gsx_viewer* v, const char* key, uint32_t world, ui
     // how this rank sizes slots and bands travels with the feedback: ranks that disagree would exchange slots of different sizes
     // (over RCCL: a hang or silent truncation) — the verification posts the disagreement and the frame fails first
     const uint32_t policy = (o->shard_balance ? kPolicyBalance : 0u) | (o->shard_pair_slots ? kPolicyPairSlots : 0u) | (m->slot_force << 8);
+    uint32_t *za = nullptr, *zb = nullptr;
+    uint32_t nza = 0, nzb = 0;
+    if (zero_verify_state) {
+        HIPCHK(m->shard_need_bits.ensure(4 * (size_t)row_words * tiles_y));
+        za = &m->counters.as<Counters>()->shard_need;  // shard_need + shard_ticket
+        nza = 2;
+        zb = m->shard_need_bits.as<uint32_t>();
+        nzb = row_words * tiles_y;
+    }
+    m->verify_state_zeroed = zero_verify_state;
     HIPCHK(launch_shard_feedback(v->stream, tile_sat, row_work, tiles_x, tiles_y, bands_of(v, world), rank, static_cast<uint32_t*>(d_out_u32),
                                  m->counters.as<Counters>(), m->shard_behind ? m->spec_done_before.as<uint32_t>() : nullptr, row_words,
-                                 (uint32_t)(o->shard_gather_root + 1), policy));
+                                 (uint32_t)(o->shard_gather_root + 1), policy, za, nza, zb, nzb));
     return GSX_OK;
 }
+
+extern "C" {
 
 gsx_status gsx_render_more(gsx_viewer* v, const char* const* keys, uint32_t n_keys) {
     gsx_status st = viewer_bind(v);
@@ -580,7 +601,9 @@ gsx_status gsx::shard_verify_staged(gsx_viewer* v, const char* key, uint32_t wor
     HIPCHK(m->shard_need_bits.ensure(4 * (size_t)((tiles_x + 31) / 32) * tiles_y));
     HIPCHK(v->verdict_stage.ensure(4 * (size_t)kVerdictWords));
     Counters* dc = m->counters.as<Counters>();
-    HIPCHK(launch_zero_words(v->stream, &dc->shard_need, 2, m->shard_need_bits.as<uint32_t>(), ((tiles_x + 31) / 32) * tiles_y));
+    if (!m->verify_state_zeroed)  // (the feedback kernel in front of the gather zeroed them on its way: shard_feedback)
+        HIPCHK(launch_zero_words(v->stream, &dc->shard_need, 2, m->shard_need_bits.as<uint32_t>(), ((tiles_x + 31) / 32) * tiles_y));
+    m->verify_state_zeroed = false;
     const gsx_viewer* o = v->parent ? v->parent : v;
     // the verdict block goes to DEVICE memory: nobody waits for it; k_shard_post_verdict posts it behind the repair round
     HIPCHK(launch_shard_verify(v->stream, m->shard_frame_limited ? m->shard_limit.as<uint32_t>() : nullptr, static_cast<const uint32_t*>(d_sat_all),
@@ -631,7 +654,11 @@ gsx_status gsx::shard_wait_ring(gsx_viewer* v, uint32_t seq, gsx_shard_verdict* 
             if ((spin & 0xFFFFFu) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(60))
                 return fail(GSX_ERR_RCCL, "sharded frame: verdict %u did not arrive within 60 s (a collective is stuck)", seq);
         }
-        if (spin > 4096) std::this_thread::sleep_for(std::chrono::microseconds(5));  // a long wait (the device is a frame behind): yield
+        // (pure spinning: with one frame in flight this wait IS the frame, and a sleep's wake-up — tens of microseconds of timer slack —
+        //  would be a bubble on the device every frame: 1307 against 1445 fps on cfg4 at world 1).  A wait that has outlasted any
+        //  frame yields its core between looks: ranks that share a host with fewer cores than spinning threads (RCCL's proxy threads
+        //  spin too) must not starve the thread that would complete the collective.
+        if (spin > 200000u) sched_yield();
         else __builtin_ia32_pause();
     }
 }

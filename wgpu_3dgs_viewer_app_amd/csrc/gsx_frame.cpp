@@ -416,6 +416,9 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
     m->cand_valid = false;
     adm.lazy = m->lazy ? 1u : 0u;
     // a lazy projection writes four bytes of tile rectangle per Gaussian instead of the 16-byte `a` record (grids up to 255 x 255 tiles)
+    // (Round 5 measured the unlazy kernel writing this 4-byte plane as well, so that the binning of an unspeculated frame could gather its
+    //  rectangles from a 40 MB plane instead of the 160 MB `a` plane: binning 200 -> 195-200 us, projection + 2-8 us: nothing.  A gather by
+    //  depth order touches one line per record whatever the record's size.  profiles/r05_ab_rect8.txt)
     m->rect8_active = m->lazy && m->fc.tiles_x <= 255u && m->fc.tiles_y <= 255u;
     if (m->rect8_active) HIPCHK(m->rect8.ensure(4 * std::max<size_t>(m->n, 1)));
     m->last_pod_mask = pod.mask;

@@ -583,7 +583,7 @@ hipError_t launch_shard_next_limits(hipStream_t s, const uint32_t* sat, uint32_t
 // this rank's feedback piece (layout: feedback_* above)
 hipError_t launch_shard_feedback(hipStream_t s, const uint32_t* tile_sat, const uint32_t* row_work, uint32_t tiles_x, uint32_t tiles_y, const BandEdges& bands,
                                  uint32_t rank, uint32_t* out, const SlabStats* stats, const uint32_t* done_before, uint32_t row_words, uint32_t gather_root_plus1,
-                                 uint32_t policy_flags = 0);
+                                 uint32_t policy_flags = 0, uint32_t* za = nullptr, uint32_t nza = 0, uint32_t* zb = nullptr, uint32_t nzb = 0 /* words zeroed on the way */);
 constexpr uint32_t kPolicyBalance = 1u, kPolicyPairSlots = 2u;  // feedback word [6]; bits 8.. : the model's forced slot size (gsx_shard_set_slot_records)
 hipError_t launch_import_records(hipStream_t s, const void* d_recv, uint32_t n, const Records& rec);
 

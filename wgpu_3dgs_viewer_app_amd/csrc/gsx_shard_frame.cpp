@@ -10,10 +10,14 @@
 //   round 0   pack -> all-to-all of fixed slots -> import + depth sort + composite into this rank's band (behind the nearer
 //             models) -> feedback -> all-gather of the saturation map -> verification: which tiles were refused records they
 //             still need, their repair windows, the count — all on the device (the verdict block staged in device memory).
-//   round 1   the repair exchange, ALWAYS enqueued when the frame was limited by windows, with slots of a fixed size R (twice what
-//             the busiest pair had in the last repair round whose verdict was read): its kernels look at the verification's count
-//             and fall through when no tile needs anything; the all-to-all moves the (empty) slots regardless.  What it
-//             delivers is composited behind what the tiles hold; feedback + all-gather once more.
+//   round 1   the repair exchange.  For every model that has another model BEHIND it: always enqueued, with slots of a fixed size R
+//             (twice the largest repair of the last frames, a maximum that decays by a sixteenth per frame): its kernels look at
+//             the verification's count and fall through when no tile needs anything; the all-to-all moves the (empty) slots
+//             regardless; feedback + all-gather once more.  Nothing may wait between two models.  For the frame's LAST model (a
+//             single model always): decided by the host when the frame is retired, exactly sized, only in the frames that need it —
+//             with frames in flight that look is off the critical path anyway, and a frame that repairs nothing pays neither ~15
+//             fall-through launches nor `world` empty slots (measured, cfg4 at world 1: 1100 / 1200 fps with one / two frames in
+//             flight when the device decided for the single model too, 1450 / 1690 when the host does; GSX_SHARD_REPAIR_DEVICE=1).
 //   verdict   one kernel posts the model's verdict block — tiles that needed the repair, a slot of either round overflowed, the
 //             count matrix, next frame's band edges — into slot (seq mod ring) of a pinned ring; next limits from the last
 //             gathered saturation map.  The next model follows at once: its records are composited behind a finished model.
@@ -105,7 +109,7 @@ gsx_status feedback_gather(Ctx& c) {
 // one exchange round of model i: pack -> all-to-all -> import + sort + composite -> feedback -> all-gather.
 // T: uniform slots of T records; caps (round 0, nullable): caps[s * world + d] = records the slot of the pair (s, d) holds — sized
 // pair by pair from the count matrix of the model's last frame, the same table on every rank.
-gsx_status exchange_round(Ctx& c, size_t i, uint32_t round, uint32_t T, const std::vector<uint32_t>* caps = nullptr, bool gated = false) {
+gsx_status exchange_round(Ctx& c, size_t i, uint32_t round, uint32_t T, const std::vector<uint32_t>* caps = nullptr, bool gated = false, bool zero_verify = false) {
     gsx_viewer* v = c.l;
     const char* key = c.p->order[i].c_str();
     gsx_shard_stats& ss = c.owner->shard_stats;
@@ -144,7 +148,8 @@ gsx_status exchange_round(Ctx& c, size_t i, uint32_t round, uint32_t T, const st
     }
     if (st) return st;
     if ((st = shard_import_slots(v, key, v->shard_recv.p, c.world, c.rank, round | (i > 0 ? GSX_SHARD_BEHIND : 0u), rcv))) return st;
-    if ((st = gsx_shard_feedback(v, key, c.world, c.rank, v->shard_sat_band.p))) return st;
+    // (round 0 of a frame that decides on the device: the verification follows the gather at once — its state is zeroed by this kernel)
+    if ((st = shard_feedback(v, key, c.world, c.rank, v->shard_sat_band.p, zero_verify))) return st;
     return feedback_gather(c);
 }
 
@@ -232,9 +237,10 @@ gsx_status timed_wait(Ctx& c, const char* key, uint32_t seq, gsx_shard_verdict* 
     return st;
 }
 
+gsx_status repair_sized(Ctx& c, size_t i);
+
 // the verdict of model i's round 0 and what it asks for; *overflow: a slot was too small, the frame has to be redone
 gsx_status settle(Ctx& c, size_t i, bool* overflow) {
-    gsx_viewer* v = c.l;
     const char* key = c.p->order[i].c_str();
     gsx_shard_verdict verdict{};
     gsx_status st = timed_wait(c, key, c.p->seq, &verdict);
@@ -246,7 +252,14 @@ gsx_status settle(Ctx& c, size_t i, bool* overflow) {
     c.p->counted[i] = true;
     *overflow = verdict.overflow != 0;
     if (*overflow || !verdict.need_tiles) return GSX_OK;
-    // the repair round, sized exactly: what each destination is owed is counted, the maximum gathered and posted
+    return repair_sized(c, i);
+}
+
+// the repair round of model i, sized exactly by the host: what each destination is owed is counted, the maximum gathered and posted
+gsx_status repair_sized(Ctx& c, size_t i) {
+    gsx_viewer* v = c.l;
+    const char* key = c.p->order[i].c_str();
+    gsx_status st = GSX_OK;
     c.p->repaired = true;
     HIPCHK(v->shard_counts.ensure(16 * (size_t)(c.world + 1)));
     char* cnt = static_cast<char*>(v->shard_counts.p);
@@ -394,12 +407,17 @@ gsx_status frame_front(Ctx& c, bool eager_gather) {
         const Model* lm = find_model(c.l, p.order[i].c_str());
         p.limited[i] = lm && lm->shard_frame_limited ? 1 : 0;
         plan_pair_slots(c, i);
-        // only a frame whose exchange was limited by windows can have refused a tile anything
-        if (p.limited[i]) p.repair_slot[i] = repair_slot_policy(find_model(c.owner, p.order[i].c_str()), p.shard_max[i]);
+        // Only a frame whose exchange was limited by windows can have refused a tile anything.  The models that have another model
+        // behind them get the device-decided round (nothing may wait between two models); the LAST model's repair is decided by the
+        // host when the frame is retired — exactly sized, and only in the frames that need it: with frames in flight that look is off
+        // the critical path anyway, and a frame that repairs nothing pays no fall-through launches and no empty slots
+        // (GSX_SHARD_REPAIR_DEVICE=1: the device decides for every model — no host look ever, at ~15 launches and `world` slots a frame).
+        static const bool all_device = getenv("GSX_SHARD_REPAIR_DEVICE") != nullptr && atoi(getenv("GSX_SHARD_REPAIR_DEVICE")) != 0;
+        if (p.limited[i] && (i + 1 < n || all_device)) p.repair_slot[i] = repair_slot_policy(find_model(c.owner, p.order[i].c_str()), p.shard_max[i]);
     }
     for (size_t i = 0; i < n; ++i) {
         const char* key = p.order[i].c_str();
-        if ((st = exchange_round(c, i, 0, p.slot[i], &p.pair_caps[i]))) return st;
+        if ((st = exchange_round(c, i, 0, p.slot[i], &p.pair_caps[i], false, true))) return st;
         if ((st = shard_verify_staged(c.l, key, c.world, c.l->shard_sat_all.p))) return st;
         // the repair round: enqueued without asking; its kernels fall through when the verification counted no tile in need
         if (p.repair_slot[i] && (st = exchange_round(c, i, 1, p.repair_slot[i], nullptr, true))) return st;
@@ -427,7 +445,7 @@ gsx_status frame_retire(gsx_viewer* owner, ShardPending& p) {
         c.bands.e[g] = p.edges.size() == (size_t)c.world + 1u ? p.edges[g] : g * ((c.tiles_y + c.world - 1) / c.world);
     gsx_status st = GSX_OK;
     gsx_shard_stats& ss = owner->shard_stats;
-    bool overflow = false;
+    bool overflow = false, host_repair = false;
     if (!p.settled) {
         for (size_t i = 0; i < p.order.size(); ++i) {
             gsx_shard_verdict verdict{};
@@ -456,7 +474,20 @@ gsx_status frame_retire(gsx_viewer* owner, ShardPending& p) {
                         block[kVerdictRepairMax], block[kVerdictRepairOver], "");
             if (verdict.need_tiles && p.repair_slot[i]) p.repaired = true;
             overflow = overflow || verdict.overflow != 0 || block[kVerdictRepairOver] != 0;
+            if (verdict.need_tiles && p.limited[i] && !p.repair_slot[i]) host_repair = true;  // (the last model: its repair waits for this look)
         }
+    }
+    if (host_repair && !overflow) {
+        // the last model's tiles were refused records they need: the exchange that brings them, sized exactly, behind what the band holds;
+        // then its limits and the band gather once more (the early ones showed the frame without the repair)
+        const bool own = p.lane == owner;
+        if (own) swap_uniforms(p.lane, p);
+        st = frame_buffers(c);
+        if (!st) st = repair_sized(c, p.order.size() - 1);
+        if (!st) st = band_gather(c);
+        if (!st) st = lane_mark(owner, p, !owner->shard_pending.empty() && &owner->shard_pending.back() == &p);
+        if (own) swap_uniforms(p.lane, p);
+        if (st) return st;
     }
     if (overflow) {
         const bool own = p.lane == owner;
@@ -568,12 +599,16 @@ gsx_status gsx_shard_render_frame_keys(gsx_viewer* v, const char* const* keys_fa
     p.margin = margin;
     p.radius = radius;
     Ctx c{v, lane, &p, v->comm_world, v->comm_rank, {}, 0, {}, 0, 0};
-    const bool eager_gather = v->shard_gather_root < 0 || v->shard_root_confirmed;
+    // The band gather is enqueued with the frame when the call is going to wait for this frame anyway (one frame in flight: the gather
+    // runs while the verdict travels); with frames in flight it waits for the retirement — a third of cfg4's orbit frames repair their last
+    // model there, and a gather that showed the frame without the repair would be bytes on the links for nothing.
+    const bool eager_gather = lanes == 1 && (v->shard_gather_root < 0 || v->shard_root_confirmed);
     if ((st = frame_front(c, eager_gather))) {
         v->shard_pending.clear();
         return st;
     }
-    if (!eager_gather && (st = retire_all(v))) return st;  // (its verdict says whether the ranks agree about the root; then the gather)
+    // (a gather to ONE rank whose root is not confirmed yet: the frame's verdict says whether the ranks agree; then the gather)
+    if (v->shard_gather_root >= 0 && !v->shard_root_confirmed && (st = retire_all(v))) return st;
     // the frames in flight: every frame but the newest L - 1 is retired — with L >= 2 its verdict arrived while this frame was being
     // enqueued (and the device has this one queued); with one frame in flight the call waits for its own frame
     while (v->shard_pending.size() > lanes - 1u) {

@@ -220,6 +220,7 @@ struct Model {
     DevBuf shard_pyr2;             // min-pyramid of the repair windows' starts (the repair round's conservative pack test)
     DevBuf shard_need_bits;        // device-resident exchange: bitmap of the tiles that need the repair round (gates its pack)
     bool repair_counted = false;
+    bool verify_state_zeroed = false;   // the last feedback kernel zeroed the verification's counters and need bitmap on its way
     uint32_t pack_rounds = 16;     // tile size (x 256 records) of the last pack_count: its table layout (kernels_shard.hip)
     bool pack_list = false, pack_travellers = false;  // how the last pack_count addressed the records / whether it left travellers to shade   // gsx_shard_repair_count has left masks / table / travellers for the repair pack
 
@@ -468,6 +469,7 @@ gsx_status shard_pack_slots(gsx_viewer* v, const char* key, uint32_t world, uint
 // a frame that decides its repair round on the device (gsx_shard_frame.cpp): the round-0 verdict staged in device memory, then — behind
 // the always-enqueued repair round — posted to slot seq % ring of the viewer's pinned verdict ring
 gsx_status shard_verify_staged(gsx_viewer* v, const char* key, uint32_t world, const void* d_sat_all);
+gsx_status shard_feedback(gsx_viewer* v, const char* key, uint32_t world, uint32_t rank, void* d_out_u32, bool zero_verify_state);
 gsx_status shard_post_verdict(gsx_viewer* v, uint32_t world, const void* d_sat_after_repair /* nullable */, uint32_t* out_seq);
 gsx_status shard_next_windows_post(gsx_viewer* v, const char* key, uint32_t world, const void* d_sat_all, float margin, uint32_t radius,
                                    const void* d_sat_after_repair /* nullable */, uint32_t* out_seq);

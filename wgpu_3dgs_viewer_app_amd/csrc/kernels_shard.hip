@@ -339,7 +339,13 @@ __device__ inline uint32_t work_at(const uint32_t* __restrict__ sat, uint32_t ty
 __global__ __launch_bounds__(256) void k_shard_feedback(const uint32_t* __restrict__ tile_sat, const uint32_t* __restrict__ row_work, uint32_t tiles_x,
                                                          uint32_t tiles_y, uint32_t row_lo, uint32_t rows, uint32_t* __restrict__ out,
                                                          const SlabStats* __restrict__ stats, const uint32_t* __restrict__ done_before,
-                                                         uint32_t row_words, uint32_t gather_root_plus1, uint32_t policy_flags) {
+                                                         uint32_t row_words, uint32_t gather_root_plus1, uint32_t policy_flags,
+                                                         uint32_t* __restrict__ za, uint32_t nza, uint32_t* __restrict__ zb, uint32_t nzb) {
+    // (za / zb: the verification's counters and its need bitmap, zeroed on the way for the launch that follows the gather — one launch less)
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < max(nza, nzb); k += gridDim.x * blockDim.x) {
+        if (k < nza) za[k] = 0u;
+        if (k < nzb) zb[k] = 0u;
+    }
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_sat = rows * tiles_x;
     if (i >= kShardExtraWords + n_sat + rows) return;
@@ -383,7 +389,8 @@ __global__ __launch_bounds__(256) void k_shard_verify(const uint32_t* __restrict
         win2[t] = need ? make_uint2(lim, 0xFFFFFFFFu) : make_uint2(0u, 0u);
         if (need) atomicOr(&need_bits[ty * ((tiles_x + 31u) / 32u) + (tx >> 5)], 1u << (tx & 31u));
     }
-    __shared__ uint32_t s_need;
+    __shared__ uint32_t s_need, s_last;
+    __shared__ uint32_t s_work[1024];  // per-row work of the whole frame (the last workgroup: rows past 1024 are read from memory)
     if (threadIdx.x == 0) s_need = 0;
     __syncthreads();
     const unsigned long long bal = __ballot(need);
@@ -391,91 +398,97 @@ __global__ __launch_bounds__(256) void k_shard_verify(const uint32_t* __restrict
     __syncthreads();
     if (threadIdx.x == 0) {
         if (s_need) atomicAdd(d_need, s_need);
-        // The last block posts the verdict of round 0 to pinned host memory — the ONE thing the host waits for in a frame
-        // (layout: gsx_internal.h, kVerdict*):
-        //   word 1 = {largest per-destination record count over all ranks | any rank's slot overflowed}
-        //   word 0 = {seq | tiles that need the repair round}     (release store: the host polls this one)
-        //   and behind them: the count matrix (slot sizes of the next frame, pair by pair), the band edges of the next frame
-        //   (balanced by the rows' work), whether the ranks agree about the gather root, the ranks' list entries.
-        // Every input is globally gathered, so every rank posts the same verdict and takes the same decisions.
         __threadfence();
-        if (atomicAdd(ticket, 1u) == gridDim.x - 1u) {
-            const uint32_t total = __hip_atomic_load(d_need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t* hv = reinterpret_cast<uint32_t*>(host_verdict);
-            uint32_t gmax = 0, over = 0, root_bad = 0, ent_sum = 0, ent_max = 0;
-            const uint32_t root0 = sat[2], flags0 = sat[6];
-            for (uint32_t g = 0; g < world; ++g) {
-                const uint32_t* x = sat + (size_t)g * stride;
-                gmax = max(gmax, x[0]);
-                over |= x[1];
-                root_bad |= x[2] != root0 ? 1u : 0u;
-                root_bad |= x[6] != flags0 ? 2u : 0u;  // (bit 1: the ranks size their slots / bands by different policies)
-                ent_sum += x[3];
-                ent_max = max(ent_max, x[3]);
-                for (uint32_t d = 0; d < world; ++d) hv[kVerdictMatrix + g * world + d] = x[8u + d];
-            }
-            hv[4] = root_bad;
-            hv[5] = ent_sum;
-            hv[6] = ent_max;
-            {   // how evenly THIS frame's bands shared the work: busiest rank x world x 1000 / all
-                unsigned long long all = 0, busiest = 0;
-                for (uint32_t g = 0; g < world; ++g) {
-                    unsigned long long wg = 0;
-                    for (uint32_t ty = bands.e[g]; ty < bands.e[g + 1u] && ty < n_tiles / tiles_x; ++ty) wg += work_at(sat, ty, tiles_x, bands, stride);
-                    all += wg;
-                    busiest = wg > busiest ? wg : busiest;
-                }
-                hv[7] = all ? (uint32_t)(busiest * world * 1000ull / all) : 1000u;
-            }
-            // next frame's bands: contiguous runs of tile rows of (as nearly as rows allow) equal work.  A row weighs what its tiles
-            // cost this frame (tile_work, gsx_internal.h) plus kTileWork for every tile (the ones that were not composited at all).
-            const uint32_t tiles_y = n_tiles / tiles_x;
-            // Hysteresis: an edge that moves shifts what every pair exchanges (the slots sized pair by pair from this frame's counts
-            // would overflow for nothing), and bands a few rows tall cannot be tuned finer than a row.  New edges are adopted only
-            // when the busiest rank carries more than kBalanceKeep x the mean AND they would have shared THIS frame's work at
-            // least a tenth better.
-            uint32_t* ne = hv + kVerdictEdges;
-            bool adopt = false;
-            if (balance && hv[7] > kBalanceKeepPermille) {
-                unsigned long long W = 0;
-                for (uint32_t ty = 0; ty < tiles_y; ++ty) W += (unsigned long long)work_at(sat, ty, tiles_x, bands, stride) + (unsigned long long)kTileWork * tiles_x;
-                unsigned long long acc = 0, band_w = 0, worst = 0;
-                uint32_t g = 1;
-                ne[0] = 0u;
-                for (uint32_t ty = 0; ty < tiles_y; ++ty) {
-                    const unsigned long long w = (unsigned long long)work_at(sat, ty, tiles_x, bands, stride) + (unsigned long long)kTileWork * tiles_x;
-                    // edge g goes in front of row ty if that is at least as close to g / world of the work as behind it
-                    while (g < world && (acc * world >= g * W || 2ull * (g * W - acc * world) <= w * world)) {
-                        ne[g++] = ty;
-                        worst = band_w > worst ? band_w : worst;
-                        band_w = 0;
-                    }
-                    acc += w;
-                    band_w += w;
-                }
-                worst = band_w > worst ? band_w : worst;
-                while (g < world) ne[g++] = tiles_y;
-                ne[world] = tiles_y;
-                // the same measure for the bands in force (rows' weights as above)
-                unsigned long long cur_worst = 0;
-                for (uint32_t gg = 0; gg < world; ++gg) {
-                    unsigned long long wg = 0;
-                    for (uint32_t ty = bands.e[gg]; ty < bands.e[gg + 1u] && ty < tiles_y; ++ty)
-                        wg += (unsigned long long)work_at(sat, ty, tiles_x, bands, stride) + (unsigned long long)kTileWork * tiles_x;
-                    cur_worst = wg > cur_worst ? wg : cur_worst;
-                }
-                adopt = worst * 10ull <= cur_worst * 9ull;
-            }
-            if (!adopt)
-                for (uint32_t g = 0; g <= world; ++g) ne[g] = bands.e[g];
-            __hip_atomic_store(host_verdict + 1, ((unsigned long long)gmax << 32) | (over ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(host_verdict, ((unsigned long long)seq << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            *ticket = 0;
+        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // The last block posts the verdict of round 0 (layout: gsx_internal.h, kVerdict*):
+    //   word 1 = {largest per-destination record count over all ranks | any rank's slot overflowed}
+    //   word 0 = {seq | tiles that need the repair round}     (release store: a host that waits polls this one)
+    //   and behind them: the count matrix (slot sizes of the next frame, pair by pair), the band edges of the next frame
+    //   (balanced by the rows' work), whether the ranks agree about the gather root and the slot policy, the ranks' list entries.
+    // Every input is globally gathered, so every rank posts the same verdict and takes the same decisions.  All 256 threads fetch —
+    // the rows' work into LDS, the matrix straight through — and one thread does the arithmetic on what they fetched (round 5: the
+    // one thread walking ~200 dependent loads was 16 us on the critical path of every sharded frame).
+    uint32_t* hv = reinterpret_cast<uint32_t*>(host_verdict);
+    const uint32_t tiles_y = n_tiles / tiles_x;
+    for (uint32_t ty = threadIdx.x; ty < min(tiles_y, 1024u); ty += 256u) s_work[ty] = work_at(sat, ty, tiles_x, bands, stride);
+    for (uint32_t k = threadIdx.x; k < world * world; k += 256u) hv[kVerdictMatrix + k] = sat[(size_t)(k / world) * stride + 8u + k % world];
+    __threadfence_system();  // (the matrix may go to pinned host memory: visible before the word a host polls)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        auto work = [&](uint32_t ty) -> uint32_t { return ty < 1024u ? s_work[ty] : work_at(sat, ty, tiles_x, bands, stride); };
+        const uint32_t total = __hip_atomic_load(d_need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t gmax = 0, over = 0, root_bad = 0, ent_sum = 0, ent_max = 0;
+        const uint32_t root0 = sat[2], flags0 = sat[6];
+        for (uint32_t g = 0; g < world; ++g) {
+            const uint32_t* x = sat + (size_t)g * stride;
+            gmax = max(gmax, x[0]);
+            over |= x[1];
+            root_bad |= x[2] != root0 ? 1u : 0u;
+            root_bad |= x[6] != flags0 ? 2u : 0u;  // (bit 1: the ranks size their slots / bands by different policies)
+            ent_sum += x[3];
+            ent_max = max(ent_max, x[3]);
         }
+        hv[4] = root_bad;
+        hv[5] = ent_sum;
+        hv[6] = ent_max;
+        {   // how evenly THIS frame's bands shared the work: busiest rank x world x 1000 / all
+            unsigned long long all = 0, busiest = 0;
+            for (uint32_t g = 0; g < world; ++g) {
+                unsigned long long wg = 0;
+                for (uint32_t ty = bands.e[g]; ty < bands.e[g + 1u] && ty < tiles_y; ++ty) wg += work(ty);
+                all += wg;
+                busiest = wg > busiest ? wg : busiest;
+            }
+            hv[7] = all ? (uint32_t)(busiest * world * 1000ull / all) : 1000u;
+        }
+        // next frame's bands: contiguous runs of tile rows of (as nearly as rows allow) equal work.  A row weighs what its tiles
+        // cost this frame (tile_work, gsx_internal.h) plus kTileWork for every tile (the ones that were not composited at all).
+        // Hysteresis: an edge that moves shifts what every pair exchanges (the slots sized pair by pair from this frame's counts
+        // would overflow for nothing), and bands a few rows tall cannot be tuned finer than a row.  New edges are adopted only
+        // when the busiest rank carries more than kBalanceKeep x the mean AND they would have shared THIS frame's work at
+        // least a tenth better.
+        uint32_t* ne = hv + kVerdictEdges;
+        bool adopt = false;
+        if (balance && hv[7] > kBalanceKeepPermille) {
+            unsigned long long W = 0;
+            for (uint32_t ty = 0; ty < tiles_y; ++ty) W += (unsigned long long)work(ty) + (unsigned long long)kTileWork * tiles_x;
+            unsigned long long acc = 0, band_w = 0, worst = 0;
+            uint32_t g = 1;
+            ne[0] = 0u;
+            for (uint32_t ty = 0; ty < tiles_y; ++ty) {
+                const unsigned long long w = (unsigned long long)work(ty) + (unsigned long long)kTileWork * tiles_x;
+                // edge g goes in front of row ty if that is at least as close to g / world of the work as behind it
+                while (g < world && (acc * world >= g * W || 2ull * (g * W - acc * world) <= w * world)) {
+                    ne[g++] = ty;
+                    worst = band_w > worst ? band_w : worst;
+                    band_w = 0;
+                }
+                acc += w;
+                band_w += w;
+            }
+            worst = band_w > worst ? band_w : worst;
+            while (g < world) ne[g++] = tiles_y;
+            ne[world] = tiles_y;
+            // the same measure for the bands in force (rows' weights as above)
+            unsigned long long cur_worst = 0;
+            for (uint32_t gg = 0; gg < world; ++gg) {
+                unsigned long long wg = 0;
+                for (uint32_t ty = bands.e[gg]; ty < bands.e[gg + 1u] && ty < tiles_y; ++ty)
+                    wg += (unsigned long long)work(ty) + (unsigned long long)kTileWork * tiles_x;
+                cur_worst = wg > cur_worst ? wg : cur_worst;
+            }
+            adopt = worst * 10ull <= cur_worst * 9ull;
+        }
+        if (!adopt)
+            for (uint32_t g = 0; g <= world; ++g) ne[g] = bands.e[g];
+        __hip_atomic_store(host_verdict + 1, ((unsigned long long)gmax << 32) | (over ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_verdict, ((unsigned long long)seq << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        *ticket = 0;
     }
 }
-
-__device__ inline unsigned long long need_of_staged(const uint32_t* __restrict__ staged) { return (unsigned long long)staged[0]; }  // low half of word 0
 
 // Sizing the repair exchange: counts_all = per rank {records it has for its busiest destination, 0, 0, 0} (all-gathered);
 // the global maximum goes to the host — the exact slot size of the repair round, the same on every rank.
@@ -511,6 +524,8 @@ __global__ __launch_bounds__(64) void k_shard_max_count(const uint32_t* __restri
 // (parallel.next_limits is the numpy statement of the same policy).  Outside the frame counts as nothing.
 // win_next (nullable): also the next frame's round-0 windows [0, limit) (saves that frame a launch); staged / host_block (nullable): block 0
 // posts the frame's verdict on its way (post_verdict_body: what k_shard_post_verdict does as a launch of its own)
+__device__ inline unsigned long long need_of_staged(const uint32_t* __restrict__ staged) { return (unsigned long long)staged[0]; }  // low half of word 0
+
 __device__ inline void post_verdict_body(const uint32_t* __restrict__ staged, const uint32_t* __restrict__ sat, uint32_t world, uint32_t stride,
                                          uint32_t* __restrict__ host_block, uint32_t seq) {
     const uint32_t n = kVerdictMatrix + world * world;
@@ -545,17 +560,37 @@ __global__ __launch_bounds__(256) void k_shard_next_limits(const uint32_t* __res
                                                             uint2* __restrict__ win_next, const uint32_t* __restrict__ staged,
                                                             const uint32_t* __restrict__ sat_verdict, uint32_t* __restrict__ host_block, uint32_t seq) {
     if (host_block && blockIdx.x == 0) post_verdict_body(staged, sat_verdict, bands.world, stride, host_block, seq);
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    // where the tile rows this workgroup's neighbourhoods reach lie in the gathered pieces: one lookup per row instead of a walk over
+    // the band edges per load (49 loads per tile at radius 3: the walk was most of the kernel's 14 us)
+    __shared__ uint32_t s_row[48];
+    const uint32_t t0 = blockIdx.x * 256u, row0 = t0 / tiles_x;
+    const int first = max((int)row0 - radius, 0);
+    if (threadIdx.x < 48u) {
+        const uint32_t y = (uint32_t)first + threadIdx.x;
+        uint32_t base = 0;
+        if (y < tiles_y) {
+            const uint32_t g = band_of(bands, y);
+            base = g * stride + kShardExtraWords + (y - bands.e[g]) * tiles_x;
+        }
+        s_row[threadIdx.x] = base;
+    }
+    __syncthreads();
+    const uint32_t t = t0 + threadIdx.x;
     if (t >= tiles_x * tiles_y) return;
     const int tx = (int)(t % tiles_x), ty = (int)(t / tiles_x);
     float deepest = 0.0f;
     bool open = false;
-    for (int y = max(ty - radius, 0); y <= min(ty + radius, (int)tiles_y - 1); ++y)
+    for (int y = max(ty - radius, 0); y <= min(ty + radius, (int)tiles_y - 1); ++y) {
+        // (a workgroup's 256 tiles span at most 256 / tiles_x + 2 rows; with the radius on both sides that fits the table for every grid
+        //  of at least 8 tiles a row — narrower frames take the walk)
+        const uint32_t k = (uint32_t)(y - first);
+        const uint32_t base = k < 48u ? s_row[k] : band_of(bands, (uint32_t)y) * stride + kShardExtraWords + ((uint32_t)y - bands.e[band_of(bands, (uint32_t)y)]) * tiles_x;
         for (int x = max(tx - radius, 0); x <= min(tx + radius, (int)tiles_x - 1); ++x) {
-            const uint32_t s = sat_at(sat, (uint32_t)x, (uint32_t)y, tiles_x, bands, stride);
+            const uint32_t s = sat[base + (uint32_t)x];
             if (s == 0u) open = true;
             else deepest = fmaxf(deepest, __uint_as_float(s));
         }
+    }
     uint32_t out = 0xFFFFFFFFu;
     if (!open) {
         const float lim = deepest * gain;
@@ -595,10 +630,10 @@ hipError_t launch_shard_verify(hipStream_t s, const uint32_t* limit, const uint3
 
 hipError_t launch_shard_feedback(hipStream_t s, const uint32_t* tile_sat, const uint32_t* row_work, uint32_t tiles_x, uint32_t tiles_y, const BandEdges& bands,
                                  uint32_t rank, uint32_t* out, const SlabStats* stats, const uint32_t* done_before, uint32_t row_words, uint32_t gather_root_plus1,
-                                 uint32_t policy_flags) {
+                                 uint32_t policy_flags, uint32_t* za, uint32_t nza, uint32_t* zb, uint32_t nzb) {
     const uint32_t rows = bands.e[rank + 1u] - bands.e[rank], n = feedback_words(bands, tiles_x, rank);
     GSX_LAUNCH(k_shard_feedback, dim3((n + 255) / 256), dim3(256), 0, s, tile_sat, row_work, tiles_x, tiles_y, bands.e[rank], rows, out, stats, done_before,
-               row_words, gather_root_plus1, policy_flags);
+               row_words, gather_root_plus1, policy_flags, za, nza, zb, nzb);
     return hipGetLastError();
 }
 
