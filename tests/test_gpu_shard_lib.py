@@ -739,7 +739,9 @@ def _open_sky_scene(n=30000):
 
 
 def test_bands_are_balanced_by_the_previous_frames_work():
-    world, size = 8, (640, 480)           # 40 x 30 tiles
+    # 40 x 60 tiles (round 5: a rank's blocks are sized for its band — finer lists, a sharper per-row work figure — and at 30 rows one
+    # row alone weighed 1.46 x an eighth of the frame: bands are whole rows)
+    world, size = 8, (640, 960)
     g = _open_sky_scene()
     poses = (10, 11, 12, 13, 14, 15, 16, 130, 131, 132)   # (a jump: the work moves, the edges follow)
     ref = _single_frames(g, poses, size)
@@ -763,9 +765,9 @@ def test_bands_are_balanced_by_the_previous_frames_work():
         for k in range(len(poses)):
             assert np.array_equal(edges[k], res[0][1][k]), "every rank derives the same edges"
     edges = res[0][1]
-    assert np.array_equal(edges[0], np.arange(world + 1) * 4), "first frame: equal bands (nothing is known yet)"
+    assert np.array_equal(edges[0], np.arange(world + 1) * 8), "first frame: equal bands (nothing is known yet)"
     assert any(not np.array_equal(edges[k], edges[k + 1]) for k in range(1, len(poses) - 1)), "the edges move with the work"
-    assert edges[-1][1] > 4, f"the empty sky must go to few ranks: {edges[-1]}"
+    assert edges[-1][1] > 8, f"the empty sky must go to few ranks: {edges[-1]}"
     stats = res[0][2]
     work = [st["last_work_permille"] / 1000.0 for st in stats]            # busiest rank's walked entries / mean, frame by frame
     entries = [st["last_entries_max"] * world / max(st["last_entries_sum"], 1) for st in stats]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where a frame's time goes between its kernels, from a rocprofv3 --kernel-trace CSV: the frames are cut at the projection
 kernel, and for the last <frames> of them the kernel time, the gaps between consecutive kernels (end -> next start) and the gap
-after each kernel (by kernel name) are averaged.  usage: kernel_gaps.py <dir> <frames> [project-kernel substring] [timeline]"""
+after each kernel (by kernel name) are averaged.  usage: kernel_gaps.py <dir> <frames> [project-kernel substring] [timeline [cuts]]"""
 import collections
 import csv
 import glob
@@ -30,7 +30,7 @@ print(f"{nf} frames: {span:.1f} us per frame = {busy / nf:.1f} us in kernels + {
 for name, v in sorted(after.items(), key=lambda kv: -sum(kv[1]))[:14]:
     print(f"  after {name:46s} {sum(v) / nf:7.1f} us per frame  ({len(v) / nf:4.1f} x {sum(v) / len(v):6.2f} us)")
 if len(sys.argv) > 4 and sys.argv[4] == "timeline":   # the last whole frame, kernel by kernel: start offset, duration, gap to the next
-    a, b = starts[-2], starts[-1]
+    a, b = starts[-1 - (int(sys.argv[5]) if len(sys.argv) > 5 else 1)], starts[-1]
     t0 = rows[a][0]
     for i in range(a, b):
         s, e, name = rows[i]

@@ -209,6 +209,7 @@ CFG5_TRS = {"a": camera.ModelTransform(pos=np.array([0.0, 0.0, 2.5], np.float32)
 WORKLOAD = "cfg4"
 PYTHON_REPLAY = False
 PASS_REPLAY = True
+MARGIN, RADIUS = 0.25, 3
 
 
 def make_viewer(cfg, rank, world, open_sky, lanes=1):
@@ -236,7 +237,7 @@ def make_viewer(cfg, rank, world, open_sky, lanes=1):
         def frame(i, speculate, sharded=True):
             v.update_camera(orbit[i % 240], (w, h))
             if sharded:
-                v.shard_render_frame_keys(keys_of[i % 240], shard_max, speculate=bool(speculate))
+                v.shard_render_frame_keys(keys_of[i % 240], shard_max, speculate=bool(speculate), margin=MARGIN, radius=RADIUS)
             else:
                 v.render_frame(keys_of[i % 240])
     else:
@@ -254,7 +255,7 @@ def make_viewer(cfg, rank, world, open_sky, lanes=1):
         def frame(i, speculate, sharded=True):
             v.update_camera(orbit[i % 240], (w, h))
             if sharded:
-                v.shard_render_frame("m", shard_max, speculate=bool(speculate))
+                v.shard_render_frame("m", shard_max, speculate=bool(speculate), margin=MARGIN, radius=RADIUS)
             else:
                 v.render_frame(["m"])
     v.update_gaussian_transform(1.0, GaussianDisplayMode.Splat, GaussianShDegree.new(sh), False)
@@ -412,14 +413,17 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--balance", type=int, default=1, help="0: equal bands of tile rows (gsx_shard_set_balance(0)) — the A/B of the balanced bands")
     ap.add_argument("--speculate", default="1,0", help="which schedules to run")
+    ap.add_argument("--margin", type=float, default=0.25, help="gsx_shard_render_frame's margin (the speculated schedule)")
+    ap.add_argument("--radius", type=int, default=3)
     ap.add_argument("--no-pass-replay", action="store_true", help="skip the second replay with the passes bracketed by events (for a kernel trace whose tail is the timed replay)")
     ap.add_argument("--python-replay", action="store_true", help="serve the replay from Python callbacks (rounds 4's transport: the A/B of the native one)")
     a = ap.parse_args()
-    global BALANCE, WORKLOAD, PYTHON_REPLAY, ORBIT, KEYS_OF, PASS_REPLAY
+    global BALANCE, WORKLOAD, PYTHON_REPLAY, ORBIT, KEYS_OF, PASS_REPLAY, MARGIN, RADIUS
     BALANCE = bool(a.balance)
     WORKLOAD = a.workload
     PYTHON_REPLAY = a.python_replay
     PASS_REPLAY = not a.no_pass_replay
+    MARGIN, RADIUS = a.margin, a.radius
     specs = [int(x) for x in a.speculate.split(",")]
     cfg = scene.CONFIGS[a.workload]
     n, sh, w, h, seed = cfg
@@ -433,7 +437,7 @@ def main():
                       "N-rank run (threads, one GPU); predicted fps = 1 / (slowest rank's ms alone + busiest rank's wire bytes / (7 x 153 GB/s)); "
                       + ("the replay transport's callbacks are Python (--python-replay)" if a.python_replay else
                          "the replay transport is native code (tools/replay_transport.cpp): no Python inside the timed rank"),
-               balanced_bands=bool(a.balance), single_gpu_fps={}, runs=[])
+               balanced_bands=bool(a.balance), margin=a.margin, radius=a.radius, single_gpu_fps={}, runs=[])
     lanes_list = [int(x) for x in a.lanes.split(",")]
     for sc in a.scenes.split(","):
         for spec in specs:

@@ -63,7 +63,7 @@ gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, const 
     if ((st = check_bands(v, world, "gsx_shard_pack"))) return st;
     const uint32_t n = (uint32_t)m->n;
     const bool from_list = !d_tile_window && m->shard_win_set && m->cand_valid;
-    const uint32_t rounds = pack_rounds(from_list), tile = 256u * rounds;
+    const uint32_t rounds = pack_rounds(from_list, n), tile = 256u * rounds;
     const uint32_t nb = (uint32_t)pack_blocks(n, rounds);
     const BandEdges bands = bands_of(v, world);
     const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE;
@@ -102,7 +102,7 @@ gsx_status gsx_shard_pack(gsx_viewer* v, const char* key, uint32_t world, const 
         // shade the travellers the first round did not: compact their indices, k_shade skips what is shaded already
         HIPCHK(m->adm_pairs.ensure(8 * std::max<size_t>(n, 1)));
         HIPCHK(launch_rowscan(v->stream, trav_counts, 1, nb, &dc->n_sorted2));
-        HIPCHK(launch_admit_scatter(v->stream, m->proj_rec().key, n, travellers, trav_counts, m->adm_pairs.as<uint2>()));
+        HIPCHK(launch_admit_scatter(v->stream, m->proj_rec().key, n, travellers, trav_counts, m->adm_pairs.as<uint2>(), nullptr, nullptr, rounds));
         if ((st = shade_admitted(v, m, LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>(), m->rect8_active}))) return st;
         m->cand_valid = false;  // adm_pairs now holds the repair travellers
     }
@@ -171,6 +171,7 @@ gsx_status gsx_shard_import(gsx_viewer* v, const char* key, const void* d_recv, 
         const BandEdges b = bands_of(v, world);
         m->row_lo = b.e[rank];
         m->row_hi = b.e[rank + 1];
+        m->rows_nominal = (((v->height + GSX_TILE - 1) / GSX_TILE) + world - 1u) / world;
     }
     m->has_window = d_tile_window != nullptr;
     m->window_ptr = nullptr;
@@ -275,7 +276,7 @@ gsx_status pack_count(gsx_viewer* v, Model* m, uint32_t world, const uint2* expl
                       const uint32_t* d_skip = nullptr) {
     const uint32_t n = (uint32_t)m->n;
     m->pack_list = !explicit_window && m->shard_win_set && m->cand_valid;
-    m->pack_rounds = pack_rounds(m->pack_list);
+    m->pack_rounds = pack_rounds(m->pack_list, n);
     const uint32_t nb = (uint32_t)pack_blocks(n, m->pack_rounds);
     const uint32_t tiles_x = (v->width + GSX_TILE - 1) / GSX_TILE;
     HIPCHK(m->pack_table.ensure(4 * ((size_t)64 * std::max(nb, 1u) + 64)));
@@ -325,7 +326,7 @@ gsx_status pack_write(gsx_viewer* v, Model* m, uint32_t world, void* d_send, con
         HIPCHK(m->adm_pairs.ensure(8 * std::max<size_t>(n, 1)));
         // (the scatter sums the raw per-workgroup counts itself and leaves the total: no scan launch in between)
         HIPCHK(launch_admit_scatter(v->stream, m->proj_rec().key, n, m->trav_ballots.as<unsigned long long>(), m->trav_counts.as<uint32_t>(),
-                                    m->adm_pairs.as<uint2>(), d_skip, &dc->n_sorted2));
+                                    m->adm_pairs.as<uint2>(), d_skip, &dc->n_sorted2, m->pack_rounds));
         gsx_status sst = shade_admitted(v, m, LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>(), m->rect8_active});
         if (sst) return sst;
         m->cand_valid = false;
@@ -520,6 +521,7 @@ gsx_status gsx::shard_import_slots(gsx_viewer* v, const char* key, const void* d
         const BandEdges b = bands_of(v, world);
         m->row_lo = b.e[rank];
         m->row_hi = b.e[rank + 1];
+        m->rows_nominal = (((v->height + GSX_TILE - 1) / GSX_TILE) + world - 1u) / world;
     }
     // the receiving side of the pack predicate: a tile bins exactly the records its window admits
     const uint2* win = round == 0 ? (m->shard_frame_limited ? m->shard_win.as<uint2>() : nullptr) : m->shard_win2.as<uint2>();

@@ -364,6 +364,7 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
     m->rec_n = m->n;
     m->row_lo = m->fc.band_lo;
     m->row_hi = m->fc.band_hi;
+    m->rows_nominal = 0;
     // selection edit / stored edits / highlight: only when something of the kind exists (spec §7)
     const uint32_t n32 = (uint32_t)m->n;
     const size_t words = ((size_t)m->n + 31) / 32;
@@ -727,7 +728,12 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
     // most blocks of this frame: GSX_BLOCKS_MAX when it was given, otherwise 256 (one 8-bit sort pass) — or 1024 while some tile's walk is long
     const uint32_t blocks_max = v->blocks_adaptive && m->blocks_fine ? 1024u : v->blocks_max;
     if (blocks) {
-        auto count = [&]() { return (uint64_t)((m->fc.tiles_x + (1u << bsx) - 1u) >> bsx) * ((m->fc.tiles_y + (1u << bsy) - 1u) >> bsy); };
+        // The grid covers the rows this viewer composites (block_grid).  An index-sharded rank sizes its blocks for the taller of its
+        // own band and an EQUAL band: every rank whose band is no taller than that bins by the same block size, so what a tile row
+        // costs — the figure the next frame's bands are balanced by — does not change with the band it happens to lie in (sized by
+        // the own band alone, a row was cheaper in a short band than in a tall one and the balance settled at 1.46 x the mean).
+        const uint32_t grid_rows = std::max(row_hi > row_lo ? row_hi - row_lo : 1u, m->use_imported ? m->rows_nominal : 0u);
+        auto count = [&]() { const BlockGrid g = block_grid(bsx, bsy, m->fc.tiles_x, 0, grid_rows); return (uint64_t)g.blocks_x * g.blocks_y; };
         while (count() > blocks_max) (bsx <= bsy ? bsx : bsy) += 1;
         HIPCHK(m->block_table.ensure(sizeof(uint4) * 1024));
         if (v->tile_profile) HIPCHK(v->tile_prof.ensure(sizeof(uint4) * (size_t)n_tiles));
@@ -834,7 +840,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
             HIPCHK(v->scratch.ensure(64));
             HIPCHK(gsx::op::MemsetAsync(v->scratch.p, 0, 64, v->stream));
             // (block lists: one range per block, list values are positions in the slab)
-            const uint32_t n_ranges = blocks ? ((m->fc.tiles_x + (1u << bsx) - 1u) >> bsx) * ((m->fc.tiles_y + (1u << bsy) - 1u) >> bsy) : n_tiles;
+            const uint32_t n_ranges = blocks ? block_grid(bsx, bsy, m->fc.tiles_x, row_lo, row_hi).blocks_x * block_grid(bsx, bsy, m->fc.tiles_x, row_lo, row_hi).blocks_y : n_tiles;
             HIPCHK(launch_validate_tiles(v->stream, m->ranges.as<uint2>(), n_ranges, m->tile_list, &dc->n_entries, blocks ? cap : slab_cap,
                                          blocks ? j1 - j0 : (uint32_t)m->rec_n, v->scratch.as<uint32_t>()));
             uint32_t rep[8];
@@ -939,7 +945,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
             // round's conservative admission test: four loads per record; an exact per-tile scan of every visible record cost
             // 260-350 us here) and the repair slab's block table
             HIPCHK(m->spec_coarse2.ensure(4 * window_pyramid_words(m->fc.tiles_x, m->fc.tiles_y)));
-            const BlockGrid grid{bsx, bsy, (m->fc.tiles_x + (1u << bsx) - 1u) >> bsx, (m->fc.tiles_y + (1u << bsy) - 1u) >> bsy};
+            const BlockGrid grid = block_grid(bsx, bsy, m->fc.tiles_x, row_lo, row_hi);
             HIPCHK(launch_spec_verify(v->stream, m->spec_win.as<uint2>(), done, row_words, m->fc.tiles_x, m->fc.tiles_y,
                                       m->spec_win2.as<uint2>(), m->spec_need.as<uint32_t>(), &dc->spec_need, row_lo, row_hi,
                                       post ? v->h_verdict : nullptr, seq, m->spec_coarse2.as<uint32_t>(), blocks ? &grid : nullptr,

@@ -383,11 +383,18 @@ __device__ __forceinline__ void tile_order_job(uint32_t* __restrict__ order_buf,
 }
 #endif
 
-// Block lists (kernels_bin.hip): the screen's tiles in at most 256 blocks of 2^bsx x 2^bsy tiles.
+// Block lists (kernels_bin.hip): the tile rows [row_lo, row_hi) a viewer composites — the whole screen, or the band of a multi-GPU
+// rank — in at most 256 blocks of 2^bsx x 2^bsy tiles.  Block rows count from row_lo: a rank that owns an eighth of the rows gets
+// blocks an eighth the size for the same one-pass block sort, and its tiles walk lists that much shorter (round 5: until then the
+// grid covered the screen whoever owned it, and a world-8 rank's 1020 tiles shared 32 lists).
 struct BlockGrid {
     uint32_t bsx, bsy;       // log2 of the block size in tiles
     uint32_t blocks_x, blocks_y;
 };
+inline BlockGrid block_grid(uint32_t bsx, uint32_t bsy, uint32_t tiles_x, uint32_t row_lo, uint32_t row_hi) {
+    const uint32_t rows = row_hi > row_lo ? row_hi - row_lo : 1u;
+    return BlockGrid{bsx, bsy, (tiles_x + (1u << bsx) - 1u) >> bsx, (rows + (1u << bsy) - 1u) >> bsy};
+}
 #ifdef __HIPCC__
 // One WAVE computes table[b] = {min window start, max window end (of the non-empty windows of the block's live tiles), live} and
 // zeroes ranges[b]; a lane per tile.  done (nullable): saturated tiles are not live; win (nullable): no windows = takes every key.
@@ -397,7 +404,7 @@ __device__ inline void wave_block_table_entry(const BlockGrid& g, uint32_t b, ui
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t bx = b % g.blocks_x, by = b / g.blocks_x;
     const uint32_t x0 = bx << g.bsx, x1 = min(x0 + (1u << g.bsx), tiles_x);
-    const uint32_t y0 = max(by << g.bsy, row_lo), y1 = min(min((by + 1u) << g.bsy, tiles_y), row_hi);
+    const uint32_t y0 = row_lo + (by << g.bsy), y1 = min(min(row_lo + ((by + 1u) << g.bsy), tiles_y), row_hi);
     uint32_t lo = 0xFFFFFFFFu, hi = 0u, live = 0u;
     const uint32_t w = x1 - x0, total = y1 > y0 ? w * (y1 - y0) : 0u;
     for (uint32_t k = lane; k < total; k += 64) {
@@ -502,11 +509,12 @@ hipError_t launch_admit_from_project(hipStream_t s, const uint32_t* key, uint32_
 // windows are [0, hi) and admission is CONSERVATIVE — every record some tile admits is admitted, plus a few more; the
 // binning applies the exact per-tile windows, so the surplus only rides through the depth sort.
 size_t admit_blocks(uint64_t n);
-// compaction from ballots over 4096-record workgroups (offsets = exclusively scanned per-workgroup counts)
+// compaction from ballots over workgroups of 256 x rounds records (rounds = 16, or 4: the tile of the pass that counted — pack_rounds)
+// (offsets = exclusively scanned per-workgroup counts)
 // d_total != nullptr: `offsets` holds the RAW per-workgroup counts — every workgroup sums the ones in front of it itself and the last
 // writes the total (no scan launch in between)
 hipError_t launch_admit_scatter(hipStream_t s, const uint32_t* key, uint32_t n, const unsigned long long* ballots,
-                                const uint32_t* offsets, uint2* pairs, const uint32_t* d_skip = nullptr, uint32_t* d_total = nullptr);
+                                const uint32_t* offsets, uint2* pairs, const uint32_t* d_skip = nullptr, uint32_t* d_total = nullptr, uint32_t rounds = 16);
 // (rec.rect8 != nullptr: rectangles are read from the packed plane)
 hipError_t launch_admit(hipStream_t s, const Records& rec, uint32_t n, const uint2* window, uint32_t tiles_x,
                         const uint32_t* gate, uint32_t row_words, const WindowPyramid& pyramid, const uint32_t* d_skip, unsigned long long* ballots, uint32_t* counts, uint32_t* d_total, uint2* pairs);
@@ -531,7 +539,7 @@ hipError_t launch_spin(hipStream_t s, uint32_t microseconds);  // one wave that 
 hipError_t launch_rowscan(hipStream_t s, uint32_t* table, uint32_t nrows, uint32_t nblocks, uint32_t* totals, const uint32_t* d_n = nullptr,
                           uint32_t tile = 1, const uint32_t* d_skip = nullptr /* points at 0: the totals are 0, nothing is read */);
 size_t pack_blocks(uint64_t n, uint32_t rounds);  // workgroups of a pack pass whose tiles hold 256 x rounds records
-uint32_t pack_rounds(bool candidate_list);
+uint32_t pack_rounds(bool candidate_list, uint64_t n);  // 2 (a candidate list), 4 (a whole shard of <= 2 M records), 16
 // bands: rank g owns the tile rows [bands.e[g], bands.e[g + 1]).  A record travels to g if its rectangle touches g's band and some
 // tile of it there has the record's key inside its window.
 // window: uint2 [lo, hi) depth-key window per tile (tiles_y * tiles_x, row-major) or nullptr = every tile takes everything.

@@ -150,6 +150,7 @@ struct Model {
     // other ranks (gsx_shard_import); binning is restricted to the band of tile rows [row_lo, row_hi)
     uint64_t rec_n = 0, rec_cap = 0;
     uint32_t row_lo = 0, row_hi = 0xFFFFFFFFu;  // band of tile rows this viewer bins (clamped to tiles_y)
+    uint32_t rows_nominal = 0;  // index-sharded frames: the height of an equal band, ceil(tiles_y / world) — the block size is chosen for max(own rows, this)
     DevBuf pack_table;
     // selection / edits / query (kernels_edit.hip); all allocated on first use
     DevBuf selection, edited, edit_a, edit_b, keep, query_flags, hits, hit_count;

@@ -68,6 +68,7 @@ __global__ __launch_bounds__(kAdmitThreads) void k_admit_count(const uint32_t* _
 // (d_total == nullptr), or — d_total != nullptr — the RAW counts: every workgroup sums the counts in front of it itself (a few
 // thousand L2-resident words at most) and the last one writes the total: the single-workgroup scan in between was a launch of
 // its own on the critical path of every speculated frame's repair round.
+template <int kRounds /* 256 x kRounds records per workgroup: the tile of the pass that wrote the ballots and the counts */>
 __global__ __launch_bounds__(kAdmitThreads) void k_admit_scatter(const uint32_t* __restrict__ key, uint32_t n,
                                                                   const unsigned long long* __restrict__ ballots,
                                                                   const uint32_t* __restrict__ offsets,
@@ -93,16 +94,16 @@ __global__ __launch_bounds__(kAdmitThreads) void k_admit_scatter(const uint32_t*
     } else {
         before = offsets[blockIdx.x];
     }
-    const uint32_t base = blockIdx.x * kAdmitTile + wave * kAdmitWaveChunk;
+    const uint32_t base = blockIdx.x * (kAdmitThreads * kRounds) + wave * (64 * kRounds);
     uint32_t c = 0;
-    for (int r = 0; r < kAdmitRounds; ++r)
+    for (int r = 0; r < kRounds; ++r)
         if (base + r * 64 < n) c += (uint32_t)__popcll(ballots[(base + r * 64) >> 6]);
     if (lane == 0) wcnt[wave] = c;
     __syncthreads();
     uint32_t o = before;
     for (uint32_t w = 0; w < wave; ++w) o += wcnt[w];
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int r = 0; r < kAdmitRounds; ++r) {
+    for (int r = 0; r < kRounds; ++r) {
         const uint32_t e0 = base + r * 64;
         if (e0 >= n) break;
         const unsigned long long bal = ballots[e0 >> 6];
@@ -255,9 +256,14 @@ hipError_t launch_admit_from_project(hipStream_t s, const uint32_t* key, uint32_
 }
 
 hipError_t launch_admit_scatter(hipStream_t s, const uint32_t* key, uint32_t n, const unsigned long long* ballots,
-                                const uint32_t* offsets, uint2* pairs, const uint32_t* d_skip, uint32_t* d_total) {
+                                const uint32_t* offsets, uint2* pairs, const uint32_t* d_skip, uint32_t* d_total, uint32_t rounds) {
+    if (rounds == 4u) {
+        const uint32_t nb = (uint32_t)((n + 1023u) / 1024u);
+        if (nb) GSX_LAUNCH(k_admit_scatter<4>, dim3(nb), dim3(kAdmitThreads), 0, s, key, n, ballots, offsets, pairs, d_skip, d_total);
+        return hipGetLastError();
+    }
     const uint32_t nb = (uint32_t)admit_blocks(n);
-    if (nb) GSX_LAUNCH(k_admit_scatter, dim3(nb), dim3(kAdmitThreads), 0, s, key, n, ballots, offsets, pairs, d_skip, d_total);
+    if (nb) GSX_LAUNCH(k_admit_scatter<kAdmitRounds>, dim3(nb), dim3(kAdmitThreads), 0, s, key, n, ballots, offsets, pairs, d_skip, d_total);
     return hipGetLastError();
 }
 
@@ -266,7 +272,7 @@ hipError_t launch_admit(hipStream_t s, const Records& rec, uint32_t n, const uin
     const uint32_t nb = (uint32_t)admit_blocks(n);
     if (!nb) return gsx::op::MemsetAsync(d_total, 0, 4, s);
     GSX_LAUNCH(k_admit_count, dim3(nb), dim3(kAdmitThreads), 0, s, rec.key, rec.a, n, window, tiles_x, gate, row_words, pyramid, d_skip, ballots, counts, rec.rect8);
-    GSX_LAUNCH(k_admit_scatter, dim3(nb), dim3(kAdmitThreads), 0, s, rec.key, n, ballots, counts, pairs, d_skip, d_total);  // (scans the raw counts itself)
+    GSX_LAUNCH(k_admit_scatter<kAdmitRounds>, dim3(nb), dim3(kAdmitThreads), 0, s, rec.key, n, ballots, counts, pairs, d_skip, d_total);  // (scans the raw counts itself)
     return hipGetLastError();
 }
 

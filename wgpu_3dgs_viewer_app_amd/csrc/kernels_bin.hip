@@ -420,8 +420,8 @@ __device__ inline bool block_rect(const BlockGrid& g, uint32_t rx, uint32_t ry, 
     if (x0 >= x1 || y0 >= y1) return false;
     bx0 = x0 >> g.bsx;
     bx1 = ((x1 - 1u) >> g.bsx) + 1u;
-    by0 = y0 >> g.bsy;
-    by1 = ((y1 - 1u) >> g.bsy) + 1u;
+    by0 = (y0 - row_lo) >> g.bsy;  // (block rows count from the first row this viewer composites)
+    by1 = ((y1 - 1u - row_lo) >> g.bsy) + 1u;
     return true;
 }
 
@@ -528,7 +528,7 @@ hipError_t launch_block_bin(hipStream_t s, uint32_t j0, uint32_t j1, const uint3
                             const uint2* window, uint32_t tiles_x, uint32_t tiles_y, uint32_t bsx, uint32_t bsy, uint4* table,
                             uint2* pairs, uint2* ranges, const ZeroJob& zero, bool table_ready) {
     const uint32_t nb = std::min<uint32_t>((uint32_t)scan_blocks(j1 > j0 ? j1 - j0 : 0), kBinGrid);
-    BlockGrid g{bsx, bsy, (tiles_x + (1u << bsx) - 1u) >> bsx, (tiles_y + (1u << bsy) - 1u) >> bsy};
+    const BlockGrid g = block_grid(bsx, bsy, tiles_x, row_lo, row_hi);
     if (!table_ready)  // (the repair round of a speculated frame: k_spec_verify_fused has built the table and zeroed the ranges)
         GSX_LAUNCH(k_block_table, dim3((g.blocks_x * g.blocks_y + 3u) / 4u), dim3(256), 0, s, g, tiles_x, tiles_y, row_lo, row_hi, done,
                    row_words, window, table, ranges, zero.a, zero.na, zero.b, zero.nb);

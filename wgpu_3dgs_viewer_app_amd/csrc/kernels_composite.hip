@@ -272,10 +272,13 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
     const float pxf = (float)px + 0.5f;
     const v2f pyf = v2f{(float)py + 0.5f, (float)(py + 1u) + 0.5f};
     const size_t fbo = (size_t)py * f.w_px + px;
-    uint2 range = ranges[(ty >> bsy) * blocks_x + (tx >> bsx)];
-    const uint2 win = window ? window[tile] : make_uint2(0u, 0xFFFFFFFFu);
     const bool owned = ty >= row_lo && ty < row_hi;
-    if (!owned || win.x >= win.y) range = make_uint2(0u, 0u);  // not this rank's tile / takes nothing
+    // (another rank's tile: nothing to composite and nothing to clear — the band gather writes it, or nobody looks at it; clearing them was
+    //  7/8 of a 3840x2160 framebuffer written by every rank of 8 for every frame's first model)
+    if (!owned) return;
+    uint2 range = ranges[((ty - row_lo) >> bsy) * blocks_x + (tx >> bsx)];  // (BlockGrid: block rows count from row_lo)
+    const uint2 win = window ? window[tile] : make_uint2(0u, 0xFFFFFFFFu);
+    if (win.x >= win.y) range = make_uint2(0u, 0u);  // takes nothing
     // The slab's entries did not fit the pair buffers (k_scan_block_sums cut it: rare, the host grows the buffers when it learns of
     // it): the splats [cut, end) of the depth order never reached the lists.  The tile composites them itself, BEHIND its list,
     // pair-free — it scans them 128 at a time and keeps those whose rectangle and window take it; the per-pixel operation sequence

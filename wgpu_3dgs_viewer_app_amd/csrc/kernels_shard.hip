@@ -29,10 +29,13 @@ constexpr int kMaxWorld = 64;
 // candidate list is — a few per cent of the shard, compacted at the front: with 4096-record tiles 0.3 M candidates kept 73
 // workgroups busy on 256 CUs (47 + 51 us for count + scatter); the grid is sized for the shard, the workgroups past the list
 // return at once.
-constexpr uint32_t kPackRoundsFull = 16, kPackRoundsList = 2;
+// A shard of at most kPackSmallShard records (an 8-GPU rank's share of cfg5's 6 M-Gaussian models: 0.75 M) is scanned in 1024-record
+// tiles: at 4096 its 183 workgroups left three CUs in four idle and the repair round's count + scatter took 70 + 46 us (round 5).
+constexpr uint32_t kPackRoundsFull = 16, kPackRoundsSmall = 4, kPackRoundsList = 2;
+constexpr uint64_t kPackSmallShard = 1u << 21;
 
 size_t pack_blocks(uint64_t n, uint32_t rounds) { return (size_t)((n + kPackThreads * rounds - 1) / (kPackThreads * rounds)); }
-uint32_t pack_rounds(bool candidate_list) { return candidate_list ? kPackRoundsList : kPackRoundsFull; }
+uint32_t pack_rounds(bool candidate_list, uint64_t n) { return candidate_list ? kPackRoundsList : (n <= kPackSmallShard ? kPackRoundsSmall : kPackRoundsFull); }
 
 // per record: destination mask (stored for the scatter pass); per workgroup and destination: record count
 // list (nullable): pack only the candidates list[0 .. *d_list_n) = (key, index) pairs (the records a lazily projected
@@ -223,9 +226,10 @@ hipError_t launch_pack_count(hipStream_t s, const Records& rec, uint32_t n, cons
                              const uint2* window, uint32_t tiles_x, unsigned long long* masks, uint32_t* table,
                              const uint2* list, const uint32_t* d_list_n, unsigned long long* travellers, uint32_t* traveller_counts,
                              const uint32_t* gate, uint32_t gate_row_words, const WindowPyramid* pyramid, const uint32_t* d_skip) {
-    const uint32_t rounds = pack_rounds(list != nullptr), nb = (uint32_t)pack_blocks(n, rounds);
+    const uint32_t rounds = pack_rounds(list != nullptr, n), nb = (uint32_t)pack_blocks(n, rounds);
     if (nb) {
-        auto kernel = rounds == kPackRoundsList ? k_pack_count<(int)kPackRoundsList> : k_pack_count<(int)kPackRoundsFull>;
+        auto kernel = rounds == kPackRoundsList ? k_pack_count<(int)kPackRoundsList>
+                      : (rounds == kPackRoundsSmall ? k_pack_count<(int)kPackRoundsSmall> : k_pack_count<(int)kPackRoundsFull>);
         GSX_LAUNCH(kernel, dim3(nb), dim3(kPackThreads), 0, s, rec.key, rec.a, n, bands, window,
                            tiles_x, masks, table, nb, list, d_list_n, travellers, traveller_counts, gate, gate_row_words,
                            pyramid ? *pyramid : WindowPyramid{}, rec.rect8, d_skip);
@@ -236,9 +240,10 @@ hipError_t launch_pack_count(hipStream_t s, const Records& rec, uint32_t n, cons
 hipError_t launch_pack_scatter(hipStream_t s, const Records& rec, uint32_t n, uint32_t world,
                                const unsigned long long* masks, const uint32_t* table, const uint32_t* totals, void* d_send,
                                uint64_t capacity, const uint2* list, const uint32_t* d_list_n, const SlotSpans* slots, const uint32_t* d_skip) {
-    const uint32_t rounds = pack_rounds(list != nullptr), nb = (uint32_t)pack_blocks(n, rounds);
+    const uint32_t rounds = pack_rounds(list != nullptr, n), nb = (uint32_t)pack_blocks(n, rounds);
     if (nb) {
-        auto kernel = rounds == kPackRoundsList ? k_pack_scatter<(int)kPackRoundsList> : k_pack_scatter<(int)kPackRoundsFull>;
+        auto kernel = rounds == kPackRoundsList ? k_pack_scatter<(int)kPackRoundsList>
+                      : (rounds == kPackRoundsSmall ? k_pack_scatter<(int)kPackRoundsSmall> : k_pack_scatter<(int)kPackRoundsFull>);
         GSX_LAUNCH(kernel, dim3(nb), dim3(kPackThreads), 0, s, masks, rec.a, rec.b, rec.c, n, world, table, nb,
                            totals, reinterpret_cast<float4*>(d_send), capacity, list, d_list_n, slots ? *slots : SlotSpans{}, slots ? 1u : 0u, d_skip);
     }
@@ -323,13 +328,21 @@ __global__ __launch_bounds__(256) void k_limits_to_windows(const uint32_t* __res
 // Verification on the device, from the all-gathered feedback (layout: gsx_internal.h, feedback_*): a tile whose window was
 // bounded and that is still open gets, in the second exchange, what it was refused: [limit, inf); every other tile nothing.
 // limit == nullptr (the round had no windows): nothing to repair.
-__device__ inline uint32_t sat_at(const uint32_t* __restrict__ sat, uint32_t tx, uint32_t ty, uint32_t tiles_x, const BandEdges& bands, uint32_t stride) {
-    const uint32_t g = band_of(bands, ty);
-    return sat[(size_t)g * stride + kShardExtraWords + (ty - bands.e[g]) * tiles_x + tx];
+// The band edges arrive as a by-value kernel argument.  A workgroup copies them to LDS once (edges_to_lds: blockDim.x > kMaxRanks) and
+// every lookup indexes LDS: indexing the argument itself with a per-lane index can compile into a select chain over all 65 words PER
+// ACCESS, with the scalar registers spilled around it — k_shard_verify was 33 000 instructions and 78 us at 3840x2160 that way (round 5).
+__device__ inline void edges_to_lds(uint32_t* s_e, const BandEdges& b) {
+    if (threadIdx.x <= (uint32_t)kMaxRanks) s_e[threadIdx.x] = b.e[threadIdx.x];
 }
-__device__ inline uint32_t work_at(const uint32_t* __restrict__ sat, uint32_t ty, uint32_t tiles_x, const BandEdges& bands, uint32_t stride) {
-    const uint32_t g = band_of(bands, ty);
-    return sat[(size_t)g * stride + kShardExtraWords + (bands.e[g + 1u] - bands.e[g]) * tiles_x + (ty - bands.e[g])];
+__device__ inline uint32_t band_of_edges(const uint32_t* e, uint32_t world, uint32_t ty) {  // (band_of, gsx_internal.h)
+    uint32_t g = 0;
+    while (g + 1u < world && ty >= e[g + 1u]) ++g;
+    return g;
+}
+// where the gathered saturation keys of tile row ty start
+__device__ inline uint32_t sat_row_base(const uint32_t* e, uint32_t world, uint32_t ty, uint32_t tiles_x, uint32_t stride) {
+    const uint32_t g = band_of_edges(e, world, ty);
+    return g * stride + kShardExtraWords + (ty - e[g]) * tiles_x;
 }
 
 // this rank's feedback piece: statistics, the saturation keys of its band, the work of its tile rows.
@@ -374,51 +387,19 @@ __global__ __launch_bounds__(256) void k_shard_feedback(const uint32_t* __restri
     out[i] = s;
 }
 
-__global__ __launch_bounds__(256) void k_shard_verify(const uint32_t* __restrict__ limit, const uint32_t* __restrict__ sat, uint32_t n_tiles,
-                                                       uint32_t tiles_x, const BandEdges bands, uint32_t stride, uint2* __restrict__ win2,
-                                                       uint32_t* __restrict__ d_need, uint32_t* __restrict__ ticket,
-                                                       unsigned long long* __restrict__ host_verdict, uint32_t seq,
-                                                       uint32_t* __restrict__ need_bits, uint32_t balance) {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t world = bands.world;
-    bool need = false;
-    if (t < n_tiles) {
-        const uint32_t lim = limit ? limit[t] : 0xFFFFFFFFu;
-        const uint32_t tx = t % tiles_x, ty = t / tiles_x;
-        need = lim < 0xFFFFFFFFu && sat_at(sat, tx, ty, tiles_x, bands, stride) == 0u;
-        win2[t] = need ? make_uint2(lim, 0xFFFFFFFFu) : make_uint2(0u, 0u);
-        if (need) atomicOr(&need_bits[ty * ((tiles_x + 31u) / 32u) + (tx >> 5)], 1u << (tx & 31u));
-    }
-    __shared__ uint32_t s_need, s_last;
-    __shared__ uint32_t s_work[1024];  // per-row work of the whole frame (the last workgroup: rows past 1024 are read from memory)
-    if (threadIdx.x == 0) s_need = 0;
-    __syncthreads();
-    const unsigned long long bal = __ballot(need);
-    if ((threadIdx.x & 63u) == 0 && bal) atomicAdd(&s_need, (uint32_t)__popcll(bal));
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (s_need) atomicAdd(d_need, s_need);
-        __threadfence();
-        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    // The last block posts the verdict of round 0 (layout: gsx_internal.h, kVerdict*):
-    //   word 1 = {largest per-destination record count over all ranks | any rank's slot overflowed}
-    //   word 0 = {seq | tiles that need the repair round}     (release store: a host that waits polls this one)
-    //   and behind them: the count matrix (slot sizes of the next frame, pair by pair), the band edges of the next frame
-    //   (balanced by the rows' work), whether the ranks agree about the gather root and the slot policy, the ranks' list entries.
-    // Every input is globally gathered, so every rank posts the same verdict and takes the same decisions.  All 256 threads fetch —
-    // the rows' work into LDS, the matrix straight through — and one thread does the arithmetic on what they fetched (round 5: the
-    // one thread walking ~200 dependent loads was 16 us on the critical path of every sharded frame).
-    uint32_t* hv = reinterpret_cast<uint32_t*>(host_verdict);
-    const uint32_t tiles_y = n_tiles / tiles_x;
-    for (uint32_t ty = threadIdx.x; ty < min(tiles_y, 1024u); ty += 256u) s_work[ty] = work_at(sat, ty, tiles_x, bands, stride);
-    for (uint32_t k = threadIdx.x; k < world * world; k += 256u) hv[kVerdictMatrix + k] = sat[(size_t)(k / world) * stride + 8u + k % world];
-    __threadfence_system();  // (the matrix may go to pinned host memory: visible before the word a host polls)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        auto work = [&](uint32_t ty) -> uint32_t { return ty < 1024u ? s_work[ty] : work_at(sat, ty, tiles_x, bands, stride); };
+// The verdict arithmetic by ONE thread, row by row: the statement the parallel tail of k_shard_verify must reproduce, and what runs for
+// a frame of more than 1024 tile rows.
+// (the edges through a pointer — LDS in k_shard_verify's last workgroup: indexing the by-value kernel argument with a computed index from
+//  a function that is not inlined would make the compiler copy the whole struct to scratch memory)
+__device__ inline uint32_t work_at_edges(const uint32_t* __restrict__ sat, uint32_t ty, uint32_t tiles_x, uint32_t world, const uint32_t* e, uint32_t stride) {
+    const uint32_t g = band_of_edges(e, world, ty);
+    return sat[(size_t)g * stride + kShardExtraWords + (e[g + 1u] - e[g]) * tiles_x + (ty - e[g])];
+}
+__device__ __noinline__ void verdict_tail_serial(const uint32_t* __restrict__ sat, uint32_t tiles_x, uint32_t tiles_y, uint32_t world, const uint32_t* e,
+                                                 uint32_t stride, uint32_t* __restrict__ hv, unsigned long long* __restrict__ host_verdict,
+                                                 uint32_t seq, const uint32_t* __restrict__ d_need, uint32_t balance) {
+    {
+        auto work = [&](uint32_t ty) -> uint32_t { return work_at_edges(sat, ty, tiles_x, world, e, stride); };
         const uint32_t total = __hip_atomic_load(d_need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t gmax = 0, over = 0, root_bad = 0, ent_sum = 0, ent_max = 0;
         const uint32_t root0 = sat[2], flags0 = sat[6];
@@ -438,7 +419,7 @@ __global__ __launch_bounds__(256) void k_shard_verify(const uint32_t* __restrict
             unsigned long long all = 0, busiest = 0;
             for (uint32_t g = 0; g < world; ++g) {
                 unsigned long long wg = 0;
-                for (uint32_t ty = bands.e[g]; ty < bands.e[g + 1u] && ty < tiles_y; ++ty) wg += work(ty);
+                for (uint32_t ty = e[g]; ty < e[g + 1u] && ty < tiles_y; ++ty) wg += work(ty);
                 all += wg;
                 busiest = wg > busiest ? wg : busiest;
             }
@@ -476,15 +457,184 @@ __global__ __launch_bounds__(256) void k_shard_verify(const uint32_t* __restrict
             unsigned long long cur_worst = 0;
             for (uint32_t gg = 0; gg < world; ++gg) {
                 unsigned long long wg = 0;
-                for (uint32_t ty = bands.e[gg]; ty < bands.e[gg + 1u] && ty < tiles_y; ++ty)
+                for (uint32_t ty = e[gg]; ty < e[gg + 1u] && ty < tiles_y; ++ty)
                     wg += (unsigned long long)work(ty) + (unsigned long long)kTileWork * tiles_x;
                 cur_worst = wg > cur_worst ? wg : cur_worst;
             }
             adopt = worst * 10ull <= cur_worst * 9ull;
         }
         if (!adopt)
-            for (uint32_t g = 0; g <= world; ++g) ne[g] = bands.e[g];
+            for (uint32_t g = 0; g <= world; ++g) ne[g] = e[g];
         __hip_atomic_store(host_verdict + 1, ((unsigned long long)gmax << 32) | (over ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_verdict, ((unsigned long long)seq << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_shard_verify(const uint32_t* __restrict__ limit, const uint32_t* __restrict__ sat, uint32_t n_tiles,
+                                                       uint32_t tiles_x, const BandEdges bands, uint32_t stride, uint2* __restrict__ win2,
+                                                       uint32_t* __restrict__ d_need, uint32_t* __restrict__ ticket,
+                                                       unsigned long long* __restrict__ host_verdict, uint32_t seq,
+                                                       uint32_t* __restrict__ need_bits, uint32_t balance) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t world = bands.world;
+    // where the gathered saturation keys of the tile rows this workgroup touches start (one walk over the band edges per ROW, by the
+    // first threads, instead of one per tile: the walk is a chain of dependent loads)
+    __shared__ uint32_t s_base[40], s_e[kMaxRanks + 1];
+    edges_to_lds(s_e, bands);
+    __syncthreads();
+    const uint32_t first = (blockIdx.x * 256u) / tiles_x;
+    if (threadIdx.x < 40u) {
+        const uint32_t y = first + threadIdx.x;
+        s_base[threadIdx.x] = y * tiles_x < n_tiles ? sat_row_base(s_e, world, y, tiles_x, stride) : 0u;
+    }
+    __syncthreads();
+    bool need = false;
+    if (t < n_tiles) {
+        const uint32_t lim = limit ? limit[t] : 0xFFFFFFFFu;
+        const uint32_t tx = t % tiles_x, ty = t / tiles_x;
+        const uint32_t k = ty - first;
+        need = lim < 0xFFFFFFFFu && sat[(k < 40u ? s_base[k] : sat_row_base(s_e, world, ty, tiles_x, stride)) + tx] == 0u;
+        win2[t] = need ? make_uint2(lim, 0xFFFFFFFFu) : make_uint2(0u, 0u);
+        if (need) atomicOr(&need_bits[ty * ((tiles_x + 31u) / 32u) + (tx >> 5)], 1u << (tx & 31u));
+    }
+    __shared__ uint32_t s_need, s_last;
+    if (threadIdx.x == 0) s_need = 0;
+    __syncthreads();
+    const unsigned long long bal = __ballot(need);
+    if ((threadIdx.x & 63u) == 0 && bal) atomicAdd(&s_need, (uint32_t)__popcll(bal));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_need) atomicAdd(d_need, s_need);
+        __threadfence();
+        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // The last block posts the verdict of round 0 (layout: gsx_internal.h, kVerdict*):
+    //   word 1 = {largest per-destination record count over all ranks | any rank's slot overflowed}
+    //   word 0 = {seq | tiles that need the repair round}     (release store: a host that waits polls this one)
+    //   and behind them: the count matrix (slot sizes of the next frame, pair by pair), the band edges of the next frame
+    //   (balanced by the rows' work), whether the ranks agree about the gather root and the slot policy, the ranks' list entries.
+    // Every input is globally gathered, so every rank posts the same verdict and takes the same decisions.  All 256 threads fetch —
+    // the rows' work into LDS, the matrix straight through — and one thread does the arithmetic on what they fetched (round 5: the
+    // one thread walking ~200 dependent loads was 16 us on the critical path of every sharded frame).
+    uint32_t* hv = reinterpret_cast<uint32_t*>(host_verdict);
+    const uint32_t tiles_y = n_tiles / tiles_x;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t k = tid; k < world * world; k += 256u) hv[kVerdictMatrix + k] = sat[(size_t)(k / world) * stride + 8u + k % world];
+    if (tiles_y > 1024u) {  // (a frame taller than 16384 pixels: the rows do not fit the tables below)
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) verdict_tail_serial(sat, tiles_x, tiles_y, world, s_e, stride, hv, host_verdict, seq, d_need, balance);
+        if (tid == 0) *ticket = 0;
+        return;
+    }
+    // Rounds 1-4 had one thread walk the rows four times (the work shares, the total, the new edges, the bands in force): 14 us at
+    // 1080p and 61 us at 3840x2160 on the critical path of every model of every sharded frame.  Now: the rows' work and its running
+    // sum in LDS (s_pre[ty] = work of the rows before ty), and every figure a difference of two entries; edge g of the next frame
+    // is the FIRST row in front of which the serial rule would put it (the rule is monotone in g: a row that takes edge g has taken
+    // every edge before it), found by all threads at once.  Same 64-bit integer arithmetic, same edges.
+    __shared__ unsigned long long s_pre[1025], s_tot[2][256], s_band[kMaxRanks], s_new[kMaxRanks];
+    __shared__ uint32_t s_edge[kMaxRanks + 1], s_stat[8];
+    {
+        unsigned long long loc[4], run = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t ty = 4u * tid + u;
+            run += ty < tiles_y ? (unsigned long long)work_at_edges(sat, ty, tiles_x, world, s_e, stride) : 0ull;
+            loc[u] = run;
+        }
+        s_tot[0][tid] = run;
+        __syncthreads();
+        int cur = 0;
+        for (uint32_t d = 1; d < 256u; d <<= 1) {  // inclusive scan of the threads' totals
+            s_tot[cur ^ 1][tid] = s_tot[cur][tid] + (tid >= d ? s_tot[cur][tid - d] : 0ull);
+            cur ^= 1;
+            __syncthreads();
+        }
+        const unsigned long long before = tid ? s_tot[cur][tid - 1u] : 0ull;
+        if (tid == 0) s_pre[0] = 0ull;
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) s_pre[4u * tid + u + 1u] = before + loc[u];
+    }
+    if (tid < 64u) {  // the ranks' statistics (wave 0)
+        const bool in = tid < world;
+        const uint32_t* x = sat + (size_t)(in ? tid : 0u) * stride;
+        const uint32_t root0 = sat[2], flags0 = sat[6];
+        uint32_t gmax = in ? x[0] : 0u, over = in ? x[1] : 0u;
+        uint32_t bad = in ? ((x[2] != root0 ? 1u : 0u) | (x[6] != flags0 ? 2u : 0u)) : 0u;  // (bit 1: the ranks size their slots / bands by different policies)
+        uint32_t ent_sum = in ? x[3] : 0u, ent_max = ent_sum;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            gmax = max(gmax, (uint32_t)__shfl_xor((int)gmax, o, 64));
+            over |= (uint32_t)__shfl_xor((int)over, o, 64);
+            bad |= (uint32_t)__shfl_xor((int)bad, o, 64);
+            ent_sum += (uint32_t)__shfl_xor((int)ent_sum, o, 64);
+            ent_max = max(ent_max, (uint32_t)__shfl_xor((int)ent_max, o, 64));
+        }
+        if (tid == 0) {
+            s_stat[0] = gmax;
+            s_stat[1] = over;
+            hv[4] = bad;
+            hv[5] = ent_sum;
+            hv[6] = ent_max;
+        }
+    }
+    if (tid <= world) s_edge[tid] = tid == 0 ? 0u : tiles_y;
+    __syncthreads();
+    const unsigned long long kw = (unsigned long long)kTileWork * tiles_x;  // every tile of a row weighs kTileWork besides what it cost
+    auto pre_w = [&](uint32_t ty) -> unsigned long long { return s_pre[ty] + kw * ty; };  // weight of the rows before ty
+    // how evenly THIS frame's bands shared the work: busiest rank x world x 1000 / all; the same with the rows' weights
+    if (tid < world) {
+        const uint32_t lo = min(s_e[tid], tiles_y), hi = max(lo, min(s_e[tid + 1u], tiles_y));
+        s_band[tid] = s_pre[hi] - s_pre[lo];
+        s_new[tid] = pre_w(hi) - pre_w(lo);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long busiest = 0, cur_worst = 0;
+        const unsigned long long all = s_pre[tiles_y];
+        for (uint32_t g = 0; g < world; ++g) {
+            busiest = s_band[g] > busiest ? s_band[g] : busiest;
+            cur_worst = s_new[g] > cur_worst ? s_new[g] : cur_worst;
+        }
+        const uint32_t share = all ? (uint32_t)(busiest * world * 1000ull / all) : 1000u;
+        hv[7] = share;
+        s_stat[2] = share;
+        s_band[0] = cur_worst;
+    }
+    __syncthreads();
+    // next frame's bands: contiguous runs of tile rows of (as nearly as rows allow) equal work.  A row weighs what its tiles
+    // cost this frame (tile_work, gsx_internal.h) plus kTileWork for every tile (the ones that were not composited at all).
+    // Hysteresis: an edge that moves shifts what every pair exchanges (the slots sized pair by pair from this frame's counts
+    // would overflow for nothing), and bands a few rows tall cannot be tuned finer than a row.  New edges are adopted only
+    // when the busiest rank carries more than kBalanceKeep x the mean AND they would have shared THIS frame's work at
+    // least a tenth better.
+    const bool rebalance = balance && s_stat[2] > kBalanceKeepPermille;
+    if (rebalance) {
+        const unsigned long long W = pre_w(tiles_y), cur_worst = s_band[0];
+        for (uint32_t ty = tid; ty < tiles_y; ty += 256u) {
+            const unsigned long long acc = pre_w(ty), w = pre_w(ty + 1u) - acc;
+            // edge g goes in front of row ty if that is at least as close to g / world of the work as behind it
+            for (uint32_t g = 1; g < world && (acc * world >= g * W || 2ull * (g * W - acc * world) <= w * world); ++g) atomicMin(&s_edge[g], ty);
+        }
+        __syncthreads();
+        if (tid < world) s_new[tid] = pre_w(s_edge[tid + 1u]) - pre_w(s_edge[tid]);
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long worst = 0;
+            for (uint32_t g = 0; g < world; ++g) worst = s_new[g] > worst ? s_new[g] : worst;
+            s_stat[3] = worst * 10ull <= cur_worst * 9ull ? 1u : 0u;
+        }
+        __syncthreads();
+    }
+    const bool adopt = rebalance && s_stat[3] != 0u;
+    if (tid <= world) hv[kVerdictEdges + tid] = adopt ? s_edge[tid] : s_e[tid];
+    __threadfence_system();  // (the block may go to pinned host memory: visible before the word a host polls)
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t total = __hip_atomic_load(d_need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(host_verdict + 1, ((unsigned long long)s_stat[0] << 32) | (s_stat[1] ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(host_verdict, ((unsigned long long)seq << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         *ticket = 0;
     }
@@ -562,17 +712,14 @@ __global__ __launch_bounds__(256) void k_shard_next_limits(const uint32_t* __res
     if (host_block && blockIdx.x == 0) post_verdict_body(staged, sat_verdict, bands.world, stride, host_block, seq);
     // where the tile rows this workgroup's neighbourhoods reach lie in the gathered pieces: one lookup per row instead of a walk over
     // the band edges per load (49 loads per tile at radius 3: the walk was most of the kernel's 14 us)
-    __shared__ uint32_t s_row[48];
+    __shared__ uint32_t s_row[48], s_e[kMaxRanks + 1];
+    edges_to_lds(s_e, bands);
+    __syncthreads();
     const uint32_t t0 = blockIdx.x * 256u, row0 = t0 / tiles_x;
     const int first = max((int)row0 - radius, 0);
     if (threadIdx.x < 48u) {
         const uint32_t y = (uint32_t)first + threadIdx.x;
-        uint32_t base = 0;
-        if (y < tiles_y) {
-            const uint32_t g = band_of(bands, y);
-            base = g * stride + kShardExtraWords + (y - bands.e[g]) * tiles_x;
-        }
-        s_row[threadIdx.x] = base;
+        s_row[threadIdx.x] = y < tiles_y ? sat_row_base(s_e, bands.world, y, tiles_x, stride) : 0u;
     }
     __syncthreads();
     const uint32_t t = t0 + threadIdx.x;
@@ -584,7 +731,7 @@ __global__ __launch_bounds__(256) void k_shard_next_limits(const uint32_t* __res
         // (a workgroup's 256 tiles span at most 256 / tiles_x + 2 rows; with the radius on both sides that fits the table for every grid
         //  of at least 8 tiles a row — narrower frames take the walk)
         const uint32_t k = (uint32_t)(y - first);
-        const uint32_t base = k < 48u ? s_row[k] : band_of(bands, (uint32_t)y) * stride + kShardExtraWords + ((uint32_t)y - bands.e[band_of(bands, (uint32_t)y)]) * tiles_x;
+        const uint32_t base = k < 48u ? s_row[k] : sat_row_base(s_e, bands.world, (uint32_t)y, tiles_x, stride);
         for (int x = max(tx - radius, 0); x <= min(tx + radius, (int)tiles_x - 1); ++x) {
             const uint32_t s = sat[base + (uint32_t)x];
             if (s == 0u) open = true;
