@@ -140,8 +140,8 @@ def cpu_baseline(cfg, n_sample, pose=0):
 # ------------------------------------------------------------------------------------------------
 def predicted_for(world, workload):
     """What tools/rank_alone.py predicted for this world size from a ONE-GPU box (every rank of an N-rank frame replayed alone on the GPU
-    against the pieces it received; profiles/r04_rank_alone.json, committed): the number this line's `value` can prove wrong."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_rank_alone.json")
+    against the pieces it received; profiles/r05_rank_alone.json, committed): the number this line's `value` can prove wrong."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_rank_alone.json")
     try:
         with open(path) as f:
             table = json.loads(f.read().strip().splitlines()[-1])
@@ -155,7 +155,7 @@ def predicted_for(world, workload):
             rows[f"speculate={r['speculate']} frames_in_flight={r['frames_in_flight']}"] = dict(
                 fps=r["predicted_fps"], slowest_rank_ms_alone=r["slowest_rank_ms"], fastest_rank_ms_alone=r["fastest_rank_ms"],
                 wire_ms_at_7x153GBps=r["wire_ms_at_7x153GBps"])
-    return dict(source="profiles/r04_rank_alone.json (tools/rank_alone.py on a one-GPU box; read from that file, not measured in this run)",
+    return dict(source="profiles/r05_rank_alone.json (tools/rank_alone.py on a one-GPU box; read from that file, not measured in this run)",
                 method=table.get("method"), single_gpu_fps_in_that_run=table.get("single_gpu_fps"), by_schedule=rows) if rows else None
 
 
@@ -420,6 +420,9 @@ def main():
     elapsed, timing, last_idx = timed_loop(0)
     launches["headline"] = launches["per_frame"]
     shard_stats_timed = viewer.shard_stats(reset=True) if lib_index else None
+    # what the library holds on the device for this scene and this schedule, right after the headline loop (every DevBuf of the process:
+    # the model's planes, its shade records, sort / bin / list buffers of every lane, framebuffers)
+    resident_bytes = viewer_mod.device_bytes()
     if args.host_profile and use_dist and rank == 0:
         print("host ms/frame by section:", {k: round(1e3 * x / args.steps, 4) for k, x in renderer.profile.items()}, file=sys.stderr)
     renderer.profile = None
@@ -899,6 +902,10 @@ def main():
                                            "code ran for real, `value` measures nothing")
         if launches:
             out["launches_per_frame"] = {k: v for k, v in launches.items() if k != "per_frame"}
+        out["resident_bytes"] = {"device_bytes_after_headline_loop": int(resident_bytes), "per_gaussian_of_this_rank": round(resident_bytes / max(count, 1), 1),
+                                 "gaussians_of_this_rank": int(count),
+                                 "what": "gsx_debug_device_bytes(): every device buffer the library holds in this process (planes, shade records, sort / bin / "
+                                         "list buffers of every lane, framebuffers); the planes alone are 236 B per Gaussian for the f32 pod"}
         if extra and "launch_graphs" in extra:
             out["launch_graphs"] = extra["launch_graphs"]
         if robustness is not None:

@@ -596,6 +596,7 @@ void gsx_debug_set_radix_rank_mode(int32_t mode);
  *      frames are bit-identical (tests/test_gpu_graph.py). ---- */
 void gsx_debug_set_launch_graphs(int32_t enabled);
 uint64_t gsx_debug_launch_count(void); /* kernel launches this process has asked for so far (recorded or submitted) */
+uint64_t gsx_debug_device_bytes(void); /* device memory the library's buffers hold in this process right now (every viewer, every model) */
 /* development (viewers created under GSX_TILE_PROFILE=1; tools/tile_profile.py): what every tile of the last frame's first block-compositor
  * launch cost — per tile 4 words: start and duration in 10 ns ticks, chunks of 128 list entries walked | chunks in its list << 16, takers blended */
 gsx_status gsx_debug_tile_profile(gsx_viewer* v, uint32_t* out4, uint64_t n_tiles);

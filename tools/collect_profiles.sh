@@ -52,7 +52,6 @@ if want C; then
 #    N-rank frame alone on the GPU (the predicted 2 / 4 / 8-GPU rates), the bench as the driver launches it with N ranks on one GPU
 tools/bench_launch > $OUT/bench_launch.txt 2>&1
 python3 tools/graph_probe.py 200 > $OUT/graph_probe.txt 2>> $OUT/bench.err
-python3 tools/rank_alone.py --out $OUT/rank_alone.json > /dev/null 2> $OUT/rank_alone.err
 for N in 2 8; do
   GSX_BENCH_ONE_DEVICE=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29600+N)) bench.py --gpus $N --steps 20 --warmup 5 > $OUT/bench_ranks_on_one_gpu_world$N.json 2>> $OUT/bench.err
 done
@@ -63,14 +62,14 @@ python3 tools/tile_profile.py > $OUT/tile_profile.txt 2>> $OUT/bench.err
 GSX_TILE_ORDER=0 python3 tools/tile_profile.py > $OUT/tile_profile_index_order.txt 2>> $OUT/bench.err
 tools/ab_env.sh GSX_TILE_ORDER=0 GSX_TILE_ORDER=1 GSX_TILE_ORDER=0 GSX_TILE_ORDER=1 > $OUT/ab_tile_order.txt 2>&1
 tools/bench_atomic > $OUT/bench_atomic.txt 2>&1
-python3 tools/rank_alone.py --worlds 8 --scenes open_sky --lanes 1 --balance 0 --out $OUT/rank_alone_equal_bands.json > /dev/null 2>> $OUT/rank_alone.err
+python3 tools/rank_alone.py --worlds 8 --scenes open_sky --lanes 1 --balance 0 --frames 60 --out $OUT/rank_alone_equal_bands.json > /dev/null 2>> $OUT/rank_alone.err
 fi
 if want D; then
 # 10. round 5: every rank of an N-rank frame alone on the GPU over the native replay transport, cfg4 and cfg5; the sharded frame and
 #     cfg5 against the round-4 protocol (build_variants/libgsx_base.so) on this box; the block size A/B; the radix tile size A/B
-python3 tools/rank_alone.py --out $OUT/rank_alone.json > /dev/null 2> $OUT/rank_alone.err
-python3 tools/rank_alone.py --workload cfg5 --worlds 8 --scenes orbit --out $OUT/rank_alone_cfg5.json > /dev/null 2>> $OUT/rank_alone.err
-python3 tools/rank_alone.py --worlds 8 --scenes orbit --lanes 1 --python-replay --out $OUT/rank_alone_python_replay.json > /dev/null 2>> $OUT/rank_alone.err
+python3 tools/rank_alone.py --frames 60 --out $OUT/rank_alone.json > /dev/null 2> $OUT/rank_alone.err
+python3 tools/rank_alone.py --workload cfg5 --worlds 2,4,8 --scenes orbit --frames 50 --out $OUT/rank_alone_cfg5.json > /dev/null 2>> $OUT/rank_alone.err
+python3 tools/rank_alone.py --worlds 8 --scenes orbit --lanes 1 --speculate 1 --frames 60 --python-replay --out $OUT/rank_alone_python_replay.json > /dev/null 2>> $OUT/rank_alone.err
 [ -f build_variants/libgsx_base.so ] && tools/ab_shard.sh base new > $OUT/ab_shard.txt 2>&1
 python3 tools/ab_blocks.py > $OUT/ab_blocks.txt 2>> $OUT/bench.err
 for n in 100000 310000 870000; do

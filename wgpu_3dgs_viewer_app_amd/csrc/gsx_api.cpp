@@ -608,7 +608,8 @@ gsx_status gsx_preprocess(gsx_viewer* v, const char* key) {
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_preprocess: no model '%s'", key ? key : "(null)");
     v->latest = nullptr;
     TraceScope trace(v, TRACE_PREPROCESS);
-    return do_preprocess(v, m);
+    if ((st = do_preprocess(v, m))) return st;
+    return trace.finish();
 }
 
 gsx_status gsx_sort(gsx_viewer* v, const char* key) {
@@ -617,7 +618,8 @@ gsx_status gsx_sort(gsx_viewer* v, const char* key) {
     Model* m = find_model(v, key);
     if (!m) return fail(GSX_ERR_NOT_FOUND, "gsx_sort: no model '%s'", key ? key : "(null)");
     TraceScope trace(v, TRACE_SORT);
-    return do_sort(v, m);
+    if ((st = do_sort(v, m))) return st;
+    return trace.finish();
 }
 
 gsx_status gsx_sync(gsx_viewer* v) {
@@ -638,7 +640,8 @@ gsx_status gsx_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys) {
     if (st) return st;
     v->latest = nullptr;
     TraceScope trace(v, TRACE_RENDER);
-    return do_render(v, keys, n_keys);
+    if ((st = do_render(v, keys, n_keys))) return st;
+    return trace.finish();
 }
 
 gsx_status gsx_render_frame(gsx_viewer* v, const char* const* keys, uint32_t n_keys) {
@@ -662,6 +665,7 @@ gsx_status gsx_render_frame(gsx_viewer* v, const char* const* keys, uint32_t n_k
             if ((st = do_sort(lane, m))) return st;
         }
         if ((st = do_render(lane, keys, n_keys))) return st;
+        if ((st = trace.finish())) return st;
     }
     if (lane != v) {
         HIPCHK(gsx::op::EventRecord(lane->lane_event, lane->stream));

@@ -241,6 +241,7 @@ gsx_status gsx_comm_all_to_all(gsx_viewer* v, const void* d_send, void* d_recv, 
     o->shard_stats.wire_bytes += (uint64_t)(o->comm_world - 1u) * bytes_per_peer;
     if (o->comm_a2a_fn) {  // the caller's transport (or the in-process group): the whole exchange, own slot included
         g_err.clear();
+        trace_flush();  // (the caller's function enqueues on the stream itself: what is still recorded must be in front of it)
         if ((st = o->comm_a2a_fn(o->comm_ctx, d_send, d_recv, bytes_per_peer, v->stream)))
             return g_err.empty() ? fail(st, "gsx_comm_all_to_all: the custom transport failed with status %d", (int)st) : st;
         return GSX_OK;
@@ -286,6 +287,7 @@ gsx_status gsx_comm_all_gather(gsx_viewer* v, const void* d_send, void* d_recv, 
     o->shard_stats.wire_bytes += (uint64_t)(o->comm_world - 1u) * bytes_per_rank;
     if (o->comm_ag_fn) {
         g_err.clear();
+        trace_flush();  // (the caller's function enqueues on the stream itself: what is still recorded must be in front of it)
         if ((st = o->comm_ag_fn(o->comm_ctx, d_send, d_recv, bytes_per_rank, v->stream)))
             return g_err.empty() ? fail(st, "gsx_comm_all_gather: the custom transport failed with status %d", (int)st) : st;
         return GSX_OK;
@@ -317,6 +319,7 @@ gsx_status gsx::comm_all_to_all_v(gsx_viewer* v, const void* d_send, const PeerS
         if (p != me) o->shard_stats.wire_bytes += snd.bytes[p];
     if (o->comm_a2a_v_fn) {
         g_err.clear();
+        trace_flush();  // (the caller's function enqueues on the stream itself: what is still recorded must be in front of it)
         if ((st = o->comm_a2a_v_fn(o->comm_ctx, d_send, snd.off, snd.bytes, d_recv, rcv.off, rcv.bytes, v->stream)))
             return g_err.empty() ? fail(st, "all-to-all: the custom transport failed with status %d", (int)st) : st;
         return GSX_OK;
@@ -354,6 +357,7 @@ gsx_status gsx::comm_gather_v(gsx_viewer* v, const void* d_send, uint64_t send_b
     o->shard_stats.wire_bytes += root < 0 ? (uint64_t)(world - 1u) * send_bytes : ((uint32_t)root == me ? 0u : send_bytes);
     if (o->comm_gather_v_fn) {
         g_err.clear();
+        trace_flush();  // (the caller's function enqueues on the stream itself: what is still recorded must be in front of it)
         if ((st = o->comm_gather_v_fn(o->comm_ctx, d_send, send_bytes, d_recv, rcv.off, rcv.bytes, root, v->stream)))
             return g_err.empty() ? fail(st, "gather: the custom transport failed with status %d", (int)st) : st;
         return GSX_OK;

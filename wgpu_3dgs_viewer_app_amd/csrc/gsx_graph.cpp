@@ -64,6 +64,7 @@ struct LaunchTrace {
     std::map<uint64_t, std::vector<Variant>> cache;  // key: scope << 32 | ordinal
     gsx_launch_stats stats{};
     std::vector<void*> ptrs;  // scratch: kernelParams of one node
+    hipError_t first_error = hipSuccess;  // of the scope in progress: a recorded launch that failed when it was finally submitted
 };
 
 namespace {
@@ -84,7 +85,8 @@ void replay(LaunchTrace* t) {
     for (const Launch& l : t->cur.launches) {
         hipKernelNodeParams kp;
         fill_params(t->cur, l, t->ptrs, &kp);
-        (void)hipLaunchKernel(l.fn, l.grid, l.block, kp.kernelParams, l.shmem, t->stream);
+        const hipError_t e = hipLaunchKernel(l.fn, l.grid, l.block, kp.kernelParams, l.shmem, t->stream);
+        if (e != hipSuccess && t->first_error == hipSuccess) t->first_error = e;
     }
     t->stats.direct_launches += t->cur.launches.size();
 }
@@ -238,17 +240,29 @@ TraceScope::TraceScope(gsx_viewer* v, uint32_t scope_id) {
     t->stream = v->stream;
     t->scope = scope_id;
     t->ordinal = 0;
+    t->first_error = hipSuccess;
     t->active = true;
     t->cur.clear();
     t_trace = t;
     mine = t;
 }
 
-TraceScope::~TraceScope() {
-    if (!mine) return;
-    close_segment(mine);
-    mine->active = false;
+TraceScope::~TraceScope() { (void)finish(); }
+
+gsx_status TraceScope::finish() {
+    if (!mine) return GSX_OK;
+    LaunchTrace* t = mine;
+    mine = nullptr;
+    close_segment(t);
+    t->active = false;
     t_trace = nullptr;
+    if (t->first_error != hipSuccess) {
+        const hipError_t e = t->first_error;
+        t->first_error = hipSuccess;
+        (void)hipGetLastError();
+        return fail(GSX_ERR_HIP, "a recorded kernel launch failed when it was submitted: %s", hipGetErrorString(e));
+    }
+    return GSX_OK;
 }
 
 void trace_destroy(LaunchTrace* t) {
@@ -266,6 +280,7 @@ void trace_stats(const LaunchTrace* t, gsx_launch_stats* out) { *out = t ? t->st
 extern "C" {
 
 uint64_t gsx_debug_launch_count(void) { return gsx::g_launch_count.load(); }
+uint64_t gsx_debug_device_bytes(void) { return gsx::g_dev_bytes.load(); }
 
 gsx_status gsx_debug_tile_profile(gsx_viewer* v, uint32_t* out4, uint64_t n_tiles) {
     gsx_status st = viewer_bind(v);

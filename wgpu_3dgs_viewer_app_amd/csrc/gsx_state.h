@@ -2,6 +2,7 @@
 // per-viewer records, and the frame scheduling entry points (gsx_frame.cpp) the C ABI files call.
 // Build-internal; the public surface is include/gsx.h.
 #pragma once
+#include <atomic>
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -27,13 +28,19 @@ gsx_status fail(gsx_status st, const char* fmt, ...);
                         hipGetErrorString(_e), __FILE__, __LINE__);                                   \
     } while (0)
 
+// device bytes held by every DevBuf of the process (gsx_debug_device_bytes: the bench line's resident_bytes)
+inline std::atomic<uint64_t> g_dev_bytes{0};
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
     bool borrowed = false;  // p belongs to another DevBuf (a lane's view of the model data, gsx_api.cpp)
     ~DevBuf() { release(); }
     void release() {
-        if (p && !borrowed) (void)gsx::op::Free(p);
+        if (p && !borrowed) {
+            (void)gsx::op::Free(p);
+            g_dev_bytes.fetch_sub(bytes, std::memory_order_relaxed);
+        }
         p = nullptr;
         bytes = 0;
         borrowed = false;
@@ -56,7 +63,10 @@ struct DevBuf {
             e = hipMalloc(&p, need);
             want = need;
         }
-        if (e == hipSuccess) bytes = want;
+        if (e == hipSuccess) {
+            bytes = want;
+            g_dev_bytes.fetch_add(want, std::memory_order_relaxed);
+        }
         return e;
     }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
@@ -275,6 +285,9 @@ struct TraceScope {
     LaunchTrace* mine = nullptr;
     TraceScope(gsx_viewer* v, uint32_t scope_id);
     ~TraceScope();
+    // Submits what is still recorded and reports the first launch of this scope that failed (a deferred launch cannot fail where its
+    // wrapper returned): GSX_OK, or GSX_ERR_HIP with the HIP error's name.  The destructor does the same and can only drop the error.
+    gsx_status finish();
     TraceScope(const TraceScope&) = delete;
     TraceScope& operator=(const TraceScope&) = delete;
 };

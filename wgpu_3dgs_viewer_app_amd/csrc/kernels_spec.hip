@@ -94,11 +94,25 @@ __device__ inline void build_window_pyramid(const uint2* __restrict__ window, co
     auto leaf_min = [](const uint2 w) -> uint32_t { return w.x == 0u ? w.y : 0u; };  // a window that does not start at 0 promises nothing
     auto join = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) -> uint32_t { return mos ? min(min(a, b), min(c, d)) : max(max(a, b), max(c, d)); };
     unsigned long long cells = 0ull;
-    for (uint32_t i = threadIdx.x; i < p.wx[0] * p.wy[0]; i += NT) {
-        const uint2 w = window[i];
-        data[i] = leaf(w);
-        if (min_ends) min_ends[i] = leaf_min(w);
-        if (mos && w.y > w.x) cells |= 1ull << ((((i / p.wx[0]) >> p.cell_sy) << 3) | ((i % p.wx[0]) >> p.cell_sx));
+    // (kPyrBatch cells per trip, their loads issued together: one window per trip made level 0 a chain of 32 memory round trips per thread at
+    //  3840x2160 — 30 us of one workgroup, four times a cfg5 frame)
+    constexpr uint32_t kPyrBatch = 8;
+    const uint32_t n0 = p.wx[0] * p.wy[0], px0 = p.wx[0];
+    for (uint32_t base = threadIdx.x; base < n0; base += NT * kPyrBatch) {
+        uint2 w[kPyrBatch];
+#pragma unroll
+        for (uint32_t u = 0; u < kPyrBatch; ++u) {
+            const uint32_t i = base + u * NT;
+            w[u] = i < n0 ? window[i] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kPyrBatch; ++u) {
+            const uint32_t i = base + u * NT;
+            if (i >= n0) continue;
+            data[i] = leaf(w[u]);
+            if (min_ends) min_ends[i] = leaf_min(w[u]);
+            if (mos && w[u].y > w[u].x) cells |= 1ull << ((((i / px0) >> p.cell_sy) << 3) | ((i % px0) >> p.cell_sx));
+        }
     }
     if (mos) {
         if (cells) atomicOr(&lds.cells, cells);
@@ -107,21 +121,36 @@ __device__ inline void build_window_pyramid(const uint2* __restrict__ window, co
     }
     uint32_t l = 1, cur = 0;
     bool prev_lds = false;
-    if (p.levels > 1 && p.wx[1] * p.wy[1] <= kPyrLds) {  // level 1 from the windows themselves
-        const uint32_t wx = p.wx[1], px = p.wx[0], py = p.wy[0];
-        for (uint32_t i = threadIdx.x; i < wx * p.wy[1]; i += NT) {
-            const uint32_t x = 2u * (i % wx), y = 2u * (i / wx), x1 = min(x + 1u, px - 1u), y1 = min(y + 1u, py - 1u);
-            const uint2 a = window[y * px + x], b = window[y * px + x1], c = window[y1 * px + x], d = window[y1 * px + x1];
-            const uint32_t v = join(leaf(a), leaf(b), leaf(c), leaf(d));
-            data[p.off[1] + i] = v;
-            lds.a[0][i] = v;
-            if (min_ends) {
-                const uint32_t mv = min(min(leaf_min(a), leaf_min(b)), min(leaf_min(c), leaf_min(d)));
-                min_ends[p.off[1] + i] = mv;
-                lds.m[0][i] = mv;
+    if (p.levels > 1) {  // level 1 from the windows themselves (it does not wait for level 0), four cells per trip
+        const uint32_t wx = p.wx[1], px = p.wx[0], py = p.wy[0], n1 = wx * p.wy[1];
+        const bool keep1 = n1 <= kPyrLds;
+        constexpr uint32_t kB1 = 4;
+        for (uint32_t base = threadIdx.x; base < n1; base += NT * kB1) {
+            uint2 a[kB1], b[kB1], c[kB1], d[kB1];
+#pragma unroll
+            for (uint32_t u = 0; u < kB1; ++u) {
+                const uint32_t i = min(base + u * NT, n1 - 1u);
+                const uint32_t x = 2u * (i % wx), y = 2u * (i / wx), x1 = min(x + 1u, px - 1u), y1 = min(y + 1u, py - 1u);
+                a[u] = window[y * px + x];
+                b[u] = window[y * px + x1];
+                c[u] = window[y1 * px + x];
+                d[u] = window[y1 * px + x1];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kB1; ++u) {
+                const uint32_t i = base + u * NT;
+                if (i >= n1) continue;
+                const uint32_t v = join(leaf(a[u]), leaf(b[u]), leaf(c[u]), leaf(d[u]));
+                data[p.off[1] + i] = v;
+                if (keep1) lds.a[0][i] = v;
+                if (min_ends) {
+                    const uint32_t mv = min(min(leaf_min(a[u]), leaf_min(b[u])), min(leaf_min(c[u]), leaf_min(d[u])));
+                    min_ends[p.off[1] + i] = mv;
+                    if (keep1) lds.m[0][i] = mv;
+                }
             }
         }
-        prev_lds = true;
+        prev_lds = keep1;
         l = 2;
     }
     for (; l < p.levels; ++l) {

@@ -619,6 +619,11 @@ def launch_count() -> int:
     return int(_lib.load().gsx_debug_launch_count())
 
 
+def device_bytes() -> int:
+    """Device memory the library's buffers hold in this process right now (``gsx_debug_device_bytes``)."""
+    return int(_lib.load().gsx_debug_device_bytes())
+
+
 def render_keys_far_to_near(viewer_models_centers: dict, camera_pos) -> list:
     """``model_render_keys`` exactly as the app builds them (src/tab/scene.rs:533-558)."""
     from .camera import model_render_order
