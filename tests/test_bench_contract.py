@@ -91,6 +91,9 @@ def test_bench_line_contract(name, d):
             assert sm["steady_state_value"] == d["steady_state"]["value"]
             assert 0.85 * d["value"] < d["steady_state"]["value"] < 1.15 * d["value"]  # two whole-orbit samples of one loop
         assert sm["roofline_frac"] == d["roofline"]["frac"]
+        # what the library holds on the device for the scene: at least the planes, at most a few KB per Gaussian
+        rb = d["resident_bytes"]
+        assert 200 * rb["gaussians_of_this_rank"] < rb["device_bytes_after_headline_loop"] < 4096 * rb["gaussians_of_this_rank"]
 
 
 def test_bench_source_prints_the_summary_last():

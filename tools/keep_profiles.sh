@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copies what tools/collect_profiles.sh wrote under gpurun_out/<dir>/ into profiles/ under the round's names (run here, after the
-# gpurun call has merged its output).  usage: tools/keep_profiles.sh r04b r04
+# gpurun call has merged its output).  usage: tools/keep_profiles.sh r05 r05
 set -u
 S=gpurun_out/$1; R=$2; P=profiles
 cpf() { [ -s "$1" ] && cp "$1" "$2" || echo "missing: $1"; }
@@ -14,6 +14,7 @@ for k in spec nospec dist; do
 done
 cpf $S/pmc_summary.csv $P/${R}_cfg4_pmc_summary.csv
 for f in bench_cfg2 bench_cfg3 bench_half_half bench_norm8_half bench_index_world1_inflight1 bench_index_world1_inflight2 bench_index_world1_inflight3 \
-         bench_inflight1 bench_inflight3 bench_cfg5 bench_ranks_on_one_gpu_world2 bench_ranks_on_one_gpu_world8 rank_alone rank_alone_equal_bands rows; do cpf $S/$f.json $P/${R}_$f.json; done
-for f in bench_hbm bench_sort shard_host_time bench_launch graph_probe tile_profile tile_profile_index_order ab_tile_order bench_atomic; do cpf $S/$f.txt $P/${R}_$f.txt; done
+         bench_inflight1 bench_inflight3 bench_cfg5 bench_ranks_on_one_gpu_world2 bench_ranks_on_one_gpu_world8 rank_alone rank_alone_equal_bands rank_alone_cfg5 \
+         rank_alone_python_replay rows; do cpf $S/$f.json $P/${R}_$f.json; done
+for f in bench_hbm bench_sort shard_host_time bench_launch graph_probe tile_profile tile_profile_index_order ab_tile_order bench_atomic ab_shard ab_blocks ab_radix_small; do cpf $S/$f.txt $P/${R}_$f.txt; done
 ls -la $P/${R}_* | awk '{print $5, $9}'
