@@ -778,6 +778,40 @@ def test_bands_are_balanced_by_the_previous_frames_work():
     assert max(entries[3:7]) < entries[0], (entries[0], entries[3:7])
 
 
+def test_the_parallel_verdict_arithmetic_posts_what_the_one_thread_walk_posts(monkeypatch):
+    """k_shard_verify's last workgroup derives the work shares and the next band edges from prefix sums, all threads at once; frames of
+    more than 1024 tile rows (and GSX_SHARD_VERIFY_SERIAL=1) take the one-thread walk over the rows it replaced.  Same gathered data in,
+    same edges, same figures out — frame by frame, incl. the frames where the edges move and the camera jump."""
+    world, size = 4, (640, 960)
+    g = _open_sky_scene()
+    poses = (10, 11, 12, 13, 130, 131, 132)
+
+    def run():
+        def body(rank, group):
+            v, shard_max = _rank_viewer(g, g.shape[0], rank, world, group)
+            edges, stats, sums = [], [], []
+            for pose in poses:
+                _uniforms(v, pose, size)
+                v.shard_render_frame("m", shard_max)
+                fb = v.download_framebuffer()
+                sums.append(int(np.frombuffer(fb.tobytes(), np.uint32).astype(np.uint64).sum()))
+                edges.append(v.shard_get_band_edges(world).tolist())
+                st = v.shard_stats()
+                stats.append((st["last_work_permille"], st["last_entries_max"], st["last_entries_sum"], st["last_slot_records"], st["repair_frames"]))
+            v.close()
+            return edges, stats, sums
+        return run_group(world, body)[0]
+
+    monkeypatch.delenv("GSX_SHARD_VERIFY_SERIAL", raising=False)
+    parallel_edges, parallel_stats, parallel_sums = run()
+    monkeypatch.setenv("GSX_SHARD_VERIFY_SERIAL", "1")
+    serial_edges, serial_stats, serial_sums = run()
+    assert any(e != parallel_edges[0] for e in parallel_edges[1:]), "the scene must move the edges, or the comparison says nothing"
+    assert serial_edges == parallel_edges
+    assert serial_stats == parallel_stats
+    assert serial_sums == parallel_sums
+
+
 @pytest.mark.parametrize("edges", [(0, 1, 1, 9, 10), (0, 0, 5, 5, 10), (0, 10, 10, 10, 10)])
 def test_forced_band_edges_with_empty_and_uneven_bands(edges):
     world = 4

@@ -522,10 +522,10 @@ __global__ __launch_bounds__(256) void k_shard_verify(const uint32_t* __restrict
     const uint32_t tiles_y = n_tiles / tiles_x;
     const uint32_t tid = threadIdx.x;
     for (uint32_t k = tid; k < world * world; k += 256u) hv[kVerdictMatrix + k] = sat[(size_t)(k / world) * stride + 8u + k % world];
-    if (tiles_y > 1024u) {  // (a frame taller than 16384 pixels: the rows do not fit the tables below)
+    if (tiles_y > 1024u || (balance & 2u)) {  // (a frame taller than 16384 pixels: the rows do not fit the tables below; or a test asks)
         __threadfence_system();
         __syncthreads();
-        if (tid == 0) verdict_tail_serial(sat, tiles_x, tiles_y, world, s_e, stride, hv, host_verdict, seq, d_need, balance);
+        if (tid == 0) verdict_tail_serial(sat, tiles_x, tiles_y, world, s_e, stride, hv, host_verdict, seq, d_need, balance & 1u);
         if (tid == 0) *ticket = 0;
         return;
     }
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(256) void k_shard_verify(const uint32_t* __restrict
     // would overflow for nothing), and bands a few rows tall cannot be tuned finer than a row.  New edges are adopted only
     // when the busiest rank carries more than kBalanceKeep x the mean AND they would have shared THIS frame's work at
     // least a tenth better.
-    const bool rebalance = balance && s_stat[2] > kBalanceKeepPermille;
+    const bool rebalance = (balance & 1u) && s_stat[2] > kBalanceKeepPermille;
     if (rebalance) {
         const unsigned long long W = pre_w(tiles_y), cur_worst = s_band[0];
         for (uint32_t ty = tid; ty < tiles_y; ty += 256u) {
@@ -770,6 +770,10 @@ hipError_t launch_shard_verify(hipStream_t s, const uint32_t* limit, const uint3
                                uint2* win2, uint32_t* d_need, uint32_t* d_ticket, unsigned long long* host_verdict, uint32_t seq,
                                uint32_t* need_bits, uint32_t balance) {
     const uint32_t n_tiles = tiles_x * tiles_y;
+    // GSX_SHARD_VERIFY_SERIAL=1 (tests): the verdict arithmetic by the one-thread walk that frames of more than 1024 tile rows take
+    // (bit 1 of `balance`): tests/test_gpu_shard_lib.py checks that both statements post the same edges and figures
+    const char* serial = getenv("GSX_SHARD_VERIFY_SERIAL");
+    if (serial && *serial == '1') balance |= 2u;
     GSX_LAUNCH(k_shard_verify, dim3((n_tiles + 255) / 256), dim3(256), 0, s, limit, sat, n_tiles, tiles_x, bands, feedback_stride(bands, tiles_x), win2,
                d_need, d_ticket, host_verdict, seq, need_bits, balance);
     return hipGetLastError();
