@@ -209,6 +209,7 @@ CFG5_TRS = {"a": camera.ModelTransform(pos=np.array([0.0, 0.0, 2.5], np.float32)
 WORKLOAD = "cfg4"
 PYTHON_REPLAY = False
 PASS_REPLAY = True
+REPLAYS = 2
 MARGIN, RADIUS = 0.25, 3
 
 
@@ -324,25 +325,33 @@ def run(cfg, world, frames, open_sky, speculate, orbit, lanes):
 
     ranks = []
     for rank in range(world):   # phase 2: one rank at a time, nothing else on the GPU
-        v, frame, models = make_viewer(cfg, rank, world, open_sky, lanes)
-        tr = attach(v, rank)
-        same = True
-        t_mark = wire_mark = None
-        for i in range(frames):
-            if i == warm:
-                v.poll()
-                t_mark, wire_mark = time.perf_counter(), tr.wire
-            frame(i, speculate)
-            if looked_at(i) and i < frames - 1:   # (checking costs a readback: only untimed frames are checked, the last one after the clock stops)
-                same = same and band_checksum(v, world, rank) == out[rank]["sums"][i]
-        v.poll()
-        elapsed = time.perf_counter() - t_mark
-        wire_timed = tr.wire - wire_mark
-        same = same and band_checksum(v, world, rank) == out[rank]["sums"][frames - 1]
-        st = v.shard_stats()
+        # the timed replay, REPLAYS times on a fresh viewer each (the recording is one fixed sequence of frames): the rank's time is the
+        # fastest of them — one replay is 30-50 frames of 0.2-1.5 ms, and a host hiccup or a tuner probe phase that falls into the window
+        # moved single cells of the table by 20-40 % from run to run
+        elapsed, same, all_ms = None, True, []
+        for rep in range(REPLAYS):
+            v, frame, models = make_viewer(cfg, rank, world, open_sky, lanes)
+            tr = attach(v, rank)
+            t_mark = wire_mark = None
+            for i in range(frames):
+                if i == warm:
+                    v.poll()
+                    t_mark, wire_mark = time.perf_counter(), tr.wire
+                frame(i, speculate)
+                if looked_at(i) and i < frames - 1:   # (checking costs a readback: only untimed frames are checked, the last one after the clock stops)
+                    same = same and band_checksum(v, world, rank) == out[rank]["sums"][i]
+            v.poll()
+            el = time.perf_counter() - t_mark
+            all_ms.append(round(1e3 * el / (frames - warm), 4))
+            elapsed = el if elapsed is None else min(elapsed, el)
+            wire_timed = tr.wire - wire_mark
+            same = same and band_checksum(v, world, rank) == out[rank]["sums"][frames - 1]
+            st = v.shard_stats()
+            v.close()
+            if rep + 1 < REPLAYS and hasattr(tr, "close"):
+                tr.close()
         timed = frames - warm
         launches = None
-        v.close()
         # once more with every pass bracketed by events (costs a few microseconds of stream gap per bracket): where the rank's time goes;
         # and the kernel launches the library asks for per frame (GSX_LAUNCH counter)
         passes, tr2 = {}, None
@@ -361,7 +370,7 @@ def run(cfg, world, frames, open_sky, speculate, orbit, lanes):
             launches = round((viewer_mod.launch_count() - l0) / timed, 1)
             v.poll()
             passes = {k: round(1e3 * t["ms"] / timed, 1) for k, t in v.get_pass_timing().items() if t["ms"] > 0}
-        ranks.append(dict(rank=rank, ms_per_frame_alone=round(1e3 * elapsed / timed, 4), pass_us_per_frame=passes, launches_per_frame=launches,
+        ranks.append(dict(rank=rank, ms_per_frame_alone=round(1e3 * elapsed / timed, 4), ms_per_frame_every_replay=all_ms, pass_us_per_frame=passes, launches_per_frame=launches,
                           wire_bytes_per_frame=int(wire_timed / timed), frames_equal_to_the_recording=bool(same),
                           list_entries_last_frame=int(out[rank]["entries"]),
                           repair_frames=round(st["repair_frames"] / max(st["frames"], 1), 3), redo_frames=round(st["redo_frames"] / max(st["frames"], 1), 3),
@@ -415,15 +424,17 @@ def main():
     ap.add_argument("--speculate", default="1,0", help="which schedules to run")
     ap.add_argument("--margin", type=float, default=0.25, help="gsx_shard_render_frame's margin (the speculated schedule)")
     ap.add_argument("--radius", type=int, default=3)
+    ap.add_argument("--replays", type=int, default=2, help="timed replays per rank (the fastest counts)")
     ap.add_argument("--no-pass-replay", action="store_true", help="skip the second replay with the passes bracketed by events (for a kernel trace whose tail is the timed replay)")
     ap.add_argument("--python-replay", action="store_true", help="serve the replay from Python callbacks (rounds 4's transport: the A/B of the native one)")
     a = ap.parse_args()
-    global BALANCE, WORKLOAD, PYTHON_REPLAY, ORBIT, KEYS_OF, PASS_REPLAY, MARGIN, RADIUS
+    global BALANCE, WORKLOAD, PYTHON_REPLAY, ORBIT, KEYS_OF, PASS_REPLAY, MARGIN, RADIUS, REPLAYS
     BALANCE = bool(a.balance)
     WORKLOAD = a.workload
     PYTHON_REPLAY = a.python_replay
     PASS_REPLAY = not a.no_pass_replay
     MARGIN, RADIUS = a.margin, a.radius
+    REPLAYS = max(1, a.replays)
     specs = [int(x) for x in a.speculate.split(",")]
     cfg = scene.CONFIGS[a.workload]
     n, sh, w, h, seed = cfg
@@ -434,7 +445,7 @@ def main():
         a.scenes = "orbit"
     res = dict(tool="tools/rank_alone.py", workload=a.workload, gaussians=n, size=[w, h],
                method="every rank of an N-rank gsx_shard_render_frame run replayed ALONE on the GPU against the pieces it received in the "
-                      "N-rank run (threads, one GPU); predicted fps = 1 / (slowest rank's ms alone + busiest rank's wire bytes / (7 x 153 GB/s)); "
+                      "N-rank run (threads, one GPU), the fastest of --replays timed replays per rank; predicted fps = 1 / (slowest rank's ms alone + busiest rank's wire bytes / (7 x 153 GB/s)); "
                       + ("the replay transport's callbacks are Python (--python-replay)" if a.python_replay else
                          "the replay transport is native code (tools/replay_transport.cpp): no Python inside the timed rank"),
                balanced_bands=bool(a.balance), margin=a.margin, radius=a.radius, single_gpu_fps={}, runs=[])

@@ -603,7 +603,14 @@ gsx_status gsx_shard_render_frame_keys(gsx_viewer* v, const char* const* keys_fa
     // runs while the verdict travels); with frames in flight it waits for the retirement — a third of cfg4's orbit frames repair their last
     // model there, and a gather that showed the frame without the repair would be bytes on the links for nothing.
     const bool eager_gather = lanes == 1 && (v->shard_gather_root < 0 || v->shard_root_confirmed);
-    if ((st = frame_front(c, eager_gather))) {
+    {
+        // (GSX_GRAPH / gsx_debug_set_launch_graphs: the frame's launches between two collectives leave as cached, patched HIP graphs —
+        //  host time only, csrc/gsx_launch.h; off by default)
+        TraceScope trace(lane, TRACE_SHARD);
+        st = frame_front(c, eager_gather);
+        if (!st) st = trace.finish();
+    }
+    if (st) {
         v->shard_pending.clear();
         return st;
     }
