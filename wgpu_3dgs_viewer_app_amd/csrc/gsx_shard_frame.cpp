@@ -413,8 +413,13 @@ gsx_status frame_front(Ctx& c, bool eager_gather) {
         // the critical path anyway, and a frame that repairs nothing pays no fall-through launches and no empty slots
         // (GSX_SHARD_REPAIR_DEVICE=1: the device decides for every model — no host look ever, at ~15 launches and `world` slots a frame).
         static const bool all_device = getenv("GSX_SHARD_REPAIR_DEVICE") != nullptr && atoi(getenv("GSX_SHARD_REPAIR_DEVICE")) != 0;
-        if (p.limited[i] && (i + 1 < n || all_device)) p.repair_slot[i] = repair_slot_policy(find_model(c.owner, p.order[i].c_str()), p.shard_max[i]);
+        // (a frame that is enqueued model by model — frame_step — reads every model's verdict before the next model goes out: host-decided
+        //  repairs throughout, no fall-through launches)
+        if (!p.stepped && p.limited[i] && (i + 1 < n || all_device)) p.repair_slot[i] = repair_slot_policy(find_model(c.owner, p.order[i].c_str()), p.shard_max[i]);
     }
+    c.l->shard_frames_enqueued += 1;
+    p.lane_frame = c.l->shard_frames_enqueued;
+    if (p.stepped) return lane_mark(c.owner, p, true);  // (the models follow one by one: frame_step)
     for (size_t i = 0; i < n; ++i) {
         const char* key = p.order[i].c_str();
         if ((st = exchange_round(c, i, 0, p.slot[i], &p.pair_caps[i], false, true))) return st;
@@ -425,56 +430,112 @@ gsx_status frame_front(Ctx& c, bool eager_gather) {
         if ((st = shard_next_windows_post(c.l, key, c.world, c.l->shard_sat_all.p, p.margin, p.radius, p.repair_slot[i] ? c.l->shard_sat_all.p : nullptr, &p.vseq[i])))
             return st;
     }
-    c.l->shard_frames_enqueued += 1;
-    p.lane_frame = c.l->shard_frames_enqueued;
+    p.next_model = (uint32_t)n;  // (everything is enqueued; the verdicts are read at retirement)
     // (a gather to ONE rank over RCCL hangs if the ranks name different roots: the first frame after gsx_shard_set_gather_root
     //  gathers only when its verdict has confirmed that they agree — the caller retires it at once)
     if (eager_gather && (st = band_gather(c))) return st;
     return lane_mark(c.owner, p, true);
 }
 
-// The frame's verdicts, read (with frames in flight they arrived while the next frame was being enqueued); a frame whose slots
-// overflowed is redone here, before its lane is used again and before anybody can read it.
-gsx_status frame_retire(gsx_viewer* owner, ShardPending& p) {
+// the context of a frame that was enqueued by an earlier call (the lane may be running a newer frame by now — with one frame in flight
+// it is the owner itself: the frame's own geometry)
+Ctx context_of(gsx_viewer* owner, ShardPending& p) {
     Ctx c{owner, p.lane, &p, owner->comm_world, owner->comm_rank, {}, 0, {}, 0, 0};
-    // (the lane may be running a newer frame by now — with one frame in flight it is the owner itself: the frame's own geometry)
     c.tiles_x = (p.uniforms.width + GSX_TILE - 1) / GSX_TILE;
     c.tiles_y = (p.uniforms.height + GSX_TILE - 1) / GSX_TILE;
     c.bands.world = c.world;
     for (uint32_t g = 0; g <= c.world; ++g)
         c.bands.e[g] = p.edges.size() == (size_t)c.world + 1u ? p.edges[g] : g * ((c.tiles_y + c.world - 1) / c.world);
+    return c;
+}
+
+// model i's verdict, read from the lane's ring (waits for it if it has not arrived): the hints for the frames to come, whether a slot
+// overflowed, whether the model's tiles were refused records they need (*need)
+gsx_status read_verdict(Ctx& c, size_t i, bool* overflow, bool* need) {
+    ShardPending& p = *c.p;
+    gsx_shard_stats& ss = c.owner->shard_stats;
+    gsx_shard_verdict verdict{};
+    const uint32_t* block = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    gsx_status st = shard_wait_ring(p.lane, p.vseq[i], &verdict, &block);
+    ss.verdict_wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    if (st) return st;
+    if ((st = read_block(c, i, block))) return st;
+    p.counted[i] = true;
+    if (Model* om = find_model(c.owner, p.order[i].c_str())) {  // next frame's slots (global figures: the same on every rank)
+        om->slot_hint = verdict.max_records;
+        om->slot_hint_known = true;
+        om->slot_hint_limited = p.limited[i] != 0;
+        if (p.repair_slot[i]) {
+            // (a third of cfg4's orbit frames repair, a few thousand records each, the others nothing: the hint is a maximum
+            //  that decays by a sixteenth per frame — a slot sized by the last frame alone overflowed in 8 % of the frames)
+            om->repair_hint = std::max(block[kVerdictRepairMax], om->repair_hint - om->repair_hint / 16u);
+            ss.last_repair_records = block[kVerdictRepairMax];
+        }
+    }
+    static const bool debug = getenv("GSX_SHARD_DEBUG") != nullptr;
+    if (debug)
+        fprintf(stderr, "[gsx shard] rank %u frame %llu model '%s': need %u, slot %u (busiest pair wanted %u, overflow %u), repair slot %u (busiest pair had %u, overflow %u)%s\n",
+                c.rank, (unsigned long long)p.lane_frame, p.order[i].c_str(), verdict.need_tiles, p.slot[i], verdict.max_records, verdict.overflow, p.repair_slot[i],
+                block[kVerdictRepairMax], block[kVerdictRepairOver], p.stepped ? " (model by model)" : "");
+    if (verdict.need_tiles && p.repair_slot[i]) p.repaired = true;
+    *overflow = verdict.overflow != 0 || block[kVerdictRepairOver] != 0;
+    *need = verdict.need_tiles != 0 && p.limited[i] && !p.repair_slot[i];
+    return GSX_OK;
+}
+
+// A layered frame with frames in flight goes out MODEL BY MODEL, its steps interleaved with another frame's (gsx_shard_render_frame_keys):
+// before model i is enqueued the verdict of model i - 1 is read — it was enqueued a step ago, and meanwhile the host enqueued a model of
+// the other frame, whose kernels keep the device busy — and its repair, where one is needed, is exchanged exactly sized.  No always-
+// enqueued repair rounds: cfg5's three inner models paid ~22 fall-through launches each per frame, and the host, at ~4.5 us a launch,
+// was what bounded two frames in flight.  false in *more: the frame has no model left (frame_retire reads the last model's verdict).
+gsx_status frame_step(gsx_viewer* owner, ShardPending& p, bool* more) {
+    const size_t n = p.order.size();
+    *more = false;
+    if (!p.stepped || p.next_model >= n || p.overflowed) return GSX_OK;
+    Ctx c = context_of(owner, p);
+    const bool own = p.lane == owner;
+    if (own) swap_uniforms(p.lane, p);  // (the caller may have moved the camera on since the frame was begun)
+    gsx_status st = frame_buffers(c);
+    const size_t i = p.next_model;
+    if (!st && i > 0 && p.read_models < i) {
+        bool overflow = false, need = false;
+        st = read_verdict(c, i - 1, &overflow, &need);
+        p.read_models = (uint32_t)i;
+        if (!st && overflow) p.overflowed = true;  // (the whole frame is redone at its retirement: nothing more of it goes out now)
+        else if (!st && need) st = repair_sized(c, i - 1);
+    }
+    if (!st && !p.overflowed) {
+        const char* key = p.order[i].c_str();
+        st = exchange_round(c, i, 0, p.slot[i], &p.pair_caps[i], false, true);
+        if (!st) st = shard_verify_staged(c.l, key, c.world, c.l->shard_sat_all.p);
+        if (!st) st = shard_next_windows_post(c.l, key, c.world, c.l->shard_sat_all.p, p.margin, p.radius, nullptr, &p.vseq[i]);
+        if (!st) p.next_model = (uint32_t)i + 1u;
+    }
+    if (!st) st = lane_mark(owner, p, !owner->shard_pending.empty() && &owner->shard_pending.back() == &p);
+    if (own) swap_uniforms(p.lane, p);
+    *more = !st && !p.overflowed && p.next_model < n;
+    return st;
+}
+
+// The frame's verdicts, read (with frames in flight they arrived while the next frame was being enqueued); a frame whose slots
+// overflowed is redone here, before its lane is used again and before anybody can read it.
+gsx_status frame_retire(gsx_viewer* owner, ShardPending& p) {
+    for (bool more = p.stepped; more;) {  // (a frame that goes out model by model: whatever has not gone out yet)
+        const gsx_status sst = frame_step(owner, p, &more);
+        if (sst) return sst;
+    }
+    Ctx c = context_of(owner, p);
     gsx_status st = GSX_OK;
     gsx_shard_stats& ss = owner->shard_stats;
-    bool overflow = false, host_repair = false;
-    if (!p.settled) {
-        for (size_t i = 0; i < p.order.size(); ++i) {
-            gsx_shard_verdict verdict{};
-            const uint32_t* block = nullptr;
-            const auto t0 = std::chrono::steady_clock::now();
-            st = shard_wait_ring(p.lane, p.vseq[i], &verdict, &block);
-            ss.verdict_wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-            if (st) return st;
-            if ((st = read_block(c, i, block))) return st;
-            p.counted[i] = true;
-            if (Model* om = find_model(owner, p.order[i].c_str())) {  // next frame's slots (global figures: the same on every rank)
-                om->slot_hint = verdict.max_records;
-                om->slot_hint_known = true;
-                om->slot_hint_limited = p.limited[i] != 0;
-                if (p.repair_slot[i]) {
-                    // (a third of cfg4's orbit frames repair, a few thousand records each, the others nothing: the hint is a maximum
-                    //  that decays by a sixteenth per frame — a slot sized by the last frame alone overflowed in 8 % of the frames)
-                    om->repair_hint = std::max(block[kVerdictRepairMax], om->repair_hint - om->repair_hint / 16u);
-                    ss.last_repair_records = block[kVerdictRepairMax];
-                }
-            }
-            static const bool debug = getenv("GSX_SHARD_DEBUG") != nullptr;
-            if (debug)
-                fprintf(stderr, "[gsx shard] rank %u frame %llu model '%s': need %u, slot %u (busiest pair wanted %u, overflow %u), repair slot %u (busiest pair had %u, overflow %u)%s\n",
-                        c.rank, (unsigned long long)p.lane_frame, p.order[i].c_str(), verdict.need_tiles, p.slot[i], verdict.max_records, verdict.overflow, p.repair_slot[i],
-                        block[kVerdictRepairMax], block[kVerdictRepairOver], "");
-            if (verdict.need_tiles && p.repair_slot[i]) p.repaired = true;
-            overflow = overflow || verdict.overflow != 0 || block[kVerdictRepairOver] != 0;
-            if (verdict.need_tiles && p.limited[i] && !p.repair_slot[i]) host_repair = true;  // (the last model: its repair waits for this look)
+    bool overflow = p.overflowed, host_repair = false;
+    if (!p.settled && !p.overflowed) {
+        for (size_t i = p.stepped ? p.read_models : 0u; i < p.order.size(); ++i) {
+            bool over = false, need = false;
+            if ((st = read_verdict(c, i, &over, &need))) return st;
+            overflow = overflow || over;
+            // (the last model — in a frame that went out model by model the only one not read yet: its repair waits for this look)
+            if (need) host_repair = true;
         }
     }
     if (host_repair && !overflow) {
@@ -598,6 +659,10 @@ gsx_status gsx_shard_render_frame_keys(gsx_viewer* v, const char* const* keys_fa
     p.speculate = speculate;
     p.margin = margin;
     p.radius = radius;
+    // layered models with frames in flight: model by model, interleaved with the frame before (frame_step; GSX_SHARD_LAYER_PIPELINE=0: all
+    // models at once with device-decided repairs, as with one frame in flight)
+    static const bool layer_pipeline = !(getenv("GSX_SHARD_LAYER_PIPELINE") && atoi(getenv("GSX_SHARD_LAYER_PIPELINE")) == 0);
+    p.stepped = layer_pipeline && lanes > 1 && n_keys > 1 && speculate != 0;
     Ctx c{v, lane, &p, v->comm_world, v->comm_rank, {}, 0, {}, 0, 0};
     // The band gather is enqueued with the frame when the call is going to wait for this frame anyway (one frame in flight: the gather
     // runs while the verdict travels); with frames in flight it waits for the retirement — a third of cfg4's orbit frames repair their last
@@ -613,6 +678,32 @@ gsx_status gsx_shard_render_frame_keys(gsx_viewer* v, const char* const* keys_fa
     if (st) {
         v->shard_pending.clear();
         return st;
+    }
+    if (p.stepped) {
+        // The new frame's models and what is left of the frames before it, one model each in turn, oldest frame first: the verdict a step
+        // waits for belongs to a model that went out a turn ago, and the other frame's model keeps the device busy meanwhile.  The new frame
+        // is left with (at least) half its models out: the next call finds as much left of it as it enqueues of the frame after.
+        const uint32_t stop_at = (n_keys + 1u) / 2u;
+        for (bool any = true; any;) {
+            any = false;
+            for (size_t k = 0; k + 1 < v->shard_pending.size(); ++k) {
+                ShardPending& old = v->shard_pending[k];
+                bool more = false;
+                if ((st = frame_step(v, old, &more))) break;
+                any = any || more;
+            }
+            if (st) break;
+            ShardPending& mine = v->shard_pending.back();
+            if (any || mine.next_model < stop_at) {
+                bool more = false;
+                if ((st = frame_step(v, mine, &more))) break;
+                any = any || (more && mine.next_model < stop_at);
+            }
+        }
+        if (st) {
+            v->shard_pending.clear();
+            return st;
+        }
     }
     // (a gather to ONE rank whose root is not confirmed yet: the frame's verdict says whether the ranks agree; then the gather)
     if (v->shard_gather_root >= 0 && !v->shard_root_confirmed && (st = retire_all(v))) return st;

@@ -335,6 +335,12 @@ struct ShardPending {
     std::vector<uint32_t> edges;              // the frame's band layout (world + 1 tile rows; empty: equal bands)
     std::vector<std::vector<uint32_t>> pair_caps;  // per model: round-0 slot sizes pair by pair ([s * world + d]; empty: uniform `slot`)
     std::vector<bool> counted;                // per model: its round 0 of THIS frame has been counted (its verdict read: Model::pair_counts)
+    // layered frames with frames in flight, model by model (gsx_shard_frame.cpp, frame_step): the models [0, next_model) are enqueued,
+    // the verdicts of [0, read_models) have been read (and their repairs, host-decided, exchanged)
+    bool stepped = false;
+    uint32_t next_model = 0, read_models = 0;
+    bool overflowed = false;                  // a slot of a model read so far overflowed: the frame is redone when it is retired
+    bool host_repair_last = false;
 };
 
 struct gsx_viewer {
