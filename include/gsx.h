@@ -601,6 +601,10 @@ void gsx_debug_set_radix_rank_mode(int32_t mode);
 void gsx_debug_set_launch_graphs(int32_t enabled);
 uint64_t gsx_debug_launch_count(void); /* kernel launches this process has asked for so far (recorded or submitted) */
 uint64_t gsx_debug_device_bytes(void); /* device memory the library's buffers hold in this process right now (every viewer, every model) */
+/* tests: the framebuffer of lane `lane` (0: the viewer itself, i: its i-th lane) as it is once that lane's stream has drained — WITHOUT
+ * completing the frames in flight (every other readback does).  With frames_in_flight = L the frame of call k sits in lane k mod L until
+ * call k + L; after call k + 1 it is retired, i.e. complete: this is how a test looks at a frame that was continued across calls. */
+gsx_status gsx_debug_download_lane_framebuffer(gsx_viewer* v, uint32_t lane, float* rgbt, uint64_t n_floats);
 /* development (viewers created under GSX_TILE_PROFILE=1; tools/tile_profile.py): what every tile of the last frame's first block-compositor
  * launch cost — per tile 4 words: start and duration in 10 ns ticks, chunks of 128 list entries walked | chunks in its list << 16, takers blended */
 gsx_status gsx_debug_tile_profile(gsx_viewer* v, uint32_t* out4, uint64_t n_tiles);

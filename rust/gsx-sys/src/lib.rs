@@ -242,6 +242,7 @@ extern "C" {
     pub fn gsx_debug_set_launch_graphs(enabled: i32);
     pub fn gsx_debug_launch_count() -> u64;
     pub fn gsx_debug_device_bytes() -> u64;
+    pub fn gsx_debug_download_lane_framebuffer(v: *mut gsx_viewer, lane: u32, rgbt: *mut f32, n_floats: u64) -> gsx_status;
     pub fn gsx_debug_tile_profile(v: *mut gsx_viewer, out4: *mut u32, n_tiles: u64) -> gsx_status;
     pub fn gsx_viewer_launch_stats(v: *mut gsx_viewer, out: *mut gsx_launch_stats, reset: u32) -> gsx_status;
     pub fn gsx_set_pass_timing(v: *mut gsx_viewer, enabled: u32) -> gsx_status;

@@ -331,7 +331,7 @@ def _layer_reference(scenes, poses=LPOSES):
 
 
 @pytest.mark.parametrize("world,mode,lanes", [(2, "natural", 1), (4, "natural", 1), (3, "all_refusing", 1), (4, "tiny_slots", 1),
-                                              (3, "off", 1), (2, "natural", 2), (4, "all_refusing", 2)])
+                                              (3, "off", 1), (2, "natural", 2), (4, "all_refusing", 2), (3, "tiny_slots", 2), (2, "natural", 3)])
 def test_layered_models_inside_the_library_call(world, mode, lanes):
     """Four models with their own TRS, layered far -> near in an order that changes with the camera, every model
     index-sharded over `world` ranks, ONE C-ABI call per frame and rank: equal to gsx_render_frame(keys) on one GPU."""
@@ -372,6 +372,51 @@ def test_layered_models_inside_the_library_call(world, mode, lanes):
         if mode == "off":
             assert stats["exchange_rounds"] == 4 * stats["frames"] and stats["repair_frames"] == 0
     print("layered", mode, world, lanes, res[0][1])
+
+
+@pytest.mark.parametrize("world,mode,lanes", [(2, "natural", 2), (3, "all_refusing", 2), (3, "tiny_slots", 2), (2, "natural", 3)])
+def test_layered_frames_that_go_out_model_by_model_are_whole_frames(world, mode, lanes):
+    """With frames in flight a layered frame is enqueued model by model, half of it by the call after its own — after the caller has moved
+    the camera on.  Nothing that completes frames is called inside the loop; frame k is looked at one call late, in its lane's
+    framebuffer (gsx_debug_download_lane_framebuffer: frame k was retired by call k + 1): EVERY frame equals the single-viewer frame,
+    incl. the frames whose repairs are exchanged between two models and the ones that are redone because their slots were too small."""
+    scenes = _layer_scenes()
+    ref = _layer_reference(scenes)
+    poses = list(LPOSES) * 2
+
+    def body(rank, group):
+        v = _layer_viewer(scenes, rank, world, group, lanes)
+        shard_max = {k: (g.shape[0] + world - 1) // world for k, g in scenes.items()}
+        bad = []
+        for k, pose in enumerate(poses):
+            _uniforms(v, pose, (LW, LH))
+            keys = _layer_keys(pose)
+            for key in keys:
+                if mode == "all_refusing":
+                    v.shard_set_limits(key, np.full(LTILES, 0x40400000, np.uint32))
+                elif mode == "tiny_slots":
+                    v.shard_set_slot_records(key, 32)
+            v.shard_render_frame_keys(keys, [shard_max[x] for x in keys])
+            if k >= lanes - 1:   # the frame of call k - (lanes - 1) has just been retired; its lane is not used again before call k + 1
+                j = k - (lanes - 1)
+                fb = v.debug_download_lane_framebuffer(j % lanes)
+                if not np.array_equal(fb, ref[j % len(LPOSES)]):
+                    bad.append((j, float(np.abs(fb - ref[j % len(LPOSES)]).max())))
+        fb = v.download_framebuffer()   # (completes what is in flight: the newest frame)
+        if not np.array_equal(fb, ref[(len(poses) - 1) % len(LPOSES)]):
+            bad.append(("last", float(np.abs(fb - ref[(len(poses) - 1) % len(LPOSES)]).max())))
+        stats = v.shard_stats()
+        v.close()
+        return bad, stats
+
+    res = run_group(world, body)
+    for rank, (bad, stats) in enumerate(res):
+        assert not bad, f"rank {rank} ({mode}, {lanes} lanes): {bad}"
+        assert stats["frames"] == len(poses)
+        if mode == "all_refusing":
+            assert stats["repair_frames"] == stats["frames"]
+        if mode == "tiny_slots":
+            assert stats["redo_frames"] == stats["frames"]
 
 
 def test_cfg5_shape_mask_selection_edit_inside_the_library_call():

@@ -39,7 +39,7 @@ EXPORTS = (
     "gsx_update_selection_edit", "gsx_model_show_unedited", "gsx_postprocess", "gsx_model_upload_selection",
     "gsx_model_download_selection", "gsx_model_download_edits", "gsx_model_upload_edits", "gsx_query_download_hits",
     "gsx_query_hit_pos_by_closest", "gsx_query_hit_pos_by_alpha_range",
-    "gsx_debug_set_launch_graphs", "gsx_debug_launch_count", "gsx_debug_device_bytes", "gsx_viewer_launch_stats", "gsx_debug_tile_profile",
+    "gsx_debug_set_launch_graphs", "gsx_debug_launch_count", "gsx_debug_device_bytes", "gsx_debug_download_lane_framebuffer", "gsx_viewer_launch_stats", "gsx_debug_tile_profile",
     "gsx_viewer_comm_init_custom_v", "gsx_shard_set_band_edges", "gsx_shard_get_band_edges", "gsx_shard_set_balance",
 )
 
@@ -237,6 +237,7 @@ def load() -> C.CDLL:
         "gsx_debug_launch_count": ([], C.c_uint64),
         "gsx_debug_device_bytes": ([], C.c_uint64),
         "gsx_debug_tile_profile": ([vp, u32p, u64], C.c_int32),
+        "gsx_debug_download_lane_framebuffer": ([vp, C.c_uint32, C.c_void_p, u64], C.c_int32),
         "gsx_viewer_launch_stats": ([vp, C.POINTER(LaunchStats), u32], C.c_int32),
         "gsx_set_pass_timing": ([vp, u32], C.c_int32),
         "gsx_get_pass_timing": ([vp, f32p, u32p], C.c_int32),

@@ -688,6 +688,17 @@ gsx_status gsx_download_framebuffer(gsx_viewer* v, float* rgbt, uint64_t n_float
     return GSX_OK;
 }
 
+gsx_status gsx_debug_download_lane_framebuffer(gsx_viewer* v, uint32_t lane, float* rgbt, uint64_t n_floats) {
+    if (!v || v->parent || lane > v->lanes.size()) return fail(GSX_ERR_INVALID_ARG, "gsx_debug_download_lane_framebuffer: no such lane");
+    HIPCHK(hipSetDevice(v->device));
+    gsx_viewer* l = lane == 0 ? v : v->lanes[lane - 1];
+    const uint64_t need = 4ull * l->width * l->height;
+    if (!rgbt || n_floats != need || !fb_ptr(l)) return fail(GSX_ERR_INVALID_ARG, "gsx_debug_download_lane_framebuffer: expected %llu floats of a lane that has rendered", (unsigned long long)need);
+    HIPCHK(gsx::op::StreamSynchronize(l->stream));  // (NOT viewer_bind: the frames in flight stay as they are)
+    HIPCHK(gsx::op::Memcpy(rgbt, fb_ptr(l), sizeof(float) * need, hipMemcpyDeviceToHost));
+    return GSX_OK;
+}
+
 gsx_status gsx_download_rgba8(gsx_viewer* v, const float bg[3], uint8_t* rgba, uint64_t n_bytes) {
     gsx_status st = viewer_bind(v);
     if (st) return st;

@@ -480,6 +480,13 @@ class MultiModelViewer:
     def comm_destroy(self) -> None:
         _lib.check(self._L.gsx_viewer_comm_destroy(self._h))
 
+    def debug_download_lane_framebuffer(self, lane: int) -> np.ndarray:
+        """Tests: lane `lane`'s framebuffer once its stream has drained, WITHOUT completing the frames in flight."""
+        w, h = self.size
+        out = np.empty((h, w, 4), np.float32)
+        _lib.check(self._L.gsx_debug_download_lane_framebuffer(self._h, int(lane), out.ctypes.data, out.size))
+        return out
+
     def shard_render_frame(self, key: str, shard_records_max: int, speculate: bool = True, margin: float = 0.25, radius: int = 3) -> None:
         """One whole index-sharded frame of this rank (``gsx_shard_render_frame``)."""
         _lib.check(self._L.gsx_shard_render_frame(self._h, key.encode(), int(shard_records_max), 1 if speculate else 0, float(margin), int(radius)))
