@@ -72,6 +72,11 @@ python3 tools/rank_alone.py --workload cfg5 --worlds 2,4,8 --scenes orbit --fram
 python3 tools/rank_alone.py --worlds 8 --scenes orbit --lanes 1 --speculate 1 --frames 60 --python-replay --out $OUT/rank_alone_python_replay.json > /dev/null 2>> $OUT/rank_alone.err
 [ -f build_variants/libgsx_base.so ] && tools/ab_shard.sh base new > $OUT/ab_shard.txt 2>&1
 python3 tools/ab_blocks.py > $OUT/ab_blocks.txt 2>> $OUT/bench.err
+# 11. layered frames model by model (frames in flight) against all models at once with device-decided repairs: cfg5 at world 1 and every rank of a
+#     world-8 cfg5 frame alone; thousands of layered frames, every one looked at one call late
+(for P in 0 1; do echo "== GSX_SHARD_LAYER_PIPELINE=$P: cfg5 through gsx_shard_render_frame_keys at world 1"; GSX_SHARD_LAYER_PIPELINE=$P python3 tools/bench_cfg5.py --edit 0 --shard 1 2>/dev/null | tail -1
+ echo "== GSX_SHARD_LAYER_PIPELINE=$P: every rank of a world-8 cfg5 frame alone, two frames in flight"; GSX_SHARD_LAYER_PIPELINE=$P python3 tools/rank_alone.py --workload cfg5 --worlds 8 --scenes orbit --lanes 2 --speculate 1 --frames 50 --no-pass-replay 2>&1 >/dev/null | grep predicted; done) > $OUT/ab_layer_pipeline.txt 2>&1
+python3 tools/long_run_layers.py 8000 2>&1 | grep "world\|long run\|Error" > $OUT/long_run_layers.txt
 for n in 100000 310000 870000; do
   echo "== n=$n, 2048-element tiles off" >> $OUT/ab_radix_small.txt; GSX_RADIX_SMALL=0 tools/bench_sort $n 32 depth >> $OUT/ab_radix_small.txt 2>&1
   echo "== n=$n, default" >> $OUT/ab_radix_small.txt; tools/bench_sort $n 32 depth >> $OUT/ab_radix_small.txt 2>&1

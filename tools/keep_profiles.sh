@@ -16,5 +16,5 @@ cpf $S/pmc_summary.csv $P/${R}_cfg4_pmc_summary.csv
 for f in bench_cfg2 bench_cfg3 bench_half_half bench_norm8_half bench_index_world1_inflight1 bench_index_world1_inflight2 bench_index_world1_inflight3 \
          bench_inflight1 bench_inflight3 bench_cfg5 bench_ranks_on_one_gpu_world2 bench_ranks_on_one_gpu_world8 rank_alone rank_alone_equal_bands rank_alone_cfg5 \
          rank_alone_python_replay rows; do cpf $S/$f.json $P/${R}_$f.json; done
-for f in bench_hbm bench_sort shard_host_time bench_launch graph_probe tile_profile tile_profile_index_order ab_tile_order bench_atomic ab_shard ab_blocks ab_radix_small; do cpf $S/$f.txt $P/${R}_$f.txt; done
+for f in bench_hbm bench_sort shard_host_time bench_launch graph_probe tile_profile tile_profile_index_order ab_tile_order bench_atomic ab_shard ab_blocks ab_radix_small ab_layer_pipeline long_run_layers; do cpf $S/$f.txt $P/${R}_$f.txt; done
 ls -la $P/${R}_* | awk '{print $5, $9}'

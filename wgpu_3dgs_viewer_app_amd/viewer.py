@@ -480,9 +480,10 @@ class MultiModelViewer:
     def comm_destroy(self) -> None:
         _lib.check(self._L.gsx_viewer_comm_destroy(self._h))
 
-    def debug_download_lane_framebuffer(self, lane: int) -> np.ndarray:
-        """Tests: lane `lane`'s framebuffer once its stream has drained, WITHOUT completing the frames in flight."""
-        w, h = self.size
+    def debug_download_lane_framebuffer(self, lane: int, size=None) -> np.ndarray:
+        """Tests: lane `lane`'s framebuffer once its stream has drained, WITHOUT completing the frames in flight (size: the viewport of
+        the frame that lane holds, if the viewer's has changed since)."""
+        w, h = size if size is not None else self.size
         out = np.empty((h, w, 4), np.float32)
         _lib.check(self._L.gsx_debug_download_lane_framebuffer(self._h, int(lane), out.ctypes.data, out.size))
         return out
