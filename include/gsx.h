@@ -474,12 +474,11 @@ gsx_status gsx_shard_render_frame(gsx_viewer* v, const char* key, uint32_t shard
  * (src/tab/scene.rs:533-558, 2302-2314), gsx_render does the same on one GPU.  Every model is index-sharded over the ranks
  * (shard_records_max[i] = largest shard of keys_far_to_near[i]); each keeps its own per-tile limits from frame to frame.  Per
  * model: exchange -> composite into this rank's band behind the nearer models -> verification -> repair exchange; one band
- * all-gather at the end.  With one frame in flight the inner models' repair exchanges are always enqueued with fixed-size slots and
- * decided on the device (nothing waits between two models), the last model's is decided when the frame is retired.  With
- * frames_in_flight >= 2 the frame goes out model by model, a call alternating between what is left of the frame before and the new one:
- * the verdict of model i - 1 is read before model i is enqueued, every repair is exchanged exactly sized, and the call returns with
- * half the new frame's models enqueued (any call that looks at a result completes them).  Pixels equal gsx_render(keys_far_to_near)
- * on one GPU bit for bit. */
+ * all-gather at the end.  The frame goes out model by model: the verdict of model i - 1 is read (a pinned word) before model i is
+ * enqueued, and its repair is exchanged exactly sized where one is needed.  With frames_in_flight >= 2 a call alternates between what
+ * is left of the frame before and the new one, and returns with half the new frame's models enqueued (any call that looks at a result
+ * completes them).  GSX_SHARD_LAYER_PIPELINE=0: all models at once, the inner models' repair exchanges always enqueued with fixed-size
+ * slots and decided on the device (measured slower).  Pixels equal gsx_render(keys_far_to_near) on one GPU bit for bit. */
 gsx_status gsx_shard_render_frame_keys(gsx_viewer* v, const char* const* keys_far_to_near, uint32_t n_keys,
                                        const uint32_t* shard_records_max, uint32_t speculate, float margin, uint32_t radius);
 

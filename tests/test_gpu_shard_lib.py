@@ -330,11 +330,20 @@ def _layer_reference(scenes, poses=LPOSES):
     return out
 
 
+@pytest.fixture(params=["model_by_model", "all_at_once"])
+def layer_schedule(request):
+    return request.param
+
+
 @pytest.mark.parametrize("world,mode,lanes", [(2, "natural", 1), (4, "natural", 1), (3, "all_refusing", 1), (4, "tiny_slots", 1),
                                               (3, "off", 1), (2, "natural", 2), (4, "all_refusing", 2), (3, "tiny_slots", 2), (2, "natural", 3)])
-def test_layered_models_inside_the_library_call(world, mode, lanes):
+def test_layered_models_inside_the_library_call(world, mode, lanes, monkeypatch, layer_schedule):
     """Four models with their own TRS, layered far -> near in an order that changes with the camera, every model
-    index-sharded over `world` ranks, ONE C-ABI call per frame and rank: equal to gsx_render_frame(keys) on one GPU."""
+    index-sharded over `world` ranks, ONE C-ABI call per frame and rank: equal to gsx_render_frame(keys) on one GPU.
+    layer_schedule: model by model with host-decided repairs (the default) / all models at once with the inner models' repair
+    exchanges always enqueued and decided on the device (GSX_SHARD_LAYER_PIPELINE=0)."""
+    if layer_schedule == "all_at_once":
+        monkeypatch.setenv("GSX_SHARD_LAYER_PIPELINE", "0")
     scenes = _layer_scenes()
     ref = _layer_reference(scenes)
     assert len({tuple(_layer_keys(p)) for p in LPOSES}) >= 2, "the layer order must change along the path"

@@ -659,10 +659,14 @@ gsx_status gsx_shard_render_frame_keys(gsx_viewer* v, const char* const* keys_fa
     p.speculate = speculate;
     p.margin = margin;
     p.radius = radius;
-    // layered models with frames in flight: model by model, interleaved with the frame before (frame_step; GSX_SHARD_LAYER_PIPELINE=0: all
-    // models at once with device-decided repairs, as with one frame in flight)
-    static const bool layer_pipeline = !(getenv("GSX_SHARD_LAYER_PIPELINE") && atoi(getenv("GSX_SHARD_LAYER_PIPELINE")) == 0);
-    p.stepped = layer_pipeline && lanes > 1 && n_keys > 1 && speculate != 0;
+    // layered models: model by model, with frames in flight interleaved with the frame before (frame_step)
+    // (GSX_SHARD_LAYER_PIPELINE, read per frame — tests switch it: 0 = all models at once with device-decided repairs; 1 = model by model
+    //  only with frames in flight; default 2 = always.  With ONE frame in flight nothing hides the host's look at a verdict, and model by
+    //  model still wins: the look is a spin on a pinned word, ~20 us a model, against ~22 fall-through launches a model — cfg5 at world 1
+    //  397 -> 475 fps, a world-8 rank alone 1.19 -> 1.13 ms, profiles/r05_ab_layer_pipeline.txt)
+    const char* lp = getenv("GSX_SHARD_LAYER_PIPELINE");
+    const int layer_pipeline = lp ? atoi(lp) : 2;
+    p.stepped = layer_pipeline != 0 && (lanes > 1 || layer_pipeline == 2) && n_keys > 1 && speculate != 0;
     Ctx c{v, lane, &p, v->comm_world, v->comm_rank, {}, 0, {}, 0, 0};
     // The band gather is enqueued with the frame when the call is going to wait for this frame anyway (one frame in flight: the gather
     // runs while the verdict travels); with frames in flight it waits for the retirement — a third of cfg4's orbit frames repair their last
