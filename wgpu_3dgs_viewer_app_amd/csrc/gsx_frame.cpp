@@ -4,6 +4,7 @@
 // + radix sort (K2), then the far -> near render loop (K3).  Nothing here waits for the device: counts stay in HBM, the host
 // plans upper bounds, overflow and statistics are looked at lazily (finish_frame).
 #include "gsx_state.h"
+#include <sched.h>
 #include <chrono>
 #include <thread>
 #include <cstdlib>
@@ -53,11 +54,10 @@ static gsx_status wait_verdict(gsx_viewer* v, uint32_t seq, uint32_t* need) {
             }
             if (e != hipErrorNotReady) return fail(GSX_ERR_HIP, "stream failed while waiting for the speculation verdict: %s", hipGetErrorString(e));
         }
-        if (spin > 4096) {
-            std::this_thread::sleep_for(std::chrono::microseconds(20));  // a long wait (the host was frames ahead): yield
-        } else {
-            __builtin_ia32_pause();
-        }
+        // (spinning, like the sharded frame's ring wait: a sleep's wake-up is tens of microseconds of timer slack, i.e. a bubble on the
+        //  device behind every verdict; a wait that has outlasted any frame yields its core between looks)
+        if (spin > 200000u) sched_yield();
+        else __builtin_ia32_pause();
     }
 }
 

@@ -340,7 +340,6 @@ struct ShardPending {
     bool stepped = false;
     uint32_t next_model = 0, read_models = 0;
     bool overflowed = false;                  // a slot of a model read so far overflowed: the frame is redone when it is retired
-    bool host_repair_last = false;
 };
 
 struct gsx_viewer {
