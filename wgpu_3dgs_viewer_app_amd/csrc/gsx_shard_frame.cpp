@@ -3,26 +3,29 @@
 // counterpart (src/main.rs:85-98: one wgpu device); what it must reproduce is the single-GPU frame — for several models the
 // reference's layering: painted far -> near, never merged (src/tab/scene.rs:533-558, 2302-2314).
 //
-// The frame, per model in COMPOSITING order (nearest first; the far -> near key list walked backwards, as gsx_render does).  The
-// call ENQUEUES all of it and returns; nothing in it waits for the device (round 5 — until then the host read a verdict per
-// model and decided about the repair round):
+// The frame, per model in COMPOSITING order (nearest first; the far -> near key list walked backwards, as gsx_render does):
 //   gsx_shard_frame_begin of every model (projection; windows from the model's own limits of its last frame), then for each model:
 //   round 0   pack -> all-to-all of fixed slots -> import + depth sort + composite into this rank's band (behind the nearer
 //             models) -> feedback -> all-gather of the saturation map -> verification: which tiles were refused records they
 //             still need, their repair windows, the count — all on the device (the verdict block staged in device memory).
-//   round 1   the repair exchange.  For every model that has another model BEHIND it: always enqueued, with slots of a fixed size R
-//             (twice the largest repair of the last frames, a maximum that decays by a sixteenth per frame): its kernels look at
-//             the verification's count and fall through when no tile needs anything; the all-to-all moves the (empty) slots
-//             regardless; feedback + all-gather once more.  Nothing may wait between two models.  For the frame's LAST model (a
-//             single model always): decided by the host when the frame is retired, exactly sized, only in the frames that need it —
-//             with frames in flight that look is off the critical path anyway, and a frame that repairs nothing pays neither ~15
-//             fall-through launches nor `world` empty slots (measured, cfg4 at world 1: 1100 / 1200 fps with one / two frames in
-//             flight when the device decided for the single model too, 1450 / 1690 when the host does; GSX_SHARD_REPAIR_DEVICE=1).
-//   verdict   one kernel posts the model's verdict block — tiles that needed the repair, a slot of either round overflowed, the
-//             count matrix, next frame's band edges — into slot (seq mod ring) of a pinned ring; next limits from the last
-//             gathered saturation map.  The next model follows at once: its records are composited behind a finished model.
+//   verdict   one kernel posts the model's verdict block — tiles that needed the repair, a slot overflowed, the count matrix, next
+//             frame's band edges — into slot (seq mod ring) of a pinned ring; next limits from the gathered saturation map.
+//   round 1   the repair exchange, decided by the HOST from the verdict block: exactly sized, only where a tile needs it.
+//             * ONE model: the whole frame is enqueued and the call returns; the verdict is read when the frame is retired (below) —
+//               with frames in flight that look is off the critical path, and a frame that repairs nothing pays nothing.
+//             * LAYERED models go out model by model (frame_step): the verdict of model i - 1 is read before model i is enqueued and
+//               its repair exchanged behind model i - 1, in front of model i.  With frames in flight a call alternates between what is
+//               left of the frame before and the new frame, one model per turn: the verdict a turn waits for belongs to a model that
+//               went out a turn ago and the other frame's model keeps the device busy; the new frame is left with half its models out.
+//             * the alternative, built first in round 5 and kept as the A/B (GSX_SHARD_LAYER_PIPELINE=0; GSX_SHARD_REPAIR_DEVICE=1
+//               for the last model too): all models at once, the repair exchange of every model that has another BEHIND it always
+//               enqueued with slots of a fixed size R (twice the largest repair of the last frames, a maximum that decays by a
+//               sixteenth per frame) and decided on the device — its kernels fall through when no tile needs anything, the all-to-all
+//               moves the (empty) slots regardless.  No host look anywhere; ~22 fall-through launches per inner model and `world`
+//               empty slots per round.  Measured slower on every count: cfg5 at world 1 396 -> 489 fps with one frame in flight,
+//               497 -> 605 with two; cfg4 with the device deciding for the single model too 1100 / 1200 against 1450 / 1690.
 //   then the in-place band gather.
-// The verdicts are read when the frame is RETIRED: after frame k is enqueued, every frame but the newest L - 1 is retired
+// The verdicts (of a layered frame: the last model's) are read when the frame is RETIRED: after frame k is enqueued, every frame but the newest L - 1 is retired
 // (L = gsx_render_options.frames_in_flight), on every rank alike — what they say (slot sizes pair by pair, band edges, the repair
 // slot size) is what every rank plans the next frame with.  With L >= 2 the verdict of frame k - L + 1 arrived while frame k was
 // being enqueued and the device has L - 1 frames queued meanwhile: nothing waits.  With L = 1 the call waits for its own frame's
