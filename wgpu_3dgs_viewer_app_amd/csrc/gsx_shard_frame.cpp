@@ -490,7 +490,7 @@ gsx_status read_verdict(Ctx& c, size_t i, bool* overflow, bool* need) {
 // A layered frame with frames in flight goes out MODEL BY MODEL, its steps interleaved with another frame's (gsx_shard_render_frame_keys):
 // before model i is enqueued the verdict of model i - 1 is read — it was enqueued a step ago, and meanwhile the host enqueued a model of
 // the other frame, whose kernels keep the device busy — and its repair, where one is needed, is exchanged exactly sized.  No always-
-// enqueued repair rounds: cfg5's three inner models paid ~22 fall-through launches each per frame, and the host, at ~4.5 us a launch,
+// enqueued repair rounds: cfg5's three inner models paid ~22 fall-through launches each per frame, and the host, at ~3 us a launch,
 // was what bounded two frames in flight.  false in *more: the frame has no model left (frame_retire reads the last model's verdict).
 gsx_status frame_step(gsx_viewer* owner, ShardPending& p, bool* more) {
     const size_t n = p.order.size();
