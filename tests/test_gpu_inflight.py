@@ -280,3 +280,27 @@ def test_colour_ops_with_frames_in_flight_unsynchronised(lanes, monkeypatch):
     assert edits_v.tobytes() == edits_r.tobytes(), "the stored edits are the same whichever lane rendered"
     v.close()
     ref.close()
+
+
+def test_a_closed_viewer_gives_every_device_byte_back():
+    """gsx_debug_device_bytes counts what every device buffer of the process holds (the bench line's resident_bytes): viewers with one
+    and three lanes, speculated and unspeculated frames, a viewport change, a removed and re-created model — after gsx_viewer_destroy
+    the count is where it started, and while the viewer lives it covers at least the model's planes."""
+    from wgpu_3dgs_viewer_app_amd import viewer as viewer_mod
+    g = common.small_scene(20000, 7)
+    before = viewer_mod.device_bytes()
+    for lanes in (1, 3):
+        v = _viewer(lanes)
+        _load(v, "m", g)
+        for k, pose in enumerate((3, 4, 5, 120, 121, 6)):
+            _enqueue(v, pose, ["m"], (W, H) if k < 4 else (320, 208))
+        v.poll()
+        held = viewer_mod.device_bytes() - before
+        assert held >= 236 * g.shape[0], f"{held} bytes for {g.shape[0]} Gaussians: less than the planes alone"
+        v.remove_model("m")
+        _load(v, "m", g)
+        v.set_render_options(speculative=0, frames_in_flight=lanes)
+        _enqueue(v, 7, ["m"])
+        v.poll()
+        v.close()
+        assert viewer_mod.device_bytes() == before, f"{lanes} lane(s): {viewer_mod.device_bytes() - before} bytes still held after close"
