@@ -69,6 +69,7 @@ def parse_args():
     ap.add_argument("--workload", default="cfg4", help="cfg2 (1 M) | cfg3 (5.8 M) | cfg4 (10 M, headline)")
     ap.add_argument("--gaussians", type=int, default=0, help="override the Gaussian count (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cfg5", action="store_true", help="N=1: skip the compact BASELINE configs[4] leg (4 x 6 M Gaussians at 3840x2160, ~10 s)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="Gaussians in the CPU baseline (0 = the whole scene)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC child passes (roofline.traffic = null)")
     ap.add_argument("--no-robustness", action="store_true", help="skip the speculation-robustness legs (random pose order, open sky)")
@@ -107,9 +108,11 @@ def parse_args():
     return a
 
 
-def cpu_baseline(cfg, n_sample, pose=0):
+def cpu_baseline(cfg, n_sample, pose=0, keep=False):
     """Oracle (reference algorithm shape: cull -> global radix sort -> back-to-front splat-major raster) on the
-    host cores: one frame of the same scene (the whole scene unless --cpu-sample bounds it)."""
+    host cores: one frame of the same scene (the whole scene unless --cpu-sample bounds it).  Timed: gsxo_project +
+    gsxo_depth_sort + gsxo_rasterize — exactly what gsxo_render_model runs, called one by one so that `keep` can hand the depth keys,
+    tile rectangles, depth order and frame to the oracle check (bench.py never routes a product result through them)."""
     import oracle
     from wgpu_3dgs_viewer_app_amd import camera, scene
 
@@ -124,12 +127,120 @@ def cpu_baseline(cfg, n_sample, pose=0):
     oracle.render_model(f, pos[:1000], color[:1000], shc[:1000], cov[:1000], fb)  # page in / thread start
     fb = oracle.new_framebuffer(f)
     t0 = time.perf_counter()
-    nvis = oracle.render_model(f, pos, color, shc, cov, fb)
+    pr = oracle.project(f, pos, color, shc, cov)
+    idx, nvis = oracle.depth_sort(pr["key"])
+    oracle.rasterize(f, pr, idx, nvis, fb)
     dt = time.perf_counter() - t0
     what = "the whole scene" if n_sample == n else f"the first {n_sample} of {n} Gaussians of the same scene"
-    return dict(value=round(1.0 / dt, 4), unit="frames/s", cores=oracle.num_threads(), kind="port",
-                sample=f"1 frame (orbit pose {pose}) of {what} ({n_sample} Gaussians) at {w}x{h}, N_vis={nvis}, {dt:.2f} s; "
-                       "oracle/gsx_oracle.c (cull -> LSD radix sort -> back-to-front splat-major 'over'), OpenMP")
+    res = dict(value=round(1.0 / dt, 4), unit="frames/s", cores=oracle.num_threads(), kind="port",
+               sample=f"1 frame (orbit pose {pose}) of {what} ({n_sample} Gaussians) at {w}x{h}, N_vis={nvis}, {dt:.2f} s; "
+                      "oracle/gsx_oracle.c (cull -> LSD radix sort -> back-to-front splat-major 'over'), OpenMP")
+    return (res, dict(key=pr["key"], rect=pr["rect"], order=idx[:nvis], n_visible=nvis, fb=fb) if n_sample == n else None) if keep else res
+
+
+def oracle_check_of(gpu, ref, pose):
+    """The HIP path's frame of the pose the CPU baseline rendered, against that very frame: integer stages bit-exact,
+    the frame within north_star's 1e-3 per-channel L-infinity — from the plainest schedule AND from a speculated frame of the default one."""
+    out = dict(pose=pose, tolerance=1e-3,
+               n_visible_equal=bool(gpu["n_visible"] == ref["n_visible"]), n_visible=int(ref["n_visible"]),
+               keys_equal=bool(np.array_equal(gpu["key"], ref["key"])), rects_equal=bool(np.array_equal(gpu["rect"], ref["rect"])),
+               depth_order_equal=bool(np.array_equal(gpu["order"], ref["order"])),
+               linf_plain=float(np.abs(gpu["fb_plain"] - ref["fb"]).max()), linf_speculated=float(np.abs(gpu["fb_spec"] - ref["fb"]).max()),
+               speculated_frame_was_speculated=bool(gpu["speculated"]), speculated_equals_plain=bool(np.array_equal(gpu["fb_plain"], gpu["fb_spec"])),
+               what="gsx_preprocess + gsx_sort + gsx_render (speculative = 0, progressive = 0) and the default schedule's frame of the same pose "
+                    "(arrived at along the orbit, frames in flight as in `value`) against oracle/gsx_oracle.c's frame of the whole scene — the frame "
+                    "cpu_baseline timed: depth keys + cull set, tile rectangles and depth order bit-exact, both frames within 1e-3 per channel")
+    out["linf"] = max(out["linf_plain"], out["linf_speculated"])
+    out["ok"] = bool(out["n_visible_equal"] and out["keys_equal"] and out["rects_equal"] and out["depth_order_equal"] and out["linf"] <= out["tolerance"])
+    return out
+
+
+def cfg5_leg(steps=60, warmup=12):
+    """BASELINE.json configs[4] on this GPU, compact (tools/bench_cfg5.py is the long form): 4 models x 6 M Gaussians
+    SH-3, each with its own TRS, a `0 - 1` mask (box minus ellipsoid, src/app.rs:1660-1783 grammar) on one, a stored rect selection with
+    an HSV edit, 3840x2160, models layered far -> near by camera distance every frame (scene.rs:533-558)."""
+    from wgpu_3dgs_viewer_app_amd import camera, parallel, query, scene
+    from wgpu_3dgs_viewer_app_amd.mask import MaskEvaluator, MaskOp, MaskShape, MaskShapeKind
+    from wgpu_3dgs_viewer_app_amd import viewer as viewer_mod
+    from wgpu_3dgs_viewer_app_amd.viewer import GaussianDisplayMode, GaussianShDegree, MultiModelViewer
+
+    t_all = time.perf_counter()
+    n_total, sh, w, h, seed = scene.CONFIGS["cfg5"]
+    n = n_total // 4
+    tr = {"a": camera.ModelTransform(pos=np.array([0.0, 0.0, 2.5], np.float32)),
+          "b": camera.ModelTransform(pos=np.array([2.0, 0.2, -1.0], np.float32), rot=np.array([0, 35, 0], np.float32)),
+          "c": camera.ModelTransform(pos=np.array([-2.5, -0.1, -0.5], np.float32), scale=np.array([0.9, 0.9, 0.9], np.float32)),
+          "d": camera.ModelTransform(pos=np.array([0.3, -0.2, 0.5], np.float32), rot=np.array([20, -35, 50], np.float32),
+                                     scale=np.array([1.2, 0.9, 1.1], np.float32))}
+    v = MultiModelViewer()
+    try:
+        for i, k in enumerate(tr):
+            g = scene.synthetic_gaussians(n, seed + i, sh)
+            v.add_model(k, n)
+            v.models[k].gaussian_buffers.gaussians_buffer.update_range(0, g)
+            v.update_model_transform(k, tr[k].pos, tr[k].quat(), tr[k].scale)
+            del g
+        shapes = [MaskShape(MaskShapeKind.Box, pos=np.array([0.0, 0.0, 2.5], np.float32), scale=np.array([3.0, 3.0, 3.0], np.float32)),
+                  MaskShape(MaskShapeKind.Ellipsoid, pos=np.array([0.0, 0.0, 2.5], np.float32), scale=np.array([1.5, 1.5, 1.5], np.float32))]
+        MaskEvaluator(v).evaluate(MaskOp.parse("0 - 1"), "a", shapes)
+        orbit = [camera.PrecomputedCamera(camera.orbit_pose(k), w / h) for k in range(240)]
+        keys_of = [parallel.model_render_keys(camera.orbit_pose(k).pos, tr) for k in range(240)]
+
+        def frame(i):
+            v.update_camera(orbit[i % 240], (w, h))
+            v.update_gaussian_transform(1.0, GaussianDisplayMode.Splat, GaussianShDegree.new(3), False)
+            v.render_frame(keys_of[i % 240])
+
+        # the stored selection: a rectangle on the frame of pose 0, Set; then the HSV edit of what it selected (GaussianEditPod per Gaussian)
+        v.update_query(query.QueryPod.rect((1200.0, 600.0), (2600.0, 1500.0), query.QuerySelectionOp.Set))
+        frame(0)
+        for k in keys_of[0]:
+            v.postprocessor.postprocess(k)
+        v.update_query(query.QueryPod.none())
+        v.update_selection_edit_with_pod(query.GaussianEditPod(query.GaussianEditFlag.ENABLED, (0.5, 1.0, 1.2), 0.1, 0.2, 1.0, 0.9))
+
+        spilled = [0]   # depth slabs of the TIMED frames that did not fit the pair buffers (complete frames, slow path)
+
+        def overflow_now():
+            return int(sum(v.frame_stats(k)["overflow_slabs"] for k in tr))
+
+        def loop(**opts):
+            v.set_render_options(**opts)
+            for i in range(warmup):
+                frame(i)
+            v.poll()
+            ov0 = overflow_now()
+            l0 = viewer_mod.launch_count()
+            t0 = time.perf_counter()
+            for i in range(warmup, warmup + steps):
+                frame(i)
+            v.poll()
+            dt = time.perf_counter() - t0
+            launched = viewer_mod.launch_count() - l0
+            spilled[0] += overflow_now() - ov0
+            return round(steps / dt, 1), round(launched / steps, 1)
+
+        fps1, launches1 = loop()
+        fps2, _ = loop(frames_in_flight=2)
+        fb_two = v.download_framebuffer().copy()   # the last frame of the two-lane loop ...
+        fpsu, launchesu = loop(speculative=0)
+        v.set_render_options(speculative=0, progressive=0)
+        frame(warmup + steps - 1)                  # ... and its pose through the plainest schedule
+        equal = bool(np.array_equal(v.download_framebuffer(), fb_two))
+        st = {k: v.frame_stats(k) for k in tr}
+        res = dict(workload=f"cfg5: 4 x {n} Gaussians SH-3, {w}x{h}, TRS per model, mask '0 - 1' on one, stored rect selection + HSV edit; "
+                            "gsx_render_frame(keys far -> near), one GPU",
+                   fps_one_frame_in_flight=fps1, fps_two_frames_in_flight=fps2, fps_unspeculated=fpsu, steps=steps,
+                   launches_per_frame=dict(one_frame_in_flight=launches1, unspeculated=launchesu),
+                   frame_check=dict(equal_to_unspeculated_single_pass=equal, pose=(warmup + steps - 1) % 240),
+                   n_visible=int(sum(s["n_visible"] for s in st.values())), overflow_slabs=int(spilled[0]),
+                   resident_bytes=int(viewer_mod.device_bytes()))
+    finally:
+        v.close()
+    res["leg_seconds"] = round(time.perf_counter() - t_all, 1)
+    if not res["frame_check"]["equal_to_unspeculated_single_pass"]:
+        raise SystemExit(f"bench.py: cfg5's two-lane frame differs from the speculative=0, progressive=0 frame: {res}")
+    return res
 
 
 # ------------------------------------------------------------------------------------------------
@@ -340,6 +451,7 @@ def main():
         return elapsed, timing, first + rounds(steps) - 1
 
     launches = {}
+    closed = False
 
     def accounting(first_round, frames=32):
         """Untimed pass over the same poses: per-frame device counts (reading them costs a sync per frame)."""
@@ -605,6 +717,28 @@ def main():
         extra["passes_raw"] = dict(speculated=(el_p, tm_p, ac_p), unspeculated=(el_pu, tm_pu, ac_pu))
         set_opts()
 
+    # ---- N = 1: the GPU side of the oracle check — pose 0 of the whole scene, the frame cpu_baseline renders on the host cores ----
+    gpu_pose0 = None
+    if single and not overrides and not args.no_cpu_baseline and not args.cpu_sample and args.pose_order == "orbit" and args.pose_stride == 1:
+        key = renderer.KEY
+        set_opts(speculative=0, progressive=0)
+        renderer.stages.set_uniforms(key, orbit[0], (w, h))
+        viewer.preprocessor.preprocess(key)
+        viewer.radix_sorter.sort(key)
+        viewer.poll()
+        gp = viewer.download_projection(key)
+        gpu_pose0 = dict(key=gp["key"], rect=gp["rect"], n_visible=gp["n_visible"], order=viewer.download_sorted(key).copy())
+        del gp
+        viewer.renderer.render([key])
+        gpu_pose0["fb_plain"] = viewer.download_framebuffer().copy()
+        set_opts(frames_in_flight=lanes)          # the headline schedule, arriving at pose 0 along the orbit
+        for i in (232, 233, 234, 235, 236, 237, 238, 239, 240):
+            frame(i)
+        renderer.poll()
+        gpu_pose0["fb_spec"] = renderer.framebuffer().copy()
+        gpu_pose0["speculated"] = bool(renderer.last_stats().get("speculated"))
+        set_opts()
+
     # ---- N = 1: speculation robustness legs (same process, same resident scene) ----
     robustness = None
     if single and not overrides and not args.no_robustness and not args.pose_stride > 1 and args.pose_order == "orbit":
@@ -715,11 +849,15 @@ def main():
                   "timed frame, list_entries_max_over_mean the ranks' binned entries",
             wire_bytes_per_frame_unspeculated=[int(x) for x in g_all[:, 15]] if shard_stats_unspec else None,
             redone_frames_redone_again_with_whole_shard_slots=[int(x) for x in g_all[:, 16]], repair_slot_records_last_frame=[int(x) for x in g_all[:, 17]],
-            protocol="every frame is enqueued whole — both exchange rounds of every model, the repair round deciding on the device whether it has "
-                     "anything to do — and its verdict is read when the frame is retired (frames in flight: after the next frame is enqueued; "
-                     "verdict_wait_us_per_frame is what the host waited then); a frame whose slots overflowed is redone at its retirement, before "
-                     "its lane is used again and before anybody can read it (frames_redone_with_whole_shard_slots)")
+            protocol=("a single model's frame is enqueued whole and nothing in it waits for the device; its verdict is read when the frame is "
+                      "retired (frames in flight: after the next frame is enqueued; verdict_wait_us_per_frame is what the host waited then) and the "
+                      "repair round, where the verdict asks for one, is exchanged exactly sized at that point (host-decided; layered frames go out "
+                      "model by model the same way); a frame whose slots overflowed is redone at its retirement, before its lane is used again and "
+                      "before anybody can read it (frames_redone_with_whole_shard_slots)"
+                      + ("; GSX_SHARD_REPAIR_DEVICE / GSX_SHARD_LAYER_PIPELINE=0 in force: repair rounds always enqueued, decided on the device"
+                         if (os.environ.get("GSX_SHARD_REPAIR_DEVICE", "0") not in ("", "0") or os.environ.get("GSX_SHARD_LAYER_PIPELINE") == "0") else "")))
 
+    comm_info = viewer.comm_info() if lib_index else None
     if rank == 0:
         fps = args.steps / elapsed
         sh_bytes = {0: 180, 1: 96, 2: 48, 3: 0}[sh_kind if sh > 0 else 3]
@@ -935,13 +1073,32 @@ def main():
             summary["robustness_fps"] = {k: [v["speculated"]["fps"], v["unspeculated"]["fps"]] for k, v in robustness.items() if isinstance(v, dict)}
         if per_rank is not None:
             summary["per_rank_wire_bytes_per_frame"] = per_rank["wire_bytes_per_frame"]
-        out["summary"] = summary
+        if lib_index:
+            # what RCCL itself says about the communicator the frames ran over (ncclCommCount / ncclCommUserRank / ncclGetVersion)
+            out["rccl"] = comm_info
+        # BASELINE configs[4] on this GPU (the main scene's buffers are released first) and the oracle check of the headline config
+        renderer.close()
+        closed = True
+        cpu_res = None
+        if single and not overrides and not args.no_cfg5 and not args.no_extra_legs:
+            out["cfg5"] = cfg5_leg()
+            summary["cfg5_fps"] = [out["cfg5"]["fps_one_frame_in_flight"], out["cfg5"]["fps_two_frames_in_flight"], out["cfg5"]["fps_unspeculated"]]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample)
+            cpu_res, oracle_frame = cpu_baseline(cfg, args.cpu_sample, keep=True)
+            if gpu_pose0 is not None and oracle_frame is not None:
+                out["oracle_check"] = oracle_check_of(gpu_pose0, oracle_frame, 0)
+                summary["oracle_check"] = {k: out["oracle_check"][k] for k in ("ok", "linf_plain", "linf_speculated", "keys_equal", "rects_equal",
+                                                                                "depth_order_equal", "n_visible_equal")}
+        out["summary"] = summary
+        if cpu_res is not None:
+            out["cpu_baseline"] = cpu_res
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        if "oracle_check" in out and not out["oracle_check"]["ok"]:
+            raise SystemExit(f"bench.py: the HIP frame of pose 0 differs from the oracle's: {out['oracle_check']}")
 
-    renderer.close()
+    if not closed:
+        renderer.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -462,6 +462,15 @@ gsx_status gsx_shard_download_limits(gsx_viewer* v, const char* key, uint32_t* l
 gsx_status gsx_comm_unique_id(uint8_t out_id[128]);
 gsx_status gsx_viewer_comm_init(gsx_viewer* v, uint32_t world, uint32_t rank, const uint8_t id[128]);
 gsx_status gsx_viewer_comm_destroy(gsx_viewer* v);
+/* What the viewer's communicator IS, asked of the transport itself (a scaling record should show that RCCL saw N ranks, not that the
+ * caller said N): transport 0 none / 1 RCCL / 2 in-process group / 3 the caller's functions; for RCCL nranks = ncclCommCount, rank =
+ * ncclCommUserRank, device = ncclCommCuDevice of the first communicator, version = ncclGetVersion (e.g. 22707), lane_comms = the
+ * further communicators frames in flight created; otherwise what the viewer was initialised with. */
+typedef struct gsx_comm_info {
+    uint32_t transport, nranks, rank, lane_comms;
+    int32_t device, version;
+} gsx_comm_info;
+gsx_status gsx_viewer_comm_info(gsx_viewer* v, gsx_comm_info* out);
 /* slot p of d_send goes to rank p, slot p of d_recv comes from rank p (grouped point-to-point: all xGMI links at once) */
 gsx_status gsx_comm_all_to_all(gsx_viewer* v, const void* d_send, void* d_recv, uint64_t bytes_per_peer);
 /* d_recv = world * bytes_per_rank; in place when d_send == d_recv + rank * bytes_per_rank */

@@ -136,6 +136,9 @@ pub struct gsx_shard_stats {
 }
 #[repr(C)]
 #[derive(Clone, Copy, Default)]
+pub struct gsx_comm_info { pub transport: u32, pub nranks: u32, pub rank: u32, pub lane_comms: u32, pub device: i32, pub version: i32 }
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
 pub struct gsx_launch_stats {
     pub graph_launches: u64, pub graph_nodes: u64, pub nodes_patched: u64, pub direct_launches: u64, pub graphs_built: u64, pub broken: u64, pub idle_direct_scopes: u64,
 }
@@ -219,6 +222,7 @@ extern "C" {
     pub fn gsx_comm_unique_id(out_id: *mut u8) -> gsx_status;
     pub fn gsx_viewer_comm_init(v: *mut gsx_viewer, world: u32, rank: u32, id: *const u8) -> gsx_status;
     pub fn gsx_viewer_comm_destroy(v: *mut gsx_viewer) -> gsx_status;
+    pub fn gsx_viewer_comm_info(v: *mut gsx_viewer, out: *mut gsx_comm_info) -> gsx_status;
     pub fn gsx_comm_all_to_all(v: *mut gsx_viewer, d_send: *const c_void, d_recv: *mut c_void, bytes_per_peer: u64) -> gsx_status;
     pub fn gsx_comm_all_gather(v: *mut gsx_viewer, d_send: *const c_void, d_recv: *mut c_void, bytes_per_rank: u64) -> gsx_status;
     pub fn gsx_shard_render_frame(v: *mut gsx_viewer, key: *const c_char, shard_records_max: u32, speculate: u32, margin: f32, radius: u32) -> gsx_status;

@@ -96,10 +96,37 @@ def test_bench_line_contract(name, d):
         assert 200 * rb["gaussians_of_this_rank"] < rb["device_bytes_after_headline_loop"] < 4096 * rb["gaussians_of_this_rank"]
 
 
+@pytest.mark.parametrize("name,d", _lines(), ids=[n for n, _ in _lines()])
+def test_bench_line_round6_keys(name, d):
+    """Round 6 onwards: the HIP frame of the pose the CPU baseline rendered is compared with that frame on
+    the line itself — integer stages bit-exact, both schedules within 1e-3 — and BASELINE configs[4] has a compact leg."""
+    if "oracle_check" not in d and "cfg5" not in d:
+        pytest.skip("a line from before round 6")
+    oc = d["oracle_check"]
+    assert oc["ok"] is True and oc["keys_equal"] and oc["rects_equal"] and oc["depth_order_equal"] and oc["n_visible_equal"]
+    assert 0.0 <= oc["linf_plain"] <= 1e-3 and 0.0 <= oc["linf_speculated"] <= 1e-3 and oc["speculated_frame_was_speculated"]
+    assert oc["speculated_equals_plain"] is True
+    assert str(oc["n_visible"]) in d["cpu_baseline"]["sample"], "the checked frame is the one cpu_baseline timed"
+    assert d["summary"]["oracle_check"]["ok"] is True
+    c5 = d["cfg5"]
+    assert "4 x 6000000" in c5["workload"] and "3840x2160" in c5["workload"] and "0 - 1" in c5["workload"]
+    assert c5["frame_check"]["equal_to_unspeculated_single_pass"] is True and c5["overflow_slabs"] == 0
+    assert 0 < c5["fps_unspeculated"] < c5["fps_one_frame_in_flight"] and c5["fps_two_frames_in_flight"] > 0
+    assert d["summary"]["cfg5_fps"] == [c5["fps_one_frame_in_flight"], c5["fps_two_frames_in_flight"], c5["fps_unspeculated"]]
+
+
+def test_bench_source_carries_the_rccl_field_on_sharded_lines():
+    """every N > 1 line says how many ranks RCCL itself counted (gsx_viewer_comm_info: ncclCommCount), so a SCALE record can be checked"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'out["rccl"] = comm_info' in src and "viewer.comm_info()" in src
+    hdr = open(os.path.join(ROOT, "include", "gsx.h")).read()
+    assert "gsx_viewer_comm_info" in hdr and "ncclCommCount" in hdr
+
+
 def test_bench_source_prints_the_summary_last():
     """bench.py assigns out["summary"] directly before out["cpu_baseline"], the last key of the line (CPU check of the source)."""
     src = open(os.path.join(ROOT, "bench.py")).read()
-    i, j = src.index('out["summary"] = summary'), src.index('out["cpu_baseline"] = cpu_baseline(')
+    i, j = src.index('out["summary"] = summary'), src.index('out["cpu_baseline"] = cpu_res')
     assert i < j and 'out["' not in src[i + len('out["summary"] = summary'):j].replace('out["cpu_baseline"]', "")
     assert src.index("os.write(real_stdout") > j
     assert "args.steps = max(args.steps, args.min_steps)" in src and '"--min-steps", type=int, default=240' in src

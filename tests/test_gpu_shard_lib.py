@@ -162,6 +162,45 @@ def test_library_frame_loop_with_peers_and_frames_in_flight(world, lanes):
         assert stats["frames"] == 4 * len(POSES) and stats["repair_frames"] >= len(POSES)
 
 
+@pytest.mark.parametrize("world,lanes", [(1, 2), (2, 2), (2, 3)])
+def test_viewport_resized_between_calls_with_frames_in_flight(world, lanes):
+    """with frames in flight lane 0 is the owner itself, and gsx_update_camera resizes it without retiring what is in
+    flight.  A frame that is retired by a LATER call must be gathered under the viewport it was enqueued with — not the caller's new
+    one (wrong row bytes and band offsets; a reallocated framebuffer).  Nothing that completes frames is called inside the loop:
+    frame k is read one call late, from its lane, at ITS size."""
+    g = _scene()
+    sizes = [(W, H), (176, 120), (W, H), (240, 168), (176, 120), (W, H), (240, 168), (176, 120)]
+    poses = [POSES[k % 3] for k in range(len(sizes))]   # (a coherent stretch: natural limits, few repairs)
+    ref = []
+    with MultiModelViewer() as v1:
+        v1.add_model("m", N)
+        v1.models["m"].gaussian_buffers.gaussians_buffer.update_range(0, g)
+        for pose, size in zip(poses, sizes):
+            _uniforms(v1, pose, size)
+            v1.render_frame(["m"])
+            ref.append(v1.download_framebuffer().copy())
+
+    def body(rank, group):
+        v, shard_max = _rank_viewer(g, N, rank, world, group, lanes=lanes)
+        bad = []
+        for k, (pose, size) in enumerate(zip(poses, sizes)):
+            _uniforms(v, pose, size)
+            v.shard_render_frame("m", shard_max)
+            if k >= lanes - 1:   # the frame of call k - (lanes - 1) has just been retired; its lane is idle until call k + 1
+                j = k - (lanes - 1)
+                fb = v.debug_download_lane_framebuffer(j % lanes, sizes[j])
+                if fb.shape != ref[j].shape or not np.array_equal(fb, ref[j]):
+                    bad.append((j, sizes[j], float(np.abs(fb - ref[j]).max()) if fb.shape == ref[j].shape else "shape"))
+        fb = v.download_framebuffer()
+        if not np.array_equal(fb, ref[-1]):
+            bad.append(("last", float(np.abs(fb - ref[-1]).max())))
+        v.close()
+        return bad
+
+    for rank, bad in enumerate(run_group(world, body)):
+        assert not bad, f"rank {rank} (world {world}, {lanes} lanes): {bad}"
+
+
 def test_a_rank_that_leaves_the_loop_is_an_error_not_a_hang():
     """Rank 1 stops calling after the first frame.  Rank 0's next frame gets GSX_ERR_RCCL from the rendezvous within the
     group's timeout — from gsx_shard_render_frame, through the C ABI — and so does every later collective call."""

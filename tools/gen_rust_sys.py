@@ -184,6 +184,9 @@ pub struct gsx_shard_stats {
 }
 #[repr(C)]
 #[derive(Clone, Copy, Default)]
+pub struct gsx_comm_info { pub transport: u32, pub nranks: u32, pub rank: u32, pub lane_comms: u32, pub device: i32, pub version: i32 }
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
 pub struct gsx_launch_stats {
     pub graph_launches: u64, pub graph_nodes: u64, pub nodes_patched: u64, pub direct_launches: u64, pub graphs_built: u64, pub broken: u64, pub idle_direct_scopes: u64,
 }

@@ -114,10 +114,15 @@ _RT = None
 
 
 def replay_lib():
-    """tools/libreplay_transport.so (tools/replay_transport.cpp, built by __graft_entry__.build()): the replay transport as native code"""
+    """tools/libreplay_transport.so (tools/replay_transport.cpp, built here on first use): the replay transport as native code"""
     global _RT
     if _RT is None:
-        _RT = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libreplay_transport.so"))
+        here = os.path.dirname(os.path.abspath(__file__))
+        so, src = os.path.join(here, "libreplay_transport.so"), os.path.join(here, "replay_transport.cpp")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            import subprocess
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", src, "-o", so])
+        _RT = C.CDLL(so)
         _RT.rt_create.restype = C.c_void_p
         _RT.rt_create.argtypes = [C.c_uint32, C.c_uint32]
         _RT.rt_destroy.argtypes = [C.c_void_p]

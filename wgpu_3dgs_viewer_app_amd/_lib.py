@@ -41,6 +41,7 @@ EXPORTS = (
     "gsx_query_hit_pos_by_closest", "gsx_query_hit_pos_by_alpha_range",
     "gsx_debug_set_launch_graphs", "gsx_debug_launch_count", "gsx_debug_device_bytes", "gsx_debug_download_lane_framebuffer", "gsx_viewer_launch_stats", "gsx_debug_tile_profile",
     "gsx_viewer_comm_init_custom_v", "gsx_shard_set_band_edges", "gsx_shard_get_band_edges", "gsx_shard_set_balance",
+    "gsx_viewer_comm_info",
 )
 
 
@@ -104,6 +105,12 @@ class ShardStats(C.Structure):
                 ("last_repair_slot_records", C.c_uint32), ("last_entries_sum", C.c_uint32), ("last_entries_max", C.c_uint32),
                 ("last_work_permille", C.c_uint32), ("redo_fallbacks", C.c_uint32),
                 ("last_repair_records", C.c_uint32), ("reserved0", C.c_uint32)]
+
+
+class CommInfo(C.Structure):
+    """``gsx_comm_info``."""
+    _fields_ = [("transport", C.c_uint32), ("nranks", C.c_uint32), ("rank", C.c_uint32), ("lane_comms", C.c_uint32),
+                ("device", C.c_int32), ("version", C.c_int32)]
 
 
 #: gsx_comm_all_to_all_fn / gsx_comm_all_gather_fn: (ctx, d_send, d_recv, bytes, hip_stream) -> gsx_status
@@ -228,6 +235,7 @@ def load() -> C.CDLL:
         "gsx_shard_set_slot_records": ([vp, cp, u32], C.c_int32),
         "gsx_shard_set_gather_root": ([vp, C.c_int32], C.c_int32),
         "gsx_shard_get_stats": ([vp, C.POINTER(ShardStats), u32], C.c_int32),
+        "gsx_viewer_comm_info": ([vp, C.POINTER(CommInfo)], C.c_int32),
         "gsx_model_buffer_retain": ([vp, cp, C.c_int, C.POINTER(vp)], C.c_int32),
         "gsx_buffer_retain": ([vp], C.c_int32),
         "gsx_buffer_release": ([vp], None),

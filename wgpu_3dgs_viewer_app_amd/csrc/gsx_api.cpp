@@ -671,6 +671,8 @@ gsx_status gsx_render_frame(gsx_viewer* v, const char* const* keys, uint32_t n_k
         HIPCHK(gsx::op::EventRecord(lane->lane_event, lane->stream));
         lane->lane_busy = true;
     }
+    lane->held_w = lane->width;
+    lane->held_h = lane->height;
     v->latest = lane == v ? nullptr : lane;
     return GSX_OK;
 }
@@ -692,7 +694,8 @@ gsx_status gsx_debug_download_lane_framebuffer(gsx_viewer* v, uint32_t lane, flo
     if (!v || v->parent || lane > v->lanes.size()) return fail(GSX_ERR_INVALID_ARG, "gsx_debug_download_lane_framebuffer: no such lane");
     HIPCHK(hipSetDevice(v->device));
     gsx_viewer* l = lane == 0 ? v : v->lanes[lane - 1];
-    const uint64_t need = 4ull * l->width * l->height;
+    // the viewport of the frame the lane HOLDS: the owner's own may have been changed by gsx_update_camera since that frame was enqueued
+    const uint64_t need = l->held_w ? 4ull * l->held_w * l->held_h : 4ull * l->width * l->height;
     if (!rgbt || n_floats != need || !fb_ptr(l)) return fail(GSX_ERR_INVALID_ARG, "gsx_debug_download_lane_framebuffer: expected %llu floats of a lane that has rendered", (unsigned long long)need);
     HIPCHK(gsx::op::StreamSynchronize(l->stream));  // (NOT viewer_bind: the frames in flight stay as they are)
     HIPCHK(gsx::op::Memcpy(rgbt, fb_ptr(l), sizeof(float) * need, hipMemcpyDeviceToHost));

@@ -44,6 +44,11 @@ struct Rccl {
     ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    // introspection only (gsx_viewer_comm_info): a library without them still runs the frame
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
     std::string error;
 };
 
@@ -89,6 +94,10 @@ void load_rccl() {
     GSX_SYM(GroupStart, "ncclGroupStart");
     GSX_SYM(GroupEnd, "ncclGroupEnd");
 #undef GSX_SYM
+    g_rccl.CommCount = reinterpret_cast<decltype(g_rccl.CommCount)>(dlsym(h, "ncclCommCount"));
+    g_rccl.CommUserRank = reinterpret_cast<decltype(g_rccl.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
+    g_rccl.CommCuDevice = reinterpret_cast<decltype(g_rccl.CommCuDevice)>(dlsym(h, "ncclCommCuDevice"));
+    g_rccl.GetVersion = reinterpret_cast<decltype(g_rccl.GetVersion)>(dlsym(h, "ncclGetVersion"));
 }
 
 gsx_status rccl_ready() {
@@ -164,6 +173,28 @@ gsx_status gsx_viewer_comm_init(gsx_viewer* v, uint32_t world, uint32_t rank, co
     v->comm_world = world;
     v->comm_rank = rank;
     v->comm_self_via_rccl = getenv("GSX_COMM_SELF_VIA_RCCL") != nullptr;
+    return GSX_OK;
+}
+
+gsx_status gsx_viewer_comm_info(gsx_viewer* v, gsx_comm_info* out) {
+    if (!v || !out) return fail(GSX_ERR_INVALID_ARG, "gsx_viewer_comm_info: null argument");
+    *out = gsx_comm_info{0u, 0u, 0u, 0u, -1, 0};
+    if (!has_comm(v)) return GSX_OK;
+    out->nranks = v->comm_world;
+    out->rank = v->comm_rank;
+    out->device = v->device;
+    out->lane_comms = (uint32_t)v->lane_comms.size();
+    if (v->comm) {  // RCCL: the communicator's own answers
+        out->transport = 1;
+        ncclComm_t c = static_cast<ncclComm_t>(v->comm);
+        int x = 0;
+        if (g_rccl.CommCount && g_rccl.CommCount(c, &x) == 0) out->nranks = (uint32_t)x;
+        if (g_rccl.CommUserRank && g_rccl.CommUserRank(c, &x) == 0) out->rank = (uint32_t)x;
+        if (g_rccl.CommCuDevice && g_rccl.CommCuDevice(c, &x) == 0) out->device = x;
+        if (g_rccl.GetVersion && g_rccl.GetVersion(&x) == 0) out->version = x;
+    } else {
+        out->transport = v->comm_group ? 2u : 3u;
+    }
     return GSX_OK;
 }
 

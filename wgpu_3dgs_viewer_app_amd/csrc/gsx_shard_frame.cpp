@@ -374,6 +374,8 @@ uint32_t repair_slot_policy(const Model* om, uint32_t shard_max) {
 //  gets its lane's event again, but results keep referring to the newer frame)
 gsx_status lane_mark(gsx_viewer* owner, ShardPending& p, bool newest) {
     p.lane->band_edges = owner->band_edges_forced;  // stage calls between frames see the caller's layout (or equal bands), not this frame's
+    p.lane->held_w = p.lane->width;  // (every caller marks the frame while ITS uniforms are in force: frame_front, or between two swap_uniforms)
+    p.lane->held_h = p.lane->height;
     if (p.lane != owner) {
         HIPCHK(gsx::op::EventRecord(p.lane->lane_event, p.lane->stream));
         p.lane->lane_busy = true;
@@ -563,9 +565,14 @@ gsx_status frame_retire(gsx_viewer* owner, ShardPending& p) {
         if (own) swap_uniforms(p.lane, p);
         if (st) return st;
     } else if (!p.gathered) {
+        // (the frame's OWN viewport: gsx_update_camera may have resized the owner since the frame was enqueued, and a gather under the new
+        //  size would use the wrong row bytes and band offsets — and frame_buffers would reallocate the framebuffer the frame lies in)
+        const bool own = p.lane == owner;
+        if (own) swap_uniforms(p.lane, p);
         st = frame_buffers(c);
         if (!st) st = band_gather(c);
         if (!st) st = lane_mark(owner, p, !owner->shard_pending.empty() && &owner->shard_pending.back() == &p);
+        if (own) swap_uniforms(p.lane, p);
         if (st) return st;
     }
     ss.frames += 1;

@@ -355,6 +355,7 @@ struct gsx_viewer {
     uint32_t lane_turn = 0;
     hipEvent_t lane_event = nullptr;     // lane: end of its last frame; parent: "everything enqueued so far" for the lanes to wait on
     bool lane_busy = false;              // lane: it has a frame the parent's stream has not been ordered after
+    uint32_t held_w = 0, held_h = 0;     // viewport of the frame this viewer / lane holds (the owner's may have changed since: gsx_debug_download_lane_framebuffer)
     uint64_t epoch = 1, seen_epoch = 0;  // parent: bumped by every call that may touch model data; lane: the epoch it has waited for
     std::vector<hipStream_t> parked_streams;  // owner only: streams that turned out to share a hardware queue with a lane (lane_create)
     uint32_t lane_index = 0;             // 0: the viewer itself; lane i of its parent otherwise

@@ -537,6 +537,14 @@ class MultiModelViewer:
         _lib.check(self._L.gsx_shard_download_limits(self._h, key.encode(), _u32p(out), out.size))
         return out
 
+    def comm_info(self) -> dict:
+        """What the communicator itself says (``gsx_viewer_comm_info``): transport, the ranks RCCL counted, its version."""
+        ci = _lib.CommInfo()
+        _lib.check(self._L.gsx_viewer_comm_info(self._h, C.byref(ci)))
+        out = {n: int(getattr(ci, n)) for n, _ in _lib.CommInfo._fields_}
+        out["transport"] = ("none", "rccl", "in-process group", "custom")[min(out["transport"], 3)]
+        return out
+
     def shard_stats(self, reset: bool = False) -> dict:
         st = _lib.ShardStats()
         _lib.check(self._L.gsx_shard_get_stats(self._h, C.byref(st), 1 if reset else 0))
