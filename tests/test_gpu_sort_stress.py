@@ -26,6 +26,24 @@ def test_sort_matches_stable_sort(case, ranks):
         env["GSX_RADIX_MATCH_RANKS"] = "1"
     p = subprocess.run([EXE, *case], capture_output=True, text=True, timeout=60, env=env)
     assert p.returncode == 0, p.stderr[-400:]
-    assert "mismatches vs std::stable_sort: 0" in p.stdout, p.stdout[-600:]
+    assert "\nmismatches vs std::stable_sort: 0" in p.stdout, p.stdout[-600:]
     want = "lane-ordered on this device: " + ("0" if ranks == "match" else "1")
     assert want in p.stdout, p.stdout[:200]
+    # the bucket sort (histogram -> MSD partition -> bucket sorts) on the same pairs: without a key range, with the range of the sort
+    # before, with a device-side count below the launch bound, empty, and from a key array — all equal to std::stable_sort
+    assert "bucket sort mismatches in all: 0" in p.stdout, p.stdout[-1200:]
+
+
+@pytest.mark.parametrize("ranks", ["lane_ordered", "match"])
+@pytest.mark.parametrize("case", [("300000", "32", "depth"), ("300000", "32", "dup"), ("40000", "32", "depth"), ("4097", "13"), ("70000", "32"), ("1", "32")],
+                         ids=lambda c: "-".join(c))
+def test_bucket_sort_large_bucket_path(case, ranks):
+    """GSX_BUCKET_CAP=48: every bucket of more than 48 pairs is sorted through global memory, tile by tile, by its one workgroup — the path
+    a bucket that does not fit the LDS takes (8.4 M-pair sorts reach it by themselves in the test above).  Same order."""
+    env = dict(os.environ, GSX_BUCKET_CAP="48")
+    env.pop("GSX_RADIX_MATCH_RANKS", None)
+    if ranks == "match":
+        env["GSX_RADIX_MATCH_RANKS"] = "1"
+    p = subprocess.run([EXE, *case], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 0, p.stderr[-400:]
+    assert "bucket sort mismatches in all: 0" in p.stdout, p.stdout[-1200:]

@@ -108,6 +108,77 @@ int main(int argc, char** argv) {
         CK(launch_radix_sort(s, rb, n, dn, bits, false));  // (the pair sort's outputs again, for the check below)
         CK(hipStreamSynchronize(s));
     }
+    // ---- the bucket sort (fine histogram -> MSD partition -> in-LDS bucket sorts) on the same pairs: three launches ----
+    // GSX_BUCKET_CAP=<pairs> forces buckets above that size through the global-memory path
+    {
+        if (getenv("GSX_BUCKET_CAP")) bucket_sort_set_cap((uint32_t)atoi(getenv("GSX_BUCKET_CAP")));
+        uint32_t* mws;
+        const size_t mwords = msd_workspace_words(n);
+        CK(hipMalloc(&mws, 4 * mwords));
+        CK(msd_workspace_init(s, mws, mwords));
+        uint32_t *ko2, *vo2;
+        CK(hipMalloc(&ko2, 4ull * n + 4));
+        CK(hipMalloc(&vo2, 4ull * n + 4));
+        RadixBuffers rb2{nullptr, nullptr, src, ko2, vo2, pa, pb, ws};
+        uint32_t seq = 0;
+        std::vector<uint2> ref = h;
+        std::stable_sort(ref.begin(), ref.end(), [](const uint2& a, const uint2& b) { return a.x < b.x; });
+        std::vector<uint32_t> k2(n), v2(n);
+        size_t bad_total = 0;
+        for (int round = 0; round < 3; ++round) {  // round 0: no key range known yet; 1, 2: the range of the sort before
+            CK(hipMemset(ko2, 0xEE, 4ull * n));
+            CK(launch_bucket_sort(s, rb2, n, dn, false, mws, seq++, false));
+            CK(hipStreamSynchronize(s));
+            CK(hipMemcpy(k2.data(), ko2, 4ull * n, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(v2.data(), vo2, 4ull * n, hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            for (uint32_t i = 0; i < n; ++i) bad += (ref[i].x != k2[i]) || (ref[i].y != v2[i]);
+            printf("bucket sort round %d: mismatches vs std::stable_sort: %zu\n", round, bad);
+            bad_total += bad;
+        }
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < reps; ++i) CK(launch_bucket_sort(s, rb2, n, dn, false, mws, seq++, false));
+        CK(hipEventRecord(e1, s));
+        CK(hipStreamSynchronize(s));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("bucket sort: n %u: %.1f us per sort (histogram + partition + bucket launch) against %.1f us for the LSD sort\n", n, 1000.0 * ms / reps,
+               1000.0 * ms_pairs / reps);
+        // a device-side count below the launch bound, and an empty sort
+        for (uint32_t part : {n / 3u, 0u}) {
+            CK(hipMemcpy(dn, &part, 4, hipMemcpyHostToDevice));
+            CK(launch_bucket_sort(s, rb2, n, dn, false, mws, seq++, false));
+            CK(hipStreamSynchronize(s));
+            std::vector<uint2> refp(h.begin(), h.begin() + part);
+            std::stable_sort(refp.begin(), refp.end(), [](const uint2& a, const uint2& b) { return a.x < b.x; });
+            CK(hipMemcpy(k2.data(), ko2, 4ull * n, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(v2.data(), vo2, 4ull * n, hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            for (uint32_t i = 0; i < part; ++i) bad += (refp[i].x != k2[i]) || (refp[i].y != v2[i]);
+            printf("bucket sort of the first %u pairs (count on the device): mismatches %zu\n", part, bad);
+            bad_total += bad;
+        }
+        CK(hipMemcpy(dn, &n, 4, hipMemcpyHostToDevice));
+        // keys as they lie + iota values (an imported band)
+        {
+            std::vector<uint32_t> keys(n);
+            for (uint32_t i = 0; i < n; ++i) keys[i] = h[i].x;
+            uint32_t* dkeys;
+            CK(hipMalloc(&dkeys, 4ull * n + 4));
+            CK(hipMemcpy(dkeys, keys.data(), 4ull * n, hipMemcpyHostToDevice));
+            RadixBuffers rk{dkeys, nullptr, nullptr, ko2, vo2, pa, pb, ws};
+            CK(launch_bucket_sort(s, rk, n, dn, true, mws, seq++, false));
+            CK(hipStreamSynchronize(s));
+            CK(hipMemcpy(k2.data(), ko2, 4ull * n, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(v2.data(), vo2, 4ull * n, hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            for (uint32_t i = 0; i < n; ++i) bad += (ref[i].x != k2[i]) || (ref[i].y != v2[i]);
+            printf("bucket sort from a key array: mismatches %zu\n", bad);
+            bad_total += bad;
+        }
+        printf("bucket sort mismatches in all: %zu\n", bad_total);
+        CK(launch_radix_sort(s, rb, n, dn, bits, false));  // (the pair sort's outputs again, for the check below)
+        CK(hipStreamSynchronize(s));
+    }
     // correctness
     std::vector<uint32_t> k(n), v(n);
     CK(hipMemcpy(k.data(), ko, 4ull * n, hipMemcpyDeviceToHost));

@@ -497,6 +497,15 @@ gsx_status complete_records(gsx_viewer* v, Model* m) {
     return GSX_OK;
 }
 
+// the bucket sort's workspace of this model (main round / repair round): allocated and initialised on first use
+static gsx_status ensure_msd(gsx_viewer* v, Model* m, DevBuf& ws) {
+    const size_t words = msd_workspace_words(std::max<uint64_t>(m->rec_cap, std::max<uint64_t>(m->n, 1)));
+    if (ws.bytes >= 4 * words) return GSX_OK;
+    HIPCHK(ws.ensure(4 * words));
+    HIPCHK(msd_workspace_init(v->stream, ws.as<uint32_t>(), ws.bytes / 4));
+    return GSX_OK;
+}
+
 gsx_status shade_admitted(gsx_viewer* v, Model* m, const LateProjection& late) {
     PodPlanes pod = m->pod();
     pod.mask = m->last_pod_mask;
@@ -520,13 +529,21 @@ gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
     if (!m->preprocessed) return fail(GSX_ERR_INVALID_ARG, "gsx_sort('%s') before gsx_preprocess", m->key.c_str());
     const uint32_t n = (uint32_t)m->rec_n;
     Counters* dc = m->counters.as<Counters>();
+    uint32_t launches_sort = 4;
     {
         ScopedPass t(v, GSX_PASS_DEPTH_SORT);
         if (m->use_imported) {  // every imported record is visible: sort the keys as they lie
             m->spec_round1 = false;
             RadixBuffers rb{m->rec().key, nullptr, nullptr, m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
                             m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
-            HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted, 32, true));  // n: an upper bound (slot import); the count is on the device
+            if (v->bucket_sort && m->has_window) {  // a windowed exchange: a band's share of the admitted records (tens of thousands): three launches, not five
+                gsx_status mst = ensure_msd(v, m, m->msd_ws);
+                if (mst) return mst;
+                HIPCHK(launch_bucket_sort(v->stream, rb, n, &dc->n_sorted, true, m->msd_ws.as<uint32_t>(), m->msd_seq++, false));
+                launches_sort = 3;
+            } else {
+                HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted, 32, true));  // n: an upper bound (slot import); the count is on the device
+            }
         } else {
             // speculated frames: compact the (key, index) pairs the projection pass admitted, then sort only those
             // (counting the sort's digit histograms inside the compaction / tile-emit kernels — LDS atomics where the pairs are
@@ -551,11 +568,24 @@ gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
                 HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted, 32, true, true));
             } else {
                 HIPCHK(m->adm_pairs.ensure(8 * std::max<size_t>(n, 1)));
-                HIPCHK(m->adm_offsets.ensure(m->adm_counts.bytes));
-                HIPCHK(launch_admit_from_project(v->stream, m->proj_rec().key, n, m->adm_ballots.as<unsigned long long>(),
-                                                 m->adm_counts.as<uint32_t>(), m->adm_offsets.as<uint32_t>(), &dc->n_sorted,
-                                                 m->adm_pairs.as<uint2>(), m->spec_round1,
-                                                 m->visible_count_pending ? m->block_vis.as<uint32_t>() : nullptr, &dc->n_visible));
+                // a speculated frame admits a few per cent of the visible records: ONE compaction launch that also counts the bucket
+                // sort's histogram, then a partition pass and a launch of in-LDS bucket sorts (gsx_internal.h "bucket sort") — four
+                // launches for what scan + scatter + histogram + four digit passes did in seven
+                const bool bucket = v->bucket_sort && m->spec_round1;
+                uint32_t seq = 0;
+                if (bucket) {
+                    gsx_status mst = ensure_msd(v, m, m->msd_ws);
+                    if (mst) return mst;
+                    seq = m->msd_seq++;
+                    HIPCHK(launch_admit_compact(v->stream, m->proj_rec().key, n, m->adm_ballots.as<unsigned long long>(), &dc->n_sorted, m->adm_pairs.as<uint2>(),
+                                                m->visible_count_pending ? m->block_vis.as<uint32_t>() : nullptr, &dc->n_visible, m->msd_ws.as<uint32_t>(), seq));
+                } else {
+                    HIPCHK(m->adm_offsets.ensure(m->adm_counts.bytes));
+                    HIPCHK(launch_admit_from_project(v->stream, m->proj_rec().key, n, m->adm_ballots.as<unsigned long long>(),
+                                                     m->adm_counts.as<uint32_t>(), m->adm_offsets.as<uint32_t>(), &dc->n_sorted,
+                                                     m->adm_pairs.as<uint2>(), m->spec_round1,
+                                                     m->visible_count_pending ? m->block_vis.as<uint32_t>() : nullptr, &dc->n_visible));
+                }
                 m->visible_count_pending = false;
                 if (m->lazy) {  // the projection pass was geometry only: shade what it admitted
                     gsx_status sst = shade_admitted(v, m, LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted, nullptr, m->rect8_active});
@@ -563,11 +593,16 @@ gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
                 }
                 RadixBuffers rb{nullptr, nullptr, m->adm_pairs.as<uint2>(), m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
                                 m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
-                HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted, 32, false));
+                if (bucket) {
+                    HIPCHK(launch_bucket_sort(v->stream, rb, n, &dc->n_sorted, false, m->msd_ws.as<uint32_t>(), seq, true));
+                    launches_sort = 2;
+                } else {
+                    HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted, 32, false));
+                }
             }
         }
         m->sorted_idx = m->sv_out.as<uint32_t>();
-        v->pass_launches[GSX_PASS_DEPTH_SORT] += n ? 4 : 0;
+        v->pass_launches[GSX_PASS_DEPTH_SORT] += n ? launches_sort : 0;
     }
     m->stats_pending = true;
     m->sorted = true;
@@ -988,7 +1023,12 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
             }
             RadixBuffers rb{nullptr, nullptr, m->adm_pairs.as<uint2>(), m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
                             m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
-            HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted2, 32, false));
+            if (v->bucket_sort) {  // (the repair round's keys lie behind the windows: a population, and a key range, of their own)
+                if ((st = ensure_msd(v, m, m->msd_ws2))) return st;
+                HIPCHK(launch_bucket_sort(v->stream, rb, n, &dc->n_sorted2, false, m->msd_ws2.as<uint32_t>(), m->msd_seq2++, false));
+            } else {
+                HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted2, 32, false));
+            }
         }
         if (repair && (st = run_slab(0, n, true, m->spec_win2.as<uint2>(), &dc->n_sorted2, (uint32_t)bounds.size(), nullptr, blocks))) return st;
         m->order_consumed = true;

@@ -236,6 +236,67 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
                              bool skip_culled = false, uint2* ranges_out = nullptr,  // skip_culled: keys == 0xFFFFFFFF do not exist; *d_n receives the count that do
                              const uint4* payload_in = nullptr, uint4* payload_out = nullptr);  // the last pass also writes payload_out[sorted position] = payload_in[value]
 
+// ---- bucket sort of (depth key, Gaussian index) pairs: one MSD partition + one launch of in-LDS bucket sorts (kernels_sort.hip) ----
+// The order the spec defines is (key, index) and the index travels with the key; what the depth sort of a speculated frame (a few
+// hundred thousand admitted pairs) paid was not bytes but launches: a histogram + four digit passes, each one tile's latency plus the
+// chain of tile prefixes.  Here: a 2048-bin "fine" histogram of the keys — counted by the kernel that makes the pairs
+// (k_admit_compact) or by k_msd_hist — is cut into 256 coarse buckets of equal population by every workgroup of the partition pass
+// alike; the partition pass is the onesweep kernel with that table as its digit (stable: ties keep index order); one more launch
+// sorts every bucket on its remaining key bits, in LDS (stable LSD passes; a bucket that does not fit runs the same passes through
+// global memory, one workgroup per bucket — slower, never wrong).  Which keys share a fine bin is a guess — from the minimum and
+// maximum of the model's previous sort — and only the balance depends on it: keys outside the guessed range land in the first /
+// last bin.
+constexpr uint32_t kMsdFine = 2048;      // fine bins
+constexpr uint32_t kMsdBuckets = 256;    // coarse buckets = the partition pass's digit
+// workspace (u32 words, zeroed at allocation except the cells): [0, 2048) fine histogram | [2048, 2054) three {min, max} cells, used
+// in rotation: sort k reads cell (k - 1) % 3 (the guess), accumulates into k % 3, resets (k + 1) % 3 | [2056] ticket, [2057] finished
+// (k_admit_compact) | [2064, 2064 + 512) bucket ranges (uint2 x 256) | from 2576: k_admit_compact's status words, 4 per tile
+constexpr uint32_t kMsdCells = 2048, kMsdTicket = 2056, kMsdRanges = 2064, kMsdStatus = 2576;
+constexpr uint32_t kCompactWordsPerTile = 1024;  // ballot words (64 Gaussians each) per k_admit_compact workgroup
+inline size_t msd_workspace_words(uint64_t n_gaussians) {
+    return kMsdStatus + 4 * (size_t)((((n_gaussians + 63) / 64) + kCompactWordsPerTile - 1) / kCompactWordsPerTile + 1);
+}
+// fine bin of a key: (max(key, lo) - lo) >> fs, at most 2047; lo / fs from the guessed key range (hint: {min, max} of an earlier sort, or
+// {0xFFFFFFFF, 0} = none: depths 2^-7 ... 2^14 then, 97 bins per octave)
+__device__ inline void msd_mapping(const uint32_t* __restrict__ hint, uint32_t& lo, uint32_t& fs) {
+    uint32_t mn = 0x3C000000u, mx = 0x46800000u;
+    const uint32_t a = hint[0], b = hint[1];
+    if (a <= b) {
+        mn = a;
+        mx = b;
+    }
+    lo = mn;
+    const int bits = 32 - __clz((int)((mx - mn) | 1u));
+    fs = bits > 11 ? (uint32_t)(bits - 11) : 0u;
+}
+__device__ inline uint32_t msd_fine(uint32_t key, uint32_t lo, uint32_t fs) { return min((max(key, lo) - lo) >> fs, kMsdFine - 1u); }
+struct MsdCells {   // the three pointers of sort number `seq` on workspace `ws`
+    uint32_t* fine;
+    const uint32_t* hint;
+    uint32_t *acc, *reset;
+    uint2* ranges;
+};
+inline MsdCells msd_cells(uint32_t* ws, uint32_t seq) {
+    return MsdCells{ws, ws + kMsdCells + 2 * ((seq + 2) % 3), ws + kMsdCells + 2 * (seq % 3), ws + kMsdCells + 2 * ((seq + 1) % 3),
+                    reinterpret_cast<uint2*>(ws + kMsdRanges)};
+}
+// the workspace's initial contents (host): zeros, the three cells at {0xFFFFFFFF, 0} = "no keys seen"
+hipError_t msd_workspace_init(hipStream_t s, uint32_t* ws, size_t words);
+// n sizes the launches; *d_n is the element count.  hist_done: the fine histogram (and the cells) of sort `seq` were made by the
+// kernel that wrote buf.pairs_src (launch_admit_compact with the same ws and seq); otherwise k_msd_hist runs first.
+// buf: pairs_src, or keys_src (+ vals_src / iota_values); pairs_a, pairs_b scratch; keys_out / vals_out the sorted result;
+// workspace = the radix workspace (ticket + status words of the partition pass).
+hipError_t launch_bucket_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n, uint32_t* d_n, bool iota_values, uint32_t* msd_ws, uint32_t seq,
+                              bool hist_done);
+// k_admit_compact (kernels_admit.hip): the admitted (key, index) pairs of a projection pass in index order from its ballots — one
+// launch (decoupled look-back over 65536-Gaussian tiles) instead of k_admit_scan + k_admit_scatter256 — and, msd_ws != nullptr, the fine
+// histogram + key range of sort `seq`.  *d_total = pairs; block_visible (nullable): the projection's per-workgroup visible counts are
+// summed into *d_n_visible on the way.
+hipError_t launch_admit_compact(hipStream_t s, const uint32_t* key, uint32_t n, const unsigned long long* ballots, uint32_t* d_total, uint2* pairs,
+                                const uint32_t* block_visible, uint32_t* d_n_visible, uint32_t* msd_ws, uint32_t seq);
+uint32_t next_sort_epoch();  // status-word epochs of every look-back kernel of the process (kernels_sort.hip)
+void bucket_sort_set_cap(uint32_t cap);  // tests: buckets above `cap` pairs take the global-memory path (0: the LDS capacity)
+
 // Device-resident per-model frame statistics; the host mirrors them lazily (no sync inside a frame).
 struct SlabStats {
     uint32_t n_visible;        // N_vis (projection pass / import)

@@ -238,6 +238,220 @@ __global__ __launch_bounds__(256) void k_admit_scatter_dense(const uint32_t* __r
     pairs[o + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))] = make_uint2(key[i], i);
 }
 
+// ---- the same compaction as ONE launch: decoupled look-back over tiles of 1024 ballot words (65536 Gaussians) ----
+// Replaces k_admit_scan (one workgroup walking every per-workgroup count: 15 us at 10 M Gaussians) + k_admit_scatter256 on speculated
+// frames, and counts, where the keys pass through anyway, what the depth sort wants to know about them: the 2048-bin fine histogram
+// and the key range of the bucket sort (gsx_internal.h).  A tile: every thread takes four consecutive ballot words; popcounts -> block
+// scan -> the tile's total is published as one 64-bit {epoch, flag, count} word (kernels_sort.hip's protocol: relaxed agent-scope
+// store / loads, "the data is the flag") and wave 0 looks back over the tiles before it, 64 at a time; wave 1 does the same for the
+// projection's visible counts (N_vis: a statistic).  The admitted indices go to LDS first, then every thread gathers keys for whole
+// runs of them: independent loads, coalesced pair stores (a lane walking the bits of its own words waited for each key in turn).
+// Tiles are taken in ticket order, so a tile only ever waits for tiles that are running.
+constexpr int kCompactThreads = 256;
+constexpr uint32_t kCompactList = 8192;   // admitted indices of a tile held in LDS (a tile that admits more walks its words directly)
+typedef unsigned long long u64c;
+constexpr u64c kCFlagAggregate = 1, kCFlagPrefix = 2;
+
+// exclusive prefix of tile `tile` over status[2 * k] (k < tile): one wave, 64 predecessors per round trip, nearest first
+__device__ inline uint32_t compact_lookback(const u64c* __restrict__ status, uint32_t tile, uint32_t epoch, uint32_t lane) {
+    uint32_t excl = 0;
+    int32_t k = (int32_t)tile - 1;
+    while (k >= 0) {
+        const int32_t kk = k - (int32_t)lane;
+        u64c w = 0;
+        if (kk >= 0) w = __hip_atomic_load(status + 2 * (size_t)kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t flag = (uint32_t)(w >> 32) & 3u;
+        const bool there = kk >= 0 && (uint32_t)(w >> 34) == epoch && flag != 0;
+        const unsigned long long missing = __ballot(kk >= 0 && !there);
+        const unsigned long long prefix = __ballot(there && flag == (uint32_t)kCFlagPrefix);
+        const uint32_t first_missing = missing ? (uint32_t)__ffsll((long long)missing) - 1u : 64u;
+        const uint32_t first_prefix = prefix ? (uint32_t)__ffsll((long long)prefix) - 1u : 64u;
+        const uint32_t take = first_prefix < first_missing ? first_prefix + 1u : first_missing;   // lanes [0, take) are consumed
+        uint32_t x = (lane < take && kk >= 0) ? (uint32_t)w : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        excl += x;
+        if (first_prefix < first_missing) break;
+        k -= (int32_t)take;
+        if (take == 0) __builtin_amdgcn_s_sleep(1);
+    }
+    return excl;
+}
+
+__global__ __launch_bounds__(kCompactThreads) void k_admit_compact(const uint32_t* __restrict__ key, uint32_t words,
+                                                                    const unsigned long long* __restrict__ ballots,
+                                                                    const uint32_t* __restrict__ block_visible, uint32_t nblocks,
+                                                                    uint2* __restrict__ pairs, uint32_t* __restrict__ d_total,
+                                                                    uint32_t* __restrict__ d_n_visible, uint32_t* __restrict__ ticket,
+                                                                    u64c* __restrict__ status, uint32_t epoch, uint32_t* __restrict__ fine,
+                                                                    const uint32_t* __restrict__ hint, uint32_t* __restrict__ acc,
+                                                                    uint32_t* __restrict__ reset) {
+    __shared__ uint32_t s_hist[kMsdFine];
+    __shared__ uint32_t s_list[kCompactList];
+    __shared__ uint32_t s_wsum[kCompactThreads / 64], s_vsum[kCompactThreads / 64], s_mn[kCompactThreads / 64], s_mx[kCompactThreads / 64];
+    __shared__ uint32_t s_tile, s_before, s_vis_before;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n_tiles = (words + kCompactWordsPerTile - 1u) / kCompactWordsPerTile;   // == gridDim.x: one tile per workgroup
+    if (tid == 0) s_tile = atomicAdd(&ticket[0], 1u);
+    if (fine)
+        for (uint32_t i = tid; i < kMsdFine; i += kCompactThreads) s_hist[i] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    if (tile == 0 && tid == 0 && reset) {  // the cell the NEXT sort accumulates into
+        reset[0] = 0xFFFFFFFFu;
+        reset[1] = 0u;
+    }
+    // the thread's four ballot words, its count, the tile's scan
+    const uint32_t w0 = tile * kCompactWordsPerTile + 4u * tid;
+    unsigned long long b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = w0 + (uint32_t)j < words ? ballots[w0 + j] : 0ull;
+    const uint32_t mine = (uint32_t)(__popcll(b[0]) + __popcll(b[1]) + __popcll(b[2]) + __popcll(b[3]));
+    uint32_t vis = 0;
+    if (block_visible) {
+        const uint32_t bi = tile * (kCompactWordsPerTile / 4u) + tid;   // 256-Gaussian projection workgroups: four ballot words each
+        if (bi < nblocks) vis = block_visible[bi];
+    }
+    uint32_t x = mine, vx = vis;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o, 64);
+        if (lane >= (uint32_t)o) x += y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vx += __shfl_xor(vx, o, 64);
+    if (lane == 63) s_wsum[wave] = x;
+    if (lane == 0) s_vsum[wave] = vx;
+    __syncthreads();
+    uint32_t woff = 0, total = 0, vtotal = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kCompactThreads / 64; ++w) {
+        if (w < wave) woff += s_wsum[w];
+        total += s_wsum[w];
+        vtotal += s_vsum[w];
+    }
+    const uint32_t local = woff + x - mine;   // first slot of this thread's pairs inside the tile
+    const u64c tag = (u64c)epoch << 34;
+    if (wave < 2) {   // wave 0: the pair counts; wave 1: the visible counts (words 2 * tile and 2 * tile + 1)
+        const uint32_t val = wave == 0 ? total : vtotal;
+        u64c* my = status + 2 * (size_t)tile + wave;
+        if (lane == 0) __hip_atomic_store(my, tag | ((tile == 0 ? kCFlagPrefix : kCFlagAggregate) << 32) | (u64c)val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0;
+        if (tile > 0) {
+            excl = compact_lookback(status + wave, tile, epoch, lane);
+            if (lane == 0) __hip_atomic_store(my, tag | (kCFlagPrefix << 32) | (u64c)(excl + val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) (wave == 0 ? s_before : s_vis_before) = excl;
+    }
+    __syncthreads();
+    const uint32_t before = s_before;
+    if (tile == n_tiles - 1u && tid == 0) {
+        *d_total = before + total;
+        if (block_visible) *d_n_visible = s_vis_before + vtotal;
+    }
+    uint32_t lo = 0, fs = 0;
+    if (fine) msd_mapping(hint, lo, fs);
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+    if (total <= kCompactList) {
+        uint32_t o = local;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned long long m = b[j];
+            while (m) {
+                s_list[o++] = (w0 + (uint32_t)j) * 64u + (uint32_t)__ffsll((long long)m) - 1u;
+                m &= m - 1ull;
+            }
+        }
+        __syncthreads();
+        constexpr int kU = 4;
+        for (uint32_t q0 = 0; q0 < total; q0 += kCompactThreads * kU) {
+            uint32_t idx[kU], kk[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const uint32_t q = q0 + (uint32_t)u * kCompactThreads + tid;
+                idx[u] = q < total ? s_list[q] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) kk[u] = idx[u] != 0xFFFFFFFFu ? key[idx[u]] : 0u;
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                if (idx[u] != 0xFFFFFFFFu) {
+                    const uint32_t q = q0 + (uint32_t)u * kCompactThreads + tid;
+                    pairs[before + q] = make_uint2(kk[u], idx[u]);
+                    if (fine) {
+                        atomicAdd(&s_hist[msd_fine(kk[u], lo, fs)], 1u);
+                        mn = min(mn, kk[u]);
+                        mx = max(mx, kk[u]);
+                    }
+                }
+            }
+        }
+    } else {
+        uint32_t o = before + local;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned long long m = b[j];
+            while (m) {
+                const uint32_t i = (w0 + (uint32_t)j) * 64u + (uint32_t)__ffsll((long long)m) - 1u;
+                m &= m - 1ull;
+                const uint32_t k = key[i];
+                pairs[o++] = make_uint2(k, i);
+                if (fine) {
+                    atomicAdd(&s_hist[msd_fine(k, lo, fs)], 1u);
+                    mn = min(mn, k);
+                    mx = max(mx, k);
+                }
+            }
+        }
+    }
+    if (fine) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+        }
+        if (lane == 0) {
+            s_mn[wave] = mn;
+            s_mx[wave] = mx;
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < kMsdFine; i += kCompactThreads)
+            if (s_hist[i]) atomicAdd(&fine[i], s_hist[i]);
+        if (tid == 0) {
+            for (uint32_t w = 1; w < kCompactThreads / 64; ++w) {
+                mn = min(mn, s_mn[w]);
+                mx = max(mx, s_mx[w]);
+            }
+            if (mn <= mx) {
+                atomicMin(&acc[0], mn);
+                atomicMax(&acc[1], mx);
+            }
+        }
+    }
+    // the last workgroup to finish re-arms the ticket for the next launch
+    if (tid == 0) {
+        const uint32_t fin = atomicAdd(&ticket[1], 1u);
+        if (fin == n_tiles - 1u) {
+            ticket[1] = 0;
+            __hip_atomic_store(&ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+hipError_t launch_admit_compact(hipStream_t s, const uint32_t* key, uint32_t n, const unsigned long long* ballots, uint32_t* d_total, uint2* pairs,
+                                const uint32_t* block_visible, uint32_t* d_n_visible, uint32_t* msd_ws, uint32_t seq) {
+    const uint32_t words = (n + 63u) / 64u;
+    if (!words) {
+        if (block_visible) (void)gsx::op::MemsetAsync(d_n_visible, 0, 4, s);
+        return gsx::op::MemsetAsync(d_total, 0, 4, s);
+    }
+    const uint32_t tiles = (words + kCompactWordsPerTile - 1u) / kCompactWordsPerTile;
+    const MsdCells mc = msd_cells(msd_ws, seq);
+    GSX_LAUNCH(k_admit_compact, dim3(tiles), dim3(kCompactThreads), 0, s, key, words, ballots, block_visible, (n + 255u) / 256u, pairs, d_total, d_n_visible,
+               msd_ws + kMsdTicket, reinterpret_cast<u64c*>(msd_ws + kMsdStatus), next_sort_epoch(), mc.fine, mc.hint, mc.acc, mc.reset);
+    return hipGetLastError();
+}
+
 hipError_t launch_admit_from_project(hipStream_t s, const uint32_t* key, uint32_t n, const unsigned long long* ballots,
                                      const uint32_t* block_counts, uint32_t* block_offsets, uint32_t* d_total, uint2* pairs,
                                      bool sparse, const uint32_t* block_visible, uint32_t* d_n_visible) {

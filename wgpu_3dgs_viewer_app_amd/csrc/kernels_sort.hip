@@ -198,7 +198,10 @@ typedef unsigned long long u64;
 // projection's key plane as it lies (culled records carry that key) and writes dense pairs: no compaction pass before the
 // sort (the unspeculated frame paid 40 MB + 68 MB + 68 MB for one).  The number of elements that do exist is the sum of this
 // pass's histogram; workgroup 0 writes it to *d_n_out, which is the element count of the passes that follow.
-template <int IN, int OUT, bool LANE_ORDERED, bool SKIP, int ROUNDS>
+// MSD: the digit of a key is s_map[msd_fine(key)] — the partition pass of the bucket sort (gsx_internal.h): `ghist` is the 2048-bin fine
+// histogram, cut here, by every workgroup alike, into 256 coarse buckets of equal population (consecutive fine bins: the digit is
+// monotone in the key); ranges_out receives the buckets.
+template <int IN, int OUT, bool LANE_ORDERED, bool SKIP, int ROUNDS, bool MSD = false>
 __device__ __forceinline__ void radix_sweep_tiles(const uint32_t* __restrict__ keys_in,
                                                                    const uint32_t* __restrict__ vals_in,
                                                                    const uint2* __restrict__ pairs_in,
@@ -214,8 +217,14 @@ __device__ __forceinline__ void radix_sweep_tiles(const uint32_t* __restrict__ k
                                                           const uint4* __restrict__ payload_in, uint4* __restrict__ payload_out,
                                                           uint2* __restrict__ s_pairs /* LDS: kRadixTile */, uint32_t (*__restrict__ cnt)[256] /* LDS: [kSweepWaves][256] */,
                                                           uint32_t* __restrict__ s_gbase /* LDS: 256 */, uint32_t* __restrict__ s_wtot /* LDS: kSweepWaves */,
-                                                          uint32_t* __restrict__ s_misc /* LDS: [0] tile, [1] last, [2] tile_n */) {
+                                                          uint32_t* __restrict__ s_misc /* LDS: [0] tile, [1] last, [2] tile_n */,
+                                                          uint8_t* __restrict__ s_map = nullptr /* MSD, LDS: kMsdFine */, uint32_t* __restrict__ s_span = nullptr /* MSD, LDS: 512 */,
+                                                          uint32_t msd_lo = 0, uint32_t msd_fs = 0) {
     constexpr int kTile = kSweepThreads * ROUNDS;  // elements per tile
+    auto digit_of = [&](uint32_t k) -> uint32_t {
+        if constexpr (MSD) return s_map[msd_fine(k, msd_lo, msd_fs)];
+        else return (k >> shift) & dmask;
+    };
     constexpr int kChunk = 64 * ROUNDS;            // contiguous elements per wave
     uint32_t& s_tile = s_misc[0];
     uint32_t& s_last = s_misc[1];
@@ -230,7 +239,48 @@ __device__ __forceinline__ void radix_sweep_tiles(const uint32_t* __restrict__ k
 
     // exclusive scan of this pass's global digit histogram: thread d -> first output slot of digit d
     uint32_t dbase;
-    {
+    if constexpr (MSD) {
+        // fine histogram -> exclusive prefix (thread t: bins 4t .. 4t + 3) -> coarse bucket of every fine bin = prefix / ceil(n / 256):
+        // a bucket holds consecutive bins whose prefixes fall into one stretch of that length — at most that many elements plus its
+        // last bin's.  [first, end) of every bucket: min / max over its bins (LDS atomics; the prefix is monotone).
+        const uint4 h4 = reinterpret_cast<const uint4*>(ghist)[tid];
+        const uint32_t sum4 = h4.x + h4.y + h4.z + h4.w;
+        uint32_t x = sum4;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= (uint32_t)o) x += y;
+        }
+        if (lane == 63) s_wtot[wave] = x;
+        s_span[tid] = tid < 256u ? 0xFFFFFFFFu : 0u;  // [0, 256): first slot of a bucket (min) | [256, 512): its end (max)
+        __syncthreads();
+        uint32_t woff = 0, total = 0;
+        for (uint32_t w = 0; w < (uint32_t)kSweepWaves; ++w) {
+            if (w < wave) woff += s_wtot[w];
+            total += s_wtot[w];
+        }
+        const uint32_t target = max(1u, (total + kMsdBuckets - 1u) / kMsdBuckets);
+        uint32_t pre = woff + x - sum4;
+        const uint32_t hh[4] = {h4.x, h4.y, h4.z, h4.w};
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t c = min(kMsdBuckets - 1u, pre / target);
+            packed |= c << (8 * j);
+            if (hh[j]) {
+                atomicMin(&s_span[c], pre);
+                atomicMax(&s_span[256u + c], pre + hh[j]);
+            }
+            pre += hh[j];
+        }
+        reinterpret_cast<uint32_t*>(s_map)[tid] = packed;
+        __syncthreads();
+        const uint32_t first = dig ? s_span[tid] : 0xFFFFFFFFu, end = dig ? s_span[256u + tid] : 0u;
+        const uint32_t v = first != 0xFFFFFFFFu ? end - first : 0u;
+        dbase = v ? first : 0u;
+        if (ranges_out && blockIdx.x == 0 && dig) ranges_out[tid] = v ? make_uint2(dbase, dbase + v) : make_uint2(0u, 0u);
+        __syncthreads();
+    } else {
         const uint32_t v = dig ? ghist[tid] : 0u;
         uint32_t x = v;
 #pragma unroll
@@ -288,7 +338,7 @@ __device__ __forceinline__ void radix_sweep_tiles(const uint32_t* __restrict__ k
 #pragma unroll
             for (int r = 0; r < ROUNDS; ++r) {
                 const bool valid = SKIP ? key[r] != 0xFFFFFFFFu : base + r * 64 + lane < n;
-                rank[r] = valid ? atomicAdd(&cnt[wave][(key[r] >> shift) & dmask], 1u) : 0u;
+                rank[r] = valid ? atomicAdd(&cnt[wave][digit_of(key[r])], 1u) : 0u;
             }
         } else {
             // Stable ranks in three straight-line phases, so that nothing waits for an LDS round trip per round (a read ->
@@ -300,14 +350,14 @@ __device__ __forceinline__ void radix_sweep_tiles(const uint32_t* __restrict__ k
 #pragma unroll
             for (int r = 0; r < ROUNDS; ++r) {
                 const bool valid = SKIP ? key[r] != 0xFFFFFFFFu : base + r * 64 + lane < n;
-                mm[r] = wave_match8((key[r] >> shift) & dmask, valid);
+                mm[r] = wave_match8(digit_of(key[r]), valid);
             }
 #pragma unroll
             for (int r = 0; r < ROUNDS; ++r) {
                 const bool valid = SKIP ? key[r] != 0xFFFFFFFFu : base + r * 64 + lane < n;
                 const uint32_t before = (uint32_t)__popcll(mm[r] & lanemask_lt());
                 rank[r] = 0;
-                if (valid && before == 0) rank[r] = atomicAdd(&cnt[wave][(key[r] >> shift) & dmask], (uint32_t)__popcll(mm[r]));
+                if (valid && before == 0) rank[r] = atomicAdd(&cnt[wave][digit_of(key[r])], (uint32_t)__popcll(mm[r]));
             }
 #pragma unroll
             for (int r = 0; r < ROUNDS; ++r) {
@@ -365,7 +415,7 @@ __device__ __forceinline__ void radix_sweep_tiles(const uint32_t* __restrict__ k
         for (int r = 0; r < ROUNDS; ++r) {
             const uint32_t e = base + r * 64 + lane;
             if (SKIP ? key[r] != 0xFFFFFFFFu : e < n) {
-                const uint32_t digit = (key[r] >> shift) & dmask;
+                const uint32_t digit = digit_of(key[r]);
                 s_pairs[cnt[wave][digit] + rank[r]] = make_uint2(key[r], val[r]);
             }
         }
@@ -413,7 +463,7 @@ __device__ __forceinline__ void radix_sweep_tiles(const uint32_t* __restrict__ k
             const uint32_t slot = r * kSweepThreads + tid;
             if (slot < tile_n) {
                 const uint2 kv = s_pairs[slot];
-                const uint32_t o = s_gbase[(kv.x >> shift) & dmask] + slot;
+                const uint32_t o = s_gbase[digit_of(kv.x)] + slot;
                 if (OUT == 0) {
                     pairs_out[o] = kv;
                 } else {
@@ -634,5 +684,423 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
     }
     return hipGetLastError();
 }
+
+// =====================================================================================================================
+// Bucket sort (gsx_internal.h "bucket sort"): fine histogram -> MSD partition (the onesweep kernel, digit = balanced bucket
+// table) -> every bucket sorted in LDS.  Three launches at most (two when the producer of the pairs counted the histogram)
+// for what the LSD sort does in five; the depth sort of a speculated frame, of its repair round, of a multi-GPU rank's band.
+// =====================================================================================================================
+uint32_t next_sort_epoch() { return (g_epoch.fetch_add(1, std::memory_order_relaxed) & 0x1FFFFFFFu) | (1u << 29); }
+
+// the fine histogram + key range of sort `seq` from keys that already lie in memory (KEY_STRIDE 1: key array, 2: pairs)
+template <int KEY_STRIDE>
+__global__ __launch_bounds__(kRadixThreads) void k_msd_hist(const uint32_t* __restrict__ keys, uint32_t n_cap, const uint32_t* __restrict__ d_n,
+                                                             uint32_t* __restrict__ fine, const uint32_t* __restrict__ hint, uint32_t* __restrict__ acc,
+                                                             uint32_t* __restrict__ reset) {
+    __shared__ uint32_t hist[kMsdFine];
+    __shared__ uint32_t s_mn[kRadixWaves], s_mx[kRadixWaves];
+    const uint32_t n = d_n ? min(*d_n, n_cap) : n_cap;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (blockIdx.x == 0 && tid == 0) {  // the cell the NEXT sort accumulates into
+        reset[0] = 0xFFFFFFFFu;
+        reset[1] = 0u;
+    }
+    const uint32_t share = max(4096u, (((n + gridDim.x - 1u) / gridDim.x) + 1023u) & ~1023u);
+    const uint32_t lo_e = blockIdx.x * share, hi_e = min(n, lo_e + share);
+    if (lo_e >= n) return;
+    for (uint32_t i = tid; i < kMsdFine; i += kRadixThreads) hist[i] = 0;
+    uint32_t lo, fs;
+    msd_mapping(hint, lo, fs);
+    __syncthreads();
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+    constexpr int kU = 4;
+    for (uint32_t base = lo_e + wave * (64u * kU); base < hi_e; base += kRadixWaves * (64u * kU)) {
+        uint32_t key[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const uint32_t e = base + u * 64u + lane;
+            key[u] = e < hi_e ? keys[(size_t)e * KEY_STRIDE] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const uint32_t e = base + u * 64u + lane;
+            if (e < hi_e) {
+                atomicAdd(&hist[msd_fine(key[u], lo, fs)], 1u);
+                mn = min(mn, key[u]);
+                mx = max(mx, key[u]);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_down((int)mn, o, 64));
+        mx = max(mx, (uint32_t)__shfl_down((int)mx, o, 64));
+    }
+    if (lane == 0) {
+        s_mn[wave] = mn;
+        s_mx[wave] = mx;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < kMsdFine; i += kRadixThreads)
+        if (hist[i]) atomicAdd(&fine[i], hist[i]);
+    if (tid == 0) {
+        for (int w = 1; w < kRadixWaves; ++w) {
+            mn = min(mn, s_mn[w]);
+            mx = max(mx, s_mx[w]);
+        }
+        if (mn <= mx) {
+            atomicMin(&acc[0], mn);
+            atomicMax(&acc[1], mx);
+        }
+    }
+}
+
+// the partition pass: k_radix_onesweep with the bucket table as its digit
+template <int IN, bool LANE_ORDERED>
+__global__ __launch_bounds__(kSweepThreads) void k_msd_sweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                              const uint2* __restrict__ pairs_in, uint2* __restrict__ pairs_out, uint32_t n_cap,
+                                                              const uint32_t* __restrict__ d_n, uint32_t* __restrict__ fine, const uint32_t* __restrict__ hint,
+                                                              uint32_t* __restrict__ ticket, u64* __restrict__ status, uint32_t epoch,
+                                                              uint2* __restrict__ ranges_out, uint32_t small_n) {
+    __shared__ uint2 s_pairs[kRadixTile];
+    __shared__ uint32_t cnt[kSweepWaves][256];
+    __shared__ uint32_t s_gbase[256];
+    __shared__ uint32_t s_wtot[kSweepWaves];
+    __shared__ uint32_t s_misc[4];
+    __shared__ uint32_t s_span[512];
+    __shared__ __attribute__((aligned(16))) uint8_t s_map[kMsdFine];
+    const uint32_t n = d_n ? min(*d_n, n_cap) : n_cap;
+    if (n == 0) {  // no tile, no workgroup takes part: the buckets of the sort before must not stay behind
+        if (blockIdx.x == 0 && threadIdx.x < kMsdBuckets) ranges_out[threadIdx.x] = make_uint2(0u, 0u);
+        return;
+    }
+    uint32_t lo, fs;
+    msd_mapping(hint, lo, fs);
+    if (n <= small_n)
+        radix_sweep_tiles<IN, 0, LANE_ORDERED, false, kRadixRoundsSmall, true>(keys_in, vals_in, pairs_in, nullptr, nullptr, pairs_out, n, 0, 255u, fine, ticket, status,
+                                                                                epoch, fine, kMsdFine, nullptr, ranges_out, nullptr, nullptr, s_pairs, cnt, s_gbase,
+                                                                                s_wtot, s_misc, s_map, s_span, lo, fs);
+    else
+        radix_sweep_tiles<IN, 0, LANE_ORDERED, false, kRadixRounds, true>(keys_in, vals_in, pairs_in, nullptr, nullptr, pairs_out, n, 0, 255u, fine, ticket, status, epoch,
+                                                                           fine, kMsdFine, nullptr, ranges_out, nullptr, nullptr, s_pairs, cnt, s_gbase, s_wtot, s_misc,
+                                                                           s_map, s_span, lo, fs);
+}
+
+// ---- every bucket sorted on the key bits that vary inside it: stable LSD passes of up to 8 bits, per-wave counters ----
+constexpr int kBucketRounds = 16;
+constexpr uint32_t kBucketCap = kSweepThreads * kBucketRounds;  // 8192 pairs in LDS
+
+// stable ranks of the wave's elements among the wave's chunk (one returning LDS add per element, or ballot matching)
+template <bool LANE_ORDERED, int ROUNDS>
+__device__ __forceinline__ void bucket_ranks(const uint32_t (&dg)[ROUNDS], const bool (&ok)[ROUNDS], uint32_t (&rank)[ROUNDS], uint32_t* __restrict__ wcnt /* LDS: this wave's 256 counters */,
+                                             int rounds) {
+    if (LANE_ORDERED) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) rank[r] = (r < rounds && ok[r]) ? atomicAdd(&wcnt[dg[r]], 1u) : 0u;
+    } else {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            rank[r] = 0;
+            if (r < rounds) {  // (uniform)
+                const unsigned long long mm = wave_match8(dg[r], ok[r]);
+                const uint32_t before = (uint32_t)__popcll(mm & lanemask_lt());
+                uint32_t base = 0;
+                if (ok[r] && before == 0) base = atomicAdd(&wcnt[dg[r]], (uint32_t)__popcll(mm));
+                const uint32_t first = ((uint32_t)__ffsll((long long)mm) - 1u) & 63u;
+                rank[r] = (uint32_t)__shfl((int)base, (int)first, 64) + before;
+            }
+        }
+    }
+}
+
+// after the ranks: thread d turns cnt[w][d] into wave w's first slot of digit d (+ base[d]); returns nothing — callers sync
+__device__ __forceinline__ void bucket_offsets(uint32_t (*__restrict__ cnt)[256], uint32_t* __restrict__ s_wtot, const uint32_t* __restrict__ s_base /* LDS, nullable: per-digit start */,
+                                               uint32_t* __restrict__ s_base_next /* LDS, nullable: += the tile's count */) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const bool dig = tid < 256u;
+    uint32_t tile_cnt = 0;
+    if (dig) {
+#pragma unroll
+        for (int w = 0; w < kSweepWaves; ++w) {
+            const uint32_t c = cnt[w][tid];
+            cnt[w][tid] = tile_cnt;
+            tile_cnt += c;
+        }
+    }
+    uint32_t start;
+    if (s_base) {  // several tiles: the digit's run begins where the tiles before left it
+        start = dig ? s_base[tid] : 0u;
+        if (dig && s_base_next) s_base_next[tid] = start + tile_cnt;
+    } else {       // one tile: exclusive scan over the digits
+        uint32_t x = tile_cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= (uint32_t)o) x += y;
+        }
+        if (lane == 63) s_wtot[wave] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t w = 0; w < wave; ++w) woff += s_wtot[w];
+        start = woff + x - tile_cnt;
+    }
+    if (dig) {
+#pragma unroll
+        for (int w = 0; w < kSweepWaves; ++w) cnt[w][tid] += start;
+    }
+}
+
+template <bool LANE_ORDERED>
+__global__ __launch_bounds__(kSweepThreads) void k_bucket_sort(uint2* src /* the partitioned pairs (large buckets ping-pong between src and tmp) */, uint2* tmp,
+                                                                uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, const uint2* __restrict__ ranges,
+                                                                uint32_t cap) {
+    uint2* const src_rw = src;
+    __shared__ uint2 s_pairs[kBucketCap];
+    __shared__ uint32_t cnt[kSweepWaves][256];
+    __shared__ uint32_t s_wtot[kSweepWaves];
+    __shared__ uint32_t s_mn[kSweepWaves], s_mx[kSweepWaves];
+    __shared__ uint32_t s_base[256];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t b = blockIdx.x; b < kMsdBuckets; b += gridDim.x) {
+        const uint2 range = ranges[b];
+        const uint32_t start = range.x, m = range.y - range.x;
+        if (m == 0) continue;  // (uniform)
+        if (m <= cap) {
+            // ---- the bucket in registers / LDS ----
+            const int rounds = (int)((m + kSweepThreads - 1u) / kSweepThreads);   // rounds per lane; wave w owns [w * 64 * rounds, ...)
+            const uint32_t chunk = 64u * (uint32_t)rounds;
+            uint32_t key[kBucketRounds], val[kBucketRounds];
+            bool ok[kBucketRounds];
+            uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+#pragma unroll
+            for (int r = 0; r < kBucketRounds; ++r) {
+                const uint32_t e = wave * chunk + (uint32_t)r * 64u + lane;
+                ok[r] = r < rounds && e < m;
+                uint2 kv = make_uint2(0u, 0u);
+                if (ok[r]) kv = src[start + e];
+                key[r] = kv.x;
+                val[r] = kv.y;
+                if (ok[r]) {
+                    mn = min(mn, kv.x);
+                    mx = max(mx, kv.x);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+                mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+            }
+            if (lane == 0) {
+                s_mn[wave] = mn;
+                s_mx[wave] = mx;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < kSweepWaves; ++w) {
+                mn = min(mn, s_mn[w]);
+                mx = max(mx, s_mx[w]);
+            }
+            const int bits = mx > mn ? 32 - __clz((int)(mx - mn)) : 0;   // key bits that vary inside the bucket
+            const int passes = (bits + 7) / 8;
+            const int dbits = passes ? (bits + passes - 1) / passes : 0;
+            const uint32_t dmask = (1u << dbits) - 1u;
+            for (int p = 0; p < passes; ++p) {
+                for (uint32_t i = tid; i < (uint32_t)kSweepWaves * 256u; i += kSweepThreads) (&cnt[0][0])[i] = 0;
+                __syncthreads();
+                uint32_t dg[kBucketRounds], rank[kBucketRounds];
+#pragma unroll
+                for (int r = 0; r < kBucketRounds; ++r) dg[r] = ((key[r] - mn) >> (dbits * p)) & dmask;
+                bucket_ranks<LANE_ORDERED, kBucketRounds>(dg, ok, rank, cnt[wave], rounds);
+                __syncthreads();
+                bucket_offsets(cnt, s_wtot, nullptr, nullptr);
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < kBucketRounds; ++r)
+                    if (ok[r]) s_pairs[cnt[wave][dg[r]] + rank[r]] = make_uint2(key[r], val[r]);
+                __syncthreads();
+                if (p + 1 < passes) {
+#pragma unroll
+                    for (int r = 0; r < kBucketRounds; ++r) {
+                        if (ok[r]) {
+                            const uint2 kv = s_pairs[wave * chunk + (uint32_t)r * 64u + lane];
+                            key[r] = kv.x;
+                            val[r] = kv.y;
+                        }
+                    }
+                }
+            }
+            if (passes == 0) {  // every key of the bucket is the same: the partition pass left them in index order
+#pragma unroll
+                for (int r = 0; r < kBucketRounds; ++r) {
+                    if (ok[r]) {
+                        const uint32_t e = wave * chunk + (uint32_t)r * 64u + lane;
+                        keys_out[start + e] = key[r];
+                        vals_out[start + e] = val[r];
+                    }
+                }
+            } else {
+                for (uint32_t slot = tid; slot < m; slot += kSweepThreads) {
+                    const uint2 kv = s_pairs[slot];
+                    keys_out[start + slot] = kv.x;
+                    vals_out[start + slot] = kv.y;
+                }
+            }
+            __syncthreads();  // s_pairs, cnt, s_mn / s_mx are reused by the next bucket
+        } else {
+            // ---- a bucket that does not fit: the same stable passes through global memory, tile by tile (one workgroup: slow, correct) ----
+            uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+            for (uint32_t e = tid; e < m; e += kSweepThreads) {
+                const uint32_t k = src[start + e].x;
+                mn = min(mn, k);
+                mx = max(mx, k);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+                mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+            }
+            if (lane == 0) {
+                s_mn[wave] = mn;
+                s_mx[wave] = mx;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < kSweepWaves; ++w) {
+                mn = min(mn, s_mn[w]);
+                mx = max(mx, s_mx[w]);
+            }
+            const int bits = mx > mn ? 32 - __clz((int)(mx - mn)) : 0;
+            const int passes = (bits + 7) / 8;
+            const int dbits = passes ? (bits + passes - 1) / passes : 0;
+            const uint32_t dmask = (1u << dbits) - 1u;
+            if (passes == 0) {
+                for (uint32_t e = tid; e < m; e += kSweepThreads) {
+                    const uint2 kv = src[start + e];
+                    keys_out[start + e] = kv.x;
+                    vals_out[start + e] = kv.y;
+                }
+            }
+            const uint2* from = src + start;
+            uint2* to = tmp + start;
+            for (int p = 0; p < passes; ++p) {
+                const bool last = p + 1 == passes;
+                // the pass's histogram over the whole bucket -> first slot of every digit
+                if (tid < 256u) s_base[tid] = 0;
+                __syncthreads();
+                for (uint32_t e = tid; e < m; e += kSweepThreads) atomicAdd(&s_base[((from[e].x - mn) >> (dbits * p)) & dmask], 1u);
+                __syncthreads();
+                {
+                    const uint32_t c = tid < 256u ? s_base[tid] : 0u;
+                    uint32_t x = c;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        uint32_t y = __shfl_up(x, o, 64);
+                        if (lane >= (uint32_t)o) x += y;
+                    }
+                    if (lane == 63) s_wtot[wave] = x;
+                    __syncthreads();
+                    uint32_t woff = 0;
+                    for (uint32_t w = 0; w < wave; ++w) woff += s_wtot[w];
+                    if (tid < 256u) s_base[tid] = woff + x - c;
+                    __syncthreads();
+                }
+                for (uint32_t t0 = 0; t0 < m; t0 += kBucketCap) {
+                    const uint32_t tm = min(kBucketCap, m - t0);
+                    const int rounds = (int)((tm + kSweepThreads - 1u) / kSweepThreads);
+                    const uint32_t chunk = 64u * (uint32_t)rounds;
+                    for (uint32_t i = tid; i < (uint32_t)kSweepWaves * 256u; i += kSweepThreads) (&cnt[0][0])[i] = 0;
+                    __syncthreads();
+                    uint32_t key[kBucketRounds], val[kBucketRounds], dg[kBucketRounds], rank[kBucketRounds];
+                    bool ok[kBucketRounds];
+#pragma unroll
+                    for (int r = 0; r < kBucketRounds; ++r) {
+                        const uint32_t e = wave * chunk + (uint32_t)r * 64u + lane;
+                        ok[r] = r < rounds && e < tm;
+                        uint2 kv = make_uint2(0u, 0u);
+                        if (ok[r]) kv = from[t0 + e];
+                        key[r] = kv.x;
+                        val[r] = kv.y;
+                        dg[r] = ((kv.x - mn) >> (dbits * p)) & dmask;
+                    }
+                    bucket_ranks<LANE_ORDERED, kBucketRounds>(dg, ok, rank, cnt[wave], rounds);
+                    __syncthreads();
+                    bucket_offsets(cnt, s_wtot, s_base, s_base);   // thread d reads s_base[d] and writes it back advanced: its own word only
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < kBucketRounds; ++r) {
+                        if (ok[r]) {
+                            const uint32_t o = cnt[wave][dg[r]] + rank[r];
+                            if (last) {
+                                keys_out[start + o] = key[r];
+                                vals_out[start + o] = val[r];
+                            } else {
+                                to[o] = make_uint2(key[r], val[r]);
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+                // what this pass wrote is what the next pass reads: visible to the whole workgroup behind the barrier
+                __threadfence_block();
+                __syncthreads();
+                const uint2* nf = to;
+                to = (to == tmp + start) ? src_rw + start : tmp + start;
+                from = nf;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+static std::atomic<uint32_t> g_bucket_cap{0};
+void bucket_sort_set_cap(uint32_t cap) { g_bucket_cap.store(cap); }
+
+hipError_t msd_workspace_init(hipStream_t s, uint32_t* ws, size_t words) {
+    hipError_t e = gsx::op::MemsetAsync(ws, 0, 4 * words, s);
+    if (e != hipSuccess) return e;
+    static const uint32_t cells[6] = {0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
+    return gsx::op::MemcpyAsync(ws + kMsdCells, cells, sizeof cells, hipMemcpyHostToDevice, s);
+}
+
+hipError_t launch_bucket_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n, uint32_t* d_n, bool iota_values, uint32_t* msd_ws, uint32_t seq,
+                              bool hist_done) {
+    if (n == 0) return hipSuccess;
+    const MsdCells mc = msd_cells(msd_ws, seq);
+    uint32_t* ticket = buf.workspace + 1024;
+    u64* status = reinterpret_cast<u64*>(buf.workspace + 1032);
+    if (!hist_done) {
+        static const uint32_t hper = 4096u;
+        const uint32_t hgrid = std::max<uint32_t>(1u, std::min<uint32_t>(256u, (uint32_t)(((uint64_t)n + hper - 1) / hper)));
+        if (buf.pairs_src)
+            GSX_LAUNCH(k_msd_hist<2>, dim3(hgrid), dim3(kRadixThreads), 0, s, reinterpret_cast<const uint32_t*>(buf.pairs_src), n, d_n, mc.fine, mc.hint, mc.acc, mc.reset);
+        else
+            GSX_LAUNCH(k_msd_hist<1>, dim3(hgrid), dim3(kRadixThreads), 0, s, buf.keys_src, n, d_n, mc.fine, mc.hint, mc.acc, mc.reset);
+    }
+    const uint32_t tiles = radix_tiles(n);
+    static const uint32_t grid_limit = getenv("GSX_RADIX_GRID") ? (uint32_t)atoi(getenv("GSX_RADIX_GRID")) : kRadixGrid;
+    const uint32_t grid = std::min<uint32_t>(grid_limit, tiles);
+    const bool lane_ordered = use_lane_ordered();
+    const uint32_t epoch = next_sort_epoch();
+#define GSX_MSD_ARGS dim3(grid), dim3(kSweepThreads), 0, s, buf.keys_src, buf.vals_src, buf.pairs_src, buf.pairs_a, n, d_n, mc.fine, mc.hint, ticket, status, epoch, mc.ranges, radix_small_n()
+    if (buf.pairs_src) {
+        if (lane_ordered) GSX_LAUNCH((k_msd_sweep<2, true>), GSX_MSD_ARGS);
+        else GSX_LAUNCH((k_msd_sweep<2, false>), GSX_MSD_ARGS);
+    } else if (iota_values) {
+        if (lane_ordered) GSX_LAUNCH((k_msd_sweep<0, true>), GSX_MSD_ARGS);
+        else GSX_LAUNCH((k_msd_sweep<0, false>), GSX_MSD_ARGS);
+    } else {
+        if (lane_ordered) GSX_LAUNCH((k_msd_sweep<1, true>), GSX_MSD_ARGS);
+        else GSX_LAUNCH((k_msd_sweep<1, false>), GSX_MSD_ARGS);
+    }
+#undef GSX_MSD_ARGS
+    const uint32_t cap_dbg = g_bucket_cap.load(std::memory_order_relaxed);
+    const uint32_t cap = cap_dbg ? std::min(cap_dbg, kBucketCap) : kBucketCap;
+    if (lane_ordered)
+        GSX_LAUNCH((k_bucket_sort<true>), dim3(kMsdBuckets), dim3(kSweepThreads), 0, s, buf.pairs_a, buf.pairs_b, buf.keys_out, buf.vals_out, mc.ranges, cap);
+    else
+        GSX_LAUNCH((k_bucket_sort<false>), dim3(kMsdBuckets), dim3(kSweepThreads), 0, s, buf.pairs_a, buf.pairs_b, buf.keys_out, buf.vals_out, mc.ranges, cap);
+    return hipGetLastError();
+}
+
 
 }  // namespace gsx
