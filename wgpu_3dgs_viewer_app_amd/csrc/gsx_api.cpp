@@ -66,6 +66,7 @@ static gsx_status lane_create(gsx_viewer* v, gsx_viewer** out) {
     l->blocks_adaptive = v->blocks_adaptive;
     l->tile_order_on = v->tile_order_on;
     l->bucket_sort = v->bucket_sort;
+    l->bin_fused = v->bin_fused;
     l->sorted_records = v->sorted_records;
     l->tile_profile = v->tile_profile;
     // a stream that does not share its hardware queue with the viewer's or another lane's: streams that do are kept (parked)
@@ -266,6 +267,7 @@ gsx_status gsx_viewer_create(const gsx_viewer_desc* desc, gsx_viewer** out) {
     v->tile_profile = getenv("GSX_TILE_PROFILE") != nullptr;
     if (const char* e = getenv("GSX_TILE_ORDER")) v->tile_order_on = atoi(e) != 0;
     if (const char* e = getenv("GSX_BUCKET_SORT")) v->bucket_sort = atoi(e) != 0;
+    if (const char* e = getenv("GSX_BIN_FUSED")) v->bin_fused = atoi(e) != 0;
     if (const char* e = getenv("GSX_BUCKET_CAP")) bucket_sort_set_cap((uint32_t)atoi(e));   // tests: buckets above this take the global-memory path
     if (const char* e = getenv("GSX_SORTED_RECORDS")) v->sorted_records = atoi(e) != 0 ? 1 : 0;
     if (const char* bx = getenv("GSX_BLOCKS_MAX")) {

@@ -350,6 +350,8 @@ gsx_status prepare_edits(gsx_viewer* v, Model* m, bool* launched) {
     return GSX_OK;
 }
 
+static gsx_status ensure_msd(gsx_viewer* v, Model* m, DevBuf& ws);
+
 gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
     frame_consts_setup(v->view, v->proj, v->width, v->height, m->mt, v->size, v->display_mode, v->sh_deg, v->no_sh0,
                        v->params, &m->fc);
@@ -439,10 +441,16 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
         // exactly those their conic / colour records; gsx_shard_pack then looks at nothing else
         Counters* dcx = m->counters.as<Counters>();
         HIPCHK(m->adm_pairs.ensure(8 * std::max<size_t>(m->n, 1)));
-        HIPCHK(m->adm_offsets.ensure(m->adm_counts.bytes));
-        HIPCHK(launch_admit_from_project(v->stream, m->proj_rec().key, n32, m->adm_ballots.as<unsigned long long>(),
-                                         m->adm_counts.as<uint32_t>(), m->adm_offsets.as<uint32_t>(), &dcx->n_candidates,
-                                         m->adm_pairs.as<uint2>(), true, m->block_vis.as<uint32_t>(), &dcx->n_visible));
+        if (v->bucket_sort) {  // one launch (look-back over 65536-Gaussian tiles) instead of scan + scatter
+            if ((st = ensure_msd(v, m, m->msd_ws))) return st;
+            HIPCHK(launch_admit_compact(v->stream, m->proj_rec().key, n32, m->adm_ballots.as<unsigned long long>(), &dcx->n_candidates, m->adm_pairs.as<uint2>(),
+                                        m->block_vis.as<uint32_t>(), &dcx->n_visible, m->msd_ws.as<uint32_t>(), 0, nullptr, false));
+        } else {
+            HIPCHK(m->adm_offsets.ensure(m->adm_counts.bytes));
+            HIPCHK(launch_admit_from_project(v->stream, m->proj_rec().key, n32, m->adm_ballots.as<unsigned long long>(),
+                                             m->adm_counts.as<uint32_t>(), m->adm_offsets.as<uint32_t>(), &dcx->n_candidates,
+                                             m->adm_pairs.as<uint2>(), true, m->block_vis.as<uint32_t>(), &dcx->n_visible));
+        }
         m->visible_count_pending = false;
         if (m->lazy && (st = shade_admitted(v, m, LateProjection{m->adm_pairs.as<uint2>(), &dcx->n_candidates, nullptr, m->rect8_active}))) return st;
         m->cand_valid = true;
@@ -811,13 +819,26 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
                 m->tile_order_valid = true;
                 order_build = false;
             }
+            const bool fused = v->bin_fused;
             {
                 ScopedPass t(v, GSX_PASS_BIN);
-                HIPCHK(launch_block_bin(v->stream, j0, j1, d_n, m->sorted_idx, m->rec(), m->sk_out.as<uint32_t>(), m->srect.as<uint4>(),
-                                        m->cnt.as<uint32_t>(), m->block_sums.as<uint32_t>(), dc, cap, row_lo, row_hi, done_in, row_words,
-                                        (progressive && later) ? done_count : nullptr, owned_tiles, slab_index, win, m->fc.tiles_x,
-                                        m->fc.tiles_y, bsx, bsy, m->block_table.as<uint4>(), m->tp_src.as<uint2>(), m->ranges.as<uint2>(),
-                                        jobs, table_ready));
+                if (fused) {
+                    const size_t bw = 4 * bin_workspace_words(m->sortbin_cap);
+                    if (m->bin_ws.bytes < bw) {
+                        HIPCHK(m->bin_ws.ensure(bw));
+                        HIPCHK(gsx::op::MemsetAsync(m->bin_ws.p, 0, m->bin_ws.bytes, v->stream));
+                    }
+                    HIPCHK(launch_block_bin_fused(v->stream, j0, j1, d_n, m->sorted_idx, m->rec(), m->sk_out.as<uint32_t>(), m->srect.as<uint4>(), dc, cap,
+                                                  row_lo, row_hi, done_in, row_words, (progressive && later) ? done_count : nullptr, owned_tiles, slab_index,
+                                                  win, m->fc.tiles_x, m->fc.tiles_y, bsx, bsy, m->block_table.as<uint4>(), m->tp_src.as<uint2>(),
+                                                  m->ranges.as<uint2>(), jobs, table_ready, m->bin_ws.as<uint32_t>(), m->tsort_ws.as<uint32_t>(), block_bits));
+                } else {
+                    HIPCHK(launch_block_bin(v->stream, j0, j1, d_n, m->sorted_idx, m->rec(), m->sk_out.as<uint32_t>(), m->srect.as<uint4>(),
+                                            m->cnt.as<uint32_t>(), m->block_sums.as<uint32_t>(), dc, cap, row_lo, row_hi, done_in, row_words,
+                                            (progressive && later) ? done_count : nullptr, owned_tiles, slab_index, win, m->fc.tiles_x,
+                                            m->fc.tiles_y, bsx, bsy, m->block_table.as<uint4>(), m->tp_src.as<uint2>(), m->ranges.as<uint2>(),
+                                            jobs, table_ready));
+                }
                 zero_pending = false;
                 v->pass_launches[GSX_PASS_BIN] += 1;
             }
@@ -834,7 +855,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
                 sorted_records = v->sorted_records >= 0 ? v->sorted_records == 1 : m->lists_long;  // (the LAST digit pass carries them)
                 if (sorted_records) HIPCHK(m->brec_sorted.ensure(sizeof(uint4) * (size_t)cap));
                 HIPCHK(launch_radix_sort(v->stream, rb, block_cap, &dc->n_entries, block_bits, false, false, block_bits <= 8 ? m->ranges.as<uint2>() : nullptr,
-                                         sorted_records ? m->srect.as<uint4>() : nullptr, sorted_records ? m->brec_sorted.as<uint4>() : nullptr));
+                                         sorted_records ? m->srect.as<uint4>() : nullptr, sorted_records ? m->brec_sorted.as<uint4>() : nullptr, fused));
                 m->tile_keys = m->tk_out.as<uint32_t>();
                 m->tile_list = m->tv_out.as<uint32_t>();
                 v->pass_launches[GSX_PASS_TILE_SORT] += 1;
@@ -1013,19 +1034,23 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
             // binning applies the exact windows)
             WindowPyramid pyr2 = window_pyramid_layout(m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse2.as<uint32_t>());
             pyr2.min_of_starts = 1;
+            uint32_t seq2 = 0;
+            if (v->bucket_sort) {  // (the repair round's keys lie behind the windows: a population, and a key range, of their own)
+                if ((st = ensure_msd(v, m, m->msd_ws2))) return st;
+                seq2 = m->msd_seq2++;
+            }
             HIPCHK(launch_admit(v->stream, m->proj_rec(), n, nullptr, m->fc.tiles_x, nullptr,
                                 row_words, pyr2, &dc->spec_need,
                                 m->adm_ballots2.as<unsigned long long>(), m->adm_counts2.as<uint32_t>(), &dc->n_sorted2,
-                                m->adm_pairs.as<uint2>()));
+                                m->adm_pairs.as<uint2>(), v->bucket_sort ? m->msd_ws2.as<uint32_t>() : nullptr, seq2));
             if (m->lazy) {  // the repair round needs records the lazy projection did not shade
                 gsx_status sst = shade_admitted(v, m, LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>(), m->rect8_active});
                 if (sst) return sst;
             }
             RadixBuffers rb{nullptr, nullptr, m->adm_pairs.as<uint2>(), m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
                             m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
-            if (v->bucket_sort) {  // (the repair round's keys lie behind the windows: a population, and a key range, of their own)
-                if ((st = ensure_msd(v, m, m->msd_ws2))) return st;
-                HIPCHK(launch_bucket_sort(v->stream, rb, n, &dc->n_sorted2, false, m->msd_ws2.as<uint32_t>(), m->msd_seq2++, false));
+            if (v->bucket_sort) {
+                HIPCHK(launch_bucket_sort(v->stream, rb, n, &dc->n_sorted2, false, m->msd_ws2.as<uint32_t>(), seq2, true));
             } else {
                 HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted2, 32, false));
             }

@@ -234,7 +234,8 @@ void radix_set_rank_override(int mode);  // -1 none | 0 ballot matching | 1 lane
 // ranges_out (one-digit sorts only: bits <= 8): [first, end) of every key value in the sorted output, (0, 0) for absent ones
 hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n, uint32_t* d_n, int bits, bool iota_values,
                              bool skip_culled = false, uint2* ranges_out = nullptr,  // skip_culled: keys == 0xFFFFFFFF do not exist; *d_n receives the count that do
-                             const uint4* payload_in = nullptr, uint4* payload_out = nullptr);  // the last pass also writes payload_out[sorted position] = payload_in[value]
+                             const uint4* payload_in = nullptr, uint4* payload_out = nullptr,  // the last pass also writes payload_out[sorted position] = payload_in[value]
+                             bool hist_done = false);  // the digit histograms are in the workspace already (k_block_bin counted them): no histogram launch
 
 // ---- bucket sort of (depth key, Gaussian index) pairs: one MSD partition + one launch of in-LDS bucket sorts (kernels_sort.hip) ----
 // The order the spec defines is (key, index) and the index travels with the key; what the depth sort of a speculated frame (a few
@@ -293,7 +294,9 @@ hipError_t launch_bucket_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n
 // histogram + key range of sort `seq`.  *d_total = pairs; block_visible (nullable): the projection's per-workgroup visible counts are
 // summed into *d_n_visible on the way.
 hipError_t launch_admit_compact(hipStream_t s, const uint32_t* key, uint32_t n, const unsigned long long* ballots, uint32_t* d_total, uint2* pairs,
-                                const uint32_t* block_visible, uint32_t* d_n_visible, uint32_t* msd_ws, uint32_t seq);
+                                const uint32_t* block_visible, uint32_t* d_n_visible, uint32_t* msd_ws, uint32_t seq,
+                                const uint32_t* d_skip = nullptr /* points at 0: nothing is admitted, no ballot is read */,
+                                bool histogram = true /* false: the compaction alone (msd_ws still holds its ticket and status words) */);
 uint32_t next_sort_epoch();  // status-word epochs of every look-back kernel of the process (kernels_sort.hip)
 void bucket_sort_set_cap(uint32_t cap);  // tests: buckets above `cap` pairs take the global-memory path (0: the LDS capacity)
 
@@ -520,6 +523,15 @@ size_t scan_blocks(uint64_t n);
 // Block lists (progressive frames): bin by blocks of 2^bsx x 2^bsy tiles (<= 256 blocks), one 8-bit sort pass, and
 // k_composite_blocks applies the exact per-tile decision.  brec: uint4 per slab record; table: 1024 uint4; ranges: the block
 // range table (zeroed here, filled by launch_tile_ranges).
+// the same as ONE launch behind the block table (k_block_bin: counts, slots by decoupled look-back, entries, and the block sort's digit
+// histograms into sort_ghist = the block sort's workspace): launch_radix_sort(..., hist_done = true) follows.  bin_ws: bin_workspace_words(records) u32, zeroed once.
+size_t bin_workspace_words(uint64_t n_records);
+hipError_t launch_block_bin_fused(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* d_n_vis, const uint32_t* sorted_idx,
+                                  const Records& rec, const uint32_t* sorted_keys, uint4* brec, SlabStats* stats, uint32_t capacity,
+                                  uint32_t row_lo, uint32_t row_hi, const uint32_t* done, uint32_t row_words, const uint32_t* d_done_count,
+                                  uint32_t owned_tiles, uint32_t slab_index, const uint2* window, uint32_t tiles_x, uint32_t tiles_y,
+                                  uint32_t bsx, uint32_t bsy, uint4* table, uint2* pairs, uint2* ranges, const ZeroJob& zero, bool table_ready,
+                                  uint32_t* bin_ws, uint32_t* sort_ghist, int block_bits);
 hipError_t launch_block_bin(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* d_n_vis, const uint32_t* sorted_idx,
                             const Records& rec, const uint32_t* sorted_keys, uint4* brec, uint32_t* cnt, uint32_t* block_sums,
                             SlabStats* stats, uint32_t capacity, uint32_t row_lo, uint32_t row_hi, const uint32_t* done,
@@ -578,7 +590,8 @@ hipError_t launch_admit_scatter(hipStream_t s, const uint32_t* key, uint32_t n, 
                                 const uint32_t* offsets, uint2* pairs, const uint32_t* d_skip = nullptr, uint32_t* d_total = nullptr, uint32_t rounds = 16);
 // (rec.rect8 != nullptr: rectangles are read from the packed plane)
 hipError_t launch_admit(hipStream_t s, const Records& rec, uint32_t n, const uint2* window, uint32_t tiles_x,
-                        const uint32_t* gate, uint32_t row_words, const WindowPyramid& pyramid, const uint32_t* d_skip, unsigned long long* ballots, uint32_t* counts, uint32_t* d_total, uint2* pairs);
+                        const uint32_t* gate, uint32_t row_words, const WindowPyramid& pyramid, const uint32_t* d_skip, unsigned long long* ballots, uint32_t* counts, uint32_t* d_total, uint2* pairs,
+                        uint32_t* msd_ws = nullptr, uint32_t seq = 0 /* msd_ws: compaction by k_admit_compact, which also counts the bucket sort's histogram of sort `seq` */);
 
 // Temporal occlusion speculation (kernels_spec.hip): verification of this frame's windows, windows of the next frame.
 // pyr2_data (nullable): + the min-pyramid of the repair windows' starts; grid / table / ranges (nullable): + the repair slab's block

@@ -223,6 +223,7 @@ struct Model {
     uint32_t* last_pod_mask = nullptr;  // the keep-bitset the projection pass used (mask, or mask & ~hidden)
     DevBuf adm_offsets, adm_counts2;  // scan output of adm_counts; counts of the admission passes that run outside the projection
     DevBuf adm_pairs, adm_ballots, adm_counts;  // admission pass: compacted (key, index) pairs, per-wave ballots, per-workgroup counts
+    DevBuf bin_ws;                   // k_block_bin: ticket + one status word per 2048-record tile
     DevBuf msd_ws, msd_ws2;          // bucket sort (gsx_internal.h): fine histogram, key-range cells, k_admit_compact's status words — main round / repair round
     uint32_t msd_seq = 0, msd_seq2 = 0;  // sorts made on them so far (the cells rotate)
     DevBuf pack_masks;             // destination bit mask per record (gsx_shard_pack)
@@ -433,6 +434,7 @@ struct gsx_viewer {
     uint32_t pass_launches[GSX_PASS_COUNT]{};
     DevBuf tile_prof;                    // GSX_TILE_PROFILE: what every tile of the LAST block-compositor launch of a frame's first slab cost
     bool tile_profile = false;
+    bool bin_fused = true;               // GSX_BIN_FUSED=0: block binning as count + scan + emit + histogram launches (A/B)
     bool bucket_sort = true;             // GSX_BUCKET_SORT=0: speculated frames, repair rounds and imported bands keep the five-launch LSD depth sort (A/B)
     bool tile_order_on = true;           // GSX_TILE_ORDER=0: the block compositor takes its tiles in index order (A/B)
     int sorted_records = -1;             // GSX_SORTED_RECORDS=0 / 1: never / always carry the block lists' records through the block sort (-1: by list length)

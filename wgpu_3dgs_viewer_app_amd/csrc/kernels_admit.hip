@@ -285,9 +285,19 @@ __global__ __launch_bounds__(kCompactThreads) void k_admit_compact(const uint32_
                                                                     uint32_t* __restrict__ d_n_visible, uint32_t* __restrict__ ticket,
                                                                     u64c* __restrict__ status, uint32_t epoch, uint32_t* __restrict__ fine,
                                                                     const uint32_t* __restrict__ hint, uint32_t* __restrict__ acc,
-                                                                    uint32_t* __restrict__ reset) {
+                                                                    uint32_t* __restrict__ reset, const uint32_t* __restrict__ d_skip) {
     __shared__ uint32_t s_hist[kMsdFine];
     __shared__ uint32_t s_list[kCompactList];
+    if (d_skip && *d_skip == 0u) {  // a repair round with nothing to repair: no ballot was written, nothing is admitted (uniform)
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            *d_total = 0u;
+            if (reset) {
+                reset[0] = 0xFFFFFFFFu;
+                reset[1] = 0u;
+            }
+        }
+        return;
+    }
     __shared__ uint32_t s_wsum[kCompactThreads / 64], s_vsum[kCompactThreads / 64], s_mn[kCompactThreads / 64], s_mx[kCompactThreads / 64];
     __shared__ uint32_t s_tile, s_before, s_vis_before;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -439,7 +449,7 @@ __global__ __launch_bounds__(kCompactThreads) void k_admit_compact(const uint32_
 }
 
 hipError_t launch_admit_compact(hipStream_t s, const uint32_t* key, uint32_t n, const unsigned long long* ballots, uint32_t* d_total, uint2* pairs,
-                                const uint32_t* block_visible, uint32_t* d_n_visible, uint32_t* msd_ws, uint32_t seq) {
+                                const uint32_t* block_visible, uint32_t* d_n_visible, uint32_t* msd_ws, uint32_t seq, const uint32_t* d_skip, bool histogram) {
     const uint32_t words = (n + 63u) / 64u;
     if (!words) {
         if (block_visible) (void)gsx::op::MemsetAsync(d_n_visible, 0, 4, s);
@@ -448,7 +458,8 @@ hipError_t launch_admit_compact(hipStream_t s, const uint32_t* key, uint32_t n, 
     const uint32_t tiles = (words + kCompactWordsPerTile - 1u) / kCompactWordsPerTile;
     const MsdCells mc = msd_cells(msd_ws, seq);
     GSX_LAUNCH(k_admit_compact, dim3(tiles), dim3(kCompactThreads), 0, s, key, words, ballots, block_visible, (n + 255u) / 256u, pairs, d_total, d_n_visible,
-               msd_ws + kMsdTicket, reinterpret_cast<u64c*>(msd_ws + kMsdStatus), next_sort_epoch(), mc.fine, mc.hint, mc.acc, mc.reset);
+               msd_ws + kMsdTicket, reinterpret_cast<u64c*>(msd_ws + kMsdStatus), next_sort_epoch(), histogram ? mc.fine : nullptr, mc.hint, mc.acc,
+               histogram ? mc.reset : nullptr, d_skip);
     return hipGetLastError();
 }
 
@@ -482,10 +493,13 @@ hipError_t launch_admit_scatter(hipStream_t s, const uint32_t* key, uint32_t n, 
 }
 
 hipError_t launch_admit(hipStream_t s, const Records& rec, uint32_t n, const uint2* window, uint32_t tiles_x,
-                        const uint32_t* gate, uint32_t row_words, const WindowPyramid& pyramid, const uint32_t* d_skip, unsigned long long* ballots, uint32_t* counts, uint32_t* d_total, uint2* pairs) {
+                        const uint32_t* gate, uint32_t row_words, const WindowPyramid& pyramid, const uint32_t* d_skip, unsigned long long* ballots, uint32_t* counts, uint32_t* d_total, uint2* pairs,
+                        uint32_t* msd_ws, uint32_t seq) {
     const uint32_t nb = (uint32_t)admit_blocks(n);
     if (!nb) return gsx::op::MemsetAsync(d_total, 0, 4, s);
     GSX_LAUNCH(k_admit_count, dim3(nb), dim3(kAdmitThreads), 0, s, rec.key, rec.a, n, window, tiles_x, gate, row_words, pyramid, d_skip, ballots, counts, rec.rect8);
+    if (msd_ws)  // the compaction by look-back, counting the bucket sort's histogram on its way: launch_bucket_sort(..., hist_done = true) follows
+        return launch_admit_compact(s, rec.key, n, ballots, d_total, pairs, nullptr, nullptr, msd_ws, seq, d_skip, true);
     GSX_LAUNCH(k_admit_scatter<kAdmitRounds>, dim3(nb), dim3(kAdmitThreads), 0, s, rec.key, n, ballots, counts, pairs, d_skip, d_total);  // (scans the raw counts itself)
     return hipGetLastError();
 }

@@ -521,6 +521,234 @@ __global__ __launch_bounds__(kBinThreads) void k_block_emit(uint32_t jbase, uint
     }
 }
 
+// ---- k_block_counts + k_scan_block_sums + k_block_emit + the block sort's histogram as ONE launch (round 6) ----
+// Persistent 1024-lane workgroups take 2048-record tiles of the slab in ticket order.  A tile: every lane gathers two records
+// (both loads in flight), counts the blocks each touches, the tile's total is published as one 64-bit {epoch, flag, count} word and
+// wave 0 looks back over the tiles before it (kernels_sort.hip's protocol; 64 predecessors per round trip) — so the entries' slots
+// are known without a scan kernel in between — then the lanes emit their (block, slab position) entries and count them into the
+// workgroup's LDS histogram of the block sort's digits, flushed once per workgroup (a few hundred workgroups at most: when every one
+// of 6144 emit workgroups flushed 256 bins, round 4, the flushes cost more than the histogram launch they replaced).
+// The slab's cut (entries that do not fit the pair buffers: SlabStats::slab_cut) falls out of the same prefix: the tile in which the
+// capacity is crossed emits up to the last record that fits and says where it stopped; tiles behind it emit nothing.
+constexpr int kFuseThreads = 1024;
+constexpr int kFuseWaves = kFuseThreads / 64;
+constexpr uint32_t kFuseTile = 2u * kFuseThreads;   // records per tile: two per lane
+constexpr uint32_t kFuseGrid = 256;
+typedef unsigned long long u64b;
+
+size_t bin_workspace_words(uint64_t n_records) { return 8 + 2 * (size_t)((n_records + kFuseTile - 1) / kFuseTile + 1); }
+
+__global__ __launch_bounds__(kFuseThreads) void k_block_bin(const uint32_t* __restrict__ d_n_vis, uint32_t j0, uint32_t j1,
+                                                             const uint32_t* __restrict__ sorted_idx, const float4* __restrict__ rec_a,
+                                                             const uint32_t* __restrict__ sorted_keys, uint4* __restrict__ brec,
+                                                             uint2* __restrict__ pairs, SlabStats* __restrict__ stats, uint32_t capacity,
+                                                             uint32_t row_lo, uint32_t row_hi, const uint32_t* __restrict__ d_done_count,
+                                                             uint32_t owned_tiles, uint32_t slab_index, BlockGrid g,
+                                                             const uint4* __restrict__ table, int keyed, uint32_t* __restrict__ order_buf,
+                                                             uint32_t order_tiles, uint32_t* __restrict__ walk_max_out,
+                                                             uint32_t* __restrict__ ticket, u64b* __restrict__ status, uint32_t epoch,
+                                                             uint32_t* __restrict__ ghist, int passes, int dbits) {
+    __shared__ uint4 tab[1024];
+    __shared__ uint32_t hist[2][256];
+    __shared__ uint32_t s_w0[kFuseWaves], s_w1[kFuseWaves];
+    __shared__ uint32_t s_tile, s_before, s_cut;
+    const uint32_t extra = order_buf ? 1u : 0u, workers = gridDim.x - extra, worker = blockIdx.x - extra;
+    if (extra && blockIdx.x == 0u) {
+        tile_order_job<kFuseThreads>(order_buf, order_tiles, reinterpret_cast<uint32_t*>(tab), walk_max_out);
+        return;
+    }
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n_vis = min(*d_n_vis, j1);
+    const uint32_t n = n_vis > j0 ? n_vis - j0 : 0u;
+    const uint32_t n_tiles = (n + kFuseTile - 1u) / kFuseTile;
+    const bool all_done = d_done_count && *d_done_count >= owned_tiles;   // every tile this rank composites is saturated
+    if (n_tiles == 0u || all_done) {
+        if (worker == 0u && tid == 0u) {
+            stats->n_entries = 0u;
+            stats->slab_cut = max(n_vis, j0);
+        }
+        return;
+    }
+    const uint32_t participants = min(workers, n_tiles);
+    if (worker >= participants) return;
+    const uint32_t n_blocks = g.blocks_x * g.blocks_y;
+    for (uint32_t b = tid; b < n_blocks; b += kFuseThreads) tab[b] = table[b];
+    if (tid < 512u) (&hist[0][0])[tid] = 0u;
+    __syncthreads();
+    const uint32_t dmask = (1u << dbits) - 1u;
+    for (;;) {
+        if (tid == 0) s_tile = atomicAdd(&ticket[0], 1u);
+        __syncthreads();
+        const uint32_t tile = s_tile;
+        if (tile >= n_tiles) break;
+        // the lane's two records: slab positions p0 < p1 (the tile's first and second half: the scan below runs half by half)
+        uint32_t pos[2], idx[2], key[2], rx[2], ry[2], c[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            pos[r] = tile * kFuseTile + (uint32_t)r * kFuseThreads + tid;
+            idx[r] = pos[r] < n ? sorted_idx[j0 + pos[r]] : 0u;
+            key[r] = pos[r] < n ? sorted_keys[j0 + pos[r]] : 0u;
+        }
+        float4 a[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) a[r] = pos[r] < n ? rec_a[idx[r]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            rx[r] = __float_as_uint(a[r].z);
+            ry[r] = __float_as_uint(a[r].w);
+            c[r] = 0;
+            uint32_t bx0, bx1, by0, by1;
+            if (pos[r] < n && block_rect(g, rx[r], ry[r], row_lo, row_hi, bx0, bx1, by0, by1))
+                for (uint32_t by = by0; by < by1; ++by)
+                    for (uint32_t bx = bx0; bx < bx1; ++bx) c[r] += block_takes(tab, by * g.blocks_x + bx, key[r], keyed != 0) ? 1u : 0u;
+            if (c[r]) brec[pos[r]] = make_uint4(rx[r], ry[r], key[r], idx[r]);   // (only records that make an entry are ever looked up)
+        }
+        // inclusive scans of both halves
+        uint32_t x0 = c[0], x1 = c[1];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y0 = __shfl_up(x0, o, 64), y1 = __shfl_up(x1, o, 64);
+            if (lane >= (uint32_t)o) {
+                x0 += y0;
+                x1 += y1;
+            }
+        }
+        if (lane == 63) {
+            s_w0[wave] = x0;
+            s_w1[wave] = x1;
+        }
+        __syncthreads();
+        uint32_t off0 = 0, off1 = 0, t0 = 0, t1 = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < (uint32_t)kFuseWaves; ++w) {
+            if (w < wave) {
+                off0 += s_w0[w];
+                off1 += s_w1[w];
+            }
+            t0 += s_w0[w];
+            t1 += s_w1[w];
+        }
+        const uint32_t total = t0 + t1;
+        const uint32_t e0 = off0 + x0 - c[0], e1 = t0 + off1 + x1 - c[1];   // first slot of each record's entries inside the tile
+        if (wave == 0) {
+            const u64b tag = (u64b)epoch << 34;
+            u64b* my = status + tile;
+            if (lane == 0) __hip_atomic_store(my, tag | ((tile == 0 ? 2ull : 1ull) << 32) | (u64b)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t excl = 0;
+            if (tile > 0) {
+                int32_t k = (int32_t)tile - 1;
+                while (k >= 0) {   // 64 predecessors per round trip, nearest first
+                    const int32_t kk = k - (int32_t)lane;
+                    u64b w = 0;
+                    if (kk >= 0) w = __hip_atomic_load(status + kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t flag = (uint32_t)(w >> 32) & 3u;
+                    const bool there = kk >= 0 && (uint32_t)(w >> 34) == epoch && flag != 0;
+                    const unsigned long long missing = __ballot(kk >= 0 && !there);
+                    const unsigned long long prefix = __ballot(there && flag == 2u);
+                    const uint32_t first_missing = missing ? (uint32_t)__ffsll((long long)missing) - 1u : 64u;
+                    const uint32_t first_prefix = prefix ? (uint32_t)__ffsll((long long)prefix) - 1u : 64u;
+                    const uint32_t take = first_prefix < first_missing ? first_prefix + 1u : first_missing;
+                    uint32_t x = (lane < take && kk >= 0) ? (uint32_t)w : 0u;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+                    excl += x;
+                    if (first_prefix < first_missing) break;
+                    k -= (int32_t)take;
+                    if (take == 0) __builtin_amdgcn_s_sleep(1);
+                }
+                if (lane == 0) __hip_atomic_store(my, tag | (2ull << 32) | (u64b)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane == 0) {
+                s_before = excl;
+                s_cut = 0xFFFFFFFFu;
+            }
+        }
+        __syncthreads();
+        const uint32_t before = s_before;
+        // the pair buffers hold `capacity` entries: the first record whose last entry would not fit is the slab's cut
+        const bool crossing = before <= capacity && before + total > capacity;
+        if (crossing) {
+            const uint32_t room = capacity - before;
+            if (c[0] && e0 + c[0] > room) atomicMin(&s_cut, pos[0]);
+            if (c[1] && e1 + c[1] > room) atomicMin(&s_cut, pos[1]);
+            __syncthreads();
+        }
+        const uint32_t cut = crossing ? s_cut : (before > capacity ? 0u : 0xFFFFFFFFu);   // (before > capacity: an earlier tile crossed)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (c[r] && pos[r] < cut) {
+                uint32_t o = before + (r == 0 ? e0 : e1);
+                uint32_t bx0, bx1, by0, by1;
+                if (block_rect(g, rx[r], ry[r], row_lo, row_hi, bx0, bx1, by0, by1))
+                    for (uint32_t by = by0; by < by1; ++by)
+                        for (uint32_t bx = bx0; bx < bx1; ++bx) {
+                            const uint32_t b = by * g.blocks_x + bx;
+                            if (!block_takes(tab, b, key[r], keyed != 0)) continue;
+                            pairs[o++] = make_uint2(b, pos[r]);
+                            atomicAdd(&hist[0][b & dmask], 1u);
+                            if (passes > 1) atomicAdd(&hist[1][(b >> dbits) & dmask], 1u);
+                        }
+            }
+        }
+        if (tid == 0) {
+            if (crossing) {   // entries up to the cut: the prefix of the record at the cut
+                stats->slab_cut = j0 + cut;
+            }
+            if (tile == n_tiles - 1u) {
+                const uint32_t all = before + total;
+                const bool over = all > capacity;
+                stats->n_entries_total += all;
+                stats->max_needed = max(stats->max_needed, all);
+                stats->slabs_used = max(stats->slabs_used, slab_index + 1u);
+                if (over) {
+                    stats->overflow = 1;
+                    stats->overflow_events += 1;
+                    stats->max_needed_ever = max(stats->max_needed_ever, all);
+                } else {
+                    stats->n_entries = all;
+                    stats->slab_cut = max(n_vis, j0);
+                }
+            }
+        }
+        if (crossing) {   // n_entries = entries in front of the cut: every lane knows its records' slots; the record AT the cut says it
+            if (c[0] && pos[0] == cut) stats->n_entries = before + e0;
+            if (c[1] && pos[1] == cut) stats->n_entries = before + e1;
+        }
+        __syncthreads();   // s_tile, s_w0 / s_w1, s_before, s_cut are reused by the next tile
+    }
+    for (uint32_t i = tid; i < 512u; i += kFuseThreads) {
+        const uint32_t v = (&hist[0][0])[i];
+        if (v && (int)(i >> 8) < passes) atomicAdd(&ghist[i], v);
+    }
+    if (tid == 0) {   // the last workgroup to leave re-arms the ticket
+        const uint32_t fin = atomicAdd(&ticket[1], 1u);
+        if (fin == participants - 1u) {
+            ticket[1] = 0;
+            __hip_atomic_store(&ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+hipError_t launch_block_bin_fused(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* d_n_vis, const uint32_t* sorted_idx,
+                                  const Records& rec, const uint32_t* sorted_keys, uint4* brec, SlabStats* stats, uint32_t capacity,
+                                  uint32_t row_lo, uint32_t row_hi, const uint32_t* done, uint32_t row_words, const uint32_t* d_done_count,
+                                  uint32_t owned_tiles, uint32_t slab_index, const uint2* window, uint32_t tiles_x, uint32_t tiles_y,
+                                  uint32_t bsx, uint32_t bsy, uint4* table, uint2* pairs, uint2* ranges, const ZeroJob& zero, bool table_ready,
+                                  uint32_t* bin_ws, uint32_t* sort_ghist, int block_bits) {
+    const BlockGrid g = block_grid(bsx, bsy, tiles_x, row_lo, row_hi);
+    if (!table_ready)
+        GSX_LAUNCH(k_block_table, dim3((g.blocks_x * g.blocks_y + 3u) / 4u), dim3(256), 0, s, g, tiles_x, tiles_y, row_lo, row_hi, done,
+                   row_words, window, table, ranges, zero.a, zero.na, zero.b, zero.nb);
+    const uint64_t tiles = ((uint64_t)(j1 > j0 ? j1 - j0 : 0) + kFuseTile - 1) / kFuseTile;
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(tiles, kFuseGrid);
+    const int passes = (block_bits + 7) / 8, dbits = (block_bits + passes - 1) / passes;
+    if (nb)
+        GSX_LAUNCH(k_block_bin, dim3(nb + (zero.order_buf ? 1u : 0u)), dim3(kFuseThreads), 0, s, d_n_vis, j0, j1, sorted_idx, rec.a, sorted_keys, brec, pairs,
+                   stats, capacity, row_lo, row_hi, d_done_count, owned_tiles, slab_index, g, table, window ? 1 : 0, zero.order_buf, zero.order_tiles,
+                   zero.order_buf ? &stats->walk_max : nullptr, bin_ws, reinterpret_cast<u64b*>(bin_ws + 8), next_sort_epoch(), sort_ghist, passes, dbits);
+    return hipGetLastError();
+}
+
 hipError_t launch_block_bin(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* d_n_vis, const uint32_t* sorted_idx,
                             const Records& rec, const uint32_t* sorted_keys, uint4* brec, uint32_t* cnt, uint32_t* block_sums,
                             SlabStats* stats, uint32_t capacity, uint32_t row_lo, uint32_t row_hi, const uint32_t* done,

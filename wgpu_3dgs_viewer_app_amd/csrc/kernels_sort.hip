@@ -615,7 +615,7 @@ static bool use_lane_ordered() {
 }
 
 hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n, uint32_t* d_n, int bits, bool iota_values,
-                             bool skip_culled, uint2* ranges_out, const uint4* payload_in, uint4* payload_out) {
+                             bool skip_culled, uint2* ranges_out, const uint4* payload_in, uint4* payload_out, bool hist_done) {
     if (n == 0) return hipSuccess;
     const int passes = (bits + 7) / 8;
     if (ranges_out && passes != 1) return hipErrorInvalidValue;  // key ranges fall out of a ONE-digit sort only
@@ -637,7 +637,9 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
     // are latency-bound: 300 k keys took 89 us with 4096 x 4 elements per workgroup, 67 us with 4096)
     static const uint32_t hper = getenv("GSX_RADIX_HPER") ? (uint32_t)atoi(getenv("GSX_RADIX_HPER")) : 4096u;
     const uint32_t hgrid = std::max<uint32_t>(1u, std::min<uint32_t>(768u, (uint32_t)(((uint64_t)n + hper - 1) / hper)));
-    if (buf.pairs_src)
+    if (hist_done) {
+        // (the kernel that wrote the pairs counted their digits into ghist: k_block_bin)
+    } else if (buf.pairs_src)
         GSX_LAUNCH(k_radix_global_hist<2>, dim3(hgrid), dim3(kRadixThreads), 0, s,
                            reinterpret_cast<const uint32_t*>(buf.pairs_src), n, d_n, passes, dbits, ghist, 0);
     else
