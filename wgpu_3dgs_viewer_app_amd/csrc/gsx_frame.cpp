@@ -73,6 +73,7 @@ static gsx_status wait_verdict(gsx_viewer* v, uint32_t seq, uint32_t* need) {
 // A decision that confirms the current mode doubles its phase — quadruples it when the verdict is clear — (64 ... 2048
 // frames: the probes then cost < 1 %), one that flips it starts over at 64.  By construction the result stays within a few per cent of the better of the two paths.
 constexpr uint32_t kWalkFineOn = 160, kWalkFineOff = 30;  // chunks of 128 candidates: finer blocks above / coarse blocks again below (measured under the finer ones)
+constexpr uint32_t kBucketSortMax = 1500000;  // pairs: above, the LSD depth sort (256 buckets of 8192 pairs fit the LDS; at 1 M the bucket sort takes half the LSD sort's time)
 constexpr uint32_t kProbeFrames = 5;   // the first is not timed (the switch itself is atypical), the other four are
 constexpr uint32_t kSettleWait = 8;    // frames enqueued behind a probe before the host waits for its timings
 constexpr uint32_t kSettleFrames = 64; // at most this many frames between a probe and the decision it feeds (normally: until its timings are in)
@@ -227,6 +228,10 @@ gsx_status finish_frame(gsx_viewer* v) {
 
             m->n_entries = m->h_counters->n_entries_total;
             m->counters_valid = true;
+            if (m->spec_round1) {
+                m->last_spec_sorted = m->h_counters->n_sorted;
+                m->last_repair_sorted = m->h_counters->n_sorted2;
+            }
             if (m->binned) m->slabs_hint = m->h_counters->slabs_used;
             m->stats_copy_inflight = false;
             note_overflow(m);
@@ -579,7 +584,9 @@ gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
                 // a speculated frame admits a few per cent of the visible records: ONE compaction launch that also counts the bucket
                 // sort's histogram, then a partition pass and a launch of in-LDS bucket sorts (gsx_internal.h "bucket sort") — four
                 // launches for what scan + scatter + histogram + four digit passes did in seven
-                const bool bucket = v->bucket_sort && m->spec_round1;
+                // (a frame that admits millions — stale windows after a camera jump, poses in random order — sorts faster in four full
+                //  digit passes: the bucket sort's buckets then outgrow the LDS.  The host only knows the count of an earlier frame: good enough)
+                const bool bucket = v->bucket_sort && m->spec_round1 && !(m->last_spec_sorted > kBucketSortMax);
                 uint32_t seq = 0;
                 if (bucket) {
                     gsx_status mst = ensure_msd(v, m, m->msd_ws);
@@ -677,6 +684,10 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
         if (progressive) {
             m->slabs_hint = m->h_counters->slabs_used;
             m->n_sorted = m->h_counters->n_sorted;
+        }
+        if (m->stats_copy_speculated) {
+            m->last_spec_sorted = m->h_counters->n_sorted;
+            m->last_repair_sorted = m->h_counters->n_sorted2;
         }
         note_overflow(m);  // a free-running loop learns here that some earlier frame spilled: larger pair buffers from now on
         // long block lists (a scene where little saturates): the block sort carries the lists' records along (k_composite_blocks
@@ -1035,21 +1046,22 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
             WindowPyramid pyr2 = window_pyramid_layout(m->fc.tiles_x, m->fc.tiles_y, m->spec_coarse2.as<uint32_t>());
             pyr2.min_of_starts = 1;
             uint32_t seq2 = 0;
-            if (v->bucket_sort) {  // (the repair round's keys lie behind the windows: a population, and a key range, of their own)
+            const bool bucket2 = v->bucket_sort && !(m->last_repair_sorted > kBucketSortMax);
+            if (bucket2) {  // (the repair round's keys lie behind the windows: a population, and a key range, of their own)
                 if ((st = ensure_msd(v, m, m->msd_ws2))) return st;
                 seq2 = m->msd_seq2++;
             }
             HIPCHK(launch_admit(v->stream, m->proj_rec(), n, nullptr, m->fc.tiles_x, nullptr,
                                 row_words, pyr2, &dc->spec_need,
                                 m->adm_ballots2.as<unsigned long long>(), m->adm_counts2.as<uint32_t>(), &dc->n_sorted2,
-                                m->adm_pairs.as<uint2>(), v->bucket_sort ? m->msd_ws2.as<uint32_t>() : nullptr, seq2));
+                                m->adm_pairs.as<uint2>(), bucket2 ? m->msd_ws2.as<uint32_t>() : nullptr, seq2));
             if (m->lazy) {  // the repair round needs records the lazy projection did not shade
                 gsx_status sst = shade_admitted(v, m, LateProjection{m->adm_pairs.as<uint2>(), &dc->n_sorted2, m->adm_ballots.as<unsigned long long>(), m->rect8_active});
                 if (sst) return sst;
             }
             RadixBuffers rb{nullptr, nullptr, m->adm_pairs.as<uint2>(), m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
                             m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
-            if (v->bucket_sort) {
+            if (bucket2) {
                 HIPCHK(launch_bucket_sort(v->stream, rb, n, &dc->n_sorted2, false, m->msd_ws2.as<uint32_t>(), seq2, true));
             } else {
                 HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted2, 32, false));

@@ -249,39 +249,50 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
 // last bin.
 constexpr uint32_t kMsdFine = 2048;      // fine bins
 constexpr uint32_t kMsdBuckets = 256;    // coarse buckets = the partition pass's digit
-// workspace (u32 words, zeroed at allocation except the cells): [0, 2048) fine histogram | [2048, 2054) three {min, max} cells, used
-// in rotation: sort k reads cell (k - 1) % 3 (the guess), accumulates into k % 3, resets (k + 1) % 3 | [2056] ticket, [2057] finished
+// workspace (u32 words, zeroed at allocation except the cells): [0, 2048) fine histogram | [2048, 2050) {min, max} of every key sorted
+// so far (the running union), [2050, 2052) its snapshot: what the kernels of a sort map keys by | [2056] ticket, [2057] finished
 // (k_admit_compact) | [2064, 2064 + 512) bucket ranges (uint2 x 256) | from 2576: k_admit_compact's status words, 4 per tile
 constexpr uint32_t kMsdCells = 2048, kMsdTicket = 2056, kMsdRanges = 2064, kMsdStatus = 2576;
 constexpr uint32_t kCompactWordsPerTile = 1024;  // ballot words (64 Gaussians each) per k_admit_compact workgroup
 inline size_t msd_workspace_words(uint64_t n_gaussians) {
     return kMsdStatus + 4 * (size_t)((((n_gaussians + 63) / 64) + kCompactWordsPerTile - 1) / kCompactWordsPerTile + 1);
 }
-// fine bin of a key: (max(key, lo) - lo) >> fs, at most 2047; lo / fs from the guessed key range (hint: {min, max} of an earlier sort, or
-// {0xFFFFFFFF, 0} = none: depths 2^-7 ... 2^14 then, 97 bins per octave)
-__device__ inline void msd_mapping(const uint32_t* __restrict__ hint, uint32_t& lo, uint32_t& fs) {
+// Fine bin of a key.  The keys of a sort are GUESSED to lie in [lo, hi] — the union of the key ranges of the model's earlier sorts (or,
+// before any, depths 2^-7 ... 2^14) — and that stretch gets bins 128 ... 1919 at 2^fs keys a bin; whatever lies outside still gets bins
+// of its own, a sixteenth of an octave wide, 128 on either side (beyond eight octaves: the outermost bin).  The guess decides the
+// balance only: a frame whose keys left the guessed range (a camera jump, a repair round that admits the far half of the scene) keeps
+// thousands of keys a bin instead of all of them in one.
+struct MsdMap {
+    uint32_t lo, hi, fs;
+};
+__device__ inline MsdMap msd_mapping(const uint32_t* __restrict__ hint) {
     uint32_t mn = 0x3C000000u, mx = 0x46800000u;
     const uint32_t a = hint[0], b = hint[1];
     if (a <= b) {
         mn = a;
         mx = b;
     }
-    lo = mn;
-    const int bits = 32 - __clz((int)((mx - mn) | 1u));
-    fs = bits > 11 ? (uint32_t)(bits - 11) : 0u;
+    const uint32_t span = mx - mn;
+    const int bits = 32 - __clz((int)(span | 1u));
+    uint32_t fs = bits > 11 ? (uint32_t)(bits - 11) : 0u;
+    if ((span >> fs) >= 1792u) fs += 1u;
+    return MsdMap{mn, mx, fs};
 }
-__device__ inline uint32_t msd_fine(uint32_t key, uint32_t lo, uint32_t fs) { return min((max(key, lo) - lo) >> fs, kMsdFine - 1u); }
-struct MsdCells {   // the three pointers of sort number `seq` on workspace `ws`
+__device__ inline uint32_t msd_fine(uint32_t key, const MsdMap& m) {
+    if (key < m.lo) return 127u - min((m.lo >> 19) - (key >> 19), 127u);
+    if (key > m.hi) return 1920u + min((key >> 19) - (m.hi >> 19), 127u);
+    return 128u + ((key - m.lo) >> m.fs);
+}
+struct MsdCells {   // pointers into workspace `ws`
     uint32_t* fine;
-    const uint32_t* hint;
-    uint32_t *acc, *reset;
+    const uint32_t* hint;   // {min, max}: the snapshot every kernel of a sort maps keys by
+    uint32_t* acc;          // {min, max}: the running union, widened by the kernel that counts the histogram; the bucket kernel copies it to `hint`
     uint2* ranges;
 };
-inline MsdCells msd_cells(uint32_t* ws, uint32_t seq) {
-    return MsdCells{ws, ws + kMsdCells + 2 * ((seq + 2) % 3), ws + kMsdCells + 2 * (seq % 3), ws + kMsdCells + 2 * ((seq + 1) % 3),
-                    reinterpret_cast<uint2*>(ws + kMsdRanges)};
+inline MsdCells msd_cells(uint32_t* ws, uint32_t /*seq*/) {
+    return MsdCells{ws, ws + kMsdCells + 2, ws + kMsdCells, reinterpret_cast<uint2*>(ws + kMsdRanges)};
 }
-// the workspace's initial contents (host): zeros, the three cells at {0xFFFFFFFF, 0} = "no keys seen"
+// the workspace's initial contents (host): zeros, both cells at {0xFFFFFFFF, 0} = "no keys seen"
 hipError_t msd_workspace_init(hipStream_t s, uint32_t* ws, size_t words);
 // n sizes the launches; *d_n is the element count.  hist_done: the fine histogram (and the cells) of sort `seq` were made by the
 // kernel that wrote buf.pairs_src (launch_admit_compact with the same ws and seq); otherwise k_msd_hist runs first.

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void k_admit_scatter_dense(const uint32_t* __r
 // runs of them: independent loads, coalesced pair stores (a lane walking the bits of its own words waited for each key in turn).
 // Tiles are taken in ticket order, so a tile only ever waits for tiles that are running.
 constexpr int kCompactThreads = 256;
-constexpr uint32_t kCompactList = 8192;   // admitted indices of a tile held in LDS (a tile that admits more walks its words directly)
+constexpr uint32_t kCompactList = 8192;   // admitted indices of a tile that lie in LDS at a time (a page)
 typedef unsigned long long u64c;
 constexpr u64c kCFlagAggregate = 1, kCFlagPrefix = 2;
 
@@ -285,17 +285,11 @@ __global__ __launch_bounds__(kCompactThreads) void k_admit_compact(const uint32_
                                                                     uint32_t* __restrict__ d_n_visible, uint32_t* __restrict__ ticket,
                                                                     u64c* __restrict__ status, uint32_t epoch, uint32_t* __restrict__ fine,
                                                                     const uint32_t* __restrict__ hint, uint32_t* __restrict__ acc,
-                                                                    uint32_t* __restrict__ reset, const uint32_t* __restrict__ d_skip) {
+                                                                    const uint32_t* __restrict__ d_skip) {
     __shared__ uint32_t s_hist[kMsdFine];
     __shared__ uint32_t s_list[kCompactList];
     if (d_skip && *d_skip == 0u) {  // a repair round with nothing to repair: no ballot was written, nothing is admitted (uniform)
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            *d_total = 0u;
-            if (reset) {
-                reset[0] = 0xFFFFFFFFu;
-                reset[1] = 0u;
-            }
-        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) *d_total = 0u;
         return;
     }
     __shared__ uint32_t s_wsum[kCompactThreads / 64], s_vsum[kCompactThreads / 64], s_mn[kCompactThreads / 64], s_mx[kCompactThreads / 64];
@@ -307,10 +301,6 @@ __global__ __launch_bounds__(kCompactThreads) void k_admit_compact(const uint32_
         for (uint32_t i = tid; i < kMsdFine; i += kCompactThreads) s_hist[i] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
-    if (tile == 0 && tid == 0 && reset) {  // the cell the NEXT sort accumulates into
-        reset[0] = 0xFFFFFFFFu;
-        reset[1] = 0u;
-    }
     // the thread's four ballot words, its count, the tile's scan
     const uint32_t w0 = tile * kCompactWordsPerTile + 4u * tid;
     unsigned long long b[4];
@@ -359,59 +349,49 @@ __global__ __launch_bounds__(kCompactThreads) void k_admit_compact(const uint32_
         *d_total = before + total;
         if (block_visible) *d_n_visible = s_vis_before + vtotal;
     }
-    uint32_t lo = 0, fs = 0;
-    if (fine) msd_mapping(hint, lo, fs);
+    MsdMap map{0u, 0u, 0u};
+    if (fine) map = msd_mapping(hint);
     uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-    if (total <= kCompactList) {
-        uint32_t o = local;
+    // the tile's admitted indices go through LDS a page of kCompactList at a time (a speculated frame's tile holds ~2000: one page;
+    // a tile where most is admitted — stale windows after a camera jump, a repair round behind them — takes up to eight): every
+    // lane hands in the indices whose slots fall into the page, in order, then all lanes gather keys for whole runs of them
+    {
+        uint32_t o = local;   // slot, inside the tile, of this lane's next index
+        for (uint32_t page_lo = 0; page_lo < total; page_lo += kCompactList) {
+            const uint32_t page_hi = page_lo + kCompactList, page_n = min(kCompactList, total - page_lo);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            unsigned long long m = b[j];
-            while (m) {
-                s_list[o++] = (w0 + (uint32_t)j) * 64u + (uint32_t)__ffsll((long long)m) - 1u;
-                m &= m - 1ull;
+            for (int j = 0; j < 4; ++j) {
+                while (b[j] && o < page_hi) {
+                    s_list[o - page_lo] = (w0 + (uint32_t)j) * 64u + (uint32_t)__ffsll((long long)b[j]) - 1u;
+                    b[j] &= b[j] - 1ull;
+                    ++o;
+                }
             }
-        }
-        __syncthreads();
-        constexpr int kU = 4;
-        for (uint32_t q0 = 0; q0 < total; q0 += kCompactThreads * kU) {
-            uint32_t idx[kU], kk[kU];
+            __syncthreads();
+            constexpr int kU = 4;
+            for (uint32_t q0 = 0; q0 < page_n; q0 += kCompactThreads * kU) {
+                uint32_t idx[kU], kk[kU];
 #pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                const uint32_t q = q0 + (uint32_t)u * kCompactThreads + tid;
-                idx[u] = q < total ? s_list[q] : 0xFFFFFFFFu;
-            }
-#pragma unroll
-            for (int u = 0; u < kU; ++u) kk[u] = idx[u] != 0xFFFFFFFFu ? key[idx[u]] : 0u;
-#pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                if (idx[u] != 0xFFFFFFFFu) {
+                for (int u = 0; u < kU; ++u) {
                     const uint32_t q = q0 + (uint32_t)u * kCompactThreads + tid;
-                    pairs[before + q] = make_uint2(kk[u], idx[u]);
-                    if (fine) {
-                        atomicAdd(&s_hist[msd_fine(kk[u], lo, fs)], 1u);
-                        mn = min(mn, kk[u]);
-                        mx = max(mx, kk[u]);
+                    idx[u] = q < page_n ? s_list[q] : 0xFFFFFFFFu;
+                }
+#pragma unroll
+                for (int u = 0; u < kU; ++u) kk[u] = idx[u] != 0xFFFFFFFFu ? key[idx[u]] : 0u;
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    if (idx[u] != 0xFFFFFFFFu) {
+                        const uint32_t q = q0 + (uint32_t)u * kCompactThreads + tid;
+                        pairs[before + page_lo + q] = make_uint2(kk[u], idx[u]);
+                        if (fine) {
+                            atomicAdd(&s_hist[msd_fine(kk[u], map)], 1u);
+                            mn = min(mn, kk[u]);
+                            mx = max(mx, kk[u]);
+                        }
                     }
                 }
             }
-        }
-    } else {
-        uint32_t o = before + local;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            unsigned long long m = b[j];
-            while (m) {
-                const uint32_t i = (w0 + (uint32_t)j) * 64u + (uint32_t)__ffsll((long long)m) - 1u;
-                m &= m - 1ull;
-                const uint32_t k = key[i];
-                pairs[o++] = make_uint2(k, i);
-                if (fine) {
-                    atomicAdd(&s_hist[msd_fine(k, lo, fs)], 1u);
-                    mn = min(mn, k);
-                    mx = max(mx, k);
-                }
-            }
+            __syncthreads();   // the next page overwrites the list
         }
     }
     if (fine) {
@@ -458,8 +438,7 @@ hipError_t launch_admit_compact(hipStream_t s, const uint32_t* key, uint32_t n, 
     const uint32_t tiles = (words + kCompactWordsPerTile - 1u) / kCompactWordsPerTile;
     const MsdCells mc = msd_cells(msd_ws, seq);
     GSX_LAUNCH(k_admit_compact, dim3(tiles), dim3(kCompactThreads), 0, s, key, words, ballots, block_visible, (n + 255u) / 256u, pairs, d_total, d_n_visible,
-               msd_ws + kMsdTicket, reinterpret_cast<u64c*>(msd_ws + kMsdStatus), next_sort_epoch(), histogram ? mc.fine : nullptr, mc.hint, mc.acc,
-               histogram ? mc.reset : nullptr, d_skip);
+               msd_ws + kMsdTicket, reinterpret_cast<u64c*>(msd_ws + kMsdStatus), next_sort_epoch(), histogram ? mc.fine : nullptr, mc.hint, mc.acc, d_skip);
     return hipGetLastError();
 }
 

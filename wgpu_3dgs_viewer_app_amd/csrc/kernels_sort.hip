@@ -219,10 +219,10 @@ __device__ __forceinline__ void radix_sweep_tiles(const uint32_t* __restrict__ k
                                                           uint32_t* __restrict__ s_gbase /* LDS: 256 */, uint32_t* __restrict__ s_wtot /* LDS: kSweepWaves */,
                                                           uint32_t* __restrict__ s_misc /* LDS: [0] tile, [1] last, [2] tile_n */,
                                                           uint8_t* __restrict__ s_map = nullptr /* MSD, LDS: kMsdFine */, uint32_t* __restrict__ s_span = nullptr /* MSD, LDS: 512 */,
-                                                          uint32_t msd_lo = 0, uint32_t msd_fs = 0) {
+                                                          const MsdMap msd_map = MsdMap{0u, 0u, 0u}) {
     constexpr int kTile = kSweepThreads * ROUNDS;  // elements per tile
     auto digit_of = [&](uint32_t k) -> uint32_t {
-        if constexpr (MSD) return s_map[msd_fine(k, msd_lo, msd_fs)];
+        if constexpr (MSD) return s_map[msd_fine(k, msd_map)];
         else return (k >> shift) & dmask;
     };
     constexpr int kChunk = 64 * ROUNDS;            // contiguous elements per wave
@@ -697,22 +697,16 @@ uint32_t next_sort_epoch() { return (g_epoch.fetch_add(1, std::memory_order_rela
 // the fine histogram + key range of sort `seq` from keys that already lie in memory (KEY_STRIDE 1: key array, 2: pairs)
 template <int KEY_STRIDE>
 __global__ __launch_bounds__(kRadixThreads) void k_msd_hist(const uint32_t* __restrict__ keys, uint32_t n_cap, const uint32_t* __restrict__ d_n,
-                                                             uint32_t* __restrict__ fine, const uint32_t* __restrict__ hint, uint32_t* __restrict__ acc,
-                                                             uint32_t* __restrict__ reset) {
+                                                             uint32_t* __restrict__ fine, const uint32_t* __restrict__ hint, uint32_t* __restrict__ acc) {
     __shared__ uint32_t hist[kMsdFine];
     __shared__ uint32_t s_mn[kRadixWaves], s_mx[kRadixWaves];
     const uint32_t n = d_n ? min(*d_n, n_cap) : n_cap;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    if (blockIdx.x == 0 && tid == 0) {  // the cell the NEXT sort accumulates into
-        reset[0] = 0xFFFFFFFFu;
-        reset[1] = 0u;
-    }
     const uint32_t share = max(4096u, (((n + gridDim.x - 1u) / gridDim.x) + 1023u) & ~1023u);
     const uint32_t lo_e = blockIdx.x * share, hi_e = min(n, lo_e + share);
     if (lo_e >= n) return;
     for (uint32_t i = tid; i < kMsdFine; i += kRadixThreads) hist[i] = 0;
-    uint32_t lo, fs;
-    msd_mapping(hint, lo, fs);
+    const MsdMap map = msd_mapping(hint);
     __syncthreads();
     uint32_t mn = 0xFFFFFFFFu, mx = 0u;
     constexpr int kU = 4;
@@ -727,7 +721,7 @@ __global__ __launch_bounds__(kRadixThreads) void k_msd_hist(const uint32_t* __re
         for (int u = 0; u < kU; ++u) {
             const uint32_t e = base + u * 64u + lane;
             if (e < hi_e) {
-                atomicAdd(&hist[msd_fine(key[u], lo, fs)], 1u);
+                atomicAdd(&hist[msd_fine(key[u], map)], 1u);
                 mn = min(mn, key[u]);
                 mx = max(mx, key[u]);
             }
@@ -776,16 +770,15 @@ __global__ __launch_bounds__(kSweepThreads) void k_msd_sweep(const uint32_t* __r
         if (blockIdx.x == 0 && threadIdx.x < kMsdBuckets) ranges_out[threadIdx.x] = make_uint2(0u, 0u);
         return;
     }
-    uint32_t lo, fs;
-    msd_mapping(hint, lo, fs);
+    const MsdMap map = msd_mapping(hint);
     if (n <= small_n)
         radix_sweep_tiles<IN, 0, LANE_ORDERED, false, kRadixRoundsSmall, true>(keys_in, vals_in, pairs_in, nullptr, nullptr, pairs_out, n, 0, 255u, fine, ticket, status,
                                                                                 epoch, fine, kMsdFine, nullptr, ranges_out, nullptr, nullptr, s_pairs, cnt, s_gbase,
-                                                                                s_wtot, s_misc, s_map, s_span, lo, fs);
+                                                                                s_wtot, s_misc, s_map, s_span, map);
     else
         radix_sweep_tiles<IN, 0, LANE_ORDERED, false, kRadixRounds, true>(keys_in, vals_in, pairs_in, nullptr, nullptr, pairs_out, n, 0, 255u, fine, ticket, status, epoch,
                                                                            fine, kMsdFine, nullptr, ranges_out, nullptr, nullptr, s_pairs, cnt, s_gbase, s_wtot, s_misc,
-                                                                           s_map, s_span, lo, fs);
+                                                                           s_map, s_span, map);
 }
 
 // ---- every bucket sorted on the key bits that vary inside it: stable LSD passes of up to 8 bits, per-wave counters ----
@@ -855,8 +848,14 @@ __device__ __forceinline__ void bucket_offsets(uint32_t (*__restrict__ cnt)[256]
 template <bool LANE_ORDERED>
 __global__ __launch_bounds__(kSweepThreads) void k_bucket_sort(uint2* src /* the partitioned pairs (large buckets ping-pong between src and tmp) */, uint2* tmp,
                                                                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, const uint2* __restrict__ ranges,
-                                                                uint32_t cap) {
+                                                                uint32_t cap, uint32_t* __restrict__ hint, const uint32_t* __restrict__ acc) {
     uint2* const src_rw = src;
+    // the last kernel of a sort: the union of the key ranges seen so far becomes the range the NEXT sort's kernels map keys by (they all
+    // run behind this kernel: the snapshot is stable while they read it)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && acc[0] <= acc[1]) {
+        hint[0] = acc[0];
+        hint[1] = acc[1];
+    }
     __shared__ uint2 s_pairs[kBucketCap];
     __shared__ uint32_t cnt[kSweepWaves][256];
     __shared__ uint32_t s_wtot[kSweepWaves];
@@ -1060,7 +1059,7 @@ void bucket_sort_set_cap(uint32_t cap) { g_bucket_cap.store(cap); }
 hipError_t msd_workspace_init(hipStream_t s, uint32_t* ws, size_t words) {
     hipError_t e = gsx::op::MemsetAsync(ws, 0, 4 * words, s);
     if (e != hipSuccess) return e;
-    static const uint32_t cells[6] = {0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
+    static const uint32_t cells[4] = {0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
     return gsx::op::MemcpyAsync(ws + kMsdCells, cells, sizeof cells, hipMemcpyHostToDevice, s);
 }
 
@@ -1074,9 +1073,9 @@ hipError_t launch_bucket_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n
         static const uint32_t hper = 4096u;
         const uint32_t hgrid = std::max<uint32_t>(1u, std::min<uint32_t>(256u, (uint32_t)(((uint64_t)n + hper - 1) / hper)));
         if (buf.pairs_src)
-            GSX_LAUNCH(k_msd_hist<2>, dim3(hgrid), dim3(kRadixThreads), 0, s, reinterpret_cast<const uint32_t*>(buf.pairs_src), n, d_n, mc.fine, mc.hint, mc.acc, mc.reset);
+            GSX_LAUNCH(k_msd_hist<2>, dim3(hgrid), dim3(kRadixThreads), 0, s, reinterpret_cast<const uint32_t*>(buf.pairs_src), n, d_n, mc.fine, mc.hint, mc.acc);
         else
-            GSX_LAUNCH(k_msd_hist<1>, dim3(hgrid), dim3(kRadixThreads), 0, s, buf.keys_src, n, d_n, mc.fine, mc.hint, mc.acc, mc.reset);
+            GSX_LAUNCH(k_msd_hist<1>, dim3(hgrid), dim3(kRadixThreads), 0, s, buf.keys_src, n, d_n, mc.fine, mc.hint, mc.acc);
     }
     const uint32_t tiles = radix_tiles(n);
     static const uint32_t grid_limit = getenv("GSX_RADIX_GRID") ? (uint32_t)atoi(getenv("GSX_RADIX_GRID")) : kRadixGrid;
@@ -1098,9 +1097,9 @@ hipError_t launch_bucket_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n
     const uint32_t cap_dbg = g_bucket_cap.load(std::memory_order_relaxed);
     const uint32_t cap = cap_dbg ? std::min(cap_dbg, kBucketCap) : kBucketCap;
     if (lane_ordered)
-        GSX_LAUNCH((k_bucket_sort<true>), dim3(kMsdBuckets), dim3(kSweepThreads), 0, s, buf.pairs_a, buf.pairs_b, buf.keys_out, buf.vals_out, mc.ranges, cap);
+        GSX_LAUNCH((k_bucket_sort<true>), dim3(kMsdBuckets), dim3(kSweepThreads), 0, s, buf.pairs_a, buf.pairs_b, buf.keys_out, buf.vals_out, mc.ranges, cap, const_cast<uint32_t*>(mc.hint), mc.acc);
     else
-        GSX_LAUNCH((k_bucket_sort<false>), dim3(kMsdBuckets), dim3(kSweepThreads), 0, s, buf.pairs_a, buf.pairs_b, buf.keys_out, buf.vals_out, mc.ranges, cap);
+        GSX_LAUNCH((k_bucket_sort<false>), dim3(kMsdBuckets), dim3(kSweepThreads), 0, s, buf.pairs_a, buf.pairs_b, buf.keys_out, buf.vals_out, mc.ranges, cap, const_cast<uint32_t*>(mc.hint), mc.acc);
     return hipGetLastError();
 }
 
