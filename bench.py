@@ -473,7 +473,7 @@ def main():
         for i in range(args.warmup + args.steps):
             frame(i)
         renderer.poll()
-        viewer.set_render_options(**dict(overrides, speculative=0))
+        viewer.set_render_options(**dict(overrides, speculative=0, slab_shading=0))   # (every Gaussian projected in full: k_project<3,0,0>)
         for i in range(args.warmup + args.steps):
             frame(i)
         renderer.poll()
@@ -591,11 +591,19 @@ def main():
 
     # ---- N = 1: the unspeculated loop of the same run (value_unspeculated + the SURVEY 8d projection roofline) ----
     elapsed_u = timing_u = acct_u = None
+    elapsed_f = timing_f = acct_f = None
     if single and "speculative" not in overrides:
         viewer.set_render_options(**dict(overrides, speculative=0))
         elapsed_u, timing_u, _ = timed_loop(0)
         launches["unspeculated"] = launches["per_frame"]
         acct_u = accounting(rounds(args.warmup))
+        # ... and the same loop with EVERY Gaussian projected in full (slab_shading = 0): the loop that runs SURVEY 8d's projection pass,
+        # k_project<3,0,0>, once per frame — the kernel `roofline` prices
+        viewer.set_render_options(**dict(overrides, speculative=0, slab_shading=0))
+        elapsed_f, timing_f, _ = timed_loop(0)
+        launches["unspeculated_full_projection"] = launches["per_frame"]
+        acct_f = accounting(rounds(args.warmup))
+        viewer.set_render_options(**dict(overrides, speculative=0))
         if lanes > 1 and args.unspeculated_in_flight:
             set_opts(speculative=0, frames_in_flight=lanes)
             elapsed_ul, _, _ = timed_loop(0)
@@ -713,8 +721,11 @@ def main():
         set_opts(speculative=0)
         el_pu, tm_pu, _ = timed_loop(0)
         ac_pu = accounting(rounds(args.warmup))
+        set_opts(speculative=0, slab_shading=0)
+        el_pf, tm_pf, _ = timed_loop(0)
+        ac_pf = accounting(rounds(args.warmup))
         args.pass_timing = saved_timing
-        extra["passes_raw"] = dict(speculated=(el_p, tm_p, ac_p), unspeculated=(el_pu, tm_pu, ac_pu))
+        extra["passes_raw"] = dict(speculated=(el_p, tm_p, ac_p), unspeculated=(el_pu, tm_pu, ac_pu), full_projection=(el_pf, tm_pf, ac_pf))
         set_opts()
 
     # ---- N = 1: the GPU side of the oracle check — pose 0 of the whole scene, the frame cpu_baseline renders on the host cores ----
@@ -964,16 +975,24 @@ def main():
         if timing_u is not None:
             out["value_unspeculated"] = round(args.steps / elapsed_u, 3)
             out["ms_per_step_unspeculated"] = round(1e3 * elapsed_u / args.steps, 4)
+            out["value_unspeculated_full_projection"] = round(args.steps / elapsed_f, 3)
+            out["unspeculated_note"] = ("value_unspeculated: speculative = 0 — no windows from an earlier frame: what every first frame and every incoherent "
+                                        "pose costs; such a frame projects geometry only, depth-sorts every visible Gaussian and shades, depth slab by depth "
+                                        "slab, exactly the records some block of tiles still takes (gsx_render_options.slab_shading, default 1).  "
+                                        "value_unspeculated_full_projection: the same loop with slab_shading = 0 — every Gaussian projected in full by "
+                                        "k_project<3,0,0> (SH colour + cov2d + cull + depth key for all N: SURVEY 8d's projection pass, what the reference's "
+                                        "K1 + K3 vertex stage computes): the loop `roofline` is measured on.  Same pixels in all three schedules (frame_check).")
             out["frame_check"] = frame_check
-            out["roofline"] = roofline_of(acct_u, timing_u, "projection pass: SH colour + cov2d + cull + depth key; measured on the "
-                                          "unspeculated timed loop of this run")
+            out["roofline"] = roofline_of(acct_f, timing_f, "projection pass: SH colour + cov2d + cull + depth key; measured on the "
+                                          "unspeculated, fully projecting timed loop of this run (slab_shading = 0)")
             out["roofline_speculated"] = roofline_of(acct, timing, "projection pass")
             out["config"]["tile_entries_unspeculated"] = int(acct_u[:, 5].mean())
         else:
             out["roofline"] = roofline_of(acct, timing, "projection pass: SH colour + cov2d + cull + depth key")
         if out.get("roofline") is not None:
-            out["roofline"]["belongs_to"] = ("value_unspeculated: that loop runs this kernel once per frame; the headline loop (`value`) "
-                                             "projects with roofline_speculated's kernel and shades only the admitted Gaussians (k_shade)"
+            out["roofline"]["belongs_to"] = ("value_unspeculated_full_projection: that loop runs this kernel once per frame; the headline loop "
+                                             "(`value`) and value_unspeculated project with roofline_speculated's kernel and shade only the Gaussians "
+                                             "that are admitted / that some block of tiles takes (k_shade)"
                                              if timing_u is not None else "value")
         if extra is not None:
             out["value_synchronised"] = round(args.steps / extra["sync_frame"], 3)
@@ -994,7 +1013,7 @@ def main():
                 n_a, nvis, nsort, _, _, d_ent = [float(ac[:, k].mean()) for k in range(6)]
                 tiles = ((w + 15) // 16) * ((h + 15) // 16)
                 p_tile = max(1, -(-max(1, (tiles - 1).bit_length()) // 8))
-                lazy = speculated and float(ac[:, 3].mean()) > 0.5
+                lazy = (speculated and float(ac[:, 3].mean()) > 0.5) or (tm.get("project_geom", {}).get("ms", 0) > tm.get("project", {}).get("ms", 0))
                 rows = {}
                 proj_name = "project_geom" if lazy else "project"
                 proj_bytes = (n_a * 24.125 + nvis * cov_bytes) if lazy else (n_a * pod_bytes + nvis * 40)
@@ -1023,6 +1042,7 @@ def main():
 
             pr = extra["passes_raw"]
             out["passes"] = dict(speculated=passes_of(*pr["speculated"], True), unspeculated=passes_of(*pr["unspeculated"], False),
+                                 full_projection=passes_of(*pr["full_projection"], False),
                                  note="one frame in flight, every pass bracketed with a pair of HIP events on the viewer's stream (each bracket costs a "
                                       "few microseconds of stream gap: the frame is slower than value_one_frame_in_flight)")
         if elapsed_dist_u is not None:
@@ -1052,7 +1072,8 @@ def main():
         summary = {"value": out["value"], "frames_in_flight": lanes, "steps_timed": args.steps}
         for k_out, k_sum in (("value_short_window", "value_short_window"), ("value_one_frame_in_flight", "value_one_frame_in_flight"),
                              ("value_synchronised", "value_synchronised"), ("value_reference_protocol", "value_reference_protocol"),
-                             ("value_unspeculated", "value_unspeculated"), ("value_synchronised_unspeculated", "value_synchronised_unspeculated")):
+                             ("value_unspeculated", "value_unspeculated"), ("value_unspeculated_full_projection", "value_unspeculated_full_projection"),
+                             ("value_synchronised_unspeculated", "value_synchronised_unspeculated")):
             if k_out in out:
                 summary[k_sum] = out[k_out]
         if "steady_state" in out:
@@ -1060,13 +1081,13 @@ def main():
         if out.get("roofline"):
             summary["roofline_frac"] = out["roofline"]["frac"]
             summary["roofline_kernel_us"] = out["roofline"]["avg_launch_us"]
-            summary["roofline_belongs_to"] = "value_unspeculated" if timing_u is not None else "value"
+            summary["roofline_belongs_to"] = "value_unspeculated_full_projection" if timing_u is not None else "value"
         if out.get("roofline_speculated"):
             summary["roofline_speculated_frac"] = out["roofline_speculated"]["frac"]
             summary["roofline_speculated_kernel_us"] = out["roofline_speculated"]["avg_launch_us"]
         if "passes" in out:
             summary["passes_us"] = {sch: {k: v["us_per_frame"] for k, v in out["passes"][sch].items() if isinstance(v, dict)}
-                                    for sch in ("speculated", "unspeculated")}
+                                    for sch in ("speculated", "unspeculated", "full_projection")}
         if launches:
             summary["launches_per_frame"] = out["launches_per_frame"]
         if robustness is not None:

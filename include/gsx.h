@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSX_ABI_VERSION 2u
+#define GSX_ABI_VERSION 3u
 #define GSX_TILE 16u /* screen tile edge in pixels (build-internal; the reference has no tiles) */
 #define GSX_SH_COEFFS 15u /* SH degree 1..3 coefficients, each an RGB triple (gs::Gaussian::sh) */
 
@@ -122,6 +122,11 @@ typedef struct gsx_render_options {
     uint32_t spec_radius;        /* default 3 (tiles) */
     uint32_t host_verify;        /* default 0 */
     uint32_t frames_in_flight;   /* default 1; 1 .. 4 — see below */
+    uint32_t slab_shading;       /* default 1: a progressive frame WITHOUT windows (the first frame, a probe of the speculation tuner,
+                                  * speculative = 0) projects geometry only and gives conic / colour records, depth slab by depth slab, to
+                                  * exactly the records some block of tiles still takes — a few per cent of the visible ones on an opaque
+                                  * scene; 0: such a frame projects every Gaussian in full (the reference's K1 + K3 vertex work for every
+                                  * visible Gaussian).  Same pixels either way. */
 } gsx_render_options;
 
 typedef struct gsx_viewer_desc {

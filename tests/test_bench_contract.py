@@ -64,7 +64,9 @@ def test_bench_line_contract(name, d):
         assert abs(d["value_synchronised"] - 1e3 / d["ms_per_step_synchronised"]) / d["value_synchronised"] < 1e-2
         assert d["steady_state"]["frames"] >= 240 and 0.7 * d["value"] < d["steady_state"]["value"] < 1.3 * d["value"]
         assert "value_unspeculated" in d["roofline"]["belongs_to"]
-        for schedule, proj in (("speculated", "project_geom"), ("unspeculated", "project")):
+        full = "full_projection" if "full_projection" in d["passes"] else "unspeculated"   # (round 6: unspeculated frames shade slab by slab)
+        schedules = [("speculated", "project_geom"), (full, "project")] + ([("unspeculated", "project_geom")] if full != "unspeculated" else [])
+        for schedule, proj in schedules:
             ps = d["passes"][schedule]
             for name in (proj, "depth_sort", "bin", "tile_sort", "composite"):
                 row = ps[name]
@@ -75,7 +77,10 @@ def test_bench_line_contract(name, d):
             total = sum(ps[n]["us_per_frame"] for n in (proj, "depth_sort", "bin", "tile_sort", "composite"))
             assert 0.7 * ps["frame_ms_with_every_pass_bracketed"] * 1e3 < total <= 1.05 * ps["frame_ms_with_every_pass_bracketed"] * 1e3
         # the projection pass of the `passes` loop and the roofline kernel of the unspeculated timed loop are the same kernel
-        assert abs(d["passes"]["unspeculated"]["project"]["us_per_frame"] - d["roofline"]["avg_launch_us"]) / d["roofline"]["avg_launch_us"] < 0.15
+        assert abs(d["passes"][full]["project"]["us_per_frame"] - d["roofline"]["avg_launch_us"]) / d["roofline"]["avg_launch_us"] < 0.15
+        if full != "unspeculated":
+            assert 0 < d["value_unspeculated_full_projection"] < d["value_unspeculated"] < d["value"]
+            assert "value_unspeculated_full_projection" in d["roofline"]["belongs_to"]
 
 
     if "summary" in d:  # round 5 onwards: `value` is a whole-orbit rate and the side-by-side figures are the last keys of the line

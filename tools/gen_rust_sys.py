@@ -57,7 +57,7 @@ HEAD = '''//! gsx-sys — raw FFI over `include/gsx.h` (libgsx.so, the MI355X-na
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_void};
 
-pub const GSX_ABI_VERSION: u32 = 2;
+pub const GSX_ABI_VERSION: u32 = 3;
 pub const GSX_TILE: u32 = 16;
 pub const GSX_SH_COEFFS: usize = 15;
 pub const GSX_RECORD_BYTES: u32 = 48;
@@ -118,7 +118,7 @@ pub struct gsx_spec_params {
 pub struct gsx_render_options {
     pub progressive: u32, pub first_slab_divisor: u32, pub min_slab: u32, pub growth: u32,
     pub speculative: u32, pub spec_margin: f32, pub spec_radius: u32, pub host_verify: u32,
-    pub frames_in_flight: u32,
+    pub frames_in_flight: u32, pub slab_shading: u32,
 }
 #[repr(C)]
 pub struct gsx_viewer_desc { pub abi_version: u32, pub device: i32, pub stream: *mut c_void, pub width: u32, pub height: u32 }

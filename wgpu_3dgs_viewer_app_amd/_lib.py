@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsx.so")
 
-GSX_ABI_VERSION = 2
+GSX_ABI_VERSION = 3
 (GSX_OK, GSX_ERR_INVALID_ARG, GSX_ERR_OOM, GSX_ERR_HIP, GSX_ERR_RCCL, GSX_ERR_IO, GSX_ERR_PLY, GSX_ERR_NOT_FOUND,
  GSX_ERR_UNSUPPORTED, GSX_ERR_NO_DEVICE) = range(10)
 GSX_PASS_NAMES = ("project", "depth_sort", "bin", "tile_sort", "composite", "project_geom")
@@ -70,7 +70,7 @@ class SpecParams(C.Structure):
 class RenderOptions(C.Structure):
     _fields_ = [("progressive", C.c_uint32), ("first_slab_divisor", C.c_uint32), ("min_slab", C.c_uint32), ("growth", C.c_uint32),
                 ("speculative", C.c_uint32), ("spec_margin", C.c_float), ("spec_radius", C.c_uint32), ("host_verify", C.c_uint32),
-                ("frames_in_flight", C.c_uint32)]
+                ("frames_in_flight", C.c_uint32), ("slab_shading", C.c_uint32)]
 
 
 class PlyHeader(C.Structure):

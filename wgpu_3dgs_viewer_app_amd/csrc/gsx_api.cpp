@@ -331,6 +331,8 @@ void gsx_render_options_default(gsx_render_options* o) {
     o->spec_radius = 3;
     o->host_verify = 0;
     o->frames_in_flight = 1;
+    o->slab_shading = 1;
+    if (const char* e = getenv("GSX_SLAB_SHADING")) o->slab_shading = atoi(e) != 0 ? 1u : 0u;   // (A/B: tools/ab_env.sh)
 }
 
 void gsx_debug_set_radix_rank_mode(int32_t mode) { radix_set_rank_override(mode); }
@@ -349,7 +351,7 @@ gsx_status gsx_viewer_set_render_options(gsx_viewer* v, const gsx_render_options
     }
     // what gsx_preprocess decided (speculated round, lazy shading) belongs to the options it saw: a model preprocessed under
     // other scheduling options must go through gsx_preprocess + gsx_sort again before it is rendered
-    if (o->progressive != v->options.progressive || o->speculative != v->options.speculative)
+    if (o->progressive != v->options.progressive || o->speculative != v->options.speculative || o->slab_shading != v->options.slab_shading)
         for (auto& kv : v->models) {
             kv.second->sorted = false;
             kv.second->spec_round1 = false;

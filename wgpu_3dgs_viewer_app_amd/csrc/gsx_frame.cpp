@@ -412,7 +412,13 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
     // (edits and the highlight are colour ops on shaded records: shade_admitted applies them to what k_shade writes; a rect /
     // brush / texture query is answered by the geometry-only kernel itself from the projected centre; a hit query reads conics)
     const bool geometric_query = v->query.kind == GSX_QUERY_RECT || v->query.kind == GSX_QUERY_BRUSH || v->query.kind == GSX_QUERY_TEXTURE;
-    m->lazy = (m->spec_round1 || shard_lazy) && (v->query.kind == GSX_QUERY_NONE || geometric_query);
+    // slab shading (gsx_render_options): a progressive frame without windows projects geometry only as well; its depth slabs then shade
+    // exactly the records some block of tiles still takes (k_block_bin's list).  Only frames that bin by blocks, slab by slab:
+    // a model small enough for ONE slab keeps complete per-tile lists and its full records (gsx_model_download_tile_lists).
+    m->slab_shading = v->options.slab_shading && v->options.progressive && v->bin_mode == 1 && v->bin_fused && !m->spec_round1 && !shard_lazy &&
+                      m->n > v->options.min_slab && m->pod().sh_aos != nullptr;
+    m->lazy = (m->spec_round1 || shard_lazy || m->slab_shading) && (v->query.kind == GSX_QUERY_NONE || geometric_query);
+    if (!m->lazy) m->slab_shading = false;
     if (m->lazy && geometric_query) {
         HIPCHK(m->query_flags.ensure(4 * std::max<size_t>(words, 1)));
         if (v->query.kind == GSX_QUERY_TEXTURE && (v->query_tex_w != v->width || v->query_tex_h != v->height))
@@ -570,7 +576,7 @@ gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
             // every visible record enters the sort (an unspeculated frame, a redone one): the first radix pass reads the
             // projection's key plane as it lies and skips the culled records — no compaction pass in front of the sort
             // (k_admit_scan + k_admit_scatter_dense: 55 us and 176 MB at 10 M Gaussians)
-            const bool dense = force_full || (!m->spec_round1 && !m->lazy && m->last_pyramid == nullptr);
+            const bool dense = force_full || (!m->spec_round1 && (!m->lazy || m->slab_shading) && m->last_pyramid == nullptr);
             if (dense) {
                 if (m->visible_count_pending) {
                     HIPCHK(launch_sum_counts(v->stream, m->block_vis.as<uint32_t>(), n, &dc->n_visible));
@@ -831,6 +837,8 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
                 order_build = false;
             }
             const bool fused = v->bin_fused;
+            const bool slab_shade = fused && m->slab_shading && m->lazy && !m->spec_round1;
+            if (slab_shade) HIPCHK(m->adm_pairs.ensure(8 * std::max<size_t>(m->rec_n, 1)));
             {
                 ScopedPass t(v, GSX_PASS_BIN);
                 if (fused) {
@@ -842,7 +850,13 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
                     HIPCHK(launch_block_bin_fused(v->stream, j0, j1, d_n, m->sorted_idx, m->rec(), m->sk_out.as<uint32_t>(), m->srect.as<uint4>(), dc, cap,
                                                   row_lo, row_hi, done_in, row_words, (progressive && later) ? done_count : nullptr, owned_tiles, slab_index,
                                                   win, m->fc.tiles_x, m->fc.tiles_y, bsx, bsy, m->block_table.as<uint4>(), m->tp_src.as<uint2>(),
-                                                  m->ranges.as<uint2>(), jobs, table_ready, m->bin_ws.as<uint32_t>(), m->tsort_ws.as<uint32_t>(), block_bits));
+                                                  m->ranges.as<uint2>(), jobs, table_ready, m->bin_ws.as<uint32_t>(), m->tsort_ws.as<uint32_t>(), block_bits,
+                                                  slab_shade ? m->adm_pairs.as<uint2>() : nullptr));
+                    // slab shading: conic / colour records for exactly the records of this slab some block takes (and the frame's colour ops on them)
+                    if (slab_shade) {
+                        const gsx_status sst = shade_admitted(v, m, LateProjection{m->adm_pairs.as<uint2>(), &dc->n_slab_shade, nullptr, m->rect8_active});
+                        if (sst) return sst;
+                    }
                 } else {
                     HIPCHK(launch_block_bin(v->stream, j0, j1, d_n, m->sorted_idx, m->rec(), m->sk_out.as<uint32_t>(), m->srect.as<uint4>(),
                                             m->cnt.as<uint32_t>(), m->block_sums.as<uint32_t>(), dc, cap, row_lo, row_hi, done_in, row_words,
@@ -931,7 +945,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
                                                d_n, m->sorted_idx, m->sk_out.as<uint32_t>(),
                                                (v->tile_profile && slab_index == 0) ? v->tile_prof.as<uint4>() : nullptr,
                                                (order_buf && m->tile_order_valid) ? order_buf + 1 + n_tiles : nullptr,
-                                               order_buf ? order_buf + 1 : nullptr));
+                                               order_buf ? order_buf + 1 : nullptr, m->rec().rect8 /* (null for imported records) */));
             } else {
                 HIPCHK(launch_composite(v->stream, m->fc, m->ranges.as<uint2>(), m->tile_list, m->rec(), fb_ptr(v),
                                         later, done, row_words, done_count, clear_ranges, tile_sat, row_work));

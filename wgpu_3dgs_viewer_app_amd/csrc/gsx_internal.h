@@ -257,6 +257,49 @@ constexpr uint32_t kCompactWordsPerTile = 1024;  // ballot words (64 Gaussians e
 inline size_t msd_workspace_words(uint64_t n_gaussians) {
     return kMsdStatus + 4 * (size_t)((((n_gaussians + 63) / 64) + kCompactWordsPerTile - 1) / kCompactWordsPerTile + 1);
 }
+#ifdef __HIPCC__
+// Decoupled look-back of a single-pass scan, one wave per call: status[k * stride] is tile k's 64-bit word {epoch << 34 | flag << 32 |
+// count}, flag 1 = the tile's own count, 2 = its inclusive prefix; written with one relaxed agent-scope store, read with relaxed
+// agent-scope loads ("the data is the flag": kernels_sort.hip).  Returns the exclusive prefix of `tile`: 64 predecessors per round
+// trip, nearest first; tiles must have been taken in ticket order (a tile only ever waits for tiles that are running).
+__device__ inline uint32_t tile_lookback(const unsigned long long* __restrict__ status, uint32_t stride, uint32_t tile, uint32_t epoch, uint32_t lane) {
+    uint32_t excl = 0;
+    int32_t k = (int32_t)tile - 1;
+    while (k >= 0) {
+        const int32_t kk = k - (int32_t)lane;
+        unsigned long long w = 0;
+        if (kk >= 0) w = __hip_atomic_load(status + (size_t)kk * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t flag = (uint32_t)(w >> 32) & 3u;
+        const bool there = kk >= 0 && (uint32_t)(w >> 34) == epoch && flag != 0;
+        const unsigned long long missing = __ballot(kk >= 0 && !there);
+        const unsigned long long prefix = __ballot(there && flag == 2u);
+        const uint32_t first_missing = missing ? (uint32_t)__ffsll((long long)missing) - 1u : 64u;
+        const uint32_t first_prefix = prefix ? (uint32_t)__ffsll((long long)prefix) - 1u : 64u;
+        const uint32_t take = first_prefix < first_missing ? first_prefix + 1u : first_missing;   // lanes [0, take) are consumed
+        uint32_t x = (lane < take && kk >= 0) ? (uint32_t)w : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        excl += x;
+        if (first_prefix < first_missing) break;
+        k -= (int32_t)take;
+        if (take == 0) __builtin_amdgcn_s_sleep(1);
+    }
+    return excl;
+}
+// publish + look back + publish the inclusive prefix: the calling wave's lane 0 owns the tile's word
+__device__ inline uint32_t tile_scan_publish(unsigned long long* __restrict__ status, uint32_t stride, uint32_t tile, uint32_t epoch, uint32_t lane, uint32_t total) {
+    const unsigned long long tag = (unsigned long long)epoch << 34;
+    unsigned long long* my = status + (size_t)tile * stride;
+    if (lane == 0) __hip_atomic_store(my, tag | ((tile == 0 ? 2ull : 1ull) << 32) | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t excl = 0;
+    if (tile > 0) {
+        excl = tile_lookback(status, stride, tile, epoch, lane);
+        if (lane == 0) __hip_atomic_store(my, tag | (2ull << 32) | (unsigned long long)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return excl;
+}
+#endif
+
 // Fine bin of a key.  The keys of a sort are GUESSED to lie in [lo, hi] — the union of the key ranges of the model's earlier sorts (or,
 // before any, depths 2^-7 ... 2^14) — and that stretch gets bins 128 ... 1919 at 2^fs keys a bin; whatever lies outside still gets bins
 // of its own, a sixteenth of an octave wide, 128 on either side (beyond eight octaves: the outermost bin).  The guess decides the
@@ -336,6 +379,7 @@ struct SlabStats {
     uint32_t n_sorted2;        // speculation: records admitted in the repair round
     uint32_t spec_need;        // speculation: tiles that needed the repair round
     uint32_t verify_ticket;    // k_spec_verify: blocks that have added their share of spec_need (the last one posts the verdict)
+    uint32_t n_slab_shade;     // slab shading (gsx_render_options): records of the current slab some block takes = the slab's shading list (k_block_bin)
     uint32_t slab_cut;         // depth-order position up to which the current slab was binned into pairs: the whole slab unless
                                // its entries overflowed the pair buffers; k_composite_spill composites [slab_cut, slab end)
 };
@@ -542,7 +586,9 @@ hipError_t launch_block_bin_fused(hipStream_t s, uint32_t j0, uint32_t j1, const
                                   uint32_t row_lo, uint32_t row_hi, const uint32_t* done, uint32_t row_words, const uint32_t* d_done_count,
                                   uint32_t owned_tiles, uint32_t slab_index, const uint2* window, uint32_t tiles_x, uint32_t tiles_y,
                                   uint32_t bsx, uint32_t bsy, uint4* table, uint2* pairs, uint2* ranges, const ZeroJob& zero, bool table_ready,
-                                  uint32_t* bin_ws, uint32_t* sort_ghist, int block_bits);
+                                  uint32_t* bin_ws, uint32_t* sort_ghist, int block_bits,
+                                  uint2* shade_pairs = nullptr /* slab shading: (key, index) of the slab's records some block takes -> stats->n_slab_shade; the
+                                                                  rectangles are then read from rec.rect8 (the records are not shaded yet) */);
 hipError_t launch_block_bin(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* d_n_vis, const uint32_t* sorted_idx,
                             const Records& rec, const uint32_t* sorted_keys, uint4* brec, uint32_t* cnt, uint32_t* block_sums,
                             SlabStats* stats, uint32_t capacity, uint32_t row_lo, uint32_t row_hi, const uint32_t* done,
@@ -558,7 +604,7 @@ hipError_t launch_composite_blocks(hipStream_t s, const FrameConsts& f, const ui
                                    const uint32_t* sorted_keys /* the slab's tail behind stats->slab_cut is composited pair-free by the same launch */,
                                    uint4* tile_prof = nullptr /* development: per tile {start, duration (10 ns ticks), chunks walked | list chunks << 16, takers} */,
                                    const uint32_t* tile_order = nullptr /* the tile workgroup i composites (nullptr: tile i) */,
-                                   uint32_t* tile_cost = nullptr /* += what each tile cost: tile_order_job's input for the model's next frame */);
+                                   uint32_t* tile_cost = nullptr /* += what each tile cost: tile_order_job's input for the model's next frame */, const uint32_t* rect8 = nullptr /* slab shading: the pair-free tail reads rectangles from the packed plane */);
 
 // Selection / edits / queries (kernels_edit.hip).
 hipError_t launch_edit_prepare(hipStream_t s, uint32_t n, const uint32_t* selection, uint32_t* edited, float4* edit_a,

@@ -250,33 +250,6 @@ __global__ __launch_bounds__(256) void k_admit_scatter_dense(const uint32_t* __r
 constexpr int kCompactThreads = 256;
 constexpr uint32_t kCompactList = 8192;   // admitted indices of a tile that lie in LDS at a time (a page)
 typedef unsigned long long u64c;
-constexpr u64c kCFlagAggregate = 1, kCFlagPrefix = 2;
-
-// exclusive prefix of tile `tile` over status[2 * k] (k < tile): one wave, 64 predecessors per round trip, nearest first
-__device__ inline uint32_t compact_lookback(const u64c* __restrict__ status, uint32_t tile, uint32_t epoch, uint32_t lane) {
-    uint32_t excl = 0;
-    int32_t k = (int32_t)tile - 1;
-    while (k >= 0) {
-        const int32_t kk = k - (int32_t)lane;
-        u64c w = 0;
-        if (kk >= 0) w = __hip_atomic_load(status + 2 * (size_t)kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t flag = (uint32_t)(w >> 32) & 3u;
-        const bool there = kk >= 0 && (uint32_t)(w >> 34) == epoch && flag != 0;
-        const unsigned long long missing = __ballot(kk >= 0 && !there);
-        const unsigned long long prefix = __ballot(there && flag == (uint32_t)kCFlagPrefix);
-        const uint32_t first_missing = missing ? (uint32_t)__ffsll((long long)missing) - 1u : 64u;
-        const uint32_t first_prefix = prefix ? (uint32_t)__ffsll((long long)prefix) - 1u : 64u;
-        const uint32_t take = first_prefix < first_missing ? first_prefix + 1u : first_missing;   // lanes [0, take) are consumed
-        uint32_t x = (lane < take && kk >= 0) ? (uint32_t)w : 0u;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-        excl += x;
-        if (first_prefix < first_missing) break;
-        k -= (int32_t)take;
-        if (take == 0) __builtin_amdgcn_s_sleep(1);
-    }
-    return excl;
-}
 
 __global__ __launch_bounds__(kCompactThreads) void k_admit_compact(const uint32_t* __restrict__ key, uint32_t words,
                                                                     const unsigned long long* __restrict__ ballots,
@@ -331,16 +304,8 @@ __global__ __launch_bounds__(kCompactThreads) void k_admit_compact(const uint32_
         vtotal += s_vsum[w];
     }
     const uint32_t local = woff + x - mine;   // first slot of this thread's pairs inside the tile
-    const u64c tag = (u64c)epoch << 34;
     if (wave < 2) {   // wave 0: the pair counts; wave 1: the visible counts (words 2 * tile and 2 * tile + 1)
-        const uint32_t val = wave == 0 ? total : vtotal;
-        u64c* my = status + 2 * (size_t)tile + wave;
-        if (lane == 0) __hip_atomic_store(my, tag | ((tile == 0 ? kCFlagPrefix : kCFlagAggregate) << 32) | (u64c)val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t excl = 0;
-        if (tile > 0) {
-            excl = compact_lookback(status + wave, tile, epoch, lane);
-            if (lane == 0) __hip_atomic_store(my, tag | (kCFlagPrefix << 32) | (u64c)(excl + val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        const uint32_t excl = tile_scan_publish(status + wave, 2u, tile, epoch, lane, wave == 0 ? total : vtotal);
         if (lane == 0) (wave == 0 ? s_before : s_vis_before) = excl;
     }
     __syncthreads();

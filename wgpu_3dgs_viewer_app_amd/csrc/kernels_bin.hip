@@ -536,7 +536,7 @@ constexpr uint32_t kFuseTile = 2u * kFuseThreads;   // records per tile: two per
 constexpr uint32_t kFuseGrid = 256;
 typedef unsigned long long u64b;
 
-size_t bin_workspace_words(uint64_t n_records) { return 8 + 2 * (size_t)((n_records + kFuseTile - 1) / kFuseTile + 1); }
+size_t bin_workspace_words(uint64_t n_records) { return 8 + 4 * (size_t)((n_records + kFuseTile - 1) / kFuseTile + 1); }  // two 64-bit status words per tile
 
 __global__ __launch_bounds__(kFuseThreads) void k_block_bin(const uint32_t* __restrict__ d_n_vis, uint32_t j0, uint32_t j1,
                                                              const uint32_t* __restrict__ sorted_idx, const float4* __restrict__ rec_a,
@@ -547,11 +547,13 @@ __global__ __launch_bounds__(kFuseThreads) void k_block_bin(const uint32_t* __re
                                                              const uint4* __restrict__ table, int keyed, uint32_t* __restrict__ order_buf,
                                                              uint32_t order_tiles, uint32_t* __restrict__ walk_max_out,
                                                              uint32_t* __restrict__ ticket, u64b* __restrict__ status, uint32_t epoch,
-                                                             uint32_t* __restrict__ ghist, int passes, int dbits) {
+                                                             uint32_t* __restrict__ ghist, int passes, int dbits,
+                                                             const uint32_t* __restrict__ rect8, uint2* __restrict__ shade_pairs) {
     __shared__ uint4 tab[1024];
     __shared__ uint32_t hist[2][256];
     __shared__ uint32_t s_w0[kFuseWaves], s_w1[kFuseWaves];
-    __shared__ uint32_t s_tile, s_before, s_cut;
+    __shared__ uint32_t s_tile, s_before, s_cut, s_shade_before;
+    __shared__ uint32_t s_f0[kFuseWaves], s_f1[kFuseWaves];
     const uint32_t extra = order_buf ? 1u : 0u, workers = gridDim.x - extra, worker = blockIdx.x - extra;
     if (extra && blockIdx.x == 0u) {
         tile_order_job<kFuseThreads>(order_buf, order_tiles, reinterpret_cast<uint32_t*>(tab), walk_max_out);
@@ -566,6 +568,7 @@ __global__ __launch_bounds__(kFuseThreads) void k_block_bin(const uint32_t* __re
         if (worker == 0u && tid == 0u) {
             stats->n_entries = 0u;
             stats->slab_cut = max(n_vis, j0);
+            if (shade_pairs) stats->n_slab_shade = 0u;
         }
         return;
     }
@@ -589,13 +592,13 @@ __global__ __launch_bounds__(kFuseThreads) void k_block_bin(const uint32_t* __re
             idx[r] = pos[r] < n ? sorted_idx[j0 + pos[r]] : 0u;
             key[r] = pos[r] < n ? sorted_keys[j0 + pos[r]] : 0u;
         }
-        float4 a[2];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) a[r] = pos[r] < n ? rec_a[idx[r]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = 0; r < 2; ++r) {   // (slab shading: the records are not shaded yet — the packed rectangle of the geometry-only projection)
+            rx[r] = ry[r] = 0;
+            if (pos[r] < n) rec_rect(rec_a, rect8, idx[r], rx[r], ry[r]);
+        }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            rx[r] = __float_as_uint(a[r].z);
-            ry[r] = __float_as_uint(a[r].w);
             c[r] = 0;
             uint32_t bx0, bx1, by0, by1;
             if (pos[r] < n && block_rect(g, rx[r], ry[r], row_lo, row_hi, bx0, bx1, by0, by1))
@@ -613,9 +616,16 @@ __global__ __launch_bounds__(kFuseThreads) void k_block_bin(const uint32_t* __re
                 x1 += y1;
             }
         }
+        // slab shading: the records some block takes, counted the same way (ballots: a flag per record)
+        const unsigned long long fb0 = __ballot(c[0] != 0u), fb1 = __ballot(c[1] != 0u);
+        const unsigned long long lt = (1ull << lane) - 1ull;
         if (lane == 63) {
             s_w0[wave] = x0;
             s_w1[wave] = x1;
+        }
+        if (lane == 0) {
+            s_f0[wave] = (uint32_t)__popcll(fb0);
+            s_f1[wave] = (uint32_t)__popcll(fb1);
         }
         __syncthreads();
         uint32_t off0 = 0, off1 = 0, t0 = 0, t1 = 0;
@@ -630,41 +640,36 @@ __global__ __launch_bounds__(kFuseThreads) void k_block_bin(const uint32_t* __re
         }
         const uint32_t total = t0 + t1;
         const uint32_t e0 = off0 + x0 - c[0], e1 = t0 + off1 + x1 - c[1];   // first slot of each record's entries inside the tile
-        if (wave == 0) {
-            const u64b tag = (u64b)epoch << 34;
-            u64b* my = status + tile;
-            if (lane == 0) __hip_atomic_store(my, tag | ((tile == 0 ? 2ull : 1ull) << 32) | (u64b)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t excl = 0;
-            if (tile > 0) {
-                int32_t k = (int32_t)tile - 1;
-                while (k >= 0) {   // 64 predecessors per round trip, nearest first
-                    const int32_t kk = k - (int32_t)lane;
-                    u64b w = 0;
-                    if (kk >= 0) w = __hip_atomic_load(status + kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint32_t flag = (uint32_t)(w >> 32) & 3u;
-                    const bool there = kk >= 0 && (uint32_t)(w >> 34) == epoch && flag != 0;
-                    const unsigned long long missing = __ballot(kk >= 0 && !there);
-                    const unsigned long long prefix = __ballot(there && flag == 2u);
-                    const uint32_t first_missing = missing ? (uint32_t)__ffsll((long long)missing) - 1u : 64u;
-                    const uint32_t first_prefix = prefix ? (uint32_t)__ffsll((long long)prefix) - 1u : 64u;
-                    const uint32_t take = first_prefix < first_missing ? first_prefix + 1u : first_missing;
-                    uint32_t x = (lane < take && kk >= 0) ? (uint32_t)w : 0u;
+        uint32_t foff0 = 0, foff1 = 0, ft0 = 0, ft1 = 0;
+        if (shade_pairs) {
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-                    excl += x;
-                    if (first_prefix < first_missing) break;
-                    k -= (int32_t)take;
-                    if (take == 0) __builtin_amdgcn_s_sleep(1);
+            for (uint32_t w = 0; w < (uint32_t)kFuseWaves; ++w) {
+                if (w < wave) {
+                    foff0 += s_f0[w];
+                    foff1 += s_f1[w];
                 }
-                if (lane == 0) __hip_atomic_store(my, tag | (2ull << 32) | (u64b)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ft0 += s_f0[w];
+                ft1 += s_f1[w];
             }
+        }
+        if (wave == 0) {
+            const uint32_t excl = tile_scan_publish(status, 2u, tile, epoch, lane, total);
             if (lane == 0) {
                 s_before = excl;
                 s_cut = 0xFFFFFFFFu;
             }
+        } else if (wave == 1 && shade_pairs) {   // the shading list's slots: a second word per tile, a second wave
+            const uint32_t excl = tile_scan_publish(status + 1, 2u, tile, epoch, lane, ft0 + ft1);
+            if (lane == 0) s_shade_before = excl;
         }
         __syncthreads();
         const uint32_t before = s_before;
+        if (shade_pairs) {   // (every record some block takes, whatever the cut: the tile compositor's pair-free tail blends them too)
+            const uint32_t sb = s_shade_before;
+            if (c[0]) shade_pairs[sb + foff0 + (uint32_t)__popcll(fb0 & lt)] = make_uint2(key[0], idx[0]);
+            if (c[1]) shade_pairs[sb + ft0 + foff1 + (uint32_t)__popcll(fb1 & lt)] = make_uint2(key[1], idx[1]);
+            if (tile == n_tiles - 1u && tid == 0) stats->n_slab_shade = sb + ft0 + ft1;
+        }
         // the pair buffers hold `capacity` entries: the first record whose last entry would not fit is the slab's cut
         const bool crossing = before <= capacity && before + total > capacity;
         if (crossing) {
@@ -734,7 +739,7 @@ hipError_t launch_block_bin_fused(hipStream_t s, uint32_t j0, uint32_t j1, const
                                   uint32_t row_lo, uint32_t row_hi, const uint32_t* done, uint32_t row_words, const uint32_t* d_done_count,
                                   uint32_t owned_tiles, uint32_t slab_index, const uint2* window, uint32_t tiles_x, uint32_t tiles_y,
                                   uint32_t bsx, uint32_t bsy, uint4* table, uint2* pairs, uint2* ranges, const ZeroJob& zero, bool table_ready,
-                                  uint32_t* bin_ws, uint32_t* sort_ghist, int block_bits) {
+                                  uint32_t* bin_ws, uint32_t* sort_ghist, int block_bits, uint2* shade_pairs) {
     const BlockGrid g = block_grid(bsx, bsy, tiles_x, row_lo, row_hi);
     if (!table_ready)
         GSX_LAUNCH(k_block_table, dim3((g.blocks_x * g.blocks_y + 3u) / 4u), dim3(256), 0, s, g, tiles_x, tiles_y, row_lo, row_hi, done,
@@ -745,7 +750,8 @@ hipError_t launch_block_bin_fused(hipStream_t s, uint32_t j0, uint32_t j1, const
     if (nb)
         GSX_LAUNCH(k_block_bin, dim3(nb + (zero.order_buf ? 1u : 0u)), dim3(kFuseThreads), 0, s, d_n_vis, j0, j1, sorted_idx, rec.a, sorted_keys, brec, pairs,
                    stats, capacity, row_lo, row_hi, d_done_count, owned_tiles, slab_index, g, table, window ? 1 : 0, zero.order_buf, zero.order_tiles,
-                   zero.order_buf ? &stats->walk_max : nullptr, bin_ws, reinterpret_cast<u64b*>(bin_ws + 8), next_sort_epoch(), sort_ghist, passes, dbits);
+                   zero.order_buf ? &stats->walk_max : nullptr, bin_ws, reinterpret_cast<u64b*>(bin_ws + 8), next_sort_epoch(), sort_ghist, passes, dbits,
+                   shade_pairs ? rec.rect8 : nullptr, shade_pairs);
     return hipGetLastError();
 }
 

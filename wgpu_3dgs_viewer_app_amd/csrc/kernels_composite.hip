@@ -251,7 +251,8 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
                                                            const SlabStats* __restrict__ stats, const uint32_t j1,
                                                            const uint32_t* __restrict__ d_n, const uint32_t* __restrict__ sorted_idx,
                                                            const uint32_t* __restrict__ sorted_keys, uint4* __restrict__ tile_prof,
-                                                           const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ tile_cost) {
+                                                           const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ tile_cost,
+                                                           const uint32_t* __restrict__ rect8 /* slab shading: rectangles of records nobody shaded */) {
     const unsigned long long t_start = tile_prof ? wall_clock64() : 0ull;  // (development: gsx_debug_tile_profile)
     __shared__ float2 s_mean[kChunk + kGroupBlocks];
     __shared__ float4 s_conic[kChunk + kGroupBlocks];
@@ -410,13 +411,14 @@ __global__ __launch_bounds__(128) void k_composite_blocks(const FrameConsts f, c
             float4 a = make_float4(0, 0, 0, 0);
             if (j < spill_end) {
                 idx = sorted_idx[j];
-                a = rec_a[idx];
-                const uint32_t rx = __float_as_uint(a.z), ry = __float_as_uint(a.w);
+                uint32_t rx, ry;
+                rec_rect(rec_a, rect8, idx, rx, ry);
                 hit = tx >= (rx & 0xFFFFu) && tx < (rx >> 16) && ty >= (ry & 0xFFFFu) && ty < (ry >> 16);
                 if (hit && window) {
                     const uint32_t key = sorted_keys[j];
                     hit = key >= win.x && key < win.y;
                 }
+                if (hit) a = rec_a[idx];   // (a record that hits was taken by the tile's block: it is shaded)
             }
             const unsigned long long bal = __ballot(hit);
             if (lane == 0) s_w[wave][0] = (uint32_t)__popcll(bal);
@@ -602,7 +604,7 @@ hipError_t launch_composite_blocks(hipStream_t s, const FrameConsts& f, const ui
                                    uint32_t* d_done_count, uint32_t* tile_sat, const uint2* window, uint32_t row_lo,
                                    uint32_t row_hi, uint32_t bsx, uint32_t bsy, uint32_t* row_work, const SlabStats* stats, uint32_t j1,
                                    const uint32_t* d_n, const uint32_t* sorted_idx, const uint32_t* sorted_keys, uint4* tile_prof,
-                                   const uint32_t* tile_order, uint32_t* tile_cost) {
+                                   const uint32_t* tile_order, uint32_t* tile_cost, const uint32_t* rect8) {
     dim3 grid(f.tiles_x * f.tiles_y), block(128);
     const uint32_t blocks_x = (f.tiles_x + (1u << bsx) - 1u) >> bsx;
     const bool clamp = f.alpha_max < 1.0f || f.alpha_min > 0.0f;  // (blend_batch: the default constants need no clamping)
@@ -610,7 +612,7 @@ hipError_t launch_composite_blocks(hipStream_t s, const FrameConsts& f, const ui
 #define GSX_CB(M, C, S)                                                                                                              \
     GSX_LAUNCH((k_composite_blocks<M, C, S>), grid, block, 0, s, f, ranges, list, brec, rec.a, rec.b, rec.c, fb, carry ? 1 : 0, done, row_words, \
                d_done_count, tile_sat, window, row_lo, row_hi, bsx, bsy, blocks_x, row_work, stats, j1, d_n, sorted_idx, sorted_keys, tile_prof,    \
-               tile_order, tile_cost)
+               tile_order, tile_cost, rect8)
     if (f.display_mode == GSX_DISPLAY_SPLAT) {
         if (clamp) { if (sorted) GSX_CB(0, true, true); else GSX_CB(0, true, false); }
         else { if (sorted) GSX_CB(0, false, true); else GSX_CB(0, false, false); }
