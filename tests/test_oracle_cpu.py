@@ -190,8 +190,8 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_render_option_defaults_and_struct_layout():
-    """gsx_render_options as the binding sees it: the defaults the header documents, and a struct of nine 4-byte fields (ABI 2:
-    frames_in_flight was appended; one frame in flight unless the caller asks for more).  No GPU needed."""
+    """gsx_render_options as the binding sees it: the defaults the header documents, and a struct of ten 4-byte fields (ABI 2:
+    frames_in_flight was appended — one frame in flight unless the caller asks for more; ABI 3: slab_shading, on by default).  No GPU needed."""
     import ctypes as C
 
     from wgpu_3dgs_viewer_app_amd import _lib
@@ -200,15 +200,16 @@ def test_render_option_defaults_and_struct_layout():
     o = _lib.RenderOptions()
     C.memset(C.byref(o), 0xFF, C.sizeof(o))
     lib.gsx_render_options_default(C.byref(o))
-    assert C.sizeof(o) == 36
-    assert (o.progressive, o.first_slab_divisor, o.min_slab, o.growth, o.speculative, o.spec_radius, o.host_verify, o.frames_in_flight) == (
-        1, 16, 131072, 2, 1, 3, 0, 1)
+    assert C.sizeof(o) == 40 and lib.gsx_abi_version() == 3
+    assert (o.progressive, o.first_slab_divisor, o.min_slab, o.growth, o.speculative, o.spec_radius, o.host_verify, o.frames_in_flight, o.slab_shading) == (
+        1, 16, 131072, 2, 1, 3, 0, 1, 1)
     assert abs(o.spec_margin - 0.25) < 1e-7
     header = open(os.path.join(ROOT, "include", "gsx.h")).read()
     body = header[header.index("typedef struct gsx_render_options {"):header.index("} gsx_render_options;")]
     assert [ln.split()[1].rstrip(";") for ln in body.splitlines()[1:] if ln.strip().startswith(("uint32_t", "float"))] == [
         f[0] for f in _lib.RenderOptions._fields_]
-    assert "pub frames_in_flight: u32" in open(os.path.join(ROOT, "rust", "gsx-sys", "src", "lib.rs")).read()
+    rs = open(os.path.join(ROOT, "rust", "gsx-sys", "src", "lib.rs")).read()
+    assert "pub frames_in_flight: u32" in rs and "pub slab_shading: u32" in rs and "GSX_ABI_VERSION: u32 = 3" in rs
 
 
 def test_rust_sys_covers_every_symbol():
