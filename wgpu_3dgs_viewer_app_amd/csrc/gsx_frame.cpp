@@ -73,6 +73,7 @@ static gsx_status wait_verdict(gsx_viewer* v, uint32_t seq, uint32_t* need) {
 // A decision that confirms the current mode doubles its phase — quadruples it when the verdict is clear — (64 ... 2048
 // frames: the probes then cost < 1 %), one that flips it starts over at 64.  By construction the result stays within a few per cent of the better of the two paths.
 constexpr uint32_t kWalkFineOn = 160, kWalkFineOff = 30;  // chunks of 128 candidates: finer blocks above / coarse blocks again below (measured under the finer ones)
+constexpr uint32_t kSlabShadingMaxPercent = 35;  // slab shading pays while the slabs shade less than this share of the visible records (break-even ~45 % on cfg4)
 constexpr uint32_t kBucketSortMax = 1500000;  // pairs: above, the LSD depth sort (256 buckets of 8192 pairs fit the LDS; at 1 M the bucket sort takes half the LSD sort's time)
 constexpr uint32_t kProbeFrames = 5;   // the first is not timed (the switch itself is atypical), the other four are
 constexpr uint32_t kSettleWait = 8;    // frames enqueued behind a probe before the host waits for its timings
@@ -232,6 +233,7 @@ gsx_status finish_frame(gsx_viewer* v) {
                 m->last_spec_sorted = m->h_counters->n_sorted;
                 m->last_repair_sorted = m->h_counters->n_sorted2;
             }
+            if (m->slab_shading && m->binned) m->slab_shading_off = (uint64_t)m->h_counters->n_shaded_total * 100u > (uint64_t)m->h_counters->n_visible * kSlabShadingMaxPercent;
             if (m->binned) m->slabs_hint = m->h_counters->slabs_used;
             m->stats_copy_inflight = false;
             note_overflow(m);
@@ -286,10 +288,16 @@ gsx_status ensure_sortbin_capacity(Model* m, uint64_t count) {
             HIPCHK(gsx::op::Memset(m->sort_ws.p, 0, m->sort_ws.bytes));  // status words must not alias a live epoch
         }
     }
-    HIPCHK(m->cnt.ensure(4 * n));
     HIPCHK(m->srect.ensure(16 * n));  // uint2 tile rectangles (tile lists) or uint4 {rect, key, index} (block lists)
-    HIPCHK(m->block_sums.ensure(4 * (scan_blocks(n) + 1)));
+    // (cnt / block_sums — per-record counts and their chunk sums — belong to the three-launch binning: per-tile lists, GSX_BIN_FUSED=0;
+    //  the slabs that take that path ask for them: ensure_count_buffers)
     m->sortbin_cap = n;
+    return GSX_OK;
+}
+
+static gsx_status ensure_count_buffers(Model* m) {
+    HIPCHK(m->cnt.ensure(4 * m->sortbin_cap));
+    HIPCHK(m->block_sums.ensure(4 * (scan_blocks(m->sortbin_cap) + 1)));
     return GSX_OK;
 }
 
@@ -417,6 +425,13 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
     // a model small enough for ONE slab keeps complete per-tile lists and its full records (gsx_model_download_tile_lists).
     m->slab_shading = v->options.slab_shading && v->options.progressive && v->bin_mode == 1 && v->bin_fused && !m->spec_round1 && !shard_lazy &&
                       m->n > v->options.min_slab && m->pod().sh_aos != nullptr;
+    // ... and only while it pays: a scene where next to nothing saturates (translucent) has every visible record taken by some block — then
+    // the streaming projection of everything (k_project: 0.67 of HBM peak) beats gathering the same records slab by slab.  Measured, lazily:
+    // the last slab-shaded frame's count (Counters::n_shaded_total); tried again every 256th plain frame.
+    if (m->slab_shading && m->slab_shading_off) {
+        if (++m->slab_shading_retry < 256u) m->slab_shading = false;
+        else m->slab_shading_retry = 0, m->slab_shading_off = false;
+    }
     m->lazy = (m->spec_round1 || shard_lazy || m->slab_shading) && (v->query.kind == GSX_QUERY_NONE || geometric_query);
     if (!m->lazy) m->slab_shading = false;
     if (m->lazy && geometric_query) {
@@ -695,6 +710,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
             m->last_spec_sorted = m->h_counters->n_sorted;
             m->last_repair_sorted = m->h_counters->n_sorted2;
         }
+        if (m->stats_copy_slab_shading) m->slab_shading_off = (uint64_t)m->h_counters->n_shaded_total * 100u > (uint64_t)m->h_counters->n_visible * kSlabShadingMaxPercent;
         note_overflow(m);  // a free-running loop learns here that some earlier frame spilled: larger pair buffers from now on
         // long block lists (a scene where little saturates): the block sort carries the lists' records along (k_composite_blocks
         // SORTED); with hysteresis, from whatever frame's statistics arrived last — either way the pixels are the same
@@ -734,7 +750,10 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
     // the buffers when it learns of it) — 32 bytes of pair / sort buffers per entry
     // (a frame without depth slabs keeps per-tile lists of the whole model: 16 as well)
     {
-        const uint64_t per_record = (!progressive || m->rec_n <= (1u << 18)) ? 16u : 6u;
+        // (round 6: large progressive models start at ONE entry per record — cfg4's largest slab makes 0.1, 32 bytes of pair / sort buffers an
+        //  entry were 192 bytes a Gaussian and lane at the 6 entries of rounds 2-5; a scene that wants more — large splats, nothing saturating —
+        //  spills on the device for the few frames it takes the host to learn of it: note_overflow doubles, or jumps to what was needed)
+        const uint64_t per_record = (!progressive || m->rec_n <= (1u << 18)) ? 16u : 1u;
         m->tile_cap = std::max<uint64_t>(m->tile_cap, std::max<uint64_t>(1u << 20, per_record * m->rec_n));
     }
     if (v->tile_cap_fixed) m->tile_cap = v->tile_cap_fixed;  // GSX_TILE_CAP (tests): a capacity that overflows on purpose
@@ -858,6 +877,8 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
                         if (sst) return sst;
                     }
                 } else {
+                    gsx_status cst = ensure_count_buffers(m);
+                    if (cst) return cst;
                     HIPCHK(launch_block_bin(v->stream, j0, j1, d_n, m->sorted_idx, m->rec(), m->sk_out.as<uint32_t>(), m->srect.as<uint4>(),
                                             m->cnt.as<uint32_t>(), m->block_sums.as<uint32_t>(), dc, cap, row_lo, row_hi, done_in, row_words,
                                             (progressive && later) ? done_count : nullptr, owned_tiles, slab_index, win, m->fc.tiles_x,
@@ -893,6 +914,8 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
         } else {
             {
                 ScopedPass t(v, GSX_PASS_BIN);
+                gsx_status cst = ensure_count_buffers(m);
+                if (cst) return cst;
                 HIPCHK(launch_tile_counts(v->stream, j0, j1, d_n, m->sorted_idx, m->rec(), m->srect.as<uint2>(),
                                           m->cnt.as<uint32_t>(), m->block_sums.as<uint32_t>(), dc, cap, row_lo, row_hi, done_in,
                                           row_words, (progressive && later) ? done_count : nullptr, owned_tiles, slab_index,
@@ -1093,6 +1116,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
         HIPCHK(gsx::op::EventRecord(m->stats_event, v->stream));
         m->stats_copy_inflight = true;
         m->stats_copy_speculated = m->spec_round1;
+        m->stats_copy_slab_shading = m->slab_shading && m->lazy;
     }
     tuner_frame_end(v, m);
     m->binned = true;

@@ -379,6 +379,7 @@ struct SlabStats {
     uint32_t n_sorted2;        // speculation: records admitted in the repair round
     uint32_t spec_need;        // speculation: tiles that needed the repair round
     uint32_t verify_ticket;    // k_spec_verify: blocks that have added their share of spec_need (the last one posts the verdict)
+    uint32_t n_shaded_total;   // slab shading: records shaded over the frame's slabs (the host stops slab shading on a scene where most visible records are: translucent)
     uint32_t n_slab_shade;     // slab shading (gsx_render_options): records of the current slab some block takes = the slab's shading list (k_block_bin)
     uint32_t slab_cut;         // depth-order position up to which the current slab was binned into pairs: the whole slab unless
                                // its entries overflowed the pair buffers; k_composite_spill composites [slab_cut, slab end)

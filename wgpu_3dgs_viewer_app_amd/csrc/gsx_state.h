@@ -225,6 +225,9 @@ struct Model {
     DevBuf adm_pairs, adm_ballots, adm_counts;  // admission pass: compacted (key, index) pairs, per-wave ballots, per-workgroup counts
     DevBuf bin_ws;                   // k_block_bin: ticket + one status word per 2048-record tile
     DevBuf msd_ws, msd_ws2;          // bucket sort (gsx_internal.h): fine histogram, key-range cells, k_admit_compact's status words — main round / repair round
+    bool slab_shading_off = false;   // the last slab-shaded frame shaded most of what it saw (a scene where nothing saturates): project in full until the data changes
+    uint32_t slab_shading_retry = 0; // plain frames since: every 256th tries again
+    bool stats_copy_slab_shading = false;
     bool slab_shading = false;       // this frame: geometry-only projection without windows; the depth slabs shade what their blocks take
     uint32_t last_spec_sorted = 0, last_repair_sorted = 0;  // admitted / repair records of the last SPECULATED frame whose statistics have arrived (lagging; 0: none yet)
     uint32_t msd_seq = 0, msd_seq2 = 0;  // sorts made on them so far (the cells rotate)

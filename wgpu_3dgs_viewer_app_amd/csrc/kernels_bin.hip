@@ -668,7 +668,10 @@ __global__ __launch_bounds__(kFuseThreads) void k_block_bin(const uint32_t* __re
             const uint32_t sb = s_shade_before;
             if (c[0]) shade_pairs[sb + foff0 + (uint32_t)__popcll(fb0 & lt)] = make_uint2(key[0], idx[0]);
             if (c[1]) shade_pairs[sb + ft0 + foff1 + (uint32_t)__popcll(fb1 & lt)] = make_uint2(key[1], idx[1]);
-            if (tile == n_tiles - 1u && tid == 0) stats->n_slab_shade = sb + ft0 + ft1;
+            if (tile == n_tiles - 1u && tid == 0) {
+                stats->n_slab_shade = sb + ft0 + ft1;
+                stats->n_shaded_total += sb + ft0 + ft1;
+            }
         }
         // the pair buffers hold `capacity` entries: the first record whose last entry would not fit is the slab's cut
         const bool crossing = before <= capacity && before + total > capacity;
