@@ -78,7 +78,7 @@ python3 tools/ab_blocks.py > $OUT/ab_blocks.txt 2>> $OUT/bench.err
  echo "== GSX_SHARD_LAYER_PIPELINE=$P: every rank of a world-8 cfg5 frame alone, two frames in flight"; GSX_SHARD_LAYER_PIPELINE=$P python3 tools/rank_alone.py --workload cfg5 --worlds 8 --scenes orbit --lanes 2 --speculate 1 --frames 50 --no-pass-replay 2>&1 >/dev/null | grep predicted; done) > $OUT/ab_layer_pipeline.txt 2>&1
 python3 tools/long_run_layers.py 8000 2>&1 | grep "world\|long run\|Error" > $OUT/long_run_layers.txt
 for n in 100000 310000 870000; do
-  echo "== n=$n, 2048-element tiles off" >> $OUT/ab_radix_small.txt; GSX_RADIX_SMALL=0 tools/bench_sort $n 32 depth >> $OUT/ab_radix_small.txt 2>&1
+  echo "== n=$n, 2048-element tiles off" >> $OUT/ab_radix_small.txt; tools/bench_sort $n 32 depth >> $OUT/ab_radix_small.txt 2>&1
   echo "== n=$n, default" >> $OUT/ab_radix_small.txt; tools/bench_sort $n 32 depth >> $OUT/ab_radix_small.txt 2>&1
 done
 fi

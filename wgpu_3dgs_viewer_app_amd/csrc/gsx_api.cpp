@@ -263,7 +263,7 @@ gsx_status gsx_viewer_create(const gsx_viewer_desc* desc, gsx_viewer** out) {
     if (const char* tc = getenv("GSX_TILE_CAP")) v->tile_cap_fixed = std::max<long long>(atoll(tc), 1);
     if (const char* bm = getenv("GSX_BIN")) v->bin_mode = atoi(bm) ? 1 : 0;
     v->edit_cache = getenv("GSX_NO_EDIT_CACHE") == nullptr;
-    v->shard_pair_slots = getenv("GSX_SHARD_UNIFORM_SLOTS") == nullptr;
+    v->shard_pair_slots = true;   // (round 3's one slot size for every pair lost the A/B of round 4: profiles/r04_*; gsx_shard_set_slot_records still forces a size)
     v->tile_profile = getenv("GSX_TILE_PROFILE") != nullptr;
     if (const char* e = getenv("GSX_TILE_ORDER")) v->tile_order_on = atoi(e) != 0;
     if (const char* e = getenv("GSX_BUCKET_SORT")) v->bucket_sort = atoi(e) != 0;
@@ -283,6 +283,7 @@ gsx_status gsx_viewer_create(const gsx_viewer_desc* desc, gsx_viewer** out) {
         v->own_stream = true;
     }
     gsx_spec_params_default(&v->params);
+    gsx_render_options_default(&v->options);   // (one source for the defaults: a field added to the struct cannot be forgotten here)
     v->width = std::max(1u, desc->width);
     v->height = std::max(1u, desc->height);
     static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};

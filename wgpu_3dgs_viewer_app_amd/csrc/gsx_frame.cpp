@@ -434,6 +434,11 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
     }
     m->lazy = (m->spec_round1 || shard_lazy || m->slab_shading) && (v->query.kind == GSX_QUERY_NONE || geometric_query);
     if (!m->lazy) m->slab_shading = false;
+    {
+        static const bool debug = getenv("GSX_SPEC_DEBUG") != nullptr && atoi(getenv("GSX_SPEC_DEBUG")) >= 2;
+        if (debug) fprintf(stderr, "[gsx frame] model '%s': speculated %d, slab shading %d (off %d), lazy %d, n %llu\n", m->key.c_str(), (int)m->spec_round1,
+                           (int)m->slab_shading, (int)m->slab_shading_off, (int)m->lazy, (unsigned long long)m->n);
+    }
     if (m->lazy && geometric_query) {
         HIPCHK(m->query_flags.ensure(4 * std::max<size_t>(words, 1)));
         if (v->query.kind == GSX_QUERY_TEXTURE && (v->query_tex_w != v->width || v->query_tex_h != v->height))

@@ -209,7 +209,7 @@ gsx_status read_block(Ctx& c, size_t i, const uint32_t* hv) {
     gsx_viewer* o = c.owner;
     if (hv[4] & 1u) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_render_frame: the ranks name different gather roots (gsx_shard_set_gather_root: this rank %d)", (int)o->shard_gather_root);
     if (hv[4] & 2u) return fail(GSX_ERR_INVALID_ARG, "gsx_shard_render_frame: the ranks size their exchange slots or bands differently (gsx_shard_set_balance, "
-                                "GSX_SHARD_UNIFORM_SLOTS, gsx_shard_set_slot_records must be the same on every rank)");
+                                "gsx_shard_set_slot_records must be the same on every rank)");
     o->shard_root_confirmed = true;
     o->next_edges.assign(hv + kVerdictEdges, hv + kVerdictEdges + c.world + 1);
     o->next_edges_tiles_y = c.tiles_y;

@@ -427,11 +427,11 @@ struct gsx_viewer {
     bool shard_root_confirmed = false;   // a verdict since the last gsx_shard_set_gather_root has shown that every rank names the same root
     uint32_t next_edges_tiles_y = 0;     // the grid next_edges was made for
     bool shard_balance = true;           // gsx_shard_set_balance
-    bool shard_pair_slots = true;        // size the exchange slots pair by pair (where the transport moves unequal pieces); GSX_SHARD_UNIFORM_SLOTS
+    bool shard_pair_slots = true;        // size the exchange slots pair by pair (where the transport moves unequal pieces)
     DevBuf shard_fb, shard_send, shard_recv, shard_sat_band, shard_sat_all, shard_counts;  // gsx_shard_render_frame's own buffers
     void* ext_fb = nullptr;              // caller-owned framebuffer (multi-GPU: the RCCL gather target)
     uint64_t ext_fb_bytes = 0;
-    gsx_render_options options{1u, 16u, 131072u, 2u, 1u, 0.25f, 3u, 0u, 1u};  // = gsx_render_options_default
+    gsx_render_options options{1u, 16u, 131072u, 2u, 1u, 0.25f, 3u, 0u, 1u, 1u};  // = gsx_render_options_default (a CPU test compares the two: gsx_viewer_get_render_options)
     uint32_t timing = 0;  // bit p: bracket pass p with events
     std::vector<PassTimer> timers;     // recorded, not yet read
     std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;

@@ -816,8 +816,8 @@ hipError_t launch_project(hipStream_t s, const FrameConsts& f, uint32_t n, const
 hipError_t launch_shade(hipStream_t s, const FrameConsts& f, uint32_t n, const PodPlanes& pod, const Records& rec,
                         const LateProjection& late) {
     if (n == 0) return hipSuccess;
-    static const bool quads = getenv("GSX_SHADE_QUADS") == nullptr || atoi(getenv("GSX_SHADE_QUADS")) != 0;  // (A/B switch)
-    if (quads && pod.sh_kind != GSX_SH_NONE && pod.sh_aos != nullptr && pod.aos_geo != 0u) {
+    // (four lanes to a record: + 3 % on the frame against one lane per record, same values — rounds 4 and 5, profiles/r05_*; the A/B switch is gone)
+    if (pod.sh_kind != GSX_SH_NONE && pod.sh_aos != nullptr && pod.aos_geo != 0u) {
         const dim3 grid(8192), block(256);   // 0.5 M quads stride over the admitted records
 #define GSX_QUADS(SHK, COVK)                                                                                                                      \
     switch ((int)f.sh_deg) {                                                                                                                      \

@@ -44,7 +44,7 @@ constexpr int kRadixTile = kSweepThreads * kRadixRounds;  // 8192 elements per t
 // leave most of the chip idle and every tile is a 16-round chain per lane — the pass is one tile's latency.  At or below
 // kRadixSmallN elements (decided ON THE DEVICE from *d_n: the host only knows an upper bound) a pass runs 2048-element tiles,
 // four rounds per lane: four times the workgroups, a quarter of the chain each.  Same ranks, same order (tile boundaries are not
-// part of the result).  tools/bench_sort.hip sweeps the threshold (GSX_RADIX_SMALL).
+// part of the result).  (Round 5 swept the threshold with an environment switch; settled, the switch is gone.)
 constexpr int kRadixRoundsSmall = 4;
 constexpr int kRadixTileSmall = kSweepThreads * kRadixRoundsSmall;  // 2048
 constexpr uint32_t kRadixSmallN = 1u << 19;
@@ -65,8 +65,7 @@ __device__ long long* g_sort_prof = nullptr;
 #endif
 
 static uint32_t radix_small_n() {
-    static const uint32_t v = getenv("GSX_RADIX_SMALL") ? (uint32_t)atoll(getenv("GSX_RADIX_SMALL")) : kRadixSmallN;
-    return v;
+    return kRadixSmallN;
 }
 // tiles a pass over at most n elements may use (status words, grid): the larger of the two tilings
 static inline uint32_t radix_tiles(uint64_t n) {
@@ -627,7 +626,7 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
     uint32_t* ticket = buf.workspace + 1024;
     u64* status = reinterpret_cast<u64*>(buf.workspace + 1032);
     const uint32_t tiles = radix_tiles(n);
-    static const uint32_t grid_limit = getenv("GSX_RADIX_GRID") ? (uint32_t)atoi(getenv("GSX_RADIX_GRID")) : kRadixGrid;
+    const uint32_t grid_limit = kRadixGrid;   // (768 / 512 / 256 workgroups swept in rounds 2-3: the resident capacity wins)
     const uint32_t grid = std::min<uint32_t>(grid_limit, tiles);
     // skip_culled: the keys are a projection's key plane (iota values); records whose key is 0xFFFFFFFF do not exist.  The
     // histogram and the first pass run over all n of them, *d_n receives how many exist, the later passes run over those.
@@ -635,7 +634,7 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
     // ghist is zero here: the workspace is cleared at allocation and every sort's last pass clears it again
     // histogram workgroups: ~one per 1024..4096 elements up to the persistent grid (sorts of a few hundred thousand elements
     // are latency-bound: 300 k keys took 89 us with 4096 x 4 elements per workgroup, 67 us with 4096)
-    static const uint32_t hper = getenv("GSX_RADIX_HPER") ? (uint32_t)atoi(getenv("GSX_RADIX_HPER")) : 4096u;
+    const uint32_t hper = 4096u;
     const uint32_t hgrid = std::max<uint32_t>(1u, std::min<uint32_t>(768u, (uint32_t)(((uint64_t)n + hper - 1) / hper)));
     if (hist_done) {
         // (the kernel that wrote the pairs counted their digits into ghist: k_block_bin)
@@ -1078,7 +1077,7 @@ hipError_t launch_bucket_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n
             GSX_LAUNCH(k_msd_hist<1>, dim3(hgrid), dim3(kRadixThreads), 0, s, buf.keys_src, n, d_n, mc.fine, mc.hint, mc.acc);
     }
     const uint32_t tiles = radix_tiles(n);
-    static const uint32_t grid_limit = getenv("GSX_RADIX_GRID") ? (uint32_t)atoi(getenv("GSX_RADIX_GRID")) : kRadixGrid;
+    const uint32_t grid_limit = kRadixGrid;   // (768 / 512 / 256 workgroups swept in rounds 2-3: the resident capacity wins)
     const uint32_t grid = std::min<uint32_t>(grid_limit, tiles);
     const bool lane_ordered = use_lane_ordered();
     const uint32_t epoch = next_sort_epoch();
