@@ -294,8 +294,23 @@ gsx_status gsx_viewer_create(const gsx_viewer_desc* desc, gsx_viewer** out) {
     return GSX_OK;
 }
 
+// GSX_MEM_DEBUG=1: what every model of a viewer (and of its lanes) holds on the device, buffer by buffer, when the viewer goes
+static void mem_debug(const gsx_viewer* v, const char* who) {
+    for (const auto& kv : v->models) {
+        const Model* m = kv.second.get();
+#define GSX_MB(b) if (m->b.bytes && !m->b.borrowed) fprintf(stderr, "[gsx mem] %s model '%s' %-16s %9.1f MB  %6.1f B / Gaussian\n", who, m->key.c_str(), #b, m->b.bytes / 1e6, (double)m->b.bytes / (double)std::max<uint64_t>(m->n, 1));
+        GSX_MB(pc) GSX_MB(cov_a) GSX_MB(cov_b) GSX_MB(sh4) GSX_MB(sh1) GSX_MB(sh_h) GSX_MB(sh_q) GSX_MB(sh_aos) GSX_MB(cov_h) GSX_MB(cov_h2) GSX_MB(mask)
+        GSX_MB(key_buf) GSX_MB(rec_a) GSX_MB(rec_b) GSX_MB(rec_c) GSX_MB(rect8) GSX_MB(imp_key) GSX_MB(imp_a) GSX_MB(imp_b) GSX_MB(imp_c)
+        GSX_MB(dp_a) GSX_MB(dp_b) GSX_MB(sk_out) GSX_MB(sv_out) GSX_MB(sort_ws) GSX_MB(cnt) GSX_MB(block_sums) GSX_MB(srect) GSX_MB(block_vis)
+        GSX_MB(tp_src) GSX_MB(tp_a) GSX_MB(tp_b) GSX_MB(tk_out) GSX_MB(tv_out) GSX_MB(tsort_ws) GSX_MB(brec_sorted) GSX_MB(adm_pairs) GSX_MB(adm_ballots)
+        GSX_MB(adm_counts) GSX_MB(adm_offsets) GSX_MB(adm_ballots2) GSX_MB(adm_counts2) GSX_MB(pack_masks) GSX_MB(edit_a) GSX_MB(edit_b) GSX_MB(msd_ws) GSX_MB(bin_ws)
+#undef GSX_MB
+    }
+}
+
 void gsx_viewer_destroy(gsx_viewer* v) {
     if (!v) return;
+    if (getenv("GSX_MEM_DEBUG")) mem_debug(v, v->parent ? "lane" : "viewer");
     (void)hipSetDevice(v->device);
     (void)gsx_viewer_comm_destroy(v);  // first: it drains the lanes' streams, then destroys the communicators (a lane has none of its own)
     for (gsx_viewer* l : v->lanes) gsx_viewer_destroy(l);  // (synchronises the lane's stream first)

@@ -202,6 +202,10 @@ static void note_overflow(Model* m) {
     if (ev == m->overflow_seen) return;
     m->overflow_slabs += ev - m->overflow_seen;
     m->overflow_seen = ev;
+    if (getenv("GSX_SPEC_DEBUG"))
+        fprintf(stderr, "[gsx overflow] model '%s': %u events so far, largest slab wanted %u entries, capacity %llu, n_sorted %u n_sorted2 %u entries_total %u speculated-copy %d\n",
+                m->key.c_str(), ev, m->h_counters->max_needed_ever, (unsigned long long)m->tile_cap, m->h_counters->n_sorted, m->h_counters->n_sorted2,
+                m->h_counters->n_entries_total, (int)m->stats_copy_speculated);
     m->tile_cap = std::max<uint64_t>(2 * m->tile_cap, (uint64_t)m->h_counters->max_needed_ever + 1024);
 }
 
@@ -234,7 +238,7 @@ gsx_status finish_frame(gsx_viewer* v) {
                 m->last_repair_sorted = m->h_counters->n_sorted2;
             }
             if (m->slab_shading && m->binned) m->slab_shading_off = (uint64_t)m->h_counters->n_shaded_total * 100u > (uint64_t)m->h_counters->n_visible * kSlabShadingMaxPercent;
-            if (m->binned) m->slabs_hint = m->h_counters->slabs_used;
+            if (m->binned && !m->spec_round1) m->slabs_hint = m->h_counters->slabs_used;   // (a speculated frame is ONE slab: it says nothing about how many a plain frame needs)
             m->stats_copy_inflight = false;
             note_overflow(m);
             // The pixels of a frame that spilled are complete (k_composite_spill); only its tile LISTS are not, and only a
@@ -675,9 +679,11 @@ static void plan_slabs(const gsx_render_options& o, uint32_t n_vis, std::vector<
 // after used + 1 are merged into ONE remainder slab.  When the prediction holds that slab falls through
 // on the device (its count pass sees every tile done); when it does not, the remainder slab simply does
 // the work — the image is the same either way, only the number of empty launches changes.
+// (round 6: TWO slabs behind the kept ones — the next as planned, then the rest.  With everything behind in one slab, a pose at which the
+//  tiles do not saturate where the last plain frame's did handed that one slab every record: 12 M entries where the plan makes 1.5 M.)
 static void merge_tail_slabs(std::vector<uint32_t>* bounds, uint32_t used) {
     if (used == 0) return;
-    const size_t keep = (size_t)used + 1;  // slabs kept as planned
+    const size_t keep = (size_t)used + 2;  // slabs kept as planned: the ones that found work, and one more
     if (bounds->size() > keep + 2) {
         const uint32_t last = bounds->back();
         bounds->resize(keep + 1);
@@ -708,7 +714,12 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
     if (m->stats_copy_inflight && hipEventQuery(m->stats_event) == hipSuccess) {
         m->stats_copy_inflight = false;
         if (progressive) {
-            m->slabs_hint = m->h_counters->slabs_used;
+            // (the slab plan of the next PLAIN frame — a probe of the speculation tuner — from the last plain frame: taken from a speculated
+            //  frame's single slab the hint merged everything behind the second slab into one, 11 M entries where four slabs make 1.5 M)
+            if (!m->stats_copy_speculated) m->slabs_hint = m->h_counters->slabs_used;
+            if (getenv("GSX_SPEC_DEBUG") && atoi(getenv("GSX_SPEC_DEBUG")) >= 3)
+                fprintf(stderr, "[gsx stats] viewer %p: copy of a %s frame: slabs_used %u, n_sorted %u, entries %u, max_needed %u\n", (void*)v, m->stats_copy_speculated ? "speculated" : "plain",
+                        m->h_counters->slabs_used, m->h_counters->n_sorted, m->h_counters->n_entries_total, m->h_counters->max_needed);
             m->n_sorted = m->h_counters->n_sorted;
         }
         if (m->stats_copy_speculated) {
@@ -741,6 +752,11 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
         plan_slabs(v->options, (uint32_t)m->rec_n, &bounds);
         if (progressive) merge_tail_slabs(&bounds, m->slabs_hint);
     }
+    if (getenv("GSX_SPEC_DEBUG") && atoi(getenv("GSX_SPEC_DEBUG")) >= 3) {
+        fprintf(stderr, "[gsx slabs] viewer %p model '%s': speculated %d, slab shading %d, hint %u, slabs", (void*)v, m->key.c_str(), (int)m->spec_round1, (int)m->slab_shading, m->slabs_hint);
+        for (uint32_t b : bounds) fprintf(stderr, " %u", b);
+        fprintf(stderr, "\n");
+    }
     Counters* dc = m->counters.as<Counters>();
     const uint32_t row_lo = std::min(m->row_lo, m->fc.tiles_y), row_hi = std::min(m->row_hi, m->fc.tiles_y);
     const uint32_t owned_tiles = (row_hi > row_lo ? row_hi - row_lo : 0) * m->fc.tiles_x;
@@ -755,10 +771,10 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
     // the buffers when it learns of it) — 32 bytes of pair / sort buffers per entry
     // (a frame without depth slabs keeps per-tile lists of the whole model: 16 as well)
     {
-        // (round 6: large progressive models start at ONE entry per record — cfg4's largest slab makes 0.1, 32 bytes of pair / sort buffers an
+        // (round 6: large progressive models start at TWO entries per record — cfg4's largest slab makes 0.2, 32 bytes of pair / sort buffers an
         //  entry were 192 bytes a Gaussian and lane at the 6 entries of rounds 2-5; a scene that wants more — large splats, nothing saturating —
         //  spills on the device for the few frames it takes the host to learn of it: note_overflow doubles, or jumps to what was needed)
-        const uint64_t per_record = (!progressive || m->rec_n <= (1u << 18)) ? 16u : 1u;
+        const uint64_t per_record = (!progressive || m->rec_n <= (1u << 18)) ? 16u : 2u;
         m->tile_cap = std::max<uint64_t>(m->tile_cap, std::max<uint64_t>(1u << 20, per_record * m->rec_n));
     }
     if (v->tile_cap_fixed) m->tile_cap = v->tile_cap_fixed;  // GSX_TILE_CAP (tests): a capacity that overflows on purpose

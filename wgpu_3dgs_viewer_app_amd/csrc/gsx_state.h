@@ -56,7 +56,9 @@ struct DevBuf {
         if (need <= bytes) return hipSuccess;
         if (borrowed) return hipErrorInvalidValue;  // a view never grows what it does not own
         release();
-        size_t want = need + need / 4 + 256;
+        // a quarter more than asked for, so that a buffer that creeps up is not reallocated every frame — for SMALL buffers: the large ones are
+        // sized by the model's Gaussian count or by a capacity plan that carries its own margin (round 6: the slack alone was 120 bytes a Gaussian)
+        size_t want = need + (need < (size_t(32) << 20) ? need / 4 : 0) + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
             p = nullptr;
