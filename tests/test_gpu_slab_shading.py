@@ -157,3 +157,20 @@ def test_viewport_changes_and_a_model_that_fills_up():
         assert np.array_equal(out[0], out[1]), f"step {k} at {size}: L-inf {np.abs(out[0] - out[1]).max()}"
     lazy.close()
     full.close()
+
+
+def test_eight_records_per_lane_tiles_on_small_slabs():
+    """k_block_bin takes eight records per lane on slabs of a million records and more (the full-size oracle tests reach that by
+    themselves); GSX_BIN_BIG_SLAB=1 puts every slab of the small scenes above through the same tile loop — slab cuts at a record,
+    overflowing slabs, shading lists, layered models: same pixels, same counters."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("GSX_BIN_BIG_SLAB"):
+        pytest.skip("already inside the rerun")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GSX_BIN_BIG_SLAB="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_slab_shading.py", "tests/test_gpu_overflow.py",
+                        "tests/test_gpu_blocks.py"], cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-500:]

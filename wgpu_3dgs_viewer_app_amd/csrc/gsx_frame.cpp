@@ -459,6 +459,9 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
     //  depth order touches one line per record whatever the record's size.  profiles/r05_ab_rect8.txt)
     m->rect8_active = m->lazy && m->fc.tiles_x <= 255u && m->fc.tiles_y <= 255u;
     if (m->rect8_active) HIPCHK(m->rect8.ensure(4 * std::max<size_t>(m->n, 1)));
+    // slab shading: a byte a Gaussian, the coarse cells of its rectangle — the depth sort carries them into depth order (do_sort)
+    m->code8_active = m->slab_shading && m->rect8_active;
+    if (m->code8_active) HIPCHK(m->code8.ensure(std::max<size_t>(m->n, 1)));
     m->last_pod_mask = pod.mask;
     m->last_pyramid = adm.pyramid.data;
     if (could_speculate && !m->use_imported) tuner_frame_begin(v, m, m->spec_round1);
@@ -531,6 +534,7 @@ gsx_status complete_records(gsx_viewer* v, Model* m) {
     PodPlanes pod = m->pod();
     pod.mask = m->last_pod_mask;
     m->rect8_active = false;  // the unlazy kernel writes every record whole
+    m->code8_active = false;
     HIPCHK(launch_project(v->stream, m->fc, (uint32_t)m->n, pod, m->proj_rec(), m->block_vis.as<uint32_t>(), adm));
     m->lazy = false;
     if (m->frame_edits || m->frame_highlight)  // every record was written again: the frame's colour ops on all of them
@@ -573,6 +577,7 @@ gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
     const uint32_t n = (uint32_t)m->rec_n;
     Counters* dc = m->counters.as<Counters>();
     uint32_t launches_sort = 4;
+    m->sorted_code_valid = false;
     {
         ScopedPass t(v, GSX_PASS_DEPTH_SORT);
         if (m->use_imported) {  // every imported record is visible: sort the keys as they lie
@@ -608,7 +613,11 @@ gsx_status do_sort(gsx_viewer* v, Model* m, bool force_full) {
                 }
                 RadixBuffers rb{m->proj_rec().key, nullptr, nullptr, m->sk_out.as<uint32_t>(), m->sv_out.as<uint32_t>(),
                                 m->dp_a.as<uint2>(), m->dp_b.as<uint2>(), m->sort_ws.as<uint32_t>()};
-                HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted, 32, true, true));
+                const bool codes = m->code8_active && !force_full && m->n <= (1u << 24);   // (the code travels in the top byte of the sort's values)
+                if (codes) HIPCHK(m->sorted_code.ensure(std::max<size_t>(m->sortbin_cap, 1)));
+                HIPCHK(launch_radix_sort(v->stream, rb, n, &dc->n_sorted, 32, true, true, nullptr, nullptr, nullptr, false, codes ? m->code8.as<uint8_t>() : nullptr,
+                                         codes ? m->sorted_code.as<uint8_t>() : nullptr));
+                m->sorted_code_valid = codes;
             } else {
                 HIPCHK(m->adm_pairs.ensure(8 * std::max<size_t>(n, 1)));
                 // a speculated frame admits a few per cent of the visible records: ONE compaction launch that also counts the bucket
@@ -891,7 +900,8 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
                                                   row_lo, row_hi, done_in, row_words, (progressive && later) ? done_count : nullptr, owned_tiles, slab_index,
                                                   win, m->fc.tiles_x, m->fc.tiles_y, bsx, bsy, m->block_table.as<uint4>(), m->tp_src.as<uint2>(),
                                                   m->ranges.as<uint2>(), jobs, table_ready, m->bin_ws.as<uint32_t>(), m->tsort_ws.as<uint32_t>(), block_bits,
-                                                  slab_shade ? m->adm_pairs.as<uint2>() : nullptr));
+                                                  slab_shade ? m->adm_pairs.as<uint2>() : nullptr,
+                                                  (slab_shade && m->sorted_code_valid) ? m->sorted_code.as<uint8_t>() : nullptr));
                     // slab shading: conic / colour records for exactly the records of this slab some block takes (and the frame's colour ops on them)
                     if (slab_shade) {
                         const gsx_status sst = shade_admitted(v, m, LateProjection{m->adm_pairs.as<uint2>(), &dc->n_slab_shade, nullptr, m->rect8_active});

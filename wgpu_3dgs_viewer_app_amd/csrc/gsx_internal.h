@@ -144,7 +144,27 @@ struct Records {
                      // culled) instead of the 16-byte `a` record — a write costs this part twice a read — and `a` (like b, c) then
                      // exists only for the Gaussians k_shade has visited.  Whoever needs the rectangle of an arbitrary visible
                      // Gaussian (the repair admission, the repair exchange's pack) reads it through rec_rect().
+    uint8_t* code8;  // N or nullptr.  Slab shading: where the rectangle lies on a 16 x 16 grid of coarse screen cells — cy << 4 | cx of its
+                     // first tile's cell when it reaches at most one cell further in x and in y, 0xFF ("look at the rectangle") otherwise
+                     // (coarse_code()).  The depth sort carries the byte into depth order in its values' top bits, and a later depth
+                     // slab refuses, without looking its rectangle up, every record none of whose (up to four) cells holds a tile that is
+                     // still open (k_block_bin) — the rectangle gather by depth order is a 64-byte sector a record.
 };
+// coarse cell of tile t on an axis of `tiles` tiles (16 cells); the code of a tile rectangle; does a code touch a live cell?
+// live: 256 bits, bit (cy * 16 + cx) — eight words
+__host__ __device__ inline uint32_t coarse_cell(uint32_t t, uint32_t tiles) { return min(t * 16u / max(tiles, 1u), 15u); }
+__host__ __device__ inline uint32_t coarse_code(uint32_t rx, uint32_t ry, uint32_t tiles_x, uint32_t tiles_y) {
+    const uint32_t cx0 = coarse_cell(rx & 0xFFFFu, tiles_x), cx1 = coarse_cell(max(rx >> 16, 1u) - 1u, tiles_x);
+    const uint32_t cy0 = coarse_cell(ry & 0xFFFFu, tiles_y), cy1 = coarse_cell(max(ry >> 16, 1u) - 1u, tiles_y);
+    return (cx1 <= cx0 + 1u && cy1 <= cy0 + 1u) ? (cy0 << 4 | cx0) : 0xFFu;
+}
+__host__ __device__ inline bool coarse_hit(uint32_t code, const uint32_t* live) {
+    if (code == 0xFFu) return true;
+    const uint32_t cx = code & 15u, cy = code >> 4;
+    uint32_t rows = (live[cy >> 1] >> ((cy & 1u) * 16u)) & 0xFFFFu;
+    if (cy < 15u) rows |= (live[(cy + 1u) >> 1] >> (((cy + 1u) & 1u) * 16u)) & 0xFFFFu;
+    return (rows & ((3u << cx) & 0xFFFFu)) != 0u;
+}
 // tile rectangle of record i in the packed (x0 | x1<<16, y0 | y1<<16) form
 __device__ inline void rec_rect(const float4* __restrict__ rec_a, const uint32_t* __restrict__ rect8, uint32_t i, uint32_t& rx, uint32_t& ry) {
     if (rect8) {
@@ -235,7 +255,8 @@ void radix_set_rank_override(int mode);  // -1 none | 0 ballot matching | 1 lane
 hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n, uint32_t* d_n, int bits, bool iota_values,
                              bool skip_culled = false, uint2* ranges_out = nullptr,  // skip_culled: keys == 0xFFFFFFFF do not exist; *d_n receives the count that do
                              const uint4* payload_in = nullptr, uint4* payload_out = nullptr,  // the last pass also writes payload_out[sorted position] = payload_in[value]
-                             bool hist_done = false);  // the digit histograms are in the workspace already (k_block_bin counted them): no histogram launch
+                             bool hist_done = false,  // the digit histograms are in the workspace already (k_block_bin counted them): no histogram launch
+                             const uint8_t* code_in = nullptr, uint8_t* code_out = nullptr);  // the last pass also writes code_out[sorted position] = code_in[value] (Records::code8)
 
 // ---- bucket sort of (depth key, Gaussian index) pairs: one MSD partition + one launch of in-LDS bucket sorts (kernels_sort.hip) ----
 // The order the spec defines is (key, index) and the index travels with the key; what the depth sort of a speculated frame (a few
@@ -352,6 +373,7 @@ hipError_t launch_admit_compact(hipStream_t s, const uint32_t* key, uint32_t n, 
                                 const uint32_t* d_skip = nullptr /* points at 0: nothing is admitted, no ballot is read */,
                                 bool histogram = true /* false: the compaction alone (msd_ws still holds its ticket and status words) */);
 uint32_t next_sort_epoch();  // status-word epochs of every look-back kernel of the process (kernels_sort.hip)
+void block_bin_set_big_slab(uint32_t records);  // tests: slabs of this many records and more take eight records per lane in k_block_bin (0: the default)
 void bucket_sort_set_cap(uint32_t cap);  // tests: buckets above `cap` pairs take the global-memory path (0: the LDS capacity)
 
 // Device-resident per-model frame statistics; the host mirrors them lazily (no sync inside a frame).
@@ -379,6 +401,7 @@ struct SlabStats {
     uint32_t n_sorted2;        // speculation: records admitted in the repair round
     uint32_t spec_need;        // speculation: tiles that needed the repair round
     uint32_t verify_ticket;    // k_spec_verify: blocks that have added their share of spec_need (the last one posts the verdict)
+    uint32_t live_cells[8][8]; // slab shading: per depth slab (index min(slab, 7)), 256 bits: the coarse cells that hold a tile still open (k_block_table; coarse_hit)
     uint32_t n_shaded_total;   // slab shading: records shaded over the frame's slabs (the host stops slab shading on a scene where most visible records are: translucent)
     uint32_t n_slab_shade;     // slab shading (gsx_render_options): records of the current slab some block takes = the slab's shading list (k_block_bin)
     uint32_t slab_cut;         // depth-order position up to which the current slab was binned into pairs: the whole slab unless
@@ -520,23 +543,42 @@ inline BlockGrid block_grid(uint32_t bsx, uint32_t bsy, uint32_t tiles_x, uint32
 // zeroes ranges[b]; a lane per tile.  done (nullable): saturated tiles are not live; win (nullable): no windows = takes every key.
 __device__ inline void wave_block_table_entry(const BlockGrid& g, uint32_t b, uint32_t tiles_x, uint32_t tiles_y, uint32_t row_lo, uint32_t row_hi,
                                               const uint32_t* __restrict__ done, uint32_t row_words, const uint2* __restrict__ win,
-                                              uint4* __restrict__ table, uint2* __restrict__ ranges) {
+                                              uint4* __restrict__ table, uint2* __restrict__ ranges, uint32_t* __restrict__ live_cells = nullptr) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t bx = b % g.blocks_x, by = b / g.blocks_x;
     const uint32_t x0 = bx << g.bsx, x1 = min(x0 + (1u << g.bsx), tiles_x);
     const uint32_t y0 = row_lo + (by << g.bsy), y1 = min(min(row_lo + ((by + 1u) << g.bsy), tiles_y), row_hi);
     uint32_t lo = 0xFFFFFFFFu, hi = 0u, live = 0u;
     const uint32_t w = x1 - x0, total = y1 > y0 ? w * (y1 - y0) : 0u;
-    for (uint32_t k = lane; k < total; k += 64) {
-        const uint32_t tx = x0 + k % w, ty = y0 + k / w;
-        if (done && ((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u)) continue;
-        if (win) {
-            const uint2 ww = win[ty * tiles_x + tx];
-            if (ww.x >= ww.y) continue;
-            lo = min(lo, ww.x);
-            hi = max(hi, ww.y);
+    for (uint32_t k0 = 0; k0 < total; k0 += 64) {   // (uniform trip count: the ballots below want every lane)
+        const uint32_t k = k0 + lane;
+        bool tile_live = false;
+        uint32_t tx = 0, ty = 0;
+        if (k < total) {
+            tx = x0 + k % w;
+            ty = y0 + k / w;
+            tile_live = !(done && ((done[ty * row_words + (tx >> 5)] >> (tx & 31u)) & 1u));
+            if (tile_live && win) {
+                const uint2 ww = win[ty * tiles_x + tx];
+                if (ww.x >= ww.y) {
+                    tile_live = false;
+                } else {
+                    lo = min(lo, ww.x);
+                    hi = max(hi, ww.y);
+                }
+            }
         }
-        live = 1u;
+        if (tile_live) live = 1u;
+        if (live_cells) {   // the coarse cells of the live tiles: one atomic per distinct cell of the wave (a block reaches over a few at most)
+            const uint32_t cell = tile_live ? coarse_cell(ty, tiles_y) * 16u + coarse_cell(tx, tiles_x) : 0xFFFFFFFFu;
+            unsigned long long pending = __ballot(cell != 0xFFFFFFFFu);
+            while (pending) {
+                const int src = __ffsll((long long)pending) - 1;
+                const uint32_t c = (uint32_t)__shfl((int)cell, src, 64);
+                if ((int)lane == src) atomicOr(&live_cells[c >> 5], 1u << (c & 31u));
+                pending &= ~__ballot(cell == c);
+            }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -589,7 +631,8 @@ hipError_t launch_block_bin_fused(hipStream_t s, uint32_t j0, uint32_t j1, const
                                   uint32_t bsx, uint32_t bsy, uint4* table, uint2* pairs, uint2* ranges, const ZeroJob& zero, bool table_ready,
                                   uint32_t* bin_ws, uint32_t* sort_ghist, int block_bits,
                                   uint2* shade_pairs = nullptr /* slab shading: (key, index) of the slab's records some block takes -> stats->n_slab_shade; the
-                                                                  rectangles are then read from rec.rect8 (the records are not shaded yet) */);
+                                                                  rectangles are then read from rec.rect8 (the records are not shaded yet) */,
+                                  const uint8_t* sorted_code = nullptr /* Records::code8 in depth order: later slabs skip records whose coarse cells hold no open tile */);
 hipError_t launch_block_bin(hipStream_t s, uint32_t j0, uint32_t j1, const uint32_t* d_n_vis, const uint32_t* sorted_idx,
                             const Records& rec, const uint32_t* sorted_keys, uint4* brec, uint32_t* cnt, uint32_t* block_sums,
                             SlabStats* stats, uint32_t capacity, uint32_t row_lo, uint32_t row_hi, const uint32_t* done,

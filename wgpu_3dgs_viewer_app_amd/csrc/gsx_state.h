@@ -123,6 +123,8 @@ struct Model {
 
     DevBuf pc, cov_a, cov_b, sh4, sh1, sh_h, sh_q, sh_aos, cov_h, cov_h2, mask;
     DevBuf key_buf, rec_a, rec_b, rec_c;        // projection records of the model's own Gaussians
+    DevBuf code8, sorted_code;                  // slab shading: coarse screen cells of every Gaussian's rectangle (Records::code8), and the same in depth order
+    bool code8_active = false, sorted_code_valid = false;
     DevBuf rect8;                               // packed tile rectangles of a lazily projected frame (Records::rect8)
     bool rect8_active = false;                  // this frame's projection wrote rect8 instead of the `a` records
     DevBuf imp_key, imp_a, imp_b, imp_c;        // records imported from other ranks (kept apart: a frame may pack twice)
@@ -274,6 +276,7 @@ struct Model {
         r.b = rec_b.as<float4>();
         r.c = rec_c.as<float4>();
         r.rect8 = rect8_active ? rect8.as<uint32_t>() : nullptr;
+        r.code8 = code8_active ? code8.as<uint8_t>() : nullptr;
         return r;
     }
     Records imp_rec() const {
@@ -283,6 +286,7 @@ struct Model {
         r.b = imp_b.as<float4>();
         r.c = imp_c.as<float4>();
         r.rect8 = nullptr;
+        r.code8 = nullptr;
         return r;
     }
     Records rec() const { return use_imported ? imp_rec() : proj_rec(); }  // the frame's active record set

@@ -7,6 +7,7 @@
 // (kernels_sort.hip, 2 passes for <= 65536 tiles) leaves every tile's list depth-ordered.
 // Integer-only; must be bit-exact against oracle/gsx_oracle.c:gsxo_tile_lists.
 // Algorithmic bytes: N_vis*44 + D*12.
+#include <atomic>
 #include <algorithm>
 
 #include "gsx_internal.h"
@@ -398,14 +399,14 @@ __global__ __launch_bounds__(256) void k_block_table(BlockGrid g, uint32_t tiles
                                                      const uint32_t* __restrict__ done, uint32_t row_words,
                                                      const uint2* __restrict__ win, uint4* __restrict__ table,
                                                      uint2* __restrict__ ranges, uint32_t* __restrict__ za, uint32_t nza,
-                                                     uint32_t* __restrict__ zb, uint32_t nzb) {
+                                                     uint32_t* __restrict__ zb, uint32_t nzb, uint32_t* __restrict__ live_cells) {
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < max(nza, nzb); i += gridDim.x * 256u) {
         if (i < nza) za[i] = 0u;
         if (i < nzb) zb[i] = 0u;
     }
     const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (b >= g.blocks_x * g.blocks_y) return;
-    wave_block_table_entry(g, b, tiles_x, tiles_y, row_lo, row_hi, done, row_words, win, table, ranges);
+    wave_block_table_entry(g, b, tiles_x, tiles_y, row_lo, row_hi, done, row_words, win, table, ranges, live_cells);
 }
 
 __device__ inline bool block_takes(const uint4* tab, uint32_t b, uint32_t key, bool keyed) {
@@ -532,169 +533,165 @@ __global__ __launch_bounds__(kBinThreads) void k_block_emit(uint32_t jbase, uint
 // capacity is crossed emits up to the last record that fits and says where it stopped; tiles behind it emit nothing.
 constexpr int kFuseThreads = 1024;
 constexpr int kFuseWaves = kFuseThreads / 64;
-constexpr uint32_t kFuseTile = 2u * kFuseThreads;   // records per tile: two per lane
+constexpr uint32_t kFuseTile = 2u * kFuseThreads;   // records per tile: two per lane (eight on slabs of kFuseBigSlab records and more)
+constexpr uint32_t kFuseBigSlab = 1u << 20;
+static std::atomic<uint32_t> g_big_slab{kFuseBigSlab};
+void block_bin_set_big_slab(uint32_t records) { g_big_slab.store(records ? records : kFuseBigSlab); }
 constexpr uint32_t kFuseGrid = 256;
 typedef unsigned long long u64b;
 
 size_t bin_workspace_words(uint64_t n_records) { return 8 + 4 * (size_t)((n_records + kFuseTile - 1) / kFuseTile + 1); }  // two 64-bit status words per tile
 
-__global__ __launch_bounds__(kFuseThreads) void k_block_bin(const uint32_t* __restrict__ d_n_vis, uint32_t j0, uint32_t j1,
-                                                             const uint32_t* __restrict__ sorted_idx, const float4* __restrict__ rec_a,
-                                                             const uint32_t* __restrict__ sorted_keys, uint4* __restrict__ brec,
-                                                             uint2* __restrict__ pairs, SlabStats* __restrict__ stats, uint32_t capacity,
-                                                             uint32_t row_lo, uint32_t row_hi, const uint32_t* __restrict__ d_done_count,
-                                                             uint32_t owned_tiles, uint32_t slab_index, BlockGrid g,
-                                                             const uint4* __restrict__ table, int keyed, uint32_t* __restrict__ order_buf,
-                                                             uint32_t order_tiles, uint32_t* __restrict__ walk_max_out,
-                                                             uint32_t* __restrict__ ticket, u64b* __restrict__ status, uint32_t epoch,
-                                                             uint32_t* __restrict__ ghist, int passes, int dbits,
-                                                             const uint32_t* __restrict__ rect8, uint2* __restrict__ shade_pairs) {
-    __shared__ uint4 tab[1024];
-    __shared__ uint32_t hist[2][256];
-    __shared__ uint32_t s_w0[kFuseWaves], s_w1[kFuseWaves];
-    __shared__ uint32_t s_tile, s_before, s_cut, s_shade_before;
-    __shared__ uint32_t s_f0[kFuseWaves], s_f1[kFuseWaves];
-    const uint32_t extra = order_buf ? 1u : 0u, workers = gridDim.x - extra, worker = blockIdx.x - extra;
-    if (extra && blockIdx.x == 0u) {
-        tile_order_job<kFuseThreads>(order_buf, order_tiles, reinterpret_cast<uint32_t*>(tab), walk_max_out);
-        return;
-    }
+// The tile loop of k_block_bin with R records per lane (a tile = R x 1024 records in depth order, lane t holding positions
+// r * 1024 + t of it: coalesced loads, R wave scans).  A workgroup's tile costs a chain of memory round trips (ticket, index, rectangle,
+// look-back) whatever R is, and 1024-lane workgroups sit one to a CU: big slabs take R = 8 (a quarter of the trips), small ones R = 2
+// (enough tiles for every CU).
+struct BinShared {
+    uint4 tab[1024];
+    uint32_t hist[2][256];
+    uint32_t w[8][kFuseWaves], f[8][kFuseWaves];
+    uint32_t tile, before, total, cut, shade_before, shade_total;
+    uint32_t live[8];
+};
+
+template <int R>
+__device__ __forceinline__ void block_bin_tiles(BinShared& sh, uint32_t n, uint32_t n_vis, uint32_t j0, const uint32_t* __restrict__ sorted_idx,
+                                                const float4* __restrict__ rec_a, const uint32_t* __restrict__ sorted_keys,
+                                                uint4* __restrict__ brec, uint2* __restrict__ pairs, SlabStats* __restrict__ stats,
+                                                uint32_t capacity, uint32_t row_lo, uint32_t row_hi, uint32_t slab_index, const BlockGrid& g,
+                                                bool keyed, uint32_t* __restrict__ ticket, u64b* __restrict__ status, uint32_t epoch, int passes,
+                                                int dbits, const uint32_t* __restrict__ rect8, uint2* __restrict__ shade_pairs,
+                                                const uint8_t* __restrict__ sorted_code, bool coarse) {
+    constexpr uint32_t kTile = (uint32_t)R * kFuseThreads;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t n_vis = min(*d_n_vis, j1);
-    const uint32_t n = n_vis > j0 ? n_vis - j0 : 0u;
-    const uint32_t n_tiles = (n + kFuseTile - 1u) / kFuseTile;
-    const bool all_done = d_done_count && *d_done_count >= owned_tiles;   // every tile this rank composites is saturated
-    if (n_tiles == 0u || all_done) {
-        if (worker == 0u && tid == 0u) {
-            stats->n_entries = 0u;
-            stats->slab_cut = max(n_vis, j0);
-            if (shade_pairs) stats->n_slab_shade = 0u;
-        }
-        return;
-    }
-    const uint32_t participants = min(workers, n_tiles);
-    if (worker >= participants) return;
-    const uint32_t n_blocks = g.blocks_x * g.blocks_y;
-    for (uint32_t b = tid; b < n_blocks; b += kFuseThreads) tab[b] = table[b];
-    if (tid < 512u) (&hist[0][0])[tid] = 0u;
-    __syncthreads();
+    const uint32_t n_tiles = (n + kTile - 1u) / kTile;
     const uint32_t dmask = (1u << dbits) - 1u;
     for (;;) {
-        if (tid == 0) s_tile = atomicAdd(&ticket[0], 1u);
+        if (tid == 0) sh.tile = atomicAdd(&ticket[0], 1u);
         __syncthreads();
-        const uint32_t tile = s_tile;
+        const uint32_t tile = sh.tile;
         if (tile >= n_tiles) break;
-        // the lane's two records: slab positions p0 < p1 (the tile's first and second half: the scan below runs half by half)
-        uint32_t pos[2], idx[2], key[2], rx[2], ry[2], c[2];
+        uint32_t idx[R], key[R], rx[R], ry[R], c[R];
+        bool look[R];
+        const uint32_t p0 = tile * kTile + tid;   // the lane's records: slab positions p0 + r * 1024
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            pos[r] = tile * kFuseTile + (uint32_t)r * kFuseThreads + tid;
-            idx[r] = pos[r] < n ? sorted_idx[j0 + pos[r]] : 0u;
-            key[r] = pos[r] < n ? sorted_keys[j0 + pos[r]] : 0u;
+        for (int r = 0; r < R; ++r) {
+            const uint32_t pos = p0 + (uint32_t)r * kFuseThreads;
+            idx[r] = pos < n ? sorted_idx[j0 + pos] : 0u;
+            key[r] = pos < n ? sorted_keys[j0 + pos] : 0u;
         }
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {   // (slab shading: the records are not shaded yet — the packed rectangle of the geometry-only projection)
+        for (int r = 0; r < R; ++r) {
+            const uint32_t pos = p0 + (uint32_t)r * kFuseThreads;
+            look[r] = pos < n;
+            if (coarse && look[r]) look[r] = coarse_hit(sorted_code[j0 + pos], sh.live);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {   // (slab shading: the records are not shaded yet — the packed rectangle of the geometry-only projection)
             rx[r] = ry[r] = 0;
-            if (pos[r] < n) rec_rect(rec_a, rect8, idx[r], rx[r], ry[r]);
+            if (look[r]) rec_rect(rec_a, rect8, idx[r], rx[r], ry[r]);
         }
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < R; ++r) {
             c[r] = 0;
             uint32_t bx0, bx1, by0, by1;
-            if (pos[r] < n && block_rect(g, rx[r], ry[r], row_lo, row_hi, bx0, bx1, by0, by1))
+            if (look[r] && block_rect(g, rx[r], ry[r], row_lo, row_hi, bx0, bx1, by0, by1))
                 for (uint32_t by = by0; by < by1; ++by)
-                    for (uint32_t bx = bx0; bx < bx1; ++bx) c[r] += block_takes(tab, by * g.blocks_x + bx, key[r], keyed != 0) ? 1u : 0u;
-            if (c[r]) brec[pos[r]] = make_uint4(rx[r], ry[r], key[r], idx[r]);   // (only records that make an entry are ever looked up)
+                    for (uint32_t bx = bx0; bx < bx1; ++bx) c[r] += block_takes(sh.tab, by * g.blocks_x + bx, key[r], keyed) ? 1u : 0u;
+            if (c[r]) brec[p0 + (uint32_t)r * kFuseThreads] = make_uint4(rx[r], ry[r], key[r], idx[r]);   // (only records that make an entry are ever looked up)
         }
-        // inclusive scans of both halves
-        uint32_t x0 = c[0], x1 = c[1];
+        // inclusive wave scans of the R stripes; slab shading: the records some block takes, counted by ballots
+        uint32_t x[R];
+        unsigned long long fb[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) x[r] = c[r];
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t y0 = __shfl_up(x0, o, 64), y1 = __shfl_up(x1, o, 64);
-            if (lane >= (uint32_t)o) {
-                x0 += y0;
-                x1 += y1;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t y = __shfl_up(x[r], o, 64);
+                if (lane >= (uint32_t)o) x[r] += y;
             }
         }
-        // slab shading: the records some block takes, counted the same way (ballots: a flag per record)
-        const unsigned long long fb0 = __ballot(c[0] != 0u), fb1 = __ballot(c[1] != 0u);
         const unsigned long long lt = (1ull << lane) - 1ull;
-        if (lane == 63) {
-            s_w0[wave] = x0;
-            s_w1[wave] = x1;
-        }
-        if (lane == 0) {
-            s_f0[wave] = (uint32_t)__popcll(fb0);
-            s_f1[wave] = (uint32_t)__popcll(fb1);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            fb[r] = __ballot(c[r] != 0u);
+            if (lane == 63) sh.w[r][wave] = x[r];
+            if (lane == 0) sh.f[r][wave] = (uint32_t)__popcll(fb[r]);
         }
         __syncthreads();
-        uint32_t off0 = 0, off1 = 0, t0 = 0, t1 = 0;
+        // the R x 16 wave totals in tile order (stripe by stripe): wave 0 turns the entry counts into their exclusive prefix and asks the
+        // tiles in front for the tile's first slot; wave 1 does the same for the shading list (a second status word per tile)
+        if (wave < 2u && (wave == 0u || shade_pairs)) {
+            uint32_t* cells = wave == 0u ? &sh.w[0][0] : &sh.f[0][0];
+            constexpr int kCells = R * kFuseWaves;
+            uint32_t carry = 0;
 #pragma unroll
-        for (uint32_t w = 0; w < (uint32_t)kFuseWaves; ++w) {
-            if (w < wave) {
-                off0 += s_w0[w];
-                off1 += s_w1[w];
-            }
-            t0 += s_w0[w];
-            t1 += s_w1[w];
-        }
-        const uint32_t total = t0 + t1;
-        const uint32_t e0 = off0 + x0 - c[0], e1 = t0 + off1 + x1 - c[1];   // first slot of each record's entries inside the tile
-        uint32_t foff0 = 0, foff1 = 0, ft0 = 0, ft1 = 0;
-        if (shade_pairs) {
+            for (int h = 0; h < (kCells + 63) / 64; ++h) {
+                const uint32_t i = (uint32_t)h * 64u + lane;
+                const uint32_t v = i < (uint32_t)kCells ? cells[i] : 0u;
+                uint32_t inc = v;
 #pragma unroll
-            for (uint32_t w = 0; w < (uint32_t)kFuseWaves; ++w) {
-                if (w < wave) {
-                    foff0 += s_f0[w];
-                    foff1 += s_f1[w];
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t y = __shfl_up(inc, o, 64);
+                    if (lane >= (uint32_t)o) inc += y;
                 }
-                ft0 += s_f0[w];
-                ft1 += s_f1[w];
+                if (i < (uint32_t)kCells) cells[i] = carry + inc - v;
+                carry += __shfl(inc, 63, 64);
             }
-        }
-        if (wave == 0) {
-            const uint32_t excl = tile_scan_publish(status, 2u, tile, epoch, lane, total);
+            const uint32_t excl = tile_scan_publish(status + wave, 2u, tile, epoch, lane, carry);
             if (lane == 0) {
-                s_before = excl;
-                s_cut = 0xFFFFFFFFu;
+                if (wave == 0u) {
+                    sh.before = excl;
+                    sh.total = carry;
+                    sh.cut = 0xFFFFFFFFu;
+                } else {
+                    sh.shade_before = excl;
+                    sh.shade_total = carry;
+                }
             }
-        } else if (wave == 1 && shade_pairs) {   // the shading list's slots: a second word per tile, a second wave
-            const uint32_t excl = tile_scan_publish(status + 1, 2u, tile, epoch, lane, ft0 + ft1);
-            if (lane == 0) s_shade_before = excl;
         }
         __syncthreads();
-        const uint32_t before = s_before;
+        const uint32_t total = sh.total;
+        uint32_t e[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) e[r] = sh.w[r][wave] + x[r] - c[r];   // first slot of each record's entries inside the tile
+        const uint32_t before = sh.before;
         if (shade_pairs) {   // (every record some block takes, whatever the cut: the tile compositor's pair-free tail blends them too)
-            const uint32_t sb = s_shade_before;
-            if (c[0]) shade_pairs[sb + foff0 + (uint32_t)__popcll(fb0 & lt)] = make_uint2(key[0], idx[0]);
-            if (c[1]) shade_pairs[sb + ft0 + foff1 + (uint32_t)__popcll(fb1 & lt)] = make_uint2(key[1], idx[1]);
+            const uint32_t sb = sh.shade_before;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (c[r]) shade_pairs[sb + sh.f[r][wave] + (uint32_t)__popcll(fb[r] & lt)] = make_uint2(key[r], idx[r]);
             if (tile == n_tiles - 1u && tid == 0) {
-                stats->n_slab_shade = sb + ft0 + ft1;
-                stats->n_shaded_total += sb + ft0 + ft1;
+                stats->n_slab_shade = sb + sh.shade_total;
+                stats->n_shaded_total += sb + sh.shade_total;
             }
         }
         // the pair buffers hold `capacity` entries: the first record whose last entry would not fit is the slab's cut
         const bool crossing = before <= capacity && before + total > capacity;
         if (crossing) {
             const uint32_t room = capacity - before;
-            if (c[0] && e0 + c[0] > room) atomicMin(&s_cut, pos[0]);
-            if (c[1] && e1 + c[1] > room) atomicMin(&s_cut, pos[1]);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (c[r] && e[r] + c[r] > room) atomicMin(&sh.cut, p0 + (uint32_t)r * kFuseThreads);
             __syncthreads();
         }
-        const uint32_t cut = crossing ? s_cut : (before > capacity ? 0u : 0xFFFFFFFFu);   // (before > capacity: an earlier tile crossed)
+        const uint32_t cut = crossing ? sh.cut : (before > capacity ? 0u : 0xFFFFFFFFu);   // (before > capacity: an earlier tile crossed)
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            if (c[r] && pos[r] < cut) {
-                uint32_t o = before + (r == 0 ? e0 : e1);
+        for (int r = 0; r < R; ++r) {
+            const uint32_t pos = p0 + (uint32_t)r * kFuseThreads;
+            if (c[r] && pos < cut) {
+                uint32_t o = before + e[r];
                 uint32_t bx0, bx1, by0, by1;
                 if (block_rect(g, rx[r], ry[r], row_lo, row_hi, bx0, bx1, by0, by1))
                     for (uint32_t by = by0; by < by1; ++by)
                         for (uint32_t bx = bx0; bx < bx1; ++bx) {
                             const uint32_t b = by * g.blocks_x + bx;
-                            if (!block_takes(tab, b, key[r], keyed != 0)) continue;
-                            pairs[o++] = make_uint2(b, pos[r]);
-                            atomicAdd(&hist[0][b & dmask], 1u);
-                            if (passes > 1) atomicAdd(&hist[1][(b >> dbits) & dmask], 1u);
+                            if (!block_takes(sh.tab, b, key[r], keyed)) continue;
+                            pairs[o++] = make_uint2(b, pos);
+                            atomicAdd(&sh.hist[0][b & dmask], 1u);
+                            if (passes > 1) atomicAdd(&sh.hist[1][(b >> dbits) & dmask], 1u);
                         }
             }
         }
@@ -719,13 +716,64 @@ __global__ __launch_bounds__(kFuseThreads) void k_block_bin(const uint32_t* __re
             }
         }
         if (crossing) {   // n_entries = entries in front of the cut: every lane knows its records' slots; the record AT the cut says it
-            if (c[0] && pos[0] == cut) stats->n_entries = before + e0;
-            if (c[1] && pos[1] == cut) stats->n_entries = before + e1;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (c[r] && p0 + (uint32_t)r * kFuseThreads == cut) stats->n_entries = before + e[r];
         }
-        __syncthreads();   // s_tile, s_w0 / s_w1, s_before, s_cut are reused by the next tile
+        __syncthreads();   // sh.tile, sh.w / sh.f, sh.before, sh.cut are reused by the next tile
     }
+}
+
+__global__ __launch_bounds__(kFuseThreads) void k_block_bin(const uint32_t* __restrict__ d_n_vis, uint32_t j0, uint32_t j1,
+                                                             const uint32_t* __restrict__ sorted_idx, const float4* __restrict__ rec_a,
+                                                             const uint32_t* __restrict__ sorted_keys, uint4* __restrict__ brec,
+                                                             uint2* __restrict__ pairs, SlabStats* __restrict__ stats, uint32_t capacity,
+                                                             uint32_t row_lo, uint32_t row_hi, const uint32_t* __restrict__ d_done_count,
+                                                             uint32_t owned_tiles, uint32_t slab_index, BlockGrid g,
+                                                             const uint4* __restrict__ table, int keyed, uint32_t* __restrict__ order_buf,
+                                                             uint32_t order_tiles, uint32_t* __restrict__ walk_max_out,
+                                                             uint32_t* __restrict__ ticket, u64b* __restrict__ status, uint32_t epoch,
+                                                             uint32_t* __restrict__ ghist, int passes, int dbits,
+                                                             const uint32_t* __restrict__ rect8, uint2* __restrict__ shade_pairs,
+                                                             const uint8_t* __restrict__ sorted_code, const uint32_t* __restrict__ live_cells, uint32_t big_slab) {
+    __shared__ BinShared sh;
+    const uint32_t extra = order_buf ? 1u : 0u, workers = gridDim.x - extra, worker = blockIdx.x - extra;
+    if (extra && blockIdx.x == 0u) {
+        tile_order_job<kFuseThreads>(order_buf, order_tiles, reinterpret_cast<uint32_t*>(sh.tab), walk_max_out);
+        return;
+    }
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_vis = min(*d_n_vis, j1);
+    const uint32_t n = n_vis > j0 ? n_vis - j0 : 0u;
+    const bool big = n >= big_slab;
+    const uint32_t tile_records = (big ? 8u : 2u) * kFuseThreads;
+    const uint32_t n_tiles = (n + tile_records - 1u) / tile_records;
+    const bool all_done = d_done_count && *d_done_count >= owned_tiles;   // every tile this rank composites is saturated
+    if (n_tiles == 0u || all_done) {
+        if (worker == 0u && tid == 0u) {
+            stats->n_entries = 0u;
+            stats->slab_cut = max(n_vis, j0);
+            if (shade_pairs) stats->n_slab_shade = 0u;
+        }
+        return;
+    }
+    const uint32_t participants = min(workers, n_tiles);
+    if (worker >= participants) return;
+    const uint32_t n_blocks = g.blocks_x * g.blocks_y;
+    for (uint32_t b = tid; b < n_blocks; b += kFuseThreads) sh.tab[b] = table[b];
+    if (tid < 512u) (&sh.hist[0][0])[tid] = 0u;
+    // later slabs: the coarse cells that still hold an open tile; a record none of whose cells does is refused before its rectangle —
+    // a 64-byte sector by depth order — is looked up (its cells arrived in depth order with the sort: one coalesced byte)
+    if (live_cells && tid < 8u) sh.live[tid] = live_cells[tid];
+    __syncthreads();
+    if (big)
+        block_bin_tiles<8>(sh, n, n_vis, j0, sorted_idx, rec_a, sorted_keys, brec, pairs, stats, capacity, row_lo, row_hi, slab_index, g, keyed != 0,
+                           ticket, status, epoch, passes, dbits, rect8, shade_pairs, sorted_code, live_cells != nullptr);
+    else
+        block_bin_tiles<2>(sh, n, n_vis, j0, sorted_idx, rec_a, sorted_keys, brec, pairs, stats, capacity, row_lo, row_hi, slab_index, g, keyed != 0,
+                           ticket, status, epoch, passes, dbits, rect8, shade_pairs, sorted_code, live_cells != nullptr);
     for (uint32_t i = tid; i < 512u; i += kFuseThreads) {
-        const uint32_t v = (&hist[0][0])[i];
+        const uint32_t v = (&sh.hist[0][0])[i];
         if (v && (int)(i >> 8) < passes) atomicAdd(&ghist[i], v);
     }
     if (tid == 0) {   // the last workgroup to leave re-arms the ticket
@@ -742,11 +790,15 @@ hipError_t launch_block_bin_fused(hipStream_t s, uint32_t j0, uint32_t j1, const
                                   uint32_t row_lo, uint32_t row_hi, const uint32_t* done, uint32_t row_words, const uint32_t* d_done_count,
                                   uint32_t owned_tiles, uint32_t slab_index, const uint2* window, uint32_t tiles_x, uint32_t tiles_y,
                                   uint32_t bsx, uint32_t bsy, uint4* table, uint2* pairs, uint2* ranges, const ZeroJob& zero, bool table_ready,
-                                  uint32_t* bin_ws, uint32_t* sort_ghist, int block_bits, uint2* shade_pairs) {
+                                  uint32_t* bin_ws, uint32_t* sort_ghist, int block_bits, uint2* shade_pairs, const uint8_t* sorted_code) {
     const BlockGrid g = block_grid(bsx, bsy, tiles_x, row_lo, row_hi);
+    // later slabs with the records' coarse cells in depth order: the table kernel also says which coarse cells still hold an open tile
+    // (zero.a is NOT this slab's word: the frame's zero job ran with the first slab, whose word nobody reads)
+    // (and not the slab whose table kernel carries the frame's zero job: that job zeroes these very words)
+    uint32_t* live = (sorted_code && done && !table_ready && zero.na == 0u && zero.nb == 0u) ? &stats->live_cells[std::min<uint32_t>(slab_index, 7u)][0] : nullptr;
     if (!table_ready)
         GSX_LAUNCH(k_block_table, dim3((g.blocks_x * g.blocks_y + 3u) / 4u), dim3(256), 0, s, g, tiles_x, tiles_y, row_lo, row_hi, done,
-                   row_words, window, table, ranges, zero.a, zero.na, zero.b, zero.nb);
+                   row_words, window, table, ranges, zero.a, zero.na, zero.b, zero.nb, live);
     const uint64_t tiles = ((uint64_t)(j1 > j0 ? j1 - j0 : 0) + kFuseTile - 1) / kFuseTile;
     const uint32_t nb = (uint32_t)std::min<uint64_t>(tiles, kFuseGrid);
     const int passes = (block_bits + 7) / 8, dbits = (block_bits + passes - 1) / passes;
@@ -754,7 +806,7 @@ hipError_t launch_block_bin_fused(hipStream_t s, uint32_t j0, uint32_t j1, const
         GSX_LAUNCH(k_block_bin, dim3(nb + (zero.order_buf ? 1u : 0u)), dim3(kFuseThreads), 0, s, d_n_vis, j0, j1, sorted_idx, rec.a, sorted_keys, brec, pairs,
                    stats, capacity, row_lo, row_hi, d_done_count, owned_tiles, slab_index, g, table, window ? 1 : 0, zero.order_buf, zero.order_tiles,
                    zero.order_buf ? &stats->walk_max : nullptr, bin_ws, reinterpret_cast<u64b*>(bin_ws + 8), next_sort_epoch(), sort_ghist, passes, dbits,
-                   shade_pairs ? rec.rect8 : nullptr, shade_pairs);
+                   shade_pairs ? rec.rect8 : nullptr, shade_pairs, live ? sorted_code : nullptr, live, g_big_slab.load());
     return hipGetLastError();
 }
 
@@ -768,7 +820,7 @@ hipError_t launch_block_bin(hipStream_t s, uint32_t j0, uint32_t j1, const uint3
     const BlockGrid g = block_grid(bsx, bsy, tiles_x, row_lo, row_hi);
     if (!table_ready)  // (the repair round of a speculated frame: k_spec_verify_fused has built the table and zeroed the ranges)
         GSX_LAUNCH(k_block_table, dim3((g.blocks_x * g.blocks_y + 3u) / 4u), dim3(256), 0, s, g, tiles_x, tiles_y, row_lo, row_hi, done,
-                   row_words, window, table, ranges, zero.a, zero.na, zero.b, zero.nb);
+                   row_words, window, table, ranges, zero.a, zero.na, zero.b, zero.nb, (uint32_t*)nullptr);
     if (nb)
         GSX_LAUNCH(k_block_counts, dim3(nb + (zero.order_buf ? 1u : 0u)), dim3(kBinThreads), 0, s, d_n_vis, j0, j1, sorted_idx, rec.a, sorted_keys,
                    brec, cnt, block_sums, row_lo, row_hi, d_done_count, owned_tiles, g, table, window ? 1 : 0, zero.order_buf, zero.order_tiles,

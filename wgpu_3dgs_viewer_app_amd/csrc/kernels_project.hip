@@ -521,6 +521,10 @@ __global__ __launch_bounds__(256) void k_project_geom(const FrameConsts f, const
             } else {
                 st_stream(&rec.a[i], make_float4(sp[k].mx, sp[k].my, __uint_as_float(sp[k].rx), __uint_as_float(sp[k].ry)));
             }
+            if (rec.code8) {   // the coarse cells of the rectangle (slab shading: later depth slabs refuse by them, k_block_bin)
+                const uint32_t code = coarse_code(sp[k].rx, sp[k].ry, f.tiles_x, f.tiles_y);
+                rec.code8[i] = vis[k] ? (uint8_t)code : (uint8_t)0;
+            }
         }
     }
 #pragma unroll

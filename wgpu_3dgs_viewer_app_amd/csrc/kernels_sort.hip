@@ -214,6 +214,7 @@ __device__ __forceinline__ void radix_sweep_tiles(const uint32_t* __restrict__ k
                                                           uint32_t ghist_clear_words, uint32_t* __restrict__ d_n_out,
                                                           uint2* __restrict__ ranges_out,
                                                           const uint4* __restrict__ payload_in, uint4* __restrict__ payload_out,
+                                                          const uint8_t* __restrict__ code_in, uint8_t* __restrict__ code_out,
                                                           uint2* __restrict__ s_pairs /* LDS: kRadixTile */, uint32_t (*__restrict__ cnt)[256] /* LDS: [kSweepWaves][256] */,
                                                           uint32_t* __restrict__ s_gbase /* LDS: 256 */, uint32_t* __restrict__ s_wtot /* LDS: kSweepWaves */,
                                                           uint32_t* __restrict__ s_misc /* LDS: [0] tile, [1] last, [2] tile_n */,
@@ -326,6 +327,9 @@ __device__ __forceinline__ void radix_sweep_tiles(const uint32_t* __restrict__ k
             } else {
                 key[r] = valid ? keys_in[e] : 0xFFFFFFFFu;
                 val[r] = valid ? (IN == 0 ? e : vals_in[e]) : 0u;
+                // (Records::code8 rides in the value's top byte — element indices below 2^24 — from the first pass, which reads it
+                //  coalesced, to the last, which splits it off again: a gather of it by depth order cost a 64-byte sector an element)
+                if (IN == 0 && code_in && valid) val[r] |= (uint32_t)code_in[e] << 24;
             }
         }
         if (LANE_ORDERED) {
@@ -467,10 +471,11 @@ __device__ __forceinline__ void radix_sweep_tiles(const uint32_t* __restrict__ k
                     pairs_out[o] = kv;
                 } else {
                     keys_out[o] = kv.x;
-                    vals_out[o] = kv.y;
+                    vals_out[o] = code_out ? (kv.y & 0xFFFFFFu) : kv.y;
                     // (the block sort: the 16-byte record its value names travels with it, so that whoever walks the sorted list
                     //  reads records side by side instead of one dependent gather per entry — k_composite_blocks)
                     if (payload_out) payload_out[o] = payload_in[kv.y];
+                    if (code_out) code_out[o] = (uint8_t)(kv.y >> 24);   // the value's top byte is the element's code (packed by the first pass)
                 }
             }
         }
@@ -504,7 +509,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t
                                                                    u64* __restrict__ status, uint32_t epoch, uint32_t* __restrict__ ghist_clear,
                                                                    uint32_t ghist_clear_words, uint32_t* __restrict__ d_n_out,
                                                                    uint2* __restrict__ ranges_out, const uint4* __restrict__ payload_in,
-                                                                   uint4* __restrict__ payload_out, uint32_t small_n) {
+                                                                   uint4* __restrict__ payload_out, uint32_t small_n, const uint8_t* __restrict__ code_in,
+                                                                   uint8_t* __restrict__ code_out) {
     __shared__ uint2 s_pairs[kRadixTile];       // tile reordered by digit
     __shared__ uint32_t cnt[kSweepWaves][256];  // per-wave digit counts, then per-wave local offsets
     __shared__ uint32_t s_gbase[256];           // global slot of the tile's local slot 0, per digit
@@ -514,11 +520,11 @@ __global__ __launch_bounds__(kSweepThreads) void k_radix_onesweep(const uint32_t
     if (!SKIP && n <= small_n)
         radix_sweep_tiles<IN, OUT, LANE_ORDERED, SKIP, kRadixRoundsSmall>(keys_in, vals_in, pairs_in, keys_out, vals_out, pairs_out, n, shift, dmask, ghist, ticket,
                                                                            status, epoch, ghist_clear, ghist_clear_words, d_n_out, ranges_out, payload_in,
-                                                                           payload_out, s_pairs, cnt, s_gbase, s_wtot, s_misc);
+                                                                           payload_out, code_in, code_out, s_pairs, cnt, s_gbase, s_wtot, s_misc);
     else
         radix_sweep_tiles<IN, OUT, LANE_ORDERED, SKIP, kRadixRounds>(keys_in, vals_in, pairs_in, keys_out, vals_out, pairs_out, n, shift, dmask, ghist, ticket,
                                                                       status, epoch, ghist_clear, ghist_clear_words, d_n_out, ranges_out, payload_in, payload_out,
-                                                                      s_pairs, cnt, s_gbase, s_wtot, s_misc);
+                                                                      code_in, code_out, s_pairs, cnt, s_gbase, s_wtot, s_misc);
 }
 
 hipError_t launch_rowscan(hipStream_t s, uint32_t* table, uint32_t nrows, uint32_t nblocks, uint32_t* totals, const uint32_t* d_n, uint32_t tile,
@@ -614,7 +620,8 @@ static bool use_lane_ordered() {
 }
 
 hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n, uint32_t* d_n, int bits, bool iota_values,
-                             bool skip_culled, uint2* ranges_out, const uint4* payload_in, uint4* payload_out, bool hist_done) {
+                             bool skip_culled, uint2* ranges_out, const uint4* payload_in, uint4* payload_out, bool hist_done,
+                             const uint8_t* code_in, uint8_t* code_out) {
     if (n == 0) return hipSuccess;
     const int passes = (bits + 7) / 8;
     if (ranges_out && passes != 1) return hipErrorInvalidValue;  // key ranges fall out of a ONE-digit sort only
@@ -654,7 +661,7 @@ hipError_t launch_radix_sort(hipStream_t s, const RadixBuffers& buf, uint32_t n,
 #define GSX_SWEEP_ARGS(DN, DNOUT)                                                                                        \
     dim3(grid), dim3(kSweepThreads), 0, s, buf.keys_src, buf.vals_src, pin, buf.keys_out, buf.vals_out, pout, n, DN, shift, dmask, \
         ghist + 256 * p, ticket, status, epoch, ghist, last ? 256u * (uint32_t)passes : 0u, DNOUT, ranges_out,                  \
-        last ? payload_in : nullptr, last ? payload_out : nullptr, radix_small_n()
+        last ? payload_in : nullptr, last ? payload_out : nullptr, radix_small_n(), (first && code_out) ? code_in : nullptr, last ? code_out : nullptr
 #define GSX_SWEEP(IN, OUT)                                                                                               \
     do {                                                                                                                 \
         if (lane_ordered)                                                                                                \
@@ -772,11 +779,11 @@ __global__ __launch_bounds__(kSweepThreads) void k_msd_sweep(const uint32_t* __r
     const MsdMap map = msd_mapping(hint);
     if (n <= small_n)
         radix_sweep_tiles<IN, 0, LANE_ORDERED, false, kRadixRoundsSmall, true>(keys_in, vals_in, pairs_in, nullptr, nullptr, pairs_out, n, 0, 255u, fine, ticket, status,
-                                                                                epoch, fine, kMsdFine, nullptr, ranges_out, nullptr, nullptr, s_pairs, cnt, s_gbase,
+                                                                                epoch, fine, kMsdFine, nullptr, ranges_out, nullptr, nullptr, nullptr, nullptr, s_pairs, cnt, s_gbase,
                                                                                 s_wtot, s_misc, s_map, s_span, map);
     else
         radix_sweep_tiles<IN, 0, LANE_ORDERED, false, kRadixRounds, true>(keys_in, vals_in, pairs_in, nullptr, nullptr, pairs_out, n, 0, 255u, fine, ticket, status, epoch,
-                                                                           fine, kMsdFine, nullptr, ranges_out, nullptr, nullptr, s_pairs, cnt, s_gbase, s_wtot, s_misc,
+                                                                           fine, kMsdFine, nullptr, ranges_out, nullptr, nullptr, nullptr, nullptr, s_pairs, cnt, s_gbase, s_wtot, s_misc,
                                                                            s_map, s_span, map);
 }
 
