@@ -22,6 +22,7 @@ ap.add_argument("--warmup", type=int, default=10)
 ap.add_argument("--edit", type=int, default=1, help="0: no selection / edit (every frame may overlap)")
 ap.add_argument("--shard", type=int, default=0, help="1: every frame through gsx_shard_render_frame_keys (one rank over the in-process "
                 "group transport: the whole exchange protocol per model, nothing on a link)")
+ap.add_argument("--only-default", action="store_true", help="the default schedule alone (for a kernel trace)")
 args = ap.parse_args()
 n_total, sh, w, h, seed = scene.CONFIGS["cfg5"]
 n = n_total // 4
@@ -84,8 +85,10 @@ def loop(**opts):
 res = {"path": "gsx_shard_render_frame_keys, world 1 (in-process group)" if args.shard else "gsx_render_frame",
        "workload": f"cfg5: 4 x {n} Gaussians SH-3, {w}x{h}, TRS per model, mask '0 - 1' on one"
                    + (", stored selection + HSV edit on the models the rectangle hit" if args.edit else ""),
-       "fps_default_schedule": round(loop(), 1), "fps_two_frames_in_flight": round(loop(frames_in_flight=2), 1),
-       "fps_unspeculated": round(loop(speculative=0), 1), "steps": args.steps}
+       "fps_default_schedule": round(loop(), 1), "steps": args.steps}
+if not args.only_default:
+    res["fps_two_frames_in_flight"] = round(loop(frames_in_flight=2), 1)
+    res["fps_unspeculated"] = round(loop(speculative=0), 1)
 st = {k: v.frame_stats(k) for k in tr}
 res["n_visible"] = int(sum(s["n_visible"] for s in st.values()))
 res["overflow_slabs"] = int(sum(s["overflow_slabs"] for s in st.values()))

@@ -813,14 +813,15 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
     }
     bool zero_pending = true;
     const uint32_t* done_before = nullptr;
+    uint32_t keep_done_words = 0;
     if (speculate) {
         const size_t bm = 4 * (size_t)row_words * m->fc.tiles_y;
         HIPCHK(m->spec_win.ensure(sizeof(uint2) * (size_t)n_tiles));
         HIPCHK(m->spec_win2.ensure(sizeof(uint2) * (size_t)n_tiles));
         if (carry) {  // nearer models already saturated some tiles: remember which, they say nothing about this model
             HIPCHK(m->spec_done_before.ensure(bm));
-            HIPCHK(gsx::op::MemcpyAsync(m->spec_done_before.p, done, bm, hipMemcpyDeviceToDevice, v->stream));
             done_before = m->spec_done_before.as<uint32_t>();
+            keep_done_words = (uint32_t)(bm / 4);
         }
     }
     const int bits = std::max<int>(1, (int)ceil_log2(n_tiles));
@@ -832,6 +833,12 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
     if (!blocks || bounds.size() < 2 || bounds[1] == bounds[0]) {  // no block-table kernel ahead (or no slab at all): zero here
         HIPCHK(launch_zero_words(v->stream, zero.a, zero.na, zero.b, zero.nb));
         zero_pending = false;
+        if (keep_done_words)
+            HIPCHK(gsx::op::MemcpyAsync(m->spec_done_before.p, done, 4 * (size_t)keep_done_words, hipMemcpyDeviceToDevice, v->stream));
+    } else if (keep_done_words) {   // ... the first slab's block-table kernel copies the bitmap on its way (it runs before anything sets a bit)
+        zero.copy_src = done;
+        zero.copy_dst = m->spec_done_before.as<uint32_t>();
+        zero.n_copy = keep_done_words;
     }
     uint32_t bsx = 0, bsy = 0;
     // most blocks of this frame: GSX_BLOCKS_MAX when it was given, otherwise 256 (one 8-bit sort pass) — or 1024 while some tile's walk is long

@@ -419,6 +419,11 @@ struct ZeroJob {
     // order_buf = {threshold, tile_cost[order_tiles], tile_order[order_tiles]}
     uint32_t* order_buf = nullptr;
     uint32_t order_tiles = 0;
+    // ... and a run of words copied on the same way (a layered model's speculated frame keeps the saturation bitmap the models in front
+    // of it left: k_spec_next must not read their tiles as this model's)
+    const uint32_t* copy_src = nullptr;
+    uint32_t* copy_dst = nullptr;
+    uint32_t n_copy = 0;
 };
 // Frames of more tiles keep index order: at 3840 x 2160 (32 400 tiles: ten dispatch rounds, the tail is a smaller share of the launch) the
 // order gains little and the job's one workgroup takes ~20 us per model — cfg5 (four models) measured 6 % slower with it.

@@ -399,10 +399,12 @@ __global__ __launch_bounds__(256) void k_block_table(BlockGrid g, uint32_t tiles
                                                      const uint32_t* __restrict__ done, uint32_t row_words,
                                                      const uint2* __restrict__ win, uint4* __restrict__ table,
                                                      uint2* __restrict__ ranges, uint32_t* __restrict__ za, uint32_t nza,
-                                                     uint32_t* __restrict__ zb, uint32_t nzb, uint32_t* __restrict__ live_cells) {
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < max(nza, nzb); i += gridDim.x * 256u) {
+                                                     uint32_t* __restrict__ zb, uint32_t nzb, uint32_t* __restrict__ live_cells,
+                                                     const uint32_t* __restrict__ copy_src, uint32_t* __restrict__ copy_dst, uint32_t n_copy) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < max(max(nza, nzb), n_copy); i += gridDim.x * 256u) {
         if (i < nza) za[i] = 0u;
         if (i < nzb) zb[i] = 0u;
+        if (i < n_copy) copy_dst[i] = copy_src[i];   // (ZeroJob: the saturation bitmap as the models in front left it)
     }
     const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (b >= g.blocks_x * g.blocks_y) return;
@@ -798,7 +800,7 @@ hipError_t launch_block_bin_fused(hipStream_t s, uint32_t j0, uint32_t j1, const
     uint32_t* live = (sorted_code && done && !table_ready && zero.na == 0u && zero.nb == 0u) ? &stats->live_cells[std::min<uint32_t>(slab_index, 7u)][0] : nullptr;
     if (!table_ready)
         GSX_LAUNCH(k_block_table, dim3((g.blocks_x * g.blocks_y + 3u) / 4u), dim3(256), 0, s, g, tiles_x, tiles_y, row_lo, row_hi, done,
-                   row_words, window, table, ranges, zero.a, zero.na, zero.b, zero.nb, live);
+                   row_words, window, table, ranges, zero.a, zero.na, zero.b, zero.nb, live, zero.copy_src, zero.copy_dst, zero.n_copy);
     const uint64_t tiles = ((uint64_t)(j1 > j0 ? j1 - j0 : 0) + kFuseTile - 1) / kFuseTile;
     const uint32_t nb = (uint32_t)std::min<uint64_t>(tiles, kFuseGrid);
     const int passes = (block_bits + 7) / 8, dbits = (block_bits + passes - 1) / passes;
@@ -820,7 +822,7 @@ hipError_t launch_block_bin(hipStream_t s, uint32_t j0, uint32_t j1, const uint3
     const BlockGrid g = block_grid(bsx, bsy, tiles_x, row_lo, row_hi);
     if (!table_ready)  // (the repair round of a speculated frame: k_spec_verify_fused has built the table and zeroed the ranges)
         GSX_LAUNCH(k_block_table, dim3((g.blocks_x * g.blocks_y + 3u) / 4u), dim3(256), 0, s, g, tiles_x, tiles_y, row_lo, row_hi, done,
-                   row_words, window, table, ranges, zero.a, zero.na, zero.b, zero.nb, (uint32_t*)nullptr);
+                   row_words, window, table, ranges, zero.a, zero.na, zero.b, zero.nb, (uint32_t*)nullptr, zero.copy_src, zero.copy_dst, zero.n_copy);
     if (nb)
         GSX_LAUNCH(k_block_counts, dim3(nb + (zero.order_buf ? 1u : 0u)), dim3(kBinThreads), 0, s, d_n_vis, j0, j1, sorted_idx, rec.a, sorted_keys,
                    brec, cnt, block_sums, row_lo, row_hi, d_done_count, owned_tiles, g, table, window ? 1 : 0, zero.order_buf, zero.order_tiles,
