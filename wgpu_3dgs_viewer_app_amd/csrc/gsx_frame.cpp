@@ -794,8 +794,6 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
         HIPCHK(m->tp_src.ensure(2 * bytes));
         HIPCHK(m->tk_out.ensure(bytes));
         HIPCHK(m->tv_out.ensure(bytes));
-        HIPCHK(m->tp_a.ensure(2 * bytes));
-        HIPCHK(m->tp_b.ensure(2 * bytes));
         const size_t ws = 4 * radix_workspace_words(cap);
         if (ws > m->tsort_ws.bytes) {
             HIPCHK(m->tsort_ws.ensure(ws));
@@ -853,6 +851,13 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
         while (count() > blocks_max) (bsx <= bsy ? bsx : bsy) += 1;
         HIPCHK(m->block_table.ensure(sizeof(uint4) * 1024));
         if (v->tile_profile) HIPCHK(v->tile_prof.ensure(sizeof(uint4) * (size_t)n_tiles));
+    }
+    {   // the pair sort's ping-pong buffers: only a sort of two digits has an intermediate, only one of three a second (block lists of
+        // <= 256 blocks — every slab of a large model — are ONE digit: emitted pairs -> sorted keys / values, 32 bytes a Gaussian and lane less)
+        const int pair_bits = blocks ? (int)std::max<uint32_t>(1u, ceil_log2(blocks_max)) : bits;
+        const size_t pair_bytes = 2 * sizeof(uint32_t) * (size_t)cap;
+        if (pair_bits > 8) HIPCHK(m->tp_a.ensure(pair_bytes));
+        if (pair_bits > 16) HIPCHK(m->tp_b.ensure(pair_bytes));
     }
     // Block compositor: the tiles that were expensive in the model's frame before are dispatched first (k_composite_blocks; a
     // schedule, not data).  The order is made by one more workgroup of the frame's first block-table kernel; a second round of the
