@@ -865,8 +865,8 @@ def main():
                       "repair round, where the verdict asks for one, is exchanged exactly sized at that point (host-decided; layered frames go out "
                       "model by model the same way); a frame whose slots overflowed is redone at its retirement, before its lane is used again and "
                       "before anybody can read it (frames_redone_with_whole_shard_slots)"
-                      + ("; GSX_SHARD_REPAIR_DEVICE / GSX_SHARD_LAYER_PIPELINE=0 in force: repair rounds always enqueued, decided on the device"
-                         if (os.environ.get("GSX_SHARD_REPAIR_DEVICE", "0") not in ("", "0") or os.environ.get("GSX_SHARD_LAYER_PIPELINE") == "0") else "")))
+                      + ("; GSX_SHARD_LAYER_PIPELINE=0 in force: repair rounds always enqueued, decided on the device"
+                         if os.environ.get("GSX_SHARD_LAYER_PIPELINE") == "0" else "")))
 
     comm_info = viewer.comm_info() if lib_index else None
     if rank == 0:
@@ -874,6 +874,7 @@ def main():
         sh_bytes = {0: 180, 1: 96, 2: 48, 3: 0}[sh_kind if sh > 0 else 3]
         cov_bytes = {0: 24, 1: 12}[cov_kind]
         pod_bytes = 16 + sh_bytes + cov_bytes
+        shade_rec_bytes = {0: 256, 1: 192 if cov_kind == 0 else 128, 2: 128, 3: 0}[sh_kind if sh > 0 else 3]   # (csrc aos_layout: whole 64-byte lines)
 
         def roofline_of(ac, tm, label_full):
             """Projection kernel of one timed loop.  ALGORITHMIC bytes per launch (means over the accounting frames):
@@ -1021,7 +1022,11 @@ def main():
                     proj_name: (proj_bytes, "geometry-only projection: N*24.125 + N_vis*cov" if lazy else f"SURVEY 8d projection: N*{pod_bytes} + N_vis*40"),
                     "depth_sort": (nsort * 68, "SURVEY 8d K2: N_sorted*68 (four 8-bit passes of 8-byte pairs, read + write, + 4 B): the records that "
                                                "enter the depth sort — all visible ones unspeculated, the admitted ones speculated; the pass also holds "
-                                               "the admission compaction and, on speculated frames, k_shade and the repair round's sort"),
+                                               "the admission compaction and, on speculated frames, the repair round's sort (shading is timed apart: `shade`)"),
+                    "shade": ((nsort * (shade_rec_bytes + 48)) if (lazy and speculated) else 0,
+                              f"conic / colour records for the Gaussians the frame admitted: N_sorted*({shade_rec_bytes} + 48) — the {shade_rec_bytes}-byte shade record in, "
+                              "48 bytes of conic / colour out (k_shade_quads + the frame's colour ops; a gather: a 64-byte sector per 16 bytes asked for). "
+                              "Unspeculated frames with slab shading: the records some block of each depth slab takes (their number is not on the line: time only)"),
                     "bin": (nsort * 44 + d_ent * 12, "BASELINE 4 binning: N_sorted*44 + D*12, D = list entries actually binned (block entries on "
                                                      "progressive frames)"),
                     "tile_sort": (d_ent * 24 + d_ent * 8, "BASELINE 4 sort: D*24*p + D*8 with p = 1 (block lists: one 8-bit pass over "
@@ -1033,6 +1038,9 @@ def main():
                     if not t or t["ms"] <= 0:
                         continue
                     us = t["ms"] * 1e3 / args.steps
+                    if not b:
+                        rows[name] = dict(us_per_frame=round(us, 1), bytes_definition=definition)
+                        continue
                     gbs = b / (us * 1e-6) / 1e9
                     rows[name] = dict(us_per_frame=round(us, 1), algorithmic_bytes=int(b), GBps=round(gbs, 1), frac_of_8TBps=round(gbs / HBM_PEAK_GBS, 4),
                                       bytes_definition=definition)

@@ -641,7 +641,10 @@ typedef enum gsx_pass {
     GSX_PASS_COMPOSITE = 4,
     GSX_PASS_PROJECT_GEOM = 5, /* the geometry-only projection of a lazily shaded (speculated / sharded) frame: another kernel,
                                   other bytes — timed apart from GSX_PASS_PROJECT so that each average is one kernel's */
-    GSX_PASS_COUNT = 6
+    GSX_PASS_SHADE = 6,        /* conic / colour records (SH colour, cov2d) for the Gaussians a lazily shaded frame admitted or a depth slab's
+                                  blocks take: the deferred half of K1's arithmetic — k_shade_quads + the frame's colour ops, wherever in
+                                  the frame they run (inside the depth sort of a speculated frame, after each slab's binning otherwise) */
+    GSX_PASS_COUNT = 7
 } gsx_pass;
 /* enabled: 0 = off, 1 = every pass, otherwise a mask with bit (p + 1) set for each pass p to bracket with events
  * (an event pair costs a few microseconds of stream gap: time only what is being measured). */

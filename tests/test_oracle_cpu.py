@@ -485,3 +485,20 @@ def test_box_mask_without_division_is_the_same_verdict():
                 got = np.abs(dd) <= lim
                 bad = np.flatnonzero(want != got)
                 assert bad.size == 0, (k, s[bad[:4]], dd[bad[:4]])
+
+
+def test_every_environment_switch_is_documented_and_placed():
+    """VERDICT r5 housekeeping: every GSX_* variable libgsx reads is a row of DESIGN.md's "Environment switches" table (what it
+    selects, why it stays, which test or tool uses it) — and nothing in that table has gone from the sources."""
+    csrc = os.path.join(ROOT, "wgpu_3dgs_viewer_app_amd", "csrc")
+    read = set()
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".cpp", ".hip", ".h")):
+            read |= set(re.findall(r'getenv\("(GSX_[A-Z0-9_]+)"\)', open(os.path.join(csrc, name)).read()))
+    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    start = text.index("### Environment switches")
+    table = text[start:text.index("\n## ", start) if "\n## " in text[start:] else len(text)]
+    rows = set(re.findall(r"^\| `(GSX_[A-Z0-9_]+)` \|", table, re.M))
+    assert read - rows == set(), f"read by libgsx, not in DESIGN.md's table: {sorted(read - rows)}"
+    assert rows - read == set(), f"in DESIGN.md's table, no longer read by libgsx: {sorted(rows - read)}"
+    assert len(read) <= 24, "a new switch needs a reason (VERDICT r5: prune the A/B losers)"

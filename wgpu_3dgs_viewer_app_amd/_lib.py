@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libgsx.so")
 GSX_ABI_VERSION = 3
 (GSX_OK, GSX_ERR_INVALID_ARG, GSX_ERR_OOM, GSX_ERR_HIP, GSX_ERR_RCCL, GSX_ERR_IO, GSX_ERR_PLY, GSX_ERR_NOT_FOUND,
  GSX_ERR_UNSUPPORTED, GSX_ERR_NO_DEVICE) = range(10)
-GSX_PASS_NAMES = ("project", "depth_sort", "bin", "tile_sort", "composite", "project_geom")
+GSX_PASS_NAMES = ("project", "depth_sort", "bin", "tile_sort", "composite", "project_geom", "shade")
 GSX_PASS_COUNT = len(GSX_PASS_NAMES)
 
 #: every symbol include/gsx.h declares (tests check the library exports exactly these)

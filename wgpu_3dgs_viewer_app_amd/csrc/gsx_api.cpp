@@ -73,13 +73,12 @@ static gsx_status lane_create(gsx_viewer* v, gsx_viewer** out) {
     // until the viewer goes, so that the next one created lands on the next queue
     std::vector<hipStream_t> busy{v->stream};
     for (gsx_viewer* o : v->lanes) busy.push_back(o->stream);
-    static const bool probe_env = getenv("GSX_NO_QUEUE_PROBE") == nullptr;
     // The probe decides from timing: with other viewers at work on the same device (ranks as threads of one process, several
     // processes per GPU) their kernels delay the candidate and the verdict is noise — every false "shares a queue" would park a
     // stream for the viewer's lifetime and spin 400 us on every busy stream.  So: only while this is the one viewer with lanes on
     // its device, and never more than kMaxParked parked streams per viewer.
     constexpr size_t kMaxParked = 8;
-    const bool probe = probe_env && g_viewers_on_device[v->device & 63].load() <= 1;
+    const bool probe = g_viewers_on_device[v->device & 63].load() <= 1;
     for (int attempt = 0; attempt < 8; ++attempt) {
         HIPCHK(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
         bool beside = true;

@@ -554,6 +554,8 @@ static gsx_status ensure_msd(gsx_viewer* v, Model* m, DevBuf& ws) {
 }
 
 gsx_status shade_admitted(gsx_viewer* v, Model* m, const LateProjection& late) {
+    ScopedPass t(v, GSX_PASS_SHADE);   // (suspends the depth sort's / the binning scope it is called from)
+    v->pass_launches[GSX_PASS_SHADE] += (m->frame_edits || m->frame_highlight) ? 2 : 1;
     PodPlanes pod = m->pod();
     pod.mask = m->last_pod_mask;
     const uint32_t n = (uint32_t)m->n;

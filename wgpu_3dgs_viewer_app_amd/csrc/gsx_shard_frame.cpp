@@ -17,7 +17,7 @@
 //               its repair exchanged behind model i - 1, in front of model i.  With frames in flight a call alternates between what is
 //               left of the frame before and the new frame, one model per turn: the verdict a turn waits for belongs to a model that
 //               went out a turn ago and the other frame's model keeps the device busy; the new frame is left with half its models out.
-//             * the alternative, built first in round 5 and kept as the A/B (GSX_SHARD_LAYER_PIPELINE=0; GSX_SHARD_REPAIR_DEVICE=1
+//             * the alternative, built first in round 5 and kept as the A/B (GSX_SHARD_LAYER_PIPELINE=0
 //               for the last model too): all models at once, the repair exchange of every model that has another BEHIND it always
 //               enqueued with slots of a fixed size R (twice the largest repair of the last frames, a maximum that decays by a
 //               sixteenth per frame) and decided on the device — its kernels fall through when no tile needs anything, the all-to-all
@@ -416,11 +416,10 @@ gsx_status frame_front(Ctx& c, bool eager_gather) {
         // behind them get the device-decided round (nothing may wait between two models); the LAST model's repair is decided by the
         // host when the frame is retired — exactly sized, and only in the frames that need it: with frames in flight that look is off
         // the critical path anyway, and a frame that repairs nothing pays no fall-through launches and no empty slots
-        // (GSX_SHARD_REPAIR_DEVICE=1: the device decides for every model — no host look ever, at ~15 launches and `world` slots a frame).
-        static const bool all_device = getenv("GSX_SHARD_REPAIR_DEVICE") != nullptr && atoi(getenv("GSX_SHARD_REPAIR_DEVICE")) != 0;
+        // (the device deciding for the last model too — no host look ever, at ~15 launches and `world` slots a frame — was the round-5 A/B's loser)
         // (a frame that is enqueued model by model — frame_step — reads every model's verdict before the next model goes out: host-decided
         //  repairs throughout, no fall-through launches)
-        if (!p.stepped && p.limited[i] && (i + 1 < n || all_device)) p.repair_slot[i] = repair_slot_policy(find_model(c.owner, p.order[i].c_str()), p.shard_max[i]);
+        if (!p.stepped && p.limited[i] && i + 1 < n) p.repair_slot[i] = repair_slot_policy(find_model(c.owner, p.order[i].c_str()), p.shard_max[i]);
     }
     c.l->shard_frames_enqueued += 1;
     p.lane_frame = c.l->shard_frames_enqueued;

@@ -356,6 +356,10 @@ struct ShardPending {
     bool overflowed = false;                  // a slot of a model read so far overflowed: the frame is redone when it is retired
 };
 
+namespace gsx {
+struct ScopedPass;
+}
+
 struct gsx_viewer {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -439,6 +443,7 @@ struct gsx_viewer {
     uint64_t ext_fb_bytes = 0;
     gsx_render_options options{1u, 16u, 131072u, 2u, 1u, 0.25f, 3u, 0u, 1u, 1u};  // = gsx_render_options_default (a CPU test compares the two: gsx_viewer_get_render_options)
     uint32_t timing = 0;  // bit p: bracket pass p with events
+    gsx::ScopedPass* open_pass = nullptr;  // the innermost pass scope open on this viewer (ScopedPass: scopes nest)
     std::vector<PassTimer> timers;     // recorded, not yet read
     std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
     float pass_ms[GSX_PASS_COUNT]{};
@@ -461,11 +466,15 @@ inline Model* find_model(gsx_viewer* v, const char* key) {
 }
 
 struct ScopedPass {
+    // Brackets a pass with a pair of events.  Scopes nest (the slab's shading inside the binning scope, the shading of admitted
+    // records inside the depth sort's): an inner scope SUSPENDS the outer one — the outer interval is closed where the inner one
+    // begins and a new one opens where it ends — so every microsecond is counted for exactly one pass.
     gsx_viewer* v;
     int pass;
     hipEvent_t a = nullptr, b = nullptr;
-    ScopedPass(gsx_viewer* v_, int pass_) : v(v_), pass(pass_) {
-        if (!((v->timing >> pass) & 1u)) return;
+    ScopedPass* outer = nullptr;
+    bool on = false;
+    void open() {
         if (!v->event_pool.empty()) {
             a = v->event_pool.back().first;
             b = v->event_pool.back().second;
@@ -476,11 +485,26 @@ struct ScopedPass {
         }
         (void)gsx::op::EventRecord(a, v->stream);
     }
-    ~ScopedPass() {
+    void close() {
         if (!a) return;
         (void)gsx::op::EventRecord(b, v->stream);
         v->timers.push_back({a, b, pass});
+        a = b = nullptr;
     }
+    ScopedPass(gsx_viewer* v_, int pass_) : v(v_), pass(pass_) {
+        outer = v->open_pass;
+        v->open_pass = this;
+        on = ((v->timing >> pass) & 1u) != 0;
+        if (outer) outer->close();
+        if (on) open();
+    }
+    ~ScopedPass() {
+        close();
+        v->open_pass = outer;
+        if (outer && outer->on) outer->open();
+    }
+    ScopedPass(const ScopedPass&) = delete;
+    ScopedPass& operator=(const ScopedPass&) = delete;
 };
 
 inline uint32_t ceil_log2(uint32_t x) {
