@@ -251,8 +251,8 @@ def cfg5_leg(steps=60, warmup=12):
 # ------------------------------------------------------------------------------------------------
 def predicted_for(world, workload):
     """What tools/rank_alone.py predicted for this world size from a ONE-GPU box (every rank of an N-rank frame replayed alone on the GPU
-    against the pieces it received; profiles/r05_rank_alone.json, committed): the number this line's `value` can prove wrong."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_rank_alone.json")
+    against the pieces it received; profiles/r06_rank_alone.json, committed): the number this line's `value` can prove wrong."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r06_rank_alone.json")
     try:
         with open(path) as f:
             table = json.loads(f.read().strip().splitlines()[-1])
@@ -266,7 +266,7 @@ def predicted_for(world, workload):
             rows[f"speculate={r['speculate']} frames_in_flight={r['frames_in_flight']}"] = dict(
                 fps=r["predicted_fps"], slowest_rank_ms_alone=r["slowest_rank_ms"], fastest_rank_ms_alone=r["fastest_rank_ms"],
                 wire_ms_at_7x153GBps=r["wire_ms_at_7x153GBps"])
-    return dict(source="profiles/r05_rank_alone.json (tools/rank_alone.py on a one-GPU box; read from that file, not measured in this run)",
+    return dict(source="profiles/r06_rank_alone.json (tools/rank_alone.py on a one-GPU box; read from that file, not measured in this run)",
                 method=table.get("method"), single_gpu_fps_in_that_run=table.get("single_gpu_fps"), by_schedule=rows) if rows else None
 
 

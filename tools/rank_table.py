@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Markdown table of a tools/rank_alone.py result (profiles/r05_rank_alone.json, ..._cfg5.json): one row per (world, scene, schedule).
+"""Markdown table of a tools/rank_alone.py result (profiles/r06_rank_alone.json, ..._cfg5.json): one row per (world, scene, schedule).
 usage: rank_table.py <json>"""
 import json
 import sys
