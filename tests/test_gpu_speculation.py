@@ -554,3 +554,33 @@ def test_viewport_resizes_with_validation(monkeypatch):
             assert np.array_equal(_frame(v, cam, ["m"], size), ref), f"frame {k} at {size}"
     for v in viewers:
         v.close()
+
+
+@pytest.mark.parametrize("host_verify", [0, 1, 2])
+def test_speculation_at_3840x2160_with_small_layered_models(host_verify):
+    """32 400 tiles (BASELINE configs[4]'s viewport) without configs[4]'s 24 M Gaussians: the verification, the window pyramids (nine levels),
+    the block tables and the repair round of two layered models over poses with jumps — every speculated frame equals the unspeculated one,
+    and the repair round runs when it must.  (The full-size cfg5 tests take the same path at 6 M Gaussians a model; this one is cheap enough
+    to run for every host_verify policy.)"""
+    size = (3840, 2160)
+    ga, gb = common.small_scene(40000, 611, scale_mul=30.0), common.small_scene(30000, 612, scale_mul=30.0)
+    mta = camera.ModelTransform(pos=np.array([0.0, 0.0, 1.0], np.float32))
+    mtb = camera.ModelTransform(pos=np.array([0.4, 0.1, -1.5], np.float32), rot=np.array([0, 30, 0], np.float32))
+    spec, plain = _viewer(True, host_verify=host_verify), _viewer(False)
+    for v in (spec, plain):
+        _load(v, "a", ga, mta)
+        _load(v, "b", gb, mtb)
+    repaired = engaged = 0
+    for k, pose in enumerate([20, 21, 22, 23, 140, 141, 142, 70, 70, 71]):
+        cam = camera.orbit_pose(pose)
+        keys = camera.model_render_order(cam.pos, {"a": mta.world_center(), "b": mtb.world_center()})
+        a, b = _frame(spec, cam, keys, size), _frame(plain, cam, keys, size)
+        assert np.array_equal(a, b), f"pose {pose} (frame {k}): L-inf {np.abs(a - b).max()}"
+        for key in keys:
+            st = spec.frame_stats(key)
+            engaged += int(st["speculated"])
+            repaired += int(st["n_repair_tiles"] > 0)
+    assert engaged >= 12 and repaired >= 1, (engaged, repaired)
+    assert a[..., 3].min() < 1e-4, "some pixels must saturate for windows to be bounded"
+    spec.close()
+    plain.close()

@@ -37,6 +37,12 @@ gsx_status ply_fail(gsx_status st, const char* fmt, ...) {
 // host_verify: spin on the pinned verdict word until k_spec_verify of this frame has posted {seq, need}.  The wait is
 // bounded by the stream itself: if the stream drains (or fails) and the word still is not there, something upstream
 // went wrong and that is reported instead of spinning forever.
+// GSX_SPEC_DEBUG=1 / 2 / 3: tuner, per-frame, per-slab lines on stderr (read once)
+static int spec_debug_level() {
+    static const int level = getenv("GSX_SPEC_DEBUG") ? std::max(1, atoi(getenv("GSX_SPEC_DEBUG"))) : 0;
+    return level;
+}
+
 static gsx_status wait_verdict(gsx_viewer* v, uint32_t seq, uint32_t* need) {
     trace_flush();  // the kernel that posts the word may still be in a recorded segment
     for (uint64_t spin = 1;; ++spin) {
@@ -103,7 +109,7 @@ static void tuner_collect(Model* m) {
 static bool tuner_wants_speculation(Model* m) {
     SpecTuner& t = m->tuner_ref ? *m->tuner_ref : m->tuner;
     tuner_collect(m);
-    static const bool debug = getenv("GSX_SPEC_DEBUG") != nullptr;
+    static const bool debug = spec_debug_level() >= 1;
     // a settle phase ends as soon as the probe's timings are in.  Eight frames after the probe the host stops running ahead
     // until they are: it waits for the probe's last event — with eight frames queued behind it the device never idles, and a
     // host that is dozens of short frames ahead (a 1 M-Gaussian scene on two lanes) would otherwise spend that long in the
@@ -202,7 +208,7 @@ static void note_overflow(Model* m) {
     if (ev == m->overflow_seen) return;
     m->overflow_slabs += ev - m->overflow_seen;
     m->overflow_seen = ev;
-    if (getenv("GSX_SPEC_DEBUG"))
+    if (spec_debug_level() >= 1)
         fprintf(stderr, "[gsx overflow] model '%s': %u events so far, largest slab wanted %u entries, capacity %llu, n_sorted %u n_sorted2 %u entries_total %u speculated-copy %d\n",
                 m->key.c_str(), ev, m->h_counters->max_needed_ever, (unsigned long long)m->tile_cap, m->h_counters->n_sorted, m->h_counters->n_sorted2,
                 m->h_counters->n_entries_total, (int)m->stats_copy_speculated);
@@ -439,7 +445,7 @@ gsx_status do_preprocess(gsx_viewer* v, Model* m, bool defer_visible_count) {
     m->lazy = (m->spec_round1 || shard_lazy || m->slab_shading) && (v->query.kind == GSX_QUERY_NONE || geometric_query);
     if (!m->lazy) m->slab_shading = false;
     {
-        static const bool debug = getenv("GSX_SPEC_DEBUG") != nullptr && atoi(getenv("GSX_SPEC_DEBUG")) >= 2;
+        static const bool debug = spec_debug_level() >= 2;
         if (debug) fprintf(stderr, "[gsx frame] model '%s': speculated %d, slab shading %d (off %d), lazy %d, n %llu\n", m->key.c_str(), (int)m->spec_round1,
                            (int)m->slab_shading, (int)m->slab_shading_off, (int)m->lazy, (unsigned long long)m->n);
     }
@@ -728,7 +734,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
             // (the slab plan of the next PLAIN frame — a probe of the speculation tuner — from the last plain frame: taken from a speculated
             //  frame's single slab the hint merged everything behind the second slab into one, 11 M entries where four slabs make 1.5 M)
             if (!m->stats_copy_speculated) m->slabs_hint = m->h_counters->slabs_used;
-            if (getenv("GSX_SPEC_DEBUG") && atoi(getenv("GSX_SPEC_DEBUG")) >= 3)
+            if (spec_debug_level() >= 3)
                 fprintf(stderr, "[gsx stats] viewer %p: copy of a %s frame: slabs_used %u, n_sorted %u, entries %u, max_needed %u\n", (void*)v, m->stats_copy_speculated ? "speculated" : "plain",
                         m->h_counters->slabs_used, m->h_counters->n_sorted, m->h_counters->n_entries_total, m->h_counters->max_needed);
             m->n_sorted = m->h_counters->n_sorted;
@@ -763,7 +769,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
         plan_slabs(v->options, (uint32_t)m->rec_n, &bounds);
         if (progressive) merge_tail_slabs(&bounds, m->slabs_hint);
     }
-    if (getenv("GSX_SPEC_DEBUG") && atoi(getenv("GSX_SPEC_DEBUG")) >= 3) {
+    if (spec_debug_level() >= 3) {
         fprintf(stderr, "[gsx slabs] viewer %p model '%s': speculated %d, slab shading %d, hint %u, slabs", (void*)v, m->key.c_str(), (int)m->spec_round1, (int)m->slab_shading, m->slabs_hint);
         for (uint32_t b : bounds) fprintf(stderr, " %u", b);
         fprintf(stderr, "\n");
@@ -1095,7 +1101,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
             // 260-350 us here) and the repair slab's block table
             HIPCHK(m->spec_coarse2.ensure(4 * window_pyramid_words(m->fc.tiles_x, m->fc.tiles_y)));
             const BlockGrid grid = block_grid(bsx, bsy, m->fc.tiles_x, row_lo, row_hi);
-            HIPCHK(launch_spec_verify(v->stream, m->spec_win.as<uint2>(), done, row_words, m->fc.tiles_x, m->fc.tiles_y,
+                HIPCHK(launch_spec_verify(v->stream, m->spec_win.as<uint2>(), done, row_words, m->fc.tiles_x, m->fc.tiles_y,
                                       m->spec_win2.as<uint2>(), m->spec_need.as<uint32_t>(), &dc->spec_need, row_lo, row_hi,
                                       post ? v->h_verdict : nullptr, seq, m->spec_coarse2.as<uint32_t>(), blocks ? &grid : nullptr,
                                       blocks ? m->block_table.as<uint4>() : nullptr, blocks ? m->ranges.as<uint2>() : nullptr));
