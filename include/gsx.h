@@ -90,7 +90,7 @@ typedef struct gsx_spec_params {
  * time.  After such a frame gsx_model_download_sorted returns the second round's (possibly empty) order, and the model
  * must go through gsx_preprocess + gsx_sort again before it is rendered once more (the app does so every frame;
  * gsx_render refuses otherwise: the frame's admission belongs to windows the frame has replaced).
- * host_verify: the (usually empty) second round is ~20 kernel launches that fall through at ~4 us of stream time each.
+ * host_verify: the (usually empty) second round is 8 kernel launches (round 6; ~20 before) that fall through at ~4 us of stream time each.
  * 0 (default): gsx_render never waits for the device; the second round is always enqueued.
  * 1: the device verification posts its verdict (how many tiles need the second round) into pinned host memory and
  * gsx_render waits for that one word before it returns; the second round is enqueued only when needed.  The next
@@ -100,7 +100,9 @@ typedef struct gsx_spec_params {
  * enqueues the second round while the device idles).
  * 2: ask only while repairs are rare — stop when six of the last eight verdicts needed the second round; the verdicts
  * keep being posted and the host looks at the latest one without waiting: eight repair-free ones in a row and it asks
- * again.  (Conservative: on cfg4, whose repairs come in bursts, it mostly stays off.)
+ * again — AND only while the app waits for its frames anyway (it has called gsx_sync or a blocking readback since the
+ * frame before, as the reference does twice per frame): a host that streams frames without waiting gets 0's behaviour
+ * (round 6: the second round is 8 launches now; asking while streaming cost 6-10 %, profiles/r06_ab_host_verify.txt).
  * frames_in_flight = L > 1: gsx_render_frame deals consecutive frames round-robin to L lanes, each with its own stream and
  * per-frame buffers (records, sort and tile buffers, framebuffer, speculation windows: a lane speculates from ITS last
  * frame, L poses back); the Gaussian data is shared.  The device then overlaps the latency-bound tail of one frame with

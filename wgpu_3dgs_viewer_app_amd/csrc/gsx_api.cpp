@@ -664,6 +664,7 @@ gsx_status gsx_render(gsx_viewer* v, const char* const* keys, uint32_t n_keys) {
     v->latest = nullptr;
     TraceScope trace(v, TRACE_RENDER);
     if ((st = do_render(v, keys, n_keys))) return st;
+    v->host_waited = false;   // (until the app waits again)
     return trace.finish();
 }
 
@@ -688,6 +689,7 @@ gsx_status gsx_render_frame(gsx_viewer* v, const char* const* keys, uint32_t n_k
             if ((st = do_sort(lane, m))) return st;
         }
         if ((st = do_render(lane, keys, n_keys))) return st;
+        v->host_waited = false;   // (until the app waits again: gsx_sync, a blocking readback)
         if ((st = trace.finish())) return st;
     }
     if (lane != v) {

@@ -218,6 +218,7 @@ static void note_overflow(Model* m) {
 // Frames are enqueued without any host round trip; this is where the host catches up: wait for the
 // stream and mirror the per-model statistics.
 gsx_status finish_frame(gsx_viewer* v) {
+    (v->parent ? v->parent : v)->host_waited = true;   // (every caller goes on to wait for the device: gsx_sync, the blocking readbacks)
     for (int attempt = 0; attempt < 8; ++attempt) {
         bool pending = false;
         for (auto& kv : v->models) pending |= kv.second->stats_pending;
@@ -1074,7 +1075,13 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
         bool repair = true;
         {
             ScopedPass t(v, GSX_PASS_DEPTH_SORT);
-            // auto (2): ask while repairs are rare.  While they are not, the verdicts are still posted and the host merely
+            // auto (2): ask while repairs are rare AND the host waits for its frames anyway (it has called gsx_sync or a blocking readback
+            // since the frame before: the app's protocol, scene.rs:614, 873).  A host that streams frames without waiting is better off with
+            // the repair round always enqueued and decided on the device — eight launches that fall through, ~38 us of stream time since
+            // round 6 (22 launches, ~100 us, when this rule was made): cfg4, two / one frames in flight streaming / waiting per frame,
+            // always-device 2350 / 2064 / 1902 fps, always-ask 1980 / 2089 / 1950, the round-5 rule (ask whenever repairs are rare)
+            // 2200 / 1836 / 1955 — the worst of both while streaming (tools/ab_host_verify.py, profiles/r06_ab_host_verify.txt).
+            // While repairs are not rare, the verdicts are still posted and the host merely
             // LOOKS at the latest one each frame (it lags by the frames in flight, and costs nothing): eight repair-free
             // verdicts in a row and the host asks again.  (A blocking probe here cost milliseconds: a host that does not wait
             // is ~10 frames ahead of the device.)
@@ -1088,7 +1095,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
                     if (m->hv_quiet >= 8) m->hv_active = true;
                 }
             }
-            const bool ask = v->options.host_verify == 1 || (automatic && m->hv_active);
+            const bool ask = v->options.host_verify == 1 || (automatic && m->hv_active && (v->parent ? v->parent : v)->host_waited);
             const bool post = ask || automatic;
             if (post && !v->h_verdict) {
                 HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&v->h_verdict), 64, hipHostMallocDefault));

@@ -442,6 +442,8 @@ struct gsx_viewer {
     void* ext_fb = nullptr;              // caller-owned framebuffer (multi-GPU: the RCCL gather target)
     uint64_t ext_fb_bytes = 0;
     gsx_render_options options{1u, 16u, 131072u, 2u, 1u, 0.25f, 3u, 0u, 1u, 1u};  // = gsx_render_options_default (a CPU test compares the two: gsx_viewer_get_render_options)
+    bool host_waited = false;  // the host has waited for this viewer's device work (gsx_sync, a blocking readback) since its last frame was enqueued:
+                               // the app synchronises per frame, so asking for a speculated frame's verdict costs it nothing (host_verify = 2)
     uint32_t timing = 0;  // bit p: bracket pass p with events
     gsx::ScopedPass* open_pass = nullptr;  // the innermost pass scope open on this viewer (ScopedPass: scopes nest)
     std::vector<PassTimer> timers;     // recorded, not yet read
