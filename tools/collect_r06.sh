@@ -14,7 +14,7 @@ open(sys.argv[1],'w').write(rows[-1]+'\n' if rows else '')" "$1"; }
 if want A; then
 # 1. the bench line as the driver runs it, and with its default window
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2> $OUT/bench.err
-python3 bench.py > $OUT/bench.json 2>> $OUT/bench.err
+GSX_SPEC_DEBUG=2 python3 bench.py > $OUT/bench.json 2> $OUT/bench_frames.err   # (per-frame mode lines on stderr: which frames the tuner ran unspeculated)
 # 2. kernel trace + stats of the same command: k_project<3,0,0> (the full-projection loop) and k_project_geom averages must agree with
 #    roofline.avg_launch_us / roofline_speculated.avg_launch_us of the line the traced run prints itself
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --no-cpu-baseline --no-pmc --no-extra-legs --no-robustness --no-cfg5 > $OUT/kt_bench.log 2>&1

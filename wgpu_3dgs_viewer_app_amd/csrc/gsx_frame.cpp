@@ -755,8 +755,13 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
         // and cost a second digit in the block sort and ~2x the entries: - 12 % on cfg4's orbit, + 16 % under an open sky
         // (tools/ab_blocks.py, round 5).  So the block size follows the longest walk of an earlier frame (SlabStats::walk_max, left
         // by tile_order_job), with hysteresis; either way the pixels are the same.
+        // (one flag per schedule: an unspeculated frame — a probe of the tuner among speculated ones — walks its first slab's whole lists,
+        //  several times the walk of the speculated frames around it; its statistic used to put THEM into fine blocks, where the walk
+        //  then stayed above the way-back threshold: the same bench command read 2040 or 1830 fps with one frame in flight, 20.0 or 21.6
+        //  launches a frame, depending on whether a stats copy happened to catch a probe frame — round 6)
         const uint32_t walk = m->h_counters->walk_max;
-        m->blocks_fine = m->blocks_fine ? walk > kWalkFineOff : walk > kWalkFineOn;
+        bool& fine = m->stats_copy_speculated ? m->blocks_fine_spec : m->blocks_fine_plain;
+        fine = fine ? walk > kWalkFineOff : walk > kWalkFineOn;
     }
     std::vector<uint32_t> bounds;
     const bool imported_windows = m->use_imported && m->has_window && progressive;
@@ -849,7 +854,7 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
     }
     uint32_t bsx = 0, bsy = 0;
     // most blocks of this frame: GSX_BLOCKS_MAX when it was given, otherwise 256 (one 8-bit sort pass) — or 1024 while some tile's walk is long
-    const uint32_t blocks_max = v->blocks_adaptive && m->blocks_fine ? 1024u : v->blocks_max;
+    const uint32_t blocks_max = v->blocks_adaptive && (m->spec_round1 ? m->blocks_fine_spec : m->blocks_fine_plain) ? 1024u : v->blocks_max;
     if (blocks) {
         // The grid covers the rows this viewer composites (block_grid).  An index-sharded rank sizes its blocks for the taller of its
         // own band and an EQUAL band: every rank whose band is no taller than that bins by the same block size, so what a tile row

@@ -135,7 +135,7 @@ struct Model {
     DevBuf block_vis;                           // per-workgroup visible counts of the projection pass
     DevBuf tp_src, tp_a, tp_b, tk_out, tv_out, tsort_ws;  // tile pairs: emitted, scratch, sorted (split), workspace
     DevBuf brec_sorted;                         // block lists: the {rect, key, index} records in list order (the block sort's write-out gathers them)
-    bool blocks_fine = false;                   // models some tile of which walks a long list: blocks of a quarter the size (1024 instead of 256; gsx_frame.cpp)
+    bool blocks_fine_spec = false, blocks_fine_plain = false;   // some tile of the model walks a long list: blocks of a quarter the size (1024 instead of 256), per schedule — speculated / unspeculated frames (gsx_frame.cpp)
     bool lists_long = false;                    // ... for models whose lists are long (decided from the last frame statistics that arrived)
     DevBuf ranges;
     DevBuf tile_order;                          // block compositor's dispatch order: {threshold, tile_cost[n_tiles], tile_order[n_tiles]} (tile_order_job)
@@ -397,7 +397,7 @@ struct gsx_viewer {
     unsigned long long* h_verdict = nullptr;  // pinned: {seq << 32 | tiles needing repair}, posted by k_spec_verify (host_verify)
     uint32_t verify_seq = 0;
     uint32_t blocks_max = 256;    // GSX_BLOCKS_MAX: most blocks of a block-list frame (256: one 8-bit sort pass)
-    bool blocks_adaptive = true;  // no GSX_BLOCKS_MAX given: 256, or 1024 for models some tile of which walks a long list (Model::blocks_fine)
+    bool blocks_adaptive = true;  // no GSX_BLOCKS_MAX given: 256, or 1024 for models some tile of which walks a long list (Model::blocks_fine_spec / _plain)
     int bin_mode = 1;             // GSX_BIN: 1 block lists for progressive frames (default), 0 per-tile lists always
     bool edit_cache = true;       // GSX_NO_EDIT_CACHE: run k_edit_prepare every frame (tests compare the two)
     uint64_t tile_cap_fixed = 0;  // GSX_TILE_CAP was set when the viewer was created: pair-buffer capacity that never grows (tests of the spill path)
