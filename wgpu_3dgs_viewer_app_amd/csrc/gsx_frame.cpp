@@ -78,7 +78,11 @@ static gsx_status wait_verdict(gsx_viewer* v, uint32_t seq, uint32_t* need) {
 //   frames until the probe's timings have arrived) -> decide;   PLAIN -> PROBE_SPEC -> SETTLE -> decide likewise.
 // A decision that confirms the current mode doubles its phase — quadruples it when the verdict is clear — (64 ... 2048
 // frames: the probes then cost < 1 %), one that flips it starts over at 64.  By construction the result stays within a few per cent of the better of the two paths.
-constexpr uint32_t kWalkFineOn = 160, kWalkFineOff = 30;  // chunks of 128 candidates: finer blocks above / coarse blocks again below (measured under the finer ones)
+// chunks of 128 candidates: finer blocks above kWalkFineOn / coarse blocks again below kWalkFineOff (measured under the finer ones).
+// Round 6: 220 / 70 (160 / 30 before).  cfg4's orbit walks 10-15 chunks a frame with rare poses of 130-170 under coarse blocks and 6-14
+// with spikes of 50 under fine ones — either state held itself and the first spike chose: - 10 % with one frame in flight whenever the
+// fine state won.  An open horizon walks 275-350 coarse, 104-146 fine (GSX_SPEC_DEBUG=3 prints the statistic).
+constexpr uint32_t kWalkFineOn = 220, kWalkFineOff = 70;
 constexpr uint32_t kSlabShadingMaxPercent = 35;  // slab shading pays while the slabs shade less than this share of the visible records (break-even ~45 % on cfg4)
 constexpr uint32_t kBucketSortMax = 1500000;  // pairs: above, the LSD depth sort (256 buckets of 8192 pairs fit the LDS; at 1 M the bucket sort takes half the LSD sort's time)
 constexpr uint32_t kProbeFrames = 5;   // the first is not timed (the switch itself is atypical), the other four are
@@ -736,8 +740,8 @@ static gsx_status do_bin_and_composite(gsx_viewer* v, Model* m, bool carry, cons
             //  frame's single slab the hint merged everything behind the second slab into one, 11 M entries where four slabs make 1.5 M)
             if (!m->stats_copy_speculated) m->slabs_hint = m->h_counters->slabs_used;
             if (spec_debug_level() >= 3)
-                fprintf(stderr, "[gsx stats] viewer %p: copy of a %s frame: slabs_used %u, n_sorted %u, entries %u, max_needed %u\n", (void*)v, m->stats_copy_speculated ? "speculated" : "plain",
-                        m->h_counters->slabs_used, m->h_counters->n_sorted, m->h_counters->n_entries_total, m->h_counters->max_needed);
+                fprintf(stderr, "[gsx stats] viewer %p: copy of a %s frame: slabs_used %u, n_sorted %u, entries %u, max_needed %u, walk_max %u chunks (fine blocks: speculated %d, plain %d)\n", (void*)v, m->stats_copy_speculated ? "speculated" : "plain",
+                        m->h_counters->slabs_used, m->h_counters->n_sorted, m->h_counters->n_entries_total, m->h_counters->max_needed, m->h_counters->walk_max, (int)m->blocks_fine_spec, (int)m->blocks_fine_plain);
             m->n_sorted = m->h_counters->n_sorted;
         }
         if (m->stats_copy_speculated) {
