@@ -142,7 +142,7 @@ pub struct gsx_comm_info { pub transport: u32, pub nranks: u32, pub rank: u32, p
 pub struct gsx_launch_stats {
     pub graph_launches: u64, pub graph_nodes: u64, pub nodes_patched: u64, pub direct_launches: u64, pub graphs_built: u64, pub broken: u64, pub idle_direct_scopes: u64,
 }
-pub type gsx_pass = u32; // 0 project, 1 depth sort, 2 bin, 3 tile sort, 4 composite, 5 project (geometry only)
+pub type gsx_pass = u32; // 0 project, 1 depth sort, 2 bin, 3 tile sort, 4 composite, 5 project (geometry only), 6 shade
 pub const GSX_PASS_COUNT: usize = 7;
 
 #[link(name = "gsx")]

@@ -274,6 +274,13 @@ impl<G: GaussianPod> MultiModelViewer<G> {
     /// Where a sharded frame's bands go: `None` = every rank ends up with the whole frame (default), `Some(r)` = only rank `r`.
     pub fn shard_set_gather_root(&mut self, root: Option<u32>) -> Result<(), Error> { check(unsafe { sys::gsx_shard_set_gather_root(self.handle.0, root.map(|r| r as i32).unwrap_or(-1)) }) }
     /// One process, one thread + one viewer per GPU: seat `rank` of an in-process group (`sys::gsx_comm_group_create`).
+    /// What the viewer's communicator really is (transport, ranks RCCL saw — `ncclCommCount` —, this rank, RCCL's version): a multi-process
+    /// deployment asserts `nranks == world` before its first frame.
+    pub fn comm_info(&mut self) -> Result<sys::gsx_comm_info, Error> {
+        let mut info = sys::gsx_comm_info::default();
+        check(unsafe { sys::gsx_viewer_comm_info(self.handle.0, &mut info) })?;
+        Ok(info)
+    }
     pub fn comm_init_group(&mut self, group: *mut sys::gsx_comm_group, rank: u32) -> Result<(), Error> { check(unsafe { sys::gsx_viewer_comm_init_group(self.handle.0, group, rank) }) }
 }
 pub fn comm_unique_id() -> Result<[u8; 128], Error> {
