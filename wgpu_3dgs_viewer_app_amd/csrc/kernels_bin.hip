@@ -537,6 +537,7 @@ constexpr int kFuseThreads = 1024;
 constexpr int kFuseWaves = kFuseThreads / 64;
 constexpr uint32_t kFuseTile = 2u * kFuseThreads;   // records per tile: two per lane (eight on slabs of kFuseBigSlab records and more)
 constexpr uint32_t kFuseBigSlab = 1u << 20;
+constexpr uint32_t kBigRect = 32;   // blocks: larger rectangles are walked by the whole wave (block_bin_tiles)
 static std::atomic<uint32_t> g_big_slab{kFuseBigSlab};
 void block_bin_set_big_slab(uint32_t records) { g_big_slab.store(records ? records : kFuseBigSlab); }
 constexpr uint32_t kFuseGrid = 256;
@@ -593,13 +594,36 @@ __device__ __forceinline__ void block_bin_tiles(BinShared& sh, uint32_t n, uint3
             rx[r] = ry[r] = 0;
             if (look[r]) rec_rect(rec_a, rect8, idx[r], rx[r], ry[r]);
         }
+        // A record asks every block its rectangle touches.  Rectangles of up to kBigRect blocks are walked by their own lane; larger ones
+        // (a splat across half the screen touches hundreds of the 1024 blocks of a long-walk scene) are taken one at a time by the whole
+        // wave, 64 blocks a step — a lane walking 1024 blocks alone held its wave for 2 x 1024 steps: k_block_bin took 200-2000 us a frame
+        // on the surfaces scene (round 6), a third of the frame.
+        bool big[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             c[r] = 0;
-            uint32_t bx0, bx1, by0, by1;
-            if (look[r] && block_rect(g, rx[r], ry[r], row_lo, row_hi, bx0, bx1, by0, by1))
+            uint32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
+            const bool has = look[r] && block_rect(g, rx[r], ry[r], row_lo, row_hi, bx0, bx1, by0, by1);
+            big[r] = has && (bx1 - bx0) * (by1 - by0) > kBigRect;
+            if (has && !big[r])
                 for (uint32_t by = by0; by < by1; ++by)
                     for (uint32_t bx = bx0; bx < bx1; ++bx) c[r] += block_takes(sh.tab, by * g.blocks_x + bx, key[r], keyed) ? 1u : 0u;
+            unsigned long long bm = __ballot(big[r]);
+            while (bm) {
+                const int L = __ffsll((long long)bm) - 1;
+                bm &= bm - 1ull;
+                const uint32_t rxL = (uint32_t)__shfl((int)rx[r], L, 64), ryL = (uint32_t)__shfl((int)ry[r], L, 64), keyL = (uint32_t)__shfl((int)key[r], L, 64);
+                uint32_t a0, a1, b0, b1;
+                (void)block_rect(g, rxL, ryL, row_lo, row_hi, a0, a1, b0, b1);
+                const uint32_t w = a1 - a0, total = w * (b1 - b0);
+                uint32_t cnt = 0;
+                for (uint32_t i0 = 0; i0 < total; i0 += 64u) {
+                    const uint32_t i = i0 + lane;
+                    const bool t = i < total && block_takes(sh.tab, (b0 + i / w) * g.blocks_x + a0 + i % w, keyL, keyed);
+                    cnt += (uint32_t)__popcll(__ballot(t));
+                }
+                if (lane == (uint32_t)L) c[r] = cnt;
+            }
             if (c[r]) brec[p0 + (uint32_t)r * kFuseThreads] = make_uint4(rx[r], ry[r], key[r], idx[r]);   // (only records that make an entry are ever looked up)
         }
         // inclusive wave scans of the R stripes; slab shading: the records some block takes, counted by ballots
@@ -683,7 +707,8 @@ __device__ __forceinline__ void block_bin_tiles(BinShared& sh, uint32_t n, uint3
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t pos = p0 + (uint32_t)r * kFuseThreads;
-            if (c[r] && pos < cut) {
+            const bool emit = c[r] && pos < cut;
+            if (emit && !big[r]) {
                 uint32_t o = before + e[r];
                 uint32_t bx0, bx1, by0, by1;
                 if (block_rect(g, rx[r], ry[r], row_lo, row_hi, bx0, bx1, by0, by1))
@@ -695,6 +720,29 @@ __device__ __forceinline__ void block_bin_tiles(BinShared& sh, uint32_t n, uint3
                             atomicAdd(&sh.hist[0][b & dmask], 1u);
                             if (passes > 1) atomicAdd(&sh.hist[1][(b >> dbits) & dmask], 1u);
                         }
+            }
+            unsigned long long bm = __ballot(emit && big[r]);   // (the wave takes the large rectangles one at a time; a record's entries go to different blocks: their order among themselves is nobody's)
+            while (bm) {
+                const int L = __ffsll((long long)bm) - 1;
+                bm &= bm - 1ull;
+                const uint32_t rxL = (uint32_t)__shfl((int)rx[r], L, 64), ryL = (uint32_t)__shfl((int)ry[r], L, 64), keyL = (uint32_t)__shfl((int)key[r], L, 64);
+                const uint32_t posL = (uint32_t)__shfl((int)pos, L, 64);
+                uint32_t o = (uint32_t)__shfl((int)(before + e[r]), L, 64);
+                uint32_t a0, a1, b0, b1;
+                (void)block_rect(g, rxL, ryL, row_lo, row_hi, a0, a1, b0, b1);
+                const uint32_t w = a1 - a0, total = w * (b1 - b0);
+                for (uint32_t i0 = 0; i0 < total; i0 += 64u) {
+                    const uint32_t i = i0 + lane;
+                    const uint32_t b = (b0 + i / w) * g.blocks_x + a0 + i % w;
+                    const bool t = i < total && block_takes(sh.tab, b, keyL, keyed);
+                    const unsigned long long bal = __ballot(t);
+                    if (t) {
+                        pairs[o + (uint32_t)__popcll(bal & lt)] = make_uint2(b, posL);
+                        atomicAdd(&sh.hist[0][b & dmask], 1u);
+                        if (passes > 1) atomicAdd(&sh.hist[1][(b >> dbits) & dmask], 1u);
+                    }
+                    o += (uint32_t)__popcll(bal);
+                }
             }
         }
         if (tid == 0) {
