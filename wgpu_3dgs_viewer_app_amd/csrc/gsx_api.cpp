@@ -267,6 +267,7 @@ gsx_status gsx_viewer_create(const gsx_viewer_desc* desc, gsx_viewer** out) {
     if (const char* e = getenv("GSX_TILE_ORDER")) v->tile_order_on = atoi(e) != 0;
     if (const char* e = getenv("GSX_BUCKET_SORT")) v->bucket_sort = atoi(e) != 0;
     if (const char* e = getenv("GSX_BIN_FUSED")) v->bin_fused = atoi(e) != 0;
+    if (const char* e = getenv("GSX_BIN_BIG_RECT")) block_bin_set_big_rect((uint32_t)atoi(e));   // tests / tuning
     if (const char* e = getenv("GSX_BIN_BIG_SLAB")) block_bin_set_big_slab((uint32_t)atoi(e));   // tests: smaller slabs take the eight-per-lane tiles
     if (const char* e = getenv("GSX_BUCKET_CAP")) bucket_sort_set_cap((uint32_t)atoi(e));   // tests: buckets above this take the global-memory path
     if (const char* e = getenv("GSX_SORTED_RECORDS")) v->sorted_records = atoi(e) != 0 ? 1 : 0;

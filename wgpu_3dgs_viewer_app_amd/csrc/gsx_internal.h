@@ -373,6 +373,7 @@ hipError_t launch_admit_compact(hipStream_t s, const uint32_t* key, uint32_t n, 
                                 const uint32_t* d_skip = nullptr /* points at 0: nothing is admitted, no ballot is read */,
                                 bool histogram = true /* false: the compaction alone (msd_ws still holds its ticket and status words) */);
 uint32_t next_sort_epoch();  // status-word epochs of every look-back kernel of the process (kernels_sort.hip)
+void block_bin_set_big_rect(uint32_t blocks);    // tests / tuning: rectangles of more blocks than this are walked by the whole wave in k_block_bin (0: the default)
 void block_bin_set_big_slab(uint32_t records);  // tests: slabs of this many records and more take eight records per lane in k_block_bin (0: the default)
 void bucket_sort_set_cap(uint32_t cap);  // tests: buckets above `cap` pairs take the global-memory path (0: the LDS capacity)
 

@@ -538,6 +538,8 @@ constexpr int kFuseWaves = kFuseThreads / 64;
 constexpr uint32_t kFuseTile = 2u * kFuseThreads;   // records per tile: two per lane (eight on slabs of kFuseBigSlab records and more)
 constexpr uint32_t kFuseBigSlab = 1u << 20;
 constexpr uint32_t kBigRect = 32;   // blocks: larger rectangles are walked by the whole wave (block_bin_tiles)
+static std::atomic<uint32_t> g_big_rect{kBigRect};
+void block_bin_set_big_rect(uint32_t blocks) { g_big_rect.store(blocks ? blocks : kBigRect); }
 static std::atomic<uint32_t> g_big_slab{kFuseBigSlab};
 void block_bin_set_big_slab(uint32_t records) { g_big_slab.store(records ? records : kFuseBigSlab); }
 constexpr uint32_t kFuseGrid = 256;
@@ -564,7 +566,7 @@ __device__ __forceinline__ void block_bin_tiles(BinShared& sh, uint32_t n, uint3
                                                 uint32_t capacity, uint32_t row_lo, uint32_t row_hi, uint32_t slab_index, const BlockGrid& g,
                                                 bool keyed, uint32_t* __restrict__ ticket, u64b* __restrict__ status, uint32_t epoch, int passes,
                                                 int dbits, const uint32_t* __restrict__ rect8, uint2* __restrict__ shade_pairs,
-                                                const uint8_t* __restrict__ sorted_code, bool coarse) {
+                                                const uint8_t* __restrict__ sorted_code, bool coarse, uint32_t big_rect) {
     constexpr uint32_t kTile = (uint32_t)R * kFuseThreads;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_tiles = (n + kTile - 1u) / kTile;
@@ -604,7 +606,7 @@ __device__ __forceinline__ void block_bin_tiles(BinShared& sh, uint32_t n, uint3
             c[r] = 0;
             uint32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
             const bool has = look[r] && block_rect(g, rx[r], ry[r], row_lo, row_hi, bx0, bx1, by0, by1);
-            big[r] = has && (bx1 - bx0) * (by1 - by0) > kBigRect;
+            big[r] = has && (bx1 - bx0) * (by1 - by0) > big_rect;
             if (has && !big[r])
                 for (uint32_t by = by0; by < by1; ++by)
                     for (uint32_t bx = bx0; bx < bx1; ++bx) c[r] += block_takes(sh.tab, by * g.blocks_x + bx, key[r], keyed) ? 1u : 0u;
@@ -785,7 +787,7 @@ __global__ __launch_bounds__(kFuseThreads) void k_block_bin(const uint32_t* __re
                                                              uint32_t* __restrict__ ticket, u64b* __restrict__ status, uint32_t epoch,
                                                              uint32_t* __restrict__ ghist, int passes, int dbits,
                                                              const uint32_t* __restrict__ rect8, uint2* __restrict__ shade_pairs,
-                                                             const uint8_t* __restrict__ sorted_code, const uint32_t* __restrict__ live_cells, uint32_t big_slab) {
+                                                             const uint8_t* __restrict__ sorted_code, const uint32_t* __restrict__ live_cells, uint32_t big_slab, uint32_t big_rect) {
     __shared__ BinShared sh;
     const uint32_t extra = order_buf ? 1u : 0u, workers = gridDim.x - extra, worker = blockIdx.x - extra;
     if (extra && blockIdx.x == 0u) {
@@ -818,10 +820,10 @@ __global__ __launch_bounds__(kFuseThreads) void k_block_bin(const uint32_t* __re
     __syncthreads();
     if (big)
         block_bin_tiles<8>(sh, n, n_vis, j0, sorted_idx, rec_a, sorted_keys, brec, pairs, stats, capacity, row_lo, row_hi, slab_index, g, keyed != 0,
-                           ticket, status, epoch, passes, dbits, rect8, shade_pairs, sorted_code, live_cells != nullptr);
+                           ticket, status, epoch, passes, dbits, rect8, shade_pairs, sorted_code, live_cells != nullptr, big_rect);
     else
         block_bin_tiles<2>(sh, n, n_vis, j0, sorted_idx, rec_a, sorted_keys, brec, pairs, stats, capacity, row_lo, row_hi, slab_index, g, keyed != 0,
-                           ticket, status, epoch, passes, dbits, rect8, shade_pairs, sorted_code, live_cells != nullptr);
+                           ticket, status, epoch, passes, dbits, rect8, shade_pairs, sorted_code, live_cells != nullptr, big_rect);
     for (uint32_t i = tid; i < 512u; i += kFuseThreads) {
         const uint32_t v = (&sh.hist[0][0])[i];
         if (v && (int)(i >> 8) < passes) atomicAdd(&ghist[i], v);
@@ -856,7 +858,7 @@ hipError_t launch_block_bin_fused(hipStream_t s, uint32_t j0, uint32_t j1, const
         GSX_LAUNCH(k_block_bin, dim3(nb + (zero.order_buf ? 1u : 0u)), dim3(kFuseThreads), 0, s, d_n_vis, j0, j1, sorted_idx, rec.a, sorted_keys, brec, pairs,
                    stats, capacity, row_lo, row_hi, d_done_count, owned_tiles, slab_index, g, table, window ? 1 : 0, zero.order_buf, zero.order_tiles,
                    zero.order_buf ? &stats->walk_max : nullptr, bin_ws, reinterpret_cast<u64b*>(bin_ws + 8), next_sort_epoch(), sort_ghist, passes, dbits,
-                   shade_pairs ? rec.rect8 : nullptr, shade_pairs, live ? sorted_code : nullptr, live, g_big_slab.load());
+                   shade_pairs ? rec.rect8 : nullptr, shade_pairs, live ? sorted_code : nullptr, live, g_big_slab.load(), g_big_rect.load());
     return hipGetLastError();
 }
 
