@@ -1,4 +1,4 @@
-"""Development: one robustness scene of bench.py (cfg4 orbit | open_sky | translucent | surfaces) on the default schedule, for a kernel trace:
+"""Development: one robustness scene of bench.py (cfg4 orbit | random | open_sky | translucent | surfaces) on the default schedule, for a kernel trace:
 rocprofv3 --kernel-trace ... -- python3 tools/trace_scene.py open_sky 160; then tools/kernel_gaps.py <dir> 60 k_project timeline 1"""
 import os
 import sys
@@ -14,6 +14,8 @@ sc = sys.argv[1] if len(sys.argv) > 1 else "open_sky"
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 160
 n, sh, w, h, seed = scene.CONFIGS["cfg4"]
 orbit = [camera.PrecomputedCamera(camera.orbit_pose(k), w / h) for k in range(240)]
+if sc == "random":   # bench.py's random_pose_order leg: the same 240 poses in a seeded random order (no temporal coherence)
+    orbit = [orbit[k] for k in np.random.default_rng(7).permutation(240)]
 g = scene.synthetic_gaussians(n, seed, sh, 0, n, variant=sc) if sc in ("translucent", "surfaces") else scene.synthetic_gaussians(n, seed, sh)
 v = MultiModelViewer()
 v.add_model("m", n)

@@ -274,9 +274,12 @@ constexpr uint32_t kMsdBuckets = 256;    // coarse buckets = the partition pass'
 // so far (the running union), [2050, 2052) its snapshot: what the kernels of a sort map keys by | [2056] ticket, [2057] finished
 // (k_admit_compact) | [2064, 2064 + 512) bucket ranges (uint2 x 256) | from 2576: k_admit_compact's status words, 4 per tile
 constexpr uint32_t kMsdCells = 2048, kMsdTicket = 2056, kMsdRanges = 2064, kMsdStatus = 2576;
-constexpr uint32_t kCompactWordsPerTile = 1024;  // ballot words (64 Gaussians each) per k_admit_compact workgroup
+constexpr uint32_t kCompactWordsPerTile = 1024;  // ballot words (64 Gaussians each) per k_admit_compact workgroup — 256 for models of fewer than
+constexpr uint32_t kCompactSmallWords = 65536;   // ... this many ballot words (4.2 M Gaussians)
 inline size_t msd_workspace_words(uint64_t n_gaussians) {
-    return kMsdStatus + 4 * (size_t)((((n_gaussians + 63) / 64) + kCompactWordsPerTile - 1) / kCompactWordsPerTile + 1);
+    const uint64_t words = (n_gaussians + 63) / 64;
+    const uint64_t tiles = words < kCompactSmallWords ? (words + 255) / 256 : (words + kCompactWordsPerTile - 1) / kCompactWordsPerTile;
+    return kMsdStatus + 4 * (size_t)(tiles + 1);
 }
 #ifdef __HIPCC__
 // Decoupled look-back of a single-pass scan, one wave per call: status[k * stride] is tile k's 64-bit word {epoch << 34 | flag << 32 |

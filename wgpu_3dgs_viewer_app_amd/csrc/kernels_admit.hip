@@ -251,6 +251,9 @@ constexpr int kCompactThreads = 256;
 constexpr uint32_t kCompactList = 8192;   // admitted indices of a tile that lie in LDS at a time (a page)
 typedef unsigned long long u64c;
 
+// WPT ballot words per thread: 4 (tiles of 1024 words = 65 536 Gaussians) for large models, 1 (256 words = 16 384 Gaussians) for models of
+// fewer than kCompactSmallWords words — a 1 M-Gaussian model was 16 tiles on 256 CUs, 56 us against the 17 us of a 10 M one (round 6)
+template <uint32_t WPT>
 __global__ __launch_bounds__(kCompactThreads) void k_admit_compact(const uint32_t* __restrict__ key, uint32_t words,
                                                                     const unsigned long long* __restrict__ ballots,
                                                                     const uint32_t* __restrict__ block_visible, uint32_t nblocks,
@@ -268,21 +271,25 @@ __global__ __launch_bounds__(kCompactThreads) void k_admit_compact(const uint32_
     __shared__ uint32_t s_wsum[kCompactThreads / 64], s_vsum[kCompactThreads / 64], s_mn[kCompactThreads / 64], s_mx[kCompactThreads / 64];
     __shared__ uint32_t s_tile, s_before, s_vis_before;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t n_tiles = (words + kCompactWordsPerTile - 1u) / kCompactWordsPerTile;   // == gridDim.x: one tile per workgroup
+    constexpr uint32_t kTileWords = WPT * (uint32_t)kCompactThreads;
+    const uint32_t n_tiles = (words + kTileWords - 1u) / kTileWords;   // == gridDim.x: one tile per workgroup
     if (tid == 0) s_tile = atomicAdd(&ticket[0], 1u);
     if (fine)
         for (uint32_t i = tid; i < kMsdFine; i += kCompactThreads) s_hist[i] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
-    // the thread's four ballot words, its count, the tile's scan
-    const uint32_t w0 = tile * kCompactWordsPerTile + 4u * tid;
-    unsigned long long b[4];
+    // the thread's ballot words, its count, the tile's scan
+    const uint32_t w0 = tile * kTileWords + WPT * tid;
+    unsigned long long b[WPT];
+    uint32_t mine = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b[j] = w0 + (uint32_t)j < words ? ballots[w0 + j] : 0ull;
-    const uint32_t mine = (uint32_t)(__popcll(b[0]) + __popcll(b[1]) + __popcll(b[2]) + __popcll(b[3]));
+    for (uint32_t j = 0; j < WPT; ++j) {
+        b[j] = w0 + j < words ? ballots[w0 + j] : 0ull;
+        mine += (uint32_t)__popcll(b[j]);
+    }
     uint32_t vis = 0;
-    if (block_visible) {
-        const uint32_t bi = tile * (kCompactWordsPerTile / 4u) + tid;   // 256-Gaussian projection workgroups: four ballot words each
+    if (block_visible && tid < kTileWords / 4u) {
+        const uint32_t bi = tile * (kTileWords / 4u) + tid;   // 256-Gaussian projection workgroups: four ballot words each
         if (bi < nblocks) vis = block_visible[bi];
     }
     uint32_t x = mine, vx = vis;
@@ -325,9 +332,9 @@ __global__ __launch_bounds__(kCompactThreads) void k_admit_compact(const uint32_
         for (uint32_t page_lo = 0; page_lo < total; page_lo += kCompactList) {
             const uint32_t page_hi = page_lo + kCompactList, page_n = min(kCompactList, total - page_lo);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (uint32_t j = 0; j < WPT; ++j) {
                 while (b[j] && o < page_hi) {
-                    s_list[o - page_lo] = (w0 + (uint32_t)j) * 64u + (uint32_t)__ffsll((long long)b[j]) - 1u;
+                    s_list[o - page_lo] = (w0 + j) * 64u + (uint32_t)__ffsll((long long)b[j]) - 1u;
                     b[j] &= b[j] - 1ull;
                     ++o;
                 }
@@ -400,10 +407,13 @@ hipError_t launch_admit_compact(hipStream_t s, const uint32_t* key, uint32_t n, 
         if (block_visible) (void)gsx::op::MemsetAsync(d_n_visible, 0, 4, s);
         return gsx::op::MemsetAsync(d_total, 0, 4, s);
     }
-    const uint32_t tiles = (words + kCompactWordsPerTile - 1u) / kCompactWordsPerTile;
     const MsdCells mc = msd_cells(msd_ws, seq);
-    GSX_LAUNCH(k_admit_compact, dim3(tiles), dim3(kCompactThreads), 0, s, key, words, ballots, block_visible, (n + 255u) / 256u, pairs, d_total, d_n_visible,
-               msd_ws + kMsdTicket, reinterpret_cast<u64c*>(msd_ws + kMsdStatus), next_sort_epoch(), histogram ? mc.fine : nullptr, mc.hint, mc.acc, d_skip);
+    if (words < kCompactSmallWords)
+        GSX_LAUNCH(k_admit_compact<1>, dim3((words + kCompactThreads - 1u) / kCompactThreads), dim3(kCompactThreads), 0, s, key, words, ballots, block_visible, (n + 255u) / 256u, pairs,
+                   d_total, d_n_visible, msd_ws + kMsdTicket, reinterpret_cast<u64c*>(msd_ws + kMsdStatus), next_sort_epoch(), histogram ? mc.fine : nullptr, mc.hint, mc.acc, d_skip);
+    else
+        GSX_LAUNCH(k_admit_compact<4>, dim3((words + kCompactWordsPerTile - 1u) / kCompactWordsPerTile), dim3(kCompactThreads), 0, s, key, words, ballots, block_visible, (n + 255u) / 256u,
+                   pairs, d_total, d_n_visible, msd_ws + kMsdTicket, reinterpret_cast<u64c*>(msd_ws + kMsdStatus), next_sort_epoch(), histogram ? mc.fine : nullptr, mc.hint, mc.acc, d_skip);
     return hipGetLastError();
 }
 
